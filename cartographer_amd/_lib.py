@@ -1,0 +1,169 @@
+"""ctypes loader of libcartographer_mi355x.so (the C ABI in include/cartographer_mi355x.h).
+
+The library is the product: there is no Python or CPU fallback.  If the
+shared object is missing, or no HIP device is usable, calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "libcartographer_mi355x.so")
+
+OK, INVALID_ARGUMENT, DEVICE_ERROR, OUT_OF_MEMORY, UNSUPPORTED = range(5)
+
+
+class CmxError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"{message} (status {status})")
+        self.status = status
+
+
+class Pose2d(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("theta", C.c_double)]
+
+
+class Pose3d(C.Structure):
+    _fields_ = [("t", C.c_double * 3), ("q", C.c_double * 4)]
+
+
+class Grid2DLimits(C.Structure):
+    _fields_ = [("resolution", C.c_double), ("max_x", C.c_double), ("max_y", C.c_double),
+                ("num_x_cells", C.c_int32), ("num_y_cells", C.c_int32),
+                ("min_correspondence_cost", C.c_float), ("max_correspondence_cost", C.c_float)]
+
+
+class RtOptions(C.Structure):
+    _fields_ = [("linear_search_window", C.c_double), ("angular_search_window", C.c_double),
+                ("translation_delta_cost_weight", C.c_double),
+                ("rotation_delta_cost_weight", C.c_double)]
+
+
+class Fast2DOptions(C.Structure):
+    _fields_ = [("linear_search_window", C.c_double), ("angular_search_window", C.c_double),
+                ("branch_and_bound_depth", C.c_int32)]
+
+
+class Fast3DOptions(C.Structure):
+    _fields_ = [("branch_and_bound_depth", C.c_int32), ("full_resolution_depth", C.c_int32),
+                ("min_rotational_score", C.c_double), ("min_low_resolution_score", C.c_double),
+                ("linear_xy_search_window", C.c_double), ("linear_z_search_window", C.c_double),
+                ("angular_search_window", C.c_double)]
+
+
+class MatchStats(C.Structure):
+    _fields_ = [("candidates_scored", C.c_int64), ("coarse_candidates", C.c_int64),
+                ("nodes_expanded", C.c_int64), ("num_scans", C.c_int32), ("reserved", C.c_int32),
+                ("device_ms", C.c_double), ("dominant_kernel_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class Voxel(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("z", C.c_int32), ("value", C.c_uint16),
+                ("pad", C.c_uint16)]
+
+
+VOXEL_DTYPE = np.dtype([("x", np.int32), ("y", np.int32), ("z", np.int32), ("value", np.uint16),
+                        ("pad", np.uint16)])
+
+
+class NodeData3D(C.Structure):
+    _fields_ = [("gravity_alignment", C.c_double * 4),
+                ("high_resolution_point_cloud", C.c_void_p),
+                ("num_high_resolution_points", C.c_int32),
+                ("low_resolution_point_cloud", C.c_void_p),
+                ("num_low_resolution_points", C.c_int32),
+                ("rotational_scan_matcher_histogram", C.c_void_p),
+                ("histogram_size", C.c_int32)]
+
+
+class Result3D(C.Structure):
+    _fields_ = [("score", C.c_float), ("pose_estimate", Pose3d), ("rotational_score", C.c_float),
+                ("low_resolution_score", C.c_float)]
+
+
+# Every symbol include/cartographer_mi355x.h declares.
+EXPORTED_SYMBOLS = [
+    "cmx_version", "cmx_status_string", "cmx_last_error", "cmx_device_count", "cmx_set_stream",
+    "cmx_rt2d_match", "cmx_fast2d_create", "cmx_fast2d_destroy", "cmx_fast2d_match",
+    "cmx_fast2d_match_full_submap", "cmx_fast2d_match_full_submap_batch", "cmx_cloud_upload",
+    "cmx_cloud_destroy", "cmx_fast2d_match_full_submap_batch_resident", "cmx_fast2d_level_dims",
+    "cmx_fast2d_level_cells", "cmx_fast2d_debug_prepare", "cmx_rt3d_match", "cmx_fast3d_create",
+    "cmx_fast3d_destroy", "cmx_fast3d_match", "cmx_fast3d_match_full_submap",
+]
+
+_lib = None
+
+
+def lib():
+    """Loads the shared library (importing torch first so both share one HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            f"{SO_PATH} is missing: build it with `python -m cartographer_amd.build` "
+            "(there is no fallback path)")
+    try:  # torch bundles libamdhip64.so.7; load it first so one runtime serves both
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is plumbing only
+        pass
+    L = C.CDLL(SO_PATH)
+    L.cmx_version.restype = C.c_char_p
+    L.cmx_status_string.restype = C.c_char_p
+    L.cmx_status_string.argtypes = [C.c_int]
+    L.cmx_last_error.restype = C.c_char_p
+    L.cmx_device_count.restype = C.c_int32
+    L.cmx_set_stream.argtypes = [C.c_int32, C.c_void_p]
+    P = C.POINTER
+    L.cmx_rt2d_match.argtypes = [P(RtOptions), P(Grid2DLimits), C.c_void_p, P(Pose2d), C.c_void_p,
+                                 C.c_int32, C.c_int32, P(C.c_double), P(Pose2d), P(MatchStats)]
+    L.cmx_fast2d_create.argtypes = [P(Fast2DOptions), P(Grid2DLimits), C.c_void_p, C.c_int32,
+                                    P(C.c_void_p)]
+    L.cmx_fast2d_destroy.argtypes = [C.c_void_p]
+    L.cmx_fast2d_destroy.restype = None
+    L.cmx_fast2d_match.argtypes = [C.c_void_p, P(Pose2d), C.c_void_p, C.c_int32, C.c_float,
+                                   P(C.c_int32), P(C.c_float), P(Pose2d), P(MatchStats)]
+    L.cmx_fast2d_match_full_submap.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float,
+                                               P(C.c_int32), P(C.c_float), P(Pose2d),
+                                               P(MatchStats)]
+    L.cmx_fast2d_match_full_submap_batch.argtypes = [P(C.c_void_p), C.c_int32, C.c_void_p,
+                                                     C.c_int32, C.c_float, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p, P(MatchStats)]
+    L.cmx_cloud_upload.argtypes = [C.c_void_p, C.c_int32, C.c_int32, P(C.c_void_p)]
+    L.cmx_cloud_destroy.argtypes = [C.c_void_p]
+    L.cmx_cloud_destroy.restype = None
+    L.cmx_fast2d_match_full_submap_batch_resident.argtypes = [
+        P(C.c_void_p), C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+        P(MatchStats)]
+    L.cmx_fast2d_level_dims.argtypes = [C.c_void_p, C.c_int32, P(C.c_int32), P(C.c_int32)]
+    L.cmx_fast2d_level_cells.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    L.cmx_fast2d_debug_prepare.argtypes = [C.c_void_p, P(Pose2d), C.c_void_p, C.c_int32,
+                                           C.c_int32, P(C.c_int32), P(C.c_double), C.c_void_p,
+                                           C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                           C.c_int64, P(C.c_int64)]
+    L.cmx_rt3d_match.argtypes = [P(RtOptions), C.c_float, C.c_void_p, C.c_int64, P(Pose3d),
+                                 C.c_void_p, C.c_int32, C.c_int32, P(C.c_float), P(Pose3d),
+                                 P(MatchStats)]
+    L.cmx_fast3d_create.argtypes = [P(Fast3DOptions), C.c_float, C.c_int32, C.c_void_p, C.c_int64,
+                                    C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
+                                    C.c_int32, P(C.c_void_p)]
+    L.cmx_fast3d_destroy.argtypes = [C.c_void_p]
+    L.cmx_fast3d_destroy.restype = None
+    L.cmx_fast3d_match.argtypes = [C.c_void_p, P(Pose3d), P(Pose3d), P(NodeData3D), C.c_float,
+                                   P(C.c_int32), P(Result3D), P(MatchStats)]
+    L.cmx_fast3d_match_full_submap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, P(NodeData3D),
+                                               C.c_float, P(C.c_int32), P(Result3D),
+                                               P(MatchStats)]
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != OK:
+        L = lib()
+        raise CmxError(status, f"{L.cmx_status_string(status).decode()}: "
+                               f"{L.cmx_last_error().decode()}")

@@ -1,0 +1,151 @@
+// Shared host-side plumbing of libcartographer_mi355x: error reporting,
+// device buffers, per-call workspaces (stream + scratch + pinned staging).
+#ifndef CMX_COMMON_H_
+#define CMX_COMMON_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/cartographer_mi355x.h"
+
+namespace cmx {
+
+void SetLastError(const char* fmt, ...);
+const char* LastError();
+
+struct HipError {
+  cmx_status status;
+};
+
+// Throws HipError on failure; caught at the C boundary.
+#define CMX_HIP(expr)                                                              \
+  do {                                                                             \
+    hipError_t cmx_err__ = (expr);                                                 \
+    if (cmx_err__ != hipSuccess) {                                                 \
+      ::cmx::SetLastError("%s failed: %s (%s:%d)", #expr,                          \
+                          hipGetErrorString(cmx_err__), __FILE__, __LINE__);       \
+      throw ::cmx::HipError{cmx_err__ == hipErrorOutOfMemory ? CMX_OUT_OF_MEMORY   \
+                                                             : CMX_DEVICE_ERROR};  \
+    }                                                                              \
+  } while (0)
+
+#define CMX_REQUIRE(cond, ...)                       \
+  do {                                               \
+    if (!(cond)) {                                   \
+      ::cmx::SetLastError(__VA_ARGS__);              \
+      throw ::cmx::HipError{CMX_INVALID_ARGUMENT};   \
+    }                                                \
+  } while (0)
+
+// Runs `body`, translating exceptions into a cmx_status.
+template <typename F>
+cmx_status Guard(F&& body) {
+  try {
+    body();
+    return CMX_OK;
+  } catch (const HipError& e) {
+    return e.status;
+  } catch (const std::bad_alloc&) {
+    SetLastError("host allocation failed");
+    return CMX_OUT_OF_MEMORY;
+  } catch (const std::exception& e) {
+    SetLastError("exception: %s", e.what());
+    return CMX_DEVICE_ERROR;
+  }
+}
+
+// Validates `device` (fails loudly without a GPU) and makes it current.
+void UseDevice(int device);
+
+// Grow-only device buffer.
+class DeviceBuffer {
+ public:
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  ~DeviceBuffer() { Free(); }
+  void* Reserve(size_t bytes) {
+    if (bytes > capacity_) {
+      Free();
+      const size_t want = bytes + bytes / 4 + 256;
+      CMX_HIP(hipMalloc(&ptr_, want));
+      capacity_ = want;
+    }
+    return ptr_;
+  }
+  template <typename T>
+  T* ReserveAs(size_t count) { return static_cast<T*>(Reserve(count * sizeof(T))); }
+  void* get() const { return ptr_; }
+  size_t capacity() const { return capacity_; }
+  void Free() {
+    if (ptr_) (void)hipFree(ptr_);
+    ptr_ = nullptr;
+    capacity_ = 0;
+  }
+ private:
+  void* ptr_ = nullptr;
+  size_t capacity_ = 0;
+};
+
+class PinnedBuffer {
+ public:
+  PinnedBuffer() = default;
+  PinnedBuffer(const PinnedBuffer&) = delete;
+  PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+  ~PinnedBuffer() { if (ptr_) (void)hipHostFree(ptr_); }
+  void* Reserve(size_t bytes) {
+    if (bytes > capacity_) {
+      if (ptr_) (void)hipHostFree(ptr_);
+      ptr_ = nullptr;
+      const size_t want = bytes + bytes / 4 + 256;
+      CMX_HIP(hipHostMalloc(&ptr_, want, hipHostMallocDefault));
+      capacity_ = want;
+    }
+    return ptr_;
+  }
+  template <typename T>
+  T* ReserveAs(size_t count) { return static_cast<T*>(Reserve(count * sizeof(T))); }
+ private:
+  void* ptr_ = nullptr;
+  size_t capacity_ = 0;
+};
+
+// Everything one in-flight call needs; handed out by a per-device pool so
+// concurrent callers never share scratch.
+struct Workspace {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;  // own_stream or the caller's (cmx_set_stream)
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;  // dominant-kernel bracket
+  static constexpr int kNumBuffers = 16;
+  DeviceBuffer dev[kNumBuffers];
+  PinnedBuffer pinned[4];
+  ~Workspace();
+};
+
+class WorkspaceLease {
+ public:
+  explicit WorkspaceLease(int device);
+  ~WorkspaceLease();
+  Workspace* operator->() { return ws_; }
+  Workspace& operator*() { return *ws_; }
+ private:
+  Workspace* ws_;
+};
+
+// Thread-local stream override (cmx_set_stream).
+hipStream_t OverrideStream(int device);
+
+inline int DivUp(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / b); }
+
+}  // namespace cmx
+
+#endif  // CMX_COMMON_H_

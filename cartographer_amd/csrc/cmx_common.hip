@@ -1,0 +1,129 @@
+// Host plumbing: error text, device selection, workspace pool, library entry
+// points that are not tied to one matcher.
+#include "cmx_common.h"
+
+#include <map>
+#include <memory>
+
+namespace cmx {
+namespace {
+thread_local std::string g_last_error;
+thread_local std::map<int, hipStream_t> g_stream_override;
+
+struct Pool {
+  std::mutex mu;
+  std::map<int, std::vector<Workspace*>> free_list;
+  ~Pool() {
+    // Intentionally leak at process exit: the HIP runtime may already be
+    // torn down when static destructors run.
+  }
+};
+Pool& ThePool() {
+  static Pool* pool = new Pool;
+  return *pool;
+}
+}  // namespace
+
+void SetLastError(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+const char* LastError() { return g_last_error.c_str(); }
+
+void UseDevice(int device) {
+  int count = 0;
+  hipError_t err = hipGetDeviceCount(&count);
+  if (err != hipSuccess || count <= 0) {
+    SetLastError("no HIP device available (%s); this library has no CPU fallback",
+                 err == hipSuccess ? "device count is 0" : hipGetErrorString(err));
+    throw HipError{CMX_DEVICE_ERROR};
+  }
+  CMX_REQUIRE(device >= 0 && device < count, "device %d out of range [0,%d)", device, count);
+  CMX_HIP(hipSetDevice(device));
+}
+
+hipStream_t OverrideStream(int device) {
+  auto it = g_stream_override.find(device);
+  return it == g_stream_override.end() ? nullptr : it->second;
+}
+
+Workspace::~Workspace() {
+  if (ev_begin) (void)hipEventDestroy(ev_begin);
+  if (ev_end) (void)hipEventDestroy(ev_end);
+  if (ev_k0) (void)hipEventDestroy(ev_k0);
+  if (ev_k1) (void)hipEventDestroy(ev_k1);
+  if (own_stream) (void)hipStreamDestroy(own_stream);
+}
+
+WorkspaceLease::WorkspaceLease(int device) : ws_(nullptr) {
+  UseDevice(device);
+  Pool& pool = ThePool();
+  {
+    std::lock_guard<std::mutex> lock(pool.mu);
+    auto& list = pool.free_list[device];
+    if (!list.empty()) {
+      ws_ = list.back();
+      list.pop_back();
+    }
+  }
+  if (!ws_) {
+    std::unique_ptr<Workspace> ws(new Workspace);
+    ws->device = device;
+    CMX_HIP(hipStreamCreateWithFlags(&ws->own_stream, hipStreamNonBlocking));
+    CMX_HIP(hipEventCreate(&ws->ev_begin));
+    CMX_HIP(hipEventCreate(&ws->ev_end));
+    CMX_HIP(hipEventCreate(&ws->ev_k0));
+    CMX_HIP(hipEventCreate(&ws->ev_k1));
+    ws_ = ws.release();
+  }
+  hipStream_t over = OverrideStream(device);
+  ws_->stream = over ? over : ws_->own_stream;
+}
+
+WorkspaceLease::~WorkspaceLease() {
+  Pool& pool = ThePool();
+  std::lock_guard<std::mutex> lock(pool.mu);
+  pool.free_list[ws_->device].push_back(ws_);
+}
+
+}  // namespace cmx
+
+extern "C" {
+
+const char* cmx_version(void) { return "cartographer_mi355x 0.1 (gfx950)"; }
+
+const char* cmx_status_string(cmx_status s) {
+  switch (s) {
+    case CMX_OK: return "CMX_OK";
+    case CMX_INVALID_ARGUMENT: return "CMX_INVALID_ARGUMENT";
+    case CMX_DEVICE_ERROR: return "CMX_DEVICE_ERROR";
+    case CMX_OUT_OF_MEMORY: return "CMX_OUT_OF_MEMORY";
+    case CMX_UNSUPPORTED: return "CMX_UNSUPPORTED";
+  }
+  return "CMX_?";
+}
+
+const char* cmx_last_error(void) { return cmx::LastError(); }
+
+int32_t cmx_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+  return count;
+}
+
+cmx_status cmx_set_stream(int32_t device, void* hip_stream) {
+  return cmx::Guard([&] {
+    cmx::UseDevice(device);
+    if (hip_stream) {
+      cmx::g_stream_override[device] = static_cast<hipStream_t>(hip_stream);
+    } else {
+      cmx::g_stream_override.erase(device);
+    }
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+// Device-side arithmetic shared by the scan-matching kernels.
+//
+// Everything here is compiled with -ffp-contract=off: the reference computes
+// these expressions without FMA contraction, and a one-ulp difference ahead of
+// an lround moves a point into a neighbouring cell.  IEEE +,-,*,/ on gfx950
+// are correctly rounded (f32 denormals enabled by default), so with identical
+// operation order the results are bit-identical to the x86 reference.
+// Transcendentals (cosf/sinf/exp) are NOT evaluated on the device where a
+// rounding difference could change a result; the host passes them in.
+#ifndef CMX_DEVICE_H_
+#define CMX_DEVICE_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cmx {
+
+constexpr int kMaxDepth = 12;   // branch_and_bound_depth upper bound
+constexpr int kWave = 64;
+
+// std::lround semantics (round half away from zero) without libm.
+__device__ __forceinline__ int LRoundF64(double x) {
+  double t = trunc(x);
+  const double frac = x - t;  // exact
+  if (frac >= 0.5) t += 1.0;
+  if (frac <= -0.5) t -= 1.0;
+  return static_cast<int>(t);
+}
+__device__ __forceinline__ int LRoundF32(float x) {
+  float t = truncf(x);
+  const float frac = x - t;  // exact
+  if (frac >= 0.5f) t += 1.0f;
+  if (frac <= -0.5f) t -= 1.0f;
+  return static_cast<int>(t);
+}
+
+struct F3 { float x, y, z; };
+struct Quat { float w, x, y, z; };
+
+__device__ __forceinline__ F3 Cross(const F3& a, const F3& b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// Eigen 3.3 Quaternion::_transformVector (used by
+// sensor/rangefinder_point.h:43-48 through Rigid3::operator*).
+__device__ __forceinline__ F3 Rotate(const Quat& q, const F3& v) {
+  const F3 qv{q.x, q.y, q.z};
+  F3 uv = Cross(qv, v);
+  uv.x += uv.x; uv.y += uv.y; uv.z += uv.z;
+  const F3 c = Cross(qv, uv);
+  return {(v.x + q.w * uv.x) + c.x, (v.y + q.w * uv.y) + c.y, (v.z + q.w * uv.z) + c.z};
+}
+__device__ __forceinline__ Quat QuatMul(const Quat& a, const Quat& b) {
+  return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z,
+          a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+          a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+          a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
+}
+
+// Wave-wide integer sum (all 64 lanes receive the total).
+__device__ __forceinline__ int WaveSum(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ int WaveMin(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ int WaveMax(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ unsigned long long WaveMaxU64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned long long o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+}  // namespace cmx
+
+#endif  // CMX_DEVICE_H_

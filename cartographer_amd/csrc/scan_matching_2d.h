@@ -1,0 +1,111 @@
+// Internal declarations of the 2D matchers (device descriptors + host classes).
+#ifndef CMX_SCAN_MATCHING_2D_H_
+#define CMX_SCAN_MATCHING_2D_H_
+
+#include <memory>
+#include <vector>
+
+#include "cmx_common.h"
+#include "cmx_device.h"
+
+namespace cmx {
+
+// One level of a PrecomputationGridStack2D in device memory
+// (SM2/fast_correlative_scan_matcher_2d.h:49-93): width 2^level, dims
+// (nx+w-1) x (ny+w-1), cell (x0,y0) stored at [(x0+w-1) + (y0+w-1)*wx].
+struct LevelDesc {
+  const uint8_t* cells;
+  int wx, wy;
+};
+
+// Device-visible description of one (scan, submap) search.
+struct Fast2DProblem {
+  LevelDesc level[kMaxDepth];
+  int depth;            // branch_and_bound_depth (number of levels)
+  int nx, ny;           // CellLimits
+  int nl;               // linear window in cells (bounds start at +-nl)
+  double res, max_x, max_y;
+  float tx, ty;         // initial translation narrowed to f32
+  float init_qw, init_qz;   // Quaternion(AngleAxisf(f32(theta0), Z))
+  int num_scans;
+  int coarse_capacity;  // size of coarse_score / coarse_sum
+  const float2* scan_rot;   // [num_scans] (w, z) of AngleAxisf(f32(delta_theta_s), Z)
+  float min_s, score_scale; // ToScore(v) = min_s + v * score_scale
+  float min_score;          // caller's acceptance threshold
+  // scratch
+  uint32_t* discrete;   // [num_scans][n] packed int16 (x | y << 16)
+  int4* bounds;         // [num_scans] (min_x, max_x, min_y, max_y) after ShrinkToFit
+  int2* coarse_dims;    // [num_scans] (#x, #y lowest-resolution candidates)
+  int* coarse_off;      // [num_scans + 1]
+  float* coarse_score;  // [coarse_capacity]
+  int* coarse_sum;      // [coarse_capacity]
+};
+
+// Branch-and-bound node.
+struct Node2D {
+  int problem;      // index into the batch
+  int scan;
+  int dx, dy;       // x/y_index_offset of the node's lowest corner
+  float score;
+  int coarse_index; // generation index of the lowest-resolution ancestor
+  unsigned path;    // sibling ranks along the descent, 2 bits per level
+  float coarse_score;
+};
+
+struct ProblemState {       // per problem, device
+  unsigned best_bits;       // float bits of the best leaf score so far (>= min_score)
+  int coarse_total;
+  int error;                // 1: cell index outside int16, 2: coarse capacity exceeded
+  int pad;
+  unsigned long long candidates_scored;
+  unsigned long long nodes_expanded;
+};
+
+struct BestLeaf {           // per problem, device → host
+  float score;
+  int scan, dx, dy;
+  int found;                // a leaf with score > min_score exists
+  int ties;                 // number of recorded leaves sharing the best score
+  int pad0, pad1;
+};
+
+class Fast2DMatcher {
+ public:
+  Fast2DMatcher(const cmx_fast2d_options& options, const cmx_grid2d_limits& limits,
+                const uint16_t* cells, int device);
+  ~Fast2DMatcher();
+  int device() const { return device_; }
+  const cmx_fast2d_options& options() const { return options_; }
+  const cmx_grid2d_limits& limits() const { return limits_; }
+  int depth() const { return options_.branch_and_bound_depth; }
+  const LevelDesc& level(int i) const { return levels_[i]; }
+  size_t level_offset(int i) const { return level_offsets_[i]; }
+  float min_s() const { return min_s_; }
+  float score_scale() const { return score_scale_; }
+
+ private:
+  cmx_fast2d_options options_;
+  cmx_grid2d_limits limits_;
+  int device_;
+  void* stack_mem_ = nullptr;      // all levels, contiguous
+  std::vector<LevelDesc> levels_;
+  std::vector<size_t> level_offsets_;
+  float min_s_, score_scale_;
+};
+
+}  // namespace cmx
+
+struct cmx_fast2d {
+  std::unique_ptr<cmx::Fast2DMatcher> impl;
+};
+
+struct cmx_cloud {
+  int device = 0;
+  int num_points = 0;
+  float* xyz = nullptr;          // device
+  float max_range_xy = 0.f;      // max ||p.xy|| (f32, as SearchParameters computes it)
+  float max_range_xyz = 0.f;
+  std::vector<float> host_xyz;
+};
+
+#endif  // CMX_SCAN_MATCHING_2D_H_

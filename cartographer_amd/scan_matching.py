@@ -1,0 +1,203 @@
+"""Host-side mirror of the reference's scan-matcher classes over the C ABI.
+
+Same names, argument meaning and failure behaviour as
+``cartographer/mapping/internal/2d/scan_matching/real_time_correlative_scan_matcher_2d.h:48-83``
+and ``.../fast_correlative_scan_matcher_2d.h:109-160`` (3D twins in
+``.../3d/scan_matching``), so the parity tests read like the reference's own
+tests.  All arithmetic happens in ``libcartographer_mi355x.so``.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import (Fast2DOptions, Grid2DLimits, MatchStats, Pose2d, RtOptions, check)
+
+K_MIN_CORRESPONDENCE_COST = float(np.float32(1) - (np.float32(1) - np.float32(0.1)))
+K_MAX_CORRESPONDENCE_COST = float(np.float32(1) - np.float32(0.1))
+
+
+@dataclass
+class Rigid2d:
+    """transform::Rigid2d: translation + rotation angle."""
+    x: float = 0.0
+    y: float = 0.0
+    theta: float = 0.0
+
+    def to_c(self):
+        return Pose2d(self.x, self.y, self.theta)
+
+
+class Grid2D:
+    """Read-only view of a ProbabilityGrid: MapLimits + correspondence-cost cells."""
+
+    def __init__(self, cells, resolution, max_x, max_y,
+                 min_correspondence_cost=K_MIN_CORRESPONDENCE_COST,
+                 max_correspondence_cost=K_MAX_CORRESPONDENCE_COST):
+        self.cells = np.ascontiguousarray(cells, dtype=np.uint16)
+        if self.cells.ndim != 2:
+            raise ValueError("cells must be [num_y_cells, num_x_cells]")
+        self.resolution = float(resolution)
+        self.max_x = float(max_x)
+        self.max_y = float(max_y)
+        self.min_correspondence_cost = float(min_correspondence_cost)
+        self.max_correspondence_cost = float(max_correspondence_cost)
+
+    @property
+    def num_x_cells(self):
+        return self.cells.shape[1]
+
+    @property
+    def num_y_cells(self):
+        return self.cells.shape[0]
+
+    def limits_c(self):
+        return Grid2DLimits(self.resolution, self.max_x, self.max_y, self.num_x_cells,
+                            self.num_y_cells, self.min_correspondence_cost,
+                            self.max_correspondence_cost)
+
+
+def _cloud(point_cloud):
+    xyz = np.ascontiguousarray(point_cloud, dtype=np.float32).reshape(-1, 3)
+    return xyz, xyz.shape[0]
+
+
+class RealTimeCorrelativeScanMatcher2D:
+    """RealTimeCorrelativeScanMatcher2D(options).Match(initial, cloud, grid) -> (score, pose)."""
+
+    def __init__(self, linear_search_window, angular_search_window,
+                 translation_delta_cost_weight, rotation_delta_cost_weight, device=0):
+        self.options = RtOptions(linear_search_window, angular_search_window,
+                                 translation_delta_cost_weight, rotation_delta_cost_weight)
+        self.device = device
+        self.last_stats = None
+
+    def match(self, initial_pose_estimate, point_cloud, grid):
+        xyz, n = _cloud(point_cloud)
+        limits = grid.limits_c()
+        init = initial_pose_estimate.to_c()
+        score = C.c_double()
+        pose = Pose2d()
+        stats = MatchStats()
+        check(_lib.lib().cmx_rt2d_match(C.byref(self.options), C.byref(limits),
+                                        grid.cells.ctypes.data, C.byref(init), xyz.ctypes.data, n,
+                                        self.device, C.byref(score), C.byref(pose),
+                                        C.byref(stats)))
+        self.last_stats = stats.as_dict()
+        return score.value, Rigid2d(pose.x, pose.y, pose.theta)
+
+
+class PointCloudOnDevice:
+    """A point cloud uploaded once (cmx_cloud) for repeated resident matches."""
+
+    def __init__(self, point_cloud, device=0):
+        xyz, n = _cloud(point_cloud)
+        self.num_points = n
+        self._h = C.c_void_p()
+        check(_lib.lib().cmx_cloud_upload(xyz.ctypes.data, n, device, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.lib().cmx_cloud_destroy(self._h)
+            self._h = None
+
+
+class FastCorrelativeScanMatcher2D:
+    """FastCorrelativeScanMatcher2D(grid, options): Match / MatchFullSubmap.
+
+    ``match*`` return ``(found, score, pose)``; ``found`` False mirrors the
+    reference returning ``false`` (score/pose are then None).
+    """
+
+    def __init__(self, grid, branch_and_bound_depth, linear_search_window=7.0,
+                 angular_search_window=float(np.deg2rad(30.0)), device=0):
+        self.grid = grid
+        self.options = Fast2DOptions(linear_search_window, angular_search_window,
+                                     branch_and_bound_depth)
+        self.device = device
+        self.last_stats = None
+        self._h = C.c_void_p()
+        limits = grid.limits_c()
+        check(_lib.lib().cmx_fast2d_create(C.byref(self.options), C.byref(limits),
+                                           grid.cells.ctypes.data, device, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.lib().cmx_fast2d_destroy(self._h)
+            self._h = None
+
+    def _result(self, found, score, pose, stats):
+        self.last_stats = stats.as_dict()
+        if not found.value:
+            return False, None, None
+        return True, float(score.value), Rigid2d(pose.x, pose.y, pose.theta)
+
+    def match(self, initial_pose_estimate, point_cloud, min_score):
+        xyz, n = _cloud(point_cloud)
+        init = initial_pose_estimate.to_c()
+        found, score, pose, stats = C.c_int32(), C.c_float(), Pose2d(), MatchStats()
+        check(_lib.lib().cmx_fast2d_match(self._h, C.byref(init), xyz.ctypes.data, n, min_score,
+                                          C.byref(found), C.byref(score), C.byref(pose),
+                                          C.byref(stats)))
+        return self._result(found, score, pose, stats)
+
+    def match_full_submap(self, point_cloud, min_score):
+        xyz, n = _cloud(point_cloud)
+        found, score, pose, stats = C.c_int32(), C.c_float(), Pose2d(), MatchStats()
+        check(_lib.lib().cmx_fast2d_match_full_submap(self._h, xyz.ctypes.data, n, min_score,
+                                                      C.byref(found), C.byref(score),
+                                                      C.byref(pose), C.byref(stats)))
+        return self._result(found, score, pose, stats)
+
+    # -- introspection for the parity tests ---------------------------------
+    def level(self, i):
+        wx, wy = C.c_int32(), C.c_int32()
+        check(_lib.lib().cmx_fast2d_level_dims(self._h, i, C.byref(wx), C.byref(wy)))
+        out = np.empty((wy.value, wx.value), np.uint8)
+        check(_lib.lib().cmx_fast2d_level_cells(self._h, i, out.ctypes.data))
+        return out
+
+    def debug_prepare(self, initial_pose_estimate, point_cloud, full_submap):
+        xyz, n = _cloud(point_cloud)
+        init = (initial_pose_estimate or Rigid2d()).to_c()
+        ns, step, ncoarse = C.c_int32(), C.c_double(), C.c_int64()
+        L = _lib.lib()
+        check(L.cmx_fast2d_debug_prepare(self._h, C.byref(init), xyz.ctypes.data, n,
+                                         int(full_submap), C.byref(ns), C.byref(step), None, 0,
+                                         None, 0, None, 0, C.byref(ncoarse)))
+        scans = np.empty((ns.value, n, 2), np.int32)
+        bounds = np.empty((ns.value, 4), np.int32)
+        sums = np.empty(ncoarse.value, np.int32)
+        check(L.cmx_fast2d_debug_prepare(self._h, C.byref(init), xyz.ctypes.data, n,
+                                         int(full_submap), C.byref(ns), C.byref(step),
+                                         scans.ctypes.data, scans.size, bounds.ctypes.data,
+                                         bounds.size, sums.ctypes.data, sums.size,
+                                         C.byref(ncoarse)))
+        return dict(num_scans=ns.value, step=step.value, scans=scans, bounds=bounds, sums=sums)
+
+
+def match_full_submap_batch(matchers, point_cloud, min_score):
+    """One scan against many submaps: the ConstraintBuilder2D fan-out
+    (constraints/constraint_builder_2d.cc:97-137) as a single device batch.
+
+    ``point_cloud`` is an array or a PointCloudOnDevice.  Returns
+    (found[int32], scores[float32], poses[n,3], stats dict).
+    """
+    num = len(matchers)
+    handles = (C.c_void_p * num)(*[m._h for m in matchers])
+    found = np.zeros(num, np.int32)
+    scores = np.zeros(num, np.float32)
+    poses = np.zeros((num, 3), np.float64)
+    stats = MatchStats()
+    L = _lib.lib()
+    if isinstance(point_cloud, PointCloudOnDevice):
+        check(L.cmx_fast2d_match_full_submap_batch_resident(
+            handles, num, point_cloud._h, min_score, found.ctypes.data, scores.ctypes.data,
+            poses.ctypes.data, C.byref(stats)))
+    else:
+        xyz, n = _cloud(point_cloud)
+        check(L.cmx_fast2d_match_full_submap_batch(handles, num, xyz.ctypes.data, n, min_score,
+                                                   found.ctypes.data, scores.ctypes.data,
+                                                   poses.ctypes.data, C.byref(stats)))
+    return found, scores, poses, stats.as_dict()

@@ -1,0 +1,160 @@
+"""Synthetic worlds, scans and probability grids (host-only tooling).
+
+ctypes binding of ``cartographer_amd/lib/libcmx_synth.so`` (sources in
+``csrc/host``): the probability-grid range-data inserter restatement
+(reference ``mapping/2d/probability_grid_range_data_inserter_2d.cc:35-133``)
+and the seeded room / lidar generator SURVEY.md §8d describes.  Used by
+``bench.py`` and the tests to produce identical bytes for the GPU path and the
+checker; not part of the device hot path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "lib", "libcmx_synth.so")
+
+_u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise RuntimeError(
+                f"{_SO} is missing - run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(_SO)
+        L.cmx_synth_world_create.argtypes = [C.c_uint64] + [C.c_double] * 4
+        L.cmx_synth_world_create.restype = C.c_void_p
+        L.cmx_synth_world_destroy.argtypes = [C.c_void_p]
+        L.cmx_synth_world_free_pose.argtypes = [C.c_void_p, C.c_uint64, C.c_double, _f64p]
+        L.cmx_synth_scan.argtypes = [C.c_void_p, _f64p, C.c_int, C.c_double, C.c_double,
+                                     C.c_uint64, _f32p]
+        L.cmx_pgrid_create.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
+        L.cmx_pgrid_create.restype = C.c_void_p
+        L.cmx_pgrid_destroy.argtypes = [C.c_void_p]
+        L.cmx_pgrid_limits.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                       C.POINTER(C.c_int)]
+        L.cmx_pgrid_cells.argtypes = [C.c_void_p, _u16p]
+        L.cmx_pgrid_set_probability.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float]
+        L.cmx_pgrid_get_probability.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.cmx_pgrid_get_probability.restype = C.c_float
+        L.cmx_pgrid_insert.argtypes = [C.c_void_p, _f32p, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_int, C.c_float, C.c_float, C.c_int]
+        L.cmx_pgrid_cropped.argtypes = [C.c_void_p]
+        L.cmx_pgrid_cropped.restype = C.c_void_p
+        L.cmx_pgrid_odds_table.argtypes = [C.c_float, _u16p]
+        L.cmx_cells_on_ray.argtypes = [C.c_int] * 5 + [_i32p, C.c_int, C.POINTER(C.c_int)]
+        L.cmx_synth_submap.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_int,
+                                       C.c_int, C.c_double, C.c_double, _u16p, _f64p]
+        L.cmx_synth_submap.restype = C.c_void_p
+        _lib = L
+    return _lib
+
+
+class ProbabilityGrid:
+    """Mirror of mapping/2d/probability_grid.h for building fixtures."""
+
+    def __init__(self, resolution, max_xy, num_x_cells, num_y_cells, _handle=None):
+        self._h = _handle or lib().cmx_pgrid_create(resolution, max_xy[0], max_xy[1],
+                                                    num_x_cells, num_y_cells)
+        if not self._h:
+            raise ValueError("invalid grid limits")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().cmx_pgrid_destroy(self._h)
+            self._h = None
+
+    @property
+    def limits(self):
+        res, mx, my, nx, ny = C.c_double(), C.c_double(), C.c_double(), C.c_int(), C.c_int()
+        lib().cmx_pgrid_limits(self._h, C.byref(res), C.byref(mx), C.byref(my), C.byref(nx),
+                               C.byref(ny))
+        return dict(resolution=res.value, max_x=mx.value, max_y=my.value,
+                    num_x_cells=nx.value, num_y_cells=ny.value)
+
+    @property
+    def cells(self):
+        lim = self.limits
+        out = np.empty((lim["num_y_cells"], lim["num_x_cells"]), np.uint16)
+        lib().cmx_pgrid_cells(self._h, out)
+        return out
+
+    def set_probability(self, ix, iy, probability):
+        if lib().cmx_pgrid_set_probability(self._h, ix, iy, probability):
+            raise ValueError("SetProbability failed (cell known or outside)")
+
+    def get_probability(self, ix, iy):
+        return float(lib().cmx_pgrid_get_probability(self._h, ix, iy))
+
+    def insert(self, origin_xy, returns_xyz, misses_xyz=None, hit_probability=0.7,
+               miss_probability=0.4, insert_free_space=True):
+        origin = np.ascontiguousarray(origin_xy, np.float32)[:2].copy()
+        ret = np.ascontiguousarray(returns_xyz, np.float32).reshape(-1, 3)
+        mis = (np.ascontiguousarray(misses_xyz, np.float32).reshape(-1, 3)
+               if misses_xyz is not None else np.zeros((0, 3), np.float32))
+        rc = lib().cmx_pgrid_insert(self._h, origin, ret.ctypes.data, ret.shape[0],
+                                    mis.ctypes.data, mis.shape[0], hit_probability,
+                                    miss_probability, int(insert_free_space))
+        if rc:
+            raise RuntimeError("range data insertion failed")
+
+    def cropped(self):
+        return ProbabilityGrid(0, (0, 0), 0, 0, _handle=lib().cmx_pgrid_cropped(self._h))
+
+
+def odds_table(probability):
+    out = np.empty(32768, np.uint16)
+    lib().cmx_pgrid_odds_table(probability, out)
+    return out
+
+
+def cells_on_ray(begin, end, scale=1000):
+    cap = 1 << 16
+    out = np.empty((cap, 2), np.int32)
+    n = C.c_int()
+    lib().cmx_cells_on_ray(begin[0], begin[1], end[0], end[1], scale, out, cap, C.byref(n))
+    return out[: n.value].copy()
+
+
+class World:
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().cmx_synth_world_destroy(self._h)
+            self._h = None
+
+    def free_pose(self, seed, clearance=0.3):
+        p = np.empty(3, np.float64)
+        lib().cmx_synth_world_free_pose(self._h, seed, clearance, p)
+        return p
+
+    def scan(self, pose_xyt, beams=1000, max_range=10.0, sigma=0.01, seed=0):
+        out = np.empty((beams, 3), np.float32)
+        n = lib().cmx_synth_scan(self._h, np.ascontiguousarray(pose_xyt, np.float64), beams,
+                                 max_range, sigma, seed, out)
+        return out[:n].copy()
+
+
+def make_submap(seed, nx=400, ny=400, resolution=0.05, num_poses=30, beams=1000,
+                max_range=10.0, sigma=0.01):
+    """Returns (cells[ny,nx] u16, limits dict, World)."""
+    cells = np.empty((ny, nx), np.uint16)
+    mx = np.empty(2, np.float64)
+    h = lib().cmx_synth_submap(seed, nx, ny, resolution, num_poses, beams, max_range, sigma,
+                               cells, mx)
+    if not h:
+        raise RuntimeError("synthetic submap generation failed (grid grew)")
+    limits = dict(resolution=resolution, max_x=float(mx[0]), max_y=float(mx[1]),
+                  num_x_cells=nx, num_y_cells=ny)
+    return cells, limits, World(h)

@@ -1,0 +1,240 @@
+/*
+ * cartographer_mi355x.h — C ABI of the MI355X-native correlative scan matchers.
+ *
+ * Drop-in boundary for cartographer's scan-matching hot path.  Every entry
+ * point replaces one method of the four reference classes (paths relative to
+ * the reference tree, `SM2` = cartographer/mapping/internal/2d/scan_matching,
+ * `SM3` = .../3d/scan_matching):
+ *
+ *   cmx_rt2d_match                 RealTimeCorrelativeScanMatcher2D::Match
+ *                                  SM2/real_time_correlative_scan_matcher_2d.h:66-68, .cc:117-149
+ *   cmx_fast2d_create / _destroy   FastCorrelativeScanMatcher2D ctor / dtor
+ *                                  SM2/fast_correlative_scan_matcher_2d.h:114-118, .cc:188-196
+ *   cmx_fast2d_match               FastCorrelativeScanMatcher2D::Match        .h:124-126, .cc:198-208
+ *   cmx_fast2d_match_full_submap   FastCorrelativeScanMatcher2D::MatchFullSubmap .h:132-133, .cc:210-225
+ *   cmx_fast2d_match_full_submap_batch
+ *                                  the ConstraintBuilder2D fan-out of independent
+ *                                  (node, submap) searches, constraints/constraint_builder_2d.cc:97-137
+ *   cmx_rt3d_match                 RealTimeCorrelativeScanMatcher3D::Match
+ *                                  SM3/real_time_correlative_scan_matcher_3d.h:47-50, .cc:34-53
+ *   cmx_fast3d_*                   FastCorrelativeScanMatcher3D ctor / Match / MatchFullSubmap
+ *                                  SM3/fast_correlative_scan_matcher_3d.h:75-101, .cc:112-170
+ *
+ * Conventions
+ *   - Plain C, POD only.  Host pointers are borrowed for the duration of the
+ *     call; outputs are written to caller memory.  No exceptions cross the
+ *     boundary: every function returns a cmx_status.
+ *   - Reference CHECK failures (invalid options, null outputs) map to
+ *     CMX_INVALID_ARGUMENT; "no match above min_score" is CMX_OK with
+ *     *found == 0, exactly like the reference's `false` / `nullptr`.
+ *   - There is NO CPU fallback: without a usable HIP device every compute
+ *     entry point returns CMX_DEVICE_ERROR.
+ *   - Matcher handles are immutable after creation and may be used from
+ *     several host threads at once (the reference calls `Match*` concurrently
+ *     from its thread pool, constraints/constraint_builder_2d.cc:97-111).
+ */
+#ifndef CARTOGRAPHER_MI355X_H_
+#define CARTOGRAPHER_MI355X_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cmx_status {
+  CMX_OK = 0,
+  CMX_INVALID_ARGUMENT = 1,
+  CMX_DEVICE_ERROR = 2,
+  CMX_OUT_OF_MEMORY = 3,
+  CMX_UNSUPPORTED = 4
+} cmx_status;
+
+/* transform::Rigid2d (transform/rigid_transform.h:34-87): translation + yaw. */
+typedef struct cmx_pose2d { double x, y, theta; } cmx_pose2d;
+/* transform::Rigid3d (rigid_transform.h:117-180): translation + quaternion (w,x,y,z). */
+typedef struct cmx_pose3d { double t[3]; double q[4]; } cmx_pose3d;
+
+/* mapping::MapLimits + the Grid2D cost range (mapping/2d/map_limits.h:40-96,
+ * grid_2d.h:60-63).  `cells` passed next to it are Grid2D's
+ * correspondence_cost_cells(): row-major nx*iy+ix, 0 = unknown. */
+typedef struct cmx_grid2d_limits {
+  double resolution;
+  double max_x, max_y;
+  int32_t num_x_cells, num_y_cells;
+  float min_correspondence_cost, max_correspondence_cost;
+} cmx_grid2d_limits;
+
+/* proto::RealTimeCorrelativeScanMatcherOptions
+ * (mapping/proto/scan_matching/real_time_correlative_scan_matcher_options.proto). */
+typedef struct cmx_rt_options {
+  double linear_search_window;
+  double angular_search_window;
+  double translation_delta_cost_weight;
+  double rotation_delta_cost_weight;
+} cmx_rt_options;
+
+/* proto::FastCorrelativeScanMatcherOptions2D. */
+typedef struct cmx_fast2d_options {
+  double linear_search_window;
+  double angular_search_window;
+  int32_t branch_and_bound_depth;
+} cmx_fast2d_options;
+
+/* proto::FastCorrelativeScanMatcherOptions3D. */
+typedef struct cmx_fast3d_options {
+  int32_t branch_and_bound_depth;
+  int32_t full_resolution_depth;
+  double min_rotational_score;
+  double min_low_resolution_score;
+  double linear_xy_search_window;
+  double linear_z_search_window;
+  double angular_search_window;
+} cmx_fast3d_options;
+
+/* Work counters of one call (or summed over a batch). */
+typedef struct cmx_match_stats {
+  int64_t candidates_scored;  /* every scored candidate, all depths */
+  int64_t coarse_candidates;  /* lowest-resolution (or exhaustive) candidates */
+  int64_t nodes_expanded;     /* branch-and-bound nodes whose children were scored */
+  int32_t num_scans;          /* rotated scans */
+  int32_t reserved;
+  double device_ms;           /* HIP-event time of the call's device work */
+  double dominant_kernel_ms;  /* HIP-event time of the dominant scoring kernel(s) */
+} cmx_match_stats;
+
+/* One flattened HybridGrid voxel (mapping/3d/hybrid_grid.h:304-372 Iterator):
+ * cell index and raw uint16 probability value (0 never appears). */
+typedef struct cmx_voxel { int32_t x, y, z; uint16_t value; uint16_t pad; } cmx_voxel;
+
+typedef struct cmx_fast2d cmx_fast2d;   /* opaque FastCorrelativeScanMatcher2D */
+typedef struct cmx_fast3d cmx_fast3d;   /* opaque FastCorrelativeScanMatcher3D */
+
+/* ---- library / device ------------------------------------------------- */
+const char* cmx_version(void);
+const char* cmx_status_string(cmx_status s);
+/* Last error text of the calling thread ("" if none). */
+const char* cmx_last_error(void);
+/* Number of HIP devices visible (0 when there is none). */
+int32_t cmx_device_count(void);
+/* Streams: by default every call runs on a library-owned stream of `device`.
+ * A caller that owns a HIP stream (e.g. torch.cuda.current_stream()) can make
+ * the calling thread's subsequent calls on `device` use it instead;
+ * pass NULL to go back to the library stream. */
+cmx_status cmx_set_stream(int32_t device, void* hip_stream);
+
+/* ---- real-time 2D ------------------------------------------------------ */
+/* Returns the best score (already weighted by the delta cost) in *score and
+ * the pose in *pose_estimate; always succeeds for valid inputs
+ * (reference: CHECK_GT(score, 0)). */
+cmx_status cmx_rt2d_match(const cmx_rt_options* options, const cmx_grid2d_limits* limits,
+                          const uint16_t* cells, const cmx_pose2d* initial_pose_estimate,
+                          const float* point_cloud_xyz, int32_t num_points, int32_t device,
+                          double* score, cmx_pose2d* pose_estimate, cmx_match_stats* stats);
+
+/* ---- fast 2D (branch and bound) ---------------------------------------- */
+/* Uploads the grid and builds the PrecomputationGridStack2D on `device`
+ * (SM2/fast_correlative_scan_matcher_2d.cc:171-186). */
+cmx_status cmx_fast2d_create(const cmx_fast2d_options* options, const cmx_grid2d_limits* limits,
+                             const uint16_t* cells, int32_t device, cmx_fast2d** out);
+void cmx_fast2d_destroy(cmx_fast2d* matcher);
+
+cmx_status cmx_fast2d_match(const cmx_fast2d* matcher, const cmx_pose2d* initial_pose_estimate,
+                            const float* point_cloud_xyz, int32_t num_points, float min_score,
+                            int32_t* found, float* score, cmx_pose2d* pose_estimate,
+                            cmx_match_stats* stats);
+cmx_status cmx_fast2d_match_full_submap(const cmx_fast2d* matcher, const float* point_cloud_xyz,
+                                        int32_t num_points, float min_score, int32_t* found,
+                                        float* score, cmx_pose2d* pose_estimate,
+                                        cmx_match_stats* stats);
+/* One scan against `num_matchers` submaps (all on the same device), results
+ * per submap; `stats` is the sum over the batch. */
+cmx_status cmx_fast2d_match_full_submap_batch(const cmx_fast2d* const* matchers,
+                                              int32_t num_matchers, const float* point_cloud_xyz,
+                                              int32_t num_points, float min_score,
+                                              int32_t* found, float* scores,
+                                              cmx_pose2d* pose_estimates, cmx_match_stats* stats);
+
+/* Device-resident variant for throughput measurement: the point cloud is
+ * uploaded once, repeated matches touch no host buffer except the results. */
+typedef struct cmx_cloud cmx_cloud;
+cmx_status cmx_cloud_upload(const float* point_cloud_xyz, int32_t num_points, int32_t device,
+                            cmx_cloud** out);
+void cmx_cloud_destroy(cmx_cloud* cloud);
+cmx_status cmx_fast2d_match_full_submap_batch_resident(
+    const cmx_fast2d* const* matchers, int32_t num_matchers, const cmx_cloud* cloud,
+    float min_score, int32_t* found, float* scores, cmx_pose2d* pose_estimates,
+    cmx_match_stats* stats);
+
+/* Introspection used by the parity tests (not needed by a caller). */
+cmx_status cmx_fast2d_level_dims(const cmx_fast2d* matcher, int32_t level, int32_t* wide_x,
+                                 int32_t* wide_y);
+cmx_status cmx_fast2d_level_cells(const cmx_fast2d* matcher, int32_t level, uint8_t* out);
+/* Prepared search of a (full-submap or windowed) match: rotated+discretised
+ * scans [num_scans][n][2], shrunk linear bounds [num_scans][4]
+ * (min_x,max_x,min_y,max_y) and the integer sums of every lowest-resolution
+ * candidate in the reference's generation order (scan, x, y).  Any output may
+ * be NULL; capacities are in elements. */
+cmx_status cmx_fast2d_debug_prepare(const cmx_fast2d* matcher,
+                                    const cmx_pose2d* initial_pose_estimate,
+                                    const float* point_cloud_xyz, int32_t num_points,
+                                    int32_t full_submap, int32_t* num_scans,
+                                    double* angular_step, int32_t* discrete_xy,
+                                    int64_t discrete_capacity, int32_t* bounds,
+                                    int64_t bounds_capacity, int32_t* coarse_sums,
+                                    int64_t sums_capacity, int64_t* num_coarse);
+
+/* ---- real-time 3D ------------------------------------------------------ */
+cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_resolution,
+                          const cmx_voxel* voxels, int64_t num_voxels,
+                          const cmx_pose3d* initial_pose_estimate, const float* point_cloud_xyz,
+                          int32_t num_points, int32_t device, float* score,
+                          cmx_pose3d* pose_estimate, cmx_match_stats* stats);
+
+/* ---- fast 3D ------------------------------------------------------------ */
+/* hybrid_grid.h:137 grid_size(): 8*8*2^bits cells per axis of the dynamic
+ * grid the voxels came from (needed by MatchFullSubmap's window). */
+cmx_status cmx_fast3d_create(const cmx_fast3d_options* options, float resolution,
+                             int32_t grid_size, const cmx_voxel* voxels, int64_t num_voxels,
+                             float low_resolution, const cmx_voxel* low_resolution_voxels,
+                             int64_t num_low_resolution_voxels,
+                             const float* rotational_scan_matcher_histogram,
+                             int32_t histogram_size, int32_t device, cmx_fast3d** out);
+void cmx_fast3d_destroy(cmx_fast3d* matcher);
+
+/* TrajectoryNode::Data (mapping/trajectory_node.h:45-63), the fields the
+ * matcher reads. */
+typedef struct cmx_node_data3d {
+  double gravity_alignment[4];                 /* quaternion w,x,y,z */
+  const float* high_resolution_point_cloud;    /* xyz */
+  int32_t num_high_resolution_points;
+  const float* low_resolution_point_cloud;     /* xyz */
+  int32_t num_low_resolution_points;
+  const float* rotational_scan_matcher_histogram;
+  int32_t histogram_size;
+} cmx_node_data3d;
+
+/* FastCorrelativeScanMatcher3D::Result. */
+typedef struct cmx_result3d {
+  float score;
+  cmx_pose3d pose_estimate;
+  float rotational_score;
+  float low_resolution_score;
+} cmx_result3d;
+
+cmx_status cmx_fast3d_match(const cmx_fast3d* matcher, const cmx_pose3d* global_node_pose,
+                            const cmx_pose3d* global_submap_pose, const cmx_node_data3d* data,
+                            float min_score, int32_t* found, cmx_result3d* result,
+                            cmx_match_stats* stats);
+cmx_status cmx_fast3d_match_full_submap(const cmx_fast3d* matcher,
+                                        const double* global_node_rotation_wxyz,
+                                        const double* global_submap_rotation_wxyz,
+                                        const cmx_node_data3d* data, float min_score,
+                                        int32_t* found, cmx_result3d* result,
+                                        cmx_match_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* CARTOGRAPHER_MI355X_H_ */

@@ -1,0 +1,223 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_common.h).
+// Flat C entry points so tests/ and bench.py's cpu_baseline leg can drive the
+// oracle through ctypes.
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <thread>
+
+#include "oracle_2d.h"
+#include "oracle_3d.h"
+
+using namespace oracle;
+
+namespace {
+ProbabilityGridView MakeView(const uint16_t* cells, int nx, int ny, double res, double max_x,
+                             double max_y) {
+  ProbabilityGridView g;
+  g.limits = MapLimits{res, max_x, max_y, nx, ny};
+  g.cells = cells;
+  return g;
+}
+PointCloud MakeCloud(const float* xyz, int n) {
+  PointCloud c(n);
+  for (int i = 0; i != n; ++i) c[i] = Point3f{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+  return c;
+}
+struct Fast2D {
+  std::vector<uint16_t> cells;
+  std::unique_ptr<FastCorrelativeScanMatcher2D> matcher;
+};
+}  // namespace
+
+extern "C" {
+
+// ---- tables / scalar helpers (pins for probability_values_test etc.) ----
+void orc_value_tables(float* value_to_probability_65536, float* value_to_cost_65536,
+                      float* grid_cost_65536) {
+  std::memcpy(value_to_probability_65536, ValueToProbabilityTable().data(), 65536 * 4);
+  std::memcpy(value_to_cost_65536, ValueToCorrespondenceCostTable().data(), 65536 * 4);
+  std::memcpy(grid_cost_65536, GridCorrespondenceCostTable().data(), 65536 * 4);
+}
+int orc_probability_to_value(float p) { return ProbabilityToValue(p); }
+int orc_correspondence_cost_to_value(float c) { return CorrespondenceCostToValue(c); }
+
+// ---- search parameters ----
+void orc_search_parameters(double lin, double ang, const float* xyz, int n, double res,
+                           int* num_angular, double* step, int* num_scans, int* num_linear) {
+  const SearchParameters sp(lin, ang, MakeCloud(xyz, n), res);
+  *num_angular = sp.num_angular_perturbations;
+  *step = sp.angular_perturbation_step_size;
+  *num_scans = sp.num_scans;
+  *num_linear = sp.linear_bounds.empty() ? 0 : sp.linear_bounds[0].max_x;
+}
+
+// GenerateRotatedScans with the testing ctor SearchParameters(nl, na, step, res).
+void orc_generate_rotated_scans(const float* xyz, int n, int na, double step,
+                                float* out_xyz /* (2na+1)*n*3 */) {
+  const SearchParameters sp(0, na, step, 0.);
+  const auto scans = GenerateRotatedScans(MakeCloud(xyz, n), sp);
+  for (size_t s = 0; s != scans.size(); ++s)
+    for (int i = 0; i != n; ++i) {
+      out_xyz[(s * n + i) * 3 + 0] = scans[s][i].x;
+      out_xyz[(s * n + i) * 3 + 1] = scans[s][i].y;
+      out_xyz[(s * n + i) * 3 + 2] = scans[s][i].z;
+    }
+}
+
+// Rotate (initial theta), generate `na` perturbations at `step`, discretise.
+void orc_discretize_scans(const float* xyz, int n, double init_theta, int na, double step,
+                          double res, double max_x, double max_y, int nx, int ny, float tx,
+                          float ty, int* out_xy /* (2na+1)*n*2 */) {
+  const SearchParameters sp(0, na, step, res);
+  const PointCloud rotated = RotateCloudYaw(MakeCloud(xyz, n), static_cast<float>(init_theta));
+  const auto scans = GenerateRotatedScans(rotated, sp);
+  const auto d = DiscretizeScans(MapLimits{res, max_x, max_y, nx, ny}, scans, tx, ty);
+  for (size_t s = 0; s != d.size(); ++s)
+    for (int i = 0; i != n; ++i) {
+      out_xy[(s * n + i) * 2 + 0] = d[s][i].x;
+      out_xy[(s * n + i) * 2 + 1] = d[s][i].y;
+    }
+}
+
+void orc_candidate2d(int nl, int na, double step, double res, int scan_index, int x_off,
+                     int y_off, double* out_xyo) {
+  const SearchParameters sp(nl, na, step, res);
+  const Candidate2D c(scan_index, x_off, y_off, sp);
+  out_xyo[0] = c.x; out_xyo[1] = c.y; out_xyo[2] = c.orientation;
+}
+
+float orc_grid_probability(const uint16_t* cells, int nx, int ny, int ix, int iy) {
+  return MakeView(cells, nx, ny, 1., 0., 0.).GetProbability(Cell2i{ix, iy});
+}
+
+// ---- real-time 2D ----
+double orc_rt2d_match(const uint16_t* cells, int nx, int ny, double res, double max_x,
+                      double max_y, const double* init_xyt, const float* xyz, int n,
+                      double lin, double ang, double tw, double rw, double* pose_xyt,
+                      int64_t* num_candidates, float* all_scores, int all_scores_capacity) {
+  const ProbabilityGridView g = MakeView(cells, nx, ny, res, max_x, max_y);
+  Pose2d pose;
+  MatchStats st;
+  std::vector<float> scores;
+  const double s = RealTimeMatch2D(g, Pose2d{init_xyt[0], init_xyt[1], init_xyt[2]},
+                                   MakeCloud(xyz, n), lin, ang, tw, rw, &pose, &st,
+                                   all_scores ? &scores : nullptr);
+  pose_xyt[0] = pose.x; pose_xyt[1] = pose.y; pose_xyt[2] = pose.theta;
+  if (num_candidates) *num_candidates = st.candidates_scored;
+  if (all_scores) {
+    const size_t m = std::min<size_t>(scores.size(), all_scores_capacity);
+    std::memcpy(all_scores, scores.data(), m * 4);
+  }
+  return s;
+}
+
+// ---- precomputation grid / fast 2D ----
+void* orc_fast2d_create(const uint16_t* cells, int nx, int ny, double res, double max_x,
+                        double max_y, int depth, double lin, double ang) {
+  auto* f = new Fast2D;
+  f->cells.assign(cells, cells + static_cast<size_t>(nx) * ny);
+  f->matcher.reset(new FastCorrelativeScanMatcher2D(
+      MakeView(f->cells.data(), nx, ny, res, max_x, max_y), depth, lin, ang));
+  return f;
+}
+void orc_fast2d_destroy(void* h) { delete static_cast<Fast2D*>(h); }
+
+void orc_fast2d_level_dims(void* h, int level, int* wx, int* wy) {
+  const auto& g = static_cast<Fast2D*>(h)->matcher->level(level);
+  *wx = g.wide_x(); *wy = g.wide_y();
+}
+void orc_fast2d_level_cells(void* h, int level, uint8_t* out) {
+  const auto& g = static_cast<Fast2D*>(h)->matcher->level(level);
+  std::memcpy(out, g.cells().data(), g.cells().size());
+}
+// PrecomputationGrid2D of an arbitrary width (reference test uses widths 3, 200).
+void orc_precompute2d(const uint16_t* cells, int nx, int ny, int width, uint8_t* out) {
+  const PrecomputationGrid2D g(MakeView(cells, nx, ny, 0.05, 0., 0.), width);
+  std::memcpy(out, g.cells().data(), g.cells().size());
+}
+
+int orc_fast2d_match(void* h, const double* init_xyt, const float* xyz, int n,
+                     int full_submap, float min_score, float* score, double* pose_xyt,
+                     int64_t* stats4 /* candidates, scans, coarse, nodes */) {
+  const auto& m = *static_cast<Fast2D*>(h)->matcher;
+  Pose2d pose{0, 0, 0};
+  MatchStats st;
+  float sc = 0.f;
+  const PointCloud cloud = MakeCloud(xyz, n);
+  const bool ok = full_submap
+      ? m.MatchFullSubmap(cloud, min_score, &sc, &pose, &st)
+      : m.Match(Pose2d{init_xyt[0], init_xyt[1], init_xyt[2]}, cloud, min_score, &sc, &pose, &st);
+  *score = sc;
+  pose_xyt[0] = pose.x; pose_xyt[1] = pose.y; pose_xyt[2] = pose.theta;
+  if (stats4) {
+    stats4[0] = st.candidates_scored; stats4[1] = st.num_scans;
+    stats4[2] = st.coarse_candidates; stats4[3] = st.nodes_expanded;
+  }
+  return ok ? 1 : 0;
+}
+
+// Prepared search: number of scans, discrete scans, shrunk bounds, coarse sums.
+int orc_fast2d_prepare(void* h, const double* init_xyt, const float* xyz, int n,
+                       int full_submap, int* num_scans, double* step, int* out_xy,
+                       int64_t out_xy_capacity /* ints */, int* out_bounds,
+                       int64_t bounds_capacity /* ints */, int* out_sums,
+                       int64_t sums_capacity, int64_t* num_sums) {
+  const auto& m = *static_cast<Fast2D*>(h)->matcher;
+  Pose2d used;
+  const auto p = m.Prepare(Pose2d{init_xyt[0], init_xyt[1], init_xyt[2]}, MakeCloud(xyz, n),
+                           full_submap != 0, &used);
+  *num_scans = static_cast<int>(p.discrete_scans.size());
+  *step = p.angular_step;
+  if (out_xy) {
+    int64_t k = 0;
+    for (const auto& s : p.discrete_scans)
+      for (const Cell2i& c : s) {
+        if (k + 2 > out_xy_capacity) return -1;
+        out_xy[k++] = c.x; out_xy[k++] = c.y;
+      }
+  }
+  if (out_bounds) {
+    int64_t k = 0;
+    for (const auto& b : p.bounds) {
+      if (k + 4 > bounds_capacity) return -1;
+      out_bounds[k++] = b.min_x; out_bounds[k++] = b.max_x;
+      out_bounds[k++] = b.min_y; out_bounds[k++] = b.max_y;
+    }
+  }
+  if (out_sums || num_sums) {
+    const std::vector<int> sums = m.CoarseSums(p);
+    if (num_sums) *num_sums = static_cast<int64_t>(sums.size());
+    if (out_sums) {
+      if (static_cast<int64_t>(sums.size()) > sums_capacity) return -1;
+      std::memcpy(out_sums, sums.data(), sums.size() * sizeof(int));
+    }
+  }
+  return 0;
+}
+
+// Batched full-submap matches over `num_threads` host threads (one submap per
+// task) — the reference's thread-pool fan-out
+// (constraints/constraint_builder_2d.cc:97-111), used as the CPU baseline.
+void orc_fast2d_match_batch(void** handles, int num, const float* xyz, int n, float min_score,
+                            int num_threads, int* found, float* scores, double* poses_xyt,
+                            int64_t* candidates_total) {
+  std::vector<int64_t> per(num, 0);
+  auto work = [&](int t) {
+    for (int i = t; i < num; i += num_threads) {
+      int64_t st[4];
+      const double init[3] = {0, 0, 0};
+      found[i] = orc_fast2d_match(handles[i], init, xyz, n, 1, min_score, &scores[i],
+                                  &poses_xyt[3 * i], st);
+      per[i] = st[0];
+    }
+  };
+  std::vector<std::thread> threads;
+  for (int t = 0; t < num_threads; ++t) threads.emplace_back(work, t);
+  for (auto& th : threads) th.join();
+  int64_t total = 0;
+  for (int64_t v : per) total += v;
+  if (candidates_total) *candidates_total = total;
+}
+
+}  // extern "C"

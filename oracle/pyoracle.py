@@ -1,0 +1,230 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's ``cpu_baseline`` leg; never from the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liboracle.so")
+
+_u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    """Compile the oracle with oracle/Makefile (g++)."""
+    if force and os.path.exists(_SO):
+        os.remove(_SO)
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _declare(_lib)
+    return _lib
+
+
+def _declare(L):
+    L.orc_value_tables.argtypes = [_f32p, _f32p, _f32p]
+    L.orc_probability_to_value.argtypes = [C.c_float]
+    L.orc_correspondence_cost_to_value.argtypes = [C.c_float]
+    L.orc_search_parameters.argtypes = [C.c_double, C.c_double, _f32p, C.c_int, C.c_double,
+                                        C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.orc_generate_rotated_scans.argtypes = [_f32p, C.c_int, C.c_int, C.c_double, _f32p]
+    L.orc_discretize_scans.argtypes = [_f32p, C.c_int, C.c_double, C.c_int, C.c_double,
+                                       C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                       C.c_float, C.c_float, _i32p]
+    L.orc_candidate2d.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                                  C.c_int, _f64p]
+    L.orc_grid_probability.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_grid_probability.restype = C.c_float
+    L.orc_rt2d_match.argtypes = [_u16p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                 _f64p, _f32p, C.c_int, C.c_double, C.c_double, C.c_double,
+                                 C.c_double, _f64p, C.POINTER(C.c_int64), C.c_void_p, C.c_int]
+    L.orc_rt2d_match.restype = C.c_double
+    L.orc_fast2d_create.argtypes = [_u16p, C.c_int, C.c_int, C.c_double, C.c_double,
+                                    C.c_double, C.c_int, C.c_double, C.c_double]
+    L.orc_fast2d_create.restype = C.c_void_p
+    L.orc_fast2d_destroy.argtypes = [C.c_void_p]
+    L.orc_fast2d_level_dims.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int)]
+    L.orc_fast2d_level_cells.argtypes = [C.c_void_p, C.c_int, _u8p]
+    L.orc_precompute2d.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, _u8p]
+    L.orc_fast2d_match.argtypes = [C.c_void_p, _f64p, _f32p, C.c_int, C.c_int, C.c_float,
+                                   C.POINTER(C.c_float), _f64p, _i64p]
+    L.orc_fast2d_prepare.argtypes = [C.c_void_p, _f64p, _f32p, C.c_int, C.c_int,
+                                     C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p,
+                                     C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                     C.POINTER(C.c_int64)]
+    L.orc_fast2d_match_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int, _f32p, C.c_int,
+                                         C.c_float, C.c_int, _i32p, _f32p, _f64p,
+                                         C.POINTER(C.c_int64)]
+
+
+def _cloud(xyz):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    return xyz, xyz.shape[0]
+
+
+def value_tables():
+    a = np.empty(65536, np.float32)
+    b = np.empty(65536, np.float32)
+    c = np.empty(65536, np.float32)
+    lib().orc_value_tables(a, b, c)
+    return a, b, c
+
+
+def search_parameters(lin, ang, xyz, res):
+    xyz, n = _cloud(xyz)
+    na, step, ns, nl = C.c_int(), C.c_double(), C.c_int(), C.c_int()
+    lib().orc_search_parameters(lin, ang, xyz, n, res, C.byref(na), C.byref(step),
+                                C.byref(ns), C.byref(nl))
+    return dict(num_angular_perturbations=na.value, angular_perturbation_step_size=step.value,
+                num_scans=ns.value, num_linear_perturbations=nl.value)
+
+
+def generate_rotated_scans(xyz, na, step):
+    xyz, n = _cloud(xyz)
+    out = np.empty((2 * na + 1, n, 3), np.float32)
+    lib().orc_generate_rotated_scans(xyz, n, na, step, out)
+    return out
+
+
+def discretize_scans(xyz, init_theta, na, step, res, max_x, max_y, nx, ny, tx=0.0, ty=0.0):
+    xyz, n = _cloud(xyz)
+    out = np.empty((2 * na + 1, n, 2), np.int32)
+    lib().orc_discretize_scans(xyz, n, init_theta, na, step, res, max_x, max_y, nx, ny,
+                               tx, ty, out)
+    return out
+
+
+def candidate2d(nl, na, step, res, scan_index, x_off, y_off):
+    out = np.empty(3, np.float64)
+    lib().orc_candidate2d(nl, na, step, res, scan_index, x_off, y_off, out)
+    return out
+
+
+def grid_probability(cells, ix, iy):
+    cells = np.ascontiguousarray(cells, np.uint16)
+    ny, nx = cells.shape
+    return float(lib().orc_grid_probability(cells, nx, ny, ix, iy))
+
+
+def rt2d_match(cells, res, max_x, max_y, init_xyt, xyz, lin, ang, tw, rw, want_scores=False):
+    cells = np.ascontiguousarray(cells, np.uint16)
+    ny, nx = cells.shape
+    xyz, n = _cloud(xyz)
+    pose = np.empty(3, np.float64)
+    ncand = C.c_int64()
+    init = np.ascontiguousarray(init_xyt, np.float64)
+    scores = None
+    if want_scores:
+        # first call to learn the count
+        s = lib().orc_rt2d_match(cells, nx, ny, res, max_x, max_y, init, xyz, n, lin, ang, tw,
+                                 rw, pose, C.byref(ncand), None, 0)
+        scores = np.empty(ncand.value, np.float32)
+        s = lib().orc_rt2d_match(cells, nx, ny, res, max_x, max_y, init, xyz, n, lin, ang, tw,
+                                 rw, pose, C.byref(ncand), scores.ctypes.data, scores.size)
+    else:
+        s = lib().orc_rt2d_match(cells, nx, ny, res, max_x, max_y, init, xyz, n, lin, ang, tw,
+                                 rw, pose, C.byref(ncand), None, 0)
+    return dict(score=float(s), pose=pose, num_candidates=ncand.value, scores=scores)
+
+
+def precompute2d(cells, width):
+    cells = np.ascontiguousarray(cells, np.uint16)
+    ny, nx = cells.shape
+    out = np.empty((ny + width - 1, nx + width - 1), np.uint8)
+    lib().orc_precompute2d(cells, nx, ny, width, out)
+    return out
+
+
+class FastCorrelativeScanMatcher2D:
+    """Oracle twin of fast_correlative_scan_matcher_2d.h:114-136."""
+
+    def __init__(self, cells, res, max_x, max_y, depth, linear_search_window=7.0,
+                 angular_search_window=np.deg2rad(30.0)):
+        cells = np.ascontiguousarray(cells, np.uint16)
+        self.ny, self.nx = cells.shape
+        self.depth = depth
+        self._h = lib().orc_fast2d_create(cells, self.nx, self.ny, res, max_x, max_y, depth,
+                                          linear_search_window, angular_search_window)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_fast2d_destroy(self._h)
+            self._h = None
+
+    def level(self, i):
+        wx, wy = C.c_int(), C.c_int()
+        lib().orc_fast2d_level_dims(self._h, i, C.byref(wx), C.byref(wy))
+        out = np.empty((wy.value, wx.value), np.uint8)
+        lib().orc_fast2d_level_cells(self._h, i, out)
+        return out
+
+    def _match(self, init, xyz, full, min_score):
+        xyz, n = _cloud(xyz)
+        score = C.c_float()
+        pose = np.zeros(3, np.float64)
+        stats = np.zeros(4, np.int64)
+        ok = lib().orc_fast2d_match(self._h, np.ascontiguousarray(init, np.float64), xyz, n,
+                                    int(full), min_score, C.byref(score), pose, stats)
+        return dict(found=bool(ok), score=float(score.value), pose=pose,
+                    candidates_scored=int(stats[0]), num_scans=int(stats[1]),
+                    coarse_candidates=int(stats[2]), nodes_expanded=int(stats[3]))
+
+    def match(self, init_xyt, xyz, min_score):
+        return self._match(init_xyt, xyz, False, min_score)
+
+    def match_full_submap(self, xyz, min_score):
+        return self._match([0.0, 0.0, 0.0], xyz, True, min_score)
+
+    def prepare(self, init_xyt, xyz, full, want_sums=True):
+        xyz, n = _cloud(xyz)
+        init = np.ascontiguousarray(init_xyt, np.float64)
+        ns, step, nsums = C.c_int(), C.c_double(), C.c_int64()
+        rc = lib().orc_fast2d_prepare(self._h, init, xyz, n, int(full), C.byref(ns),
+                                      C.byref(step), None, 0, None, 0, None, 0,
+                                      C.byref(nsums) if want_sums else None)
+        assert rc == 0
+        scans = np.empty((ns.value, n, 2), np.int32)
+        bounds = np.empty((ns.value, 4), np.int32)
+        sums = np.empty(nsums.value if want_sums else 0, np.int32)
+        rc = lib().orc_fast2d_prepare(self._h, init, xyz, n, int(full), C.byref(ns),
+                                      C.byref(step), scans.ctypes.data, scans.size,
+                                      bounds.ctypes.data, bounds.size,
+                                      sums.ctypes.data if want_sums else None, sums.size,
+                                      C.byref(nsums) if want_sums else None)
+        assert rc == 0
+        return dict(num_scans=ns.value, step=step.value, scans=scans, bounds=bounds, sums=sums)
+
+
+def fast2d_match_batch(matchers, xyz, min_score, num_threads):
+    xyz, n = _cloud(xyz)
+    num = len(matchers)
+    handles = (C.c_void_p * num)(*[m._h for m in matchers])
+    found = np.zeros(num, np.int32)
+    scores = np.zeros(num, np.float32)
+    poses = np.zeros((num, 3), np.float64)
+    total = C.c_int64()
+    lib().orc_fast2d_match_batch(handles, num, xyz, n, min_score, num_threads, found, scores,
+                                 poses, C.byref(total))
+    return dict(found=found, scores=scores, poses=poses, candidates_scored=total.value)

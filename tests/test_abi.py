@@ -1,0 +1,57 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports
+every symbol include/cartographer_mi355x.h declares, and refuses to compute
+without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cartographer_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cmx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_loader_agree():
+    from cartographer_amd import _lib
+    assert _declared_symbols() == sorted(_lib.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    from cartographer_amd import _lib
+    L = _lib.lib()
+    for name in _declared_symbols():
+        assert hasattr(L, name), f"{name} declared in the header but not exported"
+    assert b"gfx950" in L.cmx_version()
+
+
+def test_no_cpu_fallback_without_device():
+    from cartographer_amd import _lib, scan_matching as sm
+    L = _lib.lib()
+    if L.cmx_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    grid = sm.Grid2D(np.zeros((4, 4), np.uint16), 0.05, 0.1, 0.1)
+    with pytest.raises(_lib.CmxError) as e:
+        sm.FastCorrelativeScanMatcher2D(grid, 3)
+    assert e.value.status == _lib.DEVICE_ERROR
+    assert "no CPU fallback" in str(e.value)
+    m = sm.RealTimeCorrelativeScanMatcher2D(0.1, 0.1, 0.0, 0.0)
+    with pytest.raises(_lib.CmxError) as e:
+        m.match(sm.Rigid2d(), np.zeros((3, 3), np.float32), grid)
+    assert e.value.status == _lib.DEVICE_ERROR
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, "cartographer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cc")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "pyoracle" not in text and "liboracle" not in text and \
+                    "oracle_2d" not in text and "oracle_3d" not in text, os.path.join(dirpath, f)
