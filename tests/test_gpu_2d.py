@@ -229,8 +229,9 @@ def test_edge_cloud_outside_grid(sm, oracle, c2):
     far = np.array([[500.0, 500.0, 0], [501.0, 500.0, 0], [500.0, 502.0, 0]], np.float32)
     om = _oracle(oracle, cells, lim, 4, 1.0, 0.2)
     gm = sm.FastCorrelativeScanMatcher2D(_grid(sm, cells, lim), 4, 1.0, 0.2)
-    # Every candidate scores min_score (all lookups outside): not > 0.1 -> no match...
-    ref, _ = _assert_match_parity(om, gm, lim["resolution"], [0, 0, 0], far, 0.1, False, sm)
+    # Every candidate scores ToScore(0) = 1.f - kMaxCorrespondenceCost (all lookups
+    # outside the grid): not > 0.11 -> no match ...
+    ref, _ = _assert_match_parity(om, gm, lim["resolution"], [0, 0, 0], far, 0.11, False, sm)
     assert not ref["found"]
     # ... but it is > 0.05.
     ref, _ = _assert_match_parity(om, gm, lim["resolution"], [0, 0, 0], far, 0.05, False, sm)
