@@ -48,20 +48,27 @@ def cpu_baseline(cells, lim, depth, scan, min_score, seconds):
     """The oracle (CPU restatement) timed on this box's host cores: one
     MatchFullSubmap per thread, the reference's thread-pool fan-out."""
     from oracle import pyoracle as orc
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 32))
     matcher = orc.FastCorrelativeScanMatcher2D(cells, lim["resolution"], lim["max_x"],
                                                lim["max_y"], depth)
     t0 = time.perf_counter()
     one = matcher.match_full_submap(scan, min_score)
     t_one = time.perf_counter() - t0
-    rounds = max(1, int(seconds / max(t_one, 1e-3) / 1.5))
-    rounds = min(rounds, 64)
+    # Bounded sample: rounds of `cores` concurrent matches until `seconds` elapsed.
     t0 = time.perf_counter()
     total = 0
-    for _ in range(rounds):
+    rounds = 0
+    while True:
         r = orc.fast2d_match_batch([matcher] * cores, scan, min_score, cores)
         total += r["candidates_scored"]
-    dt = time.perf_counter() - t0
+        rounds += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or rounds >= 64:
+            break
     return {
         "value": total / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
         "sample": f"{rounds * cores} MatchFullSubmap calls of the bench workload "
