@@ -1,6 +1,6 @@
 // FastCorrelativeScanMatcher2D on gfx950: precomputation-grid stack
-// construction, scan preparation, lowest-resolution scoring and a batched,
-// level-synchronous branch and bound.
+// construction, scan preparation, lowest-resolution scoring and a batched
+// branch and bound.
 //
 // Reference behaviour being replaced:
 //   SM2/fast_correlative_scan_matcher_2d.cc:91-186   PrecomputationGrid2D / Stack
@@ -10,12 +10,25 @@
 //
 // Search schedule (any sound schedule returns the reference's best score):
 //   1. score every lowest-resolution candidate (reference: :264-274);
-//   2. "dive": greedily descend from the best few of them to obtain a real
-//      leaf score b0 (a valid lower bound);
-//   3. level-synchronous expansion of every node whose upper bound exceeds
-//      b0, depth by depth, all problems of a batch together;
-//   4. pick the best leaf; ties are resolved in the order the reference's
-//      depth-first search would meet them (see SelectBest*).
+//   2. "dive": greedy descents from the best few of them give a real leaf
+//      score b0, a valid lower bound;
+//   3. every lowest-resolution node whose upper bound reaches the bound is
+//      searched depth-first by one workgroup, all workgroups sharing the
+//      problem's bound through one atomic word;
+//   4. among the leaves with the best score, the one the reference's
+//      depth-first search meets first is returned (see SelectBestKernel).
+//
+// Lowest-resolution scoring ("phase planes").  Lowest-resolution candidates
+// of one rotated scan sit on a lattice of pitch w = 2^(depth-1) cells, so for
+// a given point p all of them read level cells with the same residue
+// (phase) modulo w.  The level is therefore stored a second time as w*w small
+// planes, plane(py,px)[J][I] = cell(I*w+px, J*w+py): ONE 64-byte plane holds
+// everything a point contributes to all ~13x13 candidates of its scan.  Points
+// are bucketed by the lattice block they fall in; within a bucket the lane ->
+// candidate map is fixed, so a wave adds planes into registers (one coalesced
+// 64 B load + one add per point for ALL candidates) and flushes once per
+// bucket.  Out-of-grid lookups (60 % of the reference's reads here) cost
+// nothing.
 #include <algorithm>
 #include <cmath>
 
@@ -23,6 +36,12 @@
 
 namespace cmx {
 namespace {
+
+constexpr int kMaxBuckets = 4096;      // LDS histogram size of the point bucketing
+constexpr int kMaxPlaneCells = 256;    // plane_i * plane_j
+constexpr int kMaxPlaneWidth = 128;    // w; plane index fits 14 bits
+constexpr int kMaxCoarsePerScan = 4096;  // LDS accumulators of the plane kernel
+constexpr int kSeedsPerProblem = 64;
 
 // ---------------------------------------------------------------------------
 // Precomputation stack
@@ -77,8 +96,24 @@ __global__ void BuildLevelKernel(const uint8_t* __restrict__ prev, int pwx, int 
   out[X + Y * wx] = static_cast<uint8_t>(best);
 }
 
+// planes[(py*w + px) * stride + J*PI + I] = level(I*w + px, J*w + py) (0 outside).
+__global__ void BuildPlanesKernel(const uint8_t* __restrict__ level, int wx, int wy, int w, int PI,
+                                  int PJ, int stride, uint8_t* __restrict__ planes) {
+  const int plane = blockIdx.x;             // w*w planes + 1 zero plane
+  const int px = plane % w, py = plane / w;
+  for (int c = threadIdx.x; c < stride; c += blockDim.x) {
+    int v = 0;
+    if (plane < w * w && c < PI * PJ) {
+      const int I = c % PI, J = c / PI;
+      const int x = I * w + px, y = J * w + py;
+      if (x < wx && y < wy) v = level[x + y * wx];
+    }
+    planes[static_cast<size_t>(plane) * stride + c] = static_cast<uint8_t>(v);
+  }
+}
+
 // ---------------------------------------------------------------------------
-// Scan preparation: rotate, translate, discretise, ShrinkToFit
+// Scan preparation: rotate, translate, discretise, ShrinkToFit, bucket
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 PrepScansKernel(const Fast2DProblem* __restrict__ problems, const float* __restrict__ xyz, int n,
@@ -110,6 +145,8 @@ PrepScansKernel(const Fast2DProblem* __restrict__ problems, const float* __restr
     hi_y = max(hi_y, P.ny - 1 - iy);
   }
   __shared__ int red[4][5];
+  __shared__ int4 s_bounds;
+  __shared__ int2 s_dims;
   lo_x = WaveMin(lo_x); lo_y = WaveMin(lo_y);
   hi_x = WaveMax(hi_x); hi_y = WaveMax(hi_y);
   bad = WaveMax(bad);
@@ -134,8 +171,62 @@ PrepScansKernel(const Fast2DProblem* __restrict__ problems, const float* __restr
     P.bounds[s] = bd;
     // GenerateLowestResolutionCandidates counts (SM2/fast_...2d.cc:279-292).
     const int step = 1 << (P.depth - 1);
-    P.coarse_dims[s] = make_int2((bd.y - bd.x + step) / step, (bd.w - bd.z + step) / step);
+    const int2 dims = make_int2((bd.y - bd.x + step) / step, (bd.w - bd.z + step) / step);
+    P.coarse_dims[s] = dims;
+    s_bounds = bd;
+    s_dims = dims;
     if (bad) atomicMax(&states[blockIdx.y].error, 1);
+  }
+  if (!P.use_planes) return;
+
+  // ---- bucket the points by the lattice block they fall in ---------------
+  __shared__ int hist[kMaxBuckets];
+  __shared__ int partial[256];
+  __syncthreads();
+  const int4 bd = s_bounds;
+  const int2 dims = s_dims;
+  const int shift = P.depth - 1, w = 1 << shift;
+  const int BW = dims.x + P.plane_i - 1, BH = dims.y + P.plane_j - 1;
+  const int NB = BW * BH;   // <= kMaxBuckets (checked on the host with upper bounds)
+  for (int b = threadIdx.x; b < NB; b += blockDim.x) hist[b] = 0;
+  __syncthreads();
+  auto classify = [&](uint32_t packed, int* bucket, int* plane) {
+    const int U = static_cast<short>(packed & 0xffffu) + bd.x + w - 1;
+    const int V = static_cast<short>(packed >> 16) + bd.z + w - 1;
+    const int bx = (U >> shift) + dims.x - 1, by = (V >> shift) + dims.y - 1;
+    *plane = (V & (w - 1)) * w + (U & (w - 1));
+    *bucket = (bx >= 0 && bx < BW && by >= 0 && by < BH) ? by * BW + bx : -1;
+  };
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int bucket, plane;
+    classify(out[i], &bucket, &plane);
+    if (bucket >= 0) atomicAdd(&hist[bucket], 1);
+  }
+  __syncthreads();
+  // exclusive scan of hist[0..NB)
+  const int chunk = (NB + 255) / 256;
+  const int b0 = min(static_cast<int>(threadIdx.x) * chunk, NB), b1 = min(b0 + chunk, NB);
+  int sum = 0;
+  for (int b = b0; b < b1; ++b) sum += hist[b];
+  partial[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int t = 0; t < 256; ++t) { const int v = partial[t]; partial[t] = run; run += v; }
+    P.sorted_count[s] = run;
+  }
+  __syncthreads();
+  int run = partial[threadIdx.x];
+  for (int b = b0; b < b1; ++b) { const int v = hist[b]; hist[b] = run; run += v; }
+  __syncthreads();
+  uint32_t* sorted = P.sorted + static_cast<size_t>(s) * n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int bucket, plane;
+    classify(out[i], &bucket, &plane);
+    if (bucket >= 0) {
+      const int pos = atomicAdd(&hist[bucket], 1);
+      sorted[pos] = static_cast<uint32_t>(plane) | (static_cast<uint32_t>(bucket) << 16);
+    }
   }
 }
 
@@ -146,10 +237,15 @@ CoarseLayoutKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __r
   __shared__ int partial[1024];
   const int S = P.num_scans;
   const int chunk = (S + 1023) / 1024;
-  const int begin = min(threadIdx.x * chunk, S), end = min(begin + chunk, S);
-  int sum = 0;
-  for (int s = begin; s < end; ++s) sum += P.coarse_dims[s].x * P.coarse_dims[s].y;
+  const int begin = min(static_cast<int>(threadIdx.x) * chunk, S), end = min(begin + chunk, S);
+  int sum = 0, too_many = 0;
+  for (int s = begin; s < end; ++s) {
+    const int c = P.coarse_dims[s].x * P.coarse_dims[s].y;
+    if (P.use_planes && c > kMaxCoarsePerScan) too_many = 1;
+    sum += c;
+  }
   partial[threadIdx.x] = sum;
+  if (too_many) atomicMax(&states[blockIdx.x].error, 2);
   __syncthreads();
   if (threadIdx.x == 0) {
     int run = 0;
@@ -169,9 +265,14 @@ CoarseLayoutKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __r
 // ---------------------------------------------------------------------------
 // Scoring
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ float ToScore(const Fast2DProblem& P, int sum, int n) {
+  // ToScore(sum / float(N))  (SM2/fast_...2d.cc:330-331, .h:74-76)
+  return P.min_s + (static_cast<float>(sum) / static_cast<float>(n)) * P.score_scale;
+}
 
 // Integer sum of one candidate over all points, one wave per candidate
-// (SM2/fast_...2d.cc:320-329 with GetValue of .h:56-71).
+// (SM2/fast_...2d.cc:320-329 with GetValue of .h:56-71).  Generic fallback of
+// the lowest resolution when the phase-plane layout does not apply.
 __device__ __forceinline__ int ScoreCandidateWave(const LevelDesc& L, int level,
                                                   const uint32_t* __restrict__ scan, int n, int dx,
                                                   int dy, int lane) {
@@ -190,17 +291,32 @@ __device__ __forceinline__ int ScoreCandidateWave(const LevelDesc& L, int level,
   return WaveSum(sum);
 }
 
-__device__ __forceinline__ float ToScore(const Fast2DProblem& P, int sum, int n) {
-  // ToScore(sum / float(N))  (SM2/fast_...2d.cc:330-331, .h:74-76)
-  return P.min_s + (static_cast<float>(sum) / static_cast<float>(n)) * P.score_scale;
+// Block-wide (sum, local index) maximum, smallest index on ties; result valid
+// in thread 0.
+__device__ __forceinline__ int2 BlockBest(int sum, int index, int2* scratch /*[4]*/) {
+  unsigned long long key = (static_cast<unsigned long long>(static_cast<unsigned>(sum)) << 32) |
+                           static_cast<unsigned>(0x7fffffff - index);
+  key = WaveMaxU64(key);
+  if ((threadIdx.x & 63) == 0)
+    scratch[threadIdx.x >> 6] = make_int2(static_cast<int>(key >> 32),
+                                          0x7fffffff - static_cast<int>(key & 0xffffffffu));
+  __syncthreads();
+  int2 best = scratch[0];
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      const int2 o = scratch[w];
+      if (o.x > best.x || (o.x == best.x && o.y < best.y)) best = o;
+    }
+  }
+  return best;
 }
 
 __global__ void __launch_bounds__(256)
-ScoreCoarseKernel(const Fast2DProblem* __restrict__ problems, int n,
-                  const ProblemState* __restrict__ states) {
+ScoreCoarseGenericKernel(const Fast2DProblem* __restrict__ problems, int n,
+                         const ProblemState* __restrict__ states) {
   const Fast2DProblem& P = problems[blockIdx.y];
   const int s = blockIdx.x;
-  if (s >= P.num_scans || states[blockIdx.y].error) return;
+  if (s >= P.num_scans || states[blockIdx.y].error || P.use_planes) return;
   const int level = P.depth - 1;
   const int step = 1 << level;
   const int2 dims = P.coarse_dims[s];
@@ -209,6 +325,7 @@ ScoreCoarseKernel(const Fast2DProblem* __restrict__ problems, int n,
   const uint32_t* scan = P.discrete + static_cast<size_t>(s) * n;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int count = dims.x * dims.y;
+  int best_sum = 0, best_index = 0x7ffffff;  // idle threads lose every tie
   for (int c = wave; c < count; c += 4) {
     const int ix = c / dims.y, iy = c - ix * dims.y;   // x outer, y inner (:295-307)
     const int sum = ScoreCandidateWave(P.level[level], level, scan, n, bd.x + ix * step,
@@ -217,38 +334,123 @@ ScoreCoarseKernel(const Fast2DProblem* __restrict__ problems, int n,
       P.coarse_sum[base + c] = sum;
       P.coarse_score[base + c] = ToScore(P, sum, n);
     }
+    if (sum > best_sum) { best_sum = sum; best_index = c; }
   }
+  __shared__ int2 scratch[4];
+  const int2 best = BlockBest(best_sum, best_index, scratch);
+  if (threadIdx.x == 0) P.scan_best[s] = best;
+}
+
+// Phase-plane scoring of all lowest-resolution candidates of one scan.
+template <int CHUNKS>
+__global__ void __launch_bounds__(256)
+ScoreCoarsePlanesKernel(const Fast2DProblem* __restrict__ problems, int n,
+                        const ProblemState* __restrict__ states) {
+  const Fast2DProblem& P = problems[blockIdx.y];
+  const int s = blockIdx.x;
+  if (s >= P.num_scans || states[blockIdx.y].error || !P.use_planes) return;
+  if ((P.plane_stride >> 6) != CHUNKS) return;
+  __shared__ int cand_acc[kMaxCoarsePerScan];
+  __shared__ int2 scratch[4];
+  const int2 dims = P.coarse_dims[s];
+  const int count = dims.x * dims.y;
+  for (int i = threadIdx.x; i < count; i += blockDim.x) cand_acc[i] = 0;
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int M = P.sorted_count[s];
+  const uint32_t* __restrict__ rec = P.sorted + static_cast<size_t>(s) * n;
+  const int begin = static_cast<int>(static_cast<long long>(M) * wave / 4);
+  const int end = static_cast<int>(static_cast<long long>(M) * (wave + 1) / 4);
+  const uint8_t* __restrict__ planes = P.planes;
+  const int stride = P.plane_stride;
+  const int PI = P.plane_i, PIJ = P.plane_i * P.plane_j;
+  const int BW = dims.x + PI - 1;
+  const unsigned zero_plane = 1u << (2 * (P.depth - 1));   // index w*w: the all-zero plane
+
+  int acc[CHUNKS];
+#pragma unroll
+  for (int c = 0; c < CHUNKS; ++c) acc[c] = 0;
+  int cur = -1;
+
+  auto flush = [&](int bucket) {
+    const int ax = bucket % BW - (dims.x - 1), ay = bucket / BW - (dims.y - 1);
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+      const int cell = c * 64 + lane;
+      const int I = cell % PI, J = cell / PI;
+      const int ix = I - ax, iy = J - ay;
+      if (cell < PIJ && acc[c] != 0 && ix >= 0 && ix < dims.x && iy >= 0 && iy < dims.y) {
+        atomicAdd(&cand_acc[ix * dims.y + iy], acc[c]);   // x outer, y inner (:295-307)
+      }
+      acc[c] = 0;
+    }
+  };
+
+  for (int i = begin; i < end; i += 4) {
+    // Four records (wave-uniform, scalar loads) and their planes up front so
+    // the 64-byte plane loads overlap; the tail reads the zero plane.
+    uint32_t r[4];
+    int v[4][CHUNKS];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      r[k] = (i + k < end) ? rec[i + k] : (0xffff0000u | zero_plane);
+      const uint8_t* pp = planes + static_cast<size_t>(r[k] & 0xffffu) * stride + lane;
+#pragma unroll
+      for (int c = 0; c < CHUNKS; ++c) v[k][c] = pp[c * 64];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int bucket = static_cast<int>(r[k] >> 16);
+      if (bucket != 0xffff) {
+        if (bucket != cur) {
+          if (cur >= 0) flush(cur);
+          cur = bucket;
+        }
+#pragma unroll
+        for (int c = 0; c < CHUNKS; ++c) acc[c] += v[k][c];
+      }
+    }
+  }
+  if (cur >= 0) flush(cur);
+  __syncthreads();
+
+  const int base = P.coarse_off[s];
+  int best_sum = 0, best_index = 0x7ffffff;  // idle threads lose every tie
+  for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    const int sum = cand_acc[i];
+    P.coarse_sum[base + i] = sum;
+    P.coarse_score[base + i] = ToScore(P, sum, n);
+    if (sum > best_sum) { best_sum = sum; best_index = i; }
+  }
+  const int2 best = BlockBest(best_sum, best_index, scratch);
+  if (threadIdx.x == 0) P.scan_best[s] = best;
 }
 
 // ---------------------------------------------------------------------------
 // Branch and bound
 // ---------------------------------------------------------------------------
 struct Counters {           // device, zeroed per call
-  int frontier[2];          // ping-pong frontier sizes
+  int frontier[2];
   int leaves;
-  int overflow;
-  int dive[2];
-  int pad[2];
+  int frontier_overflow;
+  int leaf_overflow;
+  int pad[3];
 };
 
-__device__ __forceinline__ int FindScan(const int* __restrict__ off, int num_scans, int c) {
-  int lo = 0, hi = num_scans;   // off[lo] <= c < off[hi]
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (off[mid] <= c) lo = mid; else hi = mid;
-  }
-  return lo;
-}
+__device__ __forceinline__ int NodeProblem(const Node2D& nd) { return nd.problem & 0xffffff; }
+__device__ __forceinline__ int NodeLevel(const Node2D& nd) { return nd.problem >> 24; }
 
-__device__ __forceinline__ Node2D CoarseNode(const Fast2DProblem& P, int problem, int c) {
-  const int s = FindScan(P.coarse_off, P.num_scans, c);
-  const int local = c - P.coarse_off[s];
+__device__ __forceinline__ Node2D CoarseNode(const Fast2DProblem& P, int problem, int s,
+                                             int local) {
   const int2 dims = P.coarse_dims[s];
   const int4 bd = P.bounds[s];
   const int step = 1 << (P.depth - 1);
   const int ix = local / dims.y, iy = local - ix * dims.y;
+  const int c = P.coarse_off[s] + local;
   Node2D nd;
-  nd.problem = problem;
+  nd.problem = problem | ((P.depth - 1) << 24);
   nd.scan = s;
   nd.dx = bd.x + ix * step;
   nd.dy = bd.z + iy * step;
@@ -259,154 +461,281 @@ __device__ __forceinline__ Node2D CoarseNode(const Fast2DProblem& P, int problem
   return nd;
 }
 
-// Seeds of the dive: the ~kSeedTarget best lowest-resolution candidates of
-// each problem, chosen with a histogram threshold on the integer sums.
-constexpr int kSeedTarget = 64;
-constexpr int kSeedCap = 256;      // per problem
-
+// Seeds of the dive: the best candidate of each of the ~64 best scans, chosen
+// with a histogram threshold on the per-scan maxima.
 __global__ void __launch_bounds__(1024)
-SeedKernel(const Fast2DProblem* __restrict__ problems, const ProblemState* __restrict__ states,
-           int n, Node2D* __restrict__ out, Counters* __restrict__ counters, int out_slot) {
+SeedSelectKernel(const Fast2DProblem* __restrict__ problems,
+                 const ProblemState* __restrict__ states, int n, Node2D* __restrict__ seeds,
+                 int* __restrict__ seed_count) {
   const int problem = blockIdx.x;
   const Fast2DProblem& P = problems[problem];
-  if (states[problem].error) return;
-  const int total = states[problem].coarse_total;
   __shared__ int hist[1024];
   __shared__ int threshold_bin;
   __shared__ int taken;
   hist[threadIdx.x] = 0;
-  if (threadIdx.x == 0) taken = 0;
+  if (threadIdx.x == 0) { taken = 0; seed_count[problem] = 0; }
+  if (states[problem].error) return;
   __syncthreads();
+  const int S = P.num_scans;
   const long long range = 255ll * n + 1;
-  for (int c = threadIdx.x; c < total; c += blockDim.x) {
-    const int bin = static_cast<int>(P.coarse_sum[c] * 1024ll / range);
-    atomicAdd(&hist[bin], 1);
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    atomicAdd(&hist[static_cast<int>(P.scan_best[s].x * 1024ll / range)], 1);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     int acc = 0, b = 1023;
     for (; b > 0; --b) {
       acc += hist[b];
-      if (acc >= kSeedTarget) break;
+      if (acc >= kSeedsPerProblem) break;
     }
     threshold_bin = b;
   }
   __syncthreads();
   const int tb = threshold_bin;
-  const float min_score = P.min_score;
-  for (int c = threadIdx.x; c < total; c += blockDim.x) {
-    const int bin = static_cast<int>(P.coarse_sum[c] * 1024ll / range);
-    if (bin >= tb && P.coarse_score[c] > min_score) {
-      if (atomicAdd(&taken, 1) < kSeedCap) {
-        const int slot = atomicAdd(&counters->dive[out_slot], 1);
-        out[slot] = CoarseNode(P, problem, c);
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    const int2 best = P.scan_best[s];
+    if (static_cast<int>(best.x * 1024ll / range) >= tb &&
+        ToScore(P, best.x, n) > P.min_score) {
+      const int slot = atomicAdd(&taken, 1);
+      if (slot < kSeedsPerProblem) {
+        seeds[problem * kSeedsPerProblem + slot] = CoarseNode(P, problem, s, best.y);
       }
     }
   }
+  __syncthreads();
+  if (threadIdx.x == 0) seed_count[problem] = min(taken, kSeedsPerProblem);
 }
 
-// Appends every lowest-resolution candidate in [chunk_begin, chunk_end) whose
-// score beats the current best of its problem (reference: :346-350).
+// Scores the <=4 children of a node (SM2/fast_...2d.cc:351-368) with the whole
+// 256-thread block: every wave takes a quarter of the points and gathers all
+// four children per point.  child_score[k] < 0 marks a child outside the
+// search bounds; ranks[k] is the position of child k in the reference's stable
+// descending sort of the children.
+struct ChildScratch {
+  int partial[4][4];
+  float child_score[4];
+  int rank[4];
+  int nvalid;
+};
+
+__device__ __forceinline__ void ScoreChildren(const Fast2DProblem& P, int n, int scan, int dx,
+                                              int dy, int child_level, ChildScratch* sh) {
+  const int4 bd = P.bounds[scan];
+  const int half = 1 << child_level;
+  const LevelDesc L = P.level[child_level];
+  const int off = half - 1;
+  const bool vx = dx + half <= bd.y, vy = dy + half <= bd.w;   // the `break`s at :356,361
+  const uint32_t* __restrict__ pts = P.discrete + static_cast<size_t>(scan) * n;
+  int s00 = 0, s01 = 0, s10 = 0, s11 = 0;   // s[x-step][y-step]
+#pragma unroll 4
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const uint32_t p = pts[i];
+    const int x = static_cast<short>(p & 0xffffu) + dx + off;
+    const int y = static_cast<short>(p >> 16) + dy + off;
+    const bool x0 = static_cast<unsigned>(x) < static_cast<unsigned>(L.wx);
+    const bool x1 = vx && static_cast<unsigned>(x + half) < static_cast<unsigned>(L.wx);
+    const bool y0 = static_cast<unsigned>(y) < static_cast<unsigned>(L.wy);
+    const bool y1 = vy && static_cast<unsigned>(y + half) < static_cast<unsigned>(L.wy);
+    const uint8_t* row0 = L.cells + static_cast<size_t>(y) * L.wx;
+    const uint8_t* row1 = row0 + static_cast<size_t>(half) * L.wx;
+    if (x0 && y0) s00 += row0[x];
+    if (x0 && y1) s01 += row1[x];
+    if (x1 && y0) s10 += row0[x + half];
+    if (x1 && y1) s11 += row1[x + half];
+  }
+  s00 = WaveSum(s00); s01 = WaveSum(s01); s10 = WaveSum(s10); s11 = WaveSum(s11);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sh->partial[wave][0] = s00; sh->partial[wave][1] = s01;
+    sh->partial[wave][2] = s10; sh->partial[wave][3] = s11;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int k = threadIdx.x;   // k = 2*x-step + y-step: generation order x outer, y inner
+    const bool valid = ((k >> 1) == 0 || vx) && ((k & 1) == 0 || vy);
+    const int total = sh->partial[0][k] + sh->partial[1][k] + sh->partial[2][k] + sh->partial[3][k];
+    sh->child_score[k] = valid ? ToScore(P, total, n) : -1.f;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int me = threadIdx.x;
+    const float mine = sh->child_score[me];
+    int rank = 0, nvalid = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float other = sh->child_score[j];
+      if (other >= 0.f) ++nvalid;
+      if (j != me && other >= 0.f && (other > mine || (other == mine && j < me))) ++rank;
+    }
+    sh->rank[me] = rank;
+    if (me == 0) sh->nvalid = nvalid;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ Node2D MakeChild(const Node2D& nd, int k, int child_level,
+                                            const ChildScratch& sh) {
+  Node2D child = nd;
+  child.problem = NodeProblem(nd) | (child_level << 24);
+  child.dx = nd.dx + (k >> 1) * (1 << child_level);
+  child.dy = nd.dy + (k & 1) * (1 << child_level);
+  child.score = sh.child_score[k];
+  child.path = nd.path | (static_cast<unsigned>(sh.rank[k]) << (2 * child_level));
+  return child;
+}
+
+__device__ __forceinline__ void RecordLeaf(const Node2D& leaf, Node2D* __restrict__ leaves,
+                                           Counters* __restrict__ counters, int capacity) {
+  const int slot = atomicAdd(&counters->leaves, 1);
+  if (slot < capacity) leaves[slot] = leaf; else counters->leaf_overflow = 1;
+}
+
+// One greedy descent per seed: always continue with the best child.  The leaf
+// reached is a real candidate, so its score is a valid bound.
+__global__ void __launch_bounds__(256)
+DiveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restrict__ states, int n,
+           const Node2D* __restrict__ seeds, const int* __restrict__ seed_count,
+           Node2D* __restrict__ leaves, Counters* __restrict__ counters, int leaf_capacity) {
+  const int problem = blockIdx.y;
+  if (blockIdx.x >= seed_count[problem]) return;
+  const Fast2DProblem& P = problems[problem];
+  ProblemState& st = states[problem];
+  __shared__ ChildScratch sh;
+  __shared__ Node2D cur;
+  if (threadIdx.x == 0) cur = seeds[problem * kSeedsPerProblem + blockIdx.x];
+  __syncthreads();
+  unsigned long long scored = 0, expanded = 0;
+  for (int child_level = P.depth - 2; child_level >= 0; --child_level) {
+    const Node2D nd = cur;
+    ScoreChildren(P, n, nd.scan, nd.dx, nd.dy, child_level, &sh);
+    scored += sh.nvalid;
+    ++expanded;
+    if (threadIdx.x == 0) {
+      for (int k = 0; k < 4; ++k)
+        if (sh.child_score[k] >= 0.f && sh.rank[k] == 0) cur = MakeChild(nd, k, child_level, sh);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const Node2D leaf = cur;
+    if (leaf.score > P.min_score) {
+      RecordLeaf(leaf, leaves, counters, leaf_capacity);
+      atomicMax(&st.best_bits, __float_as_uint(leaf.score));
+    }
+    atomicAdd(&st.candidates_scored, scored);
+    atomicAdd(&st.nodes_expanded, expanded);
+  }
+}
+
+// Lowest-resolution nodes that can still matter (reference: :346-350): one
+// block per scan; whole scans are skipped through their best candidate.
+// strict = 0 keeps nodes equal to the bound so that every leaf tied for the
+// best score is found.
 __global__ void __launch_bounds__(256)
 FilterCoarseKernel(const Fast2DProblem* __restrict__ problems,
-                   const ProblemState* __restrict__ states, int chunk, int num_chunks,
-                   Node2D* __restrict__ out, int capacity, Counters* __restrict__ counters,
-                   int out_slot) {
+                   const ProblemState* __restrict__ states, int n, int chunk, int num_chunks,
+                   int strict, Node2D* __restrict__ out, int capacity,
+                   Counters* __restrict__ counters, int slot_index) {
   const int problem = blockIdx.y;
   const Fast2DProblem& P = problems[problem];
-  if (states[problem].error) return;
-  const int total = states[problem].coarse_total;
-  const int begin = static_cast<int>(static_cast<long long>(total) * chunk / num_chunks);
-  const int end = static_cast<int>(static_cast<long long>(total) * (chunk + 1) / num_chunks);
+  const int s = blockIdx.x;
+  if (s >= P.num_scans || states[problem].error) return;
+  if (s % num_chunks != chunk) return;
   const float best = __uint_as_float(states[problem].best_bits);
-  for (int c = begin + blockIdx.x * blockDim.x + threadIdx.x; c < end;
-       c += gridDim.x * blockDim.x) {
-    if (P.coarse_score[c] > best) {
-      const int slot = atomicAdd(&counters->frontier[out_slot], 1);
-      if (slot < capacity) {
-        out[slot] = CoarseNode(P, problem, c);
-      } else {
-        counters->overflow = 1;
-      }
+  const float top = ToScore(P, P.scan_best[s].x, n);
+  if (strict ? !(top > best) : (top < best)) return;
+  const int2 dims = P.coarse_dims[s];
+  const int count = dims.x * dims.y;
+  const int base = P.coarse_off[s];
+  for (int c = threadIdx.x; c < count; c += blockDim.x) {
+    const float score = P.coarse_score[base + c];
+    if (strict ? (score > best) : (score >= best)) {
+      const int slot = atomicAdd(&counters->frontier[slot_index], 1);
+      if (slot < capacity) out[slot] = CoarseNode(P, problem, s, c);
+      else counters->frontier_overflow = 1;
     }
   }
 }
 
-enum ExpandMode { kExpandFull = 0, kExpandDive = 1 };
-
-// Expands frontier nodes of depth child_level+1 into their <=4 children
-// (SM2/fast_...2d.cc:351-368), one block per node, one wave per child.
-//   Full mode, child_level > 0: children beating the problem's bound go to `out`.
-//   Dive mode, child_level > 0: only the best child is kept.
-//   child_level == 0: the best child (first maximum in generation order, as
-//   the stable sort of <=4 leaves at :331-332 yields) is recorded as a leaf.
+// Depth-first search of the subtree below each frontier node by one block,
+// pruned with the problem's shared bound.  Nodes reaching `stop_level` (> 0)
+// are handed to `out` instead of being searched (used once near the top to
+// create enough independent roots); stop_level = 0 searches down to the
+// leaves.  At the leaves only the first-best child can be returned by the
+// reference (:340-343 after the stable sort of :331-332).
 __global__ void __launch_bounds__(256)
-ExpandKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restrict__ states, int n,
-             const Node2D* __restrict__ in, const int* __restrict__ in_count, int in_capacity,
-             int child_level, int mode, Node2D* __restrict__ out, int* __restrict__ out_count, int out_capacity,
-             Node2D* __restrict__ leaves, int* __restrict__ leaf_count, int leaf_capacity,
-             int* __restrict__ overflow) {
-  __shared__ float child_score[4];
-  const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+SubtreeKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restrict__ states, int n,
+              const Node2D* __restrict__ in, const int* __restrict__ in_count, int in_capacity,
+              int stop_level, int strict, Node2D* __restrict__ out, int* __restrict__ out_count,
+              int out_capacity, Node2D* __restrict__ leaves, Counters* __restrict__ counters,
+              int leaf_capacity) {
+  __shared__ ChildScratch sh;
+  __shared__ Node2D stack[kMaxDepth * 3 + 4];
+  __shared__ Node2D cur;
+  __shared__ int sp, have;
+  __shared__ float s_best;
   const int count = min(*in_count, in_capacity);
-  const int half = 1 << child_level;
   for (int i = blockIdx.x; i < count; i += gridDim.x) {
-    const Node2D nd = in[i];
-    const Fast2DProblem& P = problems[nd.problem];
-    ProblemState& st = states[nd.problem];
-    if (mode == kExpandFull && child_level > 0 &&
-        !(nd.score > __uint_as_float(st.best_bits))) {
-      continue;  // uniform across the block
-    }
-    const int4 bd = P.bounds[nd.scan];
-    const int xo = (k >> 1) * half, yo = (k & 1) * half;
-    const bool valid = (nd.dx + xo <= bd.y) && (nd.dy + yo <= bd.w);
-    float score = -1.f;
-    if (valid) {
-      const int sum = ScoreCandidateWave(P.level[child_level], child_level,
-                                         P.discrete + static_cast<size_t>(nd.scan) * n, n,
-                                         nd.dx + xo, nd.dy + yo, lane);
-      score = ToScore(P, sum, n);
-    }
-    if (lane == 0) child_score[k] = score;
+    if (threadIdx.x == 0) { stack[0] = in[i]; sp = 1; }
     __syncthreads();
-    if (threadIdx.x < 4) {
-      const int me = threadIdx.x;
-      const float mine = child_score[me];
-      int rank = 0, nvalid = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float other = child_score[j];
-        if (other >= 0.f) ++nvalid;
-        if (j != me && other >= 0.f && (other > mine || (other == mine && j < me))) ++rank;
+    const int problem = NodeProblem(stack[0]);
+    const Fast2DProblem& P = problems[problem];
+    ProblemState& st = states[problem];
+    unsigned long long scored = 0, expanded = 0;
+    for (;;) {
+      if (threadIdx.x == 0) {
+        have = sp > 0;
+        if (have) cur = stack[--sp];
+        s_best = __uint_as_float(__hip_atomic_load(&st.best_bits, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT));
       }
-      if (me == 0) {
-        atomicAdd(&st.candidates_scored, static_cast<unsigned long long>(nvalid));
-        atomicAdd(&st.nodes_expanded, 1ull);
-      }
-      if (mine >= 0.f) {
-        Node2D child = nd;
-        child.dx = nd.dx + (me >> 1) * half;
-        child.dy = nd.dy + (me & 1) * half;
-        child.score = mine;
-        child.path = nd.path | (static_cast<unsigned>(rank) << (2 * child_level));
-        if (child_level == 0) {
-          if (rank == 0 && mine > P.min_score &&
-              mine >= __uint_as_float(st.best_bits)) {
-            const int slot = atomicAdd(leaf_count, 1);
-            if (slot < leaf_capacity) leaves[slot] = child; else *overflow = 1;
-            atomicMax(&st.best_bits, __float_as_uint(mine));
+      __syncthreads();
+      if (!have) break;
+      const Node2D nd = cur;
+      const float best = s_best;
+      const bool skip = strict ? !(nd.score > best) : (nd.score < best);
+      if (!skip) {
+        const int child_level = NodeLevel(nd) - 1;
+        ScoreChildren(P, n, nd.scan, nd.dx, nd.dy, child_level, &sh);
+        scored += sh.nvalid;
+        ++expanded;
+        if (threadIdx.x == 0) {
+          if (child_level == 0) {
+            for (int k = 0; k < 4; ++k) {
+              if (sh.child_score[k] >= 0.f && sh.rank[k] == 0) {
+                const Node2D leaf = MakeChild(nd, k, 0, sh);
+                const bool keep = strict ? (leaf.score > best) : (leaf.score >= best);
+                if (leaf.score > P.min_score && keep) {
+                  RecordLeaf(leaf, leaves, counters, leaf_capacity);
+                  atomicMax(&st.best_bits, __float_as_uint(leaf.score));
+                }
+              }
+            }
+          } else {
+            // Push worst first so the best child is searched next.
+            for (int r = 3; r >= 0; --r) {
+              for (int k = 0; k < 4; ++k) {
+                if (sh.child_score[k] < 0.f || sh.rank[k] != r) continue;
+                const float sc = sh.child_score[k];
+                if (strict ? !(sc > best) : (sc < best)) continue;
+                const Node2D child = MakeChild(nd, k, child_level, sh);
+                if (child_level == stop_level) {
+                  const int slot = atomicAdd(out_count, 1);
+                  if (slot < out_capacity) out[slot] = child;
+                  else counters->frontier_overflow = 1;
+                } else {
+                  stack[sp++] = child;
+                }
+              }
+            }
           }
-        } else if (mode == kExpandDive) {
-          if (rank == 0) {
-            const int slot = atomicAdd(out_count, 1);
-            if (slot < out_capacity) out[slot] = child; else *overflow = 1;
-          }
-        } else if (mine > __uint_as_float(st.best_bits)) {
-          const int slot = atomicAdd(out_count, 1);
-          if (slot < out_capacity) out[slot] = child; else *overflow = 1;
         }
       }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      atomicAdd(&st.candidates_scored, scored);
+      atomicAdd(&st.nodes_expanded, expanded);
     }
     __syncthreads();
   }
@@ -415,73 +744,107 @@ ExpandKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restric
 // Best-leaf selection in the reference's depth-first visiting order among
 // equal scores: higher-scoring lowest-resolution ancestor first (the sorted
 // order of :331-332; equal ancestors fall back to generation order), then the
-// sibling ranks down the tree.
-struct SelectState {         // per problem, device, zeroed per call
+// sibling ranks down the tree.  One block; the leaf list is short.
+struct SelectState {         // per problem, device
   unsigned best_coarse_bits;
   int ties;
   unsigned long long key;    // (coarse_index << 32) | path, minimised
 };
 
-__global__ void RelaxBoundsKernel(const Fast2DProblem* __restrict__ problems,
-                                  ProblemState* __restrict__ states, int num) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < num) {
-    const unsigned floor_bits = __float_as_uint(fmaxf(problems[i].min_score, 0.f));
-    if (states[i].best_bits > floor_bits) states[i].best_bits -= 1;
+__global__ void __launch_bounds__(1024)
+SelectBestKernel(const Node2D* __restrict__ leaves, const Counters* __restrict__ counters,
+                 int capacity, const ProblemState* __restrict__ states,
+                 SelectState* __restrict__ sel, BestLeaf* __restrict__ best, int num_problems) {
+  const int total = min(counters->leaves, capacity);
+  for (int p = threadIdx.x; p < num_problems; p += blockDim.x) {
+    sel[p].best_coarse_bits = 0;
+    sel[p].ties = 0;
+    sel[p].key = ~0ull;
+    BestLeaf b{};
+    best[p] = b;
   }
-}
-
-__global__ void InitSelectKernel(SelectState* __restrict__ sel, int num) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < num) {
-    sel[i].best_coarse_bits = 0;
-    sel[i].ties = 0;
-    sel[i].key = ~0ull;
-  }
-}
-
-__global__ void SelectBestPass1(const Node2D* __restrict__ leaves, const int* __restrict__ count,
-                                int capacity, const ProblemState* __restrict__ states,
-                                SelectState* __restrict__ sel) {
-  const int total = min(*count, capacity);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  __threadfence();
+  __syncthreads();
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
     const Node2D nd = leaves[i];
-    if (__float_as_uint(nd.score) == states[nd.problem].best_bits) {
-      atomicMax(&sel[nd.problem].best_coarse_bits, __float_as_uint(nd.coarse_score));
-      atomicAdd(&sel[nd.problem].ties, 1);
+    const int p = NodeProblem(nd);
+    if (__float_as_uint(nd.score) == states[p].best_bits) {
+      atomicMax(&sel[p].best_coarse_bits, __float_as_uint(nd.coarse_score));
+      atomicAdd(&sel[p].ties, 1);
     }
   }
-}
-__global__ void SelectBestPass2(const Node2D* __restrict__ leaves, const int* __restrict__ count,
-                                int capacity, const ProblemState* __restrict__ states,
-                                SelectState* __restrict__ sel) {
-  const int total = min(*count, capacity);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  __threadfence();
+  __syncthreads();
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
     const Node2D nd = leaves[i];
-    if (__float_as_uint(nd.score) == states[nd.problem].best_bits &&
-        __float_as_uint(nd.coarse_score) == sel[nd.problem].best_coarse_bits) {
+    const int p = NodeProblem(nd);
+    if (__float_as_uint(nd.score) == states[p].best_bits &&
+        __float_as_uint(nd.coarse_score) ==
+            __hip_atomic_load(&sel[p].best_coarse_bits, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_AGENT)) {
       const unsigned long long key =
           (static_cast<unsigned long long>(static_cast<unsigned>(nd.coarse_index)) << 32) | nd.path;
-      atomicMin(&sel[nd.problem].key, key);
+      atomicMin(&sel[p].key, key);
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const Node2D nd = leaves[i];
+    const int p = NodeProblem(nd);
+    const unsigned long long key =
+        (static_cast<unsigned long long>(static_cast<unsigned>(nd.coarse_index)) << 32) | nd.path;
+    if (__float_as_uint(nd.score) == states[p].best_bits &&
+        __float_as_uint(nd.coarse_score) ==
+            __hip_atomic_load(&sel[p].best_coarse_bits, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_AGENT) &&
+        key == __hip_atomic_load(&sel[p].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      BestLeaf b;
+      b.score = nd.score; b.scan = nd.scan; b.dx = nd.dx; b.dy = nd.dy;
+      b.found = 1;
+      b.ties = __hip_atomic_load(&sel[p].ties, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      b.pad0 = b.pad1 = 0;
+      best[p] = b;   // duplicates (dive + search) carry identical content
     }
   }
 }
-__global__ void SelectBestPass3(const Node2D* __restrict__ leaves, const int* __restrict__ count,
-                                int capacity, const ProblemState* __restrict__ states,
-                                const SelectState* __restrict__ sel, BestLeaf* __restrict__ best) {
-  const int total = min(*count, capacity);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const Node2D nd = leaves[i];
-    const unsigned long long key =
-        (static_cast<unsigned long long>(static_cast<unsigned>(nd.coarse_index)) << 32) | nd.path;
-    if (__float_as_uint(nd.score) == states[nd.problem].best_bits &&
-        __float_as_uint(nd.coarse_score) == sel[nd.problem].best_coarse_bits &&
-        key == sel[nd.problem].key) {
-      BestLeaf b;
-      b.score = nd.score; b.scan = nd.scan; b.dx = nd.dx; b.dy = nd.dy;
-      b.found = 1; b.ties = sel[nd.problem].ties; b.pad0 = b.pad1 = 0;
-      best[nd.problem] = b;   // duplicates (dive + full) carry identical content
+
+// depth == 1: the lowest-resolution candidates are the leaves
+// (BranchAndBound returns candidates[0], SM2/fast_...2d.cc:340-343).
+__global__ void __launch_bounds__(1024)
+SelectDepthOneKernel(const Fast2DProblem* __restrict__ problems,
+                     const ProblemState* __restrict__ states, int n, BestLeaf* __restrict__ best) {
+  const int problem = blockIdx.x;
+  const Fast2DProblem& P = problems[problem];
+  __shared__ unsigned long long keys[16];
+  unsigned long long key = 0;
+  for (int s = threadIdx.x; s < P.num_scans; s += blockDim.x) {
+    const int2 b = P.scan_best[s];
+    // larger sum first, then smaller scan index (generation order)
+    const unsigned long long k = (static_cast<unsigned long long>(static_cast<unsigned>(b.x)) << 32) |
+                                 static_cast<unsigned>(0x7fffffff - s);
+    key = k > key ? k : key;
+  }
+  key = WaveMaxU64(key);
+  if ((threadIdx.x & 63) == 0) keys[threadIdx.x >> 6] = key;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) key = keys[w] > key ? keys[w] : key;
+    BestLeaf b{};
+    if (!states[problem].error && P.num_scans > 0) {
+      const int s = 0x7fffffff - static_cast<int>(key & 0xffffffffu);
+      const int2 sb = P.scan_best[s];
+      const float score = ToScore(P, sb.x, n);
+      if (score > P.min_score) {
+        const int2 dims = P.coarse_dims[s];
+        const int4 bd = P.bounds[s];
+        b.found = 1; b.score = score; b.scan = s;
+        b.dx = bd.x + sb.y / dims.y;
+        b.dy = bd.z + sb.y % dims.y;
+        b.ties = 1;
+      }
     }
+    best[problem] = b;
   }
 }
 
@@ -539,15 +902,29 @@ Fast2DMatcher::Fast2DMatcher(const cmx_fast2d_options& options, const cmx_grid2d
         prev.cells, prev.wx, prev.wy, 1 << (i - 1), const_cast<uint8_t*>(cur.cells), cur.wx,
         cur.wy);
   }
+  // Phase planes of the lowest-resolution level.
+  {
+    const int w = 1 << (depth - 1);
+    const LevelDesc& top = levels_[depth - 1];
+    const int PI = (top.wx + w - 1) / w, PJ = (top.wy + w - 1) / w;
+    if (w <= kMaxPlaneWidth && PI * PJ <= kMaxPlaneCells) {
+      plane_i_ = PI;
+      plane_j_ = PJ;
+      plane_stride_ = (PI * PJ + 63) & ~63;
+      const size_t bytes = static_cast<size_t>(w * w + 1) * plane_stride_;
+      CMX_HIP(hipMalloc(reinterpret_cast<void**>(&planes_), bytes));
+      BuildPlanesKernel<<<w * w + 1, 64, 0, ws->stream>>>(top.cells, top.wx, top.wy, w, PI, PJ,
+                                                          plane_stride_, planes_);
+    }
+  }
   CMX_HIP(hipGetLastError());
   CMX_HIP(hipStreamSynchronize(ws->stream));
 }
 
 Fast2DMatcher::~Fast2DMatcher() {
-  if (stack_mem_) {
-    (void)hipSetDevice(device_);
-    (void)hipFree(stack_mem_);
-  }
+  (void)hipSetDevice(device_);
+  if (stack_mem_) (void)hipFree(stack_mem_);
+  if (planes_) (void)hipFree(planes_);
 }
 
 namespace {
@@ -586,6 +963,7 @@ float MaxRangeXY(const float* xyz, int n) {
 struct PreparedBatch {
   int num_problems = 0;
   int n = 0;
+  int max_scans = 0;
   std::vector<HostSearch> search;
   std::vector<cmx_pose2d> initial;
   Fast2DProblem* d_problems = nullptr;
@@ -638,19 +1016,26 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
       const double width = std::min(2.0 * h.nl, cells - 1 + spread_cells);
       return static_cast<long long>(width / step) + 2;
     };
-    const long long per_scan = per_axis(lim.num_x_cells) * per_axis(lim.num_y_cells);
-    const long long cap = per_scan * h.num_scans;
+    const long long ax = per_axis(lim.num_x_cells), ay = per_axis(lim.num_y_cells);
+    const long long cap = ax * ay * h.num_scans;
     CMX_REQUIRE(cap < (1ll << 30), "search too large: %lld lowest-resolution candidates", cap);
-    out->h_problems[p].coarse_capacity = static_cast<int>(cap);
+    Fast2DProblem& P = out->h_problems[p];
+    P.coarse_capacity = static_cast<int>(cap);
+    P.use_planes = m.planes() != nullptr && ax * ay <= kMaxCoarsePerScan &&
+                   (ax + m.plane_i() - 1) * (ay + m.plane_j() - 1) <= kMaxBuckets &&
+                   m.depth() > 1;
     coarse_total += cap;
   }
 
   // Scratch carving.
   float2* d_rot = ws.dev[1].ReserveAs<float2>(rot_total);
-  uint32_t* d_discrete = ws.dev[2].ReserveAs<uint32_t>(discrete_total);
+  uint32_t* d_discrete = ws.dev[2].ReserveAs<uint32_t>(2 * discrete_total);
+  uint32_t* d_sorted = d_discrete + discrete_total;
   int4* d_bounds = ws.dev[3].ReserveAs<int4>(scans_total);
-  int2* d_dims = ws.dev[4].ReserveAs<int2>(scans_total);
-  int* d_off = ws.dev[5].ReserveAs<int>(scans_total);
+  int2* d_dims = ws.dev[4].ReserveAs<int2>(2 * scans_total);
+  int2* d_scan_best = d_dims + scans_total;
+  int* d_off = ws.dev[5].ReserveAs<int>(2 * scans_total);
+  int* d_sorted_count = d_off + scans_total;
   float* d_cscore = ws.dev[6].ReserveAs<float>(coarse_total);
   int* d_csum = ws.dev[7].ReserveAs<int>(coarse_total);
   out->d_problems = ws.dev[8].ReserveAs<Fast2DProblem>(num);
@@ -680,46 +1065,73 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     }
     P.num_scans = h.num_scans;
     // GenerateRotatedScans (SM2/correlative_scan_matcher_2d.cc:99-107):
-    // delta_theta accumulates in f64, each angle is narrowed to f32.
-    double delta_theta = -h.num_angular * h.step;
-    for (int s = 0; s < h.num_scans; ++s, delta_theta += h.step) {
-      const float ha = 0.5f * static_cast<float>(delta_theta);
-      h_rot[rot_off + s] = make_float2(std::cos(ha), std::sin(ha) * 1.f);
+    // delta_theta accumulates in f64, each angle is narrowed to f32.  Problems
+    // with the same (step, num_angular) as their predecessor share its table.
+    if (p > 0 && out->search[p - 1].step == h.step &&
+        out->search[p - 1].num_angular == h.num_angular) {
+      P.scan_rot = out->h_problems[p - 1].scan_rot;
+    } else {
+      double delta_theta = -h.num_angular * h.step;
+      for (int s = 0; s < h.num_scans; ++s, delta_theta += h.step) {
+        const float ha = 0.5f * static_cast<float>(delta_theta);
+        h_rot[rot_off + s] = make_float2(std::cos(ha), std::sin(ha) * 1.f);
+      }
+      P.scan_rot = d_rot + rot_off;
+      rot_off += h.num_scans;
     }
-    P.scan_rot = d_rot + rot_off;
     P.min_s = m.min_s();
     P.score_scale = m.score_scale();
     P.min_score = min_score;
+    P.planes = m.planes();
+    P.plane_i = m.plane_i();
+    P.plane_j = m.plane_j();
+    P.plane_stride = m.plane_stride();
     P.discrete = d_discrete + disc_off;
+    P.sorted = d_sorted + disc_off;
     P.bounds = d_bounds + scan_off;
     P.coarse_dims = d_dims + scan_off;
+    P.scan_best = d_scan_best + scan_off;
     P.coarse_off = d_off + scan_off;
+    P.sorted_count = d_sorted_count + scan_off;
     P.coarse_score = d_cscore + coarse_off;
     P.coarse_sum = d_csum + coarse_off;
     h_prob[p] = P;
     std::memset(&h_state[p], 0, sizeof(ProblemState));
     const float bound = std::max(min_score, 0.f);
     std::memcpy(&h_state[p].best_bits, &bound, sizeof(float));
-    rot_off += h.num_scans;
     disc_off += static_cast<size_t>(h.num_scans) * n;
     scan_off += h.num_scans + 1;
     coarse_off += P.coarse_capacity;
+    out->max_scans = std::max(out->max_scans, h.num_scans);
   }
-  CMX_HIP(hipMemcpyAsync(d_rot, h_rot, rot_total * sizeof(float2), hipMemcpyHostToDevice,
-                         ws.stream));
+  if (rot_off)
+    CMX_HIP(hipMemcpyAsync(d_rot, h_rot, rot_off * sizeof(float2), hipMemcpyHostToDevice,
+                           ws.stream));
   CMX_HIP(hipMemcpyAsync(out->d_problems, h_prob, num * sizeof(Fast2DProblem),
                          hipMemcpyHostToDevice, ws.stream));
   CMX_HIP(hipMemcpyAsync(out->d_states, h_state, num * sizeof(ProblemState),
                          hipMemcpyHostToDevice, ws.stream));
 
-  int max_scans = 0;
-  for (const HostSearch& h : out->search) max_scans = std::max(max_scans, h.num_scans);
-  PrepScansKernel<<<dim3(max_scans, num), 256, 0, ws.stream>>>(out->d_problems, d_xyz, n,
-                                                               out->d_states);
+  const dim3 per_scan(out->max_scans, num);
+  PrepScansKernel<<<per_scan, 256, 0, ws.stream>>>(out->d_problems, d_xyz, n, out->d_states);
   CoarseLayoutKernel<<<num, 1024, 0, ws.stream>>>(out->d_problems, out->d_states);
+  bool any_generic = false;
+  int chunk_mask = 0;
+  for (const Fast2DProblem& P : out->h_problems) {
+    if (P.use_planes) chunk_mask |= 1 << (P.plane_stride >> 6);
+    else any_generic = true;
+  }
   CMX_HIP(hipEventRecord(ws.ev_k0, ws.stream));
-  ScoreCoarseKernel<<<dim3(max_scans, num), 256, 0, ws.stream>>>(out->d_problems, n,
-                                                                 out->d_states);
+  if (chunk_mask & (1 << 1))
+    ScoreCoarsePlanesKernel<1><<<per_scan, 256, 0, ws.stream>>>(out->d_problems, n, out->d_states);
+  if (chunk_mask & (1 << 2))
+    ScoreCoarsePlanesKernel<2><<<per_scan, 256, 0, ws.stream>>>(out->d_problems, n, out->d_states);
+  if (chunk_mask & (1 << 3))
+    ScoreCoarsePlanesKernel<3><<<per_scan, 256, 0, ws.stream>>>(out->d_problems, n, out->d_states);
+  if (chunk_mask & (1 << 4))
+    ScoreCoarsePlanesKernel<4><<<per_scan, 256, 0, ws.stream>>>(out->d_problems, n, out->d_states);
+  if (any_generic)
+    ScoreCoarseGenericKernel<<<per_scan, 256, 0, ws.stream>>>(out->d_problems, n, out->d_states);
   CMX_HIP(hipEventRecord(ws.ev_k1, ws.stream));
   CMX_HIP(hipGetLastError());
 }
@@ -733,118 +1145,107 @@ struct BatchResult {
 // Full search of a prepared batch.
 void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* result) {
   const int num = batch.num_problems, n = batch.n;
-  int max_depth = 0;
-  for (const Fast2DProblem& P : batch.h_problems) max_depth = std::max(max_depth, P.depth);
+  const int depth = batch.h_problems[0].depth;
+  for (const Fast2DProblem& P : batch.h_problems)
+    CMX_REQUIRE(P.depth == depth, "all matchers of a batch must share branch_and_bound_depth");
 
-  const int kFrontierCapacity = 1 << 22;          // nodes per ping-pong buffer
-  const int kLeafCapacity = 1 << 22;
-  const int dive_capacity = kSeedCap * num;
+  const int kFrontierCapacity = 1 << 21;          // nodes per frontier buffer
+  const int kLeafCapacity = 1 << 20;
   Node2D* d_front[2] = {ws.dev[10].ReserveAs<Node2D>(kFrontierCapacity),
                         ws.dev[11].ReserveAs<Node2D>(kFrontierCapacity)};
   Node2D* d_leaves = ws.dev[12].ReserveAs<Node2D>(kLeafCapacity);
-  Node2D* d_dive[2] = {ws.dev[13].ReserveAs<Node2D>(2 * dive_capacity), nullptr};
-  d_dive[1] = d_dive[0] + dive_capacity;
-  char* d_misc = static_cast<char*>(
-      ws.dev[14].Reserve(sizeof(Counters) + num * (sizeof(SelectState) + sizeof(BestLeaf))));
+  Node2D* d_seeds = ws.dev[13].ReserveAs<Node2D>(static_cast<size_t>(kSeedsPerProblem) * num);
+  char* d_misc = static_cast<char*>(ws.dev[14].Reserve(
+      sizeof(Counters) + num * (sizeof(SelectState) + sizeof(BestLeaf) + sizeof(int))));
   Counters* d_counters = reinterpret_cast<Counters*>(d_misc);
   SelectState* d_sel = reinterpret_cast<SelectState*>(d_misc + sizeof(Counters));
   BestLeaf* d_best = reinterpret_cast<BestLeaf*>(d_misc + sizeof(Counters) +
                                                  num * sizeof(SelectState));
-  const int expand_blocks = 2048;
-
-  auto zero_counters = [&] {
-    CMX_HIP(hipMemsetAsync(d_counters, 0, sizeof(Counters), ws.stream));
-  };
-  zero_counters();
-  CMX_HIP(hipMemsetAsync(d_best, 0, num * sizeof(BestLeaf), ws.stream));
-
-  // Problems whose depth differs from max_depth simply start lower: nodes of
-  // a depth-d problem enter the frontier when the loop reaches level d-1.
-  // (All problems of a batch normally share the depth; mixed depths are
-  // handled by seeding/filtering per depth below.)
-  for (const Fast2DProblem& P : batch.h_problems)
-    CMX_REQUIRE(P.depth == max_depth, "all matchers of a batch must share branch_and_bound_depth");
-
-  if (max_depth == 1) {
-    // Lowest resolution is already full resolution: every candidate is a leaf.
-    // Treat level 0 candidates as children of virtual parents: reuse the
-    // filter + selection path by recording them as leaves directly.
-  }
-
-  // ---- dive -------------------------------------------------------------
-  if (max_depth > 1) {
-    SeedKernel<<<num, 1024, 0, ws.stream>>>(batch.d_problems, batch.d_states, n, d_dive[0],
-                                            d_counters, 0);
-    int cur = 0;
-    for (int child_level = max_depth - 2; child_level >= 0; --child_level) {
-      ExpandKernel<<<std::min(expand_blocks, dive_capacity), 256, 0, ws.stream>>>(
-          batch.d_problems, batch.d_states, n, d_dive[cur], &d_counters->dive[cur], dive_capacity,
-          child_level, kExpandDive, d_dive[cur ^ 1], &d_counters->dive[cur ^ 1], dive_capacity, d_leaves,
-          &d_counters->leaves, kLeafCapacity, &d_counters->overflow);
-      CMX_HIP(hipMemsetAsync(&d_counters->dive[cur], 0, sizeof(int), ws.stream));
-      cur ^= 1;
-    }
-  }
-
-  // ---- full expansion, chunked over the lowest-resolution candidates on
-  //      frontier overflow ---------------------------------------------------
+  int* d_seed_count = reinterpret_cast<int*>(d_misc + sizeof(Counters) +
+                                             num * (sizeof(SelectState) + sizeof(BestLeaf)));
   Counters* h_counters = ws.pinned[3].ReserveAs<Counters>(1);
-  int num_chunks = 1;
-  for (;;) {
-    for (int chunk = 0; chunk < num_chunks; ++chunk) {
-      CMX_HIP(hipMemsetAsync(&d_counters->frontier[0], 0, 2 * sizeof(int), ws.stream));
-      if (max_depth > 1) {
-        FilterCoarseKernel<<<dim3(128, num), 256, 0, ws.stream>>>(
-            batch.d_problems, batch.d_states, chunk, num_chunks, d_front[0], kFrontierCapacity,
-            d_counters, 0);
-        int cur = 0;
-        for (int child_level = max_depth - 2; child_level >= 0; --child_level) {
-          ExpandKernel<<<expand_blocks, 256, 0, ws.stream>>>(
-              batch.d_problems, batch.d_states, n, d_front[cur], &d_counters->frontier[cur],
-              kFrontierCapacity, child_level, kExpandFull, d_front[cur ^ 1], &d_counters->frontier[cur ^ 1],
-              kFrontierCapacity, d_leaves, &d_counters->leaves, kLeafCapacity,
-              &d_counters->overflow);
-          CMX_HIP(hipMemsetAsync(&d_counters->frontier[cur], 0, sizeof(int), ws.stream));
-          cur ^= 1;
+  CMX_HIP(hipMemsetAsync(d_counters, 0, sizeof(Counters), ws.stream));
+
+  if (depth == 1) {
+    SelectDepthOneKernel<<<num, 1024, 0, ws.stream>>>(batch.d_problems, batch.d_states, n, d_best);
+  } else {
+    // ---- dive -------------------------------------------------------------
+    SeedSelectKernel<<<num, 1024, 0, ws.stream>>>(batch.d_problems, batch.d_states, n, d_seeds,
+                                                  d_seed_count);
+    DiveKernel<<<dim3(kSeedsPerProblem, num), 256, 0, ws.stream>>>(
+        batch.d_problems, batch.d_states, n, d_seeds, d_seed_count, d_leaves, d_counters,
+        kLeafCapacity);
+
+    // ---- search -------------------------------------------------------------
+    // Top of the tree first (two levels) to create many independent roots,
+    // then the subtrees down to the leaves.
+    const int stop_level = std::max(0, depth - 3);
+    const int search_blocks = 4096;
+    int num_chunks = 1;
+    int strict = 0;
+    for (;;) {
+      for (int chunk = 0; chunk < num_chunks; ++chunk) {
+        CMX_HIP(hipMemsetAsync(&d_counters->frontier[0], 0, 2 * sizeof(int), ws.stream));
+        FilterCoarseKernel<<<dim3(batch.max_scans, num), 256, 0, ws.stream>>>(
+            batch.d_problems, batch.d_states, n, chunk, num_chunks, strict, d_front[0],
+            kFrontierCapacity, d_counters, 0);
+        if (stop_level > 0) {
+          SubtreeKernel<<<search_blocks, 256, 0, ws.stream>>>(
+              batch.d_problems, batch.d_states, n, d_front[0], &d_counters->frontier[0],
+              kFrontierCapacity, stop_level, strict, d_front[1], &d_counters->frontier[1],
+              kFrontierCapacity, d_leaves, d_counters, kLeafCapacity);
+          SubtreeKernel<<<search_blocks, 256, 0, ws.stream>>>(
+              batch.d_problems, batch.d_states, n, d_front[1], &d_counters->frontier[1],
+              kFrontierCapacity, 0, strict, nullptr, nullptr, 0, d_leaves, d_counters,
+              kLeafCapacity);
+        } else {
+          SubtreeKernel<<<search_blocks, 256, 0, ws.stream>>>(
+              batch.d_problems, batch.d_states, n, d_front[0], &d_counters->frontier[0],
+              kFrontierCapacity, 0, strict, nullptr, nullptr, 0, d_leaves, d_counters,
+              kLeafCapacity);
         }
       }
+      CMX_HIP(hipMemcpyAsync(h_counters, d_counters, sizeof(Counters), hipMemcpyDeviceToHost,
+                             ws.stream));
+      CMX_HIP(hipStreamSynchronize(ws.stream));
+      if (!h_counters->frontier_overflow && !h_counters->leaf_overflow) break;
+      // Something was dropped.  Bounds found so far are real leaf scores and
+      // stay valid; repeat the search in strict mode (prunes ties, records
+      // only improving leaves) over more, smaller chunks of scans.  The best
+      // leaf found so far is re-found by lowering the bound one ulp.
+      CMX_REQUIRE(num_chunks < (1 << 12), "branch-and-bound overflow not resolvable");
+      if (h_counters->frontier_overflow) num_chunks *= 4;
+      strict = 1;
+      std::vector<ProblemState> states(num);
+      CMX_HIP(hipMemcpy(states.data(), batch.d_states, num * sizeof(ProblemState),
+                        hipMemcpyDeviceToHost));
+      for (int p = 0; p < num; ++p) {
+        const float floor_score = std::max(batch.h_problems[p].min_score, 0.f);
+        unsigned floor_bits;
+        std::memcpy(&floor_bits, &floor_score, sizeof(float));
+        if (states[p].best_bits > floor_bits) states[p].best_bits -= 1;
+      }
+      CMX_HIP(hipMemcpy(batch.d_states, states.data(), num * sizeof(ProblemState),
+                        hipMemcpyHostToDevice));
+      CMX_HIP(hipMemsetAsync(d_counters, 0, sizeof(Counters), ws.stream));
     }
-    CMX_HIP(hipMemcpyAsync(h_counters, d_counters, sizeof(Counters), hipMemcpyDeviceToHost,
-                           ws.stream));
-    CMX_HIP(hipStreamSynchronize(ws.stream));
-    if (!h_counters->overflow) break;
-    // A frontier overflowed: children were dropped.  Redo the expansion with
-    // the lowest-resolution candidates split into more chunks; bounds found so
-    // far stay valid (they are real leaf scores), recorded leaves are kept.
-    CMX_REQUIRE(num_chunks < (1 << 16), "branch-and-bound frontier overflow not resolvable");
-    num_chunks *= 4;
-    // Restart the leaf record; lowering every bound by one ulp makes the
-    // expansion re-find the leaves that achieved it (bounds stay valid: they
-    // are below real leaf scores).
-    RelaxBoundsKernel<<<DivUp(num, 256), 256, 0, ws.stream>>>(batch.d_problems, batch.d_states,
-                                                              num);
-    CMX_HIP(hipMemsetAsync(&d_counters->overflow, 0, sizeof(int), ws.stream));
-    CMX_HIP(hipMemsetAsync(&d_counters->leaves, 0, sizeof(int), ws.stream));
+    SelectBestKernel<<<1, 1024, 0, ws.stream>>>(d_leaves, d_counters, kLeafCapacity,
+                                                batch.d_states, d_sel, d_best, num);
   }
-
-  // ---- selection ----------------------------------------------------------
-  InitSelectKernel<<<DivUp(num, 256), 256, 0, ws.stream>>>(d_sel, num);
-  SelectBestPass1<<<64, 256, 0, ws.stream>>>(d_leaves, &d_counters->leaves, kLeafCapacity,
-                                             batch.d_states, d_sel);
-  SelectBestPass2<<<64, 256, 0, ws.stream>>>(d_leaves, &d_counters->leaves, kLeafCapacity,
-                                             batch.d_states, d_sel);
-  SelectBestPass3<<<64, 256, 0, ws.stream>>>(d_leaves, &d_counters->leaves, kLeafCapacity,
-                                             batch.d_states, d_sel, d_best);
   CMX_HIP(hipGetLastError());
   CMX_HIP(hipEventRecord(ws.ev_end, ws.stream));
 
   result->best.resize(num);
   result->states.resize(num);
-  CMX_HIP(hipMemcpyAsync(result->best.data(), d_best, num * sizeof(BestLeaf),
-                         hipMemcpyDeviceToHost, ws.stream));
-  CMX_HIP(hipMemcpyAsync(result->states.data(), batch.d_states, num * sizeof(ProblemState),
+  BestLeaf* h_best = ws.pinned[0].ReserveAs<BestLeaf>(num);
+  ProblemState* h_states = ws.pinned[2].ReserveAs<ProblemState>(num);
+  CMX_HIP(hipMemcpyAsync(h_best, d_best, num * sizeof(BestLeaf), hipMemcpyDeviceToHost,
+                         ws.stream));
+  CMX_HIP(hipMemcpyAsync(h_states, batch.d_states, num * sizeof(ProblemState),
                          hipMemcpyDeviceToHost, ws.stream));
   CMX_HIP(hipStreamSynchronize(ws.stream));
+  std::copy(h_best, h_best + num, result->best.begin());
+  std::copy(h_states, h_states + num, result->states.begin());
   float ms = 0.f;
   CMX_HIP(hipEventElapsedTime(&ms, ws.ev_begin, ws.ev_end));
   result->device_ms = ms;
@@ -859,57 +1260,12 @@ void CheckProblemErrors(const BatchResult& r) {
   }
 }
 
-// depth == 1: the lowest-resolution candidates are the leaves
-// (BranchAndBound returns candidates[0], SM2/fast_...2d.cc:340-343).
-void SelectDepthOne(Workspace& ws, const PreparedBatch& batch, BatchResult* result) {
-  const int num = batch.num_problems;
-  result->best.assign(num, BestLeaf{});
-  result->states.resize(num);
-  CMX_HIP(hipEventRecord(ws.ev_end, ws.stream));
-  CMX_HIP(hipMemcpyAsync(result->states.data(), batch.d_states, num * sizeof(ProblemState),
-                         hipMemcpyDeviceToHost, ws.stream));
-  CMX_HIP(hipStreamSynchronize(ws.stream));
-  CheckProblemErrors(*result);
-  for (int p = 0; p < num; ++p) {
-    const Fast2DProblem& P = batch.h_problems[p];
-    const int total = result->states[p].coarse_total;
-    const int S = P.num_scans;
-    std::vector<float> scores(total);
-    std::vector<int> off(S + 1);
-    std::vector<int2> dims(S);
-    std::vector<int4> bounds(S);
-    CMX_HIP(hipMemcpy(scores.data(), P.coarse_score, total * sizeof(float), hipMemcpyDeviceToHost));
-    CMX_HIP(hipMemcpy(off.data(), P.coarse_off, (S + 1) * sizeof(int), hipMemcpyDeviceToHost));
-    CMX_HIP(hipMemcpy(dims.data(), P.coarse_dims, S * sizeof(int2), hipMemcpyDeviceToHost));
-    CMX_HIP(hipMemcpy(bounds.data(), P.bounds, S * sizeof(int4), hipMemcpyDeviceToHost));
-    int best = -1;
-    for (int c = 0; c < total; ++c)
-      if (best < 0 || scores[c] > scores[best]) best = c;
-    BestLeaf& b = result->best[p];
-    if (best >= 0 && scores[best] > P.min_score) {
-      const int s = static_cast<int>(std::upper_bound(off.begin(), off.end(), best) -
-                                     off.begin()) - 1;
-      const int local = best - off[s];
-      b.found = 1;
-      b.score = scores[best];
-      b.scan = s;
-      b.dx = bounds[s].x + local / dims[s].y;
-      b.dy = bounds[s].z + local % dims[s].y;
-      b.ties = 1;
-    }
-  }
-  float ms = 0.f;
-  CMX_HIP(hipEventElapsedTime(&ms, ws.ev_begin, ws.ev_end));
-  result->device_ms = ms;
-  CMX_HIP(hipEventElapsedTime(&ms, ws.ev_k0, ws.ev_k1));
-  result->dominant_ms = ms;
-}
-
 void MatchBatch(const cmx_fast2d* const* handles, int num, const cmx_pose2d* initial,
                 bool full_submap, const float* host_xyz, const cmx_cloud* cloud, int n,
                 float min_score, int32_t* found, float* scores, cmx_pose2d* poses,
                 cmx_match_stats* stats) {
   CMX_REQUIRE(handles != nullptr && num >= 1, "no matchers given");
+  CMX_REQUIRE(num < (1 << 24), "too many matchers in one batch");
   CMX_REQUIRE(found != nullptr && scores != nullptr && poses != nullptr,
               "score / pose_estimate outputs must not be null");   // CHECK at :232-233
   CMX_REQUIRE(n >= 1, "empty point cloud");
@@ -942,14 +1298,8 @@ void MatchBatch(const cmx_fast2d* const* handles, int num, const cmx_pose2d* ini
   PrepareAndScoreCoarse(*ws, matchers.data(), num, initial, full_submap, d_xyz, n, max_range,
                         min_score, &batch);
   BatchResult result;
-  if (matchers[0]->depth() == 1) {
-    for (const Fast2DMatcher* m : matchers)
-      CMX_REQUIRE(m->depth() == 1, "all matchers of a batch must share branch_and_bound_depth");
-    SelectDepthOne(*ws, batch, &result);
-  } else {
-    RunBranchAndBound(*ws, batch, &result);
-    CheckProblemErrors(result);
-  }
+  RunBranchAndBound(*ws, batch, &result);
+  CheckProblemErrors(result);
   cmx_match_stats total{};
   for (int p = 0; p < num; ++p) {
     const BestLeaf& b = result.best[p];

@@ -32,6 +32,12 @@ struct Fast2DProblem {
   const float2* scan_rot;   // [num_scans] (w, z) of AngleAxisf(f32(delta_theta_s), Z)
   float min_s, score_scale; // ToScore(v) = min_s + v * score_scale
   float min_score;          // caller's acceptance threshold
+  // Lowest-resolution level re-laid out as "phase planes" (see fast_2d.hip):
+  // plane(py,px)[J][I] = level[depth-1] cell (I*w+px, J*w+py), w = 2^(depth-1).
+  const uint8_t* planes;    // [(w*w + 1) planes][plane_stride]; the last plane is all zero
+  int plane_i, plane_j;     // cells per plane along x / y
+  int plane_stride;         // bytes per plane (multiple of 64)
+  int use_planes;           // 0: generic gather scoring of the lowest resolution
   // scratch
   uint32_t* discrete;   // [num_scans][n] packed int16 (x | y << 16)
   int4* bounds;         // [num_scans] (min_x, max_x, min_y, max_y) after ShrinkToFit
@@ -39,11 +45,14 @@ struct Fast2DProblem {
   int* coarse_off;      // [num_scans + 1]
   float* coarse_score;  // [coarse_capacity]
   int* coarse_sum;      // [coarse_capacity]
+  uint32_t* sorted;     // [num_scans][n] points bucketed by coarse block: plane | bucket << 16
+  int* sorted_count;    // [num_scans]
+  int2* scan_best;      // [num_scans] (best sum, local candidate index) of each scan
 };
 
 // Branch-and-bound node.
 struct Node2D {
-  int problem;      // index into the batch
+  int problem;      // index into the batch | level << 24
   int scan;
   int dx, dy;       // x/y_index_offset of the node's lowest corner
   float score;
@@ -79,6 +88,10 @@ class Fast2DMatcher {
   const cmx_grid2d_limits& limits() const { return limits_; }
   int depth() const { return options_.branch_and_bound_depth; }
   const LevelDesc& level(int i) const { return levels_[i]; }
+  const uint8_t* planes() const { return planes_; }
+  int plane_i() const { return plane_i_; }
+  int plane_j() const { return plane_j_; }
+  int plane_stride() const { return plane_stride_; }
   size_t level_offset(int i) const { return level_offsets_[i]; }
   float min_s() const { return min_s_; }
   float score_scale() const { return score_scale_; }
@@ -88,6 +101,8 @@ class Fast2DMatcher {
   cmx_grid2d_limits limits_;
   int device_;
   void* stack_mem_ = nullptr;      // all levels, contiguous
+  uint8_t* planes_ = nullptr;      // phase planes of the lowest-resolution level (or null)
+  int plane_i_ = 0, plane_j_ = 0, plane_stride_ = 0;
   std::vector<LevelDesc> levels_;
   std::vector<size_t> level_offsets_;
   float min_s_, score_scale_;
