@@ -194,6 +194,7 @@ def main():
                 "rotations": scans_per_launch // max(n_sub, 1),
                 "candidates_per_step": cand / args.steps,
                 "lowest_resolution_candidates_per_step": coarse / args.steps,
+                "nodes_expanded_per_step": stats["nodes_expanded"],
                 "matches_per_s": world_size * n_sub * args.steps / elapsed,
                 "found": int(found.sum()),
                 "device_ms_per_step": device_ms / args.steps,

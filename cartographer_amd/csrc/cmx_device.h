@@ -56,11 +56,17 @@ __device__ __forceinline__ Quat QuatMul(const Quat& a, const Quat& b) {
           a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
 }
 
-// Wave-wide integer sum (all 64 lanes receive the total).
+// Wave-wide integer sum (all 64 lanes receive the total).  DPP row shifts and
+// row broadcasts keep the reduction in the VALU (a __shfl_xor butterfly goes
+// through the LDS crossbar six dependent times).
 __device__ __forceinline__ int WaveSum(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   // row_bcast:15
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);   // row_bcast:31
+  return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int WaveMin(int v) {
 #pragma unroll

@@ -279,14 +279,15 @@ __device__ __forceinline__ int ScoreCandidateWave(const LevelDesc& L, int level,
   const int off = (1 << level) - 1;   // -offset_
   const int ax = dx + off, ay = dy + off;
   int sum = 0;
+#pragma unroll 4
   for (int i = lane; i < n; i += kWave) {
     const uint32_t p = scan[i];
     const int x = static_cast<short>(p & 0xffffu) + ax;
     const int y = static_cast<short>(p >> 16) + ay;
-    if (static_cast<unsigned>(x) < static_cast<unsigned>(L.wx) &&
-        static_cast<unsigned>(y) < static_cast<unsigned>(L.wy)) {
-      sum += L.cells[x + y * L.wx];
-    }
+    const bool ok = static_cast<unsigned>(x) < static_cast<unsigned>(L.wx) &&
+                    static_cast<unsigned>(y) < static_cast<unsigned>(L.wy);
+    const unsigned v = L.cells[ok ? x + y * L.wx : 0];   // unconditional load, masked value
+    sum += ok ? v : 0u;
   }
   return WaveSum(sum);
 }
@@ -388,28 +389,36 @@ ScoreCoarsePlanesKernel(const Fast2DProblem* __restrict__ problems, int n,
     }
   };
 
-  for (int i = begin; i < end; i += 4) {
-    // Four records (wave-uniform, scalar loads) and their planes up front so
-    // the 64-byte plane loads overlap; the tail reads the zero plane.
-    uint32_t r[4];
-    int v[4][CHUNKS];
+  // Records are wave-uniform: 64 of them arrive with one coalesced load (one
+  // per lane) and are broadcast with readlane; kBatch plane loads are in flight
+  // before the first one is consumed.  The tail reads the all-zero plane.
+  constexpr int kBatch = 16;
+  const uint32_t sentinel = 0xffff0000u | zero_plane;
+  for (int base_i = begin; base_i < end; base_i += 64) {
+    const uint32_t mine = (base_i + lane < end) ? rec[base_i + lane] : sentinel;
+    const int cnt = min(64, end - base_i);
+    for (int j0 = 0; j0 < cnt; j0 += kBatch) {
+      uint32_t r[kBatch];
+      int v[kBatch][CHUNKS];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      r[k] = (i + k < end) ? rec[i + k] : (0xffff0000u | zero_plane);
-      const uint8_t* pp = planes + static_cast<size_t>(r[k] & 0xffffu) * stride + lane;
+      for (int k = 0; k < kBatch; ++k) {
+        r[k] = static_cast<uint32_t>(
+            __builtin_amdgcn_readlane(static_cast<int>(mine), (j0 + k) & 63));
+        const uint8_t* pp = planes + static_cast<size_t>(r[k] & 0xffffu) * stride + lane;
 #pragma unroll
-      for (int c = 0; c < CHUNKS; ++c) v[k][c] = pp[c * 64];
-    }
+        for (int c = 0; c < CHUNKS; ++c) v[k][c] = pp[c * 64];
+      }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int bucket = static_cast<int>(r[k] >> 16);
-      if (bucket != 0xffff) {
-        if (bucket != cur) {
-          if (cur >= 0) flush(cur);
-          cur = bucket;
+      for (int k = 0; k < kBatch; ++k) {
+        const int bucket = static_cast<int>(r[k] >> 16);
+        if (bucket != 0xffff) {
+          if (bucket != cur) {
+            if (cur >= 0) flush(cur);
+            cur = bucket;
+          }
+#pragma unroll
+          for (int c = 0; c < CHUNKS; ++c) acc[c] += v[k][c];
         }
-#pragma unroll
-        for (int c = 0; c < CHUNKS; ++c) acc[c] += v[k][c];
       }
     }
   }
@@ -431,13 +440,42 @@ ScoreCoarsePlanesKernel(const Fast2DProblem* __restrict__ problems, int n,
 // ---------------------------------------------------------------------------
 // Branch and bound
 // ---------------------------------------------------------------------------
+// Node lists (frontiers, leaves) are split into kSubLists sub-lists, each with
+// its own counter, so that thousands of blocks appending at once do not
+// serialise on one atomic word (one word sustains only ~90 atomics/us).
+constexpr int kSubLists = 64;
+
+constexpr int kMaxStages = kMaxDepth + 2;   // one frontier counter array per search stage
+
 struct Counters {           // device, zeroed per call
-  int frontier[2];
-  int leaves;
+  int frontier[kMaxStages][kSubLists];
+  int leaves[kSubLists];
   int frontier_overflow;
   int leaf_overflow;
-  int pad[3];
+  int pad[2];
 };
+
+struct NodeList {
+  Node2D* nodes;      // [kSubLists][sub_capacity]
+  int* counts;        // [kSubLists]
+  int sub_capacity;
+};
+
+// Reserves `m` consecutive slots of sub-list `sub`; returns the first slot.
+__device__ __forceinline__ int ListReserve(const NodeList& list, int sub, int m) {
+  return atomicAdd(&list.counts[sub], m);
+}
+__device__ __forceinline__ bool ListStore(const NodeList& list, int sub, int slot,
+                                          const Node2D& nd) {
+  if (slot >= list.sub_capacity) return false;
+  list.nodes[static_cast<size_t>(sub) * list.sub_capacity + slot] = nd;
+  return true;
+}
+// Largest sub-list length (wave-uniform); every lane must call it.
+__device__ __forceinline__ int ListMaxCount(const NodeList& list) {
+  const int lane = threadIdx.x & 63;
+  return WaveMax(min(list.counts[lane], list.sub_capacity));
+}
 
 __device__ __forceinline__ int NodeProblem(const Node2D& nd) { return nd.problem & 0xffffff; }
 __device__ __forceinline__ int NodeLevel(const Node2D& nd) { return nd.problem >> 24; }
@@ -506,10 +544,52 @@ SeedSelectKernel(const Fast2DProblem* __restrict__ problems,
   if (threadIdx.x == 0) seed_count[problem] = min(taken, kSeedsPerProblem);
 }
 
+// Problem- and scan-invariant data a block keeps on chip while it works on
+// nodes of one rotated scan: level descriptors and score constants (so that a
+// node expansion starts without dependent global loads), the discretised
+// points (LDS when they fit) and the search bounds of the scan.
+constexpr int kPointCache = 4096;   // points kept in LDS (16 KB)
+
+struct BlockContext {
+  LevelDesc level[kMaxDepth];
+  uint32_t cache[kPointCache];
+  const uint32_t* global_pts;
+  float min_s, score_scale, min_score;
+  int n, cached;
+  int max_x, max_y;    // linear_bounds[scan].max_x / max_y
+};
+
+__device__ __forceinline__ void LoadContext(const Fast2DProblem& P, int n, int scan,
+                                            BlockContext* ctx) {
+  const uint32_t* pts = P.discrete + static_cast<size_t>(scan) * n;
+  const bool cached = n <= kPointCache;
+  if (cached) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) ctx->cache[i] = pts[i];
+  }
+  if (threadIdx.x < kMaxDepth && static_cast<int>(threadIdx.x) < P.depth)
+    ctx->level[threadIdx.x] = P.level[threadIdx.x];
+  if (threadIdx.x == 64) {
+    const int4 bd = P.bounds[scan];
+    ctx->max_x = bd.y;
+    ctx->max_y = bd.w;
+    ctx->global_pts = pts;
+    ctx->cached = cached;
+    ctx->n = n;
+    ctx->min_s = P.min_s;
+    ctx->score_scale = P.score_scale;
+    ctx->min_score = P.min_score;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float ToScoreCtx(const BlockContext& ctx, int sum) {
+  return ctx.min_s + (static_cast<float>(sum) / static_cast<float>(ctx.n)) * ctx.score_scale;
+}
+
 // Scores the <=4 children of a node (SM2/fast_...2d.cc:351-368) with the whole
 // 256-thread block: every wave takes a quarter of the points and gathers all
 // four children per point.  child_score[k] < 0 marks a child outside the
-// search bounds; ranks[k] is the position of child k in the reference's stable
+// search bounds; rank[k] is the position of child k in the reference's stable
 // descending sort of the children.
 struct ChildScratch {
   int partial[4][4];
@@ -518,30 +598,38 @@ struct ChildScratch {
   int nvalid;
 };
 
-__device__ __forceinline__ void ScoreChildren(const Fast2DProblem& P, int n, int scan, int dx,
-                                              int dy, int child_level, ChildScratch* sh) {
-  const int4 bd = P.bounds[scan];
+__device__ __forceinline__ void ScoreChildren(const BlockContext& ctx, int dx, int dy,
+                                              int child_level, ChildScratch* sh) {
+  const int n = ctx.n;
+  const LevelDesc L = ctx.level[child_level];
   const int half = 1 << child_level;
-  const LevelDesc L = P.level[child_level];
   const int off = half - 1;
-  const bool vx = dx + half <= bd.y, vy = dy + half <= bd.w;   // the `break`s at :356,361
-  const uint32_t* __restrict__ pts = P.discrete + static_cast<size_t>(scan) * n;
+  const bool vx = dx + half <= ctx.max_x, vy = dy + half <= ctx.max_y;  // `break`s at :356,361
+  const bool cached = ctx.cached;
+  const uint32_t* __restrict__ gpts = ctx.global_pts;
   int s00 = 0, s01 = 0, s10 = 0, s11 = 0;   // s[x-step][y-step]
 #pragma unroll 4
   for (int i = threadIdx.x; i < n; i += 256) {
-    const uint32_t p = pts[i];
+    const uint32_t p = cached ? ctx.cache[i] : gpts[i];
     const int x = static_cast<short>(p & 0xffffu) + dx + off;
     const int y = static_cast<short>(p >> 16) + dy + off;
     const bool x0 = static_cast<unsigned>(x) < static_cast<unsigned>(L.wx);
     const bool x1 = vx && static_cast<unsigned>(x + half) < static_cast<unsigned>(L.wx);
     const bool y0 = static_cast<unsigned>(y) < static_cast<unsigned>(L.wy);
     const bool y1 = vy && static_cast<unsigned>(y + half) < static_cast<unsigned>(L.wy);
-    const uint8_t* row0 = L.cells + static_cast<size_t>(y) * L.wx;
-    const uint8_t* row1 = row0 + static_cast<size_t>(half) * L.wx;
-    if (x0 && y0) s00 += row0[x];
-    if (x0 && y1) s01 += row1[x];
-    if (x1 && y0) s10 += row0[x + half];
-    if (x1 && y1) s11 += row1[x + half];
+    // Unconditional loads from clamped (always valid) offsets, masked
+    // afterwards: all 16 gathers of the unrolled loop are in flight together
+    // (a load inside an `if` forces a wait per load).
+    const int o00 = y * L.wx + x;
+    const int o01 = o00 + half * L.wx;
+    const unsigned v00 = L.cells[(x0 && y0) ? o00 : 0];
+    const unsigned v01 = L.cells[(x0 && y1) ? o01 : 0];
+    const unsigned v10 = L.cells[(x1 && y0) ? o00 + half : 0];
+    const unsigned v11 = L.cells[(x1 && y1) ? o01 + half : 0];
+    s00 += (x0 && y0) ? v00 : 0u;
+    s01 += (x0 && y1) ? v01 : 0u;
+    s10 += (x1 && y0) ? v10 : 0u;
+    s11 += (x1 && y1) ? v11 : 0u;
   }
   s00 = WaveSum(s00); s01 = WaveSum(s01); s10 = WaveSum(s10); s11 = WaveSum(s11);
   const int wave = threadIdx.x >> 6;
@@ -550,25 +638,25 @@ __device__ __forceinline__ void ScoreChildren(const Fast2DProblem& P, int n, int
     sh->partial[wave][2] = s10; sh->partial[wave][3] = s11;
   }
   __syncthreads();
-  if (threadIdx.x < 4) {
-    const int k = threadIdx.x;   // k = 2*x-step + y-step: generation order x outer, y inner
+  if (threadIdx.x < 64) {
+    // Lanes 0..3 finish child k = 2*x-step + y-step (generation order: x outer,
+    // y inner) and rank them through wave shuffles.
+    const int k = threadIdx.x & 3;
     const bool valid = ((k >> 1) == 0 || vx) && ((k & 1) == 0 || vy);
     const int total = sh->partial[0][k] + sh->partial[1][k] + sh->partial[2][k] + sh->partial[3][k];
-    sh->child_score[k] = valid ? ToScore(P, total, n) : -1.f;
-  }
-  __syncthreads();
-  if (threadIdx.x < 4) {
-    const int me = threadIdx.x;
-    const float mine = sh->child_score[me];
+    const float mine = valid ? ToScoreCtx(ctx, total) : -1.f;
     int rank = 0, nvalid = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float other = sh->child_score[j];
+      const float other = __shfl(mine, j, 64);
       if (other >= 0.f) ++nvalid;
-      if (j != me && other >= 0.f && (other > mine || (other == mine && j < me))) ++rank;
+      if (j != k && other >= 0.f && (other > mine || (other == mine && j < k))) ++rank;
     }
-    sh->rank[me] = rank;
-    if (me == 0) sh->nvalid = nvalid;
+    if (threadIdx.x < 4) {
+      sh->child_score[k] = mine;
+      sh->rank[k] = rank;
+      if (k == 0) sh->nvalid = nvalid;
+    }
   }
   __syncthreads();
 }
@@ -584,32 +672,34 @@ __device__ __forceinline__ Node2D MakeChild(const Node2D& nd, int k, int child_l
   return child;
 }
 
-__device__ __forceinline__ void RecordLeaf(const Node2D& leaf, Node2D* __restrict__ leaves,
-                                           Counters* __restrict__ counters, int capacity) {
-  const int slot = atomicAdd(&counters->leaves, 1);
-  if (slot < capacity) leaves[slot] = leaf; else counters->leaf_overflow = 1;
+__device__ __forceinline__ void RecordLeaf(const Node2D& leaf, const NodeList& leaves,
+                                           Counters* __restrict__ counters) {
+  const int sub = blockIdx.x & (kSubLists - 1);
+  if (!ListStore(leaves, sub, ListReserve(leaves, sub, 1), leaf)) counters->leaf_overflow = 1;
 }
 
 // One greedy descent per seed: always continue with the best child.  The leaf
 // reached is a real candidate, so its score is a valid bound.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 DiveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restrict__ states, int n,
            const Node2D* __restrict__ seeds, const int* __restrict__ seed_count,
-           Node2D* __restrict__ leaves, Counters* __restrict__ counters, int leaf_capacity) {
+           NodeList leaves, Counters* __restrict__ counters) {
   const int problem = blockIdx.y;
   if (blockIdx.x >= seed_count[problem]) return;
   const Fast2DProblem& P = problems[problem];
   ProblemState& st = states[problem];
+  __shared__ BlockContext ctx;
   __shared__ ChildScratch sh;
   __shared__ Node2D cur;
-  if (threadIdx.x == 0) cur = seeds[problem * kSeedsPerProblem + blockIdx.x];
-  __syncthreads();
-  unsigned long long scored = 0, expanded = 0;
-  for (int child_level = P.depth - 2; child_level >= 0; --child_level) {
+  const Node2D seed = seeds[problem * kSeedsPerProblem + blockIdx.x];
+  if (threadIdx.x == 0) cur = seed;
+  LoadContext(P, n, seed.scan, &ctx);
+  const int depth = NodeLevel(seed) + 1;
+  unsigned long long scored = 0;
+  for (int child_level = depth - 2; child_level >= 0; --child_level) {
     const Node2D nd = cur;
-    ScoreChildren(P, n, nd.scan, nd.dx, nd.dy, child_level, &sh);
+    ScoreChildren(ctx, nd.dx, nd.dy, child_level, &sh);
     scored += sh.nvalid;
-    ++expanded;
     if (threadIdx.x == 0) {
       for (int k = 0; k < 4; ++k)
         if (sh.child_score[k] >= 0.f && sh.rank[k] == 0) cur = MakeChild(nd, k, child_level, sh);
@@ -618,12 +708,13 @@ DiveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restrict_
   }
   if (threadIdx.x == 0) {
     const Node2D leaf = cur;
-    if (leaf.score > P.min_score) {
-      RecordLeaf(leaf, leaves, counters, leaf_capacity);
+    if (leaf.score > ctx.min_score) {
+      RecordLeaf(leaf, leaves, counters);
       atomicMax(&st.best_bits, __float_as_uint(leaf.score));
     }
-    atomicAdd(&st.candidates_scored, scored);
-    atomicAdd(&st.nodes_expanded, expanded);
+    atomicAdd(&st.scored_shard[blockIdx.x & (kStatShards - 1)], scored);
+    atomicAdd(&st.expanded_shard[blockIdx.x & (kStatShards - 1)],
+              static_cast<unsigned long long>(depth - 1));
   }
 }
 
@@ -634,8 +725,7 @@ DiveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restrict_
 __global__ void __launch_bounds__(256)
 FilterCoarseKernel(const Fast2DProblem* __restrict__ problems,
                    const ProblemState* __restrict__ states, int n, int chunk, int num_chunks,
-                   int strict, Node2D* __restrict__ out, int capacity,
-                   Counters* __restrict__ counters, int slot_index) {
+                   int strict, NodeList out, Counters* __restrict__ counters) {
   const int problem = blockIdx.y;
   const Fast2DProblem& P = problems[problem];
   const int s = blockIdx.x;
@@ -647,47 +737,157 @@ FilterCoarseKernel(const Fast2DProblem* __restrict__ problems,
   const int2 dims = P.coarse_dims[s];
   const int count = dims.x * dims.y;
   const int base = P.coarse_off[s];
+  const int sub = (blockIdx.x + blockIdx.y) & (kSubLists - 1);
   for (int c = threadIdx.x; c < count; c += blockDim.x) {
     const float score = P.coarse_score[base + c];
     if (strict ? (score > best) : (score >= best)) {
-      const int slot = atomicAdd(&counters->frontier[slot_index], 1);
-      if (slot < capacity) out[slot] = CoarseNode(P, problem, s, c);
-      else counters->frontier_overflow = 1;
+      if (!ListStore(out, sub, ListReserve(out, sub, 1), CoarseNode(P, problem, s, c)))
+        counters->frontier_overflow = 1;
+    }
+  }
+}
+
+// Level-synchronous expansion near the top of the tree, one WAVE per node
+// (four independent nodes per block, no LDS, no barriers).  The top levels
+// hold thousands of nodes most of which die after one expansion, so what
+// matters there is how many nodes are in flight, not the latency of one.
+// Children that can still matter go to `out`; child_level is always >= 1 here.
+__global__ void __launch_bounds__(256)
+ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restrict__ states,
+                 int n, NodeList in, int strict, NodeList out, Counters* __restrict__ counters) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int max_count = ListMaxCount(in);
+  const int out_sub = (blockIdx.x * 4 + wave) & (kSubLists - 1);
+  for (int i = blockIdx.x * 4 + wave; i < max_count * kSubLists; i += gridDim.x * 4) {
+    const int in_sub = i & (kSubLists - 1), j = i / kSubLists;
+    if (j >= in.counts[in_sub]) continue;   // wave-uniform
+    const Node2D nd = in.nodes[static_cast<size_t>(in_sub) * in.sub_capacity + j];
+    const int problem = NodeProblem(nd);
+    const Fast2DProblem& P = problems[problem];
+    ProblemState& st = states[problem];
+    const float best = __uint_as_float(st.best_bits);
+    if (strict ? !(nd.score > best) : (nd.score < best)) continue;
+    const int child_level = NodeLevel(nd) - 1;
+    const LevelDesc L = P.level[child_level];
+    const int4 bd = P.bounds[nd.scan];
+    const int half = 1 << child_level, off = half - 1;
+    const bool vx = nd.dx + half <= bd.y, vy = nd.dy + half <= bd.w;
+    const uint32_t* __restrict__ pts = P.discrete + static_cast<size_t>(nd.scan) * n;
+    int s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+#pragma unroll 4
+    for (int q = lane; q < n; q += kWave) {
+      const uint32_t p = pts[q];
+      const int x = static_cast<short>(p & 0xffffu) + nd.dx + off;
+      const int y = static_cast<short>(p >> 16) + nd.dy + off;
+      const bool x0 = static_cast<unsigned>(x) < static_cast<unsigned>(L.wx);
+      const bool x1 = vx && static_cast<unsigned>(x + half) < static_cast<unsigned>(L.wx);
+      const bool y0 = static_cast<unsigned>(y) < static_cast<unsigned>(L.wy);
+      const bool y1 = vy && static_cast<unsigned>(y + half) < static_cast<unsigned>(L.wy);
+      const int o00 = y * L.wx + x;
+      const int o01 = o00 + half * L.wx;
+      const unsigned v00 = L.cells[(x0 && y0) ? o00 : 0];
+      const unsigned v01 = L.cells[(x0 && y1) ? o01 : 0];
+      const unsigned v10 = L.cells[(x1 && y0) ? o00 + half : 0];
+      const unsigned v11 = L.cells[(x1 && y1) ? o01 + half : 0];
+      s00 += (x0 && y0) ? v00 : 0u;
+      s01 += (x0 && y1) ? v01 : 0u;
+      s10 += (x1 && y0) ? v10 : 0u;
+      s11 += (x1 && y1) ? v11 : 0u;
+    }
+    const int total[4] = {WaveSum(s00), WaveSum(s01), WaveSum(s10), WaveSum(s11)};
+    ChildScratch cs;   // wave-uniform, in registers
+    int nvalid = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool valid = ((k >> 1) == 0 || vx) && ((k & 1) == 0 || vy);
+      cs.child_score[k] = valid ? ToScore(P, total[k], n) : -1.f;
+      nvalid += valid;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int rank = 0;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        if (o != k && cs.child_score[o] >= 0.f &&
+            (cs.child_score[o] > cs.child_score[k] ||
+             (cs.child_score[o] == cs.child_score[k] && o < k)))
+          ++rank;
+      }
+      cs.rank[k] = rank;
+    }
+    if (lane == 0) {
+      atomicAdd(&st.scored_shard[out_sub & (kStatShards - 1)],
+                static_cast<unsigned long long>(nvalid));
+      atomicAdd(&st.expanded_shard[out_sub & (kStatShards - 1)], 1ull);
+      int keep_mask = 0, m = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float sc = cs.child_score[k];
+        if (sc < 0.f) continue;
+        if (strict ? !(sc > best) : (sc < best)) continue;
+        keep_mask |= 1 << k;
+        ++m;
+      }
+      if (m) {
+        int slot = ListReserve(out, out_sub, m);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (!(keep_mask >> k & 1)) continue;
+          if (!ListStore(out, out_sub, slot, MakeChild(nd, k, child_level, cs)))
+            counters->frontier_overflow = 1;
+          ++slot;
+        }
+      }
     }
   }
 }
 
 // Depth-first search of the subtree below each frontier node by one block,
-// pruned with the problem's shared bound.  Nodes reaching `stop_level` (> 0)
-// are handed to `out` instead of being searched (used once near the top to
-// create enough independent roots); stop_level = 0 searches down to the
-// leaves.  At the leaves only the first-best child can be returned by the
-// reference (:340-343 after the stable sort of :331-332).
-__global__ void __launch_bounds__(256)
+// pruned with the problem's shared bound (reference: :335-378).  Nodes
+// reaching `stop_level` (> 0) are handed to `out` instead of being searched
+// (used once near the top to create enough independent roots); stop_level = 0
+// searches down to the leaves, where only the first-best child can be
+// returned by the reference (:340-343 after the stable sort of :331-332).
+// strict = 0 keeps nodes / leaves EQUAL to the bound, so every leaf tied for
+// the best score is recorded and the reference's visiting order can be
+// reproduced.  The bound is re-read from global memory once per root and every
+// 8 expansions; in between the block uses its own copy, raised by its own
+// leaves (a stale bound only costs extra work).
+__global__ void __launch_bounds__(256, 4)
 SubtreeKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restrict__ states, int n,
-              const Node2D* __restrict__ in, const int* __restrict__ in_count, int in_capacity,
-              int stop_level, int strict, Node2D* __restrict__ out, int* __restrict__ out_count,
-              int out_capacity, Node2D* __restrict__ leaves, Counters* __restrict__ counters,
-              int leaf_capacity) {
-  __shared__ ChildScratch sh;
+              NodeList in, int stop_level, int strict, NodeList out, NodeList leaves,
+              Counters* __restrict__ counters) {
+  __shared__ BlockContext ctx;
+  __shared__ ChildScratch cs;
   __shared__ Node2D stack[kMaxDepth * 3 + 4];
   __shared__ Node2D cur;
   __shared__ int sp, have;
   __shared__ float s_best;
-  const int count = min(*in_count, in_capacity);
-  for (int i = blockIdx.x; i < count; i += gridDim.x) {
-    if (threadIdx.x == 0) { stack[0] = in[i]; sp = 1; }
-    __syncthreads();
-    const int problem = NodeProblem(stack[0]);
+  const int max_count = ListMaxCount(in);
+  const int out_sub = blockIdx.x & (kSubLists - 1);
+  for (int i = blockIdx.x; i < max_count * kSubLists; i += gridDim.x) {
+    const int in_sub = i & (kSubLists - 1), j = i / kSubLists;
+    if (j >= in.counts[in_sub]) continue;   // block-uniform
+    const Node2D root = in.nodes[static_cast<size_t>(in_sub) * in.sub_capacity + j];
+    const int problem = NodeProblem(root);
     const Fast2DProblem& P = problems[problem];
     ProblemState& st = states[problem];
+    if (threadIdx.x == 0) {
+      stack[0] = root;
+      sp = 1;
+      s_best = __uint_as_float(__hip_atomic_load(&st.best_bits, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT));
+    }
+    LoadContext(P, n, root.scan, &ctx);   // ends with __syncthreads()
     unsigned long long scored = 0, expanded = 0;
     for (;;) {
       if (threadIdx.x == 0) {
         have = sp > 0;
         if (have) cur = stack[--sp];
-        s_best = __uint_as_float(__hip_atomic_load(&st.best_bits, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT));
+        if (have && (expanded & 7) == 7)
+          s_best = fmaxf(s_best, __uint_as_float(__hip_atomic_load(
+                                     &st.best_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
       }
       __syncthreads();
       if (!have) break;
@@ -696,36 +896,50 @@ SubtreeKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restri
       const bool skip = strict ? !(nd.score > best) : (nd.score < best);
       if (!skip) {
         const int child_level = NodeLevel(nd) - 1;
-        ScoreChildren(P, n, nd.scan, nd.dx, nd.dy, child_level, &sh);
-        scored += sh.nvalid;
+        ScoreChildren(ctx, nd.dx, nd.dy, child_level, &cs);
+        scored += cs.nvalid;
         ++expanded;
         if (threadIdx.x == 0) {
           if (child_level == 0) {
             for (int k = 0; k < 4; ++k) {
-              if (sh.child_score[k] >= 0.f && sh.rank[k] == 0) {
-                const Node2D leaf = MakeChild(nd, k, 0, sh);
+              if (cs.child_score[k] >= 0.f && cs.rank[k] == 0) {
+                const Node2D leaf = MakeChild(nd, k, 0, cs);
                 const bool keep = strict ? (leaf.score > best) : (leaf.score >= best);
-                if (leaf.score > P.min_score && keep) {
-                  RecordLeaf(leaf, leaves, counters, leaf_capacity);
+                if (leaf.score > ctx.min_score && keep) {
+                  RecordLeaf(leaf, leaves, counters);
                   atomicMax(&st.best_bits, __float_as_uint(leaf.score));
+                  s_best = fmaxf(s_best, leaf.score);
                 }
+              }
+            }
+          } else if (child_level == stop_level) {
+            // Hand the surviving children to the next stage: one slot
+            // reservation per expansion.
+            int keep_mask = 0, m = 0;
+            for (int k = 0; k < 4; ++k) {
+              const float sc = cs.child_score[k];
+              if (sc < 0.f) continue;
+              if (strict ? !(sc > best) : (sc < best)) continue;
+              keep_mask |= 1 << k;
+              ++m;
+            }
+            if (m) {
+              int slot = ListReserve(out, out_sub, m);
+              for (int k = 0; k < 4; ++k) {
+                if (!(keep_mask >> k & 1)) continue;
+                if (!ListStore(out, out_sub, slot, MakeChild(nd, k, child_level, cs)))
+                  counters->frontier_overflow = 1;
+                ++slot;
               }
             }
           } else {
             // Push worst first so the best child is searched next.
             for (int r = 3; r >= 0; --r) {
               for (int k = 0; k < 4; ++k) {
-                if (sh.child_score[k] < 0.f || sh.rank[k] != r) continue;
-                const float sc = sh.child_score[k];
+                if (cs.child_score[k] < 0.f || cs.rank[k] != r) continue;
+                const float sc = cs.child_score[k];
                 if (strict ? !(sc > best) : (sc < best)) continue;
-                const Node2D child = MakeChild(nd, k, child_level, sh);
-                if (child_level == stop_level) {
-                  const int slot = atomicAdd(out_count, 1);
-                  if (slot < out_capacity) out[slot] = child;
-                  else counters->frontier_overflow = 1;
-                } else {
-                  stack[sp++] = child;
-                }
+                stack[sp++] = MakeChild(nd, k, child_level, cs);
               }
             }
           }
@@ -733,9 +947,9 @@ SubtreeKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restri
       }
       __syncthreads();
     }
-    if (threadIdx.x == 0) {
-      atomicAdd(&st.candidates_scored, scored);
-      atomicAdd(&st.nodes_expanded, expanded);
+    if (threadIdx.x == 0 && expanded) {
+      atomicAdd(&st.scored_shard[blockIdx.x & (kStatShards - 1)], scored);
+      atomicAdd(&st.expanded_shard[blockIdx.x & (kStatShards - 1)], expanded);
     }
     __syncthreads();
   }
@@ -752,10 +966,16 @@ struct SelectState {         // per problem, device
 };
 
 __global__ void __launch_bounds__(1024)
-SelectBestKernel(const Node2D* __restrict__ leaves, const Counters* __restrict__ counters,
-                 int capacity, const ProblemState* __restrict__ states,
+SelectBestKernel(NodeList leaves, const ProblemState* __restrict__ states,
                  SelectState* __restrict__ sel, BestLeaf* __restrict__ best, int num_problems) {
-  const int total = min(counters->leaves, capacity);
+  const int max_count = ListMaxCount(leaves);
+  const int total = max_count * kSubLists;
+  auto leaf_at = [&](int i, Node2D* nd) {
+    const int sub = i & (kSubLists - 1), j = i / kSubLists;
+    if (j >= min(leaves.counts[sub], leaves.sub_capacity)) return false;
+    *nd = leaves.nodes[static_cast<size_t>(sub) * leaves.sub_capacity + j];
+    return true;
+  };
   for (int p = threadIdx.x; p < num_problems; p += blockDim.x) {
     sel[p].best_coarse_bits = 0;
     sel[p].ties = 0;
@@ -766,7 +986,8 @@ SelectBestKernel(const Node2D* __restrict__ leaves, const Counters* __restrict__
   __threadfence();
   __syncthreads();
   for (int i = threadIdx.x; i < total; i += blockDim.x) {
-    const Node2D nd = leaves[i];
+    Node2D nd;
+    if (!leaf_at(i, &nd)) continue;
     const int p = NodeProblem(nd);
     if (__float_as_uint(nd.score) == states[p].best_bits) {
       atomicMax(&sel[p].best_coarse_bits, __float_as_uint(nd.coarse_score));
@@ -776,7 +997,8 @@ SelectBestKernel(const Node2D* __restrict__ leaves, const Counters* __restrict__
   __threadfence();
   __syncthreads();
   for (int i = threadIdx.x; i < total; i += blockDim.x) {
-    const Node2D nd = leaves[i];
+    Node2D nd;
+    if (!leaf_at(i, &nd)) continue;
     const int p = NodeProblem(nd);
     if (__float_as_uint(nd.score) == states[p].best_bits &&
         __float_as_uint(nd.coarse_score) ==
@@ -790,7 +1012,8 @@ SelectBestKernel(const Node2D* __restrict__ leaves, const Counters* __restrict__
   __threadfence();
   __syncthreads();
   for (int i = threadIdx.x; i < total; i += blockDim.x) {
-    const Node2D nd = leaves[i];
+    Node2D nd;
+    if (!leaf_at(i, &nd)) continue;
     const int p = NodeProblem(nd);
     const unsigned long long key =
         (static_cast<unsigned long long>(static_cast<unsigned>(nd.coarse_index)) << 32) | nd.path;
@@ -1151,6 +1374,7 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
 
   const int kFrontierCapacity = 1 << 21;          // nodes per frontier buffer
   const int kLeafCapacity = 1 << 20;
+  const int kFrontierSub = kFrontierCapacity / kSubLists, kLeafSub = kLeafCapacity / kSubLists;
   Node2D* d_front[2] = {ws.dev[10].ReserveAs<Node2D>(kFrontierCapacity),
                         ws.dev[11].ReserveAs<Node2D>(kFrontierCapacity)};
   Node2D* d_leaves = ws.dev[12].ReserveAs<Node2D>(kLeafCapacity);
@@ -1163,51 +1387,79 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
                                                  num * sizeof(SelectState));
   int* d_seed_count = reinterpret_cast<int*>(d_misc + sizeof(Counters) +
                                              num * (sizeof(SelectState) + sizeof(BestLeaf)));
-  Counters* h_counters = ws.pinned[3].ReserveAs<Counters>(1);
+  Counters* h_counters = nullptr;
   CMX_HIP(hipMemsetAsync(d_counters, 0, sizeof(Counters), ws.stream));
+  // Stage k reads list k and appends to list k+1 (buffers ping-pong, counters
+  // do not: they are all zeroed by the one memset above).
+  auto front = [&](int stage) {
+    return NodeList{d_front[stage & 1], d_counters->frontier[stage], kFrontierSub};
+  };
+  const NodeList leaf_list = {d_leaves, d_counters->leaves, kLeafSub};
+
+  // One D2H for counters + selection state + best leaves (contiguous in d_misc).
+  const size_t misc_bytes = sizeof(Counters) + num * (sizeof(SelectState) + sizeof(BestLeaf));
+  char* h_misc = static_cast<char*>(ws.pinned[3].Reserve(misc_bytes));
+  h_counters = reinterpret_cast<Counters*>(h_misc);
+  BestLeaf* h_best = reinterpret_cast<BestLeaf*>(h_misc + sizeof(Counters) +
+                                                 num * sizeof(SelectState));
+  ProblemState* h_states = ws.pinned[2].ReserveAs<ProblemState>(num);
+  auto fetch_results = [&] {
+    CMX_HIP(hipMemcpyAsync(h_misc, d_misc, misc_bytes, hipMemcpyDeviceToHost, ws.stream));
+    CMX_HIP(hipMemcpyAsync(h_states, batch.d_states, num * sizeof(ProblemState),
+                           hipMemcpyDeviceToHost, ws.stream));
+    CMX_HIP(hipStreamSynchronize(ws.stream));
+  };
 
   if (depth == 1) {
     SelectDepthOneKernel<<<num, 1024, 0, ws.stream>>>(batch.d_problems, batch.d_states, n, d_best);
+    CMX_HIP(hipGetLastError());
+    CMX_HIP(hipEventRecord(ws.ev_end, ws.stream));
+    fetch_results();
   } else {
     // ---- dive -------------------------------------------------------------
     SeedSelectKernel<<<num, 1024, 0, ws.stream>>>(batch.d_problems, batch.d_states, n, d_seeds,
                                                   d_seed_count);
     DiveKernel<<<dim3(kSeedsPerProblem, num), 256, 0, ws.stream>>>(
-        batch.d_problems, batch.d_states, n, d_seeds, d_seed_count, d_leaves, d_counters,
-        kLeafCapacity);
+        batch.d_problems, batch.d_states, n, d_seeds, d_seed_count, leaf_list, d_counters);
 
     // ---- search -------------------------------------------------------------
-    // Top of the tree first (two levels) to create many independent roots,
-    // then the subtrees down to the leaves.
-    const int stop_level = std::max(0, depth - 3);
+    // Top of the tree (two levels) per scan, then the subtrees of the
+    // survivors down to the leaves on many blocks.
+    constexpr int kLevelsPerStage = 2;
+    constexpr int kWaveLevels = 2;
     const int search_blocks = 4096;
     int num_chunks = 1;
     int strict = 0;
     for (;;) {
       for (int chunk = 0; chunk < num_chunks; ++chunk) {
-        CMX_HIP(hipMemsetAsync(&d_counters->frontier[0], 0, 2 * sizeof(int), ws.stream));
+        if (chunk > 0 || strict)
+          CMX_HIP(hipMemsetAsync(d_counters->frontier, 0, sizeof(d_counters->frontier),
+                                 ws.stream));
         FilterCoarseKernel<<<dim3(batch.max_scans, num), 256, 0, ws.stream>>>(
-            batch.d_problems, batch.d_states, n, chunk, num_chunks, strict, d_front[0],
-            kFrontierCapacity, d_counters, 0);
-        if (stop_level > 0) {
+            batch.d_problems, batch.d_states, n, chunk, num_chunks, strict, front(0), d_counters);
+        int stage = 0;
+        int top = depth - 1;
+        // Wave-per-node level-synchronous expansion of the (wide, shallow-lived)
+        // top levels.
+        for (int used = 0; used < kWaveLevels && top - 1 >= 1; ++used, --top, ++stage) {
+          ExpandWaveKernel<<<search_blocks, 256, 0, ws.stream>>>(
+              batch.d_problems, batch.d_states, n, front(stage), strict, front(stage + 1),
+              d_counters);
+        }
+        // Block-per-node depth-first stages of kLevelsPerStage levels: the bushy
+        // part of the tree near the optimum spreads over many blocks instead of
+        // being walked serially by one.
+        for (; top > 0; top -= kLevelsPerStage, ++stage) {
+          const int stop = std::max(0, top - kLevelsPerStage);
           SubtreeKernel<<<search_blocks, 256, 0, ws.stream>>>(
-              batch.d_problems, batch.d_states, n, d_front[0], &d_counters->frontier[0],
-              kFrontierCapacity, stop_level, strict, d_front[1], &d_counters->frontier[1],
-              kFrontierCapacity, d_leaves, d_counters, kLeafCapacity);
-          SubtreeKernel<<<search_blocks, 256, 0, ws.stream>>>(
-              batch.d_problems, batch.d_states, n, d_front[1], &d_counters->frontier[1],
-              kFrontierCapacity, 0, strict, nullptr, nullptr, 0, d_leaves, d_counters,
-              kLeafCapacity);
-        } else {
-          SubtreeKernel<<<search_blocks, 256, 0, ws.stream>>>(
-              batch.d_problems, batch.d_states, n, d_front[0], &d_counters->frontier[0],
-              kFrontierCapacity, 0, strict, nullptr, nullptr, 0, d_leaves, d_counters,
-              kLeafCapacity);
+              batch.d_problems, batch.d_states, n, front(stage), stop, strict, front(stage + 1),
+              leaf_list, d_counters);
         }
       }
-      CMX_HIP(hipMemcpyAsync(h_counters, d_counters, sizeof(Counters), hipMemcpyDeviceToHost,
-                             ws.stream));
-      CMX_HIP(hipStreamSynchronize(ws.stream));
+      SelectBestKernel<<<1, 1024, 0, ws.stream>>>(leaf_list, batch.d_states, d_sel, d_best, num);
+      CMX_HIP(hipGetLastError());
+      CMX_HIP(hipEventRecord(ws.ev_end, ws.stream));
+      fetch_results();
       if (!h_counters->frontier_overflow && !h_counters->leaf_overflow) break;
       // Something was dropped.  Bounds found so far are real leaf scores and
       // stay valid; repeat the search in strict mode (prunes ties, records
@@ -1216,36 +1468,20 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
       CMX_REQUIRE(num_chunks < (1 << 12), "branch-and-bound overflow not resolvable");
       if (h_counters->frontier_overflow) num_chunks *= 4;
       strict = 1;
-      std::vector<ProblemState> states(num);
-      CMX_HIP(hipMemcpy(states.data(), batch.d_states, num * sizeof(ProblemState),
-                        hipMemcpyDeviceToHost));
       for (int p = 0; p < num; ++p) {
         const float floor_score = std::max(batch.h_problems[p].min_score, 0.f);
         unsigned floor_bits;
         std::memcpy(&floor_bits, &floor_score, sizeof(float));
-        if (states[p].best_bits > floor_bits) states[p].best_bits -= 1;
+        if (h_states[p].best_bits > floor_bits) h_states[p].best_bits -= 1;
       }
-      CMX_HIP(hipMemcpy(batch.d_states, states.data(), num * sizeof(ProblemState),
-                        hipMemcpyHostToDevice));
+      CMX_HIP(hipMemcpyAsync(batch.d_states, h_states, num * sizeof(ProblemState),
+                             hipMemcpyHostToDevice, ws.stream));
       CMX_HIP(hipMemsetAsync(d_counters, 0, sizeof(Counters), ws.stream));
     }
-    SelectBestKernel<<<1, 1024, 0, ws.stream>>>(d_leaves, d_counters, kLeafCapacity,
-                                                batch.d_states, d_sel, d_best, num);
   }
-  CMX_HIP(hipGetLastError());
-  CMX_HIP(hipEventRecord(ws.ev_end, ws.stream));
 
-  result->best.resize(num);
-  result->states.resize(num);
-  BestLeaf* h_best = ws.pinned[0].ReserveAs<BestLeaf>(num);
-  ProblemState* h_states = ws.pinned[2].ReserveAs<ProblemState>(num);
-  CMX_HIP(hipMemcpyAsync(h_best, d_best, num * sizeof(BestLeaf), hipMemcpyDeviceToHost,
-                         ws.stream));
-  CMX_HIP(hipMemcpyAsync(h_states, batch.d_states, num * sizeof(ProblemState),
-                         hipMemcpyDeviceToHost, ws.stream));
-  CMX_HIP(hipStreamSynchronize(ws.stream));
-  std::copy(h_best, h_best + num, result->best.begin());
-  std::copy(h_states, h_states + num, result->states.begin());
+  result->best.assign(h_best, h_best + num);
+  result->states.assign(h_states, h_states + num);
   float ms = 0.f;
   CMX_HIP(hipEventElapsedTime(&ms, ws.ev_begin, ws.ev_end));
   result->device_ms = ms;
@@ -1317,9 +1553,12 @@ void MatchBatch(const cmx_fast2d* const* handles, int num, const cmx_pose2d* ini
       poses[p].y = batch.initial[p].y + cy;
       poses[p].theta = batch.initial[p].theta + orientation;
     }
-    total.candidates_scored += result.states[p].coarse_total + result.states[p].candidates_scored;
+    total.candidates_scored += result.states[p].coarse_total;
     total.coarse_candidates += result.states[p].coarse_total;
-    total.nodes_expanded += result.states[p].nodes_expanded;
+    for (int k = 0; k < kStatShards; ++k) {
+      total.candidates_scored += result.states[p].scored_shard[k];
+      total.nodes_expanded += result.states[p].expanded_shard[k];
+    }
     total.num_scans += h.num_scans;
   }
   total.device_ms = result.device_ms;

@@ -82,14 +82,15 @@ Rt2DScoreKernel(Rt2DParams P, int n, int num_candidates, float* __restrict__ unw
     const int dx = rem / side - P.nl, dy = rem % side - P.nl;   // x outer, y inner (:99-113)
     const int2* scan = P.discrete + static_cast<size_t>(s) * n;
     float acc = 0.f;
+#pragma unroll 8
     for (int i = 0; i < n; ++i) {
       const int2 p = scan[i];
       const int x = p.x + dx, y = p.y + dy;
-      float prob = 0.1f;  // kMinProbability outside the grid
-      if (static_cast<unsigned>(x) < static_cast<unsigned>(P.nx) &&
-          static_cast<unsigned>(y) < static_cast<unsigned>(P.ny)) {
-        prob = CellProbability(P.cells[static_cast<size_t>(P.nx) * y + x]);
-      }
+      const bool inside = static_cast<unsigned>(x) < static_cast<unsigned>(P.nx) &&
+                          static_cast<unsigned>(y) < static_cast<unsigned>(P.ny);
+      // Unconditional load from a clamped offset so the loop's loads pipeline.
+      const unsigned raw = P.cells[inside ? P.nx * y + x : 0];
+      const float prob = inside ? CellProbability(raw) : 0.1f;  // kMinProbability outside
       acc += prob;
     }
     acc /= static_cast<float>(n);

@@ -61,13 +61,15 @@ struct Node2D {
   float coarse_score;
 };
 
+constexpr int kStatShards = 16;   // work counters are sharded to keep atomics uncontended
+
 struct ProblemState {       // per problem, device
   unsigned best_bits;       // float bits of the best leaf score so far (>= min_score)
   int coarse_total;
   int error;                // 1: cell index outside int16, 2: coarse capacity exceeded
   int pad;
-  unsigned long long candidates_scored;
-  unsigned long long nodes_expanded;
+  unsigned long long scored_shard[kStatShards];    // candidates scored below the top level
+  unsigned long long expanded_shard[kStatShards];  // nodes whose children were scored
 };
 
 struct BestLeaf {           // per problem, device → host
