@@ -131,6 +131,21 @@ struct Workspace {
   ~Workspace();
 };
 
+// Optional per-stage timing (environment CMX_TRACE=1): an event after every
+// stage, durations printed to stderr when the call has synchronised.
+class StageTrace {
+ public:
+  explicit StageTrace(hipStream_t stream);
+  ~StageTrace();
+  void Mark(const char* name);
+  void Report();   // call after the stream has been synchronised
+  bool enabled() const { return enabled_; }
+ private:
+  bool enabled_;
+  hipStream_t stream_;
+  std::vector<std::pair<std::string, hipEvent_t>> marks_;
+};
+
 class WorkspaceLease {
  public:
   explicit WorkspaceLease(int device);

@@ -2,6 +2,7 @@
 // points that are not tied to one matcher.
 #include "cmx_common.h"
 
+#include <cstdlib>
 #include <map>
 #include <memory>
 
@@ -57,6 +58,34 @@ Workspace::~Workspace() {
   if (ev_k0) (void)hipEventDestroy(ev_k0);
   if (ev_k1) (void)hipEventDestroy(ev_k1);
   if (own_stream) (void)hipStreamDestroy(own_stream);
+}
+
+StageTrace::StageTrace(hipStream_t stream) : stream_(stream) {
+  const char* env = getenv("CMX_TRACE");
+  enabled_ = env && env[0] == '1';
+  if (enabled_) Mark("begin");
+}
+StageTrace::~StageTrace() {
+  for (auto& m : marks_) (void)hipEventDestroy(m.second);
+}
+void StageTrace::Mark(const char* name) {
+  if (!enabled_) return;
+  hipEvent_t ev;
+  if (hipEventCreate(&ev) != hipSuccess) return;
+  (void)hipEventRecord(ev, stream_);
+  marks_.emplace_back(name, ev);
+}
+void StageTrace::Report() {
+  if (!enabled_ || marks_.size() < 2) return;
+  float total = 0.f;
+  (void)hipEventElapsedTime(&total, marks_.front().second, marks_.back().second);
+  fprintf(stderr, "[cmx trace] total %.1f us:", total * 1e3f);
+  for (size_t i = 1; i < marks_.size(); ++i) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, marks_[i - 1].second, marks_[i].second);
+    fprintf(stderr, " %s=%.1f", marks_[i].first.c_str(), ms * 1e3f);
+  }
+  fprintf(stderr, "\n");
 }
 
 WorkspaceLease::WorkspaceLease(int device) : ws_(nullptr) {

@@ -1184,6 +1184,7 @@ float MaxRangeXY(const float* xyz, int n) {
 }
 
 struct PreparedBatch {
+  StageTrace* trace = nullptr;
   int num_problems = 0;
   int n = 0;
   int max_scans = 0;
@@ -1336,8 +1337,12 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
                          hipMemcpyHostToDevice, ws.stream));
 
   const dim3 per_scan(out->max_scans, num);
+  auto mark = [&](const char* name) { if (out->trace) out->trace->Mark(name); };
+  mark("upload");
   PrepScansKernel<<<per_scan, 256, 0, ws.stream>>>(out->d_problems, d_xyz, n, out->d_states);
+  mark("prep");
   CoarseLayoutKernel<<<num, 1024, 0, ws.stream>>>(out->d_problems, out->d_states);
+  mark("layout");
   bool any_generic = false;
   int chunk_mask = 0;
   for (const Fast2DProblem& P : out->h_problems) {
@@ -1356,6 +1361,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
   if (any_generic)
     ScoreCoarseGenericKernel<<<per_scan, 256, 0, ws.stream>>>(out->d_problems, n, out->d_states);
   CMX_HIP(hipEventRecord(ws.ev_k1, ws.stream));
+  mark("coarse");
   CMX_HIP(hipGetLastError());
 }
 
@@ -1389,6 +1395,7 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
                                              num * (sizeof(SelectState) + sizeof(BestLeaf)));
   Counters* h_counters = nullptr;
   CMX_HIP(hipMemsetAsync(d_counters, 0, sizeof(Counters), ws.stream));
+  auto mark = [&](const char* name) { if (batch.trace) batch.trace->Mark(name); };
   // Stage k reads list k and appends to list k+1 (buffers ping-pong, counters
   // do not: they are all zeroed by the one memset above).
   auto front = [&](int stage) {
@@ -1421,6 +1428,7 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
                                                   d_seed_count);
     DiveKernel<<<dim3(kSeedsPerProblem, num), 256, 0, ws.stream>>>(
         batch.d_problems, batch.d_states, n, d_seeds, d_seed_count, leaf_list, d_counters);
+    mark("seed+dive");
 
     // ---- search -------------------------------------------------------------
     // Top of the tree (two levels) per scan, then the subtrees of the
@@ -1437,6 +1445,7 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
                                  ws.stream));
         FilterCoarseKernel<<<dim3(batch.max_scans, num), 256, 0, ws.stream>>>(
             batch.d_problems, batch.d_states, n, chunk, num_chunks, strict, front(0), d_counters);
+        mark("filter");
         int stage = 0;
         int top = depth - 1;
         // Wave-per-node level-synchronous expansion of the (wide, shallow-lived)
@@ -1445,6 +1454,7 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
           ExpandWaveKernel<<<search_blocks, 256, 0, ws.stream>>>(
               batch.d_problems, batch.d_states, n, front(stage), strict, front(stage + 1),
               d_counters);
+          mark("wave");
         }
         // Block-per-node depth-first stages of kLevelsPerStage levels: the bushy
         // part of the tree near the optimum spreads over many blocks instead of
@@ -1454,9 +1464,11 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
           SubtreeKernel<<<search_blocks, 256, 0, ws.stream>>>(
               batch.d_problems, batch.d_states, n, front(stage), stop, strict, front(stage + 1),
               leaf_list, d_counters);
+          mark("subtree");
         }
       }
       SelectBestKernel<<<1, 1024, 0, ws.stream>>>(leaf_list, batch.d_states, d_sel, d_best, num);
+      mark("select");
       CMX_HIP(hipGetLastError());
       CMX_HIP(hipEventRecord(ws.ev_end, ws.stream));
       fetch_results();
@@ -1531,10 +1543,21 @@ void MatchBatch(const cmx_fast2d* const* handles, int num, const cmx_pose2d* ini
   }
   CMX_HIP(hipEventRecord(ws->ev_begin, ws->stream));
   PreparedBatch batch;
+  StageTrace trace(ws->stream);
+  batch.trace = &trace;
   PrepareAndScoreCoarse(*ws, matchers.data(), num, initial, full_submap, d_xyz, n, max_range,
                         min_score, &batch);
   BatchResult result;
   RunBranchAndBound(*ws, batch, &result);
+  trace.Report();
+  if (trace.enabled()) {
+    for (int p = 0; p < std::min(num, 4); ++p) {
+      unsigned long long ex = 0;
+      for (int k = 0; k < kStatShards; ++k) ex += result.states[p].expanded_shard[k];
+      fprintf(stderr, "[cmx trace] problem %d: coarse %d expanded %llu found %d ties %d\n", p,
+              result.states[p].coarse_total, ex, result.best[p].found, result.best[p].ties);
+    }
+  }
   CheckProblemErrors(result);
   cmx_match_stats total{};
   for (int p = 0; p < num; ++p) {

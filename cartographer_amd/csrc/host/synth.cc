@@ -259,3 +259,147 @@ void* cmx_synth_submap(uint64_t seed, int nx, int ny, double resolution, int num
 }
 
 }  // extern "C"
+
+// ============================================================== 3D ==========
+#include "hybrid_grid_builder.h"
+
+using cartographer_amd::host::HybridGridBuilder;
+using cartographer_amd::host::VoxelRecord;
+
+namespace {
+struct Box3 { double lo[3], hi[3]; };
+struct World3 {
+  Box3 room;                 // rays start inside and hit its walls from the inside
+  std::vector<Box3> boxes;   // solid obstacles
+  double Raycast(const double o[3], const double d[3]) const {
+    double best = std::numeric_limits<double>::infinity();
+    // room: exit distance
+    double t_exit = std::numeric_limits<double>::infinity();
+    for (int k = 0; k != 3; ++k) {
+      if (d[k] > 1e-12) t_exit = std::min(t_exit, (room.hi[k] - o[k]) / d[k]);
+      else if (d[k] < -1e-12) t_exit = std::min(t_exit, (room.lo[k] - o[k]) / d[k]);
+    }
+    best = t_exit;
+    for (const Box3& b : boxes) {
+      double t0 = 0., t1 = std::numeric_limits<double>::infinity();
+      bool miss = false;
+      for (int k = 0; k != 3 && !miss; ++k) {
+        if (std::abs(d[k]) < 1e-12) {
+          if (o[k] < b.lo[k] || o[k] > b.hi[k]) miss = true;
+        } else {
+          double a = (b.lo[k] - o[k]) / d[k], c = (b.hi[k] - o[k]) / d[k];
+          if (a > c) std::swap(a, c);
+          t0 = std::max(t0, a);
+          t1 = std::min(t1, c);
+          if (t0 > t1) miss = true;
+        }
+      }
+      if (!miss && t0 > 1e-9) best = std::min(best, t0);
+    }
+    return best;
+  }
+  bool Free(const double p[3], double margin) const {
+    for (int k = 0; k != 3; ++k)
+      if (p[k] < room.lo[k] + margin || p[k] > room.hi[k] - margin) return false;
+    for (const Box3& b : boxes) {
+      bool inside = true;
+      for (int k = 0; k != 3; ++k)
+        if (p[k] < b.lo[k] - margin || p[k] > b.hi[k] + margin) inside = false;
+      if (inside) return false;
+    }
+    return true;
+  }
+};
+}  // namespace
+
+extern "C" {
+
+void* cmx_synth3d_world_create(uint64_t seed, double size_x, double size_y, double size_z) {
+  auto* w = new World3;
+  w->room = {{-0.5 * size_x, -0.5 * size_y, 0.}, {0.5 * size_x, 0.5 * size_y, size_z}};
+  Rng rng(seed + 977);
+  const int n = 5 + static_cast<int>(rng.next() % 4);
+  for (int i = 0; i != n; ++i) {
+    Box3 b;
+    const double sx = rng.uniform(0.05, 0.15) * size_x, sy = rng.uniform(0.05, 0.15) * size_y;
+    const double sz = rng.uniform(0.2, 0.8) * size_z;
+    const double cx = rng.uniform(-0.5 * size_x + sx, 0.5 * size_x - sx);
+    const double cy = rng.uniform(-0.5 * size_y + sy, 0.5 * size_y - sy);
+    b.lo[0] = cx - 0.5 * sx; b.hi[0] = cx + 0.5 * sx;
+    b.lo[1] = cy - 0.5 * sy; b.hi[1] = cy + 0.5 * sy;
+    b.lo[2] = 0.; b.hi[2] = sz;
+    w->boxes.push_back(b);
+  }
+  return w;
+}
+void cmx_synth3d_world_destroy(void* world) { delete static_cast<World3*>(world); }
+
+void cmx_synth3d_free_position(void* world, uint64_t seed, double clearance, double* xyz) {
+  const World3& w = *static_cast<World3*>(world);
+  Rng rng(seed ^ 0x3D3D3Dull);
+  for (int tries = 0; tries != 100000; ++tries) {
+    double p[3];
+    for (int k = 0; k != 2; ++k) p[k] = rng.uniform(w.room.lo[k], w.room.hi[k]);
+    p[2] = rng.uniform(0.8, 1.8);
+    if (w.Free(p, clearance)) { xyz[0] = p[0]; xyz[1] = p[1]; xyz[2] = p[2]; return; }
+  }
+  xyz[0] = xyz[1] = 0.; xyz[2] = 1.;
+}
+
+// `rings` elevation rings in [-elev, +elev] x `azimuths` bearings; sensor pose
+// = translation + yaw.  Hits within max_range, as float xyz in the SENSOR frame.
+int cmx_synth3d_scan(void* world, const double* position_xyz, double yaw, int rings,
+                     int azimuths, double elev, double max_range, double sigma, uint64_t seed,
+                     float* xyz_out) {
+  const World3& w = *static_cast<World3*>(world);
+  Rng rng(seed ^ 0x77AAull);
+  int n = 0;
+  for (int r = 0; r != rings; ++r) {
+    const double el = rings > 1 ? -elev + 2. * elev * r / (rings - 1) : 0.;
+    for (int a = 0; a != azimuths; ++a) {
+      const double az = 2. * M_PI * a / azimuths;
+      const double ds[3] = {std::cos(el) * std::cos(az), std::cos(el) * std::sin(az), std::sin(el)};
+      const double dw[3] = {std::cos(yaw) * ds[0] - std::sin(yaw) * ds[1],
+                            std::sin(yaw) * ds[0] + std::cos(yaw) * ds[1], ds[2]};
+      double t = w.Raycast(position_xyz, dw);
+      const double noise = sigma * rng.normal();
+      if (!(t < max_range)) continue;
+      t += noise;
+      xyz_out[3 * n] = static_cast<float>(t * ds[0]);
+      xyz_out[3 * n + 1] = static_cast<float>(t * ds[1]);
+      xyz_out[3 * n + 2] = static_cast<float>(t * ds[2]);
+      ++n;
+    }
+  }
+  return n;
+}
+
+void* cmx_hgrid_create(float resolution) { return new HybridGridBuilder(resolution); }
+void cmx_hgrid_destroy(void* g) { delete static_cast<HybridGridBuilder*>(g); }
+int cmx_hgrid_size(void* g) { return static_cast<HybridGridBuilder*>(g)->grid_size(); }
+void cmx_hgrid_set_probability(void* g, int x, int y, int z, float p) {
+  static_cast<HybridGridBuilder*>(g)->SetProbability(x, y, z, p);
+}
+float cmx_hgrid_get_probability(void* g, int x, int y, int z) {
+  return static_cast<HybridGridBuilder*>(g)->GetProbability(x, y, z);
+}
+void cmx_hgrid_cell_index(void* g, const float* p, int* out) {
+  static_cast<HybridGridBuilder*>(g)->GetCellIndex(p, out);
+}
+void cmx_hgrid_insert(void* g, const float* origin, const float* returns_xyz, int n,
+                      float hit_probability, float miss_probability, int num_free_space_voxels) {
+  using namespace cartographer_amd::host;
+  auto odds = [](float p) { return p / (1.f - p); };
+  static_cast<HybridGridBuilder*>(g)->Insert(
+      origin, returns_xyz, n, ComputeLookupTableToApplyOdds(odds(hit_probability)),
+      ComputeLookupTableToApplyOdds(odds(miss_probability)), num_free_space_voxels);
+}
+int64_t cmx_hgrid_num_voxels(void* g) {
+  return static_cast<int64_t>(static_cast<HybridGridBuilder*>(g)->Voxels().size());
+}
+void cmx_hgrid_voxels(void* g, void* out /* VoxelRecord[] */) {
+  const auto v = static_cast<HybridGridBuilder*>(g)->Voxels();
+  std::memcpy(out, v.data(), v.size() * sizeof(VoxelRecord));
+}
+
+}  // extern "C"

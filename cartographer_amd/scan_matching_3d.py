@@ -1,0 +1,167 @@
+"""Host-side mirror of the reference's 3D scan-matcher classes over the C ABI
+(``cartographer/mapping/internal/3d/scan_matching/real_time_correlative_scan_matcher_3d.h:36-62``
+and ``.../fast_correlative_scan_matcher_3d.h:54-137``).
+
+A HybridGrid is handed over as the flattened voxel list its Iterator yields
+(numpy structured array ``_lib.VOXEL_DTYPE``); poses are ``Rigid3d`` =
+translation + quaternion (w, x, y, z).
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import (Fast3DOptions, MatchStats, NodeData3D, Pose3d, Result3D, RtOptions,
+                   VOXEL_DTYPE, check)
+
+
+@dataclass
+class Rigid3d:
+    translation: tuple = (0.0, 0.0, 0.0)
+    rotation: tuple = (1.0, 0.0, 0.0, 0.0)   # w, x, y, z
+
+    def to_c(self):
+        p = Pose3d()
+        p.t[:] = [float(v) for v in self.translation]
+        p.q[:] = [float(v) for v in self.rotation]
+        return p
+
+    @staticmethod
+    def from_c(p):
+        return Rigid3d(tuple(p.t), tuple(p.q))
+
+    def as_array(self):
+        return np.array(list(self.translation) + list(self.rotation), np.float64)
+
+
+def _voxels(v):
+    v = np.ascontiguousarray(v, dtype=VOXEL_DTYPE)
+    return v, v.shape[0]
+
+
+def _cloud(point_cloud):
+    xyz = np.ascontiguousarray(point_cloud, dtype=np.float32).reshape(-1, 3)
+    return xyz, xyz.shape[0]
+
+
+class RealTimeCorrelativeScanMatcher3D:
+    """Match(initial_pose, cloud, hybrid_grid) -> (score, pose)."""
+
+    def __init__(self, linear_search_window, angular_search_window,
+                 translation_delta_cost_weight, rotation_delta_cost_weight, device=0):
+        self.options = RtOptions(linear_search_window, angular_search_window,
+                                 translation_delta_cost_weight, rotation_delta_cost_weight)
+        self.device = device
+        self.last_stats = None
+
+    def match(self, initial_pose_estimate, point_cloud, grid_resolution, grid_voxels):
+        vox, nv = _voxels(grid_voxels)
+        xyz, n = _cloud(point_cloud)
+        init = initial_pose_estimate.to_c()
+        score = C.c_float()
+        pose = Pose3d()
+        stats = MatchStats()
+        check(_lib.lib().cmx_rt3d_match(C.byref(self.options), grid_resolution, vox.ctypes.data,
+                                        nv, C.byref(init), xyz.ctypes.data, n, self.device,
+                                        C.byref(score), C.byref(pose), C.byref(stats)))
+        self.last_stats = stats.as_dict()
+        return float(score.value), Rigid3d.from_c(pose)
+
+
+@dataclass
+class TrajectoryNodeData:
+    """TrajectoryNode::Data fields the 3D matcher reads (mapping/trajectory_node.h:45-63)."""
+    high_resolution_point_cloud: np.ndarray
+    low_resolution_point_cloud: np.ndarray
+    rotational_scan_matcher_histogram: np.ndarray
+    gravity_alignment: tuple = (1.0, 0.0, 0.0, 0.0)
+    _keep: list = field(default_factory=list, repr=False)
+
+    def to_c(self):
+        hi, nhi = _cloud(self.high_resolution_point_cloud)
+        lo, nlo = _cloud(self.low_resolution_point_cloud)
+        hist = np.ascontiguousarray(self.rotational_scan_matcher_histogram, np.float32)
+        self._keep[:] = [hi, lo, hist]
+        d = NodeData3D()
+        d.gravity_alignment[:] = [float(v) for v in self.gravity_alignment]
+        d.high_resolution_point_cloud = hi.ctypes.data
+        d.num_high_resolution_points = nhi
+        d.low_resolution_point_cloud = lo.ctypes.data
+        d.num_low_resolution_points = nlo
+        d.rotational_scan_matcher_histogram = hist.ctypes.data if hist.size else None
+        d.histogram_size = hist.shape[0]
+        return d
+
+
+class FastCorrelativeScanMatcher3D:
+    """FastCorrelativeScanMatcher3D(hybrid_grid, low_resolution_grid, histogram, options).
+
+    ``match*`` return a dict (score, pose_estimate, rotational_score,
+    low_resolution_score) or None — the reference's ``unique_ptr<Result>``.
+    """
+
+    def __init__(self, resolution, voxels, grid_size, low_resolution, low_resolution_voxels,
+                 rotational_scan_matcher_histogram, branch_and_bound_depth=8,
+                 full_resolution_depth=3, min_rotational_score=0.77,
+                 min_low_resolution_score=0.55, linear_xy_search_window=5.0,
+                 linear_z_search_window=1.0, angular_search_window=float(np.deg2rad(15.0)),
+                 device=0):
+        self.options = Fast3DOptions(branch_and_bound_depth, full_resolution_depth,
+                                     min_rotational_score, min_low_resolution_score,
+                                     linear_xy_search_window, linear_z_search_window,
+                                     angular_search_window)
+        vox, nv = _voxels(voxels)
+        low, nl = _voxels(low_resolution_voxels)
+        hist = np.ascontiguousarray(rotational_scan_matcher_histogram, np.float32)
+        self.depth = branch_and_bound_depth
+        self.last_stats = None
+        self._h = C.c_void_p()
+        check(_lib.lib().cmx_fast3d_create(C.byref(self.options), resolution, grid_size,
+                                           vox.ctypes.data, nv, low_resolution, low.ctypes.data,
+                                           nl, hist.ctypes.data if hist.size else None,
+                                           hist.shape[0], device, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.lib().cmx_fast3d_destroy(self._h)
+            self._h = None
+
+    def _finish(self, found, result, stats):
+        self.last_stats = stats.as_dict()
+        if not found.value:
+            return None
+        return dict(score=float(result.score), pose_estimate=Rigid3d.from_c(result.pose_estimate),
+                    rotational_score=float(result.rotational_score),
+                    low_resolution_score=float(result.low_resolution_score))
+
+    def match(self, global_node_pose, global_submap_pose, constant_data, min_score):
+        node, submap = global_node_pose.to_c(), global_submap_pose.to_c()
+        data = constant_data.to_c()
+        found, result, stats = C.c_int32(), Result3D(), MatchStats()
+        check(_lib.lib().cmx_fast3d_match(self._h, C.byref(node), C.byref(submap), C.byref(data),
+                                          min_score, C.byref(found), C.byref(result),
+                                          C.byref(stats)))
+        return self._finish(found, result, stats)
+
+    def match_full_submap(self, global_node_rotation, global_submap_rotation, constant_data,
+                          min_score):
+        nq = np.ascontiguousarray(global_node_rotation, np.float64)
+        sq = np.ascontiguousarray(global_submap_rotation, np.float64)
+        data = constant_data.to_c()
+        found, result, stats = C.c_int32(), Result3D(), MatchStats()
+        check(_lib.lib().cmx_fast3d_match_full_submap(self._h, nq.ctypes.data, sq.ctypes.data,
+                                                      C.byref(data), min_score, C.byref(found),
+                                                      C.byref(result), C.byref(stats)))
+        return self._finish(found, result, stats)
+
+    def level(self, depth):
+        """Non-zero cells of one precomputation level, int32 [n,4] (x,y,z,value) sorted (z,y,x)."""
+        lo = np.zeros(3, np.int32)
+        dims = np.zeros(3, np.int32)
+        check(_lib.lib().cmx_fast3d_level_info(self._h, depth, lo.ctypes.data, dims.ctypes.data))
+        cells = np.empty((dims[2], dims[1], dims[0]), np.uint8)
+        check(_lib.lib().cmx_fast3d_level_cells(self._h, depth, cells.ctypes.data))
+        z, y, x = np.nonzero(cells)
+        out = np.stack([x + lo[0], y + lo[1], z + lo[2], cells[z, y, x]], 1).astype(np.int32)
+        return out

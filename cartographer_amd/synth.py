@@ -158,3 +158,119 @@ def make_submap(seed, nx=400, ny=400, resolution=0.05, num_poses=30, beams=1000,
     limits = dict(resolution=resolution, max_x=float(mx[0]), max_y=float(mx[1]),
                   num_x_cells=nx, num_y_cells=ny)
     return cells, limits, World(h)
+
+
+# ---------------------------------------------------------------- 3D -------
+VOXEL_DTYPE = np.dtype([("x", np.int32), ("y", np.int32), ("z", np.int32), ("value", np.uint16),
+                        ("pad", np.uint16)])
+
+
+def _lib3d():
+    L = lib()
+    if not getattr(L, "_cmx_3d_declared", False):
+        L.cmx_synth3d_world_create.argtypes = [C.c_uint64, C.c_double, C.c_double, C.c_double]
+        L.cmx_synth3d_world_create.restype = C.c_void_p
+        L.cmx_synth3d_world_destroy.argtypes = [C.c_void_p]
+        L.cmx_synth3d_free_position.argtypes = [C.c_void_p, C.c_uint64, C.c_double, _f64p]
+        L.cmx_synth3d_scan.argtypes = [C.c_void_p, _f64p, C.c_double, C.c_int, C.c_int,
+                                       C.c_double, C.c_double, C.c_double, C.c_uint64, _f32p]
+        L.cmx_hgrid_create.argtypes = [C.c_float]
+        L.cmx_hgrid_create.restype = C.c_void_p
+        L.cmx_hgrid_destroy.argtypes = [C.c_void_p]
+        L.cmx_hgrid_size.argtypes = [C.c_void_p]
+        L.cmx_hgrid_set_probability.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float]
+        L.cmx_hgrid_get_probability.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.cmx_hgrid_get_probability.restype = C.c_float
+        L.cmx_hgrid_cell_index.argtypes = [C.c_void_p, _f32p, _i32p]
+        L.cmx_hgrid_insert.argtypes = [C.c_void_p, _f32p, _f32p, C.c_int, C.c_float, C.c_float,
+                                       C.c_int]
+        L.cmx_hgrid_num_voxels.argtypes = [C.c_void_p]
+        L.cmx_hgrid_num_voxels.restype = C.c_int64
+        L.cmx_hgrid_voxels.argtypes = [C.c_void_p, C.c_void_p]
+        L._cmx_3d_declared = True
+    return L
+
+
+class HybridGrid:
+    """Mirror of mapping/3d/hybrid_grid.h (write side) for building fixtures."""
+
+    def __init__(self, resolution):
+        self.resolution = float(np.float32(resolution))
+        self._h = _lib3d().cmx_hgrid_create(resolution)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib3d().cmx_hgrid_destroy(self._h)
+            self._h = None
+
+    @property
+    def grid_size(self):
+        return int(_lib3d().cmx_hgrid_size(self._h))
+
+    def get_cell_index(self, point):
+        out = np.empty(3, np.int32)
+        _lib3d().cmx_hgrid_cell_index(self._h, np.ascontiguousarray(point, np.float32), out)
+        return out
+
+    def set_probability(self, index, probability):
+        _lib3d().cmx_hgrid_set_probability(self._h, int(index[0]), int(index[1]), int(index[2]),
+                                           probability)
+
+    def get_probability(self, index):
+        return float(_lib3d().cmx_hgrid_get_probability(self._h, int(index[0]), int(index[1]),
+                                                        int(index[2])))
+
+    def insert(self, origin_xyz, returns_xyz, hit_probability=0.7, miss_probability=0.4,
+               num_free_space_voxels=5):
+        ret = np.ascontiguousarray(returns_xyz, np.float32).reshape(-1, 3)
+        _lib3d().cmx_hgrid_insert(self._h, np.ascontiguousarray(origin_xyz, np.float32), ret,
+                                  ret.shape[0], hit_probability, miss_probability,
+                                  num_free_space_voxels)
+
+    def voxels(self):
+        n = _lib3d().cmx_hgrid_num_voxels(self._h)
+        out = np.zeros(n, VOXEL_DTYPE)
+        if n:
+            _lib3d().cmx_hgrid_voxels(self._h, out.ctypes.data)
+        return out
+
+
+class World3D:
+    def __init__(self, seed, size=(15.0, 15.0, 7.5)):
+        self._h = _lib3d().cmx_synth3d_world_create(seed, *size)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib3d().cmx_synth3d_world_destroy(self._h)
+            self._h = None
+
+    def free_position(self, seed, clearance=0.5):
+        p = np.empty(3, np.float64)
+        _lib3d().cmx_synth3d_free_position(self._h, seed, clearance, p)
+        return p
+
+    def scan(self, position, yaw, rings=16, azimuths=256, elev=np.deg2rad(15.0), max_range=30.0,
+             sigma=0.01, seed=0):
+        out = np.empty((rings * azimuths, 3), np.float32)
+        n = _lib3d().cmx_synth3d_scan(self._h, np.ascontiguousarray(position, np.float64), yaw,
+                                      rings, azimuths, elev, max_range, sigma, seed, out)
+        return out[:n].copy()
+
+
+def make_submap_3d(seed, resolution=0.1, size=(15.0, 15.0, 7.5), num_poses=8, rings=16,
+                   azimuths=256, num_free_space_voxels=2):
+    """Returns (HybridGrid, World3D): a box room rendered from `num_poses` scans."""
+    world = World3D(seed, size)
+    grid = HybridGrid(resolution)
+    for p in range(num_poses):
+        pos = world.free_position(seed * 1009 + p, 0.5)
+        yaw = 0.37 * p
+        sensor = world.scan(pos, yaw, rings, azimuths, seed=seed * 31 + p)
+        c, s = np.cos(yaw), np.sin(yaw)
+        in_map = sensor.astype(np.float64)
+        x = pos[0] + c * in_map[:, 0] - s * in_map[:, 1]
+        y = pos[1] + s * in_map[:, 0] + c * in_map[:, 1]
+        z = pos[2] + in_map[:, 2]
+        grid.insert(pos.astype(np.float32), np.stack([x, y, z], 1).astype(np.float32),
+                    0.7, 0.4, num_free_space_voxels)
+    return grid, world

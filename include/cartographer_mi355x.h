@@ -233,6 +233,12 @@ cmx_status cmx_fast3d_match_full_submap(const cmx_fast3d* matcher,
                                         int32_t* found, cmx_result3d* result,
                                         cmx_match_stats* stats);
 
+/* Introspection used by the parity tests: one precomputation level as a dense
+ * brick (x fastest) with the cell index of its first element. */
+cmx_status cmx_fast3d_level_info(const cmx_fast3d* matcher, int32_t depth, int32_t* lo_xyz,
+                                 int32_t* dims_xyz);
+cmx_status cmx_fast3d_level_cells(const cmx_fast3d* matcher, int32_t depth, uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif

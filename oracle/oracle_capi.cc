@@ -221,3 +221,123 @@ void orc_fast2d_match_batch(void** handles, int num, const float* xyz, int n, fl
 }
 
 }  // extern "C"
+
+// ============================================================== 3D ==========
+namespace {
+Pose3d MakePose3(const double* p7) {   // t xyz, q wxyz
+  Pose3d p;
+  p.t[0] = p7[0]; p.t[1] = p7[1]; p.t[2] = p7[2];
+  p.q = {p7[3], p7[4], p7[5], p7[6]};
+  return p;
+}
+void StorePose3(const Pose3d& p, double* out7) {
+  out7[0] = p.t[0]; out7[1] = p.t[1]; out7[2] = p.t[2];
+  out7[3] = p.q.w; out7[4] = p.q.x; out7[5] = p.q.y; out7[6] = p.q.z;
+}
+PointCloud3 MakeCloud3(const float* xyz, int n) {
+  PointCloud3 c(n);
+  for (int i = 0; i != n; ++i) c[i] = V3f{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+  return c;
+}
+struct Fast3D {
+  std::unique_ptr<FastCorrelativeScanMatcher3D> matcher;
+};
+NodeData3D MakeNodeData(const double* gravity_wxyz, const float* hi, int nhi, const float* lo,
+                        int nlo, const float* hist, int nh) {
+  NodeData3D d;
+  d.gravity_alignment = {gravity_wxyz[0], gravity_wxyz[1], gravity_wxyz[2], gravity_wxyz[3]};
+  d.high_resolution_point_cloud = MakeCloud3(hi, nhi);
+  d.low_resolution_point_cloud = MakeCloud3(lo, nlo);
+  d.rotational_scan_matcher_histogram.assign(hist, hist + nh);
+  return d;
+}
+}  // namespace
+
+extern "C" {
+
+int orc_grid3d_size(float resolution, const Voxel* voxels, int64_t n) {
+  return HybridGridView(resolution, voxels, n).grid_size();
+}
+
+float orc_rt3d_match(float resolution, const Voxel* voxels, int64_t n, const double* init7,
+                     const float* xyz, int npts, double lin, double ang, double tw, double rw,
+                     double* pose7, int64_t* num_candidates) {
+  const HybridGridView grid(resolution, voxels, n);
+  Pose3d pose = MakePose3(init7);
+  const float s = RealTimeMatch3D(grid, MakePose3(init7), MakeCloud3(xyz, npts), lin, ang, tw,
+                                  rw, &pose, num_candidates);
+  StorePose3(pose, pose7);
+  return s;
+}
+
+void orc_rotational_match(const float* submap_hist, const float* scan_hist, int size,
+                          float initial_angle, const float* angles, int n, float* out) {
+  const std::vector<float> r =
+      RotationalMatch(std::vector<float>(submap_hist, submap_hist + size),
+                      std::vector<float>(scan_hist, scan_hist + size), initial_angle,
+                      std::vector<float>(angles, angles + n));
+  std::memcpy(out, r.data(), n * sizeof(float));
+}
+
+void* orc_fast3d_create(float resolution, const Voxel* voxels, int64_t n, float low_resolution,
+                        const Voxel* low_voxels, int64_t nlow, const float* hist, int nh,
+                        int depth, int full_resolution_depth, double min_rotational_score,
+                        double min_low_resolution_score, double lin_xy, double lin_z,
+                        double ang) {
+  auto* f = new Fast3D;
+  auto grid = std::make_shared<HybridGridView>(resolution, voxels, n);
+  auto low = std::make_shared<HybridGridView>(low_resolution, low_voxels, nlow);
+  const Fast3DOptions o{depth, full_resolution_depth, min_rotational_score,
+                        min_low_resolution_score, lin_xy, lin_z, ang};
+  f->matcher.reset(new FastCorrelativeScanMatcher3D(grid, low,
+                                                    std::vector<float>(hist, hist + nh), o));
+  return f;
+}
+void orc_fast3d_destroy(void* h) { delete static_cast<Fast3D*>(h); }
+
+int64_t orc_fast3d_level_count(void* h, int depth) {
+  int64_t c = 0;
+  static_cast<Fast3D*>(h)->matcher->level(depth).ForEachNonZero(
+      [&](const Cell3i&, uint8_t) { ++c; });
+  return c;
+}
+void orc_fast3d_level_voxels(void* h, int depth, int* out_xyzv) {
+  int64_t k = 0;
+  static_cast<Fast3D*>(h)->matcher->level(depth).ForEachNonZero([&](const Cell3i& c, uint8_t v) {
+    out_xyzv[4 * k] = c.x; out_xyzv[4 * k + 1] = c.y; out_xyzv[4 * k + 2] = c.z;
+    out_xyzv[4 * k + 3] = v;
+    ++k;
+  });
+}
+
+// result9: score, pose7..., (pose at [1..7]), rotational_score, low_resolution_score
+int orc_fast3d_match(void* h, int full_submap, const double* node7, const double* submap7,
+                     const double* gravity_wxyz, const float* hi, int nhi, const float* lo,
+                     int nlo, const float* hist, int nh, float min_score, double* result10,
+                     int64_t* stats4) {
+  const auto& m = *static_cast<Fast3D*>(h)->matcher;
+  const NodeData3D data = MakeNodeData(gravity_wxyz, hi, nhi, lo, nlo, hist, nh);
+  Result3D r{};
+  Stats3D st;
+  bool ok;
+  if (full_submap) {
+    ok = m.MatchFullSubmap({node7[3], node7[4], node7[5], node7[6]},
+                           {submap7[3], submap7[4], submap7[5], submap7[6]}, data, min_score, &r,
+                           &st);
+  } else {
+    ok = m.Match(MakePose3(node7), MakePose3(submap7), data, min_score, &r, &st);
+  }
+  if (ok) {
+    result10[0] = r.score;
+    StorePose3(r.pose_estimate, result10 + 1);
+    result10[8] = r.rotational_score;
+    result10[9] = r.low_resolution_score;
+  }
+  if (stats4) {
+    stats4[0] = st.candidates_scored; stats4[1] = st.num_scans;
+    stats4[2] = st.coarse_candidates; stats4[3] = st.nodes_expanded;
+  }
+  return ok ? 1 : 0;
+}
+
+}  // extern "C"

@@ -228,3 +228,118 @@ def fast2d_match_batch(matchers, xyz, min_score, num_threads):
     lib().orc_fast2d_match_batch(handles, num, xyz, n, min_score, num_threads, found, scores,
                                  poses, C.byref(total))
     return dict(found=found, scores=scores, poses=poses, candidates_scored=total.value)
+
+
+# ---------------------------------------------------------------- 3D -------
+VOXEL_DTYPE = np.dtype([("x", np.int32), ("y", np.int32), ("z", np.int32), ("value", np.uint16),
+                        ("pad", np.uint16)])
+
+
+def _lib3d():
+    L = lib()
+    if not getattr(L, "_orc_3d_declared", False):
+        L.orc_grid3d_size.argtypes = [C.c_float, C.c_void_p, C.c_int64]
+        L.orc_rt3d_match.argtypes = [C.c_float, C.c_void_p, C.c_int64, _f64p, _f32p, C.c_int,
+                                     C.c_double, C.c_double, C.c_double, C.c_double, _f64p,
+                                     C.POINTER(C.c_int64)]
+        L.orc_rt3d_match.restype = C.c_float
+        L.orc_rotational_match.argtypes = [_f32p, _f32p, C.c_int, C.c_float, _f32p, C.c_int, _f32p]
+        L.orc_fast3d_create.argtypes = [C.c_float, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
+                                        C.c_int64, _f32p, C.c_int, C.c_int, C.c_int, C.c_double,
+                                        C.c_double, C.c_double, C.c_double, C.c_double]
+        L.orc_fast3d_create.restype = C.c_void_p
+        L.orc_fast3d_destroy.argtypes = [C.c_void_p]
+        L.orc_fast3d_level_count.argtypes = [C.c_void_p, C.c_int]
+        L.orc_fast3d_level_count.restype = C.c_int64
+        L.orc_fast3d_level_voxels.argtypes = [C.c_void_p, C.c_int, _i32p]
+        L.orc_fast3d_match.argtypes = [C.c_void_p, C.c_int, _f64p, _f64p, _f64p, _f32p, C.c_int,
+                                       _f32p, C.c_int, _f32p, C.c_int, C.c_float, _f64p, _i64p]
+        L._orc_3d_declared = True
+    return L
+
+
+def _voxels(v):
+    v = np.ascontiguousarray(v, VOXEL_DTYPE)
+    return v, v.shape[0]
+
+
+def grid3d_size(resolution, voxels):
+    v, n = _voxels(voxels)
+    return int(_lib3d().orc_grid3d_size(resolution, v.ctypes.data, n))
+
+
+def rt3d_match(resolution, voxels, init_pose7, xyz, lin, ang, tw, rw):
+    """init_pose7 = (tx,ty,tz, qw,qx,qy,qz)."""
+    v, n = _voxels(voxels)
+    xyz, npts = _cloud(xyz)
+    pose = np.empty(7, np.float64)
+    ncand = C.c_int64()
+    s = _lib3d().orc_rt3d_match(resolution, v.ctypes.data, n,
+                                np.ascontiguousarray(init_pose7, np.float64), xyz, npts, lin, ang,
+                                tw, rw, pose, C.byref(ncand))
+    return dict(score=float(s), pose=pose, num_candidates=ncand.value)
+
+
+def rotational_match(submap_hist, scan_hist, initial_angle, angles):
+    a = np.ascontiguousarray(submap_hist, np.float32)
+    b = np.ascontiguousarray(scan_hist, np.float32)
+    ang = np.ascontiguousarray(angles, np.float32)
+    out = np.empty(ang.shape[0], np.float32)
+    _lib3d().orc_rotational_match(a, b, a.shape[0], initial_angle, ang, ang.shape[0], out)
+    return out
+
+
+class FastCorrelativeScanMatcher3D:
+    """Oracle twin of fast_correlative_scan_matcher_3d.h:75-101."""
+
+    def __init__(self, resolution, voxels, low_resolution, low_voxels, histogram, depth,
+                 full_resolution_depth, min_rotational_score, min_low_resolution_score,
+                 linear_xy_search_window, linear_z_search_window, angular_search_window):
+        v, n = _voxels(voxels)
+        lv, nl = _voxels(low_voxels)
+        h = np.ascontiguousarray(histogram, np.float32)
+        self.depth = depth
+        self._h = _lib3d().orc_fast3d_create(resolution, v.ctypes.data, n, low_resolution,
+                                             lv.ctypes.data, nl, h, h.shape[0], depth,
+                                             full_resolution_depth, min_rotational_score,
+                                             min_low_resolution_score, linear_xy_search_window,
+                                             linear_z_search_window, angular_search_window)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib3d().orc_fast3d_destroy(self._h)
+            self._h = None
+
+    def level(self, depth):
+        """Non-zero cells of one precomputation level as an int32 [n,4] (x,y,z,value) array,
+        sorted (z,y,x)."""
+        n = _lib3d().orc_fast3d_level_count(self._h, depth)
+        out = np.empty((n, 4), np.int32)
+        if n:
+            _lib3d().orc_fast3d_level_voxels(self._h, depth, out)
+        return out
+
+    def _match(self, full, node7, submap7, gravity, hi, lo, hist, min_score):
+        hi, nhi = _cloud(hi)
+        lo, nlo = _cloud(lo)
+        hist = np.ascontiguousarray(hist, np.float32)
+        res = np.zeros(10, np.float64)
+        stats = np.zeros(4, np.int64)
+        ok = _lib3d().orc_fast3d_match(self._h, int(full),
+                                       np.ascontiguousarray(node7, np.float64),
+                                       np.ascontiguousarray(submap7, np.float64),
+                                       np.ascontiguousarray(gravity, np.float64), hi, nhi, lo,
+                                       nlo, hist, hist.shape[0], min_score, res, stats)
+        return dict(found=bool(ok), score=float(np.float32(res[0])), pose=res[1:8].copy(),
+                    rotational_score=float(np.float32(res[8])),
+                    low_resolution_score=float(np.float32(res[9])),
+                    candidates_scored=int(stats[0]), num_scans=int(stats[1]),
+                    coarse_candidates=int(stats[2]), nodes_expanded=int(stats[3]))
+
+    def match(self, node7, submap7, gravity, hi, lo, hist, min_score):
+        return self._match(False, node7, submap7, gravity, hi, lo, hist, min_score)
+
+    def match_full_submap(self, node_q, submap_q, gravity, hi, lo, hist, min_score):
+        node7 = np.concatenate([[0, 0, 0], node_q])
+        submap7 = np.concatenate([[0, 0, 0], submap_q])
+        return self._match(True, node7, submap7, gravity, hi, lo, hist, min_score)

@@ -1,0 +1,230 @@
+"""GPU parity tests of the 3D matchers: the HIP path (through the C ABI) against
+the CPU oracle on identical point clouds + hybrid grids.
+
+Bars: precomputation levels and integer candidate sums are bit-exact (checked
+through bit-equal f32 scores); returned scores, rotational / low-resolution
+scores are bit-equal f32; poses are bit-equal (f32 values widened to f64).
+"""
+import math
+
+import numpy as np
+import pytest
+
+from test_oracle_reference_pins_3d import (FAST3D_CLOUD, RT_CLOUD, RT_INITIAL_POSES,
+                                           fast3d_fixture, quat_from_angle_axis, rt3d_fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sm3():
+    from cartographer_amd import _lib, scan_matching_3d
+    assert _lib.lib().cmx_device_count() >= 1, "no HIP device: these tests need the GPU"
+    return scan_matching_3d
+
+
+def _pose7(p):
+    return np.array(list(p.translation) + list(p.rotation))
+
+
+# ----------------------------------------------------------------------------
+# Real-time 3D
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("t,q", RT_INITIAL_POSES)
+def test_rt3d_reference_fixture(sm3, oracle, synth, t, q):
+    """RealTimeCorrelativeScanMatcher3DTest (real_time_..._3d_test.cc:36-117)."""
+    g = rt3d_fixture(synth)
+    vox = g.voxels()
+    ref = oracle.rt3d_match(0.1, vox, list(t) + list(q), RT_CLOUD, 0.3, math.radians(1.0), 1e-1,
+                            1.0)
+    m = sm3.RealTimeCorrelativeScanMatcher3D(0.3, math.radians(1.0), 1e-1, 1.0)
+    score, pose = m.match(sm3.Rigid3d(tuple(t), tuple(q)), RT_CLOUD, 0.1, vox)
+    assert m.last_stats["candidates_scored"] == ref["num_candidates"]
+    assert np.float32(score) == np.float32(ref["score"])
+    np.testing.assert_array_equal(_pose7(pose), ref["pose"])
+
+
+@pytest.mark.parametrize("seed,window,ang", [(3, 0.2, 1.0), (5, 0.1, 2.0)])
+def test_rt3d_synthetic_world(sm3, oracle, synth, seed, window, ang):
+    grid, world = synth.make_submap_3d(seed, 0.1, (8.0, 8.0, 4.0), 4, 8, 96)
+    vox = grid.voxels()
+    pos = world.free_position(seed + 1, 0.5)
+    yaw = 0.3
+    cloud = world.scan(pos, yaw, 6, 64, seed=9)
+    q = quat_from_angle_axis(yaw + 0.01, [0, 0, 1])
+    init = list(pos + np.array([0.07, -0.04, 0.02])) + q
+    ref = oracle.rt3d_match(0.1, vox, init, cloud, window, math.radians(ang), 0.1, 0.1)
+    m = sm3.RealTimeCorrelativeScanMatcher3D(window, math.radians(ang), 0.1, 0.1)
+    score, pose = m.match(sm3.Rigid3d(tuple(init[:3]), tuple(init[3:])), cloud, 0.1, vox)
+    assert m.last_stats["candidates_scored"] == ref["num_candidates"]
+    assert np.float32(score) == np.float32(ref["score"])
+    np.testing.assert_array_equal(_pose7(pose), ref["pose"])
+
+
+def test_rt3d_empty_grid_and_invalid(sm3, oracle):
+    from cartographer_amd._lib import CmxError, INVALID_ARGUMENT, VOXEL_DTYPE
+    empty = np.zeros(0, VOXEL_DTYPE)
+    cloud = np.array([[1, 0, 0], [0, 2, 0.5]], np.float32)
+    ref = oracle.rt3d_match(0.1, empty, [0, 0, 0, 1, 0, 0, 0], cloud, 0.1, 0.01, 0.5, 0.5)
+    m = sm3.RealTimeCorrelativeScanMatcher3D(0.1, 0.01, 0.5, 0.5)
+    score, pose = m.match(sm3.Rigid3d(), cloud, 0.1, empty)
+    assert np.float32(score) == np.float32(ref["score"])
+    np.testing.assert_array_equal(_pose7(pose), ref["pose"])
+    with pytest.raises(CmxError) as e:
+        m.match(sm3.Rigid3d(), np.zeros((0, 3), np.float32), 0.1, empty)
+    assert e.value.status == INVALID_ARGUMENT
+
+
+# ----------------------------------------------------------------------------
+# Fast 3D: precomputation stack
+# ----------------------------------------------------------------------------
+def _both(sm3, oracle, res, vox, grid_size, low_res, low_vox, hist, **opt):
+    om = oracle.FastCorrelativeScanMatcher3D(
+        res, vox, low_res, low_vox, hist, opt["branch_and_bound_depth"],
+        opt["full_resolution_depth"], opt["min_rotational_score"],
+        opt["min_low_resolution_score"], opt["linear_xy_search_window"],
+        opt["linear_z_search_window"], opt["angular_search_window"])
+    gm = sm3.FastCorrelativeScanMatcher3D(res, vox, grid_size, low_res, low_vox, hist, **opt)
+    return om, gm
+
+
+REF_OPTIONS = dict(branch_and_bound_depth=6, full_resolution_depth=6, min_rotational_score=0.1,
+                   min_low_resolution_score=0.15, linear_xy_search_window=0.8,
+                   linear_z_search_window=0.8, angular_search_window=0.3)
+
+
+@pytest.mark.parametrize("depth,frd", [(6, 6), (8, 3), (5, 1), (1, 1)])
+def test_fast3d_stack_matches_oracle(sm3, oracle, synth, depth, frd):
+    grid, _ = synth.make_submap_3d(11, 0.1, (6.0, 5.0, 3.0), 3, 8, 64)
+    vox = grid.voxels()
+    opt = dict(REF_OPTIONS, branch_and_bound_depth=depth, full_resolution_depth=frd)
+    om, gm = _both(sm3, oracle, 0.1, vox, grid.grid_size, 0.1, vox, np.zeros(8, np.float32), **opt)
+    for d in range(depth):
+        np.testing.assert_array_equal(gm.level(d), om.level(d), err_msg=f"depth {d}")
+
+
+# ----------------------------------------------------------------------------
+# Fast 3D: Match / MatchFullSubmap
+# ----------------------------------------------------------------------------
+def _assert_result(ref, got):
+    assert (got is not None) == ref["found"]
+    if got is None:
+        return
+    assert np.float32(got["score"]) == np.float32(ref["score"])
+    assert np.float32(got["rotational_score"]) == np.float32(ref["rotational_score"])
+    assert np.float32(got["low_resolution_score"]) == np.float32(ref["low_resolution_score"])
+    np.testing.assert_array_equal(_pose7(got["pose_estimate"]), ref["pose"])
+
+
+def test_fast3d_reference_fixture(sm3, oracle, synth):
+    """FastCorrelativeScanMatcher3DTest.CorrectPoseForMatch (fast_..._3d_test.cc:146-178)."""
+    rng = np.random.default_rng(42)
+    hist = np.zeros(10, np.float32)
+    ident = [0, 0, 0, 1, 0, 0, 0]
+    for _ in range(6):
+        t = 0.7 * rng.uniform(-1, 1, 3)
+        theta = 0.2 * rng.uniform(-1, 1)
+        g = fast3d_fixture(synth, t, theta)
+        vox = g.voxels()
+        om, gm = _both(sm3, oracle, 0.05, vox, g.grid_size, 0.05, vox, hist, **REF_OPTIONS)
+        ref = om.match(ident, ident, [1, 0, 0, 0], FAST3D_CLOUD, FAST3D_CLOUD, hist, 0.1)
+        data = sm3.TrajectoryNodeData(FAST3D_CLOUD, FAST3D_CLOUD, hist)
+        got = gm.match(sm3.Rigid3d(), sm3.Rigid3d(), data, 0.1)
+        assert ref["found"]
+        _assert_result(ref, got)
+        assert gm.last_stats["coarse_candidates"] == ref["coarse_candidates"]
+        far = np.array([[42, 42, 42]], np.float32)
+        ref2 = om.match(ident, ident, [1, 0, 0, 0], FAST3D_CLOUD, far, hist, 0.1)
+        got2 = gm.match(sm3.Rigid3d(), sm3.Rigid3d(),
+                        sm3.TrajectoryNodeData(FAST3D_CLOUD, far, hist), 0.1)
+        assert not ref2["found"]
+        _assert_result(ref2, got2)
+
+
+def test_fast3d_reference_full_submap(sm3, oracle, synth):
+    """CorrectPoseForMatchFullSubmap (:180-204)."""
+    rng = np.random.default_rng(7)
+    t = 0.7 * rng.uniform(-1, 1, 3)
+    theta = 0.2 * rng.uniform(-1, 1)
+    g = fast3d_fixture(synth, t, theta)
+    vox = g.voxels()
+    hist = np.zeros(10, np.float32)
+    om, gm = _both(sm3, oracle, 0.05, vox, g.grid_size, 0.05, vox, hist, **REF_OPTIONS)
+    ref = om.match_full_submap([1, 0, 0, 0], [1, 0, 0, 0], [1, 0, 0, 0], FAST3D_CLOUD,
+                               FAST3D_CLOUD, hist, 0.1)
+    got = gm.match_full_submap([1, 0, 0, 0], [1, 0, 0, 0],
+                               sm3.TrajectoryNodeData(FAST3D_CLOUD, FAST3D_CLOUD, hist), 0.1)
+    assert ref["found"]
+    _assert_result(ref, got)
+
+
+@pytest.mark.parametrize("seed,depth,frd", [(21, 6, 3), (22, 5, 2)])
+def test_fast3d_synthetic_world(sm3, oracle, synth, seed, depth, frd):
+    """Hi-res 0.1 m / low-res 0.45 m grids, half-resolution levels, a histogram
+    pre-filter that removes most yaws, non-identity node / submap poses."""
+    grid, world = synth.make_submap_3d(seed, 0.1, (9.0, 8.0, 4.0), 5, 10, 128)
+    low, _ = synth.make_submap_3d(seed, 0.45, (9.0, 8.0, 4.0), 5, 10, 128)
+    vox, low_vox = grid.voxels(), low.voxels()
+    rng = np.random.default_rng(seed)
+    hist = rng.uniform(0.0, 1.0, 120).astype(np.float32)
+    hist[10:14] += 6.0      # a dominant direction so the yaw filter is selective
+    pos = world.free_position(seed + 3, 0.6)
+    yaw = 0.4
+    hi = world.scan(pos, yaw, 8, 96, seed=1)
+    lo = hi[::7].copy()
+    opt = dict(branch_and_bound_depth=depth, full_resolution_depth=frd, min_rotational_score=0.9,
+               min_low_resolution_score=0.3, linear_xy_search_window=1.5,
+               linear_z_search_window=0.5, angular_search_window=math.radians(20.0))
+    om, gm = _both(sm3, oracle, 0.1, vox, grid.grid_size, 0.45, low_vox, hist, **opt)
+    submap_pose = [0.3, -0.2, 0.1] + quat_from_angle_axis(0.2, [0, 0, 1])
+    # global node pose = submap pose * (true pose in the submap frame, perturbed)
+    c, s = math.cos(0.2), math.sin(0.2)
+    local = np.array([pos[0] + 0.35, pos[1] - 0.25, pos[2] + 0.1])
+    node_t = [submap_pose[0] + c * local[0] - s * local[1],
+              submap_pose[1] + s * local[0] + c * local[1], submap_pose[2] + local[2]]
+    node_pose = node_t + quat_from_angle_axis(0.2 + yaw + 0.1, [0, 0, 1])
+    gravity = quat_from_angle_axis(0.01, [1, 0, 0])
+    for min_score in (0.3, 0.95):
+        ref = om.match(node_pose, submap_pose, gravity, hi, lo, hist, min_score)
+        data = sm3.TrajectoryNodeData(hi, lo, hist, tuple(gravity))
+        got = gm.match(sm3.Rigid3d(tuple(node_pose[:3]), tuple(node_pose[3:])),
+                       sm3.Rigid3d(tuple(submap_pose[:3]), tuple(submap_pose[3:])), data,
+                       min_score)
+        _assert_result(ref, got)
+        assert gm.last_stats["num_scans"] == ref["num_scans"]
+        assert gm.last_stats["coarse_candidates"] == ref["coarse_candidates"]
+    assert ref["num_scans"] > 0
+
+
+def test_fast3d_full_submap_synthetic(sm3, oracle, synth):
+    grid, world = synth.make_submap_3d(31, 0.2, (8.0, 8.0, 3.0), 4, 8, 96)
+    vox = grid.voxels()
+    hist = np.zeros(16, np.float32)     # zero histograms: every yaw passes (score 1)
+    pos = world.free_position(5, 0.6)
+    hi = world.scan(pos, 0.0, 6, 64, seed=2)
+    lo = hi[::5].copy()
+    opt = dict(branch_and_bound_depth=5, full_resolution_depth=2, min_rotational_score=0.5,
+               min_low_resolution_score=0.25, linear_xy_search_window=1.0,
+               linear_z_search_window=1.0, angular_search_window=0.1)
+    om, gm = _both(sm3, oracle, 0.2, vox, grid.grid_size, 0.2, vox, hist, **opt)
+    ref = om.match_full_submap([1, 0, 0, 0], [1, 0, 0, 0], [1, 0, 0, 0], hi, lo, hist, 0.4)
+    got = gm.match_full_submap([1, 0, 0, 0], [1, 0, 0, 0], sm3.TrajectoryNodeData(hi, lo, hist),
+                               0.4)
+    _assert_result(ref, got)
+    assert ref["found"]
+
+
+def test_fast3d_invalid_arguments(sm3, synth):
+    from cartographer_amd._lib import CmxError, INVALID_ARGUMENT
+    g = fast3d_fixture(synth, [0, 0, 0], 0.0)
+    vox = g.voxels()
+    with pytest.raises(CmxError) as e:
+        sm3.FastCorrelativeScanMatcher3D(0.05, vox, g.grid_size, 0.05, vox, np.zeros(4, np.float32),
+                                         branch_and_bound_depth=0)
+    assert e.value.status == INVALID_ARGUMENT
+    gm = sm3.FastCorrelativeScanMatcher3D(0.05, vox, g.grid_size, 0.05, vox,
+                                          np.zeros(4, np.float32), **REF_OPTIONS)
+    with pytest.raises(CmxError) as e:   # histogram size mismatch
+        gm.match(sm3.Rigid3d(), sm3.Rigid3d(),
+                 sm3.TrajectoryNodeData(FAST3D_CLOUD, FAST3D_CLOUD, np.zeros(7, np.float32)), 0.1)
+    assert e.value.status == INVALID_ARGUMENT
