@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "lib", "libcartographer_mi355x.so")
+SO_PATH = os.environ.get("CMX_SO_PATH") or os.path.join(_HERE, "lib", "libcartographer_mi355x.so")
 
 OK, INVALID_ARGUMENT, DEVICE_ERROR, OUT_OF_MEMORY, UNSUPPORTED = range(5)
 

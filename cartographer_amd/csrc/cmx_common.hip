@@ -2,12 +2,36 @@
 // points that are not tied to one matcher.
 #include "cmx_common.h"
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
 #include <cstdlib>
 #include <map>
 #include <memory>
 
 namespace cmx {
 namespace {
+// Debugging aid (CMX_SYNC=1): print a native backtrace on SIGSEGV / SIGABRT.
+void CrashHandler(int sig) {
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  const char msg[] = "[cmx] fatal signal, native backtrace:\n";
+  (void)!write(2, msg, sizeof(msg) - 1);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+struct CrashHandlerInstaller {
+  CrashHandlerInstaller() {
+    const char* env = getenv("CMX_SYNC");
+    if (env && env[0] == '1') {
+      signal(SIGSEGV, CrashHandler);
+      signal(SIGABRT, CrashHandler);
+    }
+  }
+} g_crash_handler_installer;
+
 thread_local std::string g_last_error;
 thread_local std::map<int, hipStream_t> g_stream_override;
 
@@ -69,6 +93,16 @@ StageTrace::~StageTrace() {
   for (auto& m : marks_) (void)hipEventDestroy(m.second);
 }
 void StageTrace::Mark(const char* name) {
+  {
+    static const bool sync_debug = [] {
+      const char* env = getenv("CMX_SYNC");
+      return env && env[0] == '1';
+    }();
+    if (sync_debug) {   // debugging aid: localise a faulting kernel
+      fprintf(stderr, "[cmx sync] %s ...\n", name);
+      (void)hipStreamSynchronize(stream_);
+    }
+  }
   if (!enabled_) return;
   hipEvent_t ev;
   if (hipEventCreate(&ev) != hipSuccess) return;

@@ -31,6 +31,7 @@
 // nothing.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "scan_matching_2d.h"
 
@@ -295,11 +296,13 @@ __device__ __forceinline__ int ScoreCandidateWave(const LevelDesc& L, int level,
 // Block-wide (sum, local index) maximum, smallest index on ties; result valid
 // in thread 0.
 __device__ __forceinline__ int2 BlockBest(int sum, int index, int2* scratch /*[4]*/) {
-  unsigned long long key = (static_cast<unsigned long long>(static_cast<unsigned>(sum)) << 32) |
-                           static_cast<unsigned>(0x7fffffff - index);
+  // sum >= -1 (idle threads pass -1); bias by one so the key is unsigned.
+  unsigned long long key =
+      (static_cast<unsigned long long>(static_cast<unsigned>(sum + 1)) << 32) |
+      static_cast<unsigned>(0x7fffffff - index);
   key = WaveMaxU64(key);
   if ((threadIdx.x & 63) == 0)
-    scratch[threadIdx.x >> 6] = make_int2(static_cast<int>(key >> 32),
+    scratch[threadIdx.x >> 6] = make_int2(static_cast<int>(key >> 32) - 1,
                                           0x7fffffff - static_cast<int>(key & 0xffffffffu));
   __syncthreads();
   int2 best = scratch[0];
@@ -326,7 +329,7 @@ ScoreCoarseGenericKernel(const Fast2DProblem* __restrict__ problems, int n,
   const uint32_t* scan = P.discrete + static_cast<size_t>(s) * n;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int count = dims.x * dims.y;
-  int best_sum = 0, best_index = 0x7ffffff;  // idle threads lose every tie
+  int best_sum = -1, best_index = 0x7ffffff;  // idle threads (sum -1) never win
   for (int c = wave; c < count; c += 4) {
     const int ix = c / dims.y, iy = c - ix * dims.y;   // x outer, y inner (:295-307)
     const int sum = ScoreCandidateWave(P.level[level], level, scan, n, bd.x + ix * step,
@@ -426,7 +429,7 @@ ScoreCoarsePlanesKernel(const Fast2DProblem* __restrict__ problems, int n,
   __syncthreads();
 
   const int base = P.coarse_off[s];
-  int best_sum = 0, best_index = 0x7ffffff;  // idle threads lose every tie
+  int best_sum = -1, best_index = 0x7ffffff;  // idle threads (sum -1) never win
   for (int i = threadIdx.x; i < count; i += blockDim.x) {
     const int sum = cand_acc[i];
     P.coarse_sum[base + i] = sum;
@@ -1371,6 +1374,11 @@ struct BatchResult {
   double device_ms = 0., dominant_ms = 0.;
 };
 
+struct ScoreIndex;
+void ResolveTies(Workspace& ws, const PreparedBatch& batch, const NodeList& leaves_dev,
+                 const Counters& h_counters, std::vector<BestLeaf>* best,
+                 const std::vector<ProblemState>& states);
+
 // Full search of a prepared batch.
 void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* result) {
   const int num = batch.num_problems, n = batch.n;
@@ -1494,11 +1502,76 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
 
   result->best.assign(h_best, h_best + num);
   result->states.assign(h_states, h_states + num);
+  if (depth > 1 && !getenv("CMX_NO_TIES"))
+    ResolveTies(ws, batch, leaf_list, *h_counters, &result->best, result->states);
   float ms = 0.f;
   CMX_HIP(hipEventElapsedTime(&ms, ws.ev_begin, ws.ev_end));
   result->device_ms = ms;
   CMX_HIP(hipEventElapsedTime(&ms, ws.ev_k0, ws.ev_k1));
   result->dominant_ms = ms;
+}
+
+
+// Exact tie resolution.  When several leaves share the best score the
+// reference returns the one its depth-first search meets first, and at the top
+// level that order is whatever std::sort (libstdc++ introsort, unstable) makes
+// of equal-score candidates (SM2/fast_...2d.cc:331-332).  The host repeats that
+// very sort on the lowest-resolution scores (same initial order, same
+// comparator) and ranks the tied leaves by (sorted position of their
+// lowest-resolution ancestor, sibling ranks down the tree).  Only runs when the
+// device reported a tie.
+struct ScoreIndex {
+  float score;
+  int index;
+  bool operator>(const ScoreIndex& other) const { return score > other.score; }
+};
+
+void ResolveTies(Workspace& ws, const PreparedBatch& batch, const NodeList& leaves_dev,
+                 const Counters& h_counters, std::vector<BestLeaf>* best,
+                 const std::vector<ProblemState>& states) {
+  bool any = false;
+  for (const BestLeaf& b : *best) any |= (b.found && b.ties > 1);
+  if (!any) return;
+  // All recorded leaves.
+  std::vector<Node2D> leaves;
+  for (int sub = 0; sub < kSubLists; ++sub) {
+    const int count = std::min(h_counters.leaves[sub], leaves_dev.sub_capacity);
+    if (count <= 0) continue;
+    const size_t old = leaves.size();
+    leaves.resize(old + count);
+    CMX_HIP(hipMemcpy(leaves.data() + old,
+                      leaves_dev.nodes + static_cast<size_t>(sub) * leaves_dev.sub_capacity,
+                      count * sizeof(Node2D), hipMemcpyDeviceToHost));
+  }
+  for (int p = 0; p < batch.num_problems; ++p) {
+    BestLeaf& b = (*best)[p];
+    if (!b.found || b.ties <= 1) continue;
+    const int total = states[p].coarse_total;
+    std::vector<float> scores(total);
+    CMX_HIP(hipMemcpy(scores.data(), batch.h_problems[p].coarse_score, total * sizeof(float),
+                      hipMemcpyDeviceToHost));
+    std::vector<ScoreIndex> sorted(total);
+    for (int c = 0; c < total; ++c) sorted[c] = {scores[c], c};
+    std::sort(sorted.begin(), sorted.end(), std::greater<ScoreIndex>());
+    std::vector<int> position(total);
+    for (int i = 0; i < total; ++i) position[sorted[i].index] = i;
+    unsigned best_bits;
+    std::memcpy(&best_bits, &b.score, sizeof(float));
+    bool have = false;
+    unsigned long long best_key = 0;
+    for (const Node2D& nd : leaves) {
+      unsigned bits;
+      std::memcpy(&bits, &nd.score, sizeof(float));
+      if ((nd.problem & 0xffffff) != p || bits != best_bits) continue;
+      const unsigned long long key =
+          (static_cast<unsigned long long>(position[nd.coarse_index]) << 32) | nd.path;
+      if (!have || key < best_key) {
+        have = true;
+        best_key = key;
+        b.scan = nd.scan; b.dx = nd.dx; b.dy = nd.dy;
+      }
+    }
+  }
 }
 
 void CheckProblemErrors(const BatchResult& r) {

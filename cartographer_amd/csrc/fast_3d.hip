@@ -17,6 +17,7 @@
 // point), including the low-resolution verification of leaves.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "scan_matching_3d.h"
 
@@ -232,6 +233,8 @@ SeedSelect3DKernel(Fast3DProblem P, List3 seeds, Counters3* __restrict__ counter
       if (slot < kSeeds3) Push3(seeds, 0, slot, CoarseNode3D(P, c));
     }
   }
+  __syncthreads();
+  if (threadIdx.x == 0) seeds.counts[0] = min(seeds.counts[0], kSeeds3);   // only kSeeds3 stored
 }
 
 // Lowest-resolution nodes that can still matter (reference: :405-408).
@@ -254,20 +257,17 @@ Filter3DKernel(Fast3DProblem P, int strict, List3 out, Counters3* __restrict__ c
 // sequentially in point order as the reference does.
 __device__ __forceinline__ float LowResolutionScore(const Fast3DProblem& P, const Quat& q, float tx,
                                                     float ty, float tz, int lane) {
+  (void)lane;
+  // Every lane evaluates the same (wave-uniform) sequential f32 sum; leaves that
+  // reach this point are few, the low-resolution cloud is small.
   float acc = 0.f;
-  for (int base = 0; base < P.n_low; base += kWave) {
-    const int i = base + lane;
-    float prob = 0.f;
-    if (i < P.n_low) {
-      const F3 p{P.low_xyz[3 * i], P.low_xyz[3 * i + 1], P.low_xyz[3 * i + 2]};
-      const F3 r = Rotate(q, p);
-      const F3 t{r.x + tx, r.y + ty, r.z + tz};
-      const int3 c = CellIndex3(t, P.low_resolution);
-      prob = ValueToProbabilityDev(BrickValueU16(P.low, c.x, c.y, c.z));
-    }
-    const int cnt = min(kWave, P.n_low - base);
-    for (int l = 0; l < cnt; ++l)
-      acc += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(prob), l));
+#pragma unroll 4
+  for (int i = 0; i < P.n_low; ++i) {
+    const F3 p{P.low_xyz[3 * i], P.low_xyz[3 * i + 1], P.low_xyz[3 * i + 2]};
+    const F3 r = Rotate(q, p);
+    const F3 t{r.x + tx, r.y + ty, r.z + tz};
+    const int3 c = CellIndex3(t, P.low_resolution);
+    acc += ValueToProbabilityDev(BrickValueU16(P.low, c.x, c.y, c.z));
   }
   return acc / static_cast<float>(P.n_low);
 }
@@ -637,7 +637,8 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
     scan_q[s] = iq;
     h_q[S + s] = make_float4(iq.x, iq.y, iq.z, iq.w);
   }
-  Counters3* h_counters = ws->pinned[1].ReserveAs<Counters3>(1);
+  Counters3* h_counters = static_cast<Counters3*>(
+      ws->pinned[1].Reserve(sizeof(Counters3) + sizeof(Best3)));
   std::memset(h_counters, 0, sizeof(Counters3));
   {
     const float floor_score = std::max(min_score, 0.f);
@@ -674,12 +675,22 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
   };
   const List3 leaf_list{d_leaves, d_counters->leaves, kLeafCapacity / kSubLists3};
 
+  const char* dbg_env = getenv("CMX_SYNC");
+  const bool dbg_sync = dbg_env && dbg_env[0] == '1';
+  auto dbg = [&](const char* name) {
+    if (!dbg_sync) return;
+    fprintf(stderr, "[cmx sync] %s ...\n", name);
+    CMX_HIP(hipStreamSynchronize(ws->stream));
+  };
+  dbg("uploads");
   CMX_HIP(hipEventRecord(ws->ev_begin, ws->stream));
   Discretize3DKernel<<<dim3(DivUp(n, 256), S), 256, 0, ws->stream>>>(
       d_hi, n, d_pose_q, pose_t.x, pose_t.y, pose_t.z, m.resolution, d_cells);
+  dbg("discretize");
   CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
   ScoreCoarse3DKernel<<<std::min<long long>(8192, DivUp(total, 4)), 256, 0, ws->stream>>>(P);
   CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
+  dbg("coarse");
 
   const int blocks = 2048;
   int strict = 0;
@@ -693,21 +704,25 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
         List3 dive[2] = {{d_seeds, d_counters->dive[0], kDiveSub},
                          {d_seeds + kDiveSub * kSubLists3, d_counters->dive[1], kDiveSub}};
         SeedSelect3DKernel<<<1, 1024, 0, ws->stream>>>(P, dive[0], d_counters);
+        dbg("seed");
         int cur = 0;
         for (int child = depth - 2; child >= 0; --child) {
           CMX_HIP(hipMemsetAsync(d_counters->dive[cur ^ 1], 0, sizeof(int) * kSubLists3,
                                  ws->stream));
           Expand3DKernel<<<64, 256, 0, ws->stream>>>(P, dive[cur], 1, 0, dive[cur ^ 1], leaf_list,
                                                      d_counters);
+          dbg("dive level");
           cur ^= 1;
         }
       }
       CMX_HIP(hipMemsetAsync(d_counters->frontier, 0, sizeof(d_counters->frontier), ws->stream));
       Filter3DKernel<<<256, 256, 0, ws->stream>>>(P, strict, front(0), d_counters);
+      dbg("filter");
       int stage = 0;
       for (int child = depth - 2; child >= 0; --child, ++stage) {
         Expand3DKernel<<<blocks, 256, 0, ws->stream>>>(P, front(stage), 0, strict,
                                                        front(stage + 1), leaf_list, d_counters);
+        dbg("expand level");
       }
     }
     SelectBest3DKernel<<<1, 1024, 0, ws->stream>>>(leaf_list, d_counters, d_best);
@@ -746,18 +761,62 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
   CMX_HIP(hipEventElapsedTime(&ms, ws->ev_k0, ws->ev_k1));
   st.dominant_kernel_ms = ms;
   if (stats) *stats = st;
-  if (h_best->found && h_best->score > min_score) {
+  Best3 best = *h_best;
+  if (best.found && best.ties > 1 && depth > 1) {
+    // Exact tie resolution (see fast_2d.hip ResolveTies): repeat the reference's
+    // std::sort of the lowest-resolution candidates (:352-353) and take the
+    // tied leaf its depth-first search meets first.
+    std::vector<float> scores(total);
+    CMX_HIP(hipMemcpy(scores.data(), d_coarse, total * sizeof(float), hipMemcpyDeviceToHost));
+    struct ScoreIndex {
+      float score; int index;
+      bool operator>(const ScoreIndex& o) const { return score > o.score; }
+    };
+    std::vector<ScoreIndex> sorted(total);
+    for (long long c = 0; c < total; ++c) sorted[c] = {scores[c], static_cast<int>(c)};
+    std::sort(sorted.begin(), sorted.end(), std::greater<ScoreIndex>());
+    std::vector<int> position(total);
+    for (long long i = 0; i < total; ++i) position[sorted[i].index] = static_cast<int>(i);
+    unsigned best_bits;
+    std::memcpy(&best_bits, &best.score, sizeof(float));
+    bool have = false;
+    int best_pos = 0;
+    unsigned long long best_path = 0;
+    std::vector<Node3D> sub_nodes;
+    for (int sub = 0; sub < kSubLists3; ++sub) {
+      const int count = std::min(h_counters->leaves[sub], leaf_list.sub_capacity);
+      if (count <= 0) continue;
+      sub_nodes.resize(count);
+      CMX_HIP(hipMemcpy(sub_nodes.data(),
+                        leaf_list.nodes + static_cast<size_t>(sub) * leaf_list.sub_capacity,
+                        count * sizeof(Node3D), hipMemcpyDeviceToHost));
+      for (const Node3D& nd : sub_nodes) {
+        unsigned bits;
+        std::memcpy(&bits, &nd.score, sizeof(float));
+        if (bits != best_bits) continue;
+        const int pos = position[nd.coarse_index];
+        if (!have || pos < best_pos || (pos == best_pos && nd.path < best_path)) {
+          have = true;
+          best_pos = pos;
+          best_path = nd.path;
+          best.scan = nd.scan; best.ox = nd.ox; best.oy = nd.oy; best.oz = nd.oz;
+          best.low_resolution_score = nd.low_resolution_score;
+        }
+      }
+    }
+  }
+  if (best.found && best.score > min_score) {
     *found = 1;
-    result->score = h_best->score;
+    result->score = best.score;
     h3::Rigid pose;
     // Translation(res * offset) * scan.pose
-    pose.t = {(pose_t.x + 0.f) + m.resolution * static_cast<float>(h_best->ox),
-              (pose_t.y + 0.f) + m.resolution * static_cast<float>(h_best->oy),
-              (pose_t.z + 0.f) + m.resolution * static_cast<float>(h_best->oz)};
-    pose.q = scan_q[h_best->scan];
+    pose.t = {(pose_t.x + 0.f) + m.resolution * static_cast<float>(best.ox),
+              (pose_t.y + 0.f) + m.resolution * static_cast<float>(best.oy),
+              (pose_t.z + 0.f) + m.resolution * static_cast<float>(best.oz)};
+    pose.q = scan_q[best.scan];
     result->pose_estimate = h3::ToPose(pose);
-    result->rotational_score = rotational_score[h_best->scan];
-    result->low_resolution_score = h_best->low_resolution_score;
+    result->rotational_score = rotational_score[best.scan];
+    result->low_resolution_score = best.low_resolution_score;
   }
 }
 

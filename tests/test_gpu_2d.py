@@ -3,9 +3,9 @@ the CPU oracle on identical scans + grids.
 
 Bars: integer work (precomputation grids, discretised scans, search bounds,
 candidate sums) is bit-exact; returned f32 scores are bit-equal; poses are
-equal to 1e-12 (they are computed from integer offsets in f64).  Where several
-leaves share the best score the reference itself is std::sort-order dependent;
-those cases are accepted only if both poses provably reach the same score.
+equal to 1e-12 (they are computed from integer offsets in f64), also where
+several leaves share the best score: the device path reproduces the order in
+which the reference's depth-first search (and its std::sort) meets them.
 """
 import math
 import threading
@@ -45,21 +45,10 @@ def _assert_match_parity(oracle_m, gpu_m, res, init, cloud, min_score, full, sm)
     if not found:
         return ref, None
     assert np.float32(score) == np.float32(ref["score"]), (score, ref["score"])
+    # Ties included: the device path reproduces the reference's depth-first /
+    # std::sort order among equal-score leaves, so the pose is always the same.
     got = np.array([pose.x, pose.y, pose.theta])
-    if not np.allclose(got, ref["pose"], rtol=0, atol=1e-12):
-        # Tie: both poses must be leaves with the same integer sum.
-        prep = oracle_m.prepare(init, cloud, full, want_sums=False)
-        level0 = oracle_m.level(0)
-        na = (prep["num_scans"] - 1) // 2
-        base = np.array(init if not full else
-                        [oracle_m_center(oracle_m, res)[0], oracle_m_center(oracle_m, res)[1], 0.0])
-
-        def leaf(p):
-            s = int(round((p[2] - base[2]) / prep["step"])) + na
-            dy = int(round(-(p[0] - base[0]) / res))
-            dx = int(round(-(p[1] - base[1]) / res))
-            return _leaf_sum(level0, prep["scans"], None, s, dx, dy)
-        assert leaf(got) == leaf(ref["pose"]), "poses differ and are not an exact score tie"
+    np.testing.assert_allclose(got, ref["pose"], rtol=0, atol=1e-12)
     return ref, gpu_m.last_stats
 
 

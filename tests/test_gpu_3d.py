@@ -168,6 +168,9 @@ def test_fast3d_synthetic_world(sm3, oracle, synth, seed, depth, frd):
     rng = np.random.default_rng(seed)
     hist = rng.uniform(0.0, 1.0, 120).astype(np.float32)
     hist[10:14] += 6.0      # a dominant direction so the yaw filter is selective
+    # The node's histogram is the submap's turned by the node's yaw in the submap
+    # frame (~0.5 rad = 19 buckets), so only yaws near zero pass the filter.
+    scan_hist = np.roll(hist, -19).copy()
     pos = world.free_position(seed + 3, 0.6)
     yaw = 0.4
     hi = world.scan(pos, yaw, 8, 96, seed=1)
@@ -193,7 +196,7 @@ def test_fast3d_synthetic_world(sm3, oracle, synth, seed, depth, frd):
         _assert_result(ref, got)
         assert gm.last_stats["num_scans"] == ref["num_scans"]
         assert gm.last_stats["coarse_candidates"] == ref["coarse_candidates"]
-    assert ref["num_scans"] > 0
+    assert 0 < ref["num_scans"] < 40      # the filter is selective but not empty
 
 
 def test_fast3d_full_submap_synthetic(sm3, oracle, synth):
