@@ -1375,6 +1375,8 @@ struct BatchResult {
 };
 
 struct ScoreIndex;
+void ResolveDepthOne(const PreparedBatch& batch, std::vector<BestLeaf>* best,
+                     const std::vector<ProblemState>& states);
 void ResolveTies(Workspace& ws, const PreparedBatch& batch, const NodeList& leaves_dev,
                  const Counters& h_counters, std::vector<BestLeaf>* best,
                  const std::vector<ProblemState>& states);
@@ -1502,8 +1504,11 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
 
   result->best.assign(h_best, h_best + num);
   result->states.assign(h_states, h_states + num);
-  if (depth > 1 && !getenv("CMX_NO_TIES"))
+  if (depth > 1) {
     ResolveTies(ws, batch, leaf_list, *h_counters, &result->best, result->states);
+  } else {
+    ResolveDepthOne(batch, &result->best, result->states);
+  }
   float ms = 0.f;
   CMX_HIP(hipEventElapsedTime(&ms, ws.ev_begin, ws.ev_end));
   result->device_ms = ms;
@@ -1571,6 +1576,41 @@ void ResolveTies(Workspace& ws, const PreparedBatch& batch, const NodeList& leav
         b.scan = nd.scan; b.dx = nd.dx; b.dy = nd.dy;
       }
     }
+  }
+}
+
+// depth == 1: BranchAndBound returns candidates[0] of the std::sort-ed
+// lowest-resolution candidates (SM2/fast_...2d.cc:340-343); replay that sort.
+void ResolveDepthOne(const PreparedBatch& batch, std::vector<BestLeaf>* best,
+                     const std::vector<ProblemState>& states) {
+  for (int p = 0; p < batch.num_problems; ++p) {
+    BestLeaf& b = (*best)[p];
+    const Fast2DProblem& P = batch.h_problems[p];
+    const int total = states[p].coarse_total;
+    if (states[p].error || total <= 0) continue;
+    std::vector<float> scores(total);
+    CMX_HIP(hipMemcpy(scores.data(), P.coarse_score, total * sizeof(float),
+                      hipMemcpyDeviceToHost));
+    std::vector<ScoreIndex> sorted(total);
+    for (int c = 0; c < total; ++c) sorted[c] = {scores[c], c};
+    std::sort(sorted.begin(), sorted.end(), std::greater<ScoreIndex>());
+    const int S = P.num_scans;
+    std::vector<int> off(S + 1);
+    std::vector<int2> dims(S);
+    std::vector<int4> bounds(S);
+    CMX_HIP(hipMemcpy(off.data(), P.coarse_off, (S + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    CMX_HIP(hipMemcpy(dims.data(), P.coarse_dims, S * sizeof(int2), hipMemcpyDeviceToHost));
+    CMX_HIP(hipMemcpy(bounds.data(), P.bounds, S * sizeof(int4), hipMemcpyDeviceToHost));
+    const int c = sorted[0].index;
+    const int s = static_cast<int>(std::upper_bound(off.begin(), off.end(), c) - off.begin()) - 1;
+    const int local = c - off[s];
+    b = BestLeaf{};
+    b.score = sorted[0].score;
+    b.found = b.score > P.min_score;
+    b.scan = s;
+    b.dx = bounds[s].x + local / dims[s].y;    // depth 1: step 1, x outer / y inner
+    b.dy = bounds[s].z + local % dims[s].y;
+    b.ties = 1;
   }
 }
 

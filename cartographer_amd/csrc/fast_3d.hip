@@ -762,7 +762,7 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
   st.dominant_kernel_ms = ms;
   if (stats) *stats = st;
   Best3 best = *h_best;
-  if (best.found && best.ties > 1 && depth > 1) {
+  if (best.found && best.ties > 1) {
     // Exact tie resolution (see fast_2d.hip ResolveTies): repeat the reference's
     // std::sort of the lowest-resolution candidates (:352-353) and take the
     // tied leaf its depth-first search meets first.

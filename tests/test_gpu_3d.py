@@ -188,8 +188,8 @@ def test_fast3d_synthetic_world(sm3, oracle, synth, seed, depth, frd):
     node_pose = node_t + quat_from_angle_axis(0.2 + yaw + 0.1, [0, 0, 1])
     gravity = quat_from_angle_axis(0.01, [1, 0, 0])
     for min_score in (0.3, 0.95):
-        ref = om.match(node_pose, submap_pose, gravity, hi, lo, hist, min_score)
-        data = sm3.TrajectoryNodeData(hi, lo, hist, tuple(gravity))
+        ref = om.match(node_pose, submap_pose, gravity, hi, lo, scan_hist, min_score)
+        data = sm3.TrajectoryNodeData(hi, lo, scan_hist, tuple(gravity))
         got = gm.match(sm3.Rigid3d(tuple(node_pose[:3]), tuple(node_pose[3:])),
                        sm3.Rigid3d(tuple(submap_pose[:3]), tuple(submap_pose[3:])), data,
                        min_score)
