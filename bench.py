@@ -82,7 +82,7 @@ def main():
     args = parse_args()
     import torch
     import torch.distributed as dist
-    from cartographer_amd import scan_matching as sm, synth
+    from cartographer_amd import scan_matching as sm, sharding, synth
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -96,8 +96,11 @@ def main():
     torch.cuda.set_device(device)
 
     # ---- synthetic inputs (identical bytes for GPU path and CPU baseline) ----
+    # Every rank holds its own replica set of `--submaps` submaps (seeds 42..42+B-1, the
+    # first one contains the scan's true pose): per-GPU work is identical, which is what
+    # "weak scaling" means here.  Global submap ids are rank * B + i.
     n_sub = args.submaps
-    base_seed = 42 + rank * n_sub
+    base_seed = 42
     matchers, grids = [], []
     world0 = None
     for i in range(n_sub):
@@ -120,9 +123,7 @@ def main():
         found, scores, poses, stats = sm.match_full_submap_batch(matchers, cloud, args.min_score)
         if world_size > 1:
             # packed (score bits << 32 | global submap id): max == best match of the node
-            i = int(np.argmax(np.where(found > 0, scores, -1.0)))
-            bits = int(np.float32(scores[i]).view(np.uint32)) if found[i] else 0
-            best_key.fill_((bits << 32) | (rank * n_sub + i))
+            best_key.fill_(sharding.pack_best_key(found, scores, rank * n_sub))
             dist.all_reduce(best_key, op=dist.ReduceOp.MAX)
         return found, scores, poses, stats
 

@@ -1,0 +1,48 @@
+"""Multi-GPU sharding of the loop-closure search (one scan vs many submaps).
+
+Every (scan, submap) search is independent
+(``cartographer/mapping/internal/constraints/constraint_builder_2d.cc:97-111`` schedules them as
+independent tasks), so submaps are partitioned over the ranks with no data-path collective.  The
+only exchange is the node-wide best match: ONE all-reduce(max) of an 8-byte key
+``score_bits << 32 | global_submap_id`` (positive f32 bit patterns order like the floats).
+``torch.distributed`` backend "nccl" is RCCL over xGMI on MI355X; the same code runs on "gloo".
+"""
+import numpy as np
+
+
+def shard_range(num_items, rank, world_size):
+    """Contiguous block partition: items [begin, end) of rank `rank`."""
+    base, extra = divmod(num_items, world_size)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def pack_best_key(found, scores, first_global_id):
+    """Key of the best local match; 0 when nothing was found."""
+    found = np.asarray(found)
+    scores = np.asarray(scores, np.float32)
+    if found.size == 0 or not found.any():
+        return 0
+    masked = np.where(found > 0, scores, np.float32(-1.0))
+    i = int(np.argmax(masked))            # first maximum: lowest submap id wins ties locally
+    bits = int(scores[i:i + 1].view(np.uint32)[0])
+    return (bits << 32) | (first_global_id + i)
+
+
+def unpack_best_key(key):
+    """Returns (score or None, global submap id or None)."""
+    key = int(key)
+    if key == 0:
+        return None, None
+    score = float(np.array([key >> 32], np.uint32).view(np.float32)[0])
+    return score, key & 0xFFFFFFFF
+
+
+def all_reduce_best(key, device=None):
+    """MAX all-reduce of the packed key across the default process group."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([key], dtype=torch.int64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())

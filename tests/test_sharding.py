@@ -1,0 +1,63 @@
+"""N > 1 path on CPU: submap partitioning + the best-match all-reduce on gloo,
+world_size 2 (the GPU path uses the same code on RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cartographer_amd import sharding
+
+
+def test_shard_range_partitions_everything():
+    for n in (0, 1, 7, 512, 513):
+        for w in (1, 2, 3, 8):
+            ranges = [sharding.shard_range(n, r, w) for r in range(w)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(w - 1))
+            sizes = [e - b for b, e in ranges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_key_roundtrip_and_order():
+    a = sharding.pack_best_key([0, 1, 1], [0.9, 0.61, 0.75], 40)
+    b = sharding.pack_best_key([1, 0, 0], [0.74, 0.99, 0.99], 3)
+    assert sharding.unpack_best_key(a) == (pytest.approx(0.75), 42)
+    assert sharding.unpack_best_key(b) == (pytest.approx(0.74), 3)
+    assert a > b                      # keys order like the scores
+    assert sharding.pack_best_key([0, 0], [0.5, 0.6], 0) == 0
+    assert sharding.unpack_best_key(0) == (None, None)
+    # equal scores: the larger submap id wins the max (deterministic)
+    c = sharding.pack_best_key([1], [0.75], 100)
+    assert max(a, c) == c
+
+
+def _worker(rank, world_size, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    num_submaps = 9
+    begin, end = sharding.shard_range(num_submaps, rank, world_size)
+    rng = np.random.default_rng(5)
+    all_scores = rng.uniform(0.3, 0.9, num_submaps).astype(np.float32)
+    all_found = (all_scores > 0.55).astype(np.int32)
+    key = sharding.pack_best_key(all_found[begin:end], all_scores[begin:end], begin)
+    best = sharding.all_reduce_best(key)
+    expect_id = int(np.argmax(np.where(all_found > 0, all_scores, -1)))
+    score, gid = sharding.unpack_best_key(best)
+    out[rank] = (gid == expect_id) and abs(score - float(all_scores[expect_id])) < 1e-7
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_reduce_best_gloo_world_size_2():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    manager = mp.Manager()
+    out = manager.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    assert out[0] and out[1]
