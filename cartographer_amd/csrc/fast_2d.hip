@@ -1028,10 +1028,24 @@ SelectBestKernel(NodeList leaves, const ProblemState* __restrict__ states,
       BestLeaf b;
       b.score = nd.score; b.scan = nd.scan; b.dx = nd.dx; b.dy = nd.dy;
       b.found = 1;
-      b.ties = __hip_atomic_load(&sel[p].ties, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      b.ties = 1;
       b.pad0 = b.pad1 = 0;
       best[p] = b;   // duplicates (dive + search) carry identical content
     }
+  }
+  __threadfence();
+  __syncthreads();
+  // ties = 1 + number of tied records that are a DIFFERENT leaf (the dive and
+  // the search record the best leaf twice; that is not a tie).
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    Node2D nd;
+    if (!leaf_at(i, &nd)) continue;
+    const int p = NodeProblem(nd);
+    if (__float_as_uint(nd.score) != states[p].best_bits) continue;
+    const int scan = __hip_atomic_load(&best[p].scan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int dx = __hip_atomic_load(&best[p].dx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int dy = __hip_atomic_load(&best[p].dy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (nd.scan != scan || nd.dx != dx || nd.dy != dy) atomicAdd(&best[p].ties, 1);
   }
 }
 
@@ -1551,6 +1565,21 @@ void ResolveTies(Workspace& ws, const PreparedBatch& batch, const NodeList& leav
   for (int p = 0; p < batch.num_problems; ++p) {
     BestLeaf& b = (*best)[p];
     if (!b.found || b.ties <= 1) continue;
+    unsigned best_bits;
+    std::memcpy(&best_bits, &b.score, sizeof(float));
+    // The dive and the search record the same leaf twice; only distinct leaves tie.
+    std::vector<const Node2D*> tied;
+    for (const Node2D& nd : leaves) {
+      unsigned bits;
+      std::memcpy(&bits, &nd.score, sizeof(float));
+      if ((nd.problem & 0xffffff) != p || bits != best_bits) continue;
+      bool duplicate = false;
+      for (const Node2D* t : tied)
+        duplicate |= (t->scan == nd.scan && t->dx == nd.dx && t->dy == nd.dy);
+      if (!duplicate) tied.push_back(&nd);
+      if (tied.size() > 4096) break;   // degenerate input: plenty of ties, stop deduplicating
+    }
+    if (tied.size() <= 1) continue;
     const int total = states[p].coarse_total;
     std::vector<float> scores(total);
     CMX_HIP(hipMemcpy(scores.data(), batch.h_problems[p].coarse_score, total * sizeof(float),
@@ -1560,8 +1589,6 @@ void ResolveTies(Workspace& ws, const PreparedBatch& batch, const NodeList& leav
     std::sort(sorted.begin(), sorted.end(), std::greater<ScoreIndex>());
     std::vector<int> position(total);
     for (int i = 0; i < total; ++i) position[sorted[i].index] = i;
-    unsigned best_bits;
-    std::memcpy(&best_bits, &b.score, sizeof(float));
     bool have = false;
     unsigned long long best_key = 0;
     for (const Node2D& nd : leaves) {

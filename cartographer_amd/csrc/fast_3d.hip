@@ -459,8 +459,19 @@ SelectBest3DKernel(List3 leaves, const Counters3* __restrict__ counters, Best3* 
       Best3 b;
       b.score = nd.score; b.scan = nd.scan; b.ox = nd.ox; b.oy = nd.oy; b.oz = nd.oz;
       b.low_resolution_score = nd.low_resolution_score;
-      b.found = 1; b.ties = ties;
+      b.found = 1; b.ties = 1;
       *out = b;
+    }
+  __threadfence();
+  __syncthreads();
+  // ties = 1 + tied records that are a different leaf (dive + search duplicate the best).
+  for (int i = threadIdx.x; i < total; i += blockDim.x)
+    if (leaf_at(i, &nd) && __float_as_uint(nd.score) == best_bits) {
+      const int scan = __hip_atomic_load(&out->scan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int ox = __hip_atomic_load(&out->ox, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int oy = __hip_atomic_load(&out->oy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int oz = __hip_atomic_load(&out->oz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (nd.scan != scan || nd.ox != ox || nd.oy != oy || nd.oz != oz) atomicAdd(&out->ties, 1);
     }
 }
 
@@ -765,23 +776,11 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
   if (best.found && best.ties > 1) {
     // Exact tie resolution (see fast_2d.hip ResolveTies): repeat the reference's
     // std::sort of the lowest-resolution candidates (:352-353) and take the
-    // tied leaf its depth-first search meets first.
-    std::vector<float> scores(total);
-    CMX_HIP(hipMemcpy(scores.data(), d_coarse, total * sizeof(float), hipMemcpyDeviceToHost));
-    struct ScoreIndex {
-      float score; int index;
-      bool operator>(const ScoreIndex& o) const { return score > o.score; }
-    };
-    std::vector<ScoreIndex> sorted(total);
-    for (long long c = 0; c < total; ++c) sorted[c] = {scores[c], static_cast<int>(c)};
-    std::sort(sorted.begin(), sorted.end(), std::greater<ScoreIndex>());
-    std::vector<int> position(total);
-    for (long long i = 0; i < total; ++i) position[sorted[i].index] = static_cast<int>(i);
+    // tied leaf its depth-first search meets first.  The dive and the search
+    // record the same leaf twice, so first check that distinct leaves tie.
     unsigned best_bits;
     std::memcpy(&best_bits, &best.score, sizeof(float));
-    bool have = false;
-    int best_pos = 0;
-    unsigned long long best_path = 0;
+    std::vector<Node3D> tied;
     std::vector<Node3D> sub_nodes;
     for (int sub = 0; sub < kSubLists3; ++sub) {
       const int count = std::min(h_counters->leaves[sub], leaf_list.sub_capacity);
@@ -793,7 +792,29 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
       for (const Node3D& nd : sub_nodes) {
         unsigned bits;
         std::memcpy(&bits, &nd.score, sizeof(float));
-        if (bits != best_bits) continue;
+        if (bits == best_bits) tied.push_back(nd);
+      }
+    }
+    bool distinct = false;
+    for (const Node3D& nd : tied)
+      distinct |= !(nd.scan == tied[0].scan && nd.ox == tied[0].ox && nd.oy == tied[0].oy &&
+                    nd.oz == tied[0].oz);
+    if (distinct) {
+      std::vector<float> scores(total);
+      CMX_HIP(hipMemcpy(scores.data(), d_coarse, total * sizeof(float), hipMemcpyDeviceToHost));
+      struct ScoreIndex {
+        float score; int index;
+        bool operator>(const ScoreIndex& o) const { return score > o.score; }
+      };
+      std::vector<ScoreIndex> sorted(total);
+      for (long long c = 0; c < total; ++c) sorted[c] = {scores[c], static_cast<int>(c)};
+      std::sort(sorted.begin(), sorted.end(), std::greater<ScoreIndex>());
+      std::vector<int> position(total);
+      for (long long i = 0; i < total; ++i) position[sorted[i].index] = static_cast<int>(i);
+      bool have = false;
+      int best_pos = 0;
+      unsigned long long best_path = 0;
+      for (const Node3D& nd : tied) {
         const int pos = position[nd.coarse_index];
         if (!have || pos < best_pos || (pos == best_pos && nd.path < best_path)) {
           have = true;
