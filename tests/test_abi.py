@@ -55,3 +55,20 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "pyoracle" not in text and "liboracle" not in text and \
                     "oracle_2d" not in text and "oracle_3d" not in text, os.path.join(dirpath, f)
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/cartographer_mi355x.h compiles as C (gcc -std=c99 -pedantic) and a C
+    program links against the shared library and runs (no GPU: DEVICE_ERROR, exit 0)."""
+    import subprocess
+    from cartographer_amd import _lib
+    exe = str(tmp_path / "c_abi_demo")
+    lib_dir = os.path.dirname(_lib.SO_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror",
+                           "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_abi_demo.c"), "-o", exe,
+                           "-L", lib_dir, "-lcartographer_mi355x",
+                           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "cartographer_mi355x" in out.stdout
