@@ -211,10 +211,23 @@ PrepScansKernel(const Fast2DProblem* __restrict__ problems, const float* __restr
   for (int b = b0; b < b1; ++b) sum += hist[b];
   partial[threadIdx.x] = sum;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int t = 0; t < 256; ++t) { const int v = partial[t]; partial[t] = run; run += v; }
-    P.sorted_count[s] = run;
+  if (threadIdx.x < 64) {   // exclusive scan of the 256 partials by one wave, 4 per lane
+    const int l = threadIdx.x;
+    const int a0 = partial[4 * l], a1 = partial[4 * l + 1], a2 = partial[4 * l + 2],
+              a3 = partial[4 * l + 3];
+    const int mine = a0 + a1 + a2 + a3;
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off, 64);
+      if (l >= off) incl += o;
+    }
+    const int base = incl - mine;
+    partial[4 * l] = base;
+    partial[4 * l + 1] = base + a0;
+    partial[4 * l + 2] = base + a0 + a1;
+    partial[4 * l + 3] = base + a0 + a1 + a2;
+    if (l == 63) P.sorted_count[s] = incl;
   }
   __syncthreads();
   int run = partial[threadIdx.x];
@@ -248,12 +261,26 @@ CoarseLayoutKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __r
   partial[threadIdx.x] = sum;
   if (too_many) atomicMax(&states[blockIdx.x].error, 2);
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int t = 0; t < 1024; ++t) { const int v = partial[t]; partial[t] = run; run += v; }
-    P.coarse_off[S] = run;
-    states[blockIdx.x].coarse_total = run;
-    if (run > P.coarse_capacity) atomicMax(&states[blockIdx.x].error, 2);
+  if (threadIdx.x < 64) {   // exclusive scan of the 1024 partials by one wave, 16 per lane
+    const int l = threadIdx.x;
+    int local[16];
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { local[k] = partial[16 * l + k]; mine += local[k]; }
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off, 64);
+      if (l >= off) incl += o;
+    }
+    int run = incl - mine;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { partial[16 * l + k] = run; run += local[k]; }
+    if (l == 63) {
+      P.coarse_off[S] = incl;
+      states[blockIdx.x].coarse_total = incl;
+      if (incl > P.coarse_capacity) atomicMax(&states[blockIdx.x].error, 2);
+    }
   }
   __syncthreads();
   int run = partial[threadIdx.x];
@@ -395,32 +422,41 @@ ScoreCoarsePlanesKernel(const Fast2DProblem* __restrict__ problems, int n,
   // Records are wave-uniform: 64 of them arrive with one coalesced load (one
   // per lane) and are broadcast with readlane; kBatch plane loads are in flight
   // before the first one is consumed.  The tail reads the all-zero plane.
-  constexpr int kBatch = 16;
+  constexpr int kBatch = CHUNKS == 1 ? 32 : (CHUNKS == 2 ? 16 : 8);
   const uint32_t sentinel = 0xffff0000u | zero_plane;
-  for (int base_i = begin; base_i < end; base_i += 64) {
-    const uint32_t mine = (base_i + lane < end) ? rec[base_i + lane] : sentinel;
-    const int cnt = min(64, end - base_i);
-    for (int j0 = 0; j0 < cnt; j0 += kBatch) {
-      uint32_t r[kBatch];
-      int v[kBatch][CHUNKS];
+  for (int base_i = begin; base_i < end; base_i += 256) {
+    // Up to 256 records of this wave in four registers, all four loads in flight.
+    uint32_t mine[4];
 #pragma unroll
-      for (int k = 0; k < kBatch; ++k) {
-        r[k] = static_cast<uint32_t>(
-            __builtin_amdgcn_readlane(static_cast<int>(mine), (j0 + k) & 63));
-        const uint8_t* pp = planes + static_cast<size_t>(r[k] & 0xffffu) * stride + lane;
+    for (int g = 0; g < 4; ++g) {
+      const int idx = base_i + g * 64 + lane;
+      mine[g] = idx < end ? rec[idx] : sentinel;
+    }
 #pragma unroll
-        for (int c = 0; c < CHUNKS; ++c) v[k][c] = pp[c * 64];
-      }
+    for (int g = 0; g < 4; ++g) {
+      const int cnt = min(64, end - (base_i + g * 64));   // <= 0: nothing left
+      for (int j0 = 0; j0 < cnt; j0 += kBatch) {
+        uint32_t r[kBatch];
+        int v[kBatch][CHUNKS];
 #pragma unroll
-      for (int k = 0; k < kBatch; ++k) {
-        const int bucket = static_cast<int>(r[k] >> 16);
-        if (bucket != 0xffff) {
-          if (bucket != cur) {
-            if (cur >= 0) flush(cur);
-            cur = bucket;
+        for (int k = 0; k < kBatch; ++k) {
+          r[k] = static_cast<uint32_t>(
+              __builtin_amdgcn_readlane(static_cast<int>(mine[g]), (j0 + k) & 63));
+          const uint8_t* pp = planes + static_cast<size_t>(r[k] & 0xffffu) * stride + lane;
+#pragma unroll
+          for (int c = 0; c < CHUNKS; ++c) v[k][c] = pp[c * 64];
+        }
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+          const int bucket = static_cast<int>(r[k] >> 16);
+          if (bucket != 0xffff) {
+            if (bucket != cur) {
+              if (cur >= 0) flush(cur);
+              cur = bucket;
+            }
+#pragma unroll
+            for (int c = 0; c < CHUNKS; ++c) acc[c] += v[k][c];
           }
-#pragma unroll
-          for (int c = 0; c < CHUNKS; ++c) acc[c] += v[k][c];
         }
       }
     }
@@ -1165,6 +1201,35 @@ Fast2DMatcher::~Fast2DMatcher() {
   (void)hipSetDevice(device_);
   if (stack_mem_) (void)hipFree(stack_mem_);
   if (planes_) (void)hipFree(planes_);
+  for (RotationEntry& e : rotation_tables_) (void)hipFree(e.table);
+}
+
+const float2* Fast2DMatcher::RotationTable(double step, int num_angular) const {
+  std::lock_guard<std::mutex> lock(rotation_mutex_);
+  for (const RotationEntry& e : rotation_tables_)
+    if (e.step == step && e.num_angular == num_angular) return e.table;
+  const int num_scans = 2 * num_angular + 1;
+  std::vector<float2> host(num_scans);
+  // delta_theta accumulates in f64, each angle is narrowed to f32 for AngleAxisf.
+  double delta_theta = -num_angular * step;
+  for (int s = 0; s < num_scans; ++s, delta_theta += step) {
+    const float ha = 0.5f * static_cast<float>(delta_theta);
+    host[s] = make_float2(std::cos(ha), std::sin(ha) * 1.f);
+  }
+  RotationEntry e{step, num_angular, nullptr};
+  CMX_HIP(hipMalloc(reinterpret_cast<void**>(&e.table), num_scans * sizeof(float2)));
+  const hipError_t err =
+      hipMemcpy(e.table, host.data(), num_scans * sizeof(float2), hipMemcpyHostToDevice);
+  if (err != hipSuccess) {
+    (void)hipFree(e.table);
+    CMX_HIP(err);
+  }
+  if (rotation_tables_.size() >= 64) {   // bound the cache
+    (void)hipFree(rotation_tables_.front().table);
+    rotation_tables_.erase(rotation_tables_.begin());
+  }
+  rotation_tables_.push_back(e);
+  return e.table;
 }
 
 namespace {
@@ -1225,7 +1290,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
   out->h_problems.resize(num);
 
   // Per-problem search parameters and scratch sizes.
-  size_t rot_total = 0, discrete_total = 0, scans_total = 0, coarse_total = 0;
+  size_t discrete_total = 0, scans_total = 0, coarse_total = 0;
   for (int p = 0; p < num; ++p) {
     const Fast2DMatcher& m = *matchers[p];
     const cmx_grid2d_limits& lim = m.limits();
@@ -1246,7 +1311,6 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
                 h.num_scans);
     out->search[p] = h;
     out->initial[p] = init;
-    rot_total += h.num_scans;
     discrete_total += static_cast<size_t>(h.num_scans) * n;
     scans_total += h.num_scans + 1;
     // Upper bound of lowest-resolution candidates per scan: the shrunk window
@@ -1269,7 +1333,6 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
   }
 
   // Scratch carving.
-  float2* d_rot = ws.dev[1].ReserveAs<float2>(rot_total);
   uint32_t* d_discrete = ws.dev[2].ReserveAs<uint32_t>(2 * discrete_total);
   uint32_t* d_sorted = d_discrete + discrete_total;
   int4* d_bounds = ws.dev[3].ReserveAs<int4>(scans_total);
@@ -1279,14 +1342,16 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
   int* d_sorted_count = d_off + scans_total;
   float* d_cscore = ws.dev[6].ReserveAs<float>(coarse_total);
   int* d_csum = ws.dev[7].ReserveAs<int>(coarse_total);
-  out->d_problems = ws.dev[8].ReserveAs<Fast2DProblem>(num);
-  out->d_states = ws.dev[9].ReserveAs<ProblemState>(num);
+  const size_t problems_bytes = (num * sizeof(Fast2DProblem) + 255) & ~size_t(255);
+  const size_t upload_bytes = problems_bytes + num * sizeof(ProblemState);
+  char* d_upload = static_cast<char*>(ws.dev[8].Reserve(upload_bytes));
+  out->d_problems = reinterpret_cast<Fast2DProblem*>(d_upload);
+  out->d_states = reinterpret_cast<ProblemState*>(d_upload + problems_bytes);
+  char* h_upload = static_cast<char*>(ws.pinned[1].Reserve(upload_bytes));
+  Fast2DProblem* h_prob = reinterpret_cast<Fast2DProblem*>(h_upload);
+  ProblemState* h_state = reinterpret_cast<ProblemState*>(h_upload + problems_bytes);
 
-  float2* h_rot = ws.pinned[0].ReserveAs<float2>(rot_total);
-  Fast2DProblem* h_prob = ws.pinned[1].ReserveAs<Fast2DProblem>(num);
-  ProblemState* h_state = ws.pinned[2].ReserveAs<ProblemState>(num);
-
-  size_t rot_off = 0, disc_off = 0, scan_off = 0, coarse_off = 0;
+  size_t disc_off = 0, scan_off = 0, coarse_off = 0;
   for (int p = 0; p < num; ++p) {
     const Fast2DMatcher& m = *matchers[p];
     const cmx_grid2d_limits& lim = m.limits();
@@ -1305,21 +1370,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
       P.init_qz = std::sin(ha) * 1.f;
     }
     P.num_scans = h.num_scans;
-    // GenerateRotatedScans (SM2/correlative_scan_matcher_2d.cc:99-107):
-    // delta_theta accumulates in f64, each angle is narrowed to f32.  Problems
-    // with the same (step, num_angular) as their predecessor share its table.
-    if (p > 0 && out->search[p - 1].step == h.step &&
-        out->search[p - 1].num_angular == h.num_angular) {
-      P.scan_rot = out->h_problems[p - 1].scan_rot;
-    } else {
-      double delta_theta = -h.num_angular * h.step;
-      for (int s = 0; s < h.num_scans; ++s, delta_theta += h.step) {
-        const float ha = 0.5f * static_cast<float>(delta_theta);
-        h_rot[rot_off + s] = make_float2(std::cos(ha), std::sin(ha) * 1.f);
-      }
-      P.scan_rot = d_rot + rot_off;
-      rot_off += h.num_scans;
-    }
+    P.scan_rot = m.RotationTable(h.step, h.num_angular);
     P.min_s = m.min_s();
     P.score_scale = m.score_scale();
     P.min_score = min_score;
@@ -1345,13 +1396,8 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     coarse_off += P.coarse_capacity;
     out->max_scans = std::max(out->max_scans, h.num_scans);
   }
-  if (rot_off)
-    CMX_HIP(hipMemcpyAsync(d_rot, h_rot, rot_off * sizeof(float2), hipMemcpyHostToDevice,
-                           ws.stream));
-  CMX_HIP(hipMemcpyAsync(out->d_problems, h_prob, num * sizeof(Fast2DProblem),
-                         hipMemcpyHostToDevice, ws.stream));
-  CMX_HIP(hipMemcpyAsync(out->d_states, h_state, num * sizeof(ProblemState),
-                         hipMemcpyHostToDevice, ws.stream));
+  // One H2D for the problem descriptors and their initial states.
+  CMX_HIP(hipMemcpyAsync(d_upload, h_upload, upload_bytes, hipMemcpyHostToDevice, ws.stream));
 
   const dim3 per_scan(out->max_scans, num);
   auto mark = [&](const char* name) { if (out->trace) out->trace->Mark(name); };
@@ -1457,9 +1503,25 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
     // ---- search -------------------------------------------------------------
     // Top of the tree (two levels) per scan, then the subtrees of the
     // survivors down to the leaves on many blocks.
-    constexpr int kLevelsPerStage = 2;
-    constexpr int kWaveLevels = 2;
-    const int search_blocks = 4096;
+    // Stage shape (tunable for experiments through the environment).
+    static const int kLevelsPerStage = [] {
+      const char* e = getenv("CMX_LEVELS_PER_STAGE");
+      return e ? std::max(1, atoi(e)) : 0;
+    }();
+    static const int kWaveLevels = [] {
+      const char* e = getenv("CMX_WAVE_LEVELS");
+      return e ? std::max(0, atoi(e)) : -1;
+    }();
+    // Single searches are latency-bound: one wave stage, then one depth-first
+    // kernel down to the leaves.  Batches are throughput-bound: two wave stages,
+    // then depth-first stages of two levels.
+    const int levels_per_stage = kLevelsPerStage > 0 ? kLevelsPerStage : (num < 4 ? kMaxDepth : 2);
+    const int wave_levels = kWaveLevels >= 0 ? kWaveLevels : (num < 4 ? 1 : 2);
+    // Frontier sizes are only known on the device; grids are sized for the
+    // typical case (a few thousand nodes at the top, tens below) and every
+    // kernel grid-strides, so larger frontiers (big batches) still fill the chip.
+    const int wide_blocks = std::min(4096, 1024 * std::max(1, (num + 3) / 4));
+    const int narrow_blocks = std::min(4096, 512 * std::max(1, (num + 3) / 4));
     int num_chunks = 1;
     int strict = 0;
     for (;;) {
@@ -1474,8 +1536,8 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
         int top = depth - 1;
         // Wave-per-node level-synchronous expansion of the (wide, shallow-lived)
         // top levels.
-        for (int used = 0; used < kWaveLevels && top - 1 >= 1; ++used, --top, ++stage) {
-          ExpandWaveKernel<<<search_blocks, 256, 0, ws.stream>>>(
+        for (int used = 0; used < wave_levels && top - 1 >= 1; ++used, --top, ++stage) {
+          ExpandWaveKernel<<<used == 0 ? wide_blocks : narrow_blocks, 256, 0, ws.stream>>>(
               batch.d_problems, batch.d_states, n, front(stage), strict, front(stage + 1),
               d_counters);
           mark("wave");
@@ -1483,9 +1545,9 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
         // Block-per-node depth-first stages of kLevelsPerStage levels: the bushy
         // part of the tree near the optimum spreads over many blocks instead of
         // being walked serially by one.
-        for (; top > 0; top -= kLevelsPerStage, ++stage) {
-          const int stop = std::max(0, top - kLevelsPerStage);
-          SubtreeKernel<<<search_blocks, 256, 0, ws.stream>>>(
+        for (; top > 0; top -= levels_per_stage, ++stage) {
+          const int stop = std::max(0, top - levels_per_stage);
+          SubtreeKernel<<<narrow_blocks, 256, 0, ws.stream>>>(
               batch.d_problems, batch.d_states, n, front(stage), stop, strict, front(stage + 1),
               leaf_list, d_counters);
           mark("subtree");
@@ -1518,6 +1580,17 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
 
   result->best.assign(h_best, h_best + num);
   result->states.assign(h_states, h_states + num);
+  if (batch.trace && batch.trace->enabled() && h_counters) {
+    fprintf(stderr, "[cmx trace] list sizes:");
+    for (int st = 0; st < kMaxStages; ++st) {
+      long long total = 0;
+      for (int k = 0; k < kSubLists; ++k) total += h_counters->frontier[st][k];
+      if (total) fprintf(stderr, " frontier[%d]=%lld", st, total);
+    }
+    long long leaves = 0;
+    for (int k = 0; k < kSubLists; ++k) leaves += h_counters->leaves[k];
+    fprintf(stderr, " leaves=%lld\n", leaves);
+  }
   if (depth > 1) {
     ResolveTies(ws, batch, leaf_list, *h_counters, &result->best, result->states);
   } else {

@@ -97,6 +97,11 @@ class Fast2DMatcher {
   size_t level_offset(int i) const { return level_offsets_[i]; }
   float min_s() const { return min_s_; }
   float score_scale() const { return score_scale_; }
+  // Device table of per-rotation (cos, sin) half-angle pairs for a search with
+  // `num_angular` perturbations of `step` radians (GenerateRotatedScans,
+  // SM2/correlative_scan_matcher_2d.cc:99-107).  Built on first use (libm on the
+  // host), then shared by every later match with the same parameters.
+  const float2* RotationTable(double step, int num_angular) const;
 
  private:
   cmx_fast2d_options options_;
@@ -108,6 +113,9 @@ class Fast2DMatcher {
   std::vector<LevelDesc> levels_;
   std::vector<size_t> level_offsets_;
   float min_s_, score_scale_;
+  struct RotationEntry { double step; int num_angular; float2* table; };
+  mutable std::mutex rotation_mutex_;
+  mutable std::vector<RotationEntry> rotation_tables_;
 };
 
 }  // namespace cmx
