@@ -88,7 +88,7 @@ class Result3D(C.Structure):
 # Every symbol include/cartographer_mi355x.h declares.
 EXPORTED_SYMBOLS = [
     "cmx_version", "cmx_status_string", "cmx_last_error", "cmx_device_count", "cmx_set_stream",
-    "cmx_rt2d_match", "cmx_fast2d_create", "cmx_fast2d_destroy", "cmx_fast2d_match",
+    "cmx_rt2d_match", "cmx_rt2d_match_tsdf", "cmx_fast2d_create", "cmx_fast2d_destroy", "cmx_fast2d_match",
     "cmx_fast2d_match_full_submap", "cmx_fast2d_match_full_submap_batch", "cmx_cloud_upload",
     "cmx_cloud_destroy", "cmx_fast2d_match_full_submap_batch_resident", "cmx_fast2d_level_dims",
     "cmx_fast2d_level_cells", "cmx_fast2d_debug_prepare", "cmx_rt3d_match", "cmx_fast3d_create",
@@ -122,6 +122,9 @@ def lib():
     P = C.POINTER
     L.cmx_rt2d_match.argtypes = [P(RtOptions), P(Grid2DLimits), C.c_void_p, P(Pose2d), C.c_void_p,
                                  C.c_int32, C.c_int32, P(C.c_double), P(Pose2d), P(MatchStats)]
+    L.cmx_rt2d_match_tsdf.argtypes = [P(RtOptions), P(Grid2DLimits), C.c_void_p, C.c_void_p,
+                                      C.c_float, C.c_float, P(Pose2d), C.c_void_p, C.c_int32,
+                                      C.c_int32, P(C.c_double), P(Pose2d), P(MatchStats)]
     L.cmx_fast2d_create.argtypes = [P(Fast2DOptions), P(Grid2DLimits), C.c_void_p, C.c_int32,
                                     P(C.c_void_p)]
     L.cmx_fast2d_destroy.argtypes = [C.c_void_p]

@@ -58,6 +58,29 @@ class Grid2D:
                             self.max_correspondence_cost)
 
 
+class TSDF2D:
+    """Read-only view of a TSDF2D (mapping/internal/2d/tsdf_2d.h): MapLimits, the tsd and
+    weight planes (uint16, 0 = unknown) and the TSDValueConverter ranges."""
+
+    def __init__(self, tsd_cells, weight_cells, resolution, max_x, max_y, truncation_distance,
+                 max_weight):
+        self.cells = np.ascontiguousarray(tsd_cells, dtype=np.uint16)
+        self.weight_cells = np.ascontiguousarray(weight_cells, dtype=np.uint16)
+        if self.cells.ndim != 2 or self.cells.shape != self.weight_cells.shape:
+            raise ValueError("tsd / weight cells must both be [num_y_cells, num_x_cells]")
+        self.resolution = float(resolution)
+        self.max_x = float(max_x)
+        self.max_y = float(max_y)
+        self.truncation_distance = float(truncation_distance)
+        self.max_weight = float(max_weight)
+
+    def limits_c(self):
+        # Grid2D(limits, -truncation_distance, truncation_distance) (tsdf_2d.cc:25-26)
+        return Grid2DLimits(self.resolution, self.max_x, self.max_y, self.cells.shape[1],
+                            self.cells.shape[0], -self.truncation_distance,
+                            self.truncation_distance)
+
+
 def _cloud(point_cloud):
     xyz = np.ascontiguousarray(point_cloud, dtype=np.float32).reshape(-1, 3)
     return xyz, xyz.shape[0]
@@ -80,10 +103,17 @@ class RealTimeCorrelativeScanMatcher2D:
         score = C.c_double()
         pose = Pose2d()
         stats = MatchStats()
-        check(_lib.lib().cmx_rt2d_match(C.byref(self.options), C.byref(limits),
-                                        grid.cells.ctypes.data, C.byref(init), xyz.ctypes.data, n,
-                                        self.device, C.byref(score), C.byref(pose),
-                                        C.byref(stats)))
+        if isinstance(grid, TSDF2D):      # GridType::TSDF branch (.cc:159-167)
+            check(_lib.lib().cmx_rt2d_match_tsdf(
+                C.byref(self.options), C.byref(limits), grid.cells.ctypes.data,
+                grid.weight_cells.ctypes.data, grid.truncation_distance, grid.max_weight,
+                C.byref(init), xyz.ctypes.data, n, self.device, C.byref(score), C.byref(pose),
+                C.byref(stats)))
+        else:
+            check(_lib.lib().cmx_rt2d_match(C.byref(self.options), C.byref(limits),
+                                            grid.cells.ctypes.data, C.byref(init),
+                                            xyz.ctypes.data, n, self.device, C.byref(score),
+                                            C.byref(pose), C.byref(stats)))
         self.last_stats = stats.as_dict()
         return score.value, Rigid2d(pose.x, pose.y, pose.theta)
 

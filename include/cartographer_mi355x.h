@@ -8,6 +8,7 @@
  *
  *   cmx_rt2d_match                 RealTimeCorrelativeScanMatcher2D::Match
  *                                  SM2/real_time_correlative_scan_matcher_2d.h:66-68, .cc:117-149
+ *   cmx_rt2d_match_tsdf            the same method on a TSDF2D grid (.cc:38-59, :159-167)
  *   cmx_fast2d_create / _destroy   FastCorrelativeScanMatcher2D ctor / dtor
  *                                  SM2/fast_correlative_scan_matcher_2d.h:114-118, .cc:188-196
  *   cmx_fast2d_match               FastCorrelativeScanMatcher2D::Match        .h:124-126, .cc:198-208
@@ -131,6 +132,18 @@ cmx_status cmx_rt2d_match(const cmx_rt_options* options, const cmx_grid2d_limits
                           const uint16_t* cells, const cmx_pose2d* initial_pose_estimate,
                           const float* point_cloud_xyz, int32_t num_points, int32_t device,
                           double* score, cmx_pose2d* pose_estimate, cmx_match_stats* stats);
+/* TSDF2D branch of the same method (SM2/real_time_correlative_scan_matcher_2d.cc:38-59,
+ * mapping/internal/2d/tsdf_2d.cc:88-98): `tsd_cells` are the grid's
+ * correspondence_cost_cells, `weight_cells` its weight plane (both uint16,
+ * 0 = unknown, bit 15 = update marker), `truncation_distance` / `max_weight`
+ * the TSDValueConverter ranges.  A TSDF may score 0 everywhere; the first
+ * candidate then wins, as std::max_element does in the reference. */
+cmx_status cmx_rt2d_match_tsdf(const cmx_rt_options* options, const cmx_grid2d_limits* limits,
+                               const uint16_t* tsd_cells, const uint16_t* weight_cells,
+                               float truncation_distance, float max_weight,
+                               const cmx_pose2d* initial_pose_estimate,
+                               const float* point_cloud_xyz, int32_t num_points, int32_t device,
+                               double* score, cmx_pose2d* pose_estimate, cmx_match_stats* stats);
 
 /* ---- fast 2D (branch and bound) ---------------------------------------- */
 /* Uploads the grid and builds the PrecomputationGridStack2D on `device`

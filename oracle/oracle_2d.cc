@@ -170,32 +170,30 @@ std::vector<DiscreteScan2D> DiscretizeScans(const MapLimits& limits,
 }
 
 // ------------------------------------------------------------ real-time 2D ---
-double RealTimeMatch2D(const ProbabilityGridView& grid, const Pose2d& initial,
-                       const PointCloud& cloud, const double linear_window,
-                       const double angular_window, const double tw, const double rw,
-                       Pose2d* pose_estimate, MatchStats* stats,
-                       std::vector<float>* all_scores) {
+namespace {
+
+// RealTimeCorrelativeScanMatcher2D::Match (:117-149); `candidate_score` is
+// ComputeCandidateScore for the grid type at hand.
+template <typename CandidateScore>
+double RealTimeMatchImpl(const MapLimits& limits, CandidateScore candidate_score,
+                         const Pose2d& initial, const PointCloud& cloud,
+                         const double linear_window, const double angular_window,
+                         const double tw, const double rw, Pose2d* pose_estimate,
+                         MatchStats* stats, std::vector<float>* all_scores) {
   const PointCloud rotated_cloud = RotateCloudYaw(cloud, static_cast<float>(initial.theta));
-  const SearchParameters sp(linear_window, angular_window, rotated_cloud,
-                            grid.limits.resolution);
+  const SearchParameters sp(linear_window, angular_window, rotated_cloud, limits.resolution);
   const std::vector<PointCloud> rotated_scans = GenerateRotatedScans(rotated_cloud, sp);
-  const std::vector<DiscreteScan2D> scans =
-      DiscretizeScans(grid.limits, rotated_scans, static_cast<float>(initial.x),
-                      static_cast<float>(initial.y));
+  const std::vector<DiscreteScan2D> scans = DiscretizeScans(
+      limits, rotated_scans, static_cast<float>(initial.x), static_cast<float>(initial.y));
   // GenerateExhaustiveSearchCandidates (:83-115): scan, x, y nesting.
   std::vector<Candidate2D> candidates;
   for (int s = 0; s != sp.num_scans; ++s)
     for (int x = sp.linear_bounds[s].min_x; x <= sp.linear_bounds[s].max_x; ++x)
       for (int y = sp.linear_bounds[s].min_y; y <= sp.linear_bounds[s].max_y; ++y)
         candidates.emplace_back(s, x, y, sp);
-  // ScoreCandidates (:151-176) with ComputeCandidateScore (:61-75).
+  // ScoreCandidates (:151-176).
   for (Candidate2D& c : candidates) {
-    float acc = 0.f;
-    for (const Cell2i& idx : scans[c.scan_index]) {
-      acc += grid.GetProbability(Cell2i{idx.x + c.x_index_offset, idx.y + c.y_index_offset});
-    }
-    acc /= static_cast<float>(scans[c.scan_index].size());
-    c.score = acc;
+    c.score = candidate_score(scans[c.scan_index], c.x_index_offset, c.y_index_offset);
     const double t = std::hypot(c.x, c.y) * tw + std::abs(c.orientation) * rw;
     c.score *= std::exp(-(t * (t * 1.)));
   }
@@ -212,6 +210,77 @@ double RealTimeMatch2D(const ProbabilityGridView& grid, const Pose2d& initial,
   *pose_estimate = Pose2d{initial.x + best.x, initial.y + best.y,
                           initial.theta + best.orientation};
   return best.score;
+}
+
+}  // namespace
+
+double RealTimeMatch2D(const ProbabilityGridView& grid, const Pose2d& initial,
+                       const PointCloud& cloud, const double linear_window,
+                       const double angular_window, const double tw, const double rw,
+                       Pose2d* pose_estimate, MatchStats* stats,
+                       std::vector<float>* all_scores) {
+  // ComputeCandidateScore(ProbabilityGrid) (:61-75).
+  const auto score = [&grid](const DiscreteScan2D& scan, const int dx, const int dy) {
+    float acc = 0.f;
+    for (const Cell2i& idx : scan) acc += grid.GetProbability(Cell2i{idx.x + dx, idx.y + dy});
+    acc /= static_cast<float>(scan.size());
+    return acc;
+  };
+  return RealTimeMatchImpl(grid.limits, score, initial, cloud, linear_window, angular_window, tw,
+                           rw, pose_estimate, stats, all_scores);
+}
+
+// ---------------------------------------------------------------- TSDF2D ---
+TsdfView::TsdfView(const MapLimits& l, const uint16_t* tsd, const uint16_t* weight,
+                   const float truncation_distance, const float max_weight_in)
+    : limits(l), tsd_cells(tsd), weight_cells(weight), max_tsd(truncation_distance),
+      min_tsd(-truncation_distance), max_weight(max_weight_in) {}
+
+namespace {
+// ValueConversionTables (mapping/value_conversion_tables.cc:29-52).
+float SlowValueToBoundedFloat(const uint16_t raw, const float unknown_result,
+                              const float lower_bound, const float upper_bound) {
+  const uint16_t value = raw & static_cast<uint16_t>(~kUpdateMarker);
+  if (value == 0) return unknown_result;
+  const float kScale = (upper_bound - lower_bound) / 32766.f;
+  return value * kScale + (lower_bound - kScale);
+}
+}  // namespace
+
+// TSDF2D::GetTSDAndWeight (mapping/internal/2d/tsdf_2d.cc:88-98) with the
+// tables TSDValueConverter builds (tsd_value_converter.cc:22-33): unknown tsd
+// -> min_tsd, unknown weight -> 0.
+std::pair<float, float> TsdfView::GetTSDAndWeight(const Cell2i& c) const {
+  if (limits.Contains(c)) {
+    const size_t flat = static_cast<size_t>(limits.num_x_cells) * c.y + c.x;
+    return {SlowValueToBoundedFloat(tsd_cells[flat], min_tsd, min_tsd, max_tsd),
+            SlowValueToBoundedFloat(weight_cells[flat], 0.f, 0.f, max_weight)};
+  }
+  return {min_tsd, 0.f};
+}
+
+double RealTimeMatch2DTsdf(const TsdfView& tsdf, const Pose2d& initial, const PointCloud& cloud,
+                           const double linear_window, const double angular_window,
+                           const double tw, const double rw, Pose2d* pose_estimate,
+                           MatchStats* stats, std::vector<float>* all_scores) {
+  // ComputeCandidateScore(TSDF2D) (:38-59); GetMaxCorrespondenceCost() is the
+  // truncation distance (tsdf_2d.cc:25-26).
+  const auto score = [&tsdf](const DiscreteScan2D& scan, const int dx, const int dy) {
+    float candidate_score = 0.f;
+    float summed_weight = 0.f;
+    for (const Cell2i& idx : scan) {
+      const std::pair<float, float> tw_ = tsdf.GetTSDAndWeight(Cell2i{idx.x + dx, idx.y + dy});
+      const float normalized_tsd_score = (tsdf.max_tsd - std::abs(tw_.first)) / tsdf.max_tsd;
+      const float weight = tw_.second;
+      candidate_score += normalized_tsd_score * weight;
+      summed_weight += weight;
+    }
+    if (summed_weight == 0.f) return 0.f;
+    candidate_score /= summed_weight;
+    return candidate_score;
+  };
+  return RealTimeMatchImpl(tsdf.limits, score, initial, cloud, linear_window, angular_window, tw,
+                           rw, pose_estimate, stats, all_scores);
 }
 
 // ------------------------------------------------------- precomputation 2D ---

@@ -9,6 +9,7 @@
 #define ORACLE_2D_H_
 
 #include <cstdint>
+#include <utility>
 #include <vector>
 
 #include "oracle_common.h"
@@ -93,6 +94,27 @@ double RealTimeMatch2D(const ProbabilityGridView& grid, const Pose2d& initial,
                        double rotation_delta_cost_weight, Pose2d* pose_estimate,
                        MatchStats* stats = nullptr,
                        std::vector<float>* all_scores = nullptr);
+
+// TSDF2D read path (mapping/internal/2d/tsdf_2d.{h,cc}, tsd_value_converter.{h,cc}):
+// two uint16 planes (tsd, weight), 0 = unknown, bit 15 = update marker.
+struct TsdfView {
+  TsdfView(const MapLimits& limits, const uint16_t* tsd_cells, const uint16_t* weight_cells,
+           float truncation_distance, float max_weight);
+  MapLimits limits;
+  const uint16_t* tsd_cells;
+  const uint16_t* weight_cells;
+  float max_tsd, min_tsd, max_weight;
+  std::pair<float, float> GetTSDAndWeight(const Cell2i& c) const;
+};
+
+// RealTimeCorrelativeScanMatcher2D::Match on a TSDF2D
+// (real_time_correlative_scan_matcher_2d.cc:38-59,117-176).
+double RealTimeMatch2DTsdf(const TsdfView& tsdf, const Pose2d& initial, const PointCloud& cloud,
+                           double linear_window, double angular_window,
+                           double translation_delta_cost_weight,
+                           double rotation_delta_cost_weight, Pose2d* pose_estimate,
+                           MatchStats* stats = nullptr,
+                           std::vector<float>* all_scores = nullptr);
 
 // fast_correlative_scan_matcher_2d.h:49-93, .cc:91-169.
 class PrecomputationGrid2D {

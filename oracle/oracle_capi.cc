@@ -112,6 +112,48 @@ double orc_rt2d_match(const uint16_t* cells, int nx, int ny, double res, double 
   return s;
 }
 
+// TSDF branch (a8'): tsd / weight planes + truncation distance + max weight.
+double orc_rt2d_match_tsdf(const uint16_t* tsd_cells, const uint16_t* weight_cells, int nx,
+                           int ny, double res, double max_x, double max_y,
+                           float truncation_distance, float max_weight, const double* init_xyt,
+                           const float* xyz, int n, double lin, double ang, double tw, double rw,
+                           double* pose_xyt, int64_t* num_candidates, float* all_scores,
+                           int all_scores_capacity) {
+  const TsdfView g(MapLimits{res, max_x, max_y, nx, ny}, tsd_cells, weight_cells,
+                   truncation_distance, max_weight);
+  Pose2d pose;
+  MatchStats st;
+  std::vector<float> scores;
+  const double s = RealTimeMatch2DTsdf(g, Pose2d{init_xyt[0], init_xyt[1], init_xyt[2]},
+                                       MakeCloud(xyz, n), lin, ang, tw, rw, &pose, &st,
+                                       all_scores ? &scores : nullptr);
+  pose_xyt[0] = pose.x; pose_xyt[1] = pose.y; pose_xyt[2] = pose.theta;
+  if (num_candidates) *num_candidates = st.candidates_scored;
+  if (all_scores) {
+    const size_t m = std::min<size_t>(scores.size(), all_scores_capacity);
+    std::memcpy(all_scores, scores.data(), m * 4);
+  }
+  return s;
+}
+
+// TSDValueConverter (mapping/internal/2d/tsd_value_converter.h:39-67, .cc:22-33).
+// kind 0: tsd in [-bound, bound]; kind 1: weight in [0, bound].
+int orc_tsd_float_to_value(int kind, float bound, float x) {
+  const float lo = kind == 0 ? -bound : 0.f, hi = bound;
+  const float resolution = 32766.f / (hi - lo);
+  const float clamped = x > hi ? hi : (x < lo ? lo : x);     // common::Clamp (math.h:31-42)
+  return static_cast<int>(std::lround((clamped - lo) * resolution)) + 1;
+}
+float orc_tsd_value_to_float(int kind, float bound, int raw) {
+  const float lo = kind == 0 ? -bound : 0.f, hi = bound;
+  const TsdfView v(MapLimits{1., 0., 0., 1, 1}, nullptr, nullptr, 1.f, 1.f);
+  (void)v;
+  const uint16_t value = static_cast<uint16_t>(raw) & static_cast<uint16_t>(~kUpdateMarker);
+  if (value == 0) return lo;                                  // unknown -> lower bound
+  const float kScale = (hi - lo) / 32766.f;
+  return value * kScale + (lo - kScale);
+}
+
 // ---- precomputation grid / fast 2D ----
 void* orc_fast2d_create(const uint16_t* cells, int nx, int ny, double res, double max_x,
                         double max_y, int depth, double lin, double ang) {

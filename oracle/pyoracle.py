@@ -60,6 +60,14 @@ def _declare(L):
                                  _f64p, _f32p, C.c_int, C.c_double, C.c_double, C.c_double,
                                  C.c_double, _f64p, C.POINTER(C.c_int64), C.c_void_p, C.c_int]
     L.orc_rt2d_match.restype = C.c_double
+    L.orc_rt2d_match_tsdf.argtypes = [_u16p, _u16p, C.c_int, C.c_int, C.c_double, C.c_double,
+                                      C.c_double, C.c_float, C.c_float, _f64p, _f32p, C.c_int,
+                                      C.c_double, C.c_double, C.c_double, C.c_double, _f64p,
+                                      C.POINTER(C.c_int64), C.c_void_p, C.c_int]
+    L.orc_rt2d_match_tsdf.restype = C.c_double
+    L.orc_tsd_float_to_value.argtypes = [C.c_int, C.c_float, C.c_float]
+    L.orc_tsd_value_to_float.argtypes = [C.c_int, C.c_float, C.c_int]
+    L.orc_tsd_value_to_float.restype = C.c_float
     L.orc_fast2d_create.argtypes = [_u16p, C.c_int, C.c_int, C.c_double, C.c_double,
                                     C.c_double, C.c_int, C.c_double, C.c_double]
     L.orc_fast2d_create.restype = C.c_void_p
@@ -147,6 +155,43 @@ def rt2d_match(cells, res, max_x, max_y, init_xyt, xyz, lin, ang, tw, rw, want_s
         s = lib().orc_rt2d_match(cells, nx, ny, res, max_x, max_y, init, xyz, n, lin, ang, tw,
                                  rw, pose, C.byref(ncand), None, 0)
     return dict(score=float(s), pose=pose, num_candidates=ncand.value, scores=scores)
+
+
+def rt2d_match_tsdf(tsd_cells, weight_cells, res, max_x, max_y, truncation_distance, max_weight,
+                    init_xyt, xyz, lin, ang, tw, rw, want_scores=False):
+    """RealTimeCorrelativeScanMatcher2D::Match on a TSDF2D (two uint16 planes)."""
+    tsd = np.ascontiguousarray(tsd_cells, np.uint16)
+    wgt = np.ascontiguousarray(weight_cells, np.uint16)
+    ny, nx = tsd.shape
+    assert wgt.shape == tsd.shape
+    xyz, n = _cloud(xyz)
+    pose = np.empty(3, np.float64)
+    ncand = C.c_int64()
+    init = np.ascontiguousarray(init_xyt, np.float64)
+    args = (tsd, wgt, nx, ny, res, max_x, max_y, truncation_distance, max_weight, init, xyz, n,
+            lin, ang, tw, rw, pose, C.byref(ncand))
+    s = lib().orc_rt2d_match_tsdf(*args, None, 0)
+    scores = None
+    if want_scores:
+        scores = np.empty(ncand.value, np.float32)
+        s = lib().orc_rt2d_match_tsdf(*args, scores.ctypes.data, scores.size)
+    return dict(score=float(s), pose=pose, num_candidates=ncand.value, scores=scores)
+
+
+def tsd_to_value(tsd, truncation_distance):
+    return lib().orc_tsd_float_to_value(0, truncation_distance, tsd)
+
+
+def weight_to_value(weight, max_weight):
+    return lib().orc_tsd_float_to_value(1, max_weight, weight)
+
+
+def value_to_tsd(value, truncation_distance):
+    return float(lib().orc_tsd_value_to_float(0, truncation_distance, value))
+
+
+def value_to_weight(value, max_weight):
+    return float(lib().orc_tsd_value_to_float(1, max_weight, value))
 
 
 def precompute2d(cells, width):

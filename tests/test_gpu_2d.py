@@ -351,3 +351,70 @@ def test_rt2d_reference_fixture(sm, oracle, synth):
     score, pose = m.match(sm.Rigid2d(0, 0, 0), L_CLOUD, _grid(sm, g.cells, lim))
     assert score == ref["score"] and score == pytest.approx(0.7, abs=1e-2)
     np.testing.assert_allclose([pose.x, pose.y, pose.theta], ref["pose"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("lin,ang", [(1.0, 0.05), (0.0, 0.0), (0.05, 0.4)])
+def test_rt2d_window_shapes(sm, oracle, synth, lin, ang):
+    """Large linear window (41x41 offsets per rotation, points pushed outside the grid),
+    the single-candidate window and a rotation-heavy one."""
+    cells, lim, world = synth.make_submap(13, 96, 80, 0.05, 8, 300, 30.0, 0.01)
+    truth = world.free_pose(2, 0.4)
+    scan = world.scan(truth, 333, 30.0, 0.01, 4)
+    init = [truth[0] + 0.4, truth[1] - 0.3, truth[2] + 0.02]
+    ref = oracle.rt2d_match(cells, 0.05, lim["max_x"], lim["max_y"], init, scan, lin, ang, 0.3,
+                            0.2)
+    m = sm.RealTimeCorrelativeScanMatcher2D(lin, ang, 0.3, 0.2)
+    score, pose = m.match(sm.Rigid2d(*init), scan, _grid(sm, cells, lim))
+    assert m.last_stats["candidates_scored"] == ref["num_candidates"]
+    assert score == ref["score"]
+    np.testing.assert_allclose([pose.x, pose.y, pose.theta], ref["pose"], rtol=0, atol=1e-12)
+
+
+# ----------------------------------------------------------------------------
+# Real-time 2D on a TSDF2D (ComputeCandidateScore(TSDF2D), real_time_..._2d.cc:38-59)
+# ----------------------------------------------------------------------------
+def _tsdf_match_both(sm, oracle, tsd, wgt, lim, trunc, max_w, init, scan, lin, ang, tw, rw):
+    ref = oracle.rt2d_match_tsdf(tsd, wgt, lim["resolution"], lim["max_x"], lim["max_y"], trunc,
+                                 max_w, init, scan, lin, ang, tw, rw)
+    m = sm.RealTimeCorrelativeScanMatcher2D(lin, ang, tw, rw)
+    grid = sm.TSDF2D(tsd, wgt, lim["resolution"], lim["max_x"], lim["max_y"], trunc, max_w)
+    score, pose = m.match(sm.Rigid2d(*init), scan, grid)
+    assert m.last_stats["candidates_scored"] == ref["num_candidates"]
+    assert score == ref["score"]          # f32 score widened to f64: bit-equal
+    np.testing.assert_allclose([pose.x, pose.y, pose.theta], ref["pose"], rtol=0, atol=1e-12)
+    return score, pose
+
+
+@pytest.mark.parametrize("seed,n", [(42, 1000), (5, 77)])
+def test_rt2d_tsdf_parity(sm, oracle, synth, seed, n):
+    from tsdf_helpers import tsdf_from_probability_grid
+    cells, lim, world = synth.make_submap(seed, 200, 200, 0.05, 25, 1000, 30.0, 0.01)
+    tsd, wgt = tsdf_from_probability_grid(oracle, cells, 0.05, 0.3, 10.0, seed)
+    truth = world.free_pose(77, 0.5)
+    scan = world.scan(truth, 1000, 30.0, 0.01, 5)[:n]
+    init = [truth[0] + 0.12, truth[1] - 0.08, truth[2] + math.radians(3.0)]
+    score, pose = _tsdf_match_both(sm, oracle, tsd, wgt, lim, 0.3, 10.0, init, scan, 0.3,
+                                   math.radians(7.0), 0.1, 0.1)
+    assert score > 0.5
+    if n == 1000:
+        assert abs(pose.x - truth[0]) < 0.11 and abs(pose.y - truth[1]) < 0.11
+
+
+def test_rt2d_tsdf_reference_fixture(sm, oracle):
+    """The L-cloud TSDF of RealTimeCorrelativeScanMatcherTest::SetUpTSDF (:66-92)."""
+    from test_oracle_reference_pins import L_CLOUD, _rt_test_tsdf
+    tsd, wgt = _rt_test_tsdf(oracle)
+    lim = dict(resolution=0.05, max_x=0.3, max_y=0.5)
+    score, _ = _tsdf_match_both(sm, oracle, tsd, wgt, lim, 0.3, 1.0, [0, 0, 0], L_CLOUD, 0.6,
+                                0.16, 0.0, 0.0)
+    assert score > 0.95
+
+
+def test_rt2d_tsdf_unknown_everywhere(sm, oracle):
+    """Summed weight 0 -> score 0 for every candidate; the first candidate is returned."""
+    from test_oracle_reference_pins import L_CLOUD
+    zeros = np.zeros((20, 20), np.uint16)
+    lim = dict(resolution=0.05, max_x=0.3, max_y=0.5)
+    score, pose = _tsdf_match_both(sm, oracle, zeros, zeros, lim, 0.3, 1.0, [0, 0, 0], L_CLOUD,
+                                   0.1, 0.05, 0.0, 0.0)
+    assert score == 0.0 and pose.theta < 0

@@ -146,6 +146,83 @@ def test_rt2d_score_partial_candidate(oracle, synth):
     assert scores[1, 1] == pytest.approx(0.7, abs=1e-2)
 
 
+# ---- internal/2d/tsd_value_converter_test.cc -------------------------------
+def test_tsd_value_converter_round_trips(oracle):
+    # :41-75  ValueToTSD/TSDToValue and ValueToWeight/WeightToValue are exact inverses on
+    # [1, 32767], with or without the update marker; truncation 0.1, max weight 10.
+    trunc, max_w = 0.1, 10.0
+    assert oracle.value_to_tsd(0, trunc) == -np.float32(trunc)       # unknown -> min tsd
+    assert oracle.value_to_weight(0, max_w) == 0.0                   # unknown -> min weight
+    for v in list(range(1, 32768, 7)) + [32767]:
+        assert oracle.tsd_to_value(oracle.value_to_tsd(v, trunc), trunc) == v
+        assert oracle.tsd_to_value(oracle.value_to_tsd(v + (1 << 15), trunc), trunc) == v
+        assert oracle.weight_to_value(oracle.value_to_weight(v, max_w), max_w) == v
+        assert oracle.weight_to_value(oracle.value_to_weight(v + (1 << 15), max_w), max_w) == v
+
+
+def test_tsd_value_converter_ranges(oracle):
+    # :77-120  float -> value -> float within one quantisation step; clamping outside.
+    trunc, max_w = 0.1, 10.0
+    for i in range(1000):
+        sdf = -trunc + i * 2.0 * trunc / 1000
+        assert oracle.value_to_tsd(oracle.tsd_to_value(sdf, trunc), trunc) == \
+            pytest.approx(sdf, abs=trunc * 2.0 / 32767.0)
+        w = i * max_w / 1000
+        assert oracle.value_to_weight(oracle.weight_to_value(w, max_w), max_w) == \
+            pytest.approx(w, abs=max_w / 32767.0)
+    assert oracle.value_to_weight(oracle.weight_to_value(2 * max_w, max_w), max_w) == \
+        pytest.approx(max_w, abs=max_w / 32767.0)
+    assert oracle.value_to_weight(oracle.weight_to_value(-max_w, max_w), max_w) == \
+        pytest.approx(0.0, abs=max_w / 32767.0)
+    assert oracle.value_to_tsd(oracle.tsd_to_value(2 * trunc, trunc), trunc) == \
+        pytest.approx(trunc, abs=trunc * 2.0 / 32767.0)
+    assert oracle.value_to_tsd(oracle.tsd_to_value(-2 * trunc, trunc), trunc) == \
+        pytest.approx(-trunc, abs=trunc * 2.0 / 32767.0)
+
+
+# ---- real_time_correlative_scan_matcher_2d_test.cc, TSDF cases --------------
+def _rt_test_tsdf(oracle):
+    # :66-92  TSDF2D(MapLimits(0.05, (0.3, 0.5), 20x20), truncation 0.3, max weight 1.0) of the
+    # L-shaped scan.  The reference fills it with TSDFRangeDataInserter2D (not restated: it
+    # is outside the matcher path); here the cells hold the distance to the same L.
+    from tsdf_helpers import polyline_tsdf
+    poly = [(0.025, 0.175), (-0.125, 0.175), (-0.125, 0.025)]
+    return polyline_tsdf(oracle, poly, 0.05, 0.3, 0.5, 20, 20, 0.3, 1.0)
+
+
+def test_rt2d_tsdf_score_perfect_candidate(oracle):
+    # :143-160  candidate (0,0,0): every point aligns, score ~1 (> 0.95)
+    tsd, wgt = _rt_test_tsdf(oracle)
+    r = oracle.rt2d_match_tsdf(tsd, wgt, 0.05, 0.3, 0.5, 0.3, 1.0, [0, 0, 0], L_CLOUD, 0.0, 0.0,
+                               0.0, 0.0, want_scores=True)
+    assert r["num_candidates"] == 1
+    assert 0.95 < r["scores"][0] <= 1.0 + 1e-6
+
+
+def test_rt2d_tsdf_score_partial_candidate(oracle):
+    # :181-199  candidate (0, 0, y_offset=1): one cell off -> between 1 - 4/(7*6) and 1
+    tsd, wgt = _rt_test_tsdf(oracle)
+    r = oracle.rt2d_match_tsdf(tsd, wgt, 0.05, 0.3, 0.5, 0.3, 1.0, [0, 0, 0], L_CLOUD, 0.05, 0.0,
+                               0.0, 0.0, want_scores=True)
+    scores = r["scores"].reshape(3, 3)
+    # With the exact distance field four points are one cell (1/6 of the truncation
+    # distance) off, i.e. the reference's lower bound itself up to the u16 quantisation.
+    assert 1.0 - 4.0 / (7.0 * 6.0) - 1e-4 < scores[1, 2] < 1.0
+    assert scores[1, 1] > scores[1, 2]
+
+
+def test_rt2d_tsdf_empty_and_outside(oracle):
+    # ComputeCandidateScore(TSDF2D) returns 0 when the summed weight is 0 (:55).
+    tsd = np.zeros((20, 20), np.uint16)
+    r = oracle.rt2d_match_tsdf(tsd, tsd, 0.05, 0.3, 0.5, 0.3, 1.0, [0, 0, 0], L_CLOUD, 0.1, 0.05,
+                               0.0, 0.0, want_scores=True)
+    assert r["score"] == 0.0 and not r["scores"].any()
+    # std::max_element keeps the first candidate: scan 0, x = -nl, y = -nl
+    # (pose offset = (-y*res, -x*res), orientation = -na*step).
+    assert r["pose"][0] == pytest.approx(0.1) and r["pose"][1] == pytest.approx(0.1)
+    assert r["pose"][2] < 0
+
+
 # ---- internal/2d/scan_matching/fast_correlative_scan_matcher_2d_test.cc ----
 def _mt19937_uniform_int(seed, lo, hi, count):
     """libstdc++ std::uniform_int_distribution<int>(lo, hi) on mt19937 for a
