@@ -27,6 +27,27 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+DOMINANT_KERNEL = "ScoreCoarsePlanesKernel"
+
+
+def pmc_traffic_bytes():
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC
+    passes of this same command (profiles/r01_pmc_{fetch,write}_size.csv; FETCH_SIZE and
+    WRITE_SIZE need separate passes, MI355X_MICROARCH.md "rocprofv3 PMC slots").  Values
+    are KiB; FETCH_SIZE is doubled per the guide's gfx950 correction (it tallies 128-B
+    requests as 64 B), which makes this an upper bound for our byte-wide gathers."""
+    import csv
+    total = 0.0
+    for name, factor in (("r01_pmc_fetch_size.csv", 2.0), ("r01_pmc_write_size.csv", 1.0)):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            return None
+        with open(path) as f:
+            rows = [r for r in csv.DictReader(f) if DOMINANT_KERNEL in r["Kernel"]]
+        if not rows:
+            return None
+        total += float(rows[0]["MeanValue"]) * 1024.0 * factor
+    return total
 
 
 def parse_args():
@@ -201,12 +222,16 @@ def main():
                 "device_ms_per_step": device_ms / args.steps,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "ScoreCoarseKernel",
+                "bound": "hbm", "kernel": DOMINANT_KERNEL,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel_ms": k_ms,
-                "note": "algorithmic bytes (1 B per candidate-point + 4 B per rotation-point); "
-                        "the 1.2 MB stack is L2/LDS resident so frac may exceed HBM-bound",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
+                "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
+                "note": "achieved = algorithmic bytes per launch (1 B per candidate-point + "
+                        "4 B per rotation-point, SURVEY 8d) / HIP-event kernel time; traffic = "
+                        "FETCH_SIZE + WRITE_SIZE bytes per launch from the PMC passes under "
+                        "profiles/ -- the 1.2 MB stack and the phase planes are L2 resident, "
+                        "so measured HBM traffic is ~2% of the algorithmic bytes and the "
+                        "kernel is bound by L1/LDS gather rate, not by HBM",
             },
         }
         if not args.no_cpu_baseline:

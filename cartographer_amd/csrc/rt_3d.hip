@@ -42,9 +42,33 @@ __global__ void ScatterVoxelsKernel(const cmx_voxel* __restrict__ voxels, long l
   }
 }
 
+// Dense f32 probability brick with a one-cell border of kMinProbability: a voxel
+// index clamped to the border reads what HybridGrid::GetProbability returns for any
+// cell outside the stored box (value 0 -> kMinProbability, hybrid_grid.h:521-523).
+struct PaddedBrick {
+  const float* cells;   // [(nz+2)][(ny+2)][(nx+2)]
+  int lo_x, lo_y, lo_z; // index of padded cell (1,1,1)
+  int nx, ny, nz;
+};
+
+__global__ void FillFloatKernel(float* __restrict__ out, size_t n, float value) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = value;
+}
+
+__global__ void ScatterProbabilitiesKernel(const cmx_voxel* __restrict__ voxels, long long n,
+                                           PaddedBrick b, float* __restrict__ out) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const cmx_voxel v = voxels[i];
+  const size_t off = (static_cast<size_t>(v.z - b.lo_z + 1) * (b.ny + 2) + (v.y - b.lo_y + 1)) *
+                         (b.nx + 2) + (v.x - b.lo_x + 1);
+  out[off] = ValueToProbabilityDev(v.value);
+}
+
 struct Rt3DParams {
-  Brick grid;                 // uint16 values
-  float resolution;
+  PaddedBrick grid;
+  float resolution, inv_resolution;
   int num_translations, num_rotations, side_t, side_r;
   const float4* rotation;     // [R] candidate rotation (x,y,z,w) = normalized(init.q * q_r)
   const float4* translation;  // [T] candidate translation (xyz) = init.q * t_c + init.t; w = |t_c|
@@ -52,26 +76,88 @@ struct Rt3DParams {
   double wt, wr;
 };
 
+// lround(c / resolution) (HybridGrid::GetCellIndex, hybrid_grid.h:428-433) without the
+// IEEE division in the common case.  q0 = c * RN(1/res) differs from the correctly
+// rounded quotient qe by less than |q0| * 2^-21; when q0 is further than |q0| * 2^-20
+// from every half-integer, qe lies strictly inside (n - 0.5, n + 0.5) with n = rint(q0),
+// so lround(qe) == n.  Otherwise (about |q0| * 2^-19 of the inputs, NaN/inf included)
+// `ok` is cleared and the caller recomputes with the reference's exact expression.
+__device__ __forceinline__ int FastCellIndex(float c, float inv_resolution, bool* ok) {
+  const float q0 = c * inv_resolution;
+  const float n = rintf(q0);
+  const float margin = 0.5f - fabsf(q0 - n);          // exact
+  *ok = *ok && (margin > fabsf(q0) * 0x1p-20f);
+  return static_cast<int>(n);
+}
+
+// One wavefront = 64 translations of one rotation.  Each lane rotates one point of the
+// next 64-point chunk into LDS (the rotation is wave-uniform, so this removes the 64x
+// redundant rotation), then all lanes walk the chunk in point order: broadcast LDS read,
+// add the lane's translation, cell index, one gather from the padded brick, and the
+// reference's sequential f32 accumulation.
 __global__ void __launch_bounds__(64)
 Rt3DScoreKernel(Rt3DParams P, const float* __restrict__ xyz, int n,
                 float* __restrict__ unweighted, float* __restrict__ weighted,
                 unsigned* __restrict__ max_bits) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float4 rotated[64];
+  const int lane = threadIdx.x;
+  const int t = blockIdx.x * 64 + lane;
   const int r = blockIdx.y;
-  float w = 0.f;
-  if (t < P.num_translations) {
-    const float4 q4 = P.rotation[r];
-    const Quat q{q4.w, q4.x, q4.y, q4.z};
-    const float4 tr = P.translation[t];
-    const float res = P.resolution;
-    float acc = 0.f;
-    for (int i = 0; i < n; ++i) {
-      const F3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};   // wave-uniform
-      const F3 rp = Rotate(q, p);                               // wave-uniform
-      const F3 c{rp.x + tr.x, rp.y + tr.y, rp.z + tr.z};        // rigid * point
-      const int3 idx = CellIndex3(c, res);
-      acc += ValueToProbabilityDev(BrickValueU16(P.grid, idx.x, idx.y, idx.z));
+  const bool valid = t < P.num_translations;
+  const float4 q4 = P.rotation[r];
+  const Quat q{q4.w, q4.x, q4.y, q4.z};
+  const float4 tr = P.translation[valid ? t : 0];
+  const float res = P.resolution, inv = P.inv_resolution;
+  const int sx = P.grid.nx + 2, sy = P.grid.ny + 2;
+  const int ox = 1 - P.grid.lo_x, oy = 1 - P.grid.lo_y, oz = 1 - P.grid.lo_z;
+  const int mx = P.grid.nx + 1, my = P.grid.ny + 1, mz = P.grid.nz + 1;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(P.grid.cells), 0, sx * sy * (P.grid.nz + 2) * 4, 0x00020000);
+
+  const auto cell_offset = [&](const float4& rp) -> int {
+    const float cx = rp.x + tr.x, cy = rp.y + tr.y, cz = rp.z + tr.z;   // rigid * point
+    bool ok = true;
+    int ix = FastCellIndex(cx, inv, &ok);
+    int iy = FastCellIndex(cy, inv, &ok);
+    int iz = FastCellIndex(cz, inv, &ok);
+    if (!ok) {
+      const int3 idx = CellIndex3(F3{cx, cy, cz}, res);
+      ix = idx.x; iy = idx.y; iz = idx.z;
     }
+    ix = min(max(ix + ox, 0), mx);
+    iy = min(max(iy + oy, 0), my);
+    iz = min(max(iz + oz, 0), mz);
+    return ((iz * sy + iy) * sx + ix) * 4;
+  };
+
+  float acc = 0.f;
+  constexpr int kBatch = 8;
+  for (int base = 0; base < n; base += 64) {
+    const int cnt = min(64, n - base);
+    __syncthreads();                       // previous chunk fully consumed
+    if (lane < cnt) {
+      const int i = base + lane;
+      const F3 rp = Rotate(q, F3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]});
+      rotated[lane] = make_float4(rp.x, rp.y, rp.z, 0.f);
+    }
+    __syncthreads();
+    int j = 0;
+    for (; j + kBatch <= cnt; j += kBatch) {
+      float v[kBatch];
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k)
+        v[k] = __uint_as_float(
+            __builtin_amdgcn_raw_buffer_load_b32(rsrc, cell_offset(rotated[j + k]), 0, 0));
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k) acc += v[k];
+    }
+    for (; j < cnt; ++j)
+      acc += __uint_as_float(
+          __builtin_amdgcn_raw_buffer_load_b32(rsrc, cell_offset(rotated[j]), 0, 0));
+  }
+
+  float w = 0.f;
+  if (valid) {
     acc /= static_cast<float>(n);
     // Candidate order of the reference: z, y, x, rz, ry, rx nesting.
     const size_t c = static_cast<size_t>(t) * P.num_rotations + r;
@@ -222,8 +308,33 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
     }
 
     WorkspaceLease ws(device);
-    DeviceBrick grid;
-    BuildBrickFromVoxels(*ws, voxels, num_voxels, 2, &grid);
+    // Padded f32 probability brick over the voxels' bounding box.
+    PaddedBrick brick{};
+    {
+      int lo[3], hi[3];
+      if (!VoxelBounds(voxels, num_voxels, lo, hi)) {
+        lo[0] = lo[1] = lo[2] = 0;
+        hi[0] = hi[1] = hi[2] = 0;
+      }
+      for (int k = 0; k < 3; ++k)
+        CMX_REQUIRE(lo[k] > -(1 << 20) && hi[k] < (1 << 20), "voxel index out of range");
+      brick.lo_x = lo[0]; brick.lo_y = lo[1]; brick.lo_z = lo[2];
+      brick.nx = hi[0] - lo[0] + 1; brick.ny = hi[1] - lo[1] + 1; brick.nz = hi[2] - lo[2] + 1;
+      const size_t cells = static_cast<size_t>(brick.nx + 2) * (brick.ny + 2) * (brick.nz + 2);
+      CMX_REQUIRE(cells < (size_t(1) << 29), "dense grid of %d x %d x %d cells is too large",
+                  brick.nx, brick.ny, brick.nz);
+      float* d_cells = ws->dev[7].ReserveAs<float>(cells);
+      brick.cells = d_cells;
+      FillFloatKernel<<<DivUp(cells, 256), 256, 0, ws->stream>>>(d_cells, cells, 0.1f);
+      if (num_voxels > 0) {
+        cmx_voxel* d_vox = ws->dev[15].ReserveAs<cmx_voxel>(num_voxels);
+        CMX_HIP(hipMemcpyAsync(d_vox, voxels, num_voxels * sizeof(cmx_voxel),
+                               hipMemcpyHostToDevice, ws->stream));
+        ScatterProbabilitiesKernel<<<DivUp(num_voxels, 256), 256, 0, ws->stream>>>(
+            d_vox, num_voxels, brick, d_cells);
+      }
+      CMX_HIP(hipGetLastError());
+    }
 
     float* d_xyz = ws->dev[0].ReserveAs<float>(3 * static_cast<size_t>(n));
     float4* d_rot = ws->dev[1].ReserveAs<float4>(R);
@@ -251,8 +362,9 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
     CMX_HIP(hipStreamSynchronize(ws->stream));
 
     Rt3DParams P;
-    P.grid = grid.desc;
+    P.grid = brick;
     P.resolution = resolution;
+    P.inv_resolution = 1.f / resolution;
     P.num_translations = static_cast<int>(T);
     P.num_rotations = static_cast<int>(R);
     P.side_t = side_t; P.side_r = side_r;
