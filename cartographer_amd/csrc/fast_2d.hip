@@ -298,6 +298,14 @@ __device__ __forceinline__ float ToScore(const Fast2DProblem& P, int sum, int n)
   return P.min_s + (static_cast<float>(sum) / static_cast<float>(n)) * P.score_scale;
 }
 
+// An integer >= the sum a node's score was computed from (inverse of ToScore,
+// rounded generously upwards; only used to prune).
+__device__ __forceinline__ int SumUpperBound(const Fast2DProblem& P, float score, int n) {
+  const float s = (score - P.min_s) / P.score_scale * static_cast<float>(n);
+  const float ub = ceilf(s * (1.f + 1e-5f)) + 2.f;
+  return static_cast<int>(fminf(fmaxf(ub, 0.f), 255.f * static_cast<float>(n)));
+}
+
 // Integer sum of one candidate over all points, one wave per candidate
 // (SM2/fast_...2d.cc:320-329 with GetValue of .h:56-71).  Generic fallback of
 // the lowest resolution when the phase-plane layout does not apply.
@@ -777,11 +785,23 @@ FilterCoarseKernel(const Fast2DProblem* __restrict__ problems,
   const int count = dims.x * dims.y;
   const int base = P.coarse_off[s];
   const int sub = (blockIdx.x + blockIdx.y) & (kSubLists - 1);
-  for (int c = threadIdx.x; c < count; c += blockDim.x) {
-    const float score = P.coarse_score[base + c];
-    if (strict ? (score > best) : (score >= best)) {
-      if (!ListStore(out, sub, ListReserve(out, sub, 1), CoarseNode(P, problem, s, c)))
-        counters->frontier_overflow = 1;
+  const int lane = threadIdx.x & 63;
+  for (int c0 = 0; c0 < count; c0 += blockDim.x) {
+    const int c = c0 + threadIdx.x;
+    bool keep = false;
+    if (c < count) {
+      const float score = P.coarse_score[base + c];
+      keep = strict ? (score > best) : (score >= best);
+    }
+    // One reservation per wave: slots go to the kept lanes in lane order.
+    const unsigned long long mask = __ballot(keep);
+    if (mask == 0) continue;
+    int first = 0;
+    if (lane == 0) first = ListReserve(out, sub, __popcll(mask));
+    first = __builtin_amdgcn_readfirstlane(first);
+    if (keep) {
+      const int slot = first + __popcll(mask & ((1ull << lane) - 1));
+      if (!ListStore(out, sub, slot, CoarseNode(P, problem, s, c))) counters->frontier_overflow = 1;
     }
   }
 }
@@ -813,26 +833,56 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
     const int half = 1 << child_level, off = half - 1;
     const bool vx = nd.dx + half <= bd.y, vy = nd.dy + half <= bd.w;
     const uint32_t* __restrict__ pts = P.discrete + static_cast<size_t>(nd.scan) * n;
-    int s00 = 0, s01 = 0, s10 = 0, s11 = 0;
-#pragma unroll 4
-    for (int q = lane; q < n; q += kWave) {
-      const uint32_t p = pts[q];
-      const int x = static_cast<short>(p & 0xffffu) + nd.dx + off;
-      const int y = static_cast<short>(p >> 16) + nd.dy + off;
-      const bool x0 = static_cast<unsigned>(x) < static_cast<unsigned>(L.wx);
-      const bool x1 = vx && static_cast<unsigned>(x + half) < static_cast<unsigned>(L.wx);
-      const bool y0 = static_cast<unsigned>(y) < static_cast<unsigned>(L.wy);
-      const bool y1 = vy && static_cast<unsigned>(y + half) < static_cast<unsigned>(L.wy);
-      const int o00 = y * L.wx + x;
-      const int o01 = o00 + half * L.wx;
-      const unsigned v00 = L.cells[(x0 && y0) ? o00 : 0];
-      const unsigned v01 = L.cells[(x0 && y1) ? o01 : 0];
-      const unsigned v10 = L.cells[(x1 && y0) ? o00 + half : 0];
-      const unsigned v11 = L.cells[(x1 && y1) ? o01 + half : 0];
-      s00 += (x0 && y0) ? v00 : 0u;
-      s01 += (x0 && y1) ? v01 : 0u;
-      s10 += (x1 && y0) ? v10 : 0u;
-      s11 += (x1 && y1) ? v11 : 0u;
+    // Early exit.  A level-(l+1) cell is the maximum of the four level-l cells its
+    // children read (the 2h window is tiled by four h windows), so for every point
+    // max(children) <= parent value and
+    //   child_k total <= partial_k + (parent total - sum of max(children) so far).
+    // Most frontier nodes pass their own bound only marginally: after a few dozen
+    // points no child can reach the bound any more and the rest of the gathers
+    // (the expensive part: 64 distinct cache lines each) is skipped.  The outcome
+    // is the same as scoring all points: no child would have been kept.
+    const int parent_ub = SumUpperBound(P, nd.score, n);
+    int s00 = 0, s01 = 0, s10 = 0, s11 = 0, seen_max = 0;
+    bool dead = false;
+    constexpr int kGroup = 2 * kWave;     // points between two checks
+    for (int q0 = 0; q0 < n; q0 += kGroup) {
+#pragma unroll
+      for (int u = 0; u < kGroup / kWave; ++u) {
+        const int q = q0 + u * kWave + lane;
+        const bool live = q < n;
+        const uint32_t p = pts[live ? q : 0];
+        const int x = static_cast<short>(p & 0xffffu) + nd.dx + off;
+        const int y = static_cast<short>(p >> 16) + nd.dy + off;
+        const bool x0 = live && static_cast<unsigned>(x) < static_cast<unsigned>(L.wx);
+        const bool x1 = live && vx && static_cast<unsigned>(x + half) < static_cast<unsigned>(L.wx);
+        const bool y0 = static_cast<unsigned>(y) < static_cast<unsigned>(L.wy);
+        const bool y1 = vy && static_cast<unsigned>(y + half) < static_cast<unsigned>(L.wy);
+        const int o00 = y * L.wx + x;
+        const int o01 = o00 + half * L.wx;
+        const unsigned v00 = L.cells[(x0 && y0) ? o00 : 0];
+        const unsigned v01 = L.cells[(x0 && y1) ? o01 : 0];
+        const unsigned v10 = L.cells[(x1 && y0) ? o00 + half : 0];
+        const unsigned v11 = L.cells[(x1 && y1) ? o01 + half : 0];
+        const int a00 = (x0 && y0) ? v00 : 0u, a01 = (x0 && y1) ? v01 : 0u;
+        const int a10 = (x1 && y0) ? v10 : 0u, a11 = (x1 && y1) ? v11 : 0u;
+        s00 += a00; s01 += a01; s10 += a10; s11 += a11;
+        seen_max += max(max(a00, a01), max(a10, a11));
+      }
+      if (q0 + kGroup < n) {
+        const int rest = parent_ub - WaveSum(seen_max);
+        const int reach = max(max(WaveSum(s00), WaveSum(s01)), max(WaveSum(s10), WaveSum(s11)));
+        // kept children satisfy score >= best (> best in strict mode)
+        if (ToScore(P, reach + rest, n) < best) { dead = true; break; }
+      }
+    }
+    if (dead) {   // every child provably below the bound: counted, not kept
+      if (lane == 0) {
+        const int nvalid = (1 + (vx ? 1 : 0)) * (1 + (vy ? 1 : 0));
+        atomicAdd(&st.scored_shard[out_sub & (kStatShards - 1)],
+                  static_cast<unsigned long long>(nvalid));
+        atomicAdd(&st.expanded_shard[out_sub & (kStatShards - 1)], 1ull);
+      }
+      continue;
     }
     const int total[4] = {WaveSum(s00), WaveSum(s01), WaveSum(s10), WaveSum(s11)};
     ChildScratch cs;   // wave-uniform, in registers

@@ -76,7 +76,7 @@ def c5(cpu):
     full = world.scan(pos, yaw, 32, 512, seed=1)
     hi = full[::6].copy()          # ~2.7 k points after "voxel filtering"
     lo = full[::80].copy()         # ~200 points
-    scan_hist = np.roll(hist, -8).copy()
+    scan_hist = np.roll(hist, -19).copy()   # node yaw in the submap frame ~0.5 rad = 19 buckets
     opt = dict(branch_and_bound_depth=8, full_resolution_depth=3, min_rotational_score=0.77,
                min_low_resolution_score=0.55, linear_xy_search_window=5.0,
                linear_z_search_window=1.0, angular_search_window=math.radians(15.0))
