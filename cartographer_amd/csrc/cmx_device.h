@@ -34,6 +34,16 @@ __device__ __forceinline__ int LRoundF32(float x) {
   return static_cast<int>(t);
 }
 
+// Pointers read from descriptor structs in memory are "generic" to the compiler, which
+// then emits flat_load (LDS-aperture check, vmcnt and lgkmcnt both tied up, no partial
+// waits).  All such pointers are HBM addresses: say so, and the loads become global_load.
+// (Keep the result in an `auto` variable: converting back to a plain pointer drops it.)
+#define CMX_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ CMX_GLOBAL T* AsGlobal(T* p) {
+  return (CMX_GLOBAL T*)p;
+}
+
 struct F3 { float x, y, z; };
 struct Quat { float w, x, y, z; };
 

@@ -314,15 +314,17 @@ __device__ __forceinline__ int ScoreCandidateWave(const LevelDesc& L, int level,
                                                   int dy, int lane) {
   const int off = (1 << level) - 1;   // -offset_
   const int ax = dx + off, ay = dy + off;
+  const auto* cells = AsGlobal(L.cells);
+  const auto* gscan = AsGlobal(scan);
   int sum = 0;
 #pragma unroll 4
   for (int i = lane; i < n; i += kWave) {
-    const uint32_t p = scan[i];
+    const uint32_t p = gscan[i];
     const int x = static_cast<short>(p & 0xffffu) + ax;
     const int y = static_cast<short>(p >> 16) + ay;
     const bool ok = static_cast<unsigned>(x) < static_cast<unsigned>(L.wx) &&
                     static_cast<unsigned>(y) < static_cast<unsigned>(L.wy);
-    const unsigned v = L.cells[ok ? x + y * L.wx : 0];   // unconditional load, masked value
+    const unsigned v = cells[ok ? x + y * L.wx : 0];   // unconditional load, masked value
     sum += ok ? v : 0u;
   }
   return WaveSum(sum);
@@ -399,10 +401,10 @@ ScoreCoarsePlanesKernel(const Fast2DProblem* __restrict__ problems, int n,
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int M = P.sorted_count[s];
-  const uint32_t* __restrict__ rec = P.sorted + static_cast<size_t>(s) * n;
+  const auto* rec = AsGlobal(P.sorted) + static_cast<size_t>(s) * n;
   const int begin = static_cast<int>(static_cast<long long>(M) * wave / 4);
   const int end = static_cast<int>(static_cast<long long>(M) * (wave + 1) / 4);
-  const uint8_t* __restrict__ planes = P.planes;
+  const auto* planes = AsGlobal(P.planes);
   const int stride = P.plane_stride;
   const int PI = P.plane_i, PIJ = P.plane_i * P.plane_j;
   const int BW = dims.x + PI - 1;
@@ -450,7 +452,7 @@ ScoreCoarsePlanesKernel(const Fast2DProblem* __restrict__ problems, int n,
         for (int k = 0; k < kBatch; ++k) {
           r[k] = static_cast<uint32_t>(
               __builtin_amdgcn_readlane(static_cast<int>(mine[g]), (j0 + k) & 63));
-          const uint8_t* pp = planes + static_cast<size_t>(r[k] & 0xffffu) * stride + lane;
+          const auto* pp = planes + static_cast<size_t>(r[k] & 0xffffu) * stride + lane;
 #pragma unroll
           for (int c = 0; c < CHUNKS; ++c) v[k][c] = pp[c * 64];
         }
@@ -473,11 +475,13 @@ ScoreCoarsePlanesKernel(const Fast2DProblem* __restrict__ problems, int n,
   __syncthreads();
 
   const int base = P.coarse_off[s];
+  auto* coarse_sum = AsGlobal(P.coarse_sum) + base;
+  auto* coarse_score = AsGlobal(P.coarse_score) + base;
   int best_sum = -1, best_index = 0x7ffffff;  // idle threads (sum -1) never win
   for (int i = threadIdx.x; i < count; i += blockDim.x) {
     const int sum = cand_acc[i];
-    P.coarse_sum[base + i] = sum;
-    P.coarse_score[base + i] = ToScore(P, sum, n);
+    coarse_sum[i] = sum;
+    coarse_score[i] = ToScore(P, sum, n);
     if (sum > best_sum) { best_sum = sum; best_index = i; }
   }
   const int2 best = BlockBest(best_sum, best_index, scratch);
@@ -611,7 +615,8 @@ __device__ __forceinline__ void LoadContext(const Fast2DProblem& P, int n, int s
   const uint32_t* pts = P.discrete + static_cast<size_t>(scan) * n;
   const bool cached = n <= kPointCache;
   if (cached) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) ctx->cache[i] = pts[i];
+    const auto* gp = AsGlobal(pts);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) ctx->cache[i] = gp[i];
   }
   if (threadIdx.x < kMaxDepth && static_cast<int>(threadIdx.x) < P.depth)
     ctx->level[threadIdx.x] = P.level[threadIdx.x];
@@ -653,7 +658,8 @@ __device__ __forceinline__ void ScoreChildren(const BlockContext& ctx, int dx, i
   const int off = half - 1;
   const bool vx = dx + half <= ctx.max_x, vy = dy + half <= ctx.max_y;  // `break`s at :356,361
   const bool cached = ctx.cached;
-  const uint32_t* __restrict__ gpts = ctx.global_pts;
+  const auto* gpts = AsGlobal(ctx.global_pts);
+  const auto* cells = AsGlobal(L.cells);
   int s00 = 0, s01 = 0, s10 = 0, s11 = 0;   // s[x-step][y-step]
 #pragma unroll 4
   for (int i = threadIdx.x; i < n; i += 256) {
@@ -669,10 +675,10 @@ __device__ __forceinline__ void ScoreChildren(const BlockContext& ctx, int dx, i
     // (a load inside an `if` forces a wait per load).
     const int o00 = y * L.wx + x;
     const int o01 = o00 + half * L.wx;
-    const unsigned v00 = L.cells[(x0 && y0) ? o00 : 0];
-    const unsigned v01 = L.cells[(x0 && y1) ? o01 : 0];
-    const unsigned v10 = L.cells[(x1 && y0) ? o00 + half : 0];
-    const unsigned v11 = L.cells[(x1 && y1) ? o01 + half : 0];
+    const unsigned v00 = cells[(x0 && y0) ? o00 : 0];
+    const unsigned v01 = cells[(x0 && y1) ? o01 : 0];
+    const unsigned v10 = cells[(x1 && y0) ? o00 + half : 0];
+    const unsigned v11 = cells[(x1 && y1) ? o01 + half : 0];
     s00 += (x0 && y0) ? v00 : 0u;
     s01 += (x0 && y1) ? v01 : 0u;
     s10 += (x1 && y0) ? v10 : 0u;
@@ -790,7 +796,7 @@ FilterCoarseKernel(const Fast2DProblem* __restrict__ problems,
     const int c = c0 + threadIdx.x;
     bool keep = false;
     if (c < count) {
-      const float score = P.coarse_score[base + c];
+      const float score = AsGlobal(P.coarse_score)[base + c];
       keep = strict ? (score > best) : (score >= best);
     }
     // One reservation per wave: slots go to the kept lanes in lane order.
@@ -829,10 +835,11 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
     if (strict ? !(nd.score > best) : (nd.score < best)) continue;
     const int child_level = NodeLevel(nd) - 1;
     const LevelDesc L = P.level[child_level];
+    const auto* cells = AsGlobal(L.cells);
     const int4 bd = P.bounds[nd.scan];
     const int half = 1 << child_level, off = half - 1;
     const bool vx = nd.dx + half <= bd.y, vy = nd.dy + half <= bd.w;
-    const uint32_t* __restrict__ pts = P.discrete + static_cast<size_t>(nd.scan) * n;
+    const auto* pts = AsGlobal(P.discrete) + static_cast<size_t>(nd.scan) * n;
     // Early exit.  A level-(l+1) cell is the maximum of the four level-l cells its
     // children read (the 2h window is tiled by four h windows), so for every point
     // max(children) <= parent value and
@@ -859,10 +866,10 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
         const bool y1 = vy && static_cast<unsigned>(y + half) < static_cast<unsigned>(L.wy);
         const int o00 = y * L.wx + x;
         const int o01 = o00 + half * L.wx;
-        const unsigned v00 = L.cells[(x0 && y0) ? o00 : 0];
-        const unsigned v01 = L.cells[(x0 && y1) ? o01 : 0];
-        const unsigned v10 = L.cells[(x1 && y0) ? o00 + half : 0];
-        const unsigned v11 = L.cells[(x1 && y1) ? o01 + half : 0];
+        const unsigned v00 = cells[(x0 && y0) ? o00 : 0];
+        const unsigned v01 = cells[(x0 && y1) ? o01 : 0];
+        const unsigned v10 = cells[(x1 && y0) ? o00 + half : 0];
+        const unsigned v11 = cells[(x1 && y1) ? o01 + half : 0];
         const int a00 = (x0 && y0) ? v00 : 0u, a01 = (x0 && y1) ? v01 : 0u;
         const int a10 = (x1 && y0) ? v10 : 0u, a11 = (x1 && y1) ? v11 : 0u;
         s00 += a00; s01 += a01; s10 += a10; s11 += a11;
