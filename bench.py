@@ -53,8 +53,9 @@ def pmc_traffic_bytes():
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=200,
+                    help="untimed steps; a step is ~0.3 ms, so the default also lets clocks settle")
     ap.add_argument("--submaps", type=int, default=1, help="submaps searched per step per GPU")
     ap.add_argument("--grid", type=int, default=400)
     ap.add_argument("--depth", type=int, default=7)

@@ -555,7 +555,12 @@ __device__ __forceinline__ Node2D CoarseNode(const Fast2DProblem& P, int problem
 __global__ void __launch_bounds__(1024)
 SeedSelectKernel(const Fast2DProblem* __restrict__ problems,
                  const ProblemState* __restrict__ states, int n, Node2D* __restrict__ seeds,
-                 int* __restrict__ seed_count) {
+                 int* __restrict__ seed_count, int* __restrict__ counters_words,
+                 int num_counter_words) {
+  // First kernel of the search: it also clears the list counters (saves a memset
+  // and its launch gap).
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < num_counter_words; i += blockDim.x) counters_words[i] = 0;
   const int problem = blockIdx.x;
   const Fast2DProblem& P = problems[problem];
   __shared__ int hist[1024];
@@ -1063,7 +1068,9 @@ struct SelectState {         // per problem, device
 
 __global__ void __launch_bounds__(1024)
 SelectBestKernel(NodeList leaves, const ProblemState* __restrict__ states,
-                 SelectState* __restrict__ sel, BestLeaf* __restrict__ best, int num_problems) {
+                 SelectState* __restrict__ sel, BestLeaf* __restrict__ best, int num_problems,
+                 ProblemState* __restrict__ states_out) {
+  for (int p = threadIdx.x; p < num_problems; p += blockDim.x) states_out[p] = states[p];
   const int max_count = ListMaxCount(leaves);
   const int total = max_count * kSubLists;
   auto leaf_at = [&](int i, Node2D* nd) {
@@ -1146,8 +1153,10 @@ SelectBestKernel(NodeList leaves, const ProblemState* __restrict__ states,
 // (BranchAndBound returns candidates[0], SM2/fast_...2d.cc:340-343).
 __global__ void __launch_bounds__(1024)
 SelectDepthOneKernel(const Fast2DProblem* __restrict__ problems,
-                     const ProblemState* __restrict__ states, int n, BestLeaf* __restrict__ best) {
+                     const ProblemState* __restrict__ states, int n, BestLeaf* __restrict__ best,
+                     ProblemState* __restrict__ states_out) {
   const int problem = blockIdx.x;
+  if (threadIdx.x == 0) states_out[problem] = states[problem];
   const Fast2DProblem& P = problems[problem];
   __shared__ unsigned long long keys[16];
   unsigned long long key = 0;
@@ -1512,16 +1521,22 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
                         ws.dev[11].ReserveAs<Node2D>(kFrontierCapacity)};
   Node2D* d_leaves = ws.dev[12].ReserveAs<Node2D>(kLeafCapacity);
   Node2D* d_seeds = ws.dev[13].ReserveAs<Node2D>(static_cast<size_t>(kSeedsPerProblem) * num);
+  // Counters | SelectState[num] | BestLeaf[num] | ProblemState[num] (copy for the host) |
+  // seed counts: the first four travel back in ONE D2H.
   char* d_misc = static_cast<char*>(ws.dev[14].Reserve(
-      sizeof(Counters) + num * (sizeof(SelectState) + sizeof(BestLeaf) + sizeof(int))));
+      sizeof(Counters) +
+      num * (sizeof(SelectState) + sizeof(BestLeaf) + sizeof(ProblemState) + sizeof(int))));
   Counters* d_counters = reinterpret_cast<Counters*>(d_misc);
   SelectState* d_sel = reinterpret_cast<SelectState*>(d_misc + sizeof(Counters));
   BestLeaf* d_best = reinterpret_cast<BestLeaf*>(d_misc + sizeof(Counters) +
                                                  num * sizeof(SelectState));
-  int* d_seed_count = reinterpret_cast<int*>(d_misc + sizeof(Counters) +
-                                             num * (sizeof(SelectState) + sizeof(BestLeaf)));
+  ProblemState* d_states_out = reinterpret_cast<ProblemState*>(
+      d_misc + sizeof(Counters) + num * (sizeof(SelectState) + sizeof(BestLeaf)));
+  int* d_seed_count = reinterpret_cast<int*>(
+      d_misc + sizeof(Counters) +
+      num * (sizeof(SelectState) + sizeof(BestLeaf) + sizeof(ProblemState)));
   Counters* h_counters = nullptr;
-  CMX_HIP(hipMemsetAsync(d_counters, 0, sizeof(Counters), ws.stream));
+  if (depth == 1) CMX_HIP(hipMemsetAsync(d_counters, 0, sizeof(Counters), ws.stream));
   auto mark = [&](const char* name) { if (batch.trace) batch.trace->Mark(name); };
   // Stage k reads list k and appends to list k+1 (buffers ping-pong, counters
   // do not: they are all zeroed by the one memset above).
@@ -1531,28 +1546,30 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
   const NodeList leaf_list = {d_leaves, d_counters->leaves, kLeafSub};
 
   // One D2H for counters + selection state + best leaves (contiguous in d_misc).
-  const size_t misc_bytes = sizeof(Counters) + num * (sizeof(SelectState) + sizeof(BestLeaf));
+  const size_t misc_bytes =
+      sizeof(Counters) + num * (sizeof(SelectState) + sizeof(BestLeaf) + sizeof(ProblemState));
   char* h_misc = static_cast<char*>(ws.pinned[3].Reserve(misc_bytes));
   h_counters = reinterpret_cast<Counters*>(h_misc);
   BestLeaf* h_best = reinterpret_cast<BestLeaf*>(h_misc + sizeof(Counters) +
                                                  num * sizeof(SelectState));
-  ProblemState* h_states = ws.pinned[2].ReserveAs<ProblemState>(num);
+  ProblemState* h_states = reinterpret_cast<ProblemState*>(
+      h_misc + sizeof(Counters) + num * (sizeof(SelectState) + sizeof(BestLeaf)));
   auto fetch_results = [&] {
     CMX_HIP(hipMemcpyAsync(h_misc, d_misc, misc_bytes, hipMemcpyDeviceToHost, ws.stream));
-    CMX_HIP(hipMemcpyAsync(h_states, batch.d_states, num * sizeof(ProblemState),
-                           hipMemcpyDeviceToHost, ws.stream));
     CMX_HIP(hipStreamSynchronize(ws.stream));
   };
 
   if (depth == 1) {
-    SelectDepthOneKernel<<<num, 1024, 0, ws.stream>>>(batch.d_problems, batch.d_states, n, d_best);
+    SelectDepthOneKernel<<<num, 1024, 0, ws.stream>>>(batch.d_problems, batch.d_states, n, d_best,
+                                                      d_states_out);
     CMX_HIP(hipGetLastError());
     CMX_HIP(hipEventRecord(ws.ev_end, ws.stream));
     fetch_results();
   } else {
     // ---- dive -------------------------------------------------------------
-    SeedSelectKernel<<<num, 1024, 0, ws.stream>>>(batch.d_problems, batch.d_states, n, d_seeds,
-                                                  d_seed_count);
+    SeedSelectKernel<<<num, 1024, 0, ws.stream>>>(
+        batch.d_problems, batch.d_states, n, d_seeds, d_seed_count,
+        reinterpret_cast<int*>(d_counters), static_cast<int>(sizeof(Counters) / sizeof(int)));
     DiveKernel<<<dim3(kSeedsPerProblem, num), 256, 0, ws.stream>>>(
         batch.d_problems, batch.d_states, n, d_seeds, d_seed_count, leaf_list, d_counters);
     mark("seed+dive");
@@ -1610,7 +1627,8 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
           mark("subtree");
         }
       }
-      SelectBestKernel<<<1, 1024, 0, ws.stream>>>(leaf_list, batch.d_states, d_sel, d_best, num);
+      SelectBestKernel<<<1, 1024, 0, ws.stream>>>(leaf_list, batch.d_states, d_sel, d_best, num,
+                                                  d_states_out);
       mark("select");
       CMX_HIP(hipGetLastError());
       CMX_HIP(hipEventRecord(ws.ev_end, ws.stream));

@@ -78,7 +78,7 @@ def c5(cpu):
     lo = full[::80].copy()         # ~200 points
     scan_hist = np.roll(hist, -19).copy()   # node yaw in the submap frame ~0.5 rad = 19 buckets
     opt = dict(branch_and_bound_depth=8, full_resolution_depth=3, min_rotational_score=0.77,
-               min_low_resolution_score=0.55, linear_xy_search_window=5.0,
+               min_low_resolution_score=0.35, linear_xy_search_window=5.0,
                linear_z_search_window=1.0, angular_search_window=math.radians(15.0))
     t0 = time.perf_counter()
     gm = sm3.FastCorrelativeScanMatcher3D(0.1, vox, grid.grid_size, 0.45, low_vox, hist, **opt)
@@ -86,7 +86,7 @@ def c5(cpu):
     node = sm3.Rigid3d((pos[0] + 0.8, pos[1] - 0.6, pos[2] + 0.2),
                        (math.cos((yaw + 0.1) / 2), 0.0, 0.0, math.sin((yaw + 0.1) / 2)))
     data = sm3.TrajectoryNodeData(hi, lo, scan_hist)
-    dt, got = timeit(lambda: gm.match(node, sm3.Rigid3d(), data, 0.4), 5, warm=1)
+    dt, got = timeit(lambda: gm.match(node, sm3.Rigid3d(), data, 0.2), 5, warm=1)
     st = gm.last_stats
     print(f"C5 fast3d (1 submap): create {t_create * 1e3:.1f} ms; match {dt * 1e3:.2f} ms wall, "
           f"device {st['device_ms']:.2f} ms, kernel {st['dominant_kernel_ms']:.3f} ms, "
@@ -96,11 +96,11 @@ def c5(cpu):
           f"found {got is not None} score {got['score'] if got else None}")
     if cpu:
         from oracle import pyoracle as orc
-        om = orc.FastCorrelativeScanMatcher3D(0.1, vox, 0.45, low_vox, hist, 8, 3, 0.77, 0.55, 5.0,
+        om = orc.FastCorrelativeScanMatcher3D(0.1, vox, 0.45, low_vox, hist, 8, 3, 0.77, 0.35, 5.0,
                                               1.0, math.radians(15.0))
         t0 = time.perf_counter()
         ref = om.match(list(node.translation) + list(node.rotation), [0, 0, 0, 1, 0, 0, 0],
-                       [1, 0, 0, 0], hi, lo, scan_hist, 0.4)
+                       [1, 0, 0, 0], hi, lo, scan_hist, 0.2)
         t = time.perf_counter() - t0
         print(f"   oracle 1 thread: {t * 1e3:.1f} ms; found {ref['found']} score "
               f"{ref.get('score')} (gpu equal: "
