@@ -41,7 +41,8 @@ namespace {
 constexpr int kMaxBuckets = 4096;      // LDS histogram size of the point bucketing
 constexpr int kMaxPlaneCells = 256;    // plane_i * plane_j
 constexpr int kMaxPlaneWidth = 128;    // w; plane index fits 14 bits
-constexpr int kMaxCoarsePerScan = 4096;  // LDS accumulators of the plane kernel
+constexpr int kMaxCoarsePerScan = 4096;  // lowest-resolution candidates per scan (plane kernel)
+constexpr int kMaxAccCells = 12288;      // padded LDS accumulators of the plane kernel (48 KB)
 constexpr int kSeedsPerProblem = 64;
 
 // ---------------------------------------------------------------------------
@@ -191,12 +192,13 @@ PrepScansKernel(const Fast2DProblem* __restrict__ problems, const float* __restr
   const int NB = BW * BH;   // <= kMaxBuckets (checked on the host with upper bounds)
   for (int b = threadIdx.x; b < NB; b += blockDim.x) hist[b] = 0;
   __syncthreads();
-  auto classify = [&](uint32_t packed, int* bucket, int* plane) {
+  auto classify = [&](uint32_t packed, int* bucket, int* plane, uint32_t* block = nullptr) {
     const int U = static_cast<short>(packed & 0xffffu) + bd.x + w - 1;
     const int V = static_cast<short>(packed >> 16) + bd.z + w - 1;
     const int bx = (U >> shift) + dims.x - 1, by = (V >> shift) + dims.y - 1;
     *plane = (V & (w - 1)) * w + (U & (w - 1));
     *bucket = (bx >= 0 && bx < BW && by >= 0 && by < BH) ? by * BW + bx : -1;
+    if (block) *block = static_cast<uint32_t>(bx) | (static_cast<uint32_t>(by) << 8);
   };
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     int bucket, plane;
@@ -236,10 +238,13 @@ PrepScansKernel(const Fast2DProblem* __restrict__ problems, const float* __restr
   uint32_t* sorted = P.sorted + static_cast<size_t>(s) * n;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     int bucket, plane;
-    classify(out[i], &bucket, &plane);
+    uint32_t block;
+    classify(out[i], &bucket, &plane, &block);
     if (bucket >= 0) {
       const int pos = atomicAdd(&hist[bucket], 1);
-      sorted[pos] = static_cast<uint32_t>(plane) | (static_cast<uint32_t>(bucket) << 16);
+      // plane | lattice block (bx | by << 8) << 16: the scorer needs the block's
+      // coordinates, not its linear index (no division in its flush).
+      sorted[pos] = static_cast<uint32_t>(plane) | (block << 16);
     }
   }
 }
@@ -344,7 +349,7 @@ __device__ __forceinline__ int2 BlockBest(int sum, int index, int2* scratch /*[4
   __syncthreads();
   int2 best = scratch[0];
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < static_cast<int>(blockDim.x >> 6); ++w) {
       const int2 o = scratch[w];
       if (o.x > best.x || (o.x == best.x && o.y < best.y)) best = o;
     }
@@ -391,87 +396,96 @@ ScoreCoarsePlanesKernel(const Fast2DProblem* __restrict__ problems, int n,
   const int s = blockIdx.x;
   if (s >= P.num_scans || states[blockIdx.y].error || !P.use_planes) return;
   if ((P.plane_stride >> 6) != CHUNKS) return;
-  __shared__ int cand_acc[kMaxCoarsePerScan];
+  // Candidate accumulators, padded by the plane extent on every side: a lane's cell
+  // (I, J) in lattice block (bx, by) belongs to candidate
+  //   (ix, iy) = (I - bx + dims.x - 1, J - by + dims.y - 1),
+  // which may lie outside [0, dims); with the padding its accumulator index
+  //   (ix + PI - 1) * pitch + (iy + PJ - 1) = lane_const - (bx * pitch + by)
+  // is always inside the array, so a flush is one subtract and one LDS add per lane,
+  // no bounds logic (out-of-range candidates collect in padding nobody reads).
+  extern __shared__ int cand_acc[];
   __shared__ int2 scratch[4];
   const int2 dims = P.coarse_dims[s];
   const int count = dims.x * dims.y;
-  for (int i = threadIdx.x; i < count; i += blockDim.x) cand_acc[i] = 0;
+  const int PI = P.plane_i, PJ = P.plane_j, PIJ = PI * PJ;
+  const int pitch = dims.y + 2 * PJ - 2;
+  const int acc_cells = (dims.x + 2 * PI - 2) * pitch;
+  for (int i = threadIdx.x; i < acc_cells; i += blockDim.x) cand_acc[i] = 0;
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int M = P.sorted_count[s];
   const auto* rec = AsGlobal(P.sorted) + static_cast<size_t>(s) * n;
-  const int begin = static_cast<int>(static_cast<long long>(M) * wave / 4);
-  const int end = static_cast<int>(static_cast<long long>(M) * (wave + 1) / 4);
-  const auto* planes = AsGlobal(P.planes);
+  const int waves = blockDim.x >> 6;     // 2..4, chosen by the host (see the launch)
+  const int begin = static_cast<int>(static_cast<long long>(M) * wave / waves);
+  const int end = static_cast<int>(static_cast<long long>(M) * (wave + 1) / waves);
   const int stride = P.plane_stride;
-  const int PI = P.plane_i, PIJ = P.plane_i * P.plane_j;
-  const int BW = dims.x + PI - 1;
   const unsigned zero_plane = 1u << (2 * (P.depth - 1));   // index w*w: the all-zero plane
 
-  int acc[CHUNKS];
+  int acc[CHUNKS], lane_const[CHUNKS];
 #pragma unroll
-  for (int c = 0; c < CHUNKS; ++c) acc[c] = 0;
+  for (int c = 0; c < CHUNKS; ++c) {
+    acc[c] = 0;
+    // Lanes past the plane read its zero padding: let them add 0 to the last cell.
+    const int cell = min(c * 64 + lane, PIJ - 1);
+    lane_const[c] = (cell % PI + dims.x + PI - 2) * pitch + (cell / PI + dims.y + PJ - 2);
+  }
   int cur = -1;
-
-  auto flush = [&](int bucket) {
-    const int ax = bucket % BW - (dims.x - 1), ay = bucket / BW - (dims.y - 1);
+  auto flush = [&](int block) {
+    const int block_const = (block & 0xff) * pitch + (block >> 8);
 #pragma unroll
     for (int c = 0; c < CHUNKS; ++c) {
-      const int cell = c * 64 + lane;
-      const int I = cell % PI, J = cell / PI;
-      const int ix = I - ax, iy = J - ay;
-      if (cell < PIJ && acc[c] != 0 && ix >= 0 && ix < dims.x && iy >= 0 && iy < dims.y) {
-        atomicAdd(&cand_acc[ix * dims.y + iy], acc[c]);   // x outer, y inner (:295-307)
-      }
+      atomicAdd(&cand_acc[lane_const[c] - block_const], acc[c]);
       acc[c] = 0;
     }
   };
 
-  // Records are wave-uniform: 64 of them arrive with one coalesced load (one
-  // per lane) and are broadcast with readlane; kBatch plane loads are in flight
-  // before the first one is consumed.  The tail reads the all-zero plane.
+  // Records are wave-uniform: 64 of them arrive with one coalesced load (one per lane,
+  // the next 64 prefetched meanwhile) and are broadcast with v_readlane (immediate lane
+  // index: the batch loops are fully unrolled).  A plane read is a buffer load: lane
+  // offset in a VGPR, plane offset in an SGPR, no vector address arithmetic.  kBatch
+  // plane loads are in flight before the first one is consumed.  Lanes past `end` hold
+  // the sentinel (all-zero plane, block 0xffff): adding zeros changes nothing.
   constexpr int kBatch = CHUNKS == 1 ? 32 : (CHUNKS == 2 ? 16 : 8);
   const uint32_t sentinel = 0xffff0000u | zero_plane;
-  for (int base_i = begin; base_i < end; base_i += 256) {
-    // Up to 256 records of this wave in four registers, all four loads in flight.
-    uint32_t mine[4];
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(P.planes), 0, static_cast<int>((zero_plane + 1) * stride), 0x00020000);
+  uint32_t mine = begin + lane < end ? rec[begin + lane] : sentinel;
+  for (int base_i = begin; base_i < end; base_i += 64) {
+    uint32_t next = sentinel;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int idx = base_i + g * 64 + lane;
-      mine[g] = idx < end ? rec[idx] : sentinel;
-    }
+    for (int j0 = 0; j0 < 64; j0 += kBatch) {
+      if (base_i + j0 >= end) break;          // wave-uniform
+      uint32_t r[kBatch];
+      int v[kBatch][CHUNKS];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int cnt = min(64, end - (base_i + g * 64));   // <= 0: nothing left
-      for (int j0 = 0; j0 < cnt; j0 += kBatch) {
-        uint32_t r[kBatch];
-        int v[kBatch][CHUNKS];
+      for (int k = 0; k < kBatch; ++k) {
+        r[k] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine), j0 + k));
+        const int plane_offset = static_cast<int>(r[k] & 0xffffu) * stride;
 #pragma unroll
-        for (int k = 0; k < kBatch; ++k) {
-          r[k] = static_cast<uint32_t>(
-              __builtin_amdgcn_readlane(static_cast<int>(mine[g]), (j0 + k) & 63));
-          const auto* pp = planes + static_cast<size_t>(r[k] & 0xffffu) * stride + lane;
+        for (int c = 0; c < CHUNKS; ++c)
+          v[k][c] = __builtin_amdgcn_raw_buffer_load_b8(rsrc, lane + c * 64, plane_offset, 0);
+      }
+      if (j0 == 0) {   // prefetch the next 64 records behind this batch's plane loads
+        const int nidx = base_i + 64 + lane;
+        next = rec[min(nidx, end - 1)];
+        if (nidx >= end) next = sentinel;
+      }
 #pragma unroll
-          for (int c = 0; c < CHUNKS; ++c) v[k][c] = pp[c * 64];
+      for (int k = 0; k < kBatch; ++k) {
+        const int block = static_cast<int>(r[k] >> 16);
+        if (block != cur) {
+          if (cur >= 0) flush(cur);
+          cur = block;     // the sentinel block (0xffff) only ever follows real ones
         }
 #pragma unroll
-        for (int k = 0; k < kBatch; ++k) {
-          const int bucket = static_cast<int>(r[k] >> 16);
-          if (bucket != 0xffff) {
-            if (bucket != cur) {
-              if (cur >= 0) flush(cur);
-              cur = bucket;
-            }
-#pragma unroll
-            for (int c = 0; c < CHUNKS; ++c) acc[c] += v[k][c];
-          }
-        }
+        for (int c = 0; c < CHUNKS; ++c) acc[c] += v[k][c];
       }
     }
+    mine = next;
   }
-  if (cur >= 0) flush(cur);
+  if (cur >= 0 && cur != 0xffff) flush(cur);
   __syncthreads();
 
   const int base = P.coarse_off[s];
@@ -479,7 +493,8 @@ ScoreCoarsePlanesKernel(const Fast2DProblem* __restrict__ problems, int n,
   auto* coarse_score = AsGlobal(P.coarse_score) + base;
   int best_sum = -1, best_index = 0x7ffffff;  // idle threads (sum -1) never win
   for (int i = threadIdx.x; i < count; i += blockDim.x) {
-    const int sum = cand_acc[i];
+    const int ix = i / dims.y, iy = i - ix * dims.y;
+    const int sum = cand_acc[(ix + PI - 1) * pitch + (iy + PJ - 1)];
     coarse_sum[i] = sum;
     coarse_score[i] = ToScore(P, sum, n);
     if (sum > best_sum) { best_sum = sum; best_index = i; }
@@ -1336,6 +1351,7 @@ struct PreparedBatch {
   int num_problems = 0;
   int n = 0;
   int max_scans = 0;
+  long long plane_acc_cells = 0;   // LDS accumulators the plane kernel needs (upper bound)
   std::vector<HostSearch> search;
   std::vector<cmx_pose2d> initial;
   Fast2DProblem* d_problems = nullptr;
@@ -1394,7 +1410,12 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     P.coarse_capacity = static_cast<int>(cap);
     P.use_planes = m.planes() != nullptr && ax * ay <= kMaxCoarsePerScan &&
                    (ax + m.plane_i() - 1) * (ay + m.plane_j() - 1) <= kMaxBuckets &&
+                   ax + m.plane_i() - 1 <= 255 && ay + m.plane_j() - 1 <= 255 &&   // 8-bit bx, by
+                   (ax + 2 * m.plane_i() - 2) * (ay + 2 * m.plane_j() - 2) <= kMaxAccCells &&
                    m.depth() > 1;
+    if (P.use_planes)
+      out->plane_acc_cells = std::max<long long>(
+          out->plane_acc_cells, (ax + 2 * m.plane_i() - 2) * (ay + 2 * m.plane_j() - 2));
     coarse_total += cap;
   }
 
@@ -1478,15 +1499,26 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     if (P.use_planes) chunk_mask |= 1 << (P.plane_stride >> 6);
     else any_generic = true;
   }
+  const size_t acc_bytes = static_cast<size_t>(out->plane_acc_cells) * sizeof(int);
+  // Waves per rotation (the kernel takes 2..4).  Measured on the bench workload: 4 waves
+  // 45 us, 3 waves (everything resident in one round) 48 us -- the kernel is bound by
+  // instruction issue (~10 instructions per record, SQ counters in DESIGN.md), not by
+  // residency, so more, shorter waves win.
+  const int plane_waves = 4;
+  const int plane_threads = 64 * plane_waves;
   CMX_HIP(hipEventRecord(ws.ev_k0, ws.stream));
   if (chunk_mask & (1 << 1))
-    ScoreCoarsePlanesKernel<1><<<per_scan, 256, 0, ws.stream>>>(out->d_problems, n, out->d_states);
+    ScoreCoarsePlanesKernel<1><<<per_scan, plane_threads, acc_bytes, ws.stream>>>(
+        out->d_problems, n, out->d_states);
   if (chunk_mask & (1 << 2))
-    ScoreCoarsePlanesKernel<2><<<per_scan, 256, 0, ws.stream>>>(out->d_problems, n, out->d_states);
+    ScoreCoarsePlanesKernel<2><<<per_scan, plane_threads, acc_bytes, ws.stream>>>(
+        out->d_problems, n, out->d_states);
   if (chunk_mask & (1 << 3))
-    ScoreCoarsePlanesKernel<3><<<per_scan, 256, 0, ws.stream>>>(out->d_problems, n, out->d_states);
+    ScoreCoarsePlanesKernel<3><<<per_scan, plane_threads, acc_bytes, ws.stream>>>(
+        out->d_problems, n, out->d_states);
   if (chunk_mask & (1 << 4))
-    ScoreCoarsePlanesKernel<4><<<per_scan, 256, 0, ws.stream>>>(out->d_problems, n, out->d_states);
+    ScoreCoarsePlanesKernel<4><<<per_scan, plane_threads, acc_bytes, ws.stream>>>(
+        out->d_problems, n, out->d_states);
   if (any_generic)
     ScoreCoarseGenericKernel<<<per_scan, 256, 0, ws.stream>>>(out->d_problems, n, out->d_states);
   CMX_HIP(hipEventRecord(ws.ev_k1, ws.stream));
