@@ -63,6 +63,8 @@ def parse_args():
     ap.add_argument("--min-score", type=float, default=0.6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and run the collectives even with one rank (plumbing test)")
     return ap.parse_args()
 
 
@@ -109,9 +111,14 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world_size > 1:
+    use_dist = args.gpus > 1 or world_size > 1 or args.force_dist
+    if use_dist:
         assert world_size == args.gpus, "launch with torch.distributed.run --nproc-per-node N"
         torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = local_rank if torch.cuda.is_available() else 0
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
@@ -143,7 +150,7 @@ def main():
 
     def step():
         found, scores, poses, stats = sm.match_full_submap_batch(matchers, cloud, args.min_score)
-        if world_size > 1:
+        if use_dist:
             # packed (score bits << 32 | global submap id): max == best match of the node
             best_key.fill_(sharding.pack_best_key(found, scores, rank * n_sub))
             dist.all_reduce(best_key, op=dist.ReduceOp.MAX)
@@ -154,7 +161,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world_size > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -174,7 +181,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     # MAX over ranks of the elapsed time; SUM of the work.
-    if world_size > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -184,6 +191,7 @@ def main():
     else:
         cand_total, coarse_total = cand, coarse
 
+    out = None
     if rank == 0:
         value = cand_total / elapsed
         # Roofline of the dominant kernel (lowest-resolution scoring): algorithmic
@@ -238,10 +246,16 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cells0, lim0, args.depth, scan, args.min_score,
                                                args.cpu_seconds)
-        print(json.dumps(out))
-    if world_size > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio, which a pipe only sees at exit:
+        # drain it first so that the JSON line is the LAST thing on stdout.
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":
