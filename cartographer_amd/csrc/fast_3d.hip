@@ -252,43 +252,59 @@ Filter3DKernel(Fast3DProblem P, int strict, List3 out, Counters3* __restrict__ c
   }
 }
 
-// CreateLowResolutionMatcher's lambda (SM3/low_resolution_matcher.cc:23-35) for
-// the pose of one leaf: probabilities are computed in parallel, then summed
-// sequentially in point order as the reference does.
+// CreateLowResolutionMatcher's lambda (SM3/low_resolution_matcher.cc:23-35) for the pose
+// of one leaf, by a whole block: the per-point probabilities are computed in parallel
+// into LDS, then summed sequentially in point order (as the reference does) by every
+// thread from LDS broadcasts.
+constexpr int kLowChunk = 2048;
+
 __device__ __forceinline__ float LowResolutionScore(const Fast3DProblem& P, const Quat& q, float tx,
-                                                    float ty, float tz, int lane) {
-  (void)lane;
-  // Every lane evaluates the same (wave-uniform) sequential f32 sum; leaves that
-  // reach this point are few, the low-resolution cloud is small.
+                                                    float ty, float tz, float* prob /*[kLowChunk]*/) {
   float acc = 0.f;
-#pragma unroll 4
-  for (int i = 0; i < P.n_low; ++i) {
-    const F3 p{P.low_xyz[3 * i], P.low_xyz[3 * i + 1], P.low_xyz[3 * i + 2]};
-    const F3 r = Rotate(q, p);
-    const F3 t{r.x + tx, r.y + ty, r.z + tz};
-    const int3 c = CellIndex3(t, P.low_resolution);
-    acc += ValueToProbabilityDev(BrickValueU16(P.low, c.x, c.y, c.z));
+  for (int base = 0; base < P.n_low; base += kLowChunk) {
+    const int cnt = min(kLowChunk, P.n_low - base);
+    __syncthreads();                                   // previous chunk consumed
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+      const float* xyz = P.low_xyz + 3 * static_cast<size_t>(base + i);
+      const F3 r = Rotate(q, F3{xyz[0], xyz[1], xyz[2]});
+      const F3 t{r.x + tx, r.y + ty, r.z + tz};
+      const int3 c = CellIndex3(t, P.low_resolution);
+      prob[i] = ValueToProbabilityDev(BrickValueU16(P.low, c.x, c.y, c.z));
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int i = 0; i < cnt; ++i) acc += prob[i];
   }
   return acc / static_cast<float>(P.n_low);
 }
 
-// One wave per node: scores the <=8 children (z outer, y, x inner with the
-// `break`s of :416-431), ranks them as the reference's stable descending sort
-// does, then
+// One 256-thread block per node: scores the <=8 children (z outer, y, x inner with the
+// `break`s of :416-431), ranks them as the reference's stable descending sort does, then
 //   child depth > 0, full: children that can still matter go to `out`;
 //   child depth > 0, dive: only the best child continues;
-//   child depth == 0: leaves are verified in rank order with the
-//     low-resolution matcher; the first one that passes is recorded (:389-402).
+//   child depth == 0: leaves are verified in rank order with the low-resolution
+//     matcher; the first one that passes is recorded (:389-402).
+// A search expands a few thousand nodes in total, so what matters is the latency of
+// one expansion: four waves share the points, the eight child cells of a point are
+// addressed from per-axis clamped offsets (two positions per axis), and the loads of
+// several points are in flight together.
 __global__ void __launch_bounds__(256)
 Expand3DKernel(Fast3DProblem P, List3 in, int dive, int strict, List3 out, List3 leaves,
                Counters3* __restrict__ counters) {
+  __shared__ int partial[4][8];
+  __shared__ float sh_score[8];
+  __shared__ float low_prob[kLowChunk];
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = threadIdx.x >> 6;
   const int max_count = ListMax3(in);
-  const int sub_id = (blockIdx.x * 4 + wave) & (kSubLists3 - 1);
-  for (int i = blockIdx.x * 4 + wave; i < max_count * kSubLists3; i += gridDim.x * 4) {
+  for (int i = blockIdx.x; i < max_count * kSubLists3; i += gridDim.x) {
     const int in_sub = i & (kSubLists3 - 1), j = i / kSubLists3;
-    if (j >= min(in.counts[in_sub], in.sub_capacity)) continue;   // wave-uniform
+    if (j >= min(in.counts[in_sub], in.sub_capacity)) continue;   // block-uniform
+    // Children go to a sub-list derived from the node's slot, not from the block: the
+    // survivors of a search cluster in a few subtrees, and appending them to their
+    // parent's sub-list would leave the next level with one long list that a handful
+    // of blocks walk serially (measured: 0.9 us per node, chip idle).
+    const int sub_id = (in_sub * 17 + j) & (kSubLists3 - 1);
     const Node3D nd = in.nodes[static_cast<size_t>(in_sub) * in.sub_capacity + j];
     const float best = __uint_as_float(
         __hip_atomic_load(&counters->best_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -296,33 +312,59 @@ Expand3DKernel(Fast3DProblem P, List3 in, int dive, int strict, List3 out, List3
     const int child_depth = nd.level - 1;
     const int half = 1 << child_depth;
     const int e = max(0, child_depth - P.full_resolution_depth + 1);
-    const Brick& L = P.level[child_depth];
+    const Brick L = P.level[child_depth];
+    const uint8_t* __restrict__ cells8 = static_cast<const uint8_t*>(L.cells);
     const int4* __restrict__ cells = P.cells + static_cast<size_t>(nd.scan) * P.n;
     const bool vx = nd.ox + half <= P.wxy, vy = nd.oy + half <= P.wxy, vz = nd.oz + half <= P.wz;
-    // Shifted offsets of the 2 positions per axis.
-    const int fx0 = nd.ox >> e, fx1 = (nd.ox + half) >> e;
-    const int fy0 = nd.oy >> e, fy1 = (nd.oy + half) >> e;
-    const int fz0 = nd.oz >> e, fz1 = (nd.oz + half) >> e;
+    // Shifted offsets of the 2 positions per axis, relative to the brick origin.
+    const int fx[2] = {(nd.ox >> e) - L.lo_x, ((nd.ox + half) >> e) - L.lo_x};
+    const int fy[2] = {(nd.oy >> e) - L.lo_y, ((nd.oy + half) >> e) - L.lo_y};
+    const int fz[2] = {(nd.oz >> e) - L.lo_z, ((nd.oz + half) >> e) - L.lo_z};
+    const int row = L.nx, slab = L.nx * L.ny;
     int sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 2
-    for (int q = lane; q < P.n; q += kWave) {
+    for (int q = threadIdx.x; q < P.n; q += 256) {
       const int3 d = DepthIndex(cells[q], e, -P.wxy, -P.wxy, -P.wz);
+      // Per axis and position: in-range flag and (clamped) address term.
+      int ax[2], ay[2], az[2];
+      bool okx[2], oky[2], okz[2];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int cx = d.x + ((k & 1) ? fx1 : fx0);
-        const int cy = d.y + ((k & 2) ? fy1 : fy0);
-        const int cz = d.z + ((k & 4) ? fz1 : fz0);
-        sum[k] += BrickValueU8(L, cx, cy, cz);
+      for (int b = 0; b < 2; ++b) {
+        const int ix = d.x + fx[b], iy = d.y + fy[b], iz = d.z + fz[b];
+        okx[b] = static_cast<unsigned>(ix) < static_cast<unsigned>(L.nx);
+        oky[b] = static_cast<unsigned>(iy) < static_cast<unsigned>(L.ny);
+        okz[b] = static_cast<unsigned>(iz) < static_cast<unsigned>(L.nz);
+        ax[b] = okx[b] ? ix : 0;
+        ay[b] = oky[b] ? iy * row : 0;
+        az[b] = okz[b] ? iz * slab : 0;
       }
+      unsigned v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)    // unconditional loads from in-range addresses
+        v[k] = cells8[az[(k >> 2) & 1] + ay[(k >> 1) & 1] + ax[k & 1]];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        sum[k] += (okx[k & 1] && oky[(k >> 1) & 1] && okz[(k >> 2) & 1]) ? v[k] : 0u;
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int total = WaveSum(sum[k]);
+      if (lane == 0) partial[wave][k] = total;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+      const int k = threadIdx.x;
+      const bool valid = (!(k & 1) || vx) && (!(k & 2) || vy) && (!(k & 4) || vz);
+      const int total = partial[0][k] + partial[1][k] + partial[2][k] + partial[3][k];
+      sh_score[k] = valid ? ToProbability(total, P.n) : -1.f;
+    }
+    __syncthreads();
     float score[8];
     int nvalid = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const bool valid = (!(k & 1) || vx) && (!(k & 2) || vy) && (!(k & 4) || vz);
-      const int total = WaveSum(sum[k]);
-      score[k] = valid ? ToProbability(total, P.n) : -1.f;
-      nvalid += valid;
+      score[k] = sh_score[k];
+      nvalid += score[k] >= 0.f;
     }
     int rank[8];
 #pragma unroll
@@ -334,7 +376,7 @@ Expand3DKernel(Fast3DProblem P, List3 in, int dive, int strict, List3 out, List3
           ++r;
       rank[k] = r;
     }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
       atomicAdd(&counters->scored[sub_id & 15], static_cast<unsigned long long>(nvalid));
       atomicAdd(&counters->expanded[sub_id & 15], 1ull);
     }
@@ -350,15 +392,20 @@ Expand3DKernel(Fast3DProblem P, List3 in, int dive, int strict, List3 out, List3
     };
     if (child_depth == 0) {
       // Leaves in descending order; the first that passes the low-resolution
-      // matcher is the result of this sibling group.
+      // matcher is the result of this sibling group.  (Everything below is
+      // block-uniform, so the barriers inside LowResolutionScore are safe.)
       for (int r = 0; r < nvalid; ++r) {
         int k = 0;
 #pragma unroll
         for (int o = 0; o < 8; ++o)
           if (score[o] >= 0.f && rank[o] == r) k = o;
         const float sc = score[k];
-        const float now = __uint_as_float(
-            __hip_atomic_load(&counters->best_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __syncthreads();
+        if (threadIdx.x == 0)
+          sh_score[0] = __uint_as_float(__hip_atomic_load(&counters->best_bits, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT));
+        __syncthreads();
+        const float now = sh_score[0];
         if (!(sc > P.min_score) || (strict ? !(sc > now) : (sc < now))) break;
         const Node3D leaf = make_child(k);
         const float4 q4 = P.scan_q[nd.scan];
@@ -366,9 +413,9 @@ Expand3DKernel(Fast3DProblem P, List3 in, int dive, int strict, List3 out, List3
             P, Quat{q4.w, q4.x, q4.y, q4.z},
             (P.pose_tx + 0.f) + P.resolution * static_cast<float>(leaf.ox),
             (P.pose_ty + 0.f) + P.resolution * static_cast<float>(leaf.oy),
-            (P.pose_tz + 0.f) + P.resolution * static_cast<float>(leaf.oz), lane);
+            (P.pose_tz + 0.f) + P.resolution * static_cast<float>(leaf.oz), low_prob);
         if (static_cast<double>(low) >= P.min_low_resolution_score) {
-          if (lane == 0) {
+          if (threadIdx.x == 0) {
             Node3D rec = leaf;
             rec.low_resolution_score = low;
             if (!Push3(leaves, sub_id, atomicAdd(&leaves.counts[sub_id], 1), rec))
@@ -378,7 +425,7 @@ Expand3DKernel(Fast3DProblem P, List3 in, int dive, int strict, List3 out, List3
           break;
         }
       }
-    } else if (lane == 0) {
+    } else if (threadIdx.x == 0) {
       int keep_mask = 0, m = 0;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -401,6 +448,7 @@ Expand3DKernel(Fast3DProblem P, List3 in, int dive, int strict, List3 out, List3
         }
       }
     }
+    __syncthreads();   // partial / sh_score reused by the next node
   }
 }
 
@@ -482,20 +530,19 @@ SelectBest3DKernel(List3 leaves, const Counters3* __restrict__ counters, Best3* 
 // dedicated wave-per-candidate pass records every passing candidate.
 __global__ void __launch_bounds__(256)
 VerifyCoarseLeaves3DKernel(Fast3DProblem P, List3 leaves, Counters3* __restrict__ counters) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  __shared__ float low_prob[kLowChunk];
   const int total = P.ncx * P.ncy * P.ncz * P.num_scans;
-  const int sub_id = (blockIdx.x * 4 + wave) & (kSubLists3 - 1);
-  for (int c = blockIdx.x * 4 + wave; c < total; c += gridDim.x * 4) {
+  const int sub_id = blockIdx.x & (kSubLists3 - 1);
+  for (int c = blockIdx.x; c < total; c += gridDim.x) {     // one block per candidate
     const Node3D nd = CoarseNode3D(P, c);
-    if (!(nd.score > P.min_score)) continue;
+    if (!(nd.score > P.min_score)) continue;                // block-uniform
     const float4 q4 = P.scan_q[nd.scan];
     const float low = LowResolutionScore(
         P, Quat{q4.w, q4.x, q4.y, q4.z},
         (P.pose_tx + 0.f) + P.resolution * static_cast<float>(nd.ox),
         (P.pose_ty + 0.f) + P.resolution * static_cast<float>(nd.oy),
-        (P.pose_tz + 0.f) + P.resolution * static_cast<float>(nd.oz), lane);
-    if (static_cast<double>(low) >= P.min_low_resolution_score && lane == 0) {
+        (P.pose_tz + 0.f) + P.resolution * static_cast<float>(nd.oz), low_prob);
+    if (static_cast<double>(low) >= P.min_low_resolution_score && threadIdx.x == 0) {
       Node3D rec = nd;
       rec.level = 0;
       rec.low_resolution_score = low;
@@ -655,7 +702,41 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
     const float floor_score = std::max(min_score, 0.f);
     std::memcpy(&h_counters->best_bits, &floor_score, sizeof(float));
   }
-  CMX_HIP(hipMemcpyAsync(d_hi, hi, 3 * sizeof(float) * n, hipMemcpyHostToDevice, ws->stream));
+  // The high-resolution cloud only ever feeds integer sums (ScoreCandidates), which do
+  // not depend on the order of the points.  Upload it sorted along a Morton curve: the
+  // 64 points a wavefront gathers together then fall into neighbouring voxels, i.e. into
+  // a handful of cache lines instead of 64 (the search is bound by that line traffic).
+  float* h_hi = ws->pinned[2].ReserveAs<float>(3 * static_cast<size_t>(n));
+  {
+    float lo3[3] = {hi[0], hi[1], hi[2]};
+    for (int i = 1; i < n; ++i)
+      for (int k = 0; k < 3; ++k) lo3[k] = std::min(lo3[k], hi[3 * i + k]);
+    const float inv_cell = 1.f / (2.f * m.resolution);
+    auto spread = [](uint32_t v) {   // 10 bits -> every third bit
+      v &= 0x3ffu;
+      v = (v | (v << 16)) & 0x030000ffu;
+      v = (v | (v << 8)) & 0x0300f00fu;
+      v = (v | (v << 4)) & 0x030c30c3u;
+      v = (v | (v << 2)) & 0x09249249u;
+      return v;
+    };
+    std::vector<uint64_t> order(n);
+    for (int i = 0; i < n; ++i) {
+      uint32_t key = 0;
+      for (int k = 0; k < 3; ++k) {
+        const float cell = (hi[3 * i + k] - lo3[k]) * inv_cell;
+        const uint32_t c = cell >= 1023.f ? 1023u : (cell > 0.f ? static_cast<uint32_t>(cell) : 0u);
+        key |= spread(c) << k;
+      }
+      order[i] = (static_cast<uint64_t>(key) << 32) | static_cast<uint32_t>(i);
+    }
+    std::sort(order.begin(), order.end());
+    for (int i = 0; i < n; ++i) {
+      const uint32_t src = static_cast<uint32_t>(order[i]);
+      h_hi[3 * i] = hi[3 * src]; h_hi[3 * i + 1] = hi[3 * src + 1]; h_hi[3 * i + 2] = hi[3 * src + 2];
+    }
+  }
+  CMX_HIP(hipMemcpyAsync(d_hi, h_hi, 3 * sizeof(float) * n, hipMemcpyHostToDevice, ws->stream));
   CMX_HIP(hipMemcpyAsync(d_low, data.low_resolution_point_cloud, 3 * sizeof(float) * n_low,
                          hipMemcpyHostToDevice, ws->stream));
   CMX_HIP(hipMemcpyAsync(d_pose_q, h_q, 2 * sizeof(float4) * S, hipMemcpyHostToDevice,
@@ -694,14 +775,19 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
     CMX_HIP(hipStreamSynchronize(ws->stream));
   };
   dbg("uploads");
+  StageTrace trace(ws->stream);
+  auto mark = [&](const char* name) { trace.Mark(name); };
+  mark("begin");
   CMX_HIP(hipEventRecord(ws->ev_begin, ws->stream));
   Discretize3DKernel<<<dim3(DivUp(n, 256), S), 256, 0, ws->stream>>>(
       d_hi, n, d_pose_q, pose_t.x, pose_t.y, pose_t.z, m.resolution, d_cells);
   dbg("discretize");
+  mark("discretize");
   CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
   ScoreCoarse3DKernel<<<std::min<long long>(8192, DivUp(total, 4)), 256, 0, ws->stream>>>(P);
   CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
   dbg("coarse");
+  mark("coarse");
 
   const int blocks = 2048;
   int strict = 0;
@@ -716,6 +802,7 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
                          {d_seeds + kDiveSub * kSubLists3, d_counters->dive[1], kDiveSub}};
         SeedSelect3DKernel<<<1, 1024, 0, ws->stream>>>(P, dive[0], d_counters);
         dbg("seed");
+        mark("seed");
         int cur = 0;
         for (int child = depth - 2; child >= 0; --child) {
           CMX_HIP(hipMemsetAsync(d_counters->dive[cur ^ 1], 0, sizeof(int) * kSubLists3,
@@ -725,23 +812,28 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
           dbg("dive level");
           cur ^= 1;
         }
+        mark("dive");
       }
       CMX_HIP(hipMemsetAsync(d_counters->frontier, 0, sizeof(d_counters->frontier), ws->stream));
       Filter3DKernel<<<256, 256, 0, ws->stream>>>(P, strict, front(0), d_counters);
       dbg("filter");
+      mark("filter");
       int stage = 0;
       for (int child = depth - 2; child >= 0; --child, ++stage) {
         Expand3DKernel<<<blocks, 256, 0, ws->stream>>>(P, front(stage), 0, strict,
                                                        front(stage + 1), leaf_list, d_counters);
         dbg("expand level");
+        mark("expand");
       }
     }
     SelectBest3DKernel<<<1, 1024, 0, ws->stream>>>(leaf_list, d_counters, d_best);
+    mark("select");
     CMX_HIP(hipGetLastError());
     CMX_HIP(hipEventRecord(ws->ev_end, ws->stream));
     CMX_HIP(hipMemcpyAsync(h_counters, d_counters, sizeof(Counters3) + sizeof(Best3),
                            hipMemcpyDeviceToHost, ws->stream));
     CMX_HIP(hipStreamSynchronize(ws->stream));
+    trace.Report();
     if (!h_counters->overflow) break;
     CMX_REQUIRE(!strict, "branch-and-bound frontier overflow (search too wide)");
     // Retry pruning ties (strict) with the bound lowered by one ulp so the best
@@ -884,6 +976,7 @@ cmx_status cmx_fast3d_create(const cmx_fast3d_options* options, float resolution
     WorkspaceLease ws(device);
     m.levels.emplace_back(new DeviceBrick);
     BuildBrickFromVoxels(*ws, voxels, num_voxels, 1, m.levels[0].get());
+    CMX_REQUIRE(m.levels[0]->bytes < (size_t(1) << 31), "grid too large");   // 32-bit cell offsets
     BuildBrickFromVoxels(*ws, low_resolution_voxels, num_low_resolution_voxels, 2, &m.low);
     // PrecomputationGridStack3D (:57-77).
     int last_width = 1;
@@ -903,6 +996,7 @@ cmx_status cmx_fast3d_create(const cmx_fast3d_options* options, float resolution
       b.nx = hi[0] - lo[0] + 1; b.ny = hi[1] - lo[1] + 1; b.nz = hi[2] - lo[2] + 1;
       std::unique_ptr<DeviceBrick> level(new DeviceBrick);
       level->bytes = static_cast<size_t>(b.nx) * b.ny * b.nz;
+      CMX_REQUIRE(level->bytes < (size_t(1) << 31), "precomputation level too large");
       CMX_HIP(hipMalloc(&level->mem, level->bytes));
       b.cells = level->mem;
       level->desc = b;
