@@ -114,6 +114,23 @@ __global__ void BuildPlanesKernel(const uint8_t* __restrict__ level, int wx, int
   }
 }
 
+// quads[(y + w) * qx + (x + w)] = level(x, y) | level(x, y+w) << 8 | level(x+w, y) << 16 |
+// level(x+w, y+w) << 24 for x in [-w, wx), y in [-w, wy); cells outside the level read 0.
+__global__ void BuildQuadsKernel(const uint8_t* __restrict__ level, int wx, int wy, int w,
+                                 uint32_t* __restrict__ quads, int qx, int qy) {
+  const int X = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Y = blockIdx.y;
+  if (X >= qx) return;
+  const int x = X - w, y = Y - w;
+  auto at = [&](int cx, int cy) -> uint32_t {
+    return (static_cast<unsigned>(cx) < static_cast<unsigned>(wx) &&
+            static_cast<unsigned>(cy) < static_cast<unsigned>(wy))
+               ? level[cx + cy * wx] : 0u;
+  };
+  quads[static_cast<size_t>(Y) * qx + X] =
+      at(x, y) | (at(x, y + w) << 8) | (at(x + w, y) << 16) | (at(x + w, y + w) << 24);
+}
+
 // ---------------------------------------------------------------------------
 // Scan preparation: rotate, translate, discretise, ShrinkToFit, bucket
 // ---------------------------------------------------------------------------
@@ -679,30 +696,31 @@ __device__ __forceinline__ void ScoreChildren(const BlockContext& ctx, int dx, i
   const bool vx = dx + half <= ctx.max_x, vy = dy + half <= ctx.max_y;  // `break`s at :356,361
   const bool cached = ctx.cached;
   const auto* gpts = AsGlobal(ctx.global_pts);
-  const auto* cells = AsGlobal(L.cells);
+  const auto* quads = AsGlobal(L.quads);
+  // Children beyond the search bounds (`break`s at :356,361) are masked out of the quad.
+  const uint32_t child_mask = (vx ? 0xffffffffu : 0x0000ffffu) & (vy ? 0xffffffffu : 0x00ff00ffu);
+  // Packed accumulators: (s00 | s10 << 16) and (s01 | s11 << 16); a lane adds at most
+  // 255 per point, so 256 points fit before the halves are widened.
   int s00 = 0, s01 = 0, s10 = 0, s11 = 0;   // s[x-step][y-step]
+  for (int base = threadIdx.x; base < n; base += 256 * 256) {
+    uint32_t even = 0, odd = 0;
+    const int stop = min(n, base + 256 * 256);
 #pragma unroll 4
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const uint32_t p = cached ? ctx.cache[i] : gpts[i];
-    const int x = static_cast<short>(p & 0xffffu) + dx + off;
-    const int y = static_cast<short>(p >> 16) + dy + off;
-    const bool x0 = static_cast<unsigned>(x) < static_cast<unsigned>(L.wx);
-    const bool x1 = vx && static_cast<unsigned>(x + half) < static_cast<unsigned>(L.wx);
-    const bool y0 = static_cast<unsigned>(y) < static_cast<unsigned>(L.wy);
-    const bool y1 = vy && static_cast<unsigned>(y + half) < static_cast<unsigned>(L.wy);
-    // Unconditional loads from clamped (always valid) offsets, masked
-    // afterwards: all 16 gathers of the unrolled loop are in flight together
-    // (a load inside an `if` forces a wait per load).
-    const int o00 = y * L.wx + x;
-    const int o01 = o00 + half * L.wx;
-    const unsigned v00 = cells[(x0 && y0) ? o00 : 0];
-    const unsigned v01 = cells[(x0 && y1) ? o01 : 0];
-    const unsigned v10 = cells[(x1 && y0) ? o00 + half : 0];
-    const unsigned v11 = cells[(x1 && y1) ? o01 + half : 0];
-    s00 += (x0 && y0) ? v00 : 0u;
-    s01 += (x0 && y1) ? v01 : 0u;
-    s10 += (x1 && y0) ? v10 : 0u;
-    s11 += (x1 && y1) ? v11 : 0u;
+    for (int i = base; i < stop; i += 256) {
+      const uint32_t p = cached ? ctx.cache[i] : gpts[i];
+      const int X = static_cast<short>(p & 0xffffu) + dx + off + half;
+      const int Y = static_cast<short>(p >> 16) + dy + off + half;
+      const bool inside = static_cast<unsigned>(X) < static_cast<unsigned>(L.qx) &&
+                          static_cast<unsigned>(Y) < static_cast<unsigned>(L.qy);
+      // Unconditional load from a clamped (always valid) offset, masked afterwards: the
+      // gathers of the unrolled loop are in flight together.
+      const uint32_t q = quads[inside ? Y * L.qx + X : 0];
+      const uint32_t v = inside ? (q & child_mask) : 0u;
+      even += v & 0x00ff00ffu;          // byte 0 (x0,y0) and byte 2 (x1,y0)
+      odd += (v >> 8) & 0x00ff00ffu;    // byte 1 (x0,y1) and byte 3 (x1,y1)
+    }
+    s00 += even & 0xffffu; s10 += even >> 16;
+    s01 += odd & 0xffffu;  s11 += odd >> 16;
   }
   s00 = WaveSum(s00); s01 = WaveSum(s01); s10 = WaveSum(s10); s11 = WaveSum(s11);
   const int wave = threadIdx.x >> 6;
@@ -869,29 +887,31 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
     // (the expensive part: 64 distinct cache lines each) is skipped.  The outcome
     // is the same as scoring all points: no child would have been kept.
     const int parent_ub = SumUpperBound(P, nd.score, n);
+    const auto* quads = AsGlobal(L.quads);
+    const uint32_t child_mask =
+        (vx ? 0xffffffffu : 0x0000ffffu) & (vy ? 0xffffffffu : 0x00ff00ffu);
     int s00 = 0, s01 = 0, s10 = 0, s11 = 0, seen_max = 0;
     bool dead = false;
-    constexpr int kGroup = 2 * kWave;     // points between two checks
+    constexpr int kIters = 4;                 // 64-point iterations between two checks
+    constexpr int kGroup = kIters * kWave;
     for (int q0 = 0; q0 < n; q0 += kGroup) {
+      uint32_t v[kIters];
 #pragma unroll
-      for (int u = 0; u < kGroup / kWave; ++u) {
+      for (int u = 0; u < kIters; ++u) {
         const int q = q0 + u * kWave + lane;
         const bool live = q < n;
         const uint32_t p = pts[live ? q : 0];
-        const int x = static_cast<short>(p & 0xffffu) + nd.dx + off;
-        const int y = static_cast<short>(p >> 16) + nd.dy + off;
-        const bool x0 = live && static_cast<unsigned>(x) < static_cast<unsigned>(L.wx);
-        const bool x1 = live && vx && static_cast<unsigned>(x + half) < static_cast<unsigned>(L.wx);
-        const bool y0 = static_cast<unsigned>(y) < static_cast<unsigned>(L.wy);
-        const bool y1 = vy && static_cast<unsigned>(y + half) < static_cast<unsigned>(L.wy);
-        const int o00 = y * L.wx + x;
-        const int o01 = o00 + half * L.wx;
-        const unsigned v00 = cells[(x0 && y0) ? o00 : 0];
-        const unsigned v01 = cells[(x0 && y1) ? o01 : 0];
-        const unsigned v10 = cells[(x1 && y0) ? o00 + half : 0];
-        const unsigned v11 = cells[(x1 && y1) ? o01 + half : 0];
-        const int a00 = (x0 && y0) ? v00 : 0u, a01 = (x0 && y1) ? v01 : 0u;
-        const int a10 = (x1 && y0) ? v10 : 0u, a11 = (x1 && y1) ? v11 : 0u;
+        const int X = static_cast<short>(p & 0xffffu) + nd.dx + off + half;
+        const int Y = static_cast<short>(p >> 16) + nd.dy + off + half;
+        const bool inside = live && static_cast<unsigned>(X) < static_cast<unsigned>(L.qx) &&
+                            static_cast<unsigned>(Y) < static_cast<unsigned>(L.qy);
+        const uint32_t quad = quads[inside ? Y * L.qx + X : 0];   // one gather, four children
+        v[u] = inside ? (quad & child_mask) : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < kIters; ++u) {
+        const int a00 = v[u] & 0xff, a01 = (v[u] >> 8) & 0xff;
+        const int a10 = (v[u] >> 16) & 0xff, a11 = v[u] >> 24;
         s00 += a00; s01 += a01; s10 += a10; s11 += a11;
         seen_max += max(max(a00, a01), max(a10, a11));
       }
@@ -1259,6 +1279,31 @@ Fast2DMatcher::Fast2DMatcher(const cmx_fast2d_options& options, const cmx_grid2d
         prev.cells, prev.wx, prev.wy, 1 << (i - 1), const_cast<uint8_t*>(cur.cells), cur.wx,
         cur.wy);
   }
+  // Quad layouts of every level that can be a child level (0 .. depth-2).
+  {
+    size_t quad_total = 0;
+    std::vector<size_t> quad_off(depth, 0);
+    for (int i = 0; i + 1 < depth; ++i) {
+      const int w = 1 << i;
+      levels_[i].qx = levels_[i].wx + w;
+      levels_[i].qy = levels_[i].wy + w;
+      quad_off[i] = quad_total;
+      quad_total += (static_cast<size_t>(levels_[i].qx) * levels_[i].qy * sizeof(uint32_t) + 255) &
+                    ~size_t(255);
+    }
+    levels_[depth - 1].quads = nullptr;
+    levels_[depth - 1].qx = levels_[depth - 1].qy = 0;
+    if (quad_total) {
+      CMX_HIP(hipMalloc(&quads_mem_, quad_total));
+      for (int i = 0; i + 1 < depth; ++i) {
+        LevelDesc& L = levels_[i];
+        uint32_t* q = reinterpret_cast<uint32_t*>(static_cast<char*>(quads_mem_) + quad_off[i]);
+        L.quads = q;
+        BuildQuadsKernel<<<dim3(DivUp(L.qx, 256), L.qy), 256, 0, ws->stream>>>(
+            L.cells, L.wx, L.wy, 1 << i, q, L.qx, L.qy);
+      }
+    }
+  }
   // Phase planes of the lowest-resolution level.
   {
     const int w = 1 << (depth - 1);
@@ -1281,6 +1326,7 @@ Fast2DMatcher::Fast2DMatcher(const cmx_fast2d_options& options, const cmx_grid2d
 Fast2DMatcher::~Fast2DMatcher() {
   (void)hipSetDevice(device_);
   if (stack_mem_) (void)hipFree(stack_mem_);
+  if (quads_mem_) (void)hipFree(quads_mem_);
   if (planes_) (void)hipFree(planes_);
   for (RotationEntry& e : rotation_tables_) (void)hipFree(e.table);
 }

@@ -13,9 +13,18 @@ namespace cmx {
 // One level of a PrecomputationGridStack2D in device memory
 // (SM2/fast_correlative_scan_matcher_2d.h:49-93): width 2^level, dims
 // (nx+w-1) x (ny+w-1), cell (x0,y0) stored at [(x0+w-1) + (y0+w-1)*wx].
+//
+// `quads` is the layout the tree search reads: one dword per cell position
+// (x, y) in [-w, wx) x [-w, wy) packing the four cells the children of a node read for
+// one point -- byte 0: (x, y), byte 1: (x, y+w), byte 2: (x+w, y), byte 3: (x+w, y+w),
+// 0 where a cell is outside the level.  A wave-wide byte gather with 64 unrelated
+// addresses costs ~90 cycles of texture-address time per instruction;
+// fetching the four children at once cuts those instructions by four.
 struct LevelDesc {
   const uint8_t* cells;
   int wx, wy;
+  const uint32_t* quads;   // [(wy + w)][(wx + w)], element (x + w, y + w); null for the top level
+  int qx, qy;              // wx + w, wy + w
 };
 
 // Device-visible description of one (scan, submap) search.
@@ -108,6 +117,7 @@ class Fast2DMatcher {
   cmx_grid2d_limits limits_;
   int device_;
   void* stack_mem_ = nullptr;      // all levels, contiguous
+  void* quads_mem_ = nullptr;      // quad layouts of levels 0 .. depth-2, contiguous
   uint8_t* planes_ = nullptr;      // phase planes of the lowest-resolution level (or null)
   int plane_i_ = 0, plane_j_ = 0, plane_stride_ = 0;
   std::vector<LevelDesc> levels_;
