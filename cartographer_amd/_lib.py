@@ -89,7 +89,8 @@ class Result3D(C.Structure):
 EXPORTED_SYMBOLS = [
     "cmx_version", "cmx_status_string", "cmx_last_error", "cmx_device_count", "cmx_set_stream",
     "cmx_rt2d_match", "cmx_rt2d_match_tsdf", "cmx_fast2d_create", "cmx_fast2d_destroy", "cmx_fast2d_match",
-    "cmx_fast2d_match_full_submap", "cmx_fast2d_match_full_submap_batch", "cmx_cloud_upload",
+    "cmx_fast2d_match_full_submap", "cmx_fast2d_match_batch",
+    "cmx_fast2d_match_full_submap_batch", "cmx_cloud_upload",
     "cmx_cloud_destroy", "cmx_fast2d_match_full_submap_batch_resident", "cmx_fast2d_level_dims",
     "cmx_fast2d_level_cells", "cmx_fast2d_debug_prepare", "cmx_rt3d_match", "cmx_fast3d_create",
     "cmx_fast3d_destroy", "cmx_fast3d_match", "cmx_fast3d_match_full_submap",
@@ -137,6 +138,9 @@ def lib():
     L.cmx_fast2d_match_full_submap_batch.argtypes = [P(C.c_void_p), C.c_int32, C.c_void_p,
                                                      C.c_int32, C.c_float, C.c_void_p,
                                                      C.c_void_p, C.c_void_p, P(MatchStats)]
+    L.cmx_fast2d_match_batch.argtypes = [P(C.c_void_p), C.c_int32, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, P(MatchStats)]
     L.cmx_cloud_upload.argtypes = [C.c_void_p, C.c_int32, C.c_int32, P(C.c_void_p)]
     L.cmx_cloud_destroy.argtypes = [C.c_void_p]
     L.cmx_cloud_destroy.restype = None

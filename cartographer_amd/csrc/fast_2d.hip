@@ -1410,7 +1410,12 @@ struct PreparedBatch {
 void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, int num,
                            const cmx_pose2d* initial_or_null, bool full_submap,
                            const float* d_xyz, int n, float max_range_xy, float min_score,
-                           PreparedBatch* out) {
+                           PreparedBatch* out, const int32_t* full_flags = nullptr,
+                           const float* min_scores = nullptr) {
+  // Mixed batches (the ConstraintBuilder front): per-problem full-submap flag and
+  // acceptance threshold override the uniform ones.
+  const auto is_full = [&](int p) { return full_flags ? full_flags[p] != 0 : full_submap; };
+  const auto min_of = [&](int p) { return min_scores ? min_scores[p] : min_score; };
   out->num_problems = num;
   out->n = n;
   out->search.resize(num);
@@ -1424,7 +1429,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     const cmx_grid2d_limits& lim = m.limits();
     HostSearch h;
     cmx_pose2d init;
-    if (full_submap) {
+    if (is_full(p)) {
       // SM2/fast_...2d.cc:213-222.
       h = MakeSearch(1e6 * lim.resolution, M_PI, max_range_xy, lim.resolution);
       init.x = lim.max_x - 0.5 * lim.resolution * lim.num_y_cells;
@@ -1506,7 +1511,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     P.scan_rot = m.RotationTable(h.step, h.num_angular);
     P.min_s = m.min_s();
     P.score_scale = m.score_scale();
-    P.min_score = min_score;
+    P.min_score = min_of(p);
     P.planes = m.planes();
     P.plane_i = m.plane_i();
     P.plane_j = m.plane_j();
@@ -1522,7 +1527,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     P.coarse_sum = d_csum + coarse_off;
     h_prob[p] = P;
     std::memset(&h_state[p], 0, sizeof(ProblemState));
-    const float bound = std::max(min_score, 0.f);
+    const float bound = std::max(min_of(p), 0.f);
     std::memcpy(&h_state[p].best_bits, &bound, sizeof(float));
     disc_off += static_cast<size_t>(h.num_scans) * n;
     scan_off += h.num_scans + 1;
@@ -1877,7 +1882,8 @@ void CheckProblemErrors(const BatchResult& r) {
 void MatchBatch(const cmx_fast2d* const* handles, int num, const cmx_pose2d* initial,
                 bool full_submap, const float* host_xyz, const cmx_cloud* cloud, int n,
                 float min_score, int32_t* found, float* scores, cmx_pose2d* poses,
-                cmx_match_stats* stats) {
+                cmx_match_stats* stats, const int32_t* full_flags = nullptr,
+                const float* min_scores = nullptr) {
   CMX_REQUIRE(handles != nullptr && num >= 1, "no matchers given");
   CMX_REQUIRE(num < (1 << 24), "too many matchers in one batch");
   CMX_REQUIRE(found != nullptr && scores != nullptr && poses != nullptr,
@@ -1912,7 +1918,7 @@ void MatchBatch(const cmx_fast2d* const* handles, int num, const cmx_pose2d* ini
   StageTrace trace(ws->stream);
   batch.trace = &trace;
   PrepareAndScoreCoarse(*ws, matchers.data(), num, initial, full_submap, d_xyz, n, max_range,
-                        min_score, &batch);
+                        min_score, &batch, full_flags, min_scores);
   BatchResult result;
   RunBranchAndBound(*ws, batch, &result);
   trace.Report();
@@ -1929,7 +1935,7 @@ void MatchBatch(const cmx_fast2d* const* handles, int num, const cmx_pose2d* ini
   for (int p = 0; p < num; ++p) {
     const BestLeaf& b = result.best[p];
     const HostSearch& h = batch.search[p];
-    const bool ok = b.found && b.score > min_score;
+    const bool ok = b.found && b.score > (min_scores ? min_scores[p] : min_score);
     found[p] = ok ? 1 : 0;
     if (ok) {
       // Candidate2D (SM2/correlative_scan_matcher_2d.h:74-84) and the pose
@@ -2058,6 +2064,24 @@ cmx_status cmx_fast2d_match_full_submap_batch_resident(
     CMX_REQUIRE(cloud != nullptr, "null cloud");
     cmx::MatchBatch(matchers, num_matchers, nullptr, true, nullptr, cloud, cloud->num_points,
                     min_score, found, scores, pose_estimates, stats);
+  });
+}
+
+cmx_status cmx_fast2d_match_batch(const cmx_fast2d* const* matchers, int32_t num_matchers,
+                                  const cmx_pose2d* initial_pose_estimates,
+                                  const int32_t* match_full_submap, const float* min_scores,
+                                  const float* point_cloud_xyz, int32_t num_points, int32_t* found,
+                                  float* scores, cmx_pose2d* pose_estimates,
+                                  cmx_match_stats* stats) {
+  return Guard([&] {
+    CMX_REQUIRE(match_full_submap != nullptr && min_scores != nullptr, "null argument");
+    bool any_windowed = false;
+    for (int p = 0; p < num_matchers; ++p) any_windowed |= match_full_submap[p] == 0;
+    CMX_REQUIRE(!any_windowed || initial_pose_estimates != nullptr,
+                "initial_pose_estimates required for windowed searches");
+    cmx::MatchBatch(matchers, num_matchers, initial_pose_estimates, false, point_cloud_xyz, nullptr,
+                    num_points, 0.f, found, scores, pose_estimates, stats, match_full_submap,
+                    min_scores);
   });
 }
 

@@ -13,7 +13,7 @@
  *                                  SM2/fast_correlative_scan_matcher_2d.h:114-118, .cc:188-196
  *   cmx_fast2d_match               FastCorrelativeScanMatcher2D::Match        .h:124-126, .cc:198-208
  *   cmx_fast2d_match_full_submap   FastCorrelativeScanMatcher2D::MatchFullSubmap .h:132-133, .cc:210-225
- *   cmx_fast2d_match_full_submap_batch
+ *   cmx_fast2d_match_batch, cmx_fast2d_match_full_submap_batch
  *                                  the ConstraintBuilder2D fan-out of independent
  *                                  (node, submap) searches, constraints/constraint_builder_2d.cc:97-137
  *   cmx_rt3d_match                 RealTimeCorrelativeScanMatcher3D::Match
@@ -167,6 +167,19 @@ cmx_status cmx_fast2d_match_full_submap_batch(const cmx_fast2d* const* matchers,
                                               int32_t num_points, float min_score,
                                               int32_t* found, float* scores,
                                               cmx_pose2d* pose_estimates, cmx_match_stats* stats);
+
+/* The general batch behind a ConstraintBuilder2D front
+ * (constraints/constraint_builder_2d.cc:77-137, :194-236): one node's scan against many
+ * submaps in ONE device batch, each entry either a windowed Match around its own
+ * initial pose (match_full_submap[i] == 0: MaybeAddConstraint) or a MatchFullSubmap
+ * (!= 0: MaybeAddGlobalConstraint), each with its own acceptance threshold
+ * (min_score / global_localization_min_score). */
+cmx_status cmx_fast2d_match_batch(const cmx_fast2d* const* matchers, int32_t num_matchers,
+                                  const cmx_pose2d* initial_pose_estimates,
+                                  const int32_t* match_full_submap, const float* min_scores,
+                                  const float* point_cloud_xyz, int32_t num_points, int32_t* found,
+                                  float* scores, cmx_pose2d* pose_estimates,
+                                  cmx_match_stats* stats);
 
 /* Device-resident variant for throughput measurement: the point cloud is
  * uploaded once, repeated matches touch no host buffer except the results. */

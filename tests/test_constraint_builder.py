@@ -1,0 +1,127 @@
+"""ConstraintBuilder2D front: the host mirror over the batched device
+search against the CPU restatement of constraints/constraint_builder_2d.cc.
+
+CPU part: sampler / filter / bookkeeping semantics that need no device, pinned on the
+reference's own tests (constraint_builder_2d_test.cc, fixed_ratio_sampler_test.cc).
+GPU part: identical constraint lists (ids, order, scores, transforms) on a multi-node,
+multi-submap scenario mixing windowed and full-submap searches.
+"""
+import math
+
+import numpy as np
+import pytest
+
+
+def test_fixed_ratio_sampler_reference_pins():
+    # common/fixed_ratio_sampler_test.cc:24-46: ratio 1 keeps all, 0 none, 0.5 every other.
+    from cartographer_amd.constraint_builder import FixedRatioSampler
+    always, never, half = FixedRatioSampler(1.0), FixedRatioSampler(0.0), FixedRatioSampler(0.5)
+    assert all(always.pulse() for _ in range(5))
+    assert not any(never.pulse() for _ in range(5))
+    pulses = [half.pulse() for _ in range(8)]
+    assert sum(pulses) == 4 and pulses[0]
+    with pytest.raises(ValueError):
+        FixedRatioSampler(1.5)
+
+
+def test_rigid2d_algebra_matches_restatement():
+    from cartographer_amd import constraint_builder as cb
+    from oracle import constraint_builder_ref as ref
+    rng = np.random.default_rng(0)
+    for _ in range(100):
+        a, b = rng.uniform(-5, 5, 3), rng.uniform(-5, 5, 3)
+        m = cb.multiply(cb.Rigid2d(*a), cb.Rigid2d(*b))
+        assert (m.x, m.y, m.theta) == ref.rigid_mul(tuple(a), tuple(b))
+        i = cb.inverse(cb.Rigid2d(*a))
+        assert (i.x, i.y, i.theta) == ref.rigid_inv(tuple(a))
+        back = cb.multiply(cb.Rigid2d(*a), i)
+        assert abs(back.x) < 1e-12 and abs(back.y) < 1e-12 and back.theta == 0.0
+
+
+def test_calls_back_without_work():
+    # ConstraintBuilder2DTest.CallsBack (constraint_builder_2d_test.cc:58-68): no pairs queued,
+    # the callback sees an empty result and the node counts as finished.  No device needed.
+    from cartographer_amd import constraint_builder as cb
+    builder = cb.ConstraintBuilder2D(cb.ConstraintBuilderOptions())
+    assert builder.get_num_finished_nodes() == 0
+    builder.notify_end_of_node()
+    seen = []
+    builder.when_done(seen.append)
+    assert seen == [[]] and builder.get_num_finished_nodes() == 1
+
+
+def test_distance_and_sampling_filters_without_device():
+    # MaybeAddConstraint returns before touching the matcher when the relative pose is too far
+    # (:82-85) or the sampler says no (:86-91): with ratio 0 nothing is ever queued.
+    from cartographer_amd import constraint_builder as cb
+    opts = cb.ConstraintBuilderOptions(sampling_ratio=0.0, max_constraint_distance=1.0)
+    builder = cb.ConstraintBuilder2D(opts)
+    cloud = np.zeros((3, 3), np.float32)
+    builder.maybe_add_constraint((0, 0), None, (0, 0), cloud, cb.Rigid2d(5.0, 0.0, 0.0))
+    builder.maybe_add_constraint((0, 0), None, (0, 1), cloud, cb.Rigid2d(0.1, 0.0, 0.0))
+    builder.notify_end_of_node()
+    seen = []
+    builder.when_done(seen.append)
+    assert seen == [[]] and builder.num_scan_matchers() == 0
+
+
+@pytest.mark.gpu
+def test_constraint_lists_match_restatement(oracle, synth):
+    from cartographer_amd import constraint_builder as cb, scan_matching as sm
+    from oracle import constraint_builder_ref as ref
+    depth, lin, ang = 5, 1.5, math.radians(20.0)
+    opts = cb.ConstraintBuilderOptions(sampling_ratio=0.5, max_constraint_distance=4.0,
+                                       min_score=0.5, global_localization_min_score=0.55,
+                                       linear_search_window=lin, angular_search_window=ang,
+                                       branch_and_bound_depth=depth)
+    builder = cb.ConstraintBuilder2D(opts)
+    restated = ref.ConstraintBuilder2DRef(0.5, 4.0, 0.5, 0.55, lin, ang, depth)
+    # Four finished submaps (identity submap pose is NOT assumed: each has its own local pose,
+    # with the grid expressed in the map frame like the reference's submaps).
+    submaps = {}
+    worlds = {}
+    for k in range(4):
+        cells, lim, world = synth.make_submap(60 + k, 160, 140, 0.05, 12, 400, 30.0, 0.01)
+        grid = sm.Grid2D(cells, lim["resolution"], lim["max_x"], lim["max_y"])
+        pose = cb.Rigid2d(0.3 * k - 0.2, 0.1 * k, 0.05 * k)
+        submaps[(0, k)] = (cb.Submap2D(pose, grid),
+                           (cells, lim["resolution"], lim["max_x"], lim["max_y"]))
+        worlds[(0, k)] = world
+    node = 0
+    for k in range(4):                       # nodes: scans taken inside each submap's world
+        truth = worlds[(0, k)].free_pose(100 + k, 0.4)
+        cloud = worlds[(0, k)].scan(truth, 300, 30.0, 0.01, k)
+        for sid, (submap, grid) in submaps.items():
+            sp = (submap.local_pose.x, submap.local_pose.y, submap.local_pose.theta)
+            # relative pose = submap_pose^-1 * (truth perturbed); far for some pairs
+            guess = (truth[0] + 0.15, truth[1] - 0.1, truth[2] + 0.03)
+            rel = ref.rigid_mul(ref.rigid_inv(sp), guess)
+            if sid[1] == (k + 2) % 4:
+                rel = (rel[0] + 10.0, rel[1], rel[2])            # beyond max_constraint_distance
+            for _ in range(2):                                    # sampler: every other call passes
+                builder.maybe_add_constraint(sid, submap, (0, node), cloud, cb.Rigid2d(*rel))
+                restated.maybe_add_constraint(sid, sp, grid, (0, node), cloud, rel)
+            if sid[1] in (k, (k + 1) % 4):
+                builder.maybe_add_global_constraint(sid, submap, (0, node), cloud)
+                restated.maybe_add_global_constraint(sid, sp, grid, (0, node), cloud)
+        builder.notify_end_of_node()
+        restated.notify_end_of_node()
+        node += 1
+        if k == 1:                                                # trimmed submap
+            builder.delete_scan_matcher((0, 0))
+            restated.delete_scan_matcher((0, 0))
+            assert builder.num_scan_matchers() == 3
+    got = []
+    builder.when_done(got.extend)
+    want = restated.when_done()
+    assert builder.get_num_finished_nodes() == restated.finished == 4
+    assert len(want) >= 6                                         # the scenario is not vacuous
+    assert [(c.submap_id, c.node_id) for c in got] == [(c["submap_id"], c["node_id"]) for c in want]
+    for c, w in zip(got, want):
+        assert np.float32(c.score) == np.float32(w["score"])
+        assert (c.zbar_ij.x, c.zbar_ij.y, c.zbar_ij.theta) == w["zbar_ij"]
+        assert c.tag == "INTER_SUBMAP"
+    # a second round after WhenDone starts from an empty queue
+    again = []
+    builder.when_done(again.extend)
+    assert again == []
