@@ -287,12 +287,18 @@ constexpr int kFinalistHead = 62;   // pairs returned with the first (512-byte) 
 
 size_t Align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
 
+}  // namespace
+
+// `cells` is a host buffer, or -- when `device_cells` is given -- ignored in favour of a
+// grid that already lives in HBM (cmx_grid2d): nothing but the scan is uploaded then.
 void Rt2DMatch(const cmx_rt_options* options, const cmx_grid2d_limits* limits,
                const uint16_t* cells, const uint16_t* weight_cells, float max_tsd,
                float max_weight, const cmx_pose2d* initial_pose_estimate,
                const float* point_cloud_xyz, int32_t num_points, int32_t device, double* score,
-               cmx_pose2d* pose_estimate, cmx_match_stats* stats) {
-  CMX_REQUIRE(options && limits && cells && initial_pose_estimate && point_cloud_xyz,
+               cmx_pose2d* pose_estimate, cmx_match_stats* stats,
+               const uint16_t* device_cells) {
+  CMX_REQUIRE(options && limits && (cells || device_cells) && initial_pose_estimate &&
+                  point_cloud_xyz,
               "null argument");
   CMX_REQUIRE(pose_estimate != nullptr && score != nullptr,
               "pose_estimate must not be null");            // CHECK at :121
@@ -341,7 +347,8 @@ void Rt2DMatch(const cmx_rt_options* options, const cmx_grid2d_limits* limits,
   const size_t cell_count = static_cast<size_t>(nx) * ny;
   const size_t off_rot = Align16(3 * sizeof(float) * n);
   const size_t off_cells = off_rot + Align16(sizeof(float2) * num_scans);
-  const size_t off_weights = off_cells + Align16(sizeof(uint16_t) * cell_count);
+  const size_t off_weights =
+      off_cells + (device_cells ? 0 : Align16(sizeof(uint16_t) * cell_count));
   const size_t in_bytes = off_weights + (tsdf ? Align16(sizeof(uint16_t) * cell_count) : 0);
   char* h_in = ws->pinned[0].ReserveAs<char>(in_bytes);
   char* d_in = ws->dev[0].ReserveAs<char>(in_bytes);
@@ -352,7 +359,7 @@ void Rt2DMatch(const cmx_rt_options* options, const cmx_grid2d_limits* limits,
     const float ha = 0.5f * static_cast<float>(delta_theta);
     h_rot[s] = make_float2(std::cos(ha), std::sin(ha) * 1.f);
   }
-  std::memcpy(h_in + off_cells, cells, sizeof(uint16_t) * cell_count);
+  if (!device_cells) std::memcpy(h_in + off_cells, cells, sizeof(uint16_t) * cell_count);
   if (tsdf) std::memcpy(h_in + off_weights, weight_cells, sizeof(uint16_t) * cell_count);
 
   const int n_pad = (n + 63) / 64 * 64;
@@ -367,7 +374,7 @@ void Rt2DMatch(const cmx_rt_options* options, const cmx_grid2d_limits* limits,
   CMX_HIP(hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, ws->stream));
 
   Rt2DParams P;
-  P.cells = reinterpret_cast<const uint16_t*>(d_in + off_cells);
+  P.cells = device_cells ? device_cells : reinterpret_cast<const uint16_t*>(d_in + off_cells);
   P.weights = tsdf ? reinterpret_cast<const uint16_t*>(d_in + off_weights) : nullptr;
   P.nx = nx; P.ny = ny;
   P.res = res; P.max_x = limits->max_x; P.max_y = limits->max_y;
@@ -473,7 +480,6 @@ void Rt2DMatch(const cmx_rt_options* options, const cmx_grid2d_limits* limits,
   }
 }
 
-}  // namespace
 }  // namespace cmx
 
 extern "C" cmx_status cmx_rt2d_match(const cmx_rt_options* options,
@@ -484,7 +490,7 @@ extern "C" cmx_status cmx_rt2d_match(const cmx_rt_options* options,
                                      cmx_match_stats* stats) {
   return cmx::Guard([&] {
     cmx::Rt2DMatch(options, limits, cells, nullptr, 0.f, 0.f, initial_pose_estimate,
-                   point_cloud_xyz, num_points, device, score, pose_estimate, stats);
+                   point_cloud_xyz, num_points, device, score, pose_estimate, stats, nullptr);
   });
 }
 
@@ -501,6 +507,6 @@ extern "C" cmx_status cmx_rt2d_match_tsdf(const cmx_rt_options* options,
     CMX_REQUIRE(weight_cells != nullptr, "null argument");
     cmx::Rt2DMatch(options, limits, tsd_cells, weight_cells, truncation_distance, max_weight,
                    initial_pose_estimate, point_cloud_xyz, num_points, device, score,
-                   pose_estimate, stats);
+                   pose_estimate, stats, nullptr);
   });
 }

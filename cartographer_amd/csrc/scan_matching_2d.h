@@ -128,6 +128,13 @@ class Fast2DMatcher {
   mutable std::vector<RotationEntry> rotation_tables_;
 };
 
+// RealTimeCorrelativeScanMatcher2D::Match (rt_2d.hip); see there.
+void Rt2DMatch(const cmx_rt_options* options, const cmx_grid2d_limits* limits,
+               const uint16_t* cells, const uint16_t* weight_cells, float max_tsd,
+               float max_weight, const cmx_pose2d* initial_pose_estimate,
+               const float* point_cloud_xyz, int32_t num_points, int32_t device, double* score,
+               cmx_pose2d* pose_estimate, cmx_match_stats* stats, const uint16_t* device_cells);
+
 }  // namespace cmx
 
 struct cmx_fast2d {

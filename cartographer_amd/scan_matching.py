@@ -98,6 +98,15 @@ class RealTimeCorrelativeScanMatcher2D:
 
     def match(self, initial_pose_estimate, point_cloud, grid):
         xyz, n = _cloud(point_cloud)
+        from .grid_2d import ProbabilityGridOnDevice
+        if isinstance(grid, ProbabilityGridOnDevice):     # grid already in HBM
+            init = initial_pose_estimate.to_c()
+            score, pose, stats = C.c_double(), Pose2d(), MatchStats()
+            check(_lib.lib().cmx_rt2d_match_grid(C.byref(self.options), grid._h, C.byref(init),
+                                                 xyz.ctypes.data, n, C.byref(score),
+                                                 C.byref(pose), C.byref(stats)))
+            self.last_stats = stats.as_dict()
+            return score.value, Rigid2d(pose.x, pose.y, pose.theta)
         limits = grid.limits_c()
         init = initial_pose_estimate.to_c()
         score = C.c_double()
@@ -151,6 +160,21 @@ class FastCorrelativeScanMatcher2D:
         limits = grid.limits_c()
         check(_lib.lib().cmx_fast2d_create(C.byref(self.options), C.byref(limits),
                                            grid.cells.ctypes.data, device, C.byref(self._h)))
+
+    @classmethod
+    def from_device_grid(cls, device_grid, branch_and_bound_depth, linear_search_window=7.0,
+                         angular_search_window=float(np.deg2rad(30.0))):
+        """Matcher of a grid that lives in HBM (cartographer_amd.grid_2d.ProbabilityGridOnDevice)."""
+        self = cls.__new__(cls)
+        self.grid = device_grid
+        self.options = Fast2DOptions(linear_search_window, angular_search_window,
+                                     branch_and_bound_depth)
+        self.device = device_grid.device
+        self.last_stats = None
+        self._h = C.c_void_p()
+        check(_lib.lib().cmx_fast2d_create_from_grid(C.byref(self.options), device_grid._h,
+                                                     C.byref(self._h)))
+        return self
 
     def __del__(self):
         if getattr(self, "_h", None):

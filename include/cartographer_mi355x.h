@@ -145,11 +145,40 @@ cmx_status cmx_rt2d_match_tsdf(const cmx_rt_options* options, const cmx_grid2d_l
                                const float* point_cloud_xyz, int32_t num_points, int32_t device,
                                double* score, cmx_pose2d* pose_estimate, cmx_match_stats* stats);
 
+/* ---- device-resident probability grid ------------------ */
+/* The active submap's ProbabilityGrid kept in HBM: LocalTrajectoryBuilder2D's per-scan
+ * pair Match() -> InsertRangeData() (mapping/internal/2d/local_trajectory_builder_2d.cc:
+ * 78-80, :288-289) then moves only the scan across PCIe.
+ *   cmx_grid2d_create     ProbabilityGrid(limits) (all unknown) or a copy of `cells`
+ *   cmx_grid2d_insert     ProbabilityGridRangeDataInserter2D::Insert + FinishUpdate
+ *                         (mapping/2d/probability_grid_range_data_inserter_2d.cc:33-96,
+ *                          mapping/internal/2d/ray_to_pixel_mask.cc:34-156); grows the
+ *                         limits like GrowAsNeeded / Grid2D::GrowLimits. Points are in the
+ *                         map frame (range data already transformed), xyz triples.
+ *   cmx_rt2d_match_grid   RealTimeCorrelativeScanMatcher2D::Match on that grid
+ *   cmx_fast2d_create_from_grid  FastCorrelativeScanMatcher2D of the (finished) grid */
+typedef struct cmx_grid2d cmx_grid2d;
+cmx_status cmx_grid2d_create(const cmx_grid2d_limits* limits, const uint16_t* cells_or_null,
+                             int32_t device, cmx_grid2d** out);
+void cmx_grid2d_destroy(cmx_grid2d* grid);
+cmx_status cmx_grid2d_get_limits(const cmx_grid2d* grid, cmx_grid2d_limits* limits);
+cmx_status cmx_grid2d_download(const cmx_grid2d* grid, uint16_t* cells);
+cmx_status cmx_grid2d_insert(cmx_grid2d* grid, const float* origin_xy, const float* returns_xyz,
+                             int32_t num_returns, const float* misses_xyz, int32_t num_misses,
+                             float hit_probability, float miss_probability,
+                             int32_t insert_free_space);
+cmx_status cmx_rt2d_match_grid(const cmx_rt_options* options, const cmx_grid2d* grid,
+                               const cmx_pose2d* initial_pose_estimate,
+                               const float* point_cloud_xyz, int32_t num_points, double* score,
+                               cmx_pose2d* pose_estimate, cmx_match_stats* stats);
+
 /* ---- fast 2D (branch and bound) ---------------------------------------- */
 /* Uploads the grid and builds the PrecomputationGridStack2D on `device`
  * (SM2/fast_correlative_scan_matcher_2d.cc:171-186). */
 cmx_status cmx_fast2d_create(const cmx_fast2d_options* options, const cmx_grid2d_limits* limits,
                              const uint16_t* cells, int32_t device, cmx_fast2d** out);
+cmx_status cmx_fast2d_create_from_grid(const cmx_fast2d_options* options, const cmx_grid2d* grid,
+                                       cmx_fast2d** out);
 void cmx_fast2d_destroy(cmx_fast2d* matcher);
 
 cmx_status cmx_fast2d_match(const cmx_fast2d* matcher, const cmx_pose2d* initial_pose_estimate,
