@@ -44,6 +44,20 @@ __device__ __forceinline__ CMX_GLOBAL T* AsGlobal(T* p) {
   return (CMX_GLOBAL T*)p;
 }
 
+// lround(t / res - 0.5) -- MapLimits::GetCellIndex (mapping/2d/map_limits.h:69-76) --
+// without the f64 division in the common case.  With inv = RN(1 / res), v0 = t * inv - 0.5
+// differs from the reference's value by less than |t / res| * 2^-50 + 2^-52; when v0 is
+// further than 16x that from every half-integer the rounded results agree and rint(v0) is
+// returned, otherwise (practically never, NaN / inf included) the exact expression runs.
+__device__ __forceinline__ int CellIndexF64(double t, double res, double inv_res) {
+  const double q0 = t * inv_res;
+  const double v0 = q0 - 0.5;
+  const double n = rint(v0);
+  const double margin = 0.5 - fabs(v0 - n);            // exact
+  if (margin > fabs(q0) * 0x1p-46 + 0x1p-46) return static_cast<int>(n);
+  return LRoundF64(t / res - 0.5);
+}
+
 struct F3 { float x, y, z; };
 struct Quat { float w, x, y, z; };
 

@@ -154,8 +154,8 @@ PrepScansKernel(const Fast2DProblem* __restrict__ problems, const float* __restr
     const float x = (1.f * b.x + 0.f * b.y) + P.tx;   // Affine2f(translation) * v
     const float y = (0.f * b.x + 1.f * b.y) + P.ty;
     // MapLimits::GetCellIndex (mapping/2d/map_limits.h:69-76).
-    const int ix = LRoundF64((P.max_y - static_cast<double>(y)) / P.res - 0.5);
-    const int iy = LRoundF64((P.max_x - static_cast<double>(x)) / P.res - 0.5);
+    const int ix = CellIndexF64(P.max_y - static_cast<double>(y), P.res, P.inv_res);
+    const int iy = CellIndexF64(P.max_x - static_cast<double>(x), P.res, P.inv_res);
     if (ix < -32768 || ix > 32767 || iy < -32768 || iy > 32767) bad = 1;
     out[i] = (static_cast<uint32_t>(ix) & 0xffffu) | (static_cast<uint32_t>(iy) << 16);
     lo_x = min(lo_x, -ix);
@@ -892,7 +892,9 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
         (vx ? 0xffffffffu : 0x0000ffffu) & (vy ? 0xffffffffu : 0x00ff00ffu);
     int s00 = 0, s01 = 0, s10 = 0, s11 = 0, seen_max = 0;
     bool dead = false;
-    constexpr int kIters = 4;                 // 64-point iterations between two checks
+    // 64-point iterations gathered between two bound checks (16, i.e. everything in
+    // flight at once, was no faster even for single searches: 37 vs 33 us).
+    constexpr int kIters = 4;
     constexpr int kGroup = kIters * kWave;
     for (int q0 = 0; q0 < n; q0 += kGroup) {
       uint32_t v[kIters];
@@ -1114,6 +1116,66 @@ SelectBestKernel(NodeList leaves, const ProblemState* __restrict__ states,
     *nd = leaves.nodes[static_cast<size_t>(sub) * leaves.sub_capacity + j];
     return true;
   };
+  // Common case (a handful of leaves, a few problems): every thread keeps its leaf in
+  // registers and the four selection rounds run on LDS atomics -- one trip to memory
+  // instead of five passes of global atomics and fences.
+  constexpr int kFastProblems = 64;
+  if (total <= static_cast<int>(blockDim.x) && num_problems <= kFastProblems) {
+    __shared__ unsigned s_best_bits[kFastProblems], s_coarse[kFastProblems];
+    __shared__ unsigned long long s_key[kFastProblems];
+    __shared__ int s_ties[kFastProblems], s_scan[kFastProblems], s_dx[kFastProblems],
+        s_dy[kFastProblems];
+    if (static_cast<int>(threadIdx.x) < num_problems) {
+      const int p = threadIdx.x;
+      s_best_bits[p] = states[p].best_bits;
+      s_coarse[p] = 0;
+      s_key[p] = ~0ull;
+      s_ties[p] = 0;
+      s_scan[p] = -1; s_dx[p] = 0; s_dy[p] = 0;
+    }
+    Node2D nd;
+    const bool have = leaf_at(threadIdx.x, &nd);
+    const int p = have ? NodeProblem(nd) : 0;
+    __syncthreads();
+    const bool tied = have && __float_as_uint(nd.score) == s_best_bits[p];
+    if (tied) {
+      atomicMax(&s_coarse[p], __float_as_uint(nd.coarse_score));
+      atomicAdd(&s_ties[p], 1);
+    }
+    __syncthreads();
+    const unsigned long long key =
+        (static_cast<unsigned long long>(static_cast<unsigned>(nd.coarse_index)) << 32) | nd.path;
+    const bool top = tied && __float_as_uint(nd.coarse_score) == s_coarse[p];
+    if (top) atomicMin(&s_key[p], key);
+    __syncthreads();
+    if (top && key == s_key[p]) {     // duplicates (dive + search) carry identical content
+      s_scan[p] = nd.scan; s_dx[p] = nd.dx; s_dy[p] = nd.dy;
+      BestLeaf b;
+      b.score = nd.score; b.scan = nd.scan; b.dx = nd.dx; b.dy = nd.dy;
+      b.found = 1; b.ties = 1; b.pad0 = b.pad1 = 0;
+      best[p] = b;
+    }
+    __syncthreads();
+    if (static_cast<int>(threadIdx.x) < num_problems) s_ties[threadIdx.x] = 0;
+    __syncthreads();
+    // ties = 1 + tied records that are a DIFFERENT leaf than the chosen one.
+    if (tied && (nd.scan != s_scan[p] || nd.dx != s_dx[p] || nd.dy != s_dy[p]))
+      atomicAdd(&s_ties[p], 1);
+    __syncthreads();
+    if (static_cast<int>(threadIdx.x) < num_problems) {
+      const int q = threadIdx.x;
+      sel[q].best_coarse_bits = s_coarse[q];
+      sel[q].key = s_key[q];
+      sel[q].ties = s_ties[q];
+      if (s_scan[q] < 0) {
+        BestLeaf b{};
+        best[q] = b;
+      } else {
+        best[q].ties = 1 + s_ties[q];
+      }
+    }
+    return;
+  }
   for (int p = threadIdx.x; p < num_problems; p += blockDim.x) {
     sel[p].best_coarse_bits = 0;
     sel[p].ties = 0;
@@ -1508,6 +1570,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
       P.init_qz = std::sin(ha) * 1.f;
     }
     P.num_scans = h.num_scans;
+    P.inv_res = 1.0 / P.res;
     P.scan_rot = m.RotationTable(h.step, h.num_angular);
     P.min_s = m.min_s();
     P.score_scale = m.score_scale();

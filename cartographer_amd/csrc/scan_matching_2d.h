@@ -34,6 +34,7 @@ struct Fast2DProblem {
   int nx, ny;           // CellLimits
   int nl;               // linear window in cells (bounds start at +-nl)
   double res, max_x, max_y;
+  double inv_res;       // RN(1 / res), for the division-free cell index (cmx_device.h)
   float tx, ty;         // initial translation narrowed to f32
   float init_qw, init_qz;   // Quaternion(AngleAxisf(f32(theta0), Z))
   int num_scans;
