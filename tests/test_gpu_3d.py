@@ -231,3 +231,57 @@ def test_fast3d_invalid_arguments(sm3, synth):
         gm.match(sm3.Rigid3d(), sm3.Rigid3d(),
                  sm3.TrajectoryNodeData(FAST3D_CLOUD, FAST3D_CLOUD, np.zeros(7, np.float32)), 0.1)
     assert e.value.status == INVALID_ARGUMENT
+
+
+# ----------------------------------------------------------------------------
+# BASELINE-sized inputs
+# ----------------------------------------------------------------------------
+def test_rt3d_c4_sized_cloud_and_grid(sm3, oracle, synth):
+    """C4's data sizes (64 x 1024 cloud, 15 x 15 x 7.5 m room at 0.1 m) with a window the
+    oracle finishes in seconds: 27 translations x 27 rotations over all 65 536 points."""
+    grid, world = synth.make_submap_3d(42, 0.1, (15.0, 15.0, 7.5), 8, 32, 512)
+    vox = grid.voxels()
+    pos = world.free_position(77, 0.5)
+    cloud = world.scan(pos, 0.3, 64, 1024, seed=9)
+    assert cloud.shape[0] > 60000
+    q = quat_from_angle_axis(0.31, [0, 0, 1])
+    init = list(pos + np.array([0.07, -0.04, 0.02])) + q
+    r_max = float(np.linalg.norm(cloud, axis=1).max())
+    step = (1 - 1e-3) * math.acos(1 - 0.1 ** 2 / (2 * r_max ** 2))
+    ang = 1.2 * step                                # lround(ang / step) == 1
+    ref = oracle.rt3d_match(0.1, vox, init, cloud, 0.1, ang, 0.1, 0.1)
+    assert ref["num_candidates"] == 27 * 27
+    m = sm3.RealTimeCorrelativeScanMatcher3D(0.1, ang, 0.1, 0.1)
+    score, pose = m.match(sm3.Rigid3d(tuple(init[:3]), tuple(init[3:])), cloud, 0.1, vox)
+    assert m.last_stats["candidates_scored"] == ref["num_candidates"]
+    assert np.float32(score) == np.float32(ref["score"])
+    np.testing.assert_array_equal(_pose7(pose), ref["pose"])
+
+
+def test_fast3d_c5_sized_submap(sm3, oracle, synth):
+    """One submap of C5: hi 0.1 m / low 0.45 m, depth 8 / full_resolution_depth 3, the
+    pose_graph.lua windows (5 m, 1 m, 15 deg), 120-bin histograms."""
+    size = (15.0, 15.0, 7.5)
+    grid, world = synth.make_submap_3d(42, 0.1, size, 8, 32, 512)
+    low, _ = synth.make_submap_3d(42, 0.45, size, 8, 32, 512)
+    vox, low_vox = grid.voxels(), low.voxels()
+    rng = np.random.default_rng(1)
+    hist = rng.uniform(0.0, 1.0, 120).astype(np.float32)
+    hist[10:14] += 6.0
+    pos = world.free_position(77, 0.6)
+    yaw = 0.4
+    full = world.scan(pos, yaw, 32, 512, seed=1)
+    hi, lo = full[::6].copy(), full[::80].copy()
+    scan_hist = np.roll(hist, -19).copy()
+    opt = dict(branch_and_bound_depth=8, full_resolution_depth=3, min_rotational_score=0.77,
+               min_low_resolution_score=0.35, linear_xy_search_window=5.0,
+               linear_z_search_window=1.0, angular_search_window=math.radians(15.0))
+    om, gm = _both(sm3, oracle, 0.1, vox, grid.grid_size, 0.45, low_vox, hist, **opt)
+    node = [pos[0] + 0.8, pos[1] - 0.6, pos[2] + 0.2] + quat_from_angle_axis(yaw + 0.1, [0, 0, 1])
+    ident = [0, 0, 0, 1, 0, 0, 0]
+    for min_score in (0.2, 0.6):
+        ref = om.match(node, ident, [1, 0, 0, 0], hi, lo, scan_hist, min_score)
+        got = gm.match(sm3.Rigid3d(tuple(node[:3]), tuple(node[3:])), sm3.Rigid3d(),
+                       sm3.TrajectoryNodeData(hi, lo, scan_hist), min_score)
+        _assert_result(ref, got)
+        assert gm.last_stats["num_scans"] == ref["num_scans"] > 0
