@@ -90,6 +90,7 @@ EXPORTED_SYMBOLS = [
     "cmx_version", "cmx_status_string", "cmx_last_error", "cmx_device_count", "cmx_set_stream",
     "cmx_rt2d_match", "cmx_rt2d_match_tsdf", "cmx_grid2d_create", "cmx_grid2d_destroy",
     "cmx_grid2d_get_limits", "cmx_grid2d_download", "cmx_grid2d_insert", "cmx_rt2d_match_grid",
+    "cmx_rt2d_match_grid_batch",
     "cmx_fast2d_create", "cmx_fast2d_create_from_grid", "cmx_fast2d_destroy", "cmx_fast2d_match",
     "cmx_fast2d_match_full_submap", "cmx_fast2d_match_batch",
     "cmx_fast2d_match_full_submap_batch", "cmx_cloud_upload",
@@ -137,6 +138,9 @@ def lib():
                                     C.c_int32, C.c_float, C.c_float, C.c_int32]
     L.cmx_rt2d_match_grid.argtypes = [P(RtOptions), C.c_void_p, P(Pose2d), C.c_void_p, C.c_int32,
                                       P(C.c_double), P(Pose2d), P(MatchStats)]
+    L.cmx_rt2d_match_grid_batch.argtypes = [P(RtOptions), P(C.c_void_p), C.c_int32, C.c_void_p,
+                                            P(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,
+                                            P(MatchStats)]
     L.cmx_fast2d_create_from_grid.argtypes = [P(Fast2DOptions), C.c_void_p, P(C.c_void_p)]
     L.cmx_fast2d_create.argtypes = [P(Fast2DOptions), P(Grid2DLimits), C.c_void_p, C.c_int32,
                                     P(C.c_void_p)]

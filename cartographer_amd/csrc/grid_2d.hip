@@ -351,6 +351,39 @@ extern "C" cmx_status cmx_rt2d_match_grid(const cmx_rt_options* options, const c
   });
 }
 
+extern "C" cmx_status cmx_rt2d_match_grid_batch(const cmx_rt_options* options,
+                                                const cmx_grid2d* const* grids,
+                                                int32_t num_matches,
+                                                const cmx_pose2d* initial_pose_estimates,
+                                                const float* const* point_clouds_xyz,
+                                                const int32_t* num_points, double* scores,
+                                                cmx_pose2d* pose_estimates,
+                                                cmx_match_stats* stats) {
+  return Guard([&] {
+    CMX_REQUIRE(grids && initial_pose_estimates && point_clouds_xyz && num_points && scores &&
+                    pose_estimates && num_matches >= 1,
+                "null argument");
+    std::vector<cmx_grid2d_limits> limits(num_matches);
+    std::vector<cmx::Rt2DItem> items(num_matches);
+    for (int m = 0; m < num_matches; ++m) {
+      const cmx_grid2d* g = grids[m];
+      CMX_REQUIRE(g != nullptr, "null grid");
+      CMX_REQUIRE(g->device == grids[0]->device, "all grids of a batch must live on one device");
+      limits[m] = cmx_grid2d_limits{g->resolution, g->max_x, g->max_y, g->nx, g->ny, 0.f, 0.f};
+      cmx::Rt2DItem item{};
+      item.limits = &limits[m];
+      item.device_cells = g->cells;
+      item.initial = &initial_pose_estimates[m];
+      item.xyz = point_clouds_xyz[m];
+      item.n = num_points[m];
+      item.score = &scores[m];
+      item.pose = &pose_estimates[m];
+      items[m] = item;
+    }
+    cmx::Rt2DMatchBatch(options, items.data(), num_matches, grids[0]->device, stats);
+  });
+}
+
 extern "C" cmx_status cmx_fast2d_create_from_grid(const cmx_fast2d_options* options,
                                                   const cmx_grid2d* grid, cmx_fast2d** out) {
   return Guard([&] {

@@ -48,7 +48,14 @@ struct Rt2DParams {
   int n_pad;                 // n rounded up to a multiple of 64
   void* padded;              // float[rows][stride] or float2[rows][stride]
   int pad, stride, rows;
-  unsigned* misc;            // [0] max weighted score bits, [1] finalist count
+  unsigned* misc;            // [0] max weighted score bits, [1] finalist count, then pairs
+  unsigned* overflow;        // finalist pairs beyond kFinalistHead
+  const float* xyz;          // device point cloud
+  int n;
+  float* unweighted;         // [num_candidates]
+  float* weighted;
+  int num_candidates;
+  int prep_blocks;           // num_scans + blocks of the grid expansion
 };
 
 // ProbabilityGrid::GetProbability (mapping/2d/probability_grid.cc:78-82) with
@@ -87,9 +94,15 @@ __device__ __forceinline__ float2 TsdfTerm(float tsd, float weight, float max_ts
   return make_float2(normalized * weight, weight);
 }
 
+// Every kernel serves a batch of independent matches: blockIdx.z picks the match, blocks
+// beyond a match's own extent return at once.
 template <bool kTsdf>
 __global__ void __launch_bounds__(256)
-Rt2DPrepKernel(Rt2DParams P, const float* __restrict__ xyz, int n) {
+Rt2DPrepKernel(const Rt2DParams* __restrict__ params) {
+  const Rt2DParams& P = params[blockIdx.z];
+  if (static_cast<int>(blockIdx.x) >= P.prep_blocks) return;
+  const float* __restrict__ xyz = P.xyz;
+  const int n = P.n;
   if (blockIdx.x == 0 && threadIdx.x == 0) { P.misc[0] = 0u; P.misc[1] = 0u; }
   if (blockIdx.x < P.num_scans) {
     const int s = blockIdx.x;
@@ -173,11 +186,15 @@ struct Acc<true> {
 // grid (ceil(side^2 / 64), num_scans), one wavefront per block.
 template <bool kTsdf>
 __global__ void __launch_bounds__(64)
-Rt2DScoreKernel(Rt2DParams P, int n, float* __restrict__ unweighted,
-                float* __restrict__ weighted) {
+Rt2DScoreKernel(const Rt2DParams* __restrict__ params) {
   using Cell = typename Acc<kTsdf>::Cell;
+  const Rt2DParams& P = params[blockIdx.z];
   const int s = blockIdx.y;
   const int side = 2 * P.nl + 1;
+  if (s >= P.num_scans || static_cast<int>(blockIdx.x) * 64 >= side * side) return;
+  const int n = P.n;
+  float* __restrict__ unweighted = P.unweighted;
+  float* __restrict__ weighted = P.weighted;
   const int rem = blockIdx.x * 64 + threadIdx.x;
   const bool valid = rem < side * side;
   const int r = valid ? rem : 0;
@@ -265,219 +282,408 @@ Rt2DScoreKernel(Rt2DParams P, int n, float* __restrict__ unweighted,
   if (threadIdx.x == 0) atomicMax(&P.misc[0], bits);
 }
 
-// Candidates whose device-weighted score is within 1e-5 of the maximum, with
-// their exact unweighted score: (index, score bits) pairs after the 2-word header.
-__global__ void Rt2DCollectKernel(const float* __restrict__ weighted,
-                                  const float* __restrict__ unweighted, int num_candidates,
-                                  unsigned* __restrict__ misc, int capacity) {
+// Probability grid, four candidates per lane: a lane owns the x offsets 4g .. 4g+3 of one
+// y offset and reads their four cells with ONE dwordx4 gather (the cells are adjacent in a
+// row of the padded grid).  A rotation's 13 x 13 window then is a single wavefront
+// (13 rows x 4 groups = 52 lanes), a quarter of the gather instructions of the scalar
+// variant; the four f32 sums per lane stay sequential in point order.
+// grid (ceil(side * ceil(side/4) / 64), num_scans, matches), one wavefront per block.
+__global__ void __launch_bounds__(64)
+Rt2DScoreX4Kernel(const Rt2DParams* __restrict__ params) {
+  const Rt2DParams& P = params[blockIdx.z];
+  const int s = blockIdx.y;
+  const int side = 2 * P.nl + 1;
+  const int groups = (side + 3) / 4;
+  if (s >= P.num_scans || static_cast<int>(blockIdx.x) * 64 >= side * groups) return;
+  const int n = P.n;
+  const int slot = blockIdx.x * 64 + threadIdx.x;
+  const bool lane_valid = slot < side * groups;
+  const int r = lane_valid ? slot : 0;
+  const int dyi = r / groups, g = r - dyi * groups;
+  // The last group of a row may reach up to three cells past the window (and, in the
+  // very last row, past the grid: the buffer descriptor returns 0 there); those sums
+  // belong to no candidate and are dropped.
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      P.padded, 0, (P.stride * P.rows + 1) * 4, 0x00020000);
+  const int lane_off = (dyi * P.stride + 4 * g) * 4;
+  const int* __restrict__ offs = P.offsets + static_cast<size_t>(s) * P.n_pad;
+  typedef float float4v __attribute__((ext_vector_type(4)));
+  const auto gather = [&](int off) -> float4v {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, off, 0);
+    return float4v{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
+                   __uint_as_float(v[3])};
+  };
+
+  constexpr int kChunks = 16;
+  constexpr int kBatch = 8;                 // x 16 bytes per lane in flight
+  constexpr int kPerChunk = 64 / kBatch;
+  const int lane = threadIdx.x;
+  const int chunks = P.n_pad / 64;
+  float4v acc = {0.f, 0.f, 0.f, 0.f};
+  int ov[kChunks], ovn[kChunks];
+#pragma unroll
+  for (int c = 0; c < kChunks; ++c) ov[c] = c < chunks ? offs[c * 64 + lane] : 0;
+  for (int base = 0; base < chunks; base += kChunks) {
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c)
+      ovn[c] = base + kChunks + c < chunks ? offs[(base + kChunks + c) * 64 + lane] : 0;
+    const int live = min(kChunks, chunks - base);
+    float4v a[kBatch], b[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) a[k] = gather(__builtin_amdgcn_readlane(ov[0], k));
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) {
+      if (c < live) {
+#pragma unroll
+        for (int h = 0; h < kPerChunk; ++h) {
+          float4v* cur = (h & 1) ? b : a;
+          float4v* nxt = (h & 1) ? a : b;
+          if (h + 1 < kPerChunk) {
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k)
+              nxt[k] = gather(__builtin_amdgcn_readlane(ov[c], (h + 1) * kBatch + k));
+          } else if (c + 1 < kChunks) {
+            if (c + 1 < live) {
+#pragma unroll
+              for (int k = 0; k < kBatch; ++k)
+                nxt[k] = gather(__builtin_amdgcn_readlane(ov[c + 1], k));
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < kBatch; ++k) acc += cur[k];   // four independent f32 chains
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) ov[c] = ovn[c];
+  }
+
+  float w_max = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int dxi = 4 * g + j;
+    if (lane_valid && dxi < side) {
+      const float score = acc[j] / static_cast<float>(n);
+      const int dx = dxi - P.nl, dy = dyi - P.nl;
+      const int c = (s * side + dxi) * side + dyi;            // x outer, y inner (:99-113)
+      P.unweighted[c] = score;
+      const double cx = -dy * P.res, cy = -dx * P.res;
+      const double theta = (s - P.num_angular) * P.step;
+      const double t = hypot(cx, cy) * P.wt + fabs(theta) * P.wr;
+      const float w = static_cast<float>(static_cast<double>(score) * exp(-(t * t)));
+      P.weighted[c] = w;
+      w_max = fmaxf(w_max, w);
+    }
+  }
+  unsigned bits = __float_as_uint(w_max);   // scores are >= 0
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) bits = max(bits, __shfl_xor(bits, off, 64));
+  if (threadIdx.x == 0) atomicMax(&P.misc[0], bits);
+}
+
+// Candidates whose device-weighted score is within 1e-5 of the maximum, with their exact
+// unweighted score: (index, score bits) pairs -- the first kFinalistHead next to the
+// counters (they travel back with them), the rest in the overflow region.
+constexpr int kFinalistCap = 4096;
+constexpr int kFinalistHead = 62;   // 2 + 2 * 62 words = 512 bytes per match
+
+__global__ void Rt2DCollectKernel(const Rt2DParams* __restrict__ params) {
+  const Rt2DParams& P = params[blockIdx.z];
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= num_candidates) return;
-  const float threshold = __uint_as_float(misc[0]) * (1.f - 1e-5f);
-  if (weighted[c] >= threshold) {
-    const unsigned slot = atomicAdd(&misc[1], 1u);
-    if (slot < static_cast<unsigned>(capacity)) {
-      misc[2 + 2 * slot] = static_cast<unsigned>(c);
-      misc[3 + 2 * slot] = __float_as_uint(unweighted[c]);
+  if (c >= P.num_candidates) return;
+  const float threshold = __uint_as_float(P.misc[0]) * (1.f - 1e-5f);
+  if (P.weighted[c] >= threshold) {
+    const unsigned slot = atomicAdd(&P.misc[1], 1u);
+    if (slot < static_cast<unsigned>(kFinalistCap)) {
+      unsigned* pair = slot < static_cast<unsigned>(kFinalistHead)
+                           ? P.misc + 2 + 2 * slot
+                           : P.overflow + 2 * (slot - kFinalistHead);
+      pair[0] = static_cast<unsigned>(c);
+      pair[1] = __float_as_uint(P.unweighted[c]);
     }
   }
 }
-
-constexpr int kFinalistCap = 4096;
-constexpr int kFinalistHead = 62;   // pairs returned with the first (512-byte) read
 
 size_t Align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
 
 }  // namespace
 
-// `cells` is a host buffer, or -- when `device_cells` is given -- ignored in favour of a
-// grid that already lives in HBM (cmx_grid2d): nothing but the scan is uploaded then.
+// A batch of independent matches (one per trajectory / robot) in one set of launches.  Per
+// item `cells` is a host buffer, or -- when `device_cells` is given -- ignored in favour of
+// a grid that already lives in HBM (cmx_grid2d): nothing but the scan is uploaded then.
+void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int num, int32_t device,
+                    cmx_match_stats* stats) {
+  CMX_REQUIRE(options && items && num >= 1, "null argument");
+  struct Plan {
+    int n, nx, ny, nl, na, num_scans, n_pad, pad;
+    long long side, num_candidates, stride, rows;
+    double res, step;
+    float q0w, q0z;
+    size_t off_xyz, off_rot, off_cells, off_weights;          // in the staging buffer
+    size_t off_offsets, off_padded, off_scores;                // element offsets, device
+  };
+  std::vector<Plan> plan(num);
+  const bool tsdf = items[0].weight_cells != nullptr;
+  size_t in_bytes = Align16(sizeof(Rt2DParams) * num);
+  size_t offsets_total = 0, padded_bytes = 0, scores_total = 0;
+  unsigned max_prep = 0, max_tiles = 0, max_tiles4 = 0, max_scans = 0, max_collect = 0;
+  for (int m = 0; m < num; ++m) {
+    const Rt2DItem& it = items[m];
+    Plan& pl = plan[m];
+    CMX_REQUIRE(it.limits && (it.cells || it.device_cells) && it.initial && it.xyz,
+                "null argument");
+    CMX_REQUIRE(it.pose != nullptr && it.score != nullptr,
+                "pose_estimate must not be null");            // CHECK at :121
+    CMX_REQUIRE(it.n >= 1 && it.n <= (1 << 24), "bad point count");
+    CMX_REQUIRE(it.limits->resolution > 0. && it.limits->num_x_cells >= 1 &&
+                    it.limits->num_y_cells >= 1,
+                "bad map limits");
+    CMX_REQUIRE((it.weight_cells != nullptr) == tsdf, "mixed grid types in one batch");
+    if (tsdf) CMX_REQUIRE(it.max_tsd > 0.f && it.max_weight > 0.f, "bad TSDF ranges");
+    pl.n = it.n; pl.nx = it.limits->num_x_cells; pl.ny = it.limits->num_y_cells;
+    pl.res = it.limits->resolution;
+    const int n = pl.n;
+    const double res = pl.res;
+
+    // SearchParameters on the cloud pre-rotated by the initial yaw (:123-130).
+    const float ha0 = 0.5f * static_cast<float>(it.initial->theta);
+    const float q0w = std::cos(ha0), q0z = std::sin(ha0) * 1.f;
+    float max_scan_range = 3.f * res;
+    for (int i = 0; i < n; ++i) {
+      // Same rotation as the device applies (Eigen operation order), f32.
+      const float px = it.xyz[3 * i], py = it.xyz[3 * i + 1], pz = it.xyz[3 * i + 2];
+      const float qx = 0.f, qy = 0.f;
+      float uvx = qy * pz - q0z * py, uvy = q0z * px - qx * pz, uvz = qx * py - qy * px;
+      uvx += uvx; uvy += uvy; uvz += uvz;
+      const float cxx = qy * uvz - q0z * uvy, cyy = q0z * uvx - qx * uvz;
+      const float rx = ((px + q0w * uvx) + cxx) + 0.f, ry = ((py + q0w * uvy) + cyy) + 0.f;
+      const float range = std::sqrt(rx * rx + ry * ry);
+      max_scan_range = std::max(range, max_scan_range);
+    }
+    const double kSafetyMargin = 1. - 1e-3;
+    const float range_sq = max_scan_range * (max_scan_range * 1.f);
+    pl.step = kSafetyMargin * std::acos(1. - (res * (res * 1.)) / (2. * range_sq));
+    pl.na = std::ceil(options->angular_search_window / pl.step);
+    pl.num_scans = 2 * pl.na + 1;
+    pl.nl = std::ceil(options->linear_search_window / res);
+    CMX_REQUIRE(pl.num_scans >= 1 && pl.num_scans < (1 << 16) && pl.nl >= 0 && pl.nl < (1 << 12),
+                "unsupported search window");
+    pl.side = 2ll * pl.nl + 1;
+    pl.num_candidates = pl.side * pl.side * pl.num_scans;
+    CMX_REQUIRE(pl.num_candidates < (1ll << 30), "search window too large");
+    pl.pad = 2 * pl.nl + 1;
+    pl.stride = pl.nx + 2ll * pl.pad;
+    pl.rows = pl.ny + 2ll * pl.pad;
+    CMX_REQUIRE(pl.stride * pl.rows < (1ll << 27), "grid plus search window too large");
+    CMX_REQUIRE(static_cast<long long>(pl.num_scans) * n < (1ll << 30), "too many rotated points");
+    pl.q0w = q0w; pl.q0z = q0z;
+    pl.n_pad = (n + 63) / 64 * 64;
+
+    // Staging buffer: [params | per item: xyz | rotations | cells | weight cells].
+    const size_t cell_count = static_cast<size_t>(pl.nx) * pl.ny;
+    pl.off_xyz = in_bytes;
+    pl.off_rot = pl.off_xyz + Align16(3 * sizeof(float) * n);
+    pl.off_cells = pl.off_rot + Align16(sizeof(float2) * pl.num_scans);
+    pl.off_weights =
+        pl.off_cells + (it.device_cells ? 0 : Align16(sizeof(uint16_t) * cell_count));
+    in_bytes = pl.off_weights + (tsdf ? Align16(sizeof(uint16_t) * cell_count) : 0);
+    pl.off_offsets = offsets_total;
+    offsets_total += static_cast<size_t>(pl.num_scans) * pl.n_pad;
+    pl.off_padded = padded_bytes;
+    padded_bytes += Align16(static_cast<size_t>(pl.stride * pl.rows + 1) *
+                            (tsdf ? sizeof(float2) : sizeof(float)));
+    pl.off_scores = scores_total;
+    scores_total += static_cast<size_t>(pl.num_candidates);
+    max_prep = std::max<unsigned>(max_prep, pl.num_scans + DivUp(pl.stride * pl.rows, 1024));
+    max_tiles = std::max<unsigned>(max_tiles, DivUp(pl.side * pl.side, 64));
+    max_tiles4 = std::max<unsigned>(max_tiles4, DivUp(pl.side * ((pl.side + 3) / 4), 64));
+    max_scans = std::max<unsigned>(max_scans, pl.num_scans);
+    max_collect = std::max<unsigned>(max_collect, DivUp(pl.num_candidates, 256));
+  }
+  CMX_REQUIRE(num <= 65535, "too many matches in one batch");
+
+  WorkspaceLease ws(device);
+  char* h_in = ws->pinned[0].ReserveAs<char>(in_bytes);
+  char* d_in = ws->dev[0].ReserveAs<char>(in_bytes);
+  int* d_offsets = ws->dev[1].ReserveAs<int>(offsets_total);
+  char* d_padded = ws->dev[2].ReserveAs<char>(padded_bytes);
+  float* d_unweighted = ws->dev[3].ReserveAs<float>(scores_total);
+  float* d_weighted = ws->dev[4].ReserveAs<float>(scores_total);
+  constexpr int kHeadWords = 2 + 2 * kFinalistHead;             // 126 words, padded to 128
+  unsigned* d_misc = ws->dev[5].ReserveAs<unsigned>(static_cast<size_t>(num) * 128);
+  unsigned* d_overflow = ws->dev[6].ReserveAs<unsigned>(static_cast<size_t>(num) * 2 *
+                                                        (kFinalistCap - kFinalistHead));
+  unsigned* h_misc = ws->pinned[1].ReserveAs<unsigned>(static_cast<size_t>(num) * 128);
+
+  Rt2DParams* h_params = reinterpret_cast<Rt2DParams*>(h_in);
+  for (int m = 0; m < num; ++m) {
+    const Rt2DItem& it = items[m];
+    const Plan& pl = plan[m];
+    const size_t cell_count = static_cast<size_t>(pl.nx) * pl.ny;
+    std::memcpy(h_in + pl.off_xyz, it.xyz, 3 * sizeof(float) * pl.n);
+    float2* h_rot = reinterpret_cast<float2*>(h_in + pl.off_rot);
+    double delta_theta = -pl.na * pl.step;
+    for (int s = 0; s < pl.num_scans; ++s, delta_theta += pl.step) {
+      const float ha = 0.5f * static_cast<float>(delta_theta);
+      h_rot[s] = make_float2(std::cos(ha), std::sin(ha) * 1.f);
+    }
+    if (!it.device_cells)
+      std::memcpy(h_in + pl.off_cells, it.cells, sizeof(uint16_t) * cell_count);
+    if (tsdf) std::memcpy(h_in + pl.off_weights, it.weight_cells, sizeof(uint16_t) * cell_count);
+
+    Rt2DParams P{};
+    P.cells = it.device_cells ? it.device_cells
+                              : reinterpret_cast<const uint16_t*>(d_in + pl.off_cells);
+    P.weights = tsdf ? reinterpret_cast<const uint16_t*>(d_in + pl.off_weights) : nullptr;
+    P.nx = pl.nx; P.ny = pl.ny;
+    P.res = pl.res; P.max_x = it.limits->max_x; P.max_y = it.limits->max_y;
+    P.tx = static_cast<float>(it.initial->x);
+    P.ty = static_cast<float>(it.initial->y);
+    P.init_qw = pl.q0w; P.init_qz = pl.q0z;
+    P.nl = pl.nl; P.num_scans = pl.num_scans; P.num_angular = pl.na;
+    P.step = pl.step;
+    P.wt = options->translation_delta_cost_weight;
+    P.wr = options->rotation_delta_cost_weight;
+    P.max_tsd = it.max_tsd; P.max_weight = it.max_weight;
+    P.scan_rot = reinterpret_cast<const float2*>(d_in + pl.off_rot);
+    P.offsets = d_offsets + pl.off_offsets;
+    P.n_pad = pl.n_pad;
+    P.padded = d_padded + pl.off_padded;
+    P.pad = pl.pad; P.stride = static_cast<int>(pl.stride); P.rows = static_cast<int>(pl.rows);
+    P.misc = d_misc + static_cast<size_t>(m) * 128;
+    P.overflow = d_overflow + static_cast<size_t>(m) * 2 * (kFinalistCap - kFinalistHead);
+    P.xyz = reinterpret_cast<const float*>(d_in + pl.off_xyz);
+    P.n = pl.n;
+    P.unweighted = d_unweighted + pl.off_scores;
+    P.weighted = d_weighted + pl.off_scores;
+    P.num_candidates = static_cast<int>(pl.num_candidates);
+    P.prep_blocks = pl.num_scans + static_cast<int>(DivUp(pl.stride * pl.rows, 1024));
+    h_params[m] = P;
+  }
+  CMX_HIP(hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, ws->stream));
+  const Rt2DParams* d_params = reinterpret_cast<const Rt2DParams*>(d_in);
+
+  CMX_HIP(hipEventRecord(ws->ev_begin, ws->stream));
+  const dim3 prep_grid(max_prep, 1, num), score_grid(max_tiles, max_scans, num),
+      collect_grid(max_collect, 1, num);
+  if (tsdf) {
+    Rt2DPrepKernel<true><<<prep_grid, 256, 0, ws->stream>>>(d_params);
+    CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
+    Rt2DScoreKernel<true><<<score_grid, 64, 0, ws->stream>>>(d_params);
+  } else {
+    Rt2DPrepKernel<false><<<prep_grid, 256, 0, ws->stream>>>(d_params);
+    CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
+    // One match (81 waves) is bound by the latency of its sequential sums: the scalar
+    // variant keeps 32 gathers in flight per wave (C1: 19 us vs 34 us).  From ~16
+    // concurrent matches on, the gather path is the limit and four candidates per
+    // gather win (128 matches: 169 us vs 293 us, 3.5e9 candidates/s).
+    if (num >= 16)
+      Rt2DScoreX4Kernel<<<dim3(max_tiles4, max_scans, num), 64, 0, ws->stream>>>(d_params);
+    else
+      Rt2DScoreKernel<false><<<score_grid, 64, 0, ws->stream>>>(d_params);
+  }
+  CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
+  Rt2DCollectKernel<<<collect_grid, 256, 0, ws->stream>>>(d_params);
+  CMX_HIP(hipGetLastError());
+  CMX_HIP(hipEventRecord(ws->ev_end, ws->stream));
+  CMX_HIP(hipMemcpyAsync(h_misc, d_misc, sizeof(unsigned) * 128 * num, hipMemcpyDeviceToHost,
+                         ws->stream));
+  CMX_HIP(hipStreamSynchronize(ws->stream));
+
+  // Exact weighting + first-maximum on the finalists (:142-143,170-174).
+  cmx_match_stats total{};
+  std::vector<std::pair<int, float>> finalists;
+  std::vector<unsigned> extra;
+  std::vector<float> all;
+  for (int m = 0; m < num; ++m) {
+    const Rt2DItem& it = items[m];
+    const Plan& pl = plan[m];
+    const unsigned* head = h_misc + static_cast<size_t>(m) * 128;
+    const long long count = head[1];
+    finalists.clear();
+    if (count <= kFinalistCap) {
+      finalists.resize(count);
+      const long long in_head = std::min<long long>(count, kFinalistHead);
+      if (count > kFinalistHead) {
+        extra.resize(2 * (count - kFinalistHead));
+        CMX_HIP(hipMemcpyAsync(extra.data(),
+                               d_overflow + static_cast<size_t>(m) * 2 *
+                                                (kFinalistCap - kFinalistHead),
+                               sizeof(unsigned) * extra.size(), hipMemcpyDeviceToHost,
+                               ws->stream));
+        CMX_HIP(hipStreamSynchronize(ws->stream));
+      }
+      for (long long i = 0; i < count; ++i) {
+        const unsigned* pair = i < in_head ? head + 2 + 2 * i : extra.data() + 2 * (i - in_head);
+        float v;
+        std::memcpy(&v, &pair[1], sizeof(float));
+        finalists[i] = {static_cast<int>(pair[0]), v};
+      }
+      std::sort(finalists.begin(), finalists.end());
+    } else {  // flat score landscape: take everything
+      all.resize(pl.num_candidates);
+      CMX_HIP(hipMemcpyAsync(all.data(), d_unweighted + pl.off_scores,
+                             sizeof(float) * pl.num_candidates, hipMemcpyDeviceToHost,
+                             ws->stream));
+      CMX_HIP(hipStreamSynchronize(ws->stream));
+      finalists.resize(pl.num_candidates);
+      for (long long c = 0; c < pl.num_candidates; ++c)
+        finalists[c] = {static_cast<int>(c), all[c]};
+    }
+    CMX_REQUIRE(!finalists.empty(), "internal error: no candidate collected");
+    const int side_i = static_cast<int>(pl.side), nl = pl.nl, na = pl.na;
+    const double res = pl.res, step = pl.step;
+    float best_score = -1.f;
+    int best = -1;
+    for (const auto& f : finalists) {
+      const int c = f.first;
+      const int s = c / (side_i * side_i);
+      const int rem = c - s * side_i * side_i;
+      const int dx = rem / side_i - nl, dy = rem % side_i - nl;
+      const double cx = -dy * res, cy = -dx * res;
+      const double theta = (s - na) * step;
+      const double t = std::hypot(cx, cy) * options->translation_delta_cost_weight +
+                       std::abs(theta) * options->rotation_delta_cost_weight;
+      float sc = f.second;
+      sc *= std::exp(-(t * (t * 1.)));
+      if (sc > best_score) { best_score = sc; best = c; }   // finalists ascend: first max wins
+    }
+    // CHECK_GT(score, 0) in the probability branch (:73); a TSDF may score 0 everywhere
+    // (CHECK_GE at :56), in which case the first candidate wins like std::max_element.
+    const int s = best / (side_i * side_i);
+    const int rem = best - s * side_i * side_i;
+    const int dx = rem / side_i - nl, dy = rem % side_i - nl;
+    it.pose->x = it.initial->x + (-dy * res);
+    it.pose->y = it.initial->y + (-dx * res);
+    it.pose->theta = it.initial->theta + (s - na) * step;
+    *it.score = best_score;
+    total.candidates_scored += pl.num_candidates;
+    total.coarse_candidates += pl.num_candidates;
+    total.num_scans += pl.num_scans;
+  }
+  if (stats) {
+    float ms = 0.f;
+    CMX_HIP(hipEventElapsedTime(&ms, ws->ev_begin, ws->ev_end));
+    total.device_ms = ms;
+    CMX_HIP(hipEventElapsedTime(&ms, ws->ev_k0, ws->ev_k1));
+    total.dominant_kernel_ms = ms;
+    *stats = total;
+  }
+}
+
 void Rt2DMatch(const cmx_rt_options* options, const cmx_grid2d_limits* limits,
                const uint16_t* cells, const uint16_t* weight_cells, float max_tsd,
                float max_weight, const cmx_pose2d* initial_pose_estimate,
                const float* point_cloud_xyz, int32_t num_points, int32_t device, double* score,
                cmx_pose2d* pose_estimate, cmx_match_stats* stats,
                const uint16_t* device_cells) {
-  CMX_REQUIRE(options && limits && (cells || device_cells) && initial_pose_estimate &&
-                  point_cloud_xyz,
-              "null argument");
-  CMX_REQUIRE(pose_estimate != nullptr && score != nullptr,
-              "pose_estimate must not be null");            // CHECK at :121
-  CMX_REQUIRE(num_points >= 1 && num_points <= (1 << 24), "bad point count");
-  CMX_REQUIRE(limits->resolution > 0. && limits->num_x_cells >= 1 && limits->num_y_cells >= 1,
-              "bad map limits");
-  const bool tsdf = weight_cells != nullptr;
-  if (tsdf) CMX_REQUIRE(max_tsd > 0.f && max_weight > 0.f, "bad TSDF ranges");
-  const int n = num_points, nx = limits->num_x_cells, ny = limits->num_y_cells;
-  const double res = limits->resolution;
-
-  // SearchParameters on the cloud pre-rotated by the initial yaw (:123-130).
-  const float ha0 = 0.5f * static_cast<float>(initial_pose_estimate->theta);
-  const float q0w = std::cos(ha0), q0z = std::sin(ha0) * 1.f;
-  float max_scan_range = 3.f * res;
-  for (int i = 0; i < n; ++i) {
-    // Same rotation as the device applies (Eigen operation order), f32.
-    const float px = point_cloud_xyz[3 * i], py = point_cloud_xyz[3 * i + 1],
-                pz = point_cloud_xyz[3 * i + 2];
-    const float qx = 0.f, qy = 0.f;
-    float uvx = qy * pz - q0z * py, uvy = q0z * px - qx * pz, uvz = qx * py - qy * px;
-    uvx += uvx; uvy += uvy; uvz += uvz;
-    const float cxx = qy * uvz - q0z * uvy, cyy = q0z * uvx - qx * uvz;
-    const float rx = ((px + q0w * uvx) + cxx) + 0.f, ry = ((py + q0w * uvy) + cyy) + 0.f;
-    const float range = std::sqrt(rx * rx + ry * ry);
-    max_scan_range = std::max(range, max_scan_range);
-  }
-  const double kSafetyMargin = 1. - 1e-3;
-  const float range_sq = max_scan_range * (max_scan_range * 1.f);
-  const double step = kSafetyMargin * std::acos(1. - (res * (res * 1.)) / (2. * range_sq));
-  const int na = std::ceil(options->angular_search_window / step);
-  const int num_scans = 2 * na + 1;
-  const int nl = std::ceil(options->linear_search_window / res);
-  CMX_REQUIRE(num_scans >= 1 && num_scans < (1 << 16) && nl >= 0 && nl < (1 << 12),
-              "unsupported search window");
-  const long long side = 2ll * nl + 1;
-  const long long num_candidates = side * side * num_scans;
-  CMX_REQUIRE(num_candidates < (1ll << 30), "search window too large");
-  const int pad = 2 * nl + 1;
-  const long long stride = nx + 2ll * pad, rows = ny + 2ll * pad;
-  CMX_REQUIRE(stride * rows < (1ll << 27), "grid plus search window too large");
-  CMX_REQUIRE(static_cast<long long>(num_scans) * n < (1ll << 30), "too many rotated points");
-
-  WorkspaceLease ws(device);
-  // One staging buffer: [xyz | rotations | cells | weight cells] -> one H2D copy.
-  const size_t cell_count = static_cast<size_t>(nx) * ny;
-  const size_t off_rot = Align16(3 * sizeof(float) * n);
-  const size_t off_cells = off_rot + Align16(sizeof(float2) * num_scans);
-  const size_t off_weights =
-      off_cells + (device_cells ? 0 : Align16(sizeof(uint16_t) * cell_count));
-  const size_t in_bytes = off_weights + (tsdf ? Align16(sizeof(uint16_t) * cell_count) : 0);
-  char* h_in = ws->pinned[0].ReserveAs<char>(in_bytes);
-  char* d_in = ws->dev[0].ReserveAs<char>(in_bytes);
-  std::memcpy(h_in, point_cloud_xyz, 3 * sizeof(float) * n);
-  float2* h_rot = reinterpret_cast<float2*>(h_in + off_rot);
-  double delta_theta = -na * step;
-  for (int s = 0; s < num_scans; ++s, delta_theta += step) {
-    const float ha = 0.5f * static_cast<float>(delta_theta);
-    h_rot[s] = make_float2(std::cos(ha), std::sin(ha) * 1.f);
-  }
-  if (!device_cells) std::memcpy(h_in + off_cells, cells, sizeof(uint16_t) * cell_count);
-  if (tsdf) std::memcpy(h_in + off_weights, weight_cells, sizeof(uint16_t) * cell_count);
-
-  const int n_pad = (n + 63) / 64 * 64;
-  int* d_offsets = ws->dev[1].ReserveAs<int>(static_cast<size_t>(num_scans) * n_pad);
-  void* d_padded = ws->dev[2].ReserveAs<char>(static_cast<size_t>(stride * rows + 1) *
-                                               (tsdf ? sizeof(float2) : sizeof(float)));
-  float* d_unweighted = ws->dev[3].ReserveAs<float>(num_candidates);
-  float* d_weighted = ws->dev[4].ReserveAs<float>(num_candidates);
-  unsigned* d_misc = ws->dev[5].ReserveAs<unsigned>(2 + 2 * kFinalistCap);
-  unsigned* h_misc = ws->pinned[1].ReserveAs<unsigned>(2 + 2 * kFinalistCap);
-
-  CMX_HIP(hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, ws->stream));
-
-  Rt2DParams P;
-  P.cells = device_cells ? device_cells : reinterpret_cast<const uint16_t*>(d_in + off_cells);
-  P.weights = tsdf ? reinterpret_cast<const uint16_t*>(d_in + off_weights) : nullptr;
-  P.nx = nx; P.ny = ny;
-  P.res = res; P.max_x = limits->max_x; P.max_y = limits->max_y;
-  P.tx = static_cast<float>(initial_pose_estimate->x);
-  P.ty = static_cast<float>(initial_pose_estimate->y);
-  P.init_qw = q0w; P.init_qz = q0z;
-  P.nl = nl; P.num_scans = num_scans; P.num_angular = na;
-  P.step = step;
-  P.wt = options->translation_delta_cost_weight;
-  P.wr = options->rotation_delta_cost_weight;
-  P.max_tsd = max_tsd; P.max_weight = max_weight;
-  P.scan_rot = reinterpret_cast<const float2*>(d_in + off_rot);
-  P.offsets = d_offsets;
-  P.n_pad = n_pad;
-  P.padded = d_padded;
-  P.pad = pad; P.stride = static_cast<int>(stride); P.rows = static_cast<int>(rows);
-  P.misc = d_misc;
-  const float* d_xyz = reinterpret_cast<const float*>(d_in);
-
-  CMX_HIP(hipEventRecord(ws->ev_begin, ws->stream));
-  const int prep_blocks = num_scans + static_cast<int>(DivUp(stride * rows, 1024));
-  const dim3 score_grid(static_cast<unsigned>(DivUp(side * side, 64)), num_scans);
-  if (tsdf) {
-    Rt2DPrepKernel<true><<<prep_blocks, 256, 0, ws->stream>>>(P, d_xyz, n);
-    CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
-    Rt2DScoreKernel<true><<<score_grid, 64, 0, ws->stream>>>(P, n, d_unweighted, d_weighted);
-  } else {
-    Rt2DPrepKernel<false><<<prep_blocks, 256, 0, ws->stream>>>(P, d_xyz, n);
-    CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
-    Rt2DScoreKernel<false><<<score_grid, 64, 0, ws->stream>>>(P, n, d_unweighted, d_weighted);
-  }
-  CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
-  Rt2DCollectKernel<<<DivUp(num_candidates, 256), 256, 0, ws->stream>>>(
-      d_weighted, d_unweighted, static_cast<int>(num_candidates), d_misc, kFinalistCap);
-  CMX_HIP(hipGetLastError());
-  CMX_HIP(hipEventRecord(ws->ev_end, ws->stream));
-  CMX_HIP(hipMemcpyAsync(h_misc, d_misc, sizeof(unsigned) * (2 + 2 * kFinalistHead),
-                         hipMemcpyDeviceToHost, ws->stream));
-  CMX_HIP(hipStreamSynchronize(ws->stream));
-
-  // Exact weighting + first-maximum on the finalists (:142-143,170-174).
-  std::vector<std::pair<int, float>> finalists;
-  const long long count = h_misc[1];
-  if (count <= kFinalistCap) {
-    if (count > kFinalistHead) {
-      CMX_HIP(hipMemcpyAsync(h_misc, d_misc, sizeof(unsigned) * (2 + 2 * count),
-                             hipMemcpyDeviceToHost, ws->stream));
-      CMX_HIP(hipStreamSynchronize(ws->stream));
-    }
-    finalists.resize(count);
-    for (long long i = 0; i < count; ++i) {
-      float v;
-      std::memcpy(&v, &h_misc[3 + 2 * i], sizeof(float));
-      finalists[i] = {static_cast<int>(h_misc[2 + 2 * i]), v};
-    }
-    std::sort(finalists.begin(), finalists.end());
-  } else {  // flat score landscape: take everything
-    std::vector<float> all(num_candidates);
-    CMX_HIP(hipMemcpyAsync(all.data(), d_unweighted, sizeof(float) * num_candidates,
-                           hipMemcpyDeviceToHost, ws->stream));
-    CMX_HIP(hipStreamSynchronize(ws->stream));
-    finalists.resize(num_candidates);
-    for (long long c = 0; c < num_candidates; ++c) finalists[c] = {static_cast<int>(c), all[c]};
-  }
-  CMX_REQUIRE(!finalists.empty(), "internal error: no candidate collected");
-  const int side_i = static_cast<int>(side);
-  float best_score = -1.f;
-  int best = -1;
-  for (const auto& f : finalists) {
-    const int c = f.first;
-    const int s = c / (side_i * side_i);
-    const int rem = c - s * side_i * side_i;
-    const int dx = rem / side_i - nl, dy = rem % side_i - nl;
-    const double cx = -dy * res, cy = -dx * res;
-    const double theta = (s - na) * step;
-    const double t = std::hypot(cx, cy) * P.wt + std::abs(theta) * P.wr;
-    float sc = f.second;
-    sc *= std::exp(-(t * (t * 1.)));
-    if (sc > best_score) { best_score = sc; best = c; }   // finalists ascend: first max wins
-  }
-  // CHECK_GT(score, 0) in the probability branch (:73); a TSDF may score 0 everywhere
-  // (CHECK_GE at :56), in which case the first candidate wins like std::max_element.
-  {
-    const int s = best / (side_i * side_i);
-    const int rem = best - s * side_i * side_i;
-    const int dx = rem / side_i - nl, dy = rem % side_i - nl;
-    pose_estimate->x = initial_pose_estimate->x + (-dy * res);
-    pose_estimate->y = initial_pose_estimate->y + (-dx * res);
-    pose_estimate->theta = initial_pose_estimate->theta + (s - na) * step;
-    *score = best_score;
-  }
-  if (stats) {
-    cmx_match_stats st{};
-    st.candidates_scored = num_candidates;
-    st.coarse_candidates = num_candidates;
-    st.num_scans = num_scans;
-    float ms = 0.f;
-    CMX_HIP(hipEventElapsedTime(&ms, ws->ev_begin, ws->ev_end));
-    st.device_ms = ms;
-    CMX_HIP(hipEventElapsedTime(&ms, ws->ev_k0, ws->ev_k1));
-    st.dominant_kernel_ms = ms;
-    *stats = st;
-  }
+  Rt2DItem item{};
+  item.limits = limits; item.cells = cells; item.weight_cells = weight_cells;
+  item.max_tsd = max_tsd; item.max_weight = max_weight; item.device_cells = device_cells;
+  item.initial = initial_pose_estimate; item.xyz = point_cloud_xyz; item.n = num_points;
+  item.score = score; item.pose = pose_estimate;
+  CMX_REQUIRE(options != nullptr, "null argument");
+  Rt2DMatchBatch(options, &item, 1, device, stats);
 }
 
 }  // namespace cmx

@@ -130,6 +130,20 @@ class Fast2DMatcher {
 };
 
 // RealTimeCorrelativeScanMatcher2D::Match (rt_2d.hip); see there.
+struct Rt2DItem {            // one match of a batch
+  const cmx_grid2d_limits* limits;
+  const uint16_t* cells;          // host grid (or null with device_cells)
+  const uint16_t* weight_cells;   // host TSDF weights (null: probability grid)
+  float max_tsd, max_weight;
+  const uint16_t* device_cells;   // grid already in HBM
+  const cmx_pose2d* initial;
+  const float* xyz;
+  int n;
+  double* score;
+  cmx_pose2d* pose;
+};
+void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int num, int32_t device,
+                    cmx_match_stats* stats);
 void Rt2DMatch(const cmx_rt_options* options, const cmx_grid2d_limits* limits,
                const uint16_t* cells, const uint16_t* weight_cells, float max_tsd,
                float max_weight, const cmx_pose2d* initial_pose_estimate,

@@ -127,6 +127,27 @@ class RealTimeCorrelativeScanMatcher2D:
         return score.value, Rigid2d(pose.x, pose.y, pose.theta)
 
 
+def rt2d_match_batch(options, grids, initial_pose_estimates, point_clouds):
+    """cmx_rt2d_match_grid_batch: match i = (point_clouds[i], grids[i], initial_pose_estimates[i]);
+    `grids` are ProbabilityGridOnDevice, `options` an RtOptions (or a
+    RealTimeCorrelativeScanMatcher2D).  Returns (scores, poses, stats)."""
+    if isinstance(options, RealTimeCorrelativeScanMatcher2D):
+        options = options.options
+    num = len(grids)
+    clouds = [_cloud(c)[0] for c in point_clouds]
+    handles = (C.c_void_p * num)(*[g._h for g in grids])
+    cloud_ptrs = (C.c_void_p * num)(*[c.ctypes.data for c in clouds])
+    counts = np.array([c.shape[0] for c in clouds], np.int32)
+    initial = (Pose2d * num)(*[p.to_c() for p in initial_pose_estimates])
+    scores = np.zeros(num, np.float64)
+    poses = (Pose2d * num)()
+    stats = MatchStats()
+    check(_lib.lib().cmx_rt2d_match_grid_batch(
+        C.byref(options), handles, num, C.cast(initial, C.c_void_p), cloud_ptrs,
+        counts.ctypes.data, scores.ctypes.data, C.cast(poses, C.c_void_p), C.byref(stats)))
+    return (scores, [Rigid2d(p.x, p.y, p.theta) for p in poses], stats.as_dict())
+
+
 class PointCloudOnDevice:
     """A point cloud uploaded once (cmx_cloud) for repeated resident matches."""
 

@@ -172,6 +172,17 @@ cmx_status cmx_rt2d_match_grid(const cmx_rt_options* options, const cmx_grid2d* 
                                const float* point_cloud_xyz, int32_t num_points, double* score,
                                cmx_pose2d* pose_estimate, cmx_match_stats* stats);
 
+/* `num_matches` independent real-time matches (one per trajectory / robot: scan i against
+ * grid i around pose i) in one set of kernel launches.  A single match occupies 81 of the
+ * chip's 8192 wave slots and is bound by the latency of its sequential f32 sums; batching
+ * is what fills the machine. */
+cmx_status cmx_rt2d_match_grid_batch(const cmx_rt_options* options,
+                                     const cmx_grid2d* const* grids, int32_t num_matches,
+                                     const cmx_pose2d* initial_pose_estimates,
+                                     const float* const* point_clouds_xyz,
+                                     const int32_t* num_points, double* scores,
+                                     cmx_pose2d* pose_estimates, cmx_match_stats* stats);
+
 /* ---- fast 2D (branch and bound) ---------------------------------------- */
 /* Uploads the grid and builds the PrecomputationGridStack2D on `device`
  * (SM2/fast_correlative_scan_matcher_2d.cc:171-186). */

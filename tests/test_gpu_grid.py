@@ -133,3 +133,33 @@ def test_fast_matcher_from_device_grid(g2, synth):
     pose = world.free_pose(1, 0.4)
     scan = world.scan(pose, 300, 30.0, 0.01, 2)
     assert a.match_full_submap(scan, 0.4)[:2] == b.match_full_submap(scan, 0.4)[:2]
+
+
+@pytest.mark.parametrize("robots", [5, 19])     # below / above the 4-candidates-per-lane switch
+def test_rt2d_batch_equals_individual(g2, synth, oracle, robots):
+    """Several robots, each with its own grid, scan and pose, matched in one batch: every
+    result equals the single-match entry point (and the oracle)."""
+    from cartographer_amd import scan_matching as sm
+    matcher = sm.RealTimeCorrelativeScanMatcher2D(0.15, math.radians(4.0), 0.1, 0.2)
+    grids, inits, scans = [], [], []
+    for k in range(robots):
+        nx, ny = 120 + 4 * k, 100 + 2 * k             # different grid sizes ...
+        cells, lim, world = synth.make_submap(70 + k, nx, ny, 0.05, 10, 300, 30.0, 0.01)
+        grids.append(g2.ProbabilityGridOnDevice(0.05, (lim["max_x"], lim["max_y"]), nx, ny,
+                                                cells=cells))
+        pose = world.free_pose(k, 0.4)
+        scans.append(world.scan(pose, 150 + 37 * k, 30.0, 0.01, k))   # ... and scan sizes
+        inits.append(sm.Rigid2d(pose[0] + 0.04, pose[1] - 0.06, pose[2] + 0.01 * k))
+    scores, poses, stats = sm.rt2d_match_batch(matcher, grids, inits, scans)
+    total = 0
+    for k in range(robots):
+        s1, p1 = matcher.match(inits[k], scans[k], grids[k])
+        total += matcher.last_stats["candidates_scored"]
+        assert scores[k] == s1
+        assert (poses[k].x, poses[k].y, poses[k].theta) == (p1.x, p1.y, p1.theta)
+        l = grids[k].limits
+        ref = oracle.rt2d_match(grids[k].cells, 0.05, l["max_x"], l["max_y"],
+                                [inits[k].x, inits[k].y, inits[k].theta], scans[k], 0.15,
+                                math.radians(4.0), 0.1, 0.2)
+        assert scores[k] == ref["score"]
+    assert stats["candidates_scored"] == total

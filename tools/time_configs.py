@@ -46,6 +46,29 @@ def c1(cpu):
               f"score equal: {np.float64(ref['score']) == score}")
 
 
+def c1b(cpu):
+    """C1 as a batch: B robots, each matching its own scan against its own resident grid."""
+    from cartographer_amd import grid_2d
+    m = sm.RealTimeCorrelativeScanMatcher2D(0.3, math.radians(7.0), 0.1, 0.1)
+    for batch in (1, 8, 32, 128):
+        grids, inits, scans = [], [], []
+        for k in range(min(batch, 8)):          # 8 distinct worlds, reused round-robin
+            cells, lim, world = synth.make_submap(42 + k, 200, 200, 0.05, 30, 1000, 5.0, 0.01)
+            pose = world.free_pose(1234, 0.5)
+            grids.append(grid_2d.ProbabilityGridOnDevice(0.05, (lim["max_x"], lim["max_y"]), 200,
+                                                         200, cells=cells))
+            scans.append(world.scan(pose, 1000, 5.0, 0.01, 7))
+            inits.append(sm.Rigid2d(pose[0] + 0.12, pose[1] - 0.08, pose[2] + math.radians(3.0)))
+        G = [grids[i % len(grids)] for i in range(batch)]
+        I = [inits[i % len(grids)] for i in range(batch)]
+        S = [scans[i % len(grids)] for i in range(batch)]
+        dt, (scores, poses, st) = timeit(lambda: sm.rt2d_match_batch(m, G, I, S), 20)
+        print(f"C1 batch {batch:4d}: {dt * 1e6:8.1f} us / batch wall, device "
+              f"{st['device_ms'] * 1e3:7.1f} us, kernel {st['dominant_kernel_ms'] * 1e3:7.1f} us, "
+              f"{st['candidates_scored']} cand -> {st['candidates_scored'] / dt:.3e} cand/s wall, "
+              f"{st['candidates_scored'] / (st['dominant_kernel_ms'] * 1e-3):.3e} cand/s kernel")
+
+
 def c4(cpu, rings=64, az=1024):
     grid, world = synth.make_submap_3d(42, 0.1, (15.0, 15.0, 7.5), 8, 32, 512)
     vox = grid.voxels()
@@ -111,4 +134,4 @@ if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if not a.startswith("-")] or ["c1", "c4", "c5"]
     cpu = "--cpu" in sys.argv
     for w in which:
-        {"c1": c1, "c4": c4, "c5": c5}[w](cpu)
+        {"c1": c1, "c1b": c1b, "c4": c4, "c5": c5}[w](cpu)
