@@ -27,7 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-DOMINANT_KERNEL = "ScoreCoarsePlanesKernel"
+DOMINANT_KERNEL = "ScoreCoarsePlanes"   # ...DwordKernel (64-byte planes) or ...Kernel<N>
 
 
 def pmc_traffic_bytes():

@@ -252,16 +252,19 @@ PrepScansKernel(const Fast2DProblem* __restrict__ problems, const float* __restr
   int run = partial[threadIdx.x];
   for (int b = b0; b < b1; ++b) { const int v = hist[b]; hist[b] = run; run += v; }
   __syncthreads();
-  uint32_t* sorted = P.sorted + static_cast<size_t>(s) * n;
+  // Records carry what the plane scorer would otherwise compute per point: the byte
+  // offset of the point's plane and the constant bx * pitch + by its lattice block
+  // subtracts in the accumulator index (pitch = dims.y + 2 * plane_j - 2).
+  uint2* sorted = P.sorted + static_cast<size_t>(s) * n;
+  const int pitch = dims.y + 2 * P.plane_j - 2;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     int bucket, plane;
     uint32_t block;
     classify(out[i], &bucket, &plane, &block);
     if (bucket >= 0) {
       const int pos = atomicAdd(&hist[bucket], 1);
-      // plane | lattice block (bx | by << 8) << 16: the scorer needs the block's
-      // coordinates, not its linear index (no division in its flush).
-      sorted[pos] = static_cast<uint32_t>(plane) | (block << 16);
+      sorted[pos] = make_uint2(static_cast<uint32_t>(plane) * P.plane_stride,
+                               (block & 0xffu) * pitch + (block >> 8));
     }
   }
 }
@@ -433,7 +436,9 @@ ScoreCoarsePlanesKernel(const Fast2DProblem* __restrict__ problems, int n,
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int M = P.sorted_count[s];
-  const auto* rec = AsGlobal(P.sorted) + static_cast<size_t>(s) * n;
+  // (x = plane byte offset, y = block constant) as one 64-bit word per record
+  const auto* rec = AsGlobal(reinterpret_cast<const unsigned long long*>(P.sorted)) +
+                    static_cast<size_t>(s) * n;
   const int waves = blockDim.x >> 6;     // 2..4, chosen by the host (see the launch)
   const int begin = static_cast<int>(static_cast<long long>(M) * wave / waves);
   const int end = static_cast<int>(static_cast<long long>(M) * (wave + 1) / waves);
@@ -449,8 +454,7 @@ ScoreCoarsePlanesKernel(const Fast2DProblem* __restrict__ problems, int n,
     lane_const[c] = (cell % PI + dims.x + PI - 2) * pitch + (cell / PI + dims.y + PJ - 2);
   }
   int cur = -1;
-  auto flush = [&](int block) {
-    const int block_const = (block & 0xff) * pitch + (block >> 8);
+  auto flush = [&](int block_const) {
 #pragma unroll
     for (int c = 0; c < CHUNKS; ++c) {
       atomicAdd(&cand_acc[lane_const[c] - block_const], acc[c]);
@@ -458,28 +462,33 @@ ScoreCoarsePlanesKernel(const Fast2DProblem* __restrict__ problems, int n,
     }
   };
 
-  // Records are wave-uniform: 64 of them arrive with one coalesced load (one per lane,
-  // the next 64 prefetched meanwhile) and are broadcast with v_readlane (immediate lane
+  // Records are wave-uniform: 64 of them arrive with one coalesced 8-byte load per lane
+  // (the next 64 prefetched meanwhile) and are broadcast with v_readlane (immediate lane
   // index: the batch loops are fully unrolled).  A plane read is a buffer load: lane
-  // offset in a VGPR, plane offset in an SGPR, no vector address arithmetic.  kBatch
-  // plane loads are in flight before the first one is consumed.  Lanes past `end` hold
-  // the sentinel (all-zero plane, block 0xffff): adding zeros changes nothing.
+  // offset in a VGPR, the record's plane offset in an SGPR, no address arithmetic at all.
+  // kBatch plane loads are in flight before the first one is consumed.  Lanes past `end`
+  // hold the sentinel (all-zero plane, block -1): adding zeros changes nothing.
   constexpr int kBatch = CHUNKS == 1 ? 32 : (CHUNKS == 2 ? 16 : 8);
-  const uint32_t sentinel = 0xffff0000u | zero_plane;
+  const int kSentinelBlock = -1;
+  const unsigned long long sentinel =
+      (static_cast<unsigned long long>(static_cast<uint32_t>(kSentinelBlock)) << 32) |
+      static_cast<uint32_t>(zero_plane * stride);
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint8_t*>(P.planes), 0, static_cast<int>((zero_plane + 1) * stride), 0x00020000);
-  uint32_t mine = begin + lane < end ? rec[begin + lane] : sentinel;
+  unsigned long long mine = sentinel;
+  if (begin + lane < end) mine = rec[begin + lane];
   for (int base_i = begin; base_i < end; base_i += 64) {
-    uint32_t next = sentinel;
+    unsigned long long next = sentinel;
 #pragma unroll
     for (int j0 = 0; j0 < 64; j0 += kBatch) {
       if (base_i + j0 >= end) break;          // wave-uniform
-      uint32_t r[kBatch];
+      int block[kBatch];
       int v[kBatch][CHUNKS];
 #pragma unroll
       for (int k = 0; k < kBatch; ++k) {
-        r[k] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine), j0 + k));
-        const int plane_offset = static_cast<int>(r[k] & 0xffffu) * stride;
+        const int plane_offset =
+            __builtin_amdgcn_readlane(static_cast<int>(mine & 0xffffffffu), j0 + k);
+        block[k] = __builtin_amdgcn_readlane(static_cast<int>(mine >> 32), j0 + k);
 #pragma unroll
         for (int c = 0; c < CHUNKS; ++c)
           v[k][c] = __builtin_amdgcn_raw_buffer_load_b8(rsrc, lane + c * 64, plane_offset, 0);
@@ -491,10 +500,9 @@ ScoreCoarsePlanesKernel(const Fast2DProblem* __restrict__ problems, int n,
       }
 #pragma unroll
       for (int k = 0; k < kBatch; ++k) {
-        const int block = static_cast<int>(r[k] >> 16);
-        if (block != cur) {
+        if (block[k] != cur) {
           if (cur >= 0) flush(cur);
-          cur = block;     // the sentinel block (0xffff) only ever follows real ones
+          cur = block[k];     // the sentinel block (-1) only ever follows real ones
         }
 #pragma unroll
         for (int c = 0; c < CHUNKS; ++c) acc[c] += v[k][c];
@@ -502,7 +510,118 @@ ScoreCoarsePlanesKernel(const Fast2DProblem* __restrict__ problems, int n,
     }
     mine = next;
   }
-  if (cur >= 0 && cur != 0xffff) flush(cur);
+  if (cur >= 0) flush(cur);
+  __syncthreads();
+
+  const int base = P.coarse_off[s];
+  auto* coarse_sum = AsGlobal(P.coarse_sum) + base;
+  auto* coarse_score = AsGlobal(P.coarse_score) + base;
+  int best_sum = -1, best_index = 0x7ffffff;  // idle threads (sum -1) never win
+  for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    const int ix = i / dims.y, iy = i - ix * dims.y;
+    const int sum = cand_acc[(ix + PI - 1) * pitch + (iy + PJ - 1)];
+    coarse_sum[i] = sum;
+    coarse_score[i] = ToScore(P, sum, n);
+    if (sum > best_sum) { best_sum = sum; best_index = i; }
+  }
+  const int2 best = BlockBest(best_sum, best_index, scratch);
+  if (threadIdx.x == 0) P.scan_best[s] = best;
+}
+
+// The same scoring for 64-byte planes (plane_i * plane_j <= 64, the usual case) with DWORD
+// gathers.  A wave-wide `buffer_load_ubyte` costs the texture-address path ~12 cycles
+// however few cache lines it touches (2.3 M of them were the 45 us of the byte variant:
+// SQ/TA counters in DESIGN.md); here a lane fetches four plane cells at once, sixteen lanes
+// cover a plane, and one instruction serves FOUR records (lane group g = lane / 16 takes
+// records 4t + g).  Groups sit in different lattice blocks, so the block bookkeeping is
+// per lane: packed 16-bit partial sums (cells 0|2 and 1|3), flushed to the LDS
+// accumulators when the lane's block changes or after 256 records.
+__global__ void __launch_bounds__(256)
+ScoreCoarsePlanesDwordKernel(const Fast2DProblem* __restrict__ problems, int n,
+                             const ProblemState* __restrict__ states) {
+  const Fast2DProblem& P = problems[blockIdx.y];
+  const int s = blockIdx.x;
+  if (s >= P.num_scans || states[blockIdx.y].error || !P.use_planes) return;
+  if (P.plane_stride != 64) return;
+  extern __shared__ int cand_acc[];
+  __shared__ int2 scratch[4];
+  const int2 dims = P.coarse_dims[s];
+  const int count = dims.x * dims.y;
+  const int PI = P.plane_i, PJ = P.plane_j, PIJ = PI * PJ;
+  const int pitch = dims.y + 2 * PJ - 2;
+  const int acc_cells = (dims.x + 2 * PI - 2) * pitch;
+  for (int i = threadIdx.x; i < acc_cells; i += blockDim.x) cand_acc[i] = 0;
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int group = lane >> 4, sub = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int M = P.sorted_count[s];
+  const auto* rec = AsGlobal(reinterpret_cast<const unsigned long long*>(P.sorted)) +
+                    static_cast<size_t>(s) * n;
+  const int waves = blockDim.x >> 6;
+  const int begin = static_cast<int>(static_cast<long long>(M) * wave / waves);
+  const int end = static_cast<int>(static_cast<long long>(M) * (wave + 1) / waves);
+  const unsigned zero_plane = 1u << (2 * (P.depth - 1));   // index w*w: the all-zero plane
+
+  int lane_const[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    // Cells past the plane are zero padding: they add 0 to the last cell.
+    const int cell = min(4 * sub + j, PIJ - 1);
+    lane_const[j] = (cell % PI + dims.x + PI - 2) * pitch + (cell / PI + dims.y + PJ - 2);
+  }
+  int cur = -1, pending = 0;
+  uint32_t even = 0, odd = 0;               // cells 0 | 2 << 16 and 1 | 3 << 16
+  const auto flush = [&]() {
+    const int a0 = even & 0xffffu, a2 = even >> 16, a1 = odd & 0xffffu, a3 = odd >> 16;
+    if (a0) atomicAdd(&cand_acc[lane_const[0] - cur], a0);
+    if (a1) atomicAdd(&cand_acc[lane_const[1] - cur], a1);
+    if (a2) atomicAdd(&cand_acc[lane_const[2] - cur], a2);
+    if (a3) atomicAdd(&cand_acc[lane_const[3] - cur], a3);
+    even = odd = 0;
+    pending = 0;
+  };
+
+  constexpr int kSteps = 8;                 // gathers (of four records each) in flight
+  const unsigned long long sentinel = (0xffffffffull << 32) | (zero_plane * 64u);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(P.planes), 0, static_cast<int>((zero_plane + 1) * 64), 0x00020000);
+  unsigned long long mine = sentinel;
+  if (begin + lane < end) mine = rec[begin + lane];
+  for (int base_i = begin; base_i < end; base_i += 64) {
+    unsigned long long next = sentinel;
+#pragma unroll
+    for (int t0 = 0; t0 < 16; t0 += kSteps) {
+      if (base_i + 4 * t0 >= end) break;      // wave-uniform
+      int block[kSteps];
+      uint32_t q[kSteps];
+#pragma unroll
+      for (int k = 0; k < kSteps; ++k) {
+        const int src = 4 * (t0 + k) + group;                 // this lane group's record
+        const int plane_offset = __shfl(static_cast<int>(mine & 0xffffffffu), src, 64);
+        block[k] = __shfl(static_cast<int>(mine >> 32), src, 64);
+        q[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, plane_offset + 4 * sub, 0, 0);
+      }
+      if (t0 == 0) {   // prefetch the next 64 records behind the first gathers
+        const int nidx = base_i + 64 + lane;
+        next = rec[min(nidx, end - 1)];
+        if (nidx >= end) next = sentinel;
+      }
+#pragma unroll
+      for (int k = 0; k < kSteps; ++k) {
+        if (block[k] != cur) {                // per lane group
+          if (cur >= 0) flush();
+          cur = block[k];                     // -1 (sentinel) only ever follows real blocks
+        }
+        even += q[k] & 0x00ff00ffu;
+        odd += (q[k] >> 8) & 0x00ff00ffu;
+        if (++pending == 256) flush();        // 16-bit partial sums: 256 x 255 fits
+      }
+    }
+    mine = next;
+  }
+  if (cur >= 0) flush();
   __syncthreads();
 
   const int base = P.coarse_off[s];
@@ -1533,8 +1652,8 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
   }
 
   // Scratch carving.
-  uint32_t* d_discrete = ws.dev[2].ReserveAs<uint32_t>(2 * discrete_total);
-  uint32_t* d_sorted = d_discrete + discrete_total;
+  uint32_t* d_discrete = ws.dev[2].ReserveAs<uint32_t>(3 * discrete_total);
+  uint2* d_sorted = reinterpret_cast<uint2*>(d_discrete + discrete_total + (discrete_total & 1));
   int4* d_bounds = ws.dev[3].ReserveAs<int4>(scans_total);
   int2* d_dims = ws.dev[4].ReserveAs<int2>(2 * scans_total);
   int2* d_scan_best = d_dims + scans_total;
@@ -1622,7 +1741,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
   const int plane_threads = 64 * plane_waves;
   CMX_HIP(hipEventRecord(ws.ev_k0, ws.stream));
   if (chunk_mask & (1 << 1))
-    ScoreCoarsePlanesKernel<1><<<per_scan, plane_threads, acc_bytes, ws.stream>>>(
+    ScoreCoarsePlanesDwordKernel<<<per_scan, plane_threads, acc_bytes, ws.stream>>>(
         out->d_problems, n, out->d_states);
   if (chunk_mask & (1 << 2))
     ScoreCoarsePlanesKernel<2><<<per_scan, plane_threads, acc_bytes, ws.stream>>>(

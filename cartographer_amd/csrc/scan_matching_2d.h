@@ -55,7 +55,8 @@ struct Fast2DProblem {
   int* coarse_off;      // [num_scans + 1]
   float* coarse_score;  // [coarse_capacity]
   int* coarse_sum;      // [coarse_capacity]
-  uint32_t* sorted;     // [num_scans][n] points bucketed by coarse block: plane | bucket << 16
+  uint2* sorted;        // [num_scans][n] points bucketed by lattice block:
+                        // (plane byte offset, bx * pitch + by of the plane scorer's accumulators)
   int* sorted_count;    // [num_scans]
   int2* scan_best;      // [num_scans] (best sum, local candidate index) of each scan
 };
