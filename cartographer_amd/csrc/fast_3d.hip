@@ -173,6 +173,41 @@ ScoreCoarse3DKernel(Fast3DProblem P) {
   }
 }
 
+// Few lowest-resolution candidates (deep stacks: one per yaw): a whole block per
+// candidate, so that its sum is not a 43-iteration chain of one wavefront.
+__global__ void __launch_bounds__(256)
+ScoreCoarse3DBlockKernel(Fast3DProblem P) {
+  __shared__ int partial[4];
+  const int per_scan = P.ncx * P.ncy * P.ncz;
+  const int total = per_scan * P.num_scans;
+  const int step = 1 << (P.depth - 1);
+  const int depth = P.depth - 1;
+  const int e = max(0, depth - P.full_resolution_depth + 1);
+  const Brick L = P.level[depth];
+  for (int c = blockIdx.x; c < total; c += gridDim.x) {
+    const int s = c / per_scan;
+    int r = c - s * per_scan;
+    const int iz = r / (P.ncy * P.ncx);
+    r -= iz * P.ncy * P.ncx;
+    const int iy = r / P.ncx, ix = r - iy * P.ncx;
+    const int fx = (-P.wxy + ix * step) >> e, fy = (-P.wxy + iy * step) >> e,
+              fz = (-P.wz + iz * step) >> e;
+    const int4* __restrict__ cells = P.cells + static_cast<size_t>(s) * P.n;
+    int sum = 0;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < P.n; i += 256) {
+      const int3 d = DepthIndex(cells[i], e, -P.wxy, -P.wxy, -P.wz);
+      sum += BrickValueU8(L, d.x + fx, d.y + fy, d.z + fz);
+    }
+    sum = WaveSum(sum);
+    if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      P.coarse_score[c] = ToProbability(partial[0] + partial[1] + partial[2] + partial[3], P.n);
+    __syncthreads();
+  }
+}
+
 __device__ __forceinline__ Node3D CoarseNode3D(const Fast3DProblem& P, int c) {
   const int per_scan = P.ncx * P.ncy * P.ncz;
   const int step = 1 << (P.depth - 1);
@@ -217,13 +252,35 @@ SeedSelect3DKernel(Fast3DProblem P, List3 seeds, Counters3* __restrict__ counter
   };
   for (int c = threadIdx.x; c < total; c += blockDim.x) atomicAdd(&hist[bin_of(P.coarse_score[c])], 1);
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int acc = 0, b = 1023;
-    for (; b > 0; --b) {
-      acc += hist[b];
-      if (acc >= kSeeds3) break;
+  // threshold_bin = the largest b >= 1 with sum_{j >= b} hist[j] >= kSeeds3, else 0 -- found
+  // by one wave (16 bins per lane, suffix sums across lanes) instead of a 1023-step serial
+  // walk by one thread (51 us when there are fewer than kSeeds3 candidates).
+  if (threadIdx.x < 64) {
+    const int l = threadIdx.x;
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mine += hist[16 * l + k];
+    int suffix = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_down(suffix, off, 64);
+      if (l + off < 64) suffix += o;
     }
-    threshold_bin = b;
+    const unsigned long long reach = __ballot(suffix >= kSeeds3);
+    if (reach == 0) {
+      if (l == 0) threshold_bin = 0;
+    } else {
+      const int owner = 63 - __clzll(reach);          // highest lane whose suffix reaches it
+      const int above = suffix - mine;                 // bins of the lanes above
+      if (l == owner) {
+        int acc = above, b = 16 * l + 15;
+        for (; b > 16 * l; --b) {
+          acc += hist[b];
+          if (acc >= kSeeds3) break;
+        }
+        threshold_bin = b;     // b == 16 l: reached with the lane's lowest bin (0 only for l == 0)
+      }
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < total; c += blockDim.x) {
@@ -288,27 +345,25 @@ __device__ __forceinline__ float LowResolutionScore(const Fast3DProblem& P, cons
 // one expansion: four waves share the points, the eight child cells of a point are
 // addressed from per-axis clamped offsets (two positions per axis), and the loads of
 // several points are in flight together.
-__global__ void __launch_bounds__(256)
-Expand3DKernel(Fast3DProblem P, List3 in, int dive, int strict, List3 out, List3 leaves,
-               Counters3* __restrict__ counters) {
-  __shared__ int partial[4][8];
-  __shared__ float sh_score[8];
-  __shared__ float low_prob[kLowChunk];
+struct ExpandShared {
+  int partial[4][8];
+  float score[8];
+  float low_prob[kLowChunk];
+  Node3D next;       // dive: the child the descent continues with
+  int has_next;
+};
+
+// Expansion of one node by the whole block (see above).  dive = 0: children that can still
+// matter are appended to `out`; dive = 1: the best child is left in sh->next.
+__device__ __forceinline__ void ExpandNode3D(const Fast3DProblem& P, const Node3D& nd, float best,
+                                             int dive, int strict, const List3& out,
+                                             const List3& leaves,
+                                             Counters3* __restrict__ counters, int sub_id,
+                                             ExpandShared* sh) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int max_count = ListMax3(in);
-  for (int i = blockIdx.x; i < max_count * kSubLists3; i += gridDim.x) {
-    const int in_sub = i & (kSubLists3 - 1), j = i / kSubLists3;
-    if (j >= min(in.counts[in_sub], in.sub_capacity)) continue;   // block-uniform
-    // Children go to a sub-list derived from the node's slot, not from the block: the
-    // survivors of a search cluster in a few subtrees, and appending them to their
-    // parent's sub-list would leave the next level with one long list that a handful
-    // of blocks walk serially (measured: 0.9 us per node, chip idle).
-    const int sub_id = (in_sub * 17 + j) & (kSubLists3 - 1);
-    const Node3D nd = in.nodes[static_cast<size_t>(in_sub) * in.sub_capacity + j];
-    const float best = __uint_as_float(
-        __hip_atomic_load(&counters->best_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    if (!dive && (strict ? !(nd.score > best) : (nd.score < best))) continue;
+  if (threadIdx.x == 0) sh->has_next = 0;
+  {
     const int child_depth = nd.level - 1;
     const int half = 1 << child_depth;
     const int e = max(0, child_depth - P.full_resolution_depth + 1);
@@ -349,21 +404,22 @@ Expand3DKernel(Fast3DProblem P, List3 in, int dive, int strict, List3 out, List3
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int total = WaveSum(sum[k]);
-      if (lane == 0) partial[wave][k] = total;
+      if (lane == 0) sh->partial[wave][k] = total;
     }
     __syncthreads();
     if (threadIdx.x < 8) {
       const int k = threadIdx.x;
       const bool valid = (!(k & 1) || vx) && (!(k & 2) || vy) && (!(k & 4) || vz);
-      const int total = partial[0][k] + partial[1][k] + partial[2][k] + partial[3][k];
-      sh_score[k] = valid ? ToProbability(total, P.n) : -1.f;
+      const int total =
+          sh->partial[0][k] + sh->partial[1][k] + sh->partial[2][k] + sh->partial[3][k];
+      sh->score[k] = valid ? ToProbability(total, P.n) : -1.f;
     }
     __syncthreads();
     float score[8];
     int nvalid = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      score[k] = sh_score[k];
+      score[k] = sh->score[k];
       nvalid += score[k] >= 0.f;
     }
     int rank[8];
@@ -402,10 +458,10 @@ Expand3DKernel(Fast3DProblem P, List3 in, int dive, int strict, List3 out, List3
         const float sc = score[k];
         __syncthreads();
         if (threadIdx.x == 0)
-          sh_score[0] = __uint_as_float(__hip_atomic_load(&counters->best_bits, __ATOMIC_RELAXED,
-                                                          __HIP_MEMORY_SCOPE_AGENT));
+          sh->score[0] = __uint_as_float(__hip_atomic_load(&counters->best_bits, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
         __syncthreads();
-        const float now = sh_score[0];
+        const float now = sh->score[0];
         if (!(sc > P.min_score) || (strict ? !(sc > now) : (sc < now))) break;
         const Node3D leaf = make_child(k);
         const float4 q4 = P.scan_q[nd.scan];
@@ -413,7 +469,7 @@ Expand3DKernel(Fast3DProblem P, List3 in, int dive, int strict, List3 out, List3
             P, Quat{q4.w, q4.x, q4.y, q4.z},
             (P.pose_tx + 0.f) + P.resolution * static_cast<float>(leaf.ox),
             (P.pose_ty + 0.f) + P.resolution * static_cast<float>(leaf.oy),
-            (P.pose_tz + 0.f) + P.resolution * static_cast<float>(leaf.oz), low_prob);
+            (P.pose_tz + 0.f) + P.resolution * static_cast<float>(leaf.oz), sh->low_prob);
         if (static_cast<double>(low) >= P.min_low_resolution_score) {
           if (threadIdx.x == 0) {
             Node3D rec = leaf;
@@ -438,7 +494,11 @@ Expand3DKernel(Fast3DProblem P, List3 in, int dive, int strict, List3 out, List3
         keep_mask |= 1 << k;
         ++m;
       }
-      if (m) {
+      if (dive) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (keep_mask >> k & 1) { sh->next = make_child(k); sh->has_next = 1; }
+      } else if (m) {
         int slot = atomicAdd(&out.counts[sub_id], m);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -448,7 +508,44 @@ Expand3DKernel(Fast3DProblem P, List3 in, int dive, int strict, List3 out, List3
         }
       }
     }
-    __syncthreads();   // partial / sh_score reused by the next node
+    __syncthreads();   // scratch reused by the next node; sh->next / has_next visible
+  }
+}
+
+__global__ void __launch_bounds__(256)
+Expand3DKernel(Fast3DProblem P, List3 in, int strict, List3 out, List3 leaves,
+               Counters3* __restrict__ counters) {
+  __shared__ ExpandShared sh;
+  const int max_count = ListMax3(in);
+  for (int i = blockIdx.x; i < max_count * kSubLists3; i += gridDim.x) {
+    const int in_sub = i & (kSubLists3 - 1), j = i / kSubLists3;
+    if (j >= min(in.counts[in_sub], in.sub_capacity)) continue;   // block-uniform
+    // Children go to a sub-list derived from the node's slot, not from the block: the
+    // survivors of a search cluster in a few subtrees, and appending them to their
+    // parent's sub-list would leave the next level with one long list that a handful
+    // of blocks walk serially (measured: 0.9 us per node, chip idle).
+    const int sub_id = (in_sub * 17 + j) & (kSubLists3 - 1);
+    const Node3D nd = in.nodes[static_cast<size_t>(in_sub) * in.sub_capacity + j];
+    const float best = __uint_as_float(
+        __hip_atomic_load(&counters->best_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (strict ? !(nd.score > best) : (nd.score < best)) continue;
+    ExpandNode3D(P, nd, best, 0, strict, out, leaves, counters, sub_id, &sh);
+  }
+}
+
+// Greedy descents (always the best child) from the seeds, one block per seed, all levels in
+// one launch: the verified leaf scores bound the search that follows.
+__global__ void __launch_bounds__(256)
+Dive3DKernel(Fast3DProblem P, List3 seeds, List3 leaves, Counters3* __restrict__ counters) {
+  __shared__ ExpandShared sh;
+  if (static_cast<int>(blockIdx.x) >= min(seeds.counts[0], seeds.sub_capacity)) return;
+  Node3D nd = seeds.nodes[blockIdx.x];
+  const int sub_id = blockIdx.x & (kSubLists3 - 1);
+  while (nd.level >= 1) {
+    ExpandNode3D(P, nd, 0.f, 1, 0, seeds, leaves, counters, sub_id, &sh);
+    if (!sh.has_next) break;
+    nd = sh.next;
+    __syncthreads();   // everyone has read sh.next before the next expansion resets it
   }
 }
 
@@ -784,7 +881,10 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
   dbg("discretize");
   mark("discretize");
   CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
-  ScoreCoarse3DKernel<<<std::min<long long>(8192, DivUp(total, 4)), 256, 0, ws->stream>>>(P);
+  if (total <= 4096)
+    ScoreCoarse3DBlockKernel<<<static_cast<unsigned>(total), 256, 0, ws->stream>>>(P);
+  else
+    ScoreCoarse3DKernel<<<std::min<long long>(8192, DivUp(total, 4)), 256, 0, ws->stream>>>(P);
   CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
   dbg("coarse");
   mark("coarse");
@@ -803,15 +903,8 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
         SeedSelect3DKernel<<<1, 1024, 0, ws->stream>>>(P, dive[0], d_counters);
         dbg("seed");
         mark("seed");
-        int cur = 0;
-        for (int child = depth - 2; child >= 0; --child) {
-          CMX_HIP(hipMemsetAsync(d_counters->dive[cur ^ 1], 0, sizeof(int) * kSubLists3,
-                                 ws->stream));
-          Expand3DKernel<<<64, 256, 0, ws->stream>>>(P, dive[cur], 1, 0, dive[cur ^ 1], leaf_list,
-                                                     d_counters);
-          dbg("dive level");
-          cur ^= 1;
-        }
+        Dive3DKernel<<<kSeeds3, 256, 0, ws->stream>>>(P, dive[0], leaf_list, d_counters);
+        dbg("dive");
         mark("dive");
       }
       CMX_HIP(hipMemsetAsync(d_counters->frontier, 0, sizeof(d_counters->frontier), ws->stream));
@@ -820,7 +913,7 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
       mark("filter");
       int stage = 0;
       for (int child = depth - 2; child >= 0; --child, ++stage) {
-        Expand3DKernel<<<blocks, 256, 0, ws->stream>>>(P, front(stage), 0, strict,
+        Expand3DKernel<<<blocks, 256, 0, ws->stream>>>(P, front(stage), strict,
                                                        front(stage + 1), leaf_list, d_counters);
         dbg("expand level");
         mark("expand");
