@@ -46,3 +46,40 @@ def all_reduce_best(key, device=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return int(t.item())
+
+
+RESULT_WORDS = 6   # found, score, x, y, theta, (pad) as float64 per submap
+
+
+def all_gather_results(found, scores, poses_xyt, num_submaps, rank, world_size, device=None):
+    """Every rank learns every submap's optional constraint: the reference semantics (one
+    optional constraint per (node, submap) pair collected by WhenDone,
+    constraint_builder_2d.cc:277-299) across ranks.  Each rank contributes the results of its
+    `shard_range` block; the exchange is one all-gather of RESULT_WORDS float64 per submap
+    (512 submaps: 24 KB -- latency-bound on xGMI, like the all-reduce above).
+
+    Returns (found[num_submaps], scores[num_submaps] f32, poses[num_submaps, 3] f64) in global
+    submap order.
+    """
+    import torch
+    import torch.distributed as dist
+    begin, end = shard_range(num_submaps, rank, world_size)
+    assert len(found) == end - begin
+    per_rank = -(-num_submaps // world_size)                     # equal-sized slots
+    local = np.zeros((per_rank, RESULT_WORDS), np.float64)
+    local[:end - begin, 0] = np.asarray(found, np.float64)
+    local[:end - begin, 1] = np.asarray(scores, np.float32).astype(np.float64)   # exact widening
+    local[:end - begin, 2:5] = np.asarray(poses_xyt, np.float64).reshape(-1, 3)
+    t = torch.from_numpy(local)
+    if device is not None:
+        t = t.to(device)
+    if dist.is_available() and dist.is_initialized() and world_size > 1:
+        gathered = [torch.empty_like(t) for _ in range(world_size)]
+        dist.all_gather(gathered, t)
+    else:
+        gathered = [t]
+    out = np.zeros((num_submaps, RESULT_WORDS), np.float64)
+    for r, g in enumerate(gathered):
+        b, e = shard_range(num_submaps, r, world_size)
+        out[b:e] = g.cpu().numpy()[:e - b]
+    return (out[:, 0].astype(np.int32), out[:, 1].astype(np.float32), out[:, 2:5].copy())

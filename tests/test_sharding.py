@@ -35,6 +35,13 @@ def test_key_roundtrip_and_order():
     assert max(a, c) == c
 
 
+def test_all_gather_results_single_process():
+    found, scores = np.array([1, 0, 1], np.int32), np.array([0.7, 0.2, 0.61], np.float32)
+    poses = np.arange(9, dtype=np.float64).reshape(3, 3)
+    f, s, p = sharding.all_gather_results(found, scores, poses, 3, 0, 1)
+    assert np.array_equal(f, found) and np.array_equal(s, scores) and np.array_equal(p, poses)
+
+
 def _worker(rank, world_size, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -48,7 +55,14 @@ def _worker(rank, world_size, port, out):
     best = sharding.all_reduce_best(key)
     expect_id = int(np.argmax(np.where(all_found > 0, all_scores, -1)))
     score, gid = sharding.unpack_best_key(best)
-    out[rank] = (gid == expect_id) and abs(score - float(all_scores[expect_id])) < 1e-7
+    ok = (gid == expect_id) and abs(score - float(all_scores[expect_id])) < 1e-7
+    # every rank learns every submap's optional constraint, bit-exactly
+    all_poses = rng.uniform(-5, 5, (num_submaps, 3))
+    f, sc, po = sharding.all_gather_results(all_found[begin:end], all_scores[begin:end],
+                                            all_poses[begin:end], num_submaps, rank, world_size)
+    ok = ok and np.array_equal(f, all_found) and np.array_equal(sc, all_scores) and \
+        np.array_equal(po, all_poses)
+    out[rank] = ok
     dist.barrier()
     dist.destroy_process_group()
 
