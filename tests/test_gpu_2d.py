@@ -418,3 +418,35 @@ def test_rt2d_tsdf_unknown_everywhere(sm, oracle):
     score, pose = _tsdf_match_both(sm, oracle, zeros, zeros, lim, 0.3, 1.0, [0, 0, 0], L_CLOUD,
                                    0.1, 0.05, 0.0, 0.0)
     assert score == 0.0 and pose.theta < 0
+
+
+# ----------------------------------------------------------------------------
+# Large clouds: beyond the on-chip staging sizes (4096-point LDS cache of the tree
+# search, 1024-point register window of the real-time scorer)
+# ----------------------------------------------------------------------------
+def test_large_cloud_fast2d(sm, oracle, synth):
+    cells, lim, world = synth.make_submap(91, 240, 200, 0.05, 15, 600, 30.0, 0.01)
+    truth = world.free_pose(8, 0.5)
+    scan = world.scan(truth, 5000, 30.0, 0.01, 6)
+    assert scan.shape[0] > 4096
+    om = _oracle(oracle, cells, lim, 6, 2.0, 0.35)
+    gm = sm.FastCorrelativeScanMatcher2D(_grid(sm, cells, lim), 6, 2.0, 0.35)
+    init = [truth[0] + 0.2, truth[1] - 0.15, truth[2] + 0.05]
+    _assert_match_parity(om, gm, lim["resolution"], init, scan, 0.5, False, sm)
+    _assert_match_parity(om, gm, lim["resolution"], init, scan, 0.5, True, sm)
+
+
+@pytest.mark.parametrize("n", [1025, 2500])
+def test_large_cloud_rt2d(sm, oracle, synth, n):
+    cells, lim, world = synth.make_submap(92, 200, 200, 0.05, 15, 600, 30.0, 0.01)
+    truth = world.free_pose(9, 0.5)
+    scan = world.scan(truth, 3000, 30.0, 0.01, 6)[:n]
+    assert scan.shape[0] == n
+    init = [truth[0] + 0.05, truth[1] - 0.04, truth[2] + 0.02]
+    ref = oracle.rt2d_match(cells, 0.05, lim["max_x"], lim["max_y"], init, scan, 0.1,
+                            math.radians(3.0), 0.1, 0.1)
+    m = sm.RealTimeCorrelativeScanMatcher2D(0.1, math.radians(3.0), 0.1, 0.1)
+    score, pose = m.match(sm.Rigid2d(*init), scan, _grid(sm, cells, lim))
+    assert m.last_stats["candidates_scored"] == ref["num_candidates"]
+    assert score == ref["score"]
+    np.testing.assert_allclose([pose.x, pose.y, pose.theta], ref["pose"], rtol=0, atol=1e-12)

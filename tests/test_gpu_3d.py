@@ -285,3 +285,23 @@ def test_fast3d_c5_sized_submap(sm3, oracle, synth):
                        sm3.TrajectoryNodeData(hi, lo, scan_hist), min_score)
         _assert_result(ref, got)
         assert gm.last_stats["num_scans"] == ref["num_scans"] > 0
+
+
+def test_rt3d_ragged_and_large_clouds(sm3, oracle, synth):
+    """Point counts around the 64-point LDS chunk of the scorer, and a cloud of several
+    thousand points."""
+    grid, world = synth.make_submap_3d(5, 0.1, (8.0, 8.0, 4.0), 4, 8, 96)
+    vox = grid.voxels()
+    pos = world.free_position(6, 0.5)
+    full = world.scan(pos, 0.3, 16, 256, seed=9)
+    assert full.shape[0] > 3000
+    q = quat_from_angle_axis(0.31, [0, 0, 1])
+    init = list(pos + np.array([0.03, -0.02, 0.01])) + q
+    for n in (63, 64, 65, 127, 3001):
+        cloud = full[:n]
+        ref = oracle.rt3d_match(0.1, vox, init, cloud, 0.1, math.radians(1.0), 0.1, 0.1)
+        m = sm3.RealTimeCorrelativeScanMatcher3D(0.1, math.radians(1.0), 0.1, 0.1)
+        score, pose = m.match(sm3.Rigid3d(tuple(init[:3]), tuple(init[3:])), cloud, 0.1, vox)
+        assert m.last_stats["candidates_scored"] == ref["num_candidates"]
+        assert np.float32(score) == np.float32(ref["score"]), n
+        np.testing.assert_array_equal(_pose7(pose), ref["pose"])
