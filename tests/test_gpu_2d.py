@@ -450,3 +450,30 @@ def test_large_cloud_rt2d(sm, oracle, synth, n):
     assert m.last_stats["candidates_scored"] == ref["num_candidates"]
     assert score == ref["score"]
     np.testing.assert_allclose([pose.x, pose.y, pose.theta], ref["pose"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("depth", [9, 11])
+def test_deep_stack_generic_lowest_resolution_path(sm, oracle, synth, depth):
+    """branch_and_bound_depth beyond the phase-plane limit (lowest-resolution width 256 / 1024
+    cells > 128): the generic wave-per-candidate scorer runs instead of the plane scorer, and
+    a lowest-resolution cell covers the whole grid."""
+    cells, lim, world = synth.make_submap(93, 150, 130, 0.05, 12, 400, 30.0, 0.01)
+    truth = world.free_pose(10, 0.5)
+    scan = world.scan(truth, 300, 30.0, 0.01, 6)
+    om = _oracle(oracle, cells, lim, depth, 3.0, 0.4)
+    gm = sm.FastCorrelativeScanMatcher2D(_grid(sm, cells, lim), depth, 3.0, 0.4)
+    init = [truth[0] + 0.3, truth[1] - 0.2, truth[2] + 0.1]
+    _assert_match_parity(om, gm, lim["resolution"], init, scan, 0.4, False, sm)
+    _assert_match_parity(om, gm, lim["resolution"], init, scan, 0.4, True, sm)
+
+
+def test_rt2d_tsdf_large_cloud(sm, oracle, synth):
+    from tsdf_helpers import tsdf_from_probability_grid
+    cells, lim, world = synth.make_submap(94, 160, 160, 0.05, 12, 600, 30.0, 0.01)
+    tsd, wgt = tsdf_from_probability_grid(oracle, cells, 0.05, 0.3, 10.0, 3)
+    truth = world.free_pose(11, 0.5)
+    scan = world.scan(truth, 1500, 30.0, 0.01, 5)
+    assert scan.shape[0] > 1024
+    init = [truth[0] + 0.06, truth[1] - 0.03, truth[2] + 0.01]
+    _tsdf_match_both(sm, oracle, tsd, wgt, lim, 0.3, 10.0, init, scan, 0.15, math.radians(3.0),
+                     0.2, 0.1)
