@@ -947,9 +947,11 @@ FilterCoarseKernel(const Fast2DProblem* __restrict__ problems,
   const int2 dims = P.coarse_dims[s];
   const int count = dims.x * dims.y;
   const int base = P.coarse_off[s];
-  const int sub = (blockIdx.x + blockIdx.y) & (kSubLists - 1);
   const int lane = threadIdx.x & 63;
   for (int c0 = 0; c0 < count; c0 += blockDim.x) {
+    // One reservation per wave; consecutive waves use consecutive sub-lists, so that one
+    // rotation's survivors do not all queue in the same one.
+    const int sub = (blockIdx.x + blockIdx.y + ((c0 + threadIdx.x) >> 6)) & (kSubLists - 1);
     const int c = c0 + threadIdx.x;
     bool keep = false;
     if (c < count) {
@@ -1779,8 +1781,15 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
   for (const Fast2DProblem& P : batch.h_problems)
     CMX_REQUIRE(P.depth == depth, "all matchers of a batch must share branch_and_bound_depth");
 
-  const int kFrontierCapacity = 1 << 21;          // nodes per frontier buffer
-  const int kLeafCapacity = 1 << 20;
+  // Nodes per frontier / leaf buffer.  CMX_FRONTIER_CAPACITY / CMX_LEAF_CAPACITY shrink them
+  // (tests only) so that the overflow -> strict, chunked retry below is exercised.
+  const auto capacity = [](const char* name, int fallback) {
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : 0;
+    return v >= kSubLists ? std::min(v, fallback) / kSubLists * kSubLists : fallback;
+  };
+  const int kFrontierCapacity = capacity("CMX_FRONTIER_CAPACITY", 1 << 21);
+  const int kLeafCapacity = capacity("CMX_LEAF_CAPACITY", 1 << 20);
   const int kFrontierSub = kFrontierCapacity / kSubLists, kLeafSub = kLeafCapacity / kSubLists;
   Node2D* d_front[2] = {ws.dev[10].ReserveAs<Node2D>(kFrontierCapacity),
                         ws.dev[11].ReserveAs<Node2D>(kFrontierCapacity)};

@@ -296,11 +296,13 @@ SeedSelect3DKernel(Fast3DProblem P, List3 seeds, Counters3* __restrict__ counter
 
 // Lowest-resolution nodes that can still matter (reference: :405-408).
 __global__ void __launch_bounds__(256)
-Filter3DKernel(Fast3DProblem P, int strict, List3 out, Counters3* __restrict__ counters) {
+Filter3DKernel(Fast3DProblem P, int strict, int chunk, int num_chunks, List3 out,
+               Counters3* __restrict__ counters) {
   const int total = P.ncx * P.ncy * P.ncz * P.num_scans;
   const float best = __uint_as_float(counters->best_bits);
   const int sub = blockIdx.x & (kSubLists3 - 1);
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < total; c += gridDim.x * blockDim.x) {
+    if (c % num_chunks != chunk) continue;
     const float sc = P.coarse_score[c];
     if (strict ? (sc > best) : (sc >= best)) {
       if (!Push3(out, sub, atomicAdd(&out.counts[sub], 1), CoarseNode3D(P, c)))
@@ -772,7 +774,12 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
   float4* d_scan_q = d_pose_q + S;
   int4* d_cells = ws->dev[3].ReserveAs<int4>(static_cast<size_t>(S) * n);
   float* d_coarse = ws->dev[4].ReserveAs<float>(total);
-  const int kFrontierCapacity = 1 << 21, kLeafCapacity = 1 << 18;
+  // CMX_FRONTIER_CAPACITY shrinks the frontier buffers (tests only): overflow -> strict retry.
+  const char* cap_env = getenv("CMX_FRONTIER_CAPACITY");
+  const int cap_req = cap_env ? atoi(cap_env) : 0;
+  const int kFrontierCapacity =
+      cap_req >= kSubLists3 ? std::min(cap_req, 1 << 21) / kSubLists3 * kSubLists3 : 1 << 21;
+  const int kLeafCapacity = 1 << 18;
   Node3D* d_front[2] = {ws->dev[5].ReserveAs<Node3D>(kFrontierCapacity),
                         ws->dev[6].ReserveAs<Node3D>(kFrontierCapacity)};
   Node3D* d_leaves = ws->dev[7].ReserveAs<Node3D>(kLeafCapacity);
@@ -890,7 +897,7 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
   mark("coarse");
 
   const int blocks = 2048;
-  int strict = 0;
+  int strict = 0, num_chunks = 1;
   for (;;) {
     if (depth == 1) {
       VerifyCoarseLeaves3DKernel<<<blocks, 256, 0, ws->stream>>>(P, leaf_list, d_counters);
@@ -907,16 +914,23 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
         dbg("dive");
         mark("dive");
       }
-      CMX_HIP(hipMemsetAsync(d_counters->frontier, 0, sizeof(d_counters->frontier), ws->stream));
-      Filter3DKernel<<<256, 256, 0, ws->stream>>>(P, strict, front(0), d_counters);
-      dbg("filter");
-      mark("filter");
-      int stage = 0;
-      for (int child = depth - 2; child >= 0; --child, ++stage) {
-        Expand3DKernel<<<blocks, 256, 0, ws->stream>>>(P, front(stage), strict,
-                                                       front(stage + 1), leaf_list, d_counters);
-        dbg("expand level");
-        mark("expand");
+      // The lowest-resolution candidates are searched in `num_chunks` interleaved subsets
+      // (1 unless an earlier pass overflowed); later chunks profit from the bound the
+      // earlier ones raised.
+      for (int chunk = 0; chunk < num_chunks; ++chunk) {
+        CMX_HIP(hipMemsetAsync(d_counters->frontier, 0, sizeof(d_counters->frontier),
+                               ws->stream));
+        Filter3DKernel<<<256, 256, 0, ws->stream>>>(P, strict, chunk, num_chunks, front(0),
+                                                    d_counters);
+        dbg("filter");
+        mark("filter");
+        int stage = 0;
+        for (int child = depth - 2; child >= 0; --child, ++stage) {
+          Expand3DKernel<<<blocks, 256, 0, ws->stream>>>(P, front(stage), strict,
+                                                         front(stage + 1), leaf_list, d_counters);
+          dbg("expand level");
+          mark("expand");
+        }
       }
     }
     SelectBest3DKernel<<<1, 1024, 0, ws->stream>>>(leaf_list, d_counters, d_best);
@@ -928,9 +942,10 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
     CMX_HIP(hipStreamSynchronize(ws->stream));
     trace.Report();
     if (!h_counters->overflow) break;
-    CMX_REQUIRE(!strict, "branch-and-bound frontier overflow (search too wide)");
-    // Retry pruning ties (strict) with the bound lowered by one ulp so the best
-    // leaf is found again.
+    // Something was dropped.  Retry pruning ties (strict) with the bound lowered by one
+    // ulp so the best leaf is found again, over four times as many, smaller chunks.
+    CMX_REQUIRE(num_chunks < (1 << 12), "branch-and-bound frontier overflow (search too wide)");
+    if (strict) num_chunks *= 4;
     strict = 1;
     const float floor_score = std::max(min_score, 0.f);
     unsigned floor_bits;
