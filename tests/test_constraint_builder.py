@@ -125,3 +125,75 @@ def test_constraint_lists_match_restatement(oracle, synth):
     again = []
     builder.when_done(again.extend)
     assert again == []
+
+
+def _finds_constraints_scenario(add_local, add_global, end_node, when_done, delete):
+    """ConstraintBuilder2DTest.FindsConstraints (constraint_builder_2d_test.cc:70-112): a
+    one-point cloud, an all-unknown 100 x 110 grid at resolution 1, sampling ratio 1 and
+    min scores 0 -> every search "finds" (unknown cells score 0.1 > 0): two rounds of
+    2 x MaybeAddConstraint + 1 x MaybeAddGlobalConstraint give 3 constraints each."""
+    rounds = []
+    for _ in range(2):
+        for _ in range(2):
+            add_local()
+        add_global()
+        end_node()
+        end_node()
+        rounds.append(when_done())
+        delete()
+    return rounds
+
+
+FINDS_OPTS = dict(sampling_ratio=1.0, max_constraint_distance=15.0, min_score=0.0,
+                  global_localization_min_score=0.0)
+
+
+def test_reference_finds_constraints_restatement():
+    from oracle import constraint_builder_ref as ref
+    r = ref.ConstraintBuilder2DRef(1.0, 15.0, 0.0, 0.0, 7.0, math.radians(30.0), 7)
+    cells = np.zeros((110, 100), np.uint16)
+    grid = (cells, 1.0, 2.0, 3.0)
+    cloud = np.array([[0.1, 0.2, 0.3]], np.float32)
+    sid, pose = (0, 1), (4.0, 5.0, 0.0)
+    rounds = _finds_constraints_scenario(
+        lambda: r.maybe_add_constraint(sid, pose, grid, (0, 0), cloud, (0.0, 0.0, 0.0)),
+        lambda: r.maybe_add_global_constraint(sid, pose, grid, (0, 0), cloud),
+        r.notify_end_of_node, r.when_done, lambda: r.delete_scan_matcher(sid))
+    assert [len(x) for x in rounds] == [3, 3] and r.finished == 4
+    for c in rounds[0]:
+        assert c["score"] == pytest.approx(0.1, abs=1e-6)
+
+
+@pytest.mark.gpu
+def test_reference_finds_constraints_device():
+    from cartographer_amd import constraint_builder as cb, scan_matching as sm
+    from oracle import constraint_builder_ref as ref
+    builder = cb.ConstraintBuilder2D(cb.ConstraintBuilderOptions(**FINDS_OPTS))
+    restated = ref.ConstraintBuilder2DRef(1.0, 15.0, 0.0, 0.0, 7.0, math.radians(30.0), 7)
+    cells = np.zeros((110, 100), np.uint16)
+    submap = cb.Submap2D(cb.Rigid2d(4.0, 5.0, 0.0), sm.Grid2D(cells, 1.0, 2.0, 3.0))
+    cloud = np.array([[0.1, 0.2, 0.3]], np.float32)
+    sid = (0, 1)
+
+    def done():
+        got = []
+        builder.when_done(got.extend)
+        return got
+    rounds = _finds_constraints_scenario(
+        lambda: builder.maybe_add_constraint(sid, submap, (0, 0), cloud, cb.Rigid2d()),
+        lambda: builder.maybe_add_global_constraint(sid, submap, (0, 0), cloud),
+        builder.notify_end_of_node, done, lambda: builder.delete_scan_matcher(sid))
+    want = _finds_constraints_scenario(
+        lambda: restated.maybe_add_constraint(sid, (4.0, 5.0, 0.0), (cells, 1.0, 2.0, 3.0), (0, 0),
+                                              cloud, (0.0, 0.0, 0.0)),
+        lambda: restated.maybe_add_global_constraint(sid, (4.0, 5.0, 0.0), (cells, 1.0, 2.0, 3.0),
+                                                     (0, 0), cloud),
+        restated.notify_end_of_node, restated.when_done,
+        lambda: restated.delete_scan_matcher(sid))
+    assert [len(x) for x in rounds] == [3, 3]
+    assert builder.get_num_finished_nodes() == 4
+    for got_round, want_round in zip(rounds, want):
+        for c, w in zip(got_round, want_round):
+            assert c.tag == "INTER_SUBMAP"
+            assert np.float32(c.score) == np.float32(w["score"])
+            assert (c.zbar_ij.x, c.zbar_ij.y, c.zbar_ij.theta) == w["zbar_ij"]

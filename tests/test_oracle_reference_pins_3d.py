@@ -178,3 +178,15 @@ def test_fast3d_correct_pose_for_match_full_submap(oracle, synth):
     r2 = m.match_full_submap([1, 0, 0, 0], [1, 0, 0, 0], [1, 0, 0, 0], FAST3D_CLOUD, far, hist,
                              0.1)
     assert not r2["found"]
+
+
+# ---- mapping/3d/hybrid_grid_test.cc ------------------------------------------
+def test_hybrid_grid_get_cell_index(synth):
+    # :106-127  resolution 2: lround(p / 2), halves round away from zero
+    g = synth.HybridGrid(2.0)
+    cases = [((0, 0, 0), (0, 0, 0)), ((0, 26, 10), (0, 13, 5)), ((14, 0, 10), (7, 0, 5)),
+             ((14, 26, 0), (7, 13, 0)), ((8.5, 11.5, 0.5), (4, 6, 0)),
+             ((7.5, 12.5, 1.5), (4, 6, 1)), ((6.5, 14.5, 2.5), (3, 7, 1)),
+             ((5.5, 13.5, 3.5), (3, 7, 2))]
+    for p, want in cases:
+        assert tuple(g.get_cell_index(np.array(p, np.float32))) == want
