@@ -243,7 +243,7 @@ def main():
                         "kernel is bound by L1/LDS gather rate, not by HBM",
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world_size == 1:     # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cells0, lim0, args.depth, scan, args.min_score,
                                                args.cpu_seconds)
     if use_dist:
