@@ -477,3 +477,28 @@ def test_rt2d_tsdf_large_cloud(sm, oracle, synth):
     init = [truth[0] + 0.06, truth[1] - 0.03, truth[2] + 0.01]
     _tsdf_match_both(sm, oracle, tsd, wgt, lim, 0.3, 10.0, init, scan, 0.15, math.radians(3.0),
                      0.2, 0.1)
+
+
+def test_caller_owned_stream(sm, oracle, c2):
+    """cmx_set_stream: the calling thread's matches run on a stream the caller owns (a torch
+    stream here) and still return the oracle's result; NULL restores the library stream."""
+    import ctypes
+    import torch
+    from cartographer_amd import _lib
+    cells, lim, _, _, scan = c2
+    om = _oracle(oracle, cells, lim, 5, 1.5, 0.3)
+    gm = sm.FastCorrelativeScanMatcher2D(_grid(sm, cells, lim), 5, 1.5, 0.3)
+    stream = torch.cuda.Stream()
+    _lib.check(_lib.lib().cmx_set_stream(0, ctypes.c_void_p(stream.cuda_stream)))
+    try:
+        # Work queued on the caller's stream before and after the match stays ordered with it.
+        with torch.cuda.stream(stream):
+            marker = torch.ones(1 << 20, device="cuda").sum()
+            _assert_match_parity(om, gm, lim["resolution"], [0.4, 0.3, 0.1], scan[:300], 0.2, False,
+                                 sm)
+            after = torch.ones(8, device="cuda").sum()
+        stream.synchronize()
+        assert float(marker) == float(1 << 20) and float(after) == 8.0
+    finally:
+        _lib.check(_lib.lib().cmx_set_stream(0, None))
+    _assert_match_parity(om, gm, lim["resolution"], [0.4, 0.3, 0.1], scan[:300], 0.2, False, sm)
