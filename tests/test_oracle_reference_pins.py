@@ -70,6 +70,41 @@ def test_value_tables(oracle):
     np.testing.assert_array_equal(grid, v2c)
 
 
+def test_probability_values_reference_pins(oracle, synth):
+    """mapping/probability_values_test.cc."""
+    v2p, v2c, _ = oracle.value_tables()
+    L = oracle.lib()
+    # :25-31 OddsConversions (ProbabilityFromOdds(Odds(p)) == p), in f32 like the reference
+    for p in (np.float32(0.1), np.float32(1) - np.float32(0.1), np.float32(0.5)):
+        odds = p / (np.float32(1) - p)
+        assert odds / (odds + np.float32(1)) == pytest.approx(float(p), abs=1e-6)
+    # :46-69 ProbabilityValue <-> CorrespondenceCostValue: value v as a probability and value
+    # 32768 - v as a correspondence cost describe the same cell (0 stays unknown), with and
+    # without the update marker -- i.e. the two tables mirror each other
+    assert v2p[0] == pytest.approx(1.0 - v2c[0], abs=1e-6)             # :72-73
+    idx = np.arange(1, 32768)
+    np.testing.assert_allclose(v2p[idx], 1.0 - v2c[32768 - idx], atol=1e-6)
+    np.testing.assert_allclose(v2p[idx + 32768], 1.0 - v2c[32768 - idx + 32768], atol=1e-6)
+    # :74-77 ConversionLookUpTable: both tables map [1, 32767] onto [0.1, 0.9] identically
+    np.testing.assert_allclose(v2p[idx], v2c[idx], atol=1e-6)
+    # :80-110 CellUpdate: for 5000 probabilities the probability value and the
+    # correspondence-cost value of the complementary cost are mirror images (+-1), and one
+    # application of the odds(0.9) table to an unknown cell gives complementary results
+    t = synth.odds_table(0.9).astype(np.int64) - 32768
+    assert 1.0 - v2c[t[0]] == pytest.approx(0.9, abs=1e-4)
+    for i in range(0, 5000, 7):
+        p = np.float32(i) / np.float32(5000) * (np.float32(0.9) - np.float32(0.1)) + np.float32(0.1)
+        pv = L.orc_probability_to_value(float(p))
+        cv = L.orc_correspondence_cost_to_value(float(np.float32(1) - p))
+        assert abs(pv - (32768 - cv)) <= 1
+        # updating the cell through the correspondence-cost table == odds update of p
+        odds = np.float32(0.9) / (np.float32(1) - np.float32(0.9))
+        p_cell = np.float32(1) - v2c[cv]
+        want = odds * (p_cell / (np.float32(1) - p_cell))
+        want = want / (want + np.float32(1))
+        assert 1.0 - v2c[t[cv]] == pytest.approx(float(np.clip(want, 0.1, 0.9)), abs=2e-4)
+
+
 # ---- 2d/probability_grid_test.cc (via the inserter restatement) ------------
 def test_apply_odds(synth):
     # :110-116  a single hit with odds(0.42)... restated: first application sets
