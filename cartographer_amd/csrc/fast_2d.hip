@@ -994,7 +994,6 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
     if (strict ? !(nd.score > best) : (nd.score < best)) continue;
     const int child_level = NodeLevel(nd) - 1;
     const LevelDesc L = P.level[child_level];
-    const auto* cells = AsGlobal(L.cells);
     const int4 bd = P.bounds[nd.scan];
     const int half = 1 << child_level, off = half - 1;
     const bool vx = nd.dx + half <= bd.y, vy = nd.dy + half <= bd.w;

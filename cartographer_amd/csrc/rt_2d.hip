@@ -509,7 +509,7 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
   char* d_padded = ws->dev[2].ReserveAs<char>(padded_bytes);
   float* d_unweighted = ws->dev[3].ReserveAs<float>(scores_total);
   float* d_weighted = ws->dev[4].ReserveAs<float>(scores_total);
-  constexpr int kHeadWords = 2 + 2 * kFinalistHead;             // 126 words, padded to 128
+  static_assert(2 + 2 * kFinalistHead <= 128, "a match's head must fit its 128-word slot");
   unsigned* d_misc = ws->dev[5].ReserveAs<unsigned>(static_cast<size_t>(num) * 128);
   unsigned* d_overflow = ws->dev[6].ReserveAs<unsigned>(static_cast<size_t>(num) * 2 *
                                                         (kFinalistCap - kFinalistHead));

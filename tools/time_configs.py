@@ -36,6 +36,19 @@ def c1(cpu):
     print(f"C1 rt2d: {dt * 1e6:.1f} us/match wall, device {st['device_ms'] * 1e3:.1f} us, kernel "
           f"{st['dominant_kernel_ms'] * 1e3:.1f} us, {st['candidates_scored']} cand, N={len(scan)} "
           f"-> {st['candidates_scored'] / dt:.3e} cand/s; score {score:.4f}")
+    from cartographer_amd import grid_2d
+    dev = grid_2d.ProbabilityGridOnDevice(0.05, (lim["max_x"], lim["max_y"]), 200, 200, cells=cells)
+    dt2, (score2, _) = timeit(lambda: m.match(init, scan, dev), 50)
+    st2 = m.last_stats
+    print(f"   grid resident in HBM: {dt2 * 1e6:.1f} us/match wall, device "
+          f"{st2['device_ms'] * 1e3:.1f} us; score equal: {score2 == score}")
+    c, s_ = math.cos(pose[2]), math.sin(pose[2])
+    in_map = np.zeros((scan.shape[0], 3), np.float32)
+    in_map[:, 0] = pose[0] + c * scan[:, 0] - s_ * scan[:, 1]
+    in_map[:, 1] = pose[1] + s_ * scan[:, 0] + c * scan[:, 1]
+    t_ins, _ = timeit(lambda: dev.insert(pose[:2], in_map), 20)
+    print(f"   range-data insertion on the device: {t_ins * 1e6:.1f} us/scan wall "
+          f"({scan.shape[0]} rays)")
     if cpu:
         from oracle import pyoracle as orc
         t0 = time.perf_counter()
