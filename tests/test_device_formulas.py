@@ -1,0 +1,77 @@
+"""CPU checks (numpy float32 / float64 emulation, same IEEE operations) of two device-side
+shortcuts whose exactness the GPU parity tests rely on but cannot enumerate:
+
+* `SumUpperBound` (fast_2d.hip): the integer recovered from a node's f32 score must never be
+  below the integer sum the score was computed from, or the early exit of `ExpandWaveKernel`
+  could drop a child the reference keeps.
+* `FastCellIndex` (rt_3d.hip) / `CellIndexF64` (cmx_device.h): when the shortcut path is taken
+  its result must equal lround of the IEEE quotient the reference computes.
+"""
+import numpy as np
+import pytest
+
+
+def _to_score(total, n, min_s, scale):
+    # ToScore: min_s + (float(sum) / float(n)) * score_scale, all f32
+    return (np.float32(min_s) + (total.astype(np.float32) / np.float32(n)) * np.float32(scale)) \
+        .astype(np.float32)
+
+
+@pytest.mark.parametrize("n", [1, 7, 200, 1000, 5000, 65536])
+def test_sum_upper_bound_is_conservative(n):
+    min_s = np.float32(1) - (np.float32(1) - np.float32(0.1))          # 1 - max_cc
+    max_s = np.float32(1) - (np.float32(1) - (np.float32(1) - np.float32(0.1)))
+    scale = (max_s - min_s) / np.float32(255)
+    hi = 255 * n
+    sums = np.unique(np.concatenate([np.arange(0, min(hi, 70000) + 1),
+                                     np.linspace(0, hi, 200001).astype(np.int64),
+                                     hi - np.arange(0, min(hi, 70000) + 1)]))
+    score = _to_score(sums, n, min_s, scale)
+    s = ((score - min_s) / scale * np.float32(n)).astype(np.float32)
+    ub = np.ceil((s * (np.float32(1) + np.float32(1e-5))).astype(np.float32)) + np.float32(2)
+    ub = np.minimum(np.maximum(ub, 0), np.float32(255) * np.float32(n)).astype(np.int64)
+    assert np.all(ub >= sums), (n, sums[ub < sums][:5])
+    # and it is not uselessly loose: within ~2e-5 relative + 3
+    assert np.all(ub - sums <= 4 + 3e-5 * sums)
+
+
+def _lround(v):
+    return np.where(v >= 0, np.floor(v + 0.5), -np.floor(-v + 0.5)).astype(np.int64)
+
+
+@pytest.mark.parametrize("res", [0.05, 0.1, 0.45, 0.2, 1.0 / 3.0])
+def test_fast_cell_index_f32_matches_ieee_division(res):
+    res = np.float32(res)
+    inv = np.float32(1) / res
+    rng = np.random.default_rng(7)
+    k = rng.integers(-5000, 5000, 1_000_000)
+    near = ((k + 0.5) * np.float64(res)).astype(np.float32)
+    near = (near.view(np.int32) + rng.integers(-8, 9, near.size).astype(np.int32)).view(np.float32)
+    c = np.concatenate([near, rng.uniform(-500, 500, 1_000_000).astype(np.float32)])
+    c = c[np.isfinite(c)]
+    q0 = (c * inv).astype(np.float32)
+    n = np.rint(q0).astype(np.float32)
+    margin = (np.float32(0.5) - np.abs((q0 - n).astype(np.float32))).astype(np.float32)
+    fast = margin > (np.abs(q0) * np.float32(2.0 ** -20)).astype(np.float32)
+    exact = _lround((c / res).astype(np.float32).astype(np.float64))
+    assert fast.mean() > 0.45                      # the shortcut is the common case ...
+    assert np.array_equal(n[fast].astype(np.int64), exact[fast])   # ... and is exact when taken
+
+
+@pytest.mark.parametrize("res", [0.05, 0.1, 0.03, 0.05 / 1000])
+def test_cell_index_f64_matches_ieee_division(res):
+    inv = 1.0 / res
+    rng = np.random.default_rng(11)
+    k = rng.integers(-30000, 30000, 1_000_000)
+    near = (k * res)
+    near = (near.view(np.int64) + rng.integers(-6, 7, near.size)).view(np.float64)
+    t = np.concatenate([near, rng.uniform(-3000, 3000, 1_000_000)])
+    t = t[np.isfinite(t)]
+    q0 = t * inv
+    v0 = q0 - 0.5
+    n = np.rint(v0)
+    margin = 0.5 - np.abs(v0 - n)
+    fast = margin > np.abs(q0) * 2.0 ** -46 + 2.0 ** -46
+    exact = _lround(t / res - 0.5)
+    assert fast.mean() > 0.45
+    assert np.array_equal(n[fast].astype(np.int64), exact[fast])
