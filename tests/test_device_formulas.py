@@ -75,3 +75,25 @@ def test_cell_index_f64_matches_ieee_division(res):
     exact = _lround(t / res - 0.5)
     assert fast.mean() > 0.45
     assert np.array_equal(n[fast].astype(np.int64), exact[fast])
+
+
+def test_parent_cell_is_max_of_child_cells(oracle, synth):
+    """The identity behind the early exit of node expansions (fast_2d.hip): a width-2h
+    precomputation cell equals the maximum of the four width-h cells its children read
+    (cells outside a level read 0), on the oracle's own PrecomputationGrid2D levels -- which
+    the device stack equals bit for bit (tests/test_gpu_2d.py)."""
+    cells, _, _ = synth.make_submap(5, 70, 53, 0.05, 6, 200, 30.0, 0.01)
+    ny, nx = cells.shape
+    for h in (1, 2, 4, 8, 16):
+        small = oracle.precompute2d(cells, h).astype(np.int32)       # [y0 + h - 1][x0 + h - 1]
+        big = oracle.precompute2d(cells, 2 * h).astype(np.int32)     # [y0 + 2h - 1][x0 + 2h - 1]
+
+        def child(x0, y0):
+            ix, iy = x0 + h - 1, y0 + h - 1
+            ok = (ix >= 0) & (ix < small.shape[1]) & (iy >= 0) & (iy < small.shape[0])
+            return np.where(ok, small[np.clip(iy, 0, small.shape[0] - 1),
+                                      np.clip(ix, 0, small.shape[1] - 1)], 0)
+        y0, x0 = np.meshgrid(np.arange(-2 * h + 1, ny), np.arange(-2 * h + 1, nx), indexing="ij")
+        want = np.maximum(np.maximum(child(x0, y0), child(x0 + h, y0)),
+                          np.maximum(child(x0, y0 + h), child(x0 + h, y0 + h)))
+        np.testing.assert_array_equal(big, want)
