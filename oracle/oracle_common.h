@@ -5,11 +5,14 @@
 // tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load
 // it, and only as the checker / reported baseline.
 //
-// Parity status: the real reference cannot be compiled in this image (Eigen,
-// glog, Abseil, protobuf, Ceres are absent), so the restatement is pinned
+// Parity status: the real reference cannot be compiled as a whole in this image
+// (Eigen, glog, Abseil, protobuf, Ceres are absent), so the restatement is pinned
 // against every known-answer test the reference holds for the path
-// (tests/test_oracle_reference_pins.py lists them with file:line).  Bit-level
-// Eigen parity (quaternion products under SSE) is UNPINNED; see DESIGN.md.
+// (tests/test_oracle_reference_pins*.py list them with file:line), and -- for the
+// value / odds / conversion tables below and the inserter's ray mask -- against
+// the reference's own translation units compiled in place (oracle/_ref,
+// tests/test_reference_ref.py: bit-identical).  Bit-level Eigen parity
+// (quaternion products under SSE) is UNPINNED; see DESIGN.md.
 //
 // This header: constants, lookup tables, rounding and the small subset of
 // Eigen geometry the path uses, restated with Eigen 3.3's operation order.

@@ -87,6 +87,35 @@ def _declare(L):
                                          C.POINTER(C.c_int64)]
 
 
+# ---- oracle/_ref: reference translation units compiled in place (ref_shims/README.md) ------
+_REF = os.path.join(_HERE, "_ref", "libref.so")
+_ref_lib = None
+
+
+def build_ref(reference="/root/reference"):
+    """`make -C oracle ref` when the reference tree is present (it is not on the GPU box)."""
+    if os.path.isdir(os.path.join(reference, "cartographer")):
+        subprocess.check_call(["make", "-C", _HERE, "ref", f"REFERENCE={reference}"],
+                              stdout=subprocess.DEVNULL)
+    return os.path.exists(_REF)
+
+
+def ref_lib():
+    """The reference's own probability_values / value_conversion_tables / ray_to_pixel_mask
+    code, or None when it has not been built (no /root/reference)."""
+    global _ref_lib
+    if _ref_lib is None and (os.path.exists(_REF) or build_ref()):
+        L = C.CDLL(_REF)
+        L.ref_ray_to_pixel_mask.argtypes = [C.c_int] * 5 + [_i32p, C.c_int]
+        L.ref_value_tables.argtypes = [_f32p, _f32p]
+        L.ref_probability_to_value.argtypes = [C.c_float]
+        L.ref_correspondence_cost_to_value.argtypes = [C.c_float]
+        L.ref_odds_tables.argtypes = [C.c_float, _u16p, _u16p]
+        L.ref_conversion_table.argtypes = [C.c_float, C.c_float, C.c_float, _f32p]
+        _ref_lib = L
+    return _ref_lib
+
+
 def _cloud(xyz):
     xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
     return xyz, xyz.shape[0]

@@ -1,0 +1,101 @@
+"""oracle/_ref: the REFERENCE'S OWN code -- probability_values.cc, value_conversion_tables.cc and
+ray_to_pixel_mask.cc compiled unmodified from /root/reference (oracle/Makefile `ref`,
+oracle/ref_shims/README.md) -- against the oracle's restatement of the value tables (SURVEY §8
+a25) and the range-data inserter restatement's ray mask (§8 f3).  Everything here is exact.
+
+Skipped where neither /root/reference nor a prebuilt oracle/_ref/libref.so exists.
+"""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def ref(oracle):
+    lib = oracle.ref_lib()
+    if lib is None:
+        pytest.skip("reference tree not available and oracle/_ref not prebuilt")
+    return lib
+
+
+def test_value_tables_equal_the_reference(ref, oracle):
+    v2p = np.empty(65536, np.float32)
+    v2c = np.empty(65536, np.float32)
+    ref.ref_value_tables(v2p, v2c)
+    o_v2p, o_v2c, o_grid = oracle.value_tables()
+    np.testing.assert_array_equal(o_v2p, v2p)        # kValueToProbability
+    np.testing.assert_array_equal(o_v2c, v2c)        # kValueToCorrespondenceCost
+    # the per-grid table a ProbabilityGrid asks for (grid_2d.cc:60-73):
+    # GetConversionTable(max_correspondence_cost, min_cc, max_cc)
+    max_cc = np.float32(1) - np.float32(0.1)
+    min_cc = np.float32(1) - (np.float32(1) - np.float32(0.1))
+    table = np.empty(65536, np.float32)
+    ref.ref_conversion_table(float(max_cc), float(min_cc), float(max_cc), table)
+    np.testing.assert_array_equal(o_grid, table)
+
+
+def test_float_to_value_equals_the_reference(ref, oracle):
+    rng = np.random.default_rng(0)
+    samples = np.concatenate([rng.uniform(-0.2, 1.2, 20000).astype(np.float32),
+                              np.float32([0.0, 0.1, 0.9, 1.0, 0.5, 0.0999999, 0.9000001])])
+    L = oracle.lib()
+    for x in samples:
+        assert L.orc_probability_to_value(float(x)) == ref.ref_probability_to_value(float(x))
+        assert L.orc_correspondence_cost_to_value(float(x)) == \
+            ref.ref_correspondence_cost_to_value(float(x))
+
+
+@pytest.mark.parametrize("probability", [0.7, 0.4, 0.55, 0.49, 0.9, 0.1, 0.5])
+def test_odds_tables_equal_the_reference(ref, synth, probability):
+    cc = np.empty(32768, np.uint16)
+    pr = np.empty(32768, np.uint16)
+    ref.ref_odds_tables(probability, cc, pr)
+    # the table the range-data inserter restatement (and the device grid) applies
+    np.testing.assert_array_equal(synth.odds_table(probability), cc)
+
+
+def test_tsd_conversion_tables_equal_the_reference(ref, oracle):
+    # TSDValueConverter (tsd_value_converter.cc:22-33): GetConversionTable(min_tsd, min_tsd,
+    # max_tsd) and (0, 0, max_weight)
+    for trunc, max_w in ((0.3, 10.0), (0.1, 1.0)):
+        t = np.empty(65536, np.float32)
+        ref.ref_conversion_table(-trunc, -trunc, trunc, t)
+        w = np.empty(65536, np.float32)
+        ref.ref_conversion_table(0.0, 0.0, max_w, w)
+        for v in list(range(0, 65536, 257)) + [1, 32767, 32768, 32769, 65535]:
+            assert oracle.value_to_tsd(v, trunc) == t[v]
+            assert oracle.value_to_weight(v, max_w) == w[v]
+
+
+def _ref_mask(ref, b, e, scale):
+    out = np.empty((1 << 14, 2), np.int32)
+    n = ref.ref_ray_to_pixel_mask(int(b[0]), int(b[1]), int(e[0]), int(e[1]), scale, out,
+                                  out.shape[0])
+    assert n <= out.shape[0]
+    return out[:n]
+
+
+def test_ray_mask_equals_the_reference(ref, synth):
+    """RayToPixelMask itself, on random rays and on the awkward ones (axis-aligned, through
+    pixel corners, inside one pixel, reversed): the same set of pixels, none twice."""
+    rng = np.random.default_rng(3)
+    scale = 1000
+    cases = []
+    for _ in range(3000):
+        cases.append((rng.integers(0, 60 * scale, 2), rng.integers(0, 60 * scale, 2)))
+    for _ in range(500):                                   # short rays
+        b = rng.integers(0, 60 * scale, 2)
+        cases.append((b, np.maximum(b + rng.integers(-1500, 1500, 2), 0)))
+    for k in range(1, 40):                                 # axis-aligned and diagonal through corners
+        cases += [((500, 500), (500 + k * scale, 500)), ((500, 500), (500, 500 + k * scale)),
+                  ((500, 500), (500 + k * scale, 500 + k * scale)),
+                  ((500 + k * scale, 500 + k * scale), (500, 500)),
+                  ((0, k * scale), (k * scale, 0)), ((k * scale, k * scale), (0, 0)),
+                  ((250, 750), (250 + k * scale, 750 + 2 * k * scale))]
+    for b, e in cases:
+        want = _ref_mask(ref, b, e, scale)
+        got = synth.cells_on_ray(b, e, scale)
+        want_set = {tuple(p) for p in want}
+        got_set = {tuple(p) for p in got}
+        assert len(want_set) == len(want), (b, e)          # the reference lists no pixel twice
+        assert got_set == want_set, (tuple(b), tuple(e))
+        assert len(got) == len(got_set)
