@@ -112,6 +112,10 @@ def ref_lib():
         L.ref_correspondence_cost_to_value.argtypes = [C.c_float]
         L.ref_odds_tables.argtypes = [C.c_float, _u16p, _u16p]
         L.ref_conversion_table.argtypes = [C.c_float, C.c_float, C.c_float, _f32p]
+        L.ref_tsd_float_to_value.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float]
+        L.ref_tsd_value_to_float.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int]
+        L.ref_tsd_value_to_float.restype = C.c_float
+        L.ref_fixed_ratio_sampler.argtypes = [C.c_double, C.c_int, _u8p]
         _ref_lib = L
     return _ref_lib
 

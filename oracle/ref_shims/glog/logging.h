@@ -42,5 +42,6 @@ struct Voidify { void operator&(NullStream&) {} };
 #define DCHECK_GE(a, b) CHECK_GE(a, b)
 #define DCHECK_GT(a, b) CHECK_GT(a, b)
 #define LOG(severity) ::ref_shims::NullStream()
+#define LOG_IF(severity, condition) ::ref_shims::NullStream()
 
 #endif  // ORACLE_REF_SHIMS_GLOG_LOGGING_H_

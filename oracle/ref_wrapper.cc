@@ -1,10 +1,12 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY.  C wrapper around three reference translation units that
+// ORACLE — TEST INFRASTRUCTURE ONLY.  C wrapper around five reference translation units that
 // `make -C oracle ref` compiles unmodified from /root/reference (see ref_shims/README.md).
 #include <cstdint>
 #include <cstring>
 #include <vector>
 
+#include "cartographer/common/fixed_ratio_sampler.h"
 #include "cartographer/mapping/internal/2d/ray_to_pixel_mask.h"
+#include "cartographer/mapping/internal/2d/tsd_value_converter.h"
 #include "cartographer/mapping/probability_values.h"
 #include "cartographer/mapping/value_conversion_tables.h"
 
@@ -53,6 +55,25 @@ void ref_conversion_table(float unknown_result, float lower_bound, float upper_b
   cartographer::mapping::ValueConversionTables tables;
   const std::vector<float>* t = tables.GetConversionTable(unknown_result, lower_bound, upper_bound);
   std::memcpy(out, t->data(), 65536 * sizeof(float));
+}
+
+// TSDValueConverter(max_tsd, max_weight): kind 0 = TSDToValue / ValueToTSD, 1 = weights.
+int ref_tsd_float_to_value(int kind, float max_tsd, float max_weight, float x) {
+  cartographer::mapping::ValueConversionTables tables;
+  const cartographer::mapping::TSDValueConverter c(max_tsd, max_weight, &tables);
+  return kind == 0 ? c.TSDToValue(x) : c.WeightToValue(x);
+}
+float ref_tsd_value_to_float(int kind, float max_tsd, float max_weight, int value) {
+  cartographer::mapping::ValueConversionTables tables;
+  const cartographer::mapping::TSDValueConverter c(max_tsd, max_weight, &tables);
+  return kind == 0 ? c.ValueToTSD(static_cast<uint16_t>(value))
+                   : c.ValueToWeight(static_cast<uint16_t>(value));
+}
+
+// FixedRatioSampler(ratio): the outcome of `count` consecutive Pulse() calls.
+void ref_fixed_ratio_sampler(double ratio, int count, uint8_t* out) {
+  cartographer::common::FixedRatioSampler sampler(ratio);
+  for (int i = 0; i != count; ++i) out[i] = sampler.Pulse() ? 1 : 0;
 }
 
 }  // extern "C"

@@ -99,3 +99,45 @@ def test_ray_mask_equals_the_reference(ref, synth):
         assert len(want_set) == len(want), (b, e)          # the reference lists no pixel twice
         assert got_set == want_set, (tuple(b), tuple(e))
         assert len(got) == len(got_set)
+
+
+def test_tsd_value_converter_equals_the_reference(ref, oracle):
+    """TSDValueConverter::TSDToValue / WeightToValue / ValueToTSD / ValueToWeight themselves
+    (mapping/internal/2d/tsd_value_converter.{h,cc})."""
+    rng = np.random.default_rng(5)
+    for trunc, max_w in ((0.3, 10.0), (0.1, 1.0), (0.05, 250.0)):
+        for x in np.concatenate([rng.uniform(-2 * trunc, 2 * trunc, 3000).astype(np.float32),
+                                 np.float32([0.0, trunc, -trunc, 2 * trunc])]):
+            assert oracle.tsd_to_value(float(x), trunc) == \
+                ref.ref_tsd_float_to_value(0, trunc, max_w, float(x))
+        for x in np.concatenate([rng.uniform(-max_w, 2 * max_w, 3000).astype(np.float32),
+                                 np.float32([0.0, max_w])]):
+            assert oracle.weight_to_value(float(x), max_w) == \
+                ref.ref_tsd_float_to_value(1, trunc, max_w, float(x))
+        for v in list(range(0, 65536, 509)) + [0, 1, 32767, 32768, 65535]:
+            assert oracle.value_to_tsd(v, trunc) == ref.ref_tsd_value_to_float(0, trunc, max_w, v)
+            assert oracle.value_to_weight(v, max_w) == \
+                ref.ref_tsd_value_to_float(1, trunc, max_w, v)
+
+
+@pytest.mark.parametrize("ratio", [0.0, 0.003, 0.1, 0.3, 0.5, 0.77, 1.0])
+def test_fixed_ratio_sampler_equals_the_reference(ref, ratio):
+    """common::FixedRatioSampler::Pulse (the ConstraintBuilder2D front's per-submap sampler)."""
+    from cartographer_amd.constraint_builder import FixedRatioSampler
+    want = np.empty(2000, np.uint8)
+    ref.ref_fixed_ratio_sampler(ratio, want.size, want)
+    mine = FixedRatioSampler(ratio)
+    got = np.array([mine.pulse() for _ in range(want.size)], np.uint8)
+    np.testing.assert_array_equal(got, want)
+    # and the restatement used by the oracle-side ConstraintBuilder2D
+    from oracle import constraint_builder_ref as cb_ref
+    r = cb_ref.ConstraintBuilder2DRef(ratio, 1e9, 0.0, 0.0, 1.0, 0.1, 1)
+    st = [0, 0]
+    out = []
+    for _ in range(want.size):
+        st[0] += 1
+        take = st[1] / st[0] < ratio
+        st[1] += int(take)
+        out.append(int(take))
+    np.testing.assert_array_equal(np.array(out, np.uint8), want)
+    del r
