@@ -9,10 +9,11 @@
 // (Eigen, glog, Abseil, protobuf, Ceres are absent), so the restatement is pinned
 // against every known-answer test the reference holds for the path
 // (tests/test_oracle_reference_pins*.py list them with file:line), and -- for the
-// value / odds / conversion tables below and the inserter's ray mask -- against
-// the reference's own translation units compiled in place (oracle/_ref,
-// tests/test_reference_ref.py: bit-identical).  Bit-level Eigen parity
-// (quaternion products under SSE) is UNPINNED; see DESIGN.md.
+// value / odds / conversion tables below, the inserter's ray mask and the whole
+// 2D matcher algorithm (oracle_2d.cc) -- against the reference's own translation
+// units compiled in place (oracle/_ref, tests/test_reference_ref.py:
+// bit-identical).  Bit-level Eigen parity (the quaternion / affine kernels, which
+// that build stands in) is UNPINNED; see DESIGN.md.
 //
 // This header: constants, lookup tables, rounding and the small subset of
 // Eigen geometry the path uses, restated with Eigen 3.3's operation order.

@@ -116,8 +116,74 @@ def ref_lib():
         L.ref_tsd_value_to_float.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int]
         L.ref_tsd_value_to_float.restype = C.c_float
         L.ref_fixed_ratio_sampler.argtypes = [C.c_double, C.c_int, _u8p]
+        L.ref_fast2d_create.argtypes = [_u16p, C.c_int, C.c_int, C.c_double, C.c_double,
+                                        C.c_double, C.c_int, C.c_double, C.c_double]
+        L.ref_fast2d_create.restype = C.c_void_p
+        L.ref_fast2d_destroy.argtypes = [C.c_void_p]
+        L.ref_fast2d_match.argtypes = [C.c_void_p, C.c_int, _f64p, _f32p, C.c_int, C.c_float,
+                                       C.POINTER(C.c_float), _f64p]
+        L.ref_precompute2d.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, _u8p]
+        L.ref_rt2d_match.argtypes = [_u16p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double,
+                                     C.c_double, C.c_float, C.c_float, _f64p, _f32p, C.c_int,
+                                     C.c_double, C.c_double, C.c_double, C.c_double, _f64p]
+        L.ref_rt2d_match.restype = C.c_double
         _ref_lib = L
     return _ref_lib
+
+
+class ReferenceFastCorrelativeScanMatcher2D:
+    """The reference's own fast_correlative_scan_matcher_2d.cc / correlative_scan_matcher_2d.cc
+    (oracle/_ref), same call shape as FastCorrelativeScanMatcher2D below."""
+
+    def __init__(self, cells, res, max_x, max_y, depth, linear_search_window=7.0,
+                 angular_search_window=float(np.deg2rad(30.0))):
+        cells = np.ascontiguousarray(cells, np.uint16)
+        ny, nx = cells.shape
+        self._h = ref_lib().ref_fast2d_create(cells, nx, ny, res, max_x, max_y, depth,
+                                              linear_search_window, angular_search_window)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            ref_lib().ref_fast2d_destroy(self._h)
+            self._h = None
+
+    def _match(self, init, xyz, full, min_score):
+        xyz, n = _cloud(xyz)
+        score = C.c_float()
+        pose = np.zeros(3, np.float64)
+        ok = ref_lib().ref_fast2d_match(self._h, int(full), np.ascontiguousarray(init, np.float64),
+                                        xyz, n, min_score, C.byref(score), pose)
+        return dict(found=bool(ok), score=float(score.value), pose=pose)
+
+    def match(self, init_xyt, xyz, min_score):
+        return self._match(init_xyt, xyz, False, min_score)
+
+    def match_full_submap(self, xyz, min_score):
+        return self._match([0.0, 0.0, 0.0], xyz, True, min_score)
+
+
+def ref_precompute2d(cells, width):
+    cells = np.ascontiguousarray(cells, np.uint16)
+    ny, nx = cells.shape
+    out = np.empty((ny + width - 1, nx + width - 1), np.uint8)
+    ref_lib().ref_precompute2d(cells, nx, ny, width, out)
+    return out
+
+
+def ref_rt2d_match(cells, res, max_x, max_y, init_xyt, xyz, lin, ang, tw, rw, weight_cells=None,
+                   truncation_distance=0.0, max_weight=0.0):
+    cells = np.ascontiguousarray(cells, np.uint16)
+    ny, nx = cells.shape
+    wptr = None
+    if weight_cells is not None:
+        weight_cells = np.ascontiguousarray(weight_cells, np.uint16)
+        wptr = weight_cells.ctypes.data
+    xyz, n = _cloud(xyz)
+    pose = np.zeros(3, np.float64)
+    s = ref_lib().ref_rt2d_match(cells, wptr, nx, ny, res, max_x, max_y, truncation_distance,
+                                 max_weight, np.ascontiguousarray(init_xyt, np.float64), xyz, n,
+                                 lin, ang, tw, rw, pose)
+    return dict(score=float(s), pose=pose)
 
 
 def _cloud(xyz):

@@ -5,6 +5,8 @@ a25) and the range-data inserter restatement's ray mask (§8 f3).  Everything he
 
 Skipped where neither /root/reference nor a prebuilt oracle/_ref/libref.so exists.
 """
+import math
+
 import numpy as np
 import pytest
 
@@ -141,3 +143,116 @@ def test_fixed_ratio_sampler_equals_the_reference(ref, ratio):
         out.append(int(take))
     np.testing.assert_array_equal(np.array(out, np.uint8), want)
     del r
+
+
+# ---------------------------------------------------------------------------------------------
+# The scan matchers themselves: the reference's correlative_scan_matcher_2d.cc,
+# fast_correlative_scan_matcher_2d.cc and real_time_correlative_scan_matcher_2d.cc, compiled
+# unmodified against stand-in data types (oracle/ref_shims/README.md), against the oracle's
+# restatement.  Everything the reference's files compute -- SearchParameters (acos step,
+# ShrinkToFit), the rotated-scan loop, DiscretizeScans, SlidingWindowMaximum and the
+# PrecomputationGrid2D stack, candidate generation, ScoreCandidates, std::sort, the recursive
+# BranchAndBound, the exhaustive real-time search with its exp() weight and max_element -- is the
+# reference's own code here; only the two Eigen floating-point kernels under it (rotating a point
+# by an angle-axis quaternion, Affine2f * vector) are stand-ins with the oracle's documented
+# evaluation order.
+# ---------------------------------------------------------------------------------------------
+def _same_match(a, b):
+    assert a["found"] == b["found"]
+    if a["found"]:
+        assert np.float32(a["score"]) == np.float32(b["score"])
+        np.testing.assert_array_equal(a["pose"], b["pose"])
+
+
+@pytest.mark.parametrize("width", [1, 2, 3, 8, 64])
+def test_precomputation_grid_equals_the_reference(ref, oracle, synth, width):
+    cells, _, _ = synth.make_submap(11, 97, 71, 0.05, 8, 300, 30.0, 0.01)
+    np.testing.assert_array_equal(oracle.precompute2d(cells, width),
+                                  oracle.ref_precompute2d(cells, width))
+
+
+def test_fast2d_bench_workload_equals_the_reference(ref, oracle, synth):
+    """BASELINE config[1] itself: 1000-point scan vs a 400x400 submap, depth 7, full-angle."""
+    cells, lim, world = synth.make_submap(42, 400, 400, 0.05, 30, 1000, 30.0, 0.01)
+    pose = world.free_pose(1234, 0.5)
+    scan = world.scan(pose, 1000, 30.0, 0.01, 7)
+    args = (cells, lim["resolution"], lim["max_x"], lim["max_y"], 7)
+    mine = oracle.FastCorrelativeScanMatcher2D(*args)
+    theirs = oracle.ReferenceFastCorrelativeScanMatcher2D(*args)
+    for min_score in (0.6, 0.99):
+        _same_match(mine.match_full_submap(scan, min_score),
+                    theirs.match_full_submap(scan, min_score))
+    init = [pose[0] + 0.4, pose[1] - 0.3, pose[2] + 0.2]
+    _same_match(mine.match(init, scan, 0.55), theirs.match(init, scan, 0.55))
+
+
+@pytest.mark.parametrize("seed", [3, 11, 29, 57])
+def test_fast2d_random_cases_equal_the_reference(ref, oracle, synth, seed):
+    rng = np.random.default_rng(seed)
+    nx, ny = int(rng.integers(40, 220)), int(rng.integers(40, 220))
+    cells, lim, world = synth.make_submap(seed, nx, ny, 0.05, 8, 300, 30.0, 0.01)
+    depth = int(rng.integers(1, 8))
+    lin, ang = float(rng.uniform(0.2, 3.0)), float(rng.uniform(0.05, 0.6))
+    args = (cells, lim["resolution"], lim["max_x"], lim["max_y"], depth, lin, ang)
+    mine = oracle.FastCorrelativeScanMatcher2D(*args)
+    theirs = oracle.ReferenceFastCorrelativeScanMatcher2D(*args)
+    truth = world.free_pose(seed + 1, 0.3)
+    for n in (1, 7, 150):
+        scan = world.scan(truth, 200, 30.0, 0.01, seed)[:n]
+        init = [truth[0] + rng.uniform(-0.3, 0.3), truth[1] + rng.uniform(-0.3, 0.3),
+                truth[2] + rng.uniform(-0.2, 0.2)]
+        for min_score in (0.05, 0.5):
+            _same_match(mine.match(init, scan, min_score), theirs.match(init, scan, min_score))
+            _same_match(mine.match_full_submap(scan, min_score),
+                        theirs.match_full_submap(scan, min_score))
+
+
+def test_fast2d_all_ties_equal_the_reference(ref, oracle):
+    """An all-unknown grid: every candidate scores 0.1, the result is decided purely by the
+    reference's candidate order, std::sort and depth-first traversal."""
+    cells = np.zeros((60, 50), np.uint16)
+    cloud = np.array([[0.1, 0.2, 0.0], [0.7, -0.4, 0.0], [-0.3, 0.5, 0.0]], np.float32)
+    for depth in (1, 3, 5):
+        args = (cells, 0.1, 2.0, 3.0, depth, 1.0, 0.5)
+        mine = oracle.FastCorrelativeScanMatcher2D(*args)
+        theirs = oracle.ReferenceFastCorrelativeScanMatcher2D(*args)
+        _same_match(mine.match([0.5, 0.4, 0.2], cloud, 0.0), theirs.match([0.5, 0.4, 0.2], cloud, 0.0))
+        _same_match(mine.match_full_submap(cloud, 0.0), theirs.match_full_submap(cloud, 0.0))
+
+
+def test_rt2d_equals_the_reference(ref, oracle, synth):
+    cells, lim, world = synth.make_submap(42, 200, 200, 0.05, 25, 1000, 30.0, 0.01)
+    truth = world.free_pose(77, 0.5)
+    scan = world.scan(truth, 1000, 30.0, 0.01, 5)
+    init = [truth[0] + 0.12, truth[1] - 0.08, truth[2] + math.radians(3.0)]
+    for n, lin, ang, tw, rw in ((1000, 0.3, math.radians(7.0), 0.1, 0.1), (7, 0.2, 0.1, 10.0, 1.0),
+                                (200, 0.0, 0.0, 0.0, 0.0)):
+        mine = oracle.rt2d_match(cells, 0.05, lim["max_x"], lim["max_y"], init, scan[:n], lin, ang,
+                                 tw, rw)
+        theirs = oracle.ref_rt2d_match(cells, 0.05, lim["max_x"], lim["max_y"], init, scan[:n], lin,
+                                       ang, tw, rw)
+        assert mine["score"] == theirs["score"]
+        np.testing.assert_array_equal(mine["pose"], theirs["pose"])
+
+
+def test_rt2d_tsdf_equals_the_reference(ref, oracle, synth):
+    from tsdf_helpers import tsdf_from_probability_grid
+    cells, lim, world = synth.make_submap(5, 160, 140, 0.05, 12, 600, 30.0, 0.01)
+    tsd, wgt = tsdf_from_probability_grid(oracle, cells, 0.05, 0.3, 10.0, 5)
+    truth = world.free_pose(9, 0.5)
+    scan = world.scan(truth, 400, 30.0, 0.01, 2)
+    init = [truth[0] + 0.06, truth[1] - 0.03, truth[2] + 0.02]
+    mine = oracle.rt2d_match_tsdf(tsd, wgt, 0.05, lim["max_x"], lim["max_y"], 0.3, 10.0, init, scan,
+                                  0.2, 0.08, 0.1, 0.2)
+    theirs = oracle.ref_rt2d_match(tsd, 0.05, lim["max_x"], lim["max_y"], init, scan, 0.2, 0.08,
+                                   0.1, 0.2, weight_cells=wgt, truncation_distance=0.3,
+                                   max_weight=10.0)
+    assert mine["score"] == theirs["score"]
+    np.testing.assert_array_equal(mine["pose"], theirs["pose"])
+    zeros = np.zeros((20, 20), np.uint16)
+    mine = oracle.rt2d_match_tsdf(zeros, zeros, 0.05, 0.3, 0.5, 0.3, 1.0, [0, 0, 0], scan[:5], 0.1,
+                                  0.05, 0.0, 0.0)
+    theirs = oracle.ref_rt2d_match(zeros, 0.05, 0.3, 0.5, [0, 0, 0], scan[:5], 0.1, 0.05, 0.0, 0.0,
+                                   weight_cells=zeros, truncation_distance=0.3, max_weight=1.0)
+    assert mine["score"] == theirs["score"] == 0.0
+    np.testing.assert_array_equal(mine["pose"], theirs["pose"])
