@@ -68,15 +68,71 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(cells, lim, depth, scan, min_score, seconds):
-    """The oracle (CPU restatement) timed on this box's host cores: one
-    MatchFullSubmap per thread, the reference's thread-pool fan-out."""
-    from oracle import pyoracle as orc
+def _cores():
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 32))
+    return max(1, min(cores, 32))
+
+
+def cpu_baseline_reference(cells, lim, depth, scan, min_score, seconds):
+    """The reference's OWN fast_correlative_scan_matcher_2d.cc (oracle/_ref, built in place from
+    /root/reference by __graft_entry__.build(); the prebuilt .so travels to the GPU box) timed
+    on this box's host cores: one MatchFullSubmap per thread, like the reference's thread pool
+    runs them (const methods, concurrent calls on one matcher).  Candidates are counted with the
+    oracle port, whose search is bit-identical (tests/test_reference_ref.py).  Returns None
+    when oracle/_ref is not available."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import pyoracle as orc
+    if orc.ref_lib() is None:
+        return None
+    cores = _cores()
+    args = (cells, lim["resolution"], lim["max_x"], lim["max_y"], depth)
+    port = orc.FastCorrelativeScanMatcher2D(*args)
+    counted = port.match_full_submap(scan, min_score)
+    matcher = orc.ReferenceFastCorrelativeScanMatcher2D(*args)
+    t0 = time.perf_counter()
+    one = matcher.match_full_submap(scan, min_score)
+    t_one = time.perf_counter() - t0
+    assert one["found"] == counted["found"]
+    if one["found"]:
+        assert np.float32(one["score"]) == np.float32(counted["score"])
+    per_match = counted["candidates_scored"]
+    # Bounded sample: rounds of `cores` concurrent matches (ctypes releases the GIL) until
+    # `seconds` have elapsed.
+    t0 = time.perf_counter()
+    matches = 0
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        while True:
+            list(pool.map(lambda _: matcher.match_full_submap(scan, min_score), range(cores)))
+            matches += cores
+            dt = time.perf_counter() - t0
+            if dt >= seconds or matches >= 64 * cores:
+                break
+    return {
+        "value": matches * per_match / dt, "unit": "candidates/s", "cores": cores,
+        "kind": "reference",
+        "sample": f"{matches} MatchFullSubmap calls of the bench workload by the reference's own "
+                  f"fast_correlative_scan_matcher_2d.cc (oracle/_ref: compiled in place with the reference's -O3 -DNDEBUG, "
+                  f"stand-in Eigen value types; {per_match} candidates each, "
+                  f"{t_one * 1e3:.0f} ms single-thread), {cores} threads, {dt:.1f} s",
+        "single_thread_candidates_per_s": per_match / t_one,
+    }
+
+
+def cpu_baseline(cells, lim, depth, scan, min_score, seconds):
+    """CPU baseline on this box's host cores: the reference's own code when oracle/_ref is
+    available, else the oracle (CPU restatement, "port"): one MatchFullSubmap per thread, the
+    reference's thread-pool fan-out."""
+    try:
+        ref = cpu_baseline_reference(cells, lim, depth, scan, min_score, seconds)
+        if ref is not None:
+            return ref
+    except Exception as e:   # never let the baseline leg break the bench line
+        sys.stderr.write(f"reference baseline unavailable ({e}); timing the port instead\n")
+    from oracle import pyoracle as orc
+    cores = _cores()
     matcher = orc.FastCorrelativeScanMatcher2D(cells, lim["resolution"], lim["max_x"],
                                                lim["max_y"], depth)
     t0 = time.perf_counter()

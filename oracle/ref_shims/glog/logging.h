@@ -34,13 +34,19 @@ struct Voidify { void operator&(NullStream&) {} };
 #define CHECK_LT(a, b) REF_SHIMS_CHECK((a) < (b))
 #define CHECK_GE(a, b) REF_SHIMS_CHECK((a) >= (b))
 #define CHECK_GT(a, b) REF_SHIMS_CHECK((a) > (b))
-#define DCHECK(cond) REF_SHIMS_CHECK(cond)
-#define DCHECK_EQ(a, b) CHECK_EQ(a, b)
-#define DCHECK_NE(a, b) CHECK_NE(a, b)
-#define DCHECK_LE(a, b) CHECK_LE(a, b)
-#define DCHECK_LT(a, b) CHECK_LT(a, b)
-#define DCHECK_GE(a, b) CHECK_GE(a, b)
-#define DCHECK_GT(a, b) CHECK_GT(a, b)
+#ifdef NDEBUG   // glog compiles DCHECKs out of release builds
+#define REF_SHIMS_DCHECK(cond) \
+  true ? (void)0 : ::ref_shims::Voidify() & (*(::ref_shims::NullStream*)0)
+#else
+#define REF_SHIMS_DCHECK(cond) REF_SHIMS_CHECK(cond)
+#endif
+#define DCHECK(cond) REF_SHIMS_DCHECK(cond)
+#define DCHECK_EQ(a, b) REF_SHIMS_DCHECK((a) == (b))
+#define DCHECK_NE(a, b) REF_SHIMS_DCHECK((a) != (b))
+#define DCHECK_LE(a, b) REF_SHIMS_DCHECK((a) <= (b))
+#define DCHECK_LT(a, b) REF_SHIMS_DCHECK((a) < (b))
+#define DCHECK_GE(a, b) REF_SHIMS_DCHECK((a) >= (b))
+#define DCHECK_GT(a, b) REF_SHIMS_DCHECK((a) > (b))
 #define LOG(severity) ::ref_shims::NullStream()
 #define LOG_IF(severity, condition) ::ref_shims::NullStream()
 
