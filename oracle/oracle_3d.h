@@ -7,6 +7,9 @@
 //   .../low_resolution_matcher.cc:23-35
 // and the read accessors of mapping/3d/hybrid_grid.h.
 //
+// Pinned bit-for-bit against those sources compiled in place (oracle/_ref,
+// tests/test_reference_ref_3d.py) over stand-in Eigen types.
+//
 // Eigen detail (UNPINNED): float quaternion products follow the
 // SSE kernel of Eigen 3.3 (Geometry/arch/Geometry_SSE.h), which is what an
 // x86-64 build of the reference uses; 4-vector squared norms reduce as

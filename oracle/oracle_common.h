@@ -9,9 +9,11 @@
 // (Eigen, glog, Abseil, protobuf, Ceres are absent), so the restatement is pinned
 // against every known-answer test the reference holds for the path
 // (tests/test_oracle_reference_pins*.py list them with file:line), and -- for the
-// value / odds / conversion tables below, the inserter's ray mask and the whole
-// 2D matcher algorithm (oracle_2d.cc) -- against the reference's own translation
-// units compiled in place (oracle/_ref, tests/test_reference_ref.py:
+// value / odds / conversion tables below, the inserter's ray mask, the whole
+// 2D matcher algorithm (oracle_2d.cc) and the whole 3D matcher algorithm
+// (oracle_3d.cc, over the reference's real hybrid_grid.h) -- against the
+// reference's own translation units compiled in place (oracle/_ref,
+// tests/test_reference_ref.py and tests/test_reference_ref_3d.py:
 // bit-identical).  Bit-level Eigen parity (the quaternion / affine kernels, which
 // that build stands in) is UNPINNED; see DESIGN.md.
 //

@@ -127,6 +127,27 @@ def ref_lib():
                                      C.c_double, C.c_float, C.c_float, _f64p, _f32p, C.c_int,
                                      C.c_double, C.c_double, C.c_double, C.c_double, _f64p]
         L.ref_rt2d_match.restype = C.c_double
+        # 3D: same layouts as the orc_*3d functions (_lib3d below).
+        L.ref_grid3d_size.argtypes = [C.c_float, C.c_void_p, C.c_int64]
+        L.ref_grid3d_iterate.argtypes = [C.c_float, C.c_void_p, C.c_int64, _i32p, C.c_int64]
+        L.ref_grid3d_iterate.restype = C.c_int64
+        L.ref_grid3d_cell_index.argtypes = [C.c_float, _f32p, C.c_int, _i32p]
+        L.ref_rt3d_match.argtypes = [C.c_float, C.c_void_p, C.c_int64, _f64p, _f32p, C.c_int,
+                                     C.c_double, C.c_double, C.c_double, C.c_double, _f64p,
+                                     C.POINTER(C.c_int64)]
+        L.ref_rt3d_match.restype = C.c_float
+        L.ref_rotational_match.argtypes = [_f32p, _f32p, C.c_int, C.c_float, _f32p, C.c_int, _f32p]
+        L.ref_compute_histogram.argtypes = [_f32p, C.c_int, C.c_int, _f32p]
+        L.ref_fast3d_create.argtypes = [C.c_float, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
+                                        C.c_int64, _f32p, C.c_int, C.c_int, C.c_int, C.c_double,
+                                        C.c_double, C.c_double, C.c_double, C.c_double]
+        L.ref_fast3d_create.restype = C.c_void_p
+        L.ref_fast3d_destroy.argtypes = [C.c_void_p]
+        L.ref_fast3d_level_count.argtypes = [C.c_void_p, C.c_int]
+        L.ref_fast3d_level_count.restype = C.c_int64
+        L.ref_fast3d_level_voxels.argtypes = [C.c_void_p, C.c_int, _i32p]
+        L.ref_fast3d_match.argtypes = [C.c_void_p, C.c_int, _f64p, _f64p, _f64p, _f32p, C.c_int,
+                                       _f32p, C.c_int, _f32p, C.c_int, C.c_float, _f64p, _i64p]
         _ref_lib = L
     return _ref_lib
 
@@ -479,6 +500,113 @@ class FastCorrelativeScanMatcher3D:
                     low_resolution_score=float(np.float32(res[9])),
                     candidates_scored=int(stats[0]), num_scans=int(stats[1]),
                     coarse_candidates=int(stats[2]), nodes_expanded=int(stats[3]))
+
+    def match(self, node7, submap7, gravity, hi, lo, hist, min_score):
+        return self._match(False, node7, submap7, gravity, hi, lo, hist, min_score)
+
+    def match_full_submap(self, node_q, submap_q, gravity, hi, lo, hist, min_score):
+        node7 = np.concatenate([[0, 0, 0], node_q])
+        submap7 = np.concatenate([[0, 0, 0], submap_q])
+        return self._match(True, node7, submap7, gravity, hi, lo, hist, min_score)
+
+
+# ---- the reference's own 3D sources (oracle/_ref), same call shapes as the oracle twins above ----
+def _sort_zyx(a):
+    return a[np.lexsort((a[:, 0], a[:, 1], a[:, 2]))] if len(a) else a
+
+
+def ref_grid3d_size(resolution, voxels):
+    v, n = _voxels(voxels)
+    return int(ref_lib().ref_grid3d_size(resolution, v.ctypes.data, n))
+
+
+def ref_grid3d_iterate(resolution, voxels):
+    """(x, y, z, value) rows the real HybridGrid's iterator yields after the voxels were written
+    through mutable_value, in iteration order."""
+    v, n = _voxels(voxels)
+    out = np.empty((max(n, 1), 4), np.int32)
+    k = ref_lib().ref_grid3d_iterate(resolution, v.ctypes.data, n, out, out.shape[0])
+    return out[:k]
+
+
+def ref_grid3d_cell_index(resolution, xyz):
+    xyz, n = _cloud(xyz)
+    out = np.empty((n, 3), np.int32)
+    ref_lib().ref_grid3d_cell_index(resolution, xyz, n, out)
+    return out
+
+
+def ref_rt3d_match(resolution, voxels, init_pose7, xyz, lin, ang, tw, rw):
+    v, n = _voxels(voxels)
+    xyz, npts = _cloud(xyz)
+    pose = np.empty(7, np.float64)
+    ncand = C.c_int64()
+    s = ref_lib().ref_rt3d_match(resolution, v.ctypes.data, n,
+                                 np.ascontiguousarray(init_pose7, np.float64), xyz, npts, lin,
+                                 ang, tw, rw, pose, C.byref(ncand))
+    return dict(score=float(s), pose=pose)
+
+
+def ref_rotational_match(submap_hist, scan_hist, initial_angle, angles):
+    a = np.ascontiguousarray(submap_hist, np.float32)
+    b = np.ascontiguousarray(scan_hist, np.float32)
+    ang = np.ascontiguousarray(angles, np.float32)
+    out = np.empty(ang.shape[0], np.float32)
+    ref_lib().ref_rotational_match(a, b, a.shape[0], initial_angle, ang, ang.shape[0], out)
+    return out
+
+
+def ref_compute_histogram(xyz, histogram_size):
+    xyz, n = _cloud(xyz)
+    out = np.empty(histogram_size, np.float32)
+    ref_lib().ref_compute_histogram(xyz, n, histogram_size, out)
+    return out
+
+
+class ReferenceFastCorrelativeScanMatcher3D:
+    """The reference's own fast_correlative_scan_matcher_3d.cc (+ precomputation_grid_3d.cc,
+    rotational_scan_matcher.cc, low_resolution_matcher.cc, the real hybrid_grid.h)."""
+
+    def __init__(self, resolution, voxels, low_resolution, low_voxels, histogram, depth,
+                 full_resolution_depth, min_rotational_score, min_low_resolution_score,
+                 linear_xy_search_window, linear_z_search_window, angular_search_window):
+        v, n = _voxels(voxels)
+        lv, nl = _voxels(low_voxels)
+        h = np.ascontiguousarray(histogram, np.float32)
+        self.depth = depth
+        self._h = ref_lib().ref_fast3d_create(resolution, v.ctypes.data, n, low_resolution,
+                                              lv.ctypes.data, nl, h, h.shape[0], depth,
+                                              full_resolution_depth, min_rotational_score,
+                                              min_low_resolution_score, linear_xy_search_window,
+                                              linear_z_search_window, angular_search_window)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            ref_lib().ref_fast3d_destroy(self._h)
+            self._h = None
+
+    def level(self, depth):
+        """Like FastCorrelativeScanMatcher3D.level: int32 [n,4], sorted (z,y,x)."""
+        n = ref_lib().ref_fast3d_level_count(self._h, depth)
+        out = np.empty((n, 4), np.int32)
+        if n:
+            ref_lib().ref_fast3d_level_voxels(self._h, depth, out)
+        return _sort_zyx(out)
+
+    def _match(self, full, node7, submap7, gravity, hi, lo, hist, min_score):
+        hi, nhi = _cloud(hi)
+        lo, nlo = _cloud(lo)
+        hist = np.ascontiguousarray(hist, np.float32)
+        res = np.zeros(10, np.float64)
+        stats = np.zeros(4, np.int64)
+        ok = ref_lib().ref_fast3d_match(self._h, int(full),
+                                        np.ascontiguousarray(node7, np.float64),
+                                        np.ascontiguousarray(submap7, np.float64),
+                                        np.ascontiguousarray(gravity, np.float64), hi, nhi, lo,
+                                        nlo, hist, hist.shape[0], min_score, res, stats)
+        return dict(found=bool(ok), score=float(np.float32(res[0])), pose=res[1:8].copy(),
+                    rotational_score=float(np.float32(res[8])),
+                    low_resolution_score=float(np.float32(res[9])))
 
     def match(self, node7, submap7, gravity, hi, lo, hist, min_score):
         return self._match(False, node7, submap7, gravity, hi, lo, hist, min_score)

@@ -5,6 +5,7 @@
 #include <vector>
 #include "Eigen/Core"
 #include "cartographer/transform/rigid_transform.h"
+#include "glog/logging.h"   // the real header pulls glog in; rotational_scan_matcher.cc relies on it
 namespace cartographer {
 namespace sensor {
 struct RangefinderPoint {
@@ -19,6 +20,7 @@ class PointCloud {
   const RangefinderPoint& operator[](size_t i) const { return points_[i]; }
   std::vector<RangefinderPoint>::const_iterator begin() const { return points_.begin(); }
   std::vector<RangefinderPoint>::const_iterator end() const { return points_.end(); }
+  const std::vector<RangefinderPoint>& points() const { return points_; }
   void push_back(RangefinderPoint p) { points_.push_back(p); }
  private:
   std::vector<RangefinderPoint> points_;

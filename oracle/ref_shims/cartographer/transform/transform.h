@@ -11,4 +11,45 @@
 #include "cartographer/common/port.h"
 #include "cartographer/transform/rigid_transform.h"
 #include "glog/logging.h"
+
+namespace cartographer {
+namespace transform {
+
+// transform/transform.h:33-37.
+template <typename FloatType>
+FloatType GetAngle(const Rigid3<FloatType>& transform) {
+  return FloatType(2) * std::atan2(transform.rotation().vec().norm(),
+                                   std::abs(transform.rotation().w()));
+}
+
+// transform/transform.h:42-47: the direction the rotation sends UnitX to.
+template <typename T>
+T GetYaw(const Eigen::Quaternion<T>& rotation) {
+  const Eigen::Matrix<T, 3, 1> direction = rotation * Eigen::Matrix<T, 3, 1>::UnitX();
+  return std::atan2(direction.y(), direction.x());
+}
+template <typename T>
+T GetYaw(const Rigid3<T>& transform) {
+  return GetYaw(transform.rotation());
+}
+
+// transform/transform.h:85-99: sin/cos of `norm / 2.` are evaluated in double whatever T is
+// (the literal 2. promotes), then narrowed to T.
+template <typename T>
+Eigen::Quaternion<T> AngleAxisVectorToRotationQuaternion(
+    const Eigen::Matrix<T, 3, 1>& angle_axis) {
+  T scale = T(0.5);
+  T w = T(1.);
+  constexpr double kCutoffAngle = 1e-8;   // linearised below this angle
+  if (angle_axis.squaredNorm() > kCutoffAngle) {
+    const T norm = angle_axis.norm();
+    scale = std::sin(norm / 2.) / norm;
+    w = std::cos(norm / 2.);
+  }
+  const Eigen::Matrix<T, 3, 1> quaternion_xyz = scale * angle_axis;
+  return Eigen::Quaternion<T>(w, quaternion_xyz.x(), quaternion_xyz.y(), quaternion_xyz.z());
+}
+
+}  // namespace transform
+}  // namespace cartographer
 #endif  // ORACLE_REF_SHIMS_CARTOGRAPHER_TRANSFORM_TRANSFORM_H_

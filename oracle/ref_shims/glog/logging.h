@@ -20,13 +20,17 @@ struct NullStream {
   std::fprintf(stderr, "%s:%d: Check failed: %s\n", file, line, expr);
   std::abort();
 }
+inline NullStream& Null() {
+  static NullStream stream;
+  return stream;
+}
 struct Voidify { void operator&(NullStream&) {} };
 }  // namespace ref_shims
 
 #define REF_SHIMS_CHECK(cond)                                                          \
   (cond) ? (void)0                                                                     \
          : ::ref_shims::Voidify() &                                                    \
-               (::ref_shims::CheckFailed(__FILE__, __LINE__, #cond), *(::ref_shims::NullStream*)0)
+               (::ref_shims::CheckFailed(__FILE__, __LINE__, #cond), ::ref_shims::Null())
 #define CHECK(cond) REF_SHIMS_CHECK(cond)
 #define CHECK_EQ(a, b) REF_SHIMS_CHECK((a) == (b))
 #define CHECK_NE(a, b) REF_SHIMS_CHECK((a) != (b))
@@ -36,7 +40,7 @@ struct Voidify { void operator&(NullStream&) {} };
 #define CHECK_GT(a, b) REF_SHIMS_CHECK((a) > (b))
 #ifdef NDEBUG   // glog compiles DCHECKs out of release builds
 #define REF_SHIMS_DCHECK(cond) \
-  true ? (void)0 : ::ref_shims::Voidify() & (*(::ref_shims::NullStream*)0)
+  true ? (void)0 : ::ref_shims::Voidify() & (::ref_shims::Null())
 #else
 #define REF_SHIMS_DCHECK(cond) REF_SHIMS_CHECK(cond)
 #endif

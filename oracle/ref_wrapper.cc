@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY.  C wrapper around five reference translation units that
+// ORACLE — TEST INFRASTRUCTURE ONLY.  C wrapper around the reference translation units that
 // `make -C oracle ref` compiles unmodified from /root/reference (see ref_shims/README.md).
 #include <cstdint>
 #include <cstring>
@@ -10,6 +10,10 @@
 #include "cartographer/mapping/2d/probability_grid.h"
 #include "cartographer/mapping/internal/2d/scan_matching/fast_correlative_scan_matcher_2d.h"
 #include "cartographer/mapping/internal/2d/scan_matching/real_time_correlative_scan_matcher_2d.h"
+#include "cartographer/mapping/3d/hybrid_grid.h"
+#include "cartographer/mapping/internal/3d/scan_matching/fast_correlative_scan_matcher_3d.h"
+#include "cartographer/mapping/internal/3d/scan_matching/real_time_correlative_scan_matcher_3d.h"
+#include "cartographer/mapping/internal/3d/scan_matching/rotational_scan_matcher.h"
 #include "cartographer/mapping/internal/2d/tsd_value_converter.h"
 #include "cartographer/mapping/internal/2d/tsdf_2d.h"
 #include "cartographer/mapping/probability_values.h"
@@ -192,6 +196,197 @@ double ref_rt2d_match(const uint16_t* cells, const uint16_t* weight_cells, int n
   pose_xyt[1] = pose.translation().y();
   pose_xyt[2] = pose.rotation().angle();
   return score;
+}
+
+}  // extern "C"
+
+// ---- the 3D scan matchers: real_time_correlative_scan_matcher_3d.cc, precomputation_grid_3d.cc,
+// rotational_scan_matcher.cc, low_resolution_matcher.cc, fast_correlative_scan_matcher_3d.cc and
+// the header-only mapping/3d/hybrid_grid.h, all compiled unmodified.  Same argument layout as the
+// orc_*3d functions of oracle_capi.cc so that one Python caller drives both. --------------------
+namespace {
+
+struct RefVoxel { int32_t x, y, z; uint16_t value; uint16_t pad; };   // = oracle::Voxel
+
+std::unique_ptr<cm::HybridGrid> MakeHybridGrid(float resolution, const RefVoxel* voxels,
+                                               int64_t n) {
+  auto grid = std::make_unique<cm::HybridGrid>(resolution);
+  for (int64_t i = 0; i != n; ++i)
+    *grid->mutable_value(Eigen::Array3i(voxels[i].x, voxels[i].y, voxels[i].z)) = voxels[i].value;
+  return grid;
+}
+
+cartographer::transform::Rigid3d MakeRigid3d(const double* p7) {   // t xyz, q wxyz
+  return cartographer::transform::Rigid3d(Eigen::Vector3d(p7[0], p7[1], p7[2]),
+                                          Eigen::Quaterniond(p7[3], p7[4], p7[5], p7[6]));
+}
+void StoreRigid3d(const cartographer::transform::Rigid3d& p, double* out7) {
+  out7[0] = p.translation().x(); out7[1] = p.translation().y(); out7[2] = p.translation().z();
+  out7[3] = p.rotation().w(); out7[4] = p.rotation().x(); out7[5] = p.rotation().y();
+  out7[6] = p.rotation().z();
+}
+Eigen::VectorXf MakeHistogram(const float* h, int n) {
+  Eigen::VectorXf v = Eigen::VectorXf::Zero(n);
+  for (int i = 0; i != n; ++i) v[i] = h[i];
+  return v;
+}
+sm::proto::FastCorrelativeScanMatcherOptions3D MakeOptions3D(int depth, int full_resolution_depth,
+                                                             double min_rotational_score,
+                                                             double min_low_resolution_score,
+                                                             double lin_xy, double lin_z,
+                                                             double ang) {
+  sm::proto::FastCorrelativeScanMatcherOptions3D o;
+  o.set_branch_and_bound_depth(depth);
+  o.set_full_resolution_depth(full_resolution_depth);
+  o.set_min_rotational_score(min_rotational_score);
+  o.set_min_low_resolution_score(min_low_resolution_score);
+  o.set_linear_xy_search_window(lin_xy);
+  o.set_linear_z_search_window(lin_z);
+  o.set_angular_search_window(ang);
+  return o;
+}
+
+struct RefFast3D {
+  std::unique_ptr<cm::HybridGrid> grid, low_grid;
+  Eigen::VectorXf histogram;
+  sm::proto::FastCorrelativeScanMatcherOptions3D options;
+  std::unique_ptr<sm::FastCorrelativeScanMatcher3D> matcher;
+  std::unique_ptr<sm::PrecomputationGridStack3D> stack;   // built on demand for level dumps
+};
+
+}  // namespace
+
+extern "C" {
+
+// DynamicGrid::grid_size() after every voxel has been written (Grow(), hybrid_grid.h:381-398).
+int ref_grid3d_size(float resolution, const void* voxels, int64_t n) {
+  return MakeHybridGrid(resolution, static_cast<const RefVoxel*>(voxels), n)->grid_size();
+}
+
+// Round trip through the real HybridGrid: its iterator's (cell index, value) pairs in iteration
+// order; returns the count, writes min(count, capacity) rows of (x, y, z, value).
+int64_t ref_grid3d_iterate(float resolution, const void* voxels, int64_t n, int32_t* out_xyzv,
+                           int64_t capacity) {
+  const auto grid = MakeHybridGrid(resolution, static_cast<const RefVoxel*>(voxels), n);
+  int64_t k = 0;
+  for (auto it = cm::HybridGrid::Iterator(*grid); !it.Done(); it.Next(), ++k) {
+    if (k >= capacity) continue;
+    const Eigen::Array3i c = it.GetCellIndex();
+    out_xyzv[4 * k] = c.x(); out_xyzv[4 * k + 1] = c.y(); out_xyzv[4 * k + 2] = c.z();
+    out_xyzv[4 * k + 3] = it.GetValue();
+  }
+  return k;
+}
+
+// HybridGridBase::GetCellIndex (hybrid_grid.h:428-433) for n points.
+void ref_grid3d_cell_index(float resolution, const float* xyz, int n, int32_t* out_xyz) {
+  const cm::HybridGrid grid(resolution);
+  for (int i = 0; i != n; ++i) {
+    const Eigen::Array3i c =
+        grid.GetCellIndex(Eigen::Vector3f(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
+    out_xyz[3 * i] = c.x(); out_xyz[3 * i + 1] = c.y(); out_xyz[3 * i + 2] = c.z();
+  }
+}
+
+float ref_rt3d_match(float resolution, const void* voxels, int64_t n, const double* init7,
+                     const float* xyz, int npts, double lin, double ang, double tw, double rw,
+                     double* pose7, int64_t* num_candidates) {
+  const auto grid = MakeHybridGrid(resolution, static_cast<const RefVoxel*>(voxels), n);
+  sm::proto::RealTimeCorrelativeScanMatcherOptions options;
+  options.set_linear_search_window(lin);
+  options.set_angular_search_window(ang);
+  options.set_translation_delta_cost_weight(tw);
+  options.set_rotation_delta_cost_weight(rw);
+  const sm::RealTimeCorrelativeScanMatcher3D matcher(options);
+  cartographer::transform::Rigid3d pose = MakeRigid3d(init7);
+  const float score = matcher.Match(MakeRigid3d(init7), MakeCloud(xyz, npts), *grid, &pose);
+  StoreRigid3d(pose, pose7);
+  if (num_candidates) *num_candidates = -1;   // the reference does not count them
+  return score;
+}
+
+void ref_rotational_match(const float* submap_hist, const float* scan_hist, int size,
+                          float initial_angle, const float* angles, int n, float* out) {
+  const Eigen::VectorXf submap = MakeHistogram(submap_hist, size);
+  const sm::RotationalScanMatcher matcher(&submap);
+  const std::vector<float> r = matcher.Match(MakeHistogram(scan_hist, size), initial_angle,
+                                             std::vector<float>(angles, angles + n));
+  std::memcpy(out, r.data(), n * sizeof(float));
+}
+
+// RotationalScanMatcher::ComputeHistogram (rotational_scan_matcher.cc:164-177).
+void ref_compute_histogram(const float* xyz, int n, int histogram_size, float* out) {
+  const Eigen::VectorXf h = sm::RotationalScanMatcher::ComputeHistogram(MakeCloud(xyz, n),
+                                                                        histogram_size);
+  for (int i = 0; i != histogram_size; ++i) out[i] = h[i];
+}
+
+void* ref_fast3d_create(float resolution, const void* voxels, int64_t n, float low_resolution,
+                        const void* low_voxels, int64_t nlow, const float* hist, int nh, int depth,
+                        int full_resolution_depth, double min_rotational_score,
+                        double min_low_resolution_score, double lin_xy, double lin_z, double ang) {
+  auto* f = new RefFast3D;
+  f->grid = MakeHybridGrid(resolution, static_cast<const RefVoxel*>(voxels), n);
+  f->low_grid = MakeHybridGrid(low_resolution, static_cast<const RefVoxel*>(low_voxels), nlow);
+  f->histogram = MakeHistogram(hist, nh);
+  f->options = MakeOptions3D(depth, full_resolution_depth, min_rotational_score,
+                             min_low_resolution_score, lin_xy, lin_z, ang);
+  f->matcher.reset(new sm::FastCorrelativeScanMatcher3D(*f->grid, f->low_grid.get(),
+                                                        &f->histogram, f->options));
+  return f;
+}
+void ref_fast3d_destroy(void* h) { delete static_cast<RefFast3D*>(h); }
+
+namespace {
+const sm::PrecomputationGrid3D& Level(void* h, int depth) {
+  auto* f = static_cast<RefFast3D*>(h);
+  if (!f->stack) f->stack.reset(new sm::PrecomputationGridStack3D(*f->grid, f->options));
+  return f->stack->Get(depth);
+}
+}  // namespace
+
+int64_t ref_fast3d_level_count(void* h, int depth) {
+  int64_t c = 0;
+  for (auto it = sm::PrecomputationGrid3D::Iterator(Level(h, depth)); !it.Done(); it.Next()) ++c;
+  return c;
+}
+void ref_fast3d_level_voxels(void* h, int depth, int* out_xyzv) {   // iteration order
+  int64_t k = 0;
+  for (auto it = sm::PrecomputationGrid3D::Iterator(Level(h, depth)); !it.Done();
+       it.Next(), ++k) {
+    const Eigen::Array3i c = it.GetCellIndex();
+    out_xyzv[4 * k] = c.x(); out_xyzv[4 * k + 1] = c.y(); out_xyzv[4 * k + 2] = c.z();
+    out_xyzv[4 * k + 3] = it.GetValue();
+  }
+}
+
+int ref_fast3d_match(void* h, int full_submap, const double* node7, const double* submap7,
+                     const double* gravity_wxyz, const float* hi, int nhi, const float* lo, int nlo,
+                     const float* hist, int nh, float min_score, double* result10,
+                     int64_t* stats4) {
+  const auto& m = *static_cast<RefFast3D*>(h)->matcher;
+  cm::TrajectoryNode::Data data;
+  data.gravity_alignment =
+      Eigen::Quaterniond(gravity_wxyz[0], gravity_wxyz[1], gravity_wxyz[2], gravity_wxyz[3]);
+  data.high_resolution_point_cloud = MakeCloud(hi, nhi);
+  data.low_resolution_point_cloud = MakeCloud(lo, nlo);
+  data.rotational_scan_matcher_histogram = MakeHistogram(hist, nh);
+  std::unique_ptr<sm::FastCorrelativeScanMatcher3D::Result> r;
+  if (full_submap) {
+    r = m.MatchFullSubmap(Eigen::Quaterniond(node7[3], node7[4], node7[5], node7[6]),
+                          Eigen::Quaterniond(submap7[3], submap7[4], submap7[5], submap7[6]), data,
+                          min_score);
+  } else {
+    r = m.Match(MakeRigid3d(node7), MakeRigid3d(submap7), data, min_score);
+  }
+  if (r != nullptr) {
+    result10[0] = r->score;
+    StoreRigid3d(r->pose_estimate, result10 + 1);
+    result10[8] = r->rotational_score;
+    result10[9] = r->low_resolution_score;
+  }
+  if (stats4) stats4[0] = stats4[1] = stats4[2] = stats4[3] = -1;   // not counted by the reference
+  return r != nullptr ? 1 : 0;
 }
 
 }  // extern "C"
