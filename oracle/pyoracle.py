@@ -127,6 +127,20 @@ def ref_lib():
                                      C.c_double, C.c_float, C.c_float, _f64p, _f32p, C.c_int,
                                      C.c_double, C.c_double, C.c_double, C.c_double, _f64p]
         L.ref_rt2d_match.restype = C.c_double
+        L.ref_grid2d_create.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                        C.c_void_p]
+        L.ref_grid2d_create.restype = C.c_void_p
+        L.ref_grid2d_destroy.argtypes = [C.c_void_p]
+        L.ref_grid2d_get_limits.argtypes = [C.c_void_p, _f64p, _i32p]
+        L.ref_grid2d_download.argtypes = [C.c_void_p, _u16p]
+        L.ref_grid2d_insert.argtypes = [C.c_void_p, _f32p, C.c_void_p, C.c_int, C.c_void_p,
+                                        C.c_int, C.c_double, C.c_double, C.c_int]
+        L.ref_grid2d_crop.argtypes = [C.c_void_p]
+        L.ref_grid2d_set_probability.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float]
+        L.ref_grid2d_get_probability.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.ref_grid2d_get_probability.restype = C.c_float
+        L.ref_map_limits_cell_index.argtypes = [C.c_double, C.c_double, C.c_double, _f32p,
+                                                C.c_int, _i32p]
         # 3D: same layouts as the orc_*3d functions (_lib3d below).
         L.ref_grid3d_size.argtypes = [C.c_float, C.c_void_p, C.c_int64]
         L.ref_grid3d_iterate.argtypes = [C.c_float, C.c_void_p, C.c_int64, _i32p, C.c_int64]
@@ -150,6 +164,65 @@ def ref_lib():
                                        _f32p, C.c_int, _f32p, C.c_int, C.c_float, _f64p, _i64p]
         _ref_lib = L
     return _ref_lib
+
+
+class ReferenceProbabilityGrid:
+    """The reference's own ProbabilityGrid (grid_2d.cc, probability_grid.cc) driven by its own
+    ProbabilityGridRangeDataInserter2D; same surface as cartographer_amd.synth.ProbabilityGrid."""
+
+    def __init__(self, resolution, max_xy, num_x_cells, num_y_cells, cells=None):
+        c = None
+        if cells is not None:
+            self._cells_in = np.ascontiguousarray(cells, np.uint16)
+            c = self._cells_in.ctypes.data
+        self._h = ref_lib().ref_grid2d_create(resolution, max_xy[0], max_xy[1], num_x_cells,
+                                              num_y_cells, c)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            ref_lib().ref_grid2d_destroy(self._h)
+            self._h = None
+
+    @property
+    def limits(self):
+        lim = np.empty(3, np.float64)
+        n = np.empty(2, np.int32)
+        ref_lib().ref_grid2d_get_limits(self._h, lim, n)
+        return dict(resolution=float(lim[0]), max_x=float(lim[1]), max_y=float(lim[2]),
+                    num_x_cells=int(n[0]), num_y_cells=int(n[1]))
+
+    @property
+    def cells(self):
+        lim = self.limits
+        out = np.empty((lim["num_y_cells"], lim["num_x_cells"]), np.uint16)
+        ref_lib().ref_grid2d_download(self._h, out)
+        return out
+
+    def insert(self, origin_xy, returns_xyz, misses_xyz=None, hit_probability=0.7,
+               miss_probability=0.4, insert_free_space=True):
+        origin = np.ascontiguousarray(origin_xy, np.float32)[:2].copy()
+        ret = np.ascontiguousarray(returns_xyz, np.float32).reshape(-1, 3)
+        mis = (np.ascontiguousarray(misses_xyz, np.float32).reshape(-1, 3)
+               if misses_xyz is not None else np.zeros((0, 3), np.float32))
+        ref_lib().ref_grid2d_insert(self._h, origin, ret.ctypes.data, ret.shape[0],
+                                    mis.ctypes.data, mis.shape[0], hit_probability,
+                                    miss_probability, int(insert_free_space))
+
+    def set_probability(self, ix, iy, probability):
+        ref_lib().ref_grid2d_set_probability(self._h, ix, iy, probability)
+
+    def get_probability(self, ix, iy):
+        return float(ref_lib().ref_grid2d_get_probability(self._h, ix, iy))
+
+    def crop(self):
+        ref_lib().ref_grid2d_crop(self._h)
+
+
+def ref_map_limits_cell_index(resolution, max_x, max_y, xy):
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    out = np.empty((xy.shape[0], 2), np.int32)
+    ref_lib().ref_map_limits_cell_index(resolution, max_x, max_y, xy, xy.shape[0], out)
+    return out
 
 
 class ReferenceFastCorrelativeScanMatcher2D:

@@ -10,6 +10,9 @@ class LuaParameterDictionary {
  public:
   double GetDouble(const std::string&) { std::abort(); }
   int GetInt(const std::string&) { std::abort(); }
+  bool GetBool(const std::string&) { std::abort(); }
+  bool HasKey(const std::string&) { std::abort(); }
+  std::string GetString(const std::string&) { std::abort(); }
 };
 }  // namespace common
 }  // namespace cartographer

@@ -4,6 +4,7 @@
 #define ORACLE_REF_SHIMS_TRAJECTORY_NODE_H_
 #include "Eigen/Core"
 #include "Eigen/Geometry"
+#include "cartographer/common/lua_parameter_dictionary.h"   // reaches grid_2d.h this way in the real tree
 #include "cartographer/sensor/point_cloud.h"
 namespace cartographer {
 namespace mapping {

@@ -9,6 +9,7 @@
 #include "Eigen/Geometry"
 #include "cartographer/common/math.h"   // the reference's own (int64, Clamp, ...)
 #include "cartographer/common/port.h"
+#include "cartographer/transform/proto/transform.pb.h"
 #include "cartographer/transform/rigid_transform.h"
 #include "glog/logging.h"
 
@@ -48,6 +49,25 @@ Eigen::Quaternion<T> AngleAxisVectorToRotationQuaternion(
   }
   const Eigen::Matrix<T, 3, 1> quaternion_xyz = scale * angle_axis;
   return Eigen::Quaternion<T>(w, quaternion_xyz.x(), quaternion_xyz.y(), quaternion_xyz.z());
+}
+
+// transform/transform.cc:40-42,94-99 and :117-127: conversions the grid headers call.
+inline Eigen::Vector2d ToEigen(const proto::Vector2d& vector) {
+  return Eigen::Vector2d(vector.x(), vector.y());
+}
+inline proto::Vector2d ToProto(const Eigen::Vector2d& vector) {
+  proto::Vector2d result;
+  result.set_x(vector.x());
+  result.set_y(vector.y());
+  return result;
+}
+inline proto::Rigid3d ToProto(const Rigid3d& rigid) {
+  proto::Rigid3d result;
+  result.t[0] = rigid.translation().x(); result.t[1] = rigid.translation().y();
+  result.t[2] = rigid.translation().z();
+  result.q[0] = rigid.rotation().w(); result.q[1] = rigid.rotation().x();
+  result.q[2] = rigid.rotation().y(); result.q[3] = rigid.rotation().z();
+  return result;
 }
 
 }  // namespace transform

@@ -8,6 +8,7 @@
 #include "cartographer/common/fixed_ratio_sampler.h"
 #include "cartographer/mapping/internal/2d/ray_to_pixel_mask.h"
 #include "cartographer/mapping/2d/probability_grid.h"
+#include "cartographer/mapping/2d/probability_grid_range_data_inserter_2d.h"
 #include "cartographer/mapping/internal/2d/scan_matching/fast_correlative_scan_matcher_2d.h"
 #include "cartographer/mapping/internal/2d/scan_matching/real_time_correlative_scan_matcher_2d.h"
 #include "cartographer/mapping/3d/hybrid_grid.h"
@@ -102,8 +103,41 @@ cartographer::sensor::PointCloud MakeCloud(const float* xyz, int n) {
   return cloud;
 }
 
+// Raw uint16 cells enter the REAL grid classes through their proto constructors
+// (grid_2d.cc:77-98, probability_grid.cc:31-35, tsdf_2d.cc:35-47).
+cm::proto::Grid2D MakeGridProto(const uint16_t* cells, int nx, int ny, double resolution,
+                                double max_x, double max_y, float min_cc, float max_cc) {
+  cm::proto::Grid2D proto;
+  *proto.mutable_limits() = cm::ToProto(
+      cm::MapLimits(resolution, Eigen::Vector2d(max_x, max_y), cm::CellLimits(nx, ny)));
+  proto.mutable_cells()->assign(cells, cells + static_cast<size_t>(nx) * ny);
+  proto.set_min_correspondence_cost(min_cc);
+  proto.set_max_correspondence_cost(max_cc);
+  return proto;
+}
+std::unique_ptr<cm::ProbabilityGrid> MakeProbabilityGrid(const uint16_t* cells, int nx, int ny,
+                                                         double resolution, double max_x,
+                                                         double max_y,
+                                                         cm::ValueConversionTables* tables) {
+  cm::proto::Grid2D proto = MakeGridProto(cells, nx, ny, resolution, max_x, max_y,
+                                          cm::kMinCorrespondenceCost, cm::kMaxCorrespondenceCost);
+  proto.mutable_probability_grid_2d();
+  return std::make_unique<cm::ProbabilityGrid>(proto, tables);
+}
+std::unique_ptr<cm::TSDF2D> MakeTsdf(const uint16_t* cells, const uint16_t* weight_cells, int nx,
+                                     int ny, double resolution, double max_x, double max_y,
+                                     float truncation_distance, float max_weight,
+                                     cm::ValueConversionTables* tables) {
+  cm::proto::Grid2D proto = MakeGridProto(cells, nx, ny, resolution, max_x, max_y,
+                                          -truncation_distance, truncation_distance);
+  proto.mutable_tsdf_2d()->set_truncation_distance(truncation_distance);
+  proto.mutable_tsdf_2d()->set_max_weight(max_weight);
+  proto.mutable_tsdf_2d()->mutable_weight_cells()->assign(
+      weight_cells, weight_cells + static_cast<size_t>(nx) * ny);
+  return std::make_unique<cm::TSDF2D>(proto, tables);
+}
+
 struct RefFast2D {
-  std::vector<uint16_t> cells;
   cm::ValueConversionTables tables;
   std::unique_ptr<cm::ProbabilityGrid> grid;
   std::unique_ptr<sm::FastCorrelativeScanMatcher2D> matcher;
@@ -118,10 +152,7 @@ void* ref_fast2d_create(const uint16_t* cells, int nx, int ny, double resolution
                         double max_y, int depth, double linear_search_window,
                         double angular_search_window) {
   auto* f = new RefFast2D;
-  f->cells.assign(cells, cells + static_cast<size_t>(nx) * ny);
-  f->grid.reset(new cm::ProbabilityGrid(
-      cm::MapLimits(resolution, Eigen::Vector2d(max_x, max_y), cm::CellLimits(nx, ny)),
-      f->cells.data(), &f->tables));
+  f->grid = MakeProbabilityGrid(cells, nx, ny, resolution, max_x, max_y, &f->tables);
   f->options.set_linear_search_window(linear_search_window);
   f->options.set_angular_search_window(angular_search_window);
   f->options.set_branch_and_bound_depth(depth);
@@ -156,10 +187,9 @@ int ref_fast2d_match(void* h, int full_submap, const double* init_xyt, const flo
 // row-major (ny + width - 1) x (nx + width - 1) like the oracle's precompute2d.
 void ref_precompute2d(const uint16_t* cells, int nx, int ny, int width, uint8_t* out) {
   cm::ValueConversionTables tables;
-  const cm::ProbabilityGrid grid(cm::MapLimits(1., Eigen::Vector2d(0., 0.), cm::CellLimits(nx, ny)),
-                                 cells, &tables);
+  const auto grid = MakeProbabilityGrid(cells, nx, ny, 1., 0., 0., &tables);
   std::vector<float> reusable;
-  const sm::PrecomputationGrid2D pre(grid, grid.limits().cell_limits(), width, &reusable);
+  const sm::PrecomputationGrid2D pre(*grid, grid->limits().cell_limits(), width, &reusable);
   const int wx = nx + width - 1;
   for (int y = -width + 1; y < ny; ++y)
     for (int x = -width + 1; x < nx; ++x)
@@ -175,12 +205,12 @@ double ref_rt2d_match(const uint16_t* cells, const uint16_t* weight_cells, int n
                       double ang, double translation_weight, double rotation_weight,
                       double* pose_xyt) {
   cm::ValueConversionTables tables;
-  const cm::MapLimits limits(resolution, Eigen::Vector2d(max_x, max_y), cm::CellLimits(nx, ny));
   std::unique_ptr<cm::Grid2D> grid;
   if (weight_cells) {
-    grid.reset(new cm::TSDF2D(limits, cells, weight_cells, truncation_distance, max_weight, &tables));
+    grid = MakeTsdf(cells, weight_cells, nx, ny, resolution, max_x, max_y, truncation_distance,
+                    max_weight, &tables);
   } else {
-    grid.reset(new cm::ProbabilityGrid(limits, cells, &tables));
+    grid = MakeProbabilityGrid(cells, nx, ny, resolution, max_x, max_y, &tables);
   }
   sm::proto::RealTimeCorrelativeScanMatcherOptions options;
   options.set_linear_search_window(lin);
@@ -196,6 +226,84 @@ double ref_rt2d_match(const uint16_t* cells, const uint16_t* weight_cells, int n
   pose_xyt[1] = pose.translation().y();
   pose_xyt[2] = pose.rotation().angle();
   return score;
+}
+
+}  // extern "C"
+
+// ---- the 2D grid and its range-data inserter: grid_2d.cc, probability_grid.cc and
+// probability_grid_range_data_inserter_2d.cc compiled unmodified (GrowLimits, ApplyLookupTable,
+// FinishUpdate, CastRays over the reference's own RayToPixelMask). ----------------------------
+namespace {
+struct RefGrid2D {
+  cm::ValueConversionTables tables;
+  std::unique_ptr<cm::ProbabilityGrid> grid;
+};
+}  // namespace
+
+extern "C" {
+
+void* ref_grid2d_create(double resolution, double max_x, double max_y, int nx, int ny,
+                        const uint16_t* cells) {
+  auto* g = new RefGrid2D;
+  if (cells) {
+    g->grid = MakeProbabilityGrid(cells, nx, ny, resolution, max_x, max_y, &g->tables);
+  } else {
+    g->grid = std::make_unique<cm::ProbabilityGrid>(
+        cm::MapLimits(resolution, Eigen::Vector2d(max_x, max_y), cm::CellLimits(nx, ny)),
+        &g->tables);
+  }
+  return g;
+}
+void ref_grid2d_destroy(void* h) { delete static_cast<RefGrid2D*>(h); }
+
+// limits4: resolution, max_x, max_y; cells2: num_x_cells, num_y_cells.
+void ref_grid2d_get_limits(void* h, double* limits3, int32_t* cells2) {
+  const cm::MapLimits& l = static_cast<RefGrid2D*>(h)->grid->limits();
+  limits3[0] = l.resolution(); limits3[1] = l.max().x(); limits3[2] = l.max().y();
+  cells2[0] = l.cell_limits().num_x_cells; cells2[1] = l.cell_limits().num_y_cells;
+}
+// Raw cells through ToProto() (grid_2d.cc:167-183).
+void ref_grid2d_download(void* h, uint16_t* out) {
+  const cm::proto::Grid2D proto = static_cast<RefGrid2D*>(h)->grid->ToProto();
+  for (int i = 0; i != proto.cells_size(); ++i) out[i] = static_cast<uint16_t>(proto.cells()[i]);
+}
+// ProbabilityGridRangeDataInserter2D::Insert (:123-132).  origin_xy and the points are in the
+// map frame, like sensor::RangeData.
+void ref_grid2d_insert(void* h, const float* origin_xy, const float* returns_xyz, int num_returns,
+                       const float* misses_xyz, int num_misses, double hit_probability,
+                       double miss_probability, int insert_free_space) {
+  cm::proto::ProbabilityGridRangeDataInserterOptions2D options;
+  options.set_hit_probability(hit_probability);
+  options.set_miss_probability(miss_probability);
+  options.set_insert_free_space(insert_free_space != 0);
+  const cm::ProbabilityGridRangeDataInserter2D inserter(options);
+  cartographer::sensor::RangeData range_data;
+  range_data.origin = Eigen::Vector3f(origin_xy[0], origin_xy[1], 0.f);
+  range_data.returns = MakeCloud(returns_xyz, num_returns);
+  range_data.misses = MakeCloud(misses_xyz, num_misses);
+  inserter.Insert(range_data, static_cast<RefGrid2D*>(h)->grid.get());
+}
+// Replaces the grid by ComputeCroppedGrid() (probability_grid.cc:90-106).
+void ref_grid2d_crop(void* h) {
+  auto* g = static_cast<RefGrid2D*>(h);
+  std::unique_ptr<cm::Grid2D> cropped = g->grid->ComputeCroppedGrid();
+  g->grid.reset(static_cast<cm::ProbabilityGrid*>(cropped.release()));
+}
+// SetProbability (probability_grid.cc:37-46; aborts on a known cell) / GetProbability (:78-83).
+void ref_grid2d_set_probability(void* h, int ix, int iy, float probability) {
+  static_cast<RefGrid2D*>(h)->grid->SetProbability(Eigen::Array2i(ix, iy), probability);
+}
+float ref_grid2d_get_probability(void* h, int ix, int iy) {
+  return static_cast<RefGrid2D*>(h)->grid->GetProbability(Eigen::Array2i(ix, iy));
+}
+// MapLimits::GetCellIndex (map_limits.h:69-76) for n points: out (x, y) pairs.
+void ref_map_limits_cell_index(double resolution, double max_x, double max_y, const float* xy,
+                               int n, int32_t* out_xy) {
+  const cm::MapLimits limits(resolution, Eigen::Vector2d(max_x, max_y), cm::CellLimits(1, 1));
+  for (int i = 0; i != n; ++i) {
+    const Eigen::Array2i c = limits.GetCellIndex(Eigen::Vector2f(xy[2 * i], xy[2 * i + 1]));
+    out_xy[2 * i] = c.x(); out_xy[2 * i + 1] = c.y();
+  }
 }
 
 }  // extern "C"
