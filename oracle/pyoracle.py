@@ -146,6 +146,17 @@ def ref_lib():
         L.ref_grid3d_iterate.argtypes = [C.c_float, C.c_void_p, C.c_int64, _i32p, C.c_int64]
         L.ref_grid3d_iterate.restype = C.c_int64
         L.ref_grid3d_cell_index.argtypes = [C.c_float, _f32p, C.c_int, _i32p]
+        L.ref_hgrid_create.argtypes = [C.c_float]
+        L.ref_hgrid_create.restype = C.c_void_p
+        L.ref_hgrid_destroy.argtypes = [C.c_void_p]
+        L.ref_hgrid_size.argtypes = [C.c_void_p]
+        L.ref_hgrid_set_probability.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float]
+        L.ref_hgrid_get_probability.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.ref_hgrid_get_probability.restype = C.c_float
+        L.ref_hgrid_insert.argtypes = [C.c_void_p, _f32p, _f32p, C.c_int, C.c_double, C.c_double,
+                                       C.c_int]
+        L.ref_hgrid_voxels.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.ref_hgrid_voxels.restype = C.c_int64
         L.ref_rt3d_match.argtypes = [C.c_float, C.c_void_p, C.c_int64, _f64p, _f32p, C.c_int,
                                      C.c_double, C.c_double, C.c_double, C.c_double, _f64p,
                                      C.POINTER(C.c_int64)]
@@ -607,6 +618,48 @@ def ref_grid3d_cell_index(resolution, xyz):
     out = np.empty((n, 3), np.int32)
     ref_lib().ref_grid3d_cell_index(resolution, xyz, n, out)
     return out
+
+
+class ReferenceHybridGrid:
+    """The reference's own HybridGrid (mapping/3d/hybrid_grid.h) driven by its own
+    RangeDataInserter3D; same surface as cartographer_amd.synth.HybridGrid."""
+
+    def __init__(self, resolution):
+        self._h = ref_lib().ref_hgrid_create(resolution)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            ref_lib().ref_hgrid_destroy(self._h)
+            self._h = None
+
+    @property
+    def grid_size(self):
+        return int(ref_lib().ref_hgrid_size(self._h))
+
+    def set_probability(self, index, probability):
+        ref_lib().ref_hgrid_set_probability(self._h, int(index[0]), int(index[1]),
+                                            int(index[2]), probability)
+
+    def get_probability(self, index):
+        return float(ref_lib().ref_hgrid_get_probability(self._h, int(index[0]), int(index[1]),
+                                                         int(index[2])))
+
+    def insert(self, origin_xyz, returns_xyz, hit_probability=0.7, miss_probability=0.4,
+               num_free_space_voxels=5):
+        ret = np.ascontiguousarray(returns_xyz, np.float32).reshape(-1, 3)
+        ref_lib().ref_hgrid_insert(self._h, np.ascontiguousarray(origin_xyz, np.float32), ret,
+                                   ret.shape[0], hit_probability, miss_probability,
+                                   num_free_space_voxels)
+
+    def voxels(self):
+        """Non-zero cells as VOXEL_DTYPE records sorted (z, y, x), like synth.HybridGrid."""
+        n = ref_lib().ref_hgrid_voxels(self._h, None, 0)
+        rows = np.empty((max(n, 1), 4), np.int32)
+        ref_lib().ref_hgrid_voxels(self._h, rows.ctypes.data, rows.shape[0])
+        rows = _sort_zyx(rows[:n])
+        out = np.zeros(n, VOXEL_DTYPE)
+        out["x"], out["y"], out["z"], out["value"] = rows[:, 0], rows[:, 1], rows[:, 2], rows[:, 3]
+        return out
 
 
 def ref_rt3d_match(resolution, voxels, init_pose7, xyz, lin, ang, tw, rw):

@@ -21,9 +21,11 @@ class PointCloud {
   std::vector<RangefinderPoint>::const_iterator begin() const { return points_.begin(); }
   std::vector<RangefinderPoint>::const_iterator end() const { return points_.end(); }
   const std::vector<RangefinderPoint>& points() const { return points_; }
+  const std::vector<float>& intensities() const { return intensities_; }
   void push_back(RangefinderPoint p) { points_.push_back(p); }
  private:
   std::vector<RangefinderPoint> points_;
+  std::vector<float> intensities_;   // always empty here
 };
 inline PointCloud TransformPointCloud(const PointCloud& point_cloud,
                                       const transform::Rigid3f& transform) {

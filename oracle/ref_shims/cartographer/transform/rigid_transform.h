@@ -4,6 +4,7 @@
 #define ORACLE_REF_SHIMS_RIGID_TRANSFORM_H_
 #include "Eigen/Core"
 #include "Eigen/Geometry"
+#include "cartographer/common/lua_parameter_dictionary.h"   // the real header declares FromDictionary
 namespace cartographer {
 namespace transform {
 template <typename FloatType>

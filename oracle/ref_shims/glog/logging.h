@@ -32,6 +32,7 @@ struct Voidify { void operator&(NullStream&) {} };
          : ::ref_shims::Voidify() &                                                    \
                (::ref_shims::CheckFailed(__FILE__, __LINE__, #cond), ::ref_shims::Null())
 #define CHECK(cond) REF_SHIMS_CHECK(cond)
+#define CHECK_NOTNULL(p) REF_SHIMS_CHECK((p) != nullptr)
 #define CHECK_EQ(a, b) REF_SHIMS_CHECK((a) == (b))
 #define CHECK_NE(a, b) REF_SHIMS_CHECK((a) != (b))
 #define CHECK_LE(a, b) REF_SHIMS_CHECK((a) <= (b))

@@ -12,6 +12,7 @@
 #include "cartographer/mapping/internal/2d/scan_matching/fast_correlative_scan_matcher_2d.h"
 #include "cartographer/mapping/internal/2d/scan_matching/real_time_correlative_scan_matcher_2d.h"
 #include "cartographer/mapping/3d/hybrid_grid.h"
+#include "cartographer/mapping/3d/range_data_inserter_3d.h"
 #include "cartographer/mapping/internal/3d/scan_matching/fast_correlative_scan_matcher_3d.h"
 #include "cartographer/mapping/internal/3d/scan_matching/real_time_correlative_scan_matcher_3d.h"
 #include "cartographer/mapping/internal/3d/scan_matching/rotational_scan_matcher.h"
@@ -394,6 +395,43 @@ void ref_grid3d_cell_index(float resolution, const float* xyz, int n, int32_t* o
         grid.GetCellIndex(Eigen::Vector3f(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
     out_xyz[3 * i] = c.x(); out_xyz[3 * i + 1] = c.y(); out_xyz[3 * i + 2] = c.z();
   }
+}
+
+// A mutable HybridGrid driven by the reference's own RangeDataInserter3D
+// (range_data_inserter_3d.cc:27-114).
+void* ref_hgrid_create(float resolution) { return new cm::HybridGrid(resolution); }
+void ref_hgrid_destroy(void* h) { delete static_cast<cm::HybridGrid*>(h); }
+int ref_hgrid_size(void* h) { return static_cast<cm::HybridGrid*>(h)->grid_size(); }
+void ref_hgrid_set_probability(void* h, int x, int y, int z, float probability) {
+  static_cast<cm::HybridGrid*>(h)->SetProbability(Eigen::Array3i(x, y, z), probability);
+}
+float ref_hgrid_get_probability(void* h, int x, int y, int z) {
+  return static_cast<cm::HybridGrid*>(h)->GetProbability(Eigen::Array3i(x, y, z));
+}
+void ref_hgrid_insert(void* h, const float* origin_xyz, const float* returns_xyz, int num_returns,
+                      double hit_probability, double miss_probability,
+                      int num_free_space_voxels) {
+  cm::proto::RangeDataInserterOptions3D options;
+  options.set_hit_probability(hit_probability);
+  options.set_miss_probability(miss_probability);
+  options.set_num_free_space_voxels(num_free_space_voxels);
+  const cm::RangeDataInserter3D inserter(options);
+  cartographer::sensor::RangeData range_data;
+  range_data.origin = Eigen::Vector3f(origin_xyz[0], origin_xyz[1], origin_xyz[2]);
+  range_data.returns = MakeCloud(returns_xyz, num_returns);
+  inserter.Insert(range_data, static_cast<cm::HybridGrid*>(h), nullptr);
+}
+// (x, y, z, value) rows in iteration order; returns the count, writes min(count, capacity).
+int64_t ref_hgrid_voxels(void* h, int32_t* out_xyzv, int64_t capacity) {
+  const auto* grid = static_cast<cm::HybridGrid*>(h);
+  int64_t k = 0;
+  for (auto it = cm::HybridGrid::Iterator(*grid); !it.Done(); it.Next(), ++k) {
+    if (k >= capacity) continue;
+    const Eigen::Array3i c = it.GetCellIndex();
+    out_xyzv[4 * k] = c.x(); out_xyzv[4 * k + 1] = c.y(); out_xyzv[4 * k + 2] = c.z();
+    out_xyzv[4 * k + 3] = it.GetValue();
+  }
+  return k;
 }
 
 float ref_rt3d_match(float resolution, const void* voxels, int64_t n, const double* init7,

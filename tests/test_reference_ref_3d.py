@@ -269,3 +269,80 @@ def test_fast3d_full_submap_synthetic_equals_the_reference(ref, oracle, synth):
         b = rm.match_full_submap(nq, q, q, hi, lo, hist, 0.4)
         _same(a, b)
     assert a["found"]
+
+
+# ----------------------------------------------------------------------------
+# HybridGrid write side + RangeDataInserter3D: the host builder every 3D
+# fixture of the tests and tools comes from, against the reference's own
+# range_data_inserter_3d.cc driving its own HybridGrid.
+# ----------------------------------------------------------------------------
+def _same_grid(host, reference):
+    assert host.grid_size == reference.grid_size
+    np.testing.assert_array_equal(host.voxels(), reference.voxels())
+
+
+def test_range_data_inserter_3d_fixture_equals_the_reference(ref, oracle, synth):
+    """RangeDataInserter3DTest::InsertPointCloud (range_data_inserter_3d_test.cc:28-53): 1 m
+    grid, origin (0, 0, -4), four returns at z = 4, hit 0.7 / miss 0.4, 1000 free-space voxels;
+    inserted twice like its InsertPointCloud / ProbabilityProgression tests."""
+    returns = np.array([[-3, -1, 4], [-2, 0, 4], [-1, 1, 4], [0, 2, 4]], np.float32)
+    origin = np.array([0, 0, -4], np.float32)
+    host, reference = synth.HybridGrid(1.0), oracle.ReferenceHybridGrid(1.0)
+    for _ in range(2):
+        host.insert(origin, returns, 0.7, 0.4, 1000)
+        reference.insert(origin, returns, 0.7, 0.4, 1000)
+        _same_grid(host, reference)
+    assert len(reference.voxels()) > 10
+
+
+@pytest.mark.parametrize("seed,free", [(2, 2), (7, 0), (9, 40), (11, 5)])
+def test_range_data_inserter_3d_scans_equal_the_reference(ref, oracle, synth, seed, free):
+    """Eight scans of a synthetic room (as synth.make_submap_3d inserts them): re-updates through
+    the odds tables, hits before misses, the last `num_free_space_voxels` voxels of each ray,
+    DynamicGrid growth from 128 to 256 voxels."""
+    world = synth.World3D(seed, (15.0, 15.0, 7.5))
+    host, reference = synth.HybridGrid(0.1), oracle.ReferenceHybridGrid(0.1)
+    for p in range(8):
+        pos = world.free_position(seed * 1009 + p, 0.5)
+        yaw = 0.37 * p
+        sensor = world.scan(pos, yaw, 8, 96, seed=seed * 31 + p).astype(np.float64)
+        c, s = math.cos(yaw), math.sin(yaw)
+        in_map = np.stack([pos[0] + c * sensor[:, 0] - s * sensor[:, 1],
+                           pos[1] + s * sensor[:, 0] + c * sensor[:, 1],
+                           pos[2] + sensor[:, 2]], 1).astype(np.float32)
+        hit, miss = (0.55, 0.49) if p % 3 == 2 else (0.7, 0.4)
+        host.insert(pos.astype(np.float32), in_map, hit, miss, free)
+        reference.insert(pos.astype(np.float32), in_map, hit, miss, free)
+        _same_grid(host, reference)
+    assert reference.grid_size == 256
+
+
+def test_make_submap_3d_equals_a_reference_built_one(ref, oracle, synth):
+    """The C4/C5 fixture of tools/time_configs.py at reduced scan density, rebuilt by the
+    reference's inserter from the same scans."""
+    seed, res, size, poses, rings, az, free = 42, 0.1, (15.0, 15.0, 7.5), 8, 8, 128, 2
+    grid, world = synth.make_submap_3d(seed, res, size, poses, rings, az, free)
+    reference = oracle.ReferenceHybridGrid(res)
+    for p in range(poses):
+        pos = world.free_position(seed * 1009 + p, 0.5)
+        yaw = 0.37 * p
+        sensor = world.scan(pos, yaw, rings, az, seed=seed * 31 + p).astype(np.float64)
+        c, s = np.cos(yaw), np.sin(yaw)
+        in_map = np.stack([pos[0] + c * sensor[:, 0] - s * sensor[:, 1],
+                           pos[1] + s * sensor[:, 0] + c * sensor[:, 1],
+                           pos[2] + sensor[:, 2]], 1).astype(np.float32)
+        reference.insert(pos.astype(np.float32), in_map, 0.7, 0.4, free)
+    _same_grid(grid, reference)
+
+
+def test_hybrid_grid_set_get_probability_equal_the_reference(ref, oracle, synth):
+    host, reference = synth.HybridGrid(0.05), oracle.ReferenceHybridGrid(0.05)
+    rng = np.random.default_rng(3)
+    cells = rng.integers(-90, 90, (200, 3))
+    for c in cells:
+        p = float(rng.uniform(0, 1))
+        host.set_probability(c, p)
+        reference.set_probability(c, p)
+    _same_grid(host, reference)
+    for c in list(cells[:20]) + [np.array([1000, 0, 0]), np.array([0, 0, -3000])]:
+        assert np.float32(host.get_probability(c)) == np.float32(reference.get_probability(c))
