@@ -63,6 +63,10 @@ def parse_args():
     ap.add_argument("--min-score", type=float, default=0.6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--concurrency", type=int, default=1,
+                    help="host threads issuing steps concurrently (the reference's thread-pool "
+                         "fan-out over independent searches, constraint_builder_2d.cc:97-111); "
+                         "the C ABI is re-entrant: every call leases its own stream + scratch")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the collectives even with one rank (plumbing test)")
     return ap.parse_args()
@@ -212,8 +216,60 @@ def main():
             dist.all_reduce(best_key, op=dist.ReduceOp.MAX)
         return found, scores, poses, stats
 
-    for _ in range(args.warmup):
-        step()
+    def match_only():
+        return sm.match_full_submap_batch(matchers, cloud, args.min_score)
+
+    def reduce_best(found, scores):
+        best_key.fill_(sharding.pack_best_key(found, scores, rank * n_sub))
+        dist.all_reduce(best_key, op=dist.ReduceOp.MAX)
+
+    def run(num_steps):
+        """Runs `num_steps` steps; returns (candidates, coarse, kernel_ms, device_ms, last)."""
+        acc = [0, 0, 0.0, 0.0]
+        last = None
+
+        def add(result):
+            acc[0] += result[3]["candidates_scored"]
+            acc[1] += result[3]["coarse_candidates"]
+            acc[2] += result[3]["dominant_kernel_ms"]
+            acc[3] += result[3]["device_ms"]
+
+        if args.concurrency <= 1:
+            for _ in range(num_steps):
+                last = step()
+                add(last)
+        elif not use_dist:
+            # Independent searches issued from T host threads, each looping over its share.
+            from concurrent.futures import ThreadPoolExecutor
+            shares = [num_steps // args.concurrency + (1 if i < num_steps % args.concurrency else 0)
+                      for i in range(args.concurrency)]
+
+            def worker(n):
+                out = []
+                for _ in range(n):
+                    out.append(match_only())
+                return out
+            with ThreadPoolExecutor(args.concurrency) as pool:
+                for results in pool.map(worker, shares):
+                    for r in results:
+                        add(r)
+                        last = r
+        else:
+            # Rounds of T concurrent searches, then one all-reduce per step on this thread
+            # (collectives must be issued in the same order on every rank).
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(args.concurrency) as pool:
+                done = 0
+                while done < num_steps:
+                    n = min(args.concurrency, num_steps - done)
+                    for r in [f.result() for f in [pool.submit(match_only) for _ in range(n)]]:
+                        reduce_best(r[0], r[1])
+                        add(r)
+                        last = r
+                    done += n
+        return acc[0], acc[1], acc[2], acc[3], last
+
+    run(args.warmup)
 
     def fence():
         torch.cuda.synchronize()
@@ -223,16 +279,7 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    cand = 0
-    coarse = 0
-    kernel_ms = 0.0
-    device_ms = 0.0
-    for _ in range(args.steps):
-        found, scores, poses, stats = step()
-        cand += stats["candidates_scored"]
-        coarse += stats["coarse_candidates"]
-        kernel_ms += stats["dominant_kernel_ms"]
-        device_ms += stats["device_ms"]
+    cand, coarse, kernel_ms, device_ms, (found, scores, poses, stats) = run(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -278,6 +325,7 @@ def main():
                             f"submap(s) per GPU, depth {args.depth}, full-angle search, "
                             f"min_score {args.min_score}",
                 "submaps_per_gpu": n_sub,
+                "host_threads": args.concurrency,
                 "rotations": scans_per_launch // max(n_sub, 1),
                 "candidates_per_step": cand / args.steps,
                 "lowest_resolution_candidates_per_step": coarse / args.steps,
