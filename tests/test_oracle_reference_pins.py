@@ -407,3 +407,66 @@ def test_fast2d_full_submap_matching(oracle, synth):
         # pose_estimate.theta is initial(0) + orientation, compare as rotations
         near += is_nearly((ex, ey, et), r["pose"], 0.03)
     assert near >= 18
+
+
+# ---- mapping/2d/range_data_inserter_2d_test.cc --------------------------------
+INSERTER_2D_RETURNS = np.array([[-3.5, 0.5, 0], [-2.5, 1.5, 0], [-1.5, 2.5, 0], [-0.5, 3.5, 0]],
+                               np.float32)
+INSERTER_2D_ORIGIN = [-0.5, 0.5]
+U, M, H = "unknown", "miss", "hit"
+INSERTER_2D_STATES = [[U, U, U, U, U],          # expected_states[column][row], :73-81
+                      [U, H, M, M, M],
+                      [U, U, H, M, M],
+                      [U, U, U, H, M],
+                      [U, U, U, U, H]]
+
+
+def check_inserter_2d_fixture(grid):
+    """RangeDataInserterTest2D.InsertPointCloud (:65-105) on any grid with synth.ProbabilityGrid's
+    surface, already holding ONE insertion of the fixture."""
+    lim = grid.limits
+    assert abs(lim["max_x"] - 1.0) < 1e-9 and abs(lim["max_y"] - 5.0) < 1e-9
+    assert (lim["num_x_cells"], lim["num_y_cells"]) == (5, 5)
+    cells = grid.cells
+    for row in range(5):
+        for column in range(5):
+            state = INSERTER_2D_STATES[column][row]          # cell_index = (row, column)
+            if state == U:
+                assert cells[column, row] == 0, (row, column)
+            else:
+                want = 0.4 if state == M else 0.7
+                assert abs(grid.get_probability(row, column) - want) < 1e-4, (row, column)
+
+
+def test_range_data_inserter_2d_insert_point_cloud(synth):
+    grid = synth.ProbabilityGrid(1.0, (1.0, 5.0), 5, 5)
+    grid.insert(INSERTER_2D_ORIGIN, INSERTER_2D_RETURNS, None, 0.7, 0.4, True)
+    check_inserter_2d_fixture(grid)
+
+
+def test_range_data_inserter_2d_probability_progression(synth):
+    """:107-134: after 1001 insertions the hit cell saturates at kMaxProbability and the miss
+    cell at kMinProbability (1e-3)."""
+    grid = synth.ProbabilityGrid(1.0, (1.0, 5.0), 5, 5)
+    grid.insert(INSERTER_2D_ORIGIN, INSERTER_2D_RETURNS, None, 0.7, 0.4, True)
+    # GetCellIndex(-3.5, 0.5) = (lround((5 - .5) / 1 - .5), lround((1 + 3.5) / 1 - .5)) = (4, 4);
+    # GetCellIndex(-2.5, 0.5) = (4, 3)
+    assert abs(grid.get_probability(4, 4) - 0.7) < 1e-4
+    assert abs(grid.get_probability(4, 3) - 0.4) < 1e-4
+    for _ in range(1000):
+        grid.insert(INSERTER_2D_ORIGIN, INSERTER_2D_RETURNS, None, 0.7, 0.4, True)
+    assert abs(grid.get_probability(4, 4) - 0.9) < 1e-3
+    assert abs(grid.get_probability(4, 3) - 0.1) < 1e-3
+
+
+# ---- mapping/2d/map_limits_test.cc, xy_index_test.cc: the index conventions -----
+def test_map_limits_cell_index_convention(synth):
+    """MapLimits(42, max (3, 0), CellLimits(2, 3)) (map_limits_test.cc:53-66): x indexes
+    columns counted from max.y downwards, y indexes rows from max.x (map_limits.h:69-76)."""
+    grid = synth.ProbabilityGrid(42.0, (3.0, 0.0), 2, 3)
+    lim = grid.limits
+    assert (lim["num_x_cells"], lim["num_y_cells"], lim["resolution"]) == (2, 3, 42.0)
+    assert (lim["max_x"], lim["max_y"]) == (3.0, 0.0)
+    grid.set_probability(1, 2, 0.8)                       # the last cell, flat index 2 * 2 + 1
+    assert grid.cells.shape == (3, 2) and grid.cells[2, 1] != 0
+    assert (grid.cells != 0).sum() == 1

@@ -190,3 +190,39 @@ def test_hybrid_grid_get_cell_index(synth):
              ((5.5, 13.5, 3.5), (3, 7, 2))]
     for p, want in cases:
         assert tuple(g.get_cell_index(np.array(p, np.float32))) == want
+
+
+# ---- mapping/3d/range_data_inserter_3d_test.cc ----------------------------------
+INSERTER_3D_RETURNS = np.array([[-3, -1, 4], [-2, 0, 4], [-1, 1, 4], [0, 2, 4]], np.float32)
+INSERTER_3D_ORIGIN = np.array([0, 0, -4], np.float32)
+
+
+def _known(grid, x, y, z):
+    v = grid.voxels()
+    return bool(((v["x"] == x) & (v["y"] == y) & (v["z"] == z)).any())
+
+
+def test_range_data_inserter_3d_insert_point_cloud(synth):
+    """:97-114: 1 m grid, hit 0.7 / miss 0.4, 1000 free-space voxels."""
+    g = synth.HybridGrid(1.0)
+    g.insert(INSERTER_3D_ORIGIN, INSERTER_3D_RETURNS, 0.7, 0.4, 1000)
+    for z in (-4, -3, -2):
+        assert abs(g.get_probability((0, 0, z)) - 0.4) < 1e-4
+    for x in range(-4, 5):
+        for y in range(-4, 5):
+            if x < -3 or x > 0 or y != x + 2:
+                assert not _known(g, x, y, 4)
+            else:
+                assert abs(g.get_probability((x, y, 4)) - 0.7) < 1e-4
+
+
+def test_range_data_inserter_3d_probability_progression(synth):
+    """:138-157: 1001 insertions saturate hit and miss cells at the probability bounds."""
+    g = synth.HybridGrid(1.0)
+    g.insert(INSERTER_3D_ORIGIN, INSERTER_3D_RETURNS, 0.7, 0.4, 1000)
+    assert abs(g.get_probability((-2, 0, 4)) - 0.7) < 1e-4
+    assert abs(g.get_probability((-2, 0, 3)) - 0.4) < 1e-4
+    for _ in range(1000):
+        g.insert(INSERTER_3D_ORIGIN, INSERTER_3D_RETURNS, 0.7, 0.4, 1000)
+    assert abs(g.get_probability((-2, 0, 4)) - 0.9) < 1e-3
+    assert abs(g.get_probability((-2, 0, 3)) - 0.1) < 1e-3
