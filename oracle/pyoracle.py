@@ -141,6 +141,13 @@ def ref_lib():
         L.ref_grid2d_get_probability.restype = C.c_float
         L.ref_map_limits_cell_index.argtypes = [C.c_double, C.c_double, C.c_double, _f32p,
                                                 C.c_int, _i32p]
+        L.ref_tsdf_create.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                      C.c_float, C.c_float]
+        L.ref_tsdf_create.restype = C.c_void_p
+        L.ref_tsdf_destroy.argtypes = [C.c_void_p]
+        L.ref_tsdf_get_limits.argtypes = [C.c_void_p, _f64p, _i32p]
+        L.ref_tsdf_download.argtypes = [C.c_void_p, _u16p, _u16p]
+        L.ref_tsdf_insert.argtypes = [C.c_void_p, _f32p, _f32p, C.c_int, _f64p]
         # 3D: same layouts as the orc_*3d functions (_lib3d below).
         L.ref_grid3d_size.argtypes = [C.c_float, C.c_void_p, C.c_int64]
         L.ref_grid3d_iterate.argtypes = [C.c_float, C.c_void_p, C.c_int64, _i32p, C.c_int64]
@@ -227,6 +234,51 @@ class ReferenceProbabilityGrid:
 
     def crop(self):
         ref_lib().ref_grid2d_crop(self._h)
+
+
+class ReferenceTSDF2D:
+    """The reference's own TSDF2D (tsdf_2d.cc) filled by its own TSDFRangeDataInserter2D
+    (tsdf_range_data_inserter_2d.cc + normal_estimation_2d.cc)."""
+
+    def __init__(self, resolution, max_xy, num_x_cells, num_y_cells, truncation_distance,
+                 max_weight):
+        self.truncation_distance, self.max_weight = truncation_distance, max_weight
+        self._h = ref_lib().ref_tsdf_create(resolution, max_xy[0], max_xy[1], num_x_cells,
+                                            num_y_cells, truncation_distance, max_weight)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            ref_lib().ref_tsdf_destroy(self._h)
+            self._h = None
+
+    @property
+    def limits(self):
+        lim = np.empty(3, np.float64)
+        n = np.empty(2, np.int32)
+        ref_lib().ref_tsdf_get_limits(self._h, lim, n)
+        return dict(resolution=float(lim[0]), max_x=float(lim[1]), max_y=float(lim[2]),
+                    num_x_cells=int(n[0]), num_y_cells=int(n[1]))
+
+    def planes(self):
+        """(tsd cells, weight cells), uint16 [ny, nx] each."""
+        lim = self.limits
+        shape = (lim["num_y_cells"], lim["num_x_cells"])
+        tsd, wgt = np.empty(shape, np.uint16), np.empty(shape, np.uint16)
+        ref_lib().ref_tsdf_download(self._h, tsd, wgt)
+        return tsd, wgt
+
+    def insert(self, origin_xyz, returns_xyz, truncation_distance, maximum_weight,
+               update_free_space, num_normal_samples, sample_radius,
+               project_sdf_distance_to_scan_normal, update_weight_range_exponent,
+               angle_kernel_bandwidth, distance_kernel_bandwidth):
+        ret = np.ascontiguousarray(returns_xyz, np.float32).reshape(-1, 3)
+        options = np.array([truncation_distance, maximum_weight, float(update_free_space),
+                            num_normal_samples, sample_radius,
+                            float(project_sdf_distance_to_scan_normal),
+                            update_weight_range_exponent, angle_kernel_bandwidth,
+                            distance_kernel_bandwidth], np.float64)
+        ref_lib().ref_tsdf_insert(self._h, np.ascontiguousarray(origin_xyz, np.float32), ret,
+                                  ret.shape[0], options)
 
 
 def ref_map_limits_cell_index(resolution, max_x, max_y, xy):

@@ -3,6 +3,7 @@
 #ifndef ORACLE_REF_SHIMS_LUA_PARAMETER_DICTIONARY_H_
 #define ORACLE_REF_SHIMS_LUA_PARAMETER_DICTIONARY_H_
 #include <cstdlib>
+#include <memory>
 #include <string>
 namespace cartographer {
 namespace common {
@@ -13,6 +14,7 @@ class LuaParameterDictionary {
   bool GetBool(const std::string&) { std::abort(); }
   bool HasKey(const std::string&) { std::abort(); }
   std::string GetString(const std::string&) { std::abort(); }
+  std::unique_ptr<LuaParameterDictionary> GetDictionary(const std::string&) { std::abort(); }
 };
 }  // namespace common
 }  // namespace cartographer

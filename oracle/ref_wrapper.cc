@@ -18,6 +18,7 @@
 #include "cartographer/mapping/internal/3d/scan_matching/rotational_scan_matcher.h"
 #include "cartographer/mapping/internal/2d/tsd_value_converter.h"
 #include "cartographer/mapping/internal/2d/tsdf_2d.h"
+#include "cartographer/mapping/internal/2d/tsdf_range_data_inserter_2d.h"
 #include "cartographer/mapping/probability_values.h"
 #include "cartographer/mapping/value_conversion_tables.h"
 
@@ -305,6 +306,62 @@ void ref_map_limits_cell_index(double resolution, double max_x, double max_y, co
     const Eigen::Array2i c = limits.GetCellIndex(Eigen::Vector2f(xy[2 * i], xy[2 * i + 1]));
     out_xy[2 * i] = c.x(); out_xy[2 * i + 1] = c.y();
   }
+}
+
+}  // extern "C"
+
+// ---- TSDF2D filled by the reference's own TSDFRangeDataInserter2D (tsdf_range_data_inserter_2d.cc,
+// normal_estimation_2d.cc): what the reference's TSDF test fixtures are made with. --------------
+namespace {
+struct RefTsdf {
+  cm::ValueConversionTables tables;
+  std::unique_ptr<cm::TSDF2D> grid;
+};
+}  // namespace
+
+extern "C" {
+
+void* ref_tsdf_create(double resolution, double max_x, double max_y, int nx, int ny,
+                      float truncation_distance, float max_weight) {
+  auto* g = new RefTsdf;
+  g->grid = std::make_unique<cm::TSDF2D>(
+      cm::MapLimits(resolution, Eigen::Vector2d(max_x, max_y), cm::CellLimits(nx, ny)),
+      truncation_distance, max_weight, &g->tables);
+  return g;
+}
+void ref_tsdf_destroy(void* h) { delete static_cast<RefTsdf*>(h); }
+void ref_tsdf_get_limits(void* h, double* limits3, int32_t* cells2) {
+  const cm::MapLimits& l = static_cast<RefTsdf*>(h)->grid->limits();
+  limits3[0] = l.resolution(); limits3[1] = l.max().x(); limits3[2] = l.max().y();
+  cells2[0] = l.cell_limits().num_x_cells; cells2[1] = l.cell_limits().num_y_cells;
+}
+void ref_tsdf_download(void* h, uint16_t* tsd_cells, uint16_t* weight_cells) {
+  const cm::proto::Grid2D proto = static_cast<RefTsdf*>(h)->grid->ToProto();
+  for (int i = 0; i != proto.cells_size(); ++i) {
+    tsd_cells[i] = static_cast<uint16_t>(proto.cells()[i]);
+    weight_cells[i] = static_cast<uint16_t>(proto.tsdf_2d().weight_cells()[i]);
+  }
+}
+// options8: truncation_distance, maximum_weight, update_free_space, num_normal_samples,
+// sample_radius, project_sdf_distance_to_scan_normal, update_weight_range_exponent,
+// angle kernel bandwidth, distance kernel bandwidth (9 values).
+void ref_tsdf_insert(void* h, const float* origin_xyz, const float* returns_xyz, int num_returns,
+                     const double* options9) {
+  cm::proto::TSDFRangeDataInserterOptions2D o;
+  o.set_truncation_distance(options9[0]);
+  o.set_maximum_weight(options9[1]);
+  o.set_update_free_space(options9[2] != 0.);
+  o.mutable_normal_estimation_options()->set_num_normal_samples(static_cast<int>(options9[3]));
+  o.mutable_normal_estimation_options()->set_sample_radius(options9[4]);
+  o.set_project_sdf_distance_to_scan_normal(options9[5] != 0.);
+  o.set_update_weight_range_exponent(static_cast<int>(options9[6]));
+  o.set_update_weight_angle_scan_normal_to_ray_kernel_bandwidth(options9[7]);
+  o.set_update_weight_distance_cell_to_hit_kernel_bandwidth(options9[8]);
+  const cm::TSDFRangeDataInserter2D inserter(o);
+  cartographer::sensor::RangeData range_data;
+  range_data.origin = Eigen::Vector3f(origin_xyz[0], origin_xyz[1], origin_xyz[2]);
+  range_data.returns = MakeCloud(returns_xyz, num_returns);
+  inserter.Insert(range_data, static_cast<RefTsdf*>(h)->grid.get());
 }
 
 }  // extern "C"
