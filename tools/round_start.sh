@@ -19,7 +19,7 @@ for B in 16 64; do               # ConstraintBuilder batches (BASELINE config[2]
   echo "== bench --submaps $B =="
   timeout 300 python bench.py --submaps $B --steps 10 --warmup 3 --no-cpu-baseline 2> "$OUT/bench_b$B.err" | tail -1 | tee "$OUT/bench_b$B.json"
 done
-echo "== other configs ==";      timeout 600 python tools/time_configs.py c1 c1b c4 c5 2>&1 | tee "$OUT/time_configs.txt"
+echo "== other configs ==";      timeout 600 python tools/time_configs.py c1 c1b c4 c5 --cpu 2>&1 | tee "$OUT/time_configs.txt"
 echo "== hbm copy ==";           timeout 120 python tools/hbm_copy_bench.py 4 2>&1 | tee "$OUT/hbm_copy.txt"
 echo "== kernel trace: single match and batch 64 =="
 bash tools/profile_bench.sh round_start > "$OUT/profile_single.txt" 2>&1

@@ -57,6 +57,15 @@ def c1(cpu):
         t = time.perf_counter() - t0
         print(f"   oracle 1 thread: {t * 1e3:.2f} ms -> {st['candidates_scored'] / t:.3e} cand/s; "
               f"score equal: {np.float64(ref['score']) == score}")
+        if orc.ref_lib() is not None:        # the reference's own source, oracle/_ref
+            t0 = time.perf_counter()
+            rr = orc.ref_rt2d_match(cells, lim["resolution"], lim["max_x"], lim["max_y"],
+                                    [init.x, init.y, init.theta], scan, 0.3, math.radians(7.0),
+                                    0.1, 0.1)
+            t = time.perf_counter() - t0
+            print(f"   reference's own real_time_correlative_scan_matcher_2d.cc, 1 thread: "
+                  f"{t * 1e3:.2f} ms -> {st['candidates_scored'] / t:.3e} cand/s; score equal: "
+                  f"{rr['score'] == score}")
 
 
 def c1b(cpu):
@@ -141,6 +150,17 @@ def c5(cpu):
         print(f"   oracle 1 thread: {t * 1e3:.1f} ms; found {ref['found']} score "
               f"{ref.get('score')} (gpu equal: "
               f"{got is not None and np.float32(got['score']) == np.float32(ref['score'])})")
+        if orc.ref_lib() is not None:        # the reference's own source, oracle/_ref
+            rm = orc.ReferenceFastCorrelativeScanMatcher3D(0.1, vox, 0.45, low_vox, hist, 8, 3,
+                                                           0.77, 0.35, 5.0, 1.0,
+                                                           math.radians(15.0))
+            t0 = time.perf_counter()
+            rr = rm.match(list(node.translation) + list(node.rotation), [0, 0, 0, 1, 0, 0, 0],
+                          [1, 0, 0, 0], hi, lo, scan_hist, 0.2)
+            t = time.perf_counter() - t0
+            print(f"   reference's own fast_correlative_scan_matcher_3d.cc, 1 thread: "
+                  f"{t * 1e3:.1f} ms; found {rr['found']} score {rr.get('score')} (gpu equal: "
+                  f"{got is not None and np.float32(got['score']) == np.float32(rr['score'])})")
 
 
 if __name__ == "__main__":
