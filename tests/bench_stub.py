@@ -1,0 +1,53 @@
+"""Runs bench.main() with the device calls replaced by stubs (CPU only): used by
+tests/test_bench_contract.py, in-process and as `python tests/bench_stub.py <bench flags>` for the
+two-rank gloo run.  The stubs stand in for torch.cuda, the RCCL backend (gloo instead) and the
+three scan_matching entry points bench.py calls; everything else is the real script.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CALLS = []
+
+
+def install(setattr_=setattr):
+    import torch
+    import torch.distributed as dist
+    from cartographer_amd import scan_matching as sm
+    setattr_(torch.cuda, "is_available", lambda: True)
+    setattr_(torch.cuda, "set_device", lambda d: None)
+    setattr_(torch.cuda, "synchronize", lambda *a, **k: None)
+    zeros, tensor = torch.zeros, torch.tensor
+    strip = lambda k: {key: v for key, v in k.items() if key != "device"}     # noqa: E731
+    setattr_(torch, "zeros", lambda *a, **k: zeros(*a, **strip(k)))
+    setattr_(torch, "tensor", lambda *a, **k: tensor(*a, **strip(k)))
+    init = dist.init_process_group
+    setattr_(dist, "init_process_group", lambda backend, device_id=None: init("gloo"))
+
+    class FakeMatcher:
+        def __init__(self, grid, depth, device=0):
+            pass
+
+    def fake_batch(matchers, cloud, min_score):
+        CALLS.append(len(matchers))
+        n = len(matchers)
+        return (np.ones(n, np.int32), np.full(n, 0.7, np.float32), np.zeros((n, 3)),
+                dict(candidates_scored=1000 * n, coarse_candidates=900 * n,
+                     dominant_kernel_ms=0.03, device_ms=0.17, num_scans=50 * n,
+                     nodes_expanded=30))
+    setattr_(sm, "FastCorrelativeScanMatcher2D", FakeMatcher)
+    setattr_(sm, "PointCloudOnDevice", lambda scan, device=0: scan)
+    setattr_(sm, "match_full_submap_batch", fake_batch)
+
+
+if __name__ == "__main__":
+    install()
+    import bench
+    sys.argv = ["bench.py"] + sys.argv[1:]
+    bench.main()
+    print(f"# rank {os.environ.get('RANK', '0')} issued {len(CALLS)} matches", file=sys.stderr)

@@ -18,37 +18,13 @@ REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 @pytest.fixture()
 def stubbed_bench(monkeypatch):
-    import torch
-    import torch.distributed as dist
-    from cartographer_amd import scan_matching as sm
-    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
-    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
-    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
-    zeros, tensor = torch.zeros, torch.tensor
-    strip = lambda k: {key: v for key, v in k.items() if key != "device"}     # noqa: E731
-    monkeypatch.setattr(torch, "zeros", lambda *a, **k: zeros(*a, **strip(k)))
-    monkeypatch.setattr(torch, "tensor", lambda *a, **k: tensor(*a, **strip(k)))
-    init = dist.init_process_group
-    monkeypatch.setattr(dist, "init_process_group",
-                        lambda backend, device_id=None: init("gloo", rank=0, world_size=1))
+    import bench_stub
+    bench_stub.install(monkeypatch.setattr)
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
     monkeypatch.setenv("MASTER_PORT", "29541")
-    calls = []
-
-    class FakeMatcher:
-        def __init__(self, grid, depth, device=0):
-            pass
-
-    def fake_batch(matchers, cloud, min_score):
-        calls.append(len(matchers))
-        n = len(matchers)
-        return (np.ones(n, np.int32), np.full(n, 0.7, np.float32), np.zeros((n, 3)),
-                dict(candidates_scored=1000 * n, coarse_candidates=900 * n,
-                     dominant_kernel_ms=0.03, device_ms=0.17, num_scans=50 * n,
-                     nodes_expanded=30))
-    monkeypatch.setattr(sm, "FastCorrelativeScanMatcher2D", FakeMatcher)
-    monkeypatch.setattr(sm, "PointCloudOnDevice", lambda scan, device=0: scan)
-    monkeypatch.setattr(sm, "match_full_submap_batch", fake_batch)
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    calls = bench_stub.CALLS
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     monkeypatch.syspath_prepend(root)
     import bench
@@ -104,3 +80,33 @@ def test_bench_cpu_baseline_leg(stubbed_bench, monkeypatch):
         assert key in base, key
     assert base["kind"] in ("reference", "port") and base["unit"] == "candidates/s"
     assert base["value"] > 0 and base["cores"] >= 1
+
+
+def test_bench_two_ranks_gloo():
+    """The N > 1 path as the driver launches it (one process per rank, RANK / WORLD_SIZE /
+    MASTER_* from the environment), on two CPU processes over gloo: only rank 0 prints, ONE line,
+    `n_gpus` 2, the work of both ranks summed, one all-reduce per step on every rank."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(root, "tests", "bench_stub.py"), "--gpus", "2",
+             "--steps", "5", "--warmup", "2", "--grid", "120"],
+            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    # The collective backend may print its own banner through C stdio (gloo here, RCCL on the
+    # box); bench.py drains that first, so the JSON is the LAST line and the only JSON line.
+    lines0 = [l for l in outs[0][0].splitlines() if l.strip()]
+    assert [l.startswith("{") for l in lines0].count(True) == 1 and lines0[-1].startswith("{")
+    assert not any(l.startswith("{") for l in outs[1][0].splitlines())    # rank 0 only
+    out = json.loads(lines0[-1])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2
+    assert out["config"]["candidates_per_step"] == 1000.0       # per rank (weak scaling)
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 * 5 - 2 * 5000.0) < 1e-6   # both ranks
+    assert "cpu_baseline" not in out                            # N = 1 only
+    for _, err in outs:
+        assert "issued 7 matches" in err
