@@ -1,7 +1,11 @@
-"""oracle/_ref: the REFERENCE'S OWN code -- probability_values.cc, value_conversion_tables.cc and
-ray_to_pixel_mask.cc compiled unmodified from /root/reference (oracle/Makefile `ref`,
-oracle/ref_shims/README.md) -- against the oracle's restatement of the value tables (SURVEY §8
-a25) and the range-data inserter restatement's ray mask (§8 f3).  Everything here is exact.
+"""oracle/_ref: the REFERENCE'S OWN code compiled unmodified from /root/reference (oracle/Makefile
+`ref`, oracle/ref_shims/README.md) against the oracle's restatement.  This file: the value /
+odds / conversion tables, the TSDF value converter (a8'), the ray mask (f3), the
+constraint front's sampler (f2), and the 2D matchers themselves -- precomputation grids, the fast
+matcher on the bench workload / random cases / all-ties grids, the real-time matcher on
+probability grids and TSDFs (a1-a15).  The 2D grid + inserter, the 3D path and the stored results
+are in test_reference_ref_grid.py, test_reference_ref_3d.py and test_golden_reference.py.
+Everything here is exact.
 
 Skipped where neither /root/reference nor a prebuilt oracle/_ref/libref.so exists.
 """
