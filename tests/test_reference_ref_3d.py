@@ -346,3 +346,26 @@ def test_hybrid_grid_set_get_probability_equal_the_reference(ref, oracle, synth)
     _same_grid(host, reference)
     for c in list(cells[:20]) + [np.array([1000, 0, 0]), np.array([0, 0, -3000])]:
         assert np.float32(host.get_probability(c)) == np.float32(reference.get_probability(c))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_insertions_3d_equal_the_reference(ref, oracle, synth, seed):
+    """Seeded random range data into the voxel grid: random resolutions, origins, ranges that
+    force DynamicGrid growth, duplicate returns, zero-length rays, 0 .. 60 free-space voxels."""
+    rng = np.random.default_rng(800 + seed)
+    res = float(rng.choice([0.05, 0.1, 0.45, 1.0]))
+    host, reference = synth.HybridGrid(res), oracle.ReferenceHybridGrid(res)
+    for _ in range(8):
+        origin = rng.uniform(-20, 20, 3).astype(np.float32) * np.float32(res)
+        n = int(rng.integers(0, 60))
+        d = rng.normal(size=(n, 3))
+        d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-9)
+        rad = rng.uniform(0, 90 * res, (n, 1)) * (rng.uniform(size=(n, 1)) > 0.1)
+        pts = (origin + d * rad).astype(np.float32)
+        if n > 3:
+            pts[1] = pts[0]
+        hit, miss = float(rng.uniform(0.51, 0.95)), float(rng.uniform(0.05, 0.49))
+        free = int(rng.choice([0, 1, 2, 10, 60]))
+        host.insert(origin, pts, hit, miss, free)
+        reference.insert(origin, pts, hit, miss, free)
+        _same_grid(host, reference)

@@ -176,3 +176,32 @@ def test_get_cell_index_equals_the_reference(ref, oracle):
         rnd = lambda v: (np.sign(v) * np.floor(np.abs(v) + 0.5)).astype(np.int64)   # noqa: E731
         np.testing.assert_array_equal(got[:, 0], rnd(vx))
         np.testing.assert_array_equal(got[:, 1], rnd(vy))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_insertions_equal_the_reference(ref, oracle, synth, seed):
+    """Seeded random range data: grids from 1x1 cells, origins inside and outside the grid,
+    returns and misses at random ranges (the grid grows in every direction), duplicate points,
+    zero-length rays, random hit / miss probabilities, free-space insertion on and off."""
+    rng = np.random.default_rng(500 + seed)
+    res = float(rng.choice([0.05, 0.1, 0.25, 1.0]))
+    nx, ny = int(rng.integers(1, 12)), int(rng.integers(1, 12))
+    corner = (float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3)))
+    host = synth.ProbabilityGrid(res, corner, nx, ny)
+    reference = oracle.ReferenceProbabilityGrid(res, corner, nx, ny)
+    for _ in range(10):
+        origin = [corner[0] - rng.uniform(-2, 6) * res * 3, corner[1] - rng.uniform(-2, 6) * res * 3]
+        n = int(rng.integers(0, 40))
+        ang = rng.uniform(0, 2 * math.pi, n)
+        rad = rng.uniform(0, 40 * res, n) * (rng.uniform(size=n) > 0.1)      # some zero-length rays
+        pts = np.zeros((n, 3), np.float32)
+        pts[:, 0] = origin[0] + rad * np.cos(ang)
+        pts[:, 1] = origin[1] + rad * np.sin(ang)
+        if n > 3:
+            pts[1] = pts[0]                                                  # a duplicate return
+        split = int(rng.integers(0, n + 1))
+        hit, miss = float(rng.uniform(0.51, 0.95)), float(rng.uniform(0.05, 0.49))
+        free = bool(rng.integers(0, 2))
+        host.insert(origin, pts[:split], pts[split:], hit, miss, free)
+        reference.insert(origin, pts[:split], pts[split:], hit, miss, free)
+        _assert_same(host, reference)
