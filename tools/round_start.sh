@@ -10,6 +10,7 @@ cd "$REPO"
 export PYTHONUNBUFFERED=1
 
 echo "== gpu tests ==";          timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee "$OUT/pytest_gpu.txt"
+echo "== device vs oracle, random odd-shaped problems ==";  timeout 300 python tools/gpu_fuzz.py 150 1 2>&1 | tail -20 | tee "$OUT/gpu_fuzz.txt"
 echo "== bench (default) ==";    timeout 300 python bench.py 2> "$OUT/bench_default.err" | tail -1 | tee "$OUT/bench_default.json"
 for T in 2 4 8; do               # host threads issuing independent searches (bench.py --concurrency)
   echo "== bench --concurrency $T =="
