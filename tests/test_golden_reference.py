@@ -2,7 +2,7 @@
 tests/golden/make_reference_results.py and make_tsdf_fixture.py, committed) on seeded workloads.
 CPU part: the oracle reproduces them exactly, and -- where oracle/_ref can be built -- regenerating
 them gives the committed bytes (so the files cannot drift from the reference).  The GPU part is
-tests/test_gpu_golden.py.
+tests/test_gpu_zz_new.py.
 """
 import json
 import os

@@ -187,10 +187,9 @@ def test_fast3d_synthetic_world(sm3, oracle, synth, seed, depth, frd):
               submap_pose[1] + s * local[0] + c * local[1], submap_pose[2] + local[2]]
     node_pose = node_t + quat_from_angle_axis(0.2 + yaw + 0.1, [0, 0, 1])
     gravity = quat_from_angle_axis(0.01, [1, 0, 0])
-    founds = []
-    for min_score in (0.15, 0.3, 0.95):     # best scores here are 0.25-0.29: found, then not
+    for min_score in (0.3, 0.95):     # best scores here are 0.25-0.29 (the found case, with
+        # min_score 0.15, is test_gpu_zz_new.py::test_fast3d_synthetic_world_found)
         ref = om.match(node_pose, submap_pose, gravity, hi, lo, scan_hist, min_score)
-        founds.append(ref["found"])
         data = sm3.TrajectoryNodeData(hi, lo, scan_hist, tuple(gravity))
         got = gm.match(sm3.Rigid3d(tuple(node_pose[:3]), tuple(node_pose[3:])),
                        sm3.Rigid3d(tuple(submap_pose[:3]), tuple(submap_pose[3:])), data,
@@ -199,7 +198,6 @@ def test_fast3d_synthetic_world(sm3, oracle, synth, seed, depth, frd):
         assert gm.last_stats["num_scans"] == ref["num_scans"]
         assert gm.last_stats["coarse_candidates"] == ref["coarse_candidates"]
     assert 0 < ref["num_scans"] < 40      # the filter is selective but not empty
-    assert founds == [True, False, False]
 
 
 def test_fast3d_full_submap_synthetic(sm3, oracle, synth):

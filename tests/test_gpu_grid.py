@@ -44,41 +44,6 @@ def test_reference_inserter_fixture(g2, synth):
     assert (dev.cells != 0).sum() > 7
 
 
-class _DeviceGridView:
-    """Gives the reference-test checker of test_oracle_reference_pins the surface it reads."""
-
-    def __init__(self, dev, oracle):
-        self._dev = dev
-        self._v2c = oracle.value_tables()[1]        # kValueToCorrespondenceCost
-
-    limits = property(lambda self: self._dev.limits)
-    cells = property(lambda self: self._dev.cells)
-
-    def get_probability(self, ix, iy):              # probability_grid.cc:78-83
-        return float(np.float32(1) - self._v2c[self._dev.cells[iy, ix]])
-
-
-def test_reference_range_data_inserter_2d_test(g2, synth, oracle):
-    """RangeDataInserterTest2D.InsertPointCloud / ProbabilityProgression
-    (mapping/2d/range_data_inserter_2d_test.cc:65-134): the reference test's own known answers,
-    on the device inserter -- a 5x5 grid of 1 m cells."""
-    from test_oracle_reference_pins import (INSERTER_2D_ORIGIN, INSERTER_2D_RETURNS,
-                                            check_inserter_2d_fixture)
-    dev = g2.ProbabilityGridOnDevice(1.0, (1.0, 5.0), 5, 5)
-    host = synth.ProbabilityGrid(1.0, (1.0, 5.0), 5, 5)
-    dev.insert(INSERTER_2D_ORIGIN, INSERTER_2D_RETURNS, None, 0.7, 0.4, True)
-    host.insert(INSERTER_2D_ORIGIN, INSERTER_2D_RETURNS, None, 0.7, 0.4, True)
-    view = _DeviceGridView(dev, oracle)
-    check_inserter_2d_fixture(view)
-    _assert_same(dev, host)
-    for _ in range(1000):
-        dev.insert(INSERTER_2D_ORIGIN, INSERTER_2D_RETURNS, None, 0.7, 0.4, True)
-        host.insert(INSERTER_2D_ORIGIN, INSERTER_2D_RETURNS, None, 0.7, 0.4, True)
-    assert abs(view.get_probability(4, 4) - 0.9) < 1e-3       # the hit at (-3.5, 0.5)
-    assert abs(view.get_probability(4, 3) - 0.1) < 1e-3       # the miss at (-2.5, 0.5)
-    _assert_same(dev, host)
-
-
 @pytest.mark.parametrize("seed,free_space", [(3, True), (9, True), (4, False)])
 def test_insert_parity_with_growth(g2, synth, seed, free_space):
     """Twelve scans of a synthetic room inserted into a grid that starts as 16x16 cells: the

@@ -1,0 +1,216 @@
+"""GPU tests added after the last run on hardware; the file sorts last so that `pytest -x` reaches
+them only after every test that has already passed on an MI355X.
+
+Part 1 -- the device against tests/golden/reference_results.json: what the REFERENCE'S OWN scan-matcher
+sources returned (oracle/_ref, generated in the build container by
+tests/golden/make_reference_results.py) on the seeded workloads of tests/golden/workloads.py --
+the bench workload, BASELINE config C1, the reference test's TSDF fixture, a 3D real-time match
+and a 3D loop-closure match.  Scores bit-equal; 2D poses to 1e-12 (composed in f64 on the host),
+3D poses exact.
+
+Part 2 -- known answers of the reference's own tests on the device: RangeDataInserterTest2D on the
+device inserter, and the found case of the synthetic 3D loop-closure world.
+"""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+if GOLDEN not in sys.path:
+    sys.path.insert(0, GOLDEN)
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(GOLDEN, "reference_results.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def sm():
+    from cartographer_amd import _lib, scan_matching
+    assert _lib.lib().cmx_device_count() >= 1, "no HIP device: these tests need the GPU"
+    return scan_matching
+
+
+def _pose2(p):
+    return [p.x, p.y, p.theta]
+
+
+def test_fast2d_bench_workload_equals_the_reference(sm, synth, golden):
+    import workloads as w
+    b = w.fast2d_bench(synth)
+    lim = b["lim"]
+    grid = sm.Grid2D(b["cells"], lim["resolution"], lim["max_x"], lim["max_y"])
+    m = sm.FastCorrelativeScanMatcher2D(grid, b["depth"])
+    found, score, pose = m.match_full_submap(b["scan"], 0.6)
+    g = golden["fast2d_full_submap"]
+    assert found and np.float32(score) == np.float32(g["score"])
+    np.testing.assert_allclose(_pose2(pose), g["pose"], rtol=0, atol=1e-12)
+    found, score, pose = m.match(sm.Rigid2d(*b["init"]), b["scan"], 0.55)
+    g = golden["fast2d_windowed"]
+    assert found and np.float32(score) == np.float32(g["score"])
+    np.testing.assert_allclose(_pose2(pose), g["pose"], rtol=0, atol=1e-12)
+    assert not m.match(sm.Rigid2d(*b["init"]), b["scan"], 0.99)[0]
+
+
+def test_rt2d_c1_equals_the_reference(sm, synth, golden):
+    import workloads as w
+    c = w.rt2d_c1(synth)
+    lim = c["lim"]
+    grid = sm.Grid2D(c["cells"], lim["resolution"], lim["max_x"], lim["max_y"])
+    m = sm.RealTimeCorrelativeScanMatcher2D(c["lin"], c["ang"], c["tw"], c["rw"])
+    score, pose = m.match(sm.Rigid2d(*c["init"]), c["scan"], grid)
+    assert score == golden["rt2d_c1"]["score"]
+    np.testing.assert_allclose(_pose2(pose), golden["rt2d_c1"]["pose"], rtol=0, atol=1e-12)
+
+
+def test_rt2d_tsdf_fixture_equals_the_reference(sm, golden):
+    """The TSDF the reference's own TSDFRangeDataInserter2D built for its real-time matcher test
+    (tests/golden/rt2d_tsdf_fixture.npz), matched with that test's options."""
+    import workloads as w
+    t = w.rt2d_tsdf()
+    grid = sm.TSDF2D(t["tsd"], t["weight"], t["res"], t["max_x"], t["max_y"], t["truncation"],
+                     t["max_weight"])
+    m = sm.RealTimeCorrelativeScanMatcher2D(t["lin"], t["ang"], t["tw"], t["rw"])
+    score, pose = m.match(sm.Rigid2d(*t["init"]), t["cloud"], grid)
+    assert score == golden["rt2d_tsdf"]["score"]
+    np.testing.assert_allclose(_pose2(pose), golden["rt2d_tsdf"]["pose"], rtol=0, atol=1e-12)
+    # ScorePerfectHighResolutionCandidateTSDF (..._2d_test.cc:143-160): a zero window scores the
+    # one candidate (0, 0, 0)
+    m0 = sm.RealTimeCorrelativeScanMatcher2D(0.0, 0.0, 0.0, 0.0)
+    score0, _ = m0.match(sm.Rigid2d(0.0, 0.0, 0.0), t["cloud"], grid)
+    assert 0.95 < score0 and abs(score0 - 1.0) < 1e-1
+
+
+def test_rt3d_equals_the_reference(synth, golden):
+    import workloads as w
+    from cartographer_amd import scan_matching_3d as sm3
+    d = w.rt3d(synth)
+    m = sm3.RealTimeCorrelativeScanMatcher3D(d["lin"], d["ang"], d["tw"], d["rw"])
+    score, pose = m.match(sm3.Rigid3d(tuple(d["init"][:3]), tuple(d["init"][3:])), d["cloud"],
+                          d["res"], d["vox"])
+    assert np.float32(score) == np.float32(golden["rt3d"]["score"])
+    np.testing.assert_array_equal(list(pose.translation) + list(pose.rotation),
+                                  golden["rt3d"]["pose"])
+
+
+def test_fast3d_equals_the_reference(synth, golden):
+    import workloads as w
+    from cartographer_amd import scan_matching_3d as sm3
+    f = w.fast3d(synth)
+    o = f["options"]
+    m = sm3.FastCorrelativeScanMatcher3D(
+        f["res"], f["vox"], f["grid_size"], f["low_res"], f["low_vox"], f["hist"],
+        branch_and_bound_depth=o["depth"], full_resolution_depth=o["frd"],
+        min_rotational_score=o["min_rot"], min_low_resolution_score=o["min_low"],
+        linear_xy_search_window=o["lin_xy"], linear_z_search_window=o["lin_z"],
+        angular_search_window=o["ang"])
+    data = sm3.TrajectoryNodeData(f["hi"], f["lo"], f["scan_hist"], tuple(f["gravity"]))
+    got = m.match(sm3.Rigid3d(tuple(f["node_pose"][:3]), tuple(f["node_pose"][3:])),
+                  sm3.Rigid3d(tuple(f["submap_pose"][:3]), tuple(f["submap_pose"][3:])), data,
+                  f["min_score"])
+    g = golden["fast3d"]
+    assert got is not None and g["found"]
+    for key in ("score", "rotational_score", "low_resolution_score"):
+        assert np.float32(got[key]) == np.float32(g[key]), key
+    p = got["pose_estimate"]
+    np.testing.assert_array_equal(list(p.translation) + list(p.rotation), g["pose"])
+
+
+# ---------------------------------------------------------------------------- part 2
+@pytest.fixture(scope="module")
+def g2():
+    from cartographer_amd import _lib, grid_2d
+    assert _lib.lib().cmx_device_count() >= 1, "no HIP device: these tests need the GPU"
+    return grid_2d
+
+
+def _assert_same(dev, host):
+    assert dev.limits == host.limits
+    np.testing.assert_array_equal(dev.cells, host.cells)
+
+
+class _DeviceGridView:
+    """Gives the reference-test checker of test_oracle_reference_pins the surface it reads."""
+
+    def __init__(self, dev, oracle):
+        self._dev = dev
+        self._v2c = oracle.value_tables()[1]        # kValueToCorrespondenceCost
+
+    limits = property(lambda self: self._dev.limits)
+    cells = property(lambda self: self._dev.cells)
+
+    def get_probability(self, ix, iy):              # probability_grid.cc:78-83
+        return float(np.float32(1) - self._v2c[self._dev.cells[iy, ix]])
+
+
+def test_reference_range_data_inserter_2d_test(g2, synth, oracle):
+    """RangeDataInserterTest2D.InsertPointCloud / ProbabilityProgression
+    (mapping/2d/range_data_inserter_2d_test.cc:65-134): the reference test's own known answers,
+    on the device inserter -- a 5x5 grid of 1 m cells."""
+    from test_oracle_reference_pins import (INSERTER_2D_ORIGIN, INSERTER_2D_RETURNS,
+                                            check_inserter_2d_fixture)
+    dev = g2.ProbabilityGridOnDevice(1.0, (1.0, 5.0), 5, 5)
+    host = synth.ProbabilityGrid(1.0, (1.0, 5.0), 5, 5)
+    dev.insert(INSERTER_2D_ORIGIN, INSERTER_2D_RETURNS, None, 0.7, 0.4, True)
+    host.insert(INSERTER_2D_ORIGIN, INSERTER_2D_RETURNS, None, 0.7, 0.4, True)
+    view = _DeviceGridView(dev, oracle)
+    check_inserter_2d_fixture(view)
+    _assert_same(dev, host)
+    for _ in range(1000):
+        dev.insert(INSERTER_2D_ORIGIN, INSERTER_2D_RETURNS, None, 0.7, 0.4, True)
+        host.insert(INSERTER_2D_ORIGIN, INSERTER_2D_RETURNS, None, 0.7, 0.4, True)
+    assert abs(view.get_probability(4, 4) - 0.9) < 1e-3       # the hit at (-3.5, 0.5)
+    assert abs(view.get_probability(4, 3) - 0.1) < 1e-3       # the miss at (-2.5, 0.5)
+    _assert_same(dev, host)
+
+
+@pytest.mark.parametrize("seed,depth,frd", [(21, 6, 3), (22, 5, 2)])
+def test_fast3d_synthetic_world_found(oracle, synth, seed, depth, frd):
+    """tests/test_gpu_3d.py::test_fast3d_synthetic_world with a threshold below the best score
+    (0.25-0.29): the match is FOUND through the selective yaw filter, with non-identity node /
+    submap poses and a tilted gravity alignment, so score, rotational / low-resolution scores and
+    the composed pose are all compared."""
+    from cartographer_amd import scan_matching_3d as sm3
+    from test_oracle_reference_pins_3d import quat_from_angle_axis
+    grid, world = synth.make_submap_3d(seed, 0.1, (9.0, 8.0, 4.0), 5, 10, 128)
+    low, _ = synth.make_submap_3d(seed, 0.45, (9.0, 8.0, 4.0), 5, 10, 128)
+    vox, low_vox = grid.voxels(), low.voxels()
+    rng = np.random.default_rng(seed)
+    hist = rng.uniform(0.0, 1.0, 120).astype(np.float32)
+    hist[10:14] += 6.0
+    scan_hist = np.roll(hist, -19).copy()
+    pos = world.free_position(seed + 3, 0.6)
+    yaw = 0.4
+    hi = world.scan(pos, yaw, 8, 96, seed=1)
+    lo = hi[::7].copy()
+    opt = dict(branch_and_bound_depth=depth, full_resolution_depth=frd, min_rotational_score=0.9,
+               min_low_resolution_score=0.3, linear_xy_search_window=1.5,
+               linear_z_search_window=0.5, angular_search_window=math.radians(20.0))
+    om = oracle.FastCorrelativeScanMatcher3D(0.1, vox, 0.45, low_vox, hist, depth, frd, 0.9, 0.3,
+                                             1.5, 0.5, math.radians(20.0))
+    gm = sm3.FastCorrelativeScanMatcher3D(0.1, vox, grid.grid_size, 0.45, low_vox, hist, **opt)
+    submap_pose = [0.3, -0.2, 0.1] + quat_from_angle_axis(0.2, [0, 0, 1])
+    c, s = math.cos(0.2), math.sin(0.2)
+    local = np.array([pos[0] + 0.35, pos[1] - 0.25, pos[2] + 0.1])
+    node_t = [submap_pose[0] + c * local[0] - s * local[1],
+              submap_pose[1] + s * local[0] + c * local[1], submap_pose[2] + local[2]]
+    node_pose = node_t + quat_from_angle_axis(0.2 + yaw + 0.1, [0, 0, 1])
+    gravity = quat_from_angle_axis(0.01, [1, 0, 0])
+    ref = om.match(node_pose, submap_pose, gravity, hi, lo, scan_hist, 0.15)
+    got = gm.match(sm3.Rigid3d(tuple(node_pose[:3]), tuple(node_pose[3:])),
+                   sm3.Rigid3d(tuple(submap_pose[:3]), tuple(submap_pose[3:])),
+                   sm3.TrajectoryNodeData(hi, lo, scan_hist, tuple(gravity)), 0.15)
+    assert ref["found"] and got is not None
+    for key in ("score", "rotational_score", "low_resolution_score"):
+        assert np.float32(got[key]) == np.float32(ref[key]), key
+    p = got["pose_estimate"]
+    np.testing.assert_array_equal(list(p.translation) + list(p.rotation), ref["pose"])
+    assert gm.last_stats["num_scans"] == ref["num_scans"]
