@@ -221,3 +221,151 @@ class ConstraintBuilder2D:
                 item.submap_id, item.node_id, constraint_transform,
                 self.options.loop_closure_translation_weight,
                 self.options.loop_closure_rotation_weight, score)
+
+
+# ---------------------------------------------------------------------------- 3D
+@dataclass
+class ConstraintBuilderOptions3D:
+    """constraints::proto::ConstraintBuilderOptions with its 3D matcher options; defaults of
+    configuration_files/pose_graph.lua."""
+    sampling_ratio: float = 0.3
+    max_constraint_distance: float = 15.0
+    min_score: float = 0.55
+    global_localization_min_score: float = 0.6
+    loop_closure_translation_weight: float = 1.1e4
+    loop_closure_rotation_weight: float = 1e5
+    branch_and_bound_depth: int = 8
+    full_resolution_depth: int = 3
+    min_rotational_score: float = 0.77
+    min_low_resolution_score: float = 0.55
+    linear_xy_search_window: float = 5.0
+    linear_z_search_window: float = 1.0
+    angular_search_window: float = math.radians(15.0)
+
+
+@dataclass
+class Submap3D:
+    """What ConstraintBuilder3D reads of a finished submap (constraint_builder_3d.cc:176-186):
+    both hybrid grids (flattened voxel lists, see scan_matching_3d) and the histogram."""
+    high_resolution: float
+    high_resolution_voxels: np.ndarray
+    grid_size: int
+    low_resolution: float
+    low_resolution_voxels: np.ndarray
+    rotational_scan_matcher_histogram: np.ndarray
+
+
+@dataclass
+class Constraint3D:
+    submap_id: SubmapId
+    node_id: NodeId
+    zbar_ij: object                       # scan_matching_3d.Rigid3d, submap i <- node j
+    translation_weight: float
+    rotation_weight: float
+    score: float
+    rotational_score: float
+    low_resolution_score: float
+    tag: str = "INTER_SUBMAP"
+
+
+class ConstraintBuilder3D:
+    """Host-side mirror of ``constraints::ConstraintBuilder3D``
+    (``cartographer/mapping/internal/constraints/constraint_builder_3d.{h,cc}``): the distance
+    filter on the GLOBAL poses (:84-87), the per-submap ``FixedRatioSampler`` (:88-93), one
+    matcher per ``SubmapId`` resident in HBM until ``DeleteScanMatcher``, ``Match`` /
+    ``MatchFullSubmap`` with the two thresholds (:218-255), results in the order the pairs were
+    added (``RunWhenDoneCallback``).  Pairs run one after the other on the device today (the 3D
+    matcher has no batch entry point yet); the Ceres refinement (:263-276) is not
+    built, ``refine`` may stand in for it.
+    """
+
+    def __init__(self, options: ConstraintBuilderOptions3D, device: int = 0,
+                 refine: Optional[Callable] = None):
+        self.options = options
+        self.device = device
+        self.refine = refine
+        self._scan_matchers = {}
+        self._samplers: Dict[SubmapId, FixedRatioSampler] = {}
+        self._constraints: List[Optional[Constraint3D]] = []
+        self._pending = []
+        self._num_finished_nodes = 0
+        self.score_histogram: List[float] = []
+
+    def maybe_add_constraint(self, submap_id, submap: Submap3D, node_id, constant_data,
+                             global_node_pose, global_submap_pose) -> None:
+        delta = (np.asarray(global_node_pose.translation, np.float64) -
+                 np.asarray(global_submap_pose.translation, np.float64))
+        # Eigen's fixed-size norm: sqrt((x*x + y*y) + z*z) in f64
+        if math.sqrt((delta[0] * delta[0] + delta[1] * delta[1]) + delta[2] * delta[2]) > \
+                self.options.max_constraint_distance:
+            return
+        sampler = self._samplers.setdefault(submap_id,
+                                            FixedRatioSampler(self.options.sampling_ratio))
+        if not sampler.pulse():
+            return
+        self._enqueue(submap_id, submap, node_id, constant_data, False, global_node_pose,
+                      global_submap_pose)
+
+    def maybe_add_global_constraint(self, submap_id, submap: Submap3D, node_id, constant_data,
+                                    global_node_rotation, global_submap_rotation) -> None:
+        self._enqueue(submap_id, submap, node_id, constant_data, True, global_node_rotation,
+                      global_submap_rotation)
+
+    def notify_end_of_node(self) -> None:
+        self._flush()
+        self._num_finished_nodes += 1
+
+    def when_done(self, callback) -> None:
+        self._flush()
+        result = [c for c in self._constraints if c is not None]
+        self._constraints = []
+        callback(result)
+
+    def get_num_finished_nodes(self) -> int:
+        return self._num_finished_nodes
+
+    def delete_scan_matcher(self, submap_id) -> None:
+        self._scan_matchers.pop(submap_id, None)
+        self._samplers.pop(submap_id, None)
+
+    def num_scan_matchers(self) -> int:
+        return len(self._scan_matchers)
+
+    def _enqueue(self, submap_id, submap, node_id, constant_data, full, node, sub):
+        from .scan_matching_3d import FastCorrelativeScanMatcher3D
+        self._constraints.append(None)
+        if submap_id not in self._scan_matchers:          # DispatchScanMatcherConstruction
+            o = self.options
+            self._scan_matchers[submap_id] = FastCorrelativeScanMatcher3D(
+                submap.high_resolution, submap.high_resolution_voxels, submap.grid_size,
+                submap.low_resolution, submap.low_resolution_voxels,
+                submap.rotational_scan_matcher_histogram,
+                branch_and_bound_depth=o.branch_and_bound_depth,
+                full_resolution_depth=o.full_resolution_depth,
+                min_rotational_score=o.min_rotational_score,
+                min_low_resolution_score=o.min_low_resolution_score,
+                linear_xy_search_window=o.linear_xy_search_window,
+                linear_z_search_window=o.linear_z_search_window,
+                angular_search_window=o.angular_search_window, device=self.device)
+        self._pending.append((len(self._constraints) - 1, submap_id, node_id, constant_data, full,
+                              node, sub))
+
+    def _flush(self):
+        pending, self._pending = self._pending, []
+        for slot, submap_id, node_id, constant_data, full, node, sub in pending:
+            matcher = self._scan_matchers[submap_id]
+            if full:
+                result = matcher.match_full_submap(node, sub, constant_data,
+                                                   self.options.global_localization_min_score)
+            else:
+                result = matcher.match(node, sub, constant_data, self.options.min_score)
+            if result is None:
+                continue                                   # `return;` at :232 / :253
+            self.score_histogram.append(result["score"])
+            pose = result["pose_estimate"]                 # already submap i <- node j
+            if self.refine is not None:
+                pose = self.refine(pose, constant_data)
+            self._constraints[slot] = Constraint3D(
+                submap_id, node_id, pose, self.options.loop_closure_translation_weight,
+                self.options.loop_closure_rotation_weight, result["score"],
+                result["rotational_score"], result["low_resolution_score"])

@@ -80,3 +80,76 @@ class ConstraintBuilder2DRef:
     def delete_scan_matcher(self, submap_id):
         self.matchers.pop(submap_id, None)
         self.samplers.pop(submap_id, None)
+
+
+class ConstraintBuilder3DRef:
+    """CPU restatement of constraints::ConstraintBuilder3D
+    (cartographer/mapping/internal/constraints/constraint_builder_3d.cc:79-147 filters and
+    queueing, :199-283 ComputeConstraint without the Ceres refinement of :263-276), one pair at a
+    time through the oracle's FastCorrelativeScanMatcher3D.  Poses are 7-vectors
+    (t xyz, q wxyz); `submap` = (resolution, voxels, low_resolution, low_voxels, histogram);
+    `data` = (gravity wxyz, high-resolution cloud, low-resolution cloud, histogram)."""
+
+    def __init__(self, sampling_ratio, max_constraint_distance, min_score,
+                 global_localization_min_score, depth, full_resolution_depth,
+                 min_rotational_score, min_low_resolution_score, lin_xy, lin_z, ang):
+        self.o = dict(sampling_ratio=sampling_ratio, max_constraint_distance=max_constraint_distance,
+                      min_score=min_score,
+                      global_localization_min_score=global_localization_min_score)
+        self.matcher_args = (depth, full_resolution_depth, min_rotational_score,
+                             min_low_resolution_score, lin_xy, lin_z, ang)
+        self.matchers = {}
+        self.samplers = {}
+        self.constraints = []
+        self.finished = 0
+
+    def _matcher(self, submap_id, submap):
+        if submap_id not in self.matchers:
+            res, vox, low_res, low_vox, hist = submap
+            self.matchers[submap_id] = orc.FastCorrelativeScanMatcher3D(
+                res, vox, low_res, low_vox, hist, *self.matcher_args)
+        return self.matchers[submap_id]
+
+    def maybe_add_constraint(self, submap_id, submap, node_id, data, node_pose, submap_pose):
+        d = [node_pose[k] - submap_pose[k] for k in range(3)]
+        if math.sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) > \
+                self.o["max_constraint_distance"]:
+            return
+        st = self.samplers.setdefault(submap_id, [0, 0])
+        st[0] += 1
+        if not (st[1] / st[0] < self.o["sampling_ratio"]):
+            return
+        st[1] += 1
+        self._compute(submap_id, submap, node_id, data, False, node_pose, submap_pose)
+
+    def maybe_add_global_constraint(self, submap_id, submap, node_id, data, node_q, submap_q):
+        self._compute(submap_id, submap, node_id, data, True, [0, 0, 0] + list(node_q),
+                      [0, 0, 0] + list(submap_q))
+
+    def _compute(self, submap_id, submap, node_id, data, full, node, sub):
+        m = self._matcher(submap_id, submap)
+        gravity, hi, lo, hist = data
+        if full:
+            r = m.match_full_submap(node[3:], sub[3:], gravity, hi, lo, hist,
+                                    self.o["global_localization_min_score"])
+        else:
+            r = m.match(node, sub, gravity, hi, lo, hist, self.o["min_score"])
+        if not r["found"]:
+            self.constraints.append(None)
+            return
+        self.constraints.append(dict(submap_id=submap_id, node_id=node_id,
+                                     zbar_ij=list(r["pose"]), score=r["score"],
+                                     rotational_score=r["rotational_score"],
+                                     low_resolution_score=r["low_resolution_score"]))
+
+    def notify_end_of_node(self):
+        self.finished += 1
+
+    def when_done(self):
+        out = [c for c in self.constraints if c is not None]
+        self.constraints = []
+        return out
+
+    def delete_scan_matcher(self, submap_id):
+        self.matchers.pop(submap_id, None)
+        self.samplers.pop(submap_id, None)

@@ -197,3 +197,63 @@ def test_reference_finds_constraints_device():
             assert c.tag == "INTER_SUBMAP"
             assert np.float32(c.score) == np.float32(w["score"])
             assert (c.zbar_ij.x, c.zbar_ij.y, c.zbar_ij.theta) == w["zbar_ij"]
+
+
+# ---------------------------------------------------------------------------- 3D front
+def test_calls_back_without_work_3d():
+    # ConstraintBuilder3DTest.CallsBack (constraint_builder_3d_test.cc:61-72).  No device needed.
+    from cartographer_amd import constraint_builder as cb
+    builder = cb.ConstraintBuilder3D(cb.ConstraintBuilderOptions3D())
+    assert builder.get_num_finished_nodes() == 0
+    builder.notify_end_of_node()
+    seen = []
+    builder.when_done(seen.append)
+    assert seen == [[]] and builder.get_num_finished_nodes() == 1
+
+
+def test_distance_and_sampling_filters_without_device_3d():
+    # MaybeAddConstraint returns before touching the matcher when the GLOBAL poses are too far
+    # apart (constraint_builder_3d.cc:84-87) or the sampler says no (:88-93).
+    from cartographer_amd import constraint_builder as cb
+    from cartographer_amd.scan_matching_3d import Rigid3d
+    opts = cb.ConstraintBuilderOptions3D(sampling_ratio=0.0, max_constraint_distance=1.0)
+    builder = cb.ConstraintBuilder3D(opts)
+    builder.maybe_add_constraint((0, 0), None, (0, 0), None, Rigid3d((3.0, 4.0, 0.0)), Rigid3d())
+    builder.maybe_add_constraint((0, 0), None, (0, 1), None, Rigid3d((0.1, 0.0, 0.0)), Rigid3d())
+    builder.notify_end_of_node()
+    seen = []
+    builder.when_done(seen.append)
+    assert seen == [[]] and builder.num_scan_matchers() == 0
+
+
+def test_reference_finds_constraints_restatement_3d():
+    """ConstraintBuilder3DTest.FindsConstraints (constraint_builder_3d_test.cc:74-119): empty
+    hybrid grids at 0.1 m, a one-point cloud, zero histograms of size 3, sampling ratio 1 and all
+    thresholds 0 -> every search "finds" (score 0.1 > 0): two rounds of 2 x MaybeAddConstraint +
+    1 x MaybeAddGlobalConstraint give 3 constraints each."""
+    from cartographer_amd._lib import VOXEL_DTYPE
+    from oracle import constraint_builder_ref as ref
+    empty = np.zeros(0, VOXEL_DTYPE)
+    hist = np.zeros(3, np.float32)
+    point = np.array([[0.1, 0.2, 0.3]], np.float32)
+    submap = (0.1, empty, 0.1, empty, hist)
+    data = ([1, 0, 0, 0], point, point, hist)
+    identity = [0, 0, 0, 1, 0, 0, 0]
+    # pose_graph.lua defaults for the matcher: depth 8, full-resolution depth 3, 5 m / 1 m / 15 deg
+    b = ref.ConstraintBuilder3DRef(1.0, 15.0, 0.0, 0.0, 8, 3, 0.0, 0.0, 5.0, 1.0, math.radians(15.0))
+    expected_nodes = 0
+    for _ in range(2):
+        assert b.finished == expected_nodes
+        for _ in range(2):
+            b.maybe_add_constraint((0, 1), submap, (0, 0), data, identity, identity)
+        b.maybe_add_global_constraint((0, 1), submap, (0, 0), data, [1, 0, 0, 0], [1, 0, 0, 0])
+        b.notify_end_of_node()
+        b.notify_end_of_node()
+        expected_nodes += 2
+        assert b.finished == expected_nodes
+        got = b.when_done()
+        assert len(got) == 3
+        assert all(np.float32(c["score"]) == np.float32(0.1) for c in got)
+        assert all(c["rotational_score"] == 1.0 for c in got)      # zero histograms (:126-128)
+        b.delete_scan_matcher((0, 1))
+        assert not b.matchers

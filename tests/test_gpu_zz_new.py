@@ -214,3 +214,76 @@ def test_fast3d_synthetic_world_found(oracle, synth, seed, depth, frd):
     p = got["pose_estimate"]
     np.testing.assert_array_equal(list(p.translation) + list(p.rotation), ref["pose"])
     assert gm.last_stats["num_scans"] == ref["num_scans"]
+
+
+def test_constraint_lists_3d_match_restatement(oracle, synth):
+    """ConstraintBuilder3D mirror (cartographer_amd/constraint_builder.py) against the restatement
+    of constraint_builder_3d.cc over the oracle: two submaps, three nodes, windowed and
+    full-submap pairs, a pair beyond max_constraint_distance, a sampler that passes every other
+    call, a trimmed submap -- identical constraint lists (ids, order, scores, transforms)."""
+    from cartographer_amd import constraint_builder as cb, scan_matching_3d as sm3
+    from oracle import constraint_builder_ref as ref
+    from test_oracle_reference_pins_3d import quat_from_angle_axis
+    opt = dict(depth=5, frd=2, min_rot=0.0, min_low=0.2, lin_xy=1.0, lin_z=0.4,
+               ang=math.radians(10.0))
+    builder = cb.ConstraintBuilder3D(cb.ConstraintBuilderOptions3D(
+        sampling_ratio=0.5, max_constraint_distance=6.0, min_score=0.12,
+        global_localization_min_score=0.12, branch_and_bound_depth=opt["depth"],
+        full_resolution_depth=opt["frd"], min_rotational_score=opt["min_rot"],
+        min_low_resolution_score=opt["min_low"], linear_xy_search_window=opt["lin_xy"],
+        linear_z_search_window=opt["lin_z"], angular_search_window=opt["ang"]))
+    restated = ref.ConstraintBuilder3DRef(0.5, 6.0, 0.12, 0.12, opt["depth"], opt["frd"],
+                                          opt["min_rot"], opt["min_low"], opt["lin_xy"],
+                                          opt["lin_z"], opt["ang"])
+    hist = np.zeros(16, np.float32)                 # zero histograms: every yaw passes
+    submaps, worlds = {}, {}
+    for k in range(2):
+        grid, world = synth.make_submap_3d(70 + k, 0.2, (8.0, 8.0, 3.0), 4, 8, 96)
+        vox = grid.voxels()
+        submaps[(0, k)] = (cb.Submap3D(0.2, vox, grid.grid_size, 0.2, vox, hist),
+                           (0.2, vox, 0.2, vox, hist))
+        worlds[(0, k)] = world
+    for node in range(3):
+        world = worlds[(0, node % 2)]
+        pos = world.free_position(200 + node, 0.6)
+        hi = world.scan(pos, 0.1 * node, 6, 64, seed=node)
+        lo = hi[::5].copy()
+        gravity = quat_from_angle_axis(0.01, [1, 0, 0])
+        data = sm3.TrajectoryNodeData(hi, lo, hist, tuple(gravity))
+        data_ref = (gravity, hi, lo, hist)
+        node_pose = list(pos + np.array([0.3, -0.2, 0.1])) + \
+            quat_from_angle_axis(0.1 * node + 0.05, [0, 0, 1])
+        for sid, (submap, submap_ref) in submaps.items():
+            submap_pose = [0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0]
+            if sid[1] != node % 2 and node == 2:
+                submap_pose = [40.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0]      # too far: filtered out
+            for _ in range(2):                                           # sampler: every other call
+                builder.maybe_add_constraint(
+                    sid, submap, (0, node), data,
+                    sm3.Rigid3d(tuple(node_pose[:3]), tuple(node_pose[3:])),
+                    sm3.Rigid3d(tuple(submap_pose[:3]), tuple(submap_pose[3:])))
+                restated.maybe_add_constraint(sid, submap_ref, (0, node), data_ref, node_pose,
+                                              submap_pose)
+            if sid[1] == node % 2:
+                builder.maybe_add_global_constraint(sid, submap, (0, node), data, node_pose[3:],
+                                                    [1, 0, 0, 0])
+                restated.maybe_add_global_constraint(sid, submap_ref, (0, node), data_ref,
+                                                     node_pose[3:], [1, 0, 0, 0])
+        builder.notify_end_of_node()
+        restated.notify_end_of_node()
+        if node == 1:                                                     # trimmed submap
+            builder.delete_scan_matcher((0, 1))
+            restated.delete_scan_matcher((0, 1))
+            assert builder.num_scan_matchers() == 1
+    got = []
+    builder.when_done(got.extend)
+    want = restated.when_done()
+    assert builder.get_num_finished_nodes() == restated.finished == 3
+    assert len(want) >= 3                                                 # not vacuous
+    assert [(c.submap_id, c.node_id) for c in got] == [(c["submap_id"], c["node_id"]) for c in want]
+    for c, w in zip(got, want):
+        for key in ("score", "rotational_score", "low_resolution_score"):
+            assert np.float32(getattr(c, key)) == np.float32(w[key]), key
+        np.testing.assert_array_equal(list(c.zbar_ij.translation) + list(c.zbar_ij.rotation),
+                                      w["zbar_ij"])
+        assert c.tag == "INTER_SUBMAP"
