@@ -14,19 +14,19 @@ namespace scan_matching {
 
 class FastCorrelativeScanMatcher2D {
  public:
-  FastCorrelativeScanMatcher2D(const Grid2D& grid,
-                               const proto::FastCorrelativeScanMatcherOptions2D& options);
+  // Uploads the grid and builds its precomputation stack in HBM (cmx_fast2d_create).
+  FastCorrelativeScanMatcher2D(const Grid2D& finished_submap_grid,
+                               const proto::FastCorrelativeScanMatcherOptions2D& opts);
   ~FastCorrelativeScanMatcher2D();
   FastCorrelativeScanMatcher2D(const FastCorrelativeScanMatcher2D&) = delete;
   FastCorrelativeScanMatcher2D& operator=(const FastCorrelativeScanMatcher2D&) = delete;
 
-  // Returns true if a score above 'min_score' (excluding equality) is possible; then
-  // 'score' and 'pose_estimate' are updated.
-  bool Match(const transform::Rigid2d& initial_pose_estimate,
-             const sensor::PointCloud& point_cloud, float min_score, float* score,
-             transform::Rigid2d* pose_estimate) const;
-  bool MatchFullSubmap(const sensor::PointCloud& point_cloud, float min_score, float* score,
-                       transform::Rigid2d* pose_estimate) const;
+  // true iff some pose scores strictly above `threshold`; only then are *score and *pose
+  // written.  Same argument order and types as the reference's methods.
+  bool Match(const transform::Rigid2d& start, const sensor::PointCloud& cloud, float threshold,
+             float* score, transform::Rigid2d* pose) const;
+  bool MatchFullSubmap(const sensor::PointCloud& cloud, float threshold, float* score,
+                       transform::Rigid2d* pose) const;
 
  private:
   cmx_fast2d* handle_ = nullptr;
@@ -35,11 +35,10 @@ class FastCorrelativeScanMatcher2D {
 class RealTimeCorrelativeScanMatcher2D {
  public:
   explicit RealTimeCorrelativeScanMatcher2D(
-      const proto::RealTimeCorrelativeScanMatcherOptions& options)
-      : options_(options) {}
-  double Match(const transform::Rigid2d& initial_pose_estimate,
-               const sensor::PointCloud& point_cloud, const Grid2D& grid,
-               transform::Rigid2d* pose_estimate) const;
+      const proto::RealTimeCorrelativeScanMatcherOptions& opts) : options_(opts) {}
+  // Best weighted score over the exhaustive window around `start`; *pose always written.
+  double Match(const transform::Rigid2d& start, const sensor::PointCloud& cloud,
+               const Grid2D& active_grid, transform::Rigid2d* pose) const;
 
  private:
   const proto::RealTimeCorrelativeScanMatcherOptions options_;

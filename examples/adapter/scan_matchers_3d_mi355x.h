@@ -20,22 +20,22 @@ class FastCorrelativeScanMatcher3D {
     float low_resolution_score;
   };
 
-  FastCorrelativeScanMatcher3D(const HybridGrid& hybrid_grid,
-                               const HybridGrid* low_resolution_hybrid_grid,
-                               const std::vector<float>* rotational_scan_matcher_histogram,
-                               const proto::FastCorrelativeScanMatcherOptions3D& options);
+  // Flattens both grids and builds the precomputation stack in HBM (cmx_fast3d_create).
+  FastCorrelativeScanMatcher3D(const HybridGrid& high_resolution,
+                               const HybridGrid* low_resolution,
+                               const std::vector<float>* submap_histogram,
+                               const proto::FastCorrelativeScanMatcherOptions3D& opts);
   ~FastCorrelativeScanMatcher3D();
   FastCorrelativeScanMatcher3D(const FastCorrelativeScanMatcher3D&) = delete;
   FastCorrelativeScanMatcher3D& operator=(const FastCorrelativeScanMatcher3D&) = delete;
 
-  // nullptr when no candidate above 'min_score' passes the low-resolution check.
-  std::unique_ptr<Result> Match(const transform::Rigid3d& global_node_pose,
-                                const transform::Rigid3d& global_submap_pose,
-                                const TrajectoryNodeData& constant_data, float min_score) const;
-  std::unique_ptr<Result> MatchFullSubmap(const transform::Quaterniond& global_node_rotation,
-                                          const transform::Quaterniond& global_submap_rotation,
-                                          const TrajectoryNodeData& constant_data,
-                                          float min_score) const;
+  // nullptr unless a candidate scoring above `threshold` also passes the low-resolution check.
+  std::unique_ptr<Result> Match(const transform::Rigid3d& node, const transform::Rigid3d& submap,
+                                const TrajectoryNodeData& node_data, float threshold) const;
+  std::unique_ptr<Result> MatchFullSubmap(const transform::Quaterniond& node_rotation,
+                                          const transform::Quaterniond& submap_rotation,
+                                          const TrajectoryNodeData& node_data,
+                                          float threshold) const;
 
  private:
   cmx_fast3d* handle_ = nullptr;
@@ -44,11 +44,9 @@ class FastCorrelativeScanMatcher3D {
 class RealTimeCorrelativeScanMatcher3D {
  public:
   explicit RealTimeCorrelativeScanMatcher3D(
-      const proto::RealTimeCorrelativeScanMatcherOptions& options)
-      : options_(options) {}
-  float Match(const transform::Rigid3d& initial_pose_estimate,
-              const sensor::PointCloud& point_cloud, const HybridGrid& hybrid_grid,
-              transform::Rigid3d* pose_estimate) const;
+      const proto::RealTimeCorrelativeScanMatcherOptions& opts) : options_(opts) {}
+  float Match(const transform::Rigid3d& start, const sensor::PointCloud& cloud,
+              const HybridGrid& active_grid, transform::Rigid3d* pose) const;
 
  private:
   const proto::RealTimeCorrelativeScanMatcherOptions options_;

@@ -1,5 +1,5 @@
-// Stand-in for mapping/submaps.h: probability_grid.cc includes it for one helper its
-// DrawToSubmapTexture uses (submaps.h:36-55; compiled, never called here).
+// Stand-in for mapping/submaps.h: probability_grid.cc includes it for the log-odds byte its
+// DrawToSubmapTexture writes (compiled, never called here).
 #ifndef ORACLE_REF_SHIMS_SUBMAPS_H_
 #define ORACLE_REF_SHIMS_SUBMAPS_H_
 #include <cmath>
@@ -7,17 +7,14 @@
 #include "cartographer/common/port.h"
 #include "cartographer/mapping/probability_values.h"
 #include "glog/logging.h"
-namespace cartographer {
-namespace mapping {
-inline float Logit(float probability) { return std::log(probability / (1.f - probability)); }
+namespace cartographer { namespace mapping {
+// [kMinProbability, kMaxProbability] in log odds, mapped linearly onto [1, 255].
 inline uint8 ProbabilityToLogOddsInteger(const float probability) {
-  const float max_log_odds = Logit(kMaxProbability), min_log_odds = Logit(kMinProbability);
-  const int value = common::RoundToInt((Logit(probability) - min_log_odds) * 254.f /
-                                       (max_log_odds - min_log_odds)) + 1;
-  CHECK_LE(1, value);
-  CHECK_GE(255, value);
-  return value;
+  const auto log_odds = [](float p) { return std::log(p / (1.f - p)); };
+  const float lo = log_odds(kMinProbability), hi = log_odds(kMaxProbability);
+  const int byte = 1 + common::RoundToInt((log_odds(probability) - lo) * 254.f / (hi - lo));
+  CHECK(byte >= 1 && byte <= 255);
+  return static_cast<uint8>(byte);
 }
-}  // namespace mapping
-}  // namespace cartographer
+} }
 #endif  // ORACLE_REF_SHIMS_SUBMAPS_H_

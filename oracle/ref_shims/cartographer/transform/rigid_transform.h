@@ -1,83 +1,81 @@
-// Stand-ins for transform::Rigid2<T> and Rigid3<T> (same algebra as
-// transform/rigid_transform.h:34-103 and :118-196) over the stand-in Eigen types.
+// Stand-ins for transform::Rigid2<T> and transform::Rigid3<T> over the stand-in Eigen types.
+// Only the members the translation units built by `make ref` use; the algebra is that of the
+// reference's class (rigid_transform.h:118-196): inverse through the conjugate, a product that
+// renormalises its rotation, rigid * point = rotation * point + translation.
 #ifndef ORACLE_REF_SHIMS_RIGID_TRANSFORM_H_
 #define ORACLE_REF_SHIMS_RIGID_TRANSFORM_H_
 #include "Eigen/Core"
 #include "Eigen/Geometry"
-#include "cartographer/common/lua_parameter_dictionary.h"   // the real header declares FromDictionary
+#include "cartographer/common/lua_parameter_dictionary.h"   // reaches includers this way upstream
+
 namespace cartographer {
 namespace transform {
-template <typename FloatType>
+
+template <typename S>
 class Rigid2 {
  public:
-  using Vector = Eigen::Vector2<FloatType>;
-  using Rotation2D = Eigen::Rotation2D<FloatType>;
-  Rigid2() : translation_(), rotation_() {}
-  Rigid2(const Vector& translation, const Rotation2D& rotation)
-      : translation_(translation), rotation_(rotation) {}
-  Rigid2(const Vector& translation, const double rotation)
-      : translation_(translation), rotation_(rotation) {}
-  static Rigid2 Translation(const Vector& vector) { return Rigid2(vector, Rotation2D()); }
-  static Rigid2 Identity() { return Rigid2(); }
-  const Vector& translation() const { return translation_; }
-  Rotation2D rotation() const { return rotation_; }
- private:
-  Vector translation_;
-  Rotation2D rotation_;
-};
-using Rigid2d = Rigid2<double>;
-using Rigid2f = Rigid2<float>;
+  typedef Eigen::Matrix<S, 2, 1> Vector;
+  typedef Eigen::Rotation2D<S> Rotation2D;
 
-// Rigid3<T>: same algebra as transform/rigid_transform.h:118-196 -- inverse() through the
-// conjugate, the product renormalises its rotation, rigid * point = rotation * point +
-// translation.
-template <typename FloatType>
+  Rigid2() {}
+  Rigid2(const Vector& t, const Rotation2D& r) : t_(t), r_(r) {}
+  Rigid2(const Vector& t, double angle) : t_(t), r_(angle) {}
+
+  static Rigid2 Identity() { return Rigid2(); }
+  static Rigid2 Translation(const Vector& t) { return Rigid2(t, Rotation2D()); }
+
+  const Vector& translation() const { return t_; }
+  Rotation2D rotation() const { return r_; }
+
+ private:
+  Vector t_;
+  Rotation2D r_;
+};
+typedef Rigid2<double> Rigid2d;
+typedef Rigid2<float> Rigid2f;
+
+template <typename S>
 class Rigid3 {
  public:
-  using Vector = Eigen::Matrix<FloatType, 3, 1>;
-  using Quaternion = Eigen::Quaternion<FloatType>;
-  using AngleAxis = Eigen::AngleAxis<FloatType>;
-  Rigid3() : translation_(Vector::Zero()), rotation_(Quaternion::Identity()) {}
-  Rigid3(const Vector& translation, const Quaternion& rotation)
-      : translation_(translation), rotation_(rotation) {}
-  Rigid3(const Vector& translation, const AngleAxis& rotation)
-      : translation_(translation), rotation_(rotation) {}
-  static Rigid3 Rotation(const AngleAxis& angle_axis) {
-    return Rigid3(Vector::Zero(), Quaternion(angle_axis));
-  }
-  static Rigid3 Rotation(const Quaternion& rotation) { return Rigid3(Vector::Zero(), rotation); }
-  static Rigid3 Translation(const Vector& vector) {
-    return Rigid3(vector, Quaternion::Identity());
-  }
+  typedef Eigen::Matrix<S, 3, 1> Vector;
+  typedef Eigen::Quaternion<S> Quaternion;
+  typedef Eigen::AngleAxis<S> AngleAxis;
+
+  Rigid3() : t_(Vector::Zero()) {}                       // Quaternion() is the identity
+  Rigid3(const Vector& t, const Quaternion& q) : t_(t), q_(q) {}
+  Rigid3(const Vector& t, const AngleAxis& aa) : t_(t), q_(aa) {}
+
   static Rigid3 Identity() { return Rigid3(); }
-  template <typename OtherType>
-  Rigid3<OtherType> cast() const {
-    return Rigid3<OtherType>(translation_.template cast<OtherType>(),
-                             rotation_.template cast<OtherType>());
+  static Rigid3 Translation(const Vector& t) { return Rigid3(t, Quaternion()); }
+  static Rigid3 Rotation(const Quaternion& q) { return Rigid3(Vector::Zero(), q); }
+  static Rigid3 Rotation(const AngleAxis& aa) { return Rigid3(Vector::Zero(), Quaternion(aa)); }
+
+  const Vector& translation() const { return t_; }
+  const Quaternion& rotation() const { return q_; }
+
+  template <typename U>
+  Rigid3<U> cast() const {
+    return Rigid3<U>(t_.template cast<U>(), q_.template cast<U>());
   }
-  const Vector& translation() const { return translation_; }
-  const Quaternion& rotation() const { return rotation_; }
+
   Rigid3 inverse() const {
-    const Quaternion rotation = rotation_.conjugate();
-    const Vector translation = -(rotation * translation_);
-    return Rigid3(translation, rotation);
+    const Quaternion back = q_.conjugate();
+    return Rigid3(-(back * t_), back);
   }
+
+  // rigid * point and rigid * rigid.
+  Vector operator*(const Vector& p) const { return q_ * p + t_; }
+  Rigid3 operator*(const Rigid3& rhs) const {
+    return Rigid3(q_ * rhs.t_ + t_, (q_ * rhs.q_).normalized());
+  }
+
  private:
-  Vector translation_;
-  Quaternion rotation_;
+  Vector t_;
+  Quaternion q_;
 };
-template <typename FloatType>
-Rigid3<FloatType> operator*(const Rigid3<FloatType>& lhs, const Rigid3<FloatType>& rhs) {
-  return Rigid3<FloatType>(lhs.rotation() * rhs.translation() + lhs.translation(),
-                           (lhs.rotation() * rhs.rotation()).normalized());
-}
-template <typename FloatType>
-typename Rigid3<FloatType>::Vector operator*(const Rigid3<FloatType>& rigid,
-                                             const typename Rigid3<FloatType>::Vector& point) {
-  return rigid.rotation() * point + rigid.translation();
-}
-using Rigid3d = Rigid3<double>;
-using Rigid3f = Rigid3<float>;
+typedef Rigid3<double> Rigid3d;
+typedef Rigid3<float> Rigid3f;
+
 }  // namespace transform
 }  // namespace cartographer
 #endif  // ORACLE_REF_SHIMS_RIGID_TRANSFORM_H_

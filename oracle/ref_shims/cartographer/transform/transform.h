@@ -16,58 +16,53 @@
 namespace cartographer {
 namespace transform {
 
-// transform/transform.h:33-37.
-template <typename FloatType>
-FloatType GetAngle(const Rigid3<FloatType>& transform) {
-  return FloatType(2) * std::atan2(transform.rotation().vec().norm(),
-                                   std::abs(transform.rotation().w()));
+// Rotation angle of a rigid transform (transform.h:33-37): 2 atan2(|q.vec|, |q.w|).
+template <typename S>
+S GetAngle(const Rigid3<S>& rigid) {
+  const Eigen::Quaternion<S>& q = rigid.rotation();
+  const S sine_half = q.vec().norm();
+  return S(2) * std::atan2(sine_half, std::abs(q.w()));
 }
 
-// transform/transform.h:42-47: the direction the rotation sends UnitX to.
-template <typename T>
-T GetYaw(const Eigen::Quaternion<T>& rotation) {
-  const Eigen::Matrix<T, 3, 1> direction = rotation * Eigen::Matrix<T, 3, 1>::UnitX();
-  return std::atan2(direction.y(), direction.x());
+// Yaw of a rotation (transform.h:42-47): heading of the rotated x axis in the xy plane.
+template <typename S>
+S GetYaw(const Eigen::Quaternion<S>& q) {
+  const Eigen::Matrix<S, 3, 1> heading = q * Eigen::Matrix<S, 3, 1>::UnitX();
+  return std::atan2(heading.y(), heading.x());
 }
-template <typename T>
-T GetYaw(const Rigid3<T>& transform) {
-  return GetYaw(transform.rotation());
-}
+template <typename S>
+S GetYaw(const Rigid3<S>& rigid) { return GetYaw(rigid.rotation()); }
 
-// transform/transform.h:85-99: sin/cos of `norm / 2.` are evaluated in double whatever T is
-// (the literal 2. promotes), then narrowed to T.
-template <typename T>
-Eigen::Quaternion<T> AngleAxisVectorToRotationQuaternion(
-    const Eigen::Matrix<T, 3, 1>& angle_axis) {
-  T scale = T(0.5);
-  T w = T(1.);
-  constexpr double kCutoffAngle = 1e-8;   // linearised below this angle
-  if (angle_axis.squaredNorm() > kCutoffAngle) {
-    const T norm = angle_axis.norm();
-    scale = std::sin(norm / 2.) / norm;
-    w = std::cos(norm / 2.);
+// Angle-axis vector -> quaternion (transform.h:85-99).  Below |v|^2 = 1e-8 the reference
+// linearises (w = 1, xyz = v / 2); above, sin and cos of |v| / 2 are evaluated in DOUBLE
+// whatever S is (its literal `2.` promotes) and narrowed to S afterwards.
+template <typename S>
+Eigen::Quaternion<S> AngleAxisVectorToRotationQuaternion(const Eigen::Matrix<S, 3, 1>& v) {
+  S w = S(1), k = S(0.5);
+  if (v.squaredNorm() > 1e-8) {
+    const S length = v.norm();
+    k = std::sin(length / 2.) / length;
+    w = std::cos(length / 2.);
   }
-  const Eigen::Matrix<T, 3, 1> quaternion_xyz = scale * angle_axis;
-  return Eigen::Quaternion<T>(w, quaternion_xyz.x(), quaternion_xyz.y(), quaternion_xyz.z());
+  const Eigen::Matrix<S, 3, 1> xyz = k * v;
+  return Eigen::Quaternion<S>(w, xyz.x(), xyz.y(), xyz.z());
 }
 
-// transform/transform.cc:40-42,94-99 and :117-127: conversions the grid headers call.
-inline Eigen::Vector2d ToEigen(const proto::Vector2d& vector) {
-  return Eigen::Vector2d(vector.x(), vector.y());
-}
-inline proto::Vector2d ToProto(const Eigen::Vector2d& vector) {
-  proto::Vector2d result;
-  result.set_x(vector.x());
-  result.set_y(vector.y());
-  return result;
+// Proto conversions the grid headers call (transform.cc).
+inline Eigen::Vector2d ToEigen(const proto::Vector2d& v) { return Eigen::Vector2d(v.x(), v.y()); }
+inline proto::Vector2d ToProto(const Eigen::Vector2d& v) {
+  proto::Vector2d out;
+  out.set_x(v.x());
+  out.set_y(v.y());
+  return out;
 }
 inline proto::Rigid3d ToProto(const Rigid3d& rigid) {
-  proto::Rigid3d result;
-  result.t[0] = rigid.translation().x(); result.t[1] = rigid.translation().y();
-  result.t[2] = rigid.translation().z();
-  result.q[0] = rigid.rotation().w(); result.q[1] = rigid.rotation().x();
-  result.q[2] = rigid.rotation().y(); result.q[3] = rigid.rotation().z();
-  return result;
+  proto::Rigid3d out;
+  const auto& t = rigid.translation();
+  const auto& q = rigid.rotation();
+  out.t[0] = t.x(); out.t[1] = t.y(); out.t[2] = t.z();
+  out.q[0] = q.w(); out.q[1] = q.x(); out.q[2] = q.y(); out.q[3] = q.z();
+  return out;
 }
 
 }  // namespace transform
