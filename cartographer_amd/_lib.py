@@ -89,7 +89,8 @@ class Result3D(C.Structure):
 EXPORTED_SYMBOLS = [
     "cmx_version", "cmx_status_string", "cmx_last_error", "cmx_device_count", "cmx_set_stream",
     "cmx_rt2d_match", "cmx_rt2d_match_tsdf", "cmx_grid2d_create", "cmx_grid2d_destroy",
-    "cmx_grid2d_get_limits", "cmx_grid2d_download", "cmx_grid2d_insert", "cmx_rt2d_match_grid",
+    "cmx_grid2d_get_limits", "cmx_grid2d_download", "cmx_grid2d_crop", "cmx_grid2d_insert",
+    "cmx_rt2d_match_grid",
     "cmx_rt2d_match_grid_batch",
     "cmx_fast2d_create", "cmx_fast2d_create_from_grid", "cmx_fast2d_destroy", "cmx_fast2d_match",
     "cmx_fast2d_match_full_submap", "cmx_fast2d_match_batch",
@@ -134,6 +135,7 @@ def lib():
     L.cmx_grid2d_destroy.restype = None
     L.cmx_grid2d_get_limits.argtypes = [C.c_void_p, P(Grid2DLimits)]
     L.cmx_grid2d_download.argtypes = [C.c_void_p, C.c_void_p]
+    L.cmx_grid2d_crop.argtypes = [C.c_void_p]
     L.cmx_grid2d_insert.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                     C.c_int32, C.c_float, C.c_float, C.c_int32]
     L.cmx_rt2d_match_grid.argtypes = [P(RtOptions), C.c_void_p, P(Pose2d), C.c_void_p, C.c_int32,

@@ -173,6 +173,40 @@ __global__ void GridGrowKernel(const uint16_t* __restrict__ old_cells, int nx, i
       old_cells[static_cast<size_t>(y) * nx + x];
 }
 
+// Grid2D::ComputeCroppedLimits (grid_2d.cc:104-114): bounding box of the known cells
+// (known_cells_box_ is extended by every SetProbability / ApplyLookupTable, and a known cell never
+// becomes unknown again, so it is the box of the non-zero cells).  box = {min_x, min_y, max_x,
+// max_y}, preset to {INT_MAX, INT_MAX, -1, -1}; one set of atomics per wavefront.
+__global__ void __launch_bounds__(256)
+GridKnownBoxKernel(const uint16_t* __restrict__ cells, int nx, int ny, int* __restrict__ box) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  const bool known = x < nx && cells[static_cast<size_t>(y) * nx + x] != 0;
+  int lo = known ? x : 0x7fffffff, hi = known ? x : -1;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    lo = min(lo, __shfl_xor(lo, off, 64));
+    hi = max(hi, __shfl_xor(hi, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0 && hi >= 0) {
+    atomicMin(&box[0], lo);
+    atomicMax(&box[2], hi);
+    atomicMin(&box[1], y);
+    atomicMax(&box[3], y);
+  }
+}
+
+// ProbabilityGrid::ComputeCroppedGrid (probability_grid.cc:90-106): the known box copied into a
+// grid of its own.  SetProbability(GetProbability(v)) is the identity on every value
+// (tests/test_device_formulas.py), so the cells are copied as they are.
+__global__ void GridCropKernel(const uint16_t* __restrict__ cells, int nx, int off_x, int off_y,
+                               uint16_t* __restrict__ cropped, int cnx) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x < cnx) cropped[static_cast<size_t>(y) * cnx + x] =
+      cells[static_cast<size_t>(y + off_y) * nx + x + off_x];
+}
+
 bool Contains(const cmx_grid2d& g, float px, float py) {
   const long ix = std::lround((g.max_y - py) / g.resolution - 0.5);
   const long iy = std::lround((g.max_x - px) / g.resolution - 0.5);
@@ -270,6 +304,50 @@ extern "C" cmx_status cmx_grid2d_download(const cmx_grid2d* grid, uint16_t* cell
     cmx::UseDevice(grid->device);
     CMX_HIP(hipMemcpy(cells, grid->cells, static_cast<size_t>(grid->nx) * grid->ny * 2,
                       hipMemcpyDeviceToHost));
+  });
+}
+
+extern "C" cmx_status cmx_grid2d_crop(cmx_grid2d* grid) {
+  using namespace cmx;
+  return Guard([&] {
+    CMX_REQUIRE(grid != nullptr, "null argument");
+    WorkspaceLease ws(grid->device);
+    int* d_box = ws->dev[2].ReserveAs<int>(4);
+    const int preset[4] = {0x7fffffff, 0x7fffffff, -1, -1};
+    int* h_box = ws->pinned[0].ReserveAs<int>(4);
+    std::memcpy(h_box, preset, sizeof(preset));
+    CMX_HIP(hipMemcpyAsync(d_box, h_box, sizeof(preset), hipMemcpyHostToDevice, ws->stream));
+    GridKnownBoxKernel<<<dim3(DivUp(grid->nx, 256), grid->ny), 256, 0, ws->stream>>>(
+        grid->cells, grid->nx, grid->ny, d_box);
+    CMX_HIP(hipGetLastError());
+    CMX_HIP(hipMemcpyAsync(h_box, d_box, sizeof(preset), hipMemcpyDeviceToHost, ws->stream));
+    CMX_HIP(hipStreamSynchronize(ws->stream));
+    const bool empty = h_box[2] < 0;
+    // ComputeCroppedLimits: no known cell -> offset 0, CellLimits(1, 1) (grid_2d.cc:106-110).
+    const int off_x = empty ? 0 : h_box[0], off_y = empty ? 0 : h_box[1];
+    const int cnx = empty ? 1 : h_box[2] - h_box[0] + 1, cny = empty ? 1 : h_box[3] - h_box[1] + 1;
+    uint16_t* cropped = nullptr;
+    const size_t bytes = static_cast<size_t>(cnx) * cny * sizeof(uint16_t);
+    CMX_HIP(hipMalloc(reinterpret_cast<void**>(&cropped), bytes));
+    if (empty) {
+      CMX_HIP(hipMemsetAsync(cropped, 0, bytes, ws->stream));       // one unknown cell
+    } else {
+      GridCropKernel<<<dim3(DivUp(cnx, 256), cny), 256, 0, ws->stream>>>(
+          grid->cells, grid->nx, off_x, off_y, cropped, cnx);
+    }
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess) err = hipStreamSynchronize(ws->stream);
+    if (err != hipSuccess) {
+      (void)hipFree(cropped);
+      CMX_HIP(err);
+    }
+    CMX_HIP(hipFree(grid->cells));
+    grid->cells = cropped;
+    // max = limits().max() - resolution * (offset.y, offset.x) (probability_grid.cc:95-96).
+    grid->max_x = grid->max_x - grid->resolution * off_y;
+    grid->max_y = grid->max_y - grid->resolution * off_x;
+    grid->nx = cnx;
+    grid->ny = cny;
   });
 }
 

@@ -58,6 +58,12 @@ class ProbabilityGridOnDevice:
             mis.ctypes.data if mis.shape[0] else None, mis.shape[0], hit_probability,
             miss_probability, int(insert_free_space)))
 
+    def crop(self):
+        """grid = grid->ComputeCroppedGrid() (probability_grid.cc:90-106): shrinks the grid to the
+        bounding box of its known cells, as Submap2D::Finish does before the loop-closure matcher
+        of the submap is built."""
+        check(_lib.lib().cmx_grid2d_crop(self._h))
+
     def fast_matcher(self, branch_and_bound_depth, linear_search_window=7.0,
                      angular_search_window=float(np.deg2rad(30.0))):
         """FastCorrelativeScanMatcher2D of this (finished) grid."""

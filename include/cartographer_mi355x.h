@@ -155,6 +155,9 @@ cmx_status cmx_rt2d_match_tsdf(const cmx_rt_options* options, const cmx_grid2d_l
  *                          mapping/internal/2d/ray_to_pixel_mask.cc:34-156); grows the
  *                         limits like GrowAsNeeded / Grid2D::GrowLimits. Points are in the
  *                         map frame (range data already transformed), xyz triples.
+ *   cmx_grid2d_crop       grid = grid->ComputeCroppedGrid(): what Submap2D::Finish does before the
+ *                         loop-closure matcher is built (mapping/2d/submap_2d.cc:146-149,
+ *                         mapping/2d/probability_grid.cc:90-106, grid_2d.cc:104-114)
  *   cmx_rt2d_match_grid   RealTimeCorrelativeScanMatcher2D::Match on that grid
  *   cmx_fast2d_create_from_grid  FastCorrelativeScanMatcher2D of the (finished) grid */
 typedef struct cmx_grid2d cmx_grid2d;
@@ -163,6 +166,7 @@ cmx_status cmx_grid2d_create(const cmx_grid2d_limits* limits, const uint16_t* ce
 void cmx_grid2d_destroy(cmx_grid2d* grid);
 cmx_status cmx_grid2d_get_limits(const cmx_grid2d* grid, cmx_grid2d_limits* limits);
 cmx_status cmx_grid2d_download(const cmx_grid2d* grid, uint16_t* cells);
+cmx_status cmx_grid2d_crop(cmx_grid2d* grid);
 cmx_status cmx_grid2d_insert(cmx_grid2d* grid, const float* origin_xy, const float* returns_xyz,
                              int32_t num_returns, const float* misses_xyz, int32_t num_misses,
                              float hit_probability, float miss_probability,

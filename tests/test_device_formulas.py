@@ -97,3 +97,17 @@ def test_parent_cell_is_max_of_child_cells(oracle, synth):
         want = np.maximum(np.maximum(child(x0, y0), child(x0 + h, y0)),
                           np.maximum(child(x0, y0 + h), child(x0 + h, y0 + h)))
         np.testing.assert_array_equal(big, want)
+
+
+def test_cropping_round_trip_is_the_identity_on_cell_values(oracle):
+    """ProbabilityGrid::ComputeCroppedGrid copies cells as
+    SetProbability(GetProbability(cell)) (probability_grid.cc:90-106), i.e. value -> cost ->
+    probability = 1 - cost -> cost' = 1 - probability -> value'.  For every value in [1, 32767]
+    value' == value, so the device crop (cmx_grid2d_crop) may copy the cells as they are."""
+    _, value_to_cost, _ = oracle.value_tables()
+    L = oracle.lib()
+    for v in range(1, 32768):
+        cost = np.float32(value_to_cost[v])
+        probability = np.float32(1) - cost               # CorrespondenceCostToProbability
+        back = np.float32(1) - probability               # ProbabilityToCorrespondenceCost
+        assert L.orc_correspondence_cost_to_value(float(back)) == v

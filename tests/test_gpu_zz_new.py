@@ -287,3 +287,52 @@ def test_constraint_lists_3d_match_restatement(oracle, synth):
         np.testing.assert_array_equal(list(c.zbar_ij.translation) + list(c.zbar_ij.rotation),
                                       w["zbar_ij"])
         assert c.tag == "INTER_SUBMAP"
+
+
+def test_device_crop_equals_compute_cropped_grid(g2, synth, oracle):
+    """cmx_grid2d_crop = ProbabilityGrid::ComputeCroppedGrid (probability_grid.cc:90-106; the host
+    restatement `cropped()` is pinned against the reference's own in
+    tests/test_reference_ref_grid.py): limits and cells after scans that made the grid grow, an
+    all-unknown grid (-> 1 x 1), a second crop (idempotent), and the loop-closure matcher built
+    from the cropped device grid against the oracle on the same cells."""
+    from cartographer_amd import scan_matching as sm
+    _, lim, world = synth.make_submap(17, 200, 200, 0.05, 2, 100, 30.0, 0.01)
+    start = (lim["max_x"] - 4.0, lim["max_y"] - 4.0)
+    host = synth.ProbabilityGrid(0.05, start, 16, 16)
+    dev = g2.ProbabilityGridOnDevice(0.05, start, 16, 16)
+    scan = None
+    for k in range(6):
+        pose = world.free_pose(1700 + k, 0.4)
+        sensor = world.scan(pose, 257, 30.0, 0.01, k)
+        c, s = math.cos(pose[2]), math.sin(pose[2])
+        cloud = np.zeros_like(sensor)
+        cloud[:, 0] = (pose[0] + c * sensor[:, 0].astype(np.float64)
+                       - s * sensor[:, 1].astype(np.float64)).astype(np.float32)
+        cloud[:, 1] = (pose[1] + s * sensor[:, 0].astype(np.float64)
+                       + c * sensor[:, 1].astype(np.float64)).astype(np.float32)
+        host.insert(pose[:2], cloud)
+        dev.insert(pose[:2], cloud)
+        scan = sensor
+    before = dev.limits
+    cropped = host.cropped()
+    dev.crop()
+    _assert_same(dev, cropped)
+    assert dev.limits["num_x_cells"] < before["num_x_cells"]          # it did shrink
+    dev.crop()                                                         # idempotent
+    _assert_same(dev, cropped)
+    # the finished submap's matcher, built from the cropped grid in HBM
+    cells, l2 = dev.cells, dev.limits
+    gm = dev.fast_matcher(5)
+    om = oracle.FastCorrelativeScanMatcher2D(cells, l2["resolution"], l2["max_x"], l2["max_y"], 5)
+    ref = om.match_full_submap(scan, 0.3)
+    found, score, pose = gm.match_full_submap(scan, 0.3)
+    assert bool(found) == ref["found"]
+    if found:
+        assert np.float32(score) == np.float32(ref["score"])
+        np.testing.assert_allclose([pose.x, pose.y, pose.theta], ref["pose"], rtol=0, atol=1e-12)
+    # all unknown -> CellLimits(1, 1), max unchanged (grid_2d.cc:106-110)
+    empty = g2.ProbabilityGridOnDevice(0.1, (3.0, -2.0), 30, 20)
+    empty.crop()
+    assert empty.limits == dict(resolution=0.1, max_x=3.0, max_y=-2.0, num_x_cells=1,
+                                num_y_cells=1)
+    assert empty.cells.tolist() == [[0]]
