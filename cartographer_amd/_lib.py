@@ -92,6 +92,8 @@ EXPORTED_SYMBOLS = [
     "cmx_grid2d_get_limits", "cmx_grid2d_download", "cmx_grid2d_crop", "cmx_grid2d_insert",
     "cmx_rt2d_match_grid",
     "cmx_rt2d_match_grid_batch",
+    "cmx_grid3d_create", "cmx_grid3d_destroy", "cmx_grid3d_insert", "cmx_grid3d_info",
+    "cmx_grid3d_download",
     "cmx_fast2d_create", "cmx_fast2d_create_from_grid", "cmx_fast2d_destroy", "cmx_fast2d_match",
     "cmx_fast2d_match_full_submap", "cmx_fast2d_match_batch",
     "cmx_fast2d_match_full_submap_batch", "cmx_cloud_upload",
@@ -136,6 +138,13 @@ def lib():
     L.cmx_grid2d_get_limits.argtypes = [C.c_void_p, P(Grid2DLimits)]
     L.cmx_grid2d_download.argtypes = [C.c_void_p, C.c_void_p]
     L.cmx_grid2d_crop.argtypes = [C.c_void_p]
+    L.cmx_grid3d_create.argtypes = [C.c_float, C.c_int32, P(C.c_void_p)]
+    L.cmx_grid3d_destroy.argtypes = [C.c_void_p]
+    L.cmx_grid3d_destroy.restype = None
+    L.cmx_grid3d_insert.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float,
+                                    C.c_float, C.c_int32]
+    L.cmx_grid3d_info.argtypes = [C.c_void_p, P(C.c_float), P(C.c_int32), P(C.c_int64)]
+    L.cmx_grid3d_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, P(C.c_int64)]
     L.cmx_grid2d_insert.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                     C.c_int32, C.c_float, C.c_float, C.c_int32]
     L.cmx_rt2d_match_grid.argtypes = [P(RtOptions), C.c_void_p, P(Pose2d), C.c_void_p, C.c_int32,

@@ -261,6 +261,28 @@ cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_resolution,
                           int32_t num_points, int32_t device, float* score,
                           cmx_pose3d* pose_estimate, cmx_match_stats* stats);
 
+/* ---- device-resident hybrid grid -------------------- */
+/* The active 3D submap's HybridGrid kept in HBM as a dense uint16 brick:
+ *   cmx_grid3d_create    HybridGrid(resolution) (mapping/3d/hybrid_grid.h:459-462)
+ *   cmx_grid3d_insert    RangeDataInserter3D::Insert without intensities
+ *                        (mapping/3d/range_data_inserter_3d.cc:27-52, :93-114): hits, then the last
+ *                        `num_free_space_voxels` voxels of every ray as misses, FinishUpdate;
+ *                        points in the map frame, xyz triples
+ *   cmx_grid3d_info      resolution(), DynamicGrid::grid_size() (hybrid_grid.h:259,381-398) and
+ *                        the number of known voxels
+ *   cmx_grid3d_download  the voxels HybridGrid::Iterator yields (hybrid_grid.h:304-372), sorted
+ *                        (z, y, x): the list cmx_rt3d_match / cmx_fast3d_create take */
+typedef struct cmx_grid3d cmx_grid3d;
+cmx_status cmx_grid3d_create(float resolution, int32_t device, cmx_grid3d** out);
+void cmx_grid3d_destroy(cmx_grid3d* grid);
+cmx_status cmx_grid3d_insert(cmx_grid3d* grid, const float* origin_xyz, const float* returns_xyz,
+                             int32_t num_returns, float hit_probability, float miss_probability,
+                             int32_t num_free_space_voxels);
+cmx_status cmx_grid3d_info(const cmx_grid3d* grid, float* resolution, int32_t* grid_size,
+                           int64_t* num_voxels);
+cmx_status cmx_grid3d_download(const cmx_grid3d* grid, cmx_voxel* voxels, int64_t capacity,
+                               int64_t* num_voxels);
+
 /* ---- fast 3D ------------------------------------------------------------ */
 /* hybrid_grid.h:137 grid_size(): 8*8*2^bits cells per axis of the dynamic
  * grid the voxels came from (needed by MatchFullSubmap's window). */

@@ -111,3 +111,33 @@ def test_cropping_round_trip_is_the_identity_on_cell_values(oracle):
         probability = np.float32(1) - cost               # CorrespondenceCostToProbability
         back = np.float32(1) - probability               # ProbabilityToCorrespondenceCost
         assert L.orc_correspondence_cost_to_value(float(back)) == v
+
+
+def test_product_probability_odds_table_equals_the_reference(oracle, tmp_path):
+    """cartographer_amd/csrc/cmx_odds_table.h -- the host table cmx_grid3d_insert uploads --
+    compiled on its own with g++ and compared, entry by entry, with the reference's own
+    ComputeLookupTableToApplyOdds (oracle/_ref)."""
+    import ctypes
+    import os
+    import subprocess
+    ref = oracle.ref_lib()
+    if ref is None:
+        pytest.skip("reference tree not available and oracle/_ref not prebuilt")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "table.cc"
+    src.write_text('#include "cmx_odds_table.h"\n'
+                   'extern "C" void table(float p, uint16_t* out) {'
+                   ' cmx::ProbabilityOddsTable(p, out); }\n')
+    lib = tmp_path / "libtable.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+                           "-I", os.path.join(root, "cartographer_amd", "csrc"), "-o", str(lib),
+                           str(src)])
+    fn = ctypes.CDLL(str(lib)).table
+    fn.argtypes = [ctypes.c_float, np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")]
+    for probability in (0.7, 0.4, 0.55, 0.49, 0.9, 0.1, 0.5, 0.62):
+        got = np.empty(32768, np.uint16)
+        fn(probability, got)
+        cost_table = np.empty(32768, np.uint16)
+        probability_table = np.empty(32768, np.uint16)
+        ref.ref_odds_tables(probability, cost_table, probability_table)
+        np.testing.assert_array_equal(got, probability_table)

@@ -336,3 +336,88 @@ def test_device_crop_equals_compute_cropped_grid(g2, synth, oracle):
     assert empty.limits == dict(resolution=0.1, max_x=3.0, max_y=-2.0, num_x_cells=1,
                                 num_y_cells=1)
     assert empty.cells.tolist() == [[0]]
+
+
+# ---------------------------------------------------------------------------- part 3: 3D grid
+def _same_voxel_grid(dev, host):
+    assert dev.grid_size == host.grid_size
+    np.testing.assert_array_equal(dev.voxels(), host.voxels())
+
+
+def test_device_range_data_inserter_3d_reference_fixture(synth):
+    """RangeDataInserter3DTest.InsertPointCloud / ProbabilityProgression
+    (mapping/3d/range_data_inserter_3d_test.cc:28-53, :97-114, :138-157) on the device inserter:
+    the reference test's known answers, and the host builder (pinned on the reference's own
+    inserter) voxel for voxel."""
+    from cartographer_amd import grid_3d
+    from test_oracle_reference_pins_3d import INSERTER_3D_ORIGIN, INSERTER_3D_RETURNS
+    dev, host = grid_3d.HybridGridOnDevice(1.0), synth.HybridGrid(1.0)
+    dev.insert(INSERTER_3D_ORIGIN, INSERTER_3D_RETURNS, 0.7, 0.4, 1000)
+    host.insert(INSERTER_3D_ORIGIN, INSERTER_3D_RETURNS, 0.7, 0.4, 1000)
+    _same_voxel_grid(dev, host)
+    v = dev.voxels()
+    value_to_probability = {int(r["value"]): None for r in v}
+    at = {(int(r["x"]), int(r["y"]), int(r["z"])): int(r["value"]) for r in v}
+    assert (0, 0, -4) in at and (0, 0, -3) in at and (0, 0, -2) in at      # misses along a ray
+    for x in range(-4, 5):
+        for y in range(-4, 5):
+            known = (x, y, 4) in at
+            assert known == (not (x < -3 or x > 0 or y != x + 2))           # the four hits
+    assert at[(-2, 0, 4)] > at[(-2, 0, 3)]                                  # hit 0.7 > miss 0.4
+    for _ in range(1000):
+        dev.insert(INSERTER_3D_ORIGIN, INSERTER_3D_RETURNS, 0.7, 0.4, 1000)
+        host.insert(INSERTER_3D_ORIGIN, INSERTER_3D_RETURNS, 0.7, 0.4, 1000)
+    _same_voxel_grid(dev, host)
+    assert abs(host.get_probability((-2, 0, 4)) - 0.9) < 1e-3               # saturated
+    del value_to_probability
+
+
+@pytest.mark.parametrize("seed,free", [(2, 2), (7, 0), (9, 40)])
+def test_device_range_data_inserter_3d_scans(synth, seed, free):
+    """Eight scans of a synthetic room, as synth.make_submap_3d inserts them: re-updates through
+    the odds tables, hits before misses, the last `free` voxels of every ray, DynamicGrid growth
+    from 128 to 256 voxels, the brick re-allocated as the scene widens."""
+    from cartographer_amd import grid_3d
+    world = synth.World3D(seed, (15.0, 15.0, 7.5))
+    dev, host = grid_3d.HybridGridOnDevice(0.1), synth.HybridGrid(0.1)
+    for p in range(8):
+        pos = world.free_position(seed * 1009 + p, 0.5)
+        yaw = 0.37 * p
+        sensor = world.scan(pos, yaw, 8, 96, seed=seed * 31 + p).astype(np.float64)
+        c, s = math.cos(yaw), math.sin(yaw)
+        in_map = np.stack([pos[0] + c * sensor[:, 0] - s * sensor[:, 1],
+                           pos[1] + s * sensor[:, 0] + c * sensor[:, 1],
+                           pos[2] + sensor[:, 2]], 1).astype(np.float32)
+        hit, miss = (0.55, 0.49) if p % 3 == 2 else (0.7, 0.4)
+        dev.insert(pos.astype(np.float32), in_map, hit, miss, free)
+        host.insert(pos.astype(np.float32), in_map, hit, miss, free)
+        _same_voxel_grid(dev, host)
+    assert dev.grid_size == 256
+    # nothing to insert: a no-op on both
+    dev.insert(pos.astype(np.float32), np.zeros((0, 3), np.float32), 0.7, 0.4, free)
+    _same_voxel_grid(dev, host)
+
+
+def test_rt3d_on_the_device_built_grid(synth, oracle):
+    """Insert -> Match: the real-time 3D matcher on the voxels of the grid built in HBM equals the
+    oracle on the host-built grid (LocalTrajectoryBuilder3D's per-scan loop)."""
+    from cartographer_amd import grid_3d, scan_matching_3d as sm3
+    from test_oracle_reference_pins_3d import quat_from_angle_axis
+    world = synth.World3D(5, (8.0, 8.0, 4.0))
+    dev, host = grid_3d.HybridGridOnDevice(0.1), synth.HybridGrid(0.1)
+    for p in range(4):
+        pos = world.free_position(50 + p, 0.5)
+        sensor = world.scan(pos, 0.2 * p, 6, 64, seed=p).astype(np.float64)
+        c, s = math.cos(0.2 * p), math.sin(0.2 * p)
+        in_map = np.stack([pos[0] + c * sensor[:, 0] - s * sensor[:, 1],
+                           pos[1] + s * sensor[:, 0] + c * sensor[:, 1],
+                           pos[2] + sensor[:, 2]], 1).astype(np.float32)
+        dev.insert(pos.astype(np.float32), in_map, 0.7, 0.4, 2)
+        host.insert(pos.astype(np.float32), in_map, 0.7, 0.4, 2)
+    cloud = world.scan(pos, 0.6, 6, 64, seed=9)
+    init = list(pos + np.array([0.07, -0.04, 0.02])) + quat_from_angle_axis(0.61, [0, 0, 1])
+    ref = oracle.rt3d_match(0.1, host.voxels(), init, cloud, 0.2, math.radians(1.0), 0.1, 0.1)
+    m = sm3.RealTimeCorrelativeScanMatcher3D(0.2, math.radians(1.0), 0.1, 0.1)
+    score, pose = m.match(sm3.Rigid3d(tuple(init[:3]), tuple(init[3:])), cloud, 0.1, dev.voxels())
+    assert np.float32(score) == np.float32(ref["score"])
+    np.testing.assert_array_equal(list(pose.translation) + list(pose.rotation), ref["pose"])
