@@ -141,3 +141,127 @@ def test_product_probability_odds_table_equals_the_reference(oracle, tmp_path):
         probability_table = np.empty(32768, np.uint16)
         ref.ref_odds_tables(probability, cost_table, probability_table)
         np.testing.assert_array_equal(got, probability_table)
+
+
+class _Grid3DModel:
+    """The ALGORITHM of cartographer_amd/csrc/grid_3d.hip in numpy (dense brick, extent pass with
+    the first / last free-space sample of every ray, 16-voxel brick growth, DynamicGrid's doubling
+    rule, all hits then all (ray, k) miss samples with first-writer-wins, marker clearing).  It
+    checks the decomposition the kernels implement -- not their HIP syntax -- against the host
+    voxel builder, which is pinned on the reference's own RangeDataInserter3D."""
+
+    MARKER = 1 << 15
+
+    def __init__(self, resolution, table_fn):
+        self.res = np.float32(resolution)
+        self.table_fn = table_fn
+        self.grid_size = 128
+        self.lo = None
+        self.cells = None                      # [nz, ny, nx] uint16
+
+    def _cell(self, p):
+        q = (np.asarray(p, np.float32) / self.res).astype(np.float64)      # f32 divide
+        return (np.sign(q) * np.floor(np.abs(q) + 0.5)).astype(np.int64)   # lround
+
+    @staticmethod
+    def _trunc_div(a, b):
+        return np.sign(a) * (np.abs(a) // b)
+
+    def insert(self, origin, returns, hit_p, miss_p, free):
+        returns = np.asarray(returns, np.float32).reshape(-1, 3)
+        if returns.shape[0] == 0:
+            return
+        hit_table, miss_table = self.table_fn(hit_p), self.table_fn(miss_p)
+        o = self._cell(origin)
+        h = self._cell(returns)
+        d = h - o
+        ns = np.abs(d).max(axis=1)
+        assert (ns < (1 << 15)).all()
+        # pass 0: extent from the hits and the first / last touched sample of every ray
+        first = np.maximum(0, ns - free)
+        has = first < ns
+        safe = np.maximum(ns, 1)[:, None]
+        c_first = o + self._trunc_div(d * first[:, None], safe)
+        c_last = o + self._trunc_div(d * (ns - 1)[:, None], safe)
+        pts = np.concatenate([h, c_first[has], c_last[has]])
+        lo, hi = pts.min(axis=0), pts.max(axis=0)
+        while not ((lo >= -(self.grid_size // 2)).all() and (hi < self.grid_size // 2).all()):
+            self.grid_size *= 2
+        nlo, nhi = lo // 16 * 16, hi // 16 * 16 + 15
+        if self.cells is not None:
+            cur_hi = self.lo + np.array(self.cells.shape[::-1]) - 1
+            nlo, nhi = np.minimum(nlo, self.lo), np.maximum(nhi, cur_hi)
+        dims = nhi - nlo + 1
+        grown = np.zeros((dims[2], dims[1], dims[0]), np.uint16)
+        if self.cells is not None:
+            off = self.lo - nlo
+            nz, ny, nx = self.cells.shape
+            grown[off[2]:off[2] + nz, off[1]:off[1] + ny, off[0]:off[0] + nx] = self.cells
+        self.cells, self.lo = grown, nlo
+
+        def apply(cells_xyz, table):
+            idx = cells_xyz - self.lo
+            assert (idx >= 0).all() and (idx < dims).all(), "a voxel fell outside the extent"
+            for x, y, z in idx:                                   # first writer wins
+                old = self.cells[z, y, x]
+                if old < self.MARKER:
+                    self.cells[z, y, x] = table[old]
+        apply(h, hit_table)
+        for k in range(free):                                     # thread (i, k)
+            position = ns - free + k
+            ok = (position >= 0) & (position < ns)
+            if ok.any():
+                c = o + self._trunc_div(d[ok] * position[ok][:, None], ns[ok][:, None])
+                apply(c, miss_table)
+        self.cells[self.cells >= self.MARKER] -= self.MARKER
+
+    def voxels(self):
+        z, y, x = np.nonzero(self.cells) if self.cells is not None else ([], [], [])
+        return [(int(a + self.lo[0]), int(b + self.lo[1]), int(c + self.lo[2]),
+                 int(self.cells[c, b, a])) for a, b, c in zip(x, y, z)]
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_grid3d_device_algorithm_model_equals_the_host_builder(oracle, synth, tmp_path, seed):
+    import ctypes
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "table.cc"
+    src.write_text('#include "cmx_odds_table.h"\n'
+                   'extern "C" void table(float p, uint16_t* out) {'
+                   ' cmx::ProbabilityOddsTable(p, out); }\n')
+    lib = tmp_path / "libtable.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+                           "-I", os.path.join(root, "cartographer_amd", "csrc"), "-o", str(lib),
+                           str(src)])
+    fn = ctypes.CDLL(str(lib)).table
+    fn.argtypes = [ctypes.c_float, np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")]
+    cache = {}
+
+    def table(p):
+        if p not in cache:
+            cache[p] = np.empty(32768, np.uint16)
+            fn(p, cache[p])
+        return cache[p]
+
+    rng = np.random.default_rng(800 + seed)                 # test_random_insertions_3d's generator
+    res = float(rng.choice([0.05, 0.1, 0.45, 1.0]))
+    host, model = synth.HybridGrid(res), _Grid3DModel(res, table)
+    for _ in range(8):
+        origin = rng.uniform(-20, 20, 3).astype(np.float32) * np.float32(res)
+        n = int(rng.integers(0, 60))
+        d = rng.normal(size=(n, 3))
+        d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-9)
+        rad = rng.uniform(0, 90 * res, (n, 1)) * (rng.uniform(size=(n, 1)) > 0.1)
+        pts = (origin + d * rad).astype(np.float32)
+        if n > 3:
+            pts[1] = pts[0]
+        hit, miss = float(rng.uniform(0.51, 0.95)), float(rng.uniform(0.05, 0.49))
+        free = int(rng.choice([0, 1, 2, 10, 60]))
+        host.insert(origin, pts, hit, miss, free)
+        model.insert(origin, pts, hit, miss, free)
+        assert model.grid_size == host.grid_size
+        hv = host.voxels()
+        want = sorted((int(r["x"]), int(r["y"]), int(r["z"]), int(r["value"])) for r in hv)
+        assert sorted(model.voxels()) == want
