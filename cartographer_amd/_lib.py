@@ -100,6 +100,7 @@ EXPORTED_SYMBOLS = [
     "cmx_cloud_destroy", "cmx_fast2d_match_full_submap_batch_resident", "cmx_fast2d_level_dims",
     "cmx_fast2d_level_cells", "cmx_fast2d_debug_prepare", "cmx_rt3d_match", "cmx_fast3d_create",
     "cmx_fast3d_destroy", "cmx_fast3d_match", "cmx_fast3d_match_full_submap",
+    "cmx_fast3d_match_batch",
     "cmx_fast3d_level_info", "cmx_fast3d_level_cells",
 ]
 
@@ -193,6 +194,9 @@ def lib():
     L.cmx_fast3d_match_full_submap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, P(NodeData3D),
                                                C.c_float, P(C.c_int32), P(Result3D),
                                                P(MatchStats)]
+    L.cmx_fast3d_match_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, P(NodeData3D), C.c_void_p,
+                                         C.c_void_p, P(MatchStats)]
     L.cmx_fast3d_level_info.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     L.cmx_fast3d_level_cells.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     _lib = L

@@ -274,9 +274,9 @@ class ConstraintBuilder3D:
     filter on the GLOBAL poses (:84-87), the per-submap ``FixedRatioSampler`` (:88-93), one
     matcher per ``SubmapId`` resident in HBM until ``DeleteScanMatcher``, ``Match`` /
     ``MatchFullSubmap`` with the two thresholds (:218-255), results in the order the pairs were
-    added (``RunWhenDoneCallback``).  Pairs run one after the other on the device today (the 3D
-    matcher has no batch entry point yet); the Ceres refinement (:263-276) is not
-    built, ``refine`` may stand in for it.
+    added (``RunWhenDoneCallback``).  ``NotifyEndOfNode`` hands the node's pairs to
+    ``cmx_fast3d_match_batch`` (searched concurrently on separate streams); the Ceres refinement
+    (:263-276) is not built, ``refine`` may stand in for it.
     """
 
     def __init__(self, options: ConstraintBuilderOptions3D, device: int = 0,
@@ -290,6 +290,7 @@ class ConstraintBuilder3D:
         self._pending = []
         self._num_finished_nodes = 0
         self.score_histogram: List[float] = []
+        self.last_batch_stats = None
 
     def maybe_add_constraint(self, submap_id, submap: Submap3D, node_id, constant_data,
                              global_node_pose, global_submap_pose) -> None:
@@ -351,21 +352,30 @@ class ConstraintBuilder3D:
                               node, sub))
 
     def _flush(self):
+        """The queued pairs of a node share its constant data: one cmx_fast3d_match_batch per
+        node (pairs searched concurrently on the device), in the order they were added."""
+        from .scan_matching_3d import Rigid3d, fast3d_match_batch
         pending, self._pending = self._pending, []
-        for slot, submap_id, node_id, constant_data, full, node, sub in pending:
-            matcher = self._scan_matchers[submap_id]
-            if full:
-                result = matcher.match_full_submap(node, sub, constant_data,
-                                                   self.options.global_localization_min_score)
-            else:
-                result = matcher.match(node, sub, constant_data, self.options.min_score)
-            if result is None:
-                continue                                   # `return;` at :232 / :253
-            self.score_histogram.append(result["score"])
-            pose = result["pose_estimate"]                 # already submap i <- node j
-            if self.refine is not None:
-                pose = self.refine(pose, constant_data)
-            self._constraints[slot] = Constraint3D(
-                submap_id, node_id, pose, self.options.loop_closure_translation_weight,
-                self.options.loop_closure_rotation_weight, result["score"],
-                result["rotational_score"], result["low_resolution_score"])
+        groups: Dict[int, list] = {}
+        for item in pending:
+            groups.setdefault(id(item[3]), []).append(item)
+        for items in groups.values():
+            constant_data = items[0][3]
+            as_pose = lambda v, full: Rigid3d((0.0, 0.0, 0.0), tuple(v)) if full else v   # noqa: E731
+            results, self.last_batch_stats = fast3d_match_batch(
+                [self._scan_matchers[i[1]] for i in items],
+                [as_pose(i[5], i[4]) for i in items], [as_pose(i[6], i[4]) for i in items],
+                [i[4] for i in items],
+                [self.options.global_localization_min_score if i[4] else self.options.min_score
+                 for i in items], constant_data)
+            for (slot, submap_id, node_id, _, full, node, sub), result in zip(items, results):
+                if result is None:
+                    continue                               # `return;` at :232 / :253
+                self.score_histogram.append(result["score"])
+                pose = result["pose_estimate"]             # already submap i <- node j
+                if self.refine is not None:
+                    pose = self.refine(pose, constant_data)
+                self._constraints[slot] = Constraint3D(
+                    submap_id, node_id, pose, self.options.loop_closure_translation_weight,
+                    self.options.loop_closure_rotation_weight, result["score"],
+                    result["rotational_score"], result["low_resolution_score"])

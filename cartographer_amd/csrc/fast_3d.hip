@@ -15,6 +15,9 @@
 // discretising every surviving yaw, scoring every lowest-resolution candidate,
 // and the branch and bound (one wave per node, eight children scored per
 // point), including the low-resolution verification of leaves.
+#include <atomic>
+#include <string>
+#include <thread>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -1172,6 +1175,64 @@ cmx_status cmx_fast3d_match_full_submap(const cmx_fast3d* matcher,
                 static_cast<float>(global_submap_rotation_wxyz[2]),
                 static_cast<float>(global_submap_rotation_wxyz[3])};
     Match3D(m, window, window, M_PI, node, submap, *data, min_score, found, result, stats);
+  });
+}
+
+// The ConstraintBuilder3D fan-out (constraints/constraint_builder_3d.cc:79-147): one node's
+// constant data against many submaps' matchers, windowed and full-submap pairs mixed.  The
+// reference runs one thread-pool task per pair; here the pairs run concurrently from a few host
+// threads, each on its own leased stream and scratch (the matchers are immutable, Match3D is
+// re-entrant), so the short dependent kernel chains of independent searches overlap on the
+// device.  `node_poses[p]` / `submap_poses[p]`: the global poses of pair p (only their rotations
+// are read where match_full_submap[p] != 0).
+cmx_status cmx_fast3d_match_batch(const cmx_fast3d* const* matchers, int32_t num_pairs,
+                                  const cmx_pose3d* node_poses, const cmx_pose3d* submap_poses,
+                                  const int32_t* match_full_submap, const float* min_scores,
+                                  const cmx_node_data3d* data, int32_t* found,
+                                  cmx_result3d* results, cmx_match_stats* stats) {
+  using namespace cmx;
+  return Guard([&] {
+    CMX_REQUIRE(matchers && node_poses && submap_poses && match_full_submap && min_scores &&
+                    data && found && results && num_pairs >= 1,
+                "null argument");
+    for (int p = 0; p < num_pairs; ++p) CMX_REQUIRE(matchers[p] != nullptr, "null matcher handle");
+    std::vector<cmx_match_stats> pair_stats(num_pairs);
+    std::vector<cmx_status> status(num_pairs, CMX_OK);
+    std::vector<std::string> errors(num_pairs);
+    std::atomic<int> next{0};
+    const auto worker = [&] {
+      for (int p = next.fetch_add(1); p < num_pairs; p = next.fetch_add(1)) {
+        found[p] = 0;
+        if (match_full_submap[p]) {
+          status[p] = cmx_fast3d_match_full_submap(matchers[p], node_poses[p].q,
+                                                   submap_poses[p].q, data, min_scores[p],
+                                                   &found[p], &results[p], &pair_stats[p]);
+        } else {
+          status[p] = cmx_fast3d_match(matchers[p], &node_poses[p], &submap_poses[p], data,
+                                       min_scores[p], &found[p], &results[p], &pair_stats[p]);
+        }
+        if (status[p] != CMX_OK) errors[p] = LastError();   // thread-local text of this worker
+      }
+    };
+    const int num_threads = std::min(num_pairs, 8);
+    std::vector<std::thread> threads;
+    for (int t = 1; t < num_threads; ++t) threads.emplace_back(worker);
+    worker();                                              // the calling thread takes its share
+    for (std::thread& t : threads) t.join();
+    cmx_match_stats total{};
+    for (int p = 0; p < num_pairs; ++p) {
+      if (status[p] != CMX_OK) {
+        SetLastError("pair %d: %s", p, errors[p].c_str());
+        throw HipError{status[p]};
+      }
+      total.candidates_scored += pair_stats[p].candidates_scored;
+      total.coarse_candidates += pair_stats[p].coarse_candidates;
+      total.nodes_expanded += pair_stats[p].nodes_expanded;
+      total.num_scans += pair_stats[p].num_scans;
+      total.device_ms += pair_stats[p].device_ms;          // summed: the searches overlap
+      total.dominant_kernel_ms += pair_stats[p].dominant_kernel_ms;
+    }
+    if (stats) *stats = total;
   });
 }
 

@@ -165,3 +165,39 @@ class FastCorrelativeScanMatcher3D:
         z, y, x = np.nonzero(cells)
         out = np.stack([x + lo[0], y + lo[1], z + lo[2], cells[z, y, x]], 1).astype(np.int32)
         return out
+
+
+def fast3d_match_batch(matchers, node_poses, submap_poses, match_full_submap, min_scores,
+                       constant_data):
+    """One node's data against many submaps' matchers (ConstraintBuilder3D's fan-out,
+    ``constraints/constraint_builder_3d.cc:79-147``) in one call: ``cmx_fast3d_match_batch`` runs
+    the pairs concurrently on separate streams.
+
+    ``node_poses[p]`` / ``submap_poses[p]`` are ``Rigid3d`` (only the rotations are read for
+    full-submap pairs).  Returns (list of result dicts or None per pair, stats dict).
+    """
+    num = len(matchers)
+    handles = (C.c_void_p * num)(*[m._h for m in matchers])
+    nodes = (Pose3d * num)(*[p.to_c() for p in node_poses])
+    submaps = (Pose3d * num)(*[p.to_c() for p in submap_poses])
+    full = np.ascontiguousarray([1 if f else 0 for f in match_full_submap], np.int32)
+    thresholds = np.ascontiguousarray(min_scores, np.float32)
+    assert full.shape[0] == num and thresholds.shape[0] == num
+    data = constant_data.to_c()
+    found = np.zeros(num, np.int32)
+    results = (Result3D * num)()
+    stats = MatchStats()
+    check(_lib.lib().cmx_fast3d_match_batch(
+        handles, num, C.cast(nodes, C.c_void_p), C.cast(submaps, C.c_void_p), full.ctypes.data,
+        thresholds.ctypes.data, C.byref(data), found.ctypes.data, C.cast(results, C.c_void_p),
+        C.byref(stats)))
+    out = []
+    for p in range(num):
+        if not found[p]:
+            out.append(None)
+            continue
+        r = results[p]
+        out.append(dict(score=float(r.score), pose_estimate=Rigid3d.from_c(r.pose_estimate),
+                        rotational_score=float(r.rotational_score),
+                        low_resolution_score=float(r.low_resolution_score)))
+    return out, stats.as_dict()

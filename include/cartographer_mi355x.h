@@ -325,6 +325,17 @@ cmx_status cmx_fast3d_match_full_submap(const cmx_fast3d* matcher,
                                         int32_t* found, cmx_result3d* result,
                                         cmx_match_stats* stats);
 
+/* ConstraintBuilder3D's fan-out for one node (constraints/constraint_builder_3d.cc:79-147):
+ * `data` against num_pairs matchers, pair p a windowed Match around node_poses[p] /
+ * submap_poses[p] or, where match_full_submap[p] != 0, a MatchFullSubmap with their rotations,
+ * against its own threshold min_scores[p].  The pairs are searched concurrently on separate
+ * streams; found[p] / results[p] as in the single calls; *stats summed. */
+cmx_status cmx_fast3d_match_batch(const cmx_fast3d* const* matchers, int32_t num_pairs,
+                                  const cmx_pose3d* node_poses, const cmx_pose3d* submap_poses,
+                                  const int32_t* match_full_submap, const float* min_scores,
+                                  const cmx_node_data3d* data, int32_t* found,
+                                  cmx_result3d* results, cmx_match_stats* stats);
+
 /* Introspection used by the parity tests: one precomputation level as a dense
  * brick (x fastest) with the cell index of its first element. */
 cmx_status cmx_fast3d_level_info(const cmx_fast3d* matcher, int32_t depth, int32_t* lo_xyz,

@@ -421,3 +421,53 @@ def test_rt3d_on_the_device_built_grid(synth, oracle):
     score, pose = m.match(sm3.Rigid3d(tuple(init[:3]), tuple(init[3:])), cloud, 0.1, dev.voxels())
     assert np.float32(score) == np.float32(ref["score"])
     np.testing.assert_array_equal(list(pose.translation) + list(pose.rotation), ref["pose"])
+
+
+def test_fast3d_batch_equals_individual(synth):
+    """cmx_fast3d_match_batch (pairs searched concurrently from host threads on separate streams)
+    returns, pair by pair, exactly what the single calls return -- windowed and full-submap pairs
+    mixed, per-pair thresholds, one pair that finds nothing; also twice in a row (the leased
+    workspaces are reused)."""
+    from cartographer_amd import scan_matching_3d as sm3
+    from test_oracle_reference_pins_3d import quat_from_angle_axis
+    hist = np.zeros(16, np.float32)
+    opt = dict(branch_and_bound_depth=5, full_resolution_depth=2, min_rotational_score=0.0,
+               min_low_resolution_score=0.2, linear_xy_search_window=1.0,
+               linear_z_search_window=0.4, angular_search_window=math.radians(10.0))
+    matchers, worlds = [], []
+    for k in range(3):
+        grid, world = synth.make_submap_3d(70 + k, 0.2, (8.0, 8.0, 3.0), 4, 8, 96)
+        vox = grid.voxels()
+        matchers.append(sm3.FastCorrelativeScanMatcher3D(0.2, vox, grid.grid_size, 0.2, vox, hist,
+                                                         **opt))
+        worlds.append(world)
+    pos = worlds[0].free_position(200, 0.6)
+    hi = worlds[0].scan(pos, 0.0, 6, 64, seed=0)
+    data = sm3.TrajectoryNodeData(hi, hi[::5].copy(), hist,
+                                  tuple(quat_from_angle_axis(0.01, [1, 0, 0])))
+    node = sm3.Rigid3d(tuple(pos + np.array([0.3, -0.2, 0.1])),
+                       tuple(quat_from_angle_axis(0.05, [0, 0, 1])))
+    ident = sm3.Rigid3d()
+    pairs = [(0, False, 0.12), (1, False, 0.12), (2, False, 0.99), (0, True, 0.12),
+             (1, True, 0.3), (2, False, 0.12), (0, False, 0.4)]
+    expected = []
+    for k, full, threshold in pairs:
+        if full:
+            expected.append(matchers[k].match_full_submap(node.rotation, ident.rotation, data,
+                                                          threshold))
+        else:
+            expected.append(matchers[k].match(node, ident, data, threshold))
+    assert any(e is not None for e in expected) and any(e is None for e in expected)
+    for _ in range(2):
+        got, stats = sm3.fast3d_match_batch([matchers[k] for k, _, _ in pairs],
+                                            [node] * len(pairs), [ident] * len(pairs),
+                                            [full for _, full, _ in pairs],
+                                            [t for _, _, t in pairs], data)
+        assert stats["candidates_scored"] > 0
+        for e, g in zip(expected, got):
+            assert (e is None) == (g is None)
+            if e is None:
+                continue
+            for key in ("score", "rotational_score", "low_resolution_score"):
+                assert np.float32(e[key]) == np.float32(g[key]), key
+            assert e["pose_estimate"] == g["pose_estimate"]
