@@ -145,6 +145,53 @@ def case_3d(rng, report):
                None if got is None else got["score"], (a["found"], a.get("score")))
 
 
+def case_grids(rng, report):
+    """Random range data into the device-resident grids (2D with a final crop, 3D) against the
+    host builders (which are pinned on the reference's own inserters)."""
+    from cartographer_amd import grid_2d, grid_3d, synth
+    res = float(rng.choice([0.05, 0.1, 0.25, 1.0]))
+    nx, ny = int(rng.integers(1, 12)), int(rng.integers(1, 12))
+    corner = (float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3)))
+    host = synth.ProbabilityGrid(res, corner, nx, ny)
+    dev = grid_2d.ProbabilityGridOnDevice(res, corner, nx, ny)
+    for _ in range(6):
+        origin = [corner[0] - rng.uniform(-2, 6) * res * 3, corner[1] - rng.uniform(-2, 6) * res * 3]
+        n = int(rng.integers(0, 40))
+        ang = rng.uniform(0, 2 * math.pi, n)
+        rad = rng.uniform(0, 40 * res, n) * (rng.uniform(size=n) > 0.1)
+        pts = np.zeros((n, 3), np.float32)
+        pts[:, 0] = origin[0] + rad * np.cos(ang)
+        pts[:, 1] = origin[1] + rad * np.sin(ang)
+        split = int(rng.integers(0, n + 1))
+        hit, miss = float(rng.uniform(0.51, 0.95)), float(rng.uniform(0.05, 0.49))
+        free = bool(rng.integers(0, 2))
+        host.insert(origin, pts[:split], pts[split:], hit, miss, free)
+        dev.insert(origin, pts[:split], pts[split:], hit, miss, free)
+        if host.limits != dev.limits or not np.array_equal(host.cells, dev.cells):
+            report("grid2d insert", dict(res=res, nx=nx, ny=ny, n=n), dev.limits, host.limits)
+            return
+    cropped = host.cropped()
+    dev.crop()
+    if cropped.limits != dev.limits or not np.array_equal(cropped.cells, dev.cells):
+        report("grid2d crop", dict(res=res, nx=nx, ny=ny), dev.limits, cropped.limits)
+    res3 = float(rng.choice([0.05, 0.1, 0.45, 1.0]))
+    h3, d3 = synth.HybridGrid(res3), grid_3d.HybridGridOnDevice(res3)
+    for _ in range(5):
+        origin = rng.uniform(-20, 20, 3).astype(np.float32) * np.float32(res3)
+        n = int(rng.integers(0, 60))
+        d = rng.normal(size=(n, 3))
+        d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-9)
+        rad = rng.uniform(0, 90 * res3, (n, 1)) * (rng.uniform(size=(n, 1)) > 0.1)
+        pts = (origin + d * rad).astype(np.float32)
+        hit, miss = float(rng.uniform(0.51, 0.95)), float(rng.uniform(0.05, 0.49))
+        free = int(rng.choice([0, 1, 2, 10, 60]))
+        h3.insert(origin, pts, hit, miss, free)
+        d3.insert(origin, pts, hit, miss, free)
+        if h3.grid_size != d3.grid_size or not np.array_equal(h3.voxels(), d3.voxels()):
+            report("grid3d insert", dict(res=res3, n=n, free=free), d3.grid_size, h3.grid_size)
+            return
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -159,7 +206,7 @@ def main():
     while time.time() - t0 < seconds:
         state = rng.bit_generator.state
         try:
-            (case_2d if cases % 2 == 0 else case_3d)(rng, report)
+            (case_2d, case_3d, case_grids)[cases % 3](rng, report)
         except CmxError as exc:            # an input the C ABI rejects is reported, not fatal
             print(f"REJECTED (case {cases}): {exc}", flush=True)
         except Exception as exc:           # noqa: BLE001
