@@ -356,7 +356,6 @@ def test_device_range_data_inserter_3d_reference_fixture(synth):
     host.insert(INSERTER_3D_ORIGIN, INSERTER_3D_RETURNS, 0.7, 0.4, 1000)
     _same_voxel_grid(dev, host)
     v = dev.voxels()
-    value_to_probability = {int(r["value"]): None for r in v}
     at = {(int(r["x"]), int(r["y"]), int(r["z"])): int(r["value"]) for r in v}
     assert (0, 0, -4) in at and (0, 0, -3) in at and (0, 0, -2) in at      # misses along a ray
     for x in range(-4, 5):
@@ -369,7 +368,6 @@ def test_device_range_data_inserter_3d_reference_fixture(synth):
         host.insert(INSERTER_3D_ORIGIN, INSERTER_3D_RETURNS, 0.7, 0.4, 1000)
     _same_voxel_grid(dev, host)
     assert abs(host.get_probability((-2, 0, 4)) - 0.9) < 1e-3               # saturated
-    del value_to_probability
 
 
 @pytest.mark.parametrize("seed,free", [(2, 2), (7, 0), (9, 40)])
