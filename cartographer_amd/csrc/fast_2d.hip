@@ -136,10 +136,15 @@ __global__ void BuildQuadsKernel(const uint8_t* __restrict__ level, int wx, int 
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 PrepScansKernel(const Fast2DProblem* __restrict__ problems, const float* __restrict__ xyz, int n,
-                ProblemState* __restrict__ states) {
+                ProblemState* __restrict__ states, int* __restrict__ counters_words,
+                int num_counter_words) {
+  // First kernel of a call: it also clears the list counters of the search (saves a
+  // memset and its launch gap).
+  if (blockIdx.x == 0 && blockIdx.y == 0 && counters_words)
+    for (int i = threadIdx.x; i < num_counter_words; i += blockDim.x) counters_words[i] = 0;
   const Fast2DProblem& P = problems[blockIdx.y];
   const int s = blockIdx.x;
-  if (s >= P.num_scans) return;
+  if (s >= P.num_scans || P.use_fused) return;
   const Quat q0{P.init_qw, 0.f, 0.f, P.init_qz};
   const float2 r = P.scan_rot[s];
   const Quat qs{r.x, 0.f, 0.f, r.y};
@@ -195,6 +200,9 @@ PrepScansKernel(const Fast2DProblem* __restrict__ problems, const float* __restr
     s_bounds = bd;
     s_dims = dims;
     if (bad) atomicMax(&states[blockIdx.y].error, 1);
+    const int count = dims.x * dims.y;
+    if (count > P.coarse_stride || (P.use_planes && count > kMaxCoarsePerScan))
+      atomicMax(&states[blockIdx.y].error, 2);
   }
   if (!P.use_planes) return;
 
@@ -266,52 +274,6 @@ PrepScansKernel(const Fast2DProblem* __restrict__ problems, const float* __restr
       sorted[pos] = make_uint2(static_cast<uint32_t>(plane) * P.plane_stride,
                                (block & 0xffu) * pitch + (block >> 8));
     }
-  }
-}
-
-// Exclusive prefix sum of per-scan candidate counts.
-__global__ void __launch_bounds__(1024)
-CoarseLayoutKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restrict__ states) {
-  const Fast2DProblem& P = problems[blockIdx.x];
-  __shared__ int partial[1024];
-  const int S = P.num_scans;
-  const int chunk = (S + 1023) / 1024;
-  const int begin = min(static_cast<int>(threadIdx.x) * chunk, S), end = min(begin + chunk, S);
-  int sum = 0, too_many = 0;
-  for (int s = begin; s < end; ++s) {
-    const int c = P.coarse_dims[s].x * P.coarse_dims[s].y;
-    if (P.use_planes && c > kMaxCoarsePerScan) too_many = 1;
-    sum += c;
-  }
-  partial[threadIdx.x] = sum;
-  if (too_many) atomicMax(&states[blockIdx.x].error, 2);
-  __syncthreads();
-  if (threadIdx.x < 64) {   // exclusive scan of the 1024 partials by one wave, 16 per lane
-    const int l = threadIdx.x;
-    int local[16];
-    int mine = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { local[k] = partial[16 * l + k]; mine += local[k]; }
-    int incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int o = __shfl_up(incl, off, 64);
-      if (l >= off) incl += o;
-    }
-    int run = incl - mine;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { partial[16 * l + k] = run; run += local[k]; }
-    if (l == 63) {
-      P.coarse_off[S] = incl;
-      states[blockIdx.x].coarse_total = incl;
-      if (incl > P.coarse_capacity) atomicMax(&states[blockIdx.x].error, 2);
-    }
-  }
-  __syncthreads();
-  int run = partial[threadIdx.x];
-  for (int s = begin; s < end; ++s) {
-    P.coarse_off[s] = run;
-    run += P.coarse_dims[s].x * P.coarse_dims[s].y;
   }
 }
 
@@ -387,7 +349,7 @@ ScoreCoarseGenericKernel(const Fast2DProblem* __restrict__ problems, int n,
   const int step = 1 << level;
   const int2 dims = P.coarse_dims[s];
   const int4 bd = P.bounds[s];
-  const int base = P.coarse_off[s];
+  const int base = s * P.coarse_stride;
   const uint32_t* scan = P.discrete + static_cast<size_t>(s) * n;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int count = dims.x * dims.y;
@@ -414,7 +376,7 @@ ScoreCoarsePlanesKernel(const Fast2DProblem* __restrict__ problems, int n,
                         const ProblemState* __restrict__ states) {
   const Fast2DProblem& P = problems[blockIdx.y];
   const int s = blockIdx.x;
-  if (s >= P.num_scans || states[blockIdx.y].error || !P.use_planes) return;
+  if (s >= P.num_scans || states[blockIdx.y].error || !P.use_planes || P.use_fused) return;
   if ((P.plane_stride >> 6) != CHUNKS) return;
   // Candidate accumulators, padded by the plane extent on every side: a lane's cell
   // (I, J) in lattice block (bx, by) belongs to candidate
@@ -513,7 +475,7 @@ ScoreCoarsePlanesKernel(const Fast2DProblem* __restrict__ problems, int n,
   if (cur >= 0) flush(cur);
   __syncthreads();
 
-  const int base = P.coarse_off[s];
+  const int base = s * P.coarse_stride;
   auto* coarse_sum = AsGlobal(P.coarse_sum) + base;
   auto* coarse_score = AsGlobal(P.coarse_score) + base;
   int best_sum = -1, best_index = 0x7ffffff;  // idle threads (sum -1) never win
@@ -541,7 +503,7 @@ ScoreCoarsePlanesDwordKernel(const Fast2DProblem* __restrict__ problems, int n,
                              const ProblemState* __restrict__ states) {
   const Fast2DProblem& P = problems[blockIdx.y];
   const int s = blockIdx.x;
-  if (s >= P.num_scans || states[blockIdx.y].error || !P.use_planes) return;
+  if (s >= P.num_scans || states[blockIdx.y].error || !P.use_planes || P.use_fused) return;
   if (P.plane_stride != 64) return;
   extern __shared__ int cand_acc[];
   __shared__ int2 scratch[4];
@@ -624,7 +586,7 @@ ScoreCoarsePlanesDwordKernel(const Fast2DProblem* __restrict__ problems, int n,
   if (cur >= 0) flush();
   __syncthreads();
 
-  const int base = P.coarse_off[s];
+  const int base = s * P.coarse_stride;
   auto* coarse_sum = AsGlobal(P.coarse_sum) + base;
   auto* coarse_score = AsGlobal(P.coarse_score) + base;
   int best_sum = -1, best_index = 0x7ffffff;  // idle threads (sum -1) never win
@@ -637,6 +599,262 @@ ScoreCoarsePlanesDwordKernel(const Fast2DProblem* __restrict__ problems, int n,
   }
   const int2 best = BlockBest(best_sum, best_index, scratch);
   if (threadIdx.x == 0) P.scan_best[s] = best;
+}
+
+// ---------------------------------------------------------------------------
+// Fused front end (the usual case: 64-byte phase planes, the scan fits in LDS)
+// ---------------------------------------------------------------------------
+// One block per rotated scan does everything the reference does for that scan before
+// branch and bound -- GenerateRotatedScans + DiscretizeScans + ShrinkToFit
+// (SM2/correlative_scan_matcher_2d.cc:73-127), GenerateLowestResolutionCandidates and
+// their ScoreCandidates (SM2/fast_correlative_scan_matcher_2d.cc:264-333) -- with the
+// discretised scan and the bucketed plane records staged in LDS only.  As separate
+// launches the same work wrote 27 MB per match (discrete scans + 64-bit records) and the
+// scorer fetched 20 MB of it back; here a scan's 4-byte cells go to HBM only when one of
+// its lowest-resolution candidates can still reach min_score (the tree search reads
+// them), and the per-scan candidate layout needs no prefix sum: scan s owns
+// [s * coarse_stride, (s + 1) * coarse_stride).
+// Arithmetic is PrepScansKernel's + ScoreCoarsePlanesDwordKernel's, operation for
+// operation (bit-exact discretisation, integer sums).
+// Dynamic LDS: rec[n_pad] u64 | pts[n_pad] u32 | hist[nb_cap] | partial[256] | misc[32] |
+// cand_acc[acc_cap].
+constexpr int kFusedMaxPoints = 4096;
+
+__global__ void __launch_bounds__(256)
+PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __restrict__ xyz,
+                     int n, ProblemState* __restrict__ states, int nb_cap, int acc_cap,
+                     int* __restrict__ counters_words, int num_counter_words) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fused_smem[];
+  // First kernel of a fully fused batch: it also clears the list counters of the search.
+  if (blockIdx.x == 0 && blockIdx.y == 0 && counters_words)
+    for (int i = threadIdx.x; i < num_counter_words; i += blockDim.x) counters_words[i] = 0;
+  const Fast2DProblem& P = problems[blockIdx.y];
+  const int s = blockIdx.x;
+  if (!P.use_fused || s >= P.num_scans) return;
+  const int n_pad = (n + 63) & ~63;
+  auto* rec = reinterpret_cast<unsigned long long*>(fused_smem);
+  auto* pts = reinterpret_cast<uint32_t*>(rec + n_pad);
+  int* hist = reinterpret_cast<int*>(pts + n_pad);
+  int* partial = hist + nb_cap;
+  int* misc = partial + 256;
+  int* cand_acc = misc + 32;
+  const int T = blockDim.x;              // 128, 192 or 256
+  const int waves = T >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+  // ---- rotate, translate, discretise (as PrepScansKernel) -------------------
+  const Quat q0{P.init_qw, 0.f, 0.f, P.init_qz};
+  const float2 r = P.scan_rot[s];
+  const Quat qs{r.x, 0.f, 0.f, r.y};
+  int lo_x = 0, lo_y = 0, hi_x = 0, hi_y = 0, bad = 0;
+  for (int i = threadIdx.x; i < n; i += T) {
+    const F3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    F3 a = Rotate(q0, p);
+    a.x += 0.f; a.y += 0.f; a.z += 0.f;
+    F3 b = Rotate(qs, a);
+    b.x += 0.f; b.y += 0.f;
+    const float x = (1.f * b.x + 0.f * b.y) + P.tx;
+    const float y = (0.f * b.x + 1.f * b.y) + P.ty;
+    const int ix = CellIndexF64(P.max_y - static_cast<double>(y), P.res, P.inv_res);
+    const int iy = CellIndexF64(P.max_x - static_cast<double>(x), P.res, P.inv_res);
+    if (ix < -32768 || ix > 32767 || iy < -32768 || iy > 32767) bad = 1;
+    pts[i] = (static_cast<uint32_t>(ix) & 0xffffu) | (static_cast<uint32_t>(iy) << 16);
+    lo_x = min(lo_x, -ix);
+    lo_y = min(lo_y, -iy);
+    hi_x = max(hi_x, P.nx - 1 - ix);
+    hi_y = max(hi_y, P.ny - 1 - iy);
+  }
+  lo_x = WaveMin(lo_x); lo_y = WaveMin(lo_y);
+  hi_x = WaveMax(hi_x); hi_y = WaveMax(hi_y);
+  bad = WaveMax(bad);
+  if (lane == 0) {
+    int* red = partial + wave * 5;       // partial[] is free until the bucket scan
+    red[0] = lo_x; red[1] = lo_y; red[2] = hi_x; red[3] = hi_y; red[4] = bad;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < waves; ++w) {
+      const int* red = partial + w * 5;
+      lo_x = min(lo_x, red[0]); lo_y = min(lo_y, red[1]);
+      hi_x = max(hi_x, red[2]); hi_y = max(hi_y, red[3]);
+      bad = max(bad, red[4]);
+    }
+    int4 bd;   // ShrinkToFit
+    bd.x = max(-P.nl, lo_x);
+    bd.y = min(P.nl, hi_x);
+    bd.z = max(-P.nl, lo_y);
+    bd.w = min(P.nl, hi_y);
+    P.bounds[s] = bd;
+    const int step = 1 << (P.depth - 1);
+    const int2 dims = make_int2((bd.y - bd.x + step) / step, (bd.w - bd.z + step) / step);
+    P.coarse_dims[s] = dims;
+    misc[0] = bd.x; misc[1] = bd.y; misc[2] = bd.z; misc[3] = bd.w;
+    misc[4] = dims.x; misc[5] = dims.y;
+    if (bad) atomicMax(&states[blockIdx.y].error, 1);
+    const int count = dims.x * dims.y;
+    const int BW = dims.x + P.plane_i - 1, BH = dims.y + P.plane_j - 1;
+    const int ok = count <= P.coarse_stride && count <= kMaxCoarsePerScan && BW * BH <= nb_cap &&
+                   BW <= 255 && BH <= 255 &&
+                   (dims.x + 2 * P.plane_i - 2) * (dims.y + 2 * P.plane_j - 2) <= acc_cap;
+    misc[6] = ok;
+    if (!ok) {
+      atomicMax(&states[blockIdx.y].error, 2);
+      P.scan_best[s] = make_int2(0, 0);
+    }
+  }
+  __syncthreads();
+  if (!misc[6]) return;
+  const int4 bd = make_int4(misc[0], misc[1], misc[2], misc[3]);
+  const int2 dims = make_int2(misc[4], misc[5]);
+  const int count = dims.x * dims.y;
+  const int PI = P.plane_i, PJ = P.plane_j, PIJ = PI * PJ;
+  const int pitch = dims.y + 2 * PJ - 2;
+  const int acc_cells = (dims.x + 2 * PI - 2) * pitch;
+
+  // ---- bucket the points by lattice block (as PrepScansKernel), records to LDS --------
+  const int shift = P.depth - 1, w = 1 << shift;
+  const int BW = dims.x + PI - 1, BH = dims.y + PJ - 1;
+  const int NB = BW * BH;
+  for (int b = threadIdx.x; b < NB; b += T) hist[b] = 0;
+  for (int i = threadIdx.x; i < acc_cells; i += T) cand_acc[i] = 0;
+  __syncthreads();
+  auto classify = [&](uint32_t packed, int* bucket, int* plane, uint32_t* block = nullptr) {
+    const int U = static_cast<short>(packed & 0xffffu) + bd.x + w - 1;
+    const int V = static_cast<short>(packed >> 16) + bd.z + w - 1;
+    const int bx = (U >> shift) + dims.x - 1, by = (V >> shift) + dims.y - 1;
+    *plane = (V & (w - 1)) * w + (U & (w - 1));
+    *bucket = (bx >= 0 && bx < BW && by >= 0 && by < BH) ? by * BW + bx : -1;
+    if (block) *block = static_cast<uint32_t>(bx) | (static_cast<uint32_t>(by) << 8);
+  };
+  for (int i = threadIdx.x; i < n; i += T) {
+    int bucket, plane;
+    classify(pts[i], &bucket, &plane);
+    if (bucket >= 0) atomicAdd(&hist[bucket], 1);
+  }
+  __syncthreads();
+  const int chunk = (NB + T - 1) / T;
+  const int b0 = min(static_cast<int>(threadIdx.x) * chunk, NB), b1 = min(b0 + chunk, NB);
+  int sum = 0;
+  for (int b = b0; b < b1; ++b) sum += hist[b];
+  partial[threadIdx.x] = sum;
+  if (threadIdx.x + T < 256) partial[threadIdx.x + T] = 0;     // T >= 128
+  __syncthreads();
+  if (threadIdx.x < 64) {   // exclusive scan of the 256 partials by one wave, 4 per lane
+    const int l = threadIdx.x;
+    const int a0 = partial[4 * l], a1 = partial[4 * l + 1], a2 = partial[4 * l + 2],
+              a3 = partial[4 * l + 3];
+    const int mine = a0 + a1 + a2 + a3;
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off, 64);
+      if (l >= off) incl += o;
+    }
+    const int base = incl - mine;
+    partial[4 * l] = base;
+    partial[4 * l + 1] = base + a0;
+    partial[4 * l + 2] = base + a0 + a1;
+    partial[4 * l + 3] = base + a0 + a1 + a2;
+    if (l == 63) misc[7] = incl;
+  }
+  __syncthreads();
+  int run = partial[threadIdx.x];
+  for (int b = b0; b < b1; ++b) { const int v = hist[b]; hist[b] = run; run += v; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += T) {
+    int bucket, plane;
+    uint32_t block;
+    classify(pts[i], &bucket, &plane, &block);
+    if (bucket >= 0) {
+      const int pos = atomicAdd(&hist[bucket], 1);
+      rec[pos] = (static_cast<unsigned long long>((block & 0xffu) * pitch + (block >> 8)) << 32) |
+                 static_cast<uint32_t>(plane * 64);
+    }
+  }
+  __syncthreads();
+
+  // ---- score (as ScoreCoarsePlanesDwordKernel), records from LDS ---------------------
+  const int group = lane >> 4, sub = lane & 15;
+  const int M = misc[7];
+  const int begin = static_cast<int>(static_cast<long long>(M) * wave / waves);
+  const int end = static_cast<int>(static_cast<long long>(M) * (wave + 1) / waves);
+  const unsigned zero_plane = 1u << (2 * (P.depth - 1));
+  int lane_const[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int cell = min(4 * sub + j, PIJ - 1);
+    lane_const[j] = (cell % PI + dims.x + PI - 2) * pitch + (cell / PI + dims.y + PJ - 2);
+  }
+  int cur = -1, pending = 0;
+  uint32_t even = 0, odd = 0;
+  const auto flush = [&]() {
+    const int a0 = even & 0xffffu, a2 = even >> 16, a1 = odd & 0xffffu, a3 = odd >> 16;
+    if (a0) atomicAdd(&cand_acc[lane_const[0] - cur], a0);
+    if (a1) atomicAdd(&cand_acc[lane_const[1] - cur], a1);
+    if (a2) atomicAdd(&cand_acc[lane_const[2] - cur], a2);
+    if (a3) atomicAdd(&cand_acc[lane_const[3] - cur], a3);
+    even = odd = 0;
+    pending = 0;
+  };
+  constexpr int kSteps = 8;
+  const unsigned long long sentinel = (0xffffffffull << 32) | (zero_plane * 64u);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(P.planes), 0, static_cast<int>((zero_plane + 1) * 64), 0x00020000);
+  for (int base_i = begin; base_i < end; base_i += 64) {
+    const unsigned long long mine = base_i + lane < end ? rec[base_i + lane] : sentinel;
+#pragma unroll
+    for (int t0 = 0; t0 < 16; t0 += kSteps) {
+      if (base_i + 4 * t0 >= end) break;      // wave-uniform
+      int block[kSteps];
+      uint32_t q[kSteps];
+#pragma unroll
+      for (int k = 0; k < kSteps; ++k) {
+        const int src = 4 * (t0 + k) + group;
+        const int plane_offset = __shfl(static_cast<int>(mine & 0xffffffffu), src, 64);
+        block[k] = __shfl(static_cast<int>(mine >> 32), src, 64);
+        q[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, plane_offset + 4 * sub, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < kSteps; ++k) {
+        if (block[k] != cur) {
+          if (cur >= 0) flush();
+          cur = block[k];
+        }
+        even += q[k] & 0x00ff00ffu;
+        odd += (q[k] >> 8) & 0x00ff00ffu;
+        if (++pending == 256) flush();
+      }
+    }
+  }
+  if (cur >= 0) flush();
+  __syncthreads();
+
+  const int base = s * P.coarse_stride;
+  auto* coarse_sum = AsGlobal(P.coarse_sum) + base;
+  auto* coarse_score = AsGlobal(P.coarse_score) + base;
+  int best_sum = -1, best_index = 0x7ffffff;
+  for (int i = threadIdx.x; i < count; i += T) {
+    const int ix = i / dims.y, iy = i - ix * dims.y;
+    const int csum = cand_acc[(ix + PI - 1) * pitch + (iy + PJ - 1)];
+    coarse_sum[i] = csum;
+    coarse_score[i] = ToScore(P, csum, n);
+    if (csum > best_sum) { best_sum = csum; best_index = i; }
+  }
+  int2* scratch = reinterpret_cast<int2*>(misc + 8);      // [4]
+  const int2 best = BlockBest(best_sum, best_index, scratch);
+  if (threadIdx.x == 0) {
+    P.scan_best[s] = best;
+    misc[16] = P.write_all_discrete ||
+               ToScore(P, best.x, n) >= fmaxf(P.min_score, 0.f);
+  }
+  __syncthreads();
+  // The tree search reads a scan's cells only below lowest-resolution nodes that reach
+  // the bound, and the bound never drops below max(min_score, 0).
+  if (misc[16]) {
+    auto* out = AsGlobal(P.discrete) + static_cast<size_t>(s) * n;
+    for (int i = threadIdx.x; i < n; i += T) out[i] = pts[i];
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -688,7 +906,7 @@ __device__ __forceinline__ Node2D CoarseNode(const Fast2DProblem& P, int problem
   const int4 bd = P.bounds[s];
   const int step = 1 << (P.depth - 1);
   const int ix = local / dims.y, iy = local - ix * dims.y;
-  const int c = P.coarse_off[s] + local;
+  const int c = s * P.coarse_stride + local;
   Node2D nd;
   nd.problem = problem | ((P.depth - 1) << 24);
   nd.scan = s;
@@ -701,54 +919,99 @@ __device__ __forceinline__ Node2D CoarseNode(const Fast2DProblem& P, int problem
   return nd;
 }
 
-// Seeds of the dive: the best candidate of each of the ~64 best scans, chosen
-// with a histogram threshold on the per-scan maxima.
-__global__ void __launch_bounds__(1024)
-SeedSelectKernel(const Fast2DProblem* __restrict__ problems,
-                 const ProblemState* __restrict__ states, int n, Node2D* __restrict__ seeds,
-                 int* __restrict__ seed_count, int* __restrict__ counters_words,
-                 int num_counter_words) {
-  // First kernel of the search: it also clears the list counters (saves a memset
-  // and its launch gap).
-  if (blockIdx.x == 0)
-    for (int i = threadIdx.x; i < num_counter_words; i += blockDim.x) counters_words[i] = 0;
-  const int problem = blockIdx.x;
-  const Fast2DProblem& P = problems[problem];
-  __shared__ int hist[1024];
-  __shared__ int threshold_bin;
-  __shared__ int taken;
-  hist[threadIdx.x] = 0;
-  if (threadIdx.x == 0) { taken = 0; seed_count[problem] = 0; }
-  if (states[problem].error) return;
+// Seeds of the dive: the best candidate of each of the ~64 best scans (histogram
+// threshold on the per-scan maxima).  Every dive block repeats the selection for its own
+// problem -- 18 KB of per-scan maxima, L2-resident after the first block -- and takes
+// seed number `want` in scan order: no separate launch (a kernel that does this alone
+// costs ~5 us plus its boundary), no cross-block hand-off.  When want == 0 the block also
+// totals the problem's lowest-resolution candidates (the layout needs no prefix sum).
+struct SeedScratch {
+  int hist[1024];
+  int wave_total[4];
+  int threshold_bin;
+  int found_scan;
+  int total;
+};
+
+__device__ __forceinline__ bool PickSeed(const Fast2DProblem& P, int n, int want,
+                                         SeedScratch* sh, int* scan_out) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < 1024; i += blockDim.x) sh->hist[i] = 0;
+  if (tid == 0) { sh->found_scan = -1; sh->total = 0; }
   __syncthreads();
   const int S = P.num_scans;
   const long long range = 255ll * n + 1;
-  for (int s = threadIdx.x; s < S; s += blockDim.x) {
-    atomicAdd(&hist[static_cast<int>(P.scan_best[s].x * 1024ll / range)], 1);
+  const int chunk = (S + static_cast<int>(blockDim.x) - 1) / static_cast<int>(blockDim.x);
+  const int s0 = min(tid * chunk, S), s1 = min(s0 + chunk, S);
+  const auto* scan_best = AsGlobal(P.scan_best);
+  int total = 0;
+  for (int s = s0; s < s1; ++s) {
+    atomicAdd(&sh->hist[static_cast<int>(scan_best[s].x * 1024ll / range)], 1);
+    if (want == 0) total += P.coarse_dims[s].x * P.coarse_dims[s].y;
+  }
+  if (want == 0) {
+    total = WaveSum(total);
+    if (lane == 0 && total) atomicAdd(&sh->total, total);
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int acc = 0, b = 1023;
-    for (; b > 0; --b) {
-      acc += hist[b];
-      if (acc >= kSeedsPerProblem) break;
+  if (tid < 64) {
+    // Highest bin b >= 1 with (number of scans in bins >= b) >= kSeedsPerProblem, else 0.
+    // Lane l owns bins 1023 - 16 l down to 1008 - 16 l.
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mine += sh->hist[1023 - 16 * lane - k];
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
     }
-    threshold_bin = b;
-  }
-  __syncthreads();
-  const int tb = threshold_bin;
-  for (int s = threadIdx.x; s < S; s += blockDim.x) {
-    const int2 best = P.scan_best[s];
-    if (static_cast<int>(best.x * 1024ll / range) >= tb &&
-        ToScore(P, best.x, n) > P.min_score) {
-      const int slot = atomicAdd(&taken, 1);
-      if (slot < kSeedsPerProblem) {
-        seeds[problem * kSeedsPerProblem + slot] = CoarseNode(P, problem, s, best.y);
+    const unsigned long long reached = __ballot(incl >= kSeedsPerProblem);
+    int tb = 0;
+    if (reached) {
+      const int first = __ffsll(static_cast<long long>(reached)) - 1;
+      if (lane == first) {
+        int acc = incl - mine;
+        for (int k = 0; k < 16; ++k) {
+          const int b = 1023 - 16 * lane - k;
+          acc += sh->hist[b];
+          if (acc >= kSeedsPerProblem) { tb = b; break; }   // b == 0 only in lane 63: tb = 0
+        }
+        sh->threshold_bin = tb;
       }
+    } else if (lane == 0) {
+      sh->threshold_bin = 0;
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) seed_count[problem] = min(taken, kSeedsPerProblem);
+  const int tb = sh->threshold_bin;
+  const auto qualifies = [&](int s) {
+    const int best = scan_best[s].x;
+    return static_cast<int>(best * 1024ll / range) >= tb && ToScore(P, best, n) > P.min_score;
+  };
+  int count = 0;
+  for (int s = s0; s < s1; ++s) count += qualifies(s) ? 1 : 0;
+  int incl = count;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) sh->wave_total[tid >> 6] = incl;
+  __syncthreads();
+  int before = incl - count;
+  for (int w = 0; w < (tid >> 6); ++w) before += sh->wave_total[w];
+  if (want >= before && want < before + count) {
+    int k = before;
+    for (int s = s0; s < s1; ++s) {
+      if (!qualifies(s)) continue;
+      if (k == want) { sh->found_scan = s; break; }
+      ++k;
+    }
+  }
+  __syncthreads();
+  *scan_out = sh->found_scan;
+  return sh->found_scan >= 0;
 }
 
 // Problem- and scan-invariant data a block keeps on chip while it works on
@@ -892,16 +1155,20 @@ __device__ __forceinline__ void RecordLeaf(const Node2D& leaf, const NodeList& l
 // reached is a real candidate, so its score is a valid bound.
 __global__ void __launch_bounds__(256, 4)
 DiveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restrict__ states, int n,
-           const Node2D* __restrict__ seeds, const int* __restrict__ seed_count,
            NodeList leaves, Counters* __restrict__ counters) {
   const int problem = blockIdx.y;
-  if (blockIdx.x >= seed_count[problem]) return;
   const Fast2DProblem& P = problems[problem];
   ProblemState& st = states[problem];
+  if (st.error) return;
   __shared__ BlockContext ctx;
   __shared__ ChildScratch sh;
   __shared__ Node2D cur;
-  const Node2D seed = seeds[problem * kSeedsPerProblem + blockIdx.x];
+  __shared__ SeedScratch seed_scratch;
+  int seed_scan;
+  const bool have_seed = PickSeed(P, n, blockIdx.x, &seed_scratch, &seed_scan);
+  if (blockIdx.x == 0 && threadIdx.x == 0) st.coarse_total = seed_scratch.total;
+  if (!have_seed) return;
+  const Node2D seed = CoarseNode(P, problem, seed_scan, P.scan_best[seed_scan].y);
   if (threadIdx.x == 0) cur = seed;
   LoadContext(P, n, seed.scan, &ctx);
   const int depth = NodeLevel(seed) + 1;
@@ -946,7 +1213,7 @@ FilterCoarseKernel(const Fast2DProblem* __restrict__ problems,
   if (strict ? !(top > best) : (top < best)) return;
   const int2 dims = P.coarse_dims[s];
   const int count = dims.x * dims.y;
-  const int base = P.coarse_off[s];
+  const int base = s * P.coarse_stride;
   const int lane = threadIdx.x & 63;
   for (int c0 = 0; c0 < count; c0 += blockDim.x) {
     // One reservation per wave; consecutive waves use consecutive sub-lists, so that one
@@ -1373,11 +1640,15 @@ SelectDepthOneKernel(const Fast2DProblem* __restrict__ problems,
                      const ProblemState* __restrict__ states, int n, BestLeaf* __restrict__ best,
                      ProblemState* __restrict__ states_out) {
   const int problem = blockIdx.x;
-  if (threadIdx.x == 0) states_out[problem] = states[problem];
   const Fast2DProblem& P = problems[problem];
   __shared__ unsigned long long keys[16];
+  __shared__ int s_total;
+  if (threadIdx.x == 0) s_total = 0;
+  __syncthreads();
   unsigned long long key = 0;
+  int total = 0;
   for (int s = threadIdx.x; s < P.num_scans; s += blockDim.x) {
+    total += P.coarse_dims[s].x * P.coarse_dims[s].y;
     const int2 b = P.scan_best[s];
     // larger sum first, then smaller scan index (generation order)
     const unsigned long long k = (static_cast<unsigned long long>(static_cast<unsigned>(b.x)) << 32) |
@@ -1385,9 +1656,16 @@ SelectDepthOneKernel(const Fast2DProblem* __restrict__ problems,
     key = k > key ? k : key;
   }
   key = WaveMaxU64(key);
-  if ((threadIdx.x & 63) == 0) keys[threadIdx.x >> 6] = key;
+  total = WaveSum(total);
+  if ((threadIdx.x & 63) == 0) {
+    keys[threadIdx.x >> 6] = key;
+    if (total) atomicAdd(&s_total, total);
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
+    ProblemState st = states[problem];
+    st.coarse_total = s_total;
+    states_out[problem] = st;
     for (int w = 1; w < 16; ++w) key = keys[w] > key ? keys[w] : key;
     BestLeaf b{};
     if (!states[problem].error && P.num_scans > 0) {
@@ -1510,35 +1788,35 @@ Fast2DMatcher::~Fast2DMatcher() {
   if (stack_mem_) (void)hipFree(stack_mem_);
   if (quads_mem_) (void)hipFree(quads_mem_);
   if (planes_) (void)hipFree(planes_);
-  for (RotationEntry& e : rotation_tables_) (void)hipFree(e.table);
 }
 
-const float2* Fast2DMatcher::RotationTable(double step, int num_angular) const {
-  std::lock_guard<std::mutex> lock(rotation_mutex_);
-  for (const RotationEntry& e : rotation_tables_)
-    if (e.step == step && e.num_angular == num_angular) return e.table;
+std::shared_ptr<const std::vector<float2>> HostRotationTable(double step, int num_angular) {
+  struct Entry {
+    double step;
+    int num_angular;
+    std::shared_ptr<const std::vector<float2>> table;
+  };
+  static std::mutex mu;
+  static std::vector<Entry>* cache = new std::vector<Entry>;   // most recent last
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    for (size_t i = cache->size(); i-- > 0;) {
+      if ((*cache)[i].step == step && (*cache)[i].num_angular == num_angular)
+        return (*cache)[i].table;
+    }
+  }
   const int num_scans = 2 * num_angular + 1;
-  std::vector<float2> host(num_scans);
+  auto table = std::make_shared<std::vector<float2>>(num_scans);
   // delta_theta accumulates in f64, each angle is narrowed to f32 for AngleAxisf.
   double delta_theta = -num_angular * step;
   for (int s = 0; s < num_scans; ++s, delta_theta += step) {
     const float ha = 0.5f * static_cast<float>(delta_theta);
-    host[s] = make_float2(std::cos(ha), std::sin(ha) * 1.f);
+    (*table)[s] = make_float2(std::cos(ha), std::sin(ha) * 1.f);
   }
-  RotationEntry e{step, num_angular, nullptr};
-  CMX_HIP(hipMalloc(reinterpret_cast<void**>(&e.table), num_scans * sizeof(float2)));
-  const hipError_t err =
-      hipMemcpy(e.table, host.data(), num_scans * sizeof(float2), hipMemcpyHostToDevice);
-  if (err != hipSuccess) {
-    (void)hipFree(e.table);
-    CMX_HIP(err);
-  }
-  if (rotation_tables_.size() >= 64) {   // bound the cache
-    (void)hipFree(rotation_tables_.front().table);
-    rotation_tables_.erase(rotation_tables_.begin());
-  }
-  rotation_tables_.push_back(e);
-  return e.table;
+  std::lock_guard<std::mutex> lock(mu);
+  if (cache->size() >= 64) cache->erase(cache->begin());      // bound the cache
+  cache->push_back(Entry{step, num_angular, table});
+  return table;
 }
 
 namespace {
@@ -1585,7 +1863,41 @@ struct PreparedBatch {
   Fast2DProblem* d_problems = nullptr;
   ProblemState* d_states = nullptr;
   std::vector<Fast2DProblem> h_problems;
+  // Search scratch carved before the first kernel so that it can clear the counters.
+  char* d_misc = nullptr;          // Counters | SelectState[num] | BestLeaf[num] | ProblemState[num]
+  bool write_all_discrete = false; // debug entry point: keep every discretised scan
 };
+
+// CMX_FUSED=0 routes every problem through the separate prep / score launches (the
+// fallback of problems the fused kernel does not take); parity tests run both.
+bool FusedEnabled() {
+  const char* e = getenv("CMX_FUSED");
+  return !(e && e[0] == '0');
+}
+
+// Blocks of PrepScoreFusedKernel the whole chip holds at once (occupancy query, cached).
+long long FusedResidentBlocks(int device, int threads, size_t lds_bytes) {
+  struct Key { int device, threads; size_t lds; long long blocks; };
+  static std::mutex mu;
+  static std::vector<Key>* cache = new std::vector<Key>;
+  const size_t lds = (lds_bytes + 1023) & ~size_t(1023);
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Key& k : *cache)
+      if (k.device == device && k.threads == threads && k.lds == lds) return k.blocks;
+  }
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, PrepScoreFusedKernel, threads, lds) !=
+          hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  const long long blocks = static_cast<long long>(per_cu) * cus;
+  std::lock_guard<std::mutex> lock(mu);
+  if (cache->size() < 256) cache->push_back(Key{device, threads, lds, blocks});
+  return blocks;
+}
 
 // Uploads problem descriptors, carves scratch and runs the preparation +
 // lowest-resolution scoring kernels.  `d_xyz` is the device point cloud.
@@ -1606,6 +1918,16 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
 
   // Per-problem search parameters and scratch sizes.
   size_t discrete_total = 0, scans_total = 0, coarse_total = 0;
+  // Rotation tables (host libm values, cached process-wide) of the distinct
+  // (step, num_angular) pairs of this batch; they travel in the problem upload.
+  struct Rotation { double step; int num_angular; std::shared_ptr<const std::vector<float2>> table; size_t offset; };
+  std::vector<Rotation> rotations;
+  std::vector<int> rotation_of(num);
+  size_t rotation_floats = 0;
+  const bool fused_enabled = FusedEnabled();
+  const int n_pad = (n + 63) & ~63;
+  long long fused_nb = 0, fused_acc = 0;
+  bool any_fused = false, any_unfused = false;
   for (int p = 0; p < num; ++p) {
     const Fast2DMatcher& m = *matchers[p];
     const cmx_grid2d_limits& lim = m.limits();
@@ -1626,6 +1948,16 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
                 h.num_scans);
     out->search[p] = h;
     out->initial[p] = init;
+    int r = -1;
+    for (size_t k = 0; k < rotations.size(); ++k)
+      if (rotations[k].step == h.step && rotations[k].num_angular == h.num_angular) r = static_cast<int>(k);
+    if (r < 0) {
+      r = static_cast<int>(rotations.size());
+      rotations.push_back(Rotation{h.step, h.num_angular, HostRotationTable(h.step, h.num_angular),
+                                   rotation_floats});
+      rotation_floats += 2 * static_cast<size_t>(h.num_scans);
+    }
+    rotation_of[p] = r;
     discrete_total += static_cast<size_t>(h.num_scans) * n;
     scans_total += h.num_scans + 1;
     // Upper bound of lowest-resolution candidates per scan: the shrunk window
@@ -1641,35 +1973,55 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     CMX_REQUIRE(cap < (1ll << 30), "search too large: %lld lowest-resolution candidates", cap);
     Fast2DProblem& P = out->h_problems[p];
     P.coarse_capacity = static_cast<int>(cap);
+    P.coarse_stride = static_cast<int>(ax * ay);
     P.use_planes = m.planes() != nullptr && ax * ay <= kMaxCoarsePerScan &&
                    (ax + m.plane_i() - 1) * (ay + m.plane_j() - 1) <= kMaxBuckets &&
                    ax + m.plane_i() - 1 <= 255 && ay + m.plane_j() - 1 <= 255 &&   // 8-bit bx, by
                    (ax + 2 * m.plane_i() - 2) * (ay + 2 * m.plane_j() - 2) <= kMaxAccCells &&
                    m.depth() > 1;
+    const long long nb = (ax + m.plane_i() - 1) * (ay + m.plane_j() - 1);
+    const long long acc = (ax + 2 * m.plane_i() - 2) * (ay + 2 * m.plane_j() - 2);
     if (P.use_planes)
-      out->plane_acc_cells = std::max<long long>(
-          out->plane_acc_cells, (ax + 2 * m.plane_i() - 2) * (ay + 2 * m.plane_j() - 2));
+      out->plane_acc_cells = std::max<long long>(out->plane_acc_cells, acc);
+    // Fused front end: 64-byte planes, the scan + its records + the accumulators within
+    // the 64 KB of dynamic LDS a launch gets without opting in to more.
+    P.use_fused = fused_enabled && P.use_planes && m.plane_stride() == 64 &&
+                  n <= kFusedMaxPoints &&
+                  12ll * n_pad + 4 * (((nb + 3) & ~3ll) + 256 + 32 + acc) <= 64 * 1024;
+    if (P.use_fused) {
+      any_fused = true;
+      fused_nb = std::max(fused_nb, (nb + 3) & ~3ll);
+      fused_acc = std::max(fused_acc, acc);
+    } else {
+      any_unfused = true;
+    }
+    P.write_all_discrete = out->write_all_discrete ? 1 : 0;
     coarse_total += cap;
   }
 
-  // Scratch carving.
-  uint32_t* d_discrete = ws.dev[2].ReserveAs<uint32_t>(3 * discrete_total);
+  // Scratch carving.  The bucketed records exist in HBM only for unfused problems.
+  uint32_t* d_discrete =
+      ws.dev[2].ReserveAs<uint32_t>(discrete_total + (any_unfused ? 2 * discrete_total + 2 : 0));
   uint2* d_sorted = reinterpret_cast<uint2*>(d_discrete + discrete_total + (discrete_total & 1));
   int4* d_bounds = ws.dev[3].ReserveAs<int4>(scans_total);
   int2* d_dims = ws.dev[4].ReserveAs<int2>(2 * scans_total);
   int2* d_scan_best = d_dims + scans_total;
-  int* d_off = ws.dev[5].ReserveAs<int>(2 * scans_total);
-  int* d_sorted_count = d_off + scans_total;
+  int* d_sorted_count = ws.dev[5].ReserveAs<int>(scans_total);
   float* d_cscore = ws.dev[6].ReserveAs<float>(coarse_total);
   int* d_csum = ws.dev[7].ReserveAs<int>(coarse_total);
   const size_t problems_bytes = (num * sizeof(Fast2DProblem) + 255) & ~size_t(255);
-  const size_t upload_bytes = problems_bytes + num * sizeof(ProblemState);
+  const size_t states_bytes = (num * sizeof(ProblemState) + 255) & ~size_t(255);
+  const size_t upload_bytes = problems_bytes + states_bytes + rotation_floats * sizeof(float);
   char* d_upload = static_cast<char*>(ws.dev[8].Reserve(upload_bytes));
   out->d_problems = reinterpret_cast<Fast2DProblem*>(d_upload);
   out->d_states = reinterpret_cast<ProblemState*>(d_upload + problems_bytes);
+  const float* d_rotations = reinterpret_cast<const float*>(d_upload + problems_bytes + states_bytes);
   char* h_upload = static_cast<char*>(ws.pinned[1].Reserve(upload_bytes));
   Fast2DProblem* h_prob = reinterpret_cast<Fast2DProblem*>(h_upload);
   ProblemState* h_state = reinterpret_cast<ProblemState*>(h_upload + problems_bytes);
+  float* h_rotations = reinterpret_cast<float*>(h_upload + problems_bytes + states_bytes);
+  for (const Rotation& r : rotations)
+    std::memcpy(h_rotations + r.offset, r.table->data(), r.table->size() * sizeof(float2));
 
   size_t disc_off = 0, scan_off = 0, coarse_off = 0;
   for (int p = 0; p < num; ++p) {
@@ -1691,7 +2043,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     }
     P.num_scans = h.num_scans;
     P.inv_res = 1.0 / P.res;
-    P.scan_rot = m.RotationTable(h.step, h.num_angular);
+    P.scan_rot = reinterpret_cast<const float2*>(d_rotations + rotations[rotation_of[p]].offset);
     P.min_s = m.min_s();
     P.score_scale = m.score_scale();
     P.min_score = min_of(p);
@@ -1704,7 +2056,6 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     P.bounds = d_bounds + scan_off;
     P.coarse_dims = d_dims + scan_off;
     P.scan_best = d_scan_best + scan_off;
-    P.coarse_off = d_off + scan_off;
     P.sorted_count = d_sorted_count + scan_off;
     P.coarse_score = d_cscore + coarse_off;
     P.coarse_sum = d_csum + coarse_off;
@@ -1717,46 +2068,63 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     coarse_off += P.coarse_capacity;
     out->max_scans = std::max(out->max_scans, h.num_scans);
   }
-  // One H2D for the problem descriptors and their initial states.
+  // One H2D for the problem descriptors, their initial states and the rotation tables.
   CMX_HIP(hipMemcpyAsync(d_upload, h_upload, upload_bytes, hipMemcpyHostToDevice, ws.stream));
 
   const dim3 per_scan(out->max_scans, num);
   auto mark = [&](const char* name) { if (out->trace) out->trace->Mark(name); };
   mark("upload");
-  PrepScansKernel<<<per_scan, 256, 0, ws.stream>>>(out->d_problems, d_xyz, n, out->d_states);
-  mark("prep");
-  CoarseLayoutKernel<<<num, 1024, 0, ws.stream>>>(out->d_problems, out->d_states);
-  mark("layout");
-  bool any_generic = false;
-  int chunk_mask = 0;
-  for (const Fast2DProblem& P : out->h_problems) {
-    if (P.use_planes) chunk_mask |= 1 << (P.plane_stride >> 6);
-    else any_generic = true;
-  }
-  const size_t acc_bytes = static_cast<size_t>(out->plane_acc_cells) * sizeof(int);
-  // Waves per rotation (the kernel takes 2..4).  Measured on the bench workload: 4 waves
-  // 45 us, 3 waves (everything resident in one round) 48 us -- the kernel is bound by
-  // instruction issue (~10 instructions per record, SQ counters in DESIGN.md), not by
-  // residency, so more, shorter waves win.
-  const int plane_waves = 4;
-  const int plane_threads = 64 * plane_waves;
+  // Whichever kernel runs first clears the search's list counters.
+  int* clear_words = reinterpret_cast<int*>(out->d_misc);
+  const int clear_count = out->d_misc ? static_cast<int>(sizeof(Counters) / sizeof(int)) : 0;
   CMX_HIP(hipEventRecord(ws.ev_k0, ws.stream));
-  if (chunk_mask & (1 << 1))
-    ScoreCoarsePlanesDwordKernel<<<per_scan, plane_threads, acc_bytes, ws.stream>>>(
-        out->d_problems, n, out->d_states);
-  if (chunk_mask & (1 << 2))
-    ScoreCoarsePlanesKernel<2><<<per_scan, plane_threads, acc_bytes, ws.stream>>>(
-        out->d_problems, n, out->d_states);
-  if (chunk_mask & (1 << 3))
-    ScoreCoarsePlanesKernel<3><<<per_scan, plane_threads, acc_bytes, ws.stream>>>(
-        out->d_problems, n, out->d_states);
-  if (chunk_mask & (1 << 4))
-    ScoreCoarsePlanesKernel<4><<<per_scan, plane_threads, acc_bytes, ws.stream>>>(
-        out->d_problems, n, out->d_states);
-  if (any_generic)
-    ScoreCoarseGenericKernel<<<per_scan, 256, 0, ws.stream>>>(out->d_problems, n, out->d_states);
+  if (any_fused) {
+    // Threads per block: with 192 (three waves) ten blocks fit a CU, i.e. a single search's
+    // ~2300 rotations are all resident at once and the launch takes one block's latency;
+    // batches run several rounds anyway and use full 256-thread blocks.
+    const long long blocks = static_cast<long long>(out->max_scans) * num;
+    const size_t lds = 12 * static_cast<size_t>(n_pad) +
+                       4 * static_cast<size_t>(fused_nb + 256 + 32 + fused_acc);
+    int threads = 256;
+    for (int t : {256, 192, 128}) {
+      if (blocks <= FusedResidentBlocks(ws.device, t, lds)) { threads = t; break; }
+    }
+    PrepScoreFusedKernel<<<per_scan, threads, lds, ws.stream>>>(
+        out->d_problems, d_xyz, n, out->d_states, static_cast<int>(fused_nb),
+        static_cast<int>(fused_acc), clear_words, clear_count);
+    clear_words = nullptr;
+    mark("fused");
+  }
+  if (any_unfused) {
+    PrepScansKernel<<<per_scan, 256, 0, ws.stream>>>(out->d_problems, d_xyz, n, out->d_states,
+                                                     clear_words, clear_count);
+    mark("prep");
+    bool any_generic = false;
+    int chunk_mask = 0;
+    for (const Fast2DProblem& P : out->h_problems) {
+      if (P.use_fused) continue;
+      if (P.use_planes) chunk_mask |= 1 << (P.plane_stride >> 6);
+      else any_generic = true;
+    }
+    const size_t acc_bytes = static_cast<size_t>(out->plane_acc_cells) * sizeof(int);
+    const int plane_threads = 256;
+    if (chunk_mask & (1 << 1))
+      ScoreCoarsePlanesDwordKernel<<<per_scan, plane_threads, acc_bytes, ws.stream>>>(
+          out->d_problems, n, out->d_states);
+    if (chunk_mask & (1 << 2))
+      ScoreCoarsePlanesKernel<2><<<per_scan, plane_threads, acc_bytes, ws.stream>>>(
+          out->d_problems, n, out->d_states);
+    if (chunk_mask & (1 << 3))
+      ScoreCoarsePlanesKernel<3><<<per_scan, plane_threads, acc_bytes, ws.stream>>>(
+          out->d_problems, n, out->d_states);
+    if (chunk_mask & (1 << 4))
+      ScoreCoarsePlanesKernel<4><<<per_scan, plane_threads, acc_bytes, ws.stream>>>(
+          out->d_problems, n, out->d_states);
+    if (any_generic)
+      ScoreCoarseGenericKernel<<<per_scan, 256, 0, ws.stream>>>(out->d_problems, n, out->d_states);
+    mark("coarse");
+  }
   CMX_HIP(hipEventRecord(ws.ev_k1, ws.stream));
-  mark("coarse");
   CMX_HIP(hipGetLastError());
 }
 
@@ -1772,6 +2140,13 @@ void ResolveDepthOne(const PreparedBatch& batch, std::vector<BestLeaf>* best,
 void ResolveTies(Workspace& ws, const PreparedBatch& batch, const NodeList& leaves_dev,
                  const Counters& h_counters, std::vector<BestLeaf>* best,
                  const std::vector<ProblemState>& states);
+
+size_t SearchMiscBytes(int num) {
+  return sizeof(Counters) + num * (sizeof(SelectState) + sizeof(BestLeaf) + sizeof(ProblemState));
+}
+void ReserveSearchScratch(Workspace& ws, int num, PreparedBatch* batch) {
+  batch->d_misc = static_cast<char*>(ws.dev[14].Reserve(SearchMiscBytes(num)));
+}
 
 // Full search of a prepared batch.
 void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* result) {
@@ -1798,23 +2173,17 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
   Node2D* d_front[2] = {ws.dev[10].ReserveAs<Node2D>(kFrontierCapacity),
                         ws.dev[11].ReserveAs<Node2D>(kFrontierCapacity)};
   Node2D* d_leaves = ws.dev[12].ReserveAs<Node2D>(kLeafCapacity);
-  Node2D* d_seeds = ws.dev[13].ReserveAs<Node2D>(static_cast<size_t>(kSeedsPerProblem) * num);
-  // Counters | SelectState[num] | BestLeaf[num] | ProblemState[num] (copy for the host) |
-  // seed counts: the first four travel back in ONE D2H.
-  char* d_misc = static_cast<char*>(ws.dev[14].Reserve(
-      sizeof(Counters) +
-      num * (sizeof(SelectState) + sizeof(BestLeaf) + sizeof(ProblemState) + sizeof(int))));
+  // Counters | SelectState[num] | BestLeaf[num] | ProblemState[num] (copy for the host):
+  // they travel back in ONE D2H.  Carved by ReserveSearchScratch before the first kernel
+  // of the call, which clears the counters.
+  char* d_misc = batch.d_misc;
   Counters* d_counters = reinterpret_cast<Counters*>(d_misc);
   SelectState* d_sel = reinterpret_cast<SelectState*>(d_misc + sizeof(Counters));
   BestLeaf* d_best = reinterpret_cast<BestLeaf*>(d_misc + sizeof(Counters) +
                                                  num * sizeof(SelectState));
   ProblemState* d_states_out = reinterpret_cast<ProblemState*>(
       d_misc + sizeof(Counters) + num * (sizeof(SelectState) + sizeof(BestLeaf)));
-  int* d_seed_count = reinterpret_cast<int*>(
-      d_misc + sizeof(Counters) +
-      num * (sizeof(SelectState) + sizeof(BestLeaf) + sizeof(ProblemState)));
   Counters* h_counters = nullptr;
-  if (depth == 1) CMX_HIP(hipMemsetAsync(d_counters, 0, sizeof(Counters), ws.stream));
   auto mark = [&](const char* name) { if (batch.trace) batch.trace->Mark(name); };
   // Stage k reads list k and appends to list k+1 (buffers ping-pong, counters
   // do not: they are all zeroed by the one memset above).
@@ -1845,11 +2214,8 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
     fetch_results();
   } else {
     // ---- dive -------------------------------------------------------------
-    SeedSelectKernel<<<num, 1024, 0, ws.stream>>>(
-        batch.d_problems, batch.d_states, n, d_seeds, d_seed_count,
-        reinterpret_cast<int*>(d_counters), static_cast<int>(sizeof(Counters) / sizeof(int)));
     DiveKernel<<<dim3(kSeedsPerProblem, num), 256, 0, ws.stream>>>(
-        batch.d_problems, batch.d_states, n, d_seeds, d_seed_count, leaf_list, d_counters);
+        batch.d_problems, batch.d_states, n, leaf_list, d_counters);
     mark("seed+dive");
 
     // ---- search -------------------------------------------------------------
@@ -1971,6 +2337,38 @@ struct ScoreIndex {
   bool operator>(const ScoreIndex& other) const { return score > other.score; }
 };
 
+// The device keeps the lowest-resolution candidates of scan s at [s * coarse_stride, ...);
+// the reference's generation order (scan, x, y) is the dense concatenation.  Host-side
+// views for the rare paths that need that order (tie replay, depth 1, introspection).
+struct CoarseLayout {
+  std::vector<int2> dims;   // [S]
+  std::vector<int> off;     // [S + 1] dense prefix
+  int Dense(const Fast2DProblem& P, int strided) const {
+    return off[strided / P.coarse_stride] + strided % P.coarse_stride;
+  }
+};
+CoarseLayout DownloadLayout(const Fast2DProblem& P) {
+  CoarseLayout L;
+  const int S = P.num_scans;
+  L.dims.resize(S);
+  L.off.resize(S + 1);
+  CMX_HIP(hipMemcpy(L.dims.data(), P.coarse_dims, S * sizeof(int2), hipMemcpyDeviceToHost));
+  L.off[0] = 0;
+  for (int s = 0; s < S; ++s) L.off[s + 1] = L.off[s] + L.dims[s].x * L.dims[s].y;
+  return L;
+}
+template <typename T>
+std::vector<T> DownloadDense(const Fast2DProblem& P, const CoarseLayout& L, const T* device) {
+  const int S = P.num_scans;
+  std::vector<T> strided(static_cast<size_t>(S) * P.coarse_stride);
+  CMX_HIP(hipMemcpy(strided.data(), device, strided.size() * sizeof(T), hipMemcpyDeviceToHost));
+  std::vector<T> dense(L.off[S]);
+  for (int s = 0; s < S; ++s)
+    std::copy_n(strided.begin() + static_cast<size_t>(s) * P.coarse_stride,
+                L.off[s + 1] - L.off[s], dense.begin() + L.off[s]);
+  return dense;
+}
+
 void ResolveTies(Workspace& ws, const PreparedBatch& batch, const NodeList& leaves_dev,
                  const Counters& h_counters, std::vector<BestLeaf>* best,
                  const std::vector<ProblemState>& states) {
@@ -2006,10 +2404,11 @@ void ResolveTies(Workspace& ws, const PreparedBatch& batch, const NodeList& leav
       if (tied.size() > 4096) break;   // degenerate input: plenty of ties, stop deduplicating
     }
     if (tied.size() <= 1) continue;
-    const int total = states[p].coarse_total;
-    std::vector<float> scores(total);
-    CMX_HIP(hipMemcpy(scores.data(), batch.h_problems[p].coarse_score, total * sizeof(float),
-                      hipMemcpyDeviceToHost));
+    const Fast2DProblem& P = batch.h_problems[p];
+    const CoarseLayout layout = DownloadLayout(P);
+    const std::vector<float> scores = DownloadDense(P, layout, P.coarse_score);
+    const int total = static_cast<int>(scores.size());
+    CMX_REQUIRE(total == states[p].coarse_total, "internal error: candidate layout mismatch");
     std::vector<ScoreIndex> sorted(total);
     for (int c = 0; c < total; ++c) sorted[c] = {scores[c], c};
     std::sort(sorted.begin(), sorted.end(), std::greater<ScoreIndex>());
@@ -2022,7 +2421,8 @@ void ResolveTies(Workspace& ws, const PreparedBatch& batch, const NodeList& leav
       std::memcpy(&bits, &nd.score, sizeof(float));
       if ((nd.problem & 0xffffff) != p || bits != best_bits) continue;
       const unsigned long long key =
-          (static_cast<unsigned long long>(position[nd.coarse_index]) << 32) | nd.path;
+          (static_cast<unsigned long long>(position[layout.Dense(P, nd.coarse_index)]) << 32) |
+          nd.path;
       if (!have || key < best_key) {
         have = true;
         best_key = key;
@@ -2039,20 +2439,17 @@ void ResolveDepthOne(const PreparedBatch& batch, std::vector<BestLeaf>* best,
   for (int p = 0; p < batch.num_problems; ++p) {
     BestLeaf& b = (*best)[p];
     const Fast2DProblem& P = batch.h_problems[p];
-    const int total = states[p].coarse_total;
-    if (states[p].error || total <= 0) continue;
-    std::vector<float> scores(total);
-    CMX_HIP(hipMemcpy(scores.data(), P.coarse_score, total * sizeof(float),
-                      hipMemcpyDeviceToHost));
+    if (states[p].error || states[p].coarse_total <= 0) continue;
+    const CoarseLayout layout = DownloadLayout(P);
+    const std::vector<float> scores = DownloadDense(P, layout, P.coarse_score);
+    const int total = static_cast<int>(scores.size());
     std::vector<ScoreIndex> sorted(total);
     for (int c = 0; c < total; ++c) sorted[c] = {scores[c], c};
     std::sort(sorted.begin(), sorted.end(), std::greater<ScoreIndex>());
     const int S = P.num_scans;
-    std::vector<int> off(S + 1);
-    std::vector<int2> dims(S);
+    const std::vector<int>& off = layout.off;
+    const std::vector<int2>& dims = layout.dims;
     std::vector<int4> bounds(S);
-    CMX_HIP(hipMemcpy(off.data(), P.coarse_off, (S + 1) * sizeof(int), hipMemcpyDeviceToHost));
-    CMX_HIP(hipMemcpy(dims.data(), P.coarse_dims, S * sizeof(int2), hipMemcpyDeviceToHost));
     CMX_HIP(hipMemcpy(bounds.data(), P.bounds, S * sizeof(int4), hipMemcpyDeviceToHost));
     const int c = sorted[0].index;
     const int s = static_cast<int>(std::upper_bound(off.begin(), off.end(), c) - off.begin()) - 1;
@@ -2112,6 +2509,7 @@ void MatchBatch(const cmx_fast2d* const* handles, int num, const cmx_pose2d* ini
   PreparedBatch batch;
   StageTrace trace(ws->stream);
   batch.trace = &trace;
+  ReserveSearchScratch(*ws, num, &batch);
   PrepareAndScoreCoarse(*ws, matchers.data(), num, initial, full_submap, d_xyz, n, max_range,
                         min_score, &batch, full_flags, min_scores);
   BatchResult result;
@@ -2319,6 +2717,7 @@ cmx_status cmx_fast2d_debug_prepare(const cmx_fast2d* matcher,
                            ws->stream));
     CMX_HIP(hipEventRecord(ws->ev_begin, ws->stream));
     cmx::PreparedBatch batch;
+    batch.write_all_discrete = true;
     cmx::PrepareAndScoreCoarse(*ws, &m, 1, initial_pose_estimate, full_submap != 0, d_xyz, n,
                                cmx::MaxRangeXY(point_cloud_xyz, n), 0.f, &batch);
     CMX_HIP(hipStreamSynchronize(ws->stream));
@@ -2327,6 +2726,8 @@ cmx_status cmx_fast2d_debug_prepare(const cmx_fast2d* matcher,
     CMX_HIP(hipMemcpy(&st, batch.d_states, sizeof(st), hipMemcpyDeviceToHost));
     CMX_REQUIRE(st.error == 0, "device preparation error %d", st.error);
     const int S = P.num_scans;
+    const cmx::CoarseLayout layout = cmx::DownloadLayout(P);
+    st.coarse_total = layout.off[S];
     if (num_scans) *num_scans = S;
     if (angular_step) *angular_step = batch.search[0].step;
     if (num_coarse) *num_coarse = st.coarse_total;
@@ -2351,8 +2752,8 @@ cmx_status cmx_fast2d_debug_prepare(const cmx_fast2d* matcher,
     }
     if (coarse_sums) {
       CMX_REQUIRE(sums_capacity >= st.coarse_total, "coarse_sums capacity too small");
-      CMX_HIP(hipMemcpy(coarse_sums, P.coarse_sum, st.coarse_total * sizeof(int),
-                        hipMemcpyDeviceToHost));
+      const std::vector<int> dense = cmx::DownloadDense(P, layout, P.coarse_sum);
+      std::copy(dense.begin(), dense.end(), coarse_sums);
     }
   });
 }

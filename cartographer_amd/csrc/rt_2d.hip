@@ -39,6 +39,7 @@ struct Rt2DParams {
   const uint16_t* weights;   // TSDF weight cells (nullptr for a probability grid)
   int nx, ny;
   double res, max_x, max_y;
+  double inv_res;            // RN(1 / res), for the division-free cell index (cmx_device.h)
   float tx, ty, init_qw, init_qz;
   int nl, num_scans, num_angular;
   double step, wt, wr;
@@ -56,6 +57,13 @@ struct Rt2DParams {
   float* weighted;
   int num_candidates;
   int prep_blocks;           // num_scans + blocks of the grid expansion
+  // LDS-staged integer bulk pass (Rt2DBulkKernel / Rt2DExactKernel, see below)
+  int wp, hp;                // staged grid: cells per row (16 x odd), rows
+  int hl, ht;                // left / top halo: LDS (x, y) = grid (x + hl, y + ht)
+  int blocks_per_row;        // aligned 4-cell blocks covering a window row at any phase
+  int rounds_rot;            // rotations prepared and scored together by a workgroup
+  int list_cap;              // per-rotation capacity of the phase-sorted address list
+  int* qsum;                 // [num_scans][side * side] integer sums of quantised cells
 };
 
 // ProbabilityGrid::GetProbability (mapping/2d/probability_grid.cc:78-82) with
@@ -404,6 +412,380 @@ __global__ void Rt2DCollectKernel(const Rt2DParams* __restrict__ params) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Probability grids that fit in LDS: integer bulk pass + exact finalists
+// ---------------------------------------------------------------------------
+// The reference's score of a candidate is mean_p P(cell_p + d) summed in f32 in point order
+// (:61-75), and P is affine in the stored uint16: P = 0.1 + u * kScale with
+// u = 32767 - value (0 for unknown / outside; real arithmetic, the f32 table rounds each
+// entry by < 1e-7).  Integer sums of u are exact and order-free, so the bulk of the search
+// needs neither the f32 chain nor one gather per (candidate, point):
+//   * the grid is staged ONCE per workgroup in LDS as 16-bit fields holding
+//     q = u >> kQShift (10 bits), rows padded with a zero halo so that no lookup needs a
+//     bounds test;
+//   * all (2 nl + 1)^2 candidates of a rotation read, for one point, a (2 nl + 1)^2 window
+//     of cells: a lane owns an aligned 4-cell block of one window row, fetches it with ONE
+//     ds_read_b64 and adds it to two packed-16-bit registers with two v_pk_add_u16 --
+//     four candidates per LDS read, 2 VALU instructions per 4 lookups;
+//   * the block is 8-byte aligned in LDS, the window is not: points are sorted by the phase
+//     (window start mod 4) and a lane's four sums belong to candidates 4 b + j - phase;
+//   * 64 points are added before the 16-bit sums are flushed to 32-bit LDS accumulators
+//     (64 * 1023 < 65536).
+// This yields, per candidate, Q with sum(u) in [2^kQShift Q, 2^kQShift Q + (2^kQShift - 1) N], i.e.
+// a score interval of width 31 kScale = 7.6e-4.  Every candidate whose weighted upper
+// bound reaches the best weighted lower bound (with 1e-4 of slack for the rounding of the
+// f32 chain) is a finalist; Rt2DExactKernel recomputes those -- a handful -- with the
+// reference's sequential f32 sum, and the host applies the libm weight and the
+// first-maximum rule to them exactly as before.  Returned score and pose are bit-identical
+// to the one-thread-per-candidate kernels above; those remain the path for TSDFs and for
+// grids that do not fit in LDS.
+constexpr int kQShift = 5;
+constexpr int kQChunk = 64;                 // points per packed accumulation
+constexpr int kBulkThreads = 1024;
+constexpr int kBulkWaves = kBulkThreads / 64;
+constexpr int kMaxRoundRot = 4;
+constexpr int kBulkMaxPoints = 8192;
+constexpr double kBoundSlack = 1e-4;        // f32-chain rounding (N * 2^-24 * sum / N, generous)
+
+// The reference's discretisation of point i of rotation (q0, qs): cell (ix, iy), clamped to
+// one cell further outside the grid than any offset can reach back in (same as
+// Rt2DPrepKernel above).
+__device__ __forceinline__ void Rt2DPointCell(const Rt2DParams& P, const Quat& q0, const Quat& qs,
+                                              const float* __restrict__ xyz, int i, int* ix,
+                                              int* iy) {
+  const F3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+  F3 a = Rotate(q0, p);
+  a.x += 0.f; a.y += 0.f; a.z += 0.f;
+  F3 b = Rotate(qs, a);
+  b.x += 0.f; b.y += 0.f;
+  const float x = (1.f * b.x + 0.f * b.y) + P.tx;
+  const float y = (0.f * b.x + 1.f * b.y) + P.ty;
+  // lround((max - v) / res - 0.5): division-free when provably equal (cmx_device.h).
+  const int cx = CellIndexF64(P.max_y - static_cast<double>(y), P.res, P.inv_res);
+  const int cy = CellIndexF64(P.max_x - static_cast<double>(x), P.res, P.inv_res);
+  *ix = min(max(cx, -(P.nl + 1)), P.nx + P.nl);
+  *iy = min(max(cy, -(P.nl + 1)), P.ny + P.nl);
+}
+
+// exp(-(hypot(x, y) w_t + |theta| w_r)^2) in f32 (relative error ~1e-6): only used for the
+// bounds below, which carry 1e-5 of relative slack on top; the returned score is weighted on
+// the host with libm.
+__device__ __forceinline__ float Rt2DWeight(const Rt2DParams& P, int s, int dx, int dy) {
+  const float res = static_cast<float>(P.res);
+  const float cx = -dy * res, cy = -dx * res;
+  const float theta = static_cast<float>((s - P.num_angular) * P.step);
+  const float t = sqrtf(cx * cx + cy * cy) * static_cast<float>(P.wt) +
+                  fabsf(theta) * static_cast<float>(P.wr);
+  return __expf(-(t * t));
+}
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// Points K0 .. K0+3 of a chunk: wave-uniform block address from lane K0+k of `addrs`
+// (immediate lane index: a v_readlane with an SGPR index needs a hazard nop), the lane's own
+// (row, block) offset on top, one ds_read_b64 each.
+template <int K0>
+__device__ __forceinline__ void Load4(int addrs, int lane_off, const unsigned char* smem,
+                                      uint2 (&v)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int a = __builtin_amdgcn_readlane(addrs, K0 + k) + lane_off;
+    v[k] = *reinterpret_cast<const uint2*>(smem + a);
+  }
+}
+// (asm: as plain integer adds LLVM reassociates the 128 additions of a chunk into a tree
+// evaluated after all 64 loads -- 128 live VGPRs and spills inside this loop.)
+__device__ __forceinline__ void Add4(const uint2 (&v)[4], uint32_t* lo, uint32_t* hi) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(*lo) : "v"(v[k].x));
+    asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(*hi) : "v"(v[k].y));
+  }
+}
+
+// grid (workgroups per match, matches); a workgroup stages its match's grid and then takes
+// the rotations blockIdx.x, blockIdx.x + gridDim.x, ... `rounds_rot` at a time.
+// Dynamic LDS: grid[hp][wp] u16 | tmp[R][n_pad] | list[R][list_cap] | counts[R][chunks][4] |
+// offs[R][chunks][4] | acc[R][side^2] | ctl[64].
+__global__ void __launch_bounds__(kBulkThreads)
+Rt2DBulkKernel(const Rt2DParams* __restrict__ params) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bulk_smem[];
+  const Rt2DParams& P = params[blockIdx.y];
+  if (static_cast<int>(blockIdx.x) >= P.num_scans) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = P.n, n_pad = P.n_pad, pchunks = n_pad >> 6;
+  const int side = 2 * P.nl + 1, cands = side * side;
+  const int R = P.rounds_rot, B = P.blocks_per_row;
+  const int wp = P.wp, hp = P.hp;
+  uint16_t* grid = reinterpret_cast<uint16_t*>(bulk_smem);
+  int* tmp = reinterpret_cast<int*>(bulk_smem + static_cast<size_t>(wp) * hp * 2);
+  int* list = tmp + R * n_pad;
+  int* counts = list + R * P.list_cap;
+  int* offs = counts + R * pchunks * 4;
+  int* acc = offs + R * pchunks * 4;
+  int* ctl = acc + R * cands;      // [0] task counter, [8 + 8 rr + ph] first chunk of phase
+                                   // ph of rotation rr (ph = 4: number of chunks)
+
+  // ---- stage the grid: zero (halo included), then quantise the cells ------------------
+  {
+    uint4* g4 = reinterpret_cast<uint4*>(grid);
+    const int vecs = (wp * hp) >> 3;
+    for (int i = tid; i < vecs; i += kBulkThreads) g4[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();
+  {
+    const auto* cells = AsGlobal(P.cells);
+    const int total = P.nx * P.ny;
+    for (int e = tid; e < total; e += kBulkThreads) {
+      const int y = e / P.nx, x = e - y * P.nx;
+      const unsigned v = cells[e] & 32767u;
+      grid[(y + P.ht) * wp + (x + P.hl)] =
+          static_cast<uint16_t>(v ? (32767u - v) >> kQShift : 0u);
+    }
+  }
+  const Quat q0{P.init_qw, 0.f, 0.f, P.init_qz};
+  const int slices = (side * B + 63) >> 6;
+  const float kScale = ((1.f - 0.1f) - (1.f - (1.f - 0.1f))) / 32766.f;   // (kMaxCC - kMinCC) / 32766
+
+  for (int s0 = blockIdx.x; s0 < P.num_scans; s0 += gridDim.x * R) {
+    // Rotations of this round: s0, s0 + gridDim.x, ... (at most R).
+    const int round_rot = min(R, (P.num_scans - s0 + static_cast<int>(gridDim.x) - 1) /
+                                     static_cast<int>(gridDim.x));
+    __syncthreads();                       // previous round's accumulators have been read
+    for (int i = tid; i < round_rot * cands; i += kBulkThreads) acc[i] = 0;
+    for (int i = tid; i < round_rot * P.list_cap; i += kBulkThreads) list[i] = 0;   // null block
+    if (tid == 0) ctl[0] = 0;
+    // ---- discretise: one wavefront per 64 points of one rotation -----------------------
+    for (int vw = wave; vw < round_rot * pchunks; vw += kBulkWaves) {
+      const int rr = vw / pchunks, pc = vw - rr * pchunks;
+      const int s = s0 + rr * gridDim.x;
+      const float2 r = P.scan_rot[s];
+      const Quat qs{r.x, 0.f, 0.f, r.y};
+      const int i = pc * 64 + lane;
+      int packed = -1;
+      if (i < n) {
+        int ix, iy;
+        Rt2DPointCell(P, q0, qs, P.xyz, i, &ix, &iy);
+        const int wx = ix - P.nl + P.hl, wy = iy - P.nl + P.ht;   // window start, LDS coordinates
+        packed = (((wy * wp + (wx & ~3)) * 2) << 2) | (wx & 3);
+      }
+      tmp[rr * n_pad + i] = packed;
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        const int c = __popcll(__ballot(packed >= 0 && (packed & 3) == ph));
+        if (lane == 0) counts[(rr * pchunks + pc) * 4 + ph] = c;
+      }
+    }
+    __syncthreads();
+    // ---- per (rotation, phase): exclusive offsets, phases padded to whole chunks --------
+    if (tid < round_rot * 4) {
+      const int rr = tid >> 2, ph = tid & 3;
+      int start = 0, mine = 0;
+      for (int q = 0; q <= ph; ++q) {
+        int total = 0;
+        for (int pc = 0; pc < pchunks; ++pc) total += counts[(rr * pchunks + pc) * 4 + q];
+        if (q < ph) start += (total + kQChunk - 1) / kQChunk;
+        else mine = total;
+      }
+      ctl[8 + 8 * rr + ph] = start;
+      if (ph == 3) ctl[8 + 8 * rr + 4] = start + (mine + kQChunk - 1) / kQChunk;
+      int run = start * kQChunk;
+      for (int pc = 0; pc < pchunks; ++pc) {
+        offs[(rr * pchunks + pc) * 4 + ph] = run;
+        run += counts[(rr * pchunks + pc) * 4 + ph];
+      }
+    }
+    __syncthreads();
+    for (int vw = wave; vw < round_rot * pchunks; vw += kBulkWaves) {
+      const int rr = vw / pchunks, pc = vw - rr * pchunks;
+      const int i = pc * 64 + lane;
+      const int packed = tmp[rr * n_pad + i];
+      const int ph = packed & 3;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned long long m = __ballot(packed >= 0 && ph == q);
+        if (packed >= 0 && ph == q) {
+          const int pos = offs[(rr * pchunks + pc) * 4 + q] +
+                          __popcll(m & ((1ull << lane) - 1ull));
+          list[rr * P.list_cap + pos] = packed >> 2;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- tasks: (rotation, 64-point chunk, lane slice), taken dynamically ---------------
+    int tasks = 0;
+    for (int rr = 0; rr < round_rot; ++rr) tasks += ctl[8 + 8 * rr + 4] * slices;
+    for (;;) {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(&ctl[0], 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= tasks) break;
+      int rr = 0;
+      for (; rr < round_rot; ++rr) {
+        const int mine = ctl[8 + 8 * rr + 4] * slices;
+        if (t < mine) break;
+        t -= mine;
+      }
+      const int chunk = t / slices, slice = t - chunk * slices;
+      int phase = 0;
+#pragma unroll
+      for (int q = 1; q < 4; ++q) phase += chunk >= ctl[8 + 8 * rr + q] ? 1 : 0;
+      const int item = slice * 64 + lane;
+      const bool valid = item < side * B;
+      const int row = valid ? item / B : 0, blk = valid ? item - row * B : 0;
+      const int lane_off = (row * wp + blk * 4) * 2;
+      const int my_addr = list[rr * P.list_cap + chunk * kQChunk + lane];
+      uint32_t lo = 0, hi = 0;      // packed 16-bit sums: cells (0 | 1 << 16), (2 | 3 << 16)
+      // Three banks of 4 LDS reads: groups g+1 and g+2 are in flight while group g is added
+      // (12 outstanding: lgkmcnt counts to 15; 16 waves per CU keep the LDS pipe busy).  The
+      // scheduling barriers keep the compiler from hoisting all 64 reads.
+      uint2 v0[4], v1[4], v2[4];
+      Load4<0>(my_addr, lane_off, bulk_smem, v0);
+      Load4<4>(my_addr, lane_off, bulk_smem, v1);
+      __builtin_amdgcn_sched_barrier(0);
+#define CMX_RT2D_STEP(K0, LOAD_BANK, ADD_BANK)                     \
+      Load4<K0>(my_addr, lane_off, bulk_smem, LOAD_BANK);           \
+      Add4(ADD_BANK, &lo, &hi);                                     \
+      __builtin_amdgcn_sched_barrier(0);
+      CMX_RT2D_STEP(8, v2, v0)
+      CMX_RT2D_STEP(12, v0, v1)
+      CMX_RT2D_STEP(16, v1, v2)
+      CMX_RT2D_STEP(20, v2, v0)
+      CMX_RT2D_STEP(24, v0, v1)
+      CMX_RT2D_STEP(28, v1, v2)
+      CMX_RT2D_STEP(32, v2, v0)
+      CMX_RT2D_STEP(36, v0, v1)
+      CMX_RT2D_STEP(40, v1, v2)
+      CMX_RT2D_STEP(44, v2, v0)
+      CMX_RT2D_STEP(48, v0, v1)
+      CMX_RT2D_STEP(52, v1, v2)
+      CMX_RT2D_STEP(56, v2, v0)
+      CMX_RT2D_STEP(60, v0, v1)
+#undef CMX_RT2D_STEP
+      Add4(v2, &lo, &hi);
+      Add4(v0, &lo, &hi);
+      if (valid) {
+        int* out = acc + rr * cands;
+        const int d0 = blk * 4 - phase;          // candidate x index of the block's first cell
+        const int sums[4] = {static_cast<int>(lo & 0xffffu), static_cast<int>(lo >> 16),
+                             static_cast<int>(hi & 0xffffu), static_cast<int>(hi >> 16)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int dxi = d0 + j;
+          if (dxi >= 0 && dxi < side && sums[j]) atomicAdd(&out[dxi * side + row], sums[j]);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- per candidate: integer sum out, weighted lower bound into the match's maximum --
+    float lb_max = 0.f;
+    for (int e = tid; e < round_rot * cands; e += kBulkThreads) {
+      const int rr = e / cands, c = e - rr * cands;
+      const int s = s0 + rr * gridDim.x;
+      const int q = acc[e];
+      P.qsum[static_cast<size_t>(s) * cands + c] = q;
+      const int dxi = c / side, dyi = c - dxi * side;
+      // (the integer is < 2^25 x 2^5: exact in f64; one f32 rounding at the end, downwards
+      // by the 1e-5 factor)
+      const double lo_score =
+          0.1 + static_cast<double>(kScale) * (static_cast<double>(q) * (1 << kQShift)) / n;
+      const float lb = static_cast<float>(lo_score - kBoundSlack) *
+                       Rt2DWeight(P, s, dxi - P.nl, dyi - P.nl) * (1.f - 1e-5f);
+      lb_max = fmaxf(lb_max, lb);
+    }
+    unsigned bits = __float_as_uint(fmaxf(lb_max, 0.f));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) bits = max(bits, __shfl_xor(bits, off, 64));
+    if (lane == 0 && bits) atomicMax(&P.misc[0], bits);
+  }
+}
+
+// grid (num_scans, matches), one wavefront: the finalists of one rotation, exact f32 chain.
+__global__ void __launch_bounds__(64)
+Rt2DExactKernel(const Rt2DParams* __restrict__ params) {
+  const Rt2DParams& P = params[blockIdx.y];
+  const int s = blockIdx.x;
+  if (s >= P.num_scans) return;
+  const int lane = threadIdx.x;
+  const int side = 2 * P.nl + 1, cands = side * side, n = P.n;
+  const float kScale = ((1.f - 0.1f) - (1.f - (1.f - 0.1f))) / 32766.f;
+  const float best_lb = __uint_as_float(P.misc[0]);
+  const int* __restrict__ qsum = P.qsum + static_cast<size_t>(s) * cands;
+  __shared__ int fin[64];
+  __shared__ uint32_t cellbuf[64];
+  __shared__ int nfin;
+  const float2 r = P.scan_rot[s];
+  const Quat q0{P.init_qw, 0.f, 0.f, P.init_qz};
+  const Quat qs{r.x, 0.f, 0.f, r.y};
+  const auto* cells = AsGlobal(P.cells);
+  for (int c0 = 0; c0 < cands; c0 += 64) {
+    // Candidates of this slice whose weighted upper bound reaches the best lower bound.
+    const int c = c0 + lane;
+    bool is_fin = false;
+    if (c < cands) {
+      const int dxi = c / side, dyi = c - dxi * side;
+      const double hi_score = 0.1 + static_cast<double>(kScale) *
+                                        (static_cast<double>(qsum[c]) * (1 << kQShift) +
+                                         ((1 << kQShift) - 1) * static_cast<double>(n)) / n;
+      const float ub = static_cast<float>(hi_score + kBoundSlack) *
+                       Rt2DWeight(P, s, dxi - P.nl, dyi - P.nl) * (1.f + 1e-5f);
+      is_fin = ub >= best_lb;
+    }
+    const unsigned long long mask = __ballot(is_fin);
+    if (mask == 0) continue;             // wave-uniform
+    if (is_fin) fin[__popcll(mask & ((1ull << lane) - 1ull))] = c;
+    if (lane == 0) nfin = __popcll(mask);
+    __syncthreads();
+    const bool have = lane < nfin;
+    const int mine = fin[have ? lane : 0];
+    const int dxi = mine / side, dyi = mine - dxi * side;
+    const int dx = dxi - P.nl, dy = dyi - P.nl;
+    float sum = 0.f;
+    for (int base = 0; base < n; base += 64) {
+      __syncthreads();
+      if (base + lane < n) {
+        int ix, iy;
+        Rt2DPointCell(P, q0, qs, P.xyz, base + lane, &ix, &iy);
+        cellbuf[lane] = (static_cast<uint32_t>(ix) & 0xffffu) | (static_cast<uint32_t>(iy) << 16);
+      }
+      __syncthreads();
+      const int cnt = min(64, n - base);
+      for (int k0 = 0; k0 < cnt; k0 += 16) {
+        unsigned raw[16];
+        bool inside[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const uint32_t pc = cellbuf[min(k0 + k, 63)];
+          const int x = static_cast<short>(pc & 0xffffu) + dx;
+          const int y = static_cast<short>(pc >> 16) + dy;
+          inside[k] = static_cast<unsigned>(x) < static_cast<unsigned>(P.nx) &&
+                      static_cast<unsigned>(y) < static_cast<unsigned>(P.ny);
+          raw[k] = cells[inside[k] ? P.nx * y + x : 0];     // unconditional load, masked below
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          if (k0 + k < cnt)                                  // wave-uniform
+            sum += inside[k] ? CellProbability(raw[k]) : 0.1f;   // kMinProbability outside
+        }
+      }
+    }
+    if (have) {
+      const float score = sum / static_cast<float>(n);
+      const int cg = (s * side + dxi) * side + dyi;           // x outer, y inner (:99-113)
+      const unsigned slot = atomicAdd(&P.misc[1], 1u);
+      if (slot < static_cast<unsigned>(kFinalistCap)) {
+        unsigned* pair = slot < static_cast<unsigned>(kFinalistHead)
+                             ? P.misc + 2 + 2 * slot
+                             : P.overflow + 2 * (slot - kFinalistHead);
+        pair[0] = static_cast<unsigned>(cg);
+        pair[1] = __float_as_uint(score);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 size_t Align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
 
 }  // namespace
@@ -411,8 +793,18 @@ size_t Align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
 // A batch of independent matches (one per trajectory / robot) in one set of launches.  Per
 // item `cells` is a host buffer, or -- when `device_cells` is given -- ignored in favour of
 // a grid that already lives in HBM (cmx_grid2d): nothing but the scan is uploaded then.
-void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int num, int32_t device,
-                    cmx_match_stats* stats) {
+namespace {
+// CMX_RT2D_BULK=0 keeps every match on the one-thread-per-candidate kernels (parity tests
+// run both paths).
+bool BulkEnabled() {
+  const char* e = getenv("CMX_RT2D_BULK");
+  return !(e && e[0] == '0');
+}
+
+// Returns false when the integer bulk pass produced more finalists than the list holds (a
+// flat score landscape); the caller then repeats the batch on the per-candidate kernels.
+bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, int num,
+                        int32_t device, cmx_match_stats* stats, bool force_legacy) {
   CMX_REQUIRE(options && items && num >= 1, "null argument");
   struct Plan {
     int n, nx, ny, nl, na, num_scans, n_pad, pad;
@@ -502,15 +894,55 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
   }
   CMX_REQUIRE(num <= 65535, "too many matches in one batch");
 
+  // ---- LDS-staged integer bulk pass: eligibility and geometry ------------------------
+  struct Bulk { int wp, hp, hl, ht, bpr, rounds, list_cap; size_t lds; size_t off_qsum; };
+  std::vector<Bulk> bulk(num);
+  bool use_bulk = !tsdf && !force_legacy && BulkEnabled();
+  size_t bulk_lds = 0, qsum_total = 0;
+  for (int m = 0; m < num && use_bulk; ++m) {
+    const Plan& pl = plan[m];
+    Bulk& b = bulk[m];
+    const int side = static_cast<int>(pl.side);
+    b.bpr = (side + 3 + 3) / 4;
+    b.hl = (2 * pl.nl + 4 + 3) & ~3;
+    b.ht = 2 * pl.nl + 1;
+    b.hp = pl.ny + 4 * pl.nl + 2;
+    int wp = (pl.nx + b.hl + 4 * b.bpr + 15) & ~15;
+    if ((wp >> 4) % 2 == 0) wp += 16;               // 16 x odd: conflict-free row pitch
+    b.wp = wp;
+    b.list_cap = pl.n_pad + 4 * kQChunk;
+    const size_t grid_bytes = static_cast<size_t>(b.wp) * b.hp * 2;
+    const size_t per_rot = 4 * (static_cast<size_t>(pl.n_pad) + b.list_cap +
+                                8 * static_cast<size_t>(pl.n_pad / 64) + side * side);
+    const size_t budget = 160 * 1024 - 512;
+    if (pl.n > kBulkMaxPoints || pl.nx > 16384 || pl.ny > 16384 ||
+        grid_bytes + per_rot + 256 > budget) {
+      use_bulk = false;
+      break;
+    }
+    b.rounds = static_cast<int>(std::min<size_t>(kMaxRoundRot, (budget - 256 - grid_bytes) / per_rot));
+    b.lds = grid_bytes + b.rounds * per_rot + 256;
+    bulk_lds = std::max(bulk_lds, b.lds);
+    b.off_qsum = qsum_total;
+    qsum_total += static_cast<size_t>(pl.num_scans) * side * side;
+  }
+  // The per-match result words ride in the upload (zeroed) so that no kernel has to clear
+  // them before the bulk kernel's atomicMax.
+  const size_t off_misc = in_bytes;
+  in_bytes += Align16(sizeof(unsigned) * 128 * static_cast<size_t>(num));
+
   WorkspaceLease ws(device);
   char* h_in = ws->pinned[0].ReserveAs<char>(in_bytes);
   char* d_in = ws->dev[0].ReserveAs<char>(in_bytes);
-  int* d_offsets = ws->dev[1].ReserveAs<int>(offsets_total);
-  char* d_padded = ws->dev[2].ReserveAs<char>(padded_bytes);
-  float* d_unweighted = ws->dev[3].ReserveAs<float>(scores_total);
-  float* d_weighted = ws->dev[4].ReserveAs<float>(scores_total);
+  // (scratch of the per-candidate kernels; the bulk path needs none of it)
+  int* d_offsets = ws->dev[1].ReserveAs<int>(use_bulk ? 1 : offsets_total);
+  char* d_padded = ws->dev[2].ReserveAs<char>(use_bulk ? 16 : padded_bytes);
+  float* d_unweighted = ws->dev[3].ReserveAs<float>(use_bulk ? 1 : scores_total);
+  float* d_weighted = ws->dev[4].ReserveAs<float>(use_bulk ? 1 : scores_total);
   static_assert(2 + 2 * kFinalistHead <= 128, "a match's head must fit its 128-word slot");
-  unsigned* d_misc = ws->dev[5].ReserveAs<unsigned>(static_cast<size_t>(num) * 128);
+  unsigned* d_misc = reinterpret_cast<unsigned*>(d_in + off_misc);
+  std::memset(h_in + off_misc, 0, sizeof(unsigned) * 128 * static_cast<size_t>(num));
+  int* d_qsum = use_bulk ? ws->dev[7].ReserveAs<int>(qsum_total) : nullptr;
   unsigned* d_overflow = ws->dev[6].ReserveAs<unsigned>(static_cast<size_t>(num) * 2 *
                                                         (kFinalistCap - kFinalistHead));
   unsigned* h_misc = ws->pinned[1].ReserveAs<unsigned>(static_cast<size_t>(num) * 128);
@@ -537,6 +969,7 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
     P.weights = tsdf ? reinterpret_cast<const uint16_t*>(d_in + pl.off_weights) : nullptr;
     P.nx = pl.nx; P.ny = pl.ny;
     P.res = pl.res; P.max_x = it.limits->max_x; P.max_y = it.limits->max_y;
+    P.inv_res = 1.0 / pl.res;
     P.tx = static_cast<float>(it.initial->x);
     P.ty = static_cast<float>(it.initial->y);
     P.init_qw = pl.q0w; P.init_qz = pl.q0z;
@@ -558,6 +991,12 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
     P.weighted = d_weighted + pl.off_scores;
     P.num_candidates = static_cast<int>(pl.num_candidates);
     P.prep_blocks = pl.num_scans + static_cast<int>(DivUp(pl.stride * pl.rows, 1024));
+    if (use_bulk) {
+      const Bulk& b = bulk[m];
+      P.wp = b.wp; P.hp = b.hp; P.hl = b.hl; P.ht = b.ht;
+      P.blocks_per_row = b.bpr; P.rounds_rot = b.rounds; P.list_cap = b.list_cap;
+      P.qsum = d_qsum + b.off_qsum;
+    }
     h_params[m] = P;
   }
   CMX_HIP(hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, ws->stream));
@@ -566,7 +1005,25 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
   CMX_HIP(hipEventRecord(ws->ev_begin, ws->stream));
   const dim3 prep_grid(max_prep, 1, num), score_grid(max_tiles, max_scans, num),
       collect_grid(max_collect, 1, num);
-  if (tsdf) {
+  if (use_bulk) {
+    static const bool lds_opt_in = [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(Rt2DBulkKernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 160 * 1024) == hipSuccess;
+    }();
+    CMX_REQUIRE(lds_opt_in, "cannot opt in to 160 KB of dynamic LDS");
+    // Workgroups per match: one rotation each for a few matches (latency), fewer for big
+    // batches (the grid is staged once per workgroup): about two rounds of the chip.
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    int per_match = static_cast<int>(max_scans);
+    if (static_cast<long long>(per_match) * num > 2ll * cus)
+      per_match = std::max(1, std::min<int>(per_match, (2 * cus + num - 1) / num));
+    CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
+    Rt2DBulkKernel<<<dim3(per_match, num), kBulkThreads, bulk_lds, ws->stream>>>(d_params);
+    CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
+    Rt2DExactKernel<<<dim3(max_scans, num), 64, 0, ws->stream>>>(d_params);
+  } else if (tsdf) {
     Rt2DPrepKernel<true><<<prep_grid, 256, 0, ws->stream>>>(d_params);
     CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
     Rt2DScoreKernel<true><<<score_grid, 64, 0, ws->stream>>>(d_params);
@@ -582,14 +1039,20 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
     else
       Rt2DScoreKernel<false><<<score_grid, 64, 0, ws->stream>>>(d_params);
   }
-  CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
-  Rt2DCollectKernel<<<collect_grid, 256, 0, ws->stream>>>(d_params);
+  if (!use_bulk) {
+    CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
+    Rt2DCollectKernel<<<collect_grid, 256, 0, ws->stream>>>(d_params);
+  }
   CMX_HIP(hipGetLastError());
   CMX_HIP(hipEventRecord(ws->ev_end, ws->stream));
   CMX_HIP(hipMemcpyAsync(h_misc, d_misc, sizeof(unsigned) * 128 * num, hipMemcpyDeviceToHost,
                          ws->stream));
   CMX_HIP(hipStreamSynchronize(ws->stream));
 
+  if (use_bulk) {
+    for (int m = 0; m < num; ++m)
+      if (h_misc[static_cast<size_t>(m) * 128 + 1] > static_cast<unsigned>(kFinalistCap)) return false;
+  }
   // Exact weighting + first-maximum on the finalists (:142-143,170-174).
   cmx_match_stats total{};
   std::vector<std::pair<int, float>> finalists;
@@ -669,6 +1132,14 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
     total.dominant_kernel_ms = ms;
     *stats = total;
   }
+  return true;
+}
+}  // namespace
+
+void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int num, int32_t device,
+                    cmx_match_stats* stats) {
+  if (!Rt2DMatchBatchImpl(options, items, num, device, stats, false))
+    Rt2DMatchBatchImpl(options, items, num, device, stats, true);
 }
 
 void Rt2DMatch(const cmx_rt_options* options, const cmx_grid2d_limits* limits,

@@ -38,7 +38,14 @@ struct Fast2DProblem {
   float tx, ty;         // initial translation narrowed to f32
   float init_qw, init_qz;   // Quaternion(AngleAxisf(f32(theta0), Z))
   int num_scans;
-  int coarse_capacity;  // size of coarse_score / coarse_sum
+  int coarse_capacity;  // size of coarse_score / coarse_sum (= num_scans * coarse_stride)
+  int coarse_stride;    // lowest-resolution candidates of scan s start at s * coarse_stride
+                        // (an upper bound of every scan's count, known on the host: the
+                        // layout needs no prefix sum over the scans)
+  int use_fused;        // 1: PrepScoreFusedKernel (prep + bucketing + plane scoring in one
+                        // block per rotation, records never leave LDS)
+  int write_all_discrete;   // debug: keep every discretised scan (default: only scans whose
+                            // best lowest-resolution score reaches min_score)
   const float2* scan_rot;   // [num_scans] (w, z) of AngleAxisf(f32(delta_theta_s), Z)
   float min_s, score_scale; // ToScore(v) = min_s + v * score_scale
   float min_score;          // caller's acceptance threshold
@@ -52,7 +59,6 @@ struct Fast2DProblem {
   uint32_t* discrete;   // [num_scans][n] packed int16 (x | y << 16)
   int4* bounds;         // [num_scans] (min_x, max_x, min_y, max_y) after ShrinkToFit
   int2* coarse_dims;    // [num_scans] (#x, #y lowest-resolution candidates)
-  int* coarse_off;      // [num_scans + 1]
   float* coarse_score;  // [coarse_capacity]
   int* coarse_sum;      // [coarse_capacity]
   uint2* sorted;        // [num_scans][n] points bucketed by lattice block:
@@ -78,7 +84,8 @@ struct ProblemState {       // per problem, device
   unsigned best_bits;       // float bits of the best leaf score so far (>= min_score)
   int coarse_total;
   int error;                // 1: cell index outside int16, 2: coarse capacity exceeded
-  int pad;
+  int done_top;             // "last block done" tickets of the fused front end:
+  int done_shard[kStatShards];   // blocks arrive on 16 sharded counters, shards on done_top
   unsigned long long scored_shard[kStatShards];    // candidates scored below the top level
   unsigned long long expanded_shard[kStatShards];  // nodes whose children were scored
 };
@@ -108,11 +115,6 @@ class Fast2DMatcher {
   size_t level_offset(int i) const { return level_offsets_[i]; }
   float min_s() const { return min_s_; }
   float score_scale() const { return score_scale_; }
-  // Device table of per-rotation (cos, sin) half-angle pairs for a search with
-  // `num_angular` perturbations of `step` radians (GenerateRotatedScans,
-  // SM2/correlative_scan_matcher_2d.cc:99-107).  Built on first use (libm on the
-  // host), then shared by every later match with the same parameters.
-  const float2* RotationTable(double step, int num_angular) const;
 
  private:
   cmx_fast2d_options options_;
@@ -125,10 +127,15 @@ class Fast2DMatcher {
   std::vector<LevelDesc> levels_;
   std::vector<size_t> level_offsets_;
   float min_s_, score_scale_;
-  struct RotationEntry { double step; int num_angular; float2* table; };
-  mutable std::mutex rotation_mutex_;
-  mutable std::vector<RotationEntry> rotation_tables_;
 };
+
+// Per-rotation (cos, sin) half-angle pairs of a search with `num_angular` perturbations
+// of `step` radians (GenerateRotatedScans, SM2/correlative_scan_matcher_2d.cc:99-107),
+// evaluated with the host's libm (bit-identical to the reference's AngleAxisf) and kept
+// in a bounded process-wide cache of HOST values: every call copies the table it needs
+// into its own upload buffer, so no device allocation is shared between calls in flight
+// and nothing is ever freed on the hot path.
+std::shared_ptr<const std::vector<float2>> HostRotationTable(double step, int num_angular);
 
 // RealTimeCorrelativeScanMatcher2D::Match (rt_2d.hip); see there.
 struct Rt2DItem {            // one match of a batch

@@ -276,3 +276,26 @@ def match_full_submap_batch(matchers, point_cloud, min_score):
                                                    found.ctypes.data, scores.ctypes.data,
                                                    poses.ctypes.data, C.byref(stats)))
     return found, scores, poses, stats.as_dict()
+
+
+def match_batch(matchers, initial_pose_estimates, match_full_submap, min_scores, point_cloud):
+    """cmx_fast2d_match_batch: one node's scan against many submaps, entry i either a windowed
+    Match around initial_pose_estimates[i] (match_full_submap[i] == 0, MaybeAddConstraint) or a
+    MatchFullSubmap (!= 0, MaybeAddGlobalConstraint), each against its own threshold
+    (constraints/constraint_builder_2d.cc:77-137, :194-236).  Returns
+    (found[int32], scores[float32], poses[list of Rigid2d], stats dict)."""
+    num = len(matchers)
+    handles = (C.c_void_p * num)(*[m._h for m in matchers])
+    initial = (Pose2d * num)(*[p.to_c() for p in initial_pose_estimates])
+    full = np.ascontiguousarray(match_full_submap, np.int32)
+    thresholds = np.ascontiguousarray(min_scores, np.float32)
+    xyz, n = _cloud(point_cloud)
+    found = np.zeros(num, np.int32)
+    scores = np.zeros(num, np.float32)
+    poses = (Pose2d * num)()
+    stats = MatchStats()
+    check(_lib.lib().cmx_fast2d_match_batch(
+        handles, num, C.cast(initial, C.c_void_p), full.ctypes.data, thresholds.ctypes.data,
+        xyz.ctypes.data, n, found.ctypes.data, scores.ctypes.data, C.cast(poses, C.c_void_p),
+        C.byref(stats)))
+    return found, scores, [Rigid2d(p.x, p.y, p.theta) for p in poses], stats.as_dict()

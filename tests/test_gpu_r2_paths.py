@@ -1,0 +1,172 @@
+"""Round-2 device paths against the oracle, old and new side by side.
+
+  * fast 2D: the fused front end (PrepScoreFusedKernel: prep + bucketing + lowest-resolution
+    scoring in one block per rotation) vs the separate launches (CMX_FUSED=0);
+  * real-time 2D: the LDS-staged integer bulk pass + exact finalists (Rt2DBulkKernel /
+    Rt2DExactKernel) vs one thread per candidate (CMX_RT2D_BULK=0).
+Both toggles are read per call, so one process runs both paths on identical inputs.  Bars as in
+test_gpu_2d.py: integer work bit-exact, f32 scores bit-equal, poses to 1e-12.
+"""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sm():
+    from cartographer_amd import _lib, scan_matching
+    assert _lib.lib().cmx_device_count() >= 1, "no HIP device: these tests need the GPU"
+    return scan_matching
+
+
+def _grid(sm, cells, lim):
+    return sm.Grid2D(cells, lim["resolution"], lim["max_x"], lim["max_y"])
+
+
+@pytest.fixture(scope="module")
+def c2(synth):
+    cells, lim, world = synth.make_submap(42, 400, 400, 0.05, 30, 1000, 30.0, 0.01)
+    pose = world.free_pose(1234, 0.5)
+    scan = world.scan(pose, 1000, 30.0, 0.01, 7)
+    return cells, lim, world, pose, scan
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_fast2d_prepare_both_front_ends(sm, oracle, c2, monkeypatch, fused):
+    monkeypatch.setenv("CMX_FUSED", fused)
+    cells, lim, _, _, scan = c2
+    om = oracle.FastCorrelativeScanMatcher2D(cells, 0.05, lim["max_x"], lim["max_y"], 7)
+    gm = sm.FastCorrelativeScanMatcher2D(_grid(sm, cells, lim), 7)
+    ref = om.prepare([0, 0, 0], scan, True)
+    got = gm.debug_prepare(None, scan, True)
+    assert got["num_scans"] == ref["num_scans"] and got["step"] == ref["step"]
+    np.testing.assert_array_equal(got["scans"], ref["scans"])
+    np.testing.assert_array_equal(got["bounds"], ref["bounds"])
+    np.testing.assert_array_equal(got["sums"], ref["sums"])
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("depth,n", [(7, 1000), (5, 333), (3, 64), (6, 1)])
+def test_fast2d_match_both_front_ends(sm, oracle, c2, monkeypatch, fused, depth, n):
+    monkeypatch.setenv("CMX_FUSED", fused)
+    cells, lim, _, truth, scan = c2
+    cloud = scan[:n]
+    om = oracle.FastCorrelativeScanMatcher2D(cells, 0.05, lim["max_x"], lim["max_y"], depth, 2.0,
+                                             math.radians(25.0))
+    gm = sm.FastCorrelativeScanMatcher2D(_grid(sm, cells, lim), depth, 2.0, math.radians(25.0))
+    for full, init, min_score in [(True, None, 0.55), (False, (truth[0] + 0.4, truth[1] - 0.3,
+                                                               truth[2] + 0.2), 0.3)]:
+        if full:
+            ref = om.match_full_submap(cloud, min_score)
+            found, score, pose = gm.match_full_submap(cloud, min_score)
+        else:
+            ref = om.match(list(init), cloud, min_score)
+            found, score, pose = gm.match(sm.Rigid2d(*init), cloud, min_score)
+        assert found == ref["found"]
+        if found:
+            assert np.float32(score) == np.float32(ref["score"])
+            np.testing.assert_allclose([pose.x, pose.y, pose.theta], ref["pose"], rtol=0,
+                                       atol=1e-12)
+        assert gm.last_stats["coarse_candidates"] == ref["coarse_candidates"]
+
+
+def test_fast2d_fused_and_unfused_batches_agree(sm, synth, c2, monkeypatch):
+    """A ConstraintBuilder batch (windowed and full-submap pairs mixed) gives the same
+    constraint list through either front end, and the min_score gate on the discretised
+    scans (only scans that can still matter are kept for the tree search) changes nothing."""
+    _, _, _, truth, scan = c2
+    matchers = []
+    for seed in (42, 43, 44, 45, 46):
+        cells, lim, _ = synth.make_submap(seed, 400, 400, 0.05, 30, 1000, 30.0, 0.01)
+        matchers.append(sm.FastCorrelativeScanMatcher2D(_grid(sm, cells, lim), 7, 3.0,
+                                                        math.radians(20.0)))
+    initial = [sm.Rigid2d(truth[0] + 0.3 * k, truth[1] - 0.2 * k, truth[2] + 0.05 * k)
+               for k in range(5)]
+    full = [1, 0, 1, 0, 1]
+    thresholds = [0.6, 0.4, 0.9, 0.55, 0.3]
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("CMX_FUSED", fused)
+        out[fused] = sm.match_batch(matchers, initial, full, thresholds, scan)
+    a, b = out["1"], out["0"]
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1][a[0] != 0], b[1][b[0] != 0])
+    for pa, pb, f in zip(a[2], b[2], a[0]):
+        if f:
+            assert (pa.x, pa.y, pa.theta) == (pb.x, pb.y, pb.theta)
+    assert a[3]["coarse_candidates"] == b[3]["coarse_candidates"]
+
+
+# ----------------------------------------------------------------------------
+# Real-time 2D: bulk pass vs per-candidate kernels vs oracle
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("bulk", ["1", "0"])
+@pytest.mark.parametrize("seed,size,beams,lin,ang,weights", [
+    (42, 200, 1000, 0.3, 7.0, (0.1, 0.1)),      # C1
+    (7, 200, 400, 0.3, 7.0, (0.0, 0.0)),        # unweighted: ties resolved by generation order
+    (11, 120, 300, 0.2, 4.0, (10.0, 1.0)),
+    (3, 160, 250, 0.15, 10.0, (0.1, 5.0)),
+    (5, 97, 61, 0.55, 1.0, (0.1, 0.1)),         # odd row length, 23 x 23 window: 3 lane slices
+    (9, 64, 64, 0.0, 0.0, (0.1, 0.1)),          # the single-candidate window
+])
+def test_rt2d_both_paths(sm, oracle, synth, monkeypatch, bulk, seed, size, beams, lin, ang,
+                         weights):
+    monkeypatch.setenv("CMX_RT2D_BULK", bulk)
+    ny = size if size != 97 else 83
+    cells, lim, world = synth.make_submap(seed, size, ny, 0.05, 20, 600, 5.0, 0.01)
+    pose = world.free_pose(seed + 100, 0.5)
+    scan = world.scan(pose, beams, 5.0, 0.01, 7)
+    init = [pose[0] + 0.12, pose[1] - 0.08, pose[2] + math.radians(3.0)]
+    ref = oracle.rt2d_match(cells, 0.05, lim["max_x"], lim["max_y"], init, scan, lin,
+                            math.radians(ang), *weights)
+    m = sm.RealTimeCorrelativeScanMatcher2D(lin, math.radians(ang), *weights)
+    score, est = m.match(sm.Rigid2d(*init), scan, _grid(sm, cells, lim))
+    assert m.last_stats["candidates_scored"] == ref["num_candidates"]
+    assert score == ref["score"]
+    np.testing.assert_allclose([est.x, est.y, est.theta], ref["pose"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("bulk", ["1", "0"])
+def test_rt2d_points_outside_and_unknown_grid(sm, oracle, monkeypatch, bulk):
+    """A cloud that mostly falls outside a small grid, on an all-unknown grid and on a
+    random one: the flat landscape makes every candidate a finalist (more than the list
+    holds: the bulk path hands the batch to the per-candidate kernels)."""
+    monkeypatch.setenv("CMX_RT2D_BULK", bulk)
+    rng = np.random.default_rng(5)
+    scan = np.zeros((130, 3), np.float32)
+    scan[:, :2] = rng.uniform(-4.0, 4.0, (130, 2))
+    for cells in (np.zeros((50, 70), np.uint16),
+                  rng.integers(0, 32768, (50, 70)).astype(np.uint16)):
+        init = [1.0, 1.2, 0.3]
+        ref = oracle.rt2d_match(cells, 0.05, 3.5, 2.5, init, scan, 0.5, 0.2, 0.0, 0.0)
+        m = sm.RealTimeCorrelativeScanMatcher2D(0.5, 0.2, 0.0, 0.0)
+        score, est = m.match(sm.Rigid2d(*init), scan, sm.Grid2D(cells, 0.05, 3.5, 2.5))
+        assert score == ref["score"]
+        np.testing.assert_allclose([est.x, est.y, est.theta], ref["pose"], rtol=0, atol=1e-12)
+
+
+def test_rt2d_batch_on_resident_grids_both_paths(sm, oracle, synth, monkeypatch):
+    from cartographer_amd import grid_2d
+    m = sm.RealTimeCorrelativeScanMatcher2D(0.3, math.radians(7.0), 0.1, 0.1)
+    grids, inits, scans, refs = [], [], [], []
+    for k in range(20):
+        cells, lim, world = synth.make_submap(60 + k % 5, 200, 200, 0.05, 20, 600, 5.0, 0.01)
+        pose = world.free_pose(300 + k, 0.5)
+        scan = world.scan(pose, 500 + 17 * k, 5.0, 0.01, k)
+        init = [pose[0] + 0.1, pose[1] - 0.05, pose[2] + 0.04]
+        grids.append(grid_2d.ProbabilityGridOnDevice(0.05, (lim["max_x"], lim["max_y"]), 200, 200,
+                                                     cells=cells))
+        inits.append(sm.Rigid2d(*init))
+        scans.append(scan)
+        refs.append(oracle.rt2d_match(cells, 0.05, lim["max_x"], lim["max_y"], init, scan, 0.3,
+                                      math.radians(7.0), 0.1, 0.1))
+    for bulk in ("1", "0"):
+        monkeypatch.setenv("CMX_RT2D_BULK", bulk)
+        scores, poses, stats = sm.rt2d_match_batch(m, grids, inits, scans)
+        for k, ref in enumerate(refs):
+            assert scores[k] == ref["score"], (bulk, k)
+            np.testing.assert_allclose([poses[k].x, poses[k].y, poses[k].theta], ref["pose"],
+                                       rtol=0, atol=1e-12)
