@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
 """Benchmark of the scan-matching hot path on MI355X.
 
-Metric (BASELINE.json): candidate poses scored per second.
+Metric (BASELINE.json): candidate poses scored per second (and loop-closure constraints,
+i.e. completed Match* calls, per second).
 
-A "step" is one loop-closure search of one 1000-point scan against the
-rank's submap(s): FastCorrelativeScanMatcher2D::MatchFullSubmap, depth 7, on
-400x400 probability grids (BASELINE config[1]; `--submaps B` widens the step
-to the ConstraintBuilder batch of config[2]).  Precomputation stacks and the
-point cloud are resident in HBM before the timed region; only the per-submap
-results (24 B each) return to the host.  With N > 1 every rank searches its own
-submaps (weak scaling: per-GPU work is fixed) and the ranks agree on the best
-(score, submap) with one RCCL all-reduce(max) per step.
+  N = 1 (default)   BASELINE config[1] "C2": one loop-closure search per step --
+                    FastCorrelativeScanMatcher2D::MatchFullSubmap of a 1000-point scan against
+                    one 400x400 submap, depth 7, full-angle.  Stack and point cloud are
+                    resident in HBM before the timed region; only the result returns.
+                    The other BASELINE configs (C1 real-time 2D single + batched, one GPU's
+                    share of C3, C4 real-time 3D, C5 fast 3D) are measured after the timed
+                    region and reported under config.other (skip with --no-other).
+  N > 1             BASELINE config[2] "C3": one scan against 64 N DISTINCT submaps (seeds
+                    42 ..., N = 8: the 512 submaps of the config), submap-sharded with
+                    sharding.shard_range, every rank searching its own block.  Per step the
+                    ranks exchange what the reference's ConstraintBuilder collects -- one
+                    optional constraint per submap (all-gather, 48 B per submap) -- and agree on
+                    the node-wide best match (all-reduce(max) of one packed 8-byte key), both on
+                    RCCL over xGMI.  Per-GPU work is fixed as N grows: weak scaling.
+  --config c1|c2|c3|c4|c5 selects the timed workload explicitly (single GPU for c1/c4/c5).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -26,28 +35,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-DOMINANT_KERNEL = "ScoreCoarsePlanes"   # ...DwordKernel (64-byte planes) or ...Kernel<N>
+# /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0        # HBM3E spec (6.3 TB/s achievable by a copy)
+L2_PEAK_GBS = 34500.0        # aggregate L2 -> L1
+LDS_PEAK_GBS = 150000.0      # ds_read_b64/b128, every CU streaming
 
-
-def pmc_traffic_bytes():
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC
-    passes of this same command (profiles/r01_pmc_{fetch,write}_size.csv; FETCH_SIZE and
-    WRITE_SIZE need separate passes, MI355X_MICROARCH.md "rocprofv3 PMC slots").  Values
-    are KiB; FETCH_SIZE is doubled per the guide's gfx950 correction (it tallies 128-B
-    requests as 64 B), which makes this an upper bound for our byte-wide gathers."""
-    import csv
-    total = 0.0
-    for name, factor in (("r01_pmc_fetch_size.csv", 2.0), ("r01_pmc_write_size.csv", 1.0)):
-        path = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(path):
-            return None
-        with open(path) as f:
-            rows = [r for r in csv.DictReader(f) if DOMINANT_KERNEL in r["Kernel"]]
-        if not rows:
-            return None
-        total += float(rows[0]["MeanValue"]) * 1024.0 * factor
-    return total
+C3_SUBMAPS_PER_GPU = 64      # 512 submaps over the 8 GPUs of BASELINE config[2]
+C3_POSITIVE = 137            # the scan is drawn from submap #137
 
 
 def parse_args():
@@ -55,13 +49,20 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=200,
-                    help="untimed steps; a step is ~0.3 ms, so the default also lets clocks settle")
-    ap.add_argument("--submaps", type=int, default=1, help="submaps searched per step per GPU")
+                    help="untimed steps; a C2 step is ~0.2 ms, so the default also lets clocks settle")
+    ap.add_argument("--config", choices=["auto", "c1", "c2", "c3", "c4", "c5"], default="auto",
+                    help="timed workload; auto = c2 on one GPU, c3 (sharded) on several")
+    ap.add_argument("--submaps", type=int, default=0,
+                    help="submaps searched per step per GPU (default: 1 for c2, 64 for c3)")
+    ap.add_argument("--matches", type=int, default=128,
+                    help="c1: independent real-time matches per step (one per trajectory / robot)")
     ap.add_argument("--grid", type=int, default=400)
     ap.add_argument("--depth", type=int, default=7)
     ap.add_argument("--beams", type=int, default=1000)
     ap.add_argument("--min-score", type=float, default=0.6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other", action="store_true",
+                    help="skip the C1 / C3-share / C4 / C5 measurements reported under config.other")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--concurrency", type=int, default=1,
                     help="host threads issuing steps concurrently (the reference's thread-pool "
@@ -69,6 +70,10 @@ def parse_args():
                          "the C ABI is re-entrant: every call leases its own stream + scratch")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the collectives even with one rank (plumbing test)")
+    ap.add_argument("--pmc-dir", default=os.path.join(ROOT, "profiles"),
+                    help="directory with <tag>_pmc_{fetch,write}_size.csv of THIS command "
+                         "(tools/profile_bench.sh writes them); roofline.traffic is null without")
+    ap.add_argument("--pmc-tag", default="r02")
     return ap.parse_args()
 
 
@@ -80,6 +85,29 @@ def _cores():
     return max(1, min(cores, 32))
 
 
+def pmc_traffic_bytes(pmc_dir, tag, kernel):
+    """HBM-side bytes per launch of `kernel` from rocprofv3 PMC passes of this command
+    (FETCH_SIZE and WRITE_SIZE need separate passes, MI355X_MICROARCH.md "rocprofv3 PMC
+    slots"; values are KiB; FETCH_SIZE is doubled per the guide's gfx950 correction).
+    None when the passes are absent or do not contain the kernel (e.g. after a rename):
+    a stale number is worse than none."""
+    import csv
+    total = 0.0
+    for name, factor in ((f"{tag}_pmc_fetch_size.csv", 2.0), (f"{tag}_pmc_write_size.csv", 1.0)):
+        path = os.path.join(pmc_dir, name)
+        if not os.path.exists(path):
+            return None
+        with open(path) as f:
+            rows = [r for r in csv.DictReader(f) if kernel in r["Kernel"]]
+        if not rows:
+            return None
+        total += float(rows[0]["MeanValue"]) * 1024.0 * factor
+    return total
+
+
+# --------------------------------------------------------------------------------------
+# CPU baseline (C2): the reference's own source where oracle/_ref is built
+# --------------------------------------------------------------------------------------
 def cpu_baseline_reference(cells, lim, depth, scan, min_score, seconds):
     """The reference's OWN fast_correlative_scan_matcher_2d.cc (oracle/_ref, built in place from
     /root/reference by __graft_entry__.build(); the prebuilt .so travels to the GPU box) timed
@@ -119,9 +147,11 @@ def cpu_baseline_reference(cells, lim, depth, scan, min_score, seconds):
         "kind": "reference",
         "sample": f"{matches} MatchFullSubmap calls of the bench workload by the reference's own "
                   f"fast_correlative_scan_matcher_2d.cc (oracle/_ref: compiled in place with the reference's -O3 -DNDEBUG, "
-                  f"stand-in Eigen value types; {per_match} candidates each, "
-                  f"{t_one * 1e3:.0f} ms single-thread), {cores} threads, {dt:.1f} s",
+                  f"stand-in Eigen value types; {per_match} candidates each -- the reference's "
+                  f"depth-first search scores more candidates per match than the device schedule, "
+                  f"each side counts its own -- {t_one * 1e3:.0f} ms single-thread), {cores} threads, {dt:.1f} s",
         "single_thread_candidates_per_s": per_match / t_one,
+        "matches_per_s": matches / dt,
     }
 
 
@@ -142,7 +172,6 @@ def cpu_baseline(cells, lim, depth, scan, min_score, seconds):
     t0 = time.perf_counter()
     one = matcher.match_full_submap(scan, min_score)
     t_one = time.perf_counter() - t0
-    # Bounded sample: rounds of `cores` concurrent matches until `seconds` elapsed.
     t0 = time.perf_counter()
     total = 0
     rounds = 0
@@ -159,14 +188,358 @@ def cpu_baseline(cells, lim, depth, scan, min_score, seconds):
                   f"({one['candidates_scored']} candidates each, {t_one * 1e3:.0f} ms "
                   f"single-thread), {cores} threads, {dt:.1f} s",
         "single_thread_candidates_per_s": one["candidates_scored"] / t_one,
+        "matches_per_s": rounds * cores / dt,
     }
+
+
+# --------------------------------------------------------------------------------------
+# Workloads.  Each exposes step() -> stats dict (candidates_scored, coarse_candidates,
+# dominant_kernel_ms, device_ms, num_scans, nodes_expanded + workload keys), describe(),
+# roofline(acc, steps) and `matches_per_step`.
+# --------------------------------------------------------------------------------------
+def _submap(synth, sm, seed, grid, depth, device):
+    cells, lim, world = synth.make_submap(seed, grid, grid, 0.05, 30, 1000, 30.0, 0.01)
+    g = sm.Grid2D(cells, lim["resolution"], lim["max_x"], lim["max_y"])
+    return sm.FastCorrelativeScanMatcher2D(g, depth, device=device), cells, lim, world
+
+
+class Fast2DWorkload:
+    """C2 (one submap per GPU) and C3 (a block of distinct submaps per GPU)."""
+
+    def __init__(self, args, device, rank, world_size, sharded):
+        from cartographer_amd import scan_matching as sm, sharding, synth
+        self.sm, self.sharding, self.args = sm, sharding, args
+        self.rank, self.world_size, self.sharded = rank, world_size, sharded
+        if sharded:
+            per_gpu = args.submaps or C3_SUBMAPS_PER_GPU
+            self.total = per_gpu * world_size
+            self.begin, self.end = sharding.shard_range(self.total, rank, world_size)
+            positive = C3_POSITIVE % self.total
+        else:
+            self.total = args.submaps or 1
+            self.begin, self.end = 0, self.total
+            positive = 0
+        self.matchers = []
+        self.cells0 = self.lim0 = None
+        for gid in range(self.begin, self.end):
+            m, cells, lim, world = _submap(synth, sm, 42 + gid, args.grid, args.depth, device)
+            self.matchers.append(m)
+            if self.cells0 is None:
+                self.cells0, self.lim0 = cells, lim
+        # Every rank draws the same scan, from the world of the one true-positive submap.
+        truth = synth.make_submap(42 + positive, args.grid, args.grid, 0.05, 30, 1000, 30.0,
+                                  0.01)[2]
+        pose = truth.free_pose(1234, 0.5)
+        self.scan = truth.scan(pose, args.beams, 30.0, 0.01, 7)
+        self.cloud = sm.PointCloudOnDevice(self.scan, device=device)
+        self.n_points = self.scan.shape[0]
+        self.matches_per_step = len(self.matchers)
+        self.positive = positive
+        self.gathered = None
+        self.best = None
+
+    def search(self):
+        return self.sm.match_full_submap_batch(self.matchers, self.cloud, self.args.min_score)
+
+    def exchange(self, found, scores, poses, torch_device):
+        """What crosses xGMI per step: every submap's optional constraint to every rank (the
+        reference's semantics) and the node-wide best match."""
+        sh = self.sharding
+        self.gathered = sh.all_gather_results(found, scores, poses, self.total, self.rank,
+                                              self.world_size, device=torch_device)
+        self.best = sh.unpack_best_key(sh.all_reduce_best(
+            sh.pack_best_key(found, scores, self.begin), device=torch_device))
+
+    def describe(self, stats, found):
+        a = self.args
+        if self.sharded:
+            what = (f"C3: 2D ConstraintBuilder loop-closure batch, one {self.n_points}-point scan vs "
+                    f"{self.total} distinct {a.grid}x{a.grid} submaps (seeds 42..{41 + self.total}, "
+                    f"true positive #{self.positive}) submap-sharded over {self.world_size} GPU(s), "
+                    f"{self.end - self.begin} per GPU; MatchFullSubmap depth {a.depth}, min_score "
+                    f"{a.min_score}; per step one all-gather of the per-submap results + one "
+                    f"all-reduce(max) of the best-match key")
+        else:
+            what = (f"C2: 2D FastCorrelativeScanMatcher MatchFullSubmap (branch and bound): "
+                    f"{self.n_points}-point scan vs {self.total} {a.grid}x{a.grid} submap(s) per GPU, "
+                    f"depth {a.depth}, full-angle search, min_score {a.min_score}")
+        out = {"workload": what, "submaps_per_gpu": self.end - self.begin,
+               "rotations": stats["num_scans"] // max(self.matches_per_step, 1),
+               "nodes_expanded_per_step": stats["nodes_expanded"], "found": int(np.sum(found))}
+        if self.sharded and self.gathered is not None:
+            out["constraints_found_node_wide"] = int(np.sum(self.gathered[0]))
+            out["best_match"] = {"score": self.best[0], "submap": self.best[1]}
+        return out
+
+    def roofline(self, acc, steps, pmc):
+        """Front-end kernel (prep + lowest-resolution scoring of every rotation).
+        Algorithmic bytes: N x 1 B per lowest-resolution candidate + 4 B per point
+        per rotation.  The bound is not HBM: the 256 KB phase-plane set is L2-resident and every
+        point gathers ONE 64-byte plane through L2 -> L1; `frac` is that gather traffic against
+        the L2 peak.  The HBM-side ratios SURVEY 8d asks for are reported next to it."""
+        launches = steps
+        coarse = acc["coarse_candidates"] / launches
+        scans = acc["num_scans"] / launches
+        k_ms = acc["dominant_kernel_ms"] / launches
+        alg = coarse * self.n_points * 1.0 + scans * self.n_points * 4.0
+        gathered = scans * self.n_points * 64.0         # <= one plane per point per rotation
+        secs = max(k_ms, 1e-9) * 1e-3
+        traffic = pmc("PrepScoreFused")
+        out = {
+            "kernel": "PrepScoreFusedKernel (prep + bucketing + lowest-resolution scoring)",
+            "bound": "l2-gather", "achieved": gathered / secs / 1e9, "peak": L2_PEAK_GBS,
+            "unit": "GB/s", "frac": gathered / secs / 1e9 / L2_PEAK_GBS, "traffic": traffic,
+            "kernel_ms": k_ms, "algorithmic_bytes": alg, "gathered_bytes": gathered,
+            "algorithmic_GBps": alg / secs / 1e9,
+            "hbm_frac_algorithmic": alg / secs / 1e9 / HBM_PEAK_GBS,
+            "hbm_frac_traffic": None if traffic is None else traffic / secs / 1e9 / HBM_PEAK_GBS,
+            "kernel_share_of_step_device_time": acc["dominant_kernel_ms"] / max(acc["device_ms"], 1e-9),
+            "note": "frac = bytes the kernel gathers through L2 (one 64-byte phase plane per point "
+                    "per rotation, an upper bound: points no candidate can reach are skipped) / "
+                    "kernel time / L2 peak 34.5 TB/s.  hbm_frac_algorithmic may exceed 1: the "
+                    "working set is on-chip (SURVEY 8d); hbm_frac_traffic = rocprofv3 FETCH_SIZE x2 "
+                    "+ WRITE_SIZE of the same command / kernel time / 8 TB/s (null without the PMC "
+                    "passes under --pmc-dir).  kernel_ms: HIP events on the kernel's own stream.",
+        }
+        return out
+
+
+class Rt2DWorkload:
+    """C1 as a throughput workload: `--matches` independent real-time matches per step (scan i
+    against resident grid i around pose i: one per trajectory / robot), 1000 beams vs 200x200,
+    window 0.3 m / 7 deg, weights 0.1 / 0.1."""
+
+    def __init__(self, args, device, matches=None):
+        from cartographer_amd import grid_2d, scan_matching as sm, synth
+        self.sm = sm
+        self.m = sm.RealTimeCorrelativeScanMatcher2D(0.3, math.radians(7.0), 0.1, 0.1,
+                                                     device=device)
+        batch = matches or args.matches
+        grids, inits, scans = [], [], []
+        for k in range(min(batch, 8)):          # 8 distinct worlds, reused round-robin
+            cells, lim, world = synth.make_submap(42 + k, 200, 200, 0.05, 30, 1000, 5.0, 0.01)
+            pose = world.free_pose(1234, 0.5)
+            grids.append(grid_2d.ProbabilityGridOnDevice(0.05, (lim["max_x"], lim["max_y"]), 200,
+                                                         200, cells=cells))
+            scans.append(world.scan(pose, args.beams, 5.0, 0.01, 7))
+            inits.append(sm.Rigid2d(pose[0] + 0.12, pose[1] - 0.08, pose[2] + math.radians(3.0)))
+        self.G = [grids[i % len(grids)] for i in range(batch)]
+        self.I = [inits[i % len(grids)] for i in range(batch)]
+        self.S = [scans[i % len(grids)] for i in range(batch)]
+        self.points = float(np.mean([len(s) for s in self.S]))
+        self.matches_per_step = batch
+        self.n_points = int(self.points)
+
+    def search(self):
+        scores, poses, stats = self.sm.rt2d_match_batch(self.m, self.G, self.I, self.S)
+        return np.ones(len(scores), np.int32), scores, poses, stats
+
+    def describe(self, stats, found):
+        return {"workload": f"C1: 2D RealTimeCorrelativeScanMatcher, {self.matches_per_step} "
+                            f"independent matches per step, {self.n_points}-point scans vs 200x200 "
+                            f"resident probability grids, window 0.3 m / 7 deg "
+                            f"({stats['candidates_scored'] // self.matches_per_step} candidates per match)",
+                "matches_per_step": self.matches_per_step}
+
+    def roofline(self, acc, steps, pmc):
+        """Integer bulk kernel: the grid is staged in LDS, a lane fetches an aligned 4-cell block
+        of one window row with one ds_read_b64 (8 B) per point.  C1: 13 x 13 window = 13 rows x 4
+        blocks = 52 lanes, 416 B of LDS reads per (rotation, point) serving 169 candidates.
+        Algorithmic bytes: 2 B per candidate per point."""
+        k_ms = acc["dominant_kernel_ms"] / steps
+        cand = acc["candidates_scored"] / steps
+        secs = max(k_ms, 1e-9) * 1e-3
+        alg = cand * self.points * 2.0
+        side = 13
+        lds = cand / (side * side) * self.points * (side * ((side + 6) // 4)) * 8.0
+        return {"kernel": "Rt2DBulkKernel (LDS-staged grid, packed 16-bit sums)", "bound": "lds",
+                "achieved": lds / secs / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                "frac": lds / secs / 1e9 / LDS_PEAK_GBS, "traffic": pmc("Rt2DBulk"),
+                "kernel_ms": k_ms, "algorithmic_bytes": alg, "lds_bytes": lds,
+                "algorithmic_GBps": alg / secs / 1e9,
+                "hbm_frac_algorithmic": alg / secs / 1e9 / HBM_PEAK_GBS,
+                "candidates_per_s_kernel": cand / secs,
+                "note": "frac = LDS bytes read by the bulk kernel / kernel time / 150 TB/s "
+                        "(ds_read_b64 aggregate); hbm_frac_algorithmic > 1 means on-chip residency"}
+
+
+class Rt3DWorkload:
+    """C4: 64 rings x 1024 azimuths vs a 150^3 HybridGrid, window 0.5 m / 2 deg."""
+
+    def __init__(self, args, device):
+        from cartographer_amd import scan_matching_3d as sm3, synth
+        grid, world = synth.make_submap_3d(42, 0.1, (15.0, 15.0, 7.5), 8, 32, 512)
+        self.vox = grid.voxels()
+        pos = world.free_position(77, 0.5)
+        self.cloud = world.scan(pos, 0.3, 64, 1024, seed=9)
+        c, s = math.cos(0.31 / 2), math.sin(0.31 / 2)
+        self.init = sm3.Rigid3d(tuple(pos + np.array([0.07, -0.04, 0.02])), (c, 0.0, 0.0, s))
+        self.m = sm3.RealTimeCorrelativeScanMatcher3D(0.5, math.radians(2.0), 0.1, 0.1)
+        self.matches_per_step = 1
+        self.n_points = len(self.cloud)
+
+    def search(self):
+        score, est = self.m.match(self.init, self.cloud, 0.1, self.vox)
+        return np.ones(1, np.int32), np.array([score], np.float32), [est], self.m.last_stats
+
+    def describe(self, stats, found):
+        return {"workload": f"C4: 3D RealTimeCorrelativeScanMatcher, {self.n_points}-point cloud vs "
+                            f"150^3 HybridGrid ({len(self.vox)} voxels), window 0.5 m / 2 deg",
+                "lookups_per_step": stats["candidates_scored"] * self.n_points}
+
+    def roofline(self, acc, steps, pmc):
+        k_ms = acc["dominant_kernel_ms"] / steps
+        cand = acc["candidates_scored"] / steps
+        scans = acc["num_scans"] / steps
+        secs = max(k_ms, 1e-9) * 1e-3
+        alg = cand * self.n_points * 2.0 + scans * self.n_points * 12.0      # SURVEY 8d
+        return {"kernel": "Rt3DScoreKernel", "bound": "hbm", "achieved": alg / secs / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / secs / 1e9 / HBM_PEAK_GBS,
+                "traffic": pmc("Rt3DScore"), "kernel_ms": k_ms, "algorithmic_bytes": alg,
+                "lookups_per_s": cand * self.n_points / secs,
+                "note": "algorithmic bytes (2 B per candidate-point + 12 B per rotation-point) / "
+                        "kernel time / 8 TB/s; the 13.5 MB brick is L2/MALL-resident, the kernel "
+                        "is VALU-bound (instructions per lookup), not HBM-bound"}
+
+
+class Fast3DWorkload:
+    """C5, one GPU's share: hi 0.1 m / low 0.45 m, depth 8 / full-resolution depth 3,
+    pose_graph.lua windows; `--submaps` pairs per step through cmx_fast3d_match_batch."""
+
+    def __init__(self, args, device, pairs=None):
+        from cartographer_amd import scan_matching_3d as sm3, synth
+        self.sm3 = sm3
+        size = (15.0, 15.0, 7.5)
+        grid, world = synth.make_submap_3d(42, 0.1, size, 8, 32, 512)
+        low, _ = synth.make_submap_3d(42, 0.45, size, 8, 32, 512)
+        vox, low_vox = grid.voxels(), low.voxels()
+        rng = np.random.default_rng(1)
+        hist = rng.uniform(0.0, 1.0, 120).astype(np.float32)
+        hist[10:14] += 6.0
+        pos = world.free_position(77, 0.6)
+        yaw = 0.4
+        full = world.scan(pos, yaw, 32, 512, seed=1)
+        self.hi = full[::6].copy()
+        self.lo = full[::80].copy()
+        scan_hist = np.roll(hist, -19).copy()
+        opt = dict(branch_and_bound_depth=8, full_resolution_depth=3, min_rotational_score=0.77,
+                   min_low_resolution_score=0.35, linear_xy_search_window=5.0,
+                   linear_z_search_window=1.0, angular_search_window=math.radians(15.0))
+        self.gm = sm3.FastCorrelativeScanMatcher3D(0.1, vox, grid.grid_size, 0.45, low_vox, hist,
+                                                   **opt)
+        self.node = sm3.Rigid3d((pos[0] + 0.8, pos[1] - 0.6, pos[2] + 0.2),
+                                (math.cos((yaw + 0.1) / 2), 0.0, 0.0, math.sin((yaw + 0.1) / 2)))
+        self.data = sm3.TrajectoryNodeData(self.hi, self.lo, scan_hist)
+        self.pairs = pairs or args.submaps or 1
+        self.matches_per_step = self.pairs
+        self.n_points = len(self.hi)
+
+    def search(self):
+        sm3 = self.sm3
+        if self.pairs == 1:
+            got = self.gm.match(self.node, sm3.Rigid3d(), self.data, 0.2)
+            stats = self.gm.last_stats
+            found = np.array([got is not None], np.int32)
+            scores = np.array([got["score"] if got else 0.0], np.float32)
+            return found, scores, [got], stats
+        results, stats = sm3.fast3d_match_batch([self.gm] * self.pairs, [self.node] * self.pairs,
+                                                [sm3.Rigid3d()] * self.pairs, [0] * self.pairs,
+                                                [0.2] * self.pairs, self.data)
+        found = np.array([r is not None for r in results], np.int32)
+        scores = np.array([r["score"] if r else 0.0 for r in results], np.float32)
+        return found, scores, results, stats
+
+    def describe(self, stats, found):
+        return {"workload": f"C5: 3D FastCorrelativeScanMatcher Match, {self.pairs} (node, submap) "
+                            f"pair(s) per step, 150^3 hi-res 0.1 m + low-res 0.45 m grids, depth 8 / "
+                            f"full-resolution depth 3, {self.n_points} hi-res points",
+                "pairs_per_step": self.pairs}
+
+    def roofline(self, acc, steps, pmc):
+        k_ms = acc["dominant_kernel_ms"] / steps
+        coarse = acc["coarse_candidates"] / steps
+        scans = acc["num_scans"] / steps
+        secs = max(k_ms, 1e-9) * 1e-3
+        alg = coarse * self.n_points * 1.0 + scans * self.n_points * 12.0     # SURVEY 8d
+        return {"kernel": "ScoreCoarse3D", "bound": "hbm", "achieved": alg / secs / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / secs / 1e9 / HBM_PEAK_GBS,
+                "traffic": pmc("ScoreCoarse3D"), "kernel_ms": k_ms, "algorithmic_bytes": alg,
+                "note": "lowest-resolution scoring: 1 B per candidate-point + 12 B per yaw-point "
+                        "(SURVEY 8d) / kernel time / 8 TB/s"}
+
+
+def make_workload(name, args, device, rank, world_size):
+    if name == "c2":
+        return Fast2DWorkload(args, device, rank, world_size, sharded=False)
+    if name == "c3":
+        return Fast2DWorkload(args, device, rank, world_size, sharded=True)
+    if name == "c1":
+        return Rt2DWorkload(args, device)
+    if name == "c4":
+        return Rt3DWorkload(args, device)
+    return Fast3DWorkload(args, device)
+
+
+STAT_KEYS = ("candidates_scored", "coarse_candidates", "dominant_kernel_ms", "device_ms",
+             "num_scans")
+
+
+def measure(workload, steps, warmup, sync):
+    """steps timed passes of workload.search(); returns (summary dict, acc, last result)."""
+    acc = {k: 0.0 for k in STAT_KEYS}
+    last = None
+    for _ in range(warmup):
+        workload.search()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = workload.search()
+        for k in STAT_KEYS:
+            acc[k] += last[3][k]
+    sync()
+    dt = time.perf_counter() - t0
+    return dt, acc, last
+
+
+def other_configs(args, device, sync, pmc):
+    """C1 (single + batched), one GPU's share of C3, C4 and C5 on this GPU, a few passes each:
+    the driver's one JSON line then carries every BASELINE config.  Failures are reported, never
+    raised: the headline must not depend on them."""
+    out = {}
+
+    def run(name, factory, steps, warmup):
+        try:
+            t0 = time.perf_counter()
+            w = factory()
+            dt, acc, last = measure(w, steps, warmup, sync)
+            entry = w.describe(last[3], last[0])
+            entry.update({
+                "ms_per_step": dt / steps * 1e3,
+                "candidates_per_s": acc["candidates_scored"] / dt,
+                "matches_per_s": w.matches_per_step * steps / dt,
+                "device_ms_per_step": acc["device_ms"] / steps,
+                "steps": steps, "roofline": w.roofline(acc, steps, pmc),
+                "setup_s": time.perf_counter() - t0 - dt,
+            })
+            out[name] = entry
+        except Exception as e:      # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+
+    run("c1_single", lambda: Rt2DWorkload(args, device, matches=1), 200, 50)
+    run("c1_batch128", lambda: Rt2DWorkload(args, device, matches=128), 30, 5)
+    sub = argparse.Namespace(**vars(args))
+    sub.submaps = 16
+    run("c3_share_16_submaps", lambda: Fast2DWorkload(sub, device, 0, 1, sharded=True), 5, 2)
+    run("c4", lambda: Rt3DWorkload(args, device), 2, 1)
+    run("c5_single", lambda: Fast3DWorkload(args, device, pairs=1), 10, 2)
+    run("c5_batch8", lambda: Fast3DWorkload(args, device, pairs=8), 4, 1)
+    return out
 
 
 def main():
     args = parse_args()
     import torch
     import torch.distributed as dist
-    from cartographer_amd import scan_matching as sm, sharding, synth
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -183,91 +556,62 @@ def main():
     device = local_rank if torch.cuda.is_available() else 0
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(device)
+    torch_device = f"cuda:{device}"
 
-    # ---- synthetic inputs (identical bytes for GPU path and CPU baseline) ----
-    # Every rank holds its own replica set of `--submaps` submaps (seeds 42..42+B-1, the
-    # first one contains the scan's true pose): per-GPU work is identical, which is what
-    # "weak scaling" means here.  Global submap ids are rank * B + i.
-    n_sub = args.submaps
-    base_seed = 42
-    matchers, grids = [], []
-    world0 = None
-    for i in range(n_sub):
-        cells, lim, world = synth.make_submap(base_seed + i, args.grid, args.grid, 0.05, 30,
-                                              1000, 30.0, 0.01)
-        if i == 0:
-            world0, cells0, lim0 = world, cells, lim
-        grid = sm.Grid2D(cells, lim["resolution"], lim["max_x"], lim["max_y"])
-        matchers.append(sm.FastCorrelativeScanMatcher2D(grid, args.depth, device=device))
-    # The scan is drawn from rank 0's first submap (one true positive).
-    truth = synth.make_submap(42, args.grid, args.grid, 0.05, 30, 1000, 30.0, 0.01)[2]
-    pose = truth.free_pose(1234, 0.5)
-    scan = truth.scan(pose, args.beams, 30.0, 0.01, 7)
-    cloud = sm.PointCloudOnDevice(scan, device=device)
-    n_points = scan.shape[0]
-
-    best_key = torch.zeros(1, dtype=torch.int64, device=f"cuda:{device}")
+    name = args.config
+    if name == "auto":
+        name = "c2" if world_size == 1 and not args.force_dist else "c3"
+    if name in ("c1", "c4", "c5"):
+        assert world_size == 1, f"--config {name} is a single-GPU workload"
+    workload = make_workload(name, args, device, rank, world_size)
+    exchange = getattr(workload, "exchange", None) if use_dist else None
 
     def step():
-        found, scores, poses, stats = sm.match_full_submap_batch(matchers, cloud, args.min_score)
-        if use_dist:
-            # packed (score bits << 32 | global submap id): max == best match of the node
-            best_key.fill_(sharding.pack_best_key(found, scores, rank * n_sub))
-            dist.all_reduce(best_key, op=dist.ReduceOp.MAX)
-        return found, scores, poses, stats
-
-    def match_only():
-        return sm.match_full_submap_batch(matchers, cloud, args.min_score)
-
-    def reduce_best(found, scores):
-        best_key.fill_(sharding.pack_best_key(found, scores, rank * n_sub))
-        dist.all_reduce(best_key, op=dist.ReduceOp.MAX)
+        result = workload.search()
+        if exchange is not None:
+            exchange(result[0], result[1], result[2], torch_device)
+        return result
 
     def run(num_steps):
-        """Runs `num_steps` steps; returns (candidates, coarse, kernel_ms, device_ms, last)."""
-        acc = [0, 0, 0.0, 0.0]
+        """Runs `num_steps` steps; returns (acc, last)."""
+        acc = {k: 0.0 for k in STAT_KEYS}
         last = None
 
         def add(result):
-            acc[0] += result[3]["candidates_scored"]
-            acc[1] += result[3]["coarse_candidates"]
-            acc[2] += result[3]["dominant_kernel_ms"]
-            acc[3] += result[3]["device_ms"]
+            for k in STAT_KEYS:
+                acc[k] += result[3][k]
 
         if args.concurrency <= 1:
             for _ in range(num_steps):
                 last = step()
                 add(last)
-        elif not use_dist:
+        elif exchange is None:
             # Independent searches issued from T host threads, each looping over its share.
             from concurrent.futures import ThreadPoolExecutor
             shares = [num_steps // args.concurrency + (1 if i < num_steps % args.concurrency else 0)
                       for i in range(args.concurrency)]
 
             def worker(n):
-                out = []
-                for _ in range(n):
-                    out.append(match_only())
-                return out
+                return [workload.search() for _ in range(n)]
             with ThreadPoolExecutor(args.concurrency) as pool:
                 for results in pool.map(worker, shares):
                     for r in results:
                         add(r)
                         last = r
         else:
-            # Rounds of T concurrent searches, then one all-reduce per step on this thread
+            # Rounds of T concurrent searches, then the collectives of each step on this thread
             # (collectives must be issued in the same order on every rank).
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(args.concurrency) as pool:
                 done = 0
                 while done < num_steps:
                     n = min(args.concurrency, num_steps - done)
-                    for r in [f.result() for f in [pool.submit(match_only) for _ in range(n)]]:
-                        reduce_best(r[0], r[1])
+                    for r in [f.result() for f in [pool.submit(workload.search) for _ in range(n)]]:
+                        exchange(r[0], r[1], r[2], torch_device)
                         add(r)
                         last = r
                     done += n
-        return acc[0], acc[1], acc[2], acc[3], last
+        return acc, last
 
     run(args.warmup)
 
@@ -279,36 +623,42 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    cand, coarse, kernel_ms, device_ms, (found, scores, poses, stats) = run(args.steps)
+    acc, (found, scores, poses, stats) = run(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
 
     # MAX over ranks of the elapsed time; SUM of the work.
+    cand_local = acc["candidates_scored"]
+    matches_local = workload.matches_per_step * args.steps
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        w = torch.tensor([cand, coarse], dtype=torch.int64, device=f"cuda:{device}")
+        w = torch.tensor([int(cand_local), int(matches_local)], dtype=torch.int64,
+                         device=torch_device)
         dist.all_reduce(w, op=dist.ReduceOp.SUM)
-        cand_total, coarse_total = int(w[0].item()), int(w[1].item())
+        cand_total, matches_total = int(w[0].item()), int(w[1].item())
     else:
-        cand_total, coarse_total = cand, coarse
+        cand_total, matches_total = cand_local, matches_local
 
     out = None
     if rank == 0:
-        value = cand_total / elapsed
-        # Roofline of the dominant kernel (lowest-resolution scoring): algorithmic
-        # bytes = N x 1 B per candidate (one u8 precomputation cell per point)
-        # + 4 B per point per rotation of discretised scan.
-        launches = args.steps
-        coarse_per_launch = coarse / launches
-        scans_per_launch = stats["num_scans"]
-        alg_bytes = coarse_per_launch * n_points * 1.0 + scans_per_launch * n_points * 4.0
-        k_ms = kernel_ms / launches
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        def pmc(kernel):
+            return pmc_traffic_bytes(args.pmc_dir, args.pmc_tag, kernel)
+        config = workload.describe(stats, found)
+        config.update({
+            "name": name,
+            "host_threads": args.concurrency,
+            "candidates_per_step": cand_local / args.steps,
+            "lowest_resolution_candidates_per_step": acc["coarse_candidates"] / args.steps,
+            "matches_per_s": matches_total / elapsed,
+            "device_ms_per_step": acc["device_ms"] / args.steps,
+            "candidate_count": "every scored candidate at every depth, counted once where it is "
+                               "scored (dive and tie re-scoring included)",
+        })
         out = {
             "metric": "candidate poses scored/sec",
-            "value": value,
+            "value": cand_total / elapsed,
             "unit": "candidates/s",
             "n_gpus": world_size,
             "steps": args.steps,
@@ -317,39 +667,18 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8/int32",
+            "dtype": "u8/int32" if name in ("c2", "c3", "c5") else
+                     ("u16->int32 bulk, f32 finalists" if name == "c1" else "f32"),
             "data": "synthetic",
-            "config": {
-                "workload": "2D FastCorrelativeScanMatcher MatchFullSubmap (branch and bound): "
-                            f"{n_points}-point scan vs {n_sub} {args.grid}x{args.grid} "
-                            f"submap(s) per GPU, depth {args.depth}, full-angle search, "
-                            f"min_score {args.min_score}",
-                "submaps_per_gpu": n_sub,
-                "host_threads": args.concurrency,
-                "rotations": scans_per_launch // max(n_sub, 1),
-                "candidates_per_step": cand / args.steps,
-                "lowest_resolution_candidates_per_step": coarse / args.steps,
-                "nodes_expanded_per_step": stats["nodes_expanded"],
-                "matches_per_s": world_size * n_sub * args.steps / elapsed,
-                "found": int(found.sum()),
-                "device_ms_per_step": device_ms / args.steps,
-            },
-            "roofline": {
-                "bound": "hbm", "kernel": DOMINANT_KERNEL,
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
-                "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes,
-                "note": "achieved = algorithmic bytes per launch (1 B per candidate-point + "
-                        "4 B per rotation-point, SURVEY 8d) / HIP-event kernel time; traffic = "
-                        "FETCH_SIZE + WRITE_SIZE bytes per launch from the PMC passes under "
-                        "profiles/ -- the 1.2 MB stack and the phase planes are L2 resident, "
-                        "so measured HBM traffic is ~2% of the algorithmic bytes and the "
-                        "kernel is bound by L1/LDS gather rate, not by HBM",
-            },
+            "constraints_per_s": matches_total / elapsed,
+            "config": config,
+            "roofline": workload.roofline(acc, args.steps, pmc),
         }
-        if not args.no_cpu_baseline and world_size == 1:     # rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(cells0, lim0, args.depth, scan, args.min_score,
-                                               args.cpu_seconds)
+        if world_size == 1 and not use_dist and not args.no_other and name == "c2":
+            config["other"] = other_configs(args, device, torch.cuda.synchronize, pmc)
+        if not args.no_cpu_baseline and world_size == 1 and name in ("c2", "c3"):   # rank 0, N = 1
+            out["cpu_baseline"] = cpu_baseline(workload.cells0, workload.lim0, args.depth,
+                                               workload.scan, args.min_score, args.cpu_seconds)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
