@@ -156,6 +156,13 @@ class WorkspaceLease {
   Workspace* ws_;
 };
 
+// In-kernel timelines (CMX_TIMELINE=1): see cmx_device.h Stamp().  `Enabled` is read once.
+bool TimelineEnabled();
+// Prints, per stamp k, the median / max over blocks of (t_k - t_0) and the span of the whole
+// launch (first t_0 to last stamp) in microseconds; `device` holds blocks x 16 stamps.
+void ReportTimeline(const char* name, const unsigned long long* device, int blocks,
+                    hipStream_t stream);
+
 // Thread-local stream override (cmx_set_stream).
 hipStream_t OverrideStream(int device);
 

@@ -6,6 +6,7 @@
 #include <signal.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <map>
 #include <memory>
@@ -120,6 +121,47 @@ void StageTrace::Report() {
     fprintf(stderr, " %s=%.1f", marks_[i].first.c_str(), ms * 1e3f);
   }
   fprintf(stderr, "\n");
+}
+
+bool TimelineEnabled() {
+  static const bool enabled = [] {
+    const char* env = getenv("CMX_TIMELINE");
+    return env && env[0] == '1';
+  }();
+  return enabled;
+}
+
+void ReportTimeline(const char* name, const unsigned long long* device, int blocks,
+                    hipStream_t stream) {
+  constexpr int K = 16;
+  std::vector<unsigned long long> h(static_cast<size_t>(blocks) * K);
+  if (hipMemcpyAsync(h.data(), device, h.size() * sizeof(unsigned long long),
+                     hipMemcpyDeviceToHost, stream) != hipSuccess ||
+      hipStreamSynchronize(stream) != hipSuccess)
+    return;
+  unsigned long long first = ~0ull, last = 0;
+  int used = 0;
+  for (int b = 0; b < blocks; ++b) {
+    if (!h[static_cast<size_t>(b) * K]) continue;
+    ++used;
+    first = std::min(first, h[static_cast<size_t>(b) * K]);
+    for (int k = 0; k < K; ++k) last = std::max(last, h[static_cast<size_t>(b) * K + k]);
+  }
+  if (!used) return;
+  fprintf(stderr, "[cmx timeline] %s: %d blocks, launch span %.2f us; stamp: median / max us after "
+                  "the block's start (start: median / max after the first block's):\n", name, used,
+          (last - first) * 0.01);
+  for (int k = 0; k < K; ++k) {
+    std::vector<double> d;
+    for (int b = 0; b < blocks; ++b) {
+      const unsigned long long t0 = h[static_cast<size_t>(b) * K], t = h[static_cast<size_t>(b) * K + k];
+      if (!t0 || !t) continue;
+      d.push_back(k == 0 ? (t0 - first) * 0.01 : (t - t0) * 0.01);
+    }
+    if (d.empty()) continue;
+    std::sort(d.begin(), d.end());
+    fprintf(stderr, "   [%2d] %7.2f / %7.2f  (%zu blocks)\n", k, d[d.size() / 2], d.back(), d.size());
+  }
 }
 
 WorkspaceLease::WorkspaceLease(int device) : ws_(nullptr) {

@@ -92,6 +92,26 @@ __device__ __forceinline__ int WaveSum(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);   // row_bcast:31
   return __builtin_amdgcn_readlane(v, 63);
 }
+// Wave-wide min / max in the VALU (same DPP ladder as WaveSum; lanes without a source keep
+// their own value).  All lanes receive the result.
+__device__ __forceinline__ int WaveMinDpp(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));   // row_shr:4
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));   // row_shr:8
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));   // row_bcast:15
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));   // row_bcast:31
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int WaveMaxDpp(int v) {
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
+  return __builtin_amdgcn_readlane(v, 63);
+}
 __device__ __forceinline__ int WaveMin(int v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
@@ -109,6 +129,14 @@ __device__ __forceinline__ unsigned long long WaveMaxU64(unsigned long long v) {
     v = o > v ? o : v;
   }
   return v;
+}
+
+// Optional in-kernel timeline (environment CMX_TIMELINE=1, tools only): thread 0 of a block
+// stores the 100 MHz wall clock at phase boundaries, 16 stamps per block.
+constexpr int kTimelineStamps = 16;
+__device__ __forceinline__ void Stamp(unsigned long long* timeline, int block, int k) {
+  if (timeline && threadIdx.x == 0)
+    timeline[static_cast<size_t>(block) * kTimelineStamps + k] = wall_clock64();
 }
 
 }  // namespace cmx

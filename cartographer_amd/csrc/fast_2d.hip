@@ -608,21 +608,29 @@ ScoreCoarsePlanesDwordKernel(const Fast2DProblem* __restrict__ problems, int n,
 // branch and bound -- GenerateRotatedScans + DiscretizeScans + ShrinkToFit
 // (SM2/correlative_scan_matcher_2d.cc:73-127), GenerateLowestResolutionCandidates and
 // their ScoreCandidates (SM2/fast_correlative_scan_matcher_2d.cc:264-333) -- with the
-// discretised scan and the bucketed plane records staged in LDS only.  As separate
-// launches the same work wrote 27 MB per match (discrete scans + 64-bit records) and the
-// scorer fetched 20 MB of it back; here a scan's 4-byte cells go to HBM only when one of
-// its lowest-resolution candidates can still reach min_score (the tree search reads
-// them), and the per-scan candidate layout needs no prefix sum: scan s owns
-// [s * coarse_stride, (s + 1) * coarse_stride).
-// Arithmetic is PrepScansKernel's + ScoreCoarsePlanesDwordKernel's, operation for
-// operation (bit-exact discretisation, integer sums).
-// Dynamic LDS: rec[n_pad] u64 | pts[n_pad] u32 | hist[nb_cap] | partial[256] | misc[32] |
-// cand_acc[acc_cap].
-constexpr int kFusedMaxPoints = 4096;
+// discretised scan staged in LDS only.  As separate launches the same work wrote 27 MB per
+// match (discrete scans + 64-bit bucketed records) and the scorer fetched 20 MB of it back;
+// here a scan's 4-byte cells go to HBM only when one of its lowest-resolution candidates can
+// still reach min_score (the tree search reads them), and the per-scan candidate layout needs
+// no prefix sum: scan s owns [s * coarse_stride, (s + 1) * coarse_stride).
+//
+// Unlike the separate launches this kernel does NOT sort the points by lattice block.  The
+// sort (histogram, scan, scatter: seven barriers) was a third of a block's latency, and it
+// buys little: a range scan is spatially coherent -- consecutive returns fall into the same
+// 2^(depth-1)-cell lattice block for dozens of points -- so scoring in point order flushes
+// the register accumulators only when a lane group's block really changes.  (An unordered
+// cloud stays correct: it flushes more often.)  Every lane classifies its own point of a
+// 64-point chunk (plane, lattice block); lane group g = lane / 16 takes points 4 t + g, so
+// one buffer_load_dword still serves four points, sixteen of them in flight per wave.
+// The integer sums are order-free: results are bit-identical to the sorted variant
+// (ScoreCoarsePlanesDwordKernel, kept for CMX_FUSED=0 and for problems this kernel does not
+// take).
+// Dynamic LDS: pts[n_pad] u32 | misc[32] | cand_acc[acc_cap].
+constexpr int kFusedMaxPoints = 8192;
 
 __global__ void __launch_bounds__(256)
 PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __restrict__ xyz,
-                     int n, ProblemState* __restrict__ states, int nb_cap, int acc_cap,
+                     int n, ProblemState* __restrict__ states, int acc_cap,
                      int* __restrict__ counters_words, int num_counter_words) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fused_smem[];
   // First kernel of a fully fused batch: it also clears the list counters of the search.
@@ -632,50 +640,63 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
   const int s = blockIdx.x;
   if (!P.use_fused || s >= P.num_scans) return;
   const int n_pad = (n + 63) & ~63;
-  auto* rec = reinterpret_cast<unsigned long long*>(fused_smem);
-  auto* pts = reinterpret_cast<uint32_t*>(rec + n_pad);
-  int* hist = reinterpret_cast<int*>(pts + n_pad);
-  int* partial = hist + nb_cap;
-  int* misc = partial + 256;
+  auto* pts = reinterpret_cast<uint32_t*>(fused_smem);
+  int* misc = reinterpret_cast<int*>(pts + n_pad);
   int* cand_acc = misc + 32;
   const int T = blockDim.x;              // 128, 192 or 256
   const int waves = T >> 6;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned long long* const tl = P.timeline;
+  const int tl_block = blockIdx.y * gridDim.x + blockIdx.x;
+  Stamp(tl, tl_block, 0);
 
   // ---- rotate, translate, discretise (as PrepScansKernel) -------------------
   const Quat q0{P.init_qw, 0.f, 0.f, P.init_qz};
   const float2 r = P.scan_rot[s];
   const Quat qs{r.x, 0.f, 0.f, r.y};
   int lo_x = 0, lo_y = 0, hi_x = 0, hi_y = 0, bad = 0;
-  for (int i = threadIdx.x; i < n; i += T) {
-    const F3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
-    F3 a = Rotate(q0, p);
-    a.x += 0.f; a.y += 0.f; a.z += 0.f;
-    F3 b = Rotate(qs, a);
-    b.x += 0.f; b.y += 0.f;
-    const float x = (1.f * b.x + 0.f * b.y) + P.tx;
-    const float y = (0.f * b.x + 1.f * b.y) + P.ty;
-    const int ix = CellIndexF64(P.max_y - static_cast<double>(y), P.res, P.inv_res);
-    const int iy = CellIndexF64(P.max_x - static_cast<double>(x), P.res, P.inv_res);
-    if (ix < -32768 || ix > 32767 || iy < -32768 || iy > 32767) bad = 1;
-    pts[i] = (static_cast<uint32_t>(ix) & 0xffffu) | (static_cast<uint32_t>(iy) << 16);
-    lo_x = min(lo_x, -ix);
-    lo_y = min(lo_y, -iy);
-    hi_x = max(hi_x, P.nx - 1 - ix);
-    hi_y = max(hi_y, P.ny - 1 - iy);
+  for (int i0 = threadIdx.x; i0 < n; i0 += 4 * T) {
+    // Four points' loads in flight before the first is used.
+    F3 p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = min(i0 + k * T, n - 1);
+      p[k] = F3{xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2]};
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k * T;
+      if (i >= n) break;
+      F3 a = Rotate(q0, p[k]);
+      a.x += 0.f; a.y += 0.f; a.z += 0.f;
+      F3 b = Rotate(qs, a);
+      b.x += 0.f; b.y += 0.f;
+      const float x = (1.f * b.x + 0.f * b.y) + P.tx;
+      const float y = (0.f * b.x + 1.f * b.y) + P.ty;
+      const int ix = CellIndexF64(P.max_y - static_cast<double>(y), P.res, P.inv_res);
+      const int iy = CellIndexF64(P.max_x - static_cast<double>(x), P.res, P.inv_res);
+      if (ix < -32768 || ix > 32767 || iy < -32768 || iy > 32767) bad = 1;
+      pts[i] = (static_cast<uint32_t>(ix) & 0xffffu) | (static_cast<uint32_t>(iy) << 16);
+      lo_x = min(lo_x, -ix);
+      lo_y = min(lo_y, -iy);
+      hi_x = max(hi_x, P.nx - 1 - ix);
+      hi_y = max(hi_y, P.ny - 1 - iy);
+    }
   }
-  lo_x = WaveMin(lo_x); lo_y = WaveMin(lo_y);
-  hi_x = WaveMax(hi_x); hi_y = WaveMax(hi_y);
-  bad = WaveMax(bad);
+  for (int i = threadIdx.x; i < acc_cap; i += T) cand_acc[i] = 0;
+  Stamp(tl, tl_block, 1);      // points discretised
+  lo_x = WaveMinDpp(lo_x); lo_y = WaveMinDpp(lo_y);
+  hi_x = WaveMaxDpp(hi_x); hi_y = WaveMaxDpp(hi_y);
+  bad = WaveMaxDpp(bad);
   if (lane == 0) {
-    int* red = partial + wave * 5;       // partial[] is free until the bucket scan
+    int* red = misc + 8 + wave * 5;      // [4][5]
     red[0] = lo_x; red[1] = lo_y; red[2] = hi_x; red[3] = hi_y; red[4] = bad;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < waves; ++w) {
-      const int* red = partial + w * 5;
+      const int* red = misc + 8 + w * 5;
       lo_x = min(lo_x, red[0]); lo_y = min(lo_y, red[1]);
       hi_x = max(hi_x, red[2]); hi_y = max(hi_y, red[3]);
       bad = max(bad, red[4]);
@@ -694,8 +715,8 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
     if (bad) atomicMax(&states[blockIdx.y].error, 1);
     const int count = dims.x * dims.y;
     const int BW = dims.x + P.plane_i - 1, BH = dims.y + P.plane_j - 1;
-    const int ok = count <= P.coarse_stride && count <= kMaxCoarsePerScan && BW * BH <= nb_cap &&
-                   BW <= 255 && BH <= 255 &&
+    const int ok = count <= P.coarse_stride && count <= kMaxCoarsePerScan && BW <= 255 &&
+                   BH <= 255 &&
                    (dims.x + 2 * P.plane_i - 2) * (dims.y + 2 * P.plane_j - 2) <= acc_cap;
     misc[6] = ok;
     if (!ok) {
@@ -705,80 +726,19 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
   }
   __syncthreads();
   if (!misc[6]) return;
+  Stamp(tl, tl_block, 2);      // bounds known
   const int4 bd = make_int4(misc[0], misc[1], misc[2], misc[3]);
   const int2 dims = make_int2(misc[4], misc[5]);
   const int count = dims.x * dims.y;
   const int PI = P.plane_i, PJ = P.plane_j, PIJ = PI * PJ;
   const int pitch = dims.y + 2 * PJ - 2;
-  const int acc_cells = (dims.x + 2 * PI - 2) * pitch;
-
-  // ---- bucket the points by lattice block (as PrepScansKernel), records to LDS --------
   const int shift = P.depth - 1, w = 1 << shift;
   const int BW = dims.x + PI - 1, BH = dims.y + PJ - 1;
-  const int NB = BW * BH;
-  for (int b = threadIdx.x; b < NB; b += T) hist[b] = 0;
-  for (int i = threadIdx.x; i < acc_cells; i += T) cand_acc[i] = 0;
-  __syncthreads();
-  auto classify = [&](uint32_t packed, int* bucket, int* plane, uint32_t* block = nullptr) {
-    const int U = static_cast<short>(packed & 0xffffu) + bd.x + w - 1;
-    const int V = static_cast<short>(packed >> 16) + bd.z + w - 1;
-    const int bx = (U >> shift) + dims.x - 1, by = (V >> shift) + dims.y - 1;
-    *plane = (V & (w - 1)) * w + (U & (w - 1));
-    *bucket = (bx >= 0 && bx < BW && by >= 0 && by < BH) ? by * BW + bx : -1;
-    if (block) *block = static_cast<uint32_t>(bx) | (static_cast<uint32_t>(by) << 8);
-  };
-  for (int i = threadIdx.x; i < n; i += T) {
-    int bucket, plane;
-    classify(pts[i], &bucket, &plane);
-    if (bucket >= 0) atomicAdd(&hist[bucket], 1);
-  }
-  __syncthreads();
-  const int chunk = (NB + T - 1) / T;
-  const int b0 = min(static_cast<int>(threadIdx.x) * chunk, NB), b1 = min(b0 + chunk, NB);
-  int sum = 0;
-  for (int b = b0; b < b1; ++b) sum += hist[b];
-  partial[threadIdx.x] = sum;
-  if (threadIdx.x + T < 256) partial[threadIdx.x + T] = 0;     // T >= 128
-  __syncthreads();
-  if (threadIdx.x < 64) {   // exclusive scan of the 256 partials by one wave, 4 per lane
-    const int l = threadIdx.x;
-    const int a0 = partial[4 * l], a1 = partial[4 * l + 1], a2 = partial[4 * l + 2],
-              a3 = partial[4 * l + 3];
-    const int mine = a0 + a1 + a2 + a3;
-    int incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int o = __shfl_up(incl, off, 64);
-      if (l >= off) incl += o;
-    }
-    const int base = incl - mine;
-    partial[4 * l] = base;
-    partial[4 * l + 1] = base + a0;
-    partial[4 * l + 2] = base + a0 + a1;
-    partial[4 * l + 3] = base + a0 + a1 + a2;
-    if (l == 63) misc[7] = incl;
-  }
-  __syncthreads();
-  int run = partial[threadIdx.x];
-  for (int b = b0; b < b1; ++b) { const int v = hist[b]; hist[b] = run; run += v; }
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += T) {
-    int bucket, plane;
-    uint32_t block;
-    classify(pts[i], &bucket, &plane, &block);
-    if (bucket >= 0) {
-      const int pos = atomicAdd(&hist[bucket], 1);
-      rec[pos] = (static_cast<unsigned long long>((block & 0xffu) * pitch + (block >> 8)) << 32) |
-                 static_cast<uint32_t>(plane * 64);
-    }
-  }
-  __syncthreads();
 
-  // ---- score (as ScoreCoarsePlanesDwordKernel), records from LDS ---------------------
+  // ---- score in point order (cf. ScoreCoarsePlanesDwordKernel) ------------------------
   const int group = lane >> 4, sub = lane & 15;
-  const int M = misc[7];
-  const int begin = static_cast<int>(static_cast<long long>(M) * wave / waves);
-  const int end = static_cast<int>(static_cast<long long>(M) * (wave + 1) / waves);
+  const int begin = static_cast<int>(static_cast<long long>(n) * wave / waves);
+  const int end = static_cast<int>(static_cast<long long>(n) * (wave + 1) / waves);
   const unsigned zero_plane = 1u << (2 * (P.depth - 1));
   int lane_const[4];
 #pragma unroll
@@ -797,38 +757,48 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
     even = odd = 0;
     pending = 0;
   };
-  constexpr int kSteps = 8;
-  const unsigned long long sentinel = (0xffffffffull << 32) | (zero_plane * 64u);
+  constexpr int kSteps = 16;                // all gathers of a 64-point chunk in flight
+  const int sentinel_plane = static_cast<int>(zero_plane * 64u);
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint8_t*>(P.planes), 0, static_cast<int>((zero_plane + 1) * 64), 0x00020000);
   for (int base_i = begin; base_i < end; base_i += 64) {
-    const unsigned long long mine = base_i + lane < end ? rec[base_i + lane] : sentinel;
-#pragma unroll
-    for (int t0 = 0; t0 < 16; t0 += kSteps) {
-      if (base_i + 4 * t0 >= end) break;      // wave-uniform
-      int block[kSteps];
-      uint32_t q[kSteps];
-#pragma unroll
-      for (int k = 0; k < kSteps; ++k) {
-        const int src = 4 * (t0 + k) + group;
-        const int plane_offset = __shfl(static_cast<int>(mine & 0xffffffffu), src, 64);
-        block[k] = __shfl(static_cast<int>(mine >> 32), src, 64);
-        q[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, plane_offset + 4 * sub, 0, 0);
+    // This lane's point of the chunk: byte offset of its phase plane and the constant
+    // bx * pitch + by of its lattice block (-1: no candidate of this scan can reach it).
+    int my_plane = sentinel_plane, my_block = -1;
+    if (base_i + lane < end) {
+      const uint32_t packed = pts[base_i + lane];
+      const int U = static_cast<short>(packed & 0xffffu) + bd.x + w - 1;
+      const int V = static_cast<short>(packed >> 16) + bd.z + w - 1;
+      const int bx = (U >> shift) + dims.x - 1, by = (V >> shift) + dims.y - 1;
+      if (bx >= 0 && bx < BW && by >= 0 && by < BH) {
+        my_plane = ((V & (w - 1)) * w + (U & (w - 1))) * 64;
+        my_block = bx * pitch + by;
       }
+    }
+    int block[kSteps];
+    uint32_t q[kSteps];
 #pragma unroll
-      for (int k = 0; k < kSteps; ++k) {
-        if (block[k] != cur) {
-          if (cur >= 0) flush();
-          cur = block[k];
-        }
-        even += q[k] & 0x00ff00ffu;
-        odd += (q[k] >> 8) & 0x00ff00ffu;
-        if (++pending == 256) flush();
+    for (int k = 0; k < kSteps; ++k) {
+      const int src = 4 * k + group;          // this lane group's point
+      const int plane_offset = __shfl(my_plane, src, 64);
+      block[k] = __shfl(my_block, src, 64);
+      q[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, plane_offset + 4 * sub, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < kSteps; ++k) {
+      if (block[k] != cur) {                // per lane group; -1 = skipped point (adds zeros)
+        if (cur >= 0) flush();
+        cur = block[k];
       }
+      even += q[k] & 0x00ff00ffu;
+      odd += (q[k] >> 8) & 0x00ff00ffu;
+      if (++pending == 256) flush();        // 16-bit partial sums: 256 x 255 fits
     }
   }
   if (cur >= 0) flush();
+  Stamp(tl, tl_block, 4);      // wave 0 done gathering
   __syncthreads();
+  Stamp(tl, tl_block, 5);      // all waves done
 
   const int base = s * P.coarse_stride;
   auto* coarse_sum = AsGlobal(P.coarse_sum) + base;
@@ -841,20 +811,21 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
     coarse_score[i] = ToScore(P, csum, n);
     if (csum > best_sum) { best_sum = csum; best_index = i; }
   }
-  int2* scratch = reinterpret_cast<int2*>(misc + 8);      // [4]
+  int2* scratch = reinterpret_cast<int2*>(misc + 8);      // [4] (the bounds partials are dead)
   const int2 best = BlockBest(best_sum, best_index, scratch);
   if (threadIdx.x == 0) {
     P.scan_best[s] = best;
-    misc[16] = P.write_all_discrete ||
-               ToScore(P, best.x, n) >= fmaxf(P.min_score, 0.f);
+    misc[7] = P.write_all_discrete || ToScore(P, best.x, n) >= fmaxf(P.min_score, 0.f);
   }
   __syncthreads();
+  Stamp(tl, tl_block, 6);      // sums written
   // The tree search reads a scan's cells only below lowest-resolution nodes that reach
   // the bound, and the bound never drops below max(min_score, 0).
-  if (misc[16]) {
+  if (misc[7]) {
     auto* out = AsGlobal(P.discrete) + static_cast<size_t>(s) * n;
     for (int i = threadIdx.x; i < n; i += T) out[i] = pts[i];
   }
+  Stamp(tl, tl_block, 7);
 }
 
 // ---------------------------------------------------------------------------
@@ -935,21 +906,32 @@ struct SeedScratch {
 
 __device__ __forceinline__ bool PickSeed(const Fast2DProblem& P, int n, int want,
                                          SeedScratch* sh, int* scan_out) {
-  const int tid = threadIdx.x, lane = tid & 63;
-  for (int i = tid; i < 1024; i += blockDim.x) sh->hist[i] = 0;
+  const int tid = threadIdx.x, lane = tid & 63, T = blockDim.x;
+  for (int i = tid; i < 1024; i += T) sh->hist[i] = 0;
   if (tid == 0) { sh->found_scan = -1; sh->total = 0; }
   __syncthreads();
   const int S = P.num_scans;
   const long long range = 255ll * n + 1;
-  const int chunk = (S + static_cast<int>(blockDim.x) - 1) / static_cast<int>(blockDim.x);
-  const int s0 = min(tid * chunk, S), s1 = min(s0 + chunk, S);
   const auto* scan_best = AsGlobal(P.scan_best);
-  int total = 0;
-  for (int s = s0; s < s1; ++s) {
-    atomicAdd(&sh->hist[static_cast<int>(scan_best[s].x * 1024ll / range)], 1);
-    if (want == 0) total += P.coarse_dims[s].x * P.coarse_dims[s].y;
+  const auto* coarse_dims = AsGlobal(P.coarse_dims);
+  // Thread t owns scans t, t + T, ...: coalesced, independent loads (a contiguous chunk per
+  // thread was a chain of L2 round trips); the first kOwn maxima stay in registers for the
+  // second pass.
+  constexpr int kOwn = 16;
+  int own[kOwn];
+#pragma unroll
+  for (int k = 0; k < kOwn; ++k) {
+    const int s = tid + k * T;
+    own[k] = s < S ? scan_best[s].x : -1;
   }
+  int total = 0;
+#pragma unroll
+  for (int k = 0; k < kOwn; ++k)
+    if (own[k] >= 0) atomicAdd(&sh->hist[static_cast<int>(own[k] * 1024ll / range)], 1);
+  for (int s = tid + kOwn * T; s < S; s += T)
+    atomicAdd(&sh->hist[static_cast<int>(scan_best[s].x * 1024ll / range)], 1);
   if (want == 0) {
+    for (int s = tid; s < S; s += T) total += coarse_dims[s].x * coarse_dims[s].y;
     total = WaveSum(total);
     if (lane == 0 && total) atomicAdd(&sh->total, total);
   }
@@ -985,12 +967,16 @@ __device__ __forceinline__ bool PickSeed(const Fast2DProblem& P, int n, int want
   }
   __syncthreads();
   const int tb = sh->threshold_bin;
-  const auto qualifies = [&](int s) {
-    const int best = scan_best[s].x;
-    return static_cast<int>(best * 1024ll / range) >= tb && ToScore(P, best, n) > P.min_score;
+  const auto qualifies = [&](int best) {
+    return best >= 0 && static_cast<int>(best * 1024ll / range) >= tb &&
+           ToScore(P, best, n) > P.min_score;
   };
+  // Seeds are numbered thread-major: thread t's qualifying scans (in its own order) follow
+  // those of threads < t.
   int count = 0;
-  for (int s = s0; s < s1; ++s) count += qualifies(s) ? 1 : 0;
+#pragma unroll
+  for (int k = 0; k < kOwn; ++k) count += qualifies(own[k]) ? 1 : 0;
+  for (int s = tid + kOwn * T; s < S; s += T) count += qualifies(scan_best[s].x) ? 1 : 0;
   int incl = count;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -1002,12 +988,20 @@ __device__ __forceinline__ bool PickSeed(const Fast2DProblem& P, int n, int want
   int before = incl - count;
   for (int w = 0; w < (tid >> 6); ++w) before += sh->wave_total[w];
   if (want >= before && want < before + count) {
-    int k = before;
-    for (int s = s0; s < s1; ++s) {
-      if (!qualifies(s)) continue;
-      if (k == want) { sh->found_scan = s; break; }
+    int k = before, found = -1;
+#pragma unroll
+    for (int j = 0; j < kOwn; ++j) {
+      if (found < 0 && qualifies(own[j])) {
+        if (k == want) found = tid + j * T;
+        ++k;
+      }
+    }
+    for (int s = tid + kOwn * T; s < S && found < 0; s += T) {
+      if (!qualifies(scan_best[s].x)) continue;
+      if (k == want) found = s;
       ++k;
     }
+    sh->found_scan = found;
   }
   __syncthreads();
   *scan_out = sh->found_scan;
@@ -1866,6 +1860,8 @@ struct PreparedBatch {
   // Search scratch carved before the first kernel so that it can clear the counters.
   char* d_misc = nullptr;          // Counters | SelectState[num] | BestLeaf[num] | ProblemState[num]
   bool write_all_discrete = false; // debug entry point: keep every discretised scan
+  unsigned long long* d_timeline = nullptr;   // CMX_TIMELINE=1
+  int timeline_blocks = 0;
 };
 
 // CMX_FUSED=0 routes every problem through the separate prep / score launches (the
@@ -1893,7 +1889,9 @@ long long FusedResidentBlocks(int device, int threads, size_t lds_bytes) {
     (void)hipGetLastError();
     return 0;
   }
-  const long long blocks = static_cast<long long>(per_cu) * cus;
+  // (one fewer per CU than the API says: it over-reports by one for some SGPR counts,
+  // MI355X_MICROARCH.md "Residency and cooperative launch")
+  const long long blocks = static_cast<long long>(std::max(per_cu - 1, 0)) * cus;
   std::lock_guard<std::mutex> lock(mu);
   if (cache->size() < 256) cache->push_back(Key{device, threads, lds, blocks});
   return blocks;
@@ -1926,7 +1924,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
   size_t rotation_floats = 0;
   const bool fused_enabled = FusedEnabled();
   const int n_pad = (n + 63) & ~63;
-  long long fused_nb = 0, fused_acc = 0;
+  long long fused_acc = 0;
   bool any_fused = false, any_unfused = false;
   for (int p = 0; p < num; ++p) {
     const Fast2DMatcher& m = *matchers[p];
@@ -1979,23 +1977,21 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
                    ax + m.plane_i() - 1 <= 255 && ay + m.plane_j() - 1 <= 255 &&   // 8-bit bx, by
                    (ax + 2 * m.plane_i() - 2) * (ay + 2 * m.plane_j() - 2) <= kMaxAccCells &&
                    m.depth() > 1;
-    const long long nb = (ax + m.plane_i() - 1) * (ay + m.plane_j() - 1);
     const long long acc = (ax + 2 * m.plane_i() - 2) * (ay + 2 * m.plane_j() - 2);
     if (P.use_planes)
       out->plane_acc_cells = std::max<long long>(out->plane_acc_cells, acc);
-    // Fused front end: 64-byte planes, the scan + its records + the accumulators within
-    // the 64 KB of dynamic LDS a launch gets without opting in to more.
+    // Fused front end: 64-byte planes, the scan + the accumulators within the 64 KB of
+    // dynamic LDS a launch gets without opting in to more.
     P.use_fused = fused_enabled && P.use_planes && m.plane_stride() == 64 &&
-                  n <= kFusedMaxPoints &&
-                  12ll * n_pad + 4 * (((nb + 3) & ~3ll) + 256 + 32 + acc) <= 64 * 1024;
+                  n <= kFusedMaxPoints && 4ll * n_pad + 4 * (32 + acc) <= 64 * 1024;
     if (P.use_fused) {
       any_fused = true;
-      fused_nb = std::max(fused_nb, (nb + 3) & ~3ll);
       fused_acc = std::max(fused_acc, acc);
     } else {
       any_unfused = true;
     }
     P.write_all_discrete = out->write_all_discrete ? 1 : 0;
+    P.timeline = nullptr;
     coarse_total += cap;
   }
 
@@ -2023,12 +2019,21 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
   for (const Rotation& r : rotations)
     std::memcpy(h_rotations + r.offset, r.table->data(), r.table->size() * sizeof(float2));
 
+  if (TimelineEnabled() && any_fused) {
+    int max_scans = 0;
+    for (const HostSearch& h : out->search) max_scans = std::max(max_scans, h.num_scans);
+    out->timeline_blocks = max_scans * num;
+    const size_t bytes = static_cast<size_t>(out->timeline_blocks) * kTimelineStamps * 8;
+    out->d_timeline = static_cast<unsigned long long*>(ws.dev[15].Reserve(bytes));
+    CMX_HIP(hipMemsetAsync(out->d_timeline, 0, bytes, ws.stream));
+  }
   size_t disc_off = 0, scan_off = 0, coarse_off = 0;
   for (int p = 0; p < num; ++p) {
     const Fast2DMatcher& m = *matchers[p];
     const cmx_grid2d_limits& lim = m.limits();
     const HostSearch& h = out->search[p];
     Fast2DProblem& P = out->h_problems[p];
+    P.timeline = out->d_timeline;
     for (int i = 0; i < m.depth(); ++i) P.level[i] = m.level(i);
     P.depth = m.depth();
     P.nx = lim.num_x_cells; P.ny = lim.num_y_cells;
@@ -2083,15 +2088,18 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     // ~2300 rotations are all resident at once and the launch takes one block's latency;
     // batches run several rounds anyway and use full 256-thread blocks.
     const long long blocks = static_cast<long long>(out->max_scans) * num;
-    const size_t lds = 12 * static_cast<size_t>(n_pad) +
-                       4 * static_cast<size_t>(fused_nb + 256 + 32 + fused_acc);
+    const size_t lds = 4 * static_cast<size_t>(n_pad) + 4 * static_cast<size_t>(32 + fused_acc);
     int threads = 256;
     for (int t : {256, 192, 128}) {
       if (blocks <= FusedResidentBlocks(ws.device, t, lds)) { threads = t; break; }
     }
+    if (const char* e = getenv("CMX_FUSED_THREADS")) threads = atoi(e);   // experiments
+    if (out->trace && out->trace->enabled())
+      fprintf(stderr, "[cmx trace] fused front end: %lld blocks x %d threads, %zu B LDS\n", blocks,
+              threads, lds);
     PrepScoreFusedKernel<<<per_scan, threads, lds, ws.stream>>>(
-        out->d_problems, d_xyz, n, out->d_states, static_cast<int>(fused_nb),
-        static_cast<int>(fused_acc), clear_words, clear_count);
+        out->d_problems, d_xyz, n, out->d_states, static_cast<int>(fused_acc), clear_words,
+        clear_count);
     clear_words = nullptr;
     mark("fused");
   }
@@ -2515,6 +2523,8 @@ void MatchBatch(const cmx_fast2d* const* handles, int num, const cmx_pose2d* ini
   BatchResult result;
   RunBranchAndBound(*ws, batch, &result);
   trace.Report();
+  if (batch.d_timeline)
+    ReportTimeline("PrepScoreFusedKernel", batch.d_timeline, batch.timeline_blocks, ws->stream);
   if (trace.enabled()) {
     for (int p = 0; p < std::min(num, 4); ++p) {
       unsigned long long ex = 0;

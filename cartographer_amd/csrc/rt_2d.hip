@@ -63,7 +63,11 @@ struct Rt2DParams {
   int blocks_per_row;        // aligned 4-cell blocks covering a window row at any phase
   int rounds_rot;            // rotations prepared and scored together by a workgroup
   int list_cap;              // per-rotation capacity of the phase-sorted address list
+  int task_cap;              // per-rotation task descriptor slots (>= chunks of a rotation)
+  int xyz_in_lds;            // the cloud is copied to LDS once per workgroup
   int* qsum;                 // [num_scans][side * side] integer sums of quantised cells
+  unsigned long long* timeline;   // CMX_TIMELINE=1: 16 stamps per bulk / exact block, else null
+  int timeline_exact_base;        // first block slot of the exact kernel
 };
 
 // ProbabilityGrid::GetProbability (mapping/2d/probability_grid.cc:78-82) with
@@ -493,20 +497,32 @@ __device__ __forceinline__ void Load4(int addrs, int lane_off, const unsigned ch
     v[k] = *reinterpret_cast<const uint2*>(smem + a);
   }
 }
-// (asm: as plain integer adds LLVM reassociates the 128 additions of a chunk into a tree
-// evaluated after all 64 loads -- 128 live VGPRs and spills inside this loop.)
+// Two points per instruction: a 64-point chunk never carries out of a 16-bit field
+// (64 * 1023 < 65536), so the packed sums are plain 32-bit additions and v_add3_u32 adds two
+// points' cells at once.  (asm: as C++ integer adds LLVM reassociates the 128 additions of a
+// chunk into a tree evaluated after all 64 loads -- 128 live VGPRs and spills in this loop.)
 __device__ __forceinline__ void Add4(const uint2 (&v)[4], uint32_t* lo, uint32_t* hi) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(*lo) : "v"(v[k].x));
-    asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(*hi) : "v"(v[k].y));
-  }
+  asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(*lo) : "v"(v[0].x), "v"(v[1].x));
+  asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(*hi) : "v"(v[0].y), "v"(v[1].y));
+  asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(*lo) : "v"(v[2].x), "v"(v[3].x));
+  asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(*hi) : "v"(v[2].y), "v"(v[3].y));
+}
+
+// Inclusive prefix sum across the 64 lanes (DPP ladder of WaveSum without the broadcast).
+__device__ __forceinline__ int WaveInclusiveScan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   // row_bcast:15
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);   // row_bcast:31
+  return v;
 }
 
 // grid (workgroups per match, matches); a workgroup stages its match's grid and then takes
 // the rotations blockIdx.x, blockIdx.x + gridDim.x, ... `rounds_rot` at a time.
 // Dynamic LDS: grid[hp][wp] u16 | tmp[R][n_pad] | list[R][list_cap] | counts[R][chunks][4] |
-// offs[R][chunks][4] | acc[R][side^2] | ctl[64].
+// acc[R][side^2] | desc[R][task_cap] | ctl[64] | xyz[3 n] (when it fits).
 __global__ void __launch_bounds__(kBulkThreads)
 Rt2DBulkKernel(const Rt2DParams* __restrict__ params) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bulk_smem[];
@@ -521,12 +537,16 @@ Rt2DBulkKernel(const Rt2DParams* __restrict__ params) {
   uint16_t* grid = reinterpret_cast<uint16_t*>(bulk_smem);
   int* tmp = reinterpret_cast<int*>(bulk_smem + static_cast<size_t>(wp) * hp * 2);
   int* list = tmp + R * n_pad;
-  int* counts = list + R * P.list_cap;
-  int* offs = counts + R * pchunks * 4;
-  int* acc = offs + R * pchunks * 4;
-  int* ctl = acc + R * cands;      // [0] task counter, [8 + 8 rr + ph] first chunk of phase
-                                   // ph of rotation rr (ph = 4: number of chunks)
+  int* counts = list + R * P.list_cap;      // [R][pchunks][4]
+  int* acc = counts + R * pchunks * 4;      // [R][cands]
+  int* desc = acc + R * cands;              // [R][tcap] task descriptors
+  int* ctl = desc + R * P.task_cap;         // [8 rr + ph]: first chunk of phase ph (4: #chunks)
+  float* xyz_lds = reinterpret_cast<float*>(ctl + 64);     // [3 n] when P.xyz_in_lds
+  const int tcap = P.task_cap;
 
+  unsigned long long* const tl = P.timeline;
+  const int tl_block = blockIdx.y * gridDim.x + blockIdx.x;
+  Stamp(tl, tl_block, 0);
   // ---- stage the grid: zero (halo included), then quantise the cells ------------------
   {
     uint4* g4 = reinterpret_cast<uint4*>(grid);
@@ -535,15 +555,64 @@ Rt2DBulkKernel(const Rt2DParams* __restrict__ params) {
   }
   __syncthreads();
   {
-    const auto* cells = AsGlobal(P.cells);
-    const int total = P.nx * P.ny;
-    for (int e = tid; e < total; e += kBulkThreads) {
-      const int y = e / P.nx, x = e - y * P.nx;
-      const unsigned v = cells[e] & 32767u;
-      grid[(y + P.ht) * wp + (x + P.hl)] =
-          static_cast<uint16_t>(v ? (32767u - v) >> kQShift : 0u);
+    // Four independent loads in flight per thread before the first is converted (one load
+    // per loop iteration made this the longest phase of a single match: a chain of L2 round
+    // trips).  Rows of a multiple of 8 cells are read 16 bytes (8 cells) at a time.
+    const auto quantise = [](unsigned v) -> unsigned {
+      v &= 32767u;
+      return v ? (32767u - v) >> kQShift : 0u;
+    };
+    if ((P.nx & 7) == 0 && (reinterpret_cast<uintptr_t>(P.cells) & 15) == 0) {
+      typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+      const auto* cells8 = AsGlobal(reinterpret_cast<const uint4v*>(P.cells));
+      const int total8 = (P.nx * P.ny) >> 3, row8 = P.nx >> 3;
+      for (int base = tid; base < total8; base += 4 * kBulkThreads) {
+        uint4v v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int e = base + k * kBulkThreads;
+          v[k] = cells8[min(e, total8 - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int e = base + k * kBulkThreads;
+          if (e >= total8) break;
+          const int y = e / row8, x = (e - y * row8) << 3;
+          const unsigned w[4] = {v[k][0], v[k][1], v[k][2], v[k][3]};
+          unsigned q[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) q[j] = quantise(w[j]) | (quantise(w[j] >> 16) << 16);
+          // (hl is a multiple of 4 cells: 8-byte aligned destination)
+          uint2* dst = reinterpret_cast<uint2*>(grid + (y + P.ht) * wp + (x + P.hl));
+          dst[0] = make_uint2(q[0], q[1]);
+          dst[1] = make_uint2(q[2], q[3]);
+        }
+      }
+    } else {
+      const auto* cells = AsGlobal(P.cells);
+      const int total = P.nx * P.ny;
+      for (int base = tid; base < total; base += 8 * kBulkThreads) {
+        unsigned v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = cells[min(base + k * kBulkThreads, total - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int e = base + k * kBulkThreads;
+          if (e >= total) break;
+          const int y = e / P.nx, x = e - y * P.nx;
+          grid[(y + P.ht) * wp + (x + P.hl)] = static_cast<uint16_t>(quantise(v[k]));
+        }
+      }
     }
   }
+  // The cloud is rotated once per rotation of this workgroup: keep it on chip (a global
+  // load per rotation and point was a chain of L2 round trips: 1.2 us per rotation).
+  const float* __restrict__ cloud = P.xyz;
+  if (P.xyz_in_lds) {
+    for (int i = tid; i < 3 * n; i += kBulkThreads) xyz_lds[i] = P.xyz[i];
+    cloud = xyz_lds;
+  }
+  Stamp(tl, tl_block, 1);      // grid staged (this wave)
   const Quat q0{P.init_qw, 0.f, 0.f, P.init_qz};
   const int slices = (side * B + 63) >> 6;
   const float kScale = ((1.f - 0.1f) - (1.f - (1.f - 0.1f))) / 32766.f;   // (kMaxCC - kMinCC) / 32766
@@ -553,9 +622,10 @@ Rt2DBulkKernel(const Rt2DParams* __restrict__ params) {
     const int round_rot = min(R, (P.num_scans - s0 + static_cast<int>(gridDim.x) - 1) /
                                      static_cast<int>(gridDim.x));
     __syncthreads();                       // previous round's accumulators have been read
+    if (s0 == static_cast<int>(blockIdx.x)) Stamp(tl, tl_block, 2);      // grid staged (all waves)
     for (int i = tid; i < round_rot * cands; i += kBulkThreads) acc[i] = 0;
     for (int i = tid; i < round_rot * P.list_cap; i += kBulkThreads) list[i] = 0;   // null block
-    if (tid == 0) ctl[0] = 0;
+    for (int i = tid; i < round_rot * tcap; i += kBulkThreads) desc[i] = -1;
     // ---- discretise: one wavefront per 64 points of one rotation -----------------------
     for (int vw = wave; vw < round_rot * pchunks; vw += kBulkWaves) {
       const int rr = vw / pchunks, pc = vw - rr * pchunks;
@@ -566,7 +636,7 @@ Rt2DBulkKernel(const Rt2DParams* __restrict__ params) {
       int packed = -1;
       if (i < n) {
         int ix, iy;
-        Rt2DPointCell(P, q0, qs, P.xyz, i, &ix, &iy);
+        Rt2DPointCell(P, q0, qs, cloud, i, &ix, &iy);
         const int wx = ix - P.nl + P.hl, wy = iy - P.nl + P.ht;   // window start, LDS coordinates
         packed = (((wy * wp + (wx & ~3)) * 2) << 2) | (wx & 3);
       }
@@ -578,23 +648,31 @@ Rt2DBulkKernel(const Rt2DParams* __restrict__ params) {
       }
     }
     __syncthreads();
-    // ---- per (rotation, phase): exclusive offsets, phases padded to whole chunks --------
-    if (tid < round_rot * 4) {
-      const int rr = tid >> 2, ph = tid & 3;
-      int start = 0, mine = 0;
-      for (int q = 0; q <= ph; ++q) {
-        int total = 0;
-        for (int pc = 0; pc < pchunks; ++pc) total += counts[(rr * pchunks + pc) * 4 + q];
-        if (q < ph) start += (total + kQChunk - 1) / kQChunk;
-        else mine = total;
+    if (s0 == static_cast<int>(blockIdx.x)) Stamp(tl, tl_block, 3);      // points discretised
+    // ---- per (rotation, phase): exclusive offsets, phases padded to whole chunks; one
+    // wavefront per rotation, lanes = 64-point chunks, DPP prefix sums ----------------------
+    if (wave < round_rot) {
+      const int rr = wave;
+      int start_chunk = 0;                  // first chunk of the current phase
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        int carry = 0;                      // points of this phase in earlier 64-chunk blocks
+        for (int p0 = 0; p0 < pchunks; p0 += 64) {
+          const int pc = p0 + lane;
+          const int c = pc < pchunks ? counts[(rr * pchunks + pc) * 4 + ph] : 0;
+          const int incl = WaveInclusiveScan(c);
+          if (pc < pchunks)
+            counts[(rr * pchunks + pc) * 4 + ph] = start_chunk * kQChunk + carry + incl - c;
+          carry += __builtin_amdgcn_readlane(incl, 63);
+        }
+        if (lane == 0) ctl[8 * rr + ph] = start_chunk;
+        const int chunks = (carry + kQChunk - 1) / kQChunk;
+        // Task descriptors of this phase's chunks: rr | phase << 4 | chunk << 8.
+        for (int c = lane; c < chunks; c += 64)
+          desc[rr * tcap + start_chunk + c] = rr | (ph << 4) | ((start_chunk + c) << 8);
+        start_chunk += chunks;
       }
-      ctl[8 + 8 * rr + ph] = start;
-      if (ph == 3) ctl[8 + 8 * rr + 4] = start + (mine + kQChunk - 1) / kQChunk;
-      int run = start * kQChunk;
-      for (int pc = 0; pc < pchunks; ++pc) {
-        offs[(rr * pchunks + pc) * 4 + ph] = run;
-        run += counts[(rr * pchunks + pc) * 4 + ph];
-      }
+      if (lane == 0) ctl[8 * rr + 4] = start_chunk;
     }
     __syncthreads();
     for (int vw = wave; vw < round_rot * pchunks; vw += kBulkWaves) {
@@ -606,31 +684,20 @@ Rt2DBulkKernel(const Rt2DParams* __restrict__ params) {
       for (int q = 0; q < 4; ++q) {
         const unsigned long long m = __ballot(packed >= 0 && ph == q);
         if (packed >= 0 && ph == q) {
-          const int pos = offs[(rr * pchunks + pc) * 4 + q] +
+          const int pos = counts[(rr * pchunks + pc) * 4 + q] +
                           __popcll(m & ((1ull << lane) - 1ull));
           list[rr * P.list_cap + pos] = packed >> 2;
         }
       }
     }
     __syncthreads();
-    // ---- tasks: (rotation, 64-point chunk, lane slice), taken dynamically ---------------
-    int tasks = 0;
-    for (int rr = 0; rr < round_rot; ++rr) tasks += ctl[8 + 8 * rr + 4] * slices;
-    for (;;) {
-      int t = 0;
-      if (lane == 0) t = atomicAdd(&ctl[0], 1);
-      t = __builtin_amdgcn_readfirstlane(t);
-      if (t >= tasks) break;
-      int rr = 0;
-      for (; rr < round_rot; ++rr) {
-        const int mine = ctl[8 + 8 * rr + 4] * slices;
-        if (t < mine) break;
-        t -= mine;
-      }
-      const int chunk = t / slices, slice = t - chunk * slices;
-      int phase = 0;
-#pragma unroll
-      for (int q = 1; q < 4; ++q) phase += chunk >= ctl[8 + 8 * rr + q] ? 1 : 0;
+    if (s0 == static_cast<int>(blockIdx.x)) Stamp(tl, tl_block, 4);      // lists sorted by phase
+    // ---- tasks: (rotation, 64-point chunk, lane slice), dealt round-robin to the waves ----
+    for (int t = wave; t < round_rot * tcap * slices; t += kBulkWaves) {
+      const int slot = t / slices, slice = t - slot * slices;
+      const int d = desc[slot];
+      if (d < 0) continue;                   // wave-uniform
+      const int rr = d & 15, phase = (d >> 4) & 15, chunk = d >> 8;
       const int item = slice * 64 + lane;
       const bool valid = item < side * B;
       const int row = valid ? item / B : 0, blk = valid ? item - row * B : 0;
@@ -677,7 +744,9 @@ Rt2DBulkKernel(const Rt2DParams* __restrict__ params) {
         }
       }
     }
+    if (s0 == static_cast<int>(blockIdx.x)) Stamp(tl, tl_block, 5);      // wave 0 out of tasks
     __syncthreads();
+    if (s0 == static_cast<int>(blockIdx.x)) Stamp(tl, tl_block, 6);      // all tasks done
     // ---- per candidate: integer sum out, weighted lower bound into the match's maximum --
     float lb_max = 0.f;
     for (int e = tid; e < round_rot * cands; e += kBulkThreads) {
@@ -698,65 +767,78 @@ Rt2DBulkKernel(const Rt2DParams* __restrict__ params) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) bits = max(bits, __shfl_xor(bits, off, 64));
     if (lane == 0 && bits) atomicMax(&P.misc[0], bits);
+    if (s0 == static_cast<int>(blockIdx.x)) Stamp(tl, tl_block, 7);      // first round finished
   }
+  Stamp(tl, tl_block, 8);
 }
 
-// grid (num_scans, matches), one wavefront: the finalists of one rotation, exact f32 chain.
-__global__ void __launch_bounds__(64)
-Rt2DExactKernel(const Rt2DParams* __restrict__ params) {
+// grid (num_scans, matches), 256 threads: the finalists of one rotation with the reference's
+// sequential f32 sum (:61-75).  The sum is a chain of N dependent additions, but the N lookups
+// behind it are independent: all threads fetch the probabilities of a finalist's points into
+// LDS (a few loads per thread, all in flight at once), then ONE lane per finalist runs the
+// chain out of LDS.  (One lane doing its own 891 gathers took 130 us of dependent round
+// trips for a single finalist.)  Up to `group` finalists share a pass.
+// Dynamic LDS: cells[n_pad] u32 | prob[group][n_pad + 1] f32 | fin[side^2].
+__global__ void __launch_bounds__(256)
+Rt2DExactKernel(const Rt2DParams* __restrict__ params, int group) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char exact_smem[];
   const Rt2DParams& P = params[blockIdx.y];
   const int s = blockIdx.x;
   if (s >= P.num_scans) return;
-  const int lane = threadIdx.x;
-  const int side = 2 * P.nl + 1, cands = side * side, n = P.n;
+  const int tid = threadIdx.x;
+  const int side = 2 * P.nl + 1, cands = side * side, n = P.n, n_pad = P.n_pad;
+  unsigned long long* const tl = P.timeline;
+  const int tl_block = P.timeline_exact_base + blockIdx.y * gridDim.x + blockIdx.x;
+  Stamp(tl, tl_block, 0);
+  uint32_t* cellbuf = reinterpret_cast<uint32_t*>(exact_smem);
+  float* prob = reinterpret_cast<float*>(cellbuf + n_pad);
+  int* fin = reinterpret_cast<int*>(prob + group * (n_pad + 1));
+  __shared__ int nfin;
+  if (tid == 0) nfin = 0;
+  __syncthreads();
   const float kScale = ((1.f - 0.1f) - (1.f - (1.f - 0.1f))) / 32766.f;
   const float best_lb = __uint_as_float(P.misc[0]);
   const int* __restrict__ qsum = P.qsum + static_cast<size_t>(s) * cands;
-  __shared__ int fin[64];
-  __shared__ uint32_t cellbuf[64];
-  __shared__ int nfin;
-  const float2 r = P.scan_rot[s];
-  const Quat q0{P.init_qw, 0.f, 0.f, P.init_qz};
-  const Quat qs{r.x, 0.f, 0.f, r.y};
-  const auto* cells = AsGlobal(P.cells);
-  for (int c0 = 0; c0 < cands; c0 += 64) {
-    // Candidates of this slice whose weighted upper bound reaches the best lower bound.
-    const int c = c0 + lane;
-    bool is_fin = false;
-    if (c < cands) {
-      const int dxi = c / side, dyi = c - dxi * side;
-      const double hi_score = 0.1 + static_cast<double>(kScale) *
-                                        (static_cast<double>(qsum[c]) * (1 << kQShift) +
-                                         ((1 << kQShift) - 1) * static_cast<double>(n)) / n;
-      const float ub = static_cast<float>(hi_score + kBoundSlack) *
-                       Rt2DWeight(P, s, dxi - P.nl, dyi - P.nl) * (1.f + 1e-5f);
-      is_fin = ub >= best_lb;
+  // Candidates of this rotation whose weighted upper bound reaches the best lower bound.
+  for (int c = tid; c < cands; c += blockDim.x) {
+    const int dxi = c / side, dyi = c - dxi * side;
+    const double hi_score = 0.1 + static_cast<double>(kScale) *
+                                      (static_cast<double>(qsum[c]) * (1 << kQShift) +
+                                       ((1 << kQShift) - 1) * static_cast<double>(n)) / n;
+    const float ub = static_cast<float>(hi_score + kBoundSlack) *
+                     Rt2DWeight(P, s, dxi - P.nl, dyi - P.nl) * (1.f + 1e-5f);
+    if (ub >= best_lb) fin[atomicAdd(&nfin, 1)] = c;
+  }
+  __syncthreads();
+  const int count = nfin;
+  if (count == 0) return;                 // most rotations
+  Stamp(tl, tl_block, 1);
+  {
+    const float2 r = P.scan_rot[s];
+    const Quat q0{P.init_qw, 0.f, 0.f, P.init_qz};
+    const Quat qs{r.x, 0.f, 0.f, r.y};
+    for (int i = tid; i < n; i += blockDim.x) {
+      int ix, iy;
+      Rt2DPointCell(P, q0, qs, P.xyz, i, &ix, &iy);
+      cellbuf[i] = (static_cast<uint32_t>(ix) & 0xffffu) | (static_cast<uint32_t>(iy) << 16);
     }
-    const unsigned long long mask = __ballot(is_fin);
-    if (mask == 0) continue;             // wave-uniform
-    if (is_fin) fin[__popcll(mask & ((1ull << lane) - 1ull))] = c;
-    if (lane == 0) nfin = __popcll(mask);
-    __syncthreads();
-    const bool have = lane < nfin;
-    const int mine = fin[have ? lane : 0];
-    const int dxi = mine / side, dyi = mine - dxi * side;
-    const int dx = dxi - P.nl, dy = dyi - P.nl;
-    float sum = 0.f;
-    for (int base = 0; base < n; base += 64) {
-      __syncthreads();
-      if (base + lane < n) {
-        int ix, iy;
-        Rt2DPointCell(P, q0, qs, P.xyz, base + lane, &ix, &iy);
-        cellbuf[lane] = (static_cast<uint32_t>(ix) & 0xffffu) | (static_cast<uint32_t>(iy) << 16);
-      }
-      __syncthreads();
-      const int cnt = min(64, n - base);
-      for (int k0 = 0; k0 < cnt; k0 += 16) {
-        unsigned raw[16];
-        bool inside[16];
+  }
+  __syncthreads();
+  Stamp(tl, tl_block, 2);
+  const auto* cells = AsGlobal(P.cells);
+  const int row = n_pad + 1;              // odd row pitch: the chain lanes hit distinct banks
+  for (int f0 = 0; f0 < count; f0 += group) {
+    const int g = min(group, count - f0);
+    for (int f = 0; f < g; ++f) {
+      const int c = fin[f0 + f];
+      const int dxi = c / side, dyi = c - dxi * side;
+      const int dx = dxi - P.nl, dy = dyi - P.nl;
+      for (int base = tid; base < n; base += 4 * blockDim.x) {
+        unsigned raw[4];
+        bool inside[4];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const uint32_t pc = cellbuf[min(k0 + k, 63)];
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t pc = cellbuf[min(base + k * static_cast<int>(blockDim.x), n - 1)];
           const int x = static_cast<short>(pc & 0xffffu) + dx;
           const int y = static_cast<short>(pc >> 16) + dy;
           inside[k] = static_cast<unsigned>(x) < static_cast<unsigned>(P.nx) &&
@@ -764,14 +846,28 @@ Rt2DExactKernel(const Rt2DParams* __restrict__ params) {
           raw[k] = cells[inside[k] ? P.nx * y + x : 0];     // unconditional load, masked below
         }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          if (k0 + k < cnt)                                  // wave-uniform
-            sum += inside[k] ? CellProbability(raw[k]) : 0.1f;   // kMinProbability outside
+        for (int k = 0; k < 4; ++k) {
+          const int i = base + k * blockDim.x;
+          if (i < n) prob[f * row + i] = inside[k] ? CellProbability(raw[k]) : 0.1f;   // kMinProbability
         }
       }
     }
-    if (have) {
+    __syncthreads();
+    if (tid < g) {
+      const float* mine = prob + tid * row;
+      float sum = 0.f;
+      int i = 0;
+      for (; i + 8 <= n; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = mine[i + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum += v[k];            // in point order
+      }
+      for (; i < n; ++i) sum += mine[i];
       const float score = sum / static_cast<float>(n);
+      const int c = fin[f0 + tid];
+      const int dxi = c / side, dyi = c - dxi * side;
       const int cg = (s * side + dxi) * side + dyi;           // x outer, y inner (:99-113)
       const unsigned slot = atomicAdd(&P.misc[1], 1u);
       if (slot < static_cast<unsigned>(kFinalistCap)) {
@@ -784,6 +880,7 @@ Rt2DExactKernel(const Rt2DParams* __restrict__ params) {
     }
     __syncthreads();
   }
+  Stamp(tl, tl_block, 3);
 }
 
 size_t Align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
@@ -895,7 +992,7 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
   CMX_REQUIRE(num <= 65535, "too many matches in one batch");
 
   // ---- LDS-staged integer bulk pass: eligibility and geometry ------------------------
-  struct Bulk { int wp, hp, hl, ht, bpr, rounds, list_cap; size_t lds; size_t off_qsum; };
+  struct Bulk { int wp, hp, hl, ht, bpr, rounds, list_cap, task_cap; bool xyz_lds; size_t lds; size_t off_qsum; };
   std::vector<Bulk> bulk(num);
   bool use_bulk = !tsdf && !force_legacy && BulkEnabled();
   size_t bulk_lds = 0, qsum_total = 0;
@@ -911,20 +1008,44 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
     if ((wp >> 4) % 2 == 0) wp += 16;               // 16 x odd: conflict-free row pitch
     b.wp = wp;
     b.list_cap = pl.n_pad + 4 * kQChunk;
+    b.task_cap = pl.n_pad / 64 + 4;
     const size_t grid_bytes = static_cast<size_t>(b.wp) * b.hp * 2;
     const size_t per_rot = 4 * (static_cast<size_t>(pl.n_pad) + b.list_cap +
-                                8 * static_cast<size_t>(pl.n_pad / 64) + side * side);
+                                4 * static_cast<size_t>(pl.n_pad / 64) + side * side + b.task_cap);
     const size_t budget = 160 * 1024 - 512;
+    const size_t fixed = grid_bytes + 256;
     if (pl.n > kBulkMaxPoints || pl.nx > 16384 || pl.ny > 16384 ||
-        grid_bytes + per_rot + 256 > budget) {
+        fixed + per_rot > budget) {
       use_bulk = false;
       break;
     }
-    b.rounds = static_cast<int>(std::min<size_t>(kMaxRoundRot, (budget - 256 - grid_bytes) / per_rot));
-    b.lds = grid_bytes + b.rounds * per_rot + 256;
+    // The cloud itself goes to LDS when at least two rotations per round still fit.
+    const size_t xyz_bytes = 12 * static_cast<size_t>(pl.n);
+    b.xyz_lds = fixed + xyz_bytes + 2 * per_rot <= budget;
+    const size_t avail = budget - fixed - (b.xyz_lds ? xyz_bytes : 0);
+    b.rounds = static_cast<int>(std::min<size_t>(kMaxRoundRot, avail / per_rot));
+    b.lds = fixed + (b.xyz_lds ? xyz_bytes : 0) + b.rounds * per_rot;
     bulk_lds = std::max(bulk_lds, b.lds);
     b.off_qsum = qsum_total;
     qsum_total += static_cast<size_t>(pl.num_scans) * side * side;
+  }
+  // Exact kernel: finalists per pass so that cells + probabilities + list stay within 60 KB.
+  int exact_group = 8;
+  size_t exact_lds = 0;
+  if (use_bulk) {
+    size_t max_npad = 0, max_cands = 0;
+    for (int m = 0; m < num; ++m) {
+      max_npad = std::max<size_t>(max_npad, plan[m].n_pad);
+      max_cands = std::max<size_t>(max_cands, plan[m].side * plan[m].side);
+    }
+    const size_t fixed = 4 * max_npad + 4 * max_cands + 16;
+    const size_t budget = 60 * 1024;
+    if (fixed + 4 * (max_npad + 1) > budget) {
+      use_bulk = false;
+    } else {
+      exact_group = static_cast<int>(std::min<size_t>(8, (budget - fixed) / (4 * (max_npad + 1))));
+      exact_lds = fixed + 4 * (max_npad + 1) * exact_group;
+    }
   }
   // The per-match result words ride in the upload (zeroed) so that no kernel has to clear
   // them before the bulk kernel's atomicMax.
@@ -947,6 +1068,25 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
                                                         (kFinalistCap - kFinalistHead));
   unsigned* h_misc = ws->pinned[1].ReserveAs<unsigned>(static_cast<size_t>(num) * 128);
 
+  // CMX_TIMELINE=1: stamps of the bulk blocks, then of the exact blocks.
+  unsigned long long* d_timeline = nullptr;
+  int per_match_wgs = static_cast<int>(max_scans);
+  if (use_bulk) {
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    // Workgroups per match: one rotation each for a few matches (latency), fewer for big
+    // batches (the grid is staged once per workgroup): about two rounds of the chip.
+    if (static_cast<long long>(per_match_wgs) * num > 2ll * cus)
+      per_match_wgs = std::max(1, std::min<int>(per_match_wgs, (2 * cus + num - 1) / num));
+    if (const char* e = getenv("CMX_RT2D_WGS")) per_match_wgs = std::max(1, atoi(e));   // experiments
+  }
+  const int timeline_bulk_blocks = per_match_wgs * num;
+  const int timeline_blocks = timeline_bulk_blocks + static_cast<int>(max_scans) * num;
+  if (use_bulk && TimelineEnabled()) {
+    const size_t bytes = static_cast<size_t>(timeline_blocks) * kTimelineStamps * 8;
+    d_timeline = static_cast<unsigned long long*>(ws->dev[8].Reserve(bytes));
+    CMX_HIP(hipMemsetAsync(d_timeline, 0, bytes, ws->stream));
+  }
   Rt2DParams* h_params = reinterpret_cast<Rt2DParams*>(h_in);
   for (int m = 0; m < num; ++m) {
     const Rt2DItem& it = items[m];
@@ -991,10 +1131,13 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
     P.weighted = d_weighted + pl.off_scores;
     P.num_candidates = static_cast<int>(pl.num_candidates);
     P.prep_blocks = pl.num_scans + static_cast<int>(DivUp(pl.stride * pl.rows, 1024));
+    P.timeline = d_timeline;
+    P.timeline_exact_base = timeline_bulk_blocks;
     if (use_bulk) {
       const Bulk& b = bulk[m];
       P.wp = b.wp; P.hp = b.hp; P.hl = b.hl; P.ht = b.ht;
       P.blocks_per_row = b.bpr; P.rounds_rot = b.rounds; P.list_cap = b.list_cap;
+      P.task_cap = b.task_cap; P.xyz_in_lds = b.xyz_lds ? 1 : 0;
       P.qsum = d_qsum + b.off_qsum;
     }
     h_params[m] = P;
@@ -1012,17 +1155,10 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
                                  160 * 1024) == hipSuccess;
     }();
     CMX_REQUIRE(lds_opt_in, "cannot opt in to 160 KB of dynamic LDS");
-    // Workgroups per match: one rotation each for a few matches (latency), fewer for big
-    // batches (the grid is staged once per workgroup): about two rounds of the chip.
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-    int per_match = static_cast<int>(max_scans);
-    if (static_cast<long long>(per_match) * num > 2ll * cus)
-      per_match = std::max(1, std::min<int>(per_match, (2 * cus + num - 1) / num));
     CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
-    Rt2DBulkKernel<<<dim3(per_match, num), kBulkThreads, bulk_lds, ws->stream>>>(d_params);
+    Rt2DBulkKernel<<<dim3(per_match_wgs, num), kBulkThreads, bulk_lds, ws->stream>>>(d_params);
     CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
-    Rt2DExactKernel<<<dim3(max_scans, num), 64, 0, ws->stream>>>(d_params);
+    Rt2DExactKernel<<<dim3(max_scans, num), 256, exact_lds, ws->stream>>>(d_params, exact_group);
   } else if (tsdf) {
     Rt2DPrepKernel<true><<<prep_grid, 256, 0, ws->stream>>>(d_params);
     CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
@@ -1049,6 +1185,12 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
                          ws->stream));
   CMX_HIP(hipStreamSynchronize(ws->stream));
 
+  if (d_timeline) {
+    ReportTimeline("Rt2DBulkKernel", d_timeline, timeline_bulk_blocks, ws->stream);
+    ReportTimeline("Rt2DExactKernel", d_timeline + static_cast<size_t>(timeline_bulk_blocks) *
+                                                       kTimelineStamps,
+                   timeline_blocks - timeline_bulk_blocks, ws->stream);
+  }
   if (use_bulk) {
     for (int m = 0; m < num; ++m)
       if (h_misc[static_cast<size_t>(m) * 128 + 1] > static_cast<unsigned>(kFinalistCap)) return false;

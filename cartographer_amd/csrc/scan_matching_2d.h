@@ -65,6 +65,7 @@ struct Fast2DProblem {
                         // (plane byte offset, bx * pitch + by of the plane scorer's accumulators)
   int* sorted_count;    // [num_scans]
   int2* scan_best;      // [num_scans] (best sum, local candidate index) of each scan
+  unsigned long long* timeline;   // CMX_TIMELINE=1: 16 stamps per fused-kernel block, else null
 };
 
 // Branch-and-bound node.
