@@ -58,6 +58,26 @@ __device__ __forceinline__ int CellIndexF64(double t, double res, double inv_res
   return LRoundF64(t / res - 0.5);
 }
 
+// The same cell index from an f32 estimate when that is provably enough.  t32 = (RN32(max)
+// - v) * RN32(1 / res) - 0.5 differs from the reference's f64 value by less than
+// (|max| + |max - v|) / res * 2^-24 + |q| * 2^-22 (three roundings and the two rounded
+// constants); when t32 is further than twice that from every half-integer, rint(t32) is the
+// reference's lround.  Otherwise (about one point in a thousand, NaN / inf / huge values
+// included) the f64 expression above decides.  The f64 path costs ~160 cycles per wavefront
+// and coordinate, most of a scan's preparation; this one ~20.
+__device__ __forceinline__ int CellIndexFast(double max_d, float v, double res, double inv_res) {
+  const float maxf = static_cast<float>(max_d);
+  const float inv_resf = static_cast<float>(inv_res);
+  const float a = maxf - v;
+  const float b = a * inv_resf;
+  const float t = b - 0.5f;
+  const float r = rintf(t);
+  const float margin = 0.5f - fabsf(t - r);
+  const float bound = (fabsf(maxf) + fabsf(a)) * inv_resf * 0x1p-23f + fabsf(b) * 0x1p-21f + 0x1p-20f;
+  if (margin > bound && fabsf(t) < 1e6f) return static_cast<int>(r);
+  return CellIndexF64(max_d - static_cast<double>(v), res, inv_res);
+}
+
 struct F3 { float x, y, z; };
 struct Quat { float w, x, y, z; };
 
@@ -73,6 +93,24 @@ __device__ __forceinline__ F3 Rotate(const Quat& q, const F3& v) {
   const F3 c = Cross(qv, uv);
   return {(v.x + q.w * uv.x) + c.x, (v.y + q.w * uv.y) + c.y, (v.z + q.w * uv.z) + c.z};
 }
+// Rotate(q, v) for q = (w, 0, 0, z) -- a yaw quaternion -- without the products by the zero
+// components.  For finite inputs the x and y results are bit-identical to Rotate's:
+//   uv = 2 ((0,0,z) x v)   = 2 (0 v.z - z v.y, z v.x - 0 v.z, .) = 2 (-(z v.y), z v.x, .)
+//   c  = (0,0,z) x uv      = (0 uv.z - z uv.y, z uv.x - 0 uv.z, .) = (-(z uv.y), z uv.x, .)
+//   out = (v + w uv) + c
+// (0 a is a signed zero; b - 0 and 0 - b differ from b and -b at most in the sign of a zero
+// result, and a zero's sign disappears in the next addition or in `max - coordinate`).  The z
+// result is not computed: the 2D cell index never reads it.  Non-finite coordinates (which
+// Rotate would turn into NaNs everywhere) are outside the contract.
+__device__ __forceinline__ void RotateZ(float w, float z, float vx, float vy, float* ox,
+                                        float* oy) {
+  float uvx = -(z * vy), uvy = z * vx;
+  uvx += uvx; uvy += uvy;
+  const float cx = -(z * uvy), cy = z * uvx;
+  *ox = (vx + w * uvx) + cx;
+  *oy = (vy + w * uvy) + cy;
+}
+
 __device__ __forceinline__ Quat QuatMul(const Quat& a, const Quat& b) {
   return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z,
           a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,

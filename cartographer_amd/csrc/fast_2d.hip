@@ -622,6 +622,9 @@ ScoreCoarsePlanesDwordKernel(const Fast2DProblem* __restrict__ problems, int n,
 // cloud stays correct: it flushes more often.)  Every lane classifies its own point of a
 // 64-point chunk (plane, lattice block); lane group g = lane / 16 takes points 4 t + g, so
 // one buffer_load_dword still serves four points, sixteen of them in flight per wave.
+// (Wider gathers do not help: the plane reads run at ~8 B/clk per CU whatever the
+// instruction width -- buffer_load_dwordx4, sixteen points per instruction, was slower --
+// because every point touches its own 64-byte half of a 128-byte L2 line.)
 // The integer sums are order-free: results are bit-identical to the sorted variant
 // (ScoreCoarsePlanesDwordKernel, kept for CMX_FUSED=0 and for problems this kernel does not
 // take).
@@ -637,7 +640,13 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
   if (blockIdx.x == 0 && blockIdx.y == 0 && counters_words)
     for (int i = threadIdx.x; i < num_counter_words; i += blockDim.x) counters_words[i] = 0;
   const Fast2DProblem& P = problems[blockIdx.y];
-  const int s = blockIdx.x;
+  // Blocks b, b + 256, b + 512, ... tend to share a CU (b % 8 picks the XCD, round-robin
+  // within it): give them ADJACENT rotations.  Neighbouring rotations move a point by less
+  // than a cell, so co-resident blocks gather the same or the neighbouring phase plane at
+  // about the same time and meet in the CU's L1 instead of each going to L2.  (Any bijection
+  // is correct; only speed depends on the dispatch order.)
+  const int slots = (gridDim.x + 255) >> 8;
+  const int s = (blockIdx.x & 255) * slots + (blockIdx.x >> 8);
   if (!P.use_fused || s >= P.num_scans) return;
   const int n_pad = (n + 63) & ~63;
   auto* pts = reinterpret_cast<uint32_t*>(fused_smem);
@@ -651,10 +660,9 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
   const int tl_block = blockIdx.y * gridDim.x + blockIdx.x;
   Stamp(tl, tl_block, 0);
 
-  // ---- rotate, translate, discretise (as PrepScansKernel) -------------------
-  const Quat q0{P.init_qw, 0.f, 0.f, P.init_qz};
+  // ---- rotate, translate, discretise (PrepScansKernel's arithmetic) ----------
   const float2 r = P.scan_rot[s];
-  const Quat qs{r.x, 0.f, 0.f, r.y};
+  const bool identity_q0 = P.init_qw == 1.f && P.init_qz == 0.f;
   int lo_x = 0, lo_y = 0, hi_x = 0, hi_y = 0, bad = 0;
   for (int i0 = threadIdx.x; i0 < n; i0 += 4 * T) {
     // Four points' loads in flight before the first is used.
@@ -668,14 +676,19 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
     for (int k = 0; k < 4; ++k) {
       const int i = i0 + k * T;
       if (i >= n) break;
-      F3 a = Rotate(q0, p[k]);
-      a.x += 0.f; a.y += 0.f; a.z += 0.f;
-      F3 b = Rotate(qs, a);
-      b.x += 0.f; b.y += 0.f;
-      const float x = (1.f * b.x + 0.f * b.y) + P.tx;
-      const float y = (0.f * b.x + 1.f * b.y) + P.ty;
-      const int ix = CellIndexF64(P.max_y - static_cast<double>(y), P.res, P.inv_res);
-      const int iy = CellIndexF64(P.max_x - static_cast<double>(x), P.res, P.inv_res);
+      // Two yaw rotations (initial estimate, then this scan's perturbation), then the
+      // translation: Rotate / `+ 0.f` / `1.f * x + 0.f * y` of PrepScansKernel without the
+      // terms that are exactly zero (RotateZ, cmx_device.h).  A full-submap search starts
+      // from yaw 0: its first rotation is the identity.
+      float ax = p[k].x, ay = p[k].y;
+      if (!identity_q0) RotateZ(P.init_qw, P.init_qz, p[k].x, p[k].y, &ax, &ay);
+      float bx, by;
+      RotateZ(r.x, r.y, ax, ay, &bx, &by);
+      const float x = bx + P.tx;
+      const float y = by + P.ty;
+      // lround((max - v) / res - 0.5) from an f32 estimate when provably equal (cmx_device.h)
+      const int ix = CellIndexFast(P.max_y, y, P.res, P.inv_res);
+      const int iy = CellIndexFast(P.max_x, x, P.res, P.inv_res);
       if (ix < -32768 || ix > 32767 || iy < -32768 || iy > 32767) bad = 1;
       pts[i] = (static_cast<uint32_t>(ix) & 0xffffu) | (static_cast<uint32_t>(iy) << 16);
       lo_x = min(lo_x, -ix);
@@ -2022,7 +2035,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
   if (TimelineEnabled() && any_fused) {
     int max_scans = 0;
     for (const HostSearch& h : out->search) max_scans = std::max(max_scans, h.num_scans);
-    out->timeline_blocks = max_scans * num;
+    out->timeline_blocks = (max_scans + 255) / 256 * 256 * num;
     const size_t bytes = static_cast<size_t>(out->timeline_blocks) * kTimelineStamps * 8;
     out->d_timeline = static_cast<unsigned long long*>(ws.dev[15].Reserve(bytes));
     CMX_HIP(hipMemsetAsync(out->d_timeline, 0, bytes, ws.stream));
@@ -2097,7 +2110,9 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     if (out->trace && out->trace->enabled())
       fprintf(stderr, "[cmx trace] fused front end: %lld blocks x %d threads, %zu B LDS\n", blocks,
               threads, lds);
-    PrepScoreFusedKernel<<<per_scan, threads, lds, ws.stream>>>(
+    // (grid.x rounded up to a multiple of 256 for the rotation -> block map of the kernel)
+    const dim3 fused_grid((out->max_scans + 255) / 256 * 256, num);
+    PrepScoreFusedKernel<<<fused_grid, threads, lds, ws.stream>>>(
         out->d_problems, d_xyz, n, out->d_states, static_cast<int>(fused_acc), clear_words,
         clear_count);
     clear_words = nullptr;

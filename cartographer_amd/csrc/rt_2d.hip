@@ -455,18 +455,17 @@ constexpr double kBoundSlack = 1e-4;        // f32-chain rounding (N * 2^-24 * s
 // one cell further outside the grid than any offset can reach back in (same as
 // Rt2DPrepKernel above).
 __device__ __forceinline__ void Rt2DPointCell(const Rt2DParams& P, const Quat& q0, const Quat& qs,
-                                              const float* __restrict__ xyz, int i, int* ix,
-                                              int* iy) {
-  const F3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
-  F3 a = Rotate(q0, p);
-  a.x += 0.f; a.y += 0.f; a.z += 0.f;
-  F3 b = Rotate(qs, a);
-  b.x += 0.f; b.y += 0.f;
-  const float x = (1.f * b.x + 0.f * b.y) + P.tx;
-  const float y = (0.f * b.x + 1.f * b.y) + P.ty;
-  // lround((max - v) / res - 0.5): division-free when provably equal (cmx_device.h).
-  const int cx = CellIndexF64(P.max_y - static_cast<double>(y), P.res, P.inv_res);
-  const int cy = CellIndexF64(P.max_x - static_cast<double>(x), P.res, P.inv_res);
+                                              const F3& p, int* ix, int* iy) {
+  // Rt2DPrepKernel's two yaw rotations and translation without the exactly-zero terms
+  // (RotateZ, cmx_device.h: bit-identical x / y for finite coordinates).
+  float ax, ay, bx, by;
+  RotateZ(q0.w, q0.z, p.x, p.y, &ax, &ay);
+  RotateZ(qs.w, qs.z, ax, ay, &bx, &by);
+  const float x = bx + P.tx;
+  const float y = by + P.ty;
+  // lround((max - v) / res - 0.5) from an f32 estimate when provably equal (cmx_device.h).
+  const int cx = CellIndexFast(P.max_y, y, P.res, P.inv_res);
+  const int cy = CellIndexFast(P.max_x, x, P.res, P.inv_res);
   *ix = min(max(cx, -(P.nl + 1)), P.nx + P.nl);
   *iy = min(max(cy, -(P.nl + 1)), P.ny + P.nl);
 }
@@ -485,18 +484,30 @@ __device__ __forceinline__ float Rt2DWeight(const Rt2DParams& P, int s, int dx, 
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-// Points K0 .. K0+3 of a chunk: wave-uniform block address from lane K0+k of `addrs`
-// (immediate lane index: a v_readlane with an SGPR index needs a hazard nop), the lane's own
-// (row, block) offset on top, one ds_read_b64 each.
-template <int K0>
-__device__ __forceinline__ void Load4(int addrs, int lane_off, const unsigned char* smem,
-                                      uint2 (&v)[4]) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int a = __builtin_amdgcn_readlane(addrs, K0 + k) + lane_off;
-    v[k] = *reinterpret_cast<const uint2*>(smem + a);
-  }
+// Points 16 J + K0 .. 16 J + K0 + 3 of a chunk.  `addrs` holds, in every row of 16 lanes, the
+// block addresses of points 16 J .. 16 J + 15: `v_add_u32_dpp ... row_newbcast:k` adds lane k
+// of the row to the lane's own (row, block) offset in ONE instruction (a v_readlane to an
+// SGPR, its hazard nop and the add were three issue slots per point).
+template <int K>
+__device__ __forceinline__ int RowBroadcastAdd(int addrs, int lane_off) {
+  int out;   // (asm: the compiler splits the intrinsic form into v_mov_b32_dpp + v_add3_u32)
+  asm("v_add_u32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+      : "=v"(out) : "v"(addrs), "v"(lane_off), "i"(K));
+  return out;
 }
+// (`lane_off` already contains the LDS address of the staged grid: the sum is an absolute LDS
+// address, read through an address_space(3) pointer -- `smem + offset` costs an extra v_add of
+// the array's base per read.)
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+typedef const uint2v __attribute__((address_space(3)))* LdsUint2Ptr;
+template <int K0>
+__device__ __forceinline__ void Load4(int addrs, int lane_off, uint2 (&v)[4]) {
+  { const uint2v t = *reinterpret_cast<LdsUint2Ptr>(static_cast<uintptr_t>(RowBroadcastAdd<K0>(addrs, lane_off))); v[0] = make_uint2(t[0], t[1]); }
+  { const uint2v t = *reinterpret_cast<LdsUint2Ptr>(static_cast<uintptr_t>(RowBroadcastAdd<K0 + 1>(addrs, lane_off))); v[1] = make_uint2(t[0], t[1]); }
+  { const uint2v t = *reinterpret_cast<LdsUint2Ptr>(static_cast<uintptr_t>(RowBroadcastAdd<K0 + 2>(addrs, lane_off))); v[2] = make_uint2(t[0], t[1]); }
+  { const uint2v t = *reinterpret_cast<LdsUint2Ptr>(static_cast<uintptr_t>(RowBroadcastAdd<K0 + 3>(addrs, lane_off))); v[3] = make_uint2(t[0], t[1]); }
+}
+
 // Two points per instruction: a 64-point chunk never carries out of a 16-bit field
 // (64 * 1023 < 65536), so the packed sums are plain 32-bit additions and v_add3_u32 adds two
 // points' cells at once.  (asm: as C++ integer adds LLVM reassociates the 128 additions of a
@@ -541,7 +552,7 @@ Rt2DBulkKernel(const Rt2DParams* __restrict__ params) {
   int* acc = counts + R * pchunks * 4;      // [R][cands]
   int* desc = acc + R * cands;              // [R][tcap] task descriptors
   int* ctl = desc + R * P.task_cap;         // [8 rr + ph]: first chunk of phase ph (4: #chunks)
-  float* xyz_lds = reinterpret_cast<float*>(ctl + 64);     // [3 n] when P.xyz_in_lds
+  float* xyz_lds = reinterpret_cast<float*>(ctl + 64);     // x[n_pad] y[n_pad] z[n_pad] when P.xyz_in_lds
   const int tcap = P.task_cap;
 
   unsigned long long* const tl = P.timeline;
@@ -607,10 +618,13 @@ Rt2DBulkKernel(const Rt2DParams* __restrict__ params) {
   }
   // The cloud is rotated once per rotation of this workgroup: keep it on chip (a global
   // load per rotation and point was a chain of L2 round trips: 1.2 us per rotation).
-  const float* __restrict__ cloud = P.xyz;
+  // (as three arrays: an xyz triple per lane is a 12-byte-strided ds_read_b96, off its natural
+  // alignment three times out of four and replayed at 64 cycles each.)
   if (P.xyz_in_lds) {
-    for (int i = tid; i < 3 * n; i += kBulkThreads) xyz_lds[i] = P.xyz[i];
-    cloud = xyz_lds;
+    for (int i = tid; i < 3 * n; i += kBulkThreads) {
+      const int pt = i / 3, c = i - 3 * pt;
+      xyz_lds[c * n_pad + pt] = P.xyz[i];
+    }
   }
   Stamp(tl, tl_block, 1);      // grid staged (this wave)
   const Quat q0{P.init_qw, 0.f, 0.f, P.init_qz};
@@ -636,7 +650,10 @@ Rt2DBulkKernel(const Rt2DParams* __restrict__ params) {
       int packed = -1;
       if (i < n) {
         int ix, iy;
-        Rt2DPointCell(P, q0, qs, cloud, i, &ix, &iy);
+        const F3 p = P.xyz_in_lds
+                         ? F3{xyz_lds[i], xyz_lds[n_pad + i], xyz_lds[2 * n_pad + i]}
+                         : F3{P.xyz[3 * i], P.xyz[3 * i + 1], P.xyz[3 * i + 2]};
+        Rt2DPointCell(P, q0, qs, p, &ix, &iy);
         const int wx = ix - P.nl + P.hl, wy = iy - P.nl + P.ht;   // window start, LDS coordinates
         packed = (((wy * wp + (wx & ~3)) * 2) << 2) | (wx & 3);
       }
@@ -693,42 +710,53 @@ Rt2DBulkKernel(const Rt2DParams* __restrict__ params) {
     __syncthreads();
     if (s0 == static_cast<int>(blockIdx.x)) Stamp(tl, tl_block, 4);      // lists sorted by phase
     // ---- tasks: (rotation, 64-point chunk, lane slice), dealt round-robin to the waves ----
-    for (int t = wave; t < round_rot * tcap * slices; t += kBulkWaves) {
-      const int slot = t / slices, slice = t - slot * slices;
-      const int d = desc[slot];
-      if (d < 0) continue;                   // wave-uniform
-      const int rr = d & 15, phase = (d >> 4) & 15, chunk = d >> 8;
+    int first_task[kMaxRoundRot + 1];        // dense numbering over the round's rotations
+    first_task[0] = 0;
+#pragma unroll
+    for (int rr = 0; rr < kMaxRoundRot; ++rr)
+      first_task[rr + 1] = first_task[rr] + (rr < round_rot ? ctl[8 * rr + 4] * slices : 0);
+    for (int t = wave; t < first_task[kMaxRoundRot]; t += kBulkWaves) {
+      int rr = 0;
+#pragma unroll
+      for (int q = 1; q < kMaxRoundRot; ++q) rr += t >= first_task[q] ? 1 : 0;
+      const int local = t - first_task[rr];
+      const int chunk = local / slices, slice = local - chunk * slices;
+      const int phase = (desc[rr * tcap + chunk] >> 4) & 15;
       const int item = slice * 64 + lane;
       const bool valid = item < side * B;
       const int row = valid ? item / B : 0, blk = valid ? item - row * B : 0;
-      const int lane_off = (row * wp + blk * 4) * 2;
-      const int my_addr = list[rr * P.list_cap + chunk * kQChunk + lane];
+      const int lane_off =
+          (row * wp + blk * 4) * 2 +
+          static_cast<int>(reinterpret_cast<uintptr_t>(
+              (const __attribute__((address_space(3))) unsigned char*)bulk_smem));
+      const int* my_list = list + rr * P.list_cap + chunk * kQChunk + (lane & 15);
+      const int a0 = my_list[0], a1 = my_list[16], a2 = my_list[32], a3 = my_list[48];
       uint32_t lo = 0, hi = 0;      // packed 16-bit sums: cells (0 | 1 << 16), (2 | 3 << 16)
       // Three banks of 4 LDS reads: groups g+1 and g+2 are in flight while group g is added
       // (12 outstanding: lgkmcnt counts to 15; 16 waves per CU keep the LDS pipe busy).  The
       // scheduling barriers keep the compiler from hoisting all 64 reads.
       uint2 v0[4], v1[4], v2[4];
-      Load4<0>(my_addr, lane_off, bulk_smem, v0);
-      Load4<4>(my_addr, lane_off, bulk_smem, v1);
+      Load4<0>(a0, lane_off, v0);
+      Load4<4>(a0, lane_off, v1);
       __builtin_amdgcn_sched_barrier(0);
-#define CMX_RT2D_STEP(K0, LOAD_BANK, ADD_BANK)                     \
-      Load4<K0>(my_addr, lane_off, bulk_smem, LOAD_BANK);           \
+#define CMX_RT2D_STEP(ADDRS, K0, LOAD_BANK, ADD_BANK)              \
+      Load4<K0>(ADDRS, lane_off, LOAD_BANK);             \
       Add4(ADD_BANK, &lo, &hi);                                     \
       __builtin_amdgcn_sched_barrier(0);
-      CMX_RT2D_STEP(8, v2, v0)
-      CMX_RT2D_STEP(12, v0, v1)
-      CMX_RT2D_STEP(16, v1, v2)
-      CMX_RT2D_STEP(20, v2, v0)
-      CMX_RT2D_STEP(24, v0, v1)
-      CMX_RT2D_STEP(28, v1, v2)
-      CMX_RT2D_STEP(32, v2, v0)
-      CMX_RT2D_STEP(36, v0, v1)
-      CMX_RT2D_STEP(40, v1, v2)
-      CMX_RT2D_STEP(44, v2, v0)
-      CMX_RT2D_STEP(48, v0, v1)
-      CMX_RT2D_STEP(52, v1, v2)
-      CMX_RT2D_STEP(56, v2, v0)
-      CMX_RT2D_STEP(60, v0, v1)
+      CMX_RT2D_STEP(a0, 8, v2, v0)
+      CMX_RT2D_STEP(a0, 12, v0, v1)
+      CMX_RT2D_STEP(a1, 0, v1, v2)
+      CMX_RT2D_STEP(a1, 4, v2, v0)
+      CMX_RT2D_STEP(a1, 8, v0, v1)
+      CMX_RT2D_STEP(a1, 12, v1, v2)
+      CMX_RT2D_STEP(a2, 0, v2, v0)
+      CMX_RT2D_STEP(a2, 4, v0, v1)
+      CMX_RT2D_STEP(a2, 8, v1, v2)
+      CMX_RT2D_STEP(a2, 12, v2, v0)
+      CMX_RT2D_STEP(a3, 0, v0, v1)
+      CMX_RT2D_STEP(a3, 4, v1, v2)
+      CMX_RT2D_STEP(a3, 8, v2, v0)
+      CMX_RT2D_STEP(a3, 12, v0, v1)
 #undef CMX_RT2D_STEP
       Add4(v2, &lo, &hi);
       Add4(v0, &lo, &hi);
@@ -819,7 +847,7 @@ Rt2DExactKernel(const Rt2DParams* __restrict__ params, int group) {
     const Quat qs{r.x, 0.f, 0.f, r.y};
     for (int i = tid; i < n; i += blockDim.x) {
       int ix, iy;
-      Rt2DPointCell(P, q0, qs, P.xyz, i, &ix, &iy);
+      Rt2DPointCell(P, q0, qs, F3{P.xyz[3 * i], P.xyz[3 * i + 1], P.xyz[3 * i + 2]}, &ix, &iy);
       cellbuf[i] = (static_cast<uint32_t>(ix) & 0xffffu) | (static_cast<uint32_t>(iy) << 16);
     }
   }
@@ -1020,7 +1048,7 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
       break;
     }
     // The cloud itself goes to LDS when at least two rotations per round still fit.
-    const size_t xyz_bytes = 12 * static_cast<size_t>(pl.n);
+    const size_t xyz_bytes = 12 * static_cast<size_t>(pl.n_pad);
     b.xyz_lds = fixed + xyz_bytes + 2 * per_rot <= budget;
     const size_t avail = budget - fixed - (b.xyz_lds ? xyz_bytes : 0);
     b.rounds = static_cast<int>(std::min<size_t>(kMaxRoundRot, avail / per_rot));

@@ -77,6 +77,77 @@ def test_cell_index_f64_matches_ieee_division(res):
     assert np.array_equal(n[fast].astype(np.int64), exact[fast])
 
 
+@pytest.mark.parametrize("res,max_v", [(0.05, 10.0), (0.05, -3.7), (0.1, 100.0), (0.025, 0.0),
+                                       (0.05, 512.35), (1.0 / 3.0, 7.0)])
+def test_cell_index_fast_f32_estimate_is_exact_when_taken(res, max_v):
+    """CellIndexFast (cmx_device.h): lround((max - v) / res - 0.5) -- MapLimits::GetCellIndex,
+    f64 in the reference -- decided from an f32 estimate whenever the estimate is further from
+    every half-integer than its error bound.  Values on, next to and far from rounding
+    boundaries, both signs, large offsets."""
+    res64, max64 = np.float64(res), np.float64(max_v)
+    inv64 = np.float64(1.0) / res64
+    rng = np.random.default_rng(11)
+    k = rng.integers(-4000, 4000, 1_500_000)
+    # v such that (max - v) / res - 0.5 is (nearly) a half-integer / an integer / anything
+    near_half = (max64 - (k + 1.0) * res64).astype(np.float32)
+    near_half = (near_half.view(np.int32) + rng.integers(-6, 7, near_half.size).astype(np.int32)) \
+        .view(np.float32)
+    near_int = (max64 - (k + 0.5) * res64).astype(np.float32)
+    anything = rng.uniform(max_v - 300.0, max_v + 300.0, 1_500_000).astype(np.float32)
+    v = np.concatenate([near_half, near_int, anything])
+    v = v[np.isfinite(v)]
+    f = np.float32
+    maxf, invf = f(max64), f(inv64)
+    a = (maxf - v).astype(np.float32)
+    b = (a * invf).astype(np.float32)
+    t = (b - f(0.5)).astype(np.float32)
+    r = np.rint(t).astype(np.float32)
+    margin = (f(0.5) - np.abs((t - r).astype(np.float32))).astype(np.float32)
+    bound = (((np.abs(maxf) + np.abs(a)).astype(np.float32) * invf).astype(np.float32)
+             * f(2.0 ** -23)).astype(np.float32)
+    bound = (bound + (np.abs(b) * f(2.0 ** -21)).astype(np.float32)).astype(np.float32)
+    bound = (bound + f(2.0 ** -20)).astype(np.float32)
+    fast = (margin > bound) & (np.abs(t) < f(1e6))
+    exact = _lround((max64 - v.astype(np.float64)) / res64 - 0.5)
+    assert np.array_equal(r[fast].astype(np.int64), exact[fast])
+    # the estimate decides all but a sliver of ordinary points
+    assert fast[-anything.size:].mean() > 0.99
+
+
+def test_rotate_z_equals_the_full_quaternion_rotation():
+    """RotateZ (cmx_device.h) drops the products by the zero components of a yaw quaternion.
+    Its x / y must equal Eigen's `_transformVector` order of operations (Rotate) bit for bit on
+    finite inputs, zeros compared by value (a zero's sign disappears in the next addition)."""
+    f = np.float32
+    rng = np.random.default_rng(3)
+    m = 2_000_000
+    ang = rng.uniform(-np.pi, np.pi, m)
+    w, z = np.cos(ang / 2).astype(f), np.sin(ang / 2).astype(f)
+    vx = rng.uniform(-40, 40, m).astype(f)
+    vy = rng.uniform(-40, 40, m).astype(f)
+    vz = rng.uniform(-3, 3, m).astype(f)
+    # some exact zeros / axis-aligned points / tiny values
+    vx[:1000] = 0; vy[1000:2000] = 0; vz[2000:3000] = 0
+    vx[3000:4000] *= f(1e-30); z[4000:5000] = 0; w[4000:5000] = 1
+    zero = np.zeros(m, f)
+
+    def cross(a, b):
+        return (a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0])
+    qv = (zero, zero, z)
+    v = (vx, vy, vz)
+    uv = cross(qv, v)
+    uv = tuple((c + c).astype(f) for c in uv)
+    c = cross(qv, uv)
+    full_x = ((vx + w * uv[0]).astype(f) + c[0]).astype(f)
+    full_y = ((vy + w * uv[1]).astype(f) + c[1]).astype(f)
+    uvx = (-(z * vy)).astype(f); uvy = (z * vx).astype(f)
+    uvx = (uvx + uvx).astype(f); uvy = (uvy + uvy).astype(f)
+    cx = (-(z * uvy)).astype(f); cy = (z * uvx).astype(f)
+    fast_x = ((vx + w * uvx).astype(f) + cx).astype(f)
+    fast_y = ((vy + w * uvy).astype(f) + cy).astype(f)
+    assert np.array_equal(full_x, fast_x) and np.array_equal(full_y, fast_y)   # -0 == +0
+
+
 def test_parent_cell_is_max_of_child_cells(oracle, synth):
     """The identity behind the early exit of node expansions (fast_2d.hip): a width-2h
     precomputation cell equals the maximum of the four width-h cells its children read
