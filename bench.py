@@ -556,7 +556,7 @@ def main():
     device = local_rank if torch.cuda.is_available() else 0
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(device)
-    torch_device = f"cuda:{device}"
+    torch_device = os.environ.get("CMX_BENCH_TORCH_DEVICE", f"cuda:{device}")   # tests: "cpu"
 
     name = args.config
     if name == "auto":
@@ -564,7 +564,8 @@ def main():
     if name in ("c1", "c4", "c5"):
         assert world_size == 1, f"--config {name} is a single-GPU workload"
     workload = make_workload(name, args, device, rank, world_size)
-    exchange = getattr(workload, "exchange", None) if use_dist else None
+    # c3 always runs its exchange (a no-op gather with one rank): same code path at every N
+    exchange = getattr(workload, "exchange", None) if (use_dist or name == "c3") else None
 
     def step():
         result = workload.search()

@@ -4,7 +4,8 @@ Every (scan, submap) search is independent
 (``cartographer/mapping/internal/constraints/constraint_builder_2d.cc:97-111`` schedules them as
 independent tasks), so submaps are partitioned over the ranks with no data-path collective.  The
 only exchange is the node-wide best match: ONE all-reduce(max) of an 8-byte key
-``score_bits << 32 | global_submap_id`` (positive f32 bit patterns order like the floats).
+``score_bits << 32 | (0xFFFFFFFF - global_submap_id)`` (positive f32 bit patterns order like the
+floats; equal scores resolve to the lowest submap id on any number of ranks).
 ``torch.distributed`` backend "nccl" is RCCL over xGMI on MI355X; the same code runs on "gloo".
 """
 import numpy as np
@@ -17,25 +18,31 @@ def shard_range(num_items, rank, world_size):
     return begin, begin + base + (1 if rank < extra else 0)
 
 
+NOT_FOUND = -1       # sentinel key: no rank found a match (distinct from every real key, all >= 0)
+
+
 def pack_best_key(found, scores, first_global_id):
-    """Key of the best local match; 0 when nothing was found."""
+    """Key of the best local match: ``score_bits << 32 | (0xFFFFFFFF - global id)``, so that the
+    MAX over ranks picks the best score and, among equal scores, the LOWEST submap id -- the same
+    rule as within a rank (first maximum), whatever the sharding.  NOT_FOUND when nothing was
+    found."""
     found = np.asarray(found)
     scores = np.asarray(scores, np.float32)
     if found.size == 0 or not found.any():
-        return 0
+        return NOT_FOUND
     masked = np.where(found > 0, scores, np.float32(-1.0))
     i = int(np.argmax(masked))            # first maximum: lowest submap id wins ties locally
-    bits = int(scores[i:i + 1].view(np.uint32)[0])
-    return (bits << 32) | (first_global_id + i)
+    bits = int(scores[i:i + 1].view(np.uint32)[0])      # scores > 0: sign bit clear, key >= 0
+    return (bits << 32) | (0xFFFFFFFF - (first_global_id + i))
 
 
 def unpack_best_key(key):
     """Returns (score or None, global submap id or None)."""
     key = int(key)
-    if key == 0:
+    if key < 0:
         return None, None
     score = float(np.array([key >> 32], np.uint32).view(np.float32)[0])
-    return score, key & 0xFFFFFFFF
+    return score, 0xFFFFFFFF - (key & 0xFFFFFFFF)
 
 
 def all_reduce_best(key, device=None):

@@ -19,6 +19,7 @@ def install(setattr_=setattr):
     import torch
     import torch.distributed as dist
     from cartographer_amd import scan_matching as sm
+    os.environ["CMX_BENCH_TORCH_DEVICE"] = "cpu"
     setattr_(torch.cuda, "is_available", lambda: True)
     setattr_(torch.cuda, "set_device", lambda d: None)
     setattr_(torch.cuda, "synchronize", lambda *a, **k: None)

@@ -31,8 +31,8 @@ def stubbed_bench(monkeypatch):
 
     def run(*argv):
         calls.clear()
-        monkeypatch.setattr(sys, "argv", ["bench.py", "--no-cpu-baseline", "--grid", "120"]
-                            + list(argv))
+        monkeypatch.setattr(sys, "argv", ["bench.py", "--no-cpu-baseline", "--no-other", "--grid",
+                                          "120"] + list(argv))
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):
             bench.main()
@@ -41,11 +41,13 @@ def stubbed_bench(monkeypatch):
     return run
 
 
-@pytest.mark.parametrize("extra", [(), ("--concurrency", "3"), ("--force-dist",),
-                                   ("--force-dist", "--concurrency", "3"), ("--submaps", "4")])
+@pytest.mark.parametrize("extra", [(), ("--concurrency", "3"), ("--force-dist", "--submaps", "2"),
+                                   ("--force-dist", "--concurrency", "3", "--submaps", "3"),
+                                   ("--submaps", "4"), ("--config", "c3", "--submaps", "5")])
 def test_bench_issues_exactly_the_requested_steps(stubbed_bench, extra):
     out, calls, num_lines = stubbed_bench("--steps", "7", "--warmup", "3", *extra)
-    submaps = 4 if "--submaps" in extra else 1
+    submaps = int(extra[extra.index("--submaps") + 1]) if "--submaps" in extra else 1
+    sharded = "--force-dist" in extra or "c3" in extra
     assert num_lines == 1                                    # one JSON line, nothing after it
     assert calls == [submaps] * 10                           # 3 untimed + exactly 7 timed
     for key in REQUIRED:
@@ -59,8 +61,17 @@ def test_bench_issues_exactly_the_requested_steps(stubbed_bench, extra):
     roof = out["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in roof, key
-    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s"
+    # the dominant kernel is bound by L2 -> L1 gathers, not by HBM: an on-chip peak, frac <= 1
+    # on hardware, and the HBM-side ratios next to it
+    assert roof["bound"] == "l2-gather" and roof["unit"] == "GB/s" and roof["peak"] == 34500.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+    for key in ("algorithmic_GBps", "hbm_frac_algorithmic", "hbm_frac_traffic",
+                "kernel_share_of_step_device_time"):
+        assert key in roof, key
+    assert out["config"]["name"] == ("c3" if sharded else "c2")
+    if sharded:      # the reference's semantics (every constraint to every rank) + the best match
+        assert out["config"]["constraints_found_node_wide"] == submaps
+        assert out["config"]["best_match"]["submap"] == 0
     assert abs(out["value"] * out["ms_per_step"] * 1e-3 * 7 - 7000.0 * submaps) < 1e-6
     assert "cpu_baseline" not in out                         # --no-cpu-baseline
 
@@ -94,7 +105,7 @@ def test_bench_two_ranks_gloo():
                    MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(root, "tests", "bench_stub.py"), "--gpus", "2",
-             "--steps", "5", "--warmup", "2", "--grid", "120"],
+             "--steps", "5", "--warmup", "2", "--grid", "120", "--submaps", "3"],
             env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=300) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
@@ -105,8 +116,11 @@ def test_bench_two_ranks_gloo():
     assert not any(l.startswith("{") for l in outs[1][0].splitlines())    # rank 0 only
     out = json.loads(lines0[-1])
     assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2
-    assert out["config"]["candidates_per_step"] == 1000.0       # per rank (weak scaling)
-    assert abs(out["value"] * out["ms_per_step"] * 1e-3 * 5 - 2 * 5000.0) < 1e-6   # both ranks
+    assert out["config"]["name"] == "c3" and out["scaling"] == "weak"
+    assert out["config"]["submaps_per_gpu"] == 3                # distinct submaps: 6 node-wide
+    assert out["config"]["constraints_found_node_wide"] == 6    # all-gathered from both ranks
+    assert out["config"]["candidates_per_step"] == 3000.0       # per rank (weak scaling)
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 * 5 - 2 * 5 * 3000.0) < 1e-6   # both ranks
     assert "cpu_baseline" not in out                            # N = 1 only
     for _, err in outs:
         assert "issued 7 matches" in err

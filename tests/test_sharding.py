@@ -28,11 +28,16 @@ def test_key_roundtrip_and_order():
     assert sharding.unpack_best_key(a) == (pytest.approx(0.75), 42)
     assert sharding.unpack_best_key(b) == (pytest.approx(0.74), 3)
     assert a > b                      # keys order like the scores
-    assert sharding.pack_best_key([0, 0], [0.5, 0.6], 0) == 0
-    assert sharding.unpack_best_key(0) == (None, None)
-    # equal scores: the larger submap id wins the max (deterministic)
+    assert sharding.pack_best_key([0, 0], [0.5, 0.6], 0) == sharding.NOT_FOUND
+    assert sharding.unpack_best_key(sharding.NOT_FOUND) == (None, None)
+    assert sharding.NOT_FOUND < min(a, b)          # any found match beats "nothing found"
+    # a match at submap 0 with the smallest positive score is still distinct from NOT_FOUND
+    z = sharding.pack_best_key([1], [np.float32(1e-45)], 0)
+    assert z > sharding.NOT_FOUND and sharding.unpack_best_key(z)[1] == 0
+    # equal scores: the LOWER submap id wins the max, as it does within a rank -- the result
+    # does not depend on how the submaps are sharded
     c = sharding.pack_best_key([1], [0.75], 100)
-    assert max(a, c) == c
+    assert max(a, c) == a and sharding.unpack_best_key(max(a, c))[1] == 42
 
 
 def test_all_gather_results_single_process():
