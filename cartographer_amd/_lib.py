@@ -61,6 +61,21 @@ class MatchStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
 
+class Ceres2DOptions(C.Structure):
+    _fields_ = [("occupied_space_weight", C.c_double), ("translation_weight", C.c_double),
+                ("rotation_weight", C.c_double), ("use_nonmonotonic_steps", C.c_int32),
+                ("max_num_iterations", C.c_int32)]
+
+
+class CeresSummary(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("num_successful_steps", C.c_int32), ("num_unsuccessful_steps", C.c_int32),
+                ("termination", C.c_int32), ("reserved", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
 class Voxel(C.Structure):
     _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("z", C.c_int32), ("value", C.c_uint16),
                 ("pad", C.c_uint16)]
@@ -102,6 +117,7 @@ EXPORTED_SYMBOLS = [
     "cmx_fast3d_destroy", "cmx_fast3d_match", "cmx_fast3d_match_full_submap",
     "cmx_fast3d_match_batch",
     "cmx_fast3d_level_info", "cmx_fast3d_level_cells",
+    "cmx_ceres2d_match", "cmx_ceres2d_match_grid", "cmx_fast2d_refine_batch",
 ]
 
 _lib = None
@@ -169,6 +185,14 @@ def lib():
     L.cmx_fast2d_match_batch.argtypes = [P(C.c_void_p), C.c_int32, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                          C.c_void_p, C.c_void_p, P(MatchStats)]
+    L.cmx_ceres2d_match.argtypes = [P(Ceres2DOptions), P(Grid2DLimits), C.c_void_p, C.c_void_p,
+                                    P(Pose2d), C.c_void_p, C.c_int32, C.c_int32, P(Pose2d),
+                                    P(CeresSummary)]
+    L.cmx_ceres2d_match_grid.argtypes = [P(Ceres2DOptions), C.c_void_p, C.c_void_p, P(Pose2d),
+                                         C.c_void_p, C.c_int32, P(Pose2d), P(CeresSummary)]
+    L.cmx_fast2d_refine_batch.argtypes = [P(Ceres2DOptions), P(C.c_void_p), C.c_int32, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                          C.c_void_p]
     L.cmx_cloud_upload.argtypes = [C.c_void_p, C.c_int32, C.c_int32, P(C.c_void_p)]
     L.cmx_cloud_destroy.argtypes = [C.c_void_p]
     L.cmx_cloud_destroy.restype = None

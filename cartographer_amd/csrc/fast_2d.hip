@@ -1733,7 +1733,8 @@ Fast2DMatcher::Fast2DMatcher(const cmx_fast2d_options& options, const cmx_grid2d
   score_scale_ = (max_s - min_s_) / 255.f;
 
   const size_t count = static_cast<size_t>(nx) * ny;
-  uint16_t* d_cells = ws->dev[0].ReserveAs<uint16_t>(count);
+  CMX_HIP(hipMalloc(reinterpret_cast<void**>(&grid_cells_), count * sizeof(uint16_t)));
+  uint16_t* d_cells = grid_cells_;
   CMX_HIP(hipMemcpyAsync(d_cells, cells, count * sizeof(uint16_t), hipMemcpyHostToDevice,
                          ws->stream));
   BuildLevel0Kernel<<<DivUp(count, 256), 256, 0, ws->stream>>>(
@@ -1795,6 +1796,7 @@ Fast2DMatcher::~Fast2DMatcher() {
   if (stack_mem_) (void)hipFree(stack_mem_);
   if (quads_mem_) (void)hipFree(quads_mem_);
   if (planes_) (void)hipFree(planes_);
+  if (grid_cells_) (void)hipFree(grid_cells_);
 }
 
 std::shared_ptr<const std::vector<float2>> HostRotationTable(double step, int num_angular) {

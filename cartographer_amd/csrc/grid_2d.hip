@@ -408,6 +408,22 @@ extern "C" cmx_status cmx_grid2d_insert(cmx_grid2d* grid, const float* origin_xy
   });
 }
 
+namespace cmx {
+// For the other translation units that read a resident grid (ceres_2d.hip).
+const uint16_t* Grid2DDeviceCells(const cmx_grid2d* grid, cmx_grid2d_limits* limits, int* device) {
+  limits->resolution = grid->resolution;
+  limits->max_x = grid->max_x;
+  limits->max_y = grid->max_y;
+  limits->num_x_cells = grid->nx;
+  limits->num_y_cells = grid->ny;
+  // ProbabilityGrid(limits, tables): Grid2D(limits, kMinCorrespondenceCost, kMaxCorrespondenceCost)
+  limits->min_correspondence_cost = 1.f - (1.f - 0.1f);
+  limits->max_correspondence_cost = 1.f - 0.1f;
+  *device = grid->device;
+  return grid->cells;
+}
+}  // namespace cmx
+
 extern "C" cmx_status cmx_rt2d_match_grid(const cmx_rt_options* options, const cmx_grid2d* grid,
                                           const cmx_pose2d* initial_pose_estimate,
                                           const float* point_cloud_xyz, int32_t num_points,

@@ -110,6 +110,9 @@ class Fast2DMatcher {
   int depth() const { return options_.branch_and_bound_depth; }
   const LevelDesc& level(int i) const { return levels_[i]; }
   const uint8_t* planes() const { return planes_; }
+  // The submap's own correspondence-cost cells (uint16, as uploaded): what the Ceres
+  // refinement after a match interpolates (constraint_builder_2d.cc:245-249).
+  const uint16_t* grid_cells() const { return grid_cells_; }
   int plane_i() const { return plane_i_; }
   int plane_j() const { return plane_j_; }
   int plane_stride() const { return plane_stride_; }
@@ -124,6 +127,7 @@ class Fast2DMatcher {
   void* stack_mem_ = nullptr;      // all levels, contiguous
   void* quads_mem_ = nullptr;      // quad layouts of levels 0 .. depth-2, contiguous
   uint8_t* planes_ = nullptr;      // phase planes of the lowest-resolution level (or null)
+  uint16_t* grid_cells_ = nullptr; // the grid itself (2 B per cell), for the refinement step
   int plane_i_ = 0, plane_j_ = 0, plane_stride_ = 0;
   std::vector<LevelDesc> levels_;
   std::vector<size_t> level_offsets_;

@@ -12,7 +12,8 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from ._lib import (Fast2DOptions, Grid2DLimits, MatchStats, Pose2d, RtOptions, check)
+from ._lib import (Ceres2DOptions, CeresSummary, Fast2DOptions, Grid2DLimits, MatchStats, Pose2d,
+                   RtOptions, check)
 
 K_MIN_CORRESPONDENCE_COST = float(np.float32(1) - (np.float32(1) - np.float32(0.1)))
 K_MAX_CORRESPONDENCE_COST = float(np.float32(1) - np.float32(0.1))
@@ -299,3 +300,50 @@ def match_batch(matchers, initial_pose_estimates, match_full_submap, min_scores,
         xyz.ctypes.data, n, found.ctypes.data, scores.ctypes.data, C.cast(poses, C.c_void_p),
         C.byref(stats)))
     return found, scores, [Rigid2d(p.x, p.y, p.theta) for p in poses], stats.as_dict()
+
+
+class CeresScanMatcher2D:
+    """CeresScanMatcher2D(options).Match(target_translation, initial_pose_estimate, point_cloud,
+    grid) -> (pose_estimate, summary)  (ceres_scan_matcher_2d.h:44-56).  `grid` is a Grid2D or a
+    grid resident in HBM (cartographer_amd.grid_2d.ProbabilityGridOnDevice)."""
+
+    def __init__(self, occupied_space_weight, translation_weight, rotation_weight,
+                 use_nonmonotonic_steps=False, max_num_iterations=20, device=0):
+        self.options = Ceres2DOptions(occupied_space_weight, translation_weight, rotation_weight,
+                                      1 if use_nonmonotonic_steps else 0, max_num_iterations)
+        self.device = device
+
+    def match(self, target_translation, initial_pose_estimate, point_cloud, grid):
+        from .grid_2d import ProbabilityGridOnDevice
+        xyz, n = _cloud(point_cloud)
+        target = np.ascontiguousarray(target_translation, np.float64)
+        init = initial_pose_estimate.to_c()
+        pose, summary = Pose2d(), CeresSummary()
+        if isinstance(grid, ProbabilityGridOnDevice):
+            check(_lib.lib().cmx_ceres2d_match_grid(C.byref(self.options), grid._h,
+                                                    target.ctypes.data, C.byref(init),
+                                                    xyz.ctypes.data, n, C.byref(pose),
+                                                    C.byref(summary)))
+        else:
+            limits = grid.limits_c()
+            check(_lib.lib().cmx_ceres2d_match(C.byref(self.options), C.byref(limits),
+                                               grid.cells.ctypes.data, target.ctypes.data,
+                                               C.byref(init), xyz.ctypes.data, n, self.device,
+                                               C.byref(pose), C.byref(summary)))
+        return Rigid2d(pose.x, pose.y, pose.theta), summary.as_dict()
+
+    def refine_batch(self, matchers, found, pose_estimates, point_cloud):
+        """ConstraintBuilder2D::ComputeConstraint's refinement of a batch of search results
+        (constraint_builder_2d.cc:245-249), each against the grid its matcher keeps in HBM."""
+        num = len(matchers)
+        xyz, n = _cloud(point_cloud)
+        handles = (C.c_void_p * num)(*[m._h for m in matchers])
+        found = np.ascontiguousarray(found, np.int32)
+        poses_in = (Pose2d * num)(*[p.to_c() for p in pose_estimates])
+        poses_out = (Pose2d * num)()
+        summaries = (CeresSummary * num)()
+        check(_lib.lib().cmx_fast2d_refine_batch(
+            C.byref(self.options), handles, num, found.ctypes.data, C.cast(poses_in, C.c_void_p),
+            xyz.ctypes.data, n, C.cast(poses_out, C.c_void_p), C.cast(summaries, C.c_void_p)))
+        return ([Rigid2d(p.x, p.y, p.theta) for p in poses_out],
+                [s_.as_dict() for s_ in summaries])

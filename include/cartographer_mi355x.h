@@ -16,6 +16,8 @@
  *   cmx_fast2d_match_batch, cmx_fast2d_match_full_submap_batch
  *                                  the ConstraintBuilder2D fan-out of independent
  *                                  (node, submap) searches, constraints/constraint_builder_2d.cc:97-137
+ *   cmx_ceres2d_match, cmx_ceres2d_match_grid, cmx_fast2d_refine_batch
+ *                                  CeresScanMatcher2D::Match, SM2/ceres_scan_matcher_2d.cc:63-107
  *   cmx_rt3d_match                 RealTimeCorrelativeScanMatcher3D::Match
  *                                  SM3/real_time_correlative_scan_matcher_3d.h:47-50, .cc:34-53
  *   cmx_fast3d_*                   FastCorrelativeScanMatcher3D ctor / Match / MatchFullSubmap
@@ -235,6 +237,51 @@ cmx_status cmx_fast2d_match_full_submap_batch_resident(
     const cmx_fast2d* const* matchers, int32_t num_matchers, const cmx_cloud* cloud,
     float min_score, int32_t* found, float* scores, cmx_pose2d* pose_estimates,
     cmx_match_stats* stats);
+
+/* ---- Ceres refinement, 2D -------------------------------- */
+/* proto::CeresScanMatcherOptions2D + the three ceres_solver_options cartographer sets
+ * (mapping/proto/scan_matching/ceres_scan_matcher_options_2d.proto,
+ * common/internal/ceres_solver_options.cc:38-45; num_threads has no meaning here). */
+typedef struct cmx_ceres2d_options {
+  double occupied_space_weight;
+  double translation_weight;
+  double rotation_weight;
+  int32_t use_nonmonotonic_steps;
+  int32_t max_num_iterations;
+} cmx_ceres2d_options;
+/* The fields of ceres::Solver::Summary the callers and tests read. */
+typedef struct cmx_ceres_summary {
+  double initial_cost, final_cost;
+  int32_t num_successful_steps, num_unsuccessful_steps;
+  int32_t termination;   /* 0 CONVERGENCE, 1 NO_CONVERGENCE, 2 FAILURE */
+  int32_t reserved;
+} cmx_ceres_summary;
+/* CeresScanMatcher2D::Match (SM2/ceres_scan_matcher_2d.h:51-56, .cc:63-107) on a probability
+ * grid: bicubic occupied-space residuals + translation / rotation delta residuals, Ceres's
+ * trust-region Levenberg-Marquardt with its default options.  `cells` as in cmx_rt2d_match. */
+cmx_status cmx_ceres2d_match(const cmx_ceres2d_options* options, const cmx_grid2d_limits* limits,
+                             const uint16_t* cells, const double* target_translation_xy,
+                             const cmx_pose2d* initial_pose_estimate, const float* point_cloud_xyz,
+                             int32_t num_points, int32_t device, cmx_pose2d* pose_estimate,
+                             cmx_ceres_summary* summary);
+/* The same on a grid resident in HBM: LocalTrajectoryBuilder2D::ScanMatch's
+ * real-time match -> Ceres match pair (local_trajectory_builder_2d.cc:78-107) without the
+ * grid crossing PCIe. */
+cmx_status cmx_ceres2d_match_grid(const cmx_ceres2d_options* options, const cmx_grid2d* grid,
+                                  const double* target_translation_xy,
+                                  const cmx_pose2d* initial_pose_estimate,
+                                  const float* point_cloud_xyz, int32_t num_points,
+                                  cmx_pose2d* pose_estimate, cmx_ceres_summary* summary);
+/* ConstraintBuilder2D::ComputeConstraint's refinement (constraints/constraint_builder_2d.cc:
+ * 245-249) for the results of cmx_fast2d_match_batch, one launch for the whole batch, each
+ * against the grid its matcher keeps in HBM: entry i refines pose_estimates_in[i] with target
+ * translation pose_estimates_in[i].{x,y}; entries with found[i] == 0 (found may be NULL) are
+ * passed through. */
+cmx_status cmx_fast2d_refine_batch(const cmx_ceres2d_options* options,
+                                   const cmx_fast2d* const* matchers, int32_t num_matchers,
+                                   const int32_t* found, const cmx_pose2d* pose_estimates_in,
+                                   const float* point_cloud_xyz, int32_t num_points,
+                                   cmx_pose2d* pose_estimates_out, cmx_ceres_summary* summaries);
 
 /* Introspection used by the parity tests (not needed by a caller). */
 cmx_status cmx_fast2d_level_dims(const cmx_fast2d* matcher, int32_t level, int32_t* wide_x,

@@ -8,6 +8,7 @@
 
 #include "oracle_2d.h"
 #include "oracle_3d.h"
+#include "oracle_ceres_2d.h"
 
 using namespace oracle;
 
@@ -380,6 +381,42 @@ int orc_fast3d_match(void* h, int full_submap, const double* node7, const double
     stats4[2] = st.coarse_candidates; stats4[3] = st.nodes_expanded;
   }
   return ok ? 1 : 0;
+}
+
+
+// ---- CeresScanMatcher2D ----
+// options5 = occupied_space_weight, translation_weight, rotation_weight, use_nonmonotonic_steps,
+// max_num_iterations; summary5 = initial_cost, final_cost, successful, unsuccessful, termination.
+void orc_ceres2d_match(const uint16_t* cells, int nx, int ny, double res, double max_x,
+                       double max_y, const double* options5, const double* target_xy,
+                       const double* init_xyt, const float* xyz, int n, double* pose_xyt,
+                       double* summary5) {
+  CeresOptions2D o;
+  o.occupied_space_weight = options5[0]; o.translation_weight = options5[1];
+  o.rotation_weight = options5[2]; o.use_nonmonotonic_steps = options5[3] != 0.;
+  o.max_num_iterations = static_cast<int>(options5[4]);
+  Pose2d out;
+  CeresSummary2D sum;
+  CeresScanMatcher2DMatch(o, target_xy, Pose2d{init_xyt[0], init_xyt[1], init_xyt[2]},
+                          MakeCloud(xyz, n), MakeView(cells, nx, ny, res, max_x, max_y), &out, &sum);
+  pose_xyt[0] = out.x; pose_xyt[1] = out.y; pose_xyt[2] = out.theta;
+  summary5[0] = sum.initial_cost; summary5[1] = sum.final_cost;
+  summary5[2] = sum.num_successful_steps; summary5[3] = sum.num_unsuccessful_steps;
+  summary5[4] = sum.termination;
+}
+// Residuals (n + 3) and Jacobian ((n + 3) x 3) of the three residual blocks at `pose`.
+void orc_ceres2d_residuals(const uint16_t* cells, int nx, int ny, double res, double max_x,
+                           double max_y, const double* options5, const double* target_xy,
+                           double target_angle, const double* pose_xyt, const float* xyz, int n,
+                           double* residuals, double* jacobian) {
+  CeresOptions2D o;
+  o.occupied_space_weight = options5[0]; o.translation_weight = options5[1];
+  o.rotation_weight = options5[2];
+  std::vector<double> r, J;
+  CeresResiduals2D(o, target_xy, target_angle, MakeCloud(xyz, n),
+                   MakeView(cells, nx, ny, res, max_x, max_y), pose_xyt, &r, &J);
+  std::memcpy(residuals, r.data(), r.size() * sizeof(double));
+  std::memcpy(jacobian, J.data(), J.size() * sizeof(double));
 }
 
 }  // extern "C"

@@ -413,6 +413,55 @@ def rt2d_match(cells, res, max_x, max_y, init_xyt, xyz, lin, ang, tw, rw, want_s
     return dict(score=float(s), pose=pose, num_candidates=ncand.value, scores=scores)
 
 
+def _ceres_options(occupied_space_weight, translation_weight, rotation_weight,
+                   use_nonmonotonic_steps, max_num_iterations):
+    return np.array([occupied_space_weight, translation_weight, rotation_weight,
+                     1.0 if use_nonmonotonic_steps else 0.0, max_num_iterations], np.float64)
+
+
+def ceres2d_match(cells, res, max_x, max_y, target_xy, init_xyt, xyz, occupied_space_weight=1.0,
+                  translation_weight=10.0, rotation_weight=40.0, use_nonmonotonic_steps=False,
+                  max_num_iterations=20):
+    """CeresScanMatcher2D::Match restated (oracle_ceres_2d.h: Ceres itself is absent, its
+    published trust-region algorithm is restated; parity with Ceres's iterates is unpinned)."""
+    cells = np.ascontiguousarray(cells, np.uint16)
+    ny, nx = cells.shape
+    xyz, n = _cloud(xyz)
+    L = lib()
+    L.orc_ceres2d_match.argtypes = [_u16p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                    _f64p, _f64p, _f64p, _f32p, C.c_int, _f64p, _f64p]
+    L.orc_ceres2d_match.restype = None
+    pose, summary = np.empty(3, np.float64), np.empty(5, np.float64)
+    L.orc_ceres2d_match(cells, nx, ny, res, max_x, max_y,
+                        _ceres_options(occupied_space_weight, translation_weight, rotation_weight,
+                                       use_nonmonotonic_steps, max_num_iterations),
+                        np.ascontiguousarray(target_xy, np.float64),
+                        np.ascontiguousarray(init_xyt, np.float64), xyz, n, pose, summary)
+    return dict(pose=pose, initial_cost=summary[0], final_cost=summary[1],
+                num_successful_steps=int(summary[2]), num_unsuccessful_steps=int(summary[3]),
+                termination=int(summary[4]))
+
+
+def ceres2d_residuals(cells, res, max_x, max_y, target_xy, target_angle, pose_xyt, xyz,
+                      occupied_space_weight=1.0, translation_weight=10.0, rotation_weight=40.0):
+    """Residuals [n + 3] and Jacobian [n + 3, 3] of the three residual blocks at `pose_xyt`."""
+    cells = np.ascontiguousarray(cells, np.uint16)
+    ny, nx = cells.shape
+    xyz, n = _cloud(xyz)
+    L = lib()
+    L.orc_ceres2d_residuals.argtypes = [_u16p, C.c_int, C.c_int, C.c_double, C.c_double,
+                                        C.c_double, _f64p, _f64p, C.c_double, _f64p, _f32p,
+                                        C.c_int, _f64p, _f64p]
+    L.orc_ceres2d_residuals.restype = None
+    r, J = np.empty(n + 3, np.float64), np.empty((n + 3, 3), np.float64)
+    L.orc_ceres2d_residuals(cells, nx, ny, res, max_x, max_y,
+                            _ceres_options(occupied_space_weight, translation_weight,
+                                           rotation_weight, False, 0),
+                            np.ascontiguousarray(target_xy, np.float64), target_angle,
+                            np.ascontiguousarray(pose_xyt, np.float64), xyz, n, r, J)
+    return r, J
+
+
 def rt2d_match_tsdf(tsd_cells, weight_cells, res, max_x, max_y, truncation_distance, max_weight,
                     init_xyt, xyz, lin, ang, tw, rw, want_scores=False):
     """RealTimeCorrelativeScanMatcher2D::Match on a TSDF2D (two uint16 planes)."""

@@ -170,3 +170,77 @@ def test_rt2d_batch_on_resident_grids_both_paths(sm, oracle, synth, monkeypatch)
             assert scores[k] == ref["score"], (bulk, k)
             np.testing.assert_allclose([poses[k].x, poses[k].y, poses[k].theta], ref["pose"],
                                        rtol=0, atol=1e-12)
+
+
+# ----------------------------------------------------------------------------
+# Ceres refinement on the device vs the oracle's restatement
+# ----------------------------------------------------------------------------
+def _assert_ceres_close(pose, summary, ref):
+    np.testing.assert_allclose([pose.x, pose.y, pose.theta], ref["pose"], rtol=0, atol=1e-6)
+    assert abs(summary["initial_cost"] - ref["initial_cost"]) <= 1e-9 * max(1.0, ref["initial_cost"])
+    assert abs(summary["final_cost"] - ref["final_cost"]) <= 1e-7 * max(1.0, ref["final_cost"])
+    assert summary["termination"] == ref["termination"]
+    assert summary["num_successful_steps"] == ref["num_successful_steps"]
+    assert summary["num_unsuccessful_steps"] == ref["num_unsuccessful_steps"]
+
+
+@pytest.mark.parametrize("init", [(-0.5, 0.5), (-0.3, 0.5), (-0.3, 0.3)])
+def test_ceres2d_reference_fixture(sm, oracle, synth, init):
+    """CeresScanMatcherTest (ceres_scan_matcher_2d_test.cc:34-112) on the device: the
+    reference's tolerances (pose 1e-2, final cost 1e-2 around 0) and the oracle's iterates."""
+    g = synth.ProbabilityGrid(1.0, (10.0, 10.0), 20, 20)
+    g.set_probability(7, 13, 0.9)
+    lim = g.limits
+    cloud = np.array([[-3.0, 2.0, 0.0]], np.float32)
+    m = sm.CeresScanMatcher2D(1.0, 0.1, 1.5, True, 50)
+    pose, summary = m.match(init, sm.Rigid2d(init[0], init[1], 0.0), cloud,
+                            sm.Grid2D(g.cells, 1.0, lim["max_x"], lim["max_y"]))
+    assert abs(summary["final_cost"]) < 1e-2
+    assert math.hypot(pose.x + 0.5, pose.y - 0.5) < 1e-2 and abs(pose.theta) < 1e-2
+
+
+@pytest.mark.parametrize("seed,weights,nonmono,iters", [
+    (9, (20.0, 10.0, 1.0), True, 10),        # pose_graph.lua constraint_builder.ceres_scan_matcher
+    (4, (1.0, 10.0, 40.0), False, 20),       # trajectory_builder_2d.lua ceres_scan_matcher
+    (17, (5.0, 1.0, 1.0), False, 50)])
+def test_ceres2d_equals_the_oracle(sm, oracle, synth, seed, weights, nonmono, iters):
+    from cartographer_amd import grid_2d
+    cells, lim, world = synth.make_submap(seed, 200, 200, 0.05, 25, 800, 10.0, 0.01)
+    truth = world.free_pose(seed + 5, 0.5)
+    scan = world.scan(truth, 300, 10.0, 0.01, 4)
+    init = (truth[0] + 0.04, truth[1] - 0.03, truth[2] + 0.015)
+    target = (init[0] + 0.01, init[1] - 0.01)
+    ref = oracle.ceres2d_match(cells, 0.05, lim["max_x"], lim["max_y"], target, init, scan,
+                               weights[0], weights[1], weights[2], nonmono, iters)
+    m = sm.CeresScanMatcher2D(weights[0], weights[1], weights[2], nonmono, iters)
+    pose, summary = m.match(target, sm.Rigid2d(*init), scan, _grid(sm, cells, lim))
+    _assert_ceres_close(pose, summary, ref)
+    dev = grid_2d.ProbabilityGridOnDevice(0.05, (lim["max_x"], lim["max_y"]), 200, 200, cells=cells)
+    pose2, summary2 = m.match(target, sm.Rigid2d(*init), scan, dev)
+    assert (pose2.x, pose2.y, pose2.theta) == (pose.x, pose.y, pose.theta)
+    assert summary2 == summary
+
+
+def test_fast2d_match_then_refine_batch(sm, oracle, synth, c2):
+    """ComputeConstraint's pair (fast correlative match, then Ceres) for a batch of submaps:
+    the refined poses equal the oracle's refinement of the oracle's search results; pairs
+    without a match pass through."""
+    _, _, _, truth, scan = c2
+    matchers, grids = [], []
+    for seed in (42, 43, 44):
+        cells, lim, _ = synth.make_submap(seed, 400, 400, 0.05, 30, 1000, 30.0, 0.01)
+        matchers.append(sm.FastCorrelativeScanMatcher2D(_grid(sm, cells, lim), 7))
+        grids.append((cells, lim))
+    found, scores, poses, _ = sm.match_full_submap_batch(matchers, scan, 0.6)
+    assert found[0] == 1
+    ceres = sm.CeresScanMatcher2D(20.0, 10.0, 1.0, True, 10)
+    pose_list = [sm.Rigid2d(*p) for p in poses]
+    refined, summaries = ceres.refine_batch(matchers, found, pose_list, scan)
+    for k, (cells, lim) in enumerate(grids):
+        if not found[k]:
+            assert (refined[k].x, refined[k].y, refined[k].theta) == tuple(poses[k])
+            continue
+        ref = oracle.ceres2d_match(cells, 0.05, lim["max_x"], lim["max_y"], poses[k][:2],
+                                   poses[k], scan, 20.0, 10.0, 1.0, True, 10)
+        _assert_ceres_close(refined[k], summaries[k], ref)
+        assert summaries[k]["final_cost"] <= summaries[k]["initial_cost"]
