@@ -118,6 +118,9 @@ EXPORTED_SYMBOLS = [
     "cmx_fast3d_match_batch",
     "cmx_fast3d_level_info", "cmx_fast3d_level_cells",
     "cmx_ceres2d_match", "cmx_ceres2d_match_grid", "cmx_fast2d_refine_batch",
+    "cmx_comm_init", "cmx_comm_destroy", "cmx_comm_num_devices", "cmx_comm_device_of",
+    "cmx_fast2d_match_sharded", "cmx_fast3d_match_sharded", "cmx_shard_range",
+    "cmx_pack_best_key", "cmx_unpack_best_key",
 ]
 
 _lib = None
@@ -193,6 +196,27 @@ def lib():
     L.cmx_fast2d_refine_batch.argtypes = [P(Ceres2DOptions), P(C.c_void_p), C.c_int32, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                           C.c_void_p]
+    L.cmx_comm_init.argtypes = [C.c_void_p, C.c_int32, P(C.c_void_p)]
+    L.cmx_comm_destroy.argtypes = [C.c_void_p]
+    L.cmx_comm_destroy.restype = None
+    L.cmx_comm_num_devices.argtypes = [C.c_void_p]
+    L.cmx_comm_num_devices.restype = C.c_int32
+    L.cmx_comm_device_of.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+    L.cmx_comm_device_of.restype = C.c_int32
+    L.cmx_fast2d_match_sharded.argtypes = [C.c_void_p, P(C.c_void_p), C.c_int32, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_int32),
+                                           P(C.c_float), P(MatchStats)]
+    L.cmx_fast3d_match_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, P(C.c_int32), P(C.c_float),
+                                           P(MatchStats)]
+    L.cmx_shard_range.argtypes = [C.c_int64, C.c_int32, C.c_int32, P(C.c_int64), P(C.c_int64)]
+    L.cmx_shard_range.restype = None
+    L.cmx_pack_best_key.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
+    L.cmx_pack_best_key.restype = C.c_int64
+    L.cmx_unpack_best_key.argtypes = [C.c_int64, P(C.c_int32), P(C.c_float), P(C.c_int64)]
+    L.cmx_unpack_best_key.restype = None
     L.cmx_cloud_upload.argtypes = [C.c_void_p, C.c_int32, C.c_int32, P(C.c_void_p)]
     L.cmx_cloud_destroy.argtypes = [C.c_void_p]
     L.cmx_cloud_destroy.restype = None

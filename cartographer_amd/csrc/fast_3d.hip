@@ -1051,6 +1051,11 @@ struct cmx_fast3d {
   cmx::Fast3DMatcher impl;
 };
 
+namespace cmx {
+// For sharded.hip: the device a 3D matcher's grids live on.
+int Fast3DDevice(const cmx_fast3d* matcher) { return matcher->impl.device; }
+}  // namespace cmx
+
 extern "C" {
 
 cmx_status cmx_fast3d_create(const cmx_fast3d_options* options, float resolution,

@@ -90,3 +90,50 @@ def all_gather_results(found, scores, poses_xyt, num_submaps, rank, world_size, 
         b, e = shard_range(num_submaps, r, world_size)
         out[b:e] = g.cpu().numpy()[:e - b]
     return (out[:, 0].astype(np.int32), out[:, 1].astype(np.float32), out[:, 2:5].copy())
+
+
+class Communicator:
+    """cmx_comm: one host process driving several GPUs of the node (RCCL through
+    ncclCommInitAll).  `match_full_submap_batch` / `match_batch` are the sharded forms of the
+    functions of the same name in scan_matching: the matchers may live on different devices."""
+
+    def __init__(self, devices):
+        import ctypes as C
+        from . import _lib
+        self._h = C.c_void_p()
+        devs = np.ascontiguousarray(devices, np.int32)
+        _lib.check(_lib.lib().cmx_comm_init(devs.ctypes.data, len(devs), C.byref(self._h)))
+        self.devices = list(map(int, devs))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            from . import _lib
+            _lib.lib().cmx_comm_destroy(self._h)
+            self._h = None
+
+    def device_of(self, index, num_items):
+        from . import _lib
+        return _lib.lib().cmx_comm_device_of(self._h, index, num_items)
+
+    def match_batch(self, matchers, initial_pose_estimates, match_full_submap, min_scores,
+                    point_cloud):
+        """Returns (found, scores, poses, best (index or -1, score), stats)."""
+        import ctypes as C
+        from . import _lib, scan_matching as sm
+        num = len(matchers)
+        handles = (C.c_void_p * num)(*[m._h for m in matchers])
+        initial = (_lib.Pose2d * num)(*[p.to_c() for p in initial_pose_estimates])
+        full = np.ascontiguousarray(match_full_submap, np.int32)
+        thresholds = np.ascontiguousarray(min_scores, np.float32)
+        xyz = np.ascontiguousarray(point_cloud, np.float32).reshape(-1, 3)
+        found = np.zeros(num, np.int32)
+        scores = np.zeros(num, np.float32)
+        poses = (_lib.Pose2d * num)()
+        best_index, best_score, stats = C.c_int32(), C.c_float(), _lib.MatchStats()
+        _lib.check(_lib.lib().cmx_fast2d_match_sharded(
+            self._h, handles, num, C.cast(initial, C.c_void_p), full.ctypes.data,
+            thresholds.ctypes.data, xyz.ctypes.data, xyz.shape[0], found.ctypes.data,
+            scores.ctypes.data, C.cast(poses, C.c_void_p), C.byref(best_index),
+            C.byref(best_score), C.byref(stats)))
+        return (found, scores, [sm.Rigid2d(p.x, p.y, p.theta) for p in poses],
+                (best_index.value, best_score.value), stats.as_dict())

@@ -383,6 +383,48 @@ cmx_status cmx_fast3d_match_batch(const cmx_fast3d* const* matchers, int32_t num
                                   const cmx_node_data3d* data, int32_t* found,
                                   cmx_result3d* results, cmx_match_stats* stats);
 
+/* ---- multi-GPU: one scan against submaps spread over the GPUs of a node ---------------- */
+/* The (node, submap) searches of a ConstraintBuilder fan-out are independent
+ * (constraints/constraint_builder_2d.cc:97-111, constraint_builder_3d.cc:79-142): submaps are
+ * partitioned over the devices -- a matcher lives on the device it was created on
+ * (cmx_comm_device_of gives the block partition) -- and every device searches its own block
+ * concurrently, one host thread per device.  Results come back per pair, in the caller's order.
+ * The node-wide best match (global localisation) is agreed on by ONE RCCL all-reduce(max) of a
+ * packed 8-byte key over xGMI (score bits << 32 | 0xFFFFFFFF - index: equal scores resolve to
+ * the lowest index whatever the partition).  RCCL is loaded by cmx_comm_init (dlopen). */
+typedef struct cmx_comm cmx_comm;
+/* devices == NULL: devices 0 .. num_devices-1. */
+cmx_status cmx_comm_init(const int32_t* devices, int32_t num_devices, cmx_comm** out);
+void cmx_comm_destroy(cmx_comm* comm);
+int32_t cmx_comm_num_devices(const cmx_comm* comm);
+/* Device that owns item `index` of `num_items` under the contiguous block partition. */
+int32_t cmx_comm_device_of(const cmx_comm* comm, int64_t index, int64_t num_items);
+/* As cmx_fast2d_match_batch, the matchers spread over the communicator's devices.
+ * best_index / best_score (may be NULL): the best found pair node-wide, -1 if none. */
+cmx_status cmx_fast2d_match_sharded(cmx_comm* comm, const cmx_fast2d* const* matchers,
+                                    int32_t num_matchers, const cmx_pose2d* initial_pose_estimates,
+                                    const int32_t* match_full_submap, const float* min_scores,
+                                    const float* point_cloud_xyz, int32_t num_points,
+                                    int32_t* found, float* scores, cmx_pose2d* pose_estimates,
+                                    int32_t* best_index, float* best_score,
+                                    cmx_match_stats* stats);
+/* As cmx_fast3d_match_batch (BASELINE config C5: one node against 256 submaps on 8 GPUs). */
+cmx_status cmx_fast3d_match_sharded(cmx_comm* comm, const cmx_fast3d* const* matchers,
+                                    int32_t num_pairs, const cmx_pose3d* node_poses,
+                                    const cmx_pose3d* submap_poses,
+                                    const int32_t* match_full_submap, const float* min_scores,
+                                    const cmx_node_data3d* data, int32_t* found,
+                                    cmx_result3d* results, int32_t* best_index, float* best_score,
+                                    cmx_match_stats* stats);
+/* The partition and the key, as plain host arithmetic (no device needed; rank processes that
+ * shard with torch.distributed / MPI instead of cmx_comm use the same rules):
+ * items [begin, end) of `rank`; key of the best found entry of a block (-1: none found). */
+void cmx_shard_range(int64_t num_items, int32_t rank, int32_t world_size, int64_t* begin,
+                     int64_t* end);
+int64_t cmx_pack_best_key(const int32_t* found, const float* scores, int64_t num,
+                          int64_t first_global_index);
+void cmx_unpack_best_key(int64_t key, int32_t* found, float* score, int64_t* global_index);
+
 /* Introspection used by the parity tests: one precomputation level as a dense
  * brick (x fastest) with the cell index of its first element. */
 cmx_status cmx_fast3d_level_info(const cmx_fast3d* matcher, int32_t depth, int32_t* lo_xyz,

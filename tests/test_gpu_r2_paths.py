@@ -244,3 +244,40 @@ def test_fast2d_match_then_refine_batch(sm, oracle, synth, c2):
                                    poses[k], scan, 20.0, 10.0, 1.0, True, 10)
         _assert_ceres_close(refined[k], summaries[k], ref)
         assert summaries[k]["final_cost"] <= summaries[k]["initial_cost"]
+
+
+# ----------------------------------------------------------------------------
+# cmx_comm: the sharded entry points on the devices this box has
+# ----------------------------------------------------------------------------
+def test_sharded_match_equals_the_batch(sm, synth, c2):
+    """cmx_fast2d_match_sharded over a communicator of every visible device (one on the test
+    box): same constraint list as cmx_fast2d_match_batch, and the RCCL all-reduce returns the
+    best found pair (lowest index among equal scores)."""
+    import torch
+    from cartographer_amd import sharding
+    _, _, _, truth, scan = c2
+    ndev = torch.cuda.device_count()
+    comm = sharding.Communicator(list(range(ndev)))
+    matchers = []
+    seeds = (42, 43, 42, 44, 42)           # submaps 0, 2, 4 are identical: equal scores
+    for k, seed in enumerate(seeds):
+        cells, lim, _ = synth.make_submap(seed, 400, 400, 0.05, 30, 1000, 30.0, 0.01)
+        dev = comm.device_of(k, len(seeds))
+        assert 0 <= dev < ndev
+        matchers.append(sm.FastCorrelativeScanMatcher2D(_grid(sm, cells, lim), 7, 3.0,
+                                                        math.radians(20.0), device=dev))
+    initial = [sm.Rigid2d(truth[0] + 0.2, truth[1] - 0.1, truth[2] + 0.03)] * len(seeds)
+    full = [1, 1, 0, 1, 1]
+    thresholds = [0.6, 0.6, 0.5, 0.6, 0.6]
+    f, s, p, best, stats = comm.match_batch(matchers, initial, full, thresholds, scan)
+    if ndev == 1:
+        f1, s1, p1, stats1 = sm.match_batch(matchers, initial, full, thresholds, scan)
+        np.testing.assert_array_equal(f, f1)
+        np.testing.assert_array_equal(s[f != 0], s1[f1 != 0])
+        for a, b, ok in zip(p, p1, f):
+            if ok:
+                assert (a.x, a.y, a.theta) == (b.x, b.y, b.theta)
+        assert stats["candidates_scored"] == stats1["candidates_scored"]
+    assert f[0] == 1 and f[4] == 1 and s[0] == s[4]
+    masked = np.where(f != 0, s, -1.0)
+    assert best[0] == int(np.argmax(masked)) and np.float32(best[1]) == masked.max()

@@ -80,3 +80,47 @@ def test_all_reduce_best_gloo_world_size_2():
     out = manager.dict()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     assert out[0] and out[1]
+
+
+def test_c_abi_partition_and_key_equal_the_python_rules():
+    """cmx_shard_range / cmx_pack_best_key / cmx_unpack_best_key (plain host arithmetic in the
+    product library, no device needed) against cartographer_amd.sharding: the single-process
+    multi-GPU path (cmx_comm) and the one-process-per-GPU path (torch.distributed) partition and
+    merge identically."""
+    import ctypes as C
+    from cartographer_amd import _lib
+    L = _lib.lib()
+    for n in (0, 1, 7, 512, 513):
+        for w in (1, 2, 3, 8):
+            for r in range(w):
+                b, e = C.c_int64(), C.c_int64()
+                L.cmx_shard_range(n, r, w, C.byref(b), C.byref(e))
+                assert (b.value, e.value) == sharding.shard_range(n, r, w)
+    rng = np.random.default_rng(2)
+    for trial in range(200):
+        m = int(rng.integers(1, 20))
+        found = (rng.random(m) < 0.5).astype(np.int32)
+        scores = rng.uniform(0.01, 1.0, m).astype(np.float32)
+        if trial % 5 == 0 and m > 2:
+            scores[1:] = scores[0]              # ties: the lowest index must win
+        first = int(rng.integers(0, 1000))
+        key = L.cmx_pack_best_key(found.ctypes.data, scores.ctypes.data, m, first)
+        assert key == sharding.pack_best_key(found, scores, first)
+        f, s, g = C.c_int32(), C.c_float(), C.c_int64()
+        L.cmx_unpack_best_key(key, C.byref(f), C.byref(s), C.byref(g))
+        score, gid = sharding.unpack_best_key(key)
+        if score is None:
+            assert f.value == 0 and g.value == -1
+        else:
+            assert f.value == 1 and g.value == gid and np.float32(s.value) == np.float32(score)
+    # merging per-block keys with max equals the key of the whole list, for every partition
+    found = np.array([0, 1, 1, 0, 1, 1, 1], np.int32)
+    scores = np.array([0.9, 0.7, 0.8, 0.95, 0.8, 0.8, 0.6], np.float32)
+    whole = L.cmx_pack_best_key(found.ctypes.data, scores.ctypes.data, 7, 0)
+    for w in (1, 2, 3, 7):
+        keys = []
+        for r in range(w):
+            b, e = sharding.shard_range(7, r, w)
+            fb, sb = np.ascontiguousarray(found[b:e]), np.ascontiguousarray(scores[b:e])
+            keys.append(L.cmx_pack_best_key(fb.ctypes.data, sb.ctypes.data, e - b, b))
+        assert max(keys) == whole and sharding.unpack_best_key(whole)[1] == 2
