@@ -9,6 +9,7 @@
 #include "oracle_2d.h"
 #include "oracle_3d.h"
 #include "oracle_ceres_2d.h"
+#include "oracle_filters.h"
 
 using namespace oracle;
 
@@ -417,6 +418,25 @@ void orc_ceres2d_residuals(const uint16_t* cells, int nx, int ny, double res, do
                    MakeView(cells, nx, ny, res, max_x, max_y), pose_xyt, &r, &J);
   std::memcpy(residuals, r.data(), r.size() * sizeof(double));
   std::memcpy(jacobian, J.data(), J.size() * sizeof(double));
+}
+
+
+// ---- voxel filters / rotational histogram ----
+void orc_voxel_filter_flags(const float* xyz, int n, float resolution, uint8_t* used) {
+  const std::vector<uint8_t> f = VoxelFilterFlags(MakeCloud(xyz, n), resolution);
+  std::memcpy(used, f.data(), f.size());
+}
+int orc_adaptive_voxel_filter(const float* xyz, int n, float max_length, float min_num_points,
+                              float max_range, float* out_xyz) {
+  const PointCloud r = AdaptiveVoxelFilter(MakeCloud(xyz, n), max_length, min_num_points, max_range);
+  for (size_t i = 0; i != r.size(); ++i) {
+    out_xyz[3 * i] = r[i].x; out_xyz[3 * i + 1] = r[i].y; out_xyz[3 * i + 2] = r[i].z;
+  }
+  return static_cast<int>(r.size());
+}
+void orc_compute_histogram(const float* xyz, int n, int histogram_size, float* out) {
+  const std::vector<float> h = ComputeHistogram(MakeCloud(xyz, n), histogram_size);
+  std::memcpy(out, h.data(), h.size() * sizeof(float));
 }
 
 }  // extern "C"

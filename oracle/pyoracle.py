@@ -696,6 +696,61 @@ class FastCorrelativeScanMatcher3D:
 
 
 # ---- the reference's own 3D sources (oracle/_ref), same call shapes as the oracle twins above ----
+def voxel_filter_flags(xyz, resolution):
+    """points_used flags of sensor::VoxelFilter (the randomised reservoir filter)."""
+    xyz, n = _cloud(xyz)
+    used = np.zeros(n, np.uint8)
+    L = lib()
+    L.orc_voxel_filter_flags.argtypes = [_f32p, C.c_int, C.c_float, C.c_void_p]
+    L.orc_voxel_filter_flags.restype = None
+    L.orc_voxel_filter_flags(xyz, n, resolution, used.ctypes.data)
+    return used.astype(bool)
+
+
+def adaptive_voxel_filter(xyz, max_length, min_num_points, max_range):
+    xyz, n = _cloud(xyz)
+    out = np.empty((max(n, 1), 3), np.float32)
+    L = lib()
+    L.orc_adaptive_voxel_filter.argtypes = [_f32p, C.c_int, C.c_float, C.c_float, C.c_float,
+                                            C.c_void_p]
+    L.orc_adaptive_voxel_filter.restype = C.c_int
+    m = L.orc_adaptive_voxel_filter(xyz, n, max_length, min_num_points, max_range,
+                                    out.ctypes.data)
+    return out[:m].copy()
+
+
+def compute_histogram(xyz, histogram_size):
+    xyz, n = _cloud(xyz)
+    out = np.empty(histogram_size, np.float32)
+    L = lib()
+    L.orc_compute_histogram.argtypes = [_f32p, C.c_int, C.c_int, C.c_void_p]
+    L.orc_compute_histogram.restype = None
+    L.orc_compute_histogram(xyz, n, histogram_size, out.ctypes.data)
+    return out
+
+
+def ref_voxel_filter(xyz, resolution):
+    """The reference's own sensor/internal/voxel_filter.cc (oracle/_ref)."""
+    xyz, n = _cloud(xyz)
+    out = np.empty((max(n, 1), 3), np.float32)
+    R = ref_lib()
+    R.ref_voxel_filter.argtypes = [_f32p, C.c_int, C.c_float, C.c_void_p]
+    R.ref_voxel_filter.restype = C.c_int
+    return out[:R.ref_voxel_filter(xyz, n, resolution, out.ctypes.data)].copy()
+
+
+def ref_adaptive_voxel_filter(xyz, max_length, min_num_points, max_range):
+    xyz, n = _cloud(xyz)
+    out = np.empty((max(n, 1), 3), np.float32)
+    R = ref_lib()
+    R.ref_adaptive_voxel_filter.argtypes = [_f32p, C.c_int, C.c_float, C.c_float, C.c_float,
+                                            C.c_void_p]
+    R.ref_adaptive_voxel_filter.restype = C.c_int
+    m = R.ref_adaptive_voxel_filter(xyz, n, max_length, min_num_points, max_range,
+                                    out.ctypes.data)
+    return out[:m].copy()
+
+
 def _sort_zyx(a):
     return a[np.lexsort((a[:, 0], a[:, 1], a[:, 2]))] if len(a) else a
 

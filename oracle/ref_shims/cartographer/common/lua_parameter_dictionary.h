@@ -11,6 +11,7 @@ class LuaParameterDictionary {
  public:
   double GetDouble(const std::string&) { std::abort(); }
   int GetInt(const std::string&) { std::abort(); }
+  int GetNonNegativeInt(const std::string&) { std::abort(); }
   bool GetBool(const std::string&) { std::abort(); }
   bool HasKey(const std::string&) { std::abort(); }
   std::string GetString(const std::string&) { std::abort(); }

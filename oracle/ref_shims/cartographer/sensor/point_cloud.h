@@ -15,6 +15,16 @@ class PointCloud {
  public:
   PointCloud() = default;
   explicit PointCloud(std::vector<RangefinderPoint> points) : points_(std::move(points)) {}
+  PointCloud(std::vector<RangefinderPoint> points, std::vector<float> intensities)
+      : points_(std::move(points)), intensities_(std::move(intensities)) {}
+  // sensor/point_cloud.h:59-84 (no intensities in this build's fixtures).
+  template <class UnaryPredicate>
+  PointCloud copy_if(UnaryPredicate predicate) const {
+    std::vector<RangefinderPoint> points;
+    for (const RangefinderPoint& p : points_)
+      if (predicate(p)) points.push_back(p);
+    return PointCloud(std::move(points));
+  }
   size_t size() const { return points_.size(); }
   bool empty() const { return points_.empty(); }
   const RangefinderPoint& operator[](size_t i) const { return points_[i]; }
@@ -25,7 +35,7 @@ class PointCloud {
   void push_back(RangefinderPoint p) { points_.push_back(p); }
  private:
   std::vector<RangefinderPoint> points_;
-  std::vector<float> intensities_;   // always empty here
+  std::vector<float> intensities_;   // always empty in this build's fixtures
 };
 inline PointCloud TransformPointCloud(const PointCloud& point_cloud,
                                       const transform::Rigid3f& transform) {

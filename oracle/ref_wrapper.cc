@@ -21,6 +21,7 @@
 #include "cartographer/mapping/internal/2d/tsdf_range_data_inserter_2d.h"
 #include "cartographer/mapping/probability_values.h"
 #include "cartographer/mapping/value_conversion_tables.h"
+#include "cartographer/sensor/internal/voxel_filter.h"
 
 extern "C" {
 
@@ -590,6 +591,36 @@ int ref_fast3d_match(void* h, int full_submap, const double* node7, const double
   }
   if (stats4) stats4[0] = stats4[1] = stats4[2] = stats4[3] = -1;   // not counted by the reference
   return r != nullptr ? 1 : 0;
+}
+
+
+// sensor::VoxelFilter(PointCloud, resolution) (sensor/internal/voxel_filter.cc:132-152): the
+// reference's own randomised reservoir filter; `out_xyz` receives the kept points in order.
+int ref_voxel_filter(const float* xyz, int n, float resolution, float* out_xyz) {
+  const cartographer::sensor::PointCloud r =
+      cartographer::sensor::VoxelFilter(MakeCloud(xyz, n), resolution);
+  for (size_t i = 0; i != r.size(); ++i) {
+    out_xyz[3 * i] = r[i].position.x();
+    out_xyz[3 * i + 1] = r[i].position.y();
+    out_xyz[3 * i + 2] = r[i].position.z();
+  }
+  return static_cast<int>(r.size());
+}
+// sensor::AdaptiveVoxelFilter (voxel_filter.cc:193-198).
+int ref_adaptive_voxel_filter(const float* xyz, int n, float max_length, float min_num_points,
+                              float max_range, float* out_xyz) {
+  cartographer::sensor::proto::AdaptiveVoxelFilterOptions options;
+  options.set_max_length(max_length);
+  options.set_min_num_points(min_num_points);
+  options.set_max_range(max_range);
+  const cartographer::sensor::PointCloud r =
+      cartographer::sensor::AdaptiveVoxelFilter(MakeCloud(xyz, n), options);
+  for (size_t i = 0; i != r.size(); ++i) {
+    out_xyz[3 * i] = r[i].position.x();
+    out_xyz[3 * i + 1] = r[i].position.y();
+    out_xyz[3 * i + 2] = r[i].position.z();
+  }
+  return static_cast<int>(r.size());
 }
 
 }  // extern "C"
