@@ -121,6 +121,7 @@ EXPORTED_SYMBOLS = [
     "cmx_comm_init", "cmx_comm_destroy", "cmx_comm_num_devices", "cmx_comm_device_of",
     "cmx_fast2d_match_sharded", "cmx_fast3d_match_sharded", "cmx_shard_range",
     "cmx_pack_best_key", "cmx_unpack_best_key",
+    "cmx_voxel_filter", "cmx_adaptive_voxel_filter", "cmx_compute_histogram",
 ]
 
 _lib = None
@@ -196,6 +197,11 @@ def lib():
     L.cmx_fast2d_refine_batch.argtypes = [P(Ceres2DOptions), P(C.c_void_p), C.c_int32, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                           C.c_void_p]
+    L.cmx_voxel_filter.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p,
+                                   P(C.c_int32)]
+    L.cmx_adaptive_voxel_filter.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float,
+                                            C.c_float, C.c_int32, C.c_void_p, P(C.c_int32)]
+    L.cmx_compute_histogram.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     L.cmx_comm_init.argtypes = [C.c_void_p, C.c_int32, P(C.c_void_p)]
     L.cmx_comm_destroy.argtypes = [C.c_void_p]
     L.cmx_comm_destroy.restype = None

@@ -1,0 +1,538 @@
+// Upstream point preparation on gfx950: the voxel filters that define the N of
+// every matcher call and the rotational histogram of the 3D loop-closure matcher.
+//   sensor/internal/voxel_filter.cc:30-36,38-75,79-115,193-198
+//   mapping/internal/3d/scan_matching/rotational_scan_matcher.cc:30-120,164-177
+//
+// VoxelFilter keeps ONE RANDOM point per voxel: a reservoir sample driven by a
+// std::minstd_rand0 that is default-seeded per call and consumed in point order, one
+// std::uniform_int_distribution(1, k) draw for the k-th point of a voxel (k >= 2).  That reads
+// as inherently sequential, but the only sequential quantity is the position of each draw in
+// the generator's stream, and that is a prefix sum:
+//   1. voxel key per point (per-axis lround(p / resolution) in f32, packed like the reference);
+//   2. stable radix sort of (key, index): a voxel's points become a segment in index order, a
+//      point's position in its segment is its k;
+//   3. exclusive prefix sum over the points (original order) of [k >= 2] = stream position t;
+//   4. minstd_rand0 is x -> 16807 x mod (2^31 - 1): the t-th output is 16807^t mod (2^31 - 1),
+//      a 31-step modular power per point; libstdc++'s distribution (downscaling with rejection,
+//      bits/uniform_int_dist.h) maps it to [1, k]; the point replaces the reservoir iff the
+//      result is k; the LAST replacing point of a segment is the voxel's sample;
+//   5. a draw is rejected with probability < k / 2^31 and shifts every later stream position:
+//      the kernels flag it, and the (practically never taken) repair pass replays the draws
+//      sequentially on one lane from the ranks already computed.
+// The result is the reference's point set, bit for bit (against a reference built with this
+// libstdc++; the standard leaves the distribution's algorithm to the implementation).
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+
+#include "cmx_common.h"
+#include "cmx_device.h"
+
+namespace cmx {
+namespace {
+
+constexpr unsigned kMinstdA = 16807u, kMinstdM = 2147483647u;      // std::minstd_rand0
+constexpr unsigned long long kUrngRange = 2147483645ull;           // max() - min()
+
+__device__ __forceinline__ unsigned MulMod(unsigned a, unsigned b) {
+  return static_cast<unsigned>((static_cast<unsigned long long>(a) * b) % kMinstdM);
+}
+// t-th output (t >= 1) of a default-seeded (state 1) minstd_rand0.
+__device__ __forceinline__ unsigned MinstdOutput(unsigned long long t) {
+  unsigned result = 1u, base = kMinstdA;
+  while (t) {
+    if (t & 1ull) result = MulMod(result, base);
+    base = MulMod(base, base);
+    t >>= 1;
+  }
+  return result;
+}
+
+// GetVoxelCellIndex (voxel_filter.cc:79-86).
+__global__ void VoxelKeyKernel(const float* __restrict__ xyz, int n, float resolution,
+                               unsigned long long* __restrict__ keys,
+                               unsigned* __restrict__ index) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long x =
+      static_cast<unsigned long long>(static_cast<long long>(LRoundF32(xyz[3 * i] / resolution)));
+  const unsigned long long y = static_cast<unsigned long long>(
+      static_cast<long long>(LRoundF32(xyz[3 * i + 1] / resolution)));
+  const unsigned long long z = static_cast<unsigned long long>(
+      static_cast<long long>(LRoundF32(xyz[3 * i + 2] / resolution)));
+  keys[i] = (x << 42) + (y << 21) + z;
+  index[i] = static_cast<unsigned>(i);
+}
+
+// Sorted position p: start of its segment if it is a head, else 0 (max-scanned afterwards).
+__global__ void SegmentHeadKernel(const unsigned long long* __restrict__ sorted_keys, int n,
+                                  int* __restrict__ head_or_zero) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  head_or_zero[p] = (p > 0 && sorted_keys[p] != sorted_keys[p - 1]) ? p : 0;
+}
+
+// Back to point order: k (1-based position in the voxel), the voxel's id (= segment start), the
+// draw flag, and the reservoir of the voxel cleared.
+__global__ void RankScatterKernel(const unsigned* __restrict__ sorted_index,
+                                  const int* __restrict__ seg_start, int n,
+                                  int* __restrict__ rank, int* __restrict__ voxel,
+                                  int* __restrict__ draws, int* __restrict__ selected) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int i = static_cast<int>(sorted_index[p]);
+  const int k = p - seg_start[p] + 1;
+  rank[i] = k;
+  voxel[i] = seg_start[p];
+  draws[i] = k >= 2 ? 1 : 0;
+  if (k == 1) selected[p] = -1;
+}
+
+// libstdc++ uniform_int_distribution<int>(1, k) on a minstd_rand0 output g:
+// ret = g - 1; scaling = urngrange / k; rejected if ret >= k * scaling; value = ret / scaling + 1.
+__global__ void DrawKernel(const int* __restrict__ rank, const int* __restrict__ voxel,
+                           const int* __restrict__ stream_pos, int n, int* __restrict__ selected,
+                           int* __restrict__ rejected) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int k = rank[i];
+  bool replace = true;                     // k == 1: the first point of a voxel is its sample
+  if (k >= 2) {
+    const unsigned long long ret = MinstdOutput(static_cast<unsigned long long>(stream_pos[i]) + 1) - 1;
+    const unsigned long long scaling = kUrngRange / static_cast<unsigned long long>(k);
+    if (ret >= static_cast<unsigned long long>(k) * scaling) {
+      *rejected = 1;
+      return;
+    }
+    replace = ret / scaling == static_cast<unsigned long long>(k - 1);
+  }
+  if (replace) atomicMax(&selected[voxel[i]], i);
+}
+
+// Repair pass (a draw was rejected somewhere): replays the generator sequentially on one lane.
+__global__ void SequentialDrawKernel(const int* __restrict__ rank, const int* __restrict__ voxel,
+                                     int n, int* __restrict__ selected) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  unsigned state = 1u;
+  for (int i = 0; i < n; ++i) {
+    const int k = rank[i];
+    bool replace = true;
+    if (k >= 2) {
+      const unsigned long long scaling = kUrngRange / static_cast<unsigned long long>(k);
+      const unsigned long long past = static_cast<unsigned long long>(k) * scaling;
+      unsigned long long ret;
+      do {
+        state = MulMod(state, kMinstdA);
+        ret = state - 1u;
+      } while (ret >= past);
+      replace = ret / scaling == static_cast<unsigned long long>(k - 1);
+    }
+    if (replace) selected[voxel[i]] = i;       // index order: the last one stays
+    else if (k == 1) selected[voxel[i]] = i;
+  }
+}
+
+__global__ void UsedFlagKernel(const int* __restrict__ voxel, const int* __restrict__ selected,
+                               int n, int* __restrict__ used) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  used[i] = selected[voxel[i]] == i ? 1 : 0;
+}
+
+__global__ void RangeFlagKernel(const float* __restrict__ xyz, int n, float max_range,
+                                int* __restrict__ used) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+  used[i] = sqrtf((x * x + y * y) + z * z) <= max_range ? 1 : 0;   // position.norm()
+}
+
+__global__ void CompactKernel(const float* __restrict__ xyz, const int* __restrict__ used,
+                              const int* __restrict__ offset, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !used[i]) return;
+  const int o = offset[i];
+  out[3 * o] = xyz[3 * i];
+  out[3 * o + 1] = xyz[3 * i + 1];
+  out[3 * o + 2] = xyz[3 * i + 2];
+}
+
+// Scratch of one filter call, carved from a workspace.
+struct FilterScratch {
+  unsigned long long *keys = nullptr, *keys_sorted = nullptr;
+  unsigned *index = nullptr, *index_sorted = nullptr;
+  int *head = nullptr, *seg_start = nullptr, *rank = nullptr, *voxel = nullptr, *draws = nullptr,
+      *stream_pos = nullptr, *selected = nullptr, *used = nullptr, *offset = nullptr,
+      *flags = nullptr;          // [0] rejected, [1] count
+  void* temp = nullptr;
+  size_t temp_bytes = 0;
+};
+
+FilterScratch Carve(Workspace& ws, int n) {
+  FilterScratch s;
+  const size_t N = static_cast<size_t>(std::max(n, 1));
+  size_t sort_bytes = 0, scan_bytes = 0, max_bytes = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, s.keys, s.keys_sorted, s.index,
+                                           s.index_sorted, n, 0, 64, ws.stream);
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, s.draws, s.stream_pos, n, ws.stream);
+  (void)hipcub::DeviceScan::InclusiveScan(nullptr, max_bytes, s.head, s.seg_start, hipcub::Max(), n,
+                                          ws.stream);
+  s.temp_bytes = std::max(sort_bytes, std::max(scan_bytes, max_bytes)) + 256;
+  char* base = static_cast<char*>(ws.dev[9].Reserve(N * (2 * 8 + 2 * 4 + 9 * 4) + 1024 + s.temp_bytes));
+  s.keys = reinterpret_cast<unsigned long long*>(base); base += N * 8;
+  s.keys_sorted = reinterpret_cast<unsigned long long*>(base); base += N * 8;
+  s.index = reinterpret_cast<unsigned*>(base); base += N * 4;
+  s.index_sorted = reinterpret_cast<unsigned*>(base); base += N * 4;
+  int** ints[] = {&s.head, &s.seg_start, &s.rank, &s.voxel, &s.draws, &s.stream_pos, &s.selected,
+                  &s.used, &s.offset};
+  for (int** p : ints) { *p = reinterpret_cast<int*>(base); base += N * 4; }
+  s.flags = reinterpret_cast<int*>(base); base += 256;
+  base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(base) + 255) & ~uintptr_t(255));
+  s.temp = base;
+  return s;
+}
+
+// points_used flags of RandomizedVoxelFilterIndices for the device cloud `d_xyz` into s.used,
+// their exclusive prefix sum into s.offset; returns the number of points kept.
+int VoxelFilterFlags(Workspace& ws, const FilterScratch& s, const float* d_xyz, int n,
+                     float resolution) {
+  if (n == 0) return 0;
+  const int blocks = DivUp(n, 256);
+  hipStream_t st = ws.stream;
+  CMX_HIP(hipMemsetAsync(s.flags, 0, 8, st));
+  VoxelKeyKernel<<<blocks, 256, 0, st>>>(d_xyz, n, resolution, s.keys, s.index);
+  size_t bytes = s.temp_bytes;
+  CMX_HIP(hipcub::DeviceRadixSort::SortPairs(s.temp, bytes, s.keys, s.keys_sorted, s.index,
+                                             s.index_sorted, n, 0, 64, st));
+  SegmentHeadKernel<<<blocks, 256, 0, st>>>(s.keys_sorted, n, s.head);
+  bytes = s.temp_bytes;
+  CMX_HIP(hipcub::DeviceScan::InclusiveScan(s.temp, bytes, s.head, s.seg_start, hipcub::Max(), n, st));
+  RankScatterKernel<<<blocks, 256, 0, st>>>(s.index_sorted, s.seg_start, n, s.rank, s.voxel, s.draws,
+                                            s.selected);
+  bytes = s.temp_bytes;
+  CMX_HIP(hipcub::DeviceScan::ExclusiveSum(s.temp, bytes, s.draws, s.stream_pos, n, st));
+  DrawKernel<<<blocks, 256, 0, st>>>(s.rank, s.voxel, s.stream_pos, n, s.selected, s.flags);
+  int rejected = 0;
+  CMX_HIP(hipMemcpyAsync(&rejected, s.flags, sizeof(int), hipMemcpyDeviceToHost, st));
+  CMX_HIP(hipStreamSynchronize(st));
+  if (rejected) SequentialDrawKernel<<<1, 64, 0, st>>>(s.rank, s.voxel, n, s.selected);
+  UsedFlagKernel<<<blocks, 256, 0, st>>>(s.voxel, s.selected, n, s.used);
+  bytes = s.temp_bytes;
+  CMX_HIP(hipcub::DeviceScan::ExclusiveSum(s.temp, bytes, s.used, s.offset, n, st));
+  int last_used = 0, last_offset = 0;
+  CMX_HIP(hipMemcpyAsync(&last_used, s.used + (n - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+  CMX_HIP(hipMemcpyAsync(&last_offset, s.offset + (n - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+  CMX_HIP(hipStreamSynchronize(st));
+  CMX_HIP(hipGetLastError());
+  return last_used + last_offset;
+}
+
+void Compact(Workspace& ws, const FilterScratch& s, const float* d_xyz, int n, float* d_out) {
+  if (n == 0) return;
+  CompactKernel<<<DivUp(n, 256), 256, 0, ws.stream>>>(d_xyz, s.used, s.offset, n, d_out);
+}
+
+// ---------------------------------------------------------------------------
+// RotationalScanMatcher::ComputeHistogram
+// ---------------------------------------------------------------------------
+constexpr float kMinDistance = 0.2f, kMaxDistance = 0.9f, kSliceHeight = 0.2f;
+
+__global__ void SliceKeyKernel(const float* __restrict__ xyz, int n, unsigned* __restrict__ keys,
+                               unsigned* __restrict__ index) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // std::map<int, ...> order: ascending RoundToInt(z / kSliceHeight); biased to unsigned.
+  keys[i] = static_cast<unsigned>(LRoundF32(xyz[3 * i + 2] / kSliceHeight)) ^ 0x80000000u;
+  index[i] = static_cast<unsigned>(i);
+}
+
+// One block per slice (slices = segments of equal key in the sorted order).  Thread 0 sums the
+// slice's points in their order (ComputeCentroid's sequential f32 sum), every thread then
+// computes its points' angle around the centroid; points closer than kMinDistance are dropped
+// (key = all ones sorts them behind the slice).  Sort key: slice rank << 32 | orderable angle.
+__global__ void SliceAngleKernel(const float* __restrict__ xyz,
+                                 const unsigned* __restrict__ sorted_index,
+                                 const int* __restrict__ slice_begin, int num_slices, int n,
+                                 unsigned long long* __restrict__ keys2,
+                                 unsigned* __restrict__ index2) {
+  const int s = blockIdx.x;
+  const int begin = slice_begin[s], end = s + 1 < num_slices ? slice_begin[s + 1] : n;
+  __shared__ float c[3];
+  if (threadIdx.x == 0) {
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int p = begin; p < end; ++p) {
+      const int i = sorted_index[p];
+      sx += xyz[3 * i]; sy += xyz[3 * i + 1]; sz += xyz[3 * i + 2];
+    }
+    const float count = static_cast<float>(end - begin);
+    c[0] = sx / count; c[1] = sy / count; c[2] = sz / count;
+  }
+  __syncthreads();
+  for (int p = begin + threadIdx.x; p < end; p += blockDim.x) {
+    const int i = sorted_index[p];
+    const float dx = xyz[3 * i] - c[0], dy = xyz[3 * i + 1] - c[1];
+    unsigned long long key = (static_cast<unsigned long long>(s) << 32) | 0xffffffffull;
+    if (!(sqrtf(dx * dx + dy * dy) < kMinDistance)) {
+      const unsigned bits = __float_as_uint(atan2f(dy, dx));
+      key = (static_cast<unsigned long long>(s) << 32) |
+            (bits ^ ((bits >> 31) ? 0xffffffffu : 0x80000000u));
+      if ((key & 0xffffffffull) == 0xffffffffull) key -= 1;     // keep the "dropped" key unique
+    }
+    keys2[p] = key;
+    index2[p] = static_cast<unsigned>(i);
+  }
+}
+
+// Per slice, in angle order: AddPointCloudSliceToHistogram's walk (the `last_point_position`
+// chain is sequential: one lane per slice), leaving (bucket, value) per sorted position.
+__global__ void SliceWalkKernel(const float* __restrict__ xyz,
+                                const unsigned long long* __restrict__ sorted_keys2,
+                                const unsigned* __restrict__ sorted_index2,
+                                const int* __restrict__ slice_begin, int num_slices, int n,
+                                int histogram_size, int* __restrict__ bucket,
+                                float* __restrict__ value) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= num_slices) return;
+  const int begin = slice_begin[s], end = s + 1 < num_slices ? slice_begin[s + 1] : n;
+  int kept_end = begin;       // dropped points sort behind the kept ones
+  while (kept_end < end && (sorted_keys2[kept_end] & 0xffffffffull) != 0xffffffffull) ++kept_end;
+  for (int p = begin; p < end; ++p) bucket[p] = -1;
+  if (kept_end == begin) return;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int p = begin; p < kept_end; ++p) {
+    const int i = sorted_index2[p];
+    sx += xyz[3 * i]; sy += xyz[3 * i + 1]; sz += xyz[3 * i + 2];
+  }
+  const float count = static_cast<float>(kept_end - begin);
+  const float cx = sx / count, cy = sy / count;
+  const int first = sorted_index2[begin];
+  float lx = xyz[3 * first], ly = xyz[3 * first + 1];
+  const float kPi = static_cast<float>(M_PI);
+  for (int p = begin; p < kept_end; ++p) {
+    const int i = sorted_index2[p];
+    const float px = xyz[3 * i], py = xyz[3 * i + 1];
+    const float dx = px - lx, dy = py - ly;
+    const float ex = px - cx, ey = py - cy;
+    const float distance = sqrtf(dx * dx + dy * dy);
+    const float direction_norm = sqrtf(ex * ex + ey * ey);
+    if (distance < kMinDistance || direction_norm < kMinDistance) continue;
+    if (distance > kMaxDistance) {
+      lx = px; ly = py;
+      continue;
+    }
+    float angle = atan2f(dy, dx);
+    const float ndx = dx / distance, ndy = dy / distance;
+    const float nex = ex / direction_norm, ney = ey / direction_norm;
+    const float v = fmaxf(0.f, 1.f - fabsf(ndx * nex + ndy * ney));
+    while (angle > kPi) angle -= kPi;
+    while (angle < 0.f) angle += kPi;
+    const float zero_to_one = angle / kPi;
+    const int b = min(max(LRoundF32(histogram_size * zero_to_one - 0.5f), 0), histogram_size - 1);
+    bucket[p] = b;
+    value[p] = v;
+  }
+}
+
+// One lane per bucket adds its values in (slice, angle) order: the reference's f32
+// accumulation order per bucket.
+__global__ void HistogramSumKernel(const int* __restrict__ bucket, const float* __restrict__ value,
+                                   int n, int histogram_size, float* __restrict__ histogram) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= histogram_size) return;
+  float h = 0.f;
+  for (int p = 0; p < n; ++p)
+    if (bucket[p] == b) h += value[p];
+  histogram[b] = h;
+}
+
+__global__ void SliceBeginKernel(const unsigned* __restrict__ sorted_keys, int n,
+                                 int* __restrict__ is_head) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  is_head[p] = (p == 0 || sorted_keys[p] != sorted_keys[p - 1]) ? 1 : 0;
+}
+__global__ void SliceBeginScatterKernel(const int* __restrict__ is_head,
+                                        const int* __restrict__ slice_rank, int n,
+                                        int* __restrict__ slice_begin) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n || !is_head[p]) return;
+  slice_begin[slice_rank[p]] = p;
+}
+
+}  // namespace
+}  // namespace cmx
+
+using cmx::Guard;
+
+extern "C" {
+
+cmx_status cmx_voxel_filter(const float* point_cloud_xyz, int32_t num_points, float resolution,
+                            int32_t device, float* filtered_xyz, int32_t* num_filtered) {
+  return Guard([&] {
+    CMX_REQUIRE(num_points >= 0 && num_points <= (1 << 26) && filtered_xyz && num_filtered &&
+                    (point_cloud_xyz || num_points == 0),
+                "bad argument");
+    CMX_REQUIRE(resolution > 0.f, "resolution must be > 0");
+    *num_filtered = 0;
+    cmx::WorkspaceLease ws(device);
+    if (num_points == 0) return;
+    const int n = num_points;
+    float* d_xyz = ws->dev[0].ReserveAs<float>(6 * static_cast<size_t>(n));
+    float* d_out = d_xyz + 3 * static_cast<size_t>(n);
+    CMX_HIP(hipMemcpyAsync(d_xyz, point_cloud_xyz, 12 * static_cast<size_t>(n),
+                           hipMemcpyHostToDevice, ws->stream));
+    const cmx::FilterScratch s = cmx::Carve(*ws, n);
+    const int kept = cmx::VoxelFilterFlags(*ws, s, d_xyz, n, resolution);
+    cmx::Compact(*ws, s, d_xyz, n, d_out);
+    CMX_HIP(hipMemcpyAsync(filtered_xyz, d_out, 12 * static_cast<size_t>(kept),
+                           hipMemcpyDeviceToHost, ws->stream));
+    CMX_HIP(hipStreamSynchronize(ws->stream));
+    *num_filtered = kept;
+  });
+}
+
+cmx_status cmx_adaptive_voxel_filter(const float* point_cloud_xyz, int32_t num_points,
+                                     float max_length, float min_num_points, float max_range,
+                                     int32_t device, float* filtered_xyz, int32_t* num_filtered) {
+  return Guard([&] {
+    CMX_REQUIRE(num_points >= 0 && num_points <= (1 << 26) && filtered_xyz && num_filtered &&
+                    (point_cloud_xyz || num_points == 0),
+                "bad argument");
+    CMX_REQUIRE(max_length > 0.f, "max_length must be > 0");
+    *num_filtered = 0;
+    cmx::WorkspaceLease ws(device);
+    if (num_points == 0) return;
+    const int n0 = num_points;
+    // dev[0]: raw cloud | in-range cloud | result | candidate.
+    float* d_raw = ws->dev[0].ReserveAs<float>(12 * static_cast<size_t>(n0));
+    float* d_in = d_raw + 3 * static_cast<size_t>(n0);
+    float* d_result = d_in + 3 * static_cast<size_t>(n0);
+    float* d_candidate = d_result + 3 * static_cast<size_t>(n0);
+    hipStream_t st = ws->stream;
+    CMX_HIP(hipMemcpyAsync(d_raw, point_cloud_xyz, 12 * static_cast<size_t>(n0),
+                           hipMemcpyHostToDevice, st));
+    const cmx::FilterScratch s = cmx::Carve(*ws, n0);
+    // FilterByMaxRange.
+    cmx::RangeFlagKernel<<<cmx::DivUp(n0, 256), 256, 0, st>>>(d_raw, n0, max_range, s.used);
+    size_t bytes = s.temp_bytes;
+    CMX_HIP(hipcub::DeviceScan::ExclusiveSum(s.temp, bytes, s.used, s.offset, n0, st));
+    cmx::Compact(*ws, s, d_raw, n0, d_in);
+    int last_used = 0, last_offset = 0;
+    CMX_HIP(hipMemcpyAsync(&last_used, s.used + (n0 - 1), 4, hipMemcpyDeviceToHost, st));
+    CMX_HIP(hipMemcpyAsync(&last_offset, s.offset + (n0 - 1), 4, hipMemcpyDeviceToHost, st));
+    CMX_HIP(hipStreamSynchronize(st));
+    const int n = last_used + last_offset;
+    const float* d_final = d_in;
+    int kept = n;
+    // AdaptivelyVoxelFiltered (voxel_filter.cc:38-75): the same sequence of VoxelFilter calls.
+    const auto filter = [&](float length, float* d_out) {
+      const int m = cmx::VoxelFilterFlags(*ws, s, d_in, n, length);
+      cmx::Compact(*ws, s, d_in, n, d_out);
+      return m;
+    };
+    if (!(static_cast<float>(n) <= min_num_points)) {
+      bool done = false;
+      kept = filter(max_length, d_result);
+      d_final = d_result;
+      if (static_cast<float>(kept) >= min_num_points) done = true;
+      for (float high_length = max_length; !done && high_length > 1e-2f * max_length;
+           high_length /= 2.f) {
+        float low_length = high_length / 2.f;
+        kept = filter(low_length, d_result);
+        if (static_cast<float>(kept) >= min_num_points) {
+          while ((high_length - low_length) / low_length > 1e-1f) {
+            const float mid_length = (low_length + high_length) / 2.f;
+            const int m = filter(mid_length, d_candidate);
+            if (static_cast<float>(m) >= min_num_points) {
+              low_length = mid_length;
+              std::swap(d_result, d_candidate);
+              d_final = d_result;
+              kept = m;
+            } else {
+              high_length = mid_length;
+            }
+          }
+          done = true;
+        }
+      }
+    }
+    CMX_HIP(hipMemcpyAsync(filtered_xyz, d_final, 12 * static_cast<size_t>(kept),
+                           hipMemcpyDeviceToHost, st));
+    CMX_HIP(hipStreamSynchronize(st));
+    *num_filtered = kept;
+  });
+}
+
+cmx_status cmx_compute_histogram(const float* point_cloud_xyz, int32_t num_points,
+                                 int32_t histogram_size, int32_t device, float* histogram) {
+  return Guard([&] {
+    CMX_REQUIRE(num_points >= 0 && num_points <= (1 << 24) && histogram && histogram_size >= 1 &&
+                    histogram_size <= 65536 && (point_cloud_xyz || num_points == 0),
+                "bad argument");
+    for (int b = 0; b < histogram_size; ++b) histogram[b] = 0.f;
+    cmx::WorkspaceLease ws(device);
+    if (num_points == 0) return;
+    const int n = num_points;
+    hipStream_t st = ws->stream;
+    const size_t N = static_cast<size_t>(n);
+    float* d_xyz = ws->dev[0].ReserveAs<float>(3 * N);
+    CMX_HIP(hipMemcpyAsync(d_xyz, point_cloud_xyz, 12 * N, hipMemcpyHostToDevice, st));
+    // keys(u32) x2 | index x2 | keys2(u64) x2 | index2 x2 | is_head | slice_rank | slice_begin |
+    // bucket | value | histogram | temp
+    size_t sort32 = 0, sort64 = 0, scan = 0;
+    unsigned *k = nullptr, *v = nullptr;
+    unsigned long long* k2 = nullptr;
+    int* ip = nullptr;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort32, k, k, v, v, n, 0, 32, st);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort64, k2, k2, v, v, n, 0, 64, st);
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, scan, ip, ip, n, st);
+    const size_t temp_bytes = std::max(sort32, std::max(sort64, scan)) + 256;
+    char* base = static_cast<char*>(ws->dev[9].Reserve(
+        N * (4 * 4 + 2 * 8 + 2 * 4 + 5 * 4) + 4 * static_cast<size_t>(histogram_size) + 1024 + temp_bytes));
+    const auto take = [&](size_t bytes) { char* p = base; base += (bytes + 15) & ~size_t(15); return p; };
+    unsigned long long* keys2 = reinterpret_cast<unsigned long long*>(take(8 * N));
+    unsigned long long* keys2_sorted = reinterpret_cast<unsigned long long*>(take(8 * N));
+    unsigned* keys = reinterpret_cast<unsigned*>(take(4 * N));
+    unsigned* keys_sorted = reinterpret_cast<unsigned*>(take(4 * N));
+    unsigned* index = reinterpret_cast<unsigned*>(take(4 * N));
+    unsigned* index_sorted = reinterpret_cast<unsigned*>(take(4 * N));
+    unsigned* index2 = reinterpret_cast<unsigned*>(take(4 * N));
+    unsigned* index2_sorted = reinterpret_cast<unsigned*>(take(4 * N));
+    int* is_head = reinterpret_cast<int*>(take(4 * N));
+    int* slice_rank = reinterpret_cast<int*>(take(4 * N));
+    int* slice_begin = reinterpret_cast<int*>(take(4 * N));
+    int* bucket = reinterpret_cast<int*>(take(4 * N));
+    float* value = reinterpret_cast<float*>(take(4 * N));
+    float* d_hist = reinterpret_cast<float*>(take(4 * static_cast<size_t>(histogram_size)));
+    base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(base) + 255) & ~uintptr_t(255));
+    void* temp = base;
+    const int blocks = cmx::DivUp(n, 256);
+    cmx::SliceKeyKernel<<<blocks, 256, 0, st>>>(d_xyz, n, keys, index);
+    size_t bytes = temp_bytes;
+    CMX_HIP(hipcub::DeviceRadixSort::SortPairs(temp, bytes, keys, keys_sorted, index, index_sorted,
+                                               n, 0, 32, st));
+    cmx::SliceBeginKernel<<<blocks, 256, 0, st>>>(keys_sorted, n, is_head);
+    bytes = temp_bytes;
+    CMX_HIP(hipcub::DeviceScan::InclusiveSum(temp, bytes, is_head, slice_rank, n, st));
+    int num_slices = 0;
+    CMX_HIP(hipMemcpyAsync(&num_slices, slice_rank + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    CMX_HIP(hipStreamSynchronize(st));
+    // slice_rank is 1-based after the inclusive sum: shift by one through the pointer.
+    cmx::SliceBeginScatterKernel<<<blocks, 256, 0, st>>>(is_head, slice_rank, n, slice_begin - 1);
+    cmx::SliceAngleKernel<<<num_slices, 256, 0, st>>>(d_xyz, index_sorted, slice_begin, num_slices,
+                                                      n, keys2, index2);
+    bytes = temp_bytes;
+    CMX_HIP(hipcub::DeviceRadixSort::SortPairs(temp, bytes, keys2, keys2_sorted, index2,
+                                               index2_sorted, n, 0, 64, st));
+    cmx::SliceWalkKernel<<<cmx::DivUp(num_slices, 64), 64, 0, st>>>(
+        d_xyz, keys2_sorted, index2_sorted, slice_begin, num_slices, n, histogram_size, bucket, value);
+    cmx::HistogramSumKernel<<<cmx::DivUp(histogram_size, 64), 64, 0, st>>>(bucket, value, n,
+                                                                           histogram_size, d_hist);
+    CMX_HIP(hipGetLastError());
+    CMX_HIP(hipMemcpyAsync(histogram, d_hist, 4 * static_cast<size_t>(histogram_size),
+                           hipMemcpyDeviceToHost, st));
+    CMX_HIP(hipStreamSynchronize(st));
+  });
+}
+
+}  // extern "C"

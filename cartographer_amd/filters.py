@@ -1,0 +1,42 @@
+"""Host-side mirror of the reference's point preparation over the C ABI:
+``sensor::VoxelFilter`` / ``sensor::AdaptiveVoxelFilter``
+(cartographer/sensor/internal/voxel_filter.h:30-45) and
+``RotationalScanMatcher::ComputeHistogram``
+(cartographer/mapping/internal/3d/scan_matching/rotational_scan_matcher.h:40-42)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _cloud(point_cloud):
+    xyz = np.ascontiguousarray(point_cloud, dtype=np.float32).reshape(-1, 3)
+    return xyz, xyz.shape[0]
+
+
+def voxel_filter(point_cloud, resolution, device=0):
+    xyz, n = _cloud(point_cloud)
+    out = np.empty((max(n, 1), 3), np.float32)
+    kept = C.c_int32()
+    _lib.check(_lib.lib().cmx_voxel_filter(xyz.ctypes.data, n, resolution, device,
+                                           out.ctypes.data, C.byref(kept)))
+    return out[:kept.value].copy()
+
+
+def adaptive_voxel_filter(point_cloud, max_length, min_num_points, max_range, device=0):
+    xyz, n = _cloud(point_cloud)
+    out = np.empty((max(n, 1), 3), np.float32)
+    kept = C.c_int32()
+    _lib.check(_lib.lib().cmx_adaptive_voxel_filter(xyz.ctypes.data, n, max_length,
+                                                    min_num_points, max_range, device,
+                                                    out.ctypes.data, C.byref(kept)))
+    return out[:kept.value].copy()
+
+
+def compute_histogram(point_cloud, histogram_size, device=0):
+    xyz, n = _cloud(point_cloud)
+    out = np.zeros(histogram_size, np.float32)
+    _lib.check(_lib.lib().cmx_compute_histogram(xyz.ctypes.data, n, histogram_size, device,
+                                                out.ctypes.data))
+    return out

@@ -383,6 +383,24 @@ cmx_status cmx_fast3d_match_batch(const cmx_fast3d* const* matchers, int32_t num
                                   const cmx_node_data3d* data, int32_t* found,
                                   cmx_result3d* results, cmx_match_stats* stats);
 
+/* ---- upstream point preparation ---------------------------------------- */
+/* sensor::VoxelFilter(PointCloud, resolution) (sensor/internal/voxel_filter.cc:88-152): one
+ * RANDOM point per voxel -- the reference's reservoir sample, reproduced exactly (the draws of
+ * its default-seeded std::minstd_rand0 are located in the generator's stream by a prefix sum).
+ * `filtered_xyz` needs room for num_points points; kept points stay in input order. */
+cmx_status cmx_voxel_filter(const float* point_cloud_xyz, int32_t num_points, float resolution,
+                            int32_t device, float* filtered_xyz, int32_t* num_filtered);
+/* sensor::AdaptiveVoxelFilter (voxel_filter.cc:30-75,193-198): range cut, then the search for
+ * the voxel length that keeps at least min_num_points (proto::AdaptiveVoxelFilterOptions). */
+cmx_status cmx_adaptive_voxel_filter(const float* point_cloud_xyz, int32_t num_points,
+                                     float max_length, float min_num_points, float max_range,
+                                     int32_t device, float* filtered_xyz, int32_t* num_filtered);
+/* RotationalScanMatcher::ComputeHistogram (SM3/rotational_scan_matcher.cc:164-177): slices of
+ * 0.2 m, points sorted by angle around the slice centroid, one weighted vote per point pair.
+ * Same accumulation order as the reference; atan2f is the device's (<= 1 ulp from libm's). */
+cmx_status cmx_compute_histogram(const float* point_cloud_xyz, int32_t num_points,
+                                 int32_t histogram_size, int32_t device, float* histogram);
+
 /* ---- multi-GPU: one scan against submaps spread over the GPUs of a node ---------------- */
 /* The (node, submap) searches of a ConstraintBuilder fan-out are independent
  * (constraints/constraint_builder_2d.cc:97-111, constraint_builder_3d.cc:79-142): submaps are

@@ -281,3 +281,63 @@ def test_sharded_match_equals_the_batch(sm, synth, c2):
     assert f[0] == 1 and f[4] == 1 and s[0] == s[4]
     masked = np.where(f != 0, s, -1.0)
     assert best[0] == int(np.argmax(masked)) and np.float32(best[1]) == masked.max()
+
+
+# ----------------------------------------------------------------------------
+# Voxel filters and rotational histogram on the device
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("seed,n,res", [(0, 2000, 0.3), (1, 20000, 0.05), (2, 500, 1.0),
+                                        (3, 5000, 0.011), (4, 1, 0.1), (5, 300000, 0.2)])
+def test_voxel_filter_keeps_the_reference_points(oracle, seed, n, res):
+    """The randomised reservoir filter, bit for bit: same kept points in the same order."""
+    from cartographer_amd import filters
+    rng = np.random.default_rng(seed)
+    cloud = rng.normal(0.0, 3.0, (n, 3)).astype(np.float32)
+    k = len(cloud[1::7])
+    cloud[::7][:k] = cloud[1::7]
+    used = oracle.voxel_filter_flags(cloud, res)
+    got = filters.voxel_filter(cloud, res)
+    np.testing.assert_array_equal(got, cloud[used])
+
+
+def test_voxel_filter_reference_tests_on_device():
+    from cartographer_amd import filters
+    cloud = np.array([[0, 0, 0], [0.1, -0.1, 0.1], [0.3, -0.1, 0], [0, 0, 0.1]], np.float32)
+    got = filters.voxel_filter(cloud, 0.3)
+    assert len(got) == 2 and any((g == cloud[2]).all() for g in got)
+    big = np.array([[100000., 0, 0], [100000.001, -0.0001, 0.0001], [100000.003, -0.0001, 0],
+                    [-200000., 0, 0]], np.float32)
+    got = filters.voxel_filter(big, 0.01)
+    assert len(got) == 2 and any((g == big[3]).all() for g in got)
+    assert len(filters.voxel_filter(np.zeros((0, 3), np.float32), 0.1)) == 0
+
+
+@pytest.mark.parametrize("seed,n,max_length,min_points,max_range", [
+    (0, 20000, 0.5, 200, 50.0), (1, 60000, 2.0, 150, 15.0), (2, 60000, 4.0, 200, 60.0),
+    (3, 100, 0.5, 200, 50.0), (4, 3000, 0.9, 2900, 80.0)])
+def test_adaptive_voxel_filter_equals_the_oracle(oracle, seed, n, max_length, min_points,
+                                                 max_range):
+    from cartographer_amd import filters
+    rng = np.random.default_rng(seed)
+    cloud = (rng.normal(0.0, 8.0, (n, 3)) * np.array([1.0, 1.0, 0.2])).astype(np.float32)
+    ref = oracle.adaptive_voxel_filter(cloud, max_length, min_points, max_range)
+    got = filters.adaptive_voxel_filter(cloud, max_length, min_points, max_range)
+    np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_compute_histogram_equals_the_oracle(oracle, synth, seed):
+    """Same slices, order and accumulation as the reference; the only difference is the
+    device's atan2f (<= 1 ulp from libm's), which can move a pair across a bucket edge or swap
+    two nearly equal angles: compared with a tolerance."""
+    from cartographer_amd import filters
+    grid, world = synth.make_submap_3d(20 + seed, 0.1, (8.0, 6.0, 3.0), 4, 10, 64)
+    pos = world.free_position(seed, 0.5)
+    cloud = world.scan(pos, 0.2 * seed, 16, 360, seed=seed)
+    ref = oracle.compute_histogram(cloud, 120)
+    got = filters.compute_histogram(cloud, 120)
+    assert got.shape == ref.shape
+    # a vote that changes bucket moves at most 1 (its weight) between neighbours
+    assert np.abs(got - ref).max() <= 1.0 + 1e-4 * ref.max()
+    assert np.abs(got.sum() - ref.sum()) <= 1e-3 * max(1.0, ref.sum())
+    assert (np.abs(got - ref) > 1e-3).sum() <= 4
