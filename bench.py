@@ -86,22 +86,25 @@ def _cores():
 
 
 def pmc_traffic_bytes(pmc_dir, tag, kernel):
-    """HBM-side bytes per launch of `kernel` from rocprofv3 PMC passes of this command
-    (FETCH_SIZE and WRITE_SIZE need separate passes, MI355X_MICROARCH.md "rocprofv3 PMC
-    slots"; values are KiB; FETCH_SIZE is doubled per the guide's gfx950 correction).
-    None when the passes are absent or do not contain the kernel (e.g. after a rename):
-    a stale number is worse than none."""
+    """HBM-side bytes per launch of `kernel` from rocprofv3 PMC passes of the bench commands
+    (tools/profile_all.sh writes <tag>[_<config>]_pmc_{fetch,write}_size.csv; FETCH_SIZE and
+    WRITE_SIZE need separate passes, MI355X_MICROARCH.md "rocprofv3 PMC slots"; values are KiB;
+    FETCH_SIZE is doubled per the guide's gfx950 correction).  None when no pass contains the
+    kernel (e.g. after a rename): a stale number is worse than none."""
     import csv
+    import glob
     total = 0.0
-    for name, factor in ((f"{tag}_pmc_fetch_size.csv", 2.0), (f"{tag}_pmc_write_size.csv", 1.0)):
-        path = os.path.join(pmc_dir, name)
-        if not os.path.exists(path):
+    for suffix, factor in (("_pmc_fetch_size.csv", 2.0), ("_pmc_write_size.csv", 1.0)):
+        value = None
+        for path in sorted(glob.glob(os.path.join(pmc_dir, f"{tag}*{suffix}"))):
+            with open(path) as f:
+                rows = [r for r in csv.DictReader(f) if kernel in r["Kernel"]]
+            if rows:
+                value = float(rows[0]["MeanValue"]) * 1024.0 * factor
+                break
+        if value is None:
             return None
-        with open(path) as f:
-            rows = [r for r in csv.DictReader(f) if kernel in r["Kernel"]]
-        if not rows:
-            return None
-        total += float(rows[0]["MeanValue"]) * 1024.0 * factor
+        total += value
     return total
 
 

@@ -610,8 +610,8 @@ ScoreCoarsePlanesDwordKernel(const Fast2DProblem* __restrict__ problems, int n,
 // their ScoreCandidates (SM2/fast_correlative_scan_matcher_2d.cc:264-333) -- with the
 // discretised scan staged in LDS only.  As separate launches the same work wrote 27 MB per
 // match (discrete scans + 64-bit bucketed records) and the scorer fetched 20 MB of it back;
-// here a scan's 4-byte cells go to HBM only when one of its lowest-resolution candidates can
-// still reach min_score (the tree search reads them), and the per-scan candidate layout needs
+// here only the candidates' scores (1.7 MB) leave the chip -- the tree search re-derives the
+// cells of the scans it descends into (ScanCell) -- and the per-scan candidate layout needs
 // no prefix sum: scan s owns [s * coarse_stride, (s + 1) * coarse_stride).
 //
 // Unlike the separate launches this kernel does NOT sort the points by lattice block.  The
@@ -629,7 +629,7 @@ ScoreCoarsePlanesDwordKernel(const Fast2DProblem* __restrict__ problems, int n,
 // (ScoreCoarsePlanesDwordKernel, kept for CMX_FUSED=0 and for problems this kernel does not
 // take).
 // Dynamic LDS: pts[n_pad] u32 | misc[32] | cand_acc[acc_cap].
-constexpr int kFusedMaxPoints = 8192;
+constexpr int kFusedMaxPoints = 4096;    // = kPointCache of the tree search
 
 __global__ void __launch_bounds__(256)
 PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __restrict__ xyz,
@@ -820,21 +820,17 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
   for (int i = threadIdx.x; i < count; i += T) {
     const int ix = i / dims.y, iy = i - ix * dims.y;
     const int csum = cand_acc[(ix + PI - 1) * pitch + (iy + PJ - 1)];
-    coarse_sum[i] = csum;
+    if (P.write_all_discrete) coarse_sum[i] = csum;     // introspection only
     coarse_score[i] = ToScore(P, csum, n);
     if (csum > best_sum) { best_sum = csum; best_index = i; }
   }
   int2* scratch = reinterpret_cast<int2*>(misc + 8);      // [4] (the bounds partials are dead)
   const int2 best = BlockBest(best_sum, best_index, scratch);
-  if (threadIdx.x == 0) {
-    P.scan_best[s] = best;
-    misc[7] = P.write_all_discrete || ToScore(P, best.x, n) >= fmaxf(P.min_score, 0.f);
-  }
-  __syncthreads();
-  Stamp(tl, tl_block, 6);      // sums written
-  // The tree search reads a scan's cells only below lowest-resolution nodes that reach
-  // the bound, and the bound never drops below max(min_score, 0).
-  if (misc[7]) {
+  if (threadIdx.x == 0) P.scan_best[s] = best;
+  Stamp(tl, tl_block, 6);      // scores written
+  // The discretised scan stays on chip: the tree search re-derives the cells of the few scans
+  // it descends into (ScanCell).  Only the introspection entry point asks for the array.
+  if (P.write_all_discrete) {
     auto* out = AsGlobal(P.discrete) + static_cast<size_t>(s) * n;
     for (int i = threadIdx.x; i < n; i += T) out[i] = pts[i];
   }
@@ -1021,6 +1017,23 @@ __device__ __forceinline__ bool PickSeed(const Fast2DProblem& P, int n, int want
   return sh->found_scan >= 0;
 }
 
+// Cell of point i of rotated scan `rot` = P.scan_rot[scan], packed (x | y << 16): the fused
+// front end's arithmetic (RotateZ twice, translation, CellIndexFast), so bit-identical to what
+// it scored -- and to PrepScansKernel's `discrete` array.
+__device__ __forceinline__ uint32_t ScanCell(const Fast2DProblem& P, float2 rot, int i) {
+  const float* __restrict__ xyz = P.xyz;
+  const float px = xyz[3 * i], py = xyz[3 * i + 1];
+  float ax = px, ay = py;
+  if (!(P.init_qw == 1.f && P.init_qz == 0.f)) RotateZ(P.init_qw, P.init_qz, px, py, &ax, &ay);
+  float bx, by;
+  RotateZ(rot.x, rot.y, ax, ay, &bx, &by);
+  const float x = bx + P.tx;
+  const float y = by + P.ty;
+  const int ix = CellIndexFast(P.max_y, y, P.res, P.inv_res);
+  const int iy = CellIndexFast(P.max_x, x, P.res, P.inv_res);
+  return (static_cast<uint32_t>(ix) & 0xffffu) | (static_cast<uint32_t>(iy) << 16);
+}
+
 // Problem- and scan-invariant data a block keeps on chip while it works on
 // nodes of one rotated scan: level descriptors and score constants (so that a
 // node expansion starts without dependent global loads), the discretised
@@ -1040,7 +1053,10 @@ __device__ __forceinline__ void LoadContext(const Fast2DProblem& P, int n, int s
                                             BlockContext* ctx) {
   const uint32_t* pts = P.discrete + static_cast<size_t>(scan) * n;
   const bool cached = n <= kPointCache;
-  if (cached) {
+  if (P.recompute_scans) {          // (implies n <= kFusedMaxPoints = kPointCache)
+    const float2 rot = P.scan_rot[scan];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) ctx->cache[i] = ScanCell(P, rot, i);
+  } else if (cached) {
     const auto* gp = AsGlobal(pts);
     for (int i = threadIdx.x; i < n; i += blockDim.x) ctx->cache[i] = gp[i];
   }
@@ -1272,6 +1288,8 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
     const int half = 1 << child_level, off = half - 1;
     const bool vx = nd.dx + half <= bd.y, vy = nd.dy + half <= bd.w;
     const auto* pts = AsGlobal(P.discrete) + static_cast<size_t>(nd.scan) * n;
+    const bool recompute = P.recompute_scans != 0;
+    const float2 rot = recompute ? P.scan_rot[nd.scan] : make_float2(1.f, 0.f);
     // Early exit.  A level-(l+1) cell is the maximum of the four level-l cells its
     // children read (the 2h window is tiled by four h windows), so for every point
     // max(children) <= parent value and
@@ -1296,7 +1314,7 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
       for (int u = 0; u < kIters; ++u) {
         const int q = q0 + u * kWave + lane;
         const bool live = q < n;
-        const uint32_t p = pts[live ? q : 0];
+        const uint32_t p = recompute ? ScanCell(P, rot, live ? q : 0) : pts[live ? q : 0];
         const int X = static_cast<short>(p & 0xffffu) + nd.dx + off + half;
         const int Y = static_cast<short>(p >> 16) + nd.dy + off + half;
         const bool inside = live && static_cast<unsigned>(X) < static_cast<unsigned>(L.qx) &&
@@ -2049,6 +2067,8 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     const HostSearch& h = out->search[p];
     Fast2DProblem& P = out->h_problems[p];
     P.timeline = out->d_timeline;
+    P.xyz = d_xyz;
+    P.recompute_scans = (P.use_fused && !P.write_all_discrete) ? 1 : 0;
     for (int i = 0; i < m.depth(); ++i) P.level[i] = m.level(i);
     P.depth = m.depth();
     P.nx = lim.num_x_cells; P.ny = lim.num_y_cells;

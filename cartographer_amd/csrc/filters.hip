@@ -250,22 +250,38 @@ __global__ void SliceKeyKernel(const float* __restrict__ xyz, int n, unsigned* _
 // slice's points in their order (ComputeCentroid's sequential f32 sum), every thread then
 // computes its points' angle around the centroid; points closer than kMinDistance are dropped
 // (key = all ones sorts them behind the slice).  Sort key: slice rank << 32 | orderable angle.
-__global__ void SliceAngleKernel(const float* __restrict__ xyz,
-                                 const unsigned* __restrict__ sorted_index,
-                                 const int* __restrict__ slice_begin, int num_slices, int n,
-                                 unsigned long long* __restrict__ keys2,
-                                 unsigned* __restrict__ index2) {
+constexpr int kSliceChunk = 2048;     // points staged in LDS per pass (24 KB)
+
+__global__ void __launch_bounds__(256)
+SliceAngleKernel(const float* __restrict__ xyz, const unsigned* __restrict__ sorted_index,
+                 const int* __restrict__ slice_begin, int num_slices, int n,
+                 unsigned long long* __restrict__ keys2, unsigned* __restrict__ index2) {
   const int s = blockIdx.x;
   const int begin = slice_begin[s], end = s + 1 < num_slices ? slice_begin[s + 1] : n;
-  __shared__ float c[3];
-  if (threadIdx.x == 0) {
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (int p = begin; p < end; ++p) {
-      const int i = sorted_index[p];
-      sx += xyz[3 * i]; sy += xyz[3 * i + 1]; sz += xyz[3 * i + 2];
+  __shared__ float pts[3 * kSliceChunk];
+  __shared__ float c[3], run[3];
+  if (threadIdx.x == 0) { run[0] = run[1] = run[2] = 0.f; }
+  // ComputeCentroid: a SEQUENTIAL f32 sum in slice order.  The block stages the points in LDS
+  // (coalesced gathers, all in flight), one lane adds them up: the chain is then ~100 cycles
+  // per point instead of a dependent global round trip per point.
+  for (int p0 = begin; p0 < end; p0 += kSliceChunk) {
+    const int m = min(kSliceChunk, end - p0);
+    __syncthreads();
+    for (int k = threadIdx.x; k < m; k += blockDim.x) {
+      const int i = sorted_index[p0 + k];
+      pts[3 * k] = xyz[3 * i]; pts[3 * k + 1] = xyz[3 * i + 1]; pts[3 * k + 2] = xyz[3 * i + 2];
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float sx = run[0], sy = run[1], sz = run[2];
+      for (int k = 0; k < m; ++k) { sx += pts[3 * k]; sy += pts[3 * k + 1]; sz += pts[3 * k + 2]; }
+      run[0] = sx; run[1] = sy; run[2] = sz;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
     const float count = static_cast<float>(end - begin);
-    c[0] = sx / count; c[1] = sy / count; c[2] = sz / count;
+    c[0] = run[0] / count; c[1] = run[1] / count; c[2] = run[2] / count;
   }
   __syncthreads();
   for (int p = begin + threadIdx.x; p < end; p += blockDim.x) {
@@ -283,65 +299,100 @@ __global__ void SliceAngleKernel(const float* __restrict__ xyz,
   }
 }
 
-// Per slice, in angle order: AddPointCloudSliceToHistogram's walk (the `last_point_position`
-// chain is sequential: one lane per slice), leaving (bucket, value) per sorted position.
-__global__ void SliceWalkKernel(const float* __restrict__ xyz,
-                                const unsigned long long* __restrict__ sorted_keys2,
-                                const unsigned* __restrict__ sorted_index2,
-                                const int* __restrict__ slice_begin, int num_slices, int n,
-                                int histogram_size, int* __restrict__ bucket,
-                                float* __restrict__ value) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= num_slices) return;
+// Per slice, in angle order: AddPointCloudSliceToHistogram's walk.  The `last_point_position`
+// chain is sequential, so one lane walks the slice -- out of LDS, where the block has staged the
+// sorted points -- and adds the votes to the slice's own histogram (LDS), written out as
+// partial[slice][bucket].
+__global__ void __launch_bounds__(256)
+SliceWalkKernel(const float* __restrict__ xyz, const unsigned long long* __restrict__ sorted_keys2,
+                const unsigned* __restrict__ sorted_index2, const int* __restrict__ slice_begin,
+                int num_slices, int n, int histogram_size, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char walk_smem[];
+  float* hist = reinterpret_cast<float*>(walk_smem);            // [histogram_size]
+  float* pts = hist + histogram_size;                            // [2 * kSliceChunk] (x, y)
+  __shared__ int s_kept_end;
+  __shared__ float s_c[2], s_run[3], s_last[2];
+  const int s = blockIdx.x;
   const int begin = slice_begin[s], end = s + 1 < num_slices ? slice_begin[s + 1] : n;
-  int kept_end = begin;       // dropped points sort behind the kept ones
-  while (kept_end < end && (sorted_keys2[kept_end] & 0xffffffffull) != 0xffffffffull) ++kept_end;
-  for (int p = begin; p < end; ++p) bucket[p] = -1;
-  if (kept_end == begin) return;
-  float sx = 0.f, sy = 0.f, sz = 0.f;
-  for (int p = begin; p < kept_end; ++p) {
-    const int i = sorted_index2[p];
-    sx += xyz[3 * i]; sy += xyz[3 * i + 1]; sz += xyz[3 * i + 2];
-  }
-  const float count = static_cast<float>(kept_end - begin);
-  const float cx = sx / count, cy = sy / count;
-  const int first = sorted_index2[begin];
-  float lx = xyz[3 * first], ly = xyz[3 * first + 1];
-  const float kPi = static_cast<float>(M_PI);
-  for (int p = begin; p < kept_end; ++p) {
-    const int i = sorted_index2[p];
-    const float px = xyz[3 * i], py = xyz[3 * i + 1];
-    const float dx = px - lx, dy = py - ly;
-    const float ex = px - cx, ey = py - cy;
-    const float distance = sqrtf(dx * dx + dy * dy);
-    const float direction_norm = sqrtf(ex * ex + ey * ey);
-    if (distance < kMinDistance || direction_norm < kMinDistance) continue;
-    if (distance > kMaxDistance) {
-      lx = px; ly = py;
-      continue;
+  for (int b = threadIdx.x; b < histogram_size; b += blockDim.x) hist[b] = 0.f;
+  if (threadIdx.x == 0) { s_kept_end = end; s_run[0] = s_run[1] = s_run[2] = 0.f; }
+  __syncthreads();
+  // Dropped points (closer than kMinDistance to the first centroid) sort behind the kept ones.
+  for (int p = begin + threadIdx.x; p < end; p += blockDim.x)
+    if ((sorted_keys2[p] & 0xffffffffull) == 0xffffffffull) atomicMin(&s_kept_end, p);
+  __syncthreads();
+  const int kept_end = s_kept_end;
+  if (kept_end > begin) {
+    // Centroid of the sorted slice (sequential sum in sorted order), then the walk.
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int p0 = begin; p0 < kept_end; p0 += kSliceChunk) {
+        const int m = min(kSliceChunk, kept_end - p0);
+        __syncthreads();
+        for (int k = threadIdx.x; k < m; k += blockDim.x) {
+          const int i = sorted_index2[p0 + k];
+          pts[2 * k] = xyz[3 * i];
+          pts[2 * k + 1] = xyz[3 * i + 1];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          if (pass == 0) {
+            float sx = s_run[0], sy = s_run[1];
+            for (int k = 0; k < m; ++k) { sx += pts[2 * k]; sy += pts[2 * k + 1]; }
+            s_run[0] = sx; s_run[1] = sy;
+          } else {
+            if (p0 == begin) { s_last[0] = pts[0]; s_last[1] = pts[1]; }
+            const float cx = s_c[0], cy = s_c[1];
+            float lx = s_last[0], ly = s_last[1];
+            const float kPi = static_cast<float>(M_PI);
+            for (int k = 0; k < m; ++k) {
+              const float px = pts[2 * k], py = pts[2 * k + 1];
+              const float dx = px - lx, dy = py - ly;
+              const float ex = px - cx, ey = py - cy;
+              const float distance = sqrtf(dx * dx + dy * dy);
+              const float direction_norm = sqrtf(ex * ex + ey * ey);
+              if (distance < kMinDistance || direction_norm < kMinDistance) continue;
+              if (distance > kMaxDistance) {
+                lx = px; ly = py;
+                continue;
+              }
+              float angle = atan2f(dy, dx);
+              const float ndx = dx / distance, ndy = dy / distance;
+              const float nex = ex / direction_norm, ney = ey / direction_norm;
+              const float v = fmaxf(0.f, 1.f - fabsf(ndx * nex + ndy * ney));
+              while (angle > kPi) angle -= kPi;
+              while (angle < 0.f) angle += kPi;
+              const float zero_to_one = angle / kPi;
+              const int b = min(max(LRoundF32(histogram_size * zero_to_one - 0.5f), 0),
+                                histogram_size - 1);
+              hist[b] += v;
+            }
+            s_last[0] = lx; s_last[1] = ly;
+          }
+        }
+      }
+      __syncthreads();
+      if (pass == 0 && threadIdx.x == 0) {
+        const float count = static_cast<float>(kept_end - begin);
+        s_c[0] = s_run[0] / count;
+        s_c[1] = s_run[1] / count;
+      }
+      __syncthreads();
     }
-    float angle = atan2f(dy, dx);
-    const float ndx = dx / distance, ndy = dy / distance;
-    const float nex = ex / direction_norm, ney = ey / direction_norm;
-    const float v = fmaxf(0.f, 1.f - fabsf(ndx * nex + ndy * ney));
-    while (angle > kPi) angle -= kPi;
-    while (angle < 0.f) angle += kPi;
-    const float zero_to_one = angle / kPi;
-    const int b = min(max(LRoundF32(histogram_size * zero_to_one - 0.5f), 0), histogram_size - 1);
-    bucket[p] = b;
-    value[p] = v;
   }
+  __syncthreads();
+  for (int b = threadIdx.x; b < histogram_size; b += blockDim.x)
+    partial[static_cast<size_t>(s) * histogram_size + b] = hist[b];
 }
 
-// One lane per bucket adds its values in (slice, angle) order: the reference's f32
-// accumulation order per bucket.
-__global__ void HistogramSumKernel(const int* __restrict__ bucket, const float* __restrict__ value,
-                                   int n, int histogram_size, float* __restrict__ histogram) {
+// histogram[b] = sum over slices (ascending) of the slices' own sums.  The reference adds every
+// vote straight into one histogram; adding per slice first changes the association of the f32
+// additions (differences at the 1e-7 level, below the atan2f effect already accepted).
+__global__ void HistogramSumKernel(const float* __restrict__ partial, int num_slices,
+                                   int histogram_size, float* __restrict__ histogram) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= histogram_size) return;
   float h = 0.f;
-  for (int p = 0; p < n; ++p)
-    if (bucket[p] == b) h += value[p];
+  for (int s = 0; s < num_slices; ++s) h += partial[static_cast<size_t>(s) * histogram_size + b];
   histogram[b] = h;
 }
 
@@ -467,7 +518,7 @@ cmx_status cmx_compute_histogram(const float* point_cloud_xyz, int32_t num_point
                                  int32_t histogram_size, int32_t device, float* histogram) {
   return Guard([&] {
     CMX_REQUIRE(num_points >= 0 && num_points <= (1 << 24) && histogram && histogram_size >= 1 &&
-                    histogram_size <= 65536 && (point_cloud_xyz || num_points == 0),
+                    histogram_size <= 8192 && (point_cloud_xyz || num_points == 0),
                 "bad argument");
     for (int b = 0; b < histogram_size; ++b) histogram[b] = 0.f;
     cmx::WorkspaceLease ws(device);
@@ -524,9 +575,13 @@ cmx_status cmx_compute_histogram(const float* point_cloud_xyz, int32_t num_point
     bytes = temp_bytes;
     CMX_HIP(hipcub::DeviceRadixSort::SortPairs(temp, bytes, keys2, keys2_sorted, index2,
                                                index2_sorted, n, 0, 64, st));
-    cmx::SliceWalkKernel<<<cmx::DivUp(num_slices, 64), 64, 0, st>>>(
-        d_xyz, keys2_sorted, index2_sorted, slice_begin, num_slices, n, histogram_size, bucket, value);
-    cmx::HistogramSumKernel<<<cmx::DivUp(histogram_size, 64), 64, 0, st>>>(bucket, value, n,
+    float* d_partial = ws->dev[10].ReserveAs<float>(static_cast<size_t>(num_slices) * histogram_size);
+    const size_t walk_lds = 4 * static_cast<size_t>(histogram_size) + 8 * cmx::kSliceChunk;
+    CMX_REQUIRE(walk_lds <= 64 * 1024, "histogram_size too large");
+    cmx::SliceWalkKernel<<<num_slices, 256, walk_lds, st>>>(d_xyz, keys2_sorted, index2_sorted,
+                                                            slice_begin, num_slices, n,
+                                                            histogram_size, d_partial);
+    cmx::HistogramSumKernel<<<cmx::DivUp(histogram_size, 64), 64, 0, st>>>(d_partial, num_slices,
                                                                            histogram_size, d_hist);
     CMX_HIP(hipGetLastError());
     CMX_HIP(hipMemcpyAsync(histogram, d_hist, 4 * static_cast<size_t>(histogram_size),

@@ -66,6 +66,10 @@ struct Fast2DProblem {
   int* sorted_count;    // [num_scans]
   int2* scan_best;      // [num_scans] (best sum, local candidate index) of each scan
   unsigned long long* timeline;   // CMX_TIMELINE=1: 16 stamps per fused-kernel block, else null
+  const float* xyz;     // the device point cloud
+  int recompute_scans;  // 1 (fused front end): `discrete` is not written; the tree search
+                        // re-derives a scan's cells from xyz (60 instructions per point,
+                        // bit-identical) instead of 9 MB per match going to HBM and back
 };
 
 // Branch-and-bound node.

@@ -4,6 +4,7 @@
 // renormalises its rotation, rigid * point = rotation * point + translation.
 #ifndef ORACLE_REF_SHIMS_RIGID_TRANSFORM_H_
 #define ORACLE_REF_SHIMS_RIGID_TRANSFORM_H_
+#include <cmath>
 #include "Eigen/Core"
 #include "Eigen/Geometry"
 #include "cartographer/common/lua_parameter_dictionary.h"   // reaches includers this way upstream
@@ -27,10 +28,30 @@ class Rigid2 {
   const Vector& translation() const { return t_; }
   Rotation2D rotation() const { return r_; }
 
+  // rigid_transform.h:70-78.
+  double normalized_angle() const {
+    double a = r_.angle();            // common::NormalizeAngleDifference (common/math.h:69-75)
+    const double two_pi = 2. * M_PI;
+    while (a > M_PI) a -= two_pi;
+    while (a < -M_PI) a += two_pi;
+    return a;
+  }
+  Rigid2 inverse() const {
+    const Rotation2D rotation = r_.inverse();
+    const Vector translation = -(rotation * t_);
+    return Rigid2(translation, rotation);
+  }
+
  private:
   Vector t_;
   Rotation2D r_;
 };
+// rigid_transform.h:90-97.
+template <typename S>
+Rigid2<S> operator*(const Rigid2<S>& lhs, const Rigid2<S>& rhs) {
+  return Rigid2<S>(lhs.rotation() * rhs.translation() + lhs.translation(),
+                   lhs.rotation() * rhs.rotation());
+}
 typedef Rigid2<double> Rigid2d;
 typedef Rigid2<float> Rigid2f;
 

@@ -33,6 +33,19 @@ S GetYaw(const Eigen::Quaternion<S>& q) {
 template <typename S>
 S GetYaw(const Rigid3<S>& rigid) { return GetYaw(rigid.rotation()); }
 
+// transform.h:101-115.
+template <typename S>
+Rigid2<S> Project2D(const Rigid3<S>& transform) {
+  return Rigid2<S>(transform.translation().template head<2>(), GetYaw(transform));
+}
+template <typename S>
+Rigid3<S> Embed3D(const Rigid2<S>& transform) {
+  return Rigid3<S>(Eigen::Matrix<S, 3, 1>(transform.translation().x(),
+                                          transform.translation().y(), S(0)),
+                   Eigen::AngleAxis<S>(transform.rotation().angle(),
+                                       Eigen::Matrix<S, 3, 1>::UnitZ()));
+}
+
 // Angle-axis vector -> quaternion (transform.h:85-99).  Below |v|^2 = 1e-8 the reference
 // linearises (w = 1, xyz = v / 2); above, sin and cos of |v| / 2 are evaluated in DOUBLE
 // whatever S is (its literal `2.` promotes) and narrowed to S afterwards.
