@@ -88,7 +88,11 @@ def test_reference_constraint_builder_on_the_gpu(oracle, synth, tmp_path):
     for g, w in zip(got, want):
         assert g[0] == w[0] and g[4] == 1          # INTER_SUBMAP
         np.testing.assert_allclose(g[1:4], w[1:4], rtol=0, atol=1e-6)
-        # and the loop closure is right: node pose in the submap frame = truth - origin
+        # and the loop closure is right: node pose in the submap frame = truth - origin (the
+        # two copies of the scan's own world; submap 1 is another world, whatever matches there
+        # is a false positive the reference would report just the same)
+        if g[0] == 1:
+            continue
         origin = submaps[g[0]][2]
         assert abs(g[1] - (truth[0] - origin[0])) < 0.05
         assert abs(g[2] - (truth[1] - origin[1])) < 0.05
