@@ -388,21 +388,45 @@ class Rt3DWorkload:
     def describe(self, stats, found):
         return {"workload": f"C4: 3D RealTimeCorrelativeScanMatcher, {self.n_points}-point cloud vs "
                             f"150^3 HybridGrid ({len(self.vox)} voxels), window 0.5 m / 2 deg",
-                "lookups_per_step": stats["candidates_scored"] * self.n_points}
+                "search_space_lookups_per_step": stats["candidates_scored"] * self.n_points,
+                "bounds_evaluated_per_step": stats["coarse_candidates"],
+                "finalists_rescored_exactly": stats["nodes_expanded"],
+                "note": "candidates = the reference's exhaustive search space (every one of them is "
+                        "either scored or excluded by an upper bound of its 2x2x2 block of "
+                        "translations); bounds_evaluated = group bounds + candidates scored one by one"}
 
     def roofline(self, acc, steps, pmc):
+        """Group pass (the dominant kernel): one byte gather per (rotation, block of translations,
+        point).  The bound is the rate at which a CU issues wave-wide byte gathers: measured
+        ceiling 19 cycles per buffer_load_ubyte of 64 lanes whatever they touch
+        (profiles/r02_rt3d_gather_ceiling.txt: the same kernel with trivially computed addresses,
+        1.16e11 lookups in 56.5 ms) = 2.05e12 lookups/s per chip."""
         k_ms = acc["dominant_kernel_ms"] / steps
         cand = acc["candidates_scored"] / steps
         scans = acc["num_scans"] / steps
         secs = max(k_ms, 1e-9) * 1e-3
+        side = round((cand / max(scans, 1)) ** (1.0 / 3.0))
+        groups = ((side + 1) // 2) ** 3
+        bulk = acc["coarse_candidates"] / steps != cand       # the bounds path ran
+        lookups = scans * (groups if bulk else cand / max(scans, 1)) * self.n_points
         alg = cand * self.n_points * 2.0 + scans * self.n_points * 12.0      # SURVEY 8d
-        return {"kernel": "Rt3DScoreKernel", "bound": "hbm", "achieved": alg / secs / 1e9,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / secs / 1e9 / HBM_PEAK_GBS,
-                "traffic": pmc("Rt3DScore"), "kernel_ms": k_ms, "algorithmic_bytes": alg,
-                "lookups_per_s": cand * self.n_points / secs,
-                "note": "algorithmic bytes (2 B per candidate-point + 12 B per rotation-point) / "
-                        "kernel time / 8 TB/s; the 13.5 MB brick is L2/MALL-resident, the kernel "
-                        "is VALU-bound (instructions per lookup), not HBM-bound"}
+        peak = 2050.0                                                         # G lookups/s
+        return {"kernel": "Rt3DBulkKernel<groups> (upper bounds of 2x2x2 blocks of translations "
+                          "on the dilated uint8 brick)" if bulk else "Rt3DScoreKernel",
+                "bound": "gather-issue", "achieved": lookups / secs / 1e9, "peak": peak,
+                "unit": "Glookup/s", "frac": lookups / secs / 1e9 / peak,
+                "traffic": pmc("Rt3DBulk"), "kernel_ms": k_ms, "algorithmic_bytes": alg,
+                "hbm_frac_algorithmic_whole_step":
+                    alg / (acc["device_ms"] / steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "kernel_share_of_step_device_time": k_ms / (acc["device_ms"] / steps),
+                "lookups_per_s_kernel": lookups / secs,
+                "note": "achieved = byte gathers the kernel performs / kernel time; peak = the "
+                        "measured gather-issue ceiling of the chip (19 cycles per 64-lane "
+                        "buffer_load_ubyte per CU, profiles/r02_rt3d_gather_ceiling.txt).  "
+                        "hbm_frac_algorithmic_whole_step prices the reference's exhaustive "
+                        "search (SURVEY 8d: 2 B per candidate-point + 12 B per rotation-point) "
+                        "at the time of the whole step against 8 TB/s; the bricks (7-15 MB) "
+                        "are L2/MALL-resident"}
 
 
 class Fast3DWorkload:

@@ -185,6 +185,431 @@ __global__ void Rt3DCollectKernel(const float* __restrict__ weighted, long long 
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Integer bounds (groups of translations, then single candidates) + exact finalists
+// ---------------------------------------------------------------------------
+// The reference's score of a candidate is mean_p P(cell(T_c p)) summed in f32 in point order
+// (:97-114), and P is affine in the stored value: P = kMin + u * kScale with
+// u = max(value, 1) - 1 (0 for unknown / outside; real arithmetic -- the f32 table rounds each
+// entry by < 1.2e-7).  Integer sums of u are exact and order-free, so most of the search
+// needs neither the f32 chain nor the IEEE divisions of GetCellIndex, and most candidates
+// need not be scored at all:
+//   * the grid becomes a padded uint8 brick q = u >> 7 with a zero halo as wide as twice the
+//     reach of the translation window; rotated points are clamped (while they are staged) to
+//     one reach outside the stored box, so no lookup needs a bounds test;
+//   * GROUP pass: the (2L+1)^3 translations are tiled by 2 x 2 x 2 blocks of lattice steps.
+//     The members of a block lie within 0.87 cells (per axis) of its centre, so the cell any
+//     member reads is the centre's cell or one of its 26 neighbours: one lookup of the centre
+//     in the 3 x 3 x 3-dilated brick bounds all eight members from above (the branch-and-bound
+//     idea of the fast matcher, one level deep).  1/6 of the lookups, no exactness needed;
+//   * CANDIDATE pass, only for the members of groups whose weighted upper bound reaches the
+//     best weighted lower bound known: the cell index is rint(fma(c, RN(1/res), pad - lo))
+//     with c = rp + tr exactly the reference's f32 coordinate; it equals the reference's
+//     lround(c / res) unless the quotient lies within `1/2 - guard` of a half-integer.  Such
+//     lookups are not repaired but COUNTED (per four points): each moves the sum by at most
+//     255, which widens the candidate's score interval instead of costing a slow path.
+//     Per candidate this yields Q and A with sum(u) in [128 (Q - 1020 A), 128 (Q + 1020 A) +
+//     127 N], i.e. an interval for the f32 score once the rounding of the N-term f32 chain
+//     ((N + 8) 2^-24, relative) is added;
+//   * every candidate whose weighted upper bound reaches the best weighted lower bound is a
+//     finalist; Rt3DExactKernel recomputes those with the reference's own arithmetic, and
+//     the host applies the libm weight and the first-maximum rule to them exactly as before.
+// Returned score and pose are bit-identical to the one-thread-per-candidate kernel above,
+// which remains the path for flat score landscapes (more finalists than the list holds) and
+// for windows / grids beyond the limits checked in cmx_rt3d_match.
+constexpr int kBulk3DThreads = 256;
+constexpr int kBulk3DChunk = 256;          // points staged per round (one per thread)
+constexpr int kAmbiguousQuad = 4 * 255;    // what one flagged group of four lookups can move Q by
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct Rt3DBulkParams {
+  const uint8_t* cells;          // [(nz+2p)][(ny+2p)][(nx+2p)] q = u >> 7 (or its dilation)
+  unsigned cell_count;
+  float pitch_x, pitch_y;        // nx + 2p, ny + 2p as floats (index arithmetic stays < 2^24)
+  int tiles_y, pitch_z;          // candidate brick: columns of 8 x 4 cells, see TiledOffset
+  float off_x, off_y, off_z;     // pad - lo
+  float inv_resolution;
+  float guard;                   // a lookup is unambiguous when max |q - rint(q)| <= guard
+  float t0x, t0y, t0z;           // init.t: rp + init.t is what gets clamped
+  float lo_x, hi_x, lo_y, hi_y, lo_z, hi_z;   // clamp range in metres
+  int num_translations;          // entries of `translation` (T, or the number of groups)
+  int num_rotations, n;
+  const float4* rotation;        // as Rt3DParams
+  const float4* translation;     // xyz + distance entering the weight (group: its smallest)
+  const float* rotation_angle;
+  // Group pass: every translation of rotation blockIdx.y.  Candidate pass: block blockIdx.x
+  // takes work descriptor (r, chunk) = blocks[blockIdx.x]: items[r][256 chunk ..] of the
+  // counts[r] listed translations.
+  const int* counts;
+  const int* items;              // [R][num_translations]
+  const int2* blocks;
+  double wt, wr;
+  double min_probability;        // the f32 constants of the value table, widened
+  double scale_over_n;           // 128 kScale / N
+  double slack_hi;               // 127 kScale + 2e-7 (quantisation + rounding of the table)
+  double delta;                  // relative slack of the f32 chain + exp
+  float* upper;                  // [R][num_translations] weighted upper bound
+  uint2* sums;                   // candidate pass: [R][T] (Q, A) accumulated over point slices
+  int slice_points;              // points per blockIdx.z (a multiple of the chunk)
+  unsigned* max_lower_bits;      // atomicMax of the weighted lower bounds (candidate pass)
+  unsigned* max_upper_bits;      // atomicMax of the weighted upper bounds (group pass)
+};
+
+__device__ __forceinline__ float ClampStage(float rp, float t0, float lo, float hi) {
+  const float b = rp + t0;
+  if (b < lo) return lo - t0;
+  if (b > hi) return hi - t0;
+  return rp;
+}
+
+// The candidate pass reads few, scattered translations per rotation: its brick is stored as
+// columns of 8 (x) by 4 (y) cells running along z, so that a 128-byte line holds an 8 x 4 x 4
+// block of cells -- the eight members of a group of translations (3 x 3 x 3 cells at most)
+// touch one or two lines instead of up to nine rows.
+//   offset = ((x >> 3) * tiles_y + (y >> 2)) * pitch_z * 32 + z * 32 + (y & 3) * 8 + (x & 7)
+// (pitch_z is a multiple of 4, so lines never straddle columns.)
+__host__ __device__ __forceinline__ unsigned TiledOffset(unsigned x, unsigned y, unsigned z,
+                                                         unsigned tiles_y, unsigned pitch_z) {
+  const unsigned column = (x >> 3) * tiles_y + (y >> 2);
+  return ((column * pitch_z + z) << 5) | ((y & 3u) << 3) | (x & 7u);
+}
+
+// Weighted bounds of the f32 score from the integer sum `acc` and `ambiguous` flagged groups
+// of four lookups; rounded outwards: a float strictly below / above the f64 bound.
+__device__ __forceinline__ void Bounds3D(const Rt3DBulkParams& P, unsigned acc,
+                                         unsigned ambiguous, float distance, int r, float* lower,
+                                         float* upper) {
+  const double spread = static_cast<double>(ambiguous) * kAmbiguousQuad;
+  const double q_lo = fmax(static_cast<double>(acc) - spread, 0.);
+  const double q_hi = static_cast<double>(acc) + spread;
+  const double mean_lo = P.min_probability + P.scale_over_n * q_lo - 2e-7;
+  const double mean_hi = P.min_probability + P.scale_over_n * q_hi + P.slack_hi;
+  const double penalty = static_cast<double>(distance) * P.wt +
+                         static_cast<double>(P.rotation_angle[r]) * P.wr;
+  const double w = exp(-(penalty * penalty));
+  *lower = static_cast<float>(mean_lo * w * (1. - P.delta)) * (1.f - 0x1p-22f);
+  *upper = static_cast<float>(mean_hi * w * (1. + P.delta)) * (1.f + 0x1p-22f);
+}
+
+// Group pass: grid (ceil(G / 256), R); candidate pass: grid (work descriptors, 1, point
+// slices).  256 threads: wave w of a block owns work items 256 chunk + 64 w .. + 63 of its
+// rotation.  kGroups: group pass (no ambiguity bookkeeping, upper
+// bounds only, all points in one block).  Candidate pass: the work lists are short, so the
+// points are split over blockIdx.z as well and (Q, A) are accumulated with atomics (integer
+// sums are order-free); Rt3DBoundsKernel turns them into bounds.
+template <bool kGroups>
+__global__ void __launch_bounds__(kBulk3DThreads)
+Rt3DBulkKernel(Rt3DBulkParams P, const float* __restrict__ xyz) {
+  // Points 2p, 2p + 1 as {x0, x1, y0, y1, z0, z1}: what the packed f32 instructions read.
+  __shared__ v2f stage[2][3 * kBulk3DChunk / 2];
+  const int tid = threadIdx.x;
+  const int2 work = kGroups ? make_int2(blockIdx.y, blockIdx.x) : P.blocks[blockIdx.x];
+  const int r = work.x;
+  const int slot = work.y * kBulk3DThreads + tid;
+  const int count = kGroups ? P.num_translations : P.counts[r];
+  if (work.y * kBulk3DThreads >= count) return;                          // whole block idle
+  const bool wave_active = work.y * kBulk3DThreads + (tid & ~63) < count;
+  const bool valid = slot < count;
+  int t = valid ? slot : count - 1;
+  if (!kGroups) t = P.items[static_cast<size_t>(r) * P.num_translations + t];
+  const float4 q4 = P.rotation[r];
+  const Quat q{q4.w, q4.x, q4.y, q4.z};
+  const float4 tr = P.translation[t];
+  const int first = kGroups ? 0 : blockIdx.z * P.slice_points;   // (blockIdx.z: point slice)
+  const int n = kGroups ? P.n : min(P.n, first + P.slice_points);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(P.cells), 0, P.cell_count, 0x00020000);
+
+  const auto stage_chunk = [&](int base, int buf) {
+    const int i = base + tid;
+    // Padding points sit one reach below the box: every translation reads the zero halo.
+    float4 out = make_float4(P.lo_x - P.t0x, P.lo_y - P.t0y, P.lo_z - P.t0z, 0.f);
+    if (i < n) {
+      const F3 rp = Rotate(q, F3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]});
+      out.x = ClampStage(rp.x, P.t0x, P.lo_x, P.hi_x);
+      out.y = ClampStage(rp.y, P.t0y, P.lo_y, P.hi_y);
+      out.z = ClampStage(rp.z, P.t0z, P.lo_z, P.hi_z);
+    }
+    float* dst = reinterpret_cast<float*>(stage[buf]) + 6 * (tid >> 1) + (tid & 1);
+    dst[0] = out.x; dst[2] = out.y; dst[4] = out.z;
+  };
+
+  const v2f trx = {tr.x, tr.x}, try_ = {tr.y, tr.y}, trz = {tr.z, tr.z};
+  const v2f inv = {P.inv_resolution, P.inv_resolution};
+  const v2f ofx = {P.off_x, P.off_x}, ofy = {P.off_y, P.off_y}, ofz = {P.off_z, P.off_z};
+  const v2f px2 = {P.pitch_x, P.pitch_x}, py2 = {P.pitch_y, P.pitch_y};
+  const float guard = P.guard;
+  unsigned acc = 0, ambiguous = 0;
+
+  stage_chunk(first, 0);
+  __syncthreads();
+  int buf = 0;
+  unsigned p0 = 0, p1 = 0, p2 = 0, p3 = 0;     // the previous four lookups, still in flight
+  for (int base = first; base < n; base += kBulk3DChunk, buf ^= 1) {
+    if (base + kBulk3DChunk < n) stage_chunk(base + kBulk3DChunk, buf ^ 1);
+    if (wave_active) {
+      const v2f* __restrict__ s = stage[buf];
+#pragma unroll 2
+      for (int j = 0; j < kBulk3DChunk; j += 4) {
+        unsigned v[4];
+        float g = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k += 2) {
+          const v2f* pr = s + 3 * ((j + k) >> 1);                // LDS broadcast reads
+          const v2f cx = pr[0] + trx;                            // rigid * point, as the reference
+          const v2f cy = pr[1] + try_;
+          const v2f cz = pr[2] + trz;
+          const v2f qx = __builtin_elementwise_fma(cx, inv, ofx);
+          const v2f qy = __builtin_elementwise_fma(cy, inv, ofy);
+          const v2f qz = __builtin_elementwise_fma(cz, inv, ofz);
+          const v2f nx = {rintf(qx.x), rintf(qx.y)};
+          const v2f ny = {rintf(qy.x), rintf(qy.y)};
+          const v2f nz = {rintf(qz.x), rintf(qz.y)};
+          if (!kGroups) {
+            const v2f dx = qx - nx, dy = qy - ny, dz = qz - nz;
+            g = fmaxf(fmaxf(g, fabsf(dx.x)), fabsf(dx.y));
+            g = fmaxf(fmaxf(g, fabsf(dy.x)), fabsf(dy.y));
+            g = fmaxf(fmaxf(g, fabsf(dz.x)), fabsf(dz.y));
+          }
+          if (kGroups) {
+            // (z * pitch_y + y) * pitch_x + x: integers below 2^24, exact in f32.
+            const v2f o =
+                __builtin_elementwise_fma(__builtin_elementwise_fma(nz, py2, ny), px2, nx);
+            v[k] = __builtin_amdgcn_raw_buffer_load_b8(rsrc, static_cast<unsigned>(o.x), 0, 0);
+            v[k + 1] = __builtin_amdgcn_raw_buffer_load_b8(rsrc, static_cast<unsigned>(o.y), 0, 0);
+          } else {
+            const unsigned o0 = TiledOffset(static_cast<unsigned>(nx.x), static_cast<unsigned>(ny.x),
+                                            static_cast<unsigned>(nz.x), P.tiles_y, P.pitch_z);
+            const unsigned o1 = TiledOffset(static_cast<unsigned>(nx.y), static_cast<unsigned>(ny.y),
+                                            static_cast<unsigned>(nz.y), P.tiles_y, P.pitch_z);
+            v[k] = __builtin_amdgcn_raw_buffer_load_b8(rsrc, o0, 0, 0);
+            v[k + 1] = __builtin_amdgcn_raw_buffer_load_b8(rsrc, o1, 0, 0);
+          }
+        }
+        if (!kGroups) ambiguous += g > guard ? 1u : 0u;
+        acc += (p0 + p1) + (p2 + p3);            // consumed one iteration after they were issued
+        p0 = v[0]; p1 = v[1]; p2 = v[2]; p3 = v[3];
+      }
+    }
+    __syncthreads();
+  }
+  acc += (p0 + p1) + (p2 + p3);
+
+  const size_t c = static_cast<size_t>(r) * P.num_translations + t;
+  if (!kGroups) {
+    if (valid) {
+      atomicAdd(&P.sums[c].x, acc);
+      if (ambiguous) atomicAdd(&P.sums[c].y, ambiguous);
+    }
+    return;
+  }
+  float lower = 0.f, upper = 0.f;
+  if (valid) {
+    Bounds3D(P, acc, 0u, tr.w, r, &lower, &upper);
+    P.upper[c] = upper;
+  }
+  // Bounds are positive: bit order == value order.
+  unsigned bits = __float_as_uint(upper);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) bits = max(bits, __shfl_xor(bits, off, 64));
+  if ((tid & 63) == 0 && bits != 0) atomicMax(P.max_upper_bits, bits);
+}
+
+// grid (work descriptors): bounds of the candidates on the work lists from their (Q, A).
+__global__ void __launch_bounds__(kBulk3DThreads)
+Rt3DBoundsKernel(Rt3DBulkParams P) {
+  const int2 work = P.blocks[blockIdx.x];
+  const int r = work.x;
+  const int slot = work.y * kBulk3DThreads + threadIdx.x;
+  const int count = P.counts[r];
+  float lower = 0.f, upper = 0.f;
+  if (slot < count) {
+    const int t = P.items[static_cast<size_t>(r) * P.num_translations + slot];
+    const size_t c = static_cast<size_t>(r) * P.num_translations + t;
+    const uint2 qa = P.sums[c];
+    Bounds3D(P, qa.x, qa.y, P.translation[t].w, r, &lower, &upper);
+    P.upper[c] = upper;
+  }
+  unsigned bits = __float_as_uint(lower);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) bits = max(bits, __shfl_xor(bits, off, 64));
+  if ((threadIdx.x & 63) == 0 && bits != 0) atomicMax(P.max_lower_bits, bits);
+}
+
+// 3 x 3 x 3 dilation of the padded brick in two passes (x, then y and z).  The halo is wider
+// than one cell, so clamped neighbours at the array border read zeros like the cell itself.
+__global__ void DilateXKernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int px,
+                              size_t cells) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= cells) return;
+  const int x = static_cast<int>(i % px);
+  unsigned v = in[i];
+  if (x > 0) v = max(v, static_cast<unsigned>(in[i - 1]));
+  if (x + 1 < px) v = max(v, static_cast<unsigned>(in[i + 1]));
+  out[i] = static_cast<uint8_t>(v);
+}
+__global__ void DilateYZKernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int px,
+                               int py, int pz) {
+  const size_t cells = static_cast<size_t>(px) * py * pz;
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= cells) return;
+  const int x = static_cast<int>(i % px);
+  const int y = static_cast<int>((i / px) % py);
+  const int z = static_cast<int>(i / (static_cast<size_t>(px) * py));
+  unsigned v = 0;
+  for (int dz = -1; dz <= 1; ++dz)
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int yy = min(max(y + dy, 0), py - 1), zz = min(max(z + dz, 0), pz - 1);
+      v = max(v, static_cast<unsigned>(in[(static_cast<size_t>(zz) * py + yy) * px + x]));
+    }
+  out[i] = static_cast<uint8_t>(v);
+}
+
+// Groups whose weighted upper bound reaches the threshold and that have not been expanded yet:
+// their member translations are flagged for the next candidate pass.
+//   threshold = *threshold_bits (as float) * factor.
+__global__ void Rt3DSelectGroupsKernel(const float* __restrict__ group_upper, int num_groups,
+                                       int num_rotations, int side, int groups_per_axis,
+                                       const unsigned* __restrict__ threshold_bits, float factor,
+                                       uint8_t* __restrict__ expanded,
+                                       uint8_t* __restrict__ flags, int num_translations) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= static_cast<long long>(num_groups) * num_rotations) return;
+  const float threshold = __uint_as_float(*threshold_bits) * factor;
+  if (expanded[i] || !(group_upper[i] >= threshold)) return;
+  expanded[i] = 1;
+  const int r = static_cast<int>(i / num_groups), g = static_cast<int>(i % num_groups);
+  const int gx = g % groups_per_axis, gy = (g / groups_per_axis) % groups_per_axis,
+            gz = g / (groups_per_axis * groups_per_axis);
+  const int nx = min(2, side - 2 * gx), ny = min(2, side - 2 * gy), nz = min(2, side - 2 * gz);
+  for (int c = 0; c < nz; ++c)
+    for (int b = 0; b < ny; ++b)
+      for (int a = 0; a < nx; ++a)
+        flags[static_cast<size_t>(r) * num_translations +
+              ((2 * gz + c) * side + (2 * gy + b)) * side + (2 * gx + a)] = 1;
+}
+
+// One block per rotation: the flagged translations in ascending order (x offsets fastest, so
+// neighbouring lanes of the candidate pass read neighbouring cells: a gather instruction costs
+// about 17 cycles plus 1.3 per distinct cache line it touches), flags cleared for the next
+// round; one work descriptor (r, chunk) per 256 of them.
+__global__ void __launch_bounds__(256)
+Rt3DCompactKernel(uint8_t* __restrict__ flags, int num_translations, int* __restrict__ counts,
+                  int* __restrict__ items, int* __restrict__ total, int2* __restrict__ blocks,
+                  int* __restrict__ num_blocks) {
+  __shared__ int wave_count[4];
+  __shared__ int base;
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint8_t* f = flags + static_cast<size_t>(r) * num_translations;
+  int* out = items + static_cast<size_t>(r) * num_translations;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < num_translations; t0 += 256) {
+    const int t = t0 + tid;
+    const bool on = t < num_translations && f[t] != 0;
+    if (on) f[t] = 0;
+    const unsigned long long mask = __ballot(on);
+    if (lane == 0) wave_count[wave] = __popcll(mask);
+    __syncthreads();
+    int offset = base;
+    for (int w = 0; w < wave; ++w) offset += wave_count[w];
+    if (on) out[offset + __popcll(mask & ((1ull << lane) - 1ull))] = t;
+    __syncthreads();
+    if (tid == 0) base += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    counts[r] = base;
+    if (base) {
+      atomicAdd(total, base);
+      const int chunks = (base + 255) / 256;
+      const int first = atomicAdd(num_blocks, chunks);
+      for (int k = 0; k < chunks; ++k) blocks[first + k] = make_int2(r, k);
+    }
+  }
+}
+
+// Candidates whose weighted upper bound reaches the best weighted lower bound; `finalists`
+// holds r * T + t (the bulk layout), unordered.  Candidates never scored have upper == 0.
+__global__ void Rt3DBulkCollectKernel(const float* __restrict__ upper, long long num_candidates,
+                                      const unsigned* __restrict__ max_lower_bits,
+                                      int* __restrict__ count, int* __restrict__ finalists,
+                                      int capacity) {
+  const long long c = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (c >= num_candidates) return;
+  if (upper[c] >= __uint_as_float(*max_lower_bits)) {
+    const int slot = atomicAdd(count, 1);
+    if (slot < capacity) finalists[slot] = static_cast<int>(c);
+  }
+}
+
+// One block per finalist: the reference's own arithmetic (Rotate, + translation, lround of the
+// IEEE quotient, padded f32 probability brick).  The N lookups of a candidate are independent,
+// its f32 sum is a chain: all threads fetch 4096 probabilities into LDS, then one lane runs
+// that part of the chain out of LDS.
+constexpr int kExact3DChunk = 4096;
+__global__ void __launch_bounds__(256)
+Rt3DExactKernel(Rt3DParams P, const float* __restrict__ xyz, int n,
+                const int* __restrict__ finalists, const int* __restrict__ count, int capacity,
+                float* __restrict__ exact) {
+  __shared__ float prob[kExact3DChunk];
+  const int f = blockIdx.x;
+  if (f >= min(*count, capacity)) return;
+  const int c = finalists[f];
+  const int r = c / P.num_translations, t = c - r * P.num_translations;
+  const float4 q4 = P.rotation[r];
+  const Quat q{q4.w, q4.x, q4.y, q4.z};
+  const float4 tr = P.translation[t];
+  const float res = P.resolution;
+  const int sx = P.grid.nx + 2, sy = P.grid.ny + 2;
+  const int ox = 1 - P.grid.lo_x, oy = 1 - P.grid.lo_y, oz = 1 - P.grid.lo_z;
+  const int mx = P.grid.nx + 1, my = P.grid.ny + 1, mz = P.grid.nz + 1;
+  float acc = 0.f;
+  for (int base = 0; base < n; base += kExact3DChunk) {
+    const int cnt = min(kExact3DChunk, n - base);
+    __syncthreads();
+    for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
+      const int i = base + j;
+      const F3 rp = Rotate(q, F3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]});
+      const int3 idx = CellIndex3(F3{rp.x + tr.x, rp.y + tr.y, rp.z + tr.z}, res);
+      const int ix = min(max(idx.x + ox, 0), mx);
+      const int iy = min(max(idx.y + oy, 0), my);
+      const int iz = min(max(idx.z + oz, 0), mz);
+      prob[j] = P.grid.cells[(static_cast<size_t>(iz) * sy + iy) * sx + ix];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int j = 0; j < cnt; ++j) acc += prob[j];
+    }
+  }
+  if (threadIdx.x == 0) exact[f] = acc / static_cast<float>(n);
+}
+
+// uint16 voxel value -> q = (max(value & 32767, 1) - 1) >> 7 in the padded bricks: row-major
+// (to be dilated for the group pass) and tiled (candidate pass).
+__global__ void ScatterBulkKernel(const cmx_voxel* __restrict__ voxels, long long n, int lo_x,
+                                  int lo_y, int lo_z, int pad, int px, int py, int tiles_y,
+                                  int pitch_z, uint8_t* __restrict__ rows,
+                                  uint8_t* __restrict__ tiled) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const cmx_voxel v = voxels[i];
+  const unsigned x = v.x - lo_x + pad, y = v.y - lo_y + pad, z = v.z - lo_z + pad;
+  const unsigned value = v.value & 32767u;
+  const uint8_t q = static_cast<uint8_t>((max(value, 1u) - 1u) >> 7);
+  rows[(static_cast<size_t>(z) * py + y) * px + x] = q;
+  tiled[TiledOffset(x, y, z, tiles_y, pitch_z)] = q;
+}
+
+// CMX_RT3D_BULK=0 keeps every candidate on the one-thread-per-candidate kernel (parity tests
+// run both paths).
+bool Bulk3DEnabled() {
+  const char* e = getenv("CMX_RT3D_BULK");
+  return !(e && e[0] == '0');
+}
+
 }  // namespace
 
 bool VoxelBounds(const cmx_voxel* voxels, int64_t n, int lo[3], int hi[3]) {
@@ -343,6 +768,7 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
     float* d_unweighted = ws->dev[4].ReserveAs<float>(num_candidates);
     float* d_weighted = ws->dev[5].ReserveAs<float>(num_candidates);
     const int kFinalistCap = 4096;
+    int num_finalists = 0;
     char* d_misc = static_cast<char*>(ws->dev[6].Reserve(16 + sizeof(long long) * kFinalistCap));
     unsigned* d_max = reinterpret_cast<unsigned*>(d_misc);
     int* d_count = reinterpret_cast<int*>(d_misc + 4);
@@ -372,7 +798,244 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
     P.wt = options->translation_delta_cost_weight;
     P.wr = options->rotation_delta_cost_weight;
 
+    std::vector<long long> finalists;     // reference candidate index t * R + r, ascending
+    std::vector<float> acc;               // their exact unweighted scores
+    bool done = false;
     CMX_HIP(hipEventRecord(ws->ev_begin, ws->stream));
+
+    // ---- integer bounds (groups, then candidates) + exact finalists --------------------
+    // Limits: finite points (a NaN would read an unchecked cell), N small enough for the
+    // rounding bound of the f32 chain to mean something, index arithmetic exact in f32,
+    // weights that decrease with distance (a group is weighted by its nearest member).
+    const int reach = static_cast<int>(std::ceil(L * 1.7320508075688772)) + 1;   // |init.q * t_c|
+    const int pad = 2 * reach + 2;
+    const long long bx = brick.nx + 2ll * pad, by = brick.ny + 2ll * pad,
+                    bz = brick.nz + 2ll * pad;
+    bool use_bulk = Bulk3DEnabled() && n <= (1 << 21) && R <= 65535 &&
+                    bx * by * bz < (1ll << 24) &&
+                    options->translation_delta_cost_weight >= 0. &&
+                    options->rotation_delta_cost_weight >= 0.;
+    for (int i = 0; i < 3 * n && use_bulk; ++i) use_bulk = std::isfinite(point_cloud_xyz[i]);
+    long long bounds_evaluated = 0;
+    if (use_bulk) {
+      const size_t cells = static_cast<size_t>(bx * by * bz);
+      const int tiles_x = DivUp(bx, 8), tiles_y = DivUp(by, 4);
+      const int pitch_z = DivUp(bz, 4) * 4;
+      const size_t tiled_cells = static_cast<size_t>(tiles_x) * tiles_y * pitch_z * 32;
+      // [row-major q (only the input of the dilation) | tiled q]
+      uint8_t* d_bulk = ws->dev[8].ReserveAs<uint8_t>(cells + 128 + tiled_cells);
+      uint8_t* d_tiled = d_bulk + (cells + 127) / 128 * 128;
+      uint8_t* d_dilated = ws->dev[9].ReserveAs<uint8_t>(cells);
+      // (dilation scratch first, then the (Q, A) pairs of the candidate pass)
+      uint8_t* d_tmp = ws->dev[10].ReserveAs<uint8_t>(
+          std::max<size_t>(cells, sizeof(uint2) * static_cast<size_t>(num_candidates)));
+      CMX_HIP(hipMemsetAsync(d_bulk, 0, (d_tiled - d_bulk) + tiled_cells, ws->stream));
+      if (num_voxels > 0) {
+        const cmx_voxel* d_vox = static_cast<const cmx_voxel*>(ws->dev[15].get());
+        ScatterBulkKernel<<<DivUp(num_voxels, 256), 256, 0, ws->stream>>>(
+            d_vox, num_voxels, brick.lo_x, brick.lo_y, brick.lo_z, pad, static_cast<int>(bx),
+            static_cast<int>(by), tiles_y, pitch_z, d_bulk, d_tiled);
+      }
+      DilateXKernel<<<DivUp(cells, 256), 256, 0, ws->stream>>>(d_bulk, d_tmp,
+                                                               static_cast<int>(bx), cells);
+      DilateYZKernel<<<DivUp(cells, 256), 256, 0, ws->stream>>>(
+          d_tmp, d_dilated, static_cast<int>(bx), static_cast<int>(by), static_cast<int>(bz));
+
+      // 2 x 2 x 2 blocks of lattice steps: centre translation + the smallest member distance.
+      const int gpa = (side_t + 1) / 2;
+      const int G = gpa * gpa * gpa;
+      std::vector<float4> group(G);
+      for (int gz = 0, g = 0; gz < gpa; ++gz)
+        for (int gy = 0; gy < gpa; ++gy)
+          for (int gx = 0; gx < gpa; ++gx, ++g) {
+            const int nx = std::min(2, side_t - 2 * gx), ny = std::min(2, side_t - 2 * gy),
+                      nz = std::min(2, side_t - 2 * gz);
+            const h3::V3 tc{(2 * gx + 0.5f * (nx - 1) - L) * resolution,
+                            (2 * gy + 0.5f * (ny - 1) - L) * resolution,
+                            (2 * gz + 0.5f * (nz - 1) - L) * resolution};
+            const h3::V3 rc = h3::Rotate(init.q, tc);
+            float nearest = INFINITY;
+            for (int c = 0; c < nz; ++c)
+              for (int b = 0; b < ny; ++b)
+                for (int a = 0; a < nx; ++a)
+                  nearest = std::min(
+                      nearest,
+                      trans[((2 * gz + c) * side_t + (2 * gy + b)) * side_t + (2 * gx + a)].w);
+            group[g] = make_float4(rc.x + init.t.x, rc.y + init.t.y, rc.z + init.t.z, nearest);
+          }
+
+      const int kBulkFinalistCap = 4096;
+      const long long RG = R * G;
+      float4* d_group = ws->dev[14].ReserveAs<float4>(G);
+      float* d_group_upper = ws->dev[11].ReserveAs<float>(RG);
+      uint8_t* d_expanded = ws->dev[12].ReserveAs<uint8_t>(RG + num_candidates);
+      uint8_t* d_flags = d_expanded + RG;                             // [R][T]
+      float* d_upper = d_weighted;                                   // [R][T], reused
+      int* d_items = reinterpret_cast<int*>(d_unweighted);           // [R][T], reused
+      const size_t head_bytes = 16 + (sizeof(int) + sizeof(float)) * kBulkFinalistCap;   // 16 | 32768
+      // work descriptors of a round: at most one per 256 translations and rotation, + count
+      const int max_blocks = static_cast<int>(R) * DivUp(T, kBulk3DThreads);
+      const size_t counts_bytes = (sizeof(int) * R + 15) / 16 * 16;
+      char* d_bmisc = static_cast<char*>(ws->dev[13].Reserve(
+          head_bytes + counts_bytes + sizeof(int2) * (max_blocks + 1)));
+      unsigned* d_max_lower = reinterpret_cast<unsigned*>(d_bmisc);
+      int* d_bcount = reinterpret_cast<int*>(d_bmisc + 4);
+      unsigned* d_max_upper = reinterpret_cast<unsigned*>(d_bmisc + 8);
+      int* d_total = reinterpret_cast<int*>(d_bmisc + 12);
+      int* d_bfinalists = reinterpret_cast<int*>(d_bmisc + 16);
+      float* d_exact = reinterpret_cast<float*>(d_bmisc + 16 + sizeof(int) * kBulkFinalistCap);
+      int* d_counts = reinterpret_cast<int*>(d_bmisc + head_bytes);
+      int2* d_blocks = reinterpret_cast<int2*>(d_bmisc + head_bytes + counts_bytes);
+      int* d_num_blocks = reinterpret_cast<int*>(d_blocks + max_blocks);
+      int* h_num_blocks = ws->pinned[1].ReserveAs<int>(4);
+      char* h_bmisc = static_cast<char*>(ws->pinned[2].Reserve(head_bytes));
+      float4* h_group = ws->pinned[3].ReserveAs<float4>(G);
+      std::memcpy(h_group, group.data(), sizeof(float4) * G);
+      CMX_HIP(hipMemcpyAsync(d_group, h_group, sizeof(float4) * G, hipMemcpyHostToDevice,
+                             ws->stream));
+      CMX_HIP(hipMemsetAsync(d_bmisc, 0, 16, ws->stream));
+      CMX_HIP(hipMemsetAsync(d_counts, 0, sizeof(int) * R, ws->stream));
+      CMX_HIP(hipMemsetAsync(d_expanded, 0, RG + num_candidates, ws->stream));
+      CMX_HIP(hipMemsetAsync(d_upper, 0, sizeof(float) * num_candidates, ws->stream));
+
+      Rt3DBulkParams B{};
+      B.cell_count = static_cast<unsigned>(cells);
+      B.pitch_x = static_cast<float>(bx); B.pitch_y = static_cast<float>(by);
+      B.off_x = static_cast<float>(pad - brick.lo_x);
+      B.off_y = static_cast<float>(pad - brick.lo_y);
+      B.off_z = static_cast<float>(pad - brick.lo_z);
+      B.inv_resolution = 1.f / resolution;
+      double q_abs = 0.;
+      const int los[3] = {brick.lo_x, brick.lo_y, brick.lo_z};
+      const int dims[3] = {brick.nx, brick.ny, brick.nz};
+      for (int k = 0; k < 3; ++k)
+        q_abs = std::max<double>(q_abs, std::max(std::abs(los[k] - pad),
+                                                 std::abs(los[k] + dims[k] - 1 + pad)));
+      const double q_pad = static_cast<double>(std::max(bx, std::max(by, bz)));
+      // |q - (qe + off)| <= (2 |c / res| + |q|) 2^-24 (rounded 1/res, one fma rounding, the
+      // reference's rounded quotient qe); 25 % on top.
+      const double e = (2. * q_abs + q_pad + 4.) * 0x1p-24 * 1.25;
+      B.guard = std::nextafter(static_cast<float>(0.5 - e), 0.f);
+      B.t0x = init.t.x; B.t0y = init.t.y; B.t0z = init.t.z;
+      B.lo_x = (brick.lo_x - reach - 1) * resolution;
+      B.hi_x = (brick.lo_x + brick.nx + reach) * resolution;
+      B.lo_y = (brick.lo_y - reach - 1) * resolution;
+      B.hi_y = (brick.lo_y + brick.ny + reach) * resolution;
+      B.lo_z = (brick.lo_z - reach - 1) * resolution;
+      B.hi_z = (brick.lo_z + brick.nz + reach) * resolution;
+      B.num_rotations = static_cast<int>(R);
+      B.n = n;
+      B.rotation = d_rot; B.rotation_angle = d_angle;
+      B.wt = options->translation_delta_cost_weight;
+      B.wr = options->rotation_delta_cost_weight;
+      const float kMinP = 0.1f, kMaxP = 1.f - kMinP;
+      const float scale = (kMaxP - kMinP) / (32768 - 2.f);
+      B.min_probability = kMinP;
+      B.scale_over_n = 128. * static_cast<double>(scale) / n;
+      B.slack_hi = 127. * static_cast<double>(scale) + 2e-7;
+      const double ku = (n + 8.) * 0x1p-24;
+      B.delta = ku / (1. - ku) * 1.01 + 2e-6;
+      B.max_lower_bits = d_max_lower; B.max_upper_bits = d_max_upper;
+
+      // Group pass: every rotation, every block of translations, on the dilated brick.
+      Rt3DBulkParams BG = B;
+      BG.cells = d_dilated;
+      BG.translation = d_group; BG.num_translations = G;
+      BG.upper = d_group_upper;
+      StageTrace trace(ws->stream);
+      trace.Mark("bricks");
+      CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
+      Rt3DBulkKernel<true><<<dim3(DivUp(G, kBulk3DThreads), static_cast<unsigned>(R)),
+                             kBulk3DThreads, 0, ws->stream>>>(BG, d_xyz);
+      CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
+      // Candidate pass, twice: the members of the groups next to the best upper bound yield a
+      // lower bound; then everything that lower bound cannot exclude.  (The threshold only
+      // rises afterwards, so no third round can add a group.)
+      Rt3DBulkParams BC = B;
+      BC.cells = d_tiled;
+      BC.cell_count = static_cast<unsigned>(tiled_cells);
+      BC.tiles_y = tiles_y; BC.pitch_z = pitch_z;
+      BC.translation = d_trans; BC.num_translations = static_cast<int>(T);
+      BC.counts = d_counts; BC.items = d_items; BC.blocks = d_blocks;
+      BC.upper = d_upper;
+      BC.sums = reinterpret_cast<uint2*>(d_tmp);
+      CMX_HIP(hipMemsetAsync(d_tmp, 0, sizeof(uint2) * static_cast<size_t>(num_candidates),
+                             ws->stream));
+      trace.Mark("group pass");
+      int cus = 256;
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+      int round_blocks[2] = {0, 0};
+      for (int round = 0; round < 2; ++round) {
+        CMX_HIP(hipMemsetAsync(d_num_blocks, 0, sizeof(int), ws->stream));
+        Rt3DSelectGroupsKernel<<<DivUp(RG, 256), 256, 0, ws->stream>>>(
+            d_group_upper, G, static_cast<int>(R), side_t, gpa,
+            round == 0 ? d_max_upper : d_max_lower, round == 0 ? 0.97f : 1.f, d_expanded,
+            d_flags, static_cast<int>(T));
+        Rt3DCompactKernel<<<static_cast<unsigned>(R), 256, 0, ws->stream>>>(
+            d_flags, static_cast<int>(T), d_counts, d_items, d_total, d_blocks, d_num_blocks);
+        // The launch is sized by what survived: one sync per round (tens of microseconds)
+        // instead of hundreds of thousands of blocks that find nothing to do.
+        CMX_HIP(hipMemcpyAsync(h_num_blocks, d_num_blocks, sizeof(int), hipMemcpyDeviceToHost,
+                               ws->stream));
+        CMX_HIP(hipStreamSynchronize(ws->stream));
+        const int nb = round_blocks[round] = *h_num_blocks;
+        if (nb == 0) continue;
+        // Points are split over blockIdx.z until the chip is covered about eight times.
+        const int want = std::max(1, DivUp(8 * cus, nb));
+        BC.slice_points = std::max(1, DivUp(DivUp(n, want), kBulk3DChunk)) * kBulk3DChunk;
+        const dim3 cand_grid(nb, 1, DivUp(n, BC.slice_points));
+        Rt3DBulkKernel<false><<<cand_grid, kBulk3DThreads, 0, ws->stream>>>(BC, d_xyz);
+        Rt3DBoundsKernel<<<nb, kBulk3DThreads, 0, ws->stream>>>(BC);
+        trace.Mark(round == 0 ? "candidate pass 1" : "candidate pass 2");
+      }
+      Rt3DBulkCollectKernel<<<DivUp(num_candidates, 256), 256, 0, ws->stream>>>(
+          d_upper, num_candidates, d_max_lower, d_bcount, d_bfinalists, kBulkFinalistCap);
+      Rt3DExactKernel<<<kBulkFinalistCap, 256, 0, ws->stream>>>(P, d_xyz, n, d_bfinalists,
+                                                                d_bcount, kBulkFinalistCap,
+                                                                d_exact);
+      trace.Mark("finalists");
+      CMX_HIP(hipGetLastError());
+      CMX_HIP(hipEventRecord(ws->ev_end, ws->stream));
+      CMX_HIP(hipMemcpyAsync(h_bmisc, d_bmisc, head_bytes, hipMemcpyDeviceToHost, ws->stream));
+      CMX_HIP(hipStreamSynchronize(ws->stream));
+      trace.Report();
+      const int count = *reinterpret_cast<int*>(h_bmisc + 4);
+      const int total_items = *reinterpret_cast<int*>(h_bmisc + 12);
+      if (getenv("CMX_RT3D_REPORT")) {
+        float ms = 0.f, all = 0.f;
+        CMX_HIP(hipEventElapsedTime(&ms, ws->ev_k0, ws->ev_k1));
+        CMX_HIP(hipEventElapsedTime(&all, ws->ev_begin, ws->ev_end));
+        float lo_f, up_f;
+        std::memcpy(&lo_f, h_bmisc, 4);
+        std::memcpy(&up_f, h_bmisc + 8, 4);
+        fprintf(stderr,
+                "[cmx] rt3d: group pass %.3f ms (%lld bounds), %d of %lld candidates scored, "
+                "%d finalists, best lower %.6f, best group upper %.6f, work blocks %d + %d, "
+                "device %.3f ms\n",
+                ms, RG, total_items, num_candidates, count, lo_f, up_f, round_blocks[0],
+                round_blocks[1], all);
+      }
+      if (count >= 1 && count <= kBulkFinalistCap) {
+        const int* fin = reinterpret_cast<const int*>(h_bmisc + 16);
+        const float* exact =
+            reinterpret_cast<const float*>(h_bmisc + 16 + sizeof(int) * kBulkFinalistCap);
+        std::vector<std::pair<long long, float>> pairs(count);
+        for (int i = 0; i < count; ++i) {
+          const long long r = fin[i] / T, t = fin[i] % T;
+          pairs[i] = {t * R + r, exact[i]};
+        }
+        std::sort(pairs.begin(), pairs.end());
+        finalists.resize(count);
+        acc.resize(count);
+        for (int i = 0; i < count; ++i) { finalists[i] = pairs[i].first; acc[i] = pairs[i].second; }
+        num_finalists = count;
+        bounds_evaluated = RG + total_items;
+        done = true;
+      }
+      // else: a flat score landscape -- every candidate on the per-candidate kernel below.
+    }
+
+    if (!done) {
     CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
     Rt3DScoreKernel<<<dim3(DivUp(T, 64), static_cast<unsigned>(R)), 64, 0, ws->stream>>>(
         P, d_xyz, n, d_unweighted, d_weighted, d_max);
@@ -387,8 +1050,6 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
 
     const int count = *reinterpret_cast<int*>(h_misc + 4);
     const long long* h_finalists = reinterpret_cast<long long*>(h_misc + 16);
-    std::vector<long long> finalists;
-    std::vector<float> acc;
     if (count <= kFinalistCap) {
       finalists.assign(h_finalists, h_finalists + count);
       std::sort(finalists.begin(), finalists.end());
@@ -402,6 +1063,7 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
       acc.resize(num_candidates);
       CMX_HIP(hipMemcpy(acc.data(), d_unweighted, sizeof(float) * num_candidates,
                         hipMemcpyDeviceToHost));
+    }
     }
     CMX_REQUIRE(!finalists.empty(), "internal error: no candidate collected");
     // Exact weighting and the strict '>' running maximum of :44-50.
@@ -426,9 +1088,13 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
     }
     if (stats) {
       cmx_match_stats st{};
+      // Bulk path: the search space is covered by bounds -- R * G group bounds plus the
+      // candidates scored one by one; `candidates_scored` stays the size of the search space
+      // (what the reference scores), `coarse_candidates` says how many bounds that took.
       st.candidates_scored = num_candidates;
-      st.coarse_candidates = num_candidates;
+      st.coarse_candidates = bounds_evaluated ? bounds_evaluated : num_candidates;
       st.num_scans = static_cast<int>(R);
+      st.nodes_expanded = num_finalists;   // bulk path: candidates re-scored exactly
       float ms = 0.f;
       CMX_HIP(hipEventElapsedTime(&ms, ws->ev_begin, ws->ev_end));
       st.device_ms = ms;

@@ -306,3 +306,66 @@ def test_rt3d_ragged_and_large_clouds(sm3, oracle, synth):
         assert m.last_stats["candidates_scored"] == ref["num_candidates"]
         assert np.float32(score) == np.float32(ref["score"]), n
         np.testing.assert_array_equal(_pose7(pose), ref["pose"])
+
+
+# ----------------------------------------------------------------------------
+# RT-3D integer bulk pass (round 2): same result as the per-candidate kernel and the oracle
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["yaw", "tilted", "far_points", "offset_box", "weights"])
+def test_rt3d_bulk_pass_equals_per_candidate_kernel(sm3, oracle, synth, case, monkeypatch):
+    """The bulk pass only selects finalists; score and pose come from the reference's own
+    arithmetic.  Tilted initial orientations (the translation lattice is then not aligned
+    with the voxel axes), points far outside the stored box (clamped while staged), a box away
+    from the origin and strong weights (finalists not at the unweighted maximum)."""
+    grid, world = synth.make_submap_3d(11, 0.1, (8.0, 8.0, 4.0), 4, 8, 96)
+    vox = grid.voxels().copy()
+    pos = world.free_position(6, 0.5)
+    cloud = world.scan(pos, 0.3, 16, 256, seed=9)[:2500].copy()
+    axis, angle = [0, 0, 1], 0.31
+    shift = np.zeros(3)
+    weights = (0.1, 0.1)
+    if case == "tilted":
+        axis, angle = [0.3, -0.5, 0.8], 0.45
+    if case == "far_points":
+        # tens of metres outside the grid (not further: the angular step shrinks with the
+        # longest range and the oracle has to finish in seconds)
+        cloud[::7] += np.array([21.0, -17.0, 9.0], np.float32)
+        cloud[5::11] += np.float32(3.0)
+    if case == "offset_box":
+        vox["x"] += 700
+        vox["y"] -= 350
+        vox["z"] += 90
+        shift = np.array([70.0, -35.0, 9.0])
+    if case == "weights":
+        weights = (4.0, 6.0)
+    q = quat_from_angle_axis(angle, axis)
+    init = list(pos + shift + np.array([0.13, -0.08, 0.06])) + q
+    ref = oracle.rt3d_match(0.1, vox, init, cloud, 0.2, math.radians(1.0), *weights)
+    m = sm3.RealTimeCorrelativeScanMatcher3D(0.2, math.radians(1.0), *weights)
+    rigid = sm3.Rigid3d(tuple(init[:3]), tuple(init[3:]))
+    got = {}
+    for bulk in ("1", "0"):
+        monkeypatch.setenv("CMX_RT3D_BULK", bulk)
+        score, pose = m.match(rigid, cloud, 0.1, vox)
+        got[bulk] = (np.float32(score), _pose7(pose), dict(m.last_stats))
+        assert m.last_stats["candidates_scored"] == ref["num_candidates"]
+        assert np.float32(score) == np.float32(ref["score"]), (case, bulk)
+        np.testing.assert_array_equal(_pose7(pose), ref["pose"])
+    # the bulk pass ran (it reports its finalists) and narrowed the search down
+    assert 1 <= got["1"][2]["nodes_expanded"] <= 4096
+    assert got["0"][2]["nodes_expanded"] == 0
+
+
+def test_rt3d_bulk_pass_flat_landscape_falls_back(sm3, oracle, monkeypatch):
+    """An empty grid scores every candidate alike: more finalists than the list holds, the
+    per-candidate kernel takes over and the first candidate wins as in the reference."""
+    from cartographer_amd._lib import VOXEL_DTYPE
+    monkeypatch.setenv("CMX_RT3D_BULK", "1")
+    empty = np.zeros(0, VOXEL_DTYPE)
+    rng = np.random.default_rng(3)
+    cloud = rng.uniform(-2, 2, (300, 3)).astype(np.float32)
+    ref = oracle.rt3d_match(0.1, empty, [0, 0, 0, 1, 0, 0, 0], cloud, 0.5, 0.02, 0.0, 0.0)
+    m = sm3.RealTimeCorrelativeScanMatcher3D(0.5, 0.02, 0.0, 0.0)
+    score, pose = m.match(sm3.Rigid3d(), cloud, 0.1, empty)
+    assert np.float32(score) == np.float32(ref["score"])
+    np.testing.assert_array_equal(_pose7(pose), ref["pose"])
