@@ -17,6 +17,7 @@
 // point), including the low-resolution verification of leaves.
 #include <atomic>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <algorithm>
 #include <cmath>
@@ -39,7 +40,7 @@ struct Node3D {
   int coarse_index;        // its generation index
   unsigned long long path; // sibling ranks along the descent, 3 bits per level
   float low_resolution_score;
-  int pad;
+  int problem;             // index into the batch's Fast3DProblem array
 };
 
 struct Counters3 {
@@ -48,7 +49,7 @@ struct Counters3 {
   int leaves[kSubLists3];
   int overflow;
   int pad0;
-  unsigned best_bits;      // float bits of the best verified leaf (>= min_score floor)
+  int pad1;
   int pad;
   unsigned long long scored[16];
   unsigned long long expanded[16];
@@ -75,6 +76,12 @@ struct Fast3DProblem {
   double min_low_resolution_score;
   int ncx, ncy, ncz;        // lowest-resolution candidates per scan and axis
   float* coarse_score;      // [num_scans * ncx*ncy*ncz]
+  // Per-problem search state (a batch of searches shares the frontier and leaf lists; nodes
+  // carry their problem's index).
+  unsigned* best_bits;      // float bits of the best verified leaf (>= min_score floor)
+  Node3D* seeds;            // [kSeeds3] dive seeds
+  int* seed_count;
+  int index;                // this problem's index in the batch
 };
 
 // ---------------------------------------------------------------------------
@@ -107,18 +114,21 @@ __global__ void PrecomputeLevel3DKernel(Brick prev, Brick out, int shift, int ha
 // ---------------------------------------------------------------------------
 // Scan discretisation (DiscretizeScan, :200-244: transform + GetCellIndex)
 // ---------------------------------------------------------------------------
+// grid (ceil(n / 256), scans of the whole batch): `pose_t[s]` = the translation of the scan's
+// problem, .w its grid resolution.
 __global__ void __launch_bounds__(256)
 Discretize3DKernel(const float* __restrict__ xyz, int n, const float4* __restrict__ pose_q,
-                   float tx, float ty, float tz, float resolution, int4* __restrict__ cells) {
+                   const float4* __restrict__ pose_t, int4* __restrict__ cells) {
   const int s = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float4 q4 = pose_q[s];
+  const float4 t4 = pose_t[s];
   const Quat q{q4.w, q4.x, q4.y, q4.z};
   const F3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
   const F3 r = Rotate(q, p);
-  const F3 t{r.x + tx, r.y + ty, r.z + tz};
-  const int3 c = CellIndex3(t, resolution);
+  const F3 t{r.x + t4.x, r.y + t4.y, r.z + t4.z};
+  const int3 c = CellIndex3(t, t4.w);
   cells[static_cast<size_t>(s) * n + i] = make_int4(c.x, c.y, c.z, 0);
 }
 
@@ -156,8 +166,10 @@ __device__ __forceinline__ int ScoreCandidate3D(const Fast3DProblem& P, int dept
   return WaveSum(sum);
 }
 
+// grid (blocks, problems)
 __global__ void __launch_bounds__(256)
-ScoreCoarse3DKernel(Fast3DProblem P) {
+ScoreCoarse3DKernel(const Fast3DProblem* __restrict__ problems) {
+  const Fast3DProblem& P = problems[blockIdx.y];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int per_scan = P.ncx * P.ncy * P.ncz;
@@ -179,7 +191,8 @@ ScoreCoarse3DKernel(Fast3DProblem P) {
 // Few lowest-resolution candidates (deep stacks: one per yaw): a whole block per
 // candidate, so that its sum is not a 43-iteration chain of one wavefront.
 __global__ void __launch_bounds__(256)
-ScoreCoarse3DBlockKernel(Fast3DProblem P) {
+ScoreCoarse3DBlockKernel(const Fast3DProblem* __restrict__ problems) {
+  const Fast3DProblem& P = problems[blockIdx.y];
   __shared__ int partial[4];
   const int per_scan = P.ncx * P.ncy * P.ncz;
   const int total = per_scan * P.num_scans;
@@ -228,7 +241,7 @@ __device__ __forceinline__ Node3D CoarseNode3D(const Fast3DProblem& P, int c) {
   nd.coarse_index = c;
   nd.path = 0;
   nd.low_resolution_score = 0.f;
-  nd.pad = 0;
+  nd.problem = P.index;
   return nd;
 }
 
@@ -244,7 +257,9 @@ __device__ __forceinline__ int ListMax3(const List3& list) {
 // Seeds of the dive: the ~64 best lowest-resolution candidates (histogram
 // threshold on the scores).
 __global__ void __launch_bounds__(1024)
-SeedSelect3DKernel(Fast3DProblem P, List3 seeds, Counters3* __restrict__ counters) {
+SeedSelect3DKernel(const Fast3DProblem* __restrict__ problems) {
+  const Fast3DProblem& P = problems[blockIdx.x];
+  const List3 seeds{P.seeds, P.seed_count, kSeeds3};
   __shared__ int hist[1024];
   __shared__ int threshold_bin;
   hist[threadIdx.x] = 0;
@@ -298,11 +313,13 @@ SeedSelect3DKernel(Fast3DProblem P, List3 seeds, Counters3* __restrict__ counter
 }
 
 // Lowest-resolution nodes that can still matter (reference: :405-408).
+// grid (blocks, problems)
 __global__ void __launch_bounds__(256)
-Filter3DKernel(Fast3DProblem P, int strict, int chunk, int num_chunks, List3 out,
-               Counters3* __restrict__ counters) {
+Filter3DKernel(const Fast3DProblem* __restrict__ problems, int strict, int chunk, int num_chunks,
+               List3 out, Counters3* __restrict__ counters) {
+  const Fast3DProblem& P = problems[blockIdx.y];
   const int total = P.ncx * P.ncy * P.ncz * P.num_scans;
-  const float best = __uint_as_float(counters->best_bits);
+  const float best = __uint_as_float(*P.best_bits);
   const int sub = blockIdx.x & (kSubLists3 - 1);
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < total; c += gridDim.x * blockDim.x) {
     if (c % num_chunks != chunk) continue;
@@ -382,6 +399,48 @@ __device__ __forceinline__ void ExpandNode3D(const Fast3DProblem& P, const Node3
     const int fz[2] = {(nd.oz >> e) - L.lo_z, ((nd.oz + half) >> e) - L.lo_z};
     const int row = L.nx, slab = L.nx * L.ny;
     int sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // The two x positions of a point lie dx = fx[1] - fx[0] cells apart in one row (1, 2 or 4
+    // for the usual full_resolution_depth <= 3).  Up to dx == 4 ONE aligned 8-byte load serves
+    // both: half the gather instructions of the search, which are what bounds it.
+    const int dx = fx[1] - fx[0];
+    if (dx <= 4) {
+#pragma unroll 2
+      for (int q = threadIdx.x; q < P.n; q += 256) {
+        const int3 d = DepthIndex(cells[q], e, -P.wxy, -P.wxy, -P.wz);
+        const int ix0 = d.x + fx[0], ix1 = ix0 + dx;
+        const bool okx0 = static_cast<unsigned>(ix0) < static_cast<unsigned>(L.nx);
+        const bool okx1 = static_cast<unsigned>(ix1) < static_cast<unsigned>(L.nx);
+        const int base = min(max(ix0, 0), L.nx - 1);   // first byte wanted (when any is)
+        int ay[2], az[2];
+        bool oky[2], okz[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int iy = d.y + fy[b], iz = d.z + fz[b];
+          oky[b] = static_cast<unsigned>(iy) < static_cast<unsigned>(L.ny);
+          okz[b] = static_cast<unsigned>(iz) < static_cast<unsigned>(L.nz);
+          ay[b] = oky[b] ? iy * row : 0;
+          az[b] = okz[b] ? iz * slab : 0;
+        }
+        uint2 w[4];
+        unsigned j0[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {     // unconditional loads from in-range addresses
+          const unsigned a = static_cast<unsigned>(az[(k >> 1) & 1] + ay[k & 1] + base);
+          j0[k] = a & 3u;
+          w[k] = *reinterpret_cast<const uint2*>(cells8 + (a & ~3u));
+        }
+        const unsigned j1 = static_cast<unsigned>(ix1 - base);   // 0 .. 4 when okx1
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned b0 = j0[k], b1 = j0[k] + j1;             // byte indices, < 8
+          const unsigned v0 = ((b0 & 4u) ? w[k].y : w[k].x) >> (8u * (b0 & 3u)) & 0xffu;
+          const unsigned v1 = ((b1 & 4u) ? w[k].y : w[k].x) >> (8u * (b1 & 3u)) & 0xffu;
+          const bool okyz = oky[k & 1] && okz[(k >> 1) & 1];
+          sum[2 * k] += (okx0 && okyz) ? v0 : 0u;
+          sum[2 * k + 1] += (okx1 && okyz) ? v1 : 0u;
+        }
+      }
+    } else {
 #pragma unroll 2
     for (int q = threadIdx.x; q < P.n; q += 256) {
       const int3 d = DepthIndex(cells[q], e, -P.wxy, -P.wxy, -P.wz);
@@ -405,6 +464,7 @@ __device__ __forceinline__ void ExpandNode3D(const Fast3DProblem& P, const Node3
 #pragma unroll
       for (int k = 0; k < 8; ++k)
         sum[k] += (okx[k & 1] && oky[(k >> 1) & 1] && okz[(k >> 2) & 1]) ? v[k] : 0u;
+    }
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -463,7 +523,7 @@ __device__ __forceinline__ void ExpandNode3D(const Fast3DProblem& P, const Node3
         const float sc = score[k];
         __syncthreads();
         if (threadIdx.x == 0)
-          sh->score[0] = __uint_as_float(__hip_atomic_load(&counters->best_bits, __ATOMIC_RELAXED,
+          sh->score[0] = __uint_as_float(__hip_atomic_load(P.best_bits, __ATOMIC_RELAXED,
                                                            __HIP_MEMORY_SCOPE_AGENT));
         __syncthreads();
         const float now = sh->score[0];
@@ -481,7 +541,7 @@ __device__ __forceinline__ void ExpandNode3D(const Fast3DProblem& P, const Node3
             rec.low_resolution_score = low;
             if (!Push3(leaves, sub_id, atomicAdd(&leaves.counts[sub_id], 1), rec))
               counters->overflow = 1;
-            atomicMax(&counters->best_bits, __float_as_uint(sc));
+            atomicMax(P.best_bits, __float_as_uint(sc));
           }
           break;
         }
@@ -518,8 +578,8 @@ __device__ __forceinline__ void ExpandNode3D(const Fast3DProblem& P, const Node3
 }
 
 __global__ void __launch_bounds__(256)
-Expand3DKernel(Fast3DProblem P, List3 in, int strict, List3 out, List3 leaves,
-               Counters3* __restrict__ counters) {
+Expand3DKernel(const Fast3DProblem* __restrict__ problems, List3 in, int strict, List3 out,
+               List3 leaves, Counters3* __restrict__ counters) {
   __shared__ ExpandShared sh;
   const int max_count = ListMax3(in);
   for (int i = blockIdx.x; i < max_count * kSubLists3; i += gridDim.x) {
@@ -531,8 +591,9 @@ Expand3DKernel(Fast3DProblem P, List3 in, int strict, List3 out, List3 leaves,
     // of blocks walk serially (measured: 0.9 us per node, chip idle).
     const int sub_id = (in_sub * 17 + j) & (kSubLists3 - 1);
     const Node3D nd = in.nodes[static_cast<size_t>(in_sub) * in.sub_capacity + j];
+    const Fast3DProblem& P = problems[nd.problem];
     const float best = __uint_as_float(
-        __hip_atomic_load(&counters->best_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __hip_atomic_load(P.best_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (strict ? !(nd.score > best) : (nd.score < best)) continue;
     ExpandNode3D(P, nd, best, 0, strict, out, leaves, counters, sub_id, &sh);
   }
@@ -540,12 +601,16 @@ Expand3DKernel(Fast3DProblem P, List3 in, int strict, List3 out, List3 leaves,
 
 // Greedy descents (always the best child) from the seeds, one block per seed, all levels in
 // one launch: the verified leaf scores bound the search that follows.
+// grid (kSeeds3, problems)
 __global__ void __launch_bounds__(256)
-Dive3DKernel(Fast3DProblem P, List3 seeds, List3 leaves, Counters3* __restrict__ counters) {
+Dive3DKernel(const Fast3DProblem* __restrict__ problems, List3 leaves,
+             Counters3* __restrict__ counters) {
   __shared__ ExpandShared sh;
+  const Fast3DProblem& P = problems[blockIdx.y];
+  const List3 seeds{P.seeds, P.seed_count, kSeeds3};
   if (static_cast<int>(blockIdx.x) >= min(seeds.counts[0], seeds.sub_capacity)) return;
   Node3D nd = seeds.nodes[blockIdx.x];
-  const int sub_id = blockIdx.x & (kSubLists3 - 1);
+  const int sub_id = (blockIdx.x + 7 * blockIdx.y) & (kSubLists3 - 1);
   while (nd.level >= 1) {
     ExpandNode3D(P, nd, 0.f, 1, 0, seeds, leaves, counters, sub_id, &sh);
     if (!sh.has_next) break;
@@ -563,13 +628,17 @@ struct Best3 {
 
 // Among the recorded leaves with the best score, the one the reference's
 // depth-first search meets first (see fast_2d.hip SelectBestKernel).
+// grid (problems): block p looks at the leaves of problem p only.
 __global__ void __launch_bounds__(1024)
-SelectBest3DKernel(List3 leaves, const Counters3* __restrict__ counters, Best3* __restrict__ out) {
+SelectBest3DKernel(List3 leaves, const Fast3DProblem* __restrict__ problems,
+                   Best3* __restrict__ results) {
   __shared__ unsigned best_coarse;
   __shared__ unsigned long long best_key[2];
   __shared__ int ties;
+  const int problem = blockIdx.x;
+  Best3* out = results + problem;
   const int total = ListMax3(leaves) * kSubLists3;
-  const unsigned best_bits = counters->best_bits;
+  const unsigned best_bits = *problems[problem].best_bits;
   if (threadIdx.x == 0) {
     best_coarse = 0; ties = 0; best_key[0] = ~0ull; best_key[1] = ~0ull;
     Best3 b{};
@@ -580,7 +649,7 @@ SelectBest3DKernel(List3 leaves, const Counters3* __restrict__ counters, Best3* 
     const int sub = i & (kSubLists3 - 1), j = i / kSubLists3;
     if (j >= min(leaves.counts[sub], leaves.sub_capacity)) return false;
     *nd = leaves.nodes[static_cast<size_t>(sub) * leaves.sub_capacity + j];
-    return true;
+    return nd->problem == problem;
   };
   Node3D nd;
   for (int i = threadIdx.x; i < total; i += blockDim.x)
@@ -631,7 +700,9 @@ SelectBest3DKernel(List3 leaves, const Counters3* __restrict__ counters, Best3* 
 // one through the generic expansion of a virtual parent is not possible, so a
 // dedicated wave-per-candidate pass records every passing candidate.
 __global__ void __launch_bounds__(256)
-VerifyCoarseLeaves3DKernel(Fast3DProblem P, List3 leaves, Counters3* __restrict__ counters) {
+VerifyCoarseLeaves3DKernel(const Fast3DProblem* __restrict__ problems, List3 leaves,
+                           Counters3* __restrict__ counters) {
+  const Fast3DProblem& P = problems[blockIdx.y];
   __shared__ float low_prob[kLowChunk];
   const int total = P.ncx * P.ncy * P.ncz * P.num_scans;
   const int sub_id = blockIdx.x & (kSubLists3 - 1);
@@ -649,7 +720,7 @@ VerifyCoarseLeaves3DKernel(Fast3DProblem P, List3 leaves, Counters3* __restrict_
       rec.level = 0;
       rec.low_resolution_score = low;
       if (!Push3(leaves, sub_id, atomicAdd(&leaves.counts[sub_id], 1), rec)) counters->overflow = 1;
-      atomicMax(&counters->best_bits, __float_as_uint(nd.score));
+      atomicMax(P.best_bits, __float_as_uint(nd.score));
     }
   }
 }
@@ -703,80 +774,170 @@ float MatchHistograms(const std::vector<float>& submap, const std::vector<float>
   return Dot(submap, scan) / normalization;
 }
 
+// One (node, submap) search of a batch: MatchWithSearchParameters' arguments (:172-198).
+struct Search3D {
+  const Fast3DMatcher* m;
+  int wxy, wz;
+  double angular_search_window;
+  h3::Rigid node, submap;
+  float min_score;
+};
+
+void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data, int32_t* found,
+                 cmx_result3d* results, cmx_match_stats* stats);
+
+// Host side of one search: the yaw pre-filter and the candidate lattice.
+struct Prepared3D {
+  std::vector<h3::Q> pose_q, scan_q;
+  std::vector<float> rotational_score;
+  h3::V3 pose_t;
+  int S = 0;
+  long long ncx = 0, ncz = 0, per_scan = 0, total = 0;
+  size_t scan_base = 0, coarse_base = 0;
+};
+
 void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_window,
              const h3::Rigid& node, const h3::Rigid& submap, const cmx_node_data3d& data,
              float min_score, int32_t* found, cmx_result3d* result, cmx_match_stats* stats) {
-  CMX_REQUIRE(found && result, "null output");
+  const Search3D one{&m, wxy, wz, angular_search_window, node, submap, min_score};
+  Match3DMany(&one, 1, data, found, result, stats);
+}
+
+// `num` searches of one node's data in ONE chain of launches: every kernel takes the array of
+// problems (blockIdx.y, or the index its nodes carry), frontier and leaf lists are shared.  All
+// searches must live on the same device.  The rare cases that need a second look at one
+// search -- a frontier overflow, distinct leaves tied for the best score -- are repeated one
+// search at a time (num == 1 owns the overflow retry and the exact tie resolution).
+void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data, int32_t* found,
+                 cmx_result3d* results, cmx_match_stats* stats) {
+  CMX_REQUIRE(searches && num >= 1 && found && results, "null output");
   CMX_REQUIRE(data.high_resolution_point_cloud && data.num_high_resolution_points >= 1,
               "empty high-resolution point cloud");
   CMX_REQUIRE(data.low_resolution_point_cloud && data.num_low_resolution_points >= 1,
               "empty low-resolution point cloud");
-  CMX_REQUIRE(data.histogram_size == static_cast<int>(m.histogram.size()),
-              "histogram size %d does not match the submap's %d", data.histogram_size,
-              static_cast<int>(m.histogram.size()));
-  CMX_REQUIRE(data.histogram_size == 0 || data.rotational_scan_matcher_histogram != nullptr,
-              "null histogram");
-  CMX_REQUIRE(wxy >= 0 && wz >= 0 && wxy < (1 << 20) && wz < (1 << 20), "bad search window");
+  // CMX_HOST_TRACE=1: wall-clock of the host phases (tools only).
+  static const bool host_trace = [] { const char* e = getenv("CMX_HOST_TRACE"); return e && e[0] == '1'; }();
+  auto t_last = std::chrono::steady_clock::now();
+  std::string host_report;
+  const auto lap = [&](const char* name) {
+    if (!host_trace) return;
+    const auto now = std::chrono::steady_clock::now();
+    char buf[64];
+    snprintf(buf, sizeof buf, " %s=%.0f", name,
+             std::chrono::duration<double, std::micro>(now - t_last).count());
+    host_report += buf;
+    t_last = now;
+  };
   const int n = data.num_high_resolution_points, n_low = data.num_low_resolution_points;
   const float* hi = data.high_resolution_point_cloud;
-  const int depth = m.options.branch_and_bound_depth;
-  *found = 0;
+  const int device = searches[0].m->device;
+  int max_depth = 0, min_depth = kMaxDepth;
+  for (int p = 0; p < num; ++p) {
+    const Fast3DMatcher& m = *searches[p].m;
+    CMX_REQUIRE(m.device == device, "the searches of a batch must share a device");
+    CMX_REQUIRE(data.histogram_size == static_cast<int>(m.histogram.size()),
+                "histogram size %d does not match the submap's %d", data.histogram_size,
+                static_cast<int>(m.histogram.size()));
+    CMX_REQUIRE(searches[p].wxy >= 0 && searches[p].wz >= 0 && searches[p].wxy < (1 << 20) &&
+                    searches[p].wz < (1 << 20),
+                "bad search window");
+    max_depth = std::max(max_depth, m.options.branch_and_bound_depth);
+    min_depth = std::min(min_depth, m.options.branch_and_bound_depth);
+    found[p] = 0;
+  }
+  CMX_REQUIRE(data.histogram_size == 0 || data.rotational_scan_matcher_histogram != nullptr,
+              "null histogram");
+  if (num > 1 && min_depth < 2) {     // depth-1 stacks take the leaf-verification path: one by one
+    cmx_match_stats total{};
+    for (int p = 0; p < num; ++p) {
+      cmx_match_stats st{};
+      Match3DMany(searches + p, 1, data, found + p, results + p, &st);
+      total.candidates_scored += st.candidates_scored; total.coarse_candidates += st.coarse_candidates;
+      total.nodes_expanded += st.nodes_expanded; total.num_scans += st.num_scans;
+      total.device_ms += st.device_ms; total.dominant_kernel_ms += st.dominant_kernel_ms;
+    }
+    if (stats) *stats = total;
+    return;
+  }
 
   // GenerateDiscreteScans (:246-295), host part.
-  float max_scan_range = 3.f * m.resolution;
+  float max_point = 0.f;
   for (int i = 0; i < n; ++i)
-    max_scan_range = std::max(h3::Norm({hi[3 * i], hi[3 * i + 1], hi[3 * i + 2]}), max_scan_range);
-  const float kSafetyMargin = 1.f - 1e-2f;
-  const float step =
-      kSafetyMargin * std::acos(1.f - (m.resolution * (m.resolution * 1.f)) /
-                                          (2.f * (max_scan_range * (max_scan_range * 1.f))));
-  const int angular_window_size = static_cast<int>(std::lround(angular_search_window / step));
-  CMX_REQUIRE(angular_window_size >= 0 && angular_window_size < (1 << 20), "bad angular window");
-  std::vector<float> angles;
-  for (int rz = -angular_window_size; rz <= angular_window_size; ++rz) angles.push_back(rz * step);
-  const h3::Rigid node_to_submap = h3::Mul(h3::InverseRigid(submap), node);
+    max_point = std::max(h3::Norm({hi[3 * i], hi[3 * i + 1], hi[3 * i + 2]}), max_point);
+  const std::vector<float> scan_hist(
+      data.rotational_scan_matcher_histogram,
+      data.rotational_scan_matcher_histogram + data.histogram_size);
   const double* g = data.gravity_alignment;   // w, x, y, z
   const double n2 = (g[1] * g[1] + g[3] * g[3]) + (g[2] * g[2] + g[0] * g[0]);
   const h3::Q g_inv{static_cast<float>(g[0] / n2), static_cast<float>(-g[1] / n2),
                     static_cast<float>(-g[2] / n2), static_cast<float>(-g[3] / n2)};
-  const float initial_angle = h3::GetYaw(h3::Mul(node_to_submap.q, g_inv));
-  const std::vector<float> scan_hist(
-      data.rotational_scan_matcher_histogram,
-      data.rotational_scan_matcher_histogram + data.histogram_size);
-  std::vector<h3::Q> pose_q;
-  std::vector<float> rotational_score;
-  for (size_t i = 0; i != angles.size(); ++i) {
-    const float sc =
-        MatchHistograms(m.histogram, RotateHistogram(scan_hist, initial_angle + angles[i]));
-    if (sc < m.options.min_rotational_score) continue;
-    pose_q.push_back(h3::Mul(h3::Mul(h3::Inverse(submap.q),
-                                     h3::FromAngleAxisVector({0.f, 0.f, angles[i]})),
-                             node.q));
-    rotational_score.push_back(sc);
-  }
-  const int S = static_cast<int>(pose_q.size());
+  std::vector<Prepared3D> prep(num);
+  size_t scans_total = 0, coarse_total = 0;
+  long long max_total = 0;
   cmx_match_stats st{};
-  st.num_scans = S;
-  if (S == 0) {
+  for (int p = 0; p < num; ++p) {
+    const Search3D& q = searches[p];
+    const Fast3DMatcher& m = *q.m;
+    Prepared3D& pr = prep[p];
+    const float max_scan_range = std::max(max_point, 3.f * m.resolution);
+    const float kSafetyMargin = 1.f - 1e-2f;
+    const float step =
+        kSafetyMargin * std::acos(1.f - (m.resolution * (m.resolution * 1.f)) /
+                                            (2.f * (max_scan_range * (max_scan_range * 1.f))));
+    const int angular_window_size = static_cast<int>(std::lround(q.angular_search_window / step));
+    CMX_REQUIRE(angular_window_size >= 0 && angular_window_size < (1 << 20), "bad angular window");
+    const h3::Rigid node_to_submap = h3::Mul(h3::InverseRigid(q.submap), q.node);
+    const float initial_angle = h3::GetYaw(h3::Mul(node_to_submap.q, g_inv));
+    for (int rz = -angular_window_size; rz <= angular_window_size; ++rz) {
+      const float angle = rz * step;
+      const float sc =
+          MatchHistograms(m.histogram, RotateHistogram(scan_hist, initial_angle + angle));
+      if (sc < m.options.min_rotational_score) continue;
+      pr.pose_q.push_back(h3::Mul(h3::Mul(h3::Inverse(q.submap.q),
+                                          h3::FromAngleAxisVector({0.f, 0.f, angle})),
+                                  q.node.q));
+      pr.rotational_score.push_back(sc);
+    }
+    pr.S = static_cast<int>(pr.pose_q.size());
+    pr.pose_t = node_to_submap.t;
+    st.num_scans += pr.S;
+    // Lowest-resolution candidates (:297-330).
+    const int depth = m.options.branch_and_bound_depth;
+    const int step_cells = 1 << (depth - 1);
+    pr.ncx = (2ll * q.wxy + step_cells) / step_cells;
+    pr.ncz = (2ll * q.wz + step_cells) / step_cells;
+    pr.per_scan = pr.ncx * pr.ncx * pr.ncz;
+    pr.total = pr.per_scan * pr.S;
+    CMX_REQUIRE(pr.total < (1ll << 30), "search too large: %lld lowest-resolution candidates",
+                pr.total);
+    pr.scan_base = scans_total;
+    pr.coarse_base = coarse_total;
+    scans_total += pr.S;
+    coarse_total += static_cast<size_t>(pr.total);
+    max_total = std::max(max_total, pr.total);
+    // GetPoseFromCandidate (:369-375): Translation(res * offset) * pose renormalises
+    // the rotation; Identity * q is exact, the normalisation is not.
+    pr.scan_q.resize(pr.S);
+    for (int s = 0; s < pr.S; ++s)
+      pr.scan_q[s] = h3::Normalized(h3::Mul(h3::Q{1.f, 0.f, 0.f, 0.f}, pr.pose_q[s]));
+  }
+  if (scans_total == 0) {
     if (stats) *stats = st;
     return;
   }
-  const h3::V3 pose_t = node_to_submap.t;
+  CMX_REQUIRE(coarse_total < (size_t(1) << 31) && scans_total * n < (size_t(1) << 31),
+              "batch too large");
 
-  // Lowest-resolution candidates (:297-330).
-  const int step_cells = 1 << (depth - 1);
-  const long long ncx = (2ll * wxy + step_cells) / step_cells, ncz = (2ll * wz + step_cells) / step_cells;
-  const long long per_scan = ncx * ncx * ncz;
-  const long long total = per_scan * S;
-  CMX_REQUIRE(total < (1ll << 30), "search too large: %lld lowest-resolution candidates", total);
-
-  WorkspaceLease ws(m.device);
+  lap("prepare");
+  WorkspaceLease ws(device);
   float* d_hi = ws->dev[0].ReserveAs<float>(3 * static_cast<size_t>(n));
   float* d_low = ws->dev[1].ReserveAs<float>(3 * static_cast<size_t>(n_low));
-  float4* d_pose_q = ws->dev[2].ReserveAs<float4>(2 * static_cast<size_t>(S));
-  float4* d_scan_q = d_pose_q + S;
-  int4* d_cells = ws->dev[3].ReserveAs<int4>(static_cast<size_t>(S) * n);
-  float* d_coarse = ws->dev[4].ReserveAs<float>(total);
+  // per scan: pose rotation | rotation of GetPoseFromCandidate | translation + resolution
+  float4* d_pose_q = ws->dev[2].ReserveAs<float4>(3 * scans_total);
+  float4* d_scan_q = d_pose_q + scans_total;
+  float4* d_pose_t = d_scan_q + scans_total;
+  int4* d_cells = ws->dev[3].ReserveAs<int4>(scans_total * n);
+  float* d_coarse = ws->dev[4].ReserveAs<float>(coarse_total);
   // CMX_FRONTIER_CAPACITY shrinks the frontier buffers (tests only): overflow -> strict retry.
   const char* cap_env = getenv("CMX_FRONTIER_CAPACITY");
   const int cap_req = cap_env ? atoi(cap_env) : 0;
@@ -786,28 +947,62 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
   Node3D* d_front[2] = {ws->dev[5].ReserveAs<Node3D>(kFrontierCapacity),
                         ws->dev[6].ReserveAs<Node3D>(kFrontierCapacity)};
   Node3D* d_leaves = ws->dev[7].ReserveAs<Node3D>(kLeafCapacity);
-  const int kDiveSub = 256;   // a dive list never holds more than kSeeds3 nodes per sub-list
-  Node3D* d_seeds = ws->dev[8].ReserveAs<Node3D>(2 * static_cast<size_t>(kDiveSub) * kSubLists3);
-  char* d_misc = static_cast<char*>(ws->dev[9].Reserve(sizeof(Counters3) + sizeof(Best3)));
+  Node3D* d_seeds = ws->dev[8].ReserveAs<Node3D>(static_cast<size_t>(kSeeds3) * num);
+  // [Counters3 | problems | per problem: best bits, seed count | Best3 per problem]
+  const size_t off_problems = sizeof(Counters3);
+  const size_t off_state = off_problems + sizeof(Fast3DProblem) * num;
+  const size_t off_best = off_state + sizeof(unsigned) * 2 * num;
+  const size_t misc_bytes = off_best + sizeof(Best3) * num;
+  static_assert(sizeof(Counters3) % 8 == 0 && sizeof(Fast3DProblem) % 8 == 0, "alignment");
+  char* d_misc = static_cast<char*>(ws->dev[9].Reserve(misc_bytes));
   Counters3* d_counters = reinterpret_cast<Counters3*>(d_misc);
-  Best3* d_best = reinterpret_cast<Best3*>(d_misc + sizeof(Counters3));
+  Fast3DProblem* d_problems = reinterpret_cast<Fast3DProblem*>(d_misc + off_problems);
+  unsigned* d_state = reinterpret_cast<unsigned*>(d_misc + off_state);   // [num][2]
+  Best3* d_best = reinterpret_cast<Best3*>(d_misc + off_best);
 
-  float4* h_q = ws->pinned[0].ReserveAs<float4>(2 * static_cast<size_t>(S));
-  std::vector<h3::Q> scan_q(S);
-  for (int s = 0; s < S; ++s) {
-    h_q[s] = make_float4(pose_q[s].x, pose_q[s].y, pose_q[s].z, pose_q[s].w);
-    // GetPoseFromCandidate (:369-375): Translation(res * offset) * pose renormalises
-    // the rotation; Identity * q is exact, the normalisation is not.
-    const h3::Q iq = h3::Normalized(h3::Mul(h3::Q{1.f, 0.f, 0.f, 0.f}, pose_q[s]));
-    scan_q[s] = iq;
-    h_q[S + s] = make_float4(iq.x, iq.y, iq.z, iq.w);
-  }
-  Counters3* h_counters = static_cast<Counters3*>(
-      ws->pinned[1].Reserve(sizeof(Counters3) + sizeof(Best3)));
-  std::memset(h_counters, 0, sizeof(Counters3));
-  {
-    const float floor_score = std::max(min_score, 0.f);
-    std::memcpy(&h_counters->best_bits, &floor_score, sizeof(float));
+  float4* h_q = ws->pinned[0].ReserveAs<float4>(3 * scans_total);
+  char* h_misc = static_cast<char*>(ws->pinned[1].Reserve(misc_bytes));
+  Counters3* h_counters = reinterpret_cast<Counters3*>(h_misc);
+  Fast3DProblem* h_problems = reinterpret_cast<Fast3DProblem*>(h_misc + off_problems);
+  unsigned* h_state = reinterpret_cast<unsigned*>(h_misc + off_state);
+  std::memset(h_misc, 0, misc_bytes);
+  for (int p = 0; p < num; ++p) {
+    const Search3D& q = searches[p];
+    const Fast3DMatcher& m = *q.m;
+    const Prepared3D& pr = prep[p];
+    for (int s = 0; s < pr.S; ++s) {
+      const size_t k = pr.scan_base + s;
+      h_q[k] = make_float4(pr.pose_q[s].x, pr.pose_q[s].y, pr.pose_q[s].z, pr.pose_q[s].w);
+      h_q[scans_total + k] =
+          make_float4(pr.scan_q[s].x, pr.scan_q[s].y, pr.scan_q[s].z, pr.scan_q[s].w);
+      h_q[2 * scans_total + k] = make_float4(pr.pose_t.x, pr.pose_t.y, pr.pose_t.z, m.resolution);
+    }
+    const float floor_score = std::max(q.min_score, 0.f);
+    std::memcpy(&h_state[2 * p], &floor_score, sizeof(float));
+    const int depth = m.options.branch_and_bound_depth;
+    Fast3DProblem P{};
+    for (int d = 0; d < depth; ++d) P.level[d] = m.levels[d]->desc;
+    P.depth = depth;
+    P.full_resolution_depth = m.options.full_resolution_depth;
+    P.low = m.low.desc;
+    P.low_resolution = m.low_resolution;
+    P.resolution = m.resolution;
+    P.wxy = q.wxy; P.wz = q.wz;
+    P.num_scans = pr.S; P.n = n; P.n_low = n_low;
+    P.cells = d_cells + pr.scan_base * n;
+    P.low_xyz = d_low;
+    P.scan_q = d_scan_q + pr.scan_base;
+    P.pose_tx = pr.pose_t.x; P.pose_ty = pr.pose_t.y; P.pose_tz = pr.pose_t.z;
+    P.min_score = q.min_score;
+    P.min_low_resolution_score = m.options.min_low_resolution_score;
+    P.ncx = static_cast<int>(pr.ncx); P.ncy = static_cast<int>(pr.ncx);
+    P.ncz = static_cast<int>(pr.ncz);
+    P.coarse_score = d_coarse + pr.coarse_base;
+    P.best_bits = d_state + 2 * p;
+    P.seed_count = reinterpret_cast<int*>(d_state + 2 * p + 1);
+    P.seeds = d_seeds + static_cast<size_t>(kSeeds3) * p;
+    P.index = p;
+    h_problems[p] = P;
   }
   // The high-resolution cloud only ever feeds integer sums (ScoreCandidates), which do
   // not depend on the order of the points.  Upload it sorted along a Morton curve: the
@@ -818,7 +1013,7 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
     float lo3[3] = {hi[0], hi[1], hi[2]};
     for (int i = 1; i < n; ++i)
       for (int k = 0; k < 3; ++k) lo3[k] = std::min(lo3[k], hi[3 * i + k]);
-    const float inv_cell = 1.f / (2.f * m.resolution);
+    const float inv_cell = 1.f / (2.f * searches[0].m->resolution);
     auto spread = [](uint32_t v) {   // 10 bits -> every third bit
       v &= 0x3ffu;
       v = (v | (v << 16)) & 0x030000ffu;
@@ -846,28 +1041,9 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
   CMX_HIP(hipMemcpyAsync(d_hi, h_hi, 3 * sizeof(float) * n, hipMemcpyHostToDevice, ws->stream));
   CMX_HIP(hipMemcpyAsync(d_low, data.low_resolution_point_cloud, 3 * sizeof(float) * n_low,
                          hipMemcpyHostToDevice, ws->stream));
-  CMX_HIP(hipMemcpyAsync(d_pose_q, h_q, 2 * sizeof(float4) * S, hipMemcpyHostToDevice,
+  CMX_HIP(hipMemcpyAsync(d_pose_q, h_q, 3 * sizeof(float4) * scans_total, hipMemcpyHostToDevice,
                          ws->stream));
-  CMX_HIP(hipMemcpyAsync(d_counters, h_counters, sizeof(Counters3), hipMemcpyHostToDevice,
-                         ws->stream));
-
-  Fast3DProblem P{};
-  for (int d = 0; d < depth; ++d) P.level[d] = m.levels[d]->desc;
-  P.depth = depth;
-  P.full_resolution_depth = m.options.full_resolution_depth;
-  P.low = m.low.desc;
-  P.low_resolution = m.low_resolution;
-  P.resolution = m.resolution;
-  P.wxy = wxy; P.wz = wz;
-  P.num_scans = S; P.n = n; P.n_low = n_low;
-  P.cells = d_cells;
-  P.low_xyz = d_low;
-  P.scan_q = d_scan_q;
-  P.pose_tx = pose_t.x; P.pose_ty = pose_t.y; P.pose_tz = pose_t.z;
-  P.min_score = min_score;
-  P.min_low_resolution_score = m.options.min_low_resolution_score;
-  P.ncx = static_cast<int>(ncx); P.ncy = static_cast<int>(ncx); P.ncz = static_cast<int>(ncz);
-  P.coarse_score = d_coarse;
+  CMX_HIP(hipMemcpyAsync(d_misc, h_misc, off_best, hipMemcpyHostToDevice, ws->stream));
 
   auto front = [&](int stage) {
     return List3{d_front[stage & 1], d_counters->frontier[stage], kFrontierCapacity / kSubLists3};
@@ -882,38 +1058,42 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
     CMX_HIP(hipStreamSynchronize(ws->stream));
   };
   dbg("uploads");
+  lap("buffers+uploads");
   StageTrace trace(ws->stream);
   auto mark = [&](const char* name) { trace.Mark(name); };
   mark("begin");
   CMX_HIP(hipEventRecord(ws->ev_begin, ws->stream));
-  Discretize3DKernel<<<dim3(DivUp(n, 256), S), 256, 0, ws->stream>>>(
-      d_hi, n, d_pose_q, pose_t.x, pose_t.y, pose_t.z, m.resolution, d_cells);
+  Discretize3DKernel<<<dim3(DivUp(n, 256), static_cast<unsigned>(scans_total)), 256, 0,
+                       ws->stream>>>(d_hi, n, d_pose_q, d_pose_t, d_cells);
   dbg("discretize");
   mark("discretize");
   CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
-  if (total <= 4096)
-    ScoreCoarse3DBlockKernel<<<static_cast<unsigned>(total), 256, 0, ws->stream>>>(P);
+  if (max_total <= 4096)
+    ScoreCoarse3DBlockKernel<<<dim3(static_cast<unsigned>(max_total), num), 256, 0,
+                               ws->stream>>>(d_problems);
   else
-    ScoreCoarse3DKernel<<<std::min<long long>(8192, DivUp(total, 4)), 256, 0, ws->stream>>>(P);
+    ScoreCoarse3DKernel<<<dim3(std::min<long long>(8192, DivUp(max_total, 4)), num), 256, 0,
+                          ws->stream>>>(d_problems);
   CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
   dbg("coarse");
   mark("coarse");
 
   const int blocks = 2048;
   int strict = 0, num_chunks = 1;
+  const Best3* h_best = reinterpret_cast<const Best3*>(h_misc + off_best);
   for (;;) {
-    if (depth == 1) {
-      VerifyCoarseLeaves3DKernel<<<blocks, 256, 0, ws->stream>>>(P, leaf_list, d_counters);
+    if (max_depth == 1) {
+      VerifyCoarseLeaves3DKernel<<<dim3(blocks, num), 256, 0, ws->stream>>>(d_problems, leaf_list,
+                                                                            d_counters);
     } else {
       if (!strict) {
         // dive: greedy descents from the best lowest-resolution candidates give
         // a verified leaf score to bound the search with.
-        List3 dive[2] = {{d_seeds, d_counters->dive[0], kDiveSub},
-                         {d_seeds + kDiveSub * kSubLists3, d_counters->dive[1], kDiveSub}};
-        SeedSelect3DKernel<<<1, 1024, 0, ws->stream>>>(P, dive[0], d_counters);
+        SeedSelect3DKernel<<<num, 1024, 0, ws->stream>>>(d_problems);
         dbg("seed");
         mark("seed");
-        Dive3DKernel<<<kSeeds3, 256, 0, ws->stream>>>(P, dive[0], leaf_list, d_counters);
+        Dive3DKernel<<<dim3(kSeeds3, num), 256, 0, ws->stream>>>(d_problems, leaf_list,
+                                                                  d_counters);
         dbg("dive");
         mark("dive");
       }
@@ -923,48 +1103,46 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
       for (int chunk = 0; chunk < num_chunks; ++chunk) {
         CMX_HIP(hipMemsetAsync(d_counters->frontier, 0, sizeof(d_counters->frontier),
                                ws->stream));
-        Filter3DKernel<<<256, 256, 0, ws->stream>>>(P, strict, chunk, num_chunks, front(0),
-                                                    d_counters);
+        Filter3DKernel<<<dim3(256, num), 256, 0, ws->stream>>>(d_problems, strict, chunk,
+                                                               num_chunks, front(0), d_counters);
         dbg("filter");
         mark("filter");
         int stage = 0;
-        for (int child = depth - 2; child >= 0; --child, ++stage) {
-          Expand3DKernel<<<blocks, 256, 0, ws->stream>>>(P, front(stage), strict,
+        for (int child = max_depth - 2; child >= 0; --child, ++stage) {
+          Expand3DKernel<<<blocks, 256, 0, ws->stream>>>(d_problems, front(stage), strict,
                                                          front(stage + 1), leaf_list, d_counters);
           dbg("expand level");
           mark("expand");
         }
       }
     }
-    SelectBest3DKernel<<<1, 1024, 0, ws->stream>>>(leaf_list, d_counters, d_best);
+    SelectBest3DKernel<<<num, 1024, 0, ws->stream>>>(leaf_list, d_problems, d_best);
     mark("select");
     CMX_HIP(hipGetLastError());
     CMX_HIP(hipEventRecord(ws->ev_end, ws->stream));
-    CMX_HIP(hipMemcpyAsync(h_counters, d_counters, sizeof(Counters3) + sizeof(Best3),
-                           hipMemcpyDeviceToHost, ws->stream));
+    CMX_HIP(hipMemcpyAsync(h_misc, d_misc, misc_bytes, hipMemcpyDeviceToHost, ws->stream));
     CMX_HIP(hipStreamSynchronize(ws->stream));
     trace.Report();
-    if (!h_counters->overflow) break;
+    lap("device");
+    if (!h_counters->overflow || num > 1) break;
     // Something was dropped.  Retry pruning ties (strict) with the bound lowered by one
     // ulp so the best leaf is found again, over four times as many, smaller chunks.
     CMX_REQUIRE(num_chunks < (1 << 12), "branch-and-bound frontier overflow (search too wide)");
     if (strict) num_chunks *= 4;
     strict = 1;
-    const float floor_score = std::max(min_score, 0.f);
+    const float floor_score = std::max(searches[0].min_score, 0.f);
     unsigned floor_bits;
     std::memcpy(&floor_bits, &floor_score, sizeof(float));
     Counters3 reset{};
-    reset.best_bits = h_counters->best_bits > floor_bits ? h_counters->best_bits - 1 : floor_bits;
     std::memcpy(reset.scored, h_counters->scored, sizeof(reset.scored));
     std::memcpy(reset.expanded, h_counters->expanded, sizeof(reset.expanded));
     *h_counters = reset;
-    CMX_HIP(hipMemcpyAsync(d_counters, h_counters, sizeof(Counters3), hipMemcpyHostToDevice,
-                           ws->stream));
+    h_state[0] = h_state[0] > floor_bits ? h_state[0] - 1 : floor_bits;
+    h_state[1] = 0;
+    CMX_HIP(hipMemcpyAsync(d_misc, h_misc, off_best, hipMemcpyHostToDevice, ws->stream));
   }
-  const Best3* h_best = reinterpret_cast<const Best3*>(reinterpret_cast<char*>(h_counters) +
-                                                       sizeof(Counters3));
-  st.coarse_candidates = total;
-  st.candidates_scored = total;
+  st.coarse_candidates = static_cast<int64_t>(coarse_total);
+  st.candidates_scored = static_cast<int64_t>(coarse_total);
   for (int k = 0; k < 16; ++k) {
     st.candidates_scored += h_counters->scored[k];
     st.nodes_expanded += h_counters->expanded[k];
@@ -974,74 +1152,117 @@ void Match3D(const Fast3DMatcher& m, int wxy, int wz, double angular_search_wind
   st.device_ms = ms;
   CMX_HIP(hipEventElapsedTime(&ms, ws->ev_k0, ws->ev_k1));
   st.dominant_kernel_ms = ms;
+
   if (stats) *stats = st;
-  Best3 best = *h_best;
-  if (best.found && best.ties > 1) {
-    // Exact tie resolution (see fast_2d.hip ResolveTies): repeat the reference's
-    // std::sort of the lowest-resolution candidates (:352-353) and take the
-    // tied leaf its depth-first search meets first.  The dive and the search
-    // record the same leaf twice, so first check that distinct leaves tie.
-    unsigned best_bits;
-    std::memcpy(&best_bits, &best.score, sizeof(float));
-    std::vector<Node3D> tied;
-    std::vector<Node3D> sub_nodes;
-    for (int sub = 0; sub < kSubLists3; ++sub) {
-      const int count = std::min(h_counters->leaves[sub], leaf_list.sub_capacity);
-      if (count <= 0) continue;
-      sub_nodes.resize(count);
-      CMX_HIP(hipMemcpy(sub_nodes.data(),
-                        leaf_list.nodes + static_cast<size_t>(sub) * leaf_list.sub_capacity,
-                        count * sizeof(Node3D), hipMemcpyDeviceToHost));
-      for (const Node3D& nd : sub_nodes) {
-        unsigned bits;
-        std::memcpy(&bits, &nd.score, sizeof(float));
-        if (bits == best_bits) tied.push_back(nd);
-      }
+  if (num > 1 && h_counters->overflow) {
+    // The shared lists dropped nodes: every search again on its own (num == 1 owns the retry).
+    for (int p = 0; p < num; ++p) {
+      cmx_match_stats again{};
+      Match3DMany(searches + p, 1, data, found + p, results + p, &again);
+      st.candidates_scored += again.candidates_scored;
+      st.nodes_expanded += again.nodes_expanded;
+      st.device_ms += again.device_ms;
     }
-    bool distinct = false;
-    for (const Node3D& nd : tied)
-      distinct |= !(nd.scan == tied[0].scan && nd.ox == tied[0].ox && nd.oy == tied[0].oy &&
-                    nd.oz == tied[0].oz);
-    if (distinct) {
-      std::vector<float> scores(total);
-      CMX_HIP(hipMemcpy(scores.data(), d_coarse, total * sizeof(float), hipMemcpyDeviceToHost));
-      struct ScoreIndex {
-        float score; int index;
-        bool operator>(const ScoreIndex& o) const { return score > o.score; }
-      };
-      std::vector<ScoreIndex> sorted(total);
-      for (long long c = 0; c < total; ++c) sorted[c] = {scores[c], static_cast<int>(c)};
-      std::sort(sorted.begin(), sorted.end(), std::greater<ScoreIndex>());
-      std::vector<int> position(total);
-      for (long long i = 0; i < total; ++i) position[sorted[i].index] = static_cast<int>(i);
-      bool have = false;
-      int best_pos = 0;
-      unsigned long long best_path = 0;
-      for (const Node3D& nd : tied) {
-        const int pos = position[nd.coarse_index];
-        if (!have || pos < best_pos || (pos == best_pos && nd.path < best_path)) {
-          have = true;
-          best_pos = pos;
-          best_path = nd.path;
-          best.scan = nd.scan; best.ox = nd.ox; best.oy = nd.oy; best.oz = nd.oz;
-          best.low_resolution_score = nd.low_resolution_score;
+    if (stats) *stats = st;
+    return;
+  }
+
+  // Leaves tied for the best score (lazily: one download of the leaf lists for the batch).
+  std::vector<Node3D> all_leaves;
+  std::vector<float> all_coarse;
+  bool have_leaves = false;
+  const auto leaves_of = [&](int p, unsigned score_bits) {
+    if (!have_leaves) {
+      have_leaves = true;
+      // one strided copy: the first max-count slots of every sub-list
+      int max_count = 0;
+      for (int sub = 0; sub < kSubLists3; ++sub)
+        max_count = std::max(max_count, std::min(h_counters->leaves[sub], leaf_list.sub_capacity));
+      if (max_count > 0) {
+        std::vector<Node3D> rows(static_cast<size_t>(max_count) * kSubLists3);
+        CMX_HIP(hipMemcpy2D(rows.data(), max_count * sizeof(Node3D), leaf_list.nodes,
+                            leaf_list.sub_capacity * sizeof(Node3D), max_count * sizeof(Node3D),
+                            kSubLists3, hipMemcpyDeviceToHost));
+        for (int sub = 0; sub < kSubLists3; ++sub) {
+          const int count = std::min(h_counters->leaves[sub], leaf_list.sub_capacity);
+          all_leaves.insert(all_leaves.end(), rows.begin() + static_cast<size_t>(sub) * max_count,
+                            rows.begin() + static_cast<size_t>(sub) * max_count + count);
         }
       }
     }
+    std::vector<Node3D> tied;
+    for (const Node3D& nd : all_leaves) {
+      unsigned bits;
+      std::memcpy(&bits, &nd.score, sizeof(float));
+      if (nd.problem == p && bits == score_bits) tied.push_back(nd);
+    }
+    return tied;
+  };
+
+  for (int p = 0; p < num; ++p) {
+    const Fast3DMatcher& m = *searches[p].m;
+    const Prepared3D& pr = prep[p];
+    const long long total = pr.total;
+    Best3 best = h_best[p];
+    if (best.found && best.ties > 1) {
+      // Exact tie resolution (see fast_2d.hip ResolveTies): repeat the reference's
+      // std::sort of the lowest-resolution candidates (:352-353) and take the
+      // tied leaf its depth-first search meets first.  The dive and the search
+      // record the same leaf twice, so first check that distinct leaves tie.
+      unsigned best_bits;
+      std::memcpy(&best_bits, &best.score, sizeof(float));
+      const std::vector<Node3D> tied = leaves_of(p, best_bits);
+      bool distinct = false;
+      for (const Node3D& nd : tied)
+        distinct |= !(nd.scan == tied[0].scan && nd.ox == tied[0].ox && nd.oy == tied[0].oy &&
+                      nd.oz == tied[0].oz);
+      if (distinct) {
+        if (all_coarse.empty()) {
+          all_coarse.resize(coarse_total);
+          CMX_HIP(hipMemcpy(all_coarse.data(), d_coarse, coarse_total * sizeof(float),
+                            hipMemcpyDeviceToHost));
+        }
+        const float* scores = all_coarse.data() + pr.coarse_base;
+        struct ScoreIndex {
+          float score; int index;
+          bool operator>(const ScoreIndex& o) const { return score > o.score; }
+        };
+        std::vector<ScoreIndex> sorted(total);
+        for (long long c = 0; c < total; ++c) sorted[c] = {scores[c], static_cast<int>(c)};
+        std::sort(sorted.begin(), sorted.end(), std::greater<ScoreIndex>());
+        std::vector<int> position(total);
+        for (long long i = 0; i < total; ++i) position[sorted[i].index] = static_cast<int>(i);
+        bool have = false;
+        int best_pos = 0;
+        unsigned long long best_path = 0;
+        for (const Node3D& nd : tied) {
+          const int pos = position[nd.coarse_index];
+          if (!have || pos < best_pos || (pos == best_pos && nd.path < best_path)) {
+            have = true;
+            best_pos = pos;
+            best_path = nd.path;
+            best.scan = nd.scan; best.ox = nd.ox; best.oy = nd.oy; best.oz = nd.oz;
+            best.low_resolution_score = nd.low_resolution_score;
+          }
+        }
+      }
+    }
+    if (best.found && best.score > searches[p].min_score) {
+      found[p] = 1;
+      results[p].score = best.score;
+      h3::Rigid pose;
+      // Translation(res * offset) * scan.pose
+      pose.t = {(pr.pose_t.x + 0.f) + m.resolution * static_cast<float>(best.ox),
+                (pr.pose_t.y + 0.f) + m.resolution * static_cast<float>(best.oy),
+                (pr.pose_t.z + 0.f) + m.resolution * static_cast<float>(best.oz)};
+      pose.q = pr.scan_q[best.scan];
+      results[p].pose_estimate = h3::ToPose(pose);
+      results[p].rotational_score = pr.rotational_score[best.scan];
+      results[p].low_resolution_score = best.low_resolution_score;
+    }
   }
-  if (best.found && best.score > min_score) {
-    *found = 1;
-    result->score = best.score;
-    h3::Rigid pose;
-    // Translation(res * offset) * scan.pose
-    pose.t = {(pose_t.x + 0.f) + m.resolution * static_cast<float>(best.ox),
-              (pose_t.y + 0.f) + m.resolution * static_cast<float>(best.oy),
-              (pose_t.z + 0.f) + m.resolution * static_cast<float>(best.oz)};
-    pose.q = scan_q[best.scan];
-    result->pose_estimate = h3::ToPose(pose);
-    result->rotational_score = rotational_score[best.scan];
-    result->low_resolution_score = best.low_resolution_score;
-  }
+  lap("results");
+  if (host_trace) fprintf(stderr, "[cmx host] Match3DMany(%d):%s us\n", num, host_report.c_str());
 }
 
 }  // namespace
@@ -1113,7 +1334,7 @@ cmx_status cmx_fast3d_create(const cmx_fast3d_options* options, float resolution
       std::unique_ptr<DeviceBrick> level(new DeviceBrick);
       level->bytes = static_cast<size_t>(b.nx) * b.ny * b.nz;
       CMX_REQUIRE(level->bytes < (size_t(1) << 31), "precomputation level too large");
-      CMX_HIP(hipMalloc(&level->mem, level->bytes));
+      CMX_HIP(hipMalloc(&level->mem, level->bytes + 16));   // (+16: aligned 8-byte reads of the last cells)
       b.cells = level->mem;
       level->desc = b;
       PrecomputeLevel3DKernel<<<DivUp(level->bytes, 256), 256, 0, ws->stream>>>(prev, b, shift,
@@ -1185,11 +1406,11 @@ cmx_status cmx_fast3d_match_full_submap(const cmx_fast3d* matcher,
 
 // The ConstraintBuilder3D fan-out (constraints/constraint_builder_3d.cc:79-147): one node's
 // constant data against many submaps' matchers, windowed and full-submap pairs mixed.  The
-// reference runs one thread-pool task per pair; here the pairs run concurrently from a few host
-// threads, each on its own leased stream and scratch (the matchers are immutable, Match3D is
-// re-entrant), so the short dependent kernel chains of independent searches overlap on the
-// device.  `node_poses[p]` / `submap_poses[p]`: the global poses of pair p (only their rotations
-// are read where match_full_submap[p] != 0).
+// reference runs one thread-pool task per pair; here the pairs of a node are ONE chain of
+// launches (Match3DMany: every kernel indexes the search with blockIdx.y or through its nodes,
+// frontier and leaf lists are shared), so a level of all searches is one launch instead of
+// one short launch per search.  `node_poses[p]` / `submap_poses[p]`: the global poses of pair
+// p (only their rotations are read where match_full_submap[p] != 0).
 cmx_status cmx_fast3d_match_batch(const cmx_fast3d* const* matchers, int32_t num_pairs,
                                   const cmx_pose3d* node_poses, const cmx_pose3d* submap_poses,
                                   const int32_t* match_full_submap, const float* min_scores,
@@ -1201,43 +1422,76 @@ cmx_status cmx_fast3d_match_batch(const cmx_fast3d* const* matchers, int32_t num
                     data && found && results && num_pairs >= 1,
                 "null argument");
     for (int p = 0; p < num_pairs; ++p) CMX_REQUIRE(matchers[p] != nullptr, "null matcher handle");
-    std::vector<cmx_match_stats> pair_stats(num_pairs);
-    std::vector<cmx_status> status(num_pairs, CMX_OK);
-    std::vector<std::string> errors(num_pairs);
-    std::atomic<int> next{0};
-    const auto worker = [&] {
-      for (int p = next.fetch_add(1); p < num_pairs; p = next.fetch_add(1)) {
-        found[p] = 0;
-        if (match_full_submap[p]) {
-          status[p] = cmx_fast3d_match_full_submap(matchers[p], node_poses[p].q,
-                                                   submap_poses[p].q, data, min_scores[p],
-                                                   &found[p], &results[p], &pair_stats[p]);
-        } else {
-          status[p] = cmx_fast3d_match(matchers[p], &node_poses[p], &submap_poses[p], data,
-                                       min_scores[p], &found[p], &results[p], &pair_stats[p]);
-        }
-        if (status[p] != CMX_OK) errors[p] = LastError();   // thread-local text of this worker
-      }
-    };
-    const int num_threads = std::min(num_pairs, 8);
-    std::vector<std::thread> threads;
-    for (int t = 1; t < num_threads; ++t) threads.emplace_back(worker);
-    worker();                                              // the calling thread takes its share
-    for (std::thread& t : threads) t.join();
-    cmx_match_stats total{};
+    const auto entry_time = std::chrono::steady_clock::now();
+    // Match (:127-146) / MatchFullSubmap (:148-170) arguments of every pair, then one chain of
+    // launches per device (Match3DMany).
+    CMX_REQUIRE(data->high_resolution_point_cloud && data->num_high_resolution_points >= 1,
+                "empty high-resolution point cloud");
+    float max_point_distance = 0.f;
+    for (int i = 0; i < data->num_high_resolution_points; ++i) {
+      const float* p = data->high_resolution_point_cloud + 3 * i;
+      max_point_distance = std::max(max_point_distance, h3::Norm({p[0], p[1], p[2]}));
+    }
+    std::vector<Search3D> searches(num_pairs);
     for (int p = 0; p < num_pairs; ++p) {
-      if (status[p] != CMX_OK) {
-        SetLastError("pair %d: %s", p, errors[p].c_str());
-        throw HipError{status[p]};
+      const Fast3DMatcher& m = matchers[p]->impl;
+      Search3D& q = searches[p];
+      q.m = &m;
+      q.min_score = min_scores[p];
+      if (match_full_submap[p]) {
+        const int window = (m.width_in_voxels + 1) / 2 +
+                           static_cast<int>(std::lround(max_point_distance / m.resolution + 0.5f));
+        q.wxy = q.wz = window;
+        q.angular_search_window = M_PI;
+        q.node.q = {static_cast<float>(node_poses[p].q[0]), static_cast<float>(node_poses[p].q[1]),
+                    static_cast<float>(node_poses[p].q[2]), static_cast<float>(node_poses[p].q[3])};
+        q.submap.q = {static_cast<float>(submap_poses[p].q[0]),
+                      static_cast<float>(submap_poses[p].q[1]),
+                      static_cast<float>(submap_poses[p].q[2]),
+                      static_cast<float>(submap_poses[p].q[3])};
+      } else {
+        q.wxy = static_cast<int>(std::lround(m.options.linear_xy_search_window / m.resolution));
+        q.wz = static_cast<int>(std::lround(m.options.linear_z_search_window / m.resolution));
+        q.angular_search_window = m.options.angular_search_window;
+        q.node = h3::FromPose(node_poses[p]);
+        q.submap = h3::FromPose(submap_poses[p]);
       }
-      total.candidates_scored += pair_stats[p].candidates_scored;
-      total.coarse_candidates += pair_stats[p].coarse_candidates;
-      total.nodes_expanded += pair_stats[p].nodes_expanded;
-      total.num_scans += pair_stats[p].num_scans;
-      total.device_ms += pair_stats[p].device_ms;          // summed: the searches overlap
-      total.dominant_kernel_ms += pair_stats[p].dominant_kernel_ms;
+    }
+    // CMX_FAST3D_BATCH caps the searches per chain (tools / tests; 1 = one by one).
+    int group = 64;
+    if (const char* e = getenv("CMX_FAST3D_BATCH")) group = std::max(1, atoi(e));
+    cmx_match_stats total{};
+    std::vector<char> done(num_pairs, 0);
+    for (int first = 0; first < num_pairs; ++first) {
+      if (done[first]) continue;
+      // the not yet searched pairs on this pair's device, `group` at a time
+      std::vector<int> idx;
+      for (int p = first; p < num_pairs && static_cast<int>(idx.size()) < group; ++p)
+        if (!done[p] && searches[p].m->device == searches[first].m->device) idx.push_back(p);
+      std::vector<Search3D> part(idx.size());
+      std::vector<int32_t> part_found(idx.size(), 0);
+      std::vector<cmx_result3d> part_results(idx.size());
+      for (size_t k = 0; k < idx.size(); ++k) part[k] = searches[idx[k]];
+      cmx_match_stats st{};
+      Match3DMany(part.data(), static_cast<int>(part.size()), *data, part_found.data(),
+                  part_results.data(), &st);
+      for (size_t k = 0; k < idx.size(); ++k) {
+        done[idx[k]] = 1;
+        found[idx[k]] = part_found[k];
+        if (part_found[k]) results[idx[k]] = part_results[k];
+      }
+      total.candidates_scored += st.candidates_scored;
+      total.coarse_candidates += st.coarse_candidates;
+      total.nodes_expanded += st.nodes_expanded;
+      total.num_scans += st.num_scans;
+      total.device_ms += st.device_ms;
+      total.dominant_kernel_ms += st.dominant_kernel_ms;
     }
     if (stats) *stats = total;
+    if (const char* e = getenv("CMX_HOST_TRACE"); e && e[0] == '1')
+      fprintf(stderr, "[cmx host] cmx_fast3d_match_batch(%d): %.0f us\n", num_pairs,
+              std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() -
+                                                        entry_time).count());
   });
 }
 

@@ -654,7 +654,7 @@ void BuildBrickFromVoxels(Workspace& ws, const cmx_voxel* voxels, int64_t n, int
   CMX_REQUIRE(cells * bytes_per_cell < (size_t(8) << 30),
               "dense grid of %d x %d x %d cells is too large", b.nx, b.ny, b.nz);
   out->bytes = cells * bytes_per_cell;
-  CMX_HIP(hipMalloc(&out->mem, out->bytes));
+  CMX_HIP(hipMalloc(&out->mem, out->bytes + 16));   // (+16: aligned 8-byte reads of the last cells)
   b.cells = out->mem;
   out->desc = b;
   CMX_HIP(hipMemsetAsync(out->mem, 0, out->bytes, ws.stream));

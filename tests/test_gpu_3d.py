@@ -369,3 +369,74 @@ def test_rt3d_bulk_pass_flat_landscape_falls_back(sm3, oracle, monkeypatch):
     score, pose = m.match(sm3.Rigid3d(), cloud, 0.1, empty)
     assert np.float32(score) == np.float32(ref["score"])
     np.testing.assert_array_equal(_pose7(pose), ref["pose"])
+
+
+# ----------------------------------------------------------------------------
+# fast-3D device batch (round 2): one chain of launches for all pairs of a node
+# ----------------------------------------------------------------------------
+def _fast3d_batch_scene(sm3, synth, depths):
+    hist = np.zeros(16, np.float32)
+    matchers, worlds = [], []
+    for k, depth in enumerate(depths):
+        opt = dict(branch_and_bound_depth=depth, full_resolution_depth=2, min_rotational_score=0.0,
+                   min_low_resolution_score=0.2, linear_xy_search_window=1.0,
+                   linear_z_search_window=0.4, angular_search_window=math.radians(10.0))
+        grid, world = synth.make_submap_3d(70 + k % 3, 0.2, (8.0, 8.0, 3.0), 4, 8, 96)
+        vox = grid.voxels()
+        matchers.append(sm3.FastCorrelativeScanMatcher3D(0.2, vox, grid.grid_size, 0.2, vox, hist,
+                                                         **opt))
+        worlds.append(world)
+    pos = worlds[0].free_position(200, 0.6)
+    hi = worlds[0].scan(pos, 0.0, 6, 64, seed=0)
+    data = sm3.TrajectoryNodeData(hi, hi[::5].copy(), hist,
+                                  tuple(quat_from_angle_axis(0.01, [1, 0, 0])))
+    return matchers, pos, data
+
+
+def _assert_same_results(expected, got):
+    for k, (e, g) in enumerate(zip(expected, got)):
+        assert (e is None) == (g is None), (k, e, g)
+        if e is None:
+            continue
+        for key in ("score", "rotational_score", "low_resolution_score"):
+            assert np.float32(e[key]) == np.float32(g[key]), (k, key, e, g)
+        assert e["pose_estimate"] == g["pose_estimate"], (k, e, g)
+
+
+@pytest.mark.parametrize("capacity", [None, "4096"])
+def test_fast3d_device_batch_mixed_depths_poses_and_overflow(sm3, synth, oracle, monkeypatch,
+                                                            capacity):
+    """Twelve pairs in one chain of launches: stacks of different depth (3 .. 6, one of depth 1:
+    that batch falls back to single searches), a different node pose per pair, windowed and
+    full-submap searches mixed -- pair by pair what the single calls return.  With the frontier
+    shrunk to 4096 nodes the shared lists overflow and every pair is repeated on its own
+    (strict retry inside)."""
+    depths = [5, 4, 6, 3, 5, 4, 6, 3, 5, 5, 4, 6]
+    matchers, pos, data = _fast3d_batch_scene(sm3, synth, depths)
+    ident = sm3.Rigid3d()
+    rng = np.random.default_rng(5)
+    nodes, fulls, thresholds = [], [], []
+    for k in range(len(depths)):
+        d = rng.uniform(-0.3, 0.3, 3) * np.array([1.0, 1.0, 0.3])
+        nodes.append(sm3.Rigid3d(tuple(pos + d),
+                                 tuple(quat_from_angle_axis(rng.uniform(-0.1, 0.1), [0, 0, 1]))))
+        fulls.append(k % 5 == 3)
+        thresholds.append([0.12, 0.3, 0.99][k % 3] if k % 4 else 0.12)
+    expected = []
+    for m, node, full, t in zip(matchers, nodes, fulls, thresholds):
+        expected.append(m.match_full_submap(node.rotation, ident.rotation, data, t) if full
+                        else m.match(node, ident, data, t))
+    assert any(e is not None for e in expected) and any(e is None for e in expected)
+    if capacity:
+        monkeypatch.setenv("CMX_FRONTIER_CAPACITY", capacity)
+    got, stats = sm3.fast3d_match_batch(matchers, nodes, [ident] * len(depths), fulls, thresholds,
+                                        data)
+    _assert_same_results(expected, got)
+    assert stats["num_scans"] > 0
+    if capacity is None:
+        # a depth-1 stack in the batch: leaf verification path, searched one by one
+        matchers1, _, _ = _fast3d_batch_scene(sm3, synth, [1, 4])
+        exp1 = [m.match(nodes[0], ident, data, 0.12) for m in matchers1]
+        got1, _ = sm3.fast3d_match_batch(matchers1, [nodes[0]] * 2, [ident] * 2, [False] * 2,
+                                         [0.12] * 2, data)
+        _assert_same_results(exp1, got1)
