@@ -114,10 +114,11 @@ __global__ void BuildPlanesKernel(const uint8_t* __restrict__ level, int wx, int
   }
 }
 
-// quads[(y + w) * qx + (x + w)] = level(x, y) | level(x, y+w) << 8 | level(x+w, y) << 16 |
+// quads(x + w, y + w) = level(x, y) | level(x, y+w) << 8 | level(x+w, y) << 16 |
 // level(x+w, y+w) << 24 for x in [-w, wx), y in [-w, wy); cells outside the level read 0.
+// Tiled storage: QuadOffset (scan_matching_2d.h).
 __global__ void BuildQuadsKernel(const uint8_t* __restrict__ level, int wx, int wy, int w,
-                                 uint32_t* __restrict__ quads, int qx, int qy) {
+                                 uint32_t* __restrict__ quads, int qx, int qy, int qtx) {
   const int X = blockIdx.x * blockDim.x + threadIdx.x;
   const int Y = blockIdx.y;
   if (X >= qx) return;
@@ -127,7 +128,7 @@ __global__ void BuildQuadsKernel(const uint8_t* __restrict__ level, int wx, int 
             static_cast<unsigned>(cy) < static_cast<unsigned>(wy))
                ? level[cx + cy * wx] : 0u;
   };
-  quads[static_cast<size_t>(Y) * qx + X] =
+  quads[QuadOffset(X, Y, qtx)] =
       at(x, y) | (at(x, y + w) << 8) | (at(x + w, y) << 16) | (at(x + w, y + w) << 24);
 }
 
@@ -1119,7 +1120,7 @@ __device__ __forceinline__ void ScoreChildren(const BlockContext& ctx, int dx, i
                           static_cast<unsigned>(Y) < static_cast<unsigned>(L.qy);
       // Unconditional load from a clamped (always valid) offset, masked afterwards: the
       // gathers of the unrolled loop are in flight together.
-      const uint32_t q = quads[inside ? Y * L.qx + X : 0];
+      const uint32_t q = quads[inside ? QuadOffset(X, Y, L.qtx) : 0u];
       const uint32_t v = inside ? (q & child_mask) : 0u;
       even += v & 0x00ff00ffu;          // byte 0 (x0,y0) and byte 2 (x1,y0)
       odd += (v >> 8) & 0x00ff00ffu;    // byte 1 (x0,y1) and byte 3 (x1,y1)
@@ -1319,7 +1320,7 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
         const int Y = static_cast<short>(p >> 16) + nd.dy + off + half;
         const bool inside = live && static_cast<unsigned>(X) < static_cast<unsigned>(L.qx) &&
                             static_cast<unsigned>(Y) < static_cast<unsigned>(L.qy);
-        const uint32_t quad = quads[inside ? Y * L.qx + X : 0];   // one gather, four children
+        const uint32_t quad = quads[inside ? QuadOffset(X, Y, L.qtx) : 0u];   // one gather, four children
         v[u] = inside ? (quad & child_mask) : 0u;
       }
 #pragma unroll
@@ -1773,12 +1774,13 @@ Fast2DMatcher::Fast2DMatcher(const cmx_fast2d_options& options, const cmx_grid2d
       const int w = 1 << i;
       levels_[i].qx = levels_[i].wx + w;
       levels_[i].qy = levels_[i].wy + w;
+      levels_[i].qtx = (levels_[i].qx + 7) / 8;
       quad_off[i] = quad_total;
-      quad_total += (static_cast<size_t>(levels_[i].qx) * levels_[i].qy * sizeof(uint32_t) + 255) &
-                    ~size_t(255);
+      // whole tiles of 32 dwords (128 bytes)
+      quad_total += static_cast<size_t>(levels_[i].qtx) * ((levels_[i].qy + 3) / 4) * 128;
     }
     levels_[depth - 1].quads = nullptr;
-    levels_[depth - 1].qx = levels_[depth - 1].qy = 0;
+    levels_[depth - 1].qx = levels_[depth - 1].qy = levels_[depth - 1].qtx = 0;
     if (quad_total) {
       CMX_HIP(hipMalloc(&quads_mem_, quad_total));
       for (int i = 0; i + 1 < depth; ++i) {
@@ -1786,7 +1788,7 @@ Fast2DMatcher::Fast2DMatcher(const cmx_fast2d_options& options, const cmx_grid2d
         uint32_t* q = reinterpret_cast<uint32_t*>(static_cast<char*>(quads_mem_) + quad_off[i]);
         L.quads = q;
         BuildQuadsKernel<<<dim3(DivUp(L.qx, 256), L.qy), 256, 0, ws->stream>>>(
-            L.cells, L.wx, L.wy, 1 << i, q, L.qx, L.qy);
+            L.cells, L.wx, L.wy, 1 << i, q, L.qx, L.qy, L.qtx);
       }
     }
   }

@@ -552,8 +552,6 @@ cmx_status cmx_compute_histogram(const float* point_cloud_xyz, int32_t num_point
     int* is_head = reinterpret_cast<int*>(take(4 * N));
     int* slice_rank = reinterpret_cast<int*>(take(4 * N));
     int* slice_begin = reinterpret_cast<int*>(take(4 * N));
-    int* bucket = reinterpret_cast<int*>(take(4 * N));
-    float* value = reinterpret_cast<float*>(take(4 * N));
     float* d_hist = reinterpret_cast<float*>(take(4 * static_cast<size_t>(histogram_size)));
     base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(base) + 255) & ~uintptr_t(255));
     void* temp = base;

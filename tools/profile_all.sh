@@ -13,6 +13,6 @@ $P ${TAG}_c1    "python bench.py --config c1 --steps 6 --warmup 2 --no-cpu-basel
     "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT"
 $P ${TAG}_c3    "python bench.py --config c3 --submaps 16 --steps 3 --warmup 1 --no-cpu-baseline" FETCH_SIZE WRITE_SIZE
 $P ${TAG}_c4    "python bench.py --config c4 --steps 1 --warmup 1 --no-cpu-baseline" FETCH_SIZE WRITE_SIZE
-$P ${TAG}_c5    "python bench.py --config c5 --submaps 4 --steps 3 --warmup 1 --no-cpu-baseline" FETCH_SIZE WRITE_SIZE
+$P ${TAG}_c5    "python bench.py --config c5 --submaps 32 --steps 3 --warmup 1 --no-cpu-baseline" FETCH_SIZE WRITE_SIZE
 $P ${TAG}_other "python tools/family_probe.py" FETCH_SIZE WRITE_SIZE
 ls -la gpurun_out/${TAG}*kernel_stats.csv
