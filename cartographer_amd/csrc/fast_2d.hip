@@ -1267,9 +1267,22 @@ FilterCoarseKernel(const Fast2DProblem* __restrict__ problems,
 // hold thousands of nodes most of which die after one expansion, so what
 // matters there is how many nodes are in flight, not the latency of one.
 // Children that can still matter go to `out`; child_level is always >= 1 here.
+constexpr int kWaveStatProblems = 1024;   // problems whose work counters a block keeps in LDS
+
+template <int kIters>
 __global__ void __launch_bounds__(256)
 ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restrict__ states,
                  int n, NodeList in, int strict, NodeList out, Counters* __restrict__ counters) {
+  // Work counters (candidates scored / nodes expanded per problem) are collected in LDS and
+  // flushed once per block: one global atomic pair PER NODE -- half a million nodes of 16
+  // problems hammering 32 cache lines -- was 64 % of this kernel on a 16-submap batch
+  // (3.36 -> 1.21 ms, profiles/r02_c3_wave_atomics.txt).
+  __shared__ unsigned stat_scored[kWaveStatProblems], stat_expanded[kWaveStatProblems];
+  for (int i = threadIdx.x; i < kWaveStatProblems; i += blockDim.x) {
+    stat_scored[i] = 0;
+    stat_expanded[i] = 0;
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int max_count = ListMaxCount(in);
@@ -1305,9 +1318,8 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
         (vx ? 0xffffffffu : 0x0000ffffu) & (vy ? 0xffffffffu : 0x00ff00ffu);
     int s00 = 0, s01 = 0, s10 = 0, s11 = 0, seen_max = 0;
     bool dead = false;
-    // 64-point iterations gathered between two bound checks (16, i.e. everything in
-    // flight at once, was no faster even for single searches: 37 vs 33 us).
-    constexpr int kIters = 4;
+    // kIters 64-point iterations are gathered between two bound checks (16, i.e. everything
+    // in flight at once, was no faster even for single searches: 37 vs 33 us).
     constexpr int kGroup = kIters * kWave;
     for (int q0 = 0; q0 < n; q0 += kGroup) {
       uint32_t v[kIters];
@@ -1337,13 +1349,18 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
         if (ToScore(P, reach + rest, n) < best) { dead = true; break; }
       }
     }
-    if (dead) {   // every child provably below the bound: counted, not kept
-      if (lane == 0) {
-        const int nvalid = (1 + (vx ? 1 : 0)) * (1 + (vy ? 1 : 0));
+    const auto count_node = [&](int nvalid) {     // lane 0
+      if (problem < kWaveStatProblems) {
+        atomicAdd(&stat_scored[problem], static_cast<unsigned>(nvalid));
+        atomicAdd(&stat_expanded[problem], 1u);
+      } else {
         atomicAdd(&st.scored_shard[out_sub & (kStatShards - 1)],
                   static_cast<unsigned long long>(nvalid));
         atomicAdd(&st.expanded_shard[out_sub & (kStatShards - 1)], 1ull);
       }
+    };
+    if (dead) {   // every child provably below the bound: counted, not kept
+      if (lane == 0) count_node((1 + (vx ? 1 : 0)) * (1 + (vy ? 1 : 0)));
       continue;
     }
     const int total[4] = {WaveSum(s00), WaveSum(s01), WaveSum(s10), WaveSum(s11)};
@@ -1368,9 +1385,7 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
       cs.rank[k] = rank;
     }
     if (lane == 0) {
-      atomicAdd(&st.scored_shard[out_sub & (kStatShards - 1)],
-                static_cast<unsigned long long>(nvalid));
-      atomicAdd(&st.expanded_shard[out_sub & (kStatShards - 1)], 1ull);
+      count_node(nvalid);
       int keep_mask = 0, m = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -1391,6 +1406,15 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
         }
       }
     }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kWaveStatProblems; i += blockDim.x) {
+    if (stat_expanded[i] == 0) continue;
+    ProblemState& st = states[i];
+    atomicAdd(&st.scored_shard[blockIdx.x & (kStatShards - 1)],
+              static_cast<unsigned long long>(stat_scored[i]));
+    atomicAdd(&st.expanded_shard[blockIdx.x & (kStatShards - 1)],
+              static_cast<unsigned long long>(stat_expanded[i]));
   }
 }
 
@@ -2302,9 +2326,26 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
         // Wave-per-node level-synchronous expansion of the (wide, shallow-lived)
         // top levels.
         for (int used = 0; used < wave_levels && top - 1 >= 1; ++used, --top, ++stage) {
-          ExpandWaveKernel<<<used == 0 ? wide_blocks : narrow_blocks, 256, 0, ws.stream>>>(
-              batch.d_problems, batch.d_states, n, front(stage), strict, front(stage + 1),
-              d_counters);
+          // Points gathered between two bound checks: batches are bound by the gather path
+          // and most of their frontier dies at the first check, so they check early.
+          static const int kWaveIters = [] {
+            const char* e = getenv("CMX_WAVE_ITERS");
+            return e ? atoi(e) : 0;
+          }();
+          const int iters = kWaveIters > 0 ? kWaveIters : (num < 4 ? 4 : 2);
+          const int wave_grid = used == 0 ? wide_blocks : narrow_blocks;
+          if (iters == 1)
+            ExpandWaveKernel<1><<<wave_grid, 256, 0, ws.stream>>>(
+                batch.d_problems, batch.d_states, n, front(stage), strict, front(stage + 1),
+                d_counters);
+          else if (iters == 2)
+            ExpandWaveKernel<2><<<wave_grid, 256, 0, ws.stream>>>(
+                batch.d_problems, batch.d_states, n, front(stage), strict, front(stage + 1),
+                d_counters);
+          else
+            ExpandWaveKernel<4><<<wave_grid, 256, 0, ws.stream>>>(
+                batch.d_problems, batch.d_states, n, front(stage), strict, front(stage + 1),
+                d_counters);
           mark("wave");
         }
         // Block-per-node depth-first stages of kLevelsPerStage levels: the bushy

@@ -373,7 +373,22 @@ struct ExpandShared {
   float low_prob[kLowChunk];
   Node3D next;       // dive: the child the descent continues with
   int has_next;
+  // Work counters of this block (flushed once by FlushWork3D: a global atomic pair per node
+  // was most of the 2D wave stage's time, profiles/r02_c3_wave_atomics.txt).
+  unsigned scored, expanded;
 };
+
+__device__ __forceinline__ void InitWork3D(ExpandShared* sh) {
+  if (threadIdx.x == 0) { sh->scored = 0; sh->expanded = 0; }
+  __syncthreads();
+}
+__device__ __forceinline__ void FlushWork3D(ExpandShared* sh, Counters3* __restrict__ counters) {
+  __syncthreads();
+  if (threadIdx.x == 0 && sh->expanded) {
+    atomicAdd(&counters->scored[blockIdx.x & 15], static_cast<unsigned long long>(sh->scored));
+    atomicAdd(&counters->expanded[blockIdx.x & 15], static_cast<unsigned long long>(sh->expanded));
+  }
+}
 
 // Expansion of one node by the whole block (see above).  dive = 0: children that can still
 // matter are appended to `out`; dive = 1: the best child is left in sh->next.
@@ -498,8 +513,8 @@ __device__ __forceinline__ void ExpandNode3D(const Fast3DProblem& P, const Node3
       rank[k] = r;
     }
     if (threadIdx.x == 0) {
-      atomicAdd(&counters->scored[sub_id & 15], static_cast<unsigned long long>(nvalid));
-      atomicAdd(&counters->expanded[sub_id & 15], 1ull);
+      sh->scored += static_cast<unsigned>(nvalid);
+      sh->expanded += 1u;
     }
     auto make_child = [&](int k) {
       Node3D child = nd;
@@ -581,6 +596,7 @@ __global__ void __launch_bounds__(256)
 Expand3DKernel(const Fast3DProblem* __restrict__ problems, List3 in, int strict, List3 out,
                List3 leaves, Counters3* __restrict__ counters) {
   __shared__ ExpandShared sh;
+  InitWork3D(&sh);
   const int max_count = ListMax3(in);
   for (int i = blockIdx.x; i < max_count * kSubLists3; i += gridDim.x) {
     const int in_sub = i & (kSubLists3 - 1), j = i / kSubLists3;
@@ -597,6 +613,7 @@ Expand3DKernel(const Fast3DProblem* __restrict__ problems, List3 in, int strict,
     if (strict ? !(nd.score > best) : (nd.score < best)) continue;
     ExpandNode3D(P, nd, best, 0, strict, out, leaves, counters, sub_id, &sh);
   }
+  FlushWork3D(&sh, counters);
 }
 
 // Greedy descents (always the best child) from the seeds, one block per seed, all levels in
@@ -609,6 +626,7 @@ Dive3DKernel(const Fast3DProblem* __restrict__ problems, List3 leaves,
   const Fast3DProblem& P = problems[blockIdx.y];
   const List3 seeds{P.seeds, P.seed_count, kSeeds3};
   if (static_cast<int>(blockIdx.x) >= min(seeds.counts[0], seeds.sub_capacity)) return;
+  InitWork3D(&sh);
   Node3D nd = seeds.nodes[blockIdx.x];
   const int sub_id = (blockIdx.x + 7 * blockIdx.y) & (kSubLists3 - 1);
   while (nd.level >= 1) {
@@ -617,6 +635,7 @@ Dive3DKernel(const Fast3DProblem* __restrict__ problems, List3 leaves,
     nd = sh.next;
     __syncthreads();   // everyone has read sh.next before the next expansion resets it
   }
+  FlushWork3D(&sh, counters);
 }
 
 struct Best3 {

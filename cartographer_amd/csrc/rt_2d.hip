@@ -965,18 +965,27 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
     // SearchParameters on the cloud pre-rotated by the initial yaw (:123-130).
     const float ha0 = 0.5f * static_cast<float>(it.initial->theta);
     const float q0w = std::cos(ha0), q0z = std::sin(ha0) * 1.f;
-    float max_scan_range = 3.f * res;
-    for (int i = 0; i < n; ++i) {
-      // Same rotation as the device applies (Eigen operation order), f32.
-      const float px = it.xyz[3 * i], py = it.xyz[3 * i + 1], pz = it.xyz[3 * i + 2];
-      const float qx = 0.f, qy = 0.f;
-      float uvx = qy * pz - q0z * py, uvy = q0z * px - qx * pz, uvz = qx * py - qy * px;
-      uvx += uvx; uvy += uvy; uvz += uvz;
-      const float cxx = qy * uvz - q0z * uvy, cyy = q0z * uvx - qx * uvz;
-      const float rx = ((px + q0w * uvx) + cxx) + 0.f, ry = ((py + q0w * uvy) + cyy) + 0.f;
-      const float range = std::sqrt(rx * rx + ry * ry);
-      max_scan_range = std::max(range, max_scan_range);
-    }
+    // Longest xy range of the cloud pre-rotated by the initial yaw (:123-130, :27-36).  The
+    // rotation is the device's RotateZ (cmx_device.h: bit-identical to Eigen's product by
+    // (w, 0, 0, z) for finite inputs); sqrt is monotone and correctly rounded, so the maximum
+    // of the norms is the norm of the largest squared norm.  Four independent maxima keep the
+    // loop free of a serial dependency (this runs once per scan on the host: ~1 us).
+    float max_sq[4] = {0.f, 0.f, 0.f, 0.f};
+    const auto squared_range = [q0w, q0z](const float* p) {
+      float uvx = -(q0z * p[1]), uvy = q0z * p[0];
+      uvx += uvx; uvy += uvy;
+      const float cxx = -(q0z * uvy), cyy = q0z * uvx;
+      const float rx = (p[0] + q0w * uvx) + cxx, ry = (p[1] + q0w * uvy) + cyy;
+      return rx * rx + ry * ry;
+    };
+    int i = 0;
+    for (; i + 4 <= n; i += 4)
+      for (int k = 0; k < 4; ++k)
+        max_sq[k] = std::max(max_sq[k], squared_range(it.xyz + 3 * (i + k)));
+    for (; i < n; ++i) max_sq[0] = std::max(max_sq[0], squared_range(it.xyz + 3 * i));
+    const float max_scan_range =
+        std::max(static_cast<float>(3.f * res),
+                 std::sqrt(std::max(std::max(max_sq[0], max_sq[1]), std::max(max_sq[2], max_sq[3]))));
     const double kSafetyMargin = 1. - 1e-3;
     const float range_sq = max_scan_range * (max_scan_range * 1.f);
     pl.step = kSafetyMargin * std::acos(1. - (res * (res * 1.)) / (2. * range_sq));

@@ -149,6 +149,35 @@ def rt2d_match_batch(options, grids, initial_pose_estimates, point_clouds):
     return (scores, [Rigid2d(p.x, p.y, p.theta) for p in poses], stats.as_dict())
 
 
+class Rt2DBatch:
+    """The argument arrays of cmx_rt2d_match_grid_batch, built once: what a C++ caller holds
+    anyway (one resident grid and one scan buffer per trajectory / robot).  `match(poses)` takes
+    the initial pose estimates as an (n, 3) float64 array (x, y, theta) and returns
+    (scores, poses as an (n, 3) array, stats)."""
+
+    def __init__(self, options, grids, point_clouds):
+        if isinstance(options, RealTimeCorrelativeScanMatcher2D):
+            options = options.options
+        self.options = options
+        self.num = len(grids)
+        self._grids = list(grids)                                  # keep the handles alive
+        self._clouds = [_cloud(c)[0] for c in point_clouds]
+        self._handles = (C.c_void_p * self.num)(*[g._h for g in grids])
+        self._cloud_ptrs = (C.c_void_p * self.num)(*[c.ctypes.data for c in self._clouds])
+        self._counts = np.array([c.shape[0] for c in self._clouds], np.int32)
+        self._scores = np.zeros(self.num, np.float64)
+        self._poses = np.zeros((self.num, 3), np.float64)          # cmx_pose2d[num]
+        self._stats = MatchStats()
+        self._fn = _lib.lib().cmx_rt2d_match_grid_batch
+
+    def match(self, initial_pose_estimates):
+        init = np.ascontiguousarray(initial_pose_estimates, np.float64).reshape(self.num, 3)
+        check(self._fn(C.byref(self.options), self._handles, self.num, init.ctypes.data,
+                       self._cloud_ptrs, self._counts.ctypes.data, self._scores.ctypes.data,
+                       self._poses.ctypes.data, C.byref(self._stats)))
+        return self._scores, self._poses, self._stats.as_dict()
+
+
 class PointCloudOnDevice:
     """A point cloud uploaded once (cmx_cloud) for repeated resident matches."""
 

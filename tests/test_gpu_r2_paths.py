@@ -170,6 +170,15 @@ def test_rt2d_batch_on_resident_grids_both_paths(sm, oracle, synth, monkeypatch)
             assert scores[k] == ref["score"], (bulk, k)
             np.testing.assert_allclose([poses[k].x, poses[k].y, poses[k].theta], ref["pose"],
                                        rtol=0, atol=1e-12)
+    # the prepared form of the same call (argument arrays built once), twice in a row
+    batch = sm.Rt2DBatch(m, grids, scans)
+    init = np.array([[p.x, p.y, p.theta] for p in inits])
+    for _ in range(2):
+        scores, poses, stats = batch.match(init)
+        assert stats["candidates_scored"] > 0
+        for k, ref in enumerate(refs):
+            assert scores[k] == ref["score"], k
+            np.testing.assert_allclose(poses[k], ref["pose"], rtol=0, atol=1e-12)
 
 
 # ----------------------------------------------------------------------------
