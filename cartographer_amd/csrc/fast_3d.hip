@@ -357,6 +357,96 @@ __device__ __forceinline__ float LowResolutionScore(const Fast3DProblem& P, cons
   return acc / static_cast<float>(P.n_low);
 }
 
+// CMX_FAST3D_WIDE=0 (tools / tests): every child cell with its own byte load.
+__device__ int g_fast3d_byte_loads = 0;
+
+// Integer sums of the <= 8 children of `nd` over the points first, first + stride, ...
+// (ScoreCandidates at the child level, :332-355): the eight child cells of a point are addressed
+// from per-axis clamped offsets (two positions per axis), loads of several points in flight.
+__device__ __forceinline__ void ChildSums3D(const Fast3DProblem& P, const Node3D& nd, int first,
+                                            int stride, int sum[8]) {
+  {
+    const int child_depth = nd.level - 1;
+    const int half = 1 << child_depth;
+    const int e = max(0, child_depth - P.full_resolution_depth + 1);
+    const Brick L = P.level[child_depth];
+    const uint8_t* __restrict__ cells8 = static_cast<const uint8_t*>(L.cells);
+    const int4* __restrict__ cells = P.cells + static_cast<size_t>(nd.scan) * P.n;
+    // Shifted offsets of the 2 positions per axis, relative to the brick origin.
+    const int fx[2] = {(nd.ox >> e) - L.lo_x, ((nd.ox + half) >> e) - L.lo_x};
+    const int fy[2] = {(nd.oy >> e) - L.lo_y, ((nd.oy + half) >> e) - L.lo_y};
+    const int fz[2] = {(nd.oz >> e) - L.lo_z, ((nd.oz + half) >> e) - L.lo_z};
+    const int row = L.nx, slab = L.nx * L.ny;
+    // The two x positions of a point lie dx = fx[1] - fx[0] cells apart in one row (1, 2 or 4
+    // for the usual full_resolution_depth <= 3).  Up to dx == 4 ONE aligned 8-byte load serves
+    // both: half the gather instructions of the search, which are what bounds it.
+    const int dx = fx[1] - fx[0];
+    if (dx <= 4 && !g_fast3d_byte_loads) {
+#pragma unroll 2
+      for (int q = first; q < P.n; q += stride) {
+        const int3 d = DepthIndex(cells[q], e, -P.wxy, -P.wxy, -P.wz);
+        const int ix0 = d.x + fx[0], ix1 = ix0 + dx;
+        const bool okx0 = static_cast<unsigned>(ix0) < static_cast<unsigned>(L.nx);
+        const bool okx1 = static_cast<unsigned>(ix1) < static_cast<unsigned>(L.nx);
+        const int base = min(max(ix0, 0), L.nx - 1);   // first byte wanted (when any is)
+        int ay[2], az[2];
+        bool oky[2], okz[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int iy = d.y + fy[b], iz = d.z + fz[b];
+          oky[b] = static_cast<unsigned>(iy) < static_cast<unsigned>(L.ny);
+          okz[b] = static_cast<unsigned>(iz) < static_cast<unsigned>(L.nz);
+          ay[b] = oky[b] ? iy * row : 0;
+          az[b] = okz[b] ? iz * slab : 0;
+        }
+        uint2 w[4];
+        unsigned j0[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {     // unconditional loads from in-range addresses
+          const unsigned a = static_cast<unsigned>(az[(k >> 1) & 1] + ay[k & 1] + base);
+          j0[k] = a & 3u;
+          w[k] = *reinterpret_cast<const uint2*>(cells8 + (a & ~3u));
+        }
+        const unsigned j1 = static_cast<unsigned>(ix1 - base);   // 0 .. 4 when okx1
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned b0 = j0[k], b1 = j0[k] + j1;             // byte indices, < 8
+          const unsigned v0 = ((b0 & 4u) ? w[k].y : w[k].x) >> (8u * (b0 & 3u)) & 0xffu;
+          const unsigned v1 = ((b1 & 4u) ? w[k].y : w[k].x) >> (8u * (b1 & 3u)) & 0xffu;
+          const bool okyz = oky[k & 1] && okz[(k >> 1) & 1];
+          sum[2 * k] += (okx0 && okyz) ? v0 : 0u;
+          sum[2 * k + 1] += (okx1 && okyz) ? v1 : 0u;
+        }
+      }
+    } else {
+#pragma unroll 2
+    for (int q = first; q < P.n; q += stride) {
+      const int3 d = DepthIndex(cells[q], e, -P.wxy, -P.wxy, -P.wz);
+      // Per axis and position: in-range flag and (clamped) address term.
+      int ax[2], ay[2], az[2];
+      bool okx[2], oky[2], okz[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int ix = d.x + fx[b], iy = d.y + fy[b], iz = d.z + fz[b];
+        okx[b] = static_cast<unsigned>(ix) < static_cast<unsigned>(L.nx);
+        oky[b] = static_cast<unsigned>(iy) < static_cast<unsigned>(L.ny);
+        okz[b] = static_cast<unsigned>(iz) < static_cast<unsigned>(L.nz);
+        ax[b] = okx[b] ? ix : 0;
+        ay[b] = oky[b] ? iy * row : 0;
+        az[b] = okz[b] ? iz * slab : 0;
+      }
+      unsigned v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)    // unconditional loads from in-range addresses
+        v[k] = cells8[az[(k >> 2) & 1] + ay[(k >> 1) & 1] + ax[k & 1]];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        sum[k] += (okx[k & 1] && oky[(k >> 1) & 1] && okz[(k >> 2) & 1]) ? v[k] : 0u;
+    }
+    }
+  }
+}
+
 // One 256-thread block per node: scores the <=8 children (z outer, y, x inner with the
 // `break`s of :416-431), ranks them as the reference's stable descending sort does, then
 //   child depth > 0, full: children that can still matter go to `out`;
@@ -403,84 +493,9 @@ __device__ __forceinline__ void ExpandNode3D(const Fast3DProblem& P, const Node3
   {
     const int child_depth = nd.level - 1;
     const int half = 1 << child_depth;
-    const int e = max(0, child_depth - P.full_resolution_depth + 1);
-    const Brick L = P.level[child_depth];
-    const uint8_t* __restrict__ cells8 = static_cast<const uint8_t*>(L.cells);
-    const int4* __restrict__ cells = P.cells + static_cast<size_t>(nd.scan) * P.n;
     const bool vx = nd.ox + half <= P.wxy, vy = nd.oy + half <= P.wxy, vz = nd.oz + half <= P.wz;
-    // Shifted offsets of the 2 positions per axis, relative to the brick origin.
-    const int fx[2] = {(nd.ox >> e) - L.lo_x, ((nd.ox + half) >> e) - L.lo_x};
-    const int fy[2] = {(nd.oy >> e) - L.lo_y, ((nd.oy + half) >> e) - L.lo_y};
-    const int fz[2] = {(nd.oz >> e) - L.lo_z, ((nd.oz + half) >> e) - L.lo_z};
-    const int row = L.nx, slab = L.nx * L.ny;
     int sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // The two x positions of a point lie dx = fx[1] - fx[0] cells apart in one row (1, 2 or 4
-    // for the usual full_resolution_depth <= 3).  Up to dx == 4 ONE aligned 8-byte load serves
-    // both: half the gather instructions of the search, which are what bounds it.
-    const int dx = fx[1] - fx[0];
-    if (dx <= 4) {
-#pragma unroll 2
-      for (int q = threadIdx.x; q < P.n; q += 256) {
-        const int3 d = DepthIndex(cells[q], e, -P.wxy, -P.wxy, -P.wz);
-        const int ix0 = d.x + fx[0], ix1 = ix0 + dx;
-        const bool okx0 = static_cast<unsigned>(ix0) < static_cast<unsigned>(L.nx);
-        const bool okx1 = static_cast<unsigned>(ix1) < static_cast<unsigned>(L.nx);
-        const int base = min(max(ix0, 0), L.nx - 1);   // first byte wanted (when any is)
-        int ay[2], az[2];
-        bool oky[2], okz[2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int iy = d.y + fy[b], iz = d.z + fz[b];
-          oky[b] = static_cast<unsigned>(iy) < static_cast<unsigned>(L.ny);
-          okz[b] = static_cast<unsigned>(iz) < static_cast<unsigned>(L.nz);
-          ay[b] = oky[b] ? iy * row : 0;
-          az[b] = okz[b] ? iz * slab : 0;
-        }
-        uint2 w[4];
-        unsigned j0[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {     // unconditional loads from in-range addresses
-          const unsigned a = static_cast<unsigned>(az[(k >> 1) & 1] + ay[k & 1] + base);
-          j0[k] = a & 3u;
-          w[k] = *reinterpret_cast<const uint2*>(cells8 + (a & ~3u));
-        }
-        const unsigned j1 = static_cast<unsigned>(ix1 - base);   // 0 .. 4 when okx1
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const unsigned b0 = j0[k], b1 = j0[k] + j1;             // byte indices, < 8
-          const unsigned v0 = ((b0 & 4u) ? w[k].y : w[k].x) >> (8u * (b0 & 3u)) & 0xffu;
-          const unsigned v1 = ((b1 & 4u) ? w[k].y : w[k].x) >> (8u * (b1 & 3u)) & 0xffu;
-          const bool okyz = oky[k & 1] && okz[(k >> 1) & 1];
-          sum[2 * k] += (okx0 && okyz) ? v0 : 0u;
-          sum[2 * k + 1] += (okx1 && okyz) ? v1 : 0u;
-        }
-      }
-    } else {
-#pragma unroll 2
-    for (int q = threadIdx.x; q < P.n; q += 256) {
-      const int3 d = DepthIndex(cells[q], e, -P.wxy, -P.wxy, -P.wz);
-      // Per axis and position: in-range flag and (clamped) address term.
-      int ax[2], ay[2], az[2];
-      bool okx[2], oky[2], okz[2];
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int ix = d.x + fx[b], iy = d.y + fy[b], iz = d.z + fz[b];
-        okx[b] = static_cast<unsigned>(ix) < static_cast<unsigned>(L.nx);
-        oky[b] = static_cast<unsigned>(iy) < static_cast<unsigned>(L.ny);
-        okz[b] = static_cast<unsigned>(iz) < static_cast<unsigned>(L.nz);
-        ax[b] = okx[b] ? ix : 0;
-        ay[b] = oky[b] ? iy * row : 0;
-        az[b] = okz[b] ? iz * slab : 0;
-      }
-      unsigned v[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k)    // unconditional loads from in-range addresses
-        v[k] = cells8[az[(k >> 2) & 1] + ay[(k >> 1) & 1] + ax[k & 1]];
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        sum[k] += (okx[k & 1] && oky[(k >> 1) & 1] && okz[(k >> 2) & 1]) ? v[k] : 0u;
-    }
-    }
+    ChildSums3D(P, nd, threadIdx.x, 256, sum);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int total = WaveSum(sum[k]);
@@ -592,9 +607,10 @@ __device__ __forceinline__ void ExpandNode3D(const Fast3DProblem& P, const Node3
   }
 }
 
+// leaves_only != 0: nodes above the leaf level were expanded by ExpandWave3DKernel.
 __global__ void __launch_bounds__(256)
 Expand3DKernel(const Fast3DProblem* __restrict__ problems, List3 in, int strict, List3 out,
-               List3 leaves, Counters3* __restrict__ counters) {
+               List3 leaves, Counters3* __restrict__ counters, int leaves_only) {
   __shared__ ExpandShared sh;
   InitWork3D(&sh);
   const int max_count = ListMax3(in);
@@ -607,13 +623,110 @@ Expand3DKernel(const Fast3DProblem* __restrict__ problems, List3 in, int strict,
     // of blocks walk serially (measured: 0.9 us per node, chip idle).
     const int sub_id = (in_sub * 17 + j) & (kSubLists3 - 1);
     const Node3D nd = in.nodes[static_cast<size_t>(in_sub) * in.sub_capacity + j];
+    if (leaves_only && nd.level > 1) continue;                    // block-uniform
     const Fast3DProblem& P = problems[nd.problem];
-    const float best = __uint_as_float(
-        __hip_atomic_load(P.best_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    if (strict ? !(nd.score > best) : (nd.score < best)) continue;
+    // The bound moves while this kernel runs: ONE thread reads it and the block shares that
+    // value.  (Every thread reading it for itself let some threads skip a node that the
+    // others expanded -- barriers of different nodes then met, children were summed from a
+    // mixture of two nodes, and about one search in fifty returned a leaf that does not
+    // exist.  Present since round 1; found with tools/stress_fast3d.py.)
+    __syncthreads();
+    if (threadIdx.x == 0)
+      sh.score[0] = __uint_as_float(
+          __hip_atomic_load(P.best_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __syncthreads();
+    const float best = sh.score[0];
+    if (strict ? !(nd.score > best) : (nd.score < best)) continue;    // block-uniform
     ExpandNode3D(P, nd, best, 0, strict, out, leaves, counters, sub_id, &sh);
   }
   FlushWork3D(&sh, counters);
+}
+
+// One WAVEFRONT per node for the levels above the leaves (child depth >= 1): a node's
+// expansion is a chain of dependent memory round trips (node, problem, cells, bricks, list
+// slot) that 11 points per thread do not amortise, and a block per node keeps only 8 nodes in
+// flight per CU.  Four times as many nodes in flight, 43 points per lane.  Nodes whose children
+// are leaves stay with Expand3DKernel (the low-resolution matcher is a block-wide pass).
+__global__ void __launch_bounds__(256)
+ExpandWave3DKernel(const Fast3DProblem* __restrict__ problems, List3 in, int strict, List3 out,
+                   Counters3* __restrict__ counters) {
+  __shared__ unsigned work_scored, work_expanded;
+  if (threadIdx.x == 0) { work_scored = 0; work_expanded = 0; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int max_count = ListMax3(in);
+  for (int i = blockIdx.x * 4 + wave; i < max_count * kSubLists3; i += gridDim.x * 4) {
+    const int in_sub = i & (kSubLists3 - 1), j = i / kSubLists3;
+    if (j >= min(in.counts[in_sub], in.sub_capacity)) continue;   // wave-uniform
+    const int sub_id = (in_sub * 17 + j) & (kSubLists3 - 1);      // as Expand3DKernel
+    const Node3D nd = in.nodes[static_cast<size_t>(in_sub) * in.sub_capacity + j];
+    const int child_depth = nd.level - 1;
+    if (child_depth < 1) continue;                                // leaves: the block kernel
+    const Fast3DProblem& P = problems[nd.problem];
+    // (one lane's view of the moving bound for the whole wavefront, see Expand3DKernel)
+    const float best = __uint_as_float(__builtin_amdgcn_readfirstlane(
+        __hip_atomic_load(P.best_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+    if (strict ? !(nd.score > best) : (nd.score < best)) continue;    // wave-uniform
+    const int half = 1 << child_depth;
+    const bool vx = nd.ox + half <= P.wxy, vy = nd.oy + half <= P.wxy, vz = nd.oz + half <= P.wz;
+    int sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    ChildSums3D(P, nd, lane, kWave, sum);
+    float score[8];
+    int nvalid = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int total = WaveSum(sum[k]);
+      const bool valid = (!(k & 1) || vx) && (!(k & 2) || vy) && (!(k & 4) || vz);
+      score[k] = valid ? ToProbability(total, P.n) : -1.f;
+      nvalid += valid;
+    }
+    int keep_mask = 0, m = 0;
+    unsigned long long ranks = 0;       // 3 bits per child
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int r = 0;
+#pragma unroll
+      for (int o = 0; o < 8; ++o)
+        if (o != k && score[o] >= 0.f && (score[o] > score[k] || (score[o] == score[k] && o < k)))
+          ++r;
+      ranks |= static_cast<unsigned long long>(r) << (3 * k);
+      if (score[k] >= 0.f && !(strict ? !(score[k] > best) : (score[k] < best))) {
+        keep_mask |= 1 << k;
+        ++m;
+      }
+    }
+    if (lane == 0) {
+      atomicAdd(&work_scored, static_cast<unsigned>(nvalid));
+      atomicAdd(&work_expanded, 1u);
+    }
+    if (m == 0) continue;
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(&out.counts[sub_id], m);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    // Lane k writes child k (kept children are numbered in child order, like the block kernel).
+    if (lane < 8 && (keep_mask >> lane & 1)) {
+      const int k = lane;
+      const int before = __popc(keep_mask & ((1 << k) - 1));
+      Node3D child = nd;
+      child.level = child_depth;
+      child.ox = nd.ox + ((k & 1) ? half : 0);
+      child.oy = nd.oy + ((k & 2) ? half : 0);
+      child.oz = nd.oz + ((k & 4) ? half : 0);
+      float sc = score[0];
+#pragma unroll
+      for (int o = 1; o < 8; ++o) sc = (o == k) ? score[o] : sc;
+      child.score = sc;
+      child.path = nd.path | (((ranks >> (3 * k)) & 7ull) << (3 * child_depth));
+      if (!Push3(out, sub_id, slot + before, child)) counters->overflow = 1;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && work_expanded) {
+    atomicAdd(&counters->scored[blockIdx.x & 15], static_cast<unsigned long long>(work_scored));
+    atomicAdd(&counters->expanded[blockIdx.x & 15],
+              static_cast<unsigned long long>(work_expanded));
+  }
 }
 
 // Greedy descents (always the best child) from the seeds, one block per seed, all levels in
@@ -949,6 +1062,15 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
 
   lap("prepare");
   WorkspaceLease ws(device);
+  {
+    const char* e = getenv("CMX_FAST3D_WIDE");
+    const int byte_loads = e && e[0] == '0' ? 1 : 0;
+    static int uploaded = -1;              // (tools only: not meant to be toggled concurrently)
+    if (uploaded != byte_loads) {
+      CMX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fast3d_byte_loads), &byte_loads, sizeof(int)));
+      uploaded = byte_loads;
+    }
+  }
   float* d_hi = ws->dev[0].ReserveAs<float>(3 * static_cast<size_t>(n));
   float* d_low = ws->dev[1].ReserveAs<float>(3 * static_cast<size_t>(n_low));
   // per scan: pose rotation | rotation of GetPoseFromCandidate | translation + resolution
@@ -1127,9 +1249,22 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
         dbg("filter");
         mark("filter");
         int stage = 0;
+        // CMX_FAST3D_WAVE=0: every level on the block-per-node kernel (tests compare both).
+        const char* wave_env = getenv("CMX_FAST3D_WAVE");
+        const bool use_wave = !(wave_env && wave_env[0] == '0');
         for (int child = max_depth - 2; child >= 0; --child, ++stage) {
-          Expand3DKernel<<<blocks, 256, 0, ws->stream>>>(d_problems, front(stage), strict,
-                                                         front(stage + 1), leaf_list, d_counters);
+          // Stage `stage` holds nodes whose children are at depth <= child (shallower stacks of
+          // a mixed batch are further down already).  Above the leaves: one wavefront per
+          // node; leaf-level nodes (all of the last stage, and shallower stacks' in earlier
+          // ones): one block per node.
+          const bool wave_stage = use_wave && child >= 1;
+          if (wave_stage)
+            ExpandWave3DKernel<<<blocks, 256, 0, ws->stream>>>(d_problems, front(stage), strict,
+                                                               front(stage + 1), d_counters);
+          if (!wave_stage || min_depth < max_depth)
+            Expand3DKernel<<<blocks, 256, 0, ws->stream>>>(d_problems, front(stage), strict,
+                                                           front(stage + 1), leaf_list, d_counters,
+                                                           wave_stage ? 1 : 0);
           dbg("expand level");
           mark("expand");
         }
