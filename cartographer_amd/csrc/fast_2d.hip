@@ -1269,7 +1269,6 @@ FilterCoarseKernel(const Fast2DProblem* __restrict__ problems,
 // Children that can still matter go to `out`; child_level is always >= 1 here.
 constexpr int kWaveStatProblems = 1024;   // problems whose work counters a block keeps in LDS
 
-template <int kIters>
 __global__ void __launch_bounds__(256)
 ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restrict__ states,
                  int n, NodeList in, int strict, NodeList out, Counters* __restrict__ counters) {
@@ -1318,8 +1317,10 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
         (vx ? 0xffffffffu : 0x0000ffffu) & (vy ? 0xffffffffu : 0x00ff00ffu);
     int s00 = 0, s01 = 0, s10 = 0, s11 = 0, seen_max = 0;
     bool dead = false;
-    // kIters 64-point iterations are gathered between two bound checks (16, i.e. everything
-    // in flight at once, was no faster even for single searches: 37 vs 33 us).
+    // 64-point iterations gathered between two bound checks (1, 2 and 4 measure the same on a
+    // 16-submap batch; 16, i.e. everything in flight at once, was no faster for single
+    // searches: 37 vs 33 us).
+    constexpr int kIters = 4;
     constexpr int kGroup = kIters * kWave;
     for (int q0 = 0; q0 < n; q0 += kGroup) {
       uint32_t v[kIters];
@@ -2326,26 +2327,9 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
         // Wave-per-node level-synchronous expansion of the (wide, shallow-lived)
         // top levels.
         for (int used = 0; used < wave_levels && top - 1 >= 1; ++used, --top, ++stage) {
-          // Points gathered between two bound checks: batches are bound by the gather path
-          // and most of their frontier dies at the first check, so they check early.
-          static const int kWaveIters = [] {
-            const char* e = getenv("CMX_WAVE_ITERS");
-            return e ? atoi(e) : 0;
-          }();
-          const int iters = kWaveIters > 0 ? kWaveIters : (num < 4 ? 4 : 2);
-          const int wave_grid = used == 0 ? wide_blocks : narrow_blocks;
-          if (iters == 1)
-            ExpandWaveKernel<1><<<wave_grid, 256, 0, ws.stream>>>(
-                batch.d_problems, batch.d_states, n, front(stage), strict, front(stage + 1),
-                d_counters);
-          else if (iters == 2)
-            ExpandWaveKernel<2><<<wave_grid, 256, 0, ws.stream>>>(
-                batch.d_problems, batch.d_states, n, front(stage), strict, front(stage + 1),
-                d_counters);
-          else
-            ExpandWaveKernel<4><<<wave_grid, 256, 0, ws.stream>>>(
-                batch.d_problems, batch.d_states, n, front(stage), strict, front(stage + 1),
-                d_counters);
+          ExpandWaveKernel<<<used == 0 ? wide_blocks : narrow_blocks, 256, 0, ws.stream>>>(
+              batch.d_problems, batch.d_states, n, front(stage), strict, front(stage + 1),
+              d_counters);
           mark("wave");
         }
         // Block-per-node depth-first stages of kLevelsPerStage levels: the bushy

@@ -607,10 +607,12 @@ __device__ __forceinline__ void ExpandNode3D(const Fast3DProblem& P, const Node3
   }
 }
 
-// leaves_only != 0: nodes above the leaf level were expanded by ExpandWave3DKernel.
+// (One wavefront per node for the levels above the leaves -- four times as many nodes in
+// flight, 43 points per lane -- was measured and changed nothing: 5.26 vs 5.34 ms for 32 pairs;
+// a single pair got slower, 0.45 vs 0.41 ms.  Removed.)
 __global__ void __launch_bounds__(256)
 Expand3DKernel(const Fast3DProblem* __restrict__ problems, List3 in, int strict, List3 out,
-               List3 leaves, Counters3* __restrict__ counters, int leaves_only) {
+               List3 leaves, Counters3* __restrict__ counters) {
   __shared__ ExpandShared sh;
   InitWork3D(&sh);
   const int max_count = ListMax3(in);
@@ -623,7 +625,6 @@ Expand3DKernel(const Fast3DProblem* __restrict__ problems, List3 in, int strict,
     // of blocks walk serially (measured: 0.9 us per node, chip idle).
     const int sub_id = (in_sub * 17 + j) & (kSubLists3 - 1);
     const Node3D nd = in.nodes[static_cast<size_t>(in_sub) * in.sub_capacity + j];
-    if (leaves_only && nd.level > 1) continue;                    // block-uniform
     const Fast3DProblem& P = problems[nd.problem];
     // The bound moves while this kernel runs: ONE thread reads it and the block shares that
     // value.  (Every thread reading it for itself let some threads skip a node that the
@@ -640,93 +641,6 @@ Expand3DKernel(const Fast3DProblem* __restrict__ problems, List3 in, int strict,
     ExpandNode3D(P, nd, best, 0, strict, out, leaves, counters, sub_id, &sh);
   }
   FlushWork3D(&sh, counters);
-}
-
-// One WAVEFRONT per node for the levels above the leaves (child depth >= 1): a node's
-// expansion is a chain of dependent memory round trips (node, problem, cells, bricks, list
-// slot) that 11 points per thread do not amortise, and a block per node keeps only 8 nodes in
-// flight per CU.  Four times as many nodes in flight, 43 points per lane.  Nodes whose children
-// are leaves stay with Expand3DKernel (the low-resolution matcher is a block-wide pass).
-__global__ void __launch_bounds__(256)
-ExpandWave3DKernel(const Fast3DProblem* __restrict__ problems, List3 in, int strict, List3 out,
-                   Counters3* __restrict__ counters) {
-  __shared__ unsigned work_scored, work_expanded;
-  if (threadIdx.x == 0) { work_scored = 0; work_expanded = 0; }
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int max_count = ListMax3(in);
-  for (int i = blockIdx.x * 4 + wave; i < max_count * kSubLists3; i += gridDim.x * 4) {
-    const int in_sub = i & (kSubLists3 - 1), j = i / kSubLists3;
-    if (j >= min(in.counts[in_sub], in.sub_capacity)) continue;   // wave-uniform
-    const int sub_id = (in_sub * 17 + j) & (kSubLists3 - 1);      // as Expand3DKernel
-    const Node3D nd = in.nodes[static_cast<size_t>(in_sub) * in.sub_capacity + j];
-    const int child_depth = nd.level - 1;
-    if (child_depth < 1) continue;                                // leaves: the block kernel
-    const Fast3DProblem& P = problems[nd.problem];
-    // (one lane's view of the moving bound for the whole wavefront, see Expand3DKernel)
-    const float best = __uint_as_float(__builtin_amdgcn_readfirstlane(
-        __hip_atomic_load(P.best_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
-    if (strict ? !(nd.score > best) : (nd.score < best)) continue;    // wave-uniform
-    const int half = 1 << child_depth;
-    const bool vx = nd.ox + half <= P.wxy, vy = nd.oy + half <= P.wxy, vz = nd.oz + half <= P.wz;
-    int sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    ChildSums3D(P, nd, lane, kWave, sum);
-    float score[8];
-    int nvalid = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int total = WaveSum(sum[k]);
-      const bool valid = (!(k & 1) || vx) && (!(k & 2) || vy) && (!(k & 4) || vz);
-      score[k] = valid ? ToProbability(total, P.n) : -1.f;
-      nvalid += valid;
-    }
-    int keep_mask = 0, m = 0;
-    unsigned long long ranks = 0;       // 3 bits per child
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      int r = 0;
-#pragma unroll
-      for (int o = 0; o < 8; ++o)
-        if (o != k && score[o] >= 0.f && (score[o] > score[k] || (score[o] == score[k] && o < k)))
-          ++r;
-      ranks |= static_cast<unsigned long long>(r) << (3 * k);
-      if (score[k] >= 0.f && !(strict ? !(score[k] > best) : (score[k] < best))) {
-        keep_mask |= 1 << k;
-        ++m;
-      }
-    }
-    if (lane == 0) {
-      atomicAdd(&work_scored, static_cast<unsigned>(nvalid));
-      atomicAdd(&work_expanded, 1u);
-    }
-    if (m == 0) continue;
-    int slot = 0;
-    if (lane == 0) slot = atomicAdd(&out.counts[sub_id], m);
-    slot = __builtin_amdgcn_readfirstlane(slot);
-    // Lane k writes child k (kept children are numbered in child order, like the block kernel).
-    if (lane < 8 && (keep_mask >> lane & 1)) {
-      const int k = lane;
-      const int before = __popc(keep_mask & ((1 << k) - 1));
-      Node3D child = nd;
-      child.level = child_depth;
-      child.ox = nd.ox + ((k & 1) ? half : 0);
-      child.oy = nd.oy + ((k & 2) ? half : 0);
-      child.oz = nd.oz + ((k & 4) ? half : 0);
-      float sc = score[0];
-#pragma unroll
-      for (int o = 1; o < 8; ++o) sc = (o == k) ? score[o] : sc;
-      child.score = sc;
-      child.path = nd.path | (((ranks >> (3 * k)) & 7ull) << (3 * child_depth));
-      if (!Push3(out, sub_id, slot + before, child)) counters->overflow = 1;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0 && work_expanded) {
-    atomicAdd(&counters->scored[blockIdx.x & 15], static_cast<unsigned long long>(work_scored));
-    atomicAdd(&counters->expanded[blockIdx.x & 15],
-              static_cast<unsigned long long>(work_expanded));
-  }
 }
 
 // Greedy descents (always the best child) from the seeds, one block per seed, all levels in
@@ -1249,22 +1163,9 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
         dbg("filter");
         mark("filter");
         int stage = 0;
-        // CMX_FAST3D_WAVE=0: every level on the block-per-node kernel (tests compare both).
-        const char* wave_env = getenv("CMX_FAST3D_WAVE");
-        const bool use_wave = !(wave_env && wave_env[0] == '0');
         for (int child = max_depth - 2; child >= 0; --child, ++stage) {
-          // Stage `stage` holds nodes whose children are at depth <= child (shallower stacks of
-          // a mixed batch are further down already).  Above the leaves: one wavefront per
-          // node; leaf-level nodes (all of the last stage, and shallower stacks' in earlier
-          // ones): one block per node.
-          const bool wave_stage = use_wave && child >= 1;
-          if (wave_stage)
-            ExpandWave3DKernel<<<blocks, 256, 0, ws->stream>>>(d_problems, front(stage), strict,
-                                                               front(stage + 1), d_counters);
-          if (!wave_stage || min_depth < max_depth)
-            Expand3DKernel<<<blocks, 256, 0, ws->stream>>>(d_problems, front(stage), strict,
-                                                           front(stage + 1), leaf_list, d_counters,
-                                                           wave_stage ? 1 : 0);
+          Expand3DKernel<<<blocks, 256, 0, ws->stream>>>(d_problems, front(stage), strict,
+                                                         front(stage + 1), leaf_list, d_counters);
           dbg("expand level");
           mark("expand");
         }

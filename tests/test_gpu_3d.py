@@ -403,37 +403,6 @@ def _assert_same_results(expected, got):
         assert e["pose_estimate"] == g["pose_estimate"], (k, e, g)
 
 
-@pytest.mark.parametrize("wave", ["1", "0"])
-def test_fast3d_wave_and_block_expansion_agree_with_the_oracle(sm3, oracle, synth, monkeypatch,
-                                                               wave):
-    """Levels above the leaves are expanded one wavefront per node (CMX_FAST3D_WAVE=0: one block
-    per node, the round-1 kernel): same result as the oracle either way, on the C5-shaped submap
-    and on a small deep stack."""
-    monkeypatch.setenv("CMX_FAST3D_WAVE", wave)
-    size = (15.0, 15.0, 7.5)
-    grid, world = synth.make_submap_3d(42, 0.1, size, 8, 32, 512)
-    low, _ = synth.make_submap_3d(42, 0.45, size, 8, 32, 512)
-    vox, low_vox = grid.voxels(), low.voxels()
-    rng = np.random.default_rng(1)
-    hist = rng.uniform(0.0, 1.0, 120).astype(np.float32)
-    hist[10:14] += 6.0
-    pos = world.free_position(77, 0.6)
-    full = world.scan(pos, 0.4, 32, 512, seed=1)
-    hi, lo = full[::6].copy(), full[::80].copy()
-    scan_hist = np.roll(hist, -19).copy()
-    opt = dict(branch_and_bound_depth=8, full_resolution_depth=3, min_rotational_score=0.77,
-               min_low_resolution_score=0.35, linear_xy_search_window=5.0,
-               linear_z_search_window=1.0, angular_search_window=math.radians(15.0))
-    om, gm = _both(sm3, oracle, 0.1, vox, grid.grid_size, 0.45, low_vox, hist, **opt)
-    node = [pos[0] + 0.8, pos[1] - 0.6, pos[2] + 0.2] + quat_from_angle_axis(0.5, [0, 0, 1])
-    ident = [0, 0, 0, 1, 0, 0, 0]
-    ref = om.match(node, ident, [1, 0, 0, 0], hi, lo, scan_hist, 0.2)
-    got = gm.match(sm3.Rigid3d(tuple(node[:3]), tuple(node[3:])), sm3.Rigid3d(),
-                   sm3.TrajectoryNodeData(hi, lo, scan_hist), 0.2)
-    _assert_result(ref, got)
-    assert gm.last_stats["nodes_expanded"] > 0
-
-
 @pytest.mark.parametrize("capacity", [None, "4096"])
 def test_fast3d_device_batch_mixed_depths_poses_and_overflow(sm3, synth, oracle, monkeypatch,
                                                             capacity):
