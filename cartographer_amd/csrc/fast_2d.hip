@@ -1227,9 +1227,14 @@ __global__ void __launch_bounds__(256)
 FilterCoarseKernel(const Fast2DProblem* __restrict__ problems,
                    const ProblemState* __restrict__ states, int n, int chunk, int num_chunks,
                    int strict, NodeList out, Counters* __restrict__ counters) {
+  // One WAVEFRONT per rotated scan (grid: ceil(scans / 4) x problems): a scan's filter is a
+  // chain of dependent loads (problem, best candidate, dimensions, scores, list slot) over
+  // ~190 candidates; a block per scan kept 8 of those chains in flight per CU, and 36 k blocks
+  // of a 16-submap batch took 320 us to dispatch and drain.
   const int problem = blockIdx.y;
   const Fast2DProblem& P = problems[problem];
-  const int s = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (s >= P.num_scans || states[problem].error) return;
   if (s % num_chunks != chunk) return;
   const float best = __uint_as_float(states[problem].best_bits);
@@ -1238,15 +1243,27 @@ FilterCoarseKernel(const Fast2DProblem* __restrict__ problems,
   const int2 dims = P.coarse_dims[s];
   const int count = dims.x * dims.y;
   const int base = s * P.coarse_stride;
-  const int lane = threadIdx.x & 63;
-  for (int c0 = 0; c0 < count; c0 += blockDim.x) {
+  // The first 256 scores are fetched together (the passes below would otherwise be a chain of
+  // load -> ballot -> list reservation round trips).
+  const auto* scores = AsGlobal(P.coarse_score) + base;
+  float ahead[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ahead[k] = k * kWave + lane < count ? scores[k * kWave + lane] : 0.f;
+  for (int c0 = 0; c0 < count; c0 += kWave) {
     // One reservation per wave; consecutive waves use consecutive sub-lists, so that one
     // rotation's survivors do not all queue in the same one.
-    const int sub = (blockIdx.x + blockIdx.y + ((c0 + threadIdx.x) >> 6)) & (kSubLists - 1);
-    const int c = c0 + threadIdx.x;
+    const int sub = (s + blockIdx.y + (c0 >> 6)) & (kSubLists - 1);
+    const int c = c0 + lane;
     bool keep = false;
     if (c < count) {
-      const float score = AsGlobal(P.coarse_score)[base + c];
+      float score;
+      switch (c0 >> 6) {
+        case 0: score = ahead[0]; break;
+        case 1: score = ahead[1]; break;
+        case 2: score = ahead[2]; break;
+        case 3: score = ahead[3]; break;
+        default: score = scores[c];
+      }
       keep = strict ? (score > best) : (score >= best);
     }
     // One reservation per wave: slots go to the kept lanes in lane order.
@@ -2319,7 +2336,7 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
         if (chunk > 0 || strict)
           CMX_HIP(hipMemsetAsync(d_counters->frontier, 0, sizeof(d_counters->frontier),
                                  ws.stream));
-        FilterCoarseKernel<<<dim3(batch.max_scans, num), 256, 0, ws.stream>>>(
+        FilterCoarseKernel<<<dim3(DivUp(batch.max_scans, 4), num), 256, 0, ws.stream>>>(
             batch.d_problems, batch.d_states, n, chunk, num_chunks, strict, front(0), d_counters);
         mark("filter");
         int stage = 0;
