@@ -848,23 +848,36 @@ constexpr int kSubLists = 64;
 
 constexpr int kMaxStages = kMaxDepth + 2;   // one frontier counter array per search stage
 
+// Sub-list counters sit one per 128-byte line: returning atomics on words of the same line
+// queue behind each other in L2 (64 adjacent counters = 2 lines took every list reservation of
+// a batch through two queues).
+constexpr int kCountStride = 32;
 struct Counters {           // device, zeroed per call
-  int frontier[kMaxStages][kSubLists];
-  int leaves[kSubLists];
+  int frontier[kMaxStages][kSubLists * kCountStride];
+  int leaves[kSubLists * kCountStride];
   int frontier_overflow;
   int leaf_overflow;
   int pad[2];
 };
 
+// What the host needs of the counters, written next to the results by the last kernel of a
+// search (the padded Counters are 120 KB: not something to copy back per match).
+struct CountersSummary {
+  int leaves[kSubLists];
+  int frontier_total[kMaxStages];
+  int frontier_overflow;
+  int leaf_overflow;
+};
+
 struct NodeList {
   Node2D* nodes;      // [kSubLists][sub_capacity]
-  int* counts;        // [kSubLists]
+  int* counts;        // [kSubLists] at stride kCountStride
   int sub_capacity;
 };
 
 // Reserves `m` consecutive slots of sub-list `sub`; returns the first slot.
 __device__ __forceinline__ int ListReserve(const NodeList& list, int sub, int m) {
-  return atomicAdd(&list.counts[sub], m);
+  return atomicAdd(&list.counts[sub * kCountStride], m);
 }
 __device__ __forceinline__ bool ListStore(const NodeList& list, int sub, int slot,
                                           const Node2D& nd) {
@@ -875,7 +888,7 @@ __device__ __forceinline__ bool ListStore(const NodeList& list, int sub, int slo
 // Largest sub-list length (wave-uniform); every lane must call it.
 __device__ __forceinline__ int ListMaxCount(const NodeList& list) {
   const int lane = threadIdx.x & 63;
-  return WaveMax(min(list.counts[lane], list.sub_capacity));
+  return WaveMax(min(list.counts[lane * kCountStride], list.sub_capacity));
 }
 
 __device__ __forceinline__ int NodeProblem(const Node2D& nd) { return nd.problem & 0xffffff; }
@@ -1305,7 +1318,7 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
   const int out_sub = (blockIdx.x * 4 + wave) & (kSubLists - 1);
   for (int i = blockIdx.x * 4 + wave; i < max_count * kSubLists; i += gridDim.x * 4) {
     const int in_sub = i & (kSubLists - 1), j = i / kSubLists;
-    if (j >= in.counts[in_sub]) continue;   // wave-uniform
+    if (j >= in.counts[in_sub * kCountStride]) continue;   // wave-uniform
     const Node2D nd = in.nodes[static_cast<size_t>(in_sub) * in.sub_capacity + j];
     const int problem = NodeProblem(nd);
     const Fast2DProblem& P = problems[problem];
@@ -1461,7 +1474,7 @@ SubtreeKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restri
   const int out_sub = blockIdx.x & (kSubLists - 1);
   for (int i = blockIdx.x; i < max_count * kSubLists; i += gridDim.x) {
     const int in_sub = i & (kSubLists - 1), j = i / kSubLists;
-    if (j >= in.counts[in_sub]) continue;   // block-uniform
+    if (j >= in.counts[in_sub * kCountStride]) continue;   // block-uniform
     const Node2D root = in.nodes[static_cast<size_t>(in_sub) * in.sub_capacity + j];
     const int problem = NodeProblem(root);
     const Fast2DProblem& P = problems[problem];
@@ -1561,13 +1574,25 @@ struct SelectState {         // per problem, device
 __global__ void __launch_bounds__(1024)
 SelectBestKernel(NodeList leaves, const ProblemState* __restrict__ states,
                  SelectState* __restrict__ sel, BestLeaf* __restrict__ best, int num_problems,
-                 ProblemState* __restrict__ states_out) {
+                 ProblemState* __restrict__ states_out, const Counters* __restrict__ counters,
+                 CountersSummary* __restrict__ summary) {
   for (int p = threadIdx.x; p < num_problems; p += blockDim.x) states_out[p] = states[p];
+  if (threadIdx.x < kSubLists) summary->leaves[threadIdx.x] = counters->leaves[threadIdx.x * kCountStride];
+  if (threadIdx.x >= 64 && threadIdx.x < 64 + kMaxStages) {
+    const int st = threadIdx.x - 64;
+    int total = 0;
+    for (int k = 0; k < kSubLists; ++k) total += counters->frontier[st][k * kCountStride];
+    summary->frontier_total[st] = total;
+  }
+  if (threadIdx.x == 128) {
+    summary->frontier_overflow = counters->frontier_overflow;
+    summary->leaf_overflow = counters->leaf_overflow;
+  }
   const int max_count = ListMaxCount(leaves);
   const int total = max_count * kSubLists;
   auto leaf_at = [&](int i, Node2D* nd) {
     const int sub = i & (kSubLists - 1), j = i / kSubLists;
-    if (j >= min(leaves.counts[sub], leaves.sub_capacity)) return false;
+    if (j >= min(leaves.counts[sub * kCountStride], leaves.sub_capacity)) return false;
     *nd = leaves.nodes[static_cast<size_t>(sub) * leaves.sub_capacity + j];
     return true;
   };
@@ -2227,12 +2252,16 @@ struct ScoreIndex;
 void ResolveDepthOne(const PreparedBatch& batch, std::vector<BestLeaf>* best,
                      const std::vector<ProblemState>& states);
 void ResolveTies(Workspace& ws, const PreparedBatch& batch, const NodeList& leaves_dev,
-                 const Counters& h_counters, std::vector<BestLeaf>* best,
+                 const CountersSummary& h_counters, std::vector<BestLeaf>* best,
                  const std::vector<ProblemState>& states);
 
-size_t SearchMiscBytes(int num) {
-  return sizeof(Counters) + num * (sizeof(SelectState) + sizeof(BestLeaf) + sizeof(ProblemState));
+// d_misc: Counters | CountersSummary | SelectState[num] | BestLeaf[num] | ProblemState[num];
+// everything after the Counters travels back in one D2H.
+size_t SearchTailBytes(int num) {
+  return sizeof(CountersSummary) +
+         num * (sizeof(SelectState) + sizeof(BestLeaf) + sizeof(ProblemState));
 }
+size_t SearchMiscBytes(int num) { return sizeof(Counters) + SearchTailBytes(num); }
 void ReserveSearchScratch(Workspace& ws, int num, PreparedBatch* batch) {
   batch->d_misc = static_cast<char*>(ws.dev[14].Reserve(SearchMiscBytes(num)));
 }
@@ -2262,17 +2291,18 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
   Node2D* d_front[2] = {ws.dev[10].ReserveAs<Node2D>(kFrontierCapacity),
                         ws.dev[11].ReserveAs<Node2D>(kFrontierCapacity)};
   Node2D* d_leaves = ws.dev[12].ReserveAs<Node2D>(kLeafCapacity);
-  // Counters | SelectState[num] | BestLeaf[num] | ProblemState[num] (copy for the host):
-  // they travel back in ONE D2H.  Carved by ReserveSearchScratch before the first kernel
-  // of the call, which clears the counters.
+  // Carved by ReserveSearchScratch before the first kernel of the call, which clears the
+  // counters.
+  static_assert(sizeof(Counters) % 16 == 0 && sizeof(CountersSummary) % 8 == 0, "alignment");
   char* d_misc = batch.d_misc;
   Counters* d_counters = reinterpret_cast<Counters*>(d_misc);
-  SelectState* d_sel = reinterpret_cast<SelectState*>(d_misc + sizeof(Counters));
-  BestLeaf* d_best = reinterpret_cast<BestLeaf*>(d_misc + sizeof(Counters) +
+  char* d_tail = d_misc + sizeof(Counters);
+  CountersSummary* d_summary = reinterpret_cast<CountersSummary*>(d_tail);
+  SelectState* d_sel = reinterpret_cast<SelectState*>(d_tail + sizeof(CountersSummary));
+  BestLeaf* d_best = reinterpret_cast<BestLeaf*>(d_tail + sizeof(CountersSummary) +
                                                  num * sizeof(SelectState));
   ProblemState* d_states_out = reinterpret_cast<ProblemState*>(
-      d_misc + sizeof(Counters) + num * (sizeof(SelectState) + sizeof(BestLeaf)));
-  Counters* h_counters = nullptr;
+      d_tail + sizeof(CountersSummary) + num * (sizeof(SelectState) + sizeof(BestLeaf)));
   auto mark = [&](const char* name) { if (batch.trace) batch.trace->Mark(name); };
   // Stage k reads list k and appends to list k+1 (buffers ping-pong, counters
   // do not: they are all zeroed by the one memset above).
@@ -2281,17 +2311,16 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
   };
   const NodeList leaf_list = {d_leaves, d_counters->leaves, kLeafSub};
 
-  // One D2H for counters + selection state + best leaves (contiguous in d_misc).
-  const size_t misc_bytes =
-      sizeof(Counters) + num * (sizeof(SelectState) + sizeof(BestLeaf) + sizeof(ProblemState));
+  // One D2H for the counters' summary + selection state + best leaves.
+  const size_t misc_bytes = SearchTailBytes(num);
   char* h_misc = static_cast<char*>(ws.pinned[3].Reserve(misc_bytes));
-  h_counters = reinterpret_cast<Counters*>(h_misc);
-  BestLeaf* h_best = reinterpret_cast<BestLeaf*>(h_misc + sizeof(Counters) +
+  CountersSummary* h_counters = reinterpret_cast<CountersSummary*>(h_misc);
+  BestLeaf* h_best = reinterpret_cast<BestLeaf*>(h_misc + sizeof(CountersSummary) +
                                                  num * sizeof(SelectState));
   ProblemState* h_states = reinterpret_cast<ProblemState*>(
-      h_misc + sizeof(Counters) + num * (sizeof(SelectState) + sizeof(BestLeaf)));
+      h_misc + sizeof(CountersSummary) + num * (sizeof(SelectState) + sizeof(BestLeaf)));
   auto fetch_results = [&] {
-    CMX_HIP(hipMemcpyAsync(h_misc, d_misc, misc_bytes, hipMemcpyDeviceToHost, ws.stream));
+    CMX_HIP(hipMemcpyAsync(h_misc, d_tail, misc_bytes, hipMemcpyDeviceToHost, ws.stream));
     CMX_HIP(hipStreamSynchronize(ws.stream));
   };
 
@@ -2361,7 +2390,7 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
         }
       }
       SelectBestKernel<<<1, 1024, 0, ws.stream>>>(leaf_list, batch.d_states, d_sel, d_best, num,
-                                                  d_states_out);
+                                                  d_states_out, d_counters, d_summary);
       mark("select");
       CMX_HIP(hipGetLastError());
       CMX_HIP(hipEventRecord(ws.ev_end, ws.stream));
@@ -2388,13 +2417,11 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
 
   result->best.assign(h_best, h_best + num);
   result->states.assign(h_states, h_states + num);
-  if (batch.trace && batch.trace->enabled() && h_counters) {
+  if (batch.trace && batch.trace->enabled() && depth > 1) {
     fprintf(stderr, "[cmx trace] list sizes:");
-    for (int st = 0; st < kMaxStages; ++st) {
-      long long total = 0;
-      for (int k = 0; k < kSubLists; ++k) total += h_counters->frontier[st][k];
-      if (total) fprintf(stderr, " frontier[%d]=%lld", st, total);
-    }
+    for (int st = 0; st < kMaxStages; ++st)
+      if (h_counters->frontier_total[st])
+        fprintf(stderr, " frontier[%d]=%d", st, h_counters->frontier_total[st]);
     long long leaves = 0;
     for (int k = 0; k < kSubLists; ++k) leaves += h_counters->leaves[k];
     fprintf(stderr, " leaves=%lld\n", leaves);
@@ -2459,7 +2486,7 @@ std::vector<T> DownloadDense(const Fast2DProblem& P, const CoarseLayout& L, cons
 }
 
 void ResolveTies(Workspace& ws, const PreparedBatch& batch, const NodeList& leaves_dev,
-                 const Counters& h_counters, std::vector<BestLeaf>* best,
+                 const CountersSummary& h_counters, std::vector<BestLeaf>* best,
                  const std::vector<ProblemState>& states) {
   bool any = false;
   for (const BestLeaf& b : *best) any |= (b.found && b.ties > 1);

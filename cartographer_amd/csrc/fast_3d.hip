@@ -29,6 +29,10 @@ namespace cmx {
 namespace {
 
 constexpr int kSubLists3 = 64;
+// (Padding the sub-list counters to a cache line each, which took the 2D coarse filter from 323
+// to 30 us, measured nothing here -- a node's list reservation is once per block -- and cost
+// 40 us per single search in the larger counter copies.)
+constexpr int kCountStride3 = 1;
 constexpr int kSeeds3 = 64;
 
 struct Node3D {
@@ -44,9 +48,9 @@ struct Node3D {
 };
 
 struct Counters3 {
-  int frontier[kMaxDepth + 2][kSubLists3];
+  int frontier[kMaxDepth + 2][kSubLists3 * kCountStride3];
   int dive[2][kSubLists3];
-  int leaves[kSubLists3];
+  int leaves[kSubLists3 * kCountStride3];
   int overflow;
   int pad0;
   int pad1;
@@ -251,7 +255,7 @@ __device__ __forceinline__ bool Push3(const List3& list, int sub, int slot, cons
   return true;
 }
 __device__ __forceinline__ int ListMax3(const List3& list) {
-  return WaveMax(min(list.counts[threadIdx.x & 63], list.sub_capacity));
+  return WaveMax(min(list.counts[(threadIdx.x & 63) * kCountStride3], list.sub_capacity));
 }
 
 // Seeds of the dive: the ~64 best lowest-resolution candidates (histogram
@@ -325,7 +329,7 @@ Filter3DKernel(const Fast3DProblem* __restrict__ problems, int strict, int chunk
     if (c % num_chunks != chunk) continue;
     const float sc = P.coarse_score[c];
     if (strict ? (sc > best) : (sc >= best)) {
-      if (!Push3(out, sub, atomicAdd(&out.counts[sub], 1), CoarseNode3D(P, c)))
+      if (!Push3(out, sub, atomicAdd(&out.counts[sub * kCountStride3], 1), CoarseNode3D(P, c)))
         counters->overflow = 1;
     }
   }
@@ -569,7 +573,7 @@ __device__ __forceinline__ void ExpandNode3D(const Fast3DProblem& P, const Node3
           if (threadIdx.x == 0) {
             Node3D rec = leaf;
             rec.low_resolution_score = low;
-            if (!Push3(leaves, sub_id, atomicAdd(&leaves.counts[sub_id], 1), rec))
+            if (!Push3(leaves, sub_id, atomicAdd(&leaves.counts[sub_id * kCountStride3], 1), rec))
               counters->overflow = 1;
             atomicMax(P.best_bits, __float_as_uint(sc));
           }
@@ -594,7 +598,7 @@ __device__ __forceinline__ void ExpandNode3D(const Fast3DProblem& P, const Node3
         for (int k = 0; k < 8; ++k)
           if (keep_mask >> k & 1) { sh->next = make_child(k); sh->has_next = 1; }
       } else if (m) {
-        int slot = atomicAdd(&out.counts[sub_id], m);
+        int slot = atomicAdd(&out.counts[sub_id * kCountStride3], m);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           if (!(keep_mask >> k & 1)) continue;
@@ -618,7 +622,7 @@ Expand3DKernel(const Fast3DProblem* __restrict__ problems, List3 in, int strict,
   const int max_count = ListMax3(in);
   for (int i = blockIdx.x; i < max_count * kSubLists3; i += gridDim.x) {
     const int in_sub = i & (kSubLists3 - 1), j = i / kSubLists3;
-    if (j >= min(in.counts[in_sub], in.sub_capacity)) continue;   // block-uniform
+    if (j >= min(in.counts[in_sub * kCountStride3], in.sub_capacity)) continue;   // block-uniform
     // Children go to a sub-list derived from the node's slot, not from the block: the
     // survivors of a search cluster in a few subtrees, and appending them to their
     // parent's sub-list would leave the next level with one long list that a handful
@@ -693,7 +697,7 @@ SelectBest3DKernel(List3 leaves, const Fast3DProblem* __restrict__ problems,
   __syncthreads();
   auto leaf_at = [&](int i, Node3D* nd) {
     const int sub = i & (kSubLists3 - 1), j = i / kSubLists3;
-    if (j >= min(leaves.counts[sub], leaves.sub_capacity)) return false;
+    if (j >= min(leaves.counts[sub * kCountStride3], leaves.sub_capacity)) return false;
     *nd = leaves.nodes[static_cast<size_t>(sub) * leaves.sub_capacity + j];
     return nd->problem == problem;
   };
@@ -765,7 +769,7 @@ VerifyCoarseLeaves3DKernel(const Fast3DProblem* __restrict__ problems, List3 lea
       Node3D rec = nd;
       rec.level = 0;
       rec.low_resolution_score = low;
-      if (!Push3(leaves, sub_id, atomicAdd(&leaves.counts[sub_id], 1), rec)) counters->overflow = 1;
+      if (!Push3(leaves, sub_id, atomicAdd(&leaves.counts[sub_id * kCountStride3], 1), rec)) counters->overflow = 1;
       atomicMax(P.best_bits, __float_as_uint(nd.score));
     }
   }
@@ -1232,14 +1236,14 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
       // one strided copy: the first max-count slots of every sub-list
       int max_count = 0;
       for (int sub = 0; sub < kSubLists3; ++sub)
-        max_count = std::max(max_count, std::min(h_counters->leaves[sub], leaf_list.sub_capacity));
+        max_count = std::max(max_count, std::min(h_counters->leaves[sub * kCountStride3], leaf_list.sub_capacity));
       if (max_count > 0) {
         std::vector<Node3D> rows(static_cast<size_t>(max_count) * kSubLists3);
         CMX_HIP(hipMemcpy2D(rows.data(), max_count * sizeof(Node3D), leaf_list.nodes,
                             leaf_list.sub_capacity * sizeof(Node3D), max_count * sizeof(Node3D),
                             kSubLists3, hipMemcpyDeviceToHost));
         for (int sub = 0; sub < kSubLists3; ++sub) {
-          const int count = std::min(h_counters->leaves[sub], leaf_list.sub_capacity);
+          const int count = std::min(h_counters->leaves[sub * kCountStride3], leaf_list.sub_capacity);
           all_leaves.insert(all_leaves.end(), rows.begin() + static_cast<size_t>(sub) * max_count,
                             rows.begin() + static_cast<size_t>(sub) * max_count + count);
         }
