@@ -9,6 +9,7 @@
 #include "oracle_2d.h"
 #include "oracle_3d.h"
 #include "oracle_ceres_2d.h"
+#include "oracle_ceres_3d.h"
 #include "oracle_filters.h"
 
 using namespace oracle;
@@ -437,6 +438,66 @@ int orc_adaptive_voxel_filter(const float* xyz, int n, float max_length, float m
 void orc_compute_histogram(const float* xyz, int n, int histogram_size, float* out) {
   const std::vector<float> h = ComputeHistogram(MakeCloud(xyz, n), histogram_size);
   std::memcpy(out, h.data(), h.size() * sizeof(float));
+}
+
+// ---- CeresScanMatcher3D ----
+// options8 = translation weight, rotation weight, only_optimize_yaw, use_nonmonotonic_steps,
+// max_num_iterations, then one occupied-space weight per pair (up to 3).  Pair k: clouds[k]
+// (xyz, counts[k] points) against grid k (resolutions[k], voxels[k], voxel_counts[k]).
+namespace {
+struct Ceres3DArgs {
+  CeresOptions3D options;
+  std::vector<PointCloud3> clouds;
+  std::vector<std::unique_ptr<HybridGridView>> grids;
+  std::vector<CloudAndGrid3D> pairs;
+};
+void MakeCeres3D(const double* options8, int num_pairs, const float* const* clouds,
+                 const int* counts, const float* resolutions, const Voxel* const* voxels,
+                 const int64_t* voxel_counts, Ceres3DArgs* a) {
+  a->options.translation_weight = options8[0];
+  a->options.rotation_weight = options8[1];
+  a->options.only_optimize_yaw = options8[2] != 0.;
+  a->options.use_nonmonotonic_steps = options8[3] != 0.;
+  a->options.max_num_iterations = static_cast<int>(options8[4]);
+  a->clouds.resize(num_pairs);
+  for (int k = 0; k < num_pairs; ++k) {
+    a->options.occupied_space_weight.push_back(options8[5 + k]);
+    a->clouds[k] = MakeCloud3(clouds[k], counts[k]);
+    a->grids.emplace_back(new HybridGridView(resolutions[k], voxels[k], voxel_counts[k]));
+  }
+  for (int k = 0; k < num_pairs; ++k)
+    a->pairs.push_back(CloudAndGrid3D{&a->clouds[k], a->grids[k].get()});
+}
+}  // namespace
+
+void orc_ceres3d_match(const double* options8, int num_pairs, const float* const* clouds,
+                       const int* counts, const float* resolutions, const Voxel* const* voxels,
+                       const int64_t* voxel_counts, const double* target_xyz,
+                       const double* init7, double* pose7, double* summary5) {
+  Ceres3DArgs a;
+  MakeCeres3D(options8, num_pairs, clouds, counts, resolutions, voxels, voxel_counts, &a);
+  Pose3d pose = MakePose3(init7);
+  CeresSummary2D sum;
+  CeresScanMatcher3DMatch(a.options, target_xyz, MakePose3(init7), a.pairs, &pose, &sum);
+  StorePose3(pose, pose7);
+  summary5[0] = sum.initial_cost; summary5[1] = sum.final_cost;
+  summary5[2] = sum.num_successful_steps; summary5[3] = sum.num_unsuccessful_steps;
+  summary5[4] = sum.termination;
+}
+
+// residuals [sum(counts) + 6], jacobian [sum(counts) + 6][7] at pose7 (t, q = w x y z);
+// the rotation residual targets target_q4.
+void orc_ceres3d_residuals(const double* options8, int num_pairs, const float* const* clouds,
+                           const int* counts, const float* resolutions,
+                           const Voxel* const* voxels, const int64_t* voxel_counts,
+                           const double* target_xyz, const double* target_q4, const double* pose7,
+                           double* residuals, double* jacobian) {
+  Ceres3DArgs a;
+  MakeCeres3D(options8, num_pairs, clouds, counts, resolutions, voxels, voxel_counts, &a);
+  std::vector<double> r, J;
+  CeresResiduals3D(a.options, target_xyz, target_q4, a.pairs, pose7, pose7 + 3, &r, &J);
+  std::memcpy(residuals, r.data(), r.size() * sizeof(double));
+  std::memcpy(jacobian, J.data(), J.size() * sizeof(double));
 }
 
 }  // extern "C"

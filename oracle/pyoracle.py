@@ -897,3 +897,64 @@ class ReferenceFastCorrelativeScanMatcher3D:
         node7 = np.concatenate([[0, 0, 0], node_q])
         submap7 = np.concatenate([[0, 0, 0], submap_q])
         return self._match(True, node7, submap7, gravity, hi, lo, hist, min_score)
+
+
+# ---- CeresScanMatcher3D: oracle_ceres_3d.h ----
+def _ceres3d_args(pairs, occupied_space_weights, translation_weight, rotation_weight,
+                  only_optimize_yaw, use_nonmonotonic_steps, max_num_iterations):
+    """pairs: [(xyz, resolution, voxels), ...] -- one per (point cloud, hybrid grid)."""
+    num = len(pairs)
+    assert 1 <= num <= 3 and len(occupied_space_weights) == num
+    options = np.zeros(8, np.float64)
+    options[:5] = [translation_weight, rotation_weight, 1.0 if only_optimize_yaw else 0.0,
+                   1.0 if use_nonmonotonic_steps else 0.0, max_num_iterations]
+    options[5:5 + num] = occupied_space_weights
+    clouds = [_cloud(p[0])[0] for p in pairs]
+    voxels = [_voxels(p[2])[0] for p in pairs]
+    keep = (clouds, voxels)
+    cloud_ptrs = (C.c_void_p * num)(*[c.ctypes.data for c in clouds])
+    counts = np.array([c.shape[0] for c in clouds], np.int32)
+    resolutions = np.array([p[1] for p in pairs], np.float32)
+    voxel_ptrs = (C.c_void_p * num)(*[v.ctypes.data for v in voxels])
+    voxel_counts = np.array([v.shape[0] for v in voxels], np.int64)
+    return (options, num, cloud_ptrs, counts.ctypes.data_as(C.c_void_p),
+            resolutions.ctypes.data_as(C.c_void_p), voxel_ptrs,
+            voxel_counts.ctypes.data_as(C.c_void_p)), (keep, counts, resolutions, voxel_counts)
+
+
+def ceres3d_match(pairs, target_xyz, init_pose7, occupied_space_weights, translation_weight=5.0,
+                  rotation_weight=400.0, only_optimize_yaw=False, use_nonmonotonic_steps=False,
+                  max_num_iterations=12):
+    """CeresScanMatcher3D::Match restated (probability grids only; parity with Ceres's iterates
+    is unpinned, see oracle_ceres_3d.h).  init_pose7 = (tx, ty, tz, qw, qx, qy, qz)."""
+    args, keep = _ceres3d_args(pairs, occupied_space_weights, translation_weight, rotation_weight,
+                               only_optimize_yaw, use_nonmonotonic_steps, max_num_iterations)
+    L = lib()
+    L.orc_ceres3d_match.argtypes = [_f64p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, _f64p, _f64p, _f64p, _f64p]
+    L.orc_ceres3d_match.restype = None
+    pose, summary = np.empty(7, np.float64), np.empty(5, np.float64)
+    L.orc_ceres3d_match(*args, np.ascontiguousarray(target_xyz, np.float64),
+                        np.ascontiguousarray(init_pose7, np.float64), pose, summary)
+    del keep
+    return dict(pose=pose, initial_cost=summary[0], final_cost=summary[1],
+                num_successful_steps=int(summary[2]), num_unsuccessful_steps=int(summary[3]),
+                termination=int(summary[4]))
+
+
+def ceres3d_residuals(pairs, target_xyz, target_q4, pose7, occupied_space_weights,
+                      translation_weight=5.0, rotation_weight=400.0):
+    """Residuals [N + 6] and their Jacobian [N + 6, 7] w.r.t. (t, q = w x y z) at pose7."""
+    args, keep = _ceres3d_args(pairs, occupied_space_weights, translation_weight, rotation_weight,
+                               False, False, 0)
+    total = int(keep[1].sum()) + 6
+    L = lib()
+    L.orc_ceres3d_residuals.argtypes = [_f64p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, _f64p, _f64p, _f64p, _f64p, _f64p]
+    L.orc_ceres3d_residuals.restype = None
+    r, J = np.empty(total, np.float64), np.empty((total, 7), np.float64)
+    L.orc_ceres3d_residuals(*args, np.ascontiguousarray(target_xyz, np.float64),
+                            np.ascontiguousarray(target_q4, np.float64),
+                            np.ascontiguousarray(pose7, np.float64), r, J)
+    del keep
+    return r, J
