@@ -76,6 +76,18 @@ class CeresSummary(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
 
+class Ceres3DOptions(C.Structure):
+    _fields_ = [("occupied_space_weight", C.c_double * 3), ("translation_weight", C.c_double),
+                ("rotation_weight", C.c_double), ("num_pairs", C.c_int32),
+                ("only_optimize_yaw", C.c_int32), ("use_nonmonotonic_steps", C.c_int32),
+                ("max_num_iterations", C.c_int32)]
+
+
+class Ceres3DPair(C.Structure):
+    _fields_ = [("point_cloud_xyz", C.c_void_p), ("num_points", C.c_int32),
+                ("resolution", C.c_float), ("voxels", C.c_void_p), ("num_voxels", C.c_int64)]
+
+
 class Voxel(C.Structure):
     _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("z", C.c_int32), ("value", C.c_uint16),
                 ("pad", C.c_uint16)]
@@ -117,7 +129,7 @@ EXPORTED_SYMBOLS = [
     "cmx_fast3d_destroy", "cmx_fast3d_match", "cmx_fast3d_match_full_submap",
     "cmx_fast3d_match_batch",
     "cmx_fast3d_level_info", "cmx_fast3d_level_cells",
-    "cmx_ceres2d_match", "cmx_ceres2d_match_grid", "cmx_fast2d_refine_batch",
+    "cmx_ceres2d_match", "cmx_ceres2d_match_grid", "cmx_fast2d_refine_batch", "cmx_ceres3d_match",
     "cmx_comm_init", "cmx_comm_destroy", "cmx_comm_num_devices", "cmx_comm_device_of",
     "cmx_fast2d_match_sharded", "cmx_fast3d_match_sharded", "cmx_shard_range",
     "cmx_pack_best_key", "cmx_unpack_best_key",
@@ -197,6 +209,8 @@ def lib():
     L.cmx_fast2d_refine_batch.argtypes = [P(Ceres2DOptions), P(C.c_void_p), C.c_int32, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                           C.c_void_p]
+    L.cmx_ceres3d_match.argtypes = [P(Ceres3DOptions), C.c_void_p, P(Pose3d), C.c_void_p, C.c_int32,
+                                    P(Pose3d), P(CeresSummary)]
     L.cmx_voxel_filter.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p,
                                    P(C.c_int32)]
     L.cmx_adaptive_voxel_filter.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float,

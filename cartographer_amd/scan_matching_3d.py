@@ -12,8 +12,8 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _lib
-from ._lib import (Fast3DOptions, MatchStats, NodeData3D, Pose3d, Result3D, RtOptions,
-                   VOXEL_DTYPE, check)
+from ._lib import (Ceres3DOptions, Ceres3DPair, CeresSummary, Fast3DOptions, MatchStats, NodeData3D,
+                   Pose3d, Result3D, RtOptions, VOXEL_DTYPE, check)
 
 
 @dataclass
@@ -67,6 +67,54 @@ class RealTimeCorrelativeScanMatcher3D:
                                         C.byref(score), C.byref(pose), C.byref(stats)))
         self.last_stats = stats.as_dict()
         return float(score.value), Rigid3d.from_c(pose)
+
+
+class CeresScanMatcher3D:
+    """CeresScanMatcher3D (SM3/ceres_scan_matcher_3d.h:48-66), probability grids only.
+
+    ``match(target_translation, initial_pose_estimate, point_clouds_and_hybrid_grids)`` with
+    ``point_clouds_and_hybrid_grids = [(point_cloud, grid_resolution, grid_voxels), ...]`` (one
+    entry per occupied_space_weight) returns ``(pose_estimate, summary dict)``."""
+
+    def __init__(self, occupied_space_weights, translation_weight, rotation_weight,
+                 only_optimize_yaw=False, use_nonmonotonic_steps=False, max_num_iterations=12,
+                 device=0):
+        o = Ceres3DOptions()
+        assert 1 <= len(occupied_space_weights) <= 3
+        for k, w in enumerate(occupied_space_weights):
+            o.occupied_space_weight[k] = float(w)
+        o.num_pairs = len(occupied_space_weights)
+        o.translation_weight = float(translation_weight)
+        o.rotation_weight = float(rotation_weight)
+        o.only_optimize_yaw = 1 if only_optimize_yaw else 0
+        o.use_nonmonotonic_steps = 1 if use_nonmonotonic_steps else 0
+        o.max_num_iterations = int(max_num_iterations)
+        self.options = o
+        self.device = device
+
+    def match(self, target_translation, initial_pose_estimate, point_clouds_and_hybrid_grids):
+        num = self.options.num_pairs
+        assert len(point_clouds_and_hybrid_grids) == num
+        keep = []
+        pairs = (Ceres3DPair * num)()
+        for k, (cloud, resolution, voxels) in enumerate(point_clouds_and_hybrid_grids):
+            xyz, n = _cloud(cloud)
+            vox, nv = _voxels(voxels)
+            keep += [xyz, vox]
+            pairs[k].point_cloud_xyz = xyz.ctypes.data
+            pairs[k].num_points = n
+            pairs[k].resolution = float(resolution)
+            pairs[k].voxels = vox.ctypes.data if nv else None
+            pairs[k].num_voxels = nv
+        target = np.ascontiguousarray(target_translation, np.float64)
+        init = initial_pose_estimate.to_c()
+        pose = Pose3d()
+        summary = CeresSummary()
+        check(_lib.lib().cmx_ceres3d_match(C.byref(self.options), target.ctypes.data, C.byref(init),
+                                           C.cast(pairs, C.c_void_p), self.device, C.byref(pose),
+                                           C.byref(summary)))
+        del keep
+        return Rigid3d.from_c(pose), summary.as_dict()
 
 
 @dataclass

@@ -18,6 +18,7 @@
  *                                  (node, submap) searches, constraints/constraint_builder_2d.cc:97-137
  *   cmx_ceres2d_match, cmx_ceres2d_match_grid, cmx_fast2d_refine_batch
  *                                  CeresScanMatcher2D::Match, SM2/ceres_scan_matcher_2d.cc:63-107
+ *   cmx_ceres3d_match              CeresScanMatcher3D::Match, SM3/ceres_scan_matcher_3d.cc:90-156
  *   cmx_rt3d_match                 RealTimeCorrelativeScanMatcher3D::Match
  *                                  SM3/real_time_correlative_scan_matcher_3d.h:47-50, .cc:34-53
  *   cmx_fast3d_*                   FastCorrelativeScanMatcher3D ctor / Match / MatchFullSubmap
@@ -282,6 +283,37 @@ cmx_status cmx_fast2d_refine_batch(const cmx_ceres2d_options* options,
                                    const int32_t* found, const cmx_pose2d* pose_estimates_in,
                                    const float* point_cloud_xyz, int32_t num_points,
                                    cmx_pose2d* pose_estimates_out, cmx_ceres_summary* summaries);
+
+/* ---- CeresScanMatcher3D ------------------------------------------- */
+/* proto::CeresScanMatcherOptions3D (mapping/proto/scan_matching/ceres_scan_matcher_options_3d.proto)
+ * without the intensity cost function, + the ceres_solver_options cartographer sets. */
+typedef struct cmx_ceres3d_options {
+  double occupied_space_weight[3];   /* one per (point cloud, hybrid grid) pair */
+  double translation_weight;
+  double rotation_weight;
+  int32_t num_pairs;                 /* 1 .. 3: high-resolution, low-resolution, ... */
+  int32_t only_optimize_yaw;
+  int32_t use_nonmonotonic_steps;
+  int32_t max_num_iterations;
+} cmx_ceres3d_options;
+/* CeresScanMatcher3D::PointCloudAndHybridGridsPointers (SM3/ceres_scan_matcher_3d.h:42-46); the
+ * grid as the voxel list HybridGrid::Iterator yields. */
+typedef struct cmx_ceres3d_pair {
+  const float* point_cloud_xyz;
+  int32_t num_points;
+  float resolution;
+  const cmx_voxel* voxels;
+  int64_t num_voxels;
+} cmx_ceres3d_pair;
+/* CeresScanMatcher3D::Match (SM3/ceres_scan_matcher_3d.h:55-60, .cc:90-156): occupied-space
+ * residuals through InterpolatedGrid (SM3/interpolated_grid.h), translation / rotation delta
+ * residuals, quaternion (or yaw-only) local parameterization, Ceres's trust-region
+ * Levenberg-Marquardt with its default options.  The rotation target is the initial rotation. */
+cmx_status cmx_ceres3d_match(const cmx_ceres3d_options* options,
+                             const double* target_translation_xyz,
+                             const cmx_pose3d* initial_pose_estimate,
+                             const cmx_ceres3d_pair* pairs, int32_t device,
+                             cmx_pose3d* pose_estimate, cmx_ceres_summary* summary);
 
 /* Introspection used by the parity tests (not needed by a caller). */
 cmx_status cmx_fast2d_level_dims(const cmx_fast2d* matcher, int32_t level, int32_t* wide_x,

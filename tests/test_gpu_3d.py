@@ -474,3 +474,69 @@ def test_fast3d_repeated_searches_return_the_same_result(sm3, synth):
     for r in range(80):
         assert single() == first, r
         assert batch() == first, r
+
+
+# ----------------------------------------------------------------------------
+# CeresScanMatcher3D on the device vs the oracle's restatement
+# ----------------------------------------------------------------------------
+def _ceres3d_compare(sm3, oracle, pairs, target, init, weights, tw, rw, **kw):
+    ref = oracle.ceres3d_match(pairs, target, init, weights, translation_weight=tw,
+                               rotation_weight=rw, **kw)
+    m = sm3.CeresScanMatcher3D(weights, tw, rw, **kw)
+    pose, summary = m.match(target, sm3.Rigid3d(tuple(init[:3]), tuple(init[3:])), pairs)
+    # f64 on both sides; the device reduces its sums in a fixed but different order, and its
+    # sin / cos / pow are not libm's
+    np.testing.assert_allclose(_pose7(pose), ref["pose"], rtol=0, atol=1e-6)
+    assert abs(summary["initial_cost"] - ref["initial_cost"]) <= 1e-9 * max(1.0, ref["initial_cost"])
+    assert abs(summary["final_cost"] - ref["final_cost"]) <= 1e-6 * max(1.0, ref["final_cost"])
+    assert summary["num_successful_steps"] == ref["num_successful_steps"]
+    assert summary["termination"] == ref["termination"]
+    return ref, pose, summary
+
+
+@pytest.mark.parametrize("t", [(-1.0, 0.0, 0.0), (-0.8, 0.0, 0.0), (-1.0, 0.0, -0.2),
+                               (-0.9, -0.2, 0.2)])
+def test_ceres3d_reference_fixture(sm3, oracle, synth, t):
+    """CeresScanMatcher3DTest (ceres_scan_matcher_3d_test.cc:36-111, without the intensity
+    term): the reference's expectations and the oracle's iterates."""
+    from test_ceres_3d import POINTS, fixture, is_nearly
+    vox = fixture(synth, POINTS)
+    init = list(t) + [1.0, 0.0, 0.0, 0.0]
+    ref, pose, summary = _ceres3d_compare(sm3, oracle, [(POINTS, 1.0, vox)], t, init, [1.0], 0.01,
+                                          0.1, use_nonmonotonic_steps=True, max_num_iterations=10)
+    assert abs(summary["final_cost"]) < 1e-2
+    assert is_nearly(_pose7(pose), [-1.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], 3e-2)
+
+
+@pytest.mark.parametrize("yaw_only,nonmono,seed", [(False, False, 7), (True, False, 7),
+                                                   (False, True, 9), (True, True, 11)])
+def test_ceres3d_equals_the_oracle(sm3, oracle, synth, yaw_only, nonmono, seed):
+    """Two (cloud, grid) pairs like the local trajectory builder's (high and low resolution),
+    tilted initial rotation, both parameterizations, monotonic and non-monotonic steps."""
+    grid, world = synth.make_submap_3d(seed, 0.1, (8.0, 8.0, 4.0), 4, 8, 96)
+    low, _ = synth.make_submap_3d(seed, 0.3, (8.0, 8.0, 4.0), 4, 8, 96)
+    pos = world.free_position(seed + 1, 0.5)
+    yaw = 0.4
+    full = world.scan(pos, yaw, 16, 128, seed=3)
+    hi, lo = full[::2].copy(), full[::9].copy()
+    pairs = [(hi, 0.1, grid.voxels()), (lo, 0.3, low.voxels())]
+    init_t = pos + np.array([0.04, -0.03, 0.02])
+    init = list(init_t) + quat_from_angle_axis(yaw + 0.02, [0.05, -0.02, 1.0])
+    ref, pose, summary = _ceres3d_compare(sm3, oracle, pairs, init_t, init, [1.0, 6.0], 5.0, 4e2,
+                                          only_optimize_yaw=yaw_only,
+                                          use_nonmonotonic_steps=nonmono, max_num_iterations=12)
+    assert summary["final_cost"] < summary["initial_cost"]
+
+
+def test_ceres3d_invalid_arguments(sm3, synth):
+    from cartographer_amd._lib import CmxError, INVALID_ARGUMENT
+    from test_ceres_3d import POINTS, fixture
+    vox = fixture(synth, POINTS)
+    with pytest.raises(CmxError) as e:      # CHECK_GT(options_.translation_weight(), 0.)
+        sm3.CeresScanMatcher3D([1.0], 0.0, 0.1).match((0, 0, 0), sm3.Rigid3d(),
+                                                      [(POINTS, 1.0, vox)])
+    assert e.value.status == INVALID_ARGUMENT
+    with pytest.raises(CmxError) as e:      # CHECK_GT(options_.occupied_space_weight(i), 0.)
+        sm3.CeresScanMatcher3D([0.0], 0.01, 0.1).match((0, 0, 0), sm3.Rigid3d(),
+                                                       [(POINTS, 1.0, vox)])
+    assert e.value.status == INVALID_ARGUMENT
