@@ -103,6 +103,10 @@ class _Pending:
     cloud_key: int
     match_full_submap: bool
     initial_relative_pose: Rigid2d
+    # The matcher the pair was scheduled on: DeleteScanMatcher only drops the builder's entry,
+    # work already scheduled keeps its matcher alive (constraint_builder_2d.cc:307-316 frees the
+    # matcher in a task that depends on the scheduled ones).
+    matcher: object = None
 
 
 class ConstraintBuilder2D:
@@ -176,7 +180,8 @@ class ConstraintBuilder2D:
         # into the same device batch.
         xyz, _ = _cloud(point_cloud)
         self._pending.append(_Pending(len(self._constraints) - 1, submap_id, submap, node_id, xyz,
-                                      id(point_cloud), full, initial_relative_pose))
+                                      id(point_cloud), full, initial_relative_pose,
+                                      self._scan_matchers[submap_id]))
 
     def _flush(self):
         pending, self._pending = self._pending, []
@@ -188,7 +193,7 @@ class ConstraintBuilder2D:
 
     def _match_group(self, xyz, items):
         num = len(items)
-        handles = (C.c_void_p * num)(*[self._scan_matchers[i.submap_id]._h for i in items])
+        handles = (C.c_void_p * num)(*[i.matcher._h for i in items])
         initial = (Pose2d * num)()
         full = np.zeros(num, np.int32)
         min_scores = np.zeros(num, np.float32)
@@ -348,8 +353,9 @@ class ConstraintBuilder3D:
                 linear_xy_search_window=o.linear_xy_search_window,
                 linear_z_search_window=o.linear_z_search_window,
                 angular_search_window=o.angular_search_window, device=self.device)
+        # (the matcher travels with the pair: a later delete_scan_matcher must not break it)
         self._pending.append((len(self._constraints) - 1, submap_id, node_id, constant_data, full,
-                              node, sub))
+                              node, sub, self._scan_matchers[submap_id]))
 
     def _flush(self):
         """The queued pairs of a node share its constant data: one cmx_fast3d_match_batch per
@@ -363,12 +369,12 @@ class ConstraintBuilder3D:
             constant_data = items[0][3]
             as_pose = lambda v, full: Rigid3d((0.0, 0.0, 0.0), tuple(v)) if full else v   # noqa: E731
             results, self.last_batch_stats = fast3d_match_batch(
-                [self._scan_matchers[i[1]] for i in items],
+                [i[7] for i in items],
                 [as_pose(i[5], i[4]) for i in items], [as_pose(i[6], i[4]) for i in items],
                 [i[4] for i in items],
                 [self.options.global_localization_min_score if i[4] else self.options.min_score
                  for i in items], constant_data)
-            for (slot, submap_id, node_id, _, full, node, sub), result in zip(items, results):
+            for (slot, submap_id, node_id, _, full, node, sub, _m), result in zip(items, results):
                 if result is None:
                     continue                               # `return;` at :232 / :253
                 self.score_histogram.append(result["score"])

@@ -127,6 +127,40 @@ def test_constraint_lists_match_restatement(oracle, synth):
     assert again == []
 
 
+@pytest.mark.gpu
+def test_delete_scan_matcher_between_enqueue_and_flush(synth):
+    """DeleteScanMatcher after MaybeAdd*Constraint but before the node ends: the scheduled pair
+    keeps its matcher (the reference frees it in a task that depends on the scheduled ones,
+    constraint_builder_2d.cc:307-316); only new pairs build a new one."""
+    from cartographer_amd import constraint_builder as cb, scan_matching as sm
+    opts = cb.ConstraintBuilderOptions(sampling_ratio=1.0, max_constraint_distance=4.0,
+                                       min_score=0.5, global_localization_min_score=0.55,
+                                       linear_search_window=1.5,
+                                       angular_search_window=math.radians(20.0),
+                                       branch_and_bound_depth=5)
+    cells, lim, world = synth.make_submap(61, 160, 140, 0.05, 12, 400, 30.0, 0.01)
+    grid = sm.Grid2D(cells, lim["resolution"], lim["max_x"], lim["max_y"])
+    submap = cb.Submap2D(cb.Rigid2d(0.0, 0.0, 0.0), grid)
+    truth = world.free_pose(100, 0.4)
+    cloud = world.scan(truth, 300, 30.0, 0.01, 1)
+    rel = cb.Rigid2d(truth[0] + 0.1, truth[1] - 0.05, truth[2] + 0.02)
+
+    def run(delete_in_between):
+        builder = cb.ConstraintBuilder2D(opts)
+        builder.maybe_add_constraint((0, 0), submap, (0, 0), cloud, rel)
+        if delete_in_between:
+            builder.delete_scan_matcher((0, 0))
+            assert builder.num_scan_matchers() == 0
+        builder.notify_end_of_node()
+        out = []
+        builder.when_done(out.extend)
+        return out
+
+    plain, deleted = run(False), run(True)
+    assert len(plain) == 1 and len(deleted) == 1
+    assert plain[0].score == deleted[0].score and plain[0].zbar_ij == deleted[0].zbar_ij
+
+
 def _finds_constraints_scenario(add_local, add_global, end_node, when_done, delete):
     """ConstraintBuilder2DTest.FindsConstraints (constraint_builder_2d_test.cc:70-112): a
     one-point cloud, an all-unknown 100 x 110 grid at resolution 1, sampling ratio 1 and
