@@ -65,8 +65,20 @@ struct List3 {
   int sub_capacity;
 };
 
+// The eight cells the children of a node read for one point, in ONE 8-byte word (what quads
+// are to the 2D search): oct(X, Y, Z) byte k = level(x + (k & 1) s, y + (k >> 1 & 1) s,
+// z + (k >> 2) s) with (x, y, z) = (X, Y, Z) - s relative to the level's brick, cells outside
+// the brick 0; s = the level's child stride 2^min(level, full_resolution_depth - 1).  One
+// gather per point and node instead of four (eight in round 1); 8x the bytes of the level
+// itself, i.e. ~90 MB per 150^3 submap instead of 12 -- HBM is not the scarce resource.
+struct OctDesc {
+  const uint2* cells;      // [(nz + s)][(ny + s)][(nx + s)]; null: not built
+  int qx, qy, qz, s;
+};
+
 struct Fast3DProblem {
   Brick level[kMaxDepth];
+  OctDesc oct[kMaxDepth];
   int depth, full_resolution_depth;
   Brick low;
   float low_resolution, resolution;
@@ -113,6 +125,27 @@ __global__ void PrecomputeLevel3DKernel(Brick prev, Brick out, int shift, int ha
                                             sub * ty + ey + shift * oy,
                                             sub * tz + ez + shift * oz));
   static_cast<uint8_t*>(const_cast<void*>(out.cells))[i] = static_cast<uint8_t>(best);
+}
+
+__global__ void BuildOct3DKernel(Brick L, int s, uint2* __restrict__ out, int qx, int qy, int qz) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= static_cast<size_t>(qx) * qy * qz) return;
+  const int X = static_cast<int>(i % qx), Y = static_cast<int>((i / qx) % qy),
+            Z = static_cast<int>(i / (static_cast<size_t>(qx) * qy));
+  const uint8_t* __restrict__ cells = static_cast<const uint8_t*>(L.cells);
+  unsigned lo = 0, hi = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int x = X - s + ((k & 1) ? s : 0), y = Y - s + ((k & 2) ? s : 0),
+              z = Z - s + ((k & 4) ? s : 0);
+    unsigned v = 0;
+    if (static_cast<unsigned>(x) < static_cast<unsigned>(L.nx) &&
+        static_cast<unsigned>(y) < static_cast<unsigned>(L.ny) &&
+        static_cast<unsigned>(z) < static_cast<unsigned>(L.nz))
+      v = cells[(static_cast<size_t>(z) * L.ny + y) * L.nx + x];
+    if (k < 4) lo |= v << (8 * k); else hi |= v << (8 * (k - 4));
+  }
+  out[i] = make_uint2(lo, hi);
 }
 
 // ---------------------------------------------------------------------------
@@ -385,7 +418,33 @@ __device__ __forceinline__ void ChildSums3D(const Fast3DProblem& P, const Node3D
     // for the usual full_resolution_depth <= 3).  Up to dx == 4 ONE aligned 8-byte load serves
     // both: half the gather instructions of the search, which are what bounds it.
     const int dx = fx[1] - fx[0];
-    if (dx <= 4 && !g_fast3d_byte_loads) {
+    const OctDesc O = P.oct[child_depth];
+    if (O.cells != nullptr && O.s == dx && !g_fast3d_byte_loads) {
+      // One 8-byte gather per point: the eight child cells (see OctDesc).  Bytes are summed
+      // as packed 16-bit pairs, widened every 256 points.
+      const int ox = fx[0] + O.s, oy = fy[0] + O.s, oz = fz[0] + O.s;
+      for (int q0 = first; q0 < P.n; q0 += 256 * stride) {
+        unsigned e0 = 0, o0 = 0, e1 = 0, o1 = 0;
+        const int stop = min(P.n, q0 + 256 * stride);
+#pragma unroll 4
+        for (int q = q0; q < stop; q += stride) {
+          const int3 d = DepthIndex(cells[q], e, -P.wxy, -P.wxy, -P.wz);
+          const int X = d.x + ox, Y = d.y + oy, Z = d.z + oz;
+          const bool inside = static_cast<unsigned>(X) < static_cast<unsigned>(O.qx) &&
+                              static_cast<unsigned>(Y) < static_cast<unsigned>(O.qy) &&
+                              static_cast<unsigned>(Z) < static_cast<unsigned>(O.qz);
+          // unconditional load from a valid offset, masked afterwards
+          const uint2 w = O.cells[inside ? (static_cast<size_t>(Z) * O.qy + Y) * O.qx + X : 0];
+          const unsigned lo = inside ? w.x : 0u, hi = inside ? w.y : 0u;
+          e0 += lo & 0x00ff00ffu; o0 += (lo >> 8) & 0x00ff00ffu;
+          e1 += hi & 0x00ff00ffu; o1 += (hi >> 8) & 0x00ff00ffu;
+        }
+        sum[0] += e0 & 0xffffu; sum[2] += e0 >> 16;      // bytes 0, 2 of the low word
+        sum[1] += o0 & 0xffffu; sum[3] += o0 >> 16;      // bytes 1, 3
+        sum[4] += e1 & 0xffffu; sum[6] += e1 >> 16;
+        sum[5] += o1 & 0xffffu; sum[7] += o1 >> 16;
+      }
+    } else if (dx <= 4 && !g_fast3d_byte_loads) {
 #pragma unroll 2
       for (int q = first; q < P.n; q += stride) {
         const int3 d = DepthIndex(cells[q], e, -P.wxy, -P.wxy, -P.wz);
@@ -786,6 +845,8 @@ struct Fast3DMatcher {
   float resolution, low_resolution;
   int width_in_voxels;
   std::vector<std::unique_ptr<DeviceBrick>> levels;
+  std::vector<std::unique_ptr<DeviceBrick>> octs;   // per child level (see OctDesc)
+  std::vector<OctDesc> oct_desc;
   DeviceBrick low;
   std::vector<float> histogram;
 };
@@ -823,6 +884,40 @@ float MatchHistograms(const std::vector<float>& submap, const std::vector<float>
   if (normalization < 1e-3f) return 1.f;
   return Dot(submap, scan) / normalization;
 }
+
+// The same two functions for the yaw sweep of a search (tens of angles per pair, hundreds of
+// pairs per node): no allocation per angle, no integer division per bucket, the submap's norm
+// computed once.  Same operations on the same operands in the same order: same floats.
+struct YawSweep {
+  const std::vector<float>& submap;
+  const std::vector<float>& scan;
+  float submap_norm;
+  std::vector<float> rotated;
+  YawSweep(const std::vector<float>& submap_histogram, const std::vector<float>& scan_histogram)
+      : submap(submap_histogram), scan(scan_histogram),
+        submap_norm(std::sqrt(Dot(submap_histogram, submap_histogram))),
+        rotated(scan_histogram.size()) {}
+  float Score(float angle) {
+    const int size = static_cast<int>(scan.size());
+    if (size != 0) {
+      const float rotate_by_buckets =
+          static_cast<float>(static_cast<double>(-angle * static_cast<float>(size)) / M_PI);
+      int full_buckets = static_cast<int>(std::lround(rotate_by_buckets - 0.5f));
+      const float fraction = rotate_by_buckets - full_buckets;
+      while (full_buckets < 0) full_buckets += size;
+      int i0 = full_buckets % size;
+      for (int i = 0; i != size; ++i) {
+        const int i1 = i0 + 1 == size ? 0 : i0 + 1;
+        rotated[i] = fraction * scan[i1] + (1.f - fraction) * scan[i0];
+        i0 = i1;
+      }
+    }
+    const float scan_norm = std::sqrt(Dot(rotated, rotated));
+    const float normalization = scan_norm * submap_norm;
+    if (normalization < 1e-3f) return 1.f;
+    return Dot(submap, rotated) / normalization;
+  }
+};
 
 // One (node, submap) search of a batch: MatchWithSearchParameters' arguments (:172-198).
 struct Search3D {
@@ -938,10 +1033,10 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
     CMX_REQUIRE(angular_window_size >= 0 && angular_window_size < (1 << 20), "bad angular window");
     const h3::Rigid node_to_submap = h3::Mul(h3::InverseRigid(q.submap), q.node);
     const float initial_angle = h3::GetYaw(h3::Mul(node_to_submap.q, g_inv));
+    YawSweep sweep(m.histogram, scan_hist);
     for (int rz = -angular_window_size; rz <= angular_window_size; ++rz) {
       const float angle = rz * step;
-      const float sc =
-          MatchHistograms(m.histogram, RotateHistogram(scan_hist, initial_angle + angle));
+      const float sc = sweep.Score(initial_angle + angle);
       if (sc < m.options.min_rotational_score) continue;
       pr.pose_q.push_back(h3::Mul(h3::Mul(h3::Inverse(q.submap.q),
                                           h3::FromAngleAxisVector({0.f, 0.f, angle})),
@@ -1041,6 +1136,7 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
     const int depth = m.options.branch_and_bound_depth;
     Fast3DProblem P{};
     for (int d = 0; d < depth; ++d) P.level[d] = m.levels[d]->desc;
+    for (size_t d = 0; d < m.oct_desc.size(); ++d) P.oct[d] = m.oct_desc[d];
     P.depth = depth;
     P.full_resolution_depth = m.options.full_resolution_depth;
     P.low = m.low.desc;
@@ -1401,6 +1497,30 @@ cmx_status cmx_fast3d_create(const cmx_fast3d_options* options, float resolution
       CMX_HIP(hipGetLastError());
       m.levels.push_back(std::move(level));
       last_width = next_width;
+    }
+    // Octs of every level that can be a child level (CMX_FAST3D_OCT=0: none, tests).
+    {
+      const char* e = getenv("CMX_FAST3D_OCT");
+      const bool build_octs = !(e && e[0] == '0');
+      const int depth = options->branch_and_bound_depth;
+      m.oct_desc.assign(depth, OctDesc{nullptr, 0, 0, 0, 0});
+      for (int i = 0; build_octs && i + 1 < depth; ++i) {
+        const Brick L = m.levels[i]->desc;
+        OctDesc O;
+        O.s = 1 << std::min(i, options->full_resolution_depth - 1);
+        O.qx = L.nx + O.s; O.qy = L.ny + O.s; O.qz = L.nz + O.s;
+        const size_t count = static_cast<size_t>(O.qx) * O.qy * O.qz;
+        if (count * sizeof(uint2) >= (size_t(1) << 32)) continue;     // 32-bit offsets elsewhere
+        std::unique_ptr<DeviceBrick> mem(new DeviceBrick);
+        mem->bytes = count * sizeof(uint2);
+        CMX_HIP(hipMalloc(&mem->mem, mem->bytes));
+        O.cells = static_cast<const uint2*>(mem->mem);
+        BuildOct3DKernel<<<DivUp(count, 256), 256, 0, ws->stream>>>(
+            L, O.s, static_cast<uint2*>(mem->mem), O.qx, O.qy, O.qz);
+        CMX_HIP(hipGetLastError());
+        m.oct_desc[i] = O;
+        m.octs.push_back(std::move(mem));
+      }
     }
     CMX_HIP(hipStreamSynchronize(ws->stream));
     *out = h.release();

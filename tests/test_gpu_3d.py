@@ -540,3 +540,47 @@ def test_ceres3d_invalid_arguments(sm3, synth):
         sm3.CeresScanMatcher3D([0.0], 0.01, 0.1).match((0, 0, 0), sm3.Rigid3d(),
                                                        [(POINTS, 1.0, vox)])
     assert e.value.status == INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("oct", ["1", "0"])
+def test_fast3d_oct_layout_equals_the_oracle(sm3, oracle, synth, monkeypatch, oct):
+    """Child cells from the 8-byte "oct" words (one gather per point and node) and from the level
+    bricks themselves (CMX_FAST3D_OCT=0 at matcher creation): the oracle's result either way, on
+    the C5-shaped submap (full and half resolution levels, strides 1, 2, 4) and on a shallow
+    stack with a window reaching far outside the grid."""
+    monkeypatch.setenv("CMX_FAST3D_OCT", oct)
+    size = (15.0, 15.0, 7.5)
+    grid, world = synth.make_submap_3d(42, 0.1, size, 8, 32, 512)
+    low, _ = synth.make_submap_3d(42, 0.45, size, 8, 32, 512)
+    vox, low_vox = grid.voxels(), low.voxels()
+    rng = np.random.default_rng(1)
+    hist = rng.uniform(0.0, 1.0, 120).astype(np.float32)
+    hist[10:14] += 6.0
+    pos = world.free_position(77, 0.6)
+    full = world.scan(pos, 0.4, 32, 512, seed=1)
+    hi, lo = full[::6].copy(), full[::80].copy()
+    scan_hist = np.roll(hist, -19).copy()
+    opt = dict(branch_and_bound_depth=8, full_resolution_depth=3, min_rotational_score=0.77,
+               min_low_resolution_score=0.35, linear_xy_search_window=5.0,
+               linear_z_search_window=1.0, angular_search_window=math.radians(15.0))
+    om, gm = _both(sm3, oracle, 0.1, vox, grid.grid_size, 0.45, low_vox, hist, **opt)
+    node = [pos[0] + 0.8, pos[1] - 0.6, pos[2] + 0.2] + quat_from_angle_axis(0.5, [0, 0, 1])
+    ident = [0, 0, 0, 1, 0, 0, 0]
+    ref = om.match(node, ident, [1, 0, 0, 0], hi, lo, scan_hist, 0.2)
+    got = gm.match(sm3.Rigid3d(tuple(node[:3]), tuple(node[3:])), sm3.Rigid3d(),
+                   sm3.TrajectoryNodeData(hi, lo, scan_hist), 0.2)
+    _assert_result(ref, got)
+    # shallow stack, full-submap search (window beyond the grid on every side)
+    g2, w2 = synth.make_submap_3d(5, 0.2, (6.0, 6.0, 3.0), 4, 8, 96)
+    v2 = g2.voxels()
+    h2 = np.zeros(8, np.float32)
+    opt2 = dict(branch_and_bound_depth=4, full_resolution_depth=2, min_rotational_score=0.0,
+                min_low_resolution_score=0.1, linear_xy_search_window=1.0,
+                linear_z_search_window=0.4, angular_search_window=math.radians(10.0))
+    om2, gm2 = _both(sm3, oracle, 0.2, v2, g2.grid_size, 0.2, v2, h2, **opt2)
+    p2 = w2.free_position(9, 0.5)
+    c2 = w2.scan(p2, 0.0, 6, 64, seed=2)
+    ref2 = om2.match_full_submap([1, 0, 0, 0], [1, 0, 0, 0], [1, 0, 0, 0], c2, c2[::4].copy(), h2, 0.1)
+    got2 = gm2.match_full_submap((1.0, 0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0),
+                                 sm3.TrajectoryNodeData(c2, c2[::4].copy(), h2), 0.1)
+    _assert_result(ref2, got2)
