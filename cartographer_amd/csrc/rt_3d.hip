@@ -293,9 +293,8 @@ __device__ __forceinline__ void Bounds3D(const Rt3DBulkParams& P, unsigned acc,
   *upper = static_cast<float>(mean_hi * w * (1. + P.delta)) * (1.f + 0x1p-22f);
 }
 
-// Group pass: grid (ceil(G / 256), R); candidate pass: grid (work descriptors, 1, point
-// slices).  256 threads: wave w of a block owns work items 256 chunk + 64 w .. + 63 of its
-// rotation.  kGroups: group pass (no ambiguity bookkeeping, upper
+// Group pass: grid (ceil(R G / 256)); candidate pass: grid (work descriptors, 1, point
+// slices).  256 threads: wave w of a block owns work items 256 chunk + 64 w .. + 63.  kGroups: group pass (no ambiguity bookkeeping, upper
 // bounds only, all points in one block).  Candidate pass: the work lists are short, so the
 // points are split over blockIdx.z as well and (Q, A) are accumulated with atomics (integer
 // sums are order-free); Rt3DBoundsKernel turns them into bounds.
@@ -303,19 +302,48 @@ template <bool kGroups>
 __global__ void __launch_bounds__(kBulk3DThreads)
 Rt3DBulkKernel(Rt3DBulkParams P, const float* __restrict__ xyz) {
   // Points 2p, 2p + 1 as {x0, x1, y0, y1, z0, z1}: what the packed f32 instructions read.
-  __shared__ v2f stage[2][3 * kBulk3DChunk / 2];
+  // Group pass: a block's 256 lanes are a window of the flat (rotation, group) sequence, i.e.
+  // they belong to one or two consecutive rotations (G groups fill 3.4 wavefronts: a block per
+  // rotation left 16 % of the lanes idle); both rotations' points are staged.
+  __shared__ v2f stage[2][kGroups ? 2 : 1][3 * kBulk3DChunk / 2];
   const int tid = threadIdx.x;
-  const int2 work = kGroups ? make_int2(blockIdx.y, blockIdx.x) : P.blocks[blockIdx.x];
-  const int r = work.x;
-  const int slot = work.y * kBulk3DThreads + tid;
-  const int count = kGroups ? P.num_translations : P.counts[r];
-  if (work.y * kBulk3DThreads >= count) return;                          // whole block idle
-  const bool wave_active = work.y * kBulk3DThreads + (tid & ~63) < count;
-  const bool valid = slot < count;
-  int t = valid ? slot : count - 1;
-  if (!kGroups) t = P.items[static_cast<size_t>(r) * P.num_translations + t];
-  const float4 q4 = P.rotation[r];
-  const Quat q{q4.w, q4.x, q4.y, q4.z};
+  int r, t, rotation_a = 0;
+  bool valid, wave_active;
+  if (kGroups && gridDim.y > 1) {
+    // (few groups per rotation, G < 128: a block would span more than two rotations; one
+    // rotation per blockIdx.y then, as the candidate pass)
+    r = blockIdx.y;
+    if (r >= P.num_rotations) return;                // (grid.y is at least 2 to mark this mode)
+    t = min(static_cast<int>(blockIdx.x * kBulk3DThreads + tid), P.num_translations - 1);
+    valid = static_cast<int>(blockIdx.x * kBulk3DThreads + tid) < P.num_translations;
+    wave_active = static_cast<int>(blockIdx.x * kBulk3DThreads + (tid & ~63)) < P.num_translations;
+    rotation_a = r;
+  } else if (kGroups) {
+    // blockDim.x <= G + 1 lanes: they belong to at most two consecutive rotations.
+    const long long first_flat = static_cast<long long>(blockIdx.x) * blockDim.x;
+    const long long flat = first_flat + tid;
+    const long long total = static_cast<long long>(P.num_rotations) * P.num_translations;
+    rotation_a = static_cast<int>(first_flat / P.num_translations);
+    valid = flat < total;
+    const long long f = valid ? flat : total - 1;
+    r = static_cast<int>(f / P.num_translations);
+    t = static_cast<int>(f - static_cast<long long>(r) * P.num_translations);
+    wave_active = first_flat + (tid & ~63) < total;
+  } else {
+    const int2 work = P.blocks[blockIdx.x];
+    r = work.x;
+    const int slot = work.y * kBulk3DThreads + tid;
+    const int count = P.counts[r];
+    if (work.y * kBulk3DThreads >= count) return;                        // whole block idle
+    wave_active = work.y * kBulk3DThreads + (tid & ~63) < count;
+    valid = slot < count;
+    t = P.items[static_cast<size_t>(r) * P.num_translations + (valid ? slot : count - 1)];
+    rotation_a = r;
+  }
+  const int which = r - rotation_a;                  // 0 or 1: which staged rotation a lane reads
+  const int rotation_b = min(rotation_a + 1, P.num_rotations - 1);
+  const float4 qa4 = P.rotation[rotation_a], qb4 = P.rotation[rotation_b];
+  const Quat q{qa4.w, qa4.x, qa4.y, qa4.z}, q_b{qb4.w, qb4.x, qb4.y, qb4.z};
   const float4 tr = P.translation[t];
   const int first = kGroups ? 0 : blockIdx.z * P.slice_points;   // (blockIdx.z: point slice)
   const int n = kGroups ? P.n : min(P.n, first + P.slice_points);
@@ -323,17 +351,22 @@ Rt3DBulkKernel(Rt3DBulkParams P, const float* __restrict__ xyz) {
       const_cast<uint8_t*>(P.cells), 0, P.cell_count, 0x00020000);
 
   const auto stage_chunk = [&](int base, int buf) {
-    const int i = base + tid;
-    // Padding points sit one reach below the box: every translation reads the zero halo.
-    float4 out = make_float4(P.lo_x - P.t0x, P.lo_y - P.t0y, P.lo_z - P.t0z, 0.f);
-    if (i < n) {
-      const F3 rp = Rotate(q, F3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]});
-      out.x = ClampStage(rp.x, P.t0x, P.lo_x, P.hi_x);
-      out.y = ClampStage(rp.y, P.t0y, P.lo_y, P.hi_y);
-      out.z = ClampStage(rp.z, P.t0z, P.lo_z, P.hi_z);
+    for (int k = tid; k < kBulk3DChunk; k += blockDim.x) {   // (the group pass may run 192 wide)
+      const int i = base + k;
+#pragma unroll
+      for (int w = 0; w < (kGroups ? 2 : 1); ++w) {
+        // Padding points sit one reach below the box: every translation reads the zero halo.
+        float4 out = make_float4(P.lo_x - P.t0x, P.lo_y - P.t0y, P.lo_z - P.t0z, 0.f);
+        if (i < n) {
+          const F3 rp = Rotate(w == 0 ? q : q_b, F3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]});
+          out.x = ClampStage(rp.x, P.t0x, P.lo_x, P.hi_x);
+          out.y = ClampStage(rp.y, P.t0y, P.lo_y, P.hi_y);
+          out.z = ClampStage(rp.z, P.t0z, P.lo_z, P.hi_z);
+        }
+        float* dst = reinterpret_cast<float*>(stage[buf][w]) + 6 * (k >> 1) + (k & 1);
+        dst[0] = out.x; dst[2] = out.y; dst[4] = out.z;
+      }
     }
-    float* dst = reinterpret_cast<float*>(stage[buf]) + 6 * (tid >> 1) + (tid & 1);
-    dst[0] = out.x; dst[2] = out.y; dst[4] = out.z;
   };
 
   const v2f trx = {tr.x, tr.x}, try_ = {tr.y, tr.y}, trz = {tr.z, tr.z};
@@ -350,7 +383,7 @@ Rt3DBulkKernel(Rt3DBulkParams P, const float* __restrict__ xyz) {
   for (int base = first; base < n; base += kBulk3DChunk, buf ^= 1) {
     if (base + kBulk3DChunk < n) stage_chunk(base + kBulk3DChunk, buf ^ 1);
     if (wave_active) {
-      const v2f* __restrict__ s = stage[buf];
+      const v2f* __restrict__ s = stage[buf][kGroups ? which : 0];
 #pragma unroll 2
       for (int j = 0; j < kBulk3DChunk; j += 4) {
         unsigned v[4];
@@ -436,6 +469,26 @@ Rt3DBoundsKernel(Rt3DBulkParams P) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) bits = max(bits, __shfl_xor(bits, off, 64));
   if ((threadIdx.x & 63) == 0 && bits != 0) atomicMax(P.max_lower_bits, bits);
+}
+
+// CMX_RT3D_VERIFY=1 (tests): a group's upper bound must not lie below the LOWER bound of any of
+// its members that was scored -- both bracket the same true score.  (A group pass reading the
+// wrong staged rotation once produced garbage bounds that every parity test survived: the
+// optimum happened not to be pruned.)  grid (work descriptors).
+__global__ void __launch_bounds__(kBulk3DThreads)
+Rt3DVerifyKernel(Rt3DBulkParams P, const float* __restrict__ group_upper, int num_groups,
+                 int side, int groups_per_axis, int* __restrict__ violations) {
+  const int2 work = P.blocks[blockIdx.x];
+  const int r = work.x;
+  const int slot = work.y * kBulk3DThreads + threadIdx.x;
+  if (slot >= P.counts[r]) return;
+  const int t = P.items[static_cast<size_t>(r) * P.num_translations + slot];
+  const uint2 qa = P.sums[static_cast<size_t>(r) * P.num_translations + t];
+  float lower, upper;
+  Bounds3D(P, qa.x, qa.y, P.translation[t].w, r, &lower, &upper);
+  const int x = t % side, y = (t / side) % side, z = t / (side * side);
+  const int g = ((z >> 1) * groups_per_axis + (y >> 1)) * groups_per_axis + (x >> 1);
+  if (group_upper[static_cast<size_t>(r) * num_groups + g] < lower) atomicAdd(violations, 1);
 }
 
 // 3 x 3 x 3 dilation of the padded brick in two passes (x, then y and z).  The halo is wider
@@ -887,6 +940,9 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
       int* d_counts = reinterpret_cast<int*>(d_bmisc + head_bytes);
       int2* d_blocks = reinterpret_cast<int2*>(d_bmisc + head_bytes + counts_bytes);
       int* d_num_blocks = reinterpret_cast<int*>(d_blocks + max_blocks);
+      int* d_violations = d_num_blocks + 1;          // (the second word of that int2 slot)
+      const char* verify_env = getenv("CMX_RT3D_VERIFY");
+      const bool verify = verify_env && verify_env[0] == '1';
       int* h_num_blocks = ws->pinned[1].ReserveAs<int>(4);
       char* h_bmisc = static_cast<char*>(ws->pinned[2].Reserve(head_bytes));
       float4* h_group = ws->pinned[3].ReserveAs<float4>(G);
@@ -945,8 +1001,13 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
       StageTrace trace(ws->stream);
       trace.Mark("bricks");
       CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
-      Rt3DBulkKernel<true><<<dim3(DivUp(G, kBulk3DThreads), static_cast<unsigned>(R)),
-                             kBulk3DThreads, 0, ws->stream>>>(BG, d_xyz);
+      // Flat (rotation, group) lanes: as many whole wavefronts per block as fit G + 1 lanes.
+      const int flat_threads = std::min(kBulk3DThreads, (G + 1) / 64 * 64);
+      if (flat_threads >= 128 && R >= 2)
+        Rt3DBulkKernel<true><<<DivUp(RG, flat_threads), flat_threads, 0, ws->stream>>>(BG, d_xyz);
+      else
+        Rt3DBulkKernel<true><<<dim3(DivUp(G, kBulk3DThreads), std::max<unsigned>(2u, R)),
+                               kBulk3DThreads, 0, ws->stream>>>(BG, d_xyz);
       CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
       // Candidate pass, twice: the members of the groups next to the best upper bound yield a
       // lower bound; then everything that lower bound cannot exclude.  (The threshold only
@@ -966,7 +1027,7 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
       int round_blocks[2] = {0, 0};
       for (int round = 0; round < 2; ++round) {
-        CMX_HIP(hipMemsetAsync(d_num_blocks, 0, sizeof(int), ws->stream));
+        CMX_HIP(hipMemsetAsync(d_num_blocks, 0, sizeof(int) * (round == 0 ? 2 : 1), ws->stream));
         Rt3DSelectGroupsKernel<<<DivUp(RG, 256), 256, 0, ws->stream>>>(
             d_group_upper, G, static_cast<int>(R), side_t, gpa,
             round == 0 ? d_max_upper : d_max_lower, round == 0 ? 0.97f : 1.f, d_expanded,
@@ -986,6 +1047,9 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
         const dim3 cand_grid(nb, 1, DivUp(n, BC.slice_points));
         Rt3DBulkKernel<false><<<cand_grid, kBulk3DThreads, 0, ws->stream>>>(BC, d_xyz);
         Rt3DBoundsKernel<<<nb, kBulk3DThreads, 0, ws->stream>>>(BC);
+        if (verify)
+          Rt3DVerifyKernel<<<nb, kBulk3DThreads, 0, ws->stream>>>(BC, d_group_upper, G, side_t,
+                                                                  gpa, d_violations);
         trace.Mark(round == 0 ? "candidate pass 1" : "candidate pass 2");
       }
       Rt3DBulkCollectKernel<<<DivUp(num_candidates, 256), 256, 0, ws->stream>>>(
@@ -1001,6 +1065,12 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
       trace.Report();
       const int count = *reinterpret_cast<int*>(h_bmisc + 4);
       const int total_items = *reinterpret_cast<int*>(h_bmisc + 12);
+      if (verify) {
+        int violations = 0;
+        CMX_HIP(hipMemcpy(&violations, d_violations, sizeof(int), hipMemcpyDeviceToHost));
+        CMX_REQUIRE(violations == 0,
+                    "internal error: %d group bounds below a member's lower bound", violations);
+      }
       if (getenv("CMX_RT3D_REPORT")) {
         float ms = 0.f, all = 0.f;
         CMX_HIP(hipEventElapsedTime(&ms, ws->ev_k0, ws->ev_k1));

@@ -344,6 +344,7 @@ def test_rt3d_bulk_pass_equals_per_candidate_kernel(sm3, oracle, synth, case, mo
     m = sm3.RealTimeCorrelativeScanMatcher3D(0.2, math.radians(1.0), *weights)
     rigid = sm3.Rigid3d(tuple(init[:3]), tuple(init[3:]))
     got = {}
+    monkeypatch.setenv("CMX_RT3D_VERIFY", "1")      # group bounds checked against member bounds
     for bulk in ("1", "0"):
         monkeypatch.setenv("CMX_RT3D_BULK", bulk)
         score, pose = m.match(rigid, cloud, 0.1, vox)
