@@ -219,6 +219,8 @@ __global__ void Rt3DCollectKernel(const float* __restrict__ weighted, long long 
 // which remains the path for flat score landscapes (more finalists than the list holds) and
 // for windows / grids beyond the limits checked in cmx_rt3d_match.
 constexpr int kBulk3DThreads = 256;
+constexpr int kCand3DThreads = 128;         // candidate pass: work lists are short (a block's idle
+                                            // wavefronts only hold wave slots)
 constexpr int kBulk3DChunk = 256;          // points staged per round (one per thread)
 constexpr int kAmbiguousQuad = 4 * 255;    // what one flagged group of four lookups can move Q by
 
@@ -332,10 +334,10 @@ Rt3DBulkKernel(Rt3DBulkParams P, const float* __restrict__ xyz) {
   } else {
     const int2 work = P.blocks[blockIdx.x];
     r = work.x;
-    const int slot = work.y * kBulk3DThreads + tid;
+    const int slot = work.y * kCand3DThreads + tid;
     const int count = P.counts[r];
-    if (work.y * kBulk3DThreads >= count) return;                        // whole block idle
-    wave_active = work.y * kBulk3DThreads + (tid & ~63) < count;
+    if (work.y * kCand3DThreads >= count) return;                        // whole block idle
+    wave_active = work.y * kCand3DThreads + (tid & ~63) < count;
     valid = slot < count;
     t = P.items[static_cast<size_t>(r) * P.num_translations + (valid ? slot : count - 1)];
     rotation_a = r;
@@ -451,11 +453,11 @@ Rt3DBulkKernel(Rt3DBulkParams P, const float* __restrict__ xyz) {
 }
 
 // grid (work descriptors): bounds of the candidates on the work lists from their (Q, A).
-__global__ void __launch_bounds__(kBulk3DThreads)
+__global__ void __launch_bounds__(kCand3DThreads)
 Rt3DBoundsKernel(Rt3DBulkParams P) {
   const int2 work = P.blocks[blockIdx.x];
   const int r = work.x;
-  const int slot = work.y * kBulk3DThreads + threadIdx.x;
+  const int slot = work.y * kCand3DThreads + threadIdx.x;
   const int count = P.counts[r];
   float lower = 0.f, upper = 0.f;
   if (slot < count) {
@@ -475,12 +477,12 @@ Rt3DBoundsKernel(Rt3DBulkParams P) {
 // its members that was scored -- both bracket the same true score.  (A group pass reading the
 // wrong staged rotation once produced garbage bounds that every parity test survived: the
 // optimum happened not to be pruned.)  grid (work descriptors).
-__global__ void __launch_bounds__(kBulk3DThreads)
+__global__ void __launch_bounds__(kCand3DThreads)
 Rt3DVerifyKernel(Rt3DBulkParams P, const float* __restrict__ group_upper, int num_groups,
                  int side, int groups_per_axis, int* __restrict__ violations) {
   const int2 work = P.blocks[blockIdx.x];
   const int r = work.x;
-  const int slot = work.y * kBulk3DThreads + threadIdx.x;
+  const int slot = work.y * kCand3DThreads + threadIdx.x;
   if (slot >= P.counts[r]) return;
   const int t = P.items[static_cast<size_t>(r) * P.num_translations + slot];
   const uint2 qa = P.sums[static_cast<size_t>(r) * P.num_translations + t];
@@ -547,7 +549,7 @@ __global__ void Rt3DSelectGroupsKernel(const float* __restrict__ group_upper, in
 // One block per rotation: the flagged translations in ascending order (x offsets fastest, so
 // neighbouring lanes of the candidate pass read neighbouring cells: a gather instruction costs
 // about 17 cycles plus 1.3 per distinct cache line it touches), flags cleared for the next
-// round; one work descriptor (r, chunk) per 256 of them.
+// round; one work descriptor (r, chunk) per kCand3DThreads of them.
 __global__ void __launch_bounds__(256)
 Rt3DCompactKernel(uint8_t* __restrict__ flags, int num_translations, int* __restrict__ counts,
                   int* __restrict__ items, int* __restrict__ total, int2* __restrict__ blocks,
@@ -577,7 +579,7 @@ Rt3DCompactKernel(uint8_t* __restrict__ flags, int num_translations, int* __rest
     counts[r] = base;
     if (base) {
       atomicAdd(total, base);
-      const int chunks = (base + 255) / 256;
+      const int chunks = (base + kCand3DThreads - 1) / kCand3DThreads;
       const int first = atomicAdd(num_blocks, chunks);
       for (int k = 0; k < chunks; ++k) blocks[first + k] = make_int2(r, k);
     }
@@ -927,7 +929,7 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
       int* d_items = reinterpret_cast<int*>(d_unweighted);           // [R][T], reused
       const size_t head_bytes = 16 + (sizeof(int) + sizeof(float)) * kBulkFinalistCap;   // 16 | 32768
       // work descriptors of a round: at most one per 256 translations and rotation, + count
-      const int max_blocks = static_cast<int>(R) * DivUp(T, kBulk3DThreads);
+      const int max_blocks = static_cast<int>(R) * DivUp(T, kCand3DThreads);
       const size_t counts_bytes = (sizeof(int) * R + 15) / 16 * 16;
       char* d_bmisc = static_cast<char*>(ws->dev[13].Reserve(
           head_bytes + counts_bytes + sizeof(int2) * (max_blocks + 1)));
@@ -1041,14 +1043,15 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
         CMX_HIP(hipStreamSynchronize(ws->stream));
         const int nb = round_blocks[round] = *h_num_blocks;
         if (nb == 0) continue;
-        // Points are split over blockIdx.z until the chip is covered about eight times.
-        const int want = std::max(1, DivUp(8 * cus, nb));
+        // Points are split over blockIdx.z until the launch is ~32 blocks per CU.
+        // (blocks of two wavefronts: sixteen fit a CU)
+        const int want = std::max(1, DivUp(32 * cus, nb));
         BC.slice_points = std::max(1, DivUp(DivUp(n, want), kBulk3DChunk)) * kBulk3DChunk;
         const dim3 cand_grid(nb, 1, DivUp(n, BC.slice_points));
-        Rt3DBulkKernel<false><<<cand_grid, kBulk3DThreads, 0, ws->stream>>>(BC, d_xyz);
-        Rt3DBoundsKernel<<<nb, kBulk3DThreads, 0, ws->stream>>>(BC);
+        Rt3DBulkKernel<false><<<cand_grid, kCand3DThreads, 0, ws->stream>>>(BC, d_xyz);
+        Rt3DBoundsKernel<<<nb, kCand3DThreads, 0, ws->stream>>>(BC);
         if (verify)
-          Rt3DVerifyKernel<<<nb, kBulk3DThreads, 0, ws->stream>>>(BC, d_group_upper, G, side_t,
+          Rt3DVerifyKernel<<<nb, kCand3DThreads, 0, ws->stream>>>(BC, d_group_upper, G, side_t,
                                                                   gpa, d_violations);
         trace.Mark(round == 0 ? "candidate pass 1" : "candidate pass 2");
       }
