@@ -74,7 +74,7 @@ def parse_args():
     ap.add_argument("--pmc-dir", default=os.path.join(ROOT, "profiles"),
                     help="directory with <tag>_pmc_{fetch,write}_size.csv of THIS command "
                          "(tools/profile_bench.sh writes them); roofline.traffic is null without")
-    ap.add_argument("--pmc-tag", default="r02")
+    ap.add_argument("--pmc-tag", default="r02e")
     return ap.parse_args()
 
 
@@ -86,26 +86,26 @@ def _cores():
     return max(1, min(cores, 32))
 
 
-def pmc_traffic_bytes(pmc_dir, tag, kernel):
-    """HBM-side bytes per launch of `kernel` from rocprofv3 PMC passes of the bench commands
-    (tools/profile_all.sh writes <tag>[_<config>]_pmc_{fetch,write}_size.csv; FETCH_SIZE and
-    WRITE_SIZE need separate passes, MI355X_MICROARCH.md "rocprofv3 PMC slots"; values are KiB;
-    FETCH_SIZE is doubled per the guide's gfx950 correction).  None when no pass contains the
-    kernel (e.g. after a rename): a stale number is worse than none."""
+def pmc_traffic_bytes(pmc_dir, tag, kernel, config=""):
+    """HBM-side bytes per launch of `kernel` from the rocprofv3 PMC passes of ONE bench command:
+    tools/profile_all.sh writes <tag>_pmc_{fetch,write}_size.csv for the default (C2) command
+    and <tag>_<config>_pmc_... for `--config c1` (128 matches), `c3 --submaps 16`, `c4` and
+    `c5 --submaps 32`.  FETCH_SIZE and WRITE_SIZE need separate passes (MI355X_MICROARCH.md
+    "rocprofv3 PMC slots"); values are KiB; FETCH_SIZE is doubled per the guide's gfx950
+    correction.  None when that pass does not exist or does not contain the kernel (a rename,
+    another batch size): a number of some other command is worse than none."""
     import csv
-    import glob
+    stem = f"{tag}_{config}" if config else tag
     total = 0.0
     for suffix, factor in (("_pmc_fetch_size.csv", 2.0), ("_pmc_write_size.csv", 1.0)):
-        value = None
-        for path in sorted(glob.glob(os.path.join(pmc_dir, f"{tag}*{suffix}"))):
-            with open(path) as f:
-                rows = [r for r in csv.DictReader(f) if kernel in r["Kernel"]]
-            if rows:
-                value = float(rows[0]["MeanValue"]) * 1024.0 * factor
-                break
-        if value is None:
+        path = os.path.join(pmc_dir, stem + suffix)
+        if not os.path.exists(path):
             return None
-        total += value
+        with open(path) as f:
+            rows = [r for r in csv.DictReader(f) if kernel in r["Kernel"]]
+        if not rows:
+            return None
+        total += float(rows[0]["MeanValue"]) * 1024.0 * factor
     return total
 
 
@@ -288,7 +288,10 @@ class Fast2DWorkload:
         alg = coarse * self.n_points * 1.0 + scans * self.n_points * 4.0
         gathered = scans * self.n_points * 64.0         # <= one plane per point per rotation
         secs = max(k_ms, 1e-9) * 1e-3
-        traffic = pmc("PrepScoreFused")
+        # PMC passes exist for the single-submap command and for 16 submaps per GPU
+        per_gpu = self.end - self.begin
+        pmc_config = "" if per_gpu == 1 else ("c3" if per_gpu == 16 else None)
+        traffic = None if pmc_config is None else pmc("PrepScoreFused", pmc_config)
         out = {
             "kernel": "PrepScoreFusedKernel (prep + bucketing + lowest-resolution scoring)",
             "bound": "l2-gather", "achieved": gathered / secs / 1e9, "peak": L2_PEAK_GBS,
@@ -305,6 +308,19 @@ class Fast2DWorkload:
                     "+ WRITE_SIZE of the same command / kernel time / 8 TB/s (null without the PMC "
                     "passes under --pmc-dir).  kernel_ms: HIP events on the kernel's own stream.",
         }
+        wave = expansion_roofline(
+            acc, steps, "ExpandWaveKernel (one wavefront per node: one quad gather per point)",
+            None if pmc_config is None else pmc("ExpandWave", pmc_config),
+            "achieved = lookups of the wave-per-node stages (64 per gather instruction issued, "
+            "counted by the kernel: nodes stop early once no child can reach the bound) / HIP-event "
+            "span of those launches / the measured gather-issue ceiling of the chip (coherent byte "
+            "gathers; the quad gathers here touch up to 64 distinct 128-byte lines each, so the "
+            "fraction is a lower bound of how close the stage is to what such gathers allow)")
+        if wave is not None and acc["expansion_ms"] > acc["dominant_kernel_ms"]:
+            wave["front_end"] = out      # batches: the expansion is the dominant kernel
+            return wave
+        if wave is not None:
+            out["expansion"] = wave
         return out
 
 
@@ -362,7 +378,8 @@ class Rt2DWorkload:
         lds = cand / (side * side) * self.points * (side * ((side + 6) // 4)) * 8.0
         return {"kernel": "Rt2DBulkKernel (LDS-staged grid, packed 16-bit sums)", "bound": "lds",
                 "achieved": lds / secs / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
-                "frac": lds / secs / 1e9 / LDS_PEAK_GBS, "traffic": pmc("Rt2DBulk"),
+                "frac": lds / secs / 1e9 / LDS_PEAK_GBS,
+                "traffic": pmc("Rt2DBulk", "c1") if self.matches_per_step == 128 else None,
                 "kernel_ms": k_ms, "algorithmic_bytes": alg, "lds_bytes": lds,
                 "algorithmic_GBps": alg / secs / 1e9,
                 "hbm_frac_algorithmic": alg / secs / 1e9 / HBM_PEAK_GBS,
@@ -420,7 +437,8 @@ class Rt3DWorkload:
                           "on the dilated uint8 brick)" if bulk else "Rt3DScoreKernel",
                 "bound": "gather-issue", "achieved": lookups / secs / 1e9, "peak": peak,
                 "unit": "Glookup/s", "frac": lookups / secs / 1e9 / peak,
-                "traffic": pmc("Rt3DBulk"), "kernel_ms": k_ms, "algorithmic_bytes": alg,
+                "traffic": pmc("Rt3DBulkKernel<true>", "c4"), "kernel_ms": k_ms,
+                "algorithmic_bytes": alg,
                 "hbm_frac_algorithmic_whole_step":
                     alg / (acc["device_ms"] / steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "kernel_share_of_step_device_time": k_ms / (acc["device_ms"] / steps),
@@ -493,11 +511,25 @@ class Fast3DWorkload:
         scans = acc["num_scans"] / steps
         secs = max(k_ms, 1e-9) * 1e-3
         alg = coarse * self.n_points * 1.0 + scans * self.n_points * 12.0
-        return {"kernel": "ScoreCoarse3D", "bound": "hbm", "achieved": alg / secs / 1e9,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / secs / 1e9 / HBM_PEAK_GBS,
-                "traffic": pmc("ScoreCoarse3D"), "kernel_ms": k_ms, "algorithmic_bytes": alg,
-                "note": "lowest-resolution scoring: 1 B per candidate-point + 12 B per yaw-point "
-                        "(SURVEY 8d) / kernel time / 8 TB/s"}
+        pmc_config = "c5" if self.pairs == 32 else None
+        coarse_line = {"kernel": "ScoreCoarse3D", "bound": "hbm", "achieved": alg / secs / 1e9,
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": alg / secs / 1e9 / HBM_PEAK_GBS,
+                       "traffic": None if pmc_config is None else pmc("ScoreCoarse3D", pmc_config),
+                       "kernel_ms": k_ms, "algorithmic_bytes": alg,
+                       "note": "lowest-resolution scoring: 1 B per candidate-point + 12 B per "
+                               "yaw-point (SURVEY 8d) / kernel time / 8 TB/s"}
+        expand = expansion_roofline(
+            acc, steps, "Expand3DKernel (one workgroup per node: one 8-byte oct gather per point)",
+            None if pmc_config is None else pmc("Expand3DKernel", pmc_config),
+            "achieved = nodes taken off the frontiers x points (an upper bound: nodes found below "
+            "the bound when they are taken are skipped) / HIP-event span of the expansion launches "
+            "/ the measured gather-issue ceiling of the chip (coherent byte gathers; the 8-byte "
+            "gathers here touch 64 distinct lines each)")
+        if expand is None:
+            return coarse_line
+        expand["lowest_resolution_scoring"] = coarse_line
+        return expand
 
 
 def make_workload(name, args, device, rank, world_size):
@@ -513,7 +545,30 @@ def make_workload(name, args, device, rank, world_size):
 
 
 STAT_KEYS = ("candidates_scored", "coarse_candidates", "dominant_kernel_ms", "device_ms",
-             "num_scans")
+             "num_scans", "expansion_ms", "expansion_launches", "expansion_nodes",
+             "expansion_lookups")
+GATHER_PEAK_GLOOKUPS = 2050.0   # measured: 19 cycles per 64-lane gather instruction per CU
+                                # (profiles/r02_rt3d_gather_ceiling.txt) x 256 CUs x 2.4 GHz
+
+
+def expansion_roofline(acc, steps, kernel, traffic, note):
+    """The level-synchronous branch-and-bound expansion launches (fast 2D: ExpandWaveKernel,
+    fast 3D: Expand3DKernel), priced against the rate at which the chip issues wave-wide
+    gathers.  None when the call timed none."""
+    launches = acc["expansion_launches"] / steps
+    if launches <= 0 or acc["expansion_ms"] <= 0:
+        return None
+    span_ms = acc["expansion_ms"] / steps
+    lookups = acc["expansion_lookups"] / steps
+    secs = span_ms * 1e-3
+    return {"kernel": kernel, "bound": "gather-issue", "achieved": lookups / secs / 1e9,
+            "peak": GATHER_PEAK_GLOOKUPS, "unit": "Glookup/s",
+            "frac": lookups / secs / 1e9 / GATHER_PEAK_GLOOKUPS, "traffic": traffic,
+            "launches_per_step": launches, "kernel_ms": span_ms / launches,
+            "span_ms_per_step": span_ms, "nodes_per_step": acc["expansion_nodes"] / steps,
+            "lookups_per_step": lookups,
+            "kernel_share_of_step_device_time": acc["expansion_ms"] / max(acc["device_ms"], 1e-9),
+            "note": note}
 
 
 def measure(workload, steps, warmup, sync):
@@ -530,7 +585,7 @@ def measure(workload, steps, warmup, sync):
         for _ in range(steps):
             last = workload.search()
             for k in STAT_KEYS:
-                acc[k] += last[3][k]
+                acc[k] += last[3].get(k, 0)
         sync()
         dt = time.perf_counter() - t0
     finally:
@@ -652,7 +707,7 @@ def main():
 
         def add(result):
             for k in STAT_KEYS:
-                acc[k] += result[3][k]
+                acc[k] += result[3].get(k, 0)
 
         if args.concurrency <= 1:
             for _ in range(num_steps):
@@ -719,8 +774,8 @@ def main():
 
     out = None
     if rank == 0:
-        def pmc(kernel):
-            return pmc_traffic_bytes(args.pmc_dir, args.pmc_tag, kernel)
+        def pmc(kernel, config=""):
+            return pmc_traffic_bytes(args.pmc_dir, args.pmc_tag, kernel, config)
         config = workload.describe(stats, found)
         config.update({
             "name": name,

@@ -54,8 +54,10 @@ class Fast3DOptions(C.Structure):
 
 class MatchStats(C.Structure):
     _fields_ = [("candidates_scored", C.c_int64), ("coarse_candidates", C.c_int64),
-                ("nodes_expanded", C.c_int64), ("num_scans", C.c_int32), ("reserved", C.c_int32),
-                ("device_ms", C.c_double), ("dominant_kernel_ms", C.c_double)]
+                ("nodes_expanded", C.c_int64), ("num_scans", C.c_int32), ("expansion_launches", C.c_int32),
+                ("device_ms", C.c_double), ("dominant_kernel_ms", C.c_double),
+                ("expansion_ms", C.c_double), ("expansion_nodes", C.c_int64),
+                ("expansion_lookups", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -125,6 +125,7 @@ struct Workspace {
   hipStream_t stream = nullptr;  // own_stream or the caller's (cmx_set_stream)
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;  // dominant-kernel bracket
+  hipEvent_t ev_x0 = nullptr, ev_x1 = nullptr;  // branch-and-bound expansion bracket
   static constexpr int kNumBuffers = 16;
   DeviceBuffer dev[kNumBuffers];
   PinnedBuffer pinned[4];

@@ -82,6 +82,8 @@ Workspace::~Workspace() {
   if (ev_end) (void)hipEventDestroy(ev_end);
   if (ev_k0) (void)hipEventDestroy(ev_k0);
   if (ev_k1) (void)hipEventDestroy(ev_k1);
+  if (ev_x0) (void)hipEventDestroy(ev_x0);
+  if (ev_x1) (void)hipEventDestroy(ev_x1);
   if (own_stream) (void)hipStreamDestroy(own_stream);
 }
 
@@ -183,6 +185,8 @@ WorkspaceLease::WorkspaceLease(int device) : ws_(nullptr) {
     CMX_HIP(hipEventCreate(&ws->ev_end));
     CMX_HIP(hipEventCreate(&ws->ev_k0));
     CMX_HIP(hipEventCreate(&ws->ev_k1));
+    CMX_HIP(hipEventCreate(&ws->ev_x0));
+    CMX_HIP(hipEventCreate(&ws->ev_x1));
     ws_ = ws.release();
   }
   hipStream_t over = OverrideStream(device);

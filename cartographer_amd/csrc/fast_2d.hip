@@ -831,7 +831,17 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
   Stamp(tl, tl_block, 6);      // scores written
   // The discretised scan stays on chip: the tree search re-derives the cells of the few scans
   // it descends into (ScanCell).  Only the introspection entry point asks for the array.
-  if (P.write_all_discrete) {
+  // Batches (store_scans): a scan whose best candidate reaches the initial bound may enter the
+  // tree search, where several nodes per scan are expanded by independent wavefronts; its
+  // cells are written for them (a superset of what the coarse filter keeps: the bound only
+  // rises).  Re-deriving the cells per node made that expansion VALU-bound.
+  bool keep_cells = P.write_all_discrete != 0;
+  if (!keep_cells && P.store_scans) {
+    int top_sum = scratch[0].x;
+    for (int w = 1; w < T >> 6; ++w) top_sum = max(top_sum, scratch[w].x);
+    keep_cells = !(ToScore(P, top_sum, n) < fmaxf(P.min_score, 0.f));
+  }
+  if (keep_cells) {
     auto* out = AsGlobal(P.discrete) + static_cast<size_t>(s) * n;
     for (int i = threadIdx.x; i < n; i += T) out[i] = pts[i];
   }
@@ -857,7 +867,8 @@ struct Counters {           // device, zeroed per call
   int leaves[kSubLists * kCountStride];
   int frontier_overflow;
   int leaf_overflow;
-  int pad[2];
+  unsigned wave_gathers;      // 64-lane quad gathers issued by ExpandWaveKernel (statistics)
+  int pad;
 };
 
 // What the host needs of the counters, written next to the results by the last kernel of a
@@ -867,6 +878,8 @@ struct CountersSummary {
   int frontier_total[kMaxStages];
   int frontier_overflow;
   int leaf_overflow;
+  unsigned wave_gathers;
+  int pad;
 };
 
 struct NodeList {
@@ -1064,10 +1077,10 @@ struct BlockContext {
 };
 
 __device__ __forceinline__ void LoadContext(const Fast2DProblem& P, int n, int scan,
-                                            BlockContext* ctx) {
+                                            BlockContext* ctx, bool stored = false) {
   const uint32_t* pts = P.discrete + static_cast<size_t>(scan) * n;
   const bool cached = n <= kPointCache;
-  if (P.recompute_scans) {          // (implies n <= kFusedMaxPoints = kPointCache)
+  if (P.recompute_scans && !stored) {   // (implies n <= kFusedMaxPoints = kPointCache)
     const float2 rot = P.scan_rot[scan];
     for (int i = threadIdx.x; i < n; i += blockDim.x) ctx->cache[i] = ScanCell(P, rot, i);
   } else if (cached) {
@@ -1239,7 +1252,7 @@ DiveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restrict_
 __global__ void __launch_bounds__(256)
 FilterCoarseKernel(const Fast2DProblem* __restrict__ problems,
                    const ProblemState* __restrict__ states, int n, int chunk, int num_chunks,
-                   int strict, NodeList out, Counters* __restrict__ counters) {
+                   int strict, int affinity, NodeList out, Counters* __restrict__ counters) {
   // One WAVEFRONT per rotated scan (grid: ceil(scans / 4) x problems): a scan's filter is a
   // chain of dependent loads (problem, best candidate, dimensions, scores, list slot) over
   // ~190 candidates; a block per scan kept 8 of those chains in flight per CU, and 36 k blocks
@@ -1265,7 +1278,11 @@ FilterCoarseKernel(const Fast2DProblem* __restrict__ problems,
   for (int c0 = 0; c0 < count; c0 += kWave) {
     // One reservation per wave; consecutive waves use consecutive sub-lists, so that one
     // rotation's survivors do not all queue in the same one.
-    const int sub = (s + blockIdx.y + (c0 >> 6)) & (kSubLists - 1);
+    // With `affinity` a problem's nodes only go to the sub-lists the workgroups of ONE XCD
+    // read (sub % 8 == problem % 8, see ExpandWaveKernel): the level data of that problem
+    // then lives in one L2 instead of eight.
+    const int sub = affinity ? (problem & 7) + 8 * ((s + (c0 >> 6)) & 7)
+                             : (s + blockIdx.y + (c0 >> 6)) & (kSubLists - 1);
     const int c = c0 + lane;
     bool keep = false;
     if (c < count) {
@@ -1301,12 +1318,15 @@ constexpr int kWaveStatProblems = 1024;   // problems whose work counters a bloc
 
 __global__ void __launch_bounds__(256)
 ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restrict__ states,
-                 int n, NodeList in, int strict, NodeList out, Counters* __restrict__ counters) {
+                 int n, NodeList in, int strict, int affinity, NodeList out,
+                 Counters* __restrict__ counters) {
   // Work counters (candidates scored / nodes expanded per problem) are collected in LDS and
   // flushed once per block: one global atomic pair PER NODE -- half a million nodes of 16
   // problems hammering 32 cache lines -- was 64 % of this kernel on a 16-submap batch
   // (3.36 -> 1.21 ms, profiles/r02_c3_wave_atomics.txt).
   __shared__ unsigned stat_scored[kWaveStatProblems], stat_expanded[kWaveStatProblems];
+  __shared__ unsigned stat_gathers;
+  if (threadIdx.x == 0) stat_gathers = 0;
   for (int i = threadIdx.x; i < kWaveStatProblems; i += blockDim.x) {
     stat_scored[i] = 0;
     stat_expanded[i] = 0;
@@ -1315,8 +1335,16 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int max_count = ListMaxCount(in);
-  const int out_sub = (blockIdx.x * 4 + wave) & (kSubLists - 1);
-  for (int i = blockIdx.x * 4 + wave; i < max_count * kSubLists; i += gridDim.x * 4) {
+  // Workgroups go to the XCDs round-robin (blockIdx.x % 8).  With `affinity` the waves of XCD
+  // x read and write only the sub-lists with sub % 8 == x (grid: a multiple of 16 blocks), so
+  // that a node's children are expanded on the XCD whose L2 already holds that problem.
+  int first = blockIdx.x * 4 + wave;
+  if (affinity) {
+    const int slot = (blockIdx.x >> 3) * 4 + wave;            // wave index within the XCD
+    first = (slot >> 3) * kSubLists + (blockIdx.x & 7) + 8 * (slot & 7);
+  }
+  const int out_sub = first & (kSubLists - 1);
+  for (int i = first; i < max_count * kSubLists; i += gridDim.x * 4) {
     const int in_sub = i & (kSubLists - 1), j = i / kSubLists;
     if (j >= in.counts[in_sub * kCountStride]) continue;   // wave-uniform
     const Node2D nd = in.nodes[static_cast<size_t>(in_sub) * in.sub_capacity + j];
@@ -1331,7 +1359,7 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
     const int half = 1 << child_level, off = half - 1;
     const bool vx = nd.dx + half <= bd.y, vy = nd.dy + half <= bd.w;
     const auto* pts = AsGlobal(P.discrete) + static_cast<size_t>(nd.scan) * n;
-    const bool recompute = P.recompute_scans != 0;
+    const bool recompute = P.recompute_scans != 0 && P.store_scans == 0;
     const float2 rot = recompute ? P.scan_rot[nd.scan] : make_float2(1.f, 0.f);
     // Early exit.  A level-(l+1) cell is the maximum of the four level-l cells its
     // children read (the 2h window is tiled by four h windows), so for every point
@@ -1346,6 +1374,7 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
     const uint32_t child_mask =
         (vx ? 0xffffffffu : 0x0000ffffu) & (vy ? 0xffffffffu : 0x00ff00ffu);
     int s00 = 0, s01 = 0, s10 = 0, s11 = 0, seen_max = 0;
+    int groups = 0;
     bool dead = false;
     // 64-point iterations gathered between two bound checks (1, 2 and 4 measure the same on a
     // 16-submap batch; 16, i.e. everything in flight at once, was no faster for single
@@ -1373,6 +1402,7 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
         s00 += a00; s01 += a01; s10 += a10; s11 += a11;
         seen_max += max(max(a00, a01), max(a10, a11));
       }
+      ++groups;
       if (q0 + kGroup < n) {
         const int rest = parent_ub - WaveSum(seen_max);
         const int reach = max(max(WaveSum(s00), WaveSum(s01)), max(WaveSum(s10), WaveSum(s11)));
@@ -1381,6 +1411,7 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
       }
     }
     const auto count_node = [&](int nvalid) {     // lane 0
+      atomicAdd(&stat_gathers, static_cast<unsigned>(min(groups * kIters, (n + kWave - 1) / kWave)));
       if (problem < kWaveStatProblems) {
         atomicAdd(&stat_scored[problem], static_cast<unsigned>(nvalid));
         atomicAdd(&stat_expanded[problem], 1u);
@@ -1439,6 +1470,7 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
     }
   }
   __syncthreads();
+  if (threadIdx.x == 0 && stat_gathers) atomicAdd(&counters->wave_gathers, stat_gathers);
   for (int i = threadIdx.x; i < kWaveStatProblems; i += blockDim.x) {
     if (stat_expanded[i] == 0) continue;
     ProblemState& st = states[i];
@@ -1485,7 +1517,7 @@ SubtreeKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restri
       s_best = __uint_as_float(__hip_atomic_load(&st.best_bits, __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_AGENT));
     }
-    LoadContext(P, n, root.scan, &ctx);   // ends with __syncthreads()
+    LoadContext(P, n, root.scan, &ctx, P.store_scans != 0);   // ends with __syncthreads()
     unsigned long long scored = 0, expanded = 0;
     for (;;) {
       if (threadIdx.x == 0) {
@@ -1587,6 +1619,7 @@ SelectBestKernel(NodeList leaves, const ProblemState* __restrict__ states,
   if (threadIdx.x == 128) {
     summary->frontier_overflow = counters->frontier_overflow;
     summary->leaf_overflow = counters->leaf_overflow;
+    summary->wave_gathers = counters->wave_gathers;
   }
   const int max_count = ListMaxCount(leaves);
   const int total = max_count * kSubLists;
@@ -2129,6 +2162,12 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     out->d_timeline = static_cast<unsigned long long*>(ws.dev[15].Reserve(bytes));
     CMX_HIP(hipMemsetAsync(out->d_timeline, 0, bytes, ws.stream));
   }
+  // Batches keep the cells of surviving scans (CMX_STORE_SCANS=0/1 overrides).
+  static const int kStoreScans = [] {
+    const char* e = getenv("CMX_STORE_SCANS");
+    return e ? atoi(e) : -1;
+  }();
+  const int store_scans = kStoreScans >= 0 ? kStoreScans : (num >= 4 ? 1 : 0);
   size_t disc_off = 0, scan_off = 0, coarse_off = 0;
   for (int p = 0; p < num; ++p) {
     const Fast2DMatcher& m = *matchers[p];
@@ -2138,6 +2177,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     P.timeline = out->d_timeline;
     P.xyz = d_xyz;
     P.recompute_scans = (P.use_fused && !P.write_all_discrete) ? 1 : 0;
+    P.store_scans = store_scans;
     for (int i = 0; i < m.depth(); ++i) P.level[i] = m.level(i);
     P.depth = m.depth();
     P.nx = lim.num_x_cells; P.ny = lim.num_y_cells;
@@ -2246,6 +2286,9 @@ struct BatchResult {
   std::vector<BestLeaf> best;
   std::vector<ProblemState> states;
   double device_ms = 0., dominant_ms = 0.;
+  double expansion_ms = 0.;          // wave-per-node stages of the first pass
+  int expansion_launches = 0;
+  long long expansion_nodes = 0, expansion_lookups = 0;
 };
 
 struct ScoreIndex;
@@ -2356,6 +2399,12 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
     // Frontier sizes are only known on the device; grids are sized for the
     // typical case (a few thousand nodes at the top, tens below) and every
     // kernel grid-strides, so larger frontiers (big batches) still fill the chip.
+    // Batches: one problem's nodes stay on one XCD (CMX_XCD_AFFINITY=0/1 overrides).
+    static const int kAffinity = [] {
+      const char* e = getenv("CMX_XCD_AFFINITY");
+      return e ? atoi(e) : -1;
+    }();
+    const int affinity = kAffinity >= 0 ? kAffinity : (num >= 16 ? 1 : 0);
     const int wide_blocks = std::min(4096, 1024 * std::max(1, (num + 3) / 4));
     const int narrow_blocks = std::min(4096, 512 * std::max(1, (num + 3) / 4));
     int num_chunks = 1;
@@ -2366,17 +2415,24 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
           CMX_HIP(hipMemsetAsync(d_counters->frontier, 0, sizeof(d_counters->frontier),
                                  ws.stream));
         FilterCoarseKernel<<<dim3(DivUp(batch.max_scans, 4), num), 256, 0, ws.stream>>>(
-            batch.d_problems, batch.d_states, n, chunk, num_chunks, strict, front(0), d_counters);
+            batch.d_problems, batch.d_states, n, chunk, num_chunks, strict, affinity, front(0),
+            d_counters);
         mark("filter");
         int stage = 0;
         int top = depth - 1;
         // Wave-per-node level-synchronous expansion of the (wide, shallow-lived)
-        // top levels.
+        // top levels.  (Timed for the statistics in the first pass.)
+        const bool timed = !strict && chunk == 0;
+        if (timed) CMX_HIP(hipEventRecord(ws.ev_x0, ws.stream));
         for (int used = 0; used < wave_levels && top - 1 >= 1; ++used, --top, ++stage) {
           ExpandWaveKernel<<<used == 0 ? wide_blocks : narrow_blocks, 256, 0, ws.stream>>>(
-              batch.d_problems, batch.d_states, n, front(stage), strict, front(stage + 1),
-              d_counters);
+              batch.d_problems, batch.d_states, n, front(stage), strict, affinity,
+              front(stage + 1), d_counters);
           mark("wave");
+        }
+        if (timed) {
+          CMX_HIP(hipEventRecord(ws.ev_x1, ws.stream));
+          result->expansion_launches = stage;
         }
         // Block-per-node depth-first stages of kLevelsPerStage levels: the bushy
         // part of the tree near the optimum spreads over many blocks instead of
@@ -2395,6 +2451,11 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
       CMX_HIP(hipGetLastError());
       CMX_HIP(hipEventRecord(ws.ev_end, ws.stream));
       fetch_results();
+      if (!strict) {
+        for (int st = 0; st < result->expansion_launches; ++st)
+          result->expansion_nodes += h_counters->frontier_total[st];
+        result->expansion_lookups = 64ll * h_counters->wave_gathers;
+      }
       if (!h_counters->frontier_overflow && !h_counters->leaf_overflow) break;
       // Something was dropped.  Bounds found so far are real leaf scores and
       // stay valid; repeat the search in strict mode (prunes ties, records
@@ -2436,6 +2497,10 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
   result->device_ms = ms;
   CMX_HIP(hipEventElapsedTime(&ms, ws.ev_k0, ws.ev_k1));
   result->dominant_ms = ms;
+  if (result->expansion_launches > 0) {
+    CMX_HIP(hipEventElapsedTime(&ms, ws.ev_x0, ws.ev_x1));
+    result->expansion_ms = ms;
+  }
 }
 
 
@@ -2669,6 +2734,10 @@ void MatchBatch(const cmx_fast2d* const* handles, int num, const cmx_pose2d* ini
   }
   total.device_ms = result.device_ms;
   total.dominant_kernel_ms = result.dominant_ms;
+  total.expansion_ms = result.expansion_ms;
+  total.expansion_launches = result.expansion_launches;
+  total.expansion_nodes = result.expansion_nodes;
+  total.expansion_lookups = result.expansion_lookups;
   if (stats) *stats = total;
 }
 

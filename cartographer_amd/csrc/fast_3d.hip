@@ -1000,6 +1000,9 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
       total.candidates_scored += st.candidates_scored; total.coarse_candidates += st.coarse_candidates;
       total.nodes_expanded += st.nodes_expanded; total.num_scans += st.num_scans;
       total.device_ms += st.device_ms; total.dominant_kernel_ms += st.dominant_kernel_ms;
+      total.expansion_ms += st.expansion_ms; total.expansion_nodes += st.expansion_nodes;
+      total.expansion_lookups += st.expansion_lookups;
+      total.expansion_launches += st.expansion_launches;
     }
     if (stats) *stats = total;
     return;
@@ -1263,11 +1266,17 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
         dbg("filter");
         mark("filter");
         int stage = 0;
+        const bool timed = !strict && chunk == 0;      // statistics: the first pass
+        if (timed) CMX_HIP(hipEventRecord(ws->ev_x0, ws->stream));
         for (int child = max_depth - 2; child >= 0; --child, ++stage) {
           Expand3DKernel<<<blocks, 256, 0, ws->stream>>>(d_problems, front(stage), strict,
                                                          front(stage + 1), leaf_list, d_counters);
           dbg("expand level");
           mark("expand");
+        }
+        if (timed) {
+          CMX_HIP(hipEventRecord(ws->ev_x1, ws->stream));
+          st.expansion_launches = stage;
         }
       }
     }
@@ -1279,6 +1288,14 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
     CMX_HIP(hipStreamSynchronize(ws->stream));
     trace.Report();
     lap("device");
+    if (!strict) {
+      for (int stage = 0; stage < st.expansion_launches; ++stage)
+        for (int sub = 0; sub < kSubLists3; ++sub)
+          st.expansion_nodes += std::min(h_counters->frontier[stage][sub * kCountStride3],
+                                         kFrontierCapacity / kSubLists3);
+      // upper bound: nodes found below the bound when they are taken off the list are skipped
+      st.expansion_lookups = st.expansion_nodes * (static_cast<int64_t>(n + 63) / 64 * 64);
+    }
     if (!h_counters->overflow || num > 1) break;
     // Something was dropped.  Retry pruning ties (strict) with the bound lowered by one
     // ulp so the best leaf is found again, over four times as many, smaller chunks.
@@ -1307,6 +1324,10 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
   st.device_ms = ms;
   CMX_HIP(hipEventElapsedTime(&ms, ws->ev_k0, ws->ev_k1));
   st.dominant_kernel_ms = ms;
+  if (st.expansion_launches > 0) {
+    CMX_HIP(hipEventElapsedTime(&ms, ws->ev_x0, ws->ev_x1));
+    st.expansion_ms = ms;
+  }
 
   if (stats) *stats = st;
   if (num > 1 && h_counters->overflow) {
@@ -1665,6 +1686,10 @@ cmx_status cmx_fast3d_match_batch(const cmx_fast3d* const* matchers, int32_t num
       total.num_scans += st.num_scans;
       total.device_ms += st.device_ms;
       total.dominant_kernel_ms += st.dominant_kernel_ms;
+      total.expansion_ms += st.expansion_ms;
+      total.expansion_nodes += st.expansion_nodes;
+      total.expansion_lookups += st.expansion_lookups;
+      total.expansion_launches += st.expansion_launches;
     }
     if (stats) *stats = total;
     if (const char* e = getenv("CMX_HOST_TRACE"); e && e[0] == '1')

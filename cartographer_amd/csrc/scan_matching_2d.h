@@ -81,6 +81,9 @@ struct Fast2DProblem {
   int recompute_scans;  // 1 (fused front end): `discrete` is not written; the tree search
                         // re-derives a scan's cells from xyz (60 instructions per point,
                         // bit-identical) instead of 9 MB per match going to HBM and back
+  int store_scans;      // with recompute_scans: the coarse filter writes the cells of the scans
+                        // that keep a candidate to `discrete`, and the wave-per-node expansion
+                        // (several nodes per such scan) reads them instead of recomputing
 };
 
 // Branch-and-bound node.

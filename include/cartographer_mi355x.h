@@ -102,9 +102,13 @@ typedef struct cmx_match_stats {
   int64_t coarse_candidates;  /* lowest-resolution (or exhaustive) candidates */
   int64_t nodes_expanded;     /* branch-and-bound nodes whose children were scored */
   int32_t num_scans;          /* rotated scans */
-  int32_t reserved;
+  int32_t expansion_launches; /* launches inside expansion_ms (0: none timed) */
   double device_ms;           /* HIP-event time of the call's device work */
-  double dominant_kernel_ms;  /* HIP-event time of the dominant scoring kernel(s) */
+  double dominant_kernel_ms;  /* HIP-event time of the lowest-resolution (or exhaustive) scoring kernel(s) */
+  double expansion_ms;        /* HIP-event time of the level-synchronous branch-and-bound expansion
+                                 launches (fast 2D: ExpandWaveKernel, fast 3D: Expand3DKernel) */
+  int64_t expansion_nodes;    /* nodes those launches took from their frontiers */
+  int64_t expansion_lookups;  /* grid lookups they issued (64 per wave-wide gather instruction) */
 } cmx_match_stats;
 
 /* One flattened HybridGrid voxel (mapping/3d/hybrid_grid.h:304-372 Iterator):
