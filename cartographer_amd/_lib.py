@@ -132,6 +132,7 @@ EXPORTED_SYMBOLS = [
     "cmx_fast3d_match_batch",
     "cmx_fast3d_level_info", "cmx_fast3d_level_cells",
     "cmx_ceres2d_match", "cmx_ceres2d_match_grid", "cmx_fast2d_refine_batch", "cmx_ceres3d_match",
+    "cmx_fast3d_refine_batch",
     "cmx_comm_init", "cmx_comm_destroy", "cmx_comm_num_devices", "cmx_comm_device_of",
     "cmx_fast2d_match_sharded", "cmx_fast3d_match_sharded", "cmx_shard_range",
     "cmx_pack_best_key", "cmx_unpack_best_key",
@@ -213,6 +214,8 @@ def lib():
                                           C.c_void_p]
     L.cmx_ceres3d_match.argtypes = [P(Ceres3DOptions), C.c_void_p, P(Pose3d), C.c_void_p, C.c_int32,
                                     P(Pose3d), P(CeresSummary)]
+    L.cmx_fast3d_refine_batch.argtypes = [P(Ceres3DOptions), P(C.c_void_p), C.c_int32, C.c_void_p,
+                                          C.c_void_p, P(NodeData3D), C.c_void_p, C.c_void_p]
     L.cmx_voxel_filter.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p,
                                    P(C.c_int32)]
     L.cmx_adaptive_voxel_filter.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float,

@@ -111,10 +111,14 @@ class _Pending:
 
 class ConstraintBuilder2D:
     def __init__(self, options: ConstraintBuilderOptions, device: int = 0,
-                 refine: Optional[Callable] = None):
+                 refine: Optional[Callable] = None, ceres=None):
+        # `ceres`: a scan_matching.CeresScanMatcher2D, the builder's ceres_scan_matcher_; the
+        # found pairs of a node are refined by one cmx_fast2d_refine_batch launch.
         self.options = options
         self.device = device
         self.refine = refine
+        self.ceres = ceres
+        self.last_refine_summaries = None
         self._scan_matchers: Dict[SubmapId, FastCorrelativeScanMatcher2D] = {}
         self._samplers: Dict[SubmapId, FixedRatioSampler] = {}
         self._constraints: List[Optional[Constraint]] = []     # constraints_ (:139-141 of the .h)
@@ -213,13 +217,20 @@ class ConstraintBuilder2D:
             xyz.ctypes.data, xyz.shape[0], found.ctypes.data, scores.ctypes.data,
             C.cast(poses, C.c_void_p), C.byref(stats)))
         self.last_batch_stats = stats.as_dict()
+        refined = None
+        if self.ceres is not None and found.any():
+            refined, self.last_refine_summaries = self.ceres.refine_batch(
+                [i.matcher for i in items], found,
+                [Rigid2d(p.x, p.y, p.theta) for p in poses], xyz)
         for k, item in enumerate(items):
             if not found[k]:
                 continue                                   # `return;` at :219 / :232
             score = float(scores[k])
             self.score_histogram.append(score)
             pose_estimate = Rigid2d(poses[k].x, poses[k].y, poses[k].theta)
-            if self.refine is not None:                    # stands in for ceres_scan_matcher_ (:245-249)
+            if refined is not None:                        # ceres_scan_matcher_.Match (:245-249)
+                pose_estimate = refined[k]
+            elif self.refine is not None:                  # host callback (experiments)
                 pose_estimate = self.refine(pose_estimate, item.point_cloud, item.submap.grid)
             constraint_transform = multiply(inverse(item.submap.local_pose), pose_estimate)
             self._constraints[item.slot] = Constraint(
@@ -280,15 +291,19 @@ class ConstraintBuilder3D:
     matcher per ``SubmapId`` resident in HBM until ``DeleteScanMatcher``, ``Match`` /
     ``MatchFullSubmap`` with the two thresholds (:218-255), results in the order the pairs were
     added (``RunWhenDoneCallback``).  ``NotifyEndOfNode`` hands the node's pairs to
-    ``cmx_fast3d_match_batch`` (searched concurrently on separate streams); the Ceres refinement
-    (:263-276) is not built, ``refine`` may stand in for it.
+    ``cmx_fast3d_match_batch`` (one chain of launches for all pairs) and, with ``ceres`` (a
+    ``scan_matching_3d.CeresScanMatcher3D`` with two occupied-space weights: the builder's
+    ``ceres_scan_matcher_``), the found ones to ``cmx_fast3d_refine_batch`` (:263-276) -- both
+    against grids that stay in HBM.  ``refine`` is a host callback instead, for experiments.
     """
 
     def __init__(self, options: ConstraintBuilderOptions3D, device: int = 0,
-                 refine: Optional[Callable] = None):
+                 refine: Optional[Callable] = None, ceres=None):
         self.options = options
         self.device = device
         self.refine = refine
+        self.ceres = ceres
+        self.last_refine_summaries = None
         self._scan_matchers = {}
         self._samplers: Dict[SubmapId, FixedRatioSampler] = {}
         self._constraints: List[Optional[Constraint3D]] = []
@@ -374,12 +389,22 @@ class ConstraintBuilder3D:
                 [i[4] for i in items],
                 [self.options.global_localization_min_score if i[4] else self.options.min_score
                  for i in items], constant_data)
-            for (slot, submap_id, node_id, _, full, node, sub, _m), result in zip(items, results):
+            refined = None
+            if self.ceres is not None and any(r is not None for r in results):
+                identity = Rigid3d()
+                refined, self.last_refine_summaries = self.ceres.refine_batch(
+                    [i[7] for i in items], [r is not None for r in results],
+                    [r["pose_estimate"] if r is not None else identity for r in results],
+                    constant_data)
+            for k, ((slot, submap_id, node_id, _, full, node, sub, _m), result) in enumerate(
+                    zip(items, results)):
                 if result is None:
                     continue                               # `return;` at :232 / :253
                 self.score_histogram.append(result["score"])
                 pose = result["pose_estimate"]             # already submap i <- node j
-                if self.refine is not None:
+                if refined is not None:
+                    pose = refined[k]                      # ceres_scan_matcher_.Match (:263-276)
+                elif self.refine is not None:
                     pose = self.refine(pose, constant_data)
                 self._constraints[slot] = Constraint3D(
                     submap_id, node_id, pose, self.options.loop_closure_translation_weight,

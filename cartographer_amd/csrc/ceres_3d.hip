@@ -445,6 +445,66 @@ Ceres3DKernel(const Ceres3DProblem* __restrict__ problems) {
   }
 }
 
+// Checks of CeresScanMatcher3D's constructor / Match that do not depend on the pairs
+// (ceres_scan_matcher_3d.cc:110,138,144).
+void CheckOptions(const cmx_ceres3d_options& o) {
+  CMX_REQUIRE(o.num_pairs >= 1 && o.num_pairs <= kMaxPairs, "num_pairs %d outside [1,%d]",
+              o.num_pairs, kMaxPairs);
+  CMX_REQUIRE(o.translation_weight > 0. && o.rotation_weight > 0.,
+              "translation_weight and rotation_weight must be > 0");
+  CMX_REQUIRE(o.max_num_iterations >= 0, "max_num_iterations must be >= 0");
+  for (int k = 0; k < o.num_pairs; ++k)
+    CMX_REQUIRE(o.occupied_space_weight[k] > 0., "occupied_space_weight must be > 0");
+}
+
+void SetOptions(const cmx_ceres3d_options& o, Ceres3DProblem* P) {
+  P->num_pairs = o.num_pairs;
+  P->yaw_only = o.only_optimize_yaw ? 1 : 0;
+  P->use_nonmonotonic_steps = o.use_nonmonotonic_steps ? 1 : 0;
+  P->max_num_iterations = o.max_num_iterations;
+  P->translation_weight = o.translation_weight;
+  P->rotation_weight = o.rotation_weight;
+}
+
+// Uploads the clouds (already laid out in h_xyz) and `num` problem records, runs one workgroup
+// per problem and brings the 12 result numbers of each back.  Problems' `out` pointers are set
+// here.
+void SolveProblems(Workspace& ws, Ceres3DProblem* problems, int num, size_t cloud_floats,
+                   const float* h_xyz, float* d_xyz, double* results /*[num][12]*/) {
+  const size_t prob_bytes = sizeof(Ceres3DProblem) * static_cast<size_t>(num);
+  const size_t out_bytes = 12 * sizeof(double) * static_cast<size_t>(num);
+  char* d_misc = static_cast<char*>(ws.dev[1].Reserve(prob_bytes + out_bytes));
+  char* h_misc = static_cast<char*>(ws.pinned[1].Reserve(prob_bytes + out_bytes));
+  double* d_out = reinterpret_cast<double*>(d_misc + prob_bytes);
+  for (int p = 0; p < num; ++p) problems[p].out = d_out + 12 * static_cast<size_t>(p);
+  std::memcpy(h_misc, problems, prob_bytes);
+  CMX_HIP(hipMemcpyAsync(d_xyz, h_xyz, sizeof(float) * cloud_floats, hipMemcpyHostToDevice,
+                         ws.stream));
+  CMX_HIP(hipMemcpyAsync(d_misc, h_misc, prob_bytes, hipMemcpyHostToDevice, ws.stream));
+  CMX_HIP(hipEventRecord(ws.ev_begin, ws.stream));
+  Ceres3DKernel<<<num, kCeres3DThreads, 0, ws.stream>>>(
+      reinterpret_cast<const Ceres3DProblem*>(d_misc));
+  CMX_HIP(hipGetLastError());
+  CMX_HIP(hipEventRecord(ws.ev_end, ws.stream));
+  double* h_out = reinterpret_cast<double*>(h_misc + prob_bytes);
+  CMX_HIP(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, ws.stream));
+  CMX_HIP(hipStreamSynchronize(ws.stream));
+  std::memcpy(results, h_out, out_bytes);
+}
+
+void WriteResult(const double* out, cmx_pose3d* pose_estimate, cmx_ceres_summary* summary) {
+  for (int a = 0; a < 3; ++a) pose_estimate->t[a] = out[a];
+  for (int a = 0; a < 4; ++a) pose_estimate->q[a] = out[3 + a];
+  if (summary) {
+    summary->initial_cost = out[7];
+    summary->final_cost = out[8];
+    summary->num_successful_steps = static_cast<int32_t>(out[9]);
+    summary->num_unsuccessful_steps = static_cast<int32_t>(out[10]);
+    summary->termination = static_cast<int32_t>(out[11]);
+    summary->reserved = 0;
+  }
+}
+
 }  // namespace
 }  // namespace cmx
 
@@ -457,20 +517,14 @@ extern "C" cmx_status cmx_ceres3d_match(const cmx_ceres3d_options* options,
   return Guard([&] {
     CMX_REQUIRE(options && target_translation_xyz && initial_pose_estimate && pairs, "null argument");
     CMX_REQUIRE(pose_estimate != nullptr, "pose_estimate must not be null");
-    CMX_REQUIRE(options->num_pairs >= 1 && options->num_pairs <= kMaxPairs,
-                "num_pairs %d outside [1,%d]", options->num_pairs, kMaxPairs);
-    // CHECK_GT of ceres_scan_matcher_3d.cc:110,138,144.
-    CMX_REQUIRE(options->translation_weight > 0. && options->rotation_weight > 0.,
-                "translation_weight and rotation_weight must be > 0");
-    CMX_REQUIRE(options->max_num_iterations >= 0, "max_num_iterations must be >= 0");
+    CheckOptions(*options);
     WorkspaceLease ws(device);
     std::vector<std::unique_ptr<DeviceBrick>> bricks;
     Ceres3DProblem P{};
-    P.num_pairs = options->num_pairs;
+    SetOptions(*options, &P);
     size_t cloud_floats = 0;
     for (int k = 0; k < P.num_pairs; ++k) {
       const cmx_ceres3d_pair& in = pairs[k];
-      CMX_REQUIRE(options->occupied_space_weight[k] > 0., "occupied_space_weight must be > 0");
       CMX_REQUIRE(in.point_cloud_xyz && in.num_points >= 1 && in.num_points <= (1 << 24),
                   "bad point cloud %d", k);
       CMX_REQUIRE(in.resolution > 0.f, "resolution must be > 0");
@@ -493,40 +547,89 @@ extern "C" cmx_status cmx_ceres3d_match(const cmx_ceres3d_options* options,
           options->occupied_space_weight[k] / std::sqrt(static_cast<double>(in.num_points));
       off += 3 * static_cast<size_t>(in.num_points);
     }
-    P.yaw_only = options->only_optimize_yaw ? 1 : 0;
-    P.use_nonmonotonic_steps = options->use_nonmonotonic_steps ? 1 : 0;
-    P.max_num_iterations = options->max_num_iterations;
-    P.translation_weight = options->translation_weight;
-    P.rotation_weight = options->rotation_weight;
     for (int a = 0; a < 3; ++a) {
       P.target[a] = target_translation_xyz[a];
       P.init[a] = initial_pose_estimate->t[a];
     }
     for (int a = 0; a < 4; ++a) P.init[3 + a] = initial_pose_estimate->q[a];
-    char* d_misc = static_cast<char*>(ws->dev[1].Reserve(sizeof(Ceres3DProblem) + 12 * sizeof(double)));
-    P.out = reinterpret_cast<double*>(d_misc + sizeof(Ceres3DProblem));
-    char* h_misc = static_cast<char*>(ws->pinned[1].Reserve(sizeof(Ceres3DProblem) + 12 * sizeof(double)));
-    std::memcpy(h_misc, &P, sizeof(P));
-    CMX_HIP(hipMemcpyAsync(d_xyz, h_xyz, sizeof(float) * cloud_floats, hipMemcpyHostToDevice,
-                           ws->stream));
-    CMX_HIP(hipMemcpyAsync(d_misc, h_misc, sizeof(P), hipMemcpyHostToDevice, ws->stream));
-    CMX_HIP(hipEventRecord(ws->ev_begin, ws->stream));
-    Ceres3DKernel<<<1, kCeres3DThreads, 0, ws->stream>>>(
-        reinterpret_cast<const Ceres3DProblem*>(d_misc));
-    CMX_HIP(hipGetLastError());
-    CMX_HIP(hipEventRecord(ws->ev_end, ws->stream));
-    double* h_out = reinterpret_cast<double*>(h_misc + sizeof(Ceres3DProblem));
-    CMX_HIP(hipMemcpyAsync(h_out, P.out, 12 * sizeof(double), hipMemcpyDeviceToHost, ws->stream));
-    CMX_HIP(hipStreamSynchronize(ws->stream));
-    for (int a = 0; a < 3; ++a) pose_estimate->t[a] = h_out[a];
-    for (int a = 0; a < 4; ++a) pose_estimate->q[a] = h_out[3 + a];
-    if (summary) {
-      summary->initial_cost = h_out[7];
-      summary->final_cost = h_out[8];
-      summary->num_successful_steps = static_cast<int32_t>(h_out[9]);
-      summary->num_unsuccessful_steps = static_cast<int32_t>(h_out[10]);
-      summary->termination = static_cast<int32_t>(h_out[11]);
-      summary->reserved = 0;
+    double out[12];
+    SolveProblems(*ws, &P, 1, cloud_floats, h_xyz, d_xyz, out);
+    WriteResult(out, pose_estimate, summary);
+  });
+}
+
+// ConstraintBuilder3D::ComputeConstraint's refinement (constraints/constraint_builder_3d.cc:
+// 263-276) for a node's batch: one workgroup per found pair, grids already in HBM.
+extern "C" cmx_status cmx_fast3d_refine_batch(const cmx_ceres3d_options* options,
+                                              const cmx_fast3d* const* matchers,
+                                              int32_t num_pairs, const int32_t* found,
+                                              const cmx_pose3d* pose_estimates_in,
+                                              const cmx_node_data3d* data,
+                                              cmx_pose3d* pose_estimates_out,
+                                              cmx_ceres_summary* summaries) {
+  using namespace cmx;
+  return Guard([&] {
+    CMX_REQUIRE(options && data && pose_estimates_in && pose_estimates_out, "null argument");
+    CMX_REQUIRE(num_pairs >= 0 && (num_pairs == 0 || matchers), "bad matcher list");
+    CheckOptions(*options);
+    // {high-resolution cloud, high-resolution grid}, {low-resolution cloud, low-resolution grid}
+    CMX_REQUIRE(options->num_pairs == 2, "the constraint refinement uses two (cloud, grid) pairs");
+    CMX_REQUIRE(data->high_resolution_point_cloud && data->num_high_resolution_points >= 1 &&
+                    data->low_resolution_point_cloud && data->num_low_resolution_points >= 1 &&
+                    data->num_high_resolution_points <= (1 << 24) &&
+                    data->num_low_resolution_points <= (1 << 24),
+                "bad point clouds");
+    for (int p = 0; p < num_pairs; ++p) {
+      CMX_REQUIRE(matchers[p] != nullptr, "matcher %d is null", p);
+      pose_estimates_out[p] = pose_estimates_in[p];        // not found: passed through
+      if (summaries) summaries[p] = cmx_ceres_summary{};
+    }
+    const int n_hi = data->num_high_resolution_points, n_lo = data->num_low_resolution_points;
+    const size_t cloud_floats = 3 * (static_cast<size_t>(n_hi) + n_lo);
+    // Pairs are grouped by the device their grids live on (a node's batch may span the GPUs
+    // of a cmx_comm); each group is one launch.
+    std::vector<int> order;
+    for (int p = 0; p < num_pairs; ++p)
+      if (!found || found[p]) order.push_back(p);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      return Fast3DDevice(matchers[a]) < Fast3DDevice(matchers[b]);
+    });
+    for (size_t begin = 0; begin < order.size();) {
+      const int device = Fast3DDevice(matchers[order[begin]]);
+      size_t end = begin;
+      while (end < order.size() && Fast3DDevice(matchers[order[end]]) == device) ++end;
+      const int num = static_cast<int>(end - begin);
+      WorkspaceLease ws(device);
+      float* d_xyz = ws->dev[0].ReserveAs<float>(cloud_floats);
+      float* h_xyz = ws->pinned[0].ReserveAs<float>(cloud_floats);
+      std::memcpy(h_xyz, data->high_resolution_point_cloud, 3 * sizeof(float) * n_hi);
+      std::memcpy(h_xyz + 3 * static_cast<size_t>(n_hi), data->low_resolution_point_cloud,
+                  3 * sizeof(float) * n_lo);
+      std::vector<Ceres3DProblem> problems(num);
+      for (int k = 0; k < num; ++k) {
+        const int p = order[begin + k];
+        Ceres3DProblem& P = problems[k];
+        SetOptions(*options, &P);
+        Fast3DGrids(matchers[p], &P.pair[0].grid, &P.pair[0].resolution, &P.pair[1].grid,
+                    &P.pair[1].resolution);
+        P.pair[0].n = n_hi;
+        P.pair[0].xyz = d_xyz;
+        P.pair[0].scaling = options->occupied_space_weight[0] / std::sqrt(static_cast<double>(n_hi));
+        P.pair[1].n = n_lo;
+        P.pair[1].xyz = d_xyz + 3 * static_cast<size_t>(n_hi);
+        P.pair[1].scaling = options->occupied_space_weight[1] / std::sqrt(static_cast<double>(n_lo));
+        // Match(match_result->pose_estimate.translation(), match_result->pose_estimate, ...)
+        for (int a = 0; a < 3; ++a) P.target[a] = P.init[a] = pose_estimates_in[p].t[a];
+        for (int a = 0; a < 4; ++a) P.init[3 + a] = pose_estimates_in[p].q[a];
+      }
+      std::vector<double> out(12 * static_cast<size_t>(num));
+      SolveProblems(*ws, problems.data(), num, cloud_floats, h_xyz, d_xyz, out.data());
+      for (int k = 0; k < num; ++k) {
+        const int p = order[begin + k];
+        WriteResult(out.data() + 12 * static_cast<size_t>(k), pose_estimates_out + p,
+                    summaries ? summaries + p : nullptr);
+      }
+      begin = end;
     }
   });
 }

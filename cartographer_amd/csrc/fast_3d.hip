@@ -848,6 +848,7 @@ struct Fast3DMatcher {
   std::vector<std::unique_ptr<DeviceBrick>> octs;   // per child level (see OctDesc)
   std::vector<OctDesc> oct_desc;
   DeviceBrick low;
+  DeviceBrick high;                                 // raw uint16 grid (Ceres refinement)
   std::vector<float> histogram;
 };
 
@@ -1451,6 +1452,14 @@ struct cmx_fast3d {
 namespace cmx {
 // For sharded.hip: the device a 3D matcher's grids live on.
 int Fast3DDevice(const cmx_fast3d* matcher) { return matcher->impl.device; }
+// For ceres_3d.hip: the raw grids a 3D matcher keeps in HBM.
+void Fast3DGrids(const cmx_fast3d* matcher, Brick* high, float* resolution, Brick* low,
+                 float* low_resolution) {
+  *high = matcher->impl.high.desc;
+  *resolution = matcher->impl.resolution;
+  *low = matcher->impl.low.desc;
+  *low_resolution = matcher->impl.low_resolution;
+}
 }  // namespace cmx
 
 extern "C" {
@@ -1491,6 +1500,9 @@ cmx_status cmx_fast3d_create(const cmx_fast3d_options* options, float resolution
     BuildBrickFromVoxels(*ws, voxels, num_voxels, 1, m.levels[0].get());
     CMX_REQUIRE(m.levels[0]->bytes < (size_t(1) << 31), "grid too large");   // 32-bit cell offsets
     BuildBrickFromVoxels(*ws, low_resolution_voxels, num_low_resolution_voxels, 2, &m.low);
+    // The raw high-resolution values (level 0 of the stack is their 8-bit quantisation) stay
+    // resident for the refinement that follows a match (cmx_fast3d_refine_batch).
+    BuildBrickFromVoxels(*ws, voxels, num_voxels, 2, &m.high);
     // PrecomputationGridStack3D (:57-77).
     int last_width = 1;
     for (int depth = 1; depth != options->branch_and_bound_depth; ++depth) {

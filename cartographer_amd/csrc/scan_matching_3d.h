@@ -167,6 +167,10 @@ void BuildBrickFromVoxels(Workspace& ws, const cmx_voxel* voxels, int64_t n, int
                           DeviceBrick* out);
 // DynamicGrid growth rule (hybrid_grid.h:259,381-398).
 int GridSizeOf(const cmx_voxel* voxels, int64_t n);
+// fast_3d.hip: device and raw (uint16) grids of a 3D matcher.
+int Fast3DDevice(const cmx_fast3d* matcher);
+void Fast3DGrids(const cmx_fast3d* matcher, Brick* high, float* resolution, Brick* low,
+                 float* low_resolution);
 
 }  // namespace cmx
 

@@ -116,6 +116,24 @@ class CeresScanMatcher3D:
         del keep
         return Rigid3d.from_c(pose), summary.as_dict()
 
+    def refine_batch(self, matchers, found, pose_estimates, constant_data):
+        """ConstraintBuilder3D::ComputeConstraint's refinement of a node's search results
+        (constraint_builder_3d.cc:263-276): entry i against the high- and low-resolution grids
+        ``matchers[i]`` keeps in HBM, one launch.  Returns (poses, summaries); entries with
+        ``found[i] == 0`` are passed through."""
+        num = len(matchers)
+        assert self.options.num_pairs == 2
+        handles = (C.c_void_p * num)(*[m._h for m in matchers])
+        found = np.ascontiguousarray([1 if f else 0 for f in found], np.int32)
+        poses_in = (Pose3d * num)(*[p.to_c() for p in pose_estimates])
+        poses_out = (Pose3d * num)()
+        summaries = (CeresSummary * num)()
+        data = constant_data.to_c()
+        check(_lib.lib().cmx_fast3d_refine_batch(
+            C.byref(self.options), handles, num, found.ctypes.data, C.cast(poses_in, C.c_void_p),
+            C.byref(data), C.cast(poses_out, C.c_void_p), C.cast(summaries, C.c_void_p)))
+        return [Rigid3d.from_c(p) for p in poses_out], [s.as_dict() for s in summaries]
+
 
 @dataclass
 class TrajectoryNodeData:

@@ -18,7 +18,8 @@
  *                                  (node, submap) searches, constraints/constraint_builder_2d.cc:97-137
  *   cmx_ceres2d_match, cmx_ceres2d_match_grid, cmx_fast2d_refine_batch
  *                                  CeresScanMatcher2D::Match, SM2/ceres_scan_matcher_2d.cc:63-107
- *   cmx_ceres3d_match              CeresScanMatcher3D::Match, SM3/ceres_scan_matcher_3d.cc:90-156
+ *   cmx_ceres3d_match, cmx_fast3d_refine_batch
+ *                                  CeresScanMatcher3D::Match, SM3/ceres_scan_matcher_3d.cc:90-156
  *   cmx_rt3d_match                 RealTimeCorrelativeScanMatcher3D::Match
  *                                  SM3/real_time_correlative_scan_matcher_3d.h:47-50, .cc:34-53
  *   cmx_fast3d_*                   FastCorrelativeScanMatcher3D ctor / Match / MatchFullSubmap
@@ -418,6 +419,18 @@ cmx_status cmx_fast3d_match_batch(const cmx_fast3d* const* matchers, int32_t num
                                   const int32_t* match_full_submap, const float* min_scores,
                                   const cmx_node_data3d* data, int32_t* found,
                                   cmx_result3d* results, cmx_match_stats* stats);
+/* ConstraintBuilder3D::ComputeConstraint's refinement (constraints/constraint_builder_3d.cc:
+ * 263-276) for the results of cmx_fast3d_match_batch: pair i runs CeresScanMatcher3D::Match
+ * (target translation = pose_estimates_in[i].t, initial pose = pose_estimates_in[i]) with
+ * {data's high-resolution cloud, matcher i's high-resolution grid} and {low-resolution cloud,
+ * low-resolution grid}; both grids are the ones the matcher keeps in HBM since
+ * cmx_fast3d_create.  One launch per device, one workgroup per pair.  options->num_pairs must
+ * be 2.  Entries with found[i] == 0 (found may be NULL) are passed through. */
+cmx_status cmx_fast3d_refine_batch(const cmx_ceres3d_options* options,
+                                   const cmx_fast3d* const* matchers, int32_t num_pairs,
+                                   const int32_t* found, const cmx_pose3d* pose_estimates_in,
+                                   const cmx_node_data3d* data, cmx_pose3d* pose_estimates_out,
+                                   cmx_ceres_summary* summaries);
 
 /* ---- upstream point preparation ---------------------------------------- */
 /* sensor::VoxelFilter(PointCloud, resolution) (sensor/internal/voxel_filter.cc:88-152): one

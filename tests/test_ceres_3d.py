@@ -137,3 +137,29 @@ def test_match_reduces_the_cost_and_keeps_the_parameterization(oracle, synth, ya
         assert np.abs(out["pose"][4:6]).max() < 1e-12
     assert abs(np.linalg.norm(out["pose"][3:]) - 1.0) < 1e-6
     del truth_q
+
+
+def test_refine_batch_checks_its_arguments_before_touching_a_device():
+    """cmx_fast3d_refine_batch: the reference's CHECKs (ceres_scan_matcher_3d.cc:110,138,144) and
+    the two-pair shape of the constraint refinement are argument errors, whatever the machine."""
+    import ctypes as C
+    from cartographer_amd import _lib
+    L = _lib.lib()
+    o = _lib.Ceres3DOptions()
+    o.occupied_space_weight[0] = 1.0
+    o.occupied_space_weight[1] = 1.0
+    o.translation_weight, o.rotation_weight = 1.0, 1.0
+    o.num_pairs, o.max_num_iterations = 1, 5
+    data = _lib.NodeData3D()
+    poses = (_lib.Pose3d * 1)()
+    out = (_lib.Pose3d * 1)()
+    handles = (C.c_void_p * 1)()
+    call = lambda opt, n: L.cmx_fast3d_refine_batch(      # noqa: E731
+        C.byref(opt), handles, n, None, C.cast(poses, C.c_void_p), C.byref(data),
+        C.cast(out, C.c_void_p), None)
+    assert call(o, 0) == _lib.INVALID_ARGUMENT          # num_pairs must be 2
+    o.num_pairs = 2
+    assert call(o, 0) == _lib.INVALID_ARGUMENT          # no point clouds
+    o.translation_weight = 0.0
+    assert call(o, 0) == _lib.INVALID_ARGUMENT
+    assert b"translation_weight" in L.cmx_last_error()

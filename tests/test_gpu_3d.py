@@ -585,3 +585,85 @@ def test_fast3d_oct_layout_equals_the_oracle(sm3, oracle, synth, monkeypatch, oc
     got2 = gm2.match_full_submap((1.0, 0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0),
                                  sm3.TrajectoryNodeData(c2, c2[::4].copy(), h2), 0.1)
     _assert_result(ref2, got2)
+
+
+def test_fast3d_refine_batch_equals_single_ceres_matches(sm3, oracle, synth):
+    """cmx_fast3d_refine_batch (ConstraintBuilder3D's ceres_scan_matcher_.Match after the search,
+    constraint_builder_3d.cc:263-276) against grids resident in HBM: entry by entry what
+    cmx_ceres3d_match returns for the same voxel lists (bit for bit: same kernel, same bricks),
+    which in turn equals the oracle; not-found entries pass through."""
+    hist = np.zeros(16, np.float32)
+    opt = dict(branch_and_bound_depth=4, full_resolution_depth=2, min_rotational_score=0.0,
+               min_low_resolution_score=0.2, linear_xy_search_window=1.0,
+               linear_z_search_window=0.4, angular_search_window=math.radians(10.0))
+    matchers, grids = [], []
+    for seed in (70, 71, 70):
+        grid, world = synth.make_submap_3d(seed, 0.1, (8.0, 8.0, 3.0), 4, 8, 96)
+        low, _ = synth.make_submap_3d(seed, 0.3, (8.0, 8.0, 3.0), 4, 8, 96)
+        matchers.append(sm3.FastCorrelativeScanMatcher3D(0.1, grid.voxels(), grid.grid_size, 0.3,
+                                                         low.voxels(), hist, **opt))
+        grids.append((grid.voxels(), low.voxels(), world))
+    world = grids[0][2]
+    pos = world.free_position(200, 0.6)
+    full = world.scan(pos, 0.2, 8, 96, seed=0)
+    data = sm3.TrajectoryNodeData(full[::2].copy(), full[::7].copy(), hist)
+    rng = np.random.default_rng(3)
+    poses = []
+    for k in range(3):
+        t = pos + rng.uniform(-0.05, 0.05, 3)
+        poses.append(sm3.Rigid3d(tuple(t), tuple(quat_from_angle_axis(0.2 + rng.uniform(-0.02, 0.02),
+                                                                       [0.02, -0.01, 1.0]))))
+    found = [True, False, True]
+    ceres = sm3.CeresScanMatcher3D([5.0, 20.0], 10.0, 1.0, only_optimize_yaw=False,
+                                   use_nonmonotonic_steps=False, max_num_iterations=10)
+    refined, summaries = ceres.refine_batch(matchers, found, poses, data)
+    assert refined[1] == poses[1] and summaries[1]["num_successful_steps"] == 0
+    for k in (0, 2):
+        pairs = [(data.high_resolution_point_cloud, 0.1, grids[k][0]),
+                 (data.low_resolution_point_cloud, 0.3, grids[k][1])]
+        single, s1 = ceres.match(poses[k].translation, poses[k], pairs)
+        assert refined[k] == single, (k, refined[k], single)
+        assert summaries[k] == s1
+        init = list(poses[k].translation) + list(poses[k].rotation)
+        ref = oracle.ceres3d_match(pairs, poses[k].translation, init, [5.0, 20.0],
+                                   translation_weight=10.0, rotation_weight=1.0,
+                                   max_num_iterations=10)
+        np.testing.assert_allclose(_pose7(refined[k]), ref["pose"], rtol=0, atol=1e-6)
+        assert summaries[k]["final_cost"] <= summaries[k]["initial_cost"]
+
+
+def test_constraint_builder_3d_refines_on_the_device(sm3, oracle, synth):
+    """ConstraintBuilder3D with its ceres_scan_matcher_: the constraint transform is the refined
+    pose (constraint_builder_3d.cc:263-281), equal to refining the search result separately."""
+    from cartographer_amd import constraint_builder as cb
+    hist = np.zeros(16, np.float32)
+    grid, world = synth.make_submap_3d(70, 0.1, (8.0, 8.0, 3.0), 4, 8, 96)
+    low, _ = synth.make_submap_3d(70, 0.3, (8.0, 8.0, 3.0), 4, 8, 96)
+    pos = world.free_position(200, 0.6)
+    full = world.scan(pos, 0.0, 8, 96, seed=0)
+    data = sm3.TrajectoryNodeData(full[::2].copy(), full[::7].copy(), hist)
+    options = cb.ConstraintBuilderOptions3D(
+        sampling_ratio=1.0, max_constraint_distance=50.0, min_score=0.2,
+        global_localization_min_score=0.2, branch_and_bound_depth=4, full_resolution_depth=2,
+        min_rotational_score=0.0, min_low_resolution_score=0.1, linear_xy_search_window=0.5,
+        linear_z_search_window=0.2, angular_search_window=math.radians(5.0))
+    ceres = sm3.CeresScanMatcher3D([5.0, 20.0], 10.0, 1.0, max_num_iterations=10)
+    submap = cb.Submap3D(0.1, grid.voxels(), grid.grid_size, 0.3, low.voxels(), hist)
+    node = sm3.Rigid3d(tuple(pos + np.array([0.1, -0.1, 0.05])), (1.0, 0.0, 0.0, 0.0))
+    plain = cb.ConstraintBuilder3D(options)
+    with_ceres = cb.ConstraintBuilder3D(options, ceres=ceres)
+    out = {}
+    for name, builder in (("plain", plain), ("ceres", with_ceres)):
+        builder.maybe_add_constraint((0, 0), submap, (0, 5), data, node, sm3.Rigid3d())
+        builder.notify_end_of_node()
+        builder.when_done(lambda constraints, name=name: out.__setitem__(name, constraints))
+    assert len(out["plain"]) == 1 and len(out["ceres"]) == 1
+    searched, refined = out["plain"][0].zbar_ij, out["ceres"][0].zbar_ij
+    pairs = [(data.high_resolution_point_cloud, 0.1, grid.voxels()),
+             (data.low_resolution_point_cloud, 0.3, low.voxels())]
+    single, _ = ceres.match(searched.translation, searched, pairs)
+    assert refined == single
+    assert refined != searched
+    # the refined pose is closer to the truth than the voxel-quantised search result
+    err = lambda p: np.linalg.norm(np.array(p.translation) - pos)      # noqa: E731
+    assert err(refined) <= err(searched) + 1e-3
