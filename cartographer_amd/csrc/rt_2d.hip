@@ -13,7 +13,9 @@
 //     device-weighted score is within 1e-5 (relative) of the device maximum,
 //     so the returned score/pose cannot depend on the device's exp().
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <string>
 #include <cstring>
 
 #include "scan_matching_2d.h"
@@ -931,6 +933,19 @@ bool BulkEnabled() {
 bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, int num,
                         int32_t device, cmx_match_stats* stats, bool force_legacy) {
   CMX_REQUIRE(options && items && num >= 1, "null argument");
+  // CMX_HOST_TRACE=1: wall-clock of the host phases (tools only).
+  static const bool host_trace = [] { const char* e = getenv("CMX_HOST_TRACE"); return e && e[0] == '1'; }();
+  auto t_last = std::chrono::steady_clock::now();
+  std::string host_report;
+  const auto lap = [&](const char* name) {
+    if (!host_trace) return;
+    const auto now = std::chrono::steady_clock::now();
+    char buf[64];
+    snprintf(buf, sizeof buf, " %s=%.0f", name,
+             std::chrono::duration<double, std::micro>(now - t_last).count());
+    host_report += buf;
+    t_last = now;
+  };
   struct Plan {
     int n, nx, ny, nl, na, num_scans, n_pad, pad;
     long long side, num_candidates, stride, rows;
@@ -1089,7 +1104,9 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
   const size_t off_misc = in_bytes;
   in_bytes += Align16(sizeof(unsigned) * 128 * static_cast<size_t>(num));
 
+  lap("plan");
   WorkspaceLease ws(device);
+  lap("lease");
   char* h_in = ws->pinned[0].ReserveAs<char>(in_bytes);
   char* d_in = ws->dev[0].ReserveAs<char>(in_bytes);
   // (scratch of the per-candidate kernels; the bulk path needs none of it)
@@ -1179,6 +1196,7 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
     }
     h_params[m] = P;
   }
+  lap("fill");
   CMX_HIP(hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, ws->stream));
   const Rt2DParams* d_params = reinterpret_cast<const Rt2DParams*>(d_in);
 
@@ -1220,7 +1238,9 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
   CMX_HIP(hipEventRecord(ws->ev_end, ws->stream));
   CMX_HIP(hipMemcpyAsync(h_misc, d_misc, sizeof(unsigned) * 128 * num, hipMemcpyDeviceToHost,
                          ws->stream));
+  lap("enqueue");
   CMX_HIP(hipStreamSynchronize(ws->stream));
+  lap("wait");
 
   if (d_timeline) {
     ReportTimeline("Rt2DBulkKernel", d_timeline, timeline_bulk_blocks, ws->stream);
@@ -1303,6 +1323,7 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
     total.coarse_candidates += pl.num_candidates;
     total.num_scans += pl.num_scans;
   }
+  lap("finish");
   if (stats) {
     float ms = 0.f;
     CMX_HIP(hipEventElapsedTime(&ms, ws->ev_begin, ws->ev_end));
@@ -1311,6 +1332,8 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
     total.dominant_kernel_ms = ms;
     *stats = total;
   }
+  if (host_trace) fprintf(stderr, "[cmx host] rt2d batch(%d):%s us (in %zu B)\n", num,
+                          host_report.c_str(), in_bytes);
   return true;
 }
 }  // namespace
