@@ -483,6 +483,16 @@ class Fast3DWorkload:
         self.pairs = pairs or args.submaps or 1
         self.matches_per_step = self.pairs
         self.n_points = len(self.hi)
+        # A batch is one node against DISTINCT submaps (C5: 256 over 8 GPUs = 32 per GPU), each
+        # with its own grids and stack in HBM (~110 MB); the node was recorded in submap #0's
+        # world, the others are the negatives a loop-closure search mostly meets.  They share
+        # the histogram so that every pair passes the yaw pre-filter and is searched in full.
+        self.matchers = [self.gm]
+        for k in range(1, self.pairs):
+            g, _ = synth.make_submap_3d(42 + k, 0.1, size, 8, 32, 512)
+            lw, _ = synth.make_submap_3d(42 + k, 0.45, size, 8, 32, 512)
+            self.matchers.append(sm3.FastCorrelativeScanMatcher3D(
+                0.1, g.voxels(), g.grid_size, 0.45, lw.voxels(), hist, **opt))
 
     def search(self):
         sm3 = self.sm3
@@ -492,7 +502,7 @@ class Fast3DWorkload:
             found = np.array([got is not None], np.int32)
             scores = np.array([got["score"] if got else 0.0], np.float32)
             return found, scores, [got], stats
-        results, stats = sm3.fast3d_match_batch([self.gm] * self.pairs, [self.node] * self.pairs,
+        results, stats = sm3.fast3d_match_batch(self.matchers, [self.node] * self.pairs,
                                                 [sm3.Rigid3d()] * self.pairs, [0] * self.pairs,
                                                 [0.2] * self.pairs, self.data)
         found = np.array([r is not None for r in results], np.int32)
@@ -500,10 +510,12 @@ class Fast3DWorkload:
         return found, scores, results, stats
 
     def describe(self, stats, found):
-        return {"workload": f"C5: 3D FastCorrelativeScanMatcher Match, {self.pairs} (node, submap) "
-                            f"pair(s) per step, 150^3 hi-res 0.1 m + low-res 0.45 m grids, depth 8 / "
+        return {"workload": f"C5: 3D FastCorrelativeScanMatcher Match, one node against {self.pairs} "
+                            f"distinct submap(s) per step (seeds 42..{41 + self.pairs}, the node from "
+                            f"#0's world), 150^3 hi-res 0.1 m + low-res 0.45 m grids, depth 8 / "
                             f"full-resolution depth 3, {self.n_points} hi-res points",
-                "pairs_per_step": self.pairs}
+                "pairs_per_step": self.pairs, "found": int(np.sum(found)),
+                "nodes_expanded_per_step": stats["nodes_expanded"]}
 
     def roofline(self, acc, steps, pmc):
         k_ms = acc["dominant_kernel_ms"] / steps

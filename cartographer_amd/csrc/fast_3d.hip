@@ -353,11 +353,15 @@ SeedSelect3DKernel(const Fast3DProblem* __restrict__ problems) {
 // grid (blocks, problems)
 __global__ void __launch_bounds__(256)
 Filter3DKernel(const Fast3DProblem* __restrict__ problems, int strict, int chunk, int num_chunks,
-               List3 out, Counters3* __restrict__ counters) {
+               int affinity, List3 out, Counters3* __restrict__ counters) {
   const Fast3DProblem& P = problems[blockIdx.y];
   const int total = P.ncx * P.ncy * P.ncz * P.num_scans;
   const float best = __uint_as_float(*P.best_bits);
-  const int sub = blockIdx.x & (kSubLists3 - 1);
+  // With `affinity` the nodes of a problem stay in the sub-lists the workgroups of ONE XCD
+  // read (sub % 8 == problem % 8, see Expand3DKernel): lines of its grids that neighbouring
+  // nodes share are then found in that XCD's L2 instead of being fetched by eight.
+  const int sub = affinity ? (blockIdx.y & 7) | ((blockIdx.x & 7) << 3)
+                           : blockIdx.x & (kSubLists3 - 1);
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < total; c += gridDim.x * blockDim.x) {
     if (c % num_chunks != chunk) continue;
     const float sc = P.coarse_score[c];
@@ -674,8 +678,8 @@ __device__ __forceinline__ void ExpandNode3D(const Fast3DProblem& P, const Node3
 // flight, 43 points per lane -- was measured and changed nothing: 5.26 vs 5.34 ms for 32 pairs;
 // a single pair got slower, 0.45 vs 0.41 ms.  Removed.)
 __global__ void __launch_bounds__(256)
-Expand3DKernel(const Fast3DProblem* __restrict__ problems, List3 in, int strict, List3 out,
-               List3 leaves, Counters3* __restrict__ counters) {
+Expand3DKernel(const Fast3DProblem* __restrict__ problems, List3 in, int strict, int affinity,
+               List3 out, List3 leaves, Counters3* __restrict__ counters) {
   __shared__ ExpandShared sh;
   InitWork3D(&sh);
   const int max_count = ListMax3(in);
@@ -686,7 +690,10 @@ Expand3DKernel(const Fast3DProblem* __restrict__ problems, List3 in, int strict,
     // survivors of a search cluster in a few subtrees, and appending them to their
     // parent's sub-list would leave the next level with one long list that a handful
     // of blocks walk serially (measured: 0.9 us per node, chip idle).
-    const int sub_id = (in_sub * 17 + j) & (kSubLists3 - 1);
+    // (Workgroup b runs on XCD b % 8 and reads the sub-lists with sub % 8 == b % 8: the grid
+    // is a multiple of 64 blocks.  With `affinity` the children stay on their parent's XCD.)
+    const int sub_id = affinity ? (in_sub & 7) | ((((in_sub >> 3) * 5 + j) & 7) << 3)
+                                : (in_sub * 17 + j) & (kSubLists3 - 1);
     const Node3D nd = in.nodes[static_cast<size_t>(in_sub) * in.sub_capacity + j];
     const Fast3DProblem& P = problems[nd.problem];
     // The bound moves while this kernel runs: ONE thread reads it and the block shares that
@@ -1238,6 +1245,12 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
   mark("coarse");
 
   const int blocks = 2048;
+  // Batches: one problem's nodes stay on one XCD (CMX_FAST3D_AFFINITY=0/1 overrides).
+  static const int kAffinity = [] {
+    const char* e = getenv("CMX_FAST3D_AFFINITY");
+    return e ? atoi(e) : -1;
+  }();
+  const int affinity = kAffinity >= 0 ? kAffinity : (num >= 16 ? 1 : 0);
   int strict = 0, num_chunks = 1;
   const Best3* h_best = reinterpret_cast<const Best3*>(h_misc + off_best);
   for (;;) {
@@ -1262,8 +1275,8 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
       for (int chunk = 0; chunk < num_chunks; ++chunk) {
         CMX_HIP(hipMemsetAsync(d_counters->frontier, 0, sizeof(d_counters->frontier),
                                ws->stream));
-        Filter3DKernel<<<dim3(256, num), 256, 0, ws->stream>>>(d_problems, strict, chunk,
-                                                               num_chunks, front(0), d_counters);
+        Filter3DKernel<<<dim3(256, num), 256, 0, ws->stream>>>(
+            d_problems, strict, chunk, num_chunks, affinity, front(0), d_counters);
         dbg("filter");
         mark("filter");
         int stage = 0;
@@ -1271,7 +1284,8 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
         if (timed) CMX_HIP(hipEventRecord(ws->ev_x0, ws->stream));
         for (int child = max_depth - 2; child >= 0; --child, ++stage) {
           Expand3DKernel<<<blocks, 256, 0, ws->stream>>>(d_problems, front(stage), strict,
-                                                         front(stage + 1), leaf_list, d_counters);
+                                                         affinity, front(stage + 1), leaf_list,
+                                                         d_counters);
           dbg("expand level");
           mark("expand");
         }

@@ -1,12 +1,9 @@
-# Round-2 experiment driver: full device tests + a host trace of the RT-2D batch.
-mkdir -p gpurun_out/r2w
-timeout 600 python -m pytest tests -m gpu -x -q -p no:cacheprovider > gpurun_out/r2w/pytest_gpu.txt 2>&1
-grep -E "passed|failed|error" gpurun_out/r2w/pytest_gpu.txt | tail -3
-grep -B30 "Error\|assert" gpurun_out/r2w/pytest_gpu.txt | tail -60
-CMX_HOST_TRACE=1 timeout 120 python bench.py --config c1 --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/r2w/c1.json 2> gpurun_out/r2w/c1_host_trace.txt
-grep "cmx host" gpurun_out/r2w/c1_host_trace.txt | tail -4
-python - <<'P'
-import json
-d=json.loads(open('gpurun_out/r2w/c1.json').read().strip().splitlines()[-1])
-print(d['ms_per_step'], d['config'].get('device_ms_per_step'), d['value'])
-P
+# C5 share of 32 distinct submaps: XCD affinity of a problem's nodes on / off.
+mkdir -p gpurun_out/r2u
+for af in 0 1 0 1; do
+CMX_FAST3D_AFFINITY=$af timeout 200 python bench.py --config c5 --submaps 32 --steps 4 --warmup 2 --no-cpu-baseline --pmc-dir gpurun_out 2> gpurun_out/r2u/c5_aff$af.err | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d['config']; r=d['roofline']
+print('affinity', $af, d['ms_per_step'], c.get('device_ms_per_step'), c.get('found'), c.get('nodes_expanded_per_step'), r.get('kernel_ms'), r.get('frac'))" | tee -a gpurun_out/r2u/c5_affinity.txt
+done
+CMX_FAST3D_AFFINITY=1 timeout 300 python -m pytest tests/test_gpu_3d.py -m gpu -x -q -p no:cacheprovider -k fast3d 2>&1 | grep -E "passed|failed" | tee -a gpurun_out/r2u/c5_affinity.txt

@@ -11,8 +11,10 @@ P="bash tools/profile_cmd.sh"
 $P ${TAG}       "python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-other" FETCH_SIZE WRITE_SIZE
 $P ${TAG}_c1    "python bench.py --config c1 --steps 6 --warmup 2 --no-cpu-baseline" FETCH_SIZE WRITE_SIZE \
     "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT"
-$P ${TAG}_c3    "python bench.py --config c3 --submaps 16 --steps 3 --warmup 1 --no-cpu-baseline" FETCH_SIZE WRITE_SIZE
+SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM"
+CACHE="TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum"
+$P ${TAG}_c3    "python bench.py --config c3 --submaps 16 --steps 3 --warmup 1 --no-cpu-baseline" FETCH_SIZE WRITE_SIZE "$SQ" "$CACHE"
 $P ${TAG}_c4    "python bench.py --config c4 --steps 1 --warmup 1 --no-cpu-baseline" FETCH_SIZE WRITE_SIZE
-$P ${TAG}_c5    "python bench.py --config c5 --submaps 32 --steps 3 --warmup 1 --no-cpu-baseline" FETCH_SIZE WRITE_SIZE
+$P ${TAG}_c5    "python bench.py --config c5 --submaps 32 --steps 3 --warmup 1 --no-cpu-baseline" FETCH_SIZE WRITE_SIZE "$SQ" "$CACHE"
 $P ${TAG}_other "python tools/family_probe.py" FETCH_SIZE WRITE_SIZE
 ls -la gpurun_out/${TAG}*kernel_stats.csv
