@@ -362,13 +362,25 @@ Filter3DKernel(const Fast3DProblem* __restrict__ problems, int strict, int chunk
   // nodes share are then found in that XCD's L2 instead of being fetched by eight.
   const int sub = affinity ? (blockIdx.y & 7) | ((blockIdx.x & 7) << 3)
                            : blockIdx.x & (kSubLists3 - 1);
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < total; c += gridDim.x * blockDim.x) {
-    if (c % num_chunks != chunk) continue;
-    const float sc = P.coarse_score[c];
-    if (strict ? (sc > best) : (sc >= best)) {
-      if (!Push3(out, sub, atomicAdd(&out.counts[sub * kCountStride3], 1), CoarseNode3D(P, c)))
-        counters->overflow = 1;
+  // One reservation per wavefront: the survivors among 64 consecutive candidates (neighbours
+  // in x, then y, z) take consecutive slots, so that nodes which read the same cache lines sit
+  // next to each other in the list and are expanded at about the same time.
+  const int lane = threadIdx.x & 63;
+  for (int c0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63); c0 < total;
+       c0 += gridDim.x * blockDim.x) {
+    const int c = c0 + lane;
+    bool keep = false;
+    if (c < total && c % num_chunks == chunk) {
+      const float sc = P.coarse_score[c];
+      keep = strict ? (sc > best) : (sc >= best);
     }
+    const unsigned long long mask = __ballot(keep);
+    if (mask == 0) continue;
+    int first = 0;
+    if (lane == 0) first = atomicAdd(&out.counts[sub * kCountStride3], __popcll(mask));
+    first = __builtin_amdgcn_readfirstlane(first);
+    if (keep && !Push3(out, sub, first + __popcll(mask & ((1ull << lane) - 1)), CoarseNode3D(P, c)))
+      counters->overflow = 1;
   }
 }
 
@@ -692,6 +704,9 @@ Expand3DKernel(const Fast3DProblem* __restrict__ problems, List3 in, int strict,
     // of blocks walk serially (measured: 0.9 us per node, chip idle).
     // (Workgroup b runs on XCD b % 8 and reads the sub-lists with sub % 8 == b % 8: the grid
     // is a multiple of 64 blocks.  With `affinity` the children stay on their parent's XCD.)
+    // (Sending the children of 32 consecutive nodes to one sub-list, to keep neighbours
+    // together in the next level, measured worse: 7.7 vs 7.2 ms for 32 pairs -- the lists of an
+    // XCD then differ in length.)
     const int sub_id = affinity ? (in_sub & 7) | ((((in_sub >> 3) * 5 + j) & 7) << 3)
                                 : (in_sub * 17 + j) & (kSubLists3 - 1);
     const Node3D nd = in.nodes[static_cast<size_t>(in_sub) * in.sub_capacity + j];
