@@ -97,3 +97,104 @@ def test_reference_constraint_builder_on_the_gpu(oracle, synth, tmp_path):
         assert abs(g[1] - (truth[0] - origin[0])) < 0.05
         assert abs(g[2] - (truth[1] - origin[1])) < 0.05
         assert abs(g[3] - truth[2]) < 0.01
+
+
+# ------------------------------------------------------------------------------------- 3D
+BINARY_3D = os.path.join(DROPIN, "_build", "constraint_builder_3d_mi355x")
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="needs the reference tree to compile")
+def test_3d_builds_from_the_reference_tree_and_links_only_the_product():
+    subprocess.run(["make", "-C", DROPIN], check=True, capture_output=True)
+    needed = subprocess.run(["readelf", "-d", BINARY_3D], check=True, capture_output=True,
+                            text=True).stdout
+    assert "libcartographer_mi355x.so" in needed
+    assert "oracle" not in needed
+    for name in ("constraint_builder_3d.cc", "hybrid_grid.h", "thread_pool.cc"):
+        assert not os.path.exists(os.path.join(DROPIN, name))
+
+
+def _write_fixture_3d(path, options, resolutions, submaps, hi, lo, hist, node7):
+    def grid(f, voxels):
+        f.write(struct.pack("<q", len(voxels)))
+        f.write(np.ascontiguousarray(voxels).tobytes())          # x, y, z int32; value, pad u16
+
+    def cloud(f, xyz):
+        f.write(struct.pack("<i", len(xyz)))
+        f.write(np.ascontiguousarray(xyz, np.float32).tobytes())
+
+    def histogram(f, h):
+        f.write(struct.pack("<i", len(h)))
+        f.write(np.ascontiguousarray(h, np.float32).tobytes())
+
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", len(submaps)))
+        f.write(struct.pack("<9d", *options))
+        f.write(struct.pack("<2f", *resolutions))
+        for vox, low_vox, h in submaps:
+            histogram(f, h)
+            grid(f, vox)
+            grid(f, low_vox)
+        cloud(f, hi)
+        cloud(f, lo)
+        histogram(f, hist)
+        f.write(struct.pack("<7d", *node7))
+
+
+@pytest.mark.gpu
+def test_reference_constraint_builder_3d_on_the_gpu(oracle, synth, tmp_path):
+    """The reference's ConstraintBuilder3D (unmodified source) on the device: its own test
+    scenario (an EMPTY submap, one point, thresholds 0: constraint_builder_3d_test.cc:61-122)
+    and a node against three submaps whose constraints must equal ComputeConstraint restated
+    with the oracle (constraint_builder_3d.cc:188-281): Match / MatchFullSubmap, then
+    CeresScanMatcher3D::Match from that pose with the high- and low-resolution pairs."""
+    import math
+    assert os.path.exists(BINARY_3D), "examples/dropin/_build is prebuilt by __graft_entry__.build()"
+    hist = np.zeros(16, np.float32)
+    submaps, world = [], None
+    for seed in (31, 32, 31):
+        g, w = synth.make_submap_3d(seed, 0.2, (8.0, 8.0, 3.0), 4, 8, 96)
+        low, _ = synth.make_submap_3d(seed, 0.4, (8.0, 8.0, 3.0), 4, 8, 96)
+        world = world or w
+        submaps.append((g.voxels(), low.voxels(), hist))
+    pos = world.free_position(5, 0.6)
+    hi = world.scan(pos, 0.0, 6, 64, seed=2)
+    lo = hi[::5].copy()
+    yaw = 0.03
+    node7 = list(pos + np.array([0.15, -0.1, 0.05])) + [math.cos(yaw / 2), 0.0, 0.0,
+                                                        math.sin(yaw / 2)]
+    # min_score, global min_score, depth, full_resolution_depth, min_rotational_score,
+    # min_low_resolution_score, xy / z / angular windows
+    options = (0.4, 0.4, 5, 2, 0.5, 0.25, 1.0, 1.0, 0.1)
+    fixture = str(tmp_path / "node3d.bin")
+    _write_fixture_3d(fixture, options, (0.2, 0.4), submaps, hi, lo, hist, node7)
+    out = subprocess.run([BINARY_3D, fixture], check=True, capture_output=True, text=True,
+                         timeout=300).stdout
+    assert "reference scenario: CallsBack + FindsConstraints OK" in out
+    got = []
+    for line in out.splitlines():
+        if line.startswith("constraint submap"):
+            w = line.split()
+            got.append((int(w[2]), [float(v) for v in w[6:9]] + [float(v) for v in w[10:14]],
+                        int(w[15])))
+    want = []
+    ident7 = [0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0]
+    for k, (vox, low_vox, h) in enumerate(submaps):
+        fast = oracle.FastCorrelativeScanMatcher3D(0.2, vox, 0.4, low_vox, h, 5, 2, 0.5, 0.25, 1.0,
+                                                   1.0, 0.1)
+        pairs = [(hi, 0.2, vox), (lo, 0.4, low_vox)]
+        for res in (fast.match(node7, ident7, (1, 0, 0, 0), hi, lo, hist, 0.4),
+                    fast.match_full_submap(node7[3:], [1, 0, 0, 0], (1, 0, 0, 0), hi, lo, hist,
+                                           0.4)):
+            if not res["found"]:
+                continue
+            refined = oracle.ceres3d_match(pairs, res["pose"][:3], list(res["pose"]), [5.0, 30.0],
+                                           translation_weight=10.0, rotation_weight=1.0,
+                                           max_num_iterations=10)["pose"]
+            want.append((k, refined))
+    assert len(want) == 5, "local matches in both copies of the world, global ones in all three"
+    assert f"constraints {len(want)}" in out
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g[0] == w[0] and g[2] == 1          # INTER_SUBMAP
+        np.testing.assert_allclose(g[1], w[1], rtol=0, atol=1e-6)

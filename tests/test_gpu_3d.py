@@ -666,3 +666,30 @@ def test_constraint_builder_3d_refines_on_the_device(sm3, oracle, synth):
     assert refined != searched
     assert with_ceres.last_refine_summaries[0]["final_cost"] < \
         with_ceres.last_refine_summaries[0]["initial_cost"]
+
+
+@pytest.mark.parametrize("affinity", [None, "0"])
+def test_fast3d_device_batch_of_twenty_pairs(sm3, synth, monkeypatch, affinity):
+    """From 16 pairs on a problem's nodes stay on one XCD (placement only: the search is
+    order-free); pair by pair the batch must return what the single searches return."""
+    if affinity is not None:
+        monkeypatch.setenv("CMX_FAST3D_AFFINITY", affinity)
+    depths = [5, 4, 6, 3] * 5
+    matchers, pos, data = _fast3d_batch_scene(sm3, synth, depths)
+    ident = sm3.Rigid3d()
+    rng = np.random.default_rng(11)
+    nodes, fulls, thresholds = [], [], []
+    for k in range(len(depths)):
+        d = rng.uniform(-0.3, 0.3, 3) * np.array([1.0, 1.0, 0.3])
+        nodes.append(sm3.Rigid3d(tuple(pos + d),
+                                 tuple(quat_from_angle_axis(rng.uniform(-0.1, 0.1), [0, 0, 1]))))
+        fulls.append(k % 7 == 3)
+        thresholds.append([0.12, 0.3, 0.99][k % 3] if k % 4 else 0.12)
+    expected = [m.match_full_submap(node.rotation, ident.rotation, data, t) if full
+                else m.match(node, ident, data, t)
+                for m, node, full, t in zip(matchers, nodes, fulls, thresholds)]
+    assert sum(e is not None for e in expected) >= 5
+    got, stats = sm3.fast3d_match_batch(matchers, nodes, [ident] * len(depths), fulls, thresholds,
+                                        data)
+    _assert_same_results(expected, got)
+    assert stats["expansion_launches"] >= 1 and stats["expansion_nodes"] > 0

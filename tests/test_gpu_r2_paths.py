@@ -350,3 +350,32 @@ def test_compute_histogram_equals_the_oracle(oracle, synth, seed):
     assert np.abs(got - ref).max() <= 1.0 + 1e-4 * ref.max()
     assert np.abs(got.sum() - ref.sum()) <= 1e-3 * max(1.0, ref.sum())
     assert (np.abs(got - ref) > 1e-3).sum() <= 4
+
+
+@pytest.mark.parametrize("env", [{}, {"CMX_STORE_SCANS": "0", "CMX_XCD_AFFINITY": "0"}])
+def test_c3_share_of_64_submaps_equals_the_single_searches(sm, synth, monkeypatch, env):
+    """One GPU's share of BASELINE config[2] at its full size: one 1000-point scan against 64
+    distinct 400x400 submaps, depth 7, full-submap search.  The batch keeps the cells of the
+    scans that can enter the search and places a problem's nodes on one XCD (both only in
+    batches); every pair must come back exactly as its single search (which re-derives the cells
+    and spreads its nodes) returns it -- found flag, f32 score, pose -- and the work counted by
+    the device must be the sum of the singles' lowest-resolution candidates."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    matchers, worlds = [], []
+    for seed in range(64):
+        cells, lim, world = synth.make_submap(300 + seed, 400, 400, 0.05, 30, 1000, 30.0, 0.01)
+        matchers.append(sm.FastCorrelativeScanMatcher2D(_grid(sm, cells, lim), 7))
+        worlds.append(world)
+    scan = worlds[17].scan(worlds[17].free_pose(1234, 0.5), 1000, 30.0, 0.01, 7)
+    found, scores, poses, stats = sm.match_full_submap_batch(matchers, scan, 0.6)
+    assert found[17] == 1 and stats["expansion_launches"] == 2 and stats["expansion_lookups"] > 0
+    coarse = 0
+    for i, m in enumerate(matchers):
+        f1, s1, p1 = m.match_full_submap(scan, 0.6)
+        coarse += m.last_stats["coarse_candidates"]
+        assert bool(found[i]) == bool(f1), i
+        if f1:
+            assert np.float32(s1) == np.float32(scores[i]), i
+            assert (p1.x, p1.y, p1.theta) == tuple(poses[i]), i
+    assert stats["coarse_candidates"] == coarse
