@@ -534,12 +534,30 @@ class Fast3DWorkload:
         expand = expansion_roofline(
             acc, steps, "Expand3DKernel (one workgroup per node: one 8-byte oct gather per point)",
             None if pmc_config is None else pmc("Expand3DKernel", pmc_config),
-            "achieved = nodes taken off the frontiers x points (an upper bound: nodes found below "
-            "the bound when they are taken are skipped) / HIP-event span of the expansion launches "
-            "/ the measured gather-issue ceiling of the chip (coherent byte gathers; the 8-byte "
-            "gathers here touch 64 distinct lines each)")
+            "lookups = nodes taken off the frontiers x points (an upper bound: nodes found below "
+            "the bound when they are taken are skipped); span = HIP events around the expansion "
+            "launches")
         if expand is None:
             return coarse_line
+        # A batch over distinct submaps is bound by the memory side: every lookup reads an
+        # 8-byte oct word from a 128-byte line nobody else wants, plus the point's 16-byte cell
+        # record (coalesced, cached).  frac prices the algorithmic bytes against HBM; the
+        # counter traffic (L2 misses x 128 B) next to it says how much of the peak the line
+        # granularity actually consumes.
+        secs = expand["kernel_ms"] * 1e-3
+        alg_launch = expand["lookups_per_step"] / expand["launches_per_step"] * 24.0
+        expand["gather_issue"] = {k: expand[k] for k in ("bound", "achieved", "peak", "unit", "frac")}
+        expand.update({"bound": "hbm", "achieved": alg_launch / secs / 1e9, "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": alg_launch / secs / 1e9 / HBM_PEAK_GBS,
+                       "algorithmic_bytes": alg_launch,
+                       "hbm_frac_traffic": None if expand["traffic"] is None
+                       else expand["traffic"] / secs / 1e9 / HBM_PEAK_GBS})
+        expand["note"] = ("achieved = algorithmic bytes per launch (24 B per lookup: 8-byte oct "
+                          "word + 16-byte cell record) / average launch time / 8 TB/s; "
+                          "hbm_frac_traffic = rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the same "
+                          "command per launch / the same time / 8 TB/s (32 distinct submaps: L2 "
+                          "misses 50 %, every miss a 128-byte line for 8 bytes); gather_issue: the "
+                          "same lookups against the chip's gather-issue ceiling.  " + expand["note"])
         expand["lowest_resolution_scoring"] = coarse_line
         return expand
 

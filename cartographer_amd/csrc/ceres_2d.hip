@@ -416,11 +416,10 @@ void RefineBatch(const cmx_ceres2d_options* options, const RefineItem* items, in
     P.out = d_out + 8 * static_cast<size_t>(p);
     h_prob[p] = P;
   }
-  CMX_HIP(hipMemcpyAsync(d_in, h_in, bytes, hipMemcpyHostToDevice, ws->stream));
+  SmallCopyAsync(d_in, h_in, bytes, /*to_device=*/true, ws->stream);
   Ceres2DKernel<<<num, kCeresThreads, 0, ws->stream>>>(reinterpret_cast<const Ceres2DProblem*>(d_in));
   CMX_HIP(hipGetLastError());
-  CMX_HIP(hipMemcpyAsync(h_out, d_out, 64 * static_cast<size_t>(num), hipMemcpyDeviceToHost,
-                         ws->stream));
+  SmallCopyAsync(h_out, d_out, 64 * static_cast<size_t>(num), /*to_device=*/false, ws->stream);
   CMX_HIP(hipStreamSynchronize(ws->stream));
   for (int p = 0; p < num; ++p) {
     const double* o = h_out + 8 * static_cast<size_t>(p);

@@ -478,16 +478,15 @@ void SolveProblems(Workspace& ws, Ceres3DProblem* problems, int num, size_t clou
   double* d_out = reinterpret_cast<double*>(d_misc + prob_bytes);
   for (int p = 0; p < num; ++p) problems[p].out = d_out + 12 * static_cast<size_t>(p);
   std::memcpy(h_misc, problems, prob_bytes);
-  CMX_HIP(hipMemcpyAsync(d_xyz, h_xyz, sizeof(float) * cloud_floats, hipMemcpyHostToDevice,
-                         ws.stream));
-  CMX_HIP(hipMemcpyAsync(d_misc, h_misc, prob_bytes, hipMemcpyHostToDevice, ws.stream));
+  SmallCopyAsync(d_xyz, h_xyz, sizeof(float) * cloud_floats, /*to_device=*/true, ws.stream);
+  SmallCopyAsync(d_misc, h_misc, prob_bytes, /*to_device=*/true, ws.stream);
   CMX_HIP(hipEventRecord(ws.ev_begin, ws.stream));
   Ceres3DKernel<<<num, kCeres3DThreads, 0, ws.stream>>>(
       reinterpret_cast<const Ceres3DProblem*>(d_misc));
   CMX_HIP(hipGetLastError());
   CMX_HIP(hipEventRecord(ws.ev_end, ws.stream));
   double* h_out = reinterpret_cast<double*>(h_misc + prob_bytes);
-  CMX_HIP(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, ws.stream));
+  SmallCopyAsync(h_out, d_out, out_bytes, /*to_device=*/false, ws.stream);
   CMX_HIP(hipStreamSynchronize(ws.stream));
   std::memcpy(results, h_out, out_bytes);
 }

@@ -117,6 +117,14 @@ class PinnedBuffer {
   size_t capacity_ = 0;
 };
 
+// Small transfers between pinned host memory (mapped into the device's address space) and
+// device memory by a one-workgroup kernel instead of a copy command: a latency-bound call is a
+// chain of launches on one stream, and a copy command in that chain costs 10-15 us of engine
+// start-up where a launch costs 3-4.  Falls back to hipMemcpyAsync above `kCopyKernelMaxBytes`
+// or with CMX_COPY_KERNELS=0.  `pinned` is the host side (source for to_device, else target).
+constexpr size_t kCopyKernelMaxBytes = 64 * 1024;
+void SmallCopyAsync(void* dst, const void* src, size_t bytes, bool to_device, hipStream_t stream);
+
 // Everything one in-flight call needs; handed out by a per-device pool so
 // concurrent callers never share scratch.
 struct Workspace {

@@ -77,6 +77,36 @@ hipStream_t OverrideStream(int device) {
   return it == g_stream_override.end() ? nullptr : it->second;
 }
 
+namespace {
+__global__ void __launch_bounds__(1024)
+SmallCopyKernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t words16,
+                unsigned char* __restrict__ dst_tail, const unsigned char* __restrict__ src_tail,
+                int tail_bytes) {
+  for (size_t i = threadIdx.x; i < words16; i += blockDim.x) dst[i] = src[i];
+  if (static_cast<int>(threadIdx.x) < tail_bytes) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+}  // namespace
+
+void SmallCopyAsync(void* dst, const void* src, size_t bytes, bool to_device, hipStream_t stream) {
+  static const bool enabled = [] {
+    const char* e = getenv("CMX_COPY_KERNELS");
+    return e ? e[0] != '0' : true;
+  }();
+  const bool aligned = (reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 16 == 0;
+  if (!enabled || !aligned || bytes == 0 || bytes > kCopyKernelMaxBytes) {
+    CMX_HIP(hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost,
+                           stream));
+    return;
+  }
+  const size_t words16 = bytes / 16;
+  const int tail = static_cast<int>(bytes - words16 * 16);
+  SmallCopyKernel<<<1, 1024, 0, stream>>>(
+      static_cast<uint4*>(dst), static_cast<const uint4*>(src), words16,
+      static_cast<unsigned char*>(dst) + words16 * 16,
+      static_cast<const unsigned char*>(src) + words16 * 16, tail);
+  CMX_HIP(hipGetLastError());
+}
+
 Workspace::~Workspace() {
   if (ev_begin) (void)hipEventDestroy(ev_begin);
   if (ev_end) (void)hipEventDestroy(ev_end);

@@ -2218,7 +2218,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     out->max_scans = std::max(out->max_scans, h.num_scans);
   }
   // One H2D for the problem descriptors, their initial states and the rotation tables.
-  CMX_HIP(hipMemcpyAsync(d_upload, h_upload, upload_bytes, hipMemcpyHostToDevice, ws.stream));
+  SmallCopyAsync(d_upload, h_upload, upload_bytes, /*to_device=*/true, ws.stream);
 
   const dim3 per_scan(out->max_scans, num);
   auto mark = [&](const char* name) { if (out->trace) out->trace->Mark(name); };
@@ -2363,7 +2363,7 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
   ProblemState* h_states = reinterpret_cast<ProblemState*>(
       h_misc + sizeof(CountersSummary) + num * (sizeof(SelectState) + sizeof(BestLeaf)));
   auto fetch_results = [&] {
-    CMX_HIP(hipMemcpyAsync(h_misc, d_tail, misc_bytes, hipMemcpyDeviceToHost, ws.stream));
+    SmallCopyAsync(h_misc, d_tail, misc_bytes, /*to_device=*/false, ws.stream);
     CMX_HIP(hipStreamSynchronize(ws.stream));
   };
 

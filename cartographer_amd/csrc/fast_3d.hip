@@ -1219,12 +1219,14 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
       h_hi[3 * i] = hi[3 * src]; h_hi[3 * i + 1] = hi[3 * src + 1]; h_hi[3 * i + 2] = hi[3 * src + 2];
     }
   }
-  CMX_HIP(hipMemcpyAsync(d_hi, h_hi, 3 * sizeof(float) * n, hipMemcpyHostToDevice, ws->stream));
-  CMX_HIP(hipMemcpyAsync(d_low, data.low_resolution_point_cloud, 3 * sizeof(float) * n_low,
-                         hipMemcpyHostToDevice, ws->stream));
-  CMX_HIP(hipMemcpyAsync(d_pose_q, h_q, 3 * sizeof(float4) * scans_total, hipMemcpyHostToDevice,
-                         ws->stream));
-  CMX_HIP(hipMemcpyAsync(d_misc, h_misc, off_best, hipMemcpyHostToDevice, ws->stream));
+  // Four small uploads, all from pinned staging (the caller's low-resolution cloud is copied
+  // there first): copy kernels where they are small (cmx_common.h: SmallCopyAsync).
+  float* h_low = ws->pinned[3].ReserveAs<float>(3 * static_cast<size_t>(n_low));
+  std::memcpy(h_low, data.low_resolution_point_cloud, 3 * sizeof(float) * n_low);
+  SmallCopyAsync(d_hi, h_hi, 3 * sizeof(float) * n, true, ws->stream);
+  SmallCopyAsync(d_low, h_low, 3 * sizeof(float) * n_low, true, ws->stream);
+  SmallCopyAsync(d_pose_q, h_q, 3 * sizeof(float4) * scans_total, true, ws->stream);
+  SmallCopyAsync(d_misc, h_misc, off_best, true, ws->stream);
 
   auto front = [&](int stage) {
     return List3{d_front[stage & 1], d_counters->frontier[stage], kFrontierCapacity / kSubLists3};
@@ -1314,7 +1316,7 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
     mark("select");
     CMX_HIP(hipGetLastError());
     CMX_HIP(hipEventRecord(ws->ev_end, ws->stream));
-    CMX_HIP(hipMemcpyAsync(h_misc, d_misc, misc_bytes, hipMemcpyDeviceToHost, ws->stream));
+    SmallCopyAsync(h_misc, d_misc, misc_bytes, false, ws->stream);
     CMX_HIP(hipStreamSynchronize(ws->stream));
     trace.Report();
     lap("device");

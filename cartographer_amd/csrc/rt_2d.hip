@@ -1197,7 +1197,7 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
     h_params[m] = P;
   }
   lap("fill");
-  CMX_HIP(hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, ws->stream));
+  SmallCopyAsync(d_in, h_in, in_bytes, /*to_device=*/true, ws->stream);
   const Rt2DParams* d_params = reinterpret_cast<const Rt2DParams*>(d_in);
 
   CMX_HIP(hipEventRecord(ws->ev_begin, ws->stream));
@@ -1236,8 +1236,7 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
   }
   CMX_HIP(hipGetLastError());
   CMX_HIP(hipEventRecord(ws->ev_end, ws->stream));
-  CMX_HIP(hipMemcpyAsync(h_misc, d_misc, sizeof(unsigned) * 128 * num, hipMemcpyDeviceToHost,
-                         ws->stream));
+  SmallCopyAsync(h_misc, d_misc, sizeof(unsigned) * 128 * num, /*to_device=*/false, ws->stream);
   lap("enqueue");
   CMX_HIP(hipStreamSynchronize(ws->stream));
   lap("wait");
