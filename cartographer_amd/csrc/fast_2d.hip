@@ -1404,10 +1404,13 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
       }
       ++groups;
       if (q0 + kGroup < n) {
-        const int rest = parent_ub - WaveSum(seen_max);
-        const int reach = max(max(WaveSum(s00), WaveSum(s01)), max(WaveSum(s10), WaveSum(s11)));
+        // max_k sum_lanes(s_k) <= sum_lanes(max_k s_k): ONE wavefront reduction (of what the
+        // best child of each lane's points still lacks to the parent) instead of five -- a
+        // slightly looser bound, the same results (the check only skips work that cannot
+        // matter), 8 of 54 vector instructions per gather less.
+        const int lacking = seen_max - max(max(s00, s01), max(s10, s11));
         // kept children satisfy score >= best (> best in strict mode)
-        if (ToScore(P, reach + rest, n) < best) { dead = true; break; }
+        if (ToScore(P, parent_ub - WaveSum(lacking), n) < best) { dead = true; break; }
       }
     }
     const auto count_node = [&](int nvalid) {     // lane 0
@@ -2421,8 +2424,10 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
         int stage = 0;
         int top = depth - 1;
         // Wave-per-node level-synchronous expansion of the (wide, shallow-lived)
-        // top levels.  (Timed for the statistics in the first pass.)
-        const bool timed = !strict && chunk == 0;
+        // top levels.  (Timed for the statistics in the first pass of a batch: there the
+        // expansion is the dominant kernel; a single search's chain of launches is not given
+        // two more event packets to wait behind.)
+        const bool timed = !strict && chunk == 0 && num >= 4;
         if (timed) CMX_HIP(hipEventRecord(ws.ev_x0, ws.stream));
         for (int used = 0; used < wave_levels && top - 1 >= 1; ++used, --top, ++stage) {
           ExpandWaveKernel<<<used == 0 ? wide_blocks : narrow_blocks, 256, 0, ws.stream>>>(
