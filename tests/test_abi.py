@@ -72,3 +72,56 @@ def test_header_is_plain_c_and_links(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "cartographer_mi355x" in out.stdout
+
+
+def test_struct_layouts_agree_with_the_header(tmp_path):
+    """Every struct the ctypes mirror declares has the size and member offsets a C compiler
+    gives the header's struct of the same role (a field added on one side only -- as happened to
+    cmx_match_stats this round -- would otherwise corrupt the caller's stack silently)."""
+    import subprocess
+    from cartographer_amd import _lib
+    pairs = {                      # header struct -> ctypes mirror
+        "cmx_pose2d": _lib.Pose2d, "cmx_pose3d": _lib.Pose3d,
+        "cmx_grid2d_limits": _lib.Grid2DLimits, "cmx_rt_options": _lib.RtOptions,
+        "cmx_fast2d_options": _lib.Fast2DOptions, "cmx_fast3d_options": _lib.Fast3DOptions,
+        "cmx_match_stats": _lib.MatchStats, "cmx_ceres2d_options": _lib.Ceres2DOptions,
+        "cmx_ceres_summary": _lib.CeresSummary, "cmx_ceres3d_options": _lib.Ceres3DOptions,
+        "cmx_ceres3d_pair": _lib.Ceres3DPair, "cmx_voxel": _lib.Voxel,
+        "cmx_node_data3d": _lib.NodeData3D, "cmx_result3d": _lib.Result3D,
+    }
+    header = open(os.path.join(ROOT, "include", "cartographer_mi355x.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cartographer_mi355x.h"',
+             'int main(void) {']
+    members = {}
+    for name in pairs:
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), header, re.S)
+        assert body, f"{name} not found in the header"
+        fields = []
+        for decl in body.group(1).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):            # "double x, y, theta" / "double t[3]"
+                ident = re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*(?:\[[^\]]*\])?\s*$", part.strip())
+                fields.append(ident[0])
+        members[name] = fields
+        lines.append(f'  printf("{name} %zu", sizeof({name}));')
+        for fld in fields:
+            lines.append(f'  printf(" %zu", offsetof({name}, {fld}));')
+        lines.append('  printf("\\n");')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "layout")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o",
+                           exe])
+    out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
+    for line in out.splitlines():
+        words = line.split()
+        name, size, offsets = words[0], int(words[1]), [int(w) for w in words[2:]]
+        mirror = pairs[name]
+        assert C.sizeof(mirror) == size, (name, C.sizeof(mirror), size)
+        got = [getattr(mirror, f[0]).offset for f in mirror._fields_]
+        assert len(got) == len(offsets), (name, members[name], [f[0] for f in mirror._fields_])
+        assert got == offsets, (name, got, offsets)
