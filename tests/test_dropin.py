@@ -198,3 +198,49 @@ def test_reference_constraint_builder_3d_on_the_gpu(oracle, synth, tmp_path):
     for g, w in zip(got, want):
         assert g[0] == w[0] and g[2] == 1          # INTER_SUBMAP
         np.testing.assert_allclose(g[1], w[1], rtol=0, atol=1e-6)
+
+
+# ------------------------------------------------------------------- batched C++ front, 2D
+BINARY_BATCHED = os.path.join(DROPIN, "_build", "constraint_builder_2d_batched_mi355x")
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="needs the reference tree to compile")
+def test_batched_front_builds_with_the_reference_interface():
+    """examples/dropin/batched: a ConstraintBuilder2D with the reference's public interface whose
+    NotifyEndOfNode hands a node's pairs to cmx_fast2d_match_batch + cmx_fast2d_refine_batch.
+    The reference's own test main compiles against it unchanged (include redirect)."""
+    subprocess.run(["make", "-C", DROPIN], check=True, capture_output=True)
+    needed = subprocess.run(["readelf", "-d", BINARY_BATCHED], check=True, capture_output=True,
+                            text=True).stdout
+    assert "libcartographer_mi355x.so" in needed and "oracle" not in needed
+    symbols = subprocess.run(["nm", "-C", BINARY_BATCHED], check=True, capture_output=True,
+                             text=True).stdout
+    assert "cmx_fast2d_match_batch" in symbols and "cmx_fast2d_refine_batch" in symbols
+    # the per-pair adapter classes are not part of this build
+    assert "FastCorrelativeScanMatcher2D::Match" not in symbols
+
+
+@pytest.mark.gpu
+def test_batched_front_gives_the_reference_builders_constraints(synth, tmp_path):
+    """The batched builder and the reference's unmodified builder (over the per-pair adapters)
+    run the same main on the same fixture: the reference's test scenario passes and the printed
+    constraints are identical, digit for digit."""
+    assert os.path.exists(BINARY) and os.path.exists(BINARY_BATCHED)
+    truth_world = None
+    submaps = []
+    for seed, origin in ((42, (1.5, -2.25)), (43, (0.0, 0.0)), (42, (-3.0, 4.5))):
+        cells, lim, world = synth.make_submap(seed, 400, 400, 0.05, 30, 1000, 30.0, 0.01)
+        truth_world = truth_world or world
+        submaps.append((cells, lim, origin))
+    truth = truth_world.free_pose(1234, 0.5)
+    scan = truth_world.scan(truth, 1000, 30.0, 0.01, 7)
+    rel = (truth[0] - 1.5 + 0.35, truth[1] + 2.25 - 0.25, truth[2] + 0.12)
+    fixture = str(tmp_path / "node.bin")
+    _write_fixture(fixture, submaps, scan, rel)
+    outs = []
+    for binary in (BINARY, BINARY_BATCHED):
+        out = subprocess.run([binary, fixture], check=True, capture_output=True, text=True,
+                             timeout=300).stdout
+        assert "reference scenario: CallsBack + FindsConstraints OK" in out
+        outs.append([line for line in out.splitlines() if line.startswith("constraint")])
+    assert len(outs[0]) >= 4 and outs[0] == outs[1]
