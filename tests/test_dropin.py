@@ -244,3 +244,48 @@ def test_batched_front_gives_the_reference_builders_constraints(synth, tmp_path)
         assert "reference scenario: CallsBack + FindsConstraints OK" in out
         outs.append([line for line in out.splitlines() if line.startswith("constraint")])
     assert len(outs[0]) >= 4 and outs[0] == outs[1]
+
+
+# ------------------------------------------------------------------- batched C++ front, 3D
+BINARY_BATCHED_3D = os.path.join(DROPIN, "_build", "constraint_builder_3d_batched_mi355x")
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="needs the reference tree to compile")
+def test_batched_front_3d_builds_with_the_reference_interface():
+    subprocess.run(["make", "-C", DROPIN], check=True, capture_output=True)
+    needed = subprocess.run(["readelf", "-d", BINARY_BATCHED_3D], check=True, capture_output=True,
+                            text=True).stdout
+    assert "libcartographer_mi355x.so" in needed and "oracle" not in needed
+    symbols = subprocess.run(["nm", "-C", BINARY_BATCHED_3D], check=True, capture_output=True,
+                             text=True).stdout
+    assert "cmx_fast3d_match_batch" in symbols and "cmx_fast3d_refine_batch" in symbols
+    assert "FastCorrelativeScanMatcher3D::Match" not in symbols
+
+
+@pytest.mark.gpu
+def test_batched_front_3d_gives_the_reference_builders_constraints(synth, tmp_path):
+    """The batched ConstraintBuilder3D and the reference's unmodified one run the same main on
+    the same fixture: identical constraints, digit for digit."""
+    import math
+    assert os.path.exists(BINARY_3D) and os.path.exists(BINARY_BATCHED_3D)
+    hist = np.zeros(16, np.float32)
+    submaps, world = [], None
+    for seed in (31, 32, 31):
+        g, w = synth.make_submap_3d(seed, 0.2, (8.0, 8.0, 3.0), 4, 8, 96)
+        low, _ = synth.make_submap_3d(seed, 0.4, (8.0, 8.0, 3.0), 4, 8, 96)
+        world = world or w
+        submaps.append((g.voxels(), low.voxels(), hist))
+    pos = world.free_position(5, 0.6)
+    hi = world.scan(pos, 0.0, 6, 64, seed=2)
+    lo = hi[::5].copy()
+    node7 = list(pos + np.array([0.15, -0.1, 0.05])) + [math.cos(0.015), 0.0, 0.0, math.sin(0.015)]
+    fixture = str(tmp_path / "node3d.bin")
+    _write_fixture_3d(fixture, (0.4, 0.4, 5, 2, 0.5, 0.25, 1.0, 1.0, 0.1), (0.2, 0.4), submaps, hi,
+                      lo, hist, node7)
+    outs = []
+    for binary in (BINARY_3D, BINARY_BATCHED_3D):
+        out = subprocess.run([binary, fixture], check=True, capture_output=True, text=True,
+                             timeout=300).stdout
+        assert "reference scenario: CallsBack + FindsConstraints OK" in out
+        outs.append([line for line in out.splitlines() if line.startswith("constraint")])
+    assert len(outs[0]) == 6 and outs[0] == outs[1]          # 5 constraints + the count line
