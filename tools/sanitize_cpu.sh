@@ -10,8 +10,8 @@ rm -rf "$SCRATCH" && mkdir -p "$SCRATCH"
 cp -r "$REPO" "$SCRATCH/repo" && cd "$SCRATCH/repo" && rm -rf .git gpurun_out
 SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -g -O1"
 mkdir -p oracle/_build oracle/_ref cartographer_amd/lib
-g++ $SAN -std=c++17 -fPIC -shared -ffp-contract=off -pthread -o oracle/_build/liboracle.so \
-    oracle/oracle_2d.cc oracle/oracle_3d.cc oracle/oracle_capi.cc
+ORACLE_SRCS=$(grep "^SRCS :=" oracle/Makefile | sed 's/SRCS := //')      # every restatement source
+(cd oracle && g++ $SAN -std=c++17 -fPIC -shared -ffp-contract=off -pthread -o _build/liboracle.so $ORACLE_SRCS)
 g++ $SAN -std=c++17 -fPIC -shared -ffp-contract=off -o cartographer_amd/lib/libcmx_synth.so \
     cartographer_amd/csrc/host/probability_grid_builder.cc \
     cartographer_amd/csrc/host/hybrid_grid_builder.cc cartographer_amd/csrc/host/synth.cc
