@@ -829,7 +829,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8/int32" if name in ("c2", "c3", "c5") else
-                     ("u16->int32 bulk, f32 finalists" if name == "c1" else "f32"),
+                     ("u16->int32 bulk, f32 finalists" if name == "c1" else
+                      "u8->int32 bounds, f32 finalists"),
             "data": "synthetic",
             "constraints_per_s": matches_total / elapsed,
             "config": config,
