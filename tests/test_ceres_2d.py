@@ -75,3 +75,16 @@ def test_match_decreases_the_cost_and_recovers_the_pose(oracle, synth, nonmonoto
     err0 = math.hypot(init[0] - truth[0], init[1] - truth[1])
     err1 = math.hypot(out["pose"][0] - truth[0], out["pose"][1] - truth[1])
     assert err1 < err0 and err1 < 0.03
+
+
+def test_reference_occupied_space_cost_function_smoke_test(oracle):
+    """OccupiedSpaceCostFunction2DTest.SmokeTest (occupied_space_cost_function_2d_test.cc:32-53):
+    an all-unknown 2 x 2 grid at resolution 1 with max (1, 1), one point at the origin, pose 0,
+    scaling factor 1: the residual is exactly kMaxProbability (1 - kMinCorrespondenceCost)."""
+    cells = np.zeros((2, 2), np.uint16)
+    r, J = oracle.ceres2d_residuals(cells, 1.0, 1.0, 1.0, np.zeros(2), 0.0, np.zeros(3),
+                                    np.zeros((1, 3), np.float32), occupied_space_weight=1.0,
+                                    translation_weight=1.0, rotation_weight=1.0)
+    k_max_probability = float(np.float32(1.0) - np.float32(0.1))   # 1.f - kMinProbability, in float
+    assert r[0] == k_max_probability
+    assert np.all(J[0] == 0.0)                               # a constant field

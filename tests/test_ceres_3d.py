@@ -163,3 +163,112 @@ def test_refine_batch_checks_its_arguments_before_touching_a_device():
     o.translation_weight = 0.0
     assert call(o, 0) == _lib.INVALID_ARGUMENT
     assert b"translation_weight" in L.cmx_last_error()
+
+
+# ---- InterpolatedGrid and the delta functors, on the reference's own unit tests ------------
+def _interpolated(oracle, vox, resolution, xyz):
+    """InterpolatedGrid::GetInterpolatedValue at every row of xyz, read off the occupied-space
+    residuals of an identity pose: residual_i = w / sqrt(N) * (1 - value_i)."""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    r, _ = oracle.ceres3d_residuals([(xyz, resolution, vox)], (0, 0, 0), (1, 0, 0, 0),
+                                    [0, 0, 0, 1, 0, 0, 0], [1.0], translation_weight=1.0,
+                                    rotation_weight=1.0)
+    return 1.0 - r[:len(xyz)] * math.sqrt(len(xyz))
+
+
+def _interpolated_grid_fixture(synth):
+    """InterpolatedGridTest (interpolated_grid_test.cc:28-48): hybrid_grid_(0.1f) with
+    probability 1 at seven points."""
+    grid = synth.HybridGrid(0.1)
+    for p in POINTS:
+        grid.set_probability(grid.get_cell_index(p), 1.0)
+    return grid
+
+
+def _lattice():
+    """The test's loops: z, y, x advanced by resolution() (the FLOAT 0.1f) in double."""
+    step = float(np.float32(0.1))
+
+    def axis(lo, hi):
+        out, v = [], lo
+        while v < hi:
+            out.append(v)
+            v += step
+        return out
+    return axis(-8.0, -2.0), axis(1.0, 5.0), axis(-1.0, 3.0)
+
+
+def test_reference_interpolated_grid_interpolates_grid_points(oracle, synth):
+    """InterpolatedGridTest.InterpolatesGridPoints (interpolated_grid_test.cc:50-60): at every
+    lattice point the interpolated value is the grid's probability, to 1e-6.  (The query points
+    pass through float32, as a RangefinderPoint does; lattice coordinates of magnitude < 8 move
+    by < 5e-7, within the reference's own tolerance on a piecewise cubic with zero slope at the
+    cell centres.)"""
+    grid = _interpolated_grid_fixture(synth)
+    xs, ys, zs = _lattice()
+    pts = np.array([(x, y, z) for z in zs[::4] for y in ys[::3] for x in xs], np.float64)
+    # the seven occupied cells and their neighbours, whatever the stride above skipped
+    near = np.array([p + d for p in POINTS.astype(np.float64)
+                     for d in ((0, 0, 0), (0.1, 0, 0), (-0.1, 0, 0), (0, 0.1, 0), (0, 0, -0.1))])
+    pts = np.vstack([pts, near])
+    want = np.array([grid.get_probability(grid.get_cell_index(np.float32(p))) for p in pts])
+    got = _interpolated(oracle, grid.voxels(), 0.1, pts)
+    assert want.max() > 0.85 and want.min() < 0.15
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+
+
+def test_reference_interpolated_grid_is_monotonic_between_grid_points(oracle, synth):
+    """InterpolatedGridTest.MonotonicBehaviorBetweenGridPointsInX (:62-87): between two lattice
+    points of different probability the value moves monotonically towards the second."""
+    grid = _interpolated_grid_fixture(synth)
+    res = float(np.float32(0.1))
+    step = res / 10.0
+    checked = 0
+    for p in POINTS.astype(np.float64):
+        for x0 in (p[0] - res, p[0]):                  # the rise into and the fall out of the cell
+            start = grid.get_probability(grid.get_cell_index(np.float32([x0, p[1], p[2]])))
+            nxt = grid.get_probability(grid.get_cell_index(np.float32([x0 + res, p[1], p[2]])))
+            if abs(nxt - start) < 1e-6:
+                continue
+            samples, s = [], step
+            while s < res - 2 * step:
+                samples.append(s)
+                s += step
+            a = _interpolated(oracle, grid.voxels(), 0.1,
+                              [(x0 + s, p[1], p[2]) for s in samples])
+            b = _interpolated(oracle, grid.voxels(), 0.1,
+                              [(x0 + s + step, p[1], p[2]) for s in samples])
+            assert np.all((nxt - start) * (b - a) > 0.0), (p, x0)
+            checked += 1
+    assert checked >= 8
+
+
+def _rotation_delta_squared_cost(oracle, rotation, scaling_factor, target):
+    """RotationDeltaCostFunctor3D's squared cost (rotation_delta_cost_functor_3d_test.cc:30-47):
+    the last three residuals of the problem."""
+    pts = np.zeros((1, 3), np.float32)
+    vox = np.zeros(0, dtype=[("x", np.int32), ("y", np.int32), ("z", np.int32),
+                             ("value", np.uint16), ("pad", np.uint16)])
+    r, _ = oracle.ceres3d_residuals([(pts, 1.0, vox)], (0, 0, 0), target,
+                                    [0, 0, 0, *rotation], [1.0], translation_weight=1.0,
+                                    rotation_weight=scaling_factor)
+    return float(np.sum(r[-3:] ** 2))
+
+
+def test_reference_rotation_delta_cost_functor(oracle):
+    """RotationDeltaCostFunctor3DTest.SameRotationGivesZeroCost / .ComputesCorrectCost
+    (rotation_delta_cost_functor_3d_test.cc:49-85), precision 1e-8."""
+    ident = np.array([1.0, 0, 0, 0])
+    unit = lambda v: np.asarray(v, np.float64) / np.linalg.norm(v)      # noqa: E731
+    assert abs(_rotation_delta_squared_cost(oracle, ident, 1.0, ident)) < 1e-8
+    rot = np.array(quat_from_angle_axis(0.9, unit([0.2, 0.1, 0.3])))
+    assert abs(_rotation_delta_squared_cost(oracle, rot, 1.0, rot)) < 1e-8
+    scaling, angle = 1.2, 0.8
+    rotation = np.array(quat_from_angle_axis(angle, unit([0.2, 0.1, 0.8])))
+    target = np.array(quat_from_angle_axis(0.2, unit([-0.5, 0.3, 0.4])))
+    expected = (scaling * math.sin(angle / 2.0)) ** 2
+    assert abs(_rotation_delta_squared_cost(oracle, rotation, scaling, ident) - expected) < 1e-8
+    assert abs(_rotation_delta_squared_cost(oracle, quat_mul(target, rotation), scaling, target)
+               - expected) < 1e-8
+    assert abs(_rotation_delta_squared_cost(oracle, quat_mul(rotation, target), scaling, target)
+               - expected) < 1e-8
