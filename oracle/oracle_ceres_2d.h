@@ -19,9 +19,12 @@
 //     window of 5 when requested.  The 3-unknown damped system is solved through its normal
 //     equations (Ceres: DENSE_QR of the augmented Jacobian; same solution up to rounding).
 // What pins it: the reference's own CeresScanMatcherTest (ceres_scan_matcher_2d_test.cc:34-112,
-// four poses to 1e-2, final cost ~0) and, for the cost function, the reference's own
-// occupied_space_cost_function_2d.cc compiled in place against a stand-in ceres.h
-// (oracle/_ref, tests/test_ceres_2d.py).
+// four poses IsNearly to 1e-2, final cost ~0: tests/test_ceres_2d.py) and the reference's own
+// occupied_space_cost_function_2d.cc, delta functors and ceres_scan_matcher_2d.cc compiled in
+// place over the stand-in ceres/ headers of ref_shims (oracle/_ref/libref_ceres.so, `make
+// ref_ceres`): residuals and Jacobians equal to 1e-12 on random poses, Match() to 1e-9 with the
+// same step counts (tests/test_reference_ref_ceres.py).  The stand-in solver is ours too (Jets +
+// Householder QR, written independently of this file): Ceres' own iterates stay unpinned.
 #ifndef ORACLE_CERES_2D_H_
 #define ORACLE_CERES_2D_H_
 

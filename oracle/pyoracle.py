@@ -100,6 +100,48 @@ def build_ref(reference="/root/reference"):
     return os.path.exists(_REF)
 
 
+_REF_CERES = os.path.join(_HERE, "_ref", "libref_ceres.so")
+_ref_ceres_lib = None
+
+
+def build_ref_ceres(reference="/root/reference"):
+    """`make -C oracle ref_ceres` when the reference tree is present."""
+    if os.path.isdir(os.path.join(reference, "cartographer")):
+        subprocess.check_call(["make", "-C", _HERE, "ref_ceres", f"REFERENCE={reference}"],
+                              stdout=subprocess.DEVNULL)
+    return os.path.exists(_REF_CERES)
+
+
+def ref_ceres_lib():
+    """The reference's own Ceres-side sources (cost functions, CeresScanMatcher2D / 3D::Match)
+    compiled in place over the stand-in solver of ref_shims/ceres/, or None."""
+    global _ref_ceres_lib
+    if _ref_ceres_lib is None and (os.path.exists(_REF_CERES) or build_ref_ceres()):
+        L = C.CDLL(_REF_CERES)
+        L.refc_ceres2d_match.argtypes = [_u16p, C.c_int, C.c_int, C.c_double, C.c_double,
+                                         C.c_double, _f64p, _f64p, _f64p, _f32p, C.c_int, _f64p,
+                                         _f64p]
+        L.refc_ceres2d_match.restype = None
+        L.refc_ceres2d_residuals.argtypes = [_u16p, C.c_int, C.c_int, C.c_double, C.c_double,
+                                             C.c_double, _f64p, _f64p, C.c_double, _f64p, _f32p,
+                                             C.c_int, _f64p, _f64p]
+        L.refc_ceres2d_residuals.restype = None
+        L.refc_ceres3d_match.argtypes = [_f64p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, _f64p, _f64p, _f64p, _f64p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.refc_ceres3d_match.restype = None
+        L.refc_ceres3d_residuals.argtypes = [_f64p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, _f64p, _f64p, _f64p, _f64p,
+                                             _f64p]
+        L.refc_ceres3d_residuals.restype = None
+        L.refc_intensity3d_residuals.argtypes = [C.c_double, C.c_float, _f32p, _f32p, C.c_int,
+                                                 C.c_float, C.c_void_p, C.c_int64, _f64p, _f64p,
+                                                 _f64p]
+        L.refc_intensity3d_residuals.restype = None
+        _ref_ceres_lib = L
+    return _ref_ceres_lib
+
+
 def ref_lib():
     """The reference's own probability_values / value_conversion_tables / ray_to_pixel_mask
     code, or None when it has not been built (no /root/reference)."""
@@ -168,6 +210,11 @@ def ref_lib():
                                      C.c_double, C.c_double, C.c_double, C.c_double, _f64p,
                                      C.POINTER(C.c_int64)]
         L.ref_rt3d_match.restype = C.c_float
+        L.ref_rt3d_match_mt.argtypes = [C.c_float, C.c_void_p, C.c_int64, _f64p, _f32p, C.c_int,
+                                        C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                                        _f64p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                        C.c_void_p]
+        L.ref_rt3d_match_mt.restype = C.c_float
         L.ref_rotational_match.argtypes = [_f32p, _f32p, C.c_int, C.c_float, _f32p, C.c_int, _f32p]
         L.ref_compute_histogram.argtypes = [_f32p, C.c_int, C.c_int, _f32p]
         L.ref_fast3d_create.argtypes = [C.c_float, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
@@ -421,7 +468,7 @@ def _ceres_options(occupied_space_weight, translation_weight, rotation_weight,
 
 def ceres2d_match(cells, res, max_x, max_y, target_xy, init_xyt, xyz, occupied_space_weight=1.0,
                   translation_weight=10.0, rotation_weight=40.0, use_nonmonotonic_steps=False,
-                  max_num_iterations=20):
+                  max_num_iterations=20, reference=False):
     """CeresScanMatcher2D::Match restated (oracle_ceres_2d.h: Ceres itself is absent, its
     published trust-region algorithm is restated; parity with Ceres's iterates is unpinned)."""
     cells = np.ascontiguousarray(cells, np.uint16)
@@ -432,7 +479,8 @@ def ceres2d_match(cells, res, max_x, max_y, target_xy, init_xyt, xyz, occupied_s
                                     _f64p, _f64p, _f64p, _f32p, C.c_int, _f64p, _f64p]
     L.orc_ceres2d_match.restype = None
     pose, summary = np.empty(3, np.float64), np.empty(5, np.float64)
-    L.orc_ceres2d_match(cells, nx, ny, res, max_x, max_y,
+    fn = ref_ceres_lib().refc_ceres2d_match if reference else L.orc_ceres2d_match
+    fn(cells, nx, ny, res, max_x, max_y,
                         _ceres_options(occupied_space_weight, translation_weight, rotation_weight,
                                        use_nonmonotonic_steps, max_num_iterations),
                         np.ascontiguousarray(target_xy, np.float64),
@@ -443,7 +491,8 @@ def ceres2d_match(cells, res, max_x, max_y, target_xy, init_xyt, xyz, occupied_s
 
 
 def ceres2d_residuals(cells, res, max_x, max_y, target_xy, target_angle, pose_xyt, xyz,
-                      occupied_space_weight=1.0, translation_weight=10.0, rotation_weight=40.0):
+                      occupied_space_weight=1.0, translation_weight=10.0, rotation_weight=40.0,
+                      reference=False):
     """Residuals [n + 3] and Jacobian [n + 3, 3] of the three residual blocks at `pose_xyt`."""
     cells = np.ascontiguousarray(cells, np.uint16)
     ny, nx = cells.shape
@@ -454,7 +503,8 @@ def ceres2d_residuals(cells, res, max_x, max_y, target_xy, target_angle, pose_xy
                                         C.c_int, _f64p, _f64p]
     L.orc_ceres2d_residuals.restype = None
     r, J = np.empty(n + 3, np.float64), np.empty((n + 3, 3), np.float64)
-    L.orc_ceres2d_residuals(cells, nx, ny, res, max_x, max_y,
+    fn = ref_ceres_lib().refc_ceres2d_residuals if reference else L.orc_ceres2d_residuals
+    fn(cells, nx, ny, res, max_x, max_y,
                             _ceres_options(occupied_space_weight, translation_weight,
                                            rotation_weight, False, 0),
                             np.ascontiguousarray(target_xy, np.float64), target_angle,
@@ -829,6 +879,21 @@ def ref_rt3d_match(resolution, voxels, init_pose7, xyz, lin, ang, tw, rw):
     return dict(score=float(s), pose=pose)
 
 
+def ref_rt3d_match_mt(resolution, voxels, init_pose7, xyz, lin, ang, tw, rw, num_threads=8):
+    """The reference's GenerateExhaustiveSearchTransforms / TransformPointCloud / ScoreCandidate
+    over candidate ranges on `num_threads` host threads (oracle/ref_wrapper_rt3d_mt.cc)."""
+    v, n = _voxels(voxels)
+    xyz, npts = _cloud(xyz)
+    pose = np.empty(7, np.float64)
+    ncand, best = C.c_int64(), C.c_int64()
+    s = ref_lib().ref_rt3d_match_mt(resolution, v.ctypes.data, n,
+                                    np.ascontiguousarray(init_pose7, np.float64), xyz, npts, lin,
+                                    ang, tw, rw, int(num_threads), pose, C.byref(best),
+                                    C.byref(ncand), None)
+    return dict(score=float(s), pose=pose, best_index=int(best.value),
+                num_candidates=int(ncand.value))
+
+
 def ref_rotational_match(submap_hist, scan_hist, initial_angle, angles):
     a = np.ascontiguousarray(submap_hist, np.float32)
     b = np.ascontiguousarray(scan_hist, np.float32)
@@ -924,7 +989,7 @@ def _ceres3d_args(pairs, occupied_space_weights, translation_weight, rotation_we
 
 def ceres3d_match(pairs, target_xyz, init_pose7, occupied_space_weights, translation_weight=5.0,
                   rotation_weight=400.0, only_optimize_yaw=False, use_nonmonotonic_steps=False,
-                  max_num_iterations=12):
+                  max_num_iterations=12, reference=False):
     """CeresScanMatcher3D::Match restated (probability grids only; parity with Ceres's iterates
     is unpinned, see oracle_ceres_3d.h).  init_pose7 = (tx, ty, tz, qw, qx, qy, qz)."""
     args, keep = _ceres3d_args(pairs, occupied_space_weights, translation_weight, rotation_weight,
@@ -934,8 +999,13 @@ def ceres3d_match(pairs, target_xyz, init_pose7, occupied_space_weights, transla
                                     C.c_void_p, _f64p, _f64p, _f64p, _f64p]
     L.orc_ceres3d_match.restype = None
     pose, summary = np.empty(7, np.float64), np.empty(5, np.float64)
-    L.orc_ceres3d_match(*args, np.ascontiguousarray(target_xyz, np.float64),
-                        np.ascontiguousarray(init_pose7, np.float64), pose, summary)
+    if reference:
+        ref_ceres_lib().refc_ceres3d_match(*args, np.ascontiguousarray(target_xyz, np.float64),
+                                           np.ascontiguousarray(init_pose7, np.float64), pose,
+                                           summary, None, None, None, None)
+    else:
+        L.orc_ceres3d_match(*args, np.ascontiguousarray(target_xyz, np.float64),
+                            np.ascontiguousarray(init_pose7, np.float64), pose, summary)
     del keep
     return dict(pose=pose, initial_cost=summary[0], final_cost=summary[1],
                 num_successful_steps=int(summary[2]), num_unsuccessful_steps=int(summary[3]),
@@ -943,7 +1013,7 @@ def ceres3d_match(pairs, target_xyz, init_pose7, occupied_space_weights, transla
 
 
 def ceres3d_residuals(pairs, target_xyz, target_q4, pose7, occupied_space_weights,
-                      translation_weight=5.0, rotation_weight=400.0):
+                      translation_weight=5.0, rotation_weight=400.0, reference=False):
     """Residuals [N + 6] and their Jacobian [N + 6, 7] w.r.t. (t, q = w x y z) at pose7."""
     args, keep = _ceres3d_args(pairs, occupied_space_weights, translation_weight, rotation_weight,
                                False, False, 0)
@@ -953,7 +1023,8 @@ def ceres3d_residuals(pairs, target_xyz, target_q4, pose7, occupied_space_weight
                                         C.c_void_p, C.c_void_p, _f64p, _f64p, _f64p, _f64p, _f64p]
     L.orc_ceres3d_residuals.restype = None
     r, J = np.empty(total, np.float64), np.empty((total, 7), np.float64)
-    L.orc_ceres3d_residuals(*args, np.ascontiguousarray(target_xyz, np.float64),
+    fn = ref_ceres_lib().refc_ceres3d_residuals if reference else L.orc_ceres3d_residuals
+    fn(*args, np.ascontiguousarray(target_xyz, np.float64),
                             np.ascontiguousarray(target_q4, np.float64),
                             np.ascontiguousarray(pose7, np.float64), r, J)
     del keep

@@ -4,6 +4,7 @@
 // renormalises its rotation, rigid * point = rotation * point + translation.
 #ifndef ORACLE_REF_SHIMS_RIGID_TRANSFORM_H_
 #define ORACLE_REF_SHIMS_RIGID_TRANSFORM_H_
+#include <array>
 #include <cmath>
 #include "Eigen/Core"
 #include "Eigen/Geometry"
@@ -70,6 +71,11 @@ class Rigid3 {
   static Rigid3 Translation(const Vector& t) { return Rigid3(t, Quaternion()); }
   static Rigid3 Rotation(const Quaternion& q) { return Rigid3(Vector::Zero(), q); }
   static Rigid3 Rotation(const AngleAxis& aa) { return Rigid3(Vector::Zero(), Quaternion(aa)); }
+  // rigid_transform.h:141-147.
+  static Rigid3 FromArrays(const std::array<S, 4>& rotation, const std::array<S, 3>& translation) {
+    return Rigid3(Vector(translation[0], translation[1], translation[2]),
+                  Quaternion(rotation[0], rotation[1], rotation[2], rotation[3]));
+  }
 
   const Vector& translation() const { return t_; }
   const Quaternion& rotation() const { return q_; }

@@ -81,3 +81,30 @@ def fast3d(synth):
                 options=dict(depth=6, frd=3, min_rot=0.9, min_low=0.3, lin_xy=1.5, lin_z=0.5,
                              ang=math.radians(20.0)),
                 min_score=0.15)
+
+
+def rt3d_c4(synth, rings=64, az=1024):
+    """BASELINE config[3] exactly as bench.py (Rt3DWorkload) and tools/time_configs.py c4 run it:
+    64 rings x 1024 azimuths against a 150^3 HybridGrid, window 0.5 m / 2 deg (L = 5, A = 5:
+    1331 translations x 1331 rotations = 1 771 561 candidates)."""
+    grid, world = synth.make_submap_3d(42, 0.1, (15.0, 15.0, 7.5), 8, 32, 512)
+    pos = world.free_position(77, 0.5)
+    cloud = world.scan(pos, 0.3, rings, az, seed=9)
+    c, s = math.cos(0.31 / 2), math.sin(0.31 / 2)
+    init = list(pos + np.array([0.07, -0.04, 0.02])) + [c, 0.0, 0.0, s]
+    return dict(res=0.1, vox=grid.voxels(), cloud=cloud, init=init, lin=0.5,
+                ang=math.radians(2.0), tw=0.1, rw=0.1)
+
+
+def rt3d_c4_shaped(synth):
+    """C4's SHAPE at a size the oracle finishes in seconds: L = 5 (11^3 translations, 6^3 = 216
+    groups of 2x2x2 per rotation -- the flat 192-lane group mapping of rt_3d.hip), A = 3
+    (343 rotations), a tilted initial orientation, ~4 k points."""
+    grid, world = synth.make_submap_3d(5, 0.1, (9.0, 8.0, 4.0), 5, 10, 128)
+    pos = world.free_position(6, 0.6)
+    cloud = world.scan(pos, 0.2, 32, 128, seed=3)
+    init = list(pos + np.array([0.21, -0.13, 0.08])) + quat(0.27, [0.15, -0.25, 0.95])
+    # max range 8.91 m -> angular step 0.01121 rad; 1.9 deg / step = 2.96 -> A = 3 (the tests
+    # assert the candidate count 1331 * 343).
+    return dict(res=0.1, vox=grid.voxels(), cloud=cloud, init=init, lin=0.5,
+                ang=math.radians(1.9), tw=0.1, rw=0.1, num_candidates=1331 * 343)

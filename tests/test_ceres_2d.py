@@ -21,8 +21,8 @@ def _reference_test_grid(synth):
 @pytest.mark.parametrize("init", [(-0.5, 0.5), (-0.3, 0.5), (-0.45, 0.3), (-0.3, 0.3)])
 def test_reference_ceres_scan_matcher_test(oracle, synth, init):
     """testPerfectEstimate / testOptimizeAlongX / AlongY / AlongXY
-    (ceres_scan_matcher_2d_test.cc:97-111): pose within 1e-2 of (-0.5, 0.5, 0), final cost
-    within 1e-2 of 0; options of the fixture (:49-59)."""
+    (ceres_scan_matcher_2d_test.cc:97-111): IsNearly((-0.5, 0.5, 0), 1e-2), final cost within
+    1e-2 of 0; options of the fixture (:49-59).  One tolerance for all four cases."""
     g = _reference_test_grid(synth)
     lim = g.limits
     cloud = np.array([[-3.0, 2.0, 0.0]], np.float32)
@@ -31,14 +31,21 @@ def test_reference_ceres_scan_matcher_test(oracle, synth, init):
                                rotation_weight=1.5, use_nonmonotonic_steps=True,
                                max_num_iterations=50)
     assert abs(out["final_cost"]) < 1e-2
-    # The reference's tolerance is 1e-2.  The problem is ill-conditioned for Gauss-Newton (the
-    # residual is 0.1, not 0, at the optimum, where the Jacobian vanishes): after 50 iterations
-    # the iterate sits 0.5 .. 1.4 cm from the expected pose depending on rounding-level details
-    # of the solver (perturbing the start by 1e-7 moves it by a millimetre).  Three of the four
-    # cases are inside the reference's 1e-2; testOptimizeAlongY lands at 1.35e-2 with this
-    # restatement of Ceres -- recorded as is (parity with Ceres's iterates is unpinned).
-    np.testing.assert_allclose(out["pose"], [-0.5, 0.5, 0.0],
-                               atol=1e-2 if init != (-0.45, 0.3) else 1.5e-2)
+    # transform::IsNearly(expected_pose, 1e-2) (rigid_transform_test_helpers.h:32-46) is Eigen's
+    # isApprox on the homogeneous 3 x 3 transforms: |a - b|_F <= 1e-2 * min(|a|_F, |b|_F) -- a
+    # relative Frobenius bound (0.0187 here), not 1e-2 per component.  (Round 2 read it as the
+    # latter and loosened one case; the minimum of this objective itself lies 1.2e-2 from the
+    # expected pose in y for testOptimizeAlongY -- the rotation residual is cheaper than the
+    # translation residual at the margin -- so no solver could meet a per-component 1e-2 there.)
+    assert _is_nearly(out["pose"], (-0.5, 0.5, 0.0), 1e-2), out
+
+
+def _is_nearly(pose, expected, epsilon):
+    def m(p):
+        c, s = math.cos(p[2]), math.sin(p[2])
+        return np.array([[c, -s, p[0]], [s, c, p[1]], [0, 0, 1.0]])
+    a, b = m(pose), m(expected)
+    return np.linalg.norm(a - b) <= epsilon * min(np.linalg.norm(a), np.linalg.norm(b))
 
 
 def test_jacobian_matches_finite_differences(oracle, synth):
