@@ -137,3 +137,39 @@ class Communicator:
             C.byref(best_score), C.byref(stats)))
         return (found, scores, [sm.Rigid2d(p.x, p.y, p.theta) for p in poses],
                 (best_index.value, best_score.value), stats.as_dict())
+
+    def match_batch_3d(self, matchers, node_poses, submap_poses, match_full_submap, min_scores,
+                       constant_data):
+        """cmx_fast3d_match_sharded: ConstraintBuilder3D's fan-out for one node
+        (constraint_builder_3d.cc:79-147) with the matchers spread over the communicator's
+        devices (BASELINE config C5: 256 submaps on 8 GPUs).  Returns (list of result dicts or
+        None per pair, best (index or -1, score), stats)."""
+        import ctypes as C
+        from . import _lib, scan_matching_3d as sm3
+        num = len(matchers)
+        handles = (C.c_void_p * num)(*[m._h for m in matchers])
+        nodes = (_lib.Pose3d * num)(*[p.to_c() for p in node_poses])
+        submaps = (_lib.Pose3d * num)(*[p.to_c() for p in submap_poses])
+        full = np.ascontiguousarray([1 if f else 0 for f in match_full_submap], np.int32)
+        thresholds = np.ascontiguousarray(min_scores, np.float32)
+        assert full.shape[0] == num and thresholds.shape[0] == num
+        data = constant_data.to_c()
+        found = np.zeros(num, np.int32)
+        results = (_lib.Result3D * num)()
+        best_index, best_score, stats = C.c_int32(), C.c_float(), _lib.MatchStats()
+        _lib.check(_lib.lib().cmx_fast3d_match_sharded(
+            self._h, C.cast(handles, C.c_void_p), num, C.cast(nodes, C.c_void_p),
+            C.cast(submaps, C.c_void_p), full.ctypes.data, thresholds.ctypes.data, C.byref(data),
+            found.ctypes.data, C.cast(results, C.c_void_p), C.byref(best_index),
+            C.byref(best_score), C.byref(stats)))
+        out = []
+        for p in range(num):
+            if not found[p]:
+                out.append(None)
+                continue
+            r = results[p]
+            out.append(dict(score=float(r.score),
+                            pose_estimate=sm3.Rigid3d.from_c(r.pose_estimate),
+                            rotational_score=float(r.rotational_score),
+                            low_resolution_score=float(r.low_resolution_score)))
+        return out, (best_index.value, best_score.value), stats.as_dict()

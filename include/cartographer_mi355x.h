@@ -412,8 +412,10 @@ cmx_status cmx_fast3d_match_full_submap(const cmx_fast3d* matcher,
 /* ConstraintBuilder3D's fan-out for one node (constraints/constraint_builder_3d.cc:79-147):
  * `data` against num_pairs matchers, pair p a windowed Match around node_poses[p] /
  * submap_poses[p] or, where match_full_submap[p] != 0, a MatchFullSubmap with their rotations,
- * against its own threshold min_scores[p].  The pairs are searched concurrently on separate
- * streams; found[p] / results[p] as in the single calls; *stats summed. */
+ * against its own threshold min_scores[p].  All pairs whose matchers live on one device are ONE
+ * chain of launches on that device (every kernel takes the array of problems; frontier and
+ * leaf lists are shared, bounds and seeds are per problem); found[p] / results[p] as in the
+ * single calls; *stats summed. */
 cmx_status cmx_fast3d_match_batch(const cmx_fast3d* const* matchers, int32_t num_pairs,
                                   const cmx_pose3d* node_poses, const cmx_pose3d* submap_poses,
                                   const int32_t* match_full_submap, const float* min_scores,

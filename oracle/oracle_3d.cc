@@ -1,6 +1,9 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_common.h).
 #include "oracle_3d.h"
 
+#include <atomic>
+#include <thread>
+
 #include <algorithm>
 #include <cassert>
 #include <cmath>
@@ -74,7 +77,8 @@ HybridGridView::HybridGridView(float resolution, const Voxel* voxels, int64_t n)
 // ------------------------------------------------------------ real-time 3D ---
 float RealTimeMatch3D(const HybridGridView& grid, const Pose3d& initial, const PointCloud3& cloud,
                       const double linear_window, const double angular_window, const double tw,
-                      const double rw, Pose3d* pose_estimate, int64_t* num_candidates) {
+                      const double rw, Pose3d* pose_estimate, int64_t* num_candidates,
+                      const int num_threads) {
   const float resolution = grid.resolution();
   // GenerateExhaustiveSearchTransforms (:55-95).
   const int linear_window_size = RoundToInt(linear_window / resolution);
@@ -86,9 +90,14 @@ float RealTimeMatch3D(const HybridGridView& grid, const Pose3d& initial, const P
                                           (2.f * (max_scan_range * (max_scan_range * 1.f))));
   const int angular_window_size = RoundToInt(angular_window / angular_step_size);
   const Rigid3f init = CastPose(initial);
-  float best_score = -1.f;
-  int64_t count = 0;
-  for (int z = -linear_window_size; z <= linear_window_size; ++z)
+  // The reference's loop is sequential (z outermost); slices of z are independent, so they may
+  // run on several threads and are joined in z order with the loop's own rule (strict '>': the
+  // first maximum wins).  num_threads = 1 is the loop as written.
+  struct SliceBest { float score = -1.f; Pose3d pose; int64_t count = 0; };
+  const int num_slices = 2 * linear_window_size + 1;
+  std::vector<SliceBest> slices(num_slices);
+  auto run_slice = [&](int z) {
+    SliceBest& out = slices[z + linear_window_size];
     for (int y = -linear_window_size; y <= linear_window_size; ++y)
       for (int x = -linear_window_size; x <= linear_window_size; ++x)
         for (int rz = -angular_window_size; rz <= angular_window_size; ++rz)
@@ -108,12 +117,33 @@ float RealTimeMatch3D(const HybridGridView& grid, const Pose3d& initial, const P
               const float angle = GetAngle(transform);
               const double t = Norm3(transform.t) * tw + angle * rw;
               score *= std::exp(-(t * (t * 1.)));
-              ++count;
-              if (score > best_score) {
-                best_score = score;
-                *pose_estimate = CastPose(candidate);
+              ++out.count;
+              if (score > out.score) {
+                out.score = score;
+                out.pose = CastPose(candidate);
               }
             }
+  };
+  if (num_threads <= 1) {
+    for (int z = -linear_window_size; z <= linear_window_size; ++z) run_slice(z);
+  } else {
+    std::atomic<int> next{-linear_window_size};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < num_threads; ++t)
+      pool.emplace_back([&] {
+        for (int z = next.fetch_add(1); z <= linear_window_size; z = next.fetch_add(1)) run_slice(z);
+      });
+    for (std::thread& th : pool) th.join();
+  }
+  float best_score = -1.f;
+  int64_t count = 0;
+  for (const SliceBest& sl : slices) {
+    count += sl.count;
+    if (sl.score > best_score) {
+      best_score = sl.score;
+      *pose_estimate = sl.pose;
+    }
+  }
   if (num_candidates) *num_candidates = count;
   return best_score;
 }

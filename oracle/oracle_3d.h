@@ -136,7 +136,7 @@ typedef std::vector<V3f> PointCloud3;
 // real_time_correlative_scan_matcher_3d.cc:34-114.
 float RealTimeMatch3D(const HybridGridView& grid, const Pose3d& initial, const PointCloud3& cloud,
                       double linear_window, double angular_window, double tw, double rw,
-                      Pose3d* pose_estimate, int64_t* num_candidates);
+                      Pose3d* pose_estimate, int64_t* num_candidates, int num_threads = 1);
 
 // precomputation_grid_3d.{h,cc}.
 typedef Brick<uint8_t> PrecomputationGrid3D;

@@ -315,6 +315,19 @@ float orc_rt3d_match(float resolution, const Voxel* voxels, int64_t n, const dou
   return s;
 }
 
+// As orc_rt3d_match with the z slices of the window spread over host threads (joined in z order
+// with the loop's first-maximum rule: the same result).
+float orc_rt3d_match_mt(float resolution, const Voxel* voxels, int64_t n, const double* init7,
+                        const float* xyz, int npts, double lin, double ang, double tw, double rw,
+                        int num_threads, double* pose7, int64_t* num_candidates) {
+  const HybridGridView grid(resolution, voxels, n);
+  Pose3d pose = MakePose3(init7);
+  const float s = RealTimeMatch3D(grid, MakePose3(init7), MakeCloud3(xyz, npts), lin, ang, tw,
+                                  rw, &pose, num_candidates, num_threads);
+  StorePose3(pose, pose7);
+  return s;
+}
+
 void orc_rotational_match(const float* submap_hist, const float* scan_hist, int size,
                           float initial_angle, const float* angles, int n, float* out) {
   const std::vector<float> r =

@@ -643,6 +643,10 @@ def _lib3d():
                                      C.c_double, C.c_double, C.c_double, C.c_double, _f64p,
                                      C.POINTER(C.c_int64)]
         L.orc_rt3d_match.restype = C.c_float
+        L.orc_rt3d_match_mt.argtypes = [C.c_float, C.c_void_p, C.c_int64, _f64p, _f32p, C.c_int,
+                                        C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                                        _f64p, C.POINTER(C.c_int64)]
+        L.orc_rt3d_match_mt.restype = C.c_float
         L.orc_rotational_match.argtypes = [_f32p, _f32p, C.c_int, C.c_float, _f32p, C.c_int, _f32p]
         L.orc_fast3d_create.argtypes = [C.c_float, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
                                         C.c_int64, _f32p, C.c_int, C.c_int, C.c_int, C.c_double,
@@ -668,12 +672,18 @@ def grid3d_size(resolution, voxels):
     return int(_lib3d().orc_grid3d_size(resolution, v.ctypes.data, n))
 
 
-def rt3d_match(resolution, voxels, init_pose7, xyz, lin, ang, tw, rw):
-    """init_pose7 = (tx,ty,tz, qw,qx,qy,qz)."""
+def rt3d_match(resolution, voxels, init_pose7, xyz, lin, ang, tw, rw, num_threads=1):
+    """init_pose7 = (tx,ty,tz, qw,qx,qy,qz).  num_threads > 1 spreads the z slices of the window
+    over host threads (same result: joined in z order with the first-maximum rule)."""
     v, n = _voxels(voxels)
     xyz, npts = _cloud(xyz)
     pose = np.empty(7, np.float64)
     ncand = C.c_int64()
+    if num_threads > 1:
+        s = _lib3d().orc_rt3d_match_mt(resolution, v.ctypes.data, n,
+                                       np.ascontiguousarray(init_pose7, np.float64), xyz, npts,
+                                       lin, ang, tw, rw, int(num_threads), pose, C.byref(ncand))
+        return dict(score=float(s), pose=pose, num_candidates=ncand.value)
     s = _lib3d().orc_rt3d_match(resolution, v.ctypes.data, n,
                                 np.ascontiguousarray(init_pose7, np.float64), xyz, npts, lin, ang,
                                 tw, rw, pose, C.byref(ncand))

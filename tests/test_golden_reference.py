@@ -101,3 +101,35 @@ def test_oracle_reproduces_the_golden_results(oracle, synth, golden):
     for key in ("score", "rotational_score", "low_resolution_score"):
         assert np.float32(r[key]) == np.float32(g[key]), key
     np.testing.assert_array_equal(r["pose"], g["pose"])
+
+
+def test_oracle_reproduces_the_c4_shaped_reference_result(oracle, synth):
+    """tests/golden/rt3d_c4_reference.json (make_rt3d_c4_golden.py: the reference's own
+    real_time_correlative_scan_matcher_3d.cc): the C4-SHAPED workload -- L = 5 (216 groups of
+    2x2x2 translations per rotation), A = 3, tilted initial orientation, 4096 points, 456 533
+    candidates -- reproduced bit for bit by the oracle (z slices on the host's threads).  The
+    full C4 entry (1 771 561 candidates x 65 536 points, ten minutes of the reference on 8 cores)
+    is only checked for presence here; the device is compared with both (-m gpu)."""
+    import workloads as w
+    with open(os.path.join(GOLDEN, "rt3d_c4_reference.json")) as f:
+        g = json.load(f)
+    assert g["rt3d_c4"]["num_candidates"] == 1331 * 1331 and g["rt3d_c4"]["num_points"] == 65536
+    d = w.rt3d_c4_shaped(synth)
+    r = oracle.rt3d_match(d["res"], d["vox"], d["init"], d["cloud"], d["lin"], d["ang"], d["tw"],
+                          d["rw"], num_threads=max(2, os.cpu_count() or 2))
+    s = g["rt3d_c4_shaped"]
+    assert r["num_candidates"] == s["num_candidates"] == d["num_candidates"]
+    assert np.float32(r["score"]) == np.float32(s["score"])
+    np.testing.assert_array_equal(r["pose"], s["pose"])
+
+
+def test_c4_golden_workload_is_the_one_bench_times(synth):
+    """The C4 golden is only worth something if bench.py's Rt3DWorkload is that workload."""
+    import bench
+    import workloads as w
+    wl = bench.Rt3DWorkload(None, 0)
+    d = w.rt3d_c4(synth)
+    assert np.array_equal(wl.cloud, d["cloud"]) and np.array_equal(wl.vox, d["vox"])
+    assert list(wl.init.translation) + list(wl.init.rotation) == list(d["init"])
+    assert (wl.m.options.linear_search_window, wl.m.options.angular_search_window) == \
+        (d["lin"], d["ang"])

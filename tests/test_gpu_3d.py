@@ -693,3 +693,52 @@ def test_fast3d_device_batch_of_twenty_pairs(sm3, synth, monkeypatch, affinity):
                                         data)
     _assert_same_results(expected, got)
     assert stats["expansion_launches"] >= 1 and stats["expansion_nodes"] > 0
+
+
+# ----------------------------------------------------------------------------
+# cmx_fast3d_match_sharded: the C5 fan-out over a communicator (north star: 256 submaps / 8 GPUs)
+# ----------------------------------------------------------------------------
+def test_fast3d_sharded_match_equals_the_batch(sm3, synth):
+    """cmx_fast3d_match_sharded over a communicator of every visible device (one on the test
+    box): pair by pair what cmx_fast3d_match_batch returns -- windowed and full-submap pairs
+    mixed, thresholds that reject some pairs -- and the RCCL all-reduce(max) of the packed key
+    returns the best found pair, the LOWEST index among equal scores (matchers 0, 3, 6 and 9
+    are built from the same submap and see the same node: ties)."""
+    import torch
+    from cartographer_amd import sharding
+    ndev = torch.cuda.device_count()
+    comm = sharding.Communicator(list(range(ndev)))
+    depths = [5, 4, 6] * 4                      # seeds 70 + k % 3: k = 0, 3, 6, 9 identical
+    matchers, pos, data = _fast3d_batch_scene(sm3, synth, depths)
+    if ndev > 1:                                # place every matcher on the device that owns it
+        pytest.skip("multi-device placement is exercised by the driver's scaling run")
+    ident = sm3.Rigid3d()
+    rng = np.random.default_rng(3)
+    node0 = sm3.Rigid3d(tuple(pos + np.array([0.2, -0.1, 0.05])),
+                        tuple(quat_from_angle_axis(0.04, [0, 0, 1])))
+    nodes, fulls, thresholds = [], [], []
+    for k in range(len(depths)):
+        if k % 3 == 0:
+            nodes.append(node0)
+            fulls.append(False)
+            thresholds.append(0.12)
+        else:
+            d = rng.uniform(-0.3, 0.3, 3) * np.array([1.0, 1.0, 0.3])
+            nodes.append(sm3.Rigid3d(tuple(pos + d), tuple(quat_from_angle_axis(
+                rng.uniform(-0.1, 0.1), [0, 0, 1]))))
+            fulls.append(k % 5 == 2)
+            thresholds.append(0.99 if k % 4 == 1 else 0.12)
+    expected, stats1 = sm3.fast3d_match_batch(matchers, nodes, [ident] * len(depths), fulls,
+                                              thresholds, data)
+    got, best, stats = comm.match_batch_3d(matchers, nodes, [ident] * len(depths), fulls,
+                                           thresholds, data)
+    _assert_same_results(expected, got)
+    assert any(g is None for g in got) and sum(g is not None for g in got) >= 4
+    assert stats["candidates_scored"] == stats1["candidates_scored"]
+    scores = np.array([-1.0 if g is None else np.float32(g["score"]) for g in got], np.float32)
+    assert got[0] is not None and scores[0] == scores[3] == scores[6] == scores[9]
+    assert best[0] == int(np.argmax(scores)) and np.float32(best[1]) == scores.max()
+    # nothing found anywhere: the sentinel
+    none, best_none, _ = comm.match_batch_3d(matchers[:3], nodes[:3], [ident] * 3, [False] * 3,
+                                             [0.999] * 3, data)
+    assert all(g is None for g in none) and best_none[0] == -1

@@ -469,3 +469,48 @@ def test_fast3d_batch_equals_individual(synth):
             for key in ("score", "rotational_score", "low_resolution_score"):
                 assert np.float32(e[key]) == np.float32(g[key]), key
             assert e["pose_estimate"] == g["pose_estimate"]
+
+
+# ---- BASELINE config C4 at its own window, against the reference's own source -----------------
+@pytest.fixture(scope="module")
+def golden_c4():
+    with open(os.path.join(GOLDEN, "rt3d_c4_reference.json")) as f:
+        return json.load(f)
+
+
+def _rt3d_against_golden(synth, d, g, monkeypatch, bulk):
+    from cartographer_amd import scan_matching_3d as sm3
+    monkeypatch.setenv("CMX_RT3D_VERIFY", "1")     # group bounds checked against member bounds
+    monkeypatch.setenv("CMX_RT3D_BULK", bulk)
+    m = sm3.RealTimeCorrelativeScanMatcher3D(d["lin"], d["ang"], d["tw"], d["rw"])
+    score, pose = m.match(sm3.Rigid3d(tuple(d["init"][:3]), tuple(d["init"][3:])), d["cloud"],
+                          d["res"], d["vox"])
+    assert m.last_stats["candidates_scored"] == g["num_candidates"]
+    assert np.float32(score) == np.float32(g["score"]), (score, g["score"])
+    np.testing.assert_array_equal(list(pose.translation) + list(pose.rotation), g["pose"])
+    return m.last_stats
+
+
+@pytest.mark.parametrize("bulk", ["1", "0"])
+def test_rt3d_c4_shaped_equals_the_reference(synth, golden_c4, monkeypatch, bulk):
+    """C4's shape at 4096 points: L = 5 -> 6^3 = 216 groups of 2x2x2 translations per rotation
+    (the flat 192-lane group mapping of rt_3d.hip spans rotations), A = 3 -> 343 rotations, a
+    tilted initial orientation.  Bounds path and exhaustive path, f32 score bit-equal and pose
+    equal to what RealTimeCorrelativeScanMatcher3D::Match itself returned
+    (tests/golden/rt3d_c4_reference.json)."""
+    import workloads as w
+    st = _rt3d_against_golden(synth, w.rt3d_c4_shaped(synth), golden_c4["rt3d_c4_shaped"],
+                              monkeypatch, bulk)
+    if bulk == "1":
+        assert st["coarse_candidates"] < st["candidates_scored"]      # bounds did exclude
+
+
+@pytest.mark.parametrize("bulk", ["1", "0"])
+def test_rt3d_c4_at_its_baseline_window_equals_the_reference(synth, golden_c4, monkeypatch, bulk):
+    """BASELINE config[3] exactly as bench.py times it (65 536 points, 150^3 grid, +-0.5 m /
+    +-2 deg: 1 771 561 candidates) against the reference's own
+    real_time_correlative_scan_matcher_3d.cc run over that search space (ten minutes on 8 host
+    cores, tests/golden/make_rt3d_c4_golden.py): score bit-equal, pose equal, with the bounds
+    (CMX_RT3D_BULK=1, CMX_RT3D_VERIFY=1) and with every candidate scored exhaustively."""
+    import workloads as w
+    _rt3d_against_golden(synth, w.rt3d_c4(synth), golden_c4["rt3d_c4"], monkeypatch, bulk)
