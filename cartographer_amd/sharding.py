@@ -107,8 +107,11 @@ class Communicator:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            from . import _lib
-            _lib.lib().cmx_comm_destroy(self._h)
+            try:
+                from . import _lib
+                _lib.lib().cmx_comm_destroy(self._h)
+            except ImportError:      # interpreter shutting down: the process frees everything
+                pass
             self._h = None
 
     def device_of(self, index, num_items):

@@ -734,7 +734,10 @@ def test_fast3d_sharded_match_equals_the_batch(sm3, synth):
                                            thresholds, data)
     _assert_same_results(expected, got)
     assert any(g is None for g in got) and sum(g is not None for g in got) >= 4
-    assert stats["candidates_scored"] == stats1["candidates_scored"]
+    # (the number of nodes a branch-and-bound search expands depends on when the bound rises:
+    # candidates_scored differs by a few hundred of 7.6 M between two runs of the same batch)
+    assert abs(stats["candidates_scored"] - stats1["candidates_scored"]) < \
+        0.01 * stats1["candidates_scored"]
     scores = np.array([-1.0 if g is None else np.float32(g["score"]) for g in got], np.float32)
     assert got[0] is not None and scores[0] == scores[3] == scores[6] == scores[9]
     assert best[0] == int(np.argmax(scores)) and np.float32(best[1]) == scores.max()
