@@ -120,7 +120,7 @@ EXPORTED_SYMBOLS = [
     "cmx_rt2d_match", "cmx_rt2d_match_tsdf", "cmx_grid2d_create", "cmx_grid2d_destroy",
     "cmx_grid2d_get_limits", "cmx_grid2d_download", "cmx_grid2d_crop", "cmx_grid2d_insert",
     "cmx_rt2d_match_grid",
-    "cmx_rt2d_match_grid_batch",
+    "cmx_rt2d_match_grid_batch", "cmx_rt2d_match_grid_batch_resident",
     "cmx_grid3d_create", "cmx_grid3d_destroy", "cmx_grid3d_insert", "cmx_grid3d_info",
     "cmx_grid3d_download",
     "cmx_fast2d_create", "cmx_fast2d_create_from_grid", "cmx_fast2d_destroy", "cmx_fast2d_match",
@@ -188,6 +188,9 @@ def lib():
     L.cmx_rt2d_match_grid_batch.argtypes = [P(RtOptions), P(C.c_void_p), C.c_int32, C.c_void_p,
                                             P(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,
                                             P(MatchStats)]
+    L.cmx_rt2d_match_grid_batch_resident.argtypes = [P(RtOptions), P(C.c_void_p), C.c_int32,
+                                                     C.c_void_p, P(C.c_void_p), C.c_void_p,
+                                                     C.c_void_p, P(MatchStats)]
     L.cmx_fast2d_create_from_grid.argtypes = [P(Fast2DOptions), C.c_void_p, P(C.c_void_p)]
     L.cmx_fast2d_create.argtypes = [P(Fast2DOptions), P(Grid2DLimits), C.c_void_p, C.c_int32,
                                     P(C.c_void_p)]

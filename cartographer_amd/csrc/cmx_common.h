@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -63,6 +64,15 @@ cmx_status Guard(F&& body) {
 
 // Validates `device` (fails loudly without a GPU) and makes it current.
 void UseDevice(int device);
+
+// Host-side parallel loop for the per-item planning of a batch call (range scans, libm rotation
+// tables, staging copies: ~2 us per item, serial host time that used to exceed the device time
+// of a 128-match batch several times over).  fn(i) runs for i in [0, n) on the calling thread
+// and on a small pool of persistent workers (CMX_HOST_THREADS, default min(16, cores / 2));
+// workers spin for ~200 us after a job before they sleep, so back-to-back calls pay no wake-up.
+// n below `serial_below` runs inline.  fn must not throw across threads: the first exception
+// is captured and rethrown on the caller.  Nested calls run inline.
+void ParallelFor(int n, int serial_below, const std::function<void(int)>& fn);
 
 // Grow-only device buffer.
 class DeviceBuffer {

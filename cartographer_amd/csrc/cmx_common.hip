@@ -2,6 +2,12 @@
 // points that are not tied to one matcher.
 #include "cmx_common.h"
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <exception>
+#include <thread>
+
 #include <execinfo.h>
 #include <signal.h>
 #include <unistd.h>
@@ -49,6 +55,120 @@ Pool& ThePool() {
   return *pool;
 }
 }  // namespace
+
+// ---------------------------------------------------------------------------
+// ParallelFor: persistent host workers
+// ---------------------------------------------------------------------------
+namespace {
+class HostPool {
+ public:
+  static HostPool& Get() {
+    static HostPool* pool = new HostPool();     // leaked on purpose: workers outlive static dtors
+    return *pool;
+  }
+  int workers() const { return num_workers_; }
+
+  void Run(int n, const std::function<void(int)>& fn) {
+    std::lock_guard<std::mutex> one_job(job_mutex_);         // one job at a time
+    Job job{&fn, n};
+    job_.store(&job, std::memory_order_seq_cst);
+    generation_.fetch_add(1, std::memory_order_seq_cst);
+    {
+      std::lock_guard<std::mutex> lk(sleep_mutex_);
+      if (sleepers_ > 0) sleep_cv_.notify_all();
+    }
+    Work(&job);
+    while (job.done.load(std::memory_order_acquire) < n) __builtin_ia32_pause();
+    // `job` lives on this stack: no worker may still hold it when we return.  A worker
+    // announces itself (active_) BEFORE it reads job_, so either it reads null below or we
+    // see it here (sequentially consistent on both sides).
+    job_.store(nullptr, std::memory_order_seq_cst);
+    while (active_.load(std::memory_order_seq_cst) != 0) __builtin_ia32_pause();
+    if (job.error) std::rethrow_exception(job.error);
+  }
+
+  static thread_local bool tls_inside_;
+
+ private:
+  struct Job {
+    const std::function<void(int)>* fn;
+    int n;
+    std::atomic<int> next{0}, done{0};
+    std::mutex error_mutex;
+    std::exception_ptr error;
+    Job(const std::function<void(int)>* f, int count) : fn(f), n(count) {}
+  };
+  HostPool() {
+    int want = 0;
+    if (const char* e = getenv("CMX_HOST_THREADS")) want = atoi(e);
+    if (want <= 0) want = std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 2));
+    num_workers_ = want - 1;
+    for (int t = 0; t < num_workers_; ++t) std::thread([this] { WorkerLoop(); }).detach();
+  }
+  static void Work(Job* job) {
+    for (;;) {
+      const int i = job->next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= job->n) break;
+      try {
+        (*job->fn)(i);
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(job->error_mutex);
+        if (!job->error) job->error = std::current_exception();
+      }
+      job->done.fetch_add(1, std::memory_order_release);
+    }
+  }
+  void WorkerLoop() {
+    tls_inside_ = true;
+    unsigned long long seen = 0;
+    for (;;) {
+      // spin for a while, then sleep until the next job
+      const auto t0 = std::chrono::steady_clock::now();
+      bool have = false;
+      for (int spins = 0;; ++spins) {
+        if (generation_.load(std::memory_order_acquire) != seen) { have = true; break; }
+        __builtin_ia32_pause();
+        if ((spins & 1023) == 1023 &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200))
+          break;
+      }
+      if (!have) {
+        std::unique_lock<std::mutex> lk(sleep_mutex_);
+        ++sleepers_;
+        sleep_cv_.wait(lk, [&] { return generation_.load(std::memory_order_acquire) != seen; });
+        --sleepers_;
+      }
+      seen = generation_.load(std::memory_order_acquire);
+      active_.fetch_add(1, std::memory_order_seq_cst);
+      if (Job* job = job_.load(std::memory_order_seq_cst)) Work(job);
+      active_.fetch_sub(1, std::memory_order_seq_cst);
+    }
+  }
+
+  int num_workers_ = 0;
+  std::mutex job_mutex_, sleep_mutex_;
+  std::condition_variable sleep_cv_;
+  int sleepers_ = 0;
+  std::atomic<unsigned long long> generation_{0};
+  std::atomic<Job*> job_{nullptr};
+  std::atomic<int> active_{0};
+};
+thread_local bool HostPool::tls_inside_ = false;
+}  // namespace
+
+void ParallelFor(int n, int serial_below, const std::function<void(int)>& fn) {
+  if (n <= 0) return;
+  if (n < serial_below || HostPool::tls_inside_) {
+    for (int i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  HostPool& pool = HostPool::Get();
+  if (pool.workers() == 0) {
+    for (int i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  pool.Run(n, fn);
+}
 
 void SetLastError(const char* fmt, ...) {
   char buf[1024];

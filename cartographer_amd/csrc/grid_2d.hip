@@ -31,6 +31,8 @@ struct cmx_grid2d {
   int nx = 0, ny = 0;
   uint16_t* cells = nullptr;                             // device, nx * ny
   std::map<uint32_t, uint16_t*> tables;                  // odds tables by float bits, device
+  unsigned long long version = 1;                        // bumped whenever the cells change
+  mutable cmx::Rt2DImageCache rt_image;                  // the real-time matcher's staged image
 };
 
 namespace cmx {
@@ -227,6 +229,7 @@ void GrowLimits(cmx_grid2d* g, Workspace& ws, float px, float py) {
     CMX_HIP(hipStreamSynchronize(ws.stream));
     CMX_HIP(hipFree(g->cells));
     g->cells = grown;
+    ++g->version;
     g->max_x += g->resolution * y_offset;
     g->max_y += g->resolution * x_offset;
     g->nx *= 2;
@@ -343,6 +346,7 @@ extern "C" cmx_status cmx_grid2d_crop(cmx_grid2d* grid) {
     }
     CMX_HIP(hipFree(grid->cells));
     grid->cells = cropped;
+    ++grid->version;
     // max = limits().max() - resolution * (offset.y, offset.x) (probability_grid.cc:95-96).
     grid->max_x = grid->max_x - grid->resolution * off_y;
     grid->max_y = grid->max_y - grid->resolution * off_x;
@@ -375,6 +379,7 @@ extern "C" cmx_status cmx_grid2d_insert(cmx_grid2d* grid, const float* origin_xy
     GrowLimits(grid, *ws, lo_x - kPadding * 1.f, lo_y - kPadding * 1.f);
     GrowLimits(grid, *ws, hi_x + kPadding * 1.f, hi_y + kPadding * 1.f);
 
+    ++grid->version;                                     // the cells change below
     const uint16_t* hit_table = DeviceTable(grid, hit_probability);
     const uint16_t* miss_table = DeviceTable(grid, miss_probability);
     const int num_points = num_returns + num_misses;
@@ -439,9 +444,18 @@ extern "C" cmx_status cmx_rt2d_match_grid(const cmx_rt_options* options, const c
     limits.num_y_cells = grid->ny;
     limits.min_correspondence_cost = 0.f;
     limits.max_correspondence_cost = 0.f;
-    cmx::Rt2DMatch(options, &limits, nullptr, nullptr, 0.f, 0.f, initial_pose_estimate,
-                   point_cloud_xyz, num_points, grid->device, score, pose_estimate, stats,
-                   grid->cells);
+    cmx::Rt2DItem item{};
+    item.limits = &limits;
+    item.device_cells = grid->cells;
+    item.initial = initial_pose_estimate;
+    item.xyz = point_cloud_xyz;
+    item.n = num_points;
+    item.score = score;
+    item.pose = pose_estimate;
+    item.image_cache = &grid->rt_image;
+    item.grid_version = grid->version;
+    CMX_REQUIRE(options != nullptr, "null argument");
+    cmx::Rt2DMatchBatch(options, &item, 1, grid->device, stats);
   });
 }
 
@@ -472,6 +486,46 @@ extern "C" cmx_status cmx_rt2d_match_grid_batch(const cmx_rt_options* options,
       item.n = num_points[m];
       item.score = &scores[m];
       item.pose = &pose_estimates[m];
+      item.image_cache = &g->rt_image;
+      item.grid_version = g->version;
+      items[m] = item;
+    }
+    cmx::Rt2DMatchBatch(options, items.data(), num_matches, grids[0]->device, stats);
+  });
+}
+
+extern "C" cmx_status cmx_rt2d_match_grid_batch_resident(const cmx_rt_options* options,
+                                                         const cmx_grid2d* const* grids,
+                                                         int32_t num_matches,
+                                                         const cmx_pose2d* initial_pose_estimates,
+                                                         const cmx_cloud* const* clouds,
+                                                         double* scores,
+                                                         cmx_pose2d* pose_estimates,
+                                                         cmx_match_stats* stats) {
+  return Guard([&] {
+    CMX_REQUIRE(grids && initial_pose_estimates && clouds && scores && pose_estimates &&
+                    num_matches >= 1,
+                "null argument");
+    std::vector<cmx_grid2d_limits> limits(num_matches);
+    std::vector<cmx::Rt2DItem> items(num_matches);
+    for (int m = 0; m < num_matches; ++m) {
+      const cmx_grid2d* g = grids[m];
+      const cmx_cloud* c = clouds[m];
+      CMX_REQUIRE(g != nullptr && c != nullptr, "null grid or cloud");
+      CMX_REQUIRE(g->device == grids[0]->device && c->device == g->device,
+                  "all grids and clouds of a batch must live on one device");
+      limits[m] = cmx_grid2d_limits{g->resolution, g->max_x, g->max_y, g->nx, g->ny, 0.f, 0.f};
+      cmx::Rt2DItem item{};
+      item.limits = &limits[m];
+      item.device_cells = g->cells;
+      item.initial = &initial_pose_estimates[m];
+      item.xyz = c->host_xyz.data();          // the range scan of SearchParameters runs on the host
+      item.device_xyz = c->xyz;
+      item.n = c->num_points;
+      item.score = &scores[m];
+      item.pose = &pose_estimates[m];
+      item.image_cache = &g->rt_image;
+      item.grid_version = g->version;
       items[m] = item;
     }
     cmx::Rt2DMatchBatch(options, items.data(), num_matches, grids[0]->device, stats);

@@ -68,6 +68,15 @@ struct Rt2DParams {
   int task_cap;              // per-rotation task descriptor slots (>= chunks of a rotation)
   int xyz_in_lds;            // the cloud is copied to LDS once per workgroup
   int* qsum;                 // [num_scans][side * side] integer sums of quantised cells
+  float* ub;                 // [num_scans][side * side] weighted upper bounds (row-pair kernel)
+  // Row-pair bulk pass (Rt2DImageKernel / Rt2DRowPairKernel, see below)
+  uint16_t* qimage;          // device: the staged grid as the workgroups copy it (zero halo baked in)
+  int pitch;                 // bytes per image row (multiple of 8; rows of a half-wave tile the banks)
+  int image_bytes;           // hp * pitch, padded to whole KiB
+  int half_rows;             // H: window rows r, r + H, ... belong to one lane
+  int rows_per_lane;         // ceil(side / H), 1 .. kMaxRowsPerLane
+  int pair_list_cap;         // per-rotation capacity of the phase-sorted u16 entry list
+  int image_build;           // 0: qimage is a cached image of a resident grid, already built
   unsigned long long* timeline;   // CMX_TIMELINE=1: 16 stamps per bulk / exact block, else null
   int timeline_exact_base;        // first block slot of the exact kernel
 };
@@ -802,6 +811,447 @@ Rt2DBulkKernel(const Rt2DParams* __restrict__ params) {
   Stamp(tl, tl_block, 8);
 }
 
+// ---------------------------------------------------------------------------
+// Row-pair bulk pass (round 3): the same integer sums, organised around the LDS
+// ---------------------------------------------------------------------------
+// What bounded Rt2DBulkKernel (profiles/r02e_c1_pmc_sq_*): 58 % of the VALU issue slots and 37 %
+// of the LDS cycles -- half of the vector instructions were NOT the window update (every
+// workgroup re-quantised the whole grid: 19 k instructions; two passes over the rotated points;
+// f64 bound arithmetic), every ds_read_b64 cost an address instruction, 12 of 64 lanes idled,
+// phases were padded to 64-point chunks, and 27 % of the LDS cycles were bank conflicts.
+// This kernel keeps the idea (aligned 4-cell blocks of 16-bit q, packed adds, phases) and
+// changes the mapping:
+//   * the staged grid is built ONCE per grid as a ready-to-copy image in HBM (quantised,
+//     zero halo, skewed pitch: Rt2DImageKernel; cached with a resident cmx_grid2d) and enters
+//     LDS by LDS-DMA while the points are being discretised;
+//   * a HALF-wavefront (32 lanes) is one stream of points of one phase: lane = (row r < H,
+//     block b < B), H * B <= 32, and a lane owns the window rows r, r + H, ... (two for the
+//     13 x 13 window of C1: H = 8, B = 4): ONE address instruction (v_add_u32_dpp
+//     row_newbcast) serves rows_per_lane reads through the instruction's immediate offset;
+//   * the row pitch is chosen on the host so that the H x B 8-byte blocks a half-wavefront
+//     reads in one cycle fall into distinct banks for every base address: the reads are
+//     conflict-free by construction;
+//   * the two halves of a wavefront run two phases side by side, phases are paired by size,
+//     lists are padded to 16 entries only, tasks are at most 64 iterations and dealt
+//     dynamically;
+//   * points are pre-rotated by the initial yaw once per workgroup and discretised ONCE per
+//     rotation (the packed entries wait in registers for the list offsets).
+// For C1: 1.5 vector instructions and 1 ds_read_b64 wave-instruction per point and
+// half-wavefront, against 2 + 1 per point and wavefront before, with all 32 lanes of a half busy.
+constexpr int kMaxRowsPerLane = 4;
+constexpr int kExactSplit = 4;              // workgroups sharing a match's rotations with finalists
+constexpr int kPairTaskIters = 64;          // iterations (entries per stream) of one task
+constexpr int kPairChunksPerWave = 16;      // (rotation, 64-point chunk) pairs a wave discretises per round
+
+// grid (ceil(image_bytes / 16 / 256), matches): the quantised image, 8 cells per thread.
+__global__ void __launch_bounds__(256)
+Rt2DImageKernel(const Rt2DParams* __restrict__ params) {
+  const Rt2DParams& P = params[blockIdx.y];
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (!P.image_build || v >= (P.image_bytes >> 4)) return;
+  const int byte = v << 4;
+  const auto* cells = AsGlobal(P.cells);
+  unsigned q[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {          // (the pitch is a multiple of 8 bytes, not of 16)
+    const int at = byte + 2 * c;
+    const int Y = at / P.pitch, X = (at - Y * P.pitch) >> 1;
+    const int gx = X - P.hl, gy = Y - P.ht;
+    unsigned val = 0;
+    if (static_cast<unsigned>(gx) < static_cast<unsigned>(P.nx) &&
+        static_cast<unsigned>(gy) < static_cast<unsigned>(P.ny)) {
+      const unsigned raw = cells[gy * P.nx + gx] & 32767u;
+      val = raw ? (32767u - raw) >> kQShift : 0u;
+    }
+    q[c] = val;
+  }
+  uint4 out = make_uint4(q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16),
+                         q[6] | (q[7] << 16));
+  reinterpret_cast<uint4*>(P.qimage)[v] = out;
+}
+
+template <int K>
+__device__ __forceinline__ int RowBcastAdd(int addrs, int lane_off) {
+  int out;
+  asm("v_add_u32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+      : "=v"(out) : "v"(addrs), "v"(lane_off), "i"(K));
+  return out;
+}
+__device__ __forceinline__ uint2 LdsRead64(int addr) {
+  const uint2v t = *reinterpret_cast<LdsUint2Ptr>(static_cast<uintptr_t>(addr));
+  return make_uint2(t[0], t[1]);
+}
+__device__ __forceinline__ void Add3(uint32_t* acc, uint32_t a, uint32_t b) {
+  asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(*acc) : "v"(a), "v"(b));
+}
+
+// One task: `iters` (a multiple of 16) entries of the two streams of this wavefront.  RPL =
+// rows per lane; `row_stride` = H * pitch bytes.  acc32[j][c]: sum of cell c of the lane's
+// block in its j-th row.
+// The loop body is hand-scheduled: loads, waits and adds are all `asm volatile`, because the
+// compiler's own s_waitcnt placement drains the LDS queue (lgkmcnt(0)) before every group of
+// adds -- eight reads in flight, then none.  Here two banks of 2 x RPL reads alternate and every
+// add waits for exactly the older bank (LDS returns in order: at most 2 RPL operations pending
+// means the older bank has landed, whatever else the compiler has in flight).
+template <int kImm>
+__device__ __forceinline__ void LdsRead64Asm(uint2v* out, int addr) {
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(*out) : "v"(addr), "i"(kImm));
+}
+template <int kPending>
+__device__ __forceinline__ void WaitLds() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(kPending) : "memory");
+}
+__device__ __forceinline__ void Add3Asm(uint32_t* acc, uint32_t a, uint32_t b) {
+  asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(*acc) : "v"(a), "v"(b));
+}
+
+template <int RPL, int kRowStride, int K>
+__device__ __forceinline__ void PairLoad(uint2v (&bank)[2][RPL], int addrs, int lane_off,
+                                         int row_stride_rt) {
+  const int va0 = RowBcastAdd<K>(addrs, lane_off);
+  const int va1 = RowBcastAdd<K + 1>(addrs, lane_off);
+  if constexpr (kRowStride > 0) {
+    LdsRead64Asm<0>(&bank[0][0], va0);
+    if constexpr (RPL > 1) LdsRead64Asm<kRowStride>(&bank[0][1], va0);
+    if constexpr (RPL > 2) LdsRead64Asm<2 * kRowStride>(&bank[0][2], va0);
+    if constexpr (RPL > 3) LdsRead64Asm<3 * kRowStride>(&bank[0][3], va0);
+    LdsRead64Asm<0>(&bank[1][0], va1);
+    if constexpr (RPL > 1) LdsRead64Asm<kRowStride>(&bank[1][1], va1);
+    if constexpr (RPL > 2) LdsRead64Asm<2 * kRowStride>(&bank[1][2], va1);
+    if constexpr (RPL > 3) LdsRead64Asm<3 * kRowStride>(&bank[1][3], va1);
+  } else {
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) LdsRead64Asm<0>(&bank[0][j], va0 + j * row_stride_rt);
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) LdsRead64Asm<0>(&bank[1][j], va1 + j * row_stride_rt);
+  }
+}
+template <int RPL>
+__device__ __forceinline__ void PairAdd(const uint2v (&bank)[2][RPL], uint32_t (&lo)[RPL],
+                                        uint32_t (&hi)[RPL]) {
+#pragma unroll
+  for (int j = 0; j < RPL; ++j) {
+    Add3Asm(&lo[j], bank[0][j][0], bank[1][j][0]);
+    Add3Asm(&hi[j], bank[0][j][1], bank[1][j][1]);
+  }
+}
+
+// One task: `iters` (a multiple of 16) entries of the two streams of this wavefront.  RPL =
+// rows per lane; kRowStride = H * pitch bytes when that is a compile-time constant (it then
+// rides in the read's immediate offset), 0: runtime stride, one v_add per extra row.
+// acc32[j][c]: sum of cell c of the lane's block in its j-th row.
+template <int RPL, int kRowStride>
+__device__ __forceinline__ void RowPairAccumulate(const uint16_t* my_list, int my_len, int iters,
+                                                  int lane, int lane_off, int row_stride_rt,
+                                                  uint32_t (&acc32)[RPL][4]) {
+  uint32_t lo[RPL], hi[RPL];
+#pragma unroll
+  for (int j = 0; j < RPL; ++j) lo[j] = hi[j] = 0;
+  const int groups = iters >> 4;
+  constexpr int kBank = 2 * RPL;             // reads of one bank
+  int e = lane & 15;
+  int addrs = e < my_len ? static_cast<int>(my_list[e]) << 3 : 0;   // 0: the zero corner
+  for (int g = 0; g < groups; ++g) {
+    // the next group's entries are fetched under this group's reads
+    const int e_next = e + 16;
+    // (unconditional read of a slot inside the padded list, selected afterwards: a branch
+    // around the read makes the compiler wait for it -- and for everything else -- at once)
+    const int raw_next = my_list[min(e_next, iters - 1)];
+    const int addrs_next = e_next < my_len ? raw_next << 3 : 0;
+    uint2v a[2][RPL], b[2][RPL];
+    PairLoad<RPL, kRowStride, 0>(a, addrs, lane_off, row_stride_rt);
+    PairLoad<RPL, kRowStride, 2>(b, addrs, lane_off, row_stride_rt);
+    WaitLds<kBank>(); PairAdd<RPL>(a, lo, hi); PairLoad<RPL, kRowStride, 4>(a, addrs, lane_off, row_stride_rt);
+    WaitLds<kBank>(); PairAdd<RPL>(b, lo, hi); PairLoad<RPL, kRowStride, 6>(b, addrs, lane_off, row_stride_rt);
+    WaitLds<kBank>(); PairAdd<RPL>(a, lo, hi); PairLoad<RPL, kRowStride, 8>(a, addrs, lane_off, row_stride_rt);
+    WaitLds<kBank>(); PairAdd<RPL>(b, lo, hi); PairLoad<RPL, kRowStride, 10>(b, addrs, lane_off, row_stride_rt);
+    WaitLds<kBank>(); PairAdd<RPL>(a, lo, hi); PairLoad<RPL, kRowStride, 12>(a, addrs, lane_off, row_stride_rt);
+    WaitLds<kBank>(); PairAdd<RPL>(b, lo, hi); PairLoad<RPL, kRowStride, 14>(b, addrs, lane_off, row_stride_rt);
+    WaitLds<kBank>(); PairAdd<RPL>(a, lo, hi);
+    WaitLds<0>();     PairAdd<RPL>(b, lo, hi);
+    if ((g & 3) == 3 || g + 1 == groups) {       // 64 entries: the 16-bit fields are full
+#pragma unroll
+      for (int j = 0; j < RPL; ++j) {
+        acc32[j][0] += lo[j] & 0xffffu; acc32[j][1] += lo[j] >> 16;
+        acc32[j][2] += hi[j] & 0xffffu; acc32[j][3] += hi[j] >> 16;
+        lo[j] = hi[j] = 0;
+      }
+    }
+    e = e_next;
+    addrs = addrs_next;
+  }
+}
+
+// grid (workgroups per match, matches), 1024 threads; dynamic LDS:
+//   image[image_bytes] | acc[R][side^2] | bases[R][pchunks][4] | cnt[R][4] | pstart[R][4] |
+//   tasks[task_cap] x 4 | ctl[16] | rots[R] | ax[n_pad] ay[n_pad] | list[R][cap] u16
+template <int RPL, int kRowStride>
+__global__ void __launch_bounds__(kBulkThreads)
+Rt2DRowPairKernel(const Rt2DParams* __restrict__ params) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bulk_smem[];
+  const Rt2DParams& P = params[blockIdx.y];
+  if (static_cast<int>(blockIdx.x) >= P.num_scans) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = P.n, n_pad = P.n_pad, pchunks = n_pad >> 6;
+  const int side = 2 * P.nl + 1, cands = side * side;
+  const int R = P.rounds_rot, B = P.blocks_per_row, H = P.half_rows;
+  const int cap = P.pair_list_cap;
+  int* acc = reinterpret_cast<int*>(bulk_smem + P.image_bytes);
+  int* bases = acc + ((R * cands + 3) & ~3);   // [R][pchunks][4]: a chunk's offset inside its phase (16-byte aligned)
+  int* cnt = bases + R * pchunks * 4;       // [R][4]
+  int* pstart = cnt + R * 4;                // [R][4]: first list slot of the phase
+  int* tasks = pstart + R * 4;              // [task_cap][4]: rr | phA << 8 | phB << 16, startA, startB, lenA | lenB << 16
+  int* ctl = tasks + P.task_cap * 4;        // [0] number of tasks, [1] next task
+  float2* rots = reinterpret_cast<float2*>(ctl + 16);       // [R]: this round's (cos, sin) pairs
+  float* ax = reinterpret_cast<float*>(rots + R);
+  float* ay = ax + n_pad;
+  uint16_t* list = reinterpret_cast<uint16_t*>(ay + n_pad);
+
+  unsigned long long* const tl = P.timeline;
+  const int tl_block = blockIdx.y * gridDim.x + blockIdx.x;
+  Stamp(tl, tl_block, 0);
+  // ---- the image enters LDS as it is, by LDS-DMA (global_load_lds_dwordx4: 1 KiB per
+  // wave-instruction, no registers, asynchronous): nothing reads it before the tasks, so the
+  // copy runs under the discretisation; vmcnt(0) + barrier order the reads behind it -------
+  {
+    // (the cloud's loads go out first: their latency runs under the DMA issue)
+    const auto* xyz = AsGlobal(P.xyz);
+    const int i0 = min(tid, n - 1);
+    const float px = xyz[3 * i0], py = xyz[3 * i0 + 1];
+    const auto* src = (const __attribute__((address_space(1))) unsigned char*)P.qimage;
+    auto* dst = (__attribute__((address_space(3))) unsigned char*)bulk_smem;
+    const int kib = P.image_bytes >> 10;              // the image is padded to whole KiB
+    for (int k = wave; k < kib; k += kBulkWaves)
+      __builtin_amdgcn_global_load_lds(src + (k << 10) + (lane << 4), dst + (k << 10), 16, 0, 0);
+    // the cloud pre-rotated by the initial yaw (once per workgroup)
+    for (int i = tid; i < n_pad; i += kBulkThreads) {
+      float x = 0.f, y = 0.f;
+      if (i < n) {
+        const float vx = i == tid ? px : xyz[3 * i], vy = i == tid ? py : xyz[3 * i + 1];
+        RotateZ(P.init_qw, P.init_qz, vx, vy, &x, &y);
+      }
+      ax[i] = x;
+      ay[i] = y;
+    }
+  }
+  Stamp(tl, tl_block, 1);
+  const float kScale = ((1.f - 0.1f) - (1.f - (1.f - 0.1f))) / 32766.f;   // (kMaxCC - kMinCC) / 32766
+  const int lds_image = static_cast<int>(reinterpret_cast<uintptr_t>(
+      (const __attribute__((address_space(3))) unsigned char*)bulk_smem));
+  // Lane geometry inside a half-wavefront.
+  const int li = lane & 31;
+  const int row = li / B, blk = li - row * B;
+  const bool lane_used = row < H;
+  // (lanes beyond H * B read the image's first rows like everyone else and drop the result)
+  const int lane_off = lds_image + (lane_used ? row * P.pitch + blk * 8 : 0);
+  const int row_stride = H * P.pitch;
+
+  for (int s0 = blockIdx.x; s0 < P.num_scans; s0 += gridDim.x * R) {
+    const int round_rot = min(R, (P.num_scans - s0 + static_cast<int>(gridDim.x) - 1) /
+                                     static_cast<int>(gridDim.x));
+    __syncthreads();                       // previous round's accumulators have been read
+    if (s0 == static_cast<int>(blockIdx.x)) Stamp(tl, tl_block, 2);
+    for (int i = tid; i < round_rot * cands; i += kBulkThreads) acc[i] = 0;
+    if (tid < round_rot * 4) cnt[tid] = 0;
+    if (tid < 2) ctl[tid] = 0;
+    if (tid < round_rot) rots[tid] = P.scan_rot[s0 + tid * gridDim.x];
+    __syncthreads();
+    // ---- discretise once: entry << 2 | phase stays in a register -------------------------
+    int pk[kPairChunksPerWave];
+    const int wave_chunks = round_rot * pchunks;
+    {
+      const float tx = P.tx, ty = P.ty;
+      const double max_x = P.max_x, max_y = P.max_y, res = P.res, inv_res = P.inv_res;
+      const int nl = P.nl, nx = P.nx, ny = P.ny, hl = P.hl, ht = P.ht, pitch = P.pitch;
+      // CellIndexFast (cmx_device.h) with its per-call constants hoisted and its error bound
+      // simplified upwards: |a| inv <= |b| (1 + 2^-23), so
+      //   (|max| + |a|) inv 2^-23 + |b| 2^-21 + 2^-20  <=  c0 + |b| 2^-20,
+      // c0 = |max| inv 2^-23 + 2^-20.  A larger bound only sends more points to the exact f64
+      // expression; the result is the same lround either way.
+      const float maxxf = static_cast<float>(max_x), maxyf = static_cast<float>(max_y);
+      const float invf = static_cast<float>(inv_res);
+      const float c0x = fabsf(maxxf) * invf * 0x1p-23f + 0x1p-20f;
+      const float c0y = fabsf(maxyf) * invf * 0x1p-23f + 0x1p-20f;
+      const auto cell = [&](float maxf, float c0, double max_d, float v) -> int {
+        const float b = (maxf - v) * invf;
+        const float t = b - 0.5f;
+        const float r = rintf(t);
+        const float margin = 0.5f - fabsf(t - r);
+        if (margin > c0 + fabsf(b) * 0x1p-20f && fabsf(t) < 1e6f) return static_cast<int>(r);
+        return CellIndexF64(max_d - static_cast<double>(v), res, inv_res);
+      };
+      int rr = wave / pchunks, pc = wave - rr * pchunks;         // chunk wave + 16 j, incrementally
+#pragma unroll
+      for (int j = 0; j < kPairChunksPerWave; ++j) {
+        int packed = -1;
+        if (wave + j * kBulkWaves < wave_chunks) {
+          const float2 rot = rots[rr];
+          const int i = pc * 64 + lane;
+          if (i < n) {
+            float bx, by;
+            RotateZ(rot.x, rot.y, ax[i], ay[i], &bx, &by);
+            const int cx = cell(maxyf, c0y, max_y, by + ty);
+            const int cy = cell(maxxf, c0x, max_x, bx + tx);
+            const int ix = min(max(cx, -(nl + 1)), nx + nl);
+            const int iy = min(max(cy, -(nl + 1)), ny + nl);
+            const int wx = ix - nl + hl, wy = iy - nl + ht;   // window start, image coordinates
+            packed = ((wy * pitch + (wx & ~3) * 2) >> 1) | (wx & 3);   // (byte >> 3) << 2 | phase
+          }
+          // the chunk's place inside each phase list: ONE returning LDS atomic (lane q = phase q)
+          const int c0 = __popcll(__ballot(packed >= 0 && (packed & 3) == 0));
+          const int c1 = __popcll(__ballot(packed >= 0 && (packed & 3) == 1));
+          const int c2 = __popcll(__ballot(packed >= 0 && (packed & 3) == 2));
+          const int c3 = __popcll(__ballot(packed >= 0 && (packed & 3) == 3));
+          if (lane < 4) {
+            const int c = lane == 0 ? c0 : lane == 1 ? c1 : lane == 2 ? c2 : c3;
+            bases[(rr * pchunks + pc) * 4 + lane] = atomicAdd(&cnt[rr * 4 + lane], c);
+          }
+        }
+        pk[j] = packed;
+        pc += kBulkWaves;
+        while (pc >= pchunks) { pc -= pchunks; ++rr; }
+      }
+    }
+    __syncthreads();
+    if (s0 == static_cast<int>(blockIdx.x)) Stamp(tl, tl_block, 3);      // points discretised
+    // ---- per rotation: phase offsets (lists padded to 16 entries), phases paired by size,
+    // tasks of at most kPairTaskIters iterations ---------------------------------------------
+    if (wave == 0) {                         // lane = rotation of the round (R <= 64)
+      const int rr = lane;
+      const bool live = rr < round_rot;
+      int key[4], start = 0, first_slot[4];   // count << 2 | phase
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        const int c = live ? cnt[rr * 4 + ph] : 0;
+        key[ph] = (c << 2) | ph;
+        first_slot[ph] = start;
+        if (live) pstart[rr * 4 + ph] = start;
+        start += (c + 15) & ~15;
+      }
+      // the four phases by count, descending (sorting network of five exchanges)
+#define CMX_CSWAP(I, J) { const int hi_k = max(key[I], key[J]), lo_k = min(key[I], key[J]); key[I] = hi_k; key[J] = lo_k; }
+      CMX_CSWAP(0, 1) CMX_CSWAP(2, 3) CMX_CSWAP(0, 2) CMX_CSWAP(1, 3) CMX_CSWAP(1, 2)
+#undef CMX_CSWAP
+      const int la0 = key[0] >> 2, la1 = key[2] >> 2;
+      const int mine = (la0 + kPairTaskIters - 1) / kPairTaskIters + (la1 + kPairTaskIters - 1) / kPairTaskIters;
+      const int incl = WaveInclusiveScan(mine);
+      int t = incl - mine;
+      if (lane == 63) ctl[0] = incl;
+#pragma unroll
+      for (int pair = 0; pair < 2; ++pair) {
+        const int pa = key[2 * pair] & 3, pb = key[2 * pair + 1] & 3;
+        const int la = key[2 * pair] >> 2, lb = key[2 * pair + 1] >> 2;
+        // (static selects instead of first_slot[pa]: no dynamically indexed private array)
+        const int sa = pa == 0 ? first_slot[0] : pa == 1 ? first_slot[1] : pa == 2 ? first_slot[2] : first_slot[3];
+        const int sb = pb == 0 ? first_slot[0] : pb == 1 ? first_slot[1] : pb == 2 ? first_slot[2] : first_slot[3];
+        for (int off = 0; off < la; off += kPairTaskIters, ++t) {
+          tasks[4 * t] = rr | (pa << 8) | (pb << 16);
+          tasks[4 * t + 1] = sa + off;
+          tasks[4 * t + 2] = sb + off;
+          tasks[4 * t + 3] = min(kPairTaskIters, la - off) | (max(0, min(kPairTaskIters, lb - off)) << 16);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- scatter the entries from the registers into the phase lists ---------------------
+    {
+      int rr = wave / pchunks, pc = wave - rr * pchunks;
+#pragma unroll
+      for (int j = 0; j < kPairChunksPerWave; ++j) {
+        if (wave + j * kBulkWaves < wave_chunks) {
+          const int packed = pk[j];
+          const int ph = packed & 3;
+          const int4 b4 = *reinterpret_cast<const int4*>(&bases[(rr * pchunks + pc) * 4]);
+          const int4 p4 = *reinterpret_cast<const int4*>(&pstart[rr * 4]);
+          const unsigned long long m0 = __ballot(packed >= 0 && ph == 0);
+          const unsigned long long m1 = __ballot(packed >= 0 && ph == 1);
+          const unsigned long long m2 = __ballot(packed >= 0 && ph == 2);
+          const unsigned long long m3 = __ballot(packed >= 0 && ph == 3);
+          if (packed >= 0) {
+            // the lane's own phase: its mask, its list start, its chunk base -- then ONE rank
+            const unsigned long long mine = ph == 0 ? m0 : ph == 1 ? m1 : ph == 2 ? m2 : m3;
+            const int first = ph == 0 ? p4.x + b4.x : ph == 1 ? p4.y + b4.y : ph == 2 ? p4.z + b4.z : p4.w + b4.w;
+            const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mine >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mine), 0));
+            list[rr * cap + first + rank] = static_cast<uint16_t>(packed >> 2);
+          }
+        }
+        pc += kBulkWaves;
+        while (pc >= pchunks) { pc -= pchunks; ++rr; }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the image has landed
+    __syncthreads();
+    if (s0 == static_cast<int>(blockIdx.x)) Stamp(tl, tl_block, 4);      // lists sorted by phase
+    // ---- tasks, dealt dynamically: the halves of a wavefront run two phases --------------
+    const int num_tasks = ctl[0];          // <= task_cap by construction (host)
+    for (;;) {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(&ctl[1], 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= num_tasks) break;
+      const int d0 = tasks[4 * t], d3 = tasks[4 * t + 3];
+      const int rr = d0 & 255;
+      const bool second = lane >= 32;
+      const int phase = second ? (d0 >> 16) & 255 : (d0 >> 8) & 255;
+      const int start = second ? tasks[4 * t + 2] : tasks[4 * t + 1];
+      const int my_len = second ? d3 >> 16 : d3 & 0xffff;
+      const int iters = ((d3 & 0xffff) + 15) & ~15;          // the first stream is the longer
+      uint32_t acc32[RPL][4];
+#pragma unroll
+      for (int j = 0; j < RPL; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc32[j][c] = 0;
+      RowPairAccumulate<RPL, kRowStride>(list + rr * cap + start, my_len, iters, lane, lane_off,
+                                         row_stride, acc32);
+      if (lane_used) {
+        int* out = acc + rr * cands;
+        const int d0x = blk * 4 - phase;           // candidate x index of the block's first cell
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+          const int wrow = row + j * H;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int dxi = d0x + c;
+            if (wrow < side && dxi >= 0 && dxi < side && acc32[j][c])
+              atomicAdd(&out[dxi * side + wrow], static_cast<int>(acc32[j][c]));
+          }
+        }
+      }
+    }
+    if (s0 == static_cast<int>(blockIdx.x)) Stamp(tl, tl_block, 5);      // this wave out of tasks
+    __syncthreads();
+    if (s0 == static_cast<int>(blockIdx.x)) Stamp(tl, tl_block, 6);      // all tasks done
+    // ---- per candidate: integer sum out; weighted lower bound into the match's maximum,
+    // weighted upper bound out for the finalist selection.  Bounds only SELECT finalists (their
+    // scores are recomputed exactly), so f32 with slack is enough: the base value carries one
+    // rounding of 2^-23 relative (1.2e-7 absolute) against kBoundSlack = 1e-4 --------------------
+    float lb_max = 0.f;
+    const float per_q = kScale * static_cast<float>(1 << kQShift) / static_cast<float>(n);
+    const float width = kScale * static_cast<float>((1 << kQShift) - 1);
+    for (int e = tid; e < round_rot * cands; e += kBulkThreads) {
+      const int rr = e / cands, c = e - rr * cands;
+      const int s = s0 + rr * gridDim.x;
+      const int q = acc[e];
+      P.qsum[static_cast<size_t>(s) * cands + c] = q;
+      const int dxi = c / side, dyi = c - dxi * side;
+      const float base = 0.1f + per_q * static_cast<float>(q);
+      const float w = Rt2DWeight(P, s, dxi - P.nl, dyi - P.nl);
+      const float lb = (base - static_cast<float>(kBoundSlack)) * w * (1.f - 1e-5f);
+      P.ub[static_cast<size_t>(s) * cands + c] =
+          (base + width + static_cast<float>(kBoundSlack)) * w * (1.f + 1e-5f);
+      lb_max = fmaxf(lb_max, lb);
+    }
+    unsigned bits = __float_as_uint(fmaxf(lb_max, 0.f));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) bits = max(bits, __shfl_xor(bits, off, 64));
+    if (lane == 0 && bits) atomicMax(&P.misc[0], bits);
+    if (s0 == static_cast<int>(blockIdx.x)) Stamp(tl, tl_block, 7);
+  }
+  Stamp(tl, tl_block, 8);
+}
+
 // grid (num_scans, matches), 256 threads: the finalists of one rotation with the reference's
 // sequential f32 sum (:61-75).  The sum is a chain of N dependent additions, but the N lookups
 // behind it are independent: all threads fetch the probabilities of a finalist's points into
@@ -913,9 +1363,139 @@ Rt2DExactKernel(const Rt2DParams* __restrict__ params, int group) {
   Stamp(tl, tl_block, 3);
 }
 
+// grid (matches, kExactSplit), 1024 threads: the same finalists, a few workgroups per MATCH (round 3).  The
+// per-rotation grid above launches num_scans x matches blocks of which 96 % only find out that
+// their rotation has no finalist (3456 blocks, 15 us for 128 matches of C1: more than a quarter
+// of the bulk kernel).  Here a match's 27 x 169 bounds are scanned by one workgroup (coalesced),
+// the few finalists are grouped by rotation, and per rotation with finalists: discretise once,
+// all threads gather the probabilities of up to `group` finalists into LDS, one lane per
+// finalist runs the reference's f32 chain out of LDS (32 values in flight ahead of the adds).
+// Dynamic LDS: cells[n_pad] u32 | prob[group][n_pad + 1] f32 | rot_count[num_scans] | fin[kFinalistCap].
+__global__ void __launch_bounds__(1024)
+Rt2DExactMatchKernel(const Rt2DParams* __restrict__ params, int group) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char exact_smem[];
+  const Rt2DParams& P = params[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int side = 2 * P.nl + 1, cands = side * side, n = P.n, n_pad = P.n_pad;
+  const int total = P.num_scans * cands;
+  unsigned long long* const tl = P.timeline;
+  const int tl_block = P.timeline_exact_base + blockIdx.x * gridDim.y + blockIdx.y;
+  Stamp(tl, tl_block, 0);
+  uint32_t* cellbuf = reinterpret_cast<uint32_t*>(exact_smem);
+  float* prob = reinterpret_cast<float*>(cellbuf + n_pad);
+  int* rot_count = reinterpret_cast<int*>(prob + group * (n_pad + 1));
+  int* fin = rot_count + ((P.num_scans + 3) & ~3);
+  __shared__ int nfin;
+  __shared__ int sel[18];
+  if (tid == 0) nfin = 0;
+  for (int s = tid; s < P.num_scans; s += blockDim.x) rot_count[s] = 0;
+  __syncthreads();
+  const float best_lb = __uint_as_float(P.misc[0]);
+  // Candidates whose weighted upper bound (stored by the bulk kernel) reaches the best lower
+  // bound.  Every block of a match selects the same list (in its own order).
+  for (int e = tid; e < total; e += blockDim.x) {
+    if (P.ub[e] >= best_lb) {
+      const int slot = atomicAdd(&nfin, 1);
+      if (slot < kFinalistCap) fin[slot] = e;
+      atomicAdd(&rot_count[e / cands], 1);
+    }
+  }
+  __syncthreads();
+  const int count = nfin;
+  if (count > kFinalistCap) {              // flat landscape: the host repeats the match on the
+    if (tid == 0 && blockIdx.y == 0) P.misc[1] = count;       // per-candidate kernels
+    return;
+  }
+  Stamp(tl, tl_block, 1);
+  const auto* cells = AsGlobal(P.cells);
+  const auto* xyz = AsGlobal(P.xyz);
+  const int row = n_pad + 1;              // odd row pitch: the chain lanes hit distinct banks
+  const Quat q0{P.init_qw, 0.f, 0.f, P.init_qz};
+  int rank = 0;                           // rotations with finalists are dealt to the match's blocks
+  for (int s = 0; s < P.num_scans; ++s) {
+    if (rot_count[s] == 0) continue;      // (uniform: LDS value, no writer since the barrier)
+    if (rank++ % static_cast<int>(gridDim.y) != static_cast<int>(blockIdx.y)) continue;
+    __syncthreads();                      // the previous rotation's cells and sums are done with
+    {
+      const float2 r = P.scan_rot[s];
+      const Quat qs{r.x, 0.f, 0.f, r.y};
+      for (int i = tid; i < n; i += blockDim.x) {
+        int ix, iy;
+        Rt2DPointCell(P, q0, qs, F3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]}, &ix, &iy);
+        cellbuf[i] = (static_cast<uint32_t>(ix) & 0xffffu) | (static_cast<uint32_t>(iy) << 16);
+      }
+    }
+    __syncthreads();
+    // this rotation's finalists, `group` (<= 16) at a time: thread 0 picks them from the list
+    int next = 0;
+    for (;;) {
+      if (tid == 0) {
+        int g = 0;
+        for (; next < count && g < group; ++next) {
+          const int e = fin[next];
+          if (e / cands == s) sel[g++] = e - s * cands;
+        }
+        sel[16] = g;
+        sel[17] = next;
+      }
+      __syncthreads();
+      const int g = sel[16];
+      next = sel[17];
+      if (g == 0) break;
+      for (int f = 0; f < g; ++f) {
+        const int c = sel[f];
+        const int dxi = c / side, dyi = c - dxi * side;
+        const int dx = dxi - P.nl, dy = dyi - P.nl;
+        for (int i = tid; i < n; i += blockDim.x) {
+          const uint32_t pc = cellbuf[i];
+          const int x = static_cast<short>(pc & 0xffffu) + dx;
+          const int y = static_cast<short>(pc >> 16) + dy;
+          const bool inside = static_cast<unsigned>(x) < static_cast<unsigned>(P.nx) &&
+                              static_cast<unsigned>(y) < static_cast<unsigned>(P.ny);
+          const unsigned raw = cells[inside ? P.nx * y + x : 0];
+          prob[f * row + i] = inside ? CellProbability(raw) : 0.1f;   // kMinProbability
+        }
+      }
+      __syncthreads();
+      if (tid < g) {
+        const float* vals = prob + tid * row;
+        float sum = 0.f;
+        int i = 0;
+        for (; i + 32 <= n; i += 32) {
+          float v[32];
+#pragma unroll
+          for (int k = 0; k < 32; ++k) v[k] = vals[i + k];
+#pragma unroll
+          for (int k = 0; k < 32; ++k) sum += v[k];            // in point order
+        }
+        for (; i < n; ++i) sum += vals[i];
+        const float score = sum / static_cast<float>(n);
+        const int c = sel[tid];
+        const int dxi = c / side, dyi = c - dxi * side;
+        const int cg = (s * side + dxi) * side + dyi;           // x outer, y inner (:99-113)
+        const unsigned slot = atomicAdd(&P.misc[1], 1u);
+        if (slot < static_cast<unsigned>(kFinalistCap)) {
+          unsigned* pair = slot < static_cast<unsigned>(kFinalistHead)
+                               ? P.misc + 2 + 2 * slot
+                               : P.overflow + 2 * (slot - kFinalistHead);
+          pair[0] = static_cast<unsigned>(cg);
+          pair[1] = __float_as_uint(score);
+        }
+      }
+      __syncthreads();
+      if (g < group) break;
+    }
+  }
+  Stamp(tl, tl_block, 3);
+}
+
 size_t Align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
 
 }  // namespace
+
+Rt2DImageCache::~Rt2DImageCache() {
+  if (image) (void)hipFree(image);
+}
 
 // A batch of independent matches (one per trajectory / robot) in one set of launches.  Per
 // item `cells` is a host buffer, or -- when `device_cells` is given -- ignored in favour of
@@ -974,37 +1554,54 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
     if (tsdf) CMX_REQUIRE(it.max_tsd > 0.f && it.max_weight > 0.f, "bad TSDF ranges");
     pl.n = it.n; pl.nx = it.limits->num_x_cells; pl.ny = it.limits->num_y_cells;
     pl.res = it.limits->resolution;
+  }
+  // SearchParameters of every item (a range scan over its cloud, acos): on the host pool.
+  ParallelFor(num, 8, [&](int m) {
+    const Rt2DItem& it = items[m];
+    Plan& pl = plan[m];
     const int n = pl.n;
     const double res = pl.res;
-
     // SearchParameters on the cloud pre-rotated by the initial yaw (:123-130).
     const float ha0 = 0.5f * static_cast<float>(it.initial->theta);
     const float q0w = std::cos(ha0), q0z = std::sin(ha0) * 1.f;
     // Longest xy range of the cloud pre-rotated by the initial yaw (:123-130, :27-36).  The
     // rotation is the device's RotateZ (cmx_device.h: bit-identical to Eigen's product by
     // (w, 0, 0, z) for finite inputs); sqrt is monotone and correctly rounded, so the maximum
-    // of the norms is the norm of the largest squared norm.  Four independent maxima keep the
-    // loop free of a serial dependency (this runs once per scan on the host: ~1 us).
-    float max_sq[4] = {0.f, 0.f, 0.f, 0.f};
-    const auto squared_range = [q0w, q0z](const float* p) {
-      float uvx = -(q0z * p[1]), uvy = q0z * p[0];
+    // of the norms is the norm of the largest squared norm.  Eight independent maxima in
+    // structure-of-arrays form: the loop vectorises (IEEE adds and multiplies only, no
+    // contraction: the same bits in every lane as in the scalar expression).
+    constexpr int kLanes = 8;
+    float max_sq[kLanes];
+    for (int k = 0; k < kLanes; ++k) max_sq[k] = 0.f;
+    const auto squared_range = [q0w, q0z](float px, float py) {
+      float uvx = -(q0z * py), uvy = q0z * px;
       uvx += uvx; uvy += uvy;
       const float cxx = -(q0z * uvy), cyy = q0z * uvx;
-      const float rx = (p[0] + q0w * uvx) + cxx, ry = (p[1] + q0w * uvy) + cyy;
+      const float rx = (px + q0w * uvx) + cxx, ry = (py + q0w * uvy) + cyy;
       return rx * rx + ry * ry;
     };
     int i = 0;
-    for (; i + 4 <= n; i += 4)
-      for (int k = 0; k < 4; ++k)
-        max_sq[k] = std::max(max_sq[k], squared_range(it.xyz + 3 * (i + k)));
-    for (; i < n; ++i) max_sq[0] = std::max(max_sq[0], squared_range(it.xyz + 3 * i));
-    const float max_scan_range =
-        std::max(static_cast<float>(3.f * res),
-                 std::sqrt(std::max(std::max(max_sq[0], max_sq[1]), std::max(max_sq[2], max_sq[3]))));
+    for (; i + kLanes <= n; i += kLanes) {
+      float px[kLanes], py[kLanes];
+      for (int k = 0; k < kLanes; ++k) { px[k] = it.xyz[3 * (i + k)]; py[k] = it.xyz[3 * (i + k) + 1]; }
+      for (int k = 0; k < kLanes; ++k) max_sq[k] = std::max(max_sq[k], squared_range(px[k], py[k]));
+    }
+    for (; i < n; ++i)
+      max_sq[0] = std::max(max_sq[0], squared_range(it.xyz[3 * i], it.xyz[3 * i + 1]));
+    float max_all = 0.f;
+    for (int k = 0; k < kLanes; ++k) max_all = std::max(max_all, max_sq[k]);
+    const float max_scan_range = std::max(static_cast<float>(3.f * res), std::sqrt(max_all));
     const double kSafetyMargin = 1. - 1e-3;
     const float range_sq = max_scan_range * (max_scan_range * 1.f);
     pl.step = kSafetyMargin * std::acos(1. - (res * (res * 1.)) / (2. * range_sq));
     pl.na = std::ceil(options->angular_search_window / pl.step);
+    pl.q0w = q0w; pl.q0z = q0z;
+  });
+  for (int m = 0; m < num; ++m) {
+    const Rt2DItem& it = items[m];
+    Plan& pl = plan[m];
+    const int n = pl.n;
+    const double res = pl.res;
     pl.num_scans = 2 * pl.na + 1;
     pl.nl = std::ceil(options->linear_search_window / res);
     CMX_REQUIRE(pl.num_scans >= 1 && pl.num_scans < (1 << 16) && pl.nl >= 0 && pl.nl < (1 << 12),
@@ -1017,13 +1614,12 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
     pl.rows = pl.ny + 2ll * pl.pad;
     CMX_REQUIRE(pl.stride * pl.rows < (1ll << 27), "grid plus search window too large");
     CMX_REQUIRE(static_cast<long long>(pl.num_scans) * n < (1ll << 30), "too many rotated points");
-    pl.q0w = q0w; pl.q0z = q0z;
     pl.n_pad = (n + 63) / 64 * 64;
 
     // Staging buffer: [params | per item: xyz | rotations | cells | weight cells].
     const size_t cell_count = static_cast<size_t>(pl.nx) * pl.ny;
     pl.off_xyz = in_bytes;
-    pl.off_rot = pl.off_xyz + Align16(3 * sizeof(float) * n);
+    pl.off_rot = pl.off_xyz + (it.device_xyz ? 0 : Align16(3 * sizeof(float) * n));
     pl.off_cells = pl.off_rot + Align16(sizeof(float2) * pl.num_scans);
     pl.off_weights =
         pl.off_cells + (it.device_cells ? 0 : Align16(sizeof(uint16_t) * cell_count));
@@ -1081,6 +1677,68 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
     b.off_qsum = qsum_total;
     qsum_total += static_cast<size_t>(pl.num_scans) * side * side;
   }
+  // ---- row-pair pass (round 3): geometry; falls back to the chunked bulk kernel above for
+  // windows that need more than kMaxRowsPerLane rows per lane, mixed geometries in one batch,
+  // or when the image and one rotation's lists do not fit in LDS together ----------------
+  struct Pair { int B, H, rpl, hl, ht, hp, pitch, image_bytes, rounds, cap, task_cap; size_t lds, off_image; };
+  std::vector<Pair> pairg(num);
+  // CMX_RT2D_ROWPAIR=0 keeps the chunked bulk kernel (parity tests run all three paths).
+  const char* pair_env = getenv("CMX_RT2D_ROWPAIR");
+  bool use_pair = use_bulk && !(pair_env && pair_env[0] == '0');
+  size_t pair_lds = 0, image_total = 0;
+  for (int m = 0; m < num && use_pair; ++m) {
+    const Plan& pl = plan[m];
+    Pair& g = pairg[m];
+    const int side = static_cast<int>(pl.side);
+    g.B = (side + 3 + 3) / 4;
+    if (g.B > 32) { use_pair = false; break; }
+    g.H = 32 / g.B;
+    g.rpl = (side + g.H - 1) / g.H;
+    g.hl = (2 * pl.nl + 4 + 3) & ~3;               // == 4 * B: the null entry's blocks are halo
+    g.ht = 2 * pl.nl + 1;
+    g.hp = pl.ny + g.ht + g.rpl * g.H;
+    const int min_pitch = (2 * (pl.nx + g.hl + 4 * g.B) + 7) & ~7;
+    g.pitch = 0;
+    for (int cand = min_pitch; cand < min_pitch + 512; cand += 8) {
+      // conflict-free: the H x B 8-byte blocks of a half-wavefront touch 2 H B distinct banks
+      unsigned long long used = 0;
+      bool ok = true;
+      for (int r = 0; r < g.H && ok; ++r)
+        for (int b = 0; b < g.B && ok; ++b)
+          for (int w = 0; w < 2; ++w) {
+            const int bank = ((r * cand + b * 8) / 4 + w) & 63;
+            if (used >> bank & 1) ok = false;
+            used |= 1ull << bank;
+          }
+      if (ok) { g.pitch = cand; break; }
+    }
+    g.image_bytes = (g.hp * g.pitch + 16 + 1023) & ~1023;        // whole KiB: LDS-DMA granule
+    g.cap = pl.n_pad + 4 * 16;
+    const int pchunks = pl.n_pad / 64;
+    const size_t budget = 160 * 1024 - 512;
+    const size_t fixed = static_cast<size_t>(g.image_bytes) + 64 + 8 * static_cast<size_t>(pl.n_pad) + 64;
+    const auto per_round = [&](int R) {
+      const size_t tasks = static_cast<size_t>(R) * 2 * (pl.n_pad / kPairTaskIters + 1);
+      return 4 * (((static_cast<size_t>(R) * side * side + 3) & ~size_t{3}) +
+                  static_cast<size_t>(R) * pchunks * 4 + 8 * static_cast<size_t>(R) + 4 * tasks +
+                  2 * static_cast<size_t>(R)) +
+             2 * static_cast<size_t>(R) * g.cap;
+    };
+    int R = std::min({pl.num_scans, 64, kPairChunksPerWave * kBulkWaves / pchunks});
+    while (R >= 1 && fixed + per_round(R) > budget) --R;
+    if (g.pitch == 0 || g.rpl > kMaxRowsPerLane || R < 1 || pl.n > kBulkMaxPoints ||
+        g.image_bytes > (1 << 19) ||
+        (m > 0 && (g.rpl != pairg[0].rpl || g.H * g.pitch != pairg[0].H * pairg[0].pitch))) {
+      use_pair = false;
+      break;
+    }
+    g.rounds = R;
+    g.task_cap = R * 2 * (pl.n_pad / kPairTaskIters + 1);
+    g.lds = fixed + per_round(R);
+    pair_lds = std::max(pair_lds, g.lds);
+    g.off_image = image_total;
+    image_total += Align16(static_cast<size_t>(g.image_bytes));
+  }
   // Exact kernel: finalists per pass so that cells + probabilities + list stay within 60 KB.
   int exact_group = 8;
   size_t exact_lds = 0;
@@ -1118,9 +1776,50 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
   unsigned* d_misc = reinterpret_cast<unsigned*>(d_in + off_misc);
   std::memset(h_in + off_misc, 0, sizeof(unsigned) * 128 * static_cast<size_t>(num));
   int* d_qsum = use_bulk ? ws->dev[7].ReserveAs<int>(qsum_total) : nullptr;
+  float* d_ub = use_pair ? ws->dev[10].ReserveAs<float>(qsum_total) : nullptr;
   unsigned* d_overflow = ws->dev[6].ReserveAs<unsigned>(static_cast<size_t>(num) * 2 *
                                                         (kFinalistCap - kFinalistHead));
   unsigned* h_misc = ws->pinned[1].ReserveAs<unsigned>(static_cast<size_t>(num) * 128);
+  char* d_images = use_pair ? ws->dev[9].ReserveAs<char>(image_total) : nullptr;
+  // Images: a resident grid keeps its own (built once per grid version and window); everything
+  // else is built into scratch by this call.  A cache being (re)built stays locked until the
+  // stream has been waited for, so a concurrent match on the same grid sees a finished image.
+  std::vector<uint16_t*> image_of(num, nullptr);
+  std::vector<int> build_image(num, 0);
+  std::vector<std::unique_lock<std::mutex>> cache_locks;
+  if (use_pair) {
+    for (int m = 0; m < num; ++m) {
+      const Pair& g = pairg[m];
+      Rt2DImageCache* c = items[m].image_cache;
+      bool seen_before = false;                      // the same grid earlier in this batch
+      for (int k = 0; k < m && !seen_before; ++k)
+        if (c && items[k].image_cache == c) { seen_before = true; image_of[m] = image_of[k]; }
+      if (seen_before) continue;
+      if (!c || !items[m].device_cells) {
+        image_of[m] = reinterpret_cast<uint16_t*>(d_images + g.off_image);
+        build_image[m] = 1;
+        continue;
+      }
+      std::unique_lock<std::mutex> lock(c->mutex);
+      const bool valid = c->image && c->version == items[m].grid_version && c->nl == plan[m].nl &&
+                         c->nx == plan[m].nx && c->ny == plan[m].ny && c->pitch == g.pitch &&
+                         c->hp == g.hp && c->image_bytes == g.image_bytes;
+      if (!valid) {
+        if (c->capacity < static_cast<size_t>(g.image_bytes)) {
+          if (c->image) (void)hipFree(c->image);
+          c->image = nullptr;
+          c->capacity = 0;
+          CMX_HIP(hipMalloc(reinterpret_cast<void**>(&c->image), g.image_bytes));
+          c->capacity = g.image_bytes;
+        }
+        c->version = items[m].grid_version; c->nl = plan[m].nl; c->nx = plan[m].nx;
+        c->ny = plan[m].ny; c->pitch = g.pitch; c->hp = g.hp; c->image_bytes = g.image_bytes;
+        build_image[m] = 1;
+        cache_locks.push_back(std::move(lock));
+      }
+      image_of[m] = c->image;
+    }
+  }
 
   // CMX_TIMELINE=1: stamps of the bulk blocks, then of the exact blocks.
   unsigned long long* d_timeline = nullptr;
@@ -1132,6 +1831,10 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
     // batches (the grid is staged once per workgroup): about two rounds of the chip.
     if (static_cast<long long>(per_match_wgs) * num > 2ll * cus)
       per_match_wgs = std::max(1, std::min<int>(per_match_wgs, (2 * cus + num - 1) / num));
+    // (row-pair kernel: the image is copied once per workgroup and its tasks are dealt
+    // dynamically: ONE round of the chip)
+    if (use_pair && static_cast<long long>(per_match_wgs) * num > cus)
+      per_match_wgs = std::max(1, std::min<int>(per_match_wgs, (cus + num - 1) / num));
     if (const char* e = getenv("CMX_RT2D_WGS")) per_match_wgs = std::max(1, atoi(e));   // experiments
   }
   const int timeline_bulk_blocks = per_match_wgs * num;
@@ -1142,11 +1845,11 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
     CMX_HIP(hipMemsetAsync(d_timeline, 0, bytes, ws->stream));
   }
   Rt2DParams* h_params = reinterpret_cast<Rt2DParams*>(h_in);
-  for (int m = 0; m < num; ++m) {
+  ParallelFor(num, 8, [&](int m) {
     const Rt2DItem& it = items[m];
     const Plan& pl = plan[m];
     const size_t cell_count = static_cast<size_t>(pl.nx) * pl.ny;
-    std::memcpy(h_in + pl.off_xyz, it.xyz, 3 * sizeof(float) * pl.n);
+    if (!it.device_xyz) std::memcpy(h_in + pl.off_xyz, it.xyz, 3 * sizeof(float) * pl.n);
     float2* h_rot = reinterpret_cast<float2*>(h_in + pl.off_rot);
     double delta_theta = -pl.na * pl.step;
     for (int s = 0; s < pl.num_scans; ++s, delta_theta += pl.step) {
@@ -1179,7 +1882,7 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
     P.pad = pl.pad; P.stride = static_cast<int>(pl.stride); P.rows = static_cast<int>(pl.rows);
     P.misc = d_misc + static_cast<size_t>(m) * 128;
     P.overflow = d_overflow + static_cast<size_t>(m) * 2 * (kFinalistCap - kFinalistHead);
-    P.xyz = reinterpret_cast<const float*>(d_in + pl.off_xyz);
+    P.xyz = it.device_xyz ? it.device_xyz : reinterpret_cast<const float*>(d_in + pl.off_xyz);
     P.n = pl.n;
     P.unweighted = d_unweighted + pl.off_scores;
     P.weighted = d_weighted + pl.off_scores;
@@ -1194,8 +1897,18 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
       P.task_cap = b.task_cap; P.xyz_in_lds = b.xyz_lds ? 1 : 0;
       P.qsum = d_qsum + b.off_qsum;
     }
+    if (use_pair) {
+      P.ub = d_ub + bulk[m].off_qsum;
+      const Pair& g = pairg[m];
+      P.hl = g.hl; P.ht = g.ht; P.hp = g.hp; P.blocks_per_row = g.B;
+      P.half_rows = g.H; P.rows_per_lane = g.rpl; P.pitch = g.pitch;
+      P.image_bytes = g.image_bytes; P.rounds_rot = g.rounds; P.pair_list_cap = g.cap;
+      P.task_cap = g.task_cap;
+      P.qimage = image_of[m];
+      P.image_build = build_image[m];
+    }
     h_params[m] = P;
-  }
+  });
   lap("fill");
   SmallCopyAsync(d_in, h_in, in_bytes, /*to_device=*/true, ws->stream);
   const Rt2DParams* d_params = reinterpret_cast<const Rt2DParams*>(d_in);
@@ -1210,10 +1923,55 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
                                  160 * 1024) == hipSuccess;
     }();
     CMX_REQUIRE(lds_opt_in, "cannot opt in to 160 KB of dynamic LDS");
-    CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
-    Rt2DBulkKernel<<<dim3(per_match_wgs, num), kBulkThreads, bulk_lds, ws->stream>>>(d_params);
+    if (use_pair) {
+      unsigned max_vecs = 0;
+      for (int m = 0; m < num; ++m) max_vecs = std::max<unsigned>(max_vecs, pairg[m].image_bytes >> 4);
+      bool any_build = false;
+      for (int m = 0; m < num; ++m) any_build = any_build || build_image[m];
+      if (any_build)
+        Rt2DImageKernel<<<dim3(DivUp(max_vecs, 256), num), 256, 0, ws->stream>>>(d_params);
+      CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
+      const dim3 grid(per_match_wgs, num);
+      const int rpl = pairg[0].rpl, stride = pairg[0].H * pairg[0].pitch;
+      const auto launch = [&](auto kernel) {
+        static thread_local const void* opted = nullptr;
+        const void* fn = reinterpret_cast<const void*>(kernel);
+        if (opted != fn) {
+          CMX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          opted = fn;
+        }
+        kernel<<<grid, kBulkThreads, pair_lds, ws->stream>>>(d_params);
+      };
+      if (rpl == 1) launch(Rt2DRowPairKernel<1, 0>);
+      else if (rpl == 2 && stride == 8 * 224) launch(Rt2DRowPairKernel<2, 8 * 224>);
+      else if (rpl == 2 && stride == 8 * 480) launch(Rt2DRowPairKernel<2, 8 * 480>);
+      else if (rpl == 2 && stride == 8 * 736) launch(Rt2DRowPairKernel<2, 8 * 736>);
+      else if (rpl == 2) launch(Rt2DRowPairKernel<2, 0>);
+      else if (rpl == 3) launch(Rt2DRowPairKernel<3, 0>);
+      else launch(Rt2DRowPairKernel<4, 0>);
+    } else {
+      CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
+      Rt2DBulkKernel<<<dim3(per_match_wgs, num), kBulkThreads, bulk_lds, ws->stream>>>(d_params);
+    }
     CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
-    Rt2DExactKernel<<<dim3(max_scans, num), 256, exact_lds, ws->stream>>>(d_params, exact_group);
+    {
+      // one workgroup per match (CMX_RT2D_EXACT_PER_ROTATION=1: the round-2 grid, for A/B runs)
+      const char* per_rot = getenv("CMX_RT2D_EXACT_PER_ROTATION");
+      if (!use_pair || (per_rot && per_rot[0] == '1')) {
+        Rt2DExactKernel<<<dim3(max_scans, num), 256, exact_lds, ws->stream>>>(d_params, exact_group);
+      } else {
+        const size_t lds = exact_lds + 4 * ((max_scans + 3) & ~3u) + 4 * static_cast<size_t>(kFinalistCap);
+        // (the kernel has a few static __shared__ words: ask for what it needs, not for all 160 KB)
+        static thread_local size_t exact_opted = 0;
+        if (lds > exact_opted) {
+          CMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(Rt2DExactMatchKernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(lds)));
+          exact_opted = lds;
+        }
+        Rt2DExactMatchKernel<<<dim3(num, kExactSplit), 1024, lds, ws->stream>>>(d_params, exact_group);
+      }
+    }
   } else if (tsdf) {
     Rt2DPrepKernel<true><<<prep_grid, 256, 0, ws->stream>>>(d_params);
     CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
@@ -1239,6 +1997,7 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
   SmallCopyAsync(h_misc, d_misc, sizeof(unsigned) * 128 * num, /*to_device=*/false, ws->stream);
   lap("enqueue");
   CMX_HIP(hipStreamSynchronize(ws->stream));
+  cache_locks.clear();                     // rebuilt images are complete
   lap("wait");
 
   if (d_timeline) {

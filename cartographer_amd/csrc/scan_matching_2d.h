@@ -3,6 +3,7 @@
 #define CMX_SCAN_MATCHING_2D_H_
 
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "cmx_common.h"
@@ -160,6 +161,19 @@ class Fast2DMatcher {
 // and nothing is ever freed on the hot path.
 std::shared_ptr<const std::vector<float2>> HostRotationTable(double step, int num_angular);
 
+// The staged image of a resident grid (rt_2d.hip, Rt2DImageKernel): quantised cells with the
+// zero halo and the row pitch the row-pair kernel copies into LDS as they are.  It depends on
+// the grid's cells (`version`, bumped by every insert / grow / crop) and on the window (nl);
+// a cmx_grid2d owns one and real-time matches against an unchanged grid reuse it.
+struct Rt2DImageCache {
+  std::mutex mutex;            // held by a call from its validity check until its build has completed
+  unsigned long long version = 0;   // grid version the image was built from (0: none)
+  int nl = -1, nx = 0, ny = 0, pitch = 0, hp = 0, image_bytes = 0;
+  uint16_t* image = nullptr;   // device
+  size_t capacity = 0;
+  ~Rt2DImageCache();
+};
+
 // RealTimeCorrelativeScanMatcher2D::Match (rt_2d.hip); see there.
 struct Rt2DItem {            // one match of a batch
   const cmx_grid2d_limits* limits;
@@ -172,6 +186,9 @@ struct Rt2DItem {            // one match of a batch
   int n;
   double* score;
   cmx_pose2d* pose;
+  const float* device_xyz = nullptr;      // the same cloud already in HBM (cmx_cloud): no upload
+  Rt2DImageCache* image_cache = nullptr;  // with device_cells of a cmx_grid2d
+  unsigned long long grid_version = 0;
 };
 void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int num, int32_t device,
                     cmx_match_stats* stats);

@@ -155,26 +155,40 @@ class Rt2DBatch:
     the initial pose estimates as an (n, 3) float64 array (x, y, theta) and returns
     (scores, poses as an (n, 3) array, stats)."""
 
-    def __init__(self, options, grids, point_clouds):
+    def __init__(self, options, grids, point_clouds, resident=False):
+        """resident=True: the scans are uploaded once (cmx_cloud) and every match() goes through
+        cmx_rt2d_match_grid_batch_resident; `point_clouds` may then also be PointCloudOnDevice."""
         if isinstance(options, RealTimeCorrelativeScanMatcher2D):
             options = options.options
         self.options = options
         self.num = len(grids)
         self._grids = list(grids)                                  # keep the handles alive
-        self._clouds = [_cloud(c)[0] for c in point_clouds]
         self._handles = (C.c_void_p * self.num)(*[g._h for g in grids])
-        self._cloud_ptrs = (C.c_void_p * self.num)(*[c.ctypes.data for c in self._clouds])
-        self._counts = np.array([c.shape[0] for c in self._clouds], np.int32)
         self._scores = np.zeros(self.num, np.float64)
         self._poses = np.zeros((self.num, 3), np.float64)          # cmx_pose2d[num]
         self._stats = MatchStats()
-        self._fn = _lib.lib().cmx_rt2d_match_grid_batch
+        self.resident = resident
+        if resident:
+            self._clouds = [c if isinstance(c, PointCloudOnDevice) else PointCloudOnDevice(c)
+                            for c in point_clouds]
+            self._cloud_ptrs = (C.c_void_p * self.num)(*[c._h for c in self._clouds])
+            self._fn = _lib.lib().cmx_rt2d_match_grid_batch_resident
+        else:
+            self._clouds = [_cloud(c)[0] for c in point_clouds]
+            self._cloud_ptrs = (C.c_void_p * self.num)(*[c.ctypes.data for c in self._clouds])
+            self._counts = np.array([c.shape[0] for c in self._clouds], np.int32)
+            self._fn = _lib.lib().cmx_rt2d_match_grid_batch
 
     def match(self, initial_pose_estimates):
         init = np.ascontiguousarray(initial_pose_estimates, np.float64).reshape(self.num, 3)
-        check(self._fn(C.byref(self.options), self._handles, self.num, init.ctypes.data,
-                       self._cloud_ptrs, self._counts.ctypes.data, self._scores.ctypes.data,
-                       self._poses.ctypes.data, C.byref(self._stats)))
+        if self.resident:
+            check(self._fn(C.byref(self.options), self._handles, self.num, init.ctypes.data,
+                           self._cloud_ptrs, self._scores.ctypes.data, self._poses.ctypes.data,
+                           C.byref(self._stats)))
+        else:
+            check(self._fn(C.byref(self.options), self._handles, self.num, init.ctypes.data,
+                           self._cloud_ptrs, self._counts.ctypes.data, self._scores.ctypes.data,
+                           self._poses.ctypes.data, C.byref(self._stats)))
         return self._scores, self._poses, self._stats.as_dict()
 
 

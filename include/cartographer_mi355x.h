@@ -195,6 +195,18 @@ cmx_status cmx_rt2d_match_grid_batch(const cmx_rt_options* options,
                                      const int32_t* num_points, double* scores,
                                      cmx_pose2d* pose_estimates, cmx_match_stats* stats);
 
+/* The same batch with the scans already in HBM (cmx_cloud_upload, declared below): per call
+ * only the initial poses, the per-scan rotation tables (libm, host) and the results cross PCIe.
+ * The grid's staged image (quantised cells + halo, what the kernel copies into LDS) is kept
+ * with the cmx_grid2d and rebuilt only after the grid changed. */
+typedef struct cmx_cloud cmx_cloud;
+cmx_status cmx_rt2d_match_grid_batch_resident(const cmx_rt_options* options,
+                                              const cmx_grid2d* const* grids,
+                                              int32_t num_matches,
+                                              const cmx_pose2d* initial_pose_estimates,
+                                              const cmx_cloud* const* clouds, double* scores,
+                                              cmx_pose2d* pose_estimates, cmx_match_stats* stats);
+
 /* ---- fast 2D (branch and bound) ---------------------------------------- */
 /* Uploads the grid and builds the PrecomputationGridStack2D on `device`
  * (SM2/fast_correlative_scan_matcher_2d.cc:171-186). */
@@ -235,7 +247,6 @@ cmx_status cmx_fast2d_match_batch(const cmx_fast2d* const* matchers, int32_t num
 
 /* Device-resident variant for throughput measurement: the point cloud is
  * uploaded once, repeated matches touch no host buffer except the results. */
-typedef struct cmx_cloud cmx_cloud;
 cmx_status cmx_cloud_upload(const float* point_cloud_xyz, int32_t num_points, int32_t device,
                             cmx_cloud** out);
 void cmx_cloud_destroy(cmx_cloud* cloud);

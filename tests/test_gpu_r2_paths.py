@@ -103,7 +103,14 @@ def test_fast2d_fused_and_unfused_batches_agree(sm, synth, c2, monkeypatch):
 # ----------------------------------------------------------------------------
 # Real-time 2D: bulk pass vs per-candidate kernels vs oracle
 # ----------------------------------------------------------------------------
-@pytest.mark.parametrize("bulk", ["1", "0"])
+def _rt2d_path(monkeypatch, path):
+    """'pair': row-pair bulk kernel (default); 'chunk': the round-2 chunked bulk kernel;
+    '0': one thread per candidate."""
+    monkeypatch.setenv("CMX_RT2D_BULK", "0" if path == "0" else "1")
+    monkeypatch.setenv("CMX_RT2D_ROWPAIR", "1" if path == "pair" else "0")
+
+
+@pytest.mark.parametrize("bulk", ["pair", "chunk", "0"])
 @pytest.mark.parametrize("seed,size,beams,lin,ang,weights", [
     (42, 200, 1000, 0.3, 7.0, (0.1, 0.1)),      # C1
     (7, 200, 400, 0.3, 7.0, (0.0, 0.0)),        # unweighted: ties resolved by generation order
@@ -111,10 +118,13 @@ def test_fast2d_fused_and_unfused_batches_agree(sm, synth, c2, monkeypatch):
     (3, 160, 250, 0.15, 10.0, (0.1, 5.0)),
     (5, 97, 61, 0.55, 1.0, (0.1, 0.1)),         # odd row length, 23 x 23 window: 3 lane slices
     (9, 64, 64, 0.0, 0.0, (0.1, 0.1)),          # the single-candidate window
+    (13, 150, 700, 0.1, 20.0, (0.1, 0.1)),      # trajectory_builder_2d.lua's own window: 5 x 5, B = 2
+    (17, 130, 333, 0.2, 6.0, (0.1, 0.1)),       # 9 x 9: B = 3, pitch a multiple of 8 only
+    (19, 110, 500, 0.4, 3.0, (0.1, 0.1)),       # 17 x 17: B = 5, three rows per lane
 ])
 def test_rt2d_both_paths(sm, oracle, synth, monkeypatch, bulk, seed, size, beams, lin, ang,
                          weights):
-    monkeypatch.setenv("CMX_RT2D_BULK", bulk)
+    _rt2d_path(monkeypatch, bulk)
     ny = size if size != 97 else 83
     cells, lim, world = synth.make_submap(seed, size, ny, 0.05, 20, 600, 5.0, 0.01)
     pose = world.free_pose(seed + 100, 0.5)
@@ -129,12 +139,12 @@ def test_rt2d_both_paths(sm, oracle, synth, monkeypatch, bulk, seed, size, beams
     np.testing.assert_allclose([est.x, est.y, est.theta], ref["pose"], rtol=0, atol=1e-12)
 
 
-@pytest.mark.parametrize("bulk", ["1", "0"])
+@pytest.mark.parametrize("bulk", ["pair", "chunk", "0"])
 def test_rt2d_points_outside_and_unknown_grid(sm, oracle, monkeypatch, bulk):
     """A cloud that mostly falls outside a small grid, on an all-unknown grid and on a
     random one: the flat landscape makes every candidate a finalist (more than the list
     holds: the bulk path hands the batch to the per-candidate kernels)."""
-    monkeypatch.setenv("CMX_RT2D_BULK", bulk)
+    _rt2d_path(monkeypatch, bulk)
     rng = np.random.default_rng(5)
     scan = np.zeros((130, 3), np.float32)
     scan[:, :2] = rng.uniform(-4.0, 4.0, (130, 2))
@@ -163,8 +173,8 @@ def test_rt2d_batch_on_resident_grids_both_paths(sm, oracle, synth, monkeypatch)
         scans.append(scan)
         refs.append(oracle.rt2d_match(cells, 0.05, lim["max_x"], lim["max_y"], init, scan, 0.3,
                                       math.radians(7.0), 0.1, 0.1))
-    for bulk in ("1", "0"):
-        monkeypatch.setenv("CMX_RT2D_BULK", bulk)
+    for bulk in ("pair", "chunk", "0"):
+        _rt2d_path(monkeypatch, bulk)
         scores, poses, stats = sm.rt2d_match_batch(m, grids, inits, scans)
         for k, ref in enumerate(refs):
             assert scores[k] == ref["score"], (bulk, k)
@@ -379,3 +389,70 @@ def test_c3_share_of_64_submaps_equals_the_single_searches(sm, synth, monkeypatc
             assert np.float32(s1) == np.float32(scores[i]), i
             assert (p1.x, p1.y, p1.theta) == tuple(poses[i]), i
     assert stats["coarse_candidates"] == coarse
+
+
+# ----------------------------------------------------------------------------
+# Round 3: scans resident in HBM, the grid's staged image cached with the grid
+# ----------------------------------------------------------------------------
+def test_rt2d_resident_batch_and_image_cache_follow_the_grid(sm, oracle, synth):
+    """cmx_rt2d_match_grid_batch_resident (clouds uploaded once) returns what the host-cloud
+    batch returns; the staged image a cmx_grid2d keeps for the row-pair kernel is rebuilt after
+    an insertion changed the cells (match -> insert -> match, each equal to the oracle on the
+    grid as it is then) and when the window changes."""
+    from cartographer_amd import grid_2d
+    m = sm.RealTimeCorrelativeScanMatcher2D(0.3, math.radians(7.0), 0.1, 0.1)
+    grids, hosts, inits, scans, worlds = [], [], [], [], []
+
+    def insert_scan(k, seed, beams):
+        at = worlds[k].free_pose(seed, 0.5)
+        pts = worlds[k].scan(at, beams, 5.0, 0.01, seed).astype(np.float64)
+        c, s = np.cos(at[2]), np.sin(at[2])
+        in_map = np.zeros((pts.shape[0], 3), np.float32)
+        in_map[:, 0] = at[0] + c * pts[:, 0] - s * pts[:, 1]
+        in_map[:, 1] = at[1] + s * pts[:, 0] + c * pts[:, 1]
+        grids[k].insert(at[:2], in_map)
+        hosts[k].insert(at[:2], in_map)
+
+    for k in range(6):
+        _, lim, world = synth.make_submap(80 + k, 200, 200, 0.05, 20, 600, 5.0, 0.01)
+        pose = world.free_pose(500 + k, 0.5)
+        scans.append(world.scan(pose, 700 + 13 * k, 5.0, 0.01, k))
+        inits.append([pose[0] + 0.1, pose[1] - 0.05, pose[2] + 0.04])
+        # the grid grows from the scans inserted into it, on the device and in the host mirror
+        grids.append(grid_2d.ProbabilityGridOnDevice(0.05, (lim["max_x"], lim["max_y"]), 200, 200))
+        hosts.append(synth.ProbabilityGrid(0.05, (lim["max_x"], lim["max_y"]), 200, 200))
+        worlds.append(world)
+        for j in range(5):
+            insert_scan(k, 600 + 10 * k + j, 400)
+        assert grids[k].limits == hosts[k].limits and np.array_equal(grids[k].cells, hosts[k].cells)
+    batch = sm.Rt2DBatch(m, grids, scans, resident=True)
+    plain = sm.Rt2DBatch(m, grids, scans)
+
+    def check_all():
+        s_res, p_res, _ = batch.match(np.array(inits))
+        s_res, p_res = s_res.copy(), p_res.copy()
+        s_host, p_host, _ = plain.match(np.array(inits))
+        np.testing.assert_array_equal(s_res, s_host)
+        np.testing.assert_array_equal(p_res, p_host)
+        for k in range(len(grids)):
+            hl = hosts[k].limits
+            ref = oracle.rt2d_match(hosts[k].cells, hl["resolution"], hl["max_x"], hl["max_y"],
+                                    inits[k], scans[k], 0.3, math.radians(7.0), 0.1, 0.1)
+            assert s_res[k] == ref["score"], k
+            np.testing.assert_allclose(p_res[k], ref["pose"], rtol=0, atol=1e-12)
+
+    check_all()
+    check_all()                                    # second call: every image comes from its cache
+    for k in (1, 4):                               # the cells of two grids change
+        insert_scan(k, 900 + k, 300)
+        assert np.array_equal(grids[k].cells, hosts[k].cells)
+    check_all()
+    # another window on the same grids: the cached geometry no longer fits
+    m2 = sm.RealTimeCorrelativeScanMatcher2D(0.1, math.radians(5.0), 0.1, 0.1)
+    s2, p2, _ = sm.Rt2DBatch(m2, grids, scans, resident=True).match(np.array(inits))
+    for k in range(len(grids)):
+        hl = hosts[k].limits
+        ref = oracle.rt2d_match(hosts[k].cells, hl["resolution"], hl["max_x"], hl["max_y"],
+                                inits[k], scans[k], 0.1, math.radians(5.0), 0.1, 0.1)
+        assert s2[k] == ref["score"], k
+    check_all()

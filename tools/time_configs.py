@@ -84,11 +84,14 @@ def c1b(cpu):
         G = [grids[i % len(grids)] for i in range(batch)]
         I = [inits[i % len(grids)] for i in range(batch)]
         S = [scans[i % len(grids)] for i in range(batch)]
-        dt, (scores, poses, st) = timeit(lambda: sm.rt2d_match_batch(m, G, I, S), 20)
-        print(f"C1 batch {batch:4d}: {dt * 1e6:8.1f} us / batch wall, device "
-              f"{st['device_ms'] * 1e3:7.1f} us, kernel {st['dominant_kernel_ms'] * 1e3:7.1f} us, "
-              f"{st['candidates_scored']} cand -> {st['candidates_scored'] / dt:.3e} cand/s wall, "
-              f"{st['candidates_scored'] / (st['dominant_kernel_ms'] * 1e-3):.3e} cand/s kernel")
+        init = np.array([[p.x, p.y, p.theta] for p in I])
+        for name, b in (("host clouds", sm.Rt2DBatch(m, G, S)),
+                        ("resident   ", sm.Rt2DBatch(m, G, S, resident=True))):
+            dt, (scores, poses, st) = timeit(lambda: b.match(init), 30, warm=3)
+            print(f"C1 batch {batch:4d} {name}: {dt * 1e6:8.1f} us / batch wall, device "
+                  f"{st['device_ms'] * 1e3:7.1f} us, kernel {st['dominant_kernel_ms'] * 1e3:7.1f} us, "
+                  f"{st['candidates_scored']} cand -> {st['candidates_scored'] / dt:.3e} cand/s wall, "
+                  f"{st['candidates_scored'] / (st['dominant_kernel_ms'] * 1e-3):.3e} cand/s kernel")
 
 
 def c4(cpu, rings=64, az=1024):
