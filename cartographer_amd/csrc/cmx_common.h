@@ -69,7 +69,7 @@ void UseDevice(int device);
 // tables, staging copies: ~2 us per item, serial host time that used to exceed the device time
 // of a 128-match batch several times over).  fn(i) runs for i in [0, n) on the calling thread
 // and on a small pool of persistent workers (CMX_HOST_THREADS, default min(16, cores / 2));
-// workers spin for ~200 us after a job before they sleep, so back-to-back calls pay no wake-up.
+// workers spin for 500 us (CMX_HOST_SPIN_US) after a job before they sleep, so back-to-back calls pay no wake-up.
 // n below `serial_below` runs inline.  fn must not throw across threads: the first exception
 // is captured and rethrown on the caller.  Nested calls run inline.
 void ParallelFor(int n, int serial_below, const std::function<void(int)>& fn);
@@ -132,7 +132,7 @@ class PinnedBuffer {
 // chain of launches on one stream, and a copy command in that chain costs 10-15 us of engine
 // start-up where a launch costs 3-4.  Falls back to hipMemcpyAsync above `kCopyKernelMaxBytes`
 // or with CMX_COPY_KERNELS=0.  `pinned` is the host side (source for to_device, else target).
-constexpr size_t kCopyKernelMaxBytes = 64 * 1024;
+constexpr size_t kCopyKernelMaxBytes = 1024 * 1024;   // one workgroup per 64 KB
 void SmallCopyAsync(void* dst, const void* src, size_t bytes, bool to_device, hipStream_t stream);
 
 // Everything one in-flight call needs; handed out by a per-device pool so

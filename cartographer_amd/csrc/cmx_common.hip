@@ -103,6 +103,7 @@ class HostPool {
     if (const char* e = getenv("CMX_HOST_THREADS")) want = atoi(e);
     if (want <= 0) want = std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 2));
     num_workers_ = want - 1;
+    if (const char* e = getenv("CMX_HOST_SPIN_US")) spin_us_ = std::max(0, atoi(e));
     for (int t = 0; t < num_workers_; ++t) std::thread([this] { WorkerLoop(); }).detach();
   }
   static void Work(Job* job) {
@@ -129,7 +130,7 @@ class HostPool {
         if (generation_.load(std::memory_order_acquire) != seen) { have = true; break; }
         __builtin_ia32_pause();
         if ((spins & 1023) == 1023 &&
-            std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200))
+            std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us_))
           break;
       }
       if (!have) {
@@ -146,6 +147,7 @@ class HostPool {
   }
 
   int num_workers_ = 0;
+  int spin_us_ = 500;          // how long an idle worker spins before it sleeps
   std::mutex job_mutex_, sleep_mutex_;
   std::condition_variable sleep_cv_;
   int sleepers_ = 0;
@@ -202,8 +204,12 @@ __global__ void __launch_bounds__(1024)
 SmallCopyKernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t words16,
                 unsigned char* __restrict__ dst_tail, const unsigned char* __restrict__ src_tail,
                 int tail_bytes) {
-  for (size_t i = threadIdx.x; i < words16; i += blockDim.x) dst[i] = src[i];
-  if (static_cast<int>(threadIdx.x) < tail_bytes) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+  // (several workgroups for transfers beyond 64 KB: each takes a contiguous share)
+  const size_t per_block = (words16 + gridDim.x - 1) / gridDim.x;
+  const size_t begin = blockIdx.x * per_block, end = min(words16, begin + per_block);
+  for (size_t i = begin + threadIdx.x; i < end; i += blockDim.x) dst[i] = src[i];
+  if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail_bytes)
+    dst_tail[threadIdx.x] = src_tail[threadIdx.x];
 }
 }  // namespace
 
@@ -220,7 +226,7 @@ void SmallCopyAsync(void* dst, const void* src, size_t bytes, bool to_device, hi
   }
   const size_t words16 = bytes / 16;
   const int tail = static_cast<int>(bytes - words16 * 16);
-  SmallCopyKernel<<<1, 1024, 0, stream>>>(
+  SmallCopyKernel<<<static_cast<unsigned>((bytes + 65535) / 65536), 1024, 0, stream>>>(
       static_cast<uint4*>(dst), static_cast<const uint4*>(src), words16,
       static_cast<unsigned char*>(dst) + words16 * 16,
       static_cast<const unsigned char*>(src) + words16 * 16, tail);

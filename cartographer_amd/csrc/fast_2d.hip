@@ -2820,6 +2820,18 @@ cmx_status cmx_cloud_upload(const float* point_cloud_xyz, int32_t num_points, in
       m = std::max(m, std::sqrt(x * x + y * y + z * z));
     }
     c->max_range_xyz = m;
+    {
+      double best = 0.;
+      for (int i = 0; i < num_points; ++i) {
+        const double x = point_cloud_xyz[3 * i], y = point_cloud_xyz[3 * i + 1];
+        best = std::max(best, x * x + y * y);
+      }
+      for (int i = 0; i < num_points && c->far_points.size() <= 64; ++i) {
+        const double x = point_cloud_xyz[3 * i], y = point_cloud_xyz[3 * i + 1];
+        if (x * x + y * y >= best * (1. - 1e-4)) c->far_points.push_back(i);
+      }
+      if (c->far_points.size() > 64) c->far_points.clear();
+    }
     CMX_HIP(hipMalloc(&c->xyz, 3 * sizeof(float) * num_points));
     hipError_t err = hipMemcpy(c->xyz, point_cloud_xyz, 3 * sizeof(float) * num_points,
                                hipMemcpyHostToDevice);

@@ -521,6 +521,10 @@ extern "C" cmx_status cmx_rt2d_match_grid_batch_resident(const cmx_rt_options* o
       item.initial = &initial_pose_estimates[m];
       item.xyz = c->host_xyz.data();          // the range scan of SearchParameters runs on the host
       item.device_xyz = c->xyz;
+      if (!c->far_points.empty()) {
+        item.far_points = c->far_points.data();
+        item.num_far_points = static_cast<int>(c->far_points.size());
+      }
       item.n = c->num_points;
       item.score = &scores[m];
       item.pose = &pose_estimates[m];

@@ -1555,6 +1555,7 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
     pl.n = it.n; pl.nx = it.limits->num_x_cells; pl.ny = it.limits->num_y_cells;
     pl.res = it.limits->resolution;
   }
+  lap("args");
   // SearchParameters of every item (a range scan over its cloud, acos): on the host pool.
   ParallelFor(num, 8, [&](int m) {
     const Rt2DItem& it = items[m];
@@ -1581,6 +1582,13 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
       return rx * rx + ry * ry;
     };
     int i = 0;
+    if (it.far_points) {            // only these points can hold the f32 maximum (cmx_cloud)
+      for (int k = 0; k < it.num_far_points; ++k) {
+        const int idx = it.far_points[k];
+        max_sq[0] = std::max(max_sq[0], squared_range(it.xyz[3 * idx], it.xyz[3 * idx + 1]));
+      }
+      i = n;
+    }
     for (; i + kLanes <= n; i += kLanes) {
       float px[kLanes], py[kLanes];
       for (int k = 0; k < kLanes; ++k) { px[k] = it.xyz[3 * (i + k)]; py[k] = it.xyz[3 * (i + k) + 1]; }
@@ -1597,6 +1605,7 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
     pl.na = std::ceil(options->angular_search_window / pl.step);
     pl.q0w = q0w; pl.q0z = q0z;
   });
+  lap("range");
   for (int m = 0; m < num; ++m) {
     const Rt2DItem& it = items[m];
     Plan& pl = plan[m];
@@ -1699,18 +1708,22 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
     g.hp = pl.ny + g.ht + g.rpl * g.H;
     const int min_pitch = (2 * (pl.nx + g.hl + 4 * g.B) + 7) & ~7;
     g.pitch = 0;
-    for (int cand = min_pitch; cand < min_pitch + 512; cand += 8) {
-      // conflict-free: the H x B 8-byte blocks of a half-wavefront touch 2 H B distinct banks
-      unsigned long long used = 0;
-      bool ok = true;
-      for (int r = 0; r < g.H && ok; ++r)
-        for (int b = 0; b < g.B && ok; ++b)
-          for (int w = 0; w < 2; ++w) {
-            const int bank = ((r * cand + b * 8) / 4 + w) & 63;
-            if (used >> bank & 1) ok = false;
-            used |= 1ull << bank;
-          }
-      if (ok) { g.pitch = cand; break; }
+    if (m > 0 && plan[m - 1].nx == pl.nx && plan[m - 1].nl == pl.nl) {
+      g.pitch = pairg[m - 1].pitch;           // same geometry as the previous item (the usual batch)
+    } else {
+      for (int cand = min_pitch; cand < min_pitch + 512; cand += 8) {
+        // conflict-free: the H x B 8-byte blocks of a half-wavefront touch 2 H B distinct banks
+        unsigned long long used = 0;
+        bool ok = true;
+        for (int r = 0; r < g.H && ok; ++r)
+          for (int b = 0; b < g.B && ok; ++b)
+            for (int w = 0; w < 2; ++w) {
+              const int bank = ((r * cand + b * 8) / 4 + w) & 63;
+              if (used >> bank & 1) ok = false;
+              used |= 1ull << bank;
+            }
+        if (ok) { g.pitch = cand; break; }
+      }
     }
     g.image_bytes = (g.hp * g.pitch + 16 + 1023) & ~1023;        // whole KiB: LDS-DMA granule
     g.cap = pl.n_pad + 4 * 16;

@@ -187,6 +187,8 @@ struct Rt2DItem {            // one match of a batch
   double* score;
   cmx_pose2d* pose;
   const float* device_xyz = nullptr;      // the same cloud already in HBM (cmx_cloud): no upload
+  const int* far_points = nullptr;        // cmx_cloud::far_points (null: scan the whole cloud)
+  int num_far_points = 0;
   Rt2DImageCache* image_cache = nullptr;  // with device_cells of a cmx_grid2d
   unsigned long long grid_version = 0;
 };
@@ -211,6 +213,13 @@ struct cmx_cloud {
   float max_range_xy = 0.f;      // max ||p.xy|| (f32, as SearchParameters computes it)
   float max_range_xyz = 0.f;
   std::vector<float> host_xyz;
+  // Indices of the points whose exact squared xy range is within 1e-4 (relative) of the largest.
+  // The real-time matcher needs max ||R p|| over the cloud rotated by the initial yaw, EVALUATED IN
+  // f32 (SearchParameters, SM2/correlative_scan_matcher_2d.cc:27-36): that value differs from
+  // the exact ||p||^2 by less than 2e-6 relative (ten roundings and |q|^2 = 1 +- 2e-7), so only
+  // these points can produce the maximum -- the per-match range scan shrinks from n points
+  // to a handful.  Empty: more than 64 candidates (scan everything).
+  std::vector<int> far_points;
 };
 
 #endif  // CMX_SCAN_MATCHING_2D_H_
