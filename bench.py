@@ -42,6 +42,7 @@ L2_PEAK_GBS = 34500.0        # aggregate L2 -> L1
 LDS_PEAK_GBS = 150000.0      # ds_read_b64/b128, every CU streaming
 
 C3_SUBMAPS_PER_GPU = 64      # 512 submaps over the 8 GPUs of BASELINE config[2]
+C5_SUBMAPS_PER_GPU = 32      # 256 submaps over the 8 GPUs of BASELINE config[4]
 C3_POSITIVE = 137            # the scan is drawn from submap #137
 
 
@@ -65,16 +66,22 @@ def parse_args():
     ap.add_argument("--no-other", action="store_true",
                     help="skip the C1 / C3-share / C4 / C5 measurements reported under config.other")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--concurrency", type=int, default=1,
-                    help="host threads issuing steps concurrently (the reference's thread-pool "
-                         "fan-out over independent searches, constraint_builder_2d.cc:97-111); "
-                         "the C ABI is re-entrant: every call leases its own stream + scratch")
+    ap.add_argument("--concurrency", type=int, default=0,
+                    help="host threads issuing the passes of a step concurrently (the reference's "
+                         "thread-pool fan-out over independent searches, "
+                         "constraint_builder_2d.cc:97-111); the C ABI is re-entrant: every call "
+                         "leases its own stream + scratch.  0 = auto: 8 for c2 on one GPU (a single "
+                         "search is a latency chain that fills a fraction of the chip), else 1")
+    ap.add_argument("--passes-per-step", type=int, default=0,
+                    help="passes of the hot path that make one step (a step is one pass over a "
+                         "BATCH of searches).  0 = auto: calibrated during warmup so that a step "
+                         "lasts >= 30 ms -- the driver's 20 timed steps are then >= 0.6 s, not 3 ms")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the collectives even with one rank (plumbing test)")
     ap.add_argument("--pmc-dir", default=os.path.join(ROOT, "profiles"),
                     help="directory with <tag>_pmc_{fetch,write}_size.csv of THIS command "
                          "(tools/profile_bench.sh writes them); roofline.traffic is null without")
-    ap.add_argument("--pmc-tag", default="r02e")
+    ap.add_argument("--pmc-tag", default="r03")
     return ap.parse_args()
 
 
@@ -196,6 +203,100 @@ def cpu_baseline(cells, lim, depth, scan, min_score, seconds):
     }
 
 
+def _timed_threads(fn, cores, seconds, max_rounds=64):
+    """Rounds of `cores` concurrent calls of fn() (ctypes releases the GIL) until `seconds` have
+    elapsed; returns (calls, elapsed)."""
+    from concurrent.futures import ThreadPoolExecutor
+    calls = 0
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        while True:
+            list(pool.map(lambda _: fn(), range(cores)))
+            calls += cores
+            dt = time.perf_counter() - t0
+            if dt >= seconds or calls >= max_rounds * cores:
+                return calls, dt
+
+
+def cpu_baseline_c1(w, seconds):
+    """BASELINE config[0] is the reference's own CPU case: its real_time_correlative_scan_matcher_2d.cc
+    (oracle/_ref) on the scans and grids the device batch matches, one Match per host thread."""
+    from oracle import pyoracle as orc
+    if orc.ref_lib() is None:
+        return None
+    cores = _cores()
+    g, lim, scan, init = w.host_cells[0], w.host_lims[0], w.S[0], w.I[0]
+    call = lambda: orc.ref_rt2d_match(g, lim["resolution"], lim["max_x"], lim["max_y"],  # noqa: E731
+                                      [init.x, init.y, init.theta], scan, 0.3, math.radians(7.0),
+                                      0.1, 0.1)
+    t0 = time.perf_counter()
+    call()
+    t_one = time.perf_counter() - t0
+    calls, dt = _timed_threads(call, cores, seconds)
+    per_match = w.candidates_per_match
+    return {"value": calls * per_match / dt, "unit": "candidates/s", "cores": cores,
+            "kind": "reference", "matches_per_s": calls / dt,
+            "single_thread_candidates_per_s": per_match / t_one,
+            "sample": f"{calls} Match calls of the C1 workload by the reference's own "
+                      f"real_time_correlative_scan_matcher_2d.cc (oracle/_ref), {per_match} "
+                      f"candidates each, {cores} threads, {dt:.1f} s"}
+
+
+def cpu_baseline_c4(w, seconds):
+    """C4: the reference's real_time_correlative_scan_matcher_3d.cc over a contiguous RANGE of
+    the 1 771 561 candidates (the whole search space is ten minutes on 8 cores: bounded sample,
+    candidates/s extrapolates linearly -- every candidate costs the same 65 536 lookups)."""
+    from oracle import pyoracle as orc
+    if orc.ref_lib() is None:
+        return None
+    cores = _cores()
+    init = list(w.init.translation) + list(w.init.rotation)
+    sample = 64 * cores
+    t0 = time.perf_counter()
+    total = 0
+    while True:
+        r = orc.ref_rt3d_match_mt(0.1, w.vox, init, w.cloud, 0.5, math.radians(2.0), 0.1, 0.1,
+                                  cores, first_candidate=total, max_candidates=sample)
+        total += sample
+        dt = time.perf_counter() - t0
+        if dt >= seconds or total >= r["num_candidates"]:
+            break
+    return {"value": total / dt, "unit": "candidates/s", "cores": cores, "kind": "reference",
+            "matches_per_s": total / dt / r["num_candidates"],
+            "sample": f"{total} of the {r['num_candidates']} candidates of the C4 search (generation "
+                      f"order, from the first) scored by the reference's own "
+                      f"real_time_correlative_scan_matcher_3d.cc (oracle/_ref: "
+                      f"TransformPointCloud + ScoreCandidate per candidate), {cores} threads, "
+                      f"{dt:.1f} s; a whole match would take {r['num_candidates'] / (total / dt):.0f} s"}
+
+
+def cpu_baseline_c5(w, seconds):
+    """C5: the reference's fast_correlative_scan_matcher_3d.cc (stack built once, outside the timed
+    sample) matching the bench node against submap #0, one Match per host thread."""
+    from oracle import pyoracle as orc
+    if orc.ref_lib() is None:
+        return None
+    cores = _cores()
+    o = w.opt
+    m = orc.ReferenceFastCorrelativeScanMatcher3D(
+        0.1, w.vox, 0.45, w.low_vox, w.hist, o["branch_and_bound_depth"],
+        o["full_resolution_depth"], o["min_rotational_score"], o["min_low_resolution_score"],
+        o["linear_xy_search_window"], o["linear_z_search_window"], o["angular_search_window"])
+    node = list(w.node.translation) + list(w.node.rotation)
+    call = lambda: m.match(node, [0, 0, 0, 1, 0, 0, 0], [1, 0, 0, 0], w.hi, w.lo,   # noqa: E731
+                           w.scan_hist, 0.2)
+    t0 = time.perf_counter()
+    one = call()
+    t_one = time.perf_counter() - t0
+    calls, dt = _timed_threads(call, cores, seconds, max_rounds=16)
+    return {"value": calls / dt, "unit": "matches/s", "cores": cores, "kind": "reference",
+            "matches_per_s": calls / dt, "single_thread_match_s": t_one,
+            "found": bool(one["found"]),
+            "sample": f"{calls} Match calls of the C5 node against submap #0 by the reference's own "
+                      f"fast_correlative_scan_matcher_3d.cc (oracle/_ref; precomputation stack built "
+                      f"beforehand), {cores} threads, {dt:.1f} s"}
+
+
 # --------------------------------------------------------------------------------------
 # Workloads.  Each exposes step() -> stats dict (candidates_scored, coarse_candidates,
 # dominant_kernel_ms, device_ms, num_scans, nodes_expanded + workload keys), describe(),
@@ -236,14 +337,21 @@ class Fast2DWorkload:
         pose = truth.free_pose(1234, 0.5)
         self.scan = truth.scan(pose, args.beams, 30.0, 0.01, 7)
         self.cloud = sm.PointCloudOnDevice(self.scan, device=device)
+        # A step is a batch of passes: pass k searches with scan k mod 8 (eight scans taken at
+        # different poses of the same world, resident in HBM like the first).
+        self.clouds = [self.cloud]
+        for k in range(1, 8):
+            sk = truth.scan(truth.free_pose(1234 + k, 0.5), args.beams, 30.0, 0.01, 7 + k)
+            self.clouds.append(sm.PointCloudOnDevice(sk, device=device))
         self.n_points = self.scan.shape[0]
         self.matches_per_step = len(self.matchers)
         self.positive = positive
         self.gathered = None
         self.best = None
 
-    def search(self):
-        return self.sm.match_full_submap_batch(self.matchers, self.cloud, self.args.min_score)
+    def search(self, k=0):
+        return self.sm.match_full_submap_batch(self.matchers, self.clouds[k % len(self.clouds)],
+                                               self.args.min_score)
 
     def exchange(self, found, scores, poses, torch_device):
         """What crosses xGMI per step: every submap's optional constraint to every rank (the
@@ -336,6 +444,7 @@ class Rt2DWorkload:
                                                      device=device)
         batch = matches or args.matches
         grids, inits, scans = [], [], []
+        self.host_cells, self.host_lims = [], []
         for k in range(min(batch, 8)):          # 8 distinct worlds, reused round-robin
             cells, lim, world = synth.make_submap(42 + k, 200, 200, 0.05, 30, 1000, 5.0, 0.01)
             pose = world.free_pose(1234, 0.5)
@@ -343,19 +452,23 @@ class Rt2DWorkload:
                                                          200, cells=cells))
             scans.append(world.scan(pose, args.beams, 5.0, 0.01, 7))
             inits.append(sm.Rigid2d(pose[0] + 0.12, pose[1] - 0.08, pose[2] + math.radians(3.0)))
+            self.host_cells.append(cells)
+            self.host_lims.append(lim)
+        self.candidates_per_match = 27 * 13 * 13      # re-read from the first search's stats
         self.G = [grids[i % len(grids)] for i in range(batch)]
         self.I = [inits[i % len(grids)] for i in range(batch)]
         self.S = [scans[i % len(grids)] for i in range(batch)]
         # Argument arrays built once, as a C++ caller holds them (the python marshalling of
         # 128 poses and pointers per call cost more than the device work).
-        self.batch = sm.Rt2DBatch(self.m, self.G, self.S)
+        self.batch = sm.Rt2DBatch(self.m, self.G, self.S, resident=True)   # scans uploaded once
         self.init = np.array([[p.x, p.y, p.theta] for p in self.I], np.float64)
         self.points = float(np.mean([len(s) for s in self.S]))
         self.matches_per_step = batch
         self.n_points = int(self.points)
 
-    def search(self):
+    def search(self, k=0):
         scores, poses, stats = self.batch.match(self.init)
+        self.candidates_per_match = stats["candidates_scored"] // self.matches_per_step
         return np.ones(len(scores), np.int32), scores, poses, stats
 
     def describe(self, stats, found):
@@ -366,26 +479,28 @@ class Rt2DWorkload:
                 "matches_per_step": self.matches_per_step}
 
     def roofline(self, acc, steps, pmc):
-        """Integer bulk kernel: the grid is staged in LDS, a lane fetches an aligned 4-cell block
-        of one window row with one ds_read_b64 (8 B) per point.  C1: 13 x 13 window = 13 rows x 4
-        blocks = 52 lanes, 416 B of LDS reads per (rotation, point) serving 169 candidates.
-        Algorithmic bytes: 2 B per candidate per point."""
+        """Row-pair bulk kernel: the grid image sits in LDS; a HALF-wavefront is one stream of
+        points, a lane fetches aligned 4-cell blocks (8 B) of two window rows per point.  C1:
+        13 x 13 window -> 8 row slots x 4 blocks x 2 rows = 512 B of ds_read_b64 per (rotation,
+        point) serving 169 candidates.  Algorithmic bytes: 2 B per candidate per
+        point."""
         k_ms = acc["dominant_kernel_ms"] / steps
         cand = acc["candidates_scored"] / steps
         secs = max(k_ms, 1e-9) * 1e-3
         alg = cand * self.points * 2.0
         side = 13
-        lds = cand / (side * side) * self.points * (side * ((side + 6) // 4)) * 8.0
-        return {"kernel": "Rt2DBulkKernel (LDS-staged grid, packed 16-bit sums)", "bound": "lds",
-                "achieved": lds / secs / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
+        lds = cand / (side * side) * self.points * 512.0
+        return {"kernel": "Rt2DRowPairKernel (LDS-resident grid image, packed 16-bit sums)",
+                "bound": "lds", "achieved": lds / secs / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
                 "frac": lds / secs / 1e9 / LDS_PEAK_GBS,
-                "traffic": pmc("Rt2DBulk", "c1") if self.matches_per_step == 128 else None,
+                "traffic": pmc("Rt2DRowPair", "c1") if self.matches_per_step == 128 else None,
                 "kernel_ms": k_ms, "algorithmic_bytes": alg, "lds_bytes": lds,
                 "algorithmic_GBps": alg / secs / 1e9,
                 "hbm_frac_algorithmic": alg / secs / 1e9 / HBM_PEAK_GBS,
                 "candidates_per_s_kernel": cand / secs,
-                "note": "frac = LDS bytes read by the bulk kernel / kernel time / 150 TB/s "
-                        "(ds_read_b64 aggregate); hbm_frac_algorithmic > 1 means on-chip residency"}
+                "note": "frac = LDS bytes read by the bulk kernel's window reads / kernel time "
+                        "(discretisation and list building included) / 150 TB/s (ds_read_b64 "
+                        "aggregate); hbm_frac_algorithmic > 1 means on-chip residency"}
 
 
 class Rt3DWorkload:
@@ -403,7 +518,7 @@ class Rt3DWorkload:
         self.matches_per_step = 1
         self.n_points = len(self.cloud)
 
-    def search(self):
+    def search(self, k=0):
         score, est = self.m.match(self.init, self.cloud, 0.1, self.vox)
         return np.ones(1, np.int32), np.array([score], np.float32), [est], self.m.last_stats
 
@@ -456,9 +571,10 @@ class Fast3DWorkload:
     """C5, one GPU's share: hi 0.1 m / low 0.45 m, depth 8 / full-resolution depth 3,
     pose_graph.lua windows; `--submaps` pairs per step through cmx_fast3d_match_batch."""
 
-    def __init__(self, args, device, pairs=None):
-        from cartographer_amd import scan_matching_3d as sm3, synth
-        self.sm3 = sm3
+    def __init__(self, args, device, pairs=None, rank=0, world_size=1, sharded=False):
+        from cartographer_amd import scan_matching_3d as sm3, sharding, synth
+        self.sm3, self.sharding = sm3, sharding
+        self.rank, self.world_size, self.sharded = rank, world_size, sharded
         size = (15.0, 15.0, 7.5)
         grid, world = synth.make_submap_3d(42, 0.1, size, 8, 32, 512)
         low, _ = synth.make_submap_3d(42, 0.45, size, 8, 32, 512)
@@ -475,30 +591,53 @@ class Fast3DWorkload:
         opt = dict(branch_and_bound_depth=8, full_resolution_depth=3, min_rotational_score=0.77,
                    min_low_resolution_score=0.35, linear_xy_search_window=5.0,
                    linear_z_search_window=1.0, angular_search_window=math.radians(15.0))
-        self.gm = sm3.FastCorrelativeScanMatcher3D(0.1, vox, grid.grid_size, 0.45, low_vox, hist,
-                                                   **opt)
+        self.vox, self.low_vox, self.hist, self.opt = vox, low_vox, hist, opt   # (cpu baseline)
+        self.scan_hist = scan_hist
         self.node = sm3.Rigid3d((pos[0] + 0.8, pos[1] - 0.6, pos[2] + 0.2),
                                 (math.cos((yaw + 0.1) / 2), 0.0, 0.0, math.sin((yaw + 0.1) / 2)))
         self.data = sm3.TrajectoryNodeData(self.hi, self.lo, scan_hist)
-        self.pairs = pairs or args.submaps or 1
+        self.pairs = pairs or args.submaps or (C5_SUBMAPS_PER_GPU if sharded else 1)
+        self.total = self.pairs * world_size
+        self.begin = rank * self.pairs                 # equal blocks: shard_range of `total`
         self.matches_per_step = self.pairs
+        self.gathered = self.best = None
         self.n_points = len(self.hi)
         # A batch is one node against DISTINCT submaps (C5: 256 over 8 GPUs = 32 per GPU), each
         # with its own grids and stack in HBM (~110 MB); the node was recorded in submap #0's
         # world, the others are the negatives a loop-closure search mostly meets.  They share
         # the histogram so that every pair passes the yaw pre-filter and is searched in full.
-        self.matchers = [self.gm]
-        for k in range(1, self.pairs):
-            g, _ = synth.make_submap_3d(42 + k, 0.1, size, 8, 32, 512)
-            lw, _ = synth.make_submap_3d(42 + k, 0.45, size, 8, 32, 512)
+        # (sharded over N GPUs: rank r owns submaps r * pairs ... ; the node comes from #0's world)
+        self.matchers = []
+        if self.begin == 0:
+            self.matchers.append(sm3.FastCorrelativeScanMatcher3D(0.1, vox, grid.grid_size, 0.45,
+                                                                  low_vox, hist, **opt))
+        for gid in range(self.begin + len(self.matchers), self.begin + self.pairs):
+            g, _ = synth.make_submap_3d(42 + gid, 0.1, size, 8, 32, 512)
+            lw, _ = synth.make_submap_3d(42 + gid, 0.45, size, 8, 32, 512)
             self.matchers.append(sm3.FastCorrelativeScanMatcher3D(
                 0.1, g.voxels(), g.grid_size, 0.45, lw.voxels(), hist, **opt))
 
-    def search(self):
+    def exchange(self, found, scores, results, torch_device):
+        """Every submap's optional constraint to every rank (9 words per submap) + the node-wide
+        best match (all-reduce(max) of the packed key), as in 2D."""
+        sh = self.sharding
+        rows = np.zeros((self.pairs, 9), np.float64)
+        for i, r in enumerate(results):
+            if r is not None:
+                rows[i, 0] = 1.0
+                rows[i, 1] = float(np.float32(r["score"]))
+                rows[i, 2:5] = r["pose_estimate"].translation
+                rows[i, 5:9] = r["pose_estimate"].rotation
+        self.gathered = sh.all_gather_rows(rows, self.total, self.rank, self.world_size,
+                                           device=torch_device)
+        self.best = sh.unpack_best_key(sh.all_reduce_best(
+            sh.pack_best_key(found, scores, self.begin), device=torch_device))
+
+    def search(self, k=0):
         sm3 = self.sm3
-        if self.pairs == 1:
-            got = self.gm.match(self.node, sm3.Rigid3d(), self.data, 0.2)
-            stats = self.gm.last_stats
+        if self.pairs == 1 and not self.sharded:
+            got = self.matchers[0].match(self.node, sm3.Rigid3d(), self.data, 0.2)
+            stats = self.matchers[0].last_stats
             found = np.array([got is not None], np.int32)
             scores = np.array([got["score"] if got else 0.0], np.float32)
             return found, scores, [got], stats
@@ -510,12 +649,18 @@ class Fast3DWorkload:
         return found, scores, results, stats
 
     def describe(self, stats, found):
-        return {"workload": f"C5: 3D FastCorrelativeScanMatcher Match, one node against {self.pairs} "
-                            f"distinct submap(s) per step (seeds 42..{41 + self.pairs}, the node from "
-                            f"#0's world), 150^3 hi-res 0.1 m + low-res 0.45 m grids, depth 8 / "
-                            f"full-resolution depth 3, {self.n_points} hi-res points",
-                "pairs_per_step": self.pairs, "found": int(np.sum(found)),
-                "nodes_expanded_per_step": stats["nodes_expanded"]}
+        out = {"workload": f"C5: 3D FastCorrelativeScanMatcher Match, one node against {self.total} "
+                           f"distinct submap(s) per step (seeds 42..{41 + self.total}, the node from "
+                           f"#0's world)" + (f", submap-sharded over {self.world_size} GPU(s), "
+                                             f"{self.pairs} per GPU" if self.sharded else "") +
+                           f", 150^3 hi-res 0.1 m + low-res 0.45 m grids, depth 8 / "
+                           f"full-resolution depth 3, {self.n_points} hi-res points",
+               "pairs_per_step": self.pairs, "submaps_per_gpu": self.pairs,
+               "found": int(np.sum(found)), "nodes_expanded_per_step": stats["nodes_expanded"]}
+        if self.gathered is not None:
+            out["constraints_found_node_wide"] = int(np.sum(self.gathered[:, 0]))
+            out["best_match"] = {"score": self.best[0], "submap": self.best[1]}
+        return out
 
     def roofline(self, acc, steps, pmc):
         k_ms = acc["dominant_kernel_ms"] / steps
@@ -571,7 +716,8 @@ def make_workload(name, args, device, rank, world_size):
         return Rt2DWorkload(args, device)
     if name == "c4":
         return Rt3DWorkload(args, device)
-    return Fast3DWorkload(args, device)
+    return Fast3DWorkload(args, device, rank=rank, world_size=world_size,
+                          sharded=world_size > 1 or args.force_dist)
 
 
 STAT_KEYS = ("candidates_scored", "coarse_candidates", "dominant_kernel_ms", "device_ms",
@@ -629,12 +775,17 @@ def other_configs(args, device, sync, pmc):
     raised: the headline must not depend on them."""
     out = {}
 
-    def run(name, factory, steps, warmup):
+    def run(name, factory, steps, warmup, cpu_leg=None):
         try:
             t0 = time.perf_counter()
             w = factory()
             dt, acc, last = measure(w, steps, warmup, sync)
             entry = w.describe(last[3], last[0])
+            if cpu_leg is not None:
+                try:
+                    entry["cpu_baseline"] = cpu_leg(w)
+                except Exception as e:      # noqa: BLE001
+                    entry["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
             entry.update({
                 "ms_per_step": dt / steps * 1e3,
                 "candidates_per_s": acc["candidates_scored"] / dt,
@@ -647,49 +798,19 @@ def other_configs(args, device, sync, pmc):
         except Exception as e:      # noqa: BLE001
             out[name] = {"error": f"{type(e).__name__}: {e}"}
 
+    cpu = {} if args.no_cpu_baseline else {
+        "c1_batch128": lambda w: cpu_baseline_c1(w, min(3.0, args.cpu_seconds)),
+        "c4": lambda w: cpu_baseline_c4(w, min(6.0, args.cpu_seconds)),
+        "c5_single": lambda w: cpu_baseline_c5(w, min(5.0, args.cpu_seconds))}
     run("c1_single", lambda: Rt2DWorkload(args, device, matches=1), 200, 50)
-    run("c1_batch128", lambda: Rt2DWorkload(args, device, matches=128), 30, 5)
+    run("c1_batch128", lambda: Rt2DWorkload(args, device, matches=128), 100, 10, cpu.get("c1_batch128"))
     sub = argparse.Namespace(**vars(args))
     sub.submaps = 16
     run("c3_share_16_submaps", lambda: Fast2DWorkload(sub, device, 0, 1, sharded=True), 5, 2)
-    run("c4", lambda: Rt3DWorkload(args, device), 2, 1)
-    run("c5_single", lambda: Fast3DWorkload(args, device, pairs=1), 10, 2)
+    run("c4", lambda: Rt3DWorkload(args, device), 3, 1, cpu.get("c4"))
+    run("c5_single", lambda: Fast3DWorkload(args, device, pairs=1), 10, 2, cpu.get("c5_single"))
     run("c5_share_32_submaps", lambda: Fast3DWorkload(args, device, pairs=32), 4, 2)
 
-    # C2 as a throughput workload: the same single searches issued from 8 host threads (the
-    # reference's execution model for this path: one thread-pool task per search,
-    # constraint_builder_2d.cc:97-111); the C ABI is re-entrant, so the latency chains of
-    # independent searches overlap on the device.
-    def concurrent_c2(threads=8, steps=400, warmup=80):
-        from concurrent.futures import ThreadPoolExecutor
-        w = Fast2DWorkload(args, device, 0, 1, sharded=False)
-        acc = {k: 0.0 for k in STAT_KEYS}
-
-        def worker(n):
-            return [w.search() for _ in range(n)]
-        with ThreadPoolExecutor(threads) as pool:
-            list(pool.map(worker, [warmup // threads] * threads))
-            sync()
-            gc.collect()
-            gc.disable()
-            try:
-                t0 = time.perf_counter()
-                for results in pool.map(worker, [steps // threads] * threads):
-                    for r in results:
-                        for k in STAT_KEYS:
-                            acc[k] += r[3][k]
-                sync()
-                dt = time.perf_counter() - t0
-            finally:
-                gc.enable()
-        done = steps // threads * threads
-        return {"workload": f"C2 searches issued concurrently from {threads} host threads",
-                "host_threads": threads, "steps": done, "ms_per_step": dt / done * 1e3,
-                "candidates_per_s": acc["candidates_scored"] / dt, "matches_per_s": done / dt}
-    try:
-        out["c2_concurrent_8_threads"] = concurrent_c2()
-    except Exception as e:      # noqa: BLE001
-        out["c2_concurrent_8_threads"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 
@@ -718,60 +839,60 @@ def main():
     name = args.config
     if name == "auto":
         name = "c2" if world_size == 1 and not args.force_dist else "c3"
-    if name in ("c1", "c4", "c5"):
+    if name in ("c1", "c4"):
         assert world_size == 1, f"--config {name} is a single-GPU workload"
     workload = make_workload(name, args, device, rank, world_size)
-    # c3 always runs its exchange (a no-op gather with one rank): same code path at every N
-    exchange = getattr(workload, "exchange", None) if (use_dist or name == "c3") else None
+    # c3 / sharded c5 always run their exchange (a no-op gather with one rank): same code path
+    # at every N
+    sharded = use_dist or name == "c3"
+    exchange = getattr(workload, "exchange", None) if sharded else None
+    threads = args.concurrency or (8 if name == "c2" and world_size == 1 and not use_dist else 1)
+    pool = None
+    if threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(threads)
 
-    def step():
-        result = workload.search()
-        if exchange is not None:
-            exchange(result[0], result[1], result[2], torch_device)
-        return result
-
-    def run(num_steps):
-        """Runs `num_steps` steps; returns (acc, last)."""
-        acc = {k: 0.0 for k in STAT_KEYS}
+    def run_passes(num_passes, acc):
+        """`num_passes` passes of the hot path (one step, or a warmup / calibration run); returns
+        the last result."""
         last = None
 
         def add(result):
             for k in STAT_KEYS:
                 acc[k] += result[3].get(k, 0)
 
-        if args.concurrency <= 1:
-            for _ in range(num_steps):
-                last = step()
+        if pool is None:
+            for k in range(num_passes):
+                last = workload.search(k)
+                if exchange is not None:
+                    exchange(last[0], last[1], last[2], torch_device)
                 add(last)
         elif exchange is None:
             # Independent searches issued from T host threads, each looping over its share.
-            from concurrent.futures import ThreadPoolExecutor
-            shares = [num_steps // args.concurrency + (1 if i < num_steps % args.concurrency else 0)
-                      for i in range(args.concurrency)]
+            shares = [num_passes // threads + (1 if i < num_passes % threads else 0)
+                      for i in range(threads)]
 
-            def worker(n):
-                return [workload.search() for _ in range(n)]
-            with ThreadPoolExecutor(args.concurrency) as pool:
-                for results in pool.map(worker, shares):
-                    for r in results:
-                        add(r)
-                        last = r
+            def worker(args_):
+                first, n = args_
+                return [workload.search(first + j) for j in range(n)]
+            starts = [sum(shares[:i]) for i in range(threads)]
+            for results in pool.map(worker, zip(starts, shares)):
+                for r in results:
+                    add(r)
+                    last = r
         else:
-            # Rounds of T concurrent searches, then the collectives of each step on this thread
+            # Rounds of T concurrent searches, then the collectives of each pass on this thread
             # (collectives must be issued in the same order on every rank).
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(args.concurrency) as pool:
-                done = 0
-                while done < num_steps:
-                    n = min(args.concurrency, num_steps - done)
-                    for r in [f.result() for f in [pool.submit(workload.search) for _ in range(n)]]:
-                        exchange(r[0], r[1], r[2], torch_device)
-                        add(r)
-                        last = r
-                    done += n
-        return acc, last
-
-    run(args.warmup)
+            done = 0
+            while done < num_passes:
+                n = min(threads, num_passes - done)
+                for r in [f.result() for f in [pool.submit(workload.search, done + j)
+                                               for j in range(n)]]:
+                    exchange(r[0], r[1], r[2], torch_device)
+                    add(r)
+                    last = r
+                done += n
+        return last
 
     def fence():
         torch.cuda.synchronize()
@@ -779,18 +900,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- passes per step: a step is one pass over a BATCH of searches, sized (untimed) so that
+    # it lasts >= 30 ms; every rank uses the same number ------------------------------------
+    scratch = {k: 0.0 for k in STAT_KEYS}
+    passes = args.passes_per_step
+    if passes <= 0:
+        probe = max(2 * threads, 4)
+        run_passes(probe, scratch)           # first touches, clocks
+        fence()
+        t0 = time.perf_counter()
+        run_passes(probe, scratch)
+        fence()
+        per_pass = (time.perf_counter() - t0) / probe
+        passes = int(min(8192, max(1, math.ceil(0.030 / max(per_pass, 1e-7)))))
+        if pool is not None:
+            passes = (passes + threads - 1) // threads * threads
+        if use_dist:
+            t = torch.tensor([passes], dtype=torch.int64, device=torch_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            passes = int(t.item())
+    for _ in range(args.warmup):
+        run_passes(passes, scratch)
+
     fence()
     gc.collect()
     gc.disable()        # see measure()
+    acc = {k: 0.0 for k in STAT_KEYS}
     t0 = time.perf_counter()
-    acc, (found, scores, poses, stats) = run(args.steps)
+    for _ in range(args.steps):
+        found, scores, poses, stats = run_passes(passes, acc)
     fence()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    total_passes = passes * args.steps
 
     # MAX over ranks of the elapsed time; SUM of the work.
     cand_local = acc["candidates_scored"]
-    matches_local = workload.matches_per_step * args.steps
+    matches_local = workload.matches_per_step * total_passes
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=torch_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -809,14 +955,22 @@ def main():
         config = workload.describe(stats, found)
         config.update({
             "name": name,
-            "host_threads": args.concurrency,
+            "host_threads": threads,
+            "passes_per_step": passes,
+            "ms_per_pass": elapsed / total_passes * 1e3,
             "candidates_per_step": cand_local / args.steps,
-            "lowest_resolution_candidates_per_step": acc["coarse_candidates"] / args.steps,
+            "candidates_per_pass": cand_local / total_passes,
+            "lowest_resolution_candidates_per_pass": acc["coarse_candidates"] / total_passes,
             "matches_per_s": matches_total / elapsed,
-            "device_ms_per_step": acc["device_ms"] / args.steps,
+            "device_ms_per_pass": acc["device_ms"] / total_passes,
+            "timed_region_s": elapsed,
             "candidate_count": "every scored candidate at every depth, counted once where it is "
                                "scored (dive and tie re-scoring included)",
         })
+        roof = workload.roofline(acc, total_passes, pmc)
+        roof["traffic_source"] = (None if roof.get("traffic") is None else
+                                  f"rocprofv3 --pmc passes of this command, {args.pmc_dir}/"
+                                  f"{args.pmc_tag}*_pmc_*.csv (not measured in this run)")
         out = {
             "metric": "candidate poses scored/sec",
             "value": cand_total / elapsed,
@@ -834,13 +988,58 @@ def main():
             "data": "synthetic",
             "constraints_per_s": matches_total / elapsed,
             "config": config,
-            "roofline": workload.roofline(acc, args.steps, pmc),
+            "roofline": roof,
         }
-        if world_size == 1 and not use_dist and not args.no_other and name == "c2":
-            config["other"] = other_configs(args, device, torch.cuda.synchronize, pmc)
         if not args.no_cpu_baseline and world_size == 1 and name in ("c2", "c3"):   # rank 0, N = 1
             out["cpu_baseline"] = cpu_baseline(workload.cells0, workload.lim0, args.depth,
                                                workload.scan, args.min_score, args.cpu_seconds)
+        elif not args.no_cpu_baseline and world_size == 1 and not use_dist:
+            leg = {"c1": cpu_baseline_c1, "c4": cpu_baseline_c4, "c5": cpu_baseline_c5}[name]
+            try:
+                out["cpu_baseline"] = leg(workload, args.cpu_seconds)
+            except Exception as e:      # noqa: BLE001
+                sys.stderr.write(f"cpu baseline unavailable: {e}\n")
+        summary = {name: {"ms": config["ms_per_pass"], "cand_per_s": out["value"],
+                          "frac": roof.get("frac"), "bound": roof.get("bound")}}
+        if world_size == 1 and not use_dist and not args.no_other and name == "c2":
+            # Single-stream latency of the headline workload, then every other BASELINE config.
+            single = Fast2DWorkload(args, device, 0, 1, sharded=False)
+            dt1, acc1, _ = measure(single, 200, 20, torch.cuda.synchronize)
+            config["single_stream_ms_per_search"] = dt1 / 200 * 1e3
+            config["single_stream_candidates_per_s"] = acc1["candidates_scored"] / dt1
+            other = other_configs(args, device, torch.cuda.synchronize, pmc)
+            out["details"] = other
+            # The driver's record keeps scalars: every config's line flat in `config` ...
+            for key, e in other.items():
+                short = key.split("_")[0] if key not in ("c1_single", "c5_single") else key
+                short = {"c1": "c1b128", "c3": "c3s16", "c5": "c5s32", "c2": "c2t8"}.get(short, short)
+                if "error" in e:
+                    config[f"{short}_error"] = e["error"][:80]
+                    continue
+                r = e.get("roofline") or {}
+                config[f"{short}_ms"] = e["ms_per_step"]
+                config[f"{short}_cand_per_s"] = e["candidates_per_s"]
+                config[f"{short}_matches_per_s"] = e["matches_per_s"]
+                if r:
+                    config[f"{short}_frac"] = r.get("frac")
+                    config[f"{short}_bound"] = r.get("bound")
+                    config[f"{short}_kernel_ms"] = r.get("kernel_ms")
+                c = e.get("cpu_baseline") or {}
+                if "value" in c:
+                    config[f"{short}_cpu"] = c["value"]
+                    config[f"{short}_cpu_unit"] = c["unit"]
+                    config[f"{short}_cpu_cores"] = c["cores"]
+                summary[short] = {"ms": e["ms_per_step"], "cand_per_s": e["candidates_per_s"],
+                                  "matches_per_s": e["matches_per_s"], "frac": r.get("frac"),
+                                  "bound": r.get("bound"), "cpu": c.get("value"),
+                                  "cpu_unit": c.get("unit"), "cpu_cores": c.get("cores")}
+        if "cpu_baseline" in out:
+            summary[name]["cpu"] = out["cpu_baseline"]["value"]
+            summary[name]["cpu_cores"] = out["cpu_baseline"]["cores"]
+        # ... and once more, compact, as the LAST key of the line (the tail of stdout).
+        out["summary"] = summary
+    if pool is not None:
+        pool.shutdown()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

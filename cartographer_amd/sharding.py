@@ -92,6 +92,34 @@ def all_gather_results(found, scores, poses_xyt, num_submaps, rank, world_size, 
     return (out[:, 0].astype(np.int32), out[:, 1].astype(np.float32), out[:, 2:5].copy())
 
 
+def all_gather_rows(rows, num_items, rank, world_size, device=None):
+    """The generic form of all_gather_results: `rows` is this rank's [end - begin, width] float64
+    block (shard_range order); returns the [num_items, width] array every rank ends up with.
+    Used for 3D results (found, score, translation, quaternion = 9 words per submap)."""
+    import torch
+    import torch.distributed as dist
+    rows = np.ascontiguousarray(rows, np.float64)
+    begin, end = shard_range(num_items, rank, world_size)
+    assert rows.shape[0] == end - begin
+    width = rows.shape[1]
+    per_rank = -(-num_items // world_size)
+    local = np.zeros((per_rank, width), np.float64)
+    local[:end - begin] = rows
+    t = torch.from_numpy(local)
+    if device is not None:
+        t = t.to(device)
+    if dist.is_available() and dist.is_initialized() and world_size > 1:
+        gathered = [torch.empty_like(t) for _ in range(world_size)]
+        dist.all_gather(gathered, t)
+    else:
+        gathered = [t]
+    out = np.zeros((num_items, width), np.float64)
+    for r, g in enumerate(gathered):
+        b, e = shard_range(num_items, r, world_size)
+        out[b:e] = g.cpu().numpy()[:e - b]
+    return out
+
+
 class Communicator:
     """cmx_comm: one host process driving several GPUs of the node (RCCL through
     ncclCommInitAll).  `match_full_submap_batch` / `match_batch` are the sharded forms of the

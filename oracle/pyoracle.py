@@ -213,7 +213,7 @@ def ref_lib():
         L.ref_rt3d_match_mt.argtypes = [C.c_float, C.c_void_p, C.c_int64, _f64p, _f32p, C.c_int,
                                         C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
                                         _f64p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
-                                        C.c_void_p]
+                                        C.c_void_p, C.c_int64, C.c_int64]
         L.ref_rt3d_match_mt.restype = C.c_float
         L.ref_rotational_match.argtypes = [_f32p, _f32p, C.c_int, C.c_float, _f32p, C.c_int, _f32p]
         L.ref_compute_histogram.argtypes = [_f32p, C.c_int, C.c_int, _f32p]
@@ -889,9 +889,11 @@ def ref_rt3d_match(resolution, voxels, init_pose7, xyz, lin, ang, tw, rw):
     return dict(score=float(s), pose=pose)
 
 
-def ref_rt3d_match_mt(resolution, voxels, init_pose7, xyz, lin, ang, tw, rw, num_threads=8):
+def ref_rt3d_match_mt(resolution, voxels, init_pose7, xyz, lin, ang, tw, rw, num_threads=8,
+                      first_candidate=0, max_candidates=0):
     """The reference's GenerateExhaustiveSearchTransforms / TransformPointCloud / ScoreCandidate
-    over candidate ranges on `num_threads` host threads (oracle/ref_wrapper_rt3d_mt.cc)."""
+    over candidate ranges on `num_threads` host threads (oracle/ref_wrapper_rt3d_mt.cc).
+    max_candidates > 0: only that many candidates from `first_candidate` on (a bounded sample)."""
     v, n = _voxels(voxels)
     xyz, npts = _cloud(xyz)
     pose = np.empty(7, np.float64)
@@ -899,7 +901,8 @@ def ref_rt3d_match_mt(resolution, voxels, init_pose7, xyz, lin, ang, tw, rw, num
     s = ref_lib().ref_rt3d_match_mt(resolution, v.ctypes.data, n,
                                     np.ascontiguousarray(init_pose7, np.float64), xyz, npts, lin,
                                     ang, tw, rw, int(num_threads), pose, C.byref(best),
-                                    C.byref(ncand), None)
+                                    C.byref(ncand), None, int(first_candidate),
+                                    int(max_candidates))
     return dict(score=float(s), pose=pose, best_index=int(best.value),
                 num_candidates=int(ncand.value))
 

@@ -38,10 +38,14 @@ extern "C" {
 // Returns the best score; pose7 = t xyz, q wxyz of the winning candidate; best_index = its
 // position in the reference's generation order; num_candidates = size of that list.
 // scores_out (optional, num_candidates floats) receives every candidate's weighted score.
+// first_candidate / max_candidates (max_candidates <= 0: all): a contiguous RANGE of the
+// generation order -- bench.py's bounded CPU sample of BASELINE config C4 (the whole search
+// space is ten minutes on 8 cores); best_index then refers to the best of that range.
 float ref_rt3d_match_mt(float resolution, const void* voxels, int64_t n, const double* init7,
                         const float* xyz, int npts, double lin, double ang, double tw, double rw,
                         int num_threads, double* pose7, int64_t* best_index,
-                        int64_t* num_candidates, float* scores_out) {
+                        int64_t* num_candidates, float* scores_out, int64_t first_candidate,
+                        int64_t max_candidates) {
   auto grid = std::make_unique<cm::HybridGrid>(resolution);
   const auto* vox = static_cast<const RefVoxelMt*>(voxels);
   for (int64_t i = 0; i != n; ++i)
@@ -61,15 +65,19 @@ float ref_rt3d_match_mt(float resolution, const void* voxels, int64_t n, const d
 
   const std::vector<cartographer::transform::Rigid3f> transforms =
       matcher.GenerateExhaustiveSearchTransforms(grid->resolution(), cloud);
-  const int64_t total = static_cast<int64_t>(transforms.size());
-  if (num_candidates) *num_candidates = total;
+  const int64_t all = static_cast<int64_t>(transforms.size());
+  if (num_candidates) *num_candidates = all;
+  const int64_t range_begin = std::min(std::max<int64_t>(first_candidate, 0), all);
+  const int64_t total = max_candidates > 0 ? std::min(max_candidates, all - range_begin)
+                                           : all - range_begin;
   num_threads = std::max(1, num_threads);
   struct Best { float score = -1.f; int64_t index = -1; };
   std::vector<Best> best(num_threads);
   std::vector<std::thread> threads;
   for (int t = 0; t != num_threads; ++t) {
     threads.emplace_back([&, t] {
-      const int64_t begin = total * t / num_threads, end = total * (t + 1) / num_threads;
+      const int64_t begin = range_begin + total * t / num_threads,
+                    end = range_begin + total * (t + 1) / num_threads;
       Best b;
       for (int64_t i = begin; i != end; ++i) {
         // real_time_correlative_scan_matcher_3d.cc:42-51

@@ -32,7 +32,8 @@ def stubbed_bench(monkeypatch):
     def run(*argv):
         calls.clear()
         monkeypatch.setattr(sys, "argv", ["bench.py", "--no-cpu-baseline", "--no-other", "--grid",
-                                          "120"] + list(argv))
+                                          "120", "--passes-per-step", "1", "--concurrency", "1"]
+                            + list(argv))
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):
             bench.main()
@@ -74,13 +75,17 @@ def test_bench_issues_exactly_the_requested_steps(stubbed_bench, extra):
         assert out["config"]["best_match"]["submap"] == 0
     assert abs(out["value"] * out["ms_per_step"] * 1e-3 * 7 - 7000.0 * submaps) < 1e-6
     assert "cpu_baseline" not in out                         # --no-cpu-baseline
+    # a step is `passes_per_step` passes; the compact per-config summary closes the line
+    assert out["config"]["passes_per_step"] == 1 and list(out)[-1] == "summary"
+    assert out["summary"][out["config"]["name"]]["cand_per_s"] == out["value"]
 
 
 def test_bench_cpu_baseline_leg(stubbed_bench, monkeypatch):
     """The `cpu_baseline` object (rank 0, N = 1 only): the reference's own matcher source where
     oracle/_ref is built, otherwise the oracle port; a bounded sample."""
     import bench
-    argv = ["bench.py", "--grid", "120", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.3"]
+    argv = ["bench.py", "--grid", "120", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.3",
+            "--no-other"]
     monkeypatch.setattr(sys, "argv", argv)
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
@@ -105,7 +110,8 @@ def test_bench_two_ranks_gloo():
                    MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(root, "tests", "bench_stub.py"), "--gpus", "2",
-             "--steps", "5", "--warmup", "2", "--grid", "120", "--submaps", "3"],
+             "--steps", "5", "--warmup", "2", "--grid", "120", "--submaps", "3",
+             "--passes-per-step", "1"],
             env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=300) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
@@ -124,3 +130,21 @@ def test_bench_two_ranks_gloo():
     assert "cpu_baseline" not in out                            # N = 1 only
     for _, err in outs:
         assert "issued 7 matches" in err
+
+
+def test_bench_calibrates_passes_per_step(stubbed_bench, monkeypatch):
+    """Without --passes-per-step a step is sized during warmup (untimed) to last >= 30 ms; the
+    stub's searches take microseconds, so many passes make one step, and exactly steps x passes
+    timed searches are accounted."""
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--no-cpu-baseline", "--no-other", "--grid",
+                                      "120", "--steps", "3", "--warmup", "1", "--concurrency", "2"])
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    out = json.loads(buf.getvalue().strip().splitlines()[-1])
+    p = out["config"]["passes_per_step"]
+    assert p > 1 and p % 2 == 0 and out["config"]["host_threads"] == 2
+    assert out["config"]["candidates_per_step"] == 1000.0 * p
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 * 3 - 3 * 1000.0 * p) < 1e-3
+    assert p == 8192 or out["config"]["timed_region_s"] >= 0.03 * 3     # (the cap, with stubs)
