@@ -72,6 +72,11 @@ def parse_args():
                          "constraint_builder_2d.cc:97-111); the C ABI is re-entrant: every call "
                          "leases its own stream + scratch.  0 = auto: 8 for c2 on one GPU (a single "
                          "search is a latency chain that fills a fraction of the chip), else 1")
+    ap.add_argument("--scans", type=int, default=1,
+                    help="c2 / c3: distinct scans (poses of the same world) the passes of a step "
+                         "cycle through; 1 = the one scan of BASELINE config[1] (rounds 1 and 2 "
+                         "timed the same search): other poses are 10x harder searches and move the "
+                         "number (8 scans, 8 threads: 3.8e9 candidates/s against 8.3e9)")
     ap.add_argument("--passes-per-step", type=int, default=0,
                     help="passes of the hot path that make one step (a step is one pass over a "
                          "BATCH of searches).  0 = auto: calibrated during warmup so that a step "
@@ -337,10 +342,10 @@ class Fast2DWorkload:
         pose = truth.free_pose(1234, 0.5)
         self.scan = truth.scan(pose, args.beams, 30.0, 0.01, 7)
         self.cloud = sm.PointCloudOnDevice(self.scan, device=device)
-        # A step is a batch of passes: pass k searches with scan k mod 8 (eight scans taken at
+        # A step is a batch of passes: pass k searches with scan k mod `--scans` (scans taken at
         # different poses of the same world, resident in HBM like the first).
         self.clouds = [self.cloud]
-        for k in range(1, 8):
+        for k in range(1, max(1, getattr(args, "scans", 1))):
             sk = truth.scan(truth.free_pose(1234 + k, 0.5), args.beams, 30.0, 0.01, 7 + k)
             self.clouds.append(sm.PointCloudOnDevice(sk, device=device))
         self.n_points = self.scan.shape[0]
@@ -915,6 +920,18 @@ def main():
         passes = int(min(8192, max(1, math.ceil(0.030 / max(per_pass, 1e-7)))))
         if pool is not None:
             passes = (passes + threads - 1) // threads * threads
+        # one trial step at that size, then the final size (the probe above includes cold starts)
+        for _ in range(2):
+            fence()
+            t0 = time.perf_counter()
+            run_passes(passes, scratch)
+            fence()
+            step_s = time.perf_counter() - t0
+            if step_s >= 0.030:
+                break
+            passes = int(min(8192, math.ceil(passes * 0.033 / max(step_s, 1e-6))))
+            if pool is not None:
+                passes = (passes + threads - 1) // threads * threads
         if use_dist:
             t = torch.tensor([passes], dtype=torch.int64, device=torch_device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -1,0 +1,11 @@
+#!/usr/bin/env python3
+"""Prints the few numbers of a bench.py JSON line read from stdin (tools only)."""
+import json
+import sys
+
+o = json.loads(sys.stdin.read().strip().splitlines()[-1])
+c = o["config"]
+print(sys.argv[1] if len(sys.argv) > 1 else "", "threads", c["host_threads"], "passes",
+      c["passes_per_step"], "ms/pass", round(c["ms_per_pass"], 4), "cand/s", "%.3e" % o["value"],
+      "timed_s", round(c["timed_region_s"], 3), "nodes", c.get("nodes_expanded_per_step"),
+      "found", c.get("found"), "frac", round(o["roofline"]["frac"], 4))
