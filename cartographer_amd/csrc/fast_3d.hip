@@ -45,6 +45,10 @@ struct Node3D {
   unsigned long long path; // sibling ranks along the descent, 3 bits per level
   float low_resolution_score;
   int problem;             // index into the batch's Fast3DProblem array
+  int family;              // > 0: this node and the next family - 1 slots of its sub-list are the
+                           // children one parent kept (same problem, scan and level, offsets
+                           // half a parent step apart); 0: a later member of such a run
+  int pad;
 };
 
 struct Counters3 {
@@ -279,6 +283,8 @@ __device__ __forceinline__ Node3D CoarseNode3D(const Fast3DProblem& P, int c) {
   nd.path = 0;
   nd.low_resolution_score = 0.f;
   nd.problem = P.index;
+  nd.family = 1;
+  nd.pad = 0;
   return nd;
 }
 
@@ -538,6 +544,9 @@ __device__ __forceinline__ void ChildSums3D(const Fast3DProblem& P, const Node3D
 // several points are in flight together.
 struct ExpandShared {
   int partial[4][8];
+  int fam_partial[4][8][8];    // [wave][member][child]
+  int fam_total[8][8];
+  Node3D fam[8];
   float score[8];
   float low_prob[kLowChunk];
   Node3D next;       // dive: the child the descent continues with
@@ -561,32 +570,24 @@ __device__ __forceinline__ void FlushWork3D(ExpandShared* sh, Counters3* __restr
 
 // Expansion of one node by the whole block (see above).  dive = 0: children that can still
 // matter are appended to `out`; dive = 1: the best child is left in sh->next.
-__device__ __forceinline__ void ExpandNode3D(const Fast3DProblem& P, const Node3D& nd, float best,
-                                             int dive, int strict, const List3& out,
-                                             const List3& leaves,
-                                             Counters3* __restrict__ counters, int sub_id,
-                                             ExpandShared* sh) {
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+// The part of an expansion after the child sums: scores, ranks, then the children that can
+// still matter (or, at the leaves, the low-resolution verification).  `totals` = the eight
+// integer child sums of `nd` (any memory every thread can read).
+__device__ __forceinline__ void FinishExpand3D(const Fast3DProblem& P, const Node3D& nd,
+                                               const int* totals, float best, int dive, int strict,
+                                               const List3& out, const List3& leaves,
+                                               Counters3* __restrict__ counters, int sub_id,
+                                               ExpandShared* sh) {
   if (threadIdx.x == 0) sh->has_next = 0;
   {
     const int child_depth = nd.level - 1;
     const int half = 1 << child_depth;
     const bool vx = nd.ox + half <= P.wxy, vy = nd.oy + half <= P.wxy, vz = nd.oz + half <= P.wz;
-    int sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    ChildSums3D(P, nd, threadIdx.x, 256, sum);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int total = WaveSum(sum[k]);
-      if (lane == 0) sh->partial[wave][k] = total;
-    }
     __syncthreads();
     if (threadIdx.x < 8) {
       const int k = threadIdx.x;
       const bool valid = (!(k & 1) || vx) && (!(k & 2) || vy) && (!(k & 4) || vz);
-      const int total =
-          sh->partial[0][k] + sh->partial[1][k] + sh->partial[2][k] + sh->partial[3][k];
-      sh->score[k] = valid ? ToProbability(total, P.n) : -1.f;
+      sh->score[k] = valid ? ToProbability(totals[k], P.n) : -1.f;
     }
     __syncthreads();
     float score[8];
@@ -612,6 +613,7 @@ __device__ __forceinline__ void ExpandNode3D(const Fast3DProblem& P, const Node3
     }
     auto make_child = [&](int k) {
       Node3D child = nd;
+      child.family = 0;
       child.level = child_depth;
       child.ox = nd.ox + ((k & 1) ? half : 0);
       child.oy = nd.oy + ((k & 2) ? half : 0);
@@ -674,10 +676,14 @@ __device__ __forceinline__ void ExpandNode3D(const Fast3DProblem& P, const Node3
           if (keep_mask >> k & 1) { sh->next = make_child(k); sh->has_next = 1; }
       } else if (m) {
         int slot = atomicAdd(&out.counts[sub_id * kCountStride3], m);
+        bool leader = true;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           if (!(keep_mask >> k & 1)) continue;
-          if (!Push3(out, sub_id, slot, make_child(k))) counters->overflow = 1;
+          Node3D child = make_child(k);
+          child.family = leader ? m : 0;       // the kept children of one parent: a family
+          leader = false;
+          if (!Push3(out, sub_id, slot, child)) counters->overflow = 1;
           ++slot;
         }
       }
@@ -686,12 +692,93 @@ __device__ __forceinline__ void ExpandNode3D(const Fast3DProblem& P, const Node3
   }
 }
 
+// Expansion of one node by the whole block (see above).  dive = 0: children that can still
+// matter are appended to `out`; dive = 1: the best child is left in sh->next.
+__device__ __forceinline__ void ExpandNode3D(const Fast3DProblem& P, const Node3D& nd, float best,
+                                             int dive, int strict, const List3& out,
+                                             const List3& leaves,
+                                             Counters3* __restrict__ counters, int sub_id,
+                                             ExpandShared* sh) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  int sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  ChildSums3D(P, nd, threadIdx.x, 256, sum);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int total = WaveSum(sum[k]);
+    if (lane == 0) sh->partial[wave][k] = total;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8)
+    sh->fam_total[0][threadIdx.x] = sh->partial[0][threadIdx.x] + sh->partial[1][threadIdx.x] +
+                                    sh->partial[2][threadIdx.x] + sh->partial[3][threadIdx.x];
+  FinishExpand3D(P, nd, sh->fam_total[0], best, dive, strict, out, leaves, counters, sub_id, sh);
+}
+
+// The child sums of a FAMILY (round 3): the kept children of one parent are expanded by one
+// block.  What bounded the per-node expansion (profiles/r02e_c5_pmc_*): 4.9 GB of 128-byte lines
+// per launch for 1.35 GB of oct words -- every (node, point) lookup fetched a line of its own,
+// and every node re-read the scan's 16-byte cell records.  Members of a family read oct words
+// `half` cells apart: the two x positions share a line, the cell record and its depth index
+// are computed once per point for all members, and up to eight gathers per point are in
+// flight together.  Returns false (nothing summed) when the level has no oct grid.
+__device__ __forceinline__ bool FamilySums3D(const Fast3DProblem& P, const Node3D* fam_nodes,
+                                             int fam, unsigned live, int first, int stride,
+                                             int (&sum)[8][8]) {
+  const int child_depth = fam_nodes[0].level - 1;
+  const int half = 1 << child_depth;
+  const int e = max(0, child_depth - P.full_resolution_depth + 1);
+  const Brick L = P.level[child_depth];
+  const OctDesc O = P.oct[child_depth];
+  if (O.cells == nullptr || g_fast3d_byte_loads) return false;
+  if ((((fam_nodes[0].ox + half) >> e) - (fam_nodes[0].ox >> e)) != O.s) return false;
+  const int4* __restrict__ cells = P.cells + static_cast<size_t>(fam_nodes[0].scan) * P.n;
+  int mx[8], my[8], mz[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const Node3D& nd = fam_nodes[min(m, fam - 1)];
+    mx[m] = (nd.ox >> e) - L.lo_x + O.s;
+    my[m] = (nd.oy >> e) - L.lo_y + O.s;
+    mz[m] = (nd.oz >> e) - L.lo_z + O.s;
+  }
+  for (int q0 = first; q0 < P.n; q0 += 256 * stride) {
+    unsigned acc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m][0] = acc[m][1] = acc[m][2] = acc[m][3] = 0;
+    const int stop = min(P.n, q0 + 256 * stride);
+#pragma unroll 2
+    for (int q = q0; q < stop; q += stride) {
+      const int3 d = DepthIndex(cells[q], e, -P.wxy, -P.wxy, -P.wz);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        if (m >= fam || !(live >> m & 1)) continue;          // block-uniform
+        const int X = d.x + mx[m], Y = d.y + my[m], Z = d.z + mz[m];
+        const bool inside = static_cast<unsigned>(X) < static_cast<unsigned>(O.qx) &&
+                            static_cast<unsigned>(Y) < static_cast<unsigned>(O.qy) &&
+                            static_cast<unsigned>(Z) < static_cast<unsigned>(O.qz);
+        const uint2 w = O.cells[inside ? (static_cast<size_t>(Z) * O.qy + Y) * O.qx + X : 0];
+        const unsigned lo = inside ? w.x : 0u, hi = inside ? w.y : 0u;
+        acc[m][0] += lo & 0x00ff00ffu; acc[m][1] += (lo >> 8) & 0x00ff00ffu;
+        acc[m][2] += hi & 0x00ff00ffu; acc[m][3] += (hi >> 8) & 0x00ff00ffu;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      sum[m][0] += acc[m][0] & 0xffffu; sum[m][2] += acc[m][0] >> 16;
+      sum[m][1] += acc[m][1] & 0xffffu; sum[m][3] += acc[m][1] >> 16;
+      sum[m][4] += acc[m][2] & 0xffffu; sum[m][6] += acc[m][2] >> 16;
+      sum[m][5] += acc[m][3] & 0xffffu; sum[m][7] += acc[m][3] >> 16;
+    }
+  }
+  return true;
+}
+
 // (One wavefront per node for the levels above the leaves -- four times as many nodes in
 // flight, 43 points per lane -- was measured and changed nothing: 5.26 vs 5.34 ms for 32 pairs;
 // a single pair got slower, 0.45 vs 0.41 ms.  Removed.)
 __global__ void __launch_bounds__(256)
 Expand3DKernel(const Fast3DProblem* __restrict__ problems, List3 in, int strict, int affinity,
-               List3 out, List3 leaves, Counters3* __restrict__ counters) {
+               int use_families, List3 out, List3 leaves, Counters3* __restrict__ counters) {
   __shared__ ExpandShared sh;
   InitWork3D(&sh);
   const int max_count = ListMax3(in);
@@ -707,10 +794,11 @@ Expand3DKernel(const Fast3DProblem* __restrict__ problems, List3 in, int strict,
     // (Sending the children of 32 consecutive nodes to one sub-list, to keep neighbours
     // together in the next level, measured worse: 7.7 vs 7.2 ms for 32 pairs -- the lists of an
     // XCD then differ in length.)
-    const int sub_id = affinity ? (in_sub & 7) | ((((in_sub >> 3) * 5 + j) & 7) << 3)
-                                : (in_sub * 17 + j) & (kSubLists3 - 1);
-    const Node3D nd = in.nodes[static_cast<size_t>(in_sub) * in.sub_capacity + j];
-    const Fast3DProblem& P = problems[nd.problem];
+    const Node3D* slot0 = in.nodes + static_cast<size_t>(in_sub) * in.sub_capacity + j;
+    const int family = slot0->family;
+    if (family == 0) continue;            // a later member: its leader's block takes it (uniform)
+    const int fam = min(family, min(in.counts[in_sub * kCountStride3], in.sub_capacity) - j);
+    const Fast3DProblem& P = problems[slot0->problem];
     // The bound moves while this kernel runs: ONE thread reads it and the block shares that
     // value.  (Every thread reading it for itself let some threads skip a node that the
     // others expanded -- barriers of different nodes then met, children were summed from a
@@ -720,10 +808,52 @@ Expand3DKernel(const Fast3DProblem* __restrict__ problems, List3 in, int strict,
     if (threadIdx.x == 0)
       sh.score[0] = __uint_as_float(
           __hip_atomic_load(P.best_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (threadIdx.x < fam) sh.fam[threadIdx.x] = slot0[threadIdx.x];
     __syncthreads();
     const float best = sh.score[0];
-    if (strict ? !(nd.score > best) : (nd.score < best)) continue;    // block-uniform
-    ExpandNode3D(P, nd, best, 0, strict, out, leaves, counters, sub_id, &sh);
+    unsigned live = 0;
+    for (int m = 0; m < fam; ++m)
+      if (!(strict ? !(sh.fam[m].score > best) : (sh.fam[m].score < best))) live |= 1u << m;
+    if (live == 0) continue;                                              // block-uniform
+    bool summed = false;
+    if (fam > 1 && use_families) {
+      int sum[8][8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum[m][k] = 0;
+      summed = FamilySums3D(P, sh.fam, fam, live, threadIdx.x, 256, sum);
+      if (summed) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          if (m >= fam || !(live >> m & 1)) continue;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int total = WaveSum(sum[m][k]);
+            if (lane == 0) sh.fam_partial[wave][m][k] = total;
+          }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+          const int m = threadIdx.x >> 3, k = threadIdx.x & 7;
+          sh.fam_total[m][k] = sh.fam_partial[0][m][k] + sh.fam_partial[1][m][k] +
+                               sh.fam_partial[2][m][k] + sh.fam_partial[3][m][k];
+        }
+        __syncthreads();
+      }
+    }
+    for (int m = 0; m < fam; ++m) {
+      if (!(live >> m & 1)) continue;
+      // (each member's children go to a sub-list of their own, as single nodes' did)
+      const int sub_m = affinity ? (in_sub & 7) | ((((in_sub >> 3) * 5 + j + m) & 7) << 3)
+                                 : (in_sub * 17 + j + m) & (kSubLists3 - 1);
+      const Node3D nd = sh.fam[m];
+      if (summed)
+        FinishExpand3D(P, nd, sh.fam_total[m], best, 0, strict, out, leaves, counters, sub_m, &sh);
+      else
+        ExpandNode3D(P, nd, best, 0, strict, out, leaves, counters, sub_m, &sh);
+    }
   }
   FlushWork3D(&sh, counters);
 }
@@ -1268,6 +1398,9 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
     return e ? atoi(e) : -1;
   }();
   const int affinity = kAffinity >= 0 ? kAffinity : (num >= 16 ? 1 : 0);
+  // CMX_FAST3D_FAMILIES=0: every node of a family expanded on its own (A/B runs, parity tests)
+  const char* fam_env = getenv("CMX_FAST3D_FAMILIES");
+  const int families = !(fam_env && fam_env[0] == '0');
   int strict = 0, num_chunks = 1;
   const Best3* h_best = reinterpret_cast<const Best3*>(h_misc + off_best);
   for (;;) {
@@ -1301,8 +1434,8 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
         if (timed) CMX_HIP(hipEventRecord(ws->ev_x0, ws->stream));
         for (int child = max_depth - 2; child >= 0; --child, ++stage) {
           Expand3DKernel<<<blocks, 256, 0, ws->stream>>>(d_problems, front(stage), strict,
-                                                         affinity, front(stage + 1), leaf_list,
-                                                         d_counters);
+                                                         affinity, families, front(stage + 1),
+                                                         leaf_list, d_counters);
           dbg("expand level");
           mark("expand");
         }

@@ -668,12 +668,15 @@ def test_constraint_builder_3d_refines_on_the_device(sm3, oracle, synth):
         with_ceres.last_refine_summaries[0]["initial_cost"]
 
 
+@pytest.mark.parametrize("families", [None, "0"])
 @pytest.mark.parametrize("affinity", [None, "0"])
-def test_fast3d_device_batch_of_twenty_pairs(sm3, synth, monkeypatch, affinity):
+def test_fast3d_device_batch_of_twenty_pairs(sm3, synth, monkeypatch, affinity, families):
     """From 16 pairs on a problem's nodes stay on one XCD (placement only: the search is
     order-free); pair by pair the batch must return what the single searches return."""
     if affinity is not None:
         monkeypatch.setenv("CMX_FAST3D_AFFINITY", affinity)
+    if families is not None:         # every node expanded on its own (round 2) instead of by family
+        monkeypatch.setenv("CMX_FAST3D_FAMILIES", families)
     depths = [5, 4, 6, 3] * 5
     matchers, pos, data = _fast3d_batch_scene(sm3, synth, depths)
     ident = sm3.Rigid3d()
