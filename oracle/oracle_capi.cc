@@ -462,8 +462,30 @@ struct Ceres3DArgs {
   CeresOptions3D options;
   std::vector<PointCloud3> clouds;
   std::vector<std::unique_ptr<HybridGridView>> grids;
+  std::vector<std::unique_ptr<IntensityGridView>> intensity_grids;
+  std::vector<std::vector<float>> intensities;
   std::vector<CloudAndGrid3D> pairs;
 };
+// Intensity part of the pairs (null `intensities`: none): per pair point intensities, intensity
+// voxels (x, y, z, count, sum) and options3 = weight, huber_scale, intensity_threshold.
+void AddIntensity3D(Ceres3DArgs* a, const float* const* intensities,
+                    const IntensityVoxel* const* voxels, const int64_t* voxel_counts,
+                    const double* options3, const float* resolutions) {
+  if (intensities == nullptr) return;
+  const size_t num = a->pairs.size();
+  a->intensity_grids.resize(num);
+  a->intensities.resize(num);
+  for (size_t k = 0; k < num; ++k) {
+    if (intensities[k] == nullptr) continue;
+    a->intensities[k].assign(intensities[k], intensities[k] + a->clouds[k].size());
+    a->intensity_grids[k].reset(new IntensityGridView(resolutions[k], voxels[k], voxel_counts[k]));
+    a->pairs[k].intensity_hybrid_grid = a->intensity_grids[k].get();
+    a->pairs[k].intensities = &a->intensities[k];
+    a->pairs[k].intensity_weight = options3[3 * k];
+    a->pairs[k].huber_scale = options3[3 * k + 1];
+    a->pairs[k].intensity_threshold = static_cast<float>(options3[3 * k + 2]);
+  }
+}
 void MakeCeres3D(const double* options8, int num_pairs, const float* const* clouds,
                  const int* counts, const float* resolutions, const Voxel* const* voxels,
                  const int64_t* voxel_counts, Ceres3DArgs* a) {
@@ -511,6 +533,55 @@ void orc_ceres3d_residuals(const double* options8, int num_pairs, const float* c
   CeresResiduals3D(a.options, target_xyz, target_q4, a.pairs, pose7, pose7 + 3, &r, &J);
   std::memcpy(residuals, r.data(), r.size() * sizeof(double));
   std::memcpy(jacobian, J.data(), J.size() * sizeof(double));
+}
+
+
+// The same two entry points with IntensityCostFunction3D blocks (argument layout of
+// refc_ceres3d_match in ref_ceres_wrapper.cc).  Residuals / Jacobian are the RAW blocks in
+// CeresResidualBlocks3D order (before the Huber correction).
+void orc_ceres3d_match_intensity(const double* options8, int num_pairs, const float* const* clouds,
+                                 const int* counts, const float* resolutions,
+                                 const Voxel* const* voxels, const int64_t* voxel_counts,
+                                 const double* target_xyz, const double* init7, double* pose7,
+                                 double* summary5, const float* const* intensities,
+                                 const IntensityVoxel* const* intensity_voxels,
+                                 const int64_t* intensity_voxel_counts,
+                                 const double* intensity_options3) {
+  Ceres3DArgs a;
+  MakeCeres3D(options8, num_pairs, clouds, counts, resolutions, voxels, voxel_counts, &a);
+  AddIntensity3D(&a, intensities, intensity_voxels, intensity_voxel_counts, intensity_options3,
+                 resolutions);
+  Pose3d pose = MakePose3(init7);
+  CeresSummary2D sum;
+  CeresScanMatcher3DMatch(a.options, target_xyz, MakePose3(init7), a.pairs, &pose, &sum);
+  StorePose3(pose, pose7);
+  summary5[0] = sum.initial_cost; summary5[1] = sum.final_cost;
+  summary5[2] = sum.num_successful_steps; summary5[3] = sum.num_unsuccessful_steps;
+  summary5[4] = sum.termination;
+}
+// IntensityCostFunction3D alone, like refc_intensity3d_residuals: residuals [n], jacobian [n][7].
+void orc_intensity3d_residuals(double scaling_factor, float intensity_threshold, const float* xyz,
+                               const float* intensities, int n, float resolution,
+                               const IntensityVoxel* voxels, int64_t num_voxels,
+                               const double* pose7, double* residuals, double* jacobian) {
+  // one pair whose occupied-space block is dropped from the output: weight sqrt(n) * scaling
+  const Voxel none{0, 0, 0, 0, 0};
+  const HybridGridView empty(resolution, &none, 0);
+  const PointCloud3 cloud = MakeCloud3(xyz, n);
+  const IntensityGridView grid(resolution, voxels, num_voxels);
+  const std::vector<float> in(intensities, intensities + n);
+  CloudAndGrid3D pair{&cloud, &empty};
+  pair.intensity_hybrid_grid = &grid;
+  pair.intensities = &in;
+  pair.intensity_weight = scaling_factor * std::sqrt(static_cast<double>(n));
+  pair.intensity_threshold = intensity_threshold;
+  CeresOptions3D o;
+  o.occupied_space_weight = {1.};
+  const double zero3[3] = {0, 0, 0}, ident[4] = {1, 0, 0, 0};
+  std::vector<double> r, J;
+  CeresResiduals3D(o, zero3, ident, {pair}, pose7, pose7 + 3, &r, &J);
+  std::memcpy(residuals, r.data() + n, n * sizeof(double));
+  std::memcpy(jacobian, J.data() + 7 * static_cast<size_t>(n), 7 * static_cast<size_t>(n) * sizeof(double));
 }
 
 }  // extern "C"

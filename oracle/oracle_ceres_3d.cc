@@ -2,6 +2,8 @@
 // pins it).
 #include "oracle_ceres_3d.h"
 
+#include <limits>
+
 #include <algorithm>
 #include <cmath>
 
@@ -96,8 +98,12 @@ void Plus(bool yaw_only, const double q[4], const double* delta, double out[4]) 
 
 }  // namespace
 
-double InterpolatedProbability(const HybridGridView& grid, double x, double y, double z,
-                               double gradient[3]) {
+namespace {
+// InterpolatedGrid<GridType>::GetInterpolatedValue (interpolated_grid.h:52-93) for either grid:
+// `cell_of` = GetCellIndex, `value_at` = GetProbability / GetIntensity.
+template <typename Grid, typename ValueAt>
+double Interpolated(const Grid& grid, ValueAt value_at, double x, double y, double z,
+                    double gradient[3]) {
   const float res = grid.resolution();
   // CenterOfLowerVoxel (:113-130): centre of the cell containing the point (f32), moved to the
   // next lower centre where it lies above the coordinate.
@@ -112,7 +118,7 @@ double InterpolatedProbability(const HybridGridView& grid, double x, double y, d
   const double x2 = cx + res, y2 = cy + res, z2 = cz + res;     // f32 additions (:100-110)
   const Cell3i i1 = grid.GetCellIndex(V3f{cx, cy, cz});
   const auto q = [&](int dx, int dy, int dz) {
-    return static_cast<double>(grid.GetProbability(Cell3i{i1.x + dx, i1.y + dy, i1.z + dz}));
+    return static_cast<double>(value_at(Cell3i{i1.x + dx, i1.y + dy, i1.z + dz}));
   };
   const double q111 = q(0, 0, 0), q112 = q(0, 0, 1), q121 = q(0, 1, 0), q122 = q(0, 1, 1);
   const double q211 = q(1, 0, 0), q212 = q(1, 0, 1), q221 = q(1, 1, 0), q222 = q(1, 1, 1);
@@ -142,13 +148,59 @@ double InterpolatedProbability(const HybridGridView& grid, double x, double y, d
   }
   return value;
 }
+}  // namespace
+
+double InterpolatedProbability(const HybridGridView& grid, double x, double y, double z,
+                               double gradient[3]) {
+  return Interpolated(grid, [&](const Cell3i& c) { return grid.GetProbability(c); }, x, y, z,
+                      gradient);
+}
+double InterpolatedIntensity(const IntensityGridView& grid, double x, double y, double z,
+                             double gradient[3]) {
+  return Interpolated(grid, [&](const Cell3i& c) { return grid.GetIntensity(c); }, x, y, z,
+                      gradient);
+}
+
+IntensityGridView::IntensityGridView(float resolution, const IntensityVoxel* voxels, int64_t n)
+    : resolution_(resolution) {
+  if (n <= 0) return;
+  Cell3i lo{voxels[0].x, voxels[0].y, voxels[0].z}, hi = lo;
+  for (int64_t i = 1; i < n; ++i) {
+    lo.x = std::min(lo.x, voxels[i].x); hi.x = std::max(hi.x, voxels[i].x);
+    lo.y = std::min(lo.y, voxels[i].y); hi.y = std::max(hi.y, voxels[i].y);
+    lo.z = std::min(lo.z, voxels[i].z); hi.z = std::max(hi.z, voxels[i].z);
+  }
+  cells_.Reset(lo, hi);
+  for (int64_t i = 0; i < n; ++i)
+    if (voxels[i].count != 0)       // GetIntensity: cell.sum / cell.count (hybrid_grid.h:563-570)
+      *cells_.mutable_value(voxels[i].x, voxels[i].y, voxels[i].z) =
+          voxels[i].sum / voxels[i].count;
+}
+
+std::vector<ResidualBlock3D> CeresResidualBlocks3D(const std::vector<CloudAndGrid3D>& pairs) {
+  std::vector<ResidualBlock3D> blocks;
+  size_t row = 0;
+  for (const CloudAndGrid3D& p : pairs) {
+    const size_t n = p.point_cloud->size();
+    blocks.push_back({row, row + n, 0.});
+    row += n;
+    if (p.intensity_hybrid_grid) {
+      blocks.push_back({row, row + n, p.huber_scale});
+      row += n;
+    }
+  }
+  blocks.push_back({row, row + 3, 0.});
+  blocks.push_back({row + 3, row + 6, 0.});
+  return blocks;
+}
 
 void CeresResiduals3D(const CeresOptions3D& options, const double target_translation[3],
                       const double target_rotation[4], const std::vector<CloudAndGrid3D>& pairs,
                       const double translation[3], const double rotation[4],
                       std::vector<double>* residuals, std::vector<double>* jacobian) {
   size_t total = 6;
-  for (const CloudAndGrid3D& p : pairs) total += p.point_cloud->size();
+  for (const CloudAndGrid3D& p : pairs)
+    total += p.point_cloud->size() * (p.intensity_hybrid_grid ? 2 : 1);
   residuals->assign(total, 0.);
   if (jacobian) jacobian->assign(total * 7, 0.);
   const double w = rotation[0];
@@ -159,37 +211,58 @@ void CeresResiduals3D(const CeresOptions3D& options, const double target_transla
     const HybridGridView& grid = *pairs[k].hybrid_grid;
     const double scaling =
         options.occupied_space_weight[k] / std::sqrt(static_cast<double>(cloud.size()));
-    for (size_t i = 0; i < cloud.size(); ++i, ++row) {
-      const double v[3] = {static_cast<double>(cloud[i].x), static_cast<double>(cloud[i].y),
-                           static_cast<double>(cloud[i].z)};
-      // Eigen: uv = 2 (u x v); rotated = v + w uv + u x uv; world = rotated + translation.
-      double uv[3], uuv[3];
-      Cross(u, v, uv);
-      for (int a = 0; a < 3; ++a) uv[a] += uv[a];
-      Cross(u, uv, uuv);
-      double world[3];
-      for (int a = 0; a < 3; ++a) world[a] = ((v[a] + w * uv[a]) + uuv[a]) + translation[a];
-      double grad[3];
-      const double probability =
-          InterpolatedProbability(grid, world[0], world[1], world[2], jacobian ? grad : nullptr);
-      (*residuals)[row] = scaling * (1. - probability);
-      if (jacobian) {
-        double* J = jacobian->data() + 7 * row;
-        for (int a = 0; a < 3; ++a) J[a] = -scaling * grad[a];              // d world / d t = I
-        // d world / d w = uv
-        J[3] = -scaling * (grad[0] * uv[0] + grad[1] * uv[1] + grad[2] * uv[2]);
-        for (int c = 0; c < 3; ++c) {
-          // d world / d u_c = w 2 (e_c x v) + e_c x uv + u x (2 e_c x v)
-          double e[3] = {0., 0., 0.};
-          e[c] = 1.;
-          double ev[3], euv[3], uev[3];
-          Cross(e, v, ev);
-          for (int a = 0; a < 3; ++a) ev[a] += ev[a];
-          Cross(e, uv, euv);
-          Cross(u, ev, uev);
-          double d = 0.;
-          for (int a = 0; a < 3; ++a) d += grad[a] * ((w * ev[a] + euv[a]) + uev[a]);
-          J[4 + c] = -scaling * d;
+    // One residual block per grid of the pair: occupied space, then (optional) intensity.
+    for (int term = 0; term < (pairs[k].intensity_hybrid_grid ? 2 : 1); ++term) {
+      const bool intensity_term = term == 1;
+      const double term_scaling =
+          intensity_term ? pairs[k].intensity_weight / std::sqrt(static_cast<double>(cloud.size()))
+                         : scaling;
+      for (size_t i = 0; i < cloud.size(); ++i, ++row) {
+        if (intensity_term && (*pairs[k].intensities)[i] > pairs[k].intensity_threshold)
+          continue;                       // residual[i] = T(0.f) (intensity_cost_function_3d.h:69-71)
+        const double v[3] = {static_cast<double>(cloud[i].x), static_cast<double>(cloud[i].y),
+                             static_cast<double>(cloud[i].z)};
+        // Eigen: uv = 2 (u x v); rotated = v + w uv + u x uv; world = rotated + translation.
+        double uv[3], uuv[3];
+        Cross(u, v, uv);
+        for (int a = 0; a < 3; ++a) uv[a] += uv[a];
+        Cross(u, uv, uuv);
+        double world[3];
+        for (int a = 0; a < 3; ++a) world[a] = ((v[a] + w * uv[a]) + uuv[a]) + translation[a];
+        double grad[3];
+        double sign;                      // d residual / d interpolated value, over the scaling
+        if (intensity_term) {
+          const double interpolated = InterpolatedIntensity(
+              *pairs[k].intensity_hybrid_grid, world[0], world[1], world[2],
+              jacobian ? grad : nullptr);
+          (*residuals)[row] =
+              term_scaling * (interpolated - static_cast<double>((*pairs[k].intensities)[i]));
+          sign = 1.;
+        } else {
+          const double probability = InterpolatedProbability(grid, world[0], world[1], world[2],
+                                                             jacobian ? grad : nullptr);
+          (*residuals)[row] = term_scaling * (1. - probability);
+          sign = -1.;
+        }
+        if (jacobian) {
+          const double sc = sign * term_scaling;
+          double* J = jacobian->data() + 7 * row;
+          for (int a = 0; a < 3; ++a) J[a] = sc * grad[a];              // d world / d t = I
+          // d world / d w = uv
+          J[3] = sc * (grad[0] * uv[0] + grad[1] * uv[1] + grad[2] * uv[2]);
+          for (int c = 0; c < 3; ++c) {
+            // d world / d u_c = w 2 (e_c x v) + e_c x uv + u x (2 e_c x v)
+            double e[3] = {0., 0., 0.};
+            e[c] = 1.;
+            double ev[3], euv[3], uev[3];
+            Cross(e, v, ev);
+            for (int a = 0; a < 3; ++a) ev[a] += ev[a];
+            Cross(e, uv, euv);
+            Cross(u, ev, uev);
+            double d = 0.;
+            for (int a = 0; a < 3; ++a) d += grad[a] * ((w * ev[a] + euv[a]) + uev[a]);
+            J[4 + c] = sc * d;
+          }
         }
       }
     }
@@ -230,24 +303,40 @@ void CeresScanMatcher3DMatch(const CeresOptions3D& options, const double target_
   const double target_rotation[4] = {initial_pose_estimate.q.w, initial_pose_estimate.q.x,
                                      initial_pose_estimate.q.y, initial_pose_estimate.q.z};
   std::vector<double> r, J;
+  const std::vector<ResidualBlock3D> blocks = CeresResidualBlocks3D(pairs);
   const auto evaluate = [&](const double x[7], Evaluation* e) {
     CeresResiduals3D(options, target_translation, target_rotation, pairs, x, x + 3, &r, &J);
     double plus[4][3];
     const int kr = PlusJacobian(yaw_only, x + 3, plus);
     *e = Evaluation();
     double local[kMaxLocal];
-    for (size_t i = 0; i < r.size(); ++i) {
-      const double* row = J.data() + 7 * i;
-      for (int a = 0; a < 3; ++a) local[a] = row[a];
-      for (int c = 0; c < kr; ++c) {
-        double s = 0.;
-        for (int m = 0; m < 4; ++m) s += row[3 + m] * plus[m][c];
-        local[3 + c] = s;
+    for (const ResidualBlock3D& block : blocks) {
+      // ResidualBlock::Evaluate: rho over the block's squared norm; Corrector (rho'' <= 0 for
+      // Huber): residuals and Jacobian times sqrt(rho'), cost 1/2 rho.
+      double s = 0.;
+      for (size_t i = block.begin; i < block.end; ++i) s += r[i] * r[i];
+      double rho0 = s, rho1 = 1.;
+      if (block.huber_a > 0.) {
+        const double a_ = block.huber_a, b_ = a_ * a_;
+        if (s > b_) {
+          const double root = std::sqrt(s);
+          rho0 = 2. * a_ * root - b_;
+          rho1 = std::max(std::numeric_limits<double>::min(), a_ / root);
+        }
       }
-      e->cost += r[i] * r[i];
-      for (int a = 0; a < K; ++a) {
-        e->g[a] += local[a] * r[i];
-        for (int b = 0; b < K; ++b) e->H[a][b] += local[a] * local[b];
+      e->cost += rho0;
+      for (size_t i = block.begin; i < block.end; ++i) {
+        const double* row = J.data() + 7 * i;
+        for (int a = 0; a < 3; ++a) local[a] = row[a];
+        for (int c = 0; c < kr; ++c) {
+          double sum = 0.;
+          for (int m = 0; m < 4; ++m) sum += row[3 + m] * plus[m][c];
+          local[3 + c] = sum;
+        }
+        for (int a = 0; a < K; ++a) {
+          e->g[a] += rho1 * (local[a] * r[i]);
+          for (int b = 0; b < K; ++b) e->H[a][b] += rho1 * (local[a] * local[b]);
+        }
       }
     }
     e->cost *= 0.5;

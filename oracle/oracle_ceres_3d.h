@@ -46,14 +46,47 @@ struct CeresOptions3D {            // proto::CeresScanMatcherOptions3D
   int max_num_iterations = 12;
 };
 
+// IntensityHybridGrid read side (mapping/3d/hybrid_grid.h:543-571): AverageIntensityData
+// {sum, count} per voxel, GetIntensity = sum / count (f32 / int) or 0 where nothing was added.
+struct IntensityVoxel { int32_t x, y, z; int32_t count; float sum; };
+class IntensityGridView {
+ public:
+  IntensityGridView(float resolution, const IntensityVoxel* voxels, int64_t n);
+  float resolution() const { return resolution_; }
+  Cell3i GetCellIndex(const V3f& p) const {      // HybridGridBase::GetCellIndex
+    return {RoundToInt(p.x / resolution_), RoundToInt(p.y / resolution_),
+            RoundToInt(p.z / resolution_)};
+  }
+  float GetIntensity(const Cell3i& c) const { return cells_.value(c.x, c.y, c.z); }
+ private:
+  float resolution_;
+  Brick<float> cells_;     // the quotient as the reference evaluates it on every read
+};
+
 struct CloudAndGrid3D {            // CeresScanMatcher3D::PointCloudAndHybridGridsPointers
   const PointCloud3* point_cloud;
   const HybridGridView* hybrid_grid;
+  // IntensityCostFunction3D (SM3/intensity_cost_function_3d.h, ceres_scan_matcher_3d.cc:118-137):
+  // null grid = no intensity residual block for this pair (what ConstraintBuilder3D passes).
+  const IntensityGridView* intensity_hybrid_grid = nullptr;
+  const std::vector<float>* intensities = nullptr;        // PointCloud::intensities()
+  double intensity_weight = 0., huber_scale = 0.;          // IntensityCostFunctionOptions
+  float intensity_threshold = 0.f;
 };
 
 // InterpolatedGrid::GetInterpolatedValue at (x, y, z) and its gradient (interpolated_grid.h).
 double InterpolatedProbability(const HybridGridView& grid, double x, double y, double z,
                                double gradient[3]);
+double InterpolatedIntensity(const IntensityGridView& grid, double x, double y, double z,
+                             double gradient[3]);
+
+// Residual blocks in the order CeresScanMatcher3D::Match adds them: per pair its occupied-space
+// block and (with an intensity grid) its intensity block, then translation, then rotation.
+// `huber_a` > 0: the block carries ceres::HuberLoss(a) -- applied to the BLOCK's squared norm s
+// (residual_block.cc): cost 1/2 rho(s), residuals and Jacobian scaled by sqrt(rho'(s))
+// (corrector.cc with rho'' <= 0).  CeresResiduals3D returns the RAW residuals and Jacobian.
+struct ResidualBlock3D { size_t begin, end; double huber_a; };
+std::vector<ResidualBlock3D> CeresResidualBlocks3D(const std::vector<CloudAndGrid3D>& pairs);
 
 // All residuals (sum of cloud sizes + 6) at translation[3], rotation[4] (w, x, y, z) and, when
 // `jacobian` is non-null, their Jacobian w.r.t. the 7 ambient parameters (row-major, 7 columns).

@@ -1025,6 +1025,75 @@ def ceres3d_match(pairs, target_xyz, init_pose7, occupied_space_weights, transla
                 termination=int(summary[4]))
 
 
+INTENSITY_VOXEL_DTYPE = np.dtype([("x", np.int32), ("y", np.int32), ("z", np.int32),
+                                  ("count", np.int32), ("sum", np.float32)])
+
+
+def _intensity_args(pairs):
+    """pairs with optional 4th..6th entries (intensities, intensity voxels, (weight, huber_scale,
+    threshold)); returns the four trailing arguments of *_ceres3d_match(_intensity) + keepalive."""
+    num = len(pairs)
+    if not any(len(p) > 3 and p[3] is not None for p in pairs):
+        return (None, None, None, None), None
+    ints = [np.ascontiguousarray(p[3], np.float32) if len(p) > 3 and p[3] is not None else None
+            for p in pairs]
+    voxs = [np.ascontiguousarray(p[4], INTENSITY_VOXEL_DTYPE) if ints[i] is not None else None
+            for i, p in enumerate(pairs)]
+    opts = np.zeros(3 * num, np.float64)
+    for i, p in enumerate(pairs):
+        if ints[i] is not None:
+            opts[3 * i:3 * i + 3] = p[5]
+    int_ptrs = (C.c_void_p * num)(*[a.ctypes.data if a is not None else None for a in ints])
+    vox_ptrs = (C.c_void_p * num)(*[a.ctypes.data if a is not None else None for a in voxs])
+    counts = np.array([a.shape[0] if a is not None else 0 for a in voxs], np.int64)
+    return (int_ptrs, vox_ptrs, counts.ctypes.data_as(C.c_void_p),
+            opts.ctypes.data_as(C.c_void_p)), (ints, voxs, opts, counts)
+
+
+def ceres3d_match_intensity(pairs, target_xyz, init_pose7, occupied_space_weights,
+                            translation_weight=5.0, rotation_weight=400.0,
+                            only_optimize_yaw=False, use_nonmonotonic_steps=False,
+                            max_num_iterations=12, reference=False):
+    """CeresScanMatcher3D::Match with IntensityCostFunction3D blocks: pairs =
+    [(xyz, resolution, voxels, intensities, intensity_voxels, (weight, huber_scale, threshold)), ...]
+    (entries 3.. may be missing / None for a pair without intensity grid).  reference=True: the
+    reference's own ceres_scan_matcher_3d.cc + intensity_cost_function_3d.{h,cc} (oracle/_ref)."""
+    args, keep = _ceres3d_args([p[:3] for p in pairs], occupied_space_weights, translation_weight,
+                               rotation_weight, only_optimize_yaw, use_nonmonotonic_steps,
+                               max_num_iterations)
+    iargs, ikeep = _intensity_args(pairs)
+    sig = [_f64p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _f64p, _f64p,
+           _f64p, _f64p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    if reference:
+        fn = ref_ceres_lib().refc_ceres3d_match
+    else:
+        fn = lib().orc_ceres3d_match_intensity
+        fn.argtypes, fn.restype = sig, None
+    pose, summary = np.empty(7, np.float64), np.empty(5, np.float64)
+    fn(*args, np.ascontiguousarray(target_xyz, np.float64),
+       np.ascontiguousarray(init_pose7, np.float64), pose, summary, *iargs)
+    del keep, ikeep
+    return dict(pose=pose, initial_cost=summary[0], final_cost=summary[1],
+                num_successful_steps=int(summary[2]), num_unsuccessful_steps=int(summary[3]),
+                termination=int(summary[4]))
+
+
+def intensity3d_residuals(scaling_factor, intensity_threshold, xyz, intensities, resolution,
+                          intensity_voxels, pose7, reference=False):
+    """IntensityCostFunction3D's residuals [n] and Jacobian [n, 7] at pose7 (before the loss)."""
+    xyz, n = _cloud(xyz)
+    ints = np.ascontiguousarray(intensities, np.float32)
+    vox = np.ascontiguousarray(intensity_voxels, INTENSITY_VOXEL_DTYPE)
+    fn = ref_ceres_lib().refc_intensity3d_residuals if reference else lib().orc_intensity3d_residuals
+    fn.argtypes = [C.c_double, C.c_float, _f32p, _f32p, C.c_int, C.c_float, C.c_void_p, C.c_int64,
+                   _f64p, _f64p, _f64p]
+    fn.restype = None
+    r, J = np.empty(n, np.float64), np.empty((n, 7), np.float64)
+    fn(scaling_factor, intensity_threshold, xyz, ints, n, resolution, vox.ctypes.data, vox.shape[0],
+       np.ascontiguousarray(pose7, np.float64), r, J)
+    return r, J
+
+
 def ceres3d_residuals(pairs, target_xyz, target_q4, pose7, occupied_space_weights,
                       translation_weight=5.0, rotation_weight=400.0, reference=False):
     """Residuals [N + 6] and their Jacobian [N + 6, 7] w.r.t. (t, q = w x y z) at pose7."""

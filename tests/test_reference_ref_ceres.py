@@ -188,3 +188,82 @@ def test_reference_ceres_scan_matcher_3d_test_through_the_reference_source(refc,
                                 max_num_iterations=10)
     np.testing.assert_allclose(mine["pose"], out["pose"], rtol=0, atol=1e-8)
 
+
+
+# ------------------------------------------------------------- intensity (f1, 3D) ---
+def _intensity_world(synth, oracle, seed):
+    """A probability grid from a synthetic room plus an intensity grid over the same voxels:
+    AddIntensity-style (count, sum) records with a smooth intensity field and per-point
+    intensities that partly exceed the threshold."""
+    grid, world = synth.make_submap_3d(seed, 0.1, (8.0, 8.0, 4.0), 4, 8, 96)
+    vox = grid.voxels()
+    rng = np.random.default_rng(seed)
+    iv = np.zeros(len(vox), oracle.INTENSITY_VOXEL_DTYPE)
+    iv["x"], iv["y"], iv["z"] = vox["x"], vox["y"], vox["z"]
+    iv["count"] = rng.integers(1, 5, len(vox))
+    field = 60.0 + 25.0 * np.sin(0.21 * vox["x"]) + 15.0 * np.cos(0.17 * vox["y"] + 0.3 * vox["z"])
+    iv["sum"] = (field * iv["count"]).astype(np.float32)
+    iv["count"][::17] = 0                                  # cells that were never hit: intensity 0
+    pos = world.free_position(seed + 1, 0.5)
+    cloud = world.scan(pos, 0.3, 8, 64, seed=9)[::2].copy()
+    intensities = rng.uniform(20.0, 140.0, len(cloud)).astype(np.float32)
+    return vox, iv, pos, cloud, intensities
+
+
+def test_reference_intensity_cost_function_smoke_test(refc, oracle):
+    """IntensityCostFunction3DTest.SmokeTest (intensity_cost_function_3d_test.cc:36-64) on the
+    reference's own intensity_cost_function_3d.{h,cc} and on the restatement: residuals
+    (0, -100, 0)."""
+    cloud = np.array([[0, 0, 0], [1, 1, 1], [2, 2, 2]], np.float32)
+    intensities = np.array([50.0, 100.0, 150.0], np.float32)
+    iv = np.zeros(1, oracle.INTENSITY_VOXEL_DTYPE)
+    iv["count"], iv["sum"] = 1, 50.0                        # AddIntensity(cell of (0,0,0), 50)
+    pose = [0, 0, 0, 1, 0, 0, 0]
+    for reference in (True, False):
+        r, _ = oracle.intensity3d_residuals(1.0, 100.0, cloud, intensities, 0.3, iv, pose,
+                                            reference=reference)
+        np.testing.assert_allclose(r, [0.0, -100.0, 0.0], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("seed", [5, 8])
+def test_intensity_residuals_and_jacobians_equal_the_reference(refc, oracle, synth, seed):
+    """IntensityCostFunction3D over InterpolatedGrid<IntensityHybridGrid> through Jets against
+    the restatement: residuals and 7-column Jacobians on random poses, points above the
+    threshold included (residual and derivative zero)."""
+    _, iv, pos, cloud, intensities = _intensity_world(synth, oracle, seed)
+    rng = np.random.default_rng(seed)
+    for _ in range(4):
+        q = np.array(quat_from_angle_axis(rng.uniform(0.05, 0.6), rng.uniform(-1, 1, 3)))
+        pose = np.array(list(pos * 0 + rng.uniform(-0.05, 0.05, 3)) + list(q))
+        r, J = oracle.intensity3d_residuals(0.7, 100.0, cloud, intensities, 0.1, iv, pose)
+        rr, JJ = oracle.intensity3d_residuals(0.7, 100.0, cloud, intensities, 0.1, iv, pose,
+                                              reference=True)
+        np.testing.assert_allclose(r, rr, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(J, JJ, rtol=0, atol=1e-10 * max(1.0, np.abs(J).max()))
+        above = intensities > 100.0
+        assert above.any() and (~above).any()
+        assert np.all(r[above] == 0.0) and np.all(J[above] == 0.0) and np.abs(r[~above]).max() > 1.0
+
+
+@pytest.mark.parametrize("huber_scale", [0.3, 1e6])
+def test_3d_match_with_intensity_equals_the_reference_match(refc, oracle, synth, huber_scale):
+    """CeresScanMatcher3D::Match with an IntensityCostFunction3D block under ceres::HuberLoss
+    (ceres_scan_matcher_3d.cc:118-137): huber_scale 0.3 puts the block in the outlier region
+    (rho' < 1), 1e6 leaves it quadratic.  The reference's own source against the restatement."""
+    vox, iv, pos, cloud, intensities = _intensity_world(synth, oracle, 7)
+    low, _ = synth.make_submap_3d(7, 0.3, (8.0, 8.0, 4.0), 4, 8, 96)
+    pairs = [(cloud, 0.1, vox, intensities, iv, (0.5, huber_scale, 100.0)),
+             (cloud[::4].copy(), 0.3, low.voxels())]
+    init_t = np.array([0.04, -0.03, 0.02])
+    init = list(init_t) + quat_from_angle_axis(0.02, [0.05, -0.02, 1.0])
+    kw = dict(translation_weight=5.0, rotation_weight=4e2, max_num_iterations=12)
+    a = oracle.ceres3d_match_intensity(pairs, init_t, init, [1.0, 6.0], **kw)
+    b = oracle.ceres3d_match_intensity(pairs, init_t, init, [1.0, 6.0], reference=True, **kw)
+    np.testing.assert_allclose(a["pose"], b["pose"], rtol=0, atol=1e-9)
+    assert a["initial_cost"] == pytest.approx(b["initial_cost"], rel=1e-12)
+    assert a["final_cost"] == pytest.approx(b["final_cost"], rel=1e-9)
+    assert (a["num_successful_steps"], a["num_unsuccessful_steps"], a["termination"]) == \
+        (b["num_successful_steps"], b["num_unsuccessful_steps"], b["termination"])
+    # the intensity block matters: without it the match ends elsewhere
+    plain = oracle.ceres3d_match([p[:3] for p in pairs], init_t, init, [1.0, 6.0], **kw)
+    assert np.abs(plain["pose"] - a["pose"]).max() > 1e-6
