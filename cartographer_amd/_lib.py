@@ -85,9 +85,22 @@ class Ceres3DOptions(C.Structure):
                 ("max_num_iterations", C.c_int32)]
 
 
+class IntensityVoxel(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("z", C.c_int32), ("count", C.c_int32),
+                ("sum", C.c_float)]
+
+
+INTENSITY_VOXEL_DTYPE = np.dtype([("x", np.int32), ("y", np.int32), ("z", np.int32),
+                                  ("count", np.int32), ("sum", np.float32)])
+
+
 class Ceres3DPair(C.Structure):
     _fields_ = [("point_cloud_xyz", C.c_void_p), ("num_points", C.c_int32),
-                ("resolution", C.c_float), ("voxels", C.c_void_p), ("num_voxels", C.c_int64)]
+                ("resolution", C.c_float), ("voxels", C.c_void_p), ("num_voxels", C.c_int64),
+                ("intensities", C.c_void_p), ("intensity_voxels", C.c_void_p),
+                ("num_intensity_voxels", C.c_int64), ("intensity_weight", C.c_double),
+                ("intensity_huber_scale", C.c_double), ("intensity_threshold", C.c_float),
+                ("reserved", C.c_int32)]
 
 
 class Voxel(C.Structure):

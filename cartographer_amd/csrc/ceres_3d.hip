@@ -6,8 +6,9 @@
 // Reference: SM3/ceres_scan_matcher_3d.cc:90-156, SM3/occupied_space_cost_function_3d.h:66-97,
 // SM3/interpolated_grid.h:36-151 (piecewise cubic with vanishing derivatives at the voxel
 // centres), SM3/translation_delta_cost_functor_3d.h:43-50, SM3/rotation_delta_cost_functor_3d.h:
-// 43-55, mapping/internal/3d/rotation_parameterization.h:27-39.  Probability grids only (the
-// intensity cost function belongs to IntensityHybridGrid, out of scope).
+// 43-55, mapping/internal/3d/rotation_parameterization.h:27-39, SM3/intensity_cost_function_3d.h:
+// 37-91 (optional per pair: InterpolatedGrid over the IntensityHybridGrid, ceres::HuberLoss on
+// the block).
 // The least-squares solver is Ceres (third party, absent from the reference tree): what runs
 // here is its published trust-region Levenberg-Marquardt loop with Solver::Options defaults in
 // the tangent space of the pose (translation: identity; rotation: QuaternionParameterization,
@@ -39,6 +40,13 @@ struct Ceres3DPair {
   int n;
   const float* xyz;
   double scaling;          // occupied_space_weight / sqrt(n)
+  // IntensityCostFunction3D of this pair (has_intensity != 0)
+  int has_intensity;
+  float intensity_threshold;
+  Brick igrid;             // f32: AverageIntensityData sum / count, 0 elsewhere
+  const float* intensities;
+  double iscaling;         // weight / sqrt(n)
+  double huber_a;          // HuberLoss(a): rho over the block's squared norm
 };
 
 struct Ceres3DProblem {
@@ -59,9 +67,24 @@ __device__ __forceinline__ double Probability(const Brick& b, int x, int y, int 
 
 // InterpolatedGrid::GetInterpolatedValue and its gradient (SM3/interpolated_grid.h:57-92,
 // 99-130).
+__device__ __forceinline__ double Intensity(const Brick& b, int x, int y, int z) {
+  const int ix = x - b.lo_x, iy = y - b.lo_y, iz = z - b.lo_z;
+  const bool inside = static_cast<unsigned>(ix) < static_cast<unsigned>(b.nx) &&
+                      static_cast<unsigned>(iy) < static_cast<unsigned>(b.ny) &&
+                      static_cast<unsigned>(iz) < static_cast<unsigned>(b.nz);
+  const float v = static_cast<const float*>(b.cells)[
+      inside ? (static_cast<size_t>(iz) * b.ny + iy) * b.nx + ix : 0];
+  return inside ? static_cast<double>(v) : 0.;
+}
+
+template <bool kIntensity>
 __device__ __forceinline__ double Interpolate(const Ceres3DPair& p, double x, double y, double z,
                                               double gradient[3]) {
   const float res = p.resolution;
+  const Brick& grid = kIntensity ? p.igrid : p.grid;
+  const auto value = [&](int cx_, int cy_, int cz_) {
+    return kIntensity ? Intensity(grid, cx_, cy_, cz_) : Probability(grid, cx_, cy_, cz_);
+  };
   const int3 at = CellIndex3(F3{static_cast<float>(x), static_cast<float>(y), static_cast<float>(z)},
                              res);
   float cx = static_cast<float>(at.x) * res, cy = static_cast<float>(at.y) * res,
@@ -72,14 +95,14 @@ __device__ __forceinline__ double Interpolate(const Ceres3DPair& p, double x, do
   const double x1 = cx, y1 = cy, z1 = cz;
   const double x2 = cx + res, y2 = cy + res, z2 = cz + res;     // f32 additions
   const int3 i1 = CellIndex3(F3{cx, cy, cz}, res);
-  const double q111 = Probability(p.grid, i1.x, i1.y, i1.z);
-  const double q112 = Probability(p.grid, i1.x, i1.y, i1.z + 1);
-  const double q121 = Probability(p.grid, i1.x, i1.y + 1, i1.z);
-  const double q122 = Probability(p.grid, i1.x, i1.y + 1, i1.z + 1);
-  const double q211 = Probability(p.grid, i1.x + 1, i1.y, i1.z);
-  const double q212 = Probability(p.grid, i1.x + 1, i1.y, i1.z + 1);
-  const double q221 = Probability(p.grid, i1.x + 1, i1.y + 1, i1.z);
-  const double q222 = Probability(p.grid, i1.x + 1, i1.y + 1, i1.z + 1);
+  const double q111 = value(i1.x, i1.y, i1.z);
+  const double q112 = value(i1.x, i1.y, i1.z + 1);
+  const double q121 = value(i1.x, i1.y + 1, i1.z);
+  const double q122 = value(i1.x, i1.y + 1, i1.z + 1);
+  const double q211 = value(i1.x + 1, i1.y, i1.z);
+  const double q212 = value(i1.x + 1, i1.y, i1.z + 1);
+  const double q221 = value(i1.x + 1, i1.y + 1, i1.z);
+  const double q222 = value(i1.x + 1, i1.y + 1, i1.z + 1);
   const double nx = (x - x1) / (x2 - x1), ny = (y - y1) / (y2 - y1), nz = (z - z1) / (z2 - z1);
   const double nxx = nx * nx, nxxx = nx * nxx, nyy = ny * ny, nyyy = ny * nyy, nzz = nz * nz,
                nzzz = nz * nzz;
@@ -155,59 +178,96 @@ __device__ void Evaluate3D(const Ceres3DProblem& P, const double x[7], int K,
     plus[3][0] = x[5];  plus[3][1] = -x[4]; plus[3][2] = x[3];
   }
   const int kr = K - 3;
+  // One residual of point i of pair `pr`: occupied space (sign -1: scaling (1 - p)) or intensity
+  // (sign +1: scaling (interpolated - intensity)); accumulated into `acc`.
+  const auto point_row = [&](const Ceres3DPair& pr, int i, bool intensity_term, double* acc) {
+    const double v[3] = {static_cast<double>(pr.xyz[3 * i]), static_cast<double>(pr.xyz[3 * i + 1]),
+                         static_cast<double>(pr.xyz[3 * i + 2])};
+    double uv[3], uuv[3];
+    Cross3(u, v, uv);
+    for (int a = 0; a < 3; ++a) uv[a] += uv[a];
+    Cross3(u, uv, uuv);
+    double world[3];
+    for (int a = 0; a < 3; ++a) world[a] = ((v[a] + w * uv[a]) + uuv[a]) + x[a];
+    double grad[3];
+    double r, sc;
+    if (intensity_term) {
+      const double interpolated = Interpolate<true>(pr, world[0], world[1], world[2], grad);
+      r = pr.iscaling * (interpolated - static_cast<double>(pr.intensities[i]));
+      sc = pr.iscaling;
+    } else {
+      const double probability = Interpolate<false>(pr, world[0], world[1], world[2], grad);
+      r = pr.scaling * (1. - probability);
+      sc = -pr.scaling;
+    }
+    double amb[4];            // d r / d (w, ux, uy, uz)
+    amb[0] = sc * (grad[0] * uv[0] + grad[1] * uv[1] + grad[2] * uv[2]);
+    for (int c = 0; c < 3; ++c) {
+      double e3[3] = {0., 0., 0.};
+      e3[c] = 1.;
+      double ev[3], euv[3], uev[3];
+      Cross3(e3, v, ev);
+      for (int a = 0; a < 3; ++a) ev[a] += ev[a];
+      Cross3(e3, uv, euv);
+      Cross3(u, ev, uev);
+      double d = 0.;
+      for (int a = 0; a < 3; ++a) d += grad[a] * ((w * ev[a] + euv[a]) + uev[a]);
+      amb[1 + c] = sc * d;
+    }
+    double local[kMaxLocal] = {0., 0., 0., 0., 0., 0.};
+    for (int a = 0; a < 3; ++a) local[a] = sc * grad[a];
+    for (int c = 0; c < kr; ++c) {
+      double s = 0.;
+      for (int m = 0; m < 4; ++m) s += amb[m] * plus[m][c];
+      local[3 + c] = s;
+    }
+    Accumulate(r, local, K, acc);
+  };
+  const int wave = threadIdx.x >> 6;
+  // Block-wide sums of a thread-local accumulator, in a FIXED order (valid in every thread).
+  const auto reduce = [&](const double* acc, double* total) {
+#pragma unroll
+    for (int k = 0; k < kNumSums; ++k) {
+      const double t = WaveSumF64(acc[k]);
+      if ((threadIdx.x & 63) == 0) scratch[wave][k] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kNumSums; ++k)
+      total[k] = ((scratch[0][k] + scratch[1][k]) + scratch[2][k]) + scratch[3][k];
+    __syncthreads();
+  };
   double acc[kNumSums];
 #pragma unroll
   for (int k = 0; k < kNumSums; ++k) acc[k] = 0.;
   for (int pi = 0; pi < P.num_pairs; ++pi) {
     const Ceres3DPair& pr = P.pair[pi];
-    for (int i = threadIdx.x; i < pr.n; i += kCeres3DThreads) {
-      const double v[3] = {static_cast<double>(pr.xyz[3 * i]), static_cast<double>(pr.xyz[3 * i + 1]),
-                           static_cast<double>(pr.xyz[3 * i + 2])};
-      double uv[3], uuv[3];
-      Cross3(u, v, uv);
-      for (int a = 0; a < 3; ++a) uv[a] += uv[a];
-      Cross3(u, uv, uuv);
-      double world[3];
-      for (int a = 0; a < 3; ++a) world[a] = ((v[a] + w * uv[a]) + uuv[a]) + x[a];
-      double grad[3];
-      const double probability = Interpolate(pr, world[0], world[1], world[2], grad);
-      const double r = pr.scaling * (1. - probability);
-      double amb[4];            // d r / d (w, ux, uy, uz)
-      amb[0] = -pr.scaling * (grad[0] * uv[0] + grad[1] * uv[1] + grad[2] * uv[2]);
-      for (int c = 0; c < 3; ++c) {
-        double e3[3] = {0., 0., 0.};
-        e3[c] = 1.;
-        double ev[3], euv[3], uev[3];
-        Cross3(e3, v, ev);
-        for (int a = 0; a < 3; ++a) ev[a] += ev[a];
-        Cross3(e3, uv, euv);
-        Cross3(u, ev, uev);
-        double d = 0.;
-        for (int a = 0; a < 3; ++a) d += grad[a] * ((w * ev[a] + euv[a]) + uev[a]);
-        amb[1 + c] = -pr.scaling * d;
-      }
-      double local[kMaxLocal] = {0., 0., 0., 0., 0., 0.};
-      for (int a = 0; a < 3; ++a) local[a] = -pr.scaling * grad[a];
-      for (int c = 0; c < kr; ++c) {
-        double s = 0.;
-        for (int m = 0; m < 4; ++m) s += amb[m] * plus[m][c];
-        local[3 + c] = s;
-      }
-      Accumulate(r, local, K, acc);
-    }
+    for (int i = threadIdx.x; i < pr.n; i += kCeres3DThreads) point_row(pr, i, false, acc);
   }
-  const int wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < kNumSums; ++k) {
-    const double t = WaveSumF64(acc[k]);
-    if ((threadIdx.x & 63) == 0) scratch[wave][k] = t;
-  }
-  __syncthreads();
   double total[kNumSums];
+  reduce(acc, total);
+  // Intensity blocks: ceres::HuberLoss acts on the BLOCK's squared norm s (residual_block.cc,
+  // corrector.cc with rho'' <= 0): cost 1/2 rho(s), J^T r and J^T J times rho'(s).
+  for (int pi = 0; pi < P.num_pairs; ++pi) {
+    const Ceres3DPair& pr = P.pair[pi];
+    if (!pr.has_intensity) continue;                          // (uniform)
 #pragma unroll
-  for (int k = 0; k < kNumSums; ++k)
-    total[k] = ((scratch[0][k] + scratch[1][k]) + scratch[2][k]) + scratch[3][k];
-  __syncthreads();
+    for (int k = 0; k < kNumSums; ++k) acc[k] = 0.;
+    for (int i = threadIdx.x; i < pr.n; i += kCeres3DThreads)
+      if (!(pr.intensities[i] > pr.intensity_threshold)) point_row(pr, i, true, acc);
+    double block[kNumSums];
+    reduce(acc, block);
+    const double s = block[0], b_ = pr.huber_a * pr.huber_a;
+    double rho0 = s, rho1 = 1.;
+    if (s > b_) {
+      const double root = sqrt(s);
+      rho0 = 2. * pr.huber_a * root - b_;
+      rho1 = fmax(2.2250738585072014e-308, pr.huber_a / root);
+    }
+    total[0] += rho0;
+#pragma unroll
+    for (int k = 1; k < kNumSums; ++k) total[k] += rho1 * block[k];
+  }
   // TranslationDeltaCostFunctor3D and RotationDeltaCostFunctor3D: six more rows, the same in
   // every thread.
   for (int a = 0; a < 3; ++a) {
@@ -314,9 +374,15 @@ Ceres3DKernel(const Ceres3DProblem* __restrict__ problems) {
     for (int a = 0; a < 7; ++a) s += v[a] * v[a];
     return sqrt(s);
   };
-  const auto gradient_max_norm = [K](const Eval3D& e) {
+  // TrustRegionMinimizer::ComputeGradientMaxNorm: |x - Plus(x, -g)|_inf over the ambient
+  // coordinates (`x` is always the point the evaluation was taken at).
+  const auto gradient_max_norm = [K, yaw_only, &x](const Eval3D& e) {
     double m = 0.;
-    for (int a = 0; a < K; ++a) m = fmax(m, fabs(e.g[a]));
+    for (int a = 0; a < 3; ++a) m = fmax(m, fabs(e.g[a]));
+    double negative[3] = {0., 0., 0.}, projected[4];
+    for (int a = 3; a < K; ++a) negative[a - 3] = -e.g[a];
+    PlusRotation(yaw_only, x + 3, negative, projected);
+    for (int a = 0; a < 4; ++a) m = fmax(m, fabs(x[3 + a] - projected[a]));
     return m;
   };
   double x_cost = at_x.cost, x_norm = norm7(x);
@@ -452,9 +518,62 @@ void CheckOptions(const cmx_ceres3d_options& o) {
               o.num_pairs, kMaxPairs);
   CMX_REQUIRE(o.translation_weight > 0. && o.rotation_weight > 0.,
               "translation_weight and rotation_weight must be > 0");
-  CMX_REQUIRE(o.max_num_iterations >= 0, "max_num_iterations must be >= 0");
+  // common/internal/ceres_solver_options.cc:30 CHECK_GT (the 2D entry points check the same)
+  CMX_REQUIRE(o.max_num_iterations > 0, "max_num_iterations must be > 0");
   for (int k = 0; k < o.num_pairs; ++k)
     CMX_REQUIRE(o.occupied_space_weight[k] > 0., "occupied_space_weight must be > 0");
+}
+
+// IntensityHybridGrid as a dense f32 brick of GetIntensity values (hybrid_grid.h:560-566: sum /
+// count in f32, 0 where the cell holds no data; the division is done on the host).
+struct IntensityCell { int32_t x, y, z; float value; };
+__global__ void ScatterIntensityKernel(const IntensityCell* __restrict__ cells, long long n, Brick b,
+                                       float* __restrict__ out) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const IntensityCell c = cells[i];
+  const int ix = c.x - b.lo_x, iy = c.y - b.lo_y, iz = c.z - b.lo_z;
+  out[(static_cast<size_t>(iz) * b.ny + iy) * b.nx + ix] = c.value;
+}
+
+void BuildIntensityBrick(Workspace& ws, const cmx_intensity_voxel* voxels, int64_t n,
+                         DeviceBrick* out) {
+  int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  std::vector<IntensityCell> cells;
+  cells.reserve(static_cast<size_t>(n));
+  for (int64_t i = 0; i < n; ++i) {
+    const cmx_intensity_voxel& v = voxels[i];
+    CMX_REQUIRE(v.count >= 0, "intensity voxel %lld has a negative count",
+                static_cast<long long>(i));
+    if (v.count == 0) continue;
+    const int at[3] = {v.x, v.y, v.z};
+    for (int k = 0; k < 3; ++k) {
+      CMX_REQUIRE(at[k] > -(1 << 20) && at[k] < (1 << 20), "voxel index out of range");
+      lo[k] = cells.empty() ? at[k] : std::min(lo[k], at[k]);
+      hi[k] = cells.empty() ? at[k] : std::max(hi[k], at[k]);
+    }
+    cells.push_back({v.x, v.y, v.z, v.sum / static_cast<float>(v.count)});
+  }
+  Brick b{};
+  b.lo_x = lo[0]; b.lo_y = lo[1]; b.lo_z = lo[2];
+  b.nx = hi[0] - lo[0] + 1; b.ny = hi[1] - lo[1] + 1; b.nz = hi[2] - lo[2] + 1;
+  const size_t num_cells = static_cast<size_t>(b.nx) * b.ny * b.nz;
+  CMX_REQUIRE(num_cells * sizeof(float) < (size_t(8) << 30),
+              "dense intensity grid of %d x %d x %d cells is too large", b.nx, b.ny, b.nz);
+  out->bytes = num_cells * sizeof(float);
+  CMX_HIP(hipMalloc(&out->mem, out->bytes + 16));
+  b.cells = out->mem;
+  out->desc = b;
+  CMX_HIP(hipMemsetAsync(out->mem, 0, out->bytes, ws.stream));
+  if (!cells.empty()) {
+    IntensityCell* d_cells = ws.dev[15].ReserveAs<IntensityCell>(cells.size());
+    CMX_HIP(hipMemcpyAsync(d_cells, cells.data(), cells.size() * sizeof(IntensityCell),
+                           hipMemcpyHostToDevice, ws.stream));
+    ScatterIntensityKernel<<<DivUp(static_cast<long long>(cells.size()), 256), 256, 0, ws.stream>>>(
+        d_cells, static_cast<long long>(cells.size()), b, static_cast<float*>(out->mem));
+    CMX_HIP(hipGetLastError());
+  }
+  CMX_HIP(hipStreamSynchronize(ws.stream));   // `cells` is host memory of this frame
 }
 
 void SetOptions(const cmx_ceres3d_options& o, Ceres3DProblem* P) {
@@ -529,6 +648,17 @@ extern "C" cmx_status cmx_ceres3d_match(const cmx_ceres3d_options* options,
       CMX_REQUIRE(in.resolution > 0.f, "resolution must be > 0");
       CMX_REQUIRE(in.num_voxels == 0 || in.voxels != nullptr, "voxels is null");
       cloud_floats += 3 * static_cast<size_t>(in.num_points);
+      if (in.intensities != nullptr) {
+        // CHECKs of CreateIntensityCostFunctionOptions' consumers (ceres_scan_matcher_3d.cc:
+        // 118-137, intensity_cost_function_3d.h:41-47) and of ceres::HuberLoss (a > 0).
+        CMX_REQUIRE(in.num_intensity_voxels >= 0 &&
+                        (in.num_intensity_voxels == 0 || in.intensity_voxels != nullptr),
+                    "intensity_voxels is null");
+        CMX_REQUIRE(in.intensity_weight > 0., "intensity weight must be > 0");
+        CMX_REQUIRE(in.intensity_huber_scale > 0., "intensity huber_scale must be > 0");
+        CMX_REQUIRE(in.intensity_threshold > 0.f, "intensity_threshold must be > 0");
+        cloud_floats += static_cast<size_t>(in.num_points);
+      }
     }
     float* d_xyz = ws->dev[0].ReserveAs<float>(cloud_floats);
     float* h_xyz = ws->pinned[0].ReserveAs<float>(cloud_floats);
@@ -545,6 +675,18 @@ extern "C" cmx_status cmx_ceres3d_match(const cmx_ceres3d_options* options,
       P.pair[k].scaling =
           options->occupied_space_weight[k] / std::sqrt(static_cast<double>(in.num_points));
       off += 3 * static_cast<size_t>(in.num_points);
+      if (in.intensities != nullptr) {
+        bricks.emplace_back(new DeviceBrick);
+        BuildIntensityBrick(*ws, in.intensity_voxels, in.num_intensity_voxels, bricks.back().get());
+        std::memcpy(h_xyz + off, in.intensities, sizeof(float) * in.num_points);
+        P.pair[k].has_intensity = 1;
+        P.pair[k].intensity_threshold = in.intensity_threshold;
+        P.pair[k].igrid = bricks.back()->desc;
+        P.pair[k].intensities = d_xyz + off;
+        P.pair[k].iscaling = in.intensity_weight / std::sqrt(static_cast<double>(in.num_points));
+        P.pair[k].huber_a = in.intensity_huber_scale;
+        off += static_cast<size_t>(in.num_points);
+      }
     }
     for (int a = 0; a < 3; ++a) {
       P.target[a] = target_translation_xyz[a];

@@ -167,7 +167,18 @@ cmx_status cmx_comm_init(const int32_t* devices, int32_t num_devices, cmx_comm**
       cmx::SetLastError("no HIP device available; this library has no CPU fallback");
       throw cmx::HipError{CMX_DEVICE_ERROR};
     }
-    std::unique_ptr<cmx_comm> comm(new cmx_comm);
+    int current = -1;
+    if (hipGetDevice(&current) != hipSuccess) current = -1;
+    // cmx_comm_destroy releases whatever exists so far (comms, streams, keys, workers): a
+    // failure half-way through leaks nothing.
+    struct Release {
+      int device;
+      void operator()(cmx_comm* c) const {
+        cmx_comm_destroy(c);
+        if (device >= 0) (void)hipSetDevice(device);
+      }
+    };
+    std::unique_ptr<cmx_comm, Release> comm(new cmx_comm, Release{current});
     for (int i = 0; i < num_devices; ++i) {
       const int d = devices ? devices[i] : i;
       CMX_REQUIRE(d >= 0 && d < count, "device %d out of range [0,%d)", d, count);
@@ -194,11 +205,14 @@ cmx_status cmx_comm_init(const int32_t* devices, int32_t num_devices, cmx_comm**
       comm->workers.emplace_back(new cmx::DeviceWorker(comm->devices[i]));
     }
     *out = comm.release();
+    if (current >= 0) (void)hipSetDevice(current);
   });
 }
 
 void cmx_comm_destroy(cmx_comm* comm) {
   if (!comm) return;
+  int current = -1;
+  if (hipGetDevice(&current) != hipSuccess) current = -1;
   const cmx::Rccl& rccl = cmx::LoadRccl();
   comm->workers.clear();
   for (size_t i = 0; i < comm->devices.size(); ++i) {
@@ -207,6 +221,7 @@ void cmx_comm_destroy(cmx_comm* comm) {
     if (i < comm->streams.size() && comm->streams[i]) (void)hipStreamDestroy(comm->streams[i]);
     if (i < comm->comms.size() && comm->comms[i] && rccl.CommDestroy) rccl.CommDestroy(comm->comms[i]);
   }
+  if (current >= 0) (void)hipSetDevice(current);
   delete comm;
 }
 
@@ -230,9 +245,18 @@ int32_t cmx_comm_device_of(const cmx_comm* comm, int64_t index, int64_t num_item
 namespace cmx {
 namespace {
 
+// The sharded calls make every device of the communicator current in turn on the CALLING
+// thread; the caller's own current device (torch's, say) is put back on every exit path.
+struct RestoreDevice {
+  int device = -1;
+  RestoreDevice() { if (hipGetDevice(&device) != hipSuccess) device = -1; }
+  ~RestoreDevice() { if (device >= 0) (void)hipSetDevice(device); }
+};
+
 // Node-wide best match: every device contributes the key of its own block, one
 // all-reduce(max) over the communicator; returns the reduced key (read back from rank 0).
 int64_t AllReduceBest(cmx_comm* comm, const std::vector<int64_t>& keys) {
+  const RestoreDevice restore;
   const Rccl& rccl = LoadRccl();
   const int world = static_cast<int>(comm->devices.size());
   for (int r = 0; r < world; ++r) {
@@ -283,7 +307,11 @@ void FanOut(cmx_comm* comm, int num, DeviceOf device_of, PerRank per_rank) {
   for (int r = 0; r < world; ++r) {
     if (mine[r].empty()) continue;
     comm->workers[r]->Submit([&, r] {
-      status[r] = per_rank(r, mine[r]);
+      // The job body allocates (std::vector) before it reaches the guarded ABI call: an
+      // exception must not leave the worker thread (std::terminate).
+      cmx_status inner = CMX_OK;
+      const cmx_status outer = Guard([&] { inner = per_rank(r, mine[r]); });
+      status[r] = outer != CMX_OK ? outer : inner;
       if (status[r] != CMX_OK) errors[r] = LastError();
     });
   }
@@ -303,6 +331,10 @@ void AddStats(cmx_match_stats* total, const cmx_match_stats& s) {
   total->num_scans += s.num_scans;
   total->device_ms = std::max(total->device_ms, s.device_ms);        // the devices overlap
   total->dominant_kernel_ms = std::max(total->dominant_kernel_ms, s.dominant_kernel_ms);
+  total->expansion_ms = std::max(total->expansion_ms, s.expansion_ms);
+  total->expansion_launches += s.expansion_launches;
+  total->expansion_nodes += s.expansion_nodes;
+  total->expansion_lookups += s.expansion_lookups;
 }
 
 }  // namespace

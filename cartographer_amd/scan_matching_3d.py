@@ -70,11 +70,13 @@ class RealTimeCorrelativeScanMatcher3D:
 
 
 class CeresScanMatcher3D:
-    """CeresScanMatcher3D (SM3/ceres_scan_matcher_3d.h:48-66), probability grids only.
+    """CeresScanMatcher3D (SM3/ceres_scan_matcher_3d.h:48-66).
 
     ``match(target_translation, initial_pose_estimate, point_clouds_and_hybrid_grids)`` with
     ``point_clouds_and_hybrid_grids = [(point_cloud, grid_resolution, grid_voxels), ...]`` (one
-    entry per occupied_space_weight) returns ``(pose_estimate, summary dict)``."""
+    entry per occupied_space_weight) returns ``(pose_estimate, summary dict)``.  An entry may
+    continue with ``intensities, intensity_voxels, (weight, huber_scale, intensity_threshold)``:
+    the pair's intensity_hybrid_grid with its IntensityCostFunctionOptions."""
 
     def __init__(self, occupied_space_weights, translation_weight, rotation_weight,
                  only_optimize_yaw=False, use_nonmonotonic_steps=False, max_num_iterations=12,
@@ -97,7 +99,8 @@ class CeresScanMatcher3D:
         assert len(point_clouds_and_hybrid_grids) == num
         keep = []
         pairs = (Ceres3DPair * num)()
-        for k, (cloud, resolution, voxels) in enumerate(point_clouds_and_hybrid_grids):
+        for k, entry in enumerate(point_clouds_and_hybrid_grids):
+            cloud, resolution, voxels = entry[:3]
             xyz, n = _cloud(cloud)
             vox, nv = _voxels(voxels)
             keep += [xyz, vox]
@@ -106,6 +109,20 @@ class CeresScanMatcher3D:
             pairs[k].resolution = float(resolution)
             pairs[k].voxels = vox.ctypes.data if nv else None
             pairs[k].num_voxels = nv
+            if len(entry) > 3 and entry[3] is not None:
+                # (intensities, intensity voxels, (weight, huber_scale, intensity_threshold)):
+                # the pair's intensity_hybrid_grid and its IntensityCostFunctionOptions
+                from ._lib import INTENSITY_VOXEL_DTYPE
+                ints = np.ascontiguousarray(entry[3], np.float32)
+                ivox = np.ascontiguousarray(entry[4], INTENSITY_VOXEL_DTYPE)
+                keep += [ints, ivox]
+                assert ints.shape[0] == n
+                pairs[k].intensities = ints.ctypes.data
+                pairs[k].intensity_voxels = ivox.ctypes.data if ivox.shape[0] else None
+                pairs[k].num_intensity_voxels = ivox.shape[0]
+                pairs[k].intensity_weight = float(entry[5][0])
+                pairs[k].intensity_huber_scale = float(entry[5][1])
+                pairs[k].intensity_threshold = float(entry[5][2])
         target = np.ascontiguousarray(target_translation, np.float64)
         init = initial_pose_estimate.to_c()
         pose = Pose3d()

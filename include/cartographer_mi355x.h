@@ -302,7 +302,8 @@ cmx_status cmx_fast2d_refine_batch(const cmx_ceres2d_options* options,
 
 /* ---- CeresScanMatcher3D ------------------------------------------- */
 /* proto::CeresScanMatcherOptions3D (mapping/proto/scan_matching/ceres_scan_matcher_options_3d.proto)
- * without the intensity cost function, + the ceres_solver_options cartographer sets. */
+ * + the ceres_solver_options cartographer sets; the per-pair IntensityCostFunctionOptions ride
+ * with the pair they belong to (cmx_ceres3d_pair). */
 typedef struct cmx_ceres3d_options {
   double occupied_space_weight[3];   /* one per (point cloud, hybrid grid) pair */
   double translation_weight;
@@ -312,6 +313,13 @@ typedef struct cmx_ceres3d_options {
   int32_t use_nonmonotonic_steps;
   int32_t max_num_iterations;
 } cmx_ceres3d_options;
+/* One cell of an IntensityHybridGrid (mapping/3d/hybrid_grid.h:543-571): AverageIntensityData
+ * {sum, count}; GetIntensity = sum / count, 0 where count == 0 or the cell is absent. */
+typedef struct cmx_intensity_voxel {
+  int32_t x, y, z;
+  int32_t count;
+  float sum;
+} cmx_intensity_voxel;
 /* CeresScanMatcher3D::PointCloudAndHybridGridsPointers (SM3/ceres_scan_matcher_3d.h:42-46); the
  * grid as the voxel list HybridGrid::Iterator yields. */
 typedef struct cmx_ceres3d_pair {
@@ -320,6 +328,18 @@ typedef struct cmx_ceres3d_pair {
   float resolution;
   const cmx_voxel* voxels;
   int64_t num_voxels;
+  /* IntensityCostFunction3D (SM3/intensity_cost_function_3d.h, ceres_scan_matcher_3d.cc:118-137):
+   * `intensities` == NULL: the pair has no intensity_hybrid_grid (what ConstraintBuilder3D
+   * passes).  Otherwise num_points intensities (PointCloud::intensities()), the intensity grid
+   * (same resolution as the pair's hybrid grid) and its IntensityCostFunctionOptions; the block
+   * carries ceres::HuberLoss(intensity_huber_scale). */
+  const float* intensities;
+  const cmx_intensity_voxel* intensity_voxels;
+  int64_t num_intensity_voxels;
+  double intensity_weight;
+  double intensity_huber_scale;
+  float intensity_threshold;
+  int32_t reserved;
 } cmx_ceres3d_pair;
 /* CeresScanMatcher3D::Match (SM3/ceres_scan_matcher_3d.h:55-60, .cc:90-156): occupied-space
  * residuals through InterpolatedGrid (SM3/interpolated_grid.h), translation / rotation delta

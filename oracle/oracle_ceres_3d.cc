@@ -359,9 +359,17 @@ void CeresScanMatcher3DMatch(const CeresOptions3D& options, const double target_
   for (int a = 0; a < K; ++a) scale[a] = 1. / (1. + std::sqrt(at_x.H[a][a]));
   double x_cost = at_x.cost;
   double x_norm = norm7(x);
-  const auto gradient_max_norm = [K](const Evaluation& e) {
+  // TrustRegionMinimizer::ComputeGradientMaxNorm (trust_region_minimizer.cc): the gradient
+  // PROJECTED through the parameterization, |x - Plus(x, -g)|_inf over the ambient coordinates.
+  // For the Euclidean translation block that is |g|; for the rotation block it is not.  (`x`
+  // is always the point at_x was evaluated at.)
+  const auto gradient_max_norm = [K, &x, &options](const Evaluation& e) {
     double m = 0.;
-    for (int a = 0; a < K; ++a) m = std::max(m, std::fabs(e.g[a]));
+    for (int a = 0; a < 3; ++a) m = std::max(m, std::fabs(e.g[a]));
+    double negative[3] = {0., 0., 0.}, projected[4];
+    for (int a = 3; a < K; ++a) negative[a - 3] = -e.g[a];
+    Plus(options.only_optimize_yaw, x + 3, negative, projected);
+    for (int a = 0; a < 4; ++a) m = std::max(m, std::fabs(x[3 + a] - projected[a]));
     return m;
   };
 

@@ -529,6 +529,49 @@ def test_ceres3d_equals_the_oracle(sm3, oracle, synth, yaw_only, nonmono, seed):
     assert summary["final_cost"] < summary["initial_cost"]
 
 
+@pytest.mark.parametrize("huber_scale,yaw_only", [(0.3, False), (1e6, False), (0.3, True)])
+def test_ceres3d_with_the_intensity_cost_function_equals_the_oracle(sm3, oracle, synth,
+                                                                    huber_scale, yaw_only):
+    """IntensityCostFunction3D under ceres::HuberLoss (ceres_scan_matcher_3d.cc:118-137,
+    intensity_cost_function_3d.h:37-91) on the device: the first pair carries an
+    intensity_hybrid_grid, huber_scale 0.3 puts its block in the outlier region (rho' < 1) and
+    1e6 leaves it quadratic; cells with count 0 and points above the threshold included.  The
+    oracle side of this is pinned on the reference's own compiled sources
+    (tests/test_reference_ref_ceres.py)."""
+    from test_reference_ref_ceres import _intensity_world
+    vox, iv, pos, cloud, intensities = _intensity_world(synth, oracle, 7)
+    low, _ = synth.make_submap_3d(7, 0.3, (8.0, 8.0, 4.0), 4, 8, 96)
+    pairs = [(cloud, 0.1, vox, intensities, iv, (0.5, huber_scale, 100.0)),
+             (cloud[::4].copy(), 0.3, low.voxels())]
+    init_t = np.array([0.04, -0.03, 0.02])
+    init = list(init_t) + quat_from_angle_axis(0.02, [0.05, -0.02, 1.0])
+    kw = dict(only_optimize_yaw=yaw_only, max_num_iterations=12)
+    ref = oracle.ceres3d_match_intensity(pairs, init_t, init, [1.0, 6.0], translation_weight=5.0,
+                                         rotation_weight=4e2, **kw)
+    m = sm3.CeresScanMatcher3D([1.0, 6.0], 5.0, 4e2, **kw)
+    pose, summary = m.match(init_t, sm3.Rigid3d(tuple(init[:3]), tuple(init[3:])), pairs)
+    np.testing.assert_allclose(_pose7(pose), ref["pose"], rtol=0, atol=1e-6)
+    assert abs(summary["initial_cost"] - ref["initial_cost"]) <= 1e-9 * max(1.0, ref["initial_cost"])
+    assert abs(summary["final_cost"] - ref["final_cost"]) <= 1e-6 * max(1.0, ref["final_cost"])
+    assert summary["num_successful_steps"] == ref["num_successful_steps"]
+    assert summary["termination"] == ref["termination"]
+    # the block is there: the match without it ends elsewhere
+    plain, _ = m.match(init_t, sm3.Rigid3d(tuple(init[:3]), tuple(init[3:])),
+                       [p[:3] for p in pairs])
+    assert np.abs(np.array(_pose7(plain)) - ref["pose"]).max() > 1e-6
+
+
+def test_ceres3d_intensity_options_are_checked(sm3, oracle, synth):
+    from cartographer_amd._lib import CmxError, INVALID_ARGUMENT
+    from test_reference_ref_ceres import _intensity_world
+    vox, iv, pos, cloud, intensities = _intensity_world(synth, oracle, 7)
+    m = sm3.CeresScanMatcher3D([1.0], 5.0, 4e2)
+    for bad in ((0.0, 0.3, 100.0), (0.5, 0.0, 100.0), (0.5, 0.3, 0.0)):
+        with pytest.raises(CmxError) as e:      # CHECK_GT(weight / huber_scale / threshold, 0)
+            m.match((0, 0, 0), sm3.Rigid3d(), [(cloud, 0.1, vox, intensities, iv, bad)])
+        assert e.value.status == INVALID_ARGUMENT
+
+
 def test_ceres3d_invalid_arguments(sm3, synth):
     from cartographer_amd._lib import CmxError, INVALID_ARGUMENT
     from test_ceres_3d import POINTS, fixture
@@ -666,6 +709,23 @@ def test_constraint_builder_3d_refines_on_the_device(sm3, oracle, synth):
     assert refined != searched
     assert with_ceres.last_refine_summaries[0]["final_cost"] < \
         with_ceres.last_refine_summaries[0]["initial_cost"]
+    # ... and what the oracle's CeresScanMatcher3D makes of the same search result (wiring of the
+    # refine target = initial pose = search result, constraint_builder_3d.cc:263-270)
+    init7 = list(searched.translation) + list(searched.rotation)
+    ref = oracle.ceres3d_match(pairs, searched.translation, init7, [5.0, 20.0],
+                               translation_weight=10.0, rotation_weight=1.0, max_num_iterations=10)
+    np.testing.assert_allclose(_pose7(refined), ref["pose"], rtol=0, atol=1e-6)
+    # geometry: the scan was taken at `pos` with identity rotation.  The search result is
+    # quantised to the 0.1 m voxel lattice around the (offset) initial pose; refinement must not
+    # move it away from the truth by more than a fraction of a voxel, and both stay within the
+    # lattice's reach.  (min_score is 0.12 and not the 0.2 of round 1: the submap holds 8 sparse
+    # synthetic scans, only ~17 % of this scan's returns land in a known cell even at the true
+    # pose, whose score is therefore ~0.20 -- right AT the old threshold, which made the test
+    # depend on the last bit of the score.)
+    err_searched = np.linalg.norm(np.array(searched.translation) - pos)
+    err_refined = np.linalg.norm(np.array(refined.translation) - pos)
+    assert err_searched < 0.1 * math.sqrt(3.0)
+    assert err_refined <= err_searched + 0.05
 
 
 @pytest.mark.parametrize("families", [None, "0"])
