@@ -715,17 +715,16 @@ def test_constraint_builder_3d_refines_on_the_device(sm3, oracle, synth):
     ref = oracle.ceres3d_match(pairs, searched.translation, init7, [5.0, 20.0],
                                translation_weight=10.0, rotation_weight=1.0, max_num_iterations=10)
     np.testing.assert_allclose(_pose7(refined), ref["pose"], rtol=0, atol=1e-6)
-    # geometry: the scan was taken at `pos` with identity rotation.  The search result is
-    # quantised to the 0.1 m voxel lattice around the (offset) initial pose; refinement must not
-    # move it away from the truth by more than a fraction of a voxel, and both stay within the
-    # lattice's reach.  (min_score is 0.12 and not the 0.2 of round 1: the submap holds 8 sparse
-    # synthetic scans, only ~17 % of this scan's returns land in a known cell even at the true
-    # pose, whose score is therefore ~0.20 -- right AT the old threshold, which made the test
-    # depend on the last bit of the score.)
+    # geometry: the scan was taken at `pos` with identity rotation; the search result is quantised
+    # to the 0.1 m voxel lattice around the (offset) initial pose and must lie within its reach.
+    # No such bound holds for the REFINED pose here: on this sparse synthetic submap (8 scans;
+    # ~17 % of the scan's returns land in a known cell at the true pose, whose score ~0.20 is why
+    # min_score is 0.12 and not round 1's 0.2, which sat on the last bit of the score) the
+    # least-squares optimum of the reference's own cost lies 0.13 m from the truth -- the oracle's
+    # CeresScanMatcher3D goes there too, which is what the equality above guards.
     err_searched = np.linalg.norm(np.array(searched.translation) - pos)
-    err_refined = np.linalg.norm(np.array(refined.translation) - pos)
     assert err_searched < 0.1 * math.sqrt(3.0)
-    assert err_refined <= err_searched + 0.05
+    assert np.linalg.norm(np.array(refined.translation) - np.array(searched.translation)) < 0.3
 
 
 @pytest.mark.parametrize("families", [None, "0"])
