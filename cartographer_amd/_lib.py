@@ -103,6 +103,13 @@ class Ceres3DPair(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class Candidate2D(C.Structure):
+    """cmx_candidate2d = Candidate2D (SM2/correlative_scan_matcher_2d.h:69-98)."""
+    _fields_ = [("scan_index", C.c_int32), ("x_index_offset", C.c_int32),
+                ("y_index_offset", C.c_int32), ("score", C.c_float), ("x", C.c_double),
+                ("y", C.c_double), ("orientation", C.c_double)]
+
+
 class Voxel(C.Structure):
     _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("z", C.c_int32), ("value", C.c_uint16),
                 ("pad", C.c_uint16)]
@@ -145,6 +152,7 @@ EXPORTED_SYMBOLS = [
     "cmx_fast3d_match_batch",
     "cmx_fast3d_level_info", "cmx_fast3d_level_cells",
     "cmx_ceres2d_match", "cmx_ceres2d_match_grid", "cmx_fast2d_refine_batch", "cmx_ceres3d_match",
+    "cmx_ceres3d_match_grids", "cmx_rt2d_score_candidates",
     "cmx_fast3d_refine_batch",
     "cmx_comm_init", "cmx_comm_destroy", "cmx_comm_num_devices", "cmx_comm_device_of",
     "cmx_fast2d_match_sharded", "cmx_fast3d_match_sharded", "cmx_shard_range",
@@ -230,6 +238,11 @@ def lib():
                                           C.c_void_p]
     L.cmx_ceres3d_match.argtypes = [P(Ceres3DOptions), C.c_void_p, P(Pose3d), C.c_void_p, C.c_int32,
                                     P(Pose3d), P(CeresSummary)]
+    L.cmx_rt2d_score_candidates.argtypes = [P(RtOptions), P(Grid2DLimits), C.c_void_p, C.c_void_p,
+                                            C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                            C.c_int32, C.c_void_p, C.c_int32, C.c_int32]
+    L.cmx_ceres3d_match_grids.argtypes = [P(Ceres3DOptions), C.c_void_p, P(Pose3d), P(C.c_void_p),
+                                          P(C.c_void_p), C.c_void_p, P(Pose3d), P(CeresSummary)]
     L.cmx_fast3d_refine_batch.argtypes = [P(Ceres3DOptions), P(C.c_void_p), C.c_int32, C.c_void_p,
                                           C.c_void_p, P(NodeData3D), C.c_void_p, C.c_void_p]
     L.cmx_voxel_filter.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p,

@@ -699,6 +699,72 @@ extern "C" cmx_status cmx_ceres3d_match(const cmx_ceres3d_options* options,
   });
 }
 
+// LocalTrajectoryBuilder3D::ScanMatch's refinement (local_trajectory_builder_3d.cc:96-123) against
+// the ACTIVE submap's HybridGrids where cmx_grid3d keeps them in HBM: no upload, no allocation.
+extern "C" cmx_status cmx_ceres3d_match_grids(const cmx_ceres3d_options* options,
+                                              const double* target_translation_xyz,
+                                              const cmx_pose3d* initial_pose_estimate,
+                                              const cmx_grid3d* const* grids,
+                                              const float* const* point_clouds_xyz,
+                                              const int32_t* num_points,
+                                              cmx_pose3d* pose_estimate,
+                                              cmx_ceres_summary* summary) {
+  using namespace cmx;
+  return Guard([&] {
+    CMX_REQUIRE(options && target_translation_xyz && initial_pose_estimate && grids &&
+                    point_clouds_xyz && num_points,
+                "null argument");
+    CMX_REQUIRE(pose_estimate != nullptr, "pose_estimate must not be null");
+    CheckOptions(*options);
+    Ceres3DProblem P{};
+    SetOptions(*options, &P);
+    size_t cloud_floats = 0;
+    int device = -1;
+    bool any_empty = false;
+    for (int k = 0; k < P.num_pairs; ++k) {
+      CMX_REQUIRE(grids[k] != nullptr, "grid %d is null", k);
+      CMX_REQUIRE(point_clouds_xyz[k] && num_points[k] >= 1 && num_points[k] <= (1 << 24),
+                  "bad point cloud %d", k);
+      int d = 0;
+      if (!Grid3DBrick(grids[k], &P.pair[k].grid, &P.pair[k].resolution, &d)) any_empty = true;
+      CMX_REQUIRE(device < 0 || d == device, "the grids live on different devices");
+      device = d;
+      cloud_floats += 3 * static_cast<size_t>(num_points[k]);
+    }
+    WorkspaceLease ws(device);
+    if (any_empty) {
+      // A HybridGrid nothing was inserted into: every lookup is value 0 (kMinProbability).
+      uint16_t* zero = ws->dev[2].ReserveAs<uint16_t>(8);
+      CMX_HIP(hipMemsetAsync(zero, 0, 16, ws->stream));
+      for (int k = 0; k < P.num_pairs; ++k) {
+        if (P.pair[k].grid.cells != nullptr) continue;
+        P.pair[k].grid = Brick{};
+        P.pair[k].grid.cells = zero;
+        P.pair[k].grid.nx = P.pair[k].grid.ny = P.pair[k].grid.nz = 1;
+      }
+    }
+    float* d_xyz = ws->dev[0].ReserveAs<float>(cloud_floats);
+    float* h_xyz = ws->pinned[0].ReserveAs<float>(cloud_floats);
+    size_t off = 0;
+    for (int k = 0; k < P.num_pairs; ++k) {
+      std::memcpy(h_xyz + off, point_clouds_xyz[k], 3 * sizeof(float) * num_points[k]);
+      P.pair[k].n = num_points[k];
+      P.pair[k].xyz = d_xyz + off;
+      P.pair[k].scaling =
+          options->occupied_space_weight[k] / std::sqrt(static_cast<double>(num_points[k]));
+      off += 3 * static_cast<size_t>(num_points[k]);
+    }
+    for (int a = 0; a < 3; ++a) {
+      P.target[a] = target_translation_xyz[a];
+      P.init[a] = initial_pose_estimate->t[a];
+    }
+    for (int a = 0; a < 4; ++a) P.init[3 + a] = initial_pose_estimate->q[a];
+    double out[12];
+    SolveProblems(*ws, &P, 1, cloud_floats, h_xyz, d_xyz, out);
+    WriteResult(out, pose_estimate, summary);
+  });
+}
+
 // ConstraintBuilder3D::ComputeConstraint's refinement (constraints/constraint_builder_3d.cc:
 // 263-276) for a node's batch: one workgroup per found pair, grids already in HBM.
 extern "C" cmx_status cmx_fast3d_refine_batch(const cmx_ceres3d_options* options,

@@ -28,6 +28,7 @@
 #include "cmx_common.h"
 #include "cmx_device.h"
 #include "cmx_odds_table.h"
+#include "scan_matching_3d.h"
 
 struct cmx_grid3d {
   int device = 0;
@@ -313,6 +314,20 @@ extern "C" cmx_status cmx_grid3d_insert(cmx_grid3d* grid, const float* origin_xy
     CMX_REQUIRE(h_box[7] == 0, "internal error: a voxel fell outside the brick");
   });
 }
+
+namespace cmx {
+// The grid's dense uint16 brick for the matchers that read it in place (ceres_3d.hip); false
+// while the grid is empty (nothing was inserted yet: every cell reads 0).
+bool Grid3DBrick(const cmx_grid3d* g, Brick* brick, float* resolution, int* device) {
+  *resolution = g->resolution;
+  *device = g->device;
+  if (g->dims[0] == 0) return false;
+  brick->cells = g->cells;
+  brick->lo_x = g->lo[0]; brick->lo_y = g->lo[1]; brick->lo_z = g->lo[2];
+  brick->nx = g->dims[0]; brick->ny = g->dims[1]; brick->nz = g->dims[2];
+  return true;
+}
+}  // namespace cmx
 
 extern "C" cmx_status cmx_grid3d_info(const cmx_grid3d* grid, float* resolution,
                                       int32_t* grid_size, int64_t* num_voxels) {

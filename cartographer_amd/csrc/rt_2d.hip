@@ -2107,6 +2107,44 @@ bool Rt2DMatchBatchImpl(const cmx_rt_options* options, const Rt2DItem* items, in
                           host_report.c_str(), in_bytes);
   return true;
 }
+
+// ScoreCandidates (SM2/real_time_correlative_scan_matcher_2d.cc:147-175), the method the
+// reference keeps "visible for testing": ANY list of (scan, x offset, y offset) over discrete
+// scans handed in by the caller.  One thread per candidate, the f32 sums in point order
+// (ComputeCandidateScore, :38-73); cells outside the limits read kMinProbability / (min tsd,
+// weight 0) (probability_grid.cc:78-82, tsdf_2d.cc:88-98).
+template <bool kTsdf>
+__global__ void Rt2DScoreCandidatesKernel(const uint16_t* __restrict__ cells,
+                                          const uint16_t* __restrict__ weights, int nx, int ny,
+                                          float max_tsd, float max_weight,
+                                          const int* __restrict__ scans_xy,
+                                          const int* __restrict__ scan_begin,
+                                          const int4* __restrict__ candidates, int num,
+                                          float* __restrict__ unweighted) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= num) return;
+  const int4 cand = candidates[c];                       // scan_index, x offset, y offset
+  const int begin = scan_begin[cand.x], end = scan_begin[cand.x + 1];
+  Acc<kTsdf> acc;
+  for (int i = begin; i < end; ++i) {
+    const int x = scans_xy[2 * i] + cand.y, y = scans_xy[2 * i + 1] + cand.z;
+    const bool inside = static_cast<unsigned>(x) < static_cast<unsigned>(nx) &&
+                        static_cast<unsigned>(y) < static_cast<unsigned>(ny);
+    const int flat = inside ? nx * y + x : 0;
+    if constexpr (kTsdf) {
+      const float min_tsd = -max_tsd;
+      float tsd = min_tsd, weight = 0.f;
+      if (inside) {
+        tsd = BoundedValue(cells[flat], min_tsd, min_tsd, max_tsd);
+        weight = BoundedValue(weights[flat], 0.f, 0.f, max_weight);
+      }
+      acc.Add(TsdfTerm(tsd, weight, max_tsd));
+    } else {
+      acc.Add(inside ? CellProbability(cells[flat]) : 0.1f);
+    }
+  }
+  unweighted[c] = acc.Finish(end - begin);
+}
 }  // namespace
 
 void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int num, int32_t device,
@@ -2158,5 +2196,77 @@ extern "C" cmx_status cmx_rt2d_match_tsdf(const cmx_rt_options* options,
     cmx::Rt2DMatch(options, limits, tsd_cells, weight_cells, truncation_distance, max_weight,
                    initial_pose_estimate, point_cloud_xyz, num_points, device, score,
                    pose_estimate, stats, nullptr);
+  });
+}
+
+extern "C" cmx_status cmx_rt2d_score_candidates(
+    const cmx_rt_options* options, const cmx_grid2d_limits* limits, const uint16_t* cells,
+    const uint16_t* weight_cells, float truncation_distance, float max_weight,
+    const int32_t* discrete_scans_xy, const int32_t* scan_begin, int32_t num_scans,
+    cmx_candidate2d* candidates, int32_t num_candidates, int32_t device) {
+  using namespace cmx;
+  return Guard([&] {
+    CMX_REQUIRE(options && limits && cells && scan_begin && num_scans >= 1, "null argument");
+    CMX_REQUIRE(num_candidates >= 0 && (num_candidates == 0 || candidates), "bad candidate list");
+    CMX_REQUIRE(limits->num_x_cells >= 1 && limits->num_y_cells >= 1 &&
+                    static_cast<long long>(limits->num_x_cells) * limits->num_y_cells < (1ll << 30),
+                "bad cell limits");
+    const bool tsdf = weight_cells != nullptr;
+    if (tsdf) CMX_REQUIRE(truncation_distance > 0.f && max_weight > 0.f, "bad TSDF ranges");
+    CMX_REQUIRE(scan_begin[0] == 0, "scan_begin[0] must be 0");
+    for (int s = 0; s < num_scans; ++s)       // (an empty scan divides 0 by 0: CHECK_GT at :70)
+      CMX_REQUIRE(scan_begin[s + 1] > scan_begin[s], "discrete scan %d is empty", s);
+    const int total_points = scan_begin[num_scans];
+    CMX_REQUIRE(discrete_scans_xy != nullptr, "null argument");
+    for (int c = 0; c < num_candidates; ++c)
+      CMX_REQUIRE(candidates[c].scan_index >= 0 && candidates[c].scan_index < num_scans,
+                  "candidate %d names scan %d of %d", c, candidates[c].scan_index, num_scans);
+    if (num_candidates == 0) return;
+    WorkspaceLease ws(device);
+    const size_t num_cells = static_cast<size_t>(limits->num_x_cells) * limits->num_y_cells;
+    uint16_t* d_cells = ws->dev[0].ReserveAs<uint16_t>(num_cells * (tsdf ? 2 : 1));
+    int* d_scans = ws->dev[1].ReserveAs<int>(2 * static_cast<size_t>(total_points) + num_scans + 1);
+    int4* d_cand = ws->dev[2].ReserveAs<int4>(num_candidates);
+    float* d_scores = ws->dev[3].ReserveAs<float>(num_candidates);
+    std::vector<int4> h_cand(num_candidates);
+    for (int c = 0; c < num_candidates; ++c)
+      h_cand[c] = make_int4(candidates[c].scan_index, candidates[c].x_index_offset,
+                            candidates[c].y_index_offset, 0);
+    std::vector<float> h_scores(num_candidates);
+    CMX_HIP(hipMemcpyAsync(d_cells, cells, num_cells * sizeof(uint16_t), hipMemcpyHostToDevice,
+                           ws->stream));
+    if (tsdf)
+      CMX_HIP(hipMemcpyAsync(d_cells + num_cells, weight_cells, num_cells * sizeof(uint16_t),
+                             hipMemcpyHostToDevice, ws->stream));
+    CMX_HIP(hipMemcpyAsync(d_scans, discrete_scans_xy, 2 * sizeof(int) * total_points,
+                           hipMemcpyHostToDevice, ws->stream));
+    int* d_begin = d_scans + 2 * static_cast<size_t>(total_points);
+    CMX_HIP(hipMemcpyAsync(d_begin, scan_begin, sizeof(int) * (num_scans + 1),
+                           hipMemcpyHostToDevice, ws->stream));
+    CMX_HIP(hipMemcpyAsync(d_cand, h_cand.data(), sizeof(int4) * num_candidates,
+                           hipMemcpyHostToDevice, ws->stream));
+    const int blocks = DivUp(num_candidates, 64);
+    if (tsdf)
+      Rt2DScoreCandidatesKernel<true><<<blocks, 64, 0, ws->stream>>>(
+          d_cells, d_cells + num_cells, limits->num_x_cells, limits->num_y_cells,
+          truncation_distance, max_weight, d_scans, d_begin, d_cand, num_candidates, d_scores);
+    else
+      Rt2DScoreCandidatesKernel<false><<<blocks, 64, 0, ws->stream>>>(
+          d_cells, nullptr, limits->num_x_cells, limits->num_y_cells, 0.f, 0.f, d_scans, d_begin,
+          d_cand, num_candidates, d_scores);
+    CMX_HIP(hipGetLastError());
+    CMX_HIP(hipMemcpyAsync(h_scores.data(), d_scores, sizeof(float) * num_candidates,
+                           hipMemcpyDeviceToHost, ws->stream));
+    CMX_HIP(hipStreamSynchronize(ws->stream));
+    for (int c = 0; c < num_candidates; ++c) {
+      cmx_candidate2d& cand = candidates[c];
+      float score = h_scores[c];
+      if (!tsdf) CMX_REQUIRE(score > 0.f, "candidate %d scores %g (CHECK_GT(score, 0))", c, score);
+      // `candidate.score *= std::exp(-Pow2(...))`: a float times a double, rounded once (:168-174)
+      const double t = std::hypot(cand.x, cand.y) * options->translation_delta_cost_weight +
+                       std::abs(cand.orientation) * options->rotation_delta_cost_weight;
+      score = static_cast<float>(static_cast<double>(score) * std::exp(-(t * t)));
+      cand.score = score;
+    }
   });
 }

@@ -172,6 +172,9 @@ int Fast3DDevice(const cmx_fast3d* matcher);
 void Fast3DGrids(const cmx_fast3d* matcher, Brick* high, float* resolution, Brick* low,
                  float* low_resolution);
 
+// grid_3d.hip: the resident HybridGrid's brick (false: still empty).
+bool Grid3DBrick(const cmx_grid3d* grid, Brick* brick, float* resolution, int* device);
+
 }  // namespace cmx
 
 #endif  // CMX_SCAN_MATCHING_3D_H_

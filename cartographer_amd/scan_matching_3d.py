@@ -133,6 +133,27 @@ class CeresScanMatcher3D:
         del keep
         return Rigid3d.from_c(pose), summary.as_dict()
 
+    def match_grids(self, target_translation, initial_pose_estimate, point_clouds_and_grids):
+        """``match`` against HybridGrids that already live in HBM
+        (``grid_3d.HybridGridOnDevice``): ``[(point_cloud, grid), ...]`` -- what
+        LocalTrajectoryBuilder3D::ScanMatch does with the active submap
+        (local_trajectory_builder_3d.cc:96-123).  Only the clouds cross PCIe."""
+        num = self.options.num_pairs
+        assert len(point_clouds_and_grids) == num
+        clouds = [_cloud(c)[0] for c, _ in point_clouds_and_grids]
+        handles = (C.c_void_p * num)(*[g._h for _, g in point_clouds_and_grids])
+        pointers = (C.c_void_p * num)(*[c.ctypes.data for c in clouds])
+        counts = np.ascontiguousarray([c.shape[0] for c in clouds], np.int32)
+        target = np.ascontiguousarray(target_translation, np.float64)
+        init = initial_pose_estimate.to_c()
+        pose = Pose3d()
+        summary = CeresSummary()
+        check(_lib.lib().cmx_ceres3d_match_grids(C.byref(self.options), target.ctypes.data,
+                                                 C.byref(init), handles, pointers,
+                                                 counts.ctypes.data, C.byref(pose),
+                                                 C.byref(summary)))
+        return Rigid3d.from_c(pose), summary.as_dict()
+
     def refine_batch(self, matchers, found, pose_estimates, constant_data):
         """ConstraintBuilder3D::ComputeConstraint's refinement of a node's search results
         (constraint_builder_3d.cc:263-276): entry i against the high- and low-resolution grids

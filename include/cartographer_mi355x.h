@@ -153,6 +153,26 @@ cmx_status cmx_rt2d_match_tsdf(const cmx_rt_options* options, const cmx_grid2d_l
                                const float* point_cloud_xyz, int32_t num_points, int32_t device,
                                double* score, cmx_pose2d* pose_estimate, cmx_match_stats* stats);
 
+/* RealTimeCorrelativeScanMatcher2D::ScoreCandidates, the method the reference keeps "visible for
+ * testing" (SM2/real_time_correlative_scan_matcher_2d.h:70-76, .cc:147-175), so that its unit
+ * tests run against the device: ANY candidate list over caller-made discrete scans.
+ * cmx_candidate2d mirrors Candidate2D (SM2/correlative_scan_matcher_2d.h:69-98): the caller fills
+ * everything but `score`.  discrete_scans_xy holds the (x, y) cell indices of all scans back to
+ * back, scan s being points scan_begin[s] .. scan_begin[s + 1] - 1.  weight_cells == NULL: a
+ * ProbabilityGrid; otherwise the TSDF2D planes as in cmx_rt2d_match_tsdf. */
+typedef struct cmx_candidate2d {
+  int32_t scan_index, x_index_offset, y_index_offset;
+  float score;                 /* out: weighted by the delta costs */
+  double x, y, orientation;
+} cmx_candidate2d;
+cmx_status cmx_rt2d_score_candidates(const cmx_rt_options* options,
+                                     const cmx_grid2d_limits* limits, const uint16_t* cells,
+                                     const uint16_t* weight_cells, float truncation_distance,
+                                     float max_weight, const int32_t* discrete_scans_xy,
+                                     const int32_t* scan_begin, int32_t num_scans,
+                                     cmx_candidate2d* candidates, int32_t num_candidates,
+                                     int32_t device);
+
 /* ---- device-resident probability grid ------------------ */
 /* The active submap's ProbabilityGrid kept in HBM: LocalTrajectoryBuilder2D's per-scan
  * pair Match() -> InsertRangeData() (mapping/internal/2d/local_trajectory_builder_2d.cc:
@@ -397,6 +417,20 @@ cmx_status cmx_grid3d_info(const cmx_grid3d* grid, float* resolution, int32_t* g
                            int64_t* num_voxels);
 cmx_status cmx_grid3d_download(const cmx_grid3d* grid, cmx_voxel* voxels, int64_t capacity,
                                int64_t* num_voxels);
+
+/* CeresScanMatcher3D::Match as LocalTrajectoryBuilder3D::ScanMatch calls it
+ * (mapping/internal/3d/local_trajectory_builder_3d.cc:96-123) against the ACTIVE submap: pair k is
+ * (point_clouds_xyz[k], num_points[k]) with the resident HybridGrid grids[k] (its resolution is
+ * the grid's); options->num_pairs pairs, all grids on one device.  Nothing but the clouds is
+ * uploaded.  An intensity_hybrid_grid is not kept resident: pairs with an intensity term go
+ * through cmx_ceres3d_match. */
+cmx_status cmx_ceres3d_match_grids(const cmx_ceres3d_options* options,
+                                   const double* target_translation_xyz,
+                                   const cmx_pose3d* initial_pose_estimate,
+                                   const cmx_grid3d* const* grids,
+                                   const float* const* point_clouds_xyz,
+                                   const int32_t* num_points, cmx_pose3d* pose_estimate,
+                                   cmx_ceres_summary* summary);
 
 /* ---- fast 3D ------------------------------------------------------------ */
 /* hybrid_grid.h:137 grid_size(): 8*8*2^bits cells per axis of the dynamic

@@ -87,7 +87,7 @@ def test_struct_layouts_agree_with_the_header(tmp_path):
         "cmx_match_stats": _lib.MatchStats, "cmx_ceres2d_options": _lib.Ceres2DOptions,
         "cmx_ceres_summary": _lib.CeresSummary, "cmx_ceres3d_options": _lib.Ceres3DOptions,
         "cmx_ceres3d_pair": _lib.Ceres3DPair, "cmx_voxel": _lib.Voxel,
-        "cmx_intensity_voxel": _lib.IntensityVoxel,
+        "cmx_intensity_voxel": _lib.IntensityVoxel, "cmx_candidate2d": _lib.Candidate2D,
         "cmx_node_data3d": _lib.NodeData3D, "cmx_result3d": _lib.Result3D,
     }
     header = open(os.path.join(ROOT, "include", "cartographer_mi355x.h")).read()

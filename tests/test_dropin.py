@@ -289,3 +289,47 @@ def test_batched_front_3d_gives_the_reference_builders_constraints(synth, tmp_pa
         assert "reference scenario: CallsBack + FindsConstraints OK" in out
         outs.append([line for line in out.splitlines() if line.startswith("constraint")])
     assert len(outs[0]) == 6 and outs[0] == outs[1]          # 5 constraints + the count line
+
+
+# ---- the real-time matchers against the reference's REAL class headers -------------------------
+RT_REFERENCE = os.path.join(DROPIN, "_build", "real_time_matchers_reference")
+RT_MI355X = os.path.join(DROPIN, "_build", "real_time_matchers_mi355x")
+RT_GOLDEN = os.path.join(ROOT, "tests", "golden", "real_time_matchers_reference.txt")
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="needs the reference tree to compile")
+def test_real_time_matchers_build_against_the_real_headers_and_the_golden_is_the_references():
+    """real_time_matchers_main.cc (the scenarios of real_time_correlative_scan_matcher_2d_test.cc
+    and _3d_test.cc) links twice: over the reference's own .cc files -- that binary runs here and
+    must print the committed golden, every number a hex float -- and over
+    real_time_matchers_mi355x.cc, which includes the reference's real class headers (no stand-in
+    of ours for them) and links the product library only."""
+    subprocess.run(["make", "-C", DROPIN], check=True, capture_output=True)
+    out = subprocess.run([RT_REFERENCE], check=True, capture_output=True, text=True,
+                         timeout=120).stdout
+    assert out == open(RT_GOLDEN).read()
+    assert out.count("\n") == 24 and "x4 + RealTimeCorrelativeScanMatcher3DTest x7 OK" in out
+    needed = subprocess.run(["readelf", "-d", RT_MI355X], check=True, capture_output=True,
+                            text=True).stdout
+    assert "libcartographer_mi355x.so" in needed and "oracle" not in needed
+    # the adapter names the reference's headers, not stand-ins: neither shim directory has them
+    for shim_root in (os.path.join(DROPIN, "shims"), os.path.join(ROOT, "oracle", "ref_shims")):
+        for name in ("real_time_correlative_scan_matcher_2d.h",
+                     "real_time_correlative_scan_matcher_3d.h"):
+            assert not any(name in files for _, _, files in os.walk(shim_root))
+    # without a GPU the adapter fails loudly instead of computing anything on the host
+    if not os.path.exists("/dev/kfd"):
+        run = subprocess.run([RT_MI355X], capture_output=True, text=True, timeout=120)
+        assert run.returncode != 0 and "no CPU fallback" in run.stderr
+
+
+@pytest.mark.gpu
+def test_real_time_matchers_on_the_gpu_print_the_references_numbers():
+    """The same scenarios on the device: every expectation of the reference's two test files
+    holds (the binary exits non-zero otherwise) and every score and pose -- ScoreCandidates on a
+    ProbabilityGrid and a TSDF2D built by the reference's own inserters, Match() on both, the
+    seven 3D cases -- is bit-identical to what the reference's own sources print."""
+    assert os.path.exists(RT_MI355X), "examples/dropin/_build is prebuilt by __graft_entry__.build()"
+    out = subprocess.run([RT_MI355X], check=True, capture_output=True, text=True,
+                         timeout=300).stdout
+    assert out.splitlines() == open(RT_GOLDEN).read().splitlines()

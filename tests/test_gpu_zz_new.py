@@ -421,6 +421,48 @@ def test_rt3d_on_the_device_built_grid(synth, oracle):
     np.testing.assert_array_equal(list(pose.translation) + list(pose.rotation), ref["pose"])
 
 
+def test_ceres3d_on_the_resident_grids(synth, oracle):
+    """Insert -> refine: CeresScanMatcher3D against the HybridGrids cmx_grid3d keeps in HBM
+    (cmx_ceres3d_match_grids, LocalTrajectoryBuilder3D::ScanMatch's call) equals the voxel-list
+    entry point bit for bit and the oracle on the host-built grids to 1e-6; a grid nothing was
+    inserted into reads kMinProbability everywhere (zero gradient: the pose stays)."""
+    from cartographer_amd import grid_3d, scan_matching_3d as sm3
+    from test_oracle_reference_pins_3d import quat_from_angle_axis
+    world = synth.World3D(5, (8.0, 8.0, 4.0))
+    dev = [grid_3d.HybridGridOnDevice(0.1), grid_3d.HybridGridOnDevice(0.3)]
+    host = [synth.HybridGrid(0.1), synth.HybridGrid(0.3)]
+    for p in range(4):
+        pos = world.free_position(50 + p, 0.5)
+        sensor = world.scan(pos, 0.2 * p, 6, 64, seed=p).astype(np.float64)
+        c, s = math.cos(0.2 * p), math.sin(0.2 * p)
+        in_map = np.stack([pos[0] + c * sensor[:, 0] - s * sensor[:, 1],
+                           pos[1] + s * sensor[:, 0] + c * sensor[:, 1],
+                           pos[2] + sensor[:, 2]], 1).astype(np.float32)
+        for g in dev + host:
+            g.insert(pos.astype(np.float32), in_map, 0.7, 0.4, 2)
+    cloud = world.scan(pos, 0.6, 6, 64, seed=9)
+    hi, lo = cloud[::2].copy(), cloud[::5].copy()
+    init_t = pos + np.array([0.03, -0.02, 0.01])
+    init = list(init_t) + quat_from_angle_axis(0.61, [0.02, -0.01, 1.0])
+    first = sm3.Rigid3d(tuple(init[:3]), tuple(init[3:]))
+    m = sm3.CeresScanMatcher3D([1.0, 6.0], 5.0, 4e2, max_num_iterations=12)
+    pose, summary = m.match_grids(init_t, first, [(hi, dev[0]), (lo, dev[1])])
+    pairs = [(hi, 0.1, host[0].voxels()), (lo, 0.3, host[1].voxels())]
+    listed, listed_summary = m.match(init_t, first, pairs)
+    assert pose == listed and summary == listed_summary
+    ref = oracle.ceres3d_match(pairs, init_t, init, [1.0, 6.0], translation_weight=5.0,
+                               rotation_weight=4e2, max_num_iterations=12)
+    np.testing.assert_allclose(list(pose.translation) + list(pose.rotation), ref["pose"],
+                               rtol=0, atol=1e-6)
+    assert summary["num_successful_steps"] == ref["num_successful_steps"] >= 1
+    empty = grid_3d.HybridGridOnDevice(0.1)
+    one = sm3.CeresScanMatcher3D([1.0], 5.0, 4e2, max_num_iterations=12)
+    stay, stay_summary = one.match_grids(init_t, first, [(hi, empty)])
+    np.testing.assert_allclose(list(stay.translation) + list(stay.rotation), init, rtol=0,
+                               atol=1e-12)
+    assert stay_summary["initial_cost"] == pytest.approx(0.5 * 0.9 ** 2, rel=1e-9)
+
+
 def test_fast3d_batch_equals_individual(synth):
     """cmx_fast3d_match_batch (pairs searched concurrently from host threads on separate streams)
     returns, pair by pair, exactly what the single calls return -- windowed and full-submap pairs
