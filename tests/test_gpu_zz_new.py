@@ -460,7 +460,7 @@ def test_ceres3d_on_the_resident_grids(synth, oracle):
     stay, stay_summary = one.match_grids(init_t, first, [(hi, empty)])
     np.testing.assert_allclose(list(stay.translation) + list(stay.rotation), init, rtol=0,
                                atol=1e-12)
-    assert stay_summary["initial_cost"] == pytest.approx(0.5 * 0.9 ** 2, rel=1e-9)
+    assert stay_summary["initial_cost"] == pytest.approx(0.5 * 0.9 ** 2, rel=1e-7)   # (0.1f)
 
 
 def test_fast3d_batch_equals_individual(synth):
