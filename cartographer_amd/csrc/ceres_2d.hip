@@ -24,6 +24,8 @@
 // candidate is wasted; evaluating it separately would be a second pass over the points).
 #include <climits>
 #include <cmath>
+#include <map>
+#include <vector>
 
 #include "scan_matching_2d.h"
 
@@ -486,25 +488,38 @@ cmx_status cmx_fast2d_refine_batch(const cmx_ceres2d_options* options,
   return Guard([&] {
     CMX_REQUIRE(matchers && num_matchers >= 1 && pose_estimates_in && pose_estimates_out,
                 "null argument");
-    std::vector<cmx::RefineItem> items(num_matchers);
-    int device = -1;
+    // Entries are grouped by the device their grid lives on (a node's batch may span the GPUs of
+    // a cmx_comm); every group is one launch.
+    std::map<int, std::vector<int>> by_device;
     for (int p = 0; p < num_matchers; ++p) {
       CMX_REQUIRE(matchers[p] && matchers[p]->impl, "null matcher handle");
-      const cmx::Fast2DMatcher& m = *matchers[p]->impl;
-      CMX_REQUIRE(device < 0 || m.device() == device,
-                  "all matchers of a batch must live on the same device");
-      device = m.device();
-      cmx::RefineItem& it = items[p];
-      it.device_cells = m.grid_cells();
-      it.limits = m.limits();
-      // constraint_builder_2d.cc:245-249: Match(pose_estimate.translation(), pose_estimate, ...)
-      it.initial = pose_estimates_in[p];
-      it.target[0] = pose_estimates_in[p].x;
-      it.target[1] = pose_estimates_in[p].y;
-      it.skip = found && !found[p] ? 1 : 0;
+      by_device[matchers[p]->impl->device()].push_back(p);
     }
-    cmx::RefineBatch(options, items.data(), num_matchers, point_cloud_xyz, num_points, device,
-                     pose_estimates_out, summaries);
+    for (const auto& group : by_device) {
+      const std::vector<int>& idx = group.second;
+      const int m = static_cast<int>(idx.size());
+      std::vector<cmx::RefineItem> items(m);
+      for (int k = 0; k < m; ++k) {
+        const int p = idx[k];
+        const cmx::Fast2DMatcher& matcher = *matchers[p]->impl;
+        cmx::RefineItem& it = items[k];
+        it.device_cells = matcher.grid_cells();
+        it.limits = matcher.limits();
+        // constraint_builder_2d.cc:245-249: Match(pose_estimate.translation(), pose_estimate, ...)
+        it.initial = pose_estimates_in[p];
+        it.target[0] = pose_estimates_in[p].x;
+        it.target[1] = pose_estimates_in[p].y;
+        it.skip = found && !found[p] ? 1 : 0;
+      }
+      std::vector<cmx_pose2d> poses(m);
+      std::vector<cmx_ceres_summary> sums(m);
+      cmx::RefineBatch(options, items.data(), m, point_cloud_xyz, num_points, group.first,
+                       poses.data(), summaries ? sums.data() : nullptr);
+      for (int k = 0; k < m; ++k) {
+        pose_estimates_out[idx[k]] = poses[k];
+        if (summaries) summaries[idx[k]] = sums[k];
+      }
+    }
   });
 }
 

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <set>
+#include <string>
 
 #include "cartographer/mapping/2d/grid_2d.h"
 #include "cartographer/transform/transform.h"
@@ -42,9 +43,28 @@ cmx_grid2d_limits LimitsOf(const Grid2D& grid) {
 cmx_pose2d PoseOf(const transform::Rigid2d& t) {
   return cmx_pose2d{t.translation().x(), t.translation().y(), t.rotation().angle()};
 }
-int Device() {
-  const char* e = std::getenv("CMX_DEVICE");
-  return e ? std::atoi(e) : 0;
+// The GPUs the builder spreads its submaps over: CMX_DEVICES="0,1,2,3" (or "all"), else the one
+// device CMX_DEVICE names (default 0).
+std::vector<int32_t> Devices() {
+  std::vector<int32_t> devices;
+  if (const char* list = std::getenv("CMX_DEVICES")) {
+    if (std::string(list) == "all") {
+      for (int d = 0; d < cmx_device_count(); ++d) devices.push_back(d);
+    } else {
+      for (const char* at = list; *at;) {
+        char* end = nullptr;
+        const long d = std::strtol(at, &end, 10);
+        if (end == at) break;
+        devices.push_back(static_cast<int32_t>(d));
+        at = *end == ',' ? end + 1 : end;
+      }
+    }
+  }
+  if (devices.empty()) {
+    const char* e = std::getenv("CMX_DEVICE");
+    devices.push_back(e ? std::atoi(e) : 0);
+  }
+  return devices;
 }
 
 }  // namespace
@@ -56,7 +76,11 @@ transform::Rigid2d ComputeSubmapPose(const Submap2D& submap) {
 ConstraintBuilder2D::ConstraintBuilder2D(const proto::ConstraintBuilderOptions& options,
                                          common::ThreadPoolInterface* const thread_pool)
     : options_(options), thread_pool_(thread_pool),
-      when_done_task_(std::make_unique<common::Task>()) {}
+      when_done_task_(std::make_unique<common::Task>()) {
+  const std::vector<int32_t> devices = Devices();
+  CheckOk(cmx_comm_init(devices.data(), static_cast<int32_t>(devices.size()), &comm_),
+          "cmx_comm_init");
+}
 
 ConstraintBuilder2D::~ConstraintBuilder2D() {
   absl::MutexLock locker(&mutex_);
@@ -65,6 +89,8 @@ ConstraintBuilder2D::~ConstraintBuilder2D() {
   Require(constraints_.empty(), "WhenDone() was not called");
   Require(num_started_nodes_ == num_finished_nodes_, "nodes still being computed");
   Require(when_done_ == nullptr, "WhenDone callback pending");
+  matchers_.clear();
+  cmx_comm_destroy(comm_);
 }
 
 // CB:77-111.  The distance filter and the sampler run at the call, the search later.
@@ -114,10 +140,13 @@ std::shared_ptr<ConstraintBuilder2D::DeviceMatcher> ConstraintBuilder2D::Matcher
   const auto& o = options_.fast_correlative_scan_matcher_options();
   const cmx_fast2d_options fast{o.linear_search_window(), o.angular_search_window(),
                                 o.branch_and_bound_depth()};
+  // Placement: submap k of this builder lives in the HBM of device k mod world (mutex_ held).
+  const int world = cmx_comm_num_devices(comm_);
+  const int device = cmx_comm_device_of(comm_, num_matchers_created_++ % world, world);
   auto task = std::make_unique<common::Task>();
-  task->SetWorkItem([matcher, grid, fast] {         // (the task keeps the matcher alive)
+  task->SetWorkItem([matcher, grid, fast, device] {   // (the task keeps the matcher alive)
     const cmx_grid2d_limits limits = LimitsOf(*grid);
-    CheckOk(cmx_fast2d_create(&fast, &limits, CellsOf(*grid), Device(), &matcher->handle),
+    CheckOk(cmx_fast2d_create(&fast, &limits, CellsOf(*grid), device, &matcher->handle),
             "cmx_fast2d_create");
   });
   matcher->creation_task = thread_pool_->Schedule(std::move(task));
@@ -175,11 +204,12 @@ void ConstraintBuilder2D::ComputeNode(const std::vector<Pair>& pairs) {
                                              ? options_.global_localization_min_score()
                                              : options_.min_score());
     }
-    // 1. + 2.: the correlative searches, pruned by their thresholds (CB:211-236).
-    CheckOk(cmx_fast2d_match_batch(handles.data(), num, initial.data(), full.data(),
-                                   min_scores.data(), xyz.data(), num_points, found.data(),
-                                   scores.data(), searched.data(), nullptr),
-            "cmx_fast2d_match_batch");
+    // 1. + 2.: the correlative searches, pruned by their thresholds (CB:211-236): every device
+    // of the communicator searches the submaps it holds, concurrently.
+    CheckOk(cmx_fast2d_match_sharded(comm_, handles.data(), num, initial.data(), full.data(),
+                                     min_scores.data(), xyz.data(), num_points, found.data(),
+                                     scores.data(), searched.data(), nullptr, nullptr, nullptr),
+            "cmx_fast2d_match_sharded");
     // 3.: refinement from the found pose, which is also its target (CB:242-249).
     CheckOk(cmx_fast2d_refine_batch(&ceres, handles.data(), num, found.data(), searched.data(),
                                     xyz.data(), num_points, refined.data(), nullptr),

@@ -3,7 +3,8 @@
 // either), a different inside.  The reference schedules one thread-pool task per (node, submap)
 // pair, each running a search and a refinement on a host core.  Here a node's pairs are
 // queued and NotifyEndOfNode schedules ONE task that hands all of them to the device:
-// cmx_fast2d_match_batch (every search of the node in one chain of launches), then
+// cmx_fast2d_match_sharded (every search of the node in one chain of launches per GPU of the
+// builder's cmx_comm: CMX_DEVICES lists them, submap k lives on device k mod world), then
 // cmx_fast2d_refine_batch (every found pair's Ceres refinement in one launch), against
 // precomputation stacks and grids that stay in HBM from the first use of a submap until
 // DeleteScanMatcher.  Results, their order, the sampler, the distance filter, the WhenDone /
@@ -86,6 +87,11 @@ class ConstraintBuilder2D {
   void RunWhenDoneCallback();
 
   const proto::ConstraintBuilderOptions options_;
+  // The node's GPUs (constraint_builder_2d.cc schedules a node's pairs as independent thread-pool
+  // tasks; here they are one sharded device call over this communicator): submap k's matcher is
+  // created on device k mod world, NotifyEndOfNode's task issues ONE cmx_fast2d_match_sharded.
+  cmx_comm* comm_ = nullptr;
+  int num_matchers_created_ = 0;
   common::ThreadPoolInterface* const thread_pool_;
   absl::Mutex mutex_;
   std::unique_ptr<std::function<void(const Result&)>> when_done_;

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <set>
+#include <string>
 
 #include "cartographer/mapping/3d/hybrid_grid.h"
 
@@ -56,9 +57,28 @@ transform::Rigid3d PoseFrom(const cmx_pose3d& p) {
   return transform::Rigid3d(Eigen::Vector3d(p.t[0], p.t[1], p.t[2]),
                             Eigen::Quaterniond(p.q[0], p.q[1], p.q[2], p.q[3]));
 }
-int Device() {
-  const char* e = std::getenv("CMX_DEVICE");
-  return e ? std::atoi(e) : 0;
+// The GPUs the builder spreads its submaps over: CMX_DEVICES="0,1,2,3" (or "all"), else the one
+// device CMX_DEVICE names (default 0).
+std::vector<int32_t> Devices() {
+  std::vector<int32_t> devices;
+  if (const char* list = std::getenv("CMX_DEVICES")) {
+    if (std::string(list) == "all") {
+      for (int d = 0; d < cmx_device_count(); ++d) devices.push_back(d);
+    } else {
+      for (const char* at = list; *at;) {
+        char* end = nullptr;
+        const long d = std::strtol(at, &end, 10);
+        if (end == at) break;
+        devices.push_back(static_cast<int32_t>(d));
+        at = *end == ',' ? end + 1 : end;
+      }
+    }
+  }
+  if (devices.empty()) {
+    const char* e = std::getenv("CMX_DEVICE");
+    devices.push_back(e ? std::atoi(e) : 0);
+  }
+  return devices;
 }
 
 }  // namespace
@@ -66,7 +86,11 @@ int Device() {
 ConstraintBuilder3D::ConstraintBuilder3D(const proto::ConstraintBuilderOptions& options,
                                          common::ThreadPoolInterface* const thread_pool)
     : options_(options), thread_pool_(thread_pool),
-      when_done_task_(std::make_unique<common::Task>()) {}
+      when_done_task_(std::make_unique<common::Task>()) {
+  const std::vector<int32_t> devices = Devices();
+  CheckOk(cmx_comm_init(devices.data(), static_cast<int32_t>(devices.size()), &comm_),
+          "cmx_comm_init");
+}
 
 ConstraintBuilder3D::~ConstraintBuilder3D() {
   absl::MutexLock locker(&mutex_);
@@ -75,6 +99,8 @@ ConstraintBuilder3D::~ConstraintBuilder3D() {
   Require(constraints_.empty(), "WhenDone() was not called");
   Require(num_started_nodes_ == num_finished_nodes_, "nodes still being computed");
   Require(when_done_ == nullptr, "WhenDone callback pending");
+  matchers_.clear();
+  cmx_comm_destroy(comm_);
 }
 
 // CB3:79-114: distance between the GLOBAL poses, then the per-submap sampler.
@@ -136,14 +162,17 @@ std::shared_ptr<ConstraintBuilder3D::DeviceMatcher> ConstraintBuilder3D::Matcher
   const HybridGrid* const high = &submap->high_resolution_hybrid_grid();
   const HybridGrid* const low = &submap->low_resolution_hybrid_grid();
   const Eigen::VectorXf* const histogram = &submap->rotational_scan_matcher_histogram();
+  // Placement: submap k of this builder lives in the HBM of device k mod world (mutex_ held).
+  const int world = cmx_comm_num_devices(comm_);
+  const int device = cmx_comm_device_of(comm_, num_matchers_created_++ % world, world);
   auto task = std::make_unique<common::Task>();
-  task->SetWorkItem([matcher, high, low, histogram, fast] {
+  task->SetWorkItem([matcher, high, low, histogram, fast, device] {
     const std::vector<cmx_voxel> voxels = Flatten(*high), low_voxels = Flatten(*low);
     const std::vector<float> h = Flatten(*histogram);
     CheckOk(cmx_fast3d_create(&fast, high->resolution(), high->grid_size(), voxels.data(),
                               static_cast<int64_t>(voxels.size()), low->resolution(),
                               low_voxels.data(), static_cast<int64_t>(low_voxels.size()), h.data(),
-                              static_cast<int32_t>(h.size()), Device(), &matcher->handle),
+                              static_cast<int32_t>(h.size()), device, &matcher->handle),
             "cmx_fast3d_create");
   });
   matcher->creation_task = thread_pool_->Schedule(std::move(task));
@@ -216,10 +245,11 @@ void ConstraintBuilder3D::ComputeNode(const std::vector<Pair>& pairs) {
                                              : options_.min_score());
     }
     // 1. + 2.: Match / MatchFullSubmap of every pair, pruned by its threshold (CB3:224-256).
-    CheckOk(cmx_fast3d_match_batch(handles.data(), num, node_poses.data(), submap_poses.data(),
-                                   full.data(), min_scores.data(), &data, found.data(),
-                                   results.data(), nullptr),
-            "cmx_fast3d_match_batch");
+    // (every device of the communicator searches the submaps it holds, concurrently)
+    CheckOk(cmx_fast3d_match_sharded(comm_, handles.data(), num, node_poses.data(),
+                                     submap_poses.data(), full.data(), min_scores.data(), &data,
+                                     found.data(), results.data(), nullptr, nullptr, nullptr),
+            "cmx_fast3d_match_sharded");
     for (int i = 0; i < num; ++i) searched[i] = results[i].pose_estimate;
     // 3.: the refinement from the found pose, which is also its target (CB3:263-276).
     CheckOk(cmx_fast3d_refine_batch(&ceres, handles.data(), num, found.data(), searched.data(),

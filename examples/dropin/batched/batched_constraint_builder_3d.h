@@ -1,6 +1,7 @@
 // ConstraintBuilder3D for the MI355X: the public interface of the reference's class
 // (mapping/internal/constraints/constraint_builder_3d.h:50-106), a node's pairs as ONE
-// cmx_fast3d_match_batch (every search in one chain of launches) followed by ONE
+// cmx_fast3d_match_sharded (every search in one chain of launches per GPU of the builder's cmx_comm:
+// CMX_DEVICES lists them, submap k lives on device k mod world) followed by ONE
 // cmx_fast3d_refine_batch (CeresScanMatcher3D::Match for every found pair against the grids
 // the matcher keeps in HBM).  See batched_constraint_builder_2d.h for the structure.
 #ifndef DROPIN_BATCHED_CONSTRAINT_BUILDER_3D_H_
@@ -80,6 +81,11 @@ class ConstraintBuilder3D {
   void RunWhenDoneCallback();
 
   const proto::ConstraintBuilderOptions options_;
+  // The node's GPUs (constraint_builder_3d.cc schedules a node's pairs as independent thread-pool
+  // tasks; here they are one sharded device call over this communicator): submap k's matcher is
+  // created on device k mod world, NotifyEndOfNode's task issues ONE cmx_fast3d_match_sharded.
+  cmx_comm* comm_ = nullptr;
+  int num_matchers_created_ = 0;
   common::ThreadPoolInterface* const thread_pool_;
   absl::Mutex mutex_;
   std::unique_ptr<std::function<void(const Result&)>> when_done_;

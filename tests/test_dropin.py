@@ -207,15 +207,17 @@ BINARY_BATCHED = os.path.join(DROPIN, "_build", "constraint_builder_2d_batched_m
 @pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="needs the reference tree to compile")
 def test_batched_front_builds_with_the_reference_interface():
     """examples/dropin/batched: a ConstraintBuilder2D with the reference's public interface whose
-    NotifyEndOfNode hands a node's pairs to cmx_fast2d_match_batch + cmx_fast2d_refine_batch.
-    The reference's own test main compiles against it unchanged (include redirect)."""
+    NotifyEndOfNode hands a node's pairs to ONE cmx_fast2d_match_sharded over the builder's
+    cmx_comm (CMX_DEVICES; submap k on device k mod world) + cmx_fast2d_refine_batch.  The
+    reference's own test main compiles against it unchanged (include redirect)."""
     subprocess.run(["make", "-C", DROPIN], check=True, capture_output=True)
     needed = subprocess.run(["readelf", "-d", BINARY_BATCHED], check=True, capture_output=True,
                             text=True).stdout
     assert "libcartographer_mi355x.so" in needed and "oracle" not in needed
     symbols = subprocess.run(["nm", "-C", BINARY_BATCHED], check=True, capture_output=True,
                              text=True).stdout
-    assert "cmx_fast2d_match_batch" in symbols and "cmx_fast2d_refine_batch" in symbols
+    assert "cmx_fast2d_match_sharded" in symbols and "cmx_fast2d_refine_batch" in symbols
+    assert "cmx_comm_init" in symbols and "cmx_comm_device_of" in symbols
     # the per-pair adapter classes are not part of this build
     assert "FastCorrelativeScanMatcher2D::Match" not in symbols
 
@@ -238,12 +240,18 @@ def test_batched_front_gives_the_reference_builders_constraints(synth, tmp_path)
     fixture = str(tmp_path / "node.bin")
     _write_fixture(fixture, submaps, scan, rel)
     outs = []
-    for binary in (BINARY, BINARY_BATCHED):
+    # the batched builder twice: a 1-device communicator, and every GPU of the box ("all": the
+    # submaps then live round-robin on all of them; on a 1-GPU box the same as the first)
+    for binary, devices in ((BINARY, None), (BINARY_BATCHED, "0"), (BINARY_BATCHED, "all")):
+        env = dict(os.environ)
+        env.pop("CMX_DEVICES", None)
+        if devices:
+            env["CMX_DEVICES"] = devices
         out = subprocess.run([binary, fixture], check=True, capture_output=True, text=True,
-                             timeout=300).stdout
+                             timeout=300, env=env).stdout
         assert "reference scenario: CallsBack + FindsConstraints OK" in out
         outs.append([line for line in out.splitlines() if line.startswith("constraint")])
-    assert len(outs[0]) >= 4 and outs[0] == outs[1]
+    assert len(outs[0]) >= 4 and outs[0] == outs[1] == outs[2]
 
 
 # ------------------------------------------------------------------- batched C++ front, 3D
@@ -258,7 +266,8 @@ def test_batched_front_3d_builds_with_the_reference_interface():
     assert "libcartographer_mi355x.so" in needed and "oracle" not in needed
     symbols = subprocess.run(["nm", "-C", BINARY_BATCHED_3D], check=True, capture_output=True,
                              text=True).stdout
-    assert "cmx_fast3d_match_batch" in symbols and "cmx_fast3d_refine_batch" in symbols
+    assert "cmx_fast3d_match_sharded" in symbols and "cmx_fast3d_refine_batch" in symbols
+    assert "cmx_comm_init" in symbols and "cmx_comm_device_of" in symbols
     assert "FastCorrelativeScanMatcher3D::Match" not in symbols
 
 
@@ -283,12 +292,16 @@ def test_batched_front_3d_gives_the_reference_builders_constraints(synth, tmp_pa
     _write_fixture_3d(fixture, (0.4, 0.4, 5, 2, 0.5, 0.25, 1.0, 1.0, 0.1), (0.2, 0.4), submaps, hi,
                       lo, hist, node7)
     outs = []
-    for binary in (BINARY_3D, BINARY_BATCHED_3D):
+    for binary, devices in ((BINARY_3D, None), (BINARY_BATCHED_3D, "0"), (BINARY_BATCHED_3D, "all")):
+        env = dict(os.environ)
+        env.pop("CMX_DEVICES", None)
+        if devices:                      # the builder's cmx_comm: one device, then all of the box
+            env["CMX_DEVICES"] = devices
         out = subprocess.run([binary, fixture], check=True, capture_output=True, text=True,
-                             timeout=300).stdout
+                             timeout=300, env=env).stdout
         assert "reference scenario: CallsBack + FindsConstraints OK" in out
         outs.append([line for line in out.splitlines() if line.startswith("constraint")])
-    assert len(outs[0]) == 6 and outs[0] == outs[1]          # 5 constraints + the count line
+    assert len(outs[0]) == 6 and outs[0] == outs[1] == outs[2]   # 5 constraints + the count line
 
 
 # ---- the real-time matchers against the reference's REAL class headers -------------------------
