@@ -17,6 +17,7 @@
 //   * exp() weighting and the strict-'>' first-maximum rule are finished on the
 //     host for the candidates within 1e-5 (relative) of the device maximum.
 #include <algorithm>
+#include <type_traits>
 
 #include "scan_matching_3d.h"
 
@@ -253,6 +254,9 @@ struct Rt3DBulkParams {
   double slack_hi;               // 127 kScale + 2e-7 (quantisation + rounding of the table)
   double delta;                  // relative slack of the f32 chain + exp
   float* upper;                  // [R][num_translations] weighted upper bound
+  int block_items;               // candidate pass: items per work descriptor (= blockDim.x)
+  int list_rotations;            // candidate pass: consecutive rotations sharing one work list;
+                                 // an entry is w * num_translations + t (w: rotation in the list)
   uint2* sums;                   // candidate pass: [R][T] (Q, A) accumulated over point slices
   int slice_points;              // points per blockIdx.z (a multiple of the chunk)
   unsigned* max_lower_bits;      // atomicMax of the weighted lower bounds (candidate pass)
@@ -333,11 +337,11 @@ Rt3DBulkKernel(Rt3DBulkParams P, const float* __restrict__ xyz) {
     wave_active = first_flat + (tid & ~63) < total;
   } else {
     const int2 work = P.blocks[blockIdx.x];
-    r = work.x;
-    const int slot = work.y * kCand3DThreads + tid;
+    r = work.x;                                      // (this kernel: lists of one rotation)
+    const int slot = work.y * P.block_items + tid;
     const int count = P.counts[r];
-    if (work.y * kCand3DThreads >= count) return;                        // whole block idle
-    wave_active = work.y * kCand3DThreads + (tid & ~63) < count;
+    if (work.y * P.block_items >= count) return;                         // whole block idle
+    wave_active = work.y * P.block_items + (tid & ~63) < count;
     valid = slot < count;
     t = P.items[static_cast<size_t>(r) * P.num_translations + (valid ? slot : count - 1)];
     rotation_a = r;
@@ -453,15 +457,18 @@ Rt3DBulkKernel(Rt3DBulkParams P, const float* __restrict__ xyz) {
 }
 
 // grid (work descriptors): bounds of the candidates on the work lists from their (Q, A).
-__global__ void __launch_bounds__(kCand3DThreads)
+__global__ void __launch_bounds__(512)
 Rt3DBoundsKernel(Rt3DBulkParams P) {
   const int2 work = P.blocks[blockIdx.x];
-  const int r = work.x;
-  const int slot = work.y * kCand3DThreads + threadIdx.x;
-  const int count = P.counts[r];
+  const int list = work.x;
+  const int slot = work.y * P.block_items + threadIdx.x;
+  const int count = P.counts[list];
   float lower = 0.f, upper = 0.f;
   if (slot < count) {
-    const int t = P.items[static_cast<size_t>(r) * P.num_translations + slot];
+    const int entry =
+        P.items[static_cast<size_t>(list) * P.list_rotations * P.num_translations + slot];
+    const int w = entry / P.num_translations, t = entry - w * P.num_translations;
+    const int r = list * P.list_rotations + w;
     const size_t c = static_cast<size_t>(r) * P.num_translations + t;
     const uint2 qa = P.sums[c];
     Bounds3D(P, qa.x, qa.y, P.translation[t].w, r, &lower, &upper);
@@ -477,20 +484,502 @@ Rt3DBoundsKernel(Rt3DBulkParams P) {
 // its members that was scored -- both bracket the same true score.  (A group pass reading the
 // wrong staged rotation once produced garbage bounds that every parity test survived: the
 // optimum happened not to be pruned.)  grid (work descriptors).
-__global__ void __launch_bounds__(kCand3DThreads)
+__global__ void __launch_bounds__(512)
 Rt3DVerifyKernel(Rt3DBulkParams P, const float* __restrict__ group_upper, int num_groups,
                  int side, int groups_per_axis, int* __restrict__ violations) {
   const int2 work = P.blocks[blockIdx.x];
-  const int r = work.x;
-  const int slot = work.y * kCand3DThreads + threadIdx.x;
-  if (slot >= P.counts[r]) return;
-  const int t = P.items[static_cast<size_t>(r) * P.num_translations + slot];
+  const int list = work.x;
+  const int slot = work.y * P.block_items + threadIdx.x;
+  if (slot >= P.counts[list]) return;
+  const int entry =
+      P.items[static_cast<size_t>(list) * P.list_rotations * P.num_translations + slot];
+  const int w = entry / P.num_translations, t = entry - w * P.num_translations;
+  const int r = list * P.list_rotations + w;
   const uint2 qa = P.sums[static_cast<size_t>(r) * P.num_translations + t];
   float lower, upper;
   Bounds3D(P, qa.x, qa.y, P.translation[t].w, r, &lower, &upper);
   const int x = t % side, y = (t / side) % side, z = t / (side * side);
   const int g = ((z >> 1) * groups_per_axis + (y >> 1)) * groups_per_axis + (x >> 1);
   if (group_upper[static_cast<size_t>(r) * num_groups + g] < lower) atomicAdd(violations, 1);
+}
+
+
+// ---------------------------------------------------------------------------
+// LDS-tiled bulk passes
+// ---------------------------------------------------------------------------
+// The gathers of the passes above go to memory one byte per lane: a wave's 64 lookups of one
+// point touch ~30 cache lines, and the L1's tag rate (~1 line per cycle and CU) is what bounds
+// them (1.3e12 lookups/s, profiles/r03_gather_ceiling.txt).  But all lanes of a workgroup read
+// the SAME point at the same time, displaced only by their translations (a window of a dozen
+// cells) -- so for a spatially compact CHUNK of points everything a workgroup reads lies in a
+// box of a few ten cells per axis.  The cloud is therefore sorted into bins of kTileBin^3 cells
+// (counting sort on the device, integer sums do not care about the order) and cut into chunks
+// of at most kTileChunk points; per chunk a workgroup
+//   1. rotates the chunk by its rotation(s) into LDS (as before) and takes the bounding box of
+//      the rotated points in cell coordinates (wave reductions + LDS atomics),
+//   2. widens the box by the span of the translation table, copies that box of the brick into
+//      LDS with aligned dword loads (row-major brick, pitch a multiple of 4),
+//   3. runs the same lookup loop against the tile: ds_read_u8 instead of buffer_load_ubyte.
+// A box that does not fit the tile capacity (a chunk of far points under a wide rotation
+// block) takes the memory gathers for that chunk -- same arithmetic, same sums.  The integer
+// sums are accumulated over chunk slices (blockIdx.y) with atomics; bounds come from
+// Rt3DSumBoundsKernel / Rt3DBoundsKernel.  Every sum is identical to what Rt3DBulkKernel
+// computes (CMX_RT3D_TILES=0 runs that kernel; tests compare the two).
+constexpr int kTileChunk = 256;
+constexpr int kTileBin = 16;
+constexpr int kTileMaxRotations = 8;
+constexpr int kTileStageStride = 3 * kTileChunk / 2 + 2;     // v2f per staged rotation (+16 B: bank shift)
+
+struct Rt3DTileParams {
+  const float* sorted_xyz;       // bin-sorted cloud
+  const int2* chunks;            // (first point, length)
+  const int* num_chunks;
+  int pitch_x, pitch_y, pitch_z; // brick dims (pitch_x a multiple of 4)
+  float tr_lo[3], tr_hi[3];      // span of translation * inv_resolution over the table
+  int rotations_per_block;       // group pass: rotations of a workgroup
+  int tile_capacity;             // bytes of dynamic LDS behind the staged points
+  int block_items;               // candidate pass: items per work descriptor (= blockDim.x)
+  int fixed_point;               // group pass: packed fixed-point cell arithmetic (see kernel)
+  int experiment;                // CMX_RT3D_TILE_EXPERIMENT (timing only, wrong results): 1 = no
+                                 // tile gathers, 2 = no point reads, 3 = neither
+  unsigned long long* stats;     // CMX_RT3D_REPORT: [0] chunks in LDS, [1] on the gather path,
+                                 // [2] tile bytes, [3] points (per workgroup and chunk); or null
+};
+
+// Bin of a point: its cell at the central candidate (rotation index R/2, translation T/2).
+struct Rt3DBinParams {
+  float4 rotation, translation;
+  float inv_resolution, off_x, off_y, off_z;
+  float t0x, t0y, t0z, lo_x, hi_x, lo_y, hi_y, lo_z, hi_z;     // ClampStage
+  int bins_x, bins_y, bins_z;
+  int n;
+};
+
+__device__ __forceinline__ int Rt3DBinOf(const Rt3DBinParams& P, const float* __restrict__ xyz,
+                                         int i) {
+  const Quat q{P.rotation.w, P.rotation.x, P.rotation.y, P.rotation.z};
+  const F3 rp = Rotate(q, F3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]});
+  const float x = ClampStage(rp.x, P.t0x, P.lo_x, P.hi_x) + P.translation.x;
+  const float y = ClampStage(rp.y, P.t0y, P.lo_y, P.hi_y) + P.translation.y;
+  const float z = ClampStage(rp.z, P.t0z, P.lo_z, P.hi_z) + P.translation.z;
+  // (NaN coordinates never get here: the bulk path requires finite points)
+  const int cx = static_cast<int>(rintf(fmaf(x, P.inv_resolution, P.off_x)));
+  const int cy = static_cast<int>(rintf(fmaf(y, P.inv_resolution, P.off_y)));
+  const int cz = static_cast<int>(rintf(fmaf(z, P.inv_resolution, P.off_z)));
+  const int bx = min(max(cx / kTileBin, 0), P.bins_x - 1);
+  const int by = min(max(cy / kTileBin, 0), P.bins_y - 1);
+  const int bz = min(max(cz / kTileBin, 0), P.bins_z - 1);
+  return (bz * P.bins_y + by) * P.bins_x + bx;
+}
+
+// counters[bin] += (lanes of this wave with that bin); returns the lane's own slot.  Scan order
+// puts neighbouring points into the same bin, so a wave needs one or two atomics.
+__device__ __forceinline__ int WaveAggregatedAdd(int* __restrict__ counters, int bin, bool active) {
+  const int lane = threadIdx.x & 63;
+  int slot = 0;
+  for (;;) {
+    const unsigned long long todo = __ballot(active);
+    if (todo == 0ull) break;
+    const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+    const int leader_bin = __shfl(bin, leader, 64);
+    const bool mine = active && bin == leader_bin;
+    const unsigned long long group = __ballot(mine);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&counters[leader_bin], __popcll(group));
+    base = __shfl(base, leader, 64);
+    if (mine) {
+      slot = base + __popcll(group & ((1ull << lane) - 1ull));
+      active = false;
+    }
+  }
+  return slot;
+}
+
+__global__ void Rt3DBinCountKernel(Rt3DBinParams P, const float* __restrict__ xyz,
+                                   int* __restrict__ bin_count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < P.n;
+  const int bin = active ? Rt3DBinOf(P, xyz, i) : 0;
+  (void)WaveAggregatedAdd(bin_count, bin, active);
+}
+
+// One workgroup: exclusive scan of the bin counts -> first point of every bin (written over the
+// counts: the scatter kernel's cursors) and the chunk list.
+__global__ void __launch_bounds__(1024)
+Rt3DBinScanKernel(int* __restrict__ bin_count, int num_bins, int2* __restrict__ chunks,
+                  int* __restrict__ num_chunks) {
+  __shared__ int part_points[1024], part_chunks[1024];
+  const int tid = threadIdx.x;
+  const int per = (num_bins + 1023) / 1024;
+  const int begin = min(tid * per, num_bins), end = min(begin + per, num_bins);
+  int points = 0, pieces = 0;
+  for (int b = begin; b < end; ++b) {
+    points += bin_count[b];
+    pieces += (bin_count[b] + kTileChunk - 1) / kTileChunk;
+  }
+  part_points[tid] = points;
+  part_chunks[tid] = pieces;
+  __syncthreads();
+  if (tid == 0) {
+    int p = 0, c = 0;
+    for (int k = 0; k < 1024; ++k) {
+      const int pp = part_points[k], cc = part_chunks[k];
+      part_points[k] = p; part_chunks[k] = c;
+      p += pp; c += cc;
+    }
+    *num_chunks = c;
+  }
+  __syncthreads();
+  int p = part_points[tid], c = part_chunks[tid];
+  for (int b = begin; b < end; ++b) {
+    const int count = bin_count[b];
+    bin_count[b] = p;
+    for (int first = 0; first < count; first += kTileChunk)
+      chunks[c++] = make_int2(p + first, min(kTileChunk, count - first));
+    p += count;
+  }
+}
+
+__global__ void Rt3DBinScatterKernel(Rt3DBinParams P, const float* __restrict__ xyz,
+                                     int* __restrict__ cursor, float* __restrict__ sorted) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < P.n;
+  const int bin = active ? Rt3DBinOf(P, xyz, i) : 0;
+  const int slot = WaveAggregatedAdd(cursor, bin, active);
+  if (active) {
+    sorted[3 * slot] = xyz[3 * i];
+    sorted[3 * slot + 1] = xyz[3 * i + 1];
+    sorted[3 * slot + 2] = xyz[3 * i + 2];
+  }
+}
+
+// kGroups: grid (ceil(R / rotations_per_block), chunk slices), blockDim = the (rotation, group)
+// lanes of a block rounded up to whole waves.  Candidate pass: grid (work descriptors, chunk
+// slices), blockDim = block_items.  Dynamic LDS: staged points | tile.
+template <bool kGroups>
+__global__ void __launch_bounds__(1024)
+Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
+  const int tid = threadIdx.x;
+  const int rotations = kGroups ? TP.rotations_per_block : P.list_rotations;
+  // Dynamic LDS: tile | staged points | (group pass) the points again as packed fixed-point
+  // words, see step 2b.  The tile comes first: its LDS address is then a compile-time constant
+  // that folds into the gathers' offset field.
+  uint8_t* const tile = tile_smem;
+  if (static_cast<unsigned>(reinterpret_cast<uintptr_t>(tile)) != 0u) __builtin_trap();
+  v2f* const stage = reinterpret_cast<v2f*>(tile_smem + TP.tile_capacity);
+  uint32_t* const packed = reinterpret_cast<uint32_t*>(stage + kTileStageStride * rotations);
+  // min x, y, z, max x, y, z of the rotated chunk (cells).  (No static __shared__ in this kernel:
+  // the tile then starts at LDS address 0 and the gathers need no base.)
+  int* const box = reinterpret_cast<int*>(packed + (kGroups ? kTileChunk * rotations : 0));
+
+  int r, t, rotation_a, num_rot;
+  bool valid;
+  if (kGroups) {
+    rotation_a = blockIdx.x * rotations;
+    num_rot = min(rotations, P.num_rotations - rotation_a);
+    const int item = tid;
+    valid = item < num_rot * P.num_translations;
+    const int which = valid ? item / P.num_translations : 0;
+    r = rotation_a + which;
+    t = valid ? item - which * P.num_translations : 0;
+  } else {
+    const int2 work = P.blocks[blockIdx.x];
+    const int list = work.x;
+    rotation_a = list * P.list_rotations;
+    num_rot = min(P.list_rotations, P.num_rotations - rotation_a);
+    const int count = P.counts[list];
+    const int slot = work.y * TP.block_items + tid;
+    valid = slot < count;
+    if (work.y * TP.block_items >= count) return;
+    const int entry = P.items[static_cast<size_t>(list) * P.list_rotations * P.num_translations +
+                              (valid ? slot : count - 1)];
+    const int w = entry / P.num_translations;
+    t = entry - w * P.num_translations;
+    r = rotation_a + w;
+  }
+  const v2f* const my_stage = stage + (r - rotation_a) * kTileStageStride;
+  const float4 tr = P.translation[t];
+  const v2f trx = {tr.x, tr.x}, try_ = {tr.y, tr.y}, trz = {tr.z, tr.z};
+  const v2f inv = {P.inv_resolution, P.inv_resolution};
+  const v2f ofx = {P.off_x, P.off_x}, ofy = {P.off_y, P.off_y}, ofz = {P.off_z, P.off_z};
+  const float guard = P.guard;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(P.cells), 0, P.cell_count, 0x00020000);
+  unsigned acc = 0, ambiguous = 0;
+  const int num_chunks = *TP.num_chunks;
+  // Fixed-point group pass.  The centre of a group needs no exact cell: its lookup in the
+  // 3 x 3 x 3-dilated brick covers the members as long as the cell it reads is the cell of a
+  // point within 1 - 0.87 = 0.13 cells (per axis) of the true centre.  So cell coordinates are
+  // kept in 1/16 cells: 10 bits per axis, three axes in one word, tile-relative.  The point
+  // word (built once per chunk and rotation) carries + 0.5 for the rounding, the lane word
+  // (built once) the translation above the table's minimum; ONE integer add then yields all
+  // three cell indices -- against 3 + 3 packed f32 operations and six roundings.  Error: both
+  // words are rounded to 1/32 cell: 1/16 in total (+ 1e-5 of f32 arithmetic) < 0.13.
+  constexpr int kFrac = 4;
+  unsigned lane_word = 0;
+  if (kGroups) {
+    const float s = static_cast<float>(1 << kFrac);
+    const unsigned tx = static_cast<unsigned>(rintf((tr.x * P.inv_resolution - TP.tr_lo[0]) * s));
+    const unsigned ty = static_cast<unsigned>(rintf((tr.y * P.inv_resolution - TP.tr_lo[1]) * s));
+    const unsigned tz = static_cast<unsigned>(rintf((tr.z * P.inv_resolution - TP.tr_lo[2]) * s));
+    lane_word = tx | (ty << 10) | (tz << 20);
+  }
+
+  for (int chunk = blockIdx.y; chunk < num_chunks; chunk += gridDim.y) {
+    const int2 span = TP.chunks[chunk];
+    const int len = span.y;
+    __syncthreads();                                     // the previous chunk is done with
+    if (tid < 3) box[tid] = 0x7fffffff;
+    else if (tid < 6) box[tid] = -0x7fffffff;
+    __syncthreads();
+    // 1. rotate the chunk by every rotation of the block; bounding box in cell coordinates
+    {
+      float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+      const int len_even = (len + 1) & ~1;               // (an odd chunk's pair partner is defined)
+      for (int s = tid; s < num_rot * kTileChunk; s += blockDim.x) {
+        const int w = s / kTileChunk, k = s % kTileChunk;      // (a power of two: shifts)
+        if (k >= len_even) continue;
+        const int i = span.x + min(k, len - 1);
+        const float4 q4 = P.rotation[rotation_a + w];
+        const F3 rp = Rotate(Quat{q4.w, q4.x, q4.y, q4.z},
+                             F3{TP.sorted_xyz[3 * i], TP.sorted_xyz[3 * i + 1],
+                                TP.sorted_xyz[3 * i + 2]});
+        const float x = ClampStage(rp.x, P.t0x, P.lo_x, P.hi_x);
+        const float y = ClampStage(rp.y, P.t0y, P.lo_y, P.hi_y);
+        const float z = ClampStage(rp.z, P.t0z, P.lo_z, P.hi_z);
+        float* dst = reinterpret_cast<float*>(stage + w * kTileStageStride) + 6 * (k >> 1) + (k & 1);
+        dst[0] = x; dst[2] = y; dst[4] = z;
+        const float c[3] = {x * P.inv_resolution, y * P.inv_resolution, z * P.inv_resolution};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], c[a]); mx[a] = fmaxf(mx[a], c[a]); }
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
+          mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
+        }
+      }
+      if ((tid & 63) == 0 && mn[0] <= mx[0]) {
+        const float offs[3] = {P.off_x, P.off_y, P.off_z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          // one cell of slack either side: the lookups round (c + tr) * inv + off, not this sum
+          atomicMin(&box[a], static_cast<int>(floorf(mn[a] + TP.tr_lo[a] + offs[a])) - 1);
+          atomicMax(&box[3 + a], static_cast<int>(ceilf(mx[a] + TP.tr_hi[a] + offs[a])) + 1);
+        }
+      }
+    }
+    __syncthreads();
+    // 2. the box, clipped to the brick (ClampStage keeps every lookup inside it), x aligned to 4
+    const int lo_x = max(box[0], 0) & ~3, lo_y = max(box[1], 0), lo_z = max(box[2], 0);
+    const int hi_x = min(box[3], TP.pitch_x - 1), hi_y = min(box[4], TP.pitch_y - 1),
+              hi_z = min(box[5], TP.pitch_z - 1);
+    const int dx = (hi_x - lo_x + 4) & ~3, dy = hi_y - lo_y + 1, dz = hi_z - lo_z + 1;
+    const bool in_lds = dx > 0 && dx <= 256 && dy > 0 && dz > 0 &&
+                        static_cast<long long>(dx) * dy * dz <= TP.tile_capacity;
+    if (in_lds) {
+      // Division-free copy: a wave takes whole z slices; its lanes are (row within a group of
+      // 64 / lanes_per_row rows, dword within the row).
+      const int qx = dx >> 2;
+      int shift = 2;                                     // lanes per row = 1 << shift >= qx
+      while ((1 << shift) < qx) ++shift;
+      const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(P.cells);
+      uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(tile);
+      const int row_q = TP.pitch_x >> 2;
+      const int lane = tid & 63, wave = tid >> 6, waves = blockDim.x >> 6;
+      const int xq = lane & ((1 << shift) - 1), sub = lane >> shift, rows_per_step = 64 >> shift;
+      if (shift <= 6 && xq < qx) {
+        for (int z = wave; z < dz; z += waves) {
+          const uint32_t* zsrc = src + (static_cast<size_t>(lo_z + z) * TP.pitch_y + lo_y) * row_q +
+                                 (lo_x >> 2) + xq;
+          uint32_t* zdst = dst + z * dy * qx + xq;
+          for (int y = sub; y < dy; y += rows_per_step) zdst[y * qx] = zsrc[static_cast<size_t>(y) * row_q];
+        }
+      }
+    }
+    // 2b. group pass: the staged points as fixed-point words relative to the tile
+    const bool fixed = kGroups && TP.fixed_point && in_lds && dx <= 63 && dy <= 63 && dz <= 63;
+    if (fixed) {
+      const float s = static_cast<float>(1 << kFrac);
+      const float bx = P.off_x + TP.tr_lo[0] - static_cast<float>(lo_x) + 0.5f;
+      const float by = P.off_y + TP.tr_lo[1] - static_cast<float>(lo_y) + 0.5f;
+      const float bz = P.off_z + TP.tr_lo[2] - static_cast<float>(lo_z) + 0.5f;
+      const int len_even = (len + 1) & ~1;
+      for (int e = tid; e < num_rot * kTileChunk; e += blockDim.x) {
+        const int w = e / kTileChunk, k = e % kTileChunk;
+        if (k >= len_even) continue;
+        const float* src = reinterpret_cast<const float*>(stage + w * kTileStageStride) +
+                           6 * (k >> 1) + (k & 1);
+        const unsigned px = static_cast<unsigned>(rintf(fmaf(src[0], P.inv_resolution, bx) * s));
+        const unsigned py = static_cast<unsigned>(rintf(fmaf(src[2], P.inv_resolution, by) * s));
+        const unsigned pz = static_cast<unsigned>(rintf(fmaf(src[4], P.inv_resolution, bz) * s));
+        packed[w * kTileChunk + k] = px | (py << 10) | (pz << 20);
+      }
+    }
+    __syncthreads();
+    if (TP.stats != nullptr && tid == 0) {
+      atomicAdd(&TP.stats[in_lds ? 0 : 1], 1ull);
+      atomicAdd(&TP.stats[2], static_cast<unsigned long long>(dx) * dy * dz);
+      atomicAdd(&TP.stats[3], static_cast<unsigned long long>(len));
+    }
+    if (!valid) continue;
+    // 3. the lookups.  Cell indices are computed exactly as in Rt3DBulkKernel (the candidate
+    //    pass's ambiguity argument rests on that expression); only the address differs.
+    const v2f lx = {static_cast<float>(lo_x), static_cast<float>(lo_x)};
+    const v2f ly = {static_cast<float>(lo_y), static_cast<float>(lo_y)};
+    const v2f lz = {static_cast<float>(lo_z), static_cast<float>(lo_z)};
+    const v2f dxf = {static_cast<float>(dx), static_cast<float>(dx)};
+    const v2f dyf = {static_cast<float>(dy), static_cast<float>(dy)};
+    const v2f px2 = {static_cast<float>(TP.pitch_x), static_cast<float>(TP.pitch_x)};
+    const v2f py2 = {static_cast<float>(TP.pitch_y), static_cast<float>(TP.pitch_y)};
+    // One pair of points (already in registers) -> two lookups.  kLds is a compile-time
+    // property of the loop it runs in: the two address paths never share a loop body.
+    const auto pair = [&](auto lds_tag, const v2f* pr, unsigned* v0, unsigned* v1, float* g) {
+      constexpr bool kLds = decltype(lds_tag)::value;
+      const v2f cx = pr[0] + trx, cy = pr[1] + try_, cz = pr[2] + trz;
+      const v2f qx = __builtin_elementwise_fma(cx, inv, ofx);
+      const v2f qy = __builtin_elementwise_fma(cy, inv, ofy);
+      const v2f qz = __builtin_elementwise_fma(cz, inv, ofz);
+      const v2f nx = {rintf(qx.x), rintf(qx.y)};
+      const v2f ny = {rintf(qy.x), rintf(qy.y)};
+      const v2f nz = {rintf(qz.x), rintf(qz.y)};
+      if (!kGroups) {
+        const v2f ex = qx - nx, ey = qy - ny, ez = qz - nz;
+        float m = fmaxf(fmaxf(*g, fabsf(ex.x)), fabsf(ex.y));
+        m = fmaxf(fmaxf(m, fabsf(ey.x)), fabsf(ey.y));
+        *g = fmaxf(fmaxf(m, fabsf(ez.x)), fabsf(ez.y));
+      }
+      if (kLds) {
+        const v2f o = __builtin_elementwise_fma(
+            __builtin_elementwise_fma(nz - lz, dyf, ny - ly), dxf, nx - lx);
+        if (TP.experiment & 1) {
+          *v0 = static_cast<unsigned>(o.x);
+          *v1 = static_cast<unsigned>(o.y);
+        } else {
+          *v0 = tile[static_cast<unsigned>(o.x)];
+          *v1 = tile[static_cast<unsigned>(o.y)];
+        }
+      } else {
+        const v2f o = __builtin_elementwise_fma(__builtin_elementwise_fma(nz, py2, ny), px2, nx);
+        *v0 = __builtin_amdgcn_raw_buffer_load_b8(rsrc, static_cast<unsigned>(o.x), 0, 0);
+        *v1 = __builtin_amdgcn_raw_buffer_load_b8(rsrc, static_cast<unsigned>(o.y), 0, 0);
+      }
+    };
+    const int len4 = len & ~3;
+    // LDS returns in issue order: a wait for point data also waits for every gather issued
+    // before that read.  So the points of iteration j + 1 are requested BEFORE the gathers of
+    // iteration j are issued, and the gathers of iteration j are consumed in iteration j + 1:
+    // every wait is for something issued a whole iteration earlier.
+    const auto run = [&](auto lds_tag) {
+      unsigned p0 = 0, p1 = 0, p2 = 0, p3 = 0;          // the previous four lookups, in flight
+      v2f cur[6], nxt[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) cur[k] = my_stage[k];
+#pragma unroll 2
+      for (int j = 0; j < len4; j += 4) {
+        const v2f* ahead = my_stage + 3 * (min(j + 4, kTileChunk - 4) >> 1);
+        if (TP.experiment & 2) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) nxt[k] = cur[k] + inv;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) nxt[k] = ahead[k];
+        }
+        unsigned v[4];
+        float g = 0.f;
+        pair(lds_tag, cur, &v[0], &v[1], &g);
+        pair(lds_tag, cur + 3, &v[2], &v[3], &g);
+        if (!kGroups) ambiguous += g > guard ? 1u : 0u;
+        acc += (p0 + p1) + (p2 + p3);
+        p0 = v[0]; p1 = v[1]; p2 = v[2]; p3 = v[3];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cur[k] = nxt[k];
+      }
+      acc += (p0 + p1) + (p2 + p3);
+      // the last 1..3 points: pairs whose second element may lie beyond the chunk (an odd
+      // chunk staged its last point twice; the duplicate can only flag an ambiguity its twin
+      // flags as well)
+      for (int j = len4; j < len; j += 2) {
+        unsigned v0, v1;
+        float g = 0.f;
+        pair(lds_tag, my_stage + 3 * (j >> 1), &v0, &v1, &g);
+        acc += v0 + (j + 1 < len ? v1 : 0u);
+        if (!kGroups) ambiguous += g > guard ? 1u : 0u;
+      }
+    };
+    if (TP.experiment & 4) continue;                    // (timing: everything but the lookups)
+    if (fixed) {
+      const uint32_t* __restrict__ words = packed + (r - rotation_a) * kTileChunk;
+      const unsigned udx = dx, udy = dy;
+      const auto cell = [&](unsigned point_word) -> unsigned {
+        const unsigned sum = point_word + lane_word;
+        const unsigned x = (sum >> kFrac) & 63u, y = (sum >> (10 + kFrac)) & 63u,
+                       z = sum >> (20 + kFrac);
+        unsigned row, at;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row) : "v"(z), "s"(udy), "v"(y));
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(at) : "v"(row), "s"(udx), "v"(x));
+        // (the tile starts at LDS address 0, checked at kernel entry: `at` IS the address)
+        typedef __attribute__((address_space(3))) const uint8_t LdsByte;
+        return *reinterpret_cast<LdsByte*>(static_cast<uintptr_t>(at));
+      };
+      unsigned p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+      const int len4 = len & ~3;
+      uint4 cur = *reinterpret_cast<const uint4*>(words);
+#pragma unroll 2
+      for (int j = 0; j < len4; j += 4) {
+        const uint4 nxt = *reinterpret_cast<const uint4*>(words + min(j + 4, kTileChunk - 4));
+        const unsigned v0 = cell(cur.x), v1 = cell(cur.y), v2 = cell(cur.z), v3 = cell(cur.w);
+        acc += (p0 + p1) + (p2 + p3);
+        p0 = v0; p1 = v1; p2 = v2; p3 = v3;
+        cur = nxt;
+      }
+      acc += (p0 + p1) + (p2 + p3);
+      for (int j = len4; j < len; ++j) acc += cell(words[j]);
+    } else if (in_lds) {
+      run(std::true_type{});
+    } else {
+      run(std::false_type{});
+    }
+  }
+  if (valid && (acc | ambiguous)) {
+    const size_t c = static_cast<size_t>(r) * P.num_translations + t;
+    atomicAdd(&P.sums[c].x, acc);
+    if (ambiguous) atomicAdd(&P.sums[c].y, ambiguous);
+  }
+}
+
+// CMX_RT3D_CROSSCHECK=1 (tests): the tiled passes against the memory-gather kernels, element by
+// element -- group upper bounds (bitwise) and candidate sums Q.
+__global__ void Rt3DCompareFloatsKernel(const float* __restrict__ a, const float* __restrict__ b,
+                                        long long n, int* __restrict__ mismatches) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n && __float_as_uint(a[i]) != __float_as_uint(b[i])) atomicAdd(mismatches, 1);
+}
+__global__ void Rt3DCompareSumsKernel(const uint2* __restrict__ a, const uint2* __restrict__ b,
+                                      long long n, int* __restrict__ mismatches) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n && a[i].x != b[i].x) atomicAdd(mismatches, 1);
+}
+
+// Group pass of the tiled path: weighted upper bounds from the accumulated sums.
+__global__ void Rt3DSumBoundsKernel(Rt3DBulkParams P) {
+  const long long c = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const long long total = static_cast<long long>(P.num_rotations) * P.num_translations;
+  float upper = 0.f;
+  if (c < total) {
+    const int r = static_cast<int>(c / P.num_translations);
+    const int t = static_cast<int>(c - static_cast<long long>(r) * P.num_translations);
+    float lower;
+    Bounds3D(P, P.sums[c].x, 0u, P.translation[t].w, r, &lower, &upper);
+    P.upper[c] = upper;
+  }
+  unsigned bits = __float_as_uint(upper);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) bits = max(bits, __shfl_xor(bits, off, 64));
+  if ((threadIdx.x & 63) == 0 && bits != 0) atomicMax(P.max_upper_bits, bits);
 }
 
 // 3 x 3 x 3 dilation of the padded brick in two passes (x, then y and z).  The halo is wider
@@ -546,42 +1035,47 @@ __global__ void Rt3DSelectGroupsKernel(const float* __restrict__ group_upper, in
               ((2 * gz + c) * side + (2 * gy + b)) * side + (2 * gx + a)] = 1;
 }
 
-// One block per rotation: the flagged translations in ascending order (x offsets fastest, so
-// neighbouring lanes of the candidate pass read neighbouring cells: a gather instruction costs
-// about 17 cycles plus 1.3 per distinct cache line it touches), flags cleared for the next
-// round; one work descriptor (r, chunk) per kCand3DThreads of them.
+// One block per work list (= `list_rotations` consecutive rotations): the flagged translations
+// of its rotations, rotation by rotation in ascending order (x offsets fastest, so neighbouring
+// lanes of the candidate pass read neighbouring cells), as entries w * T + t; flags cleared for
+// the next round; one work descriptor (list, chunk) per `block_items` entries.
 __global__ void __launch_bounds__(256)
-Rt3DCompactKernel(uint8_t* __restrict__ flags, int num_translations, int* __restrict__ counts,
-                  int* __restrict__ items, int* __restrict__ total, int2* __restrict__ blocks,
-                  int* __restrict__ num_blocks) {
+Rt3DCompactKernel(uint8_t* __restrict__ flags, int num_translations, int num_rotations,
+                  int list_rotations, int* __restrict__ counts, int* __restrict__ items,
+                  int* __restrict__ total, int2* __restrict__ blocks,
+                  int* __restrict__ num_blocks, int block_items) {
   __shared__ int wave_count[4];
   __shared__ int base;
-  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  uint8_t* f = flags + static_cast<size_t>(r) * num_translations;
-  int* out = items + static_cast<size_t>(r) * num_translations;
+  const int list = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int* out = items + static_cast<size_t>(list) * list_rotations * num_translations;
   if (tid == 0) base = 0;
   __syncthreads();
-  for (int t0 = 0; t0 < num_translations; t0 += 256) {
-    const int t = t0 + tid;
-    const bool on = t < num_translations && f[t] != 0;
-    if (on) f[t] = 0;
-    const unsigned long long mask = __ballot(on);
-    if (lane == 0) wave_count[wave] = __popcll(mask);
-    __syncthreads();
-    int offset = base;
-    for (int w = 0; w < wave; ++w) offset += wave_count[w];
-    if (on) out[offset + __popcll(mask & ((1ull << lane) - 1ull))] = t;
-    __syncthreads();
-    if (tid == 0) base += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
-    __syncthreads();
+  for (int w = 0; w < list_rotations; ++w) {
+    const int r = list * list_rotations + w;
+    if (r >= num_rotations) break;
+    uint8_t* f = flags + static_cast<size_t>(r) * num_translations;
+    for (int t0 = 0; t0 < num_translations; t0 += 256) {
+      const int t = t0 + tid;
+      const bool on = t < num_translations && f[t] != 0;
+      if (on) f[t] = 0;
+      const unsigned long long mask = __ballot(on);
+      if (lane == 0) wave_count[wave] = __popcll(mask);
+      __syncthreads();
+      int offset = base;
+      for (int k = 0; k < wave; ++k) offset += wave_count[k];
+      if (on) out[offset + __popcll(mask & ((1ull << lane) - 1ull))] = w * num_translations + t;
+      __syncthreads();
+      if (tid == 0) base += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+      __syncthreads();
+    }
   }
   if (tid == 0) {
-    counts[r] = base;
+    counts[list] = base;
     if (base) {
       atomicAdd(total, base);
-      const int chunks = (base + kCand3DThreads - 1) / kCand3DThreads;
+      const int chunks = (base + block_items - 1) / block_items;
       const int first = atomicAdd(num_blocks, chunks);
-      for (int k = 0; k < chunks; ++k) blocks[first + k] = make_int2(r, k);
+      for (int k = 0; k < chunks; ++k) blocks[first + k] = make_int2(list, k);
     }
   }
 }
@@ -660,6 +1154,17 @@ __global__ void ScatterBulkKernel(const cmx_voxel* __restrict__ voxels, long lon
 
 // CMX_RT3D_BULK=0 keeps every candidate on the one-thread-per-candidate kernel (parity tests
 // run both paths).
+// CMX_RT3D_TILES=0 keeps the bulk passes on the memory gathers (Rt3DBulkKernel); parity tests
+// run both.
+bool Tiles3DEnabled() {
+  const char* e = getenv("CMX_RT3D_TILES");
+  return !(e && e[0] == '0');
+}
+int EnvInt(const char* name, int fallback) {
+  const char* e = getenv(name);
+  return e && e[0] ? atoi(e) : fallback;
+}
+
 bool Bulk3DEnabled() {
   const char* e = getenv("CMX_RT3D_BULK");
   return !(e && e[0] == '0');
@@ -864,7 +1369,8 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
     // weights that decrease with distance (a group is weighted by its nearest member).
     const int reach = static_cast<int>(std::ceil(L * 1.7320508075688772)) + 1;   // |init.q * t_c|
     const int pad = 2 * reach + 2;
-    const long long bx = brick.nx + 2ll * pad, by = brick.ny + 2ll * pad,
+    // (rows a multiple of 4 cells: the tiled passes copy boxes of the brick with aligned dwords)
+    const long long bx = (brick.nx + 2ll * pad + 3) & ~3ll, by = brick.ny + 2ll * pad,
                     bz = brick.nz + 2ll * pad;
     bool use_bulk = Bulk3DEnabled() && n <= (1 << 21) && R <= 65535 &&
                     bx * by * bz < (1ll << 24) &&
@@ -929,7 +1435,7 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
       int* d_items = reinterpret_cast<int*>(d_unweighted);           // [R][T], reused
       const size_t head_bytes = 16 + (sizeof(int) + sizeof(float)) * kBulkFinalistCap;   // 16 | 32768
       // work descriptors of a round: at most one per 256 translations and rotation, + count
-      const int max_blocks = static_cast<int>(R) * DivUp(T, kCand3DThreads);
+      const int max_blocks = static_cast<int>(R) * DivUp(T, kCand3DThreads);   // (>= any block size used)
       const size_t counts_bytes = (sizeof(int) * R + 15) / 16 * 16;
       char* d_bmisc = static_cast<char*>(ws->dev[13].Reserve(
           head_bytes + counts_bytes + sizeof(int2) * (max_blocks + 1)));
@@ -1002,7 +1508,130 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
       BG.upper = d_group_upper;
       StageTrace trace(ws->stream);
       trace.Mark("bricks");
+      int cus = 256;
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+      // Tiled passes: the cloud sorted into bins of kTileBin^3 cells at the central candidate.
+      const int rot_per_block = std::max(1, std::min(kTileMaxRotations, 1024 / std::max(G, 1)));
+      const bool use_tiles = Tiles3DEnabled() && G <= 1024;
+      const bool crosscheck = use_tiles && EnvInt("CMX_RT3D_CROSSCHECK", 0) == 1;
+      Rt3DTileParams TG{};
+      int max_chunks = 0;
+      if (use_tiles) {
+        Rt3DBinParams BP{};
+        BP.rotation = rot[R / 2];
+        BP.translation = trans[T / 2];
+        BP.inv_resolution = B.inv_resolution;
+        BP.off_x = B.off_x; BP.off_y = B.off_y; BP.off_z = B.off_z;
+        BP.t0x = B.t0x; BP.t0y = B.t0y; BP.t0z = B.t0z;
+        BP.lo_x = B.lo_x; BP.hi_x = B.hi_x; BP.lo_y = B.lo_y; BP.hi_y = B.hi_y;
+        BP.lo_z = B.lo_z; BP.hi_z = B.hi_z;
+        BP.bins_x = DivUp(bx, kTileBin); BP.bins_y = DivUp(by, kTileBin);
+        BP.bins_z = DivUp(bz, kTileBin);
+        BP.n = n;
+        const int num_bins = BP.bins_x * BP.bins_y * BP.bins_z;
+        max_chunks = n / kTileChunk + num_bins + 1;
+        float* d_sorted = ws->dev[16].ReserveAs<float>(3 * static_cast<size_t>(n));
+        char* d_bins = static_cast<char*>(ws->dev[17].Reserve(
+            sizeof(int) * (num_bins + 4) + sizeof(int2) * static_cast<size_t>(max_chunks)));
+        int* d_bin_count = reinterpret_cast<int*>(d_bins);
+        int* d_chunk_count = d_bin_count + num_bins;
+        int2* d_chunks = reinterpret_cast<int2*>(d_bin_count + num_bins + 4);
+        CMX_HIP(hipMemsetAsync(d_bin_count, 0, sizeof(int) * (num_bins + 4), ws->stream));
+        Rt3DBinCountKernel<<<DivUp(n, 256), 256, 0, ws->stream>>>(BP, d_xyz, d_bin_count);
+        Rt3DBinScanKernel<<<1, 1024, 0, ws->stream>>>(d_bin_count, num_bins, d_chunks,
+                                                      d_chunk_count);
+        Rt3DBinScatterKernel<<<DivUp(n, 256), 256, 0, ws->stream>>>(BP, d_xyz, d_bin_count,
+                                                                    d_sorted);
+        CMX_HIP(hipGetLastError());
+        if (getenv("CMX_RT3D_REPORT")) {
+          TG.stats = reinterpret_cast<unsigned long long*>(ws->dev[19].Reserve(64));
+          CMX_HIP(hipMemsetAsync(TG.stats, 0, 64, ws->stream));
+        }
+        TG.experiment = EnvInt("CMX_RT3D_TILE_EXPERIMENT", 0);
+        TG.sorted_xyz = d_sorted;
+        TG.chunks = d_chunks;
+        TG.num_chunks = d_chunk_count;
+        TG.pitch_x = static_cast<int>(bx); TG.pitch_y = static_cast<int>(by);
+        TG.pitch_z = static_cast<int>(bz);
+        trace.Mark("bins");
+      }
+      // Span of a translation table in cells (what widens a chunk's box into its tile).
+      const auto span_of = [&](const std::vector<float4>& table, Rt3DTileParams* tp) {
+        for (int a = 0; a < 3; ++a) { tp->tr_lo[a] = INFINITY; tp->tr_hi[a] = -INFINITY; }
+        for (const float4& v : table) {
+          const float c[3] = {v.x * B.inv_resolution, v.y * B.inv_resolution,
+                              v.z * B.inv_resolution};
+          for (int a = 0; a < 3; ++a) {
+            tp->tr_lo[a] = std::min(tp->tr_lo[a], c[a]);
+            tp->tr_hi[a] = std::max(tp->tr_hi[a], c[a]);
+          }
+        }
+      };
       CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
+      if (use_tiles) {
+        Rt3DTileParams TP = TG;
+        span_of(group, &TP);
+        TP.rotations_per_block = rot_per_block;
+        TP.tile_capacity = EnvInt("CMX_RT3D_GROUP_TILE_KB", 64) * 1024;
+        const int threads = std::min(1024, DivUp(rot_per_block * G, 64) * 64);
+        TP.fixed_point = EnvInt("CMX_RT3D_GROUP_FIXED", 1);
+        if (crosscheck) TP.fixed_point = 0;       // (the float path reproduces the gather kernel's sums)
+        const size_t lds = (sizeof(v2f) * kTileStageStride + sizeof(uint32_t) * kTileChunk) *
+                               rot_per_block + TP.tile_capacity + 32;
+        const int blocks = DivUp(R, rot_per_block);
+        const int slices = std::max(1, std::min(max_chunks, DivUp(8 * cus, blocks)));
+        BG.cell_count = static_cast<unsigned>(cells);
+        BG.sums = reinterpret_cast<uint2*>(ws->dev[18].Reserve(sizeof(uint2) * RG));
+        CMX_HIP(hipMemsetAsync(BG.sums, 0, sizeof(uint2) * RG, ws->stream));
+        static thread_local size_t opted_groups = 0;
+        if (lds > opted_groups) {
+          CMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(Rt3DTileKernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(lds)));
+          opted_groups = lds;
+        }
+        Rt3DTileKernel<true><<<dim3(blocks, slices), threads, lds, ws->stream>>>(BG, TP);
+        Rt3DSumBoundsKernel<<<DivUp(RG, 256), 256, 0, ws->stream>>>(BG);
+        if (TG.stats) {
+          unsigned long long h[4];
+          int chunks_made = 0;
+          CMX_HIP(hipMemcpyAsync(h, TG.stats, sizeof(h), hipMemcpyDeviceToHost, ws->stream));
+          CMX_HIP(hipMemcpyAsync(&chunks_made, TG.num_chunks, sizeof(int), hipMemcpyDeviceToHost,
+                                 ws->stream));
+          CMX_HIP(hipMemsetAsync(TG.stats, 0, 64, ws->stream));
+          CMX_HIP(hipStreamSynchronize(ws->stream));
+          const double units = static_cast<double>(h[0] + h[1]);
+          fprintf(stderr,
+                  "[cmx] rt3d tiles (groups): %d chunks, %d rotations x %d lanes per block, %d "
+                  "slices; %.0f (block, chunk) units: %.1f %% in LDS, mean tile %.1f KB, mean "
+                  "chunk %.1f points\n",
+                  chunks_made, rot_per_block, threads, slices, units, 100. * h[0] / std::max(units, 1.),
+                  h[2] / std::max(units, 1.) / 1024., h[3] / std::max(units, 1.));
+        }
+        if (crosscheck) {
+          Rt3DBulkParams B2 = BG;
+          float* d_upper2 = ws->dev[19].ReserveAs<float>(RG + 4);
+          B2.upper = d_upper2;
+          B2.max_upper_bits = reinterpret_cast<unsigned*>(d_upper2 + RG);
+          int* d_mismatch = reinterpret_cast<int*>(d_upper2 + RG + 1);
+          CMX_HIP(hipMemsetAsync(d_upper2 + RG, 0, 16, ws->stream));
+          const int flat_threads = std::min(kBulk3DThreads, (G + 1) / 64 * 64);
+          if (flat_threads >= 128 && R >= 2)
+            Rt3DBulkKernel<true><<<DivUp(RG, flat_threads), flat_threads, 0, ws->stream>>>(B2, d_xyz);
+          else
+            Rt3DBulkKernel<true><<<dim3(DivUp(G, kBulk3DThreads), std::max<unsigned>(2u, R)),
+                                   kBulk3DThreads, 0, ws->stream>>>(B2, d_xyz);
+          Rt3DCompareFloatsKernel<<<DivUp(RG, 256), 256, 0, ws->stream>>>(d_group_upper, d_upper2,
+                                                                         RG, d_mismatch);
+          int mismatches = -1;
+          CMX_HIP(hipMemcpyAsync(&mismatches, d_mismatch, sizeof(int), hipMemcpyDeviceToHost,
+                                 ws->stream));
+          CMX_HIP(hipStreamSynchronize(ws->stream));
+          CMX_REQUIRE(mismatches == 0,
+                      "internal error: %d of %lld tiled group bounds differ from the gather kernel's",
+                      mismatches, RG);
+        }
+      } else {
       // Flat (rotation, group) lanes: as many whole wavefronts per block as fit G + 1 lanes.
       const int flat_threads = std::min(kBulk3DThreads, (G + 1) / 64 * 64);
       if (flat_threads >= 128 && R >= 2)
@@ -1010,6 +1639,7 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
       else
         Rt3DBulkKernel<true><<<dim3(DivUp(G, kBulk3DThreads), std::max<unsigned>(2u, R)),
                                kBulk3DThreads, 0, ws->stream>>>(BG, d_xyz);
+      }
       CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
       // Candidate pass, twice: the members of the groups next to the best upper bound yield a
       // lower bound; then everything that lower bound cannot exclude.  (The threshold only
@@ -1025,17 +1655,37 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
       CMX_HIP(hipMemsetAsync(d_tmp, 0, sizeof(uint2) * static_cast<size_t>(num_candidates),
                              ws->stream));
       trace.Mark("group pass");
-      int cus = 256;
-      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+      Rt3DTileParams TC = TG;
+      const int block_items =
+          !use_tiles ? kCand3DThreads : crosscheck ? 256 : EnvInt("CMX_RT3D_CAND_THREADS", 512);
+      BC.block_items = block_items;
+      // (tiled: work lists span several rotations, so that a tile serves some hundred lanes even
+      // when a rotation keeps only a few dozen candidates)
+      const int list_rotations =
+          use_tiles && !crosscheck ? std::max(1, std::min(8, EnvInt("CMX_RT3D_CAND_ROTATIONS", 4))) : 1;
+      const int num_lists = DivUp(R, list_rotations);
+      BC.list_rotations = list_rotations;
+      if (use_tiles) {
+        span_of(trans, &TC);
+        TC.rotations_per_block = 1;
+        TC.tile_capacity = EnvInt("CMX_RT3D_CAND_TILE_KB", 32) * 1024;
+        TC.block_items = block_items;
+        BC.cells = d_bulk;                              // the row-major q brick
+        BC.cell_count = static_cast<unsigned>(cells);
+      }
       int round_blocks[2] = {0, 0};
+      // CMX_RT3D_EXPAND_ALL=1 (tests, with CMX_RT3D_VERIFY): every group is expanded in the first
+      // round, so every group bound is checked against every one of its members.
+      const float first_round_factor = EnvInt("CMX_RT3D_EXPAND_ALL", 0) == 1 ? 0.f : 0.97f;
       for (int round = 0; round < 2; ++round) {
         CMX_HIP(hipMemsetAsync(d_num_blocks, 0, sizeof(int) * (round == 0 ? 2 : 1), ws->stream));
         Rt3DSelectGroupsKernel<<<DivUp(RG, 256), 256, 0, ws->stream>>>(
             d_group_upper, G, static_cast<int>(R), side_t, gpa,
-            round == 0 ? d_max_upper : d_max_lower, round == 0 ? 0.97f : 1.f, d_expanded,
+            round == 0 ? d_max_upper : d_max_lower, round == 0 ? first_round_factor : 1.f, d_expanded,
             d_flags, static_cast<int>(T));
-        Rt3DCompactKernel<<<static_cast<unsigned>(R), 256, 0, ws->stream>>>(
-            d_flags, static_cast<int>(T), d_counts, d_items, d_total, d_blocks, d_num_blocks);
+        Rt3DCompactKernel<<<num_lists, 256, 0, ws->stream>>>(
+            d_flags, static_cast<int>(T), static_cast<int>(R), list_rotations, d_counts, d_items,
+            d_total, d_blocks, d_num_blocks, block_items);
         // The launch is sized by what survived: one sync per round (tens of microseconds)
         // instead of hundreds of thousands of blocks that find nothing to do.
         CMX_HIP(hipMemcpyAsync(h_num_blocks, d_num_blocks, sizeof(int), hipMemcpyDeviceToHost,
@@ -1043,15 +1693,53 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
         CMX_HIP(hipStreamSynchronize(ws->stream));
         const int nb = round_blocks[round] = *h_num_blocks;
         if (nb == 0) continue;
+        if (use_tiles) {
+          const size_t lds = sizeof(v2f) * kTileStageStride * list_rotations + TC.tile_capacity + 32;
+          static thread_local size_t opted_candidates = 0;
+          if (lds > opted_candidates) {
+            CMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(Rt3DTileKernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(lds)));
+            opted_candidates = lds;
+          }
+          const int slices = std::max(1, std::min(max_chunks, DivUp(8 * cus, nb)));
+          Rt3DTileKernel<false><<<dim3(nb, slices), block_items, lds, ws->stream>>>(BC, TC);
+          if (crosscheck) {
+            // the same work lists on the gather kernel, into a second (Q, A) array
+            Rt3DBulkParams B2 = BC;
+            uint2* d_sums2 = reinterpret_cast<uint2*>(
+                ws->dev[19].Reserve(sizeof(uint2) * static_cast<size_t>(num_candidates) + 16));
+            int* d_mismatch = reinterpret_cast<int*>(d_sums2 + num_candidates);
+            B2.sums = d_sums2;
+            B2.cells = d_tiled;
+            B2.cell_count = static_cast<unsigned>(tiled_cells);
+            if (round == 0)
+              CMX_HIP(hipMemsetAsync(d_sums2, 0,
+                                     sizeof(uint2) * static_cast<size_t>(num_candidates) + 16,
+                                     ws->stream));
+            B2.slice_points = DivUp(n, kBulk3DChunk) * kBulk3DChunk;
+            Rt3DBulkKernel<false><<<dim3(nb, 1, 1), block_items, 0, ws->stream>>>(B2, d_xyz);
+            Rt3DCompareSumsKernel<<<DivUp(num_candidates, 256), 256, 0, ws->stream>>>(
+                BC.sums, d_sums2, num_candidates, d_mismatch);
+            int mismatches = -1;
+            CMX_HIP(hipMemcpyAsync(&mismatches, d_mismatch, sizeof(int), hipMemcpyDeviceToHost,
+                                   ws->stream));
+            CMX_HIP(hipStreamSynchronize(ws->stream));
+            CMX_REQUIRE(mismatches == 0,
+                        "internal error: %d tiled candidate sums differ from the gather kernel's",
+                        mismatches);
+          }
+        } else {
         // Points are split over blockIdx.z until the launch is ~32 blocks per CU.
         // (blocks of two wavefronts: sixteen fit a CU)
         const int want = std::max(1, DivUp(32 * cus, nb));
         BC.slice_points = std::max(1, DivUp(DivUp(n, want), kBulk3DChunk)) * kBulk3DChunk;
         const dim3 cand_grid(nb, 1, DivUp(n, BC.slice_points));
         Rt3DBulkKernel<false><<<cand_grid, kCand3DThreads, 0, ws->stream>>>(BC, d_xyz);
-        Rt3DBoundsKernel<<<nb, kCand3DThreads, 0, ws->stream>>>(BC);
+        }
+        Rt3DBoundsKernel<<<nb, block_items, 0, ws->stream>>>(BC);
         if (verify)
-          Rt3DVerifyKernel<<<nb, kCand3DThreads, 0, ws->stream>>>(BC, d_group_upper, G, side_t,
+          Rt3DVerifyKernel<<<nb, block_items, 0, ws->stream>>>(BC, d_group_upper, G, side_t,
                                                                   gpa, d_violations);
         trace.Mark(round == 0 ? "candidate pass 1" : "candidate pass 2");
       }

@@ -345,8 +345,17 @@ def test_rt3d_bulk_pass_equals_per_candidate_kernel(sm3, oracle, synth, case, mo
     rigid = sm3.Rigid3d(tuple(init[:3]), tuple(init[3:]))
     got = {}
     monkeypatch.setenv("CMX_RT3D_VERIFY", "1")      # group bounds checked against member bounds
-    for bulk in ("1", "0"):
-        monkeypatch.setenv("CMX_RT3D_BULK", bulk)
+    # "tiles": the LDS-tiled bulk passes, cross-checked element by element against the gather
+    # kernels (CMX_RT3D_CROSSCHECK: every group bound bitwise, every candidate sum); "1": the
+    # gather kernels alone; "0": every candidate scored exhaustively
+    # "fixed": the tiled passes as shipped (group centres in packed fixed-point, a different but
+    # equally valid centre cell next to boundaries: checked with EVERY group expanded, so that
+    # CMX_RT3D_VERIFY compares every group bound with every member's own bounds)
+    for bulk in ("tiles", "fixed", "1", "0"):
+        monkeypatch.setenv("CMX_RT3D_BULK", "0" if bulk == "0" else "1")
+        monkeypatch.setenv("CMX_RT3D_TILES", "1" if bulk in ("tiles", "fixed") else "0")
+        monkeypatch.setenv("CMX_RT3D_CROSSCHECK", "1" if bulk == "tiles" else "0")
+        monkeypatch.setenv("CMX_RT3D_EXPAND_ALL", "1" if bulk == "fixed" else "0")
         score, pose = m.match(rigid, cloud, 0.1, vox)
         got[bulk] = (np.float32(score), _pose7(pose), dict(m.last_stats))
         assert m.last_stats["candidates_scored"] == ref["num_candidates"]
@@ -354,7 +363,14 @@ def test_rt3d_bulk_pass_equals_per_candidate_kernel(sm3, oracle, synth, case, mo
         np.testing.assert_array_equal(_pose7(pose), ref["pose"])
     # the bulk pass ran (it reports its finalists) and narrowed the search down
     assert 1 <= got["1"][2]["nodes_expanded"] <= 4096
+    assert 1 <= got["tiles"][2]["nodes_expanded"] <= 4096
+    assert 1 <= got["fixed"][2]["nodes_expanded"] <= 4096
     assert got["0"][2]["nodes_expanded"] == 0
+    # same group bounds, same candidate sums: the two bulk paths evaluate (almost) the same
+    # number of bounds (the ambiguity counts group lookups differently, which moves the second
+    # round's threshold by rounding-level amounts)
+    a, b = got["tiles"][2]["coarse_candidates"], got["1"][2]["coarse_candidates"]
+    assert abs(a - b) <= 0.02 * b
 
 
 def test_rt3d_bulk_pass_flat_landscape_falls_back(sm3, oracle, monkeypatch):

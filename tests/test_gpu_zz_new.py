@@ -523,7 +523,14 @@ def golden_c4():
 def _rt3d_against_golden(synth, d, g, monkeypatch, bulk):
     from cartographer_amd import scan_matching_3d as sm3
     monkeypatch.setenv("CMX_RT3D_VERIFY", "1")     # group bounds checked against member bounds
-    monkeypatch.setenv("CMX_RT3D_BULK", bulk)
+    # "tiles": LDS-tiled bulk passes (cross-checked against the gather kernels element by
+    # element); "1": gather kernels; "0": exhaustive
+    # "fixed": the tiled passes as shipped (fixed-point group centres), "fixed-all": the same
+    # with every group expanded so that VERIFY compares every group bound with all its members
+    monkeypatch.setenv("CMX_RT3D_BULK", "0" if bulk == "0" else "1")
+    monkeypatch.setenv("CMX_RT3D_TILES", "1" if bulk in ("tiles", "fixed", "fixed-all") else "0")
+    monkeypatch.setenv("CMX_RT3D_CROSSCHECK", "1" if bulk == "tiles" else "0")
+    monkeypatch.setenv("CMX_RT3D_EXPAND_ALL", "1" if bulk == "fixed-all" else "0")
     m = sm3.RealTimeCorrelativeScanMatcher3D(d["lin"], d["ang"], d["tw"], d["rw"])
     score, pose = m.match(sm3.Rigid3d(tuple(d["init"][:3]), tuple(d["init"][3:])), d["cloud"],
                           d["res"], d["vox"])
@@ -533,7 +540,7 @@ def _rt3d_against_golden(synth, d, g, monkeypatch, bulk):
     return m.last_stats
 
 
-@pytest.mark.parametrize("bulk", ["1", "0"])
+@pytest.mark.parametrize("bulk", ["tiles", "fixed", "fixed-all", "1", "0"])
 def test_rt3d_c4_shaped_equals_the_reference(synth, golden_c4, monkeypatch, bulk):
     """C4's shape at 4096 points: L = 5 -> 6^3 = 216 groups of 2x2x2 translations per rotation
     (the flat 192-lane group mapping of rt_3d.hip spans rotations), A = 3 -> 343 rotations, a
@@ -543,11 +550,11 @@ def test_rt3d_c4_shaped_equals_the_reference(synth, golden_c4, monkeypatch, bulk
     import workloads as w
     st = _rt3d_against_golden(synth, w.rt3d_c4_shaped(synth), golden_c4["rt3d_c4_shaped"],
                               monkeypatch, bulk)
-    if bulk == "1":
+    if bulk not in ("0", "fixed-all"):
         assert st["coarse_candidates"] < st["candidates_scored"]      # bounds did exclude
 
 
-@pytest.mark.parametrize("bulk", ["1", "0"])
+@pytest.mark.parametrize("bulk", ["tiles", "fixed", "1", "0"])
 def test_rt3d_c4_at_its_baseline_window_equals_the_reference(synth, golden_c4, monkeypatch, bulk):
     """BASELINE config[3] exactly as bench.py times it (65 536 points, 150^3 grid, +-0.5 m /
     +-2 deg: 1 771 561 candidates) against the reference's own
