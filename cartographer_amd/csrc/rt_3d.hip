@@ -457,7 +457,7 @@ Rt3DBulkKernel(Rt3DBulkParams P, const float* __restrict__ xyz) {
 }
 
 // grid (work descriptors): bounds of the candidates on the work lists from their (Q, A).
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(1024)
 Rt3DBoundsKernel(Rt3DBulkParams P) {
   const int2 work = P.blocks[blockIdx.x];
   const int list = work.x;
@@ -484,7 +484,7 @@ Rt3DBoundsKernel(Rt3DBulkParams P) {
 // its members that was scored -- both bracket the same true score.  (A group pass reading the
 // wrong staged rotation once produced garbage bounds that every parity test survived: the
 // optimum happened not to be pruned.)  grid (work descriptors).
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(1024)
 Rt3DVerifyKernel(Rt3DBulkParams P, const float* __restrict__ group_upper, int num_groups,
                  int side, int groups_per_axis, int* __restrict__ violations) {
   const int2 work = P.blocks[blockIdx.x];
@@ -542,7 +542,7 @@ struct Rt3DTileParams {
   int fixed_point;               // group pass: packed fixed-point cell arithmetic (see kernel)
   int experiment;                // CMX_RT3D_TILE_EXPERIMENT (timing only, wrong results): 1 = no
                                  // tile gathers, 2 = no point reads, 3 = neither
-  unsigned long long* stats;     // CMX_RT3D_REPORT: [0] chunks in LDS, [1] on the gather path,
+  unsigned long long* stats;     // CMX_RT3D_REPORT (its atomics cost ~0.5 ms per pass: not for timing): [0] chunks in LDS, [1] on the gather path,
                                  // [2] tile bytes, [3] points (per workgroup and chunk); or null
 };
 
@@ -1096,14 +1096,14 @@ __global__ void Rt3DBulkCollectKernel(const float* __restrict__ upper, long long
 
 // One block per finalist: the reference's own arithmetic (Rotate, + translation, lround of the
 // IEEE quotient, padded f32 probability brick).  The N lookups of a candidate are independent,
-// its f32 sum is a chain: all threads fetch 4096 probabilities into LDS, then one lane runs
-// that part of the chain out of LDS.
+// its f32 sum is a chain: waves 1..3 fetch the next 4096 probabilities into one LDS buffer while
+// lane 0 of wave 0 runs the chain over the other (the two used to alternate).
 constexpr int kExact3DChunk = 4096;
 __global__ void __launch_bounds__(256)
 Rt3DExactKernel(Rt3DParams P, const float* __restrict__ xyz, int n,
                 const int* __restrict__ finalists, const int* __restrict__ count, int capacity,
                 float* __restrict__ exact) {
-  __shared__ float prob[kExact3DChunk];
+  __shared__ __attribute__((aligned(16))) float prob[2][kExact3DChunk];
   const int f = blockIdx.x;
   if (f >= min(*count, capacity)) return;
   const int c = finalists[f];
@@ -1115,23 +1115,49 @@ Rt3DExactKernel(Rt3DParams P, const float* __restrict__ xyz, int n,
   const int sx = P.grid.nx + 2, sy = P.grid.ny + 2;
   const int ox = 1 - P.grid.lo_x, oy = 1 - P.grid.lo_y, oz = 1 - P.grid.lo_z;
   const int mx = P.grid.nx + 1, my = P.grid.ny + 1, mz = P.grid.nz + 1;
-  float acc = 0.f;
-  for (int base = 0; base < n; base += kExact3DChunk) {
+  const auto fetch = [&](int base, float* out, int first, int stride) {
     const int cnt = min(kExact3DChunk, n - base);
-    __syncthreads();
-    for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
+    for (int j = first; j < cnt; j += stride) {
       const int i = base + j;
       const F3 rp = Rotate(q, F3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]});
       const int3 idx = CellIndex3(F3{rp.x + tr.x, rp.y + tr.y, rp.z + tr.z}, res);
       const int ix = min(max(idx.x + ox, 0), mx);
       const int iy = min(max(idx.y + oy, 0), my);
       const int iz = min(max(idx.z + oz, 0), mz);
-      prob[j] = P.grid.cells[(static_cast<size_t>(iz) * sy + iy) * sx + ix];
+      out[j] = P.grid.cells[(static_cast<size_t>(iz) * sy + iy) * sx + ix];
+    }
+  };
+  float acc = 0.f;
+  fetch(0, prob[0], threadIdx.x, blockDim.x);
+  __syncthreads();
+  int b = 0;
+  for (int base = 0; base < n; base += kExact3DChunk, b ^= 1) {
+    if (threadIdx.x >= 64) {
+      if (base + kExact3DChunk < n) fetch(base + kExact3DChunk, prob[b ^ 1], threadIdx.x - 64,
+                                          blockDim.x - 64);
+    } else if (threadIdx.x == 0) {
+      const int cnt = min(kExact3DChunk, n - base);
+      const float* p = prob[b];
+      int j = 0;
+      // 32 values (eight 16-byte LDS reads) requested ahead of the 32 dependent adds, the next
+      // 32 while those run
+      float4 v[8], w[8];
+      if (cnt >= 32) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + 4 * u);
+      }
+      for (; j + 32 <= cnt; j += 32) {
+        const int ahead = min(j + 32, (cnt - 32) & ~3);       // (aligned; the last one is not used)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const float4*>(p + ahead + 4 * u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc += v[u].x; acc += v[u].y; acc += v[u].z; acc += v[u].w; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = w[u];
+      }
+      for (; j < cnt; ++j) acc += p[j];
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int j = 0; j < cnt; ++j) acc += prob[j];
-    }
   }
   if (threadIdx.x == 0) exact[f] = acc / static_cast<float>(n);
 }
@@ -1662,7 +1688,7 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
       // (tiled: work lists span several rotations, so that a tile serves some hundred lanes even
       // when a rotation keeps only a few dozen candidates)
       const int list_rotations =
-          use_tiles && !crosscheck ? std::max(1, std::min(8, EnvInt("CMX_RT3D_CAND_ROTATIONS", 4))) : 1;
+          use_tiles && !crosscheck ? std::max(1, std::min(8, EnvInt("CMX_RT3D_CAND_ROTATIONS", 8))) : 1;
       const int num_lists = DivUp(R, list_rotations);
       BC.list_rotations = list_rotations;
       if (use_tiles) {
