@@ -538,11 +538,15 @@ class Rt3DWorkload:
                         "translations); bounds_evaluated = group bounds + candidates scored one by one"}
 
     def roofline(self, acc, steps, pmc):
-        """Group pass (the dominant kernel): one byte gather per (rotation, block of translations,
-        point).  The bound is the rate at which a CU issues wave-wide byte gathers: measured
-        ceiling 19 cycles per buffer_load_ubyte of 64 lanes whatever they touch
-        (profiles/r02_rt3d_gather_ceiling.txt: the same kernel with trivially computed addresses,
-        1.16e11 lookups in 56.5 ms) = 2.05e12 lookups/s per chip."""
+        """Group pass (the dominant kernel): one byte lookup per (rotation, block of translations,
+        point).  Tiled path (default): the lookups are ds_read_u8 gathers from an LDS tile of the
+        dilated brick, 2 LDS cycles per conflict-free wave-instruction (MI355X_MICROARCH.md, LDS
+        table) = 256 CUs x 2.4 GHz / 2 x 64 lanes = 1.97e13 lookups/s; the r03_c4 SQ counters
+        (profiles/) show where the rest goes: LDS array busy 47 % of the kernel (40 % of that
+        bank conflicts), 10.6 vector instructions per wave-lookup of which 6.5 are the lookup
+        itself, waves in s_waitcnt half of their time (five barriers per point chunk).  Gather
+        path (CMX_RT3D_TILES=0): buffer_load_ubyte from L2, measured ceiling 19 cycles per
+        64-lane gather per CU = 2.05e12 lookups/s (profiles/r02_rt3d_gather_ceiling.txt)."""
         k_ms = acc["dominant_kernel_ms"] / steps
         cand = acc["candidates_scored"] / steps
         scans = acc["num_scans"] / steps
@@ -550,23 +554,30 @@ class Rt3DWorkload:
         side = round((cand / max(scans, 1)) ** (1.0 / 3.0))
         groups = ((side + 1) // 2) ** 3
         bulk = acc["coarse_candidates"] / steps != cand       # the bounds path ran
+        tiles = bulk and os.environ.get("CMX_RT3D_TILES", "1") != "0" and groups <= 1024
         lookups = scans * (groups if bulk else cand / max(scans, 1)) * self.n_points
         alg = cand * self.n_points * 2.0 + scans * self.n_points * 12.0
-        peak = 2050.0                                                         # G lookups/s
-        return {"kernel": "Rt3DBulkKernel<groups> (upper bounds of 2x2x2 blocks of translations "
-                          "on the dilated uint8 brick)" if bulk else "Rt3DScoreKernel",
-                "bound": "gather-issue", "achieved": lookups / secs / 1e9, "peak": peak,
-                "unit": "Glookup/s", "frac": lookups / secs / 1e9 / peak,
-                "traffic": pmc("Rt3DBulkKernel<true>", "c4"), "kernel_ms": k_ms,
+        peak = 256 * 2.4e9 / 2 * 64 / 1e9 if tiles else 2050.0              # G lookups/s
+        kernel = ("Rt3DTileKernel<groups> (upper bounds of 2x2x2 blocks of translations: fixed-point "
+                  "cell arithmetic, byte gathers from LDS tiles of the dilated uint8 brick)" if tiles
+                  else "Rt3DBulkKernel<groups> (upper bounds of 2x2x2 blocks of translations on the "
+                       "dilated uint8 brick)" if bulk else "Rt3DScoreKernel")
+        return {"kernel": kernel,
+                "bound": "lds" if tiles else "gather-issue", "achieved": lookups / secs / 1e9,
+                "peak": peak, "unit": "Glookup/s", "frac": lookups / secs / 1e9 / peak,
+                "traffic": pmc("Rt3DTileKernel<true>" if tiles else "Rt3DBulkKernel<true>", "c4"),
+                "kernel_ms": k_ms,
                 "algorithmic_bytes": alg,
                 "hbm_frac_algorithmic_whole_step":
                     alg / (acc["device_ms"] / steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "kernel_share_of_step_device_time": k_ms / (acc["device_ms"] / steps),
                 "lookups_per_s_kernel": lookups / secs,
-                "note": "achieved = byte gathers the kernel performs / kernel time; peak = the "
-                        "measured gather-issue ceiling of the chip (19 cycles per 64-lane "
-                        "buffer_load_ubyte per CU, profiles/r02_rt3d_gather_ceiling.txt).  "
-                        "hbm_frac_algorithmic_whole_step prices the reference's exhaustive "
+                "note": "achieved = byte lookups the kernel performs / kernel time; peak = "
+                        + ("the LDS rate of conflict-free ds_read_u8 gathers (2 cycles per "
+                           "wave-instruction and CU: 1.97e13 lookups/s)" if tiles else
+                           "the measured gather-issue ceiling of the chip (19 cycles per 64-lane "
+                           "buffer_load_ubyte per CU, profiles/r02_rt3d_gather_ceiling.txt)")
+                        + ".  hbm_frac_algorithmic_whole_step prices the reference's exhaustive "
                         "search (SURVEY 8d: 2 B per candidate-point + 12 B per rotation-point) "
                         "at the time of the whole step against 8 TB/s; the bricks (7-15 MB) "
                         "are L2/MALL-resident"}
