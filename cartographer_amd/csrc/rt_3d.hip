@@ -525,8 +525,10 @@ Rt3DVerifyKernel(Rt3DBulkParams P, const float* __restrict__ group_upper, int nu
 // sums are accumulated over chunk slices (blockIdx.y) with atomics; bounds come from
 // Rt3DSumBoundsKernel / Rt3DBoundsKernel.  Every sum is identical to what Rt3DBulkKernel
 // computes (CMX_RT3D_TILES=0 runs that kernel; tests compare the two).
-constexpr int kTileChunk = 256;
-constexpr int kTileBin = 16;
+constexpr int kTileChunkGroups = 512;      // points per chunk, group pass (fewer, fuller work units)
+constexpr int kTileChunkCandidates = 256;  // ... candidate pass (its f32 stage is 12 B per point and rotation)
+constexpr int kTileChunk = kTileChunkGroups;   // (the larger one: sizes the shared declarations)
+constexpr int kTileBin = 24;
 constexpr int kTileMaxRotations = 8;
 constexpr int kTileStageStride = 3 * kTileChunk / 2 + 2;     // v2f per staged rotation (+16 B: bank shift)
 
@@ -604,38 +606,44 @@ __global__ void Rt3DBinCountKernel(Rt3DBinParams P, const float* __restrict__ xy
 }
 
 // One workgroup: exclusive scan of the bin counts -> first point of every bin (written over the
-// counts: the scatter kernel's cursors) and the chunk list.
+// counts: the scatter kernel's cursors) and the two chunk lists (pieces of at most
+// kTileChunkGroups / kTileChunkCandidates points of one bin).
 __global__ void __launch_bounds__(1024)
-Rt3DBinScanKernel(int* __restrict__ bin_count, int num_bins, int2* __restrict__ chunks,
-                  int* __restrict__ num_chunks) {
-  __shared__ int part_points[1024], part_chunks[1024];
+Rt3DBinScanKernel(int* __restrict__ bin_count, int num_bins, int2* __restrict__ chunks_groups,
+                  int2* __restrict__ chunks_candidates, int* __restrict__ num_chunks) {
+  __shared__ int part_points[1024], part_a[1024], part_b[1024];
   const int tid = threadIdx.x;
   const int per = (num_bins + 1023) / 1024;
   const int begin = min(tid * per, num_bins), end = min(begin + per, num_bins);
-  int points = 0, pieces = 0;
+  int points = 0, pieces_a = 0, pieces_b = 0;
   for (int b = begin; b < end; ++b) {
     points += bin_count[b];
-    pieces += (bin_count[b] + kTileChunk - 1) / kTileChunk;
+    pieces_a += (bin_count[b] + kTileChunkGroups - 1) / kTileChunkGroups;
+    pieces_b += (bin_count[b] + kTileChunkCandidates - 1) / kTileChunkCandidates;
   }
   part_points[tid] = points;
-  part_chunks[tid] = pieces;
+  part_a[tid] = pieces_a;
+  part_b[tid] = pieces_b;
   __syncthreads();
   if (tid == 0) {
-    int p = 0, c = 0;
+    int p = 0, ca = 0, cb = 0;
     for (int k = 0; k < 1024; ++k) {
-      const int pp = part_points[k], cc = part_chunks[k];
-      part_points[k] = p; part_chunks[k] = c;
-      p += pp; c += cc;
+      const int pp = part_points[k], aa = part_a[k], bb = part_b[k];
+      part_points[k] = p; part_a[k] = ca; part_b[k] = cb;
+      p += pp; ca += aa; cb += bb;
     }
-    *num_chunks = c;
+    num_chunks[0] = ca;
+    num_chunks[1] = cb;
   }
   __syncthreads();
-  int p = part_points[tid], c = part_chunks[tid];
+  int p = part_points[tid], ca = part_a[tid], cb = part_b[tid];
   for (int b = begin; b < end; ++b) {
     const int count = bin_count[b];
     bin_count[b] = p;
-    for (int first = 0; first < count; first += kTileChunk)
-      chunks[c++] = make_int2(p + first, min(kTileChunk, count - first));
+    for (int first = 0; first < count; first += kTileChunkGroups)
+      chunks_groups[ca++] = make_int2(p + first, min(kTileChunkGroups, count - first));
+    for (int first = 0; first < count; first += kTileChunkCandidates)
+      chunks_candidates[cb++] = make_int2(p + first, min(kTileChunkCandidates, count - first));
     p += count;
   }
 }
@@ -660,6 +668,8 @@ template <bool kGroups>
 __global__ void __launch_bounds__(1024)
 Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
+  constexpr int kChunk = kGroups ? kTileChunkGroups : kTileChunkCandidates;
+  constexpr int kStageStride = 3 * kChunk / 2 + 2;     // v2f per staged rotation (+16 B: bank shift)
   const int tid = threadIdx.x;
   const int rotations = kGroups ? TP.rotations_per_block : P.list_rotations;
   // Dynamic LDS: tile | staged points | (group pass) the points again as packed fixed-point
@@ -668,10 +678,10 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
   uint8_t* const tile = tile_smem;
   if (static_cast<unsigned>(reinterpret_cast<uintptr_t>(tile)) != 0u) __builtin_trap();
   v2f* const stage = reinterpret_cast<v2f*>(tile_smem + TP.tile_capacity);
-  uint32_t* const packed = reinterpret_cast<uint32_t*>(stage + kTileStageStride * rotations);
+  uint32_t* const packed = reinterpret_cast<uint32_t*>(stage + kStageStride * rotations);
   // min x, y, z, max x, y, z of the rotated chunk (cells).  (No static __shared__ in this kernel:
   // the tile then starts at LDS address 0 and the gathers need no base.)
-  int* const box = reinterpret_cast<int*>(packed + (kGroups ? kTileChunk * rotations : 0));
+  int* const box = reinterpret_cast<int*>(packed + (kGroups ? kChunk * rotations : 0));
 
   int r, t, rotation_a, num_rot;
   bool valid;
@@ -698,7 +708,7 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
     t = entry - w * P.num_translations;
     r = rotation_a + w;
   }
-  const v2f* const my_stage = stage + (r - rotation_a) * kTileStageStride;
+  const v2f* const my_stage = stage + (r - rotation_a) * kStageStride;
   const float4 tr = P.translation[t];
   const v2f trx = {tr.x, tr.x}, try_ = {tr.y, tr.y}, trz = {tr.z, tr.z};
   const v2f inv = {P.inv_resolution, P.inv_resolution};
@@ -737,8 +747,8 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
     {
       float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
       const int len_even = (len + 1) & ~1;               // (an odd chunk's pair partner is defined)
-      for (int s = tid; s < num_rot * kTileChunk; s += blockDim.x) {
-        const int w = s / kTileChunk, k = s % kTileChunk;      // (a power of two: shifts)
+      for (int s = tid; s < num_rot * kChunk; s += blockDim.x) {
+        const int w = s / kChunk, k = s % kChunk;      // (a power of two: shifts)
         if (k >= len_even) continue;
         const int i = span.x + min(k, len - 1);
         const float4 q4 = P.rotation[rotation_a + w];
@@ -748,7 +758,7 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
         const float x = ClampStage(rp.x, P.t0x, P.lo_x, P.hi_x);
         const float y = ClampStage(rp.y, P.t0y, P.lo_y, P.hi_y);
         const float z = ClampStage(rp.z, P.t0z, P.lo_z, P.hi_z);
-        float* dst = reinterpret_cast<float*>(stage + w * kTileStageStride) + 6 * (k >> 1) + (k & 1);
+        float* dst = reinterpret_cast<float*>(stage + w * kStageStride) + 6 * (k >> 1) + (k & 1);
         dst[0] = x; dst[2] = y; dst[4] = z;
         const float c[3] = {x * P.inv_resolution, y * P.inv_resolution, z * P.inv_resolution};
 #pragma unroll
@@ -808,15 +818,15 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
       const float by = P.off_y + TP.tr_lo[1] - static_cast<float>(lo_y) + 0.5f;
       const float bz = P.off_z + TP.tr_lo[2] - static_cast<float>(lo_z) + 0.5f;
       const int len_even = (len + 1) & ~1;
-      for (int e = tid; e < num_rot * kTileChunk; e += blockDim.x) {
-        const int w = e / kTileChunk, k = e % kTileChunk;
+      for (int e = tid; e < num_rot * kChunk; e += blockDim.x) {
+        const int w = e / kChunk, k = e % kChunk;
         if (k >= len_even) continue;
-        const float* src = reinterpret_cast<const float*>(stage + w * kTileStageStride) +
+        const float* src = reinterpret_cast<const float*>(stage + w * kStageStride) +
                            6 * (k >> 1) + (k & 1);
         const unsigned px = static_cast<unsigned>(rintf(fmaf(src[0], P.inv_resolution, bx) * s));
         const unsigned py = static_cast<unsigned>(rintf(fmaf(src[2], P.inv_resolution, by) * s));
         const unsigned pz = static_cast<unsigned>(rintf(fmaf(src[4], P.inv_resolution, bz) * s));
-        packed[w * kTileChunk + k] = px | (py << 10) | (pz << 20);
+        packed[w * kChunk + k] = px | (py << 10) | (pz << 20);
       }
     }
     __syncthreads();
@@ -880,7 +890,7 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
       for (int k = 0; k < 6; ++k) cur[k] = my_stage[k];
 #pragma unroll 2
       for (int j = 0; j < len4; j += 4) {
-        const v2f* ahead = my_stage + 3 * (min(j + 4, kTileChunk - 4) >> 1);
+        const v2f* ahead = my_stage + 3 * (min(j + 4, kChunk - 4) >> 1);
         if (TP.experiment & 2) {
 #pragma unroll
           for (int k = 0; k < 6; ++k) nxt[k] = cur[k] + inv;
@@ -912,7 +922,7 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
     };
     if (TP.experiment & 4) continue;                    // (timing: everything but the lookups)
     if (fixed) {
-      const uint32_t* __restrict__ words = packed + (r - rotation_a) * kTileChunk;
+      const uint32_t* __restrict__ words = packed + (r - rotation_a) * kChunk;
       const unsigned udx = dx, udy = dy;
       const auto cell = [&](unsigned point_word) -> unsigned {
         const unsigned sum = point_word + lane_word;
@@ -930,7 +940,7 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
       uint4 cur = *reinterpret_cast<const uint4*>(words);
 #pragma unroll 2
       for (int j = 0; j < len4; j += 4) {
-        const uint4 nxt = *reinterpret_cast<const uint4*>(words + min(j + 4, kTileChunk - 4));
+        const uint4 nxt = *reinterpret_cast<const uint4*>(words + min(j + 4, kChunk - 4));
         const unsigned v0 = cell(cur.x), v1 = cell(cur.y), v2 = cell(cur.z), v3 = cell(cur.w);
         acc += (p0 + p1) + (p2 + p3);
         p0 = v0; p1 = v1; p2 = v2; p3 = v3;
@@ -1555,17 +1565,18 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
         BP.bins_z = DivUp(bz, kTileBin);
         BP.n = n;
         const int num_bins = BP.bins_x * BP.bins_y * BP.bins_z;
-        max_chunks = n / kTileChunk + num_bins + 1;
+        max_chunks = n / kTileChunkCandidates + num_bins + 1;      // (either list)
         float* d_sorted = ws->dev[16].ReserveAs<float>(3 * static_cast<size_t>(n));
         char* d_bins = static_cast<char*>(ws->dev[17].Reserve(
-            sizeof(int) * (num_bins + 4) + sizeof(int2) * static_cast<size_t>(max_chunks)));
+            sizeof(int) * (num_bins + 4) + 2 * sizeof(int2) * static_cast<size_t>(max_chunks)));
         int* d_bin_count = reinterpret_cast<int*>(d_bins);
-        int* d_chunk_count = d_bin_count + num_bins;
+        int* d_chunk_count = d_bin_count + num_bins;               // [0] group list, [1] candidate list
         int2* d_chunks = reinterpret_cast<int2*>(d_bin_count + num_bins + 4);
+        int2* d_chunks_candidates = d_chunks + max_chunks;
         CMX_HIP(hipMemsetAsync(d_bin_count, 0, sizeof(int) * (num_bins + 4), ws->stream));
         Rt3DBinCountKernel<<<DivUp(n, 256), 256, 0, ws->stream>>>(BP, d_xyz, d_bin_count);
         Rt3DBinScanKernel<<<1, 1024, 0, ws->stream>>>(d_bin_count, num_bins, d_chunks,
-                                                      d_chunk_count);
+                                                      d_chunks_candidates, d_chunk_count);
         Rt3DBinScatterKernel<<<DivUp(n, 256), 256, 0, ws->stream>>>(BP, d_xyz, d_bin_count,
                                                                     d_sorted);
         CMX_HIP(hipGetLastError());
@@ -1598,12 +1609,13 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
         Rt3DTileParams TP = TG;
         span_of(group, &TP);
         TP.rotations_per_block = rot_per_block;
-        TP.tile_capacity = EnvInt("CMX_RT3D_GROUP_TILE_KB", 64) * 1024;
+        TP.tile_capacity = EnvInt("CMX_RT3D_GROUP_TILE_KB", 44) * 1024;
         const int threads = std::min(1024, DivUp(rot_per_block * G, 64) * 64);
         TP.fixed_point = EnvInt("CMX_RT3D_GROUP_FIXED", 1);
         if (crosscheck) TP.fixed_point = 0;       // (the float path reproduces the gather kernel's sums)
-        const size_t lds = (sizeof(v2f) * kTileStageStride + sizeof(uint32_t) * kTileChunk) *
-                               rot_per_block + TP.tile_capacity + 32;
+        const size_t lds = (sizeof(v2f) * (3 * kTileChunkGroups / 2 + 2) +
+                            sizeof(uint32_t) * kTileChunkGroups) * rot_per_block +
+                           TP.tile_capacity + 32;
         const int blocks = DivUp(R, rot_per_block);
         const int slices = std::max(1, std::min(max_chunks, DivUp(8 * cus, blocks)));
         BG.cell_count = static_cast<unsigned>(cells);
@@ -1693,6 +1705,8 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
       BC.list_rotations = list_rotations;
       if (use_tiles) {
         span_of(trans, &TC);
+        TC.chunks = TG.chunks + max_chunks;                        // the candidate pass's own list
+        TC.num_chunks = TG.num_chunks + 1;
         TC.rotations_per_block = 1;
         TC.tile_capacity = EnvInt("CMX_RT3D_CAND_TILE_KB", 32) * 1024;
         TC.block_items = block_items;
@@ -1720,7 +1734,8 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
         const int nb = round_blocks[round] = *h_num_blocks;
         if (nb == 0) continue;
         if (use_tiles) {
-          const size_t lds = sizeof(v2f) * kTileStageStride * list_rotations + TC.tile_capacity + 32;
+          const size_t lds = sizeof(v2f) * (3 * kTileChunkCandidates / 2 + 2) * list_rotations +
+                             TC.tile_capacity + 32;
           static thread_local size_t opted_candidates = 0;
           if (lds > opted_candidates) {
             CMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(Rt3DTileKernel<false>),
