@@ -152,7 +152,7 @@ EXPORTED_SYMBOLS = [
     "cmx_fast3d_match_batch",
     "cmx_fast3d_level_info", "cmx_fast3d_level_cells",
     "cmx_ceres2d_match", "cmx_ceres2d_match_grid", "cmx_fast2d_refine_batch", "cmx_ceres3d_match",
-    "cmx_ceres3d_match_grids", "cmx_rt2d_score_candidates",
+    "cmx_ceres3d_match_grids", "cmx_rt2d_score_candidates", "cmx_rt3d_match_grid",
     "cmx_fast3d_refine_batch",
     "cmx_comm_init", "cmx_comm_destroy", "cmx_comm_num_devices", "cmx_comm_device_of",
     "cmx_fast2d_match_sharded", "cmx_fast3d_match_sharded", "cmx_shard_range",
@@ -241,6 +241,8 @@ def lib():
     L.cmx_rt2d_score_candidates.argtypes = [P(RtOptions), P(Grid2DLimits), C.c_void_p, C.c_void_p,
                                             C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                             C.c_int32, C.c_void_p, C.c_int32, C.c_int32]
+    L.cmx_rt3d_match_grid.argtypes = [P(RtOptions), C.c_void_p, P(Pose3d), C.c_void_p, C.c_int32,
+                                      P(C.c_float), P(Pose3d), P(MatchStats)]
     L.cmx_ceres3d_match_grids.argtypes = [P(Ceres3DOptions), C.c_void_p, P(Pose3d), P(C.c_void_p),
                                           P(C.c_void_p), C.c_void_p, P(Pose3d), P(CeresSummary)]
     L.cmx_fast3d_refine_batch.argtypes = [P(Ceres3DOptions), P(C.c_void_p), C.c_int32, C.c_void_p,

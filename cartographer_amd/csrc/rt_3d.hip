@@ -1188,6 +1188,35 @@ __global__ void ScatterBulkKernel(const cmx_voxel* __restrict__ voxels, long lon
   tiled[TiledOffset(x, y, z, tiles_y, pitch_z)] = q;
 }
 
+// The same two conversions from a HybridGrid that already lives in HBM as a dense uint16 brick
+// (cmx_grid3d): one thread per cell of that brick.
+__global__ void BrickProbabilitiesKernel(const uint16_t* __restrict__ cells, long long n, int nx,
+                                         int ny, PaddedBrick b, float* __restrict__ out) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned value = cells[i];
+  if (value == 0) return;
+  const int x = static_cast<int>(i % nx), y = static_cast<int>((i / nx) % ny),
+            z = static_cast<int>(i / (static_cast<long long>(nx) * ny));
+  out[(static_cast<size_t>(z + 1) * (b.ny + 2) + (y + 1)) * (b.nx + 2) + (x + 1)] =
+      ValueToProbabilityDev(value);
+}
+__global__ void BrickBulkKernel(const uint16_t* __restrict__ cells, long long n, int nx, int ny,
+                                int pad, int px, int py, int tiles_y, int pitch_z,
+                                uint8_t* __restrict__ rows, uint8_t* __restrict__ tiled) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned raw = cells[i];
+  if (raw == 0) return;
+  const unsigned x = static_cast<unsigned>(i % nx) + pad,
+                 y = static_cast<unsigned>((i / nx) % ny) + pad,
+                 z = static_cast<unsigned>(i / (static_cast<long long>(nx) * ny)) + pad;
+  const unsigned value = raw & 32767u;
+  const uint8_t q = static_cast<uint8_t>((max(value, 1u) - 1u) >> 7);
+  rows[(static_cast<size_t>(z) * py + y) * px + x] = q;
+  tiled[TiledOffset(x, y, z, tiles_y, pitch_z)] = q;
+}
+
 // CMX_RT3D_BULK=0 keeps every candidate on the one-thread-per-candidate kernel (parity tests
 // run both paths).
 // CMX_RT3D_TILES=0 keeps the bulk passes on the memory gathers (Rt3DBulkKernel); parity tests
@@ -1266,18 +1295,21 @@ void BuildBrickFromVoxels(Workspace& ws, const cmx_voxel* voxels, int64_t n, int
 
 }  // namespace cmx
 
-extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_resolution,
-                                     const cmx_voxel* voxels, int64_t num_voxels,
-                                     const cmx_pose3d* initial_pose_estimate,
-                                     const float* point_cloud_xyz, int32_t num_points,
-                                     int32_t device, float* score, cmx_pose3d* pose_estimate,
-                                     cmx_match_stats* stats) {
-  using namespace cmx;
+namespace cmx {
+namespace {
+// RealTimeCorrelativeScanMatcher3D::Match.  The HybridGrid is either the voxel list (host
+// memory) or, when `resident` is set, the dense uint16 brick cmx_grid3d keeps in HBM
+// (`voxels` unused then).
+cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
+                         const cmx_voxel* voxels, int64_t num_voxels, const Brick* resident,
+                         const cmx_pose3d* initial_pose_estimate, const float* point_cloud_xyz,
+                         int32_t num_points, int32_t device, float* score,
+                         cmx_pose3d* pose_estimate, cmx_match_stats* stats) {
   return Guard([&] {
     CMX_REQUIRE(options && initial_pose_estimate && point_cloud_xyz, "null argument");
     CMX_REQUIRE(pose_estimate != nullptr && score != nullptr,
                 "pose_estimate must not be null");                       // CHECK at :39
-    CMX_REQUIRE(num_voxels == 0 || voxels != nullptr, "voxels is null");
+    CMX_REQUIRE(resident != nullptr || num_voxels == 0 || voxels != nullptr, "voxels is null");
     CMX_REQUIRE(num_points >= 1 && num_points <= (1 << 24), "bad point count");
     CMX_REQUIRE(grid_resolution > 0.f, "resolution must be > 0");
     const int n = num_points;
@@ -1333,7 +1365,11 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
     PaddedBrick brick{};
     {
       int lo[3], hi[3];
-      if (!VoxelBounds(voxels, num_voxels, lo, hi)) {
+      if (resident != nullptr) {             // the brick's own box (cells never written hold 0)
+        lo[0] = resident->lo_x; lo[1] = resident->lo_y; lo[2] = resident->lo_z;
+        hi[0] = lo[0] + resident->nx - 1; hi[1] = lo[1] + resident->ny - 1;
+        hi[2] = lo[2] + resident->nz - 1;
+      } else if (!VoxelBounds(voxels, num_voxels, lo, hi)) {
         lo[0] = lo[1] = lo[2] = 0;
         hi[0] = hi[1] = hi[2] = 0;
       }
@@ -1347,7 +1383,12 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
       float* d_cells = ws->dev[7].ReserveAs<float>(cells);
       brick.cells = d_cells;
       FillFloatKernel<<<DivUp(cells, 256), 256, 0, ws->stream>>>(d_cells, cells, 0.1f);
-      if (num_voxels > 0) {
+      if (resident != nullptr) {
+        const long long count = static_cast<long long>(resident->nx) * resident->ny * resident->nz;
+        BrickProbabilitiesKernel<<<DivUp(count, 256), 256, 0, ws->stream>>>(
+            static_cast<const uint16_t*>(resident->cells), count, resident->nx, resident->ny, brick,
+            d_cells);
+      } else if (num_voxels > 0) {
         cmx_voxel* d_vox = ws->dev[15].ReserveAs<cmx_voxel>(num_voxels);
         CMX_HIP(hipMemcpyAsync(d_vox, voxels, num_voxels * sizeof(cmx_voxel),
                                hipMemcpyHostToDevice, ws->stream));
@@ -1427,7 +1468,12 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
       uint8_t* d_tmp = ws->dev[10].ReserveAs<uint8_t>(
           std::max<size_t>(cells, sizeof(uint2) * static_cast<size_t>(num_candidates)));
       CMX_HIP(hipMemsetAsync(d_bulk, 0, (d_tiled - d_bulk) + tiled_cells, ws->stream));
-      if (num_voxels > 0) {
+      if (resident != nullptr) {
+        const long long count = static_cast<long long>(resident->nx) * resident->ny * resident->nz;
+        BrickBulkKernel<<<DivUp(count, 256), 256, 0, ws->stream>>>(
+            static_cast<const uint16_t*>(resident->cells), count, resident->nx, resident->ny, pad,
+            static_cast<int>(bx), static_cast<int>(by), tiles_y, pitch_z, d_bulk, d_tiled);
+      } else if (num_voxels > 0) {
         const cmx_voxel* d_vox = static_cast<const cmx_voxel*>(ws->dev[15].get());
         ScatterBulkKernel<<<DivUp(num_voxels, 256), 256, 0, ws->stream>>>(
             d_vox, num_voxels, brick.lo_x, brick.lo_y, brick.lo_z, pad, static_cast<int>(bx),
@@ -1906,3 +1952,41 @@ extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_r
     }
   });
 }
+}  // namespace
+}  // namespace cmx
+
+extern "C" cmx_status cmx_rt3d_match(const cmx_rt_options* options, float grid_resolution,
+                                     const cmx_voxel* voxels, int64_t num_voxels,
+                                     const cmx_pose3d* initial_pose_estimate,
+                                     const float* point_cloud_xyz, int32_t num_points,
+                                     int32_t device, float* score, cmx_pose3d* pose_estimate,
+                                     cmx_match_stats* stats) {
+  return cmx::Rt3DMatchImpl(options, grid_resolution, voxels, num_voxels, nullptr,
+                            initial_pose_estimate, point_cloud_xyz, num_points, device, score,
+                            pose_estimate, stats);
+}
+
+// The same search on the ACTIVE submap's HybridGrid where cmx_grid3d keeps it in HBM
+// (LocalTrajectoryBuilder3D's per-scan Match -> InsertRangeData pair, mapping/internal/3d/
+// local_trajectory_builder_3d.cc:96-108): only the scan crosses PCIe.
+extern "C" cmx_status cmx_rt3d_match_grid(const cmx_rt_options* options, const cmx_grid3d* grid,
+                                          const cmx_pose3d* initial_pose_estimate,
+                                          const float* point_cloud_xyz, int32_t num_points,
+                                          float* score, cmx_pose3d* pose_estimate,
+                                          cmx_match_stats* stats) {
+  using namespace cmx;
+  if (grid == nullptr) {
+    return Guard([] { CMX_REQUIRE(false, "null argument"); });
+  }
+  Brick brick{};
+  float resolution = 0.f;
+  int device = 0;
+  if (!Grid3DBrick(grid, &brick, &resolution, &device)) {
+    // nothing inserted yet: an empty voxel list (every candidate scores kMinProbability)
+    return Rt3DMatchImpl(options, resolution, nullptr, 0, nullptr, initial_pose_estimate,
+                         point_cloud_xyz, num_points, device, score, pose_estimate, stats);
+  }
+  return Rt3DMatchImpl(options, resolution, nullptr, 0, &brick, initial_pose_estimate,
+                       point_cloud_xyz, num_points, device, score, pose_estimate, stats);
+}
+

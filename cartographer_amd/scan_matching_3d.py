@@ -55,6 +55,18 @@ class RealTimeCorrelativeScanMatcher3D:
         self.device = device
         self.last_stats = None
 
+    def match_grid(self, initial_pose_estimate, point_cloud, grid):
+        """``match`` against a HybridGrid that already lives in HBM
+        (``grid_3d.HybridGridOnDevice``): only the scan crosses PCIe."""
+        xyz, n = _cloud(point_cloud)
+        init = initial_pose_estimate.to_c()
+        score, pose, stats = C.c_float(), Pose3d(), MatchStats()
+        check(_lib.lib().cmx_rt3d_match_grid(C.byref(self.options), grid._h, C.byref(init),
+                                             xyz.ctypes.data, n, C.byref(score), C.byref(pose),
+                                             C.byref(stats)))
+        self.last_stats = stats.as_dict()
+        return float(score.value), Rigid3d.from_c(pose)
+
     def match(self, initial_pose_estimate, point_cloud, grid_resolution, grid_voxels):
         vox, nv = _voxels(grid_voxels)
         xyz, n = _cloud(point_cloud)

@@ -418,6 +418,15 @@ cmx_status cmx_grid3d_info(const cmx_grid3d* grid, float* resolution, int32_t* g
 cmx_status cmx_grid3d_download(const cmx_grid3d* grid, cmx_voxel* voxels, int64_t capacity,
                                int64_t* num_voxels);
 
+/* RealTimeCorrelativeScanMatcher3D::Match on the resident grid: LocalTrajectoryBuilder3D's per-scan
+ * pair Match() -> InsertRangeData() (mapping/internal/3d/local_trajectory_builder_3d.cc:96-108,
+ * :344-347) then moves only the scan across PCIe.  Same result as cmx_rt3d_match on
+ * cmx_grid3d_download's voxel list. */
+cmx_status cmx_rt3d_match_grid(const cmx_rt_options* options, const cmx_grid3d* grid,
+                               const cmx_pose3d* initial_pose_estimate,
+                               const float* point_cloud_xyz, int32_t num_points, float* score,
+                               cmx_pose3d* pose_estimate, cmx_match_stats* stats);
+
 /* CeresScanMatcher3D::Match as LocalTrajectoryBuilder3D::ScanMatch calls it
  * (mapping/internal/3d/local_trajectory_builder_3d.cc:96-123) against the ACTIVE submap: pair k is
  * (point_clouds_xyz[k], num_points[k]) with the resident HybridGrid grids[k] (its resolution is

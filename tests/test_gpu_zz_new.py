@@ -419,6 +419,19 @@ def test_rt3d_on_the_device_built_grid(synth, oracle):
     score, pose = m.match(sm3.Rigid3d(tuple(init[:3]), tuple(init[3:])), cloud, 0.1, dev.voxels())
     assert np.float32(score) == np.float32(ref["score"])
     np.testing.assert_array_equal(list(pose.translation) + list(pose.rotation), ref["pose"])
+    # ... and on the brick itself, where it lies in HBM (cmx_rt3d_match_grid: no voxel list)
+    score, pose = m.match_grid(sm3.Rigid3d(tuple(init[:3]), tuple(init[3:])), cloud, dev)
+    assert np.float32(score) == np.float32(ref["score"])
+    np.testing.assert_array_equal(list(pose.translation) + list(pose.rotation), ref["pose"])
+    assert 1 <= m.last_stats["nodes_expanded"] <= 4096          # the bounds path ran
+    # a grid nothing was inserted into: every candidate scores kMinProbability, the first wins
+    empty = grid_3d.HybridGridOnDevice(0.1)
+    none = oracle.rt3d_match(0.1, host.voxels()[:0], init, cloud[:200], 0.1, math.radians(1.0),
+                             0.0, 0.0)
+    small = sm3.RealTimeCorrelativeScanMatcher3D(0.1, math.radians(1.0), 0.0, 0.0)
+    score, pose = small.match_grid(sm3.Rigid3d(tuple(init[:3]), tuple(init[3:])), cloud[:200], empty)
+    assert np.float32(score) == np.float32(none["score"])
+    np.testing.assert_array_equal(list(pose.translation) + list(pose.rotation), none["pose"])
 
 
 def test_ceres3d_on_the_resident_grids(synth, oracle):
