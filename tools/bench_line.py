@@ -3,7 +3,9 @@
 import json
 import sys
 
-o = json.loads(sys.stdin.read().strip().splitlines()[-1])
+# (a file name, or stdin when there is none: never block on a terminal-less box)
+src = open(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].endswith(".json") else sys.stdin
+o = json.loads([l for l in src.read().strip().splitlines() if l.startswith("{")][-1])
 c = o["config"]
 print(sys.argv[1] if len(sys.argv) > 1 else "", "threads", c["host_threads"], "passes",
       c["passes_per_step"], "ms/pass", round(c["ms_per_pass"], 4), "cand/s", "%.3e" % o["value"],
