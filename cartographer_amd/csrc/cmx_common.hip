@@ -77,7 +77,9 @@ class HostPool {
       std::lock_guard<std::mutex> lk(sleep_mutex_);
       if (sleepers_ > 0) sleep_cv_.notify_all();
     }
+    tls_inside_ = true;          // a ParallelFor inside fn runs inline on this thread as well
     Work(&job);
+    tls_inside_ = false;
     while (job.done.load(std::memory_order_acquire) < n) __builtin_ia32_pause();
     // `job` lives on this stack: no worker may still hold it when we return.  A worker
     // announces itself (active_) BEFORE it reads job_, so either it reads null below or we

@@ -191,6 +191,47 @@ def test_rt2d_batch_on_resident_grids_both_paths(sm, oracle, synth, monkeypatch)
             np.testing.assert_allclose(poses[k], ref["pose"], rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("resident", [False, True])
+def test_rt2d_large_batch_goes_out_as_two_halves(sm, synth, monkeypatch, resident):
+    """From 64 matches on a batch is issued as two half-batches from two host threads (own
+    workspace and stream each): 71 matches over five grids with scans of different sizes return,
+    match by match, what one batch (CMX_RT2D_SPLIT=1 is read once per process: the single-match
+    entry point serves as the unsplit result) returns; the statistics are those of both halves;
+    an error in the second half comes back as the call's status with its message."""
+    from cartographer_amd import grid_2d
+    from cartographer_amd._lib import CmxError
+    m = sm.RealTimeCorrelativeScanMatcher2D(0.3, math.radians(7.0), 0.1, 0.1)
+    worlds = []
+    for k in range(5):
+        cells, lim, world = synth.make_submap(60 + k, 200, 200, 0.05, 20, 600, 5.0, 0.01)
+        worlds.append((grid_2d.ProbabilityGridOnDevice(0.05, (lim["max_x"], lim["max_y"]), 200, 200,
+                                                       cells=cells), world))
+    grids, inits, scans = [], [], []
+    for k in range(71):
+        grid, world = worlds[k % 5]
+        pose = world.free_pose(300 + k, 0.5)
+        grids.append(grid)
+        scans.append(world.scan(pose, 300 + 9 * k, 5.0, 0.01, k))
+        inits.append(sm.Rigid2d(pose[0] + 0.1, pose[1] - 0.05, pose[2] + 0.04))
+    singles, candidates = [], 0
+    for k in range(71):
+        singles.append(m.match(inits[k], scans[k], grids[k]))
+        candidates += m.last_stats["candidates_scored"]
+    batch = sm.Rt2DBatch(m, grids, scans, resident=resident)
+    init = np.array([[p.x, p.y, p.theta] for p in inits])
+    for _ in range(2):
+        scores, poses, stats = batch.match(init)
+        for k, (score, pose) in enumerate(singles):
+            assert scores[k] == score, k
+            np.testing.assert_array_equal(poses[k], [pose.x, pose.y, pose.theta])
+        assert stats["candidates_scored"] == candidates          # both halves counted
+    if not resident:
+        bad = list(scans)
+        bad[70] = np.zeros((0, 3), np.float32)            # an empty scan in the SECOND half
+        with pytest.raises(CmxError):
+            sm.rt2d_match_batch(m, grids, inits, bad)
+
+
 # ----------------------------------------------------------------------------
 # Ceres refinement on the device (SURVEY.md 8 f1) vs the oracle's restatement
 # ----------------------------------------------------------------------------
