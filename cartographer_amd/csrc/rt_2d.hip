@@ -2149,46 +2149,48 @@ __global__ void Rt2DScoreCandidatesKernel(const uint16_t* __restrict__ cells,
 
 void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int num, int32_t device,
                     cmx_match_stats* stats) {
-  // A large batch goes out as two half-batches from two host threads (the caller and one pool
-  // worker), each with its own workspace and stream: the host's preparation of one half runs
+  // A large batch goes out as two half-batches (CMX_RT2D_SPLIT parts) from as many host threads
+  // (the caller and pool workers), each with its own workspace and stream: the host's preparation of one half runs
   // under the kernels of the other (of 172 us for 128 C1 matches the host held 75 before the
   // first launch).  Not when the caller ordered the work on a stream of its own (cmx_set_stream
   // is per thread), and CMX_RT2D_SPLIT=1 keeps one batch.
-  static const int parts = [] {
+  static const int max_parts = [] {
     const char* e = getenv("CMX_RT2D_SPLIT");
-    return e && e[0] ? std::max(1, std::min(2, atoi(e))) : 2;
+    return e && e[0] ? std::max(1, std::min(8, atoi(e))) : 2;
   }();
-  if (parts == 1 || num < 64 || OverrideStream(device) != nullptr) {
+  const int parts = std::min(max_parts, num / 32);             // (at least 32 matches per part)
+  if (parts <= 1 || OverrideStream(device) != nullptr) {
     if (!Rt2DMatchBatchImpl(options, items, num, device, stats, false))
       Rt2DMatchBatchImpl(options, items, num, device, stats, true);
     return;
   }
-  const int first = (num + 1) / 2;
-  cmx_match_stats part[2] = {};
-  cmx_status status[2] = {CMX_OK, CMX_OK};
-  std::string error[2];
-  ParallelFor(2, 0, [&](int h) {
-    const Rt2DItem* mine = items + (h == 0 ? 0 : first);
-    const int count = h == 0 ? first : num - first;
+  std::vector<cmx_match_stats> part(parts);
+  std::vector<cmx_status> status(parts, CMX_OK);
+  std::vector<std::string> error(parts);
+  ParallelFor(parts, 0, [&](int h) {
+    const int begin = static_cast<int>(static_cast<long long>(num) * h / parts),
+              end = static_cast<int>(static_cast<long long>(num) * (h + 1) / parts);
     status[h] = Guard([&] {
-      if (!Rt2DMatchBatchImpl(options, mine, count, device, &part[h], false))
-        Rt2DMatchBatchImpl(options, mine, count, device, &part[h], true);
+      if (!Rt2DMatchBatchImpl(options, items + begin, end - begin, device, &part[h], false))
+        Rt2DMatchBatchImpl(options, items + begin, end - begin, device, &part[h], true);
     });
     if (status[h] != CMX_OK) error[h] = LastError();      // (the message is per thread)
   });
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < parts; ++h) {
     if (status[h] == CMX_OK) continue;
     SetLastError("%s", error[h].c_str());
     throw HipError{status[h]};
   }
   if (stats) {
     *stats = part[0];
-    stats->candidates_scored += part[1].candidates_scored;
-    stats->coarse_candidates += part[1].coarse_candidates;
-    stats->nodes_expanded += part[1].nodes_expanded;
-    stats->num_scans += part[1].num_scans;
-    stats->device_ms = std::max(part[0].device_ms, part[1].device_ms);     // the halves overlap
-    stats->dominant_kernel_ms = part[0].dominant_kernel_ms + part[1].dominant_kernel_ms;
+    for (int h = 1; h < parts; ++h) {
+      stats->candidates_scored += part[h].candidates_scored;
+      stats->coarse_candidates += part[h].coarse_candidates;
+      stats->nodes_expanded += part[h].nodes_expanded;
+      stats->num_scans += part[h].num_scans;
+      stats->device_ms = std::max(stats->device_ms, part[h].device_ms);     // the parts overlap
+      stats->dominant_kernel_ms += part[h].dominant_kernel_ms;
+    }
   }
 }
 
