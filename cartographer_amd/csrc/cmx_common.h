@@ -144,7 +144,7 @@ struct Workspace {
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;  // dominant-kernel bracket
   hipEvent_t ev_x0 = nullptr, ev_x1 = nullptr;  // branch-and-bound expansion bracket
-  static constexpr int kNumBuffers = 20;
+  static constexpr int kNumBuffers = 24;
   DeviceBuffer dev[kNumBuffers];
   PinnedBuffer pinned[4];
   ~Workspace();

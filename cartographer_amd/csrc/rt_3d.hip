@@ -544,6 +544,8 @@ struct Rt3DTileParams {
   int fixed_point;               // group pass: packed fixed-point cell arithmetic (see kernel)
   int experiment;                // CMX_RT3D_TILE_EXPERIMENT (timing only, wrong results): 1 = no
                                  // tile gathers, 2 = no point reads, 3 = neither
+  const float* boxes;            // Rt3DChunkBoxKernel: [rotation block][chunk][6], or null (boxes
+                                 // are then reduced inside the tile kernel)
   unsigned long long* stats;     // CMX_RT3D_REPORT (its atomics cost ~0.5 ms per pass: not for timing): [0] chunks in LDS, [1] on the gather path,
                                  // [2] tile bytes, [3] points (per workgroup and chunk); or null
 };
@@ -661,6 +663,56 @@ __global__ void Rt3DBinScatterKernel(Rt3DBinParams P, const float* __restrict__ 
   }
 }
 
+// Bounding boxes of the rotated chunks, once per match: box[(block, chunk)] = min x, y, z, max
+// x, y, z over the chunk's points rotated by every rotation of rotation block `block`
+// (`rotations_per_block` consecutive rotations), clamped like the staged points, in cells
+// (coordinate * inv_resolution; no offset, no translation).  grid (rotation blocks, chunk slices).
+template <int kChunk>
+__global__ void __launch_bounds__(kChunk)
+Rt3DChunkBoxKernel(Rt3DBulkParams P, const float* __restrict__ sorted_xyz,
+                   const int2* __restrict__ chunks, const int* __restrict__ num_chunks,
+                   int rotations_per_block, float* __restrict__ boxes) {
+  __shared__ float part[kChunk / 64][6];
+  const int block = blockIdx.x, tid = threadIdx.x;
+  const int rotation_a = block * rotations_per_block;
+  const int num_rot = min(rotations_per_block, P.num_rotations - rotation_a);
+  const int total = *num_chunks;
+  for (int chunk = blockIdx.y; chunk < total; chunk += gridDim.y) {
+    const int2 span = chunks[chunk];
+    const int i = span.x + min(tid, span.y - 1);
+    const F3 p{sorted_xyz[3 * i], sorted_xyz[3 * i + 1], sorted_xyz[3 * i + 2]};
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int w = 0; w < num_rot; ++w) {
+      const float4 q4 = P.rotation[rotation_a + w];
+      const F3 rp = Rotate(Quat{q4.w, q4.x, q4.y, q4.z}, p);
+      const float c[3] = {ClampStage(rp.x, P.t0x, P.lo_x, P.hi_x) * P.inv_resolution,
+                          ClampStage(rp.y, P.t0y, P.lo_y, P.hi_y) * P.inv_resolution,
+                          ClampStage(rp.z, P.t0z, P.lo_z, P.hi_z) * P.inv_resolution};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], c[a]); mx[a] = fmaxf(mx[a], c[a]); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
+        mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
+      }
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { part[tid >> 6][a] = mn[a]; part[tid >> 6][3 + a] = mx[a]; }
+    }
+    __syncthreads();
+    if (tid < 6) {
+      float v = part[0][tid];
+      for (int w = 1; w < kChunk / 64; ++w) v = tid < 3 ? fminf(v, part[w][tid]) : fmaxf(v, part[w][tid]);
+      boxes[(static_cast<size_t>(block) * total + chunk) * 6 + tid] = v;
+    }
+  }
+}
+
 // kGroups: grid (ceil(R / rotations_per_block), chunk slices), blockDim = the (rotation, group)
 // lanes of a block rounded up to whole waves.  Candidate pass: grid (work descriptors, chunk
 // slices), blockDim = block_items.  Dynamic LDS: staged points | tile.
@@ -740,6 +792,18 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
     const int2 span = TP.chunks[chunk];
     const int len = span.y;
     __syncthreads();                                     // the previous chunk is done with
+    const bool have_box = TP.boxes != nullptr;
+    if (have_box) {
+      // The box comes from the pre-pass: no reduction, no barrier, and the points are rotated
+      // ONCE, straight into the form the lookups read (step 2c).
+      if (tid < 6) {
+        const int block_index = kGroups ? static_cast<int>(blockIdx.x) : rotation_a / rotations;
+        const float v = TP.boxes[(static_cast<size_t>(block_index) * num_chunks + chunk) * 6 + tid];
+        const float offs[3] = {P.off_x, P.off_y, P.off_z};
+        box[tid] = tid < 3 ? static_cast<int>(floorf(v + TP.tr_lo[tid] + offs[tid])) - 1
+                           : static_cast<int>(ceilf(v + TP.tr_hi[tid - 3] + offs[tid - 3])) + 1;
+      }
+    } else {
     if (tid < 3) box[tid] = 0x7fffffff;
     else if (tid < 6) box[tid] = -0x7fffffff;
     __syncthreads();
@@ -782,6 +846,7 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
         }
       }
     }
+    }
     __syncthreads();
     // 2. the box, clipped to the brick (ClampStage keeps every lookup inside it), x aligned to 4
     const int lo_x = max(box[0], 0) & ~3, lo_y = max(box[1], 0), lo_z = max(box[2], 0);
@@ -812,7 +877,7 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
     }
     // 2b. group pass: the staged points as fixed-point words relative to the tile
     const bool fixed = kGroups && TP.fixed_point && in_lds && dx <= 63 && dy <= 63 && dz <= 63;
-    if (fixed) {
+    if (fixed && !have_box) {
       const float s = static_cast<float>(1 << kFrac);
       const float bx = P.off_x + TP.tr_lo[0] - static_cast<float>(lo_x) + 0.5f;
       const float by = P.off_y + TP.tr_lo[1] - static_cast<float>(lo_y) + 0.5f;
@@ -827,6 +892,35 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
         const unsigned py = static_cast<unsigned>(rintf(fmaf(src[2], P.inv_resolution, by) * s));
         const unsigned pz = static_cast<unsigned>(rintf(fmaf(src[4], P.inv_resolution, bz) * s));
         packed[w * kChunk + k] = px | (py << 10) | (pz << 20);
+      }
+    }
+    // 2c. with the box from the pre-pass: ONE rotation pass, into fixed-point words or f32 triples
+    if (have_box) {
+      const float s = static_cast<float>(1 << kFrac);
+      const float bx = P.off_x + TP.tr_lo[0] - static_cast<float>(lo_x) + 0.5f;
+      const float by = P.off_y + TP.tr_lo[1] - static_cast<float>(lo_y) + 0.5f;
+      const float bz = P.off_z + TP.tr_lo[2] - static_cast<float>(lo_z) + 0.5f;
+      const int len_even = (len + 1) & ~1;
+      for (int e = tid; e < num_rot * kChunk; e += blockDim.x) {
+        const int w = e / kChunk, k = e % kChunk;
+        if (k >= len_even) continue;
+        const int i = span.x + min(k, len - 1);
+        const float4 q4 = P.rotation[rotation_a + w];
+        const F3 rp = Rotate(Quat{q4.w, q4.x, q4.y, q4.z},
+                             F3{TP.sorted_xyz[3 * i], TP.sorted_xyz[3 * i + 1],
+                                TP.sorted_xyz[3 * i + 2]});
+        const float x = ClampStage(rp.x, P.t0x, P.lo_x, P.hi_x);
+        const float y = ClampStage(rp.y, P.t0y, P.lo_y, P.hi_y);
+        const float z = ClampStage(rp.z, P.t0z, P.lo_z, P.hi_z);
+        if (fixed) {
+          const unsigned px = static_cast<unsigned>(rintf(fmaf(x, P.inv_resolution, bx) * s));
+          const unsigned py = static_cast<unsigned>(rintf(fmaf(y, P.inv_resolution, by) * s));
+          const unsigned pz = static_cast<unsigned>(rintf(fmaf(z, P.inv_resolution, bz) * s));
+          packed[w * kChunk + k] = px | (py << 10) | (pz << 20);
+        } else {
+          float* dst = reinterpret_cast<float*>(stage + w * kStageStride) + 6 * (k >> 1) + (k & 1);
+          dst[0] = x; dst[2] = y; dst[4] = z;
+        }
       }
     }
     __syncthreads();
@@ -1596,6 +1690,9 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
       const int rot_per_block = std::max(1, std::min(kTileMaxRotations, 1024 / std::max(G, 1)));
       const bool use_tiles = Tiles3DEnabled() && G <= 1024;
       const bool crosscheck = use_tiles && EnvInt("CMX_RT3D_CROSSCHECK", 0) == 1;
+      // (boxes of the rotated chunks from a pre-pass kernel instead of a reduction per chunk
+      // inside the tile kernel; CMX_RT3D_BOXES=0 for the A/B)
+      const bool use_boxes = EnvInt("CMX_RT3D_BOXES", 1) == 1;
       Rt3DTileParams TG{};
       int max_chunks = 0;
       if (use_tiles) {
@@ -1673,6 +1770,12 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(lds)));
           opted_groups = lds;
+        }
+        if (use_boxes) {
+          float* d_boxes = ws->dev[20].ReserveAs<float>(static_cast<size_t>(blocks) * max_chunks * 6);
+          Rt3DChunkBoxKernel<kTileChunkGroups><<<dim3(blocks, 16), kTileChunkGroups, 0, ws->stream>>>(
+              BG, TG.sorted_xyz, TG.chunks, TG.num_chunks, rot_per_block, d_boxes);
+          TP.boxes = d_boxes;
         }
         Rt3DTileKernel<true><<<dim3(blocks, slices), threads, lds, ws->stream>>>(BG, TP);
         Rt3DSumBoundsKernel<<<DivUp(RG, 256), 256, 0, ws->stream>>>(BG);
@@ -1754,6 +1857,13 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
         TC.chunks = TG.chunks + max_chunks;                        // the candidate pass's own list
         TC.num_chunks = TG.num_chunks + 1;
         TC.rotations_per_block = 1;
+        if (use_boxes) {
+          float* d_boxes = ws->dev[21].ReserveAs<float>(static_cast<size_t>(num_lists) * max_chunks * 6);
+          Rt3DChunkBoxKernel<kTileChunkCandidates>
+              <<<dim3(num_lists, 16), kTileChunkCandidates, 0, ws->stream>>>(
+                  BC, TG.sorted_xyz, TC.chunks, TC.num_chunks, list_rotations, d_boxes);
+          TC.boxes = d_boxes;
+        }
         TC.tile_capacity = EnvInt("CMX_RT3D_CAND_TILE_KB", 32) * 1024;
         TC.block_items = block_items;
         BC.cells = d_bulk;                              // the row-major q brick
