@@ -853,26 +853,31 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
     const int hi_x = min(box[3], TP.pitch_x - 1), hi_y = min(box[4], TP.pitch_y - 1),
               hi_z = min(box[5], TP.pitch_z - 1);
     const int dx = (hi_x - lo_x + 4) & ~3, dy = hi_y - lo_y + 1, dz = hi_z - lo_z + 1;
+    // (a wave's DMA instruction writes 256 bytes: the last one may run past the box's end)
     const bool in_lds = dx > 0 && dx <= 256 && dy > 0 && dz > 0 &&
-                        static_cast<long long>(dx) * dy * dz <= TP.tile_capacity;
+                        static_cast<long long>(dx) * dy * dz + 256 <= TP.tile_capacity;
     if (in_lds) {
-      // Division-free copy: a wave takes whole z slices; its lanes are (row within a group of
-      // 64 / lanes_per_row rows, dword within the row).
-      const int qx = dx >> 2;
-      int shift = 2;                                     // lanes per row = 1 << shift >= qx
-      while ((1 << shift) < qx) ++shift;
-      const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(P.cells);
-      uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(tile);
-      const int row_q = TP.pitch_x >> 2;
-      const int lane = tid & 63, wave = tid >> 6, waves = blockDim.x >> 6;
-      const int xq = lane & ((1 << shift) - 1), sub = lane >> shift, rows_per_step = 64 >> shift;
-      if (shift <= 6 && xq < qx) {
-        for (int z = wave; z < dz; z += waves) {
-          const uint32_t* zsrc = src + (static_cast<size_t>(lo_z + z) * TP.pitch_y + lo_y) * row_q +
-                                 (lo_x >> 2) + xq;
-          uint32_t* zdst = dst + z * dy * qx + xq;
-          for (int y = sub; y < dy; y += rows_per_step) zdst[y * qx] = zsrc[static_cast<size_t>(y) * row_q];
-        }
+      // The box enters LDS by LDS-DMA (global_load_lds_dword: lane l of a wave writes base + 4 l,
+      // no registers, all loads of a wave in flight at once; ordered by vmcnt(0) + the barrier
+      // below): dword e = row * (dx / 4) + xq of the tile, row = z * dy + y; the two divisions
+      // through 2^32 reciprocals (exact: e, row < 2^16).  The rotation pass (2c) runs meanwhile.
+      const unsigned qx = dx >> 2, total = qx * dy * dz;
+      const unsigned rq = static_cast<unsigned>((1ull << 32) / qx) + 1u;
+      const unsigned ry = static_cast<unsigned>((1ull << 32) / static_cast<unsigned>(dy)) + 1u;
+      const unsigned row_q = TP.pitch_x >> 2, slice_q = TP.pitch_y * row_q;
+      const uint32_t* base = reinterpret_cast<const uint32_t*>(P.cells) +
+                             (static_cast<size_t>(lo_z) * TP.pitch_y + lo_y) * row_q + (lo_x >> 2);
+      const unsigned wave_first = __builtin_amdgcn_readfirstlane(tid & ~63);
+      auto* dst = (__attribute__((address_space(3))) unsigned char*)tile;
+      for (unsigned first = wave_first; first < total; first += blockDim.x) {
+        const unsigned e = min(first + (tid & 63), total - 1);       // (the tail re-reads the last dword)
+        const unsigned row = qx == 1 ? e : __umulhi(e, rq);
+        const unsigned xq = e - row * qx;
+        const unsigned z = dy == 1 ? row : __umulhi(row, ry);
+        const unsigned y = row - z * dy;
+        const auto* src = (const __attribute__((address_space(1))) unsigned char*)(
+            base + (z * slice_q + y * row_q + xq));
+        __builtin_amdgcn_global_load_lds(src, dst + 4 * first, 4, 0, 0);
       }
     }
     // 2b. group pass: the staged points as fixed-point words relative to the tile
@@ -923,6 +928,7 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
         }
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's LDS-DMA has landed
     __syncthreads();
     if (TP.stats != nullptr && tid == 0) {
       atomicAdd(&TP.stats[in_lds ? 0 : 1], 1ull);
