@@ -666,30 +666,32 @@ __global__ void Rt3DBinScatterKernel(Rt3DBinParams P, const float* __restrict__ 
 // Bounding boxes of the rotated chunks, once per match: box[(block, chunk)] = min x, y, z, max
 // x, y, z over the chunk's points rotated by every rotation of rotation block `block`
 // (`rotations_per_block` consecutive rotations), clamped like the staged points, in cells
-// (coordinate * inv_resolution; no offset, no translation).  grid (rotation blocks, chunk slices).
-template <int kChunk>
-__global__ void __launch_bounds__(kChunk)
+// (coordinate * inv_resolution; no offset, no translation).  grid (rotation blocks, chunk
+// slices), 256 threads: ONE WAVE per chunk (no workgroup barrier, no LDS: a block per chunk
+// with an LDS reduction cost 0.5 ms per match).
+__global__ void __launch_bounds__(256)
 Rt3DChunkBoxKernel(Rt3DBulkParams P, const float* __restrict__ sorted_xyz,
                    const int2* __restrict__ chunks, const int* __restrict__ num_chunks,
                    int rotations_per_block, float* __restrict__ boxes) {
-  __shared__ float part[kChunk / 64][6];
-  const int block = blockIdx.x, tid = threadIdx.x;
+  const int block = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rotation_a = block * rotations_per_block;
   const int num_rot = min(rotations_per_block, P.num_rotations - rotation_a);
   const int total = *num_chunks;
-  for (int chunk = blockIdx.y; chunk < total; chunk += gridDim.y) {
+  for (int chunk = blockIdx.y * 4 + wave; chunk < total; chunk += gridDim.y * 4) {
     const int2 span = chunks[chunk];
-    const int i = span.x + min(tid, span.y - 1);
-    const F3 p{sorted_xyz[3 * i], sorted_xyz[3 * i + 1], sorted_xyz[3 * i + 2]};
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int w = 0; w < num_rot; ++w) {
-      const float4 q4 = P.rotation[rotation_a + w];
-      const F3 rp = Rotate(Quat{q4.w, q4.x, q4.y, q4.z}, p);
-      const float c[3] = {ClampStage(rp.x, P.t0x, P.lo_x, P.hi_x) * P.inv_resolution,
-                          ClampStage(rp.y, P.t0y, P.lo_y, P.hi_y) * P.inv_resolution,
-                          ClampStage(rp.z, P.t0z, P.lo_z, P.hi_z) * P.inv_resolution};
+    for (int k = lane; k < span.y; k += 64) {
+      const int i = span.x + k;
+      const F3 p{sorted_xyz[3 * i], sorted_xyz[3 * i + 1], sorted_xyz[3 * i + 2]};
+      for (int w = 0; w < num_rot; ++w) {
+        const float4 q4 = P.rotation[rotation_a + w];
+        const F3 rp = Rotate(Quat{q4.w, q4.x, q4.y, q4.z}, p);
+        const float c[3] = {ClampStage(rp.x, P.t0x, P.lo_x, P.hi_x) * P.inv_resolution,
+                            ClampStage(rp.y, P.t0y, P.lo_y, P.hi_y) * P.inv_resolution,
+                            ClampStage(rp.z, P.t0z, P.lo_z, P.hi_z) * P.inv_resolution};
 #pragma unroll
-      for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], c[a]); mx[a] = fmaxf(mx[a], c[a]); }
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], c[a]); mx[a] = fmaxf(mx[a], c[a]); }
+      }
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -699,16 +701,10 @@ Rt3DChunkBoxKernel(Rt3DBulkParams P, const float* __restrict__ sorted_xyz,
         mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
       }
     }
-    __syncthreads();
-    if ((tid & 63) == 0) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) { part[tid >> 6][a] = mn[a]; part[tid >> 6][3 + a] = mx[a]; }
-    }
-    __syncthreads();
-    if (tid < 6) {
-      float v = part[0][tid];
-      for (int w = 1; w < kChunk / 64; ++w) v = tid < 3 ? fminf(v, part[w][tid]) : fmaxf(v, part[w][tid]);
-      boxes[(static_cast<size_t>(block) * total + chunk) * 6 + tid] = v;
+    if (lane < 6) {
+      const float v = lane == 0 ? mn[0] : lane == 1 ? mn[1] : lane == 2 ? mn[2]
+                      : lane == 3 ? mx[0] : lane == 4 ? mx[1] : mx[2];
+      boxes[(static_cast<size_t>(block) * total + chunk) * 6 + lane] = v;
     }
   }
 }
@@ -1779,7 +1775,7 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
         }
         if (use_boxes) {
           float* d_boxes = ws->dev[20].ReserveAs<float>(static_cast<size_t>(blocks) * max_chunks * 6);
-          Rt3DChunkBoxKernel<kTileChunkGroups><<<dim3(blocks, 16), kTileChunkGroups, 0, ws->stream>>>(
+          Rt3DChunkBoxKernel<<<dim3(blocks, 8), 256, 0, ws->stream>>>(
               BG, TG.sorted_xyz, TG.chunks, TG.num_chunks, rot_per_block, d_boxes);
           TP.boxes = d_boxes;
         }
@@ -1865,8 +1861,7 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
         TC.rotations_per_block = 1;
         if (use_boxes) {
           float* d_boxes = ws->dev[21].ReserveAs<float>(static_cast<size_t>(num_lists) * max_chunks * 6);
-          Rt3DChunkBoxKernel<kTileChunkCandidates>
-              <<<dim3(num_lists, 16), kTileChunkCandidates, 0, ws->stream>>>(
+          Rt3DChunkBoxKernel<<<dim3(num_lists, 8), 256, 0, ws->stream>>>(
                   BC, TG.sorted_xyz, TC.chunks, TC.num_chunks, list_rotations, d_boxes);
           TC.boxes = d_boxes;
         }
