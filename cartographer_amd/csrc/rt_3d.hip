@@ -1865,7 +1865,7 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
                   BC, TG.sorted_xyz, TC.chunks, TC.num_chunks, list_rotations, d_boxes);
           TC.boxes = d_boxes;
         }
-        TC.tile_capacity = EnvInt("CMX_RT3D_CAND_TILE_KB", 32) * 1024;
+        TC.tile_capacity = EnvInt("CMX_RT3D_CAND_TILE_KB", 48) * 1024;
         TC.block_items = block_items;
         BC.cells = d_bulk;                              // the row-major q brick
         BC.cell_count = static_cast<unsigned>(cells);
