@@ -798,10 +798,7 @@ def other_configs(args, device, sync, pmc):
             dt, acc, last = measure(w, steps, warmup, sync)
             entry = w.describe(last[3], last[0])
             if cpu_leg is not None:
-                try:
-                    entry["cpu_baseline"] = cpu_leg(w)
-                except Exception as e:      # noqa: BLE001
-                    entry["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+                pending_cpu.append((name, cpu_leg, w))     # after every GPU leg, see below
             entry.update({
                 "ms_per_step": dt / steps * 1e3,
                 "candidates_per_s": acc["candidates_scored"] / dt,
@@ -814,6 +811,9 @@ def other_configs(args, device, sync, pmc):
         except Exception as e:      # noqa: BLE001
             out[name] = {"error": f"{type(e).__name__}: {e}"}
 
+    # The CPU baselines (32 host threads for seconds each) run after ALL GPU legs: a host-bound
+    # leg measured right behind one of them came out 1.5x slower (C1 batch: 0.19 vs 0.13 ms).
+    pending_cpu = []
     cpu = {} if args.no_cpu_baseline else {
         "c1_batch128": lambda w: cpu_baseline_c1(w, min(3.0, args.cpu_seconds)),
         "c4": lambda w: cpu_baseline_c4(w, min(6.0, args.cpu_seconds)),
@@ -826,6 +826,11 @@ def other_configs(args, device, sync, pmc):
     run("c4", lambda: Rt3DWorkload(args, device), 3, 1, cpu.get("c4"))
     run("c5_single", lambda: Fast3DWorkload(args, device, pairs=1), 10, 2, cpu.get("c5_single"))
     run("c5_share_32_submaps", lambda: Fast3DWorkload(args, device, pairs=32), 4, 2)
+    for name, cpu_leg, w in pending_cpu:
+        try:
+            out[name]["cpu_baseline"] = cpu_leg(w)
+        except Exception as e:      # noqa: BLE001
+            out[name]["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
 
     return out
 
@@ -1018,15 +1023,6 @@ def main():
             "config": config,
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and world_size == 1 and name in ("c2", "c3"):   # rank 0, N = 1
-            out["cpu_baseline"] = cpu_baseline(workload.cells0, workload.lim0, args.depth,
-                                               workload.scan, args.min_score, args.cpu_seconds)
-        elif not args.no_cpu_baseline and world_size == 1 and not use_dist:
-            leg = {"c1": cpu_baseline_c1, "c4": cpu_baseline_c4, "c5": cpu_baseline_c5}[name]
-            try:
-                out["cpu_baseline"] = leg(workload, args.cpu_seconds)
-            except Exception as e:      # noqa: BLE001
-                sys.stderr.write(f"cpu baseline unavailable: {e}\n")
         summary = {name: {"ms": config["ms_per_pass"], "cand_per_s": out["value"],
                           "frac": roof.get("frac"), "bound": roof.get("bound")}}
         if world_size == 1 and not use_dist and not args.no_other and name == "c2":
@@ -1076,6 +1072,17 @@ def main():
                                   "matches_per_s": e["matches_per_s"], "frac": r.get("frac"),
                                   "bound": r.get("bound"), "cpu": c.get("value"),
                                   "cpu_unit": c.get("unit"), "cpu_cores": c.get("cores")}
+        # The headline's CPU baseline runs LAST (after every GPU leg: seconds of 32 busy host
+        # threads right before a host-bound GPU leg distort it).  JSON key order is irrelevant.
+        if not args.no_cpu_baseline and world_size == 1 and name in ("c2", "c3"):   # rank 0, N = 1
+            out["cpu_baseline"] = cpu_baseline(workload.cells0, workload.lim0, args.depth,
+                                               workload.scan, args.min_score, args.cpu_seconds)
+        elif not args.no_cpu_baseline and world_size == 1 and not use_dist:
+            leg = {"c1": cpu_baseline_c1, "c4": cpu_baseline_c4, "c5": cpu_baseline_c5}[name]
+            try:
+                out["cpu_baseline"] = leg(workload, args.cpu_seconds)
+            except Exception as e:      # noqa: BLE001
+                sys.stderr.write(f"cpu baseline unavailable: {e}\n")
         if "cpu_baseline" in out:
             summary[name]["cpu"] = out["cpu_baseline"]["value"]
             summary[name]["cpu_cores"] = out["cpu_baseline"]["cores"]
