@@ -925,6 +925,23 @@ def main():
     # it lasts >= 30 ms; every rank uses the same number ------------------------------------
     scratch = {k: 0.0 for k in STAT_KEYS}
     passes = args.passes_per_step
+
+    def agree(count):
+        """The same pass count on every rank (MAX).  A sharded pass contains collectives, so
+        ranks must never run different numbers of passes -- not in the calibration either --
+        and must take the same decisions about repeating it."""
+        if not use_dist:
+            return count
+        t = torch.tensor([count], dtype=torch.int64, device=torch_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item())
+
+    def round_up(count):
+        count = int(min(8192, max(1, count)))
+        if pool is not None:
+            count = (count + threads - 1) // threads * threads
+        return count
+
     if passes <= 0:
         probe = max(2 * threads, 4)
         run_passes(probe, scratch)           # first touches, clocks
@@ -933,9 +950,7 @@ def main():
         run_passes(probe, scratch)
         fence()
         per_pass = (time.perf_counter() - t0) / probe
-        passes = int(min(8192, max(1, math.ceil(0.030 / max(per_pass, 1e-7)))))
-        if pool is not None:
-            passes = (passes + threads - 1) // threads * threads
+        passes = agree(round_up(math.ceil(0.030 / max(per_pass, 1e-7))))
         # one trial step at that size, then the final size (the probe above includes cold starts)
         for _ in range(2):
             fence()
@@ -943,15 +958,12 @@ def main():
             run_passes(passes, scratch)
             fence()
             step_s = time.perf_counter() - t0
-            if step_s >= 0.030:
+            wanted = passes if step_s >= 0.030 else round_up(
+                math.ceil(passes * 0.033 / max(step_s, 1e-6)))
+            wanted = agree(wanted)
+            if wanted == passes:
                 break
-            passes = int(min(8192, math.ceil(passes * 0.033 / max(step_s, 1e-6))))
-            if pool is not None:
-                passes = (passes + threads - 1) // threads * threads
-        if use_dist:
-            t = torch.tensor([passes], dtype=torch.int64, device=torch_device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            passes = int(t.item())
+            passes = wanted
     for _ in range(args.warmup):
         run_passes(passes, scratch)
 

@@ -34,8 +34,15 @@ def install(setattr_=setattr):
         def __init__(self, grid, depth, device=0):
             pass
 
+    # CMX_STUB_SLEEP_US: a search takes that long (per rank: unequal ranks must still agree
+    # on the calibrated pass count)
+    sleep_s = float(os.environ.get("CMX_STUB_SLEEP_US", "0")) * 1e-6
+
     def fake_batch(matchers, cloud, min_score):
         CALLS.append(len(matchers))
+        if sleep_s:
+            import time
+            time.sleep(sleep_s)
         n = len(matchers)
         return (np.ones(n, np.int32), np.full(n, 0.7, np.float32), np.zeros((n, 3)),
                 dict(candidates_scored=1000 * n, coarse_candidates=900 * n,

@@ -132,6 +132,34 @@ def test_bench_two_ranks_gloo():
         assert "issued 7 matches" in err
 
 
+def test_bench_two_ranks_calibrate_together():
+    """The driver's own command line (no --passes-per-step) on two ranks of unequal speed: the
+    calibrated pass count is agreed on (all-reduce MAX) BEFORE any rank runs a trial step -- a
+    sharded pass contains collectives, so ranks running different numbers of passes would
+    deadlock -- and both ranks issue exactly the same number of searches."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT="29549",
+                   CMX_STUB_SLEEP_US="1500" if rank == 1 else "100")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(root, "tests", "bench_stub.py"), "--gpus", "2",
+             "--steps", "3", "--warmup", "1", "--grid", "120", "--submaps", "2"],
+            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    issued = [int(re.search(r"issued (\d+) matches", err).group(1)) for _, err in outs]
+    assert issued[0] == issued[1], issued
+    out = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    p = out["config"]["passes_per_step"]
+    assert p >= 2 and out["n_gpus"] == 2                 # >= 30 ms of the slower rank's passes
+    assert out["config"]["candidates_per_step"] == 2000.0 * p
+    assert out["ms_per_step"] >= 30.0 * 0.8
+
+
 def test_bench_calibrates_passes_per_step(stubbed_bench, monkeypatch):
     """Without --passes-per-step a step is sized during warmup (untimed) to last >= 30 ms; the
     stub's searches take microseconds, so many passes make one step, and exactly steps x passes
