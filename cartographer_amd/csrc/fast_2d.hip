@@ -114,27 +114,6 @@ __global__ void BuildPlanesKernel(const uint8_t* __restrict__ level, int wx, int
   }
 }
 
-// The same planes for PrepScoreLdsKernel: four quarters of 16 bytes per plane, each quarter a
-// contiguous array that is copied into LDS as it is (Fast2DProblem::plane_quarters).
-__global__ void BuildPlaneQuartersKernel(const uint8_t* __restrict__ level, int wx, int wy, int w,
-                                         int PI, int PJ, int quarter_bytes,
-                                         uint8_t* __restrict__ out) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // byte of one quarter
-  const int q = blockIdx.y;
-  if (idx >= quarter_bytes) return;
-  const int slot = idx >> 4, b = idx & 15;
-  const int pitch = w + kPlaneSkew;
-  const int px = slot % pitch, py = slot / pitch;
-  int v = 0;
-  const int c = 16 * q + b;
-  if (py < w && px < w && c < PI * PJ) {
-    const int I = c % PI, J = c / PI;
-    const int x = I * w + px, y = J * w + py;
-    if (x < wx && y < wy) v = level[x + y * wx];
-  }
-  out[static_cast<size_t>(q) * quarter_bytes + idx] = static_cast<uint8_t>(v);
-}
-
 // quads(x + w, y + w) = level(x, y) | level(x, y+w) << 8 | level(x+w, y) << 16 |
 // level(x+w, y+w) << 24 for x in [-w, wx), y in [-w, wy); cells outside the level read 0.
 // Tiled storage: QuadOffset (scan_matching_2d.h).
@@ -669,7 +648,7 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
   // is correct; only speed depends on the dispatch order.)
   const int slots = (gridDim.x + 255) >> 8;
   const int s = (blockIdx.x & 255) * slots + (blockIdx.x >> 8);
-  if (!P.use_fused || P.use_lds_front || s >= P.num_scans) return;
+  if (!P.use_fused || s >= P.num_scans) return;
   const int n_pad = (n + 63) & ~63;
   auto* pts = reinterpret_cast<uint32_t*>(fused_smem);
   int* misc = reinterpret_cast<int*>(pts + n_pad);
@@ -867,280 +846,6 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
     for (int i = threadIdx.x; i < n; i += T) out[i] = pts[i];
   }
   Stamp(tl, tl_block, 7);
-}
-
-// ---------------------------------------------------------------------------
-// Fused front end with the phase planes staged in LDS (full-submap searches)
-// ---------------------------------------------------------------------------
-// PrepScoreFusedKernel gathers one 64-byte plane per point and rotation from L2: 146 MB of
-// 64-byte requests per C2 search, each its own half of a 128-byte line, through 32 KB L1s that
-// hold an eighth of the 256 KB of planes -- measured 5.8 B/clk per CU, 41 us, 0.10 of the L2
-// peak, with the vector units at a third of their issue slots.  The planes of ONE submap are
-// what all ~2300 rotations read, so this kernel turns the loop nest around: a workgroup is
-// one CU's share of the rotations (one WAVEFRONT per rotated scan, W = ceil(S / #CU) of
-// them), and the planes come to the CU instead -- cut into four quarters of 16 bytes per
-// plane (64 + 3 KB each, Fast2DProblem::plane_quarters), which every workgroup copies into
-// LDS one after the other (256 KB of contiguous reads per workgroup, instead of W x 64 KB
-// of scattered ones) and all its wavefronts gather from at LDS speed.
-//   * A wavefront prepares its scan alone: 16 points per lane in registers, bounds by DPP
-//     reductions, no workgroup barrier; the only barriers are the three quarter changes.
-//   * Records (plane slot, lattice block) are built once and kept in LDS per wavefront;
-//     four lanes share a point (one dword of the 16-byte quarter each), sixteen points per
-//     ds_read_b32, and lane group g owns the CONTIGUOUS points [g C, (g + 1) C): a range scan
-//     stays in one lattice block for dozens of points, so the packed 16-bit register
-//     accumulators are flushed (LDS atomics into the wavefront's own candidate sums) about
-//     once per group and quarter.  At most C <= 64 points are added between flushes: no
-//     overflow of the 16-bit halves.
-//   * The next quarter is loaded into registers BEFORE the current one is gathered, so its
-//     L2 latency runs under the gather; barrier, store, barrier.
-//   * plane slots have a row pitch of w + 3 (kPlaneSkew) and record rows one of C + 1 dwords:
-//     sixteen groups read sixteen different banks whatever direction the wall runs in.
-// The integer sums are order-free: every output (bounds, dims, scores, per-scan best, kept
-// cells) is bit-identical to PrepScoreFusedKernel's; CMX_LDS_FRONT=0 selects that one and
-// the parity tests run both.
-//   * The candidate sums are a dense dims.x x dims.y array: a flush computes the candidate
-//     (cell - block) of each of its four bytes and drops those outside the search window
-//     (PrepScoreFusedKernel adds them into a halo that is never read, 2.3 x the array).
-// Dynamic LDS: quarter[quarter_words] | per wavefront: recs[16 (C + 1)] | acc[acc_cap].
-constexpr int kLdsFrontMaxPoints = 1024;     // 16 points per lane in registers
-constexpr int kLdsFrontMaxWaves = 12;
-constexpr int kLdsFrontMinScans = 1024;      // below: the fill would outweigh the gathers
-constexpr int kLdsFrontFillVecs = 8;         // uint4 per thread held in registers per quarter
-constexpr uint32_t kLdsNoBlock = 0xffffu;
-
-__global__ void __launch_bounds__(64 * kLdsFrontMaxWaves)
-PrepScoreLdsKernel(const Fast2DProblem* __restrict__ problems, const float* __restrict__ xyz,
-                   int n, ProblemState* __restrict__ states, int acc_cap, int quarter_words,
-                   int C, float inv_C, int per_wave_words, int* __restrict__ counters_words,
-                   int num_counter_words, int debug_mode) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_front[];
-  if (blockIdx.x == 0 && blockIdx.y == 0 && counters_words)
-    for (int i = threadIdx.x; i < num_counter_words; i += blockDim.x) counters_words[i] = 0;
-  const Fast2DProblem& P = problems[blockIdx.y];
-  const int T = blockDim.x, W = T >> 6;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (!P.use_lds_front || blockIdx.x * W >= P.num_scans) return;      // (block-uniform)
-  const int s = blockIdx.x * W + wave;
-  bool work = s < P.num_scans;                                        // (wave-uniform)
-  unsigned long long* const tl = P.timeline;                          // CMX_TIMELINE=1
-  const int tl_block = blockIdx.y * gridDim.x + blockIdx.x;
-  Stamp(tl, tl_block, 0);
-
-  uint32_t* const plane32 = reinterpret_cast<uint32_t*>(lds_front);
-  typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));   // (a native vector: the array
-  U32x4* const plane128 = reinterpret_cast<U32x4*>(lds_front);  // of them stays in registers)
-  uint32_t* const recs = plane32 + quarter_words + wave * per_wave_words;
-  const int rec_words = 16 * (C + 1);
-  int* const acc = reinterpret_cast<int*>(recs + rec_words);
-
-  // ---- quarter 0 on its way while the scans are prepared ---------------------------------
-  const int qvecs = P.quarter_bytes >> 4;
-  const auto* quarters = AsGlobal(reinterpret_cast<const U32x4*>(P.plane_quarters));
-  U32x4 fill[kLdsFrontFillVecs];
-  const auto load_quarter = [&](int q) {
-#pragma unroll
-    for (int k = 0; k < kLdsFrontFillVecs; ++k) {
-      const int idx = threadIdx.x + k * T;
-      fill[k] = quarters[q * qvecs + min(idx, qvecs - 1)];
-    }
-  };
-  const auto store_quarter = [&](int q) {
-#pragma unroll
-    for (int k = 0; k < kLdsFrontFillVecs; ++k) {
-      const int idx = threadIdx.x + k * T;
-      if (idx < qvecs) plane128[idx] = fill[k];
-    }
-    for (int idx = threadIdx.x + kLdsFrontFillVecs * T; idx < qvecs; idx += T)   // small blocks
-      plane128[idx] = quarters[q * qvecs + idx];
-  };
-  load_quarter(0);
-
-  // ---- rotate, translate, discretise: PrepScoreFusedKernel's arithmetic, 16 points per lane
-  uint32_t cells[16];
-  int lo_x = 0, lo_y = 0, hi_x = 0, hi_y = 0, bad = 0;
-  const float2 r = P.scan_rot[work ? s : 0];
-  const bool identity_q0 = P.init_qw == 1.f && P.init_qz == 0.f;
-#pragma unroll
-  for (int kk = 0; kk < 16; kk += 4) {
-    F3 p[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int j = min(lane + (kk + k) * 64, n - 1);
-      p[k] = F3{xyz[3 * j], xyz[3 * j + 1], 0.f};
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = lane + (kk + k) * 64;
-      cells[kk + k] = 0;
-      if (i < n && work) {
-        float ax = p[k].x, ay = p[k].y;
-        if (!identity_q0) RotateZ(P.init_qw, P.init_qz, p[k].x, p[k].y, &ax, &ay);
-        float bx, by;
-        RotateZ(r.x, r.y, ax, ay, &bx, &by);
-        const float x = bx + P.tx;
-        const float y = by + P.ty;
-        const int ix = CellIndexFast(P.max_y, y, P.res, P.inv_res);
-        const int iy = CellIndexFast(P.max_x, x, P.res, P.inv_res);
-        if (ix < -32768 || ix > 32767 || iy < -32768 || iy > 32767) bad = 1;
-        cells[kk + k] = (static_cast<uint32_t>(ix) & 0xffffu) | (static_cast<uint32_t>(iy) << 16);
-        lo_x = min(lo_x, -ix);
-        lo_y = min(lo_y, -iy);
-        hi_x = max(hi_x, P.nx - 1 - ix);
-        hi_y = max(hi_y, P.ny - 1 - iy);
-      }
-    }
-  }
-  Stamp(tl, tl_block, 1);      // wavefront 0: points discretised
-  lo_x = WaveMinDpp(lo_x); lo_y = WaveMinDpp(lo_y);
-  hi_x = WaveMaxDpp(hi_x); hi_y = WaveMaxDpp(hi_y);
-  bad = WaveMaxDpp(bad);
-  int4 bd;   // ShrinkToFit
-  bd.x = max(-P.nl, lo_x);
-  bd.y = min(P.nl, hi_x);
-  bd.z = max(-P.nl, lo_y);
-  bd.w = min(P.nl, hi_y);
-  const int PI = P.plane_i, PJ = P.plane_j, PIJ = PI * PJ;
-  const int shift = P.depth - 1, w = 1 << shift;
-  const int2 dims = make_int2((bd.y - bd.x + w) / w, (bd.w - bd.z + w) / w);
-  const int count = dims.x * dims.y;
-  const int BW = dims.x + PI - 1, BH = dims.y + PJ - 1;
-  if (work) {
-    const bool ok = count <= P.coarse_stride && count <= kMaxCoarsePerScan && BW <= 255 &&
-                    BH <= 255 && count <= acc_cap;
-    if (lane == 0) {
-      P.bounds[s] = bd;
-      P.coarse_dims[s] = dims;
-      if (bad) atomicMax(&states[blockIdx.y].error, 1);
-      if (!ok) {
-        atomicMax(&states[blockIdx.y].error, 2);
-        P.scan_best[s] = make_int2(0, 0);
-      }
-    }
-    work = ok;
-  }
-
-  // ---- records: (plane slot * 4) << 16 | bx << 8 | by, row g of C + 1 dwords per group ------
-  const int slot_pitch = w + kPlaneSkew;
-  const uint32_t no_record = (static_cast<uint32_t>(w * slot_pitch * 4) << 16) | kLdsNoBlock;
-  if (work) {
-    for (int i = lane; i < count; i += 64) acc[i] = 0;
-    for (int j = lane; j < rec_words; j += 64) recs[j] = no_record;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int i = lane + k * 64;
-      if (i < n) {
-        const uint32_t packed = cells[k];
-        const int U = static_cast<short>(packed & 0xffffu) + bd.x + w - 1;
-        const int V = static_cast<short>(packed >> 16) + bd.z + w - 1;
-        const int bx = (U >> shift) + dims.x - 1, by = (V >> shift) + dims.y - 1;
-        uint32_t rec = no_record;
-        if (bx >= 0 && bx < BW && by >= 0 && by < BH) {
-          const int slot = (V & (w - 1)) * slot_pitch + (U & (w - 1));
-          rec = (static_cast<uint32_t>(slot * 4) << 16) | static_cast<uint32_t>(bx << 8 | by);
-        }
-        // group = i / C: (i + 0.5) / C is at least 0.5 / C from an integer, the f32 product
-        // within 2e-6 of it
-        const int g = static_cast<int>((static_cast<float>(i) + 0.5f) * inv_C);
-        recs[g * (C + 1) + (i - g * C)] = rec;
-      }
-    }
-  }
-  Stamp(tl, tl_block, 2);      // records written
-  store_quarter(0);
-  __syncthreads();
-  Stamp(tl, tl_block, 3);      // every wavefront's scan prepared, quarter 0 in LDS
-
-  // ---- four quarters: gather, accumulate, flush ---------------------------------------------
-  const int group = lane >> 2, sub = lane & 3;
-  const uint32_t* const my_recs = recs + group * (C + 1);
-  for (int q = 0; q < 4; ++q) {
-    if (q < 3) load_quarter(q + 1);
-    if (work) {
-      // Byte j of this lane's dword is plane cell c = 16 q + 4 sub + j = (c % PI, c / PI); added
-      // for a point of lattice block (bx, by) it belongs to candidate
-      // (c % PI - bx + dims.x - 1, c / PI - by + dims.y - 1).  (Cells >= PI PJ hold zeros.)
-      int cand_x[4], cand_y[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int cell = min(16 * q + 4 * sub + j, PIJ - 1);
-        cand_x[j] = cell % PI + dims.x - 1;
-        cand_y[j] = cell / PI + dims.y - 1;
-      }
-      uint32_t cur = kLdsNoBlock, even = 0, odd = 0;
-      const auto flush = [&]() {
-        if (debug_mode & 1) { even = odd = 0; return; }     // (timing experiments only)
-        const int a[4] = {static_cast<int>(even & 0xffffu), static_cast<int>(odd & 0xffffu),
-                          static_cast<int>(even >> 16), static_cast<int>(odd >> 16)};
-        const int bx = static_cast<int>(cur >> 8), by = static_cast<int>(cur & 255u);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int ix = cand_x[j] - bx, iy = cand_y[j] - by;
-          if (a[j] && static_cast<unsigned>(ix) < static_cast<unsigned>(dims.x) &&
-              static_cast<unsigned>(iy) < static_cast<unsigned>(dims.y))
-            atomicAdd(&acc[ix * dims.y + iy], a[j]);
-        }
-        even = odd = 0;
-      };
-      for (int t0 = (debug_mode & 2) ? C : 0; t0 < C; t0 += 16) {
-        uint32_t rec[16], v[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) rec[k] = my_recs[t0 + k];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = plane32[(rec[k] >> 16) + sub];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const uint32_t block = rec[k] & 0xffffu;
-          if (block != cur) {               // per lane group; kLdsNoBlock adds the zero plane
-            if (cur != kLdsNoBlock) flush();
-            cur = block;
-          }
-          even += v[k] & 0x00ff00ffu;
-          odd += (v[k] >> 8) & 0x00ff00ffu;
-        }
-      }
-      if (cur != kLdsNoBlock) flush();
-    }
-    Stamp(tl, tl_block, 4 + 2 * q);         // wavefront 0 done with quarter q
-    if (q < 3) {
-      __syncthreads();                      // every wavefront is done with quarter q
-      store_quarter(q + 1);
-      __syncthreads();
-      Stamp(tl, tl_block, 5 + 2 * q);       // quarter q + 1 in LDS
-    }
-  }
-  if (!work) return;
-
-  // ---- scores, the scan's best candidate, kept cells -------------------------------------
-  const int base = s * P.coarse_stride;
-  auto* coarse_sum = AsGlobal(P.coarse_sum) + base;
-  auto* coarse_score = AsGlobal(P.coarse_score) + base;
-  int best_sum = -1, best_index = 0x7ffffff;
-  for (int i = lane; i < count; i += 64) {
-    const int csum = acc[i];
-    if (P.write_all_discrete) coarse_sum[i] = csum;     // introspection only
-    coarse_score[i] = ToScore(P, csum, n);
-    if (csum > best_sum) { best_sum = csum; best_index = i; }
-  }
-  unsigned long long key =
-      (static_cast<unsigned long long>(static_cast<unsigned>(best_sum + 1)) << 32) |
-      static_cast<unsigned>(0x7fffffff - best_index);
-  key = WaveMaxU64(key);                    // largest sum, smallest index on ties (BlockBest)
-  const int top_sum = static_cast<int>(key >> 32) - 1;
-  if (lane == 0)
-    P.scan_best[s] = make_int2(top_sum, 0x7fffffff - static_cast<int>(key & 0xffffffffu));
-  bool keep_cells = P.write_all_discrete != 0;
-  if (!keep_cells && P.store_scans)
-    keep_cells = !(ToScore(P, top_sum, n) < fmaxf(P.min_score, 0.f));
-  if (keep_cells) {
-    auto* out = AsGlobal(P.discrete) + static_cast<size_t>(s) * n;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int i = lane + k * 64;
-      if (i < n) out[i] = cells[k];
-    }
-  }
-  Stamp(tl, tl_block, 11);
 }
 
 // ---------------------------------------------------------------------------
@@ -2203,12 +1908,6 @@ Fast2DMatcher::Fast2DMatcher(const cmx_fast2d_options& options, const cmx_grid2d
       CMX_HIP(hipMalloc(reinterpret_cast<void**>(&planes_), bytes));
       BuildPlanesKernel<<<w * w + 1, 64, 0, ws->stream>>>(top.cells, top.wx, top.wy, w, PI, PJ,
                                                           plane_stride_, planes_);
-      if (plane_stride_ == 64 && w <= 64) {
-        quarter_bytes_ = ((w * (w + kPlaneSkew) + 1) * 16 + 255) & ~255;
-        CMX_HIP(hipMalloc(reinterpret_cast<void**>(&plane_quarters_), 4 * static_cast<size_t>(quarter_bytes_)));
-        BuildPlaneQuartersKernel<<<dim3(DivUp(quarter_bytes_, 256), 4), 256, 0, ws->stream>>>(
-            top.cells, top.wx, top.wy, w, PI, PJ, quarter_bytes_, plane_quarters_);
-      }
     }
   }
   CMX_HIP(hipGetLastError());
@@ -2220,7 +1919,6 @@ Fast2DMatcher::~Fast2DMatcher() {
   if (stack_mem_) (void)hipFree(stack_mem_);
   if (quads_mem_) (void)hipFree(quads_mem_);
   if (planes_) (void)hipFree(planes_);
-  if (plane_quarters_) (void)hipFree(plane_quarters_);
   if (grid_cells_) (void)hipFree(grid_cells_);
 }
 
@@ -2311,18 +2009,6 @@ bool FusedEnabled() {
   return !(e && e[0] == '0');
 }
 
-// CMX_LDS_FRONT=0 keeps full-submap searches on PrepScoreFusedKernel (parity tests run both).
-bool LdsFrontEnabled() {
-  const char* e = getenv("CMX_LDS_FRONT");
-  return !(e && e[0] == '0');
-}
-constexpr size_t kLdsFrontBytes = 160 * 1024;
-// Fewest rotations of a search the LDS front end takes (CMX_LDS_FRONT_MIN_SCANS: tests).
-int LdsFrontMinScans() {
-  const char* e = getenv("CMX_LDS_FRONT_MIN_SCANS");
-  return e ? atoi(e) : kLdsFrontMinScans;
-}
-
 // Blocks of PrepScoreFusedKernel the whole chip holds at once (occupancy query, cached).
 long long FusedResidentBlocks(int device, int threads, size_t lds_bytes) {
   struct Key { int device, threads; size_t lds; long long blocks; };
@@ -2375,12 +2061,9 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
   std::vector<int> rotation_of(num);
   size_t rotation_floats = 0;
   const bool fused_enabled = FusedEnabled();
-  const bool lds_front_enabled = fused_enabled && LdsFrontEnabled();
-  const int lds_min_scans = LdsFrontMinScans();
   const int n_pad = (n + 63) & ~63;
-  long long fused_acc = 0, lds_acc = 0;
-  int lds_quarter_bytes = 0, lds_max_scans = 0;
-  bool any_fused = false, any_unfused = false, any_lds = false;
+  long long fused_acc = 0;
+  bool any_fused = false, any_unfused = false;
   for (int p = 0; p < num; ++p) {
     const Fast2DMatcher& m = *matchers[p];
     const cmx_grid2d_limits& lim = m.limits();
@@ -2439,16 +2122,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     // dynamic LDS a launch gets without opting in to more.
     P.use_fused = fused_enabled && P.use_planes && m.plane_stride() == 64 &&
                   n <= kFusedMaxPoints && 4ll * n_pad + 4 * (32 + acc) <= 64 * 1024;
-    // LDS-staged planes: searches over (nearly) all rotations, where a CU's share of the scans
-    // repays copying the planes into its LDS.
-    P.use_lds_front = P.use_fused && lds_front_enabled && m.plane_quarters() != nullptr &&
-                      n <= kLdsFrontMaxPoints && h.num_scans >= lds_min_scans;
-    if (P.use_lds_front) {
-      any_lds = true;
-      lds_acc = std::max<long long>(lds_acc, ax * ay);      // dense candidate sums, no halo
-      lds_quarter_bytes = std::max(lds_quarter_bytes, m.quarter_bytes());
-      lds_max_scans = std::max(lds_max_scans, h.num_scans);
-    } else if (P.use_fused) {
+    if (P.use_fused) {
       any_fused = true;
       fused_acc = std::max(fused_acc, acc);
     } else {
@@ -2483,7 +2157,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
   for (const Rotation& r : rotations)
     std::memcpy(h_rotations + r.offset, r.table->data(), r.table->size() * sizeof(float2));
 
-  if (TimelineEnabled() && (any_fused || any_lds)) {
+  if (TimelineEnabled() && any_fused) {
     int max_scans = 0;
     for (const HostSearch& h : out->search) max_scans = std::max(max_scans, h.num_scans);
     out->timeline_blocks = (max_scans + 255) / 256 * 256 * num;
@@ -2529,8 +2203,6 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     P.plane_i = m.plane_i();
     P.plane_j = m.plane_j();
     P.plane_stride = m.plane_stride();
-    P.plane_quarters = m.plane_quarters();
-    P.quarter_bytes = m.quarter_bytes();
     P.discrete = d_discrete + disc_off;
     P.sorted = d_sorted + disc_off;
     P.bounds = d_bounds + scan_off;
@@ -2558,39 +2230,6 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
   int* clear_words = reinterpret_cast<int*>(out->d_misc);
   const int clear_count = out->d_misc ? static_cast<int>(sizeof(Counters) / sizeof(int)) : 0;
   CMX_HIP(hipEventRecord(ws.ev_k0, ws.stream));
-  if (any_lds) {
-    // One wavefront per rotated scan, W = a CU's share of the rotations per workgroup (so that a
-    // single search is ONE round of workgroups), as far as the LDS next to a quarter holds their
-    // records and candidate sums.
-    static const bool lds_opt_in = [] {
-      return hipFuncSetAttribute(reinterpret_cast<const void*>(PrepScoreLdsKernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 static_cast<int>(kLdsFrontBytes)) == hipSuccess;
-    }();
-    CMX_REQUIRE(lds_opt_in, "cannot opt in to 160 KB of dynamic LDS");
-    const int C = 16 * std::max(1, (n + 255) / 256);
-    const int rec_words = 16 * (C + 1);
-    const int per_wave_words = (rec_words + static_cast<int>(lds_acc) + 3) & ~3;
-    const int quarter_words = lds_quarter_bytes / 4;
-    const long long room = static_cast<long long>(kLdsFrontBytes) - lds_quarter_bytes;
-    const int w_max = static_cast<int>(std::min<long long>(kLdsFrontMaxWaves, room / (4ll * per_wave_words)));
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ws.device);
-    int waves = std::min(w_max, std::max(4, DivUp(lds_max_scans, std::max(cus, 1))));
-    if (const char* e = getenv("CMX_LDS_FRONT_WAVES")) waves = std::min(w_max, std::max(1, atoi(e)));
-    CMX_REQUIRE(waves >= 1, "PrepScoreLdsKernel: %d candidate sums per scan do not fit in LDS",
-                static_cast<int>(lds_acc));
-    const size_t lds = static_cast<size_t>(lds_quarter_bytes) + 4ull * per_wave_words * waves;
-    if (out->trace && out->trace->enabled())
-      fprintf(stderr, "[cmx trace] LDS front end: %d x %d workgroups of %d wavefronts, %zu B LDS\n",
-              DivUp(lds_max_scans, waves), num, waves, lds);
-    PrepScoreLdsKernel<<<dim3(DivUp(lds_max_scans, waves), num), 64 * waves, lds, ws.stream>>>(
-        out->d_problems, d_xyz, n, out->d_states, static_cast<int>(lds_acc), quarter_words, C,
-        1.f / static_cast<float>(C), per_wave_words, clear_words, clear_count,
-        getenv("CMX_LDS_FRONT_DEBUG") ? atoi(getenv("CMX_LDS_FRONT_DEBUG")) : 0);
-    clear_words = nullptr;
-    mark("lds front");
-  }
   if (any_fused) {
     // Threads per block: with 192 (three waves) ten blocks fit a CU, i.e. a single search's
     // ~2300 rotations are all resident at once and the launch takes one block's latency;

@@ -85,18 +85,7 @@ struct Fast2DProblem {
   int store_scans;      // with recompute_scans: the coarse filter writes the cells of the scans
                         // that keep a candidate to `discrete`, and the wave-per-node expansion
                         // (several nodes per such scan) reads them instead of recomputing
-  // The phase planes a second time, cut into four 16-byte quarters that are staged in LDS one
-  // after the other (PrepScoreLdsKernel, fast_2d.hip): quarter q of plane (py, px) -- bytes
-  // [16 q, 16 q + 16) of the 64-byte plane -- sits at
-  // plane_quarters[q * quarter_bytes + (py * (w + kPlaneSkew) + px) * 16]; slot w * (w + kPlaneSkew)
-  // of every quarter is the zero plane.  Null when the level has no 64-byte planes or w > 64.
-  const uint8_t* plane_quarters;
-  int quarter_bytes;    // multiple of 256
-  int use_lds_front;    // 1: PrepScoreLdsKernel takes this problem (implies use_fused)
 };
-
-constexpr int kPlaneSkew = 3;   // row pitch w + 3 slots: walls along x, y and both diagonals
-                                // advance the LDS bank group from point to point
 
 // Branch-and-bound node.
 struct Node2D {
@@ -146,8 +135,6 @@ class Fast2DMatcher {
   int plane_i() const { return plane_i_; }
   int plane_j() const { return plane_j_; }
   int plane_stride() const { return plane_stride_; }
-  const uint8_t* plane_quarters() const { return plane_quarters_; }
-  int quarter_bytes() const { return quarter_bytes_; }
   size_t level_offset(int i) const { return level_offsets_[i]; }
   float min_s() const { return min_s_; }
   float score_scale() const { return score_scale_; }
@@ -161,8 +148,6 @@ class Fast2DMatcher {
   uint8_t* planes_ = nullptr;      // phase planes of the lowest-resolution level (or null)
   uint16_t* grid_cells_ = nullptr; // the grid itself (2 B per cell), for the refinement step
   int plane_i_ = 0, plane_j_ = 0, plane_stride_ = 0;
-  uint8_t* plane_quarters_ = nullptr;   // the planes cut into LDS-sized quarters (or null)
-  int quarter_bytes_ = 0;
   std::vector<LevelDesc> levels_;
   std::vector<size_t> level_offsets_;
   float min_s_, score_scale_;
