@@ -508,6 +508,64 @@ class Rt2DWorkload:
                         "aggregate); hbm_frac_algorithmic > 1 means on-chip residency"}
 
 
+class Rt2DPipelinedWorkload(Rt2DWorkload):
+    """C1 as the throughput a fleet sees: `threads` host threads (one per group of trajectories)
+    each issue `calls` batches of `matches` resident matches per step, every thread on its own
+    argument arrays and, inside the library, its own workspaces and streams -- how C2's headline
+    is issued, and what hides the host's share of a call (plan, descriptor fill, launch, wait)
+    behind the device work of the other threads' calls.  Same entry point, same results."""
+
+    def __init__(self, args, device, matches=128, threads=4, calls=4):
+        super().__init__(args, device, matches=matches)
+        from concurrent.futures import ThreadPoolExecutor
+        clouds = self.batch._clouds                          # uploaded once, shared
+        self.batches = [self.batch] + [self.sm.Rt2DBatch(self.m, self.G, clouds, resident=True)
+                                       for _ in range(threads - 1)]
+        self.threads, self.calls = threads, calls
+        self.batch_matches = matches
+        self.matches_per_step = matches * threads * calls
+        self.pool = ThreadPoolExecutor(threads)
+
+    def _worker(self, batch):
+        total = None
+        for _ in range(self.calls):
+            scores, poses, stats = batch.match(self.init)
+            if total is None:
+                total = dict(stats)
+            else:
+                for k, v in stats.items():
+                    total[k] = total.get(k, 0) + v
+        return scores.copy(), poses.copy(), total
+
+    def search(self, k=0):
+        results = list(self.pool.map(self._worker, self.batches))
+        stats = dict(results[0][2])
+        for r in results[1:]:
+            for key, v in r[2].items():
+                stats[key] = stats.get(key, 0) + v
+        self.candidates_per_match = stats["candidates_scored"] // self.matches_per_step
+        scores, poses = results[0][0], results[0][1]
+        return np.ones(len(scores), np.int32), scores, poses, stats
+
+    def describe(self, stats, found):
+        d = super().describe(stats, found)
+        d["workload"] = (f"C1, pipelined ({self.threads} host threads x {self.calls} calls of "
+                         f"{self.batch_matches} resident matches per step): " + d["workload"])
+        d["host_threads"] = self.threads
+        d["calls_per_thread_per_step"] = self.calls
+        d["matches_per_call"] = self.batch_matches
+        return d
+
+    def roofline(self, acc, steps, pmc):
+        r = super().roofline(acc, steps, pmc)
+        r["traffic"] = None
+        r["note"] += ("  Pipelined leg: kernel_ms is the SUM of the bulk kernels' durations per "
+                      "step (HIP events on each call's own stream); launches of different calls "
+                      "share the chip, so the per-launch figure of the single-call leg is the one "
+                      "to read as a kernel roofline.")
+        return r
+
+
 class Rt3DWorkload:
     """C4: 64 rings x 1024 azimuths vs a 150^3 HybridGrid, window 0.5 m / 2 deg."""
 
@@ -820,6 +878,7 @@ def other_configs(args, device, sync, pmc):
         "c5_single": lambda w: cpu_baseline_c5(w, min(5.0, args.cpu_seconds))}
     run("c1_single", lambda: Rt2DWorkload(args, device, matches=1), 200, 50)
     run("c1_batch128", lambda: Rt2DWorkload(args, device, matches=128), 100, 10, cpu.get("c1_batch128"))
+    run("c1_batch128_4_threads", lambda: Rt2DPipelinedWorkload(args, device, 128, 4, 4), 25, 5)
     sub = argparse.Namespace(**vars(args))
     sub.submaps = 16
     run("c3_share_16_submaps", lambda: Fast2DWorkload(sub, device, 0, 1, sharded=True), 5, 2)
@@ -1062,8 +1121,10 @@ def main():
             out["details"] = other
             # The driver's record keeps scalars: every config's line flat in `config` ...
             for key, e in other.items():
-                short = key.split("_")[0] if key not in ("c1_single", "c5_single") else key
-                short = {"c1": "c1b128", "c3": "c3s16", "c5": "c5s32", "c2": "c2t8"}.get(short, short)
+                short = {"c1_single": "c1_single", "c1_batch128": "c1b128",
+                         "c1_batch128_4_threads": "c1b128t4", "c3_share_16_submaps": "c3s16",
+                         "c4": "c4", "c5_single": "c5_single",
+                         "c5_share_32_submaps": "c5s32"}.get(key, key)
                 if "error" in e:
                     config[f"{short}_error"] = e["error"][:80]
                     continue

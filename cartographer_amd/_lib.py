@@ -172,10 +172,13 @@ def lib():
         raise RuntimeError(
             f"{SO_PATH} is missing: build it with `python -m cartographer_amd.build` "
             "(there is no fallback path)")
-    try:  # torch bundles libamdhip64.so.7; load it first so one runtime serves both
-        import torch  # noqa: F401
-    except Exception:  # pragma: no cover - torch is plumbing only
-        pass
+    # torch bundles libamdhip64.so.7; load it first so one runtime serves both.  A process that
+    # never touches torch (the timing probes under tools/) may skip its minute of first import.
+    if os.environ.get("CMX_SKIP_TORCH_IMPORT") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is plumbing only
+            pass
     L = C.CDLL(SO_PATH)
     L.cmx_version.restype = C.c_char_p
     L.cmx_status_string.restype = C.c_char_p

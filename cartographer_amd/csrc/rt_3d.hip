@@ -480,6 +480,90 @@ Rt3DBoundsKernel(Rt3DBulkParams P) {
   if ((threadIdx.x & 63) == 0 && bits != 0) atomicMax(P.max_lower_bits, bits);
 }
 
+// ---- Staged candidate pass --------------------------------------------------------------
+// The second candidate round scores every member of every group the best lower bound cannot
+// exclude -- a tenth of C4's 1.77 M candidates, each over all 65 536 points, although all but a
+// handful lose by a wide margin: the group bound is loose (a 3 x 3 x 3 dilation), the candidates
+// themselves are not close.  But the group bound is a sum over POINTS of values that dominate
+// the member's own value point by point, so for any part S of the cloud
+//     score sum of c  <=  (sum of c over S)  +  (group sum over the rest),
+// and the right-hand side tightens as S grows.  The cloud is cut into three segments (a
+// quarter, a quarter, a half: Rt3DBinScanKernel), the group pass reports a group's sum by
+// segment, and the round runs segment by segment: after the first and after the second,
+// candidates whose weighted bound has fallen below the best lower bound are dropped from the
+// work lists (they keep `upper` = 0: never finalists, exactly what their full evaluation would
+// have concluded).  C4 (tools/prototype numbers in DESIGN.md 5.4): of 154 k candidates 48 % are
+// alive after a quarter of the points, 10 % after half.
+//
+// grid (work descriptors): flags[r][t] = 1 for the listed candidates that stay.  `stage` = the
+// segment just finished (0 or 1).  Verification mode (`stage_ub` != null: CMX_RT3D_VERIFY): the
+// lists stay as they are, every candidate is evaluated in full, and this kernel only records the
+// decision (`dropped`) and the smallest bound seen (in units of q) for Rt3DStageCheckKernel.
+__global__ void __launch_bounds__(1024)
+Rt3DStageFilterKernel(Rt3DBulkParams P, const uint2* __restrict__ group_total,
+                      const uint2* __restrict__ group_seg, int num_groups, int side,
+                      int groups_per_axis, int stage, uint8_t* __restrict__ flags,
+                      unsigned long long* __restrict__ stage_ub, uint8_t* __restrict__ dropped) {
+  const int2 work = P.blocks[blockIdx.x];
+  const int list = work.x;
+  const int slot = work.y * P.block_items + threadIdx.x;
+  if (slot >= P.counts[list]) return;
+  const int entry =
+      P.items[static_cast<size_t>(list) * P.list_rotations * P.num_translations + slot];
+  const int w = entry / P.num_translations, t = entry - w * P.num_translations;
+  const int r = list * P.list_rotations + w;
+  const size_t c = static_cast<size_t>(r) * P.num_translations + t;
+  const uint2 qa = P.sums[c];                       // over the segments done so far
+  const int x = t % side, y = (t / side) % side, z = t / (side * side);
+  const int g = ((z >> 1) * groups_per_axis + (y >> 1)) * groups_per_axis + (x >> 1);
+  const size_t gi = static_cast<size_t>(r) * num_groups + g;
+  const uint2 seg = group_seg[gi];
+  const unsigned long long rest = static_cast<unsigned long long>(group_total[gi].x) - seg.x -
+                                  (stage >= 1 ? seg.y : 0u);
+  const unsigned long long q_hi = static_cast<unsigned long long>(qa.x) +
+                                  static_cast<unsigned long long>(qa.y) * kAmbiguousQuad + rest;
+  // Bounds3D's upper bound for an integer sum of q_hi (quantisation, table rounding and the f32
+  // chain's slack included), rounded outwards
+  const double mean_hi = P.min_probability + P.scale_over_n * static_cast<double>(q_hi) + P.slack_hi;
+  const double penalty = static_cast<double>(P.translation[t].w) * P.wt +
+                         static_cast<double>(P.rotation_angle[r]) * P.wr;
+  const double weight = exp(-(penalty * penalty));
+  const float upper = static_cast<float>(mean_hi * weight * (1. + P.delta)) * (1.f + 0x1p-22f);
+  const bool stays = upper >= __uint_as_float(*P.max_lower_bits);
+  if (stage_ub != nullptr) {
+    stage_ub[c] = stage == 0 ? q_hi : min(stage_ub[c], q_hi);
+    if (stage == 0) dropped[c] = stays ? 0 : 1;
+    else if (!stays) dropped[c] = 1;
+    return;
+  }
+  if (stays) flags[c] = 1;
+}
+
+// Verification mode of the staged pass, after the round's bounds: every bound recorded on the way
+// must dominate the candidate's own full sum (at its lower end), and a candidate the shipped
+// path would have dropped gets the `upper` = 0 it would have kept there.  grid (work descriptors).
+__global__ void __launch_bounds__(1024)
+Rt3DStageCheckKernel(Rt3DBulkParams P, const unsigned long long* __restrict__ stage_ub,
+                     const uint8_t* __restrict__ dropped, int* __restrict__ violations) {
+  const int2 work = P.blocks[blockIdx.x];
+  const int list = work.x;
+  const int slot = work.y * P.block_items + threadIdx.x;
+  if (slot >= P.counts[list]) return;
+  const int entry =
+      P.items[static_cast<size_t>(list) * P.list_rotations * P.num_translations + slot];
+  const int w = entry / P.num_translations, t = entry - w * P.num_translations;
+  const int r = list * P.list_rotations + w;
+  const size_t c = static_cast<size_t>(r) * P.num_translations + t;
+  const uint2 qa = P.sums[c];                       // the full sum now
+  const unsigned long long spread = static_cast<unsigned long long>(qa.y) * kAmbiguousQuad;
+  const unsigned long long q_lo = qa.x > spread ? qa.x - spread : 0ull;
+  if (stage_ub[c] < q_lo) atomicAdd(violations, 1);
+  if (dropped[c]) {
+    if (P.upper[c] >= __uint_as_float(*P.max_lower_bits)) atomicAdd(violations, 1);   // a finalist!
+    P.upper[c] = 0.f;
+  }
+}
+
 // CMX_RT3D_VERIFY=1 (tests): a group's upper bound must not lie below the LOWER bound of any of
 // its members that was scored -- both bracket the same true score.  (A group pass reading the
 // wrong staged rotation once produced garbage bounds that every parity test survived: the
@@ -546,6 +630,13 @@ struct Rt3DTileParams {
                                  // tile gathers, 2 = no point reads, 3 = neither
   const float* boxes;            // Rt3DChunkBoxKernel: [rotation block][chunk][6], or null (boxes
                                  // are then reduced inside the tile kernel)
+  // Point segments (Rt3DBinScanKernel): seg_bounds[0], [1] = first chunk of segments 1 and 2 of
+  // this pass's list, or null (one segment: every chunk).  The pass takes the chunks of segments
+  // seg_first .. seg_last.  Group pass: seg_sums[(r, group)] = (sum over segment 0, sum over
+  // segment 1) next to the total in P.sums, or null.
+  const int* seg_bounds;
+  int seg_first, seg_last;
+  uint2* seg_sums;
   unsigned long long* stats;     // CMX_RT3D_REPORT (its atomics cost ~0.5 ms per pass: not for timing): [0] chunks in LDS, [1] on the gather path,
                                  // [2] tile bytes, [3] points (per workgroup and chunk); or null
 };
@@ -607,45 +698,116 @@ __global__ void Rt3DBinCountKernel(Rt3DBinParams P, const float* __restrict__ xy
   (void)WaveAggregatedAdd(bin_count, bin, active);
 }
 
+// Point segments of the staged candidate pass (see "Staged candidate pass" below): the cloud is
+// cut into three parts -- about a quarter, a quarter and a half of the points -- that BOTH chunk
+// lists respect, so that the group pass can report a group's sum over each part and the
+// candidate pass can stop after the first or the second.  The unit is a group-pass piece (at
+// most kTileChunkGroups points of one bin; the candidate pass's pieces are its halves): a
+// piece belongs to the segment its midpoint falls into on the axis of bin-sorted point
+// indices, which is cut into windows of `window` points -- first quarter of a window: segment
+// 0, second quarter: 1, rest: 2.  Any assignment is correct; this one keeps the parts close to
+// their nominal sizes whatever the bins hold and interleaves them through the volume.
+__device__ __forceinline__ int Rt3DSegmentOf(int first_point, int length, int window) {
+  const int at = (first_point + (length >> 1)) & (window - 1);       // window: a power of two
+  return at < (window >> 2) ? 0 : at < (window >> 1) ? 1 : 2;
+}
+
 // One workgroup: exclusive scan of the bin counts -> first point of every bin (written over the
 // counts: the scatter kernel's cursors) and the two chunk lists (pieces of at most
-// kTileChunkGroups / kTileChunkCandidates points of one bin).
+// kTileChunkGroups / kTileChunkCandidates points of one bin), each ordered by segment:
+// num_chunks[0 / 1] = pieces of the group / candidate list, [2], [3] = where segments 1 and 2
+// of the group list begin, [4], [5] = the same for the candidate list.
 __global__ void __launch_bounds__(1024)
 Rt3DBinScanKernel(int* __restrict__ bin_count, int num_bins, int2* __restrict__ chunks_groups,
-                  int2* __restrict__ chunks_candidates, int* __restrict__ num_chunks) {
-  __shared__ int part_points[1024], part_a[1024], part_b[1024];
+                  int2* __restrict__ chunks_candidates, int* __restrict__ num_chunks,
+                  int window) {
+  static_assert(kTileChunkGroups == 2 * kTileChunkCandidates, "candidate pieces are halves");
+  __shared__ int part_points[1024], part_a[3][1024], part_b[3][1024];
+  __shared__ int seg_base_a[3], seg_base_b[3];
   const int tid = threadIdx.x;
   const int per = (num_bins + 1023) / 1024;
   const int begin = min(tid * per, num_bins), end = min(begin + per, num_bins);
-  int points = 0, pieces_a = 0, pieces_b = 0;
-  for (int b = begin; b < end; ++b) {
-    points += bin_count[b];
-    pieces_a += (bin_count[b] + kTileChunkGroups - 1) / kTileChunkGroups;
-    pieces_b += (bin_count[b] + kTileChunkCandidates - 1) / kTileChunkCandidates;
-  }
+  // pass 1: points per thread (the segment of a piece depends on its first point)
+  int points = 0;
+  for (int b = begin; b < end; ++b) points += bin_count[b];
   part_points[tid] = points;
-  part_a[tid] = pieces_a;
-  part_b[tid] = pieces_b;
   __syncthreads();
   if (tid == 0) {
-    int p = 0, ca = 0, cb = 0;
+    int p = 0;
     for (int k = 0; k < 1024; ++k) {
-      const int pp = part_points[k], aa = part_a[k], bb = part_b[k];
-      part_points[k] = p; part_a[k] = ca; part_b[k] = cb;
-      p += pp; ca += aa; cb += bb;
+      const int pp = part_points[k];
+      part_points[k] = p;
+      p += pp;
     }
-    num_chunks[0] = ca;
-    num_chunks[1] = cb;
   }
   __syncthreads();
-  int p = part_points[tid], ca = part_a[tid], cb = part_b[tid];
+  // pass 2: pieces per segment
+  int na[3] = {0, 0, 0}, nb[3] = {0, 0, 0};
+  {
+    int p = part_points[tid];
+    for (int b = begin; b < end; ++b) {
+      const int count = bin_count[b];
+      for (int first = 0; first < count; first += kTileChunkGroups) {
+        const int len = min(kTileChunkGroups, count - first);
+        const int seg = Rt3DSegmentOf(p + first, len, window);
+        const int halves = (len + kTileChunkCandidates - 1) / kTileChunkCandidates;
+        if (seg == 0) { na[0] += 1; nb[0] += halves; }
+        else if (seg == 1) { na[1] += 1; nb[1] += halves; }
+        else { na[2] += 1; nb[2] += halves; }
+      }
+      p += count;
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 3; ++g) { part_a[g][tid] = na[g]; part_b[g][tid] = nb[g]; }
+  __syncthreads();
+  if (tid < 6) {                           // six independent serial scans
+    int* part = tid < 3 ? part_a[tid] : part_b[tid - 3];
+    int run = 0;
+    for (int k = 0; k < 1024; ++k) {
+      const int v = part[k];
+      part[k] = run;
+      run += v;
+    }
+    (tid < 3 ? seg_base_a : seg_base_b)[tid % 3] = run;       // totals, turned into bases below
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int a0 = seg_base_a[0], a1 = seg_base_a[1], a2 = seg_base_a[2];
+    const int b0 = seg_base_b[0], b1 = seg_base_b[1], b2 = seg_base_b[2];
+    seg_base_a[0] = 0; seg_base_a[1] = a0; seg_base_a[2] = a0 + a1;
+    seg_base_b[0] = 0; seg_base_b[1] = b0; seg_base_b[2] = b0 + b1;
+    num_chunks[0] = a0 + a1 + a2;
+    num_chunks[1] = b0 + b1 + b2;
+    num_chunks[2] = a0; num_chunks[3] = a0 + a1;
+    num_chunks[4] = b0; num_chunks[5] = b0 + b1;
+  }
+  __syncthreads();
+  // pass 3: the lists
+  int ca[3], cb[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    ca[g] = seg_base_a[g] + part_a[g][tid];
+    cb[g] = seg_base_b[g] + part_b[g][tid];
+  }
+  int p = part_points[tid];
   for (int b = begin; b < end; ++b) {
     const int count = bin_count[b];
     bin_count[b] = p;
-    for (int first = 0; first < count; first += kTileChunkGroups)
-      chunks_groups[ca++] = make_int2(p + first, min(kTileChunkGroups, count - first));
-    for (int first = 0; first < count; first += kTileChunkCandidates)
-      chunks_candidates[cb++] = make_int2(p + first, min(kTileChunkCandidates, count - first));
+    for (int first = 0; first < count; first += kTileChunkGroups) {
+      const int len = min(kTileChunkGroups, count - first);
+      const int seg = Rt3DSegmentOf(p + first, len, window);
+      // (static selects: no dynamically indexed private array)
+      int at_a = seg == 0 ? ca[0] : seg == 1 ? ca[1] : ca[2];
+      int at_b = seg == 0 ? cb[0] : seg == 1 ? cb[1] : cb[2];
+      chunks_groups[at_a++] = make_int2(p + first, len);
+      for (int half = 0; half < len; half += kTileChunkCandidates)
+        chunks_candidates[at_b++] =
+            make_int2(p + first + half, min(kTileChunkCandidates, len - half));
+      if (seg == 0) { ca[0] = at_a; cb[0] = at_b; }
+      else if (seg == 1) { ca[1] = at_a; cb[1] = at_b; }
+      else { ca[2] = at_a; cb[2] = at_b; }
+    }
     p += count;
   }
 }
@@ -766,6 +928,15 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
       const_cast<uint8_t*>(P.cells), 0, P.cell_count, 0x00020000);
   unsigned acc = 0, ambiguous = 0;
   const int num_chunks = *TP.num_chunks;
+  // the chunks of this pass: all of them, or the segments seg_first .. seg_last of the list
+  int chunk_begin = 0, chunk_end = num_chunks, split0 = num_chunks, split1 = num_chunks;
+  if (TP.seg_bounds != nullptr) {
+    split0 = TP.seg_bounds[0];
+    split1 = TP.seg_bounds[1];
+    chunk_begin = TP.seg_first <= 0 ? 0 : TP.seg_first == 1 ? split0 : split1;
+    chunk_end = TP.seg_last >= 2 ? num_chunks : TP.seg_last == 1 ? split1 : split0;
+  }
+  unsigned acc_seen = 0, acc_seg0 = 0, acc_seg1 = 0;     // group pass: the total by segment
   // Fixed-point group pass.  The centre of a group needs no exact cell: its lookup in the
   // 3 x 3 x 3-dilated brick covers the members as long as the cell it reads is the cell of a
   // point within 1 - 0.87 = 0.13 cells (per axis) of the true centre.  So cell coordinates are
@@ -784,9 +955,18 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
     lane_word = tx | (ty << 10) | (tz << 20);
   }
 
-  for (int chunk = blockIdx.y; chunk < num_chunks; chunk += gridDim.y) {
+  for (int chunk = chunk_begin + blockIdx.y; chunk < chunk_end; chunk += gridDim.y) {
     const int2 span = TP.chunks[chunk];
     const int len = span.y;
+    if (kGroups) {
+      // what the previous chunk added belongs to that chunk's segment (chunks ascend; lanes that
+      // skip the lookups add nothing)
+      const int previous = chunk - static_cast<int>(gridDim.y);
+      const unsigned added = acc - acc_seen;
+      acc_seen = acc;
+      if (previous < split0) acc_seg0 += added;
+      else if (previous < split1) acc_seg1 += added;
+    }
     __syncthreads();                                     // the previous chunk is done with
     const bool have_box = TP.boxes != nullptr;
     if (have_box) {
@@ -1054,6 +1234,18 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
     const size_t c = static_cast<size_t>(r) * P.num_translations + t;
     atomicAdd(&P.sums[c].x, acc);
     if (ambiguous) atomicAdd(&P.sums[c].y, ambiguous);
+    if (kGroups && TP.seg_sums != nullptr) {
+      // the last chunk of this lane's loop: chunk_begin + blockIdx.y + k gridDim.y < chunk_end
+      const int steps = (chunk_end - chunk_begin - static_cast<int>(blockIdx.y) +
+                         static_cast<int>(gridDim.y) - 1) / static_cast<int>(gridDim.y);
+      const int last = chunk_begin + static_cast<int>(blockIdx.y) +
+                       (steps - 1) * static_cast<int>(gridDim.y);
+      const unsigned added = acc - acc_seen;
+      if (last < split0) acc_seg0 += added;
+      else if (last < split1) acc_seg1 += added;
+      if (acc_seg0) atomicAdd(&TP.seg_sums[c].x, acc_seg0);
+      if (acc_seg1) atomicAdd(&TP.seg_sums[c].y, acc_seg1);
+    }
   }
 }
 
@@ -1616,7 +1808,7 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
       const int max_blocks = static_cast<int>(R) * DivUp(T, kCand3DThreads);   // (>= any block size used)
       const size_t counts_bytes = (sizeof(int) * R + 15) / 16 * 16;
       char* d_bmisc = static_cast<char*>(ws->dev[13].Reserve(
-          head_bytes + counts_bytes + sizeof(int2) * (max_blocks + 1)));
+          head_bytes + counts_bytes + sizeof(int2) * (max_blocks + 2)));
       unsigned* d_max_lower = reinterpret_cast<unsigned*>(d_bmisc);
       int* d_bcount = reinterpret_cast<int*>(d_bmisc + 4);
       unsigned* d_max_upper = reinterpret_cast<unsigned*>(d_bmisc + 8);
@@ -1627,9 +1819,10 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
       int2* d_blocks = reinterpret_cast<int2*>(d_bmisc + head_bytes + counts_bytes);
       int* d_num_blocks = reinterpret_cast<int*>(d_blocks + max_blocks);
       int* d_violations = d_num_blocks + 1;          // (the second word of that int2 slot)
+      int* d_stage_scratch = d_num_blocks + 2;       // item total of the staged re-compactions (unused)
       const char* verify_env = getenv("CMX_RT3D_VERIFY");
       const bool verify = verify_env && verify_env[0] == '1';
-      int* h_num_blocks = ws->pinned[1].ReserveAs<int>(4);
+      int* h_num_blocks = ws->pinned[1].ReserveAs<int>(16);
       char* h_bmisc = static_cast<char*>(ws->pinned[2].Reserve(head_bytes));
       float4* h_group = ws->pinned[3].ReserveAs<float4>(G);
       std::memcpy(h_group, group.data(), sizeof(float4) * G);
@@ -1697,6 +1890,11 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
       const bool use_boxes = EnvInt("CMX_RT3D_BOXES", 1) == 1;
       Rt3DTileParams TG{};
       int max_chunks = 0;
+      int* d_segment_counts = nullptr;
+      // Staged second candidate round (see Rt3DStageFilterKernel); CMX_RT3D_STAGED=0 for the A/B.
+      // The cross-check compares complete sums and the expand-all mode has no second round.
+      const bool staged = use_tiles && !crosscheck && EnvInt("CMX_RT3D_STAGED", 1) == 1 &&
+                          EnvInt("CMX_RT3D_EXPAND_ALL", 0) != 1;
       if (use_tiles) {
         Rt3DBinParams BP{};
         BP.rotation = rot[R / 2];
@@ -1713,15 +1911,21 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
         max_chunks = n / kTileChunkCandidates + num_bins + 1;      // (either list)
         float* d_sorted = ws->dev[16].ReserveAs<float>(3 * static_cast<size_t>(n));
         char* d_bins = static_cast<char*>(ws->dev[17].Reserve(
-            sizeof(int) * (num_bins + 4) + 2 * sizeof(int2) * static_cast<size_t>(max_chunks)));
+            sizeof(int) * (num_bins + 8) + 2 * sizeof(int2) * static_cast<size_t>(max_chunks)));
         int* d_bin_count = reinterpret_cast<int*>(d_bins);
-        int* d_chunk_count = d_bin_count + num_bins;               // [0] group list, [1] candidate list
-        int2* d_chunks = reinterpret_cast<int2*>(d_bin_count + num_bins + 4);
+        // [0] group list, [1] candidate list, [2..3] / [4..5] their segment boundaries
+        int* d_chunk_count = d_bin_count + num_bins;
+        int2* d_chunks = reinterpret_cast<int2*>(d_bin_count + num_bins + 8);
         int2* d_chunks_candidates = d_chunks + max_chunks;
-        CMX_HIP(hipMemsetAsync(d_bin_count, 0, sizeof(int) * (num_bins + 4), ws->stream));
+        CMX_HIP(hipMemsetAsync(d_bin_count, 0, sizeof(int) * (num_bins + 8), ws->stream));
         Rt3DBinCountKernel<<<DivUp(n, 256), 256, 0, ws->stream>>>(BP, d_xyz, d_bin_count);
+        // (segment windows: sixteen or more periods over a large cloud, never shorter than four
+        // group-pass pieces)
+        const int segment_window = n >= 32768 ? 4096 : 2048;
         Rt3DBinScanKernel<<<1, 1024, 0, ws->stream>>>(d_bin_count, num_bins, d_chunks,
-                                                      d_chunks_candidates, d_chunk_count);
+                                                      d_chunks_candidates, d_chunk_count,
+                                                      segment_window);
+        d_segment_counts = d_chunk_count;
         Rt3DBinScatterKernel<<<DivUp(n, 256), 256, 0, ws->stream>>>(BP, d_xyz, d_bin_count,
                                                                     d_sorted);
         CMX_HIP(hipGetLastError());
@@ -1764,8 +1968,13 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
         const int blocks = DivUp(R, rot_per_block);
         const int slices = std::max(1, std::min(max_chunks, DivUp(8 * cus, blocks)));
         BG.cell_count = static_cast<unsigned>(cells);
-        BG.sums = reinterpret_cast<uint2*>(ws->dev[18].Reserve(sizeof(uint2) * RG));
-        CMX_HIP(hipMemsetAsync(BG.sums, 0, sizeof(uint2) * RG, ws->stream));
+        BG.sums = reinterpret_cast<uint2*>(ws->dev[18].Reserve(sizeof(uint2) * RG * (staged ? 2 : 1)));
+        CMX_HIP(hipMemsetAsync(BG.sums, 0, sizeof(uint2) * RG * (staged ? 2 : 1), ws->stream));
+        if (staged) {
+          TP.seg_bounds = d_segment_counts + 2;
+          TP.seg_first = 0; TP.seg_last = 2;
+          TP.seg_sums = BG.sums + RG;
+        }
         static thread_local size_t opted_groups = 0;
         if (lds > opted_groups) {
           CMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(Rt3DTileKernel<true>),
@@ -1871,6 +2080,9 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
         BC.cell_count = static_cast<unsigned>(cells);
       }
       int round_blocks[2] = {0, 0};
+      int stage_blocks[2] = {-1, -1};            // work blocks left after segments 0 and 1
+      int* h_segments = h_num_blocks + 4;        // pinned: the chunk counts by segment
+      int* d_stage_total = d_stage_scratch;      // (re-compactions must not count items twice)
       // CMX_RT3D_EXPAND_ALL=1 (tests, with CMX_RT3D_VERIFY): every group is expanded in the first
       // round, so every group bound is checked against every one of its members.
       const float first_round_factor = EnvInt("CMX_RT3D_EXPAND_ALL", 0) == 1 ? 0.f : 0.97f;
@@ -1887,8 +2099,11 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
         // instead of hundreds of thousands of blocks that find nothing to do.
         CMX_HIP(hipMemcpyAsync(h_num_blocks, d_num_blocks, sizeof(int), hipMemcpyDeviceToHost,
                                ws->stream));
+        if (staged && round == 0)
+          CMX_HIP(hipMemcpyAsync(h_segments, d_segment_counts, sizeof(int) * 8,
+                                 hipMemcpyDeviceToHost, ws->stream));
         CMX_HIP(hipStreamSynchronize(ws->stream));
-        const int nb = round_blocks[round] = *h_num_blocks;
+        int nb = round_blocks[round] = *h_num_blocks;
         if (nb == 0) continue;
         if (use_tiles) {
           const size_t lds = sizeof(v2f) * (3 * kTileChunkCandidates / 2 + 2) * list_rotations +
@@ -1899,6 +2114,57 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
                                         hipFuncAttributeMaxDynamicSharedMemorySize,
                                         static_cast<int>(lds)));
             opted_candidates = lds;
+          }
+          if (staged && round == 1) {
+            // Segment by segment; after the first and the second, the candidates whose bound
+            // (own sum so far + the group's sum over the rest) has fallen below the best lower
+            // bound leave the work lists.  Verification mode keeps the lists and records the
+            // decisions instead (Rt3DStageCheckKernel).
+            unsigned long long* d_stage_ub = nullptr;
+            uint8_t* d_dropped = nullptr;
+            if (verify) {
+              d_stage_ub = reinterpret_cast<unsigned long long*>(
+                  ws->dev[22].Reserve(sizeof(unsigned long long) * static_cast<size_t>(num_candidates)));
+              d_dropped = ws->dev[23].ReserveAs<uint8_t>(static_cast<size_t>(num_candidates));
+            }
+            int live = nb;
+            for (int stage = 0; stage < 3 && live > 0; ++stage) {
+              Rt3DTileParams TS = TC;
+              TS.seg_bounds = d_segment_counts + 4;
+              TS.seg_first = TS.seg_last = stage;
+              const int seg_chunks =
+                  stage == 0 ? h_segments[4] : stage == 1 ? h_segments[5] - h_segments[4]
+                                                          : h_segments[1] - h_segments[5];
+              if (seg_chunks > 0) {
+                const int slices = std::max(1, std::min(seg_chunks, DivUp(8 * cus, live)));
+                Rt3DTileKernel<false><<<dim3(live, slices), block_items, lds, ws->stream>>>(BC, TS);
+              }
+              if (stage == 2) break;
+              Rt3DStageFilterKernel<<<live, block_items, 0, ws->stream>>>(
+                  BC, BG.sums, BG.sums + RG, G, side_t, gpa, stage, d_flags, d_stage_ub, d_dropped);
+              if (verify) continue;
+              CMX_HIP(hipMemsetAsync(d_num_blocks, 0, sizeof(int), ws->stream));
+              Rt3DCompactKernel<<<num_lists, 256, 0, ws->stream>>>(
+                  d_flags, static_cast<int>(T), static_cast<int>(R), list_rotations, d_counts,
+                  d_items, d_stage_total, d_blocks, d_num_blocks, block_items);
+              CMX_HIP(hipMemcpyAsync(h_num_blocks, d_num_blocks, sizeof(int), hipMemcpyDeviceToHost,
+                                     ws->stream));
+              CMX_HIP(hipStreamSynchronize(ws->stream));
+              live = *h_num_blocks;
+              stage_blocks[stage] = live;
+            }
+            nb = live;
+            if (nb > 0) {
+              Rt3DBoundsKernel<<<nb, block_items, 0, ws->stream>>>(BC);
+              if (verify) {
+                Rt3DStageCheckKernel<<<nb, block_items, 0, ws->stream>>>(BC, d_stage_ub, d_dropped,
+                                                                          d_violations);
+                Rt3DVerifyKernel<<<nb, block_items, 0, ws->stream>>>(BC, d_group_upper, G, side_t,
+                                                                        gpa, d_violations);
+              }
+            }
+            trace.Mark("candidate pass 2 (staged)");
+            continue;
           }
           const int slices = std::max(1, std::min(max_chunks, DivUp(8 * cus, nb)));
           Rt3DTileKernel<false><<<dim3(nb, slices), block_items, lds, ws->stream>>>(BC, TC);
@@ -1969,10 +2235,10 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
         std::memcpy(&up_f, h_bmisc + 8, 4);
         fprintf(stderr,
                 "[cmx] rt3d: group pass %.3f ms (%lld bounds), %d of %lld candidates scored, "
-                "%d finalists, best lower %.6f, best group upper %.6f, work blocks %d + %d, "
-                "device %.3f ms\n",
+                "%d finalists, best lower %.6f, best group upper %.6f, work blocks %d + %d "
+                "(staged: %d after a quarter of the points, %d after half), device %.3f ms\n",
                 ms, RG, total_items, num_candidates, count, lo_f, up_f, round_blocks[0],
-                round_blocks[1], all);
+                round_blocks[1], stage_blocks[0], stage_blocks[1], all);
       }
       if (count >= 1 && count <= kBulkFinalistCap) {
         const int* fin = reinterpret_cast<const int*>(h_bmisc + 16);

@@ -351,9 +351,14 @@ def test_rt3d_bulk_pass_equals_per_candidate_kernel(sm3, oracle, synth, case, mo
     # "fixed": the tiled passes as shipped (group centres in packed fixed-point, a different but
     # equally valid centre cell next to boundaries: checked with EVERY group expanded, so that
     # CMX_RT3D_VERIFY compares every group bound with every member's own bounds)
-    for bulk in ("tiles", "fixed", "1", "0"):
+    # "staged": the shipped configuration under CMX_RT3D_VERIFY (second candidate round by point
+    # segments: every intermediate bound checked against the candidate's final sum);
+    # "shipped": the same without the verification mode (candidates really leave the lists)
+    for bulk in ("tiles", "fixed", "staged", "shipped", "1", "0"):
+        monkeypatch.setenv("CMX_RT3D_VERIFY", "0" if bulk == "shipped" else "1")
         monkeypatch.setenv("CMX_RT3D_BULK", "0" if bulk == "0" else "1")
-        monkeypatch.setenv("CMX_RT3D_TILES", "1" if bulk in ("tiles", "fixed") else "0")
+        monkeypatch.setenv("CMX_RT3D_TILES",
+                           "1" if bulk in ("tiles", "fixed", "staged", "shipped") else "0")
         monkeypatch.setenv("CMX_RT3D_CROSSCHECK", "1" if bulk == "tiles" else "0")
         monkeypatch.setenv("CMX_RT3D_EXPAND_ALL", "1" if bulk == "fixed" else "0")
         score, pose = m.match(rigid, cloud, 0.1, vox)

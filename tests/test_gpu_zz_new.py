@@ -535,13 +535,20 @@ def golden_c4():
 
 def _rt3d_against_golden(synth, d, g, monkeypatch, bulk):
     from cartographer_amd import scan_matching_3d as sm3
-    monkeypatch.setenv("CMX_RT3D_VERIFY", "1")     # group bounds checked against member bounds
+    # group bounds checked against member bounds; staged second round: every candidate still
+    # evaluated in full, every intermediate bound checked against its final sum, the drops
+    # applied afterwards
+    monkeypatch.setenv("CMX_RT3D_VERIFY", "0" if bulk in ("shipped", "unstaged") else "1")
     # "tiles": LDS-tiled bulk passes (cross-checked against the gather kernels element by
     # element); "1": gather kernels; "0": exhaustive
     # "fixed": the tiled passes as shipped (fixed-point group centres), "fixed-all": the same
     # with every group expanded so that VERIFY compares every group bound with all its members
+    # "shipped": exactly what a caller gets (no verification mode: the staged second round
+    # really drops candidates from its work lists); "unstaged": the same without the stages
     monkeypatch.setenv("CMX_RT3D_BULK", "0" if bulk == "0" else "1")
-    monkeypatch.setenv("CMX_RT3D_TILES", "1" if bulk in ("tiles", "fixed", "fixed-all") else "0")
+    monkeypatch.setenv("CMX_RT3D_TILES",
+                       "1" if bulk in ("tiles", "fixed", "fixed-all", "shipped", "unstaged") else "0")
+    monkeypatch.setenv("CMX_RT3D_STAGED", "0" if bulk == "unstaged" else "1")
     monkeypatch.setenv("CMX_RT3D_CROSSCHECK", "1" if bulk == "tiles" else "0")
     monkeypatch.setenv("CMX_RT3D_EXPAND_ALL", "1" if bulk == "fixed-all" else "0")
     m = sm3.RealTimeCorrelativeScanMatcher3D(d["lin"], d["ang"], d["tw"], d["rw"])
@@ -553,7 +560,7 @@ def _rt3d_against_golden(synth, d, g, monkeypatch, bulk):
     return m.last_stats
 
 
-@pytest.mark.parametrize("bulk", ["tiles", "fixed", "fixed-all", "1", "0"])
+@pytest.mark.parametrize("bulk", ["tiles", "fixed", "fixed-all", "shipped", "unstaged", "1", "0"])
 def test_rt3d_c4_shaped_equals_the_reference(synth, golden_c4, monkeypatch, bulk):
     """C4's shape at 4096 points: L = 5 -> 6^3 = 216 groups of 2x2x2 translations per rotation
     (the flat 192-lane group mapping of rt_3d.hip spans rotations), A = 3 -> 343 rotations, a
@@ -567,7 +574,7 @@ def test_rt3d_c4_shaped_equals_the_reference(synth, golden_c4, monkeypatch, bulk
         assert st["coarse_candidates"] < st["candidates_scored"]      # bounds did exclude
 
 
-@pytest.mark.parametrize("bulk", ["tiles", "fixed", "1", "0"])
+@pytest.mark.parametrize("bulk", ["tiles", "fixed", "shipped", "unstaged", "1", "0"])
 def test_rt3d_c4_at_its_baseline_window_equals_the_reference(synth, golden_c4, monkeypatch, bulk):
     """BASELINE config[3] exactly as bench.py times it (65 536 points, 150^3 grid, +-0.5 m /
     +-2 deg: 1 771 561 candidates) against the reference's own
