@@ -707,9 +707,10 @@ __global__ void Rt3DBinCountKernel(Rt3DBinParams P, const float* __restrict__ xy
 // indices, which is cut into windows of `window` points -- first quarter of a window: segment
 // 0, second quarter: 1, rest: 2.  Any assignment is correct; this one keeps the parts close to
 // their nominal sizes whatever the bins hold and interleaves them through the volume.
-__device__ __forceinline__ int Rt3DSegmentOf(int first_point, int length, int window) {
+__device__ __forceinline__ int Rt3DSegmentOf(int first_point, int length, int window, int end0,
+                                             int end1) {
   const int at = (first_point + (length >> 1)) & (window - 1);       // window: a power of two
-  return at < (window >> 2) ? 0 : at < (window >> 1) ? 1 : 2;
+  return at < end0 ? 0 : at < end1 ? 1 : 2;          // (end0, end1: window / 4, window / 2)
 }
 
 // One workgroup: exclusive scan of the bin counts -> first point of every bin (written over the
@@ -720,7 +721,7 @@ __device__ __forceinline__ int Rt3DSegmentOf(int first_point, int length, int wi
 __global__ void __launch_bounds__(1024)
 Rt3DBinScanKernel(int* __restrict__ bin_count, int num_bins, int2* __restrict__ chunks_groups,
                   int2* __restrict__ chunks_candidates, int* __restrict__ num_chunks,
-                  int window) {
+                  int window, int end0, int end1) {
   static_assert(kTileChunkGroups == 2 * kTileChunkCandidates, "candidate pieces are halves");
   __shared__ int part_points[1024], part_a[3][1024], part_b[3][1024];
   __shared__ int seg_base_a[3], seg_base_b[3];
@@ -749,7 +750,7 @@ Rt3DBinScanKernel(int* __restrict__ bin_count, int num_bins, int2* __restrict__ 
       const int count = bin_count[b];
       for (int first = 0; first < count; first += kTileChunkGroups) {
         const int len = min(kTileChunkGroups, count - first);
-        const int seg = Rt3DSegmentOf(p + first, len, window);
+        const int seg = Rt3DSegmentOf(p + first, len, window, end0, end1);
         const int halves = (len + kTileChunkCandidates - 1) / kTileChunkCandidates;
         if (seg == 0) { na[0] += 1; nb[0] += halves; }
         else if (seg == 1) { na[1] += 1; nb[1] += halves; }
@@ -796,7 +797,7 @@ Rt3DBinScanKernel(int* __restrict__ bin_count, int num_bins, int2* __restrict__ 
     bin_count[b] = p;
     for (int first = 0; first < count; first += kTileChunkGroups) {
       const int len = min(kTileChunkGroups, count - first);
-      const int seg = Rt3DSegmentOf(p + first, len, window);
+      const int seg = Rt3DSegmentOf(p + first, len, window, end0, end1);
       // (static selects: no dynamically indexed private array)
       int at_a = seg == 0 ? ca[0] : seg == 1 ? ca[1] : ca[2];
       int at_b = seg == 0 ? cb[0] : seg == 1 ? cb[1] : cb[2];
@@ -869,6 +870,14 @@ Rt3DChunkBoxKernel(Rt3DBulkParams P, const float* __restrict__ sorted_xyz,
       boxes[(static_cast<size_t>(block) * total + chunk) * 6 + lane] = v;
     }
   }
+}
+
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void LdsRead128Asm(uint4v* out, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(*out) : "v"(addr));
+}
+__device__ __forceinline__ void LdsReadU8Asm(unsigned* out, unsigned addr) {
+  asm volatile("ds_read_u8 %0, %1" : "=v"(*out) : "v"(addr));
 }
 
 // kGroups: grid (ceil(R / rotations_per_block), chunk slices), blockDim = the (rotation, group)
@@ -1211,19 +1220,61 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
         typedef __attribute__((address_space(3))) const uint8_t LdsByte;
         return *reinterpret_cast<LdsByte*>(static_cast<uintptr_t>(at));
       };
-      unsigned p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-      const int len4 = len & ~3;
-      uint4 cur = *reinterpret_cast<const uint4*>(words);
-#pragma unroll 2
-      for (int j = 0; j < len4; j += 4) {
-        const uint4 nxt = *reinterpret_cast<const uint4*>(words + min(j + 4, kChunk - 4));
-        const unsigned v0 = cell(cur.x), v1 = cell(cur.y), v2 = cell(cur.z), v3 = cell(cur.w);
-        acc += (p0 + p1) + (p2 + p3);
-        p0 = v0; p1 = v1; p2 = v2; p3 = v3;
-        cur = nxt;
+      // Hand-scheduled (as the window loop of rt_2d.hip): the compiler's version of this loop kept
+      // four register copies per four lookups (its unroll-by-two failed) and loaded the next
+      // point words right before their use -- an LDS round trip exposed in every iteration of
+      // the pass the match spends half its time in.  Eight lookups per iteration in two halves
+      // A and B.  LDS operations are issued in the order  A x 4, W0', B x 4, Wb'  (W': the point
+      // words of the NEXT iteration) and return in issue order, so every wait names exactly how
+      // many later operations may still be pending: A's gathers and the word loads land under
+      // B's address arithmetic, B's gathers under the next iteration's A addresses.  Every
+      // asynchronous result is waited for before the loop's back edge -- what crosses it (the A
+      // addresses, the B words) are ordinary values the compiler may copy as it likes -- and the
+      // waits carry the registers they release as in/out operands, which pins the consuming
+      // arithmetic behind them.
+      const auto address = [&](unsigned point_word) -> unsigned {
+        const unsigned sum = point_word + lane_word;
+        const unsigned x = (sum >> kFrac) & 63u, y = (sum >> (10 + kFrac)) & 63u,
+                       z = sum >> (20 + kFrac);
+        unsigned row, at;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row) : "v"(z), "s"(udy), "v"(y));
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(at) : "v"(row), "s"(udx), "v"(x));
+        return at;
+      };
+      const int len8 = len & ~7;
+      if (len8 > 0) {
+        const unsigned wbase = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
+            (const __attribute__((address_space(3))) uint32_t*)words));
+        uint4v Wa, Wb;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // nothing of the compiler's pending
+        LdsRead128Asm(&Wa, wbase);
+        LdsRead128Asm(&Wb, wbase + 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Wa), "+v"(Wb));
+        unsigned a0 = address(Wa.x), a1 = address(Wa.y), a2 = address(Wa.z), a3 = address(Wa.w);
+        for (int j = 0; j < len8; j += 8) {
+          const unsigned next = wbase + 4u * static_cast<unsigned>(min(j + 8, kChunk - 8));
+          unsigned A0, A1, A2, A3, B0, B1, B2, B3;
+          uint4v W0;
+          LdsReadU8Asm(&A0, a0); LdsReadU8Asm(&A1, a1); LdsReadU8Asm(&A2, a2); LdsReadU8Asm(&A3, a3);
+          LdsRead128Asm(&W0, next);
+          const unsigned b0 = address(Wb.x), b1 = address(Wb.y), b2 = address(Wb.z),
+                         b3 = address(Wb.w);
+          LdsReadU8Asm(&B0, b0); LdsReadU8Asm(&B1, b1); LdsReadU8Asm(&B2, b2); LdsReadU8Asm(&B3, b3);
+          // (Wb's words have been turned into addresses: the next ones go straight into it)
+          asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(Wb) : "v"(next));
+          asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3));   // after A: W0', B x 4, Wb'
+          acc += (A0 + A1) + (A2 + A3);
+          asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(W0));                                  // after W0': B x 4, Wb'
+          a0 = address(W0.x); a1 = address(W0.y); a2 = address(W0.z); a3 = address(W0.w);
+          // (the A addresses of the next iteration are operands too: their arithmetic is what
+          // B's gathers land under, it must not sink below this wait)
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(B0), "+v"(B1), "+v"(B2), "+v"(B3), "+v"(Wb), "+v"(a0), "+v"(a1),
+                         "+v"(a2), "+v"(a3));
+          acc += (B0 + B1) + (B2 + B3);
+        }
       }
-      acc += (p0 + p1) + (p2 + p3);
-      for (int j = len4; j < len; ++j) acc += cell(words[j]);
+      for (int j = len8; j < len; ++j) acc += cell(words[j]);
     } else if (in_lds) {
       run(std::true_type{});
     } else {
@@ -1922,9 +1973,19 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
         // (segment windows: sixteen or more periods over a large cloud, never shorter than four
         // group-pass pieces)
         const int segment_window = n >= 32768 ? 4096 : 2048;
-        Rt3DBinScanKernel<<<1, 1024, 0, ws->stream>>>(d_bin_count, num_bins, d_chunks,
-                                                      d_chunks_candidates, d_chunk_count,
-                                                      segment_window);
+        // (CMX_RT3D_SEGMENTS=ab: the first segment ends at a / 16, the second at b / 16 of a
+        // window, hex digits; default 48 = a quarter and a half.  Experiments.)
+        int sixteenths0 = 4, sixteenths1 = 8;
+        if (const char* e = getenv("CMX_RT3D_SEGMENTS")) {
+          const auto digit = [](char c) { return c >= 'a' ? c - 'a' + 10 : c - '0'; };
+          if (e[0] && e[1]) {
+            sixteenths0 = std::max(1, std::min(15, digit(e[0])));
+            sixteenths1 = std::max(sixteenths0, std::min(15, digit(e[1])));
+          }
+        }
+        Rt3DBinScanKernel<<<1, 1024, 0, ws->stream>>>(
+            d_bin_count, num_bins, d_chunks, d_chunks_candidates, d_chunk_count, segment_window,
+            segment_window / 16 * sixteenths0, segment_window / 16 * sixteenths1);
         d_segment_counts = d_chunk_count;
         Rt3DBinScatterKernel<<<DivUp(n, 256), 256, 0, ws->stream>>>(BP, d_xyz, d_bin_count,
                                                                     d_sorted);

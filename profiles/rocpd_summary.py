@@ -6,8 +6,20 @@ import sqlite3
 import sys
 
 
+def calls(con, pattern):
+    """Every launch whose name contains `pattern`, in start order: duration in microseconds."""
+    rows = con.execute("select name, start, duration from kernels where name like ? order by start",
+                       (f"%{pattern}%",)).fetchall()
+    t0 = rows[0][1] if rows else 0
+    for name, start, duration in rows:
+        short = name.split("(")[0].split("::")[-1]
+        print(f"{(start - t0) / 1e3:12.1f} us  {duration / 1e3:10.1f} us  {short}")
+
+
 def main():
     con = sqlite3.connect(sys.argv[1])
+    if len(sys.argv) > 3 and sys.argv[2] == "--calls":
+        return calls(con, sys.argv[3])
     rows = con.execute(
         "select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
         "max(vgpr_count), max(sgpr_count), max(lds_size) from kernels group by name "
