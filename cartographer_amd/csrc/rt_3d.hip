@@ -1933,7 +1933,13 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
       int cus = 256;
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
       // Tiled passes: the cloud sorted into bins of kTileBin^3 cells at the central candidate.
-      const int rot_per_block = std::max(1, std::min(kTileMaxRotations, 1024 / std::max(G, 1)));
+      // Rotations of a group-pass workgroup: as many as fit 512 lanes, so that TWO workgroups
+      // share a CU and one computes while the other stages its next chunk (C4, 216 groups: two
+      // rotations = 448 lanes, group pass 5.51 -> 4.91 ms against four rotations in one 896-lane
+      // workgroup per CU; CMX_RT3D_GROUP_ROTATIONS overrides, experiments).
+      const int rot_per_block = std::max(
+          1, std::min({kTileMaxRotations, std::max(1, 512 / std::max(G, 1)),
+                       EnvInt("CMX_RT3D_GROUP_ROTATIONS", kTileMaxRotations)}));
       const bool use_tiles = Tiles3DEnabled() && G <= 1024;
       const bool crosscheck = use_tiles && EnvInt("CMX_RT3D_CROSSCHECK", 0) == 1;
       // (boxes of the rotated chunks from a pre-pass kernel instead of a reduction per chunk
