@@ -626,8 +626,11 @@ struct Rt3DTileParams {
   int tile_capacity;             // bytes of dynamic LDS behind the staged points
   int block_items;               // candidate pass: items per work descriptor (= blockDim.x)
   int fixed_point;               // group pass: packed fixed-point cell arithmetic (see kernel)
-  int experiment;                // CMX_RT3D_TILE_EXPERIMENT (timing only, wrong results): 1 = no
-                                 // tile gathers, 2 = no point reads, 3 = neither
+  int experiment;                // CMX_RT3D_TILE_EXPERIMENT (timing only, wrong results): 4 = no
+                                 // lookups at all.  (Bits 1 and 2 -- no tile gathers / no point
+                                 // reads -- sat INSIDE the lookup loops until late in round 3:
+                                 // two runtime branches per pair of lookups, each a basic-block
+                                 // boundary with a full s_waitcnt in the shipped kernel.)
   const float* boxes;            // Rt3DChunkBoxKernel: [rotation block][chunk][6], or null (boxes
                                  // are then reduced inside the tile kernel)
   // Point segments (Rt3DBinScanKernel): seg_bounds[0], [1] = first chunk of segments 1 and 2 of
@@ -1150,13 +1153,8 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
       if (kLds) {
         const v2f o = __builtin_elementwise_fma(
             __builtin_elementwise_fma(nz - lz, dyf, ny - ly), dxf, nx - lx);
-        if (TP.experiment & 1) {
-          *v0 = static_cast<unsigned>(o.x);
-          *v1 = static_cast<unsigned>(o.y);
-        } else {
-          *v0 = tile[static_cast<unsigned>(o.x)];
-          *v1 = tile[static_cast<unsigned>(o.y)];
-        }
+        *v0 = tile[static_cast<unsigned>(o.x)];
+        *v1 = tile[static_cast<unsigned>(o.y)];
       } else {
         const v2f o = __builtin_elementwise_fma(__builtin_elementwise_fma(nz, py2, ny), px2, nx);
         *v0 = __builtin_amdgcn_raw_buffer_load_b8(rsrc, static_cast<unsigned>(o.x), 0, 0);
@@ -1176,13 +1174,8 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
 #pragma unroll 2
       for (int j = 0; j < len4; j += 4) {
         const v2f* ahead = my_stage + 3 * (min(j + 4, kChunk - 4) >> 1);
-        if (TP.experiment & 2) {
 #pragma unroll
-          for (int k = 0; k < 6; ++k) nxt[k] = cur[k] + inv;
-        } else {
-#pragma unroll
-          for (int k = 0; k < 6; ++k) nxt[k] = ahead[k];
-        }
+        for (int k = 0; k < 6; ++k) nxt[k] = ahead[k];
         unsigned v[4];
         float g = 0.f;
         pair(lds_tag, cur, &v[0], &v[1], &g);
