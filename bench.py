@@ -602,7 +602,9 @@ class Rt3DWorkload:
         table) = 256 CUs x 2.4 GHz / 2 x 64 lanes = 1.97e13 lookups/s; the r03_c4 SQ counters
         (profiles/) show where the rest goes: LDS array busy 47 % of the kernel (40 % of that
         bank conflicts), 10.6 vector instructions per wave-lookup of which 6.5 are the lookup
-        itself, waves in s_waitcnt half of their time (five barriers per point chunk).  Gather
+        itself, waves in s_waitcnt half of their time (five barriers per point chunk) -- counters
+        taken before the lookup loop was hand-scheduled and the workgroups halved (DESIGN 5.4:
+        6.6 per lookup in the loop, two workgroups per CU).  Gather
         path (CMX_RT3D_TILES=0): buffer_load_ubyte from L2, measured ceiling 19 cycles per
         64-lane gather per CU = 2.05e12 lookups/s (profiles/r02_rt3d_gather_ceiling.txt)."""
         k_ms = acc["dominant_kernel_ms"] / steps
