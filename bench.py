@@ -880,7 +880,7 @@ def other_configs(args, device, sync, pmc):
         "c5_single": lambda w: cpu_baseline_c5(w, min(5.0, args.cpu_seconds))}
     run("c1_single", lambda: Rt2DWorkload(args, device, matches=1), 200, 50)
     run("c1_batch128", lambda: Rt2DWorkload(args, device, matches=128), 100, 10, cpu.get("c1_batch128"))
-    run("c1_batch128_4_threads", lambda: Rt2DPipelinedWorkload(args, device, 128, 4, 4), 25, 5)
+    run("c1_batch128_8_threads", lambda: Rt2DPipelinedWorkload(args, device, 128, 8, 4), 25, 5)
     sub = argparse.Namespace(**vars(args))
     sub.submaps = 16
     run("c3_share_16_submaps", lambda: Fast2DWorkload(sub, device, 0, 1, sharded=True), 5, 2)
@@ -1124,7 +1124,7 @@ def main():
             # The driver's record keeps scalars: every config's line flat in `config` ...
             for key, e in other.items():
                 short = {"c1_single": "c1_single", "c1_batch128": "c1b128",
-                         "c1_batch128_4_threads": "c1b128t4", "c3_share_16_submaps": "c3s16",
+                         "c1_batch128_8_threads": "c1b128t8", "c3_share_16_submaps": "c3s16",
                          "c4": "c4", "c5_single": "c5_single",
                          "c5_share_32_submaps": "c5s32"}.get(key, key)
                 if "error" in e:
