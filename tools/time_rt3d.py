@@ -17,7 +17,8 @@ cloud = world.scan(pos, 0.3, 64, 1024, seed=9)
 c, s = math.cos(0.31 / 2), math.sin(0.31 / 2)
 init = sm3.Rigid3d(tuple(pos + np.array([0.07, -0.04, 0.02])), (c, 0.0, 0.0, s))
 m = sm3.RealTimeCorrelativeScanMatcher3D(0.5, math.radians(2.0), 0.1, 0.1)
-os.environ["CMX_RT3D_REPORT"] = "1"
+if os.environ.get("CMX_NO_REPORT") != "1":      # (the report's statistics atomics cost ~0.5 ms per pass)
+    os.environ["CMX_RT3D_REPORT"] = "1"
 for mode in (sys.argv[1:] or ["1", "0"]):          # CMX_RT3D_BULK
     os.environ["CMX_RT3D_BULK"] = mode
     for rep in range(2):
