@@ -1,0 +1,118 @@
+"""Statistics only: how many of C4's candidates that survive the 2x2x2 group bound are still
+alive after a fraction of the points (UB_c = U_g - U_g(Q) + s_c(Q))."""
+import os, sys, math, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from cartographer_amd import synth
+from scipy.ndimage import maximum_filter
+
+t0 = time.time()
+grid, world = synth.make_submap_3d(42, 0.1, (15.0, 15.0, 7.5), 8, 32, 512)
+vox = grid.voxels()
+print("voxel dtype", vox.dtype, len(vox))
+pos = world.free_position(77, 0.5)
+cloud = world.scan(pos, 0.3, 64, 1024, seed=9).astype(np.float64)
+print("cloud", cloud.shape)
+SUB = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+rng = np.random.default_rng(0)
+perm = rng.permutation(len(cloud))
+pts = cloud[perm[: len(cloud) // SUB]]
+N = len(pts)
+res = 0.1
+names = vox.dtype.names
+xs, ys, zs, val = (vox[names[0]].astype(np.int64), vox[names[1]].astype(np.int64),
+                   vox[names[2]].astype(np.int64), vox[names[3]].astype(np.int64))
+pad = 16
+lo = np.array([xs.min(), ys.min(), zs.min()]) - pad
+dims = np.array([xs.max(), ys.max(), zs.max()]) - lo + pad + 1
+B = np.zeros(dims, np.uint8)
+u = np.maximum(val & 32767, 1) - 1
+B[xs - lo[0], ys - lo[1], zs - lo[2]] = (u >> 7).astype(np.uint8)
+D = maximum_filter(B, size=3, mode="constant")
+print("brick", B.shape, "nonzero", (B > 0).mean())
+
+# search space (reference: real_time_correlative_scan_matcher_3d.cc:116-160)
+L = int(math.ceil(0.5 / res))
+maxr = np.linalg.norm(cloud, axis=1).max()
+step = math.acos(1 - res * res / (2 * maxr * maxr))
+aw = int(math.ceil(math.radians(2.0) / step))
+print("L", L, "angular window", aw, "step deg", math.degrees(step))
+def quat_from_aa(v):
+    a = np.linalg.norm(v)
+    if a < 1e-12: return np.array([1.0, 0, 0, 0])
+    return np.concatenate([[math.cos(a / 2)], math.sin(a / 2) * v / a])
+def qmul(a, b):
+    w1, x1, y1, z1 = a; w2, x2, y2, z2 = b
+    return np.array([w1*w2-x1*x2-y1*y2-z1*z2, w1*x2+x1*w2+y1*z2-z1*y2, w1*y2-x1*z2+y1*w2+z1*x2, w1*z2+x1*y2-y1*x2+z1*w2])
+def rotm(q):
+    w, x, y, z = q
+    return np.array([[1-2*(y*y+z*z), 2*(x*y-z*w), 2*(x*z+y*w)], [2*(x*y+z*w), 1-2*(x*x+z*z), 2*(y*z-x*w)], [2*(x*z-y*w), 2*(y*z+x*w), 1-2*(x*x+y*y)]])
+c, s = math.cos(0.31 / 2), math.sin(0.31 / 2)
+q0 = np.array([c, 0, 0, s]); t0v = pos + np.array([0.07, -0.04, 0.02])
+R0 = rotm(q0)
+rots, angs = [], []
+for z in range(-aw, aw + 1):
+    for y in range(-aw, aw + 1):
+        for x in range(-aw, aw + 1):
+            v = np.array([x, y, z]) * step
+            rots.append(rotm(quat_from_aa(v))); angs.append(np.linalg.norm(v))
+rots = np.array(rots); angs = np.array(angs); R = len(rots)
+side = 2 * L + 1
+tr = np.array([[x, y, z] for z in range(-L, L + 1) for y in range(-L, L + 1) for x in range(-L, L + 1)]) * res
+T = len(tr)
+gpa = (side + 1) // 2
+groups, gmembers, gdist = [], [], []
+for gz in range(gpa):
+    for gy in range(gpa):
+        for gx in range(gpa):
+            mem = [((2*gz+c_)*side + (2*gy+b_))*side + (2*gx+a_) for c_ in range(min(2, side-2*gz)) for b_ in range(min(2, side-2*gy)) for a_ in range(min(2, side-2*gx))]
+            gmembers.append(mem)
+            groups.append(tr[mem].mean(axis=0)); gdist.append(np.linalg.norm(tr[mem], axis=1).min())
+groups = np.array(groups); G = len(groups); gdist = np.array(gdist)
+print("R", R, "T", T, "G", G, "N", N)
+wt = wr = 0.1
+kscale = 0.8 / 32766 * 128
+
+# point subsets: quarter / half by random split
+quarter = np.arange(N) < N // 4
+half = np.arange(N) < N // 2
+eighth = np.arange(N) < N // 8
+
+def lookup(brick, P):   # P (..., 3) metres in map frame
+    idx = np.rint(P / res).astype(np.int64) - lo
+    np.clip(idx, 0, dims - 1, out=idx)
+    return brick[idx[..., 0], idx[..., 1], idx[..., 2]]
+
+
+from scipy.ndimage import maximum_filter as mf
+D5 = mf(B, size=5, mode="constant")
+b = 0.5904488961615459     # best lower bound of the earlier run (same workload, same sample)
+# rotation blocks: 2x2x2 in the angle-axis lattice, centre at half steps
+A = 2 * aw + 1
+rb = (A + 1) // 2
+gt = groups @ R0.T + t0v
+alive_pairs = 0
+total_pairs = 0
+blocks_alive = 0
+ub_all = []
+for bz in range(rb):
+    for by in range(rb):
+        for bx in range(rb):
+            mem = [((2*bz+c_)*A + (2*by+b_))*A + (2*bx+a_) for c_ in range(min(2, A-2*bz)) for b_ in range(min(2, A-2*by)) for a_ in range(min(2, A-2*bx))]
+            nx_, ny_, nz_ = min(2, A-2*bx), min(2, A-2*by), min(2, A-2*bz)
+            v = np.array([2*bx + 0.5*(nx_-1) - aw, 2*by + 0.5*(ny_-1) - aw, 2*bz + 0.5*(nz_-1) - aw]) * step
+            Rc = rotm(quat_from_aa(v))
+            rp = pts @ (R0 @ Rc).T
+            val = lookup(D5, rp[None, :, :] + gt[:, None, :]).astype(np.int64)   # (G, N)
+            U2 = val.sum(1)
+            amin = angs[mem].min()
+            w = np.exp(-((gdist * wt + amin * wr) ** 2))
+            ub = (0.1 + kscale * (U2 + 0.99 * N) / N) * w
+            keep = ub >= b
+            alive_pairs += int(keep.sum()) * len(mem)
+            total_pairs += G * len(mem)
+            blocks_alive += int(keep.sum())
+            ub_all.append(ub)
+    print("rotation blocks z", bz, time.time() - t0, flush=True)
+print(f"super-blocks (rotation block x translation group): {rb**3 * G}, alive {blocks_alive} ({blocks_alive / (rb**3 * G):.3f})")
+print(f"level-1 (rotation, group) pairs still to evaluate: {alive_pairs} of {total_pairs} ({alive_pairs / total_pairs:.3f})")
+print(f"cost relative to the present group pass: {rb**3 / R:.3f} + {alive_pairs / total_pairs:.3f}")
