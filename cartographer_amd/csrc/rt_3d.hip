@@ -2284,7 +2284,8 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
         int violations = 0;
         CMX_HIP(hipMemcpy(&violations, d_violations, sizeof(int), hipMemcpyDeviceToHost));
         CMX_REQUIRE(violations == 0,
-                    "internal error: %d group bounds below a member's lower bound", violations);
+                    "internal error: %d bound violations (a group bound below a member's lower "
+                    "bound, or a staged bound below the candidate's final sum)", violations);
       }
       if (getenv("CMX_RT3D_REPORT")) {
         float ms = 0.f, all = 0.f;
