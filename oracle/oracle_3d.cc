@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <cassert>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 
 namespace oracle {
@@ -361,6 +363,8 @@ FastCorrelativeScanMatcher3D::GenerateDiscreteScans(const Search& sp, const Node
   return result;
 }
 
+static FILE* g_node_dump = nullptr;      // see MatchWithSearchParameters
+
 void FastCorrelativeScanMatcher3D::ScoreCandidates(const int depth,
                                                    const std::vector<DiscreteScan3D>& scans,
                                                    std::vector<Candidate3D>* candidates,
@@ -409,6 +413,10 @@ FastCorrelativeScanMatcher3D::Candidate3D FastCorrelativeScanMatcher3D::BranchAn
   for (const Candidate3D& c : candidates) {
     if (c.score <= min_score) break;
     if (stats) ++stats->nodes_expanded;
+    if (g_node_dump) {        // ORC_DUMP_NODES (design studies): scan, depth, offset of the expansion
+      const int32_t rec[5] = {c.scan_index, candidate_depth, c.offset.x, c.offset.y, c.offset.z};
+      fwrite(rec, sizeof rec, 1, g_node_dump);
+    }
     std::vector<Candidate3D> children;
     const int half = 1 << (candidate_depth - 1);
     for (int z : {0, half}) {
@@ -447,7 +455,26 @@ bool FastCorrelativeScanMatcher3D::MatchWithSearchParameters(
     stats->coarse_candidates = lowest.size();
   }
   ScoreCandidates(max_depth, scans, &lowest, stats);
+  // ORC_DUMP_NODES=<file> (design studies, tools/prototypes): the discrete scans (cells per depth)
+  // and every expanded node of this search, binary.  Not thread-safe: one search at a time.
+  if (const char* path = getenv("ORC_DUMP_NODES")) {
+    g_node_dump = fopen(path, "wb");
+    if (g_node_dump) {
+      const int32_t head[4] = {static_cast<int32_t>(scans.size()), depth(),
+                               static_cast<int32_t>(scans.empty() ? 0 : scans[0].cell_indices_per_depth[0].size()),
+                               options_.full_resolution_depth};
+      fwrite(head, sizeof head, 1, g_node_dump);
+      for (const DiscreteScan3D& scan : scans)
+        for (int d = 0; d < depth(); ++d)
+          fwrite(scan.cell_indices_per_depth[d].data(), sizeof(Cell3i),
+                 scan.cell_indices_per_depth[d].size(), g_node_dump);
+    }
+  }
   const Candidate3D best = BranchAndBound(sp, scans, lowest, max_depth, min_score, stats);
+  if (g_node_dump) {
+    fclose(g_node_dump);
+    g_node_dump = nullptr;
+  }
   if (best.score > min_score) {
     result->score = best.score;
     result->pose_estimate = CastPose(GetPoseFromCandidate(scans, best));
