@@ -44,6 +44,29 @@ __device__ __forceinline__ CMX_GLOBAL T* AsGlobal(T* p) {
   return (CMX_GLOBAL T*)p;
 }
 
+// A wavefront-uniform 64-bit value (pointers and sizes that come out of LDS or out of a
+// descriptor in memory: the compiler does not know they are uniform and would wrap every
+// buffer load that uses them in a waterfall loop).  Through `unsigned`: readfirstlane returns an
+// int, and a low word with its top bit set must not sign-extend over the high word.
+__device__ __forceinline__ unsigned long long UniformU64(unsigned long long v) {
+  const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
+  const unsigned hi =
+      static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(v >> 32)));
+  return static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi) << 32);
+}
+// Buffer resource over `bytes` (< 2 GB) at `base`: raw buffer loads through it are never
+// predicated (an offset >= bytes -- kOutOfBuffer -- reads 0 without touching memory), so the
+// gathers of an unrolled loop can be issued back to back and consumed at vmcnt(k).
+constexpr unsigned kOutOfBuffer = 0xfffffff0u;
+constexpr unsigned long long kMaxBufferBytes = 1ull << 31;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t UniformBuffer(const void* base,
+                                                                unsigned long long bytes) {
+  const unsigned long long b = UniformU64(bytes);
+  return __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void*>(UniformU64(reinterpret_cast<unsigned long long>(base))), 0,
+      b < kMaxBufferBytes ? static_cast<int>(b) : 0, 0x00020000);
+}
+
 // lround(t / res - 0.5) -- MapLimits::GetCellIndex (mapping/2d/map_limits.h:69-76) --
 // without the f64 division in the common case.  With inv = RN(1 / res), v0 = t * inv - 0.5
 // differs from the reference's value by less than |t / res| * 2^-50 + 2^-52; when v0 is

@@ -1134,25 +1134,67 @@ __device__ __forceinline__ void ScoreChildren(const BlockContext& ctx, int dx, i
   // Packed accumulators: (s00 | s10 << 16) and (s01 | s11 << 16); a lane adds at most
   // 255 per point, so 256 points fit before the halves are widened.
   int s00 = 0, s01 = 0, s10 = 0, s11 = 0;   // s[x-step][y-step]
-  for (int base = threadIdx.x; base < n; base += 256 * 256) {
-    uint32_t even = 0, odd = 0;
-    const int stop = min(n, base + 256 * 256);
+  // The gathers of the unrolled loop are meant to be in flight together.  Until the end of
+  // round 3 they were not: `cached ? ctx.cache[i] : gpts[i]` inside the body gave every unrolled
+  // iteration a branch and a basic block of its own, closed with s_waitcnt vmcnt(0) lgkmcnt(0) --
+  // which also waited for the previous iteration's gather -- and the plain
+  // `quads[inside ? offset : 0]` became a load under an exec mask.  Now: one loop per source of
+  // the cells (compile-time), quads by buffer loads (out-of-range offsets read 0; a level of more
+  // than 2 GB of quads keeps plain loads).
+  // (the level comes out of LDS: the compiler does not take it for wavefront-uniform and would
+  // wrap every buffer load in a waterfall loop -- readfirstlane says it is)
+  const unsigned long long quads_address = reinterpret_cast<unsigned long long>(L.quads);
+  // (readfirstlane returns an int: through `unsigned`, or a low word with its top bit set
+  // sign-extends over the high word -- the first version of this faulted on exactly that)
+  const unsigned long long quads_uniform =
+      static_cast<unsigned long long>(static_cast<unsigned>(
+          __builtin_amdgcn_readfirstlane(static_cast<unsigned>(quads_address)))) |
+      (static_cast<unsigned long long>(static_cast<unsigned>(
+           __builtin_amdgcn_readfirstlane(static_cast<unsigned>(quads_address >> 32)))) << 32);
+  const unsigned long long quad_bytes =
+      static_cast<unsigned long long>((__builtin_amdgcn_readfirstlane(L.qy) + 3) >> 2) *
+      static_cast<unsigned>(__builtin_amdgcn_readfirstlane(L.qtx)) * 128ull;
+  const bool quads_by_buffer = quad_bytes < (1ull << 31);
+  const __amdgpu_buffer_rsrc_t quad_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<uint32_t*>(quads_uniform), 0,
+      quads_by_buffer ? static_cast<int>(quad_bytes) : 0, 0x00020000);
+  const auto walk = [&](auto cached_tag, auto buffer_tag) {
+    constexpr bool kCached = decltype(cached_tag)::value;
+    constexpr bool kBuffer = decltype(buffer_tag)::value;
+    for (int base = threadIdx.x; base < n; base += 256 * 256) {
+      uint32_t even = 0, odd = 0;
+      const int stop = min(n, base + 256 * 256);
 #pragma unroll 4
-    for (int i = base; i < stop; i += 256) {
-      const uint32_t p = cached ? ctx.cache[i] : gpts[i];
-      const int X = static_cast<short>(p & 0xffffu) + dx + off + half;
-      const int Y = static_cast<short>(p >> 16) + dy + off + half;
-      const bool inside = static_cast<unsigned>(X) < static_cast<unsigned>(L.qx) &&
-                          static_cast<unsigned>(Y) < static_cast<unsigned>(L.qy);
-      // Unconditional load from a clamped (always valid) offset, masked afterwards: the
-      // gathers of the unrolled loop are in flight together.
-      const uint32_t q = quads[inside ? QuadOffset(X, Y, L.qtx) : 0u];
-      const uint32_t v = inside ? (q & child_mask) : 0u;
-      even += v & 0x00ff00ffu;          // byte 0 (x0,y0) and byte 2 (x1,y0)
-      odd += (v >> 8) & 0x00ff00ffu;    // byte 1 (x0,y1) and byte 3 (x1,y1)
+      for (int i = base; i < stop; i += 256) {
+        uint32_t p;
+        if constexpr (kCached) p = ctx.cache[i];
+        else p = gpts[i];
+        const int X = static_cast<short>(p & 0xffffu) + dx + off + half;
+        const int Y = static_cast<short>(p >> 16) + dy + off + half;
+        const bool inside = static_cast<unsigned>(X) < static_cast<unsigned>(L.qx) &&
+                            static_cast<unsigned>(Y) < static_cast<unsigned>(L.qy);
+        uint32_t v;
+        if constexpr (kBuffer) {
+          v = __builtin_amdgcn_raw_buffer_load_b32(
+                  quad_rsrc, inside ? QuadOffset(X, Y, L.qtx) * 4u : 0xfffffff0u, 0, 0) &
+              child_mask;
+        } else {
+          const uint32_t q = quads[inside ? QuadOffset(X, Y, L.qtx) : 0u];
+          v = inside ? (q & child_mask) : 0u;
+        }
+        even += v & 0x00ff00ffu;          // byte 0 (x0,y0) and byte 2 (x1,y0)
+        odd += (v >> 8) & 0x00ff00ffu;    // byte 1 (x0,y1) and byte 3 (x1,y1)
+      }
+      s00 += even & 0xffffu; s10 += even >> 16;
+      s01 += odd & 0xffffu;  s11 += odd >> 16;
     }
-    s00 += even & 0xffffu; s10 += even >> 16;
-    s01 += odd & 0xffffu;  s11 += odd >> 16;
+  };
+  if (quads_by_buffer) {
+    if (cached) walk(std::true_type{}, std::true_type{});
+    else walk(std::false_type{}, std::true_type{});
+  } else {
+    if (cached) walk(std::true_type{}, std::false_type{});
+    else walk(std::false_type{}, std::false_type{});
   }
   s00 = WaveSum(s00); s01 = WaveSum(s01); s10 = WaveSum(s10); s11 = WaveSum(s11);
   const int wave = threadIdx.x >> 6;
@@ -1370,6 +1412,14 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
     // (the expensive part: 64 distinct cache lines each) is skipped.  The outcome
     // is the same as scoring all points: no child would have been kept.
     const int parent_ub = SumUpperBound(P, nd.score, n);
+    // (the tiled quad array: ceil(qy / 4) rows of qtx tiles of 32 dwords; a buffer resource
+    // addresses up to 2 GB of it -- a level of more than 23 000 x 23 000 cells keeps plain loads)
+    const unsigned long long quad_bytes =
+        static_cast<unsigned long long>((L.qy + 3) >> 2) * static_cast<unsigned>(L.qtx) * 128ull;
+    const bool quads_by_buffer = quad_bytes < (1ull << 31);
+    const __amdgpu_buffer_rsrc_t quad_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(L.quads), 0, quads_by_buffer ? static_cast<int>(quad_bytes) : 0,
+        0x00020000);
     const auto* quads = AsGlobal(L.quads);
     const uint32_t child_mask =
         (vx ? 0xffffffffu : 0x0000ffffu) & (vy ? 0xffffffffu : 0x00ff00ffu);
@@ -1381,37 +1431,70 @@ ExpandWaveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __res
     // searches: 37 vs 33 us).
     constexpr int kIters = 4;
     constexpr int kGroup = kIters * kWave;
-    for (int q0 = 0; q0 < n; q0 += kGroup) {
-      uint32_t v[kIters];
+    // (The loop is instantiated twice, for stored and for re-derived scan cells.  With the choice
+    // made per point -- `recompute ? ScanCell(...) : pts[...]` inside the unrolled body, as it
+    // stood until the end of round 3 -- every one of the four "gathers in flight" began with a
+    // branch and a basic block of its own, and the compiler closed each with s_waitcnt vmcnt(0):
+    // ONE gather in flight per wavefront, sixteen dependent round trips per node.)
+    const auto walk = [&](auto recompute_tag, auto buffer_tag) {
+      constexpr bool kRecompute = decltype(recompute_tag)::value;
+      constexpr bool kBuffer = decltype(buffer_tag)::value;
+      for (int q0 = 0; q0 < n; q0 += kGroup) {
+        uint32_t cell[kIters];
 #pragma unroll
-      for (int u = 0; u < kIters; ++u) {
-        const int q = q0 + u * kWave + lane;
-        const bool live = q < n;
-        const uint32_t p = recompute ? ScanCell(P, rot, live ? q : 0) : pts[live ? q : 0];
-        const int X = static_cast<short>(p & 0xffffu) + nd.dx + off + half;
-        const int Y = static_cast<short>(p >> 16) + nd.dy + off + half;
-        const bool inside = live && static_cast<unsigned>(X) < static_cast<unsigned>(L.qx) &&
-                            static_cast<unsigned>(Y) < static_cast<unsigned>(L.qy);
-        const uint32_t quad = quads[inside ? QuadOffset(X, Y, L.qtx) : 0u];   // one gather, four children
-        v[u] = inside ? (quad & child_mask) : 0u;
-      }
+        for (int u = 0; u < kIters; ++u) {      // the four cells first: independent loads
+          const int q = q0 + u * kWave + lane;
+          const int at = q < n ? q : 0;
+          if constexpr (kRecompute) cell[u] = ScanCell(P, rot, at);
+          else cell[u] = pts[at];
+        }
+        uint32_t v[kIters];
 #pragma unroll
-      for (int u = 0; u < kIters; ++u) {
-        const int a00 = v[u] & 0xff, a01 = (v[u] >> 8) & 0xff;
-        const int a10 = (v[u] >> 16) & 0xff, a11 = v[u] >> 24;
-        s00 += a00; s01 += a01; s10 += a10; s11 += a11;
-        seen_max += max(max(a00, a01), max(a10, a11));
+        for (int u = 0; u < kIters; ++u) {
+          const int q = q0 + u * kWave + lane;
+          const bool live = q < n;
+          const uint32_t p = cell[u];
+          const int X = static_cast<short>(p & 0xffffu) + nd.dx + off + half;
+          const int Y = static_cast<short>(p >> 16) + nd.dy + off + half;
+          const bool inside = live && static_cast<unsigned>(X) < static_cast<unsigned>(L.qx) &&
+                              static_cast<unsigned>(Y) < static_cast<unsigned>(L.qy);
+          // one gather, four children.  A buffer load: the compiler turned the plain
+          // `quads[inside ? offset : 0]` into a load under an exec mask with its own s_waitcnt --
+          // the four gathers went out one after the other.  Out-of-range offsets read 0.
+          if constexpr (kBuffer) {
+            const uint32_t quad = __builtin_amdgcn_raw_buffer_load_b32(
+                quad_rsrc, inside ? QuadOffset(X, Y, L.qtx) * 4u : 0xfffffff0u, 0, 0);
+            v[u] = quad & child_mask;
+          } else {
+            const uint32_t quad = quads[inside ? QuadOffset(X, Y, L.qtx) : 0u];
+            v[u] = inside ? (quad & child_mask) : 0u;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kIters; ++u) {
+          const int a00 = v[u] & 0xff, a01 = (v[u] >> 8) & 0xff;
+          const int a10 = (v[u] >> 16) & 0xff, a11 = v[u] >> 24;
+          s00 += a00; s01 += a01; s10 += a10; s11 += a11;
+          seen_max += max(max(a00, a01), max(a10, a11));
+        }
+        ++groups;
+        if (q0 + kGroup < n) {
+          // max_k sum_lanes(s_k) <= sum_lanes(max_k s_k): ONE wavefront reduction (of what the
+          // best child of each lane's points still lacks to the parent) instead of five -- a
+          // slightly looser bound, the same results (the check only skips work that cannot
+          // matter), 8 of 54 vector instructions per gather less.
+          const int lacking = seen_max - max(max(s00, s01), max(s10, s11));
+          // kept children satisfy score >= best (> best in strict mode)
+          if (ToScore(P, parent_ub - WaveSum(lacking), n) < best) { dead = true; break; }
+        }
       }
-      ++groups;
-      if (q0 + kGroup < n) {
-        // max_k sum_lanes(s_k) <= sum_lanes(max_k s_k): ONE wavefront reduction (of what the
-        // best child of each lane's points still lacks to the parent) instead of five -- a
-        // slightly looser bound, the same results (the check only skips work that cannot
-        // matter), 8 of 54 vector instructions per gather less.
-        const int lacking = seen_max - max(max(s00, s01), max(s10, s11));
-        // kept children satisfy score >= best (> best in strict mode)
-        if (ToScore(P, parent_ub - WaveSum(lacking), n) < best) { dead = true; break; }
-      }
+    };
+    if (quads_by_buffer) {
+      if (recompute) walk(std::true_type{}, std::true_type{});
+      else walk(std::false_type{}, std::true_type{});
+    } else {
+      if (recompute) walk(std::true_type{}, std::false_type{});
+      else walk(std::false_type{}, std::false_type{});
     }
     const auto count_node = [&](int nvalid) {     // lane 0
       atomicAdd(&stat_gathers, static_cast<unsigned>(min(groups * kIters, (n + kWave - 1) / kWave)));

@@ -75,10 +75,20 @@ struct List3 {
 // the brick 0; s = the level's child stride 2^min(level, full_resolution_depth - 1).  One
 // gather per point and node instead of four (eight in round 1); 8x the bytes of the level
 // itself, i.e. ~90 MB per 150^3 submap instead of 12 -- HBM is not the scarce resource.
+typedef int I4 __attribute__((ext_vector_type(4)));   // (an int4 the compiler can load from address space 1)
+
 struct OctDesc {
   const uint2* cells;      // [(nz + s)][(ny + s)][(nx + s)]; null: not built
   int qx, qy, qz, s;
 };
+
+// Bytes of a level's oct array (the buffer resource's range); 0 = not addressable by one
+// (>= 2 GB: a level of more than ~640^3 cells keeps plain loads).
+__device__ __forceinline__ unsigned long long OctBytes(const OctDesc& O) {
+  const unsigned long long bytes =
+      static_cast<unsigned long long>(O.qx) * O.qy * static_cast<unsigned long long>(O.qz) * 8ull;
+  return bytes < kMaxBufferBytes ? bytes : 0ull;
+}
 
 struct Fast3DProblem {
   Brick level[kMaxDepth];
@@ -189,6 +199,14 @@ __device__ __forceinline__ int3 DepthIndex(const int4& c, int e, int sx, int sy,
   if (e == 0) return make_int3(c.x, c.y, c.z);
   return make_int3(((c.x + sx) >> e) - (sx >> e), ((c.y + sy) >> e) - (sy >> e),
                    ((c.z + sz) >> e) - (sz >> e));
+}
+
+// The same without the branch on e (for e == 0 the shifts are no-ops and the expression is c):
+// a branch inside an unrolled gather loop is a basic-block boundary the loads cannot cross.
+__device__ __forceinline__ int3 DepthIndexAny(int cx, int cy, int cz, int e, int sx, int sy,
+                                              int sz) {
+  return make_int3(((cx + sx) >> e) - (sx >> e), ((cy + sy) >> e) - (sy >> e),
+                   ((cz + sz) >> e) - (sz >> e));
 }
 
 // Integer sum of one candidate, one wave (ScoreCandidates, :332-355).
@@ -445,21 +463,56 @@ __device__ __forceinline__ void ChildSums3D(const Fast3DProblem& P, const Node3D
       // One 8-byte gather per point: the eight child cells (see OctDesc).  Bytes are summed
       // as packed 16-bit pairs, widened every 256 points.
       const int ox = fx[0] + O.s, oy = fy[0] + O.s, oz = fz[0] + O.s;
-      for (int q0 = first; q0 < P.n; q0 += 256 * stride) {
+      // (round 4: through a buffer resource when the array is addressable by one -- the plain
+      // `O.cells[inside ? index : 0]` was a flat load under an exec mask with a wait of its
+      // own, so the four gathers of the unrolled loop went out one after the other)
+      const unsigned long long oct_bytes = OctBytes(O);
+      const __amdgpu_buffer_rsrc_t oct = UniformBuffer(O.cells, oct_bytes);
+      const auto* gcells = AsGlobal(reinterpret_cast<const I4*>(cells));
+      const int n = P.n, wxy = P.wxy, wz = P.wz;
+      typedef unsigned U2 __attribute__((ext_vector_type(2)));
+      for (int q0 = first; q0 < n; q0 += 256 * stride) {
         unsigned e0 = 0, o0 = 0, e1 = 0, o1 = 0;
-        const int stop = min(P.n, q0 + 256 * stride);
+        const int stop = min(n, q0 + 256 * stride);
+        if (oct_bytes != 0) {
+          constexpr int kPoints = 4;             // cells first, then their four gathers
+          for (int q = q0; q < stop; q += kPoints * stride) {
+            I4 cv[kPoints];
+#pragma unroll
+            for (int u = 0; u < kPoints; ++u) cv[u] = gcells[min(q + u * stride, n - 1)];
+            U2 w[kPoints];
+#pragma unroll
+            for (int u = 0; u < kPoints; ++u) {
+              const int3 d = DepthIndexAny(cv[u].x, cv[u].y, cv[u].z, e, -wxy, -wxy, -wz);
+              const int X = d.x + ox, Y = d.y + oy, Z = d.z + oz;
+              const bool inside = q + u * stride < stop &&
+                                  static_cast<unsigned>(X) < static_cast<unsigned>(O.qx) &&
+                                  static_cast<unsigned>(Y) < static_cast<unsigned>(O.qy) &&
+                                  static_cast<unsigned>(Z) < static_cast<unsigned>(O.qz);
+              const unsigned offset = static_cast<unsigned>((Z * O.qy + Y) * O.qx + X) * 8u;
+              w[u] = __builtin_bit_cast(U2, __builtin_amdgcn_raw_buffer_load_b64(
+                                                oct, inside ? offset : kOutOfBuffer, 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < kPoints; ++u) {
+              e0 += w[u].x & 0x00ff00ffu; o0 += (w[u].x >> 8) & 0x00ff00ffu;
+              e1 += w[u].y & 0x00ff00ffu; o1 += (w[u].y >> 8) & 0x00ff00ffu;
+            }
+          }
+        } else {
 #pragma unroll 4
-        for (int q = q0; q < stop; q += stride) {
-          const int3 d = DepthIndex(cells[q], e, -P.wxy, -P.wxy, -P.wz);
-          const int X = d.x + ox, Y = d.y + oy, Z = d.z + oz;
-          const bool inside = static_cast<unsigned>(X) < static_cast<unsigned>(O.qx) &&
-                              static_cast<unsigned>(Y) < static_cast<unsigned>(O.qy) &&
-                              static_cast<unsigned>(Z) < static_cast<unsigned>(O.qz);
-          // unconditional load from a valid offset, masked afterwards
-          const uint2 w = O.cells[inside ? (static_cast<size_t>(Z) * O.qy + Y) * O.qx + X : 0];
-          const unsigned lo = inside ? w.x : 0u, hi = inside ? w.y : 0u;
-          e0 += lo & 0x00ff00ffu; o0 += (lo >> 8) & 0x00ff00ffu;
-          e1 += hi & 0x00ff00ffu; o1 += (hi >> 8) & 0x00ff00ffu;
+          for (int q = q0; q < stop; q += stride) {
+            const int3 d = DepthIndex(cells[q], e, -P.wxy, -P.wxy, -P.wz);
+            const int X = d.x + ox, Y = d.y + oy, Z = d.z + oz;
+            const bool inside = static_cast<unsigned>(X) < static_cast<unsigned>(O.qx) &&
+                                static_cast<unsigned>(Y) < static_cast<unsigned>(O.qy) &&
+                                static_cast<unsigned>(Z) < static_cast<unsigned>(O.qz);
+            // unconditional load from a valid offset, masked afterwards
+            const uint2 w = O.cells[inside ? (static_cast<size_t>(Z) * O.qy + Y) * O.qx + X : 0];
+            const unsigned lo = inside ? w.x : 0u, hi = inside ? w.y : 0u;
+            e0 += lo & 0x00ff00ffu; o0 += (lo >> 8) & 0x00ff00ffu;
+            e1 += hi & 0x00ff00ffu; o1 += (hi >> 8) & 0x00ff00ffu;
+          }
         }
         sum[0] += e0 & 0xffffu; sum[2] += e0 >> 16;      // bytes 0, 2 of the low word
         sum[1] += o0 & 0xffffu; sum[3] += o0 >> 16;      // bytes 1, 3
@@ -722,9 +775,78 @@ __device__ __forceinline__ void ExpandNode3D(const Fast3DProblem& P, const Node3
 // `half` cells apart: the two x positions share a line, the cell record and its depth index
 // are computed once per point for all members, and up to eight gathers per point are in
 // flight together.  Returns false (nothing summed) when the level has no oct grid.
+// The family loop for a compile-time family size F (round 4).  Until the end of round 3 the
+// member loop `if (m >= fam || !(live >> m & 1)) continue;` gave every member a basic block of
+// its own -- flat_load_dwordx2 with 64-bit address arithmetic, closed by s_waitcnt vmcnt(0)
+// lgkmcnt(0): ONE gather in flight per wavefront where the comment above promises eight.  Now
+// the loop body is branch-free: oct words come through a buffer resource (32-bit offsets; dead
+// members and cells outside the grid use an out-of-range offset, which reads 0 and fetches
+// nothing), so the F gathers of a point -- 2 F with the unroll -- go out back to back.
+template <int F>
+__device__ __forceinline__ void FamilyLoop3D(__amdgpu_buffer_rsrc_t oct, const OctDesc& O,
+                                             const I4 CMX_GLOBAL* __restrict__ cells, int n,
+                                             int e, int wxy, int wz, const int (&mx)[8],
+                                             const int (&my)[8], const int (&mz)[8],
+                                             unsigned live, int first, int stride,
+                                             ExpandShared* sh) {
+  typedef unsigned U2 __attribute__((ext_vector_type(2)));
+  constexpr int kPoints = 2;          // points per iteration: 2 F gathers in flight
+  // (n <= 256 * stride, FamilySums3D checks it: a lane adds at most 255 per point, so the
+  // packed 16-bit halves cannot overflow and are widened once, after the loop)
+  unsigned acc[F][4];
+#pragma unroll
+  for (int m = 0; m < F; ++m) acc[m][0] = acc[m][1] = acc[m][2] = acc[m][3] = 0;
+  for (int q = first; q < n; q += kPoints * stride) {
+    I4 cv[kPoints];
+#pragma unroll
+    for (int u = 0; u < kPoints; ++u) cv[u] = cells[min(q + u * stride, n - 1)];
+    U2 w[kPoints][F];
+#pragma unroll
+    for (int u = 0; u < kPoints; ++u) {
+      const bool in_cloud = q + u * stride < n;
+      const int3 d = DepthIndexAny(cv[u].x, cv[u].y, cv[u].z, e, -wxy, -wxy, -wz);
+#pragma unroll
+      for (int m = 0; m < F; ++m) {
+        const int X = d.x + mx[m], Y = d.y + my[m], Z = d.z + mz[m];
+        const bool inside = in_cloud && (live >> m & 1) &&
+                            static_cast<unsigned>(X) < static_cast<unsigned>(O.qx) &&
+                            static_cast<unsigned>(Y) < static_cast<unsigned>(O.qy) &&
+                            static_cast<unsigned>(Z) < static_cast<unsigned>(O.qz);
+        const unsigned offset = static_cast<unsigned>((Z * O.qy + Y) * O.qx + X) * 8u;
+        w[u][m] = __builtin_bit_cast(U2, __builtin_amdgcn_raw_buffer_load_b64(
+                                             oct, inside ? offset : kOutOfBuffer, 0, 0));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kPoints; ++u) {
+#pragma unroll
+      for (int m = 0; m < F; ++m) {
+        acc[m][0] += w[u][m].x & 0x00ff00ffu; acc[m][1] += (w[u][m].x >> 8) & 0x00ff00ffu;
+        acc[m][2] += w[u][m].y & 0x00ff00ffu; acc[m][3] += (w[u][m].y >> 8) & 0x00ff00ffu;
+      }
+    }
+  }
+  // Wave totals of the live members' eight child sums, left in sh->fam_partial[wave][m][k]
+  // (the caller adds the four waves after a barrier).
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int m = 0; m < F; ++m) {
+    if (!(live >> m & 1)) continue;                   // block-uniform
+    const int s8[8] = {static_cast<int>(acc[m][0] & 0xffffu), static_cast<int>(acc[m][1] & 0xffffu),
+                       static_cast<int>(acc[m][0] >> 16),     static_cast<int>(acc[m][1] >> 16),
+                       static_cast<int>(acc[m][2] & 0xffffu), static_cast<int>(acc[m][3] & 0xffffu),
+                       static_cast<int>(acc[m][2] >> 16),     static_cast<int>(acc[m][3] >> 16)};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int total = WaveSum(s8[k]);
+      if (lane == 0) sh->fam_partial[wave][m][k] = total;
+    }
+  }
+}
+
 __device__ __forceinline__ bool FamilySums3D(const Fast3DProblem& P, const Node3D* fam_nodes,
                                              int fam, unsigned live, int first, int stride,
-                                             int (&sum)[8][8]) {
+                                             ExpandShared* sh) {
   const int child_depth = fam_nodes[0].level - 1;
   const int half = 1 << child_depth;
   const int e = max(0, child_depth - P.full_resolution_depth + 1);
@@ -732,43 +854,29 @@ __device__ __forceinline__ bool FamilySums3D(const Fast3DProblem& P, const Node3
   const OctDesc O = P.oct[child_depth];
   if (O.cells == nullptr || g_fast3d_byte_loads) return false;
   if ((((fam_nodes[0].ox + half) >> e) - (fam_nodes[0].ox >> e)) != O.s) return false;
-  const int4* __restrict__ cells = P.cells + static_cast<size_t>(fam_nodes[0].scan) * P.n;
-  int mx[8], my[8], mz[8];
+  const unsigned long long oct_bytes = OctBytes(O);
+  if (oct_bytes == 0) return false;                 // (the per-node path has plain loads)
+  const __amdgpu_buffer_rsrc_t oct = UniformBuffer(O.cells, oct_bytes);
+  const auto* cells = AsGlobal(
+      reinterpret_cast<const I4*>(P.cells + static_cast<size_t>(fam_nodes[0].scan) * P.n));
+  if (P.n > 256 * stride) return false;            // (packed sums: see FamilyLoop3D)
+  int mx[8], my[8], mz[8];                          // block-uniform (the family lies in LDS)
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
     const Node3D& nd = fam_nodes[min(m, fam - 1)];
-    mx[m] = (nd.ox >> e) - L.lo_x + O.s;
-    my[m] = (nd.oy >> e) - L.lo_y + O.s;
-    mz[m] = (nd.oz >> e) - L.lo_z + O.s;
+    mx[m] = __builtin_amdgcn_readfirstlane((nd.ox >> e) - L.lo_x + O.s);
+    my[m] = __builtin_amdgcn_readfirstlane((nd.oy >> e) - L.lo_y + O.s);
+    mz[m] = __builtin_amdgcn_readfirstlane((nd.oz >> e) - L.lo_z + O.s);
   }
-  for (int q0 = first; q0 < P.n; q0 += 256 * stride) {
-    unsigned acc[8][4];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) acc[m][0] = acc[m][1] = acc[m][2] = acc[m][3] = 0;
-    const int stop = min(P.n, q0 + 256 * stride);
-#pragma unroll 2
-    for (int q = q0; q < stop; q += stride) {
-      const int3 d = DepthIndex(cells[q], e, -P.wxy, -P.wxy, -P.wz);
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        if (m >= fam || !(live >> m & 1)) continue;          // block-uniform
-        const int X = d.x + mx[m], Y = d.y + my[m], Z = d.z + mz[m];
-        const bool inside = static_cast<unsigned>(X) < static_cast<unsigned>(O.qx) &&
-                            static_cast<unsigned>(Y) < static_cast<unsigned>(O.qy) &&
-                            static_cast<unsigned>(Z) < static_cast<unsigned>(O.qz);
-        const uint2 w = O.cells[inside ? (static_cast<size_t>(Z) * O.qy + Y) * O.qx + X : 0];
-        const unsigned lo = inside ? w.x : 0u, hi = inside ? w.y : 0u;
-        acc[m][0] += lo & 0x00ff00ffu; acc[m][1] += (lo >> 8) & 0x00ff00ffu;
-        acc[m][2] += hi & 0x00ff00ffu; acc[m][3] += (hi >> 8) & 0x00ff00ffu;
-      }
-    }
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      sum[m][0] += acc[m][0] & 0xffffu; sum[m][2] += acc[m][0] >> 16;
-      sum[m][1] += acc[m][1] & 0xffffu; sum[m][3] += acc[m][1] >> 16;
-      sum[m][4] += acc[m][2] & 0xffffu; sum[m][6] += acc[m][2] >> 16;
-      sum[m][5] += acc[m][3] & 0xffffu; sum[m][7] += acc[m][3] >> 16;
-    }
+  const int n = P.n, wxy = P.wxy, wz = P.wz;
+  switch (fam) {                                    // block-uniform
+    case 2: FamilyLoop3D<2>(oct, O, cells, n, e, wxy, wz, mx, my, mz, live, first, stride, sh); break;
+    case 3: FamilyLoop3D<3>(oct, O, cells, n, e, wxy, wz, mx, my, mz, live, first, stride, sh); break;
+    case 4: FamilyLoop3D<4>(oct, O, cells, n, e, wxy, wz, mx, my, mz, live, first, stride, sh); break;
+    case 5: FamilyLoop3D<5>(oct, O, cells, n, e, wxy, wz, mx, my, mz, live, first, stride, sh); break;
+    case 6: FamilyLoop3D<6>(oct, O, cells, n, e, wxy, wz, mx, my, mz, live, first, stride, sh); break;
+    case 7: FamilyLoop3D<7>(oct, O, cells, n, e, wxy, wz, mx, my, mz, live, first, stride, sh); break;
+    default: FamilyLoop3D<8>(oct, O, cells, n, e, wxy, wz, mx, my, mz, live, first, stride, sh); break;
   }
   return true;
 }
@@ -817,23 +925,8 @@ Expand3DKernel(const Fast3DProblem* __restrict__ problems, List3 in, int strict,
     if (live == 0) continue;                                              // block-uniform
     bool summed = false;
     if (fam > 1 && use_families) {
-      int sum[8][8];
-#pragma unroll
-      for (int m = 0; m < 8; ++m)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) sum[m][k] = 0;
-      summed = FamilySums3D(P, sh.fam, fam, live, threadIdx.x, 256, sum);
+      summed = FamilySums3D(P, sh.fam, fam, live, threadIdx.x, 256, &sh);
       if (summed) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          if (m >= fam || !(live >> m & 1)) continue;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const int total = WaveSum(sum[m][k]);
-            if (lane == 0) sh.fam_partial[wave][m][k] = total;
-          }
-        }
         __syncthreads();
         if (threadIdx.x < 64) {
           const int m = threadIdx.x >> 3, k = threadIdx.x & 7;
