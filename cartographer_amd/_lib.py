@@ -57,7 +57,8 @@ class MatchStats(C.Structure):
                 ("nodes_expanded", C.c_int64), ("num_scans", C.c_int32), ("expansion_launches", C.c_int32),
                 ("device_ms", C.c_double), ("dominant_kernel_ms", C.c_double),
                 ("expansion_ms", C.c_double), ("expansion_nodes", C.c_int64),
-                ("expansion_lookups", C.c_int64)]
+                ("expansion_lookups", C.c_int64), ("refined_candidates", C.c_int64),
+                ("finalists", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -159,6 +160,9 @@ EXPORTED_SYMBOLS = [
     "cmx_pack_best_key", "cmx_unpack_best_key",
     "cmx_voxel_filter", "cmx_adaptive_voxel_filter", "cmx_compute_histogram",
 ]
+
+# include/cartographer_mi355x_debug.h (test and tool switches, not part of the boundary).
+DEBUG_SYMBOLS = ["cmx_debug_set", "cmx_debug_reset"]
 
 _lib = None
 
@@ -306,8 +310,23 @@ def lib():
                                          C.c_void_p, P(MatchStats)]
     L.cmx_fast3d_level_info.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     L.cmx_fast3d_level_cells.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    if hasattr(L, "cmx_debug_set"):        # (absent from the round-3 library the A/B tools load)
+        L.cmx_debug_set.argtypes = [C.c_char_p, C.c_int32]
+        L.cmx_debug_reset.restype = None
     _lib = L
     return L
+
+
+def debug_set(**switches):
+    """cmx_debug_set for every keyword (tests and tools: which of two equivalent device paths runs,
+    verification modes, tuning overrides).  Process-wide; `debug_reset()` puts everything back."""
+    L = lib()
+    for name, value in switches.items():
+        check(L.cmx_debug_set(name.encode(), int(value)))
+
+
+def debug_reset():
+    lib().cmx_debug_reset()
 
 
 def check(status):

@@ -62,6 +62,57 @@ cmx_status Guard(F&& body) {
   }
 }
 
+// Test and tool switches (cmx_debug_set, include/cartographer_mi355x_debug.h): which of two
+// equivalent paths runs, verification modes, tuning overrides.  All zero in production; the
+// product reads no environment variable on a call path.  `Debug()` is a relaxed snapshot: set
+// the switches before the calls they should affect.
+#define CMX_DEBUG_OPTIONS(X)                                                                      \
+  X(rt2d_legacy)          /* 1: real-time 2D on the one-thread-per-candidate kernels only */       \
+  X(rt2d_tile)            /* tile core size override (multiple of 8) */                            \
+  X(rt2d_groups)          /* rotation groups per tile override */                                  \
+  X(rt2d_no_image_cache)  /* 1: grid images are always built into scratch of the call */           \
+  X(rt2d_parts)           /* parts a large batch is issued in (0: default) */                      \
+  X(timeline)             /* 1: in-kernel timelines (cmx_device.h Stamp) reported on stderr */     \
+  X(trace)                /* 1: an event after every stage of a call, durations on stderr */       \
+  X(host_trace)           /* 1: wall clock of the host phases of a call on stderr */               \
+  X(sync)                 /* 1: synchronise after every stage (localises a faulting kernel) */     \
+  X(no_copy_kernels)      /* 1: small transfers by copy commands instead of a copy kernel */       \
+  X(frontier_capacity)    /* nodes per frontier / leaf buffer (tests: forces the overflow path) */ \
+  X(fast2d_unfused)       /* 1: fast 2D front end as separate prep / score launches */             \
+  X(fast2d_store_scans)   /* 1: never keep the surviving scans' cells, 2: always */                \
+  X(fast2d_fused_threads) /* threads per block of the fused front end */                           \
+  X(fast2d_levels_per_stage) /* levels per depth-first stage */                                   \
+  X(fast2d_wave_levels)   /* k > 0: k - 1 levels of wave-per-node expansion */                     \
+  X(fast2d_xcd_affinity)  /* 1: nodes of a problem on any XCD, 2: on one */                        \
+  X(fast3d_byte_loads)    /* 1: every child cell with its own byte load */                         \
+  X(fast3d_affinity)      /* 1: nodes of a problem on any XCD, 2: on one */                        \
+  X(fast3d_no_families)   /* 1: one node per block in the 3D expansion */                          \
+  X(fast3d_no_oct)        /* 1: no oct words (byte levels only) */                                 \
+  X(fast3d_batch)         /* pairs per chain of launches */                                        \
+  X(rt3d_legacy)          /* 1: real-time 3D on the exhaustive per-candidate kernel only */        \
+  X(rt3d_no_tiles)        /* 1: bulk passes by memory gathers instead of LDS tiles */              \
+  X(rt3d_verify)          /* 1: every bound checked on the device against what it bounds */        \
+  X(rt3d_crosscheck)      /* 1: tiled passes next to the gather kernels, every sum compared */     \
+  X(rt3d_expand_all)      /* 1: every group expanded (with rt3d_verify: every group bound checked) */ \
+  X(rt3d_unstaged)        /* 1: second candidate round in one piece */                             \
+  X(rt3d_no_boxes)        /* 1: chunk boxes computed inside the tile kernels */                    \
+  X(rt3d_report)          /* 1: pass-by-pass report on stderr */                                   \
+  X(rt3d_segments)        /* segment schedule override (percent | percent << 8) */                 \
+  X(rt3d_group_rotations) /* rotations per group-pass workgroup */                                 \
+  X(rt3d_group_tile_kb)   /* LDS tile capacity of the group pass */                                \
+  X(rt3d_group_float)     /* 1: group centres in f32 instead of fixed point */                     \
+  X(rt3d_cand_threads)    /* threads per candidate-pass workgroup */                               \
+  X(rt3d_cand_rotations)  /* rotations per candidate work list */                                  \
+  X(rt3d_cand_tile_kb)    /* LDS tile capacity of the candidate pass */
+struct DebugOptions {
+#define CMX_DEBUG_FIELD(name) int name = 0;
+  CMX_DEBUG_OPTIONS(CMX_DEBUG_FIELD)
+#undef CMX_DEBUG_FIELD
+};
+const DebugOptions& Debug();
+// name = a field of DebugOptions; false: unknown name.
+bool DebugSet(const char* name, int value);
+
 // Validates `device` (fails loudly without a GPU) and makes it current.
 void UseDevice(int device);
 

@@ -183,6 +183,22 @@ void ParallelFor(int n, int serial_below, const std::function<void(int)>& fn) {
   pool.Run(n, fn);
 }
 
+// ---------------------------------------------------------------------------
+// Debug switches (cmx_debug_set)
+// ---------------------------------------------------------------------------
+namespace {
+DebugOptions g_debug;       // (plain ints written by cmx_debug_set before the calls they affect)
+}
+const DebugOptions& Debug() { return g_debug; }
+bool DebugSet(const char* name, int value) {
+  if (name == nullptr) return false;
+#define CMX_DEBUG_SET(field) \
+  if (std::strcmp(name, #field) == 0) { g_debug.field = value; return true; }
+  CMX_DEBUG_OPTIONS(CMX_DEBUG_SET)
+#undef CMX_DEBUG_SET
+  return false;
+}
+
 void SetLastError(const char* fmt, ...) {
   char buf[1024];
   va_list ap;
@@ -292,13 +308,7 @@ void StageTrace::Report() {
   fprintf(stderr, "\n");
 }
 
-bool TimelineEnabled() {
-  static const bool enabled = [] {
-    const char* env = getenv("CMX_TIMELINE");
-    return env && env[0] == '1';
-  }();
-  return enabled;
-}
+bool TimelineEnabled() { return Debug().timeline != 0; }
 
 void ReportTimeline(const char* name, const unsigned long long* device, int blocks,
                     hipStream_t stream) {
@@ -370,7 +380,18 @@ WorkspaceLease::~WorkspaceLease() {
 
 extern "C" {
 
-const char* cmx_version(void) { return "cartographer_mi355x 0.1 (gfx950)"; }
+const char* cmx_version(void) { return "cartographer_mi355x 0.2 (gfx950)"; }
+
+cmx_status cmx_debug_set(const char* name, int32_t value) {
+  return cmx::Guard([&] {
+    CMX_REQUIRE(cmx::DebugSet(name, value), "unknown debug switch '%s'", name ? name : "(null)");
+  });
+}
+void cmx_debug_reset(void) {
+#define CMX_DEBUG_RESET(field) (void)cmx::DebugSet(#field, 0);
+  CMX_DEBUG_OPTIONS(CMX_DEBUG_RESET)
+#undef CMX_DEBUG_RESET
+}
 
 const char* cmx_status_string(cmx_status s) {
   switch (s) {

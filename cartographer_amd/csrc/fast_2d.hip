@@ -2085,12 +2085,9 @@ struct PreparedBatch {
   int timeline_blocks = 0;
 };
 
-// CMX_FUSED=0 routes every problem through the separate prep / score launches (the
-// fallback of problems the fused kernel does not take); parity tests run both.
-bool FusedEnabled() {
-  const char* e = getenv("CMX_FUSED");
-  return !(e && e[0] == '0');
-}
+// The debug switch fast2d_unfused routes every problem through the separate prep / score
+// launches (the fallback of problems the fused kernel does not take); parity tests run both.
+bool FusedEnabled() { return Debug().fast2d_unfused == 0; }
 
 // Blocks of PrepScoreFusedKernel the whole chip holds at once (occupancy query, cached).
 long long FusedResidentBlocks(int device, int threads, size_t lds_bytes) {
@@ -2248,12 +2245,9 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     out->d_timeline = static_cast<unsigned long long*>(ws.dev[15].Reserve(bytes));
     CMX_HIP(hipMemsetAsync(out->d_timeline, 0, bytes, ws.stream));
   }
-  // Batches keep the cells of surviving scans (CMX_STORE_SCANS=0/1 overrides).
-  static const int kStoreScans = [] {
-    const char* e = getenv("CMX_STORE_SCANS");
-    return e ? atoi(e) : -1;
-  }();
-  const int store_scans = kStoreScans >= 0 ? kStoreScans : (num >= 4 ? 1 : 0);
+  // Batches keep the cells of surviving scans (debug switch fast2d_store_scans overrides).
+  const int store_override = Debug().fast2d_store_scans;
+  const int store_scans = store_override ? store_override - 1 : (num >= 4 ? 1 : 0);
   size_t disc_off = 0, scan_off = 0, coarse_off = 0;
   for (int p = 0; p < num; ++p) {
     const Fast2DMatcher& m = *matchers[p];
@@ -2323,7 +2317,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     for (int t : {256, 192, 128}) {
       if (blocks <= FusedResidentBlocks(ws.device, t, lds)) { threads = t; break; }
     }
-    if (const char* e = getenv("CMX_FUSED_THREADS")) threads = atoi(e);   // experiments
+    if (Debug().fast2d_fused_threads > 0) threads = Debug().fast2d_fused_threads;   // experiments
     if (out->trace && out->trace->enabled())
       fprintf(stderr, "[cmx trace] fused front end: %lld blocks x %d threads, %zu B LDS\n", blocks,
               threads, lds);
@@ -2402,11 +2396,9 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
   for (const Fast2DProblem& P : batch.h_problems)
     CMX_REQUIRE(P.depth == depth, "all matchers of a batch must share branch_and_bound_depth");
 
-  // Nodes per frontier / leaf buffer.  CMX_FRONTIER_CAPACITY / CMX_LEAF_CAPACITY shrink them
+  // Nodes per frontier / leaf buffer.  The debug switch frontier_capacity shrinks the frontiers
   // (tests only) so that the overflow -> strict, chunked retry below is exercised.
-  const auto capacity = [](const char* name, int fallback) {
-    const char* e = getenv(name);
-    const int v = e ? atoi(e) : 0;
+  const auto capacity = [](int v, int fallback) {
     return v >= kSubLists ? std::min(v, fallback) / kSubLists * kSubLists : fallback;
   };
   // 64 K nodes per problem (a weak match keeps ~30 k lowest-resolution nodes alive), at
@@ -2414,8 +2406,8 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
   // an overflow costs a whole second, chunked pass (64 submaps: 34 -> 20 ms per scan).
   const int frontier_default = static_cast<int>(
       std::min<long long>(1ll << 25, std::max<long long>(1ll << 21, 65536ll * num)));
-  const int kFrontierCapacity = capacity("CMX_FRONTIER_CAPACITY", frontier_default);
-  const int kLeafCapacity = capacity("CMX_LEAF_CAPACITY", 1 << 20);
+  const int kFrontierCapacity = capacity(Debug().frontier_capacity, frontier_default);
+  const int kLeafCapacity = capacity(0, 1 << 20);
   const int kFrontierSub = kFrontierCapacity / kSubLists, kLeafSub = kLeafCapacity / kSubLists;
   Node2D* d_front[2] = {ws.dev[10].ReserveAs<Node2D>(kFrontierCapacity),
                         ws.dev[11].ReserveAs<Node2D>(kFrontierCapacity)};
@@ -2469,14 +2461,8 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
     // Top of the tree (two levels) per scan, then the subtrees of the
     // survivors down to the leaves on many blocks.
     // Stage shape (tunable for experiments through the environment).
-    static const int kLevelsPerStage = [] {
-      const char* e = getenv("CMX_LEVELS_PER_STAGE");
-      return e ? std::max(1, atoi(e)) : 0;
-    }();
-    static const int kWaveLevels = [] {
-      const char* e = getenv("CMX_WAVE_LEVELS");
-      return e ? std::max(0, atoi(e)) : -1;
-    }();
+    const int kLevelsPerStage = std::max(0, Debug().fast2d_levels_per_stage);
+    const int kWaveLevels = Debug().fast2d_wave_levels > 0 ? Debug().fast2d_wave_levels - 1 : -1;
     // Single searches are latency-bound: one wave stage, then one depth-first
     // kernel down to the leaves.  Batches are throughput-bound: two wave stages,
     // then depth-first stages of two levels.
@@ -2485,12 +2471,9 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
     // Frontier sizes are only known on the device; grids are sized for the
     // typical case (a few thousand nodes at the top, tens below) and every
     // kernel grid-strides, so larger frontiers (big batches) still fill the chip.
-    // Batches: one problem's nodes stay on one XCD (CMX_XCD_AFFINITY=0/1 overrides).
-    static const int kAffinity = [] {
-      const char* e = getenv("CMX_XCD_AFFINITY");
-      return e ? atoi(e) : -1;
-    }();
-    const int affinity = kAffinity >= 0 ? kAffinity : (num >= 16 ? 1 : 0);
+    // Batches: one problem's nodes stay on one XCD (debug switch fast2d_xcd_affinity overrides).
+    const int affinity_override = Debug().fast2d_xcd_affinity;
+    const int affinity = affinity_override ? affinity_override - 1 : (num >= 16 ? 1 : 0);
     const int wide_blocks = std::min(4096, 1024 * std::max(1, (num + 3) / 4));
     const int narrow_blocks = std::min(4096, 512 * std::max(1, (num + 3) / 4));
     int num_chunks = 1;

@@ -434,7 +434,7 @@ __device__ __forceinline__ float LowResolutionScore(const Fast3DProblem& P, cons
   return acc / static_cast<float>(P.n_low);
 }
 
-// CMX_FAST3D_WIDE=0 (tools / tests): every child cell with its own byte load.
+// Debug switch fast3d_byte_loads (tools / tests): every child cell with its own byte load.
 __device__ int g_fast3d_byte_loads = 0;
 
 // Integer sums of the <= 8 children of `nd` over the points first, first + stride, ...
@@ -1206,8 +1206,8 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
               "empty high-resolution point cloud");
   CMX_REQUIRE(data.low_resolution_point_cloud && data.num_low_resolution_points >= 1,
               "empty low-resolution point cloud");
-  // CMX_HOST_TRACE=1: wall-clock of the host phases (tools only).
-  static const bool host_trace = [] { const char* e = getenv("CMX_HOST_TRACE"); return e && e[0] == '1'; }();
+  // Debug switch host_trace: wall-clock of the host phases (tools only).
+  const bool host_trace = Debug().host_trace != 0;
   auto t_last = std::chrono::steady_clock::now();
   std::string host_report;
   const auto lap = [&](const char* name) {
@@ -1325,8 +1325,7 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
   lap("prepare");
   WorkspaceLease ws(device);
   {
-    const char* e = getenv("CMX_FAST3D_WIDE");
-    const int byte_loads = e && e[0] == '0' ? 1 : 0;
+    const int byte_loads = Debug().fast3d_byte_loads ? 1 : 0;
     static int uploaded = -1;              // (tools only: not meant to be toggled concurrently)
     if (uploaded != byte_loads) {
       CMX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fast3d_byte_loads), &byte_loads, sizeof(int)));
@@ -1341,9 +1340,9 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
   float4* d_pose_t = d_scan_q + scans_total;
   int4* d_cells = ws->dev[3].ReserveAs<int4>(scans_total * n);
   float* d_coarse = ws->dev[4].ReserveAs<float>(coarse_total);
-  // CMX_FRONTIER_CAPACITY shrinks the frontier buffers (tests only): overflow -> strict retry.
-  const char* cap_env = getenv("CMX_FRONTIER_CAPACITY");
-  const int cap_req = cap_env ? atoi(cap_env) : 0;
+  // The debug switch frontier_capacity shrinks the frontier buffers (tests only): overflow ->
+  // strict retry.
+  const int cap_req = Debug().frontier_capacity;
   const int kFrontierCapacity =
       cap_req >= kSubLists3 ? std::min(cap_req, 1 << 21) / kSubLists3 * kSubLists3 : 1 << 21;
   const int kLeafCapacity = 1 << 18;
@@ -1456,8 +1455,7 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
   };
   const List3 leaf_list{d_leaves, d_counters->leaves, kLeafCapacity / kSubLists3};
 
-  const char* dbg_env = getenv("CMX_SYNC");
-  const bool dbg_sync = dbg_env && dbg_env[0] == '1';
+  const bool dbg_sync = Debug().sync != 0;
   auto dbg = [&](const char* name) {
     if (!dbg_sync) return;
     fprintf(stderr, "[cmx sync] %s ...\n", name);
@@ -1485,15 +1483,11 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
   mark("coarse");
 
   const int blocks = 2048;
-  // Batches: one problem's nodes stay on one XCD (CMX_FAST3D_AFFINITY=0/1 overrides).
-  static const int kAffinity = [] {
-    const char* e = getenv("CMX_FAST3D_AFFINITY");
-    return e ? atoi(e) : -1;
-  }();
-  const int affinity = kAffinity >= 0 ? kAffinity : (num >= 16 ? 1 : 0);
-  // CMX_FAST3D_FAMILIES=0: every node of a family expanded on its own (A/B runs, parity tests)
-  const char* fam_env = getenv("CMX_FAST3D_FAMILIES");
-  const int families = !(fam_env && fam_env[0] == '0');
+  // Batches: one problem's nodes stay on one XCD (debug switch fast3d_affinity overrides).
+  const int affinity_override = Debug().fast3d_affinity;
+  const int affinity = affinity_override ? affinity_override - 1 : (num >= 16 ? 1 : 0);
+  // fast3d_no_families: every node of a family expanded on its own (A/B runs, parity tests)
+  const int families = Debug().fast3d_no_families ? 0 : 1;
   int strict = 0, num_chunks = 1;
   const Best3* h_best = reinterpret_cast<const Best3*>(h_misc + off_best);
   for (;;) {
@@ -1788,10 +1782,9 @@ cmx_status cmx_fast3d_create(const cmx_fast3d_options* options, float resolution
       m.levels.push_back(std::move(level));
       last_width = next_width;
     }
-    // Octs of every level that can be a child level (CMX_FAST3D_OCT=0: none, tests).
+    // Octs of every level that can be a child level (debug switch fast3d_no_oct: none, tests).
     {
-      const char* e = getenv("CMX_FAST3D_OCT");
-      const bool build_octs = !(e && e[0] == '0');
+      const bool build_octs = Debug().fast3d_no_oct == 0;
       const int depth = options->branch_and_bound_depth;
       m.oct_desc.assign(depth, OctDesc{nullptr, 0, 0, 0, 0});
       for (int i = 0; build_octs && i + 1 < depth; ++i) {
@@ -1926,9 +1919,8 @@ cmx_status cmx_fast3d_match_batch(const cmx_fast3d* const* matchers, int32_t num
         q.submap = h3::FromPose(submap_poses[p]);
       }
     }
-    // CMX_FAST3D_BATCH caps the searches per chain (tools / tests; 1 = one by one).
-    int group = 64;
-    if (const char* e = getenv("CMX_FAST3D_BATCH")) group = std::max(1, atoi(e));
+    // The debug switch fast3d_batch caps the searches per chain (tools / tests; 1 = one by one).
+    const int group = Debug().fast3d_batch > 0 ? Debug().fast3d_batch : 64;
     cmx_match_stats total{};
     std::vector<char> done(num_pairs, 0);
     for (int first = 0; first < num_pairs; ++first) {
@@ -1961,7 +1953,7 @@ cmx_status cmx_fast3d_match_batch(const cmx_fast3d* const* matchers, int32_t num
       total.expansion_launches += st.expansion_launches;
     }
     if (stats) *stats = total;
-    if (const char* e = getenv("CMX_HOST_TRACE"); e && e[0] == '1')
+    if (Debug().host_trace)
       fprintf(stderr, "[cmx host] cmx_fast3d_match_batch(%d): %.0f us\n", num_pairs,
               std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() -
                                                         entry_time).count());

@@ -1,0 +1,1278 @@
+// RealTimeCorrelativeScanMatcher2D::Match on probability grids: the integer bulk pass out of LDS
+// TILES of the grid (round 4), then exact finalists.
+//
+// Reference: SM2/real_time_correlative_scan_matcher_2d.cc:61-75 (ComputeCandidateScore),
+// :83-115 (GenerateExhaustiveSearchCandidates), :117-149 (Match), :151-176 (ScoreCandidates).
+//
+// The reference's score of a candidate is mean_p P(cell_p + d) summed in f32 in point order
+// (:61-75), and P is affine in the stored uint16: P = 0.1 + u * kScale with u = 32767 - value
+// (0 for unknown / outside).  Integer sums of u are exact and order-free, so the bulk of the
+// search needs neither the f32 chain nor one gather per (candidate, point):
+//   * cells are quantised to q = u >> kQShift (10 bits) in 16-bit fields; all (2 nl + 1)^2
+//     candidates of a rotation read, for one point, a (2 nl + 1)^2 window of cells, four
+//     candidates per ds_read_b64 (rt_2d_device.h, RowPairAccumulate);
+//   * every candidate whose weighted upper bound reaches the best weighted lower bound is
+//     re-summed with the EXACT integers (wave-parallel, order-free), which leaves the handful
+//     within the rounding of the f32 chain of the best: those repeat the reference's sequential
+//     f32 sum, and the host applies the libm weight and the first-maximum rule.
+//
+// Until round 3 a workgroup staged the WHOLE grid (plus halo) in LDS: 110 KB for 200 x 200, one
+// workgroup per CU, nothing at all for the 400 x 400 the reference's active submap grows to
+// (mapping/2d/submap_2d.cc:194, grid_2d.cc:130-164), and the preparation (rotate, discretise,
+// sort by phase) ran inside that one-workgroup-per-CU kernel.  Now:
+//   Rt2DQuantKernel     the grid as a quantised image with a zero halo in HBM, once per grid
+//                       VERSION (cached with a resident cmx_grid2d; built inside the call when
+//                       the grid has changed -- the real caller inserts a scan after every match);
+//   Rt2DTilePrepKernel  one workgroup per (match, rotation) at full occupancy: discretise, bin by
+//                       TILE of the scan's bounding box and by phase, lists to HBM (L2);
+//   Rt2DTileKernel      one workgroup per (match, tile, rotation group): the tile's image enters
+//                       LDS by gather-DMA (global_load_lds_dwordx4 with per-lane row addresses),
+//                       its lists by plain copies, then the window tasks; two or more workgroups
+//                       share a CU, so one computes while another stages.  Sums of a match's
+//                       tiles meet in HBM by integer atomics;
+//   Rt2DFinishKernel    one workgroup per match: bounds, exact integer re-sums, f32 finalists.
+// Grids of any size stay on this path: the image a workgroup holds depends on the tile size, not
+// on the grid.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <string>
+
+#include "rt_2d_device.h"
+#include "scan_matching_2d.h"
+
+namespace cmx {
+namespace {
+
+constexpr int kTileThreads = 512;
+constexpr int kTileWaves = kTileThreads / 64;
+constexpr int kFinishThreads = 512;
+constexpr int kMaxTiles = 16;               // tiles of a match's bounding box (x 4 phases = 64 keys)
+constexpr int kStage1Cap = 1024;            // candidates the exact integer pass takes per match
+constexpr unsigned kFlat = 0xffffffffu;     // misc[1]: more candidates than the lists hold
+constexpr unsigned kOutOfBox = 0xfffffffeu; // misc[1]: a point fell outside the predicted box
+
+struct Rt2DTileParams {
+  // grid and initial pose
+  const uint16_t* cells;
+  int nx, ny;
+  double res, max_x, max_y, inv_res;
+  float tx, ty, init_qw, init_qz;
+  int nl, num_scans, num_angular;
+  double step, wt, wr;
+  const float2* scan_rot;
+  const float* xyz;
+  int n, n_pad;
+  // window geometry (rt_2d_device.h): blocks per window row, rows per half-wave, rows per lane
+  int B, H, rpl;
+  int hl, ht;                // image (X, Y) = grid (X - hl, Y - ht)
+  // quantised image of the whole grid in HBM
+  uint16_t* qimage;
+  int gpitch;                // bytes per image row (multiple of 16)
+  int grows;
+  int image_build;           // 1: Rt2DQuantKernel fills qimage in this call
+  // tiles of the scan's bounding box (window-start coordinates)
+  int box_x0, box_y0;        // of tile (0, 0); box_x0 is a multiple of 8
+  int T;                     // tile core: window starts [k T, (k + 1) T) per axis (multiple of 8)
+  unsigned T_magic;          // ceil(2^32 / T)
+  int ntx, nty;
+  int lp;                    // LDS row pitch in bytes (multiple of 16, conflict-free)
+  int th_img;                // image rows of a tile: T + rpl * H
+  int tile_image_bytes;      // (th_img + rpl * H null rows) * lp, whole KiB
+  int null_addr;             // th_img * lp: the all-zero block padding slots read
+  // lists (HBM scratch): per rotation cap_s u16 entries, keys (tile, phase) in order
+  uint16_t* lists;
+  int cap_s;
+  uint32_t* hdr;             // [num_scans][ntiles * 4]: start | count << 16
+  // rotation groups: workgroup (tile, g) takes rotations g, g + G, ...
+  int G, rw;                 // rw = ceil(num_scans / G) <= 64
+  int list_lds;              // u16 entries of the LDS list buffer
+  int task_cap;
+  int flush_atomic;          // more than one tile: sums meet by atomics (qsum zeroed by the prep)
+  int* qsum;                 // [num_scans][side^2]
+  unsigned* misc;            // [0] best weighted lower bound bits, [1] finalist count, then pairs
+  unsigned* overflow;        // finalist pairs beyond kFinalistHead
+  unsigned* stage;           // [0] candidates of the exact integer pass, [1] f32 finalists | rotations with finalists << 16
+  unsigned long long* timeline;   // debug switch `timeline`: 16 stamps per tile / finish workgroup, else null
+  int timeline_finish_base;       // first slot of the finish kernel's workgroups
+};
+
+__device__ __forceinline__ Rt2DFrame FrameOf(const Rt2DTileParams& P) {
+  return Rt2DFrame{P.res, P.inv_res, P.max_x, P.max_y, P.tx, P.ty, P.init_qw, P.init_qz,
+                   P.nx, P.ny, P.nl};
+}
+
+// exp(-(hypot(x, y) w_t + |theta| w_r)^2) in f32 (relative error ~1e-6): only used for bounds,
+// which carry 1e-5 of relative slack on top; the returned score is weighted on the host with libm.
+__device__ __forceinline__ float TileWeight(const Rt2DTileParams& P, int s, int dx, int dy) {
+  const float res = static_cast<float>(P.res);
+  const float cx = -dy * res, cy = -dx * res;
+  const float theta = static_cast<float>((s - P.num_angular) * P.step);
+  const float t = sqrtf(cx * cx + cy * cy) * static_cast<float>(P.wt) +
+                  fabsf(theta) * static_cast<float>(P.wr);
+  return __expf(-(t * t));
+}
+
+// ---------------------------------------------------------------------------------------------
+// grid (ceil(grows * gpitch / 16 / 256), items): the quantised image, 8 cells per thread.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+Rt2DQuantKernel(const Rt2DTileParams* __restrict__ params) {
+  const Rt2DTileParams& P = params[blockIdx.y];
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (!P.image_build || v >= ((P.grows * P.gpitch) >> 4)) return;
+  const int byte = v << 4;
+  const int Y = byte / P.gpitch, X0 = (byte - Y * P.gpitch) >> 1;
+  const auto* cells = AsGlobal(P.cells);
+  const int gy = Y - P.ht;
+  unsigned q[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int gx = X0 + c - P.hl;
+    unsigned val = 0;
+    if (static_cast<unsigned>(gx) < static_cast<unsigned>(P.nx) &&
+        static_cast<unsigned>(gy) < static_cast<unsigned>(P.ny)) {
+      const unsigned raw = cells[gy * P.nx + gx] & 32767u;
+      val = raw ? (32767u - raw) >> kQShift : 0u;
+    }
+    q[c] = val;
+  }
+  reinterpret_cast<uint4*>(P.qimage)[v] = make_uint4(q[0] | (q[1] << 16), q[2] | (q[3] << 16),
+                                                     q[4] | (q[5] << 16), q[6] | (q[7] << 16));
+}
+
+// ---------------------------------------------------------------------------------------------
+// grid (max rotations, matches), 256 threads: one rotation of one match.
+// Dynamic LDS: tmp[n_pad] u32 (entry | key << 16) | loc[n_pad] u16 | cnt[64] | start[64].
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+Rt2DTilePrepKernel(const Rt2DTileParams* __restrict__ params) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char prep_smem[];
+  const Rt2DTileParams& P = params[blockIdx.y];
+  const int s = blockIdx.x;
+  if (s >= P.num_scans) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int n = P.n, n_pad = P.n_pad;
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(prep_smem);
+  uint16_t* loc = reinterpret_cast<uint16_t*>(tmp + n_pad);
+  int* cnt = reinterpret_cast<int*>(loc + n_pad);
+  int* start = cnt + 64;
+  if (tid < 64) cnt[tid] = 0;
+  const int side = 2 * P.nl + 1, cands = side * side;
+  if (P.flush_atomic)
+    for (int e = tid; e < cands; e += 256) P.qsum[static_cast<size_t>(s) * cands + e] = 0;
+  __syncthreads();
+  const Rt2DFrame F = FrameOf(P);
+  const float2 rot = P.scan_rot[s];
+  const auto* xyz = AsGlobal(P.xyz);
+  const int nkeys = P.ntx * P.nty * 4;
+  bool outside = false;
+  for (int i = tid; i < n; i += 256) {
+    int ix, iy;
+    Rt2DCellOf(F, rot.x, rot.y, xyz[3 * i], xyz[3 * i + 1], &ix, &iy);
+    // window start in image coordinates, relative to the box of this match
+    const int rx = ix - P.nl + P.hl - P.box_x0, ry = iy - P.nl + P.ht - P.box_y0;
+    const unsigned tX = __umulhi(static_cast<unsigned>(max(rx, 0)), P.T_magic);
+    const unsigned tY = __umulhi(static_cast<unsigned>(max(ry, 0)), P.T_magic);
+    uint32_t packed = 0xffffffffu;
+    if (rx < 0 || ry < 0 || tX >= static_cast<unsigned>(P.ntx) ||
+        tY >= static_cast<unsigned>(P.nty)) {
+      outside = true;                          // (the host's box is conservative: never expected)
+    } else {
+      const int lx = rx - static_cast<int>(tX) * P.T, ly = ry - static_cast<int>(tY) * P.T;
+      const int entry = (ly * P.lp + (lx & ~3) * 2) >> 3;
+      const int key = (static_cast<int>(tY) * P.ntx + static_cast<int>(tX)) * 4 + (lx & 3);
+      loc[i] = static_cast<uint16_t>(atomicAdd(&cnt[key], 1));
+      packed = static_cast<uint32_t>(entry) | (static_cast<uint32_t>(key) << 16);
+    }
+    tmp[i] = packed;
+  }
+  if (outside) atomicMax(&P.misc[1], kOutOfBox);
+  __syncthreads();
+  if (tid < 64) {
+    // list starts: every key's list is padded to 16 entries (a group of the window update)
+    const int c = lane < nkeys ? cnt[lane] : 0;
+    const int padded = (c + 15) & ~15;
+    const int incl = WaveInclusiveScan(padded);
+    start[lane] = incl - padded;
+    if (lane < nkeys)
+      P.hdr[static_cast<size_t>(s) * nkeys + lane] =
+          static_cast<uint32_t>(incl - padded) | (static_cast<uint32_t>(c) << 16);
+  }
+  __syncthreads();
+  uint16_t* out = P.lists + static_cast<size_t>(s) * P.cap_s;
+  for (int i = tid; i < n; i += 256) {
+    const uint32_t packed = tmp[i];
+    if (packed == 0xffffffffu) continue;
+    out[start[packed >> 16] + loc[i]] = static_cast<uint16_t>(packed & 0xffffu);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// grid (work items), 512 threads; work = (match, tile, rotation group, -).  Dynamic LDS:
+//   image[tile_image_bytes] | acc[rw][side^2] | hdrs[rw][4] | slot[rw + 1] | tasks[task_cap][4] |
+//   ctl[16] | list[list_lds] u16
+// ---------------------------------------------------------------------------------------------
+template <int RPL, int kRowStride, bool kTimeline>
+__global__ void __launch_bounds__(kTileThreads)
+Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict__ work) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
+  const int4 item = work[blockIdx.x];
+  const Rt2DTileParams& P = params[item.x];
+  const int tile = item.y, g = item.z;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int side = 2 * P.nl + 1, cands = side * side;
+  const int B = P.B, H = P.H, G = P.G, lp = P.lp;
+  const int rw = (P.num_scans - g + G - 1) / G;          // rotations g, g + G, ... of this workgroup
+  if (rw <= 0) return;
+  // (in-kernel timeline of the profiling tools: compiled in only for the instrumented
+  // instantiation the debug switch `timeline` selects)
+  const auto stamp = [&](int k) {
+    if constexpr (kTimeline) Stamp(P.timeline, blockIdx.x, k);
+  };
+  stamp(0);
+  const int nkeys = P.ntx * P.nty * 4;
+  int* acc = reinterpret_cast<int*>(tile_smem + P.tile_image_bytes);
+  int* hdrs = acc + ((P.rw * cands + 3) & ~3);           // [rw][4] start | count << 16 of this tile
+  int* slot = hdrs + P.rw * 4;                           // [rw + 1] cumulative list lengths
+  int* tasks = slot + ((P.rw + 1 + 3) & ~3);             // [task_cap][4]
+  int* ctl = tasks + P.task_cap * 4;                     // [0] tasks, [1] next task, [2] round end
+  uint16_t* list = reinterpret_cast<uint16_t*>(ctl + 16);
+
+  // ---- the tile's image: th_img rows of the quantised grid image + rpl * H rows of zeros,
+  // LDS-DMA with one row piece (16 bytes) per lane.  The first piece of the grid image is halo
+  // (zeros): the source of the null rows and of every piece outside the image -----------------
+  {
+    const int tY = tile / P.ntx, tX = tile - tY * P.ntx;
+    const int gx0 = P.box_x0 + tX * P.T, gy0 = P.box_y0 + tY * P.T;
+    const int ppr = lp >> 4;
+    const int pieces_img = P.th_img * ppr;
+    const auto* src = (const __attribute__((address_space(1))) unsigned char*)P.qimage;
+    auto* dst = (__attribute__((address_space(3))) unsigned char*)tile_smem;
+    const int kib = P.tile_image_bytes >> 10;
+    const int gw = P.gpitch >> 1;                         // cells per image row
+    for (int k = wave; k < kib; k += kTileWaves) {
+      const int p = (k << 6) + lane;
+      const int row = p / ppr, c = p - row * ppr;
+      const int X0 = gx0 + (c << 3), Y = gy0 + row;
+      // (pieces right of / below the image are outside the grid: zeros, like the corner)
+      const bool zero = p >= pieces_img || X0 >= gw || Y >= P.grows;
+      const size_t at = zero ? 0 : static_cast<size_t>(Y) * P.gpitch + static_cast<size_t>(X0) * 2;
+      __builtin_amdgcn_global_load_lds(src + at, dst + (k << 10), 16, 0, 0);
+    }
+  }
+  stamp(1);                                              // image DMA issued
+  for (int i = tid; i < rw * cands; i += kTileThreads) acc[i] = 0;
+  if (tid < rw * 4) {
+    const int rr = tid >> 2, ph = tid & 3;
+    hdrs[tid] = static_cast<int>(P.hdr[static_cast<size_t>(g + rr * G) * nkeys + tile * 4 + ph]);
+  }
+  __syncthreads();
+  if (wave == 0) {                     // cumulative (padded) list lengths of this tile's rotations
+    const int rr = lane;
+    int len = 0;
+    if (rr < rw) {
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) len += ((hdrs[rr * 4 + ph] >> 16) + 15) & ~15;
+    }
+    const int incl = WaveInclusiveScan(len);
+    if (rr < rw) slot[rr + 1] = incl;
+    if (lane == 0) slot[0] = 0;
+  }
+  const int lds_image = static_cast<int>(reinterpret_cast<uintptr_t>(
+      (const __attribute__((address_space(3))) unsigned char*)tile_smem));
+  // Lane geometry inside a half-wavefront.
+  const int li = lane & 31;
+  const int row = li / B, blk = li - row * B;
+  const bool lane_used = row < H;
+  // (lanes beyond H * B read the image's first rows like everyone else and drop the result)
+  const int lane_off = lds_image + (lane_used ? row * lp + blk * 8 : 0);
+  const int row_stride = H * lp;
+  __syncthreads();
+  stamp(2);                                              // headers, list lengths
+
+  // ---- rounds: as many rotations as the LDS list buffer holds ------------------------------
+  for (int rr0 = 0; rr0 < rw;) {
+    const int base = slot[rr0];
+    int rr1 = rr0 + 1;                                 // (one rotation always fits: host)
+    while (rr1 < rw && slot[rr1 + 1] - base <= P.list_lds) ++rr1;
+    __syncthreads();                                   // the previous round's lists are done with
+    if (tid < 2) ctl[tid] = 0;
+    // lists: rotation rr's entries of this tile are contiguous in HBM (keys in order)
+    for (int rr = rr0 + wave; rr < rr1; rr += kTileWaves) {
+      const int first = hdrs[rr * 4] & 0xffff;
+      const int len = slot[rr + 1] - slot[rr];
+      typedef unsigned U4 __attribute__((ext_vector_type(4)));
+      const auto* src = AsGlobal(reinterpret_cast<const U4*>(
+          P.lists + static_cast<size_t>(g + rr * G) * P.cap_s + first));
+      U4* dst = reinterpret_cast<U4*>(list + (slot[rr] - base));
+      for (int q = lane; q < (len >> 3); q += 64) dst[q] = src[q];
+    }
+    __syncthreads();
+    if (rr0 == 0) stamp(3);                              // first round's lists in LDS
+    // ---- per rotation: phases paired by size, tasks of at most kPairTaskIters iterations ---
+    if (wave == 0) {
+      const int rr = rr0 + lane;
+      const bool live = rr < rr1;
+      int key[4], first_slot[4];                 // count << 2 | phase
+      const int g_first = live ? hdrs[rr * 4] & 0xffff : 0;
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        const int h = live ? hdrs[rr * 4 + ph] : 0;
+        key[ph] = ((h >> 16) << 2) | ph;
+        first_slot[ph] = (h & 0xffff) - g_first + (live ? slot[rr] - base : 0);
+      }
+      // the four phases by count, descending (sorting network of five exchanges)
+#define CMX_CSWAP(I, J) { const int hi_k = max(key[I], key[J]), lo_k = min(key[I], key[J]); key[I] = hi_k; key[J] = lo_k; }
+      CMX_CSWAP(0, 1) CMX_CSWAP(2, 3) CMX_CSWAP(0, 2) CMX_CSWAP(1, 3) CMX_CSWAP(1, 2)
+#undef CMX_CSWAP
+      const int la0 = key[0] >> 2, la1 = key[2] >> 2;
+      const int mine = (la0 + kPairTaskIters - 1) / kPairTaskIters +
+                       (la1 + kPairTaskIters - 1) / kPairTaskIters;
+      const int incl = WaveInclusiveScan(mine);
+      int t = incl - mine;
+      if (lane == 63) ctl[0] = incl;
+#pragma unroll
+      for (int pair = 0; pair < 2; ++pair) {
+        const int pa = key[2 * pair] & 3, pb = key[2 * pair + 1] & 3;
+        const int la = key[2 * pair] >> 2, lb = key[2 * pair + 1] >> 2;
+        // (static selects instead of first_slot[pa]: no dynamically indexed private array)
+        const int sa = pa == 0 ? first_slot[0] : pa == 1 ? first_slot[1] : pa == 2 ? first_slot[2] : first_slot[3];
+        const int sb = pb == 0 ? first_slot[0] : pb == 1 ? first_slot[1] : pb == 2 ? first_slot[2] : first_slot[3];
+        for (int off = 0; off < la; off += kPairTaskIters, ++t) {
+          tasks[4 * t] = rr | (pa << 8) | (pb << 16);
+          tasks[4 * t + 1] = sa + off;
+          tasks[4 * t + 2] = sb + off;
+          tasks[4 * t + 3] = min(kPairTaskIters, la - off) | (max(0, min(kPairTaskIters, lb - off)) << 16);
+        }
+      }
+    }
+    if (rr0 == 0) stamp(4);                              // tasks built
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the image has landed
+    __syncthreads();
+    if (rr0 == 0) stamp(5);                              // image landed
+    // ---- tasks, dealt dynamically: the halves of a wavefront run two phases ----------------
+    const int num_tasks = ctl[0];          // <= task_cap by construction (host)
+    for (;;) {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(&ctl[1], 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= num_tasks) break;
+      const int d0 = tasks[4 * t], d3 = tasks[4 * t + 3];
+      const int rr = d0 & 255;
+      const bool second = lane >= 32;
+      const int phase = second ? (d0 >> 16) & 255 : (d0 >> 8) & 255;
+      const int start = second ? tasks[4 * t + 2] : tasks[4 * t + 1];
+      const int my_len = second ? d3 >> 16 : d3 & 0xffff;
+      const int iters = ((d3 & 0xffff) + 15) & ~15;          // the first stream is the longer
+      uint32_t acc32[RPL][4];
+#pragma unroll
+      for (int j = 0; j < RPL; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc32[j][c] = 0;
+      RowPairAccumulate<RPL, kRowStride>(list + start, my_len, iters, lane, lane_off, row_stride,
+                                         P.null_addr, acc32);
+      if (lane_used) {
+        int* out = acc + rr * cands;
+        const int d0x = blk * 4 - phase;           // candidate x index of the block's first cell
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+          const int wrow = row + j * H;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int dxi = d0x + c;
+            if (wrow < side && dxi >= 0 && dxi < side && acc32[j][c])
+              atomicAdd(&out[dxi * side + wrow], static_cast<int>(acc32[j][c]));
+          }
+        }
+      }
+    }
+    if (rr0 == 0) stamp(6);                              // wave 0 out of tasks (first round)
+    rr0 = rr1;
+  }
+  __syncthreads();
+  stamp(7);                                              // all rounds done
+  // ---- this tile's share of the candidates' integer sums --------------------------------------
+  for (int e = tid; e < rw * cands; e += kTileThreads) {
+    const int rr = e / cands, c = e - rr * cands;
+    auto* out = AsGlobal(P.qsum) + static_cast<size_t>(g + rr * G) * cands + c;
+    const int v = acc[e];
+    if (P.flush_atomic) {
+      if (v) __hip_atomic_fetch_add(out, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      *out = v;
+    }
+  }
+  stamp(8);
+}
+
+// ---------------------------------------------------------------------------------------------
+// grid (matches), 512 threads.  Three stages, each narrower and more exact than the one before:
+//   1. bounds from the quantised sums: every candidate whose weighted upper bound reaches the
+//      best weighted lower bound (a few dozen);
+//   2. those candidates with the EXACT integers, one wavefront per candidate (order-free sums:
+//      the points of a rotation are discretised once into LDS): what remains undecided is the
+//      rounding of the reference's f32 chain;
+//   3. the candidates within that rounding of the best (one or two): the reference's sequential
+//      f32 sum (:61-75) -- all threads fetch the probabilities of a finalist's points into LDS,
+//      one lane per finalist runs the chain -- left for the host as (index, score bits) pairs.
+// Dynamic LDS: cells[n_pad] u32 | prob[group][n_pad + 1] f32 | rot_flag[num_scans] |
+//   fin[kStage1Cap] | exact[kStage1Cap] | fin2[kStage1Cap]
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kFinishThreads)
+Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fin_smem[];
+  const Rt2DTileParams& P = params[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int kWaves = kFinishThreads / 64;
+  const int side = 2 * P.nl + 1, cands = side * side, n = P.n, n_pad = P.n_pad;
+  const int total = P.num_scans * cands;
+  uint32_t* cellbuf = reinterpret_cast<uint32_t*>(fin_smem);
+  float* prob = reinterpret_cast<float*>(cellbuf + n_pad);
+  int* rot_flag = reinterpret_cast<int*>(prob + group * (n_pad + 1));
+  int* fin = rot_flag + ((P.num_scans + 3) & ~3);
+  int* exact = fin + kStage1Cap;
+  int* fin2 = exact + kStage1Cap;
+  __shared__ unsigned red[kWaves];
+  __shared__ int nfin, nfin2;
+  __shared__ int sel[18];
+  if (P.misc[1] == kOutOfBox) return;      // (uniform: written by the prep kernel, read-only here)
+  unsigned long long* const tl = P.timeline;
+  const int tl_block = P.timeline_finish_base + blockIdx.x;
+  Stamp(tl, tl_block, 0);
+  if (tid == 0) { nfin = 0; nfin2 = 0; }
+  for (int s = tid; s < P.num_scans; s += kFinishThreads) rot_flag[s] = 0;
+  const float kScale = ((1.f - 0.1f) - (1.f - (1.f - 0.1f))) / 32766.f;   // (kMaxCC - kMinCC) / 32766
+  const float slack = Rt2DBoundSlack(n);
+  const float per_q = kScale * static_cast<float>(1 << kQShift) / static_cast<float>(n);
+  const float width = kScale * static_cast<float>((1 << kQShift) - 1);
+  const int* __restrict__ qsum = P.qsum;
+  // ---- stage 1: the best weighted lower bound, then everyone whose upper bound reaches it.
+  // Bounds only SELECT candidates (scores are recomputed exactly), so f32 with slack is enough --
+  float lb_max = 0.f;
+  for (int e = tid; e < total; e += kFinishThreads) {
+    const int s = e / cands, c = e - s * cands;
+    const int dxi = c / side, dyi = c - dxi * side;
+    const float base = 0.1f + per_q * static_cast<float>(qsum[e]);
+    const float w = TileWeight(P, s, dxi - P.nl, dyi - P.nl);
+    lb_max = fmaxf(lb_max, (base - slack) * w * (1.f - 1e-5f));
+  }
+  {
+    unsigned bits = __float_as_uint(fmaxf(lb_max, 0.f));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) bits = max(bits, __shfl_xor(bits, off, 64));
+    if (lane == 0) red[wave] = bits;
+  }
+  __syncthreads();
+  unsigned best_bits = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) best_bits = max(best_bits, red[w]);
+  const float best_lb = __uint_as_float(best_bits);
+  for (int e = tid; e < total; e += kFinishThreads) {
+    const int s = e / cands, c = e - s * cands;
+    const int dxi = c / side, dyi = c - dxi * side;
+    const float base = 0.1f + per_q * static_cast<float>(qsum[e]);
+    const float w = TileWeight(P, s, dxi - P.nl, dyi - P.nl);
+    if ((base + width + slack) * w * (1.f + 1e-5f) >= best_lb) {
+      const int at = atomicAdd(&nfin, 1);
+      if (at < kStage1Cap) fin[at] = e;
+      rot_flag[s] = 1;
+    }
+  }
+  __syncthreads();
+  Stamp(tl, tl_block, 1);                  // stage 1 done
+  const int count = nfin;
+  if (tid == 0) P.stage[0] = static_cast<unsigned>(count);
+  if (count > kStage1Cap) {              // flat landscape: the host repeats the match on the
+    if (tid == 0) P.misc[1] = kFlat;     // per-candidate kernels
+    return;
+  }
+  const auto* cells = AsGlobal(P.cells);
+  const auto* xyz = AsGlobal(P.xyz);
+  const Rt2DFrame F = FrameOf(P);
+  const auto discretise = [&](int s) {
+    const float2 r = P.scan_rot[s];
+    for (int i = tid; i < n; i += kFinishThreads) {
+      int ix, iy;
+      Rt2DCellOf(F, r.x, r.y, xyz[3 * i], xyz[3 * i + 1], &ix, &iy);
+      cellbuf[i] = (static_cast<uint32_t>(ix) & 0xffffu) | (static_cast<uint32_t>(iy) << 16);
+    }
+  };
+  // (a handful of candidates -- the usual case -- go straight to the f32 chain: re-summing them
+  // exactly first would only add a pass)
+  const bool direct = count <= group;
+  if (direct) {
+    if (tid < count) fin2[tid] = fin[tid];
+    if (tid == 0) {
+      nfin2 = count;
+      int rotations = 0;
+      for (int s = 0; s < P.num_scans; ++s) rotations += rot_flag[s];
+      P.stage[1] = static_cast<unsigned>(count) | (static_cast<unsigned>(rotations) << 16);
+    }
+    __syncthreads();
+  } else {
+    // ---- stage 2: exact integer sums, a wavefront per candidate -------------------------------
+    for (int s = 0; s < P.num_scans; ++s) {
+      if (!rot_flag[s]) continue;           // (uniform: LDS value, no writer since the barrier)
+      __syncthreads();                      // the previous rotation's cells are done with
+      discretise(s);
+      __syncthreads();
+      for (int j = wave; j < count; j += kWaves) {
+        const int e = fin[j];
+        if (e / cands != s) continue;       // (wave-uniform)
+        const int c = e - s * cands;
+        const int dx = c / side - P.nl, dy = c % side - P.nl;
+        int sum = 0;
+        for (int i0 = 0; i0 < n; i0 += 256) {
+          unsigned raw[4];
+          bool inside[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {      // four gathers in flight
+            const int i = i0 + k * 64 + lane;
+            const uint32_t pc = cellbuf[min(i, n - 1)];
+            const int x = static_cast<short>(pc & 0xffffu) + dx;
+            const int y = static_cast<short>(pc >> 16) + dy;
+            inside[k] = i < n && static_cast<unsigned>(x) < static_cast<unsigned>(P.nx) &&
+                        static_cast<unsigned>(y) < static_cast<unsigned>(P.ny);
+            raw[k] = cells[inside[k] ? P.nx * y + x : 0];     // unconditional load, masked below
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const unsigned v = raw[k] & 32767u;
+            sum += (inside[k] && v) ? static_cast<int>(32767u - v) : 0;
+          }
+        }
+        sum = WaveSum(sum);
+        if (lane == 0) exact[j] = sum;
+      }
+    }
+    __syncthreads();
+    Stamp(tl, tl_block, 2);                  // exact integer sums done
+    // ---- bounds from the exact sums: what is left is the rounding of the f32 chain --------------
+    const float per_u = kScale / static_cast<float>(n);
+    lb_max = 0.f;
+    for (int j = tid; j < count; j += kFinishThreads) {
+      const int e = fin[j];
+      const int s = e / cands, c = e - s * cands;
+      const float base = 0.1f + per_u * static_cast<float>(exact[j]);
+      const float w = TileWeight(P, s, c / side - P.nl, c % side - P.nl);
+      lb_max = fmaxf(lb_max, (base - slack) * w * (1.f - 1e-5f));
+    }
+    {
+      unsigned bits = __float_as_uint(fmaxf(lb_max, 0.f));
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) bits = max(bits, __shfl_xor(bits, off, 64));
+      __syncthreads();                      // (red[] of stage 1 has been read by everyone)
+      if (lane == 0) red[wave] = bits;
+    }
+    for (int s = tid; s < P.num_scans; s += kFinishThreads) rot_flag[s] = 0;
+    __syncthreads();
+    best_bits = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) best_bits = max(best_bits, red[w]);
+    const float best_lb2 = __uint_as_float(best_bits);
+    for (int j = tid; j < count; j += kFinishThreads) {
+      const int e = fin[j];
+      const int s = e / cands, c = e - s * cands;
+      const float base = 0.1f + per_u * static_cast<float>(exact[j]);
+      const float w = TileWeight(P, s, c / side - P.nl, c % side - P.nl);
+      if ((base + slack) * w * (1.f + 1e-5f) >= best_lb2) {
+        fin2[atomicAdd(&nfin2, 1)] = e;
+        rot_flag[s] = 1;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int rotations = 0;
+      for (int s = 0; s < P.num_scans; ++s) rotations += rot_flag[s];
+      P.stage[1] = static_cast<unsigned>(nfin2) | (static_cast<unsigned>(rotations) << 16);
+    }
+  }
+  const int count2 = nfin2;
+  Stamp(tl, tl_block, 3);                  // finalists selected
+  // ---- stage 3: the reference's sequential f32 sums ---------------------------------------
+  const int row = n_pad + 1;              // odd row pitch: the chain lanes hit distinct banks
+  for (int s = 0; s < P.num_scans; ++s) {
+    if (!rot_flag[s]) continue;           // (uniform)
+    __syncthreads();
+    discretise(s);
+    __syncthreads();
+    // this rotation's finalists, `group` (<= 16) at a time: thread 0 picks them from the list
+    int next = 0;
+    for (;;) {
+      if (tid == 0) {
+        int gcount = 0;
+        for (; next < count2 && gcount < group; ++next) {
+          const int e = fin2[next];
+          if (e / cands == s) sel[gcount++] = e - s * cands;
+        }
+        sel[16] = gcount;
+        sel[17] = next;
+      }
+      __syncthreads();
+      const int gcount = sel[16];
+      next = sel[17];
+      if (gcount == 0) break;
+      for (int f = wave; f < gcount; f += kWaves) {       // a wavefront per finalist
+        const int c = sel[f];
+        const int dx = c / side - P.nl, dy = c % side - P.nl;
+        for (int i0 = 0; i0 < n; i0 += 256) {
+          unsigned raw[4];
+          bool inside[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * 64 + lane;
+            const uint32_t pc = cellbuf[min(i, n - 1)];
+            const int x = static_cast<short>(pc & 0xffffu) + dx;
+            const int y = static_cast<short>(pc >> 16) + dy;
+            inside[k] = static_cast<unsigned>(x) < static_cast<unsigned>(P.nx) &&
+                        static_cast<unsigned>(y) < static_cast<unsigned>(P.ny);
+            raw[k] = cells[inside[k] ? P.nx * y + x : 0];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * 64 + lane;
+            if (i < n) prob[f * row + i] = inside[k] ? CellProbability(raw[k]) : 0.1f;   // kMinProbability
+          }
+        }
+      }
+      __syncthreads();
+      Stamp(tl, tl_block, 4);              // probabilities of a group of finalists in LDS
+      if (tid < gcount) {
+        const float* vals = prob + tid * row;
+        float sum = 0.f;
+        int i = 0;
+        for (; i + 32 <= n; i += 32) {
+          float v[32];
+#pragma unroll
+          for (int k = 0; k < 32; ++k) v[k] = vals[i + k];
+#pragma unroll
+          for (int k = 0; k < 32; ++k) sum += v[k];            // in point order
+        }
+        for (; i < n; ++i) sum += vals[i];
+        const float score = sum / static_cast<float>(n);
+        const int c = sel[tid];
+        const int dxi = c / side, dyi = c - dxi * side;
+        const int cg = (s * side + dxi) * side + dyi;           // x outer, y inner (:99-113)
+        const unsigned at = atomicAdd(&P.misc[1], 1u);
+        if (at < static_cast<unsigned>(kFinalistCap)) {
+          unsigned* pair = at < static_cast<unsigned>(kFinalistHead)
+                               ? P.misc + 2 + 2 * at
+                               : P.overflow + 2 * (at - kFinalistHead);
+          pair[0] = static_cast<unsigned>(cg);
+          pair[1] = __float_as_uint(score);
+        }
+      }
+      __syncthreads();
+      Stamp(tl, tl_block, 5);              // chains done
+      if (gcount < group) break;
+    }
+  }
+  Stamp(tl, tl_block, 6);
+}
+
+size_t Align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
+
+// Opt-in to more than 64 KB of dynamic LDS, once per (device, kernel): HIP keeps function
+// attributes per device.
+void OptInLds(const void* fn, int device, size_t bytes) {
+  struct Seen { const void* fn; int device; size_t bytes; };
+  static std::mutex mu;
+  static std::vector<Seen>* seen = new std::vector<Seen>;
+  std::lock_guard<std::mutex> lock(mu);
+  for (Seen& s : *seen) {
+    if (s.fn == fn && s.device == device) {
+      if (s.bytes >= bytes) return;
+      CMX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
+      s.bytes = bytes;
+      return;
+    }
+  }
+  CMX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
+  seen->push_back(Seen{fn, device, bytes});
+}
+
+// Conflict-free LDS row pitch (bytes, a multiple of 16, >= min_bytes): the H x B 8-byte blocks a
+// half-wavefront reads in one LDS cycle fall into 2 H B distinct banks for every base address.
+int ConflictFreePitch(int H, int B, int min_bytes) {
+  for (int cand = (min_bytes + 15) & ~15; cand < min_bytes + 1024; cand += 16) {
+    unsigned long long used = 0;
+    bool ok = true;
+    for (int r = 0; r < H && ok; ++r)
+      for (int b = 0; b < B && ok; ++b)
+        for (int w = 0; w < 2; ++w) {
+          const int bank = ((r * cand + b * 8) / 4 + w) & 63;
+          if (used >> bank & 1) ok = false;
+          used |= 1ull << bank;
+        }
+    if (ok) return cand;
+  }
+  return 0;
+}
+
+struct TileGeometry {
+  int B, H, hl, ht, gpitch, grows;
+  int box_x0, box_y0, T, ntx, nty, lp, th_img, tile_image_bytes;
+  int cap_s, G, rw, list_lds, task_cap;
+  size_t lds;               // of the tile kernel
+  size_t image_bytes;       // of the grid image in HBM
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// The image of a resident grid: two buffers, so that the image of a NEW grid version is built
+// while matches on the old one may still be reading theirs.
+// ---------------------------------------------------------------------------------------------
+Rt2DImageCache::~Rt2DImageCache() {
+  for (Buffer& b : buffer)
+    if (b.image) (void)hipFree(b.image);
+}
+
+// Returns the buffer holding the image of (version, nl, geometry), pinned for reading, or a
+// buffer to build it into (`*build` = true; exclusive until Publish / Abandon), or -1 when both
+// buffers are in use by other calls (the caller builds into scratch of its own).
+int Rt2DImageCache::Acquire(unsigned long long version, int nl, int gpitch, int grows,
+                            size_t bytes, bool* build) {
+  std::lock_guard<std::mutex> lock(mutex);
+  *build = false;
+  for (int k = 0; k < 2; ++k) {
+    Buffer& b = buffer[k];
+    if (b.valid && b.version == version && b.nl == nl && b.gpitch == gpitch && b.grows == grows) {
+      ++b.readers;
+      return k;
+    }
+  }
+  // a buffer nobody reads and nobody builds: prefer the one that does not hold the newest image
+  int pick = -1;
+  for (int k = 0; k < 2; ++k) {
+    const Buffer& b = buffer[k];
+    if (b.readers != 0 || b.building) continue;
+    if (pick < 0 || !b.valid || (buffer[pick].valid && b.version < buffer[pick].version)) pick = k;
+  }
+  if (pick < 0) return -1;
+  Buffer& b = buffer[pick];
+  if (b.capacity < bytes) {
+    if (b.image) (void)hipFree(b.image);
+    b.image = nullptr;
+    b.capacity = 0;
+    b.valid = false;
+    CMX_HIP(hipMalloc(reinterpret_cast<void**>(&b.image), bytes + bytes / 4));
+    b.capacity = bytes + bytes / 4;
+  }
+  b.valid = false;
+  b.building = true;
+  *build = true;
+  return pick;
+}
+
+void Rt2DImageCache::Publish(int k, unsigned long long version, int nl, int gpitch, int grows) {
+  std::lock_guard<std::mutex> lock(mutex);
+  Buffer& b = buffer[k];
+  b.version = version; b.nl = nl; b.gpitch = gpitch; b.grows = grows;
+  b.building = false;
+  b.valid = true;
+}
+
+void Rt2DImageCache::Release(int k, bool was_building) {
+  std::lock_guard<std::mutex> lock(mutex);
+  Buffer& b = buffer[k];
+  if (was_building) { b.building = false; b.valid = false; }
+  else --b.readers;
+}
+
+namespace {
+
+// Releases / publishes the cache buffers of a call on every path out of it.
+struct CacheHold {
+  Rt2DImageCache* cache = nullptr;
+  int buffer = -1;
+  bool building = false;
+  unsigned long long version = 0;
+  int nl = 0, gpitch = 0, grows = 0;
+};
+struct CacheHolds {
+  std::vector<CacheHold> holds;
+  hipStream_t stream = nullptr;
+  bool built = false;                   // the stream has been waited for: builds are complete
+  ~CacheHolds() {
+    // (a call that fails between its launches and its wait: nothing of it may still be writing
+    // or reading a buffer that is handed back)
+    if (!built && !holds.empty()) (void)hipStreamSynchronize(stream);
+    for (CacheHold& h : holds) {
+      if (h.buffer < 0) continue;
+      if (h.building && built) {
+        h.cache->Publish(h.buffer, h.version, h.nl, h.gpitch, h.grows);
+        // (the builder keeps reading it until this call returns: nothing to release, Publish
+        // cleared `building`; a buffer that is neither read nor built may be picked again, but
+        // only by a call that starts after this one's kernels have completed)
+      } else {
+        h.cache->Release(h.buffer, h.building);
+      }
+    }
+  }
+};
+
+}  // namespace
+
+void Rt2DComputeSearch(const cmx_rt_options* options, const Rt2DItem& it, Rt2DSearch* out) {
+  const int n = it.n;
+  const double res = it.limits->resolution;
+  // SearchParameters on the cloud pre-rotated by the initial yaw (:123-130).
+  const float ha0 = 0.5f * static_cast<float>(it.initial->theta);
+  const float q0w = std::cos(ha0), q0z = std::sin(ha0) * 1.f;
+  // Longest xy range of the cloud pre-rotated by the initial yaw (:123-130, :27-36).  The
+  // rotation is the device's RotateZ (cmx_device.h: bit-identical to Eigen's product by
+  // (w, 0, 0, z) for finite inputs); sqrt is monotone and correctly rounded, so the maximum
+  // of the norms is the norm of the largest squared norm.  Eight independent maxima in
+  // structure-of-arrays form: the loop vectorises (IEEE adds and multiplies only, no
+  // contraction: the same bits in every lane as in the scalar expression).
+  constexpr int kLanes = 8;
+  float max_sq[kLanes];
+  for (int k = 0; k < kLanes; ++k) max_sq[k] = 0.f;
+  const auto squared_range = [q0w, q0z](float px, float py) {
+    float uvx = -(q0z * py), uvy = q0z * px;
+    uvx += uvx; uvy += uvy;
+    const float cxx = -(q0z * uvy), cyy = q0z * uvx;
+    const float rx = (px + q0w * uvx) + cxx, ry = (py + q0w * uvy) + cyy;
+    return rx * rx + ry * ry;
+  };
+  int i = 0;
+  if (it.far_points) {            // only these points can hold the f32 maximum (cmx_cloud)
+    for (int k = 0; k < it.num_far_points; ++k) {
+      const int idx = it.far_points[k];
+      max_sq[0] = std::max(max_sq[0], squared_range(it.xyz[3 * idx], it.xyz[3 * idx + 1]));
+    }
+    i = n;
+  }
+  for (; i + kLanes <= n; i += kLanes) {
+    float px[kLanes], py[kLanes];
+    for (int k = 0; k < kLanes; ++k) { px[k] = it.xyz[3 * (i + k)]; py[k] = it.xyz[3 * (i + k) + 1]; }
+    for (int k = 0; k < kLanes; ++k) max_sq[k] = std::max(max_sq[k], squared_range(px[k], py[k]));
+  }
+  for (; i < n; ++i)
+    max_sq[0] = std::max(max_sq[0], squared_range(it.xyz[3 * i], it.xyz[3 * i + 1]));
+  float max_all = 0.f;
+  for (int k = 0; k < kLanes; ++k) max_all = std::max(max_all, max_sq[k]);
+  const float max_scan_range = std::max(static_cast<float>(3.f * res), std::sqrt(max_all));
+  const double kSafetyMargin = 1. - 1e-3;
+  const float range_sq = max_scan_range * (max_scan_range * 1.f);
+  out->step = kSafetyMargin * std::acos(1. - (res * (res * 1.)) / (2. * range_sq));
+  out->na = std::ceil(options->angular_search_window / out->step);
+  out->q0w = q0w; out->q0z = q0z;
+  out->max_range = std::sqrt(max_all);
+  out->num_scans = 2 * out->na + 1;
+  out->nl = std::ceil(options->linear_search_window / res);
+}
+
+void Rt2DFinishOnHost(const cmx_rt_options* options, const Rt2DItem& it, const Rt2DSearch& sr,
+                      const std::pair<int, float>* finalists, size_t count) {
+  // Exact weighting + first-maximum on the finalists (:142-143,170-174); `finalists` ascend by
+  // candidate index (the reference's generation order), so the first maximum wins.
+  const int side_i = 2 * sr.nl + 1, nl = sr.nl, na = sr.na;
+  const double res = it.limits->resolution, step = sr.step;
+  float best_score = -1.f;
+  int best = -1;
+  for (size_t k = 0; k < count; ++k) {
+    const int c = finalists[k].first;
+    const int s = c / (side_i * side_i);
+    const int rem = c - s * side_i * side_i;
+    const int dx = rem / side_i - nl, dy = rem % side_i - nl;
+    const double cx = -dy * res, cy = -dx * res;
+    const double theta = (s - na) * step;
+    const double t = std::hypot(cx, cy) * options->translation_delta_cost_weight +
+                     std::abs(theta) * options->rotation_delta_cost_weight;
+    float sc = finalists[k].second;
+    sc *= std::exp(-(t * (t * 1.)));
+    if (sc > best_score) { best_score = sc; best = c; }
+  }
+  // CHECK_GT(score, 0) in the probability branch (:73); a TSDF may score 0 everywhere
+  // (CHECK_GE at :56), in which case the first candidate wins like std::max_element.
+  const int s = best / (side_i * side_i);
+  const int rem = best - s * side_i * side_i;
+  const int dx = rem / side_i - nl, dy = rem % side_i - nl;
+  it.pose->x = it.initial->x + (-dy * res);
+  it.pose->y = it.initial->y + (-dx * res);
+  it.pose->theta = it.initial->theta + (s - na) * step;
+  *it.score = best_score;
+}
+
+// The tile path for a batch of probability-grid matches.  Returns false -- nothing written to
+// the items -- when a match is not eligible (huge window or cloud), when a score landscape is
+// flat (more candidates within the bounds than the lists hold) or when a point fell outside the
+// predicted box: the caller then runs the batch on the per-candidate kernels.
+bool Rt2DTileBatch(const cmx_rt_options* options, const Rt2DItem* items,
+                   const Rt2DSearch* search, int num, int32_t device, cmx_match_stats* stats) {
+  const DebugOptions& dbg = Debug();
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+  std::vector<TileGeometry> geo(num);
+  // ---- launch-wide rows per lane: the largest any item needs ---------------------------------
+  // (H = the most rows of B blocks a half-wavefront holds for which a conflict-free pitch of whole
+  // 16-byte DMA pieces exists: e.g. 8 rather than 10 rows of 3 blocks)
+  int rpl = 1;
+  for (int m = 0; m < num; ++m) {
+    const int side = 2 * search[m].nl + 1;
+    const int B = (side + 3 + 3) / 4;
+    if (B > 32 || items[m].n > kRt2DMaxPoints || search[m].num_scans > 4096) return false;
+    int H = 32 / B;
+    while (H > 1 && ConflictFreePitch(H, B, 16) == 0) --H;
+    geo[m].B = B;
+    geo[m].H = H;
+    rpl = std::max(rpl, (side + H - 1) / H);
+  }
+  if (rpl > kMaxRowsPerLane) return false;
+  if (rpl == 5) rpl = 6;
+  if (rpl == 7) rpl = 8;                         // (instantiated: 1, 2, 3, 4, 6, 8 rows per lane)
+  // ---- per item: window geometry, box, tiles -------------------------------------------------
+  const size_t kLdsPerWorkgroup = 80 * 1024 - 512;        // two workgroups per CU
+  size_t tile_lds = 0, prep_lds = 0, finish_lds = 0;
+  size_t lists_total = 0, hdr_total = 0, qsum_total = 0, scratch_images = 0;
+  long long work_total = 0;
+  int max_scans = 0, common_stride = -1, group = 8;
+  for (int m = 0; m < num; ++m) {
+    const Rt2DItem& it = items[m];
+    const Rt2DSearch& sr = search[m];
+    TileGeometry& g = geo[m];
+    const int nx = it.limits->num_x_cells, ny = it.limits->num_y_cells, nl = sr.nl;
+    const int side = 2 * nl + 1, n_pad = (it.n + 63) / 64 * 64;
+    if (nx > 32000 || ny > 32000) return false;             // (cells travel as int16 pairs)
+    g.hl = (2 * nl + 1 + 7) & ~7;
+    g.ht = 2 * nl + 1;
+    // The box of window starts the scan can reach: every rotated point lies within max_range of
+    // the initial translation (plus a cell for the f32 roundings of rotation and index, plus the
+    // half cell of lround); cells are clamped to [-(nl + 1), n + nl] as on the device.
+    const double res = it.limits->resolution;
+    const double reach = (sr.max_range * (1.0 + 1e-5)) / res + 2.0;
+    const double cxc = (it.limits->max_y - it.initial->y) / res - 0.5;   // cell x from the map's y
+    const double cyc = (it.limits->max_x - it.initial->x) / res - 0.5;
+    const auto clampi = [](double v, int lo, int hi) {
+      return static_cast<int>(std::min<double>(std::max<double>(v, lo), hi));
+    };
+    const int ix_lo = clampi(std::floor(cxc - reach), -(nl + 1), nx + nl);
+    const int ix_hi = clampi(std::ceil(cxc + reach), -(nl + 1), nx + nl);
+    const int iy_lo = clampi(std::floor(cyc - reach), -(nl + 1), ny + nl);
+    const int iy_hi = clampi(std::ceil(cyc + reach), -(nl + 1), ny + nl);
+    g.box_x0 = (ix_lo - nl + g.hl) & ~7;
+    g.box_y0 = iy_lo - nl + g.ht;
+    const int span_x = ix_hi - nl + g.hl - g.box_x0 + 1, span_y = iy_hi - nl + g.ht - g.box_y0 + 1;
+    // rotation groups: about two workgroups per CU over the whole batch
+    const int rows_extra = rpl * g.H;
+    const int cap_tile = n_pad + 64;                  // a rotation's entries of ONE tile, padded
+    // The largest tile core that leaves room for two workgroups per CU, then the smallest core
+    // with the same number of tiles (less image to stage, more room for lists).
+    const auto try_tile = [&](int T, TileGeometry* out) {
+      const int ntx = (span_x + T - 1) / T, nty = (span_y + T - 1) / T;
+      if (ntx * nty > kMaxTiles) return false;
+      const int lp = ConflictFreePitch(g.H, g.B, 2 * (T + 4 * g.B));
+      if (lp == 0) return false;
+      const int th_img = T + rows_extra;
+      const int image = ((th_img + rows_extra) * lp + 1023) & ~1023;
+      int G = dbg.rt2d_groups > 0 ? dbg.rt2d_groups
+                                  : static_cast<int>((2ll * cus + static_cast<long long>(num) * ntx * nty - 1) /
+                                                     (static_cast<long long>(num) * ntx * nty));
+      G = std::max(std::max(1, (sr.num_scans + 63) / 64), std::min(G, sr.num_scans));
+      const int rw = (sr.num_scans + G - 1) / G;
+      const int task_cap = rw * (n_pad / kPairTaskIters + 2);
+      const size_t fixed = static_cast<size_t>(image) + 4 * ((static_cast<size_t>(rw) * side * side + 3) & ~size_t{3}) +
+                           16 * static_cast<size_t>(rw) + 4 * ((static_cast<size_t>(rw) + 1 + 3) & ~size_t{3}) +
+                           16 * static_cast<size_t>(task_cap) + 64;
+      if (fixed + 2 * static_cast<size_t>(cap_tile) > kLdsPerWorkgroup) return false;
+      // list buffer: what is left, at most every rotation's entries at once
+      const size_t want = static_cast<size_t>(rw) * cap_tile;
+      const size_t room = (kLdsPerWorkgroup - fixed) / 2;
+      out->list_lds = static_cast<int>(std::min(want, room) & ~size_t{7});
+      out->T = T; out->ntx = ntx; out->nty = nty; out->lp = lp; out->th_img = th_img;
+      out->tile_image_bytes = image; out->G = G; out->rw = rw; out->task_cap = task_cap;
+      out->lds = fixed + 2 * static_cast<size_t>(out->list_lds);
+      return true;
+    };
+    bool found = false;
+    const int t_first = dbg.rt2d_tile > 0 ? (dbg.rt2d_tile & ~7) : 128;
+    for (int T = t_first; T >= 16 && !found; T -= 8) found = try_tile(T, &g);
+    if (found && dbg.rt2d_tile <= 0) {
+      TileGeometry smaller = g;
+      for (int T = g.T - 8; T >= 16; T -= 8) {
+        if ((span_x + T - 1) / T != g.ntx || (span_y + T - 1) / T != g.nty) break;
+        if (try_tile(T, &smaller)) g = smaller;
+      }
+    }
+    if (!found) return false;
+    g.cap_s = n_pad + 16 * 4 * g.ntx * g.nty;
+    // the grid image: halo + grid, rows of whole 16-byte pieces, one zero row below (what lies
+    // right of or below it is zeros by definition: the tile DMA substitutes the zero corner)
+    g.gpitch = 2 * ((g.hl + nx + 7) & ~7);
+    g.grows = g.ht + ny + 1;
+    g.image_bytes = static_cast<size_t>(g.gpitch) * g.grows;
+    tile_lds = std::max(tile_lds, g.lds);
+    prep_lds = std::max<size_t>(prep_lds, 6 * static_cast<size_t>(n_pad) + 512);
+    lists_total += Align16(2 * static_cast<size_t>(sr.num_scans) * g.cap_s);
+    hdr_total += static_cast<size_t>(sr.num_scans) * g.ntx * g.nty * 4;
+    qsum_total += static_cast<size_t>(sr.num_scans) * side * side;
+    work_total += static_cast<long long>(g.ntx) * g.nty * g.G;
+    max_scans = std::max(max_scans, sr.num_scans);
+    const int stride = g.H * g.lp;
+    common_stride = m == 0 ? stride : (common_stride == stride ? stride : 0);
+    // finish kernel: cells + `group` probability rows + lists within 64 KB
+    const size_t fin_fixed = 4 * static_cast<size_t>(n_pad) + 4 * ((static_cast<size_t>(sr.num_scans) + 3) & ~size_t{3}) +
+                             12 * static_cast<size_t>(kStage1Cap) + 64;
+    const size_t row = 4 * (static_cast<size_t>(n_pad) + 1);
+    const size_t budget = 96 * 1024;
+    if (fin_fixed + row > budget) return false;
+    group = std::min<int>(group, static_cast<int>((budget - fin_fixed) / row));
+  }
+  for (int m = 0; m < num; ++m) {
+    const Rt2DSearch& sr = search[m];
+    const int n_pad = (items[m].n + 63) / 64 * 64;
+    finish_lds = std::max(finish_lds,
+                          4 * static_cast<size_t>(n_pad) + 4 * static_cast<size_t>(group) * (n_pad + 1) +
+                              4 * ((static_cast<size_t>(sr.num_scans) + 3) & ~size_t{3}) +
+                              12 * static_cast<size_t>(kStage1Cap) + 64);
+  }
+  CMX_REQUIRE(work_total < (1ll << 24) && num <= 65535, "too many matches in one batch");
+
+  // ---- staging: params | per item: xyz, rotations, cells | work items | misc ---------------
+  struct Off { size_t xyz, rot, cells; };
+  std::vector<Off> off(num);
+  size_t in_bytes = Align16(sizeof(Rt2DTileParams) * num);
+  std::vector<std::shared_ptr<const std::vector<float2>>> tables(num);
+  for (int m = 0; m < num; ++m) {
+    const Rt2DItem& it = items[m];
+    off[m].xyz = in_bytes;
+    off[m].rot = off[m].xyz + (it.device_xyz ? 0 : Align16(3 * sizeof(float) * it.n));
+    off[m].cells = off[m].rot + Align16(sizeof(float2) * search[m].num_scans);
+    in_bytes = off[m].cells + (it.device_cells ? 0 : Align16(sizeof(uint16_t) * static_cast<size_t>(it.limits->num_x_cells) * it.limits->num_y_cells));
+  }
+  const size_t off_work = in_bytes;
+  in_bytes += Align16(sizeof(int4) * static_cast<size_t>(work_total));
+  const size_t off_misc = in_bytes;
+  in_bytes += Align16(sizeof(unsigned) * 128 * static_cast<size_t>(num));
+
+  WorkspaceLease ws(device);
+  char* h_in = ws->pinned[0].ReserveAs<char>(in_bytes);
+  char* d_in = ws->dev[0].ReserveAs<char>(in_bytes);
+  uint16_t* d_lists = reinterpret_cast<uint16_t*>(ws->dev[1].Reserve(lists_total + 64));
+  uint32_t* d_hdr = ws->dev[2].ReserveAs<uint32_t>(hdr_total + 16);
+  int* d_qsum = ws->dev[3].ReserveAs<int>(qsum_total + 16);
+  unsigned* d_overflow = ws->dev[4].ReserveAs<unsigned>(static_cast<size_t>(num) * 2 * (kFinalistCap - kFinalistHead));
+  unsigned* h_misc = ws->pinned[1].ReserveAs<unsigned>(static_cast<size_t>(num) * 128);
+  unsigned* d_misc = reinterpret_cast<unsigned*>(d_in + off_misc);
+  std::memset(h_in + off_misc, 0, sizeof(unsigned) * 128 * static_cast<size_t>(num));
+  unsigned long long* d_timeline = nullptr;
+  if (dbg.timeline) {
+    const size_t bytes = (static_cast<size_t>(work_total) + num) * kTimelineStamps * 8;
+    d_timeline = static_cast<unsigned long long*>(ws->dev[7].Reserve(bytes));
+    CMX_HIP(hipMemsetAsync(d_timeline, 0, bytes, ws->stream));
+  }
+
+  // ---- grid images: a resident grid keeps its own (two buffers per grid); everything else is
+  // built into scratch by this call ---------------------------------------------------------
+  std::vector<uint16_t*> image_of(num, nullptr);
+  std::vector<long long> scratch_at(num, -1);       // offset in this call's scratch (-1: cached)
+  std::vector<int> build_image(num, 0), same_as(num, -1);
+  CacheHolds holds;
+  holds.stream = ws->stream;
+  for (int m = 0; m < num; ++m) {
+    const TileGeometry& g = geo[m];
+    Rt2DImageCache* c = items[m].image_cache;
+    for (int k = 0; k < m; ++k) {                  // the same grid earlier in this batch
+      if (same_as[k] < 0 && items[k].cells == items[m].cells &&
+          items[k].device_cells == items[m].device_cells && items[k].image_cache == c &&
+          items[k].grid_version == items[m].grid_version && search[k].nl == search[m].nl &&
+          geo[k].gpitch == g.gpitch && geo[k].grows == g.grows) {
+        same_as[m] = k;
+        break;
+      }
+    }
+    if (same_as[m] >= 0) continue;
+    int buffer = -1;
+    bool build = true;
+    if (c && items[m].device_cells && !dbg.rt2d_no_image_cache) {
+      buffer = c->Acquire(items[m].grid_version, search[m].nl, g.gpitch, g.grows, g.image_bytes, &build);
+      if (buffer >= 0) {
+        holds.holds.push_back(CacheHold{c, buffer, build, items[m].grid_version, search[m].nl, g.gpitch, g.grows});
+        image_of[m] = c->buffer[buffer].image;
+      }
+    }
+    if (buffer < 0) {
+      scratch_at[m] = static_cast<long long>(scratch_images);
+      scratch_images += Align16(g.image_bytes);
+      build = true;
+    }
+    build_image[m] = build ? 1 : 0;
+  }
+  char* d_images = static_cast<char*>(ws->dev[5].Reserve(scratch_images + 64));
+  for (int m = 0; m < num; ++m)
+    if (scratch_at[m] >= 0) image_of[m] = reinterpret_cast<uint16_t*>(d_images + scratch_at[m]);
+  for (int m = 0; m < num; ++m)
+    if (same_as[m] >= 0) image_of[m] = image_of[same_as[m]];
+
+  // ---- parameters -------------------------------------------------------------------------------
+  Rt2DTileParams* h_params = reinterpret_cast<Rt2DTileParams*>(h_in);
+  int4* h_work = reinterpret_cast<int4*>(h_in + off_work);
+  {
+    size_t lists_at = 0, hdr_at = 0, qsum_at = 0, work_at = 0;
+    std::vector<size_t> lists_off(num), hdr_off(num), qsum_off(num), work_off(num);
+    for (int m = 0; m < num; ++m) {
+      const TileGeometry& g = geo[m];
+      const int side = 2 * search[m].nl + 1;
+      lists_off[m] = lists_at; lists_at += Align16(2 * static_cast<size_t>(search[m].num_scans) * g.cap_s);
+      hdr_off[m] = hdr_at; hdr_at += static_cast<size_t>(search[m].num_scans) * g.ntx * g.nty * 4;
+      qsum_off[m] = qsum_at; qsum_at += static_cast<size_t>(search[m].num_scans) * side * side;
+      work_off[m] = work_at; work_at += static_cast<size_t>(g.ntx) * g.nty * g.G;
+    }
+    ParallelFor(num, 8, [&](int m) {
+      const Rt2DItem& it = items[m];
+      const Rt2DSearch& sr = search[m];
+      const TileGeometry& g = geo[m];
+      const size_t cell_count = static_cast<size_t>(it.limits->num_x_cells) * it.limits->num_y_cells;
+      if (!it.device_xyz) std::memcpy(h_in + off[m].xyz, it.xyz, 3 * sizeof(float) * it.n);
+      tables[m] = HostRotationTable(sr.step, sr.na);
+      std::memcpy(h_in + off[m].rot, tables[m]->data(), sizeof(float2) * sr.num_scans);
+      if (!it.device_cells) std::memcpy(h_in + off[m].cells, it.cells, sizeof(uint16_t) * cell_count);
+      Rt2DTileParams P{};
+      P.cells = it.device_cells ? it.device_cells : reinterpret_cast<const uint16_t*>(d_in + off[m].cells);
+      P.nx = it.limits->num_x_cells; P.ny = it.limits->num_y_cells;
+      P.res = it.limits->resolution; P.max_x = it.limits->max_x; P.max_y = it.limits->max_y;
+      P.inv_res = 1.0 / P.res;
+      P.tx = static_cast<float>(it.initial->x);
+      P.ty = static_cast<float>(it.initial->y);
+      P.init_qw = sr.q0w; P.init_qz = sr.q0z;
+      P.nl = sr.nl; P.num_scans = sr.num_scans; P.num_angular = sr.na;
+      P.step = sr.step;
+      P.wt = options->translation_delta_cost_weight;
+      P.wr = options->rotation_delta_cost_weight;
+      P.scan_rot = reinterpret_cast<const float2*>(d_in + off[m].rot);
+      P.xyz = it.device_xyz ? it.device_xyz : reinterpret_cast<const float*>(d_in + off[m].xyz);
+      P.n = it.n; P.n_pad = (it.n + 63) / 64 * 64;
+      P.B = g.B; P.H = g.H; P.rpl = rpl; P.hl = g.hl; P.ht = g.ht;
+      P.qimage = image_of[m]; P.gpitch = g.gpitch; P.grows = g.grows; P.image_build = build_image[m];
+      P.box_x0 = g.box_x0; P.box_y0 = g.box_y0; P.T = g.T;
+      P.T_magic = static_cast<unsigned>((0x100000000ull + g.T - 1) / g.T);
+      P.ntx = g.ntx; P.nty = g.nty; P.lp = g.lp; P.th_img = g.th_img;
+      P.tile_image_bytes = g.tile_image_bytes; P.null_addr = g.th_img * g.lp;
+      P.lists = d_lists + lists_off[m] / 2; P.cap_s = g.cap_s;
+      P.hdr = d_hdr + hdr_off[m];
+      P.G = g.G; P.rw = g.rw; P.list_lds = g.list_lds; P.task_cap = g.task_cap;
+      P.flush_atomic = g.ntx * g.nty > 1 ? 1 : 0;
+      P.qsum = d_qsum + qsum_off[m];
+      P.misc = d_misc + static_cast<size_t>(m) * 128;
+      P.overflow = d_overflow + static_cast<size_t>(m) * 2 * (kFinalistCap - kFinalistHead);
+      P.stage = P.misc + 126;
+      P.timeline = d_timeline;
+      P.timeline_finish_base = static_cast<int>(work_total);
+      h_params[m] = P;
+      int4* w = h_work + work_off[m];
+      for (int t = 0; t < g.ntx * g.nty; ++t)
+        for (int gg = 0; gg < g.G; ++gg) *w++ = make_int4(m, t, gg, 0);
+    });
+  }
+  // (the stage counters ride in the last words of a match's slot: the finalist head must stop short)
+  static_assert(2 + 2 * kFinalistHead <= 126, "a match's head and stage counters share 128 words");
+  SmallCopyAsync(d_in, h_in, in_bytes, /*to_device=*/true, ws->stream);
+  const Rt2DTileParams* d_params = reinterpret_cast<const Rt2DTileParams*>(d_in);
+  const int4* d_work = reinterpret_cast<const int4*>(d_in + off_work);
+
+  CMX_HIP(hipEventRecord(ws->ev_begin, ws->stream));
+  {
+    bool any_build = false;
+    size_t max_vecs = 0;
+    for (int m = 0; m < num; ++m) {
+      any_build = any_build || build_image[m];
+      if (build_image[m]) max_vecs = std::max(max_vecs, geo[m].image_bytes >> 4);
+    }
+    if (any_build)
+      Rt2DQuantKernel<<<dim3(DivUp(max_vecs, 256), num), 256, 0, ws->stream>>>(d_params);
+  }
+  Rt2DTilePrepKernel<<<dim3(max_scans, num), 256, prep_lds, ws->stream>>>(d_params);
+  CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
+  {
+    const auto launch = [&](auto kernel) {
+      OptInLds(reinterpret_cast<const void*>(kernel), device, 160 * 1024);
+      kernel<<<static_cast<unsigned>(work_total), kTileThreads, tile_lds, ws->stream>>>(d_params, d_work);
+    };
+    if (d_timeline) {                 // the instrumented instantiations (runtime row stride)
+      if (rpl == 1) launch(Rt2DTileKernel<1, 0, true>);
+      else if (rpl == 2) launch(Rt2DTileKernel<2, 0, true>);
+      else if (rpl == 3) launch(Rt2DTileKernel<3, 0, true>);
+      else if (rpl == 4) launch(Rt2DTileKernel<4, 0, true>);
+      else if (rpl <= 6) launch(Rt2DTileKernel<6, 0, true>);
+      else launch(Rt2DTileKernel<8, 0, true>);
+    } else if (rpl == 1) launch(Rt2DTileKernel<1, 0, false>);
+    else if (rpl == 2 && common_stride == 8 * 288) launch(Rt2DTileKernel<2, 8 * 288, false>);
+    else if (rpl == 2 && common_stride == 8 * 224) launch(Rt2DTileKernel<2, 8 * 224, false>);
+    else if (rpl == 2) launch(Rt2DTileKernel<2, 0, false>);
+    else if (rpl == 3) launch(Rt2DTileKernel<3, 0, false>);
+    else if (rpl == 4) launch(Rt2DTileKernel<4, 0, false>);
+    else if (rpl <= 6) launch(Rt2DTileKernel<6, 0, false>);
+    else launch(Rt2DTileKernel<8, 0, false>);
+  }
+  CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
+  OptInLds(reinterpret_cast<const void*>(Rt2DFinishKernel), device, 128 * 1024);
+  Rt2DFinishKernel<<<num, kFinishThreads, finish_lds, ws->stream>>>(d_params, group);
+  CMX_HIP(hipGetLastError());
+  CMX_HIP(hipEventRecord(ws->ev_end, ws->stream));
+  SmallCopyAsync(h_misc, d_misc, sizeof(unsigned) * 128 * num, /*to_device=*/false, ws->stream);
+  CMX_HIP(hipStreamSynchronize(ws->stream));
+  holds.built = true;
+  if (d_timeline) {
+    ReportTimeline("Rt2DTileKernel", d_timeline, static_cast<int>(work_total), ws->stream);
+    ReportTimeline("Rt2DFinishKernel", d_timeline + static_cast<size_t>(work_total) * kTimelineStamps,
+                   num, ws->stream);
+  }
+
+  for (int m = 0; m < num; ++m) {
+    const unsigned count = h_misc[static_cast<size_t>(m) * 128 + 1];
+    if (count == kOutOfBox)
+      fprintf(stderr, "[cmx] rt2d: a point fell outside the predicted box of match %d; the batch "
+                      "is repeated on the per-candidate kernels\n", m);
+    if (count > static_cast<unsigned>(kFinalistCap)) return false;    // kFlat, kOutOfBox, overflow
+  }
+  cmx_match_stats total{};
+  std::vector<std::pair<int, float>> finalists;
+  std::vector<unsigned> extra;
+  long long stage1 = 0, stage2 = 0;
+  for (int m = 0; m < num; ++m) {
+    const unsigned* head = h_misc + static_cast<size_t>(m) * 128;
+    const long long count = head[1];
+    CMX_REQUIRE(count >= 1, "internal error: no candidate collected");
+    finalists.resize(count);
+    const long long in_head = std::min<long long>(count, kFinalistHead);
+    if (count > kFinalistHead) {
+      extra.resize(2 * (count - kFinalistHead));
+      CMX_HIP(hipMemcpyAsync(extra.data(), d_overflow + static_cast<size_t>(m) * 2 * (kFinalistCap - kFinalistHead),
+                             sizeof(unsigned) * extra.size(), hipMemcpyDeviceToHost, ws->stream));
+      CMX_HIP(hipStreamSynchronize(ws->stream));
+    }
+    for (long long i = 0; i < count; ++i) {
+      const unsigned* pair = i < in_head ? head + 2 + 2 * i : extra.data() + 2 * (i - in_head);
+      float v;
+      std::memcpy(&v, &pair[1], sizeof(float));
+      finalists[i] = {static_cast<int>(pair[0]), v};
+    }
+    std::sort(finalists.begin(), finalists.end());
+    Rt2DFinishOnHost(options, items[m], search[m], finalists.data(), finalists.size());
+    const long long cands = static_cast<long long>(search[m].num_scans) * (2 * search[m].nl + 1) * (2 * search[m].nl + 1);
+    total.candidates_scored += cands;
+    total.coarse_candidates += cands;
+    total.num_scans += search[m].num_scans;
+    stage1 += head[126];
+    stage2 += head[127] & 0xffffu;
+  }
+  if (stats) {
+    float ms = 0.f;
+    CMX_HIP(hipEventElapsedTime(&ms, ws->ev_begin, ws->ev_end));
+    total.device_ms = ms;
+    CMX_HIP(hipEventElapsedTime(&ms, ws->ev_k0, ws->ev_k1));
+    total.dominant_kernel_ms = ms;
+    total.refined_candidates = stage1;        // candidates re-summed with exact integers
+    total.finalists = stage2;                 // candidates scored with the reference's f32 chain
+    *stats = total;
+  }
+  return true;
+}
+
+}  // namespace cmx

@@ -626,11 +626,6 @@ struct Rt3DTileParams {
   int tile_capacity;             // bytes of dynamic LDS behind the staged points
   int block_items;               // candidate pass: items per work descriptor (= blockDim.x)
   int fixed_point;               // group pass: packed fixed-point cell arithmetic (see kernel)
-  int experiment;                // CMX_RT3D_TILE_EXPERIMENT (timing only, wrong results): 4 = no
-                                 // lookups at all.  (Bits 1 and 2 -- no tile gathers / no point
-                                 // reads -- sat INSIDE the lookup loops until late in round 3:
-                                 // two runtime branches per pair of lookups, each a basic-block
-                                 // boundary with a full s_waitcnt in the shipped kernel.)
   const float* boxes;            // Rt3DChunkBoxKernel: [rotation block][chunk][6], or null (boxes
                                  // are then reduced inside the tile kernel)
   // Point segments (Rt3DBinScanKernel): seg_bounds[0], [1] = first chunk of segments 1 and 2 of
@@ -1198,7 +1193,6 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
         if (!kGroups) ambiguous += g > guard ? 1u : 0u;
       }
     };
-    if (TP.experiment & 4) continue;                    // (timing: everything but the lookups)
     if (fixed) {
       const uint32_t* __restrict__ words = packed + (r - rotation_a) * kChunk;
       const unsigned udx = dx, udy = dy;
@@ -1549,23 +1543,13 @@ __global__ void BrickBulkKernel(const uint16_t* __restrict__ cells, long long n,
   tiled[TiledOffset(x, y, z, tiles_y, pitch_z)] = q;
 }
 
-// CMX_RT3D_BULK=0 keeps every candidate on the one-thread-per-candidate kernel (parity tests
-// run both paths).
-// CMX_RT3D_TILES=0 keeps the bulk passes on the memory gathers (Rt3DBulkKernel); parity tests
-// run both.
-bool Tiles3DEnabled() {
-  const char* e = getenv("CMX_RT3D_TILES");
-  return !(e && e[0] == '0');
-}
-int EnvInt(const char* name, int fallback) {
-  const char* e = getenv(name);
-  return e && e[0] ? atoi(e) : fallback;
-}
-
-bool Bulk3DEnabled() {
-  const char* e = getenv("CMX_RT3D_BULK");
-  return !(e && e[0] == '0');
-}
+// Debug switch rt3d_legacy keeps every candidate on the one-thread-per-candidate kernel,
+// rt3d_no_tiles keeps the bulk passes on the memory gathers (Rt3DBulkKernel); parity tests run
+// every path.
+bool Tiles3DEnabled() { return Debug().rt3d_no_tiles == 0; }
+bool Bulk3DEnabled() { return Debug().rt3d_legacy == 0; }
+// A tuning override (debug switches of the profiling tools): 0 = the default.
+int Override(int value, int fallback) { return value > 0 ? value : fallback; }
 
 }  // namespace
 
@@ -1864,8 +1848,7 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
       int* d_num_blocks = reinterpret_cast<int*>(d_blocks + max_blocks);
       int* d_violations = d_num_blocks + 1;          // (the second word of that int2 slot)
       int* d_stage_scratch = d_num_blocks + 2;       // item total of the staged re-compactions (unused)
-      const char* verify_env = getenv("CMX_RT3D_VERIFY");
-      const bool verify = verify_env && verify_env[0] == '1';
+      const bool verify = Debug().rt3d_verify != 0;
       int* h_num_blocks = ws->pinned[1].ReserveAs<int>(16);
       char* h_bmisc = static_cast<char*>(ws->pinned[2].Reserve(head_bytes));
       float4* h_group = ws->pinned[3].ReserveAs<float4>(G);
@@ -1929,22 +1912,22 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
       // Rotations of a group-pass workgroup: as many as fit 512 lanes, so that TWO workgroups
       // share a CU and one computes while the other stages its next chunk (C4, 216 groups: two
       // rotations = 448 lanes, group pass 5.51 -> 4.91 ms against four rotations in one 896-lane
-      // workgroup per CU; CMX_RT3D_GROUP_ROTATIONS overrides, experiments).
+      // workgroup per CU; debug switch rt3d_group_rotations overrides, experiments).
       const int rot_per_block = std::max(
           1, std::min({kTileMaxRotations, std::max(1, 512 / std::max(G, 1)),
-                       EnvInt("CMX_RT3D_GROUP_ROTATIONS", kTileMaxRotations)}));
+                       Override(Debug().rt3d_group_rotations, kTileMaxRotations)}));
       const bool use_tiles = Tiles3DEnabled() && G <= 1024;
-      const bool crosscheck = use_tiles && EnvInt("CMX_RT3D_CROSSCHECK", 0) == 1;
+      const bool crosscheck = use_tiles && Debug().rt3d_crosscheck != 0;
       // (boxes of the rotated chunks from a pre-pass kernel instead of a reduction per chunk
-      // inside the tile kernel; CMX_RT3D_BOXES=0 for the A/B)
-      const bool use_boxes = EnvInt("CMX_RT3D_BOXES", 1) == 1;
+      // inside the tile kernel; debug switch rt3d_no_boxes for the A/B)
+      const bool use_boxes = Debug().rt3d_no_boxes == 0;
       Rt3DTileParams TG{};
       int max_chunks = 0;
       int* d_segment_counts = nullptr;
       // Staged second candidate round (see Rt3DStageFilterKernel); CMX_RT3D_STAGED=0 for the A/B.
       // The cross-check compares complete sums and the expand-all mode has no second round.
-      const bool staged = use_tiles && !crosscheck && EnvInt("CMX_RT3D_STAGED", 1) == 1 &&
-                          EnvInt("CMX_RT3D_EXPAND_ALL", 0) != 1;
+      const bool staged = use_tiles && !crosscheck && Debug().rt3d_unstaged == 0 &&
+                          Debug().rt3d_expand_all == 0;
       if (use_tiles) {
         Rt3DBinParams BP{};
         BP.rotation = rot[R / 2];
@@ -1972,15 +1955,12 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
         // (segment windows: sixteen or more periods over a large cloud, never shorter than four
         // group-pass pieces)
         const int segment_window = n >= 32768 ? 4096 : 2048;
-        // (CMX_RT3D_SEGMENTS=ab: the first segment ends at a / 16, the second at b / 16 of a
-        // window, hex digits; default 48 = a quarter and a half.  Experiments.)
+        // (debug switch rt3d_segments = a | b << 8: the first segment ends at a / 16, the second
+        // at b / 16 of a window; default a quarter and a half.  Experiments.)
         int sixteenths0 = 4, sixteenths1 = 8;
-        if (const char* e = getenv("CMX_RT3D_SEGMENTS")) {
-          const auto digit = [](char c) { return c >= 'a' ? c - 'a' + 10 : c - '0'; };
-          if (e[0] && e[1]) {
-            sixteenths0 = std::max(1, std::min(15, digit(e[0])));
-            sixteenths1 = std::max(sixteenths0, std::min(15, digit(e[1])));
-          }
+        if (const int seg = Debug().rt3d_segments; seg > 0) {
+          sixteenths0 = std::max(1, std::min(15, seg & 0xff));
+          sixteenths1 = std::max(sixteenths0, std::min(15, (seg >> 8) & 0xff));
         }
         Rt3DBinScanKernel<<<1, 1024, 0, ws->stream>>>(
             d_bin_count, num_bins, d_chunks, d_chunks_candidates, d_chunk_count, segment_window,
@@ -1989,11 +1969,10 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
         Rt3DBinScatterKernel<<<DivUp(n, 256), 256, 0, ws->stream>>>(BP, d_xyz, d_bin_count,
                                                                     d_sorted);
         CMX_HIP(hipGetLastError());
-        if (getenv("CMX_RT3D_REPORT")) {
+        if (Debug().rt3d_report) {
           TG.stats = reinterpret_cast<unsigned long long*>(ws->dev[19].Reserve(64));
           CMX_HIP(hipMemsetAsync(TG.stats, 0, 64, ws->stream));
         }
-        TG.experiment = EnvInt("CMX_RT3D_TILE_EXPERIMENT", 0);
         TG.sorted_xyz = d_sorted;
         TG.chunks = d_chunks;
         TG.num_chunks = d_chunk_count;
@@ -2018,9 +1997,9 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
         Rt3DTileParams TP = TG;
         span_of(group, &TP);
         TP.rotations_per_block = rot_per_block;
-        TP.tile_capacity = EnvInt("CMX_RT3D_GROUP_TILE_KB", 44) * 1024;
+        TP.tile_capacity = Override(Debug().rt3d_group_tile_kb, 44) * 1024;
         const int threads = std::min(1024, DivUp(rot_per_block * G, 64) * 64);
-        TP.fixed_point = EnvInt("CMX_RT3D_GROUP_FIXED", 1);
+        TP.fixed_point = Debug().rt3d_group_float ? 0 : 1;
         if (crosscheck) TP.fixed_point = 0;       // (the float path reproduces the gather kernel's sums)
         const size_t lds = (sizeof(v2f) * (3 * kTileChunkGroups / 2 + 2) +
                             sizeof(uint32_t) * kTileChunkGroups) * rot_per_block +
@@ -2115,12 +2094,12 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
       trace.Mark("group pass");
       Rt3DTileParams TC = TG;
       const int block_items =
-          !use_tiles ? kCand3DThreads : crosscheck ? 256 : EnvInt("CMX_RT3D_CAND_THREADS", 512);
+          !use_tiles ? kCand3DThreads : crosscheck ? 256 : Override(Debug().rt3d_cand_threads, 512);
       BC.block_items = block_items;
       // (tiled: work lists span several rotations, so that a tile serves some hundred lanes even
       // when a rotation keeps only a few dozen candidates)
       const int list_rotations =
-          use_tiles && !crosscheck ? std::max(1, std::min(8, EnvInt("CMX_RT3D_CAND_ROTATIONS", 8))) : 1;
+          use_tiles && !crosscheck ? std::max(1, std::min(8, Override(Debug().rt3d_cand_rotations, 8))) : 1;
       const int num_lists = DivUp(R, list_rotations);
       BC.list_rotations = list_rotations;
       if (use_tiles) {
@@ -2134,7 +2113,7 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
                   BC, TG.sorted_xyz, TC.chunks, TC.num_chunks, list_rotations, d_boxes);
           TC.boxes = d_boxes;
         }
-        TC.tile_capacity = EnvInt("CMX_RT3D_CAND_TILE_KB", 48) * 1024;
+        TC.tile_capacity = Override(Debug().rt3d_cand_tile_kb, 48) * 1024;
         TC.block_items = block_items;
         BC.cells = d_bulk;                              // the row-major q brick
         BC.cell_count = static_cast<unsigned>(cells);
@@ -2143,9 +2122,9 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
       int stage_blocks[2] = {-1, -1};            // work blocks left after segments 0 and 1
       int* h_segments = h_num_blocks + 4;        // pinned: the chunk counts by segment
       int* d_stage_total = d_stage_scratch;      // (re-compactions must not count items twice)
-      // CMX_RT3D_EXPAND_ALL=1 (tests, with CMX_RT3D_VERIFY): every group is expanded in the first
-      // round, so every group bound is checked against every one of its members.
-      const float first_round_factor = EnvInt("CMX_RT3D_EXPAND_ALL", 0) == 1 ? 0.f : 0.97f;
+      // Debug switch rt3d_expand_all (tests, with rt3d_verify): every group is expanded in the
+      // first round, so every group bound is checked against every one of its members.
+      const float first_round_factor = Debug().rt3d_expand_all ? 0.f : 0.97f;
       for (int round = 0; round < 2; ++round) {
         CMX_HIP(hipMemsetAsync(d_num_blocks, 0, sizeof(int) * (round == 0 ? 2 : 1), ws->stream));
         Rt3DSelectGroupsKernel<<<DivUp(RG, 256), 256, 0, ws->stream>>>(
@@ -2287,7 +2266,7 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
                     "internal error: %d bound violations (a group bound below a member's lower "
                     "bound, or a staged bound below the candidate's final sum)", violations);
       }
-      if (getenv("CMX_RT3D_REPORT")) {
+      if (Debug().rt3d_report) {
         float ms = 0.f, all = 0.f;
         CMX_HIP(hipEventElapsedTime(&ms, ws->ev_k0, ws->ev_k1));
         CMX_HIP(hipEventElapsedTime(&all, ws->ev_begin, ws->ev_end));

@@ -161,16 +161,29 @@ class Fast2DMatcher {
 // and nothing is ever freed on the hot path.
 std::shared_ptr<const std::vector<float2>> HostRotationTable(double step, int num_angular);
 
-// The staged image of a resident grid (rt_2d.hip, Rt2DImageKernel): quantised cells with the
-// zero halo and the row pitch the row-pair kernel copies into LDS as they are.  It depends on
-// the grid's cells (`version`, bumped by every insert / grow / crop) and on the window (nl);
-// a cmx_grid2d owns one and real-time matches against an unchanged grid reuse it.
+// The quantised image of a resident grid (rt_2d_tiles.hip, Rt2DQuantKernel): cells as 16-bit
+// q = (32767 - value) >> 5 with a zero halo, what the tile workgroups of the real-time matcher
+// copy into LDS.  It depends on the grid's cells (`version`, bumped by every insert / grow /
+// crop) and on the window (nl); a cmx_grid2d owns one cache.  TWO buffers: the real caller
+// inserts a scan after every match, so every match meets a new version -- its image is built
+// into the buffer nobody reads while matches on the previous version may still be reading
+// theirs.  No lock is held across kernels: a buffer is pinned by a reader count, a buffer being
+// built is exclusive, and its metadata is published only after the build's stream has been
+// waited for (a failed call leaves it invalid).
 struct Rt2DImageCache {
-  std::mutex mutex;            // held by a call from its validity check until its build has completed
-  unsigned long long version = 0;   // grid version the image was built from (0: none)
-  int nl = -1, nx = 0, ny = 0, pitch = 0, hp = 0, image_bytes = 0;
-  uint16_t* image = nullptr;   // device
-  size_t capacity = 0;
+  struct Buffer {
+    uint16_t* image = nullptr;   // device
+    size_t capacity = 0;
+    bool valid = false, building = false;
+    int readers = 0;
+    unsigned long long version = 0;
+    int nl = -1, gpitch = 0, grows = 0;
+  };
+  std::mutex mutex;              // guards the fields above; never held across device work
+  Buffer buffer[2];
+  int Acquire(unsigned long long version, int nl, int gpitch, int grows, size_t bytes, bool* build);
+  void Publish(int k, unsigned long long version, int nl, int gpitch, int grows);
+  void Release(int k, bool was_building);
   ~Rt2DImageCache();
 };
 
@@ -192,6 +205,22 @@ struct Rt2DItem {            // one match of a batch
   Rt2DImageCache* image_cache = nullptr;  // with device_cells of a cmx_grid2d
   unsigned long long grid_version = 0;
 };
+// SearchParameters of one match (SM2/correlative_scan_matcher_2d.cc:27-47 on the cloud
+// pre-rotated by the initial yaw, real_time_..._2d.cc:123-130): host, libm.
+struct Rt2DSearch {
+  double step;            // angular_perturbation_step_size
+  int na, num_scans, nl;  // num_angular_perturbations, 2 na + 1, linear window in cells
+  float q0w, q0z;         // Quaternion(AngleAxisf(f32(theta0), Z))
+  float max_range;        // longest xy range of the cloud (f32, as SearchParameters computes it)
+};
+void Rt2DComputeSearch(const cmx_rt_options* options, const Rt2DItem& item, Rt2DSearch* out);
+// Exact weighting (libm) + first-maximum rule over a match's finalists, ascending by candidate
+// index (:142-143,170-174): writes the item's score and pose.
+void Rt2DFinishOnHost(const cmx_rt_options* options, const Rt2DItem& item, const Rt2DSearch& search,
+                      const std::pair<int, float>* finalists, size_t count);
+// rt_2d_tiles.hip: the bulk path for probability grids; false = not taken (see there).
+bool Rt2DTileBatch(const cmx_rt_options* options, const Rt2DItem* items, const Rt2DSearch* search,
+                   int num, int32_t device, cmx_match_stats* stats);
 void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int num, int32_t device,
                     cmx_match_stats* stats);
 void Rt2DMatch(const cmx_rt_options* options, const cmx_grid2d_limits* limits,

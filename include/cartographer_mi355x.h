@@ -110,6 +110,10 @@ typedef struct cmx_match_stats {
                                  launches (fast 2D: ExpandWaveKernel, fast 3D: Expand3DKernel) */
   int64_t expansion_nodes;    /* nodes those launches took from their frontiers */
   int64_t expansion_lookups;  /* grid lookups they issued (64 per wave-wide gather instruction) */
+  int64_t refined_candidates; /* real-time matchers: candidates the integer bounds could not decide,
+                                 re-summed with exact integers */
+  int64_t finalists;          /* real-time matchers: candidates scored with the reference's own
+                                 sequential f32 sum (the only ones whose score is returned) */
 } cmx_match_stats;
 
 /* One flattened HybridGrid voxel (mapping/3d/hybrid_grid.h:304-372 Iterator):

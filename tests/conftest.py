@@ -24,3 +24,12 @@ def synth():
     from cartographer_amd import synth as s
     s.lib()
     return s
+
+
+@pytest.fixture
+def debug():
+    """Test switches of the library (include/cartographer_mi355x_debug.h): `debug(name=value, ...)`
+    selects a device path / verification mode for this test; everything is reset afterwards."""
+    from cartographer_amd import _lib
+    yield _lib.debug_set
+    _lib.debug_reset()

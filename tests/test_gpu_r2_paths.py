@@ -3,7 +3,7 @@
   * fast 2D: the fused front end (PrepScoreFusedKernel: prep + bucketing + lowest-resolution
     scoring in one block per rotation) vs the separate launches (CMX_FUSED=0);
   * real-time 2D: the LDS-staged integer bulk pass + exact finalists (Rt2DBulkKernel /
-    Rt2DExactKernel) vs one thread per candidate (CMX_RT2D_BULK=0).
+    Rt2DFinishKernel) vs one thread per candidate (debug switch rt2d_legacy).
 Both toggles are read per call, so one process runs both paths on identical inputs.  Bars as in
 test_gpu_2d.py: integer work bit-exact, f32 scores bit-equal, poses to 1e-12.
 """
@@ -103,14 +103,22 @@ def test_fast2d_fused_and_unfused_batches_agree(sm, synth, c2, monkeypatch):
 # ----------------------------------------------------------------------------
 # Real-time 2D: bulk pass vs per-candidate kernels vs oracle
 # ----------------------------------------------------------------------------
-def _rt2d_path(monkeypatch, path):
-    """'pair': row-pair bulk kernel (default); 'chunk': the round-2 chunked bulk kernel;
-    '0': one thread per candidate."""
-    monkeypatch.setenv("CMX_RT2D_BULK", "0" if path == "0" else "1")
-    monkeypatch.setenv("CMX_RT2D_ROWPAIR", "1" if path == "pair" else "0")
+RT2D_PATHS = ["tiles", "tiles64", "tiles56g", "0"]
 
 
-@pytest.mark.parametrize("bulk", ["pair", "chunk", "0"])
+def _rt2d_path(debug, path):
+    """'tiles': integer bulk pass out of LDS tiles + exact finalists (default); 'tiles64' /
+    'tiles56g': the same with small tiles (up to 4 x 4 per match: sums meet by atomics) and
+    with one workgroup per (tile, rotation); '0': one thread per candidate."""
+    if path == "0":
+        debug(rt2d_legacy=1)
+    elif path == "tiles64":
+        debug(rt2d_tile=64, rt2d_no_image_cache=1)
+    elif path == "tiles56g":
+        debug(rt2d_tile=56, rt2d_groups=1000)
+
+
+@pytest.mark.parametrize("bulk", RT2D_PATHS)
 @pytest.mark.parametrize("seed,size,beams,lin,ang,weights", [
     (42, 200, 1000, 0.3, 7.0, (0.1, 0.1)),      # C1
     (7, 200, 400, 0.3, 7.0, (0.0, 0.0)),        # unweighted: ties resolved by generation order
@@ -122,9 +130,9 @@ def _rt2d_path(monkeypatch, path):
     (17, 130, 333, 0.2, 6.0, (0.1, 0.1)),       # 9 x 9: B = 3, pitch a multiple of 8 only
     (19, 110, 500, 0.4, 3.0, (0.1, 0.1)),       # 17 x 17: B = 5, three rows per lane
 ])
-def test_rt2d_both_paths(sm, oracle, synth, monkeypatch, bulk, seed, size, beams, lin, ang,
+def test_rt2d_both_paths(sm, oracle, synth, debug, bulk, seed, size, beams, lin, ang,
                          weights):
-    _rt2d_path(monkeypatch, bulk)
+    _rt2d_path(debug, bulk)
     ny = size if size != 97 else 83
     cells, lim, world = synth.make_submap(seed, size, ny, 0.05, 20, 600, 5.0, 0.01)
     pose = world.free_pose(seed + 100, 0.5)
@@ -137,14 +145,23 @@ def test_rt2d_both_paths(sm, oracle, synth, monkeypatch, bulk, seed, size, beams
     assert m.last_stats["candidates_scored"] == ref["num_candidates"]
     assert score == ref["score"]
     np.testing.assert_allclose([est.x, est.y, est.theta], ref["pose"], rtol=0, atol=1e-12)
+    # the path asked for is the path that ran (no silent fall-back to the per-candidate kernels):
+    # only the tile path re-sums candidates with exact integers, and it scores a handful with
+    # the f32 chain where the per-candidate kernels score everything
+    st = m.last_stats
+    if bulk == "0":
+        assert st["refined_candidates"] == 0 and st["finalists"] == ref["num_candidates"]
+    else:
+        assert 1 <= st["finalists"] <= st["refined_candidates"] < ref["num_candidates"] or \
+            ref["num_candidates"] <= 64
 
 
-@pytest.mark.parametrize("bulk", ["pair", "chunk", "0"])
-def test_rt2d_points_outside_and_unknown_grid(sm, oracle, monkeypatch, bulk):
+@pytest.mark.parametrize("bulk", RT2D_PATHS)
+def test_rt2d_points_outside_and_unknown_grid(sm, oracle, debug, bulk):
     """A cloud that mostly falls outside a small grid, on an all-unknown grid and on a
     random one: the flat landscape makes every candidate a finalist (more than the list
     holds: the bulk path hands the batch to the per-candidate kernels)."""
-    _rt2d_path(monkeypatch, bulk)
+    _rt2d_path(debug, bulk)
     rng = np.random.default_rng(5)
     scan = np.zeros((130, 3), np.float32)
     scan[:, :2] = rng.uniform(-4.0, 4.0, (130, 2))
@@ -158,7 +175,7 @@ def test_rt2d_points_outside_and_unknown_grid(sm, oracle, monkeypatch, bulk):
         np.testing.assert_allclose([est.x, est.y, est.theta], ref["pose"], rtol=0, atol=1e-12)
 
 
-def test_rt2d_batch_on_resident_grids_both_paths(sm, oracle, synth, monkeypatch):
+def test_rt2d_batch_on_resident_grids_both_paths(sm, oracle, synth, debug):
     from cartographer_amd import grid_2d
     m = sm.RealTimeCorrelativeScanMatcher2D(0.3, math.radians(7.0), 0.1, 0.1)
     grids, inits, scans, refs = [], [], [], []
@@ -173,13 +190,16 @@ def test_rt2d_batch_on_resident_grids_both_paths(sm, oracle, synth, monkeypatch)
         scans.append(scan)
         refs.append(oracle.rt2d_match(cells, 0.05, lim["max_x"], lim["max_y"], init, scan, 0.3,
                                       math.radians(7.0), 0.1, 0.1))
-    for bulk in ("pair", "chunk", "0"):
-        _rt2d_path(monkeypatch, bulk)
+    from cartographer_amd import _lib
+    for bulk in RT2D_PATHS:
+        _lib.debug_reset()
+        _rt2d_path(debug, bulk)
         scores, poses, stats = sm.rt2d_match_batch(m, grids, inits, scans)
         for k, ref in enumerate(refs):
             assert scores[k] == ref["score"], (bulk, k)
             np.testing.assert_allclose([poses[k].x, poses[k].y, poses[k].theta], ref["pose"],
                                        rtol=0, atol=1e-12)
+    _lib.debug_reset()
     # the prepared form of the same call (argument arrays built once), twice in a row
     batch = sm.Rt2DBatch(m, grids, scans)
     init = np.array([[p.x, p.y, p.theta] for p in inits])
@@ -192,11 +212,10 @@ def test_rt2d_batch_on_resident_grids_both_paths(sm, oracle, synth, monkeypatch)
 
 
 @pytest.mark.parametrize("resident", [False, True])
-def test_rt2d_large_batch_goes_out_as_two_halves(sm, synth, monkeypatch, resident):
+def test_rt2d_large_batch_goes_out_as_two_halves(sm, synth, resident):
     """From 64 matches on a batch is issued as two half-batches from two host threads (own
     workspace and stream each): 71 matches over five grids with scans of different sizes return,
-    match by match, what one batch (CMX_RT2D_SPLIT=1 is read once per process: the single-match
-    entry point serves as the unsplit result) returns; the statistics are those of both halves;
+    match by match, what the single-match entry point returns; the statistics are those of both halves;
     an error in the second half comes back as the call's status with its message."""
     from cartographer_amd import grid_2d
     from cartographer_amd._lib import CmxError
