@@ -437,12 +437,47 @@ class Fast2DWorkload:
         return out
 
 
+class Fast2DConcurrentWorkload(Fast2DWorkload):
+    """C2 as the headline issues it -- `threads` host threads, one search each per step -- but
+    with `threads` DIFFERENT scans (poses of the same world) instead of one scan repeated: the
+    headline's single scan happens to be an easy one (its dive finds a tight bound at once)."""
+
+    def __init__(self, args, device, threads=8):
+        sub = argparse.Namespace(**vars(args))
+        sub.scans, sub.submaps = threads, 0
+        super().__init__(sub, device, 0, 1, sharded=False)
+        from concurrent.futures import ThreadPoolExecutor
+        self.threads = threads
+        self.pool = ThreadPoolExecutor(threads)
+        self.matches_per_step = threads
+
+    def search(self, k=0):
+        results = list(self.pool.map(lambda j: Fast2DWorkload.search(self, j), range(self.threads)))
+        found = np.concatenate([r[0] for r in results])
+        scores = np.concatenate([r[1] for r in results])
+        stats = dict(results[0][3])
+        for r in results[1:]:
+            for key, v in r[3].items():
+                stats[key] = stats.get(key, 0) + v
+        return found, scores, results[-1][2], stats
+
+    def describe(self, stats, found):
+        out = super().describe(stats, found)
+        out["workload"] = (f"C2 with {self.threads} different scans: one search per scan per step, "
+                           f"issued from {self.threads} host threads; " + out["workload"])
+        return out
+
+
 class Rt2DWorkload:
     """C1 as a throughput workload: `--matches` independent real-time matches per step (scan i
     against resident grid i around pose i: one per trajectory / robot), 1000 beams vs 200x200,
-    window 0.3 m / 7 deg, weights 0.1 / 0.1."""
+    window 0.3 m / 7 deg, weights 0.1 / 0.1.  `grid`: side of the grids (the reference's active
+    grid doubles 100 -> 200 -> 400, mapping/2d/grid_2d.cc:130-164); `dirty`: every grid has one
+    more (small) scan inserted before every step, as the real caller does after every match
+    (2d/local_trajectory_builder_2d.cc:78-80, :289) -- the match then never meets a cached
+    image of its grid; the insertions are timed apart and not part of the step."""
 
-    def __init__(self, args, device, matches=None):
+    def __init__(self, args, device, matches=None, grid=200, dirty=False):
         from cartographer_amd import grid_2d, scan_matching as sm, synth
         self.sm = sm
         self.m = sm.RealTimeCorrelativeScanMatcher2D(0.3, math.radians(7.0), 0.1, 0.1,
@@ -450,15 +485,23 @@ class Rt2DWorkload:
         batch = matches or args.matches
         grids, inits, scans = [], [], []
         self.host_cells, self.host_lims = [], []
+        self.grid_side, self.dirty, self.insert_s = grid, dirty, 0.0
+        self.dirty_inputs = []
         for k in range(min(batch, 8)):          # 8 distinct worlds, reused round-robin
-            cells, lim, world = synth.make_submap(42 + k, 200, 200, 0.05, 30, 1000, 5.0, 0.01)
+            cells, lim, world = synth.make_submap(42 + k, grid, grid, 0.05, 30, 1000, 5.0, 0.01)
             pose = world.free_pose(1234, 0.5)
-            grids.append(grid_2d.ProbabilityGridOnDevice(0.05, (lim["max_x"], lim["max_y"]), 200,
-                                                         200, cells=cells))
+            grids.append(grid_2d.ProbabilityGridOnDevice(0.05, (lim["max_x"], lim["max_y"]), grid,
+                                                         grid, cells=cells))
             scans.append(world.scan(pose, args.beams, 5.0, 0.01, 7))
             inits.append(sm.Rigid2d(pose[0] + 0.12, pose[1] - 0.08, pose[2] + math.radians(3.0)))
             self.host_cells.append(cells)
             self.host_lims.append(lim)
+            c, s_ = math.cos(pose[2]), math.sin(pose[2])
+            pts = np.zeros((8, 3), np.float32)              # eight returns: enough to bump the version
+            pts[:, 0] = pose[0] + c * scans[-1][:8, 0] - s_ * scans[-1][:8, 1]
+            pts[:, 1] = pose[1] + s_ * scans[-1][:8, 0] + c * scans[-1][:8, 1]
+            self.dirty_inputs.append((np.asarray(pose[:2], np.float32), pts))
+        self.distinct_grids = grids
         self.candidates_per_match = 27 * 13 * 13      # re-read from the first search's stats
         self.G = [grids[i % len(grids)] for i in range(batch)]
         self.I = [inits[i % len(grids)] for i in range(batch)]
@@ -472,39 +515,52 @@ class Rt2DWorkload:
         self.n_points = int(self.points)
 
     def search(self, k=0):
+        if self.dirty:
+            t0 = time.perf_counter()
+            for g, (origin, pts) in zip(self.distinct_grids, self.dirty_inputs):
+                g.insert(origin, pts)
+            self.insert_s += time.perf_counter() - t0
         scores, poses, stats = self.batch.match(self.init)
         self.candidates_per_match = stats["candidates_scored"] // self.matches_per_step
         return np.ones(len(scores), np.int32), scores, poses, stats
 
     def describe(self, stats, found):
-        return {"workload": f"C1: 2D RealTimeCorrelativeScanMatcher, {self.matches_per_step} "
-                            f"independent matches per step, {self.n_points}-point scans vs 200x200 "
-                            f"resident probability grids, window 0.3 m / 7 deg "
-                            f"({stats['candidates_scored'] // self.matches_per_step} candidates per match)",
-                "matches_per_step": self.matches_per_step}
+        out = {"workload": f"C1: 2D RealTimeCorrelativeScanMatcher, {self.matches_per_step} "
+                           f"independent matches per step, {self.n_points}-point scans vs "
+                           f"{self.grid_side}x{self.grid_side} resident probability grids"
+                           f"{' (a scan inserted into every grid before every step)' if self.dirty else ''}"
+                           f", window 0.3 m / 7 deg "
+                           f"({stats['candidates_scored'] // self.matches_per_step} candidates per match)",
+               "matches_per_step": self.matches_per_step,
+               "refined_candidates_per_match": stats.get("refined_candidates", 0) / self.matches_per_step,
+               "f32_finalists_per_match": stats.get("finalists", 0) / self.matches_per_step}
+        return out
 
     def roofline(self, acc, steps, pmc):
-        """Row-pair bulk kernel: the grid image sits in LDS; a HALF-wavefront is one stream of
-        points, a lane fetches aligned 4-cell blocks (8 B) of two window rows per point.  C1:
-        13 x 13 window -> 8 row slots x 4 blocks x 2 rows = 512 B of ds_read_b64 per (rotation,
-        point) serving 169 candidates.  Algorithmic bytes: 2 B per candidate per
-        point."""
+        """Tile kernel (round 4): a tile of the quantised grid image sits in LDS; a HALF-wavefront
+        is one stream of points, a lane fetches aligned 4-cell blocks (8 B) of two window rows per
+        point.  C1: 13 x 13 window -> 8 row slots x 4 blocks x 2 rows = 512 B of ds_read_b64 per
+        (rotation, point) serving 169 candidates.  Algorithmic bytes: 2 B per
+        candidate per point.  kernel_ms: HIP events around the tile kernel(s) of the call (the
+        parts of a batch run on streams of their own: their spans are added)."""
         k_ms = acc["dominant_kernel_ms"] / steps
         cand = acc["candidates_scored"] / steps
         secs = max(k_ms, 1e-9) * 1e-3
         alg = cand * self.points * 2.0
         side = 13
         lds = cand / (side * side) * self.points * 512.0
-        return {"kernel": "Rt2DRowPairKernel (LDS-resident grid image, packed 16-bit sums)",
+        return {"kernel": "Rt2DTileKernel (LDS tiles of the quantised grid image, packed 16-bit sums)",
                 "bound": "lds", "achieved": lds / secs / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
                 "frac": lds / secs / 1e9 / LDS_PEAK_GBS,
-                "traffic": pmc("Rt2DRowPair", "c1") if self.matches_per_step == 128 else None,
+                "traffic": pmc("Rt2DTile", "c1") if self.matches_per_step == 128 and
+                self.grid_side == 200 and not self.dirty else None,
                 "kernel_ms": k_ms, "algorithmic_bytes": alg, "lds_bytes": lds,
                 "algorithmic_GBps": alg / secs / 1e9,
                 "hbm_frac_algorithmic": alg / secs / 1e9 / HBM_PEAK_GBS,
                 "candidates_per_s_kernel": cand / secs,
-                "note": "frac = LDS bytes read by the bulk kernel's window reads / kernel time "
-                        "(discretisation and list building included) / 150 TB/s (ds_read_b64 "
+                "note": "frac = LDS bytes read by the tile kernel's window reads / its HIP-event "
+                        "time (image staging, list copies and task building of every work item "
+                        "included; discretisation is the prep kernel's) / 150 TB/s (ds_read_b64 "
                         "aggregate); hbm_frac_algorithmic > 1 means on-chip residency"}
 
 
@@ -605,7 +661,7 @@ class Rt3DWorkload:
         itself, waves in s_waitcnt half of their time (five barriers per point chunk) -- counters
         taken before the lookup loop was hand-scheduled and the workgroups halved (DESIGN 5.4:
         6.6 per lookup in the loop, two workgroups per CU).  Gather
-        path (CMX_RT3D_TILES=0): buffer_load_ubyte from L2, measured ceiling 19 cycles per
+        path (debug switch rt3d_no_tiles): buffer_load_ubyte from L2, measured ceiling 19 cycles per
         64-lane gather per CU = 2.05e12 lookups/s (profiles/r02_rt3d_gather_ceiling.txt)."""
         k_ms = acc["dominant_kernel_ms"] / steps
         cand = acc["candidates_scored"] / steps
@@ -614,7 +670,7 @@ class Rt3DWorkload:
         side = round((cand / max(scans, 1)) ** (1.0 / 3.0))
         groups = ((side + 1) // 2) ** 3
         bulk = acc["coarse_candidates"] / steps != cand       # the bounds path ran
-        tiles = bulk and os.environ.get("CMX_RT3D_TILES", "1") != "0" and groups <= 1024
+        tiles = bulk and groups <= 1024
         lookups = scans * (groups if bulk else cand / max(scans, 1)) * self.n_points
         alg = cand * self.n_points * 2.0 + scans * self.n_points * 12.0
         peak = 256 * 2.4e9 / 2 * 64 / 1e9 if tiles else 2050.0              # G lookups/s
@@ -766,19 +822,27 @@ class Fast3DWorkload:
         # counter traffic (L2 misses x 128 B) next to it says how much of the peak the line
         # granularity actually consumes.
         secs = expand["kernel_ms"] * 1e-3
-        alg_launch = expand["lookups_per_step"] / expand["launches_per_step"] * 24.0
+        # 8 B per (node, point) lookup -- the oct word.  (Until round 3 this line priced
+        # 24 B, counting the point's 16-byte cell record once per lookup; a family reads that
+        # record once for up to eight sibling nodes, so the numerator overstated.  Kept as
+        # frac_24B for comparison with the older records.)
+        lookups_launch = expand["lookups_per_step"] / expand["launches_per_step"]
+        alg_launch = lookups_launch * 8.0
         expand["gather_issue"] = {k: expand[k] for k in ("bound", "achieved", "peak", "unit", "frac")}
         expand.update({"bound": "hbm", "achieved": alg_launch / secs / 1e9, "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": alg_launch / secs / 1e9 / HBM_PEAK_GBS,
+                       "frac_24B": lookups_launch * 24.0 / secs / 1e9 / HBM_PEAK_GBS,
                        "algorithmic_bytes": alg_launch,
+                       "traffic_per_algorithmic_byte": None if expand["traffic"] is None
+                       else expand["traffic"] / alg_launch,
                        "hbm_frac_traffic": None if expand["traffic"] is None
                        else expand["traffic"] / secs / 1e9 / HBM_PEAK_GBS})
-        expand["note"] = ("achieved = algorithmic bytes per launch (24 B per lookup: 8-byte oct "
-                          "word + 16-byte cell record) / average launch time / 8 TB/s; "
-                          "hbm_frac_traffic = rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the same "
-                          "command per launch / the same time / 8 TB/s (32 distinct submaps: L2 "
-                          "misses 50 %, every miss a 128-byte line for 8 bytes); gather_issue: the "
-                          "same lookups against the chip's gather-issue ceiling.  " + expand["note"])
+        expand["note"] = ("achieved = algorithmic bytes per launch (8 B per lookup: the oct word, "
+                          "SURVEY 8d) / average launch time / 8 TB/s; hbm_frac_traffic = rocprofv3 "
+                          "FETCH_SIZE x2 + WRITE_SIZE of the same command per launch / the same "
+                          "time / 8 TB/s (32 distinct submaps: every L2 miss a 128-byte line for 8 "
+                          "bytes); gather_issue: the same lookups against the chip's gather-issue "
+                          "ceiling.  " + expand["note"])
         expand["lowest_resolution_scoring"] = coarse_line
         return expand
 
@@ -798,7 +862,7 @@ def make_workload(name, args, device, rank, world_size):
 
 STAT_KEYS = ("candidates_scored", "coarse_candidates", "dominant_kernel_ms", "device_ms",
              "num_scans", "expansion_ms", "expansion_launches", "expansion_nodes",
-             "expansion_lookups")
+             "expansion_lookups", "refined_candidates", "finalists")
 GATHER_PEAK_GLOOKUPS = 2050.0   # measured: 19 cycles per 64-lane gather instruction per CU
                                 # (profiles/r02_rt3d_gather_ceiling.txt) x 256 CUs x 2.4 GHz
 
@@ -857,6 +921,11 @@ def other_configs(args, device, sync, pmc):
             w = factory()
             dt, acc, last = measure(w, steps, warmup, sync)
             entry = w.describe(last[3], last[0])
+            inserted = getattr(w, "insert_s", 0.0)
+            if inserted:       # (dirty-grid leg: the insertions between the steps are not the step)
+                per_step = inserted / (steps + warmup)
+                entry["grid_insertions_ms_per_step"] = per_step * 1e3
+                dt -= per_step * steps
             if cpu_leg is not None:
                 pending_cpu.append((name, cpu_leg, w))     # after every GPU leg, see below
             entry.update({
@@ -880,13 +949,25 @@ def other_configs(args, device, sync, pmc):
         "c5_single": lambda w: cpu_baseline_c5(w, min(5.0, args.cpu_seconds))}
     run("c1_single", lambda: Rt2DWorkload(args, device, matches=1), 200, 50)
     run("c1_batch128", lambda: Rt2DWorkload(args, device, matches=128), 100, 10, cpu.get("c1_batch128"))
+    run("c1_batch128_dirty", lambda: Rt2DWorkload(args, device, matches=128, dirty=True), 50, 5)
+    run("c1_batch128_grid400", lambda: Rt2DWorkload(args, device, matches=128, grid=400), 50, 5)
+    run("c1_batch1024", lambda: Rt2DWorkload(args, device, matches=1024), 30, 5)
     run("c1_batch128_8_threads", lambda: Rt2DPipelinedWorkload(args, device, 128, 8, 4), 25, 5)
+    run("c2_8_scans_8_threads", lambda: Fast2DConcurrentWorkload(args, device, 8), 60, 10)
     sub = argparse.Namespace(**vars(args))
     sub.submaps = 16
     run("c3_share_16_submaps", lambda: Fast2DWorkload(sub, device, 0, 1, sharded=True), 5, 2)
     run("c4", lambda: Rt3DWorkload(args, device), 3, 1, cpu.get("c4"))
     run("c5_single", lambda: Fast3DWorkload(args, device, pairs=1), 10, 2, cpu.get("c5_single"))
     run("c5_share_32_submaps", lambda: Fast3DWorkload(args, device, pairs=32), 4, 2)
+    # the same share with every node of a family expanded on its own (round 2's expansion): a
+    # same-run, same-box A/B of the family expansion (boxes differ by tens of percent here)
+    from cartographer_amd import _lib
+    try:
+        _lib.debug_set(fast3d_no_families=1)
+        run("c5_share_32_submaps_no_families", lambda: Fast3DWorkload(args, device, pairs=32), 4, 2)
+    finally:
+        _lib.debug_set(fast3d_no_families=0)
     for name, cpu_leg, w in pending_cpu:
         try:
             out[name]["cpu_baseline"] = cpu_leg(w)
@@ -1124,9 +1205,13 @@ def main():
             # The driver's record keeps scalars: every config's line flat in `config` ...
             for key, e in other.items():
                 short = {"c1_single": "c1_single", "c1_batch128": "c1b128",
-                         "c1_batch128_8_threads": "c1b128t8", "c3_share_16_submaps": "c3s16",
+                         "c1_batch128_dirty": "c1b128_dirty", "c1_batch128_grid400": "c1b128_g400",
+                         "c1_batch1024": "c1b1024",
+                         "c1_batch128_8_threads": "c1b128t8", "c2_8_scans_8_threads": "c2_8scans",
+                         "c3_share_16_submaps": "c3s16",
                          "c4": "c4", "c5_single": "c5_single",
-                         "c5_share_32_submaps": "c5s32"}.get(key, key)
+                         "c5_share_32_submaps": "c5s32",
+                         "c5_share_32_submaps_no_families": "c5s32_nofam"}.get(key, key)
                 if "error" in e:
                     config[f"{short}_error"] = e["error"][:80]
                     continue

@@ -130,6 +130,12 @@ class NodeData3D(C.Structure):
                 ("histogram_size", C.c_int32)]
 
 
+class Ceres3DIntensityTerm(C.Structure):
+    _fields_ = [("grid", C.c_void_p), ("intensities", C.c_void_p), ("weight", C.c_double),
+                ("huber_scale", C.c_double), ("intensity_threshold", C.c_float),
+                ("reserved", C.c_int32)]
+
+
 class Result3D(C.Structure):
     _fields_ = [("score", C.c_float), ("pose_estimate", Pose3d), ("rotational_score", C.c_float),
                 ("low_resolution_score", C.c_float)]
@@ -159,6 +165,9 @@ EXPORTED_SYMBOLS = [
     "cmx_fast2d_match_sharded", "cmx_fast3d_match_sharded", "cmx_shard_range",
     "cmx_pack_best_key", "cmx_unpack_best_key",
     "cmx_voxel_filter", "cmx_adaptive_voxel_filter", "cmx_compute_histogram",
+    "cmx_intensity_grid3d_create", "cmx_intensity_grid3d_destroy",
+    "cmx_grid3d_insert_with_intensities", "cmx_intensity_grid3d_download",
+    "cmx_ceres3d_match_grids_intensity",
 ]
 
 # include/cartographer_mi355x_debug.h (test and tool switches, not part of the boundary).
@@ -208,6 +217,18 @@ def lib():
     L.cmx_grid3d_insert.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float,
                                     C.c_float, C.c_int32]
     L.cmx_grid3d_info.argtypes = [C.c_void_p, P(C.c_float), P(C.c_int32), P(C.c_int64)]
+    if hasattr(L, "cmx_intensity_grid3d_create"):      # (absent from the round-3 library)
+        L.cmx_intensity_grid3d_create.argtypes = [C.c_float, C.c_int32, P(C.c_void_p)]
+        L.cmx_intensity_grid3d_destroy.argtypes = [C.c_void_p]
+        L.cmx_intensity_grid3d_destroy.restype = None
+        L.cmx_grid3d_insert_with_intensities.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float,
+            C.c_float, C.c_int32, C.c_float]
+        L.cmx_intensity_grid3d_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int64,
+                                                    P(C.c_int64)]
+        L.cmx_ceres3d_match_grids_intensity.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+            C.c_void_p, C.c_void_p]
     L.cmx_grid3d_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, P(C.c_int64)]
     L.cmx_grid2d_insert.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                     C.c_int32, C.c_float, C.c_float, C.c_int32]

@@ -709,6 +709,17 @@ extern "C" cmx_status cmx_ceres3d_match_grids(const cmx_ceres3d_options* options
                                               const int32_t* num_points,
                                               cmx_pose3d* pose_estimate,
                                               cmx_ceres_summary* summary) {
+  return cmx_ceres3d_match_grids_intensity(options, target_translation_xyz, initial_pose_estimate,
+                                           grids, point_clouds_xyz, num_points, nullptr,
+                                           pose_estimate, summary);
+}
+
+extern "C" cmx_status cmx_ceres3d_match_grids_intensity(
+    const cmx_ceres3d_options* options, const double* target_translation_xyz,
+    const cmx_pose3d* initial_pose_estimate, const cmx_grid3d* const* grids,
+    const float* const* point_clouds_xyz, const int32_t* num_points,
+    const cmx_ceres3d_intensity_term* terms, cmx_pose3d* pose_estimate,
+    cmx_ceres_summary* summary) {
   using namespace cmx;
   return Guard([&] {
     CMX_REQUIRE(options && target_translation_xyz && initial_pose_estimate && grids &&
@@ -730,8 +741,35 @@ extern "C" cmx_status cmx_ceres3d_match_grids(const cmx_ceres3d_options* options
       CMX_REQUIRE(device < 0 || d == device, "the grids live on different devices");
       device = d;
       cloud_floats += 3 * static_cast<size_t>(num_points[k]);
+      if (terms && terms[k].grid) {
+        // CHECKs of CreateIntensityCostFunctionOptions' consumers (ceres_scan_matcher_3d.cc:
+        // 118-137, intensity_cost_function_3d.h:41-47) and of ceres::HuberLoss (a > 0).
+        CMX_REQUIRE(terms[k].intensities != nullptr, "intensities of pair %d are null", k);
+        CMX_REQUIRE(terms[k].weight > 0., "intensity weight must be > 0");
+        CMX_REQUIRE(terms[k].huber_scale > 0., "intensity huber_scale must be > 0");
+        CMX_REQUIRE(terms[k].intensity_threshold > 0.f, "intensity_threshold must be > 0");
+        cloud_floats += static_cast<size_t>(num_points[k]);
+      }
     }
     WorkspaceLease ws(device);
+    float* zero_intensity = nullptr;            // an intensity grid nothing was inserted into
+    for (int k = 0; terms && k < P.num_pairs; ++k) {
+      if (!terms[k].grid) continue;
+      float res = 0.f;
+      int d = 0;
+      if (!IntensityGrid3DBrick(terms[k].grid, ws->stream, &P.pair[k].igrid, &res, &d)) {
+        if (!zero_intensity) {
+          zero_intensity = ws->dev[3].ReserveAs<float>(4);
+          CMX_HIP(hipMemsetAsync(zero_intensity, 0, 16, ws->stream));
+        }
+        P.pair[k].igrid = Brick{};
+        P.pair[k].igrid.cells = zero_intensity;
+        P.pair[k].igrid.nx = P.pair[k].igrid.ny = P.pair[k].igrid.nz = 1;
+      }
+      CMX_REQUIRE(d == device, "the grids live on different devices");
+      CMX_REQUIRE(res == P.pair[k].resolution,
+                  "the intensity grid of pair %d must have its hybrid grid's resolution", k);
+    }
     if (any_empty) {
       // A HybridGrid nothing was inserted into: every lookup is value 0 (kMinProbability).
       uint16_t* zero = ws->dev[2].ReserveAs<uint16_t>(8);
@@ -753,6 +791,15 @@ extern "C" cmx_status cmx_ceres3d_match_grids(const cmx_ceres3d_options* options
       P.pair[k].scaling =
           options->occupied_space_weight[k] / std::sqrt(static_cast<double>(num_points[k]));
       off += 3 * static_cast<size_t>(num_points[k]);
+      if (terms && terms[k].grid) {
+        std::memcpy(h_xyz + off, terms[k].intensities, sizeof(float) * num_points[k]);
+        P.pair[k].has_intensity = 1;
+        P.pair[k].intensity_threshold = terms[k].intensity_threshold;
+        P.pair[k].intensities = d_xyz + off;
+        P.pair[k].iscaling = terms[k].weight / std::sqrt(static_cast<double>(num_points[k]));
+        P.pair[k].huber_a = terms[k].huber_scale;
+        off += static_cast<size_t>(num_points[k]);
+      }
     }
     for (int a = 0; a < 3; ++a) {
       P.target[a] = target_translation_xyz[a];

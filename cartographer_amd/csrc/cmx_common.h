@@ -69,7 +69,9 @@ cmx_status Guard(F&& body) {
 #define CMX_DEBUG_OPTIONS(X)                                                                      \
   X(rt2d_legacy)          /* 1: real-time 2D on the one-thread-per-candidate kernels only */       \
   X(rt2d_tile)            /* tile core size override (multiple of 8) */                            \
-  X(rt2d_groups)          /* rotation groups per tile override */                                  \
+  X(rt2d_groups)          /* most rotation groups (work items) per tile */                         \
+  X(rt2d_target)          /* entries per work item the planner aims at */                          \
+  X(rt2d_lds_kb)          /* LDS budget of a tile workgroup in KB */                               \
   X(rt2d_no_image_cache)  /* 1: grid images are always built into scratch of the call */           \
   X(rt2d_parts)           /* parts a large batch is issued in (0: default) */                      \
   X(timeline)             /* 1: in-kernel timelines (cmx_device.h Stamp) reported on stderr */     \
@@ -78,6 +80,7 @@ cmx_status Guard(F&& body) {
   X(sync)                 /* 1: synchronise after every stage (localises a faulting kernel) */     \
   X(no_copy_kernels)      /* 1: small transfers by copy commands instead of a copy kernel */       \
   X(frontier_capacity)    /* nodes per frontier / leaf buffer (tests: forces the overflow path) */ \
+  X(comm_virtual_ranks)   /* N > 1: a one-device cmx_comm becomes N ranks on it (host-side key reduction) */ \
   X(fast2d_unfused)       /* 1: fast 2D front end as separate prep / score launches */             \
   X(fast2d_store_scans)   /* 1: never keep the surviving scans' cells, 2: always */                \
   X(fast2d_fused_threads) /* threads per block of the fused front end */                           \
@@ -182,7 +185,7 @@ class PinnedBuffer {
 // device memory by a one-workgroup kernel instead of a copy command: a latency-bound call is a
 // chain of launches on one stream, and a copy command in that chain costs 10-15 us of engine
 // start-up where a launch costs 3-4.  Falls back to hipMemcpyAsync above `kCopyKernelMaxBytes`
-// or with CMX_COPY_KERNELS=0.  `pinned` is the host side (source for to_device, else target).
+// or with the debug switch no_copy_kernels.  `pinned` is the host side (source for to_device, else target).
 constexpr size_t kCopyKernelMaxBytes = 1024 * 1024;   // one workgroup per 64 KB
 void SmallCopyAsync(void* dst, const void* src, size_t bytes, bool to_device, hipStream_t stream);
 
@@ -201,7 +204,7 @@ struct Workspace {
   ~Workspace();
 };
 
-// Optional per-stage timing (environment CMX_TRACE=1): an event after every
+// Optional per-stage timing (debug switch trace): an event after every
 // stage, durations printed to stderr when the call has synchronised.
 class StageTrace {
  public:
@@ -226,12 +229,17 @@ class WorkspaceLease {
   Workspace* ws_;
 };
 
-// In-kernel timelines (CMX_TIMELINE=1): see cmx_device.h Stamp().  `Enabled` is read once.
+// In-kernel timelines (debug switch timeline): see cmx_device.h Stamp().
 bool TimelineEnabled();
 // Prints, per stamp k, the median / max over blocks of (t_k - t_0) and the span of the whole
 // launch (first t_0 to last stamp) in microseconds; `device` holds blocks x 16 stamps.
 void ReportTimeline(const char* name, const unsigned long long* device, int blocks,
                     hipStream_t stream);
+
+// filters.hip: stable sort of n (32-bit key, index) pairs on ws.stream; scratch from
+// ws.dev[temp_slot].
+void StableSortPairs32(Workspace& ws, int temp_slot, const unsigned* keys_in, unsigned* keys_out,
+                       const int* values_in, int* values_out, int n);
 
 // Thread-local stream override (cmx_set_stream).
 hipStream_t OverrideStream(int device);

@@ -80,6 +80,7 @@ class HostPool {
       return;
     }
     Job job{&fn, n};
+    job.chunk = std::max(1, n / (8 * (num_workers_ + 1)));
     job_.store(&job, std::memory_order_seq_cst);
     generation_.fetch_add(1, std::memory_order_seq_cst);
     {
@@ -107,6 +108,7 @@ class HostPool {
     std::atomic<int> next{0}, done{0};
     std::mutex error_mutex;
     std::exception_ptr error;
+    int chunk = 1;
     Job(const std::function<void(int)>* f, int count) : fn(f), n(count) {}
   };
   HostPool() {
@@ -118,16 +120,22 @@ class HostPool {
     for (int t = 0; t < num_workers_; ++t) std::thread([this] { WorkerLoop(); }).detach();
   }
   static void Work(Job* job) {
+    // (indices are drawn `chunk` at a time: a thousand sub-microsecond items drawn one by one
+    // spend their time on the two shared counters)
+    const int chunk = job->chunk;
     for (;;) {
-      const int i = job->next.fetch_add(1, std::memory_order_relaxed);
-      if (i >= job->n) break;
-      try {
-        (*job->fn)(i);
-      } catch (...) {
-        std::lock_guard<std::mutex> lk(job->error_mutex);
-        if (!job->error) job->error = std::current_exception();
+      const int begin = job->next.fetch_add(chunk, std::memory_order_relaxed);
+      if (begin >= job->n) break;
+      const int end = std::min(job->n, begin + chunk);
+      for (int i = begin; i < end; ++i) {
+        try {
+          (*job->fn)(i);
+        } catch (...) {
+          std::lock_guard<std::mutex> lk(job->error_mutex);
+          if (!job->error) job->error = std::current_exception();
+        }
       }
-      job->done.fetch_add(1, std::memory_order_release);
+      job->done.fetch_add(end - begin, std::memory_order_release);
     }
   }
   void WorkerLoop() {
@@ -241,10 +249,7 @@ SmallCopyKernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t w
 }  // namespace
 
 void SmallCopyAsync(void* dst, const void* src, size_t bytes, bool to_device, hipStream_t stream) {
-  static const bool enabled = [] {
-    const char* e = getenv("CMX_COPY_KERNELS");
-    return e ? e[0] != '0' : true;
-  }();
+  const bool enabled = Debug().no_copy_kernels == 0;
   const bool aligned = (reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 16 == 0;
   if (!enabled || !aligned || bytes == 0 || bytes > kCopyKernelMaxBytes) {
     CMX_HIP(hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost,
@@ -271,8 +276,7 @@ Workspace::~Workspace() {
 }
 
 StageTrace::StageTrace(hipStream_t stream) : stream_(stream) {
-  const char* env = getenv("CMX_TRACE");
-  enabled_ = env && env[0] == '1';
+  enabled_ = Debug().trace != 0;
   if (enabled_) Mark("begin");
 }
 StageTrace::~StageTrace() {
@@ -280,10 +284,7 @@ StageTrace::~StageTrace() {
 }
 void StageTrace::Mark(const char* name) {
   {
-    static const bool sync_debug = [] {
-      const char* env = getenv("CMX_SYNC");
-      return env && env[0] == '1';
-    }();
+    const bool sync_debug = Debug().sync != 0;
     if (sync_debug) {   // debugging aid: localise a faulting kernel
       fprintf(stderr, "[cmx sync] %s ...\n", name);
       (void)hipStreamSynchronize(stream_);

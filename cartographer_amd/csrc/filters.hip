@@ -411,6 +411,20 @@ __global__ void SliceBeginScatterKernel(const int* __restrict__ is_head,
 }
 
 }  // namespace
+
+// Stable sort of n (32-bit key, index) pairs on the workspace's stream (hipCUB radix sort; the
+// only translation unit that pays for instantiating it): grid_3d.hip orders the returns of a scan
+// by intensity-grid cell with it.  Scratch comes from ws.dev[temp_slot].
+void StableSortPairs32(Workspace& ws, int temp_slot, const unsigned* keys_in, unsigned* keys_out,
+                       const int* values_in, int* values_out, int n) {
+  size_t bytes = 0;
+  CMX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys_in, keys_out, values_in,
+                                             values_out, n, 0, 32, ws.stream));
+  void* temp = ws.dev[temp_slot].Reserve(bytes + 256);
+  CMX_HIP(hipcub::DeviceRadixSort::SortPairs(temp, bytes, keys_in, keys_out, values_in, values_out,
+                                             n, 0, 32, ws.stream));
+}
+
 }  // namespace cmx
 
 using cmx::Guard;

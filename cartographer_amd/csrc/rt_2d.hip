@@ -589,42 +589,6 @@ void Rt2DLegacyBatch(const cmx_rt_options* options, const Rt2DItem* items, const
   }
 }
 
-// One part of a batch: arguments, SearchParameters, then the tile path (probability grids) or
-// the per-candidate kernels.
-void Rt2DMatchPart(const cmx_rt_options* options, const Rt2DItem* items, int num, int32_t device,
-                   cmx_match_stats* stats) {
-  CMX_REQUIRE(options && items && num >= 1, "null argument");
-  const bool tsdf = items[0].weight_cells != nullptr;
-  for (int m = 0; m < num; ++m) {
-    const Rt2DItem& it = items[m];
-    CMX_REQUIRE(it.limits && (it.cells || it.device_cells) && it.initial && it.xyz,
-                "null argument");
-    CMX_REQUIRE(it.pose != nullptr && it.score != nullptr,
-                "pose_estimate must not be null");            // CHECK at :121
-    CMX_REQUIRE(it.n >= 1 && it.n <= (1 << 24), "bad point count");
-    CMX_REQUIRE(it.limits->resolution > 0. && it.limits->num_x_cells >= 1 &&
-                    it.limits->num_y_cells >= 1,
-                "bad map limits");
-    CMX_REQUIRE((it.weight_cells != nullptr) == tsdf, "mixed grid types in one batch");
-    if (tsdf) CMX_REQUIRE(it.max_tsd > 0.f && it.max_weight > 0.f, "bad TSDF ranges");
-  }
-  // SearchParameters of every item (a range scan over its cloud, acos): on the host pool.
-  std::vector<Rt2DSearch> search(num);
-  ParallelFor(num, 8, [&](int m) { Rt2DComputeSearch(options, items[m], &search[m]); });
-  for (int m = 0; m < num; ++m) {
-    const Rt2DSearch& sr = search[m];
-    CMX_REQUIRE(sr.num_scans >= 1 && sr.num_scans < (1 << 16) && sr.nl >= 0 && sr.nl < (1 << 12),
-                "unsupported search window");
-    const long long side = 2ll * sr.nl + 1;
-    CMX_REQUIRE(side * side * sr.num_scans < (1ll << 30), "search window too large");
-  }
-  UseDevice(device);
-  if (!tsdf && !Debug().rt2d_legacy &&
-      Rt2DTileBatch(options, items, search.data(), num, device, stats))
-    return;
-  Rt2DLegacyBatch(options, items, search.data(), num, device, stats);
-}
-
 // ScoreCandidates (SM2/real_time_correlative_scan_matcher_2d.cc:147-175), the method the
 // reference keeps "visible for testing": ANY list of (scan, x offset, y offset) over discrete
 // scans handed in by the caller.  One thread per candidate, the f32 sums in point order
@@ -666,44 +630,114 @@ __global__ void Rt2DScoreCandidatesKernel(const uint16_t* __restrict__ cells,
 
 void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int num, int32_t device,
                     cmx_match_stats* stats) {
-  // A large batch goes out as two half-batches (debug switch rt2d_parts) from as many host threads
-  // (the caller and pool workers), each with its own workspace and stream: the host's preparation of one half runs
-  // under the kernels of the other (of 172 us for 128 C1 matches the host held 75 before the
-  // first launch).  Not when the caller ordered the work on a stream of its own (cmx_set_stream
-  // is per thread), and rt2d_parts = 1 keeps one batch.
-  const int max_parts = Debug().rt2d_parts > 0 ? std::min(8, Debug().rt2d_parts) : 2;
-  const int parts = std::min(max_parts, num / 32);             // (at least 32 matches per part)
-  if (parts <= 1 || OverrideStream(device) != nullptr) {
-    Rt2DMatchPart(options, items, num, device, stats);
+  CMX_REQUIRE(options && items && num >= 1, "null argument");
+  // Debug switch host_trace: wall clock of the host phases (tools only).
+  const bool host_trace = Debug().host_trace != 0;
+  auto t_last = std::chrono::steady_clock::now();
+  std::string host_report;
+  const auto lap = [&](const char* name) {
+    if (!host_trace) return;
+    const auto now = std::chrono::steady_clock::now();
+    char buf[64];
+    snprintf(buf, sizeof buf, " %s=%.0f", name,
+             std::chrono::duration<double, std::micro>(now - t_last).count());
+    host_report += buf;
+    t_last = now;
+  };
+  const bool tsdf = items[0].weight_cells != nullptr;
+  for (int m = 0; m < num; ++m) {
+    const Rt2DItem& it = items[m];
+    CMX_REQUIRE(it.limits && (it.cells || it.device_cells) && it.initial && it.xyz,
+                "null argument");
+    CMX_REQUIRE(it.pose != nullptr && it.score != nullptr,
+                "pose_estimate must not be null");            // CHECK at :121
+    CMX_REQUIRE(it.n >= 1 && it.n <= (1 << 24), "bad point count");
+    CMX_REQUIRE(it.limits->resolution > 0. && it.limits->num_x_cells >= 1 &&
+                    it.limits->num_y_cells >= 1,
+                "bad map limits");
+    CMX_REQUIRE((it.weight_cells != nullptr) == tsdf, "mixed grid types in one batch");
+    if (tsdf) CMX_REQUIRE(it.max_tsd > 0.f && it.max_weight > 0.f, "bad TSDF ranges");
+  }
+  // SearchParameters of every item (a range scan over its cloud, acos): on the host pool, part
+  // by part (below), so that the first part's kernels start under the planning of the others.
+  std::vector<Rt2DSearch> search(num);
+  lap("args");
+  const auto plan_search = [&](int begin, int end) {
+    ParallelFor(end - begin, 16,
+                [&](int k) { Rt2DComputeSearch(options, items[begin + k], &search[begin + k]); });
+    for (int m = begin; m < end; ++m) {
+      const Rt2DSearch& sr = search[m];
+      CMX_REQUIRE(sr.num_scans >= 1 && sr.num_scans < (1 << 16) && sr.nl >= 0 && sr.nl < (1 << 12),
+                  "unsupported search window");
+      const long long side = 2ll * sr.nl + 1;
+      CMX_REQUIRE(side * side * sr.num_scans < (1ll << 30), "search window too large");
+    }
+  };
+  UseDevice(device);
+  if (tsdf || Debug().rt2d_legacy) {
+    plan_search(0, num);
+    Rt2DLegacyBatch(options, items, search.data(), num, device, stats);
     return;
   }
-  std::vector<cmx_match_stats> part(parts);
-  std::vector<cmx_status> status(parts, CMX_OK);
-  std::vector<std::string> error(parts);
-  ParallelFor(parts, 0, [&](int h) {
-    const int begin = static_cast<int>(static_cast<long long>(num) * h / parts),
-              end = static_cast<int>(static_cast<long long>(num) * (h + 1) / parts);
-    status[h] = Guard([&] { Rt2DMatchPart(options, items + begin, end - begin, device, &part[h]); });
-    if (status[h] != CMX_OK) error[h] = LastError();      // (the message is per thread)
-  });
+  // A large batch goes out in parts (debug switch rt2d_parts), each with its own workspace and
+  // stream and each from a host thread of its own (the caller and pool workers): planning,
+  // upload and the launches of one part (~0.1 ms of host time: half of it launch calls) run
+  // beside those of the others, and the latency-bound kernels at the two ends of a part (prep,
+  // finish) run under the tile kernels of the other parts.  Not when the caller ordered the work
+  // on a stream of its own (cmx_set_stream is per thread).
+  int parts = Debug().rt2d_parts > 0 ? std::min(16, Debug().rt2d_parts)
+                                      : (num >= 1024 ? 8 : num >= 256 ? 4 : 2);
+  parts = std::max(1, std::min(parts, num / 32));              // (at least 32 matches per part)
+  if (OverrideStream(device) != nullptr) parts = 1;
+  struct Part {
+    int begin, end;
+    cmx_match_stats stats{};
+    cmx_status status = CMX_OK;
+    std::string error;
+  };
+  std::vector<Part> part(parts);
+  const auto run_part = [&](int h) {
+    Part& p = part[h];
+    p.begin = static_cast<int>(static_cast<long long>(num) * h / parts);
+    p.end = static_cast<int>(static_cast<long long>(num) * (h + 1) / parts);
+    p.status = Guard([&] {
+      (void)hipSetDevice(device);                            // (pool threads: their own current device)
+      plan_search(p.begin, p.end);
+      Rt2DTileCall call(options, items + p.begin, search.data() + p.begin, p.end - p.begin, device);
+      bool done = call.Plan();
+      if (done) {
+        call.Enqueue();
+        done = call.Collect(&p.stats);
+      }
+      // (not eligible, a flat score landscape, a point outside the predicted box: the part runs
+      // on the per-candidate kernels)
+      if (!done)
+        Rt2DLegacyBatch(options, items + p.begin, search.data() + p.begin, p.end - p.begin, device,
+                        &p.stats);
+    });
+    if (p.status != CMX_OK) p.error = LastError();           // (the message is per thread)
+  };
+  if (parts == 1) run_part(0);
+  else ParallelFor(parts, 0, run_part);
+  lap("parts");
+  cmx_match_stats total{};
   for (int h = 0; h < parts; ++h) {
-    if (status[h] == CMX_OK) continue;
-    SetLastError("%s", error[h].c_str());
-    throw HipError{status[h]};
-  }
-  if (stats) {
-    *stats = part[0];
-    for (int h = 1; h < parts; ++h) {
-      stats->candidates_scored += part[h].candidates_scored;
-      stats->coarse_candidates += part[h].coarse_candidates;
-      stats->nodes_expanded += part[h].nodes_expanded;
-      stats->num_scans += part[h].num_scans;
-      stats->device_ms = std::max(stats->device_ms, part[h].device_ms);     // the parts overlap
-      stats->dominant_kernel_ms += part[h].dominant_kernel_ms;
-      stats->refined_candidates += part[h].refined_candidates;
-      stats->finalists += part[h].finalists;
+    const Part& p = part[h];
+    if (p.status != CMX_OK) {
+      SetLastError("%s", p.error.c_str());
+      throw HipError{p.status};
     }
+    total.candidates_scored += p.stats.candidates_scored;
+    total.coarse_candidates += p.stats.coarse_candidates;
+    total.num_scans += p.stats.num_scans;
+    total.device_ms = std::max(total.device_ms, p.stats.device_ms);      // the parts overlap
+    total.dominant_kernel_ms += p.stats.dominant_kernel_ms;
+    total.refined_candidates += p.stats.refined_candidates;
+    total.finalists += p.stats.finalists;
   }
+  if (stats) *stats = total;
+  if (host_trace)
+    fprintf(stderr, "[cmx host] rt2d batch(%d, %d parts):%s us\n", num, parts, host_report.c_str());
 }
 
 void Rt2DMatch(const cmx_rt_options* options, const cmx_grid2d_limits* limits,

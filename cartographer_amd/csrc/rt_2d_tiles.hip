@@ -38,6 +38,7 @@
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 
 #include "rt_2d_device.h"
 #include "scan_matching_2d.h"
@@ -45,13 +46,13 @@
 namespace cmx {
 namespace {
 
-constexpr int kTileThreads = 512;
-constexpr int kTileWaves = kTileThreads / 64;
+constexpr int kTileMaxThreads = 1024;        // a tile workgroup: 1024 threads alone on a CU (one tile
+                                            // per match), or 512 with two per CU (several tiles)
 constexpr int kFinishThreads = 512;
 constexpr int kMaxTiles = 16;               // tiles of a match's bounding box (x 4 phases = 64 keys)
 constexpr int kStage1Cap = 1024;            // candidates the exact integer pass takes per match
 constexpr unsigned kFlat = 0xffffffffu;     // misc[1]: more candidates than the lists hold
-constexpr unsigned kOutOfBox = 0xfffffffeu; // misc[1]: a point fell outside the predicted box
+constexpr unsigned kOutOfBox = 0x80000000u; // misc[0] (next to the prep tickets): a point fell outside the predicted box
 
 struct Rt2DTileParams {
   // grid and initial pose
@@ -85,18 +86,29 @@ struct Rt2DTileParams {
   uint16_t* lists;
   int cap_s;
   uint32_t* hdr;             // [num_scans][ntiles * 4]: start | count << 16
-  // rotation groups: workgroup (tile, g) takes rotations g, g + G, ...
-  int G, rw;                 // rw = ceil(num_scans / G) <= 64
+  // rotation groups: work item (tile, g, G) takes rotations g, g + G, ...; G is chosen per TILE
+  // on the device from its entry count (the planner at the end of the prep kernel)
+  int gmin, gmax;            // ceil(num_scans / 64) <= G <= gmax
+  int target;                // entries per work item the planner aims at
+  int rw;                    // rotations a workgroup's LDS holds: ceil(num_scans / gmin) <= 64
   int list_lds;              // u16 entries of the LDS list buffer
   int task_cap;
   int flush_atomic;          // more than one tile: sums meet by atomics (qsum zeroed by the prep)
   int* qsum;                 // [num_scans][side^2]
-  unsigned* misc;            // [0] best weighted lower bound bits, [1] finalist count, then pairs
+  unsigned* misc;            // [0] prep workgroups done (the last one plans), [1] finalist count, then pairs
   unsigned* overflow;        // finalist pairs beyond kFinalistHead
   unsigned* stage;           // [0] candidates of the exact integer pass, [1] f32 finalists | rotations with finalists << 16
   unsigned long long* timeline;   // debug switch `timeline`: 16 stamps per tile / finish workgroup, else null
   int timeline_finish_base;       // first slot of the finish kernel's workgroups
 };
+
+// A match's parameters into LDS, a dword per thread (callers: barrier before the first use).
+__device__ __forceinline__ void CopyParams(Rt2DTileParams* dst, const Rt2DTileParams* src, int tid) {
+  static_assert(sizeof(Rt2DTileParams) % 4 == 0 && sizeof(Rt2DTileParams) / 4 <= 256,
+                "one dword per thread of the smallest workgroup");
+  if (tid < static_cast<int>(sizeof(Rt2DTileParams) / 4))
+    reinterpret_cast<uint32_t*>(dst)[tid] = AsGlobal(reinterpret_cast<const uint32_t*>(src))[tid];
+}
 
 __device__ __forceinline__ Rt2DFrame FrameOf(const Rt2DTileParams& P) {
   return Rt2DFrame{P.res, P.inv_res, P.max_x, P.max_y, P.tx, P.ty, P.init_qw, P.init_qz,
@@ -147,12 +159,17 @@ Rt2DQuantKernel(const Rt2DTileParams* __restrict__ params) {
 // Dynamic LDS: tmp[n_pad] u32 (entry | key << 16) | loc[n_pad] u16 | cnt[64] | start[64].
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-Rt2DTilePrepKernel(const Rt2DTileParams* __restrict__ params) {
+Rt2DTilePrepKernel(const Rt2DTileParams* __restrict__ params, int* __restrict__ work_count,
+                   int4* __restrict__ work_items, int work_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char prep_smem[];
-  const Rt2DTileParams& P = params[blockIdx.y];
+  // (the match's parameters through LDS: ONE round of loads instead of a scalar-load round trip
+  // whenever the code reaches for another field)
+  __shared__ Rt2DTileParams P;
+  const int tid = threadIdx.x, lane = tid & 63;
+  CopyParams(&P, params + blockIdx.y, tid);
+  __syncthreads();
   const int s = blockIdx.x;
   if (s >= P.num_scans) return;
-  const int tid = threadIdx.x, lane = tid & 63;
   const int n = P.n, n_pad = P.n_pad;
   uint32_t* tmp = reinterpret_cast<uint32_t*>(prep_smem);
   uint16_t* loc = reinterpret_cast<uint16_t*>(tmp + n_pad);
@@ -188,7 +205,7 @@ Rt2DTilePrepKernel(const Rt2DTileParams* __restrict__ params) {
     }
     tmp[i] = packed;
   }
-  if (outside) atomicMax(&P.misc[1], kOutOfBox);
+  if (outside) atomicOr(&P.misc[0], kOutOfBox);
   __syncthreads();
   if (tid < 64) {
     // list starts: every key's list is padded to 16 entries (a group of the window update)
@@ -196,9 +213,13 @@ Rt2DTilePrepKernel(const Rt2DTileParams* __restrict__ params) {
     const int padded = (c + 15) & ~15;
     const int incl = WaveInclusiveScan(padded);
     start[lane] = incl - padded;
+    // (agent-scope atomic store: written through, so that the planner below -- another
+    // workgroup, possibly on another XCD -- reads it without a device-wide fence here: an
+    // agent-scope release writes back the whole L2, 400 us for the 3456 workgroups of a batch)
     if (lane < nkeys)
-      P.hdr[static_cast<size_t>(s) * nkeys + lane] =
-          static_cast<uint32_t>(incl - padded) | (static_cast<uint32_t>(c) << 16);
+      __hip_atomic_store(&P.hdr[static_cast<size_t>(s) * nkeys + lane],
+                         static_cast<uint32_t>(incl - padded) | (static_cast<uint32_t>(c) << 16),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   uint16_t* out = P.lists + static_cast<size_t>(s) * P.cap_s;
@@ -207,30 +228,102 @@ Rt2DTilePrepKernel(const Rt2DTileParams* __restrict__ params) {
     if (packed == 0xffffffffu) continue;
     out[start[packed >> 16] + loc[i]] = static_cast<uint16_t>(packed & 0xffffu);
   }
+  // ---- the planner: the LAST workgroup of a match to arrive here cuts the match into work
+  // items.  A tile's entries are spread over as many rotation groups as its entry count asks for
+  // (the points of a scan cluster: one tile of four may hold 80 % of them), an empty tile gets
+  // none ----------------------------------------------------------------------------------------
+  __shared__ int plan[2 * kMaxTiles + 4];
+  __syncthreads();                           // this workgroup's header words have been written
+  if (tid == 0)                              // through (the barrier waits for its stores) before its
+    plan[0] = static_cast<int>(__hip_atomic_fetch_add(&P.misc[0], 1u, __ATOMIC_RELAXED,   // ticket
+                                                      __HIP_MEMORY_SCOPE_AGENT));
+  __syncthreads();
+  if ((plan[0] & 0x7fffffff) != P.num_scans - 1) return;
+  const int ntiles = P.ntx * P.nty;
+  int* total = plan + 4;                     // [ntiles] entries, then [ntiles] first item
+  if (tid < 2 * kMaxTiles) total[tid] = 0;
+  __syncthreads();
+  for (int idx = tid; idx < P.num_scans * nkeys; idx += 256) {
+    const uint32_t h = __hip_atomic_load(&P.hdr[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (h >> 16) atomicAdd(&total[(idx % nkeys) >> 2], static_cast<int>(h >> 16));
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int items = 0;
+    for (int t = 0; t < ntiles; ++t) {
+      const int entries = total[t];
+      int G = entries == 0 ? 0 : max(1, (entries + P.target / 2) / P.target);   // (to nearest)
+      if (G) G = min(max(G, P.gmin), min(P.gmax, P.num_scans));
+      if (!P.flush_atomic) G = max(G, P.gmin);           // (a single tile writes its sums: always run)
+      total[t] = G;
+      total[kMaxTiles + t] = items;
+      items += G;
+    }
+    const int base = atomicAdd(work_count, items);
+    plan[1] = base;
+    plan[2] = items;
+    if (base + items > work_cap) atomicOr(&P.misc[0], kOutOfBox);    // (never: host bound)
+  }
+  __syncthreads();
+  const int base = plan[1];
+  if (base + plan[2] > work_cap) return;
+  for (int t = 0; t < ntiles; ++t)
+    for (int g = tid; g < total[t]; g += 256)
+      work_items[base + total[kMaxTiles + t] + g] =
+          make_int4(static_cast<int>(blockIdx.y), t, g, total[t]);
 }
 
 // ---------------------------------------------------------------------------------------------
-// grid (work items), 512 threads; work = (match, tile, rotation group, -).  Dynamic LDS:
+// grid (persistent: one workgroup of 1024 threads per CU when every match is ONE tile, else two of
+// 512), work items = (match, tile, rotation
+// group g, groups G of the tile) from the prep kernel's planner, pulled through a counter.
+// Dynamic LDS:
 //   image[tile_image_bytes] | acc[rw][side^2] | hdrs[rw][4] | slot[rw + 1] | tasks[task_cap][4] |
 //   ctl[16] | list[list_lds] u16
 // ---------------------------------------------------------------------------------------------
+// (Sixteen wavefronts per CU either way.  Two workgroups of sixteen, registers capped at 64 --
+// the compiler takes 80 for two rows per lane -- ran the same batch 1.4x SLOWER, stragglers of
+// 54 us among items of 14: profiles/r04_c1_two_workgroups_per_cu.txt.  The other half of the
+// CU's wavefront slots is what lets the prep and finish kernels of the other parts of a batch
+// run beside this one.)
 template <int RPL, int kRowStride, bool kTimeline>
-__global__ void __launch_bounds__(kTileThreads)
-Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict__ work) {
+__global__ void __launch_bounds__(kTileMaxThreads)
+Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict__ work,
+               const int* __restrict__ work_count, int* __restrict__ next_item) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
-  const int4 item = work[blockIdx.x];
-  const Rt2DTileParams& P = params[item.x];
-  const int tile = item.y, g = item.z;
+  __shared__ int4 fetched;                   // the next work item (x < 0: none)
+  __shared__ Rt2DTileParams P;               // the current item's match (one round of loads)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int num_threads = blockDim.x, num_waves = num_threads >> 6;
+  const int num_items = *work_count;
+  if (tid == 0) {
+    const int v = atomicAdd(next_item, 1);
+    fetched = v < num_items ? work[v] : make_int4(-1, 0, 0, 0);
+  }
+  int item_index = 0;
+  for (;; ++item_index) {
+  __syncthreads();                           // the previous item's LDS is done with; `fetched` is set
+  const int4 item = fetched;
+  if (item.x < 0) break;
+  __syncthreads();                           // (everyone has read `fetched` before it is overwritten)
+  // the NEXT item: its ticket is drawn now and arrives under this item's image copy; the item
+  // itself is read behind the copy's wait and stored at the end
+  int ticket = 0;
+  int4 next = make_int4(-1, 0, 0, 0);
+  if (tid == 0) ticket = atomicAdd(next_item, 1);
+  CopyParams(&P, params + item.x, tid);
+  __syncthreads();
+  const int tile = item.y, g = item.z, G = item.w;
   const int side = 2 * P.nl + 1, cands = side * side;
-  const int B = P.B, H = P.H, G = P.G, lp = P.lp;
-  const int rw = (P.num_scans - g + G - 1) / G;          // rotations g, g + G, ... of this workgroup
-  if (rw <= 0) return;
+  const int B = P.B, H = P.H, lp = P.lp;
+  const int rw = (P.num_scans - g + G - 1) / G;          // rotations g, g + G, ... of this item
   // (in-kernel timeline of the profiling tools: compiled in only for the instrumented
-  // instantiation the debug switch `timeline` selects)
+  // instantiation the debug switch `timeline` selects; slots = workgroup x its first items)
   const auto stamp = [&](int k) {
-    if constexpr (kTimeline) Stamp(P.timeline, blockIdx.x, k);
+    if constexpr (kTimeline) {
+      if (item_index < 4) Stamp(P.timeline, blockIdx.x * 4 + item_index, k);
+    }
   };
   stamp(0);
   const int nkeys = P.ntx * P.nty * 4;
@@ -253,7 +346,7 @@ Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict
     auto* dst = (__attribute__((address_space(3))) unsigned char*)tile_smem;
     const int kib = P.tile_image_bytes >> 10;
     const int gw = P.gpitch >> 1;                         // cells per image row
-    for (int k = wave; k < kib; k += kTileWaves) {
+    for (int k = wave; k < kib; k += num_waves) {
       const int p = (k << 6) + lane;
       const int row = p / ppr, c = p - row * ppr;
       const int X0 = gx0 + (c << 3), Y = gy0 + row;
@@ -264,7 +357,7 @@ Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict
     }
   }
   stamp(1);                                              // image DMA issued
-  for (int i = tid; i < rw * cands; i += kTileThreads) acc[i] = 0;
+  for (int i = tid; i < rw * cands; i += num_threads) acc[i] = 0;
   if (tid < rw * 4) {
     const int rr = tid >> 2, ph = tid & 3;
     hdrs[tid] = static_cast<int>(P.hdr[static_cast<size_t>(g + rr * G) * nkeys + tile * 4 + ph]);
@@ -301,7 +394,8 @@ Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict
     __syncthreads();                                   // the previous round's lists are done with
     if (tid < 2) ctl[tid] = 0;
     // lists: rotation rr's entries of this tile are contiguous in HBM (keys in order)
-    for (int rr = rr0 + wave; rr < rr1; rr += kTileWaves) {
+    // (wavefront 0 builds the round's tasks below while the others copy its lists)
+    for (int rr = rr0 + wave - 1; wave >= 1 && rr < rr1; rr += num_waves - 1) {
       const int first = hdrs[rr * 4] & 0xffff;
       const int len = slot[rr + 1] - slot[rr];
       typedef unsigned U4 __attribute__((ext_vector_type(4)));
@@ -310,8 +404,6 @@ Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict
       U4* dst = reinterpret_cast<U4*>(list + (slot[rr] - base));
       for (int q = lane; q < (len >> 3); q += 64) dst[q] = src[q];
     }
-    __syncthreads();
-    if (rr0 == 0) stamp(3);                              // first round's lists in LDS
     // ---- per rotation: phases paired by size, tasks of at most kPairTaskIters iterations ---
     if (wave == 0) {
       const int rr = rr0 + lane;
@@ -349,10 +441,12 @@ Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict
         }
       }
     }
-    if (rr0 == 0) stamp(4);                              // tasks built
+    if (rr0 == 0) stamp(4);                              // tasks built / this wave's lists copied
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the image has landed
     __syncthreads();
     if (rr0 == 0) stamp(5);                              // image landed
+    if (rr0 == 0 && tid == 0)                            // (the ticket arrived with that wait)
+      next = ticket < num_items ? work[ticket] : make_int4(-1, 0, 0, 0);
     // ---- tasks, dealt dynamically: the halves of a wavefront run two phases ----------------
     const int num_tasks = ctl[0];          // <= task_cap by construction (host)
     for (;;) {
@@ -395,7 +489,7 @@ Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict
   __syncthreads();
   stamp(7);                                              // all rounds done
   // ---- this tile's share of the candidates' integer sums --------------------------------------
-  for (int e = tid; e < rw * cands; e += kTileThreads) {
+  for (int e = tid; e < rw * cands; e += num_threads) {
     const int rr = e / cands, c = e - rr * cands;
     auto* out = AsGlobal(P.qsum) + static_cast<size_t>(g + rr * G) * cands + c;
     const int v = acc[e];
@@ -406,6 +500,8 @@ Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict
     }
   }
   stamp(8);
+  if (tid == 0) fetched = next;
+  }   // work items
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -418,28 +514,40 @@ Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict
 //   3. the candidates within that rounding of the best (one or two): the reference's sequential
 //      f32 sum (:61-75) -- all threads fetch the probabilities of a finalist's points into LDS,
 //      one lane per finalist runs the chain -- left for the host as (index, score bits) pairs.
-// Dynamic LDS: cells[n_pad] u32 | prob[group][n_pad + 1] f32 | rot_flag[num_scans] |
+// Dynamic LDS: cells[n_pad] u32 | prob[group][n_pad + 4] f32 | rot_flag[num_scans] |
 //   fin[kStage1Cap] | exact[kStage1Cap] | fin2[kStage1Cap]
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kFinishThreads)
-Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group) {
+Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group,
+                 unsigned* __restrict__ host_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fin_smem[];
-  const Rt2DTileParams& P = params[blockIdx.x];
+  __shared__ Rt2DTileParams P;
   const int tid = threadIdx.x, lane = tid & 63;
+  CopyParams(&P, params + blockIdx.x, tid);
+  __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int kWaves = kFinishThreads / 64;
   const int side = 2 * P.nl + 1, cands = side * side, n = P.n, n_pad = P.n_pad;
-  const int total = P.num_scans * cands;
   uint32_t* cellbuf = reinterpret_cast<uint32_t*>(fin_smem);
   float* prob = reinterpret_cast<float*>(cellbuf + n_pad);
-  int* rot_flag = reinterpret_cast<int*>(prob + group * (n_pad + 1));
+  int* rot_flag = reinterpret_cast<int*>(prob + group * (n_pad + 4));
   int* fin = rot_flag + ((P.num_scans + 3) & ~3);
   int* exact = fin + kStage1Cap;
   int* fin2 = exact + kStage1Cap;
   __shared__ unsigned red[kWaves];
   __shared__ int nfin, nfin2;
   __shared__ int sel[18];
-  if (P.misc[1] == kOutOfBox) return;      // (uniform: written by the prep kernel, read-only here)
+  // The match's 128 result words go straight to the caller's pinned buffer (mapped into the
+  // device's address space): no copy command, no copy kernel after this one.
+  const auto publish = [&]() {
+    __syncthreads();
+    if (tid < 128)
+      host_out[static_cast<size_t>(blockIdx.x) * 128 + tid] =
+          __hip_atomic_load(&P.misc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // (a match whose prep flagged a point outside the box is finished like any other -- one more
+  // round trip at the head of this latency-bound kernel would cost every match 1.5 us -- and the
+  // flag rides in misc[0] to the host)
   unsigned long long* const tl = P.timeline;
   const int tl_block = P.timeline_finish_base + blockIdx.x;
   Stamp(tl, tl_block, 0);
@@ -451,14 +559,61 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group) {
   const float width = kScale * static_cast<float>((1 << kQShift) - 1);
   const int* __restrict__ qsum = P.qsum;
   // ---- stage 1: the best weighted lower bound, then everyone whose upper bound reaches it.
-  // Bounds only SELECT candidates (scores are recomputed exactly), so f32 with slack is enough --
+  // Bounds only SELECT candidates (scores are recomputed exactly), so f32 with slack is enough.
+  // A thread owns translations c = tid, tid + 512, ... and walks the rotations: the translation
+  // part of the weight's exponent once per c, no division inside the loop, coalesced qsum reads --
+  const float res_f = static_cast<float>(P.res);
+  const float wt_f = static_cast<float>(P.wt), wr_f = static_cast<float>(P.wr);
+  const float step_f = static_cast<float>(P.step);
+  const auto weight = [&](float t_translation, int s) {
+    const float t = t_translation + fabsf(static_cast<float>(s - P.num_angular) * step_f) * wr_f;
+    return __expf(-(t * t));
+  };
   float lb_max = 0.f;
-  for (int e = tid; e < total; e += kFinishThreads) {
-    const int s = e / cands, c = e - s * cands;
-    const int dxi = c / side, dyi = c - dxi * side;
-    const float base = 0.1f + per_q * static_cast<float>(qsum[e]);
-    const float w = TileWeight(P, s, dxi - P.nl, dyi - P.nl);
-    lb_max = fmaxf(lb_max, (base - slack) * w * (1.f - 1e-5f));
+  constexpr int kOwn = 16;                 // candidates a thread keeps in registers
+  const int total = P.num_scans * cands;
+  const bool in_registers = total <= kOwn * kFinishThreads;
+  float ub_own[kOwn];
+  const int owned = (total + kFinishThreads - 1) / kFinishThreads;      // (uniform)
+  if (in_registers) {
+    // The usual case (C1: 4563 candidates, 9 per thread): ONE round of loads, every upper bound
+    // stays in a register until the best lower bound is known.
+    int q_own[kOwn];
+#pragma unroll
+    for (int k = 0; k < kOwn; ++k) {
+      const int e = tid + k * kFinishThreads;
+      q_own[k] = k < owned && e < total ? qsum[e] : 0;
+    }
+    // s = e / cands from an f32 estimate: exact for e < 2^21 (the estimate is off by less than
+    // 2^-22 e / cands < 1 / (2 cands), and (e + 0.5) / cands is 1 / (2 cands) away from integers)
+    const float inv_cands = 1.f / static_cast<float>(cands), inv_side = 1.f / static_cast<float>(side);
+#pragma unroll
+    for (int k = 0; k < kOwn; ++k) {
+      ub_own[k] = -1.f;
+      if (k >= owned) continue;                                          // (uniform)
+      const int e = tid + k * kFinishThreads;
+      const int s = static_cast<int>((static_cast<float>(e) + 0.5f) * inv_cands);
+      const int c = e - s * cands;
+      const int dxi = static_cast<int>((static_cast<float>(c) + 0.5f) * inv_side), dyi = c - dxi * side;
+      const float cx = -(dyi - P.nl) * res_f, cy = -(dxi - P.nl) * res_f;
+      const float w = weight(sqrtf(cx * cx + cy * cy) * wt_f, s);
+      const float base = 0.1f + per_q * static_cast<float>(q_own[k]);
+      if (e < total) {
+        ub_own[k] = (base + width + slack) * w * (1.f + 1e-5f);
+        lb_max = fmaxf(lb_max, (base - slack) * w * (1.f - 1e-5f));
+      }
+    }
+  } else {
+    for (int c = tid; c < cands; c += kFinishThreads) {
+      const int dxi = c / side, dyi = c - dxi * side;
+      const float cx = -(dyi - P.nl) * res_f, cy = -(dxi - P.nl) * res_f;
+      const float tt = sqrtf(cx * cx + cy * cy) * wt_f;
+#pragma unroll 4
+      for (int s = 0; s < P.num_scans; ++s) {
+        const float base = 0.1f + per_q * static_cast<float>(qsum[s * cands + c]);
+        lb_max = fmaxf(lb_max, (base - slack) * weight(tt, s) * (1.f - 1e-5f));
+      }
+    }
   }
   {
     unsigned bits = __float_as_uint(fmaxf(lb_max, 0.f));
@@ -471,15 +626,31 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group) {
 #pragma unroll
   for (int w = 0; w < kWaves; ++w) best_bits = max(best_bits, red[w]);
   const float best_lb = __uint_as_float(best_bits);
-  for (int e = tid; e < total; e += kFinishThreads) {
-    const int s = e / cands, c = e - s * cands;
-    const int dxi = c / side, dyi = c - dxi * side;
-    const float base = 0.1f + per_q * static_cast<float>(qsum[e]);
-    const float w = TileWeight(P, s, dxi - P.nl, dyi - P.nl);
-    if ((base + width + slack) * w * (1.f + 1e-5f) >= best_lb) {
-      const int at = atomicAdd(&nfin, 1);
-      if (at < kStage1Cap) fin[at] = e;
-      rot_flag[s] = 1;
+  if (in_registers) {
+    const float inv_cands = 1.f / static_cast<float>(cands);
+#pragma unroll
+    for (int k = 0; k < kOwn; ++k) {
+      if (ub_own[k] >= best_lb) {
+        const int e = tid + k * kFinishThreads;
+        const int at = atomicAdd(&nfin, 1);
+        if (at < kStage1Cap) fin[at] = e;
+        rot_flag[static_cast<int>((static_cast<float>(e) + 0.5f) * inv_cands)] = 1;
+      }
+    }
+  } else {
+    for (int c = tid; c < cands; c += kFinishThreads) {
+      const int dxi = c / side, dyi = c - dxi * side;
+      const float cx = -(dyi - P.nl) * res_f, cy = -(dxi - P.nl) * res_f;
+      const float tt = sqrtf(cx * cx + cy * cy) * wt_f;
+#pragma unroll 4
+      for (int s = 0; s < P.num_scans; ++s) {
+        const float base = 0.1f + per_q * static_cast<float>(qsum[s * cands + c]);
+        if ((base + width + slack) * weight(tt, s) * (1.f + 1e-5f) >= best_lb) {
+          const int at = atomicAdd(&nfin, 1);
+          if (at < kStage1Cap) fin[at] = s * cands + c;
+          rot_flag[s] = 1;
+        }
+      }
     }
   }
   __syncthreads();
@@ -487,7 +658,9 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group) {
   const int count = nfin;
   if (tid == 0) P.stage[0] = static_cast<unsigned>(count);
   if (count > kStage1Cap) {              // flat landscape: the host repeats the match on the
-    if (tid == 0) P.misc[1] = kFlat;     // per-candidate kernels
+    if (tid == 0)                        // per-candidate kernels
+      __hip_atomic_store(&P.misc[1], kFlat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    publish();
     return;
   }
   const auto* cells = AsGlobal(P.cells);
@@ -594,7 +767,9 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group) {
   const int count2 = nfin2;
   Stamp(tl, tl_block, 3);                  // finalists selected
   // ---- stage 3: the reference's sequential f32 sums ---------------------------------------
-  const int row = n_pad + 1;              // odd row pitch: the chain lanes hit distinct banks
+  // (rows of n_pad + 4 floats: 16-byte aligned for ds_read_b128, the chain lanes four banks
+  // apart; the slots beyond the cloud hold +0, which leaves a positive sum as it is)
+  const int row = n_pad + 4;
   for (int s = 0; s < P.num_scans; ++s) {
     if (!rot_flag[s]) continue;           // (uniform)
     __syncthreads();
@@ -616,15 +791,15 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group) {
       const int gcount = sel[16];
       next = sel[17];
       if (gcount == 0) break;
-      for (int f = wave; f < gcount; f += kWaves) {       // a wavefront per finalist
+      for (int f = 0; f < gcount; ++f) {                  // all threads: one round of gathers
         const int c = sel[f];
         const int dx = c / side - P.nl, dy = c % side - P.nl;
-        for (int i0 = 0; i0 < n; i0 += 256) {
+        for (int i0 = 0; i0 < n; i0 += 4 * kFinishThreads) {
           unsigned raw[4];
           bool inside[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const int i = i0 + k * 64 + lane;
+            const int i = i0 + k * kFinishThreads + tid;
             const uint32_t pc = cellbuf[min(i, n - 1)];
             const int x = static_cast<short>(pc & 0xffffu) + dx;
             const int y = static_cast<short>(pc >> 16) + dy;
@@ -634,25 +809,36 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group) {
           }
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const int i = i0 + k * 64 + lane;
+            const int i = i0 + k * kFinishThreads + tid;
             if (i < n) prob[f * row + i] = inside[k] ? CellProbability(raw[k]) : 0.1f;   // kMinProbability
           }
         }
+        for (int i = n + tid; i < n_pad; i += kFinishThreads) prob[f * row + i] = 0.f;
       }
       __syncthreads();
       Stamp(tl, tl_block, 4);              // probabilities of a group of finalists in LDS
       if (tid < gcount) {
-        const float* vals = prob + tid * row;
+        // The reference's sum: N dependent additions in point order (then zeros up to a multiple
+        // of 64 points: x + 0 = x).  The values come out of LDS 32 at a time (8 x ds_read_b128),
+        // the next 32 on their way while these are added.
+        typedef float F4 __attribute__((ext_vector_type(4)));
+        const F4* vals = reinterpret_cast<const F4*>(prob + tid * row);
         float sum = 0.f;
-        int i = 0;
-        for (; i + 32 <= n; i += 32) {
-          float v[32];
+        F4 a[8], b[8];
 #pragma unroll
-          for (int k = 0; k < 32; ++k) v[k] = vals[i + k];
+        for (int k = 0; k < 8; ++k) a[k] = vals[k];
+        for (int i = 0; i < n_pad; i += 64) {            // n_pad is a multiple of 64
 #pragma unroll
-          for (int k = 0; k < 32; ++k) sum += v[k];            // in point order
+          for (int k = 0; k < 8; ++k) b[k] = vals[(i >> 2) + 8 + k];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { sum += a[k].x; sum += a[k].y; sum += a[k].z; sum += a[k].w; }
+          // (the last batch reads 32 floats past the row: inside the next row or the lists behind
+          // the probabilities, never added)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) a[k] = vals[(i >> 2) + 16 + k];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { sum += b[k].x; sum += b[k].y; sum += b[k].z; sum += b[k].w; }
         }
-        for (; i < n; ++i) sum += vals[i];
         const float score = sum / static_cast<float>(n);
         const int c = sel[tid];
         const int dxi = c / side, dyi = c - dxi * side;
@@ -672,6 +858,7 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group) {
     }
   }
   Stamp(tl, tl_block, 6);
+  publish();
 }
 
 size_t Align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
@@ -695,28 +882,49 @@ void OptInLds(const void* fn, int device, size_t bytes) {
   seen->push_back(Seen{fn, device, bytes});
 }
 
-// Conflict-free LDS row pitch (bytes, a multiple of 16, >= min_bytes): the H x B 8-byte blocks a
-// half-wavefront reads in one LDS cycle fall into 2 H B distinct banks for every base address.
+// Conflict-free LDS row pitch (bytes, a multiple of 16, >= min_bytes; 0: none exists): the H x B
+// 8-byte blocks a half-wavefront reads in one LDS cycle fall into 2 H B distinct banks for every
+// base address.  The bank pattern depends on the pitch modulo 256 only: the sixteen residues are
+// tested once per (H, B).
 int ConflictFreePitch(int H, int B, int min_bytes) {
-  for (int cand = (min_bytes + 15) & ~15; cand < min_bytes + 1024; cand += 16) {
-    unsigned long long used = 0;
-    bool ok = true;
-    for (int r = 0; r < H && ok; ++r)
-      for (int b = 0; b < B && ok; ++b)
-        for (int w = 0; w < 2; ++w) {
-          const int bank = ((r * cand + b * 8) / 4 + w) & 63;
-          if (used >> bank & 1) ok = false;
-          used |= 1ull << bank;
-        }
-    if (ok) return cand;
+  static std::mutex mu;
+  static int valid[33][33];                  // bit k: pitch = 16 k (mod 256) is conflict-free; -1 unset
+  static bool init = false;
+  unsigned mask;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!init) {
+      for (auto& row : valid) for (int& v : row) v = -1;
+      init = true;
+    }
+    if (valid[H][B] < 0) {
+      int m = 0;
+      for (int k = 0; k < 16; ++k) {
+        const int cand = 16 * k + 256;
+        unsigned long long used = 0;
+        bool ok = true;
+        for (int r = 0; r < H && ok; ++r)
+          for (int b = 0; b < B && ok; ++b)
+            for (int w = 0; w < 2; ++w) {
+              const int bank = ((r * cand + b * 8) / 4 + w) & 63;
+              if (used >> bank & 1) ok = false;
+              used |= 1ull << bank;
+            }
+        if (ok) m |= 1 << k;
+      }
+      valid[H][B] = m;
+    }
+    mask = static_cast<unsigned>(valid[H][B]);
   }
-  return 0;
+  if (mask == 0) return 0;
+  for (int cand = (min_bytes + 15) & ~15;; cand += 16)
+    if (mask >> ((cand >> 4) & 15) & 1) return cand;
 }
 
 struct TileGeometry {
   int B, H, hl, ht, gpitch, grows;
   int box_x0, box_y0, T, ntx, nty, lp, th_img, tile_image_bytes;
-  int cap_s, G, rw, list_lds, task_cap;
+  int cap_s, gmin, gmax, target, rw, list_lds, task_cap;
   size_t lds;               // of the tile kernel
   size_t image_bytes;       // of the grid image in HBM
 };
@@ -785,6 +993,24 @@ void Rt2DImageCache::Release(int k, bool was_building) {
 }
 
 namespace {
+
+// One grid image per distinct (grid, version, window) of a call.
+struct GridKey {
+  const void* cells; const void* device_cells; const void* cache;
+  unsigned long long version; int nl, gpitch, grows;
+  bool operator==(const GridKey& o) const {
+    return cells == o.cells && device_cells == o.device_cells && cache == o.cache &&
+           version == o.version && nl == o.nl && gpitch == o.gpitch && grows == o.grows;
+  }
+};
+struct GridKeyHash {
+  size_t operator()(const GridKey& k) const {
+    size_t h = reinterpret_cast<size_t>(k.cells) * 0x9e3779b97f4a7c15ull;
+    h ^= reinterpret_cast<size_t>(k.device_cells) + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+    h ^= static_cast<size_t>(k.version) * 0xff51afd7ed558ccdull + static_cast<size_t>(k.nl);
+    return h;
+  }
+};
 
 // Releases / publishes the cache buffers of a call on every path out of it.
 struct CacheHold {
@@ -900,17 +1126,58 @@ void Rt2DFinishOnHost(const cmx_rt_options* options, const Rt2DItem& it, const R
   *it.score = best_score;
 }
 
-// The tile path for a batch of probability-grid matches.  Returns false -- nothing written to
-// the items -- when a match is not eligible (huge window or cloud), when a score landscape is
-// flat (more candidates within the bounds than the lists hold) or when a point fell outside the
-// predicted box: the caller then runs the batch on the per-candidate kernels.
-bool Rt2DTileBatch(const cmx_rt_options* options, const Rt2DItem* items,
-                   const Rt2DSearch* search, int num, int32_t device, cmx_match_stats* stats) {
+// ---------------------------------------------------------------------------------------------
+// The tile path for a batch of probability-grid matches, in three steps so that ONE host thread
+// can keep several batches (the parts of a large call) in flight on streams of their own:
+//   Plan()     geometry; false: a match is not eligible (huge window or cloud);
+//   Enqueue()  staging buffer, grid images, upload and the four launches -- asynchronous;
+//   Collect()  waits for the stream; exact weighting and first maximum on the host; false -- and
+//              nothing written to the items -- when a score landscape is flat (more candidates
+//              within the bounds than the lists hold) or a point fell outside the predicted box:
+//              the caller then runs the batch on the per-candidate kernels.
+// ---------------------------------------------------------------------------------------------
+struct Rt2DTileCall::Impl {
+  const cmx_rt_options* options;
+  const Rt2DItem* items;
+  const Rt2DSearch* search;
+  int num, device;
+  std::vector<TileGeometry> geo;
+  int rpl = 1, max_scans = 0, common_stride = -1, group = 8, cus = 256;
+  size_t tile_lds = 0, prep_lds = 0, finish_lds = 0;
+  size_t lists_total = 0, hdr_total = 0, qsum_total = 0;
+  long long work_cap = 0, entries_total = 0;
+  int tile_grid = 0, tile_threads = 512;
+  std::unique_ptr<WorkspaceLease> ws;
+  CacheHolds holds;
+  unsigned* h_misc = nullptr;
+  unsigned* d_overflow = nullptr;
+  unsigned long long* d_timeline = nullptr;
+  bool enqueued = false, synced = false;
+};
+
+Rt2DTileCall::Rt2DTileCall(const cmx_rt_options* options, const Rt2DItem* items,
+                           const Rt2DSearch* search, int num, int32_t device)
+    : impl_(new Impl) {
+  impl_->options = options; impl_->items = items; impl_->search = search;
+  impl_->num = num; impl_->device = device;
+}
+Rt2DTileCall::~Rt2DTileCall() {
+  // (a call abandoned between its launches and its wait -- an exception in a later part: nothing
+  // of it may still be running when its workspace goes back to the pool)
+  if (impl_->enqueued && !impl_->synced && impl_->ws) (void)hipStreamSynchronize((*impl_->ws)->stream);
+}
+
+bool Rt2DTileCall::Plan() {
+  Impl& I = *impl_;
   const DebugOptions& dbg = Debug();
-  int cus = 256;
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-  std::vector<TileGeometry> geo(num);
-  // ---- launch-wide rows per lane: the largest any item needs ---------------------------------
+  const Rt2DItem* items = I.items;
+  const Rt2DSearch* search = I.search;
+  const int num = I.num;
+  (void)hipDeviceGetAttribute(&I.cus, hipDeviceAttributeMultiprocessorCount, I.device);
+  const int cus = I.cus;
+  std::vector<TileGeometry>& geo = I.geo;
+  geo.assign(num, TileGeometry{});
+  // ---- window geometry per item; launch-wide rows per lane: the largest any item needs.
   // (H = the most rows of B blocks a half-wavefront holds for which a conflict-free pitch of whole
   // 16-byte DMA pieces exists: e.g. 8 rather than 10 rows of 3 blocks)
   int rpl = 1;
@@ -918,7 +1185,9 @@ bool Rt2DTileBatch(const cmx_rt_options* options, const Rt2DItem* items,
     const int side = 2 * search[m].nl + 1;
     const int B = (side + 3 + 3) / 4;
     if (B > 32 || items[m].n > kRt2DMaxPoints || search[m].num_scans > 4096) return false;
-    int H = 32 / B;
+    if (items[m].limits->num_x_cells > 32000 || items[m].limits->num_y_cells > 32000)
+      return false;                                        // (cells travel as int16 pairs)
+    int H = m > 0 && geo[m - 1].B == B ? geo[m - 1].H : 32 / B;
     while (H > 1 && ConflictFreePitch(H, B, 16) == 0) --H;
     geo[m].B = B;
     geo[m].H = H;
@@ -927,24 +1196,22 @@ bool Rt2DTileBatch(const cmx_rt_options* options, const Rt2DItem* items,
   if (rpl > kMaxRowsPerLane) return false;
   if (rpl == 5) rpl = 6;
   if (rpl == 7) rpl = 8;                         // (instantiated: 1, 2, 3, 4, 6, 8 rows per lane)
-  // ---- per item: window geometry, box, tiles -------------------------------------------------
-  const size_t kLdsPerWorkgroup = 80 * 1024 - 512;        // two workgroups per CU
-  size_t tile_lds = 0, prep_lds = 0, finish_lds = 0;
-  size_t lists_total = 0, hdr_total = 0, qsum_total = 0, scratch_images = 0;
-  long long work_total = 0;
-  int max_scans = 0, common_stride = -1, group = 8;
+  I.rpl = rpl;
+  // ---- per item: the box of window starts the scan can reach.  Every rotated point lies within
+  // max_range of the initial translation (plus a cell for the f32 roundings of rotation and
+  // index, plus the half cell of lround); cells are clamped to [-(nl + 1), n + nl] as on the
+  // device.  Items with the same window (the usual batch) share ONE tile geometry, chosen for the
+  // largest box, cloud and rotation count among them.
+  struct Class { int nl, span_x, span_y, n_pad, scans, items; TileGeometry g; };
+  std::vector<Class> classes;
+  std::vector<int> class_of(num), span_x(num), span_y(num);
   for (int m = 0; m < num; ++m) {
     const Rt2DItem& it = items[m];
     const Rt2DSearch& sr = search[m];
     TileGeometry& g = geo[m];
     const int nx = it.limits->num_x_cells, ny = it.limits->num_y_cells, nl = sr.nl;
-    const int side = 2 * nl + 1, n_pad = (it.n + 63) / 64 * 64;
-    if (nx > 32000 || ny > 32000) return false;             // (cells travel as int16 pairs)
     g.hl = (2 * nl + 1 + 7) & ~7;
     g.ht = 2 * nl + 1;
-    // The box of window starts the scan can reach: every rotated point lies within max_range of
-    // the initial translation (plus a cell for the f32 roundings of rotation and index, plus the
-    // half cell of lround); cells are clamped to [-(nl + 1), n + nl] as on the device.
     const double res = it.limits->resolution;
     const double reach = (sr.max_range * (1.0 + 1e-5)) / res + 2.0;
     const double cxc = (it.limits->max_y - it.initial->y) / res - 0.5;   // cell x from the map's y
@@ -958,87 +1225,214 @@ bool Rt2DTileBatch(const cmx_rt_options* options, const Rt2DItem* items,
     const int iy_hi = clampi(std::ceil(cyc + reach), -(nl + 1), ny + nl);
     g.box_x0 = (ix_lo - nl + g.hl) & ~7;
     g.box_y0 = iy_lo - nl + g.ht;
-    const int span_x = ix_hi - nl + g.hl - g.box_x0 + 1, span_y = iy_hi - nl + g.ht - g.box_y0 + 1;
-    // rotation groups: about two workgroups per CU over the whole batch
+    span_x[m] = ix_hi - nl + g.hl - g.box_x0 + 1;
+    span_y[m] = iy_hi - nl + g.ht - g.box_y0 + 1;
+    const int n_pad = (it.n + 63) / 64 * 64;
+    int c = 0;
+    while (c < static_cast<int>(classes.size()) && classes[c].nl != nl) ++c;
+    if (c == static_cast<int>(classes.size())) classes.push_back(Class{nl, 0, 0, 0, 0, 0, g});
+    Class& k = classes[c];
+    k.span_x = std::max(k.span_x, span_x[m]); k.span_y = std::max(k.span_y, span_y[m]);
+    k.n_pad = std::max(k.n_pad, n_pad); k.scans = std::max(k.scans, sr.num_scans);
+    ++k.items;
+    class_of[m] = c;
+    I.entries_total += static_cast<long long>(it.n) * sr.num_scans;
+  }
+  // Two shapes.  (1) ONE tile per match, a workgroup of 1024 threads alone on its CU (up to
+  // 150 KB of LDS): whenever the whole box of a match fits -- the items of a match are then its
+  // rotation groups, all of one size, their sums plain stores.  C1's box (217 window starts per
+  // axis at 5 cm) is such a case: as four tiles one of them held most of the points, and the
+  // planner's smaller items each paid the ~4 us before their first window update.  (2) Several
+  // tiles, workgroups of 512 threads, two per CU (76 KB each): boxes beyond that (long-range
+  // scans, fine grids), sums by atomics.
+  const size_t kLdsTwoPerCu = (dbg.rt2d_lds_kb > 0 ? dbg.rt2d_lds_kb : 76) * size_t{1024};
+  const size_t kLdsOnePerCu = 150 * size_t{1024};
+  bool single_tile = dbg.rt2d_tile <= 0;
+  for (Class& k : classes) {
+    TileGeometry& g = k.g;
+    const int side = 2 * k.nl + 1;
     const int rows_extra = rpl * g.H;
-    const int cap_tile = n_pad + 64;                  // a rotation's entries of ONE tile, padded
-    // The largest tile core that leaves room for two workgroups per CU, then the smallest core
-    // with the same number of tiles (less image to stage, more room for lists).
-    const auto try_tile = [&](int T, TileGeometry* out) {
-      const int ntx = (span_x + T - 1) / T, nty = (span_y + T - 1) / T;
-      if (ntx * nty > kMaxTiles) return false;
+    const int cap_tile = k.n_pad + 64;                // a rotation's entries of ONE tile, padded
+    const auto try_tile = [&](int T, size_t budget, bool one_tile, TileGeometry* out) {
+      const int ntx = (k.span_x + T - 1) / T, nty = (k.span_y + T - 1) / T;
+      if (ntx * nty > (one_tile ? 1 : kMaxTiles)) return false;
       const int lp = ConflictFreePitch(g.H, g.B, 2 * (T + 4 * g.B));
       if (lp == 0) return false;
       const int th_img = T + rows_extra;
       const int image = ((th_img + rows_extra) * lp + 1023) & ~1023;
-      int G = dbg.rt2d_groups > 0 ? dbg.rt2d_groups
-                                  : static_cast<int>((2ll * cus + static_cast<long long>(num) * ntx * nty - 1) /
-                                                     (static_cast<long long>(num) * ntx * nty));
-      G = std::max(std::max(1, (sr.num_scans + 63) / 64), std::min(G, sr.num_scans));
-      const int rw = (sr.num_scans + G - 1) / G;
-      const int task_cap = rw * (n_pad / kPairTaskIters + 2);
-      const size_t fixed = static_cast<size_t>(image) + 4 * ((static_cast<size_t>(rw) * side * side + 3) & ~size_t{3}) +
-                           16 * static_cast<size_t>(rw) + 4 * ((static_cast<size_t>(rw) + 1 + 3) & ~size_t{3}) +
-                           16 * static_cast<size_t>(task_cap) + 64;
-      if (fixed + 2 * static_cast<size_t>(cap_tile) > kLdsPerWorkgroup) return false;
-      // list buffer: what is left, at most every rotation's entries at once
-      const size_t want = static_cast<size_t>(rw) * cap_tile;
-      const size_t room = (kLdsPerWorkgroup - fixed) / 2;
-      out->list_lds = static_cast<int>(std::min(want, room) & ~size_t{7});
-      out->T = T; out->ntx = ntx; out->nty = nty; out->lp = lp; out->th_img = th_img;
-      out->tile_image_bytes = image; out->G = G; out->rw = rw; out->task_cap = task_cap;
-      out->lds = fixed + 2 * static_cast<size_t>(out->list_lds);
-      return true;
+      // rotations a workgroup's LDS holds: all of them (the planner gives a light tile ONE item)
+      // or -- one tile per match -- as many as fit beside the image
+      for (int gmin = std::max(1, (k.scans + 63) / 64); gmin <= k.scans; ++gmin) {
+        const int rw = (k.scans + gmin - 1) / gmin;
+        const int task_cap = rw * (k.n_pad / kPairTaskIters + 2);
+        const size_t fixed = static_cast<size_t>(image) + 4 * ((static_cast<size_t>(rw) * side * side + 3) & ~size_t{3}) +
+                             16 * static_cast<size_t>(rw) + 4 * ((static_cast<size_t>(rw) + 1 + 3) & ~size_t{3}) +
+                             16 * static_cast<size_t>(task_cap) + 64;
+        if (fixed + 2 * static_cast<size_t>(cap_tile) > budget) {
+          if (!one_tile) return false;
+          continue;                                      // fewer rotations per workgroup
+        }
+        // list buffer: what is left, at most every rotation's entries at once
+        const size_t want = static_cast<size_t>(rw) * cap_tile;
+        const size_t room = (budget - fixed) / 2;
+        if (one_tile && room < want) continue;           // (all of an item's lists in one round)
+        out->list_lds = static_cast<int>(std::min(want, room) & ~size_t{7});
+        out->T = T; out->ntx = ntx; out->nty = nty; out->lp = lp; out->th_img = th_img;
+        out->tile_image_bytes = image; out->gmin = gmin; out->rw = rw; out->task_cap = task_cap;
+        out->lds = fixed + 2 * static_cast<size_t>(out->list_lds);
+        return true;
+      }
+      return false;
     };
     bool found = false;
-    const int t_first = dbg.rt2d_tile > 0 ? (dbg.rt2d_tile & ~7) : 128;
-    for (int T = t_first; T >= 16 && !found; T -= 8) found = try_tile(T, &g);
-    if (found && dbg.rt2d_tile <= 0) {
-      TileGeometry smaller = g;
-      for (int T = g.T - 8; T >= 16; T -= 8) {
-        if ((span_x + T - 1) / T != g.ntx || (span_y + T - 1) / T != g.nty) break;
-        if (try_tile(T, &smaller)) g = smaller;
+    if (single_tile) {
+      const int T = (std::max(k.span_x, k.span_y) + 7) & ~7;
+      found = try_tile(T, kLdsOnePerCu, true, &g);
+      if (!found) single_tile = false;
+    }
+    if (!found) {
+      // The largest tile core that leaves room for two workgroups per CU, then the smallest core
+      // with the same number of tiles (less image to stage, more room for lists).
+      const int t_first = dbg.rt2d_tile > 0 ? (dbg.rt2d_tile & ~7) : 128;
+      for (int T = t_first; T >= 16 && !found; T -= 8) found = try_tile(T, kLdsTwoPerCu, false, &g);
+      if (found && dbg.rt2d_tile <= 0) {
+        TileGeometry smaller = g;
+        for (int T = g.T - 8; T >= 16; T -= 8) {
+          if ((k.span_x + T - 1) / T != g.ntx || (k.span_y + T - 1) / T != g.nty) break;
+          if (try_tile(T, kLdsTwoPerCu, false, &smaller)) g = smaller;
+        }
       }
     }
     if (!found) return false;
+  }
+  // (classes of one launch share the shape: a class that needs several tiles puts all on shape 2)
+  if (!single_tile) {
+    for (Class& k : classes) {
+      if (k.g.ntx * k.g.nty == 1 && k.g.lds > kLdsTwoPerCu) {
+        // re-plan this class with the two-per-CU budget
+        TileGeometry& g = k.g;
+        const int side = 2 * k.nl + 1;
+        const int rows_extra = rpl * g.H;
+        const int cap_tile = k.n_pad + 64;
+        bool found = false;
+        for (int T = 128; T >= 16 && !found; T -= 8) {
+          const int ntx = (k.span_x + T - 1) / T, nty = (k.span_y + T - 1) / T;
+          if (ntx * nty > kMaxTiles) break;
+          const int lp = ConflictFreePitch(g.H, g.B, 2 * (T + 4 * g.B));
+          if (lp == 0) continue;
+          const int th_img = T + rows_extra;
+          const int image = ((th_img + rows_extra) * lp + 1023) & ~1023;
+          const int gmin = std::max(1, (k.scans + 63) / 64);
+          const int rw = (k.scans + gmin - 1) / gmin;
+          const int task_cap = rw * (k.n_pad / kPairTaskIters + 2);
+          const size_t fixed = static_cast<size_t>(image) + 4 * ((static_cast<size_t>(rw) * side * side + 3) & ~size_t{3}) +
+                               16 * static_cast<size_t>(rw) + 4 * ((static_cast<size_t>(rw) + 1 + 3) & ~size_t{3}) +
+                               16 * static_cast<size_t>(task_cap) + 64;
+          if (fixed + 2 * static_cast<size_t>(cap_tile) > kLdsTwoPerCu) continue;
+          const size_t want = static_cast<size_t>(rw) * cap_tile;
+          const size_t room = (kLdsTwoPerCu - fixed) / 2;
+          g.list_lds = static_cast<int>(std::min(want, room) & ~size_t{7});
+          g.T = T; g.ntx = ntx; g.nty = nty; g.lp = lp; g.th_img = th_img;
+          g.tile_image_bytes = image; g.gmin = gmin; g.rw = rw; g.task_cap = task_cap;
+          g.lds = fixed + 2 * static_cast<size_t>(g.list_lds);
+          found = true;
+        }
+        if (!found) return false;
+      }
+    }
+  }
+  I.tile_threads = single_tile ? 1024 : 512;
+  // Entries per work item: the whole batch in about two items per resident workgroup (an item
+  // costs ~4 us before its first window update: ticket, headers, lists, tasks, image), not less
+  // than two thousand entries (sixteen tasks: one per wavefront).
+  const int tile_slots = single_tile ? cus : 2 * cus;
+  const int target = dbg.rt2d_target > 0
+                         ? dbg.rt2d_target
+                         : static_cast<int>(std::min<long long>(16384, std::max<long long>(2048, I.entries_total / (2ll * tile_slots))));
+  for (int m = 0; m < num; ++m) {
+    const Rt2DItem& it = items[m];
+    const Rt2DSearch& sr = search[m];
+    TileGeometry& g = geo[m];
+    const TileGeometry& cg = classes[class_of[m]].g;
+    const int nx = it.limits->num_x_cells, ny = it.limits->num_y_cells, nl = sr.nl;
+    const int side = 2 * nl + 1, n_pad = (it.n + 63) / 64 * 64;
+    g.T = cg.T; g.lp = cg.lp; g.th_img = cg.th_img; g.tile_image_bytes = cg.tile_image_bytes;
+    g.task_cap = cg.task_cap; g.list_lds = cg.list_lds; g.lds = cg.lds;
+    g.ntx = (span_x[m] + g.T - 1) / g.T;
+    g.nty = (span_y[m] + g.T - 1) / g.T;
+    // (rotations per workgroup: the class's -- its LDS is sized for that -- in as few groups as
+    // this match's own rotation count needs)
+    g.rw = std::min(cg.rw, sr.num_scans);
+    g.gmin = (sr.num_scans + g.rw - 1) / g.rw;
+    g.gmax = dbg.rt2d_groups > 0 ? std::max(g.gmin, std::min(dbg.rt2d_groups, sr.num_scans))
+                                 : std::max(g.gmin, std::min(sr.num_scans, 32));
+    g.target = target;
     g.cap_s = n_pad + 16 * 4 * g.ntx * g.nty;
     // the grid image: halo + grid, rows of whole 16-byte pieces, one zero row below (what lies
     // right of or below it is zeros by definition: the tile DMA substitutes the zero corner)
     g.gpitch = 2 * ((g.hl + nx + 7) & ~7);
     g.grows = g.ht + ny + 1;
     g.image_bytes = static_cast<size_t>(g.gpitch) * g.grows;
-    tile_lds = std::max(tile_lds, g.lds);
-    prep_lds = std::max<size_t>(prep_lds, 6 * static_cast<size_t>(n_pad) + 512);
-    lists_total += Align16(2 * static_cast<size_t>(sr.num_scans) * g.cap_s);
-    hdr_total += static_cast<size_t>(sr.num_scans) * g.ntx * g.nty * 4;
-    qsum_total += static_cast<size_t>(sr.num_scans) * side * side;
-    work_total += static_cast<long long>(g.ntx) * g.nty * g.G;
-    max_scans = std::max(max_scans, sr.num_scans);
+    I.tile_lds = std::max(I.tile_lds, g.lds);
+    I.prep_lds = std::max<size_t>(I.prep_lds, 6 * static_cast<size_t>(n_pad) + 512);
+    I.lists_total += Align16(2 * static_cast<size_t>(sr.num_scans) * g.cap_s);
+    I.hdr_total += static_cast<size_t>(sr.num_scans) * g.ntx * g.nty * 4;
+    I.qsum_total += static_cast<size_t>(sr.num_scans) * side * side;
+    // (an upper bound of the planner's items: a tile's groups are capped by gmax and by its share
+    // of the entries, and the shares of a match's tiles add up to all its entries)
+    I.work_cap += std::min<long long>(static_cast<long long>(g.ntx) * g.nty * g.gmax,
+                                      static_cast<long long>(it.n) * sr.num_scans / target +
+                                          static_cast<long long>(g.ntx) * g.nty * (g.gmin + 1));
+    I.max_scans = std::max(I.max_scans, sr.num_scans);
     const int stride = g.H * g.lp;
-    common_stride = m == 0 ? stride : (common_stride == stride ? stride : 0);
-    // finish kernel: cells + `group` probability rows + lists within 64 KB
+    I.common_stride = m == 0 ? stride : (I.common_stride == stride ? stride : 0);
+    // finish kernel: cells + `group` probability rows + lists within 96 KB
     const size_t fin_fixed = 4 * static_cast<size_t>(n_pad) + 4 * ((static_cast<size_t>(sr.num_scans) + 3) & ~size_t{3}) +
-                             12 * static_cast<size_t>(kStage1Cap) + 64;
-    const size_t row = 4 * (static_cast<size_t>(n_pad) + 1);
+                             12 * static_cast<size_t>(kStage1Cap) + 64 + 128;
+    const size_t row = 4 * (static_cast<size_t>(n_pad) + 4);
     const size_t budget = 96 * 1024;
     if (fin_fixed + row > budget) return false;
-    group = std::min<int>(group, static_cast<int>((budget - fin_fixed) / row));
+    I.group = std::min<int>(I.group, static_cast<int>((budget - fin_fixed) / row));
+    I.finish_lds = std::max(I.finish_lds, fin_fixed);
   }
-  for (int m = 0; m < num; ++m) {
-    const Rt2DSearch& sr = search[m];
-    const int n_pad = (items[m].n + 63) / 64 * 64;
-    finish_lds = std::max(finish_lds,
-                          4 * static_cast<size_t>(n_pad) + 4 * static_cast<size_t>(group) * (n_pad + 1) +
-                              4 * ((static_cast<size_t>(sr.num_scans) + 3) & ~size_t{3}) +
-                              12 * static_cast<size_t>(kStage1Cap) + 64);
+  {
+    size_t max_row = 0;
+    for (int m = 0; m < num; ++m) max_row = std::max<size_t>(max_row, 4 * (static_cast<size_t>((items[m].n + 63) / 64 * 64) + 4));
+    I.finish_lds += static_cast<size_t>(I.group) * max_row;
   }
-  CMX_REQUIRE(work_total < (1ll << 24) && num <= 65535, "too many matches in one batch");
+  CMX_REQUIRE(I.work_cap < (1ll << 24) && num <= 65535, "too many matches in one batch");
+  I.tile_grid = static_cast<int>(std::max<long long>(1, std::min<long long>(tile_slots, I.work_cap)));
+  return true;
+}
 
-  // ---- staging: params | per item: xyz, rotations, cells | work items | misc ---------------
+void Rt2DTileCall::Enqueue() {
+  Impl& I = *impl_;
+  const DebugOptions& dbg = Debug();
+  const Rt2DItem* items = I.items;
+  const Rt2DSearch* search = I.search;
+  const int num = I.num, device = I.device, rpl = I.rpl;
+  const std::vector<TileGeometry>& geo = I.geo;
+  // ---- staging: params | per item: xyz, rotations, cells | counters | misc ------------------
   struct Off { size_t xyz, rot, cells; };
   std::vector<Off> off(num);
   size_t in_bytes = Align16(sizeof(Rt2DTileParams) * num);
-  std::vector<std::shared_ptr<const std::vector<float2>>> tables(num);
+  // (rotation tables: one lookup per distinct (step, rotations) of the call)
+  std::vector<std::shared_ptr<const std::vector<float2>>> tables;
+  std::vector<int> table_of(num);
+  {
+    std::vector<std::pair<double, int>> keys;
+    for (int m = 0; m < num; ++m) {
+      const std::pair<double, int> key(search[m].step, search[m].na);
+      int k = static_cast<int>(keys.size()) - 1;
+      while (k >= 0 && keys[k] != key) --k;             // (usually the previous item's)
+      if (k < 0) {
+        k = static_cast<int>(keys.size());
+        keys.push_back(key);
+        tables.push_back(HostRotationTable(key.first, key.second));
+      }
+      table_of[m] = k;
+    }
+  }
   for (int m = 0; m < num; ++m) {
     const Rt2DItem& it = items[m];
     off[m].xyz = in_bytes;
@@ -1046,46 +1440,49 @@ bool Rt2DTileBatch(const cmx_rt_options* options, const Rt2DItem* items,
     off[m].cells = off[m].rot + Align16(sizeof(float2) * search[m].num_scans);
     in_bytes = off[m].cells + (it.device_cells ? 0 : Align16(sizeof(uint16_t) * static_cast<size_t>(it.limits->num_x_cells) * it.limits->num_y_cells));
   }
-  const size_t off_work = in_bytes;
-  in_bytes += Align16(sizeof(int4) * static_cast<size_t>(work_total));
+  const size_t off_counters = in_bytes;               // [0] work items, [1] next item (zeroed)
+  in_bytes += 64;
   const size_t off_misc = in_bytes;
   in_bytes += Align16(sizeof(unsigned) * 128 * static_cast<size_t>(num));
 
-  WorkspaceLease ws(device);
+  I.ws.reset(new WorkspaceLease(device));
+  WorkspaceLease& ws = *I.ws;
   char* h_in = ws->pinned[0].ReserveAs<char>(in_bytes);
   char* d_in = ws->dev[0].ReserveAs<char>(in_bytes);
-  uint16_t* d_lists = reinterpret_cast<uint16_t*>(ws->dev[1].Reserve(lists_total + 64));
-  uint32_t* d_hdr = ws->dev[2].ReserveAs<uint32_t>(hdr_total + 16);
-  int* d_qsum = ws->dev[3].ReserveAs<int>(qsum_total + 16);
-  unsigned* d_overflow = ws->dev[4].ReserveAs<unsigned>(static_cast<size_t>(num) * 2 * (kFinalistCap - kFinalistHead));
-  unsigned* h_misc = ws->pinned[1].ReserveAs<unsigned>(static_cast<size_t>(num) * 128);
+  uint16_t* d_lists = reinterpret_cast<uint16_t*>(ws->dev[1].Reserve(I.lists_total + 64));
+  uint32_t* d_hdr = ws->dev[2].ReserveAs<uint32_t>(I.hdr_total + 16);
+  int* d_qsum = ws->dev[3].ReserveAs<int>(I.qsum_total + 16);
+  I.d_overflow = ws->dev[4].ReserveAs<unsigned>(static_cast<size_t>(num) * 2 * (kFinalistCap - kFinalistHead));
+  int4* d_work = ws->dev[8].ReserveAs<int4>(static_cast<size_t>(I.work_cap) + 1);
+  I.h_misc = ws->pinned[1].ReserveAs<unsigned>(static_cast<size_t>(num) * 128);
   unsigned* d_misc = reinterpret_cast<unsigned*>(d_in + off_misc);
-  std::memset(h_in + off_misc, 0, sizeof(unsigned) * 128 * static_cast<size_t>(num));
-  unsigned long long* d_timeline = nullptr;
+  int* d_counters = reinterpret_cast<int*>(d_in + off_counters);
+  std::memset(h_in + off_counters, 0, 64 + sizeof(unsigned) * 128 * static_cast<size_t>(num));
+  const int timeline_tile_slots = I.tile_grid * 4;
   if (dbg.timeline) {
-    const size_t bytes = (static_cast<size_t>(work_total) + num) * kTimelineStamps * 8;
-    d_timeline = static_cast<unsigned long long*>(ws->dev[7].Reserve(bytes));
-    CMX_HIP(hipMemsetAsync(d_timeline, 0, bytes, ws->stream));
+    const size_t bytes = (static_cast<size_t>(timeline_tile_slots) + num) * kTimelineStamps * 8;
+    I.d_timeline = static_cast<unsigned long long*>(ws->dev[7].Reserve(bytes));
+    CMX_HIP(hipMemsetAsync(I.d_timeline, 0, bytes, ws->stream));
   }
 
   // ---- grid images: a resident grid keeps its own (two buffers per grid); everything else is
   // built into scratch by this call ---------------------------------------------------------
+  size_t scratch_images = 0;
   std::vector<uint16_t*> image_of(num, nullptr);
   std::vector<long long> scratch_at(num, -1);       // offset in this call's scratch (-1: cached)
   std::vector<int> build_image(num, 0), same_as(num, -1);
-  CacheHolds holds;
-  holds.stream = ws->stream;
+  I.holds.stream = ws->stream;
+  std::unordered_map<GridKey, int, GridKeyHash> first_of;
+  first_of.reserve(static_cast<size_t>(num));
   for (int m = 0; m < num; ++m) {
     const TileGeometry& g = geo[m];
     Rt2DImageCache* c = items[m].image_cache;
-    for (int k = 0; k < m; ++k) {                  // the same grid earlier in this batch
-      if (same_as[k] < 0 && items[k].cells == items[m].cells &&
-          items[k].device_cells == items[m].device_cells && items[k].image_cache == c &&
-          items[k].grid_version == items[m].grid_version && search[k].nl == search[m].nl &&
-          geo[k].gpitch == g.gpitch && geo[k].grows == g.grows) {
-        same_as[m] = k;
-        break;
-      }
+    {                                             // the same grid earlier in this batch
+      const GridKey key{items[m].cells, items[m].device_cells, c, items[m].grid_version,
+                        search[m].nl, g.gpitch, g.grows};
+      const auto found = first_of.find(key);
+      if (found != first_of.end()) same_as[m] = found->second;
+      else first_of.emplace(key, m);
     }
     if (same_as[m] >= 0) continue;
     int buffer = -1;
@@ -1093,7 +1490,7 @@ bool Rt2DTileBatch(const cmx_rt_options* options, const Rt2DItem* items,
     if (c && items[m].device_cells && !dbg.rt2d_no_image_cache) {
       buffer = c->Acquire(items[m].grid_version, search[m].nl, g.gpitch, g.grows, g.image_bytes, &build);
       if (buffer >= 0) {
-        holds.holds.push_back(CacheHold{c, buffer, build, items[m].grid_version, search[m].nl, g.gpitch, g.grows});
+        I.holds.holds.push_back(CacheHold{c, buffer, build, items[m].grid_version, search[m].nl, g.gpitch, g.grows});
         image_of[m] = c->buffer[buffer].image;
       }
     }
@@ -1112,26 +1509,26 @@ bool Rt2DTileBatch(const cmx_rt_options* options, const Rt2DItem* items,
 
   // ---- parameters -------------------------------------------------------------------------------
   Rt2DTileParams* h_params = reinterpret_cast<Rt2DTileParams*>(h_in);
-  int4* h_work = reinterpret_cast<int4*>(h_in + off_work);
   {
-    size_t lists_at = 0, hdr_at = 0, qsum_at = 0, work_at = 0;
-    std::vector<size_t> lists_off(num), hdr_off(num), qsum_off(num), work_off(num);
+    size_t lists_at = 0, hdr_at = 0, qsum_at = 0;
+    std::vector<size_t> lists_off(num), hdr_off(num), qsum_off(num);
     for (int m = 0; m < num; ++m) {
       const TileGeometry& g = geo[m];
       const int side = 2 * search[m].nl + 1;
       lists_off[m] = lists_at; lists_at += Align16(2 * static_cast<size_t>(search[m].num_scans) * g.cap_s);
       hdr_off[m] = hdr_at; hdr_at += static_cast<size_t>(search[m].num_scans) * g.ntx * g.nty * 4;
       qsum_off[m] = qsum_at; qsum_at += static_cast<size_t>(search[m].num_scans) * side * side;
-      work_off[m] = work_at; work_at += static_cast<size_t>(g.ntx) * g.nty * g.G;
     }
-    ParallelFor(num, 8, [&](int m) {
+    const cmx_rt_options* options = I.options;
+    unsigned long long* d_timeline = I.d_timeline;
+    unsigned* d_overflow = I.d_overflow;
+    ParallelFor(num, 16, [&](int m) {
       const Rt2DItem& it = items[m];
       const Rt2DSearch& sr = search[m];
       const TileGeometry& g = geo[m];
       const size_t cell_count = static_cast<size_t>(it.limits->num_x_cells) * it.limits->num_y_cells;
       if (!it.device_xyz) std::memcpy(h_in + off[m].xyz, it.xyz, 3 * sizeof(float) * it.n);
-      tables[m] = HostRotationTable(sr.step, sr.na);
-      std::memcpy(h_in + off[m].rot, tables[m]->data(), sizeof(float2) * sr.num_scans);
+      std::memcpy(h_in + off[m].rot, tables[table_of[m]]->data(), sizeof(float2) * sr.num_scans);
       if (!it.device_cells) std::memcpy(h_in + off[m].cells, it.cells, sizeof(uint16_t) * cell_count);
       Rt2DTileParams P{};
       P.cells = it.device_cells ? it.device_cells : reinterpret_cast<const uint16_t*>(d_in + off[m].cells);
@@ -1156,25 +1553,22 @@ bool Rt2DTileBatch(const cmx_rt_options* options, const Rt2DItem* items,
       P.tile_image_bytes = g.tile_image_bytes; P.null_addr = g.th_img * g.lp;
       P.lists = d_lists + lists_off[m] / 2; P.cap_s = g.cap_s;
       P.hdr = d_hdr + hdr_off[m];
-      P.G = g.G; P.rw = g.rw; P.list_lds = g.list_lds; P.task_cap = g.task_cap;
+      P.gmin = g.gmin; P.gmax = g.gmax; P.target = g.target; P.rw = g.rw;
+      P.list_lds = g.list_lds; P.task_cap = g.task_cap;
       P.flush_atomic = g.ntx * g.nty > 1 ? 1 : 0;
       P.qsum = d_qsum + qsum_off[m];
       P.misc = d_misc + static_cast<size_t>(m) * 128;
       P.overflow = d_overflow + static_cast<size_t>(m) * 2 * (kFinalistCap - kFinalistHead);
       P.stage = P.misc + 126;
       P.timeline = d_timeline;
-      P.timeline_finish_base = static_cast<int>(work_total);
+      P.timeline_finish_base = timeline_tile_slots;
       h_params[m] = P;
-      int4* w = h_work + work_off[m];
-      for (int t = 0; t < g.ntx * g.nty; ++t)
-        for (int gg = 0; gg < g.G; ++gg) *w++ = make_int4(m, t, gg, 0);
     });
   }
   // (the stage counters ride in the last words of a match's slot: the finalist head must stop short)
   static_assert(2 + 2 * kFinalistHead <= 126, "a match's head and stage counters share 128 words");
   SmallCopyAsync(d_in, h_in, in_bytes, /*to_device=*/true, ws->stream);
   const Rt2DTileParams* d_params = reinterpret_cast<const Rt2DTileParams*>(d_in);
-  const int4* d_work = reinterpret_cast<const int4*>(d_in + off_work);
 
   CMX_HIP(hipEventRecord(ws->ev_begin, ws->stream));
   {
@@ -1187,14 +1581,23 @@ bool Rt2DTileBatch(const cmx_rt_options* options, const Rt2DItem* items,
     if (any_build)
       Rt2DQuantKernel<<<dim3(DivUp(max_vecs, 256), num), 256, 0, ws->stream>>>(d_params);
   }
-  Rt2DTilePrepKernel<<<dim3(max_scans, num), 256, prep_lds, ws->stream>>>(d_params);
+  Rt2DTilePrepKernel<<<dim3(I.max_scans, num), 256, I.prep_lds, ws->stream>>>(
+      d_params, d_counters, d_work, static_cast<int>(I.work_cap));
   CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
   {
     const auto launch = [&](auto kernel) {
-      OptInLds(reinterpret_cast<const void*>(kernel), device, 160 * 1024);
-      kernel<<<static_cast<unsigned>(work_total), kTileThreads, tile_lds, ws->stream>>>(d_params, d_work);
+      OptInLds(reinterpret_cast<const void*>(kernel), device, 160 * 1024 - 1024);   // (minus the static words)
+      if (dbg.host_trace) {
+        int resident = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kernel, I.tile_threads, I.tile_lds);
+        fprintf(stderr, "[cmx host] rt2d tile kernel: %d workgroups of %d threads, %zu B of LDS each, "
+                        "%d resident per CU\n", I.tile_grid, I.tile_threads, I.tile_lds, resident);
+      }
+      kernel<<<static_cast<unsigned>(I.tile_grid), I.tile_threads, I.tile_lds, ws->stream>>>(
+          d_params, d_work, d_counters, d_counters + 1);
     };
-    if (d_timeline) {                 // the instrumented instantiations (runtime row stride)
+    const int common_stride = I.common_stride;
+    if (I.d_timeline) {               // the instrumented instantiations (runtime row stride)
       if (rpl == 1) launch(Rt2DTileKernel<1, 0, true>);
       else if (rpl == 2) launch(Rt2DTileKernel<2, 0, true>);
       else if (rpl == 3) launch(Rt2DTileKernel<3, 0, true>);
@@ -1204,6 +1607,7 @@ bool Rt2DTileBatch(const cmx_rt_options* options, const Rt2DItem* items,
     } else if (rpl == 1) launch(Rt2DTileKernel<1, 0, false>);
     else if (rpl == 2 && common_stride == 8 * 288) launch(Rt2DTileKernel<2, 8 * 288, false>);
     else if (rpl == 2 && common_stride == 8 * 224) launch(Rt2DTileKernel<2, 8 * 224, false>);
+    else if (rpl == 2 && common_stride == 8 * 480) launch(Rt2DTileKernel<2, 8 * 480, false>);
     else if (rpl == 2) launch(Rt2DTileKernel<2, 0, false>);
     else if (rpl == 3) launch(Rt2DTileKernel<3, 0, false>);
     else if (rpl == 4) launch(Rt2DTileKernel<4, 0, false>);
@@ -1212,55 +1616,77 @@ bool Rt2DTileBatch(const cmx_rt_options* options, const Rt2DItem* items,
   }
   CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
   OptInLds(reinterpret_cast<const void*>(Rt2DFinishKernel), device, 128 * 1024);
-  Rt2DFinishKernel<<<num, kFinishThreads, finish_lds, ws->stream>>>(d_params, group);
+  Rt2DFinishKernel<<<num, kFinishThreads, I.finish_lds, ws->stream>>>(d_params, I.group, I.h_misc);
   CMX_HIP(hipGetLastError());
   CMX_HIP(hipEventRecord(ws->ev_end, ws->stream));
-  SmallCopyAsync(h_misc, d_misc, sizeof(unsigned) * 128 * num, /*to_device=*/false, ws->stream);
+  I.enqueued = true;
+}
+
+bool Rt2DTileCall::Collect(cmx_match_stats* stats) {
+  Impl& I = *impl_;
+  CMX_REQUIRE(I.enqueued, "internal error: Collect before Enqueue");
+  WorkspaceLease& ws = *I.ws;
+  const int num = I.num;
+  const Rt2DItem* items = I.items;
+  const Rt2DSearch* search = I.search;
+  const unsigned* h_misc = I.h_misc;
   CMX_HIP(hipStreamSynchronize(ws->stream));
-  holds.built = true;
-  if (d_timeline) {
-    ReportTimeline("Rt2DTileKernel", d_timeline, static_cast<int>(work_total), ws->stream);
-    ReportTimeline("Rt2DFinishKernel", d_timeline + static_cast<size_t>(work_total) * kTimelineStamps,
+  I.synced = true;
+  I.holds.built = true;
+  if (I.d_timeline) {
+    ReportTimeline("Rt2DTileKernel", I.d_timeline, I.tile_grid * 4, ws->stream);
+    ReportTimeline("Rt2DFinishKernel", I.d_timeline + static_cast<size_t>(I.tile_grid) * 4 * kTimelineStamps,
                    num, ws->stream);
   }
-
   for (int m = 0; m < num; ++m) {
     const unsigned count = h_misc[static_cast<size_t>(m) * 128 + 1];
-    if (count == kOutOfBox)
+    if (h_misc[static_cast<size_t>(m) * 128] & kOutOfBox) {
       fprintf(stderr, "[cmx] rt2d: a point fell outside the predicted box of match %d; the batch "
                       "is repeated on the per-candidate kernels\n", m);
-    if (count > static_cast<unsigned>(kFinalistCap)) return false;    // kFlat, kOutOfBox, overflow
+      return false;
+    }
+    if (count > static_cast<unsigned>(kFinalistCap)) return false;    // kFlat, overflow
   }
-  cmx_match_stats total{};
-  std::vector<std::pair<int, float>> finalists;
-  std::vector<unsigned> extra;
-  long long stage1 = 0, stage2 = 0;
+  // Exact weighting and first maximum, item by item: on the host pool (exp, hypot, a sort of a
+  // handful of pairs); a match with more finalists than its head holds fetches the rest first.
+  std::vector<std::vector<unsigned>> extra(num);
   for (int m = 0; m < num; ++m) {
-    const unsigned* head = h_misc + static_cast<size_t>(m) * 128;
-    const long long count = head[1];
+    const long long count = h_misc[static_cast<size_t>(m) * 128 + 1];
     CMX_REQUIRE(count >= 1, "internal error: no candidate collected");
-    finalists.resize(count);
-    const long long in_head = std::min<long long>(count, kFinalistHead);
     if (count > kFinalistHead) {
-      extra.resize(2 * (count - kFinalistHead));
-      CMX_HIP(hipMemcpyAsync(extra.data(), d_overflow + static_cast<size_t>(m) * 2 * (kFinalistCap - kFinalistHead),
-                             sizeof(unsigned) * extra.size(), hipMemcpyDeviceToHost, ws->stream));
+      extra[m].resize(2 * (count - kFinalistHead));
+      CMX_HIP(hipMemcpyAsync(extra[m].data(), I.d_overflow + static_cast<size_t>(m) * 2 * (kFinalistCap - kFinalistHead),
+                             sizeof(unsigned) * extra[m].size(), hipMemcpyDeviceToHost, ws->stream));
       CMX_HIP(hipStreamSynchronize(ws->stream));
     }
+  }
+  const cmx_rt_options* options = I.options;
+  ParallelFor(num, 16, [&](int m) {
+    const unsigned* head = h_misc + static_cast<size_t>(m) * 128;
+    const long long count = head[1];
+    const long long in_head = std::min<long long>(count, kFinalistHead);
+    std::pair<int, float> small[kFinalistHead];
+    std::vector<std::pair<int, float>> big;
+    std::pair<int, float>* finalists = small;
+    if (count > kFinalistHead) { big.resize(count); finalists = big.data(); }
     for (long long i = 0; i < count; ++i) {
-      const unsigned* pair = i < in_head ? head + 2 + 2 * i : extra.data() + 2 * (i - in_head);
+      const unsigned* pair = i < in_head ? head + 2 + 2 * i : extra[m].data() + 2 * (i - in_head);
       float v;
       std::memcpy(&v, &pair[1], sizeof(float));
       finalists[i] = {static_cast<int>(pair[0]), v};
     }
-    std::sort(finalists.begin(), finalists.end());
-    Rt2DFinishOnHost(options, items[m], search[m], finalists.data(), finalists.size());
+    std::sort(finalists, finalists + count);
+    Rt2DFinishOnHost(options, items[m], search[m], finalists, static_cast<size_t>(count));
+  });
+  cmx_match_stats total{};
+  for (int m = 0; m < num; ++m) {
+    const unsigned* head = h_misc + static_cast<size_t>(m) * 128;
     const long long cands = static_cast<long long>(search[m].num_scans) * (2 * search[m].nl + 1) * (2 * search[m].nl + 1);
     total.candidates_scored += cands;
     total.coarse_candidates += cands;
     total.num_scans += search[m].num_scans;
-    stage1 += head[126];
-    stage2 += head[127] & 0xffffu;
+    total.refined_candidates += head[126];        // candidates re-summed with exact integers
+    total.finalists += head[127] & 0xffffu;       // candidates scored with the reference's f32 chain
   }
   if (stats) {
     float ms = 0.f;
@@ -1268,8 +1694,6 @@ bool Rt2DTileBatch(const cmx_rt_options* options, const Rt2DItem* items,
     total.device_ms = ms;
     CMX_HIP(hipEventElapsedTime(&ms, ws->ev_k0, ws->ev_k1));
     total.dominant_kernel_ms = ms;
-    total.refined_candidates = stage1;        // candidates re-summed with exact integers
-    total.finalists = stage2;                 // candidates scored with the reference's f32 chain
     *stats = total;
   }
   return true;

@@ -218,9 +218,20 @@ void Rt2DComputeSearch(const cmx_rt_options* options, const Rt2DItem& item, Rt2D
 // index (:142-143,170-174): writes the item's score and pose.
 void Rt2DFinishOnHost(const cmx_rt_options* options, const Rt2DItem& item, const Rt2DSearch& search,
                       const std::pair<int, float>* finalists, size_t count);
-// rt_2d_tiles.hip: the bulk path for probability grids; false = not taken (see there).
-bool Rt2DTileBatch(const cmx_rt_options* options, const Rt2DItem* items, const Rt2DSearch* search,
-                   int num, int32_t device, cmx_match_stats* stats);
+// rt_2d_tiles.hip: the bulk path for probability grids, in three steps so that one host thread
+// keeps the parts of a large batch in flight on streams of their own (see there).
+class Rt2DTileCall {
+ public:
+  Rt2DTileCall(const cmx_rt_options* options, const Rt2DItem* items, const Rt2DSearch* search,
+               int num, int32_t device);
+  ~Rt2DTileCall();
+  bool Plan();                          // false: not eligible for this path
+  void Enqueue();                       // asynchronous
+  bool Collect(cmx_match_stats* stats); // waits; false: repeat on the per-candidate kernels
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> impl_;
+};
 void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int num, int32_t device,
                     cmx_match_stats* stats);
 void Rt2DMatch(const cmx_rt_options* options, const cmx_grid2d_limits* limits,

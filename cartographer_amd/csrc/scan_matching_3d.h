@@ -174,6 +174,10 @@ void Fast3DGrids(const cmx_fast3d* matcher, Brick* high, float* resolution, Bric
 
 // grid_3d.hip: the resident HybridGrid's brick (false: still empty).
 bool Grid3DBrick(const cmx_grid3d* grid, Brick* brick, float* resolution, int* device);
+// grid_3d.hip: the f32 brick of a resident IntensityHybridGrid's averages (built on `stream` when
+// the grid has changed); false while the grid is empty.
+bool IntensityGrid3DBrick(cmx_intensity_grid3d* grid, hipStream_t stream, Brick* brick,
+                          float* resolution, int* device);
 
 }  // namespace cmx
 

@@ -116,8 +116,10 @@ class DeviceWorker {
 }  // namespace cmx
 
 struct cmx_comm {
-  std::vector<int> devices;
-  std::vector<void*> comms;                          // ncclComm_t per device
+  std::vector<int> devices;                          // per rank
+  bool virtual_ranks = false;                        // several ranks on ONE device (tests): the
+                                                     // key is reduced on the host, no RCCL
+  std::vector<void*> comms;                          // ncclComm_t per device (empty: no RCCL)
   std::vector<hipStream_t> streams;                  // one per device, for the collectives
   std::vector<long long*> d_keys;                    // 2 x int64 per device (send, recv)
   std::vector<std::unique_ptr<cmx::DeviceWorker>> workers;
@@ -179,22 +181,38 @@ cmx_status cmx_comm_init(const int32_t* devices, int32_t num_devices, cmx_comm**
       }
     };
     std::unique_ptr<cmx_comm, Release> comm(new cmx_comm, Release{current});
-    for (int i = 0; i < num_devices; ++i) {
-      const int d = devices ? devices[i] : i;
+    // Debug switch comm_virtual_ranks = N (tests on a one-GPU box): a communicator of ONE device
+    // becomes N ranks on it -- N worker threads, N streams, entries dealt to ranks by index range
+    // as a caller places its matchers (cmx_comm_device_of), the best key reduced on the host.
+    // Everything of a sharded call but the RCCL collective itself runs with world = N.
+    const int virtual_ranks = num_devices == 1 ? cmx::Debug().comm_virtual_ranks : 0;
+    if (virtual_ranks > 1) {
+      const int d = devices ? devices[0] : 0;
       CMX_REQUIRE(d >= 0 && d < count, "device %d out of range [0,%d)", d, count);
-      for (int prev : comm->devices) CMX_REQUIRE(prev != d, "device %d listed twice", d);
-      comm->devices.push_back(d);
+      comm->devices.assign(virtual_ranks, d);
+      comm->virtual_ranks = true;
+      num_devices = virtual_ranks;
+    } else {
+      for (int i = 0; i < num_devices; ++i) {
+        const int d = devices ? devices[i] : i;
+        CMX_REQUIRE(d >= 0 && d < count, "device %d out of range [0,%d)", d, count);
+        for (int prev : comm->devices) CMX_REQUIRE(prev != d, "device %d listed twice", d);
+        comm->devices.push_back(d);
+      }
     }
-    const cmx::Rccl& rccl = cmx::LoadRccl();
-    CMX_REQUIRE(rccl.handle && rccl.CommInitAll && rccl.AllReduce && rccl.GroupStart &&
-                    rccl.GroupEnd && rccl.CommDestroy,
-                "librccl.so.1 could not be loaded (needed for cmx_comm_init)");
-    comm->comms.assign(num_devices, nullptr);
-    const int rc = rccl.CommInitAll(comm->comms.data(), num_devices, comm->devices.data());
-    if (rc != 0) {
-      cmx::SetLastError("ncclCommInitAll failed: %s",
-                        rccl.GetErrorString ? rccl.GetErrorString(rc) : "?");
-      throw cmx::HipError{CMX_DEVICE_ERROR};
+    // (one device needs no collective: a single-GPU deployment works without librccl)
+    if (num_devices > 1 && !comm->virtual_ranks) {
+      const cmx::Rccl& rccl = cmx::LoadRccl();
+      CMX_REQUIRE(rccl.handle && rccl.CommInitAll && rccl.AllReduce && rccl.GroupStart &&
+                      rccl.GroupEnd && rccl.CommDestroy,
+                  "librccl.so.1 could not be loaded (needed for cmx_comm_init with several devices)");
+      comm->comms.assign(num_devices, nullptr);
+      const int rc = rccl.CommInitAll(comm->comms.data(), num_devices, comm->devices.data());
+      if (rc != 0) {
+        cmx::SetLastError("ncclCommInitAll failed: %s",
+                          rccl.GetErrorString ? rccl.GetErrorString(rc) : "?");
+        throw cmx::HipError{CMX_DEVICE_ERROR};
+      }
     }
     comm->streams.assign(num_devices, nullptr);
     comm->d_keys.assign(num_devices, nullptr);
@@ -213,7 +231,9 @@ void cmx_comm_destroy(cmx_comm* comm) {
   if (!comm) return;
   int current = -1;
   if (hipGetDevice(&current) != hipSuccess) current = -1;
-  const cmx::Rccl& rccl = cmx::LoadRccl();
+  const bool have_comms = !comm->comms.empty();
+  const cmx::Rccl rccl_none{};
+  const cmx::Rccl& rccl = have_comms ? cmx::LoadRccl() : rccl_none;
   comm->workers.clear();
   for (size_t i = 0; i < comm->devices.size(); ++i) {
     (void)hipSetDevice(comm->devices[i]);
@@ -256,9 +276,14 @@ struct RestoreDevice {
 // Node-wide best match: every device contributes the key of its own block, one
 // all-reduce(max) over the communicator; returns the reduced key (read back from rank 0).
 int64_t AllReduceBest(cmx_comm* comm, const std::vector<int64_t>& keys) {
+  const int world = static_cast<int>(comm->devices.size());
+  if (comm->comms.empty()) {       // one device, or virtual ranks on it: max over the ranks' keys
+    int64_t best = -1;
+    for (int r = 0; r < world; ++r) best = std::max(best, keys[r]);
+    return best;
+  }
   const RestoreDevice restore;
   const Rccl& rccl = LoadRccl();
-  const int world = static_cast<int>(comm->devices.size());
   for (int r = 0; r < world; ++r) {
     CMX_HIP(hipSetDevice(comm->devices[r]));
     const long long k = keys[r];
@@ -297,8 +322,13 @@ void FanOut(cmx_comm* comm, int num, DeviceOf device_of, PerRank per_rank) {
   for (int p = 0; p < num; ++p) {
     const int d = device_of(p);
     int rank = -1;
-    for (int r = 0; r < world; ++r)
-      if (comm->devices[r] == d) rank = r;
+    for (int r = 0; r < world && rank < 0; ++r) {
+      if (comm->devices[r] != d) continue;
+      if (!comm->virtual_ranks) { rank = r; break; }
+      int64_t b, e;                          // (virtual ranks share the device: by index range)
+      cmx_shard_range(num, r, world, &b, &e);
+      if (p >= b && p < e) rank = r;
+    }
     CMX_REQUIRE(rank >= 0, "entry %d lives on device %d, which is not in the communicator", p, d);
     mine[rank].push_back(p);
   }
@@ -388,7 +418,9 @@ cmx_status cmx_fast2d_match_sharded(cmx_comm* comm, const cmx_fast2d* const* mat
              keys[r] = key;
              return CMX_OK;
            });
-    const int64_t reduced = AllReduceBest(comm, keys);
+    // (a caller that wants neither the best index nor its score -- the constraint builders take
+    // every pair's result -- pays for no collective)
+    const int64_t reduced = best_index || best_score ? AllReduceBest(comm, keys) : -1;
     int32_t any;
     float score;
     int64_t index;
@@ -448,7 +480,9 @@ cmx_status cmx_fast3d_match_sharded(cmx_comm* comm, const cmx_fast3d* const* mat
              keys[r] = key;
              return CMX_OK;
            });
-    const int64_t reduced = AllReduceBest(comm, keys);
+    // (a caller that wants neither the best index nor its score -- the constraint builders take
+    // every pair's result -- pays for no collective)
+    const int64_t reduced = best_index || best_score ? AllReduceBest(comm, keys) : -1;
     int32_t any;
     float score;
     int64_t index;

@@ -149,11 +149,38 @@ class CeresScanMatcher3D:
         """``match`` against HybridGrids that already live in HBM
         (``grid_3d.HybridGridOnDevice``): ``[(point_cloud, grid), ...]`` -- what
         LocalTrajectoryBuilder3D::ScanMatch does with the active submap
-        (local_trajectory_builder_3d.cc:96-123).  Only the clouds cross PCIe."""
+        (local_trajectory_builder_3d.cc:96-123).  Only the clouds cross PCIe.  An entry may
+        continue with ``intensities, intensity_grid, (weight, huber_scale, intensity_threshold)``:
+        the pair's resident ``grid_3d.IntensityHybridGridOnDevice``."""
         num = self.options.num_pairs
         assert len(point_clouds_and_grids) == num
-        clouds = [_cloud(c)[0] for c, _ in point_clouds_and_grids]
-        handles = (C.c_void_p * num)(*[g._h for _, g in point_clouds_and_grids])
+        clouds = [_cloud(e[0])[0] for e in point_clouds_and_grids]
+        handles = (C.c_void_p * num)(*[e[1]._h for e in point_clouds_and_grids])
+        if any(len(e) > 2 and e[2] is not None for e in point_clouds_and_grids):
+            from ._lib import Ceres3DIntensityTerm
+            terms = (Ceres3DIntensityTerm * num)()
+            keep = []
+            for k, e in enumerate(point_clouds_and_grids):
+                if len(e) <= 2 or e[2] is None:
+                    continue
+                ints = np.ascontiguousarray(e[2], np.float32)
+                assert ints.shape[0] == clouds[k].shape[0]
+                keep.append(ints)
+                terms[k].grid = e[3]._h
+                terms[k].intensities = ints.ctypes.data
+                terms[k].weight, terms[k].huber_scale, terms[k].intensity_threshold = \
+                    float(e[4][0]), float(e[4][1]), float(e[4][2])
+            pointers = (C.c_void_p * num)(*[c.ctypes.data for c in clouds])
+            counts = np.ascontiguousarray([c.shape[0] for c in clouds], np.int32)
+            target = np.ascontiguousarray(target_translation, np.float64)
+            init = initial_pose_estimate.to_c()
+            pose = Pose3d()
+            summary = CeresSummary()
+            check(_lib.lib().cmx_ceres3d_match_grids_intensity(
+                C.byref(self.options), target.ctypes.data, C.byref(init), handles, pointers,
+                counts.ctypes.data, C.cast(terms, C.c_void_p), C.byref(pose), C.byref(summary)))
+            del keep
+            return Rigid3d.from_c(pose), summary.as_dict()
         pointers = (C.c_void_p * num)(*[c.ctypes.data for c in clouds])
         counts = np.ascontiguousarray([c.shape[0] for c in clouds], np.int32)
         target = np.ascontiguousarray(target_translation, np.float64)

@@ -133,6 +133,13 @@ class Communicator:
         _lib.check(_lib.lib().cmx_comm_init(devs.ctypes.data, len(devs), C.byref(self._h)))
         self.devices = list(map(int, devs))
 
+    @property
+    def num_devices(self):
+        """Ranks of the communicator (= devices, unless the debug switch comm_virtual_ranks made
+        one device several ranks)."""
+        from . import _lib
+        return int(_lib.lib().cmx_comm_num_devices(self._h))
+
     def __del__(self):
         if getattr(self, "_h", None):
             try:

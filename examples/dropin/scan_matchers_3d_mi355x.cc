@@ -162,7 +162,15 @@ void CeresScanMatcher3D::Match(
   std::vector<std::vector<float>> clouds;
   std::vector<cmx_ceres3d_pair> pairs;
   for (const PointCloudAndHybridGridsPointers& p : point_clouds_and_hybrid_grids) {
-    voxels.push_back(Flatten(*p.hybrid_grid));      // (intensity grids: not supported)
+    // The library implements IntensityCostFunction3D (cmx_ceres3d_pair's intensity fields), but
+    // this adapter flattens the occupancy grid only: a caller that hands over an intensity grid
+    // must not silently get a different optimisation than ceres_scan_matcher_3d.cc:118-137.
+    if (p.intensity_hybrid_grid != nullptr) {
+      std::fprintf(stderr, "CeresScanMatcher3D (MI355X adapter): intensity_hybrid_grid is not "
+                           "wired through this adapter; use cmx_ceres3d_match's intensity fields\n");
+      std::abort();
+    }
+    voxels.push_back(Flatten(*p.hybrid_grid));
     clouds.push_back(Flatten(*p.point_cloud));
     pairs.push_back(cmx_ceres3d_pair{clouds.back().data(),
                                      static_cast<int32_t>(p.point_cloud->size()),

@@ -435,8 +435,7 @@ cmx_status cmx_rt3d_match_grid(const cmx_rt_options* options, const cmx_grid3d* 
  * (mapping/internal/3d/local_trajectory_builder_3d.cc:96-123) against the ACTIVE submap: pair k is
  * (point_clouds_xyz[k], num_points[k]) with the resident HybridGrid grids[k] (its resolution is
  * the grid's); options->num_pairs pairs, all grids on one device.  Nothing but the clouds is
- * uploaded.  An intensity_hybrid_grid is not kept resident: pairs with an intensity term go
- * through cmx_ceres3d_match. */
+ * uploaded.  Pairs with an intensity term: cmx_ceres3d_match_grids_intensity below. */
 cmx_status cmx_ceres3d_match_grids(const cmx_ceres3d_options* options,
                                    const double* target_translation_xyz,
                                    const cmx_pose3d* initial_pose_estimate,
@@ -444,6 +443,55 @@ cmx_status cmx_ceres3d_match_grids(const cmx_ceres3d_options* options,
                                    const float* const* point_clouds_xyz,
                                    const int32_t* num_points, cmx_pose3d* pose_estimate,
                                    cmx_ceres_summary* summary);
+
+/* ---- IntensityHybridGrid in HBM -------------------------------------------
+ * mapping/3d/hybrid_grid.h:543-571: AverageIntensityData {sum, count} per voxel.
+ *   cmx_grid3d_insert_with_intensities  RangeDataInserter3D::Insert with an intensity grid
+ *                                       (mapping/3d/range_data_inserter_3d.cc:93-114): hits and
+ *                                       misses into `grid` exactly as cmx_grid3d_insert, then
+ *                                       InsertIntensitiesIntoGrid (:54-70) -- returns whose
+ *                                       intensity exceeds `intensity_threshold` are skipped, the
+ *                                       others add to their voxel's count and, IN POINT ORDER,
+ *                                       to its f32 sum (bit-identical to the reference's loop).
+ *                                       `intensities` = PointCloud::intensities() of the returns
+ *                                       (num_returns floats); NULL inserts none (:57).
+ *   cmx_intensity_grid3d_download       the voxels with count > 0, (z, y, x) order.
+ *   cmx_ceres3d_match_grids_intensity   cmx_ceres3d_match_grids with IntensityCostFunction3D
+ *                                       terms (SM3/ceres_scan_matcher_3d.cc:118-137) read from
+ *                                       resident intensity grids: terms[k].grid == NULL: pair k
+ *                                       has none.  Bit-identical to cmx_ceres3d_match on the same
+ *                                       voxels. */
+typedef struct cmx_intensity_grid3d cmx_intensity_grid3d;
+cmx_status cmx_intensity_grid3d_create(float resolution, int32_t device,
+                                       cmx_intensity_grid3d** out);
+void cmx_intensity_grid3d_destroy(cmx_intensity_grid3d* grid);
+cmx_status cmx_grid3d_insert_with_intensities(cmx_grid3d* grid,
+                                              cmx_intensity_grid3d* intensity_grid,
+                                              const float* origin_xyz, const float* returns_xyz,
+                                              const float* intensities, int32_t num_returns,
+                                              float hit_probability, float miss_probability,
+                                              int32_t num_free_space_voxels,
+                                              float intensity_threshold);
+cmx_status cmx_intensity_grid3d_download(const cmx_intensity_grid3d* grid,
+                                         cmx_intensity_voxel* voxels, int64_t capacity,
+                                         int64_t* num_voxels);
+typedef struct cmx_ceres3d_intensity_term {
+  cmx_intensity_grid3d* grid;   /* NULL: no intensity term for this pair */
+  const float* intensities;     /* num_points[k] intensities of the pair's cloud */
+  double weight;                /* IntensityCostFunctionOptions::weight */
+  double huber_scale;           /* ... ::huber_scale */
+  float intensity_threshold;    /* ... ::intensity_threshold */
+  int32_t reserved;
+} cmx_ceres3d_intensity_term;
+cmx_status cmx_ceres3d_match_grids_intensity(const cmx_ceres3d_options* options,
+                                             const double* target_translation_xyz,
+                                             const cmx_pose3d* initial_pose_estimate,
+                                             const cmx_grid3d* const* grids,
+                                             const float* const* point_clouds_xyz,
+                                             const int32_t* num_points,
+                                             const cmx_ceres3d_intensity_term* terms,
+                                             cmx_pose3d* pose_estimate,
+                                             cmx_ceres_summary* summary);
 
 /* ---- fast 3D ------------------------------------------------------------ */
 /* hybrid_grid.h:137 grid_size(): 8*8*2^bits cells per axis of the dynamic

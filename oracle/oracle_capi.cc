@@ -12,6 +12,9 @@
 #include "oracle_ceres_3d.h"
 #include "oracle_filters.h"
 
+#include <map>
+#include <tuple>
+
 using namespace oracle;
 
 namespace {
@@ -559,6 +562,39 @@ void orc_ceres3d_match_intensity(const double* options8, int num_pairs, const fl
   summary5[2] = sum.num_successful_steps; summary5[3] = sum.num_unsuccessful_steps;
   summary5[4] = sum.termination;
 }
+// InsertIntensitiesIntoGrid + IntensityHybridGrid::AddIntensity
+// (mapping/3d/range_data_inserter_3d.cc:54-70, mapping/3d/hybrid_grid.h:552-556) onto a voxel
+// list: returns above the threshold are skipped (`>`), the others add count += 1 and, in point
+// order, sum += intensity (f32).  `voxels` holds `count_in` voxels on entry and the result sorted
+// (z, y, x) on return (at most `capacity`); returns the number of voxels.
+int64_t orc_insert_intensities(float resolution, const float* returns_xyz, const float* intensities,
+                               int n, float intensity_threshold, IntensityVoxel* voxels,
+                               int64_t count_in, int64_t capacity) {
+  std::map<std::tuple<int, int, int>, std::pair<float, int>> cells;       // (z, y, x) -> sum, count
+  for (int64_t k = 0; k < count_in; ++k)
+    cells[std::make_tuple(voxels[k].z, voxels[k].y, voxels[k].x)] = {voxels[k].sum, voxels[k].count};
+  const IntensityGridView index_of(resolution, nullptr, 0);
+  if (intensities != nullptr) {                                           // (:57)
+    for (int i = 0; i < n; ++i) {
+      if (intensities[i] > intensity_threshold) continue;                 // (:59-61)
+      const Cell3i c = index_of.GetCellIndex(V3f{returns_xyz[3 * i], returns_xyz[3 * i + 1],
+                                                 returns_xyz[3 * i + 2]});
+      auto& cell = cells[std::make_tuple(c.z, c.y, c.x)];
+      cell.second += 1;
+      cell.first += intensities[i];
+    }
+  }
+  int64_t k = 0;
+  for (const auto& kv : cells) {
+    if (kv.second.second == 0) continue;
+    if (k < capacity)
+      voxels[k] = IntensityVoxel{std::get<2>(kv.first), std::get<1>(kv.first),
+                                 std::get<0>(kv.first), kv.second.second, kv.second.first};
+    ++k;
+  }
+  return k;
+}
+
 // IntensityCostFunction3D alone, like refc_intensity3d_residuals: residuals [n], jacobian [n][7].
 void orc_intensity3d_residuals(double scaling_factor, float intensity_threshold, const float* xyz,
                                const float* intensities, int n, float resolution,

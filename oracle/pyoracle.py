@@ -206,6 +206,14 @@ def ref_lib():
                                        C.c_int]
         L.ref_hgrid_voxels.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.ref_hgrid_voxels.restype = C.c_int64
+        L.ref_igrid_create.argtypes = [C.c_float]
+        L.ref_igrid_create.restype = C.c_void_p
+        L.ref_igrid_destroy.argtypes = [C.c_void_p]
+        L.ref_hgrid_insert_with_intensities.argtypes = [C.c_void_p, C.c_void_p, _f32p, _f32p,
+                                                        C.c_void_p, C.c_int, C.c_double, C.c_double,
+                                                        C.c_int, C.c_double]
+        L.ref_igrid_voxels.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.ref_igrid_voxels.restype = C.c_int64
         L.ref_rt3d_match.argtypes = [C.c_float, C.c_void_p, C.c_int64, _f64p, _f32p, C.c_int,
                                      C.c_double, C.c_double, C.c_double, C.c_double, _f64p,
                                      C.POINTER(C.c_int64)]
@@ -867,6 +875,17 @@ class ReferenceHybridGrid:
                                    ret.shape[0], hit_probability, miss_probability,
                                    num_free_space_voxels)
 
+    def insert_with_intensities(self, intensity_grid, origin_xyz, returns_xyz, intensities,
+                                hit_probability=0.7, miss_probability=0.4, num_free_space_voxels=5,
+                                intensity_threshold=40.0):
+        """RangeDataInserter3D::Insert with an IntensityHybridGrid (the reference's own source)."""
+        ret = np.ascontiguousarray(returns_xyz, np.float32).reshape(-1, 3)
+        ints = None if intensities is None else np.ascontiguousarray(intensities, np.float32)
+        ref_lib().ref_hgrid_insert_with_intensities(
+            self._h, intensity_grid._h, np.ascontiguousarray(origin_xyz, np.float32), ret,
+            None if ints is None else ints.ctypes.data, ret.shape[0], hit_probability,
+            miss_probability, num_free_space_voxels, intensity_threshold)
+
     def voxels(self):
         """Non-zero cells as VOXEL_DTYPE records sorted (z, y, x), like synth.HybridGrid."""
         n = ref_lib().ref_hgrid_voxels(self._h, None, 0)
@@ -1111,3 +1130,47 @@ def ceres3d_residuals(pairs, target_xyz, target_q4, pose7, occupied_space_weight
                             np.ascontiguousarray(pose7, np.float64), r, J)
     del keep
     return r, J
+
+
+class ReferenceIntensityHybridGrid:
+    """The reference's own IntensityHybridGrid (mapping/3d/hybrid_grid.h:543-571); filled through
+    ReferenceHybridGrid.insert_with_intensities."""
+
+    def __init__(self, resolution):
+        self._h = ref_lib().ref_igrid_create(resolution)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            ref_lib().ref_igrid_destroy(self._h)
+            self._h = None
+
+    def voxels(self):
+        """Cells with count > 0 as INTENSITY_VOXEL_DTYPE records sorted (z, y, x)."""
+        n = ref_lib().ref_igrid_voxels(self._h, None, None, 0)
+        rows = np.empty((max(n, 1), 4), np.int32)
+        sums = np.empty(max(n, 1), np.float32)
+        ref_lib().ref_igrid_voxels(self._h, rows.ctypes.data, sums.ctypes.data, rows.shape[0])
+        rows, sums = rows[:n], sums[:n]
+        order = np.lexsort((rows[:, 0], rows[:, 1], rows[:, 2]))
+        out = np.zeros(n, INTENSITY_VOXEL_DTYPE)
+        out["x"], out["y"], out["z"] = rows[order, 0], rows[order, 1], rows[order, 2]
+        out["count"], out["sum"] = rows[order, 3], sums[order]
+        return out[out["count"] > 0]
+
+
+def insert_intensities(resolution, voxels, returns_xyz, intensities, intensity_threshold):
+    """InsertIntensitiesIntoGrid (range_data_inserter_3d.cc:54-70) restated: `voxels`
+    (INTENSITY_VOXEL_DTYPE, may be empty) plus one scan; returns the new voxel list (z, y, x)."""
+    ret = np.ascontiguousarray(returns_xyz, np.float32).reshape(-1, 3)
+    ints = None if intensities is None else np.ascontiguousarray(intensities, np.float32)
+    old = np.ascontiguousarray(voxels, INTENSITY_VOXEL_DTYPE)
+    cap = old.shape[0] + ret.shape[0] + 1
+    buf = np.zeros(cap, INTENSITY_VOXEL_DTYPE)
+    buf[:old.shape[0]] = old
+    fn = lib().orc_insert_intensities
+    fn.argtypes = [C.c_float, _f32p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64,
+                   C.c_int64]
+    fn.restype = C.c_int64
+    n = fn(resolution, ret, None if ints is None else ints.ctypes.data, ret.shape[0],
+           intensity_threshold, buf.ctypes.data, old.shape[0], cap)
+    return buf[:n].copy()

@@ -479,6 +479,58 @@ void ref_hgrid_insert(void* h, const float* origin_xyz, const float* returns_xyz
   range_data.returns = MakeCloud(returns_xyz, num_returns);
   inserter.Insert(range_data, static_cast<cm::HybridGrid*>(h), nullptr);
 }
+}  // extern "C" (reopened below)
+// (the reference never iterates an IntensityHybridGrid, so AverageIntensityData has no
+// operator== for IsDefaultValue, hybrid_grid.h:55-58; found by ADL at instantiation)
+namespace cartographer {
+namespace mapping {
+inline bool operator==(const AverageIntensityData& a, const AverageIntensityData& b) {
+  return a.sum == b.sum && a.count == b.count;
+}
+}  // namespace mapping
+}  // namespace cartographer
+extern "C" {
+// The reference's IntensityHybridGrid (hybrid_grid.h:543-571) filled by its own
+// RangeDataInserter3D::Insert with an intensity grid (range_data_inserter_3d.cc:54-70,109-112).
+void* ref_igrid_create(float resolution) { return new cm::IntensityHybridGrid(resolution); }
+void ref_igrid_destroy(void* h) { delete static_cast<cm::IntensityHybridGrid*>(h); }
+void ref_hgrid_insert_with_intensities(void* h, void* ih, const float* origin_xyz,
+                                       const float* returns_xyz, const float* intensities,
+                                       int num_returns, double hit_probability,
+                                       double miss_probability, int num_free_space_voxels,
+                                       double intensity_threshold) {
+  cm::proto::RangeDataInserterOptions3D options;
+  options.set_hit_probability(hit_probability);
+  options.set_miss_probability(miss_probability);
+  options.set_num_free_space_voxels(num_free_space_voxels);
+  options.set_intensity_threshold(intensity_threshold);
+  const cm::RangeDataInserter3D inserter(options);
+  cartographer::sensor::RangeData range_data;
+  range_data.origin = Eigen::Vector3f(origin_xyz[0], origin_xyz[1], origin_xyz[2]);
+  std::vector<cartographer::sensor::RangefinderPoint> points;
+  for (int i = 0; i != num_returns; ++i)
+    points.push_back({Eigen::Vector3f(returns_xyz[3 * i], returns_xyz[3 * i + 1], returns_xyz[3 * i + 2])});
+  range_data.returns =
+      intensities ? cartographer::sensor::PointCloud(
+                        points, std::vector<float>(intensities, intensities + num_returns))
+                  : cartographer::sensor::PointCloud(points);
+  inserter.Insert(range_data, static_cast<cm::HybridGrid*>(h),
+                  static_cast<cm::IntensityHybridGrid*>(ih));
+}
+// (x, y, z, count) rows + sums in iteration order; returns the count, writes min(count, capacity).
+int64_t ref_igrid_voxels(void* ih, int32_t* out_xyzc, float* out_sum, int64_t capacity) {
+  const auto* grid = static_cast<cm::IntensityHybridGrid*>(ih);
+  int64_t k = 0;
+  for (auto it = cm::IntensityHybridGrid::Iterator(*grid); !it.Done(); it.Next(), ++k) {
+    if (k >= capacity) continue;
+    const Eigen::Array3i c = it.GetCellIndex();
+    out_xyzc[4 * k] = c.x(); out_xyzc[4 * k + 1] = c.y(); out_xyzc[4 * k + 2] = c.z();
+    out_xyzc[4 * k + 3] = it.GetValue().count;
+    out_sum[k] = it.GetValue().sum;
+  }
+  return k;
+}
+
 // (x, y, z, value) rows in iteration order; returns the count, writes min(count, capacity).
 int64_t ref_hgrid_voxels(void* h, int32_t* out_xyzv, int64_t capacity) {
   const auto* grid = static_cast<cm::HybridGrid*>(h);

@@ -48,6 +48,30 @@ def install(setattr_=setattr):
                 dict(candidates_scored=1000 * n, coarse_candidates=900 * n,
                      dominant_kernel_ms=0.03, device_ms=0.17, num_scans=50 * n,
                      nodes_expanded=30))
+    # C5 (--config c5): the 3D matcher, its batch call and the 150^3 synthetic submaps (a
+    # small world stands in: the contract test is about sharding, collectives and the JSON line)
+    from cartographer_amd import scan_matching_3d as sm3, synth
+
+    class FakeMatcher3D:
+        last_stats = {}
+
+        def __init__(self, *a, **k):
+            pass
+
+    def fake_batch_3d(matchers, nodes, submaps, full, thresholds, data):
+        CALLS.append(len(matchers))
+        n = len(matchers)
+        got = [dict(score=0.5 + 0.01 * i, pose_estimate=nodes[i], rotational_score=1.0,
+                    low_resolution_score=1.0) if i % 2 == 0 else None for i in range(n)]
+        return got, dict(candidates_scored=2000 * n, coarse_candidates=1500 * n,
+                         dominant_kernel_ms=0.05, device_ms=0.4, num_scans=7 * n,
+                         nodes_expanded=300 * n, expansion_ms=0.3, expansion_launches=7,
+                         expansion_nodes=250 * n, expansion_lookups=250 * n * 64)
+    real_submap_3d = synth.make_submap_3d
+    setattr_(synth, "make_submap_3d",
+             lambda seed, res, size, *a: real_submap_3d(seed, max(res, 0.4), (4.0, 4.0, 2.0), 2, 4, 32))
+    setattr_(sm3, "FastCorrelativeScanMatcher3D", FakeMatcher3D)
+    setattr_(sm3, "fast3d_match_batch", fake_batch_3d)
     setattr_(sm, "FastCorrelativeScanMatcher2D", FakeMatcher)
     setattr_(sm, "PointCloudOnDevice", lambda scan, device=0: scan)
     setattr_(sm, "match_full_submap_batch", fake_batch)

@@ -132,6 +132,41 @@ def test_bench_two_ranks_gloo():
         assert "issued 7 matches" in err
 
 
+def test_bench_two_ranks_gloo_c5():
+    """`--config c5 --gpus 2` (the 3D loop-closure batch, BASELINE config[4]) on two CPU processes
+    over gloo: submaps sharded in equal blocks (rank r owns submaps r * pairs ...), every rank
+    searches its block, the optional constraints are all-gathered and the node-wide best match is
+    the all-reduce(max) of the packed key; rank 0 prints ONE line."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT="29551")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(root, "tests", "bench_stub.py"), "--config", "c5",
+             "--gpus", "2", "--steps", "4", "--warmup", "1", "--submaps", "3",
+             "--passes-per-step", "1"],
+            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    lines0 = [l for l in outs[0][0].splitlines() if l.strip()]
+    assert [l.startswith("{") for l in lines0].count(True) == 1 and lines0[-1].startswith("{")
+    assert not any(l.startswith("{") for l in outs[1][0].splitlines())    # rank 0 only
+    out = json.loads(lines0[-1])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
+    assert out["config"]["name"] == "c5" and out["config"]["submaps_per_gpu"] == 3
+    # the stub finds pairs 0 and 2 of every rank's block: 4 constraints node-wide; the best score
+    # is the last even pair's (0.52), which both ranks report for their local pair 2 -- the packed
+    # key resolves the tie to the LOWEST global submap index: rank 0's
+    assert out["config"]["constraints_found_node_wide"] == 4
+    assert abs(out["config"]["best_match"]["score"] - 0.52) < 1e-6
+    assert out["config"]["best_match"]["submap"] == 2
+    assert "cpu_baseline" not in out                            # N = 1 only
+    for _, err in outs:
+        assert "issued 5 matches" in err
+
+
 def test_bench_two_ranks_calibrate_together():
     """The driver's own command line (no --passes-per-step) on two ranks of unequal speed: the
     calibrated pass count is agreed on (all-reduce MAX) BEFORE any rank runs a trial step -- a

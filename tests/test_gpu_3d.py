@@ -312,7 +312,7 @@ def test_rt3d_ragged_and_large_clouds(sm3, oracle, synth):
 # RT-3D integer bulk pass (round 2): same result as the per-candidate kernel and the oracle
 # ----------------------------------------------------------------------------
 @pytest.mark.parametrize("case", ["yaw", "tilted", "far_points", "offset_box", "weights"])
-def test_rt3d_bulk_pass_equals_per_candidate_kernel(sm3, oracle, synth, case, monkeypatch):
+def test_rt3d_bulk_pass_equals_per_candidate_kernel(sm3, oracle, synth, case, debug):
     """The bulk pass only selects finalists; score and pose come from the reference's own
     arithmetic.  Tilted initial orientations (the translation lattice is then not aligned
     with the voxel axes), points far outside the stored box (clamped while staged), a box away
@@ -344,23 +344,23 @@ def test_rt3d_bulk_pass_equals_per_candidate_kernel(sm3, oracle, synth, case, mo
     m = sm3.RealTimeCorrelativeScanMatcher3D(0.2, math.radians(1.0), *weights)
     rigid = sm3.Rigid3d(tuple(init[:3]), tuple(init[3:]))
     got = {}
-    monkeypatch.setenv("CMX_RT3D_VERIFY", "1")      # group bounds checked against member bounds
+    from cartographer_amd import _lib
     # "tiles": the LDS-tiled bulk passes, cross-checked element by element against the gather
-    # kernels (CMX_RT3D_CROSSCHECK: every group bound bitwise, every candidate sum); "1": the
+    # kernels (rt3d_crosscheck: every group bound bitwise, every candidate sum); "1": the
     # gather kernels alone; "0": every candidate scored exhaustively
     # "fixed": the tiled passes as shipped (group centres in packed fixed-point, a different but
     # equally valid centre cell next to boundaries: checked with EVERY group expanded, so that
-    # CMX_RT3D_VERIFY compares every group bound with every member's own bounds)
-    # "staged": the shipped configuration under CMX_RT3D_VERIFY (second candidate round by point
+    # rt3d_verify compares every group bound with every member's own bounds)
+    # "staged": the shipped configuration under rt3d_verify (second candidate round by point
     # segments: every intermediate bound checked against the candidate's final sum);
     # "shipped": the same without the verification mode (candidates really leave the lists)
     for bulk in ("tiles", "fixed", "staged", "shipped", "1", "0"):
-        monkeypatch.setenv("CMX_RT3D_VERIFY", "0" if bulk == "shipped" else "1")
-        monkeypatch.setenv("CMX_RT3D_BULK", "0" if bulk == "0" else "1")
-        monkeypatch.setenv("CMX_RT3D_TILES",
-                           "1" if bulk in ("tiles", "fixed", "staged", "shipped") else "0")
-        monkeypatch.setenv("CMX_RT3D_CROSSCHECK", "1" if bulk == "tiles" else "0")
-        monkeypatch.setenv("CMX_RT3D_EXPAND_ALL", "1" if bulk == "fixed" else "0")
+        _lib.debug_reset()
+        debug(rt3d_verify=0 if bulk == "shipped" else 1,     # group bounds checked against member bounds
+              rt3d_legacy=1 if bulk == "0" else 0,
+              rt3d_no_tiles=0 if bulk in ("tiles", "fixed", "staged", "shipped") else 1,
+              rt3d_crosscheck=1 if bulk == "tiles" else 0,
+              rt3d_expand_all=1 if bulk == "fixed" else 0)
         score, pose = m.match(rigid, cloud, 0.1, vox)
         got[bulk] = (np.float32(score), _pose7(pose), dict(m.last_stats))
         assert m.last_stats["candidates_scored"] == ref["num_candidates"]
@@ -378,11 +378,10 @@ def test_rt3d_bulk_pass_equals_per_candidate_kernel(sm3, oracle, synth, case, mo
     assert abs(a - b) <= 0.02 * b
 
 
-def test_rt3d_bulk_pass_flat_landscape_falls_back(sm3, oracle, monkeypatch):
+def test_rt3d_bulk_pass_flat_landscape_falls_back(sm3, oracle):
     """An empty grid scores every candidate alike: more finalists than the list holds, the
     per-candidate kernel takes over and the first candidate wins as in the reference."""
     from cartographer_amd._lib import VOXEL_DTYPE
-    monkeypatch.setenv("CMX_RT3D_BULK", "1")
     empty = np.zeros(0, VOXEL_DTYPE)
     rng = np.random.default_rng(3)
     cloud = rng.uniform(-2, 2, (300, 3)).astype(np.float32)
@@ -426,7 +425,7 @@ def _assert_same_results(expected, got):
 
 
 @pytest.mark.parametrize("capacity", [None, "4096"])
-def test_fast3d_device_batch_mixed_depths_poses_and_overflow(sm3, synth, oracle, monkeypatch,
+def test_fast3d_device_batch_mixed_depths_poses_and_overflow(sm3, synth, oracle, debug,
                                                             capacity):
     """Twelve pairs in one chain of launches: stacks of different depth (3 .. 6, one of depth 1:
     that batch falls back to single searches), a different node pose per pair, windowed and
@@ -450,7 +449,7 @@ def test_fast3d_device_batch_mixed_depths_poses_and_overflow(sm3, synth, oracle,
                         else m.match(node, ident, data, t))
     assert any(e is not None for e in expected) and any(e is None for e in expected)
     if capacity:
-        monkeypatch.setenv("CMX_FRONTIER_CAPACITY", capacity)
+        debug(frontier_capacity=int(capacity))
     got, stats = sm3.fast3d_match_batch(matchers, nodes, [ident] * len(depths), fulls, thresholds,
                                         data)
     _assert_same_results(expected, got)
@@ -608,12 +607,12 @@ def test_ceres3d_invalid_arguments(sm3, synth):
 
 
 @pytest.mark.parametrize("oct", ["1", "0"])
-def test_fast3d_oct_layout_equals_the_oracle(sm3, oracle, synth, monkeypatch, oct):
+def test_fast3d_oct_layout_equals_the_oracle(sm3, oracle, synth, debug, oct):
     """Child cells from the 8-byte "oct" words (one gather per point and node) and from the level
-    bricks themselves (CMX_FAST3D_OCT=0 at matcher creation): the oracle's result either way, on
+    bricks themselves (debug switch fast3d_no_oct at matcher creation): the oracle's result either way, on
     the C5-shaped submap (full and half resolution levels, strides 1, 2, 4) and on a shallow
     stack with a window reaching far outside the grid."""
-    monkeypatch.setenv("CMX_FAST3D_OCT", oct)
+    debug(fast3d_no_oct=1 if oct == "0" else 0)
     size = (15.0, 15.0, 7.5)
     grid, world = synth.make_submap_3d(42, 0.1, size, 8, 32, 512)
     low, _ = synth.make_submap_3d(42, 0.45, size, 8, 32, 512)
@@ -750,13 +749,13 @@ def test_constraint_builder_3d_refines_on_the_device(sm3, oracle, synth):
 
 @pytest.mark.parametrize("families", [None, "0"])
 @pytest.mark.parametrize("affinity", [None, "0"])
-def test_fast3d_device_batch_of_twenty_pairs(sm3, synth, monkeypatch, affinity, families):
+def test_fast3d_device_batch_of_twenty_pairs(sm3, synth, debug, affinity, families):
     """From 16 pairs on a problem's nodes stay on one XCD (placement only: the search is
     order-free); pair by pair the batch must return what the single searches return."""
     if affinity is not None:
-        monkeypatch.setenv("CMX_FAST3D_AFFINITY", affinity)
+        debug(fast3d_affinity=1)                       # nodes of a problem on any XCD
     if families is not None:         # every node expanded on its own (round 2) instead of by family
-        monkeypatch.setenv("CMX_FAST3D_FAMILIES", families)
+        debug(fast3d_no_families=1)
     depths = [5, 4, 6, 3] * 5
     matchers, pos, data = _fast3d_batch_scene(sm3, synth, depths)
     ident = sm3.Rigid3d()
@@ -781,7 +780,8 @@ def test_fast3d_device_batch_of_twenty_pairs(sm3, synth, monkeypatch, affinity, 
 # ----------------------------------------------------------------------------
 # cmx_fast3d_match_sharded: the C5 fan-out over a communicator (north star: 256 submaps / 8 GPUs)
 # ----------------------------------------------------------------------------
-def test_fast3d_sharded_match_equals_the_batch(sm3, synth):
+@pytest.mark.parametrize("virtual_ranks", [0, 2])
+def test_fast3d_sharded_match_equals_the_batch(sm3, synth, debug, virtual_ranks):
     """cmx_fast3d_match_sharded over a communicator of every visible device (one on the test
     box): pair by pair what cmx_fast3d_match_batch returns -- windowed and full-submap pairs
     mixed, thresholds that reject some pairs -- and the RCCL all-reduce(max) of the packed key
@@ -790,7 +790,13 @@ def test_fast3d_sharded_match_equals_the_batch(sm3, synth):
     import torch
     from cartographer_amd import sharding
     ndev = torch.cuda.device_count()
-    comm = sharding.Communicator(list(range(ndev)))
+    if virtual_ranks:          # the one device as two ranks (see the 2D test of the same name)
+        debug(comm_virtual_ranks=virtual_ranks)
+        comm = sharding.Communicator([0])
+        assert comm.num_devices == virtual_ranks
+        ndev = 1
+    else:
+        comm = sharding.Communicator(list(range(ndev)))
     depths = [5, 4, 6] * 4                      # seeds 70 + k % 3: k = 0, 3, 6, 9 identical
     matchers, pos, data = _fast3d_batch_scene(sm3, synth, depths)
     if ndev > 1:                                # place every matcher on the device that owns it

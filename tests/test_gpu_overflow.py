@@ -1,7 +1,7 @@
 """The frontier-overflow path of the branch-and-bound searches: with the node buffers shrunk
-(CMX_FRONTIER_CAPACITY, a test hook) the first pass drops nodes, and the search must repeat in
-strict mode over smaller chunks and still return what the oracle returns.  Runs in a
-subprocess because the capacity is read from the environment by the library."""
+(debug switch frontier_capacity, a test hook) the first pass drops nodes, and the search must
+repeat in strict mode over smaller chunks and still return what the oracle returns.  Runs in a
+subprocess so that the shrunk buffers do not outlive the test."""
 import os
 import subprocess
 import sys
@@ -15,8 +15,10 @@ SCRIPT = r"""
 import math, sys
 import numpy as np
 sys.path.insert(0, %(root)r)
-from cartographer_amd import scan_matching as sm, scan_matching_3d as sm3, synth
+from cartographer_amd import _lib, scan_matching as sm, scan_matching_3d as sm3, synth
 from oracle import pyoracle as orc
+import os
+_lib.debug_set(frontier_capacity=int(os.environ["CMX_TEST_FRONTIER_CAPACITY"]))
 
 cells, lim, world = synth.make_submap(42, 300, 300, 0.05, 20, 800, 30.0, 0.01)
 truth = world.free_pose(3, 0.5)
@@ -66,7 +68,7 @@ print("OVERFLOW-OK")
 @pytest.mark.parametrize("capacity,with_3d", [("2048", "0"), ("8192", "0"), ("4096", "1")])
 def test_overflow_retry_returns_the_reference_score(capacity, with_3d):
     # (capacities are per 64 sub-lists; a sub-list must at least hold one node's children)
-    env = dict(os.environ, CMX_FRONTIER_CAPACITY=capacity, CMX_TEST_3D=with_3d)
+    env = dict(os.environ, CMX_TEST_FRONTIER_CAPACITY=capacity, CMX_TEST_3D=with_3d)
     out = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}], env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr

@@ -1,7 +1,7 @@
 """Round-2 device paths against the oracle, old and new side by side.
 
   * fast 2D: the fused front end (PrepScoreFusedKernel: prep + bucketing + lowest-resolution
-    scoring in one block per rotation) vs the separate launches (CMX_FUSED=0);
+    scoring in one block per rotation) vs the separate launches (debug switch fast2d_unfused);
   * real-time 2D: the LDS-staged integer bulk pass + exact finalists (Rt2DBulkKernel /
     Rt2DFinishKernel) vs one thread per candidate (debug switch rt2d_legacy).
 Both toggles are read per call, so one process runs both paths on identical inputs.  Bars as in
@@ -35,8 +35,8 @@ def c2(synth):
 
 
 @pytest.mark.parametrize("fused", ["1", "0"])
-def test_fast2d_prepare_both_front_ends(sm, oracle, c2, monkeypatch, fused):
-    monkeypatch.setenv("CMX_FUSED", fused)
+def test_fast2d_prepare_both_front_ends(sm, oracle, c2, debug, fused):
+    debug(fast2d_unfused=1 if fused == "0" else 0)
     cells, lim, _, _, scan = c2
     om = oracle.FastCorrelativeScanMatcher2D(cells, 0.05, lim["max_x"], lim["max_y"], 7)
     gm = sm.FastCorrelativeScanMatcher2D(_grid(sm, cells, lim), 7)
@@ -50,8 +50,8 @@ def test_fast2d_prepare_both_front_ends(sm, oracle, c2, monkeypatch, fused):
 
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("depth,n", [(7, 1000), (5, 333), (3, 64), (6, 1)])
-def test_fast2d_match_both_front_ends(sm, oracle, c2, monkeypatch, fused, depth, n):
-    monkeypatch.setenv("CMX_FUSED", fused)
+def test_fast2d_match_both_front_ends(sm, oracle, c2, debug, fused, depth, n):
+    debug(fast2d_unfused=1 if fused == "0" else 0)
     cells, lim, _, truth, scan = c2
     cloud = scan[:n]
     om = oracle.FastCorrelativeScanMatcher2D(cells, 0.05, lim["max_x"], lim["max_y"], depth, 2.0,
@@ -73,7 +73,7 @@ def test_fast2d_match_both_front_ends(sm, oracle, c2, monkeypatch, fused, depth,
         assert gm.last_stats["coarse_candidates"] == ref["coarse_candidates"]
 
 
-def test_fast2d_fused_and_unfused_batches_agree(sm, synth, c2, monkeypatch):
+def test_fast2d_fused_and_unfused_batches_agree(sm, synth, c2, debug):
     """A ConstraintBuilder batch (windowed and full-submap pairs mixed) gives the same
     constraint list through either front end, and the min_score gate on the discretised
     scans (only scans that can still matter are kept for the tree search) changes nothing."""
@@ -89,7 +89,7 @@ def test_fast2d_fused_and_unfused_batches_agree(sm, synth, c2, monkeypatch):
     thresholds = [0.6, 0.4, 0.9, 0.55, 0.3]
     out = {}
     for fused in ("1", "0"):
-        monkeypatch.setenv("CMX_FUSED", fused)
+        debug(fast2d_unfused=1 if fused == "0" else 0)
         out[fused] = sm.match_batch(matchers, initial, full, thresholds, scan)
     a, b = out["1"], out["0"]
     np.testing.assert_array_equal(a[0], b[0])
@@ -109,13 +109,13 @@ RT2D_PATHS = ["tiles", "tiles64", "tiles56g", "0"]
 def _rt2d_path(debug, path):
     """'tiles': integer bulk pass out of LDS tiles + exact finalists (default); 'tiles64' /
     'tiles56g': the same with small tiles (up to 4 x 4 per match: sums meet by atomics) and
-    with one workgroup per (tile, rotation); '0': one thread per candidate."""
+    with one work item per (tile, rotation); '0': one thread per candidate."""
     if path == "0":
         debug(rt2d_legacy=1)
     elif path == "tiles64":
         debug(rt2d_tile=64, rt2d_no_image_cache=1)
     elif path == "tiles56g":
-        debug(rt2d_tile=56, rt2d_groups=1000)
+        debug(rt2d_tile=56, rt2d_groups=1000, rt2d_target=1)
 
 
 @pytest.mark.parametrize("bulk", RT2D_PATHS)
@@ -328,15 +328,26 @@ def test_fast2d_match_then_refine_batch(sm, oracle, synth, c2):
 # ----------------------------------------------------------------------------
 # cmx_comm: the sharded entry points on the devices this box has
 # ----------------------------------------------------------------------------
-def test_sharded_match_equals_the_batch(sm, synth, c2):
+@pytest.mark.parametrize("virtual_ranks", [0, 2, 3])
+def test_sharded_match_equals_the_batch(sm, synth, c2, debug, virtual_ranks):
     """cmx_fast2d_match_sharded over a communicator of every visible device (one on the test
-    box): same constraint list as cmx_fast2d_match_batch, and the RCCL all-reduce returns the
-    best found pair (lowest index among equal scores)."""
+    box): same constraint list as cmx_fast2d_match_batch, and the all-reduce returns the best
+    found pair (lowest index among equal scores).  virtual_ranks = N: the one device as N ranks
+    (debug switch comm_virtual_ranks) -- N device workers, the five submaps dealt to them by
+    index range, each rank's batch on its own stream, the packed keys of all ranks reduced (on
+    the host: RCCL refuses one device twice): the fan-out, the result order and the key
+    arithmetic run with world = N on a one-GPU box."""
     import torch
     from cartographer_amd import sharding
     _, _, _, truth, scan = c2
     ndev = torch.cuda.device_count()
-    comm = sharding.Communicator(list(range(ndev)))
+    if virtual_ranks:
+        debug(comm_virtual_ranks=virtual_ranks)
+        comm = sharding.Communicator([0])
+        assert comm.num_devices == virtual_ranks
+        ndev = 1
+    else:
+        comm = sharding.Communicator(list(range(ndev)))
     matchers = []
     seeds = (42, 43, 42, 44, 42)           # submaps 0, 2, 4 are identical: equal scores
     for k, seed in enumerate(seeds):
@@ -356,7 +367,11 @@ def test_sharded_match_equals_the_batch(sm, synth, c2):
         for a, b, ok in zip(p, p1, f):
             if ok:
                 assert (a.x, a.y, a.theta) == (b.x, b.y, b.theta)
-        assert stats["candidates_scored"] == stats1["candidates_scored"]
+        if virtual_ranks:      # (smaller batches per rank: the bound rises at other moments)
+            assert abs(stats["candidates_scored"] - stats1["candidates_scored"]) < \
+                0.05 * stats1["candidates_scored"]
+        else:
+            assert stats["candidates_scored"] == stats1["candidates_scored"]
     assert f[0] == 1 and f[4] == 1 and s[0] == s[4]
     masked = np.where(f != 0, s, -1.0)
     assert best[0] == int(np.argmax(masked)) and np.float32(best[1]) == masked.max()
@@ -422,16 +437,15 @@ def test_compute_histogram_equals_the_oracle(oracle, synth, seed):
     assert (np.abs(got - ref) > 1e-3).sum() <= 4
 
 
-@pytest.mark.parametrize("env", [{}, {"CMX_STORE_SCANS": "0", "CMX_XCD_AFFINITY": "0"}])
-def test_c3_share_of_64_submaps_equals_the_single_searches(sm, synth, monkeypatch, env):
+@pytest.mark.parametrize("env", [{}, {"fast2d_store_scans": 1, "fast2d_xcd_affinity": 1}])
+def test_c3_share_of_64_submaps_equals_the_single_searches(sm, synth, debug, env):
     """One GPU's share of BASELINE config[2] at its full size: one 1000-point scan against 64
     distinct 400x400 submaps, depth 7, full-submap search.  The batch keeps the cells of the
     scans that can enter the search and places a problem's nodes on one XCD (both only in
     batches); every pair must come back exactly as its single search (which re-derives the cells
     and spreads its nodes) returns it -- found flag, f32 score, pose -- and the work counted by
     the device must be the sum of the singles' lowest-resolution candidates."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    debug(**env)            # (1 = "never keep the scans' cells" / "nodes on any XCD")
     matchers, worlds = [], []
     for seed in range(64):
         cells, lim, world = synth.make_submap(300 + seed, 400, 400, 0.05, 30, 1000, 30.0, 0.01)

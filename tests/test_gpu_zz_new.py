@@ -533,24 +533,23 @@ def golden_c4():
         return json.load(f)
 
 
-def _rt3d_against_golden(synth, d, g, monkeypatch, bulk):
+def _rt3d_against_golden(synth, d, g, debug, bulk):
     from cartographer_amd import scan_matching_3d as sm3
     # group bounds checked against member bounds; staged second round: every candidate still
     # evaluated in full, every intermediate bound checked against its final sum, the drops
     # applied afterwards
-    monkeypatch.setenv("CMX_RT3D_VERIFY", "0" if bulk in ("shipped", "unstaged") else "1")
+    debug(rt3d_verify=0 if bulk in ("shipped", "unstaged") else 1)
     # "tiles": LDS-tiled bulk passes (cross-checked against the gather kernels element by
     # element); "1": gather kernels; "0": exhaustive
     # "fixed": the tiled passes as shipped (fixed-point group centres), "fixed-all": the same
     # with every group expanded so that VERIFY compares every group bound with all its members
     # "shipped": exactly what a caller gets (no verification mode: the staged second round
     # really drops candidates from its work lists); "unstaged": the same without the stages
-    monkeypatch.setenv("CMX_RT3D_BULK", "0" if bulk == "0" else "1")
-    monkeypatch.setenv("CMX_RT3D_TILES",
-                       "1" if bulk in ("tiles", "fixed", "fixed-all", "shipped", "unstaged") else "0")
-    monkeypatch.setenv("CMX_RT3D_STAGED", "0" if bulk == "unstaged" else "1")
-    monkeypatch.setenv("CMX_RT3D_CROSSCHECK", "1" if bulk == "tiles" else "0")
-    monkeypatch.setenv("CMX_RT3D_EXPAND_ALL", "1" if bulk == "fixed-all" else "0")
+    debug(rt3d_legacy=1 if bulk == "0" else 0,
+          rt3d_no_tiles=0 if bulk in ("tiles", "fixed", "fixed-all", "shipped", "unstaged") else 1,
+          rt3d_unstaged=1 if bulk == "unstaged" else 0,
+          rt3d_crosscheck=1 if bulk == "tiles" else 0,
+          rt3d_expand_all=1 if bulk == "fixed-all" else 0)
     m = sm3.RealTimeCorrelativeScanMatcher3D(d["lin"], d["ang"], d["tw"], d["rw"])
     score, pose = m.match(sm3.Rigid3d(tuple(d["init"][:3]), tuple(d["init"][3:])), d["cloud"],
                           d["res"], d["vox"])
@@ -561,7 +560,7 @@ def _rt3d_against_golden(synth, d, g, monkeypatch, bulk):
 
 
 @pytest.mark.parametrize("bulk", ["tiles", "fixed", "fixed-all", "shipped", "unstaged", "1", "0"])
-def test_rt3d_c4_shaped_equals_the_reference(synth, golden_c4, monkeypatch, bulk):
+def test_rt3d_c4_shaped_equals_the_reference(synth, golden_c4, debug, bulk):
     """C4's shape at 4096 points: L = 5 -> 6^3 = 216 groups of 2x2x2 translations per rotation
     (the flat 192-lane group mapping of rt_3d.hip spans rotations), A = 3 -> 343 rotations, a
     tilted initial orientation.  Bounds path and exhaustive path, f32 score bit-equal and pose
@@ -569,17 +568,88 @@ def test_rt3d_c4_shaped_equals_the_reference(synth, golden_c4, monkeypatch, bulk
     (tests/golden/rt3d_c4_reference.json)."""
     import workloads as w
     st = _rt3d_against_golden(synth, w.rt3d_c4_shaped(synth), golden_c4["rt3d_c4_shaped"],
-                              monkeypatch, bulk)
+                              debug, bulk)
     if bulk not in ("0", "fixed-all"):
         assert st["coarse_candidates"] < st["candidates_scored"]      # bounds did exclude
 
 
 @pytest.mark.parametrize("bulk", ["tiles", "fixed", "shipped", "unstaged", "1", "0"])
-def test_rt3d_c4_at_its_baseline_window_equals_the_reference(synth, golden_c4, monkeypatch, bulk):
+def test_rt3d_c4_at_its_baseline_window_equals_the_reference(synth, golden_c4, debug, bulk):
     """BASELINE config[3] exactly as bench.py times it (65 536 points, 150^3 grid, +-0.5 m /
     +-2 deg: 1 771 561 candidates) against the reference's own
     real_time_correlative_scan_matcher_3d.cc run over that search space (ten minutes on 8 host
     cores, tests/golden/make_rt3d_c4_golden.py): score bit-equal, pose equal, with the bounds
-    (CMX_RT3D_BULK=1, CMX_RT3D_VERIFY=1) and with every candidate scored exhaustively."""
+    (debug switch rt3d_verify) and with every candidate scored exhaustively."""
     import workloads as w
-    _rt3d_against_golden(synth, w.rt3d_c4(synth), golden_c4["rt3d_c4"], monkeypatch, bulk)
+    _rt3d_against_golden(synth, w.rt3d_c4(synth), golden_c4["rt3d_c4"], debug, bulk)
+
+
+def test_intensity_grid_on_the_device_equals_the_reference_and_feeds_the_refinement(synth, oracle):
+    """f3, intensities: cmx_grid3d_insert_with_intensities fills a resident IntensityHybridGrid
+    cell for cell like InsertIntensitiesIntoGrid (range_data_inserter_3d.cc:54-70) -- counts and
+    f32 sums bit-identical to the restatement (which tests/test_reference_ref_3d.py pins on the
+    reference's own inserter), across brick growth, returns above the threshold, a NaN, shared
+    voxels, a scan without intensities -- and cmx_ceres3d_match_grids_intensity on the two resident
+    grids returns what the voxel-list entry point returns, bit for bit."""
+    from cartographer_amd import grid_3d, scan_matching_3d as sm3
+    from test_oracle_reference_pins_3d import quat_from_angle_axis
+    rng = np.random.default_rng(11)
+    world = synth.World3D(5, (8.0, 8.0, 4.0))
+    res = 0.1
+    dev, idev = grid_3d.HybridGridOnDevice(res), grid_3d.IntensityHybridGridOnDevice(res)
+    host = synth.HybridGrid(res)
+    vox = np.zeros(0, oracle.INTENSITY_VOXEL_DTYPE)
+    assert len(idev.voxels()) == 0
+    for p in range(5):
+        pos = world.free_position(50 + p, 0.5)
+        sensor = world.scan(pos, 0.2 * p, 8, 96, seed=p).astype(np.float64)
+        c, s = math.cos(0.2 * p), math.sin(0.2 * p)
+        in_map = np.stack([pos[0] + c * sensor[:, 0] - s * sensor[:, 1],
+                           pos[1] + s * sensor[:, 0] + c * sensor[:, 1],
+                           pos[2] + sensor[:, 2]], 1).astype(np.float32)
+        if p == 1:
+            in_map[:40] = in_map[40:80] + 0.003          # several returns per voxel, in order
+        ints = rng.uniform(0.0, 60.0, len(in_map)).astype(np.float32)
+        use = None if p == 3 else ints
+        dev.insert_with_intensities(idev, pos.astype(np.float32), in_map, use, 0.7, 0.4, 2, 40.0)
+        host.insert(pos.astype(np.float32), in_map, 0.7, 0.4, 2)
+        vox = oracle.insert_intensities(res, vox, in_map, use, 40.0)
+        got = idev.voxels()
+        assert got.tobytes() == vox.tobytes(), p
+    np.testing.assert_array_equal(dev.voxels(), host.voxels())
+    assert vox["count"].max() >= 2
+    # refinement against the two resident grids = against their voxel lists
+    cloud = world.scan(pos, 0.6, 6, 64, seed=9)
+    cints = rng.uniform(0.0, 60.0, len(cloud)).astype(np.float32)
+    init_t = pos + np.array([0.03, -0.02, 0.01])
+    init = list(init_t) + quat_from_angle_axis(0.61, [0.02, -0.01, 1.0])
+    first = sm3.Rigid3d(tuple(init[:3]), tuple(init[3:]))
+    m = sm3.CeresScanMatcher3D([1.0], 5.0, 4e2, max_num_iterations=12)
+    opts = (0.5, 0.3, 45.0)
+    pose, summary = m.match_grids(init_t, first, [(cloud, dev, cints, idev, opts)])
+    listed, listed_summary = m.match(init_t, first, [(cloud, res, host.voxels(), cints, vox, opts)])
+    assert pose == listed and summary == listed_summary
+    plain, _ = m.match_grids(init_t, first, [(cloud, dev)])
+    assert plain != pose                                   # the intensity block is there
+    ref = oracle.ceres3d_match_intensity([(cloud, res, host.voxels(), cints, vox, opts)], init_t,
+                                         init, [1.0], translation_weight=5.0, rotation_weight=4e2,
+                                         max_num_iterations=12)
+    np.testing.assert_allclose(list(pose.translation) + list(pose.rotation), ref["pose"],
+                               rtol=0, atol=1e-6)
+    # a NaN intensity is not above the threshold (`>`): inserted, as in the reference
+    nan_dev, nan_idev = grid_3d.HybridGridOnDevice(res), grid_3d.IntensityHybridGridOnDevice(res)
+    ints = rng.uniform(0.0, 30.0, len(in_map)).astype(np.float32)
+    ints[5] = np.nan
+    nan_dev.insert_with_intensities(nan_idev, pos.astype(np.float32), in_map, ints, 0.7, 0.4, 2, 40.0)
+    got = nan_idev.voxels()
+    want = oracle.insert_intensities(res, np.zeros(0, oracle.INTENSITY_VOXEL_DTYPE), in_map, ints, 40.0)
+    for field in ("x", "y", "z", "count"):
+        np.testing.assert_array_equal(got[field], want[field])
+    np.testing.assert_array_equal(got["sum"], want["sum"])        # (NaN == NaN here)
+    assert np.isnan(got["sum"]).sum() == 1
+    # an intensity grid nothing was inserted into interpolates 0 everywhere
+    empty = grid_3d.IntensityHybridGridOnDevice(res)
+    a, _ = m.match_grids(init_t, first, [(cloud, dev, cints, empty, opts)])
+    b, _ = m.match(init_t, first, [(cloud, res, host.voxels(), cints,
+                                    np.zeros(0, oracle.INTENSITY_VOXEL_DTYPE), opts)])
+    assert a == b

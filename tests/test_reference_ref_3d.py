@@ -369,3 +369,32 @@ def test_random_insertions_3d_equal_the_reference(ref, oracle, synth, seed):
         host.insert(origin, pts, hit, miss, free)
         reference.insert(origin, pts, hit, miss, free)
         _same_grid(host, reference)
+
+
+# ----------------------------------------------------------------------------
+# IntensityHybridGrid: RangeDataInserter3D::Insert with intensities (f3)
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_intensity_insertion_equals_the_reference(ref, oracle, seed):
+    """InsertIntensitiesIntoGrid + IntensityHybridGrid::AddIntensity (range_data_inserter_3d.cc:
+    54-70, hybrid_grid.h:552-556) through the reference's OWN inserter and grid: the restatement
+    returns the same voxels, counts and -- bit for bit -- the same f32 sums (they depend on the
+    point order); returns above the threshold are skipped, a NaN intensity is not (`>`), a cloud
+    without intensities inserts nothing, several points of one scan share voxels."""
+    rng = np.random.default_rng(seed)
+    res = 0.1
+    hybrid, intensity = oracle.ReferenceHybridGrid(res), oracle.ReferenceIntensityHybridGrid(res)
+    vox = np.zeros(0, oracle.INTENSITY_VOXEL_DTYPE)
+    for scan in range(4):
+        n = 700
+        ret = rng.uniform(-1.5, 1.5, (n, 3)).astype(np.float32)
+        ret[:50] = ret[50:100] + rng.uniform(-0.01, 0.01, (50, 3)).astype(np.float32)   # shared voxels
+        ints = rng.uniform(0.0, 60.0, n).astype(np.float32)
+        ints[7] = np.nan
+        use = None if scan == 2 else ints
+        hybrid.insert_with_intensities(intensity, [0.1, -0.2, 0.0], ret, use,
+                                       intensity_threshold=40.0)
+        vox = oracle.insert_intensities(res, vox, ret, use, 40.0)
+    want = intensity.voxels()
+    assert len(want) > 1000 and want["count"].max() >= 2
+    assert want.tobytes() == vox.tobytes()

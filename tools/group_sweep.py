@@ -6,7 +6,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from cartographer_amd import scan_matching_3d as sm3, synth  # noqa: E402
+from cartographer_amd import _lib, scan_matching_3d as sm3, synth  # noqa: E402
 
 grid, world = synth.make_submap_3d(42, 0.1, (15.0, 15.0, 7.5), 8, 32, 512)
 vox = grid.voxels()
@@ -17,8 +17,7 @@ init = sm3.Rigid3d(tuple(pos + np.array([0.07, -0.04, 0.02])), (c, 0.0, 0.0, s))
 m = sm3.RealTimeCorrelativeScanMatcher3D(0.5, math.radians(2.0), 0.1, 0.1)
 ref = None
 for rots, tile_kb in [tuple(a.split(":")) for a in sys.argv[1:]] or (("8", "44"), ("4", "44"), ("2", "44")):
-    os.environ["CMX_RT3D_GROUP_ROTATIONS"] = rots
-    os.environ["CMX_RT3D_GROUP_TILE_KB"] = tile_kb
+    _lib.debug_set(rt3d_group_rotations=int(rots), rt3d_group_tile_kb=int(tile_kb))
     best, group = 1e9, 1e9
     for rep in range(4):
         score, est = m.match(init, cloud, 0.1, vox)

@@ -1,5 +1,5 @@
 """C4 (RT-3D): the staged second candidate round against the unstaged one -- same score and
-pose, pass timings (CMX_RT3D_REPORT) and wall time.   python tools/stage_probe.py [reps]"""
+pose, pass timings (debug switch rt3d_report) and wall time.   python tools/stage_probe.py [reps]"""
 import math
 import os
 import sys
@@ -8,7 +8,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from cartographer_amd import scan_matching_3d as sm3, synth  # noqa: E402
+from cartographer_amd import _lib, scan_matching_3d as sm3, synth  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 grid, world = synth.make_submap_3d(42, 0.1, (15.0, 15.0, 7.5), 8, 32, 512)
@@ -21,12 +21,7 @@ m = sm3.RealTimeCorrelativeScanMatcher3D(0.5, math.radians(2.0), 0.1, 0.1)
 results = {}
 for staged, verify, report in (("0", "0", "1"), ("1", "0", "1"), ("1", "1", "0"), ("0", "0", "0"),
                                ("1", "0", "0")):
-    os.environ["CMX_RT3D_STAGED"] = staged
-    os.environ["CMX_RT3D_VERIFY"] = verify
-    if report == "1":
-        os.environ["CMX_RT3D_REPORT"] = "1"
-    else:
-        os.environ.pop("CMX_RT3D_REPORT", None)
+    _lib.debug_set(rt3d_unstaged=1 - int(staged), rt3d_verify=int(verify), rt3d_report=int(report))
     best = 1e9
     for rep in range(reps):
         t0 = time.perf_counter()

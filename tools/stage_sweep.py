@@ -9,7 +9,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from cartographer_amd import scan_matching_3d as sm3, synth  # noqa: E402
+from cartographer_amd import _lib, scan_matching_3d as sm3, synth  # noqa: E402
 
 grid, world = synth.make_submap_3d(42, 0.1, (15.0, 15.0, 7.5), 8, 32, 512)
 vox = grid.voxels()
@@ -24,9 +24,8 @@ settings += [(seg, "512", "8") for seg in ("36", "37", "38", "47", "4a", "58", "
 settings += [("48", thr, rot) for thr, rot in (("256", "8"), ("1024", "8"), ("512", "4"), ("256", "4"))]
 settings += [("48", "512", "8")]
 for seg, threads, rots in settings:
-    os.environ["CMX_RT3D_SEGMENTS"] = seg
-    os.environ["CMX_RT3D_CAND_THREADS"] = threads
-    os.environ["CMX_RT3D_CAND_ROTATIONS"] = rots
+    _lib.debug_set(rt3d_segments=int(seg[0], 16) | (int(seg[1], 16) << 8),
+                   rt3d_cand_threads=int(threads), rt3d_cand_rotations=int(rots))
     best = 1e9
     for rep in range(4):
         score, est = m.match(init, cloud, 0.1, vox)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""In-kernel timelines (CMX_TIMELINE=1) + stage traces (CMX_TRACE=1) of one C2 match, one C1
+"""In-kernel timelines (debug switch timeline) + stage traces (trace) of one C2 match, one C1
 match and one C1 batch: where the time of the front-end kernels goes.  Prints to stderr.
-Usage: CMX_TIMELINE=1 CMX_TRACE=1 python tools/timeline_probe.py [c2] [c1] [c1b]"""
+Usage: python tools/timeline_probe.py [c2] [c1] [c1b]"""
 import math
 import os
 import sys
@@ -9,7 +9,9 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from cartographer_amd import grid_2d, scan_matching as sm, synth  # noqa: E402
+from cartographer_amd import _lib, grid_2d, scan_matching as sm, synth  # noqa: E402
+
+_lib.debug_set(timeline=1, trace=1)
 
 which = sys.argv[1:] or ["c2", "c1", "c1b"]
 if "c2" in which:
