@@ -86,7 +86,7 @@ def parse_args():
     ap.add_argument("--pmc-dir", default=os.path.join(ROOT, "profiles"),
                     help="directory with <tag>_pmc_{fetch,write}_size.csv of THIS command "
                          "(tools/profile_bench.sh writes them); roofline.traffic is null without")
-    ap.add_argument("--pmc-tag", default="r03")
+    ap.add_argument("--pmc-tag", default="r04")
     return ap.parse_args()
 
 

@@ -632,6 +632,7 @@ ScoreCoarsePlanesDwordKernel(const Fast2DProblem* __restrict__ problems, int n,
 // Dynamic LDS: pts[n_pad] u32 | misc[32] | cand_acc[acc_cap].
 constexpr int kFusedMaxPoints = 4096;    // = kPointCache of the tree search
 
+template <bool kTimeline>    // (true: the debug switch `timeline`; the shipped instantiation has no stamps)
 __global__ void __launch_bounds__(256)
 PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __restrict__ xyz,
                      int n, ProblemState* __restrict__ states, int acc_cap,
@@ -657,9 +658,10 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
   const int waves = T >> 6;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  unsigned long long* const tl = P.timeline;
-  const int tl_block = blockIdx.y * gridDim.x + blockIdx.x;
-  Stamp(tl, tl_block, 0);
+  const auto stamp = [&](int k) {
+    if constexpr (kTimeline) Stamp(P.timeline, blockIdx.y * gridDim.x + blockIdx.x, k);
+  };
+  stamp(0);
 
   // ---- rotate, translate, discretise (PrepScansKernel's arithmetic) ----------
   const float2 r = P.scan_rot[s];
@@ -699,7 +701,7 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
     }
   }
   for (int i = threadIdx.x; i < acc_cap; i += T) cand_acc[i] = 0;
-  Stamp(tl, tl_block, 1);      // points discretised
+  stamp(1);      // points discretised
   lo_x = WaveMinDpp(lo_x); lo_y = WaveMinDpp(lo_y);
   hi_x = WaveMaxDpp(hi_x); hi_y = WaveMaxDpp(hi_y);
   bad = WaveMaxDpp(bad);
@@ -740,7 +742,7 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
   }
   __syncthreads();
   if (!misc[6]) return;
-  Stamp(tl, tl_block, 2);      // bounds known
+  stamp(2);      // bounds known
   const int4 bd = make_int4(misc[0], misc[1], misc[2], misc[3]);
   const int2 dims = make_int2(misc[4], misc[5]);
   const int count = dims.x * dims.y;
@@ -810,9 +812,9 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
     }
   }
   if (cur >= 0) flush();
-  Stamp(tl, tl_block, 4);      // wave 0 done gathering
+  stamp(4);      // wave 0 done gathering
   __syncthreads();
-  Stamp(tl, tl_block, 5);      // all waves done
+  stamp(5);      // all waves done
 
   const int base = s * P.coarse_stride;
   auto* coarse_sum = AsGlobal(P.coarse_sum) + base;
@@ -828,7 +830,7 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
   int2* scratch = reinterpret_cast<int2*>(misc + 8);      // [4] (the bounds partials are dead)
   const int2 best = BlockBest(best_sum, best_index, scratch);
   if (threadIdx.x == 0) P.scan_best[s] = best;
-  Stamp(tl, tl_block, 6);      // scores written
+  stamp(6);      // scores written
   // The discretised scan stays on chip: the tree search re-derives the cells of the few scans
   // it descends into (ScanCell).  Only the introspection entry point asks for the array.
   // Batches (store_scans): a scan whose best candidate reaches the initial bound may enter the
@@ -845,7 +847,7 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
     auto* out = AsGlobal(P.discrete) + static_cast<size_t>(s) * n;
     for (int i = threadIdx.x; i < n; i += T) out[i] = pts[i];
   }
-  Stamp(tl, tl_block, 7);
+  stamp(7);
 }
 
 // ---------------------------------------------------------------------------
@@ -2101,7 +2103,7 @@ long long FusedResidentBlocks(int device, int threads, size_t lds_bytes) {
       if (k.device == device && k.threads == threads && k.lds == lds) return k.blocks;
   }
   int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, PrepScoreFusedKernel, threads, lds) !=
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, PrepScoreFusedKernel<false>, threads, lds) !=
           hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) {
     (void)hipGetLastError();
@@ -2323,9 +2325,10 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
               threads, lds);
     // (grid.x rounded up to a multiple of 256 for the rotation -> block map of the kernel)
     const dim3 fused_grid((out->max_scans + 255) / 256 * 256, num);
-    PrepScoreFusedKernel<<<fused_grid, threads, lds, ws.stream>>>(
-        out->d_problems, d_xyz, n, out->d_states, static_cast<int>(fused_acc), clear_words,
-        clear_count);
+    (out->d_timeline ? PrepScoreFusedKernel<true> : PrepScoreFusedKernel<false>)
+        <<<fused_grid, threads, lds, ws.stream>>>(out->d_problems, d_xyz, n, out->d_states,
+                                                  static_cast<int>(fused_acc), clear_words,
+                                                  clear_count);
     clear_words = nullptr;
     mark("fused");
   }

@@ -1541,11 +1541,8 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
     trace.Report();
     lap("device");
     if (!strict) {
-      for (int stage = 0; stage < st.expansion_launches; ++stage)
-        for (int sub = 0; sub < kSubLists3; ++sub)
-          st.expansion_nodes += std::min(h_counters->frontier[stage][sub * kCountStride3],
-                                         kFrontierCapacity / kSubLists3);
-      // upper bound: nodes found below the bound when they are taken off the list are skipped
+      // (the nodes the expansion kernel took off its lists and found at or above the bound)
+      for (int k = 0; k < 16; ++k) st.expansion_nodes += static_cast<int64_t>(h_counters->expanded[k]);
       st.expansion_lookups = st.expansion_nodes * (static_cast<int64_t>(n + 63) / 64 * 64);
     }
     if (!h_counters->overflow || num > 1) break;

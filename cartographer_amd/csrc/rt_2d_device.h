@@ -67,6 +67,20 @@ __device__ __forceinline__ void Rt2DCellOf(const Rt2DFrame& F, float qsw, float 
   *iy = min(max(cy, -(F.nl + 1)), F.ny + F.nl);
 }
 
+// The same from a point already rotated by the initial yaw (RotateZ(F.q0w, F.q0z, px, py): the
+// intermediate of Rt2DCellOf, so the cell is the same bit for bit).
+__device__ __forceinline__ void Rt2DCellOfPrerotated(const Rt2DFrame& F, float qsw, float qsz,
+                                                     float ax, float ay, int* ix, int* iy) {
+  float bx, by;
+  RotateZ(qsw, qsz, ax, ay, &bx, &by);
+  const float x = bx + F.tx;
+  const float y = by + F.ty;
+  const int cx = CellIndexFast(F.max_y, y, F.res, F.inv_res);
+  const int cy = CellIndexFast(F.max_x, x, F.res, F.inv_res);
+  *ix = min(max(cx, -(F.nl + 1)), F.nx + F.nl);
+  *iy = min(max(cy, -(F.nl + 1)), F.ny + F.nl);
+}
+
 // Inclusive prefix sum across the 64 lanes (DPP ladder of WaveSum without the broadcast).
 __device__ __forceinline__ int WaveInclusiveScan(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1

@@ -49,6 +49,8 @@ namespace {
 constexpr int kTileMaxThreads = 1024;        // a tile workgroup: 1024 threads alone on a CU (one tile
                                             // per match), or 512 with two per CU (several tiles)
 constexpr int kFinishThreads = 512;
+constexpr int kFusedIdleWaves = 1;           // (wavefront 0 lays out the lists and builds the tasks instead)
+constexpr int kFusedMaxPoints = 2048;        // (clouds beyond: the prep kernel, more rotations per workgroup)
 constexpr int kMaxTiles = 16;               // tiles of a match's bounding box (x 4 phases = 64 keys)
 constexpr int kStage1Cap = 1024;            // candidates the exact integer pass takes per match
 constexpr unsigned kFlat = 0xffffffffu;     // misc[1]: more candidates than the lists hold
@@ -94,6 +96,8 @@ struct Rt2DTileParams {
   int list_lds;              // u16 entries of the LDS list buffer
   int task_cap;
   int flush_atomic;          // more than one tile: sums meet by atomics (qsum zeroed by the prep)
+  int fused;                 // one tile per match: the tile kernel discretises its rotations itself
+                             // (no prep kernel, no lists in HBM, work items listed by the host)
   int* qsum;                 // [num_scans][side^2]
   unsigned* misc;            // [0] prep workgroups done (the last one plans), [1] finalist count, then pairs
   unsigned* overflow;        // finalist pairs beyond kFinalistHead
@@ -101,6 +105,13 @@ struct Rt2DTileParams {
   unsigned long long* timeline;   // debug switch `timeline`: 16 stamps per tile / finish workgroup, else null
   int timeline_finish_base;       // first slot of the finish kernel's workgroups
 };
+
+// A barrier for data that travels through LDS only.  __syncthreads() carries a workgroup-scope
+// fence, i.e. s_waitcnt vmcnt(0): with an LDS-DMA copy in flight it would wait for the copy
+// (cdna_hip_programming.md, "glds in flight across the barrier").
+__device__ __forceinline__ void LdsBarrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // A match's parameters into LDS, a dword per thread (callers: barrier before the first use).
 __device__ __forceinline__ void CopyParams(Rt2DTileParams* dst, const Rt2DTileParams* src, int tid) {
@@ -274,238 +285,9 @@ Rt2DTilePrepKernel(const Rt2DTileParams* __restrict__ params, int* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// grid (persistent: one workgroup of 1024 threads per CU when every match is ONE tile, else two of
-// 512), work items = (match, tile, rotation
-// group g, groups G of the tile) from the prep kernel's planner, pulled through a counter.
-// Dynamic LDS:
-//   image[tile_image_bytes] | acc[rw][side^2] | hdrs[rw][4] | slot[rw + 1] | tasks[task_cap][4] |
-//   ctl[16] | list[list_lds] u16
-// ---------------------------------------------------------------------------------------------
-// (Sixteen wavefronts per CU either way.  Two workgroups of sixteen, registers capped at 64 --
-// the compiler takes 80 for two rows per lane -- ran the same batch 1.4x SLOWER, stragglers of
-// 54 us among items of 14: profiles/r04_c1_two_workgroups_per_cu.txt.  The other half of the
-// CU's wavefront slots is what lets the prep and finish kernels of the other parts of a batch
-// run beside this one.)
-template <int RPL, int kRowStride, bool kTimeline>
-__global__ void __launch_bounds__(kTileMaxThreads)
-Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict__ work,
-               const int* __restrict__ work_count, int* __restrict__ next_item) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
-  __shared__ int4 fetched;                   // the next work item (x < 0: none)
-  __shared__ Rt2DTileParams P;               // the current item's match (one round of loads)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int num_threads = blockDim.x, num_waves = num_threads >> 6;
-  const int num_items = *work_count;
-  if (tid == 0) {
-    const int v = atomicAdd(next_item, 1);
-    fetched = v < num_items ? work[v] : make_int4(-1, 0, 0, 0);
-  }
-  int item_index = 0;
-  for (;; ++item_index) {
-  __syncthreads();                           // the previous item's LDS is done with; `fetched` is set
-  const int4 item = fetched;
-  if (item.x < 0) break;
-  __syncthreads();                           // (everyone has read `fetched` before it is overwritten)
-  // the NEXT item: its ticket is drawn now and arrives under this item's image copy; the item
-  // itself is read behind the copy's wait and stored at the end
-  int ticket = 0;
-  int4 next = make_int4(-1, 0, 0, 0);
-  if (tid == 0) ticket = atomicAdd(next_item, 1);
-  CopyParams(&P, params + item.x, tid);
-  __syncthreads();
-  const int tile = item.y, g = item.z, G = item.w;
-  const int side = 2 * P.nl + 1, cands = side * side;
-  const int B = P.B, H = P.H, lp = P.lp;
-  const int rw = (P.num_scans - g + G - 1) / G;          // rotations g, g + G, ... of this item
-  // (in-kernel timeline of the profiling tools: compiled in only for the instrumented
-  // instantiation the debug switch `timeline` selects; slots = workgroup x its first items)
-  const auto stamp = [&](int k) {
-    if constexpr (kTimeline) {
-      if (item_index < 4) Stamp(P.timeline, blockIdx.x * 4 + item_index, k);
-    }
-  };
-  stamp(0);
-  const int nkeys = P.ntx * P.nty * 4;
-  int* acc = reinterpret_cast<int*>(tile_smem + P.tile_image_bytes);
-  int* hdrs = acc + ((P.rw * cands + 3) & ~3);           // [rw][4] start | count << 16 of this tile
-  int* slot = hdrs + P.rw * 4;                           // [rw + 1] cumulative list lengths
-  int* tasks = slot + ((P.rw + 1 + 3) & ~3);             // [task_cap][4]
-  int* ctl = tasks + P.task_cap * 4;                     // [0] tasks, [1] next task, [2] round end
-  uint16_t* list = reinterpret_cast<uint16_t*>(ctl + 16);
-
-  // ---- the tile's image: th_img rows of the quantised grid image + rpl * H rows of zeros,
-  // LDS-DMA with one row piece (16 bytes) per lane.  The first piece of the grid image is halo
-  // (zeros): the source of the null rows and of every piece outside the image -----------------
-  {
-    const int tY = tile / P.ntx, tX = tile - tY * P.ntx;
-    const int gx0 = P.box_x0 + tX * P.T, gy0 = P.box_y0 + tY * P.T;
-    const int ppr = lp >> 4;
-    const int pieces_img = P.th_img * ppr;
-    const auto* src = (const __attribute__((address_space(1))) unsigned char*)P.qimage;
-    auto* dst = (__attribute__((address_space(3))) unsigned char*)tile_smem;
-    const int kib = P.tile_image_bytes >> 10;
-    const int gw = P.gpitch >> 1;                         // cells per image row
-    for (int k = wave; k < kib; k += num_waves) {
-      const int p = (k << 6) + lane;
-      const int row = p / ppr, c = p - row * ppr;
-      const int X0 = gx0 + (c << 3), Y = gy0 + row;
-      // (pieces right of / below the image are outside the grid: zeros, like the corner)
-      const bool zero = p >= pieces_img || X0 >= gw || Y >= P.grows;
-      const size_t at = zero ? 0 : static_cast<size_t>(Y) * P.gpitch + static_cast<size_t>(X0) * 2;
-      __builtin_amdgcn_global_load_lds(src + at, dst + (k << 10), 16, 0, 0);
-    }
-  }
-  stamp(1);                                              // image DMA issued
-  for (int i = tid; i < rw * cands; i += num_threads) acc[i] = 0;
-  if (tid < rw * 4) {
-    const int rr = tid >> 2, ph = tid & 3;
-    hdrs[tid] = static_cast<int>(P.hdr[static_cast<size_t>(g + rr * G) * nkeys + tile * 4 + ph]);
-  }
-  __syncthreads();
-  if (wave == 0) {                     // cumulative (padded) list lengths of this tile's rotations
-    const int rr = lane;
-    int len = 0;
-    if (rr < rw) {
-#pragma unroll
-      for (int ph = 0; ph < 4; ++ph) len += ((hdrs[rr * 4 + ph] >> 16) + 15) & ~15;
-    }
-    const int incl = WaveInclusiveScan(len);
-    if (rr < rw) slot[rr + 1] = incl;
-    if (lane == 0) slot[0] = 0;
-  }
-  const int lds_image = static_cast<int>(reinterpret_cast<uintptr_t>(
-      (const __attribute__((address_space(3))) unsigned char*)tile_smem));
-  // Lane geometry inside a half-wavefront.
-  const int li = lane & 31;
-  const int row = li / B, blk = li - row * B;
-  const bool lane_used = row < H;
-  // (lanes beyond H * B read the image's first rows like everyone else and drop the result)
-  const int lane_off = lds_image + (lane_used ? row * lp + blk * 8 : 0);
-  const int row_stride = H * lp;
-  __syncthreads();
-  stamp(2);                                              // headers, list lengths
-
-  // ---- rounds: as many rotations as the LDS list buffer holds ------------------------------
-  for (int rr0 = 0; rr0 < rw;) {
-    const int base = slot[rr0];
-    int rr1 = rr0 + 1;                                 // (one rotation always fits: host)
-    while (rr1 < rw && slot[rr1 + 1] - base <= P.list_lds) ++rr1;
-    __syncthreads();                                   // the previous round's lists are done with
-    if (tid < 2) ctl[tid] = 0;
-    // lists: rotation rr's entries of this tile are contiguous in HBM (keys in order)
-    // (wavefront 0 builds the round's tasks below while the others copy its lists)
-    for (int rr = rr0 + wave - 1; wave >= 1 && rr < rr1; rr += num_waves - 1) {
-      const int first = hdrs[rr * 4] & 0xffff;
-      const int len = slot[rr + 1] - slot[rr];
-      typedef unsigned U4 __attribute__((ext_vector_type(4)));
-      const auto* src = AsGlobal(reinterpret_cast<const U4*>(
-          P.lists + static_cast<size_t>(g + rr * G) * P.cap_s + first));
-      U4* dst = reinterpret_cast<U4*>(list + (slot[rr] - base));
-      for (int q = lane; q < (len >> 3); q += 64) dst[q] = src[q];
-    }
-    // ---- per rotation: phases paired by size, tasks of at most kPairTaskIters iterations ---
-    if (wave == 0) {
-      const int rr = rr0 + lane;
-      const bool live = rr < rr1;
-      int key[4], first_slot[4];                 // count << 2 | phase
-      const int g_first = live ? hdrs[rr * 4] & 0xffff : 0;
-#pragma unroll
-      for (int ph = 0; ph < 4; ++ph) {
-        const int h = live ? hdrs[rr * 4 + ph] : 0;
-        key[ph] = ((h >> 16) << 2) | ph;
-        first_slot[ph] = (h & 0xffff) - g_first + (live ? slot[rr] - base : 0);
-      }
-      // the four phases by count, descending (sorting network of five exchanges)
-#define CMX_CSWAP(I, J) { const int hi_k = max(key[I], key[J]), lo_k = min(key[I], key[J]); key[I] = hi_k; key[J] = lo_k; }
-      CMX_CSWAP(0, 1) CMX_CSWAP(2, 3) CMX_CSWAP(0, 2) CMX_CSWAP(1, 3) CMX_CSWAP(1, 2)
-#undef CMX_CSWAP
-      const int la0 = key[0] >> 2, la1 = key[2] >> 2;
-      const int mine = (la0 + kPairTaskIters - 1) / kPairTaskIters +
-                       (la1 + kPairTaskIters - 1) / kPairTaskIters;
-      const int incl = WaveInclusiveScan(mine);
-      int t = incl - mine;
-      if (lane == 63) ctl[0] = incl;
-#pragma unroll
-      for (int pair = 0; pair < 2; ++pair) {
-        const int pa = key[2 * pair] & 3, pb = key[2 * pair + 1] & 3;
-        const int la = key[2 * pair] >> 2, lb = key[2 * pair + 1] >> 2;
-        // (static selects instead of first_slot[pa]: no dynamically indexed private array)
-        const int sa = pa == 0 ? first_slot[0] : pa == 1 ? first_slot[1] : pa == 2 ? first_slot[2] : first_slot[3];
-        const int sb = pb == 0 ? first_slot[0] : pb == 1 ? first_slot[1] : pb == 2 ? first_slot[2] : first_slot[3];
-        for (int off = 0; off < la; off += kPairTaskIters, ++t) {
-          tasks[4 * t] = rr | (pa << 8) | (pb << 16);
-          tasks[4 * t + 1] = sa + off;
-          tasks[4 * t + 2] = sb + off;
-          tasks[4 * t + 3] = min(kPairTaskIters, la - off) | (max(0, min(kPairTaskIters, lb - off)) << 16);
-        }
-      }
-    }
-    if (rr0 == 0) stamp(4);                              // tasks built / this wave's lists copied
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the image has landed
-    __syncthreads();
-    if (rr0 == 0) stamp(5);                              // image landed
-    if (rr0 == 0 && tid == 0)                            // (the ticket arrived with that wait)
-      next = ticket < num_items ? work[ticket] : make_int4(-1, 0, 0, 0);
-    // ---- tasks, dealt dynamically: the halves of a wavefront run two phases ----------------
-    const int num_tasks = ctl[0];          // <= task_cap by construction (host)
-    for (;;) {
-      int t = 0;
-      if (lane == 0) t = atomicAdd(&ctl[1], 1);
-      t = __builtin_amdgcn_readfirstlane(t);
-      if (t >= num_tasks) break;
-      const int d0 = tasks[4 * t], d3 = tasks[4 * t + 3];
-      const int rr = d0 & 255;
-      const bool second = lane >= 32;
-      const int phase = second ? (d0 >> 16) & 255 : (d0 >> 8) & 255;
-      const int start = second ? tasks[4 * t + 2] : tasks[4 * t + 1];
-      const int my_len = second ? d3 >> 16 : d3 & 0xffff;
-      const int iters = ((d3 & 0xffff) + 15) & ~15;          // the first stream is the longer
-      uint32_t acc32[RPL][4];
-#pragma unroll
-      for (int j = 0; j < RPL; ++j)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc32[j][c] = 0;
-      RowPairAccumulate<RPL, kRowStride>(list + start, my_len, iters, lane, lane_off, row_stride,
-                                         P.null_addr, acc32);
-      if (lane_used) {
-        int* out = acc + rr * cands;
-        const int d0x = blk * 4 - phase;           // candidate x index of the block's first cell
-#pragma unroll
-        for (int j = 0; j < RPL; ++j) {
-          const int wrow = row + j * H;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int dxi = d0x + c;
-            if (wrow < side && dxi >= 0 && dxi < side && acc32[j][c])
-              atomicAdd(&out[dxi * side + wrow], static_cast<int>(acc32[j][c]));
-          }
-        }
-      }
-    }
-    if (rr0 == 0) stamp(6);                              // wave 0 out of tasks (first round)
-    rr0 = rr1;
-  }
-  __syncthreads();
-  stamp(7);                                              // all rounds done
-  // ---- this tile's share of the candidates' integer sums --------------------------------------
-  for (int e = tid; e < rw * cands; e += num_threads) {
-    const int rr = e / cands, c = e - rr * cands;
-    auto* out = AsGlobal(P.qsum) + static_cast<size_t>(g + rr * G) * cands + c;
-    const int v = acc[e];
-    if (P.flush_atomic) {
-      if (v) __hip_atomic_fetch_add(out, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      *out = v;
-    }
-  }
-  stamp(8);
-  if (tid == 0) fetched = next;
-  }   // work items
-}
-
-// ---------------------------------------------------------------------------------------------
-// grid (matches), 512 threads.  Three stages, each narrower and more exact than the one before:
+// One match's candidates from their integer sums to the finalists' f32 scores, by a whole
+// workgroup (kThreads threads): the finish kernel -- grid (matches), 512 threads -- or the tile
+// kernel's last workgroup of a match (fused path, 1024 threads).  Three stages, each narrower and more exact than the one before:
 //   1. bounds from the quantised sums: every candidate whose weighted upper bound reaches the
 //      best weighted lower bound (a few dozen);
 //   2. those candidates with the EXACT integers, one wavefront per candidate (order-free sums:
@@ -517,16 +299,12 @@ Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict
 // Dynamic LDS: cells[n_pad] u32 | prob[group][n_pad + 4] f32 | rot_flag[num_scans] |
 //   fin[kStage1Cap] | exact[kStage1Cap] | fin2[kStage1Cap]
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kFinishThreads)
-Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group,
-                 unsigned* __restrict__ host_out) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char fin_smem[];
-  __shared__ Rt2DTileParams P;
+template <int kThreads, bool kCoherent, bool kTimeline>
+__device__ __forceinline__ void Rt2DFinishMatch(Rt2DTileParams& P, unsigned char* fin_smem, int group,
+                                                unsigned* __restrict__ host_out, int match) {
   const int tid = threadIdx.x, lane = tid & 63;
-  CopyParams(&P, params + blockIdx.x, tid);
-  __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int kWaves = kFinishThreads / 64;
+  constexpr int kWaves = kThreads / 64;
   const int side = 2 * P.nl + 1, cands = side * side, n = P.n, n_pad = P.n_pad;
   uint32_t* cellbuf = reinterpret_cast<uint32_t*>(fin_smem);
   float* prob = reinterpret_cast<float*>(cellbuf + n_pad);
@@ -542,22 +320,27 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group,
   const auto publish = [&]() {
     __syncthreads();
     if (tid < 128)
-      host_out[static_cast<size_t>(blockIdx.x) * 128 + tid] =
+      host_out[static_cast<size_t>(match) * 128 + tid] =
           __hip_atomic_load(&P.misc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   // (a match whose prep flagged a point outside the box is finished like any other -- one more
   // round trip at the head of this latency-bound kernel would cost every match 1.5 us -- and the
   // flag rides in misc[0] to the host)
-  unsigned long long* const tl = P.timeline;
-  const int tl_block = P.timeline_finish_base + blockIdx.x;
+  unsigned long long* const tl = kTimeline ? P.timeline : nullptr;
+  const int tl_block = P.timeline_finish_base + match;
   Stamp(tl, tl_block, 0);
   if (tid == 0) { nfin = 0; nfin2 = 0; }
-  for (int s = tid; s < P.num_scans; s += kFinishThreads) rot_flag[s] = 0;
+  for (int s = tid; s < P.num_scans; s += kThreads) rot_flag[s] = 0;
   const float kScale = ((1.f - 0.1f) - (1.f - (1.f - 0.1f))) / 32766.f;   // (kMaxCC - kMinCC) / 32766
   const float slack = Rt2DBoundSlack(n);
   const float per_q = kScale * static_cast<float>(1 << kQShift) / static_cast<float>(n);
   const float width = kScale * static_cast<float>((1 << kQShift) - 1);
   const int* __restrict__ qsum = P.qsum;
+  // (kCoherent: the sums were written by other workgroups of the SAME launch, through to memory)
+  const auto load_sum = [&](int at) {
+    if constexpr (kCoherent) return __hip_atomic_load(&qsum[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return qsum[at];
+  };
   // ---- stage 1: the best weighted lower bound, then everyone whose upper bound reaches it.
   // Bounds only SELECT candidates (scores are recomputed exactly), so f32 with slack is enough.
   // A thread owns translations c = tid, tid + 512, ... and walks the rotations: the translation
@@ -570,19 +353,19 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group,
     return __expf(-(t * t));
   };
   float lb_max = 0.f;
-  constexpr int kOwn = 16;                 // candidates a thread keeps in registers
+  constexpr int kOwn = kThreads > 512 ? 8 : 16;   // candidates a thread keeps in registers (8192 in all)
   const int total = P.num_scans * cands;
-  const bool in_registers = total <= kOwn * kFinishThreads;
+  const bool in_registers = total <= kOwn * kThreads;
   float ub_own[kOwn];
-  const int owned = (total + kFinishThreads - 1) / kFinishThreads;      // (uniform)
+  const int owned = (total + kThreads - 1) / kThreads;      // (uniform)
   if (in_registers) {
     // The usual case (C1: 4563 candidates, 9 per thread): ONE round of loads, every upper bound
     // stays in a register until the best lower bound is known.
     int q_own[kOwn];
 #pragma unroll
     for (int k = 0; k < kOwn; ++k) {
-      const int e = tid + k * kFinishThreads;
-      q_own[k] = k < owned && e < total ? qsum[e] : 0;
+      const int e = tid + k * kThreads;
+      q_own[k] = k < owned && e < total ? load_sum(e) : 0;
     }
     // s = e / cands from an f32 estimate: exact for e < 2^21 (the estimate is off by less than
     // 2^-22 e / cands < 1 / (2 cands), and (e + 0.5) / cands is 1 / (2 cands) away from integers)
@@ -591,7 +374,7 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group,
     for (int k = 0; k < kOwn; ++k) {
       ub_own[k] = -1.f;
       if (k >= owned) continue;                                          // (uniform)
-      const int e = tid + k * kFinishThreads;
+      const int e = tid + k * kThreads;
       const int s = static_cast<int>((static_cast<float>(e) + 0.5f) * inv_cands);
       const int c = e - s * cands;
       const int dxi = static_cast<int>((static_cast<float>(c) + 0.5f) * inv_side), dyi = c - dxi * side;
@@ -604,13 +387,13 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group,
       }
     }
   } else {
-    for (int c = tid; c < cands; c += kFinishThreads) {
+    for (int c = tid; c < cands; c += kThreads) {
       const int dxi = c / side, dyi = c - dxi * side;
       const float cx = -(dyi - P.nl) * res_f, cy = -(dxi - P.nl) * res_f;
       const float tt = sqrtf(cx * cx + cy * cy) * wt_f;
 #pragma unroll 4
       for (int s = 0; s < P.num_scans; ++s) {
-        const float base = 0.1f + per_q * static_cast<float>(qsum[s * cands + c]);
+        const float base = 0.1f + per_q * static_cast<float>(load_sum(s * cands + c));
         lb_max = fmaxf(lb_max, (base - slack) * weight(tt, s) * (1.f - 1e-5f));
       }
     }
@@ -631,20 +414,20 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group,
 #pragma unroll
     for (int k = 0; k < kOwn; ++k) {
       if (ub_own[k] >= best_lb) {
-        const int e = tid + k * kFinishThreads;
+        const int e = tid + k * kThreads;
         const int at = atomicAdd(&nfin, 1);
         if (at < kStage1Cap) fin[at] = e;
         rot_flag[static_cast<int>((static_cast<float>(e) + 0.5f) * inv_cands)] = 1;
       }
     }
   } else {
-    for (int c = tid; c < cands; c += kFinishThreads) {
+    for (int c = tid; c < cands; c += kThreads) {
       const int dxi = c / side, dyi = c - dxi * side;
       const float cx = -(dyi - P.nl) * res_f, cy = -(dxi - P.nl) * res_f;
       const float tt = sqrtf(cx * cx + cy * cy) * wt_f;
 #pragma unroll 4
       for (int s = 0; s < P.num_scans; ++s) {
-        const float base = 0.1f + per_q * static_cast<float>(qsum[s * cands + c]);
+        const float base = 0.1f + per_q * static_cast<float>(load_sum(s * cands + c));
         if ((base + width + slack) * weight(tt, s) * (1.f + 1e-5f) >= best_lb) {
           const int at = atomicAdd(&nfin, 1);
           if (at < kStage1Cap) fin[at] = s * cands + c;
@@ -668,7 +451,7 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group,
   const Rt2DFrame F = FrameOf(P);
   const auto discretise = [&](int s) {
     const float2 r = P.scan_rot[s];
-    for (int i = tid; i < n; i += kFinishThreads) {
+    for (int i = tid; i < n; i += kThreads) {
       int ix, iy;
       Rt2DCellOf(F, r.x, r.y, xyz[3 * i], xyz[3 * i + 1], &ix, &iy);
       cellbuf[i] = (static_cast<uint32_t>(ix) & 0xffffu) | (static_cast<uint32_t>(iy) << 16);
@@ -727,7 +510,7 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group,
     // ---- bounds from the exact sums: what is left is the rounding of the f32 chain --------------
     const float per_u = kScale / static_cast<float>(n);
     lb_max = 0.f;
-    for (int j = tid; j < count; j += kFinishThreads) {
+    for (int j = tid; j < count; j += kThreads) {
       const int e = fin[j];
       const int s = e / cands, c = e - s * cands;
       const float base = 0.1f + per_u * static_cast<float>(exact[j]);
@@ -741,13 +524,13 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group,
       __syncthreads();                      // (red[] of stage 1 has been read by everyone)
       if (lane == 0) red[wave] = bits;
     }
-    for (int s = tid; s < P.num_scans; s += kFinishThreads) rot_flag[s] = 0;
+    for (int s = tid; s < P.num_scans; s += kThreads) rot_flag[s] = 0;
     __syncthreads();
     best_bits = 0;
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) best_bits = max(best_bits, red[w]);
     const float best_lb2 = __uint_as_float(best_bits);
-    for (int j = tid; j < count; j += kFinishThreads) {
+    for (int j = tid; j < count; j += kThreads) {
       const int e = fin[j];
       const int s = e / cands, c = e - s * cands;
       const float base = 0.1f + per_u * static_cast<float>(exact[j]);
@@ -794,12 +577,12 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group,
       for (int f = 0; f < gcount; ++f) {                  // all threads: one round of gathers
         const int c = sel[f];
         const int dx = c / side - P.nl, dy = c % side - P.nl;
-        for (int i0 = 0; i0 < n; i0 += 4 * kFinishThreads) {
+        for (int i0 = 0; i0 < n; i0 += 4 * kThreads) {
           unsigned raw[4];
           bool inside[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const int i = i0 + k * kFinishThreads + tid;
+            const int i = i0 + k * kThreads + tid;
             const uint32_t pc = cellbuf[min(i, n - 1)];
             const int x = static_cast<short>(pc & 0xffffu) + dx;
             const int y = static_cast<short>(pc >> 16) + dy;
@@ -809,11 +592,11 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group,
           }
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const int i = i0 + k * kFinishThreads + tid;
+            const int i = i0 + k * kThreads + tid;
             if (i < n) prob[f * row + i] = inside[k] ? CellProbability(raw[k]) : 0.1f;   // kMinProbability
           }
         }
-        for (int i = n + tid; i < n_pad; i += kFinishThreads) prob[f * row + i] = 0.f;
+        for (int i = n + tid; i < n_pad; i += kThreads) prob[f * row + i] = 0.f;
       }
       __syncthreads();
       Stamp(tl, tl_block, 4);              // probabilities of a group of finalists in LDS
@@ -824,20 +607,22 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group,
         typedef float F4 __attribute__((ext_vector_type(4)));
         const F4* vals = reinterpret_cast<const F4*>(prob + tid * row);
         float sum = 0.f;
-        F4 a[8], b[8];
+        // (the tile kernel's workgroups of 1024 threads have 128 registers a thread: half the batch)
+        constexpr int kB = kThreads > 512 ? 4 : 8;
+        F4 a[kB], b[kB];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) a[k] = vals[k];
-        for (int i = 0; i < n_pad; i += 64) {            // n_pad is a multiple of 64
+        for (int k = 0; k < kB; ++k) a[k] = vals[k];
+        for (int i = 0; i < n_pad; i += 8 * kB) {        // n_pad is a multiple of 64
 #pragma unroll
-          for (int k = 0; k < 8; ++k) b[k] = vals[(i >> 2) + 8 + k];
+          for (int k = 0; k < kB; ++k) b[k] = vals[(i >> 2) + kB + k];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) { sum += a[k].x; sum += a[k].y; sum += a[k].z; sum += a[k].w; }
-          // (the last batch reads 32 floats past the row: inside the next row or the lists behind
+          for (int k = 0; k < kB; ++k) { sum += a[k].x; sum += a[k].y; sum += a[k].z; sum += a[k].w; }
+          // (the last batch reads 4 kB floats past the row: inside the next row or the lists behind
           // the probabilities, never added)
 #pragma unroll
-          for (int k = 0; k < 8; ++k) a[k] = vals[(i >> 2) + 16 + k];
+          for (int k = 0; k < kB; ++k) a[k] = vals[(i >> 2) + 2 * kB + k];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) { sum += b[k].x; sum += b[k].y; sum += b[k].z; sum += b[k].w; }
+          for (int k = 0; k < kB; ++k) { sum += b[k].x; sum += b[k].y; sum += b[k].z; sum += b[k].w; }
         }
         const float score = sum / static_cast<float>(n);
         const int c = sel[tid];
@@ -859,6 +644,400 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group,
   }
   Stamp(tl, tl_block, 6);
   publish();
+}
+
+// ---------------------------------------------------------------------------------------------
+// grid (persistent: one workgroup of 1024 threads per CU when every match is ONE tile, else two of
+// 512), work items = (match, tile, rotation
+// group g, groups G of the tile) from the prep kernel's planner, pulled through a counter.
+// Dynamic LDS:
+//   image[tile_image_bytes] | acc[rw][side^2] | hdrs[rw][4] | slot[rw + 1] | tasks[task_cap][4] |
+//   ctl[16] | list[list_lds] u16
+// ---------------------------------------------------------------------------------------------
+// (Sixteen wavefronts per CU either way.  Two workgroups of sixteen, registers capped at 64 --
+// the compiler takes 80 for two rows per lane -- ran the same batch 1.4x SLOWER, stragglers of
+// 54 us among items of 14: profiles/r04_c1_two_workgroups_per_cu.txt.  The other half of the
+// CU's wavefront slots is what lets the prep and finish kernels of the other parts of a batch
+// run beside this one.)
+template <int RPL, int kRowStride, bool kTimeline>
+__global__ void __launch_bounds__(kTileMaxThreads)
+Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict__ work,
+               const int* __restrict__ work_count, int* __restrict__ next_item, int work_stride) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
+  // the next work item (x < 0: none).  Planned on the device: (match, tile, g, G).  Fused (listed by
+  // the host, work_stride 3): + (cloud address, rotation table address) + (points, rotations) --
+  // the loads of the cloud and of the rotations then leave together with those of the parameters
+  __shared__ int4 fetched[3];
+  __shared__ Rt2DTileParams P;               // the current item's match (one round of loads)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int num_threads = blockDim.x, num_waves = num_threads >> 6;
+  const int num_items = *work_count;
+  if (tid == 0) {
+    const int v = atomicAdd(next_item, 1);
+    if (v < num_items) {
+      for (int q = 0; q < work_stride; ++q) fetched[q] = work[v * work_stride + q];
+    } else {
+      fetched[0] = make_int4(-1, 0, 0, 0);
+    }
+  }
+  int item_index = 0;
+  for (;; ++item_index) {
+  __syncthreads();                           // the previous item's LDS is done with; `fetched` is set
+  const int4 item = fetched[0];
+  if (item.x < 0) break;
+  const int4 aux = fetched[1], aux2 = fetched[2];
+  __syncthreads();                           // (everyone has read `fetched` before it is overwritten)
+  // the NEXT item: its ticket is drawn now and arrives under this item's image copy; the item
+  // itself is read behind the copy's wait and stored at the end
+  int ticket = 0;
+  int4 next = make_int4(-1, 0, 0, 0);
+  if (tid == 0) ticket = atomicAdd(next_item, 1);
+  float px = 0.f, py = 0.f;
+  float2 rot_mine = make_float2(1.f, 0.f);
+  if (work_stride == 3) {
+    const auto* xyz = AsGlobal(reinterpret_cast<const float*>(
+        static_cast<uintptr_t>(static_cast<uint32_t>(aux.x)) | (static_cast<uintptr_t>(static_cast<uint32_t>(aux.y)) << 32)));
+    const auto* rot = AsGlobal(reinterpret_cast<const float*>(
+        static_cast<uintptr_t>(static_cast<uint32_t>(aux.z)) | (static_cast<uintptr_t>(static_cast<uint32_t>(aux.w)) << 32)));
+    if (tid < aux2.x) { px = xyz[3 * tid]; py = xyz[3 * tid + 1]; }
+    if (tid < (aux2.y - item.z + item.w - 1) / item.w) {
+      const int at = item.z + tid * item.w;
+      rot_mine = make_float2(rot[2 * at], rot[2 * at + 1]);
+    }
+  }
+  CopyParams(&P, params + item.x, tid);
+  __syncthreads();
+  const int tile = item.y, g = item.z, G = item.w;
+  const int side = 2 * P.nl + 1, cands = side * side;
+  const int B = P.B, H = P.H, lp = P.lp;
+  const int rw = (P.num_scans - g + G - 1) / G;          // rotations g, g + G, ... of this item
+  // (in-kernel timeline of the profiling tools: compiled in only for the instrumented
+  // instantiation the debug switch `timeline` selects; slots = workgroup x its first items)
+  const auto stamp = [&](int k) {
+    if constexpr (kTimeline) {
+      if (item_index < 4) Stamp(P.timeline, blockIdx.x * 4 + item_index, k);
+    }
+  };
+  stamp(0);
+  const int nkeys = P.ntx * P.nty * 4;
+  int* acc = reinterpret_cast<int*>(tile_smem + P.tile_image_bytes);
+  int* hdrs = acc + ((P.rw * cands + 3) & ~3);           // [rw][4] start | count << 16 of this tile
+  int* slot = hdrs + P.rw * 4;                           // [rw + 1] cumulative list lengths
+  int* tasks = slot + ((P.rw + 1 + 3) & ~3);             // [task_cap][4]
+  int* ctl = tasks + P.task_cap * 4;                     // [0] tasks, [1] next task, [2] round end
+  // (fused: + bases[rw][4] | rots[rw] | ax[n_pad] ay[n_pad] before the lists)
+  const bool fused = P.fused != 0;
+  const int pchunks = P.n_pad >> 6;
+  int* bases = ctl + 16;                                 // fused, [rw][4]: the cursors of the phase lists
+  float2* rots = reinterpret_cast<float2*>(bases + (fused ? P.rw * 4 : 0));
+  float* ax = reinterpret_cast<float*>(rots + (fused ? (P.rw + 1) & ~1 : 0));   // the cloud rotated by
+  float* ay = ax + (fused ? P.n_pad : 0);                                       // the initial yaw
+  uint16_t* list = reinterpret_cast<uint16_t*>(ay + (fused ? P.n_pad : 0));
+
+  if (fused) {
+    // the cloud rotated by the initial yaw and this item's rotations: into LDS BEFORE the image
+    // copy is issued (loads return in order: behind the copy they would wait for it to land)
+    const auto* xyz = AsGlobal(P.xyz);
+    for (int i = tid; i < P.n_pad; i += num_threads) {
+      float x = 0.f, y = 0.f;
+      if (i < P.n) RotateZ(P.init_qw, P.init_qz, i == tid ? px : xyz[3 * i], i == tid ? py : xyz[3 * i + 1], &x, &y);
+      ax[i] = x;
+      ay[i] = y;
+    }
+    if (tid < rw) rots[tid] = rot_mine;
+    if (tid < rw * 4) hdrs[tid] = 0;                     // (counts first, start | count << 16 below)
+  }
+  // ---- the tile's image: th_img rows of the quantised grid image + rpl * H rows of zeros,
+  // LDS-DMA with one row piece (16 bytes) per lane.  The first piece of the grid image is halo
+  // (zeros): the source of the null rows and of every piece outside the image -----------------
+  const auto issue_image_copy = [&]() {
+    const int tY = tile / P.ntx, tX = tile - tY * P.ntx;
+    const int gx0 = P.box_x0 + tX * P.T, gy0 = P.box_y0 + tY * P.T;
+    const int ppr = lp >> 4;
+    const int pieces_img = P.th_img * ppr;
+    const auto* src = (const __attribute__((address_space(1))) unsigned char*)P.qimage;
+    auto* dst = (__attribute__((address_space(3))) unsigned char*)tile_smem;
+    const int kib = P.tile_image_bytes >> 10;
+    const int gw = P.gpitch >> 1;                         // cells per image row
+    for (int k = wave; k < kib; k += num_waves) {
+      const int p = (k << 6) + lane;
+      const int row = p / ppr, c = p - row * ppr;
+      const int X0 = gx0 + (c << 3), Y = gy0 + row;
+      // (pieces right of / below the image are outside the grid: zeros, like the corner)
+      const bool zero = p >= pieces_img || X0 >= gw || Y >= P.grows;
+      const size_t at = zero ? 0 : static_cast<size_t>(Y) * P.gpitch + static_cast<size_t>(X0) * 2;
+      __builtin_amdgcn_global_load_lds(src + at, dst + (k << 10), 16, 0, 0);
+    }
+  };
+  issue_image_copy();
+  stamp(1);                                              // image DMA issued
+  for (int i = tid; i < rw * cands; i += num_threads) acc[i] = 0;
+  const int wave_chunks = rw * pchunks;
+  const int cw = wave - kFusedIdleWaves, compute_waves = num_waves - kFusedIdleWaves;
+  if (fused) {
+    // ---- one tile per match: the rotations of this item are discretised HERE (what the prep
+    // kernel does for tiled matches: same cells, same entries), from the cloud in LDS.  A chunk =
+    // 64 consecutive points of one rotation.  ~100 vector instructions per point and rotation:
+    // 4 us per pass for C1's seven rotations of 891 points on one CU -- the price of having no
+    // prep launch and no lists in HBM (measured equal on the wall for 128 matches, 10 us less
+    // for a single one: profiles/r04_c1_fused_prep.txt) -------------------------------------
+    LdsBarrier();                                        // (not __syncthreads: the copy stays in flight)
+    // pass 1 of 2: the sizes of the phase lists.  (The entries are computed again in pass 2 rather
+    // than kept: nine chunks of registers a wavefront, live across the layout step, spilled -- and
+    // scratch accesses queue behind the image copy like any other load.)
+    bool outside = false;
+    if (cw >= 0) {
+      // (everything the loop needs in registers: P lives in LDS, and every field read would be a
+      // round trip of its own behind the atomics)
+      const Rt2DFrame F = FrameOf(P);
+      const int n_pts = P.n, off_x = P.hl - P.nl - P.box_x0, off_y = P.ht - P.nl - P.box_y0, T = P.T;
+      int rr = cw / pchunks, pc = cw - rr * pchunks;     // chunk cw + j * compute_waves, incrementally
+#pragma unroll 1
+      for (int chunk = cw; chunk < wave_chunks; chunk += compute_waves) {
+        const int i = pc * 64 + lane;
+        int phase = -1;
+        if (i < n_pts) {
+          const float2 rot = rots[rr];
+          int ix, iy;
+          Rt2DCellOfPrerotated(F, rot.x, rot.y, ax[i], ay[i], &ix, &iy);
+          const int rx = ix + off_x, ry = iy + off_y;
+          if (rx < 0 || ry < 0 || rx >= T || ry >= T) outside = true;         // (never: the host's box)
+          else phase = rx & 3;
+        }
+        const int c0 = __popcll(__ballot(phase == 0)), c1 = __popcll(__ballot(phase == 1));
+        const int c2 = __popcll(__ballot(phase == 2)), c3 = __popcll(__ballot(phase == 3));
+        if (lane < 4) atomicAdd(&hdrs[rr * 4 + lane], lane == 0 ? c0 : lane == 1 ? c1 : lane == 2 ? c2 : c3);
+        pc += compute_waves;
+        while (pc >= pchunks) { pc -= pchunks; ++rr; }
+      }
+    }
+    if (outside) atomicOr(&P.misc[0], kOutOfBox);
+    LdsBarrier();
+    if (wave == 0) {                   // per rotation: phase starts (lists padded to 16 entries)
+      const int rr = lane;
+      int len = 0;
+      if (rr < rw) {
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+          const int c = hdrs[rr * 4 + ph];
+          hdrs[rr * 4 + ph] = len | (c << 16);
+          len += (c + 15) & ~15;
+        }
+      }
+      const int incl = WaveInclusiveScan(len);
+      if (rr < rw) {
+        slot[rr + 1] = incl;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) bases[rr * 4 + ph] = incl - len + (hdrs[rr * 4 + ph] & 0xffff);
+      }
+      if (lane == 0) slot[0] = 0;
+    }
+  } else {
+    if (tid < rw * 4) {
+      const int rr = tid >> 2, ph = tid & 3;
+      hdrs[tid] = static_cast<int>(P.hdr[static_cast<size_t>(g + rr * G) * nkeys + tile * 4 + ph]);
+    }
+    __syncthreads();
+    if (wave == 0) {                   // cumulative (padded) list lengths of this tile's rotations
+      const int rr = lane;
+      int len = 0;
+      if (rr < rw) {
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) len += ((hdrs[rr * 4 + ph] >> 16) + 15) & ~15;
+      }
+      const int incl = WaveInclusiveScan(len);
+      if (rr < rw) slot[rr + 1] = incl;
+      if (lane == 0) slot[0] = 0;
+    }
+  }
+  const int lds_image = static_cast<int>(reinterpret_cast<uintptr_t>(
+      (const __attribute__((address_space(3))) unsigned char*)tile_smem));
+  // Lane geometry inside a half-wavefront.
+  const int li = lane & 31;
+  const int row = li / B, blk = li - row * B;
+  const bool lane_used = row < H;
+  // (lanes beyond H * B read the image's first rows like everyone else and drop the result)
+  const int lane_off = lds_image + (lane_used ? row * lp + blk * 8 : 0);
+  const int row_stride = H * lp;
+  if (fused) LdsBarrier(); else __syncthreads();
+  stamp(2);                                              // headers, list lengths
+
+  // ---- rounds: as many rotations as the LDS list buffer holds ------------------------------
+  for (int rr0 = 0; rr0 < rw;) {
+    const int base = slot[rr0];
+    int rr1 = rr0 + 1;                                 // (one rotation always fits: host)
+    while (rr1 < rw && slot[rr1 + 1] - base <= P.list_lds) ++rr1;
+    if (fused) LdsBarrier(); else __syncthreads();     // the previous round's lists are done with
+    if (tid < 2) ctl[tid] = 0;
+    // lists: rotation rr's entries of this tile are contiguous in HBM (keys in order)
+    // (wavefront 0 builds the round's tasks below while the others copy its lists)
+    for (int rr = rr0 + wave - 1; !fused && wave >= 1 && rr < rr1; rr += num_waves - 1) {
+      const int first = hdrs[rr * 4] & 0xffff;
+      const int len = slot[rr + 1] - slot[rr];
+      typedef unsigned U4 __attribute__((ext_vector_type(4)));
+      const auto* src = AsGlobal(reinterpret_cast<const U4*>(
+          P.lists + static_cast<size_t>(g + rr * G) * P.cap_s + first));
+      U4* dst = reinterpret_cast<U4*>(list + (slot[rr] - base));
+      for (int q = lane; q < (len >> 3); q += 64) dst[q] = src[q];
+    }
+    // ---- per rotation: phases paired by size, tasks of at most kPairTaskIters iterations ---
+    if (wave == 0) {
+      const int rr = rr0 + lane;
+      const bool live = rr < rr1;
+      int key[4], first_slot[4];                 // count << 2 | phase
+      const int g_first = live ? hdrs[rr * 4] & 0xffff : 0;
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        const int h = live ? hdrs[rr * 4 + ph] : 0;
+        key[ph] = ((h >> 16) << 2) | ph;
+        first_slot[ph] = (h & 0xffff) - g_first + (live ? slot[rr] - base : 0);
+      }
+      // the four phases by count, descending (sorting network of five exchanges)
+#define CMX_CSWAP(I, J) { const int hi_k = max(key[I], key[J]), lo_k = min(key[I], key[J]); key[I] = hi_k; key[J] = lo_k; }
+      CMX_CSWAP(0, 1) CMX_CSWAP(2, 3) CMX_CSWAP(0, 2) CMX_CSWAP(1, 3) CMX_CSWAP(1, 2)
+#undef CMX_CSWAP
+      const int la0 = key[0] >> 2, la1 = key[2] >> 2;
+      const int mine = (la0 + kPairTaskIters - 1) / kPairTaskIters +
+                       (la1 + kPairTaskIters - 1) / kPairTaskIters;
+      const int incl = WaveInclusiveScan(mine);
+      int t = incl - mine;
+      if (lane == 63) ctl[0] = incl;
+#pragma unroll
+      for (int pair = 0; pair < 2; ++pair) {
+        const int pa = key[2 * pair] & 3, pb = key[2 * pair + 1] & 3;
+        const int la = key[2 * pair] >> 2, lb = key[2 * pair + 1] >> 2;
+        // (static selects instead of first_slot[pa]: no dynamically indexed private array)
+        const int sa = pa == 0 ? first_slot[0] : pa == 1 ? first_slot[1] : pa == 2 ? first_slot[2] : first_slot[3];
+        const int sb = pb == 0 ? first_slot[0] : pb == 1 ? first_slot[1] : pb == 2 ? first_slot[2] : first_slot[3];
+        for (int off = 0; off < la; off += kPairTaskIters, ++t) {
+          tasks[4 * t] = rr | (pa << 8) | (pb << 16);
+          tasks[4 * t + 1] = sa + off;
+          tasks[4 * t + 2] = sb + off;
+          tasks[4 * t + 3] = min(kPairTaskIters, la - off) | (max(0, min(kPairTaskIters, lb - off)) << 16);
+        }
+      }
+    }
+    if (fused) {
+      // ---- the entries from the registers into the phase lists (one round: the host sized the
+      // list buffer for all of this item's rotations) ------------------------------------------
+      // pass 2: the entries into the phase lists; a chunk's place in each list is drawn from the
+      // list's cursor (any order inside a list: the sums are integers)
+      if (cw >= 0) {
+        // (everything the loop needs in registers: P lives in LDS, and every field read would be a
+        // round trip of its own behind the atomics)
+        const Rt2DFrame F = FrameOf(P);
+        const int n_pts = P.n, off_x = P.hl - P.nl - P.box_x0, off_y = P.ht - P.nl - P.box_y0, T = P.T;
+        int rr = cw / pchunks, pc = cw - rr * pchunks;
+#pragma unroll 1
+        for (int chunk = cw; chunk < wave_chunks; chunk += compute_waves) {
+          const int i = pc * 64 + lane;
+          int packed = -1;
+          if (i < n_pts) {
+            const float2 rot = rots[rr];
+            int ix, iy;
+            Rt2DCellOfPrerotated(F, rot.x, rot.y, ax[i], ay[i], &ix, &iy);
+            const int rx = ix + off_x, ry = iy + off_y;
+            if (!(rx < 0 || ry < 0 || rx >= T || ry >= T))
+              packed = (((ry * lp + (rx & ~3) * 2) >> 3) << 2) | (rx & 3);
+          }
+          const int ph = packed & 3;
+          const unsigned long long m0 = __ballot(packed >= 0 && ph == 0);
+          const unsigned long long m1 = __ballot(packed >= 0 && ph == 1);
+          const unsigned long long m2 = __ballot(packed >= 0 && ph == 2);
+          const unsigned long long m3 = __ballot(packed >= 0 && ph == 3);
+          int first = 0;
+          if (lane < 4)
+            first = atomicAdd(&bases[rr * 4 + lane],
+                              __popcll(lane == 0 ? m0 : lane == 1 ? m1 : lane == 2 ? m2 : m3));
+          const int f0 = __builtin_amdgcn_readlane(first, 0), f1 = __builtin_amdgcn_readlane(first, 1);
+          const int f2 = __builtin_amdgcn_readlane(first, 2), f3 = __builtin_amdgcn_readlane(first, 3);
+          if (packed >= 0) {
+            const unsigned long long mine = ph == 0 ? m0 : ph == 1 ? m1 : ph == 2 ? m2 : m3;
+            const int at = ph == 0 ? f0 : ph == 1 ? f1 : ph == 2 ? f2 : f3;
+            const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mine >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mine), 0));
+            list[at + rank] = static_cast<uint16_t>(packed >> 2);
+          }
+          pc += compute_waves;
+          while (pc >= pchunks) { pc -= pchunks; ++rr; }
+        }
+      }
+    }
+    if (rr0 == 0) stamp(4);                              // tasks built / this wave's lists in LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the image has landed
+    if (rr0 == 0 && tid == 0) ctl[4] = ticket;           // (the ticket arrived with that wait)
+    __syncthreads();
+    if (rr0 == 0) stamp(5);                              // image landed
+    if (rr0 == 0 && tid < work_stride) {
+      const int t = ctl[4];
+      next = t < num_items ? work[t * work_stride + tid] : make_int4(-1, 0, 0, 0);
+    }
+    // ---- tasks, dealt dynamically: the halves of a wavefront run two phases ----------------
+    const int num_tasks = ctl[0];          // <= task_cap by construction (host)
+    for (;;) {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(&ctl[1], 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= num_tasks) break;
+      const int d0 = tasks[4 * t], d3 = tasks[4 * t + 3];
+      const int rr = d0 & 255;
+      const bool second = lane >= 32;
+      const int phase = second ? (d0 >> 16) & 255 : (d0 >> 8) & 255;
+      const int start = second ? tasks[4 * t + 2] : tasks[4 * t + 1];
+      const int my_len = second ? d3 >> 16 : d3 & 0xffff;
+      const int iters = ((d3 & 0xffff) + 15) & ~15;          // the first stream is the longer
+      uint32_t acc32[RPL][4];
+#pragma unroll
+      for (int j = 0; j < RPL; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc32[j][c] = 0;
+      RowPairAccumulate<RPL, kRowStride>(list + start, my_len, iters, lane, lane_off, row_stride,
+                                         P.null_addr, acc32);
+      if (lane_used) {
+        int* out = acc + rr * cands;
+        const int d0x = blk * 4 - phase;           // candidate x index of the block's first cell
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+          const int wrow = row + j * H;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int dxi = d0x + c;
+            if (wrow < side && dxi >= 0 && dxi < side && acc32[j][c])
+              atomicAdd(&out[dxi * side + wrow], static_cast<int>(acc32[j][c]));
+          }
+        }
+      }
+    }
+    if (rr0 == 0) stamp(6);                              // wave 0 out of tasks (first round)
+    rr0 = rr1;
+  }
+  __syncthreads();
+  stamp(7);                                              // all rounds done
+  // ---- this tile's share of the candidates' integer sums --------------------------------------
+  for (int e = tid; e < rw * cands; e += num_threads) {
+    const int rr = e / cands, c = e - rr * cands;
+    auto* out = AsGlobal(P.qsum) + static_cast<size_t>(g + rr * G) * cands + c;
+    const int v = acc[e];
+    if (P.flush_atomic) {
+      if (v) __hip_atomic_fetch_add(out, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      *out = v;
+    }
+  }
+  stamp(8);
+  if (tid < work_stride) fetched[tid] = next;
+  }   // work items
+}
+
+__global__ void __launch_bounds__(kFinishThreads)
+Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group,
+                 unsigned* __restrict__ host_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fin_smem[];
+  __shared__ Rt2DTileParams P;
+  CopyParams(&P, params + blockIdx.x, threadIdx.x);
+  __syncthreads();
+  Rt2DFinishMatch<kFinishThreads, false, true>(P, fin_smem, group, host_out, blockIdx.x);
 }
 
 size_t Align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
@@ -925,6 +1104,7 @@ struct TileGeometry {
   int B, H, hl, ht, gpitch, grows;
   int box_x0, box_y0, T, ntx, nty, lp, th_img, tile_image_bytes;
   int cap_s, gmin, gmax, target, rw, list_lds, task_cap;
+  int groups;               // fused: the rotation groups (work items) of this match, chosen by the host
   size_t lds;               // of the tile kernel
   size_t image_bytes;       // of the grid image in HBM
 };
@@ -1147,6 +1327,7 @@ struct Rt2DTileCall::Impl {
   size_t lists_total = 0, hdr_total = 0, qsum_total = 0;
   long long work_cap = 0, entries_total = 0;
   int tile_grid = 0, tile_threads = 512;
+  bool fused = false;                   // one tile per match, prep fused into the tile kernel
   std::unique_ptr<WorkspaceLease> ws;
   CacheHolds holds;
   unsigned* h_misc = nullptr;
@@ -1248,11 +1429,14 @@ bool Rt2DTileCall::Plan() {
   const size_t kLdsTwoPerCu = (dbg.rt2d_lds_kb > 0 ? dbg.rt2d_lds_kb : 76) * size_t{1024};
   const size_t kLdsOnePerCu = 150 * size_t{1024};
   bool single_tile = dbg.rt2d_tile <= 0;
+  bool want_fused = !dbg.rt2d_unfused;
+  for (const Class& k : classes) want_fused = want_fused && k.n_pad <= kFusedMaxPoints;
   for (Class& k : classes) {
     TileGeometry& g = k.g;
     const int side = 2 * k.nl + 1;
     const int rows_extra = rpl * g.H;
     const int cap_tile = k.n_pad + 64;                // a rotation's entries of ONE tile, padded
+    const bool fuse = want_fused;
     const auto try_tile = [&](int T, size_t budget, bool one_tile, TileGeometry* out) {
       const int ntx = (k.span_x + T - 1) / T, nty = (k.span_y + T - 1) / T;
       if (ntx * nty > (one_tile ? 1 : kMaxTiles)) return false;
@@ -1265,9 +1449,14 @@ bool Rt2DTileCall::Plan() {
       for (int gmin = std::max(1, (k.scans + 63) / 64); gmin <= k.scans; ++gmin) {
         const int rw = (k.scans + gmin - 1) / gmin;
         const int task_cap = rw * (k.n_pad / kPairTaskIters + 2);
-        const size_t fixed = static_cast<size_t>(image) + 4 * ((static_cast<size_t>(rw) * side * side + 3) & ~size_t{3}) +
-                             16 * static_cast<size_t>(rw) + 4 * ((static_cast<size_t>(rw) + 1 + 3) & ~size_t{3}) +
-                             16 * static_cast<size_t>(task_cap) + 64;
+        size_t fixed = static_cast<size_t>(image) + 4 * ((static_cast<size_t>(rw) * side * side + 3) & ~size_t{3}) +
+                       16 * static_cast<size_t>(rw) + 4 * ((static_cast<size_t>(rw) + 1 + 3) & ~size_t{3}) +
+                       16 * static_cast<size_t>(task_cap) + 64;
+        if (one_tile && fuse) {
+          // (list cursors, rotations, the cloud rotated by the initial yaw)
+          fixed += 16 * static_cast<size_t>(rw) + 8 * ((static_cast<size_t>(rw) + 1) & ~size_t{1}) +
+                   8 * static_cast<size_t>(k.n_pad);
+        }
         if (fixed + 2 * static_cast<size_t>(cap_tile) > budget) {
           if (!one_tile) return false;
           continue;                                      // fewer rotations per workgroup
@@ -1342,6 +1531,7 @@ bool Rt2DTileCall::Plan() {
     }
   }
   I.tile_threads = single_tile ? 1024 : 512;
+  I.fused = single_tile && want_fused;
   // Entries per work item: the whole batch in about two items per resident workgroup (an item
   // costs ~4 us before its first window update: ticket, headers, lists, tasks, image), not less
   // than two thousand entries (sixteen tasks: one per wavefront).
@@ -1367,6 +1557,13 @@ bool Rt2DTileCall::Plan() {
     g.gmax = dbg.rt2d_groups > 0 ? std::max(g.gmin, std::min(dbg.rt2d_groups, sr.num_scans))
                                  : std::max(g.gmin, std::min(sr.num_scans, 32));
     g.target = target;
+    g.groups = 0;
+    if (I.fused) {                       // the planner's rule (Rt2DTilePrepKernel), on the host
+      const long long entries = static_cast<long long>(it.n) * sr.num_scans;
+      long long G = std::max<long long>(1, (entries + target / 2) / target);
+      G = std::min<long long>(std::max<long long>(G, g.gmin), std::min(g.gmax, sr.num_scans));
+      g.groups = static_cast<int>(std::max<long long>(G, g.gmin));
+    }
     g.cap_s = n_pad + 16 * 4 * g.ntx * g.nty;
     // the grid image: halo + grid, rows of whole 16-byte pieces, one zero row below (what lies
     // right of or below it is zeros by definition: the tile DMA substitutes the zero corner)
@@ -1380,9 +1577,10 @@ bool Rt2DTileCall::Plan() {
     I.qsum_total += static_cast<size_t>(sr.num_scans) * side * side;
     // (an upper bound of the planner's items: a tile's groups are capped by gmax and by its share
     // of the entries, and the shares of a match's tiles add up to all its entries)
-    I.work_cap += std::min<long long>(static_cast<long long>(g.ntx) * g.nty * g.gmax,
-                                      static_cast<long long>(it.n) * sr.num_scans / target +
-                                          static_cast<long long>(g.ntx) * g.nty * (g.gmin + 1));
+    I.work_cap += I.fused ? g.groups
+                          : std::min<long long>(static_cast<long long>(g.ntx) * g.nty * g.gmax,
+                                                static_cast<long long>(it.n) * sr.num_scans / target +
+                                                    static_cast<long long>(g.ntx) * g.nty * (g.gmin + 1));
     I.max_scans = std::max(I.max_scans, sr.num_scans);
     const int stride = g.H * g.lp;
     I.common_stride = m == 0 ? stride : (I.common_stride == stride ? stride : 0);
@@ -1442,6 +1640,8 @@ void Rt2DTileCall::Enqueue() {
   }
   const size_t off_counters = in_bytes;               // [0] work items, [1] next item (zeroed)
   in_bytes += 64;
+  const size_t off_work = in_bytes;                   // fused: the work items, listed here
+  if (I.fused) in_bytes += Align16(3 * sizeof(int4) * static_cast<size_t>(I.work_cap));
   const size_t off_misc = in_bytes;
   in_bytes += Align16(sizeof(unsigned) * 128 * static_cast<size_t>(num));
 
@@ -1449,15 +1649,33 @@ void Rt2DTileCall::Enqueue() {
   WorkspaceLease& ws = *I.ws;
   char* h_in = ws->pinned[0].ReserveAs<char>(in_bytes);
   char* d_in = ws->dev[0].ReserveAs<char>(in_bytes);
-  uint16_t* d_lists = reinterpret_cast<uint16_t*>(ws->dev[1].Reserve(I.lists_total + 64));
-  uint32_t* d_hdr = ws->dev[2].ReserveAs<uint32_t>(I.hdr_total + 16);
+  uint16_t* d_lists = I.fused ? nullptr : reinterpret_cast<uint16_t*>(ws->dev[1].Reserve(I.lists_total + 64));
+  uint32_t* d_hdr = I.fused ? nullptr : ws->dev[2].ReserveAs<uint32_t>(I.hdr_total + 16);
   int* d_qsum = ws->dev[3].ReserveAs<int>(I.qsum_total + 16);
   I.d_overflow = ws->dev[4].ReserveAs<unsigned>(static_cast<size_t>(num) * 2 * (kFinalistCap - kFinalistHead));
-  int4* d_work = ws->dev[8].ReserveAs<int4>(static_cast<size_t>(I.work_cap) + 1);
+  int4* d_work = I.fused ? reinterpret_cast<int4*>(d_in + off_work)
+                         : ws->dev[8].ReserveAs<int4>(static_cast<size_t>(I.work_cap) + 1);
   I.h_misc = ws->pinned[1].ReserveAs<unsigned>(static_cast<size_t>(num) * 128);
   unsigned* d_misc = reinterpret_cast<unsigned*>(d_in + off_misc);
   int* d_counters = reinterpret_cast<int*>(d_in + off_counters);
-  std::memset(h_in + off_counters, 0, 64 + sizeof(unsigned) * 128 * static_cast<size_t>(num));
+  std::memset(h_in + off_counters, 0, 64);
+  std::memset(h_in + off_misc, 0, sizeof(unsigned) * 128 * static_cast<size_t>(num));
+  if (I.fused) {
+    int4* h_work = reinterpret_cast<int4*>(h_in + off_work);
+    int count = 0;
+    for (int m = 0; m < num; ++m) {
+      const uintptr_t xyz = reinterpret_cast<uintptr_t>(
+          items[m].device_xyz ? items[m].device_xyz : reinterpret_cast<const float*>(d_in + off[m].xyz));
+      const uintptr_t rot = reinterpret_cast<uintptr_t>(d_in + off[m].rot);
+      for (int g = 0; g < geo[m].groups; ++g, ++count) {
+        h_work[3 * count] = make_int4(m, 0, g, geo[m].groups);
+        h_work[3 * count + 1] = make_int4(static_cast<int>(static_cast<uint32_t>(xyz)), static_cast<int>(static_cast<uint32_t>(xyz >> 32)),
+                                          static_cast<int>(static_cast<uint32_t>(rot)), static_cast<int>(static_cast<uint32_t>(rot >> 32)));
+        h_work[3 * count + 2] = make_int4(items[m].n, search[m].num_scans, 0, 0);
+      }
+    }
+    reinterpret_cast<int*>(h_in + off_counters)[0] = count;
+  }
   const int timeline_tile_slots = I.tile_grid * 4;
   if (dbg.timeline) {
     const size_t bytes = (static_cast<size_t>(timeline_tile_slots) + num) * kTimelineStamps * 8;
@@ -1551,8 +1769,9 @@ void Rt2DTileCall::Enqueue() {
       P.T_magic = static_cast<unsigned>((0x100000000ull + g.T - 1) / g.T);
       P.ntx = g.ntx; P.nty = g.nty; P.lp = g.lp; P.th_img = g.th_img;
       P.tile_image_bytes = g.tile_image_bytes; P.null_addr = g.th_img * g.lp;
-      P.lists = d_lists + lists_off[m] / 2; P.cap_s = g.cap_s;
-      P.hdr = d_hdr + hdr_off[m];
+      P.lists = d_lists ? d_lists + lists_off[m] / 2 : nullptr; P.cap_s = g.cap_s;
+      P.hdr = d_hdr ? d_hdr + hdr_off[m] : nullptr;
+      P.fused = I.fused ? 1 : 0;
       P.gmin = g.gmin; P.gmax = g.gmax; P.target = g.target; P.rw = g.rw;
       P.list_lds = g.list_lds; P.task_cap = g.task_cap;
       P.flush_atomic = g.ntx * g.nty > 1 ? 1 : 0;
@@ -1581,8 +1800,9 @@ void Rt2DTileCall::Enqueue() {
     if (any_build)
       Rt2DQuantKernel<<<dim3(DivUp(max_vecs, 256), num), 256, 0, ws->stream>>>(d_params);
   }
-  Rt2DTilePrepKernel<<<dim3(I.max_scans, num), 256, I.prep_lds, ws->stream>>>(
-      d_params, d_counters, d_work, static_cast<int>(I.work_cap));
+  if (!I.fused)
+    Rt2DTilePrepKernel<<<dim3(I.max_scans, num), 256, I.prep_lds, ws->stream>>>(
+        d_params, d_counters, d_work, static_cast<int>(I.work_cap));
   CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
   {
     const auto launch = [&](auto kernel) {
@@ -1594,7 +1814,7 @@ void Rt2DTileCall::Enqueue() {
                         "%d resident per CU\n", I.tile_grid, I.tile_threads, I.tile_lds, resident);
       }
       kernel<<<static_cast<unsigned>(I.tile_grid), I.tile_threads, I.tile_lds, ws->stream>>>(
-          d_params, d_work, d_counters, d_counters + 1);
+          d_params, d_work, d_counters, d_counters + 1, I.fused ? 3 : 1);
     };
     const int common_stride = I.common_stride;
     if (I.d_timeline) {               // the instrumented instantiations (runtime row stride)

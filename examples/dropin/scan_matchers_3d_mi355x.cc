@@ -13,6 +13,11 @@
 
 namespace cartographer {
 namespace mapping {
+// The reference never iterates an IntensityHybridGrid, so AverageIntensityData has no operator==
+// for IsDefaultValue (hybrid_grid.h:55-58); found by ADL when the iterator is instantiated below.
+inline bool operator==(const AverageIntensityData& a, const AverageIntensityData& b) {
+  return a.sum == b.sum && a.count == b.count;
+}
 namespace scan_matching {
 namespace {
 
@@ -161,21 +166,38 @@ void CeresScanMatcher3D::Match(
   std::vector<std::vector<cmx_voxel>> voxels;
   std::vector<std::vector<float>> clouds;
   std::vector<cmx_ceres3d_pair> pairs;
-  for (const PointCloudAndHybridGridsPointers& p : point_clouds_and_hybrid_grids) {
-    // The library implements IntensityCostFunction3D (cmx_ceres3d_pair's intensity fields), but
-    // this adapter flattens the occupancy grid only: a caller that hands over an intensity grid
-    // must not silently get a different optimisation than ceres_scan_matcher_3d.cc:118-137.
-    if (p.intensity_hybrid_grid != nullptr) {
-      std::fprintf(stderr, "CeresScanMatcher3D (MI355X adapter): intensity_hybrid_grid is not "
-                           "wired through this adapter; use cmx_ceres3d_match's intensity fields\n");
-      std::abort();
-    }
+  std::vector<std::vector<cmx_intensity_voxel>> intensity_voxels;
+  voxels.reserve(o.num_pairs); clouds.reserve(o.num_pairs); intensity_voxels.reserve(o.num_pairs);
+  for (int i = 0; i != o.num_pairs; ++i) {
+    const PointCloudAndHybridGridsPointers& p = point_clouds_and_hybrid_grids[i];
     voxels.push_back(Flatten(*p.hybrid_grid));
     clouds.push_back(Flatten(*p.point_cloud));
-    pairs.push_back(cmx_ceres3d_pair{clouds.back().data(),
-                                     static_cast<int32_t>(p.point_cloud->size()),
-                                     p.hybrid_grid->resolution(), voxels.back().data(),
-                                     static_cast<int64_t>(voxels.back().size())});
+    cmx_ceres3d_pair pair{};
+    pair.point_cloud_xyz = clouds.back().data();
+    pair.num_points = static_cast<int32_t>(p.point_cloud->size());
+    pair.resolution = p.hybrid_grid->resolution();
+    pair.voxels = voxels.back().data();
+    pair.num_voxels = static_cast<int64_t>(voxels.back().size());
+    if (p.intensity_hybrid_grid != nullptr) {                  // ceres_scan_matcher_3d.cc:118-137
+      const auto& io = options_.intensity_cost_function_options(i);
+      if (!(io.huber_scale() > 0.) || !(io.weight() > 0.) ||
+          p.point_cloud->intensities().size() != p.point_cloud->size()) {     // CHECK_GT :124-125
+        std::fprintf(stderr, "Check failed: intensity_cost_function_options_%d / intensities\n", i);
+        std::abort();
+      }
+      intensity_voxels.emplace_back();                         // the AverageIntensityData cells
+      for (auto it = IntensityHybridGrid::Iterator(*p.intensity_hybrid_grid); !it.Done(); it.Next())
+        intensity_voxels.back().push_back(cmx_intensity_voxel{it.GetCellIndex().x(), it.GetCellIndex().y(),
+                                                              it.GetCellIndex().z(), it.GetValue().count,
+                                                              it.GetValue().sum});
+      pair.intensities = p.point_cloud->intensities().data();
+      pair.intensity_voxels = intensity_voxels.back().data();
+      pair.num_intensity_voxels = static_cast<int64_t>(intensity_voxels.back().size());
+      pair.intensity_weight = io.weight();
+      pair.intensity_huber_scale = io.huber_scale();
+      pair.intensity_threshold = static_cast<float>(io.intensity_threshold());
+    }
+    pairs.push_back(pair);
   }
   const double target[3] = {target_translation.x(), target_translation.y(),
                             target_translation.z()};

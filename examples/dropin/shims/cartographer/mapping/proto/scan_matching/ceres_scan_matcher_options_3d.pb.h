@@ -5,8 +5,28 @@
 #include <vector>
 #include "cartographer/mapping/proto/scan_matching/ceres_scan_matcher_options_2d.pb.h"
 namespace cartographer { namespace mapping { namespace scan_matching { namespace proto {
+struct IntensityCostFunctionOptions {       // ceres_scan_matcher_options_3d.proto:21-25
+  double weight_ = 0., huber_scale_ = 0., intensity_threshold_ = 0.;
+  double weight() const { return weight_; }
+  double huber_scale() const { return huber_scale_; }
+  double intensity_threshold() const { return intensity_threshold_; }
+  void set_weight(double v) { weight_ = v; }
+  void set_huber_scale(double v) { huber_scale_ = v; }
+  void set_intensity_threshold(double v) { intensity_threshold_ = v; }
+};
 struct CeresScanMatcherOptions3D {
   std::vector<double> occupied_space_weight_;
+  std::vector<IntensityCostFunctionOptions> intensity_cost_function_options_;
+  int intensity_cost_function_options_size() const {
+    return static_cast<int>(intensity_cost_function_options_.size());
+  }
+  const IntensityCostFunctionOptions& intensity_cost_function_options(int i) const {
+    return intensity_cost_function_options_.at(i);
+  }
+  IntensityCostFunctionOptions* add_intensity_cost_function_options() {
+    intensity_cost_function_options_.emplace_back();
+    return &intensity_cost_function_options_.back();
+  }
   double translation_weight_ = 0., rotation_weight_ = 0.;
   bool only_optimize_yaw_ = false;
   common::proto::CeresSolverOptions solver_;

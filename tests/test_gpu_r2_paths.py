@@ -103,15 +103,18 @@ def test_fast2d_fused_and_unfused_batches_agree(sm, synth, c2, debug):
 # ----------------------------------------------------------------------------
 # Real-time 2D: bulk pass vs per-candidate kernels vs oracle
 # ----------------------------------------------------------------------------
-RT2D_PATHS = ["tiles", "tiles64", "tiles56g", "0"]
+RT2D_PATHS = ["tiles", "tiles1", "tiles64", "tiles56g", "0"]
 
 
 def _rt2d_path(debug, path):
-    """'tiles': integer bulk pass out of LDS tiles + exact finalists (default); 'tiles64' /
-    'tiles56g': the same with small tiles (up to 4 x 4 per match: sums meet by atomics) and
+    """'tiles': integer bulk pass out of LDS tiles + exact finalists (default: one tile per match
+    where it fits, discretised inside the tile kernel); 'tiles1': that shape through the prep
+    kernel and its planner; 'tiles64' / 'tiles56g': the same with small tiles (up to 4 x 4 per match: sums meet by atomics) and
     with one work item per (tile, rotation); '0': one thread per candidate."""
     if path == "0":
         debug(rt2d_legacy=1)
+    elif path == "tiles1":
+        debug(rt2d_unfused=1)
     elif path == "tiles64":
         debug(rt2d_tile=64, rt2d_no_image_cache=1)
     elif path == "tiles56g":
