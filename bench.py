@@ -800,7 +800,8 @@ class Fast3DWorkload:
         scans = acc["num_scans"] / steps
         secs = max(k_ms, 1e-9) * 1e-3
         alg = coarse * self.n_points * 1.0 + scans * self.n_points * 12.0
-        pmc_config = "c5" if self.pairs == 32 else None
+        # (the counter passes are of the shipped configuration: none for the no-families A/B leg)
+        pmc_config = "c5" if self.pairs == 32 and not getattr(self, "no_pmc", False) else None
         coarse_line = {"kernel": "ScoreCoarse3D", "bound": "hbm", "achieved": alg / secs / 1e9,
                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": alg / secs / 1e9 / HBM_PEAK_GBS,
@@ -965,7 +966,11 @@ def other_configs(args, device, sync, pmc):
     from cartographer_amd import _lib
     try:
         _lib.debug_set(fast3d_no_families=1)
-        run("c5_share_32_submaps_no_families", lambda: Fast3DWorkload(args, device, pairs=32), 4, 2)
+        def nofam():
+            w = Fast3DWorkload(args, device, pairs=32)
+            w.no_pmc = True
+            return w
+        run("c5_share_32_submaps_no_families", nofam, 4, 2)
     finally:
         _lib.debug_set(fast3d_no_families=0)
     for name, cpu_leg, w in pending_cpu:
