@@ -96,6 +96,8 @@ cmx_status Guard(F&& body) {
   X(rt3d_legacy)          /* 1: real-time 3D on the exhaustive per-candidate kernel only */        \
   X(rt3d_no_tiles)        /* 1: bulk passes by memory gathers instead of LDS tiles */              \
   X(rt3d_verify)          /* 1: every bound checked on the device against what it bounds */        \
+  X(rt3d_no_rotblocks)    /* 1: the dense group pass (no rotation-block level above it) */          \
+  X(rt3d_rotblock_permille) /* first group round: pairs of blocks within this of the best (0: 970) */ \
   X(rt3d_crosscheck)      /* 1: tiled passes next to the gather kernels, every sum compared */     \
   X(rt3d_expand_all)      /* 1: every group expanded (with rt3d_verify: every group bound checked) */ \
   X(rt3d_unstaged)        /* 1: second candidate round in one piece */                             \
@@ -199,7 +201,7 @@ struct Workspace {
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;  // dominant-kernel bracket
   hipEvent_t ev_x0 = nullptr, ev_x1 = nullptr;  // branch-and-bound expansion bracket
-  static constexpr int kNumBuffers = 24;
+  static constexpr int kNumBuffers = 32;
   DeviceBuffer dev[kNumBuffers];
   PinnedBuffer pinned[4];
   ~Workspace();

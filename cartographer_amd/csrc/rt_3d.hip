@@ -17,6 +17,7 @@
 //   * exp() weighting and the strict-'>' first-maximum rule are finished on the
 //     host for the candidates within 1e-5 (relative) of the device maximum.
 #include <algorithm>
+#include <functional>
 #include <type_traits>
 
 #include "scan_matching_3d.h"
@@ -881,14 +882,21 @@ __device__ __forceinline__ void LdsReadU8Asm(unsigned* out, unsigned addr) {
 // kGroups: grid (ceil(R / rotations_per_block), chunk slices), blockDim = the (rotation, group)
 // lanes of a block rounded up to whole waves.  Candidate pass: grid (work descriptors, chunk
 // slices), blockDim = block_items.  Dynamic LDS: staged points | tile.
-template <bool kGroups>
+// kGroups: the arithmetic of the group pass (centre lookups in a dilated brick: fixed-point
+// words, no ambiguity bookkeeping, sums by segment).  kLists: lanes are entries of work lists over
+// P.list_rotations rotations (Rt3DCompactKernel) instead of all (rotation, translation) pairs of
+// TP.rotations_per_block rotations.  <true, false>: the dense group pass (and the rotation-block
+// pass above it); <true, true>: the group pass over the (rotation, group) pairs a rotation-block
+// bound could not exclude; <false, true>: the candidate passes.
+template <bool kGroups, bool kLists>
 __global__ void __launch_bounds__(1024)
 Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
-  constexpr int kChunk = kGroups ? kTileChunkGroups : kTileChunkCandidates;
+  static_assert(kGroups || kLists, "candidates always come from work lists");
+  constexpr int kChunk = kLists ? kTileChunkCandidates : kTileChunkGroups;
   constexpr int kStageStride = 3 * kChunk / 2 + 2;     // v2f per staged rotation (+16 B: bank shift)
   const int tid = threadIdx.x;
-  const int rotations = kGroups ? TP.rotations_per_block : P.list_rotations;
+  const int rotations = kLists ? P.list_rotations : TP.rotations_per_block;
   // Dynamic LDS: tile | staged points | (group pass) the points again as packed fixed-point
   // words, see step 2b.  The tile comes first: its LDS address is then a compile-time constant
   // that folds into the gathers' offset field.
@@ -902,7 +910,7 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
 
   int r, t, rotation_a, num_rot;
   bool valid;
-  if (kGroups) {
+  if (!kLists) {
     rotation_a = blockIdx.x * rotations;
     num_rot = min(rotations, P.num_rotations - rotation_a);
     const int item = tid;
@@ -980,7 +988,7 @@ Rt3DTileKernel(Rt3DBulkParams P, Rt3DTileParams TP) {
       // The box comes from the pre-pass: no reduction, no barrier, and the points are rotated
       // ONCE, straight into the form the lookups read (step 2c).
       if (tid < 6) {
-        const int block_index = kGroups ? static_cast<int>(blockIdx.x) : rotation_a / rotations;
+        const int block_index = kLists ? rotation_a / rotations : static_cast<int>(blockIdx.x);
         const float v = TP.boxes[(static_cast<size_t>(block_index) * num_chunks + chunk) * 6 + tid];
         const float offs[3] = {P.off_x, P.off_y, P.off_z};
         box[tid] = tid < 3 ? static_cast<int>(floorf(v + TP.tr_lo[tid] + offs[tid])) - 1
@@ -1316,6 +1324,72 @@ __global__ void Rt3DSumBoundsKernel(Rt3DBulkParams P) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) bits = max(bits, __shfl_xor(bits, off, 64));
   if ((threadIdx.x & 63) == 0 && bits != 0) atomicMax(P.max_upper_bits, bits);
+}
+
+// ---- the level above the groups: blocks of 2 x 2 x 2 ROTATIONS ----------------------------------
+// A rotation block (rb, g) = the rotations of a 2 x 2 x 2 block of the angle-axis lattice x the
+// translations of group g, bounded by ONE lookup per point at the block's centre rotation and the
+// group's centre translation in the brick dilated TWICE (5 x 5 x 5): a member's rotation vector
+// lies within half a step per axis of the centre vector, i.e. within 0.866 steps (x 1.03 for the
+// non-commuting part while the window stays below 0.2 rad), a step moves the farthest point by
+// one cell (step = 0.999 acos(1 - res^2 / 2 r_max^2)), so the member's rotated point lies within
+// 0.89 cells of the centre's, + 0.87 for the translation block + 1/16 for the fixed-point cell:
+// 1.82 < 2 cells per axis.  Weight: the smallest member angle and distance.  The (rotation, group)
+// pairs of the blocks a threshold cannot exclude then go through the group pass proper
+// (Rt3DTileKernel<true, true>, work lists as in the candidate passes); all other pairs keep an
+// upper bound of -1: never selected.  As every bound here, these only SELECT what is scored.
+//
+// pair (r, g) := flagged for the group pass if its block's bound reaches threshold * factor and it
+// has not been computed yet.
+__global__ void Rt3DSelectPairsKernel(const float* __restrict__ block_upper, int num_groups,
+                                      int num_rotations, int side_r, int blocks_per_axis,
+                                      const unsigned* __restrict__ threshold_bits, float factor,
+                                      uint8_t* __restrict__ computed, uint8_t* __restrict__ flags) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= static_cast<long long>(num_groups) * num_rotations) return;
+  const int r = static_cast<int>(i / num_groups), g = static_cast<int>(i % num_groups);
+  const int rx = r % side_r, ry = (r / side_r) % side_r, rz = r / (side_r * side_r);
+  const int rb = ((rz >> 1) * blocks_per_axis + (ry >> 1)) * blocks_per_axis + (rx >> 1);
+  const float threshold = __uint_as_float(*threshold_bits) * factor;
+  if (computed[i] || !(block_upper[static_cast<size_t>(rb) * num_groups + g] >= threshold)) return;
+  computed[i] = 1;
+  flags[i] = 1;
+}
+
+// Rt3DSumBoundsKernel for a partly computed group table: pairs never computed get -1.
+__global__ void Rt3DSumBoundsMaskedKernel(Rt3DBulkParams P, const uint8_t* __restrict__ computed) {
+  const long long c = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const long long total = static_cast<long long>(P.num_rotations) * P.num_translations;
+  float upper = 0.f;
+  if (c < total) {
+    if (computed[c]) {
+      const int r = static_cast<int>(c / P.num_translations);
+      const int t = static_cast<int>(c - static_cast<long long>(r) * P.num_translations);
+      float lower;
+      Bounds3D(P, P.sums[c].x, 0u, P.translation[t].w, r, &lower, &upper);
+      P.upper[c] = upper;
+    } else {
+      P.upper[c] = -1.f;
+    }
+  }
+  unsigned bits = __float_as_uint(upper);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) bits = max(bits, __shfl_xor(bits, off, 64));
+  if ((threadIdx.x & 63) == 0 && bits != 0) atomicMax(P.max_upper_bits, bits);
+}
+
+// Debug switch rt3d_verify: every computed (rotation, group) bound against its block's.
+__global__ void Rt3DVerifyBlocksKernel(const float* __restrict__ block_upper,
+                                       const float* __restrict__ group_upper,
+                                       const uint8_t* __restrict__ computed, int num_groups,
+                                       int num_rotations, int side_r, int blocks_per_axis,
+                                       int* __restrict__ violations) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= static_cast<long long>(num_groups) * num_rotations || !computed[i]) return;
+  const int r = static_cast<int>(i / num_groups), g = static_cast<int>(i % num_groups);
+  const int rx = r % side_r, ry = (r / side_r) % side_r, rz = r / (side_r * side_r);
+  const int rb = ((rz >> 1) * blocks_per_axis + (ry >> 1)) * blocks_per_axis + (rx >> 1);
+  if (!(block_upper[static_cast<size_t>(rb) * num_groups + g] >= group_upper[i])) atomicAdd(violations, 1);
 }
 
 // 3 x 3 x 3 dilation of the padded brick in two passes (x, then y and z).  The halo is wider
@@ -1676,6 +1750,34 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
           }
     }
 
+    // Rotation blocks (2 x 2 x 2 of the angle-axis lattice, see Rt3DSelectPairsKernel): the
+    // centre rotation and the smallest member angle of each.
+    const int Ab = (side_r + 1) / 2;
+    const long long Rb = 1ll * Ab * Ab * Ab;
+    std::vector<float4> rot_b(Rb);
+    std::vector<float> angle_b(Rb);
+    {
+      long long k = 0;
+      for (int bz = 0; bz < Ab; ++bz)
+        for (int by = 0; by < Ab; ++by)
+          for (int bx = 0; bx < Ab; ++bx, ++k) {
+            const int nx = std::min(2, side_r - 2 * bx), ny = std::min(2, side_r - 2 * by),
+                      nz = std::min(2, side_r - 2 * bz);
+            h3::Rigid tf;
+            tf.q = h3::FromAngleAxisVector({(2 * bx + 0.5f * (nx - 1) - A) * step,
+                                            (2 * by + 0.5f * (ny - 1) - A) * step,
+                                            (2 * bz + 0.5f * (nz - 1) - A) * step});
+            const h3::Q q = h3::Normalized(h3::Mul(init.q, tf.q));
+            rot_b[k] = make_float4(q.x, q.y, q.z, q.w);
+            float smallest = INFINITY;
+            for (int c = 0; c < nz; ++c)
+              for (int b = 0; b < ny; ++b)
+                for (int a = 0; a < nx; ++a)
+                  smallest = std::min(smallest, angle[((2 * bz + c) * side_r + (2 * by + b)) * side_r + (2 * bx + a)]);
+            angle_b[k] = smallest;
+          }
+    }
+
     WorkspaceLease ws(device);
     // Padded f32 probability brick over the voxels' bounding box.
     PaddedBrick brick{};
@@ -1736,6 +1838,12 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
                            ws->stream));
     CMX_HIP(hipMemcpyAsync(d_angle, angle.data(), R * sizeof(float), hipMemcpyHostToDevice,
                            ws->stream));
+    float4* d_rot_b = ws->dev[24].ReserveAs<float4>(Rb);
+    float* d_angle_b = ws->dev[25].ReserveAs<float>(Rb);
+    CMX_HIP(hipMemcpyAsync(d_rot_b, rot_b.data(), Rb * sizeof(float4), hipMemcpyHostToDevice,
+                           ws->stream));
+    CMX_HIP(hipMemcpyAsync(d_angle_b, angle_b.data(), Rb * sizeof(float), hipMemcpyHostToDevice,
+                           ws->stream));
     CMX_HIP(hipMemsetAsync(d_misc, 0, 16, ws->stream));
     // pageable sources above: make sure the copies are done before they go away
     CMX_HIP(hipStreamSynchronize(ws->stream));
@@ -1771,6 +1879,8 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
                     options->rotation_delta_cost_weight >= 0.;
     for (int i = 0; i < 3 * n && use_bulk; ++i) use_bulk = std::isfinite(point_cloud_xyz[i]);
     long long bounds_evaluated = 0;
+    long long group_bounds = 0;          // bounds above the candidates: rotation blocks + (rotation, group) pairs
+    bool second_pairs_pass = false;      // (its span: ev_x0 .. ev_x1)
     if (use_bulk) {
       const size_t cells = static_cast<size_t>(bx * by * bz);
       const int tiles_x = DivUp(bx, 8), tiles_y = DivUp(by, 4);
@@ -1856,6 +1966,7 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
       CMX_HIP(hipMemcpyAsync(d_group, h_group, sizeof(float4) * G, hipMemcpyHostToDevice,
                              ws->stream));
       CMX_HIP(hipMemsetAsync(d_bmisc, 0, 16, ws->stream));
+      CMX_HIP(hipMemsetAsync(d_num_blocks, 0, sizeof(int) * 4, ws->stream));   // blocks, violations, totals
       CMX_HIP(hipMemsetAsync(d_counts, 0, sizeof(int) * R, ws->stream));
       CMX_HIP(hipMemsetAsync(d_expanded, 0, RG + num_candidates, ws->stream));
       CMX_HIP(hipMemsetAsync(d_upper, 0, sizeof(float) * num_candidates, ws->stream));
@@ -1928,6 +2039,21 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
       // The cross-check compares complete sums and the expand-all mode has no second round.
       const bool staged = use_tiles && !crosscheck && Debug().rt3d_unstaged == 0 &&
                           Debug().rt3d_expand_all == 0;
+      // The rotation-block level above the group pass (Rt3DSelectPairsKernel): needs a window of
+      // more than one rotation per axis, small enough for the 1.03 of its bound, and the lists of
+      // the tiled passes.
+      const bool rotblocks = use_tiles && !crosscheck && Debug().rt3d_no_rotblocks == 0 && A >= 1 &&
+                             (A + 1) * static_cast<double>(step) * 1.7320508 <= 0.2;
+      // (work lists of the tiled list passes: several rotations each, so that a tile serves some
+      // hundred lanes even when a rotation keeps only a few dozen entries)
+      const int list_rotations =
+          use_tiles && !crosscheck ? std::max(1, std::min(8, Override(Debug().rt3d_cand_rotations, 8))) : 1;
+      const int num_lists = DivUp(R, list_rotations);
+      uint8_t* d_computed = nullptr;       // rotblocks: [R][G] pair computed | [R][G] pair flagged
+      float* d_block_upper = nullptr;      // rotblocks: [Rb][G]
+      unsigned* d_block_max = nullptr;
+      float* d_list_boxes = nullptr;       // chunk boxes of the candidate chunk list, per work list
+      std::function<void(const unsigned*, float)> run_pairs;   // one round of the sparse group pass
       if (use_tiles) {
         Rt3DBinParams BP{};
         BP.rotation = rot[R / 2];
@@ -2016,19 +2142,115 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
         }
         static thread_local size_t opted_groups = 0;
         if (lds > opted_groups) {
-          CMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(Rt3DTileKernel<true>),
+          CMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(Rt3DTileKernel<true, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(lds)));
           opted_groups = lds;
         }
         if (use_boxes) {
-          float* d_boxes = ws->dev[20].ReserveAs<float>(static_cast<size_t>(blocks) * max_chunks * 6);
-          Rt3DChunkBoxKernel<<<dim3(blocks, 8), 256, 0, ws->stream>>>(
-              BG, TG.sorted_xyz, TG.chunks, TG.num_chunks, rot_per_block, d_boxes);
-          TP.boxes = d_boxes;
+          // (the chunk boxes of the list passes: the candidate chunk list under list_rotations
+          // rotations -- the sparse group pass and the candidate passes share them)
+          d_list_boxes = ws->dev[21].ReserveAs<float>(static_cast<size_t>(num_lists) * max_chunks * 6);
+          Rt3DChunkBoxKernel<<<dim3(num_lists, 8), 256, 0, ws->stream>>>(
+              BG, TG.sorted_xyz, TG.chunks + max_chunks, TG.num_chunks + 1, list_rotations, d_list_boxes);
         }
-        Rt3DTileKernel<true><<<dim3(blocks, slices), threads, lds, ws->stream>>>(BG, TP);
-        Rt3DSumBoundsKernel<<<DivUp(RG, 256), 256, 0, ws->stream>>>(BG);
+        if (rotblocks) {
+          // ---- blocks of 2 x 2 x 2 rotations x groups: the same kernel over the centre rotations
+          // and the twice-dilated brick --------------------------------------------------------
+          uint8_t* d_dilated2 = ws->dev[26].ReserveAs<uint8_t>(cells);
+          DilateXKernel<<<DivUp(cells, 256), 256, 0, ws->stream>>>(d_dilated, d_tmp,
+                                                                   static_cast<int>(bx), cells);
+          DilateYZKernel<<<DivUp(cells, 256), 256, 0, ws->stream>>>(
+              d_tmp, d_dilated2, static_cast<int>(bx), static_cast<int>(by), static_cast<int>(bz));
+          const long long RbG = Rb * G;
+          char* d_block = static_cast<char*>(ws->dev[27].Reserve((sizeof(uint2) + sizeof(float)) * RbG + 16));
+          uint2* d_block_sums = reinterpret_cast<uint2*>(d_block);
+          d_block_upper = reinterpret_cast<float*>(d_block + sizeof(uint2) * RbG);
+          d_block_max = reinterpret_cast<unsigned*>(d_block + (sizeof(uint2) + sizeof(float)) * RbG);
+          CMX_HIP(hipMemsetAsync(d_block, 0, (sizeof(uint2) + sizeof(float)) * RbG + 16, ws->stream));
+          d_computed = ws->dev[28].ReserveAs<uint8_t>(2 * RG);
+          CMX_HIP(hipMemsetAsync(d_computed, 0, 2 * RG, ws->stream));
+          Rt3DBulkParams BS = BG;
+          BS.cells = d_dilated2;
+          BS.num_rotations = static_cast<int>(Rb);
+          BS.rotation = d_rot_b; BS.rotation_angle = d_angle_b;
+          BS.upper = d_block_upper; BS.sums = d_block_sums; BS.max_upper_bits = d_block_max;
+          Rt3DTileParams TB = TP;
+          TB.seg_bounds = nullptr; TB.seg_sums = nullptr; TB.seg_first = 0; TB.seg_last = 2;
+          const int blocks_b = DivUp(Rb, rot_per_block);
+          const int slices_b = std::max(1, std::min(max_chunks, DivUp(8 * cus, blocks_b)));
+          if (use_boxes) {
+            float* d_boxes = ws->dev[20].ReserveAs<float>(static_cast<size_t>(blocks_b) * max_chunks * 6);
+            Rt3DChunkBoxKernel<<<dim3(blocks_b, 8), 256, 0, ws->stream>>>(
+                BS, TG.sorted_xyz, TG.chunks, TG.num_chunks, rot_per_block, d_boxes);
+            TB.boxes = d_boxes;
+          }
+          Rt3DTileKernel<true, false><<<dim3(blocks_b, slices_b), threads, lds, ws->stream>>>(BS, TB);
+          Rt3DSumBoundsKernel<<<DivUp(RbG, 256), 256, 0, ws->stream>>>(BS);
+          trace.Mark("rotation blocks");
+          // ---- the group pass proper over the pairs a threshold cannot exclude -----------------
+          const int pair_items = 512;
+          Rt3DBulkParams BQ = BG;                // (sums, upper, group table, once-dilated brick)
+          BQ.counts = d_counts; BQ.items = d_items; BQ.blocks = d_blocks;
+          BQ.list_rotations = list_rotations; BQ.block_items = pair_items;
+          Rt3DTileParams TQ = TP;
+          TQ.chunks = TG.chunks + max_chunks;    // the candidate pass's chunk list (256 points)
+          TQ.num_chunks = TG.num_chunks + 1;
+          TQ.block_items = pair_items;
+          TQ.boxes = d_list_boxes;
+          if (staged) TQ.seg_bounds = d_segment_counts + 4;      // (seg_first .. seg_last, seg_sums: TP's)
+          const size_t lds_q = (sizeof(v2f) * (3 * kTileChunkCandidates / 2 + 2) +
+                                sizeof(uint32_t) * kTileChunkCandidates) * list_rotations +
+                               TQ.tile_capacity + 32;
+          static thread_local size_t opted_pairs = 0;
+          if (lds_q > opted_pairs) {
+            CMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(Rt3DTileKernel<true, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(lds_q)));
+            opted_pairs = lds_q;
+          }
+          int* d_pair_total = d_num_blocks + 3;
+          uint8_t* d_pair_flags = d_computed + RG;
+          const bool check_blocks = verify;
+          run_pairs = [=, &ws](const unsigned* threshold_bits, float factor) {
+            CMX_HIP(hipMemsetAsync(d_num_blocks, 0, sizeof(int), ws->stream));
+            Rt3DSelectPairsKernel<<<DivUp(RG, 256), 256, 0, ws->stream>>>(
+                d_block_upper, G, static_cast<int>(R), side_r, Ab, threshold_bits, factor, d_computed,
+                d_pair_flags);
+            Rt3DCompactKernel<<<num_lists, 256, 0, ws->stream>>>(
+                d_pair_flags, G, static_cast<int>(R), list_rotations, d_counts, d_items, d_pair_total,
+                d_blocks, d_num_blocks, pair_items);
+            CMX_HIP(hipMemcpyAsync(h_num_blocks, d_num_blocks, sizeof(int), hipMemcpyDeviceToHost,
+                                   ws->stream));
+            CMX_HIP(hipMemcpyAsync(h_num_blocks + 4, d_segment_counts, sizeof(int) * 8,
+                                   hipMemcpyDeviceToHost, ws->stream));
+            CMX_HIP(hipStreamSynchronize(ws->stream));
+            const int nbq = *h_num_blocks;
+            const int list_chunks = h_num_blocks[4 + 1];         // chunks of the candidate list
+            if (nbq > 0 && list_chunks > 0) {
+              const int slices_q = std::max(1, std::min(list_chunks, DivUp(8 * cus, nbq)));
+              Rt3DTileKernel<true, true><<<dim3(nbq, slices_q), pair_items, lds_q, ws->stream>>>(BQ, TQ);
+            }
+            Rt3DSumBoundsMaskedKernel<<<DivUp(RG, 256), 256, 0, ws->stream>>>(BG, d_computed);
+            if (check_blocks)
+              Rt3DVerifyBlocksKernel<<<DivUp(RG, 256), 256, 0, ws->stream>>>(
+                  d_block_upper, d_group_upper, d_computed, G, static_cast<int>(R), side_r, Ab,
+                  d_violations);
+          };
+          // first round: the pairs of the blocks next to the best block bound (all of them when
+          // every group is to be expanded: rt3d_expand_all)
+          const int permille = Debug().rt3d_rotblock_permille;
+          run_pairs(d_block_max, Debug().rt3d_expand_all ? 0.f : permille > 0 ? std::min(permille, 1000) * 1e-3f : 0.97f);
+        } else {
+          if (use_boxes) {
+            float* d_boxes = ws->dev[20].ReserveAs<float>(static_cast<size_t>(blocks) * max_chunks * 6);
+            Rt3DChunkBoxKernel<<<dim3(blocks, 8), 256, 0, ws->stream>>>(
+                BG, TG.sorted_xyz, TG.chunks, TG.num_chunks, rot_per_block, d_boxes);
+            TP.boxes = d_boxes;
+          }
+          Rt3DTileKernel<true, false><<<dim3(blocks, slices), threads, lds, ws->stream>>>(BG, TP);
+          Rt3DSumBoundsKernel<<<DivUp(RG, 256), 256, 0, ws->stream>>>(BG);
+        }
         if (TG.stats) {
           unsigned long long h[4];
           int chunks_made = 0;
@@ -2096,23 +2318,13 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
       const int block_items =
           !use_tiles ? kCand3DThreads : crosscheck ? 256 : Override(Debug().rt3d_cand_threads, 512);
       BC.block_items = block_items;
-      // (tiled: work lists span several rotations, so that a tile serves some hundred lanes even
-      // when a rotation keeps only a few dozen candidates)
-      const int list_rotations =
-          use_tiles && !crosscheck ? std::max(1, std::min(8, Override(Debug().rt3d_cand_rotations, 8))) : 1;
-      const int num_lists = DivUp(R, list_rotations);
       BC.list_rotations = list_rotations;
       if (use_tiles) {
         span_of(trans, &TC);
         TC.chunks = TG.chunks + max_chunks;                        // the candidate pass's own list
         TC.num_chunks = TG.num_chunks + 1;
         TC.rotations_per_block = 1;
-        if (use_boxes) {
-          float* d_boxes = ws->dev[21].ReserveAs<float>(static_cast<size_t>(num_lists) * max_chunks * 6);
-          Rt3DChunkBoxKernel<<<dim3(num_lists, 8), 256, 0, ws->stream>>>(
-                  BC, TG.sorted_xyz, TC.chunks, TC.num_chunks, list_rotations, d_boxes);
-          TC.boxes = d_boxes;
-        }
+        TC.boxes = d_list_boxes;                        // (computed before the group pass)
         TC.tile_capacity = Override(Debug().rt3d_cand_tile_kb, 48) * 1024;
         TC.block_items = block_items;
         BC.cells = d_bulk;                              // the row-major q brick
@@ -2126,7 +2338,16 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
       // first round, so every group bound is checked against every one of its members.
       const float first_round_factor = Debug().rt3d_expand_all ? 0.f : 0.97f;
       for (int round = 0; round < 2; ++round) {
-        CMX_HIP(hipMemsetAsync(d_num_blocks, 0, sizeof(int) * (round == 0 ? 2 : 1), ws->stream));
+        CMX_HIP(hipMemsetAsync(d_num_blocks, 0, sizeof(int), ws->stream));
+        if (round == 1 && rotblocks) {
+          // the pairs of every rotation block the lower bound of round 0 cannot exclude
+          CMX_HIP(hipEventRecord(ws->ev_x0, ws->stream));
+          run_pairs(d_max_lower, 1.f);
+          CMX_HIP(hipEventRecord(ws->ev_x1, ws->stream));
+          second_pairs_pass = true;
+          CMX_HIP(hipMemsetAsync(d_num_blocks, 0, sizeof(int), ws->stream));
+          trace.Mark("group pass 2 (pairs)");
+        }
         Rt3DSelectGroupsKernel<<<DivUp(RG, 256), 256, 0, ws->stream>>>(
             d_group_upper, G, static_cast<int>(R), side_t, gpa,
             round == 0 ? d_max_upper : d_max_lower, round == 0 ? first_round_factor : 1.f, d_expanded,
@@ -2149,7 +2370,7 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
                              TC.tile_capacity + 32;
           static thread_local size_t opted_candidates = 0;
           if (lds > opted_candidates) {
-            CMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(Rt3DTileKernel<false>),
+            CMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(Rt3DTileKernel<false, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize,
                                         static_cast<int>(lds)));
             opted_candidates = lds;
@@ -2176,7 +2397,7 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
                                                           : h_segments[1] - h_segments[5];
               if (seg_chunks > 0) {
                 const int slices = std::max(1, std::min(seg_chunks, DivUp(8 * cus, live)));
-                Rt3DTileKernel<false><<<dim3(live, slices), block_items, lds, ws->stream>>>(BC, TS);
+                Rt3DTileKernel<false, true><<<dim3(live, slices), block_items, lds, ws->stream>>>(BC, TS);
               }
               if (stage == 2) break;
               Rt3DStageFilterKernel<<<live, block_items, 0, ws->stream>>>(
@@ -2206,7 +2427,7 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
             continue;
           }
           const int slices = std::max(1, std::min(max_chunks, DivUp(8 * cus, nb)));
-          Rt3DTileKernel<false><<<dim3(nb, slices), block_items, lds, ws->stream>>>(BC, TC);
+          Rt3DTileKernel<false, true><<<dim3(nb, slices), block_items, lds, ws->stream>>>(BC, TC);
           if (crosscheck) {
             // the same work lists on the gather kernel, into a second (Q, A) array
             Rt3DBulkParams B2 = BC;
@@ -2255,6 +2476,8 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
       CMX_HIP(hipGetLastError());
       CMX_HIP(hipEventRecord(ws->ev_end, ws->stream));
       CMX_HIP(hipMemcpyAsync(h_bmisc, d_bmisc, head_bytes, hipMemcpyDeviceToHost, ws->stream));
+      CMX_HIP(hipMemcpyAsync(h_num_blocks + 12, d_num_blocks + 3, sizeof(int), hipMemcpyDeviceToHost,
+                             ws->stream));          // (rotation blocks: pairs that went through the group pass)
       CMX_HIP(hipStreamSynchronize(ws->stream));
       trace.Report();
       const int count = *reinterpret_cast<int*>(h_bmisc + 4);
@@ -2277,7 +2500,7 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
                 "[cmx] rt3d: group pass %.3f ms (%lld bounds), %d of %lld candidates scored, "
                 "%d finalists, best lower %.6f, best group upper %.6f, work blocks %d + %d "
                 "(staged: %d after a quarter of the points, %d after half), device %.3f ms\n",
-                ms, RG, total_items, num_candidates, count, lo_f, up_f, round_blocks[0],
+                ms, rotblocks ? Rb * G + h_num_blocks[12] : RG, total_items, num_candidates, count, lo_f, up_f, round_blocks[0],
                 round_blocks[1], stage_blocks[0], stage_blocks[1], all);
       }
       if (count >= 1 && count <= kBulkFinalistCap) {
@@ -2294,7 +2517,8 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
         acc.resize(count);
         for (int i = 0; i < count; ++i) { finalists[i] = pairs[i].first; acc[i] = pairs[i].second; }
         num_finalists = count;
-        bounds_evaluated = RG + total_items;
+        group_bounds = rotblocks ? Rb * G + h_num_blocks[12] : RG;
+        bounds_evaluated = group_bounds + total_items;
         done = true;
       }
       // else: a flat score landscape -- every candidate on the per-candidate kernel below.
@@ -2365,6 +2589,15 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
       st.device_ms = ms;
       CMX_HIP(hipEventElapsedTime(&ms, ws->ev_k0, ws->ev_k1));
       st.dominant_kernel_ms = ms;
+      // the bounds above the candidates (rotation blocks, then the (rotation, group) pairs they
+      // leave): how many, their lookups, and the time of ALL their passes
+      st.expansion_nodes = group_bounds;
+      st.expansion_lookups = group_bounds * n;
+      st.expansion_ms = ms;
+      if (second_pairs_pass) {
+        CMX_HIP(hipEventElapsedTime(&ms, ws->ev_x0, ws->ev_x1));
+        st.expansion_ms += ms;
+      }
       *stats = st;
     }
   });

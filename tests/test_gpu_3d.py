@@ -354,13 +354,21 @@ def test_rt3d_bulk_pass_equals_per_candidate_kernel(sm3, oracle, synth, case, de
     # "staged": the shipped configuration under rt3d_verify (second candidate round by point
     # segments: every intermediate bound checked against the candidate's final sum);
     # "shipped": the same without the verification mode (candidates really leave the lists)
-    for bulk in ("tiles", "fixed", "staged", "shipped", "1", "0"):
+    # Since round 4 "fixed" / "staged" / "shipped" include the rotation-block level above the
+    # group pass ("fixed": every (rotation, group) pair computed and every block bound checked
+    # against all of its pairs' bounds; "staged": the pairs the thresholds keep); "dense": the
+    # group pass over all pairs as before; "best_block": the first group round takes only the
+    # pairs of the best block.
+    for bulk in ("tiles", "fixed", "staged", "shipped", "dense", "best_block", "1", "0"):
         _lib.debug_reset()
+        tiled = bulk in ("tiles", "fixed", "staged", "shipped", "dense", "best_block")
         debug(rt3d_verify=0 if bulk == "shipped" else 1,     # group bounds checked against member bounds
               rt3d_legacy=1 if bulk == "0" else 0,
-              rt3d_no_tiles=0 if bulk in ("tiles", "fixed", "staged", "shipped") else 1,
+              rt3d_no_tiles=0 if tiled else 1,
               rt3d_crosscheck=1 if bulk == "tiles" else 0,
-              rt3d_expand_all=1 if bulk == "fixed" else 0)
+              rt3d_expand_all=1 if bulk == "fixed" else 0,
+              rt3d_no_rotblocks=1 if bulk == "dense" else 0,
+              rt3d_rotblock_permille=1000 if bulk == "best_block" else 0)
         score, pose = m.match(rigid, cloud, 0.1, vox)
         got[bulk] = (np.float32(score), _pose7(pose), dict(m.last_stats))
         assert m.last_stats["candidates_scored"] == ref["num_candidates"]

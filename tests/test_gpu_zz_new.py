@@ -545,11 +545,18 @@ def _rt3d_against_golden(synth, d, g, debug, bulk):
     # with every group expanded so that VERIFY compares every group bound with all its members
     # "shipped": exactly what a caller gets (no verification mode: the staged second round
     # really drops candidates from its work lists); "unstaged": the same without the stages
+    # Round 4: "fixed" / "fixed-all" / "shipped" / "unstaged" run the rotation-block level above
+    # the group pass (verification: every computed (rotation, group) bound against its block's;
+    # "fixed-all" computes and checks every pair); "dense": the group pass over all pairs, verified;
+    # "dense-shipped": that without verification
+    debug(rt3d_verify=0 if bulk in ("shipped", "unstaged", "dense-shipped") else 1)
     debug(rt3d_legacy=1 if bulk == "0" else 0,
-          rt3d_no_tiles=0 if bulk in ("tiles", "fixed", "fixed-all", "shipped", "unstaged") else 1,
+          rt3d_no_tiles=0 if bulk in ("tiles", "fixed", "fixed-all", "shipped", "unstaged", "dense",
+                                      "dense-shipped") else 1,
           rt3d_unstaged=1 if bulk == "unstaged" else 0,
           rt3d_crosscheck=1 if bulk == "tiles" else 0,
-          rt3d_expand_all=1 if bulk == "fixed-all" else 0)
+          rt3d_expand_all=1 if bulk == "fixed-all" else 0,
+          rt3d_no_rotblocks=1 if bulk in ("dense", "dense-shipped") else 0)
     m = sm3.RealTimeCorrelativeScanMatcher3D(d["lin"], d["ang"], d["tw"], d["rw"])
     score, pose = m.match(sm3.Rigid3d(tuple(d["init"][:3]), tuple(d["init"][3:])), d["cloud"],
                           d["res"], d["vox"])
@@ -559,7 +566,8 @@ def _rt3d_against_golden(synth, d, g, debug, bulk):
     return m.last_stats
 
 
-@pytest.mark.parametrize("bulk", ["tiles", "fixed", "fixed-all", "shipped", "unstaged", "1", "0"])
+@pytest.mark.parametrize("bulk", ["tiles", "fixed", "fixed-all", "shipped", "unstaged", "dense",
+                                  "dense-shipped", "1", "0"])
 def test_rt3d_c4_shaped_equals_the_reference(synth, golden_c4, debug, bulk):
     """C4's shape at 4096 points: L = 5 -> 6^3 = 216 groups of 2x2x2 translations per rotation
     (the flat 192-lane group mapping of rt_3d.hip spans rotations), A = 3 -> 343 rotations, a
@@ -573,7 +581,7 @@ def test_rt3d_c4_shaped_equals_the_reference(synth, golden_c4, debug, bulk):
         assert st["coarse_candidates"] < st["candidates_scored"]      # bounds did exclude
 
 
-@pytest.mark.parametrize("bulk", ["tiles", "fixed", "shipped", "unstaged", "1", "0"])
+@pytest.mark.parametrize("bulk", ["tiles", "fixed", "shipped", "unstaged", "dense", "1", "0"])
 def test_rt3d_c4_at_its_baseline_window_equals_the_reference(synth, golden_c4, debug, bulk):
     """BASELINE config[3] exactly as bench.py times it (65 536 points, 150^3 grid, +-0.5 m /
     +-2 deg: 1 771 561 candidates) against the reference's own
