@@ -634,6 +634,7 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
   // Debug switch host_trace: wall clock of the host phases (tools only).
   const bool host_trace = Debug().host_trace != 0;
   auto t_last = std::chrono::steady_clock::now();
+  const auto t_call = t_last;
   std::string host_report;
   const auto lap = [&](const char* name) {
     if (!host_trace) return;
@@ -663,7 +664,7 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
   std::vector<Rt2DSearch> search(num);
   lap("args");
   const auto plan_search = [&](int begin, int end) {
-    ParallelFor(end - begin, 16,
+    ParallelFor(end - begin, 4096,          // (0.03 us per match; a pool dispatch costs ~25 us)
                 [&](int k) { Rt2DComputeSearch(options, items[begin + k], &search[begin + k]); });
     for (int m = begin; m < end; ++m) {
       const Rt2DSearch& sr = search[m];
@@ -679,46 +680,81 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
     Rt2DLegacyBatch(options, items, search.data(), num, device, stats);
     return;
   }
-  // A large batch goes out in parts (debug switch rt2d_parts), each with its own workspace and
-  // stream and each from a host thread of its own (the caller and pool workers): planning,
-  // upload and the launches of one part (~0.1 ms of host time: half of it launch calls) run
-  // beside those of the others, and the latency-bound kernels at the two ends of a part (prep,
-  // finish) run under the tile kernels of the other parts.  Not when the caller ordered the work
-  // on a stream of its own (cmx_set_stream is per thread).
-  int parts = Debug().rt2d_parts > 0 ? std::min(16, Debug().rt2d_parts)
-                                      : (num >= 1024 ? 8 : num >= 256 ? 4 : 2);
-  parts = std::max(1, std::min(parts, num / 32));              // (at least 32 matches per part)
-  if (OverrideStream(device) != nullptr) parts = 1;
+  // A large batch goes out in PARTS, each with its own workspace and stream, all from the calling
+  // thread: part k is planned, uploaded and launched while the kernels of the parts before it run,
+  // then the parts are collected in order (the finalisation of one under the kernels of the next).
+  // The first part is small, so that the device starts after ~40 us of host time, the following
+  // ones grow by half: the host prepares a match in ~0.2 us, the device needs ~0.35 us for it.
+  // (Until round 4 the parts ran on pool threads: a dispatch to the pool costs ~25 us, a cold
+  // worker ran its part three times slower than the caller, and eight streams share four hardware
+  // queues -- the second four parts waited for the first four.)  One part when the caller ordered
+  // the work on a stream of its own (cmx_set_stream is per thread).
+  std::vector<int> part_end;
+  if (OverrideStream(device) != nullptr) {
+    part_end.push_back(num);
+  } else if (Debug().rt2d_parts > 0) {
+    const int parts = std::max(1, std::min(std::min(16, Debug().rt2d_parts), num / 32));
+    for (int h = 0; h < parts; ++h)
+      part_end.push_back(static_cast<int>(static_cast<long long>(num) * (h + 1) / parts));
+  } else {
+    int size = 128, at = 0;
+    while (num - at > size + 96) {
+      at += size;
+      part_end.push_back(at);
+      size = std::min(512, (size * 3 / 2 + 63) / 64 * 64);
+    }
+    part_end.push_back(num);
+  }
+  const int parts = static_cast<int>(part_end.size());
   struct Part {
     int begin, end;
+    std::unique_ptr<Rt2DTileCall> call;
+    bool enqueued = false;
     cmx_match_stats stats{};
     cmx_status status = CMX_OK;
     std::string error;
   };
   std::vector<Part> part(parts);
-  const auto run_part = [&](int h) {
+  const auto since_call = [&]() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count();
+  };
+  for (int h = 0; h < parts; ++h) {
     Part& p = part[h];
-    p.begin = static_cast<int>(static_cast<long long>(num) * h / parts);
-    p.end = static_cast<int>(static_cast<long long>(num) * (h + 1) / parts);
+    p.begin = h ? part_end[h - 1] : 0;
+    p.end = part_end[h];
     p.status = Guard([&] {
-      (void)hipSetDevice(device);                            // (pool threads: their own current device)
+      const double t0 = since_call();
       plan_search(p.begin, p.end);
-      Rt2DTileCall call(options, items + p.begin, search.data() + p.begin, p.end - p.begin, device);
-      bool done = call.Plan();
-      if (done) {
-        call.Enqueue();
-        done = call.Collect(&p.stats);
+      const double t_search = since_call();
+      p.call.reset(new Rt2DTileCall(options, items + p.begin, search.data() + p.begin, p.end - p.begin, device));
+      const bool eligible = p.call->Plan();
+      const double t_plan = since_call();
+      if (eligible) {
+        p.call->Enqueue();
+        p.enqueued = true;
       }
+      if (host_trace)
+        fprintf(stderr, "[cmx host] rt2d part %d (%d matches), us since the call's start: begins %.0f, search "
+                        "%.0f, plan %.0f, enqueued %.0f\n", h, p.end - p.begin, t0, t_search, t_plan, since_call());
+    });
+    if (p.status != CMX_OK) p.error = LastError();
+  }
+  for (int h = 0; h < parts; ++h) {
+    Part& p = part[h];
+    if (p.status != CMX_OK) continue;
+    p.status = Guard([&] {
+      const bool done = p.enqueued && p.call->Collect(&p.stats);
       // (not eligible, a flat score landscape, a point outside the predicted box: the part runs
       // on the per-candidate kernels)
       if (!done)
         Rt2DLegacyBatch(options, items + p.begin, search.data() + p.begin, p.end - p.begin, device,
                         &p.stats);
+      if (host_trace)
+        fprintf(stderr, "[cmx host] rt2d part %d collected %.0f us since the call's start\n", h, since_call());
     });
-    if (p.status != CMX_OK) p.error = LastError();           // (the message is per thread)
-  };
-  if (parts == 1) run_part(0);
-  else ParallelFor(parts, 0, run_part);
+    if (p.status != CMX_OK) p.error = LastError();
+    p.call.reset();
+  }
   lap("parts");
   cmx_match_stats total{};
   for (int h = 0; h < parts; ++h) {

@@ -16,7 +16,10 @@ constexpr int kRt2DMaxPoints = 8192;        // points per scan the tile path tak
 constexpr int kFinalistCap = 4096;
 constexpr int kFinalistHead = 62;           // 2 + 2 * 62 words = 512 bytes per match
 constexpr int kMaxRowsPerLane = 8;
-constexpr int kPairTaskIters = 64;          // iterations (entries per stream) of one task
+#ifndef CMX_RT2D_TASK_ITERS
+#define CMX_RT2D_TASK_ITERS 64
+#endif
+constexpr int kPairTaskIters = CMX_RT2D_TASK_ITERS;          // iterations (entries per stream) of one task
 
 // Slack of a score bound for the rounding of the reference's N-term f32 chain: the chain's
 // result differs from the real sum of the N probabilities (each <= 0.9, each rounded by the

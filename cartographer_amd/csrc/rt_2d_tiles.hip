@@ -35,6 +35,7 @@
 // on the grid.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -49,7 +50,10 @@ namespace {
 constexpr int kTileMaxThreads = 1024;        // a tile workgroup: 1024 threads alone on a CU (one tile
                                             // per match), or 512 with two per CU (several tiles)
 constexpr int kFinishThreads = 512;
-constexpr int kFusedIdleWaves = 1;           // (wavefront 0 lays out the lists and builds the tasks instead)
+#ifndef CMX_RT2D_JOB_CHUNKS
+#define CMX_RT2D_JOB_CHUNKS 8
+#endif
+constexpr int kJobChunks = CMX_RT2D_JOB_CHUNKS;                // chunks of 64 points of one rotation a wavefront discretises in one job
 constexpr int kFusedMaxPoints = 2048;        // (clouds beyond: the prep kernel, more rotations per workgroup)
 constexpr int kMaxTiles = 16;               // tiles of a match's bounding box (x 4 phases = 64 keys)
 constexpr int kStage1Cap = 1024;            // candidates the exact integer pass takes per match
@@ -711,7 +715,9 @@ Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict
   const int tile = item.y, g = item.z, G = item.w;
   const int side = 2 * P.nl + 1, cands = side * side;
   const int B = P.B, H = P.H, lp = P.lp;
-  const int rw = (P.num_scans - g + G - 1) / G;          // rotations g, g + G, ... of this item
+  // rotations g, g + G, ... of this item.  Tiled matches: all of them fit the workgroup's LDS (the
+  // planner's G >= gmin); one tile per match: taken in ROUNDS of P.rw rotations.
+  const int rw = (P.num_scans - g + G - 1) / G;
   // (in-kernel timeline of the profiling tools: compiled in only for the instrumented
   // instantiation the debug switch `timeline` selects; slots = workgroup x its first items)
   const auto stamp = [&](int k) {
@@ -725,14 +731,13 @@ Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict
   int* hdrs = acc + ((P.rw * cands + 3) & ~3);           // [rw][4] start | count << 16 of this tile
   int* slot = hdrs + P.rw * 4;                           // [rw + 1] cumulative list lengths
   int* tasks = slot + ((P.rw + 1 + 3) & ~3);             // [task_cap][4]
-  int* ctl = tasks + P.task_cap * 4;                     // [0] tasks, [1] next task, [2] round end
-  // (fused: + bases[rw][4] | rots[rw] | ax[n_pad] ay[n_pad] before the lists)
+  int* ctl = tasks + P.task_cap * 4;                     // [0] tasks, [1] next task, [2] next job, [4] ticket
+  // (fused: + rots[num_scans] | ax[n_pad] ay[n_pad] before the lists)
   const bool fused = P.fused != 0;
   const int pchunks = P.n_pad >> 6;
-  int* bases = ctl + 16;                                 // fused, [rw][4]: the cursors of the phase lists
-  float2* rots = reinterpret_cast<float2*>(bases + (fused ? P.rw * 4 : 0));
-  float* ax = reinterpret_cast<float*>(rots + (fused ? (P.rw + 1) & ~1 : 0));   // the cloud rotated by
-  float* ay = ax + (fused ? P.n_pad : 0);                                       // the initial yaw
+  float2* rots = reinterpret_cast<float2*>(ctl + 16);
+  float* ax = reinterpret_cast<float*>(rots + (fused ? (P.num_scans + 1) & ~1 : 0));   // the cloud rotated by
+  float* ay = ax + (fused ? P.n_pad : 0);                                              // the initial yaw
   uint16_t* list = reinterpret_cast<uint16_t*>(ay + (fused ? P.n_pad : 0));
 
   if (fused) {
@@ -746,7 +751,6 @@ Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict
       ay[i] = y;
     }
     if (tid < rw) rots[tid] = rot_mine;
-    if (tid < rw * 4) hdrs[tid] = 0;                     // (counts first, start | count << 16 below)
   }
   // ---- the tile's image: th_img rows of the quantised grid image + rpl * H rows of zeros,
   // LDS-DMA with one row piece (16 bytes) per lane.  The first piece of the grid image is halo
@@ -772,85 +776,6 @@ Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict
   };
   issue_image_copy();
   stamp(1);                                              // image DMA issued
-  for (int i = tid; i < rw * cands; i += num_threads) acc[i] = 0;
-  const int wave_chunks = rw * pchunks;
-  const int cw = wave - kFusedIdleWaves, compute_waves = num_waves - kFusedIdleWaves;
-  if (fused) {
-    // ---- one tile per match: the rotations of this item are discretised HERE (what the prep
-    // kernel does for tiled matches: same cells, same entries), from the cloud in LDS.  A chunk =
-    // 64 consecutive points of one rotation.  ~100 vector instructions per point and rotation:
-    // 4 us per pass for C1's seven rotations of 891 points on one CU -- the price of having no
-    // prep launch and no lists in HBM (measured equal on the wall for 128 matches, 10 us less
-    // for a single one: profiles/r04_c1_fused_prep.txt) -------------------------------------
-    LdsBarrier();                                        // (not __syncthreads: the copy stays in flight)
-    // pass 1 of 2: the sizes of the phase lists.  (The entries are computed again in pass 2 rather
-    // than kept: nine chunks of registers a wavefront, live across the layout step, spilled -- and
-    // scratch accesses queue behind the image copy like any other load.)
-    bool outside = false;
-    if (cw >= 0) {
-      // (everything the loop needs in registers: P lives in LDS, and every field read would be a
-      // round trip of its own behind the atomics)
-      const Rt2DFrame F = FrameOf(P);
-      const int n_pts = P.n, off_x = P.hl - P.nl - P.box_x0, off_y = P.ht - P.nl - P.box_y0, T = P.T;
-      int rr = cw / pchunks, pc = cw - rr * pchunks;     // chunk cw + j * compute_waves, incrementally
-#pragma unroll 1
-      for (int chunk = cw; chunk < wave_chunks; chunk += compute_waves) {
-        const int i = pc * 64 + lane;
-        int phase = -1;
-        if (i < n_pts) {
-          const float2 rot = rots[rr];
-          int ix, iy;
-          Rt2DCellOfPrerotated(F, rot.x, rot.y, ax[i], ay[i], &ix, &iy);
-          const int rx = ix + off_x, ry = iy + off_y;
-          if (rx < 0 || ry < 0 || rx >= T || ry >= T) outside = true;         // (never: the host's box)
-          else phase = rx & 3;
-        }
-        const int c0 = __popcll(__ballot(phase == 0)), c1 = __popcll(__ballot(phase == 1));
-        const int c2 = __popcll(__ballot(phase == 2)), c3 = __popcll(__ballot(phase == 3));
-        if (lane < 4) atomicAdd(&hdrs[rr * 4 + lane], lane == 0 ? c0 : lane == 1 ? c1 : lane == 2 ? c2 : c3);
-        pc += compute_waves;
-        while (pc >= pchunks) { pc -= pchunks; ++rr; }
-      }
-    }
-    if (outside) atomicOr(&P.misc[0], kOutOfBox);
-    LdsBarrier();
-    if (wave == 0) {                   // per rotation: phase starts (lists padded to 16 entries)
-      const int rr = lane;
-      int len = 0;
-      if (rr < rw) {
-#pragma unroll
-        for (int ph = 0; ph < 4; ++ph) {
-          const int c = hdrs[rr * 4 + ph];
-          hdrs[rr * 4 + ph] = len | (c << 16);
-          len += (c + 15) & ~15;
-        }
-      }
-      const int incl = WaveInclusiveScan(len);
-      if (rr < rw) {
-        slot[rr + 1] = incl;
-#pragma unroll
-        for (int ph = 0; ph < 4; ++ph) bases[rr * 4 + ph] = incl - len + (hdrs[rr * 4 + ph] & 0xffff);
-      }
-      if (lane == 0) slot[0] = 0;
-    }
-  } else {
-    if (tid < rw * 4) {
-      const int rr = tid >> 2, ph = tid & 3;
-      hdrs[tid] = static_cast<int>(P.hdr[static_cast<size_t>(g + rr * G) * nkeys + tile * 4 + ph]);
-    }
-    __syncthreads();
-    if (wave == 0) {                   // cumulative (padded) list lengths of this tile's rotations
-      const int rr = lane;
-      int len = 0;
-      if (rr < rw) {
-#pragma unroll
-        for (int ph = 0; ph < 4; ++ph) len += ((hdrs[rr * 4 + ph] >> 16) + 15) & ~15;
-      }
-      const int incl = WaveInclusiveScan(len);
-      if (rr < rw) slot[rr + 1] = incl;
-      if (lane == 0) slot[0] = 0;
-    }
-  }
   const int lds_image = static_cast<int>(reinterpret_cast<uintptr_t>(
       (const __attribute__((address_space(3))) unsigned char*)tile_smem));
   // Lane geometry inside a half-wavefront.
@@ -860,7 +785,237 @@ Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict
   // (lanes beyond H * B read the image's first rows like everyone else and drop the result)
   const int lane_off = lds_image + (lane_used ? row * lp + blk * 8 : 0);
   const int row_stride = H * lp;
-  if (fused) LdsBarrier(); else __syncthreads();
+  // ---- the window tasks of a round, dealt dynamically: the halves of a wavefront run two phases --
+  const auto run_tasks = [&](int num_tasks) {
+    for (;;) {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(&ctl[1], 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= num_tasks) break;
+      const int d0 = tasks[4 * t], d3 = tasks[4 * t + 3];
+      const int rr = d0 & 255;
+      const bool second = lane >= 32;
+      const int phase = second ? (d0 >> 16) & 255 : (d0 >> 8) & 255;
+      const int start = second ? tasks[4 * t + 2] : tasks[4 * t + 1];
+      const int my_len = second ? d3 >> 16 : d3 & 0xffff;
+      const int iters = ((d3 & 0xffff) + 15) & ~15;          // the first stream is the longer
+      uint32_t acc32[RPL][4];
+#pragma unroll
+      for (int j = 0; j < RPL; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc32[j][c] = 0;
+      RowPairAccumulate<RPL, kRowStride>(list + start, my_len, iters, lane, lane_off, row_stride,
+                                         P.null_addr, acc32);
+      if (lane_used) {
+        int* out = acc + rr * cands;
+        const int d0x = blk * 4 - phase;           // candidate x index of the block's first cell
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+          const int wrow = row + j * H;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int dxi = d0x + c;
+            if (wrow < side && dxi >= 0 && dxi < side && acc32[j][c])
+              atomicAdd(&out[dxi * side + wrow], static_cast<int>(acc32[j][c]));
+          }
+        }
+      }
+    }
+  };
+
+  if (fused) {
+    // ---- one tile per match: the rotations of this item are discretised HERE, from the cloud in
+    // LDS (what the prep kernel does for tiled matches: same cells, same entries), in rounds of
+    // P.rw rotations -- the image and the cloud are staged once per item, however many rounds.
+    // A JOB = up to kJobChunks chunks (64 consecutive points each) of one rotation, done by ONE
+    // wavefront in ONE pass: the entries stay in registers while the four phase counts are taken
+    // (ballots: wave-uniform), the job's own fixed region of the list buffer is laid out from them
+    // (sub-lists padded to 16 entries), the entries go to their places (rank by mbcnt: no atomics)
+    // and the job's tasks -- its phases paired by size -- are appended to the round's.
+    // The cell of a point comes from an f32 ESTIMATE of the reference's value
+    //     t = (max - translation) / res - 0.5 - (rotated coordinate) / res
+    // in two FMAs per coordinate; it differs from the f64 value the reference rounds
+    // (GetCellIndex over RotateZ's f32 chain) by less than
+    //     2^-24 [((k_z + 4) (|ax| + |ay|) + |translation|) / res + 3 |K|]
+    // (RotateZ's chain for the rotation (w, z): a (2 + 4 z^2) + b (1 + 6 |w z|) <= k_z r; its sum
+    // with the translation: r + |t|; the estimate's rounded constants and two FMAs: 3 r, 3 |K|),
+    // and when it lies further than 1.25 x that from every half-integer its rounding is the
+    // reference's cell.  Otherwise -- a chunk in forty or so -- the whole chunk runs the exact
+    // expressions (Rt2DCellOfPrerotated).
+    const int rcap = P.rw;
+    const int jpr = (pchunks + kJobChunks - 1) / kJobChunks;          // jobs per rotation
+    const int rot_stride = P.n_pad + 64 * jpr;                        // list entries per rotation
+    const int n_pts = P.n, off_x = P.hl - P.nl - P.box_x0, off_y = P.ht - P.nl - P.box_y0, T = P.T;
+    const int half_pitch = lp >> 1;
+    const int ix_lo = -(P.nl + 1), ix_hi = P.nx + P.nl, iy_hi = P.ny + P.nl;
+    const double inv_res = P.inv_res;
+    const double Kyd = (P.max_y - static_cast<double>(P.ty)) * inv_res - 0.5;
+    const double Kxd = (P.max_x - static_cast<double>(P.tx)) * inv_res - 0.5;
+    const float Ky = static_cast<float>(Kyd), Kx = static_cast<float>(Kxd);
+    // (bound = 1.25 x 2^-24 [((k_z + 4) r + |translation|) / res + 3 |K| + 1], r = |ax| + |ay|,
+    // k_z = max(2 + 4 z^2, 1 + 6 |z|) for the rotation (w, z): the terms of RotateZ's chain)
+    const double bound_unit = 1.25 * 0x1p-24 * inv_res;
+    const float bound_fixed = static_cast<float>(
+        1.25 * 0x1p-24 * (inv_res * fmax(fabs(static_cast<double>(P.tx)), fabs(static_cast<double>(P.ty))) +
+                          3.0 * fmax(fabs(Kxd), fabs(Kyd)) + 1.0));
+    bool outside = false;
+    for (int rbase = 0; rbase < rw; rbase += rcap) {
+      const int rw_round = min(rcap, rw - rbase);
+      // (acc is all zero here: by the loop below in the first round, by the flush afterwards)
+      if (rbase == 0)
+        for (int i = tid; i < rw_round * cands; i += num_threads) acc[i] = 0;
+      if (tid < 3) ctl[tid] = tid == 2 ? num_waves : 0;
+      LdsBarrier();                                        // (not __syncthreads: the copy stays in flight)
+      if (rbase == 0) stamp(2);                            // cloud in LDS
+      const int jobs = rw_round * jpr;
+      // (the first job of a wavefront is its own number, the others are drawn: a job whose chunks
+      // need the exact expressions takes twice as long as one that does not)
+#pragma unroll 1
+      for (int job = wave; job < jobs;
+           job = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(&ctl[2], 1) : 0)) {
+        const int rr = job / jpr, jj = job - rr * jpr;
+        const float2 rot = rots[rbase + rr];
+        const double wd = rot.x, zd = rot.y;
+        const float Ci = static_cast<float>((1.0 - 2.0 * zd * zd) * inv_res);
+        const float Si = static_cast<float>(2.0 * wd * zd * inv_res);
+        const float bound_per_m =
+            static_cast<float>(bound_unit * (4.0 + fmax(2.0 + 4.0 * zd * zd, 1.0 + 6.0 * fabs(zd))));
+        int packed[kJobChunks];
+        unsigned inexact = 0;                                // chunks the estimate could not decide
+        const auto pack = [&](int ix, int iy, bool valid) {
+          const int rx = ix + off_x, ry = iy + off_y;
+          const bool inside = static_cast<unsigned>(rx) < static_cast<unsigned>(T) &&
+                              static_cast<unsigned>(ry) < static_cast<unsigned>(T);
+          if (valid && !inside) outside = true;              // (never: the host's box)
+          // entry << 2 | phase = ((ry lp + (rx & ~3) 2) >> 3) << 2 | (rx & 3) = ry lp / 2 + rx
+          return valid && inside ? ry * half_pitch + rx : -1;
+        };
+#pragma unroll
+        for (int c = 0; c < kJobChunks; ++c) {
+          // (every chunk of the job, without a branch: the chunks beyond the cloud read what lies
+          // behind it in LDS and are masked by i < n)
+          const int i = (jj * kJobChunks + c) * 64 + lane;
+          const float x = ax[i], y = ay[i];
+          const bool valid = i < n_pts;
+          const float tY = fmaf(-Ci, y, fmaf(-Si, x, Ky));   // cell x index from the map's y
+          const float tX = fmaf(-Ci, x, fmaf(Si, y, Kx));
+          const float nY = rintf(tY), nX = rintf(tX);
+          const float margin = fminf(0.5f - fabsf(tY - nY), 0.5f - fabsf(tX - nX));
+          const float bound = fmaf(fabsf(x) + fabsf(y), bound_per_m, bound_fixed);
+          if (__ballot(valid && !(margin > bound))) inexact |= 1u << c;   // (NaN: not greater)
+          const int ix = min(max(static_cast<int>(nY), ix_lo), ix_hi);
+          const int iy = min(max(static_cast<int>(nX), ix_lo), iy_hi);
+          packed[c] = pack(ix, iy, valid);
+        }
+#pragma unroll 1
+        while (inexact) {                                    // (uniform; a chunk in twelve or so)
+          const int c = __builtin_ctz(inexact);
+          inexact &= inexact - 1;
+          const int i = (jj * kJobChunks + c) * 64 + lane;
+          int ix, iy;
+          Rt2DCellOfPrerotated(FrameOf(P), rot.x, rot.y, ax[i], ay[i], &ix, &iy);
+          const int pk = pack(ix, iy, i < n_pts);
+#pragma unroll
+          for (int k = 0; k < kJobChunks; ++k) packed[k] = k == c ? pk : packed[k];
+        }
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+        for (int c = 0; c < kJobChunks; ++c) {
+          const int pk = packed[c];
+          c0 += __popcll(__ballot(pk >= 0 && (pk & 3) == 0));
+          c1 += __popcll(__ballot(pk >= 0 && (pk & 3) == 1));
+          c2 += __popcll(__ballot(pk >= 0 && (pk & 3) == 2));
+          c3 += __popcll(__ballot(pk >= 0 && (pk & 3) == 3));
+        }
+        // the job's region: sub-lists in phase order, each padded to 16 entries
+        const int region = rr * rot_stride + jj * (kJobChunks * 64 + 64);
+        int s0 = region, s1 = s0 + ((c0 + 15) & ~15), s2 = s1 + ((c1 + 15) & ~15),
+            s3 = s2 + ((c2 + 15) & ~15);
+        {
+          // tasks: the four phases by count, descending (sorting network of five exchanges),
+          // paired (1st, 2nd), (3rd, 4th); a task = at most kPairTaskIters entries of each
+          int key[4] = {(c0 << 2) | 0, (c1 << 2) | 1, (c2 << 2) | 2, (c3 << 2) | 3};
+#define CMX_CSWAP(I, J) { const int hi_k = max(key[I], key[J]), lo_k = min(key[I], key[J]); key[I] = hi_k; key[J] = lo_k; }
+          CMX_CSWAP(0, 1) CMX_CSWAP(2, 3) CMX_CSWAP(0, 2) CMX_CSWAP(1, 3) CMX_CSWAP(1, 2)
+#undef CMX_CSWAP
+          const int nA = ((key[0] >> 2) + kPairTaskIters - 1) / kPairTaskIters;
+          const int nB = ((key[2] >> 2) + kPairTaskIters - 1) / kPairTaskIters;
+          int t0 = 0;
+          if (lane == 0) t0 = atomicAdd(&ctl[0], nA + nB);
+          t0 = __builtin_amdgcn_readfirstlane(t0);
+          if (lane < nA + nB) {
+            const bool second = lane >= nA;
+            const int off = (lane - (second ? nA : 0)) * kPairTaskIters;
+            const int ka = second ? key[2] : key[0], kb = second ? key[3] : key[1];
+            const int pa = ka & 3, pb = kb & 3, la = ka >> 2, lb = kb >> 2;
+            const int sa = pa == 0 ? s0 : pa == 1 ? s1 : pa == 2 ? s2 : s3;
+            const int sb = pb == 0 ? s0 : pb == 1 ? s1 : pb == 2 ? s2 : s3;
+            reinterpret_cast<int4*>(tasks)[t0 + lane] =
+                make_int4(rr | (pa << 8) | (pb << 16), sa + off, sb + off,
+                          min(kPairTaskIters, la - off) | (max(0, min(kPairTaskIters, lb - off)) << 16));
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < kJobChunks; ++c) {
+          const int pk = packed[c];
+          const int ph = pk & 3;
+          const unsigned long long m0 = __ballot(pk >= 0 && ph == 0);
+          const unsigned long long m1 = __ballot(pk >= 0 && ph == 1);
+          const unsigned long long m2 = __ballot(pk >= 0 && ph == 2);
+          const unsigned long long m3 = __ballot(pk >= 0 && ph == 3);
+          const unsigned long long mine = ph == 0 ? m0 : ph == 1 ? m1 : ph == 2 ? m2 : m3;
+          const int at = ph == 0 ? s0 : ph == 1 ? s1 : ph == 2 ? s2 : s3;
+          const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mine >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mine), 0));
+          if (pk >= 0) list[at + rank] = static_cast<uint16_t>(pk >> 2);
+          s0 += __popcll(m0); s1 += __popcll(m1); s2 += __popcll(m2); s3 += __popcll(m3);
+        }
+      }
+      if (rbase == 0) {
+        stamp(4);                                            // this wave's jobs done
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the image has landed
+        if (tid == 0) ctl[4] = ticket;                       // (the ticket arrived with that wait)
+      }
+      LdsBarrier();
+      if (rbase == 0) {
+        stamp(5);                                            // image landed
+        if (tid < work_stride) {
+          const int t = ctl[4];
+          next = t < num_items ? work[t * work_stride + tid] : make_int4(-1, 0, 0, 0);
+        }
+      }
+      run_tasks(ctl[0]);                                     // <= task_cap by construction (host)
+      if (rbase == 0) stamp(6);                              // wave 0 out of tasks (first round)
+      LdsBarrier();
+      // ---- this round's sums (plain stores: the match's only tile), the accumulators zeroed for
+      // the next round ---------------------------------------------------------------------------
+      for (int e = tid; e < rw_round * cands; e += num_threads) {
+        const int rr = e / cands, c = e - rr * cands;
+        AsGlobal(P.qsum)[static_cast<size_t>(g + (rbase + rr) * G) * cands + c] = acc[e];
+        acc[e] = 0;
+      }
+    }
+    if (outside) atomicOr(&P.misc[0], kOutOfBox);
+    stamp(7);
+  } else {
+  for (int i = tid; i < rw * cands; i += num_threads) acc[i] = 0;
+  if (tid < rw * 4) {
+    const int rr = tid >> 2, ph = tid & 3;
+    hdrs[tid] = static_cast<int>(P.hdr[static_cast<size_t>(g + rr * G) * nkeys + tile * 4 + ph]);
+  }
+  __syncthreads();
+  if (wave == 0) {                   // cumulative (padded) list lengths of this tile's rotations
+    const int rr = lane;
+    int len = 0;
+    if (rr < rw) {
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) len += ((hdrs[rr * 4 + ph] >> 16) + 15) & ~15;
+    }
+    const int incl = WaveInclusiveScan(len);
+    if (rr < rw) slot[rr + 1] = incl;
+    if (lane == 0) slot[0] = 0;
+  }
+  __syncthreads();
   stamp(2);                                              // headers, list lengths
 
   // ---- rounds: as many rotations as the LDS list buffer holds ------------------------------
@@ -868,11 +1023,11 @@ Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict
     const int base = slot[rr0];
     int rr1 = rr0 + 1;                                 // (one rotation always fits: host)
     while (rr1 < rw && slot[rr1 + 1] - base <= P.list_lds) ++rr1;
-    if (fused) LdsBarrier(); else __syncthreads();     // the previous round's lists are done with
+    __syncthreads();                                   // the previous round's lists are done with
     if (tid < 2) ctl[tid] = 0;
     // lists: rotation rr's entries of this tile are contiguous in HBM (keys in order)
     // (wavefront 0 builds the round's tasks below while the others copy its lists)
-    for (int rr = rr0 + wave - 1; !fused && wave >= 1 && rr < rr1; rr += num_waves - 1) {
+    for (int rr = rr0 + wave - 1; wave >= 1 && rr < rr1; rr += num_waves - 1) {
       const int first = hdrs[rr * 4] & 0xffff;
       const int len = slot[rr + 1] - slot[rr];
       typedef unsigned U4 __attribute__((ext_vector_type(4)));
@@ -918,52 +1073,6 @@ Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict
         }
       }
     }
-    if (fused) {
-      // ---- the entries from the registers into the phase lists (one round: the host sized the
-      // list buffer for all of this item's rotations) ------------------------------------------
-      // pass 2: the entries into the phase lists; a chunk's place in each list is drawn from the
-      // list's cursor (any order inside a list: the sums are integers)
-      if (cw >= 0) {
-        // (everything the loop needs in registers: P lives in LDS, and every field read would be a
-        // round trip of its own behind the atomics)
-        const Rt2DFrame F = FrameOf(P);
-        const int n_pts = P.n, off_x = P.hl - P.nl - P.box_x0, off_y = P.ht - P.nl - P.box_y0, T = P.T;
-        int rr = cw / pchunks, pc = cw - rr * pchunks;
-#pragma unroll 1
-        for (int chunk = cw; chunk < wave_chunks; chunk += compute_waves) {
-          const int i = pc * 64 + lane;
-          int packed = -1;
-          if (i < n_pts) {
-            const float2 rot = rots[rr];
-            int ix, iy;
-            Rt2DCellOfPrerotated(F, rot.x, rot.y, ax[i], ay[i], &ix, &iy);
-            const int rx = ix + off_x, ry = iy + off_y;
-            if (!(rx < 0 || ry < 0 || rx >= T || ry >= T))
-              packed = (((ry * lp + (rx & ~3) * 2) >> 3) << 2) | (rx & 3);
-          }
-          const int ph = packed & 3;
-          const unsigned long long m0 = __ballot(packed >= 0 && ph == 0);
-          const unsigned long long m1 = __ballot(packed >= 0 && ph == 1);
-          const unsigned long long m2 = __ballot(packed >= 0 && ph == 2);
-          const unsigned long long m3 = __ballot(packed >= 0 && ph == 3);
-          int first = 0;
-          if (lane < 4)
-            first = atomicAdd(&bases[rr * 4 + lane],
-                              __popcll(lane == 0 ? m0 : lane == 1 ? m1 : lane == 2 ? m2 : m3));
-          const int f0 = __builtin_amdgcn_readlane(first, 0), f1 = __builtin_amdgcn_readlane(first, 1);
-          const int f2 = __builtin_amdgcn_readlane(first, 2), f3 = __builtin_amdgcn_readlane(first, 3);
-          if (packed >= 0) {
-            const unsigned long long mine = ph == 0 ? m0 : ph == 1 ? m1 : ph == 2 ? m2 : m3;
-            const int at = ph == 0 ? f0 : ph == 1 ? f1 : ph == 2 ? f2 : f3;
-            const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mine >> 32),
-                                                       __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mine), 0));
-            list[at + rank] = static_cast<uint16_t>(packed >> 2);
-          }
-          pc += compute_waves;
-          while (pc >= pchunks) { pc -= pchunks; ++rr; }
-        }
-      }
-    }
     if (rr0 == 0) stamp(4);                              // tasks built / this wave's lists in LDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the image has landed
     if (rr0 == 0 && tid == 0) ctl[4] = ticket;           // (the ticket arrived with that wait)
@@ -973,42 +1082,7 @@ Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict
       const int t = ctl[4];
       next = t < num_items ? work[t * work_stride + tid] : make_int4(-1, 0, 0, 0);
     }
-    // ---- tasks, dealt dynamically: the halves of a wavefront run two phases ----------------
-    const int num_tasks = ctl[0];          // <= task_cap by construction (host)
-    for (;;) {
-      int t = 0;
-      if (lane == 0) t = atomicAdd(&ctl[1], 1);
-      t = __builtin_amdgcn_readfirstlane(t);
-      if (t >= num_tasks) break;
-      const int d0 = tasks[4 * t], d3 = tasks[4 * t + 3];
-      const int rr = d0 & 255;
-      const bool second = lane >= 32;
-      const int phase = second ? (d0 >> 16) & 255 : (d0 >> 8) & 255;
-      const int start = second ? tasks[4 * t + 2] : tasks[4 * t + 1];
-      const int my_len = second ? d3 >> 16 : d3 & 0xffff;
-      const int iters = ((d3 & 0xffff) + 15) & ~15;          // the first stream is the longer
-      uint32_t acc32[RPL][4];
-#pragma unroll
-      for (int j = 0; j < RPL; ++j)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc32[j][c] = 0;
-      RowPairAccumulate<RPL, kRowStride>(list + start, my_len, iters, lane, lane_off, row_stride,
-                                         P.null_addr, acc32);
-      if (lane_used) {
-        int* out = acc + rr * cands;
-        const int d0x = blk * 4 - phase;           // candidate x index of the block's first cell
-#pragma unroll
-        for (int j = 0; j < RPL; ++j) {
-          const int wrow = row + j * H;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int dxi = d0x + c;
-            if (wrow < side && dxi >= 0 && dxi < side && acc32[j][c])
-              atomicAdd(&out[dxi * side + wrow], static_cast<int>(acc32[j][c]));
-          }
-        }
-      }
-    }
+    run_tasks(ctl[0]);                                   // <= task_cap by construction (host)
     if (rr0 == 0) stamp(6);                              // wave 0 out of tasks (first round)
     rr0 = rr1;
   }
@@ -1025,6 +1099,7 @@ Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict
       *out = v;
     }
   }
+  }   // tiled matches
   stamp(8);
   if (tid < work_stride) fetched[tid] = next;
   }   // work items
@@ -1448,21 +1523,26 @@ bool Rt2DTileCall::Plan() {
       // or -- one tile per match -- as many as fit beside the image
       for (int gmin = std::max(1, (k.scans + 63) / 64); gmin <= k.scans; ++gmin) {
         const int rw = (k.scans + gmin - 1) / gmin;
-        const int task_cap = rw * (k.n_pad / kPairTaskIters + 2);
+        const bool fused_shape = one_tile && fuse;
+        // (fused: rw = the rotations of one ROUND; a discretisation job's region of the list buffer
+        // holds its chunks' entries plus the padding of four sub-lists, its tasks two more than its
+        // chunks: Rt2DTileKernel)
+        const int jpr = (k.n_pad / 64 + kJobChunks - 1) / kJobChunks;
+        const int cap_rot = fused_shape ? k.n_pad + 64 * jpr : cap_tile;
+        const int task_cap = fused_shape ? rw * jpr * (kJobChunks + 2) : rw * (k.n_pad / kPairTaskIters + 2);
         size_t fixed = static_cast<size_t>(image) + 4 * ((static_cast<size_t>(rw) * side * side + 3) & ~size_t{3}) +
                        16 * static_cast<size_t>(rw) + 4 * ((static_cast<size_t>(rw) + 1 + 3) & ~size_t{3}) +
                        16 * static_cast<size_t>(task_cap) + 64;
-        if (one_tile && fuse) {
-          // (list cursors, rotations, the cloud rotated by the initial yaw)
-          fixed += 16 * static_cast<size_t>(rw) + 8 * ((static_cast<size_t>(rw) + 1) & ~size_t{1}) +
-                   8 * static_cast<size_t>(k.n_pad);
+        if (fused_shape) {
+          // (all rotations of the match, the cloud rotated by the initial yaw)
+          fixed += 8 * ((static_cast<size_t>(k.scans) + 1) & ~size_t{1}) + 8 * static_cast<size_t>(k.n_pad);
         }
-        if (fixed + 2 * static_cast<size_t>(cap_tile) > budget) {
+        if (fixed + 2 * static_cast<size_t>(cap_rot) > budget) {
           if (!one_tile) return false;
           continue;                                      // fewer rotations per workgroup
         }
         // list buffer: what is left, at most every rotation's entries at once
-        const size_t want = static_cast<size_t>(rw) * cap_tile;
+        const size_t want = static_cast<size_t>(rw) * cap_rot;
         const size_t room = (budget - fixed) / 2;
         if (one_tile && room < want) continue;           // (all of an item's lists in one round)
         out->list_lds = static_cast<int>(std::min(want, room) & ~size_t{7});
@@ -1554,15 +1634,16 @@ bool Rt2DTileCall::Plan() {
     // this match's own rotation count needs)
     g.rw = std::min(cg.rw, sr.num_scans);
     g.gmin = (sr.num_scans + g.rw - 1) / g.rw;
-    g.gmax = dbg.rt2d_groups > 0 ? std::max(g.gmin, std::min(dbg.rt2d_groups, sr.num_scans))
+    g.gmax = dbg.rt2d_groups > 0 ? std::max(I.fused ? 1 : g.gmin, std::min(dbg.rt2d_groups, sr.num_scans))
                                  : std::max(g.gmin, std::min(sr.num_scans, 32));
     g.target = target;
     g.groups = 0;
     if (I.fused) {                       // the planner's rule (Rt2DTilePrepKernel), on the host
       const long long entries = static_cast<long long>(it.n) * sr.num_scans;
+      // (any number of groups: an item takes its rotations in rounds of g.rw)
       long long G = std::max<long long>(1, (entries + target / 2) / target);
-      G = std::min<long long>(std::max<long long>(G, g.gmin), std::min(g.gmax, sr.num_scans));
-      g.groups = static_cast<int>(std::max<long long>(G, g.gmin));
+      G = std::min<long long>(G, std::min(g.gmax, sr.num_scans));
+      g.groups = static_cast<int>(std::max<long long>(G, 1));
     }
     g.cap_s = n_pad + 16 * 4 * g.ntx * g.nty;
     // the grid image: halo + grid, rows of whole 16-byte pieces, one zero row below (what lies
@@ -1606,6 +1687,11 @@ bool Rt2DTileCall::Plan() {
 void Rt2DTileCall::Enqueue() {
   Impl& I = *impl_;
   const DebugOptions& dbg = Debug();
+  const auto t_enter = std::chrono::steady_clock::now();
+  const auto lap_us = [&]() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enter).count();
+  };
+  double t_images = 0, t_params = 0, t_upload = 0;
   const Rt2DItem* items = I.items;
   const Rt2DSearch* search = I.search;
   const int num = I.num, device = I.device, rpl = I.rpl;
@@ -1725,6 +1811,7 @@ void Rt2DTileCall::Enqueue() {
   for (int m = 0; m < num; ++m)
     if (same_as[m] >= 0) image_of[m] = image_of[same_as[m]];
 
+  t_images = lap_us();
   // ---- parameters -------------------------------------------------------------------------------
   Rt2DTileParams* h_params = reinterpret_cast<Rt2DTileParams*>(h_in);
   {
@@ -1740,7 +1827,11 @@ void Rt2DTileCall::Enqueue() {
     const cmx_rt_options* options = I.options;
     unsigned long long* d_timeline = I.d_timeline;
     unsigned* d_overflow = I.d_overflow;
-    ParallelFor(num, 16, [&](int m) {
+    // (resident grids and clouds: a fraction of a microsecond per match, and dispatching to the
+    // host pool costs ~25 us; host grids are copied into the staging buffer here: worth the pool)
+    bool copies = false;
+    for (int m = 0; m < num; ++m) copies = copies || !items[m].device_cells;
+    ParallelFor(num, copies ? 16 : 4096, [&](int m) {
       const Rt2DItem& it = items[m];
       const Rt2DSearch& sr = search[m];
       const TileGeometry& g = geo[m];
@@ -1786,7 +1877,9 @@ void Rt2DTileCall::Enqueue() {
   }
   // (the stage counters ride in the last words of a match's slot: the finalist head must stop short)
   static_assert(2 + 2 * kFinalistHead <= 126, "a match's head and stage counters share 128 words");
+  t_params = lap_us();
   SmallCopyAsync(d_in, h_in, in_bytes, /*to_device=*/true, ws->stream);
+  t_upload = lap_us();
   const Rt2DTileParams* d_params = reinterpret_cast<const Rt2DTileParams*>(d_in);
 
   CMX_HIP(hipEventRecord(ws->ev_begin, ws->stream));
@@ -1840,6 +1933,9 @@ void Rt2DTileCall::Enqueue() {
   CMX_HIP(hipGetLastError());
   CMX_HIP(hipEventRecord(ws->ev_end, ws->stream));
   I.enqueued = true;
+  if (dbg.host_trace)
+    fprintf(stderr, "[cmx host] rt2d enqueue(%d): workspace + images %.0f, parameters %.0f, upload call %.0f, "
+                    "launches %.0f us (%zu bytes up)\n", num, t_images, t_params, t_upload, lap_us(), in_bytes);
 }
 
 bool Rt2DTileCall::Collect(cmx_match_stats* stats) {
@@ -1850,7 +1946,9 @@ bool Rt2DTileCall::Collect(cmx_match_stats* stats) {
   const Rt2DItem* items = I.items;
   const Rt2DSearch* search = I.search;
   const unsigned* h_misc = I.h_misc;
+  const auto t_enter = std::chrono::steady_clock::now();
   CMX_HIP(hipStreamSynchronize(ws->stream));
+  const double t_wait = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enter).count();
   I.synced = true;
   I.holds.built = true;
   if (I.d_timeline) {
@@ -1881,7 +1979,7 @@ bool Rt2DTileCall::Collect(cmx_match_stats* stats) {
     }
   }
   const cmx_rt_options* options = I.options;
-  ParallelFor(num, 16, [&](int m) {
+  ParallelFor(num, 4096, [&](int m) {
     const unsigned* head = h_misc + static_cast<size_t>(m) * 128;
     const long long count = head[1];
     const long long in_head = std::min<long long>(count, kFinalistHead);
@@ -1916,6 +2014,9 @@ bool Rt2DTileCall::Collect(cmx_match_stats* stats) {
     total.dominant_kernel_ms = ms;
     *stats = total;
   }
+  if (Debug().host_trace)
+    fprintf(stderr, "[cmx host] rt2d collect(%d): wait %.0f, all %.0f us\n", num, t_wait,
+            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enter).count());
   return true;
 }
 

@@ -215,11 +215,14 @@ def test_rt2d_batch_on_resident_grids_both_paths(sm, oracle, synth, debug):
 
 
 @pytest.mark.parametrize("resident", [False, True])
-def test_rt2d_large_batch_goes_out_as_two_halves(sm, synth, resident):
-    """From 64 matches on a batch is issued as two half-batches from two host threads (own
-    workspace and stream each): 71 matches over five grids with scans of different sizes return,
-    match by match, what the single-match entry point returns; the statistics are those of both halves;
-    an error in the second half comes back as the call's status with its message."""
+@pytest.mark.parametrize("parts", [2, 3])
+def test_rt2d_large_batch_goes_out_as_two_halves(sm, synth, debug, resident, parts):
+    """A large batch is issued in parts (own workspace and stream each, planned and launched one
+    after the other by the calling thread, collected in order; from 192 matches on by default,
+    forced here): 71 matches over five grids with scans of different sizes return, match by
+    match, what the single-match entry point returns; the statistics are those of all parts; an
+    error in the last part comes back as the call's status with its message."""
+    debug(rt2d_parts=parts)
     from cartographer_amd import grid_2d
     from cartographer_amd._lib import CmxError
     m = sm.RealTimeCorrelativeScanMatcher2D(0.3, math.radians(7.0), 0.1, 0.1)
@@ -246,10 +249,10 @@ def test_rt2d_large_batch_goes_out_as_two_halves(sm, synth, resident):
         for k, (score, pose) in enumerate(singles):
             assert scores[k] == score, k
             np.testing.assert_array_equal(poses[k], [pose.x, pose.y, pose.theta])
-        assert stats["candidates_scored"] == candidates          # both halves counted
+        assert stats["candidates_scored"] == candidates          # every part counted
     if not resident:
         bad = list(scans)
-        bad[70] = np.zeros((0, 3), np.float32)            # an empty scan in the SECOND half
+        bad[70] = np.zeros((0, 3), np.float32)            # an empty scan in the LAST part
         with pytest.raises(CmxError):
             sm.rt2d_match_batch(m, grids, inits, bad)
 
