@@ -192,6 +192,52 @@ __device__ __forceinline__ unsigned long long WaveMaxU64(unsigned long long v) {
   return v;
 }
 
+// The reference's sequential f32 sum of `count` floats in LDS (count a multiple of 64, `p` 16-byte
+// aligned), continued from `acc`: one lane, N dependent additions in index order.  The values
+// arrive 32 at a time (eight ds_read_b128) in two register banks: a bank is requested BEFORE the
+// other bank's 32 additions start, so its LDS latency runs under them (the compiler's own
+// schedule requested it behind them and then copied it across: 16 cycles per addition instead of
+// the adder's latency).  Loads and waits are asm -- a wait names its bank as an in/out operand, so
+// that the additions stay behind it; LDS returns in order: "at most 8 pending" = the older bank.
+typedef float ChainF4 __attribute__((ext_vector_type(4)));
+template <int kImm>
+__device__ __forceinline__ void ChainRead(ChainF4* out, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(*out) : "v"(addr), "i"(kImm));
+}
+__device__ __forceinline__ void ChainReadBank(ChainF4 (&b)[8], unsigned addr) {
+  ChainRead<0>(&b[0], addr);   ChainRead<16>(&b[1], addr);  ChainRead<32>(&b[2], addr);
+  ChainRead<48>(&b[3], addr);  ChainRead<64>(&b[4], addr);  ChainRead<80>(&b[5], addr);
+  ChainRead<96>(&b[6], addr);  ChainRead<112>(&b[7], addr);
+}
+template <int kPending>
+__device__ __forceinline__ void ChainWaitBank(ChainF4 (&b)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7])
+               : "i"(kPending));
+}
+__device__ __forceinline__ float ChainAddBank(float acc, const ChainF4 (&b)[8]) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { acc += b[k].x; acc += b[k].y; acc += b[k].z; acc += b[k].w; }
+  return acc;
+}
+__device__ __forceinline__ float ChainSumLds(const float* p, int count, float acc) {
+  const unsigned base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
+      (const __attribute__((address_space(3))) float*)p));
+  const int last = count - 32;                     // first float of the last bank
+  ChainF4 a[8], b[8];
+  ChainReadBank(a, base);
+  for (int j = 0; j < count; j += 64) {
+    ChainReadBank(b, base + 4u * static_cast<unsigned>(j + 32));
+    ChainWaitBank<8>(a);
+    acc = ChainAddBank(acc, a);
+    ChainReadBank(a, base + 4u * static_cast<unsigned>(min(j + 64, last)));   // (past the end: re-read, unused)
+    ChainWaitBank<8>(b);
+    acc = ChainAddBank(acc, b);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  return acc;
+}
+
 // Optional in-kernel timeline (environment CMX_TIMELINE=1, tools only): thread 0 of a block
 // stores the 100 MHz wall clock at phase boundaries, 16 stamps per block.
 constexpr int kTimelineStamps = 16;

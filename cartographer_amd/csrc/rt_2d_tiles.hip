@@ -608,26 +608,7 @@ __device__ __forceinline__ void Rt2DFinishMatch(Rt2DTileParams& P, unsigned char
         // The reference's sum: N dependent additions in point order (then zeros up to a multiple
         // of 64 points: x + 0 = x).  The values come out of LDS 32 at a time (8 x ds_read_b128),
         // the next 32 on their way while these are added.
-        typedef float F4 __attribute__((ext_vector_type(4)));
-        const F4* vals = reinterpret_cast<const F4*>(prob + tid * row);
-        float sum = 0.f;
-        // (the tile kernel's workgroups of 1024 threads have 128 registers a thread: half the batch)
-        constexpr int kB = kThreads > 512 ? 4 : 8;
-        F4 a[kB], b[kB];
-#pragma unroll
-        for (int k = 0; k < kB; ++k) a[k] = vals[k];
-        for (int i = 0; i < n_pad; i += 8 * kB) {        // n_pad is a multiple of 64
-#pragma unroll
-          for (int k = 0; k < kB; ++k) b[k] = vals[(i >> 2) + kB + k];
-#pragma unroll
-          for (int k = 0; k < kB; ++k) { sum += a[k].x; sum += a[k].y; sum += a[k].z; sum += a[k].w; }
-          // (the last batch reads 4 kB floats past the row: inside the next row or the lists behind
-          // the probabilities, never added)
-#pragma unroll
-          for (int k = 0; k < kB; ++k) a[k] = vals[(i >> 2) + 2 * kB + k];
-#pragma unroll
-          for (int k = 0; k < kB; ++k) { sum += b[k].x; sum += b[k].y; sum += b[k].z; sum += b[k].w; }
-        }
+        const float sum = ChainSumLds(prob + tid * row, n_pad, 0.f);
         const float score = sum / static_cast<float>(n);
         const int c = sel[tid];
         const int dxi = c / side, dyi = c - dxi * side;

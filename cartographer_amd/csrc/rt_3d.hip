@@ -1507,7 +1507,7 @@ __global__ void Rt3DBulkCollectKernel(const float* __restrict__ upper, long long
 // One block per finalist: the reference's own arithmetic (Rotate, + translation, lround of the
 // IEEE quotient, padded f32 probability brick).  The N lookups of a candidate are independent,
 // its f32 sum is a chain: waves 1..3 fetch the next 4096 probabilities into one LDS buffer while
-// lane 0 of wave 0 runs the chain over the other (the two used to alternate).
+// lane 0 of wave 0 runs the chain over the other (ChainSumLds, cmx_device.h).
 constexpr int kExact3DChunk = 4096;
 __global__ void __launch_bounds__(256)
 Rt3DExactKernel(Rt3DParams P, const float* __restrict__ xyz, int n,
@@ -1536,6 +1536,8 @@ Rt3DExactKernel(Rt3DParams P, const float* __restrict__ xyz, int n,
       const int iz = min(max(idx.z + oz, 0), mz);
       out[j] = P.grid.cells[(static_cast<size_t>(iz) * sy + iy) * sx + ix];
     }
+    // (the chain runs over whole banks of 64: + 0 leaves the non-negative sum as it is)
+    for (int j = cnt + first; j < ((cnt + 63) & ~63); j += stride) out[j] = 0.f;
   };
   float acc = 0.f;
   fetch(0, prob[0], threadIdx.x, blockDim.x);
@@ -1547,25 +1549,7 @@ Rt3DExactKernel(Rt3DParams P, const float* __restrict__ xyz, int n,
                                           blockDim.x - 64);
     } else if (threadIdx.x == 0) {
       const int cnt = min(kExact3DChunk, n - base);
-      const float* p = prob[b];
-      int j = 0;
-      // 32 values (eight 16-byte LDS reads) requested ahead of the 32 dependent adds, the next
-      // 32 while those run
-      float4 v[8], w[8];
-      if (cnt >= 32) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + 4 * u);
-      }
-      for (; j + 32 <= cnt; j += 32) {
-        const int ahead = min(j + 32, (cnt - 32) & ~3);       // (aligned; the last one is not used)
-#pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const float4*>(p + ahead + 4 * u);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { acc += v[u].x; acc += v[u].y; acc += v[u].z; acc += v[u].w; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = w[u];
-      }
-      for (; j < cnt; ++j) acc += p[j];
+      acc = ChainSumLds(prob[b], (cnt + 63) & ~63, acc);
     }
     __syncthreads();
   }
