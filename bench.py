@@ -876,6 +876,8 @@ def make_workload(name, args, device, rank, world_size):
 STAT_KEYS = ("candidates_scored", "coarse_candidates", "dominant_kernel_ms", "device_ms",
              "num_scans", "expansion_ms", "expansion_launches", "expansion_nodes",
              "expansion_lookups", "refined_candidates", "finalists")
+MS_KEYS = ("dominant_kernel_ms", "device_ms", "expansion_ms")    # HIP-event times: only recorded
+                                                                 # under cmx_debug_set("timing", 1)
 GATHER_PEAK_GLOOKUPS = 2050.0   # measured: 19 cycles per 64-lane gather instruction per CU
                                 # (profiles/r02_rt3d_gather_ceiling.txt) x 256 CUs x 2.4 GHz
 
@@ -900,10 +902,41 @@ def expansion_roofline(acc, steps, kernel, traffic, note):
             "note": note}
 
 
+def set_timing(on):
+    """The library's HIP-event brackets (cmx_match_stats *_ms).  OFF in every timed region -- a
+    production caller does not ask for them and they cost a latency-bound call ~15 % of its wall
+    time -- and ON for the untimed instrumented passes the kernel times come from."""
+    from cartographer_amd import _lib
+    _lib.debug_set(timing=1 if on else 0)
+
+
+def instrumented(workload, acc, steps, passes=None):
+    """A few untimed passes with the event brackets on; their *_ms sums, scaled to `steps`
+    passes, replace the (zero) ones of the timed region in `acc`."""
+    n = passes or max(3, min(steps, 20))
+    inserted = getattr(workload, "insert_s", None)      # (dirty-grid leg: its own bookkeeping)
+    set_timing(True)
+    try:
+        ms = {k: 0.0 for k in MS_KEYS}
+        workload.search()
+        for _ in range(n):
+            r = workload.search()
+            for k in MS_KEYS:
+                ms[k] += r[3].get(k, 0)
+    finally:
+        set_timing(False)
+        if inserted is not None:
+            workload.insert_s = inserted
+    for k in MS_KEYS:
+        acc[k] = ms[k] * steps / n
+
+
 def measure(workload, steps, warmup, sync):
-    """steps timed passes of workload.search(); returns (summary dict, acc, last result)."""
+    """steps timed passes of workload.search() without the library's event brackets, then the
+    instrumented passes for the kernel times; returns (seconds, acc, last result)."""
     acc = {k: 0.0 for k in STAT_KEYS}
     last = None
+    set_timing(False)
     for _ in range(warmup):
         workload.search()
     sync()
@@ -919,6 +952,8 @@ def measure(workload, steps, warmup, sync):
         dt = time.perf_counter() - t0
     finally:
         gc.enable()
+    instrumented(workload, acc, steps)
+    sync()
     return dt, acc, last
 
 
@@ -1123,6 +1158,7 @@ def main():
             if wanted == passes:
                 break
             passes = wanted
+    set_timing(False)          # (the probe and calibration above ran without them too: default)
     for _ in range(args.warmup):
         run_passes(passes, scratch)
 
@@ -1137,6 +1173,17 @@ def main():
     elapsed = time.perf_counter() - t0
     gc.enable()
     total_passes = passes * args.steps
+    # One more step, untimed, with the library's HIP-event brackets on: the kernel / device times
+    # of the roofline block (every rank runs it: a sharded pass contains collectives).
+    set_timing(True)
+    try:
+        acc_ms = {k: 0.0 for k in STAT_KEYS}
+        run_passes(passes, acc_ms)
+        fence()
+    finally:
+        set_timing(False)
+    for k in MS_KEYS:
+        acc[k] = acc_ms[k] * args.steps
 
     # MAX over ranks of the elapsed time; SUM of the work.
     cand_local = acc["candidates_scored"]

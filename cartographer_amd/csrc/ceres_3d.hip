@@ -599,11 +599,11 @@ void SolveProblems(Workspace& ws, Ceres3DProblem* problems, int num, size_t clou
   std::memcpy(h_misc, problems, prob_bytes);
   SmallCopyAsync(d_xyz, h_xyz, sizeof(float) * cloud_floats, /*to_device=*/true, ws.stream);
   SmallCopyAsync(d_misc, h_misc, prob_bytes, /*to_device=*/true, ws.stream);
-  CMX_HIP(hipEventRecord(ws.ev_begin, ws.stream));
+  RecordEvent(ws.ev_begin, ws.stream);
   Ceres3DKernel<<<num, kCeres3DThreads, 0, ws.stream>>>(
       reinterpret_cast<const Ceres3DProblem*>(d_misc));
   CMX_HIP(hipGetLastError());
-  CMX_HIP(hipEventRecord(ws.ev_end, ws.stream));
+  RecordEvent(ws.ev_end, ws.stream);
   double* h_out = reinterpret_cast<double*>(h_misc + prob_bytes);
   SmallCopyAsync(h_out, d_out, out_bytes, /*to_device=*/false, ws.stream);
   CMX_HIP(hipStreamSynchronize(ws.stream));

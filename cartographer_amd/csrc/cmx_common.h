@@ -80,6 +80,8 @@ cmx_status Guard(F&& body) {
   X(host_trace)           /* 1: wall clock of the host phases of a call on stderr */               \
   X(sync)                 /* 1: synchronise after every stage (localises a faulting kernel) */     \
   X(no_copy_kernels)      /* 1: small transfers by copy commands instead of a copy kernel */       \
+  X(timing)               /* 1: HIP-event brackets around the device work (cmx_match_stats *_ms; else 0) */ \
+  X(no_direct_results)    /* 1: results through a copy kernel, not stored to pinned memory by the last kernel */ \
   X(frontier_capacity)    /* nodes per frontier / leaf buffer (tests: forces the overflow path) */ \
   X(comm_virtual_ranks)   /* N > 1: a one-device cmx_comm becomes N ranks on it (host-side key reduction) */ \
   X(fast2d_unfused)       /* 1: fast 2D front end as separate prep / score launches */             \
@@ -206,6 +208,21 @@ struct Workspace {
   PinnedBuffer pinned[4];
   ~Workspace();
 };
+
+// The HIP-event brackets behind cmx_match_stats' *_ms fields: four to six event packets in a
+// chain of seven launches cost a single fast-2D search 24 of its 156 us (round 4, same box), so
+// they are recorded only under the debug option `timing` (bench legs that report kernel times,
+// the profiling tools); without it the *_ms fields are 0.
+inline bool TimingEnabled() { return Debug().timing != 0; }
+inline void RecordEvent(hipEvent_t ev, hipStream_t stream) {
+  if (TimingEnabled()) CMX_HIP(hipEventRecord(ev, stream));
+}
+inline float ElapsedMs(hipEvent_t from, hipEvent_t to) {
+  if (!TimingEnabled()) return 0.f;
+  float ms = 0.f;
+  CMX_HIP(hipEventElapsedTime(&ms, from, to));
+  return ms;
+}
 
 // Optional per-stage timing (debug switch trace): an event after every
 // stage, durations printed to stderr when the call has synchronised.

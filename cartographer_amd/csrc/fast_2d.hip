@@ -1691,11 +1691,11 @@ struct SelectState {         // per problem, device
   unsigned long long key;    // (coarse_index << 32) | path, minimised
 };
 
-__global__ void __launch_bounds__(1024)
-SelectBestKernel(NodeList leaves, const ProblemState* __restrict__ states,
-                 SelectState* __restrict__ sel, BestLeaf* __restrict__ best, int num_problems,
-                 ProblemState* __restrict__ states_out, const Counters* __restrict__ counters,
-                 CountersSummary* __restrict__ summary) {
+__device__ __forceinline__ void
+SelectBestBody(NodeList leaves, const ProblemState* __restrict__ states,
+               SelectState* __restrict__ sel, BestLeaf* __restrict__ best, int num_problems,
+               ProblemState* __restrict__ states_out, const Counters* __restrict__ counters,
+               CountersSummary* __restrict__ summary) {
   for (int p = threadIdx.x; p < num_problems; p += blockDim.x) states_out[p] = states[p];
   if (threadIdx.x < kSubLists) summary->leaves[threadIdx.x] = counters->leaves[threadIdx.x * kCountStride];
   if (threadIdx.x >= 64 && threadIdx.x < 64 + kMaxStages) {
@@ -1845,6 +1845,25 @@ SelectBestKernel(NodeList leaves, const ProblemState* __restrict__ states,
     const int dy = __hip_atomic_load(&best[p].dy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (nd.scan != scan || nd.dx != dx || nd.dy != dy) atomicAdd(&best[p].ties, 1);
   }
+}
+
+// The one block that selects also PUBLISHES: everything the host reads after a search (the
+// counters' summary, selection states, best leaves, problem states: `tail_words` dwords behind
+// the counters) goes from device memory straight into the caller's pinned buffer (mapped into
+// the device's address space) -- no copy kernel behind this one in a chain of launches that is
+// latency from end to end.  tail_host == nullptr: the host fetches the tail itself.
+__global__ void __launch_bounds__(1024)
+SelectBestKernel(NodeList leaves, const ProblemState* __restrict__ states,
+                 SelectState* __restrict__ sel, BestLeaf* __restrict__ best, int num_problems,
+                 ProblemState* __restrict__ states_out, const Counters* __restrict__ counters,
+                 CountersSummary* __restrict__ summary, const unsigned* __restrict__ tail_dev,
+                 unsigned* __restrict__ tail_host, int tail_words) {
+  SelectBestBody(leaves, states, sel, best, num_problems, states_out, counters, summary);
+  if (tail_host == nullptr) return;
+  __threadfence();
+  __syncthreads();
+  for (int i = threadIdx.x; i < tail_words; i += blockDim.x)
+    tail_host[i] = __hip_atomic_load(&tail_dev[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // depth == 1: the lowest-resolution candidates are the leaves
@@ -2308,7 +2327,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
   // Whichever kernel runs first clears the search's list counters.
   int* clear_words = reinterpret_cast<int*>(out->d_misc);
   const int clear_count = out->d_misc ? static_cast<int>(sizeof(Counters) / sizeof(int)) : 0;
-  CMX_HIP(hipEventRecord(ws.ev_k0, ws.stream));
+  RecordEvent(ws.ev_k0, ws.stream);
   if (any_fused) {
     // Threads per block: with 192 (three waves) ten blocks fit a CU, i.e. a single search's
     // ~2300 rotations are all resident at once and the launch takes one block's latency;
@@ -2361,7 +2380,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
       ScoreCoarseGenericKernel<<<per_scan, 256, 0, ws.stream>>>(out->d_problems, n, out->d_states);
     mark("coarse");
   }
-  CMX_HIP(hipEventRecord(ws.ev_k1, ws.stream));
+  RecordEvent(ws.ev_k1, ws.stream);
   CMX_HIP(hipGetLastError());
 }
 
@@ -2443,8 +2462,10 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
                                                  num * sizeof(SelectState));
   ProblemState* h_states = reinterpret_cast<ProblemState*>(
       h_misc + sizeof(CountersSummary) + num * (sizeof(SelectState) + sizeof(BestLeaf)));
-  auto fetch_results = [&] {
-    SmallCopyAsync(h_misc, d_tail, misc_bytes, /*to_device=*/false, ws.stream);
+  // (depth > 1: SelectBestKernel stores the tail into h_misc itself)
+  const bool direct = Debug().no_direct_results == 0 && misc_bytes % sizeof(unsigned) == 0;
+  auto fetch_results = [&](bool published) {
+    if (!published) SmallCopyAsync(h_misc, d_tail, misc_bytes, /*to_device=*/false, ws.stream);
     CMX_HIP(hipStreamSynchronize(ws.stream));
   };
 
@@ -2452,8 +2473,8 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
     SelectDepthOneKernel<<<num, 1024, 0, ws.stream>>>(batch.d_problems, batch.d_states, n, d_best,
                                                       d_states_out);
     CMX_HIP(hipGetLastError());
-    CMX_HIP(hipEventRecord(ws.ev_end, ws.stream));
-    fetch_results();
+    RecordEvent(ws.ev_end, ws.stream);
+    fetch_results(false);
   } else {
     // ---- dive -------------------------------------------------------------
     DiveKernel<<<dim3(kSeedsPerProblem, num), 256, 0, ws.stream>>>(
@@ -2497,7 +2518,7 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
         // expansion is the dominant kernel; a single search's chain of launches is not given
         // two more event packets to wait behind.)
         const bool timed = !strict && chunk == 0 && num >= 4;
-        if (timed) CMX_HIP(hipEventRecord(ws.ev_x0, ws.stream));
+        if (timed) RecordEvent(ws.ev_x0, ws.stream);
         for (int used = 0; used < wave_levels && top - 1 >= 1; ++used, --top, ++stage) {
           ExpandWaveKernel<<<used == 0 ? wide_blocks : narrow_blocks, 256, 0, ws.stream>>>(
               batch.d_problems, batch.d_states, n, front(stage), strict, affinity,
@@ -2505,7 +2526,7 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
           mark("wave");
         }
         if (timed) {
-          CMX_HIP(hipEventRecord(ws.ev_x1, ws.stream));
+          RecordEvent(ws.ev_x1, ws.stream);
           result->expansion_launches = stage;
         }
         // Block-per-node depth-first stages of kLevelsPerStage levels: the bushy
@@ -2519,12 +2540,15 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
           mark("subtree");
         }
       }
-      SelectBestKernel<<<1, 1024, 0, ws.stream>>>(leaf_list, batch.d_states, d_sel, d_best, num,
-                                                  d_states_out, d_counters, d_summary);
+      SelectBestKernel<<<1, 1024, 0, ws.stream>>>(
+          leaf_list, batch.d_states, d_sel, d_best, num, d_states_out, d_counters, d_summary,
+          reinterpret_cast<const unsigned*>(d_tail),
+          direct ? reinterpret_cast<unsigned*>(h_misc) : nullptr,
+          static_cast<int>(misc_bytes / sizeof(unsigned)));
       mark("select");
       CMX_HIP(hipGetLastError());
-      CMX_HIP(hipEventRecord(ws.ev_end, ws.stream));
-      fetch_results();
+      RecordEvent(ws.ev_end, ws.stream);
+      fetch_results(direct);
       if (!strict) {
         for (int st = 0; st < result->expansion_launches; ++st)
           result->expansion_nodes += h_counters->frontier_total[st];
@@ -2567,12 +2591,12 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
     ResolveDepthOne(batch, &result->best, result->states);
   }
   float ms = 0.f;
-  CMX_HIP(hipEventElapsedTime(&ms, ws.ev_begin, ws.ev_end));
+  ms = ElapsedMs(ws.ev_begin, ws.ev_end);
   result->device_ms = ms;
-  CMX_HIP(hipEventElapsedTime(&ms, ws.ev_k0, ws.ev_k1));
+  ms = ElapsedMs(ws.ev_k0, ws.ev_k1);
   result->dominant_ms = ms;
   if (result->expansion_launches > 0) {
-    CMX_HIP(hipEventElapsedTime(&ms, ws.ev_x0, ws.ev_x1));
+    ms = ElapsedMs(ws.ev_x0, ws.ev_x1);
     result->expansion_ms = ms;
   }
 }
@@ -2760,7 +2784,7 @@ void MatchBatch(const cmx_fast2d* const* handles, int num, const cmx_pose2d* ini
     d_xyz = buf;
     max_range = MaxRangeXY(host_xyz, n);
   }
-  CMX_HIP(hipEventRecord(ws->ev_begin, ws->stream));
+  RecordEvent(ws->ev_begin, ws->stream);
   PreparedBatch batch;
   StageTrace trace(ws->stream);
   batch.trace = &trace;
@@ -2988,7 +3012,7 @@ cmx_status cmx_fast2d_debug_prepare(const cmx_fast2d* matcher,
     float* d_xyz = ws->dev[0].ReserveAs<float>(3 * static_cast<size_t>(n));
     CMX_HIP(hipMemcpyAsync(d_xyz, point_cloud_xyz, 3 * sizeof(float) * n, hipMemcpyHostToDevice,
                            ws->stream));
-    CMX_HIP(hipEventRecord(ws->ev_begin, ws->stream));
+    cmx::RecordEvent(ws->ev_begin, ws->stream);
     cmx::PreparedBatch batch;
     batch.write_all_discrete = true;
     cmx::PrepareAndScoreCoarse(*ws, &m, 1, initial_pose_estimate, full_submap != 0, d_xyz, n,

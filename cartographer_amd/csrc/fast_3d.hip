@@ -983,9 +983,15 @@ struct Best3 {
 // Among the recorded leaves with the best score, the one the reference's
 // depth-first search meets first (see fast_2d.hip SelectBestKernel).
 // grid (problems): block p looks at the leaves of problem p only.
+// Block p also PUBLISHES problem p's record -- and block 0 the counters and the problems' states,
+// complete since the kernels before this one -- into the caller's pinned mirror of `misc` (mapped
+// into the device's address space): no copy kernel behind the last launch of the chain.
+// misc_host == nullptr: the host fetches `misc` itself.
 __global__ void __launch_bounds__(1024)
 SelectBest3DKernel(List3 leaves, const Fast3DProblem* __restrict__ problems,
-                   Best3* __restrict__ results) {
+                   Best3* __restrict__ results, const unsigned* __restrict__ misc_dev,
+                   unsigned* __restrict__ misc_host, int counters_words, int state_word0,
+                   int state_words, int best_word0) {
   __shared__ unsigned best_coarse;
   __shared__ unsigned long long best_key[2];
   __shared__ int ties;
@@ -1046,6 +1052,20 @@ SelectBest3DKernel(List3 leaves, const Fast3DProblem* __restrict__ problems,
       const int oz = __hip_atomic_load(&out->oz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (nd.scan != scan || nd.ox != ox || nd.oy != oy || nd.oz != oz) atomicAdd(&out->ties, 1);
     }
+  if (misc_host == nullptr) return;
+  __threadfence();
+  __syncthreads();
+  const auto publish = [&](int word0, int words) {
+    for (int i = threadIdx.x; i < words; i += blockDim.x)
+      misc_host[word0 + i] =
+          __hip_atomic_load(&misc_dev[word0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  constexpr int kBestWords = static_cast<int>(sizeof(Best3) / sizeof(unsigned));
+  publish(best_word0 + problem * kBestWords, kBestWords);
+  if (problem == 0) {
+    publish(0, counters_words);
+    publish(state_word0, state_words);
+  }
 }
 
 // depth == 1: lowest-resolution candidates are the leaves; they are verified
@@ -1332,10 +1352,27 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
       uploaded = byte_loads;
     }
   }
-  float* d_hi = ws->dev[0].ReserveAs<float>(3 * static_cast<size_t>(n));
-  float* d_low = ws->dev[1].ReserveAs<float>(3 * static_cast<size_t>(n_low));
+  // Everything the call uploads lives in ONE device buffer with ONE pinned mirror, in the order
+  //   high-resolution cloud | low-resolution cloud | per-scan poses | misc (counters, problems, states)
+  // and goes up in one transfer (they were four copy kernels in a chain of launches that is
+  // latency from end to end); the Best3 records behind `misc` are only ever written on the device.
+  const auto align256 = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
+  const size_t up_low = align256(3 * sizeof(float) * static_cast<size_t>(n));
+  const size_t up_q = up_low + align256(3 * sizeof(float) * static_cast<size_t>(n_low));
+  const size_t up_misc = up_q + align256(3 * sizeof(float4) * scans_total);
+  // [Counters3 | problems | per problem: best bits, seed count | Best3 per problem]
+  const size_t off_problems = sizeof(Counters3);
+  const size_t off_state = off_problems + sizeof(Fast3DProblem) * num;
+  const size_t off_best = off_state + sizeof(unsigned) * 2 * num;
+  const size_t misc_bytes = off_best + sizeof(Best3) * num;
+  static_assert(sizeof(Counters3) % 8 == 0 && sizeof(Fast3DProblem) % 8 == 0, "alignment");
+  static_assert(sizeof(Best3) % sizeof(unsigned) == 0, "Best3 is copied by dwords");
+  char* d_up = static_cast<char*>(ws->dev[0].Reserve(up_misc + misc_bytes));
+  char* h_up = static_cast<char*>(ws->pinned[0].Reserve(up_misc + misc_bytes));
+  float* d_hi = reinterpret_cast<float*>(d_up);
+  float* d_low = reinterpret_cast<float*>(d_up + up_low);
   // per scan: pose rotation | rotation of GetPoseFromCandidate | translation + resolution
-  float4* d_pose_q = ws->dev[2].ReserveAs<float4>(3 * scans_total);
+  float4* d_pose_q = reinterpret_cast<float4*>(d_up + up_q);
   float4* d_scan_q = d_pose_q + scans_total;
   float4* d_pose_t = d_scan_q + scans_total;
   int4* d_cells = ws->dev[3].ReserveAs<int4>(scans_total * n);
@@ -1350,20 +1387,14 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
                         ws->dev[6].ReserveAs<Node3D>(kFrontierCapacity)};
   Node3D* d_leaves = ws->dev[7].ReserveAs<Node3D>(kLeafCapacity);
   Node3D* d_seeds = ws->dev[8].ReserveAs<Node3D>(static_cast<size_t>(kSeeds3) * num);
-  // [Counters3 | problems | per problem: best bits, seed count | Best3 per problem]
-  const size_t off_problems = sizeof(Counters3);
-  const size_t off_state = off_problems + sizeof(Fast3DProblem) * num;
-  const size_t off_best = off_state + sizeof(unsigned) * 2 * num;
-  const size_t misc_bytes = off_best + sizeof(Best3) * num;
-  static_assert(sizeof(Counters3) % 8 == 0 && sizeof(Fast3DProblem) % 8 == 0, "alignment");
-  char* d_misc = static_cast<char*>(ws->dev[9].Reserve(misc_bytes));
+  char* d_misc = d_up + up_misc;
   Counters3* d_counters = reinterpret_cast<Counters3*>(d_misc);
   Fast3DProblem* d_problems = reinterpret_cast<Fast3DProblem*>(d_misc + off_problems);
   unsigned* d_state = reinterpret_cast<unsigned*>(d_misc + off_state);   // [num][2]
   Best3* d_best = reinterpret_cast<Best3*>(d_misc + off_best);
 
-  float4* h_q = ws->pinned[0].ReserveAs<float4>(3 * scans_total);
-  char* h_misc = static_cast<char*>(ws->pinned[1].Reserve(misc_bytes));
+  float4* h_q = reinterpret_cast<float4*>(h_up + up_q);
+  char* h_misc = h_up + up_misc;
   Counters3* h_counters = reinterpret_cast<Counters3*>(h_misc);
   Fast3DProblem* h_problems = reinterpret_cast<Fast3DProblem*>(h_misc + off_problems);
   unsigned* h_state = reinterpret_cast<unsigned*>(h_misc + off_state);
@@ -1411,7 +1442,7 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
   // not depend on the order of the points.  Upload it sorted along a Morton curve: the
   // 64 points a wavefront gathers together then fall into neighbouring voxels, i.e. into
   // a handful of cache lines instead of 64 (the search is bound by that line traffic).
-  float* h_hi = ws->pinned[2].ReserveAs<float>(3 * static_cast<size_t>(n));
+  float* h_hi = reinterpret_cast<float*>(h_up);
   {
     float lo3[3] = {hi[0], hi[1], hi[2]};
     for (int i = 1; i < n; ++i)
@@ -1441,14 +1472,11 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
       h_hi[3 * i] = hi[3 * src]; h_hi[3 * i + 1] = hi[3 * src + 1]; h_hi[3 * i + 2] = hi[3 * src + 2];
     }
   }
-  // Four small uploads, all from pinned staging (the caller's low-resolution cloud is copied
-  // there first): copy kernels where they are small (cmx_common.h: SmallCopyAsync).
-  float* h_low = ws->pinned[3].ReserveAs<float>(3 * static_cast<size_t>(n_low));
+  // One upload from the pinned mirror (the caller's low-resolution cloud is copied there
+  // first): a copy kernel while it is small (cmx_common.h: SmallCopyAsync).
+  float* h_low = reinterpret_cast<float*>(h_up + up_low);
   std::memcpy(h_low, data.low_resolution_point_cloud, 3 * sizeof(float) * n_low);
-  SmallCopyAsync(d_hi, h_hi, 3 * sizeof(float) * n, true, ws->stream);
-  SmallCopyAsync(d_low, h_low, 3 * sizeof(float) * n_low, true, ws->stream);
-  SmallCopyAsync(d_pose_q, h_q, 3 * sizeof(float4) * scans_total, true, ws->stream);
-  SmallCopyAsync(d_misc, h_misc, off_best, true, ws->stream);
+  SmallCopyAsync(d_up, h_up, up_misc + off_best, true, ws->stream);
 
   auto front = [&](int stage) {
     return List3{d_front[stage & 1], d_counters->frontier[stage], kFrontierCapacity / kSubLists3};
@@ -1466,19 +1494,19 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
   StageTrace trace(ws->stream);
   auto mark = [&](const char* name) { trace.Mark(name); };
   mark("begin");
-  CMX_HIP(hipEventRecord(ws->ev_begin, ws->stream));
+  RecordEvent(ws->ev_begin, ws->stream);
   Discretize3DKernel<<<dim3(DivUp(n, 256), static_cast<unsigned>(scans_total)), 256, 0,
                        ws->stream>>>(d_hi, n, d_pose_q, d_pose_t, d_cells);
   dbg("discretize");
   mark("discretize");
-  CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
+  RecordEvent(ws->ev_k0, ws->stream);
   if (max_total <= 4096)
     ScoreCoarse3DBlockKernel<<<dim3(static_cast<unsigned>(max_total), num), 256, 0,
                                ws->stream>>>(d_problems);
   else
     ScoreCoarse3DKernel<<<dim3(std::min<long long>(8192, DivUp(max_total, 4)), num), 256, 0,
                           ws->stream>>>(d_problems);
-  CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
+  RecordEvent(ws->ev_k1, ws->stream);
   dbg("coarse");
   mark("coarse");
 
@@ -1518,7 +1546,7 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
         mark("filter");
         int stage = 0;
         const bool timed = !strict && chunk == 0;      // statistics: the first pass
-        if (timed) CMX_HIP(hipEventRecord(ws->ev_x0, ws->stream));
+        if (timed) RecordEvent(ws->ev_x0, ws->stream);
         for (int child = max_depth - 2; child >= 0; --child, ++stage) {
           Expand3DKernel<<<blocks, 256, 0, ws->stream>>>(d_problems, front(stage), strict,
                                                          affinity, families, front(stage + 1),
@@ -1527,16 +1555,22 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
           mark("expand");
         }
         if (timed) {
-          CMX_HIP(hipEventRecord(ws->ev_x1, ws->stream));
+          RecordEvent(ws->ev_x1, ws->stream);
           st.expansion_launches = stage;
         }
       }
     }
-    SelectBest3DKernel<<<num, 1024, 0, ws->stream>>>(leaf_list, d_problems, d_best);
+    const bool direct = Debug().no_direct_results == 0;
+    SelectBest3DKernel<<<num, 1024, 0, ws->stream>>>(
+        leaf_list, d_problems, d_best, reinterpret_cast<const unsigned*>(d_misc),
+        direct ? reinterpret_cast<unsigned*>(h_misc) : nullptr,
+        static_cast<int>(sizeof(Counters3) / sizeof(unsigned)),
+        static_cast<int>(off_state / sizeof(unsigned)), 2 * num,
+        static_cast<int>(off_best / sizeof(unsigned)));
     mark("select");
     CMX_HIP(hipGetLastError());
-    CMX_HIP(hipEventRecord(ws->ev_end, ws->stream));
-    SmallCopyAsync(h_misc, d_misc, misc_bytes, false, ws->stream);
+    RecordEvent(ws->ev_end, ws->stream);
+    if (!direct) SmallCopyAsync(h_misc, d_misc, misc_bytes, false, ws->stream);
     CMX_HIP(hipStreamSynchronize(ws->stream));
     trace.Report();
     lap("device");
@@ -1569,12 +1603,12 @@ void Match3DMany(const Search3D* searches, int num, const cmx_node_data3d& data,
     st.nodes_expanded += h_counters->expanded[k];
   }
   float ms = 0.f;
-  CMX_HIP(hipEventElapsedTime(&ms, ws->ev_begin, ws->ev_end));
+  ms = ElapsedMs(ws->ev_begin, ws->ev_end);
   st.device_ms = ms;
-  CMX_HIP(hipEventElapsedTime(&ms, ws->ev_k0, ws->ev_k1));
+  ms = ElapsedMs(ws->ev_k0, ws->ev_k1);
   st.dominant_kernel_ms = ms;
   if (st.expansion_launches > 0) {
-    CMX_HIP(hipEventElapsedTime(&ms, ws->ev_x0, ws->ev_x1));
+    ms = ElapsedMs(ws->ev_x0, ws->ev_x1);
     st.expansion_ms = ms;
   }
 

@@ -508,16 +508,16 @@ void Rt2DLegacyBatch(const cmx_rt_options* options, const Rt2DItem* items, const
   SmallCopyAsync(d_in, h_in, in_bytes, /*to_device=*/true, ws->stream);
   const Rt2DParams* d_params = reinterpret_cast<const Rt2DParams*>(d_in);
 
-  CMX_HIP(hipEventRecord(ws->ev_begin, ws->stream));
+  RecordEvent(ws->ev_begin, ws->stream);
   const dim3 prep_grid(max_prep, 1, num), score_grid(max_tiles, max_scans, num),
       collect_grid(max_collect, 1, num);
   if (tsdf) {
     Rt2DPrepKernel<true><<<prep_grid, 256, 0, ws->stream>>>(d_params);
-    CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
+    RecordEvent(ws->ev_k0, ws->stream);
     Rt2DScoreKernel<true><<<score_grid, 64, 0, ws->stream>>>(d_params);
   } else {
     Rt2DPrepKernel<false><<<prep_grid, 256, 0, ws->stream>>>(d_params);
-    CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
+    RecordEvent(ws->ev_k0, ws->stream);
     // One match (81 waves) is bound by the latency of its sequential sums: the scalar
     // variant keeps 32 gathers in flight per wave (C1: 19 us vs 34 us).  From ~16
     // concurrent matches on, the gather path is the limit and four candidates per
@@ -527,10 +527,10 @@ void Rt2DLegacyBatch(const cmx_rt_options* options, const Rt2DItem* items, const
     else
       Rt2DScoreKernel<false><<<score_grid, 64, 0, ws->stream>>>(d_params);
   }
-  CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
+  RecordEvent(ws->ev_k1, ws->stream);
   Rt2DCollectKernel<<<collect_grid, 256, 0, ws->stream>>>(d_params);
   CMX_HIP(hipGetLastError());
-  CMX_HIP(hipEventRecord(ws->ev_end, ws->stream));
+  RecordEvent(ws->ev_end, ws->stream);
   SmallCopyAsync(h_misc, d_misc, sizeof(unsigned) * 128 * num, /*to_device=*/false, ws->stream);
   CMX_HIP(hipStreamSynchronize(ws->stream));
 
@@ -581,9 +581,9 @@ void Rt2DLegacyBatch(const cmx_rt_options* options, const Rt2DItem* items, const
   }
   if (stats) {
     float ms = 0.f;
-    CMX_HIP(hipEventElapsedTime(&ms, ws->ev_begin, ws->ev_end));
+    ms = ElapsedMs(ws->ev_begin, ws->ev_end);
     total.device_ms = ms;
-    CMX_HIP(hipEventElapsedTime(&ms, ws->ev_k0, ws->ev_k1));
+    ms = ElapsedMs(ws->ev_k0, ws->ev_k1);
     total.dominant_kernel_ms = ms;
     *stats = total;
   }

@@ -1863,7 +1863,7 @@ void Rt2DTileCall::Enqueue() {
   t_upload = lap_us();
   const Rt2DTileParams* d_params = reinterpret_cast<const Rt2DTileParams*>(d_in);
 
-  CMX_HIP(hipEventRecord(ws->ev_begin, ws->stream));
+  RecordEvent(ws->ev_begin, ws->stream);
   {
     bool any_build = false;
     size_t max_vecs = 0;
@@ -1877,7 +1877,7 @@ void Rt2DTileCall::Enqueue() {
   if (!I.fused)
     Rt2DTilePrepKernel<<<dim3(I.max_scans, num), 256, I.prep_lds, ws->stream>>>(
         d_params, d_counters, d_work, static_cast<int>(I.work_cap));
-  CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
+  RecordEvent(ws->ev_k0, ws->stream);
   {
     const auto launch = [&](auto kernel) {
       OptInLds(reinterpret_cast<const void*>(kernel), device, 160 * 1024 - 1024);   // (minus the static words)
@@ -1908,11 +1908,11 @@ void Rt2DTileCall::Enqueue() {
     else if (rpl <= 6) launch(Rt2DTileKernel<6, 0, false>);
     else launch(Rt2DTileKernel<8, 0, false>);
   }
-  CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
+  RecordEvent(ws->ev_k1, ws->stream);
   OptInLds(reinterpret_cast<const void*>(Rt2DFinishKernel), device, 128 * 1024);
   Rt2DFinishKernel<<<num, kFinishThreads, I.finish_lds, ws->stream>>>(d_params, I.group, I.h_misc);
   CMX_HIP(hipGetLastError());
-  CMX_HIP(hipEventRecord(ws->ev_end, ws->stream));
+  RecordEvent(ws->ev_end, ws->stream);
   I.enqueued = true;
   if (dbg.host_trace)
     fprintf(stderr, "[cmx host] rt2d enqueue(%d): workspace + images %.0f, parameters %.0f, upload call %.0f, "
@@ -1989,9 +1989,9 @@ bool Rt2DTileCall::Collect(cmx_match_stats* stats) {
   }
   if (stats) {
     float ms = 0.f;
-    CMX_HIP(hipEventElapsedTime(&ms, ws->ev_begin, ws->ev_end));
+    ms = ElapsedMs(ws->ev_begin, ws->ev_end);
     total.device_ms = ms;
-    CMX_HIP(hipEventElapsedTime(&ms, ws->ev_k0, ws->ev_k1));
+    ms = ElapsedMs(ws->ev_k0, ws->ev_k1);
     total.dominant_kernel_ms = ms;
     *stats = total;
   }

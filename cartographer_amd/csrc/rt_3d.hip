@@ -1846,7 +1846,7 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
     std::vector<long long> finalists;     // reference candidate index t * R + r, ascending
     std::vector<float> acc;               // their exact unweighted scores
     bool done = false;
-    CMX_HIP(hipEventRecord(ws->ev_begin, ws->stream));
+    RecordEvent(ws->ev_begin, ws->stream);
 
     // ---- integer bounds (groups, then candidates) + exact finalists --------------------
     // Limits: finite points (a NaN would read an unchecked cell), N small enough for the
@@ -2102,7 +2102,7 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
           }
         }
       };
-      CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
+      RecordEvent(ws->ev_k0, ws->stream);
       if (use_tiles) {
         Rt3DTileParams TP = TG;
         span_of(group, &TP);
@@ -2283,7 +2283,7 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
         Rt3DBulkKernel<true><<<dim3(DivUp(G, kBulk3DThreads), std::max<unsigned>(2u, R)),
                                kBulk3DThreads, 0, ws->stream>>>(BG, d_xyz);
       }
-      CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
+      RecordEvent(ws->ev_k1, ws->stream);
       // Candidate pass, twice: the members of the groups next to the best upper bound yield a
       // lower bound; then everything that lower bound cannot exclude.  (The threshold only
       // rises afterwards, so no third round can add a group.)
@@ -2325,9 +2325,9 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
         CMX_HIP(hipMemsetAsync(d_num_blocks, 0, sizeof(int), ws->stream));
         if (round == 1 && rotblocks) {
           // the pairs of every rotation block the lower bound of round 0 cannot exclude
-          CMX_HIP(hipEventRecord(ws->ev_x0, ws->stream));
+          RecordEvent(ws->ev_x0, ws->stream);
           run_pairs(d_max_lower, 1.f);
-          CMX_HIP(hipEventRecord(ws->ev_x1, ws->stream));
+          RecordEvent(ws->ev_x1, ws->stream);
           second_pairs_pass = true;
           CMX_HIP(hipMemsetAsync(d_num_blocks, 0, sizeof(int), ws->stream));
           trace.Mark("group pass 2 (pairs)");
@@ -2458,7 +2458,7 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
                                                                 d_exact);
       trace.Mark("finalists");
       CMX_HIP(hipGetLastError());
-      CMX_HIP(hipEventRecord(ws->ev_end, ws->stream));
+      RecordEvent(ws->ev_end, ws->stream);
       CMX_HIP(hipMemcpyAsync(h_bmisc, d_bmisc, head_bytes, hipMemcpyDeviceToHost, ws->stream));
       CMX_HIP(hipMemcpyAsync(h_num_blocks + 12, d_num_blocks + 3, sizeof(int), hipMemcpyDeviceToHost,
                              ws->stream));          // (rotation blocks: pairs that went through the group pass)
@@ -2475,8 +2475,8 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
       }
       if (Debug().rt3d_report) {
         float ms = 0.f, all = 0.f;
-        CMX_HIP(hipEventElapsedTime(&ms, ws->ev_k0, ws->ev_k1));
-        CMX_HIP(hipEventElapsedTime(&all, ws->ev_begin, ws->ev_end));
+        ms = ElapsedMs(ws->ev_k0, ws->ev_k1);
+        all = ElapsedMs(ws->ev_begin, ws->ev_end);
         float lo_f, up_f;
         std::memcpy(&lo_f, h_bmisc, 4);
         std::memcpy(&up_f, h_bmisc + 8, 4);
@@ -2509,14 +2509,14 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
     }
 
     if (!done) {
-    CMX_HIP(hipEventRecord(ws->ev_k0, ws->stream));
+    RecordEvent(ws->ev_k0, ws->stream);
     Rt3DScoreKernel<<<dim3(DivUp(T, 64), static_cast<unsigned>(R)), 64, 0, ws->stream>>>(
         P, d_xyz, n, d_unweighted, d_weighted, d_max);
-    CMX_HIP(hipEventRecord(ws->ev_k1, ws->stream));
+    RecordEvent(ws->ev_k1, ws->stream);
     Rt3DCollectKernel<<<DivUp(num_candidates, 256), 256, 0, ws->stream>>>(
         d_weighted, num_candidates, d_max, d_count, d_finalists, kFinalistCap);
     CMX_HIP(hipGetLastError());
-    CMX_HIP(hipEventRecord(ws->ev_end, ws->stream));
+    RecordEvent(ws->ev_end, ws->stream);
     CMX_HIP(hipMemcpyAsync(h_misc, d_misc, 16 + sizeof(long long) * kFinalistCap,
                            hipMemcpyDeviceToHost, ws->stream));
     CMX_HIP(hipStreamSynchronize(ws->stream));
@@ -2569,9 +2569,9 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
       st.num_scans = static_cast<int>(R);
       st.nodes_expanded = num_finalists;   // bulk path: candidates re-scored exactly
       float ms = 0.f;
-      CMX_HIP(hipEventElapsedTime(&ms, ws->ev_begin, ws->ev_end));
+      ms = ElapsedMs(ws->ev_begin, ws->ev_end);
       st.device_ms = ms;
-      CMX_HIP(hipEventElapsedTime(&ms, ws->ev_k0, ws->ev_k1));
+      ms = ElapsedMs(ws->ev_k0, ws->ev_k1);
       st.dominant_kernel_ms = ms;
       // the bounds above the candidates (rotation blocks, then the (rotation, group) pairs they
       // leave): how many, their lookups, and the time of ALL their passes
@@ -2579,7 +2579,7 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
       st.expansion_lookups = group_bounds * n;
       st.expansion_ms = ms;
       if (second_pairs_pass) {
-        CMX_HIP(hipEventElapsedTime(&ms, ws->ev_x0, ws->ev_x1));
+        ms = ElapsedMs(ws->ev_x0, ws->ev_x1);
         st.expansion_ms += ms;
       }
       *stats = st;

@@ -104,6 +104,8 @@ typedef struct cmx_match_stats {
   int64_t nodes_expanded;     /* branch-and-bound nodes whose children were scored */
   int32_t num_scans;          /* rotated scans */
   int32_t expansion_launches; /* launches inside expansion_ms (0: none timed) */
+  /* The three *_ms fields are recorded only after cmx_debug_set("timing", 1) (the event packets
+     cost a latency-bound call ~15 % of its wall time); otherwise they are 0. */
   double device_ms;           /* HIP-event time of the call's device work */
   double dominant_kernel_ms;  /* HIP-event time of the lowest-resolution (or exhaustive) scoring kernel(s) */
   double expansion_ms;        /* HIP-event time of the level-synchronous branch-and-bound expansion

@@ -7,6 +7,8 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
+from cartographer_amd import _lib as _cmx_lib  # noqa: E402
+_cmx_lib.debug_set(timing=1)   # cmx_match_stats *_ms are recorded only on request
 
 args = argparse.Namespace(matches=128, beams=1000)
 single = bench.Rt2DWorkload(args, 0, matches=128)

@@ -12,6 +12,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from cartographer_amd import scan_matching_3d as sm3  # noqa: E402
+from cartographer_amd import _lib as _cmx_lib  # noqa: E402
+_cmx_lib.debug_set(timing=1)   # cmx_match_stats *_ms are recorded only on request
 
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 args = argparse.Namespace(submaps=pairs, beams=1000)

@@ -10,6 +10,8 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cartographer_amd import _lib, scan_matching_3d as sm3, synth  # noqa: E402
+from cartographer_amd import _lib as _cmx_lib  # noqa: E402
+_cmx_lib.debug_set(timing=1)   # cmx_match_stats *_ms are recorded only on request
 
 grid, world = synth.make_submap_3d(42, 0.1, (15.0, 15.0, 7.5), 8, 32, 512)
 vox = grid.voxels()

@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from cartographer_amd import scan_matching as sm, scan_matching_3d as sm3, synth  # noqa: E402
+from cartographer_amd import _lib as _cmx_lib  # noqa: E402
+_cmx_lib.debug_set(timing=1)   # cmx_match_stats *_ms are recorded only on request
 
 
 def timeit(fn, reps, warm=2):

@@ -10,6 +10,8 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from cartographer_amd import _lib, grid_2d, scan_matching as sm, synth  # noqa: E402
+from cartographer_amd import _lib as _cmx_lib  # noqa: E402
+_cmx_lib.debug_set(timing=1)   # cmx_match_stats *_ms are recorded only on request
 
 _lib.debug_set(timeline=1, trace=1)
 
