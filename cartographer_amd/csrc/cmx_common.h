@@ -130,7 +130,11 @@ void UseDevice(int device);
 // and on a small pool of persistent workers (CMX_HOST_THREADS, default min(16, cores / 2));
 // workers spin for 500 us (CMX_HOST_SPIN_US) after a job before they sleep, so back-to-back calls pay no wake-up.
 // n below `serial_below` runs inline.  fn must not throw across threads: the first exception
-// is captured and rethrown on the caller.  Nested calls run inline.
+// is captured and rethrown on the caller.  Nested calls run inline.  The workers are detached
+// threads of the process that first used the pool: after fork() the child has none (POSIX keeps
+// only the forking thread).  Its loops still complete -- the caller draws items like any worker
+// and then takes all of them -- unless the fork happened in the middle of a job of another
+// thread (the copied `active_` count never drops): fork before the first call, or exec.
 void ParallelFor(int n, int serial_below, const std::function<void(int)>& fn);
 
 // Grow-only device buffer.
@@ -193,6 +197,12 @@ class PinnedBuffer {
 // or with the debug switch no_copy_kernels.  `pinned` is the host side (source for to_device, else target).
 constexpr size_t kCopyKernelMaxBytes = 1024 * 1024;   // one workgroup per 64 KB
 void SmallCopyAsync(void* dst, const void* src, size_t bytes, bool to_device, hipStream_t stream);
+
+// Opt-in to `bytes` (> 64 KB) of dynamic LDS for kernel `fn` on `device`: HIP keeps function
+// attributes per device, so the cache behind this is keyed by (device, kernel), not by the thread
+// or the size alone (a host thread that matched on device 0 and then on device 1 would
+// otherwise skip the opt-in on the second device).
+void OptInLds(const void* fn, int device, size_t bytes);
 
 // Everything one in-flight call needs; handed out by a per-device pool so
 // concurrent callers never share scratch.

@@ -90,12 +90,20 @@ class HostPool {
     tls_inside_ = true;          // a ParallelFor inside fn runs inline on this thread as well
     Work(&job);
     tls_inside_ = false;
-    while (job.done.load(std::memory_order_acquire) < n) __builtin_ia32_pause();
+    // (items are microseconds of host work: a short spin, then the core is handed back between
+    // polls instead of burning it for as long as the slowest worker takes)
+    const auto wait_until = [](const auto& ready) {
+      for (int spins = 0; !ready(); ++spins) {
+        if (spins < 4096) __builtin_ia32_pause();
+        else std::this_thread::yield();
+      }
+    };
+    wait_until([&] { return job.done.load(std::memory_order_acquire) >= n; });
     // `job` lives on this stack: no worker may still hold it when we return.  A worker
     // announces itself (active_) BEFORE it reads job_, so either it reads null below or we
     // see it here (sequentially consistent on both sides).
     job_.store(nullptr, std::memory_order_seq_cst);
-    while (active_.load(std::memory_order_seq_cst) != 0) __builtin_ia32_pause();
+    wait_until([&] { return active_.load(std::memory_order_seq_cst) == 0; });
     if (job.error) std::rethrow_exception(job.error);
   }
 
@@ -263,6 +271,25 @@ void SmallCopyAsync(void* dst, const void* src, size_t bytes, bool to_device, hi
       static_cast<unsigned char*>(dst) + words16 * 16,
       static_cast<const unsigned char*>(src) + words16 * 16, tail);
   CMX_HIP(hipGetLastError());
+}
+
+// Opt-in to more than 64 KB of dynamic LDS, once per (device, kernel): HIP keeps function
+// attributes per device.
+void OptInLds(const void* fn, int device, size_t bytes) {
+  struct Seen { const void* fn; int device; size_t bytes; };
+  static std::mutex mu;
+  static std::vector<Seen>* seen = new std::vector<Seen>;
+  std::lock_guard<std::mutex> lock(mu);
+  for (Seen& s : *seen) {
+    if (s.fn == fn && s.device == device) {
+      if (s.bytes >= bytes) return;
+      CMX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
+      s.bytes = bytes;
+      return;
+    }
+  }
+  CMX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
+  seen->push_back(Seen{fn, device, bytes});
 }
 
 Workspace::~Workspace() {

@@ -1098,25 +1098,6 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group,
 
 size_t Align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
 
-// Opt-in to more than 64 KB of dynamic LDS, once per (device, kernel): HIP keeps function
-// attributes per device.
-void OptInLds(const void* fn, int device, size_t bytes) {
-  struct Seen { const void* fn; int device; size_t bytes; };
-  static std::mutex mu;
-  static std::vector<Seen>* seen = new std::vector<Seen>;
-  std::lock_guard<std::mutex> lock(mu);
-  for (Seen& s : *seen) {
-    if (s.fn == fn && s.device == device) {
-      if (s.bytes >= bytes) return;
-      CMX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
-      s.bytes = bytes;
-      return;
-    }
-  }
-  CMX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
-  seen->push_back(Seen{fn, device, bytes});
-}
-
 // Conflict-free LDS row pitch (bytes, a multiple of 16, >= min_bytes; 0: none exists): the H x B
 // 8-byte blocks a half-wavefront reads in one LDS cycle fall into 2 H B distinct banks for every
 // base address.  The bank pattern depends on the pitch modulo 256 only: the sixteen residues are

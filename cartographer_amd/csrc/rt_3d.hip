@@ -2124,13 +2124,7 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
           TP.seg_first = 0; TP.seg_last = 2;
           TP.seg_sums = BG.sums + RG;
         }
-        static thread_local size_t opted_groups = 0;
-        if (lds > opted_groups) {
-          CMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(Rt3DTileKernel<true, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      static_cast<int>(lds)));
-          opted_groups = lds;
-        }
+        OptInLds(reinterpret_cast<const void*>(Rt3DTileKernel<true, false>), ws->device, lds);
         if (use_boxes) {
           // (the chunk boxes of the list passes: the candidate chunk list under list_rotations
           // rotations -- the sparse group pass and the candidate passes share them)
@@ -2186,13 +2180,7 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
           const size_t lds_q = (sizeof(v2f) * (3 * kTileChunkCandidates / 2 + 2) +
                                 sizeof(uint32_t) * kTileChunkCandidates) * list_rotations +
                                TQ.tile_capacity + 32;
-          static thread_local size_t opted_pairs = 0;
-          if (lds_q > opted_pairs) {
-            CMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(Rt3DTileKernel<true, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        static_cast<int>(lds_q)));
-            opted_pairs = lds_q;
-          }
+          OptInLds(reinterpret_cast<const void*>(Rt3DTileKernel<true, true>), ws->device, lds_q);
           int* d_pair_total = d_num_blocks + 3;
           uint8_t* d_pair_flags = d_computed + RG;
           const bool check_blocks = verify;
@@ -2352,13 +2340,7 @@ cmx_status Rt3DMatchImpl(const cmx_rt_options* options, float grid_resolution,
         if (use_tiles) {
           const size_t lds = sizeof(v2f) * (3 * kTileChunkCandidates / 2 + 2) * list_rotations +
                              TC.tile_capacity + 32;
-          static thread_local size_t opted_candidates = 0;
-          if (lds > opted_candidates) {
-            CMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(Rt3DTileKernel<false, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        static_cast<int>(lds)));
-            opted_candidates = lds;
-          }
+          OptInLds(reinterpret_cast<const void*>(Rt3DTileKernel<false, true>), ws->device, lds);
           if (staged && round == 1) {
             // Segment by segment; after the first and the second, the candidates whose bound
             // (own sum so far + the group's sum over the rest) has fallen below the best lower
