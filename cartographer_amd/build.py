@@ -56,13 +56,14 @@ def build_hip(force=False, verbose=False):
 
 def build_synth(force=False):
     os.makedirs(LIB, exist_ok=True)
-    srcs = [os.path.join(CSRC, "host", f) for f in ("probability_grid_builder.cc", "hybrid_grid_builder.cc", "synth.cc")]
+    srcs = [os.path.join(CSRC, "host", f) for f in ("probability_grid_builder.cc", "hybrid_grid_builder.cc", "synth.cc",
+                                                  "thread_driver.cc")]
     hdrs = [os.path.join(CSRC, "host", h) for h in ("probability_grid_builder.h",
                                                   "hybrid_grid_builder.h")]
     out = os.path.join(LIB, "libcmx_synth.so")
     if force or _newer(out, srcs + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                               "-o", out] + srcs)
+                               "-pthread", "-o", out] + srcs)
     return out
 
 

@@ -25,6 +25,7 @@
 
 #include <cmath>
 
+#include "cmx_atan2f.h"
 #include "cmx_common.h"
 #include "cmx_device.h"
 
@@ -246,11 +247,14 @@ __global__ void SliceKeyKernel(const float* __restrict__ xyz, int n, unsigned* _
   index[i] = static_cast<unsigned>(i);
 }
 
-// One block per slice (slices = segments of equal key in the sorted order).  Thread 0 sums the
-// slice's points in their order (ComputeCentroid's sequential f32 sum), every thread then
-// computes its points' angle around the centroid; points closer than kMinDistance are dropped
-// (key = all ones sorts them behind the slice).  Sort key: slice rank << 32 | orderable angle.
-constexpr int kSliceChunk = 2048;     // points staged in LDS per pass (24 KB)
+// One block per slice (slices = segments of equal key in the sorted order).  ComputeCentroid
+// (:47-53) is a SEQUENTIAL f32 sum in slice order: the block stages the coordinates in LDS as
+// three zero-padded rows, one lane per coordinate adds its row in index order (ChainSumLds,
+// cmx_device.h: ~7 cycles per dependent addition; x + 0 = x exactly).  Every thread then computes
+// its points' angle around the centroid with libm's own atan2f arithmetic (cmx_atan2f.h); points
+// closer than kMinDistance are dropped (key = all ones sorts them behind the slice).
+// Sort key: slice rank << 32 | orderable angle.
+constexpr int kSliceChunk = 2048;     // points staged in LDS per pass
 
 __global__ void __launch_bounds__(256)
 SliceAngleKernel(const float* __restrict__ xyz, const unsigned* __restrict__ sorted_index,
@@ -258,38 +262,33 @@ SliceAngleKernel(const float* __restrict__ xyz, const unsigned* __restrict__ sor
                  unsigned long long* __restrict__ keys2, unsigned* __restrict__ index2) {
   const int s = blockIdx.x;
   const int begin = slice_begin[s], end = s + 1 < num_slices ? slice_begin[s + 1] : n;
-  __shared__ float pts[3 * kSliceChunk];
+  __shared__ __attribute__((aligned(16))) float rows[3][kSliceChunk];
   __shared__ float c[3], run[3];
-  if (threadIdx.x == 0) { run[0] = run[1] = run[2] = 0.f; }
-  // ComputeCentroid: a SEQUENTIAL f32 sum in slice order.  The block stages the points in LDS
-  // (coalesced gathers, all in flight), one lane adds them up: the chain is then ~100 cycles
-  // per point instead of a dependent global round trip per point.
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x < 3) run[threadIdx.x] = 0.f;
   for (int p0 = begin; p0 < end; p0 += kSliceChunk) {
-    const int m = min(kSliceChunk, end - p0);
+    const int m = min(kSliceChunk, end - p0), m_pad = (m + 63) & ~63;
     __syncthreads();
-    for (int k = threadIdx.x; k < m; k += blockDim.x) {
-      const int i = sorted_index[p0 + k];
-      pts[3 * k] = xyz[3 * i]; pts[3 * k + 1] = xyz[3 * i + 1]; pts[3 * k + 2] = xyz[3 * i + 2];
+    for (int k = threadIdx.x; k < m_pad; k += blockDim.x) {
+      float x = 0.f, y = 0.f, z = 0.f;
+      if (k < m) {
+        const int i = sorted_index[p0 + k];
+        x = xyz[3 * i]; y = xyz[3 * i + 1]; z = xyz[3 * i + 2];
+      }
+      rows[0][k] = x; rows[1][k] = y; rows[2][k] = z;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      float sx = run[0], sy = run[1], sz = run[2];
-      for (int k = 0; k < m; ++k) { sx += pts[3 * k]; sy += pts[3 * k + 1]; sz += pts[3 * k + 2]; }
-      run[0] = sx; run[1] = sy; run[2] = sz;
-    }
+    if (wave < 3 && lane == 0) run[wave] = ChainSumLds(rows[wave], m_pad, run[wave]);
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const float count = static_cast<float>(end - begin);
-    c[0] = run[0] / count; c[1] = run[1] / count; c[2] = run[2] / count;
-  }
+  if (threadIdx.x < 3) c[threadIdx.x] = run[threadIdx.x] / static_cast<float>(end - begin);
   __syncthreads();
   for (int p = begin + threadIdx.x; p < end; p += blockDim.x) {
     const int i = sorted_index[p];
     const float dx = xyz[3 * i] - c[0], dy = xyz[3 * i + 1] - c[1];
     unsigned long long key = (static_cast<unsigned long long>(s) << 32) | 0xffffffffull;
     if (!(sqrtf(dx * dx + dy * dy) < kMinDistance)) {
-      const unsigned bits = __float_as_uint(atan2f(dy, dx));
+      const unsigned bits = FloatToBits(Atan2fGlibc(dy, dx));
       key = (static_cast<unsigned long long>(s) << 32) |
             (bits ^ ((bits >> 31) ? 0xffffffffu : 0x80000000u));
       if ((key & 0xffffffffull) == 0xffffffffull) key -= 1;     // keep the "dropped" key unique
@@ -299,100 +298,155 @@ SliceAngleKernel(const float* __restrict__ xyz, const unsigned* __restrict__ sor
   }
 }
 
-// Per slice, in angle order: AddPointCloudSliceToHistogram's walk.  The `last_point_position`
-// chain is sequential, so one lane walks the slice -- out of LDS, where the block has staged the
-// sorted points -- and adds the votes to the slice's own histogram (LDS), written out as
-// partial[slice][bucket].
+// Per slice, in angle order: AddPointCloudSliceToHistogram's walk (:55-83), in three steps.
+//  1. The centroid of the sorted slice: sequential sums of the x and y rows (as above).
+//  2. The `last_point_position` chain.  It only moves when a point lies further than
+//     kMaxDistance from it, so ONE WAVEFRONT walks 64 points per step: every lane tests its point
+//     against the current `last`, a ballot finds the first that moves it, the lanes before it
+//     record `last` for their point, the walk resumes behind it.  A slice of a range scan moves
+//     `last` every few dozen points: n / 64 + (moves) steps instead of n dependent iterations.
+//  3. All threads: the vote (bucket, value) of every point from its recorded `last`, with the
+//     reference's expressions and libm's atan2f arithmetic, written at the point's position in
+//     the global (slice, angle) order -- the order in which the reference adds them.
+// The additions themselves are HistogramChainKernel's.
+constexpr unsigned kNoVote = 0xffffu;      // bucket key of a point without a vote (> any bucket)
+
 __global__ void __launch_bounds__(256)
 SliceWalkKernel(const float* __restrict__ xyz, const unsigned long long* __restrict__ sorted_keys2,
                 const unsigned* __restrict__ sorted_index2, const int* __restrict__ slice_begin,
-                int num_slices, int n, int histogram_size, float* __restrict__ partial) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char walk_smem[];
-  float* hist = reinterpret_cast<float*>(walk_smem);            // [histogram_size]
-  float* pts = hist + histogram_size;                            // [2 * kSliceChunk] (x, y)
+                int num_slices, int n, int histogram_size, unsigned* __restrict__ vote_bucket,
+                unsigned* __restrict__ vote_value) {
+  __shared__ __attribute__((aligned(16))) float X[kSliceChunk], Y[kSliceChunk];
+  __shared__ float LX[kSliceChunk], LY[kSliceChunk];
   __shared__ int s_kept_end;
-  __shared__ float s_c[2], s_run[3], s_last[2];
+  __shared__ float s_c[2], s_run[2], s_last[2];
   const int s = blockIdx.x;
   const int begin = slice_begin[s], end = s + 1 < num_slices ? slice_begin[s + 1] : n;
-  for (int b = threadIdx.x; b < histogram_size; b += blockDim.x) hist[b] = 0.f;
-  if (threadIdx.x == 0) { s_kept_end = end; s_run[0] = s_run[1] = s_run[2] = 0.f; }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) { s_kept_end = end; s_run[0] = s_run[1] = 0.f; }
   __syncthreads();
   // Dropped points (closer than kMinDistance to the first centroid) sort behind the kept ones.
   for (int p = begin + threadIdx.x; p < end; p += blockDim.x)
     if ((sorted_keys2[p] & 0xffffffffull) == 0xffffffffull) atomicMin(&s_kept_end, p);
   __syncthreads();
   const int kept_end = s_kept_end;
-  if (kept_end > begin) {
-    // Centroid of the sorted slice (sequential sum in sorted order), then the walk.
-    for (int pass = 0; pass < 2; ++pass) {
-      for (int p0 = begin; p0 < kept_end; p0 += kSliceChunk) {
-        const int m = min(kSliceChunk, kept_end - p0);
-        __syncthreads();
-        for (int k = threadIdx.x; k < m; k += blockDim.x) {
+  for (int p = kept_end + threadIdx.x; p < end; p += blockDim.x) {
+    vote_bucket[p] = kNoVote;
+    vote_value[p] = 0u;
+  }
+  if (kept_end <= begin) return;
+  const float kNaN = __uint_as_float(0x7fc00000u);
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int p0 = begin; p0 < kept_end; p0 += kSliceChunk) {
+      const int m = min(kSliceChunk, kept_end - p0), m_pad = (m + 63) & ~63;
+      __syncthreads();
+      for (int k = threadIdx.x; k < m_pad; k += blockDim.x) {
+        float x = 0.f, y = 0.f;
+        if (k < m) {
           const int i = sorted_index2[p0 + k];
-          pts[2 * k] = xyz[3 * i];
-          pts[2 * k + 1] = xyz[3 * i + 1];
+          x = xyz[3 * i]; y = xyz[3 * i + 1];
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-          if (pass == 0) {
-            float sx = s_run[0], sy = s_run[1];
-            for (int k = 0; k < m; ++k) { sx += pts[2 * k]; sy += pts[2 * k + 1]; }
-            s_run[0] = sx; s_run[1] = sy;
+        X[k] = x; Y[k] = y;
+      }
+      __syncthreads();
+      if (pass == 0) {
+        if (wave < 2 && lane == 0) s_run[wave] = ChainSumLds(wave == 0 ? X : Y, m_pad, s_run[wave]);
+        continue;
+      }
+      if (wave == 0) {
+        const float cx = s_c[0], cy = s_c[1];
+        float lx = p0 == begin ? X[0] : s_last[0], ly = p0 == begin ? Y[0] : s_last[1];
+        for (int c = 0; c < m;) {
+          const int k = c + lane;
+          const bool valid = k < m;
+          const float px = valid ? X[k] : 0.f, py = valid ? Y[k] : 0.f;
+          const float dx = px - lx, dy = py - ly;
+          const float ex = px - cx, ey = py - cy;
+          const float distance = sqrtf(dx * dx + dy * dy);
+          const float direction_norm = sqrtf(ex * ex + ey * ey);
+          const bool skip = distance < kMinDistance || direction_norm < kMinDistance;
+          const unsigned long long moves = __ballot(valid && !skip && distance > kMaxDistance);
+          const int j = moves ? __builtin_ctzll(moves) : 64;
+          if (valid && lane <= j) {             // (lane j: the point that becomes `last` -- no vote)
+            LX[k] = lane == j ? kNaN : lx;
+            LY[k] = ly;
+          }
+          if (j < 64) {
+            lx = __shfl(px, j, 64);
+            ly = __shfl(py, j, 64);
+            c += j + 1;
           } else {
-            if (p0 == begin) { s_last[0] = pts[0]; s_last[1] = pts[1]; }
-            const float cx = s_c[0], cy = s_c[1];
-            float lx = s_last[0], ly = s_last[1];
-            const float kPi = static_cast<float>(M_PI);
-            for (int k = 0; k < m; ++k) {
-              const float px = pts[2 * k], py = pts[2 * k + 1];
-              const float dx = px - lx, dy = py - ly;
-              const float ex = px - cx, ey = py - cy;
-              const float distance = sqrtf(dx * dx + dy * dy);
-              const float direction_norm = sqrtf(ex * ex + ey * ey);
-              if (distance < kMinDistance || direction_norm < kMinDistance) continue;
-              if (distance > kMaxDistance) {
-                lx = px; ly = py;
-                continue;
-              }
-              float angle = atan2f(dy, dx);
-              const float ndx = dx / distance, ndy = dy / distance;
-              const float nex = ex / direction_norm, ney = ey / direction_norm;
-              const float v = fmaxf(0.f, 1.f - fabsf(ndx * nex + ndy * ney));
-              while (angle > kPi) angle -= kPi;
-              while (angle < 0.f) angle += kPi;
-              const float zero_to_one = angle / kPi;
-              const int b = min(max(LRoundF32(histogram_size * zero_to_one - 0.5f), 0),
-                                histogram_size - 1);
-              hist[b] += v;
-            }
-            s_last[0] = lx; s_last[1] = ly;
+            c += 64;
           }
         }
+        if (lane == 0) { s_last[0] = lx; s_last[1] = ly; }
       }
       __syncthreads();
-      if (pass == 0 && threadIdx.x == 0) {
-        const float count = static_cast<float>(kept_end - begin);
-        s_c[0] = s_run[0] / count;
-        s_c[1] = s_run[1] / count;
+      const float cx = s_c[0], cy = s_c[1];
+      const float kPi = static_cast<float>(M_PI);
+      for (int k = threadIdx.x; k < m; k += blockDim.x) {
+        unsigned bucket = kNoVote;
+        float v = 0.f;
+        const float lx = LX[k];
+        if (!(lx != lx)) {
+          const float px = X[k], py = Y[k];
+          const float dx = px - lx, dy = py - LY[k];
+          const float ex = px - cx, ey = py - cy;
+          const float distance = sqrtf(dx * dx + dy * dy);
+          const float direction_norm = sqrtf(ex * ex + ey * ey);
+          // (distance > kMaxDistance cannot occur here: that point moved `last`)
+          if (!(distance < kMinDistance || direction_norm < kMinDistance)) {
+            float angle = Atan2fGlibc(dy, dx);
+            const float ndx = dx / distance, ndy = dy / distance;
+            const float nex = ex / direction_norm, ney = ey / direction_norm;
+            v = fmaxf(0.f, 1.f - fabsf(ndx * nex + ndy * ney));
+            while (angle > kPi) angle -= kPi;
+            while (angle < 0.f) angle += kPi;
+            const float zero_to_one = angle / kPi;
+            bucket = static_cast<unsigned>(min(
+                max(LRoundF32(histogram_size * zero_to_one - 0.5f), 0), histogram_size - 1));
+          }
+        }
+        vote_bucket[p0 + k] = bucket;
+        vote_value[p0 + k] = __float_as_uint(v);
       }
-      __syncthreads();
     }
+    __syncthreads();
+    if (pass == 0 && threadIdx.x < 2)
+      s_c[threadIdx.x] = s_run[threadIdx.x] / static_cast<float>(kept_end - begin);
+    __syncthreads();
   }
-  __syncthreads();
-  for (int b = threadIdx.x; b < histogram_size; b += blockDim.x)
-    partial[static_cast<size_t>(s) * histogram_size + b] = hist[b];
 }
 
-// histogram[b] = sum over slices (ascending) of the slices' own sums.  The reference adds every
-// vote straight into one histogram; adding per slice first changes the association of the f32
-// additions (differences at the 1e-7 level, below the atan2f effect already accepted).
-__global__ void HistogramSumKernel(const float* __restrict__ partial, int num_slices,
-                                   int histogram_size, float* __restrict__ histogram) {
+// histogram[b] = the votes of bucket b added one by one in the reference's order -- slices
+// ascending, a slice's points by angle (:85-120, :164-177) -- into a zero: `votes` are the
+// (bucket, value) pairs stably sorted by bucket (a radix sort keeps the order inside a bucket), a
+// thread per bucket finds its segment and adds it up.  f32 addition does not associate: any other
+// order (per-slice partial histograms, atomics) differs in the last bits.
+__global__ void HistogramChainKernel(const unsigned* __restrict__ sorted_bucket,
+                                     const unsigned* __restrict__ sorted_value, int n,
+                                     int histogram_size, float* __restrict__ histogram) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= histogram_size) return;
+  const auto lower_bound = [&](unsigned key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (sorted_bucket[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  const int first = lower_bound(static_cast<unsigned>(b)), last = lower_bound(static_cast<unsigned>(b) + 1);
   float h = 0.f;
-  for (int s = 0; s < num_slices; ++s) h += partial[static_cast<size_t>(s) * histogram_size + b];
+  int i = first;
+  for (; i + 8 <= last; i += 8) {           // eight loads in flight, then the eight additions
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = __uint_as_float(sorted_value[i + k]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) h += v[k];
+  }
+  for (; i < last; ++i) h += __uint_as_float(sorted_value[i]);
   histogram[b] = h;
 }
 
@@ -587,14 +641,19 @@ cmx_status cmx_compute_histogram(const float* point_cloud_xyz, int32_t num_point
     bytes = temp_bytes;
     CMX_HIP(hipcub::DeviceRadixSort::SortPairs(temp, bytes, keys2, keys2_sorted, index2,
                                                index2_sorted, n, 0, 64, st));
-    float* d_partial = ws->dev[10].ReserveAs<float>(static_cast<size_t>(num_slices) * histogram_size);
-    const size_t walk_lds = 4 * static_cast<size_t>(histogram_size) + 8 * cmx::kSliceChunk;
-    CMX_REQUIRE(walk_lds <= 64 * 1024, "histogram_size too large");
-    cmx::SliceWalkKernel<<<num_slices, 256, walk_lds, st>>>(d_xyz, keys2_sorted, index2_sorted,
-                                                            slice_begin, num_slices, n,
-                                                            histogram_size, d_partial);
-    cmx::HistogramSumKernel<<<cmx::DivUp(histogram_size, 64), 64, 0, st>>>(d_partial, num_slices,
-                                                                           histogram_size, d_hist);
+    // votes in (slice, angle) order, then stably by bucket (the first sort's buffers are free)
+    unsigned* vote_bucket = keys;
+    unsigned* vote_value = index;
+    unsigned* vote_bucket_sorted = keys_sorted;
+    unsigned* vote_value_sorted = index_sorted;
+    cmx::SliceWalkKernel<<<num_slices, 256, 0, st>>>(d_xyz, keys2_sorted, index2_sorted,
+                                                     slice_begin, num_slices, n, histogram_size,
+                                                     vote_bucket, vote_value);
+    bytes = temp_bytes;
+    CMX_HIP(hipcub::DeviceRadixSort::SortPairs(temp, bytes, vote_bucket, vote_bucket_sorted,
+                                               vote_value, vote_value_sorted, n, 0, 16, st));
+    cmx::HistogramChainKernel<<<cmx::DivUp(histogram_size, 64), 64, 0, st>>>(
+        vote_bucket_sorted, vote_value_sorted, n, histogram_size, d_hist);
     CMX_HIP(hipGetLastError());
     CMX_HIP(hipMemcpyAsync(histogram, d_hist, 4 * static_cast<size_t>(histogram_size),
                            hipMemcpyDeviceToHost, st));

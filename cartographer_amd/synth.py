@@ -55,6 +55,10 @@ def lib():
         L.cmx_synth_submap.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_int,
                                        C.c_int, C.c_double, C.c_double, _u16p, _f64p]
         L.cmx_synth_submap.restype = C.c_void_p
+        L.cmx_thread_driver_fast2d.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                               C.c_int32, C.c_float, C.c_int32, C.c_int32,
+                                               C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.cmx_thread_driver_fast2d.restype = C.c_double
         _lib = L
     return _lib
 
@@ -274,3 +278,21 @@ def make_submap_3d(seed, resolution=0.1, size=(15.0, 15.0, 7.5), num_poses=8, ri
         grid.insert(pos.astype(np.float32), np.stack([x, y, z], 1).astype(np.float32),
                     0.7, 0.4, num_free_space_voxels)
     return grid, world
+
+
+def threaded_full_submap_searches(matchers, clouds, min_score, threads, calls_per_thread):
+    """`threads` native threads (csrc/host/thread_driver.cc: a C++ caller's thread pool in
+    miniature) each issue `calls_per_thread` cmx_fast2d_match_full_submap_batch_resident calls of
+    `matchers` (scan_matching.FastCorrelativeScanMatcher2D) against `clouds` (PointCloudOnDevice,
+    round-robin).  Returns (wall seconds inside the driver, candidates scored, matches found)."""
+    from . import _lib as product
+    entry = C.cast(product.lib().cmx_fast2d_match_full_submap_batch_resident, C.c_void_p)
+    handles = (C.c_void_p * len(matchers))(*[m._h for m in matchers])
+    cloud_handles = (C.c_void_p * len(clouds))(*[c._h for c in clouds])
+    cand, found = C.c_int64(), C.c_int64()
+    seconds = lib().cmx_thread_driver_fast2d(entry, handles, len(matchers), cloud_handles,
+                                             len(clouds), min_score, threads, calls_per_thread,
+                                             C.byref(cand), C.byref(found))
+    if seconds < 0:
+        raise RuntimeError(f"a search failed inside the thread driver: status {int(-seconds)}")
+    return seconds, cand.value, found.value

@@ -49,6 +49,15 @@ if cli.threads > 1:
     cand = r[3]["candidates_scored"]
     print(f"[{tag}] C2 x {T} threads: {best * 1e6:.1f} us per search -> {cand / best:.3e} "
           f"candidates/s", flush=True)
+    # the same from native threads (csrc/host/thread_driver.cc): no interpreter lock between calls
+    from cartographer_amd import synth
+    synth.threaded_full_submap_searches(w.matchers, w.clouds, 0.6, T, 50)
+    best = 1e9
+    for _ in range(3):
+        secs, cand_n, found_n = synth.threaded_full_submap_searches(w.matchers, w.clouds, 0.6, T, per)
+        best = min(best, secs / (T * per))
+    print(f"[{tag}] C2 x {T} native threads: {best * 1e6:.1f} us per search -> "
+          f"{cand_n / (T * per) / best:.3e} candidates/s, found {found_n} of {T * per}", flush=True)
 if not cli.no_c3:
     args.submaps = 16
     w = bench.Fast2DWorkload(args, 0, 0, 1, sharded=True)
