@@ -940,6 +940,8 @@ def measure(workload, steps, warmup, sync):
     for _ in range(warmup):
         workload.search()
     sync()
+    if hasattr(workload, "insert_s"):
+        workload.insert_s = 0.0     # (dirty-grid leg: only the insertions between the TIMED steps)
     gc.collect()
     gc.disable()        # a generation-2 pass of the interpreter (tens of ms with torch loaded)
     try:                # must not land in a timed region of a few steps
@@ -971,9 +973,8 @@ def other_configs(args, device, sync, pmc):
             entry = w.describe(last[3], last[0])
             inserted = getattr(w, "insert_s", 0.0)
             if inserted:       # (dirty-grid leg: the insertions between the steps are not the step)
-                per_step = inserted / (steps + warmup)
-                entry["grid_insertions_ms_per_step"] = per_step * 1e3
-                dt -= per_step * steps
+                entry["grid_insertions_ms_per_step"] = inserted / steps * 1e3
+                dt -= inserted
             if cpu_leg is not None:
                 pending_cpu.append((name, cpu_leg, w))     # after every GPU leg, see below
             entry.update({
