@@ -687,10 +687,18 @@ class Rt3DWorkload:
                   "cell arithmetic, byte gathers from LDS tiles of the dilated uint8 brick)" if tiles
                   else "Rt3DBulkKernel<groups> (upper bounds of 2x2x2 blocks of translations on the "
                        "dilated uint8 brick)" if bulk else "Rt3DScoreKernel")
+        # (counter traffic of what `achieved` spans: the rotation-block launch + the two launches
+        # over the surviving (rotation, group) pairs; older passes name one dense group pass)
+        if tiles:
+            blocks_t, pairs_t = pmc("Rt3DTileKernel<true, false>", "c4"), pmc("Rt3DTileKernel<true, true>", "c4")
+            traffic = (blocks_t + 2.0 * pairs_t if blocks_t is not None and pairs_t is not None
+                       else pmc("Rt3DTileKernel<true>", "c4"))
+        else:
+            traffic = pmc("Rt3DBulkKernel<true>", "c4")
         return {"kernel": kernel,
                 "bound": "lds" if tiles else "gather-issue", "achieved": lookups / secs / 1e9,
                 "peak": peak, "unit": "Glookup/s", "frac": lookups / secs / 1e9 / peak,
-                "traffic": pmc("Rt3DTileKernel<true>" if tiles else "Rt3DBulkKernel<true>", "c4"),
+                "traffic": traffic,
                 "kernel_ms": k_ms,
                 "group_level_bounds": acc.get("expansion_nodes", 0) / steps,
                 "dense_group_bounds": scans * groups,
