@@ -314,10 +314,12 @@ constexpr unsigned kNoVote = 0xffffu;      // bucket key of a point without a vo
 __global__ void __launch_bounds__(256)
 SliceWalkKernel(const float* __restrict__ xyz, const unsigned long long* __restrict__ sorted_keys2,
                 const unsigned* __restrict__ sorted_index2, const int* __restrict__ slice_begin,
-                int num_slices, int n, int histogram_size, unsigned* __restrict__ vote_bucket,
+                int num_slices, int n, int histogram_size, float min_distance_sq,
+                float max_distance_sq, unsigned* __restrict__ vote_bucket,
                 unsigned* __restrict__ vote_value) {
   __shared__ __attribute__((aligned(16))) float X[kSliceChunk], Y[kSliceChunk];
   __shared__ float LX[kSliceChunk], LY[kSliceChunk];
+  __shared__ unsigned char near_centroid[kSliceChunk];   // direction.norm() < kMinDistance
   __shared__ int s_kept_end;
   __shared__ float s_c[2], s_run[2], s_last[2];
   const int s = blockIdx.x;
@@ -347,6 +349,10 @@ SliceWalkKernel(const float* __restrict__ xyz, const unsigned long long* __restr
           x = xyz[3 * i]; y = xyz[3 * i + 1];
         }
         X[k] = x; Y[k] = y;
+        if (pass == 1) {
+          const float ex = x - s_c[0], ey = y - s_c[1];
+          near_centroid[k] = sqrtf(ex * ex + ey * ey) < kMinDistance ? 1 : 0;
+        }
       }
       __syncthreads();
       if (pass == 0) {
@@ -354,30 +360,35 @@ SliceWalkKernel(const float* __restrict__ xyz, const unsigned long long* __restr
         continue;
       }
       if (wave == 0) {
-        const float cx = s_c[0], cy = s_c[1];
+        // 64 points per window, kept in registers while `last` moves inside it: a move costs a
+        // dozen dependent vector instructions, a ballot and two v_readlane -- no LDS round trip,
+        // no square root (distance < kMin <=> d2 < min_distance_sq, distance > kMax <=> d2 >
+        // max_distance_sq: the host rounds the two thresholds so that the correctly rounded
+        // sqrtf of the reference decides the same way, cmx_compute_histogram).
         float lx = p0 == begin ? X[0] : s_last[0], ly = p0 == begin ? Y[0] : s_last[1];
-        for (int c = 0; c < m;) {
+        for (int c = 0; c < m; c += 64) {
           const int k = c + lane;
           const bool valid = k < m;
           const float px = valid ? X[k] : 0.f, py = valid ? Y[k] : 0.f;
-          const float dx = px - lx, dy = py - ly;
-          const float ex = px - cx, ey = py - cy;
-          const float distance = sqrtf(dx * dx + dy * dy);
-          const float direction_norm = sqrtf(ex * ex + ey * ey);
-          const bool skip = distance < kMinDistance || direction_norm < kMinDistance;
-          const unsigned long long moves = __ballot(valid && !skip && distance > kMaxDistance);
-          const int j = moves ? __builtin_ctzll(moves) : 64;
-          if (valid && lane <= j) {             // (lane j: the point that becomes `last` -- no vote)
-            LX[k] = lane == j ? kNaN : lx;
-            LY[k] = ly;
+          const bool near = valid && near_centroid[k] != 0;
+          float my_lx = 0.f, my_ly = 0.f;
+          for (int start = 0;;) {
+            const float dx = px - lx, dy = py - ly;
+            const float d2 = dx * dx + dy * dy;
+            const bool skip = d2 < min_distance_sq || near;
+            const unsigned long long moves =
+                __ballot(valid && lane >= start && !skip && d2 > max_distance_sq);
+            const int j = moves ? __builtin_ctzll(moves) : 64;
+            if (lane >= start && lane <= j) {      // (lane j: the point that becomes `last` -- no vote)
+              my_lx = lane == j ? kNaN : lx;
+              my_ly = ly;
+            }
+            if (j == 64) break;
+            lx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px), j));
+            ly = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py), j));
+            start = j + 1;
           }
-          if (j < 64) {
-            lx = __shfl(px, j, 64);
-            ly = __shfl(py, j, 64);
-            c += j + 1;
-          } else {
-            c += 64;
-          }
+          if (valid) { LX[k] = my_lx; LY[k] = my_ly; }
         }
         if (lane == 0) { s_last[0] = lx; s_last[1] = ly; }
       }
@@ -421,13 +432,17 @@ SliceWalkKernel(const float* __restrict__ xyz, const unsigned long long* __restr
 // histogram[b] = the votes of bucket b added one by one in the reference's order -- slices
 // ascending, a slice's points by angle (:85-120, :164-177) -- into a zero: `votes` are the
 // (bucket, value) pairs stably sorted by bucket (a radix sort keeps the order inside a bucket), a
-// thread per bucket finds its segment and adds it up.  f32 addition does not associate: any other
+// wavefront per bucket finds its segment and adds it up.  f32 addition does not associate: any other
 // order (per-slice partial histograms, atomics) differs in the last bits.
-__global__ void HistogramChainKernel(const unsigned* __restrict__ sorted_bucket,
-                                     const unsigned* __restrict__ sorted_value, int n,
-                                     int histogram_size, float* __restrict__ histogram) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= histogram_size) return;
+__global__ void __launch_bounds__(64)
+HistogramChainKernel(const unsigned* __restrict__ sorted_bucket,
+                     const unsigned* __restrict__ sorted_value, int n, int histogram_size,
+                     float* __restrict__ histogram) {
+  // One wavefront per bucket: the segment is staged in LDS 2048 values at a time (coalesced
+  // loads, zero-padded to 64: h + 0 = h, the votes are >= 0) and one lane adds it up in order
+  // (ChainSumLds: ~7 cycles per dependent addition instead of a global round trip per eight).
+  __shared__ __attribute__((aligned(16))) float row[kSliceChunk];
+  const int b = blockIdx.x, lane = threadIdx.x;
   const auto lower_bound = [&](unsigned key) {
     int lo = 0, hi = n;
     while (lo < hi) {
@@ -438,16 +453,14 @@ __global__ void HistogramChainKernel(const unsigned* __restrict__ sorted_bucket,
   };
   const int first = lower_bound(static_cast<unsigned>(b)), last = lower_bound(static_cast<unsigned>(b) + 1);
   float h = 0.f;
-  int i = first;
-  for (; i + 8 <= last; i += 8) {           // eight loads in flight, then the eight additions
-    float v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = __uint_as_float(sorted_value[i + k]);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) h += v[k];
+  for (int c = first; c < last; c += kSliceChunk) {
+    const int m = min(kSliceChunk, last - c), m_pad = (m + 63) & ~63;
+    __syncthreads();
+    for (int k = lane; k < m_pad; k += 64) row[k] = k < m ? __uint_as_float(sorted_value[c + k]) : 0.f;
+    __syncthreads();
+    if (lane == 0) h = ChainSumLds(row, m_pad, h);
   }
-  for (; i < last; ++i) h += __uint_as_float(sorted_value[i]);
-  histogram[b] = h;
+  if (lane == 0) histogram[b] = h;
 }
 
 __global__ void SliceBeginKernel(const unsigned* __restrict__ sorted_keys, int n,
@@ -646,13 +659,28 @@ cmx_status cmx_compute_histogram(const float* point_cloud_xyz, int32_t num_point
     unsigned* vote_value = index;
     unsigned* vote_bucket_sorted = keys_sorted;
     unsigned* vote_value_sorted = index_sorted;
+    // distance < kMin <=> d2 < min_sq, distance > kMax <=> d2 > max_sq for the correctly rounded
+    // f32 square root of the reference (monotone): the smallest d2 whose root reaches kMin, the
+    // largest whose root does not exceed kMax.
+    static const float min_sq = [] {
+      float x = cmx::kMinDistance * cmx::kMinDistance;
+      while (std::sqrt(x) >= cmx::kMinDistance) x = std::nextafter(x, 0.f);
+      while (std::sqrt(x) < cmx::kMinDistance) x = std::nextafter(x, 1.f);
+      return x;
+    }();
+    static const float max_sq = [] {
+      float x = cmx::kMaxDistance * cmx::kMaxDistance;
+      while (std::sqrt(x) <= cmx::kMaxDistance) x = std::nextafter(x, 2.f);
+      while (std::sqrt(x) > cmx::kMaxDistance) x = std::nextafter(x, 0.f);
+      return x;
+    }();
     cmx::SliceWalkKernel<<<num_slices, 256, 0, st>>>(d_xyz, keys2_sorted, index2_sorted,
                                                      slice_begin, num_slices, n, histogram_size,
-                                                     vote_bucket, vote_value);
+                                                     min_sq, max_sq, vote_bucket, vote_value);
     bytes = temp_bytes;
     CMX_HIP(hipcub::DeviceRadixSort::SortPairs(temp, bytes, vote_bucket, vote_bucket_sorted,
                                                vote_value, vote_value_sorted, n, 0, 16, st));
-    cmx::HistogramChainKernel<<<cmx::DivUp(histogram_size, 64), 64, 0, st>>>(
+    cmx::HistogramChainKernel<<<histogram_size, 64, 0, st>>>(
         vote_bucket_sorted, vote_value_sorted, n, histogram_size, d_hist);
     CMX_HIP(hipGetLastError());
     CMX_HIP(hipMemcpyAsync(histogram, d_hist, 4 * static_cast<size_t>(histogram_size),

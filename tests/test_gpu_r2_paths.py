@@ -48,6 +48,23 @@ def test_fast2d_prepare_both_front_ends(sm, oracle, c2, debug, fused):
     np.testing.assert_array_equal(got["sums"], ref["sums"])
 
 
+def test_timing_brackets_only_on_request(sm, c2, debug):
+    """cmx_match_stats.*_ms: 0 by default (no HIP-event packets in the chain of launches), filled
+    after cmx_debug_set("timing", 1); the result and the counters are the same either way."""
+    cells, lim, _, _, scan = c2
+    gm = sm.FastCorrelativeScanMatcher2D(_grid(sm, cells, lim), 7)
+    plain = gm.match_full_submap(scan, 0.55)
+    quiet = dict(gm.last_stats)
+    debug(timing=1)
+    timed = gm.match_full_submap(scan, 0.55)
+    loud = dict(gm.last_stats)
+    assert plain[0] and timed[0] and plain[1] == timed[1]
+    assert quiet["device_ms"] == 0.0 and quiet["dominant_kernel_ms"] == 0.0
+    assert loud["device_ms"] > 0.0 and 0.0 < loud["dominant_kernel_ms"] < loud["device_ms"]
+    for key in ("candidates_scored", "coarse_candidates", "num_scans"):
+        assert quiet[key] == loud[key] > 0
+
+
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("depth,n", [(7, 1000), (5, 333), (3, 64), (6, 1)])
 def test_fast2d_match_both_front_ends(sm, oracle, c2, debug, fused, depth, n):
