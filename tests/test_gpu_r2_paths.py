@@ -48,6 +48,23 @@ def test_fast2d_prepare_both_front_ends(sm, oracle, c2, debug, fused):
     np.testing.assert_array_equal(got["sums"], ref["sums"])
 
 
+def test_concurrent_native_callers_get_the_single_caller_results(sm, c2):
+    """Four std::threads (csrc/host/thread_driver.cc: a C++ caller's thread pool in miniature)
+    issue three full-submap searches each through the C ABI at once: every one finds the match
+    and scores about as many candidates as a search on its own (workspaces, streams and scratch are per
+    call)."""
+    from cartographer_amd import synth
+    cells, lim, _, _, scan = c2
+    gm = sm.FastCorrelativeScanMatcher2D(_grid(sm, cells, lim), 7)
+    cloud = sm.PointCloudOnDevice(scan)
+    found, scores, poses, stats = sm.match_full_submap_batch([gm], cloud, 0.55)
+    assert found[0] == 1
+    seconds, candidates, hits = synth.threaded_full_submap_searches([gm], [cloud], 0.55, 4, 3)
+    assert seconds > 0 and hits == 12
+    # (how many nodes a search expands depends a little on when its blocks see the rising bound)
+    assert abs(candidates - 12 * stats["candidates_scored"]) <= 0.02 * 12 * stats["candidates_scored"]
+
+
 def test_timing_brackets_only_on_request(sm, c2, debug):
     """cmx_match_stats.*_ms: 0 by default (no HIP-event packets in the chain of launches), filled
     after cmx_debug_set("timing", 1); the result and the counters are the same either way."""
