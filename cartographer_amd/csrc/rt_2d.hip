@@ -682,29 +682,33 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
   }
   // A large batch goes out in PARTS, each with its own workspace and stream, all from the calling
   // thread: part k is planned, uploaded and launched while the kernels of the parts before it run,
-  // then the parts are collected in order (the finalisation of one under the kernels of the next).
-  // The first part is small, so that the device starts after ~40 us of host time, the following
-  // ones grow by half: the host prepares a match in ~0.2 us, the device needs ~0.35 us for it.
-  // (Until round 4 the parts ran on pool threads: a dispatch to the pool costs ~25 us, a cold
-  // worker ran its part three times slower than the caller, and eight streams share four hardware
-  // queues -- the second four parts waited for the first four.)  One part when the caller ordered
-  // the work on a stream of its own (cmx_set_stream is per thread).
+  // then the parts are collected in order.  (Until round 4 the parts ran on pool threads: a
+  // dispatch to the pool costs ~25 us, a cold worker ran its part three times slower than the
+  // caller, and eight streams share four hardware queues.)  How many parts, measured on C1's
+  // shape at 256 ... 2048 matches (tools/r04_call5{5,6,7}.sh, one box): EQUAL parts of roughly
+  // 800 matches, two at least -- the first schedule of the round, small first part then growing
+  // by half (128, 192, 320, 384 for 1024 matches), started the device 30 us earlier and then
+  // spread a match's rotations over more, smaller work items in every small part: 536 against
+  // 450 us at 1024 matches, 899 against 830 at 2048.  Below ~900 matches the parts also SHARE
+  // the CUs (each sizes its persistent tile grid and its work items for 1 / parts of them: the
+  // parts then run side by side from the start instead of one part's workgroups waiting for
+  // the other's to leave their CUs): 185 -> 169 us at 256 matches, 448 -> 368 at 768; above,
+  // the second part is still on the host while the first would idle half the chip, and the
+  // parts take all CUs as they come.  One part when the caller ordered the work on a stream of
+  // its own (cmx_set_stream is per thread).
   std::vector<int> part_end;
+  int num_parts = 1;
   if (OverrideStream(device) != nullptr) {
-    part_end.push_back(num);
+    num_parts = 1;
   } else if (Debug().rt2d_parts > 0) {
-    const int parts = std::max(1, std::min(std::min(16, Debug().rt2d_parts), num / 32));
-    for (int h = 0; h < parts; ++h)
-      part_end.push_back(static_cast<int>(static_cast<long long>(num) * (h + 1) / parts));
-  } else {
-    int size = 128, at = 0;
-    while (num - at > size + 96) {
-      at += size;
-      part_end.push_back(at);
-      size = std::min(512, (size * 3 / 2 + 63) / 64 * 64);
-    }
-    part_end.push_back(num);
+    num_parts = std::max(1, std::min(std::min(16, Debug().rt2d_parts), num / 32));
+  } else if (num >= 256) {
+    num_parts = std::max(2, std::min(8, (num + 400) / 800));
   }
+  for (int h = 0; h < num_parts; ++h)
+    part_end.push_back(static_cast<int>(static_cast<long long>(num) * (h + 1) / num_parts));
+  const bool share_cus = Debug().rt2d_grid_share ? Debug().rt2d_grid_share == 1
+                                                 : (num_parts > 1 && num < 896);
   const int parts = static_cast<int>(part_end.size());
   struct Part {
     int begin, end;
@@ -726,7 +730,8 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
       const double t0 = since_call();
       plan_search(p.begin, p.end);
       const double t_search = since_call();
-      p.call.reset(new Rt2DTileCall(options, items + p.begin, search.data() + p.begin, p.end - p.begin, device));
+      p.call.reset(new Rt2DTileCall(options, items + p.begin, search.data() + p.begin, p.end - p.begin, device,
+                                    share_cus ? parts : 1));
       const bool eligible = p.call->Plan();
       const double t_plan = since_call();
       if (eligible) {

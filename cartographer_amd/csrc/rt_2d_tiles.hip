@@ -1360,6 +1360,7 @@ struct Rt2DTileCall::Impl {
   int num, device;
   std::vector<TileGeometry> geo;
   int rpl = 1, max_scans = 0, common_stride = -1, group = 8, cus = 256;
+  int share = 1;                        // calls sharing the device (the parts of a batch)
   size_t tile_lds = 0, prep_lds = 0, finish_lds = 0;
   size_t lists_total = 0, hdr_total = 0, qsum_total = 0;
   long long work_cap = 0, entries_total = 0;
@@ -1374,10 +1375,11 @@ struct Rt2DTileCall::Impl {
 };
 
 Rt2DTileCall::Rt2DTileCall(const cmx_rt_options* options, const Rt2DItem* items,
-                           const Rt2DSearch* search, int num, int32_t device)
+                           const Rt2DSearch* search, int num, int32_t device, int concurrent_calls)
     : impl_(new Impl) {
   impl_->options = options; impl_->items = items; impl_->search = search;
   impl_->num = num; impl_->device = device;
+  impl_->share = std::max(1, concurrent_calls);
 }
 Rt2DTileCall::~Rt2DTileCall() {
   // (a call abandoned between its launches and its wait -- an exception in a later part: nothing
@@ -1577,7 +1579,7 @@ bool Rt2DTileCall::Plan() {
   // Entries per work item: the whole batch in about two items per resident workgroup (an item
   // costs ~4 us before its first window update: ticket, headers, lists, tasks, image), not less
   // than two thousand entries (sixteen tasks: one per wavefront).
-  const int tile_slots = single_tile ? cus : 2 * cus;
+  const int tile_slots = std::max(1, (single_tile ? cus : 2 * cus) / I.share);
   const int target = dbg.rt2d_target > 0
                          ? dbg.rt2d_target
                          : static_cast<int>(std::min<long long>(16384, std::max<long long>(2048, I.entries_total / (2ll * tile_slots))));

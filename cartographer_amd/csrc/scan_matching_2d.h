@@ -222,8 +222,10 @@ void Rt2DFinishOnHost(const cmx_rt_options* options, const Rt2DItem& item, const
 // keeps the parts of a large batch in flight on streams of their own (see there).
 class Rt2DTileCall {
  public:
+  // `concurrent_calls`: how many calls of this kind share the device at the same time (the parts
+  // of a batch): each sizes its tile grid and its work items for 1 / concurrent_calls of the CUs.
   Rt2DTileCall(const cmx_rt_options* options, const Rt2DItem* items, const Rt2DSearch* search,
-               int num, int32_t device);
+               int num, int32_t device, int concurrent_calls = 1);
   ~Rt2DTileCall();
   bool Plan();                          // false: not eligible for this path
   void Enqueue();                       // asynchronous
