@@ -260,6 +260,25 @@ class WorkspaceLease {
   Workspace* ws_;
 };
 
+// Four streams created one right after the other, for the parts of ONE call that must overlap on
+// the device.  The runtime deals its hardware queues (four by default) to streams as they are
+// created, least-loaded queue first, and two streams on one queue run one after the other: the
+// workspaces' own streams are created whenever a caller first needs one, so the two workspaces a
+// batch call happens to get may well share a queue (a 512-match RT-2D call measured 409 us in a
+// process that had served eight concurrent fast-2D callers, 256 us in a fresh one).  Streams
+// created back to back land on different queues.  Leased like workspaces; a set is never used by
+// two calls at once.
+class StreamSetLease {
+ public:
+  static constexpr int kStreams = 4;
+  explicit StreamSetLease(int device);
+  ~StreamSetLease();
+  hipStream_t stream(int k) const { return set_->s[k % kStreams]; }
+  struct Set { int device; hipStream_t s[kStreams]; };
+ private:
+  Set* set_;
+};
+
 // In-kernel timelines (debug switch timeline): see cmx_device.h Stamp().
 bool TimelineEnabled();
 // Prints, per stamp k, the median / max over blocks of (t_k - t_0) and the span of the whole

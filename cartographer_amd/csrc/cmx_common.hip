@@ -45,6 +45,7 @@ thread_local std::map<int, hipStream_t> g_stream_override;
 struct Pool {
   std::mutex mu;
   std::map<int, std::vector<Workspace*>> free_list;
+  std::map<int, std::vector<StreamSetLease::Set*>> free_stream_sets;
   ~Pool() {
     // Intentionally leak at process exit: the HIP runtime may already be
     // torn down when static destructors run.
@@ -396,6 +397,35 @@ WorkspaceLease::WorkspaceLease(int device) : ws_(nullptr) {
   }
   hipStream_t over = OverrideStream(device);
   ws_->stream = over ? over : ws_->own_stream;
+}
+
+StreamSetLease::StreamSetLease(int device) : set_(nullptr) {
+  UseDevice(device);
+  Pool& pool = ThePool();
+  {
+    std::lock_guard<std::mutex> lock(pool.mu);
+    auto& list = pool.free_stream_sets[device];
+    if (!list.empty()) {
+      set_ = list.back();
+      list.pop_back();
+    }
+  }
+  if (!set_) {
+    std::unique_ptr<Set> set(new Set);
+    set->device = device;
+    for (int k = 0; k < kStreams; ++k) set->s[k] = nullptr;
+    // (under the pool's lock: no other stream of this library is created in between)
+    std::lock_guard<std::mutex> lock(pool.mu);
+    for (int k = 0; k < kStreams; ++k)
+      CMX_HIP(hipStreamCreateWithFlags(&set->s[k], hipStreamNonBlocking));
+    set_ = set.release();       // (leaked with the pool at process exit, like the workspaces)
+  }
+}
+
+StreamSetLease::~StreamSetLease() {
+  Pool& pool = ThePool();
+  std::lock_guard<std::mutex> lock(pool.mu);
+  pool.free_stream_sets[set_->device].push_back(set_);
 }
 
 WorkspaceLease::~WorkspaceLease() {

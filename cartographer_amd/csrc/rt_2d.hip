@@ -719,6 +719,9 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
     std::string error;
   };
   std::vector<Part> part(parts);
+  // (the parts must overlap on the device: streams that sit on different hardware queues)
+  std::unique_ptr<StreamSetLease> part_streams;
+  if (parts > 1) part_streams.reset(new StreamSetLease(device));
   const auto since_call = [&]() {
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count();
   };
@@ -735,7 +738,7 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
       const bool eligible = p.call->Plan();
       const double t_plan = since_call();
       if (eligible) {
-        p.call->Enqueue();
+        p.call->Enqueue(part_streams ? part_streams->stream(h) : nullptr);
         p.enqueued = true;
       }
       if (host_trace)

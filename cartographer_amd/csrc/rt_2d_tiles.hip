@@ -1648,7 +1648,7 @@ bool Rt2DTileCall::Plan() {
   return true;
 }
 
-void Rt2DTileCall::Enqueue() {
+void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
   Impl& I = *impl_;
   const DebugOptions& dbg = Debug();
   const auto t_enter = std::chrono::steady_clock::now();
@@ -1697,6 +1697,7 @@ void Rt2DTileCall::Enqueue() {
 
   I.ws.reset(new WorkspaceLease(device));
   WorkspaceLease& ws = *I.ws;
+  if (on_stream) ws->stream = on_stream;      // (a lease sets its workspace's stream anew every time)
   char* h_in = ws->pinned[0].ReserveAs<char>(in_bytes);
   char* d_in = ws->dev[0].ReserveAs<char>(in_bytes);
   uint16_t* d_lists = I.fused ? nullptr : reinterpret_cast<uint16_t*>(ws->dev[1].Reserve(I.lists_total + 64));

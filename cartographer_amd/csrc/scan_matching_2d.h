@@ -228,7 +228,9 @@ class Rt2DTileCall {
                int num, int32_t device, int concurrent_calls = 1);
   ~Rt2DTileCall();
   bool Plan();                          // false: not eligible for this path
-  void Enqueue();                       // asynchronous
+  // asynchronous.  `on_stream`: the call's work goes on that stream instead of its workspace's
+  // own (the parts of a batch: StreamSetLease).
+  void Enqueue(hipStream_t on_stream = nullptr);
   bool Collect(cmx_match_stats* stats); // waits; false: repeat on the per-candidate kernels
  private:
   struct Impl;
