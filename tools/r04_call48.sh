@@ -3,7 +3,7 @@
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$REPO"
-OUT=gpurun_out/r04_final2
+OUT=gpurun_out/r04_final3
 mkdir -p $OUT
 export PYTHONUNBUFFERED=1
 ( time timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider ) > $OUT/pytest_gpu.txt 2>&1 < /dev/null
