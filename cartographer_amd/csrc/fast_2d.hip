@@ -796,22 +796,33 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
     const int cell = min(4 * sub + j, PIJ - 1);
     lane_const[j] = (cell % PI + dims.x + PI - 2) * pitch + (cell / PI + dims.y + PJ - 2);
   }
-  int cur = -1, pending = 0;
-  uint32_t even = 0, odd = 0;
+  // Four 32-bit running sums, one per plane cell of the lane's dword (round 4's per-chunk stamps:
+  // a step of this loop is ~15 issued instructions on a SIMD shared by 4.5 wavefronts -- 1.9 of a
+  // chunk's 2.1 us, the gathers themselves land in 0.16 -- so the packed 16-bit pairs, whose
+  // overflow guard cost a counter, a compare and a branch per step, are gone: byte k of the dword
+  // is added with one (SDWA) instruction each).
+  int cur = -1;
+  uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
   const auto flush = [&]() {
-    const int a0 = even & 0xffffu, a2 = even >> 16, a1 = odd & 0xffffu, a3 = odd >> 16;
-    if (a0) atomicAdd(&cand_acc[lane_const[0] - cur], a0);
-    if (a1) atomicAdd(&cand_acc[lane_const[1] - cur], a1);
-    if (a2) atomicAdd(&cand_acc[lane_const[2] - cur], a2);
-    if (a3) atomicAdd(&cand_acc[lane_const[3] - cur], a3);
-    even = odd = 0;
-    pending = 0;
+    if (a0) atomicAdd(&cand_acc[lane_const[0] - cur], static_cast<int>(a0));
+    if (a1) atomicAdd(&cand_acc[lane_const[1] - cur], static_cast<int>(a1));
+    if (a2) atomicAdd(&cand_acc[lane_const[2] - cur], static_cast<int>(a2));
+    if (a3) atomicAdd(&cand_acc[lane_const[3] - cur], static_cast<int>(a3));
+    a0 = a1 = a2 = a3 = 0;
   };
   constexpr int kSteps = 16;                // all gathers of a 64-point chunk in flight
   const int sentinel_plane = static_cast<int>(zero_plane * 64u);
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint8_t*>(P.planes), 0, static_cast<int>((zero_plane + 1) * 64), 0x00020000);
   for (int base_i = begin; base_i < end; base_i += 64) {
+    // (instrumented instantiation only -- wavefront 0's first chunk step by step: [8] chunk
+    // begins, [9] its sixteen gathers issued, [10] all of them landed, [11] consumed; [12..15]:
+    // the next four chunks begin.  DESIGN 5.1: which part of a chunk takes its 2.25 us)
+    const int chunk_index = (base_i - begin) >> 6;
+    if constexpr (kTimeline) {
+      if (chunk_index == 0) stamp(8);
+      else if (chunk_index <= 4) stamp(11 + chunk_index);
+    }
     // This lane's point of the chunk: byte offset of its phase plane and the constant
     // bx * pitch + by of its lattice block (-1: no candidate of this scan can reach it).
     int my_plane = sentinel_plane, my_block = -1;
@@ -834,15 +845,26 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
       block[k] = __shfl(my_block, src, 64);
       q[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, plane_offset + 4 * sub, 0, 0);
     }
+    if constexpr (kTimeline) {
+      if (chunk_index == 0) {
+        stamp(9);
+        __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the gathers' latency on its own
+        stamp(10);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < kSteps; ++k) {
       if (block[k] != cur) {                // per lane group; -1 = skipped point (adds zeros)
         if (cur >= 0) flush();
         cur = block[k];
       }
-      even += q[k] & 0x00ff00ffu;
-      odd += (q[k] >> 8) & 0x00ff00ffu;
-      if (++pending == 256) flush();        // 16-bit partial sums: 256 x 255 fits
+      a0 += q[k] & 0xffu;
+      a1 += (q[k] >> 8) & 0xffu;
+      a2 += (q[k] >> 16) & 0xffu;
+      a3 += q[k] >> 24;
+    }
+    if constexpr (kTimeline) {
+      if (chunk_index == 0) stamp(11);
     }
   }
   if (cur >= 0) flush();
