@@ -55,6 +55,20 @@ def test_adaptive_voxel_filter_equals_the_reference_source(oracle, seed, n, max_
         len(got) == len(ref)
 
 
+@pytest.mark.parametrize("n,size,spread", [(1, 120, 1.0), (2, 7, 0.3), (63, 1, 2.0), (65, 16, 0.5),
+                                           (5000, 120, 4.0), (70000, 120, 6.0), (20000, 8192, 3.0)])
+def test_compute_histogram_odd_shapes_equal_the_reference_source(oracle, n, size, spread):
+    """The shapes the device is checked on (tests/test_gpu_r2_paths.py::
+    test_compute_histogram_odd_shapes): the oracle those tests compare with IS the reference's
+    rotational_scan_matcher.cc there too -- one-point slices, slices of thousands of points,
+    sparse and dense clouds, histogram sizes 1 ... 8192."""
+    _need_ref(oracle)
+    rng = np.random.default_rng(n + size)
+    cloud = (rng.normal(0.0, spread, (n, 3)) * np.array([1.0, 1.0, 0.15])).astype(np.float32)
+    np.testing.assert_array_equal(oracle.compute_histogram(cloud, size),
+                                  oracle.ref_compute_histogram(cloud, size))
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_compute_histogram_equals_the_reference_source(oracle, synth, seed):
     _need_ref(oracle)
