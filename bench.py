@@ -20,6 +20,12 @@ i.e. completed Match* calls, per second).
                     RCCL over xGMI.  Per-GPU work is fixed as N grows: weak scaling.
   --config c1|c2|c3|c4|c5 selects the timed workload explicitly (single GPU for c1/c4/c5).
 
+Timed regions run the library as a production caller does: WITHOUT the HIP-event brackets behind
+cmx_match_stats' *_ms fields (they are packets the chain of launches waits behind: 24 of a single
+search's 156 us).  The kernel / device times of the roofline blocks come from a few untimed
+"instrumented" passes of the same workload right behind each region, with the brackets switched
+on (set_timing, instrumented; the headline: one extra step after the K timed ones).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
