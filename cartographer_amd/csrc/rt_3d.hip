@@ -612,10 +612,8 @@ Rt3DVerifyKernel(Rt3DBulkParams P, const float* __restrict__ group_upper, int nu
 // computes (CMX_RT3D_TILES=0 runs that kernel; tests compare the two).
 constexpr int kTileChunkGroups = 512;      // points per chunk, group pass (fewer, fuller work units)
 constexpr int kTileChunkCandidates = 256;  // ... candidate pass (its f32 stage is 12 B per point and rotation)
-constexpr int kTileChunk = kTileChunkGroups;   // (the larger one: sizes the shared declarations)
 constexpr int kTileBin = 24;
 constexpr int kTileMaxRotations = 8;
-constexpr int kTileStageStride = 3 * kTileChunk / 2 + 2;     // v2f per staged rotation (+16 B: bank shift)
 
 struct Rt3DTileParams {
   const float* sorted_xyz;       // bin-sorted cloud
