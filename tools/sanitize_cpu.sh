@@ -12,9 +12,10 @@ SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -g -O1"
 mkdir -p oracle/_build oracle/_ref cartographer_amd/lib
 ORACLE_SRCS=$(grep "^SRCS :=" oracle/Makefile | sed 's/SRCS := //')      # every restatement source
 (cd oracle && g++ $SAN -std=c++17 -fPIC -shared -ffp-contract=off -pthread -o _build/liboracle.so $ORACLE_SRCS)
-g++ $SAN -std=c++17 -fPIC -shared -ffp-contract=off -o cartographer_amd/lib/libcmx_synth.so \
+g++ $SAN -std=c++17 -fPIC -shared -ffp-contract=off -pthread -o cartographer_amd/lib/libcmx_synth.so \
     cartographer_amd/csrc/host/probability_grid_builder.cc \
-    cartographer_amd/csrc/host/hybrid_grid_builder.cc cartographer_amd/csrc/host/synth.cc
+    cartographer_amd/csrc/host/hybrid_grid_builder.cc cartographer_amd/csrc/host/synth.cc \
+    cartographer_amd/csrc/host/thread_driver.cc
 if [ -d /root/reference/cartographer ]; then
   SRCS=$(make -pn -C oracle ref 2>/dev/null | grep "^REF_SRCS" | head -1 | sed 's/REF_SRCS := //' |
          sed 's#\$(REFERENCE)#/root/reference#g')
