@@ -2,6 +2,7 @@
 
   cartographer_amd/lib/libcartographer_mi355x.so   HIP kernels + C ABI (hipcc, gfx950)
   cartographer_amd/lib/libcmx_synth.so             host-only fixture tooling (g++)
+  tools/bin/{gather_ceiling,row_gather_ceiling}    stand-alone micro-benchmarks (hipcc, gfx950)
 
 No JIT cache: the .so files live in the tree so they travel to the GPU box.
 """
@@ -67,8 +68,24 @@ def build_synth(force=False):
     return out
 
 
+def build_tools(force=False):
+    """The stand-alone micro-benchmarks under tools/ (gather ceilings the rooflines are priced on):
+    tools/bin/*, cross-compiled like the library so that they travel to the GPU box."""
+    root = os.path.dirname(HERE)
+    out_dir = os.path.join(root, "tools", "bin")
+    os.makedirs(out_dir, exist_ok=True)
+    built = []
+    for name in ("gather_ceiling", "row_gather_ceiling"):
+        src = os.path.join(root, "tools", name + ".hip")
+        out = os.path.join(out_dir, name)
+        if os.path.exists(src) and (force or _newer(out, [src])):
+            subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", src, "-o", out])
+        built.append(out)
+    return built
+
+
 def build_all(force=False, verbose=False):
-    return build_hip(force, verbose), build_synth(force)
+    return build_hip(force, verbose), build_synth(force), build_tools(force)
 
 
 if __name__ == "__main__":
