@@ -420,6 +420,12 @@ class Fast2DWorkload:
             "hbm_frac_algorithmic": alg / secs / 1e9 / HBM_PEAK_GBS,
             "hbm_frac_traffic": None if traffic is None else traffic / secs / 1e9 / HBM_PEAK_GBS,
             "kernel_share_of_step_device_time": acc["dominant_kernel_ms"] / max(acc["device_ms"], 1e-9),
+            # the same kernel against the measured rate of ITS OWN access pattern (four random
+            # 64-byte rows of a 256 KB table per wave-wide gather: tools/row_gather_ceiling.hip,
+            # profiles/r04_row_gather_ceiling.txt: 10.83 cycles per instruction and CU)
+            "gather_instructions": scans * self.n_points / 4.0,
+            "frac_of_gather_pattern_rate": (scans * self.n_points / 4.0) / secs /
+                                           (256 * 2.4e9 / 10.83),
             "note": "frac = bytes the kernel gathers through L2 (one 64-byte phase plane per point "
                     "per rotation, an upper bound: points no candidate can reach are skipped) / "
                     "kernel time / L2 peak 34.5 TB/s.  hbm_frac_algorithmic may exceed 1: the "

@@ -20,9 +20,13 @@ if [ -d /root/reference/cartographer ]; then
   SRCS=$(make -pn -C oracle ref 2>/dev/null | grep "^REF_SRCS" | head -1 | sed 's/REF_SRCS := //' |
          sed 's#\$(REFERENCE)#/root/reference#g')
   (cd oracle && g++ $SAN -DNDEBUG -ffp-contract=off -std=c++17 -fPIC -shared -pthread \
-      -Iref_shims -I/root/reference -o _ref/libref.so ref_wrapper.cc $SRCS)
+      -Iref_shims -I/root/reference -o _ref/libref.so ref_wrapper.cc ref_wrapper_rt3d_mt.cc $SRCS)
+  CERES_SRCS=$(make -pn -C oracle ref_ceres 2>/dev/null | grep "^REF_CERES_SRCS" | head -1 | sed 's/REF_CERES_SRCS := //' |
+         sed 's#\$(REFERENCE)#/root/reference#g')
+  (cd oracle && g++ $SAN -DNDEBUG -ffp-contract=off -std=c++17 -fPIC -shared -pthread \
+      -Iref_shims -I/root/reference -o _ref/libref_ceres.so ref_ceres_wrapper.cc $CERES_SRCS)
 fi
-touch oracle/_build/liboracle.so cartographer_amd/lib/libcmx_synth.so oracle/_ref/libref.so 2>/dev/null || true
+touch oracle/_build/liboracle.so cartographer_amd/lib/libcmx_synth.so oracle/_ref/libref.so oracle/_ref/libref_ceres.so 2>/dev/null || true
 export LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)"
 export ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1
 # (the ABI / adapter / bench-contract tests load the HIP library or spawn subprocesses: left out)
