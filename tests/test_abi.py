@@ -126,3 +126,18 @@ def test_struct_layouts_agree_with_the_header(tmp_path):
         got = [getattr(mirror, f[0]).offset for f in mirror._fields_]
         assert len(got) == len(offsets), (name, members[name], [f[0] for f in mirror._fields_])
         assert got == offsets, (name, got, offsets)
+
+
+def test_debug_switches_the_bench_and_the_tools_rely_on_exist():
+    """cmx_debug_set works without a device (it only stores the value): `timing` brackets the calls
+    with HIP events for cmx_match_stats' *_ms fields (bench.py switches it on for its instrumented
+    passes only), the RT-2D batch knobs drive tools/c1_probe.py; an unknown name is an error, not
+    a silent no-op."""
+    from cartographer_amd import _lib
+    try:
+        _lib.debug_set(timing=1, rt2d_parts=2, rt2d_grid_share=2, no_copy_kernels=1,
+                       no_direct_results=1)
+        with pytest.raises(_lib.CmxError):
+            _lib.debug_set(no_such_switch=1)
+    finally:
+        _lib.debug_reset()
