@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of an experiment: the debug switch it sets was removed together with the variant that lost -- DESIGN.md 5.3)
 # tile workgroups that exit after N items (CUs free up for the other parts' finish kernels)
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record: fast_2d.hip at the time of this call held the pipelined-gather variant that was removed -- DESIGN.md 5.1)
 # fused front end: branch-free accumulation, half-chunk gathers kept in flight across chunks
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
