@@ -69,6 +69,9 @@ def parse_args():
     ap.add_argument("--beams", type=int, default=1000)
     ap.add_argument("--min-score", type=float, default=0.6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the device-vs-reference gate in front of the timed regions "
+                         "(profiling runs only: the line then carries no `parity`)")
     ap.add_argument("--no-other", action="store_true",
                     help="skip the C1 / C3-share / C4 / C5 measurements reported under config.other")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -93,6 +96,10 @@ def parse_args():
                     help="directory with <tag>_pmc_{fetch,write}_size.csv of THIS command "
                          "(tools/profile_bench.sh writes them); roofline.traffic is null without")
     ap.add_argument("--pmc-tag", default="r04")
+    ap.add_argument("--details", default=os.path.join(ROOT, "gpurun_out", "bench_details.json"),
+                    help="file the FULL record goes to (per-config blocks, notes, nested "
+                         "rooflines); the line on stdout is the compact headline (< 4 KB); "
+                         "'' = do not write it")
     return ap.parse_args()
 
 
@@ -288,14 +295,7 @@ def cpu_baseline_c5(w, seconds):
     if orc.ref_lib() is None:
         return None
     cores = _cores()
-    o = w.opt
-    m = orc.ReferenceFastCorrelativeScanMatcher3D(
-        0.1, w.vox, 0.45, w.low_vox, w.hist, o["branch_and_bound_depth"],
-        o["full_resolution_depth"], o["min_rotational_score"], o["min_low_resolution_score"],
-        o["linear_xy_search_window"], o["linear_z_search_window"], o["angular_search_window"])
-    node = list(w.node.translation) + list(w.node.rotation)
-    call = lambda: m.match(node, [0, 0, 0, 1, 0, 0, 0], [1, 0, 0, 0], w.hi, w.lo,   # noqa: E731
-                           w.scan_hist, 0.2)
+    call = w.reference_match
     t0 = time.perf_counter()
     one = call()
     t_one = time.perf_counter() - t0
@@ -306,6 +306,73 @@ def cpu_baseline_c5(w, seconds):
             "sample": f"{calls} Match calls of the C5 node against submap #0 by the reference's own "
                       f"fast_correlative_scan_matcher_3d.cc (oracle/_ref; precomputation stack built "
                       f"beforehand), {cores} threads, {dt:.1f} s"}
+
+
+# --------------------------------------------------------------------------------------
+# Parity gate ("parity gate before any timing is reported").  Every
+# workload compares what the DEVICE returned with what the REFERENCE returns on the same bytes
+# -- the reference's own sources (oracle/_ref) where the prebuilt library travelled with the
+# repo, else the oracle port (bit-identical to them: tests/test_reference_ref*.py), for C4 the
+# committed output of the reference (tests/golden/rt3d_c4_reference.json: ten CPU-minutes) --
+# BEFORE its timed region; a mismatch beyond the north star's 1e-4 aborts the run.  The checker
+# is never inside a timed region.
+# --------------------------------------------------------------------------------------
+PARITY_TOL = 1e-4
+
+
+class ParityError(RuntimeError):
+    pass
+
+
+def _reference_kind():
+    from oracle import pyoracle as orc
+    try:
+        return "reference" if orc.ref_lib() is not None else "port"
+    except Exception:       # noqa: BLE001
+        return "port"
+
+
+def parity_record(kind, pairs):
+    """pairs: (device_found, device_score, device_pose, ref_found, ref_score, ref_pose) per
+    checked match; poses as flat sequences (None when not found)."""
+    dscore = dpose = 0.0
+    exact = True
+    for i, (df, ds, dp, rf, rs, rp) in enumerate(pairs):
+        if bool(df) != bool(rf):
+            raise ParityError(f"parity: match {i}: device found={bool(df)} vs {kind} found={bool(rf)}")
+        if not rf:
+            continue
+        a, b = float(np.float32(ds)), float(np.float32(rs))
+        dscore = max(dscore, abs(a - b))
+        d = float(np.max(np.abs(np.asarray(dp, np.float64) - np.asarray(rp, np.float64))))
+        dpose = max(dpose, d)
+        exact = exact and a == b and d == 0.0
+    out = {"vs": kind, "checked": len(pairs), "max_abs_dscore": dscore, "max_abs_dpose": dpose,
+           "bit_exact": exact, "tol": PARITY_TOL}
+    if dscore > PARITY_TOL or dpose > PARITY_TOL:
+        raise ParityError(f"parity: device differs from the {kind}: {out}")
+    return out
+
+
+def _parity_word(record):
+    """One word for the summary: "exact", the largest difference, or None (not checked)."""
+    if not record or not record.get("checked"):
+        return None
+    if record.get("bit_exact"):
+        return "exact"
+    return f"{max(record['max_abs_dscore'], record['max_abs_dpose']):.1e}"
+
+
+def parity_gate(workload, result=None):
+    """workload.parity(result) with the library's event brackets off; `result` = a device result
+    of workload.search() (one is taken when None).  Raises ParityError; returns the record, or
+    {"vs": None} for a leg that has no reference of its own (it repeats a checked workload)."""
+    check = getattr(workload, "parity", None)
+    if check is None:
+        return {"vs": None, "checked": 0}
+    if result is None:
+        result = workload.search()
+    return check(result)
 
 
 # --------------------------------------------------------------------------------------
@@ -337,11 +404,14 @@ class Fast2DWorkload:
             positive = 0
         self.matchers = []
         self.cells0 = self.lim0 = None
+        self.host_submaps = []
         for gid in range(self.begin, self.end):
             m, cells, lim, world = _submap(synth, sm, 42 + gid, args.grid, args.depth, device)
             self.matchers.append(m)
             if self.cells0 is None:
                 self.cells0, self.lim0 = cells, lim
+            if len(self.host_submaps) < 4:          # (the parity gate's share of a block)
+                self.host_submaps.append((cells, lim))
         # Every rank draws the same scan, from the world of the one true-positive submap.
         truth = synth.make_submap(42 + positive, args.grid, args.grid, 0.05, 30, 1000, 30.0,
                                   0.01)[2]
@@ -363,6 +433,27 @@ class Fast2DWorkload:
     def search(self, k=0):
         return self.sm.match_full_submap_batch(self.matchers, self.clouds[k % len(self.clouds)],
                                                self.args.min_score)
+
+    def parity(self, result):
+        """The first submaps of this rank's block (at most four: 0.4 s of one host core each)
+        searched by the reference with the bench scan; found / score / pose against the device's."""
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import pyoracle as orc
+        kind = _reference_kind()
+        cls = (orc.ReferenceFastCorrelativeScanMatcher2D if kind == "reference"
+               else orc.FastCorrelativeScanMatcher2D)
+        a = self.args
+
+        def one(host):
+            cells, lim = host
+            return cls(cells, lim["resolution"], lim["max_x"], lim["max_y"],
+                       a.depth).match_full_submap(self.scan, a.min_score)
+        with ThreadPoolExecutor(len(self.host_submaps)) as pool:
+            refs = list(pool.map(one, self.host_submaps))
+        self.reference_result = refs[0]
+        found, scores, poses = result[0], result[1], result[2]
+        return parity_record(kind, [(found[i], scores[i], poses[i], r["found"], r["score"],
+                                     r["pose"]) for i, r in enumerate(refs)])
 
     def exchange(self, found, scores, poses, torch_device):
         """What crosses xGMI per step: every submap's optional constraint to every rank (the
@@ -536,6 +627,27 @@ class Rt2DWorkload:
         self.candidates_per_match = stats["candidates_scored"] // self.matches_per_step
         return np.ones(len(scores), np.int32), scores, poses, stats
 
+    def parity(self, result):
+        """Every distinct (grid, scan, initial pose) of the batch -- at most eight -- matched by
+        the reference's real_time_correlative_scan_matcher_2d.cc (a few ms each)."""
+        from oracle import pyoracle as orc
+        kind = _reference_kind()
+        fn = orc.ref_rt2d_match if kind == "reference" else orc.rt2d_match
+        if self.dirty:      # the device grids have had scans inserted: read them back
+            grids = [(g.cells, g.limits) for g in self.distinct_grids]
+        else:
+            grids = list(zip(self.host_cells, self.host_lims))
+        scores, poses = result[1], result[2]
+        pairs = []
+        for i in range(min(self.matches_per_step, len(grids))):
+            cells, lim = grids[i]
+            init = self.I[i]
+            r = fn(cells, lim["resolution"], lim["max_x"], lim["max_y"],
+                   [init.x, init.y, init.theta], self.S[i], 0.3, math.radians(7.0), 0.1, 0.1)
+            pairs.append((True, scores[i], np.asarray(poses[i], np.float64).reshape(-1)[:3], True,
+                          r["score"], r["pose"]))
+        return parity_record(kind, pairs)
+
     def describe(self, stats, found):
         out = {"workload": f"C1: 2D RealTimeCorrelativeScanMatcher, {self.matches_per_step} "
                            f"independent matches per step, {self.n_points}-point scans vs "
@@ -652,6 +764,20 @@ class Rt3DWorkload:
     def search(self, k=0):
         score, est = self.m.match(self.init, self.cloud, 0.1, self.vox)
         return np.ones(1, np.int32), np.array([score], np.float32), [est], self.m.last_stats
+
+    def parity(self, result):
+        """The reference's real_time_correlative_scan_matcher_3d.cc on this workload is ten
+        minutes of eight host cores: its committed output (tests/golden/rt3d_c4_reference.json,
+        made by tests/golden/make_rt3d_c4_golden.py from the same seeded inputs,
+        tests/golden/workloads.py rt3d_c4)."""
+        path = os.path.join(ROOT, "tests", "golden", "rt3d_c4_reference.json")
+        with open(path) as f:
+            g = json.load(f)["rt3d_c4"]
+        assert g["num_points"] == self.n_points, "the golden file is of another cloud"
+        est = result[2][0]
+        pose = list(est.translation) + list(est.rotation)
+        return parity_record("reference (committed output, tests/golden/rt3d_c4_reference.json)",
+                             [(True, result[1][0], pose, True, g["score"], g["pose"])])
 
     def describe(self, stats, found):
         return {"workload": f"C4: 3D RealTimeCorrelativeScanMatcher, {self.n_points}-point cloud vs "
@@ -811,6 +937,40 @@ class Fast3DWorkload:
         found = np.array([r is not None for r in results], np.int32)
         scores = np.array([r["score"] if r else 0.0 for r in results], np.float32)
         return found, scores, results, stats
+
+    def reference_matcher(self):
+        """The reference's fast_correlative_scan_matcher_3d.cc over submap #0's grids (or the
+        oracle port when oracle/_ref did not travel); built once: the parity gate and the CPU
+        baseline leg share it."""
+        if getattr(self, "_reference", None) is None:
+            from oracle import pyoracle as orc
+            kind = _reference_kind()
+            cls = (orc.ReferenceFastCorrelativeScanMatcher3D if kind == "reference"
+                   else orc.FastCorrelativeScanMatcher3D)
+            o = self.opt
+            self._reference = (kind, cls(
+                0.1, self.vox, 0.45, self.low_vox, self.hist, o["branch_and_bound_depth"],
+                o["full_resolution_depth"], o["min_rotational_score"],
+                o["min_low_resolution_score"], o["linear_xy_search_window"],
+                o["linear_z_search_window"], o["angular_search_window"]))
+        return self._reference
+
+    def reference_match(self):
+        node = list(self.node.translation) + list(self.node.rotation)
+        return self.reference_matcher()[1].match(node, [0, 0, 0, 1, 0, 0, 0], [1, 0, 0, 0],
+                                                 self.hi, self.lo, self.scan_hist, 0.2)
+
+    def parity(self, result):
+        """Submap #0 (the node's own world; on the rank that owns it) matched by the reference."""
+        if self.begin != 0:
+            return {"vs": None, "checked": 0}
+        ref = self.reference_match()
+        got = result[2][0]
+        pose = None if got is None else (list(got["pose_estimate"].translation) +
+                                         list(got["pose_estimate"].rotation))
+        return parity_record(self.reference_matcher()[0],
+                             [(got is not None, 0.0 if got is None else got["score"], pose,
+                               ref["found"], ref["score"], ref["pose"])])
 
     def describe(self, stats, found):
         out = {"workload": f"C5: 3D FastCorrelativeScanMatcher Match, one node against {self.total} "
@@ -989,8 +1149,10 @@ def other_configs(args, device, sync, pmc):
         try:
             t0 = time.perf_counter()
             w = factory()
+            par = None if args.no_parity else parity_gate(w)   # device vs reference, BEFORE timing
             dt, acc, last = measure(w, steps, warmup, sync)
             entry = w.describe(last[3], last[0])
+            entry["parity"] = par
             inserted = getattr(w, "insert_s", 0.0)
             if inserted:       # (dirty-grid leg: the insertions between the steps are not the step)
                 entry["grid_insertions_ms_per_step"] = inserted / steps * 1e3
@@ -1048,6 +1210,91 @@ def other_configs(args, device, sync, pmc):
             out[name]["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
 
     return out
+
+
+# --------------------------------------------------------------------------------------
+# The ONE line on stdout.  The driver's record keeps a line of a few KB (round 4's 30 KB line
+# came back unparsed): the headline is scalars + five small objects, everything else -- the
+# per-config blocks with their notes and nested rooflines -- goes to a file next to it.
+# --------------------------------------------------------------------------------------
+LINE_LIMIT = 4096
+
+CONFIG_KEYS = ("name", "host_threads", "passes_per_step", "ms_per_pass", "candidates_per_step",
+               "candidates_per_pass", "lowest_resolution_candidates_per_pass", "matches_per_s",
+               "device_ms_per_pass", "timed_region_s", "submaps_per_gpu", "rotations", "found",
+               "nodes_expanded_per_step", "single_stream_ms_per_search",
+               "constraints_found_node_wide", "best_match", "matches_per_step", "pairs_per_step")
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms",
+                 "algorithmic_bytes", "hbm_frac_algorithmic", "hbm_frac_traffic",
+                 "kernel_ms_in_the_timed_region", "frac_in_the_timed_region")
+CPU_KEYS = ("value", "unit", "cores", "kind", "matches_per_s", "single_thread_candidates_per_s")
+SUMMARY_KEYS = ("ms", "cand_per_s", "matches_per_s", "frac", "bound", "cpu", "parity", "error")
+
+
+def _num(v, digits=6):
+    """Floats to `digits` significant figures (the line is for reading; the details file keeps
+    everything); containers recursively."""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, (float, np.floating)):
+        v = float(v)
+        return v if v == 0 or not math.isfinite(v) else float(f"{v:.{digits}g}")
+    if isinstance(v, (np.integer,)):
+        return int(v)
+    if isinstance(v, dict):
+        return {k: _num(x, digits) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_num(x, digits) for x in v]
+    return v
+
+
+def _clip(text, limit):
+    text = str(text)
+    return text if len(text) <= limit else text[:limit - 3] + "..."
+
+
+def headline(out, details_path):
+    """The compact line from the full record: contract keys as they are; `config`, `roofline`,
+    `cpu_baseline` cut down to their scalar keys (text clipped); `summary` one small object per
+    measured config.  Asserts the size: a longer line is a bug here, not a driver problem."""
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup",
+                                "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                "dtype", "data", "constraints_per_s")}
+    cfg = out["config"]
+    line["config"] = {"workload": _clip(cfg["workload"], 200)}
+    line["config"].update({k: cfg[k] for k in CONFIG_KEYS if k in cfg})
+    roof = out["roofline"]
+    line["roofline"] = {"kernel": _clip(roof.get("kernel", ""), 80)}
+    line["roofline"].update({k: roof[k] for k in ROOFLINE_KEYS if k in roof})
+    line["roofline"]["traffic_source"] = None if roof.get("traffic") is None else "profiles/"
+    if "cpu_baseline" in out:
+        base = out["cpu_baseline"]
+        line["cpu_baseline"] = {k: base[k] for k in CPU_KEYS if k in base}
+        line["cpu_baseline"]["sample"] = _clip(base.get("sample", ""), 160)
+    if "parity" in out:
+        line["parity"] = out["parity"]
+    line["details"] = details_path
+    line["summary"] = {name: {k: e[k] for k in SUMMARY_KEYS if e.get(k) is not None}
+                       for name, e in out.get("summary", {}).items()}
+    line = _num(line)
+    line["summary"] = _num(line["summary"], 4)
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, f"bench line is {len(text)} bytes (limit {LINE_LIMIT})"
+    return text
+
+
+def write_details(out, path):
+    """The full record (per-config blocks, notes, nested rooflines): a file, and stderr."""
+    if not path:
+        return None
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1, default=float)
+        return os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT) else path
+    except OSError as e:
+        sys.stderr.write(f"bench details not written ({e})\n")
+        return None
 
 
 def main():
@@ -1135,6 +1382,9 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # ---- parity gate: this rank's device result against the reference, before any timing ----
+    parity = None if args.no_parity else parity_gate(workload)
 
     # ---- passes per step: a step is one pass over a BATCH of searches, sized (untimed) so that
     # it lasts >= 30 ms; every rank uses the same number ------------------------------------
@@ -1262,8 +1512,11 @@ def main():
             "config": config,
             "roofline": roof,
         }
+        if parity is not None:
+            out["parity"] = parity
         summary = {name: {"ms": config["ms_per_pass"], "cand_per_s": out["value"],
-                          "frac": roof.get("frac"), "bound": roof.get("bound")}}
+                          "frac": roof.get("frac"), "bound": roof.get("bound"),
+                          "parity": _parity_word(parity)}}
         if world_size == 1 and not use_dist and not args.no_other and name == "c2":
             # Single-stream latency of the headline workload, then every other BASELINE config.
             single = Fast2DWorkload(args, device, 0, 1, sharded=False)
@@ -1299,6 +1552,9 @@ def main():
                          "c5_share_32_submaps_no_families": "c5s32_nofam"}.get(key, key)
                 if "error" in e:
                     config[f"{short}_error"] = e["error"][:80]
+                    summary[short] = {"error": e["error"][:60]}
+                    if e["error"].startswith("ParityError") and "parity" in out:
+                        out["parity"].setdefault("failed_elsewhere", []).append(short)
                     continue
                 r = e.get("roofline") or {}
                 config[f"{short}_ms"] = e["ms_per_step"]
@@ -1316,7 +1572,8 @@ def main():
                 summary[short] = {"ms": e["ms_per_step"], "cand_per_s": e["candidates_per_s"],
                                   "matches_per_s": e["matches_per_s"], "frac": r.get("frac"),
                                   "bound": r.get("bound"), "cpu": c.get("value"),
-                                  "cpu_unit": c.get("unit"), "cpu_cores": c.get("cores")}
+                                  "cpu_unit": c.get("unit"), "cpu_cores": c.get("cores"),
+                                  "parity": _parity_word(e.get("parity"))}
         # The headline's CPU baseline runs LAST (after every GPU leg: seconds of 32 busy host
         # threads right before a host-bound GPU leg distort it).  JSON key order is irrelevant.
         if not args.no_cpu_baseline and world_size == 1 and name in ("c2", "c3"):   # rank 0, N = 1
@@ -1343,7 +1600,8 @@ def main():
         # drain it first so that the JSON line is the LAST thing on stdout.
         import ctypes
         ctypes.CDLL(None).fflush(None)
-        sys.stdout.write(json.dumps(out) + "\n")
+        details = write_details(out, args.details)
+        sys.stdout.write(headline(out, details) + "\n")
         sys.stdout.flush()
 
 
