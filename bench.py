@@ -421,8 +421,10 @@ class Fast2DWorkload:
         # A step is a batch of passes: pass k searches with scan k mod `--scans` (scans taken at
         # different poses of the same world, resident in HBM like the first).
         self.clouds = [self.cloud]
+        self.host_scans = [self.scan]
         for k in range(1, max(1, getattr(args, "scans", 1))):
             sk = truth.scan(truth.free_pose(1234 + k, 0.5), args.beams, 30.0, 0.01, 7 + k)
+            self.host_scans.append(sk)
             self.clouds.append(sm.PointCloudOnDevice(sk, device=device))
         self.n_points = self.scan.shape[0]
         self.matches_per_step = len(self.matchers)
@@ -556,6 +558,7 @@ class Fast2DConcurrentWorkload(Fast2DWorkload):
 
     def search(self, k=0):
         results = list(self.pool.map(lambda j: Fast2DWorkload.search(self, j), range(self.threads)))
+        self.last_results = results
         found = np.concatenate([r[0] for r in results])
         scores = np.concatenate([r[1] for r in results])
         stats = dict(results[0][3])
@@ -563,6 +566,20 @@ class Fast2DConcurrentWorkload(Fast2DWorkload):
             for key, v in r[3].items():
                 stats[key] = stats.get(key, 0) + v
         return found, scores, results[-1][2], stats
+
+    def parity(self, result):
+        """Every one of the scans searched by the reference (one host thread each) against the
+        device result of the same scan."""
+        from oracle import pyoracle as orc
+        kind = _reference_kind()
+        cls = (orc.ReferenceFastCorrelativeScanMatcher2D if kind == "reference"
+               else orc.FastCorrelativeScanMatcher2D)
+        a, lim = self.args, self.lim0
+        matcher = cls(self.cells0, lim["resolution"], lim["max_x"], lim["max_y"], a.depth)
+        refs = list(self.pool.map(lambda sc: matcher.match_full_submap(sc, a.min_score),
+                                  self.host_scans[:self.threads]))
+        return parity_record(kind, [(d[0][0], d[1][0], d[2][0], r["found"], r["score"], r["pose"])
+                                    for d, r in zip(self.last_results, refs)])
 
     def describe(self, stats, found):
         out = super().describe(stats, found)

@@ -855,7 +855,9 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
 #pragma unroll
     for (int k = 0; k < kSteps; ++k) {
       if (block[k] != cur) {                // per lane group; -1 = skipped point (adds zeros)
-        if (cur >= 0) flush();
+        // (cur == -1: nothing has been added but bytes of the zero plane, every sum is 0 and
+        // flush() issues no addition -- no second test per step)
+        flush();
         cur = block[k];
       }
       a0 += q[k] & 0xffu;
