@@ -14,7 +14,7 @@ constexpr int kRt2DMaxPoints = 8192;        // points per scan the tile path tak
 // Finalists of a match: (candidate index, f32 score bits) pairs -- the first kFinalistHead next
 // to the counters (they travel back with them), the rest in the overflow region.
 constexpr int kFinalistCap = 4096;
-constexpr int kFinalistHead = 62;           // 2 + 2 * 62 words = 512 bytes per match
+constexpr int kFinalistHead = 61;           // 2 + 2 * 61 words, then two bound and two stage counters: 512 bytes per match
 constexpr int kMaxRowsPerLane = 8;
 #ifndef CMX_RT2D_TASK_ITERS
 #define CMX_RT2D_TASK_ITERS 64

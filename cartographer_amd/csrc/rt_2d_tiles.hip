@@ -59,6 +59,8 @@ constexpr int kMaxTiles = 16;               // tiles of a match's bounding box (
 constexpr int kStage1Cap = 1024;            // candidates the exact integer pass takes per match
 constexpr unsigned kFlat = 0xffffffffu;     // misc[1]: more candidates than the lists hold
 constexpr unsigned kOutOfBox = 0x80000000u; // misc[0] (next to the prep tickets): a point fell outside the predicted box
+constexpr unsigned kBoundFlat = 0x20000000u;       // misc[0]: more blocks reach the bound than the bound kernel lists (flat landscape)
+constexpr unsigned kBoundViolated = 0x40000000u;   // misc[0], debug switch rt2d_bounds_verify: a block bound below one of its candidates
 
 struct Rt2DTileParams {
   // grid and initial pose
@@ -108,6 +110,16 @@ struct Rt2DTileParams {
   unsigned* stage;           // [0] candidates of the exact integer pass, [1] f32 finalists | rotations with finalists << 16
   unsigned long long* timeline;   // debug switch `timeline`: 16 stamps per tile / finish workgroup, else null
   int timeline_finish_base;       // first slot of the finish kernel's workgroups
+  // block bounds (rt_2d_bounds.h): the four parity planes of the 2 x 2 max-pooled image behind
+  // the quantised image (null: window beyond 16 x 16), and this match's LDS copy of them
+  const uint8_t* m2;
+  int m2_pitch, m2_rows;     // bytes per plane row (multiple of 4), rows per plane
+  int b_c0, b_r0;            // first plane column (multiple of 4) / row of the LDS copy
+  int b_lpb, b_lh;           // its pitch in bytes (multiple of 4) and rows
+  unsigned* bstat;           // misc + 124: [0] blocks summed exactly, [1] block bounds evaluated
+  int b_verify;              // debug switch rt2d_bounds_verify
+  int b_ub_at;               // this match's block sums in the launch's HBM scratch (rotation groups > 1)
+  int b_tail_at;             // LDS offset of rotations | block sums | list | sums (behind the fused finish's region)
 };
 
 // A barrier for data that travels through LDS only.  __syncthreads() carries a workgroup-scope
@@ -303,9 +315,14 @@ Rt2DTilePrepKernel(const Rt2DTileParams* __restrict__ params, int* __restrict__ 
 // Dynamic LDS: cells[n_pad] u32 | prob[group][n_pad + 4] f32 | rot_flag[num_scans] |
 //   fin[kStage1Cap] | exact[kStage1Cap] | fin2[kStage1Cap]
 // ---------------------------------------------------------------------------------------------
+// `cand_e` / `cand_q` (LDS, outside the region this function lays out; or null): the candidates
+// the caller has summed and their quantised sums -- the bound kernel, rt_2d_bounds.h: every other
+// candidate of the match lies below the best lower bound and is not looked at.
 template <int kThreads, bool kCoherent, bool kTimeline>
 __device__ __forceinline__ void Rt2DFinishMatch(Rt2DTileParams& P, unsigned char* fin_smem, int group,
-                                                unsigned* __restrict__ host_out, int match) {
+                                                unsigned* __restrict__ host_out, int match,
+                                                const int* cand_e = nullptr, const int* cand_q = nullptr,
+                                                int cand_count = 0) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int kWaves = kThreads / 64;
@@ -359,10 +376,27 @@ __device__ __forceinline__ void Rt2DFinishMatch(Rt2DTileParams& P, unsigned char
   float lb_max = 0.f;
   constexpr int kOwn = kThreads > 512 ? 8 : 16;   // candidates a thread keeps in registers (8192 in all)
   const int total = P.num_scans * cands;
-  const bool in_registers = total <= kOwn * kThreads;
+  const bool listed = cand_e != nullptr;
+  const bool in_registers = !listed && total <= kOwn * kThreads;
   float ub_own[kOwn];
   const int owned = (total + kThreads - 1) / kThreads;      // (uniform)
-  if (in_registers) {
+  // weighted [lower, upper] bound of candidate e from its quantised sum
+  const auto bounds_of = [&](int e, int q, float* lower, float* upper) {
+    const int s = e / cands, c = e - s * cands;
+    const int dxi = c / side, dyi = c - dxi * side;
+    const float cx = -(dyi - P.nl) * res_f, cy = -(dxi - P.nl) * res_f;
+    const float w = weight(sqrtf(cx * cx + cy * cy) * wt_f, s);
+    const float base = 0.1f + per_q * static_cast<float>(q);
+    *lower = (base - slack) * w * (1.f - 1e-5f);
+    *upper = (base + width + slack) * w * (1.f + 1e-5f);
+  };
+  if (listed) {
+    for (int k = tid; k < cand_count; k += kThreads) {
+      float lower, upper;
+      bounds_of(cand_e[k], cand_q[k], &lower, &upper);
+      lb_max = fmaxf(lb_max, lower);
+    }
+  } else if (in_registers) {
     // The usual case (C1: 4563 candidates, 9 per thread): ONE round of loads, every upper bound
     // stays in a register until the best lower bound is known.
     int q_own[kOwn];
@@ -413,7 +447,18 @@ __device__ __forceinline__ void Rt2DFinishMatch(Rt2DTileParams& P, unsigned char
 #pragma unroll
   for (int w = 0; w < kWaves; ++w) best_bits = max(best_bits, red[w]);
   const float best_lb = __uint_as_float(best_bits);
-  if (in_registers) {
+  if (listed) {
+    for (int k = tid; k < cand_count; k += kThreads) {
+      float lower, upper;
+      const int e = cand_e[k];
+      bounds_of(e, cand_q[k], &lower, &upper);
+      if (upper >= best_lb) {
+        const int at = atomicAdd(&nfin, 1);
+        if (at < kStage1Cap) fin[at] = e;
+        rot_flag[e / cands] = 1;
+      }
+    }
+  } else if (in_registers) {
     const float inv_cands = 1.f / static_cast<float>(cands);
 #pragma unroll
     for (int k = 0; k < kOwn; ++k) {
@@ -1096,6 +1141,8 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group,
   Rt2DFinishMatch<kFinishThreads, false, true>(P, fin_smem, group, host_out, blockIdx.x);
 }
 
+#include "rt_2d_bounds.h"
+
 size_t Align16(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
 
 // Conflict-free LDS row pitch (bytes, a multiple of 16, >= min_bytes; 0: none exists): the H x B
@@ -1143,7 +1190,13 @@ struct TileGeometry {
   int cap_s, gmin, gmax, target, rw, list_lds, task_cap;
   int groups;               // fused: the rotation groups (work items) of this match, chosen by the host
   size_t lds;               // of the tile kernel
-  size_t image_bytes;       // of the grid image in HBM
+  size_t image_bytes;       // of the grid image in HBM: quantised image + pooled planes
+  size_t q_bytes;           // of the quantised image alone (the planes start behind it)
+  int m2_pitch, m2_rows;    // pooled planes (0: window beyond 16 x 16, no planes)
+  int b_lpb, b_lh;          // bound kernel: LDS copy of the planes
+  size_t b_lds;             // bound kernel: dynamic LDS of this match
+  size_t b_finish_room;     // of it: planes | zeros | cloud, which its fused finish lays out anew
+  size_t b_tail_at;         // where the rest starts: behind those, and behind what the finish needs
 };
 
 }  // namespace
@@ -1366,6 +1419,9 @@ struct Rt2DTileCall::Impl {
   long long work_cap = 0, entries_total = 0;
   int tile_grid = 0, tile_threads = 512;
   bool fused = false;                   // one tile per match, prep fused into the tile kernel
+  bool bounds = false;                  // block bounds first (rt_2d_bounds.h): fused shape only
+  int bound_nb = 0;                     // blocks per window axis (launch-wide: the largest)
+  size_t bound_lds = 0;
   std::unique_ptr<WorkspaceLease> ws;
   CacheHolds holds;
   unsigned* h_misc = nullptr;
@@ -1579,6 +1635,8 @@ bool Rt2DTileCall::Plan() {
   // Entries per work item: the whole batch in about two items per resident workgroup (an item
   // costs ~4 us before its first window update: ticket, headers, lists, tasks, image), not less
   // than two thousand entries (sixteen tasks: one per wavefront).
+  int launch_nb = 1;                     // block bounds: blocks per window axis, launch-wide
+  for (int m = 0; m < num; ++m) launch_nb = std::max(launch_nb, search[m].nl + 1);
   const int tile_slots = std::max(1, (single_tile ? cus : 2 * cus) / I.share);
   const int target = dbg.rt2d_target > 0
                          ? dbg.rt2d_target
@@ -1614,7 +1672,30 @@ bool Rt2DTileCall::Plan() {
     // right of or below it is zeros by definition: the tile DMA substitutes the zero corner)
     g.gpitch = 2 * ((g.hl + nx + 7) & ~7);
     g.grows = g.ht + ny + 1;
-    g.image_bytes = static_cast<size_t>(g.gpitch) * g.grows;
+    g.q_bytes = Align16(static_cast<size_t>(g.gpitch) * g.grows);
+    // the pooled planes (rt_2d_bounds.h) are part of the image whenever the window allows them,
+    // whichever kernel this call runs: a cached image serves both
+    g.m2_pitch = g.m2_rows = 0;
+    if (side <= 2 * kBoundMaxBlocks) {
+      // (room behind the last column a window reads: the bound kernel copies 8-byte pieces)
+      g.m2_pitch = (((nx + g.hl) >> 1) + 28 + 3) & ~3;
+      g.m2_rows = ((ny + g.ht) >> 1) + kBoundMaxBlocks + 2;
+    }
+    g.image_bytes = g.q_bytes + 4 * static_cast<size_t>(g.m2_pitch) * g.m2_rows;
+    {
+      const int nb = launch_nb;                         // (the kernel is instantiated for the largest)
+      // (rows are read as three aligned dwords and copied in 8-byte pieces; an odd number of
+      // 8-byte pieces: the rows of a wall on different banks)
+      g.b_lpb = ((g.T >> 1) + 12 + 4 + 7) & ~7;
+      if ((g.b_lpb & 15) == 0) g.b_lpb += 8;
+      g.b_lh = (g.T >> 1) + nb + 1;
+      // planes | zeros | cloud: what the finish of the match is laid out in afterwards
+      g.b_finish_room = 4 * static_cast<size_t>(g.b_lh) * g.b_lpb + ((static_cast<size_t>(nb) * g.b_lpb + 16 + 15) & ~size_t{15}) +
+                        8 * static_cast<size_t>(n_pad);
+      // | rotations | block sums (later: the summed candidates and their sums) | list | its sums
+      g.b_lds = 8 * ((static_cast<size_t>(sr.num_scans) + 1) & ~size_t{1}) +
+                4 * BoundSumWords(sr.num_scans * nb * nb) + 20 * size_t{kBoundListCap};   // (+ b_tail_at: below)
+    }
     I.tile_lds = std::max(I.tile_lds, g.lds);
     I.prep_lds = std::max<size_t>(I.prep_lds, 6 * static_cast<size_t>(n_pad) + 512);
     I.lists_total += Align16(2 * static_cast<size_t>(sr.num_scans) * g.cap_s);
@@ -1643,8 +1724,46 @@ bool Rt2DTileCall::Plan() {
     for (int m = 0; m < num; ++m) max_row = std::max<size_t>(max_row, 4 * (static_cast<size_t>((items[m].n + 63) / 64 * 64) + 4));
     I.finish_lds += static_cast<size_t>(I.group) * max_row;
   }
+  // ---- block bounds first (rt_2d_bounds.h): every match ONE work item of the bound kernel, two
+  // workgroups of 512 threads per CU where their LDS allows.  Not for windows beyond 16 x 16
+  // cells (the block columns of a row are one 8-byte read) -- the exhaustive tile kernel keeps
+  // those, and stays the parity partner behind the debug switch.
+  // From kBoundMinMatches matches per call on: below, the tile kernel's finer work items (a match
+  // in four or more, none of which waits for a last one) give the shorter call -- measured on C1,
+  // one box, bounds / tiles: 1 match 62 / 52 us, 16: 92 / 74, 128: 114 / 118, 1024: 330 / 449
+  // (profiles/r05_c1_bounds.txt).  Debug switches: rt2d_bounds = 1 always, rt2d_no_bounds never.
+  I.bounds = I.fused && !dbg.rt2d_no_bounds && (num >= kBoundMinMatches || dbg.rt2d_bounds);
+  for (int m = 0; m < num && I.bounds; ++m) {
+    const int side = 2 * search[m].nl + 1;
+    // (the bound kernel finishes a match itself, in the LDS of its planes and cloud -- a small
+    // box leaves less than the finish needs: the rest of the layout moves back)
+    geo[m].b_tail_at = std::max(geo[m].b_finish_room, Align16(I.finish_lds));
+    geo[m].b_lds += geo[m].b_tail_at;
+    I.bounds = side <= 2 * kBoundMaxBlocks && geo[m].b_lds <= 150 * size_t{1024};
+    I.bound_nb = std::max(I.bound_nb, (side + 1) / 2);
+    I.bound_lds = std::max(I.bound_lds, geo[m].b_lds);
+  }
+  if (I.bounds) {
+    // rotation groups per match: about two items per CU over the whole call (an item stages the
+    // match's planes and cloud: ~4 us), one per match in large batches
+    const int per_cu = I.bound_lds <= 78 * size_t{1024} ? 2 : 1;
+    const int slots = std::max(1, per_cu * cus / I.share);
+    I.work_cap = 0;
+    for (int m = 0; m < num; ++m) {
+      const int G = dbg.rt2d_groups > 0 ? dbg.rt2d_groups : slots / num;
+      geo[m].groups = std::max(1, std::min(G, search[m].num_scans));
+      I.work_cap += geo[m].groups;
+    }
+  }
   CMX_REQUIRE(I.work_cap < (1ll << 24) && num <= 65535, "too many matches in one batch");
   I.tile_grid = static_cast<int>(std::max<long long>(1, std::min<long long>(tile_slots, I.work_cap)));
+  if (I.bounds) {
+    const int per_cu = I.bound_lds <= 78 * size_t{1024} ? 2 : 1;
+    // (the whole chip even when the call is one part of a batch: the workgroups are persistent and
+    // two of them share a CU -- a part whose grid is its share of the CUs leaves a wavefront per
+    // SIMD short of hiding the LDS latency of phase A whenever the parts do not overlap)
+    I.tile_grid = static_cast<int>(std::max<long long>(1, std::min<long long>(per_cu * cus, I.work_cap)));
+  }
   return true;
 }
 
@@ -1690,6 +1809,8 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
   }
   const size_t off_counters = in_bytes;               // [0] work items, [1] next item (zeroed)
   in_bytes += 64;
+  const size_t off_tickets = in_bytes;                // block bounds: a ticket counter per match (zeroed)
+  if (I.bounds) in_bytes += Align16(sizeof(int) * static_cast<size_t>(num));
   const size_t off_work = in_bytes;                   // fused: the work items, listed here
   if (I.fused) in_bytes += Align16(3 * sizeof(int4) * static_cast<size_t>(I.work_cap));
   const size_t off_misc = in_bytes;
@@ -1710,6 +1831,15 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
   unsigned* d_misc = reinterpret_cast<unsigned*>(d_in + off_misc);
   int* d_counters = reinterpret_cast<int*>(d_in + off_counters);
   std::memset(h_in + off_counters, 0, 64);
+  if (I.bounds) std::memset(h_in + off_tickets, 0, Align16(sizeof(int) * static_cast<size_t>(num)));
+  // (block sums of matches bounded by several workgroups; read only where groups > 1)
+  std::vector<int> ub_at(num, 0);
+  size_t ub_total = 0;
+  for (int m = 0; m < num && I.bounds; ++m) {
+    ub_at[m] = static_cast<int>(ub_total);
+    ub_total += static_cast<size_t>(search[m].num_scans) * I.bound_nb * I.bound_nb;
+  }
+  int* d_ub = I.bounds ? ws->dev[6].ReserveAs<int>(ub_total + 16) : nullptr;
   std::memset(h_in + off_misc, 0, sizeof(unsigned) * 128 * static_cast<size_t>(num));
   if (I.fused) {
     int4* h_work = reinterpret_cast<int4*>(h_in + off_work);
@@ -1837,11 +1967,18 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
       P.stage = P.misc + 126;
       P.timeline = d_timeline;
       P.timeline_finish_base = timeline_tile_slots;
+      P.m2 = g.m2_rows ? reinterpret_cast<const uint8_t*>(image_of[m]) + g.q_bytes : nullptr;
+      P.m2_pitch = g.m2_pitch; P.m2_rows = g.m2_rows;
+      P.b_c0 = (g.box_x0 >> 1) & ~3; P.b_r0 = g.box_y0 >> 1;
+      P.b_lpb = g.b_lpb; P.b_lh = g.b_lh; P.b_tail_at = static_cast<int>(g.b_tail_at);
+      P.bstat = P.misc + 124;
+      P.b_verify = dbg.rt2d_bounds_verify ? 1 : 0;
+      P.b_ub_at = ub_at[m];
       h_params[m] = P;
     });
   }
   // (the stage counters ride in the last words of a match's slot: the finalist head must stop short)
-  static_assert(2 + 2 * kFinalistHead <= 126, "a match's head and stage counters share 128 words");
+  static_assert(2 + 2 * kFinalistHead <= 124, "a match's head, bound and stage counters share 128 words");
   t_params = lap_us();
   SmallCopyAsync(d_in, h_in, in_bytes, /*to_device=*/true, ws->stream);
   t_upload = lap_us();
@@ -1857,6 +1994,11 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
     }
     if (any_build)
       Rt2DQuantKernel<<<dim3(DivUp(max_vecs, 256), num), 256, 0, ws->stream>>>(d_params);
+    size_t max_words = 0;
+    for (int m = 0; m < num; ++m)
+      if (build_image[m]) max_words = std::max(max_words, static_cast<size_t>(geo[m].m2_pitch) * geo[m].m2_rows);
+    if (max_words)
+      Rt2DPoolKernel<<<dim3(DivUp(max_words, 256), num), 256, 0, ws->stream>>>(d_params);
   }
   if (!I.fused)
     Rt2DTilePrepKernel<<<dim3(I.max_scans, num), 256, I.prep_lds, ws->stream>>>(
@@ -1874,8 +2016,31 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
       kernel<<<static_cast<unsigned>(I.tile_grid), I.tile_threads, I.tile_lds, ws->stream>>>(
           d_params, d_work, d_counters, d_counters + 1, I.fused ? 3 : 1);
     };
+    const auto launch_bounds = [&](auto kernel) {
+      OptInLds(reinterpret_cast<const void*>(kernel), device, 160 * 1024 - 4096);
+      if (dbg.host_trace) {
+        int resident = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kernel, kBoundThreads, I.bound_lds);
+        fprintf(stderr, "[cmx host] rt2d bound kernel<%d>: %d workgroups of %d threads, %zu B of LDS each, "
+                        "%d resident per CU\n", I.bound_nb, I.tile_grid, kBoundThreads, I.bound_lds, resident);
+      }
+      kernel<<<static_cast<unsigned>(I.tile_grid), kBoundThreads, I.bound_lds, ws->stream>>>(
+          d_params, d_work, d_counters, d_counters + 1, reinterpret_cast<int*>(d_in + off_tickets), d_ub,
+          I.group, I.h_misc);
+    };
     const int common_stride = I.common_stride;
-    if (I.d_timeline) {               // the instrumented instantiations (runtime row stride)
+    if (I.bounds) {
+      switch (I.bound_nb) {
+        case 1: launch_bounds(Rt2DBoundKernel<1>); break;
+        case 2: launch_bounds(Rt2DBoundKernel<2>); break;
+        case 3: launch_bounds(Rt2DBoundKernel<3>); break;
+        case 4: launch_bounds(Rt2DBoundKernel<4>); break;
+        case 5: launch_bounds(Rt2DBoundKernel<5>); break;
+        case 6: launch_bounds(Rt2DBoundKernel<6>); break;
+        case 7: launch_bounds(Rt2DBoundKernel<7>); break;
+        default: launch_bounds(Rt2DBoundKernel<8>); break;
+      }
+    } else if (I.d_timeline) {               // the instrumented instantiations (runtime row stride)
       if (rpl == 1) launch(Rt2DTileKernel<1, 0, true>);
       else if (rpl == 2) launch(Rt2DTileKernel<2, 0, true>);
       else if (rpl == 3) launch(Rt2DTileKernel<3, 0, true>);
@@ -1893,8 +2058,11 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
     else launch(Rt2DTileKernel<8, 0, false>);
   }
   RecordEvent(ws->ev_k1, ws->stream);
-  OptInLds(reinterpret_cast<const void*>(Rt2DFinishKernel), device, 128 * 1024);
-  Rt2DFinishKernel<<<num, kFinishThreads, I.finish_lds, ws->stream>>>(d_params, I.group, I.h_misc);
+  // (the bound kernel has finished its matches itself; in its verify mode it leaves every sum)
+  if (!I.bounds || dbg.rt2d_bounds_verify) {
+    OptInLds(reinterpret_cast<const void*>(Rt2DFinishKernel), device, 128 * 1024);
+    Rt2DFinishKernel<<<num, kFinishThreads, I.finish_lds, ws->stream>>>(d_params, I.group, I.h_misc);
+  }
   CMX_HIP(hipGetLastError());
   RecordEvent(ws->ev_end, ws->stream);
   I.enqueued = true;
@@ -1917,12 +2085,15 @@ bool Rt2DTileCall::Collect(cmx_match_stats* stats) {
   I.synced = true;
   I.holds.built = true;
   if (I.d_timeline) {
-    ReportTimeline("Rt2DTileKernel", I.d_timeline, I.tile_grid * 4, ws->stream);
+    ReportTimeline(I.bounds ? "Rt2DBoundKernel" : "Rt2DTileKernel", I.d_timeline, I.tile_grid * 4, ws->stream);
     ReportTimeline("Rt2DFinishKernel", I.d_timeline + static_cast<size_t>(I.tile_grid) * 4 * kTimelineStamps,
                    num, ws->stream);
   }
   for (int m = 0; m < num; ++m) {
     const unsigned count = h_misc[static_cast<size_t>(m) * 128 + 1];
+    CMX_REQUIRE(!(h_misc[static_cast<size_t>(m) * 128] & kBoundViolated),
+                "internal error: rt2d block bound below one of its candidates (rt2d_bounds_verify)");
+    if (h_misc[static_cast<size_t>(m) * 128] & kBoundFlat) return false;   // (flat landscape: the per-candidate kernels)
     if (h_misc[static_cast<size_t>(m) * 128] & kOutOfBox) {
       fprintf(stderr, "[cmx] rt2d: a point fell outside the predicted box of match %d; the batch "
                       "is repeated on the per-candidate kernels\n", m);
@@ -1966,7 +2137,9 @@ bool Rt2DTileCall::Collect(cmx_match_stats* stats) {
     const unsigned* head = h_misc + static_cast<size_t>(m) * 128;
     const long long cands = static_cast<long long>(search[m].num_scans) * (2 * search[m].nl + 1) * (2 * search[m].nl + 1);
     total.candidates_scored += cands;
-    total.coarse_candidates += cands;
+    // (what the device summed: the whole search space, or -- block bounds -- one bound per
+    // 2 x 2 block of translations plus the four candidates of the blocks that reach the bound)
+    total.coarse_candidates += I.bounds ? static_cast<long long>(head[125]) + 4ll * head[124] : cands;
     total.num_scans += search[m].num_scans;
     total.refined_candidates += head[126];        // candidates re-summed with exact integers
     total.finalists += head[127] & 0xffffu;       // candidates scored with the reference's f32 chain

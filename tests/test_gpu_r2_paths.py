@@ -137,16 +137,24 @@ def test_fast2d_fused_and_unfused_batches_agree(sm, synth, c2, debug):
 # ----------------------------------------------------------------------------
 # Real-time 2D: bulk pass vs per-candidate kernels vs oracle
 # ----------------------------------------------------------------------------
-RT2D_PATHS = ["tiles", "tiles1", "tiles64", "tiles56g", "0"]
+RT2D_PATHS = ["bounds", "tiles", "tiles1", "tiles64", "tiles56g", "0"]
 
 
 def _rt2d_path(debug, path):
-    """'tiles': integer bulk pass out of LDS tiles + exact finalists (default: one tile per match
+    """'bounds' (round 5): upper bounds of 2 x 2 blocks of translations from a max-pooled
+    image first, sums only for the blocks that reach the best lower bound (rt_2d_bounds.h; windows
+    beyond 16 x 16 cells take the next path); 'tiles': the exhaustive integer bulk pass out of LDS
+    tiles + exact finalists (one tile per match
     where it fits, discretised inside the tile kernel); 'tiles1': that shape through the prep
     kernel and its planner; 'tiles64' / 'tiles56g': the same with small tiles (up to 4 x 4 per match: sums meet by atomics) and
     with one work item per (tile, rotation); '0': one thread per candidate."""
+    if path == "bounds":     # block bounds first where the window is at most 16 x 16 (the
+        debug(rt2d_bounds=1)  # default from 96 matches per call on; here: calls of any size)
+        return
     if path == "0":
         debug(rt2d_legacy=1)
+    elif path == "tiles":
+        debug(rt2d_no_bounds=1)
     elif path == "tiles1":
         debug(rt2d_unfused=1)
     elif path == "tiles64":
@@ -191,6 +199,43 @@ def test_rt2d_both_paths(sm, oracle, synth, debug, bulk, seed, size, beams, lin,
     else:
         assert 1 <= st["finalists"] <= st["refined_candidates"] < ref["num_candidates"] or \
             ref["num_candidates"] <= 64
+    # block bounds: the device summed a fraction of the search space (a bound per 2 x 2 block +
+    # four candidates per surviving block), the exhaustive paths all of it
+    side = 2 * math.ceil(lin / 0.05 - 1e-9) + 1
+    if bulk == "bounds" and 1 < side <= 16:
+        assert st["coarse_candidates"] < 0.6 * ref["num_candidates"], st
+    elif bulk not in ("0", "bounds") or side > 16:
+        assert st["coarse_candidates"] == ref["num_candidates"]
+
+
+@pytest.mark.parametrize("seed,size,beams,lin,ang,weights", [
+    (42, 200, 1000, 0.3, 7.0, (0.1, 0.1)),      # C1: 7 x 7 blocks per rotation
+    (7, 200, 400, 0.3, 7.0, (0.0, 0.0)),
+    (13, 150, 700, 0.1, 20.0, (0.1, 0.1)),      # 5 x 5 window: 3 x 3 blocks, the last one a single row / column
+    (3, 160, 250, 0.15, 10.0, (0.1, 5.0)),      # 7 x 7: 4 x 4 blocks
+    (21, 90, 300, 0.35, 2.0, (0.1, 0.1)),       # 15 x 15: 8 x 8 blocks (the widest row read), a small grid
+    (23, 64, 200, 0.05, 30.0, (0.1, 0.1)),      # 3 x 3: 2 x 2 blocks, many rotations
+])
+def test_rt2d_block_bounds_dominate_their_candidates(sm, oracle, synth, debug, seed, size, beams,
+                                                      lin, ang, weights):
+    """The invariant the pruning of rt_2d_bounds.h rests on, checked on the device for EVERY block
+    of the search space (debug switch rt2d_bounds_verify: all blocks are summed; the call fails
+    if the weighted bound of a block lies below the weighted value of one of its own candidates):
+    the max-pooled byte image, the parity planes and their addressing, the weights' maxima."""
+    debug(rt2d_bounds_verify=1, rt2d_bounds=1)
+    cells, lim, world = synth.make_submap(seed, size, size, 0.05, 20, 600, 5.0, 0.01)
+    pose = world.free_pose(seed + 100, 0.5)
+    scan = world.scan(pose, beams, 5.0, 0.01, 7)
+    init = [pose[0] + 0.12, pose[1] - 0.08, pose[2] + math.radians(3.0)]
+    ref = oracle.rt2d_match(cells, 0.05, lim["max_x"], lim["max_y"], init, scan, lin,
+                            math.radians(ang), *weights)
+    m = sm.RealTimeCorrelativeScanMatcher2D(lin, math.radians(ang), *weights)
+    score, est = m.match(sm.Rigid2d(*init), scan, _grid(sm, cells, lim))
+    assert score == ref["score"]
+    np.testing.assert_allclose([est.x, est.y, est.theta], ref["pose"], rtol=0, atol=1e-12)
+    side = 2 * math.ceil(lin / 0.05 - 1e-9) + 1
+    blocks = ref["num_candidates"] // (side * side) * ((side + 1) // 2) ** 2
+    assert m.last_stats["coarse_candidates"] == 5 * blocks        # every bound + every block summed
 
 
 @pytest.mark.parametrize("bulk", RT2D_PATHS)
@@ -246,6 +291,40 @@ def test_rt2d_batch_on_resident_grids_both_paths(sm, oracle, synth, debug):
         for k, ref in enumerate(refs):
             assert scores[k] == ref["score"], k
             np.testing.assert_allclose(poses[k], ref["pose"], rtol=0, atol=1e-12)
+
+
+def test_rt2d_a_batch_of_a_hundred_takes_the_bound_kernel(sm, synth, debug):
+    """From 96 matches per call on the block bounds are the default (rt_2d_bounds.h: the bound
+    kernel also finishes its matches, one launch per call): 100 matches over five grids with
+    scans of different sizes return, match by match, what the exhaustive tile kernel returns for
+    them one by one, and the statistics show that a fraction of the search space was summed."""
+    from cartographer_amd import grid_2d
+    m = sm.RealTimeCorrelativeScanMatcher2D(0.3, math.radians(7.0), 0.1, 0.1)
+    worlds = []
+    for k in range(5):
+        cells, lim, world = synth.make_submap(70 + k, 200, 200, 0.05, 20, 600, 5.0, 0.01)
+        worlds.append((grid_2d.ProbabilityGridOnDevice(0.05, (lim["max_x"], lim["max_y"]), 200, 200,
+                                                       cells=cells), world))
+    grids, inits, scans = [], [], []
+    for k in range(100):
+        grid, world = worlds[k % 5]
+        pose = world.free_pose(400 + k, 0.5)
+        grids.append(grid)
+        scans.append(world.scan(pose, 250 + 7 * k, 5.0, 0.01, k))
+        inits.append(sm.Rigid2d(pose[0] + 0.1, pose[1] - 0.05, pose[2] + 0.04))
+    debug(rt2d_no_bounds=1)
+    singles = [m.match(inits[k], scans[k], grids[k]) for k in range(100)]
+    from cartographer_amd import _lib
+    _lib.debug_reset()
+    batch = sm.Rt2DBatch(m, grids, scans, resident=True)
+    init = np.array([[p.x, p.y, p.theta] for p in inits])
+    for _ in range(2):
+        scores, poses, stats = batch.match(init)
+        for k, (score, pose) in enumerate(singles):
+            assert scores[k] == score, k
+            np.testing.assert_array_equal(poses[k], [pose.x, pose.y, pose.theta])
+        assert stats["coarse_candidates"] < 0.6 * stats["candidates_scored"], stats
+        assert 100 <= stats["finalists"] <= stats["refined_candidates"] < 0.1 * stats["candidates_scored"]
 
 
 @pytest.mark.parametrize("resident", [False, True])
