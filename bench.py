@@ -673,6 +673,8 @@ class Rt2DWorkload:
                            f", window 0.3 m / 7 deg "
                            f"({stats['candidates_scored'] // self.matches_per_step} candidates per match)",
                "matches_per_step": self.matches_per_step,
+               "search_space_candidates_per_match": stats["candidates_scored"] / self.matches_per_step,
+               "summed_candidates_per_match": stats.get("coarse_candidates", 0) / self.matches_per_step,
                "refined_candidates_per_match": stats.get("refined_candidates", 0) / self.matches_per_step,
                "f32_finalists_per_match": stats.get("finalists", 0) / self.matches_per_step}
         return out
@@ -688,7 +690,31 @@ class Rt2DWorkload:
         cand = acc["candidates_scored"] / steps
         secs = max(k_ms, 1e-9) * 1e-3
         alg = cand * self.points * 2.0
-        side = 13
+        scans = acc["num_scans"] / steps
+        side = int(round(math.sqrt(cand / max(scans, 1))))
+        summed = acc["coarse_candidates"] / steps
+        if summed < cand:
+            # Round 5, from 96 matches per call on: block bounds first (rt_2d_bounds.h).  Per
+            # (rotation, point) the bound kernel reads (side + 1) / 2 block rows of three aligned
+            # dwords each from the max-pooled byte planes in LDS, and the point's two coordinates;
+            # the handful of blocks that reach the bound are summed from the image in HBM (L2).
+            # kernel_ms covers the whole kernel: staging, bounds, the sums and the match's finish.
+            nb = (side + 1) // 2
+            lds = scans * self.points * (12.0 * nb + 8.0)
+            return {"kernel": "Rt2DBoundKernel (2x2 block bounds from pooled byte planes in LDS + sums + finish)",
+                    "bound": "lds", "achieved": lds / secs / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                    "frac": lds / secs / 1e9 / LDS_PEAK_GBS, "traffic": None,
+                    "kernel_ms": k_ms, "algorithmic_bytes": alg, "lds_bytes": lds,
+                    "algorithmic_GBps": alg / secs / 1e9,
+                    "hbm_frac_algorithmic": alg / secs / 1e9 / HBM_PEAK_GBS,
+                    "candidates_per_s_kernel": cand / secs,
+                    "summed_candidates_per_s_kernel": summed / secs,
+                    "note": "block bounds: frac = LDS bytes of the bound kernel's row reads / its "
+                            "HIP-event time (staging, the surviving blocks' sums and the finish of "
+                            "every match included) / 150 TB/s; algorithmic bytes stay SURVEY 8d's "
+                            "2 B per candidate of the SEARCH SPACE per point (what the reference "
+                            "reads), of which the device reads a fraction: "
+                            "summed_candidates = block bounds + candidates of surviving blocks"}
         lds = cand / (side * side) * self.points * 512.0
         return {"kernel": "Rt2DTileKernel (LDS tiles of the quantised grid image, packed 16-bit sums)",
                 "bound": "lds", "achieved": lds / secs / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
@@ -703,6 +729,84 @@ class Rt2DWorkload:
                         "time (image staging, list copies and task building of every work item "
                         "included; discretisation is the prep kernel's) / 150 TB/s (ds_read_b64 "
                         "aggregate); hbm_frac_algorithmic > 1 means on-chip residency"}
+
+
+class Rt2DTsdfWorkload:
+    """C1 on a TSDF2D (SURVEY 8 a8', ComputeCandidateScore(TSDF2D),
+    real_time_correlative_scan_matcher_2d.cc:38-59): the same world, scan and window as C1, the
+    grid a truncated signed distance field of it (tsd and weight planes through the reference's
+    TSDValueConverter expressions, tsd_value_converter.h:39-67).  A score is a ratio of two f32
+    sums, not an integer sum: this branch runs on the one-thread-per-candidate kernels
+    (rt_2d.hip), every candidate with the reference's sequential f32 chains -- the leg exists so
+    that the slow path has a number."""
+    TRUNCATION, MAX_WEIGHT = 0.3, 10.0
+
+    def __init__(self, args, device):
+        from scipy import ndimage
+        from cartographer_amd import scan_matching as sm, synth
+        self.sm = sm
+        self.m = sm.RealTimeCorrelativeScanMatcher2D(0.3, math.radians(7.0), 0.1, 0.1,
+                                                     device=device)
+        cells, lim, world = synth.make_submap(42, 200, 200, 0.05, 30, 1000, 5.0, 0.01)
+        pose = world.free_pose(1234, 0.5)
+        self.scan = world.scan(pose, args.beams, 5.0, 0.01, 7)
+        self.init = sm.Rigid2d(pose[0] + 0.12, pose[1] - 0.08, pose[2] + math.radians(3.0))
+        # walls = cells whose correspondence cost lies in the lower half; distance to the nearest
+        value = cells & 32767
+        wall = (value > 0) & (value < 16384)
+        d = ndimage.distance_transform_edt(~wall) * 0.05
+        rng = np.random.default_rng(42)
+        weight = rng.uniform(1.0, self.MAX_WEIGHT, cells.shape)
+        known = d < self.TRUNCATION
+
+        def to_value(x, lo, hi):          # BoundedFloatToValue (probability_values.h:32-44)
+            return (np.round((np.clip(x, lo, hi) - lo) * (32766.0 / (hi - lo))).astype(np.int64) + 1)
+        self.tsd = np.where(known, to_value(d, -self.TRUNCATION, self.TRUNCATION), 0).astype(np.uint16)
+        self.wgt = np.where(known, to_value(weight, 0.0, self.MAX_WEIGHT), 0).astype(np.uint16)
+        self.lim = lim
+        self.grid = sm.TSDF2D(self.tsd, self.wgt, 0.05, lim["max_x"], lim["max_y"], self.TRUNCATION,
+                              self.MAX_WEIGHT)
+        self.matches_per_step = 1
+        self.n_points = len(self.scan)
+
+    def search(self, k=0):
+        score, est = self.m.match(self.init, self.scan, self.grid)
+        return (np.ones(1, np.int32), np.array([score], np.float64),
+                np.array([[est.x, est.y, est.theta]], np.float64), self.m.last_stats)
+
+    def parity(self, result):
+        from oracle import pyoracle as orc
+        kind = _reference_kind()
+        lim, i = self.lim, self.init
+        if kind == "reference":
+            r = orc.ref_rt2d_match(self.tsd, lim["resolution"], lim["max_x"], lim["max_y"],
+                                   [i.x, i.y, i.theta], self.scan, 0.3, math.radians(7.0), 0.1, 0.1,
+                                   weight_cells=self.wgt, truncation_distance=self.TRUNCATION,
+                                   max_weight=self.MAX_WEIGHT)
+        else:
+            r = orc.rt2d_match_tsdf(self.tsd, self.wgt, lim["resolution"], lim["max_x"], lim["max_y"],
+                                    self.TRUNCATION, self.MAX_WEIGHT, [i.x, i.y, i.theta], self.scan,
+                                    0.3, math.radians(7.0), 0.1, 0.1)
+        return parity_record(kind, [(True, result[1][0], result[2][0], True, r["score"], r["pose"])])
+
+    def describe(self, stats, found):
+        return {"workload": f"C1 on a TSDF2D: 2D RealTimeCorrelativeScanMatcher, one match per step, "
+                            f"{self.n_points}-point scan vs a 200x200 TSDF (tsd + weight planes), "
+                            f"window 0.3 m / 7 deg ({stats['candidates_scored']} candidates)",
+                "matches_per_step": 1}
+
+    def roofline(self, acc, steps, pmc):
+        """Per-candidate kernels: two 2-byte gathers (tsd, weight) per candidate and point from the
+        80 KB + 80 KB planes (L2 / L1 resident): algorithmic bytes 4 B per candidate and point,
+        priced against the chip's gather-issue ceiling like the other gather kernels."""
+        k_ms = acc["dominant_kernel_ms"] / steps
+        cand = acc["candidates_scored"] / steps
+        secs = max(k_ms, 1e-9) * 1e-3
+        lookups = cand * self.n_points * 2.0
+        return {"kernel": "Rt2DScoreKernel<tsdf> (one thread per candidate, sequential f32 chains)",
+                "bound": "gather-issue", "achieved": lookups / secs / 1e9, "peak": GATHER_PEAK_GLOOKUPS,
+                "unit": "Glookup/s", "frac": lookups / secs / 1e9 / GATHER_PEAK_GLOOKUPS,
+                "traffic": None, "kernel_ms": k_ms, "algorithmic_bytes": cand * self.n_points * 4.0}
 
 
 class Rt2DPipelinedWorkload(Rt2DWorkload):
@@ -1179,6 +1283,7 @@ def other_configs(args, device, sync, pmc):
             entry.update({
                 "ms_per_step": dt / steps * 1e3,
                 "candidates_per_s": acc["candidates_scored"] / dt,
+                "summed_candidates_per_s": acc.get("coarse_candidates", 0) / dt,
                 "matches_per_s": w.matches_per_step * steps / dt,
                 "device_ms_per_step": acc["device_ms"] / steps,
                 "steps": steps, "roofline": w.roofline(acc, steps, pmc),
@@ -1201,6 +1306,7 @@ def other_configs(args, device, sync, pmc):
     run("c1_batch128_grid400", lambda: Rt2DWorkload(args, device, matches=128, grid=400), 50, 5)
     run("c1_batch1024", lambda: Rt2DWorkload(args, device, matches=1024), 30, 5)
     run("c1_batch128_8_threads", lambda: Rt2DPipelinedWorkload(args, device, 128, 8, 4), 25, 5)
+    run("c1_tsdf", lambda: Rt2DTsdfWorkload(args, device), 30, 5)
     run("c2_8_scans_8_threads", lambda: Fast2DConcurrentWorkload(args, device, 8), 60, 10)
     sub = argparse.Namespace(**vars(args))
     sub.submaps = 16
@@ -1562,7 +1668,8 @@ def main():
                 short = {"c1_single": "c1_single", "c1_batch128": "c1b128",
                          "c1_batch128_dirty": "c1b128_dirty", "c1_batch128_grid400": "c1b128_g400",
                          "c1_batch1024": "c1b1024",
-                         "c1_batch128_8_threads": "c1b128t8", "c2_8_scans_8_threads": "c2_8scans",
+                         "c1_batch128_8_threads": "c1b128t8", "c1_tsdf": "c1_tsdf",
+                         "c2_8_scans_8_threads": "c2_8scans",
                          "c3_share_16_submaps": "c3s16",
                          "c4": "c4", "c5_single": "c5_single",
                          "c5_share_32_submaps": "c5s32",

@@ -162,6 +162,7 @@ EXPORTED_SYMBOLS = [
     "cmx_ceres3d_match_grids", "cmx_rt2d_score_candidates", "cmx_rt3d_match_grid",
     "cmx_fast3d_refine_batch",
     "cmx_comm_init", "cmx_comm_destroy", "cmx_comm_num_devices", "cmx_comm_device_of",
+    "cmx_comm_uses_rccl",
     "cmx_fast2d_match_sharded", "cmx_fast3d_match_sharded", "cmx_shard_range",
     "cmx_pack_best_key", "cmx_unpack_best_key",
     "cmx_voxel_filter", "cmx_adaptive_voxel_filter", "cmx_compute_histogram",
@@ -285,6 +286,8 @@ def lib():
     L.cmx_comm_destroy.restype = None
     L.cmx_comm_num_devices.argtypes = [C.c_void_p]
     L.cmx_comm_num_devices.restype = C.c_int32
+    L.cmx_comm_uses_rccl.argtypes = [C.c_void_p]
+    L.cmx_comm_uses_rccl.restype = C.c_int32
     L.cmx_comm_device_of.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
     L.cmx_comm_device_of.restype = C.c_int32
     L.cmx_fast2d_match_sharded.argtypes = [C.c_void_p, P(C.c_void_p), C.c_int32, C.c_void_p,

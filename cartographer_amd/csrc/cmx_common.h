@@ -88,6 +88,7 @@ cmx_status Guard(F&& body) {
   X(no_direct_results)    /* 1: results through a copy kernel, not stored to pinned memory by the last kernel */ \
   X(frontier_capacity)    /* nodes per frontier / leaf buffer (tests: forces the overflow path) */ \
   X(comm_virtual_ranks)   /* N > 1: a one-device cmx_comm becomes N ranks on it (host-side key reduction) */ \
+  X(comm_force_rccl)      /* 1: a one-device cmx_comm is built by RCCL too, its all-reduce is RCCL's */ \
   X(fast2d_unfused)       /* 1: fast 2D front end as separate prep / score launches */             \
   X(fast2d_store_scans)   /* 1: never keep the surviving scans' cells, 2: always */                \
   X(fast2d_fused_threads) /* threads per block of the fused front end */                           \

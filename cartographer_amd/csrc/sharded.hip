@@ -200,8 +200,11 @@ cmx_status cmx_comm_init(const int32_t* devices, int32_t num_devices, cmx_comm**
         comm->devices.push_back(d);
       }
     }
-    // (one device needs no collective: a single-GPU deployment works without librccl)
-    if (num_devices > 1 && !comm->virtual_ranks) {
+    // (one device needs no collective: a single-GPU deployment works without librccl.  Debug
+    // switch comm_force_rccl: a communicator of ONE device is built by RCCL all the same and its
+    // all-reduce is RCCL's -- the binding below, its prototypes and enum values, executed on a
+    // one-GPU box: tests/test_gpu_r2_paths.py)
+    if ((num_devices > 1 || cmx::Debug().comm_force_rccl) && !comm->virtual_ranks) {
       const cmx::Rccl& rccl = cmx::LoadRccl();
       CMX_REQUIRE(rccl.handle && rccl.CommInitAll && rccl.AllReduce && rccl.GroupStart &&
                       rccl.GroupEnd && rccl.CommDestroy,
@@ -243,6 +246,10 @@ void cmx_comm_destroy(cmx_comm* comm) {
   }
   if (current >= 0) (void)hipSetDevice(current);
   delete comm;
+}
+
+int32_t cmx_comm_uses_rccl(const cmx_comm* comm) {
+  return comm && !comm->comms.empty() ? 1 : 0;
 }
 
 int32_t cmx_comm_num_devices(const cmx_comm* comm) {

@@ -140,6 +140,13 @@ class Communicator:
         from . import _lib
         return int(_lib.lib().cmx_comm_num_devices(self._h))
 
+    @property
+    def uses_rccl(self):
+        """True if the best-match key is reduced by RCCL (several devices; one with the debug
+        switch comm_force_rccl), False if the communicator needs no collective."""
+        from . import _lib
+        return bool(_lib.lib().cmx_comm_uses_rccl(self._h))
+
     def __del__(self):
         if getattr(self, "_h", None):
             try:

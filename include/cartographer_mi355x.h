@@ -594,6 +594,9 @@ typedef struct cmx_comm cmx_comm;
 cmx_status cmx_comm_init(const int32_t* devices, int32_t num_devices, cmx_comm** out);
 void cmx_comm_destroy(cmx_comm* comm);
 int32_t cmx_comm_num_devices(const cmx_comm* comm);
+/* 1 if the communicator's collective is RCCL's (several devices), 0 if it needs none (one
+ * device: the key is its own). */
+int32_t cmx_comm_uses_rccl(const cmx_comm* comm);
 /* Device that owns item `index` of `num_items` under the contiguous block partition. */
 int32_t cmx_comm_device_of(const cmx_comm* comm, int64_t index, int64_t num_items);
 /* As cmx_fast2d_match_batch, the matchers spread over the communicator's devices.

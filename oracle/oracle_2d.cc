@@ -64,7 +64,17 @@ Cell2i MapLimits::GetCellIndex(float px, float py) const {
 
 float ProbabilityGridView::GetCorrespondenceCost(const Cell2i& c) const {
   if (!limits.Contains(c)) return max_correspondence_cost;
-  return GridCorrespondenceCostTable()[cells[limits.num_x_cells * c.y + c.x]];
+  const uint16_t raw = cells[limits.num_x_cells * c.y + c.x];
+  if (min_correspondence_cost == kMinCorrespondenceCost &&
+      max_correspondence_cost == kMaxCorrespondenceCost)
+    return GridCorrespondenceCostTable()[raw];
+  // Any other Grid2D (a TSDF2D: [-truncation_distance, truncation_distance], tsdf_2d.cc:25-26):
+  // the entry of the grid's own table, value_conversion_tables.cc:29-38 -- unknown (0) is
+  // max_correspondence_cost (grid_2d.cc:60-66), the update marker is masked.
+  const uint16_t value = raw & 0x7fffu;
+  if (value == 0) return max_correspondence_cost;
+  const float kScale = (max_correspondence_cost - min_correspondence_cost) / 32766.f;
+  return value * kScale + (min_correspondence_cost - kScale);
 }
 float ProbabilityGridView::GetProbability(const Cell2i& c) const {
   // probability_grid.cc:78-82 uses the *global* 32768-entry table.

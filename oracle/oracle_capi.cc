@@ -185,6 +185,17 @@ void orc_precompute2d(const uint16_t* cells, int nx, int ny, int width, uint8_t*
   std::memcpy(out, g.cells().data(), g.cells().size());
 }
 
+// The same over a Grid2D with other correspondence-cost bounds (a TSDF2D's tsd plane:
+// min = -truncation_distance, max = truncation_distance).
+void orc_precompute2d_range(const uint16_t* cells, int nx, int ny, int width, float min_cc,
+                            float max_cc, uint8_t* out) {
+  ProbabilityGridView view = MakeView(cells, nx, ny, 0.05, 0., 0.);
+  view.min_correspondence_cost = min_cc;
+  view.max_correspondence_cost = max_cc;
+  const PrecomputationGrid2D g(view, width);
+  std::memcpy(out, g.cells().data(), g.cells().size());
+}
+
 int orc_fast2d_match(void* h, const double* init_xyt, const float* xyz, int n,
                      int full_submap, float min_score, float* score, double* pose_xyt,
                      int64_t* stats4 /* candidates, scans, coarse, nodes */) {

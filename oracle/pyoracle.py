@@ -76,6 +76,8 @@ def _declare(L):
                                         C.POINTER(C.c_int)]
     L.orc_fast2d_level_cells.argtypes = [C.c_void_p, C.c_int, _u8p]
     L.orc_precompute2d.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, _u8p]
+    L.orc_precompute2d_range.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                         _u8p]
     L.orc_fast2d_match.argtypes = [C.c_void_p, _f64p, _f32p, C.c_int, C.c_int, C.c_float,
                                    C.POINTER(C.c_float), _f64p, _i64p]
     L.orc_fast2d_prepare.argtypes = [C.c_void_p, _f64p, _f32p, C.c_int, C.c_int,
@@ -165,6 +167,8 @@ def ref_lib():
         L.ref_fast2d_match.argtypes = [C.c_void_p, C.c_int, _f64p, _f32p, C.c_int, C.c_float,
                                        C.POINTER(C.c_float), _f64p]
         L.ref_precompute2d.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, _u8p]
+        L.ref_precompute2d_tsdf.argtypes = [_u16p, _u16p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                            C.c_float, _u8p]
         L.ref_rt2d_match.argtypes = [_u16p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double,
                                      C.c_double, C.c_float, C.c_float, _f64p, _f32p, C.c_int,
                                      C.c_double, C.c_double, C.c_double, C.c_double, _f64p]
@@ -382,6 +386,16 @@ def ref_precompute2d(cells, width):
     return out
 
 
+def ref_precompute2d_tsdf(tsd_cells, weight_cells, width, truncation_distance, max_weight):
+    """The reference's PrecomputationGrid2D over its own TSDF2D (two uint16 planes)."""
+    tsd = np.ascontiguousarray(tsd_cells, np.uint16)
+    wgt = np.ascontiguousarray(weight_cells, np.uint16)
+    ny, nx = tsd.shape
+    out = np.empty((ny + width - 1, nx + width - 1), np.uint8)
+    ref_lib().ref_precompute2d_tsdf(tsd, wgt, nx, ny, width, truncation_distance, max_weight, out)
+    return out
+
+
 def ref_rt2d_match(cells, res, max_x, max_y, init_xyt, xyz, lin, ang, tw, rw, weight_cells=None,
                    truncation_distance=0.0, max_weight=0.0):
     cells = np.ascontiguousarray(cells, np.uint16)
@@ -562,6 +576,17 @@ def precompute2d(cells, width):
     ny, nx = cells.shape
     out = np.empty((ny + width - 1, nx + width - 1), np.uint8)
     lib().orc_precompute2d(cells, nx, ny, width, out)
+    return out
+
+
+def precompute2d_range(cells, width, min_correspondence_cost, max_correspondence_cost):
+    """PrecomputationGrid2D over a Grid2D with other correspondence-cost bounds (a TSDF2D's tsd
+    plane: -truncation_distance, truncation_distance)."""
+    cells = np.ascontiguousarray(cells, np.uint16)
+    ny, nx = cells.shape
+    out = np.empty((ny + width - 1, nx + width - 1), np.uint8)
+    lib().orc_precompute2d_range(cells, nx, ny, width, min_correspondence_cost,
+                                 max_correspondence_cost, out)
     return out
 
 

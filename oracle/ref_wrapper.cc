@@ -186,6 +186,22 @@ int ref_fast2d_match(void* h, int full_submap, const double* init_xyt, const flo
   return found ? 1 : 0;
 }
 
+// The same over the reference's TSDF2D (fast_correlative_scan_matcher_2d.cc:91-108 takes any
+// Grid2D: 1 - |cost| with cost in [-truncation_distance, truncation_distance]).
+void ref_precompute2d_tsdf(const uint16_t* cells, const uint16_t* weight_cells, int nx, int ny,
+                           int width, float truncation_distance, float max_weight, uint8_t* out) {
+  cm::ValueConversionTables tables;
+  const auto grid = MakeTsdf(cells, weight_cells, nx, ny, 1., 0., 0., truncation_distance,
+                             max_weight, &tables);
+  std::vector<float> reusable;
+  const sm::PrecomputationGrid2D pre(*grid, grid->limits().cell_limits(), width, &reusable);
+  const int wx = nx + width - 1;
+  for (int y = -width + 1; y < ny; ++y)
+    for (int x = -width + 1; x < nx; ++x)
+      out[static_cast<size_t>(y + width - 1) * wx + (x + width - 1)] =
+          static_cast<uint8_t>(pre.GetValue(Eigen::Array2i(x, y)));
+}
+
 // PrecomputationGrid2D of `width` = 2^level: values for x in [-width+1, nx), y likewise,
 // row-major (ny + width - 1) x (nx + width - 1) like the oracle's precompute2d.
 void ref_precompute2d(const uint16_t* cells, int nx, int ny, int width, uint8_t* out) {

@@ -83,6 +83,26 @@ def test_stack_matches_oracle(sm, oracle, synth, nx, ny, depth, seed):
         np.testing.assert_array_equal(gm.level(level), om.level(level), err_msg=f"level {level}")
 
 
+def test_stack_over_a_tsdf_cost_range(sm, oracle, synth):
+    """cmx_fast2d_create over a Grid2D whose correspondence costs span [-truncation_distance,
+    truncation_distance] -- a TSDF2D's tsd plane, fast_correlative_scan_matcher_2d.cc:91-108 takes
+    any Grid2D: 1 - |cost| -- every level of the stack equals the oracle's, which
+    tests/test_reference_ref.py pins on the reference's PrecomputationGrid2D over its own TSDF2D."""
+    from tsdf_helpers import tsdf_from_probability_grid
+    cells, lim, _ = synth.make_submap(11, 130, 97, 0.05, 8, 300, 30.0, 0.01)
+    tsd, _ = tsdf_from_probability_grid(oracle, cells, 0.05, 0.3, 10.0, 5)
+    tsd = tsd.copy()
+    tsd[::7, ::5] |= 0x8000
+    grid = sm.Grid2D(tsd, 0.05, lim["max_x"], lim["max_y"], -0.3, 0.3)
+    gm = sm.FastCorrelativeScanMatcher2D(grid, 6)
+    for level in range(6):
+        np.testing.assert_array_equal(gm.level(level),
+                                      oracle.precompute2d_range(tsd, 1 << level, -0.3, 0.3),
+                                      err_msg=f"level {level}")
+    values = np.unique(gm.level(0))
+    assert values.min() == 0 and 100 < values.max() <= 128 and len(values) > 20   # 1 - |tsd| in [0.7, 1.0] of [0.7, 1.3]
+
+
 def test_stack_reference_fixture(sm, oracle, synth):
     """PrecomputationGridTest.CorrectValues fixture (fast_..._2d_test.cc:37-57):
     uint8-exact probabilities; widths 1,2,8 are stack levels 0,1,3."""

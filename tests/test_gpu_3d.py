@@ -788,7 +788,7 @@ def test_fast3d_device_batch_of_twenty_pairs(sm3, synth, debug, affinity, famili
 # ----------------------------------------------------------------------------
 # cmx_fast3d_match_sharded: the C5 fan-out over a communicator (north star: 256 submaps / 8 GPUs)
 # ----------------------------------------------------------------------------
-@pytest.mark.parametrize("virtual_ranks", [0, 2])
+@pytest.mark.parametrize("virtual_ranks", [0, 2, "rccl"])
 def test_fast3d_sharded_match_equals_the_batch(sm3, synth, debug, virtual_ranks):
     """cmx_fast3d_match_sharded over a communicator of every visible device (one on the test
     box): pair by pair what cmx_fast3d_match_batch returns -- windowed and full-submap pairs
@@ -798,7 +798,14 @@ def test_fast3d_sharded_match_equals_the_batch(sm3, synth, debug, virtual_ranks)
     import torch
     from cartographer_amd import sharding
     ndev = torch.cuda.device_count()
-    if virtual_ranks:          # the one device as two ranks (see the 2D test of the same name)
+    if virtual_ranks == "rccl":
+        # the one device through RCCL itself (debug switch comm_force_rccl: ncclCommInitAll with
+        # one device, the key through a grouped ncclAllReduce(int64, max)): the binding executed
+        debug(comm_force_rccl=1)
+        comm = sharding.Communicator([0])
+        assert comm.uses_rccl and comm.num_devices == 1
+        ndev = 1
+    elif virtual_ranks:        # the one device as two ranks (see the 2D test of the same name)
         debug(comm_virtual_ranks=virtual_ranks)
         comm = sharding.Communicator([0])
         assert comm.num_devices == virtual_ranks

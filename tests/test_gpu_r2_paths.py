@@ -496,6 +496,38 @@ def test_sharded_match_equals_the_batch(sm, synth, c2, debug, virtual_ranks):
     assert best[0] == int(np.argmax(masked)) and np.float32(best[1]) == masked.max()
 
 
+def test_sharded_match_through_rccl_on_one_device(sm, synth, c2, debug):
+    """The RCCL binding of sharded.hip (dlopen, hand-typed prototypes, enum values) EXECUTED: with
+    the debug switch comm_force_rccl a communicator of the one device is built by
+    ncclCommInitAll(ndev = 1) and the node-wide best key goes through a grouped
+    ncclAllReduce(int64, max) on the communicator's stream -- the reduction of one rank's key is
+    that key: the call returns what the communicator without RCCL returns, bit for bit."""
+    from cartographer_amd import sharding
+    _, _, _, truth, scan = c2
+    plain = sharding.Communicator([0])
+    assert not plain.uses_rccl
+    debug(comm_force_rccl=1)
+    comm = sharding.Communicator([0])
+    assert comm.uses_rccl and comm.num_devices == 1
+    matchers = []
+    for seed in (42, 43, 44):
+        cells, lim, _ = synth.make_submap(seed, 400, 400, 0.05, 30, 1000, 30.0, 0.01)
+        matchers.append(sm.FastCorrelativeScanMatcher2D(_grid(sm, cells, lim), 7, 3.0,
+                                                        math.radians(20.0), device=0))
+    initial = [sm.Rigid2d(truth[0] + 0.2, truth[1] - 0.1, truth[2] + 0.03)] * 3
+    args = (matchers, initial, [1, 1, 1], [0.6, 0.6, 0.6], scan)
+    for _ in range(2):                       # (the communicator is reusable)
+        f, s, p, best, stats = comm.match_batch(*args)
+        f0, s0, p0, best0, stats0 = plain.match_batch(*args)
+        np.testing.assert_array_equal(f, f0)
+        np.testing.assert_array_equal(s, s0)
+        assert best == best0 and best[0] == 0 and np.float32(best[1]) == s[0]
+    # nothing found anywhere: the reduced key is "not found" (-1) on this path too
+    none = comm.match_batch(matchers, initial, [1, 1, 1], [0.999, 0.999, 0.999], scan)
+    assert int(np.sum(none[0])) == 0 and none[3][0] == -1
+    del comm                                  # ncclCommDestroy
+
+
 # ----------------------------------------------------------------------------
 # Voxel filters and rotational histogram on the device (SURVEY.md 8 f4)
 # ----------------------------------------------------------------------------

@@ -661,3 +661,28 @@ def test_intensity_grid_on_the_device_equals_the_reference_and_feeds_the_refinem
     b, _ = m.match(init_t, first, [(cloud, res, host.voxels(), cints,
                                     np.zeros(0, oracle.INTENSITY_VOXEL_DTYPE), opts)])
     assert a == b
+
+
+def test_bench_force_dist_on_one_gpu():
+    """bench.py's distributed branch on the one GPU of the box: `--force-dist --gpus 1` initialises
+    torch.distributed over RCCL (backend "nccl") with one rank and runs the collectives of a
+    sharded step -- the all-gather of the per-submap results and the all-reduce(max) of the best
+    key -- on the device; rank 0 prints the ONE compact line, parity gate included."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29561")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--gpus",
+                          "1", "--steps", "2", "--warmup", "1", "--submaps", "2", "--no-other",
+                          "--no-cpu-baseline", "--passes-per-step", "2", "--details", ""],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["config"]["name"] == "c3"
+    assert line["config"]["constraints_found_node_wide"] >= 1
+    assert line["parity"]["bit_exact"] and line["parity"]["checked"] == 2

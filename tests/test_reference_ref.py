@@ -175,6 +175,24 @@ def test_precomputation_grid_equals_the_reference(ref, oracle, synth, width):
                                   oracle.ref_precompute2d(cells, width))
 
 
+@pytest.mark.parametrize("width", [1, 2, 4, 8, 64])
+def test_precomputation_grid_over_a_tsdf_equals_the_reference(ref, oracle, synth, width):
+    """FastCorrelativeScanMatcher2D takes any Grid2D (fast_correlative_scan_matcher_2d.cc:91-108:
+    1 - |cost|): over the reference's TSDF2D the cost range is [-truncation_distance,
+    truncation_distance] (tsdf_2d.cc:25-26), min_score 1 - truncation_distance, max_score
+    1 + truncation_distance.  The oracle's table expression for that range against the
+    reference's PrecomputationGrid2D over its own TSDF2D, cell for cell."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from tsdf_helpers import tsdf_from_probability_grid
+    cells, _, _ = synth.make_submap(11, 97, 71, 0.05, 8, 300, 30.0, 0.01)
+    tsd, wgt = tsdf_from_probability_grid(oracle, cells, 0.05, 0.3, 10.0, 5)
+    tsd = tsd.copy()
+    tsd[::7, ::5] |= 0x8000                       # update markers are masked (grid_2d.cc:60-66)
+    np.testing.assert_array_equal(oracle.precompute2d_range(tsd, width, -0.3, 0.3),
+                                  oracle.ref_precompute2d_tsdf(tsd, wgt, width, 0.3, 10.0))
+
+
 def test_fast2d_bench_workload_equals_the_reference(ref, oracle, synth):
     """BASELINE config[1] itself: 1000-point scan vs a 400x400 submap, depth 7, full-angle."""
     cells, lim, world = synth.make_submap(42, 400, 400, 0.05, 30, 1000, 30.0, 0.01)
