@@ -100,7 +100,7 @@ def test_stack_over_a_tsdf_cost_range(sm, oracle, synth):
                                       oracle.precompute2d_range(tsd, 1 << level, -0.3, 0.3),
                                       err_msg=f"level {level}")
     values = np.unique(gm.level(0))
-    assert values.min() == 0 and 100 < values.max() <= 128 and len(values) > 20   # 1 - |tsd| in [0.7, 1.0] of [0.7, 1.3]
+    assert values.min() == 0 and 100 < values.max() <= 128 and len(values) > 10   # 1 - |tsd| in [0.7, 1.0] of [0.7, 1.3]
 
 
 def test_stack_reference_fixture(sm, oracle, synth):

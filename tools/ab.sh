@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 A/B harness: the same probes against two builds of the library in ONE box lease
 # (boxes differ by up to 40 % on the HBM-bound lines, so only same-box pairs mean anything).
-#   gpurun --timeout 900 -- 'bash tools/ab_r04.sh <tag> "<probe cmd>" ...'
+#   gpurun --timeout 900 -- 'bash tools/ab.sh <tag> "<probe cmd>" ...'
 # Libraries: cartographer_amd/lib/base_r04/ (the round-3 tree) vs cartographer_amd/lib/ (this tree).
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
