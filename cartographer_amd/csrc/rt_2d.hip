@@ -685,7 +685,7 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
   // then the parts are collected in order.  (Until round 4 the parts ran on pool threads: a
   // dispatch to the pool costs ~25 us, a cold worker ran its part three times slower than the
   // caller, and eight streams share four hardware queues.)  How many parts, measured on C1's
-  // shape at 256 ... 2048 matches (round 4, one box: profiles/r04_c1_parts.txt): EQUAL parts of roughly
+  // shape at 256 ... 2048 matches (round 4, one box): EQUAL parts of roughly
   // 800 matches, two at least -- the first schedule of the round, small first part then growing
   // by half (128, 192, 320, 384 for 1024 matches), started the device 30 us earlier and then
   // spread a match's rotations over more, smaller work items in every small part: 536 against
