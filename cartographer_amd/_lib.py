@@ -162,7 +162,7 @@ EXPORTED_SYMBOLS = [
     "cmx_ceres3d_match_grids", "cmx_rt2d_score_candidates", "cmx_rt3d_match_grid",
     "cmx_fast3d_refine_batch",
     "cmx_comm_init", "cmx_comm_destroy", "cmx_comm_num_devices", "cmx_comm_device_of",
-    "cmx_comm_uses_rccl",
+    "cmx_comm_uses_rccl", "cmx_sizeof_match_stats",
     "cmx_fast2d_match_sharded", "cmx_fast3d_match_sharded", "cmx_shard_range",
     "cmx_pack_best_key", "cmx_unpack_best_key",
     "cmx_voxel_filter", "cmx_adaptive_voxel_filter", "cmx_compute_histogram",
@@ -199,6 +199,11 @@ def lib():
     L.cmx_status_string.argtypes = [C.c_int]
     L.cmx_last_error.restype = C.c_char_p
     L.cmx_device_count.restype = C.c_int32
+    L.cmx_sizeof_match_stats.restype = C.c_int32
+    # (the struct has no size field: a mirror of another size would be overrun by the library)
+    if L.cmx_sizeof_match_stats() != C.sizeof(MatchStats):
+        raise CmxError(INVALID_ARGUMENT, "cmx_match_stats of the library is "
+                       f"{L.cmx_sizeof_match_stats()} bytes, this module's mirror {C.sizeof(MatchStats)}")
     L.cmx_set_stream.argtypes = [C.c_int32, C.c_void_p]
     P = C.POINTER
     L.cmx_rt2d_match.argtypes = [P(RtOptions), P(Grid2DLimits), C.c_void_p, P(Pose2d), C.c_void_p,

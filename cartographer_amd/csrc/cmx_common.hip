@@ -439,6 +439,7 @@ WorkspaceLease::~WorkspaceLease() {
 extern "C" {
 
 const char* cmx_version(void) { return "cartographer_mi355x 0.2 (gfx950)"; }
+int32_t cmx_sizeof_match_stats(void) { return static_cast<int32_t>(sizeof(cmx_match_stats)); }
 
 cmx_status cmx_debug_set(const char* name, int32_t value) {
   return cmx::Guard([&] {

@@ -414,30 +414,34 @@ void InsertIntensities(cmx_intensity_grid3d* g, Workspace& ws, const float* d_re
   IntensityApplyKernel<<<DivUp(n, 256), 256, 0, ws.stream>>>(view, keys + n, index + n, n,
                                                             d_intensities);
   CMX_HIP(hipGetLastError());
+  // The brick of averages the intensity cost function interpolates, built HERE, on the insert's
+  // stream and under its synchronisation: a match never writes to the grid handle (two matches
+  // on one grid from different threads used to race on a lazily built brick).
+  const size_t cells = static_cast<size_t>(g->dims[0]) * g->dims[1] * g->dims[2];
+  if (g->average == nullptr)
+    CMX_HIP(hipMalloc(reinterpret_cast<void**>(&g->average), cells * sizeof(float) + 16));
+  IntensityAverageKernel<<<DivUp(cells, 256), 256, 0, ws.stream>>>(g->sum, g->count, cells, g->average);
+  CMX_HIP(hipGetLastError());
   CMX_HIP(hipMemcpyAsync(h_box, d_box, sizeof(preset), hipMemcpyDeviceToHost, ws.stream));
   CMX_HIP(hipStreamSynchronize(ws.stream));
   CMX_REQUIRE(h_box[7] == 0, "internal error: a voxel fell outside the intensity brick");
   ++g->version;
+  g->average_version = g->version;
 }
 
 }  // namespace
 
 // The grid's f32 brick of average intensities for the cost function that interpolates it in place
-// (ceres_3d.hip); false while the grid is empty (every cell reads 0).  Built on `stream` when the
-// grid has changed since the last call.
-bool IntensityGrid3DBrick(cmx_intensity_grid3d* g, hipStream_t stream, Brick* brick,
+// (ceres_3d.hip); false while the grid is empty (every cell reads 0).  Read-only: the brick is
+// built by the insertion that changed the grid (InsertIntensities), so concurrent matches on one
+// grid share it like any other resident grid.
+bool IntensityGrid3DBrick(cmx_intensity_grid3d* g, hipStream_t /*stream*/, Brick* brick,
                           float* resolution, int* device) {
   *resolution = g->resolution;
   *device = g->device;
   if (g->dims[0] == 0) return false;
-  const size_t cells = static_cast<size_t>(g->dims[0]) * g->dims[1] * g->dims[2];
-  if (g->average == nullptr)
-    CMX_HIP(hipMalloc(reinterpret_cast<void**>(&g->average), cells * sizeof(float) + 16));
-  if (g->average_version != g->version) {
-    IntensityAverageKernel<<<DivUp(cells, 256), 256, 0, stream>>>(g->sum, g->count, cells, g->average);
-    CMX_HIP(hipGetLastError());
-    g->average_version = g->version;
-  }
+  CMX_REQUIRE(g->average != nullptr && g->average_version == g->version,
+              "internal error: intensity grid without its brick of averages");
   brick->cells = g->average;
   brick->lo_x = g->lo[0]; brick->lo_y = g->lo[1]; brick->lo_z = g->lo[2];
   brick->nx = g->dims[0]; brick->ny = g->dims[1]; brick->nz = g->dims[2];

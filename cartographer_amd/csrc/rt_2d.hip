@@ -718,10 +718,12 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
     cmx_status status = CMX_OK;
     std::string error;
   };
-  std::vector<Part> part(parts);
-  // (the parts must overlap on the device: streams that sit on different hardware queues)
+  // (the parts must overlap on the device: streams that sit on different hardware queues.
+  // Declared BEFORE the parts: a part abandoned by an exception synchronises its stream in its
+  // destructor, and that must happen before the streams go back to the pool)
   std::unique_ptr<StreamSetLease> part_streams;
   if (parts > 1) part_streams.reset(new StreamSetLease(device));
+  std::vector<Part> part(parts);
   const auto since_call = [&]() {
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count();
   };
@@ -747,9 +749,12 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
     });
     if (p.status != CMX_OK) p.error = LastError();
   }
+  bool failed = false;
+  for (int h = 0; h < parts; ++h) failed = failed || part[h].status != CMX_OK;
   for (int h = 0; h < parts; ++h) {
     Part& p = part[h];
-    if (p.status != CMX_OK) continue;
+    if (p.status != CMX_OK) { p.call.reset(); continue; }    // (waits for what it had in flight)
+    if (failed) { p.call.reset(); continue; }                // (the call fails: no reruns)
     p.status = Guard([&] {
       const bool done = p.enqueued && p.call->Collect(&p.stats);
       // (not eligible, a flat score landscape, a point outside the predicted box: the part runs

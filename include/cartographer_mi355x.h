@@ -100,12 +100,14 @@ typedef struct cmx_fast3d_options {
 /* Work counters of one call (or summed over a batch). */
 typedef struct cmx_match_stats {
   int64_t candidates_scored;  /* every scored candidate, all depths */
-  int64_t coarse_candidates;  /* lowest-resolution (or exhaustive) candidates */
+  int64_t coarse_candidates;  /* lowest-resolution (or exhaustive) candidates; real-time 2D with block
+                                 bounds: the bounds evaluated + the candidates summed behind them */
   int64_t nodes_expanded;     /* branch-and-bound nodes whose children were scored */
   int32_t num_scans;          /* rotated scans */
   int32_t expansion_launches; /* launches inside expansion_ms (0: none timed) */
   /* The three *_ms fields are recorded only after cmx_debug_set("timing", 1) (the event packets
-     cost a latency-bound call ~15 % of its wall time); otherwise they are 0. */
+     cost a latency-bound call ~15 % of its wall time); otherwise they are 0.  The switch is
+     process-wide: set it while no call is in flight. */
   double device_ms;           /* HIP-event time of the call's device work */
   double dominant_kernel_ms;  /* HIP-event time of the lowest-resolution (or exhaustive) scoring kernel(s) */
   double expansion_ms;        /* HIP-event time of the level-synchronous branch-and-bound expansion
@@ -127,6 +129,10 @@ typedef struct cmx_fast3d cmx_fast3d;   /* opaque FastCorrelativeScanMatcher3D *
 
 /* ---- library / device ------------------------------------------------- */
 const char* cmx_version(void);
+/* sizeof(cmx_match_stats) of the LIBRARY.  The struct has grown between versions (0.1: 88 bytes;
+ * since 0.2: 104) and carries no size field: a caller built against another header passes a
+ * buffer of the wrong size -- compare once at start-up ("ABI"). */
+int32_t cmx_sizeof_match_stats(void);
 const char* cmx_status_string(cmx_status s);
 /* Last error text of the calling thread ("" if none). */
 const char* cmx_last_error(void);
