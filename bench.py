@@ -69,6 +69,9 @@ def parse_args():
     ap.add_argument("--beams", type=int, default=1000)
     ap.add_argument("--min-score", type=float, default=0.6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-submaps", type=int, default=4,
+                    help="c2 / c3: submaps of this rank's block the parity gate searches with the "
+                         "reference (0.4 s of one host core each; 512 = every submap of config[2])")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the device-vs-reference gate in front of the timed regions "
                          "(profiling runs only: the line then carries no `parity`)")
@@ -410,7 +413,7 @@ class Fast2DWorkload:
             self.matchers.append(m)
             if self.cells0 is None:
                 self.cells0, self.lim0 = cells, lim
-            if len(self.host_submaps) < 4:          # (the parity gate's share of a block)
+            if len(self.host_submaps) < getattr(args, "parity_submaps", 4):   # (the parity gate's share of a block)
                 self.host_submaps.append((cells, lim))
         # Every rank draws the same scan, from the world of the one true-positive submap.
         truth = synth.make_submap(42 + positive, args.grid, args.grid, 0.05, 30, 1000, 30.0,
@@ -450,7 +453,7 @@ class Fast2DWorkload:
             cells, lim = host
             return cls(cells, lim["resolution"], lim["max_x"], lim["max_y"],
                        a.depth).match_full_submap(self.scan, a.min_score)
-        with ThreadPoolExecutor(len(self.host_submaps)) as pool:
+        with ThreadPoolExecutor(min(len(self.host_submaps), _cores())) as pool:
             refs = list(pool.map(one, self.host_submaps))
         self.reference_result = refs[0]
         found, scores, poses = result[0], result[1], result[2]

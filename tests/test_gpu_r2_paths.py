@@ -8,6 +8,7 @@ Both toggles are read per call, so one process runs both paths on identical inpu
 test_gpu_2d.py: integer work bit-exact, f32 scores bit-equal, poses to 1e-12.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -625,6 +626,26 @@ def test_c3_share_of_64_submaps_equals_the_single_searches(sm, synth, debug, env
             assert np.float32(s1) == np.float32(scores[i]), i
             assert (p1.x, p1.y, p1.theta) == tuple(poses[i]), i
     assert stats["coarse_candidates"] == coarse
+    if not env:
+        # ... and exactly as the CPU restatement of the reference returns it (the oracle port,
+        # itself pinned on the reference's own sources: tests/test_reference_ref.py), every one of
+        # the 64 pairs, one host thread each
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import pyoracle as orc
+        cells_of = [synth.make_submap(300 + seed, 400, 400, 0.05, 30, 1000, 30.0, 0.01)[:2]
+                    for seed in range(64)]
+
+        def one(k):
+            cells, lim = cells_of[k]
+            return orc.FastCorrelativeScanMatcher2D(cells, 0.05, lim["max_x"], lim["max_y"],
+                                                    7).match_full_submap(scan, 0.6)
+        with ThreadPoolExecutor(min(32, os.cpu_count() or 8)) as pool:
+            refs = list(pool.map(one, range(64)))
+        for i, r in enumerate(refs):
+            assert bool(found[i]) == bool(r["found"]), i
+            if r["found"]:
+                assert np.float32(r["score"]) == np.float32(scores[i]), i
+                np.testing.assert_allclose(poses[i], r["pose"], rtol=0, atol=1e-12, err_msg=str(i))
 
 
 # ----------------------------------------------------------------------------
