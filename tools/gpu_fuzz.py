@@ -84,6 +84,16 @@ def case_2d(rng, report):
     if not (score == a["score"] and
             np.allclose([pose.x, pose.y, pose.theta], a["pose"], rtol=0, atol=1e-12)):
         report("rt2d", dict(what, rt=rt), score, a["score"])
+    # the same match through the block bounds (the default only from 96 matches per call on)
+    from cartographer_amd import _lib
+    _lib.debug_set(rt2d_bounds=1)
+    try:
+        score, pose = m.match(sm.Rigid2d(*init), pts, sm.Grid2D(cells, res, max_x, max_y))
+    finally:
+        _lib.debug_set(rt2d_bounds=0)
+    if not (score == a["score"] and
+            np.allclose([pose.x, pose.y, pose.theta], a["pose"], rtol=0, atol=1e-12)):
+        report("rt2d bounds", dict(what, rt=rt), score, a["score"])
 
 
 def case_3d(rng, report):
