@@ -98,7 +98,7 @@ def parse_args():
     ap.add_argument("--pmc-dir", default=os.path.join(ROOT, "profiles"),
                     help="directory with <tag>_pmc_{fetch,write}_size.csv of THIS command "
                          "(tools/profile_bench.sh writes them); roofline.traffic is null without")
-    ap.add_argument("--pmc-tag", default="r04")
+    ap.add_argument("--pmc-tag", default="r05")
     ap.add_argument("--details", default=os.path.join(ROOT, "gpurun_out", "bench_details.json"),
                     help="file the FULL record goes to (per-config blocks, notes, nested "
                          "rooflines); the line on stdout is the compact headline (< 4 KB); "
@@ -706,7 +706,10 @@ class Rt2DWorkload:
             lds = scans * self.points * (12.0 * nb + 8.0)
             return {"kernel": "Rt2DBoundKernel (2x2 block bounds from pooled byte planes in LDS + sums + finish)",
                     "bound": "lds", "achieved": lds / secs / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
-                    "frac": lds / secs / 1e9 / LDS_PEAK_GBS, "traffic": None,
+                    "frac": lds / secs / 1e9 / LDS_PEAK_GBS,
+                    "traffic": (pmc("Rt2DBound", "c1" if self.matches_per_step == 128 else "c1b1024")
+                                if self.matches_per_step in (128, 1024) and self.grid_side == 200
+                                and not self.dirty else None),
                     "kernel_ms": k_ms, "algorithmic_bytes": alg, "lds_bytes": lds,
                     "algorithmic_GBps": alg / secs / 1e9,
                     "hbm_frac_algorithmic": alg / secs / 1e9 / HBM_PEAK_GBS,

@@ -494,7 +494,7 @@ ScoreCoarsePlanesKernel(const Fast2DProblem* __restrict__ problems, int n,
 // The same scoring for 64-byte planes (plane_i * plane_j <= 64, the usual case) with DWORD
 // gathers.  A wave-wide `buffer_load_ubyte` costs the texture-address path ~12 cycles
 // however few cache lines it touches (2.3 M of them were the 45 us of the byte variant:
-// SQ/TA counters in DESIGN.md); here a lane fetches four plane cells at once, sixteen lanes
+// SQ/TA counters in profiles/HISTORY.md); here a lane fetches four plane cells at once, sixteen lanes
 // cover a plane, and one instruction serves FOUR records (lane group g = lane / 16 takes
 // records 4t + g).  Groups sit in different lattice blocks, so the block bookkeeping is
 // per lane: packed 16-bit partial sums (cells 0|2 and 1|3), flushed to the LDS
@@ -817,7 +817,7 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
   for (int base_i = begin; base_i < end; base_i += 64) {
     // (instrumented instantiation only -- wavefront 0's first chunk step by step: [8] chunk
     // begins, [9] its sixteen gathers issued, [10] all of them landed, [11] consumed; [12..15]:
-    // the next four chunks begin.  DESIGN 5.1: which part of a chunk takes its 2.25 us)
+    // the next four chunks begin.  profiles/HISTORY.md 5.1: which part of a chunk takes its 2.25 us)
     const int chunk_index = (base_i - begin) >> 6;
     if constexpr (kTimeline) {
       if (chunk_index == 0) stamp(8);

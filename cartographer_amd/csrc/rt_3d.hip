@@ -493,7 +493,7 @@ Rt3DBoundsKernel(Rt3DBulkParams P) {
 // segment, and the round runs segment by segment: after the first and after the second,
 // candidates whose weighted bound has fallen below the best lower bound are dropped from the
 // work lists (they keep `upper` = 0: never finalists, exactly what their full evaluation would
-// have concluded).  C4 (tools/prototype numbers in DESIGN.md 5.4): of 154 k candidates 48 % are
+// have concluded).  C4 (tools/prototype numbers in profiles/HISTORY.md 5.4): of 154 k candidates 48 % are
 // alive after a quarter of the points, 10 % after half.
 //
 // grid (work descriptors): flags[r][t] = 1 for the listed candidates that stay.  `stage` = the

@@ -19,7 +19,7 @@ namespace cmx {
 // (x, y) in [-w, wx) x [-w, wy) packing the four cells the children of a node read for
 // one point -- byte 0: (x, y), byte 1: (x, y+w), byte 2: (x+w, y), byte 3: (x+w, y+w),
 // 0 where a cell is outside the level.  A wave-wide byte gather with 64 unrelated
-// addresses costs ~90 cycles of texture-address time per instruction;
+// addresses costs ~90 cycles of texture-address time per instruction (profiles/HISTORY.md 5.3);
 // fetching the four children at once cuts those instructions by four.
 struct LevelDesc {
   const uint8_t* cells;
