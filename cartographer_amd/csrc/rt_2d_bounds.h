@@ -226,13 +226,18 @@ Rt2DBoundKernel(const Rt2DTileParams* __restrict__ params, const int4* __restric
       const auto* src = (const __attribute__((address_space(1))) unsigned char*)P.m2;
       const int src_plane = P.m2_rows * P.m2_pitch;
       constexpr int kInFlight = 8;
+      // (piece -> (plane, row, piece of the row) by multiplication: the quotients are exact for
+      // dividends below 2^16, and two integer divisions per piece were a tenth of the kernel's
+      // vector instructions)
+      const unsigned ppr_magic = 0xffffffffu / static_cast<unsigned>(ppr) + 1u;
+      const unsigned lh_magic = 0xffffffffu / static_cast<unsigned>(lh) + 1u;
       for (int p0 = tid; p0 < pieces; p0 += kInFlight * kBoundThreads) {
         U2 v[kInFlight];
 #pragma unroll
         for (int q = 0; q < kInFlight; ++q) {
           const int p = min(p0 + q * kBoundThreads, pieces - 1);
-          const int pr = p / ppr, piece = p - pr * ppr;
-          const int plane = pr / lh, row = pr - plane * lh;
+          const int pr = static_cast<int>(__umulhi(static_cast<unsigned>(p), ppr_magic)), piece = p - pr * ppr;
+          const int plane = static_cast<int>(__umulhi(static_cast<unsigned>(pr), lh_magic)), row = pr - plane * lh;
           const int col = min(P.b_c0 + (piece << 3), P.m2_pitch - 8);
           const int srow = min(P.b_r0 + row, P.m2_rows - 1);
           v[q] = *reinterpret_cast<const __attribute__((address_space(1))) U2*>(
@@ -373,22 +378,27 @@ Rt2DBoundKernel(const Rt2DTileParams* __restrict__ params, const int4* __restric
             odd[j][w] += (packed[j][w] >> 8) & 0x00ff00ffu;
           }
       }
-      // (both fields of a register are summed across the lanes at once: no carry between them)
+      // (both fields of a register are summed across the lanes at once: no carry between them.
+      // Lane l collects the total of register l -- one select per register -- and every lane then
+      // adds its two blocks' sums into the match's array: two LDS operations per rotation instead
+      // of a predicated one per block)
+      uint32_t mine = 0;
 #pragma unroll
       for (int j = 0; j < NB; ++j)
 #pragma unroll
         for (int w = 0; w < kRowWords; ++w) {
-          const unsigned te = static_cast<unsigned>(WaveSum(static_cast<int>(even[j][w])));
-          const unsigned to = static_cast<unsigned>(WaveSum(static_cast<int>(odd[j][w])));
+          const uint32_t te = static_cast<uint32_t>(WaveSum(static_cast<int>(even[j][w])));
+          const uint32_t to = static_cast<uint32_t>(WaveSum(static_cast<int>(odd[j][w])));
           if (j == 0 && w == 0 && wave == 0 && rotations_done < 8) Stamp(tl, tl_block, 6 + rotations_done++);   // (wave 0: its rotations)
-          if (lane == 0) {
-            int* row = ub + (s * NB + j) * NB;
-            if (4 * w + 0 < NB) atomicAdd(&row[4 * w + 0], static_cast<int>(te & 0xffffu));
-            if (4 * w + 1 < NB) atomicAdd(&row[4 * w + 1], static_cast<int>(to & 0xffffu));
-            if (4 * w + 2 < NB) atomicAdd(&row[4 * w + 2], static_cast<int>(te >> 16));
-            if (4 * w + 3 < NB) atomicAdd(&row[4 * w + 3], static_cast<int>(to >> 16));
-          }
+          mine = lane == 2 * (j * kRowWords + w) ? te : mine;
+          mine = lane == 2 * (j * kRowWords + w) + 1 ? to : mine;
         }
+      if (lane < 2 * NB * kRowWords) {
+        const int reg = lane >> 1, j = reg / kRowWords, w = reg - j * kRowWords, par = lane & 1;
+        int* row = ub + (s * NB + j) * NB;
+        if (4 * w + par < NB) atomicAdd(&row[4 * w + par], static_cast<int>(mine & 0xffffu));
+        if (4 * w + 2 + par < NB) atomicAdd(&row[4 * w + 2 + par], static_cast<int>(mine >> 16));
+      }
     }
     __syncthreads();
     Stamp(tl, tl_block, 2);                    // phase A: the byte sums of this item's blocks

@@ -1,16 +1,19 @@
-# Round-end validation on the GPU box: device tests, profiles of every config, the full bench line.
-TAG=${1:-r02e}
-mkdir -p gpurun_out/final
-timeout 600 python -m pytest tests -m gpu -x -q -p no:cacheprovider > gpurun_out/final/pytest_gpu.txt 2>&1
-grep -E "passed|failed|error" gpurun_out/final/pytest_gpu.txt | tail -3
-PROFILE_TIMEOUT=100 bash tools/profile_all.sh $TAG > gpurun_out/final/profile_all.log 2>&1
-tail -12 gpurun_out/final/profile_all.log
-timeout 400 python bench.py --pmc-dir gpurun_out --pmc-tag $TAG > gpurun_out/final/bench_full.json 2> gpurun_out/final/bench_full.err
-python - <<'P'
-import json
-d=json.loads(open('gpurun_out/final/bench_full.json').read().strip().splitlines()[-1])
-r=d['roofline']; print('c2', d['ms_per_step'], d['value'], r['frac'], r.get('traffic'), d['cpu_baseline']['value'])
-for k,v in d['config']['other'].items():
-    rf=v.get('roofline') or {}
-    print(k, v.get('ms_per_step'), v.get('device_ms_per_step'), v.get('candidates_per_s'), v.get('matches_per_s'), v.get('error'), (rf.get('kernel') or '')[:18], rf.get('frac'), rf.get('traffic'))
-P
+#!/bin/bash
+# The round's last GPU call: what the driver runs at round end (GPU suite, smoke, the default bench),
+# the rocprofv3 passes of every config (tools/profile_all.sh -> gpurun_out/<tag>_*.csv: copy into
+# profiles/), and the default bench once more with those passes in place.
+#   gpurun --timeout 2400 -- 'bash tools/final_run.sh r05'
+set -u
+TAG=${1:-r05}
+cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+OUT=gpurun_out/final_$TAG; mkdir -p $OUT
+export PYTHONUNBUFFERED=1
+echo "== gpu tests"; timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -6 | tee $OUT/pytest_gpu.txt
+echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.txt
+echo "== profiles"; bash tools/profile_all.sh $TAG 2>&1 | tail -3
+cp gpurun_out/${TAG}*_kernel_stats.csv gpurun_out/${TAG}*_pmc_*.csv profiles/ 2>/dev/null
+echo "== default bench (as the driver runs it)"
+timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "rc $?"; wc -c $OUT/bench.json; cat $OUT/bench.json; tail -n 3 $OUT/bench.err
+cp gpurun_out/bench_details.json $OUT/bench_details.json
+echo "== c1 1024 as the timed config"
+timeout 600 python bench.py --config c1 --matches 1024 --steps 20 --warmup 5 --details $OUT/bench_c1b1024_details.json 2>/dev/null | tee $OUT/bench_c1b1024.json | cut -c1-600
