@@ -697,7 +697,7 @@ class Rt2DWorkload:
         side = int(round(math.sqrt(cand / max(scans, 1))))
         summed = acc["coarse_candidates"] / steps
         if summed < cand:
-            # Round 5, from 96 matches per call on: block bounds first (rt_2d_bounds.h).  Per
+            # Round 5, from 192 matches per call on: block bounds first (rt_2d_bounds.h).  Per
             # (rotation, point) the bound kernel reads (side + 1) / 2 block rows of three aligned
             # dwords each from the max-pooled byte planes in LDS, and the point's two coordinates;
             # the handful of blocks that reach the bound are summed from the image in HBM (L2).

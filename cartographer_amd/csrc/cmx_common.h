@@ -77,7 +77,7 @@ cmx_status Guard(F&& body) {
   X(rt2d_grid_share)      /* a part's tile grid and work items sized for its share of the CUs: 1 always, 2 never (0: by batch size) */ \
   X(rt2d_unfused)         /* 1: one-tile matches through the prep kernel too (parity partner) */   \
   X(rt2d_no_bounds)       /* 1: no block bounds, the tile kernel sums every candidate (parity partner) */ \
-  X(rt2d_bounds)          /* 1: block bounds for calls of any size (default: from 96 matches per call on) */ \
+  X(rt2d_bounds)          /* 1: block bounds for calls of any size (default: from 192 matches per call on) */ \
   X(rt2d_bounds_verify)   /* 1: every block is summed and checked against its bound (an error if one is below) */ \
   X(timeline)             /* 1: in-kernel timelines (cmx_device.h Stamp) reported on stderr */     \
   X(trace)                /* 1: an event after every stage of a call, durations on stderr */       \

@@ -739,7 +739,7 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
       plan_search(p.begin, p.end);
       const double t_search = since_call();
       p.call.reset(new Rt2DTileCall(options, items + p.begin, search.data() + p.begin, p.end - p.begin, device,
-                                    share_cus ? parts : 1));
+                                    share_cus ? parts : 1, num));
       const bool eligible = p.call->Plan();
       const double t_plan = since_call();
       if (eligible) {

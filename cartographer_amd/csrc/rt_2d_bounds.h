@@ -42,7 +42,7 @@
 #define CMX_RT_2D_BOUNDS_H_
 
 constexpr int kBoundThreads = 512;          // eight wavefronts; two workgroups per CU
-constexpr int kBoundMinMatches = 96;        // matches per call from which the bound kernel is the default
+constexpr int kBoundMinMatches = 192;       // matches per call from which the bound kernel is the default
 constexpr int kBoundMaxBlocks = 8;          // block columns in one ds_read_b64: side <= 16
 #ifndef CMX_RT2D_BOUND_BITS
 #define CMX_RT2D_BOUND_BITS 5

@@ -1414,6 +1414,7 @@ struct Rt2DTileCall::Impl {
   std::vector<TileGeometry> geo;
   int rpl = 1, max_scans = 0, common_stride = -1, group = 8, cus = 256;
   int share = 1;                        // calls sharing the device (the parts of a batch)
+  int batch_matches = 0;                // matches of the whole batch (>= num)
   size_t tile_lds = 0, prep_lds = 0, finish_lds = 0;
   size_t lists_total = 0, hdr_total = 0, qsum_total = 0;
   long long work_cap = 0, entries_total = 0;
@@ -1431,11 +1432,13 @@ struct Rt2DTileCall::Impl {
 };
 
 Rt2DTileCall::Rt2DTileCall(const cmx_rt_options* options, const Rt2DItem* items,
-                           const Rt2DSearch* search, int num, int32_t device, int concurrent_calls)
+                           const Rt2DSearch* search, int num, int32_t device, int concurrent_calls,
+                           int batch_matches)
     : impl_(new Impl) {
   impl_->options = options; impl_->items = items; impl_->search = search;
   impl_->num = num; impl_->device = device;
   impl_->share = std::max(1, concurrent_calls);
+  impl_->batch_matches = std::max(num, batch_matches);
 }
 Rt2DTileCall::~Rt2DTileCall() {
   // (a call abandoned between its launches and its wait -- an exception in a later part: nothing
@@ -1730,9 +1733,10 @@ bool Rt2DTileCall::Plan() {
   // those, and stays the parity partner behind the debug switch.
   // From kBoundMinMatches matches per call on: below, the tile kernel's finer work items (a match
   // in four or more, none of which waits for a last one) give the shorter call -- measured on C1,
-  // one box, bounds / tiles: 1 match 62 / 52 us, 16: 92 / 74, 128: 114 / 118, 1024: 330 / 449
-  // (profiles/r05_c1_bounds.txt).  Debug switches: rt2d_bounds = 1 always, rt2d_no_bounds never.
-  I.bounds = I.fused && !dbg.rt2d_no_bounds && (num >= kBoundMinMatches || dbg.rt2d_bounds);
+  // bounds / tiles: 1 match 62 / 52 us, 16: 92 / 74, 128: 114 - 126 / 117 (on 400 x 400 grids
+  // 139 - 161 / 106), 256: 144 / 168, 1024: 330 - 357 / 449 - 503 (profiles/r05_c1_bounds.txt).
+  // Debug switches: rt2d_bounds = 1 always, rt2d_no_bounds never.
+  I.bounds = I.fused && !dbg.rt2d_no_bounds && (I.batch_matches >= kBoundMinMatches || dbg.rt2d_bounds);
   for (int m = 0; m < num && I.bounds; ++m) {
     const int side = 2 * search[m].nl + 1;
     // (the bound kernel finishes a match itself, in the LDS of its planes and cloud -- a small

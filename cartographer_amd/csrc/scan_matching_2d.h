@@ -225,7 +225,9 @@ class Rt2DTileCall {
   // `concurrent_calls`: how many calls of this kind share the device at the same time (the parts
   // of a batch): each sizes its tile grid and its work items for 1 / concurrent_calls of the CUs.
   Rt2DTileCall(const cmx_rt_options* options, const Rt2DItem* items, const Rt2DSearch* search,
-               int num, int32_t device, int concurrent_calls = 1);
+               int num, int32_t device, int concurrent_calls = 1, int batch_matches = 0);
+  // (`batch_matches`: matches of the whole batch this call is a part of -- 0: `num` -- which is
+  // what decides between the block bounds and the exhaustive tile kernel)
   ~Rt2DTileCall();
   bool Plan();                          // false: not eligible for this path
   // asynchronous.  `on_stream`: the call's work goes on that stream instead of its workspace's

@@ -150,7 +150,7 @@ def _rt2d_path(debug, path):
     kernel and its planner; 'tiles64' / 'tiles56g': the same with small tiles (up to 4 x 4 per match: sums meet by atomics) and
     with one work item per (tile, rotation); '0': one thread per candidate."""
     if path == "bounds":     # block bounds first where the window is at most 16 x 16 (the
-        debug(rt2d_bounds=1)  # default from 96 matches per call on; here: calls of any size)
+        debug(rt2d_bounds=1)  # default from 192 matches per call on; here: calls of any size)
         return
     if path == "0":
         debug(rt2d_legacy=1)
@@ -294,9 +294,9 @@ def test_rt2d_batch_on_resident_grids_both_paths(sm, oracle, synth, debug):
             np.testing.assert_allclose(poses[k], ref["pose"], rtol=0, atol=1e-12)
 
 
-def test_rt2d_a_batch_of_a_hundred_takes_the_bound_kernel(sm, synth, debug):
-    """From 96 matches per call on the block bounds are the default (rt_2d_bounds.h: the bound
-    kernel also finishes its matches, one launch per call): 100 matches over five grids with
+def test_rt2d_a_batch_of_two_hundred_takes_the_bound_kernel(sm, synth, debug):
+    """From 192 matches per call on the block bounds are the default (rt_2d_bounds.h: the bound
+    kernel also finishes its matches, one launch per call): 200 matches over five grids with
     scans of different sizes return, match by match, what the exhaustive tile kernel returns for
     them one by one, and the statistics show that a fraction of the search space was summed."""
     from cartographer_amd import grid_2d
@@ -307,14 +307,14 @@ def test_rt2d_a_batch_of_a_hundred_takes_the_bound_kernel(sm, synth, debug):
         worlds.append((grid_2d.ProbabilityGridOnDevice(0.05, (lim["max_x"], lim["max_y"]), 200, 200,
                                                        cells=cells), world))
     grids, inits, scans = [], [], []
-    for k in range(100):
+    for k in range(200):
         grid, world = worlds[k % 5]
         pose = world.free_pose(400 + k, 0.5)
         grids.append(grid)
-        scans.append(world.scan(pose, 250 + 7 * k, 5.0, 0.01, k))
+        scans.append(world.scan(pose, 250 + 3 * k, 5.0, 0.01, k))
         inits.append(sm.Rigid2d(pose[0] + 0.1, pose[1] - 0.05, pose[2] + 0.04))
     debug(rt2d_no_bounds=1)
-    singles = [m.match(inits[k], scans[k], grids[k]) for k in range(100)]
+    singles = [m.match(inits[k], scans[k], grids[k]) for k in range(200)]
     from cartographer_amd import _lib
     _lib.debug_reset()
     batch = sm.Rt2DBatch(m, grids, scans, resident=True)
@@ -325,7 +325,7 @@ def test_rt2d_a_batch_of_a_hundred_takes_the_bound_kernel(sm, synth, debug):
             assert scores[k] == score, k
             np.testing.assert_array_equal(poses[k], [pose.x, pose.y, pose.theta])
         assert stats["coarse_candidates"] < 0.6 * stats["candidates_scored"], stats
-        assert 100 <= stats["finalists"] <= stats["refined_candidates"] < 0.1 * stats["candidates_scored"]
+        assert 200 <= stats["finalists"] <= stats["refined_candidates"] < 0.1 * stats["candidates_scored"]
 
 
 @pytest.mark.parametrize("resident", [False, True])

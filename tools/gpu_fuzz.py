@@ -84,7 +84,7 @@ def case_2d(rng, report):
     if not (score == a["score"] and
             np.allclose([pose.x, pose.y, pose.theta], a["pose"], rtol=0, atol=1e-12)):
         report("rt2d", dict(what, rt=rt), score, a["score"])
-    # the same match through the block bounds (the default only from 96 matches per call on)
+    # the same match through the block bounds (the default only from 192 matches per call on)
     from cartographer_amd import _lib
     _lib.debug_set(rt2d_bounds=1)
     try:
