@@ -258,6 +258,29 @@ def test_rt2d_points_outside_and_unknown_grid(sm, oracle, debug, bulk):
         np.testing.assert_allclose([est.x, est.y, est.theta], ref["pose"], rtol=0, atol=1e-12)
 
 
+def test_rt2d_block_bounds_on_flat_landscapes(sm, oracle, debug):
+    """Score landscapes the bounds cannot prune, inside the bound kernel's window limit (13 x 13):
+    an all-unknown grid -- every candidate ties, every block reaches the lower bound, more blocks
+    than the kernel lists: it says so and the match is repeated on the per-candidate kernels -- and
+    a random grid, where a few dozen blocks survive and are summed.  Results = the oracle's,
+    first-maximum rule included."""
+    debug(rt2d_bounds=1)
+    rng = np.random.default_rng(11)
+    scan = np.zeros((200, 3), np.float32)
+    scan[:, :2] = rng.uniform(-1.5, 1.5, (200, 2))
+    for cells, weights in ((np.zeros((80, 90), np.uint16), (0.0, 0.0)),
+                           (np.zeros((80, 90), np.uint16), (0.1, 0.1)),
+                           (rng.integers(0, 32768, (80, 90)).astype(np.uint16), (0.0, 0.0)),
+                           (rng.integers(1, 32768, (80, 90)).astype(np.uint16), (0.1, 0.1))):
+        init = [2.0, 2.3, 0.3]
+        ref = oracle.rt2d_match(cells, 0.05, 4.5, 4.0, init, scan, 0.3, 0.1, *weights)
+        m = sm.RealTimeCorrelativeScanMatcher2D(0.3, 0.1, *weights)
+        score, est = m.match(sm.Rigid2d(*init), scan, sm.Grid2D(cells, 0.05, 4.5, 4.0))
+        assert score == ref["score"]
+        np.testing.assert_allclose([est.x, est.y, est.theta], ref["pose"], rtol=0, atol=1e-12)
+        assert m.last_stats["candidates_scored"] == ref["num_candidates"]
+
+
 def test_rt2d_batch_on_resident_grids_both_paths(sm, oracle, synth, debug):
     from cartographer_amd import grid_2d
     m = sm.RealTimeCorrelativeScanMatcher2D(0.3, math.radians(7.0), 0.1, 0.1)
