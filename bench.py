@@ -97,7 +97,7 @@ def parse_args():
                     help="initialise RCCL and run the collectives even with one rank (plumbing test)")
     ap.add_argument("--pmc-dir", default=os.path.join(ROOT, "profiles"),
                     help="directory with <tag>_pmc_{fetch,write}_size.csv of THIS command "
-                         "(tools/profile_bench.sh writes them); roofline.traffic is null without")
+                         "(tools/profile_all.sh writes them); roofline.traffic is null without")
     ap.add_argument("--pmc-tag", default="r05")
     ap.add_argument("--details", default=os.path.join(ROOT, "gpurun_out", "bench_details.json"),
                     help="file the FULL record goes to (per-config blocks, notes, nested "
