@@ -258,6 +258,36 @@ def test_rt2d_points_outside_and_unknown_grid(sm, oracle, debug, bulk):
         np.testing.assert_allclose([est.x, est.y, est.theta], ref["pose"], rtol=0, atol=1e-12)
 
 
+def test_rt2d_bound_kernel_with_two_window_classes_in_one_batch(sm, synth, debug):
+    """One batch, two grid resolutions: 0.3 m is 13 x 13 candidates on the 5 cm grids (7 x 7 blocks)
+    and 7 x 7 on the 10 cm grids (4 x 4 blocks).  The bound kernel is instantiated for the larger
+    count and the smaller matches leave its outer blocks without a candidate; grids of three sizes,
+    clouds of 60 ... 1100 points.  Every match equals the exhaustive path's result for it."""
+    from cartographer_amd import grid_2d
+    m = sm.RealTimeCorrelativeScanMatcher2D(0.3, math.radians(5.0), 0.1, 0.1)
+    worlds = []
+    for k, (res, size) in enumerate([(0.05, 200), (0.1, 120), (0.05, 140), (0.1, 90)]):
+        cells, lim, world = synth.make_submap(80 + k, size, size, res, 20, 600, 5.0, 0.01)
+        worlds.append((grid_2d.ProbabilityGridOnDevice(res, (lim["max_x"], lim["max_y"]), size, size,
+                                                       cells=cells), world))
+    grids, inits, scans = [], [], []
+    for k in range(208):
+        grid, world = worlds[k % 4]
+        pose = world.free_pose(500 + k, 0.5)
+        grids.append(grid)
+        scans.append(world.scan(pose, 60 + 5 * k, 5.0, 0.01, k))
+        inits.append(sm.Rigid2d(pose[0] + 0.08, pose[1] - 0.06, pose[2] - 0.03))
+    debug(rt2d_no_bounds=1)
+    singles = [m.match(inits[k], scans[k], grids[k]) for k in range(208)]
+    from cartographer_amd import _lib
+    _lib.debug_reset()
+    scores, poses, stats = sm.rt2d_match_batch(m, grids, inits, scans)
+    for k, (score, pose) in enumerate(singles):
+        assert scores[k] == score, k
+        assert (poses[k].x, poses[k].y, poses[k].theta) == (pose.x, pose.y, pose.theta), k
+    assert stats["coarse_candidates"] < 0.6 * stats["candidates_scored"], stats   # the bounds ran
+
+
 def test_rt2d_block_bounds_on_flat_landscapes(sm, oracle, debug):
     """Score landscapes the bounds cannot prune, inside the bound kernel's window limit (13 x 13):
     an all-unknown grid -- every candidate ties, every block reaches the lower bound, more blocks
