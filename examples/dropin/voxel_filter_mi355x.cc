@@ -1,0 +1,76 @@
+// Bodies of sensor::VoxelFilter(PointCloud) and sensor::AdaptiveVoxelFilter over
+// libcartographer_mi355x, compiled against the reference's REAL sensor/internal/voxel_filter.h:
+// the source a maintainer swaps for sensor/internal/voxel_filter.cc in a build whose local
+// trajectory builder filters on the device (2d/local_trajectory_builder_2d.cc:59-61,227-229
+// compile unmodified).  The other overloads of the header (timed point clouds, range
+// measurements) have no caller on the 2D path and are not defined here.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "cartographer/sensor/internal/voxel_filter.h"
+#include "cartographer_mi355x.h"
+
+namespace cartographer {
+namespace sensor {
+namespace {
+
+void CheckOk(cmx_status status, const char* what) {
+  if (status == CMX_OK) return;
+  std::fprintf(stderr, "Check failed: %s: %s (%s)\n", what, cmx_status_string(status),
+               cmx_last_error());
+  std::abort();
+}
+
+int Device() {
+  const char* e = std::getenv("CMX_DEVICE");
+  return e ? std::atoi(e) : 0;
+}
+
+std::vector<float> Flatten(const PointCloud& cloud) {
+  std::vector<float> xyz;
+  xyz.reserve(3 * cloud.size());
+  for (const RangefinderPoint& p : cloud) {
+    xyz.push_back(p.position.x());
+    xyz.push_back(p.position.y());
+    xyz.push_back(p.position.z());
+  }
+  return xyz;
+}
+
+PointCloud Unflatten(const std::vector<float>& xyz, const int32_t count) {
+  std::vector<RangefinderPoint> points;
+  points.reserve(count);
+  for (int32_t i = 0; i != count; ++i)
+    points.push_back({Eigen::Vector3f(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2])});
+  return PointCloud(std::move(points));
+}
+
+}  // namespace
+
+PointCloud VoxelFilter(const PointCloud& point_cloud, const float resolution) {
+  if (point_cloud.empty()) return PointCloud();
+  const std::vector<float> xyz = Flatten(point_cloud);
+  std::vector<float> kept(xyz.size());
+  int32_t count = 0;
+  CheckOk(cmx_voxel_filter(xyz.data(), static_cast<int32_t>(point_cloud.size()), resolution,
+                           Device(), kept.data(), &count),
+          "cmx_voxel_filter");
+  return Unflatten(kept, count);
+}
+
+PointCloud AdaptiveVoxelFilter(const PointCloud& point_cloud,
+                               const proto::AdaptiveVoxelFilterOptions& options) {
+  if (point_cloud.empty()) return PointCloud();
+  const std::vector<float> xyz = Flatten(point_cloud);
+  std::vector<float> kept(xyz.size());
+  int32_t count = 0;
+  CheckOk(cmx_adaptive_voxel_filter(xyz.data(), static_cast<int32_t>(point_cloud.size()),
+                                    options.max_length(), options.min_num_points(),
+                                    options.max_range(), Device(), kept.data(), &count),
+          "cmx_adaptive_voxel_filter");
+  return Unflatten(kept, count);
+}
+
+}  // namespace sensor
+}  // namespace cartographer

@@ -37,6 +37,10 @@ class Rigid2 {
     while (a < -M_PI) a += two_pi;
     return a;
   }
+  template <typename U>
+  Rigid2<U> cast() const {
+    return Rigid2<U>(t_.template cast<U>(), r_.template cast<U>());
+  }
   Rigid2 inverse() const {
     const Rotation2D rotation = r_.inverse();
     const Vector translation = -(rotation * t_);

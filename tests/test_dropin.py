@@ -346,3 +346,81 @@ def test_real_time_matchers_on_the_gpu_print_the_references_numbers():
     out = subprocess.run([RT_MI355X], check=True, capture_output=True, text=True,
                          timeout=300).stdout
     assert out.splitlines() == open(RT_GOLDEN).read().splitlines()
+
+
+# ---- the reference's LocalTrajectoryBuilder2D, unmodified, scan after scan ---------------------
+LTB_REFERENCE = os.path.join(DROPIN, "_build", "local_trajectory_builder_2d_reference")
+LTB_MI355X = os.path.join(DROPIN, "_build", "local_trajectory_builder_2d_mi355x")
+LTB_GOLDEN = os.path.join(ROOT, "tests", "golden", "local_trajectory_builder_2d_reference.txt")
+
+
+def _drive(text):
+    """(scan index, [x, y, yaw], points matched, submaps inserted into) of every result line,
+    the submap digests, the worst distance from the simulated truth."""
+    poses, submaps, worst = [], [], None
+    for line in text.splitlines():
+        w = line.split()
+        if line.startswith("scan") and "pose" in line:
+            poses.append((int(w[1]), [float(v) for v in w[5:8]], int(w[13]), int(w[15])))
+        elif line.startswith("submap"):
+            submaps.append((int(w[2]), int(w[4]), int(w[6]), int(w[8]), int(w[10]), float(w[12])))
+        elif line.startswith("results"):
+            worst = float(w[5])
+    return poses, submaps, worst
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="needs the reference tree to compile")
+def test_local_trajectory_builder_2d_builds_unmodified_and_the_golden_is_the_references():
+    """local_trajectory_builder_2d.cc compiles where it lies, twice: with the reference's own
+    real-time matcher, Ceres matcher and voxel filter (that binary runs here; its drive of 80
+    simulated scans must print the committed golden and stay within 2.5 cm of the truth) and
+    with the three adapter files over the product library only."""
+    subprocess.run(["make", "-C", DROPIN], check=True, capture_output=True)
+    out = subprocess.run([LTB_REFERENCE], check=True, capture_output=True, text=True,
+                         timeout=120).stdout
+    assert out == open(LTB_GOLDEN).read()
+    poses, submaps, worst = _drive(out)
+    assert len(poses) == 79 and worst < 0.025
+    assert sum(1 for p in poses if p[3] == 2) > 20      # a second submap was started and filled
+    assert len(submaps) == 2
+    needed = subprocess.run(["readelf", "-d", LTB_MI355X], check=True, capture_output=True,
+                            text=True).stdout
+    assert "libcartographer_mi355x.so" in needed and "oracle" not in needed
+    symbols = subprocess.run(["nm", "-C", LTB_MI355X], check=True, capture_output=True,
+                             text=True).stdout
+    for name in ("cmx_rt2d_match", "cmx_ceres2d_match", "cmx_voxel_filter",
+                 "cmx_adaptive_voxel_filter"):
+        assert name in symbols
+    assert "LocalTrajectoryBuilder2D::AddAccumulatedRangeData" in symbols
+    # neither the builder nor its header is stood in or copied
+    for root in (DROPIN, os.path.join(ROOT, "oracle", "ref_shims")):
+        for _, _, files in os.walk(root):
+            assert "local_trajectory_builder_2d.cc" not in files
+            assert "local_trajectory_builder_2d.h" not in files
+    if not os.path.exists("/dev/kfd"):
+        run = subprocess.run([LTB_MI355X], capture_output=True, text=True, timeout=120)
+        assert run.returncode != 0 and "no CPU fallback" in run.stderr
+
+
+@pytest.mark.gpu
+def test_local_trajectory_builder_2d_on_the_gpu_follows_the_references_drive():
+    """The same 80 scans with the device under the unmodified builder: voxel filters
+    (bit-exact), real-time correlative matcher (bit-exact), Ceres matcher (the device's solver:
+    equal to ~1e-9 per solve).  The loop is closed -- every pose moves the next scan's insertion
+    -- so the rounding-level differences of the solver grow once they flip a grid cell: the first
+    ten results must agree to 1e-6, all of them to 5 mm, the same scans must be inserted into the
+    same number of submaps, and the drive must stay as close to the truth as the reference's."""
+    assert os.path.exists(LTB_MI355X), "examples/dropin/_build is prebuilt by __graft_entry__.build()"
+    out = subprocess.run([LTB_MI355X], check=True, capture_output=True, text=True,
+                         timeout=300).stdout
+    got, got_submaps, got_worst = _drive(out)
+    want, want_submaps, want_worst = _drive(open(LTB_GOLDEN).read())
+    assert len(got) == len(want) == 79
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g[0] == w[0] and g[3] == w[3]
+        np.testing.assert_allclose(g[1], w[1], rtol=0, atol=1e-6 if k < 10 else 5e-3)
+        assert abs(g[2] - w[2]) <= 3                   # points the adaptive filter kept
+    assert got_worst < 0.025 and abs(got_worst - want_worst) < 5e-3
+    for g, w in zip(got_submaps, want_submaps):
+        assert g[:4] == w[:4]                          # scans, finished, cells
+        assert abs(g[4] - w[4]) < 0.01 * w[4] and abs(g[5] - w[5]) < 0.01 * w[5]
