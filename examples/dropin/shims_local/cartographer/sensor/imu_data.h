@@ -5,11 +5,17 @@
 #include "cartographer/common/time.h"
 namespace cartographer {
 namespace sensor {
+namespace proto {
+struct ImuData {};   // options.initial_imu_data() of the 3D builder: left empty in this build
+}  // namespace proto
 struct ImuData {
   common::Time time;
   Eigen::Vector3d linear_acceleration;
   Eigen::Vector3d angular_velocity;
 };
+inline ImuData FromProto(const proto::ImuData&) {
+  return ImuData{common::Time::min(), Eigen::Vector3d::Zero(), Eigen::Vector3d::Zero()};
+}
 }  // namespace sensor
 }  // namespace cartographer
 #endif  // DROPIN_SHIMS_LOCAL_IMU_DATA_H_

@@ -2,8 +2,10 @@
 // libcartographer_mi355x, compiled against the reference's REAL sensor/internal/voxel_filter.h:
 // the source a maintainer swaps for sensor/internal/voxel_filter.cc in a build whose local
 // trajectory builder filters on the device (2d/local_trajectory_builder_2d.cc:59-61,227-229
-// compile unmodified).  The other overloads of the header (timed point clouds, range
-// measurements) have no caller on the 2D path and are not defined here.
+// and 3d/local_trajectory_builder_3d.cc:158-159,250-252,281-296 compile unmodified).  The
+// range-measurement overload (the 3D builder's first filter) runs the same device filter on the
+// positions and hands back the measurements of the points it kept; the two remaining overloads of
+// the header have no caller on either path and are not defined here.
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -57,6 +59,42 @@ PointCloud VoxelFilter(const PointCloud& point_cloud, const float resolution) {
                            Device(), kept.data(), &count),
           "cmx_voxel_filter");
   return Unflatten(kept, count);
+}
+
+// The filter keeps a subset of the points in input order: walk both lists once to find which
+// measurements those are.  (Two measurements at the very same position in one voxel are
+// indistinguishable to the C ABI; the first is taken.  cmx_voxel_filter_indices would lift that.)
+std::vector<TimedPointCloudOriginData::RangeMeasurement> VoxelFilter(
+    const std::vector<TimedPointCloudOriginData::RangeMeasurement>& range_measurements,
+    const float resolution) {
+  std::vector<TimedPointCloudOriginData::RangeMeasurement> results;
+  if (range_measurements.empty()) return results;
+  std::vector<float> xyz;
+  xyz.reserve(3 * range_measurements.size());
+  for (const auto& m : range_measurements) {
+    xyz.push_back(m.point_time.position.x());
+    xyz.push_back(m.point_time.position.y());
+    xyz.push_back(m.point_time.position.z());
+  }
+  std::vector<float> kept(xyz.size());
+  int32_t count = 0;
+  CheckOk(cmx_voxel_filter(xyz.data(), static_cast<int32_t>(range_measurements.size()), resolution,
+                           Device(), kept.data(), &count),
+          "cmx_voxel_filter");
+  results.reserve(count);
+  size_t at = 0;
+  for (int32_t k = 0; k != count; ++k) {
+    while (at != range_measurements.size() &&
+           !(xyz[3 * at] == kept[3 * k] && xyz[3 * at + 1] == kept[3 * k + 1] &&
+             xyz[3 * at + 2] == kept[3 * k + 2]))
+      ++at;
+    if (at == range_measurements.size()) {
+      std::fprintf(stderr, "Check failed: a kept point is not one of the input points\n");
+      std::abort();
+    }
+    results.push_back(range_measurements[at++]);
+  }
+  return results;
 }
 
 PointCloud AdaptiveVoxelFilter(const PointCloud& point_cloud,
