@@ -218,6 +218,7 @@ int main(int argc, char** argv) {
   for (const auto& submap : {last_front, last_back}) {
     if (submap == nullptr) continue;
     const Grid2D& grid = *submap->grid();
+    DropinSyncGridToHost(grid);
     const CellLimits& cells = grid.limits().cell_limits();
     int known = 0;
     double sum = 0.;

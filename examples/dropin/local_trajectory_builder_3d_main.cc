@@ -247,6 +247,7 @@ int main(int argc, char** argv) {
   }
   for (const auto& submap : {last_front, last_back}) {
     if (submap == nullptr) continue;
+    DropinSyncSubmapToHost(*submap);
     float histogram_sum = 0.f;
     for (int i = 0; i != submap->rotational_scan_matcher_histogram().size(); ++i)
       histogram_sum += submap->rotational_scan_matcher_histogram()(i);

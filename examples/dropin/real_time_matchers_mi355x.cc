@@ -17,6 +17,7 @@
 #include "cartographer/mapping/internal/2d/tsdf_2d.h"
 #include "cartographer/mapping/internal/3d/scan_matching/real_time_correlative_scan_matcher_3d.h"
 #include "cartographer_mi355x.h"
+#include "device_grids.h"
 
 namespace cartographer {
 namespace mapping {
@@ -97,6 +98,14 @@ double RealTimeCorrelativeScanMatcher2D::Match(const transform::Rigid2d& initial
   const std::vector<float> xyz = Flatten(point_cloud);
   double score = 0.;
   cmx_pose2d pose{};
+  if (const auto* resident = dynamic_cast<const dropin::DeviceGrid2DView*>(&grid)) {
+    // the submap's grid is in HBM already (device_grids.h): only the scan crosses PCIe
+    CheckOk(cmx_rt2d_match_grid(&o, resident->device_grid(), &init, xyz.data(),
+                                static_cast<int32_t>(point_cloud.size()), &score, &pose, nullptr),
+            "cmx_rt2d_match_grid");
+    *pose_estimate = transform::Rigid2d({pose.x, pose.y}, pose.theta);
+    return score;
+  }
   switch (grid.GetGridType()) {
     case GridType::PROBABILITY_GRID:
       CheckOk(cmx_rt2d_match(&o, &limits, CellsOf(grid).data(), &init, xyz.data(),
@@ -163,6 +172,22 @@ float RealTimeCorrelativeScanMatcher3D::Match(const transform::Rigid3d& initial_
                                               transform::Rigid3d* pose_estimate) const {
   CHECK(pose_estimate != nullptr);
   const cmx_rt_options o = OptionsOf(options_);
+  if (const cmx_grid3d* resident = dropin::DeviceGridOf(&hybrid_grid)) {
+    const cmx_pose3d init{
+        {initial_pose_estimate.translation().x(), initial_pose_estimate.translation().y(),
+         initial_pose_estimate.translation().z()},
+        {initial_pose_estimate.rotation().w(), initial_pose_estimate.rotation().x(),
+         initial_pose_estimate.rotation().y(), initial_pose_estimate.rotation().z()}};
+    const std::vector<float> xyz = Flatten(point_cloud);
+    float score = 0.f;
+    cmx_pose3d pose{};
+    CheckOk(cmx_rt3d_match_grid(&o, resident, &init, xyz.data(),
+                                static_cast<int32_t>(point_cloud.size()), &score, &pose, nullptr),
+            "cmx_rt3d_match_grid");
+    *pose_estimate = transform::Rigid3d(Eigen::Vector3d(pose.t[0], pose.t[1], pose.t[2]),
+                                        Eigen::Quaterniond(pose.q[0], pose.q[1], pose.q[2], pose.q[3]));
+    return score;
+  }
   std::vector<cmx_voxel> voxels;             // what HybridGrid::Iterator yields (hybrid_grid.h:304-372)
   for (auto it = HybridGrid::Iterator(hybrid_grid); !it.Done(); it.Next()) {
     const Eigen::Array3i index = it.GetCellIndex();

@@ -8,6 +8,7 @@
 
 #include "cartographer/mapping/internal/2d/scan_matching/ceres_scan_matcher_2d.h"
 #include "cartographer/mapping/internal/2d/scan_matching/fast_correlative_scan_matcher_2d.h"
+#include "device_grids.h"
 
 namespace cartographer {
 namespace mapping {
@@ -126,10 +127,16 @@ void CeresScanMatcher2D::Match(const Eigen::Vector2d& target_translation,
   const std::vector<float> xyz = Flatten(point_cloud);
   cmx_pose2d pose{};
   cmx_ceres_summary s{};
-  CheckOk(cmx_ceres2d_match(&o, &limits, CellsOf(grid), target, &init,
-                            xyz.data(), static_cast<int32_t>(point_cloud.size()), Device(), &pose,
-                            &s),
-          "cmx_ceres2d_match");
+  if (const auto* resident = dynamic_cast<const dropin::DeviceGrid2DView*>(&grid)) {
+    CheckOk(cmx_ceres2d_match_grid(&o, resident->device_grid(), target, &init, xyz.data(),
+                                   static_cast<int32_t>(point_cloud.size()), &pose, &s),
+            "cmx_ceres2d_match_grid");
+  } else {
+    CheckOk(cmx_ceres2d_match(&o, &limits, CellsOf(grid), target, &init,
+                              xyz.data(), static_cast<int32_t>(point_cloud.size()), Device(), &pose,
+                              &s),
+            "cmx_ceres2d_match");
+  }
   *pose_estimate = transform::Rigid2d({pose.x, pose.y}, pose.theta);
   if (summary) {
     summary->initial_cost = s.initial_cost;

@@ -10,6 +10,7 @@
 
 #include "cartographer/mapping/internal/3d/scan_matching/ceres_scan_matcher_3d.h"
 #include "cartographer/mapping/internal/3d/scan_matching/fast_correlative_scan_matcher_3d.h"
+#include "device_grids.h"
 
 namespace cartographer {
 namespace mapping {
@@ -163,6 +164,44 @@ void CeresScanMatcher3D::Match(
   o.only_optimize_yaw = options_.only_optimize_yaw() ? 1 : 0;
   o.use_nonmonotonic_steps = options_.ceres_solver_options().use_nonmonotonic_steps() ? 1 : 0;
   o.max_num_iterations = options_.ceres_solver_options().max_num_iterations();
+  // Every grid of the call in HBM already (device_grids.h) and no intensity term: only the clouds
+  // cross PCIe.
+  {
+    std::vector<const cmx_grid3d*> resident;
+    for (const PointCloudAndHybridGridsPointers& p : point_clouds_and_hybrid_grids) {
+      const cmx_grid3d* grid =
+          p.intensity_hybrid_grid == nullptr ? dropin::DeviceGridOf(p.hybrid_grid) : nullptr;
+      if (grid == nullptr) break;
+      resident.push_back(grid);
+    }
+    if (static_cast<int>(resident.size()) == o.num_pairs) {
+      std::vector<std::vector<float>> flat;
+      std::vector<const float*> xyz;
+      std::vector<int32_t> counts;
+      for (const PointCloudAndHybridGridsPointers& p : point_clouds_and_hybrid_grids) {
+        flat.push_back(Flatten(*p.point_cloud));
+        counts.push_back(static_cast<int32_t>(p.point_cloud->size()));
+      }
+      for (const std::vector<float>& f : flat) xyz.push_back(f.data());
+      const double target[3] = {target_translation.x(), target_translation.y(),
+                                target_translation.z()};
+      const cmx_pose3d init = PoseOf(initial_pose_estimate);
+      cmx_pose3d pose{};
+      cmx_ceres_summary s{};
+      CheckOk(cmx_ceres3d_match_grids(&o, target, &init, resident.data(), xyz.data(), counts.data(),
+                                      &pose, &s),
+              "cmx_ceres3d_match_grids");
+      *pose_estimate = PoseFrom(pose);
+      if (summary) {
+        summary->initial_cost = s.initial_cost;
+        summary->final_cost = s.final_cost;
+        summary->num_successful_steps = s.num_successful_steps;
+        summary->num_unsuccessful_steps = s.num_unsuccessful_steps;
+        summary->termination_type = s.termination;
+      }
+      return;
+    }
+  }
   std::vector<std::vector<cmx_voxel>> voxels;
   std::vector<std::vector<float>> clouds;
   std::vector<cmx_ceres3d_pair> pairs;

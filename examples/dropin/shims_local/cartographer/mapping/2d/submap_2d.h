@@ -22,6 +22,8 @@
 #include "cartographer/sensor/range_data.h"
 #include "cartographer/transform/rigid_transform.h"
 namespace cartographer { namespace mapping {
+inline void DropinSyncGridToHost(const Grid2D&) {}   // (resident/: downloads the device grid)
+
 class Submap2D {
  public:
   Submap2D(const Eigen::Vector2f& origin, std::unique_ptr<Grid2D> grid,

@@ -76,6 +76,8 @@ class Submap3D {
   bool insertion_finished_ = false;
 };
 
+inline void DropinSyncSubmapToHost(const Submap3D&) {}   // (resident/: downloads the device grids)
+
 class ActiveSubmaps3D {
  public:
   explicit ActiveSubmaps3D(const proto::SubmapsOptions3D& options)

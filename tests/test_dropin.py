@@ -402,17 +402,44 @@ def test_local_trajectory_builder_2d_builds_unmodified_and_the_golden_is_the_ref
         assert run.returncode != 0 and "no CPU fallback" in run.stderr
 
 
+LTB_RESIDENT = os.path.join(DROPIN, "_build", "local_trajectory_builder_2d_resident_mi355x")
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="needs the reference tree to compile")
+def test_resident_local_trajectory_builders_link_the_device_grid_calls():
+    """The third build of both drives (examples/dropin/resident): the submaps' grids live in HBM
+    -- insertion, crop and both matchers through the handle entry points -- and the reference's
+    range-data inserters are not even linked."""
+    subprocess.run(["make", "-C", DROPIN], check=True, capture_output=True)
+    symbols = subprocess.run(["nm", "-C", LTB_RESIDENT], check=True, capture_output=True,
+                             text=True).stdout
+    for name in ("cmx_grid2d_create", "cmx_grid2d_insert", "cmx_grid2d_crop",
+                 "cmx_rt2d_match_grid", "cmx_ceres2d_match_grid"):
+        assert name in symbols
+    assert "ProbabilityGridRangeDataInserter2D::Insert" not in symbols
+    assert "LocalTrajectoryBuilder2D::AddAccumulatedRangeData" in symbols
+    symbols = subprocess.run(["nm", "-C", LTB3_RESIDENT], check=True, capture_output=True,
+                             text=True).stdout
+    for name in ("cmx_grid3d_create", "cmx_grid3d_insert", "cmx_rt3d_match_grid",
+                 "cmx_ceres3d_match_grids"):
+        assert name in symbols
+    assert "RangeDataInserter3D::Insert" not in symbols
+    assert "LocalTrajectoryBuilder3D::AddAccumulatedRangeData" in symbols
+
+
 @pytest.mark.gpu
-def test_local_trajectory_builder_2d_on_the_gpu_follows_the_references_drive():
-    """The same 80 scans with the device under the unmodified builder: voxel filters
+@pytest.mark.parametrize("binary", ["adapters", "resident"])
+def test_local_trajectory_builder_2d_on_the_gpu_follows_the_references_drive(binary):
+    """The same 80 scans with the device under the unmodified builder ("resident": the submaps'
+    grids in HBM too, inserted into by cmx_grid2d_insert): voxel filters
     (bit-exact), real-time correlative matcher (bit-exact), Ceres matcher (the device's solver:
     equal to ~1e-9 per solve).  The loop is closed -- every pose moves the next scan's insertion
     -- so the rounding-level differences of the solver grow once they flip a grid cell: the first
     ten results must agree to 1e-6, all of them to 5 mm, the same scans must be inserted into the
     same number of submaps, and the drive must stay as close to the truth as the reference's."""
-    assert os.path.exists(LTB_MI355X), "examples/dropin/_build is prebuilt by __graft_entry__.build()"
-    out = subprocess.run([LTB_MI355X], check=True, capture_output=True, text=True,
-                         timeout=300).stdout
+    path = LTB_MI355X if binary == "adapters" else LTB_RESIDENT
+    assert os.path.exists(path), "examples/dropin/_build is prebuilt by __graft_entry__.build()"
+    out = subprocess.run([path], check=True, capture_output=True, text=True, timeout=300).stdout
     got, got_submaps, got_worst = _drive(out)
     want, want_submaps, want_worst = _drive(open(LTB_GOLDEN).read())
     assert len(got) == len(want) == 79
@@ -484,16 +511,21 @@ def test_local_trajectory_builder_3d_builds_unmodified_and_the_golden_is_the_ref
         assert run.returncode != 0 and "no CPU fallback" in run.stderr
 
 
+LTB3_RESIDENT = os.path.join(DROPIN, "_build", "local_trajectory_builder_3d_resident_mi355x")
+
+
 @pytest.mark.gpu
-def test_local_trajectory_builder_3d_on_the_gpu_follows_the_references_drive():
-    """The same 60 sweeps with the device under the unmodified builder: three voxel filters
+@pytest.mark.parametrize("binary", ["adapters", "resident"])
+def test_local_trajectory_builder_3d_on_the_gpu_follows_the_references_drive(binary):
+    """The same 60 sweeps with the device under the unmodified builder ("resident": both hybrid
+    grids of every submap in HBM too, inserted into by cmx_grid3d_insert): three voxel filters
     (bit-exact), the 3D real-time correlative matcher (bit-exact), the 3D Ceres matcher on both
     hybrid grids (the device's solver).  On the builder's boxes the output has been byte-identical
     to the reference-linked build's; what is REQUIRED is the closed-loop bound of the 2D test:
     the first ten poses to 1e-6, all of them to 5 mm, the same insertions, the same submaps to 1 %."""
-    assert os.path.exists(LTB3_MI355X), "examples/dropin/_build is prebuilt by __graft_entry__.build()"
-    out = subprocess.run([LTB3_MI355X], check=True, capture_output=True, text=True,
-                         timeout=600).stdout
+    path = LTB3_MI355X if binary == "adapters" else LTB3_RESIDENT
+    assert os.path.exists(path), "examples/dropin/_build is prebuilt by __graft_entry__.build()"
+    out = subprocess.run([path], check=True, capture_output=True, text=True, timeout=600).stdout
     got, got_submaps, got_worst = _drive_3d(out)
     want, want_submaps, want_worst = _drive_3d(open(LTB3_GOLDEN).read())
     assert len(got) == len(want) == 60
