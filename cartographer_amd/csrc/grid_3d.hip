@@ -308,9 +308,30 @@ __global__ void IntensityApplyKernel(IntensityView b, const unsigned* __restrict
   if (key == 0xffffffffu || (j > 0 && keys_sorted[j - 1] == key)) return;
   float sum = b.sum[key];
   int count = b.count[key];
-  for (int k = j; k < n && keys_sorted[k] == key; ++k) {
-    count += 1;
-    sum += intensities[index_sorted[k]];
+  // The run's head walks it: the f32 sum must be taken in point order (bit parity with the
+  // reference's loop), but its LOADS need not wait for one another -- eight returns are fetched
+  // (key, index, then intensity: independent chains) before the eight dependent additions, so a
+  // long run (dense near-range returns in one voxel) costs an eighth of the round trips.
+  constexpr int kAhead = 8;
+  for (int k = j; k < n; k += kAhead) {
+    float value[kAhead];
+    bool same[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const int at = k + u;
+      same[u] = at < n && keys_sorted[min(at, n - 1)] == key;
+      value[u] = intensities[index_sorted[same[u] ? at : j]];
+    }
+    bool ended = false;
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      ended = ended || !same[u];
+      if (!ended) {
+        count += 1;
+        sum += value[u];
+      }
+    }
+    if (ended) break;
   }
   b.sum[key] = sum;
   b.count[key] = count;

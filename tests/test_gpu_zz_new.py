@@ -663,6 +663,35 @@ def test_intensity_grid_on_the_device_equals_the_reference_and_feeds_the_refinem
     assert a == b
 
 
+def test_intensity_runs_of_every_length_keep_the_point_order(oracle):
+    """Many returns in ONE voxel (dense near-range returns, coarse grids): the run's head adds them
+    in point order, fetching eight ahead.  Runs of 1..20, 63, 64, 65 and 500 returns, interleaved
+    with one another and with skipped returns, against the restatement's sequential loop: counts and
+    f32 sums bit-identical -- sums that depend on the order (values over eight decades)."""
+    from cartographer_amd import grid_3d
+    rng = np.random.default_rng(5)
+    res = 0.4
+    lengths = list(range(1, 21)) + [63, 64, 65, 500]
+    points, ints = [], []
+    for k, length in enumerate(lengths):
+        centre = res * np.array([k % 6, k // 6, 1.0])     # (cells are ROUNDED coordinates)
+        points.append(centre + rng.uniform(-0.15, 0.15, (length, 3)))
+        ints.append(10.0 ** rng.uniform(-4.0, 1.5, length))
+    points = np.concatenate(points).astype(np.float32)
+    ints = np.concatenate(ints).astype(np.float32)
+    order = rng.permutation(len(points))                  # runs interleaved in the scan
+    points, ints = points[order], ints[order]
+    ints[::37] = 50.0                                     # above the threshold: skipped
+    origin = np.array([0.0, 0.0, 5.0], np.float32)
+    dev, idev = grid_3d.HybridGridOnDevice(res), grid_3d.IntensityHybridGridOnDevice(res)
+    vox = np.zeros(0, oracle.INTENSITY_VOXEL_DTYPE)
+    for _ in range(2):                                    # the second scan adds to existing sums
+        dev.insert_with_intensities(idev, origin, points, ints, 0.7, 0.4, 2, 40.0)
+        vox = oracle.insert_intensities(res, vox, points, ints, 40.0)
+        assert idev.voxels().tobytes() == vox.tobytes()
+    assert len(vox) == len(lengths) and vox["count"].max() >= 900
+
+
 def test_bench_force_dist_on_one_gpu():
     """bench.py's distributed branch on the one GPU of the box: `--force-dist --gpus 1` initialises
     torch.distributed over RCCL (backend "nccl") with one rank and runs the collectives of a
