@@ -158,6 +158,12 @@ __global__ void CompactKernel(const float* __restrict__ xyz, const int* __restri
   out[3 * o + 2] = xyz[3 * i + 2];
 }
 
+__global__ void CompactIndexKernel(const int* __restrict__ used, const int* __restrict__ offset,
+                                   int n, int* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && used[i]) out[offset[i]] = i;
+}
+
 // Scratch of one filter call, carved from a workspace.
 struct FilterScratch {
   unsigned long long *keys = nullptr, *keys_sorted = nullptr;
@@ -517,6 +523,33 @@ cmx_status cmx_voxel_filter(const float* point_cloud_xyz, int32_t num_points, fl
     const int kept = cmx::VoxelFilterFlags(*ws, s, d_xyz, n, resolution);
     cmx::Compact(*ws, s, d_xyz, n, d_out);
     CMX_HIP(hipMemcpyAsync(filtered_xyz, d_out, 12 * static_cast<size_t>(kept),
+                           hipMemcpyDeviceToHost, ws->stream));
+    CMX_HIP(hipStreamSynchronize(ws->stream));
+    *num_filtered = kept;
+  });
+}
+
+cmx_status cmx_voxel_filter_indices(const float* point_cloud_xyz, int32_t num_points,
+                                    float resolution, int32_t device, int32_t* kept_indices,
+                                    int32_t* num_filtered) {
+  return Guard([&] {
+    CMX_REQUIRE(num_points >= 0 && num_points <= (1 << 26) && kept_indices && num_filtered &&
+                    (point_cloud_xyz || num_points == 0),
+                "bad argument");
+    CMX_REQUIRE(resolution > 0.f, "resolution must be > 0");
+    *num_filtered = 0;
+    cmx::WorkspaceLease ws(device);
+    if (num_points == 0) return;
+    const int n = num_points;
+    // dev[0]: the cloud | the kept indices
+    float* d_xyz = ws->dev[0].ReserveAs<float>(4 * static_cast<size_t>(n));
+    int* d_out = reinterpret_cast<int*>(d_xyz + 3 * static_cast<size_t>(n));
+    CMX_HIP(hipMemcpyAsync(d_xyz, point_cloud_xyz, 12 * static_cast<size_t>(n),
+                           hipMemcpyHostToDevice, ws->stream));
+    const cmx::FilterScratch s = cmx::Carve(*ws, n);
+    const int kept = cmx::VoxelFilterFlags(*ws, s, d_xyz, n, resolution);
+    cmx::CompactIndexKernel<<<cmx::DivUp(n, 256), 256, 0, ws->stream>>>(s.used, s.offset, n, d_out);
+    CMX_HIP(hipMemcpyAsync(kept_indices, d_out, 4 * static_cast<size_t>(kept),
                            hipMemcpyDeviceToHost, ws->stream));
     CMX_HIP(hipStreamSynchronize(ws->stream));
     *num_filtered = kept;

@@ -24,6 +24,18 @@ def voxel_filter(point_cloud, resolution, device=0):
     return out[:kept.value].copy()
 
 
+def voxel_filter_indices(point_cloud, resolution, device=0):
+    """Which points ``voxel_filter`` keeps (ascending indices): the overloads of
+    ``sensor::VoxelFilter`` over timed points / range measurements
+    (cartographer/sensor/internal/voxel_filter.cc:154-191) select payload with them."""
+    xyz, n = _cloud(point_cloud)
+    out = np.empty(max(n, 1), np.int32)
+    kept = C.c_int32()
+    _lib.check(_lib.lib().cmx_voxel_filter_indices(xyz.ctypes.data, n, resolution, device,
+                                                   out.ctypes.data, C.byref(kept)))
+    return out[:kept.value].copy()
+
+
 def adaptive_voxel_filter(point_cloud, max_length, min_num_points, max_range, device=0):
     xyz, n = _cloud(point_cloud)
     out = np.empty((max(n, 1), 3), np.float32)

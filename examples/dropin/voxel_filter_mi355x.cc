@@ -4,8 +4,8 @@
 // trajectory builder filters on the device (2d/local_trajectory_builder_2d.cc:59-61,227-229
 // and 3d/local_trajectory_builder_3d.cc:158-159,250-252,281-296 compile unmodified).  The
 // range-measurement overload (the 3D builder's first filter) runs the same device filter on the
-// positions and hands back the measurements of the points it kept; the two remaining overloads of
-// the header have no caller on either path and are not defined here.
+// positions (cmx_voxel_filter_indices); the two remaining overloads of the header have no caller on
+// either path and are not defined here.
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -61,9 +61,8 @@ PointCloud VoxelFilter(const PointCloud& point_cloud, const float resolution) {
   return Unflatten(kept, count);
 }
 
-// The filter keeps a subset of the points in input order: walk both lists once to find which
-// measurements those are.  (Two measurements at the very same position in one voxel are
-// indistinguishable to the C ABI; the first is taken.  cmx_voxel_filter_indices would lift that.)
+// sensor::VoxelFilter over range measurements (voxel_filter.cc:176-191): the same filter on
+// their positions; cmx_voxel_filter_indices says which measurements it kept.
 std::vector<TimedPointCloudOriginData::RangeMeasurement> VoxelFilter(
     const std::vector<TimedPointCloudOriginData::RangeMeasurement>& range_measurements,
     const float resolution) {
@@ -76,24 +75,13 @@ std::vector<TimedPointCloudOriginData::RangeMeasurement> VoxelFilter(
     xyz.push_back(m.point_time.position.y());
     xyz.push_back(m.point_time.position.z());
   }
-  std::vector<float> kept(xyz.size());
+  std::vector<int32_t> kept(range_measurements.size());
   int32_t count = 0;
-  CheckOk(cmx_voxel_filter(xyz.data(), static_cast<int32_t>(range_measurements.size()), resolution,
-                           Device(), kept.data(), &count),
-          "cmx_voxel_filter");
+  CheckOk(cmx_voxel_filter_indices(xyz.data(), static_cast<int32_t>(range_measurements.size()),
+                                   resolution, Device(), kept.data(), &count),
+          "cmx_voxel_filter_indices");
   results.reserve(count);
-  size_t at = 0;
-  for (int32_t k = 0; k != count; ++k) {
-    while (at != range_measurements.size() &&
-           !(xyz[3 * at] == kept[3 * k] && xyz[3 * at + 1] == kept[3 * k + 1] &&
-             xyz[3 * at + 2] == kept[3 * k + 2]))
-      ++at;
-    if (at == range_measurements.size()) {
-      std::fprintf(stderr, "Check failed: a kept point is not one of the input points\n");
-      std::abort();
-    }
-    results.push_back(range_measurements[at++]);
-  }
+  for (int32_t k = 0; k != count; ++k) results.push_back(range_measurements[kept[k]]);
   return results;
 }
 

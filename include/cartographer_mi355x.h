@@ -575,6 +575,14 @@ cmx_status cmx_fast3d_refine_batch(const cmx_ceres3d_options* options,
  * `filtered_xyz` needs room for num_points points; kept points stay in input order. */
 cmx_status cmx_voxel_filter(const float* point_cloud_xyz, int32_t num_points, float resolution,
                             int32_t device, float* filtered_xyz, int32_t* num_filtered);
+/* The same filter, returning WHICH points it kept (ascending indices into the input; room for
+ * num_points of them): what the overloads of sensor::VoxelFilter over timed points and range
+ * measurements (voxel_filter.cc:154-191) need to carry the points' payload along --
+ * LocalTrajectoryBuilder3D filters TimedPointCloudOriginData::RangeMeasurement lists
+ * (3d/local_trajectory_builder_3d.cc:158-159). */
+cmx_status cmx_voxel_filter_indices(const float* point_cloud_xyz, int32_t num_points,
+                                    float resolution, int32_t device, int32_t* kept_indices,
+                                    int32_t* num_filtered);
 /* sensor::AdaptiveVoxelFilter (voxel_filter.cc:30-75,193-198): range cut, then the search for
  * the voxel length that keeps at least min_num_points (proto::AdaptiveVoxelFilterOptions). */
 cmx_status cmx_adaptive_voxel_filter(const float* point_cloud_xyz, int32_t num_points,

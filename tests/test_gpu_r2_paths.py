@@ -597,6 +597,9 @@ def test_voxel_filter_keeps_the_reference_points(oracle, seed, n, res):
     used = oracle.voxel_filter_flags(cloud, res)
     got = filters.voxel_filter(cloud, res)
     np.testing.assert_array_equal(got, cloud[used])
+    # ... and WHICH points: what the overloads over timed points and range measurements select
+    # their payload with (the cloud has duplicated positions: the values alone could not tell)
+    np.testing.assert_array_equal(filters.voxel_filter_indices(cloud, res), np.nonzero(used)[0])
 
 
 def test_voxel_filter_reference_tests_on_device():
@@ -609,6 +612,7 @@ def test_voxel_filter_reference_tests_on_device():
     got = filters.voxel_filter(big, 0.01)
     assert len(got) == 2 and any((g == big[3]).all() for g in got)
     assert len(filters.voxel_filter(np.zeros((0, 3), np.float32), 0.1)) == 0
+    assert len(filters.voxel_filter_indices(np.zeros((0, 3), np.float32), 0.1)) == 0
 
 
 @pytest.mark.parametrize("seed,n,max_length,min_points,max_range", [
