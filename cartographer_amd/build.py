@@ -75,12 +75,13 @@ def build_tools(force=False):
     out_dir = os.path.join(root, "tools", "bin")
     os.makedirs(out_dir, exist_ok=True)
     built = []
-    for name in ("gather_ceiling", "row_gather_ceiling", os.path.join("probes", "lds_unaligned")):
+    for name in ("gather_ceiling", "row_gather_ceiling", os.path.join("probes", "lds_unaligned"),
+                 os.path.join("probes", "launch_rate")):
         src = os.path.join(root, "tools", name + ".hip")
         name = os.path.basename(name)
         out = os.path.join(out_dir, name)
         if os.path.exists(src) and (force or _newer(out, [src])):
-            subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", src, "-o", out])
+            subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-pthread", src, "-o", out])
         built.append(out)
     return built
 

@@ -629,11 +629,35 @@ ScoreCoarsePlanesDwordKernel(const Fast2DProblem* __restrict__ problems, int n,
 // The integer sums are order-free: results are bit-identical to the sorted variant
 // (ScoreCoarsePlanesDwordKernel, kept for CMX_FUSED=0 and for problems this kernel does not
 // take).
-// Dynamic LDS: pts[n_pad] u32 | misc[32] | cand_acc[acc_cap].
+// Dynamic LDS: pts[n_pad] u32 | misc[32] | cand_acc[acc_cap] | point words[waves][64].
 constexpr int kFusedMaxPoints = 4096;    // = kPointCache of the tree search
 
+// Points kFirst .. kFirst + 7 of a lane group (LDS words at a stride of 16 bytes from `base`): the
+// low halves into lo[0..7], the high halves into hi[0..7], zero-extended; returns when they landed.
+template <int kFirst>
+__device__ __forceinline__ void ReadHalves8(unsigned base, uint32_t* lo, uint32_t* hi) {
+  constexpr int o = 16 * kFirst;
+  asm volatile(
+      "ds_read_u16 %0, %16 offset:%17\n\tds_read_u16 %8, %16 offset:%18\n\t"
+      "ds_read_u16 %1, %16 offset:%19\n\tds_read_u16 %9, %16 offset:%20\n\t"
+      "ds_read_u16 %2, %16 offset:%21\n\tds_read_u16 %10, %16 offset:%22\n\t"
+      "ds_read_u16 %3, %16 offset:%23\n\tds_read_u16 %11, %16 offset:%24\n\t"
+      "ds_read_u16 %4, %16 offset:%25\n\tds_read_u16 %12, %16 offset:%26\n\t"
+      "ds_read_u16 %5, %16 offset:%27\n\tds_read_u16 %13, %16 offset:%28\n\t"
+      "ds_read_u16 %6, %16 offset:%29\n\tds_read_u16 %14, %16 offset:%30\n\t"
+      "ds_read_u16 %7, %16 offset:%31\n\tds_read_u16 %15, %16 offset:%32\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(lo[4]), "=&v"(lo[5]),
+        "=&v"(lo[6]), "=&v"(lo[7]), "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]),
+        "=&v"(hi[4]), "=&v"(hi[5]), "=&v"(hi[6]), "=&v"(hi[7])
+      : "v"(base), "n"(o), "n"(o + 2), "n"(o + 16), "n"(o + 18), "n"(o + 32), "n"(o + 34),
+        "n"(o + 48), "n"(o + 50), "n"(o + 64), "n"(o + 66), "n"(o + 80), "n"(o + 82),
+        "n"(o + 96), "n"(o + 98), "n"(o + 112), "n"(o + 114)
+      : "memory");
+}
+
 template <bool kTimeline>    // (true: the debug switch `timeline`; the shipped instantiation has no stamps)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 8)   // (eight wavefronts per SIMD: at most 64 VGPRs)
 PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __restrict__ xyz,
                      int n, ProblemState* __restrict__ states, int acc_cap,
                      int* __restrict__ counters_words, int num_counter_words) {
@@ -765,8 +789,9 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
     if (bad) atomicMax(&states[blockIdx.y].error, 1);
     const int count = dims.x * dims.y;
     const int BW = dims.x + P.plane_i - 1, BH = dims.y + P.plane_j - 1;
+    // (block + 1 = bx * pitch + by + 1 travels in 16 bits, see the scoring loop)
     const int ok = count <= P.coarse_stride && count <= kMaxCoarsePerScan && BW <= 255 &&
-                   BH <= 255 &&
+                   BH <= 255 && (BW - 1) * (dims.y + 2 * P.plane_j - 2) + BH <= 65535 &&
                    (dims.x + 2 * P.plane_i - 2) * (dims.y + 2 * P.plane_j - 2) <= acc_cap;
     misc[6] = ok;
     if (!ok) {
@@ -801,17 +826,20 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
   // chunk's 2.1 us, the gathers themselves land in 0.16 -- so the packed 16-bit pairs, whose
   // overflow guard cost a counter, a compare and a branch per step, are gone: byte k of the dword
   // is added with one (SDWA) instruction each).
-  int cur = -1;
+  uint32_t cur = 0;                         // lattice block + 1 of the running sums; 0: none yet
   uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
   const auto flush = [&]() {
-    if (a0) atomicAdd(&cand_acc[lane_const[0] - cur], static_cast<int>(a0));
-    if (a1) atomicAdd(&cand_acc[lane_const[1] - cur], static_cast<int>(a1));
-    if (a2) atomicAdd(&cand_acc[lane_const[2] - cur], static_cast<int>(a2));
-    if (a3) atomicAdd(&cand_acc[lane_const[3] - cur], static_cast<int>(a3));
+    const int at = static_cast<int>(cur) - 1;
+    if (a0) atomicAdd(&cand_acc[lane_const[0] - at], static_cast<int>(a0));
+    if (a1) atomicAdd(&cand_acc[lane_const[1] - at], static_cast<int>(a1));
+    if (a2) atomicAdd(&cand_acc[lane_const[2] - at], static_cast<int>(a2));
+    if (a3) atomicAdd(&cand_acc[lane_const[3] - at], static_cast<int>(a3));
     a0 = a1 = a2 = a3 = 0;
   };
   constexpr int kSteps = 16;                // all gathers of a 64-point chunk in flight
-  const int sentinel_plane = static_cast<int>(zero_plane * 64u);
+  uint32_t* const wave_words = reinterpret_cast<uint32_t*>(cand_acc + acc_cap) + 64 * wave;
+  const unsigned group_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
+      (__attribute__((address_space(3))) uint32_t*)(wave_words + group)));
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint8_t*>(P.planes), 0, static_cast<int>((zero_plane + 1) * 64), 0x00020000);
   for (int base_i = begin; base_i < end; base_i += 64) {
@@ -825,26 +853,36 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
     }
     // This lane's point of the chunk: byte offset of its phase plane and the constant
     // bx * pitch + by of its lattice block (-1: no candidate of this scan can reach it).
-    int my_plane = sentinel_plane, my_block = -1;
+    // ONE word per point: plane index (low half; the zero plane for a point no candidate
+    // reaches) and lattice block + 1 (high half; BW, BH <= 255 and the host keeps the pitch so
+    // that it fits).  The wavefront parks its 64 words in LDS and a lane group reads point
+    // 4 k + group of the chunk at the IMMEDIATE offset 16 k from its own base, as two 16-bit
+    // halves: the plane index needs one shift-or to become the gather's offset and the block goes
+    // straight into the compare.  (Before: two ds_bpermute and an address add per step; as ONE
+    // packed word a shift, a mask and a decrement more -- on the unit the loop is bound by.)
+    uint32_t my_word = zero_plane;
     if (base_i + lane < end) {
       const uint32_t packed = pts[base_i + lane];
       const int U = static_cast<short>(packed & 0xffffu) + bd.x + w - 1;
       const int V = static_cast<short>(packed >> 16) + bd.z + w - 1;
       const int bx = (U >> shift) + dims.x - 1, by = (V >> shift) + dims.y - 1;
-      if (bx >= 0 && bx < BW && by >= 0 && by < BH) {
-        my_plane = ((V & (w - 1)) * w + (U & (w - 1))) * 64;
-        my_block = bx * pitch + by;
-      }
+      if (bx >= 0 && bx < BW && by >= 0 && by < BH)
+        my_word = static_cast<uint32_t>((V & (w - 1)) * w + (U & (w - 1))) |
+                  (static_cast<uint32_t>(bx * pitch + by + 1) << 16);
     }
-    int block[kSteps];
+    wave_words[lane] = my_word;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t block[kSteps];                            // lattice block + 1; 0: a skipped point
+    uint32_t plane[kSteps];
     uint32_t q[kSteps];
+    // (inline assembly: written as 16-bit loads in C++, the compiler merges the two halves of a
+    // word into one ds_read_b32 and takes them apart again with a mask and a shift per step)
+    ReadHalves8<0>(group_base, plane, block);
+    ReadHalves8<8>(group_base, plane + 8, block + 8);
 #pragma unroll
-    for (int k = 0; k < kSteps; ++k) {
-      const int src = 4 * k + group;          // this lane group's point
-      const int plane_offset = __shfl(my_plane, src, 64);
-      block[k] = __shfl(my_block, src, 64);
-      q[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, plane_offset + 4 * sub, 0, 0);
-    }
+    for (int k = 0; k < kSteps; ++k)
+      q[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (plane[k] << 6) | (4 * sub), 0, 0);
+    __builtin_amdgcn_wave_barrier();                   // (the next chunk overwrites the words)
     if constexpr (kTimeline) {
       if (chunk_index == 0) {
         stamp(9);
@@ -854,8 +892,8 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
     }
 #pragma unroll
     for (int k = 0; k < kSteps; ++k) {
-      if (block[k] != cur) {                // per lane group; -1 = skipped point (adds zeros)
-        // (cur == -1: nothing has been added but bytes of the zero plane, every sum is 0 and
+      if (block[k] != cur) {                // per lane group; 0 = skipped point (adds zeros)
+        // (cur == 0: nothing has been added but bytes of the zero plane, every sum is 0 and
         // flush() issues no addition -- no second test per step)
         flush();
         cur = block[k];
@@ -869,7 +907,7 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
       if (chunk_index == 0) stamp(11);
     }
   }
-  if (cur >= 0) flush();
+  if (cur != 0) flush();
   stamp(4);      // wave 0 done gathering
   __syncthreads();
   stamp(5);      // all waves done
@@ -2279,8 +2317,10 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
       out->plane_acc_cells = std::max<long long>(out->plane_acc_cells, acc);
     // Fused front end: 64-byte planes, the scan + the accumulators within the 64 KB of
     // dynamic LDS a launch gets without opting in to more.
+    // (... and the lattice block of a point + 1 within 16 bits: the fused kernel's point words)
     P.use_fused = fused_enabled && P.use_planes && m.plane_stride() == 64 &&
-                  n <= kFusedMaxPoints && 4ll * n_pad + 4 * (32 + acc) <= 64 * 1024;
+                  n <= kFusedMaxPoints && 4ll * n_pad + 4 * (32 + acc) + 1024 <= 64 * 1024 &&
+                  (ax + m.plane_i() - 2) * (ay + 2 * m.plane_j() - 2) + (ay + m.plane_j() - 1) <= 65535;
     if (P.use_fused) {
       any_fused = true;
       fused_acc = std::max(fused_acc, acc);
@@ -2391,7 +2431,8 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     // ~2300 rotations are all resident at once and the launch takes one block's latency;
     // batches run several rounds anyway and use full 256-thread blocks.
     const long long blocks = static_cast<long long>(out->max_scans) * num;
-    const size_t lds = 4 * static_cast<size_t>(n_pad) + 4 * static_cast<size_t>(32 + fused_acc);
+    // pts | misc | candidate sums | 64 point words per wavefront (at most four)
+    const size_t lds = 4 * static_cast<size_t>(n_pad) + 4 * static_cast<size_t>(32 + fused_acc) + 4 * 256;
     int threads = 256;
     for (int t : {256, 192, 128}) {
       if (blocks <= FusedResidentBlocks(ws.device, t, lds)) { threads = t; break; }
