@@ -235,7 +235,12 @@ inline void RecordEvent(hipEvent_t ev, hipStream_t stream) {
 inline float ElapsedMs(hipEvent_t from, hipEvent_t to) {
   if (!TimingEnabled()) return 0.f;
   float ms = 0.f;
-  CMX_HIP(hipEventElapsedTime(&ms, from, to));
+  // (the switch is process-wide and may be turned on while a call is in flight: that call's
+  // events were never recorded -- it reports no timing, it does not fail)
+  if (hipEventElapsedTime(&ms, from, to) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0.f;
+  }
   return ms;
 }
 

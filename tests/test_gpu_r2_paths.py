@@ -83,6 +83,33 @@ def test_timing_brackets_only_on_request(sm, c2, debug):
         assert quiet[key] == loud[key] > 0
 
 
+def test_timing_switch_flipped_while_calls_are_in_flight(sm, c2, debug):
+    """The switch is process-wide and unsynchronised: flipped by one thread while another is inside
+    a match, that call finds events that were never recorded.  It reports no timing for itself and
+    returns its result -- it does not fail."""
+    import threading
+    cells, lim, _, _, scan = c2
+    gm = sm.FastCorrelativeScanMatcher2D(_grid(sm, cells, lim), 7)
+    want = gm.match_full_submap(scan, 0.55)
+    stop = threading.Event()
+
+    def flip():
+        k = 0
+        while not stop.is_set():
+            k += 1
+            debug(timing=k & 1)
+
+    flipper = threading.Thread(target=flip)
+    flipper.start()
+    try:
+        for _ in range(300):
+            assert gm.match_full_submap(scan, 0.55) == want
+    finally:
+        stop.set()
+        flipper.join()
+        debug(timing=0)
+
+
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("depth,n", [(7, 1000), (5, 333), (3, 64), (6, 1)])
 def test_fast2d_match_both_front_ends(sm, oracle, c2, debug, fused, depth, n):
