@@ -84,11 +84,15 @@ def parse_args():
                          "constraint_builder_2d.cc:97-111); the C ABI is re-entrant: every call "
                          "leases its own stream + scratch.  0 = auto: 8 for c2 on one GPU (a single "
                          "search is a latency chain that fills a fraction of the chip), else 1")
-    ap.add_argument("--scans", type=int, default=1,
+    ap.add_argument("--scans", type=int, default=8,
                     help="c2 / c3: distinct scans (poses of the same world) the passes of a step "
-                         "cycle through; 1 = the one scan of BASELINE config[1] (rounds 1 and 2 "
-                         "timed the same search): other poses are 10x harder searches and move the "
-                         "number (8 scans, 8 threads: 3.8e9 candidates/s against 8.3e9)")
+                         "cycle through.  Default 8 since round 6: the one scan rounds 1 - 5 timed "
+                         "(--scans 1, still measured as the `c2_easy` leg) is an easy search -- its "
+                         "dive finds a tight bound at once, 3 000 nodes are expanded -- while other "
+                         "poses of the same world expand 17 000 - 93 000")
+    ap.add_argument("--c1-distinct", type=int, default=0,
+                    help="c1: distinct (grid, scan, pose) triples of a batch (0 = one per match up "
+                         "to 128 matches, 256 for larger batches)")
     ap.add_argument("--passes-per-step", type=int, default=0,
                     help="passes of the hot path that make one step (a step is one pass over a "
                          "BATCH of searches).  0 = auto: calibrated during warmup so that a step "
@@ -140,13 +144,14 @@ def pmc_traffic_bytes(pmc_dir, tag, kernel, config=""):
 # --------------------------------------------------------------------------------------
 # CPU baseline (C2): the reference's own source where oracle/_ref is built
 # --------------------------------------------------------------------------------------
-def cpu_baseline_reference(cells, lim, depth, scan, min_score, seconds):
+def cpu_baseline_reference(cells, lim, depth, scans, min_score, seconds):
     """The reference's OWN fast_correlative_scan_matcher_2d.cc (oracle/_ref, built in place from
     /root/reference by __graft_entry__.build(); the prebuilt .so travels to the GPU box) timed
     on this box's host cores: one MatchFullSubmap per thread, like the reference's thread pool
-    runs them (const methods, concurrent calls on one matcher).  Candidates are counted with the
-    oracle port, whose search is bit-identical (tests/test_reference_ref.py).  Returns None
-    when oracle/_ref is not available."""
+    runs them (const methods, concurrent calls on one matcher), call i with scan i mod len(scans)
+    -- the scans the device's passes cycle through.  Candidates are counted with the oracle port,
+    whose search is bit-identical (tests/test_reference_ref.py).  Returns None when oracle/_ref
+    is not available."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import pyoracle as orc
     if orc.ref_lib() is None:
@@ -154,45 +159,50 @@ def cpu_baseline_reference(cells, lim, depth, scan, min_score, seconds):
     cores = _cores()
     args = (cells, lim["resolution"], lim["max_x"], lim["max_y"], depth)
     port = orc.FastCorrelativeScanMatcher2D(*args)
-    counted = port.match_full_submap(scan, min_score)
     matcher = orc.ReferenceFastCorrelativeScanMatcher2D(*args)
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        counted = list(pool.map(lambda sc: port.match_full_submap(sc, min_score), scans))
     t0 = time.perf_counter()
-    one = matcher.match_full_submap(scan, min_score)
+    one = matcher.match_full_submap(scans[0], min_score)
     t_one = time.perf_counter() - t0
-    assert one["found"] == counted["found"]
+    assert one["found"] == counted[0]["found"]
     if one["found"]:
-        assert np.float32(one["score"]) == np.float32(counted["score"])
-    per_match = counted["candidates_scored"]
+        assert np.float32(one["score"]) == np.float32(counted[0]["score"])
+    per_match = [c["candidates_scored"] for c in counted]
     # Bounded sample: rounds of `cores` concurrent matches (ctypes releases the GIL) until
     # `seconds` have elapsed.
     t0 = time.perf_counter()
     matches = 0
+    candidates = 0
     with ThreadPoolExecutor(max_workers=cores) as pool:
         while True:
-            list(pool.map(lambda _: matcher.match_full_submap(scan, min_score), range(cores)))
+            ks = [(matches + j) % len(scans) for j in range(cores)]
+            list(pool.map(lambda k: matcher.match_full_submap(scans[k], min_score), ks))
             matches += cores
+            candidates += sum(per_match[k] for k in ks)
             dt = time.perf_counter() - t0
             if dt >= seconds or matches >= 64 * cores:
                 break
     return {
-        "value": matches * per_match / dt, "unit": "candidates/s", "cores": cores,
+        "value": candidates / dt, "unit": "candidates/s", "cores": cores,
         "kind": "reference",
-        "sample": f"{matches} MatchFullSubmap calls of the bench workload by the reference's own "
+        "sample": f"{matches} MatchFullSubmap calls of the bench workload ({len(scans)} scans in "
+                  f"turn) by the reference's own "
                   f"fast_correlative_scan_matcher_2d.cc (oracle/_ref: compiled in place with the reference's -O3 -DNDEBUG, "
-                  f"stand-in Eigen value types; {per_match} candidates each -- the reference's "
+                  f"stand-in Eigen value types; {min(per_match)} - {max(per_match)} candidates each -- the reference's "
                   f"depth-first search scores more candidates per match than the device schedule, "
-                  f"each side counts its own -- {t_one * 1e3:.0f} ms single-thread), {cores} threads, {dt:.1f} s",
-        "single_thread_candidates_per_s": per_match / t_one,
+                  f"each side counts its own -- {t_one * 1e3:.0f} ms single-thread for scan 0), {cores} threads, {dt:.1f} s",
+        "single_thread_candidates_per_s": per_match[0] / t_one,
         "matches_per_s": matches / dt,
     }
 
 
-def cpu_baseline(cells, lim, depth, scan, min_score, seconds):
+def cpu_baseline(cells, lim, depth, scans, min_score, seconds):
     """CPU baseline on this box's host cores: the reference's own code when oracle/_ref is
     available, else the oracle (CPU restatement, "port"): one MatchFullSubmap per thread, the
-    reference's thread-pool fan-out."""
+    reference's thread-pool fan-out, over the scans the device's passes cycle through."""
     try:
-        ref = cpu_baseline_reference(cells, lim, depth, scan, min_score, seconds)
+        ref = cpu_baseline_reference(cells, lim, depth, scans, min_score, seconds)
         if ref is not None:
             return ref
     except Exception as e:   # never let the baseline leg break the bench line
@@ -202,13 +212,13 @@ def cpu_baseline(cells, lim, depth, scan, min_score, seconds):
     matcher = orc.FastCorrelativeScanMatcher2D(cells, lim["resolution"], lim["max_x"],
                                                lim["max_y"], depth)
     t0 = time.perf_counter()
-    one = matcher.match_full_submap(scan, min_score)
+    one = matcher.match_full_submap(scans[0], min_score)
     t_one = time.perf_counter() - t0
     t0 = time.perf_counter()
     total = 0
     rounds = 0
     while True:
-        r = orc.fast2d_match_batch([matcher] * cores, scan, min_score, cores)
+        r = orc.fast2d_match_batch([matcher] * cores, scans[rounds % len(scans)], min_score, cores)
         total += r["candidates_scored"]
         rounds += 1
         dt = time.perf_counter() - t0
@@ -216,8 +226,8 @@ def cpu_baseline(cells, lim, depth, scan, min_score, seconds):
             break
     return {
         "value": total / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
-        "sample": f"{rounds * cores} MatchFullSubmap calls of the bench workload "
-                  f"({one['candidates_scored']} candidates each, {t_one * 1e3:.0f} ms "
+        "sample": f"{rounds * cores} MatchFullSubmap calls of the bench workload ({len(scans)} scans "
+                  f"in turn; {one['candidates_scored']} candidates for scan 0, {t_one * 1e3:.0f} ms "
                   f"single-thread), {cores} threads, {dt:.1f} s",
         "single_thread_candidates_per_s": one["candidates_scored"] / t_one,
         "matches_per_s": rounds * cores / dt,
@@ -374,7 +384,7 @@ def parity_gate(workload, result=None):
     if check is None:
         return {"vs": None, "checked": 0}
     if result is None:
-        result = workload.search()
+        result = workload.search(0)
     return check(result)
 
 
@@ -434,31 +444,41 @@ class Fast2DWorkload:
         self.positive = positive
         self.gathered = None
         self.best = None
+        self._next = 0
 
-    def search(self, k=0):
+    def search(self, k=None):
+        """Pass k searches with scan k mod `--scans`; without k the scans are taken in turn."""
+        if k is None:
+            k = self._next
+            self._next += 1
         return self.sm.match_full_submap_batch(self.matchers, self.clouds[k % len(self.clouds)],
                                                self.args.min_score)
 
     def parity(self, result):
-        """The first submaps of this rank's block (at most four: 0.4 s of one host core each)
-        searched by the reference with the bench scan; found / score / pose against the device's."""
+        """EVERY scan the passes cycle through against the first submaps of this rank's block (at
+        most `--parity-submaps`; 0.2 - 0.6 s of one host core per search), searched by the
+        reference; found / score / pose against the device's result of the same (scan, submap)."""
         from concurrent.futures import ThreadPoolExecutor
         from oracle import pyoracle as orc
         kind = _reference_kind()
         cls = (orc.ReferenceFastCorrelativeScanMatcher2D if kind == "reference"
                else orc.FastCorrelativeScanMatcher2D)
         a = self.args
+        pairs = [(k, i) for k in range(len(self.host_scans)) for i in range(len(self.host_submaps))]
 
-        def one(host):
-            cells, lim = host
+        def one(pair):
+            k, i = pair
+            cells, lim = self.host_submaps[i]
             return cls(cells, lim["resolution"], lim["max_x"], lim["max_y"],
-                       a.depth).match_full_submap(self.scan, a.min_score)
-        with ThreadPoolExecutor(min(len(self.host_submaps), _cores())) as pool:
-            refs = list(pool.map(one, self.host_submaps))
+                       a.depth).match_full_submap(self.host_scans[k], a.min_score)
+        with ThreadPoolExecutor(min(len(pairs), _cores())) as pool:
+            refs = list(pool.map(one, pairs))
         self.reference_result = refs[0]
-        found, scores, poses = result[0], result[1], result[2]
-        return parity_record(kind, [(found[i], scores[i], poses[i], r["found"], r["score"],
-                                     r["pose"]) for i, r in enumerate(refs)])
+        device = {0: result}        # (the gate's own search is pass 0: scan 0)
+        for k in range(1, len(self.host_scans)):
+            device[k] = Fast2DWorkload.search(self, k)
+        return parity_record(kind, [(device[k][0][i], device[k][1][i], device[k][2][i], r["found"],
+                                     r["score"], r["pose"]) for (k, i), r in zip(pairs, refs)])
 
     def exchange(self, found, scores, poses, torch_device):
         """What crosses xGMI per step: every submap's optional constraint to every rank (the
@@ -546,13 +566,14 @@ class Fast2DWorkload:
 
 
 class Fast2DConcurrentWorkload(Fast2DWorkload):
-    """C2 as the headline issues it -- `threads` host threads, one search each per step -- but
-    with `threads` DIFFERENT scans (poses of the same world) instead of one scan repeated: the
-    headline's single scan happens to be an easy one (its dive finds a tight bound at once)."""
+    """C2 from `threads` host threads, one search each per step, over `scans` different scans
+    (poses of the same world).  scans = 1 is the `c2_easy` leg: the ONE scan rounds 1 - 5 timed
+    as the headline, which happens to be an easy search (its dive finds a tight bound at once);
+    the headline itself cycles through `--scans` = 8 since round 6."""
 
-    def __init__(self, args, device, threads=8):
+    def __init__(self, args, device, threads=8, scans=None):
         sub = argparse.Namespace(**vars(args))
-        sub.scans, sub.submaps = threads, 0
+        sub.scans, sub.submaps = scans or threads, 0
         super().__init__(sub, device, 0, 1, sharded=False)
         from concurrent.futures import ThreadPoolExecutor
         self.threads = threads
@@ -586,9 +607,27 @@ class Fast2DConcurrentWorkload(Fast2DWorkload):
 
     def describe(self, stats, found):
         out = super().describe(stats, found)
-        out["workload"] = (f"C2 with {self.threads} different scans: one search per scan per step, "
+        out["workload"] = (f"C2 over {len(self.clouds)} scan(s): {self.threads} searches per step, "
                            f"issued from {self.threads} host threads; " + out["workload"])
         return out
+
+
+def c1_scan(world, pose, beams, max_range, seed):
+    """A scan of EXACTLY `beams` points within `max_range` (C1: 1000 beams, r_max < 5 m, hence
+    the 27 rotations x 13 x 13 = 4563 candidates BASELINE.md prices): the lidar is given as many
+    more beams per revolution as its returns beyond max_range take away, and `beams` of the
+    returns, evenly spread in angular order, are kept.  (Rounds 1 - 5 asked for `beams` beams and
+    matched the ~850 that came back.)"""
+    asked = beams
+    for _ in range(8):
+        pts = world.scan(pose, asked, max_range, 0.01, seed)
+        if len(pts) >= beams:
+            break
+        asked = int(math.ceil(asked * beams / max(len(pts), 1) * 1.02)) + 8
+    if len(pts) <= beams:
+        return pts
+    keep = np.unique(np.floor(np.arange(beams) * (len(pts) / beams)).astype(np.int64))
+    return np.ascontiguousarray(pts[keep])
 
 
 class Rt2DWorkload:
@@ -600,22 +639,28 @@ class Rt2DWorkload:
     (2d/local_trajectory_builder_2d.cc:78-80, :289) -- the match then never meets a cached
     image of its grid; the insertions are timed apart and not part of the step."""
 
-    def __init__(self, args, device, matches=None, grid=200, dirty=False):
+    def __init__(self, args, device, matches=None, grid=200, dirty=False, distinct=None):
         from cartographer_amd import grid_2d, scan_matching as sm, synth
         self.sm = sm
         self.m = sm.RealTimeCorrelativeScanMatcher2D(0.3, math.radians(7.0), 0.1, 0.1,
                                                      device=device)
         batch = matches or args.matches
+        # DISTINCT (grid, scan, initial pose) triples: one world per match up to `distinct`
+        # (default: every match of a batch up to 128 its own, 256 for larger batches -- 256 grids
+        # with their derived images are ~45 MB, far beyond what the L2s hold), reused round-robin
+        # beyond that.  Rounds 2 - 5 cycled through 8 triples (every grid image L2-hot).
+        distinct = distinct or getattr(args, "c1_distinct", 0) or (batch if batch <= 128 else 256)
+        distinct = min(batch, distinct)
         grids, inits, scans = [], [], []
         self.host_cells, self.host_lims = [], []
         self.grid_side, self.dirty, self.insert_s = grid, dirty, 0.0
         self.dirty_inputs = []
-        for k in range(min(batch, 8)):          # 8 distinct worlds, reused round-robin
+        for k in range(distinct):
             cells, lim, world = synth.make_submap(42 + k, grid, grid, 0.05, 30, 1000, 5.0, 0.01)
             pose = world.free_pose(1234, 0.5)
             grids.append(grid_2d.ProbabilityGridOnDevice(0.05, (lim["max_x"], lim["max_y"]), grid,
                                                          grid, cells=cells))
-            scans.append(world.scan(pose, args.beams, 5.0, 0.01, 7))
+            scans.append(c1_scan(world, pose, args.beams, 5.0, 7))
             inits.append(sm.Rigid2d(pose[0] + 0.12, pose[1] - 0.08, pose[2] + math.radians(3.0)))
             self.host_cells.append(cells)
             self.host_lims.append(lim)
@@ -625,6 +670,7 @@ class Rt2DWorkload:
             pts[:, 1] = pose[1] + s_ * scans[-1][:8, 0] + c * scans[-1][:8, 1]
             self.dirty_inputs.append((np.asarray(pose[:2], np.float32), pts))
         self.distinct_grids = grids
+        self.distinct = distinct
         self.candidates_per_match = 27 * 13 * 13      # re-read from the first search's stats
         self.G = [grids[i % len(grids)] for i in range(batch)]
         self.I = [inits[i % len(grids)] for i in range(batch)]
@@ -648,8 +694,9 @@ class Rt2DWorkload:
         return np.ones(len(scores), np.int32), scores, poses, stats
 
     def parity(self, result):
-        """Every distinct (grid, scan, initial pose) of the batch -- at most eight -- matched by
-        the reference's real_time_correlative_scan_matcher_2d.cc (a few ms each)."""
+        """EVERY distinct (grid, scan, initial pose) of the batch matched by the reference's
+        real_time_correlative_scan_matcher_2d.cc (a few ms each, on the host's threads)."""
+        from concurrent.futures import ThreadPoolExecutor
         from oracle import pyoracle as orc
         kind = _reference_kind()
         fn = orc.ref_rt2d_match if kind == "reference" else orc.rt2d_match
@@ -658,19 +705,23 @@ class Rt2DWorkload:
         else:
             grids = list(zip(self.host_cells, self.host_lims))
         scores, poses = result[1], result[2]
-        pairs = []
-        for i in range(min(self.matches_per_step, len(grids))):
+        count = min(self.matches_per_step, len(grids))
+
+        def one(i):
             cells, lim = grids[i]
             init = self.I[i]
-            r = fn(cells, lim["resolution"], lim["max_x"], lim["max_y"],
-                   [init.x, init.y, init.theta], self.S[i], 0.3, math.radians(7.0), 0.1, 0.1)
-            pairs.append((True, scores[i], np.asarray(poses[i], np.float64).reshape(-1)[:3], True,
-                          r["score"], r["pose"]))
+            return fn(cells, lim["resolution"], lim["max_x"], lim["max_y"],
+                      [init.x, init.y, init.theta], self.S[i], 0.3, math.radians(7.0), 0.1, 0.1)
+        with ThreadPoolExecutor(_cores()) as pool:
+            refs = list(pool.map(one, range(count)))
+        pairs = [(True, scores[i], np.asarray(poses[i], np.float64).reshape(-1)[:3], True,
+                  r["score"], r["pose"]) for i, r in enumerate(refs)]
         return parity_record(kind, pairs)
 
     def describe(self, stats, found):
         out = {"workload": f"C1: 2D RealTimeCorrelativeScanMatcher, {self.matches_per_step} "
-                           f"independent matches per step, {self.n_points}-point scans vs "
+                           f"independent matches per step ({self.distinct} distinct grid / scan / pose "
+                           f"triples), {self.n_points}-point scans vs "
                            f"{self.grid_side}x{self.grid_side} resident probability grids"
                            f"{' (a scan inserted into every grid before every step)' if self.dirty else ''}"
                            f", window 0.3 m / 7 deg "
@@ -755,7 +806,7 @@ class Rt2DTsdfWorkload:
                                                      device=device)
         cells, lim, world = synth.make_submap(42, 200, 200, 0.05, 30, 1000, 5.0, 0.01)
         pose = world.free_pose(1234, 0.5)
-        self.scan = world.scan(pose, args.beams, 5.0, 0.01, 7)
+        self.scan = c1_scan(world, pose, args.beams, 5.0, 7)
         self.init = sm.Rigid2d(pose[0] + 0.12, pose[1] - 0.08, pose[2] + math.radians(3.0))
         # walls = cells whose correspondence cost lies in the lower half; distance to the nearest
         value = cells & 32767
@@ -1311,27 +1362,16 @@ def other_configs(args, device, sync, pmc):
     run("c1_batch128_dirty", lambda: Rt2DWorkload(args, device, matches=128, dirty=True), 50, 5)
     run("c1_batch128_grid400", lambda: Rt2DWorkload(args, device, matches=128, grid=400), 50, 5)
     run("c1_batch1024", lambda: Rt2DWorkload(args, device, matches=1024), 30, 5)
+    run("c1_batch1024_dirty", lambda: Rt2DWorkload(args, device, matches=1024, dirty=True), 15, 3)
     run("c1_batch128_8_threads", lambda: Rt2DPipelinedWorkload(args, device, 128, 8, 4), 25, 5)
     run("c1_tsdf", lambda: Rt2DTsdfWorkload(args, device), 30, 5)
-    run("c2_8_scans_8_threads", lambda: Fast2DConcurrentWorkload(args, device, 8), 60, 10)
+    run("c2_easy", lambda: Fast2DConcurrentWorkload(args, device, 8, scans=1), 100, 10)
     sub = argparse.Namespace(**vars(args))
     sub.submaps = 16
     run("c3_share_16_submaps", lambda: Fast2DWorkload(sub, device, 0, 1, sharded=True), 5, 2)
     run("c4", lambda: Rt3DWorkload(args, device), 3, 1, cpu.get("c4"))
     run("c5_single", lambda: Fast3DWorkload(args, device, pairs=1), 10, 2, cpu.get("c5_single"))
     run("c5_share_32_submaps", lambda: Fast3DWorkload(args, device, pairs=32), 4, 2)
-    # the same share with every node of a family expanded on its own (round 2's expansion): a
-    # same-run, same-box A/B of the family expansion (boxes differ by tens of percent here)
-    from cartographer_amd import _lib
-    try:
-        _lib.debug_set(fast3d_no_families=1)
-        def nofam():
-            w = Fast3DWorkload(args, device, pairs=32)
-            w.no_pmc = True
-            return w
-        run("c5_share_32_submaps_no_families", nofam, 4, 2)
-    finally:
-        _lib.debug_set(fast3d_no_families=0)
     for name, cpu_leg, w in pending_cpu:
         try:
             out[name]["cpu_baseline"] = cpu_leg(w)
@@ -1675,11 +1715,10 @@ def main():
                          "c1_batch128_dirty": "c1b128_dirty", "c1_batch128_grid400": "c1b128_g400",
                          "c1_batch1024": "c1b1024",
                          "c1_batch128_8_threads": "c1b128t8", "c1_tsdf": "c1_tsdf",
-                         "c2_8_scans_8_threads": "c2_8scans",
+                         "c2_easy": "c2_easy", "c1_batch1024_dirty": "c1b1024_dirty",
                          "c3_share_16_submaps": "c3s16",
                          "c4": "c4", "c5_single": "c5_single",
-                         "c5_share_32_submaps": "c5s32",
-                         "c5_share_32_submaps_no_families": "c5s32_nofam"}.get(key, key)
+                         "c5_share_32_submaps": "c5s32"}.get(key, key)
                 if "error" in e:
                     config[f"{short}_error"] = e["error"][:80]
                     summary[short] = {"error": e["error"][:60]}
@@ -1708,7 +1747,8 @@ def main():
         # threads right before a host-bound GPU leg distort it).  JSON key order is irrelevant.
         if not args.no_cpu_baseline and world_size == 1 and name in ("c2", "c3"):   # rank 0, N = 1
             out["cpu_baseline"] = cpu_baseline(workload.cells0, workload.lim0, args.depth,
-                                               workload.scan, args.min_score, args.cpu_seconds)
+                                               workload.host_scans, args.min_score,
+                                               args.cpu_seconds)
         elif not args.no_cpu_baseline and world_size == 1 and not use_dist:
             leg = {"c1": cpu_baseline_c1, "c4": cpu_baseline_c4, "c5": cpu_baseline_c5}[name]
             try:
