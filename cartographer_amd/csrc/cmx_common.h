@@ -95,6 +95,10 @@ cmx_status Guard(F&& body) {
   X(fast2d_levels_per_stage) /* levels per depth-first stage */                                   \
   X(fast2d_wave_levels)   /* k > 0: k - 1 levels of wave-per-node expansion */                     \
   X(fast2d_xcd_affinity)  /* 1: nodes of a problem on any XCD, 2: on one */                        \
+  X(fast2d_queue)         /* 2: tree search by the level-synchronous launches (no work queue) */   \
+  X(fast2d_queue_blocks)  /* workgroups of the work-queue tree search (0: default) */              \
+  X(fast2d_queue_capacity) /* nodes per sub-queue (tests: forces the overflow path) */             \
+  X(fast2d_queue_lost)    /* lost races after which a wavefront stops looking for work (0: 3) */   \
   X(fast3d_byte_loads)    /* 1: every child cell with its own byte load */                         \
   X(fast3d_affinity)      /* 1: nodes of a problem on any XCD, 2: on one */                        \
   X(fast3d_no_families)   /* 1: one node per block in the 3D expansion */                          \
@@ -209,6 +213,24 @@ void SmallCopyAsync(void* dst, const void* src, size_t bytes, bool to_device, hi
 // otherwise skip the opt-in on the second device).
 void OptInLds(const void* fn, int device, size_t bytes);
 
+// Scratch whose words carry the tag ("epoch") of the call that wrote them -- work queues whose
+// slots are polled by tag, so that nothing has to be cleared per call: zeroed when it is
+// (re)allocated, the epoch counts the calls that have used it (never 0).
+struct TaggedBuffer {
+  DeviceBuffer buffer;
+  unsigned epoch = 0;
+  void* Acquire(size_t bytes, hipStream_t stream, unsigned* epoch_out) {
+    const bool grew = bytes > buffer.capacity();
+    void* p = buffer.Reserve(bytes);
+    if (grew || epoch == 0xffffffffu) {
+      CMX_HIP(hipMemsetAsync(p, 0, buffer.capacity(), stream));
+      epoch = 0;
+    }
+    *epoch_out = ++epoch;
+    return p;
+  }
+};
+
 // Everything one in-flight call needs; handed out by a per-device pool so
 // concurrent callers never share scratch.
 struct Workspace {
@@ -220,6 +242,7 @@ struct Workspace {
   hipEvent_t ev_x0 = nullptr, ev_x1 = nullptr;  // branch-and-bound expansion bracket
   static constexpr int kNumBuffers = 32;
   DeviceBuffer dev[kNumBuffers];
+  TaggedBuffer tagged[2];
   PinnedBuffer pinned[4];
   ~Workspace();
 };

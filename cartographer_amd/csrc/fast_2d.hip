@@ -141,8 +141,11 @@ PrepScansKernel(const Fast2DProblem* __restrict__ problems, const float* __restr
                 int num_counter_words) {
   // First kernel of a call: it also clears the list counters of the search (saves a
   // memset and its launch gap).
-  if (blockIdx.x == 0 && blockIdx.y == 0 && counters_words)
-    for (int i = threadIdx.x; i < num_counter_words; i += blockDim.x) counters_words[i] = 0;
+  // (every workgroup clears a slice: the counters with the work queue's control words are 376 KB)
+  if (counters_words)
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+         i < num_counter_words; i += gridDim.x * gridDim.y * blockDim.x)
+      counters_words[i] = 0;
   const Fast2DProblem& P = problems[blockIdx.y];
   const int s = blockIdx.x;
   if (s >= P.num_scans || P.use_fused) return;
@@ -663,8 +666,11 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
                      int* __restrict__ counters_words, int num_counter_words) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fused_smem[];
   // First kernel of a fully fused batch: it also clears the list counters of the search.
-  if (blockIdx.x == 0 && blockIdx.y == 0 && counters_words)
-    for (int i = threadIdx.x; i < num_counter_words; i += blockDim.x) counters_words[i] = 0;
+  // (every workgroup clears a slice: the counters with the work queue's control words are 376 KB)
+  if (counters_words)
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+         i < num_counter_words; i += gridDim.x * gridDim.y * blockDim.x)
+      counters_words[i] = 0;
   const Fast2DProblem& P = problems[blockIdx.y];
   // Blocks b, b + 256, b + 512, ... tend to share a CU (b % 8 picks the XCD, round-robin
   // within it): give them ADJACENT rotations.  Neighbouring rotations move a point by less
@@ -960,13 +966,26 @@ constexpr int kMaxStages = kMaxDepth + 2;   // one frontier counter array per se
 // queue behind each other in L2 (64 adjacent counters = 2 lines took every list reservation of
 // a batch through two queues).
 constexpr int kCountStride = 32;
+// The work queue of TreeQueueKernel (below): kQueues sub-queues, control words one 128-byte line
+// per sub-queue (a word takes ~90 atomics per microsecond, and atomics on one line queue behind
+// each other).
+constexpr int kQueues = 2048;
+struct alignas(8) QueueCtl {
+  int head;           // nodes taken (CAS)
+  int reserved;       // slots reserved by producers (every one of them gets published)
+  int pad[30];        // (a pop reads the pair with ONE 8-byte load: both only grow, so halves of
+};                    // different ages are harmless -- the CAS on `head` decides)
 struct Counters {           // device, zeroed per call
   int frontier[kMaxStages][kSubLists * kCountStride];
   int leaves[kSubLists * kCountStride];
   int frontier_overflow;
   int leaf_overflow;
-  unsigned wave_gathers;      // 64-lane quad gathers issued by ExpandWaveKernel (statistics)
-  int pad;
+  unsigned wave_gathers;      // 64-lane quad gathers issued by the wave-per-node expansion (statistics)
+  int blocks_done;            // TreeQueueKernel: workgroups that have run out of work
+  int pad[28];
+  unsigned gathers_shard[16 * kCountStride];   // TreeQueueKernel's share of wave_gathers, by workgroup
+  unsigned queue_stats[16 * kCountStride];     // [shard][8] trace counters of the queue (CountersSummary)
+  QueueCtl queue[kQueues];
 };
 
 // What the host needs of the counters, written next to the results by the last kernel of a
@@ -978,6 +997,7 @@ struct CountersSummary {
   int leaf_overflow;
   unsigned wave_gathers;
   int pad;
+  unsigned queue_stats[8];    // trace: pops, lost races, slot re-reads, pushed nodes, list nodes, chains, -, -
 };
 
 struct NodeList {
@@ -1787,30 +1807,76 @@ struct SelectState {         // per problem, device
   unsigned long long key;    // (coarse_index << 32) | path, minimised
 };
 
+// A word another workgroup of the SAME launch may have written (atomics, agent-scope stores):
+// read past this CU's L1 (global_load ... sc1).
+template <typename T>
+__device__ __forceinline__ T LoadAgent(const T* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// kSameLaunch: the leaves, counters and problem states were written by other workgroups of the
+// launch this runs in (TreeQueueKernel's last workgroup), not by an earlier launch: every word of
+// them is read with agent-scope loads (the producers stored / updated them with agent-scope
+// stores and atomics and drained their stores before they arrived on `blocks_done`).
+template <bool kSameLaunch>
 __device__ __forceinline__ void
 SelectBestBody(NodeList leaves, const ProblemState* __restrict__ states,
                SelectState* __restrict__ sel, BestLeaf* __restrict__ best, int num_problems,
                ProblemState* __restrict__ states_out, const Counters* __restrict__ counters,
                CountersSummary* __restrict__ summary) {
-  for (int p = threadIdx.x; p < num_problems; p += blockDim.x) states_out[p] = states[p];
-  if (threadIdx.x < kSubLists) summary->leaves[threadIdx.x] = counters->leaves[threadIdx.x * kCountStride];
+  if constexpr (kSameLaunch) {
+    static_assert(sizeof(ProblemState) % sizeof(unsigned) == 0, "copied by words");
+    constexpr int kWords = sizeof(ProblemState) / sizeof(unsigned);
+    const unsigned* from = reinterpret_cast<const unsigned*>(states);
+    unsigned* to = reinterpret_cast<unsigned*>(states_out);
+    for (int i = threadIdx.x; i < num_problems * kWords; i += blockDim.x) to[i] = LoadAgent(&from[i]);
+  } else {
+    for (int p = threadIdx.x; p < num_problems; p += blockDim.x) states_out[p] = states[p];
+  }
+  const auto word = [](const auto* p) {
+    if constexpr (kSameLaunch) return LoadAgent(p);
+    else return *p;
+  };
+  if (threadIdx.x < kSubLists) summary->leaves[threadIdx.x] = word(&counters->leaves[threadIdx.x * kCountStride]);
   if (threadIdx.x >= 64 && threadIdx.x < 64 + kMaxStages) {
     const int st = threadIdx.x - 64;
     int total = 0;
-    for (int k = 0; k < kSubLists; ++k) total += counters->frontier[st][k * kCountStride];
+    for (int k = 0; k < kSubLists; ++k) total += word(&counters->frontier[st][k * kCountStride]);
     summary->frontier_total[st] = total;
   }
   if (threadIdx.x == 128) {
-    summary->frontier_overflow = counters->frontier_overflow;
-    summary->leaf_overflow = counters->leaf_overflow;
-    summary->wave_gathers = counters->wave_gathers;
+    summary->frontier_overflow = word(&counters->frontier_overflow);
+    summary->leaf_overflow = word(&counters->leaf_overflow);
+    unsigned gathers = word(&counters->wave_gathers);
+    for (int k = 0; k < 16; ++k) gathers += word(&counters->gathers_shard[k * kCountStride]);
+    summary->wave_gathers = gathers;
   }
-  const int max_count = ListMaxCount(leaves);
+  if (threadIdx.x >= 192 && threadIdx.x < 200) {
+    unsigned total = 0;
+    for (int k = 0; k < 16; ++k) total += word(&counters->queue_stats[k * kCountStride + (threadIdx.x - 192)]);
+    summary->queue_stats[threadIdx.x - 192] = total;
+  }
+  __syncthreads();      // (states_out is complete: the selection below reads it, not `states`)
+  states = states_out;
+  int max_count;
+  {
+    const int lane = threadIdx.x & 63;
+    max_count = WaveMax(min(word(&leaves.counts[lane * kCountStride]), leaves.sub_capacity));
+  }
   const int total = max_count * kSubLists;
   auto leaf_at = [&](int i, Node2D* nd) {
     const int sub = i & (kSubLists - 1), j = i / kSubLists;
-    if (j >= min(leaves.counts[sub * kCountStride], leaves.sub_capacity)) return false;
-    *nd = leaves.nodes[static_cast<size_t>(sub) * leaves.sub_capacity + j];
+    if (j >= min(word(&leaves.counts[sub * kCountStride]), leaves.sub_capacity)) return false;
+    const Node2D* at = &leaves.nodes[static_cast<size_t>(sub) * leaves.sub_capacity + j];
+    if constexpr (kSameLaunch) {
+      const unsigned long long* w = reinterpret_cast<const unsigned long long*>(at);
+      unsigned long long v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = LoadAgent(&w[k]);
+      __builtin_memcpy(nd, v, sizeof(Node2D));
+    } else {
+      *nd = *at;
+    }
     return true;
   };
   // Common case (a handful of leaves, a few problems): every thread keeps its leaf in
@@ -1954,7 +2020,474 @@ SelectBestKernel(NodeList leaves, const ProblemState* __restrict__ states,
                  ProblemState* __restrict__ states_out, const Counters* __restrict__ counters,
                  CountersSummary* __restrict__ summary, const unsigned* __restrict__ tail_dev,
                  unsigned* __restrict__ tail_host, int tail_words) {
-  SelectBestBody(leaves, states, sel, best, num_problems, states_out, counters, summary);
+  SelectBestBody<false>(leaves, states, sel, best, num_problems, states_out, counters, summary);
+  if (tail_host == nullptr) return;
+  __threadfence();
+  __syncthreads();
+  for (int i = threadIdx.x; i < tail_words; i += blockDim.x)
+    tail_host[i] = __hip_atomic_load(&tail_dev[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------
+// Branch and bound through a work queue (round 6): ONE launch behind the dive and the
+// lowest-resolution filter instead of the wave / subtree / select chain of launches.
+//
+// A worker is a WAVEFRONT.  It takes a node from the queue and walks a CHAIN from it: expand
+// (one quad gather per point, the node's scan held in registers: 16 cells per lane), continue
+// with the best child, hand the other children that can still matter to the queue; a chain ends
+// at a leaf (which raises the problem's bound) or when no child reaches the bound.  Every chain is
+// a greedy dive, so the bound tightens as fast as the reference's depth-first search tightens it
+// (SM2/fast_...2d.cc:335-378), while thousands of chains run at once.  The level-synchronous
+// kernels this replaces expanded a whole level against the bound the dive had left: 93 000 node
+// expansions on a hard scan where the reference's own order needs 40 000.
+//
+// The queue: kQueues sub-queues (a control word takes ~90 atomics per microsecond).  A slot is
+// eight 8-byte granules {tag = the call's epoch, word of the node}, each written by ONE
+// agent-scope store and polled with agent-scope loads: the data is its own flag, no fence
+// (MI355X guide, inter-workgroup hand-off R2).  push: one atomic add on `reserved`, then the
+// granules.  pop: look at every sub-queue (one wave-wide load), CAS `head` of one that has
+// something -- never a ticket for a node that does not exist yet, so a worker NEVER waits for
+// work: a wavefront that finds every sub-queue empty is done for good.  That is safe because
+// whoever publishes a node looks again when its own chain has ended, and it is what makes eight
+// such launches share the chip: no wavefront spins on another one's progress (only, briefly,
+// on the granules of a slot that has been reserved and is being written).  The last workgroup to
+// run out of work selects the best leaves and publishes the results (SelectBestBody).
+// Slots are never reused within a call; a sub-queue that fills up sets frontier_overflow and
+// the host repeats the search on the strict, chunked path below.
+// ---------------------------------------------------------------------------
+struct TreeQueue {
+  unsigned long long* slots;     // [kQueues][capacity][8] granules
+  int capacity;                  // nodes per sub-queue
+  unsigned epoch;                // tag of this call (never 0; the buffer only holds older tags)
+};
+
+__device__ __forceinline__ unsigned long long* QueueSlot(const TreeQueue& Q, int q, int slot) {
+  return Q.slots + (static_cast<size_t>(q) * Q.capacity + slot) * 8;
+}
+
+__device__ __forceinline__ void StoreGranule(unsigned long long* g, unsigned epoch, unsigned value) {
+  __hip_atomic_store(g, (static_cast<unsigned long long>(epoch) << 32) | value, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One lane writes one node (the calling lanes hold different nodes).
+__device__ __forceinline__ void StoreNodeGranules(const TreeQueue& Q, int q, int slot,
+                                                  const Node2D& nd) {
+  unsigned long long* g = QueueSlot(Q, q, slot);
+  StoreGranule(g + 0, Q.epoch, static_cast<unsigned>(nd.problem));
+  StoreGranule(g + 1, Q.epoch, static_cast<unsigned>(nd.scan));
+  StoreGranule(g + 2, Q.epoch, static_cast<unsigned>(nd.dx));
+  StoreGranule(g + 3, Q.epoch, static_cast<unsigned>(nd.dy));
+  StoreGranule(g + 4, Q.epoch, __float_as_uint(nd.score));
+  StoreGranule(g + 5, Q.epoch, static_cast<unsigned>(nd.coarse_index));
+  StoreGranule(g + 6, Q.epoch, nd.path);
+  StoreGranule(g + 7, Q.epoch, __float_as_uint(nd.coarse_score));
+}
+
+// Wave-wide push of the lanes with `keep` to sub-queue q: one reservation, slots in lane order.
+// A full sub-queue raises the overflow flag (the reservation stands: poppers never look beyond
+// `capacity`; slots below it are still filled, so every reserved slot below it IS published).
+__device__ __forceinline__ void QueuePush(const TreeQueue& Q, Counters* __restrict__ counters,
+                                          int q, bool keep, const Node2D& nd) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long mask = __ballot(keep);
+  if (mask == 0) return;
+  const int m = __popcll(mask);
+  int first = 0;
+  if (lane == 0)
+    first = __hip_atomic_fetch_add(&counters->queue[q].reserved, m, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+  first = __builtin_amdgcn_readfirstlane(first);
+  if (first + m > Q.capacity && lane == 0) counters->frontier_overflow = 1;
+  if (keep) {
+    const int slot = first + __popcll(mask & ((1ull << lane) - 1));
+    if (slot < Q.capacity) StoreNodeGranules(Q, q, slot, nd);
+  }
+}
+
+// Lanes 0..7 sweep the granules of a slot that has been taken -- it is reserved, i.e. written or
+// being written -- until every tag is this call's; the node comes back wave-uniform.
+__device__ __forceinline__ void ReadSlot(const TreeQueue& Q, int q, int slot, Node2D* out,
+                                         unsigned* slot_rereads) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long* g = QueueSlot(Q, q, slot);
+  unsigned word = 0;
+  for (;;) {
+    bool ok = true;
+    if (lane < 8) {
+      const unsigned long long x = LoadAgent(&g[lane]);
+      word = static_cast<unsigned>(x);
+      ok = static_cast<unsigned>(x >> 32) == Q.epoch;
+    }
+    if (__all(ok)) break;
+    ++*slot_rereads;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  out->problem = static_cast<int>(__builtin_amdgcn_readlane(word, 0));
+  out->scan = static_cast<int>(__builtin_amdgcn_readlane(word, 1));
+  out->dx = static_cast<int>(__builtin_amdgcn_readlane(word, 2));
+  out->dy = static_cast<int>(__builtin_amdgcn_readlane(word, 3));
+  out->score = __uint_as_float(__builtin_amdgcn_readlane(word, 4));
+  out->coarse_index = static_cast<int>(__builtin_amdgcn_readlane(word, 5));
+  out->path = __builtin_amdgcn_readlane(word, 6);
+  out->coarse_score = __uint_as_float(__builtin_amdgcn_readlane(word, 7));
+}
+
+__device__ __forceinline__ bool TakeSlot(Counters* __restrict__ counters, int q, int slot) {
+  int got = 0;
+  if ((threadIdx.x & 63) == 0) {
+    int expected = slot;
+    got = __hip_atomic_compare_exchange_strong(&counters->queue[q].head, &expected, slot + 1,
+                                               __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+  }
+  return __builtin_amdgcn_readfirstlane(got) != 0;
+}
+
+// The wavefront's HOME sub-queue (the only one it pushes to).  false: it is empty -- and, no
+// push of this wavefront being outstanding, it stays empty: the wavefront may leave.
+__device__ __forceinline__ bool PopHome(const TreeQueue& Q, Counters* __restrict__ counters,
+                                        int home, Node2D* out, unsigned* lost_races,
+                                        unsigned* slot_rereads) {
+  for (;;) {
+    const unsigned long long hr =
+        LoadAgent(reinterpret_cast<const unsigned long long*>(&counters->queue[home].head));
+    const int head = static_cast<int>(hr & 0xffffffffu);
+    const int reserved = min(static_cast<int>(hr >> 32), Q.capacity);
+    if (reserved <= head) return false;
+    if (TakeSlot(counters, home, head)) {
+      ReadSlot(Q, home, head, out, slot_rereads);
+      return true;
+    }
+    ++*lost_races;          // a thief was faster: look again (the sub-queue only loses nodes that way)
+  }
+}
+
+// Somebody else's node: up to `windows` windows of 64 sub-queues from a start that differs per
+// wavefront and attempt, one of the busy sub-queues of a window (not the first: every thief
+// would race for the same word).  A thief that loses `max_lost` races, or finds its windows
+// empty, gives up: supply is short then, and whoever published a node takes it in the end.
+__device__ __forceinline__ bool Steal(const TreeQueue& Q, Counters* __restrict__ counters,
+                                      int home, int queues, unsigned salt, int windows,
+                                      int max_lost, Node2D* out, unsigned* lost_races,
+                                      unsigned* slot_rereads) {
+  const int lane = threadIdx.x & 63;
+  int lost = 0;
+  for (int w = 0; w < windows; ++w) {
+    const int base = static_cast<int>((static_cast<unsigned>(home) * 2654435761u + salt * 40503u + w * 64u) %
+                                      static_cast<unsigned>(queues));
+    const int mine = (base + lane) % queues;
+    const unsigned long long hr =
+        LoadAgent(reinterpret_cast<const unsigned long long*>(&counters->queue[mine].head));
+    const int head = static_cast<int>(hr & 0xffffffffu);
+    const int reserved = min(static_cast<int>(hr >> 32), Q.capacity);
+    const unsigned long long avail = __ballot(reserved > head);
+    if (avail == 0) continue;
+    int skip = static_cast<int>((salt + home) % static_cast<unsigned>(__popcll(avail)));
+    unsigned long long rest = avail;
+    while (skip-- > 0) rest &= rest - 1;
+    const int l = __ffsll(static_cast<long long>(rest)) - 1;
+    const int q = (base + l) % queues;
+    const int slot = __builtin_amdgcn_readlane(head, l);
+    if (TakeSlot(counters, q, slot)) {
+      ReadSlot(Q, q, slot, out, slot_rereads);
+      return true;
+    }
+    ++*lost_races;
+    if (++lost >= max_lost) return false;
+    --w;                    // the same window again (another sub-queue of it: salt)
+    ++salt;
+  }
+  return false;
+}
+
+constexpr int kChainCells = 16;     // cells per lane held in registers: clouds of up to 1024 points
+constexpr uint32_t kNoCell = 0x80008000u;   // (x, y) = (-32768, -32768): outside every level
+
+// One leaf record, stored so that the selecting workgroup of the SAME launch reads it.
+__device__ __forceinline__ void RecordLeafAgent(const Node2D& leaf, const NodeList& leaves,
+                                                int sub, Counters* __restrict__ counters) {
+  const int slot = ListReserve(leaves, sub, 1);
+  if (slot >= leaves.sub_capacity) { counters->leaf_overflow = 1; return; }
+  unsigned long long v[4];
+  __builtin_memcpy(v, &leaf, sizeof(Node2D));
+  unsigned long long* at = reinterpret_cast<unsigned long long*>(
+      &leaves.nodes[static_cast<size_t>(sub) * leaves.sub_capacity + slot]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    __hip_atomic_store(&at[k], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(256)
+TreeQueueKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restrict__ states, int n,
+                NodeList in, TreeQueue Q, NodeList leaves, Counters* __restrict__ counters,
+                SelectState* __restrict__ sel, BestLeaf* __restrict__ best_out, int num_problems,
+                ProblemState* __restrict__ states_out, CountersSummary* __restrict__ summary,
+                const unsigned* __restrict__ tail_dev, unsigned* __restrict__ tail_host,
+                int tail_words, int counters_trace, int max_lost) {
+  static_assert(sizeof(Node2D) == 32, "a node is eight words: eight granules, four leaf stores");
+  const int lane = threadIdx.x & 63;
+  const int wave_id = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int num_waves = gridDim.x * 4;
+  const int queues = min(num_waves, kQueues);          // sub-queues in use
+  const int home = wave_id % queues;
+  unsigned steals = 0;
+  unsigned long long scored = 0, expanded = 0;
+  unsigned gathers = 0;
+  unsigned q_pops = 0, q_lost = 0, q_rereads = 0, q_pushed = 0, q_listed = 0, q_chains = 0;
+  int stat_problem = -1;
+  const auto flush_stats = [&]() {
+    if (lane == 0 && stat_problem >= 0 && expanded) {
+      ProblemState& st = states[stat_problem];
+      atomicAdd(&st.scored_shard[wave_id & (kStatShards - 1)], scored);
+      atomicAdd(&st.expanded_shard[wave_id & (kStatShards - 1)], expanded);
+    }
+    scored = expanded = 0;
+  };
+  // Phase 1: this wavefront's share of the filter's list (written by the launch before: plain
+  // loads), node i of the interleaved sub-lists for i = wave, wave + W, ...  Phase 2: the queue.
+  // A static share is safe here because nobody ever waits for anybody: a workgroup that is not
+  // resident yet simply walks its share when it gets there.
+  // The share is dealt in TILES of kTile consecutive entries of one sub-list, fetched by ONE
+  // wave-wide load (lane l: entry l of the tile), so that the trip to memory for a node is paid
+  // once per tile; tile t = (sub-list t mod 64, entries 8 (t / 64) ...) for t = wave, wave + W, ...
+  // (tiles of one entry while the list is short -- a wavefront per node -- up to eight when every
+  // wavefront gets several tiles anyway)
+  const int in_longest = ListMaxCount(in);
+  const int kTile = max(1, min(8, in_longest * kSubLists / (4 * num_waves)));
+  const int in_tiles = (in_longest + kTile - 1) / kTile * kSubLists;
+  int next_tile = wave_id;
+  Node2D tile_node{};          // lane l < tile_count: entry l of the current tile
+  int tile_count = 0, tile_at = 0;
+  bool pushed_any = false;
+  Node2D nd;
+  for (;;) {
+    bool have = false;
+    while (!have) {
+      if (tile_at < tile_count) {
+        const int l = tile_at++;
+        nd.problem = __builtin_amdgcn_readlane(tile_node.problem, l);
+        nd.scan = __builtin_amdgcn_readlane(tile_node.scan, l);
+        nd.dx = __builtin_amdgcn_readlane(tile_node.dx, l);
+        nd.dy = __builtin_amdgcn_readlane(tile_node.dy, l);
+        nd.score = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tile_node.score), l));
+        nd.coarse_index = __builtin_amdgcn_readlane(tile_node.coarse_index, l);
+        nd.path = __builtin_amdgcn_readlane(tile_node.path, l);
+        nd.coarse_score =
+            __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tile_node.coarse_score), l));
+        have = true;
+        ++q_listed;
+        break;
+      }
+      if (next_tile >= in_tiles) break;
+      const int in_sub = next_tile & (kSubLists - 1), first = (next_tile / kSubLists) * kTile;
+      next_tile += num_waves;
+      const int count = min(in.counts[in_sub * kCountStride], in.sub_capacity);   // wave-uniform
+      tile_count = max(0, min(kTile, count - first));
+      tile_at = 0;
+      if (lane < tile_count)
+        tile_node = in.nodes[static_cast<size_t>(in_sub) * in.sub_capacity + first + lane];
+    }
+    if (!have) {
+      // its own sub-queue first (whoever publishes nodes is who guarantees that they are taken:
+      // by a thief, or in the end by itself), then somebody else's; nothing there, or the races
+      // lost: this wavefront is done -- its own sub-queue is empty and stays so
+      if (!(pushed_any && PopHome(Q, counters, home, &nd, &q_lost, &q_rereads)) &&
+          !Steal(Q, counters, home, queues, ++steals, 2, max_lost, &nd, &q_lost, &q_rereads))
+        break;
+      ++q_pops;
+    }
+    const int problem = __builtin_amdgcn_readfirstlane(NodeProblem(nd));
+    const Fast2DProblem& P = problems[problem];
+    ProblemState& st = states[problem];
+    float best = __uint_as_float(LoadAgent(&st.best_bits));
+    if (nd.score < best) continue;                       // the bound has risen since the push
+    if (problem != stat_problem) { flush_stats(); stat_problem = problem; }
+    ++q_chains;
+    // the node's scan: 16 cells per lane, kept for the whole chain
+    const auto* pts = AsGlobal(P.discrete) + static_cast<size_t>(nd.scan) * n;
+    uint32_t cell[kChainCells];
+#pragma unroll
+    for (int j = 0; j < kChainCells; ++j) {
+      const int i = j * kWave + lane;
+      cell[j] = kNoCell;
+      if (j * kWave < n) cell[j] = i < n ? pts[i] : kNoCell;
+    }
+    const int4 bd = P.bounds[nd.scan];
+    const float min_score = P.min_score;
+    for (;;) {                                           // the chain
+      const int child_level = NodeLevel(nd) - 1;
+      const LevelDesc L = P.level[child_level];
+      const int half = 1 << child_level;
+      const bool vx = nd.dx + half <= bd.y, vy = nd.dy + half <= bd.w;
+      const int ax = nd.dx + 2 * half - 1, ay = nd.dy + 2 * half - 1;
+      const int parent_ub = SumUpperBound(P, nd.score, n);
+      const unsigned long long quad_bytes =
+          static_cast<unsigned long long>((L.qy + 3) >> 2) * static_cast<unsigned>(L.qtx) * 128ull;
+      // (levels beyond the 2 GB a buffer resource addresses do not come here: see QueueEligible)
+      const __amdgpu_buffer_rsrc_t quad_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<uint32_t*>(L.quads), 0, static_cast<int>(quad_bytes), 0x00020000);
+      const uint32_t child_mask =
+          (vx ? 0xffffffffu : 0x0000ffffu) & (vy ? 0xffffffffu : 0x00ff00ffu);
+      // packed 16-bit sums: (child 00 | child 10 << 16) and (child 01 | child 11 << 16); a lane adds
+      // at most 16 x 255
+      uint32_t even = 0, odd = 0;
+      int seen_max = 0;
+      bool dead = false;
+      // The first 256 points, then -- unless no child can reach the bound any more -- ALL the
+      // others in flight at once: two trips to memory per expansion at most (a check after every
+      // 256 points was four).
+      const auto gather = [&](auto first_tag, auto count_tag) {
+        constexpr int kFirst = decltype(first_tag)::value, kCount = decltype(count_tag)::value;
+        uint32_t v[kCount];
+#pragma unroll
+        for (int u = 0; u < kCount; ++u) {
+          const uint32_t p = cell[kFirst + u];
+          const int X = static_cast<short>(p & 0xffffu) + ax;
+          const int Y = static_cast<short>(p >> 16) + ay;
+          const bool inside = static_cast<unsigned>(X) < static_cast<unsigned>(L.qx) &&
+                              static_cast<unsigned>(Y) < static_cast<unsigned>(L.qy);
+          v[u] = __builtin_amdgcn_raw_buffer_load_b32(
+              quad_rsrc, inside ? QuadOffset(X, Y, L.qtx) * 4u : 0xfffffff0u, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < kCount; ++u) {
+          const uint32_t q = v[u] & child_mask;
+          const uint32_t e = q & 0x00ff00ffu, o = (q >> 8) & 0x00ff00ffu;
+          even += e;
+          odd += o;
+          const uint32_t a = max(e & 0xffu, o & 0xffu), b = max(e >> 16, o >> 16);
+          seen_max += static_cast<int>(max(a, b));
+        }
+      };
+      gather(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+      gathers += 4;
+      if (n > 4 * kWave) {
+        // what the best child of this lane's points still lacks to the parent (see
+        // ExpandWaveKernel): no child can reach the bound -> the rest of the gathers is skipped
+        const int most = static_cast<int>(max(max(even & 0xffffu, even >> 16),
+                                              max(odd & 0xffffu, odd >> 16)));
+        if (ToScore(P, parent_ub - WaveSum(seen_max - most), n) < best) {
+          dead = true;
+        } else {
+          if (n > 8 * kWave) {
+            gather(std::integral_constant<int, 4>{}, std::integral_constant<int, 12>{});
+            gathers += 12;
+          } else {
+            gather(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
+            gathers += 4;
+          }
+        }
+      }
+      ++expanded;
+      scored += (1 + (vx ? 1 : 0)) * (1 + (vy ? 1 : 0));
+      if (dead) break;
+      const int total[4] = {WaveSum(static_cast<int>(even & 0xffffu)), WaveSum(static_cast<int>(odd & 0xffffu)),
+                            WaveSum(static_cast<int>(even >> 16)), WaveSum(static_cast<int>(odd >> 16))};
+      // lane k < 4 is child k = 2 * x-step + y-step (generation order: x outer, y inner)
+      float sc[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool valid = ((k >> 1) == 0 || vx) && ((k & 1) == 0 || vy);
+        sc[k] = valid ? ToScore(P, total[k], n) : -1.f;
+      }
+      const int k = lane & 3;
+      const float mine = k == 0 ? sc[0] : (k == 1 ? sc[1] : (k == 2 ? sc[2] : sc[3]));
+      int rank = 0;
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (o != k && sc[o] >= 0.f && (sc[o] > mine || (sc[o] == mine && o < k))) ++rank;
+      best = fmaxf(best, __uint_as_float(LoadAgent(&st.best_bits)));
+      const bool keep = lane < 4 && mine >= 0.f && mine >= best;
+      // the best valid child (rank 0; child 0 is always valid)
+      const int kbest = __ffsll(static_cast<long long>(__ballot(lane < 4 && mine >= 0.f && rank == 0))) - 1;
+      Node2D child;
+      child.problem = problem | (child_level << 24);
+      child.scan = nd.scan;
+      child.dx = nd.dx + (k >> 1) * half;
+      child.dy = nd.dy + (k & 1) * half;
+      child.score = mine;
+      child.coarse_index = nd.coarse_index;
+      child.path = nd.path | (static_cast<unsigned>(rank) << (2 * child_level));
+      child.coarse_score = nd.coarse_score;
+      const bool best_kept = (__ballot(keep) >> kbest) & 1ull;
+      if (child_level == 0) {
+        // leaves: only the first-best child can be returned by the reference (:340-343 after the
+        // stable sort of :331-332)
+        if (best_kept && lane == kbest && child.score > min_score) {
+          RecordLeafAgent(child, leaves, wave_id & (kSubLists - 1), counters);
+          atomicMax(&st.best_bits, __float_as_uint(child.score));
+        }
+        break;
+      }
+      if (!best_kept) break;                              // the best child is below the bound: all are
+      // the other children that can still matter go to the queue ...
+      const bool others = keep && lane != kbest;
+      if (__ballot(others)) {
+        QueuePush(Q, counters, home, others, child);
+        pushed_any = true;
+        q_pushed += __popcll(__ballot(others));
+      }
+      // ... and the chain goes on with the best one
+      nd.problem = child.problem;
+      nd.dx = __builtin_amdgcn_readlane(child.dx, kbest);
+      nd.dy = __builtin_amdgcn_readlane(child.dy, kbest);
+      nd.score = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(child.score), kbest));
+      nd.path = __builtin_amdgcn_readlane(child.path, kbest);
+    }
+  }
+  // ---- out of work.  The work counters of the four wavefronts go out as one set of atomics per
+  // workgroup (one per WAVEFRONT on a word per problem took 20 us of a 2048-wavefront launch: a
+  // word takes ~90 atomics per microsecond), then the last workgroup to get here selects and
+  // publishes. ---------------------------------------------------------------------------------
+  __shared__ unsigned long long s_scored[4], s_expanded[4];
+  __shared__ unsigned s_gathers[4];
+  __shared__ unsigned s_queue_stats[8];
+  __shared__ int s_problem[4];
+  if (threadIdx.x < 8) s_queue_stats[threadIdx.x] = 0;
+  __syncthreads();
+  if (lane == 0 && counters_trace) {
+    atomicAdd(&s_queue_stats[0], q_pops);
+    atomicAdd(&s_queue_stats[1], q_lost);
+    atomicAdd(&s_queue_stats[2], q_rereads);
+    atomicAdd(&s_queue_stats[3], q_pushed);
+    atomicAdd(&s_queue_stats[4], q_listed);
+    atomicAdd(&s_queue_stats[5], q_chains);
+  }
+  __shared__ int s_last;
+  if (lane == 0) {
+    const int w = threadIdx.x >> 6;
+    s_scored[w] = scored;
+    s_expanded[w] = expanded;
+    s_gathers[w] = gathers;
+    s_problem[w] = expanded ? stat_problem : -1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's stores have landed
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned g = 0;
+    for (int w = 0; w < 4; ++w) {
+      g += s_gathers[w];
+      if (s_problem[w] < 0) continue;
+      unsigned long long sc = s_scored[w], ex = s_expanded[w];
+      for (int v = w + 1; v < 4; ++v)
+        if (s_problem[v] == s_problem[w]) { sc += s_scored[v]; ex += s_expanded[v]; s_problem[v] = -1; }
+      ProblemState& st = states[s_problem[w]];
+      atomicAdd(&st.scored_shard[blockIdx.x & (kStatShards - 1)], sc);
+      atomicAdd(&st.expanded_shard[blockIdx.x & (kStatShards - 1)], ex);
+    }
+    if (g) atomicAdd(&counters->gathers_shard[(blockIdx.x & 15) * kCountStride], g);
+    if (counters_trace)
+      for (int k = 0; k < 6; ++k)
+        if (s_queue_stats[k])
+          atomicAdd(&counters->queue_stats[(blockIdx.x & 15) * kCountStride + k], s_queue_stats[k]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = __hip_atomic_fetch_add(&counters->blocks_done, 1, __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT) == static_cast<int>(gridDim.x) - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  SelectBestBody<true>(leaves, states, sel, best_out, num_problems, states_out, counters, summary);
   if (tail_host == nullptr) return;
   __threadfence();
   __syncthreads();
@@ -2234,6 +2767,13 @@ long long FusedResidentBlocks(int device, int threads, size_t lds_bytes) {
 
 // Uploads problem descriptors, carves scratch and runs the preparation +
 // lowest-resolution scoring kernels.  `d_xyz` is the device point cloud.
+// The work-queue tree search (TreeQueueKernel) holds a scan in registers, 16 cells per lane.
+// Debug switch fast2d_queue: 2 = the chain of level-synchronous launches of rounds 2 - 5 (the
+// parity partner, and the path a queue overflow falls back to).
+bool QueueSearchWanted(int n) {
+  return Debug().fast2d_queue != 2 && n <= kChainCells * kWave;
+}
+
 void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, int num,
                            const cmx_pose2d* initial_or_null, bool full_submap,
                            const float* d_xyz, int n, float max_range_xy, float min_score,
@@ -2364,9 +2904,11 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     out->d_timeline = static_cast<unsigned long long*>(ws.dev[15].Reserve(bytes));
     CMX_HIP(hipMemsetAsync(out->d_timeline, 0, bytes, ws.stream));
   }
-  // Batches keep the cells of surviving scans (debug switch fast2d_store_scans overrides).
+  // Batches and the work-queue search keep the cells of surviving scans (debug switch
+  // fast2d_store_scans overrides).
   const int store_override = Debug().fast2d_store_scans;
-  const int store_scans = store_override ? store_override - 1 : (num >= 4 ? 1 : 0);
+  const int store_scans =
+      store_override ? store_override - 1 : ((num >= 4 || QueueSearchWanted(n)) ? 1 : 0);
   size_t disc_off = 0, scan_off = 0, coarse_off = 0;
   for (int p = 0; p < num; ++p) {
     const Fast2DMatcher& m = *matchers[p];
@@ -2530,8 +3072,8 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
   const int kFrontierCapacity = capacity(Debug().frontier_capacity, frontier_default);
   const int kLeafCapacity = capacity(0, 1 << 20);
   const int kFrontierSub = kFrontierCapacity / kSubLists, kLeafSub = kLeafCapacity / kSubLists;
-  Node2D* d_front[2] = {ws.dev[10].ReserveAs<Node2D>(kFrontierCapacity),
-                        ws.dev[11].ReserveAs<Node2D>(kFrontierCapacity)};
+  // (the two frontier buffers of the level-synchronous path: reserved when that path runs)
+  Node2D* d_front[2] = {nullptr, nullptr};
   Node2D* d_leaves = ws.dev[12].ReserveAs<Node2D>(kLeafCapacity);
   // Carved by ReserveSearchScratch before the first kernel of the call, which clears the
   // counters.
@@ -2601,7 +3143,80 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
     const int narrow_blocks = std::min(4096, 512 * std::max(1, (num + 3) / 4));
     int num_chunks = 1;
     int strict = 0;
-    for (;;) {
+    // Something was dropped (a full frontier / queue / leaf list).  Bounds found so far are real
+    // leaf scores and stay valid; the search is repeated in strict mode (prunes ties, records
+    // only improving leaves) over more, smaller chunks of scans.  The best leaf found so far is
+    // re-found by lowering the bound one ulp.
+    const auto prepare_strict_retry = [&]() {
+      CMX_REQUIRE(num_chunks < (1 << 12), "branch-and-bound overflow not resolvable");
+      if (h_counters->frontier_overflow) num_chunks *= 4;
+      strict = 1;
+      for (int p = 0; p < num; ++p) {
+        const float floor_score = std::max(batch.h_problems[p].min_score, 0.f);
+        unsigned floor_bits;
+        std::memcpy(&floor_bits, &floor_score, sizeof(float));
+        if (h_states[p].best_bits > floor_bits) h_states[p].best_bits -= 1;
+      }
+      CMX_HIP(hipMemcpyAsync(batch.d_states, h_states, num * sizeof(ProblemState),
+                             hipMemcpyHostToDevice, ws.stream));
+      CMX_HIP(hipMemsetAsync(d_counters, 0, sizeof(Counters), ws.stream));
+    };
+    // ---- the work queue: filter + ONE launch for the whole tree and the selection ---------
+    bool queue_ok = QueueSearchWanted(n);
+    for (const Fast2DProblem& P : batch.h_problems) {
+      queue_ok = queue_ok && (P.recompute_scans == 0 || P.store_scans != 0);
+      for (int l = 0; l + 1 < depth; ++l)
+        queue_ok = queue_ok && static_cast<unsigned long long>((P.level[l].qy + 3) >> 2) *
+                                       static_cast<unsigned>(P.level[l].qtx) * 128ull < (1ull << 31);
+    }
+    bool searched = false;
+    if (queue_ok) {
+      // 16 K nodes per sub-queue (1 M nodes, 64 MB) for up to 16 problems, 64 K per problem
+      // beyond; slots are not reused within a call.
+      const long long wanted = std::max<long long>(1ll << 20, 65536ll * num);
+      int sub_capacity = static_cast<int>(std::min<long long>(wanted, 1ll << 23) / kQueues);
+      if (Debug().fast2d_queue_capacity > 0) sub_capacity = Debug().fast2d_queue_capacity;
+      TreeQueue queue;
+      queue.capacity = sub_capacity;
+      queue.slots = static_cast<unsigned long long*>(ws.tagged[0].Acquire(
+          static_cast<size_t>(kQueues) * sub_capacity * 8 * sizeof(unsigned long long), ws.stream,
+          &queue.epoch));
+      d_front[0] = ws.dev[10].ReserveAs<Node2D>(kFrontierCapacity);
+      FilterCoarseKernel<<<dim3(DivUp(batch.max_scans, 4), num), 256, 0, ws.stream>>>(
+          batch.d_problems, batch.d_states, n, 0, 1, /*strict=*/0, /*affinity=*/0, front(0),
+          d_counters);
+      mark("filter");
+      const bool timed = num >= 4;
+      if (timed) RecordEvent(ws.ev_x0, ws.stream);
+      const int blocks = Debug().fast2d_queue_blocks > 0
+                             ? Debug().fast2d_queue_blocks
+                             : std::min(2048, 512 * std::max(1, (num + 3) / 4));
+      TreeQueueKernel<<<blocks, 256, 0, ws.stream>>>(
+          batch.d_problems, batch.d_states, n, front(0), queue, leaf_list, d_counters, d_sel,
+          d_best, num, d_states_out, d_summary, reinterpret_cast<const unsigned*>(d_tail),
+          direct ? reinterpret_cast<unsigned*>(h_misc) : nullptr,
+          static_cast<int>(misc_bytes / sizeof(unsigned)),
+          batch.trace && batch.trace->enabled() ? 1 : 0,
+          Debug().fast2d_queue_lost > 0 ? Debug().fast2d_queue_lost : 3);
+      mark("queue");
+      CMX_HIP(hipGetLastError());
+      if (timed) {
+        RecordEvent(ws.ev_x1, ws.stream);
+        result->expansion_launches = 1;
+      }
+      RecordEvent(ws.ev_end, ws.stream);
+      fetch_results(direct);
+      result->expansion_lookups = 64ll * h_counters->wave_gathers;
+      for (int p = 0; p < num; ++p)
+        for (int k = 0; k < kStatShards; ++k) result->expansion_nodes += h_states[p].expanded_shard[k];
+      if (!h_counters->frontier_overflow && !h_counters->leaf_overflow) searched = true;
+      else prepare_strict_retry();
+    }
+    if (!searched) {
+      d_front[0] = ws.dev[10].ReserveAs<Node2D>(kFrontierCapacity);
+      d_front[1] = ws.dev[11].ReserveAs<Node2D>(kFrontierCapacity);
+    }
+    while (!searched) {
       for (int chunk = 0; chunk < num_chunks; ++chunk) {
         if (chunk > 0 || strict)
           CMX_HIP(hipMemsetAsync(d_counters->frontier, 0, sizeof(d_counters->frontier),
@@ -2654,22 +3269,7 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
         result->expansion_lookups = 64ll * h_counters->wave_gathers;
       }
       if (!h_counters->frontier_overflow && !h_counters->leaf_overflow) break;
-      // Something was dropped.  Bounds found so far are real leaf scores and
-      // stay valid; repeat the search in strict mode (prunes ties, records
-      // only improving leaves) over more, smaller chunks of scans.  The best
-      // leaf found so far is re-found by lowering the bound one ulp.
-      CMX_REQUIRE(num_chunks < (1 << 12), "branch-and-bound overflow not resolvable");
-      if (h_counters->frontier_overflow) num_chunks *= 4;
-      strict = 1;
-      for (int p = 0; p < num; ++p) {
-        const float floor_score = std::max(batch.h_problems[p].min_score, 0.f);
-        unsigned floor_bits;
-        std::memcpy(&floor_bits, &floor_score, sizeof(float));
-        if (h_states[p].best_bits > floor_bits) h_states[p].best_bits -= 1;
-      }
-      CMX_HIP(hipMemcpyAsync(batch.d_states, h_states, num * sizeof(ProblemState),
-                             hipMemcpyHostToDevice, ws.stream));
-      CMX_HIP(hipMemsetAsync(d_counters, 0, sizeof(Counters), ws.stream));
+      prepare_strict_retry();
     }
   }
 
@@ -2683,6 +3283,10 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
     long long leaves = 0;
     for (int k = 0; k < kSubLists; ++k) leaves += h_counters->leaves[k];
     fprintf(stderr, " leaves=%lld\n", leaves);
+    const unsigned* q = h_counters->queue_stats;
+    if (q[5])
+      fprintf(stderr, "[cmx trace] work queue: %u chains (%u nodes from the list, %u popped), %u "
+              "pushed, %u lost races, %u slot re-reads\n", q[5], q[4], q[0], q[3], q[1], q[2]);
   }
   if (depth > 1) {
     ResolveTies(ws, batch, leaf_list, *h_counters, &result->best, result->states);
