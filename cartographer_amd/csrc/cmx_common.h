@@ -95,7 +95,7 @@ cmx_status Guard(F&& body) {
   X(fast2d_levels_per_stage) /* levels per depth-first stage */                                   \
   X(fast2d_wave_levels)   /* k > 0: k - 1 levels of wave-per-node expansion */                     \
   X(fast2d_xcd_affinity)  /* 1: nodes of a problem on any XCD, 2: on one */                        \
-  X(fast2d_queue)         /* 2: tree search by the level-synchronous launches (no work queue) */   \
+  X(fast2d_queue)         /* 2: tree search by the level-synchronous launches (no work queue), 1: the queue for batches too */ \
   X(fast2d_queue_blocks)  /* workgroups of the work-queue tree search (0: default) */              \
   X(fast2d_queue_capacity) /* nodes per sub-queue (tests: forces the overflow path) */             \
   X(fast2d_queue_lost)    /* lost races after which a wavefront stops looking for work (0: 3) */   \

@@ -2098,7 +2098,9 @@ __device__ __forceinline__ void QueuePush(const TreeQueue& Q, Counters* __restri
     first = __hip_atomic_fetch_add(&counters->queue[q].reserved, m, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
   first = __builtin_amdgcn_readfirstlane(first);
-  if (first + m > Q.capacity && lane == 0) counters->frontier_overflow = 1;
+  // (agent-scope stores: the selecting workgroup of this launch reads the flag)
+  if (first + m > Q.capacity && lane == 0)
+    __hip_atomic_store(&counters->frontier_overflow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (keep) {
     const int slot = first + __popcll(mask & ((1ull << lane) - 1));
     if (slot < Q.capacity) StoreNodeGranules(Q, q, slot, nd);
@@ -2208,7 +2210,10 @@ constexpr uint32_t kNoCell = 0x80008000u;   // (x, y) = (-32768, -32768): outsid
 __device__ __forceinline__ void RecordLeafAgent(const Node2D& leaf, const NodeList& leaves,
                                                 int sub, Counters* __restrict__ counters) {
   const int slot = ListReserve(leaves, sub, 1);
-  if (slot >= leaves.sub_capacity) { counters->leaf_overflow = 1; return; }
+  if (slot >= leaves.sub_capacity) {
+    __hip_atomic_store(&counters->leaf_overflow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   unsigned long long v[4];
   __builtin_memcpy(v, &leaf, sizeof(Node2D));
   unsigned long long* at = reinterpret_cast<unsigned long long*>(
@@ -2770,8 +2775,10 @@ long long FusedResidentBlocks(int device, int threads, size_t lds_bytes) {
 // The work-queue tree search (TreeQueueKernel) holds a scan in registers, 16 cells per lane.
 // Debug switch fast2d_queue: 2 = the chain of level-synchronous launches of rounds 2 - 5 (the
 // parity partner, and the path a queue overflow falls back to).
-bool QueueSearchWanted(int n) {
-  return Debug().fast2d_queue != 2 && n <= kChainCells * kWave;
+// Batches of four or more problems stay on the level-synchronous launches: wide frontiers of many
+// problems keep the chip busy there, and they measure faster (16 submaps: 1.4 against 2.7 ms).
+bool QueueSearchWanted(int n, int num) {
+  return Debug().fast2d_queue != 2 && n <= kChainCells * kWave && (num < 4 || Debug().fast2d_queue == 1);
 }
 
 void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, int num,
@@ -2908,7 +2915,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
   // fast2d_store_scans overrides).
   const int store_override = Debug().fast2d_store_scans;
   const int store_scans =
-      store_override ? store_override - 1 : ((num >= 4 || QueueSearchWanted(n)) ? 1 : 0);
+      store_override ? store_override - 1 : ((num >= 4 || QueueSearchWanted(n, num)) ? 1 : 0);
   size_t disc_off = 0, scan_off = 0, coarse_off = 0;
   for (int p = 0; p < num; ++p) {
     const Fast2DMatcher& m = *matchers[p];
@@ -3162,7 +3169,7 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
       CMX_HIP(hipMemsetAsync(d_counters, 0, sizeof(Counters), ws.stream));
     };
     // ---- the work queue: filter + ONE launch for the whole tree and the selection ---------
-    bool queue_ok = QueueSearchWanted(n);
+    bool queue_ok = QueueSearchWanted(n, num);
     for (const Fast2DProblem& P : batch.h_problems) {
       queue_ok = queue_ok && (P.recompute_scans == 0 || P.store_scans != 0);
       for (int l = 0; l + 1 < depth; ++l)
@@ -3209,8 +3216,18 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
       result->expansion_lookups = 64ll * h_counters->wave_gathers;
       for (int p = 0; p < num; ++p)
         for (int k = 0; k < kStatShards; ++k) result->expansion_nodes += h_states[p].expanded_shard[k];
-      if (!h_counters->frontier_overflow && !h_counters->leaf_overflow) searched = true;
-      else prepare_strict_retry();
+      if (!h_counters->frontier_overflow && !h_counters->leaf_overflow) {
+        searched = true;
+      } else if (h_counters->leaf_overflow) {
+        prepare_strict_retry();
+      } else {
+        // A sub-queue filled up (it holds 1 K nodes: one wavefront's siblings -- landscapes where
+        // nearly everything ties fill it).  The level-synchronous path has room for millions of
+        // nodes and reproduces the reference's order among ANY number of tied leaves, which the
+        // strict retry cannot: it runs first, from the bounds found so far (real leaf scores),
+        // with the lists cleared.
+        CMX_HIP(hipMemsetAsync(d_counters, 0, sizeof(Counters), ws.stream));
+      }
     }
     if (!searched) {
       d_front[0] = ws.dev[10].ReserveAs<Node2D>(kFrontierCapacity);
