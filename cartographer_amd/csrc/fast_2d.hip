@@ -2321,21 +2321,37 @@ TreeQueueKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __rest
     const int4 bd = P.bounds[nd.scan];
     const float min_score = P.min_score;
     for (;;) {                                           // the chain
-      const int child_level = NodeLevel(nd) - 1;
-      const LevelDesc L = P.level[child_level];
+      // (everything about the node is wavefront-uniform, and the compiler is TOLD so: a buffer
+      // resource it cannot prove uniform gets every one of the sixteen gathers wrapped in a
+      // readfirstlane loop of thirty instructions)
+      const int child_level = __builtin_amdgcn_readfirstlane(NodeLevel(nd) - 1);
+      const LevelDesc& Lm = P.level[child_level];
       const int half = 1 << child_level;
-      const bool vx = nd.dx + half <= bd.y, vy = nd.dy + half <= bd.w;
-      const int ax = nd.dx + 2 * half - 1, ay = nd.dy + 2 * half - 1;
+      const int ndx = __builtin_amdgcn_readfirstlane(nd.dx), ndy = __builtin_amdgcn_readfirstlane(nd.dy);
+      const bool vx = ndx + half <= bd.y, vy = ndy + half <= bd.w;
+      const int ax = ndx + 2 * half - 1, ay = ndy + 2 * half - 1;
       const int parent_ub = SumUpperBound(P, nd.score, n);
+      struct { int qx, qy, qtx; } L;
+      L.qx = __builtin_amdgcn_readfirstlane(Lm.qx);
+      L.qy = __builtin_amdgcn_readfirstlane(Lm.qy);
+      L.qtx = __builtin_amdgcn_readfirstlane(Lm.qtx);
+      const unsigned long long quads_address = reinterpret_cast<unsigned long long>(Lm.quads);
+      const unsigned long long quads_uniform =
+          static_cast<unsigned long long>(static_cast<unsigned>(
+              __builtin_amdgcn_readfirstlane(static_cast<unsigned>(quads_address)))) |
+          (static_cast<unsigned long long>(static_cast<unsigned>(
+               __builtin_amdgcn_readfirstlane(static_cast<unsigned>(quads_address >> 32)))) << 32);
       const unsigned long long quad_bytes =
           static_cast<unsigned long long>((L.qy + 3) >> 2) * static_cast<unsigned>(L.qtx) * 128ull;
-      // (levels beyond the 2 GB a buffer resource addresses do not come here: see QueueEligible)
+      // (levels beyond the 2 GB a buffer resource addresses do not come here: see queue_ok)
       const __amdgpu_buffer_rsrc_t quad_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<uint32_t*>(L.quads), 0, static_cast<int>(quad_bytes), 0x00020000);
-      const uint32_t child_mask =
-          (vx ? 0xffffffffu : 0x0000ffffu) & (vy ? 0xffffffffu : 0x00ff00ffu);
+          reinterpret_cast<uint32_t*>(quads_uniform), 0, static_cast<int>(quad_bytes), 0x00020000);
       // packed 16-bit sums: (child 00 | child 10 << 16) and (child 01 | child 11 << 16); a lane adds
-      // at most 16 x 255
+      // at most 16 x 255.  Children beyond the search bounds (`break`s at :356,361) are summed
+      // like the others and dropped when the scores are formed: the level-(l+1) cell is the
+      // maximum of all four level-l cells whatever the bounds say, so the early-exit bound below
+      // holds with them in it.
+      typedef unsigned short Halves __attribute__((ext_vector_type(2)));
       uint32_t even = 0, odd = 0;
       int seen_max = 0;
       bool dead = false;
@@ -2348,21 +2364,25 @@ TreeQueueKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __rest
 #pragma unroll
         for (int u = 0; u < kCount; ++u) {
           const uint32_t p = cell[kFirst + u];
-          const int X = static_cast<short>(p & 0xffffu) + ax;
-          const int Y = static_cast<short>(p >> 16) + ay;
-          const bool inside = static_cast<unsigned>(X) < static_cast<unsigned>(L.qx) &&
-                              static_cast<unsigned>(Y) < static_cast<unsigned>(L.qy);
-          v[u] = __builtin_amdgcn_raw_buffer_load_b32(
-              quad_rsrc, inside ? QuadOffset(X, Y, L.qtx) * 4u : 0xfffffff0u, 0, 0);
+          const unsigned X = static_cast<unsigned>(static_cast<short>(p & 0xffffu) + ax);
+          const unsigned Y = static_cast<unsigned>(static_cast<short>(p >> 16) + ay);
+          const bool inside = X < static_cast<unsigned>(L.qx) && Y < static_cast<unsigned>(L.qy);
+          // QuadOffset(X, Y, qtx) * 4, branch-free, the tile index by a 24-bit multiply-add
+          // (inside: Y >> 2 and qtx are far below 2^24)
+          const unsigned tile = __umul24(Y >> 2, static_cast<unsigned>(L.qtx)) + (X >> 3);
+          const unsigned byte = (tile << 7) | ((Y & 3u) << 5) | ((X & 7u) << 2);
+          v[u] = __builtin_amdgcn_raw_buffer_load_b32(quad_rsrc, inside ? byte : 0xfffffff0u, 0, 0);
         }
 #pragma unroll
         for (int u = 0; u < kCount; ++u) {
-          const uint32_t q = v[u] & child_mask;
-          const uint32_t e = q & 0x00ff00ffu, o = (q >> 8) & 0x00ff00ffu;
+          const uint32_t e = v[u] & 0x00ff00ffu, o = (v[u] >> 8) & 0x00ff00ffu;
           even += e;
           odd += o;
-          const uint32_t a = max(e & 0xffu, o & 0xffu), b = max(e >> 16, o >> 16);
-          seen_max += static_cast<int>(max(a, b));
+          Halves eh, oh;
+          __builtin_memcpy(&eh, &e, 4);
+          __builtin_memcpy(&oh, &o, 4);
+          const Halves m = __builtin_elementwise_max(eh, oh);
+          seen_max += static_cast<int>(max(m.x, m.y));
         }
       };
       gather(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
@@ -3195,9 +3215,13 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
       mark("filter");
       const bool timed = num >= 4;
       if (timed) RecordEvent(ws.ev_x0, ws.stream);
+      // One workgroup per CU: 1024 wavefronts.  More of them shorten a single hard search (512
+      // workgroups: 240 against 290 us on the hardest of the bench's eight scans) and cost the
+      // eight-thread line more than that (17 200 against 19 300 matches/s): wavefronts that find
+      // nothing to steal are pure overhead for the searches that share the chip.
       const int blocks = Debug().fast2d_queue_blocks > 0
                              ? Debug().fast2d_queue_blocks
-                             : std::min(2048, 512 * std::max(1, (num + 3) / 4));
+                             : std::min(2048, 256 * std::max(1, (num + 3) / 4));
       TreeQueueKernel<<<blocks, 256, 0, ws.stream>>>(
           batch.d_problems, batch.d_states, n, front(0), queue, leaf_list, d_counters, d_sel,
           d_best, num, d_states_out, d_summary, reinterpret_cast<const unsigned*>(d_tail),

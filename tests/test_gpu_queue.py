@@ -1,0 +1,181 @@
+"""The work-queue branch and bound of round 6 (fast_2d.hip, TreeQueueKernel) against the oracle and
+against the level-synchronous launches it replaces (debug switch fast2d_queue = 2), on searches
+that expand from 1 600 to 60 000 nodes, in every shape the queue can take: one workgroup, a grid
+that does not divide the list, sub-queues so small that they overflow (the fall-back paths), the
+queue for a batch, eight host threads at once.  Bars as in test_gpu_2d.py: found flag and f32 score
+bit-equal, pose to 1e-12 (f64 from integer offsets).
+(SM2 = /root/reference/cartographer/mapping/internal/2d/scan_matching; the search restated is
+SM2/fast_correlative_scan_matcher_2d.cc:264-378.)
+"""
+import math
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sm():
+    from cartographer_amd import _lib, scan_matching
+    assert _lib.lib().cmx_device_count() >= 1, "no HIP device: these tests need the GPU"
+    return scan_matching
+
+
+@pytest.fixture(scope="module")
+def world8(synth, oracle):
+    """bench.py's C2 world (seed 42, 400 x 400, depth 7) with the eight scans its headline cycles
+    through, and the oracle's full-submap result for each (0.2 - 0.7 s of one core each)."""
+    cells, lim, world = synth.make_submap(42, 400, 400, 0.05, 30, 1000, 30.0, 0.01)
+    scans = [world.scan(world.free_pose(1234 + k, 0.5), 1000, 30.0, 0.01, 7 + k) for k in range(8)]
+    om = oracle.FastCorrelativeScanMatcher2D(cells, 0.05, lim["max_x"], lim["max_y"], 7)
+    with ThreadPoolExecutor(8) as pool:
+        refs = list(pool.map(lambda sc: om.match_full_submap(sc, 0.6), scans))
+    return cells, lim, world, scans, refs
+
+
+def _matcher(sm, cells, lim, depth=7, **kw):
+    return sm.FastCorrelativeScanMatcher2D(
+        sm.Grid2D(cells, lim["resolution"], lim["max_x"], lim["max_y"]), depth, **kw)
+
+
+def _xyt(pose):
+    return (pose.x, pose.y, pose.theta) if hasattr(pose, "theta") else tuple(np.asarray(pose)[:3])
+
+
+def _same(got, ref):
+    found, score, pose = got
+    assert bool(found) == bool(ref["found"])
+    if ref["found"]:
+        assert np.float32(score) == np.float32(ref["score"])
+        assert np.max(np.abs(np.asarray(_xyt(pose)) - np.asarray(ref["pose"][:3]))) < 1e-12
+
+
+@pytest.mark.parametrize("switches", [
+    {},                                                   # as shipped
+    {"fast2d_queue": 2},                                  # the level-synchronous launches
+    {"fast2d_queue_blocks": 1},                           # four wavefronts do everything
+    {"fast2d_queue_blocks": 37},                          # a grid that divides nothing
+    {"fast2d_queue_blocks": 2048},                        # more wavefronts than sub-queues
+    {"fast2d_queue_lost": 1},
+    {"fast2d_queue_lost": 1000},
+    {"fast2d_queue_capacity": 2},                         # sub-queues overflow: level path takes over
+    {"fast2d_queue_capacity": 2, "frontier_capacity": 4096},   # ... and overflows too: strict, chunked
+], ids=lambda s: ",".join(f"{k}={v}" for k, v in s.items()) or "default")
+def test_queue_search_equals_the_oracle_on_eight_scans(sm, world8, debug, switches):
+    cells, lim, _, scans, refs = world8
+    debug(**switches)
+    gm = _matcher(sm, cells, lim)
+    for scan, ref in zip(scans, refs):
+        assert ref["found"]
+        _same(gm.match_full_submap(scan, 0.6), ref)
+
+
+def test_queue_search_counts_its_work(sm, world8, debug):
+    """The work counters of the queue path: every scored candidate at every depth.  The count
+    depends on when the bound rises (it is not the same from run to run), but never falls below
+    what the reference's own order needs less the dive's head start, and the easy scan (#0, whose
+    dive finds the optimum) expands exactly the level path's 3 076 nodes."""
+    cells, lim, _, scans, _ = world8
+    gm = _matcher(sm, cells, lim)
+    gm.match_full_submap(scans[0], 0.6)
+    queue = dict(gm.last_stats)
+    debug(fast2d_queue=2)
+    gm.match_full_submap(scans[0], 0.6)
+    level = dict(gm.last_stats)
+    assert queue["coarse_candidates"] == level["coarse_candidates"]
+    assert queue["nodes_expanded"] == level["nodes_expanded"]
+    assert queue["candidates_scored"] == level["candidates_scored"]
+    debug(fast2d_queue=0)
+    gm.match_full_submap(scans[7], 0.6)       # the hardest of the eight
+    hard = dict(gm.last_stats)
+    assert 20000 < hard["nodes_expanded"] < 90000      # level path: 66 000 - 93 000
+    assert hard["expansion_lookups"] > 0
+
+
+def test_queue_search_windowed_and_not_found(sm, oracle, world8, debug):
+    """Match() with a search window (children beyond the bounds are masked), and a threshold
+    nothing reaches: found = 0 on both sides."""
+    cells, lim, world, scans, _ = world8
+    om = oracle.FastCorrelativeScanMatcher2D(cells, 0.05, lim["max_x"], lim["max_y"], 7, 3.0,
+                                             math.radians(20.0))
+    gm = _matcher(sm, cells, lim, linear_search_window=3.0,
+                  angular_search_window=math.radians(20.0))
+    for k in (1, 4, 7):
+        truth = world.free_pose(1234 + k, 0.5)
+        init = [truth[0] + 0.4, truth[1] - 0.3, truth[2] + 0.1]
+        ref = om.match(init, scans[k], 0.5)
+        _same(gm.match(sm.Rigid2d(*init), scans[k], 0.5), ref)
+    ref = om.match_full_submap(scans[2], 0.97)
+    assert not ref["found"]
+    _same(gm.match_full_submap(scans[2], 0.97), ref)
+
+
+@pytest.mark.parametrize("depth", [2, 3, 5])
+def test_queue_search_shallow_trees(sm, oracle, synth, depth):
+    """Depth 2 (the chain's first expansion already scores leaves) to 5, on a small grid."""
+    cells, lim, world = synth.make_submap(7, 160, 160, 0.05, 12, 500, 30.0, 0.01)
+    scan = world.scan(world.free_pose(5, 0.5), 700, 30.0, 0.01, 2)
+    om = oracle.FastCorrelativeScanMatcher2D(cells, 0.05, lim["max_x"], lim["max_y"], depth)
+    gm = _matcher(sm, cells, lim, depth)
+    _same(gm.match_full_submap(scan, 0.5), om.match_full_submap(scan, 0.5))
+
+
+def test_queue_search_all_ties(sm, oracle, debug):
+    """A grid of unknown cells: every candidate of the search space ties.  The queue's sub-queues
+    fill up, the level-synchronous path takes over from the bounds found so far, and the leaf
+    the reference's depth-first order meets first comes back (ConstraintBuilder2DTest's grid,
+    mapping/internal/constraints/constraint_builder_2d_test.cc:60-75)."""
+    cells = np.zeros((110, 100), np.uint16)
+    cloud = np.array([[0.1, 0.2, 0.3]], np.float32)
+    om = oracle.FastCorrelativeScanMatcher2D(cells, 1.0, 2.0, 3.0, 7, 7.0, math.radians(30.0))
+    gm = sm.FastCorrelativeScanMatcher2D(sm.Grid2D(cells, 1.0, 2.0, 3.0), 7,
+                                         linear_search_window=7.0,
+                                         angular_search_window=math.radians(30.0))
+    _same(gm.match_full_submap(cloud, 0.0), om.match_full_submap(cloud, 0.0))
+    _same(gm.match(sm.Rigid2d(4.0, 5.0, 0.0), cloud, 0.0), om.match([4.0, 5.0, 0.0], cloud, 0.0))
+
+
+def test_queue_search_for_a_batch(sm, world8, synth, oracle, debug):
+    """fast2d_queue = 1: the queue for a batch of five problems too (several problems' nodes in
+    one set of sub-queues, work counters per problem)."""
+    cells, lim, _, scans, refs = world8
+    debug(fast2d_queue=1)
+    grids = [(cells, lim)]
+    for seed in (43, 44):
+        c, l, _ = synth.make_submap(seed, 400, 400, 0.05, 30, 1000, 30.0, 0.01)
+        grids.append((c, l))
+    order = [0, 1, 0, 2, 0]
+    matchers = [_matcher(sm, *grids[g]) for g in order]
+    found, scores, poses, stats = sm.match_full_submap_batch(matchers, scans[1], 0.6)
+    debug(fast2d_queue=2)
+    found2, scores2, poses2, _ = sm.match_full_submap_batch(matchers, scans[1], 0.6)
+    np.testing.assert_array_equal(found, found2)
+    np.testing.assert_array_equal(scores[found != 0], scores2[found2 != 0])
+    for a, b, ok in zip(poses, poses2, found):
+        if ok:
+            assert _xyt(a) == _xyt(b)
+    assert found[0] and np.float32(scores[0]) == np.float32(refs[1]["score"])
+    assert scores[0] == scores[2] == scores[4]
+
+
+def test_queue_search_from_eight_threads(sm, world8):
+    """Eight host threads, each cycling through the eight scans (the bench headline's shape):
+    every call leases its own workspace, queue buffer and epoch; 160 searches, every one equal to
+    the oracle's."""
+    cells, lim, _, scans, refs = world8
+    gm = _matcher(sm, cells, lim)
+    clouds = [sm.PointCloudOnDevice(s) for s in scans]
+
+    def worker(t):
+        out = []
+        for j in range(20):
+            k = (t + j) % 8
+            f, s, p, _ = sm.match_full_submap_batch([gm], clouds[k], 0.6)
+            out.append((k, f[0], s[0], p[0]))
+        return out
+    with ThreadPoolExecutor(8) as pool:
+        for results in pool.map(worker, range(8)):
+            for k, f, s, p in results:
+                _same((f, s, p), refs[k])
