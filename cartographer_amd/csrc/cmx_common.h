@@ -74,6 +74,7 @@ cmx_status Guard(F&& body) {
   X(rt2d_lds_kb)          /* LDS budget of a tile workgroup in KB */                               \
   X(rt2d_no_image_cache)  /* 1: grid images are always built into scratch of the call */           \
   X(rt2d_parts)           /* parts a large batch is issued in (0: default) */                      \
+  X(rt2d_parts_pool)      /* 1: the parts of a batch are planned and enqueued by host pool threads */ \
   X(rt2d_grid_share)      /* a part's tile grid and work items sized for its share of the CUs: 1 always, 2 never (0: by batch size) */ \
   X(rt2d_unfused)         /* 1: one-tile matches through the prep kernel too (parity partner) */   \
   X(rt2d_no_bounds)       /* 1: no block bounds, the tile kernel sums every candidate (parity partner) */ \

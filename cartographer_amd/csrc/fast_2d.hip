@@ -2680,6 +2680,16 @@ Fast2DMatcher::~Fast2DMatcher() {
   if (grid_cells_) (void)hipFree(grid_cells_);
 }
 
+void FillRotationTable(double step, int num_angular, float2* out) {
+  // delta_theta accumulates in f64, each angle is narrowed to f32 for AngleAxisf.
+  const int num_scans = 2 * num_angular + 1;
+  double delta_theta = -num_angular * step;
+  for (int s = 0; s < num_scans; ++s, delta_theta += step) {
+    const float ha = 0.5f * static_cast<float>(delta_theta);
+    out[s] = make_float2(std::cos(ha), std::sin(ha) * 1.f);
+  }
+}
+
 std::shared_ptr<const std::vector<float2>> HostRotationTable(double step, int num_angular) {
   struct Entry {
     double step;
@@ -2697,12 +2707,7 @@ std::shared_ptr<const std::vector<float2>> HostRotationTable(double step, int nu
   }
   const int num_scans = 2 * num_angular + 1;
   auto table = std::make_shared<std::vector<float2>>(num_scans);
-  // delta_theta accumulates in f64, each angle is narrowed to f32 for AngleAxisf.
-  double delta_theta = -num_angular * step;
-  for (int s = 0; s < num_scans; ++s, delta_theta += step) {
-    const float ha = 0.5f * static_cast<float>(delta_theta);
-    (*table)[s] = make_float2(std::cos(ha), std::sin(ha) * 1.f);
-  }
+  FillRotationTable(step, num_angular, table->data());
   std::lock_guard<std::mutex> lock(mu);
   if (cache->size() >= 64) cache->erase(cache->begin());      // bound the cache
   cache->push_back(Entry{step, num_angular, table});

@@ -731,9 +731,14 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count();
   };
   for (int h = 0; h < parts; ++h) {
+    part[h].begin = h ? part_end[h - 1] : 0;
+    part[h].end = part_end[h];
+  }
+  // (round 6, debug switch rt2d_parts_pool: the parts planned and enqueued by host pool threads,
+  // one each, instead of one after the other by the caller)
+  const auto issue_part = [&](int h) {
     Part& p = part[h];
-    p.begin = h ? part_end[h - 1] : 0;
-    p.end = part_end[h];
+    UseDevice(device);
     p.status = Guard([&] {
       const double t0 = since_call();
       plan_search(p.begin, p.end);
@@ -751,6 +756,11 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
                         "%.0f, plan %.0f, enqueued %.0f\n", h, p.end - p.begin, t0, t_search, t_plan, since_call());
     });
     if (p.status != CMX_OK) p.error = LastError();
+  };
+  if (Debug().rt2d_parts_pool && parts > 1) {
+    ParallelFor(parts, 2, issue_part);
+  } else {
+    for (int h = 0; h < parts; ++h) issue_part(h);
   }
   bool failed = false;
   for (int h = 0; h < parts; ++h) failed = failed || part[h].status != CMX_OK;

@@ -1787,23 +1787,6 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
   struct Off { size_t xyz, rot, cells; };
   std::vector<Off> off(num);
   size_t in_bytes = Align16(sizeof(Rt2DTileParams) * num);
-  // (rotation tables: one lookup per distinct (step, rotations) of the call)
-  std::vector<std::shared_ptr<const std::vector<float2>>> tables;
-  std::vector<int> table_of(num);
-  {
-    std::vector<std::pair<double, int>> keys;
-    for (int m = 0; m < num; ++m) {
-      const std::pair<double, int> key(search[m].step, search[m].na);
-      int k = static_cast<int>(keys.size()) - 1;
-      while (k >= 0 && keys[k] != key) --k;             // (usually the previous item's)
-      if (k < 0) {
-        k = static_cast<int>(keys.size());
-        keys.push_back(key);
-        tables.push_back(HostRotationTable(key.first, key.second));
-      }
-      table_of[m] = k;
-    }
-  }
   for (int m = 0; m < num; ++m) {
     const Rt2DItem& it = items[m];
     off[m].xyz = in_bytes;
@@ -1936,7 +1919,8 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
       const TileGeometry& g = geo[m];
       const size_t cell_count = static_cast<size_t>(it.limits->num_x_cells) * it.limits->num_y_cells;
       if (!it.device_xyz) std::memcpy(h_in + off[m].xyz, it.xyz, 3 * sizeof(float) * it.n);
-      std::memcpy(h_in + off[m].rot, tables[table_of[m]]->data(), sizeof(float2) * sr.num_scans);
+      // (the per-rotation (cos, sin) pairs: libm, straight into the staging buffer)
+      FillRotationTable(sr.step, sr.na, reinterpret_cast<float2*>(h_in + off[m].rot));
       if (!it.device_cells) std::memcpy(h_in + off[m].cells, it.cells, sizeof(uint16_t) * cell_count);
       Rt2DTileParams P{};
       P.cells = it.device_cells ? it.device_cells : reinterpret_cast<const uint16_t*>(d_in + off[m].cells);

@@ -160,6 +160,10 @@ class Fast2DMatcher {
 // into its own upload buffer, so no device allocation is shared between calls in flight
 // and nothing is ever freed on the hot path.
 std::shared_ptr<const std::vector<float2>> HostRotationTable(double step, int num_angular);
+// The same values written to out[0 .. 2 num_angular]: no cache, no lock (the real-time matcher:
+// every scan has a step of its own -- it depends on the scan's longest range -- so a cache keyed
+// by the step only ever misses, and its lock serialised the host threads of concurrent callers).
+void FillRotationTable(double step, int num_angular, float2* out);
 
 // The quantised image of a resident grid (rt_2d_tiles.hip, Rt2DQuantKernel): cells as 16-bit
 // q = (32767 - value) >> 5 with a zero halo, what the tile workgroups of the real-time matcher
