@@ -46,6 +46,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # HBM3E spec (6.3 TB/s achievable by a copy)
 L2_PEAK_GBS = 34500.0        # aggregate L2 -> L1
 LDS_PEAK_GBS = 150000.0      # ds_read_b64/b128, every CU streaming
+LDS_B32_PEAK_GBS = 75000.0   # ds_read_b32: half of it (the bound kernel's aligned dword reads)
 
 C3_SUBMAPS_PER_GPU = 64      # 512 submaps over the 8 GPUs of BASELINE config[2]
 C5_SUBMAPS_PER_GPU = 32      # 256 submaps over the 8 GPUs of BASELINE config[4]
@@ -102,7 +103,7 @@ def parse_args():
     ap.add_argument("--pmc-dir", default=os.path.join(ROOT, "profiles"),
                     help="directory with <tag>_pmc_{fetch,write}_size.csv of THIS command "
                          "(tools/profile_all.sh writes them); roofline.traffic is null without")
-    ap.add_argument("--pmc-tag", default="r05")
+    ap.add_argument("--pmc-tag", default="r06")
     ap.add_argument("--details", default=os.path.join(ROOT, "gpurun_out", "bench_details.json"),
                     help="file the FULL record goes to (per-config blocks, notes, nested "
                          "rooflines); the line on stdout is the compact headline (< 4 KB); "
@@ -549,19 +550,32 @@ class Fast2DWorkload:
                     "+ WRITE_SIZE of the same command / kernel time / 8 TB/s (null without the PMC "
                     "passes under --pmc-dir).  kernel_ms: HIP events on the kernel's own stream.",
         }
-        wave = expansion_roofline(
-            acc, steps, "ExpandWaveKernel (one wavefront per node: one quad gather per point)",
-            None if pmc_config is None else pmc("ExpandWave", pmc_config),
-            "achieved = lookups of the wave-per-node stages (64 per gather instruction issued, "
-            "counted by the kernel: nodes stop early once no child can reach the bound) / HIP-event "
-            "span of those launches / the measured gather-issue ceiling of the chip (coherent byte "
-            "gathers; the quad gathers here touch up to 64 distinct 128-byte lines each, so the "
-            "fraction is a lower bound of how close the stage is to what such gathers allow)")
-        if wave is not None and acc["expansion_ms"] > acc["dominant_kernel_ms"]:
-            wave["front_end"] = out      # batches: the expansion is the dominant kernel
-            return wave
-        if wave is not None:
-            out["expansion"] = wave
+        # The tree search behind the front end.  Single searches (fewer than four problems per
+        # call): ONE launch since round 6, TreeQueueKernel -- chains of best children per wavefront
+        # over a work queue; batches: the level-synchronous ExpandWaveKernel launches.  Priced
+        # against the chip's measured gather-issue ceiling, with SURVEY 8d's algorithmic bytes
+        # (N x 1 B per candidate scored below the lowest resolution) next to it.
+        queue = per_gpu < 4
+        tree = expansion_roofline(
+            acc, steps,
+            "TreeQueueKernel (branch and bound through a work queue: one quad gather per point and "
+            "expansion, chains of best children per wavefront)" if queue else
+            "ExpandWaveKernel (one wavefront per node: one quad gather per point)",
+            None if pmc_config is None else pmc("TreeQueue" if queue else "ExpandWave", pmc_config),
+            "achieved = lookups of the tree search (64 per gather instruction issued, counted by "
+            "the kernel: an expansion stops once no child can reach the bound) / HIP-event time of "
+            "the launch(es) / the measured gather-issue ceiling of the chip (coherent byte gathers; "
+            "a quad gather touches up to 64 distinct 128-byte lines, so the fraction is a lower "
+            "bound of how close the stage is to what such gathers allow).  algorithmic_bytes: "
+            "SURVEY 8d's N x 1 B per candidate scored below the lowest resolution"
+            + (" (the launch also takes and hands on nodes, selects the best leaf and publishes "
+               "the results)" if queue else " (all levels; the wave launches score the top ones)"),
+            algorithmic=(acc["candidates_scored"] - acc["coarse_candidates"]) / steps * self.n_points)
+        if tree is not None and acc["expansion_ms"] > acc["dominant_kernel_ms"]:
+            tree["front_end"] = out      # the tree search is the dominant kernel
+            return tree
+        if tree is not None:
+            out["expansion"] = tree
         return out
 
 
@@ -571,25 +585,31 @@ class Fast2DConcurrentWorkload(Fast2DWorkload):
     as the headline, which happens to be an easy search (its dive finds a tight bound at once);
     the headline itself cycles through `--scans` = 8 since round 6."""
 
-    def __init__(self, args, device, threads=8, scans=None):
+    def __init__(self, args, device, threads=8, scans=None, per_thread=16):
         sub = argparse.Namespace(**vars(args))
         sub.scans, sub.submaps = scans or threads, 0
         super().__init__(sub, device, 0, 1, sharded=False)
         from concurrent.futures import ThreadPoolExecutor
-        self.threads = threads
+        self.threads, self.per_thread = threads, per_thread
         self.pool = ThreadPoolExecutor(threads)
-        self.matches_per_step = threads
+        self.matches_per_step = threads * per_thread
 
     def search(self, k=0):
-        results = list(self.pool.map(lambda j: Fast2DWorkload.search(self, j), range(self.threads)))
-        self.last_results = results
-        found = np.concatenate([r[0] for r in results])
-        scores = np.concatenate([r[1] for r in results])
-        stats = dict(results[0][3])
-        for r in results[1:]:
+        """A step: every thread issues `per_thread` searches back to back (thread t: scans t,
+        t + 1, ...), as the headline's passes are issued -- one search per thread and step would
+        time the barrier between the steps."""
+        def worker(t):
+            return [Fast2DWorkload.search(self, t + j) for j in range(self.per_thread)]
+        per = list(self.pool.map(worker, range(self.threads)))
+        self.last_results = [r[0] for r in per]
+        flat = [r for rs in per for r in rs]
+        found = np.concatenate([r[0] for r in flat])
+        scores = np.concatenate([r[1] for r in flat])
+        stats = dict(flat[0][3])
+        for r in flat[1:]:
             for key, v in r[3].items():
                 stats[key] = stats.get(key, 0) + v
-        return found, scores, results[-1][2], stats
+        return found, scores, flat[-1][2], stats
 
     def parity(self, result):
         """Every one of the scans searched by the reference (one host thread each) against the
@@ -607,8 +627,8 @@ class Fast2DConcurrentWorkload(Fast2DWorkload):
 
     def describe(self, stats, found):
         out = super().describe(stats, found)
-        out["workload"] = (f"C2 over {len(self.clouds)} scan(s): {self.threads} searches per step, "
-                           f"issued from {self.threads} host threads; " + out["workload"])
+        out["workload"] = (f"C2 over {len(self.clouds)} scan(s): {self.matches_per_step} searches per "
+                           f"step, issued from {self.threads} host threads; " + out["workload"])
         return out
 
 
@@ -756,19 +776,22 @@ class Rt2DWorkload:
             nb = (side + 1) // 2
             lds = scans * self.points * (12.0 * nb + 8.0)
             return {"kernel": "Rt2DBoundKernel (2x2 block bounds from pooled byte planes in LDS + sums + finish)",
-                    "bound": "lds", "achieved": lds / secs / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
-                    "frac": lds / secs / 1e9 / LDS_PEAK_GBS,
+                    "bound": "lds", "achieved": lds / secs / 1e9, "peak": LDS_B32_PEAK_GBS, "unit": "GB/s",
+                    "frac": lds / secs / 1e9 / LDS_B32_PEAK_GBS,
                     "traffic": (pmc("Rt2DBound", "c1" if self.matches_per_step == 128 else "c1b1024")
                                 if self.matches_per_step in (128, 1024) and self.grid_side == 200
                                 and not self.dirty else None),
                     "kernel_ms": k_ms, "algorithmic_bytes": alg, "lds_bytes": lds,
+                    # (calls of 256 matches and more go out in two or three PARTS on streams of
+                    # their own: kernel_ms is the SUM of their launches' durations, which overlap)
+                    "kernel_ms_is_sum_of_concurrent_parts": self.matches_per_step >= 256,
                     "algorithmic_GBps": alg / secs / 1e9,
                     "hbm_frac_algorithmic": alg / secs / 1e9 / HBM_PEAK_GBS,
                     "candidates_per_s_kernel": cand / secs,
                     "summed_candidates_per_s_kernel": summed / secs,
                     "note": "block bounds: frac = LDS bytes of the bound kernel's row reads / its "
                             "HIP-event time (staging, the surviving blocks' sums and the finish of "
-                            "every match included) / 150 TB/s; algorithmic bytes stay SURVEY 8d's "
+                            "every match included) / 75 TB/s (the LDS peak of dword reads); algorithmic bytes stay SURVEY 8d's "
                             "2 B per candidate of the SEARCH SPACE per point (what the reference "
                             "reads), of which the device reads a fraction: "
                             "summed_candidates = block bounds + candidates of surviving blocks"}
@@ -863,7 +886,13 @@ class Rt2DTsdfWorkload:
         return {"kernel": "Rt2DScoreKernel<tsdf> (one thread per candidate, sequential f32 chains)",
                 "bound": "gather-issue", "achieved": lookups / secs / 1e9, "peak": GATHER_PEAK_GLOOKUPS,
                 "unit": "Glookup/s", "frac": lookups / secs / 1e9 / GATHER_PEAK_GLOOKUPS,
-                "traffic": None, "kernel_ms": k_ms, "algorithmic_bytes": cand * self.n_points * 4.0}
+                "traffic": None, "kernel_ms": k_ms, "algorithmic_bytes": cand * self.n_points * 4.0,
+                "algorithmic_GBps": cand * self.n_points * 4.0 / secs / 1e9,
+                "hbm_frac_algorithmic": cand * self.n_points * 4.0 / secs / 1e9 / HBM_PEAK_GBS,
+                "note": "frac = lookups / kernel time / the builder-measured gather-issue ceiling "
+                        "(tools/gather_ceiling.hip); SURVEY 8d's ratio next to it: "
+                        "hbm_frac_algorithmic = 4 B per candidate and point / kernel time / 8 TB/s "
+                        "(the planes are on-chip)"}
 
 
 class Rt2DPipelinedWorkload(Rt2DWorkload):
@@ -1240,24 +1269,32 @@ GATHER_PEAK_GLOOKUPS = 2050.0   # measured: 19 cycles per 64-lane gather instruc
                                 # (profiles/r02_rt3d_gather_ceiling.txt) x 256 CUs x 2.4 GHz
 
 
-def expansion_roofline(acc, steps, kernel, traffic, note):
-    """The level-synchronous branch-and-bound expansion launches (fast 2D: ExpandWaveKernel,
-    fast 3D: Expand3DKernel), priced against the rate at which the chip issues wave-wide
-    gathers.  None when the call timed none."""
+def expansion_roofline(acc, steps, kernel, traffic, note, algorithmic=None):
+    """The branch-and-bound expansion launches (fast 2D: TreeQueueKernel / ExpandWaveKernel, fast
+    3D: Expand3DKernel), priced against the rate at which the chip issues wave-wide gathers --
+    a builder-measured ceiling (tools/gather_ceiling.hip), so SURVEY 8d's algorithmic bytes over
+    the HBM peak are printed next to it.  None when the call timed none."""
     launches = acc["expansion_launches"] / steps
     if launches <= 0 or acc["expansion_ms"] <= 0:
         return None
     span_ms = acc["expansion_ms"] / steps
     lookups = acc["expansion_lookups"] / steps
     secs = span_ms * 1e-3
-    return {"kernel": kernel, "bound": "gather-issue", "achieved": lookups / secs / 1e9,
-            "peak": GATHER_PEAK_GLOOKUPS, "unit": "Glookup/s",
-            "frac": lookups / secs / 1e9 / GATHER_PEAK_GLOOKUPS, "traffic": traffic,
-            "launches_per_step": launches, "kernel_ms": span_ms / launches,
-            "span_ms_per_step": span_ms, "nodes_per_step": acc["expansion_nodes"] / steps,
-            "lookups_per_step": lookups,
-            "kernel_share_of_step_device_time": acc["expansion_ms"] / max(acc["device_ms"], 1e-9),
-            "note": note}
+    out = {"kernel": kernel, "bound": "gather-issue", "achieved": lookups / secs / 1e9,
+           "peak": GATHER_PEAK_GLOOKUPS, "unit": "Glookup/s",
+           "frac": lookups / secs / 1e9 / GATHER_PEAK_GLOOKUPS, "traffic": traffic,
+           "launches_per_step": launches, "kernel_ms": span_ms / launches,
+           "span_ms_per_step": span_ms, "nodes_per_step": acc["expansion_nodes"] / steps,
+           "lookups_per_step": lookups,
+           "kernel_share_of_step_device_time": acc["expansion_ms"] / max(acc["device_ms"], 1e-9),
+           "note": note}
+    if algorithmic is not None:
+        out["algorithmic_bytes"] = algorithmic
+        out["algorithmic_GBps"] = algorithmic / secs / 1e9
+        out["hbm_frac_algorithmic"] = algorithmic / secs / 1e9 / HBM_PEAK_GBS
+        out["hbm_frac_traffic"] = (None if traffic is None else
+                                   traffic / secs / 1e9 / HBM_PEAK_GBS)
+    return out
 
 
 def set_timing(on):
@@ -1365,7 +1402,7 @@ def other_configs(args, device, sync, pmc):
     run("c1_batch1024_dirty", lambda: Rt2DWorkload(args, device, matches=1024, dirty=True), 15, 3)
     run("c1_batch128_8_threads", lambda: Rt2DPipelinedWorkload(args, device, 128, 8, 4), 25, 5)
     run("c1_tsdf", lambda: Rt2DTsdfWorkload(args, device), 30, 5)
-    run("c2_easy", lambda: Fast2DConcurrentWorkload(args, device, 8, scans=1), 100, 10)
+    run("c2_easy", lambda: Fast2DConcurrentWorkload(args, device, 8, scans=1), 40, 5)
     sub = argparse.Namespace(**vars(args))
     sub.submaps = 16
     run("c3_share_16_submaps", lambda: Fast2DWorkload(sub, device, 0, 1, sharded=True), 5, 2)

@@ -3218,7 +3218,8 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
           batch.d_problems, batch.d_states, n, 0, 1, /*strict=*/0, /*affinity=*/0, front(0),
           d_counters);
       mark("filter");
-      const bool timed = num >= 4;
+      // (events only under the debug switch `timing`: RecordEvent is a no-op otherwise)
+      const bool timed = true;
       if (timed) RecordEvent(ws.ev_x0, ws.stream);
       // One workgroup per CU: 1024 wavefronts.  More of them shorten a single hard search (512
       // workgroups: 240 against 290 us on the hardest of the bench's eight scans) and cost the
