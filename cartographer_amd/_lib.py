@@ -166,6 +166,7 @@ EXPORTED_SYMBOLS = [
     "cmx_fast2d_match_sharded", "cmx_fast3d_match_sharded", "cmx_shard_range",
     "cmx_pack_best_key", "cmx_unpack_best_key",
     "cmx_voxel_filter", "cmx_voxel_filter_indices", "cmx_adaptive_voxel_filter",
+    "cmx_adaptive_voxel_filter_indices",
     "cmx_compute_histogram",
     "cmx_intensity_grid3d_create", "cmx_intensity_grid3d_destroy",
     "cmx_grid3d_insert_with_intensities", "cmx_intensity_grid3d_download",
@@ -288,6 +289,8 @@ def lib():
                                            C.c_void_p, P(C.c_int32)]
     L.cmx_adaptive_voxel_filter.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float,
                                             C.c_float, C.c_int32, C.c_void_p, P(C.c_int32)]
+    L.cmx_adaptive_voxel_filter_indices.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float,
+                                                    C.c_float, C.c_int32, C.c_void_p, P(C.c_int32)]
     L.cmx_compute_histogram.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     L.cmx_comm_init.argtypes = [C.c_void_p, C.c_int32, P(C.c_void_p)]
     L.cmx_comm_destroy.argtypes = [C.c_void_p]

@@ -100,6 +100,7 @@ cmx_status Guard(F&& body) {
   X(fast2d_queue_blocks)  /* workgroups of the work-queue tree search (0: default) */              \
   X(fast2d_queue_capacity) /* nodes per sub-queue (tests: forces the overflow path) */             \
   X(fast2d_queue_lost)    /* lost races after which a wavefront stops looking for work (0: 3) */   \
+  X(filters_generic)      /* 1: voxel filters of small clouds through the multi-launch path too */ \
   X(fast3d_byte_loads)    /* 1: every child cell with its own byte load */                         \
   X(fast3d_affinity)      /* 1: nodes of a problem on any XCD, 2: on one */                        \
   X(fast3d_no_families)   /* 1: one node per block in the 3D expansion */                          \

@@ -24,6 +24,8 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cmath>
+#include <cstring>
+#include <mutex>
 
 #include "cmx_atan2f.h"
 #include "cmx_common.h"
@@ -164,6 +166,13 @@ __global__ void CompactIndexKernel(const int* __restrict__ used, const int* __re
   if (i < n && used[i]) out[offset[i]] = i;
 }
 
+// out[offset[i]] = map[i] for the kept i: the kept points' indices in the cloud `map` refers to.
+__global__ void CompactMappedIndexKernel(const int* __restrict__ used, const int* __restrict__ offset,
+                                         int n, const int* __restrict__ map, int* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && used[i]) out[offset[i]] = map[i];
+}
+
 // Scratch of one filter call, carved from a workspace.
 struct FilterScratch {
   unsigned long long *keys = nullptr, *keys_sorted = nullptr;
@@ -238,6 +247,355 @@ void Compact(Workspace& ws, const FilterScratch& s, const float* d_xyz, int n, f
   if (n == 0) return;
   CompactKernel<<<DivUp(n, 256), 256, 0, ws.stream>>>(d_xyz, s.used, s.offset, n, d_out);
 }
+
+// ---------------------------------------------------------------------------
+// Small clouds (round 6): the whole filter in ONE workgroup.
+// The local trajectory builders filter clouds of 10^2 - 10^3 points (adaptive filter:
+// min_num_points 200 / 150, configuration_files/trajectory_builder_2d.lua:26-28), and a call of
+// the generic path above is ~13 launches, three small read-backs and two synchronisations per
+// VoxelFilter -- 0.14 ms of host time for 0.04 ms of kernels, five to ten times over for an
+// AdaptiveVoxelFilter, whose next length depends on the previous count.  Up to kSmallCloud
+// points the same steps run out of LDS in one workgroup: bitonic sort of (key, index), segment
+// heads, ranks, the prefix sum of the draws, the draws, the reservoir's last writer, the prefix
+// sum of the kept flags -- and the adaptive filter's whole search (voxel_filter.cc:38-75), the
+// lengths decided by the workgroup itself.  One launch, one synchronisation, the result stored
+// straight into pinned host memory.  Same arithmetic, same point sets (tests: both paths against
+// the oracle and each other).
+// ---------------------------------------------------------------------------
+constexpr int kSmallCloud = 4096;
+constexpr int kSmallThreads = 1024;
+
+struct SmallFilterLds {       // carved from dynamic LDS; N = the cloud's size rounded up to a power of two
+  unsigned long long* key;    // [N]
+  unsigned* idx;              // [N]
+  int *seg, *rank, *voxel, *pos, *selected;   // [N] each
+  int* used;                  // = seg: the segment starts are dead when the flags are written
+  int* wave_totals;           // [kSmallThreads / 64]
+};
+// (N = 4096: 128 KB of arrays + the kernel's 20 KB active list and result flags: under the 160 KB)
+__host__ __device__ inline size_t SmallFilterLdsBytes(int N) {
+  return static_cast<size_t>(N) * (8 + 4 + 5 * 4) + 64 * 4 + 64;
+}
+__device__ __forceinline__ SmallFilterLds CarveSmall(unsigned char* base, int N) {
+  SmallFilterLds L;
+  L.key = reinterpret_cast<unsigned long long*>(base); base += static_cast<size_t>(N) * 8;
+  L.idx = reinterpret_cast<unsigned*>(base); base += static_cast<size_t>(N) * 4;
+  int** ints[] = {&L.seg, &L.rank, &L.voxel, &L.pos, &L.selected};
+  for (int** p : ints) { *p = reinterpret_cast<int*>(base); base += static_cast<size_t>(N) * 4; }
+  L.used = L.seg;
+  L.wave_totals = reinterpret_cast<int*>(base);
+  return L;
+}
+
+// In place: data[i] <- sum of data[0 .. i - 1] (i < n <= 4 x blockDim); returns the total.
+// Thread t owns elements 4 t .. 4 t + 3.
+__device__ __forceinline__ int BlockExclusiveScan4(int* data, int n, int* wave_totals) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int v[4], sum = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = 4 * t + k;
+    v[k] = i < n ? data[i] : 0;
+    sum += v[k];
+  }
+  int incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) wave_totals[wave] = incl;
+  __syncthreads();
+  int before = incl - sum;
+  int total = 0;
+  for (int w = 0; w < static_cast<int>(blockDim.x >> 6); ++w) {
+    const int wt = wave_totals[w];
+    if (w < wave) before += wt;
+    total += wt;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = 4 * t + k;
+    if (i < n) data[i] = before;
+    before += v[k];
+  }
+  __syncthreads();
+  return total;
+}
+
+// In place inclusive MAX scan (segment starts from head-or-zero flags), same ownership.
+__device__ __forceinline__ void BlockInclusiveMaxScan4(int* data, int n, int* wave_totals) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int v[4], top = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = 4 * t + k;
+    v[k] = i < n ? data[i] : 0;
+    top = max(top, v[k]);
+    v[k] = top;                          // running maximum inside the thread
+  }
+  int incl = top;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl = max(incl, o);
+  }
+  if (lane == 63) wave_totals[wave] = incl;
+  __syncthreads();
+  int before = __shfl_up(incl, 1, 64);
+  if (lane == 0) before = 0;
+  for (int w = 0; w < wave; ++w) before = max(before, wave_totals[w]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = 4 * t + k;
+    if (i < n) data[i] = max(v[k], before);
+  }
+  __syncthreads();
+}
+
+// RandomizedVoxelFilterIndices (voxel_filter.cc:88-131) of the n <= N points xyz[src[i]] (src:
+// LDS or null = identity): L.used[i] = 1 for the kept ones, L.pos[i] = their exclusive prefix
+// sum; returns the number kept.  Every thread of the workgroup calls it.
+__device__ int SmallVoxelFilter(const float* __restrict__ xyz, const int* src, int n, int N,
+                                float resolution, const SmallFilterLds& L, int* rejected_flag) {
+  const int t = threadIdx.x, T = blockDim.x;
+  // 1. keys, padded with the largest key (sorted behind every point)
+  for (int i = t; i < N; i += T) {
+    unsigned long long key = ~0ull;
+    if (i < n) {
+      const int at = src ? src[i] : i;
+      const unsigned long long x = static_cast<unsigned long long>(
+          static_cast<long long>(LRoundF32(xyz[3 * at] / resolution)));
+      const unsigned long long y = static_cast<unsigned long long>(
+          static_cast<long long>(LRoundF32(xyz[3 * at + 1] / resolution)));
+      const unsigned long long z = static_cast<unsigned long long>(
+          static_cast<long long>(LRoundF32(xyz[3 * at + 2] / resolution)));
+      key = (x << 42) + (y << 21) + z;
+    }
+    L.key[i] = key;
+    L.idx[i] = static_cast<unsigned>(i);
+  }
+  if (t == 0) *rejected_flag = 0;
+  __syncthreads();
+  // 2. bitonic sort by (key, index): indices are distinct, so this is the stable sort by key
+  for (int k = 2; k <= N; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < N; i += T) {
+        const int partner = i ^ j;
+        if (partner > i) {
+          const unsigned long long ka = L.key[i], kb = L.key[partner];
+          const unsigned ia = L.idx[i], ib = L.idx[partner];
+          const bool greater = ka > kb || (ka == kb && ia > ib);
+          const bool ascending = (i & k) == 0;
+          if (greater == ascending) {
+            L.key[i] = kb; L.key[partner] = ka;
+            L.idx[i] = ib; L.idx[partner] = ia;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // 3. segment starts (sorted position p: its own position if it opens a voxel, else 0; max-scan)
+  for (int p = t; p < n; p += T) L.seg[p] = (p > 0 && L.key[p] != L.key[p - 1]) ? p : 0;
+  __syncthreads();
+  BlockInclusiveMaxScan4(L.seg, n, L.wave_totals);
+  // 4. back to point order: k (1-based position in the voxel), the voxel (= segment start), the
+  //    draw flag; the voxel's reservoir cleared
+  for (int p = t; p < n; p += T) {
+    const int i = static_cast<int>(L.idx[p]);
+    const int k = p - L.seg[p] + 1;
+    L.rank[i] = k;
+    L.voxel[i] = L.seg[p];
+    L.pos[i] = k >= 2 ? 1 : 0;
+    if (k == 1) L.selected[p] = -1;
+  }
+  __syncthreads();
+  // 5. stream position of every draw, the draws, the reservoir's last writer
+  BlockExclusiveScan4(L.pos, n, L.wave_totals);
+  for (int i = t; i < n; i += T) {
+    const int k = L.rank[i];
+    bool replace = true;
+    if (k >= 2) {
+      const unsigned long long ret = MinstdOutput(static_cast<unsigned long long>(L.pos[i]) + 1) - 1;
+      const unsigned long long scaling = kUrngRange / static_cast<unsigned long long>(k);
+      if (ret >= static_cast<unsigned long long>(k) * scaling) {
+        *rejected_flag = 1;
+        replace = false;
+      } else {
+        replace = ret / scaling == static_cast<unsigned long long>(k - 1);
+      }
+    }
+    if (replace) atomicMax(&L.selected[L.voxel[i]], i);
+  }
+  __syncthreads();
+  if (*rejected_flag) {
+    // a draw was rejected (probability < k / 2^31 each) and shifts every later stream position:
+    // one lane replays the generator in point order (SequentialDrawKernel)
+    if (t == 0) {
+      unsigned state = 1u;
+      for (int i = 0; i < n; ++i) {
+        const int k = L.rank[i];
+        if (k >= 2) {
+          const unsigned long long scaling = kUrngRange / static_cast<unsigned long long>(k);
+          const unsigned long long past = static_cast<unsigned long long>(k) * scaling;
+          unsigned long long ret;
+          do {
+            state = MulMod(state, kMinstdA);
+            ret = state - 1u;
+          } while (ret >= past);
+          if (ret / scaling == static_cast<unsigned long long>(k - 1)) L.selected[L.voxel[i]] = i;
+        } else {
+          L.selected[L.voxel[i]] = i;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // 6. points_used and their prefix sum
+  for (int i = t; i < n; i += T) {
+    const int u = L.selected[L.voxel[i]] == i ? 1 : 0;
+    L.used[i] = u;
+    L.pos[i] = u;
+  }
+  __syncthreads();
+  return BlockExclusiveScan4(L.pos, n, L.wave_totals);
+}
+
+// mode 0: VoxelFilter(resolution = length);  mode 1: AdaptiveVoxelFilter(max_length = length,
+// min_num_points, max_range).  out[0] = number kept, out[1 ..] = their indices in the input
+// (ascending), then (out_xyz) their coordinates: pinned host memory.
+__global__ void __launch_bounds__(kSmallThreads)
+SmallFilterKernel(const float* __restrict__ xyz, int n0, int N, int mode, float length,
+                  float min_num_points, float max_range, int* __restrict__ out,
+                  float* __restrict__ out_xyz) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char small_smem[];
+  const SmallFilterLds L = CarveSmall(small_smem, N);
+  // behind the filter's arrays: the active list (adaptive: the points in range), the best
+  // result so far as flags, three control words
+  int* src = L.wave_totals + 64;
+  unsigned char* best_used = reinterpret_cast<unsigned char*>(src + N);
+  __shared__ int rejected, ctl_n, ctl_state;
+  __shared__ float ctl_length;
+  const int t = threadIdx.x, T = blockDim.x;
+  int n = n0;
+  const int* active = nullptr;
+  if (mode == 1) {
+    // FilterByMaxRange (voxel_filter.cc:30-36)
+    for (int i = t; i < n0; i += T) {
+      const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+      const int u = sqrtf((x * x + y * y) + z * z) <= max_range ? 1 : 0;   // position.norm()
+      L.used[i] = u;
+      L.pos[i] = u;
+    }
+    __syncthreads();
+    n = BlockExclusiveScan4(L.pos, n0, L.wave_totals);
+    for (int i = t; i < n0; i += T)
+      if (L.used[i]) src[L.pos[i]] = i;
+    __syncthreads();
+    active = src;
+  }
+  int kept = n;
+  bool have_flags = false;             // false: every active point is kept
+  if (mode == 0) {
+    kept = SmallVoxelFilter(xyz, active, n, N, length, L, &rejected);
+    for (int i = t; i < n; i += T) best_used[i] = static_cast<unsigned char>(L.used[i]);
+    have_flags = true;
+    __syncthreads();
+  } else if (!(static_cast<float>(n) <= min_num_points)) {
+    // AdaptivelyVoxelFiltered (voxel_filter.cc:38-75): the same sequence of VoxelFilter calls;
+    // every thread walks the same control flow (counts come back uniform).
+    const auto evaluate = [&](float len, bool accept_always, int* count) {
+      const int m = SmallVoxelFilter(xyz, active, n, N, len, L, &rejected);
+      *count = m;
+      const bool accept = accept_always || static_cast<float>(m) >= min_num_points;
+      if (accept) {
+        for (int i = t; i < n; i += T) best_used[i] = static_cast<unsigned char>(L.used[i]);
+        __syncthreads();
+      }
+      return accept;
+    };
+    int m = 0;
+    bool done = false;
+    evaluate(length, true, &m);                      // result = VoxelFilter(cloud, max_length)
+    kept = m;
+    have_flags = true;
+    if (static_cast<float>(m) >= min_num_points) done = true;
+    for (float high_length = length; !done && high_length > 1e-2f * length; high_length /= 2.f) {
+      float low_length = high_length / 2.f;
+      evaluate(low_length, true, &m);                // result = VoxelFilter(cloud, low_length)
+      kept = m;
+      if (static_cast<float>(m) >= min_num_points) {
+        while ((high_length - low_length) / low_length > 1e-1f) {
+          const float mid_length = (low_length + high_length) / 2.f;
+          if (evaluate(mid_length, false, &m)) {
+            low_length = mid_length;
+            kept = m;
+          } else {
+            high_length = mid_length;
+          }
+        }
+        done = true;
+      }
+    }
+  }
+  (void)ctl_n; (void)ctl_state; (void)ctl_length;
+  // ---- the result: indices into the input, ascending, and the points -------------------------
+  for (int i = t; i < n; i += T) {
+    const int u = have_flags ? best_used[i] : 1;
+    L.used[i] = u;
+    L.pos[i] = u;
+  }
+  __syncthreads();
+  const int total = BlockExclusiveScan4(L.pos, n, L.wave_totals);
+  for (int i = t; i < n; i += T) {
+    if (!L.used[i]) continue;
+    const int at = active ? active[i] : i;
+    const int o = L.pos[i];
+    out[1 + o] = at;
+    if (out_xyz) {
+      out_xyz[3 * o] = xyz[3 * at];
+      out_xyz[3 * o + 1] = xyz[3 * at + 1];
+      out_xyz[3 * o + 2] = xyz[3 * at + 2];
+    }
+  }
+  if (t == 0) out[0] = total;
+  (void)kept;
+}
+
+// Host side of the small-cloud path: one upload, one launch, one synchronisation.  `filtered_xyz`
+// and `kept_indices` may each be null.
+void SmallFilter(int mode, const float* point_cloud_xyz, int n, float length, float min_num_points,
+                 float max_range, int device, float* filtered_xyz, int32_t* kept_indices,
+                 int32_t* num_filtered) {
+  WorkspaceLease ws(device);
+  int N = 64;
+  while (N < n) N <<= 1;
+  const size_t lds = SmallFilterLdsBytes(N) + static_cast<size_t>(N) * 5 + 64;
+  OptInLds(reinterpret_cast<const void*>(SmallFilterKernel), device, 160 * 1024 - 256);
+  // pinned: the cloud up | count + indices | points down
+  const size_t in_bytes = (12 * static_cast<size_t>(n) + 255) & ~size_t{255};
+  const size_t idx_bytes = (4 * static_cast<size_t>(n + 1) + 255) & ~size_t{255};
+  char* h = ws->pinned[0].ReserveAs<char>(in_bytes + idx_bytes + in_bytes);
+  std::memcpy(h, point_cloud_xyz, 12 * static_cast<size_t>(n));
+  float* d_xyz = ws->dev[0].ReserveAs<float>(3 * static_cast<size_t>(n) + 64);
+  SmallCopyAsync(d_xyz, h, in_bytes, /*to_device=*/true, ws->stream);
+  int* h_out = reinterpret_cast<int*>(h + in_bytes);
+  float* h_xyz = reinterpret_cast<float*>(h + in_bytes + idx_bytes);
+  SmallFilterKernel<<<1, kSmallThreads, lds, ws->stream>>>(d_xyz, n, N, mode, length, min_num_points,
+                                                           max_range, h_out, filtered_xyz ? h_xyz : nullptr);
+  CMX_HIP(hipGetLastError());
+  CMX_HIP(hipStreamSynchronize(ws->stream));
+  const int kept = h_out[0];
+  CMX_REQUIRE(kept >= 0 && kept <= n, "internal error: small filter count %d of %d", kept, n);
+  if (kept_indices) std::memcpy(kept_indices, h_out + 1, 4 * static_cast<size_t>(kept));
+  if (filtered_xyz) std::memcpy(filtered_xyz, h_xyz, 12 * static_cast<size_t>(kept));
+  *num_filtered = kept;
+}
+
+// (debug switch filters_generic = 1: every cloud through the multi-launch path -- the parity
+// partner of the one-workgroup path)
+bool UseSmallFilter(int n) { return n >= 1 && n <= kSmallCloud && Debug().filters_generic == 0; }
 
 // ---------------------------------------------------------------------------
 // RotationalScanMatcher::ComputeHistogram
@@ -512,8 +870,13 @@ cmx_status cmx_voxel_filter(const float* point_cloud_xyz, int32_t num_points, fl
                 "bad argument");
     CMX_REQUIRE(resolution > 0.f, "resolution must be > 0");
     *num_filtered = 0;
-    cmx::WorkspaceLease ws(device);
     if (num_points == 0) return;
+    if (cmx::UseSmallFilter(num_points)) {
+      cmx::SmallFilter(0, point_cloud_xyz, num_points, resolution, 0.f, 0.f, device, filtered_xyz,
+                       nullptr, num_filtered);
+      return;
+    }
+    cmx::WorkspaceLease ws(device);
     const int n = num_points;
     float* d_xyz = ws->dev[0].ReserveAs<float>(6 * static_cast<size_t>(n));
     float* d_out = d_xyz + 3 * static_cast<size_t>(n);
@@ -538,8 +901,13 @@ cmx_status cmx_voxel_filter_indices(const float* point_cloud_xyz, int32_t num_po
                 "bad argument");
     CMX_REQUIRE(resolution > 0.f, "resolution must be > 0");
     *num_filtered = 0;
-    cmx::WorkspaceLease ws(device);
     if (num_points == 0) return;
+    if (cmx::UseSmallFilter(num_points)) {
+      cmx::SmallFilter(0, point_cloud_xyz, num_points, resolution, 0.f, 0.f, device, nullptr,
+                       kept_indices, num_filtered);
+      return;
+    }
+    cmx::WorkspaceLease ws(device);
     const int n = num_points;
     // dev[0]: the cloud | the kept indices
     float* d_xyz = ws->dev[0].ReserveAs<float>(4 * static_cast<size_t>(n));
@@ -556,75 +924,120 @@ cmx_status cmx_voxel_filter_indices(const float* point_cloud_xyz, int32_t num_po
   });
 }
 
+namespace cmx {
+namespace {
+// sensor::AdaptiveVoxelFilter; the kept points (`filtered_xyz`, may be null) and / or their
+// indices in the input (`kept_indices`, may be null), ascending.
+void AdaptiveVoxelFilterImpl(const float* point_cloud_xyz, int32_t num_points, float max_length,
+                             float min_num_points, float max_range, int32_t device,
+                             float* filtered_xyz, int32_t* kept_indices, int32_t* num_filtered) {
+  CMX_REQUIRE(num_points >= 0 && num_points <= (1 << 26) && (filtered_xyz || kept_indices) &&
+                  num_filtered && (point_cloud_xyz || num_points == 0),
+              "bad argument");
+  CMX_REQUIRE(max_length > 0.f, "max_length must be > 0");
+  *num_filtered = 0;
+  if (num_points == 0) return;
+  if (UseSmallFilter(num_points)) {
+    SmallFilter(1, point_cloud_xyz, num_points, max_length, min_num_points, max_range, device,
+                filtered_xyz, kept_indices, num_filtered);
+    return;
+  }
+  WorkspaceLease ws(device);
+  const int n0 = num_points;
+  // dev[0]: raw cloud | in-range cloud | result | candidate | the same three as index lists.
+  float* d_raw = ws->dev[0].ReserveAs<float>(15 * static_cast<size_t>(n0));
+  float* d_in = d_raw + 3 * static_cast<size_t>(n0);
+  float* d_result = d_in + 3 * static_cast<size_t>(n0);
+  float* d_candidate = d_result + 3 * static_cast<size_t>(n0);
+  int* i_in = reinterpret_cast<int*>(d_candidate + 3 * static_cast<size_t>(n0));
+  int* i_result = i_in + n0;
+  int* i_candidate = i_result + n0;
+  const bool indices = kept_indices != nullptr;
+  hipStream_t st = ws->stream;
+  CMX_HIP(hipMemcpyAsync(d_raw, point_cloud_xyz, 12 * static_cast<size_t>(n0),
+                         hipMemcpyHostToDevice, st));
+  const FilterScratch s = Carve(*ws, n0);
+  // FilterByMaxRange.
+  RangeFlagKernel<<<DivUp(n0, 256), 256, 0, st>>>(d_raw, n0, max_range, s.used);
+  size_t bytes = s.temp_bytes;
+  CMX_HIP(hipcub::DeviceScan::ExclusiveSum(s.temp, bytes, s.used, s.offset, n0, st));
+  Compact(*ws, s, d_raw, n0, d_in);
+  if (indices) CompactIndexKernel<<<DivUp(n0, 256), 256, 0, st>>>(s.used, s.offset, n0, i_in);
+  int last_used = 0, last_offset = 0;
+  CMX_HIP(hipMemcpyAsync(&last_used, s.used + (n0 - 1), 4, hipMemcpyDeviceToHost, st));
+  CMX_HIP(hipMemcpyAsync(&last_offset, s.offset + (n0 - 1), 4, hipMemcpyDeviceToHost, st));
+  CMX_HIP(hipStreamSynchronize(st));
+  const int n = last_used + last_offset;
+  const float* d_final = d_in;
+  const int* i_final = i_in;
+  int kept = n;
+  // AdaptivelyVoxelFiltered (voxel_filter.cc:38-75): the same sequence of VoxelFilter calls.
+  const auto filter = [&](float length, float* d_out, int* i_out) {
+    const int m = VoxelFilterFlags(*ws, s, d_in, n, length);
+    Compact(*ws, s, d_in, n, d_out);
+    if (indices && n > 0)
+      CompactMappedIndexKernel<<<DivUp(n, 256), 256, 0, st>>>(s.used, s.offset, n, i_in, i_out);
+    return m;
+  };
+  if (!(static_cast<float>(n) <= min_num_points)) {
+    bool done = false;
+    kept = filter(max_length, d_result, i_result);
+    d_final = d_result;
+    i_final = i_result;
+    if (static_cast<float>(kept) >= min_num_points) done = true;
+    for (float high_length = max_length; !done && high_length > 1e-2f * max_length;
+         high_length /= 2.f) {
+      float low_length = high_length / 2.f;
+      kept = filter(low_length, d_result, i_result);
+      if (static_cast<float>(kept) >= min_num_points) {
+        while ((high_length - low_length) / low_length > 1e-1f) {
+          const float mid_length = (low_length + high_length) / 2.f;
+          const int m = filter(mid_length, d_candidate, i_candidate);
+          if (static_cast<float>(m) >= min_num_points) {
+            low_length = mid_length;
+            std::swap(d_result, d_candidate);
+            std::swap(i_result, i_candidate);
+            d_final = d_result;
+            i_final = i_result;
+            kept = m;
+          } else {
+            high_length = mid_length;
+          }
+        }
+        done = true;
+      }
+    }
+  }
+  if (filtered_xyz)
+    CMX_HIP(hipMemcpyAsync(filtered_xyz, d_final, 12 * static_cast<size_t>(kept),
+                           hipMemcpyDeviceToHost, st));
+  if (indices)
+    CMX_HIP(hipMemcpyAsync(kept_indices, i_final, 4 * static_cast<size_t>(kept),
+                           hipMemcpyDeviceToHost, st));
+  CMX_HIP(hipStreamSynchronize(st));
+  *num_filtered = kept;
+}
+}  // namespace
+}  // namespace cmx
+
 cmx_status cmx_adaptive_voxel_filter(const float* point_cloud_xyz, int32_t num_points,
                                      float max_length, float min_num_points, float max_range,
                                      int32_t device, float* filtered_xyz, int32_t* num_filtered) {
   return Guard([&] {
-    CMX_REQUIRE(num_points >= 0 && num_points <= (1 << 26) && filtered_xyz && num_filtered &&
-                    (point_cloud_xyz || num_points == 0),
-                "bad argument");
-    CMX_REQUIRE(max_length > 0.f, "max_length must be > 0");
-    *num_filtered = 0;
-    cmx::WorkspaceLease ws(device);
-    if (num_points == 0) return;
-    const int n0 = num_points;
-    // dev[0]: raw cloud | in-range cloud | result | candidate.
-    float* d_raw = ws->dev[0].ReserveAs<float>(12 * static_cast<size_t>(n0));
-    float* d_in = d_raw + 3 * static_cast<size_t>(n0);
-    float* d_result = d_in + 3 * static_cast<size_t>(n0);
-    float* d_candidate = d_result + 3 * static_cast<size_t>(n0);
-    hipStream_t st = ws->stream;
-    CMX_HIP(hipMemcpyAsync(d_raw, point_cloud_xyz, 12 * static_cast<size_t>(n0),
-                           hipMemcpyHostToDevice, st));
-    const cmx::FilterScratch s = cmx::Carve(*ws, n0);
-    // FilterByMaxRange.
-    cmx::RangeFlagKernel<<<cmx::DivUp(n0, 256), 256, 0, st>>>(d_raw, n0, max_range, s.used);
-    size_t bytes = s.temp_bytes;
-    CMX_HIP(hipcub::DeviceScan::ExclusiveSum(s.temp, bytes, s.used, s.offset, n0, st));
-    cmx::Compact(*ws, s, d_raw, n0, d_in);
-    int last_used = 0, last_offset = 0;
-    CMX_HIP(hipMemcpyAsync(&last_used, s.used + (n0 - 1), 4, hipMemcpyDeviceToHost, st));
-    CMX_HIP(hipMemcpyAsync(&last_offset, s.offset + (n0 - 1), 4, hipMemcpyDeviceToHost, st));
-    CMX_HIP(hipStreamSynchronize(st));
-    const int n = last_used + last_offset;
-    const float* d_final = d_in;
-    int kept = n;
-    // AdaptivelyVoxelFiltered (voxel_filter.cc:38-75): the same sequence of VoxelFilter calls.
-    const auto filter = [&](float length, float* d_out) {
-      const int m = cmx::VoxelFilterFlags(*ws, s, d_in, n, length);
-      cmx::Compact(*ws, s, d_in, n, d_out);
-      return m;
-    };
-    if (!(static_cast<float>(n) <= min_num_points)) {
-      bool done = false;
-      kept = filter(max_length, d_result);
-      d_final = d_result;
-      if (static_cast<float>(kept) >= min_num_points) done = true;
-      for (float high_length = max_length; !done && high_length > 1e-2f * max_length;
-           high_length /= 2.f) {
-        float low_length = high_length / 2.f;
-        kept = filter(low_length, d_result);
-        if (static_cast<float>(kept) >= min_num_points) {
-          while ((high_length - low_length) / low_length > 1e-1f) {
-            const float mid_length = (low_length + high_length) / 2.f;
-            const int m = filter(mid_length, d_candidate);
-            if (static_cast<float>(m) >= min_num_points) {
-              low_length = mid_length;
-              std::swap(d_result, d_candidate);
-              d_final = d_result;
-              kept = m;
-            } else {
-              high_length = mid_length;
-            }
-          }
-          done = true;
-        }
-      }
-    }
-    CMX_HIP(hipMemcpyAsync(filtered_xyz, d_final, 12 * static_cast<size_t>(kept),
-                           hipMemcpyDeviceToHost, st));
-    CMX_HIP(hipStreamSynchronize(st));
-    *num_filtered = kept;
+    CMX_REQUIRE(filtered_xyz != nullptr, "bad argument");
+    cmx::AdaptiveVoxelFilterImpl(point_cloud_xyz, num_points, max_length, min_num_points,
+                                 max_range, device, filtered_xyz, nullptr, num_filtered);
+  });
+}
+
+cmx_status cmx_adaptive_voxel_filter_indices(const float* point_cloud_xyz, int32_t num_points,
+                                             float max_length, float min_num_points,
+                                             float max_range, int32_t device,
+                                             int32_t* kept_indices, int32_t* num_filtered) {
+  return Guard([&] {
+    CMX_REQUIRE(kept_indices != nullptr, "bad argument");
+    cmx::AdaptiveVoxelFilterImpl(point_cloud_xyz, num_points, max_length, min_num_points,
+                                 max_range, device, nullptr, kept_indices, num_filtered);
   });
 }
 

@@ -46,6 +46,19 @@ def adaptive_voxel_filter(point_cloud, max_length, min_num_points, max_range, de
     return out[:kept.value].copy()
 
 
+def adaptive_voxel_filter_indices(point_cloud, max_length, min_num_points, max_range, device=0):
+    """Which points ``adaptive_voxel_filter`` keeps (ascending indices into the input): a
+    ``sensor::PointCloud`` keeps the intensities of the kept points
+    (cartographer/sensor/internal/voxel_filter.cc:138-161,193-198)."""
+    xyz, n = _cloud(point_cloud)
+    out = np.empty(max(n, 1), np.int32)
+    kept = C.c_int32()
+    _lib.check(_lib.lib().cmx_adaptive_voxel_filter_indices(xyz.ctypes.data, n, max_length,
+                                                            min_num_points, max_range, device,
+                                                            out.ctypes.data, C.byref(kept)))
+    return out[:kept.value].copy()
+
+
 def compute_histogram(point_cloud, histogram_size, device=0):
     xyz, n = _cloud(point_cloud)
     out = np.zeros(histogram_size, np.float32)

@@ -45,7 +45,14 @@ cmx_rt_options OptionsOf(const proto::RealTimeCorrelativeScanMatcherOptions& o) 
 struct CellAccess : Grid2D {
   using Grid2D::correspondence_cost_cells;
 };
+// (host cells: a grid resident in HBM -- device_grids.h -- hands out an all-zero host image;
+// Match() looks for the resident grid first, a path without a resident form stops here)
 const std::vector<uint16>& CellsOf(const Grid2D& grid) {
+  if (dynamic_cast<const dropin::DeviceGrid2DView*>(&grid) != nullptr) {
+    std::fprintf(stderr, "Check failed: a grid resident in HBM reached a host-upload path of the "
+                         "real-time matcher adapters (real_time_matchers_mi355x.cc)\n");
+    std::abort();
+  }
   return (grid.*(&CellAccess::correspondence_cost_cells))();
 }
 

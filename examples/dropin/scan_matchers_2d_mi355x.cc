@@ -28,7 +28,15 @@ void CheckOk(cmx_status status, const char* what) {
 struct CellAccess : Grid2D {
   using Grid2D::correspondence_cost_cells;
 };
+// (host cells: a grid that lives in HBM -- device_grids.h -- hands out an all-zero host image,
+// which must never be uploaded in its place: every caller below looks for the resident grid
+// first, and a path that has no resident form stops here instead of matching against nothing)
 const uint16_t* CellsOf(const Grid2D& grid) {
+  if (dynamic_cast<const dropin::DeviceGrid2DView*>(&grid) != nullptr) {
+    std::fprintf(stderr, "Check failed: a grid resident in HBM reached a host-upload path of the "
+                         "2D scan matcher adapters (scan_matchers_2d_mi355x.cc)\n");
+    std::abort();
+  }
   return (grid.*(&CellAccess::correspondence_cost_cells))().data();
 }
 
@@ -67,6 +75,12 @@ FastCorrelativeScanMatcher2D::FastCorrelativeScanMatcher2D(
     const Grid2D& grid, const proto::FastCorrelativeScanMatcherOptions2D& options) {
   const cmx_fast2d_options o{options.linear_search_window(), options.angular_search_window(),
                              options.branch_and_bound_depth()};
+  if (const auto* resident = dynamic_cast<const dropin::DeviceGrid2DView*>(&grid)) {
+    // the submap's grid is in HBM already: the stack is built from it there
+    CheckOk(cmx_fast2d_create_from_grid(&o, resident->device_grid(), &handle_),
+            "cmx_fast2d_create_from_grid");
+    return;
+  }
   const cmx_grid2d_limits limits = LimitsOf(grid);
   CheckOk(cmx_fast2d_create(&o, &limits, CellsOf(grid), Device(),
                             &handle_),

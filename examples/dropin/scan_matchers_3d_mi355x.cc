@@ -29,7 +29,16 @@ void CheckOk(cmx_status status, const char* what) {
   std::abort();
 }
 
+// (host voxels: the HybridGrid a resident submap hands out is EMPTY -- its voxels are in HBM,
+// device_grids.h -- and must never be uploaded in its place: a path that has no resident form
+// stops here instead of silently matching against nothing)
 std::vector<cmx_voxel> Flatten(const HybridGrid& grid) {
+  if (dropin::DeviceGridOf(&grid) != nullptr) {
+    std::fprintf(stderr, "Check failed: a hybrid grid resident in HBM reached a host-upload path "
+                         "of the 3D scan matcher adapters (scan_matchers_3d_mi355x.cc): with an "
+                         "intensity grid in the call, keep the submap's grids on the host\n");
+    std::abort();
+  }
   std::vector<cmx_voxel> out;
   for (auto it = HybridGrid::Iterator(grid); !it.Done(); it.Next()) {
     const Eigen::Array3i index = it.GetCellIndex();

@@ -5,7 +5,9 @@
 // and 3d/local_trajectory_builder_3d.cc:158-159,250-252,281-296 compile unmodified).  The
 // range-measurement overload (the 3D builder's first filter) runs the same device filter on the
 // positions (cmx_voxel_filter_indices); the two remaining overloads of the header have no caller on
-// either path and are not defined here.
+// either path and are not defined here.  Every overload asks the device WHICH points it kept
+// (cmx_voxel_filter_indices, cmx_adaptive_voxel_filter_indices) and selects the payload -- the
+// points themselves and, for a PointCloud, its intensities (voxel_filter.cc:138-161) -- here.
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -40,12 +42,24 @@ std::vector<float> Flatten(const PointCloud& cloud) {
   return xyz;
 }
 
-PointCloud Unflatten(const std::vector<float>& xyz, const int32_t count) {
+// The points the device filter kept, WITH their intensities when the cloud carries any
+// (voxel_filter.cc:138-161: PointCloud(filtered_points, filtered_intensities)): the device says
+// which points, the payload is selected here.
+PointCloud Select(const PointCloud& cloud, const std::vector<int32_t>& kept, const int32_t count) {
   std::vector<RangefinderPoint> points;
   points.reserve(count);
-  for (int32_t i = 0; i != count; ++i)
-    points.push_back({Eigen::Vector3f(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2])});
-  return PointCloud(std::move(points));
+  for (int32_t k = 0; k != count; ++k) points.push_back(cloud[kept[k]]);
+  std::vector<float> intensities;
+  if (!cloud.intensities().empty()) {
+    if (cloud.intensities().size() != cloud.size()) {
+      std::fprintf(stderr, "Check failed: a point cloud with %zu points and %zu intensities\n",
+                   cloud.size(), cloud.intensities().size());
+      std::abort();
+    }
+    intensities.reserve(count);
+    for (int32_t k = 0; k != count; ++k) intensities.push_back(cloud.intensities()[kept[k]]);
+  }
+  return PointCloud(std::move(points), std::move(intensities));
 }
 
 }  // namespace
@@ -53,12 +67,12 @@ PointCloud Unflatten(const std::vector<float>& xyz, const int32_t count) {
 PointCloud VoxelFilter(const PointCloud& point_cloud, const float resolution) {
   if (point_cloud.empty()) return PointCloud();
   const std::vector<float> xyz = Flatten(point_cloud);
-  std::vector<float> kept(xyz.size());
+  std::vector<int32_t> kept(point_cloud.size());
   int32_t count = 0;
-  CheckOk(cmx_voxel_filter(xyz.data(), static_cast<int32_t>(point_cloud.size()), resolution,
-                           Device(), kept.data(), &count),
-          "cmx_voxel_filter");
-  return Unflatten(kept, count);
+  CheckOk(cmx_voxel_filter_indices(xyz.data(), static_cast<int32_t>(point_cloud.size()), resolution,
+                                   Device(), kept.data(), &count),
+          "cmx_voxel_filter_indices");
+  return Select(point_cloud, kept, count);
 }
 
 // sensor::VoxelFilter over range measurements (voxel_filter.cc:176-191): the same filter on
@@ -89,13 +103,13 @@ PointCloud AdaptiveVoxelFilter(const PointCloud& point_cloud,
                                const proto::AdaptiveVoxelFilterOptions& options) {
   if (point_cloud.empty()) return PointCloud();
   const std::vector<float> xyz = Flatten(point_cloud);
-  std::vector<float> kept(xyz.size());
+  std::vector<int32_t> kept(point_cloud.size());
   int32_t count = 0;
-  CheckOk(cmx_adaptive_voxel_filter(xyz.data(), static_cast<int32_t>(point_cloud.size()),
-                                    options.max_length(), options.min_num_points(),
-                                    options.max_range(), Device(), kept.data(), &count),
-          "cmx_adaptive_voxel_filter");
-  return Unflatten(kept, count);
+  CheckOk(cmx_adaptive_voxel_filter_indices(xyz.data(), static_cast<int32_t>(point_cloud.size()),
+                                            options.max_length(), options.min_num_points(),
+                                            options.max_range(), Device(), kept.data(), &count),
+          "cmx_adaptive_voxel_filter_indices");
+  return Select(point_cloud, kept, count);
 }
 
 }  // namespace sensor

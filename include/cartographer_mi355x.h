@@ -588,6 +588,15 @@ cmx_status cmx_voxel_filter_indices(const float* point_cloud_xyz, int32_t num_po
 cmx_status cmx_adaptive_voxel_filter(const float* point_cloud_xyz, int32_t num_points,
                                      float max_length, float min_num_points, float max_range,
                                      int32_t device, float* filtered_xyz, int32_t* num_filtered);
+/* The same filter, returning WHICH points it kept (ascending indices into the input; room for
+ * num_points of them), so that a caller can carry the points' payload along: sensor::PointCloud
+ * keeps the intensities of the kept points (voxel_filter.cc:138-161,193-198), which
+ * LocalTrajectoryBuilder3D needs when use_intensities is set
+ * (3d/local_trajectory_builder_3d.cc:262,298). */
+cmx_status cmx_adaptive_voxel_filter_indices(const float* point_cloud_xyz, int32_t num_points,
+                                             float max_length, float min_num_points,
+                                             float max_range, int32_t device,
+                                             int32_t* kept_indices, int32_t* num_filtered);
 /* RotationalScanMatcher::ComputeHistogram (SM3/rotational_scan_matcher.cc:164-177): slices of
  * 0.2 m, points sorted by angle around the slice centroid, one weighted vote per point pair.
  * Same accumulation order as the reference; atan2f is the device's (<= 1 ulp from libm's). */

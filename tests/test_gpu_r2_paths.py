@@ -612,11 +612,20 @@ def test_sharded_match_through_rccl_on_one_device(sm, synth, c2, debug):
 # ----------------------------------------------------------------------------
 # Voxel filters and rotational histogram on the device
 # ----------------------------------------------------------------------------
+@pytest.mark.parametrize("generic", [0, 1])
 @pytest.mark.parametrize("seed,n,res", [(0, 2000, 0.3), (1, 20000, 0.05), (2, 500, 1.0),
-                                        (3, 5000, 0.011), (4, 1, 0.1), (5, 300000, 0.2)])
-def test_voxel_filter_keeps_the_reference_points(oracle, seed, n, res):
-    """The randomised reservoir filter, bit for bit: same kept points in the same order."""
+                                        (3, 5000, 0.011), (4, 1, 0.1), (5, 300000, 0.2),
+                                        (6, 4096, 0.2), (7, 4097, 0.2), (8, 63, 50.0),
+                                        (9, 3333, 1000.0), (10, 4000, 1e-4)])
+def test_voxel_filter_keeps_the_reference_points(oracle, debug, seed, n, res, generic):
+    """The randomised reservoir filter, bit for bit: same kept points in the same order -- through
+    the one-workgroup path of clouds up to 4096 points (round 6) and through the multi-launch
+    path (generic = 1: debug switch filters_generic), every voxel its own point (res 1e-4), all
+    points in one voxel (res 1000)."""
     from cartographer_amd import filters
+    if generic and n > 4096:
+        pytest.skip("the generic path is the only one for this size")
+    debug(filters_generic=generic)
     rng = np.random.default_rng(seed)
     cloud = rng.normal(0.0, 3.0, (n, 3)).astype(np.float32)
     k = len(cloud[1::7])
@@ -642,17 +651,33 @@ def test_voxel_filter_reference_tests_on_device():
     assert len(filters.voxel_filter_indices(np.zeros((0, 3), np.float32), 0.1)) == 0
 
 
+@pytest.mark.parametrize("generic", [0, 1])
 @pytest.mark.parametrize("seed,n,max_length,min_points,max_range", [
     (0, 20000, 0.5, 200, 50.0), (1, 60000, 2.0, 150, 15.0), (2, 60000, 4.0, 200, 60.0),
-    (3, 100, 0.5, 200, 50.0), (4, 3000, 0.9, 2900, 80.0)])
-def test_adaptive_voxel_filter_equals_the_oracle(oracle, seed, n, max_length, min_points,
-                                                 max_range):
+    (3, 100, 0.5, 200, 50.0), (4, 3000, 0.9, 2900, 80.0), (5, 1500, 0.5, 200, 50.0),
+    (6, 4096, 2.0, 150, 15.0), (7, 900, 0.5, 200, 4.0), (8, 700, 4.0, 650, 60.0),
+    (9, 2500, 0.5, 200, 0.01)])
+def test_adaptive_voxel_filter_equals_the_oracle(oracle, debug, seed, n, max_length, min_points,
+                                                 max_range, generic):
+    """AdaptiveVoxelFilter, same points in the same order: clouds of the local trajectory builders'
+    sizes through the one-workgroup path (the whole search of voxel_filter.cc:38-75 in one launch,
+    round 6) and through the multi-launch path (generic = 1); searches that end at max_length, in
+    the halving loop, in the bisection, with the full cloud (nothing dense enough), and with an
+    empty range cut."""
     from cartographer_amd import filters
+    if generic and n > 4096:
+        pytest.skip("the generic path is the only one for this size")
+    debug(filters_generic=generic)
     rng = np.random.default_rng(seed)
     cloud = (rng.normal(0.0, 8.0, (n, 3)) * np.array([1.0, 1.0, 0.2])).astype(np.float32)
     ref = oracle.adaptive_voxel_filter(cloud, max_length, min_points, max_range)
     got = filters.adaptive_voxel_filter(cloud, max_length, min_points, max_range)
     np.testing.assert_array_equal(got, ref)
+    # ... and WHICH points: ascending indices into the input that select exactly that cloud (a
+    # sensor::PointCloud carries its intensities along by them, voxel_filter.cc:138-161)
+    kept = filters.adaptive_voxel_filter_indices(cloud, max_length, min_points, max_range)
+    assert len(kept) == len(ref) and (np.diff(kept) > 0).all()
+    np.testing.assert_array_equal(cloud[kept], ref)
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
