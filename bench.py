@@ -1105,14 +1105,20 @@ class Fast3DWorkload:
         # the histogram so that every pair passes the yaw pre-filter and is searched in full.
         # (sharded over N GPUs: rank r owns submaps r * pairs ... ; the node comes from #0's world)
         self.matchers = []
+        self.host_grids = []           # (the parity gate's share of the block: voxel lists)
+        keep = getattr(args, "parity_submaps", 4)
         if self.begin == 0:
             self.matchers.append(sm3.FastCorrelativeScanMatcher3D(0.1, vox, grid.grid_size, 0.45,
                                                                   low_vox, hist, **opt))
+            self.host_grids.append((vox, low_vox))
         for gid in range(self.begin + len(self.matchers), self.begin + self.pairs):
             g, _ = synth.make_submap_3d(42 + gid, 0.1, size, 8, 32, 512)
             lw, _ = synth.make_submap_3d(42 + gid, 0.45, size, 8, 32, 512)
+            gv, lv = g.voxels(), lw.voxels()
             self.matchers.append(sm3.FastCorrelativeScanMatcher3D(
-                0.1, g.voxels(), g.grid_size, 0.45, lw.voxels(), hist, **opt))
+                0.1, gv, g.grid_size, 0.45, lv, hist, **opt))
+            if len(self.host_grids) < keep:
+                self.host_grids.append((gv, lv))
 
     def exchange(self, found, scores, results, torch_device):
         """Every submap's optional constraint to every rank (9 words per submap) + the node-wide
@@ -1145,39 +1151,51 @@ class Fast3DWorkload:
         scores = np.array([r["score"] if r else 0.0 for r in results], np.float32)
         return found, scores, results, stats
 
-    def reference_matcher(self):
-        """The reference's fast_correlative_scan_matcher_3d.cc over submap #0's grids (or the
-        oracle port when oracle/_ref did not travel); built once: the parity gate and the CPU
-        baseline leg share it."""
-        if getattr(self, "_reference", None) is None:
+    def reference_matcher(self, k=0):
+        """The reference's fast_correlative_scan_matcher_3d.cc over the grids of this rank's
+        submap #k (or the oracle port when oracle/_ref did not travel); built once per submap: the
+        parity gate and the CPU baseline leg (submap #0) share them."""
+        cache = self.__dict__.setdefault("_references", {})
+        if k not in cache:
             from oracle import pyoracle as orc
             kind = _reference_kind()
             cls = (orc.ReferenceFastCorrelativeScanMatcher3D if kind == "reference"
                    else orc.FastCorrelativeScanMatcher3D)
             o = self.opt
-            self._reference = (kind, cls(
-                0.1, self.vox, 0.45, self.low_vox, self.hist, o["branch_and_bound_depth"],
+            vox, low_vox = self.host_grids[k]
+            cache[k] = (kind, cls(
+                0.1, vox, 0.45, low_vox, self.hist, o["branch_and_bound_depth"],
                 o["full_resolution_depth"], o["min_rotational_score"],
                 o["min_low_resolution_score"], o["linear_xy_search_window"],
                 o["linear_z_search_window"], o["angular_search_window"]))
-        return self._reference
+        return cache[k]
 
-    def reference_match(self):
+    def reference_match(self, k=0):
         node = list(self.node.translation) + list(self.node.rotation)
-        return self.reference_matcher()[1].match(node, [0, 0, 0, 1, 0, 0, 0], [1, 0, 0, 0],
-                                                 self.hi, self.lo, self.scan_hist, 0.2)
+        return self.reference_matcher(k)[1].match(node, [0, 0, 0, 1, 0, 0, 0], [1, 0, 0, 0],
+                                                  self.hi, self.lo, self.scan_hist, 0.2)
 
     def parity(self, result):
-        """Submap #0 (the node's own world; on the rank that owns it) matched by the reference."""
-        if self.begin != 0:
+        """The first `--parity-submaps` submaps of this rank's block (default 4: 0.7 s of one host
+        core each incl. the reference's own stack; `--parity-submaps 256` = every pair of config
+        [4]) matched by the reference: found / score / pose against the device's result of the same
+        pair."""
+        from concurrent.futures import ThreadPoolExecutor
+        count = len(self.host_grids)
+        if count == 0:
             return {"vs": None, "checked": 0}
-        ref = self.reference_match()
-        got = result[2][0]
-        pose = None if got is None else (list(got["pose_estimate"].translation) +
-                                         list(got["pose_estimate"].rotation))
-        return parity_record(self.reference_matcher()[0],
-                             [(got is not None, 0.0 if got is None else got["score"], pose,
-                               ref["found"], ref["score"], ref["pose"])])
+        with ThreadPoolExecutor(min(count, _cores())) as pool:
+            refs = list(pool.map(self.reference_match, range(count)))
+        pairs = []
+        for k, ref in enumerate(refs):
+            got = result[2][k]
+            pose = None if got is None else (list(got["pose_estimate"].translation) +
+                                             list(got["pose_estimate"].rotation))
+            pairs.append((got is not None, 0.0 if got is None else got["score"], pose,
+                          ref["found"], ref["score"], ref["pose"]))
+        for k in range(1, count):       # (the CPU baseline leg keeps submap #0's matcher only)
+            self._references.pop(k, None)
+        return parity_record(_reference_kind(), pairs)
 
     def describe(self, stats, found):
         out = {"workload": f"C5: 3D FastCorrelativeScanMatcher Match, one node against {self.total} "
