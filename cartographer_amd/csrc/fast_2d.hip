@@ -2253,45 +2253,58 @@ TreeQueueKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __rest
   // loads), node i of the interleaved sub-lists for i = wave, wave + W, ...  Phase 2: the queue.
   // A static share is safe here because nobody ever waits for anybody: a workgroup that is not
   // resident yet simply walks its share when it gets there.
-  // The share is dealt in TILES of kTile consecutive entries of one sub-list, fetched by ONE
-  // wave-wide load (lane l: entry l of the tile), so that the trip to memory for a node is paid
-  // once per tile; tile t = (sub-list t mod 64, entries 8 (t / 64) ...) for t = wave, wave + W, ...
-  // (tiles of one entry while the list is short -- a wavefront per node -- up to eight when every
-  // wavefront gets several tiles anyway)
-  const int in_longest = ListMaxCount(in);
-  const int kTile = max(1, min(8, in_longest * kSubLists / (4 * num_waves)));
-  const int in_tiles = (in_longest + kTile - 1) / kTile * kSubLists;
-  int next_tile = wave_id;
-  Node2D tile_node{};          // lane l < tile_count: entry l of the current tile
-  int tile_count = 0, tile_at = 0;
+  // BEST FIRST within the share: 64 nodes of it at a time, one per lane (one wave-wide load), the
+  // highest score among them taken next -- and the round dropped as soon as that score is below
+  // the bound.  Every wavefront starts with the best node it owns, so the first thousand chains
+  // are dives from the best thousand nodes of the list and the bound is close to its final value
+  // when they end; the rest of the list then dies at a compare.  (In list order -- the filter's,
+  // i.e. by rotation -- a hard scan expanded 23 000 nodes where 2 400 suffice with the final
+  // bound known from the start: profiles/r06_queue_development.txt.)
+  const int in_slots = ListMaxCount(in) * kSubLists;
+  int round = 0;
+  Node2D mine{};               // this lane's node of the current round
+  unsigned mine_bits = 0;      // its score's bits; 0: none (taken, or no such node)
+  bool round_loaded = false, share_done = false;
   bool pushed_any = false;
   Node2D nd;
   for (;;) {
     bool have = false;
-    while (!have) {
-      if (tile_at < tile_count) {
-        const int l = tile_at++;
-        nd.problem = __builtin_amdgcn_readlane(tile_node.problem, l);
-        nd.scan = __builtin_amdgcn_readlane(tile_node.scan, l);
-        nd.dx = __builtin_amdgcn_readlane(tile_node.dx, l);
-        nd.dy = __builtin_amdgcn_readlane(tile_node.dy, l);
-        nd.score = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tile_node.score), l));
-        nd.coarse_index = __builtin_amdgcn_readlane(tile_node.coarse_index, l);
-        nd.path = __builtin_amdgcn_readlane(tile_node.path, l);
-        nd.coarse_score =
-            __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tile_node.coarse_score), l));
-        have = true;
-        ++q_listed;
-        break;
+    while (!have && !share_done) {
+      if (!round_loaded) {
+        // (wave-uniform: the first lane's index is the smallest of the round)
+        if (wave_id + static_cast<long long>(round) * 64 * num_waves >= in_slots) { share_done = true; break; }
+        const long long i = wave_id + (static_cast<long long>(round) * 64 + lane) * num_waves;
+        ++round;
+        mine_bits = 0;
+        if (i < in_slots) {
+          const int in_sub = static_cast<int>(i & (kSubLists - 1)), j = static_cast<int>(i / kSubLists);
+          if (j < min(in.counts[in_sub * kCountStride], in.sub_capacity)) {
+            mine = in.nodes[static_cast<size_t>(in_sub) * in.sub_capacity + j];
+            mine_bits = max(__float_as_uint(fmaxf(mine.score, 0.f)), 1u);
+          }
+        }
+        round_loaded = true;
       }
-      if (next_tile >= in_tiles) break;
-      const int in_sub = next_tile & (kSubLists - 1), first = (next_tile / kSubLists) * kTile;
-      next_tile += num_waves;
-      const int count = min(in.counts[in_sub * kCountStride], in.sub_capacity);   // wave-uniform
-      tile_count = max(0, min(kTile, count - first));
-      tile_at = 0;
-      if (lane < tile_count)
-        tile_node = in.nodes[static_cast<size_t>(in_sub) * in.sub_capacity + first + lane];
+      const unsigned top = static_cast<unsigned>(WaveMax(static_cast<int>(mine_bits)));
+      const float bound_now = __uint_as_float(LoadAgent(&states[0].best_bits));
+      // (the bound of problem 0 only prunes rounds of a single search; batches check per node)
+      if (top == 0 || (num_problems == 1 && __uint_as_float(top) < bound_now)) {
+        round_loaded = false;      // nothing left in this round that can matter
+        continue;
+      }
+      const int l = __ffsll(static_cast<long long>(__ballot(mine_bits == top))) - 1;
+      nd.problem = __builtin_amdgcn_readlane(mine.problem, l);
+      nd.scan = __builtin_amdgcn_readlane(mine.scan, l);
+      nd.dx = __builtin_amdgcn_readlane(mine.dx, l);
+      nd.dy = __builtin_amdgcn_readlane(mine.dy, l);
+      nd.score = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mine.score), l));
+      nd.coarse_index = __builtin_amdgcn_readlane(mine.coarse_index, l);
+      nd.path = __builtin_amdgcn_readlane(mine.path, l);
+      nd.coarse_score =
+          __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mine.coarse_score), l));
+      if (lane == l) mine_bits = 0;
+      have = true;
+      ++q_listed;
     }
     if (!have) {
       // its own sub-queue first (whoever publishes nodes is who guarantees that they are taken:

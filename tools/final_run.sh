@@ -2,9 +2,9 @@
 # The round's last GPU call: what the driver runs at round end (GPU suite, smoke, the default bench),
 # the rocprofv3 passes of every config (tools/profile_all.sh -> gpurun_out/<tag>_*.csv: copy into
 # profiles/), and the default bench once more with those passes in place.
-#   gpurun --timeout 2400 -- 'bash tools/final_run.sh r05'
+#   gpurun --timeout 2400 -- 'bash tools/final_run.sh r06'
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT=gpurun_out/final_$TAG; mkdir -p $OUT
 export PYTHONUNBUFFERED=1
