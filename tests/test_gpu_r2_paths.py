@@ -567,9 +567,11 @@ def test_sharded_match_equals_the_batch(sm, synth, c2, debug, virtual_ranks):
         for a, b, ok in zip(p, p1, f):
             if ok:
                 assert (a.x, a.y, a.theta) == (b.x, b.y, b.theta)
-        if virtual_ranks:      # (smaller batches per rank: the bound rises at other moments)
+        if virtual_ranks:      # (smaller batches per rank: the bound rises at other moments, and
+            # a rank's two or three problems go through the work-queue search, whose chains
+            # expand fewer nodes than the level-synchronous launches the batch of five takes)
             assert abs(stats["candidates_scored"] - stats1["candidates_scored"]) < \
-                0.05 * stats1["candidates_scored"]
+                0.15 * stats1["candidates_scored"]
         else:
             assert stats["candidates_scored"] == stats1["candidates_scored"]
     assert f[0] == 1 and f[4] == 1 and s[0] == s[4]
