@@ -79,6 +79,8 @@ cmx_status Guard(F&& body) {
   X(rt2d_unfused)         /* 1: one-tile matches through the prep kernel too (parity partner) */   \
   X(rt2d_no_bounds)       /* 1: no block bounds, the tile kernel sums every candidate (parity partner) */ \
   X(rt2d_bounds)          /* 1: block bounds for calls of any size (default: from 192 matches per call on) */ \
+  X(rt2d_bounds_fused)    /* 1: the bound kernel finishes its matches itself (no tail kernel: round 5's shape) */ \
+  X(rt2d_bounds_level)    /* 2: blocks of 2 x 2 translations as the first level (default: 4 x 4, refined through 2 x 2) */ \
   X(rt2d_bounds_verify)   /* 1: every block is summed and checked against its bound (an error if one is below) */ \
   X(timeline)             /* 1: in-kernel timelines (cmx_device.h Stamp) reported on stderr */     \
   X(trace)                /* 1: an event after every stage of a call, durations on stderr */       \

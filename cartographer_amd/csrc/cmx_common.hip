@@ -353,13 +353,27 @@ void ReportTimeline(const char* name, const unsigned long long* device, int bloc
     if (!h[static_cast<size_t>(b) * K]) continue;
     ++used;
     first = std::min(first, h[static_cast<size_t>(b) * K]);
-    for (int k = 0; k < K; ++k) last = std::max(last, h[static_cast<size_t>(b) * K + k]);
+    for (int k = 0; k < 14; ++k) last = std::max(last, h[static_cast<size_t>(b) * K + k]);
   }
   if (!used) return;
+  // (tools: CMX_TIMELINE_DUMP=<file> appends the raw stamps, a line per block -- slots 14 and 15
+  // carry what the kernel put there instead of a time: the work item and the hardware id)
+  if (const char* path = getenv("CMX_TIMELINE_DUMP")) {
+    if (FILE* f = fopen(path, "a")) {
+      fprintf(f, "# %s %d\n", name, blocks);
+      for (int b = 0; b < blocks; ++b) {
+        if (!h[static_cast<size_t>(b) * K]) continue;
+        fprintf(f, "%d", b);
+        for (int k = 0; k < K; ++k) fprintf(f, " %llu", h[static_cast<size_t>(b) * K + k] - (k < 14 && h[static_cast<size_t>(b) * K + k] ? first : 0));
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
   fprintf(stderr, "[cmx timeline] %s: %d blocks, launch span %.2f us; stamp: median / max us after "
                   "the block's start (start: median / max after the first block's):\n", name, used,
           (last - first) * 0.01);
-  for (int k = 0; k < K; ++k) {
+  for (int k = 0; k < 14; ++k) {
     std::vector<double> d;
     for (int b = 0; b < blocks; ++b) {
       const unsigned long long t0 = h[static_cast<size_t>(b) * K], t = h[static_cast<size_t>(b) * K + k];

@@ -88,6 +88,43 @@ Rt2DPoolKernel(const Rt2DTileParams* __restrict__ params) {
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// grid (ceil(m4_rows * m4_pitch / 256), items): the image max-pooled over 4 x 4 cells, from the
+// 2 x 2 one: m4(X, Y) = max of m2 at (X, Y), (X + 2, Y), (X, Y + 2), (X + 2, Y + 2) -- ceil is
+// monotone, so the maximum of the ceilings is the ceiling of the maximum -- as SIXTEEN phase
+// planes plane(Y & 3, X & 3)[Y >> 2][X >> 2]: the NB block columns of a window row are NB
+// consecutive bytes of the plane the window start's phase selects.  Four bytes per thread.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+Rt2DPool4Kernel(const Rt2DTileParams* __restrict__ params) {
+  const Rt2DTileParams& P = params[blockIdx.y];
+  if (!P.image_build || P.m4 == nullptr) return;
+  const int wpr = P.m4_pitch >> 2;                       // dwords per plane row
+  const int words = P.m4_rows * wpr;                     // per plane
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= 16 * words) return;
+  const int plane = v / words, w = v - plane * words;
+  const int row = w / wpr, col4 = (w - row * wpr) << 2;
+  const int py = plane >> 2, px = plane & 3;
+  const auto* m2 = AsGlobal(P.m2);
+  const int plane2 = P.m2_rows * P.m2_pitch;
+  const auto m2_of = [&](int X, int Y) -> unsigned {     // (beyond the stored planes: beyond the grid, 0)
+    const int r = Y >> 1, c = X >> 1;
+    if (r >= P.m2_rows || c >= P.m2_pitch) return 0u;
+    return m2[(((Y & 1) << 1) | (X & 1)) * plane2 + r * P.m2_pitch + c];
+  };
+  const int Y = 4 * row + py;
+  unsigned out = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int X = 4 * (col4 + c) + px;
+    const unsigned m = max(max(m2_of(X, Y), m2_of(X + 2, Y)), max(m2_of(X, Y + 2), m2_of(X + 2, Y + 2)));
+    out |= m << (8 * c);
+  }
+  reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(P.m4))[v] = out;
+}
+
+
 // The discretisation of the tile kernel's fused path (see the long comment there): cells from a
 // two-FMA f32 estimate where it provably equals the reference's rounding, the exact expressions
 // for a whole chunk otherwise.  One set of constants per (match, rotation).
@@ -133,6 +170,272 @@ __device__ __forceinline__ void BoundCellOf(const BoundDisc& D, const Rt2DFrame&
   }
 }
 
+constexpr int kBoundListCap = 128;           // blocks phase C sums per match; more: the per-candidate kernels
+// words of the block-sum region: the sums of the match's blocks, later the summed candidates
+// (index, quantised sum) the fused finish looks at
+__host__ __device__ constexpr size_t BoundSumWords(int blocks) {
+  return (static_cast<size_t>(blocks > 8 * (kBoundListCap + 1) ? blocks : 8 * (kBoundListCap + 1)) + 3) & ~size_t{3};
+}
+
+// ---------------------------------------------------------------------------------------------
+// Phases B and C and the finish of ONE match by a whole workgroup of kThreads threads, from the
+// byte sums of all its blocks in LDS (`ub`): the tail of the fused kernel's item, or the tail
+// kernel's whole job (round 6).  `ax`, `ay`: the cloud rotated by the initial yaw; `rots`: the
+// rotation table; `list`, `sums`: kBoundListCap / 4 kBoundListCap words; `ctl`, `red`,
+// `best_sum`: the caller's static words (ctl[1] = ctl[3] = 0, best_sum = 0); `fin_smem`: where
+// Rt2DFinishMatch may lay its region out (nothing of the above inside it, the cloud may be).
+// ---------------------------------------------------------------------------------------------
+template <int NB, int kThreads>
+__device__ __forceinline__ void Rt2DBoundTail(Rt2DTileParams& P, unsigned char* fin_smem, const float* ax,
+                                              const float* ay, const float2* rots, int* ub, int* list,
+                                              int* sums, int* ctl, unsigned long long* red, int* best_sum,
+                                              bool outside, int group, unsigned* __restrict__ host_out,
+                                              int match, unsigned long long* tl, int tl_block) {
+  constexpr int kWaves = kThreads / 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = P.n, n_pad = P.n_pad, S = P.num_scans, nl = P.nl;
+  const int side = 2 * nl + 1, cands = side * side;
+  const int nblk = S * NB * NB;
+  float* ubw = reinterpret_cast<float*>(ub);            // (phase B rewrites the sums as bounds)
+  const Rt2DFrame F = FrameOf(P);
+  const int off_x = P.hl - nl, off_y = P.ht - nl;       // window start in image coordinates
+  const int box_x0 = P.box_x0, box_y0 = P.box_y0, T = P.T;
+  const int pchunks = n_pad >> 6;
+  // window start of this lane's point of chunk c under D (image coordinates); false: no point
+  // here, or one outside the predicted box (flagged: the host repeats the match elsewhere)
+  const auto window_start = [&](const BoundDisc& D, int c, int* Xs, int* Ys) {
+    const int i = (c << 6) + lane;
+    const bool valid = i < n;
+    int ix, iy;
+    BoundCellOf(D, F, ax[i], ay[i], valid, &ix, &iy);
+    *Xs = ix + off_x;
+    *Ys = iy + off_y;
+    const bool inside = static_cast<unsigned>(*Xs - box_x0) < static_cast<unsigned>(T) &&
+                        static_cast<unsigned>(*Ys - box_y0) < static_cast<unsigned>(T);
+    if (valid && !inside) outside = true;
+    return valid && inside;
+  };
+  const bool verify = P.b_verify != 0;
+  if (verify) {
+    // (verify mode leaves every candidate's sum for the finish KERNEL, as the tile kernel does;
+    // only this item writes them: zeros first, the blocks' sums behind a barrier)
+    auto* qsum = AsGlobal(P.qsum);
+    for (int e = tid; e < S * cands; e += kThreads) qsum[e] = 0;
+  }
+
+  // ---- phase B: weighted upper bounds, the best block ---------------------------------------
+  const float kScale = ((1.f - 0.1f) - (1.f - (1.f - 0.1f))) / 32766.f;   // (kMaxCC - kMinCC) / 32766
+  const float slack = Rt2DBoundSlack(n);
+  const float per_m = kScale * static_cast<float>(kBoundUnit) / static_cast<float>(n);
+  const float per_q = kScale * static_cast<float>(1 << kQShift) / static_cast<float>(n);
+  {
+    unsigned long long key = 0;
+    for (int e = tid; e < nblk; e += kThreads) {
+      const int s = e / (NB * NB), b = e - s * (NB * NB);
+      const int j = b / NB, k = b - j * NB;
+      float wmax = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int dxi = 2 * k + (q & 1), dyi = 2 * j + (q >> 1);
+        if (dxi < side && dyi < side) wmax = fmaxf(wmax, TileWeight(P, s, dxi - nl, dyi - nl));
+      }
+      const float bound = (0.1f + per_m * static_cast<float>(ub[e]) + slack) * wmax * (1.f + 1e-5f);
+      ubw[e] = bound;
+      const unsigned long long mine =
+          (static_cast<unsigned long long>(__float_as_uint(fmaxf(bound, 0.f))) << 32) |
+          static_cast<unsigned>(0x7fffffff - e);
+      key = mine > key ? mine : key;
+    }
+    key = WaveMaxU64(key);
+    if (lane == 0) red[wave] = key;
+  }
+  __syncthreads();
+  unsigned long long best_key = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) best_key = red[w] > best_key ? red[w] : best_key;
+  const int best_e = 0x7fffffff - static_cast<int>(static_cast<unsigned>(best_key));
+  Stamp(tl, tl_block, 3);                    // weighted bounds, the best block known
+
+  // The quantised sums of a block's four candidates over `count` chunks from c_first on, c_step
+  // apart: what the tile kernel sums for them (cells of the HBM image; outside it: 0).  Four
+  // chunks at a time: their sixteen gathers leave together.
+  const auto* qimage = AsGlobal(P.qimage);
+  const int gw = P.gpitch >> 1, grows = P.grows;
+  const auto block_sums = [&](int e, int c_first, int c_step, int count, int (&sum)[4]) {
+    const int s = e / (NB * NB), b = e - s * (NB * NB);
+    const int j = b / NB, k = b - j * NB;
+    const BoundDisc D = MakeBoundDisc(P, rots[s]);
+    sum[0] = sum[1] = sum[2] = sum[3] = 0;
+#pragma unroll 1
+    for (int t = 0; t < count; t += 4) {
+      unsigned v[4][4];
+      bool ok[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cu = c_first + (t + u) * c_step;
+        int Xs = 0, Ys = 0;
+        const bool live = t + u < count && cu < pchunks && window_start(D, min(cu, pchunks - 1), &Xs, &Ys);
+        const int X = Xs + 2 * k, Y = Ys + 2 * j;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int Xc = X + (q & 1), Yc = Y + (q >> 1);
+          ok[u][q] = live && Xc < gw && Yc < grows;
+          v[u][q] = qimage[ok[u][q] ? Yc * gw + Xc : 0];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sum[q] += ok[u][q] ? static_cast<int>(v[u][q]) : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sum[q] = WaveSum(sum[q]);
+  };
+  const auto lower_bound_of = [&](int e, const int (&sum)[4]) {
+    const int s = e / (NB * NB), b = e - s * (NB * NB);
+    const int j = b / NB, k = b - j * NB;
+    float lb = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int dxi = 2 * k + (q & 1), dyi = 2 * j + (q >> 1);
+      if (dxi < side && dyi < side) {
+        const float base = 0.1f + per_q * static_cast<float>(sum[q]);
+        lb = fmaxf(lb, (base - slack) * TileWeight(P, s, dxi - nl, dyi - nl) * (1.f - 1e-5f));
+      }
+    }
+    return lb;
+  };
+  const auto store_sums = [&](int e, const int (&sum)[4]) {      // (one lane)
+    const int s = e / (NB * NB), b = e - s * (NB * NB);
+    const int j = b / NB, k = b - j * NB;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int dxi = 2 * k + (q & 1), dyi = 2 * j + (q >> 1);
+      if (dxi < side && dyi < side)
+        AsGlobal(P.qsum)[static_cast<size_t>(s) * cands + dxi * side + dyi] = sum[q];
+    }
+  };
+  {
+    // the best block: its chunks dealt over the wavefronts, the sums meet in LDS
+    int sum[4];
+    block_sums(best_e, wave, kWaves, (pchunks - wave + kWaves - 1) / kWaves, sum);
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) atomicAdd(&best_sum[q], sum[q]);
+    }
+  }
+  __syncthreads();                           // (and the zeros of qsum are behind every later store)
+  Stamp(tl, tl_block, 4);                    // the best block summed
+  float lb;
+  {
+    const int sum[4] = {best_sum[0], best_sum[1], best_sum[2], best_sum[3]};
+    lb = lower_bound_of(best_e, sum);
+    if (verify && tid == 0) store_sums(best_e, sum);
+  }
+  // ---- phase C: every other block that reaches the bound ----------------------------------------
+  if (verify) {
+    // (debug switch rt2d_bounds_verify: EVERY block is summed, a wavefront per block, and a block
+    // whose weighted bound lies below the weighted value of one of its own candidates is
+    // reported -- the invariant the pruning rests on, tests/test_gpu_r2_paths.py)
+    bool violated = false;
+    int summed = 0;
+#pragma unroll 1
+    for (int e = wave; e < nblk; e += kWaves) {
+      int sum[4];
+      block_sums(e, 0, 1, pchunks, sum);
+      if (e != best_e) {
+        if (lane == 0) store_sums(e, sum);
+        ++summed;
+      }
+      const int s = e / (NB * NB), b = e - s * (NB * NB);
+      const int j = b / NB, k = b - j * NB;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int dxi = 2 * k + (q & 1), dyi = 2 * j + (q >> 1);
+        if (dxi < side && dyi < side &&
+            ubw[e] < (0.1f + per_q * static_cast<float>(sum[q])) * TileWeight(P, s, dxi - nl, dyi - nl))
+          violated = true;
+      }
+    }
+    if (lane == 0 && summed) atomicAdd(&ctl[1], summed);
+    if (violated && lane == 0) atomicOr(&P.misc[0], kBoundViolated);
+    __syncthreads();
+  } else {
+    // the blocks that reach the bound, listed; their chunks in units of four dealt over the
+    // wavefronts, the sums meet in LDS.  (More than the list holds -- a flat landscape: the
+    // host repeats the match on the per-candidate kernels, as it does when the finish kernel
+    // meets more finalists than it lists.)
+    for (int e = tid; e < nblk; e += kThreads) {
+      if (e != best_e && ubw[e] >= lb) {
+        const int at = atomicAdd(&ctl[1], 1);
+        if (at < kBoundListCap) {
+          list[at] = e;
+          sums[4 * at] = sums[4 * at + 1] = sums[4 * at + 2] = sums[4 * at + 3] = 0;
+        }
+      }
+    }
+    __syncthreads();
+    const int listed = ctl[1];
+    if (listed > kBoundListCap) {
+      if (tid == 0) atomicOr(&P.misc[0], kBoundFlat);
+    } else {
+      const int groups = (pchunks + 3) >> 2;
+#pragma unroll 1
+      for (int u = wave; u < listed * groups; u += kWaves) {
+        const int at = u / groups, grp = u - at * groups;
+        int sum[4];
+        block_sums(list[at], 4 * grp, 1, min(4, pchunks - 4 * grp), sum);
+        if (lane == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) atomicAdd(&sums[4 * at + q], sum[q]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (outside) atomicOr(&P.misc[0], kOutOfBox);
+  Stamp(tl, tl_block, 5);                    // phase C: the surviving blocks summed
+  const int listed = min(ctl[1], kBoundListCap);
+  if (tid == 0) {
+    P.bstat[0] = static_cast<unsigned>((verify ? ctl[1] : listed) + 1);   // blocks summed exactly
+    P.bstat[1] = static_cast<unsigned>(nblk);                           // block bounds evaluated
+  }
+  if (verify) return;                      // (the finish kernel takes it from the sums in HBM)
+  if (ctl[1] > kBoundListCap) {
+    // nothing to finish: the flag travels with the match's words, as the finish would send them
+    __syncthreads();
+    if (tid < 128)
+      host_out[static_cast<size_t>(match) * 128 + tid] =
+          __hip_atomic_load(&P.misc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  // ---- the finish of the match, here: the candidates of the summed blocks (the best one and
+  // the listed ones) with their sums take the place of the block sums, Rt2DFinishMatch selects
+  // among them (every other candidate lies below the best lower bound) and lays its own LDS
+  // out over the planes and the cloud, which nobody reads any more.
+  int* cand_e = ub;
+  int* cand_q = ub + 4 * (kBoundListCap + 1);
+  if (tid == 0) ctl[3] = 0;
+  __syncthreads();                           // (the bounds in `ub` have been read by everyone)
+  if (tid <= listed) {
+    const int e = tid == 0 ? best_e : list[tid - 1];
+    const int s = e / (NB * NB), b = e - s * (NB * NB);
+    const int j = b / NB, k = b - j * NB;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int dxi = 2 * k + (q & 1), dyi = 2 * j + (q >> 1);
+      if (dxi < side && dyi < side) {
+        const int at = atomicAdd(&ctl[3], 1);
+        cand_e[at] = s * cands + dxi * side + dyi;
+        cand_q[at] = tid == 0 ? best_sum[q] : sums[4 * (tid - 1) + q];
+      }
+    }
+  }
+  __syncthreads();
+  Rt2DFinishMatch<kThreads, true, false>(P, fin_smem, group, host_out, match, cand_e, cand_q, ctl[3]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // grid (persistent: two workgroups of 512 threads per CU), work items = (match, rotation group g
 // of G) from the fused path's list, pulled through a counter.  An item bounds the blocks of its
@@ -143,19 +446,19 @@ __device__ __forceinline__ void BoundCellOf(const BoundDisc& D, const Rt2DFrame&
 //   b_tail_at: what the fused finish needs) rots[num_scans] | ub[BoundSumWords] |
 //   list[kBoundListCap] | sums[kBoundListCap][4]
 // ---------------------------------------------------------------------------------------------
-constexpr int kBoundListCap = 128;           // blocks phase C sums per match; more: the per-candidate kernels
-// words of the block-sum region: the sums of the match's blocks, later the summed candidates
-// (index, quantised sum) the fused finish looks at
-__host__ __device__ constexpr size_t BoundSumWords(int blocks) {
-  return (static_cast<size_t>(blocks > 8 * (kBoundListCap + 1) ? blocks : 8 * (kBoundListCap + 1)) + 3) & ~size_t{3};
-}
 
-template <int NB>
+// LOG = 1: blocks of 2 x 2 translations (four parity planes, NB <= 8 block columns in three
+// dwords); LOG = 2 (round 6): blocks of 4 x 4 translations -- sixteen phase planes
+// plane(Y & 3, X & 3)[Y >> 2][X >> 2] of the 4 x 4 max-pooled image (Rt2DPool4Kernel), NB <= 4
+// block columns in two dwords, always split: the tail kernel (Rt2DBoundTail4Kernel) refines the
+// few blocks that survive through their 2 x 2 sub-blocks.  C1: 4 rows of two dwords per (point,
+// rotation) instead of 7 rows of three.
+template <int NB, int LOG>
 __global__ void __launch_bounds__(kBoundThreads, 4)       // (HIP: min WAVES per SIMD -- two workgroups per CU, at most 128 VGPRs)
 Rt2DBoundKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict__ work,
                 const int* __restrict__ work_count, int* __restrict__ next_item,
                 int* __restrict__ tickets, int* __restrict__ ub_global, int group,
-                unsigned* __restrict__ host_out) {
+                unsigned* __restrict__ host_out, int split) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bound_smem[];
   __shared__ Rt2DTileParams P;
   __shared__ int fetched;
@@ -182,26 +485,33 @@ Rt2DBoundKernel(const Rt2DTileParams* __restrict__ params, const int4* __restric
     unsigned long long* const tl = item_index < 4 ? P.timeline : nullptr;
     const int tl_block = blockIdx.x * 4 + item_index;
     Stamp(tl, tl_block, 0);
+    if (tl && tid == 0) {                      // (tools: which item, and where it ran: XCC | HW_ID)
+      tl[static_cast<size_t>(tl_block) * kTimelineStamps + 14] = static_cast<unsigned>(item_at);
+      tl[static_cast<size_t>(tl_block) * kTimelineStamps + 15] =
+          (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((31 << 11) | 20)) << 32) |
+          static_cast<unsigned>(__builtin_amdgcn_s_getreg((31 << 11) | 4));
+    }
     const int n = P.n, n_pad = P.n_pad, S = P.num_scans, nl = P.nl;
-    const int side = 2 * nl + 1, cands = side * side;
-    const int lpb = P.b_lpb, lh = P.b_lh;
-    const int plane_bytes = lh * lpb;
+    static_assert(LOG == 1 || (LOG == 2 && NB <= 4), "4 x 4 blocks: at most 16 x 16 windows");
+    constexpr int kPlanes = 1 << (2 * LOG), kPhase = (1 << LOG) - 1;
+    const int lpb = LOG == 1 ? P.b_lpb : P.b4_lpb, lh = LOG == 1 ? P.b_lh : P.b4_lh;
+    const int plane_bytes = LOG == 1 ? lh * lpb : P.b4_pstride;   // (4 x 4: plane p starts two banks behind plane p - 1)
+    const int c0 = LOG == 1 ? P.b_c0 : P.b4_c0, r0 = LOG == 1 ? P.b_r0 : P.b4_r0;
     unsigned char* planes = bound_smem;
     const int lds_planes = static_cast<int>(reinterpret_cast<uintptr_t>(
         (const __attribute__((address_space(3))) unsigned char*)bound_smem));
-    const int zero_at = 4 * plane_bytes;                  // NB rows of zeros at the planes' pitch
+    const int zero_at = kPlanes * plane_bytes;            // NB rows of zeros at the planes' pitch
     const int zero_bytes = (NB * lpb + 16 + 15) & ~15;
     float* ax = reinterpret_cast<float*>(bound_smem + zero_at + zero_bytes);
     float* ay = ax + n_pad;
     const int lds_ax = lds_planes + static_cast<int>(reinterpret_cast<unsigned char*>(ax) - bound_smem);
     const int lds_ay = lds_ax + 4 * n_pad;
-    float2* rots = reinterpret_cast<float2*>(bound_smem + P.b_tail_at);
+    float2* rots = reinterpret_cast<float2*>(bound_smem + (LOG == 1 ? P.b_tail_at : P.b4_tail_at));
     int* ub = reinterpret_cast<int*>(rots + ((S + 1) & ~1));
-    float* ubw = reinterpret_cast<float*>(ub);            // (phase B rewrites the sums as bounds)
     const int nblk = S * NB * NB;
-    int* list = ub + BoundSumWords(nblk);
+    int* list = ub + BoundSumWords(nblk);                 // (LOG = 1 only: the fused tail's lists)
     int* sums = list + kBoundListCap;
-    int* ub_match = ub_global + P.b_ub_at;                // this match's byte sums in HBM (G > 1)
+    int* ub_match = ub_global + (LOG == 1 ? P.b_ub_at : P.b4_ub_at);   // this match's byte sums in HBM
 
     // ---- staging: cloud rotated by the initial yaw, rotations, planes ---------------------------
     {
@@ -222,9 +532,11 @@ Rt2DBoundKernel(const Rt2DTileParams* __restrict__ params, const int4* __restric
       // the planes from the last row.
       typedef unsigned U2 __attribute__((ext_vector_type(2)));
       const int ppr = lpb >> 3;
-      const int pieces = 4 * lh * ppr;
-      const auto* src = (const __attribute__((address_space(1))) unsigned char*)P.m2;
-      const int src_plane = P.m2_rows * P.m2_pitch;
+      const int pieces = kPlanes * lh * ppr;
+      const auto* src = (const __attribute__((address_space(1))) unsigned char*)(LOG == 1 ? P.m2 : P.m4);
+      const int src_pitch = LOG == 1 ? P.m2_pitch : P.m4_pitch, src_rows = LOG == 1 ? P.m2_rows : P.m4_rows;
+      const int src_plane = src_rows * src_pitch;
+      const int plane_gap = plane_bytes - lh * lpb;       // (LDS bytes between the planes)
       constexpr int kInFlight = 8;
       // (piece -> (plane, row, piece of the row) by multiplication: the quotients are exact for
       // dividends below 2^16, and two integer divisions per piece were a tenth of the kernel's
@@ -233,20 +545,22 @@ Rt2DBoundKernel(const Rt2DTileParams* __restrict__ params, const int4* __restric
       const unsigned lh_magic = 0xffffffffu / static_cast<unsigned>(lh) + 1u;
       for (int p0 = tid; p0 < pieces; p0 += kInFlight * kBoundThreads) {
         U2 v[kInFlight];
+        int dst_gap[kInFlight];
 #pragma unroll
         for (int q = 0; q < kInFlight; ++q) {
           const int p = min(p0 + q * kBoundThreads, pieces - 1);
           const int pr = static_cast<int>(__umulhi(static_cast<unsigned>(p), ppr_magic)), piece = p - pr * ppr;
           const int plane = static_cast<int>(__umulhi(static_cast<unsigned>(pr), lh_magic)), row = pr - plane * lh;
-          const int col = min(P.b_c0 + (piece << 3), P.m2_pitch - 8);
-          const int srow = min(P.b_r0 + row, P.m2_rows - 1);
+          const int col = min(c0 + (piece << 3), src_pitch - 8);
+          const int srow = min(r0 + row, src_rows - 1);
           v[q] = *reinterpret_cast<const __attribute__((address_space(1))) U2*>(
-              src + plane * src_plane + srow * P.m2_pitch + col);
+              src + plane * src_plane + srow * src_pitch + col);
+          if (LOG == 2) dst_gap[q] = plane * plane_gap;
         }
 #pragma unroll
         for (int q = 0; q < kInFlight; ++q) {
           const int p = p0 + q * kBoundThreads;
-          if (p < pieces) reinterpret_cast<U2*>(planes)[p] = v[q];
+          if (p < pieces) *reinterpret_cast<U2*>(planes + (p << 3) + (LOG == 2 ? dst_gap[q] : 0)) = v[q];
         }
       }
       for (int w = tid; w < (zero_bytes >> 2); w += kBoundThreads)
@@ -262,20 +576,6 @@ Rt2DBoundKernel(const Rt2DTileParams* __restrict__ params, const int4* __restric
     const int box_x0 = P.box_x0, box_y0 = P.box_y0, T = P.T;
     const int pchunks = n_pad >> 6;
     bool outside = false;
-    // window start of this lane's point of chunk c under D (image coordinates); false: no point
-    // here, or one outside the predicted box (flagged: the host repeats the match elsewhere)
-    const auto window_start = [&](const BoundDisc& D, int c, int* Xs, int* Ys) {
-      const int i = (c << 6) + lane;
-      const bool valid = i < n;
-      int ix, iy;
-      BoundCellOf(D, F, ax[i], ay[i], valid, &ix, &iy);
-      *Xs = ix + off_x;
-      *Ys = iy + off_y;
-      const bool inside = static_cast<unsigned>(*Xs - box_x0) < static_cast<unsigned>(T) &&
-                          static_cast<unsigned>(*Ys - box_y0) < static_cast<unsigned>(T);
-      if (valid && !inside) outside = true;
-      return valid && inside;
-    };
 
     // ---- phase A: the byte sums of every block of this item's rotations, a wavefront per
     // rotation.  A lane adds the dwords of its points' block rows as they are -- kBoundFlush
@@ -313,8 +613,8 @@ Rt2DBoundKernel(const Rt2DTileParams* __restrict__ params, const int4* __restric
         const bool inside = static_cast<unsigned>(Xs - box_x0) < static_cast<unsigned>(T) &&
                             static_cast<unsigned>(Ys - box_y0) < static_cast<unsigned>(T);
         if (valid && !inside) outside = true;
-        const int plane = ((Ys & 1) << 1) | (Xs & 1);
-        return valid && inside ? plane * plane_bytes + ((Ys >> 1) - P.b_r0) * lpb + ((Xs >> 1) - P.b_c0)
+        const int plane = ((Ys & kPhase) << LOG) | (Xs & kPhase);
+        return valid && inside ? plane * plane_bytes + ((Ys >> LOG) - r0) * lpb + ((Xs >> LOG) - c0)
                                : zero_at;
       };
       const int last = chunk_end - 1;
@@ -403,6 +703,17 @@ Rt2DBoundKernel(const Rt2DTileParams* __restrict__ params, const int4* __restric
     __syncthreads();
     Stamp(tl, tl_block, 2);                    // phase A: the byte sums of this item's blocks
     if (outside) atomicOr(&P.misc[0], kOutOfBox);
+    if (split || LOG == 2) {
+      // (round 6) the sums of this item's rotations to HBM: the tail kernel, behind this one on
+      // the stream, takes the match from there -- this workgroup's LDS and its place on the CU go
+      // to the next item's phase A instead of ~30 us of dependent round trips
+      for (int e = tid; e < my_rotations * NB * NB; e += kBoundThreads) {
+        const int ri = e / (NB * NB), b = e - ri * (NB * NB);
+        const int at = (g + ri * G) * (NB * NB) + b;
+        ub_match[at] = ub[at];
+      }
+      continue;
+    }
     if (G > 1) {
       // the sums of this item's rotations to HBM, written through (other workgroups -- other
       // XCDs -- read them); then the match's ticket: the last item carries on
@@ -420,225 +731,459 @@ Rt2DBoundKernel(const Rt2DTileParams* __restrict__ params, const int4* __restric
         ub[e] = __hip_atomic_load(&ub_match[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
     }
-    const bool verify = P.b_verify != 0;
-    if (verify) {
-      // (verify mode leaves every candidate's sum for the finish KERNEL, as the tile kernel does;
-      // only this item writes them: zeros first, the blocks' sums behind a barrier)
-      auto* qsum = AsGlobal(P.qsum);
-      for (int e = tid; e < S * cands; e += kBoundThreads) qsum[e] = 0;
-    }
-
-    // ---- phase B: weighted upper bounds, the best block ---------------------------------------
-    const float kScale = ((1.f - 0.1f) - (1.f - (1.f - 0.1f))) / 32766.f;   // (kMaxCC - kMinCC) / 32766
-    const float slack = Rt2DBoundSlack(n);
-    const float per_m = kScale * static_cast<float>(kBoundUnit) / static_cast<float>(n);
-    const float per_q = kScale * static_cast<float>(1 << kQShift) / static_cast<float>(n);
-    {
-      unsigned long long key = 0;
-      for (int e = tid; e < nblk; e += kBoundThreads) {
-        const int s = e / (NB * NB), b = e - s * (NB * NB);
-        const int j = b / NB, k = b - j * NB;
-        float wmax = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int dxi = 2 * k + (q & 1), dyi = 2 * j + (q >> 1);
-          if (dxi < side && dyi < side) wmax = fmaxf(wmax, TileWeight(P, s, dxi - nl, dyi - nl));
-        }
-        const float bound = (0.1f + per_m * static_cast<float>(ub[e]) + slack) * wmax * (1.f + 1e-5f);
-        ubw[e] = bound;
-        const unsigned long long mine =
-            (static_cast<unsigned long long>(__float_as_uint(fmaxf(bound, 0.f))) << 32) |
-            static_cast<unsigned>(0x7fffffff - e);
-        key = mine > key ? mine : key;
-      }
-      key = WaveMaxU64(key);
-      if (lane == 0) red[wave] = key;
-    }
-    __syncthreads();
-    unsigned long long best_key = 0;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) best_key = red[w] > best_key ? red[w] : best_key;
-    const int best_e = 0x7fffffff - static_cast<int>(static_cast<unsigned>(best_key));
-    Stamp(tl, tl_block, 3);                    // weighted bounds, the best block known
-
-    // The quantised sums of a block's four candidates over `count` chunks from c_first on, c_step
-    // apart: what the tile kernel sums for them (cells of the HBM image; outside it: 0).  Four
-    // chunks at a time: their sixteen gathers leave together.
-    const auto* qimage = AsGlobal(P.qimage);
-    const int gw = P.gpitch >> 1, grows = P.grows;
-    const auto block_sums = [&](int e, int c_first, int c_step, int count, int (&sum)[4]) {
-      const int s = e / (NB * NB), b = e - s * (NB * NB);
-      const int j = b / NB, k = b - j * NB;
-      const BoundDisc D = MakeBoundDisc(P, rots[s]);
-      sum[0] = sum[1] = sum[2] = sum[3] = 0;
-#pragma unroll 1
-      for (int t = 0; t < count; t += 4) {
-        unsigned v[4][4];
-        bool ok[4][4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int cu = c_first + (t + u) * c_step;
-          int Xs = 0, Ys = 0;
-          const bool live = t + u < count && cu < pchunks && window_start(D, min(cu, pchunks - 1), &Xs, &Ys);
-          const int X = Xs + 2 * k, Y = Ys + 2 * j;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int Xc = X + (q & 1), Yc = Y + (q >> 1);
-            ok[u][q] = live && Xc < gw && Yc < grows;
-            v[u][q] = qimage[ok[u][q] ? Yc * gw + Xc : 0];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) sum[q] += ok[u][q] ? static_cast<int>(v[u][q]) : 0;
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) sum[q] = WaveSum(sum[q]);
-    };
-    const auto lower_bound_of = [&](int e, const int (&sum)[4]) {
-      const int s = e / (NB * NB), b = e - s * (NB * NB);
-      const int j = b / NB, k = b - j * NB;
-      float lb = 0.f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int dxi = 2 * k + (q & 1), dyi = 2 * j + (q >> 1);
-        if (dxi < side && dyi < side) {
-          const float base = 0.1f + per_q * static_cast<float>(sum[q]);
-          lb = fmaxf(lb, (base - slack) * TileWeight(P, s, dxi - nl, dyi - nl) * (1.f - 1e-5f));
-        }
-      }
-      return lb;
-    };
-    const auto store_sums = [&](int e, const int (&sum)[4]) {      // (one lane)
-      const int s = e / (NB * NB), b = e - s * (NB * NB);
-      const int j = b / NB, k = b - j * NB;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int dxi = 2 * k + (q & 1), dyi = 2 * j + (q >> 1);
-        if (dxi < side && dyi < side)
-          AsGlobal(P.qsum)[static_cast<size_t>(s) * cands + dxi * side + dyi] = sum[q];
-      }
-    };
-    {
-      // the best block: its chunks dealt over the wavefronts, the sums meet in LDS
-      int sum[4];
-      block_sums(best_e, wave, kWaves, (pchunks - wave + kWaves - 1) / kWaves, sum);
-      if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) atomicAdd(&best_sum[q], sum[q]);
-      }
-    }
-    __syncthreads();                           // (and the zeros of qsum are behind every later store)
-    Stamp(tl, tl_block, 4);                    // the best block summed
-    float lb;
-    {
-      const int sum[4] = {best_sum[0], best_sum[1], best_sum[2], best_sum[3]};
-      lb = lower_bound_of(best_e, sum);
-      if (verify && tid == 0) store_sums(best_e, sum);
-    }
-    // ---- phase C: every other block that reaches the bound ----------------------------------------
-    if (verify) {
-      // (debug switch rt2d_bounds_verify: EVERY block is summed, a wavefront per block, and a block
-      // whose weighted bound lies below the weighted value of one of its own candidates is
-      // reported -- the invariant the pruning rests on, tests/test_gpu_r2_paths.py)
-      bool violated = false;
-      int summed = 0;
-#pragma unroll 1
-      for (int e = wave; e < nblk; e += kWaves) {
-        int sum[4];
-        block_sums(e, 0, 1, pchunks, sum);
-        if (e != best_e) {
-          if (lane == 0) store_sums(e, sum);
-          ++summed;
-        }
-        const int s = e / (NB * NB), b = e - s * (NB * NB);
-        const int j = b / NB, k = b - j * NB;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int dxi = 2 * k + (q & 1), dyi = 2 * j + (q >> 1);
-          if (dxi < side && dyi < side &&
-              ubw[e] < (0.1f + per_q * static_cast<float>(sum[q])) * TileWeight(P, s, dxi - nl, dyi - nl))
-            violated = true;
-        }
-      }
-      if (lane == 0 && summed) atomicAdd(&ctl[1], summed);
-      if (violated && lane == 0) atomicOr(&P.misc[0], kBoundViolated);
-      __syncthreads();
-    } else {
-      // the blocks that reach the bound, listed; their chunks in units of four dealt over the
-      // wavefronts, the sums meet in LDS.  (More than the list holds -- a flat landscape: the
-      // host repeats the match on the per-candidate kernels, as it does when the finish kernel
-      // meets more finalists than it lists.)
-      for (int e = tid; e < nblk; e += kBoundThreads) {
-        if (e != best_e && ubw[e] >= lb) {
-          const int at = atomicAdd(&ctl[1], 1);
-          if (at < kBoundListCap) {
-            list[at] = e;
-            sums[4 * at] = sums[4 * at + 1] = sums[4 * at + 2] = sums[4 * at + 3] = 0;
-          }
-        }
-      }
-      __syncthreads();
-      const int listed = ctl[1];
-      if (listed > kBoundListCap) {
-        if (tid == 0) atomicOr(&P.misc[0], kBoundFlat);
-      } else {
-        const int groups = (pchunks + 3) >> 2;
-#pragma unroll 1
-        for (int u = wave; u < listed * groups; u += kWaves) {
-          const int at = u / groups, grp = u - at * groups;
-          int sum[4];
-          block_sums(list[at], 4 * grp, 1, min(4, pchunks - 4 * grp), sum);
-          if (lane == 0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) atomicAdd(&sums[4 * at + q], sum[q]);
-          }
-        }
-        __syncthreads();
-      }
-    }
-    if (outside) atomicOr(&P.misc[0], kOutOfBox);
-    Stamp(tl, tl_block, 5);                    // phase C: the surviving blocks summed
-    const int listed = min(ctl[1], kBoundListCap);
-    if (tid == 0) {
-      P.bstat[0] = static_cast<unsigned>((verify ? ctl[1] : listed) + 1);   // blocks summed exactly
-      P.bstat[1] = static_cast<unsigned>(nblk);                           // block bounds evaluated
-    }
-    if (verify) continue;                      // (the finish kernel takes it from the sums in HBM)
-    if (ctl[1] > kBoundListCap) {
-      // nothing to finish: the flag travels with the match's words, as the finish would send them
-      __syncthreads();
-      if (tid < 128)
-        host_out[static_cast<size_t>(match) * 128 + tid] =
-            __hip_atomic_load(&P.misc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      continue;
-    }
-    // ---- the finish of the match, here: the candidates of the summed blocks (the best one and
-    // the listed ones) with their sums take the place of the block sums, Rt2DFinishMatch selects
-    // among them (every other candidate lies below the best lower bound) and lays its own LDS
-    // out over the planes and the cloud, which nobody reads any more.
-    int* cand_e = ub;
-    int* cand_q = ub + 4 * (kBoundListCap + 1);
-    if (tid == 0) ctl[3] = 0;
-    __syncthreads();                           // (the bounds in `ub` have been read by everyone)
-    if (tid <= listed) {
-      const int e = tid == 0 ? best_e : list[tid - 1];
-      const int s = e / (NB * NB), b = e - s * (NB * NB);
-      const int j = b / NB, k = b - j * NB;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int dxi = 2 * k + (q & 1), dyi = 2 * j + (q >> 1);
-        if (dxi < side && dyi < side) {
-          const int at = atomicAdd(&ctl[3], 1);
-          cand_e[at] = s * cands + dxi * side + dyi;
-          cand_q[at] = tid == 0 ? best_sum[q] : sums[4 * (tid - 1) + q];
-        }
-      }
-    }
-    __syncthreads();
-    Rt2DFinishMatch<kBoundThreads, true, false>(P, bound_smem, group, host_out, match, cand_e, cand_q, ctl[3]);
+    if constexpr (LOG == 1)
+      Rt2DBoundTail<NB, kBoundThreads>(P, bound_smem, ax, ay, rots, ub, list, sums, ctl, red, best_sum, outside,
+                                       group, host_out, match, tl, tl_block);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// grid (matches), 512 threads: the tail of a match whose block sums the bound kernel (split = 1)
+// left in HBM.  ~33 KB of LDS: four or five workgroups per CU, every match of a part in flight at
+// once -- the tail is a chain of a dozen dependent round trips (weighted bounds, the best block,
+// the listed blocks, the finalists' gathers and f32 chains), latency that only other matches hide.
+// Dynamic LDS: [Rt2DFinishMatch's region, over] ax[n_pad] | ay[n_pad] | (at BoundTailRegion)
+//   rots[num_scans] | ub[BoundSumWords] | list[kBoundListCap] | sums[kBoundListCap][4]
+// ---------------------------------------------------------------------------------------------
+constexpr int kBoundTailThreads = 512;
+constexpr int kBoundTailGroup = 2;           // finalists per round of f32 chains (LDS rows)
+__host__ __device__ constexpr size_t BoundTailRegion(int n_pad, int num_scans) {
+  const size_t fin = 4 * static_cast<size_t>(n_pad) + static_cast<size_t>(kBoundTailGroup) * 4 * (static_cast<size_t>(n_pad) + 4) +
+                     4 * ((static_cast<size_t>(num_scans) + 3) & ~size_t{3}) + 12 * static_cast<size_t>(kStage1Cap);
+  const size_t cloud = 8 * static_cast<size_t>(n_pad);
+  return ((fin > cloud ? fin : cloud) + 15) & ~size_t{15};
+}
+__host__ __device__ constexpr size_t BoundTailLds(int n_pad, int num_scans, int nb) {
+  return BoundTailRegion(n_pad, num_scans) + 8 * ((static_cast<size_t>(num_scans) + 1) & ~size_t{1}) +
+         4 * BoundSumWords(num_scans * nb * nb) + 20 * size_t{kBoundListCap};
+}
+
+template <int NB>
+__global__ void __launch_bounds__(kBoundTailThreads)
+Rt2DBoundTailKernel(const Rt2DTileParams* __restrict__ params, const int* __restrict__ ub_global,
+                    unsigned* __restrict__ host_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tail_smem[];
+  __shared__ Rt2DTileParams P;
+  __shared__ int ctl[4];
+  __shared__ unsigned long long red[kBoundTailThreads / 64];
+  __shared__ int best_sum[4];
+  const int tid = threadIdx.x;
+  const int match = blockIdx.x;
+  CopyParams(&P, params + match, tid);
+  __syncthreads();
+  unsigned long long* const tl = P.timeline;
+  const int tl_block = P.timeline_finish_base + match;
+  Stamp(tl, tl_block, 0);
+  const int n = P.n, n_pad = P.n_pad, S = P.num_scans;
+  float* ax = reinterpret_cast<float*>(tail_smem);
+  float* ay = ax + n_pad;
+  float2* rots = reinterpret_cast<float2*>(tail_smem + BoundTailRegion(n_pad, S));
+  int* ub = reinterpret_cast<int*>(rots + ((S + 1) & ~1));
+  const int nblk = S * NB * NB;
+  int* list = ub + BoundSumWords(nblk);
+  int* sums = list + kBoundListCap;
+  {
+    const auto* xyz = AsGlobal(P.xyz);
+    for (int i = tid; i < n_pad; i += kBoundTailThreads) {
+      float x = 0.f, y = 0.f;
+      if (i < n) RotateZ(P.init_qw, P.init_qz, xyz[3 * i], xyz[3 * i + 1], &x, &y);
+      ax[i] = x;
+      ay[i] = y;
+    }
+    const auto* rot = AsGlobal(reinterpret_cast<const float*>(P.scan_rot));
+    for (int s = tid; s < S; s += kBoundTailThreads) rots[s] = make_float2(rot[2 * s], rot[2 * s + 1]);
+    const auto* ubm = AsGlobal(ub_global + P.b_ub_at);
+    for (int e = tid; e < nblk; e += kBoundTailThreads) ub[e] = ubm[e];
+    if (tid < 4) { ctl[tid] = 0; best_sum[tid] = 0; }
+  }
+  __syncthreads();
+  Stamp(tl, tl_block, 7);                      // staged: cloud, rotations, block sums
+  Rt2DBoundTail<NB, kBoundTailThreads>(P, tail_smem, ax, ay, rots, ub, list, sums, ctl, red, best_sum,
+                                       /*outside=*/false, kBoundTailGroup, host_out, match, tl, tl_block);
+}
+
+// ---------------------------------------------------------------------------------------------
+// grid (matches), 512 threads: the tail of a match behind Rt2DBoundKernel<NB4, 2>, two levels
+// (round 6).  From the byte sums of the match's 4 x 4 blocks:
+//   B  weighted upper bounds; the best block's SIXTEEN candidates summed (quantised cells of the
+//      HBM image): the best weighted lower bound among them;
+//   C4 every other 4 x 4 block whose bound reaches it is listed (C1: eight or nine of 432) and its
+//      four 2 x 2 sub-blocks are bounded -- four bytes of the 2 x 2 planes (HBM / L2) per point;
+//   C2 the sub-blocks whose bound reaches the lower bound are listed (C1: five) and their four
+//      candidates summed, as the 2 x 2 tail sums them;
+//   the finish (Rt2DFinishMatch) over the best block's sixteen and the listed sub-blocks' four
+//   candidates each.
+// Why the result cannot change: as in the header of this file, with one more level -- a 4 x 4
+// block is dropped only if its bound (>= every member's weighted f32-chain score) lies strictly
+// below the lower bound of a candidate that IS summed, a sub-block likewise.  Debug switch
+// rt2d_bounds_verify: EVERY block's sixteen candidates are summed and checked against the 4 x 4
+// bound and against their sub-block's 2 x 2 bound as this kernel computes it.
+// Dynamic LDS: [Rt2DFinishMatch's region, over] ax[n_pad] | ay[n_pad] | (at BoundTailRegion)
+//   rots[num_scans] | ub[Tail4SumWords] | list4[kList4Cap] | sub[kList4Cap][4] |
+//   list2[kBoundListCap] | sums[kBoundListCap][4] | best16[16]
+// ---------------------------------------------------------------------------------------------
+constexpr int kList4Cap = 96;                // 4 x 4 blocks refined per match; more: the per-candidate kernels
+__host__ __device__ constexpr size_t Tail4SumWords(int blocks) {
+  // (the block sums, later the summed candidates and their sums: 16 + 4 kBoundListCap of each)
+  const size_t cand = 2 * (16 + 4 * static_cast<size_t>(kBoundListCap));
+  return ((static_cast<size_t>(blocks) > cand ? static_cast<size_t>(blocks) : cand) + 3) & ~size_t{3};
+}
+__host__ __device__ constexpr size_t BoundTail4Lds(int n_pad, int num_scans, int nb4) {
+  return BoundTailRegion(n_pad, num_scans) + 8 * ((static_cast<size_t>(num_scans) + 1) & ~size_t{1}) +
+         4 * Tail4SumWords(num_scans * nb4 * nb4) + 20 * size_t{kList4Cap} + 20 * size_t{kBoundListCap} + 64;
+}
+
+template <int NB4>
+__global__ void __launch_bounds__(kBoundTailThreads)
+Rt2DBoundTail4Kernel(const Rt2DTileParams* __restrict__ params, const int* __restrict__ ub_global,
+                     unsigned* __restrict__ host_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tail_smem[];
+  __shared__ Rt2DTileParams P;
+  __shared__ int ctl[4];                       // [1] listed 4 x 4 blocks, [2] listed sub-blocks, [3] candidates
+  __shared__ unsigned long long red[kBoundTailThreads / 64];
+  constexpr int kThreads = kBoundTailThreads, kWaves = kThreads / 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int match = blockIdx.x;
+  CopyParams(&P, params + match, tid);
+  __syncthreads();
+  unsigned long long* const tl = P.timeline;
+  const int tl_block = P.timeline_finish_base + match;
+  Stamp(tl, tl_block, 0);
+  const int n = P.n, n_pad = P.n_pad, S = P.num_scans, nl = P.nl;
+  const int side = 2 * nl + 1, cands = side * side;
+  float* ax = reinterpret_cast<float*>(tail_smem);
+  float* ay = ax + n_pad;
+  float2* rots = reinterpret_cast<float2*>(tail_smem + BoundTailRegion(n_pad, S));
+  int* ub = reinterpret_cast<int*>(rots + ((S + 1) & ~1));
+  float* ubw = reinterpret_cast<float*>(ub);
+  const int nblk = S * NB4 * NB4;
+  int* list4 = ub + Tail4SumWords(nblk);
+  int* sub = list4 + kList4Cap;
+  int* list2 = sub + 4 * kList4Cap;
+  int* sums = list2 + kBoundListCap;
+  int* best16 = sums + 4 * kBoundListCap;
+  {
+    const auto* xyz = AsGlobal(P.xyz);
+    for (int i = tid; i < n_pad; i += kThreads) {
+      float x = 0.f, y = 0.f;
+      if (i < n) RotateZ(P.init_qw, P.init_qz, xyz[3 * i], xyz[3 * i + 1], &x, &y);
+      ax[i] = x;
+      ay[i] = y;
+    }
+    const auto* rot = AsGlobal(reinterpret_cast<const float*>(P.scan_rot));
+    for (int s = tid; s < S; s += kThreads) rots[s] = make_float2(rot[2 * s], rot[2 * s + 1]);
+    const auto* ubm = AsGlobal(ub_global + P.b4_ub_at);
+    for (int e = tid; e < nblk; e += kThreads) ub[e] = ubm[e];
+    if (tid < 4) ctl[tid] = 0;
+    if (tid < 16) best16[tid] = 0;
+  }
+  __syncthreads();
+  Stamp(tl, tl_block, 7);                      // staged: cloud, rotations, block sums
+  const Rt2DFrame F = FrameOf(P);
+  const int off_x = P.hl - nl, off_y = P.ht - nl;       // window start in image coordinates
+  const int box_x0 = P.box_x0, box_y0 = P.box_y0, T = P.T;
+  const int pchunks = n_pad >> 6;
+  bool outside = false;
+  const auto window_start = [&](const BoundDisc& D, int c, int* Xs, int* Ys) {
+    const int i = (c << 6) + lane;
+    const bool valid = i < n;
+    int ix, iy;
+    BoundCellOf(D, F, ax[i], ay[i], valid, &ix, &iy);
+    *Xs = ix + off_x;
+    *Ys = iy + off_y;
+    const bool inside = static_cast<unsigned>(*Xs - box_x0) < static_cast<unsigned>(T) &&
+                        static_cast<unsigned>(*Ys - box_y0) < static_cast<unsigned>(T);
+    if (valid && !inside) outside = true;
+    return valid && inside;
+  };
+  const bool verify = P.b_verify != 0;
+  const float kScale = ((1.f - 0.1f) - (1.f - (1.f - 0.1f))) / 32766.f;   // (kMaxCC - kMinCC) / 32766
+  const float slack = Rt2DBoundSlack(n);
+  const float per_m = kScale * static_cast<float>(kBoundUnit) / static_cast<float>(n);
+  const float per_q = kScale * static_cast<float>(1 << kQShift) / static_cast<float>(n);
+  // the largest weight among the candidates (x0 .. x0 + w - 1, y0 .. y0 + w - 1) of rotation s
+  const auto weight_max = [&](int s, int x0, int y0, int w) {
+    float wmax = 0.f;
+    for (int dyi = y0; dyi < min(y0 + w, side); ++dyi)
+      for (int dxi = x0; dxi < min(x0 + w, side); ++dxi) wmax = fmaxf(wmax, TileWeight(P, s, dxi - nl, dyi - nl));
+    return wmax;
+  };
+  const auto upper = [&](int byte_sum, float wmax) {
+    return (0.1f + per_m * static_cast<float>(byte_sum) + slack) * wmax * (1.f + 1e-5f);
+  };
+  const auto lower = [&](int q_sum, float w) {
+    return (0.1f + per_q * static_cast<float>(q_sum) - slack) * w * (1.f - 1e-5f);
+  };
+
+  // ---- B: weighted upper bounds of the 4 x 4 blocks, the best one -------------------------------
+  {
+    unsigned long long key = 0;
+    for (int e = tid; e < nblk; e += kThreads) {
+      const int s = e / (NB4 * NB4), b = e - s * (NB4 * NB4);
+      const int j = b / NB4, k = b - j * NB4;
+      const float bound = upper(ub[e], weight_max(s, 4 * k, 4 * j, 4));
+      ubw[e] = bound;
+      const unsigned long long mine =
+          (static_cast<unsigned long long>(__float_as_uint(fmaxf(bound, 0.f))) << 32) |
+          static_cast<unsigned>(0x7fffffff - e);
+      key = mine > key ? mine : key;
+    }
+    key = WaveMaxU64(key);
+    if (lane == 0) red[wave] = key;
+  }
+  __syncthreads();
+  unsigned long long best_key = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) best_key = red[w] > best_key ? red[w] : best_key;
+  const int best_e = 0x7fffffff - static_cast<int>(static_cast<unsigned>(best_key));
+  Stamp(tl, tl_block, 3);                      // weighted bounds, the best block known
+
+  const auto* qimage = AsGlobal(P.qimage);
+  const int gw = P.gpitch >> 1, grows = P.grows;
+  // the quantised sums of the W x W candidates at (x0, y0) of rotation s over `count` chunks from
+  // c_first on, c_step apart (cells of the HBM image; outside it: 0)
+  const auto cand_sums16 = [&](int s, int x0, int y0, int c_first, int c_step, int count, int (&sum)[16]) {
+    const BoundDisc D = MakeBoundDisc(P, rots[s]);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sum[q] = 0;
+#pragma unroll 1
+    for (int t = 0; t < count; ++t) {
+      const int cu = c_first + t * c_step;
+      int Xs = 0, Ys = 0;
+      const bool live = cu < pchunks && window_start(D, min(cu, pchunks - 1), &Xs, &Ys);
+      const int X = Xs + x0, Y = Ys + y0;
+      unsigned v[16];
+      bool ok[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int Xc = X + (q & 3), Yc = Y + (q >> 2);
+        ok[q] = live && Xc < gw && Yc < grows;
+        v[q] = qimage[ok[q] ? Yc * gw + Xc : 0];
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sum[q] += ok[q] ? static_cast<int>(v[q]) : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sum[q] = WaveSum(sum[q]);
+  };
+  const auto cand_sums4 = [&](int s, int x0, int y0, int c_first, int count, int (&sum)[4]) {
+    const BoundDisc D = MakeBoundDisc(P, rots[s]);
+    sum[0] = sum[1] = sum[2] = sum[3] = 0;
+    unsigned v[4][4];
+    bool ok[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int cu = c_first + u;
+      int Xs = 0, Ys = 0;
+      const bool live = u < count && cu < pchunks && window_start(D, min(cu, pchunks - 1), &Xs, &Ys);
+      const int X = Xs + x0, Y = Ys + y0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int Xc = X + (q & 1), Yc = Y + (q >> 1);
+        ok[u][q] = live && Xc < gw && Yc < grows;
+        v[u][q] = qimage[ok[u][q] ? Yc * gw + Xc : 0];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sum[q] += ok[u][q] ? static_cast<int>(v[u][q]) : 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sum[q] = WaveSum(sum[q]);
+  };
+  // the byte sums of the four 2 x 2 sub-blocks of the 4 x 4 block at (x0, y0) (multiples of 4)
+  // of rotation s over up to four chunks from c_first on: m2 at (Xs + x0 + 2 dk, Ys + y0 + 2 dj)
+  // -- the window start's own parity plane, two rows of two bytes
+  const auto* m2 = AsGlobal(P.m2);
+  const int m2_plane = P.m2_rows * P.m2_pitch;
+  const auto sub_sums = [&](int s, int x0, int y0, int c_first, int count, int (&sum)[4]) {
+    const BoundDisc D = MakeBoundDisc(P, rots[s]);
+    sum[0] = sum[1] = sum[2] = sum[3] = 0;
+    unsigned v[4][4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int cu = c_first + u;
+      int Xs = 0, Ys = 0;
+      ok[u] = u < count && cu < pchunks && window_start(D, min(cu, pchunks - 1), &Xs, &Ys);
+      const int at = ok[u] ? (((Ys & 1) << 1) | (Xs & 1)) * m2_plane + (((Ys + y0) >> 1)) * P.m2_pitch + ((Xs + x0) >> 1)
+                           : 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[u][q] = m2[at + (q >> 1) * P.m2_pitch + (q & 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sum[q] += ok[u] ? static_cast<int>(v[u][q]) : 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sum[q] = WaveSum(sum[q]);
+  };
+
+  if (verify) {
+    // EVERY block: its sixteen candidates, its four sub-block bounds; the sums go to qsum for
+    // the finish KERNEL (every candidate of the search space lies in exactly one block)
+    auto* qsum = AsGlobal(P.qsum);
+    bool violated = false;
+#pragma unroll 1
+    for (int e = wave; e < nblk; e += kWaves) {
+      const int s = e / (NB4 * NB4), b = e - s * (NB4 * NB4);
+      const int j = b / NB4, k = b - j * NB4;
+      int sum[16], sb[4] = {0, 0, 0, 0};
+      cand_sums16(s, 4 * k, 4 * j, 0, 1, pchunks, sum);
+      for (int c = 0; c < pchunks; c += 4) {
+        int part[4];
+        sub_sums(s, 4 * k, 4 * j, c, min(4, pchunks - c), part);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sb[q] += part[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int dxi = 4 * k + (q & 3), dyi = 4 * j + (q >> 2);
+        if (dxi >= side || dyi >= side) continue;
+        const float value = (0.1f + per_q * static_cast<float>(sum[q])) * TileWeight(P, s, dxi - nl, dyi - nl);
+        const int sq = ((q >> 3) << 1) | ((q >> 1) & 1);        // the sub-block (dj, dk) of candidate q
+        const float bound2 = upper(sb[sq], weight_max(s, 4 * k + 2 * (sq & 1), 4 * j + 2 * (sq >> 1), 2));
+        if (ubw[e] < value || bound2 < value) violated = true;
+        if (lane == 0) qsum[static_cast<size_t>(s) * cands + dxi * side + dyi] = sum[q];
+      }
+    }
+    if (violated && lane == 0) atomicOr(&P.misc[0], kBoundViolated);
+    if (outside) atomicOr(&P.misc[0], kOutOfBox);
+    if (tid == 0) {
+      P.bstat[0] = static_cast<unsigned>(4 * nblk);      // (x 4: sixteen candidates per block)
+      P.bstat[1] = static_cast<unsigned>(5 * nblk);      // bounds evaluated: the blocks' and their sub-blocks'
+    }
+    return;
+  }
+
+  // ---- the best block's sixteen candidates: chunks dealt over the wavefronts -------------------
+  const int best_s = best_e / (NB4 * NB4), best_b = best_e - best_s * (NB4 * NB4);
+  const int best_j = best_b / NB4, best_k = best_b - best_j * NB4;
+  {
+    int sum[16];
+    cand_sums16(best_s, 4 * best_k, 4 * best_j, wave, kWaves, (pchunks - wave + kWaves - 1) / kWaves, sum);
+    if (lane < 16) {
+      int mine = 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) mine = lane == q ? sum[q] : mine;
+      atomicAdd(&best16[lane], mine);
+    }
+  }
+  __syncthreads();
+  Stamp(tl, tl_block, 4);                      // the best block summed
+  float lb = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int dxi = 4 * best_k + (q & 3), dyi = 4 * best_j + (q >> 2);
+    if (dxi < side && dyi < side) lb = fmaxf(lb, lower(best16[q], TileWeight(P, best_s, dxi - nl, dyi - nl)));
+  }
+  // ---- C4: the other 4 x 4 blocks that reach the bound, their sub-blocks' byte sums ---------------
+  for (int e = tid; e < nblk; e += kThreads) {
+    if (e != best_e && ubw[e] >= lb) {
+      const int at = atomicAdd(&ctl[1], 1);
+      if (at < kList4Cap) {
+        list4[at] = e;
+        sub[4 * at] = sub[4 * at + 1] = sub[4 * at + 2] = sub[4 * at + 3] = 0;
+      }
+    }
+  }
+  __syncthreads();
+  const int listed4 = ctl[1];
+  const int groups = (pchunks + 3) >> 2;
+  bool flat = listed4 > kList4Cap;
+  if (!flat) {
+#pragma unroll 1
+    for (int u = wave; u < listed4 * groups; u += kWaves) {
+      const int at = u / groups, grp = u - at * groups;
+      const int e = list4[at];
+      const int s = e / (NB4 * NB4), b = e - s * (NB4 * NB4);
+      const int j = b / NB4, k = b - j * NB4;
+      int sum[4];
+      sub_sums(s, 4 * k, 4 * j, 4 * grp, min(4, pchunks - 4 * grp), sum);
+      if (lane < 4) {
+        int mine = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mine = lane == q ? sum[q] : mine;
+        atomicAdd(&sub[4 * at + lane], mine);
+      }
+    }
+    __syncthreads();
+    Stamp(tl, tl_block, 8);                    // the listed blocks' sub-blocks bounded
+    // ---- C2: the sub-blocks that reach the bound, their four candidates ---------------------------
+    for (int t = tid; t < 4 * listed4; t += kThreads) {
+      const int at = t >> 2, q = t & 3;
+      const int e = list4[at];
+      const int s = e / (NB4 * NB4), b = e - s * (NB4 * NB4);
+      const int j = b / NB4, k = b - j * NB4;
+      const int x0 = 4 * k + 2 * (q & 1), y0 = 4 * j + 2 * (q >> 1);
+      if (x0 >= side || y0 >= side) continue;
+      if (upper(sub[t], weight_max(s, x0, y0, 2)) >= lb) {
+        const int slot = atomicAdd(&ctl[2], 1);
+        if (slot < kBoundListCap) {
+          list2[slot] = (s << 16) | (y0 << 8) | x0;
+          sums[4 * slot] = sums[4 * slot + 1] = sums[4 * slot + 2] = sums[4 * slot + 3] = 0;
+        }
+      }
+    }
+    __syncthreads();
+    flat = ctl[2] > kBoundListCap;
+  }
+  const int listed2 = min(ctl[2], kBoundListCap);
+  if (!flat) {
+#pragma unroll 1
+    for (int u = wave; u < listed2 * groups; u += kWaves) {
+      const int at = u / groups, grp = u - at * groups;
+      const int code = list2[at];
+      int sum[4];
+      cand_sums4(code >> 16, code & 0xff, (code >> 8) & 0xff, 4 * grp, min(4, pchunks - 4 * grp), sum);
+      if (lane < 4) {
+        int mine = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mine = lane == q ? sum[q] : mine;
+        atomicAdd(&sums[4 * at + lane], mine);
+      }
+    }
+    __syncthreads();
+  }
+  if (outside) atomicOr(&P.misc[0], kOutOfBox);
+  Stamp(tl, tl_block, 5);                      // the surviving sub-blocks summed
+  if (tid == 0) {
+    P.bstat[0] = static_cast<unsigned>(4 + listed2);                               // (x 4: candidates summed)
+    P.bstat[1] = static_cast<unsigned>(nblk + 4 * min(listed4, kList4Cap));        // bounds evaluated
+    if (flat) atomicOr(&P.misc[0], kBoundFlat);
+  }
+  if (flat) {
+    // nothing to finish: the flag travels with the match's words, as the finish would send them
+    __syncthreads();
+    if (tid < 128)
+      host_out[static_cast<size_t>(match) * 128 + tid] =
+          __hip_atomic_load(&P.misc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  // ---- the finish: the best block's sixteen and the listed sub-blocks' four candidates each ------
+  int* cand_e = ub;
+  int* cand_q = ub + 16 + 4 * kBoundListCap;
+  __syncthreads();                             // (the bounds in `ub` have been read by everyone)
+  if (tid < 16 + 4 * listed2) {
+    int s, dxi, dyi, q_sum;
+    if (tid < 16) {
+      s = best_s; dxi = 4 * best_k + (tid & 3); dyi = 4 * best_j + (tid >> 2);
+      q_sum = best16[tid];
+    } else {
+      const int at = (tid - 16) >> 2, q = (tid - 16) & 3;
+      const int code = list2[at];
+      s = code >> 16; dxi = (code & 0xff) + (q & 1); dyi = ((code >> 8) & 0xff) + (q >> 1);
+      q_sum = sums[4 * at + q];
+    }
+    if (dxi < side && dyi < side) {
+      const int at = atomicAdd(&ctl[3], 1);
+      cand_e[at] = s * cands + dxi * side + dyi;
+      cand_q[at] = q_sum;
+    }
+  }
+  __syncthreads();
+  Rt2DFinishMatch<kThreads, true, false>(P, tail_smem, kBoundTailGroup, host_out, match, cand_e, cand_q, ctl[3]);
 }
 
 #endif  // CMX_RT_2D_BOUNDS_H_

@@ -120,6 +120,15 @@ struct Rt2DTileParams {
   int b_verify;              // debug switch rt2d_bounds_verify
   int b_ub_at;               // this match's block sums in the launch's HBM scratch (rotation groups > 1)
   int b_tail_at;             // LDS offset of rotations | block sums | list | sums (behind the fused finish's region)
+  // blocks of 4 x 4 translations (round 6): the sixteen phase planes of the 4 x 4 max-pooled image
+  // behind the 2 x 2 ones, and this match's LDS copy of them
+  const uint8_t* m4;
+  int m4_pitch, m4_rows;     // bytes per plane row (multiple of 4), rows per plane
+  int b4_c0, b4_r0;          // first plane column (multiple of 4) / row of the LDS copy
+  int b4_lpb, b4_lh;         // its pitch in bytes (an odd number of 8-byte pieces) and rows
+  int b4_pstride;            // LDS bytes from plane to plane (= 8 mod 128: two banks apart)
+  int b4_tail_at;            // LDS offset of rotations | block sums
+  int b4_ub_at;              // this match's 4 x 4 block sums in the launch's HBM scratch
 };
 
 // A barrier for data that travels through LDS only.  __syncthreads() carries a workgroup-scope
@@ -1197,6 +1206,9 @@ struct TileGeometry {
   size_t b_lds;             // bound kernel: dynamic LDS of this match
   size_t b_finish_room;     // of it: planes | zeros | cloud, which its fused finish lays out anew
   size_t b_tail_at;         // where the rest starts: behind those, and behind what the finish needs
+  int m4_pitch, m4_rows;    // 4 x 4 pooled planes (round 6)
+  int b4_lpb, b4_lh, b4_pstride;
+  size_t b4_tail_at, b4_lds;
 };
 
 }  // namespace
@@ -1421,6 +1433,10 @@ struct Rt2DTileCall::Impl {
   int tile_grid = 0, tile_threads = 512;
   bool fused = false;                   // one tile per match, prep fused into the tile kernel
   bool bounds = false;                  // block bounds first (rt_2d_bounds.h): fused shape only
+  bool split = false;                   // ... with the tail of every match in a kernel of its own
+  bool level4 = false;                  // ... and blocks of 4 x 4 translations first (always split)
+  size_t tail_lds = 0;
+  size_t bound4_lds = 0, tail4_lds = 0;
   int bound_nb = 0;                     // blocks per window axis (launch-wide: the largest)
   size_t bound_lds = 0;
   std::unique_ptr<WorkspaceLease> ws;
@@ -1684,7 +1700,15 @@ bool Rt2DTileCall::Plan() {
       g.m2_pitch = (((nx + g.hl) >> 1) + 28 + 3) & ~3;
       g.m2_rows = ((ny + g.ht) >> 1) + kBoundMaxBlocks + 2;
     }
-    g.image_bytes = g.q_bytes + 4 * static_cast<size_t>(g.m2_pitch) * g.m2_rows;
+    g.m4_pitch = g.m4_rows = 0;
+    if (side <= 2 * kBoundMaxBlocks) {
+      // (the sixteen phase planes of the 4 x 4 pooling: four block columns / rows and the 8-byte
+      // pieces of the LDS copy behind the last window start)
+      g.m4_pitch = (((nx + g.hl) >> 2) + 20 + 3) & ~3;
+      g.m4_rows = ((ny + g.ht) >> 2) + 4 + 2;
+    }
+    g.image_bytes = g.q_bytes + 4 * static_cast<size_t>(g.m2_pitch) * g.m2_rows +
+                    16 * static_cast<size_t>(g.m4_pitch) * g.m4_rows;
     {
       const int nb = launch_nb;                         // (the kernel is instantiated for the largest)
       // (rows are read as three aligned dwords and copied in 8-byte pieces; an odd number of
@@ -1698,6 +1722,21 @@ bool Rt2DTileCall::Plan() {
       // | rotations | block sums (later: the summed candidates and their sums) | list | its sums
       g.b_lds = 8 * ((static_cast<size_t>(sr.num_scans) + 1) & ~size_t{1}) +
                 4 * BoundSumWords(sr.num_scans * nb * nb) + 20 * size_t{kBoundListCap};   // (+ b_tail_at: below)
+      // 4 x 4 blocks: sixteen planes of (T / 4 + nb4 + 1) rows; a row holds T / 4 window starts,
+      // nb4 block columns, up to two columns in front (b4_c0 is a multiple of 4) and the seven
+      // bytes a shifted pair of dwords reads behind -- in an ODD number of 8-byte pieces (rows on
+      // different banks), the planes two banks apart (neighbouring cells lie in different planes)
+      const int nb4 = (launch_nb + 1) / 2;
+      g.b4_lpb = ((g.T >> 2) + nb4 + 9 + 7) & ~7;
+      if ((g.b4_lpb & 15) == 0) g.b4_lpb += 8;
+      g.b4_lh = (g.T >> 2) + nb4 + 1;
+      g.b4_pstride = g.b4_lh * g.b4_lpb;
+      g.b4_pstride += (8 - g.b4_pstride % 128 + 128) % 128;
+      g.b4_tail_at = 16 * static_cast<size_t>(g.b4_pstride) + ((static_cast<size_t>(nb4) * g.b4_lpb + 16 + 15) & ~size_t{15}) +
+                     8 * static_cast<size_t>(n_pad);
+      // | rotations | block sums (nothing else: the tail kernel has LDS of its own)
+      g.b4_lds = g.b4_tail_at + 8 * ((static_cast<size_t>(sr.num_scans) + 1) & ~size_t{1}) +
+                 4 * ((static_cast<size_t>(sr.num_scans) * nb4 * nb4 + 3) & ~size_t{3});
     }
     I.tile_lds = std::max(I.tile_lds, g.lds);
     I.prep_lds = std::max<size_t>(I.prep_lds, 6 * static_cast<size_t>(n_pad) + 512);
@@ -1737,16 +1776,29 @@ bool Rt2DTileCall::Plan() {
   // 139 - 161 / 106), 256: 144 / 168, 1024: 330 - 357 / 449 - 503 (profiles/r05_c1_bounds.txt).
   // Debug switches: rt2d_bounds = 1 always, rt2d_no_bounds never.
   I.bounds = I.fused && !dbg.rt2d_no_bounds && (I.batch_matches >= kBoundMinMatches || dbg.rt2d_bounds);
+  // (round 6) the tail of a match -- phases B, C and the finish: ~30 us of dependent round trips
+  // during which a workgroup's 70 KB of LDS and its place on the CU did nothing -- in a kernel of
+  // its own behind the bound kernel (Rt2DBoundTailKernel: 33 KB, every match of the part in flight
+  // at once).  rt2d_bounds_fused = 1: one kernel as in round 5 (the parity partner; verify mode).
+  I.split = I.bounds && !dbg.rt2d_bounds_verify && !dbg.rt2d_bounds_fused;
+  // (round 6) blocks of 4 x 4 translations first, their survivors refined by the tail kernel:
+  // rt2d_bounds_level = 2 keeps the 2 x 2 blocks as the first level (the parity partner)
+  I.level4 = I.bounds && !dbg.rt2d_bounds_fused && dbg.rt2d_bounds_level != 2;
   for (int m = 0; m < num && I.bounds; ++m) {
     const int side = 2 * search[m].nl + 1;
-    // (the bound kernel finishes a match itself, in the LDS of its planes and cloud -- a small
-    // box leaves less than the finish needs: the rest of the layout moves back)
-    geo[m].b_tail_at = std::max(geo[m].b_finish_room, Align16(I.finish_lds));
+    // (the fused bound kernel finishes a match itself, in the LDS of its planes and cloud -- a
+    // small box leaves less than the finish needs: the rest of the layout moves back)
+    geo[m].b_tail_at = I.split ? geo[m].b_finish_room : std::max(geo[m].b_finish_room, Align16(I.finish_lds));
+    I.tail_lds = std::max(I.tail_lds, BoundTailLds((items[m].n + 63) / 64 * 64, search[m].num_scans, launch_nb));
     geo[m].b_lds += geo[m].b_tail_at;
     I.bounds = side <= 2 * kBoundMaxBlocks && geo[m].b_lds <= 150 * size_t{1024};
     I.bound_nb = std::max(I.bound_nb, (side + 1) / 2);
     I.bound_lds = std::max(I.bound_lds, geo[m].b_lds);
+    I.bound4_lds = std::max(I.bound4_lds, geo[m].b4_lds);
+    I.tail4_lds = std::max(I.tail4_lds, BoundTail4Lds((items[m].n + 63) / 64 * 64, search[m].num_scans, (launch_nb + 1) / 2));
   }
+  I.level4 = I.level4 && I.bounds && I.bound4_lds <= 150 * size_t{1024};
+  if (I.level4) { I.split = true; I.bound_lds = I.bound4_lds; }
   if (I.bounds) {
     // rotation groups per match: about two items per CU over the whole call (an item stages the
     // match's planes and cloud: ~4 us), one per match in large batches
@@ -1824,7 +1876,8 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
   size_t ub_total = 0;
   for (int m = 0; m < num && I.bounds; ++m) {
     ub_at[m] = static_cast<int>(ub_total);
-    ub_total += static_cast<size_t>(search[m].num_scans) * I.bound_nb * I.bound_nb;
+    const int nb_level = I.level4 ? (I.bound_nb + 1) / 2 : I.bound_nb;
+    ub_total += static_cast<size_t>(search[m].num_scans) * nb_level * nb_level;
   }
   int* d_ub = I.bounds ? ws->dev[6].ReserveAs<int>(ub_total + 16) : nullptr;
   std::memset(h_in + off_misc, 0, sizeof(unsigned) * 128 * static_cast<size_t>(num));
@@ -1959,6 +2012,12 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
       P.m2_pitch = g.m2_pitch; P.m2_rows = g.m2_rows;
       P.b_c0 = (g.box_x0 >> 1) & ~3; P.b_r0 = g.box_y0 >> 1;
       P.b_lpb = g.b_lpb; P.b_lh = g.b_lh; P.b_tail_at = static_cast<int>(g.b_tail_at);
+      P.m4 = g.m4_rows ? P.m2 + 4 * static_cast<size_t>(g.m2_pitch) * g.m2_rows : nullptr;
+      P.m4_pitch = g.m4_pitch; P.m4_rows = g.m4_rows;
+      P.b4_c0 = (g.box_x0 >> 2) & ~3; P.b4_r0 = g.box_y0 >> 2;
+      P.b4_lpb = g.b4_lpb; P.b4_lh = g.b4_lh; P.b4_pstride = g.b4_pstride;
+      P.b4_tail_at = static_cast<int>(g.b4_tail_at);
+      P.b4_ub_at = ub_at[m];
       P.bstat = P.misc + 124;
       P.b_verify = dbg.rt2d_bounds_verify ? 1 : 0;
       P.b_ub_at = ub_at[m];
@@ -1987,6 +2046,11 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
       if (build_image[m]) max_words = std::max(max_words, static_cast<size_t>(geo[m].m2_pitch) * geo[m].m2_rows);
     if (max_words)
       Rt2DPoolKernel<<<dim3(DivUp(max_words, 256), num), 256, 0, ws->stream>>>(d_params);
+    size_t max_words4 = 0;
+    for (int m = 0; m < num; ++m)
+      if (build_image[m]) max_words4 = std::max(max_words4, 4 * static_cast<size_t>(geo[m].m4_pitch) * geo[m].m4_rows);
+    if (max_words4)
+      Rt2DPool4Kernel<<<dim3(DivUp(max_words4, 256), num), 256, 0, ws->stream>>>(d_params);
   }
   if (!I.fused)
     Rt2DTilePrepKernel<<<dim3(I.max_scans, num), 256, I.prep_lds, ws->stream>>>(
@@ -2014,19 +2078,43 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
       }
       kernel<<<static_cast<unsigned>(I.tile_grid), kBoundThreads, I.bound_lds, ws->stream>>>(
           d_params, d_work, d_counters, d_counters + 1, reinterpret_cast<int*>(d_in + off_tickets), d_ub,
-          I.group, I.h_misc);
+          I.group, I.h_misc, I.split ? 1 : 0);
+    };
+    const auto launch_tail = [&](auto kernel) {
+      OptInLds(reinterpret_cast<const void*>(kernel), device, 64 * 1024);
+      kernel<<<static_cast<unsigned>(num), kBoundTailThreads, I.level4 ? I.tail4_lds : I.tail_lds, ws->stream>>>(
+          d_params, d_ub, I.h_misc);
     };
     const int common_stride = I.common_stride;
-    if (I.bounds) {
+    if (I.level4) {
+      switch ((I.bound_nb + 1) / 2) {
+        case 1: launch_bounds(Rt2DBoundKernel<1, 2>); launch_tail(Rt2DBoundTail4Kernel<1>); break;
+        case 2: launch_bounds(Rt2DBoundKernel<2, 2>); launch_tail(Rt2DBoundTail4Kernel<2>); break;
+        case 3: launch_bounds(Rt2DBoundKernel<3, 2>); launch_tail(Rt2DBoundTail4Kernel<3>); break;
+        default: launch_bounds(Rt2DBoundKernel<4, 2>); launch_tail(Rt2DBoundTail4Kernel<4>); break;
+      }
+    } else if (I.bounds) {
       switch (I.bound_nb) {
-        case 1: launch_bounds(Rt2DBoundKernel<1>); break;
-        case 2: launch_bounds(Rt2DBoundKernel<2>); break;
-        case 3: launch_bounds(Rt2DBoundKernel<3>); break;
-        case 4: launch_bounds(Rt2DBoundKernel<4>); break;
-        case 5: launch_bounds(Rt2DBoundKernel<5>); break;
-        case 6: launch_bounds(Rt2DBoundKernel<6>); break;
-        case 7: launch_bounds(Rt2DBoundKernel<7>); break;
-        default: launch_bounds(Rt2DBoundKernel<8>); break;
+        case 1: launch_bounds(Rt2DBoundKernel<1, 1>); break;
+        case 2: launch_bounds(Rt2DBoundKernel<2, 1>); break;
+        case 3: launch_bounds(Rt2DBoundKernel<3, 1>); break;
+        case 4: launch_bounds(Rt2DBoundKernel<4, 1>); break;
+        case 5: launch_bounds(Rt2DBoundKernel<5, 1>); break;
+        case 6: launch_bounds(Rt2DBoundKernel<6, 1>); break;
+        case 7: launch_bounds(Rt2DBoundKernel<7, 1>); break;
+        default: launch_bounds(Rt2DBoundKernel<8, 1>); break;
+      }
+      if (I.split) {
+        switch (I.bound_nb) {
+          case 1: launch_tail(Rt2DBoundTailKernel<1>); break;
+          case 2: launch_tail(Rt2DBoundTailKernel<2>); break;
+          case 3: launch_tail(Rt2DBoundTailKernel<3>); break;
+          case 4: launch_tail(Rt2DBoundTailKernel<4>); break;
+          case 5: launch_tail(Rt2DBoundTailKernel<5>); break;
+          case 6: launch_tail(Rt2DBoundTailKernel<6>); break;
+          case 7: launch_tail(Rt2DBoundTailKernel<7>); break;
+          default: launch_tail(Rt2DBoundTailKernel<8>); break;
+        }
       }
     } else if (I.d_timeline) {               // the instrumented instantiations (runtime row stride)
       if (rpl == 1) launch(Rt2DTileKernel<1, 0, true>);

@@ -165,19 +165,29 @@ def test_fast2d_fused_and_unfused_batches_agree(sm, synth, c2, debug):
 # ----------------------------------------------------------------------------
 # Real-time 2D: bulk pass vs per-candidate kernels vs oracle
 # ----------------------------------------------------------------------------
-RT2D_PATHS = ["bounds", "tiles", "tiles1", "tiles64", "tiles56g", "0"]
+RT2D_PATHS = ["bounds", "bounds2", "bounds1", "tiles", "tiles1", "tiles64", "tiles56g", "0"]
 
 
 def _rt2d_path(debug, path):
     """'bounds' (round 5): upper bounds of 2 x 2 blocks of translations from a max-pooled
     image first, sums only for the blocks that reach the best lower bound (rt_2d_bounds.h; windows
-    beyond 16 x 16 cells take the next path); 'tiles': the exhaustive integer bulk pass out of LDS
+    beyond 16 x 16 cells take the next path) -- since round 6 as two kernels, the bounds of every
+    match (blocks of 4 x 4 translations first) and then the tails of every match (the surviving
+    blocks refined through their 2 x 2 sub-blocks); 'bounds2': two kernels, 2 x 2 blocks as the
+    first level; 'bounds1': 2 x 2 bounds and tail of a match by one workgroup in one kernel
+    (round 5's shape); 'tiles': the exhaustive integer bulk pass out of LDS
     tiles + exact finalists (one tile per match
     where it fits, discretised inside the tile kernel); 'tiles1': that shape through the prep
     kernel and its planner; 'tiles64' / 'tiles56g': the same with small tiles (up to 4 x 4 per match: sums meet by atomics) and
     with one work item per (tile, rotation); '0': one thread per candidate."""
     if path == "bounds":     # block bounds first where the window is at most 16 x 16 (the
         debug(rt2d_bounds=1)  # default from 192 matches per call on; here: calls of any size)
+        return
+    if path == "bounds2":
+        debug(rt2d_bounds=1, rt2d_bounds_level=2)
+        return
+    if path == "bounds1":
+        debug(rt2d_bounds=1, rt2d_bounds_fused=1)
         return
     if path == "0":
         debug(rt2d_legacy=1)
@@ -230,12 +240,13 @@ def test_rt2d_both_paths(sm, oracle, synth, debug, bulk, seed, size, beams, lin,
     # block bounds: the device summed a fraction of the search space (a bound per 2 x 2 block +
     # four candidates per surviving block), the exhaustive paths all of it
     side = 2 * math.ceil(lin / 0.05 - 1e-9) + 1
-    if bulk == "bounds" and 1 < side <= 16:
+    if bulk in ("bounds", "bounds2", "bounds1") and 1 < side <= 16:
         assert st["coarse_candidates"] < 0.6 * ref["num_candidates"], st
-    elif bulk not in ("0", "bounds") or side > 16:
+    elif bulk not in ("0", "bounds", "bounds2", "bounds1") or side > 16:
         assert st["coarse_candidates"] == ref["num_candidates"]
 
 
+@pytest.mark.parametrize("level", [4, 2])
 @pytest.mark.parametrize("seed,size,beams,lin,ang,weights", [
     (42, 200, 1000, 0.3, 7.0, (0.1, 0.1)),      # C1: 7 x 7 blocks per rotation
     (7, 200, 400, 0.3, 7.0, (0.0, 0.0)),
@@ -245,12 +256,14 @@ def test_rt2d_both_paths(sm, oracle, synth, debug, bulk, seed, size, beams, lin,
     (23, 64, 200, 0.05, 30.0, (0.1, 0.1)),      # 3 x 3: 2 x 2 blocks, many rotations
 ])
 def test_rt2d_block_bounds_dominate_their_candidates(sm, oracle, synth, debug, seed, size, beams,
-                                                      lin, ang, weights):
+                                                      lin, ang, weights, level):
     """The invariant the pruning of rt_2d_bounds.h rests on, checked on the device for EVERY block
     of the search space (debug switch rt2d_bounds_verify: all blocks are summed; the call fails
     if the weighted bound of a block lies below the weighted value of one of its own candidates):
-    the max-pooled byte image, the parity planes and their addressing, the weights' maxima."""
-    debug(rt2d_bounds_verify=1, rt2d_bounds=1)
+    the max-pooled byte image, the parity planes and their addressing, the weights' maxima.
+    level 4 (round 6): the 4 x 4 blocks of the first level AND the 2 x 2 sub-block bounds as the
+    tail kernel computes them, for every block; level 2: the 2 x 2 blocks as the first level."""
+    debug(rt2d_bounds_verify=1, rt2d_bounds=1, rt2d_bounds_level=level)
     cells, lim, world = synth.make_submap(seed, size, size, 0.05, 20, 600, 5.0, 0.01)
     pose = world.free_pose(seed + 100, 0.5)
     scan = world.scan(pose, beams, 5.0, 0.01, 7)
@@ -262,8 +275,12 @@ def test_rt2d_block_bounds_dominate_their_candidates(sm, oracle, synth, debug, s
     assert score == ref["score"]
     np.testing.assert_allclose([est.x, est.y, est.theta], ref["pose"], rtol=0, atol=1e-12)
     side = 2 * math.ceil(lin / 0.05 - 1e-9) + 1
-    blocks = ref["num_candidates"] // (side * side) * ((side + 1) // 2) ** 2
-    assert m.last_stats["coarse_candidates"] == 5 * blocks        # every bound + every block summed
+    if level == 2:
+        blocks = ref["num_candidates"] // (side * side) * ((side + 1) // 2) ** 2
+        assert m.last_stats["coarse_candidates"] == 5 * blocks    # every bound + every block summed
+    else:
+        blocks = ref["num_candidates"] // (side * side) * ((side + 3) // 4) ** 2
+        assert m.last_stats["coarse_candidates"] == 21 * blocks   # + sub-block bounds, sixteen candidates each
 
 
 @pytest.mark.parametrize("bulk", RT2D_PATHS)
