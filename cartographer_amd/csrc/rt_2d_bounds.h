@@ -803,45 +803,60 @@ Rt2DBoundTailKernel(const Rt2DTileParams* __restrict__ params, const int* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// grid (matches), 512 threads: the tail of a match behind Rt2DBoundKernel<NB4, 2>, two levels
+// grid (matches), kBoundTail4Threads threads: the tail of a match behind Rt2DBoundKernel<NB4, 2>
 // (round 6).  From the byte sums of the match's 4 x 4 blocks:
-//   B  weighted upper bounds; the best block's SIXTEEN candidates summed (quantised cells of the
-//      HBM image): the best weighted lower bound among them;
-//   C4 every other 4 x 4 block whose bound reaches it is listed (C1: eight or nine of 432) and its
-//      four 2 x 2 sub-blocks are bounded -- four bytes of the 2 x 2 planes (HBM / L2) per point;
-//   C2 the sub-blocks whose bound reaches the lower bound are listed (C1: five) and their four
-//      candidates summed, as the 2 x 2 tail sums them;
-//   the finish (Rt2DFinishMatch) over the best block's sixteen and the listed sub-blocks' four
-//   candidates each.
-// Why the result cannot change: as in the header of this file, with one more level -- a 4 x 4
-// block is dropped only if its bound (>= every member's weighted f32-chain score) lies strictly
-// below the lower bound of a candidate that IS summed, a sub-block likewise.  Debug switch
-// rt2d_bounds_verify: EVERY block's sixteen candidates are summed and checked against the 4 x 4
-// bound and against their sub-block's 2 x 2 bound as this kernel computes it.
-// Dynamic LDS: [Rt2DFinishMatch's region, over] ax[n_pad] | ay[n_pad] | (at BoundTailRegion)
-//   rots[num_scans] | ub[Tail4SumWords] | list4[kList4Cap] | sub[kList4Cap][4] |
-//   list2[kBoundListCap] | sums[kBoundListCap][4] | best16[16]
+//   B  weighted upper bounds; the best block's SIXTEEN candidates summed: the best weighted lower
+//      bound among them;
+//   C  every other block whose bound reaches it (C1: eight or nine of 432) has its sixteen
+//      candidates summed the same way, a wavefront per block;
+//   the finish (Rt2DFinishMatch) over the candidates of the summed blocks.
+// The candidates are summed out of LDS: the match's box of the BYTE image q8 = u >> 7
+// (Rt2DQuantKernel writes it next to the 10-bit one), the four candidates of a window row one
+// shifted dword, added as packed 16-bit fields.  A wave-wide gather from HBM / L2 with 64 distinct
+// lines costs 100 - 130 cycles of the CU's address path (profiles/r03_gather_ceiling.txt), and the
+// first version of this kernel -- 2 x 2 sub-block bounds from the planes in HBM, then the
+// candidates' cells -- spent 480 - 580 of them per match: 140 us per 1024 matches against the
+// bound kernel's 80.  The bytes are four times coarser than the 10-bit cells: a few more
+// candidates reach the finish's exact stages (its bounds carry the width of the quantisation).
+// Why the result cannot change: as in the header of this file -- a block is dropped only if its
+// bound (>= every member's weighted f32-chain score) lies strictly below the lower bound of a
+// candidate that IS summed.  Debug switch rt2d_bounds_verify: EVERY block's sixteen candidates are
+// summed and checked against the block's bound.
+// Dynamic LDS: [Rt2DFinishMatch's region, over] box[b8_lh][b8_lp] | zeros[4 b8_lp + 16] |
+//   ax[n_pad] | ay[n_pad] | (at Tail4Region) discs[num_scans] | ub[nblk] |
+//   raw[1 + kList4Cap][16] | list4[kList4Cap]; behind the finish's region, once the sums are
+//   done: cand_e[16 (1 + kList4Cap)] | cand_q[same]
 // ---------------------------------------------------------------------------------------------
-constexpr int kList4Cap = 96;                // 4 x 4 blocks refined per match; more: the per-candidate kernels
-__host__ __device__ constexpr size_t Tail4SumWords(int blocks) {
-  // (the block sums, later the summed candidates and their sums: 16 + 4 kBoundListCap of each)
-  const size_t cand = 2 * (16 + 4 * static_cast<size_t>(kBoundListCap));
-  return ((static_cast<size_t>(blocks) > cand ? static_cast<size_t>(blocks) : cand) + 3) & ~size_t{3};
+#ifndef CMX_RT2D_TAIL4_THREADS
+#define CMX_RT2D_TAIL4_THREADS 512
+#endif
+constexpr int kBoundTail4Threads = CMX_RT2D_TAIL4_THREADS;
+constexpr int kList4Cap = 128;               // 4 x 4 blocks summed per match besides the best; more: the per-candidate kernels
+__host__ __device__ constexpr size_t Tail4Region(int lp, int lh, int n_pad, int num_scans) {
+  const size_t fin = BoundTailRegion(n_pad, num_scans);
+  const size_t own = static_cast<size_t>(lh) * lp + ((4 * static_cast<size_t>(lp) + 16 + 15) & ~size_t{15}) +
+                     8 * static_cast<size_t>(n_pad);
+  // (behind the finish's region, over the box and the cloud that nobody reads any more: the
+  // candidates it is handed, index and sum)
+  const size_t handed = fin + 2 * 4 * 16 * static_cast<size_t>(1 + kList4Cap);
+  return ((handed > own ? handed : own) + 15) & ~size_t{15};
 }
-__host__ __device__ constexpr size_t BoundTail4Lds(int n_pad, int num_scans, int nb4) {
-  return BoundTailRegion(n_pad, num_scans) + 8 * ((static_cast<size_t>(num_scans) + 1) & ~size_t{1}) +
-         4 * Tail4SumWords(num_scans * nb4 * nb4) + 20 * size_t{kList4Cap} + 20 * size_t{kBoundListCap} + 64;
+__host__ __device__ constexpr size_t BoundTail4Lds(int lp, int lh, int n_pad, int num_scans, int nb4) {
+  return Tail4Region(lp, lh, n_pad, num_scans) + sizeof(BoundDisc) * static_cast<size_t>(num_scans) +
+         4 * ((static_cast<size_t>(num_scans) * nb4 * nb4 + 3) & ~size_t{3}) +
+         4 * (16 + 1) * static_cast<size_t>(1 + kList4Cap) + 64;
 }
 
 template <int NB4>
-__global__ void __launch_bounds__(kBoundTailThreads)
+__global__ void __launch_bounds__(kBoundTail4Threads, 4)
 Rt2DBoundTail4Kernel(const Rt2DTileParams* __restrict__ params, const int* __restrict__ ub_global,
                      unsigned* __restrict__ host_out) {
+  typedef unsigned U2 __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) unsigned char tail_smem[];
   __shared__ Rt2DTileParams P;
-  __shared__ int ctl[4];                       // [1] listed 4 x 4 blocks, [2] listed sub-blocks, [3] candidates
-  __shared__ unsigned long long red[kBoundTailThreads / 64];
-  constexpr int kThreads = kBoundTailThreads, kWaves = kThreads / 64;
+  __shared__ int ctl[4];                       // [1] listed blocks, [3] candidates for the finish
+  __shared__ unsigned long long red[kBoundTail4Threads / 64];
+  constexpr int kThreads = kBoundTail4Threads, kWaves = kThreads / 64;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int match = blockIdx.x;
@@ -852,17 +867,19 @@ Rt2DBoundTail4Kernel(const Rt2DTileParams* __restrict__ params, const int* __res
   Stamp(tl, tl_block, 0);
   const int n = P.n, n_pad = P.n_pad, S = P.num_scans, nl = P.nl;
   const int side = 2 * nl + 1, cands = side * side;
-  float* ax = reinterpret_cast<float*>(tail_smem);
-  float* ay = ax + n_pad;
-  float2* rots = reinterpret_cast<float2*>(tail_smem + BoundTailRegion(n_pad, S));
-  int* ub = reinterpret_cast<int*>(rots + ((S + 1) & ~1));
-  float* ubw = reinterpret_cast<float*>(ub);
   const int nblk = S * NB4 * NB4;
-  int* list4 = ub + Tail4SumWords(nblk);
-  int* sub = list4 + kList4Cap;
-  int* list2 = sub + 4 * kList4Cap;
-  int* sums = list2 + kBoundListCap;
-  int* best16 = sums + 4 * kBoundListCap;
+  const int lp = P.b8_lp, lh = P.b8_lh;
+  const int zero_at = lh * lp;                 // four rows of zeros at the box's pitch: what a lane without a point reads
+  const int zero_bytes = (4 * lp + 16 + 15) & ~15;
+  float* ax = reinterpret_cast<float*>(tail_smem + zero_at + zero_bytes);
+  float* ay = ax + n_pad;
+  BoundDisc* discs = reinterpret_cast<BoundDisc*>(tail_smem + Tail4Region(lp, lh, n_pad, S));
+  int* ub = reinterpret_cast<int*>(discs + S);
+  float* ubw = reinterpret_cast<float*>(ub);
+  int* raw = ub + ((nblk + 3) & ~3);           // [0]: the best block's sixteen sums, [1 + at]: listed block at
+  int* list4 = raw + 16 * (1 + kList4Cap);
+  int* cand_e = reinterpret_cast<int*>(tail_smem + BoundTailRegion(n_pad, S));   // (over the box: see Tail4Region)
+  int* cand_q = cand_e + 16 * (1 + kList4Cap);
   {
     const auto* xyz = AsGlobal(P.xyz);
     for (int i = tid; i < n_pad; i += kThreads) {
@@ -872,57 +889,65 @@ Rt2DBoundTail4Kernel(const Rt2DTileParams* __restrict__ params, const int* __res
       ay[i] = y;
     }
     const auto* rot = AsGlobal(reinterpret_cast<const float*>(P.scan_rot));
-    for (int s = tid; s < S; s += kThreads) rots[s] = make_float2(rot[2 * s], rot[2 * s + 1]);
+    for (int s = tid; s < S; s += kThreads) discs[s] = MakeBoundDisc(P, make_float2(rot[2 * s], rot[2 * s + 1]));
     const auto* ubm = AsGlobal(ub_global + P.b4_ub_at);
     for (int e = tid; e < nblk; e += kThreads) ub[e] = ubm[e];
     if (tid < 4) ctl[tid] = 0;
-    if (tid < 16) best16[tid] = 0;
+    if (tid < 16) raw[tid] = 0;
+    // the box of the byte image: 8-byte pieces (box_x0 and the image's pitch are multiples of 8),
+    // eight in flight per thread; beyond the image: zeros
+    const int ppr = lp >> 3, pieces = lh * ppr;
+    const int gw8 = P.gpitch >> 1;
+    const auto* src = (const __attribute__((address_space(1))) unsigned char*)P.q8;
+    const unsigned ppr_magic = 0xffffffffu / static_cast<unsigned>(ppr) + 1u;   // (exact below 2^16 pieces)
+    constexpr int kInFlight = 8;
+    for (int p0 = tid; p0 < pieces; p0 += kInFlight * kThreads) {
+      U2 v[kInFlight];
+#pragma unroll
+      for (int q = 0; q < kInFlight; ++q) {
+        const int p = min(p0 + q * kThreads, pieces - 1);
+        const int row = static_cast<int>(__umulhi(static_cast<unsigned>(p), ppr_magic)), piece = p - row * ppr;
+        const int X = P.box_x0 + (piece << 3), Y = P.box_y0 + row;
+        const bool in = X < gw8 && Y < P.grows;
+        v[q] = *reinterpret_cast<const __attribute__((address_space(1))) U2*>(src + (in ? Y * gw8 + X : 0));
+        if (!in) v[q] = U2{0u, 0u};
+      }
+#pragma unroll
+      for (int q = 0; q < kInFlight; ++q) {
+        const int p = p0 + q * kThreads;
+        if (p < pieces) reinterpret_cast<U2*>(tail_smem)[p] = v[q];
+      }
+    }
+    for (int w = tid; w < (zero_bytes >> 2); w += kThreads) reinterpret_cast<uint32_t*>(tail_smem + zero_at)[w] = 0;
   }
   __syncthreads();
-  Stamp(tl, tl_block, 7);                      // staged: cloud, rotations, block sums
+  Stamp(tl, tl_block, 7);                      // staged: box, cloud, discretisation constants, block sums
   const Rt2DFrame F = FrameOf(P);
   const int off_x = P.hl - nl, off_y = P.ht - nl;       // window start in image coordinates
   const int box_x0 = P.box_x0, box_y0 = P.box_y0, T = P.T;
   const int pchunks = n_pad >> 6;
   bool outside = false;
-  const auto window_start = [&](const BoundDisc& D, int c, int* Xs, int* Ys) {
-    const int i = (c << 6) + lane;
-    const bool valid = i < n;
-    int ix, iy;
-    BoundCellOf(D, F, ax[i], ay[i], valid, &ix, &iy);
-    *Xs = ix + off_x;
-    *Ys = iy + off_y;
-    const bool inside = static_cast<unsigned>(*Xs - box_x0) < static_cast<unsigned>(T) &&
-                        static_cast<unsigned>(*Ys - box_y0) < static_cast<unsigned>(T);
-    if (valid && !inside) outside = true;
-    return valid && inside;
-  };
   const bool verify = P.b_verify != 0;
   const float kScale = ((1.f - 0.1f) - (1.f - (1.f - 0.1f))) / 32766.f;   // (kMaxCC - kMinCC) / 32766
   const float slack = Rt2DBoundSlack(n);
   const float per_m = kScale * static_cast<float>(kBoundUnit) / static_cast<float>(n);
-  const float per_q = kScale * static_cast<float>(1 << kQShift) / static_cast<float>(n);
-  // the largest weight among the candidates (x0 .. x0 + w - 1, y0 .. y0 + w - 1) of rotation s
-  const auto weight_max = [&](int s, int x0, int y0, int w) {
-    float wmax = 0.f;
-    for (int dyi = y0; dyi < min(y0 + w, side); ++dyi)
-      for (int dxi = x0; dxi < min(x0 + w, side); ++dxi) wmax = fmaxf(wmax, TileWeight(P, s, dxi - nl, dyi - nl));
-    return wmax;
-  };
-  const auto upper = [&](int byte_sum, float wmax) {
-    return (0.1f + per_m * static_cast<float>(byte_sum) + slack) * wmax * (1.f + 1e-5f);
-  };
-  const auto lower = [&](int q_sum, float w) {
-    return (0.1f + per_q * static_cast<float>(q_sum) - slack) * w * (1.f - 1e-5f);
+  const float per_q = kScale * static_cast<float>(1 << kQ8Shift) / static_cast<float>(n);
+  // (the weight falls with the distance from the window's centre -- sqrt, the products and the
+  // exponential are monotone, and what a last-bit wobble of __expf could do lies far inside the
+  // 1e-5 the bounds carry: the block's largest weight is that of its candidate nearest the centre)
+  const auto weight_max = [&](int s, int x0, int y0) {
+    if (x0 >= side || y0 >= side) return 0.f;      // (no candidate: a smaller window in a launch for a larger one)
+    const int dxi = min(max(nl, x0), min(x0 + 4, side) - 1), dyi = min(max(nl, y0), min(y0 + 4, side) - 1);
+    return TileWeight(P, s, dxi - nl, dyi - nl);
   };
 
-  // ---- B: weighted upper bounds of the 4 x 4 blocks, the best one -------------------------------
+  // ---- B: weighted upper bounds of the blocks, the best one ------------------------------------
   {
     unsigned long long key = 0;
     for (int e = tid; e < nblk; e += kThreads) {
       const int s = e / (NB4 * NB4), b = e - s * (NB4 * NB4);
       const int j = b / NB4, k = b - j * NB4;
-      const float bound = upper(ub[e], weight_max(s, 4 * k, 4 * j, 4));
+      const float bound = (0.1f + per_m * static_cast<float>(ub[e]) + slack) * weight_max(s, 4 * k, 4 * j) * (1.f + 1e-5f);
       ubw[e] = bound;
       const unsigned long long mine =
           (static_cast<unsigned long long>(__float_as_uint(fmaxf(bound, 0.f))) << 32) |
@@ -939,218 +964,139 @@ Rt2DBoundTail4Kernel(const Rt2DTileParams* __restrict__ params, const int* __res
   const int best_e = 0x7fffffff - static_cast<int>(static_cast<unsigned>(best_key));
   Stamp(tl, tl_block, 3);                      // weighted bounds, the best block known
 
-  const auto* qimage = AsGlobal(P.qimage);
-  const int gw = P.gpitch >> 1, grows = P.grows;
-  // the quantised sums of the W x W candidates at (x0, y0) of rotation s over `count` chunks from
-  // c_first on, c_step apart (cells of the HBM image; outside it: 0)
-  const auto cand_sums16 = [&](int s, int x0, int y0, int c_first, int c_step, int count, int (&sum)[16]) {
-    const BoundDisc D = MakeBoundDisc(P, rots[s]);
+  // The byte sums of the sixteen candidates of block e over the chunks c_first, c_first +
+  // c_step, ...: lane q (< 16) returns the wavefront's sum of candidate q = 4 dy + dx.  Four chunks
+  // at a time; the four candidates of a window row are four neighbouring bytes of the box: two
+  // aligned dwords shifted into one (v_alignbyte_b32), added as two registers of 16-bit fields
+  // (a lane's thirty-two chunks of at most 255 stay far below 2^16).
+  const uint32_t* box32 = reinterpret_cast<const uint32_t*>(tail_smem);
+  const auto block_sums16 = [&](int e, int c_first, int c_step) -> int {
+    const int s = e / (NB4 * NB4), b = e - s * (NB4 * NB4);
+    const int j = b / NB4, k = b - j * NB4;
+    const BoundDisc D = discs[s];
+    const int rel = (4 * j - box_y0) * lp + 4 * k - box_x0;
+    unsigned acc[4][2];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) sum[q] = 0;
+    for (int r = 0; r < 4; ++r) acc[r][0] = acc[r][1] = 0;
 #pragma unroll 1
-    for (int t = 0; t < count; ++t) {
-      const int cu = c_first + t * c_step;
-      int Xs = 0, Ys = 0;
-      const bool live = cu < pchunks && window_start(D, min(cu, pchunks - 1), &Xs, &Ys);
-      const int X = Xs + x0, Y = Ys + y0;
-      unsigned v[16];
-      bool ok[16];
+    for (int c0 = c_first; c0 < pchunks; c0 += 4 * c_step) {
+      int at[4];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int Xc = X + (q & 3), Yc = Y + (q >> 2);
-        ok[q] = live && Xc < gw && Yc < grows;
-        v[q] = qimage[ok[q] ? Yc * gw + Xc : 0];
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u * c_step;
+        const int i = (min(c, pchunks - 1) << 6) + lane;
+        const bool valid = c < pchunks && i < n;
+        int ix, iy;
+        BoundCellOf(D, F, ax[i], ay[i], valid, &ix, &iy);
+        const int Xs = ix + off_x, Ys = iy + off_y;
+        const bool inside = static_cast<unsigned>(Xs - box_x0) < static_cast<unsigned>(T) &&
+                            static_cast<unsigned>(Ys - box_y0) < static_cast<unsigned>(T);
+        if (valid && !inside) outside = true;
+        at[u] = valid && inside ? Ys * lp + Xs + rel : zero_at;
       }
+      uint32_t w0[4][4], w1[4][4];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) sum[q] += ok[q] ? static_cast<int>(v[q]) : 0;
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int word = (at[u] + r * lp) >> 2;
+          w0[u][r] = box32[word];
+          w1[u][r] = box32[word + 1];
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // (the pitch is a multiple of 4: the byte shift is that of the block's first row)
+          const uint32_t w = __builtin_amdgcn_alignbyte(w1[u][r], w0[u][r], static_cast<unsigned>(at[u]) & 3u);
+          acc[r][0] += w & 0x00ff00ffu;            // candidates dx = 0 and 2
+          acc[r][1] += (w >> 8) & 0x00ff00ffu;     // candidates dx = 1 and 3
+        }
     }
+    int mine = 0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) sum[q] = WaveSum(sum[q]);
-  };
-  const auto cand_sums4 = [&](int s, int x0, int y0, int c_first, int count, int (&sum)[4]) {
-    const BoundDisc D = MakeBoundDisc(P, rots[s]);
-    sum[0] = sum[1] = sum[2] = sum[3] = 0;
-    unsigned v[4][4];
-    bool ok[4][4];
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int cu = c_first + u;
-      int Xs = 0, Ys = 0;
-      const bool live = u < count && cu < pchunks && window_start(D, min(cu, pchunks - 1), &Xs, &Ys);
-      const int X = Xs + x0, Y = Ys + y0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int Xc = X + (q & 1), Yc = Y + (q >> 1);
-        ok[u][q] = live && Xc < gw && Yc < grows;
-        v[u][q] = qimage[ok[u][q] ? Yc * gw + Xc : 0];
+      for (int h = 0; h < 4; ++h) {
+        const unsigned word = acc[r][h & 1];
+        const int total = WaveSum(static_cast<int>((h >> 1) ? word >> 16 : word & 0xffffu));
+        mine = lane == 4 * r + h ? total : mine;
       }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) sum[q] += ok[u][q] ? static_cast<int>(v[u][q]) : 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) sum[q] = WaveSum(sum[q]);
+    return mine;
   };
-  // the byte sums of the four 2 x 2 sub-blocks of the 4 x 4 block at (x0, y0) (multiples of 4)
-  // of rotation s over up to four chunks from c_first on: m2 at (Xs + x0 + 2 dk, Ys + y0 + 2 dj)
-  // -- the window start's own parity plane, two rows of two bytes
-  const auto* m2 = AsGlobal(P.m2);
-  const int m2_plane = P.m2_rows * P.m2_pitch;
-  const auto sub_sums = [&](int s, int x0, int y0, int c_first, int count, int (&sum)[4]) {
-    const BoundDisc D = MakeBoundDisc(P, rots[s]);
-    sum[0] = sum[1] = sum[2] = sum[3] = 0;
-    unsigned v[4][4];
-    bool ok[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int cu = c_first + u;
-      int Xs = 0, Ys = 0;
-      ok[u] = u < count && cu < pchunks && window_start(D, min(cu, pchunks - 1), &Xs, &Ys);
-      const int at = ok[u] ? (((Ys & 1) << 1) | (Xs & 1)) * m2_plane + (((Ys + y0) >> 1)) * P.m2_pitch + ((Xs + x0) >> 1)
-                           : 0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[u][q] = m2[at + (q >> 1) * P.m2_pitch + (q & 1)];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) sum[q] += ok[u] ? static_cast<int>(v[u][q]) : 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) sum[q] = WaveSum(sum[q]);
+  // candidate q of block e: its index in the search space, -1: outside the window
+  const auto candidate_of = [&](int e, int q) {
+    const int s = e / (NB4 * NB4), b = e - s * (NB4 * NB4);
+    const int j = b / NB4, k = b - j * NB4;
+    const int dxi = 4 * k + (q & 3), dyi = 4 * j + (q >> 2);
+    return dxi < side && dyi < side ? s * cands + dxi * side + dyi : -1;
+  };
+  const auto weight_of = [&](int candidate) {
+    const int s = candidate / cands, c = candidate - s * cands;
+    const int dxi = c / side, dyi = c - dxi * side;
+    return TileWeight(P, s, dxi - nl, dyi - nl);
   };
 
   if (verify) {
-    // EVERY block: its sixteen candidates, its four sub-block bounds; the sums go to qsum for
-    // the finish KERNEL (every candidate of the search space lies in exactly one block)
+    // EVERY block: its sixteen candidates against its bound; the sums go to qsum for the finish
+    // KERNEL (every candidate of the search space lies in exactly one block)
     auto* qsum = AsGlobal(P.qsum);
     bool violated = false;
 #pragma unroll 1
     for (int e = wave; e < nblk; e += kWaves) {
-      const int s = e / (NB4 * NB4), b = e - s * (NB4 * NB4);
-      const int j = b / NB4, k = b - j * NB4;
-      int sum[16], sb[4] = {0, 0, 0, 0};
-      cand_sums16(s, 4 * k, 4 * j, 0, 1, pchunks, sum);
-      for (int c = 0; c < pchunks; c += 4) {
-        int part[4];
-        sub_sums(s, 4 * k, 4 * j, c, min(4, pchunks - c), part);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) sb[q] += part[q];
-      }
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int dxi = 4 * k + (q & 3), dyi = 4 * j + (q >> 2);
-        if (dxi >= side || dyi >= side) continue;
-        const float value = (0.1f + per_q * static_cast<float>(sum[q])) * TileWeight(P, s, dxi - nl, dyi - nl);
-        const int sq = ((q >> 3) << 1) | ((q >> 1) & 1);        // the sub-block (dj, dk) of candidate q
-        const float bound2 = upper(sb[sq], weight_max(s, 4 * k + 2 * (sq & 1), 4 * j + 2 * (sq >> 1), 2));
-        if (ubw[e] < value || bound2 < value) violated = true;
-        if (lane == 0) qsum[static_cast<size_t>(s) * cands + dxi * side + dyi] = sum[q];
+      const int sum = block_sums16(e, 0, 1);
+      const int candidate = lane < 16 ? candidate_of(e, lane) : -1;
+      if (candidate >= 0) {
+        if (ubw[e] < (0.1f + per_q * static_cast<float>(sum)) * weight_of(candidate)) violated = true;
+        qsum[candidate] = sum;
       }
     }
-    if (violated && lane == 0) atomicOr(&P.misc[0], kBoundViolated);
+    if (violated) atomicOr(&P.misc[0], kBoundViolated);
     if (outside) atomicOr(&P.misc[0], kOutOfBox);
     if (tid == 0) {
-      P.bstat[0] = static_cast<unsigned>(4 * nblk);      // (x 4: sixteen candidates per block)
-      P.bstat[1] = static_cast<unsigned>(5 * nblk);      // bounds evaluated: the blocks' and their sub-blocks'
+      P.bstat[0] = static_cast<unsigned>(S * cands);     // candidates summed: all
+      P.bstat[1] = static_cast<unsigned>(nblk);          // bounds evaluated
     }
     return;
   }
 
-  // ---- the best block's sixteen candidates: chunks dealt over the wavefronts -------------------
-  const int best_s = best_e / (NB4 * NB4), best_b = best_e - best_s * (NB4 * NB4);
-  const int best_j = best_b / NB4, best_k = best_b - best_j * NB4;
+  // ---- the best block's sixteen candidates: its chunks dealt over the wavefronts -----------------
   {
-    int sum[16];
-    cand_sums16(best_s, 4 * best_k, 4 * best_j, wave, kWaves, (pchunks - wave + kWaves - 1) / kWaves, sum);
-    if (lane < 16) {
-      int mine = 0;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) mine = lane == q ? sum[q] : mine;
-      atomicAdd(&best16[lane], mine);
-    }
+    const int sum = block_sums16(best_e, wave, kWaves);
+    if (lane < 16) atomicAdd(&raw[lane], sum);
   }
   __syncthreads();
   Stamp(tl, tl_block, 4);                      // the best block summed
   float lb = 0.f;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int dxi = 4 * best_k + (q & 3), dyi = 4 * best_j + (q >> 2);
-    if (dxi < side && dyi < side) lb = fmaxf(lb, lower(best16[q], TileWeight(P, best_s, dxi - nl, dyi - nl)));
+  {
+    // (sixteen lanes of every wavefront: the same sixteen values, no barrier for a broadcast)
+    const int candidate = lane < 16 ? candidate_of(best_e, lane) : -1;
+    if (candidate >= 0)
+      lb = (0.1f + per_q * static_cast<float>(raw[lane]) - slack) * weight_of(candidate) * (1.f - 1e-5f);
+    lb = __uint_as_float(static_cast<unsigned>(WaveMaxDpp(static_cast<int>(__float_as_uint(fmaxf(lb, 0.f))))));
   }
-  // ---- C4: the other 4 x 4 blocks that reach the bound, their sub-blocks' byte sums ---------------
+  // ---- C: the other blocks that reach the bound, a wavefront per block --------------------------
   for (int e = tid; e < nblk; e += kThreads) {
     if (e != best_e && ubw[e] >= lb) {
       const int at = atomicAdd(&ctl[1], 1);
-      if (at < kList4Cap) {
-        list4[at] = e;
-        sub[4 * at] = sub[4 * at + 1] = sub[4 * at + 2] = sub[4 * at + 3] = 0;
-      }
+      if (at < kList4Cap) list4[at] = e;
     }
   }
   __syncthreads();
-  const int listed4 = ctl[1];
-  const int groups = (pchunks + 3) >> 2;
-  bool flat = listed4 > kList4Cap;
+  const bool flat = ctl[1] > kList4Cap;
+  const int listed4 = min(ctl[1], kList4Cap);
   if (!flat) {
 #pragma unroll 1
-    for (int u = wave; u < listed4 * groups; u += kWaves) {
-      const int at = u / groups, grp = u - at * groups;
-      const int e = list4[at];
-      const int s = e / (NB4 * NB4), b = e - s * (NB4 * NB4);
-      const int j = b / NB4, k = b - j * NB4;
-      int sum[4];
-      sub_sums(s, 4 * k, 4 * j, 4 * grp, min(4, pchunks - 4 * grp), sum);
-      if (lane < 4) {
-        int mine = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) mine = lane == q ? sum[q] : mine;
-        atomicAdd(&sub[4 * at + lane], mine);
-      }
+    for (int at = wave; at < listed4; at += kWaves) {
+      const int sum = block_sums16(list4[at], 0, 1);
+      if (lane < 16) raw[16 * (1 + at) + lane] = sum;
     }
-    __syncthreads();
-    Stamp(tl, tl_block, 8);                    // the listed blocks' sub-blocks bounded
-    // ---- C2: the sub-blocks that reach the bound, their four candidates ---------------------------
-    for (int t = tid; t < 4 * listed4; t += kThreads) {
-      const int at = t >> 2, q = t & 3;
-      const int e = list4[at];
-      const int s = e / (NB4 * NB4), b = e - s * (NB4 * NB4);
-      const int j = b / NB4, k = b - j * NB4;
-      const int x0 = 4 * k + 2 * (q & 1), y0 = 4 * j + 2 * (q >> 1);
-      if (x0 >= side || y0 >= side) continue;
-      if (upper(sub[t], weight_max(s, x0, y0, 2)) >= lb) {
-        const int slot = atomicAdd(&ctl[2], 1);
-        if (slot < kBoundListCap) {
-          list2[slot] = (s << 16) | (y0 << 8) | x0;
-          sums[4 * slot] = sums[4 * slot + 1] = sums[4 * slot + 2] = sums[4 * slot + 3] = 0;
-        }
-      }
-    }
-    __syncthreads();
-    flat = ctl[2] > kBoundListCap;
-  }
-  const int listed2 = min(ctl[2], kBoundListCap);
-  if (!flat) {
-#pragma unroll 1
-    for (int u = wave; u < listed2 * groups; u += kWaves) {
-      const int at = u / groups, grp = u - at * groups;
-      const int code = list2[at];
-      int sum[4];
-      cand_sums4(code >> 16, code & 0xff, (code >> 8) & 0xff, 4 * grp, min(4, pchunks - 4 * grp), sum);
-      if (lane < 4) {
-        int mine = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) mine = lane == q ? sum[q] : mine;
-        atomicAdd(&sums[4 * at + lane], mine);
-      }
-    }
-    __syncthreads();
   }
   if (outside) atomicOr(&P.misc[0], kOutOfBox);
-  Stamp(tl, tl_block, 5);                      // the surviving sub-blocks summed
+  __syncthreads();
+  Stamp(tl, tl_block, 5);                      // the surviving blocks summed
   if (tid == 0) {
-    P.bstat[0] = static_cast<unsigned>(4 + listed2);                               // (x 4: candidates summed)
-    P.bstat[1] = static_cast<unsigned>(nblk + 4 * min(listed4, kList4Cap));        // bounds evaluated
+    P.bstat[1] = static_cast<unsigned>(nblk);                                      // bounds evaluated
     if (flat) atomicOr(&P.misc[0], kBoundFlat);
   }
   if (flat) {
@@ -1161,29 +1107,20 @@ Rt2DBoundTail4Kernel(const Rt2DTileParams* __restrict__ params, const int* __res
           __hip_atomic_load(&P.misc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
-  // ---- the finish: the best block's sixteen and the listed sub-blocks' four candidates each ------
-  int* cand_e = ub;
-  int* cand_q = ub + 16 + 4 * kBoundListCap;
-  __syncthreads();                             // (the bounds in `ub` have been read by everyone)
-  if (tid < 16 + 4 * listed2) {
-    int s, dxi, dyi, q_sum;
-    if (tid < 16) {
-      s = best_s; dxi = 4 * best_k + (tid & 3); dyi = 4 * best_j + (tid >> 2);
-      q_sum = best16[tid];
-    } else {
-      const int at = (tid - 16) >> 2, q = (tid - 16) & 3;
-      const int code = list2[at];
-      s = code >> 16; dxi = (code & 0xff) + (q & 1); dyi = ((code >> 8) & 0xff) + (q >> 1);
-      q_sum = sums[4 * at + q];
-    }
-    if (dxi < side && dyi < side) {
+  // ---- the finish over the candidates of the summed blocks ----------------------------------------
+  for (int t = tid; t < 16 * (1 + listed4); t += kThreads) {
+    const int e = t < 16 ? best_e : list4[(t >> 4) - 1];
+    const int candidate = candidate_of(e, t & 15);
+    if (candidate >= 0) {
       const int at = atomicAdd(&ctl[3], 1);
-      cand_e[at] = s * cands + dxi * side + dyi;
-      cand_q[at] = q_sum;
+      cand_e[at] = candidate;
+      cand_q[at] = raw[t];
     }
   }
   __syncthreads();
-  Rt2DFinishMatch<kThreads, true, false>(P, tail_smem, kBoundTailGroup, host_out, match, cand_e, cand_q, ctl[3]);
+  if (tid == 0) P.bstat[0] = static_cast<unsigned>(ctl[3]);                        // candidates summed
+  Rt2DFinishMatch<kThreads, true, false, kQ8Shift>(P, tail_smem, kBoundTailGroup, host_out, match, cand_e, cand_q,
+                                                    ctl[3]);
 }
 
 #endif  // CMX_RT_2D_BOUNDS_H_

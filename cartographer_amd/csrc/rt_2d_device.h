@@ -10,6 +10,7 @@ namespace cmx {
 
 // Integer bulk pass (rt_2d_tiles.hip): cells enter LDS as q = u >> kQShift, u = 32767 - value.
 constexpr int kQShift = 5;
+constexpr int kQ8Shift = 7;                  // the byte image of the bound kernel's tail: q8 = u >> 7 <= 255
 constexpr int kRt2DMaxPoints = 8192;        // points per scan the tile path takes
 // Finalists of a match: (candidate index, f32 score bits) pairs -- the first kFinalistHead next
 // to the counters (they travel back with them), the rest in the overflow region.

@@ -129,6 +129,10 @@ struct Rt2DTileParams {
   int b4_pstride;            // LDS bytes from plane to plane (= 8 mod 128: two banks apart)
   int b4_tail_at;            // LDS offset of rotations | block sums
   int b4_ub_at;              // this match's 4 x 4 block sums in the launch's HBM scratch
+  // the image once more as BYTES, q8 = u >> 7, rows of gpitch / 2 bytes behind the planes: the tail
+  // kernel holds the match's box of it in LDS (b8_lh rows of b8_lp bytes from (box_x0, box_y0) on)
+  uint8_t* q8;
+  int b8_lp, b8_lh;
 };
 
 // A barrier for data that travels through LDS only.  __syncthreads() carries a workgroup-scope
@@ -175,6 +179,7 @@ Rt2DQuantKernel(const Rt2DTileParams* __restrict__ params) {
   const auto* cells = AsGlobal(P.cells);
   const int gy = Y - P.ht;
   unsigned q[8];
+  unsigned long long bytes = 0;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int gx = X0 + c - P.hl;
@@ -185,7 +190,9 @@ Rt2DQuantKernel(const Rt2DTileParams* __restrict__ params) {
       val = raw ? (32767u - raw) >> kQShift : 0u;
     }
     q[c] = val;
+    bytes |= static_cast<unsigned long long>(val >> (kQ8Shift - kQShift)) << (8 * c);
   }
+  if (P.q8) reinterpret_cast<unsigned long long*>(P.q8)[v] = bytes;
   reinterpret_cast<uint4*>(P.qimage)[v] = make_uint4(q[0] | (q[1] << 16), q[2] | (q[3] << 16),
                                                      q[4] | (q[5] << 16), q[6] | (q[7] << 16));
 }
@@ -327,7 +334,7 @@ Rt2DTilePrepKernel(const Rt2DTileParams* __restrict__ params, int* __restrict__ 
 // `cand_e` / `cand_q` (LDS, outside the region this function lays out; or null): the candidates
 // the caller has summed and their quantised sums -- the bound kernel, rt_2d_bounds.h: every other
 // candidate of the match lies below the best lower bound and is not looked at.
-template <int kThreads, bool kCoherent, bool kTimeline>
+template <int kThreads, bool kCoherent, bool kTimeline, int kShift = kQShift>
 __device__ __forceinline__ void Rt2DFinishMatch(Rt2DTileParams& P, unsigned char* fin_smem, int group,
                                                 unsigned* __restrict__ host_out, int match,
                                                 const int* cand_e = nullptr, const int* cand_q = nullptr,
@@ -363,8 +370,9 @@ __device__ __forceinline__ void Rt2DFinishMatch(Rt2DTileParams& P, unsigned char
   for (int s = tid; s < P.num_scans; s += kThreads) rot_flag[s] = 0;
   const float kScale = ((1.f - 0.1f) - (1.f - (1.f - 0.1f))) / 32766.f;   // (kMaxCC - kMinCC) / 32766
   const float slack = Rt2DBoundSlack(n);
-  const float per_q = kScale * static_cast<float>(1 << kQShift) / static_cast<float>(n);
-  const float width = kScale * static_cast<float>((1 << kQShift) - 1);
+  // (kShift: how coarsely the caller's sums were quantised -- the bound kernel's tail sums bytes)
+  const float per_q = kScale * static_cast<float>(1 << kShift) / static_cast<float>(n);
+  const float width = kScale * static_cast<float>((1 << kShift) - 1);
   const int* __restrict__ qsum = P.qsum;
   // (kCoherent: the sums were written by other workgroups of the SAME launch, through to memory)
   const auto load_sum = [&](int at) {
@@ -1140,6 +1148,9 @@ Rt2DTileKernel(const Rt2DTileParams* __restrict__ params, const int4* __restrict
   }   // work items
 }
 
+// (kShift: what the sums in qsum were quantised by -- the tile kernels' 10-bit cells, or the bytes
+// of the bound kernel's tail in its verify mode)
+template <int kShift>
 __global__ void __launch_bounds__(kFinishThreads)
 Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group,
                  unsigned* __restrict__ host_out) {
@@ -1147,7 +1158,7 @@ Rt2DFinishKernel(const Rt2DTileParams* __restrict__ params, int group,
   __shared__ Rt2DTileParams P;
   CopyParams(&P, params + blockIdx.x, threadIdx.x);
   __syncthreads();
-  Rt2DFinishMatch<kFinishThreads, false, true>(P, fin_smem, group, host_out, blockIdx.x);
+  Rt2DFinishMatch<kFinishThreads, false, true, kShift>(P, fin_smem, group, host_out, blockIdx.x);
 }
 
 #include "rt_2d_bounds.h"
@@ -1207,6 +1218,9 @@ struct TileGeometry {
   size_t b_finish_room;     // of it: planes | zeros | cloud, which its fused finish lays out anew
   size_t b_tail_at;         // where the rest starts: behind those, and behind what the finish needs
   int m4_pitch, m4_rows;    // 4 x 4 pooled planes (round 6)
+  size_t q8_bytes;          // the byte image behind them
+  int b8_lp, b8_lh;         // tail kernel: LDS box of the byte image
+  size_t t4_lds;
   int b4_lpb, b4_lh, b4_pstride;
   size_t b4_tail_at, b4_lds;
 };
@@ -1707,8 +1721,9 @@ bool Rt2DTileCall::Plan() {
       g.m4_pitch = (((nx + g.hl) >> 2) + 20 + 3) & ~3;
       g.m4_rows = ((ny + g.ht) >> 2) + 4 + 2;
     }
+    g.q8_bytes = g.m4_rows ? Align16(static_cast<size_t>(g.gpitch >> 1) * g.grows) : 0;
     g.image_bytes = g.q_bytes + 4 * static_cast<size_t>(g.m2_pitch) * g.m2_rows +
-                    16 * static_cast<size_t>(g.m4_pitch) * g.m4_rows;
+                    16 * static_cast<size_t>(g.m4_pitch) * g.m4_rows + g.q8_bytes;
     {
       const int nb = launch_nb;                         // (the kernel is instantiated for the largest)
       // (rows are read as three aligned dwords and copied in 8-byte pieces; an odd number of
@@ -1734,6 +1749,12 @@ bool Rt2DTileCall::Plan() {
       g.b4_pstride += (8 - g.b4_pstride % 128 + 128) % 128;
       g.b4_tail_at = 16 * static_cast<size_t>(g.b4_pstride) + ((static_cast<size_t>(nb4) * g.b4_lpb + 16 + 15) & ~size_t{15}) +
                      8 * static_cast<size_t>(n_pad);
+      // the tail kernel's box of the byte image: every window start of the box plus the 4 nb4
+      // cells of the blocks, eight bytes for the shifted dword pair; an odd number of 8-byte pieces
+      g.b8_lp = (g.T + 4 * nb4 + 8 + 7) & ~7;
+      if ((g.b8_lp & 15) == 0) g.b8_lp += 8;
+      g.b8_lh = g.T + 4 * nb4;
+      g.t4_lds = BoundTail4Lds(g.b8_lp, g.b8_lh, n_pad, sr.num_scans, nb4);
       // | rotations | block sums (nothing else: the tail kernel has LDS of its own)
       g.b4_lds = g.b4_tail_at + 8 * ((static_cast<size_t>(sr.num_scans) + 1) & ~size_t{1}) +
                  4 * ((static_cast<size_t>(sr.num_scans) * nb4 * nb4 + 3) & ~size_t{3});
@@ -1795,7 +1816,7 @@ bool Rt2DTileCall::Plan() {
     I.bound_nb = std::max(I.bound_nb, (side + 1) / 2);
     I.bound_lds = std::max(I.bound_lds, geo[m].b_lds);
     I.bound4_lds = std::max(I.bound4_lds, geo[m].b4_lds);
-    I.tail4_lds = std::max(I.tail4_lds, BoundTail4Lds((items[m].n + 63) / 64 * 64, search[m].num_scans, (launch_nb + 1) / 2));
+    I.tail4_lds = std::max(I.tail4_lds, geo[m].t4_lds);
   }
   I.level4 = I.level4 && I.bounds && I.bound4_lds <= 150 * size_t{1024};
   if (I.level4) { I.split = true; I.bound_lds = I.bound4_lds; }
@@ -2018,6 +2039,8 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
       P.b4_lpb = g.b4_lpb; P.b4_lh = g.b4_lh; P.b4_pstride = g.b4_pstride;
       P.b4_tail_at = static_cast<int>(g.b4_tail_at);
       P.b4_ub_at = ub_at[m];
+      P.q8 = g.q8_bytes ? const_cast<uint8_t*>(P.m4) + 16 * static_cast<size_t>(g.m4_pitch) * g.m4_rows : nullptr;
+      P.b8_lp = g.b8_lp; P.b8_lh = g.b8_lh;
       P.bstat = P.misc + 124;
       P.b_verify = dbg.rt2d_bounds_verify ? 1 : 0;
       P.b_ub_at = ub_at[m];
@@ -2081,9 +2104,9 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
           I.group, I.h_misc, I.split ? 1 : 0);
     };
     const auto launch_tail = [&](auto kernel) {
-      OptInLds(reinterpret_cast<const void*>(kernel), device, 64 * 1024);
-      kernel<<<static_cast<unsigned>(num), kBoundTailThreads, I.level4 ? I.tail4_lds : I.tail_lds, ws->stream>>>(
-          d_params, d_ub, I.h_misc);
+      OptInLds(reinterpret_cast<const void*>(kernel), device, 160 * 1024 - 4096);
+      kernel<<<static_cast<unsigned>(num), I.level4 ? kBoundTail4Threads : kBoundTailThreads,
+               I.level4 ? I.tail4_lds : I.tail_lds, ws->stream>>>(d_params, d_ub, I.h_misc);
     };
     const int common_stride = I.common_stride;
     if (I.level4) {
@@ -2136,8 +2159,13 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
   RecordEvent(ws->ev_k1, ws->stream);
   // (the bound kernel has finished its matches itself; in its verify mode it leaves every sum)
   if (!I.bounds || dbg.rt2d_bounds_verify) {
-    OptInLds(reinterpret_cast<const void*>(Rt2DFinishKernel), device, 128 * 1024);
-    Rt2DFinishKernel<<<num, kFinishThreads, I.finish_lds, ws->stream>>>(d_params, I.group, I.h_misc);
+    if (I.level4) {     // (verify mode of the 4 x 4 level: byte sums)
+      OptInLds(reinterpret_cast<const void*>(Rt2DFinishKernel<kQ8Shift>), device, 128 * 1024);
+      Rt2DFinishKernel<kQ8Shift><<<num, kFinishThreads, I.finish_lds, ws->stream>>>(d_params, I.group, I.h_misc);
+    } else {
+      OptInLds(reinterpret_cast<const void*>(Rt2DFinishKernel<kQShift>), device, 128 * 1024);
+      Rt2DFinishKernel<kQShift><<<num, kFinishThreads, I.finish_lds, ws->stream>>>(d_params, I.group, I.h_misc);
+    }
   }
   CMX_HIP(hipGetLastError());
   RecordEvent(ws->ev_end, ws->stream);
@@ -2215,7 +2243,8 @@ bool Rt2DTileCall::Collect(cmx_match_stats* stats) {
     total.candidates_scored += cands;
     // (what the device summed: the whole search space, or -- block bounds -- one bound per
     // 2 x 2 block of translations plus the four candidates of the blocks that reach the bound)
-    total.coarse_candidates += I.bounds ? static_cast<long long>(head[125]) + 4ll * head[124] : cands;
+    // (head[124]: 2 x 2 blocks summed, four candidates each -- or, 4 x 4 level, the candidates summed)
+    total.coarse_candidates += I.bounds ? static_cast<long long>(head[125]) + (I.level4 ? 1ll : 4ll) * head[124] : cands;
     total.num_scans += search[m].num_scans;
     total.refined_candidates += head[126];        // candidates re-summed with exact integers
     total.finalists += head[127] & 0xffffu;       // candidates scored with the reference's f32 chain

@@ -172,8 +172,8 @@ def _rt2d_path(debug, path):
     """'bounds' (round 5): upper bounds of 2 x 2 blocks of translations from a max-pooled
     image first, sums only for the blocks that reach the best lower bound (rt_2d_bounds.h; windows
     beyond 16 x 16 cells take the next path) -- since round 6 as two kernels, the bounds of every
-    match (blocks of 4 x 4 translations first) and then the tails of every match (the surviving
-    blocks refined through their 2 x 2 sub-blocks); 'bounds2': two kernels, 2 x 2 blocks as the
+    match (blocks of 4 x 4 translations) and then the tails of every match (the sixteen
+    candidates of every surviving block summed); 'bounds2': two kernels, 2 x 2 blocks as the
     first level; 'bounds1': 2 x 2 bounds and tail of a match by one workgroup in one kernel
     (round 5's shape); 'tiles': the exhaustive integer bulk pass out of LDS
     tiles + exact finalists (one tile per match
@@ -240,7 +240,9 @@ def test_rt2d_both_paths(sm, oracle, synth, debug, bulk, seed, size, beams, lin,
     # block bounds: the device summed a fraction of the search space (a bound per 2 x 2 block +
     # four candidates per surviving block), the exhaustive paths all of it
     side = 2 * math.ceil(lin / 0.05 - 1e-9) + 1
-    if bulk in ("bounds", "bounds2", "bounds1") and 1 < side <= 16:
+    if bulk == "bounds" and 1 < side <= 16:      # (4 x 4 blocks: a bound per block + sixteen candidates per survivor)
+        assert st["coarse_candidates"] < 0.75 * ref["num_candidates"], st
+    elif bulk in ("bounds2", "bounds1") and 1 < side <= 16:
         assert st["coarse_candidates"] < 0.6 * ref["num_candidates"], st
     elif bulk not in ("0", "bounds", "bounds2", "bounds1") or side > 16:
         assert st["coarse_candidates"] == ref["num_candidates"]
@@ -261,8 +263,7 @@ def test_rt2d_block_bounds_dominate_their_candidates(sm, oracle, synth, debug, s
     of the search space (debug switch rt2d_bounds_verify: all blocks are summed; the call fails
     if the weighted bound of a block lies below the weighted value of one of its own candidates):
     the max-pooled byte image, the parity planes and their addressing, the weights' maxima.
-    level 4 (round 6): the 4 x 4 blocks of the first level AND the 2 x 2 sub-block bounds as the
-    tail kernel computes them, for every block; level 2: the 2 x 2 blocks as the first level."""
+    level 4 (round 6): the 4 x 4 blocks the default path bounds first; level 2: 2 x 2 blocks."""
     debug(rt2d_bounds_verify=1, rt2d_bounds=1, rt2d_bounds_level=level)
     cells, lim, world = synth.make_submap(seed, size, size, 0.05, 20, 600, 5.0, 0.01)
     pose = world.free_pose(seed + 100, 0.5)
@@ -280,7 +281,7 @@ def test_rt2d_block_bounds_dominate_their_candidates(sm, oracle, synth, debug, s
         assert m.last_stats["coarse_candidates"] == 5 * blocks    # every bound + every block summed
     else:
         blocks = ref["num_candidates"] // (side * side) * ((side + 3) // 4) ** 2
-        assert m.last_stats["coarse_candidates"] == 21 * blocks   # + sub-block bounds, sixteen candidates each
+        assert m.last_stats["coarse_candidates"] == blocks + ref["num_candidates"]   # every bound + every candidate
 
 
 @pytest.mark.parametrize("bulk", RT2D_PATHS)

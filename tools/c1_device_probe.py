@@ -15,11 +15,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("batch", nargs="?", type=int, default=1024)
 ap.add_argument("--set", action="append", default=[])
 ap.add_argument("--no-timeline", action="store_true")
+ap.add_argument("--parts", type=int, nargs="*", default=[0, 1, 2])
 cli = ap.parse_args()
 base = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in cli.set}
 args = argparse.Namespace(beams=1000, matches=128, c1_distinct=0)
 w = bench.Rt2DWorkload(args, 0, matches=cli.batch, grid=200, dirty=False)
-for parts in (0, 1, 2):
+for parts in cli.parts:
     _lib.debug_set(rt2d_parts=parts, **base)
     for _ in range(5):
         w.search()
@@ -43,4 +44,4 @@ if not cli.no_timeline:
         w.search()
     _lib.debug_set(timeline=0)
 sys.stdout.flush()
-os._exit(0)
+sys.exit(0)

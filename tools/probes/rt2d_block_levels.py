@@ -85,6 +85,16 @@ for k in range(worlds):
         s, kk, j = np.unravel_index(np.argmax(ub), ub.shape)
         return score[s, w * kk:w * kk + w, w * j:w * j + w].max() * (1 - 2e-5)
     lb2, lb4 = lb_of(ub2, 2), lb_of(ub4, 4)
+    # the lower bound from the K best blocks (by upper bound) instead of the best one
+    order = np.argsort(-ub4.ravel())
+    topk = []
+    for K in (1, 2, 3, 4):
+        lbk = 0.0
+        for e in order[:K]:
+            s_, kk_, j_ = np.unravel_index(e, ub4.shape)
+            lbk = max(lbk, score[s_, 4 * kk_:4 * kk_ + 4, 4 * j_:4 * j_ + 4].max() * (1 - 2e-5))
+        topk.append(int((ub4 >= lbk).sum()))
+    print("   4x4 survivors with the lower bound from the best 1 / 2 / 3 / 4 blocks:", topk, flush=True)
     surv2 = int((ub2 >= lb2).sum())
     surv4 = int((ub4 >= lb4).sum())
     # with the TRUE best as the bound (a second pass after the survivors' own candidates are known)
