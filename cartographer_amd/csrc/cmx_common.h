@@ -74,6 +74,10 @@ cmx_status Guard(F&& body) {
   X(rt2d_lds_kb)          /* LDS budget of a tile workgroup in KB */                               \
   X(rt2d_no_image_cache)  /* 1: grid images are always built into scratch of the call */           \
   X(rt2d_parts)           /* parts a large batch is issued in (0: default) */                      \
+  X(rt2d_host_par)        /* matches per call from which the per-match host loops go to the host pool (0: 4096) */ \
+  X(rt2d_tables_serial)   /* 1: the rotation tables of a part by one thread (no host pool) */ \
+  X(rt2d_first_part)      /* matches of a large batch's first part (0: default; -1: none, decreasing parts only) */ \
+  X(rt2d_no_lane)         /* 1: the parts of a batch are prepared by the calling thread itself (no helper lane) */ \
   X(rt2d_parts_pool)      /* 1: the parts of a batch are planned and enqueued by host pool threads */ \
   X(rt2d_grid_share)      /* a part's tile grid and work items sized for its share of the CUs: 1 always, 2 never (0: by batch size) */ \
   X(rt2d_unfused)         /* 1: one-tile matches through the prep kernel too (parity partner) */   \
@@ -149,6 +153,27 @@ void UseDevice(int device);
 // and then takes all of them -- unless the fork happened in the middle of a job of another
 // thread (the copied `active_` count never drops): fork before the first call, or exec.
 void ParallelFor(int n, int serial_below, const std::function<void(int)>& fn);
+
+// ONE helper thread next to a caller (round 6): a call that goes out in parts has the next part's
+// host-only preparation (search parameters, plan) run here while the calling thread uploads and
+// launches the current one.  A lease is exclusive -- a caller that finds the lane taken runs its
+// jobs itself (Run() inline) -- and a job is a few tens of microseconds: the helper spins for a
+// while after its last job, then sleeps.
+class HostLane {
+ public:
+  HostLane();                        // takes the process-wide lane if it is free
+  ~HostLane();                       // (waits for a job in flight)
+  HostLane(const HostLane&) = delete;
+  HostLane& operator=(const HostLane&) = delete;
+  // Starts fn on the helper (or runs it here and now when this lease did not get the lane).
+  // One job at a time: Wait() before the next Run().
+  void Run(std::function<void()> fn);
+  void Wait();
+  bool own() const { return own_; }
+
+ private:
+  bool own_ = false, pending_ = false;
+};
 
 // Grow-only device buffer.
 class DeviceBuffer {

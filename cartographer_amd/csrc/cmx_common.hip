@@ -201,6 +201,81 @@ void ParallelFor(int n, int serial_below, const std::function<void(int)>& fn) {
 }
 
 // ---------------------------------------------------------------------------
+// HostLane: one helper thread
+// ---------------------------------------------------------------------------
+namespace {
+struct LaneState {
+  std::mutex lease;                          // who may post jobs
+  std::mutex sleep_mutex;
+  std::condition_variable sleep_cv;
+  bool sleeping = false;
+  std::atomic<int> state{0};                 // 0: idle, 1: a job is posted, 2: it is done
+  std::function<void()> job;
+  bool started = false;
+  void Loop() {
+    for (;;) {
+      const auto t0 = std::chrono::steady_clock::now();
+      bool have = false;
+      for (int spins = 0;; ++spins) {
+        if (state.load(std::memory_order_acquire) == 1) { have = true; break; }
+        __builtin_ia32_pause();
+        if ((spins & 1023) == 1023 &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300))
+          break;
+      }
+      if (!have) {
+        std::unique_lock<std::mutex> lk(sleep_mutex);
+        sleeping = true;
+        sleep_cv.wait(lk, [&] { return state.load(std::memory_order_acquire) == 1; });
+        sleeping = false;
+      }
+      job();
+      job = nullptr;
+      state.store(2, std::memory_order_release);
+    }
+  }
+};
+LaneState& TheLane() {
+  static LaneState* lane = new LaneState;    // leaked on purpose, like the pool
+  return *lane;
+}
+}  // namespace
+
+HostLane::HostLane() {
+  LaneState& L = TheLane();
+  own_ = L.lease.try_lock();
+  if (own_ && !L.started) {
+    L.started = true;
+    std::thread([&L] { L.Loop(); }).detach();
+  }
+}
+HostLane::~HostLane() {
+  if (!own_) return;
+  Wait();
+  TheLane().lease.unlock();
+}
+void HostLane::Run(std::function<void()> fn) {
+  if (!own_) { fn(); return; }
+  Wait();
+  LaneState& L = TheLane();
+  L.job = std::move(fn);
+  pending_ = true;
+  L.state.store(1, std::memory_order_release);
+  std::lock_guard<std::mutex> lk(L.sleep_mutex);
+  if (L.sleeping) L.sleep_cv.notify_one();
+}
+void HostLane::Wait() {
+  if (!own_ || !pending_) return;
+  LaneState& L = TheLane();
+  for (int spins = 0; L.state.load(std::memory_order_acquire) != 2; ++spins) {
+    if (spins < 4096) __builtin_ia32_pause();
+    else std::this_thread::yield();
+  }
+  L.state.store(0, std::memory_order_relaxed);
+  pending_ = false;
+}
+
+// ---------------------------------------------------------------------------
 // Debug switches (cmx_debug_set)
 // ---------------------------------------------------------------------------
 namespace {

@@ -664,7 +664,7 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
   std::vector<Rt2DSearch> search(num);
   lap("args");
   const auto plan_search = [&](int begin, int end) {
-    ParallelFor(end - begin, 4096,          // (0.03 us per match; a pool dispatch costs ~25 us)
+    ParallelFor(end - begin, Debug().rt2d_host_par > 0 ? Debug().rt2d_host_par : 4096,   // (0.03 us per match; a pool dispatch costs ~25 us)
                 [&](int k) { Rt2DComputeSearch(options, items[begin + k], &search[begin + k]); });
     for (int m = begin; m < end; ++m) {
       const Rt2DSearch& sr = search[m];
@@ -698,6 +698,7 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
   // its own (cmx_set_stream is per thread).
   std::vector<int> part_end;
   int num_parts = 1;
+  bool decreasing = false;
   if (OverrideStream(device) != nullptr) {
     num_parts = 1;
   } else if (Debug().rt2d_parts > 0) {
@@ -707,16 +708,39 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
     // (round 5, with the bound kernel taking such batches: 1024 matches in three parts 325 us, in
     // two 340, in four 422 -- the first part reaches the device 20 us earlier)
     if (num >= 900 && num_parts == 2) num_parts = 3;
+    // (round 6: the kernels of a part now take less than its host work, and a call ends with
+    // the whole device latency of its LAST part -- two launches, the stragglers of the tail
+    // kernel: 126 us for 341 matches.  Parts of DECREASING size, weights k, k - 1, ... 1: the
+    // host's time is the same, the last part a sixth of the call.)
+    // Three at most: the streams of a StreamSetLease sit on three hardware queues, a fourth
+    // part shares one and waits behind its neighbour (dispatch timeline, profiles/r06b_*).
+    decreasing = true;
   }
-  for (int h = 0; h < num_parts; ++h)
-    part_end.push_back(static_cast<int>(static_cast<long long>(num) * (h + 1) / num_parts));
+  if (decreasing) {
+    // (and a SMALL first part: with the helper lane the host prepares parts faster than the
+    // device takes them, so what counts is how soon the device starts -- the first part an eighth
+    // of the call, the rest with weights k - 1, ... 1)
+    int first = Debug().rt2d_first_part > 0 ? std::min(Debug().rt2d_first_part, num / 2) : 0;
+    if (Debug().rt2d_first_part == 0 && num >= 512 && num_parts >= 3) first = num / 10;
+    const int rest_parts = first > 0 ? num_parts - 1 : num_parts;
+    if (first > 0) part_end.push_back(first);
+    const long long total_weight = static_cast<long long>(rest_parts) * (rest_parts + 1) / 2;
+    long long weight = 0;
+    for (int h = 0; h < rest_parts; ++h) {
+      weight += rest_parts - h;
+      part_end.push_back(first + static_cast<int>(static_cast<long long>(num - first) * weight / total_weight));
+    }
+  } else {
+    for (int h = 0; h < num_parts; ++h)
+      part_end.push_back(static_cast<int>(static_cast<long long>(num) * (h + 1) / num_parts));
+  }
   const bool share_cus = Debug().rt2d_grid_share ? Debug().rt2d_grid_share == 1
                                                  : (num_parts > 1 && num < 896);
   const int parts = static_cast<int>(part_end.size());
   struct Part {
     int begin, end;
     std::unique_ptr<Rt2DTileCall> call;
-    bool enqueued = false;
+    bool eligible = false, enqueued = false;
     cmx_match_stats stats{};
     cmx_status status = CMX_OK;
     std::string error;
@@ -736,31 +760,49 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
   }
   // (round 6, debug switch rt2d_parts_pool: the parts planned and enqueued by host pool threads,
   // one each, instead of one after the other by the caller)
-  const auto issue_part = [&](int h) {
+  // A part in two steps: its host-only preparation (search parameters, plan: no device call, no
+  // shared lock) and its issue (staging buffer, grid images, upload, launches).  Round 6: the
+  // preparation of part h + 1 runs on the helper lane (HostLane) while the calling thread issues
+  // part h -- a third of a part's host time off the critical path of every part but the first.
+  const auto prepare_part = [&](int h) {
     Part& p = part[h];
-    UseDevice(device);
     p.status = Guard([&] {
       const double t0 = since_call();
       plan_search(p.begin, p.end);
       const double t_search = since_call();
       p.call.reset(new Rt2DTileCall(options, items + p.begin, search.data() + p.begin, p.end - p.begin, device,
                                     share_cus ? parts : 1, num));
-      const bool eligible = p.call->Plan();
-      const double t_plan = since_call();
-      if (eligible) {
-        p.call->Enqueue(part_streams ? part_streams->stream(h) : nullptr);
-        p.enqueued = true;
-      }
+      p.eligible = p.call->Plan();
       if (host_trace)
         fprintf(stderr, "[cmx host] rt2d part %d (%d matches), us since the call's start: begins %.0f, search "
-                        "%.0f, plan %.0f, enqueued %.0f\n", h, p.end - p.begin, t0, t_search, t_plan, since_call());
+                        "%.0f, plan %.0f\n", h, p.end - p.begin, t0, t_search, since_call());
+    });
+    if (p.status != CMX_OK) p.error = LastError();
+  };
+  const auto enqueue_part = [&](int h) {
+    Part& p = part[h];
+    if (p.status != CMX_OK || !p.eligible) return;
+    UseDevice(device);
+    p.status = Guard([&] {
+      p.call->Enqueue(part_streams ? part_streams->stream(h) : nullptr);
+      p.enqueued = true;
+      if (host_trace)
+        fprintf(stderr, "[cmx host] rt2d part %d enqueued %.0f us since the call's start\n", h, since_call());
     });
     if (p.status != CMX_OK) p.error = LastError();
   };
   if (Debug().rt2d_parts_pool && parts > 1) {
-    ParallelFor(parts, 2, issue_part);
+    ParallelFor(parts, 2, [&](int h) { prepare_part(h); enqueue_part(h); });
+  } else if (parts > 1 && !Debug().rt2d_no_lane) {
+    HostLane lane;
+    prepare_part(0);
+    for (int h = 0; h < parts; ++h) {
+      if (h + 1 < parts) lane.Run([&prepare_part, h] { prepare_part(h + 1); });
+      enqueue_part(h);
+      lane.Wait();
+    }
   } else {
-    for (int h = 0; h < parts; ++h) issue_part(h);
+    for (int h = 0; h < parts; ++h) { prepare_part(h); enqueue_part(h); }
   }
   bool failed = false;
   for (int h = 0; h < parts; ++h) failed = failed || part[h].status != CMX_OK;
@@ -769,12 +811,29 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
     if (p.status != CMX_OK) { p.call.reset(); continue; }    // (waits for what it had in flight)
     if (failed) { p.call.reset(); continue; }                // (the call fails: no reruns)
     p.status = Guard([&] {
-      const bool done = p.enqueued && p.call->Collect(&p.stats);
-      // (not eligible, a flat score landscape, a point outside the predicted box: the part runs
-      // on the per-candidate kernels)
-      if (!done)
+      std::vector<int> redo;
+      const bool done = p.enqueued && p.call->Collect(&p.stats, &redo);
+      // (not eligible: the part runs on the per-candidate kernels; so do the matches of it whose
+      // score landscape was too flat for the lists, or that had a point outside the predicted box)
+      if (!done) {
         Rt2DLegacyBatch(options, items + p.begin, search.data() + p.begin, p.end - p.begin, device,
                         &p.stats);
+      } else if (!redo.empty()) {
+        std::vector<Rt2DItem> again_items;
+        std::vector<Rt2DSearch> again_search;
+        for (int m : redo) {
+          again_items.push_back(items[p.begin + m]);
+          again_search.push_back(search[p.begin + m]);
+        }
+        cmx_match_stats again{};
+        Rt2DLegacyBatch(options, again_items.data(), again_search.data(), static_cast<int>(redo.size()), device,
+                        &again);
+        p.stats.candidates_scored += again.candidates_scored;
+        p.stats.coarse_candidates += again.coarse_candidates;
+        p.stats.num_scans += again.num_scans;
+        p.stats.refined_candidates += again.refined_candidates;
+        p.stats.finalists += again.finalists;
+      }
       if (host_trace)
         fprintf(stderr, "[cmx host] rt2d part %d collected %.0f us since the call's start\n", h, since_call());
     });

@@ -824,27 +824,24 @@ Rt2DBoundTailKernel(const Rt2DTileParams* __restrict__ params, const int* __rest
 // summed and checked against the block's bound.
 // Dynamic LDS: [Rt2DFinishMatch's region, over] box[b8_lh][b8_lp] | zeros[4 b8_lp + 16] |
 //   ax[n_pad] | ay[n_pad] | (at Tail4Region) discs[num_scans] | ub[nblk] |
-//   raw[1 + kList4Cap][16] | list4[kList4Cap]; behind the finish's region, once the sums are
-//   done: cand_e[16 (1 + kList4Cap)] | cand_q[same]
+//   best16[16] | list4[kList4Cap] | cand_e[kCand4Cap] | cand_q[same]
 // ---------------------------------------------------------------------------------------------
 #ifndef CMX_RT2D_TAIL4_THREADS
 #define CMX_RT2D_TAIL4_THREADS 512
 #endif
 constexpr int kBoundTail4Threads = CMX_RT2D_TAIL4_THREADS;
-constexpr int kList4Cap = 128;               // 4 x 4 blocks summed per match besides the best; more: the per-candidate kernels
+constexpr int kList4Cap = 1024;              // 4 x 4 blocks summed per match besides the best; more: the per-candidate kernels
+constexpr int kCand4Cap = 512;               // candidates handed to the finish; more (a landscape of ties): the same
 __host__ __device__ constexpr size_t Tail4Region(int lp, int lh, int n_pad, int num_scans) {
   const size_t fin = BoundTailRegion(n_pad, num_scans);
   const size_t own = static_cast<size_t>(lh) * lp + ((4 * static_cast<size_t>(lp) + 16 + 15) & ~size_t{15}) +
                      8 * static_cast<size_t>(n_pad);
-  // (behind the finish's region, over the box and the cloud that nobody reads any more: the
-  // candidates it is handed, index and sum)
-  const size_t handed = fin + 2 * 4 * 16 * static_cast<size_t>(1 + kList4Cap);
-  return ((handed > own ? handed : own) + 15) & ~size_t{15};
+  return ((fin > own ? fin : own) + 15) & ~size_t{15};
 }
 __host__ __device__ constexpr size_t BoundTail4Lds(int lp, int lh, int n_pad, int num_scans, int nb4) {
   return Tail4Region(lp, lh, n_pad, num_scans) + sizeof(BoundDisc) * static_cast<size_t>(num_scans) +
          4 * ((static_cast<size_t>(num_scans) * nb4 * nb4 + 3) & ~size_t{3}) +
-         4 * (16 + 1) * static_cast<size_t>(1 + kList4Cap) + 64;
+         4 * static_cast<size_t>(16 + kList4Cap + 2 * kCand4Cap) + 64;
 }
 
 template <int NB4>
@@ -876,10 +873,10 @@ Rt2DBoundTail4Kernel(const Rt2DTileParams* __restrict__ params, const int* __res
   BoundDisc* discs = reinterpret_cast<BoundDisc*>(tail_smem + Tail4Region(lp, lh, n_pad, S));
   int* ub = reinterpret_cast<int*>(discs + S);
   float* ubw = reinterpret_cast<float*>(ub);
-  int* raw = ub + ((nblk + 3) & ~3);           // [0]: the best block's sixteen sums, [1 + at]: listed block at
-  int* list4 = raw + 16 * (1 + kList4Cap);
-  int* cand_e = reinterpret_cast<int*>(tail_smem + BoundTailRegion(n_pad, S));   // (over the box: see Tail4Region)
-  int* cand_q = cand_e + 16 * (1 + kList4Cap);
+  int* raw = ub + ((nblk + 3) & ~3);           // the best block's sixteen sums
+  int* list4 = raw + 16;
+  int* cand_e = list4 + kList4Cap;             // the candidates handed to the finish: index, byte sum
+  int* cand_q = cand_e + kCand4Cap;
   {
     const auto* xyz = AsGlobal(P.xyz);
     for (int i = tid; i < n_pad; i += kThreads) {
@@ -1075,27 +1072,65 @@ Rt2DBoundTail4Kernel(const Rt2DTileParams* __restrict__ params, const int* __res
       lb = (0.1f + per_q * static_cast<float>(raw[lane]) - slack) * weight_of(candidate) * (1.f - 1e-5f);
     lb = __uint_as_float(static_cast<unsigned>(WaveMaxDpp(static_cast<int>(__float_as_uint(fmaxf(lb, 0.f))))));
   }
-  // ---- C: the other blocks that reach the bound, a wavefront per block --------------------------
+  // ---- C: the other blocks that reach the bound, a wavefront per block.  What a block's
+  // candidates are worth is known as soon as they are summed: the finish's own bounds (byte
+  // quantisation: `width`) give every candidate an interval, the best lower end seen so far is
+  // kept in LDS (it only rises), and a candidate is handed to the finish only if its upper end
+  // reaches it -- the finish would drop the others at its first step, against a bound at least as
+  // high.  So what is listed for the finish are the candidates near the top, however many blocks
+  // had to be looked at: a flat landscape costs time, not a repeat on the per-candidate kernels
+  // (that is left to landscapes of TIES: more near-best candidates than the list holds).
+  const float width = kScale * static_cast<float>((1 << kQ8Shift) - 1);
   for (int e = tid; e < nblk; e += kThreads) {
     if (e != best_e && ubw[e] >= lb) {
       const int at = atomicAdd(&ctl[1], 1);
       if (at < kList4Cap) list4[at] = e;
     }
   }
+  if (tid == 0) ctl[2] = static_cast<int>(__float_as_uint(lb));
+  if (tid < 16) {                              // (the best block's candidates: all of them)
+    const int candidate = candidate_of(best_e, tid);
+    if (candidate >= 0) {
+      const int at = atomicAdd(&ctl[3], 1);
+      cand_e[at] = candidate;
+      cand_q[at] = raw[tid];
+      atomicAdd(&ctl[0], 1);
+    }
+  }
   __syncthreads();
-  const bool flat = ctl[1] > kList4Cap;
+  bool flat = ctl[1] > kList4Cap;
   const int listed4 = min(ctl[1], kList4Cap);
+  int summed = 0;
   if (!flat) {
 #pragma unroll 1
     for (int at = wave; at < listed4; at += kWaves) {
-      const int sum = block_sums16(list4[at], 0, 1);
-      if (lane < 16) raw[16 * (1 + at) + lane] = sum;
+      const int e = list4[at];
+      const int sum = block_sums16(e, 0, 1);
+      const int candidate = lane < 16 ? candidate_of(e, lane) : -1;
+      float lo = 0.f, hi = -1.f;
+      if (candidate >= 0) {
+        const float base = 0.1f + per_q * static_cast<float>(sum);
+        const float w = weight_of(candidate);
+        lo = (base - slack) * w * (1.f - 1e-5f);
+        hi = (base + width + slack) * w * (1.f + 1e-5f);
+      }
+      const float seen = __uint_as_float(static_cast<unsigned>(__hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
+      if (hi >= seen) {
+        const int slot = atomicAdd(&ctl[3], 1);
+        if (slot < kCand4Cap) { cand_e[slot] = candidate; cand_q[slot] = sum; }
+      }
+      const int best_lo = WaveMaxDpp(static_cast<int>(__float_as_uint(fmaxf(lo, 0.f))));
+      if (lane == 0) atomicMax(&ctl[2], best_lo);
+      summed += __popcll(__ballot(candidate >= 0));
     }
   }
   if (outside) atomicOr(&P.misc[0], kOutOfBox);
+  if (lane == 0 && summed) atomicAdd(&ctl[0], summed);
   __syncthreads();
   Stamp(tl, tl_block, 5);                      // the surviving blocks summed
+  flat = flat || ctl[3] > kCand4Cap;
   if (tid == 0) {
+    P.bstat[0] = static_cast<unsigned>(ctl[0]);                                    // candidates summed
     P.bstat[1] = static_cast<unsigned>(nblk);                                      // bounds evaluated
     if (flat) atomicOr(&P.misc[0], kBoundFlat);
   }
@@ -1107,18 +1142,6 @@ Rt2DBoundTail4Kernel(const Rt2DTileParams* __restrict__ params, const int* __res
           __hip_atomic_load(&P.misc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
-  // ---- the finish over the candidates of the summed blocks ----------------------------------------
-  for (int t = tid; t < 16 * (1 + listed4); t += kThreads) {
-    const int e = t < 16 ? best_e : list4[(t >> 4) - 1];
-    const int candidate = candidate_of(e, t & 15);
-    if (candidate >= 0) {
-      const int at = atomicAdd(&ctl[3], 1);
-      cand_e[at] = candidate;
-      cand_q[at] = raw[t];
-    }
-  }
-  __syncthreads();
-  if (tid == 0) P.bstat[0] = static_cast<unsigned>(ctl[3]);                        // candidates summed
   Rt2DFinishMatch<kThreads, true, false, kQ8Shift>(P, tail_smem, kBoundTailGroup, host_out, match, cand_e, cand_q,
                                                     ctl[3]);
 }

@@ -1453,6 +1453,10 @@ struct Rt2DTileCall::Impl {
   size_t bound4_lds = 0, tail4_lds = 0;
   int bound_nb = 0;                     // blocks per window axis (launch-wide: the largest)
   size_t bound_lds = 0;
+  // (the per-rotation (cos, sin) pairs of every match, libm: worked out by Plan() -- off the
+  // calling thread when the batch goes out in parts -- and copied into the staging buffer)
+  std::vector<float2> tables;
+  std::vector<size_t> table_at;
   std::unique_ptr<WorkspaceLease> ws;
   CacheHolds holds;
   unsigned* h_misc = nullptr;
@@ -1833,6 +1837,22 @@ bool Rt2DTileCall::Plan() {
     }
   }
   CMX_REQUIRE(I.work_cap < (1ll << 24) && num <= 65535, "too many matches in one batch");
+  {
+    I.table_at.resize(num);
+    size_t at = 0;
+    for (int m = 0; m < num; ++m) { I.table_at[m] = at; at += search[m].num_scans; }
+    I.tables.resize(at);
+    // (libm, ~5 ns per pair, a third of a match's host time and nothing shared: blocks of >= 32
+    // matches over the host pool)
+    // matches, six blocks at most, over the host pool)
+    const int blocks = std::min(6, (num + 31) / 32);
+    ParallelFor(blocks, dbg.rt2d_tables_serial ? (1 << 30) : 3, [&](int b) {
+      const int begin = static_cast<int>(static_cast<long long>(num) * b / blocks);
+      const int end = static_cast<int>(static_cast<long long>(num) * (b + 1) / blocks);
+      for (int m = begin; m < end; ++m)
+        FillRotationTable(search[m].step, search[m].na, I.tables.data() + I.table_at[m]);
+    });
+  }
   I.tile_grid = static_cast<int>(std::max<long long>(1, std::min<long long>(tile_slots, I.work_cap)));
   if (I.bounds) {
     const int per_cu = I.bound_lds <= 78 * size_t{1024} ? 2 : 1;
@@ -1987,14 +2007,13 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
     // host pool costs ~25 us; host grids are copied into the staging buffer here: worth the pool)
     bool copies = false;
     for (int m = 0; m < num; ++m) copies = copies || !items[m].device_cells;
-    ParallelFor(num, copies ? 16 : 4096, [&](int m) {
+    ParallelFor(num, copies ? 16 : (dbg.rt2d_host_par > 0 ? dbg.rt2d_host_par : 4096), [&](int m) {
       const Rt2DItem& it = items[m];
       const Rt2DSearch& sr = search[m];
       const TileGeometry& g = geo[m];
       const size_t cell_count = static_cast<size_t>(it.limits->num_x_cells) * it.limits->num_y_cells;
       if (!it.device_xyz) std::memcpy(h_in + off[m].xyz, it.xyz, 3 * sizeof(float) * it.n);
-      // (the per-rotation (cos, sin) pairs: libm, straight into the staging buffer)
-      FillRotationTable(sr.step, sr.na, reinterpret_cast<float2*>(h_in + off[m].rot));
+      std::memcpy(h_in + off[m].rot, I.tables.data() + I.table_at[m], sizeof(float2) * sr.num_scans);
       if (!it.device_cells) std::memcpy(h_in + off[m].cells, it.cells, sizeof(uint16_t) * cell_count);
       Rt2DTileParams P{};
       P.cells = it.device_cells ? it.device_cells : reinterpret_cast<const uint16_t*>(d_in + off[m].cells);
@@ -2175,7 +2194,7 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
                     "launches %.0f us (%zu bytes up)\n", num, t_images, t_params, t_upload, lap_us(), in_bytes);
 }
 
-bool Rt2DTileCall::Collect(cmx_match_stats* stats) {
+bool Rt2DTileCall::Collect(cmx_match_stats* stats, std::vector<int>* redo) {
   Impl& I = *impl_;
   CMX_REQUIRE(I.enqueued, "internal error: Collect before Enqueue");
   WorkspaceLease& ws = *I.ws;
@@ -2193,22 +2212,33 @@ bool Rt2DTileCall::Collect(cmx_match_stats* stats) {
     ReportTimeline("Rt2DFinishKernel", I.d_timeline + static_cast<size_t>(I.tile_grid) * 4 * kTimelineStamps,
                    num, ws->stream);
   }
+  // Matches the bulk path could not decide -- a flat score landscape (more blocks or candidates
+  // within the bounds than the lists hold), a point outside the predicted box -- are left to the
+  // caller, match by match (round 6: until then one of them sent its whole batch to the
+  // per-candidate kernels); without a list to put them on, the whole call is.
+  std::vector<char> undecided(num, 0);
   for (int m = 0; m < num; ++m) {
     const unsigned count = h_misc[static_cast<size_t>(m) * 128 + 1];
     CMX_REQUIRE(!(h_misc[static_cast<size_t>(m) * 128] & kBoundViolated),
                 "internal error: rt2d block bound below one of its candidates (rt2d_bounds_verify)");
-    if (h_misc[static_cast<size_t>(m) * 128] & kBoundFlat) return false;   // (flat landscape: the per-candidate kernels)
+    bool bad = (h_misc[static_cast<size_t>(m) * 128] & kBoundFlat) != 0;   // (flat landscape)
     if (h_misc[static_cast<size_t>(m) * 128] & kOutOfBox) {
-      fprintf(stderr, "[cmx] rt2d: a point fell outside the predicted box of match %d; the batch "
-                      "is repeated on the per-candidate kernels\n", m);
-      return false;
+      fprintf(stderr, "[cmx] rt2d: a point fell outside the predicted box of match %d; it is "
+                      "repeated on the per-candidate kernels\n", m);
+      bad = true;
     }
-    if (count > static_cast<unsigned>(kFinalistCap)) return false;    // kFlat, overflow
+    if (count > static_cast<unsigned>(kFinalistCap)) bad = true;    // kFlat, overflow
+    if (bad) {
+      if (!redo) return false;
+      undecided[m] = 1;
+      redo->push_back(m);
+    }
   }
   // Exact weighting and first maximum, item by item: on the host pool (exp, hypot, a sort of a
   // handful of pairs); a match with more finalists than its head holds fetches the rest first.
   std::vector<std::vector<unsigned>> extra(num);
   for (int m = 0; m < num; ++m) {
+    if (undecided[m]) continue;
     const long long count = h_misc[static_cast<size_t>(m) * 128 + 1];
     CMX_REQUIRE(count >= 1, "internal error: no candidate collected");
     if (count > kFinalistHead) {
@@ -2219,7 +2249,8 @@ bool Rt2DTileCall::Collect(cmx_match_stats* stats) {
     }
   }
   const cmx_rt_options* options = I.options;
-  ParallelFor(num, 4096, [&](int m) {
+  ParallelFor(num, Debug().rt2d_host_par > 0 ? Debug().rt2d_host_par : 4096, [&](int m) {
+    if (undecided[m]) return;
     const unsigned* head = h_misc + static_cast<size_t>(m) * 128;
     const long long count = head[1];
     const long long in_head = std::min<long long>(count, kFinalistHead);
@@ -2238,6 +2269,7 @@ bool Rt2DTileCall::Collect(cmx_match_stats* stats) {
   });
   cmx_match_stats total{};
   for (int m = 0; m < num; ++m) {
+    if (undecided[m]) continue;               // (counted by whoever repeats it)
     const unsigned* head = h_misc + static_cast<size_t>(m) * 128;
     const long long cands = static_cast<long long>(search[m].num_scans) * (2 * search[m].nl + 1) * (2 * search[m].nl + 1);
     total.candidates_scored += cands;

@@ -237,7 +237,9 @@ class Rt2DTileCall {
   // asynchronous.  `on_stream`: the call's work goes on that stream instead of its workspace's
   // own (the parts of a batch: StreamSetLease).
   void Enqueue(hipStream_t on_stream = nullptr);
-  bool Collect(cmx_match_stats* stats); // waits; false: repeat on the per-candidate kernels
+  // waits.  Matches the bulk path could not decide go on `redo` (indices into this call's items:
+  // the caller repeats them on the per-candidate kernels); without a list: false, nothing written
+  bool Collect(cmx_match_stats* stats, std::vector<int>* redo = nullptr);
  private:
   struct Impl;
   std::unique_ptr<Impl> impl_;

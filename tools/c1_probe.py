@@ -48,4 +48,4 @@ for batch in cli.batches:
           f"{st.get('finalists', 0) / batch:.1f}; score[0] {r[1][0]:.6f}", flush=True)
     del w
 sys.stdout.flush()
-os._exit(0)
+sys.exit(0)

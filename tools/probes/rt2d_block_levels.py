@@ -11,13 +11,14 @@ import bench  # noqa: E402
 from cartographer_amd import synth  # noqa: E402
 
 worlds = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+GRID = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 res, lin, ang, wt, wr = 0.05, 0.3, math.radians(7.0), 0.1, 0.1
 nl = math.ceil(lin / res)
 side = 2 * nl + 1
 UNIT = 1057
 out = []
 for k in range(worlds):
-    cells, lim, world = synth.make_submap(42 + k, 200, 200, res, 30, 1000, 5.0, 0.01)
+    cells, lim, world = synth.make_submap(42 + k, GRID, GRID, res, 30, 1000, 5.0, 0.01)
     pose = world.free_pose(1234, 0.5)
     scan = bench.c1_scan(world, pose, 1000, 5.0, 7)
     init = (pose[0] + 0.12, pose[1] - 0.08, pose[2] + math.radians(3.0))
