@@ -768,33 +768,38 @@ class Rt2DWorkload:
         side = int(round(math.sqrt(cand / max(scans, 1))))
         summed = acc["coarse_candidates"] / steps
         if summed < cand:
-            # Round 5, from 192 matches per call on: block bounds first (rt_2d_bounds.h).  Per
-            # (rotation, point) the bound kernel reads (side + 1) / 2 block rows of three aligned
-            # dwords each from the max-pooled byte planes in LDS, and the point's two coordinates;
-            # the handful of blocks that reach the bound are summed from the image in HBM (L2).
-            # kernel_ms covers the whole kernel: staging, bounds, the sums and the match's finish.
-            nb = (side + 1) // 2
-            lds = scans * self.points * (12.0 * nb + 8.0)
-            return {"kernel": "Rt2DBoundKernel (2x2 block bounds from pooled byte planes in LDS + sums + finish)",
+            # From 192 matches per call on: block bounds first (rt_2d_bounds.h).  Round 6: blocks of
+            # 4 x 4 translations -- per (rotation, point) the bound kernel reads (side + 3) / 4
+            # block rows of two aligned dwords each from the sixteen phase planes of the 4 x 4
+            # max-pooled byte image in LDS, and the point's two coordinates; a second kernel
+            # (Rt2DBoundTail4Kernel) sums the candidates of the few blocks that reach the bound out
+            # of a byte image of the match's box in LDS and finishes the match.  kernel_ms is the
+            # BOUND kernel alone (HIP events around it; the tail kernel is in device_ms).
+            nb = (side + 3) // 4
+            lds = scans * self.points * (8.0 * nb + 8.0)
+            return {"kernel": "Rt2DBoundKernel<NB4, 2> (4x4 block bounds from sixteen pooled byte planes in LDS)",
                     "bound": "lds", "achieved": lds / secs / 1e9, "peak": LDS_B32_PEAK_GBS, "unit": "GB/s",
                     "frac": lds / secs / 1e9 / LDS_B32_PEAK_GBS,
-                    "traffic": (pmc("Rt2DBound", "c1" if self.matches_per_step == 128 else "c1b1024")
+                    "traffic": (pmc("Rt2DBoundKernel", "c1" if self.matches_per_step == 128 else "c1b1024")
                                 if self.matches_per_step in (128, 1024) and self.grid_side == 200
                                 and not self.dirty else None),
                     "kernel_ms": k_ms, "algorithmic_bytes": alg, "lds_bytes": lds,
-                    # (calls of 256 matches and more go out in two or three PARTS on streams of
-                    # their own: kernel_ms is the SUM of their launches' durations, which overlap)
+                    # (calls of 256 matches and more go out in three PARTS on streams of their own:
+                    # kernel_ms is the SUM of their launches' durations, which overlap)
                     "kernel_ms_is_sum_of_concurrent_parts": self.matches_per_step >= 256,
                     "algorithmic_GBps": alg / secs / 1e9,
                     "hbm_frac_algorithmic": alg / secs / 1e9 / HBM_PEAK_GBS,
                     "candidates_per_s_kernel": cand / secs,
                     "summed_candidates_per_s_kernel": summed / secs,
                     "note": "block bounds: frac = LDS bytes of the bound kernel's row reads / its "
-                            "HIP-event time (staging, the surviving blocks' sums and the finish of "
-                            "every match included) / 75 TB/s (the LDS peak of dword reads); algorithmic bytes stay SURVEY 8d's "
-                            "2 B per candidate of the SEARCH SPACE per point (what the reference "
-                            "reads), of which the device reads a fraction: "
-                            "summed_candidates = block bounds + candidates of surviving blocks"}
+                            "HIP-event time (staging of the planes and the cloud included) / 75 TB/s "
+                            "(the LDS peak of dword reads); the kernel is co-limited by its vector "
+                            "instructions (37 k wave-instructions per match, 0.73 of the VALU issue "
+                            "rate: profiles/r06b_c1dev_*) and by bank conflicts of its random dword "
+                            "pairs; algorithmic bytes stay SURVEY 8d's 2 B per candidate of the "
+                            "SEARCH SPACE per point (what the reference reads), of which the device "
+                            "reads a fraction: summed_candidates = block bounds + candidates of "
+                            "surviving blocks"}
         lds = cand / (side * side) * self.points * 512.0
         return {"kernel": "Rt2DTileKernel (LDS tiles of the quantised grid image, packed 16-bit sums)",
                 "bound": "lds", "achieved": lds / secs / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
@@ -1413,11 +1418,13 @@ def other_configs(args, device, sync, pmc):
         "c4": lambda w: cpu_baseline_c4(w, min(6.0, args.cpu_seconds)),
         "c5_single": lambda w: cpu_baseline_c5(w, min(5.0, args.cpu_seconds))}
     run("c1_single", lambda: Rt2DWorkload(args, device, matches=1), 200, 50)
-    run("c1_batch128", lambda: Rt2DWorkload(args, device, matches=128), 100, 10, cpu.get("c1_batch128"))
+    run("c1_batch128", lambda: Rt2DWorkload(args, device, matches=128), 200, 30, cpu.get("c1_batch128"))
     run("c1_batch128_dirty", lambda: Rt2DWorkload(args, device, matches=128, dirty=True), 50, 5)
     run("c1_batch128_grid400", lambda: Rt2DWorkload(args, device, matches=128, grid=400), 50, 5)
-    run("c1_batch1024", lambda: Rt2DWorkload(args, device, matches=1024), 30, 5)
-    run("c1_batch1024_dirty", lambda: Rt2DWorkload(args, device, matches=1024, dirty=True), 15, 3)
+    # (host-bound legs right behind their parity gate -- 256 reference matches on every host
+    # thread: thirty warm-up calls before the clock starts, the first ones run 1.3x slower)
+    run("c1_batch1024", lambda: Rt2DWorkload(args, device, matches=1024), 100, 30)
+    run("c1_batch1024_dirty", lambda: Rt2DWorkload(args, device, matches=1024, dirty=True), 30, 10)
     run("c1_batch128_8_threads", lambda: Rt2DPipelinedWorkload(args, device, 128, 8, 4), 25, 5)
     run("c1_tsdf", lambda: Rt2DTsdfWorkload(args, device), 30, 5)
     run("c2_easy", lambda: Fast2DConcurrentWorkload(args, device, 8, scans=1), 40, 5)

@@ -42,7 +42,7 @@
 #define CMX_RT_2D_BOUNDS_H_
 
 constexpr int kBoundThreads = 512;          // eight wavefronts; two workgroups per CU
-constexpr int kBoundMinMatches = 192;       // matches per call from which the bound kernel is the default
+constexpr int kBoundMinMatches = 96;        // matches per call from which the bound kernel is the default
 constexpr int kBoundMaxBlocks = 8;          // block columns in one ds_read_b64: side <= 16
 #ifndef CMX_RT2D_BOUND_BITS
 #define CMX_RT2D_BOUND_BITS 5
@@ -830,7 +830,9 @@ Rt2DBoundTailKernel(const Rt2DTileParams* __restrict__ params, const int* __rest
 #define CMX_RT2D_TAIL4_THREADS 512
 #endif
 constexpr int kBoundTail4Threads = CMX_RT2D_TAIL4_THREADS;
-constexpr int kList4Cap = 1024;              // 4 x 4 blocks summed per match besides the best; more: the per-candidate kernels
+constexpr int kList4Cap = 96;                // 4 x 4 blocks summed per match besides the best; more: the per-candidate kernels
+                                             // (a wavefront per block: a match with hundreds of them holds its
+                                             // whole launch up for longer than its repeat takes)
 constexpr int kCand4Cap = 512;               // candidates handed to the finish; more (a landscape of ties): the same
 __host__ __device__ constexpr size_t Tail4Region(int lp, int lh, int n_pad, int num_scans) {
   const size_t fin = BoundTailRegion(n_pad, num_scans);

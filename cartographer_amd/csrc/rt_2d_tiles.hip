@@ -2129,11 +2129,12 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
     };
     const int common_stride = I.common_stride;
     if (I.level4) {
+      // (ev_k1 between the two: the bound kernel's own span)
       switch ((I.bound_nb + 1) / 2) {
-        case 1: launch_bounds(Rt2DBoundKernel<1, 2>); launch_tail(Rt2DBoundTail4Kernel<1>); break;
-        case 2: launch_bounds(Rt2DBoundKernel<2, 2>); launch_tail(Rt2DBoundTail4Kernel<2>); break;
-        case 3: launch_bounds(Rt2DBoundKernel<3, 2>); launch_tail(Rt2DBoundTail4Kernel<3>); break;
-        default: launch_bounds(Rt2DBoundKernel<4, 2>); launch_tail(Rt2DBoundTail4Kernel<4>); break;
+        case 1: launch_bounds(Rt2DBoundKernel<1, 2>); RecordEvent(ws->ev_k1, ws->stream); launch_tail(Rt2DBoundTail4Kernel<1>); break;
+        case 2: launch_bounds(Rt2DBoundKernel<2, 2>); RecordEvent(ws->ev_k1, ws->stream); launch_tail(Rt2DBoundTail4Kernel<2>); break;
+        case 3: launch_bounds(Rt2DBoundKernel<3, 2>); RecordEvent(ws->ev_k1, ws->stream); launch_tail(Rt2DBoundTail4Kernel<3>); break;
+        default: launch_bounds(Rt2DBoundKernel<4, 2>); RecordEvent(ws->ev_k1, ws->stream); launch_tail(Rt2DBoundTail4Kernel<4>); break;
       }
     } else if (I.bounds) {
       switch (I.bound_nb) {
@@ -2175,7 +2176,7 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
     else if (rpl <= 6) launch(Rt2DTileKernel<6, 0, false>);
     else launch(Rt2DTileKernel<8, 0, false>);
   }
-  RecordEvent(ws->ev_k1, ws->stream);
+  if (!I.level4) RecordEvent(ws->ev_k1, ws->stream);
   // (the bound kernel has finished its matches itself; in its verify mode it leaves every sum)
   if (!I.bounds || dbg.rt2d_bounds_verify) {
     if (I.level4) {     // (verify mode of the 4 x 4 level: byte sums)

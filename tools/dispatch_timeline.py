@@ -12,6 +12,8 @@ rows = con.execute(f"select {sel} from kernels order by start").fetchall()
 rows = rows[-count:]
 t0 = rows[0][1]
 for r in rows:
-    short = r[0].split("(")[0].split("::")[-1]
+    import re
+    m = re.search(r"::(\w+)(<[^>]*>)?\(", r[0])
+    short = (m.group(1) + (m.group(2) or "")) if m else r[0][:28]
     extra = " ".join(str(x) for x in r[3:])
     print(f"{(r[1] - t0) / 1e3:9.1f} -> {(r[2] - t0) / 1e3:9.1f} us ({(r[2] - r[1]) / 1e3:7.1f})  {short:28s} {extra}")
