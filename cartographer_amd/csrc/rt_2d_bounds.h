@@ -512,6 +512,9 @@ Rt2DBoundKernel(const Rt2DTileParams* __restrict__ params, const int4* __restric
     int* list = ub + BoundSumWords(nblk);                 // (LOG = 1 only: the fused tail's lists)
     int* sums = list + kBoundListCap;
     int* ub_match = ub_global + (LOG == 1 ? P.b_ub_at : P.b4_ub_at);   // this match's byte sums in HBM
+    // (LOG = 2: the per-rotation constants of the discretisation -- a few dozen f64 operations --
+    // once per item instead of once per (wavefront, rotation): behind the block sums)
+    BoundDisc* discs = reinterpret_cast<BoundDisc*>(ub + ((nblk + 3) & ~3));
 
     // ---- staging: cloud rotated by the initial yaw, rotations, planes ---------------------------
     {
@@ -523,7 +526,10 @@ Rt2DBoundKernel(const Rt2DTileParams* __restrict__ params, const int4* __restric
         ay[i] = y;
       }
       const auto* rot = AsGlobal(reinterpret_cast<const float*>(P.scan_rot));
-      for (int s = tid; s < S; s += kBoundThreads) rots[s] = make_float2(rot[2 * s], rot[2 * s + 1]);
+      for (int s = tid; s < S; s += kBoundThreads) {
+        rots[s] = make_float2(rot[2 * s], rot[2 * s + 1]);
+        if (LOG == 2) discs[s] = MakeBoundDisc(P, rots[s]);
+      }
       // the planes: 8-byte pieces (b_lpb is a multiple of 8 -- and not of 16: thirty-four dwords
       // from row to row spread the rows of a wall over the banks, a pitch of 128 bytes put them
       // all on two -- b_c0 and m2_pitch are multiples of 4), eight in flight per thread.  A piece
@@ -585,6 +591,9 @@ Rt2DBoundKernel(const Rt2DTileParams* __restrict__ params, const int4* __restric
     // An item with fewer rotations than wavefronts (a single match spread over the chip) slices
     // every rotation's chunks over several of them.
     const int my_rotations = (S - g + G - 1) / G;
+    // (C1's 27 rotations over 8 wavefronts leave the last round three of eight busy; halves of
+    // rotations -- 54 units -- measured: 86.5 against 81.7 us per 1024 matches, the second
+    // workgroup of the CU fills the gap better than twice the reductions do)
     const int slices = max(1, min(kWaves / my_rotations, pchunks));
     const int slice_chunks = (pchunks + slices - 1) / slices;
     int rotations_done = 0;
@@ -594,7 +603,7 @@ Rt2DBoundKernel(const Rt2DTileParams* __restrict__ params, const int4* __restric
       const int ri = unit / slices, slice = unit - ri * slices;
       const int chunk_first = slice * slice_chunks, chunk_end = min(pchunks, chunk_first + slice_chunks);
       const int s = g + ri * G;
-      const BoundDisc D = MakeBoundDisc(P, rots[s]);
+      const BoundDisc D = LOG == 2 ? discs[s] : MakeBoundDisc(P, rots[s]);
       uint32_t even[NB][kRowWords], odd[NB][kRowWords];   // 16-bit fields: blocks (4 w, 4 w + 2) / (4 w + 1, 4 w + 3)
 #pragma unroll
       for (int j = 0; j < NB; ++j)

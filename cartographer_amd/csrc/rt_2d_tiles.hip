@@ -1759,9 +1759,10 @@ bool Rt2DTileCall::Plan() {
       if ((g.b8_lp & 15) == 0) g.b8_lp += 8;
       g.b8_lh = g.T + 4 * nb4;
       g.t4_lds = BoundTail4Lds(g.b8_lp, g.b8_lh, n_pad, sr.num_scans, nb4);
-      // | rotations | block sums (nothing else: the tail kernel has LDS of its own)
+      // | rotations | block sums | discretisation constants (the tail kernel has LDS of its own)
       g.b4_lds = g.b4_tail_at + 8 * ((static_cast<size_t>(sr.num_scans) + 1) & ~size_t{1}) +
-                 4 * ((static_cast<size_t>(sr.num_scans) * nb4 * nb4 + 3) & ~size_t{3});
+                 4 * ((static_cast<size_t>(sr.num_scans) * nb4 * nb4 + 3) & ~size_t{3}) +
+                 sizeof(BoundDisc) * static_cast<size_t>(sr.num_scans);
     }
     I.tile_lds = std::max(I.tile_lds, g.lds);
     I.prep_lds = std::max<size_t>(I.prep_lds, 6 * static_cast<size_t>(n_pad) + 512);
