@@ -234,7 +234,9 @@ class PinnedBuffer {
 // start-up where a launch costs 3-4.  Falls back to hipMemcpyAsync above `kCopyKernelMaxBytes`
 // or with the debug switch no_copy_kernels.  `pinned` is the host side (source for to_device, else target).
 constexpr size_t kCopyKernelMaxBytes = 1024 * 1024;   // one workgroup per 64 KB
-void SmallCopyAsync(void* dst, const void* src, size_t bytes, bool to_device, hipStream_t stream);
+// (`zero`, `zero_bytes`: a device region, 16-byte aligned and sized, the same launch fills with zeros)
+void SmallCopyAsync(void* dst, const void* src, size_t bytes, bool to_device, hipStream_t stream,
+                    void* zero = nullptr, size_t zero_bytes = 0);
 
 // Opt-in to `bytes` (> 64 KB) of dynamic LDS for kernel `fn` on `device`: HIP keeps function
 // attributes per device, so the cache behind this is keyed by (device, kernel), not by the thread

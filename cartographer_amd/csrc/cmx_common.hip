@@ -322,22 +322,29 @@ namespace {
 __global__ void __launch_bounds__(1024)
 SmallCopyKernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t words16,
                 unsigned char* __restrict__ dst_tail, const unsigned char* __restrict__ src_tail,
-                int tail_bytes) {
+                int tail_bytes, uint4* __restrict__ zero, size_t zero_words16) {
   // (several workgroups for transfers beyond 64 KB: each takes a contiguous share)
   const size_t per_block = (words16 + gridDim.x - 1) / gridDim.x;
   const size_t begin = blockIdx.x * per_block, end = min(words16, begin + per_block);
   for (size_t i = begin + threadIdx.x; i < end; i += blockDim.x) dst[i] = src[i];
+  // (a region the caller wants zeroed on the device: zeros that do not cross the bus)
+  const size_t zper = (zero_words16 + gridDim.x - 1) / gridDim.x;
+  const size_t zbegin = blockIdx.x * zper, zend = min(zero_words16, zbegin + zper);
+  for (size_t i = zbegin + threadIdx.x; i < zend; i += blockDim.x) zero[i] = make_uint4(0, 0, 0, 0);
   if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail_bytes)
     dst_tail[threadIdx.x] = src_tail[threadIdx.x];
 }
 }  // namespace
 
-void SmallCopyAsync(void* dst, const void* src, size_t bytes, bool to_device, hipStream_t stream) {
+void SmallCopyAsync(void* dst, const void* src, size_t bytes, bool to_device, hipStream_t stream,
+                    void* zero, size_t zero_bytes) {
   const bool enabled = Debug().no_copy_kernels == 0;
-  const bool aligned = (reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 16 == 0;
+  const bool aligned = (reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) |
+                        reinterpret_cast<uintptr_t>(zero) | zero_bytes) % 16 == 0;
   if (!enabled || !aligned || bytes == 0 || bytes > kCopyKernelMaxBytes) {
     CMX_HIP(hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost,
                            stream));
+    if (zero_bytes) CMX_HIP(hipMemsetAsync(zero, 0, zero_bytes, stream));
     return;
   }
   const size_t words16 = bytes / 16;
@@ -345,7 +352,7 @@ void SmallCopyAsync(void* dst, const void* src, size_t bytes, bool to_device, hi
   SmallCopyKernel<<<static_cast<unsigned>((bytes + 65535) / 65536), 1024, 0, stream>>>(
       static_cast<uint4*>(dst), static_cast<const uint4*>(src), words16,
       static_cast<unsigned char*>(dst) + words16 * 16,
-      static_cast<const unsigned char*>(src) + words16 * 16, tail);
+      static_cast<const unsigned char*>(src) + words16 * 16, tail, static_cast<uint4*>(zero), zero_bytes / 16);
   CMX_HIP(hipGetLastError());
 }
 

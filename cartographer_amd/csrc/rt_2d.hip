@@ -724,10 +724,12 @@ void Rt2DMatchBatch(const cmx_rt_options* options, const Rt2DItem* items, int nu
     if (Debug().rt2d_first_part == 0 && num >= 512 && num_parts >= 3) first = num / 10;
     const int rest_parts = first > 0 ? num_parts - 1 : num_parts;
     if (first > 0) part_end.push_back(first);
-    const long long total_weight = static_cast<long long>(rest_parts) * (rest_parts + 1) / 2;
-    long long weight = 0;
+    // (weights k + 2, k + 1, ... 3: 4 : 3 for two parts -- neither of 1024 matches' later parts
+    // beyond the 512 workgroups of the tail kernel the chip holds at once)
+    long long total_weight = 0, weight = 0;
+    for (int h = 0; h < rest_parts; ++h) total_weight += rest_parts - h + 2;
     for (int h = 0; h < rest_parts; ++h) {
-      weight += rest_parts - h;
+      weight += rest_parts - h + 2;
       part_end.push_back(first + static_cast<int>(static_cast<long long>(num - first) * weight / total_weight));
     }
   } else {

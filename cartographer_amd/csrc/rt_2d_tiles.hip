@@ -1922,7 +1922,6 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
     ub_total += static_cast<size_t>(search[m].num_scans) * nb_level * nb_level;
   }
   int* d_ub = I.bounds ? ws->dev[6].ReserveAs<int>(ub_total + 16) : nullptr;
-  std::memset(h_in + off_misc, 0, sizeof(unsigned) * 128 * static_cast<size_t>(num));
   if (I.fused) {
     int4* h_work = reinterpret_cast<int4*>(h_in + off_work);
     int count = 0;
@@ -2070,7 +2069,9 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
   // (the stage counters ride in the last words of a match's slot: the finalist head must stop short)
   static_assert(2 + 2 * kFinalistHead <= 124, "a match's head, bound and stage counters share 128 words");
   t_params = lap_us();
-  SmallCopyAsync(d_in, h_in, in_bytes, /*to_device=*/true, ws->stream);
+  // (the matches' result words -- 512 bytes each, the last region of the buffer -- are zeroed by
+  // the copy kernel itself: 40 % of the upload did not have to cross the bus)
+  SmallCopyAsync(d_in, h_in, off_misc, /*to_device=*/true, ws->stream, d_in + off_misc, in_bytes - off_misc);
   t_upload = lap_us();
   const Rt2DTileParams* d_params = reinterpret_cast<const Rt2DTileParams*>(d_in);
 
