@@ -52,6 +52,9 @@ constexpr int kBoundUnit = (32766 + kBoundMax - 1) / kBoundMax;   // u units per
 constexpr int kBoundFlush = 255 / kBoundMax;                      // pooled values a byte sums without a carry
 // (a wavefront's block sums are reduced as 16-bit fields: 64 lanes x 32 chunks x kBoundMax)
 static_assert(64 * 32 * kBoundMax < 65536, "block sums of a rotation must fit 16 bits");
+// (... and 32 chunks are what the fused path admits: kFusedMaxPoints, rt_2d_tiles.hip -- raising it
+// must not overflow the fields unnoticed)
+static_assert(kFusedMaxPoints <= 64 * 32, "the bound kernels' 16-bit lane fields hold 32 chunks of points");
 
 // ---------------------------------------------------------------------------------------------
 // grid (ceil(m2_rows * m2_pitch / 256), items): four bytes of each parity plane per thread.

@@ -99,7 +99,9 @@ typedef struct cmx_fast3d_options {
 
 /* Work counters of one call (or summed over a batch). */
 typedef struct cmx_match_stats {
-  int64_t candidates_scored;  /* every scored candidate, all depths */
+  int64_t candidates_scored;  /* every scored candidate, all depths; real-time matchers: the SEARCH
+                                 SPACE the call covered (what the reference scores) -- how much of it
+                                 the device summed is coarse_candidates */
   int64_t coarse_candidates;  /* lowest-resolution (or exhaustive) candidates; real-time 2D with block
                                  bounds: the bounds evaluated + the candidates summed behind them */
   int64_t nodes_expanded;     /* branch-and-bound nodes whose children were scored */

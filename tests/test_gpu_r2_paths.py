@@ -469,6 +469,76 @@ def test_rt2d_large_batch_goes_out_as_two_halves(sm, synth, debug, resident, par
             sm.rt2d_match_batch(m, grids, inits, bad)
 
 
+@pytest.mark.parametrize("count", [260, 530])
+def test_rt2d_default_schedule_of_a_large_batch(sm, synth, debug, count):
+    """Round 6: a call of 256 matches and more goes out in parts of DIFFERENT sizes (from 512 on a
+    small first part, then 4 : 3), the next part prepared on the helper lane -- search parameters,
+    plan, rotation tables over the host pool -- while the calling thread issues the current one,
+    every part through the two bound kernels.  Every match equals the exhaustive tile kernel's
+    single-match result, three calls in a row (the lane and its workers are reused), and the
+    same with the lane switched off."""
+    from cartographer_amd import grid_2d
+    from cartographer_amd import _lib
+    m = sm.RealTimeCorrelativeScanMatcher2D(0.3, math.radians(7.0), 0.1, 0.1)
+    worlds = []
+    for k in range(6):
+        cells, lim, world = synth.make_submap(90 + k, 160, 160, 0.05, 20, 600, 5.0, 0.01)
+        worlds.append((grid_2d.ProbabilityGridOnDevice(0.05, (lim["max_x"], lim["max_y"]), 160, 160,
+                                                       cells=cells), world))
+    grids, inits, scans = [], [], []
+    for k in range(count):
+        grid, world = worlds[k % 6]
+        pose = world.free_pose(700 + k % 40, 0.5)
+        grids.append(grid)
+        scans.append(world.scan(pose, 120 + 7 * (k % 50), 5.0, 0.01, k % 40))
+        inits.append(sm.Rigid2d(pose[0] + 0.02 * (k % 7), pose[1] - 0.015 * (k % 5), pose[2] + 0.01 * (k % 9)))
+    debug(rt2d_no_bounds=1)
+    singles = [m.match(inits[k], scans[k], grids[k]) for k in range(count)]
+    _lib.debug_reset()
+    batch = sm.Rt2DBatch(m, grids, scans, resident=True)
+    init = np.array([[p.x, p.y, p.theta] for p in inits])
+    for lane_off in (0, 0, 0, 1):
+        debug(rt2d_no_lane=lane_off)
+        scores, poses, stats = batch.match(init)
+        for k, (score, pose) in enumerate(singles):
+            assert scores[k] == score, (lane_off, k)
+            np.testing.assert_array_equal(poses[k], [pose.x, pose.y, pose.theta])
+        assert stats["coarse_candidates"] < 0.75 * stats["candidates_scored"], stats   # the bounds ran
+
+
+def test_rt2d_a_flat_match_is_repeated_on_its_own(sm, oracle, synth, debug):
+    """A batch through the bound kernels in which three matches have landscapes too flat for the
+    lists (all-unknown grids: every candidate ties): those three -- and only those -- are
+    repeated on the per-candidate kernels (until round 6: their whole part); every result is the
+    oracle's, first-maximum rule included, and the statistics show the bounds at work for the
+    rest."""
+    m = sm.RealTimeCorrelativeScanMatcher2D(0.3, math.radians(5.0), 0.1, 0.1)
+    cells, lim, world = synth.make_submap(33, 160, 160, 0.05, 20, 600, 5.0, 0.01)
+    unknown = np.zeros_like(cells)
+    from cartographer_amd import grid_2d
+    on_device = {id(c): grid_2d.ProbabilityGridOnDevice(0.05, (lim["max_x"], lim["max_y"]), 160, 160, cells=c)
+                 for c in (cells, unknown)}
+    grids, inits, scans, refs = [], [], [], []
+    for k in range(100):
+        pose = world.free_pose(800 + k, 0.5)
+        scan = world.scan(pose, 150 + 3 * k, 5.0, 0.01, k)
+        init = [pose[0] + 0.07, pose[1] - 0.04, pose[2] + 0.02]
+        use = unknown if k in (5, 50, 99) else cells
+        grids.append(on_device[id(use)])
+        inits.append(sm.Rigid2d(*init))
+        scans.append(scan)
+        refs.append(oracle.rt2d_match(use, 0.05, lim["max_x"], lim["max_y"], init, scan, 0.3,
+                                      math.radians(5.0), 0.1, 0.1))
+    scores, poses, stats = sm.rt2d_match_batch(m, grids, inits, scans)
+    for k, ref in enumerate(refs):
+        assert scores[k] == ref["score"], k
+        np.testing.assert_allclose([poses[k].x, poses[k].y, poses[k].theta], ref["pose"], rtol=0, atol=1e-12)
+    per_match = refs[0]["num_candidates"]
+    # (three matches scored every candidate with the f32 chain, the others a handful)
+    assert 3 * per_match <= stats["finalists"] < 3 * per_match + 97 * 40, stats
+    assert stats["candidates_scored"] == sum(r["num_candidates"] for r in refs)
+
+
 # ----------------------------------------------------------------------------
 # Ceres refinement on the device (SURVEY.md 8 f1) vs the oracle's restatement
 # ----------------------------------------------------------------------------

@@ -84,16 +84,19 @@ def case_2d(rng, report):
     if not (score == a["score"] and
             np.allclose([pose.x, pose.y, pose.theta], a["pose"], rtol=0, atol=1e-12)):
         report("rt2d", dict(what, rt=rt), score, a["score"])
-    # the same match through the block bounds (the default only from 192 matches per call on)
+    # the same match through the block bounds (the default only from 96 matches per call on): 4 x 4
+    # blocks + tail kernel (round 6), 2 x 2 blocks + tail kernel, 2 x 2 blocks in one kernel
     from cartographer_amd import _lib
-    _lib.debug_set(rt2d_bounds=1)
-    try:
-        score, pose = m.match(sm.Rigid2d(*init), pts, sm.Grid2D(cells, res, max_x, max_y))
-    finally:
-        _lib.debug_set(rt2d_bounds=0)
-    if not (score == a["score"] and
-            np.allclose([pose.x, pose.y, pose.theta], a["pose"], rtol=0, atol=1e-12)):
-        report("rt2d bounds", dict(what, rt=rt), score, a["score"])
+    for name, switches in (("rt2d bounds", {}), ("rt2d bounds level 2", dict(rt2d_bounds_level=2)),
+                           ("rt2d bounds fused", dict(rt2d_bounds_fused=1))):
+        _lib.debug_set(rt2d_bounds=1, **switches)
+        try:
+            score, pose = m.match(sm.Rigid2d(*init), pts, sm.Grid2D(cells, res, max_x, max_y))
+        finally:
+            _lib.debug_set(rt2d_bounds=0, **{k: 0 for k in switches})
+        if not (score == a["score"] and
+                np.allclose([pose.x, pose.y, pose.theta], a["pose"], rtol=0, atol=1e-12)):
+            report(name, dict(what, rt=rt), score, a["score"])
 
 
 def case_3d(rng, report):
