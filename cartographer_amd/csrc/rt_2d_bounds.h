@@ -626,7 +626,9 @@ Rt2DBoundKernel(const Rt2DTileParams* __restrict__ params, const int4* __restric
                             static_cast<unsigned>(Ys - box_y0) < static_cast<unsigned>(T);
         if (valid && !inside) outside = true;
         const int plane = ((Ys & kPhase) << LOG) | (Xs & kPhase);
-        return valid && inside ? plane * plane_bytes + ((Ys >> LOG) - r0) * lpb + ((Xs >> LOG) - c0)
+        // (24-bit multiplies: full rate, where v_mul_lo_u32 takes four issue slots -- a plane
+        // index and a row times strides far below 2^24)
+        return valid && inside ? __mul24(plane, plane_bytes) + __mul24((Ys >> LOG) - r0, lpb) + ((Xs >> LOG) - c0)
                                : zero_at;
       };
       const int last = chunk_end - 1;
@@ -1003,7 +1005,7 @@ Rt2DBoundTail4Kernel(const Rt2DTileParams* __restrict__ params, const int* __res
         const bool inside = static_cast<unsigned>(Xs - box_x0) < static_cast<unsigned>(T) &&
                             static_cast<unsigned>(Ys - box_y0) < static_cast<unsigned>(T);
         if (valid && !inside) outside = true;
-        at[u] = valid && inside ? Ys * lp + Xs + rel : zero_at;
+        at[u] = valid && inside ? __mul24(Ys, lp) + Xs + rel : zero_at;
       }
       uint32_t w0[4][4], w1[4][4];
 #pragma unroll
