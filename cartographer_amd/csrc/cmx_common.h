@@ -77,6 +77,7 @@ cmx_status Guard(F&& body) {
   X(rt2d_host_par)        /* matches per call from which the per-match host loops go to the host pool (0: 4096) */ \
   X(rt2d_tables_serial)   /* 1: the rotation tables of a part by one thread (no host pool) */ \
   X(rt2d_first_part)      /* matches of a large batch's first part (0: default; -1: none, decreasing parts only) */ \
+  X(rt2d_image_kernels)   /* 1: a grid's derived images by the three kernels of rounds 4 - 5 (parity partner of Rt2DImageKernel) */ \
   X(rt2d_no_lane)         /* 1: the parts of a batch are prepared by the calling thread itself (no helper lane) */ \
   X(rt2d_parts_pool)      /* 1: the parts of a batch are planned and enqueued by host pool threads */ \
   X(rt2d_grid_share)      /* a part's tile grid and work items sized for its share of the CUs: 1 always, 2 never (0: by batch size) */ \

@@ -128,6 +128,102 @@ Rt2DPool4Kernel(const Rt2DTileParams* __restrict__ params) {
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// grid (tiles_x * tiles_y, items), 256 threads: ALL derived images of a grid in one launch (round
+// 6; until then Rt2DQuantKernel, Rt2DPoolKernel and Rt2DPool4Kernel one after the other, every
+// cell read four to sixteen times with its bounds checks: 130 us per 256 grids, which a caller
+// that inserts a scan after every match pays on every call).  A workgroup takes a tile of
+// 64 x 16 cells of the image: `u` of the tile and three cells of halo into LDS (each cell of
+// the grid read once), the 2 x 2 maxima of 66 x 18 cells into LDS, then one DWORD per thread and
+// image: the 10-bit cells (two), the bytes, the four parity planes, the sixteen phase planes.
+// The kernels it replaces stay the statement of what every image holds (rt2d_image_kernels = 1
+// launches them instead: the parity partner).
+// ---------------------------------------------------------------------------------------------
+constexpr int kImageTileX = 64, kImageTileY = 16;
+__global__ void __launch_bounds__(256)
+Rt2DImageKernel(const Rt2DTileParams* __restrict__ params, int tiles_x) {
+  const Rt2DTileParams& P = params[blockIdx.y];
+  if (!P.image_build) return;
+  __shared__ uint16_t u[kImageTileY + 3][kImageTileX + 4];
+  __shared__ uint8_t m2s[kImageTileY + 2][kImageTileX + 4];
+  const int tid = threadIdx.x;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int X0 = tx * kImageTileX, Y0 = ty * kImageTileY;
+  const int gw = P.gpitch >> 1;
+  const bool planes = P.m2 != nullptr;
+  const int xe = planes ? max(gw, max(2 * P.m2_pitch, 4 * P.m4_pitch)) : gw;
+  const int ye = planes ? max(P.grows, max(2 * P.m2_rows, 4 * P.m4_rows)) : P.grows;
+  if (X0 >= xe || Y0 >= ye) return;              // (uniform)
+  const auto* cells = AsGlobal(P.cells);
+  for (int i = tid; i < (kImageTileY + 3) * (kImageTileX + 3); i += 256) {
+    const int r = i / (kImageTileX + 3), c = i - r * (kImageTileX + 3);
+    const int gx = X0 + c - P.hl, gy = Y0 + r - P.ht;   // image (X, Y) = grid (X - hl, Y - ht)
+    unsigned val = 0;
+    if (static_cast<unsigned>(gx) < static_cast<unsigned>(P.nx) &&
+        static_cast<unsigned>(gy) < static_cast<unsigned>(P.ny)) {
+      const unsigned raw = cells[gy * P.nx + gx] & 32767u;
+      val = raw ? 32767u - raw : 0u;
+    }
+    u[r][c] = static_cast<uint16_t>(val);
+  }
+  __syncthreads();
+  {
+    // the 10-bit cells (two dwords per thread) and the bytes (one)
+    const int r = tid >> 4, c4 = (tid & 15) << 2;
+    const int X = X0 + c4, Y = Y0 + r;
+    if (Y < P.grows && X < gw) {                 // (gw is a multiple of 8: four cells in or out)
+      const unsigned a = u[r][c4], b = u[r][c4 + 1], c = u[r][c4 + 2], d = u[r][c4 + 3];
+      uint2v q;
+      q.x = (a >> kQShift) | ((b >> kQShift) << 16);
+      q.y = (c >> kQShift) | ((d >> kQShift) << 16);
+      *reinterpret_cast<uint2v*>(P.qimage + static_cast<size_t>(Y) * gw + X) = q;
+      if (P.q8)
+        *reinterpret_cast<uint32_t*>(P.q8 + static_cast<size_t>(Y) * gw + X) =
+            (a >> kQ8Shift) | ((b >> kQ8Shift) << 8) | ((c >> kQ8Shift) << 16) | ((d >> kQ8Shift) << 24);
+    }
+  }
+  if (!planes) return;                           // (uniform)
+  for (int i = tid; i < (kImageTileY + 2) * (kImageTileX + 2); i += 256) {
+    const int r = i / (kImageTileX + 2), c = i - r * (kImageTileX + 2);
+    const unsigned m = max(max(static_cast<unsigned>(u[r][c]), static_cast<unsigned>(u[r][c + 1])),
+                           max(static_cast<unsigned>(u[r + 1][c]), static_cast<unsigned>(u[r + 1][c + 1])));
+    m2s[r][c] = static_cast<uint8_t>((m + kBoundUnit - 1) / kBoundUnit);
+  }
+  __syncthreads();
+  {
+    // the parity planes: plane(Y & 1, X & 1)[Y >> 1][X >> 1] -- a thread's dword is four cells
+    // two apart of one plane row
+    const int plane = tid >> 6, rr = (tid >> 3) & 7, dw = tid & 7;
+    const int py = plane >> 1, px = plane & 1;
+    const int row = (Y0 >> 1) + rr, col = (X0 >> 1) + 4 * dw;
+    if (row < P.m2_rows && col < P.m2_pitch) {   // (the pitch is a multiple of 4)
+      const int r = 2 * rr + py, c = 8 * dw + px;
+      const unsigned out = m2s[r][c] | (m2s[r][c + 2] << 8) | (m2s[r][c + 4] << 16) | (m2s[r][c + 6] << 24);
+      *reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(P.m2) + static_cast<size_t>(plane) * P.m2_rows * P.m2_pitch +
+                                   static_cast<size_t>(row) * P.m2_pitch + col) = out;
+    }
+  }
+  {
+    // the phase planes of the 4 x 4 pooling: m4 = the maximum of four m2 two cells apart
+    const int plane = tid >> 4, rr = (tid >> 2) & 3, dw = tid & 3;
+    const int py = plane >> 2, px = plane & 3;
+    const int row = (Y0 >> 2) + rr, col = (X0 >> 2) + 4 * dw;
+    if (row < P.m4_rows && col < P.m4_pitch) {
+      const int r = 4 * rr + py;
+      unsigned out = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = 4 * (4 * dw + i) + px;
+        const unsigned m = max(max(static_cast<unsigned>(m2s[r][c]), static_cast<unsigned>(m2s[r][c + 2])),
+                               max(static_cast<unsigned>(m2s[r + 2][c]), static_cast<unsigned>(m2s[r + 2][c + 2])));
+        out |= m << (8 * i);
+      }
+      *reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(P.m4) + static_cast<size_t>(plane) * P.m4_rows * P.m4_pitch +
+                                   static_cast<size_t>(row) * P.m4_pitch + col) = out;
+    }
+  }
+}
+
 // The discretisation of the tile kernel's fused path (see the long comment there): cells from a
 // two-FMA f32 estimate where it provably equals the reference's rounding, the exact expressions
 // for a whole chunk otherwise.  One set of constants per (match, rotation).

@@ -2078,23 +2078,28 @@ void Rt2DTileCall::Enqueue(hipStream_t on_stream) {
   RecordEvent(ws->ev_begin, ws->stream);
   {
     bool any_build = false;
-    size_t max_vecs = 0;
+    size_t max_vecs = 0, max_words = 0, max_words4 = 0;
+    int max_xe = 0, max_ye = 0;
     for (int m = 0; m < num; ++m) {
-      any_build = any_build || build_image[m];
-      if (build_image[m]) max_vecs = std::max(max_vecs, geo[m].image_bytes >> 4);
+      if (!build_image[m]) continue;
+      any_build = true;
+      max_vecs = std::max(max_vecs, (static_cast<size_t>(geo[m].gpitch) * geo[m].grows) >> 4);
+      max_words = std::max(max_words, static_cast<size_t>(geo[m].m2_pitch) * geo[m].m2_rows);
+      max_words4 = std::max(max_words4, 4 * static_cast<size_t>(geo[m].m4_pitch) * geo[m].m4_rows);
+      max_xe = std::max(max_xe, std::max(geo[m].gpitch >> 1, std::max(2 * geo[m].m2_pitch, 4 * geo[m].m4_pitch)));
+      max_ye = std::max(max_ye, std::max(geo[m].grows, std::max(2 * geo[m].m2_rows, 4 * geo[m].m4_rows)));
     }
-    if (any_build)
+    if (any_build && !dbg.rt2d_image_kernels) {
+      // (round 6) every derived image of a grid in ONE launch: Rt2DImageKernel
+      const int tiles_x = DivUp(max_xe, kImageTileX), tiles_y = DivUp(max_ye, kImageTileY);
+      Rt2DImageKernel<<<dim3(tiles_x * tiles_y, num), 256, 0, ws->stream>>>(d_params, tiles_x);
+    } else if (any_build) {
       Rt2DQuantKernel<<<dim3(DivUp(max_vecs, 256), num), 256, 0, ws->stream>>>(d_params);
-    size_t max_words = 0;
-    for (int m = 0; m < num; ++m)
-      if (build_image[m]) max_words = std::max(max_words, static_cast<size_t>(geo[m].m2_pitch) * geo[m].m2_rows);
-    if (max_words)
-      Rt2DPoolKernel<<<dim3(DivUp(max_words, 256), num), 256, 0, ws->stream>>>(d_params);
-    size_t max_words4 = 0;
-    for (int m = 0; m < num; ++m)
-      if (build_image[m]) max_words4 = std::max(max_words4, 4 * static_cast<size_t>(geo[m].m4_pitch) * geo[m].m4_rows);
-    if (max_words4)
-      Rt2DPool4Kernel<<<dim3(DivUp(max_words4, 256), num), 256, 0, ws->stream>>>(d_params);
+      if (max_words)
+        Rt2DPoolKernel<<<dim3(DivUp(max_words, 256), num), 256, 0, ws->stream>>>(d_params);
+      if (max_words4)
+        Rt2DPool4Kernel<<<dim3(DivUp(max_words4, 256), num), 256, 0, ws->stream>>>(d_params);
+    }
   }
   if (!I.fused)
     Rt2DTilePrepKernel<<<dim3(I.max_scans, num), 256, I.prep_lds, ws->stream>>>(

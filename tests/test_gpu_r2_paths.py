@@ -165,7 +165,7 @@ def test_fast2d_fused_and_unfused_batches_agree(sm, synth, c2, debug):
 # ----------------------------------------------------------------------------
 # Real-time 2D: bulk pass vs per-candidate kernels vs oracle
 # ----------------------------------------------------------------------------
-RT2D_PATHS = ["bounds", "bounds2", "bounds1", "tiles", "tiles1", "tiles64", "tiles56g", "0"]
+RT2D_PATHS = ["bounds", "bounds_img3", "bounds2", "bounds1", "tiles", "tiles1", "tiles64", "tiles56g", "0"]
 
 
 def _rt2d_path(debug, path):
@@ -182,6 +182,9 @@ def _rt2d_path(debug, path):
     with one work item per (tile, rotation); '0': one thread per candidate."""
     if path == "bounds":     # block bounds first where the window is at most 16 x 16 (the
         debug(rt2d_bounds=1)  # default from 192 matches per call on; here: calls of any size)
+        return
+    if path == "bounds_img3":   # (the grid's derived images by the three kernels Rt2DImageKernel replaced)
+        debug(rt2d_bounds=1, rt2d_image_kernels=1, rt2d_no_image_cache=1)
         return
     if path == "bounds2":
         debug(rt2d_bounds=1, rt2d_bounds_level=2)
@@ -240,11 +243,11 @@ def test_rt2d_both_paths(sm, oracle, synth, debug, bulk, seed, size, beams, lin,
     # block bounds: the device summed a fraction of the search space (a bound per 2 x 2 block +
     # four candidates per surviving block), the exhaustive paths all of it
     side = 2 * math.ceil(lin / 0.05 - 1e-9) + 1
-    if bulk == "bounds" and 1 < side <= 16:      # (4 x 4 blocks: a bound per block + sixteen candidates per survivor)
+    if bulk in ("bounds", "bounds_img3") and 1 < side <= 16:      # (4 x 4 blocks: a bound per block + sixteen candidates per survivor)
         assert st["coarse_candidates"] < 0.75 * ref["num_candidates"], st
     elif bulk in ("bounds2", "bounds1") and 1 < side <= 16:
         assert st["coarse_candidates"] < 0.6 * ref["num_candidates"], st
-    elif bulk not in ("0", "bounds", "bounds2", "bounds1") or side > 16:
+    elif bulk not in ("0", "bounds", "bounds_img3", "bounds2", "bounds1") or side > 16:
         assert st["coarse_candidates"] == ref["num_candidates"]
 
 
