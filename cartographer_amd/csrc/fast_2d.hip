@@ -114,6 +114,29 @@ __global__ void BuildPlanesKernel(const uint8_t* __restrict__ level, int wx, int
   }
 }
 
+// out(X, Y) = max of level(X - 2 + a, Y - 2 + b), a, b in [0, 4] (cells outside the level read 0), for
+// X in [0, wx + 4), Y in [0, wy + 4): the level dilated by two cells either way, stored two cells
+// up so that the border's dilation has a place (the group bounds of the fused front end).
+constexpr int kGroupDilation = 2;
+__global__ void DilateLevelKernel(const uint8_t* __restrict__ level, int wx, int wy,
+                                  uint8_t* __restrict__ out) {
+  const int X = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Y = blockIdx.y;
+  const int ox = wx + 2 * kGroupDilation;
+  if (X >= ox) return;
+  int best = 0;
+  for (int b = -kGroupDilation; b <= kGroupDilation; ++b) {
+    const int y = Y - kGroupDilation + b;
+    if (static_cast<unsigned>(y) >= static_cast<unsigned>(wy)) continue;
+    for (int a = -kGroupDilation; a <= kGroupDilation; ++a) {
+      const int x = X - kGroupDilation + a;
+      if (static_cast<unsigned>(x) >= static_cast<unsigned>(wx)) continue;
+      best = max(best, static_cast<int>(level[x + y * wx]));
+    }
+  }
+  out[X + Y * ox] = static_cast<uint8_t>(best);
+}
+
 // quads(x + w, y + w) = level(x, y) | level(x, y+w) << 8 | level(x+w, y) << 16 |
 // level(x+w, y+w) << 24 for x in [-w, wx), y in [-w, wy); cells outside the level read 0.
 // Tiled storage: QuadOffset (scan_matching_2d.h).
@@ -632,8 +655,10 @@ ScoreCoarsePlanesDwordKernel(const Fast2DProblem* __restrict__ problems, int n,
 // The integer sums are order-free: results are bit-identical to the sorted variant
 // (ScoreCoarsePlanesDwordKernel, kept for CMX_FUSED=0 and for problems this kernel does not
 // take).
-// Dynamic LDS: pts[n_pad] u32 | misc[32] | cand_acc[acc_cap] | point words[waves][64].
+// Dynamic LDS: pts[group][n_pad] u32 | misc[kFusedMisc] | cand_acc[acc_cap] | point words[waves][64].
 constexpr int kFusedMaxPoints = 4096;    // = kPointCache of the tree search
+constexpr int kFusedGroup = 3;           // rotations per workgroup under group bounds (see the kernel)
+constexpr int kFusedMisc = 128;          // ints of bookkeeping between the cells and the accumulators
 
 // Points kFirst .. kFirst + 7 of a lane group (LDS words at a stride of 16 bytes from `base`): the
 // low halves into lo[0..7], the high halves into hi[0..7], zero-extended; returns when they landed.
@@ -659,168 +684,54 @@ __device__ __forceinline__ void ReadHalves8(unsigned base, uint32_t* lo, uint32_
       : "memory");
 }
 
-template <bool kTimeline>    // (true: the debug switch `timeline`; the shipped instantiation has no stamps)
-__global__ void __launch_bounds__(256, 8)   // (eight wavefronts per SIMD: at most 64 VGPRs)
-PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __restrict__ xyz,
-                     int n, ProblemState* __restrict__ states, int acc_cap,
-                     int* __restrict__ counters_words, int num_counter_words) {
+// The sums of a unit of PrepScoreFusedKernel (below, where the terms are explained): the cells of ONE
+// rotation of the unit summed over the phase planes -- the dilated level's under group bounds, the
+// level's own otherwise -- and the sums handed to the rotations they stand for.  Everything it needs
+// comes out of the block's bookkeeping words in LDS, so that nothing but those is live across the
+// gather loop (which fills the 64 VGPRs of eight wavefronts per SIMD on its own: no scratch).
+template <bool kTimeline>
+__device__ __forceinline__ void FusedPass(const Fast2DProblem& P, ProblemState* state, int n,
+                                          int acc_cap, int s0, int timeline_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fused_smem[];
-  // First kernel of a fully fused batch: it also clears the list counters of the search.
-  // (every workgroup clears a slice: the counters with the work queue's control words are 376 KB)
-  if (counters_words)
-    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
-         i < num_counter_words; i += gridDim.x * gridDim.y * blockDim.x)
-      counters_words[i] = 0;
-  const Fast2DProblem& P = problems[blockIdx.y];
-  // Blocks b, b + 256, b + 512, ... tend to share a CU (b % 8 picks the XCD, round-robin
-  // within it): give them ADJACENT rotations.  Neighbouring rotations move a point by less
-  // than a cell, so co-resident blocks gather the same or the neighbouring phase plane at
-  // about the same time and meet in the CU's L1 instead of each going to L2.  (Any bijection
-  // is correct; only speed depends on the dispatch order.)
-  const int slots = (gridDim.x + 255) >> 8;
-  const int s = (blockIdx.x & 255) * slots + (blockIdx.x >> 8);
-  if (!P.use_fused || s >= P.num_scans) return;
+  const auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
   const int n_pad = (n + 63) & ~63;
-  auto* pts = reinterpret_cast<uint32_t*>(fused_smem);
-  int* misc = reinterpret_cast<int*>(pts + n_pad);
-  int* cand_acc = misc + 32;
-  const int T = blockDim.x;              // 128, 192 or 256
+  const int G = P.group > 1 ? kFusedGroup : 1;
+  auto* pts_all = reinterpret_cast<uint32_t*>(fused_smem);        // [G][n_pad]
+  int* misc = reinterpret_cast<int*>(pts_all + G * n_pad);
+  int* cand_acc = misc + kFusedMisc;
+  const int T = blockDim.x;
   const int waves = T >> 6;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const auto stamp = [&](int k) {
-    if constexpr (kTimeline) Stamp(P.timeline, blockIdx.y * gridDim.x + blockIdx.x, k);
+    if constexpr (kTimeline) Stamp(P.timeline, timeline_block, k);
   };
-  stamp(0);
-
-  // ---- rotate, translate, discretise (PrepScansKernel's arithmetic) ----------
-  const float2 r = P.scan_rot[s];
-  const bool identity_q0 = P.init_qw == 1.f && P.init_qz == 0.f;
-  // The cell of a point from an f32 ESTIMATE of the value the reference rounds,
-  //     t = (max - translation) / res - 0.5 - (rotated coordinate) / res,
-  // in two FMAs per coordinate (the real-time matcher's discretisation, rt_2d_tiles.hip, where
-  // the error bound is derived: the estimate differs from GetCellIndex over RotateZ's f32 chain
-  // by less than 2^-24 [((k_z + 4) (|ax| + |ay|) + |translation|) / res + 3 |K|], k_z =
-  // max(2 + 4 z^2, 1 + 6 |z|) for this scan's rotation (w, z)); when it lies further than
-  // 1.25 x that from every half-integer its rounding IS the reference's cell.  Otherwise -- three
-  // points in a thousand at 60 m (20 M random points over the full circle: 0 wrong cells among
-  // the decided ones) -- the exact expressions below run for that lane.  ~30 instead of ~110
-  // vector instructions per point (a third of this kernel's instructions) -- and no measurable
-  // change of its duration (same-box A/B: 132.4 -> 130.4 - 132.5 us per search): the kernel is
-  // not bound by instruction issue but by the plane gathers below (DESIGN 5.1).
-  const double inv_res_d = P.inv_res, zd = r.y;
-  const float Ci = static_cast<float>((1.0 - 2.0 * zd * zd) * inv_res_d);
-  const float Si = static_cast<float>(2.0 * static_cast<double>(r.x) * zd * inv_res_d);
-  const double Kyd = (P.max_y - static_cast<double>(P.ty)) * inv_res_d - 0.5;
-  const double Kxd = (P.max_x - static_cast<double>(P.tx)) * inv_res_d - 0.5;
-  const float Ky = static_cast<float>(Kyd), Kx = static_cast<float>(Kxd);
-  const float bound_per_m = static_cast<float>(
-      1.25 * 0x1p-24 * inv_res_d * (4.0 + fmax(2.0 + 4.0 * zd * zd, 1.0 + 6.0 * fabs(zd))));
-  const float bound_fixed = static_cast<float>(
-      1.25 * 0x1p-24 * (inv_res_d * fmax(fabs(static_cast<double>(P.tx)), fabs(static_cast<double>(P.ty))) +
-                        3.0 * fmax(fabs(Kxd), fabs(Kyd)) + 1.0));
-  int lo_x = 0, lo_y = 0, hi_x = 0, hi_y = 0, bad = 0;
-  for (int i0 = threadIdx.x; i0 < n; i0 += 4 * T) {
-    // Four points' loads in flight before the first is used.
-    F3 p[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int j = min(i0 + k * T, n - 1);
-      p[k] = F3{xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2]};
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = i0 + k * T;
-      if (i >= n) break;
-      // Two yaw rotations (initial estimate, then this scan's perturbation), then the
-      // translation: Rotate / `+ 0.f` / `1.f * x + 0.f * y` of PrepScansKernel without the
-      // terms that are exactly zero (RotateZ, cmx_device.h).  A full-submap search starts
-      // from yaw 0: its first rotation is the identity.
-      float ax = p[k].x, ay = p[k].y;
-      if (!identity_q0) RotateZ(P.init_qw, P.init_qz, p[k].x, p[k].y, &ax, &ay);
-      const float tY = fmaf(-Ci, ay, fmaf(-Si, ax, Ky));    // cell x index from the map's y
-      const float tX = fmaf(-Ci, ax, fmaf(Si, ay, Kx));
-      const float nY = rintf(tY), nX = rintf(tX);
-      const float margin = fminf(0.5f - fabsf(tY - nY), 0.5f - fabsf(tX - nX));
-      const float bound = fmaf(fabsf(ax) + fabsf(ay), bound_per_m, bound_fixed);
-      int ix, iy;
-      if (margin > bound && fabsf(tY) < 1e6f && fabsf(tX) < 1e6f) {     // (NaN: not greater)
-        ix = static_cast<int>(nY);
-        iy = static_cast<int>(nX);
-      } else {
-        float bx, by;
-        RotateZ(r.x, r.y, ax, ay, &bx, &by);
-        const float x = bx + P.tx;
-        const float y = by + P.ty;
-        // lround((max - v) / res - 0.5), exact (cmx_device.h)
-        ix = CellIndexFast(P.max_y, y, P.res, P.inv_res);
-        iy = CellIndexFast(P.max_x, x, P.res, P.inv_res);
-      }
-      if (ix < -32768 || ix > 32767 || iy < -32768 || iy > 32767) bad = 1;
-      pts[i] = (static_cast<uint32_t>(ix) & 0xffffu) | (static_cast<uint32_t>(iy) << 16);
-      lo_x = min(lo_x, -ix);
-      lo_y = min(lo_y, -iy);
-      hi_x = max(hi_x, P.nx - 1 - ix);
-      hi_y = max(hi_y, P.ny - 1 - iy);
-    }
-  }
-  for (int i = threadIdx.x; i < acc_cap; i += T) cand_acc[i] = 0;
-  stamp(1);      // points discretised
-  lo_x = WaveMinDpp(lo_x); lo_y = WaveMinDpp(lo_y);
-  hi_x = WaveMaxDpp(hi_x); hi_y = WaveMaxDpp(hi_y);
-  bad = WaveMaxDpp(bad);
-  if (lane == 0) {
-    int* red = misc + 8 + wave * 5;      // [4][5]
-    red[0] = lo_x; red[1] = lo_y; red[2] = hi_x; red[3] = hi_y; red[4] = bad;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < waves; ++w) {
-      const int* red = misc + 8 + w * 5;
-      lo_x = min(lo_x, red[0]); lo_y = min(lo_y, red[1]);
-      hi_x = max(hi_x, red[2]); hi_y = max(hi_y, red[3]);
-      bad = max(bad, red[4]);
-    }
-    int4 bd;   // ShrinkToFit
-    bd.x = max(-P.nl, lo_x);
-    bd.y = min(P.nl, hi_x);
-    bd.z = max(-P.nl, lo_y);
-    bd.w = min(P.nl, hi_y);
-    P.bounds[s] = bd;
-    const int step = 1 << (P.depth - 1);
-    const int2 dims = make_int2((bd.y - bd.x + step) / step, (bd.w - bd.z + step) / step);
-    P.coarse_dims[s] = dims;
-    misc[0] = bd.x; misc[1] = bd.y; misc[2] = bd.z; misc[3] = bd.w;
-    misc[4] = dims.x; misc[5] = dims.y;
-    if (bad) atomicMax(&states[blockIdx.y].error, 1);
-    const int count = dims.x * dims.y;
-    const int BW = dims.x + P.plane_i - 1, BH = dims.y + P.plane_j - 1;
-    // (block + 1 = bx * pitch + by + 1 travels in 16 bits, see the scoring loop)
-    const int ok = count <= P.coarse_stride && count <= kMaxCoarsePerScan && BW <= 255 &&
-                   BH <= 255 && (BW - 1) * (dims.y + 2 * P.plane_j - 2) + BH <= 65535 &&
-                   (dims.x + 2 * P.plane_i - 2) * (dims.y + 2 * P.plane_j - 2) <= acc_cap;
-    misc[6] = ok;
-    if (!ok) {
-      atomicMax(&states[blockIdx.y].error, 2);
-      P.scan_best[s] = make_int2(0, 0);
-    }
-  }
-  __syncthreads();
-  if (!misc[6]) return;
-  stamp(2);      // bounds known
-  const int4 bd = make_int4(misc[0], misc[1], misc[2], misc[3]);
-  const int2 dims = make_int2(misc[4], misc[5]);
-  const int count = dims.x * dims.y;
+  const int gcount = uni(misc[1]), gm = uni(misc[2]);
+  const bool far = uni(misc[7]) != 0;       // the premise of the group bound failed for this unit
+  const int2 dims_all = make_int2(uni(misc[4]), uni(misc[5]));
   const int PI = P.plane_i, PJ = P.plane_j, PIJ = PI * PJ;
-  const int pitch = dims.y + 2 * PJ - 2;
   const int shift = P.depth - 1, w = 1 << shift;
-  const int BW = dims.x + PI - 1, BH = dims.y + PJ - 1;
-
-  // ---- score in point order (cf. ScoreCoarsePlanesDwordKernel) ------------------------
+  const unsigned zero_plane = 1u << (2 * (P.depth - 1));
   const int group = lane >> 4, sub = lane & 15;
   const int begin = static_cast<int>(static_cast<long long>(n) * wave / waves);
   const int end = static_cast<int>(static_cast<long long>(n) * (wave + 1) / waves);
-  const unsigned zero_plane = 1u << (2 * (P.depth - 1));
+  constexpr int kSteps = 16;                // all gathers of a 64-point chunk in flight
+  uint32_t* const wave_words = reinterpret_cast<uint32_t*>(cand_acc + acc_cap) + 64 * wave;
+  const unsigned group_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
+      (__attribute__((address_space(3))) uint32_t*)(wave_words + group)));
+  int2* const scratch = reinterpret_cast<int2*>(misc + 8);      // [4]
+  const bool verify = (P.group_verify & 1) != 0;
+    const bool group_pass = G > 1;
+    const int gp = group_pass ? gm : 0;                  // whose cells are summed
+    const uint32_t* const pts = pts_all + gp * n_pad;
+    const int* const mine = misc + 16 + 8 * gp;
+    const int4 bd = make_int4(uni(mine[0]), uni(mine[1]), uni(mine[2]), uni(mine[3]));
+    const int2 dims = group_pass ? dims_all : make_int2(uni(mine[4]), uni(mine[5]));
+    const int lift = group_pass ? kGroupDilation : 0;    // (the dilated level is stored two cells up)
+    const int pitch = dims.y + 2 * PJ - 2;
+    const int BW = dims.x + PI - 1, BH = dims.y + PJ - 1;
+
+  // ---- score in point order (cf. ScoreCoarsePlanesDwordKernel) ------------------------
   int lane_const[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -842,12 +753,20 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
     if (a3) atomicAdd(&cand_acc[lane_const[3] - at], static_cast<int>(a3));
     a0 = a1 = a2 = a3 = 0;
   };
-  constexpr int kSteps = 16;                // all gathers of a 64-point chunk in flight
-  uint32_t* const wave_words = reinterpret_cast<uint32_t*>(cand_acc + acc_cap) + 64 * wave;
-  const unsigned group_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
-      (__attribute__((address_space(3))) uint32_t*)(wave_words + group)));
+  // (the selected pointer made uniform by hand: the compiler turns the selection into ONE vector
+  // load from a selected address, and a resource out of vector registers costs a waterfall loop
+  // around every gather)
+  const unsigned long long planes_bits =
+      reinterpret_cast<unsigned long long>(group_pass ? P.planes_group : P.planes);
+  // (readfirstlane returns an int: through `unsigned`, or the low half sign-extends over the high one)
+  const unsigned planes_lo = static_cast<unsigned>(
+      __builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<unsigned>(planes_bits))));
+  const unsigned planes_hi = static_cast<unsigned>(
+      __builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<unsigned>(planes_bits >> 32))));
+  const uint8_t* const planes_uniform = reinterpret_cast<const uint8_t*>(
+      (static_cast<unsigned long long>(planes_hi) << 32) | planes_lo);
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint8_t*>(P.planes), 0, static_cast<int>((zero_plane + 1) * 64), 0x00020000);
+      const_cast<uint8_t*>(planes_uniform), 0, static_cast<int>((zero_plane + 1) * 64), 0x00020000);
   for (int base_i = begin; base_i < end; base_i += 64) {
     // (instrumented instantiation only -- wavefront 0's first chunk step by step: [8] chunk
     // begins, [9] its sixteen gathers issued, [10] all of them landed, [11] consumed; [12..15]:
@@ -869,8 +788,8 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
     uint32_t my_word = zero_plane;
     if (base_i + lane < end) {
       const uint32_t packed = pts[base_i + lane];
-      const int U = static_cast<short>(packed & 0xffffu) + bd.x + w - 1;
-      const int V = static_cast<short>(packed >> 16) + bd.z + w - 1;
+      const int U = static_cast<short>(packed & 0xffffu) + bd.x + w - 1 + lift;
+      const int V = static_cast<short>(packed >> 16) + bd.z + w - 1 + lift;
       const int bx = (U >> shift) + dims.x - 1, by = (V >> shift) + dims.y - 1;
       if (bx >= 0 && bx < BW && by >= 0 && by < BH)
         my_word = static_cast<uint32_t>((V & (w - 1)) * w + (U & (w - 1))) |
@@ -918,37 +837,270 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
   __syncthreads();
   stamp(5);      // all waves done
 
-  const int base = s * P.coarse_stride;
-  auto* coarse_sum = AsGlobal(P.coarse_sum) + base;
-  auto* coarse_score = AsGlobal(P.coarse_score) + base;
-  int best_sum = -1, best_index = 0x7ffffff;
-  for (int i = threadIdx.x; i < count; i += T) {
-    const int ix = i / dims.y, iy = i - ix * dims.y;
-    const int csum = cand_acc[(ix + PI - 1) * pitch + (iy + PJ - 1)];
-    if (P.write_all_discrete) coarse_sum[i] = csum;     // introspection only
-    coarse_score[i] = ToScore(P, csum, n);
-    if (csum > best_sum) { best_sum = csum; best_index = i; }
+    // ---- the sums of this pass to the rotations they stand for ------------------------------
+    // (a unit whose premise failed -- a point's cell, or a bound, further than one from the middle
+    // rotation's: not seen so far, the angular step excludes it up to rounding -- keeps the middle
+    // rotation's bound, which holds whatever the others do, and gives every candidate of the other
+    // rotations the largest sum there is: nothing of them is excluded up here)
+    for (int t = 0; t < gcount; ++t) {
+      const int s = s0 + t;
+      const int2 tdims = make_int2(misc[16 + 8 * t + 4], misc[16 + 8 * t + 5]);
+      const int count = tdims.x * tdims.y;
+      const int base = s * P.coarse_stride;
+      auto* coarse_sum = AsGlobal(P.coarse_sum) + base;
+      auto* coarse_score = AsGlobal(P.coarse_score) + base;
+      const bool unbounded = far && t != gm;
+      int best_sum = -1, best_index = 0x7ffffff;
+      for (int i = threadIdx.x; i < count; i += T) {
+        const int ix = i / tdims.y, iy = i - ix * tdims.y;
+        const int csum = unbounded ? 255 * n : cand_acc[(ix + PI - 1) * pitch + (iy + PJ - 1)];
+        if (group_pass) {
+          // fast2d_group_verify: the exact sums of an earlier launch (group = 1) are in place
+          if (verify && coarse_sum[i] > csum) atomicMax(&state->error, 3);
+        } else if (P.write_all_discrete || verify) {
+          coarse_sum[i] = csum;     // introspection only
+        }
+        coarse_score[i] = ToScore(P, csum, n);
+        if (csum > best_sum) { best_sum = csum; best_index = i; }
+      }
+      const int2 best = BlockBest(best_sum, best_index, scratch);
+      if (threadIdx.x == 0) P.scan_best[s] = best;
+      stamp(6);      // scores written
+      // The discretised scan stays on chip: the tree search re-derives the cells of the few scans
+      // it descends into (ScanCell).  Only the introspection entry point asks for the array.
+      // Batches (store_scans): a scan whose best candidate reaches the initial bound may enter the
+      // tree search, where several nodes per scan are expanded by independent wavefronts; its
+      // cells are written for them (a superset of what the coarse filter keeps: the bound only
+      // rises).  Re-deriving the cells per node made that expansion VALU-bound.
+      bool keep_cells = P.write_all_discrete != 0;
+      if (!keep_cells && P.store_scans) {
+        int top_sum = scratch[0].x;
+        for (int k = 1; k < T >> 6; ++k) top_sum = max(top_sum, scratch[k].x);
+        keep_cells = !(ToScore(P, top_sum, n) < fmaxf(P.min_score, 0.f));
+      }
+      if (keep_cells) {
+        auto* out = AsGlobal(P.discrete) + static_cast<size_t>(s) * n;
+        const uint32_t* const cells = pts_all + t * n_pad;
+        for (int i = threadIdx.x; i < n; i += T) out[i] = cells[i];
+      }
+      __syncthreads();                       // (the next rotation's BlockBest reuses the scratch)
+    }
+}
+
+template <bool kTimeline>    // (true: the debug switch `timeline`; the shipped instantiation has no stamps)
+__global__ void __launch_bounds__(256, 8)   // (eight wavefronts per SIMD: at most 64 VGPRs)
+PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __restrict__ xyz,
+                     int n, ProblemState* __restrict__ states, int acc_cap,
+                     int* __restrict__ counters_words, int num_counter_words) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fused_smem[];
+  // First kernel of a fully fused batch: it also clears the list counters of the search.
+  // (every workgroup clears a slice: the counters with the work queue's control words are 376 KB)
+  if (counters_words)
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+         i < num_counter_words; i += gridDim.x * gridDim.y * blockDim.x)
+      counters_words[i] = 0;
+  const Fast2DProblem& P = problems[blockIdx.y];
+  // GROUP BOUNDS (round 6).  Neighbouring rotations move a point by at most one cell (the angular
+  // step is chosen so, SM2/correlative_scan_matcher_2d.cc:49-60), and their search bounds -- the
+  // minimum over the points -- by at most one with it.  So for the G = 3 rotations g of a unit and
+  // the middle one m, the cell a lowest-resolution candidate (kx, ky) of rotation g reads for point
+  // p lies within two cells (per axis) of the cell candidate (kx, ky) of rotation m reads for p,
+  // and ONE sum of m's cells over the level DILATED by two cells bounds the score of (kx, ky) of
+  // all three from above.  Everything behind the front end (dive, filter, tree search) takes a
+  // lowest-resolution score as the upper bound of the subtree below it and nothing else, so the
+  // bound takes the score's place: a third of the gathers.  What needs the exact scores -- the
+  // replay of the reference's std::sort when leaves tie (ResolveTies), depth 1, the introspection
+  // entry point -- runs this kernel (again) with group = 1.  The premise is CHECKED per unit (every
+  // point's cells, every bound): in a unit that fails it the outer rotations get the largest sum
+  // there is, i.e. no bound (FusedPass).  fast2d_group_verify: every bound against the exact sums
+  // of a launch with group = 1, on the device.
+  const int G = P.group > 1 ? kFusedGroup : 1;
+  // Units u, u + 256, u + 512, ... tend to share a CU (u % 8 picks the XCD, round-robin
+  // within it): give them ADJACENT rotations.  Neighbouring rotations move a point by less
+  // than a cell, so co-resident blocks gather the same or the neighbouring phase plane at
+  // about the same time and meet in the CU's L1 instead of each going to L2.  (Any bijection
+  // is correct; only speed depends on the dispatch order.)
+  const int slots = (gridDim.x + 255) >> 8;
+  const int unit = (blockIdx.x & 255) * slots + (blockIdx.x >> 8);
+  const int s0 = unit * G;
+  if (!P.use_fused || s0 >= P.num_scans) return;
+  const int gcount = min(G, P.num_scans - s0);
+  const int gm = gcount == 3 ? 1 : 0;       // the rotation of the unit whose cells are summed
+  const int n_pad = (n + 63) & ~63;
+  auto* pts_all = reinterpret_cast<uint32_t*>(fused_smem);        // [G][n_pad]
+  int* misc = reinterpret_cast<int*>(pts_all + G * n_pad);
+  int* cand_acc = misc + kFusedMisc;
+  // misc: [0, 8) the pass (bounds, dims, ok, grouped) | [8, 16) BlockBest | [16 + 8 g, ...) bounds
+  // and dims of rotation g | [40 + 20 g + 5 wave, ...) partials | [100 + wave] cell deltas
+  const int T = blockDim.x;              // 128, 192 or 256
+  const int waves = T >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const auto stamp = [&](int k) {
+    if constexpr (kTimeline) Stamp(P.timeline, blockIdx.y * gridDim.x + blockIdx.x, k);
+  };
+  stamp(0);
+
+  // ---- rotate, translate, discretise (PrepScansKernel's arithmetic) ----------
+  const bool identity_q0 = P.init_qw == 1.f && P.init_qz == 0.f;
+  // The cell of a point from an f32 ESTIMATE of the value the reference rounds,
+  //     t = (max - translation) / res - 0.5 - (rotated coordinate) / res,
+  // in two FMAs per coordinate (the real-time matcher's discretisation, rt_2d_tiles.hip, where
+  // the error bound is derived: the estimate differs from GetCellIndex over RotateZ's f32 chain
+  // by less than 2^-24 [((k_z + 4) (|ax| + |ay|) + |translation|) / res + 3 |K|], k_z =
+  // max(2 + 4 z^2, 1 + 6 |z|) for this scan's rotation (w, z)); when it lies further than
+  // 1.25 x that from every half-integer its rounding IS the reference's cell.  Otherwise -- three
+  // points in a thousand at 60 m (20 M random points over the full circle: 0 wrong cells among
+  // the decided ones) -- the exact expressions below run for that lane.  ~30 instead of ~110
+  // vector instructions per point (a third of this kernel's instructions) -- and no measurable
+  // change of its duration (same-box A/B: 132.4 -> 130.4 - 132.5 us per search): the kernel is
+  // not bound by instruction issue but by the plane gathers below (DESIGN 5.1).
+  const double inv_res_d = P.inv_res;
+  const double Kyd = (P.max_y - static_cast<double>(P.ty)) * inv_res_d - 0.5;
+  const double Kxd = (P.max_x - static_cast<double>(P.tx)) * inv_res_d - 0.5;
+  const float Ky = static_cast<float>(Kyd), Kx = static_cast<float>(Kxd);
+  const float bound_fixed = static_cast<float>(
+      1.25 * 0x1p-24 * (inv_res_d * fmax(fabs(static_cast<double>(P.tx)), fabs(static_cast<double>(P.ty))) +
+                        3.0 * fmax(fabs(Kxd), fabs(Kyd)) + 1.0));
+  for (int g = 0; g < gcount; ++g) {
+    const float2 r = P.scan_rot[s0 + g];
+    const double zd = r.y;
+    const float Ci = static_cast<float>((1.0 - 2.0 * zd * zd) * inv_res_d);
+    const float Si = static_cast<float>(2.0 * static_cast<double>(r.x) * zd * inv_res_d);
+    const float bound_per_m = static_cast<float>(
+        1.25 * 0x1p-24 * inv_res_d * (4.0 + fmax(2.0 + 4.0 * zd * zd, 1.0 + 6.0 * fabs(zd))));
+    uint32_t* const pts = pts_all + g * n_pad;
+    int lo_x = 0, lo_y = 0, hi_x = 0, hi_y = 0, bad = 0;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * T) {
+      // Four points' loads in flight before the first is used.
+      F3 p[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int j = min(i0 + k * T, n - 1);
+        p[k] = F3{xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2]};
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * T;
+        if (i >= n) break;
+        // Two yaw rotations (initial estimate, then this scan's perturbation), then the
+        // translation: Rotate / `+ 0.f` / `1.f * x + 0.f * y` of PrepScansKernel without the
+        // terms that are exactly zero (RotateZ, cmx_device.h).  A full-submap search starts
+        // from yaw 0: its first rotation is the identity.
+        float ax = p[k].x, ay = p[k].y;
+        if (!identity_q0) RotateZ(P.init_qw, P.init_qz, p[k].x, p[k].y, &ax, &ay);
+        const float tY = fmaf(-Ci, ay, fmaf(-Si, ax, Ky));    // cell x index from the map's y
+        const float tX = fmaf(-Ci, ax, fmaf(Si, ay, Kx));
+        const float nY = rintf(tY), nX = rintf(tX);
+        const float margin = fminf(0.5f - fabsf(tY - nY), 0.5f - fabsf(tX - nX));
+        const float bound = fmaf(fabsf(ax) + fabsf(ay), bound_per_m, bound_fixed);
+        int ix, iy;
+        if (margin > bound && fabsf(tY) < 1e6f && fabsf(tX) < 1e6f) {     // (NaN: not greater)
+          ix = static_cast<int>(nY);
+          iy = static_cast<int>(nX);
+        } else {
+          float bx, by;
+          RotateZ(r.x, r.y, ax, ay, &bx, &by);
+          const float x = bx + P.tx;
+          const float y = by + P.ty;
+          // lround((max - v) / res - 0.5), exact (cmx_device.h)
+          ix = CellIndexFast(P.max_y, y, P.res, P.inv_res);
+          iy = CellIndexFast(P.max_x, x, P.res, P.inv_res);
+        }
+        if (ix < -32768 || ix > 32767 || iy < -32768 || iy > 32767) bad = 1;
+        pts[i] = (static_cast<uint32_t>(ix) & 0xffffu) | (static_cast<uint32_t>(iy) << 16);
+        lo_x = min(lo_x, -ix);
+        lo_y = min(lo_y, -iy);
+        hi_x = max(hi_x, P.nx - 1 - ix);
+        hi_y = max(hi_y, P.ny - 1 - iy);
+      }
+    }
+    lo_x = WaveMinDpp(lo_x); lo_y = WaveMinDpp(lo_y);
+    hi_x = WaveMaxDpp(hi_x); hi_y = WaveMaxDpp(hi_y);
+    bad = WaveMaxDpp(bad);
+    if (lane == 0) {
+      int* red = misc + 40 + 20 * g + wave * 5;      // [G][4][5]
+      red[0] = lo_x; red[1] = lo_y; red[2] = hi_x; red[3] = hi_y; red[4] = bad;
+    }
   }
-  int2* scratch = reinterpret_cast<int2*>(misc + 8);      // [4] (the bounds partials are dead)
-  const int2 best = BlockBest(best_sum, best_index, scratch);
-  if (threadIdx.x == 0) P.scan_best[s] = best;
-  stamp(6);      // scores written
-  // The discretised scan stays on chip: the tree search re-derives the cells of the few scans
-  // it descends into (ScanCell).  Only the introspection entry point asks for the array.
-  // Batches (store_scans): a scan whose best candidate reaches the initial bound may enter the
-  // tree search, where several nodes per scan are expanded by independent wavefronts; its
-  // cells are written for them (a superset of what the coarse filter keeps: the bound only
-  // rises).  Re-deriving the cells per node made that expansion VALU-bound.
-  bool keep_cells = P.write_all_discrete != 0;
-  if (!keep_cells && P.store_scans) {
-    int top_sum = scratch[0].x;
-    for (int w = 1; w < T >> 6; ++w) top_sum = max(top_sum, scratch[w].x);
-    keep_cells = !(ToScore(P, top_sum, n) < fmaxf(P.min_score, 0.f));
+  for (int i = threadIdx.x; i < acc_cap; i += T) cand_acc[i] = 0;
+  stamp(1);      // points discretised
+  __syncthreads();
+  if (gcount > 1) {            // (uniform)
+    // the premise of the group bound: no point's cell further than one from the middle rotation's
+    int far = 0;
+    const uint32_t* const mid = pts_all + gm * n_pad;
+    for (int g = 0; g < gcount; ++g) {
+      if (g == gm) continue;
+      const uint32_t* const other = pts_all + g * n_pad;
+      for (int i = threadIdx.x; i < n; i += T) {
+        const uint32_t a = mid[i], b = other[i];
+        const int dx = static_cast<short>(a & 0xffffu) - static_cast<short>(b & 0xffffu);
+        const int dy = static_cast<short>(a >> 16) - static_cast<short>(b >> 16);
+        far |= (dx < -1 || dx > 1 || dy < -1 || dy > 1) ? 1 : 0;
+      }
+    }
+    far = WaveMaxDpp(far);
+    if (lane == 0) misc[100 + wave] = far;
+    __syncthreads();
   }
-  if (keep_cells) {
-    auto* out = AsGlobal(P.discrete) + static_cast<size_t>(s) * n;
-    for (int i = threadIdx.x; i < n; i += T) out[i] = pts[i];
+  if (threadIdx.x == 0) {
+    const int step = 1 << (P.depth - 1);
+    int bad = 0, far = 0;
+    int2 dims_all = make_int2(0, 0);
+    for (int g = 0; g < gcount; ++g) {
+      const int* red = misc + 40 + 20 * g;
+      int lo_x = red[0], lo_y = red[1], hi_x = red[2], hi_y = red[3];
+      bad = max(bad, red[4]);
+      for (int w = 1; w < waves; ++w) {
+        red += 5;
+        lo_x = min(lo_x, red[0]); lo_y = min(lo_y, red[1]);
+        hi_x = max(hi_x, red[2]); hi_y = max(hi_y, red[3]);
+        bad = max(bad, red[4]);
+      }
+      int4 bd;   // ShrinkToFit
+      bd.x = max(-P.nl, lo_x);
+      bd.y = min(P.nl, hi_x);
+      bd.z = max(-P.nl, lo_y);
+      bd.w = min(P.nl, hi_y);
+      P.bounds[s0 + g] = bd;
+      const int2 dims = make_int2((bd.y - bd.x + step) / step, (bd.w - bd.z + step) / step);
+      P.coarse_dims[s0 + g] = dims;
+      int* mine = misc + 16 + 8 * g;
+      mine[0] = bd.x; mine[1] = bd.y; mine[2] = bd.z; mine[3] = bd.w;
+      mine[4] = dims.x; mine[5] = dims.y;
+      dims_all.x = max(dims_all.x, dims.x);
+      dims_all.y = max(dims_all.y, dims.y);
+    }
+    if (gcount > 1) {
+      far = (P.group_verify & 2) ? 1 : 0;       // (tests: every unit as if its premise had failed)
+      for (int w = 0; w < waves; ++w) far |= misc[100 + w];
+      for (int g = 0; g < gcount; ++g)
+        far |= (abs(misc[16 + 8 * g] - misc[16 + 8 * gm]) > 1 ||
+                abs(misc[16 + 8 * g + 2] - misc[16 + 8 * gm + 2]) > 1) ? 1 : 0;
+    }
+    if (bad) atomicMax(&states[blockIdx.y].error, 1);
+    // (checked on the largest candidate grid of the unit: the accumulators of a group pass hold it)
+    const int count = dims_all.x * dims_all.y;
+    const int BW = dims_all.x + P.plane_i - 1, BH = dims_all.y + P.plane_j - 1;
+    // (block + 1 = bx * pitch + by + 1 travels in 16 bits, see the scoring loop)
+    const int ok = count <= P.coarse_stride && count <= kMaxCoarsePerScan && BW <= 255 &&
+                   BH <= 255 && (BW - 1) * (dims_all.y + 2 * P.plane_j - 2) + BH <= 65535 &&
+                   (dims_all.x + 2 * P.plane_i - 2) * (dims_all.y + 2 * P.plane_j - 2) <= acc_cap;
+    misc[1] = gcount; misc[2] = gm;
+    misc[4] = dims_all.x; misc[5] = dims_all.y;
+    misc[6] = ok;
+    misc[7] = far;
+    if (far) atomicAdd(&states[blockIdx.y].done_top, 1);      // (statistics: units without a group bound)
+    if (!ok) {
+      atomicMax(&states[blockIdx.y].error, 2);
+      for (int g = 0; g < gcount; ++g) P.scan_best[s0 + g] = make_int2(0, 0);
+    }
   }
+  __syncthreads();
+  if (!misc[6]) return;
+  stamp(2);      // bounds known
+  FusedPass<kTimeline>(P, &states[blockIdx.y], n, acc_cap, s0, blockIdx.y * gridDim.x + blockIdx.x);
   stamp(7);
 }
 
@@ -1071,19 +1223,31 @@ __device__ __forceinline__ bool PickSeed(const Fast2DProblem& P, int n, int want
   // Thread t owns scans t, t + T, ...: coalesced, independent loads (a contiguous chunk per
   // thread was a chain of L2 round trips); the first kOwn maxima stay in registers for the
   // second pass.
+  // Under group bounds the rotations of a unit share their sums: only the one whose cells were
+  // summed (the middle one) stands for its unit, or the seeds would be a third as many units.
+  const bool grouped = P.group > 1;
+  const auto best_of = [&](int s) -> int {
+    if (grouped) {
+      const int first = s - s % kFusedGroup;
+      if (s != first + (S - first >= kFusedGroup ? 1 : 0)) return -1;
+    }
+    return scan_best[s].x;
+  };
   constexpr int kOwn = 16;
   int own[kOwn];
 #pragma unroll
   for (int k = 0; k < kOwn; ++k) {
     const int s = tid + k * T;
-    own[k] = s < S ? scan_best[s].x : -1;
+    own[k] = s < S ? best_of(s) : -1;
   }
   int total = 0;
 #pragma unroll
   for (int k = 0; k < kOwn; ++k)
     if (own[k] >= 0) atomicAdd(&sh->hist[static_cast<int>(own[k] * 1024ll / range)], 1);
-  for (int s = tid + kOwn * T; s < S; s += T)
-    atomicAdd(&sh->hist[static_cast<int>(scan_best[s].x * 1024ll / range)], 1);
+  for (int s = tid + kOwn * T; s < S; s += T) {
+    const int b = best_of(s);
+    if (b >= 0) atomicAdd(&sh->hist[static_cast<int>(b * 1024ll / range)], 1);
+  }
   if (want == 0) {
     for (int s = tid; s < S; s += T) total += coarse_dims[s].x * coarse_dims[s].y;
     total = WaveSum(total);
@@ -1130,7 +1294,7 @@ __device__ __forceinline__ bool PickSeed(const Fast2DProblem& P, int n, int want
   int count = 0;
 #pragma unroll
   for (int k = 0; k < kOwn; ++k) count += qualifies(own[k]) ? 1 : 0;
-  for (int s = tid + kOwn * T; s < S; s += T) count += qualifies(scan_best[s].x) ? 1 : 0;
+  for (int s = tid + kOwn * T; s < S; s += T) count += qualifies(best_of(s)) ? 1 : 0;
   int incl = count;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -1151,7 +1315,7 @@ __device__ __forceinline__ bool PickSeed(const Fast2DProblem& P, int n, int want
       }
     }
     for (int s = tid + kOwn * T; s < S && found < 0; s += T) {
-      if (!qualifies(scan_best[s].x)) continue;
+      if (!qualifies(best_of(s))) continue;
       if (k == want) found = s;
       ++k;
     }
@@ -1374,10 +1538,18 @@ DiveKernel(const Fast2DProblem* __restrict__ problems, ProblemState* __restrict_
   __shared__ ChildScratch sh;
   __shared__ Node2D cur;
   __shared__ SeedScratch seed_scratch;
+  // Under group bounds a seed is a unit of three rotations (PickSeed) whose bound says nothing
+  // about which of them holds the good leaf: a dive per rotation (blocks 3 k, 3 k + 1, 3 k + 2).
+  const int per_seed = P.group > 1 ? kFusedGroup : 1;
+  if (static_cast<int>(blockIdx.x) >= kSeedsPerProblem * per_seed) return;
   int seed_scan;
-  const bool have_seed = PickSeed(P, n, blockIdx.x, &seed_scratch, &seed_scan);
+  const bool have_seed = PickSeed(P, n, blockIdx.x / per_seed, &seed_scratch, &seed_scan);
   if (blockIdx.x == 0 && threadIdx.x == 0) st.coarse_total = seed_scratch.total;
   if (!have_seed) return;
+  if (per_seed > 1) {
+    seed_scan = seed_scan - seed_scan % kFusedGroup + static_cast<int>(blockIdx.x) % per_seed;
+    if (seed_scan >= P.num_scans) return;
+  }
   const Node2D seed = CoarseNode(P, problem, seed_scan, P.scan_best[seed_scan].y);
   if (threadIdx.x == 0) cur = seed;
   LoadContext(P, n, seed.scan, &ctx);
@@ -2679,6 +2851,17 @@ Fast2DMatcher::Fast2DMatcher(const cmx_fast2d_options& options, const cmx_grid2d
       CMX_HIP(hipMalloc(reinterpret_cast<void**>(&planes_), bytes));
       BuildPlanesKernel<<<w * w + 1, 64, 0, ws->stream>>>(top.cells, top.wx, top.wy, w, PI, PJ,
                                                           plane_stride_, planes_);
+      // The same planes of the level dilated by two cells (group bounds of the fused front end),
+      // where the dilated image still fits the planes' PI x PJ lattice cells.
+      const int dwx = top.wx + 2 * kGroupDilation, dwy = top.wy + 2 * kGroupDilation;
+      if (plane_stride_ == 64 && depth > 1 && dwx <= PI * w && dwy <= PJ * w) {
+        uint8_t* dilated = ws->dev[0].ReserveAs<uint8_t>(static_cast<size_t>(dwx) * dwy);
+        DilateLevelKernel<<<dim3(DivUp(dwx, 256), dwy), 256, 0, ws->stream>>>(top.cells, top.wx,
+                                                                             top.wy, dilated);
+        CMX_HIP(hipMalloc(reinterpret_cast<void**>(&planes_group_), bytes));
+        BuildPlanesKernel<<<w * w + 1, 64, 0, ws->stream>>>(dilated, dwx, dwy, w, PI, PJ,
+                                                            plane_stride_, planes_group_);
+      }
     }
   }
   CMX_HIP(hipGetLastError());
@@ -2690,6 +2873,7 @@ Fast2DMatcher::~Fast2DMatcher() {
   if (stack_mem_) (void)hipFree(stack_mem_);
   if (quads_mem_) (void)hipFree(quads_mem_);
   if (planes_) (void)hipFree(planes_);
+  if (planes_group_) (void)hipFree(planes_group_);
   if (grid_cells_) (void)hipFree(grid_cells_);
 }
 
@@ -2776,6 +2960,12 @@ struct PreparedBatch {
   bool write_all_discrete = false; // debug entry point: keep every discretised scan
   unsigned long long* d_timeline = nullptr;   // CMX_TIMELINE=1
   int timeline_blocks = 0;
+  // The fused front end's launch, kept for the exact re-run of a problem whose leaves tie
+  // (RescoreExact): under group bounds the lowest-resolution scores are bounds.
+  bool any_group = false;
+  size_t fused_lds = 0;
+  int fused_acc = 0, fused_threads = 0;
+  const float* d_xyz = nullptr;
 };
 
 // The debug switch fast2d_unfused routes every problem through the separate prep / score
@@ -2904,7 +3094,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     // dynamic LDS a launch gets without opting in to more.
     // (... and the lattice block of a point + 1 within 16 bits: the fused kernel's point words)
     P.use_fused = fused_enabled && P.use_planes && m.plane_stride() == 64 &&
-                  n <= kFusedMaxPoints && 4ll * n_pad + 4 * (32 + acc) + 1024 <= 64 * 1024 &&
+                  n <= kFusedMaxPoints && 4ll * n_pad + 4 * (kFusedMisc + acc) + 1024 <= 64 * 1024 &&
                   (ax + m.plane_i() - 2) * (ay + 2 * m.plane_j() - 2) + (ay + m.plane_j() - 1) <= 65535;
     if (P.use_fused) {
       any_fused = true;
@@ -2913,6 +3103,21 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
       any_unfused = true;
     }
     P.write_all_discrete = out->write_all_discrete ? 1 : 0;
+    // Group bounds: three rotations per workgroup, one sum over the dilated level (the kernel's
+    // long comment).  Not for the callers that need every exact lowest-resolution score
+    // (introspection, depth 1), not where two cells of dilation are a large part of the
+    // lowest-resolution window (below 16 cells the bounds stop excluding anything).
+    // fast2d_group: 1 never, 2 whenever the planes exist.
+    {
+      const int sw = Debug().fast2d_group;
+      const bool wanted = sw == 1 ? false : sw == 2 ? true : m.depth() >= 5;
+      P.group = (wanted && P.use_fused && m.planes_group() != nullptr && m.depth() > 1 &&
+                 !out->write_all_discrete && h.num_scans >= kFusedGroup &&
+                 4ll * kFusedGroup * n_pad + 4 * (kFusedMisc + acc) + 1024 <= 64 * 1024)
+                    ? kFusedGroup : 1;
+      P.group_verify = Debug().fast2d_group_verify;
+      if (P.group > 1) out->any_group = true;
+    }
     P.timeline = nullptr;
     coarse_total += cap;
   }
@@ -2983,6 +3188,7 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     P.score_scale = m.score_scale();
     P.min_score = min_of(p);
     P.planes = m.planes();
+    P.planes_group = m.planes_group();
     P.plane_i = m.plane_i();
     P.plane_j = m.plane_j();
     P.plane_stride = m.plane_stride();
@@ -3017,9 +3223,19 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     // Threads per block: with 192 (three waves) ten blocks fit a CU, i.e. a single search's
     // ~2300 rotations are all resident at once and the launch takes one block's latency;
     // batches run several rounds anyway and use full 256-thread blocks.
-    const long long blocks = static_cast<long long>(out->max_scans) * num;
+    // (units of a launch: rotations, or groups of three; a batch that mixes both is sized for
+    // single rotations -- surplus workgroups of a grouped problem return at once)
+    bool all_group = true;
+    for (const Fast2DProblem& P : out->h_problems) all_group = all_group && (!P.use_fused || P.group > 1);
+    const int per_unit = all_group ? kFusedGroup : 1;
+    const int units = (out->max_scans + per_unit - 1) / per_unit;
+    const long long blocks = static_cast<long long>(units) * num;
     // pts | misc | candidate sums | 64 point words per wavefront (at most four)
-    const size_t lds = 4 * static_cast<size_t>(n_pad) + 4 * static_cast<size_t>(32 + fused_acc) + 4 * 256;
+    const size_t lds = 4 * static_cast<size_t>(n_pad) * (out->any_group ? kFusedGroup : 1) +
+                       4 * static_cast<size_t>(kFusedMisc + fused_acc) + 4 * 256;
+    out->fused_lds = lds;
+    out->fused_acc = static_cast<int>(fused_acc);
+    out->d_xyz = d_xyz;
     int threads = 256;
     for (int t : {256, 192, 128}) {
       if (blocks <= FusedResidentBlocks(ws.device, t, lds)) { threads = t; break; }
@@ -3029,7 +3245,23 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
       fprintf(stderr, "[cmx trace] fused front end: %lld blocks x %d threads, %zu B LDS\n", blocks,
               threads, lds);
     // (grid.x rounded up to a multiple of 256 for the rotation -> block map of the kernel)
-    const dim3 fused_grid((out->max_scans + 255) / 256 * 256, num);
+    const dim3 fused_grid((units + 255) / 256 * 256, num);
+    out->fused_threads = threads;
+    if (out->any_group && (Debug().fast2d_group_verify & 1)) {
+      // Verification of the group bounds: first every rotation on the level itself (the same
+      // descriptors with group = 1; the exact sums stay in coarse_sum), then the launch proper,
+      // which compares every bound with them (error 3).
+      std::vector<Fast2DProblem> exact(out->h_problems);
+      for (Fast2DProblem& P : exact) { P.group = 1; P.store_scans = 0; }
+      Fast2DProblem* d_exact = ws.dev[16].ReserveAs<Fast2DProblem>(num);
+      CMX_HIP(hipMemcpyAsync(d_exact, exact.data(), num * sizeof(Fast2DProblem), hipMemcpyHostToDevice,
+                             ws.stream));
+      CMX_HIP(hipStreamSynchronize(ws.stream));        // (`exact` is a local)
+      const dim3 exact_grid((out->max_scans + 255) / 256 * 256, num);
+      PrepScoreFusedKernel<false><<<exact_grid, threads, lds, ws.stream>>>(
+          d_exact, d_xyz, n, out->d_states, static_cast<int>(fused_acc), clear_words, clear_count);
+      clear_words = nullptr;
+    }
     (out->d_timeline ? PrepScoreFusedKernel<true> : PrepScoreFusedKernel<false>)
         <<<fused_grid, threads, lds, ws.stream>>>(out->d_problems, d_xyz, n, out->d_states,
                                                   static_cast<int>(fused_acc), clear_words,
@@ -3163,7 +3395,7 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
     fetch_results(false);
   } else {
     // ---- dive -------------------------------------------------------------
-    DiveKernel<<<dim3(kSeedsPerProblem, num), 256, 0, ws.stream>>>(
+    DiveKernel<<<dim3(kSeedsPerProblem * (batch.any_group ? kFusedGroup : 1), num), 256, 0, ws.stream>>>(
         batch.d_problems, batch.d_states, n, leaf_list, d_counters);
     mark("seed+dive");
 
@@ -3411,6 +3643,26 @@ std::vector<T> DownloadDense(const Fast2DProblem& P, const CoarseLayout& L, cons
   return dense;
 }
 
+// Under group bounds the lowest-resolution scores of a problem are upper bounds shared by three
+// rotations.  The replay of the reference's order needs the scores themselves: the fused front
+// end once more for THIS problem, every rotation summed on the level itself (group = 1; same
+// buffers, the search is over).  Rare: leaves that tie for the best score.
+void RescoreExact(Workspace& ws, const PreparedBatch& batch, int p) {
+  Fast2DProblem P = batch.h_problems[p];
+  if (P.group <= 1) return;
+  P.group = 1;
+  P.group_verify = 0;
+  P.store_scans = 0;
+  P.timeline = nullptr;
+  CMX_HIP(hipMemcpyAsync(batch.d_problems + p, &P, sizeof(P), hipMemcpyHostToDevice, ws.stream));
+  CMX_HIP(hipStreamSynchronize(ws.stream));          // (`P` is a local)
+  const dim3 grid((P.num_scans + 255) / 256 * 256, 1);
+  PrepScoreFusedKernel<false><<<grid, batch.fused_threads, batch.fused_lds, ws.stream>>>(
+      batch.d_problems + p, batch.d_xyz, batch.n, batch.d_states + p, batch.fused_acc, nullptr, 0);
+  CMX_HIP(hipGetLastError());
+  CMX_HIP(hipStreamSynchronize(ws.stream));
+}
+
 void ResolveTies(Workspace& ws, const PreparedBatch& batch, const NodeList& leaves_dev,
                  const CountersSummary& h_counters, std::vector<BestLeaf>* best,
                  const std::vector<ProblemState>& states) {
@@ -3447,6 +3699,7 @@ void ResolveTies(Workspace& ws, const PreparedBatch& batch, const NodeList& leav
     }
     if (tied.size() <= 1) continue;
     const Fast2DProblem& P = batch.h_problems[p];
+    RescoreExact(ws, batch, p);
     const CoarseLayout layout = DownloadLayout(P);
     const std::vector<float> scores = DownloadDense(P, layout, P.coarse_score);
     const int total = static_cast<int>(scores.size());
@@ -3510,6 +3763,7 @@ void CheckProblemErrors(const BatchResult& r) {
   for (const ProblemState& st : r.states) {
     CMX_REQUIRE(st.error != 1, "scan cell indices exceed the int16 range supported on device");
     CMX_REQUIRE(st.error != 2, "internal error: lowest-resolution candidate capacity exceeded");
+    CMX_REQUIRE(st.error != 3, "internal error: a group bound of the fused front end lies below one of its rotations' sums");
   }
 }
 

@@ -67,6 +67,15 @@ struct Fast2DProblem {
   int plane_i, plane_j;     // cells per plane along x / y
   int plane_stride;         // bytes per plane (multiple of 64)
   int use_planes;           // 0: generic gather scoring of the lowest resolution
+  // Group bounds of the fused front end (round 6, fast_2d.hip "group bounds"): the same planes of
+  // the lowest-resolution level dilated by two cells either way (and stored two cells up: cell
+  // (X + 2, Y + 2) of the dilated image bounds the cells within two of (X, Y)); `group` adjacent
+  // rotations share ONE sum over them.  group == 1: every rotation summed on `planes` itself.
+  const uint8_t* planes_group;
+  int group;                // rotations per workgroup of the fused front end: 1 or 3
+  int group_verify;         // debug (fast2d_group_verify): bit 0 every group bound checked against the
+                            // exact sums of its rotations on the device (error 3 on a violation),
+                            // bit 1 every unit treated as if its premise had failed
   // scratch
   uint32_t* discrete;   // [num_scans][n] packed int16 (x | y << 16)
   int4* bounds;         // [num_scans] (min_x, max_x, min_y, max_y) after ShrinkToFit
@@ -104,8 +113,8 @@ struct ProblemState {       // per problem, device
   unsigned best_bits;       // float bits of the best leaf score so far (>= min_score)
   int coarse_total;
   int error;                // 1: cell index outside int16, 2: coarse capacity exceeded
-  int done_top;             // "last block done" tickets of the fused front end:
-  int done_shard[kStatShards];   // blocks arrive on 16 sharded counters, shards on done_top
+  int done_top;             // units of the fused front end whose group-bound premise failed
+  int done_shard[kStatShards];   // (unused since round 5)
   unsigned long long scored_shard[kStatShards];    // candidates scored below the top level
   unsigned long long expanded_shard[kStatShards];  // nodes whose children were scored
 };
@@ -129,6 +138,7 @@ class Fast2DMatcher {
   int depth() const { return options_.branch_and_bound_depth; }
   const LevelDesc& level(int i) const { return levels_[i]; }
   const uint8_t* planes() const { return planes_; }
+  const uint8_t* planes_group() const { return planes_group_; }   // (or null: no group bounds)
   // The submap's own correspondence-cost cells (uint16, as uploaded): what the Ceres
   // refinement after a match interpolates (constraint_builder_2d.cc:245-249).
   const uint16_t* grid_cells() const { return grid_cells_; }
@@ -146,6 +156,7 @@ class Fast2DMatcher {
   void* stack_mem_ = nullptr;      // all levels, contiguous
   void* quads_mem_ = nullptr;      // quad layouts of levels 0 .. depth-2, contiguous
   uint8_t* planes_ = nullptr;      // phase planes of the lowest-resolution level (or null)
+  uint8_t* planes_group_ = nullptr;   // phase planes of its dilation by two cells (or null)
   uint16_t* grid_cells_ = nullptr; // the grid itself (2 B per cell), for the refinement step
   int plane_i_ = 0, plane_j_ = 0, plane_stride_ = 0;
   std::vector<LevelDesc> levels_;

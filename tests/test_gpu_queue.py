@@ -75,24 +75,109 @@ def test_queue_search_equals_the_oracle_on_eight_scans(sm, world8, debug, switch
 def test_queue_search_counts_its_work(sm, world8, debug):
     """The work counters of the queue path: every scored candidate at every depth.  The count
     depends on when the bound rises (it is not the same from run to run); on the easy scan (#0,
-    whose dive finds the optimum) both paths expand exactly the 3 076 nodes that reach the final
-    bound, and on the hardest of the eight the queue's chains, taken best first, need a third of
-    what the level-synchronous launches expand."""
+    whose dive finds the optimum when the lowest-resolution scores are exact: fast2d_group = 1)
+    both paths expand exactly the 3 076 nodes that reach the final bound, and on the hardest of the
+    eight the queue's chains, taken best first, need a third of what the level-synchronous launches
+    expand.  Under group bounds (the default at this depth) the dives start from bounds: a few
+    thousand nodes on the easy scan, the same order on the hard one."""
     cells, lim, _, scans, _ = world8
     gm = _matcher(sm, cells, lim)
+    debug(fast2d_group=1)
     gm.match_full_submap(scans[0], 0.6)
     queue = dict(gm.last_stats)
-    debug(fast2d_queue=2)
+    debug(fast2d_group=1, fast2d_queue=2)
     gm.match_full_submap(scans[0], 0.6)
     level = dict(gm.last_stats)
     assert queue["coarse_candidates"] == level["coarse_candidates"]
-    assert queue["nodes_expanded"] == level["nodes_expanded"]
+    assert queue["nodes_expanded"] == level["nodes_expanded"] == 3076
     assert queue["candidates_scored"] == level["candidates_scored"]
-    debug(fast2d_queue=0)
+    debug(fast2d_group=0, fast2d_queue=0)
+    gm.match_full_submap(scans[0], 0.6)
+    grouped = dict(gm.last_stats)
+    assert grouped["coarse_candidates"] == queue["coarse_candidates"]
+    assert 3076 <= grouped["nodes_expanded"] < 12000
     gm.match_full_submap(scans[7], 0.6)       # the hardest of the eight
     hard = dict(gm.last_stats)
     assert 20000 < hard["nodes_expanded"] < 45000      # level path: 66 000 - 93 000; perfect seed: 25 000
     assert hard["expansion_lookups"] > 0
+
+
+# ----------------------------------------------------------------------------
+# Group bounds of the fused front end (round 6): three rotations, one sum over the dilated level
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("switches", [
+    {"fast2d_group_verify": 1},                           # as shipped + every bound checked on the device
+    {"fast2d_group": 1},                                  # every rotation summed on the level itself
+    {"fast2d_group_verify": 3},                           # every unit as if its premise had failed
+    {"fast2d_group_verify": 1, "fast2d_queue": 2},        # the level-synchronous launches behind it
+], ids=lambda s: ",".join(f"{k}={v}" for k, v in s.items()))
+def test_group_bounds_equal_the_oracle_on_eight_scans(sm, world8, debug, switches):
+    """The lowest-resolution scores of the default path are upper bounds shared by three
+    neighbouring rotations (fast_2d.hip, PrepScoreFusedKernel): results bit-equal to the oracle's on
+    all eight scans, with the device checking every bound against the exact sums of its rotations
+    (a violation fails the call), and with every unit's outer rotations unbounded."""
+    cells, lim, _, scans, refs = world8
+    debug(**switches)
+    gm = _matcher(sm, cells, lim)
+    for scan, ref in zip(scans, refs):
+        _same(gm.match_full_submap(scan, 0.6), ref)
+    assert gm.last_stats["coarse_candidates"] > 300000     # (the search space, bounded or summed)
+
+
+@pytest.mark.parametrize("depth,group", [(2, 2), (3, 2), (4, 2), (5, 0), (6, 0)])
+def test_group_bounds_at_every_depth(sm, oracle, synth, debug, depth, group):
+    """Group bounds forced on below their default depth (two cells of dilation against windows of
+    2 - 8 cells: valid, if useless) and as shipped above it; windowed and full-submap searches,
+    bounds verified on the device."""
+    cells, lim, world = synth.make_submap(7, 160, 160, 0.05, 12, 500, 30.0, 0.01)
+    scan = world.scan(world.free_pose(5, 0.5), 700, 30.0, 0.01, 2)
+    om = oracle.FastCorrelativeScanMatcher2D(cells, 0.05, lim["max_x"], lim["max_y"], depth, 2.0,
+                                             math.radians(25.0))
+    gm = _matcher(sm, cells, lim, depth, linear_search_window=2.0,
+                  angular_search_window=math.radians(25.0))
+    debug(fast2d_group=group, fast2d_group_verify=1)
+    _same(gm.match_full_submap(scan, 0.5), om.match_full_submap(scan, 0.5))
+    truth = world.free_pose(5, 0.5)
+    init = [truth[0] + 0.3, truth[1] - 0.2, truth[2] + 0.1]
+    _same(gm.match(sm.Rigid2d(*init), scan, 0.4), om.match(init, scan, 0.4))
+
+
+def test_group_bounds_and_ties(sm, oracle, debug):
+    """Leaves that tie for the best score: the replay of the reference's order needs the exact
+    lowest-resolution scores, which the front end computes again for that problem (RescoreExact).
+    A grid with two identical islands far apart: the two best leaves tie, their lowest-resolution
+    ancestors differ."""
+    cells = np.zeros((128, 128), np.uint16)
+    for (cy, cx) in ((30, 30), (95, 95)):
+        cells[cy:cy + 3, cx:cx + 3] = 2000            # (a low correspondence cost: occupied)
+    cloud = np.array([[0.0, 0.0, 0.0], [0.05, 0.0, 0.0], [0.0, 0.05, 0.0]], np.float32)
+    om = oracle.FastCorrelativeScanMatcher2D(cells, 0.05, 6.4, 6.4, 5, 7.0, math.radians(30.0))
+    gm = sm.FastCorrelativeScanMatcher2D(sm.Grid2D(cells, 0.05, 6.4, 6.4), 5,
+                                         linear_search_window=7.0,
+                                         angular_search_window=math.radians(30.0))
+    ref = om.match_full_submap(cloud, 0.1)
+    for group in (2, 1):
+        debug(fast2d_group=group, fast2d_group_verify=1 if group == 2 else 0)
+        _same(gm.match_full_submap(cloud, 0.1), ref)
+
+
+def test_group_bounds_for_a_batch(sm, world8, synth, debug):
+    """A batch (the level-synchronous launches, store_scans) under group bounds, verified, against
+    the same batch with exact lowest-resolution scores."""
+    cells, lim, _, scans, refs = world8
+    grids = [(cells, lim)]
+    for seed in (43, 44):
+        c, l, _ = synth.make_submap(seed, 400, 400, 0.05, 30, 1000, 30.0, 0.01)
+        grids.append((c, l))
+    matchers = [_matcher(sm, *grids[g]) for g in (0, 1, 0, 2, 0, 1)]
+    debug(fast2d_group_verify=1)
+    found, scores, poses, _ = sm.match_full_submap_batch(matchers, scans[3], 0.6)
+    debug(fast2d_group=1, fast2d_group_verify=0)
+    found2, scores2, poses2, _ = sm.match_full_submap_batch(matchers, scans[3], 0.6)
+    np.testing.assert_array_equal(found, found2)
+    np.testing.assert_array_equal(scores[found != 0], scores2[found2 != 0])
+    np.testing.assert_array_equal(np.asarray(poses)[found != 0], np.asarray(poses2)[found2 != 0])
+    assert found[0] and np.float32(scores[0]) == np.float32(refs[3]["score"])
 
 
 def test_queue_search_windowed_and_not_found(sm, oracle, world8, debug):
