@@ -36,7 +36,14 @@ import os
 import sys
 import time
 
-import numpy as np
+# The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4):
+# searches issued from sixteen host threads share four queues, and kernels of different streams on
+# one queue wait for each other (16 threads: 21 000 matches/s on 4 queues, 27 000 on 16).  A
+# deployment setting of the runtime, read when it initialises -- so before torch is imported; the
+# library sets the same default when it is loaded first (cmx_common.hip).  An explicit value wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -83,8 +90,9 @@ def parse_args():
                     help="host threads issuing the passes of a step concurrently (the reference's "
                          "thread-pool fan-out over independent searches, "
                          "constraint_builder_2d.cc:97-111); the C ABI is re-entrant: every call "
-                         "leases its own stream + scratch.  0 = auto: 8 for c2 on one GPU (a single "
-                         "search is a latency chain that fills a fraction of the chip), else 1")
+                         "leases its own stream + scratch.  0 = auto: 16 for c2 on one GPU (a single "
+                         "search is a latency chain that fills a fraction of the chip; round 6: "
+                         "16 threads on 16 hardware queues, until then 8 on the runtime's 4), else 1")
     ap.add_argument("--scans", type=int, default=8,
                     help="c2 / c3: distinct scans (poses of the same world) the passes of a step "
                          "cycle through.  Default 8 since round 6: the one scan rounds 1 - 5 timed "
@@ -1427,7 +1435,7 @@ def other_configs(args, device, sync, pmc):
     run("c1_batch1024_dirty", lambda: Rt2DWorkload(args, device, matches=1024, dirty=True), 30, 10)
     run("c1_batch128_8_threads", lambda: Rt2DPipelinedWorkload(args, device, 128, 8, 4), 25, 5)
     run("c1_tsdf", lambda: Rt2DTsdfWorkload(args, device), 30, 5)
-    run("c2_easy", lambda: Fast2DConcurrentWorkload(args, device, 8, scans=1), 40, 5)
+    run("c2_easy", lambda: Fast2DConcurrentWorkload(args, device, 16, scans=1), 40, 5)
     sub = argparse.Namespace(**vars(args))
     sub.submaps = 16
     run("c3_share_16_submaps", lambda: Fast2DWorkload(sub, device, 0, 1, sharded=True), 5, 2)
@@ -1560,7 +1568,7 @@ def main():
     # at every N
     sharded = use_dist or name == "c3"
     exchange = getattr(workload, "exchange", None) if sharded else None
-    threads = args.concurrency or (8 if name == "c2" and world_size == 1 and not use_dist else 1)
+    threads = args.concurrency or (16 if name == "c2" and world_size == 1 and not use_dist else 1)
     pool = None
     if threads > 1:
         from concurrent.futures import ThreadPoolExecutor

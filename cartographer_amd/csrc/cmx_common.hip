@@ -29,6 +29,15 @@ void CrashHandler(int sig) {
   signal(sig, SIG_DFL);
   raise(sig);
 }
+// The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4);
+// kernels of different streams that share a queue wait for each other, so a thread pool of callers
+// (the reference's: constraint_builder_2d.cc:97-111) gets four searches in flight whatever its
+// size.  Sixteen unless the deployment says otherwise -- effective when this library is loaded
+// before the runtime initialises (the variable is read once, at its first call).
+struct HardwareQueueDefault {
+  HardwareQueueDefault() { setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0); }
+} g_hardware_queue_default;
+
 struct CrashHandlerInstaller {
   CrashHandlerInstaller() {
     const char* env = getenv("CMX_SYNC");
