@@ -1459,7 +1459,8 @@ def other_configs(args, device, sync, pmc):
 LINE_LIMIT = 4096
 
 CONFIG_KEYS = ("name", "host_threads", "passes_per_step", "ms_per_pass", "candidates_per_step",
-               "candidates_per_pass", "lowest_resolution_candidates_per_pass", "matches_per_s",
+               "candidates_per_pass", "lowest_resolution_candidates_per_pass",
+               "candidates_summed_per_pass", "matches_per_s",
                "device_ms_per_pass", "timed_region_s", "submaps_per_gpu", "rotations", "found",
                "nodes_expanded_per_step", "single_stream_ms_per_search",
                "constraints_found_node_wide", "best_match", "matches_per_step", "pairs_per_step")
@@ -1726,8 +1727,13 @@ def main():
             "device_ms_per_pass": acc["device_ms"] / total_passes,
             "timed_region_s": elapsed,
             "candidate_count": "every scored candidate at every depth, counted once where it is "
-                               "scored (dive and tie re-scoring included)",
+                               "scored (dive and tie re-scoring included); fast 2D from depth 5 on: "
+                               "the lowest-resolution candidates get ONE sum per three rotations "
+                               "(group bounds, DESIGN 5.1) -- candidates_summed_per_pass counts sums",
         })
+        if name in ("c2", "c3") and args.depth >= 5:
+            coarse = acc["coarse_candidates"] / total_passes
+            config["candidates_summed_per_pass"] = cand_local / total_passes - coarse + coarse / 3.0
         roof = workload.roofline(acc, total_passes, pmc)
         roof["traffic_source"] = (None if roof.get("traffic") is None else
                                   f"rocprofv3 --pmc passes of this command, {args.pmc_dir}/"

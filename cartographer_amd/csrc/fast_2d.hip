@@ -30,6 +30,8 @@
 // bucket.  Out-of-grid lookups (60 % of the reference's reads here) cost
 // nothing.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 
@@ -3330,6 +3332,10 @@ void ReserveSearchScratch(Workspace& ws, int num, PreparedBatch* batch) {
 }
 
 // Full search of a prepared batch.
+// (debug switch host_trace: where a caller's wall clock goes -- tools only)
+thread_local long long g_host_wait_ns = 0;
+std::atomic<long long> g_host_calls{0}, g_host_total_ns{0}, g_host_waited_ns{0};
+
 void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* result) {
   const int num = batch.num_problems, n = batch.n;
   const int depth = batch.h_problems[0].depth;
@@ -3384,7 +3390,10 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
   const bool direct = Debug().no_direct_results == 0 && misc_bytes % sizeof(unsigned) == 0;
   auto fetch_results = [&](bool published) {
     if (!published) SmallCopyAsync(h_misc, d_tail, misc_bytes, /*to_device=*/false, ws.stream);
+    const auto t0 = std::chrono::steady_clock::now();
     CMX_HIP(hipStreamSynchronize(ws.stream));
+    g_host_wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(
+                          std::chrono::steady_clock::now() - t0).count();
   };
 
   if (depth == 1) {
@@ -3786,6 +3795,8 @@ void MatchBatch(const cmx_fast2d* const* handles, int num, const cmx_pose2d* ini
                 "all matchers of a batch must live on the same device");
   }
   const int device = matchers[0]->device();
+  const auto t_call = std::chrono::steady_clock::now();
+  g_host_wait_ns = 0;
   WorkspaceLease ws(device);
   const float* d_xyz;
   float max_range;
@@ -3810,6 +3821,15 @@ void MatchBatch(const cmx_fast2d* const* handles, int num, const cmx_pose2d* ini
                         min_score, &batch, full_flags, min_scores);
   BatchResult result;
   RunBranchAndBound(*ws, batch, &result);
+  if (Debug().host_trace) {
+    g_host_total_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(
+                           std::chrono::steady_clock::now() - t_call).count();
+    g_host_waited_ns += g_host_wait_ns;
+    const long long calls = ++g_host_calls;
+    if (calls % 2000 == 0)
+      fprintf(stderr, "[cmx host] fast2d: %lld calls, mean %.1f us per call, of which %.1f us in the final synchronisation\n",
+              calls, g_host_total_ns.load() * 1e-3 / calls, g_host_waited_ns.load() * 1e-3 / calls);
+  }
   trace.Report();
   if (batch.d_timeline)
     ReportTimeline("PrepScoreFusedKernel", batch.d_timeline, batch.timeline_blocks, ws->stream);

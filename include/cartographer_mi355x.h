@@ -103,7 +103,10 @@ typedef struct cmx_match_stats {
                                  SPACE the call covered (what the reference scores) -- how much of it
                                  the device summed is coarse_candidates */
   int64_t coarse_candidates;  /* lowest-resolution (or exhaustive) candidates; real-time 2D with block
-                                 bounds: the bounds evaluated + the candidates summed behind them */
+                                 bounds: the bounds evaluated + the candidates summed behind them.
+                                 Fast 2D from branch_and_bound_depth 5 on: every lowest-resolution
+                                 candidate is counted (here and in candidates_scored), three
+                                 neighbouring rotations share ONE sum that bounds all three */
   int64_t nodes_expanded;     /* branch-and-bound nodes whose children were scored */
   int32_t num_scans;          /* rotated scans */
   int32_t expansion_launches; /* launches inside expansion_ms (0: none timed) */

@@ -14,11 +14,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("threads", nargs="*", type=int, default=[8, 12, 16])
 ap.add_argument("--set", action="append", default=[])
 ap.add_argument("--scans", type=int, default=8)
+ap.add_argument("--grid", type=int, default=400)
+ap.add_argument("--beams", type=int, default=1000)
+ap.add_argument("--depth", type=int, default=7)
 cli = ap.parse_args()
 if cli.set:
     _lib.debug_set(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in cli.set})
 tag = " ".join(cli.set) or "default"
-args = argparse.Namespace(submaps=0, grid=400, depth=7, beams=1000, min_score=0.6, scans=cli.scans,
+args = argparse.Namespace(submaps=0, grid=cli.grid, depth=cli.depth, beams=cli.beams, min_score=0.6, scans=cli.scans,
                           parity_submaps=1)
 w = bench.Fast2DWorkload(args, 0, 0, 1, sharded=False)
 for k in range(4 * cli.scans):
