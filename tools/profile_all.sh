@@ -11,7 +11,7 @@ P="bash tools/profile_cmd.sh"
 # (--no-parity: the device-vs-reference gate of bench.py is CPU time, repeated by every pass)
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM"
 CACHE="TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum"
-# the headline: C2 from 8 host threads over 8 DIFFERENT scans (round 6; rounds 2 - 5 profiled one
+# the headline: C2 from 16 host threads (16 hardware queues) over 8 DIFFERENT scans (round 6; rounds 2 - 5 profiled one
 # easy scan), then the same single-stream
 $P ${TAG}       "python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-other --no-parity" FETCH_SIZE WRITE_SIZE "$SQ" "$CACHE"
 $P ${TAG}_c2single "python bench.py --steps 12 --warmup 3 --concurrency 1 --no-cpu-baseline --no-other --no-parity" FETCH_SIZE WRITE_SIZE
