@@ -76,7 +76,7 @@ def build_tools(force=False):
     os.makedirs(out_dir, exist_ok=True)
     built = []
     for name in ("gather_ceiling", "row_gather_ceiling", os.path.join("probes", "lds_unaligned"),
-                 os.path.join("probes", "launch_rate")):
+                 os.path.join("probes", "launch_rate"), os.path.join("probes", "dispatch_rate")):
         src = os.path.join(root, "tools", name + ".hip")
         name = os.path.basename(name)
         out = os.path.join(out_dir, name)

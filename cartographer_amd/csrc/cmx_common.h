@@ -90,6 +90,7 @@ cmx_status Guard(F&& body) {
   X(timeline)             /* 1: in-kernel timelines (cmx_device.h Stamp) reported on stderr */     \
   X(trace)                /* 1: an event after every stage of a call, durations on stderr */       \
   X(host_trace)           /* 1: wall clock of the host phases of a call on stderr */               \
+  X(launch_serial)        /* 1: callers issue their launches without taking turns (LaunchTurn off) */ \
   X(sync)                 /* 1: synchronise after every stage (localises a faulting kernel) */     \
   X(no_copy_kernels)      /* 1: small transfers by copy commands instead of a copy kernel */       \
   X(timing)               /* 1: HIP-event brackets around the device work (cmx_match_stats *_ms; else 0) */ \
@@ -162,6 +163,22 @@ void ParallelFor(int n, int serial_below, const std::function<void(int)>& fn);
 // launches the current one.  A lease is exclusive -- a caller that finds the lane taken runs its
 // jobs itself (Run() inline) -- and a job is a few tens of microseconds: the helper spins for a
 // while after its last job, then sleeps.
+// The runtime's launch path does not scale with the number of calling threads: sixteen threads
+// that each push a chain of five EMPTY launches and synchronise complete a chain every 15 us,
+// four threads every 5 - 12 (tools/probes/dispatch_rate.hip, launch_rate.hip) -- threads that meet
+// inside the runtime put each other to sleep.  Callers of the latency chains (a fast-2D search:
+// upload, front end, dive, filter, tree) therefore take TURNS at issuing: a ticket lock of our own,
+// spinning (a turn is a few microseconds), so that the runtime sees one caller at a time.
+class LaunchTurn {
+ public:
+  LaunchTurn();
+  ~LaunchTurn();
+  LaunchTurn(const LaunchTurn&) = delete;
+  LaunchTurn& operator=(const LaunchTurn&) = delete;
+ private:
+  bool held_;
+};
+
 class HostLane {
  public:
   HostLane();                        // takes the process-wide lane if it is free

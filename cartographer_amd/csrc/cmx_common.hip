@@ -38,6 +38,9 @@ struct HardwareQueueDefault {
   HardwareQueueDefault() { setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0); }
 } g_hardware_queue_default;
 
+struct alignas(64) TurnCounter { std::atomic<unsigned> value{0}; };
+TurnCounter g_turn_next, g_turn_serving;
+
 struct CrashHandlerInstaller {
   CrashHandlerInstaller() {
     const char* env = getenv("CMX_SYNC");
@@ -64,6 +67,23 @@ Pool& ThePool() {
   static Pool* pool = new Pool;
   return *pool;
 }
+}  // namespace
+
+LaunchTurn::LaunchTurn() : held_(Debug().launch_serial == 0) {
+  if (!held_) return;
+  const unsigned mine = g_turn_next.value.fetch_add(1, std::memory_order_relaxed);
+  int spins = 0;
+  while (g_turn_serving.value.load(std::memory_order_acquire) != mine) {
+    __builtin_ia32_pause();
+    // (a holder that was descheduled: let it run)
+    if (++spins > 20000) { std::this_thread::yield(); spins = 0; }
+  }
+}
+LaunchTurn::~LaunchTurn() {
+  if (held_) g_turn_serving.value.fetch_add(1, std::memory_order_release);
+}
+
+namespace {
 }  // namespace
 
 // ---------------------------------------------------------------------------

@@ -3211,6 +3211,8 @@ void PrepareAndScoreCoarse(Workspace& ws, const Fast2DMatcher* const* matchers, 
     coarse_off += P.coarse_capacity;
     out->max_scans = std::max(out->max_scans, h.num_scans);
   }
+  // (from here to the end of this function: the call's turn at the runtime's launch path)
+  LaunchTurn turn;
   // One H2D for the problem descriptors, their initial states and the rotation tables.
   SmallCopyAsync(d_upload, h_upload, upload_bytes, /*to_device=*/true, ws.stream);
 
@@ -3404,6 +3406,8 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
     fetch_results(false);
   } else {
     // ---- dive -------------------------------------------------------------
+    // (the launches of the search proper: one turn from the dive to the tree launch)
+    std::unique_ptr<LaunchTurn> turn(new LaunchTurn);
     DiveKernel<<<dim3(kSeedsPerProblem * (batch.any_group ? kFusedGroup : 1), num), 256, 0, ws.stream>>>(
         batch.d_problems, batch.d_states, n, leaf_list, d_counters);
     mark("seed+dive");
@@ -3496,6 +3500,7 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
         result->expansion_launches = 1;
       }
       RecordEvent(ws.ev_end, ws.stream);
+      turn.reset();
       fetch_results(direct);
       result->expansion_lookups = 64ll * h_counters->wave_gathers;
       for (int p = 0; p < num; ++p)
@@ -3513,6 +3518,7 @@ void RunBranchAndBound(Workspace& ws, const PreparedBatch& batch, BatchResult* r
         CMX_HIP(hipMemsetAsync(d_counters, 0, sizeof(Counters), ws.stream));
       }
     }
+    turn.reset();      // (the level-synchronous launches below issue as they come)
     if (!searched) {
       d_front[0] = ws.dev[10].ReserveAs<Node2D>(kFrontierCapacity);
       d_front[1] = ws.dev[11].ReserveAs<Node2D>(kFrontierCapacity);
