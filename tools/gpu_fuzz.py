@@ -76,6 +76,24 @@ def case_2d(rng, report):
             np.allclose([pose.x, pose.y, pose.theta], a["pose"], rtol=0, atol=1e-12)))
         if not ok:
             report("fast2d", dict(what, full=full), (found, score), (a["found"], a.get("score")))
+        # the group bounds of the front end (round 6) at ANY depth > 1, every bound checked against
+        # the exact sums on the device (a violation fails the call); then with every unit's outer
+        # rotations unbounded, and with exact lowest-resolution scores
+        from cartographer_amd import _lib as lib
+        for name, switches in (("fast2d group bounds", dict(fast2d_group=2, fast2d_group_verify=1)),
+                               ("fast2d group bounds, premise failed", dict(fast2d_group=2, fast2d_group_verify=3)),
+                               ("fast2d exact", dict(fast2d_group=1))):
+            lib.debug_set(**switches)
+            try:
+                found, score, pose = (gm.match_full_submap(pts, min_score) if full
+                                      else gm.match(sm.Rigid2d(*init), pts, min_score))
+            finally:
+                lib.debug_set(**{k: 0 for k in switches})
+            ok = bool(found) == a["found"] and (not found or (
+                np.float32(score) == np.float32(a["score"]) and
+                np.allclose([pose.x, pose.y, pose.theta], a["pose"], rtol=0, atol=1e-12)))
+            if not ok:
+                report(name, dict(what, full=full), (found, score), (a["found"], a.get("score")))
     rt = (float(rng.uniform(0, 6 * res)), float(rng.uniform(0, 0.3)),
           float(rng.choice([0, 0.1, 10])), float(rng.choice([0, 0.5, 3])))
     a = orc.rt2d_match(cells, res, max_x, max_y, init, pts, *rt)
