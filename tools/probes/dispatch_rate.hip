@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e)); std::exit(1); } } while (0)
 __global__ void __launch_bounds__(256) Tiny(int* p, int spin) {
@@ -42,8 +43,20 @@ double Run(int threads, int chains, int kernels, int blocks, int spin) {
   return us / (static_cast<double>(threads) * chains);
 }
 
-int main() {
+int main(int argc, char** argv) {
   CK(hipSetDevice(0));
+  if (argc >= 3) {
+    // dispatch_rate <threads> <chains>: one configuration (several PROCESSES side by side: is it
+    // the runtime -- one per process -- or the device that takes 3 us per launch?)
+    const int threads = std::atoi(argv[1]), chains = std::atoi(argv[2]);
+    Run(threads, 50, 5, 64, 0);
+    const auto t0 = std::chrono::steady_clock::now();
+    const double per = Run(threads, chains, 5, 64, 0);
+    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("process %d: %d threads x %d chains of 5 launches: %.1f us per chain, %.0f chains/s over %.2f s\n",
+           static_cast<int>(getpid()), threads, chains, per, threads * chains / s, s);
+    return 0;
+  }
   Run(1, 50, 5, 64, 0);
   for (int spin : {0, 2000})
     for (int blocks : {1, 64, 256, 512, 1024, 2048})
