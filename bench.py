@@ -563,7 +563,10 @@ class Fast2DWorkload:
         # over a work queue; batches: the level-synchronous ExpandWaveKernel launches.  Priced
         # against the chip's measured gather-issue ceiling, with SURVEY 8d's algorithmic bytes
         # (N x 1 B per candidate scored below the lowest resolution) next to it.
-        queue = per_gpu < 4
+        # (round 6: batches of 32 and more problems run as independent single searches over the
+        # library's host pool -- the work queue again; their kernel times are SUMS over searches
+        # that run concurrently)
+        queue = per_gpu < 4 or per_gpu >= 32
         tree = expansion_roofline(
             acc, steps,
             "TreeQueueKernel (branch and bound through a work queue: one quad gather per point and "
@@ -579,6 +582,11 @@ class Fast2DWorkload:
             + (" (the launch also takes and hands on nodes, selects the best leaf and publishes "
                "the results)" if queue else " (all levels; the wave launches score the top ones)"),
             algorithmic=(acc["candidates_scored"] - acc["coarse_candidates"]) / steps * self.n_points)
+        if per_gpu >= 32:
+            out["kernel_ms_is_sum_of_concurrent_launches"] = True
+            out["gathered_bytes"] = gathered / 3.0      # (group bounds: one sum per three rotations)
+            if tree is not None:
+                tree["kernel_ms_is_sum_of_concurrent_launches"] = True
         if tree is not None and acc["expansion_ms"] > acc["dominant_kernel_ms"]:
             tree["front_end"] = out      # the tree search is the dominant kernel
             return tree

@@ -101,6 +101,7 @@ cmx_status Guard(F&& body) {
   X(fast2d_unfused)       /* 1: fast 2D front end as separate prep / score launches */             \
   X(fast2d_store_scans)   /* 1: never keep the surviving scans' cells, 2: always */                \
   X(fast2d_fused_threads) /* threads per block of the fused front end */                           \
+  X(fast2d_fanout)        /* batches of at least this many problems run as independent single searches over the host pool (0: from 32 on, 1: never) */ \
   X(fast2d_group)         /* group bounds of the fused front end (three rotations, one sum over the dilated level): 1 never, 2 at any depth > 1 (0: from depth 5 on) */ \
   X(fast2d_group_verify)  /* 1: every group bound checked against the exact sums of its rotations on the device; 2: every unit treated as if its premise had failed (outer rotations unbounded); 3: both */ \
   X(fast2d_levels_per_stage) /* levels per depth-first stage */                                   \

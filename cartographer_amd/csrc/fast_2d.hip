@@ -3801,6 +3801,39 @@ void MatchBatch(const cmx_fast2d* const* handles, int num, const cmx_pose2d* ini
                 "all matchers of a batch must live on the same device");
   }
   const int device = matchers[0]->device();
+  // Large batches (from 32 problems on; debug switch fast2d_fanout: 1 never, N > 1 from N on) as
+  // INDEPENDENT searches over the host pool: every problem the single-search chain (front end, dive,
+  // filter, work-queue tree) on a workspace and stream of its own, sixteen in flight on sixteen
+  // hardware queues, instead of the level-synchronous launches over the whole batch -- 64 submaps
+  // 6.6 against 9.8 ms, 128: 11.8 against 17.9, 16: the same (profiles/r06g_fanout.txt; with the
+  // runtime's four queues of until round 6 it lost: 1.69 against 1.42 ms for 16).  Same results: a
+  // problem's search does not depend on its neighbours in the batch.  A caller that finds the
+  // pool busy (another batch of the process) runs its problems one after the other itself.
+  const int fanout_from = Debug().fast2d_fanout == 0 ? 32 : Debug().fast2d_fanout == 1 ? (1 << 30)
+                                                                                       : Debug().fast2d_fanout;
+  if (num >= fanout_from && OverrideStream(device) == nullptr) {
+    std::vector<cmx_match_stats> part(num);
+    ParallelFor(num, 2, [&](int p) {
+      MatchBatch(handles + p, 1, initial ? initial + p : nullptr, full_submap, host_xyz, cloud, n,
+                 min_scores ? min_scores[p] : min_score, found + p, scores + p, poses + p, &part[p],
+                 full_flags ? full_flags + p : nullptr, nullptr);
+    });
+    cmx_match_stats total{};
+    for (const cmx_match_stats& st : part) {
+      total.candidates_scored += st.candidates_scored;
+      total.coarse_candidates += st.coarse_candidates;
+      total.nodes_expanded += st.nodes_expanded;
+      total.num_scans += st.num_scans;
+      total.device_ms += st.device_ms;                      // (sums over concurrent searches)
+      total.dominant_kernel_ms += st.dominant_kernel_ms;
+      total.expansion_ms += st.expansion_ms;
+      total.expansion_launches += st.expansion_launches;
+      total.expansion_nodes += st.expansion_nodes;
+      total.expansion_lookups += st.expansion_lookups;
+    }
+    if (stats) *stats = total;
+    return;
+  }
   const auto t_call = std::chrono::steady_clock::now();
   g_host_wait_ns = 0;
   WorkspaceLease ws(device);

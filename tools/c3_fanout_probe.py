@@ -48,5 +48,16 @@ k = cli.reps - 1
 found = np.array([int(r[0][0]) for r in out])
 scores = np.array([r[1][0] for r in out], np.float32)
 assert (found == batch[0]).all() and (scores[found != 0] == batch[1][found != 0]).all()
+_lib.debug_set(fast2d_fanout=4)
+for k in range(8):
+    w.search(k)
+t0 = time.perf_counter()
+for k in range(cli.reps):
+    native = w.search(k)
+dt_native = (time.perf_counter() - t0) / cli.reps
+_lib.debug_set(fast2d_fanout=0)
+assert (native[0] == batch[0]).all() and (native[1][batch[0] != 0] == batch[1][batch[0] != 0]).all()
+assert (np.asarray(native[2])[batch[0] != 0] == np.asarray(batch[2])[batch[0] != 0]).all()
+print(f"C3 {cli.submaps} submaps: native fan-out over the host pool {dt_native * 1e3:.3f} ms")
 print(f"C3 {cli.submaps} submaps: batch call {dt_batch * 1e3:.3f} ms, {cli.threads} threads x single searches "
       f"{dt_fan * 1e3:.3f} ms; found {int(found.sum())} of {len(found)} (results equal)", flush=True)
