@@ -3811,7 +3811,11 @@ void MatchBatch(const cmx_fast2d* const* handles, int num, const cmx_pose2d* ini
   // pool busy (another batch of the process) runs its problems one after the other itself.
   const int fanout_from = Debug().fast2d_fanout == 0 ? 32 : Debug().fast2d_fanout == 1 ? (1 << 30)
                                                                                        : Debug().fast2d_fanout;
-  if (num >= fanout_from && OverrideStream(device) == nullptr) {
+  // (full-submap searches only: a windowed search is a few launches' worth of work, and a batch of
+  // them is cheaper in the batch's few launches than in five launches each)
+  bool all_full = true;
+  for (int p = 0; p < num && all_full; ++p) all_full = full_flags ? full_flags[p] != 0 : full_submap;
+  if (num >= fanout_from && all_full && OverrideStream(device) == nullptr) {
     std::vector<cmx_match_stats> part(num);
     ParallelFor(num, 2, [&](int p) {
       MatchBatch(handles + p, 1, initial ? initial + p : nullptr, full_submap, host_xyz, cloud, n,
