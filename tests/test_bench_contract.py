@@ -241,11 +241,11 @@ def test_line_is_small_and_the_details_go_to_a_file(stubbed_bench, tmp_path, mon
 
 
 def test_headline_of_a_full_record_stays_under_the_limit():
-    """A record with every leg of the default run (13 configs, CPU baselines, parity records,
+    """A record with every leg of the default run (14 configs, CPU baselines, parity records,
     long workload texts and notes) still makes a line < 4 KB."""
     import bench
     names = ["c1_single", "c1b128", "c1b128_dirty", "c1b128_g400", "c1b1024", "c1b1024_dirty",
-             "c1b128t8", "c2_easy", "c3s16", "c4", "c5_single", "c5s32", "c1_tsdf"]
+             "c1b128t8", "c2_easy", "c3s16", "c3s64", "c4", "c5_single", "c5s32", "c1_tsdf"]
     entry = {"ms": 0.147787290043, "cand_per_s": 3952058393.04, "matches_per_s": 866109.66316,
              "frac": 0.12346093812, "bound": "gather-issue", "cpu": 7270691.4588,
              "cpu_unit": "candidates/s", "cpu_cores": 32, "parity": "exact"}
