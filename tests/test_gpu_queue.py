@@ -265,3 +265,37 @@ def test_queue_search_from_eight_threads(sm, world8):
         for results in pool.map(worker, range(8)):
             for k, f, s, p in results:
                 _same((f, s, p), refs[k])
+
+
+def test_large_batches_fan_out_with_the_same_results(sm, synth, debug):
+    """cmx_fast2d_match_batch with 40 full-submap searches (per-problem thresholds): as shipped the
+    batch runs as independent single searches over the host pool (fast2d_fanout, from 32 problems
+    on); with the switch at 1 as level-synchronous launches over the whole batch.  Same found
+    flags, scores, poses and candidate counts; a batch with ONE windowed search among them stays
+    on the batch launches either way."""
+    grids = [synth.make_submap(900 + k, 160, 160, 0.05, 12, 500, 30.0, 0.01) for k in range(5)]
+    scan = grids[2][2].scan(grids[2][2].free_pose(5, 0.5), 600, 30.0, 0.01, 3)
+    matchers = [_matcher(sm, grids[k % 5][0], grids[k % 5][1], 6) for k in range(40)]
+    initial = [sm.Rigid2d(0.0, 0.0, 0.0)] * 40
+    thresholds = [0.3 + 0.01 * (k % 7) for k in range(40)]
+    out = sm.match_batch(matchers, initial, [1] * 40, thresholds, scan)
+    debug(fast2d_fanout=1)
+    ref = sm.match_batch(matchers, initial, [1] * 40, thresholds, scan)
+    debug(fast2d_fanout=0)
+    np.testing.assert_array_equal(out[0], ref[0])
+    np.testing.assert_array_equal(out[1][ref[0] != 0], ref[1][ref[0] != 0])
+    for a, b, ok in zip(out[2], ref[2], ref[0]):
+        if ok:
+            assert _xyt(a) == _xyt(b)
+    assert out[0][2] == 1 and out[3]["coarse_candidates"] == ref[3]["coarse_candidates"]
+    # one windowed search in the batch: no fan-out (the batch's own launches), same results
+    truth = grids[2][2].free_pose(5, 0.5)
+    flags = [1] * 40
+    flags[2] = 0
+    initial = list(initial)
+    initial[2] = sm.Rigid2d(truth[0] + 0.2, truth[1] - 0.1, truth[2] + 0.05)
+    mixed = sm.match_batch(matchers, initial, flags, thresholds, scan)
+    assert mixed[0][2] == 1
+    for k in (0, 7, 39):
+        assert mixed[0][k] == ref[0][k] and (not ref[0][k] or mixed[1][k] == ref[1][k])
+
