@@ -1609,12 +1609,22 @@ def main():
                       for i in range(threads)]
 
             def worker(args_):
+                # (every thread sums the counters of its own searches -- between its calls, while
+                # the other threads are inside theirs -- instead of the issuing thread walking all
+                # results after the last search has returned: that walk was 5 % of a step)
                 first, n = args_
-                return [workload.search(first + j) for j in range(n)]
+                mine = {k: 0 for k in STAT_KEYS}
+                r = None
+                for j in range(n):
+                    r = workload.search(first + j)
+                    for k in STAT_KEYS:
+                        mine[k] += r[3].get(k, 0)
+                return mine, r
             starts = [sum(shares[:i]) for i in range(threads)]
-            for results in pool.map(worker, zip(starts, shares)):
-                for r in results:
-                    add(r)
+            for mine, r in pool.map(worker, zip(starts, shares)):
+                for k in STAT_KEYS:
+                    acc[k] += mine[k]
+                if r is not None:
                     last = r
         else:
             # Rounds of T concurrent searches, then the collectives of each pass on this thread
