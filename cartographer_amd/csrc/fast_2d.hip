@@ -903,7 +903,7 @@ PrepScoreFusedKernel(const Fast2DProblem* __restrict__ problems, const float* __
       counters_words[i] = 0;
   const Fast2DProblem& P = problems[blockIdx.y];
   // GROUP BOUNDS (round 6).  Neighbouring rotations move a point by at most one cell (the angular
-  // step is chosen so, SM2/correlative_scan_matcher_2d.cc:49-60), and their search bounds -- the
+  // step is chosen so, SM2/correlative_scan_matcher_2d.cc:31-44), and their search bounds -- the
   // minimum over the points -- by at most one with it.  So for the G = 3 rotations g of a unit and
   // the middle one m, the cell a lowest-resolution candidate (kx, ky) of rotation g reads for point
   // p lies within two cells (per axis) of the cell candidate (kx, ky) of rotation m reads for p,
